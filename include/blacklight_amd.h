@@ -1,0 +1,241 @@
+/* blacklight_amd.h - C-ABI of the MI355X-native hot path of blacklight (c-white/blacklight).
+ *
+ * The reference has no plugin / FFI boundary: its hot path is entered by three C++ member calls
+ * made from main() (reference src/blacklight.cpp:93-94, 203-204, 221):
+ *
+ *     double GeodesicIntegrator::Integrate()                      geodesic_integrator.cpp:194
+ *     bool   RadiationIntegrator::Integrate(int, double*, ...)    radiation_integrator.cpp:676
+ *     double GeodesicIntegrator::AddGeodesics(RadiationIntegrator*) geodesic_integrator.cpp:236
+ *
+ * with inputs = the InputReader fields copied in the two constructors
+ * (geodesic_integrator.cpp:26-104, radiation_integrator.cpp:30-357) plus the read-only grid arrays
+ * owned by SimulationReader (simulation_sampling.cpp:38-78), and outputs = image[level](n_q,n_pix),
+ * sample_num, sample_flags, camera_pos/dir (output_writer.cpp:116-124, 172-246).
+ *
+ * This header is the drop-in replacement for exactly that surface, as plain C: a parameter block
+ * that mirrors InputReader key-for-key (bl_params), a borrowed view of the grid (bl_grid_desc), and
+ * one call per adaptive level (bl_render) that runs camera + geodesics + sampling + coefficients +
+ * transfer on the GPU. No C++ or torch types cross the boundary; every function returns 0 on
+ * success or a BL_E_* code, with the message text (identical to the reference's where the
+ * reference has one) available from bl_last_error().
+ */
+#ifndef BLACKLIGHT_AMD_H_
+#define BLACKLIGHT_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BL_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------ error codes */
+enum {
+  BL_OK = 0,
+  BL_E_INPUT = 1,      /* malformed .input file or bad value: message = reference text            */
+  BL_E_MISSING = 2,    /* a required key is absent (reference: std::bad_optional_access)          */
+  BL_E_UNSUPPORTED = 3,/* valid reference configuration outside the hot-path scope of this build  */
+  BL_E_DEVICE = 4,     /* HIP runtime failure or no gfx950 device                                 */
+  BL_E_ARG = 5,        /* bad argument to the C-ABI itself                                        */
+  BL_E_STATE = 6       /* call out of order (e.g. simulation render before bl_set_grid)           */
+};
+
+/* ------------------------------------------------------------------ enumerations
+ * Same members, same order as reference src/blacklight.hpp:36-46. */
+enum { BL_MODEL_SIMULATION = 0, BL_MODEL_FORMULA = 1 };
+enum { BL_OUTPUT_NPZ = 0, BL_OUTPUT_NPY = 1, BL_OUTPUT_RAW = 2 };
+enum { BL_SIMFMT_ATHENA = 0, BL_SIMFMT_ATHENAK = 1, BL_SIMFMT_IHARM3D = 2, BL_SIMFMT_HARM3D = 3 };
+enum { BL_COORD_CKS = 0, BL_COORD_SKS = 1, BL_COORD_FMKS = 2 };
+enum { BL_CAMERA_PLANE = 0, BL_CAMERA_PINHOLE = 1 };
+enum { BL_TERMINATE_PHOTON = 0, BL_TERMINATE_MULTIPLICATIVE = 1, BL_TERMINATE_ADDITIVE = 2 };
+enum { BL_INTEGRATOR_DP = 0, BL_INTEGRATOR_RK4 = 1, BL_INTEGRATOR_RK2 = 2 };
+enum { BL_SPACING_LIN_FREQ = 0, BL_SPACING_LIN_WAVE = 1, BL_SPACING_LOG = 2 };
+enum { BL_NORM_CAMERA = 0, BL_NORM_INFINITY = 1 };
+enum { BL_PLASMA_TI_TE_BETA = 0, BL_PLASMA_CODE_KAPPA = 1 };
+
+#define BL_STR_LEN 512
+#define BL_MAX_REGIONS 32
+
+/* ------------------------------------------------------------------ parameter block
+ * One entry per key of the reference's .input grammar (src/input_reader/input_reader.cpp:101-407),
+ * in the same order. X(kind, name):
+ *   B bool (int32 0/1)   I int32   D double   F float   S string   E enum (int32)
+ *   G double given in degrees in the file, stored in radians as val * pi / 180
+ *     (input_reader.cpp:185-201, 389)
+ * camera_th additionally sets camera_pole when the written value is exactly 0 or 180
+ * (input_reader.cpp:492-500).
+ */
+#define BL_PARAM_LIST(X) \
+  X(E, model_type) X(I, num_threads) \
+  X(E, output_format) X(S, output_file) X(B, output_camera) \
+  X(B, checkpoint_geodesic_save) X(B, checkpoint_geodesic_load) X(S, checkpoint_geodesic_file) \
+  X(B, checkpoint_sample_save) X(B, checkpoint_sample_load) X(S, checkpoint_sample_file) \
+  X(E, simulation_format) X(S, simulation_file) X(B, simulation_multiple) X(I, simulation_start) \
+  X(I, simulation_end) X(E, simulation_coord) X(D, simulation_a) X(D, simulation_m_msun) \
+  X(D, simulation_rho_cgs) X(S, simulation_kappa_name) X(B, simulation_interp) \
+  X(B, simulation_block_interp) \
+  X(D, formula_mass) X(D, formula_spin) X(D, formula_r0) X(D, formula_h) X(D, formula_l0) \
+  X(D, formula_q) X(D, formula_nup) X(D, formula_cn0) X(D, formula_alpha) X(D, formula_a) \
+  X(D, formula_beta) \
+  X(E, camera_type) X(D, camera_r) X(G, camera_th) X(G, camera_ph) X(D, camera_urn) \
+  X(D, camera_uthn) X(D, camera_uphn) X(D, camera_k_r) X(D, camera_k_th) X(D, camera_k_ph) \
+  X(G, camera_rotation) X(D, camera_width) X(I, camera_resolution) X(B, camera_pole) \
+  X(B, ray_flat) X(E, ray_terminate) X(D, ray_factor) X(E, ray_integrator) X(D, ray_step) \
+  X(I, ray_max_steps) X(I, ray_max_retries) X(D, ray_tol_abs) X(D, ray_tol_rel) \
+  X(B, image_light) X(I, image_num_frequencies) X(D, image_frequency) X(D, image_frequency_start) \
+  X(D, image_frequency_end) X(E, image_frequency_spacing) X(E, image_normalization) \
+  X(B, image_polarization) X(B, image_rotation_split) X(B, image_time) X(B, image_length) \
+  X(B, image_lambda) X(B, image_emission) X(B, image_tau) X(B, image_lambda_ave) \
+  X(B, image_emission_ave) X(B, image_tau_int) X(B, image_crossings) \
+  X(I, render_num_images) \
+  X(B, slow_light_on) X(B, slow_interp) X(I, slow_chunk_size) X(D, slow_t_start) X(D, slow_dt) \
+  X(I, slow_num_images) X(I, slow_offset) \
+  X(I, adaptive_max_level) X(I, adaptive_block_size) X(I, adaptive_frequency_num) \
+  X(D, adaptive_val_cut) X(D, adaptive_val_frac) X(D, adaptive_abs_grad_cut) \
+  X(D, adaptive_abs_grad_frac) X(D, adaptive_rel_grad_cut) X(D, adaptive_rel_grad_frac) \
+  X(D, adaptive_abs_lapl_cut) X(D, adaptive_abs_lapl_frac) X(D, adaptive_rel_lapl_cut) \
+  X(D, adaptive_rel_lapl_frac) X(I, adaptive_num_regions) \
+  X(D, plasma_mu) X(D, plasma_ne_ni) X(E, plasma_model) X(B, plasma_use_p) X(D, plasma_gamma) \
+  X(D, plasma_gamma_i) X(D, plasma_gamma_e) X(D, plasma_rat_low) X(D, plasma_rat_high) \
+  X(D, plasma_power_frac) X(D, plasma_p) X(D, plasma_gamma_min) X(D, plasma_gamma_max) \
+  X(D, plasma_kappa_frac) X(D, plasma_kappa) X(D, plasma_w) \
+  X(D, cut_rho_min) X(D, cut_rho_max) X(D, cut_n_e_min) X(D, cut_n_e_max) X(D, cut_p_gas_min) \
+  X(D, cut_p_gas_max) X(D, cut_theta_e_min) X(D, cut_theta_e_max) X(D, cut_b_min) X(D, cut_b_max) \
+  X(D, cut_sigma_min) X(D, cut_sigma_max) X(D, cut_beta_inverse_min) X(D, cut_beta_inverse_max) \
+  X(B, cut_omit_near) X(B, cut_omit_far) X(D, cut_omit_in) X(D, cut_omit_out) \
+  X(G, cut_midplane_theta) X(D, cut_midplane_z) X(B, cut_plane) \
+  X(D, cut_plane_origin_x) X(D, cut_plane_origin_y) X(D, cut_plane_origin_z) \
+  X(D, cut_plane_normal_x) X(D, cut_plane_normal_y) X(D, cut_plane_normal_z) \
+  X(B, fallback_nan) X(F, fallback_rho) X(F, fallback_pgas) X(F, fallback_kappa)
+
+typedef struct bl_str { char s[BL_STR_LEN]; } bl_str;
+
+#define BL_PT_B int32_t
+#define BL_PT_I int32_t
+#define BL_PT_E int32_t
+#define BL_PT_D double
+#define BL_PT_G double
+#define BL_PT_F float
+#define BL_PT_S bl_str
+#define BL_X_FIELD(kind, name) BL_PT_##kind name;
+#define BL_X_INDEX(kind, name) BL_P_##name,
+
+enum { BL_PARAM_LIST(BL_X_INDEX) BL_P_COUNT };
+
+typedef struct bl_params {
+  /* has[i] != 0 iff field i (enum BL_P_*) was given: the std::optional of the reference */
+  uint8_t has[((BL_P_COUNT + 7) / 8) * 8];
+  BL_PARAM_LIST(BL_X_FIELD)
+  /* adaptive_region_<n>_{level,x_min,x_max,y_min,y_max}  (src/input_reader/adaptive_reader.cpp) */
+  int32_t adaptive_region_has[BL_MAX_REGIONS];     /* bit 0..4 = level, x_min, x_max, y_min, y_max */
+  int32_t adaptive_region_level[BL_MAX_REGIONS];
+  double adaptive_region_x_min[BL_MAX_REGIONS];
+  double adaptive_region_x_max[BL_MAX_REGIONS];
+  double adaptive_region_y_min[BL_MAX_REGIONS];
+  double adaptive_region_y_max[BL_MAX_REGIONS];
+} bl_params;
+
+/* Zero a parameter block (nothing present). */
+BL_API void bl_params_clear(bl_params *p);
+BL_API size_t bl_params_sizeof(void);
+/* Parse one "key = value" assignment exactly as a line of the .input file would be
+ * (whitespace stripped, '#' comments removed); err receives "Error: ...\n" text on failure. */
+BL_API int bl_params_set_line(bl_params *p, const char *line, char *err, size_t err_len);
+/* Parse a whole .input file: replaces InputReader::Read() (input_reader.cpp:72-428).
+ * *num_runs receives the run count (1 unless simulation_multiple). */
+BL_API int bl_params_read_file(bl_params *p, const char *path, int *num_runs, char *err,
+                               size_t err_len);
+/* Typed read-back by key name (used by the Python host layer and the tests). */
+BL_API int bl_params_get(const bl_params *p, const char *key, double *value, int *present);
+BL_API int bl_params_get_string(const bl_params *p, const char *key, char *out, size_t out_len);
+
+/* ------------------------------------------------------------------ grid view
+ * What RadiationIntegrator::ObtainGridData() takes from SimulationReader
+ * (simulation_sampling.cpp:26-95). All pointers are host pointers borrowed for the duration of
+ * bl_set_grid(); layouts are the reference's Array<T> layouts (n1 fastest):
+ *   prim  float  [n_var][n_blocks][n_k][n_j][n_i]     simulation_reader.cpp:767-780
+ *   x1f   double [n_blocks][n_i+1], x1v double [n_blocks][n_i]  (x2*, x3* alike)
+ * Coordinates are the values the reader hands over, i.e. file float32 promoted to double
+ * (simulation_reader.cpp:615-620) after its angular-range fix (:724-758). */
+typedef struct bl_grid_desc {
+  int32_t n_blocks, n_i, n_j, n_k, n_var;
+  const float *prim;
+  const double *x1f, *x2f, *x3f, *x1v, *x2v, *x3v;
+  int32_t ind_rho, ind_pgas, ind_kappa, ind_uu1, ind_uu2, ind_uu3, ind_bb1, ind_bb2, ind_bb3;
+  double plasma_gamma, plasma_gamma_i, plasma_gamma_e; /* possibly modified by the reader */
+} bl_grid_desc;
+
+/* ------------------------------------------------------------------ camera frame
+ * The seven 4-vectors GeodesicIntegrator::InitializeCamera() derives (camera.cpp:61-380,
+ * geodesic_integrator.hpp) and the frequency list (:30-50). Filled by bl_init. */
+typedef struct bl_camera_frame {
+  double cam_x[4], u_con[4], u_cov[4], norm_con[4], norm_con_c[4], hor_con_c[4], vert_con_c[4];
+  double bh_m, bh_a, r_horizon, r_terminate, mass_msun;
+} bl_camera_frame;
+
+/* ------------------------------------------------------------------ one render call
+ * Replaces, for one adaptive level, InitializeCamera/AugmentCamera + IntegrateGeodesics* +
+ * ReverseGeodesics + CalculateSimulationSampling + SampleSimulation + Calculate*Coefficients +
+ * IntegrateUnpolarizedRadiation. The refinement decision between levels
+ * (radiation_adaptive.cpp) stays with the caller, as in blacklight.cpp:196-233. */
+typedef struct bl_render_desc {
+  int32_t level;              /* 0 = root camera; L>0 = refined blocks at res * 2^L              */
+  int32_t n_blocks;           /* level>0: number of blocks                                        */
+  const int32_t *block_locs;  /* level>0: host [n_blocks][2] = (block_v, block_u), camera.cpp:457  */
+  int64_t n_rays;             /* rays to trace in this call                                       */
+  const int32_t *pixel_map;   /* optional host [n_rays]: ray r is pixel pixel_map[r] of the level's
+                                 pixel array (multi-GPU tiling); NULL = pixels 0..n_rays-1        */
+  int32_t outputs_on_device;  /* 0: pointers below are host memory; 1: device memory (HBM)        */
+  double *image;              /* [n_q][n_rays] f64, row order = reference image offsets            */
+  int32_t *sample_num;        /* [n_rays] or NULL                                                  */
+  uint8_t *sample_flags;      /* [n_rays] or NULL                                                  */
+  double *camera_pos;         /* [n_rays][4] or NULL                                               */
+  double *camera_dir;         /* [n_rays][4] or NULL                                               */
+} bl_render_desc;
+
+typedef struct bl_stats {
+  int64_t n_rays;             /* rays traced by the last bl_render                                 */
+  int64_t n_samples;          /* kept samples (sum of sample_num)                                  */
+  int64_t n_samples_emitted;  /* samples written by the geodesic kernel (before truncation)        */
+  int64_t n_gathers;          /* S_in: samples that read the grid (8 var x 8 corners, or x1)        */
+  int64_t n_flagged;          /* rays with sample_flags set                                        */
+  int32_t max_sample_num;     /* geodesic_num_steps                                                */
+  int32_t n_chunks;
+  double algorithmic_bytes;   /* 256 (or 32) * n_gathers + 13 * n_rays                */
+  float ms_geodesic, ms_shade, ms_transfer, ms_total; /* HIP-event kernel time, last bl_render     */
+  int32_t launches_geodesic, launches_shade, launches_transfer;
+} bl_stats;
+
+typedef struct bl_ctx bl_ctx;
+
+/* Validate parameters exactly like the two reference constructors, compute the camera frame and
+ * frequency list on the host, select the device (device < 0: current device) and allocate
+ * nothing large yet. */
+BL_API int bl_init(const bl_params *p, int device, bl_ctx **out);
+/* Repack the grid into the HBM layout ([k][j][i][8 floats]) and upload it; once per snapshot. */
+BL_API int bl_set_grid(bl_ctx *ctx, const bl_grid_desc *g);
+/* Number of image rows n_q and their offsets (radiation_integrator.cpp:436-520). */
+BL_API int bl_image_num_quantities(const bl_ctx *ctx);
+BL_API int bl_camera_frame_get(const bl_ctx *ctx, bl_camera_frame *out);
+BL_API int bl_frequencies(const bl_ctx *ctx, double *out, int n);
+/* Cap on scratch HBM (bytes) used for per-sample records; default 48 GiB. */
+BL_API int bl_set_scratch_limit(bl_ctx *ctx, uint64_t bytes);
+BL_API int bl_render(bl_ctx *ctx, const bl_render_desc *d);
+BL_API int bl_get_stats(const bl_ctx *ctx, bl_stats *out);
+/* Text of the last failure on this context ("Error: ...\n"), or "" */
+BL_API const char *bl_last_error(const bl_ctx *ctx);
+/* Text of the last failure of a call that has no context (bl_init) */
+BL_API const char *bl_last_global_error(void);
+/* Warnings raised by the last call, newline separated, reference wording ("Warning: ...\n") */
+BL_API const char *bl_warnings(const bl_ctx *ctx);
+BL_API void bl_free(bl_ctx *ctx);
+
+/* Library self-description: "gfx950;hip" etc. Lets a loader verify the HIP path is the one built. */
+BL_API const char *bl_build_info(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BLACKLIGHT_AMD_H_ */

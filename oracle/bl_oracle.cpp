@@ -1,0 +1,1810 @@
+// bl_oracle.cpp - CPU oracle: restatement of the reference's per-pixel geodesic + radiative
+// transfer algorithm. TEST INFRASTRUCTURE ONLY (see bl_oracle.h). Not linked into, imported by or
+// executed from the product path.
+//
+// Each function cites the reference file:line it follows. Expression order is kept exactly as in
+// the reference wherever floating-point rounding depends on it; the file must be compiled with
+// -ffp-contract=off (oracle/Makefile) so that no product-sum is fused.
+//
+// Difference in organisation (not in arithmetic): the reference materialises every stage for all
+// pixels (geodesics -> sampling -> coefficients -> transfer); this restatement runs the same
+// stages for one ray at a time, so memory is O(ray_max_steps) per thread.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include <omp.h>
+
+#include "bl_oracle.h"
+#include "blmath.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// Math selection: glibc (tier A, -DBLO_LIBM) or the build's pinned blmath (tier B, default).
+#ifdef BLO_LIBM
+namespace M {
+inline double hypot(double x, double y) { return std::hypot(x, y); }
+inline double hypot3(double x, double y, double z) { return std::hypot(x, y, z); }
+inline double pow(double x, double y) { return std::pow(x, y); }
+inline double exp(double x) { return std::exp(x); }
+inline double expm1(double x) { return std::expm1(x); }
+inline double log(double x) { return std::log(x); }
+inline double cbrt(double x) { return std::cbrt(x); }
+inline double sin(double x) { return std::sin(x); }
+inline double cos(double x) { return std::cos(x); }
+inline double acos(double x) { return std::acos(x); }
+inline double atan(double x) { return std::atan(x); }
+inline double atan2(double y, double x) { return std::atan2(y, x); }
+}  // namespace M
+#else
+namespace M {
+inline double hypot(double x, double y) { return bl_hypot(x, y); }
+inline double hypot3(double x, double y, double z) { return bl_hypot3(x, y, z); }
+inline double pow(double x, double y) { return bl_pow(x, y); }
+inline double exp(double x) { return bl_exp(x); }
+inline double expm1(double x) { return bl_expm1(x); }
+inline double log(double x) { return bl_log(x); }
+inline double cbrt(double x) { return bl_cbrt(x); }
+inline double sin(double x) { return bl_sin(x); }
+inline double cos(double x) { return bl_cos(x); }
+inline double acos(double x) { return bl_acos(x); }
+inline double atan(double x) { return bl_atan(x); }
+inline double atan2(double y, double x) { return bl_atan2(y, x); }
+}  // namespace M
+#endif
+
+// Constants, digit-for-digit from reference src/blacklight.hpp:10-27
+namespace Math {
+constexpr double pi = 3.141592653589793;
+constexpr double sqrt2 = 1.4142135623730951;
+}  // namespace Math
+namespace Physics {
+constexpr double c = 2.99792458e10;
+constexpr double h = 6.62607015e-27;
+constexpr double k_b = 1.380649e-16;
+constexpr double m_p = 1.67262192369e-24;
+constexpr double m_e = 9.1093837015e-28;
+constexpr double e = 4.80320425e-10;
+constexpr double gg_msun = 1.32712440018e26;
+}  // namespace Physics
+constexpr int num_cell_values = 7;  // blacklight.hpp:30-33: rho, n_e, p_gas, theta_e, bb, sigma, beta_inv
+
+// std::pow(2.0, 11.0 / 12.0) of simulation_coefficients.cpp:480. g++ folds this call at compile
+// time to the correctly rounded value (checked: the constant below is in the reference binary's
+// .rodata and 11.0/12.0 is not), so it never reaches libm / the preloaded math library.
+constexpr double pow_2_11_12 = 0x1.e3437e7101343p+0;
+
+struct Oracle {
+  const bl_params *p;
+  const bl_grid_desc *g;
+  // geometry (geodesic_integrator.cpp:107-123, radiation_integrator.cpp:420-431)
+  double bh_m, bh_a, r_horizon, r_terminate, mass_msun;
+  bool ray_flat;
+  // camera (camera.cpp:27-415)
+  double cam_x[4], u_con[4], u_cov[4], norm_con[4], norm_con_c[4], hor_con_c[4], vert_con_c[4];
+  std::vector<double> image_frequencies;
+  // image rows (radiation_integrator.cpp:436-520)
+  int image_num_quantities;
+  int image_offset_time, image_offset_length, image_offset_lambda, image_offset_emission,
+      image_offset_tau, image_offset_lambda_ave, image_offset_emission_ave, image_offset_tau_int,
+      image_offset_crossings;
+  bool image_polarization;  // forced false in formula mode
+  double plasma_thermal_frac;
+};
+
+bool need(const bl_params *p, int index) { return p->has[index] != 0; }
+
+// ---------------------------------------------------------------------------------------------
+// geodesic_geometry.cpp:19-26
+double RadialGeodesicCoordinate(const Oracle &o, double x, double y, double z) {
+  double a2 = o.bh_a * o.bh_a;
+  double rr2 = x * x + y * y + z * z;
+  double r2 = 0.5 * (rr2 - a2 + M::hypot(rr2 - a2, 2.0 * o.bh_a * z));
+  double r = std::sqrt(r2);
+  return r;
+}
+
+void FlatMetric(double g[4][4]) {
+  for (int mu = 0; mu < 4; mu++)
+    for (int nu = 0; nu < 4; nu++) g[mu][nu] = 0.0;
+  g[0][0] = -1.0;
+  g[1][1] = 1.0;
+  g[2][2] = 1.0;
+  g[3][3] = 1.0;
+}
+
+// geodesic_geometry.cpp:38-93 (identical body in radiation_geometry.cpp:138-194)
+void CovariantGeodesicMetric(const Oracle &o, double x, double y, double z, double gcov[4][4]) {
+  if (o.ray_flat) return FlatMetric(gcov);
+  double a2 = o.bh_a * o.bh_a;
+  double rr2 = x * x + y * y + z * z;
+  double r2 = 0.5 * (rr2 - a2 + M::hypot(rr2 - a2, 2.0 * o.bh_a * z));
+  double r = std::sqrt(r2);
+  double f = 2.0 * o.bh_m * r2 * r / (r2 * r2 + a2 * z * z);
+  double l[4];
+  l[0] = 1.0;
+  l[1] = (r * x + o.bh_a * y) / (r2 + a2);
+  l[2] = (r * y - o.bh_a * x) / (r2 + a2);
+  l[3] = z / r;
+  for (int mu = 0; mu < 4; mu++)
+    for (int nu = 0; nu < 4; nu++) gcov[mu][nu] = f * l[mu] * l[nu];
+  gcov[0][0] = f * l[0] * l[0] - 1.0;
+  gcov[1][1] = f * l[1] * l[1] + 1.0;
+  gcov[2][2] = f * l[2] * l[2] + 1.0;
+  gcov[3][3] = f * l[3] * l[3] + 1.0;
+}
+
+// geodesic_geometry.cpp:105-161 (identical body in radiation_geometry.cpp:206-262)
+void ContravariantGeodesicMetric(const Oracle &o, double x, double y, double z, double gcon[4][4]) {
+  if (o.ray_flat) return FlatMetric(gcon);
+  double a2 = o.bh_a * o.bh_a;
+  double rr2 = x * x + y * y + z * z;
+  double r2 = 0.5 * (rr2 - a2 + M::hypot(rr2 - a2, 2.0 * o.bh_a * z));
+  double r = std::sqrt(r2);
+  double f = 2.0 * o.bh_m * r2 * r / (r2 * r2 + a2 * z * z);
+  double l[4];
+  l[0] = -1.0;
+  l[1] = (r * x + o.bh_a * y) / (r2 + a2);
+  l[2] = (r * y - o.bh_a * x) / (r2 + a2);
+  l[3] = z / r;
+  for (int mu = 0; mu < 4; mu++)
+    for (int nu = 0; nu < 4; nu++) gcon[mu][nu] = -f * l[mu] * l[nu];
+  gcon[0][0] = -f * l[0] * l[0] - 1.0;
+  gcon[1][1] = -f * l[1] * l[1] + 1.0;
+  gcon[2][2] = -f * l[2] * l[2] + 1.0;
+  gcon[3][3] = -f * l[3] * l[3] + 1.0;
+}
+
+// geodesic_geometry.cpp:173-276
+void ContravariantGeodesicMetricDerivative(const Oracle &o, double x, double y, double z,
+                                           double dgcon[3][4][4]) {
+  if (o.ray_flat) {
+    for (int a = 0; a < 3; a++)
+      for (int mu = 0; mu < 4; mu++)
+        for (int nu = 0; nu < 4; nu++) dgcon[a][mu][nu] = 0.0;
+    return;
+  }
+  double bh_a = o.bh_a;
+  double a2 = bh_a * bh_a;
+  double rr2 = x * x + y * y + z * z;
+  double r2 = 0.5 * (rr2 - a2 + M::hypot(rr2 - a2, 2.0 * bh_a * z));
+  double r = std::sqrt(r2);
+  double f = 2.0 * o.bh_m * r2 * r / (r2 * r2 + a2 * z * z);
+  double l[4];
+  l[0] = -1.0;
+  l[1] = (r * x + bh_a * y) / (r2 + a2);
+  l[2] = (r * y - bh_a * x) / (r2 + a2);
+  l[3] = z / r;
+  double dr[3], df[3], dl[4][3];
+  dr[0] = r * x / (2.0 * r2 - rr2 + a2);
+  dr[1] = r * y / (2.0 * r2 - rr2 + a2);
+  dr[2] = (r * z + a2 * z / r) / (2.0 * r2 - rr2 + a2);
+  df[0] = -(r2 * r2 - 3.0 * a2 * z * z) * dr[0] / (r * (r2 * r2 + a2 * z * z)) * f;
+  df[1] = -(r2 * r2 - 3.0 * a2 * z * z) * dr[1] / (r * (r2 * r2 + a2 * z * z)) * f;
+  df[2] = -((r2 * r2 - 3.0 * a2 * z * z) * dr[2] + 2.0 * a2 * r * z) / (r * (r2 * r2 + a2 * z * z)) * f;
+  dl[0][0] = 0.0;
+  dl[0][1] = 0.0;
+  dl[0][2] = 0.0;
+  dl[1][0] = ((x - 2.0 * r * l[1]) * dr[0] + r) / (r2 + a2);
+  dl[1][1] = ((x - 2.0 * r * l[1]) * dr[1] + bh_a) / (r2 + a2);
+  dl[1][2] = (x - 2.0 * r * l[1]) * dr[2] / (r2 + a2);
+  dl[2][0] = ((y - 2.0 * r * l[2]) * dr[0] - bh_a) / (r2 + a2);
+  dl[2][1] = ((y - 2.0 * r * l[2]) * dr[1] + r) / (r2 + a2);
+  dl[2][2] = (y - 2.0 * r * l[2]) * dr[2] / (r2 + a2);
+  dl[3][0] = -z / r2 * dr[0];
+  dl[3][1] = -z / r2 * dr[1];
+  dl[3][2] = -z / r2 * dr[2] + 1.0 / r;
+  // :223-274, one pattern for all 48 components
+  for (int a = 0; a < 3; a++)
+    for (int mu = 0; mu < 4; mu++)
+      for (int nu = 0; nu < 4; nu++)
+        dgcon[a][mu][nu] = -(df[a] * l[mu] * l[nu] + f * dl[mu][a] * l[nu] + f * l[mu] * dl[nu][a]);
+}
+
+// geodesics.cpp:867-893
+void GeodesicSubstepWithDistance(const Oracle &o, const double y[9], double k[9]) {
+  double gcov[4][4], gcon[4][4], dgcon[3][4][4];
+  CovariantGeodesicMetric(o, y[1], y[2], y[3], gcov);
+  ContravariantGeodesicMetric(o, y[1], y[2], y[3], gcon);
+  ContravariantGeodesicMetricDerivative(o, y[1], y[2], y[3], dgcon);
+  for (int p = 0; p < 9; p++) k[p] = 0.0;
+  for (int mu = 0; mu < 4; mu++)
+    for (int nu = 0; nu < 4; nu++) k[mu] += gcon[mu][nu] * y[4 + nu];
+  for (int a = 1; a < 4; a++)
+    for (int mu = 0; mu < 4; mu++)
+      for (int nu = 0; nu < 4; nu++) k[4 + a] -= 0.5 * dgcon[a - 1][mu][nu] * y[4 + mu] * y[4 + nu];
+  double temp_a[4] = {};
+  for (int a = 1; a < 4; a++)
+    for (int mu = 0; mu < 4; mu++)
+      temp_a[a] += (gcon[a][mu] - gcon[0][a] * gcon[0][mu] / gcon[0][0]) * y[4 + mu];
+  for (int a = 1; a < 4; a++)
+    for (int b = 1; b < 4; b++) k[8] += gcov[a][b] * temp_a[a] * temp_a[b];
+  k[8] = -std::sqrt(k[8]);
+}
+
+// geodesics.cpp:909-925
+void GeodesicSubstepWithoutDistance(const Oracle &o, const double y[8], double k[8]) {
+  double gcon[4][4], dgcon[3][4][4];
+  ContravariantGeodesicMetric(o, y[1], y[2], y[3], gcon);
+  ContravariantGeodesicMetricDerivative(o, y[1], y[2], y[3], dgcon);
+  for (int p = 0; p < 8; p++) k[p] = 0.0;
+  for (int mu = 0; mu < 4; mu++)
+    for (int nu = 0; nu < 4; nu++) k[mu] += gcon[mu][nu] * y[4 + nu];
+  for (int a = 1; a < 4; a++)
+    for (int mu = 0; mu < 4; mu++)
+      for (int nu = 0; nu < 4; nu++) k[4 + a] -= 0.5 * dgcon[a - 1][mu][nu] * y[4 + mu] * y[4 + nu];
+}
+
+// Null-condition renormalisation of the spatial momentum (geodesics.cpp:296-309, :352-371)
+void RenormalizeMomentum(const Oracle &o, double x, double y, double z, double k0, double k[3]) {
+  double gcon[4][4];
+  ContravariantGeodesicMetric(o, x, y, z, gcon);
+  double kk[4] = {k0, k[0], k[1], k[2]};
+  double temp_a = 0.0;
+  for (int a = 1; a < 4; a++)
+    for (int b = 1; b < 4; b++) temp_a += gcon[a][b] * kk[a] * kk[b];
+  double temp_b = 0.0;
+  for (int a = 1; a < 4; a++) temp_b += 2.0 * gcon[0][a] * kk[0] * kk[a];
+  double temp_c = gcon[0][0] * kk[0] * kk[0];
+  double temp_d = std::sqrt(temp_b * temp_b - 4.0 * temp_a * temp_c);
+  double factor = temp_b < 0.0 ? (temp_d - temp_b) / (2.0 * temp_a) : -2.0 * temp_c / (temp_b + temp_d);
+  for (int a = 0; a < 3; a++) k[a] *= factor;
+}
+
+// ---------------------------------------------------------------------------------------------
+// camera.cpp:27-380 (serial part of InitializeCamera)
+void InitializeCamera(Oracle &o) {
+  const bl_params &p = *o.p;
+  int nf = p.image_num_frequencies;
+  o.image_frequencies.assign(nf, 0.0);
+  if (nf == 1)
+    o.image_frequencies[0] = p.image_frequency;
+  else {
+    o.image_frequencies[0] = p.image_frequency_start;
+    o.image_frequencies[nf - 1] = p.image_frequency_end;
+    for (int l = 1; l < nf - 1; l++) {
+      double frac = static_cast<double>(l) / static_cast<double>(nf - 1);
+      if (p.image_frequency_spacing == BL_SPACING_LIN_FREQ)
+        o.image_frequencies[l] =
+            p.image_frequency_start + frac * (p.image_frequency_end - p.image_frequency_start);
+      else if (p.image_frequency_spacing == BL_SPACING_LIN_WAVE)
+        o.image_frequencies[l] = 1.0 / (1.0 / p.image_frequency_start
+            + frac * (1.0 / p.image_frequency_end - 1.0 / p.image_frequency_start));
+      else if (p.image_frequency_spacing == BL_SPACING_LOG)
+        o.image_frequencies[l] = M::exp(M::log(p.image_frequency_start)
+            + frac * M::log(p.image_frequency_end / p.image_frequency_start));
+    }
+  }
+
+  double bh_m = o.bh_m, bh_a = o.bh_a;
+  double camera_r = p.camera_r;
+  bool ray_flat = o.ray_flat;
+  bool camera_pole = p.camera_pole != 0;
+  double sth = M::sin(p.camera_th);
+  double cth = M::cos(p.camera_th);
+  double sph = M::sin(p.camera_ph);
+  double cph = M::cos(p.camera_ph);
+  double srot = M::sin(p.camera_rotation);
+  double crot = M::cos(p.camera_rotation);
+  double *cam_x = o.cam_x, *u_con = o.u_con, *u_cov = o.u_cov, *norm_con = o.norm_con;
+  double *norm_con_c = o.norm_con_c, *hor_con_c = o.hor_con_c, *vert_con_c = o.vert_con_c;
+
+  cam_x[0] = 0.0;
+  cam_x[1] = sth * (camera_r * cph - bh_a * sph);
+  cam_x[2] = sth * (camera_r * sph + bh_a * cph);
+  cam_x[3] = camera_r * cth;
+  if (ray_flat) {
+    cam_x[1] = camera_r * sth * cph;
+    cam_x[2] = camera_r * sth * sph;
+  }
+  double z_sign = cam_x[3] >= 0.0 ? 1.0 : -1.0;
+
+  double a2 = bh_a * bh_a;
+  double r2 = camera_r * camera_r;
+  double delta = r2 - 2.0 * bh_m * camera_r + a2;
+  double sigma = r2 + a2 * cth * cth;
+  double g_cov_r_r = 1.0 + 2.0 * bh_m * camera_r / sigma;
+  double g_cov_r_th = 0.0;
+  double g_cov_r_ph = -(1.0 + 2.0 * bh_m * camera_r / sigma) * bh_a * sth * sth;
+  double g_cov_th_th = sigma;
+  double g_cov_th_ph = 0.0;
+  double g_cov_ph_ph = (r2 + a2 + 2.0 * bh_m * a2 * camera_r / sigma * sth * sth) * sth * sth;
+  double g_con_t_t = -(1.0 + 2.0 * bh_m * camera_r / sigma);
+  double g_con_t_r = 2.0 * bh_m * camera_r / sigma;
+  double g_con_t_th = 0.0;
+  double g_con_t_ph = 0.0;
+  double g_con_r_r = delta / sigma;
+  double g_con_r_th = 0.0;
+  double g_con_r_ph = bh_a / sigma;
+  double g_con_th_th = 1.0 / sigma;
+  double g_con_th_ph = 0.0;
+  double g_con_ph_ph = 1.0 / (sigma * sth * sth);
+  if (ray_flat and not camera_pole) {
+    g_cov_r_r = 1.0; g_cov_r_th = 0.0; g_cov_r_ph = 0.0; g_cov_th_th = r2; g_cov_th_ph = 0.0;
+    g_cov_ph_ph = r2 * sth * sth;
+    g_con_t_t = -1.0; g_con_t_r = 0.0; g_con_t_th = 0.0; g_con_t_ph = 0.0; g_con_r_r = 1.0;
+    g_con_r_th = 0.0; g_con_r_ph = 0.0; g_con_th_th = 1.0 / r2; g_con_th_ph = 0.0;
+    g_con_ph_ph = 1.0 / (r2 * sth * sth);
+  }
+  if (camera_pole and not ray_flat) {
+    double f = 2.0 * bh_m * camera_r / (r2 + a2);
+    g_cov_r_r = 1.0 + f; g_cov_r_th = 0.0; g_cov_r_ph = 0.0; g_cov_th_th = 1.0; g_cov_th_ph = 0.0;
+    g_cov_ph_ph = 1.0;
+    g_con_t_t = -1.0 - f; g_con_t_r = z_sign * f; g_con_t_th = 0.0; g_con_t_ph = 0.0;
+    g_con_r_r = 1.0 - f; g_con_r_th = 0.0; g_con_r_ph = 0.0; g_con_th_th = 1.0; g_con_th_ph = 0.0;
+    g_con_ph_ph = 1.0;
+  }
+  if (ray_flat and camera_pole) {
+    g_cov_r_r = 1.0; g_cov_r_th = 0.0; g_cov_r_ph = 0.0; g_cov_th_th = 1.0; g_cov_th_ph = 0.0;
+    g_cov_ph_ph = 1.0;
+    g_con_t_t = -1.0; g_con_t_r = 0.0; g_con_t_th = 0.0; g_con_t_ph = 0.0; g_con_r_r = 1.0;
+    g_con_r_th = 0.0; g_con_r_ph = 0.0; g_con_th_th = 1.0; g_con_th_ph = 0.0; g_con_ph_ph = 1.0;
+  }
+
+  // camera velocity in spherical coordinates (:152-164)
+  double camera_urn = p.camera_urn, camera_uthn = p.camera_uthn, camera_uphn = p.camera_uphn;
+  double alpha = 1.0 / std::sqrt(-g_con_t_t);
+  double beta_con_r = -g_con_t_r / g_con_t_t;
+  double beta_con_th = -g_con_t_th / g_con_t_t;
+  double beta_con_ph = -g_con_t_ph / g_con_t_t;
+  double utn = std::sqrt(1.0 + g_cov_r_r * camera_urn * camera_urn
+      + 2.0 * g_cov_r_th * camera_urn * camera_uthn + 2.0 * g_cov_r_ph * camera_urn * camera_uphn
+      + g_cov_th_th * camera_uthn * camera_uthn + 2.0 * g_cov_th_ph * camera_uthn * camera_uphn
+      + g_cov_ph_ph * camera_uphn * camera_uphn);
+  u_con[0] = utn / alpha;
+  double ur = camera_urn - beta_con_r / alpha * utn;
+  double uth = camera_uthn - beta_con_th / alpha * utn;
+  double uph = camera_uphn - beta_con_ph / alpha * utn;
+
+  // Jacobian (:166-199)
+  double dx_dr = sth * cph;
+  double dy_dr = sth * sph;
+  double dz_dr = cth;
+  double dx_dth = cth * (camera_r * cph - bh_a * sph);
+  double dy_dth = cth * (camera_r * sph + bh_a * cph);
+  double dz_dth = -camera_r * sth;
+  double dx_dph = sth * (-camera_r * sph - bh_a * cph);
+  double dy_dph = sth * (camera_r * cph - bh_a * sph);
+  double dz_dph = 0.0;
+  if (ray_flat and not camera_pole) {
+    dx_dr = sth * cph; dy_dr = sth * sph; dz_dr = cth;
+    dx_dth = camera_r * cth * cph; dy_dth = camera_r * cth * sph; dz_dth = -camera_r * sth;
+    dx_dph = -camera_r * sth * sph; dy_dph = camera_r * sth * cph; dz_dph = 0.0;
+  }
+  if (camera_pole) {
+    dx_dr = 0.0; dy_dr = 0.0; dz_dr = z_sign;
+    dx_dth = 1.0; dy_dth = 0.0; dz_dth = 0.0;
+    dx_dph = 0.0; dy_dph = 1.0; dz_dph = 0.0;
+  }
+
+  // camera velocity (:201-212)
+  u_con[1] = dx_dr * ur + dx_dth * uth + dx_dph * uph;
+  u_con[2] = dy_dr * ur + dy_dth * uth + dy_dph * uph;
+  u_con[3] = dz_dr * ur + dz_dth * uth + dz_dph * uph;
+  double g_cov[4][4];
+  CovariantGeodesicMetric(o, cam_x[1], cam_x[2], cam_x[3], g_cov);
+  for (int mu = 0; mu < 4; mu++) {
+    u_cov[mu] = 0.0;
+    for (int nu = 0; nu < 4; nu++) u_cov[mu] += g_cov[mu][nu] * u_con[nu];
+  }
+
+  // photon momentum in spherical coordinates (:214-227)
+  double g_con_rn_rn = (g_con_t_t * g_con_r_r - g_con_t_r * g_con_t_r) / g_con_t_t;
+  double g_con_rn_thn = (g_con_t_t * g_con_r_th - g_con_t_r * g_con_t_th) / g_con_t_t;
+  double g_con_rn_phn = (g_con_t_t * g_con_r_ph - g_con_t_r * g_con_t_ph) / g_con_t_t;
+  double g_con_thn_thn = (g_con_t_t * g_con_th_th - g_con_t_th * g_con_t_th) / g_con_t_t;
+  double g_con_thn_phn = (g_con_t_t * g_con_th_ph - g_con_t_th * g_con_t_ph) / g_con_t_t;
+  double g_con_phn_phn = (g_con_t_t * g_con_ph_ph - g_con_t_ph * g_con_t_ph) / g_con_t_t;
+  double k_rn = p.camera_k_r;
+  double k_thn = p.camera_k_th;
+  double k_phn = p.camera_k_ph;
+  double k_tn = -std::sqrt(g_con_rn_rn * k_rn * k_rn + 2.0 * g_con_rn_thn * k_rn * k_thn
+      + 2.0 * g_con_rn_phn * k_rn * k_phn + g_con_thn_thn * k_thn * k_thn
+      + 2.0 * g_con_thn_phn * k_thn * k_phn + g_con_phn_phn * k_phn * k_phn);
+  double k_t = alpha * k_tn + (beta_con_r * k_rn + beta_con_th * k_thn + beta_con_ph * k_phn);
+
+  // Jacobian (:229-264)
+  double rr2 = cam_x[1] * cam_x[1] + cam_x[2] * cam_x[2] + cam_x[3] * cam_x[3];
+  double dr_dx = camera_r * cam_x[1] / (2.0 * r2 - rr2 + a2);
+  double dr_dy = camera_r * cam_x[2] / (2.0 * r2 - rr2 + a2);
+  double dr_dz = (camera_r * cam_x[3] + a2 * cam_x[3] / camera_r) / (2.0 * r2 - rr2 + a2);
+  double dth_dx = cam_x[3] * dr_dx / (r2 * sth);
+  double dth_dy = cam_x[3] * dr_dy / (r2 * sth);
+  double dth_dz = (cam_x[3] * dr_dz - camera_r) / (r2 * sth);
+  double dph_dx = -cam_x[2] / (cam_x[1] * cam_x[1] + cam_x[2] * cam_x[2]) + bh_a / (r2 + a2) * dr_dx;
+  double dph_dy = cam_x[1] / (cam_x[1] * cam_x[1] + cam_x[2] * cam_x[2]) + bh_a / (r2 + a2) * dr_dy;
+  double dph_dz = bh_a / (r2 + a2) * dr_dz;
+  if (ray_flat and not camera_pole) {
+    dr_dx = cam_x[1] / camera_r; dr_dy = cam_x[2] / camera_r; dr_dz = cam_x[3] / camera_r;
+    dth_dx = cth * cph / camera_r; dth_dy = cth * sph / camera_r; dth_dz = -sth / camera_r;
+    dph_dx = -sph / (camera_r * sth); dph_dy = cph / (camera_r * sth); dph_dz = 0.0;
+  }
+  if (camera_pole) {
+    dr_dx = 0.0; dr_dy = 0.0; dr_dz = z_sign;
+    dth_dx = 1.0; dth_dy = 0.0; dth_dz = 0.0;
+    dph_dx = 0.0; dph_dy = 1.0; dph_dz = 0.0;
+  }
+
+  // photon momentum (:266-270)
+  double k_x = dr_dx * p.camera_k_r + dth_dx * p.camera_k_th + dph_dx * p.camera_k_ph;
+  double k_y = dr_dy * p.camera_k_r + dth_dy * p.camera_k_th + dph_dy * p.camera_k_ph;
+  double k_z = dr_dz * p.camera_k_r + dth_dz * p.camera_k_th + dph_dz * p.camera_k_ph;
+  double k_tc = u_con[0] * k_t + u_con[1] * k_x + u_con[2] * k_y + u_con[3] * k_z;
+
+  // contravariant metric in camera frame (:272-280)
+  double g_con[4][4];
+  ContravariantGeodesicMetric(o, cam_x[1], cam_x[2], cam_x[3], g_con);
+  double g_con_xc_xc = g_con[1][1] + u_con[1] * u_con[1];
+  double g_con_xc_yc = g_con[1][2] + u_con[1] * u_con[2];
+  double g_con_xc_zc = g_con[1][3] + u_con[1] * u_con[3];
+  double g_con_yc_yc = g_con[2][2] + u_con[2] * u_con[2];
+  double g_con_yc_zc = g_con[2][3] + u_con[2] * u_con[3];
+  double g_con_zc_zc = g_con[3][3] + u_con[3] * u_con[3];
+
+  // camera normal (:282-303)
+  double norm_cov_xc = k_x - u_cov[1] / u_cov[0] * k_t;
+  double norm_cov_yc = k_y - u_cov[2] / u_cov[0] * k_t;
+  double norm_cov_zc = k_z - u_cov[3] / u_cov[0] * k_t;
+  norm_con_c[0] = -k_tc;
+  norm_con_c[1] = g_con_xc_xc * norm_cov_xc + g_con_xc_yc * norm_cov_yc + g_con_xc_zc * norm_cov_zc;
+  norm_con_c[2] = g_con_xc_yc * norm_cov_xc + g_con_yc_yc * norm_cov_yc + g_con_yc_zc * norm_cov_zc;
+  norm_con_c[3] = g_con_xc_zc * norm_cov_xc + g_con_yc_zc * norm_cov_yc + g_con_zc_zc * norm_cov_zc;
+  double norm_norm = std::sqrt(norm_cov_xc * norm_con_c[1] + norm_cov_yc * norm_con_c[2]
+      + norm_cov_zc * norm_con_c[3]);
+  norm_cov_xc /= norm_norm;
+  norm_cov_yc /= norm_norm;
+  norm_cov_zc /= norm_norm;
+  norm_con_c[0] /= norm_norm;
+  norm_con_c[1] /= norm_norm;
+  norm_con_c[2] /= norm_norm;
+  norm_con_c[3] /= norm_norm;
+  norm_con[0] = u_con[0] * norm_con_c[0]
+      - (u_cov[1] * norm_con_c[1] + u_cov[2] * norm_con_c[2] + u_cov[3] * norm_con_c[3]) / u_cov[0];
+  norm_con[1] = norm_con_c[1] + u_con[1] * norm_con_c[0];
+  norm_con[2] = norm_con_c[2] + u_con[2] * norm_con_c[0];
+  norm_con[3] = norm_con_c[3] + u_con[3] * norm_con_c[0];
+
+  // up direction (:305-313)
+  double up_con_xc = 0.0;
+  double up_con_yc = 0.0;
+  double up_con_zc = 1.0;
+  if (camera_pole) {
+    up_con_yc = 1.0;
+    up_con_zc = 0.0;
+  }
+
+  // covariant metric in camera frame (:315-333)
+  double g_cov_xc_xc = g_cov[1][1] - u_cov[1] / u_cov[0] * g_cov[1][0]
+      - u_cov[1] / u_cov[0] * g_cov[1][0] + u_cov[1] * u_cov[1] / (u_cov[0] * u_cov[0]) * g_cov[0][0];
+  double g_cov_xc_yc = g_cov[1][2] - u_cov[1] / u_cov[0] * g_cov[2][0]
+      - u_cov[2] / u_cov[0] * g_cov[1][0] + u_cov[1] * u_cov[2] / (u_cov[0] * u_cov[0]) * g_cov[0][0];
+  double g_cov_xc_zc = g_cov[1][3] - u_cov[1] / u_cov[0] * g_cov[3][0]
+      - u_cov[3] / u_cov[0] * g_cov[1][0] + u_cov[1] * u_cov[3] / (u_cov[0] * u_cov[0]) * g_cov[0][0];
+  double g_cov_yc_yc = g_cov[2][2] - u_cov[2] / u_cov[0] * g_cov[2][0]
+      - u_cov[2] / u_cov[0] * g_cov[2][0] + u_cov[2] * u_cov[2] / (u_cov[0] * u_cov[0]) * g_cov[0][0];
+  double g_cov_yc_zc = g_cov[2][3] - u_cov[2] / u_cov[0] * g_cov[3][0]
+      - u_cov[3] / u_cov[0] * g_cov[2][0] + u_cov[2] * u_cov[3] / (u_cov[0] * u_cov[0]) * g_cov[0][0];
+  double g_cov_zc_zc = g_cov[3][3] - u_cov[3] / u_cov[0] * g_cov[3][0]
+      - u_cov[3] / u_cov[0] * g_cov[3][0] + u_cov[3] * u_cov[3] / (u_cov[0] * u_cov[0]) * g_cov[0][0];
+
+  // vertical direction (:335-354)
+  double up_norm = up_con_xc * norm_cov_xc + up_con_yc * norm_cov_yc + up_con_zc * norm_cov_zc;
+  vert_con_c[0] = 0.0;
+  vert_con_c[1] = up_con_xc - up_norm * norm_con_c[1];
+  vert_con_c[2] = up_con_yc - up_norm * norm_con_c[2];
+  vert_con_c[3] = up_con_zc - up_norm * norm_con_c[3];
+  double vert_cov_xc = g_cov_xc_xc * vert_con_c[1] + g_cov_xc_yc * vert_con_c[2] + g_cov_xc_zc * vert_con_c[3];
+  double vert_cov_yc = g_cov_xc_yc * vert_con_c[1] + g_cov_yc_yc * vert_con_c[2] + g_cov_yc_zc * vert_con_c[3];
+  double vert_cov_zc = g_cov_xc_zc * vert_con_c[1] + g_cov_yc_zc * vert_con_c[2] + g_cov_zc_zc * vert_con_c[3];
+  double vert_norm = std::sqrt(vert_cov_xc * vert_con_c[1] + vert_cov_yc * vert_con_c[2]
+      + vert_cov_zc * vert_con_c[3]);
+  vert_cov_xc /= vert_norm;
+  vert_cov_yc /= vert_norm;
+  vert_cov_zc /= vert_norm;
+  vert_con_c[1] /= vert_norm;
+  vert_con_c[2] /= vert_norm;
+  vert_con_c[3] /= vert_norm;
+
+  // determinant (:356-360)
+  double det = g_cov_xc_xc * (g_cov_yc_yc * g_cov_zc_zc - g_cov_yc_zc * g_cov_yc_zc)
+      + g_cov_xc_yc * (g_cov_yc_zc * g_cov_xc_zc - g_cov_xc_yc * g_cov_zc_zc)
+      + g_cov_xc_zc * (g_cov_xc_yc * g_cov_yc_zc - g_cov_yc_yc * g_cov_xc_zc);
+  double det_sqrt = std::sqrt(det);
+
+  // horizontal direction (:362-366)
+  hor_con_c[0] = 0.0;
+  hor_con_c[1] = (vert_cov_yc * norm_cov_zc - vert_cov_zc * norm_cov_yc) / det_sqrt;
+  hor_con_c[2] = (vert_cov_zc * norm_cov_xc - vert_cov_xc * norm_cov_zc) / det_sqrt;
+  hor_con_c[3] = (vert_cov_xc * norm_cov_yc - vert_cov_yc * norm_cov_xc) / det_sqrt;
+
+  // rotation (:368-380)
+  double temp_hor_con_xc = hor_con_c[1];
+  double temp_hor_con_yc = hor_con_c[2];
+  double temp_hor_con_zc = hor_con_c[3];
+  double temp_vert_con_xc = vert_con_c[1];
+  double temp_vert_con_yc = vert_con_c[2];
+  double temp_vert_con_zc = vert_con_c[3];
+  hor_con_c[1] = temp_hor_con_xc * crot - temp_vert_con_xc * srot;
+  hor_con_c[2] = temp_hor_con_yc * crot - temp_vert_con_yc * srot;
+  hor_con_c[3] = temp_hor_con_zc * crot - temp_vert_con_zc * srot;
+  vert_con_c[1] = temp_vert_con_xc * crot + temp_hor_con_xc * srot;
+  vert_con_c[2] = temp_vert_con_yc * crot + temp_hor_con_yc * srot;
+  vert_con_c[3] = temp_vert_con_zc * crot + temp_hor_con_zc * srot;
+}
+
+// Shared tail of SetPixelPlane / SetPixelPinhole (camera.cpp:553-583, :639-669)
+void FinishPixel(const Oracle &o, const double position[4], double pcon[4], double direction[4],
+                 double *factor) {
+  double gcov[4][4];
+  CovariantGeodesicMetric(o, position[1], position[2], position[3], gcov);
+  double temp_a = gcov[0][0];
+  double temp_b = 0.0;
+  for (int a = 1; a < 4; a++) temp_b += 2.0 * gcov[0][a] * pcon[a];
+  double temp_c = 0.0;
+  for (int a = 1; a < 4; a++)
+    for (int b = 1; b < 4; b++) temp_c += gcov[a][b] * pcon[a] * pcon[b];
+  double temp_d = std::sqrt(std::max(temp_b * temp_b - 4.0 * temp_a * temp_c, 0.0));
+  pcon[0] = temp_a == 0.0 ? -temp_c / (2.0 * temp_b)
+      : (temp_b < 0.0 ? 2.0 * temp_c / (temp_d - temp_b) : -(temp_b + temp_d) / (2.0 * temp_a));
+  for (int mu = 0; mu < 4; mu++) {
+    direction[mu] = 0.0;
+    for (int nu = 0; nu < 4; nu++) direction[mu] += gcov[mu][nu] * pcon[nu];
+  }
+  double nu_local = 0.0;
+  if (o.p->image_normalization == BL_NORM_CAMERA)
+    for (int mu = 0; mu < 4; mu++) nu_local -= direction[mu] * o.u_con[mu];
+  else if (o.p->image_normalization == BL_NORM_INFINITY)
+    nu_local = -direction[0];
+  *factor = 1.0 / nu_local;
+}
+
+// camera.cpp:528-585
+void SetPixelPlane(const Oracle &o, double u_ind, double v_ind, double position[4],
+                   double direction[4], double *factor) {
+  double u = u_ind * o.bh_m * o.p->camera_width;
+  double v = v_ind * o.bh_m * o.p->camera_width;
+  double dtc = u * o.hor_con_c[0] + v * o.vert_con_c[0];
+  double dxc = u * o.hor_con_c[1] + v * o.vert_con_c[1];
+  double dyc = u * o.hor_con_c[2] + v * o.vert_con_c[2];
+  double dzc = u * o.hor_con_c[3] + v * o.vert_con_c[3];
+  double dt = o.u_con[0] * dtc - (o.u_cov[1] * dxc + o.u_cov[2] * dyc + o.u_cov[3] * dzc) / o.u_cov[0];
+  double dx = dxc + o.u_con[1] * dtc;
+  double dy = dyc + o.u_con[2] * dtc;
+  double dz = dzc + o.u_con[3] * dtc;
+  position[0] = o.cam_x[0] + dt;
+  position[1] = o.cam_x[1] + dx;
+  position[2] = o.cam_x[2] + dy;
+  position[3] = o.cam_x[3] + dz;
+  double pcon[4];
+  pcon[1] = o.norm_con[1];
+  pcon[2] = o.norm_con[2];
+  pcon[3] = o.norm_con[3];
+  FinishPixel(o, position, pcon, direction, factor);
+}
+
+// camera.cpp:608-671
+void SetPixelPinhole(const Oracle &o, double u_ind, double v_ind, double position[4],
+                     double direction[4], double *factor) {
+  position[0] = o.cam_x[0];
+  position[1] = o.cam_x[1];
+  position[2] = o.cam_x[2];
+  position[3] = o.cam_x[3];
+  double u = u_ind * o.bh_m * o.p->camera_width;
+  double v = v_ind * o.bh_m * o.p->camera_width;
+  double normalization = M::hypot3(u, v, o.p->camera_r);
+  double frac_norm = o.p->camera_r / normalization;
+  double frac_hor = -u / normalization;
+  double frac_vert = -v / normalization;
+  double dir_con_tc = o.norm_con_c[0];
+  double dir_con_xc = frac_norm * o.norm_con_c[1] + frac_hor * o.hor_con_c[1] + frac_vert * o.vert_con_c[1];
+  double dir_con_yc = frac_norm * o.norm_con_c[2] + frac_hor * o.hor_con_c[2] + frac_vert * o.vert_con_c[2];
+  double dir_con_zc = frac_norm * o.norm_con_c[3] + frac_hor * o.hor_con_c[3] + frac_vert * o.vert_con_c[3];
+  double pcon[4];
+  pcon[1] = dir_con_xc + o.u_con[1] * dir_con_tc;
+  pcon[2] = dir_con_yc + o.u_con[2] * dir_con_tc;
+  pcon[3] = dir_con_zc + o.u_con[3] * dir_con_tc;
+  FinishPixel(o, position, pcon, direction, factor);
+}
+
+// Pixel index within a level -> fractional image-plane coordinates
+// (camera.cpp:393-396 for the root camera, :465-479 for refined blocks)
+void PixelIndices(const Oracle &o, const bl_render_desc &d, int64_t pixel, double *u_ind, double *v_ind) {
+  const bl_params &p = *o.p;
+  if (d.level == 0) {
+    int m2 = static_cast<int>(pixel / p.camera_resolution);
+    int m1 = static_cast<int>(pixel % p.camera_resolution);
+    *u_ind = (m1 - p.camera_resolution / 2.0 + 0.5) / p.camera_resolution;
+    *v_ind = (m2 - p.camera_resolution / 2.0 + 0.5) / p.camera_resolution;
+  } else {
+    int bs = p.adaptive_block_size;
+    int block_num_pix = bs * bs;
+    int64_t block = pixel / block_num_pix;
+    int m = static_cast<int>(pixel % block_num_pix);
+    int effective_resolution = p.camera_resolution;
+    for (int n = 1; n <= d.level; n++) effective_resolution *= 2;
+    int block_v = d.block_locs[2 * block + 0];
+    int block_u = d.block_locs[2 * block + 1];
+    int m_offset = block_v * bs;
+    int l_offset = block_u * bs;
+    int m2 = m / bs;
+    int m1 = m % bs;
+    *u_ind = (m1 + l_offset - effective_resolution / 2.0 + 0.5) / effective_resolution;
+    *v_ind = (m2 + m_offset - effective_resolution / 2.0 + 0.5) / effective_resolution;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Per-ray scratch
+struct RayBuffers {
+  std::vector<double> geodesic_pos, geodesic_dir, geodesic_len;  // forward order, ray_max_steps
+  std::vector<double> sample_pos, sample_dir, sample_len;        // reversed
+  std::vector<double> j_i, alpha_i;                              // [n_nu][n]
+  std::vector<double> cell_values;                               // [7][n]
+  std::vector<unsigned char> sample_cut;
+  explicit RayBuffers(int max_steps, int n_nu)
+      : geodesic_pos(4 * static_cast<size_t>(max_steps)), geodesic_dir(4 * static_cast<size_t>(max_steps)),
+        geodesic_len(max_steps), sample_pos(4 * static_cast<size_t>(max_steps)),
+        sample_dir(4 * static_cast<size_t>(max_steps)), sample_len(max_steps),
+        j_i(static_cast<size_t>(n_nu) * max_steps), alpha_i(static_cast<size_t>(n_nu) * max_steps),
+        cell_values(static_cast<size_t>(num_cell_values) * max_steps), sample_cut(max_steps) {}
+};
+
+// geodesics.cpp:39-324 (per-ray body of IntegrateGeodesicsDP)
+void IntegrateRayDP(const Oracle &o, const double camera_pos[4], const double camera_dir[4],
+                    RayBuffers &b, int *p_sample_num, bool *p_flag) {
+  // coefficients (:42-72)
+  double a_vals[7][6] = {};
+  a_vals[1][0] = 1.0 / 5.0;
+  a_vals[2][0] = 3.0 / 40.0;
+  a_vals[2][1] = 9.0 / 40.0;
+  a_vals[3][0] = 44.0 / 45.0;
+  a_vals[3][1] = -56.0 / 15.0;
+  a_vals[3][2] = 32.0 / 9.0;
+  a_vals[4][0] = 19372.0 / 6561.0;
+  a_vals[4][1] = -25360.0 / 2187.0;
+  a_vals[4][2] = 64448.0 / 6561.0;
+  a_vals[4][3] = -212.0 / 729.0;
+  a_vals[5][0] = 9017.0 / 3168.0;
+  a_vals[5][1] = -355.0 / 33.0;
+  a_vals[5][2] = 46732.0 / 5247.0;
+  a_vals[5][3] = 49.0 / 176.0;
+  a_vals[5][4] = -5103.0 / 18656.0;
+  a_vals[6][0] = 35.0 / 384.0;
+  a_vals[6][2] = 500.0 / 1113.0;
+  a_vals[6][3] = 125.0 / 192.0;
+  a_vals[6][4] = -2187.0 / 6784.0;
+  a_vals[6][5] = 11.0 / 84.0;
+  double b_vals_5[7] = {35.0 / 384.0, 0.0, 500.0 / 1113.0, 125.0 / 192.0, -2187.0 / 6784.0, 11.0 / 84.0, 0.0};
+  double b_vals_4[7] = {5179.0 / 57600.0, 0.0, 7571.0 / 16695.0, 393.0 / 640.0, -92097.0 / 339200.0,
+      187.0 / 2100.0, 1.0 / 40.0};
+  double b_vals_4m[7] = {6025192743.0 / 30085553152.0, 0.0, 51252292925.0 / 65400821598.0,
+      -2691868925.0 / 45128329728.0, 187940372067.0 / 1594534317056.0,
+      -1776094331.0 / 19743644256.0, 11237099.0 / 235043384.0};
+  double d_vals[7] = {-12715105075.0 / 11282082432.0, 0.0, 87487479700.0 / 32700410799.0,
+      -10690763975.0 / 1880347072.0, 701980252875.0 / 199316789632.0, -1453857185.0 / 822651844.0,
+      69997945.0 / 29380423.0};
+  // numerical parameters (:75-78)
+  double err_power = 0.2;
+  double ray_err_factor = 0.9;
+  double ray_min_factor = 0.2;
+  double ray_max_factor = 10.0;
+
+  const bl_params &p = *o.p;
+  int ray_max_steps = p.ray_max_steps;
+  double ray_step = p.ray_step;
+  double y_vals[9], y_vals_temp[9], y_vals_5[9], y_vals_4[9], y_vals_4m[8], k_vals[7][9], r_vals[4][8];
+  double gcon[4][4];
+  bool flag = false;
+  int sample_num = 0;
+  double *gpos = b.geodesic_pos.data(), *gdir = b.geodesic_dir.data(), *glen = b.geodesic_len.data();
+
+  for (int mu = 0; mu < 4; mu++) {
+    y_vals[mu] = camera_pos[mu];
+    y_vals[4 + mu] = camera_dir[mu];
+  }
+  y_vals[8] = 0.0;
+  for (int q = 0; q < 9; q++) y_vals_5[q] = y_vals[q];
+  double r_new = RadialGeodesicCoordinate(o, y_vals[1], y_vals[2], y_vals[3]);
+  double h_new = -ray_step * r_new;
+  int num_retry = 0;
+  bool previous_fail = false;
+
+  for (int n = 0; n < ray_max_steps;) {
+    if (num_retry > p.ray_max_retries) {  // :139-143
+      flag = true;
+      break;
+    }
+    double h = h_new;
+    if (not previous_fail and n > 0)  // :149-154
+      for (int q = 0; q < 9; q++) {
+        y_vals[q] = y_vals_5[q];
+        k_vals[0][q] = k_vals[6][q];
+      }
+    if (not previous_fail and n == 0) GeodesicSubstepWithDistance(o, y_vals, k_vals[0]);
+    double r = r_new;
+    if (previous_fail) r = RadialGeodesicCoordinate(o, y_vals[1], y_vals[2], y_vals[3]);
+
+    for (int substep = 1; substep < 7; substep++) {  // :162-170
+      for (int q = 0; q < 9; q++) y_vals_temp[q] = y_vals[q];
+      for (int s = 0; s < substep; s++)
+        for (int q = 0; q < 9; q++) y_vals_temp[q] += a_vals[substep][s] * h * k_vals[s][q];
+      GeodesicSubstepWithDistance(o, y_vals_temp, k_vals[substep]);
+    }
+
+    for (int q = 0; q < 9; q++) {  // :173-183
+      y_vals_5[q] = y_vals[q];
+      y_vals_4[q] = y_vals[q];
+    }
+    for (int s = 0; s < 7; s++)
+      for (int q = 0; q < 9; q++) {
+        y_vals_5[q] += b_vals_5[s] * h * k_vals[s][q];
+        y_vals_4[q] += b_vals_4[s] * h * k_vals[s][q];
+      }
+    r_new = RadialGeodesicCoordinate(o, y_vals_5[1], y_vals_5[2], y_vals_5[3]);
+
+    double error = 0.0;  // :187-194
+    for (int q = 0; q < 8; q++) {
+      double y_abs = std::max(std::abs(y_vals[q]), std::abs(y_vals_5[q]));
+      double error_scale = p.ray_tol_abs + p.ray_tol_rel * y_abs;
+      double delta_y = std::abs(y_vals_5[q] - y_vals_4[q]);
+      error = std::max(error, delta_y / error_scale);
+    }
+
+    if (not (error <= 1.0)) {  // :197-209
+      double h_factor = ray_min_factor;
+      if (std::isfinite(error)) {
+        double h_factor_ideal = ray_err_factor * M::pow(error, -err_power);
+        h_factor = std::max(h_factor_ideal, ray_min_factor);
+      }
+      h_new = h * h_factor;
+      num_retry += 1;
+      previous_fail = true;
+      continue;
+    } else {  // :210-224
+      double h_factor = ray_max_factor;
+      if (error > 0.0) {
+        h_factor = ray_err_factor * M::pow(error, -err_power);
+        h_factor = std::max(h_factor, ray_min_factor);
+        h_factor = std::min(h_factor, ray_max_factor);
+      }
+      if (previous_fail) h_factor = std::min(h_factor, 1.0);
+      h_new = h * h_factor;
+      num_retry = 0;
+      previous_fail = false;
+    }
+
+    for (int q = 0; q < 8; q++) y_vals_4m[q] = y_vals[q];  // :227-231
+    for (int s = 0; s < 7; s++)
+      for (int q = 0; q < 8; q++) y_vals_4m[q] += b_vals_4m[s] * h * k_vals[s][q];
+
+    double r_mid = RadialGeodesicCoordinate(o, y_vals_4m[1], y_vals_4m[2], y_vals_4m[3]);  // :234-245
+    double delta_s_step = ray_step * r_mid;
+    double delta_s_full = y_vals_5[8] - y_vals[8];
+    int num_steps_ideal = static_cast<int>(std::ceil(delta_s_full / delta_s_step));
+    int num_steps_max = ray_max_steps - n;
+    int num_steps = num_steps_ideal;
+    if (num_steps > num_steps_max) {
+      num_steps = num_steps_max;
+      flag = true;
+    }
+
+    if (num_steps_ideal == 1) {  // :248-259
+      for (int mu = 0; mu < 4; mu++) {
+        gpos[4 * n + mu] = y_vals_4m[mu];
+        gdir[4 * n + mu] = y_vals_4m[4 + mu];
+      }
+      glen[n] = h;
+    }
+    if (num_steps_ideal > 1) {  // :262-274
+      for (int q = 0; q < 8; q++) {
+        r_vals[0][q] = y_vals_5[q] - y_vals[q];
+        r_vals[1][q] = y_vals[q] - y_vals_5[q] + h * k_vals[0][q];
+        r_vals[2][q] = 2.0 * (y_vals_5[q] - y_vals[q]) - h * (k_vals[0][q] + k_vals[6][q]);
+        r_vals[3][q] = 0.0;
+      }
+      for (int s = 0; s < 7; s++)
+        for (int q = 0; q < 8; q++) r_vals[3][q] += d_vals[s] * h * k_vals[s][q];
+    }
+    if (num_steps_ideal > 1)  // :277-293
+      for (int nn = 0; nn < num_steps; nn++) {
+        double frac = (nn + 0.5) / num_steps_ideal;
+        for (int q = 0; q < 8; q++)
+          y_vals_temp[q] = y_vals[q] + frac * (r_vals[0][q] + (1.0 - frac) * (r_vals[1][q]
+              + frac * (r_vals[2][q] + (1.0 - frac) * r_vals[3][q])));
+        for (int mu = 0; mu < 4; mu++) {
+          gpos[4 * (n + nn) + mu] = y_vals_temp[mu];
+          gdir[4 * (n + nn) + mu] = y_vals_temp[4 + mu];
+        }
+        glen[n + nn] = h / num_steps_ideal;
+      }
+
+    // renormalize momentum (:296-309)
+    ContravariantGeodesicMetric(o, y_vals_5[1], y_vals_5[2], y_vals_5[3], gcon);
+    double temp_a = 0.0;
+    for (int a = 1; a < 4; a++)
+      for (int bb = 1; bb < 4; bb++) temp_a += gcon[a][bb] * y_vals_5[4 + a] * y_vals_5[4 + bb];
+    double temp_b = 0.0;
+    for (int a = 1; a < 4; a++) temp_b += 2.0 * gcon[0][a] * y_vals_5[4] * y_vals_5[4 + a];
+    double temp_c = gcon[0][0] * y_vals_5[4] * y_vals_5[4];
+    double temp_d = std::sqrt(temp_b * temp_b - 4.0 * temp_a * temp_c);
+    double factor = temp_b < 0.0 ? (temp_d - temp_b) / (2.0 * temp_a) : -2.0 * temp_c / (temp_b + temp_d);
+    for (int a = 1; a < 4; a++) y_vals_5[4 + a] *= factor;
+
+    // termination (:312-322)
+    sample_num += num_steps;
+    bool terminate_outer = r_new > p.camera_r and r_new > r;
+    bool terminate_inner = r_new < o.r_terminate;
+    if (terminate_outer or terminate_inner) break;
+    bool last_step = n + num_steps >= ray_max_steps;
+    if (last_step) flag = true;
+    n += num_steps;
+  }
+  *p_sample_num = sample_num;
+  *p_flag = flag;
+}
+
+// geodesics.cpp:418-534 (RK4) and :626-723 (RK2), per-ray bodies
+void IntegrateRayRK(const Oracle &o, bool rk4, const double camera_pos[4], const double camera_dir[4],
+                    RayBuffers &b, int *p_sample_num, bool *p_flag) {
+  const bl_params &p = *o.p;
+  int ray_max_steps = p.ray_max_steps;
+  double gcon[4][4], y_vals[8], y_vals_substep[8], y_vals_accumulate[8], k_vals[8];
+  double *gpos = b.geodesic_pos.data(), *gdir = b.geodesic_dir.data(), *glen = b.geodesic_len.data();
+  bool flag = false;
+  int sample_num = 0;
+  for (int mu = 0; mu < 4; mu++) {
+    y_vals[mu] = camera_pos[mu];
+    y_vals[4 + mu] = camera_dir[mu];
+  }
+  double r_new = RadialGeodesicCoordinate(o, y_vals[1], y_vals[2], y_vals[3]);
+  for (int n = 0; n < ray_max_steps; n++) {
+    double r = r_new;
+    double h = -p.ray_step * (r - o.r_horizon);
+    if (rk4) {
+      GeodesicSubstepWithoutDistance(o, y_vals, k_vals);
+      for (int q = 0; q < 8; q++) y_vals_accumulate[q] = y_vals[q] + 1.0 / 6.0 * h * k_vals[q];
+      for (int q = 0; q < 8; q++) y_vals_substep[q] = y_vals[q] + 0.5 * h * k_vals[q];
+      GeodesicSubstepWithoutDistance(o, y_vals_substep, k_vals);
+      for (int q = 0; q < 8; q++) y_vals_accumulate[q] += 1.0 / 3.0 * h * k_vals[q];
+      for (int q = 0; q < 8; q++) y_vals_substep[q] = y_vals[q] + 0.5 * h * k_vals[q];
+      GeodesicSubstepWithoutDistance(o, y_vals_substep, k_vals);
+      for (int q = 0; q < 8; q++) y_vals_accumulate[q] += 1.0 / 3.0 * h * k_vals[q];
+      for (int q = 0; q < 8; q++) y_vals_substep[q] = y_vals[q] + h * k_vals[q];
+      GeodesicSubstepWithoutDistance(o, y_vals_substep, k_vals);
+      for (int q = 0; q < 8; q++) y_vals_accumulate[q] += 1.0 / 6.0 * h * k_vals[q];
+      for (int mu = 0; mu < 4; mu++) {
+        gpos[4 * n + mu] = 0.5 * (y_vals[mu] + y_vals_accumulate[mu]);
+        gdir[4 * n + mu] = 0.5 * (y_vals[4 + mu] + y_vals_accumulate[4 + mu]);
+      }
+      glen[n] = h;
+      for (int q = 0; q < 8; q++) y_vals[q] = y_vals_accumulate[q];
+    } else {
+      GeodesicSubstepWithoutDistance(o, y_vals, k_vals);
+      for (int q = 0; q < 8; q++) y_vals_substep[q] = y_vals[q] + h * k_vals[q];
+      for (int q = 0; q < 8; q++) y_vals[q] += 1.0 / 2.0 * h * k_vals[q];
+      for (int mu = 0; mu < 4; mu++) {
+        gpos[4 * n + mu] = y_vals[mu];
+        gdir[4 * n + mu] = y_vals[4 + mu];
+      }
+      glen[n] = h;
+      GeodesicSubstepWithoutDistance(o, y_vals_substep, k_vals);
+      for (int q = 0; q < 8; q++) y_vals[q] += 1.0 / 2.0 * h * k_vals[q];
+    }
+    ContravariantGeodesicMetric(o, y_vals[1], y_vals[2], y_vals[3], gcon);
+    double temp_a = 0.0;
+    for (int a = 1; a < 4; a++)
+      for (int bb = 1; bb < 4; bb++) temp_a += gcon[a][bb] * y_vals[4 + a] * y_vals[4 + bb];
+    double temp_b = 0.0;
+    for (int a = 1; a < 4; a++) temp_b += 2.0 * gcon[0][a] * y_vals[4] * y_vals[4 + a];
+    double temp_c = gcon[0][0] * y_vals[4] * y_vals[4];
+    double temp_d = std::sqrt(temp_b * temp_b - 4.0 * temp_a * temp_c);
+    double factor = temp_b < 0.0 ? (temp_d - temp_b) / (2.0 * temp_a) : -2.0 * temp_c / (temp_b + temp_d);
+    for (int a = 1; a < 4; a++) y_vals[4 + a] *= factor;
+    sample_num++;
+    r_new = RadialGeodesicCoordinate(o, y_vals[1], y_vals[2], y_vals[3]);
+    bool terminate_outer = r_new > p.camera_r and r_new > r;
+    bool terminate_inner = r_new < o.r_terminate;
+    if (terminate_outer or terminate_inner) break;
+    bool last_step = n + 1 >= ray_max_steps;
+    if (last_step) flag = true;
+  }
+  *p_sample_num = sample_num;
+  *p_flag = flag;
+}
+
+// geodesics.cpp:327-371 (truncate, renormalise) and :808-849 (reverse), per ray.
+// Returns the final sample_num.
+int FinishRay(const Oracle &o, RayBuffers &b, int sample_num) {
+  double *gpos = b.geodesic_pos.data(), *gdir = b.geodesic_dir.data(), *glen = b.geodesic_len.data();
+  int num_samples = sample_num;
+  if (num_samples > 1) {
+    double r_new = RadialGeodesicCoordinate(o, gpos[1], gpos[2], gpos[3]);
+    for (int n = 1; n < num_samples; n++) {
+      double r_old = r_new;
+      r_new = RadialGeodesicCoordinate(o, gpos[4 * n + 1], gpos[4 * n + 2], gpos[4 * n + 3]);
+      bool terminate_outer = r_new > o.p->camera_r and r_new > r_old;
+      bool terminate_inner = r_new < o.r_terminate;
+      if (terminate_outer or terminate_inner) {
+        sample_num = n;
+        break;
+      }
+    }
+  }
+  for (int n = 0; n < sample_num; n++)
+    RenormalizeMomentum(o, gpos[4 * n + 1], gpos[4 * n + 2], gpos[4 * n + 3], gdir[4 * n + 0], &gdir[4 * n + 1]);
+  // reverse (:820-842); sample_len zero-initialised there, samples after a zero length are skipped
+  std::fill(b.sample_len.begin(), b.sample_len.begin() + std::max(sample_num, 0), 0.0);
+  for (int n = 0; n < sample_num; n++) {
+    double len = glen[n];
+    if (len == 0.0) break;
+    int nr = sample_num - 1 - n;
+    for (int mu = 0; mu < 4; mu++) {
+      b.sample_pos[4 * nr + mu] = gpos[4 * n + mu];
+      b.sample_dir[4 * nr + mu] = gdir[4 * n + mu];
+    }
+    b.sample_len[nr] = -len;
+  }
+  return sample_num;
+}
+
+// ---------------------------------------------------------------------------------------------
+// radiation_geometry.cpp:37-57
+void ConvertFromCKS(const Oracle &o, double *p_x1, double *p_x2, double *p_x3) {
+  int coord = o.p->simulation_coord;
+  if (coord == BL_COORD_SKS or coord == BL_COORD_FMKS) {
+    double x = *p_x1, y = *p_x2, z = *p_x3;
+    double a2 = o.bh_a * o.bh_a;
+    double rr2 = x * x + y * y + z * z;
+    double r2 = 0.5 * (rr2 - a2 + M::hypot(rr2 - a2, 2.0 * o.bh_a * z));
+    double r = std::sqrt(r2);
+    double th = M::acos(z / r);
+    double ph = M::atan2(y, x) - M::atan(o.bh_a / r);
+    ph += ph < 0.0 ? 2.0 * Math::pi : 0.0;
+    ph -= ph >= 2.0 * Math::pi ? 2.0 * Math::pi : 0.0;
+    *p_x1 = r;
+    *p_x2 = th;
+    *p_x3 = ph;
+  }
+}
+
+// radiation_geometry.cpp:69-126
+void CoordinateJacobian(const Oracle &o, double x, double y, double z, double jacobian[4][4]) {
+  for (int mu = 0; mu < 4; mu++)
+    for (int nu = 0; nu < 4; nu++) jacobian[mu][nu] = mu == nu ? 1.0 : 0.0;
+  int coord = o.p->simulation_coord;
+  if (coord == BL_COORD_SKS or coord == BL_COORD_FMKS) {
+    double bh_a = o.bh_a;
+    double a2 = bh_a * bh_a;
+    double rr2 = x * x + y * y + z * z;
+    double r2 = 0.5 * (rr2 - a2 + M::hypot(rr2 - a2, 2.0 * bh_a * z));
+    double r = std::sqrt(r2);
+    double cth = z / r;
+    double sth = std::sqrt(1.0 - cth * cth);
+    double ph = M::atan2(y, x) - M::atan(bh_a / r);
+    double sph = M::sin(ph);
+    double cph = M::cos(ph);
+    jacobian[1][1] = sth * cph;
+    jacobian[1][2] = cth * (r * cph - bh_a * sph);
+    jacobian[1][3] = sth * (-r * sph - bh_a * cph);
+    jacobian[2][1] = sth * sph;
+    jacobian[2][2] = cth * (r * sph + bh_a * cph);
+    jacobian[2][3] = sth * (r * cph - bh_a * sph);
+    jacobian[3][1] = cth;
+    jacobian[3][2] = -r * sth;
+    jacobian[3][3] = 0.0;
+  }
+}
+
+// radiation_geometry.cpp:421-491
+void CovariantSimulationMetric(const Oracle &o, double x, double y, double z, double gcov[4][4]) {
+  double bh_a = o.bh_a, bh_m = o.bh_m;
+  if (o.p->simulation_coord == BL_COORD_CKS) {
+    double a2 = bh_a * bh_a;
+    double rr2 = x * x + y * y + z * z;
+    double r2 = 0.5 * (rr2 - a2 + M::hypot(rr2 - a2, 2.0 * bh_a * z));
+    double r = std::sqrt(r2);
+    double f = 2.0 * bh_m * r2 * r / (r2 * r2 + a2 * z * z);
+    double l[4] = {1.0, (r * x + bh_a * y) / (r2 + a2), (r * y - bh_a * x) / (r2 + a2), z / r};
+    for (int mu = 0; mu < 4; mu++)
+      for (int nu = 0; nu < 4; nu++) gcov[mu][nu] = f * l[mu] * l[nu];
+    gcov[0][0] = f * l[0] * l[0] - 1.0;
+    gcov[1][1] = f * l[1] * l[1] + 1.0;
+    gcov[2][2] = f * l[2] * l[2] + 1.0;
+    gcov[3][3] = f * l[3] * l[3] + 1.0;
+  } else {
+    double a2 = bh_a * bh_a;
+    double rr2 = x * x + y * y + z * z;
+    double r2 = 0.5 * (rr2 - a2 + M::hypot(rr2 - a2, 2.0 * bh_a * z));
+    double r = std::sqrt(r2);
+    double cth = z / r;
+    double cth2 = cth * cth;
+    double sth2 = 1.0 - cth2;
+    double sigma = r2 + a2 * cth2;
+    gcov[0][0] = -(1.0 - 2.0 * bh_m * r / sigma);
+    gcov[0][1] = 2.0 * bh_m * r / sigma;
+    gcov[0][2] = 0.0;
+    gcov[0][3] = -2.0 * bh_m * bh_a * r * sth2 / sigma;
+    gcov[1][0] = 2.0 * bh_m * r / sigma;
+    gcov[1][1] = 1.0 + 2.0 * bh_m * r / sigma;
+    gcov[1][2] = 0.0;
+    gcov[1][3] = -(1.0 + 2.0 * bh_m * r / sigma) * bh_a * sth2;
+    gcov[2][0] = 0.0;
+    gcov[2][1] = 0.0;
+    gcov[2][2] = sigma;
+    gcov[2][3] = 0.0;
+    gcov[3][0] = -2.0 * bh_m * bh_a * r * sth2 / sigma;
+    gcov[3][1] = -(1.0 + 2.0 * bh_m * r / sigma) * bh_a * sth2;
+    gcov[3][2] = 0.0;
+    gcov[3][3] = (r2 + a2 + 2.0 * bh_m * a2 * r * sth2 / sigma) * sth2;
+  }
+}
+
+// radiation_geometry.cpp:502-573
+void ContravariantSimulationMetric(const Oracle &o, double x, double y, double z, double gcon[4][4]) {
+  double bh_a = o.bh_a, bh_m = o.bh_m;
+  if (o.p->simulation_coord == BL_COORD_CKS) {
+    double a2 = bh_a * bh_a;
+    double rr2 = x * x + y * y + z * z;
+    double r2 = 0.5 * (rr2 - a2 + M::hypot(rr2 - a2, 2.0 * bh_a * z));
+    double r = std::sqrt(r2);
+    double f = 2.0 * bh_m * r2 * r / (r2 * r2 + a2 * z * z);
+    double l[4] = {-1.0, (r * x + bh_a * y) / (r2 + a2), (r * y - bh_a * x) / (r2 + a2), z / r};
+    for (int mu = 0; mu < 4; mu++)
+      for (int nu = 0; nu < 4; nu++) gcon[mu][nu] = -f * l[mu] * l[nu];
+    gcon[0][0] = -f * l[0] * l[0] - 1.0;
+    gcon[1][1] = -f * l[1] * l[1] + 1.0;
+    gcon[2][2] = -f * l[2] * l[2] + 1.0;
+    gcon[3][3] = -f * l[3] * l[3] + 1.0;
+  } else {
+    double a2 = bh_a * bh_a;
+    double rr2 = x * x + y * y + z * z;
+    double r2 = 0.5 * (rr2 - a2 + M::hypot(rr2 - a2, 2.0 * bh_a * z));
+    double r = std::sqrt(r2);
+    double cth = z / r;
+    double cth2 = cth * cth;
+    double sth2 = 1.0 - cth2;
+    double delta = r2 - 2.0 * bh_m * r + a2;
+    double sigma = r2 + a2 * cth2;
+    gcon[0][0] = -(1.0 + 2.0 * bh_m * r / sigma);
+    gcon[0][1] = 2.0 * bh_m * r / sigma;
+    gcon[0][2] = 0.0;
+    gcon[0][3] = 0.0;
+    gcon[1][0] = 2.0 * bh_m * r / sigma;
+    gcon[1][1] = delta / sigma;
+    gcon[1][2] = 0.0;
+    gcon[1][3] = bh_a / sigma;
+    gcon[2][0] = 0.0;
+    gcon[2][1] = 0.0;
+    gcon[2][2] = 1.0 / sigma;
+    gcon[2][3] = 0.0;
+    gcon[3][0] = 0.0;
+    gcon[3][1] = bh_a / sigma;
+    gcon[3][2] = 0.0;
+    gcon[3][3] = 1.0 / (sigma * sth2);
+  }
+}
+
+// radiation_geometry.cpp:597-658
+void Tetrad(const double ucon[4], const double ucov[4], const double kcon[4], const double kcov[4],
+            const double up_con[4], const double gcov[4][4], const double gcon[4][4], double tetrad[4][4]) {
+  double omega = 0.0;
+  for (int mu = 0; mu < 4; mu++) omega -= kcov[mu] * ucon[mu];
+  double k_up_over_omega = 0.0;
+  for (int mu = 0; mu < 4; mu++) k_up_over_omega += kcov[mu] * up_con[mu];
+  k_up_over_omega /= omega;
+  double u_up_over_omega = 0.0;
+  for (int mu = 0; mu < 4; mu++) u_up_over_omega += ucov[mu] * up_con[mu];
+  u_up_over_omega /= omega;
+  for (int mu = 0; mu < 4; mu++) tetrad[0][mu] = ucon[mu];
+  for (int mu = 0; mu < 4; mu++) tetrad[3][mu] = kcon[mu] / omega - ucon[mu];
+  for (int mu = 0; mu < 4; mu++)
+    tetrad[2][mu] = up_con[mu] - k_up_over_omega * tetrad[3][mu] + u_up_over_omega * kcon[mu];
+  double norm = 0.0;
+  for (int mu = 0; mu < 4; mu++)
+    for (int nu = 0; nu < 4; nu++) norm += gcov[mu][nu] * tetrad[2][mu] * tetrad[2][nu];
+  norm = std::sqrt(norm);
+  for (int mu = 0; mu < 4; mu++) tetrad[2][mu] /= norm;
+  double tetrad_1_cov[4];
+  tetrad_1_cov[0] = tetrad[0][1] * (tetrad[2][3] * tetrad[3][2] - tetrad[2][2] * tetrad[3][3])
+      + tetrad[0][2] * (tetrad[2][1] * tetrad[3][3] - tetrad[2][3] * tetrad[3][1])
+      + tetrad[0][3] * (tetrad[2][2] * tetrad[3][1] - tetrad[2][1] * tetrad[3][2]);
+  tetrad_1_cov[1] = tetrad[0][0] * (tetrad[2][2] * tetrad[3][3] - tetrad[2][3] * tetrad[3][2])
+      + tetrad[0][2] * (tetrad[2][3] * tetrad[3][0] - tetrad[2][0] * tetrad[3][3])
+      + tetrad[0][3] * (tetrad[2][0] * tetrad[3][2] - tetrad[2][2] * tetrad[3][0]);
+  tetrad_1_cov[2] = tetrad[0][0] * (tetrad[2][3] * tetrad[3][1] - tetrad[2][1] * tetrad[3][3])
+      + tetrad[0][1] * (tetrad[2][0] * tetrad[3][3] - tetrad[2][3] * tetrad[3][0])
+      + tetrad[0][3] * (tetrad[2][1] * tetrad[3][0] - tetrad[2][0] * tetrad[3][1]);
+  tetrad_1_cov[3] = tetrad[0][0] * (tetrad[2][1] * tetrad[3][2] - tetrad[2][2] * tetrad[3][1])
+      + tetrad[0][1] * (tetrad[2][2] * tetrad[3][0] - tetrad[2][0] * tetrad[3][2])
+      + tetrad[0][2] * (tetrad[2][0] * tetrad[3][1] - tetrad[2][1] * tetrad[3][0]);
+  for (int mu = 0; mu < 4; mu++) {
+    tetrad[1][mu] = 0.0;
+    for (int nu = 0; nu < 4; nu++) tetrad[1][mu] += gcon[mu][nu] * tetrad_1_cov[nu];
+  }
+}
+
+// Geometric cuts shared by simulation_sampling.cpp:237-292 and formula_coefficients.cpp:73-116.
+// Returns true if the sample is cut.
+bool GeometricCut(const Oracle &o, double x1, double x2, double x3, double r) {
+  const bl_params &p = *o.p;
+  if (r > p.camera_r) return true;
+  if (p.cut_omit_near or p.cut_omit_far) {
+    double dot_product = x1 * o.cam_x[1] + x2 * o.cam_x[2] + x3 * o.cam_x[3];
+    if ((p.cut_omit_near and dot_product > 0.0) or (p.cut_omit_far and dot_product < 0.0)) return true;
+  }
+  if ((p.cut_omit_in >= 0.0 and r < p.cut_omit_in) or (p.cut_omit_out >= 0.0 and r > p.cut_omit_out))
+    return true;
+  if (p.cut_midplane_theta > 0.0 or p.cut_midplane_theta < 0.0) {
+    double th = M::acos(x3 / r);
+    if ((p.cut_midplane_theta > 0.0 and std::abs(th - Math::pi / 2.0) > p.cut_midplane_theta)
+        or (p.cut_midplane_theta < 0.0 and std::abs(th - Math::pi / 2.0) < -p.cut_midplane_theta))
+      return true;
+  }
+  if ((p.cut_midplane_z > 0.0 and std::abs(x3) > p.cut_midplane_z)
+      or (p.cut_midplane_z < 0.0 and std::abs(x3) < -p.cut_midplane_z))
+    return true;
+  if (p.cut_plane) {
+    double dot_product = (x1 - p.cut_plane_origin_x) * p.cut_plane_normal_x
+        + (x2 - p.cut_plane_origin_y) * p.cut_plane_normal_y
+        + (x3 - p.cut_plane_origin_z) * p.cut_plane_normal_z;
+    if (dot_product < 0.0) return true;
+  }
+  return false;
+}
+
+inline float GridVal(const bl_grid_desc &g, int var, int k, int j, int i) {
+  // Array<float>(n_var, n_b, n_k, n_j, n_i), block 0 (utils/array.cpp:317-325)
+  size_t idx = ((static_cast<size_t>(var) * g.n_blocks + 0) * g.n_k + k) * g.n_j + j;
+  return g.prim[idx * g.n_i + i];
+}
+
+// simulation_sampling.cpp:1334-1351
+double InterpolateSimple(const bl_grid_desc &g, int var, int k, int j, int i, double f_k, double f_j, double f_i) {
+  double val_mmm = static_cast<double>(GridVal(g, var, k, j, i));
+  double val_mmp = static_cast<double>(GridVal(g, var, k, j, i + 1));
+  double val_mpm = static_cast<double>(GridVal(g, var, k, j + 1, i));
+  double val_mpp = static_cast<double>(GridVal(g, var, k, j + 1, i + 1));
+  double val_pmm = static_cast<double>(GridVal(g, var, k + 1, j, i));
+  double val_pmp = static_cast<double>(GridVal(g, var, k + 1, j, i + 1));
+  double val_ppm = static_cast<double>(GridVal(g, var, k + 1, j + 1, i));
+  double val_ppp = static_cast<double>(GridVal(g, var, k + 1, j + 1, i + 1));
+  double val = (1.0 - f_k) * (1.0 - f_j) * (1.0 - f_i) * val_mmm
+      + (1.0 - f_k) * (1.0 - f_j) * f_i * val_mmp + (1.0 - f_k) * f_j * (1.0 - f_i) * val_mpm
+      + (1.0 - f_k) * f_j * f_i * val_mpp + f_k * (1.0 - f_j) * (1.0 - f_i) * val_pmm
+      + f_k * (1.0 - f_j) * f_i * val_pmp + f_k * f_j * (1.0 - f_i) * val_ppm
+      + f_k * f_j * f_i * val_ppp;
+  return val;
+}
+
+struct Prims {
+  float rho, pgas, kappa, uu1, uu2, uu3, bb1, bb2, bb3;
+};
+
+// simulation_sampling.cpp:201-575 + :666-1033 for one sample (single block, no slow light).
+// Returns: 0 = sampled, 1 = cut, 2 = NaN, 3 = fallback values. *gathered set if the grid was read.
+int SampleOne(const Oracle &o, const double pos[4], Prims *out, bool *gathered) {
+  const bl_params &p = *o.p;
+  const bl_grid_desc &g = *o.g;
+  *gathered = false;
+  double x1 = pos[1], x2 = pos[2], x3 = pos[3];
+  double r = RadialGeodesicCoordinate(o, x1, x2, x3);
+  if (GeometricCut(o, x1, x2, x3, r)) return 1;
+  ConvertFromCKS(o, &x1, &x2, &x3);
+  int n_i = g.n_i, n_j = g.n_j, n_k = g.n_k;
+  const double *x1f = g.x1f, *x2f = g.x2f, *x3f = g.x3f, *x1v = g.x1v, *x2v = g.x2v, *x3v = g.x3v;
+  // block test (:352-394), n_b = 1
+  if (x1 < x1f[0] or x1 > x1f[n_i] or x2 < x2f[0] or x2 > x2f[n_j] or x3 < x3f[0] or x3 > x3f[n_k]) {
+    if (p.fallback_nan) return 2;
+    return 3;
+  }
+  int i, j, k;  // :458-466
+  for (i = 0; i < n_i; i++)
+    if (x1f[i + 1] >= x1) break;
+  for (j = 0; j < n_j; j++)
+    if (x2f[j + 1] >= x2) break;
+  for (k = 0; k < n_k; k++)
+    if (x3f[k + 1] >= x3) break;
+  bool code_kappa = p.plasma_model == BL_PLASMA_CODE_KAPPA;
+  *gathered = true;
+  if (not p.simulation_interp) {  // :710-734
+    out->rho = GridVal(g, g.ind_rho, k, j, i);
+    out->pgas = GridVal(g, g.ind_pgas, k, j, i);
+    out->kappa = code_kappa ? GridVal(g, g.ind_kappa, k, j, i) : 0.0f;
+    out->uu1 = GridVal(g, g.ind_uu1, k, j, i);
+    out->uu2 = GridVal(g, g.ind_uu2, k, j, i);
+    out->uu3 = GridVal(g, g.ind_uu3, k, j, i);
+    out->bb1 = GridVal(g, g.ind_bb1, k, j, i);
+    out->bb2 = GridVal(g, g.ind_bb2, k, j, i);
+    out->bb3 = GridVal(g, g.ind_bb3, k, j, i);
+    return 0;
+  }
+  // intrablock interpolation (:485-490, :809-839)
+  int i_m = i == 0 or (i != n_i - 1 and x1 >= x1v[i]) ? i : i - 1;
+  int j_m = j == 0 or (j != n_j - 1 and x2 >= x2v[j]) ? j : j - 1;
+  int k_m = k == 0 or (k != n_k - 1 and x3 >= x3v[k]) ? k : k - 1;
+  double f_i = (x1 - x1v[i_m]) / (x1v[i_m + 1] - x1v[i_m]);
+  double f_j = (x2 - x2v[j_m]) / (x2v[j_m + 1] - x2v[j_m]);
+  double f_k = (x3 - x3v[k_m]) / (x3v[k_m + 1] - x3v[k_m]);
+  double rho = InterpolateSimple(g, g.ind_rho, k_m, j_m, i_m, f_k, f_j, f_i);
+  double pgas = InterpolateSimple(g, g.ind_pgas, k_m, j_m, i_m, f_k, f_j, f_i);
+  double kappa = 0.0;
+  if (code_kappa) kappa = InterpolateSimple(g, g.ind_kappa, k_m, j_m, i_m, f_k, f_j, f_i);
+  double uu1 = InterpolateSimple(g, g.ind_uu1, k_m, j_m, i_m, f_k, f_j, f_i);
+  double uu2 = InterpolateSimple(g, g.ind_uu2, k_m, j_m, i_m, f_k, f_j, f_i);
+  double uu3 = InterpolateSimple(g, g.ind_uu3, k_m, j_m, i_m, f_k, f_j, f_i);
+  double bb1 = InterpolateSimple(g, g.ind_bb1, k_m, j_m, i_m, f_k, f_j, f_i);
+  double bb2 = InterpolateSimple(g, g.ind_bb2, k_m, j_m, i_m, f_k, f_j, f_i);
+  double bb3 = InterpolateSimple(g, g.ind_bb3, k_m, j_m, i_m, f_k, f_j, f_i);
+  if (rho <= 0.0) rho = static_cast<double>(GridVal(g, g.ind_rho, k_m, j_m, i_m));
+  if (pgas <= 0.0) pgas = static_cast<double>(GridVal(g, g.ind_pgas, k_m, j_m, i_m));
+  if (code_kappa and kappa <= 0.0) kappa = static_cast<double>(GridVal(g, g.ind_kappa, k_m, j_m, i_m));
+  out->rho = static_cast<float>(rho);
+  out->pgas = static_cast<float>(pgas);
+  out->kappa = static_cast<float>(kappa);
+  out->uu1 = static_cast<float>(uu1);
+  out->uu2 = static_cast<float>(uu2);
+  out->uu3 = static_cast<float>(uu3);
+  out->bb1 = static_cast<float>(bb1);
+  out->bb2 = static_cast<float>(bb2);
+  out->bb3 = static_cast<float>(bb3);
+  return 0;
+}
+
+// simulation_coefficients.cpp:253-700 for one sample (thermal electrons, unpolarized outputs).
+// j[l], alpha[l] must be zero on entry (as after Array::Zero(), :226-229); cell[7] NaN on entry.
+void SimulationCoefficientsOne(const Oracle &o, const double pos[4], const double kcov_in[4],
+                               const Prims &s, double momentum_factor, double *j, double *alpha,
+                               int stride, double cell[num_cell_values]) {
+  const bl_params &p = *o.p;
+  double d_unit = p.simulation_rho_cgs;  // :237-239
+  double e_unit = d_unit * Physics::c * Physics::c;
+  double b_unit = std::sqrt(4.0 * Math::pi * e_unit);
+  double gcov_sim[4][4], gcon_sim[4][4], gcov[4][4], gcon[4][4], jacobian[4][4], tetrad[4][4];
+  double x1 = pos[1], x2 = pos[2], x3 = pos[3];
+  double kcov[4] = {kcov_in[0], kcov_in[1], kcov_in[2], kcov_in[3]};
+  double rho = s.rho;
+  double pgas = s.pgas;
+  double kappa = 0.0;
+  if (p.plasma_model == BL_PLASMA_CODE_KAPPA) kappa = s.kappa;
+  double uu1_sim = s.uu1, uu2_sim = s.uu2, uu3_sim = s.uu3;
+  double bb1_sim = s.bb1, bb2_sim = s.bb2, bb3_sim = s.bb3;
+
+  double rho_cgs = rho * d_unit;  // :287-290
+  double pgas_cgs = pgas * e_unit;
+  double n_cgs = rho_cgs / (p.plasma_mu * Physics::m_p);
+  double n_e_cgs = n_cgs / (1.0 + 1.0 / p.plasma_ne_ni);
+
+  CovariantSimulationMetric(o, x1, x2, x3, gcov_sim);
+  ContravariantSimulationMetric(o, x1, x2, x3, gcon_sim);
+
+  double uu0_sim = std::sqrt(1.0 + gcov_sim[1][1] * uu1_sim * uu1_sim  // :297-313
+      + 2.0 * gcov_sim[1][2] * uu1_sim * uu2_sim + 2.0 * gcov_sim[1][3] * uu1_sim * uu3_sim
+      + gcov_sim[2][2] * uu2_sim * uu2_sim + 2.0 * gcov_sim[2][3] * uu2_sim * uu3_sim
+      + gcov_sim[3][3] * uu3_sim * uu3_sim);
+  double lapse_sim = 1.0 / std::sqrt(-gcon_sim[0][0]);
+  double shift1_sim = -gcon_sim[0][1] / gcon_sim[0][0];
+  double shift2_sim = -gcon_sim[0][2] / gcon_sim[0][0];
+  double shift3_sim = -gcon_sim[0][3] / gcon_sim[0][0];
+  double ucon_sim[4];
+  ucon_sim[0] = uu0_sim / lapse_sim;
+  ucon_sim[1] = uu1_sim - shift1_sim * uu0_sim / lapse_sim;
+  ucon_sim[2] = uu2_sim - shift2_sim * uu0_sim / lapse_sim;
+  ucon_sim[3] = uu3_sim - shift3_sim * uu0_sim / lapse_sim;
+  double ucov_sim[4] = {};
+  for (int mu = 0; mu < 4; mu++)
+    for (int nu = 0; nu < 4; nu++) ucov_sim[mu] += gcov_sim[mu][nu] * ucon_sim[nu];
+
+  double bcon_sim[4];  // :316-330
+  bcon_sim[0] = ucov_sim[1] * bb1_sim + ucov_sim[2] * bb2_sim + ucov_sim[3] * bb3_sim;
+  bcon_sim[1] = (bb1_sim + bcon_sim[0] * ucon_sim[1]) / ucon_sim[0];
+  bcon_sim[2] = (bb2_sim + bcon_sim[0] * ucon_sim[2]) / ucon_sim[0];
+  bcon_sim[3] = (bb3_sim + bcon_sim[0] * ucon_sim[3]) / ucon_sim[0];
+  double bcov_sim[4] = {};
+  for (int mu = 0; mu < 4; mu++)
+    for (int nu = 0; nu < 4; nu++) bcov_sim[mu] += gcov_sim[mu][nu] * bcon_sim[nu];
+  double b_sq = 0.0;
+  for (int mu = 0; mu < 4; mu++) b_sq += bcov_sim[mu] * bcon_sim[mu];
+  double bb_cgs = std::sqrt(b_sq) * b_unit;
+  double sigma = b_sq / rho;
+  double beta_inv = b_sq / (2.0 * pgas);
+
+  double kb_tt_e_cgs = std::numeric_limits<double>::quiet_NaN();  // :333-358
+  double theta_e = std::numeric_limits<double>::quiet_NaN();
+  if (o.plasma_thermal_frac != 0.0 and p.plasma_model == BL_PLASMA_TI_TE_BETA) {
+    double tti_tte = (p.plasma_rat_high + p.plasma_rat_low * beta_inv * beta_inv) / (1.0 + beta_inv * beta_inv);
+    double kb_tt_tot_cgs = p.plasma_mu * Physics::m_p * pgas_cgs / rho_cgs;
+    if (p.plasma_use_p)
+      kb_tt_e_cgs = (1.0 + p.plasma_ne_ni) / (tti_tte + p.plasma_ne_ni) * kb_tt_tot_cgs;
+    else {
+      kb_tt_e_cgs = (1.0 + p.plasma_ne_ni) * kb_tt_tot_cgs / (o.g->plasma_gamma - 1.0);
+      kb_tt_e_cgs /= tti_tte / (o.g->plasma_gamma_i - 1.0) + p.plasma_ne_ni / (o.g->plasma_gamma_e - 1.0);
+    }
+    theta_e = kb_tt_e_cgs / (Physics::m_e * Physics::c * Physics::c);
+  }
+  if (o.plasma_thermal_frac != 0.0 and p.plasma_model == BL_PLASMA_CODE_KAPPA) {
+    double mu_e = p.plasma_mu * (1.0 + 1.0 / p.plasma_ne_ni);
+    double rho_e = rho * Physics::m_e / (mu_e * Physics::m_p);
+    double rho_kappa_e_cbrt = M::cbrt(rho_e * kappa);
+    theta_e = 1.0 / 5.0 * (std::sqrt(1.0 + 25.0 * rho_kappa_e_cbrt * rho_kappa_e_cbrt) - 1.0);
+    kb_tt_e_cgs = theta_e * Physics::m_e * Physics::c * Physics::c;
+  }
+
+  if ((p.cut_rho_min >= 0.0 and rho_cgs < p.cut_rho_min)  // :361-375
+      or (p.cut_rho_max >= 0.0 and rho_cgs > p.cut_rho_max)
+      or (p.cut_n_e_min >= 0.0 and n_e_cgs < p.cut_n_e_min)
+      or (p.cut_n_e_max >= 0.0 and n_e_cgs > p.cut_n_e_max)
+      or (p.cut_p_gas_min >= 0.0 and pgas_cgs < p.cut_p_gas_min)
+      or (p.cut_p_gas_max >= 0.0 and pgas_cgs > p.cut_p_gas_max)
+      or (p.cut_theta_e_min >= 0.0 and theta_e < p.cut_theta_e_min)
+      or (p.cut_theta_e_max >= 0.0 and theta_e > p.cut_theta_e_max)
+      or (p.cut_b_min >= 0.0 and bb_cgs < p.cut_b_min)
+      or (p.cut_b_max >= 0.0 and bb_cgs > p.cut_b_max)
+      or (p.cut_sigma_min >= 0.0 and sigma < p.cut_sigma_min)
+      or (p.cut_sigma_max >= 0.0 and sigma > p.cut_sigma_max)
+      or (p.cut_beta_inverse_min >= 0.0 and beta_inv < p.cut_beta_inverse_min)
+      or (p.cut_beta_inverse_max >= 0.0 and beta_inv > p.cut_beta_inverse_max))
+    return;
+
+  if (p.image_lambda_ave or p.image_emission_ave or p.image_tau_int) {  // :378-387
+    cell[0] = rho_cgs;
+    cell[1] = n_e_cgs;
+    cell[2] = pgas_cgs;
+    cell[3] = theta_e;
+    cell[4] = bb_cgs;
+    cell[5] = sigma;
+    cell[6] = beta_inv;
+  }
+  if (not (p.image_light or p.image_emission or p.image_tau or p.image_emission_ave or p.image_tau_int))
+    return;
+  if (bb1_sim == 0.0 and bb2_sim == 0.0 and bb3_sim == 0.0) return;  // :394
+
+  CoordinateJacobian(o, x1, x2, x3, jacobian);  // :398-408
+  double ucon[4] = {};
+  for (int mu = 0; mu < 4; mu++)
+    for (int nu = 0; nu < 4; nu++) ucon[mu] += jacobian[mu][nu] * ucon_sim[nu];
+  double bcon[4] = {};
+  for (int mu = 0; mu < 4; mu++)
+    for (int nu = 0; nu < 4; nu++) bcon[mu] += jacobian[mu][nu] * bcon_sim[nu];
+  CovariantGeodesicMetric(o, x1, x2, x3, gcov);  // :411-428
+  ContravariantGeodesicMetric(o, x1, x2, x3, gcon);
+  double kcon[4] = {};
+  for (int mu = 0; mu < 4; mu++)
+    for (int nu = 0; nu < 4; nu++) kcon[mu] += gcon[mu][nu] * kcov[nu];
+  double ucov[4] = {};
+  for (int mu = 0; mu < 4; mu++)
+    for (int nu = 0; nu < 4; nu++) ucov[mu] += gcov[mu][nu] * ucon[nu];
+  double bcov[4] = {};
+  for (int mu = 0; mu < 4; mu++)
+    for (int nu = 0; nu < 4; nu++) bcov[mu] += gcov[mu][nu] * bcon[nu];
+  Tetrad(ucon, ucov, kcon, kcov, bcon, gcov, gcon, tetrad);  // :431
+
+  double k_tet_1 = 0.0, k_tet_2 = 0.0, k_tet_3 = 0.0, b_tet_1 = 0.0, b_tet_2 = 0.0, b_tet_3 = 0.0;  // :434-455
+  for (int mu = 0; mu < 4; mu++) {
+    k_tet_1 += tetrad[1][mu] * kcov[mu];
+    k_tet_2 += tetrad[2][mu] * kcov[mu];
+    k_tet_3 += tetrad[3][mu] * kcov[mu];
+    b_tet_1 += tetrad[1][mu] * bcov[mu];
+    b_tet_2 += tetrad[2][mu] * bcov[mu];
+    b_tet_3 += tetrad[3][mu] * bcov[mu];
+  }
+  double k_sq_tet = k_tet_1 * k_tet_1 + k_tet_2 * k_tet_2 + k_tet_3 * k_tet_3;
+  double b_sq_tet = b_tet_1 * b_tet_1 + b_tet_2 * b_tet_2 + b_tet_3 * b_tet_3;
+  double k_b_tet = k_tet_1 * b_tet_1 + k_tet_2 * b_tet_2 + k_tet_3 * b_tet_3;
+  double cos2_theta_b = std::min(k_b_tet * k_b_tet / (k_sq_tet * b_sq_tet), 1.0);
+  double sin2_theta_b = 1.0 - cos2_theta_b;
+  double sin_theta_b = std::sqrt(sin2_theta_b);
+
+  int nf = p.image_num_frequencies;
+  for (int l = 0; l < nf; l++) {  // :458-524 (thermal, unpolarized)
+    double nu_cgs = 0.0;
+    for (int mu = 0; mu < 4; mu++) nu_cgs -= kcov[mu] * ucon[mu];
+    nu_cgs *= o.image_frequencies[l] * momentum_factor;
+    double nu_2_cgs = nu_cgs * nu_cgs;
+    double nu_c_cgs = Physics::e * bb_cgs / (2.0 * Math::pi * Physics::m_e * Physics::c);
+    double nu_s_cgs = 2.0 / 9.0 * nu_c_cgs * theta_e * theta_e * sin_theta_b;
+    double j_i_val = 0.0;
+    if (o.plasma_thermal_frac != 0.0) {
+      double xx = nu_cgs / nu_s_cgs;
+      double xx_1_2 = std::sqrt(xx);
+      double xx_1_3 = M::cbrt(xx);
+      double xx_1_6 = std::sqrt(xx_1_3);
+      double coefficient = o.plasma_thermal_frac * n_e_cgs * Physics::e * Physics::e * nu_c_cgs
+          / (Physics::c * nu_2_cgs) * M::exp(-xx_1_3);
+      double var_a = Math::sqrt2 * Math::pi / 27.0 * sin_theta_b;
+      double var_b = pow_2_11_12;
+      double var_c = xx_1_2 + var_b * xx_1_6;
+      j_i_val = coefficient * var_a * var_c * var_c;
+      if (p.image_light or p.image_emission or p.image_emission_ave) j[l * stride] = j_i_val;
+    }
+    if (o.plasma_thermal_frac != 0.0) {
+      double b_nu_nu_3_cgs = 2.0 * Physics::h / (Physics::c * Physics::c)
+          / M::expm1(Physics::h * nu_cgs / kb_tt_e_cgs);
+      if (p.image_light or p.image_tau or p.image_tau_int) alpha[l * stride] = j_i_val / b_nu_nu_3_cgs;
+      if ((p.image_light or p.image_tau or p.image_tau_int)
+          and 1.0 / (alpha[l * stride] * alpha[l * stride]) == std::numeric_limits<double>::infinity())
+        alpha[l * stride] = 0.0;
+    }
+  }
+}
+
+// formula_coefficients.cpp:62-180 for one sample. j, alpha zero on entry.
+void FormulaCoefficientsOne(const Oracle &o, const double pos[4], const double kcov[4],
+                            double momentum_factor, double *j, double *alpha, int stride) {
+  const bl_params &p = *o.p;
+  double bh_a = o.bh_a, bh_m = o.bh_m;
+  double x = pos[1], y = pos[2], z = pos[3];
+  double k_0 = kcov[0], k_1 = kcov[1], k_2 = kcov[2], k_3 = kcov[3];
+  double r = RadialGeodesicCoordinate(o, x, y, z);
+  if (GeometricCut(o, x, y, z, r)) return;
+  double rr = std::sqrt(r * r - z * z);
+  double cth = z / r;
+  double sth = std::sqrt(1.0 - cth * cth);
+  double ph = M::atan2(y, x) - M::atan(bh_a / r);
+  double sph = M::sin(ph);
+  double cph = M::cos(ph);
+  double delta = r * r - 2.0 * bh_m * r + bh_a * bh_a;
+  double sigma = r * r + bh_a * bh_a * cth * cth;
+  double gtt_bl = -(1.0 + 2.0 * bh_m * r * (r * r + bh_a * bh_a) / (delta * sigma));
+  double gtph_bl = -2.0 * bh_m * bh_a * r / (delta * sigma);
+  double grr_bl = delta / sigma;
+  double gthth_bl = 1.0 / sigma;
+  double gphph_bl = (sigma - 2.0 * bh_m * r) / (delta * sigma * sth * sth);
+  double ll = p.formula_l0 / (1.0 + rr) * M::pow(rr, 1.0 + p.formula_q);
+  double u_norm = 1.0 / std::sqrt(-gtt_bl + 2.0 * gtph_bl * ll - gphph_bl * ll * ll);
+  double u_t_bl = -u_norm;
+  double u_r_bl = 0.0;
+  double u_th_bl = 0.0;
+  double u_ph_bl = u_norm * ll;
+  double ut_bl = gtt_bl * u_t_bl + gtph_bl * u_ph_bl;
+  double ur_bl = grr_bl * u_r_bl;
+  double uth_bl = gthth_bl * u_th_bl;
+  double uph_bl = gtph_bl * u_t_bl + gphph_bl * u_ph_bl;
+  double ut = ut_bl + 2.0 * bh_m * r / delta * ur_bl;
+  double ur = ur_bl;
+  double uth = uth_bl;
+  double uph = uph_bl + bh_a / delta * ur_bl;
+  double u0 = ut;
+  double u1 = sth * cph * ur + cth * (r * cph - bh_a * sph) * uth + sth * (-r * sph - bh_a * cph) * uph;
+  double u2 = sth * sph * ur + cth * (r * sph + bh_a * cph) * uth + sth * (r * cph - bh_a * sph) * uph;
+  double u3 = cth * ur - r * sth * uth;
+  double n_n0_fluid = M::exp(-0.5 * (r * r / (p.formula_r0 * p.formula_r0) + p.formula_h * p.formula_h * cth * cth));
+  for (int l = 0; l < p.image_num_frequencies; l++) {
+    double nu_fluid_cgs = -(u0 * k_0 + u1 * k_1 + u2 * k_2 + u3 * k_3) * o.image_frequencies[l] * momentum_factor;
+    double j_nu_fluid_cgs = p.formula_cn0 * n_n0_fluid * M::pow(nu_fluid_cgs / p.formula_nup, -p.formula_alpha);
+    j[l * stride] = j_nu_fluid_cgs / (nu_fluid_cgs * nu_fluid_cgs);
+    double alpha_nu_fluid_cgs = p.formula_a * p.formula_cn0 * n_n0_fluid
+        * M::pow(nu_fluid_cgs / p.formula_nup, -p.formula_beta - p.formula_alpha);
+    alpha[l * stride] = alpha_nu_fluid_cgs * nu_fluid_cgs;
+  }
+}
+
+// unpolarized.cpp:53-208 for one pixel. image_col[q] = image(q, m).
+void IntegrateUnpolarizedOne(const Oracle &o, const RayBuffers &b, int num_steps, int max_steps,
+                             double momentum_factor, double *image_col) {
+  const bl_params &p = *o.p;
+  constexpr double delta_tau_max = 100.0;  // radiation_integrator.hpp:191
+  double x_unit = Physics::gg_msun * o.mass_msun / (Physics::c * Physics::c);
+  double t_unit = x_unit / Physics::c;
+  int nf = p.image_num_frequencies;
+  for (int q = 0; q < o.image_num_quantities; q++) image_col[q] = 0.0;
+  for (int l = 0; l < nf; l++) {
+    double integrated_lambda = 0.0;
+    double integrated_emission = 0.0;
+    double x1_init = b.sample_pos[1], x2_init = b.sample_pos[2], x3_init = b.sample_pos[3];
+    bool plane_sign = o.cam_x[1] * x1_init + o.cam_x[2] * x2_init + o.cam_x[3] * x3_init > 0.0;
+    int crossings_count = 0;
+    for (int n = 0; n < num_steps; n++) {
+      double delta_lambda = b.sample_len[n];
+      double delta_lambda_cgs = delta_lambda * x_unit / (o.image_frequencies[l] * momentum_factor);
+      double t_cgs = b.sample_pos[4 * n + 0] * t_unit;
+      double x1 = b.sample_pos[4 * n + 1], x2 = b.sample_pos[4 * n + 2], x3 = b.sample_pos[4 * n + 3];
+      double kcov[4] = {b.sample_dir[4 * n + 0], b.sample_dir[4 * n + 1], b.sample_dir[4 * n + 2], b.sample_dir[4 * n + 3]};
+      double j = std::numeric_limits<double>::quiet_NaN();
+      if (p.image_light or p.image_emission or p.image_emission_ave) j = b.j_i[static_cast<size_t>(l) * max_steps + n];
+      double alpha = std::numeric_limits<double>::quiet_NaN();
+      if (p.image_light or p.image_tau or p.image_tau_int) alpha = b.alpha_i[static_cast<size_t>(l) * max_steps + n];
+      double ss = j / alpha;
+      double delta_tau = alpha * delta_lambda_cgs;
+      double exp_neg = M::exp(-delta_tau);
+      double expm1 = M::expm1(delta_tau);
+      bool optically_thin = delta_tau <= delta_tau_max;
+      if (p.image_light) {
+        if (alpha > 0.0) {
+          if (optically_thin)
+            image_col[l] = exp_neg * (image_col[l] + ss * expm1);
+          else
+            image_col[l] = ss;
+        } else
+          image_col[l] += j * delta_lambda_cgs;
+      }
+      if (p.image_time and l == 0)
+        image_col[o.image_offset_time] = std::min(image_col[o.image_offset_time], t_cgs);
+      if (p.image_length and l == 0) {
+        double gcov[4][4], gcon[4][4];
+        CovariantGeodesicMetric(o, x1, x2, x3, gcov);
+        ContravariantGeodesicMetric(o, x1, x2, x3, gcon);
+        double temp_a[4] = {};
+        for (int a = 1; a < 4; a++)
+          for (int mu = 0; mu < 4; mu++)
+            temp_a[a] += (gcon[a][mu] - gcon[0][a] * gcon[0][mu] / gcon[0][0]) * kcov[mu];
+        double dl_dlambda_sq = 0.0;
+        for (int a = 1; a < 4; a++)
+          for (int bb = 1; bb < 4; bb++) dl_dlambda_sq += gcov[a][bb] * temp_a[a] * temp_a[bb];
+        image_col[o.image_offset_length] += std::sqrt(dl_dlambda_sq) * delta_lambda * x_unit;
+      }
+      if (p.image_lambda or p.image_lambda_ave) integrated_lambda += delta_lambda_cgs;
+      if (p.image_emission or p.image_emission_ave) integrated_emission += j * delta_lambda_cgs;
+      if (p.image_tau) image_col[o.image_offset_tau + l] += delta_tau;
+      const double *cell = &b.cell_values[0];
+      bool cell_ok = not std::isnan(cell[0 * static_cast<size_t>(max_steps) + n]);
+      if (p.image_lambda_ave and cell_ok)
+        for (int a = 0; a < num_cell_values; a++)
+          image_col[o.image_offset_lambda_ave + l * num_cell_values + a] +=
+              cell[a * static_cast<size_t>(max_steps) + n] * delta_lambda_cgs;
+      if (p.image_emission_ave and cell_ok)
+        for (int a = 0; a < num_cell_values; a++)
+          image_col[o.image_offset_emission_ave + l * num_cell_values + a] +=
+              cell[a * static_cast<size_t>(max_steps) + n] * j * delta_lambda_cgs;
+      if (p.image_tau_int and cell_ok) {
+        if (optically_thin)
+          for (int a = 0; a < num_cell_values; a++) {
+            int index = o.image_offset_tau_int + l * num_cell_values + a;
+            image_col[index] = exp_neg * (image_col[index] + cell[a * static_cast<size_t>(max_steps) + n] * expm1);
+          }
+        else
+          for (int a = 0; a < num_cell_values; a++)
+            image_col[o.image_offset_tau_int + l * num_cell_values + a] = cell[a * static_cast<size_t>(max_steps) + n];
+      }
+      if (p.image_crossings and l == 0) {
+        bool plane_sign_new = o.cam_x[1] * x1 + o.cam_x[2] * x2 + o.cam_x[3] * x3 > 0.0;
+        if (plane_sign_new != plane_sign) crossings_count++;
+        plane_sign = plane_sign_new;
+      }
+    }
+    if (p.image_lambda) image_col[o.image_offset_lambda + l] = integrated_lambda;
+    if (p.image_emission) image_col[o.image_offset_emission + l] = integrated_emission;
+    if (p.image_crossings and l == 0) image_col[o.image_offset_crossings] = static_cast<double>(crossings_count);
+    if (p.image_lambda_ave)
+      for (int a = 0; a < num_cell_values; a++)
+        image_col[o.image_offset_lambda_ave + l * num_cell_values + a] /= integrated_lambda;
+    if (p.image_emission_ave)
+      for (int a = 0; a < num_cell_values; a++)
+        image_col[o.image_offset_emission_ave + l * num_cell_values + a] /= integrated_emission;
+  }
+  if (p.image_light)  // :200-208
+    for (int l = 0; l < nf; l++) {
+      double nu_cu = o.image_frequencies[l] * o.image_frequencies[l] * o.image_frequencies[l];
+      image_col[l] *= nu_cu;
+    }
+}
+
+// radiation_integrator.cpp:436-520
+void ImageOffsets(Oracle &o) {
+  const bl_params &p = *o.p;
+  int nf = p.image_num_frequencies;
+  int n = 0;
+  int *offs[9] = {&o.image_offset_time, &o.image_offset_length, &o.image_offset_lambda,
+                  &o.image_offset_emission, &o.image_offset_tau, &o.image_offset_lambda_ave,
+                  &o.image_offset_emission_ave, &o.image_offset_tau_int, &o.image_offset_crossings};
+  auto set_from = [&](int first) { for (int q = first; q < 9; q++) *offs[q] = n; };
+  set_from(0);
+  if (p.image_light) { n += nf * (p.model_type == BL_MODEL_SIMULATION and o.image_polarization ? 4 : 1); set_from(0); }
+  if (p.image_time) { n++; set_from(1); }
+  if (p.image_length) { n++; set_from(2); }
+  if (p.image_lambda) { n += nf; set_from(3); }
+  if (p.image_emission) { n += nf; set_from(4); }
+  if (p.image_tau) { n += nf; set_from(5); }
+  bool sim = p.model_type == BL_MODEL_SIMULATION;
+  if (sim and p.image_lambda_ave) { n += nf * num_cell_values; set_from(6); }
+  if (sim and p.image_emission_ave) { n += nf * num_cell_values; set_from(7); }
+  if (sim and p.image_tau_int) { n += nf * num_cell_values; set_from(8); }
+  if (p.image_crossings) n++;
+  o.image_num_quantities = n;
+}
+
+int Fail(char *err, size_t err_len, const char *message, int code) {
+  if (err != nullptr && err_len > 0) std::snprintf(err, err_len, "Error: %s\n", message);
+  return code;
+}
+
+int Setup(Oracle &o, const bl_params *p, const bl_grid_desc *g, char *err, size_t err_len) {
+  o.p = p;
+  o.g = g;
+  o.bh_m = 1.0;
+  if (p->model_type == BL_MODEL_SIMULATION) {
+    o.bh_a = p->simulation_a;
+    o.mass_msun = p->simulation_m_msun;
+  } else {
+    o.bh_a = p->formula_spin;
+    o.mass_msun = p->formula_mass * Physics::c * Physics::c / Physics::gg_msun;
+  }
+  o.ray_flat = p->ray_flat != 0;
+  o.r_horizon = o.bh_m + std::sqrt(o.bh_m * o.bh_m - o.bh_a * o.bh_a);  // geodesic_integrator.cpp:117-123
+  if (p->ray_terminate == BL_TERMINATE_PHOTON)
+    o.r_terminate = 2.0 * o.bh_m * (1.0 + M::cos(2.0 / 3.0 * M::acos(-std::abs(o.bh_a) / o.bh_m)));
+  else if (p->ray_terminate == BL_TERMINATE_MULTIPLICATIVE)
+    o.r_terminate = o.r_horizon * p->ray_factor;
+  else
+    o.r_terminate = o.r_horizon + p->ray_factor;
+  o.image_polarization = p->model_type == BL_MODEL_SIMULATION and p->image_light and p->image_polarization;
+  if (o.image_polarization) return Fail(err, err_len, "oracle: polarized transfer not restated yet", BL_E_UNSUPPORTED);
+  if (p->model_type == BL_MODEL_SIMULATION) {
+    if (g == nullptr) return Fail(err, err_len, "oracle: simulation mode needs a grid", BL_E_ARG);
+    if (g->n_blocks != 1) return Fail(err, err_len, "oracle: multi-block grids not restated yet", BL_E_UNSUPPORTED);
+    if (p->slow_light_on) return Fail(err, err_len, "oracle: slow light not restated yet", BL_E_UNSUPPORTED);
+    if (p->simulation_coord == BL_COORD_FMKS) return Fail(err, err_len, "oracle: fmks not restated yet", BL_E_UNSUPPORTED);
+    if (p->plasma_power_frac != 0.0 or p->plasma_kappa_frac != 0.0)
+      return Fail(err, err_len, "oracle: non-thermal electrons not restated yet", BL_E_UNSUPPORTED);
+    o.plasma_thermal_frac = 1.0 - (p->plasma_power_frac + p->plasma_kappa_frac);
+  } else
+    o.plasma_thermal_frac = 0.0;
+  ImageOffsets(o);
+  InitializeCamera(o);
+  (void)need;
+  return BL_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int blo_image_num_quantities(const bl_params *p) {
+  Oracle o{};
+  o.p = p;
+  o.image_polarization = p->model_type == BL_MODEL_SIMULATION and p->image_light and p->image_polarization;
+  ImageOffsets(o);
+  return o.image_num_quantities;
+}
+
+const char *blo_build_info(void) {
+#ifdef BLO_LIBM
+  return "oracle;libm";
+#else
+  return "oracle;blmath";
+#endif
+}
+
+int blo_render(const bl_params *p, const bl_grid_desc *g, const bl_render_desc *d,
+               bl_camera_frame *frame, double *frequencies, blo_extra *extra, char *err,
+               size_t err_len) {
+  if (p == nullptr || d == nullptr) return BL_E_ARG;
+  if (d->outputs_on_device) return Fail(err, err_len, "oracle works on host memory only", BL_E_ARG);
+  Oracle o{};
+  int rc = Setup(o, p, g, err, err_len);
+  if (rc != BL_OK) return rc;
+  if (frame != nullptr) {
+    for (int mu = 0; mu < 4; mu++) {
+      frame->cam_x[mu] = o.cam_x[mu];
+      frame->u_con[mu] = o.u_con[mu];
+      frame->u_cov[mu] = o.u_cov[mu];
+      frame->norm_con[mu] = o.norm_con[mu];
+      frame->norm_con_c[mu] = o.norm_con_c[mu];
+      frame->hor_con_c[mu] = o.hor_con_c[mu];
+      frame->vert_con_c[mu] = o.vert_con_c[mu];
+    }
+    frame->bh_m = o.bh_m;
+    frame->bh_a = o.bh_a;
+    frame->r_horizon = o.r_horizon;
+    frame->r_terminate = o.r_terminate;
+    frame->mass_msun = o.mass_msun;
+  }
+  if (frequencies != nullptr)
+    for (int l = 0; l < p->image_num_frequencies; l++) frequencies[l] = o.image_frequencies[l];
+
+  int64_t n_rays = d->n_rays;
+  int max_steps = p->ray_max_steps;
+  int nf = p->image_num_frequencies;
+  int n_q = o.image_num_quantities;
+  bool simulation = p->model_type == BL_MODEL_SIMULATION;
+  int num_threads = (extra != nullptr && extra->num_threads > 0) ? extra->num_threads : omp_get_max_threads();
+  int64_t total_samples = 0, total_gathers = 0, total_flagged = 0;
+  int max_sample_num = 0;
+  if (extra != nullptr) extra->dump_num = 0;
+  double time_start = omp_get_wtime();
+
+  #pragma omp parallel num_threads(num_threads) reduction(+: total_samples, total_gathers, total_flagged) reduction(max: max_sample_num)
+  {
+    RayBuffers b(max_steps, nf);
+    std::vector<double> image_col(std::max(n_q, 1));
+    #pragma omp for schedule(dynamic, 16)
+    for (int64_t ray = 0; ray < n_rays; ray++) {
+      int64_t pixel = d->pixel_map != nullptr ? d->pixel_map[ray] : ray;
+      double u_ind, v_ind;
+      PixelIndices(o, *d, pixel, &u_ind, &v_ind);
+      double cpos[4], cdir[4], factor;
+      if (p->camera_type == BL_CAMERA_PLANE)
+        SetPixelPlane(o, u_ind, v_ind, cpos, cdir, &factor);
+      else
+        SetPixelPinhole(o, u_ind, v_ind, cpos, cdir, &factor);
+      if (d->camera_pos != nullptr)
+        for (int mu = 0; mu < 4; mu++) d->camera_pos[4 * ray + mu] = cpos[mu];
+      if (d->camera_dir != nullptr)
+        for (int mu = 0; mu < 4; mu++) d->camera_dir[4 * ray + mu] = cdir[mu];
+
+      int sample_num = 0;
+      bool flag = false;
+      if (p->ray_integrator == BL_INTEGRATOR_DP)
+        IntegrateRayDP(o, cpos, cdir, b, &sample_num, &flag);
+      else
+        IntegrateRayRK(o, p->ray_integrator == BL_INTEGRATOR_RK4, cpos, cdir, b, &sample_num, &flag);
+      sample_num = FinishRay(o, b, sample_num);
+      if (d->sample_num != nullptr) d->sample_num[ray] = sample_num;
+      if (d->sample_flags != nullptr) d->sample_flags[ray] = flag ? 1 : 0;
+      total_samples += sample_num;
+      total_flagged += flag ? 1 : 0;
+      max_sample_num = std::max(max_sample_num, sample_num);
+      if (extra != nullptr && extra->dump_ray == ray && extra->dump_pos != nullptr) {
+        std::memcpy(extra->dump_pos, b.sample_pos.data(), sizeof(double) * 4 * sample_num);
+        std::memcpy(extra->dump_dir, b.sample_dir.data(), sizeof(double) * 4 * sample_num);
+        std::memcpy(extra->dump_len, b.sample_len.data(), sizeof(double) * sample_num);
+        extra->dump_num = sample_num;
+      }
+
+      // coefficients: zero-initialised like j_i.Zero() / alpha_i.Zero(), cell_values NaN
+      for (int l = 0; l < nf; l++)
+        for (int n = 0; n < sample_num; n++) {
+          b.j_i[static_cast<size_t>(l) * max_steps + n] = 0.0;
+          b.alpha_i[static_cast<size_t>(l) * max_steps + n] = 0.0;
+        }
+      for (int a = 0; a < num_cell_values; a++)
+        for (int n = 0; n < sample_num; n++)
+          b.cell_values[a * static_cast<size_t>(max_steps) + n] = std::numeric_limits<double>::quiet_NaN();
+      const double nan = std::numeric_limits<double>::quiet_NaN();
+      if (simulation) {
+        bool nan_ray = p->fallback_nan and flag;  // simulation_sampling.cpp:211-216
+        for (int n = 0; n < sample_num; n++) {
+          Prims s;
+          bool gathered = false;
+          int status;
+          if (nan_ray)
+            status = 2;
+          else
+            status = SampleOne(o, &b.sample_pos[4 * n], &s, &gathered);
+          if (gathered) total_gathers++;
+          if (status == 1) continue;  // cut: simulation_coefficients.cpp:260-261
+          if (status == 2) {
+            float fnan = std::numeric_limits<float>::quiet_NaN();
+            s = Prims{fnan, fnan, fnan, fnan, fnan, fnan, fnan, fnan, fnan};
+          } else if (status == 3) {
+            // fallback values (simulation_sampling.cpp:695-707); velocities and fields default to
+            // zero there (radiation_integrator.hpp fallback_uu*, fallback_bb*)
+            s = Prims{p->fallback_rho, p->fallback_pgas, p->fallback_kappa, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+          }
+          double cell[num_cell_values];
+          for (int a = 0; a < num_cell_values; a++) cell[a] = nan;
+          SimulationCoefficientsOne(o, &b.sample_pos[4 * n], &b.sample_dir[4 * n], s, factor,
+                                    &b.j_i[n], &b.alpha_i[n], max_steps, cell);
+          for (int a = 0; a < num_cell_values; a++) b.cell_values[a * static_cast<size_t>(max_steps) + n] = cell[a];
+        }
+      } else if (sample_num > 0) {
+        if (p->fallback_nan and flag) {  // formula_coefficients.cpp:51-59 (only frequency 0 is filled)
+          for (int n = 0; n < sample_num; n++) {
+            b.j_i[n] = nan;
+            b.alpha_i[n] = nan;
+          }
+        } else
+          for (int n = 0; n < sample_num; n++)
+            FormulaCoefficientsOne(o, &b.sample_pos[4 * n], &b.sample_dir[4 * n], factor, &b.j_i[n],
+                                   &b.alpha_i[n], max_steps);
+      }
+      IntegrateUnpolarizedOne(o, b, sample_num, max_steps, factor, image_col.data());
+      if (d->image != nullptr)
+        for (int q = 0; q < n_q; q++) d->image[static_cast<size_t>(q) * n_rays + ray] = image_col[q];
+    }
+  }
+  if (extra != nullptr) {
+    extra->n_samples = total_samples;
+    extra->n_gathers = total_gathers;
+    extra->n_flagged = total_flagged;
+    extra->max_sample_num = max_sample_num;
+    extra->seconds = omp_get_wtime() - time_start;
+  }
+  return BL_OK;
+}
+
+}  // extern "C"

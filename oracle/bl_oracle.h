@@ -1,0 +1,52 @@
+/* bl_oracle.h - C-ABI of the CPU oracle (TEST INFRASTRUCTURE, not product code).
+ *
+ * The oracle is a plain CPU restatement of the reference's hot-path algorithm
+ * (src/geodesic_integrator/*, src/radiation_integrator/{simulation_sampling,
+ * simulation_coefficients,formula_coefficients,unpolarized,radiation_geometry}.cpp), written
+ * ray-at-a-time so it fits in memory at any camera size. It is pinned against the compiled
+ * reference itself (oracle/_ref/blacklight, built by oracle/Makefile from /root/reference/src):
+ *   - libbl_oracle_libm.so (built with -DBLO_LIBM, glibc math) must equal the stock reference
+ *     bit-for-bit (tier A), and
+ *   - libbl_oracle.so (blmath) must equal the reference run under
+ *     LD_PRELOAD=oracle/_ref/libblmath_preload.so bit-for-bit (tier B),
+ * on the committed golden vectors in tests/golden/ (tests/test_oracle_golden.py).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+ */
+#ifndef BL_ORACLE_H_
+#define BL_ORACLE_H_
+
+#include "blacklight_amd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct blo_extra {
+  int32_t num_threads;        /* OpenMP threads (<=0: all)                                        */
+  /* optional dump of one ray's samples in reference (reversed) order, as in the geodesic
+     checkpoint: sample_pos/dir [n][4], sample_len [n]; buffers sized ray_max_steps            */
+  int64_t dump_ray;           /* ray index to dump, or -1                                          */
+  double *dump_pos, *dump_dir, *dump_len;
+  int32_t dump_num;           /* out: samples written                                              */
+  /* out: statistics over the call */
+  int64_t n_samples, n_gathers, n_flagged;
+  int32_t max_sample_num;
+  double seconds;             /* wall time of the ray loop                                         */
+} blo_extra;
+
+/* Same contract as bl_render() with host pointers (d->outputs_on_device must be 0). g may be NULL
+ * in formula mode. frame (optional) receives the camera frame. */
+int blo_render(const bl_params *p, const bl_grid_desc *g, const bl_render_desc *d,
+               bl_camera_frame *frame, double *frequencies, blo_extra *extra, char *err,
+               size_t err_len);
+
+/* number of image rows for these parameters (radiation_integrator.cpp:436-520) */
+int blo_image_num_quantities(const bl_params *p);
+
+const char *blo_build_info(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

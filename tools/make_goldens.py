@@ -1,0 +1,269 @@
+#!/opt/conda/bin/python3.9
+"""Generate the golden vectors in tests/golden/ by running the compiled reference.
+
+Runs ONLY in the build container (needs /root/reference, oracle/_ref/blacklight built by
+`make -C oracle ref preload`, and a Python with h5py for the reference's mock-data script:
+/opt/conda/bin/python3.9). Nothing here travels to the GPU box except the .npz fixtures it writes.
+
+For every case the unmodified reference binary is run twice:
+  tier A: stock (glibc libm)
+  tier B: LD_PRELOAD=oracle/_ref/libblmath_preload.so  (the build's pinned math library)
+with checkpoint_geodesic_save = true, and the fixture records, for both tiers, the image rows,
+sample_num, sample_flags, the camera frame, and complete per-sample data for a few rays.
+
+Usage:  /opt/conda/bin/python3.9 tools/make_goldens.py [case ...]
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_BIN = os.path.join(REPO, "oracle", "_ref", "blacklight")
+PRELOAD = os.path.join(REPO, "oracle", "_ref", "libblmath_preload.so")
+MOCK_SCRIPT = "/root/reference/scripts/generate_mock_simulation.py"
+WORK = "/tmp/blgold"
+OUT = os.path.join(REPO, "tests", "golden")
+
+# Parameter sets (values of the reference's example inputs; keys are the .input grammar).
+SIM_BASE = dict(
+    model_type="simulation", num_threads=8, output_format="npz", output_file="output/out.npz",
+    output_camera="false", checkpoint_geodesic_save="true", checkpoint_geodesic_load="false",
+    checkpoint_geodesic_file="data/geo.dat", checkpoint_sample_save="false",
+    checkpoint_sample_load="false", simulation_format="athena", simulation_file="data/mock.athdf",
+    simulation_multiple="false", simulation_coord="sks", simulation_a=0.0,
+    simulation_m_msun=4.152e6, simulation_rho_cgs=1.0e-16, simulation_interp="true",
+    simulation_block_interp="false", camera_type="plane", camera_r=50.0, camera_th=45.0,
+    camera_ph=0.0, camera_urn=0.0, camera_uthn=0.0, camera_uphn=0.0, camera_k_r=1.0,
+    camera_k_th=0.0, camera_k_ph=0.0, camera_rotation=0.0, camera_width=24.0,
+    camera_resolution=32, ray_flat="false", ray_terminate="multiplicative", ray_factor=1.005,
+    ray_integrator="dp", ray_step=0.01, ray_max_steps=2000, ray_max_retries=20,
+    ray_tol_abs=1.0e-8, ray_tol_rel=1.0e-8, image_light="true", image_num_frequencies=1,
+    image_frequency=2.3e11, image_normalization="infinity", image_polarization="false",
+    image_rotation_split="false", image_time="false", image_length="false", image_lambda="false",
+    image_emission="false", image_tau="false", image_lambda_ave="false",
+    image_emission_ave="false", image_tau_int="false", image_crossings="false",
+    render_num_images=0, slow_light_on="false", adaptive_max_level=0, plasma_mu=0.5,
+    plasma_ne_ni=1.0, plasma_model="ti_te_beta", plasma_use_p="true", plasma_rat_low=1.0,
+    plasma_rat_high=10.0, plasma_power_frac=0.0, plasma_kappa_frac=0.0, cut_rho_min=-1.0,
+    cut_rho_max=-1.0, cut_n_e_min=-1.0, cut_n_e_max=-1.0, cut_p_gas_min=-1.0, cut_p_gas_max=-1.0,
+    cut_theta_e_min=-1.0, cut_theta_e_max=-1.0, cut_b_min=-1.0, cut_b_max=-1.0,
+    cut_sigma_min=-1.0, cut_sigma_max=1.0, cut_beta_inverse_min=-1.0, cut_beta_inverse_max=-1.0,
+    cut_omit_near="false", cut_omit_far="false", cut_omit_in=-1.0, cut_omit_out=-1.0,
+    cut_midplane_theta=0.0, cut_midplane_z=0.0, cut_plane="false", fallback_nan="true",
+)
+
+FORMULA_BASE = dict(
+    model_type="formula", num_threads=8, output_format="npz", output_file="output/out.npz",
+    output_camera="false", checkpoint_geodesic_save="true", checkpoint_geodesic_load="false",
+    checkpoint_geodesic_file="data/geo.dat", formula_mass=6.0e11, formula_spin=0.9,
+    formula_r0=10.0, formula_h=0.0, formula_l0=0.0, formula_q=0.5, formula_nup=2.3e11,
+    formula_cn0=3.0e-18, formula_alpha=-3.0, formula_a=0.0, formula_beta=2.5,
+    camera_type="plane", camera_r=1000.0, camera_th=60.0, camera_ph=0.0,
+    camera_urn=0.0019980065868325484, camera_uthn=0.0, camera_uphn=0.0, camera_k_r=1.0,
+    camera_k_th=0.0, camera_k_ph=0.0, camera_rotation=0.0, camera_width=30.0,
+    camera_resolution=32, ray_flat="false", ray_terminate="additive", ray_factor=5.0e-4,
+    ray_integrator="dp", ray_step=0.01, ray_max_steps=7000, ray_max_retries=20,
+    ray_tol_abs=1.0e-8, ray_tol_rel=1.0e-8, image_light="true", image_num_frequencies=1,
+    image_frequency=2.3e11, image_normalization="camera", image_time="false",
+    image_length="false", image_lambda="false", image_emission="false", image_tau="false",
+    image_lambda_ave="false", image_emission_ave="false", image_tau_int="false",
+    image_crossings="false", render_num_images=0, adaptive_max_level=0, cut_omit_near="false",
+    cut_omit_far="false", cut_omit_in=-1.0, cut_omit_out=-1.0, cut_midplane_theta=0.0,
+    cut_midplane_z=0.0, cut_plane="false", fallback_nan="true",
+)
+
+SMALL_MOCK = dict(n_r=32, n_th=24, n_ph=32)
+
+CASES = {
+    # name: (base, overrides, mock args or None, rays to dump in full)
+    "sim_dp_interp": (SIM_BASE, dict(camera_resolution=32), SMALL_MOCK, [0, 495, 528, 1023]),
+    "sim_dp_nearest": (SIM_BASE, dict(camera_resolution=24, simulation_interp="false"), SMALL_MOCK, [300]),
+    "sim_rk4": (SIM_BASE, dict(camera_resolution=16, ray_integrator="rk4", ray_max_steps=3000), SMALL_MOCK, [120]),
+    "sim_rk2": (SIM_BASE, dict(camera_resolution=16, ray_integrator="rk2", ray_max_steps=3000), SMALL_MOCK, [120]),
+    "sim_spin_fallback": (SIM_BASE, dict(camera_resolution=24, simulation_a=0.9, fallback_nan="false",
+                                         fallback_rho=1.0e-6, fallback_pgas=1.0e-8), SMALL_MOCK, [276, 300]),
+    "sim_spin_nan": (SIM_BASE, dict(camera_resolution=16, simulation_a=0.5), SMALL_MOCK, [136]),
+    "sim_pinhole_camera_norm": (SIM_BASE, dict(camera_resolution=24, camera_type="pinhole", camera_r=30.0,
+                                               camera_width=20.0, image_normalization="camera",
+                                               camera_urn=-0.05, camera_uphn=0.002, camera_th=70.0,
+                                               camera_ph=30.0, camera_rotation=15.0), SMALL_MOCK, [300]),
+    "sim_multifreq": (SIM_BASE, dict(camera_resolution=16, image_num_frequencies=3, image_frequency_start=1.0e11,
+                                     image_frequency_end=4.0e11, image_frequency_spacing="log"), SMALL_MOCK, [136]),
+    "sim_cuts": (SIM_BASE, dict(camera_resolution=24, cut_omit_near="true", cut_omit_in=3.0, cut_omit_out=30.0,
+                                cut_midplane_theta=50.0, cut_midplane_z=20.0, cut_plane="true",
+                                cut_plane_origin="0.0,0.0,0.0", cut_plane_normal="1.0,0.2,0.1",
+                                cut_rho_min=1.0e-19, cut_b_max=1.0e3, cut_beta_inverse_max=5.0), SMALL_MOCK, [300]),
+    "sim_few_steps": (SIM_BASE, dict(camera_resolution=16, ray_max_steps=450), SMALL_MOCK, [136]),
+    "sim_pole": (SIM_BASE, dict(camera_resolution=16, camera_th=0.0), SMALL_MOCK, [136]),
+    "sim_aux_images": (SIM_BASE, dict(camera_resolution=16, image_time="true", image_length="true",
+                                      image_lambda="true", image_emission="true", image_tau="true",
+                                      image_lambda_ave="true", image_emission_ave="true", image_tau_int="true",
+                                      image_crossings="true"), SMALL_MOCK, [136]),
+    "formula_dp": (FORMULA_BASE, dict(camera_resolution=32), None, [0, 528, 1023]),
+    "formula_absorb": (FORMULA_BASE, dict(camera_resolution=16, formula_a=1.0e6, formula_l0=1.0, formula_h=3.33,
+                                          formula_alpha=0.0, camera_type="pinhole", camera_r=100.0), None, [136]),
+    "formula_flat": (FORMULA_BASE, dict(camera_resolution=16, ray_flat="true", camera_r=100.0, formula_spin=0.0), None, [136]),
+}
+
+
+def write_input(path, params):
+    with open(path, "w") as f:
+        for key, value in params.items():
+            f.write(f"{key} = {value}\n")
+
+
+def read_checkpoint(path, dump_rays):
+    """Layout: reference src/geodesic_integrator/geodesic_checkpoint.cpp:36-57, utils/file_io.cpp:65-76."""
+    out = {}
+    with open(path, "rb") as f:
+        for name in ("cam_x", "u_con", "u_cov", "norm_con", "norm_con_c", "hor_con_c", "vert_con_c"):
+            out[name] = np.frombuffer(f.read(32), dtype="<f8").copy()
+
+        def read_array(dtype, rank, keep=True, rows=None):
+            dims = np.frombuffer(f.read(20), dtype="<i4")
+            count = int(np.prod([max(int(d), 1) for d in dims]))
+            itemsize = np.dtype(dtype).itemsize
+            if not keep:
+                if rows is None:
+                    f.seek(count * itemsize, 1)
+                    return dims, None
+                # read selected rows of the slowest non-trivial dimension only
+                shape = [int(d) for d in dims[:rank]][::-1]   # slowest first
+                row_items = int(np.prod(shape[1:]))
+                base = f.tell()
+                picked = {}
+                for row in rows:
+                    f.seek(base + row * row_items * itemsize)
+                    picked[row] = np.frombuffer(f.read(row_items * itemsize), dtype=dtype).reshape(shape[1:]).copy()
+                f.seek(base + count * itemsize)
+                return dims, picked
+            data = np.frombuffer(f.read(count * itemsize), dtype=dtype).copy()
+            shape = [int(d) for d in dims[:rank]][::-1]
+            return dims, data.reshape(shape)
+
+        _, out["camera_pos"] = read_array("<f8", 2)
+        _, out["camera_dir"] = read_array("<f8", 2)
+        _, out["image_frequencies"] = read_array("<f8", 1)
+        _, out["momentum_factors"] = read_array("<f8", 1)
+        out["geodesic_num_steps"] = int(np.frombuffer(f.read(4), dtype="<i4")[0])
+        _, flags = read_array("u1", 1)
+        out["sample_flags"] = flags
+        _, out["sample_num"] = read_array("<i4", 1)
+        _, pos = read_array("<f8", 3, keep=False, rows=dump_rays)
+        _, dirs = read_array("<f8", 3, keep=False, rows=dump_rays)
+        _, lens = read_array("<f8", 2, keep=False, rows=dump_rays)
+        for ray in dump_rays:
+            n = int(out["sample_num"][ray])
+            out[f"ray{ray}_pos"] = pos[ray][:n]
+            out[f"ray{ray}_dir"] = dirs[ray][:n]
+            out[f"ray{ray}_len"] = lens[ray][:n]
+    return out
+
+
+def run_reference(workdir, input_name, preload):
+    env = dict(os.environ)
+    if preload:
+        env["LD_PRELOAD"] = PRELOAD
+    result = subprocess.run([REF_BIN, input_name], cwd=workdir, env=env, capture_output=True, text=True)
+    if "Calculation completed" not in result.stdout:
+        raise RuntimeError(f"reference failed: {result.stdout}\n{result.stderr}")
+    return result.stderr
+
+
+def mock_arrays(path):
+    import h5py
+    with h5py.File(path, "r") as f:
+        prim = np.concatenate([f["prim"][...], f["B"][...]], axis=0).astype(np.float32)
+        coords = {name: f[name][...].astype(np.float32) for name in ("x1f", "x2f", "x3f", "x1v", "x2v", "x3v")}
+    return prim, coords
+
+
+def make_case(name):
+    base, overrides, mock, dump_rays = CASES[name]
+    params = dict(base)
+    params.update(overrides)
+    workdir = os.path.join(WORK, name)
+    os.makedirs(os.path.join(workdir, "data"), exist_ok=True)
+    os.makedirs(os.path.join(workdir, "output"), exist_ok=True)
+    fixture = {}
+    if mock is not None:
+        mock_path = os.path.join(workdir, "data", "mock.athdf")
+        args = [sys.executable, "-W", "ignore", MOCK_SCRIPT, mock_path]
+        for key, value in mock.items():
+            args += [f"--{key}", str(value)]
+        subprocess.run(args, check=True)
+        fixture["mock_args"] = json.dumps(mock)
+    write_input(os.path.join(workdir, "case.input"), params)
+    # what the test feeds to the build: same keys without file plumbing
+    skip = {"checkpoint_geodesic_save", "checkpoint_geodesic_file"}
+    test_params = {k: v for k, v in params.items() if k not in skip}
+    test_params["checkpoint_geodesic_save"] = "false"
+    fixture["params"] = json.dumps(test_params)
+    fixture["dump_rays"] = np.array(dump_rays, dtype=np.int64)
+    for tier, preload in (("A", False), ("B", True)):
+        warnings = run_reference(workdir, "case.input", preload)
+        npz = np.load(os.path.join(workdir, "output", "out.npz"))
+        fixture[f"{tier}_warnings"] = warnings
+        for key in npz.files:
+            fixture[f"{tier}_npz_{key}"] = npz[key]
+        chk = read_checkpoint(os.path.join(workdir, "data", "geo.dat"), dump_rays)
+        for key, value in chk.items():
+            if key in ("camera_pos", "camera_dir", "momentum_factors"):
+                # keep a handful of pixels only (corner, centre-ish, last)
+                n = value.shape[0]
+                picks = np.array(sorted(set([0, n // 2 + 7, n - 1] + list(dump_rays))), dtype=np.int64)
+                fixture[f"{tier}_{key}_pixels"] = picks
+                fixture[f"{tier}_{key}"] = value[picks]
+            else:
+                fixture[f"{tier}_{key}"] = value
+        os.remove(os.path.join(workdir, "data", "geo.dat"))
+    os.makedirs(OUT, exist_ok=True)
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **fixture)
+    a, b = fixture["A_npz_I_nu"], fixture["B_npz_I_nu"]
+    same_num = np.array_equal(fixture["A_sample_num"], fixture["B_sample_num"])
+    print(f"{name}: I_nu {a.shape} nan={int(np.isnan(b).sum())} A-vs-B max rel "
+          f"{np.nanmax(np.abs(a - b) / np.nanmax(np.abs(b))):.2e} sample_num equal A/B: {same_num} "
+          f"flags B: {int(fixture['B_sample_flags'].sum())}")
+
+
+def make_mock_fixture():
+    """Small-mock arrays exactly as produced by the reference's script (for tests/test_mock.py)."""
+    workdir = os.path.join(WORK, "mock")
+    os.makedirs(workdir, exist_ok=True)
+    path = os.path.join(workdir, "mock.athdf")
+    args = [sys.executable, "-W", "ignore", MOCK_SCRIPT, path]
+    for key, value in SMALL_MOCK.items():
+        args += [f"--{key}", str(value)]
+    subprocess.run(args, check=True)
+    prim, coords = mock_arrays(path)
+    np.savez_compressed(os.path.join(OUT, "mock_small.npz"), prim=prim, mock_args=json.dumps(SMALL_MOCK), **coords)
+    # hashes of the default and 256^3 mocks (too large to commit)
+    import hashlib
+    hashes = {}
+    for label, extra in (("default_77x64x128", {}), ("n256", dict(n_r=256, n_th=256, n_ph=256))):
+        p = os.path.join(workdir, f"{label}.athdf")
+        a = [sys.executable, "-W", "ignore", MOCK_SCRIPT, p]
+        for key, value in extra.items():
+            a += [f"--{key}", str(value)]
+        subprocess.run(a, check=True)
+        prim_l, coords_l = mock_arrays(p)
+        hashes[label] = dict(prim_sha256=hashlib.sha256(prim_l.tobytes()).hexdigest(),
+                             per_var_sha256=[hashlib.sha256(prim_l[v].tobytes()).hexdigest() for v in range(8)],
+                             coords_sha256={k: hashlib.sha256(v.tobytes()).hexdigest() for k, v in coords_l.items()},
+                             shape=list(prim_l.shape))
+        os.remove(p)
+    with open(os.path.join(OUT, "mock_hashes.json"), "w") as f:
+        json.dump(hashes, f, indent=1)
+    print("mock fixtures written")
+
+
+if __name__ == "__main__":
+    names = sys.argv[1:] or (["mock"] + list(CASES))
+    for case_name in names:
+        if case_name == "mock":
+            make_mock_fixture()
+        else:
+            make_case(case_name)
