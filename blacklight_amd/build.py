@@ -1,0 +1,74 @@
+"""Build libblacklight_amd.so (HIP, gfx950 only) in-tree with hipcc.
+
+    python -m blacklight_amd.build [--force] [--verbose]
+
+Objects are cached under blacklight_amd/csrc/_obj and rebuilt when a source or header is newer.
+-ffp-contract=off is mandatory: bit-exact ray-step counts depend on no implicit FMA contraction
+(blmath.h); the only fused operations are the explicit fma calls of the math library.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "_obj")
+LIB = os.path.join(HERE, "libblacklight_amd.so")
+INCLUDE = os.path.join(os.path.dirname(HERE), "include")
+
+SOURCES = ["bl_kernels.hip", "bl_api.hip", "bl_params.cpp"]
+ARCH = "gfx950"
+COMMON = ["-std=c++17", "-O3", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden", f"-I{INCLUDE}", f"-I{CSRC}"]
+
+
+def hipcc():
+    path = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(path):
+        raise RuntimeError("hipcc not found: the MI355X path cannot be built (there is no CPU fallback)")
+    return path
+
+
+def _newest_header():
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers.append(os.path.join(INCLUDE, "blacklight_amd.h"))
+    return max(os.path.getmtime(h) for h in headers)
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OBJ, exist_ok=True)
+    cc = hipcc()
+    header_time = _newest_header()
+    objects = []
+    rebuilt = False
+    for src in SOURCES:
+        src_path = os.path.join(CSRC, src)
+        obj_path = os.path.join(OBJ, src.rsplit(".", 1)[0] + ".o")
+        objects.append(obj_path)
+        stale = (force or not os.path.exists(obj_path)
+                 or os.path.getmtime(obj_path) < max(os.path.getmtime(src_path), header_time))
+        if not stale:
+            continue
+        cmd = [cc, "-c", src_path, "-o", obj_path] + COMMON
+        if src.endswith(".hip"):
+            cmd += [f"--offload-arch={ARCH}", "-Rpass-analysis=kernel-resource-usage"] if verbose else [f"--offload-arch={ARCH}"]
+        else:
+            cmd += ["-x", "c++"] if False else []
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        result = subprocess.run(cmd, capture_output=True, text=True)
+        if result.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{result.stdout}\n{result.stderr}")
+        if verbose and result.stderr:
+            print(result.stderr)
+        rebuilt = True
+    if rebuilt or force or not os.path.exists(LIB):
+        cmd = [cc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objects
+        result = subprocess.run(cmd, capture_output=True, text=True)
+        if result.returncode != 0:
+            raise RuntimeError(f"link failed:\n{result.stdout}\n{result.stderr}")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv))

@@ -1,0 +1,153 @@
+"""Host-side driver object over the C-ABI (bl_init / bl_set_grid / bl_render).
+
+Mirrors how the reference's main() drives the hot path (src/blacklight.cpp:93-94, 178-233):
+construct once from the input parameters, hand over the grid once per snapshot, render one adaptive
+level per call. All computation happens in libblacklight_amd.so on the GPU.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from .params import Params
+
+
+class Context:
+    def __init__(self, params: Params, device: int = -1):
+        L = _capi.lib()
+        self._lib = L
+        self.params = params
+        handle = C.c_void_p()
+        rc = L.bl_init(params.ptr, device, C.byref(handle))
+        if rc != 0:
+            raise _capi.BlacklightError(rc, L.bl_last_global_error().decode())
+        self._ctx = handle
+        self._grid_keepalive = None
+        self.n_freq = int(params.get("image_num_frequencies"))
+        self.resolution = int(params.get("camera_resolution"))
+
+    def close(self):
+        if self._ctx:
+            self._lib.bl_free(self._ctx)
+            self._ctx = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise _capi.BlacklightError(rc, self._lib.bl_last_error(self._ctx).decode())
+
+    # ------------------------------------------------------------------ queries
+    @property
+    def num_quantities(self):
+        return self._lib.bl_image_num_quantities(self._ctx)
+
+    @property
+    def camera_frame(self):
+        frame = _capi.CameraFrame()
+        self._check(self._lib.bl_camera_frame_get(self._ctx, C.byref(frame)))
+        return frame
+
+    @property
+    def frequencies(self):
+        out = np.zeros(self.n_freq)
+        self._check(self._lib.bl_frequencies(self._ctx, out.ctypes.data_as(C.POINTER(C.c_double)), self.n_freq))
+        return out
+
+    @property
+    def warnings(self):
+        return self._lib.bl_warnings(self._ctx).decode()
+
+    @property
+    def stats(self):
+        st = _capi.Stats()
+        self._check(self._lib.bl_get_stats(self._ctx, C.byref(st)))
+        return st
+
+    def set_scratch_limit(self, nbytes):
+        self._check(self._lib.bl_set_scratch_limit(self._ctx, int(nbytes)))
+
+    # ------------------------------------------------------------------ grid
+    def set_grid(self, grid):
+        """grid: blacklight_amd.mock.Grid (or anything with .desc())."""
+        desc = grid.desc()
+        self._grid_keepalive = grid
+        self._check(self._lib.bl_set_grid(self._ctx, C.byref(desc)))
+
+    # ------------------------------------------------------------------ render
+    def level_pixels(self, level=0, n_blocks=0):
+        if level == 0:
+            return self.resolution * self.resolution
+        bs = int(self.params.get("adaptive_block_size"))
+        return n_blocks * bs * bs
+
+    def render(self, level=0, block_locs=None, pixel_map=None, want_camera=False):
+        """Trace one adaptive level into host arrays. Returns a dict."""
+        d = _capi.RenderDesc()
+        d.level = level
+        keep = []
+        n_blocks = 0
+        if block_locs is not None:
+            bl = np.ascontiguousarray(block_locs, dtype=np.int32).reshape(-1, 2)
+            keep.append(bl)
+            d.block_locs = bl.ctypes.data_as(C.c_void_p)
+            n_blocks = bl.shape[0]
+            d.n_blocks = n_blocks
+        if pixel_map is not None:
+            pm = np.ascontiguousarray(pixel_map, dtype=np.int32)
+            keep.append(pm)
+            d.pixel_map = pm.ctypes.data_as(C.c_void_p)
+            n_rays = pm.size
+        else:
+            n_rays = self.level_pixels(level, n_blocks)
+        d.n_rays = n_rays
+        d.outputs_on_device = 0
+        n_q = self.num_quantities
+        image = np.empty((n_q, n_rays), dtype=np.float64)
+        sample_num = np.empty(n_rays, dtype=np.int32)
+        sample_flags = np.empty(n_rays, dtype=np.uint8)
+        d.image = image.ctypes.data_as(C.c_void_p)
+        d.sample_num = sample_num.ctypes.data_as(C.c_void_p)
+        d.sample_flags = sample_flags.ctypes.data_as(C.c_void_p)
+        camera_pos = camera_dir = None
+        if want_camera:
+            camera_pos = np.empty((n_rays, 4))
+            camera_dir = np.empty((n_rays, 4))
+            d.camera_pos = camera_pos.ctypes.data_as(C.c_void_p)
+            d.camera_dir = camera_dir.ctypes.data_as(C.c_void_p)
+        self._check(self._lib.bl_render(self._ctx, C.byref(d)))
+        return dict(image=image, sample_num=sample_num, sample_flags=sample_flags,
+                    camera_pos=camera_pos, camera_dir=camera_dir, stats=self.stats)
+
+    def render_device(self, image_ptr, n_rays, level=0, pixel_map=None, sample_num_ptr=0, sample_flags_ptr=0,
+                      block_locs=None):
+        """Trace into caller-owned HBM (raw device pointers, e.g. torch.Tensor.data_ptr())."""
+        d = _capi.RenderDesc()
+        d.level = level
+        keep = []
+        if block_locs is not None:
+            bl = np.ascontiguousarray(block_locs, dtype=np.int32).reshape(-1, 2)
+            keep.append(bl)
+            d.block_locs = bl.ctypes.data_as(C.c_void_p)
+            d.n_blocks = bl.shape[0]
+        if pixel_map is not None:
+            pm = np.ascontiguousarray(pixel_map, dtype=np.int32)
+            keep.append(pm)
+            d.pixel_map = pm.ctypes.data_as(C.c_void_p)
+        d.n_rays = n_rays
+        d.outputs_on_device = 1
+        d.image = C.c_void_p(image_ptr)
+        d.sample_num = C.c_void_p(sample_num_ptr) if sample_num_ptr else None
+        d.sample_flags = C.c_void_p(sample_flags_ptr) if sample_flags_ptr else None
+        self._check(self._lib.bl_render(self._ctx, C.byref(d)))
+        return self.stats

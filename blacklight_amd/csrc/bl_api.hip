@@ -1,0 +1,764 @@
+// bl_api.hip - C-ABI of the MI355X hot path (include/blacklight_amd.h): context, parameter
+// validation in the reference's words, grid repack + upload, chunked kernel pipeline, statistics.
+//
+// Host-side counterpart of the reference's GeodesicIntegrator / RadiationIntegrator constructors
+// (src/geodesic_integrator/geodesic_integrator.cpp:23-157, src/radiation_integrator/
+// radiation_integrator.cpp:26-541) and of their Integrate() drivers, for the configurations in the
+// hot-path scope. Configurations outside it are rejected loudly (BL_E_UNSUPPORTED); nothing falls
+// back to a CPU path.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/blacklight_amd.h"
+#include "bl_camera.h"
+#include "bl_device.h"
+
+extern "C" hipError_t bl_launch_geodesic(const BlTraceArgs *args, int integrator, int grid, hipStream_t stream);
+extern "C" int bl_geodesic_occupancy(int integrator);
+extern "C" hipError_t bl_launch_shade(const BlShadeArgs *args, int model, int grid, hipStream_t stream);
+extern "C" hipError_t bl_launch_transfer(const BlTransferArgs *args, hipStream_t stream);
+
+namespace {
+
+constexpr double kPi = 3.141592653589793;
+constexpr double kC = 2.99792458e10;
+constexpr double kGGMsun = 1.32712440018e26;
+constexpr int kNumCellValues = 7;
+
+thread_local std::string g_global_error;
+
+struct Failure {
+  int code;
+  std::string message;
+};
+
+template <typename T>
+struct DeviceBuffer {
+  T *ptr = nullptr;
+  size_t count = 0;
+  void Free() {
+    if (ptr != nullptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    count = 0;
+  }
+  void Ensure(size_t n) {
+    if (n <= count) return;
+    Free();
+    hipError_t err = hipMalloc(reinterpret_cast<void **>(&ptr), n * sizeof(T));
+    if (err != hipSuccess)
+      throw Failure{BL_E_DEVICE, std::string("hipMalloc of ") + std::to_string(n * sizeof(T)) + " bytes failed: " + hipGetErrorString(err)};
+    count = n;
+  }
+};
+
+void Check(hipError_t err, const char *what) {
+  if (err != hipSuccess) throw Failure{BL_E_DEVICE, std::string(what) + ": " + hipGetErrorString(err)};
+}
+
+}  // namespace
+
+struct bl_ctx {
+  bl_params params;
+  bl_camera_frame frame;
+  BlSpacetime st;
+  std::vector<double> frequencies;
+  std::string last_error, warnings;
+  int device = 0;
+  int num_cus = 256;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  uint64_t scratch_limit = 48ull << 30;
+
+  // image rows (radiation_integrator.cpp:436-520)
+  int image_num_quantities = 0;
+  double plasma_thermal_frac = 0.0;
+
+  // grid
+  bool have_grid = false;
+  int n_i = 0, n_j = 0, n_k = 0;
+  bl_grid_desc grid_meta{};
+  DeviceBuffer<float> d_cells;
+  DeviceBuffer<double> d_coords;   // x1f x1v x2f x2v x3f x3v packed
+  DeviceBuffer<int> d_buckets;
+  BlGridDevice grid_dev{};
+
+  // per-chunk scratch
+  DeviceBuffer<BlSampleRecord> d_records;
+  DeviceBuffer<double2> d_transfer;
+  DeviceBuffer<double> d_ray_kt, d_ray_factor, d_freq;
+  DeviceBuffer<int> d_ray_sample_num;
+  DeviceBuffer<unsigned char> d_ray_flags;
+  DeviceBuffer<long long> d_ray_out_index;
+  DeviceBuffer<unsigned long long> d_counters;   // BL_CNT_COUNT + 4 stats
+  DeviceBuffer<int> d_pixel_map, d_block_locs;
+  // host-output staging
+  DeviceBuffer<double> d_image, d_camera_pos, d_camera_dir;
+  DeviceBuffer<int> d_out_sample_num;
+  DeviceBuffer<unsigned char> d_out_flags;
+
+  bl_stats stats{};
+};
+
+namespace {
+
+void Warn(bl_ctx *ctx, const std::string &message) { ctx->warnings += "Warning: " + message + "\n"; }
+
+bool Has(const bl_params &p, int index) { return p.has[index] != 0; }
+
+// std::optional::value() of the reference: a missing key surfaces as bad_optional_access, which
+// main() reports per stage (blacklight.cpp:100-104, 147-151)
+void Require(const bl_params &p, std::initializer_list<int> keys, const char *stage_message) {
+  for (int key : keys)
+    if (!Has(p, key)) throw Failure{BL_E_MISSING, stage_message};
+}
+
+constexpr const char *kGeoMissing = "GeodesicIntegrator unable to find all needed values in input file.";
+constexpr const char *kRadMissing = "RadiationIntegrator unable to find all needed values in input file.";
+
+// GeodesicIntegrator::GeodesicIntegrator (geodesic_integrator.cpp:23-157)
+void ValidateGeodesic(bl_ctx *ctx) {
+  const bl_params &p = ctx->params;
+  Require(p, {BL_P_model_type, BL_P_checkpoint_geodesic_save, BL_P_checkpoint_geodesic_load}, kGeoMissing);
+  if (p.checkpoint_geodesic_save && p.checkpoint_geodesic_load)
+    throw Failure{BL_E_INPUT, "Cannot both save and load a geodesic checkpoint."};
+  if (p.checkpoint_geodesic_save || p.checkpoint_geodesic_load)
+    throw Failure{BL_E_UNSUPPORTED, "Geodesic checkpoints are outside the scope of the MI355X hot path."};
+  Require(p, {BL_P_camera_type, BL_P_camera_r, BL_P_camera_th, BL_P_camera_ph, BL_P_camera_urn, BL_P_camera_uthn,
+              BL_P_camera_uphn, BL_P_camera_k_r, BL_P_camera_k_th, BL_P_camera_k_ph, BL_P_camera_rotation,
+              BL_P_camera_width, BL_P_camera_resolution, BL_P_camera_pole},
+          kGeoMissing);
+  if (p.camera_resolution <= 0) throw Failure{BL_E_INPUT, "Must have positive camera_resolution."};
+  Require(p, {BL_P_ray_flat, BL_P_ray_terminate}, kGeoMissing);
+  if (p.ray_terminate != BL_TERMINATE_PHOTON) Require(p, {BL_P_ray_factor}, kGeoMissing);
+  Require(p, {BL_P_ray_integrator, BL_P_ray_step, BL_P_ray_max_steps}, kGeoMissing);
+  if (p.ray_max_steps <= 0) throw Failure{BL_E_INPUT, "Must have positive ray_max_steps."};
+  if (p.ray_integrator == BL_INTEGRATOR_DP) {
+    Require(p, {BL_P_ray_max_retries}, kGeoMissing);
+    if (p.ray_max_retries <= 0) throw Failure{BL_E_INPUT, "Must have nonnegative ray_max_retries."};
+    Require(p, {BL_P_ray_tol_abs, BL_P_ray_tol_rel}, kGeoMissing);
+  }
+  Require(p, {BL_P_image_num_frequencies}, kGeoMissing);
+  if (p.image_num_frequencies == 1) {
+    Require(p, {BL_P_image_frequency}, kGeoMissing);
+    if (p.image_frequency <= 0.0) throw Failure{BL_E_INPUT, "Must choose positive image_frequency."};
+  } else if (p.image_num_frequencies > 1) {
+    Require(p, {BL_P_image_frequency_start}, kGeoMissing);
+    if (p.image_frequency_start <= 0.0) throw Failure{BL_E_INPUT, "Must choose positive image_frequency_start."};
+    Require(p, {BL_P_image_frequency_end}, kGeoMissing);
+    if (p.image_frequency_end <= 0.0) throw Failure{BL_E_INPUT, "Must choose positive image_frequency_end."};
+    Require(p, {BL_P_image_frequency_spacing}, kGeoMissing);
+  } else {
+    throw Failure{BL_E_INPUT, "Must have positive image_num_frequencies."};
+  }
+  Require(p, {BL_P_image_normalization, BL_P_adaptive_max_level}, kGeoMissing);
+  if (p.adaptive_max_level > 0) {
+    Require(p, {BL_P_adaptive_block_size}, kGeoMissing);
+    if (p.adaptive_block_size <= 0) throw Failure{BL_E_INPUT, "Must have positive adaptive_block_size."};
+    if (p.camera_resolution % p.adaptive_block_size != 0)
+      throw Failure{BL_E_INPUT, "Must have adaptive_block_size divide camera_resolution."};
+  }
+  // geometry (:107-123)
+  ctx->st.bh_m = 1.0;
+  if (p.model_type == BL_MODEL_SIMULATION) {
+    Require(p, {BL_P_simulation_a}, kGeoMissing);
+    ctx->st.bh_a = p.simulation_a;
+  } else {
+    Require(p, {BL_P_formula_spin}, kGeoMissing);
+    ctx->st.bh_a = p.formula_spin;
+  }
+  ctx->st.ray_flat = p.ray_flat;
+  bl_camera_frame &f = ctx->frame;
+  f.bh_m = ctx->st.bh_m;
+  f.bh_a = ctx->st.bh_a;
+  f.r_horizon = f.bh_m + blm_sqrt(f.bh_m * f.bh_m - f.bh_a * f.bh_a);
+  if (p.ray_terminate == BL_TERMINATE_PHOTON)
+    f.r_terminate = 2.0 * f.bh_m * (1.0 + bl_cos(2.0 / 3.0 * bl_acos(-blm_abs(f.bh_a) / f.bh_m)));
+  else if (p.ray_terminate == BL_TERMINATE_MULTIPLICATIVE)
+    f.r_terminate = f.r_horizon * p.ray_factor;
+  else
+    f.r_terminate = f.r_horizon + p.ray_factor;
+}
+
+// InitializeCamera frequency list (camera.cpp:30-50)
+void BuildFrequencies(bl_ctx *ctx) {
+  const bl_params &p = ctx->params;
+  int nf = p.image_num_frequencies;
+  ctx->frequencies.assign(nf, 0.0);
+  if (nf == 1) {
+    ctx->frequencies[0] = p.image_frequency;
+    return;
+  }
+  ctx->frequencies[0] = p.image_frequency_start;
+  ctx->frequencies[nf - 1] = p.image_frequency_end;
+  for (int l = 1; l < nf - 1; l++) {
+    double frac = static_cast<double>(l) / static_cast<double>(nf - 1);
+    if (p.image_frequency_spacing == BL_SPACING_LIN_FREQ)
+      ctx->frequencies[l] = p.image_frequency_start + frac * (p.image_frequency_end - p.image_frequency_start);
+    else if (p.image_frequency_spacing == BL_SPACING_LIN_WAVE)
+      ctx->frequencies[l] = 1.0 / (1.0 / p.image_frequency_start
+          + frac * (1.0 / p.image_frequency_end - 1.0 / p.image_frequency_start));
+    else
+      ctx->frequencies[l] = bl_exp(bl_log(p.image_frequency_start) + frac * bl_log(p.image_frequency_end / p.image_frequency_start));
+  }
+}
+
+// RadiationIntegrator::RadiationIntegrator (radiation_integrator.cpp:26-541), hot-path subset
+void ValidateRadiation(bl_ctx *ctx) {
+  bl_params &p = ctx->params;
+  const bool simulation = p.model_type == BL_MODEL_SIMULATION;
+  Require(p, {BL_P_num_threads}, kRadMissing);
+  if (simulation) {
+    Require(p, {BL_P_checkpoint_sample_save, BL_P_checkpoint_sample_load}, kRadMissing);
+    if (p.checkpoint_sample_save && p.checkpoint_sample_load)
+      throw Failure{BL_E_INPUT, "Cannot both save and load a sample checkpoint."};
+    if (p.checkpoint_sample_save || p.checkpoint_sample_load)
+      throw Failure{BL_E_UNSUPPORTED, "Sample checkpoints are outside the scope of the MI355X hot path."};
+    Require(p, {BL_P_simulation_format, BL_P_simulation_coord, BL_P_simulation_m_msun, BL_P_simulation_rho_cgs,
+                BL_P_simulation_interp},
+            kRadMissing);
+    if ((p.simulation_format == BL_SIMFMT_ATHENA || p.simulation_format == BL_SIMFMT_ATHENAK) && p.simulation_interp) {
+      Require(p, {BL_P_simulation_block_interp}, kRadMissing);
+      if (p.simulation_block_interp)
+        throw Failure{BL_E_UNSUPPORTED, "simulation_block_interp = true (inter-block interpolation) is not built yet."};
+    } else if (Has(p, BL_P_simulation_block_interp)) {
+      Warn(ctx, "Ignoring simulation_block_interp selection.");
+    }
+    if (p.simulation_coord == BL_COORD_FMKS)
+      throw Failure{BL_E_UNSUPPORTED, "simulation_coord = fmks is not built yet."};
+  } else {
+    if (Has(p, BL_P_checkpoint_sample_save) && p.checkpoint_sample_save) Warn(ctx, "Ignoring checkpoint_sample_save selection.");
+    if (Has(p, BL_P_checkpoint_sample_load) && p.checkpoint_sample_load) Warn(ctx, "Ignoring checkpoint_sample_load selection.");
+    Require(p, {BL_P_formula_mass, BL_P_formula_r0, BL_P_formula_h, BL_P_formula_l0, BL_P_formula_q, BL_P_formula_nup,
+                BL_P_formula_cn0, BL_P_formula_alpha, BL_P_formula_a, BL_P_formula_beta},
+            kRadMissing);
+  }
+  Require(p, {BL_P_image_light}, kRadMissing);
+  bool polarization = false;
+  if (p.image_light) {
+    if (simulation) {
+      Require(p, {BL_P_image_polarization}, kRadMissing);
+      polarization = p.image_polarization != 0;
+    } else if (Has(p, BL_P_image_polarization) && p.image_polarization) {
+      Warn(ctx, "Ignoring image_polarization selection.");
+    }
+    if (polarization) Require(p, {BL_P_image_rotation_split}, kRadMissing);
+  } else if (Has(p, BL_P_image_polarization) && p.image_polarization) {
+    Warn(ctx, "Ignoring image_polarization selection.");
+  }
+  Require(p, {BL_P_image_time, BL_P_image_length, BL_P_image_lambda, BL_P_image_emission, BL_P_image_tau}, kRadMissing);
+  if (simulation) {
+    Require(p, {BL_P_image_lambda_ave, BL_P_image_emission_ave, BL_P_image_tau_int}, kRadMissing);
+  } else {
+    if (Has(p, BL_P_image_lambda_ave) && p.image_lambda_ave) Warn(ctx, "Ignoring image_lambda_ave selection.");
+    if (Has(p, BL_P_image_emission_ave) && p.image_emission_ave) Warn(ctx, "Ignoring image_emission_ave selection.");
+    if (Has(p, BL_P_image_tau_int) && p.image_tau_int) Warn(ctx, "Ignoring image_tau_int selection.");
+    p.image_lambda_ave = p.image_emission_ave = p.image_tau_int = 0;
+  }
+  Require(p, {BL_P_image_crossings}, kRadMissing);
+  int render_num_images = 0;
+  if (simulation) {
+    Require(p, {BL_P_render_num_images}, kRadMissing);
+    render_num_images = p.render_num_images;
+  } else if (Has(p, BL_P_render_num_images) && p.render_num_images > 0) {
+    Warn(ctx, "Ignoring request for rendering.");
+  }
+  if (!(p.image_light || p.image_time || p.image_length || p.image_lambda || p.image_emission || p.image_tau
+        || p.image_lambda_ave || p.image_emission_ave || p.image_tau_int || p.image_crossings || render_num_images > 0))
+    throw Failure{BL_E_INPUT, "No image or rendering selected."};
+  if (render_num_images > 0)
+    throw Failure{BL_E_UNSUPPORTED, "False-colour rendering (render_num_images > 0) is outside the hot-path scope."};
+  if (polarization)
+    throw Failure{BL_E_UNSUPPORTED, "image_polarization = true (polarized transfer) is not built yet."};
+  if (p.image_time || p.image_length || p.image_lambda || p.image_emission || p.image_tau || p.image_lambda_ave
+      || p.image_emission_ave || p.image_tau_int || p.image_crossings)
+    throw Failure{BL_E_UNSUPPORTED, "Auxiliary images (image_time ... image_crossings) are not built yet; only image_light."};
+  if (simulation) {
+    Require(p, {BL_P_slow_light_on}, kRadMissing);
+    if (p.slow_light_on) throw Failure{BL_E_UNSUPPORTED, "slow_light_on = true is not built yet."};
+  }
+  if (p.adaptive_max_level > 0 && !p.image_light) throw Failure{BL_E_INPUT, "Adaptive ray tracing requires image_light."};
+  if (simulation) {
+    Require(p, {BL_P_plasma_mu, BL_P_plasma_ne_ni, BL_P_plasma_model}, kRadMissing);
+    if (p.plasma_model == BL_PLASMA_TI_TE_BETA)
+      Require(p, {BL_P_plasma_use_p, BL_P_plasma_rat_low, BL_P_plasma_rat_high}, kRadMissing);
+    else
+      throw Failure{BL_E_UNSUPPORTED, "plasma_model = code_kappa is not built yet."};
+    Require(p, {BL_P_plasma_power_frac}, kRadMissing);
+    if (p.plasma_power_frac < 0.0 || p.plasma_power_frac > 1.0) Warn(ctx, "Fraction of power-law electrons outside [0, 1].");
+    Require(p, {BL_P_plasma_kappa_frac}, kRadMissing);
+    if (p.plasma_kappa_frac < 0.0 || p.plasma_kappa_frac > 1.0) Warn(ctx, "Fraction of kappa-distribution electrons outside [0, 1].");
+    if (p.plasma_power_frac != 0.0 || p.plasma_kappa_frac != 0.0)
+      throw Failure{BL_E_UNSUPPORTED, "Non-thermal electrons (plasma_power_frac / plasma_kappa_frac != 0) are not built yet."};
+    ctx->plasma_thermal_frac = 1.0 - (p.plasma_power_frac + p.plasma_kappa_frac);
+    if (ctx->plasma_thermal_frac < 0.0 || ctx->plasma_thermal_frac > 1.0) Warn(ctx, "Fraction of thermal electrons outside [0, 1].");
+    Require(p, {BL_P_cut_rho_min, BL_P_cut_rho_max, BL_P_cut_n_e_min, BL_P_cut_n_e_max, BL_P_cut_p_gas_min,
+                BL_P_cut_p_gas_max, BL_P_cut_theta_e_min, BL_P_cut_theta_e_max, BL_P_cut_b_min, BL_P_cut_b_max,
+                BL_P_cut_sigma_min, BL_P_cut_sigma_max, BL_P_cut_beta_inverse_min, BL_P_cut_beta_inverse_max},
+            kRadMissing);
+  }
+  Require(p, {BL_P_cut_omit_near, BL_P_cut_omit_far, BL_P_cut_omit_in, BL_P_cut_omit_out, BL_P_cut_midplane_theta,
+              BL_P_cut_midplane_z, BL_P_cut_plane},
+          kRadMissing);
+  if (p.cut_plane)
+    Require(p, {BL_P_cut_plane_origin_x, BL_P_cut_plane_origin_y, BL_P_cut_plane_origin_z, BL_P_cut_plane_normal_x,
+                BL_P_cut_plane_normal_y, BL_P_cut_plane_normal_z},
+            kRadMissing);
+  Require(p, {BL_P_fallback_nan}, kRadMissing);
+  if (simulation && !p.fallback_nan) Require(p, {BL_P_fallback_rho, BL_P_fallback_pgas}, kRadMissing);
+
+  // geometry data and image rows (:419-520)
+  ctx->frame.mass_msun = simulation ? p.simulation_m_msun : p.formula_mass * kC * kC / kGGMsun;
+  int n_q = 0;
+  if (p.image_light) n_q += p.image_num_frequencies;
+  (void)kNumCellValues;
+  ctx->image_num_quantities = n_q;
+}
+
+void BuildBuckets(const double *xf, int n, int n_bucket, std::vector<int> *table, double *x0, double *inv_w) {
+  // bucket b covers [x0 + b w, x0 + (b+1) w); table[b] = first cell c with xf[c+1] >= x0 + (b-1) w,
+  // i.e. a start index that is never beyond the reference's linear-scan result for any x whose
+  // bucket index evaluates to b (one bucket of slack covers rounding of the index computation)
+  double lo = xf[0], hi = xf[n];
+  double w = (hi - lo) / n_bucket;
+  *x0 = lo;
+  *inv_w = 1.0 / w;
+  table->resize(n_bucket);
+  int c = 0;
+  for (int b = 0; b < n_bucket; b++) {
+    double edge = lo + (b - 1) * w;
+    while (c < n - 1 && !(xf[c + 1] >= edge)) c++;
+    (*table)[b] = c;
+  }
+}
+
+void EnsureEvents(bl_ctx *ctx) {
+  if (ctx->stream == nullptr) Check(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking), "hipStreamCreate");
+  for (auto &e : ctx->ev)
+    if (e == nullptr) Check(hipEventCreate(&e), "hipEventCreate");
+}
+
+int Fail(bl_ctx *ctx, const Failure &failure) {
+  std::string text = "Error: " + failure.message + "\n";
+  if (ctx != nullptr)
+    ctx->last_error = text;
+  else
+    g_global_error = text;
+  return failure.code;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bl_init(const bl_params *p, int device, bl_ctx **out) {
+  if (p == nullptr || out == nullptr) return BL_E_ARG;
+  *out = nullptr;
+  bl_ctx *ctx = new bl_ctx();
+  ctx->params = *p;
+  try {
+    ValidateGeodesic(ctx);
+    ValidateRadiation(ctx);
+    BuildFrequencies(ctx);
+    bl_camera_frame_build(ctx->params, ctx->st, &ctx->frame);
+    int count = 0;
+    hipError_t err = hipGetDeviceCount(&count);
+    if (err != hipSuccess || count <= 0)
+      throw Failure{BL_E_DEVICE, "No HIP device available: the MI355X hot path has no CPU fallback."};
+    if (device < 0) Check(hipGetDevice(&device), "hipGetDevice");
+    if (device >= count) throw Failure{BL_E_DEVICE, "Requested device index out of range."};
+    Check(hipSetDevice(device), "hipSetDevice");
+    ctx->device = device;
+    hipDeviceProp_t prop;
+    Check(hipGetDeviceProperties(&prop, device), "hipGetDeviceProperties");
+    ctx->num_cus = prop.multiProcessorCount;
+    EnsureEvents(ctx);
+  } catch (const Failure &failure) {
+    int code = Fail(nullptr, failure);
+    delete ctx;
+    return code;
+  }
+  *out = ctx;
+  return BL_OK;
+}
+
+int bl_set_grid(bl_ctx *ctx, const bl_grid_desc *g) {
+  if (ctx == nullptr || g == nullptr) return BL_E_ARG;
+  try {
+    if (ctx->params.model_type != BL_MODEL_SIMULATION) throw Failure{BL_E_STATE, "bl_set_grid called in formula mode."};
+    if (g->n_blocks != 1)
+      throw Failure{BL_E_UNSUPPORTED, "Multi-block (mesh-refined) grids are not built yet; single-block grids only."};
+    if (g->n_i < 2 || g->n_j < 2 || g->n_k < 2 || g->prim == nullptr) throw Failure{BL_E_ARG, "Bad grid description."};
+    Check(hipSetDevice(ctx->device), "hipSetDevice");
+    const int n_i = g->n_i, n_j = g->n_j, n_k = g->n_k;
+    const size_t n_cells = static_cast<size_t>(n_i) * n_j * n_k;
+    // Repack [var][k][j][i] -> [k][j][i][8]: rho, pgas, uu1, uu2, uu3, bb1, bb2, bb3
+    const int order[8] = {g->ind_rho, g->ind_pgas, g->ind_uu1, g->ind_uu2, g->ind_uu3, g->ind_bb1, g->ind_bb2, g->ind_bb3};
+    for (int v : order)
+      if (v < 0 || v >= g->n_var) throw Failure{BL_E_ARG, "Grid variable index out of range."};
+    std::vector<float> cells(n_cells * 8);
+    for (int v = 0; v < 8; v++) {
+      const float *src = g->prim + static_cast<size_t>(order[v]) * n_cells;
+      for (size_t c = 0; c < n_cells; c++) cells[c * 8 + v] = src[c];
+    }
+    ctx->d_cells.Ensure(cells.size());
+    Check(hipMemcpy(ctx->d_cells.ptr, cells.data(), cells.size() * sizeof(float), hipMemcpyHostToDevice), "grid upload");
+    // coordinates
+    const int n[3] = {n_i, n_j, n_k};
+    const double *xf[3] = {g->x1f, g->x2f, g->x3f};
+    const double *xv[3] = {g->x1v, g->x2v, g->x3v};
+    std::vector<double> coords;
+    size_t off_f[3], off_v[3];
+    for (int a = 0; a < 3; a++) {
+      off_f[a] = coords.size();
+      coords.insert(coords.end(), xf[a], xf[a] + n[a] + 1);
+      off_v[a] = coords.size();
+      coords.insert(coords.end(), xv[a], xv[a] + n[a]);
+    }
+    ctx->d_coords.Ensure(coords.size());
+    Check(hipMemcpy(ctx->d_coords.ptr, coords.data(), coords.size() * sizeof(double), hipMemcpyHostToDevice), "coordinate upload");
+    // bucket tables for the cell search
+    std::vector<int> buckets;
+    size_t off_b[3];
+    BlGridDevice dev{};
+    for (int a = 0; a < 3; a++) {
+      int n_bucket = std::max(1024, 16 * n[a]);
+      std::vector<int> table;
+      BuildBuckets(xf[a], n[a], n_bucket, &table, &dev.bucket_x0[a], &dev.bucket_inv_w[a]);
+      dev.n_bucket[a] = n_bucket;
+      off_b[a] = buckets.size();
+      buckets.insert(buckets.end(), table.begin(), table.end());
+    }
+    ctx->d_buckets.Ensure(buckets.size());
+    Check(hipMemcpy(ctx->d_buckets.ptr, buckets.data(), buckets.size() * sizeof(int), hipMemcpyHostToDevice), "bucket upload");
+    dev.cells = ctx->d_cells.ptr;
+    for (int a = 0; a < 3; a++) {
+      dev.xf[a] = ctx->d_coords.ptr + off_f[a];
+      dev.xv[a] = ctx->d_coords.ptr + off_v[a];
+      dev.bucket[a] = ctx->d_buckets.ptr + off_b[a];
+      dev.n[a] = n[a];
+    }
+    ctx->grid_dev = dev;
+    ctx->grid_meta = *g;
+    ctx->n_i = n_i;
+    ctx->n_j = n_j;
+    ctx->n_k = n_k;
+    ctx->have_grid = true;
+  } catch (const Failure &failure) {
+    return Fail(ctx, failure);
+  }
+  return BL_OK;
+}
+
+int bl_image_num_quantities(const bl_ctx *ctx) { return ctx != nullptr ? ctx->image_num_quantities : -1; }
+
+int bl_camera_frame_get(const bl_ctx *ctx, bl_camera_frame *out) {
+  if (ctx == nullptr || out == nullptr) return BL_E_ARG;
+  *out = ctx->frame;
+  return BL_OK;
+}
+
+int bl_frequencies(const bl_ctx *ctx, double *out, int n) {
+  if (ctx == nullptr || out == nullptr) return BL_E_ARG;
+  for (int l = 0; l < n && l < static_cast<int>(ctx->frequencies.size()); l++) out[l] = ctx->frequencies[l];
+  return BL_OK;
+}
+
+int bl_set_scratch_limit(bl_ctx *ctx, uint64_t bytes) {
+  if (ctx == nullptr || bytes < (1ull << 20)) return BL_E_ARG;
+  ctx->scratch_limit = bytes;
+  return BL_OK;
+}
+
+int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
+  if (ctx == nullptr || d == nullptr) return BL_E_ARG;
+  try {
+    const bl_params &p = ctx->params;
+    const bool simulation = p.model_type == BL_MODEL_SIMULATION;
+    if (simulation && !ctx->have_grid) throw Failure{BL_E_STATE, "bl_render called before bl_set_grid."};
+    if (d->n_rays <= 0 || d->image == nullptr) throw Failure{BL_E_ARG, "bl_render needs n_rays > 0 and an image buffer."};
+    if (d->n_rays > 0x7fffffffll) throw Failure{BL_E_ARG, "Too many rays in one bl_render call."};
+    if (d->level < 0 || d->level > p.adaptive_max_level) throw Failure{BL_E_ARG, "Adaptive level out of range."};
+    if (d->level > 0 && (d->block_locs == nullptr || d->n_blocks <= 0)) throw Failure{BL_E_ARG, "Refined level needs block_locs."};
+    Check(hipSetDevice(ctx->device), "hipSetDevice");
+    EnsureEvents(ctx);
+    hipStream_t stream = ctx->stream;
+    const int n_nu = p.image_num_frequencies;
+    const int n_q = ctx->image_num_quantities;
+    const int max_steps = p.ray_max_steps;
+    const long long n_rays = d->n_rays;
+
+    // level pixel count check
+    long long level_pixels = static_cast<long long>(p.camera_resolution) * p.camera_resolution;
+    if (d->level > 0) level_pixels = static_cast<long long>(d->n_blocks) * p.adaptive_block_size * p.adaptive_block_size;
+    if (d->pixel_map == nullptr && n_rays > level_pixels) throw Failure{BL_E_ARG, "n_rays exceeds the pixels of this level."};
+
+    // chunk size from the scratch budget: per ray max_steps * (64 B record + 16 B * n_nu transfer)
+    const uint64_t per_ray = static_cast<uint64_t>(max_steps) * (sizeof(BlSampleRecord) + sizeof(double2) * n_nu) + 64;
+    long long chunk = static_cast<long long>(ctx->scratch_limit / per_ray);
+    chunk = std::max<long long>(chunk, 64);
+    chunk = std::min<long long>(chunk, n_rays);
+    if (chunk < n_rays) chunk = (chunk / 64) * 64;   // keep 8x8 tiles whole
+    const int n_chunks = static_cast<int>((n_rays + chunk - 1) / chunk);
+
+    ctx->d_records.Ensure(static_cast<size_t>(chunk) * max_steps);
+    ctx->d_transfer.Ensure(static_cast<size_t>(chunk) * max_steps * n_nu);
+    ctx->d_ray_kt.Ensure(chunk);
+    ctx->d_ray_factor.Ensure(chunk);
+    ctx->d_ray_sample_num.Ensure(chunk);
+    ctx->d_ray_flags.Ensure(chunk);
+    ctx->d_ray_out_index.Ensure(chunk);
+    ctx->d_counters.Ensure(BL_CNT_COUNT + 4);
+    ctx->d_freq.Ensure(n_nu);
+    Check(hipMemcpyAsync(ctx->d_freq.ptr, ctx->frequencies.data(), n_nu * sizeof(double), hipMemcpyHostToDevice, stream), "freq upload");
+
+    const int *d_pixel_map = nullptr, *d_block_locs = nullptr;
+    if (d->pixel_map != nullptr) {
+      ctx->d_pixel_map.Ensure(n_rays);
+      Check(hipMemcpyAsync(ctx->d_pixel_map.ptr, d->pixel_map, n_rays * sizeof(int), hipMemcpyHostToDevice, stream), "pixel_map upload");
+      d_pixel_map = ctx->d_pixel_map.ptr;
+    }
+    if (d->level > 0) {
+      ctx->d_block_locs.Ensure(static_cast<size_t>(d->n_blocks) * 2);
+      Check(hipMemcpyAsync(ctx->d_block_locs.ptr, d->block_locs, static_cast<size_t>(d->n_blocks) * 2 * sizeof(int), hipMemcpyHostToDevice, stream), "block_locs upload");
+      d_block_locs = ctx->d_block_locs.ptr;
+    }
+
+    // output buffers: caller's HBM, or staging
+    double *image = d->image, *cam_pos = d->camera_pos, *cam_dir = d->camera_dir;
+    int *out_num = d->sample_num;
+    unsigned char *out_flags = d->sample_flags;
+    if (!d->outputs_on_device) {
+      ctx->d_image.Ensure(static_cast<size_t>(n_q) * n_rays);
+      image = ctx->d_image.ptr;
+      if (d->sample_num != nullptr) { ctx->d_out_sample_num.Ensure(n_rays); out_num = ctx->d_out_sample_num.ptr; }
+      if (d->sample_flags != nullptr) { ctx->d_out_flags.Ensure(n_rays); out_flags = ctx->d_out_flags.ptr; }
+      if (d->camera_pos != nullptr) { ctx->d_camera_pos.Ensure(static_cast<size_t>(n_rays) * 4); cam_pos = ctx->d_camera_pos.ptr; }
+      if (d->camera_dir != nullptr) { ctx->d_camera_dir.Ensure(static_cast<size_t>(n_rays) * 4); cam_dir = ctx->d_camera_dir.ptr; }
+    }
+
+    // ---- kernel arguments common to all chunks
+    BlTraceArgs ta{};
+    ta.st = ctx->st;
+    BlCameraDevice &cam = ta.cam;
+    for (int mu = 0; mu < 4; mu++) {
+      cam.cam_x[mu] = ctx->frame.cam_x[mu];
+      cam.u_con[mu] = ctx->frame.u_con[mu];
+      cam.u_cov[mu] = ctx->frame.u_cov[mu];
+      cam.norm_con[mu] = ctx->frame.norm_con[mu];
+      cam.norm_con_c[mu] = ctx->frame.norm_con_c[mu];
+      cam.hor_con_c[mu] = ctx->frame.hor_con_c[mu];
+      cam.vert_con_c[mu] = ctx->frame.vert_con_c[mu];
+    }
+    cam.camera_width = p.camera_width;
+    cam.camera_r = p.camera_r;
+    cam.camera_type = p.camera_type;
+    cam.image_normalization = p.image_normalization;
+    cam.camera_resolution = p.camera_resolution;
+    cam.level = d->level;
+    cam.block_size = p.adaptive_max_level > 0 ? p.adaptive_block_size : 1;
+    cam.effective_resolution = p.camera_resolution;
+    for (int l = 1; l <= d->level; l++) cam.effective_resolution *= 2;
+    ta.r_terminate = ctx->frame.r_terminate;
+    ta.r_horizon = ctx->frame.r_horizon;
+    ta.camera_r = p.camera_r;
+    ta.ray_step = p.ray_step;
+    ta.ray_tol_abs = p.ray_integrator == BL_INTEGRATOR_DP ? p.ray_tol_abs : 0.0;
+    ta.ray_tol_rel = p.ray_integrator == BL_INTEGRATOR_DP ? p.ray_tol_rel : 0.0;
+    ta.ray_max_steps = max_steps;
+    ta.ray_max_retries = p.ray_integrator == BL_INTEGRATOR_DP ? p.ray_max_retries : 0;
+    ta.n_rays_total = n_rays;
+    ta.swizzle_tiles = (d->level == 0 && d->pixel_map == nullptr && p.camera_resolution % 8 == 0 && n_rays == level_pixels)
+        ? p.camera_resolution : 0;
+    ta.pixel_map = d_pixel_map;
+    ta.block_locs = d_block_locs;
+    ta.records = ctx->d_records.ptr;
+    ta.record_capacity = static_cast<long long>(chunk) * max_steps;
+    ta.counters = ctx->d_counters.ptr;
+    ta.ray_kt = ctx->d_ray_kt.ptr;
+    ta.ray_factor = ctx->d_ray_factor.ptr;
+    ta.ray_sample_num = ctx->d_ray_sample_num.ptr;
+    ta.ray_flags = ctx->d_ray_flags.ptr;
+    ta.ray_out_index = ctx->d_ray_out_index.ptr;
+    ta.camera_pos = cam_pos;
+    ta.camera_dir = cam_dir;
+
+    BlShadeArgs sa{};
+    sa.st = ctx->st;
+    sa.cuts.omit_near = p.cut_omit_near;
+    sa.cuts.omit_far = p.cut_omit_far;
+    sa.cuts.plane = p.cut_plane;
+    sa.cuts.omit_in = p.cut_omit_in;
+    sa.cuts.omit_out = p.cut_omit_out;
+    sa.cuts.midplane_theta = p.cut_midplane_theta;
+    sa.cuts.midplane_z = p.cut_midplane_z;
+    sa.cuts.plane_origin[0] = p.cut_plane_origin_x;
+    sa.cuts.plane_origin[1] = p.cut_plane_origin_y;
+    sa.cuts.plane_origin[2] = p.cut_plane_origin_z;
+    sa.cuts.plane_normal[0] = p.cut_plane_normal_x;
+    sa.cuts.plane_normal[1] = p.cut_plane_normal_y;
+    sa.cuts.plane_normal[2] = p.cut_plane_normal_z;
+    sa.cuts.camera_r = p.camera_r;
+    for (int mu = 0; mu < 4; mu++) sa.cuts.cam_x[mu] = ctx->frame.cam_x[mu];
+    if (simulation) {
+      BlPlasmaDevice &pl = sa.plasma;
+      pl.d_unit = p.simulation_rho_cgs;                       // simulation_coefficients.cpp:237-239
+      pl.e_unit = pl.d_unit * kC * kC;
+      pl.b_unit = blm_sqrt(4.0 * kPi * pl.e_unit);
+      pl.plasma_mu = p.plasma_mu;
+      pl.plasma_ne_ni = p.plasma_ne_ni;
+      pl.plasma_rat_low = p.plasma_rat_low;
+      pl.plasma_rat_high = p.plasma_rat_high;
+      pl.plasma_thermal_frac = ctx->plasma_thermal_frac;
+      pl.plasma_gamma = ctx->grid_meta.plasma_gamma;
+      pl.plasma_gamma_i = ctx->grid_meta.plasma_gamma_i;
+      pl.plasma_gamma_e = ctx->grid_meta.plasma_gamma_e;
+      pl.plasma_use_p = p.plasma_use_p;
+      pl.simulation_interp = p.simulation_interp;
+      pl.simulation_coord = p.simulation_coord;
+      pl.fallback_nan = p.fallback_nan;
+      pl.fallback_rho = p.fallback_nan ? 0.0f : p.fallback_rho;
+      pl.fallback_pgas = p.fallback_nan ? 0.0f : p.fallback_pgas;
+      pl.cut_rho_min = p.cut_rho_min; pl.cut_rho_max = p.cut_rho_max;
+      pl.cut_n_e_min = p.cut_n_e_min; pl.cut_n_e_max = p.cut_n_e_max;
+      pl.cut_p_gas_min = p.cut_p_gas_min; pl.cut_p_gas_max = p.cut_p_gas_max;
+      pl.cut_theta_e_min = p.cut_theta_e_min; pl.cut_theta_e_max = p.cut_theta_e_max;
+      pl.cut_b_min = p.cut_b_min; pl.cut_b_max = p.cut_b_max;
+      pl.cut_sigma_min = p.cut_sigma_min; pl.cut_sigma_max = p.cut_sigma_max;
+      pl.cut_beta_inverse_min = p.cut_beta_inverse_min; pl.cut_beta_inverse_max = p.cut_beta_inverse_max;
+      sa.grid = ctx->grid_dev;
+    } else {
+      BlFormulaDevice &fm = sa.formula;
+      fm.r0 = p.formula_r0; fm.h = p.formula_h; fm.l0 = p.formula_l0; fm.q = p.formula_q; fm.nup = p.formula_nup;
+      fm.cn0 = p.formula_cn0; fm.alpha = p.formula_alpha; fm.a = p.formula_a; fm.beta = p.formula_beta;
+    }
+    sa.records = ctx->d_records.ptr;
+    sa.counters_in = ctx->d_counters.ptr;
+    sa.counters = ctx->d_counters.ptr;
+    sa.ray_kt = ctx->d_ray_kt.ptr;
+    sa.ray_factor = ctx->d_ray_factor.ptr;
+    sa.frequencies = ctx->d_freq.ptr;
+    sa.n_nu = n_nu;
+    sa.ray_max_steps = max_steps;
+    sa.x_unit = kGGMsun * ctx->frame.mass_msun / (kC * kC);   // unpolarized.cpp:42
+    sa.transfer = ctx->d_transfer.ptr;
+
+    BlTransferArgs xa{};
+    xa.transfer = ctx->d_transfer.ptr;
+    xa.ray_sample_num = ctx->d_ray_sample_num.ptr;
+    xa.ray_flags = ctx->d_ray_flags.ptr;
+    xa.ray_out_index = ctx->d_ray_out_index.ptr;
+    xa.frequencies = ctx->d_freq.ptr;
+    xa.n_nu = n_nu;
+    xa.ray_max_steps = max_steps;
+    xa.fallback_nan = p.fallback_nan;
+    xa.model_type = p.model_type;
+    xa.n_rays_total = n_rays;
+    xa.image = image;
+    xa.out_sample_num = out_num;
+    xa.out_flags = out_flags;
+    xa.stats = ctx->d_counters.ptr + BL_CNT_COUNT;
+
+    const int geo_blocks_per_cu = bl_geodesic_occupancy(p.ray_integrator);
+    const int geo_grid = ctx->num_cus * geo_blocks_per_cu;
+    const int shade_grid = ctx->num_cus * 8;
+
+    bl_stats st{};
+    st.n_rays = n_rays;
+    st.n_chunks = n_chunks;
+    float ms_geo = 0.0f, ms_shade = 0.0f, ms_transfer = 0.0f;
+    std::vector<unsigned long long> host_counters(BL_CNT_COUNT + 4);
+    unsigned long long total_samples = 0, total_flagged = 0, total_records = 0, total_gathers = 0, max_num = 0;
+
+    for (int c = 0; c < n_chunks; c++) {
+      const long long begin = static_cast<long long>(c) * chunk;
+      const int rays = static_cast<int>(std::min<long long>(chunk, n_rays - begin));
+      Check(hipMemsetAsync(ctx->d_counters.ptr, 0, (BL_CNT_COUNT + 4) * sizeof(unsigned long long), stream), "counter reset");
+      ta.chunk_begin = begin;
+      ta.chunk_rays = rays;
+      xa.chunk_rays = rays;
+      Check(hipEventRecord(ctx->ev[0], stream), "event");
+      Check(bl_launch_geodesic(&ta, p.ray_integrator, std::min(geo_grid, (rays + 63) / 64), stream), "geodesic kernel launch");
+      Check(hipEventRecord(ctx->ev[1], stream), "event");
+      Check(bl_launch_shade(&sa, p.model_type, shade_grid, stream), "shade kernel launch");
+      Check(hipEventRecord(ctx->ev[2], stream), "event");
+      Check(bl_launch_transfer(&xa, stream), "transfer kernel launch");
+      Check(hipEventRecord(ctx->ev[3], stream), "event");
+      Check(hipMemcpyAsync(host_counters.data(), ctx->d_counters.ptr, host_counters.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream), "counter download");
+      Check(hipStreamSynchronize(stream), "kernel execution");
+      float ms = 0.0f;
+      Check(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]), "event time"); ms_geo += ms;
+      Check(hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]), "event time"); ms_shade += ms;
+      Check(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]), "event time"); ms_transfer += ms;
+      if (host_counters[BL_CNT_OVERFLOW] != 0) throw Failure{BL_E_DEVICE, "Sample record buffer overflow."};
+      total_records += host_counters[BL_CNT_RECORDS];
+      total_gathers += host_counters[BL_CNT_GATHERS];
+      total_samples += host_counters[BL_CNT_COUNT + 0];
+      total_flagged += host_counters[BL_CNT_COUNT + 1];
+      max_num = std::max(max_num, host_counters[BL_CNT_COUNT + 2]);
+      st.launches_geodesic++;
+      st.launches_shade++;
+      st.launches_transfer++;
+    }
+
+    if (!d->outputs_on_device) {
+      Check(hipMemcpy(d->image, image, static_cast<size_t>(n_q) * n_rays * sizeof(double), hipMemcpyDeviceToHost), "image download");
+      if (d->sample_num != nullptr) Check(hipMemcpy(d->sample_num, out_num, n_rays * sizeof(int), hipMemcpyDeviceToHost), "sample_num download");
+      if (d->sample_flags != nullptr) Check(hipMemcpy(d->sample_flags, out_flags, n_rays, hipMemcpyDeviceToHost), "flags download");
+      if (d->camera_pos != nullptr) Check(hipMemcpy(d->camera_pos, cam_pos, static_cast<size_t>(n_rays) * 32, hipMemcpyDeviceToHost), "camera_pos download");
+      if (d->camera_dir != nullptr) Check(hipMemcpy(d->camera_dir, cam_dir, static_cast<size_t>(n_rays) * 32, hipMemcpyDeviceToHost), "camera_dir download");
+    }
+
+    st.n_samples = static_cast<int64_t>(total_samples);
+    st.n_samples_emitted = static_cast<int64_t>(total_records);
+    st.n_gathers = static_cast<int64_t>(total_gathers);
+    st.n_flagged = static_cast<int64_t>(total_flagged);
+    st.max_sample_num = static_cast<int32_t>(max_num);
+    const double bytes_per_gather = (simulation && !p.simulation_interp) ? 32.0 : 256.0;
+    st.algorithmic_bytes = bytes_per_gather * static_cast<double>(total_gathers) + 13.0 * static_cast<double>(n_rays);
+    st.ms_geodesic = ms_geo;
+    st.ms_shade = ms_shade;
+    st.ms_transfer = ms_transfer;
+    st.ms_total = ms_geo + ms_shade + ms_transfer;
+    ctx->stats = st;
+    // Warning text of the reference (geodesics.cpp:389-394)
+    if (total_flagged > 0)
+      Warn(ctx, std::to_string(total_flagged) + " out of " + std::to_string(n_rays) + " geodesics terminate unexpectedly.");
+  } catch (const Failure &failure) {
+    return Fail(ctx, failure);
+  }
+  return BL_OK;
+}
+
+int bl_get_stats(const bl_ctx *ctx, bl_stats *out) {
+  if (ctx == nullptr || out == nullptr) return BL_E_ARG;
+  *out = ctx->stats;
+  return BL_OK;
+}
+
+const char *bl_last_error(const bl_ctx *ctx) { return ctx != nullptr ? ctx->last_error.c_str() : ""; }
+const char *bl_last_global_error(void) { return g_global_error.c_str(); }
+const char *bl_warnings(const bl_ctx *ctx) { return ctx != nullptr ? ctx->warnings.c_str() : ""; }
+
+void bl_free(bl_ctx *ctx) {
+  if (ctx == nullptr) return;
+  (void)hipSetDevice(ctx->device);
+  ctx->d_cells.Free(); ctx->d_coords.Free(); ctx->d_buckets.Free(); ctx->d_records.Free(); ctx->d_transfer.Free();
+  ctx->d_ray_kt.Free(); ctx->d_ray_factor.Free(); ctx->d_freq.Free(); ctx->d_ray_sample_num.Free();
+  ctx->d_ray_flags.Free(); ctx->d_ray_out_index.Free(); ctx->d_counters.Free(); ctx->d_pixel_map.Free();
+  ctx->d_block_locs.Free(); ctx->d_image.Free(); ctx->d_camera_pos.Free(); ctx->d_camera_dir.Free();
+  ctx->d_out_sample_num.Free(); ctx->d_out_flags.Free();
+  for (auto &e : ctx->ev)
+    if (e != nullptr) (void)hipEventDestroy(e);
+  if (ctx->stream != nullptr) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char *bl_build_info(void) { return "blacklight_amd;hip;gfx950;fp-contract=off"; }
+
+}  // extern "C"

@@ -1,0 +1,143 @@
+// bl_device.h - data layout shared by the HIP kernels (bl_kernels.hip) and their host driver
+// (bl_api.hip).
+//
+// HBM layout of one render chunk (all sizes for C rays, ray_max_steps = S, n_nu frequencies):
+//
+//   grid cells    float  [n_k][n_j][n_i][8]      32 B per cell: rho, pgas, uu1, uu2, uu3, bb1, bb2,
+//                                                bb3 interleaved, i fastest, so the 8 corners of a
+//                                                trilinear fetch are four 64-B segments
+//   face / centre double x{1,2,3}f[n+1], x{1,2,3}v[n]  + per-axis bucket tables for the cell search
+//   records       BlSampleRecord [<= C*S]        64 B per emitted sample, written by the geodesic
+//                                                kernel in wave-contiguous runs, read once by the
+//                                                shading kernel (coalesced 4 KiB per wave)
+//   transfer      double2 [C][S][n_nu]           (a, b) of the per-sample affine update
+//                                                I <- a * (I + b), written by the shading kernel,
+//                                                replayed far -> near by the transfer kernel
+//   per ray       k_t, 1/nu_local, sample_num, flags, output index
+#ifndef BLACKLIGHT_AMD_BL_DEVICE_H_
+#define BLACKLIGHT_AMD_BL_DEVICE_H_
+
+#include <stdint.h>
+
+#include "bl_camera.h"
+#include "bl_geometry.h"
+
+// One emitted geodesic sample (geodesic_pos/dir/len entries of the reference,
+// geodesics.cpp:250-293), before the per-sample momentum renormalisation of :352-371.
+struct alignas(16) BlSampleRecord {
+  double x, y, z;     // position (CKS)
+  double kx, ky, kz;  // covariant spatial momentum, not yet renormalised
+  double len;         // affine step length as stored by the integrator (negative: camera -> source)
+  uint32_t ray;       // chunk-local ray slot, 0xFFFFFFFF = dead slot (sample dropped by truncation)
+  uint32_t n;         // sample index along the ray in integration order
+};
+static_assert(sizeof(BlSampleRecord) == 64, "record must be 64 bytes");
+
+#define BL_DEAD_RAY 0xFFFFFFFFu
+// Marker for "optically thick: I <- b" in the transfer record (exp(-dtau) is never negative)
+#define BL_THICK_MARK (-1.0)
+
+enum BlCounter {
+  BL_CNT_NEXT_RAY = 0,      // work queue head of the geodesic kernel
+  BL_CNT_RECORDS = 1,       // sample records allocated
+  BL_CNT_GATHERS = 2,       // samples that read the grid (S_in)
+  BL_CNT_OVERFLOW = 3,      // record buffer overflow flag
+  BL_CNT_COUNT = 8
+};
+
+struct BlGridDevice {
+  const float *cells;        // [n_k][n_j][n_i][8]
+  const double *xf[3];       // faces  (r, theta, phi)
+  const double *xv[3];       // centres
+  const int *bucket[3];      // bucket -> first candidate cell
+  double bucket_x0[3], bucket_inv_w[3];
+  int n_bucket[3];
+  int n[3];                  // n_i, n_j, n_k
+};
+
+struct BlPlasmaDevice {
+  // units (simulation_coefficients.cpp:237-239)
+  double d_unit, e_unit, b_unit;
+  double plasma_mu, plasma_ne_ni, plasma_rat_low, plasma_rat_high, plasma_thermal_frac;
+  double plasma_gamma, plasma_gamma_i, plasma_gamma_e;
+  int plasma_use_p;
+  int simulation_interp;
+  int simulation_coord;
+  int fallback_nan;
+  float fallback_rho, fallback_pgas;
+  // cell cuts (:361-375); negative = disabled
+  double cut_rho_min, cut_rho_max, cut_n_e_min, cut_n_e_max, cut_p_gas_min, cut_p_gas_max;
+  double cut_theta_e_min, cut_theta_e_max, cut_b_min, cut_b_max, cut_sigma_min, cut_sigma_max;
+  double cut_beta_inverse_min, cut_beta_inverse_max;
+};
+
+struct BlFormulaDevice {
+  double r0, h, l0, q, nup, cn0, alpha, a, beta;
+};
+
+struct BlCutsDevice {
+  int omit_near, omit_far, plane;
+  double omit_in, omit_out, midplane_theta, midplane_z;
+  double plane_origin[3], plane_normal[3];
+  double camera_r;
+  double cam_x[4];
+};
+
+// Kernel arguments: geodesic kernel
+struct BlTraceArgs {
+  BlSpacetime st;
+  BlCameraDevice cam;
+  double r_terminate, r_horizon, camera_r;
+  double ray_step, ray_tol_abs, ray_tol_rel;
+  int ray_max_steps, ray_max_retries;
+  long long chunk_begin;      // first traversal index of this chunk
+  int chunk_rays;
+  long long n_rays_total;
+  int swizzle_tiles;          // >0: traversal order walks 8x8 pixel tiles of a swizzle_tiles-wide image
+  const int *pixel_map;       // device, or null
+  const int *block_locs;      // device, or null
+  BlSampleRecord *records;
+  long long record_capacity;
+  unsigned long long *counters;
+  double *ray_kt, *ray_factor;
+  int *ray_sample_num;
+  unsigned char *ray_flags;
+  long long *ray_out_index;
+  double *camera_pos, *camera_dir;  // optional [n_rays][4] indexed by output index
+};
+
+// Kernel arguments: shading kernel
+struct BlShadeArgs {
+  BlSpacetime st;
+  BlCutsDevice cuts;
+  BlPlasmaDevice plasma;
+  BlFormulaDevice formula;
+  BlGridDevice grid;
+  const BlSampleRecord *records;
+  const unsigned long long *counters_in;
+  unsigned long long *counters;
+  const double *ray_kt, *ray_factor;
+  const double *frequencies;  // device [n_nu]
+  int n_nu;
+  int ray_max_steps;
+  double x_unit;              // GM/c^2 in cm (unpolarized.cpp:42)
+  double2 *transfer;          // [chunk_rays][ray_max_steps][n_nu]
+};
+
+// Kernel arguments: transfer kernel
+struct BlTransferArgs {
+  const double2 *transfer;
+  const int *ray_sample_num;
+  const unsigned char *ray_flags;
+  const long long *ray_out_index;
+  const double *frequencies;
+  int n_nu, ray_max_steps, chunk_rays;
+  int fallback_nan, model_type;
+  long long n_rays_total;
+  double *image;              // [n_q][n_rays_total]; rows 0..n_nu-1 = I_nu
+  int *out_sample_num;        // [n_rays_total] or null
+  unsigned char *out_flags;   // [n_rays_total] or null
+  unsigned long long *stats;  // [0] sum sample_num, [1] flagged rays, [2] max sample_num
+};
+
+#endif  // BLACKLIGHT_AMD_BL_DEVICE_H_

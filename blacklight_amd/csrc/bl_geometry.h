@@ -1,0 +1,242 @@
+// bl_geometry.h - Kerr geometry in Cartesian Kerr-Schild coordinates for host and gfx950 device.
+//
+// Arithmetic contract: every value produced here is bit-identical to what the reference computes
+// in src/geodesic_integrator/geodesic_geometry.cpp (and its duplicate in
+// src/radiation_integrator/radiation_geometry.cpp) when both use the same hypot. The reference
+// evaluates the same scalars (r, f, l_i) three times per right-hand side (once each in
+// Covariant/Contravariant/...Derivative); here they are evaluated once and the 16 + 16 + 48 tensor
+// components are never materialised. That is exact, not approximate, because
+//   * identical operations on identical inputs give identical bits (common subexpressions),
+//   * multiplying by l_0 = +-1 and negating are exact, fl(-a - b) = -fl(a + b),
+//   * terms with the vanishing derivative d(l_0) = 0 contribute +-0, and x + (+-0) = x for x != 0
+//     (the reference itself is built with -fno-signed-zeros).
+// Everything else keeps the reference's operand order, e.g. g_ij = (f*l_i)*l_j is NOT symmetrised.
+// The translation unit must be compiled with -ffp-contract=off.
+#ifndef BLACKLIGHT_AMD_BL_GEOMETRY_H_
+#define BLACKLIGHT_AMD_BL_GEOMETRY_H_
+
+#include "blmath.h"
+
+#if defined(__HIPCC__) || defined(__HIP__)
+#define BL_HD __host__ __device__ __forceinline__
+#else
+#define BL_HD inline
+#endif
+
+struct BlSpacetime {
+  double bh_m;
+  double bh_a;
+  int ray_flat;
+};
+
+// Scalars shared by all metric functions (geodesic_geometry.cpp:63-73, :131-141, :187-197)
+struct BlKerrSchild {
+  double r2, r, f;
+  double l[3];    // l_1, l_2, l_3 (same for the covariant and contravariant null vector)
+  double fl[3];   // f * l_i
+  double a2, rr2;
+};
+
+// geodesic_geometry.cpp:19-26
+BL_HD double bl_radial_coordinate(const BlSpacetime &st, double x, double y, double z) {
+  double a2 = st.bh_a * st.bh_a;
+  double rr2 = x * x + y * y + z * z;
+  double r2 = 0.5 * (rr2 - a2 + bl_hypot(rr2 - a2, 2.0 * st.bh_a * z));
+  return blm_sqrt(r2);
+}
+
+BL_HD void bl_kerr_schild(const BlSpacetime &st, double x, double y, double z, BlKerrSchild *ks) {
+  double bh_a = st.bh_a;
+  double a2 = bh_a * bh_a;
+  double rr2 = x * x + y * y + z * z;
+  double r2 = 0.5 * (rr2 - a2 + bl_hypot(rr2 - a2, 2.0 * bh_a * z));
+  double r = blm_sqrt(r2);
+  double f = 2.0 * st.bh_m * r2 * r / (r2 * r2 + a2 * z * z);
+  ks->a2 = a2;
+  ks->rr2 = rr2;
+  ks->r2 = r2;
+  ks->r = r;
+  ks->f = f;
+  ks->l[0] = (r * x + bh_a * y) / (r2 + a2);
+  ks->l[1] = (r * y - bh_a * x) / (r2 + a2);
+  ks->l[2] = z / r;
+  for (int i = 0; i < 3; i++) ks->fl[i] = f * ks->l[i];
+}
+
+// Full covariant metric g_{mu nu} (geodesic_geometry.cpp:38-93). Used by the camera set-up and
+// by the coefficient kernels where all 16 components are contracted.
+BL_HD void bl_gcov(const BlSpacetime &st, double x, double y, double z, double g[4][4]) {
+  if (st.ray_flat) {
+    for (int mu = 0; mu < 4; mu++)
+      for (int nu = 0; nu < 4; nu++) g[mu][nu] = mu == nu ? (mu == 0 ? -1.0 : 1.0) : 0.0;
+    return;
+  }
+  BlKerrSchild ks;
+  bl_kerr_schild(st, x, y, z, &ks);
+  g[0][0] = ks.f - 1.0;                       // f * l_0 * l_0 - 1, l_0 = 1
+  for (int i = 0; i < 3; i++) {
+    g[0][i + 1] = ks.fl[i];                   // f * l_0 * l_i
+    g[i + 1][0] = ks.fl[i];                   // f * l_i * l_0
+    for (int j = 0; j < 3; j++) g[i + 1][j + 1] = ks.fl[i] * ks.l[j];
+    g[i + 1][i + 1] = ks.fl[i] * ks.l[i] + 1.0;
+  }
+}
+
+// Full contravariant metric g^{mu nu} (geodesic_geometry.cpp:105-161), l^0 = -1
+BL_HD void bl_gcon(const BlSpacetime &st, double x, double y, double z, double g[4][4]) {
+  if (st.ray_flat) {
+    for (int mu = 0; mu < 4; mu++)
+      for (int nu = 0; nu < 4; nu++) g[mu][nu] = mu == nu ? (mu == 0 ? -1.0 : 1.0) : 0.0;
+    return;
+  }
+  BlKerrSchild ks;
+  bl_kerr_schild(st, x, y, z, &ks);
+  g[0][0] = -ks.f - 1.0;                      // -f * l0 * l0 - 1
+  for (int i = 0; i < 3; i++) {
+    g[0][i + 1] = ks.fl[i];                   // -f * l0 * l_i = f * l_i
+    g[i + 1][0] = ks.fl[i];                   // -f * l_i * l0
+    for (int j = 0; j < 3; j++) g[i + 1][j + 1] = -(ks.fl[i] * ks.l[j]);
+    g[i + 1][i + 1] = -(ks.fl[i] * ks.l[i]) + 1.0;
+  }
+}
+
+// Null-condition renormalisation factor for the spatial covariant momentum
+// (geodesics.cpp:296-309 and :352-371): solves g^{mu nu} k_mu k_nu = 0 for a common factor on k_i.
+BL_HD double bl_renormalization_factor(const BlSpacetime &st, double x, double y, double z,
+                                       double k0, double k1, double k2, double k3) {
+  double gcon[4][4];
+  bl_gcon(st, x, y, z, gcon);
+  double k[4] = {k0, k1, k2, k3};
+  double temp_a = 0.0;
+  for (int a = 1; a < 4; a++)
+    for (int b = 1; b < 4; b++) temp_a += gcon[a][b] * k[a] * k[b];
+  double temp_b = 0.0;
+  for (int a = 1; a < 4; a++) temp_b += 2.0 * gcon[0][a] * k[0] * k[a];
+  double temp_c = gcon[0][0] * k[0] * k[0];
+  double temp_d = blm_sqrt(temp_b * temp_b - 4.0 * temp_a * temp_c);
+  return temp_b < 0.0 ? (temp_d - temp_b) / (2.0 * temp_a) : -2.0 * temp_c / (temp_b + temp_d);
+}
+
+// Right-hand side of the geodesic equations (geodesics.cpp:867-893 with distance, :909-925
+// without). State: pos = (x, y, z); kcov = (k_t, k_x, k_y, k_z).
+//   dpos[0..3] = d(t, x, y, z)/d lambda = g^{mu nu} k_nu
+//   dk[0..2]   = d(k_x, k_y, k_z)/d lambda = -1/2 d_i g^{mu nu} k_mu k_nu      (d k_t = 0)
+//   *ds        = d s / d lambda (proper distance), only if kWithDistance
+// Returns r at the evaluation point through *r_out.
+template <bool kWithDistance>
+BL_HD void bl_geodesic_rhs(const BlSpacetime &st, const double pos[3], const double kcov[4],
+                           double dpos[4], double dk[3], double *ds, double *r_out) {
+  if (st.ray_flat) {
+    // Minkowski: g = diag(-1,1,1,1), all derivatives zero (geodesic_geometry.cpp:41-60, :177-184)
+    dpos[0] = -kcov[0];
+    for (int i = 0; i < 3; i++) dpos[i + 1] = kcov[i + 1];
+    // k[4+a] = 0 - 0.5*0*k*k ... stays (+-)0
+    for (int i = 0; i < 3; i++) dk[i] = 0.0;
+    if (kWithDistance) {
+      // temp_a[a] = sum_mu (g^{a mu} - g^{0a} g^{0 mu}/g^{00}) k_mu = k_a ; k[8] = -sqrt(sum k_a^2)
+      double acc = 0.0;
+      for (int a = 1; a < 4; a++) acc += kcov[a] * kcov[a];
+      *ds = -blm_sqrt(acc);
+    }
+    // RadialGeodesicCoordinate ignores ray_flat (geodesic_geometry.cpp:19-26)
+    *r_out = bl_radial_coordinate(st, pos[0], pos[1], pos[2]);
+    return;
+  }
+  double x = pos[0], y = pos[1], z = pos[2];
+  double bh_a = st.bh_a;
+  BlKerrSchild ks;
+  bl_kerr_schild(st, x, y, z, &ks);
+  double r = ks.r, r2 = ks.r2, f = ks.f, a2 = ks.a2, rr2 = ks.rr2;
+  const double *l = ks.l;
+  const double *fl = ks.fl;
+  *r_out = r;
+
+  // g^{mu nu} rows needed below. gcon[0][0] = -f - 1; gcon[0][i] = gcon[i][0] = f l_i;
+  // gcon[i][j] = -(f l_i) l_j (+1 on the diagonal)
+  double g00 = -f - 1.0;
+  double gij[3][3];
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) gij[i][j] = -(fl[i] * l[j]);
+    gij[i][i] = -(fl[i] * l[i]) + 1.0;
+  }
+
+  // k[mu] += gcon[mu][nu] * y[4+nu], nu = 0..3 in order, starting from 0 (:877-879)
+  {
+    double acc = g00 * kcov[0];
+    for (int j = 0; j < 3; j++) acc += fl[j] * kcov[j + 1];
+    dpos[0] = acc;
+    for (int i = 0; i < 3; i++) {
+      double a = fl[i] * kcov[0];
+      for (int j = 0; j < 3; j++) a += gij[i][j] * kcov[j + 1];
+      dpos[i + 1] = a;
+    }
+  }
+
+  // Scalar and vector derivatives (geodesic_geometry.cpp:199-220)
+  double dr[3], df[3], dl[3][3];  // dl[i][a] = d l_{i+1} / d x^a
+  double denom = 2.0 * r2 - rr2 + a2;
+  dr[0] = r * x / denom;
+  dr[1] = r * y / denom;
+  dr[2] = (r * z + a2 * z / r) / denom;
+  double num_f = r2 * r2 - 3.0 * a2 * z * z;
+  double den_f = r * (r2 * r2 + a2 * z * z);
+  df[0] = -num_f * dr[0] / den_f * f;
+  df[1] = -num_f * dr[1] / den_f * f;
+  df[2] = -(num_f * dr[2] + 2.0 * a2 * r * z) / den_f * f;
+  double xl = x - 2.0 * r * l[0];
+  double yl = y - 2.0 * r * l[1];
+  double ra = r2 + a2;
+  dl[0][0] = (xl * dr[0] + r) / ra;
+  dl[0][1] = (xl * dr[1] + bh_a) / ra;
+  dl[0][2] = xl * dr[2] / ra;
+  dl[1][0] = (yl * dr[0] - bh_a) / ra;
+  dl[1][1] = (yl * dr[1] + r) / ra;
+  dl[1][2] = yl * dr[2] / ra;
+  double mz_r2 = -z / r2;
+  dl[2][0] = mz_r2 * dr[0];
+  dl[2][1] = mz_r2 * dr[1];
+  dl[2][2] = mz_r2 * dr[2] + 1.0 / r;
+
+  // k[4+a] -= 0.5 * dgcon[a-1][mu][nu] * y[4+mu] * y[4+nu], (mu, nu) row-major (:880-883), with
+  // dgcon[a][mu][nu] = -(df_a l_mu l_nu + f dl_mu,a l_nu + f l_mu dl_nu,a) (geodesic_geometry.cpp:223-274)
+  //   [0][0] = -df_a ; [0][j] = [j][0] = df_a l_j + f dl_j,a ; [i][j] as written.
+  for (int a = 0; a < 3; a++) {
+    double dfl[3], fdl[3];
+    for (int i = 0; i < 3; i++) {
+      dfl[i] = df[a] * l[i];
+      fdl[i] = f * dl[i][a];
+    }
+    double acc = 0.0;
+    acc -= 0.5 * (-df[a]) * kcov[0] * kcov[0];
+    for (int j = 0; j < 3; j++) acc -= 0.5 * (dfl[j] + fdl[j]) * kcov[0] * kcov[j + 1];
+    for (int i = 0; i < 3; i++) {
+      acc -= 0.5 * (dfl[i] + fdl[i]) * kcov[i + 1] * kcov[0];
+      for (int j = 0; j < 3; j++) {
+        double dg = -(dfl[i] * l[j] + fdl[i] * l[j] + fl[i] * dl[j][a]);
+        acc -= 0.5 * dg * kcov[i + 1] * kcov[j + 1];
+      }
+    }
+    dk[a] = acc;
+  }
+
+  if (kWithDistance) {
+    // temp_a[a] += (gcon[a][mu] - gcon[0][a] * gcon[0][mu] / gcon[0][0]) * y[4+mu] (:884-887)
+    double temp_a[3];
+    for (int a = 0; a < 3; a++) {
+      double g0a = fl[a];
+      double acc = (fl[a] - g0a * g00 / g00) * kcov[0];
+      for (int j = 0; j < 3; j++) acc += (gij[a][j] - g0a * fl[j] / g00) * kcov[j + 1];
+      temp_a[a] = acc;
+    }
+    // k[8] += gcov[a][b] * temp_a[a] * temp_a[b] (:888-891); gcov[i][j] = (f l_i) l_j (+1 diag)
+    double acc = 0.0;
+    for (int a = 0; a < 3; a++)
+      for (int b = 0; b < 3; b++) {
+        double gab = a == b ? fl[a] * l[b] + 1.0 : fl[a] * l[b];
+        acc += gab * temp_a[a] * temp_a[b];
+      }
+    *ds = -blm_sqrt(acc);
+  }
+}
+
+#endif  // BLACKLIGHT_AMD_BL_GEOMETRY_H_

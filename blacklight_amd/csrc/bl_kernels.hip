@@ -1,0 +1,1075 @@
+// bl_kernels.hip - hand-written gfx950 (MI355X, CDNA4) kernels of the blacklight hot path.
+//
+// Pipeline per chunk of rays (fp64 throughout, grid primitives fp32 in HBM; no MFMA: the work is
+// per-ray ODE integration and gathers, not a contraction):
+//
+//   bl_geodesic_kernel   one ray per lane, wave64, persistent waves. Camera pixel -> (x^mu, k_mu),
+//                        Dormand-Prince 5(4) / RK4 / RK2 stepping in Kerr-Schild coordinates with the
+//                        reference's controller, dense-output sampling, online truncation test.
+//                        Lanes whose ray has terminated are refilled from a global work queue
+//                        (ballot + popcount prefix, one atomic per wave); sample slots for a whole
+//                        wave-step are allocated with one wave scan + one atomic and written as
+//                        64-byte records.   (reference geodesics.cpp:39-396, camera.cpp:528-671)
+//   bl_shade_kernel      one SAMPLE per lane (no ray divergence, high occupancy to hide gather
+//                        latency): per-sample momentum renormalisation, cuts, CKS->SKS, cell search,
+//                        8-variable trilinear gather from the interleaved grid, thermal-synchrotron
+//                        j_nu / alpha_nu, and the per-sample transfer coefficients (a, b) of
+//                        I <- a (I + b).   (simulation_sampling.cpp:201-575, :666-1033,
+//                        simulation_coefficients.cpp:253-524, formula_coefficients.cpp:62-180,
+//                        unpolarized.cpp:74-110)
+//   bl_transfer_kernel   one ray per lane: replays the (a, b) records far -> near in the reference's
+//                        order and scales by nu^3.   (unpolarized.cpp:71-110, :200-208)
+//
+// The reference integrates camera -> source but evaluates the transfer equation source -> camera
+// (ReverseGeodesics, geodesics.cpp:808-849); recording (a, b) per sample in the forward pass keeps
+// the recurrence bit-identical to the reference's while never materialising its per-sample arrays.
+//
+// Compile with -ffp-contract=off: bit-exact sample counts depend on it (see blmath.h).
+#include <hip/hip_runtime.h>
+
+#include "bl_device.h"
+
+namespace {
+
+constexpr double kPi = 3.141592653589793;    // reference src/blacklight.hpp:12
+constexpr double kSqrt2 = 1.4142135623730951;
+constexpr double kC = 2.99792458e10;
+constexpr double kH = 6.62607015e-27;
+constexpr double kMp = 1.67262192369e-24;
+constexpr double kMe = 9.1093837015e-28;
+constexpr double kE = 4.80320425e-10;
+// std::pow(2.0, 11.0 / 12.0) of simulation_coefficients.cpp:480, which g++ folds at compile time to
+// the correctly rounded value (the constant is in the reference binary; 11/12 is not)
+constexpr double kPow2_11_12 = 0x1.e3437e7101343p+0;
+constexpr double kDeltaTauMax = 100.0;       // radiation_integrator.hpp:191
+
+// Dormand-Prince RK5(4)7M tableau exactly as written in geodesics.cpp:42-72
+constexpr double kA[7][6] = {
+    {0.0, 0.0, 0.0, 0.0, 0.0, 0.0},
+    {1.0 / 5.0, 0.0, 0.0, 0.0, 0.0, 0.0},
+    {3.0 / 40.0, 9.0 / 40.0, 0.0, 0.0, 0.0, 0.0},
+    {44.0 / 45.0, -56.0 / 15.0, 32.0 / 9.0, 0.0, 0.0, 0.0},
+    {19372.0 / 6561.0, -25360.0 / 2187.0, 64448.0 / 6561.0, -212.0 / 729.0, 0.0, 0.0},
+    {9017.0 / 3168.0, -355.0 / 33.0, 46732.0 / 5247.0, 49.0 / 176.0, -5103.0 / 18656.0, 0.0},
+    {35.0 / 384.0, 0.0, 500.0 / 1113.0, 125.0 / 192.0, -2187.0 / 6784.0, 11.0 / 84.0}};
+constexpr double kB5[7] = {35.0 / 384.0, 0.0, 500.0 / 1113.0, 125.0 / 192.0, -2187.0 / 6784.0, 11.0 / 84.0, 0.0};
+constexpr double kB4[7] = {5179.0 / 57600.0, 0.0, 7571.0 / 16695.0, 393.0 / 640.0, -92097.0 / 339200.0,
+                           187.0 / 2100.0, 1.0 / 40.0};
+constexpr double kB4m[7] = {6025192743.0 / 30085553152.0, 0.0, 51252292925.0 / 65400821598.0,
+                            -2691868925.0 / 45128329728.0, 187940372067.0 / 1594534317056.0,
+                            -1776094331.0 / 19743644256.0, 11237099.0 / 235043384.0};
+constexpr double kD[7] = {-12715105075.0 / 11282082432.0, 0.0, 87487479700.0 / 32700410799.0,
+                          -10690763975.0 / 1880347072.0, 701980252875.0 / 199316789632.0,
+                          -1453857185.0 / 822651844.0, 69997945.0 / 29380423.0};
+
+// std::max / std::min semantics of the reference (first argument wins on NaN / equality)
+__device__ __forceinline__ double std_max(double a, double b) { return (a < b) ? b : a; }
+__device__ __forceinline__ double std_min(double a, double b) { return (b < a) ? b : a; }
+
+__device__ __forceinline__ int wave_lane() { return threadIdx.x & 63; }
+
+// Inclusive wave scan of non-negative ints (64 lanes), via ds_bpermute-free shuffles
+__device__ __forceinline__ int wave_inclusive_scan(int v) {
+  const int lane = wave_lane();
+#pragma unroll
+  for (int offset = 1; offset < 64; offset <<= 1) {
+    int up = __shfl_up(v, offset, 64);
+    if (lane >= offset) v += up;
+  }
+  return v;
+}
+
+// State vector component order used in the geodesic kernel:
+//   0 t, 1 x, 2 y, 3 z, 4 k_x, 5 k_y, 6 k_z, 7 s      (k_t is constant along the ray: d k_t = 0)
+// which is the reference's y_vals[0..8] without y_vals[4].
+struct RayState {
+  double y[8];
+  double kt;
+};
+
+template <bool kWithDistance>
+__device__ __forceinline__ void rhs(const BlSpacetime &st, const double y[8], double kt, double k[8], double *r) {
+  double pos[3] = {y[1], y[2], y[3]};
+  double kcov[4] = {kt, y[4], y[5], y[6]};
+  double dpos[4], dk[3], ds = 0.0;
+  bl_geodesic_rhs<kWithDistance>(st, pos, kcov, dpos, dk, &ds, r);
+  k[0] = dpos[0];
+  k[1] = dpos[1];
+  k[2] = dpos[2];
+  k[3] = dpos[3];
+  k[4] = dk[0];
+  k[5] = dk[1];
+  k[6] = dk[2];
+  k[7] = ds;
+}
+
+// Map a traversal index to the output (ray) index: walk 8x8 pixel tiles so that the 64 lanes of a
+// wave start as a compact patch of the image (similar path lengths, shared grid cells).
+__device__ __forceinline__ long long traversal_to_ray(long long q, int res) {
+  if (res <= 0) return q;
+  int tiles_per_row = res >> 3;
+  long long tile = q >> 6;
+  int within = (int)(q & 63);
+  long long tile_row = tile / tiles_per_row;
+  int tile_col = (int)(tile % tiles_per_row);
+  long long m2 = tile_row * 8 + (within >> 3);
+  int m1 = tile_col * 8 + (within & 7);
+  return m2 * res + m1;
+}
+
+}  // namespace
+
+// =================================================================================================
+// Geodesic kernel
+// =================================================================================================
+template <int kIntegrator>
+__global__ void __launch_bounds__(64, 1) bl_geodesic_kernel(BlTraceArgs P) {
+  const int lane = wave_lane();
+  const BlSpacetime st = P.st;
+
+  bool have_ray = false;
+  bool exhausted = false;
+  // per-ray persistent state
+  RayState s;
+  double k0[8];
+  double h_new = 0.0, r_cur = 0.0, r_prev_sample = 0.0;
+  int num_retry = 0, n = 0, sample_num = 0, trunc_at = -1;
+  unsigned int slot = 0;
+  bool previous_fail = false, flag = false;
+  for (int p = 0; p < 8; p++) {
+    s.y[p] = 0.0;
+    k0[p] = 0.0;
+  }
+  s.kt = 0.0;
+
+  while (true) {
+    // ------------------------------------------------------------------ refill idle lanes
+    bool need = !have_ray && !exhausted;
+    unsigned long long need_mask = __ballot(need);
+    if (need_mask != 0ull) {
+      int count = __popcll(need_mask);
+      int leader = __ffsll((long long)need_mask) - 1;
+      unsigned long long base = 0ull;
+      if (lane == leader) base = atomicAdd(&P.counters[BL_CNT_NEXT_RAY], (unsigned long long)count);
+      base = __shfl(base, leader, 64);
+      if (need) {
+        int rank = __popcll(need_mask & ((1ull << lane) - 1ull));
+        unsigned long long q = base + (unsigned long long)rank;
+        if (q >= (unsigned long long)P.chunk_rays) {
+          exhausted = true;
+        } else {
+          have_ray = true;
+          slot = (unsigned int)q;
+          long long ray = traversal_to_ray(P.chunk_begin + (long long)q, P.swizzle_tiles);
+          long long pixel = P.pixel_map != nullptr ? (long long)P.pixel_map[ray] : ray;
+          double u_ind, v_ind, position[4], direction[4], factor;
+          bl_pixel_indices(P.cam, pixel, P.block_locs, &u_ind, &v_ind);
+          bl_pixel_ray(st, P.cam, u_ind, v_ind, position, direction, &factor);
+          P.ray_kt[slot] = direction[0];
+          P.ray_factor[slot] = factor;
+          P.ray_out_index[slot] = ray;
+          if (P.camera_pos != nullptr)
+            for (int mu = 0; mu < 4; mu++) P.camera_pos[4 * ray + mu] = position[mu];
+          if (P.camera_dir != nullptr)
+            for (int mu = 0; mu < 4; mu++) P.camera_dir[4 * ray + mu] = direction[mu];
+          // geodesics.cpp:113-133
+          s.y[0] = position[0];
+          s.y[1] = position[1];
+          s.y[2] = position[2];
+          s.y[3] = position[3];
+          s.kt = direction[0];
+          s.y[4] = direction[1];
+          s.y[5] = direction[2];
+          s.y[6] = direction[3];
+          s.y[7] = 0.0;
+          r_cur = bl_radial_coordinate(st, s.y[1], s.y[2], s.y[3]);
+          h_new = -P.ray_step * r_cur;
+          num_retry = 0;
+          previous_fail = false;
+          flag = false;
+          n = 0;
+          sample_num = 0;
+          trunc_at = -1;
+          r_prev_sample = 0.0;
+          if (kIntegrator == BL_INTEGRATOR_DP) {
+            double r_unused;
+            rhs<true>(st, s.y, s.kt, k0, &r_unused);  // :155-156 (first stage of the first step)
+          }
+        }
+      }
+    }
+    if (__ballot(have_ray) == 0ull) break;
+
+    // ------------------------------------------------------------------ one step attempt
+    int emit = 0;               // samples this lane writes in this iteration
+    int num_steps = 0;          // samples the step contributes to sample_num
+    int num_steps_ideal = 1;
+    bool accepted = false;
+    bool finish = false;
+    double h = 0.0;
+    double y5[8], k6[8], y4m[8];
+    double rv0[8], rv1[8], rv2[8], rv3[8];   // dense-output coefficients (geodesics.cpp:264-273)
+    double r_new = 0.0;
+    for (int p = 0; p < 8; p++) {
+      y5[p] = 0.0; k6[p] = 0.0; y4m[p] = 0.0; rv0[p] = 0.0; rv1[p] = 0.0; rv2[p] = 0.0; rv3[p] = 0.0;
+    }
+
+    if (have_ray) {
+      if (kIntegrator == BL_INTEGRATOR_DP) {
+        if (num_retry > P.ray_max_retries) {   // :139-143
+          flag = true;
+          finish = true;
+        } else {
+          h = h_new;
+          double k1[8], k2[8], k3[8], k4[8], k5[8];
+          double yt[8], r_stage;
+          // stages 1..6 (:162-170): y_temp = y + sum_{q<s} a[s][q] * h * k[q], terms added in q order
+#define BL_STAGE(S, KOUT, ...)                                                  \
+          {                                                                      \
+            const double *kq[6] = {__VA_ARGS__};                                 \
+            _Pragma("unroll") for (int p = 0; p < 8; p++) {                      \
+              double acc = s.y[p];                                               \
+              _Pragma("unroll") for (int q = 0; q < S; q++) acc += kA[S][q] * h * kq[q][p]; \
+              yt[p] = acc;                                                       \
+            }                                                                    \
+            rhs<true>(st, yt, s.kt, KOUT, &r_stage);                             \
+          }
+          BL_STAGE(1, k1, k0, k0, k0, k0, k0, k0)
+          BL_STAGE(2, k2, k0, k1, k0, k0, k0, k0)
+          BL_STAGE(3, k3, k0, k1, k2, k0, k0, k0)
+          BL_STAGE(4, k4, k0, k1, k2, k3, k0, k0)
+          BL_STAGE(5, k5, k0, k1, k2, k3, k4, k0)
+          BL_STAGE(6, k6, k0, k1, k2, k3, k4, k5)
+#undef BL_STAGE
+          // 5th / 4th order solutions and error (:173-194). y_vals_5 equals the stage-6 argument
+          // bit for bit (same coefficients, same order, the extra b5[6] = 0 term adds +-0), so
+          // r_new = RadialGeodesicCoordinate(y_vals_5) is the r of stage 6.
+          const double *kk[7] = {k0, k1, k2, k3, k4, k5, k6};
+          double error = 0.0;
+#pragma unroll
+          for (int p = 0; p < 8; p++) {
+            double a5 = s.y[p], a4 = s.y[p];
+#pragma unroll
+            for (int q = 0; q < 7; q++) {
+              a5 += kB5[q] * h * kk[q][p];
+              a4 += kB4[q] * h * kk[q][p];
+            }
+            y5[p] = a5;
+            if (p < 7) {   // reference p < 8 covers t, x, y, z, k_t (zero difference), k_x, k_y, k_z
+              double y_abs = std_max(blm_abs(s.y[p]), blm_abs(a5));
+              double error_scale = P.ray_tol_abs + P.ray_tol_rel * y_abs;
+              double delta_y = blm_abs(a5 - a4);
+              error = std_max(error, delta_y / error_scale);
+            }
+          }
+          r_new = r_stage;
+
+          if (!(error <= 1.0)) {   // :197-209
+            double h_factor = 0.2;
+            if (error - error == 0.0) {   // std::isfinite
+              double h_factor_ideal = 0.9 * bl_pow(error, -0.2);
+              h_factor = std_max(h_factor_ideal, 0.2);
+            }
+            h_new = h * h_factor;
+            num_retry += 1;
+            previous_fail = true;
+          } else {                 // :210-224
+            double h_factor = 10.0;
+            if (error > 0.0) {
+              h_factor = 0.9 * bl_pow(error, -0.2);
+              h_factor = std_max(h_factor, 0.2);
+              h_factor = std_min(h_factor, 10.0);
+            }
+            if (previous_fail) h_factor = std_min(h_factor, 1.0);
+            h_new = h * h_factor;
+            num_retry = 0;
+            previous_fail = false;
+            accepted = true;
+
+            // midpoint (:227-231), subdivision (:234-245)
+#pragma unroll
+            for (int p = 0; p < 7; p++) {
+              double acc = s.y[p];
+#pragma unroll
+              for (int q = 0; q < 7; q++) acc += kB4m[q] * h * kk[q][p];
+              y4m[p] = acc;
+            }
+            double r_mid = bl_radial_coordinate(st, y4m[1], y4m[2], y4m[3]);
+            double delta_s_step = P.ray_step * r_mid;
+            double delta_s_full = y5[7] - s.y[7];
+            num_steps_ideal = (int)ceil(delta_s_full / delta_s_step);
+            int num_steps_max = P.ray_max_steps - n;
+            num_steps = num_steps_ideal;
+            if (num_steps > num_steps_max) {
+              num_steps = num_steps_max;
+              flag = true;
+            }
+            emit = num_steps;
+            if (num_steps_ideal > 1) {   // :262-274
+#pragma unroll
+              for (int p = 0; p < 7; p++) {
+                rv0[p] = y5[p] - s.y[p];
+                rv1[p] = s.y[p] - y5[p] + h * k0[p];
+                rv2[p] = 2.0 * (y5[p] - s.y[p]) - h * (k0[p] + k6[p]);
+                double acc = 0.0;
+#pragma unroll
+                for (int q = 0; q < 7; q++) acc += kD[q] * h * kk[q][p];
+                rv3[p] = acc;
+              }
+            }
+          }
+        }
+      } else {
+        // RK4 (:463-533) / RK2 (:670-722): one sample per step, fixed step rule
+        double r = r_cur;
+        h = -P.ray_step * (r - P.r_horizon);
+        double kv[8], ysub[8], yacc[8], r_unused;
+        if (kIntegrator == BL_INTEGRATOR_RK4) {
+          rhs<false>(st, s.y, s.kt, kv, &r_unused);
+          for (int p = 0; p < 7; p++) yacc[p] = s.y[p] + 1.0 / 6.0 * h * kv[p];
+          for (int p = 0; p < 7; p++) ysub[p] = s.y[p] + 0.5 * h * kv[p];
+          ysub[7] = 0.0;
+          rhs<false>(st, ysub, s.kt, kv, &r_unused);
+          for (int p = 0; p < 7; p++) yacc[p] += 1.0 / 3.0 * h * kv[p];
+          for (int p = 0; p < 7; p++) ysub[p] = s.y[p] + 0.5 * h * kv[p];
+          rhs<false>(st, ysub, s.kt, kv, &r_unused);
+          for (int p = 0; p < 7; p++) yacc[p] += 1.0 / 3.0 * h * kv[p];
+          for (int p = 0; p < 7; p++) ysub[p] = s.y[p] + h * kv[p];
+          rhs<false>(st, ysub, s.kt, kv, &r_unused);
+          for (int p = 0; p < 7; p++) yacc[p] += 1.0 / 6.0 * h * kv[p];
+          for (int p = 0; p < 7; p++) y4m[p] = 0.5 * (s.y[p] + yacc[p]);   // stored midpoint (:496-500)
+          for (int p = 0; p < 7; p++) y5[p] = yacc[p];
+        } else {
+          rhs<false>(st, s.y, s.kt, kv, &r_unused);
+          for (int p = 0; p < 7; p++) ysub[p] = s.y[p] + h * kv[p];
+          ysub[7] = 0.0;
+          for (int p = 0; p < 7; p++) yacc[p] = s.y[p] + 1.0 / 2.0 * h * kv[p];
+          for (int p = 0; p < 7; p++) y4m[p] = yacc[p];                    // stored half-step state (:684-688)
+          rhs<false>(st, ysub, s.kt, kv, &r_unused);
+          for (int p = 0; p < 7; p++) y5[p] = yacc[p] + 1.0 / 2.0 * h * kv[p];
+        }
+        y5[7] = 0.0;
+        accepted = true;
+        num_steps_ideal = 1;
+        num_steps = 1;
+        emit = 1;
+      }
+    }
+
+    // ------------------------------------------------------------------ allocate sample slots
+    // One wave scan + one atomic for the whole wave-step; each lane's samples are contiguous.
+    int scan = wave_inclusive_scan(emit);
+    int total = __shfl(scan, 63, 64);
+    unsigned long long wave_base = 0ull;
+    if (total > 0) {
+      if (lane == 63) wave_base = atomicAdd(&P.counters[BL_CNT_RECORDS], (unsigned long long)total);
+      wave_base = __shfl(wave_base, 63, 64);
+    }
+    long long my_base = (long long)wave_base + (long long)(scan - emit);
+    if (emit > 0 && my_base + emit > P.record_capacity) {
+      // cannot happen when capacity = chunk_rays * ray_max_steps; flagged for the host if it does
+      atomicExch(&P.counters[BL_CNT_OVERFLOW], 1ull);
+      emit = 0;
+    }
+
+    // ------------------------------------------------------------------ emit samples
+    int max_emit = emit;
+#pragma unroll
+    for (int offset = 32; offset > 0; offset >>= 1) {
+      int other = __shfl_xor(max_emit, offset, 64);
+      max_emit = other > max_emit ? other : max_emit;
+    }
+    for (int nn = 0; nn < max_emit; nn++) {
+      if (nn < emit) {
+        double smp[7];
+        double len;
+        if (num_steps_ideal == 1) {   // :248-259 (and the RK4 / RK2 stored state)
+#pragma unroll
+          for (int p = 0; p < 7; p++) smp[p] = y4m[p];
+          len = h;
+        } else {                      // :277-293
+          double frac = (nn + 0.5) / num_steps_ideal;
+#pragma unroll
+          for (int p = 0; p < 7; p++)
+            smp[p] = s.y[p] + frac * (rv0[p] + (1.0 - frac) * (rv1[p] + frac * (rv2[p] + (1.0 - frac) * rv3[p])));
+          len = h / num_steps_ideal;
+        }
+        // online form of the truncation pass (:327-349): the first sample (index >= 1) that moves
+        // outward beyond the camera radius or falls inside r_terminate ends the kept part of the ray
+        int index = n + nn;
+        bool dead = trunc_at >= 0;
+        if (!dead) {
+          double r_s = bl_radial_coordinate(st, smp[1], smp[2], smp[3]);
+          if (index >= 1) {
+            bool terminate_outer = r_s > P.camera_r && r_s > r_prev_sample;
+            bool terminate_inner = r_s < P.r_terminate;
+            if (terminate_outer || terminate_inner) {
+              trunc_at = index;
+              dead = true;
+            }
+          }
+          r_prev_sample = r_s;
+        }
+        BlSampleRecord rec;
+        rec.x = smp[1];
+        rec.y = smp[2];
+        rec.z = smp[3];
+        rec.kx = smp[4];
+        rec.ky = smp[5];
+        rec.kz = smp[6];
+        rec.len = len;
+        rec.ray = dead ? BL_DEAD_RAY : slot;
+        rec.n = (unsigned int)index;
+        P.records[my_base + nn] = rec;
+      }
+    }
+
+    // ------------------------------------------------------------------ finish the step
+    if (have_ray && accepted) {
+      // renormalise the spatial momentum at the new point (:296-309 / :507-521 / :696-710)
+      double factor = bl_renormalization_factor(st, y5[1], y5[2], y5[3], s.kt, y5[4], y5[5], y5[6]);
+      y5[4] *= factor;
+      y5[5] *= factor;
+      y5[6] *= factor;
+      double r_before = r_cur;
+      if (kIntegrator != BL_INTEGRATOR_DP) r_new = bl_radial_coordinate(st, y5[1], y5[2], y5[3]);
+      sample_num += num_steps;
+      bool terminate_outer = r_new > P.camera_r && r_new > r_before;
+      bool terminate_inner = r_new < P.r_terminate;
+      if (terminate_outer || terminate_inner) {
+        finish = true;
+      } else {
+        bool last_step = n + num_steps >= P.ray_max_steps;
+        if (last_step) flag = true;
+        n += num_steps;
+        if (n >= P.ray_max_steps) finish = true;
+      }
+      // FSAL: next step starts from y_vals_5 with k_vals[0] = k_vals[6], the latter evaluated
+      // BEFORE the renormalisation above (:149-154)
+#pragma unroll
+      for (int p = 0; p < 8; p++) {
+        s.y[p] = y5[p];
+        k0[p] = k6[p];
+      }
+      r_cur = r_new;
+    }
+    if (have_ray && finish) {
+      int final_num = (trunc_at >= 0) ? trunc_at : sample_num;
+      P.ray_sample_num[slot] = final_num;
+      P.ray_flags[slot] = flag ? 1 : 0;
+      have_ray = false;
+    }
+  }
+}
+
+// =================================================================================================
+// Shading kernel
+// =================================================================================================
+namespace {
+
+// simulation_sampling.cpp:458-466: first cell index c with xf[c+1] >= x, started from a bucket table
+__device__ __forceinline__ int find_cell(const BlGridDevice &g, int axis, double x) {
+  int n = g.n[axis];
+  double t = (x - g.bucket_x0[axis]) * g.bucket_inv_w[axis];
+  int b = (int)t;
+  b = b < 0 ? 0 : (b >= g.n_bucket[axis] ? g.n_bucket[axis] - 1 : b);
+  int c = g.bucket[axis][b];
+  const double *xf = g.xf[axis];
+  while (c < n - 1 && !(xf[c + 1] >= x)) c++;
+  if (!(xf[c + 1] >= x)) c = n;   // loop ran off the end (cannot happen after the block test)
+  return c;
+}
+
+struct Prims {
+  float rho, pgas, uu1, uu2, uu3, bb1, bb2, bb3;
+};
+
+__device__ __forceinline__ void load_cell(const BlGridDevice &g, int k, int j, int i, float v[8]) {
+  size_t idx = (((size_t)k * g.n[1] + j) * g.n[0] + i) * 8;
+  const float4 *p = reinterpret_cast<const float4 *>(g.cells + idx);
+  float4 a = p[0], b = p[1];
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+  v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+
+// radiation_geometry.cpp:597-658
+__device__ __forceinline__ void tetrad_build(const double ucon[4], const double ucov[4], const double kcon[4],
+                                             const double kcov[4], const double up_con[4],
+                                             const double gcov[4][4], const double gcon[4][4],
+                                             double tetrad[4][4]) {
+  double omega = 0.0;
+  for (int mu = 0; mu < 4; mu++) omega -= kcov[mu] * ucon[mu];
+  double k_up_over_omega = 0.0;
+  for (int mu = 0; mu < 4; mu++) k_up_over_omega += kcov[mu] * up_con[mu];
+  k_up_over_omega /= omega;
+  double u_up_over_omega = 0.0;
+  for (int mu = 0; mu < 4; mu++) u_up_over_omega += ucov[mu] * up_con[mu];
+  u_up_over_omega /= omega;
+  for (int mu = 0; mu < 4; mu++) tetrad[0][mu] = ucon[mu];
+  for (int mu = 0; mu < 4; mu++) tetrad[3][mu] = kcon[mu] / omega - ucon[mu];
+  for (int mu = 0; mu < 4; mu++)
+    tetrad[2][mu] = up_con[mu] - k_up_over_omega * tetrad[3][mu] + u_up_over_omega * kcon[mu];
+  double norm = 0.0;
+  for (int mu = 0; mu < 4; mu++)
+    for (int nu = 0; nu < 4; nu++) norm += gcov[mu][nu] * tetrad[2][mu] * tetrad[2][nu];
+  norm = blm_sqrt(norm);
+  for (int mu = 0; mu < 4; mu++) tetrad[2][mu] /= norm;
+  double t1[4];
+  t1[0] = tetrad[0][1] * (tetrad[2][3] * tetrad[3][2] - tetrad[2][2] * tetrad[3][3])
+      + tetrad[0][2] * (tetrad[2][1] * tetrad[3][3] - tetrad[2][3] * tetrad[3][1])
+      + tetrad[0][3] * (tetrad[2][2] * tetrad[3][1] - tetrad[2][1] * tetrad[3][2]);
+  t1[1] = tetrad[0][0] * (tetrad[2][2] * tetrad[3][3] - tetrad[2][3] * tetrad[3][2])
+      + tetrad[0][2] * (tetrad[2][3] * tetrad[3][0] - tetrad[2][0] * tetrad[3][3])
+      + tetrad[0][3] * (tetrad[2][0] * tetrad[3][2] - tetrad[2][2] * tetrad[3][0]);
+  t1[2] = tetrad[0][0] * (tetrad[2][3] * tetrad[3][1] - tetrad[2][1] * tetrad[3][3])
+      + tetrad[0][1] * (tetrad[2][0] * tetrad[3][3] - tetrad[2][3] * tetrad[3][0])
+      + tetrad[0][3] * (tetrad[2][1] * tetrad[3][0] - tetrad[2][0] * tetrad[3][1]);
+  t1[3] = tetrad[0][0] * (tetrad[2][1] * tetrad[3][2] - tetrad[2][2] * tetrad[3][1])
+      + tetrad[0][1] * (tetrad[2][2] * tetrad[3][0] - tetrad[2][0] * tetrad[3][2])
+      + tetrad[0][2] * (tetrad[2][0] * tetrad[3][1] - tetrad[2][1] * tetrad[3][0]);
+  for (int mu = 0; mu < 4; mu++) {
+    double acc = 0.0;
+    for (int nu = 0; nu < 4; nu++) acc += gcon[mu][nu] * t1[nu];
+    tetrad[1][mu] = acc;
+  }
+}
+
+// Geometric cuts (simulation_sampling.cpp:237-292, formula_coefficients.cpp:73-116)
+__device__ __forceinline__ bool geometric_cut(const BlCutsDevice &c, double x1, double x2, double x3, double r) {
+  if (r > c.camera_r) return true;
+  if (c.omit_near || c.omit_far) {
+    double dot_product = x1 * c.cam_x[1] + x2 * c.cam_x[2] + x3 * c.cam_x[3];
+    if ((c.omit_near && dot_product > 0.0) || (c.omit_far && dot_product < 0.0)) return true;
+  }
+  if ((c.omit_in >= 0.0 && r < c.omit_in) || (c.omit_out >= 0.0 && r > c.omit_out)) return true;
+  if (c.midplane_theta > 0.0 || c.midplane_theta < 0.0) {
+    double th = bl_acos(x3 / r);
+    if ((c.midplane_theta > 0.0 && blm_abs(th - kPi / 2.0) > c.midplane_theta)
+        || (c.midplane_theta < 0.0 && blm_abs(th - kPi / 2.0) < -c.midplane_theta))
+      return true;
+  }
+  if ((c.midplane_z > 0.0 && blm_abs(x3) > c.midplane_z) || (c.midplane_z < 0.0 && blm_abs(x3) < -c.midplane_z))
+    return true;
+  if (c.plane) {
+    double dot_product = (x1 - c.plane_origin[0]) * c.plane_normal[0] + (x2 - c.plane_origin[1]) * c.plane_normal[1]
+        + (x3 - c.plane_origin[2]) * c.plane_normal[2];
+    if (dot_product < 0.0) return true;
+  }
+  return false;
+}
+
+// (a, b) of the affine update for one frequency (unpolarized.cpp:92-110); delta_lambda_cgs given
+__device__ __forceinline__ double2 transfer_record(double j, double alpha, double delta_lambda_cgs) {
+  double2 rec;
+  if (alpha > 0.0) {
+    double ss = j / alpha;
+    double delta_tau = alpha * delta_lambda_cgs;
+    if (delta_tau <= kDeltaTauMax) {
+      rec.x = bl_exp(-delta_tau);
+      rec.y = ss * bl_expm1(delta_tau);
+    } else {
+      rec.x = BL_THICK_MARK;
+      rec.y = ss;
+    }
+  } else {
+    rec.x = 1.0;
+    rec.y = j * delta_lambda_cgs;
+  }
+  return rec;
+}
+
+}  // namespace
+
+template <int kModel>
+__global__ void __launch_bounds__(256) bl_shade_kernel(BlShadeArgs P) {
+  const BlSpacetime st = P.st;
+  const unsigned long long n_records = P.counters_in[BL_CNT_RECORDS];
+  unsigned long long gathers_local = 0ull;
+  const double bh_a = st.bh_a, bh_m = st.bh_m;
+
+  for (unsigned long long idx = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; idx < n_records;
+       idx += (unsigned long long)gridDim.x * blockDim.x) {
+    // one 64-byte record per lane: four 16-byte loads, a wave reads 4 KiB contiguously
+    const double2 *src = reinterpret_cast<const double2 *>(P.records + idx);
+    double2 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
+    uint32_t ray = (uint32_t)__double_as_longlong(q3.y);
+    uint32_t n = (uint32_t)(((unsigned long long)__double_as_longlong(q3.y)) >> 32);
+    if (ray == BL_DEAD_RAY) continue;
+    double x1 = q0.x, x2 = q0.y, x3 = q1.x;
+    double kcov[4];
+    kcov[0] = P.ray_kt[ray];
+    kcov[1] = q1.y;
+    kcov[2] = q2.x;
+    kcov[3] = q2.y;
+    double len = q3.x;
+    double momentum_factor = P.ray_factor[ray];
+    double2 *out = P.transfer + ((size_t)ray * P.ray_max_steps + n) * P.n_nu;
+
+    // per-sample renormalisation of the stored momentum (geodesics.cpp:352-371)
+    {
+      double factor = bl_renormalization_factor(st, x1, x2, x3, kcov[0], kcov[1], kcov[2], kcov[3]);
+      kcov[1] *= factor;
+      kcov[2] *= factor;
+      kcov[3] *= factor;
+    }
+    double delta_lambda = -len;   // ReverseGeodesics: sample_len = -geodesic_len (:840)
+
+    double r = bl_radial_coordinate(st, x1, x2, x3);
+    bool skip = geometric_cut(P.cuts, x1, x2, x3, r);
+    bool have_coefficients = false;   // false -> j = alpha = 0 for every frequency
+    // quantities shared by all frequencies
+    double nu_fluid_over_nu = 0.0;    // -k_mu u^mu * factor
+    // simulation
+    double n_e_cgs = 0.0, nu_c_cgs = 0.0, theta_e = 0.0, sin_theta_b = 0.0, kb_tt_e_cgs = 0.0;
+    // formula
+    double n_n0_fluid = 0.0;
+
+    if (!skip && kModel == BL_MODEL_SIMULATION) {
+      const BlPlasmaDevice &pl = P.plasma;
+      const BlGridDevice &g = P.grid;
+      // ConvertFromCKS (radiation_geometry.cpp:37-57)
+      double s1 = x1, s2 = x2, s3 = x3;
+      double atan2_yx = 0.0, atan_ar = 0.0;
+      if (pl.simulation_coord == BL_COORD_SKS) {
+        double th = bl_acos(x3 / r);
+        atan2_yx = bl_atan2(x2, x1);
+        atan_ar = bl_atan(bh_a / r);
+        double ph = atan2_yx - atan_ar;
+        ph += ph < 0.0 ? 2.0 * kPi : 0.0;
+        ph -= ph >= 2.0 * kPi ? 2.0 * kPi : 0.0;
+        s1 = r;
+        s2 = th;
+        s3 = ph;
+      }
+      Prims pr;
+      bool valid = true;
+      // block test (simulation_sampling.cpp:352-394), single block
+      if (s1 < g.xf[0][0] || s1 > g.xf[0][g.n[0]] || s2 < g.xf[1][0] || s2 > g.xf[1][g.n[1]]
+          || s3 < g.xf[2][0] || s3 > g.xf[2][g.n[2]]) {
+        if (pl.fallback_nan) {
+          float fnan = __int_as_float(0x7fc00000);
+          pr = Prims{fnan, fnan, fnan, fnan, fnan, fnan, fnan, fnan};
+        } else {
+          pr = Prims{pl.fallback_rho, pl.fallback_pgas, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        }
+      } else {
+        int i = find_cell(g, 0, s1);
+        int j = find_cell(g, 1, s2);
+        int k = find_cell(g, 2, s3);
+        gathers_local++;
+        if (!pl.simulation_interp) {   // :710-734
+          float v[8];
+          load_cell(g, k, j, i, v);
+          pr = Prims{v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
+        } else {                       // :485-490, :809-839, InterpolateSimple :1334-1351
+          int n_i = g.n[0], n_j = g.n[1], n_k = g.n[2];
+          int i_m = (i == 0 || (i != n_i - 1 && s1 >= g.xv[0][i])) ? i : i - 1;
+          int j_m = (j == 0 || (j != n_j - 1 && s2 >= g.xv[1][j])) ? j : j - 1;
+          int k_m = (k == 0 || (k != n_k - 1 && s3 >= g.xv[2][k])) ? k : k - 1;
+          double f_i = (s1 - g.xv[0][i_m]) / (g.xv[0][i_m + 1] - g.xv[0][i_m]);
+          double f_j = (s2 - g.xv[1][j_m]) / (g.xv[1][j_m + 1] - g.xv[1][j_m]);
+          double f_k = (s3 - g.xv[2][k_m]) / (g.xv[2][k_m + 1] - g.xv[2][k_m]);
+          float c[8][8];   // corner order mmm, mmp, mpm, mpp, pmm, pmp, ppm, ppp
+          load_cell(g, k_m, j_m, i_m, c[0]);
+          load_cell(g, k_m, j_m, i_m + 1, c[1]);
+          load_cell(g, k_m, j_m + 1, i_m, c[2]);
+          load_cell(g, k_m, j_m + 1, i_m + 1, c[3]);
+          load_cell(g, k_m + 1, j_m, i_m, c[4]);
+          load_cell(g, k_m + 1, j_m, i_m + 1, c[5]);
+          load_cell(g, k_m + 1, j_m + 1, i_m, c[6]);
+          load_cell(g, k_m + 1, j_m + 1, i_m + 1, c[7]);
+          double w[8];
+          w[0] = (1.0 - f_k) * (1.0 - f_j) * (1.0 - f_i);
+          w[1] = (1.0 - f_k) * (1.0 - f_j) * f_i;
+          w[2] = (1.0 - f_k) * f_j * (1.0 - f_i);
+          w[3] = (1.0 - f_k) * f_j * f_i;
+          w[4] = f_k * (1.0 - f_j) * (1.0 - f_i);
+          w[5] = f_k * (1.0 - f_j) * f_i;
+          w[6] = f_k * f_j * (1.0 - f_i);
+          w[7] = f_k * f_j * f_i;
+          double val[8];
+#pragma unroll
+          for (int v = 0; v < 8; v++) {
+            double acc = w[0] * (double)c[0][v];
+#pragma unroll
+            for (int corner = 1; corner < 8; corner++) acc += w[corner] * (double)c[corner][v];
+            val[v] = acc;
+          }
+          if (val[0] <= 0.0) val[0] = (double)c[0][0];   // :822-825
+          if (val[1] <= 0.0) val[1] = (double)c[0][1];
+          pr = Prims{(float)val[0], (float)val[1], (float)val[2], (float)val[3],
+                     (float)val[4], (float)val[5], (float)val[6], (float)val[7]};
+        }
+      }
+      (void)valid;
+
+      // ---------------- coefficients (simulation_coefficients.cpp:253-455)
+      double rho = pr.rho, pgas = pr.pgas;
+      double uu1_sim = pr.uu1, uu2_sim = pr.uu2, uu3_sim = pr.uu3;
+      double bb1_sim = pr.bb1, bb2_sim = pr.bb2, bb3_sim = pr.bb3;
+      double rho_cgs = rho * pl.d_unit;
+      double pgas_cgs = pgas * pl.e_unit;
+      double n_cgs = rho_cgs / (pl.plasma_mu * kMp);
+      n_e_cgs = n_cgs / (1.0 + 1.0 / pl.plasma_ne_ni);
+
+      // simulation metric (radiation_geometry.cpp:421-573)
+      double gcov_sim[4][4], gcon_sim[4][4];
+      if (pl.simulation_coord == BL_COORD_CKS) {
+        bl_gcov(BlSpacetime{bh_m, bh_a, 0}, x1, x2, x3, gcov_sim);
+        bl_gcon(BlSpacetime{bh_m, bh_a, 0}, x1, x2, x3, gcon_sim);
+      } else {
+        double a2 = bh_a * bh_a;
+        double r2 = r * r;   // placeholder, recomputed below exactly as the reference does
+        {
+          double rr2 = x1 * x1 + x2 * x2 + x3 * x3;
+          r2 = 0.5 * (rr2 - a2 + bl_hypot(rr2 - a2, 2.0 * bh_a * x3));
+        }
+        double rs = blm_sqrt(r2);
+        double cth = x3 / rs;
+        double cth2 = cth * cth;
+        double sth2 = 1.0 - cth2;
+        double delta = r2 - 2.0 * bh_m * rs + a2;
+        double sigma = r2 + a2 * cth2;
+        for (int mu = 0; mu < 4; mu++)
+          for (int nu = 0; nu < 4; nu++) {
+            gcov_sim[mu][nu] = 0.0;
+            gcon_sim[mu][nu] = 0.0;
+          }
+        gcov_sim[0][0] = -(1.0 - 2.0 * bh_m * rs / sigma);
+        gcov_sim[0][1] = 2.0 * bh_m * rs / sigma;
+        gcov_sim[0][3] = -2.0 * bh_m * bh_a * rs * sth2 / sigma;
+        gcov_sim[1][0] = 2.0 * bh_m * rs / sigma;
+        gcov_sim[1][1] = 1.0 + 2.0 * bh_m * rs / sigma;
+        gcov_sim[1][3] = -(1.0 + 2.0 * bh_m * rs / sigma) * bh_a * sth2;
+        gcov_sim[2][2] = sigma;
+        gcov_sim[3][0] = -2.0 * bh_m * bh_a * rs * sth2 / sigma;
+        gcov_sim[3][1] = -(1.0 + 2.0 * bh_m * rs / sigma) * bh_a * sth2;
+        gcov_sim[3][3] = (r2 + a2 + 2.0 * bh_m * a2 * rs * sth2 / sigma) * sth2;
+        gcon_sim[0][0] = -(1.0 + 2.0 * bh_m * rs / sigma);
+        gcon_sim[0][1] = 2.0 * bh_m * rs / sigma;
+        gcon_sim[1][0] = 2.0 * bh_m * rs / sigma;
+        gcon_sim[1][1] = delta / sigma;
+        gcon_sim[1][3] = bh_a / sigma;
+        gcon_sim[2][2] = 1.0 / sigma;
+        gcon_sim[3][1] = bh_a / sigma;
+        gcon_sim[3][3] = 1.0 / (sigma * sth2);
+      }
+
+      // simulation velocity (:297-313)
+      double uu0_sim = blm_sqrt(1.0 + gcov_sim[1][1] * uu1_sim * uu1_sim
+          + 2.0 * gcov_sim[1][2] * uu1_sim * uu2_sim + 2.0 * gcov_sim[1][3] * uu1_sim * uu3_sim
+          + gcov_sim[2][2] * uu2_sim * uu2_sim + 2.0 * gcov_sim[2][3] * uu2_sim * uu3_sim
+          + gcov_sim[3][3] * uu3_sim * uu3_sim);
+      double lapse_sim = 1.0 / blm_sqrt(-gcon_sim[0][0]);
+      double shift1_sim = -gcon_sim[0][1] / gcon_sim[0][0];
+      double shift2_sim = -gcon_sim[0][2] / gcon_sim[0][0];
+      double shift3_sim = -gcon_sim[0][3] / gcon_sim[0][0];
+      double ucon_sim[4];
+      ucon_sim[0] = uu0_sim / lapse_sim;
+      ucon_sim[1] = uu1_sim - shift1_sim * uu0_sim / lapse_sim;
+      ucon_sim[2] = uu2_sim - shift2_sim * uu0_sim / lapse_sim;
+      ucon_sim[3] = uu3_sim - shift3_sim * uu0_sim / lapse_sim;
+      double ucov_sim[4];
+      for (int mu = 0; mu < 4; mu++) {
+        double acc = 0.0;
+        for (int nu = 0; nu < 4; nu++) acc += gcov_sim[mu][nu] * ucon_sim[nu];
+        ucov_sim[mu] = acc;
+      }
+      // simulation magnetic field (:316-330)
+      double bcon_sim[4];
+      bcon_sim[0] = ucov_sim[1] * bb1_sim + ucov_sim[2] * bb2_sim + ucov_sim[3] * bb3_sim;
+      bcon_sim[1] = (bb1_sim + bcon_sim[0] * ucon_sim[1]) / ucon_sim[0];
+      bcon_sim[2] = (bb2_sim + bcon_sim[0] * ucon_sim[2]) / ucon_sim[0];
+      bcon_sim[3] = (bb3_sim + bcon_sim[0] * ucon_sim[3]) / ucon_sim[0];
+      double b_sq = 0.0;
+      for (int mu = 0; mu < 4; mu++) {
+        double acc = 0.0;
+        for (int nu = 0; nu < 4; nu++) acc += gcov_sim[mu][nu] * bcon_sim[nu];
+        b_sq += acc * bcon_sim[mu];
+      }
+      double bb_cgs = blm_sqrt(b_sq) * pl.b_unit;
+      double sigma_cut = b_sq / rho;
+      double beta_inv = b_sq / (2.0 * pgas);
+
+      // electron temperature, T_i/T_e(beta) model (:333-348)
+      theta_e = __longlong_as_double(0x7ff8000000000000ll);
+      kb_tt_e_cgs = theta_e;
+      if (pl.plasma_thermal_frac != 0.0) {
+        double tti_tte = (pl.plasma_rat_high + pl.plasma_rat_low * beta_inv * beta_inv) / (1.0 + beta_inv * beta_inv);
+        double kb_tt_tot_cgs = pl.plasma_mu * kMp * pgas_cgs / rho_cgs;
+        if (pl.plasma_use_p) {
+          kb_tt_e_cgs = (1.0 + pl.plasma_ne_ni) / (tti_tte + pl.plasma_ne_ni) * kb_tt_tot_cgs;
+        } else {
+          kb_tt_e_cgs = (1.0 + pl.plasma_ne_ni) * kb_tt_tot_cgs / (pl.plasma_gamma - 1.0);
+          kb_tt_e_cgs /= tti_tte / (pl.plasma_gamma_i - 1.0) + pl.plasma_ne_ni / (pl.plasma_gamma_e - 1.0);
+        }
+        theta_e = kb_tt_e_cgs / (kMe * kC * kC);
+      }
+
+      // cell cuts (:361-375)
+      bool cell_cut = (pl.cut_rho_min >= 0.0 && rho_cgs < pl.cut_rho_min)
+          || (pl.cut_rho_max >= 0.0 && rho_cgs > pl.cut_rho_max)
+          || (pl.cut_n_e_min >= 0.0 && n_e_cgs < pl.cut_n_e_min)
+          || (pl.cut_n_e_max >= 0.0 && n_e_cgs > pl.cut_n_e_max)
+          || (pl.cut_p_gas_min >= 0.0 && pgas_cgs < pl.cut_p_gas_min)
+          || (pl.cut_p_gas_max >= 0.0 && pgas_cgs > pl.cut_p_gas_max)
+          || (pl.cut_theta_e_min >= 0.0 && theta_e < pl.cut_theta_e_min)
+          || (pl.cut_theta_e_max >= 0.0 && theta_e > pl.cut_theta_e_max)
+          || (pl.cut_b_min >= 0.0 && bb_cgs < pl.cut_b_min)
+          || (pl.cut_b_max >= 0.0 && bb_cgs > pl.cut_b_max)
+          || (pl.cut_sigma_min >= 0.0 && sigma_cut < pl.cut_sigma_min)
+          || (pl.cut_sigma_max >= 0.0 && sigma_cut > pl.cut_sigma_max)
+          || (pl.cut_beta_inverse_min >= 0.0 && beta_inv < pl.cut_beta_inverse_min)
+          || (pl.cut_beta_inverse_max >= 0.0 && beta_inv > pl.cut_beta_inverse_max);
+      bool no_field = bb1_sim == 0.0 && bb2_sim == 0.0 && bb3_sim == 0.0;   // :394
+      if (!cell_cut && !no_field) {
+        // Jacobian to geodesic (CKS) coordinates (radiation_geometry.cpp:69-126)
+        double jac[4][4];
+        for (int mu = 0; mu < 4; mu++)
+          for (int nu = 0; nu < 4; nu++) jac[mu][nu] = mu == nu ? 1.0 : 0.0;
+        if (pl.simulation_coord == BL_COORD_SKS) {
+          double cth = x3 / r;
+          double sth = blm_sqrt(1.0 - cth * cth);
+          double ph = atan2_yx - atan_ar;
+          double sph, cph;
+          bl_sincos(ph, &sph, &cph);
+          jac[1][1] = sth * cph;
+          jac[1][2] = cth * (r * cph - bh_a * sph);
+          jac[1][3] = sth * (-r * sph - bh_a * cph);
+          jac[2][1] = sth * sph;
+          jac[2][2] = cth * (r * sph + bh_a * cph);
+          jac[2][3] = sth * (r * cph - bh_a * sph);
+          jac[3][1] = cth;
+          jac[3][2] = -r * sth;
+          jac[3][3] = 0.0;
+        }
+        double ucon[4], bcon[4];
+        for (int mu = 0; mu < 4; mu++) {
+          double au = 0.0, ab = 0.0;
+          for (int nu = 0; nu < 4; nu++) {
+            au += jac[mu][nu] * ucon_sim[nu];
+            ab += jac[mu][nu] * bcon_sim[nu];
+          }
+          ucon[mu] = au;
+          bcon[mu] = ab;
+        }
+        double gcov[4][4], gcon[4][4];
+        bl_gcov(st, x1, x2, x3, gcov);
+        bl_gcon(st, x1, x2, x3, gcon);
+        double kcon[4], ucov[4], bcov[4];
+        for (int mu = 0; mu < 4; mu++) {
+          double ak = 0.0, au = 0.0, ab = 0.0;
+          for (int nu = 0; nu < 4; nu++) {
+            ak += gcon[mu][nu] * kcov[nu];
+            au += gcov[mu][nu] * ucon[nu];
+            ab += gcov[mu][nu] * bcon[nu];
+          }
+          kcon[mu] = ak;
+          ucov[mu] = au;
+          bcov[mu] = ab;
+        }
+        double tetrad[4][4];
+        tetrad_build(ucon, ucov, kcon, kcov, bcon, gcov, gcon, tetrad);
+        double k_tet[3] = {0.0, 0.0, 0.0}, b_tet[3] = {0.0, 0.0, 0.0};   // :434-455
+        for (int mu = 0; mu < 4; mu++)
+          for (int a = 0; a < 3; a++) {
+            k_tet[a] += tetrad[a + 1][mu] * kcov[mu];
+            b_tet[a] += tetrad[a + 1][mu] * bcov[mu];
+          }
+        double k_sq_tet = k_tet[0] * k_tet[0] + k_tet[1] * k_tet[1] + k_tet[2] * k_tet[2];
+        double b_sq_tet = b_tet[0] * b_tet[0] + b_tet[1] * b_tet[1] + b_tet[2] * b_tet[2];
+        double k_b_tet = k_tet[0] * b_tet[0] + k_tet[1] * b_tet[1] + k_tet[2] * b_tet[2];
+        double cos2_theta_b = std_min(k_b_tet * k_b_tet / (k_sq_tet * b_sq_tet), 1.0);
+        double sin2_theta_b = 1.0 - cos2_theta_b;
+        sin_theta_b = blm_sqrt(sin2_theta_b);
+        double nu_sum = 0.0;   // :461-463
+        for (int mu = 0; mu < 4; mu++) nu_sum -= kcov[mu] * ucon[mu];
+        nu_fluid_over_nu = nu_sum;
+        nu_c_cgs = kE * bb_cgs / (2.0 * kPi * kMe * kC);
+        have_coefficients = true;
+      }
+    }
+
+    // formula model geometry (formula_coefficients.cpp:118-161)
+    double fu[4] = {0.0, 0.0, 0.0, 0.0};
+    if (!skip && kModel == BL_MODEL_FORMULA) {
+      const BlFormulaDevice &fm = P.formula;
+      double rr = blm_sqrt(r * r - x3 * x3);
+      double cth = x3 / r;
+      double sth = blm_sqrt(1.0 - cth * cth);
+      double ph = bl_atan2(x2, x1) - bl_atan(bh_a / r);
+      double sph, cph;
+      bl_sincos(ph, &sph, &cph);
+      double delta = r * r - 2.0 * bh_m * r + bh_a * bh_a;
+      double sigma = r * r + bh_a * bh_a * cth * cth;
+      double gtt_bl = -(1.0 + 2.0 * bh_m * r * (r * r + bh_a * bh_a) / (delta * sigma));
+      double gtph_bl = -2.0 * bh_m * bh_a * r / (delta * sigma);
+      double grr_bl = delta / sigma;
+      double gthth_bl = 1.0 / sigma;
+      double gphph_bl = (sigma - 2.0 * bh_m * r) / (delta * sigma * sth * sth);
+      double ll = fm.l0 / (1.0 + rr) * bl_pow(rr, 1.0 + fm.q);
+      double u_norm = 1.0 / blm_sqrt(-gtt_bl + 2.0 * gtph_bl * ll - gphph_bl * ll * ll);
+      double u_t_bl = -u_norm;
+      double u_r_bl = 0.0;
+      double u_th_bl = 0.0;
+      double u_ph_bl = u_norm * ll;
+      double ut_bl = gtt_bl * u_t_bl + gtph_bl * u_ph_bl;
+      double ur_bl = grr_bl * u_r_bl;
+      double uth_bl = gthth_bl * u_th_bl;
+      double uph_bl = gtph_bl * u_t_bl + gphph_bl * u_ph_bl;
+      double ut = ut_bl + 2.0 * bh_m * r / delta * ur_bl;
+      double ur = ur_bl;
+      double uth = uth_bl;
+      double uph = uph_bl + bh_a / delta * ur_bl;
+      fu[0] = ut;
+      fu[1] = sth * cph * ur + cth * (r * cph - bh_a * sph) * uth + sth * (-r * sph - bh_a * cph) * uph;
+      fu[2] = sth * sph * ur + cth * (r * sph + bh_a * cph) * uth + sth * (r * cph - bh_a * sph) * uph;
+      fu[3] = cth * ur - r * sth * uth;
+      n_n0_fluid = bl_exp(-0.5 * (r * r / (fm.r0 * fm.r0) + fm.h * fm.h * cth * cth));
+      have_coefficients = true;
+    }
+
+    // ---------------- per-frequency coefficients and transfer records
+    for (int l = 0; l < P.n_nu; l++) {
+      double freq = P.frequencies[l];
+      double j_val = 0.0, alpha_val = 0.0;
+      if (have_coefficients && kModel == BL_MODEL_SIMULATION) {
+        // simulation_coefficients.cpp:464-523, thermal electrons, unpolarized
+        const BlPlasmaDevice &pl = P.plasma;
+        double nu_cgs = nu_fluid_over_nu * (freq * momentum_factor);
+        double nu_2_cgs = nu_cgs * nu_cgs;
+        double nu_s_cgs = 2.0 / 9.0 * nu_c_cgs * theta_e * theta_e * sin_theta_b;
+        if (pl.plasma_thermal_frac != 0.0) {
+          double xx = nu_cgs / nu_s_cgs;
+          double xx_1_2 = blm_sqrt(xx);
+          double xx_1_3 = bl_cbrt(xx);
+          double xx_1_6 = blm_sqrt(xx_1_3);
+          double coefficient = pl.plasma_thermal_frac * n_e_cgs * kE * kE * nu_c_cgs / (kC * nu_2_cgs) * bl_exp(-xx_1_3);
+          double var_a = kSqrt2 * kPi / 27.0 * sin_theta_b;
+          double var_b = kPow2_11_12;
+          double var_c = xx_1_2 + var_b * xx_1_6;
+          j_val = coefficient * var_a * var_c * var_c;
+          double b_nu_nu_3_cgs = 2.0 * kH / (kC * kC) / bl_expm1(kH * nu_cgs / kb_tt_e_cgs);
+          alpha_val = j_val / b_nu_nu_3_cgs;
+          if (1.0 / (alpha_val * alpha_val) == __longlong_as_double(0x7ff0000000000000ll)) alpha_val = 0.0;   // :513-523
+        }
+      } else if (have_coefficients && kModel == BL_MODEL_FORMULA) {
+        // formula_coefficients.cpp:164-179
+        const BlFormulaDevice &fm = P.formula;
+        double nu_fluid_cgs = -(fu[0] * kcov[0] + fu[1] * kcov[1] + fu[2] * kcov[2] + fu[3] * kcov[3]) * freq * momentum_factor;
+        double j_nu_fluid_cgs = fm.cn0 * n_n0_fluid * bl_pow(nu_fluid_cgs / fm.nup, -fm.alpha);
+        j_val = j_nu_fluid_cgs / (nu_fluid_cgs * nu_fluid_cgs);
+        double alpha_nu_fluid_cgs = fm.a * fm.cn0 * n_n0_fluid * bl_pow(nu_fluid_cgs / fm.nup, -fm.beta - fm.alpha);
+        alpha_val = alpha_nu_fluid_cgs * nu_fluid_cgs;
+      }
+      double delta_lambda_cgs = delta_lambda * P.x_unit / (freq * momentum_factor);   // unpolarized.cpp:75-76
+      out[l] = transfer_record(j_val, alpha_val, delta_lambda_cgs);
+    }
+  }
+
+  // S_in accounting: one atomic per wave
+  for (int offset = 32; offset > 0; offset >>= 1) gathers_local += __shfl_xor(gathers_local, offset, 64);
+  if ((threadIdx.x & 63) == 0 && gathers_local != 0ull) atomicAdd(&P.counters[BL_CNT_GATHERS], gathers_local);
+}
+
+// =================================================================================================
+// Transfer kernel
+// =================================================================================================
+__global__ void __launch_bounds__(256) bl_transfer_kernel(BlTransferArgs P) {
+  int slot = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long samples = 0ull, flagged = 0ull;
+  int max_num = 0;
+  if (slot < P.chunk_rays) {
+    int num = P.ray_sample_num[slot];
+    bool flag = P.ray_flags[slot] != 0;
+    long long out_index = P.ray_out_index[slot];
+    samples = (unsigned long long)num;
+    flagged = flag ? 1ull : 0ull;
+    max_num = num;
+    if (P.out_sample_num != nullptr) P.out_sample_num[out_index] = num;
+    if (P.out_flags != nullptr) P.out_flags[out_index] = flag ? 1 : 0;
+    const double nan = __longlong_as_double(0x7ff8000000000000ll);
+    for (int l = 0; l < P.n_nu; l++) {
+      double intensity = 0.0;
+      if (P.fallback_nan && flag) {
+        // simulation: every sample of a flagged ray carries NaN primitives
+        // (simulation_sampling.cpp:211-216); formula: only frequency index 0 is NaN-filled
+        // (formula_coefficients.cpp:51-59 indexes a 3-D array with two indices)
+        bool nan_row = P.model_type == BL_MODEL_SIMULATION || l == 0;
+        intensity = (num > 0 && nan_row) ? nan : 0.0;
+      } else {
+        const double2 *rec = P.transfer + (size_t)slot * P.ray_max_steps * P.n_nu + l;
+        // reference sample order is reversed integration order (geodesics.cpp:832-840)
+        for (int n = num - 1; n >= 0; n--) {
+          double2 ab = rec[(size_t)n * P.n_nu];
+          intensity = (ab.x == BL_THICK_MARK) ? ab.y : ab.x * (intensity + ab.y);
+        }
+      }
+      double freq = P.frequencies[l];
+      double nu_cu = freq * freq * freq;   // unpolarized.cpp:206-207
+      P.image[(size_t)l * P.n_rays_total + out_index] = intensity * nu_cu;
+    }
+  }
+  // statistics: wave reduce, one atomic per wave
+  for (int offset = 32; offset > 0; offset >>= 1) {
+    samples += __shfl_xor(samples, offset, 64);
+    flagged += __shfl_xor(flagged, offset, 64);
+    int other = __shfl_xor(max_num, offset, 64);
+    max_num = other > max_num ? other : max_num;
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (samples) atomicAdd(&P.stats[0], samples);
+    if (flagged) atomicAdd(&P.stats[1], flagged);
+    atomicMax(&P.stats[2], (unsigned long long)max_num);
+  }
+}
+
+// =================================================================================================
+// Launch wrappers (called from bl_api.hip)
+// =================================================================================================
+extern "C" hipError_t bl_launch_geodesic(const BlTraceArgs *args, int integrator, int grid, hipStream_t stream) {
+  switch (integrator) {
+    case BL_INTEGRATOR_DP:
+      hipLaunchKernelGGL(bl_geodesic_kernel<BL_INTEGRATOR_DP>, dim3(grid), dim3(64), 0, stream, *args);
+      break;
+    case BL_INTEGRATOR_RK4:
+      hipLaunchKernelGGL(bl_geodesic_kernel<BL_INTEGRATOR_RK4>, dim3(grid), dim3(64), 0, stream, *args);
+      break;
+    default:
+      hipLaunchKernelGGL(bl_geodesic_kernel<BL_INTEGRATOR_RK2>, dim3(grid), dim3(64), 0, stream, *args);
+      break;
+  }
+  return hipGetLastError();
+}
+
+extern "C" int bl_geodesic_occupancy(int integrator) {
+  int blocks = 0;
+  hipError_t err;
+  switch (integrator) {
+    case BL_INTEGRATOR_DP:
+      err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, bl_geodesic_kernel<BL_INTEGRATOR_DP>, 64, 0);
+      break;
+    case BL_INTEGRATOR_RK4:
+      err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, bl_geodesic_kernel<BL_INTEGRATOR_RK4>, 64, 0);
+      break;
+    default:
+      err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, bl_geodesic_kernel<BL_INTEGRATOR_RK2>, 64, 0);
+      break;
+  }
+  if (err != hipSuccess || blocks < 1) blocks = 4;
+  return blocks;
+}
+
+extern "C" hipError_t bl_launch_shade(const BlShadeArgs *args, int model, int grid, hipStream_t stream) {
+  if (model == BL_MODEL_SIMULATION)
+    hipLaunchKernelGGL(bl_shade_kernel<BL_MODEL_SIMULATION>, dim3(grid), dim3(256), 0, stream, *args);
+  else
+    hipLaunchKernelGGL(bl_shade_kernel<BL_MODEL_FORMULA>, dim3(grid), dim3(256), 0, stream, *args);
+  return hipGetLastError();
+}
+
+extern "C" hipError_t bl_launch_transfer(const BlTransferArgs *args, hipStream_t stream) {
+  int grid = (args->chunk_rays + 255) / 256;
+  hipLaunchKernelGGL(bl_transfer_kernel, dim3(grid), dim3(256), 0, stream, *args);
+  return hipGetLastError();
+}

@@ -1,0 +1,50 @@
+"""Helpers shared by the parity tests: load a golden fixture (tests/golden/*.npz, produced by
+tools/make_goldens.py from the compiled reference) and turn it into inputs for the oracle and the
+HIP library."""
+import json
+import os
+
+import numpy as np
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+CASES = sorted(f[:-4] for f in os.listdir(GOLDEN_DIR)
+               if f.endswith(".npz") and not f.startswith("mock_") and not f.startswith("window_"))
+# cases whose parameters are inside the scope of the HIP path today
+GPU_CASES = [c for c in CASES if c != "sim_aux_images"]
+
+FRAME_KEYS = ("cam_x", "u_con", "u_cov", "norm_con", "norm_con_c", "hor_con_c", "vert_con_c")
+
+
+def load_case(name):
+    fx = np.load(os.path.join(GOLDEN_DIR, f"{name}.npz"), allow_pickle=False)
+    params = json.loads(str(fx["params"]))
+    mock_args = json.loads(str(fx["mock_args"])) if "mock_args" in fx.files else None
+    return fx, params, mock_args
+
+
+def golden_grid(mock_args):
+    """Grid built from the arrays the reference's own script wrote (mock_small.npz), not from the
+    build's generator, so that parity tests do not depend on blacklight_amd.mock."""
+    from blacklight_amd.mock import Grid
+    fx = np.load(os.path.join(GOLDEN_DIR, "mock_small.npz"), allow_pickle=False)
+    assert json.loads(str(fx["mock_args"])) == mock_args
+    prim = np.ascontiguousarray(fx["prim"], dtype=np.float32)
+
+    def coord(name):
+        return np.ascontiguousarray(fx[name].astype(np.float32).astype(np.float64).reshape(1, -1))
+
+    return Grid(prim=prim, x1f=coord("x1f"), x2f=coord("x2f"), x3f=coord("x3f"),
+                x1v=coord("x1v"), x2v=coord("x2v"), x3v=coord("x3v"))
+
+
+def expected_image(fx, tier, n_pix):
+    """Rows of image[0] in reference order for the light-only cases: (n_nu, n_pix)."""
+    arr = fx[f"{tier}_npz_I_nu"]
+    return arr.reshape(-1, n_pix)
+
+
+def same_bits(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return (a.view(np.uint64) == b.view(np.uint64)) | (np.isnan(a) & np.isnan(b)) | ((a == 0) & (b == 0))

@@ -1,0 +1,118 @@
+"""GPU parity: the HIP path (through the C-ABI) against the reference's golden vectors and the
+CPU oracle. Integer outputs (sample_num, flags) and, with the pinned math library, every pixel
+must be bit-exact (tier B); against the stock glibc-linked reference (tier A) the stated fp64
+tolerance is per-pixel L-infinity < 1e-6 relative to the image maximum for the a = 0 cases."""
+import numpy as np
+import pytest
+
+import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+
+def _render(case, **extra):
+    import blacklight_amd as bl
+    fx, params, mock_args = gu.load_case(case)
+    params = dict(params)
+    params.update(extra)
+    p = bl.Params.from_dict(params)
+    ctx = bl.Context(p)
+    if mock_args is not None:
+        ctx.set_grid(gu.golden_grid(mock_args))
+    out = ctx.render(want_camera=True)
+    out["frame"] = ctx.camera_frame
+    out["frequencies"] = ctx.frequencies
+    out["warnings"] = ctx.warnings
+    ctx.close()
+    return fx, p, out
+
+
+@pytest.mark.parametrize("case", gu.GPU_CASES)
+def test_tier_b_bit_exact(case, built_library):
+    fx, p, out = _render(case)
+    n_pix = out["sample_num"].size
+    # camera frame and frequencies (host side of the boundary)
+    for key in gu.FRAME_KEYS:
+        assert np.array_equal(np.array(getattr(out["frame"], key)), fx[f"B_{key}"]), key
+    assert np.array_equal(out["frequencies"], fx["B_image_frequencies"])
+    # per-pixel initial conditions at the recorded pixels
+    picks = fx["B_camera_pos_pixels"]
+    assert np.array_equal(out["camera_pos"][picks], fx["B_camera_pos"])
+    assert np.array_equal(out["camera_dir"][picks], fx["B_camera_dir"])
+    # integer outputs: bit-exact
+    assert np.array_equal(out["sample_num"], fx["B_sample_num"])
+    assert np.array_equal(out["sample_flags"], fx["B_sample_flags"])
+    assert out["stats"].max_sample_num == int(fx["B_geodesic_num_steps"])
+    # image: bit-exact (NaN positions included)
+    want = gu.expected_image(fx, "B", n_pix)
+    got = out["image"]
+    assert got.shape == want.shape
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    same = gu.same_bits(got, want)
+    assert same.all(), f"{(~same).sum()} of {same.size} pixels differ; max rel " \
+                       f"{np.nanmax(np.abs(got - want)) / np.nanmax(np.abs(want)):.3e}"
+    # warning text of the reference
+    n_bad = int(fx["B_sample_flags"].sum())
+    if n_bad:
+        assert f"Warning: {n_bad} out of {n_pix} geodesics terminate unexpectedly." in out["warnings"]
+
+
+@pytest.mark.parametrize("case", [c for c in gu.GPU_CASES if c.startswith("sim_") and "spin" not in c])
+def test_tier_a_tolerance(case, built_library):
+    """Against the stock (glibc) reference: a = 0 cases keep sample counts and stay within 1e-6."""
+    fx, p, out = _render(case)
+    n_pix = out["sample_num"].size
+    assert np.array_equal(out["sample_num"], fx["A_sample_num"])
+    assert np.array_equal(out["sample_flags"], fx["A_sample_flags"])
+    want = gu.expected_image(fx, "A", n_pix)
+    got = out["image"]
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    scale = np.nanmax(np.abs(want))
+    if np.isfinite(scale) and scale > 0:
+        assert np.nanmax(np.abs(got - want)) / scale < 1.0e-6
+
+
+@pytest.mark.parametrize("case", ["sim_dp_interp", "formula_dp"])
+def test_pixel_map_and_chunking(case, built_library):
+    """A shuffled pixel subset rendered in several small chunks gives the same bits per pixel."""
+    import blacklight_amd as bl
+    fx, params, mock_args = gu.load_case(case)
+    p = bl.Params.from_dict(params)
+    with bl.Context(p) as ctx:
+        if mock_args is not None:
+            ctx.set_grid(gu.golden_grid(mock_args))
+        full = ctx.render()
+        rng = np.random.default_rng(7)
+        n_pix = full["sample_num"].size
+        subset = rng.permutation(n_pix)[: n_pix // 3].astype(np.int32)
+        per_ray = int(p.get("ray_max_steps")) * 80 + 64
+        ctx.set_scratch_limit(max(per_ray * 100, 1 << 20))   # forces several chunks
+        part = ctx.render(pixel_map=subset)
+        assert part["stats"].n_chunks > 1
+    assert np.array_equal(part["sample_num"], full["sample_num"][subset])
+    assert np.array_equal(part["sample_flags"], full["sample_flags"][subset])
+    assert gu.same_bits(part["image"], full["image"][:, subset]).all()
+
+
+def test_oracle_agreement_other_configuration(built_library):
+    """Seeded variation away from the golden cases: HIP vs CPU oracle, bit-exact."""
+    import blacklight_amd as bl
+    from blacklight_amd import _capi
+    import oracle_api
+    fx, params, mock_args = gu.load_case("sim_dp_interp")
+    params = dict(params)
+    params.update(camera_resolution=40, camera_th=63.0, camera_ph=111.0, camera_rotation=-20.0, simulation_a=0.3,
+                  fallback_nan="false", fallback_rho=1.0e-7, fallback_pgas=1.0e-9, image_frequency=8.6e10,
+                  ray_step=0.02, camera_width=30.0)
+    p = bl.Params.from_dict(params)
+    grid = gu.golden_grid(mock_args)
+    with bl.Context(p) as ctx:
+        ctx.set_grid(grid)
+        got = ctx.render()
+    desc = grid.desc()
+    want = oracle_api.render(p.ptr, desc, _capi.RenderDesc, _capi.CameraFrame, n_rays=40 * 40)
+    assert np.array_equal(got["sample_num"], want["sample_num"])
+    assert np.array_equal(got["sample_flags"], want["sample_flags"])
+    assert gu.same_bits(got["image"], want["image"]).all()
+    assert got["stats"].n_gathers == want["n_gathers"]
+    assert got["stats"].n_samples == want["n_samples"]
