@@ -1,0 +1,251 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path on BASELINE.json's metric:
+Mrays/s (+ achieved HBM GB/s) for a 1024^2 camera over a 256^3 mock GRMHD snapshot.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one complete render (camera -> geodesics -> sampling -> coefficients -> transfer ->
+image in HBM) of the 1024^2 example_simulation camera over the 256^3 mock snapshot, both synthetic
+and generated natively (blacklight_amd.mock restates the reference's generator). The grid is staged
+into HBM once, before the timed region.
+
+Multi-GPU (one process per GPU, torch.distributed nccl = RCCL): the path shards over independent
+rays, so by default every rank renders its own full 1024^2 frame of the replicated snapshot (a
+multi-view job: rank r looks from azimuth 360 r / N degrees) and the frames are gathered on rank 0
+over RCCL - weak scaling, value = all rays of all ranks / max-over-ranks time. `--mode tiled`
+instead splits ONE 1024^2 frame into 32x32-pixel tiles dealt block-cyclically to the ranks and
+gathers the image (strong scaling).
+
+The JSON line also carries
+  roofline     HBM-read roofline of the dominant kernel (bl_shade_kernel): algorithmic bytes
+               (256 B per gathered sample + 13 B per ray) over its HIP-event time
+  cpu_baseline the CPU oracle (a port of the reference's algorithm, oracle/) timed on this host's
+               cores on a bounded sample of the same workload (rank 0, N = 1 only)
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md; 6290 GB/s measured copy ceiling)
+TILE = 32
+
+# input/example_simulation.input of the reference with camera_resolution = 1024
+WORKLOAD = dict(
+    model_type="simulation", num_threads=1, output_format="npz", output_file="bench.npz",
+    output_camera=False, checkpoint_geodesic_save=False, checkpoint_geodesic_load=False,
+    checkpoint_sample_save=False, checkpoint_sample_load=False, simulation_format="athena",
+    simulation_file="mock", simulation_multiple=False, simulation_coord="sks", simulation_a=0.0,
+    simulation_m_msun=4.152e6, simulation_rho_cgs=1.0e-16, simulation_interp=True,
+    simulation_block_interp=False, camera_type="plane", camera_r=50.0, camera_th=45.0,
+    camera_ph=0.0, camera_urn=0.0, camera_uthn=0.0, camera_uphn=0.0, camera_k_r=1.0,
+    camera_k_th=0.0, camera_k_ph=0.0, camera_rotation=0.0, camera_width=24.0,
+    camera_resolution=1024, ray_flat=False, ray_terminate="multiplicative", ray_factor=1.005,
+    ray_integrator="dp", ray_step=0.01, ray_max_steps=2000, ray_max_retries=20, ray_tol_abs=1.0e-8,
+    ray_tol_rel=1.0e-8, image_light=True, image_num_frequencies=1, image_frequency=2.3e11,
+    image_normalization="infinity", image_polarization=False, image_rotation_split=False,
+    image_time=False, image_length=False, image_lambda=False, image_emission=False, image_tau=False,
+    image_lambda_ave=False, image_emission_ave=False, image_tau_int=False, image_crossings=False,
+    render_num_images=0, slow_light_on=False, adaptive_max_level=0, plasma_mu=0.5, plasma_ne_ni=1.0,
+    plasma_model="ti_te_beta", plasma_use_p=True, plasma_rat_low=1.0, plasma_rat_high=10.0,
+    plasma_power_frac=0.0, plasma_kappa_frac=0.0, cut_rho_min=-1.0, cut_rho_max=-1.0,
+    cut_n_e_min=-1.0, cut_n_e_max=-1.0, cut_p_gas_min=-1.0, cut_p_gas_max=-1.0,
+    cut_theta_e_min=-1.0, cut_theta_e_max=-1.0, cut_b_min=-1.0, cut_b_max=-1.0, cut_sigma_min=-1.0,
+    cut_sigma_max=1.0, cut_beta_inverse_min=-1.0, cut_beta_inverse_max=-1.0, cut_omit_near=False,
+    cut_omit_far=False, cut_omit_in=-1.0, cut_omit_out=-1.0, cut_midplane_theta=0.0,
+    cut_midplane_z=0.0, cut_plane=False, fallback_nan=True,
+)
+
+
+def tile_pixels(resolution, rank, world, tile=TILE):
+    """Pixels of the tiles dealt block-cyclically to `rank` (tile t -> rank t % world), tile-major,
+    row-major inside a tile: the order the geodesic kernel wants (compact 2-D patches per wave)."""
+    tiles_per_side = resolution // tile
+    ids = np.arange(rank, tiles_per_side * tiles_per_side, world)
+    ty, tx = ids // tiles_per_side, ids % tiles_per_side
+    yy, xx = np.meshgrid(np.arange(tile), np.arange(tile), indexing="ij")
+    m2 = (ty[:, None, None] * tile + yy[None]).reshape(-1)
+    m1 = (tx[:, None, None] * tile + xx[None]).reshape(-1)
+    return (m2 * resolution + m1).astype(np.int32)
+
+
+def cpu_baseline(params_dict, grid, resolution, stride):
+    """Time the CPU oracle (port of the reference algorithm) on a regular sub-lattice of the camera."""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import oracle_api
+    import blacklight_amd as bl
+    from blacklight_amd import _capi
+    p = bl.Params.from_dict(params_dict)
+    idx = np.arange(stride // 2, resolution, stride)
+    pixels = (idx[:, None] * resolution + idx[None, :]).reshape(-1).astype(np.int32)
+    desc = grid.desc()
+    cores = os.cpu_count() or 1
+    out = oracle_api.render(p.ptr, desc, _capi.RenderDesc, _capi.CameraFrame, n_rays=pixels.size,
+                            pixel_map=pixels, num_threads=cores)
+    return pixels, out, cores
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--mode", choices=["frames", "tiled"], default="frames")
+    ap.add_argument("--resolution", type=int, default=1024)
+    ap.add_argument("--grid", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-stride", type=int, default=4, help="CPU baseline traces every stride-th pixel per axis")
+    args = ap.parse_args()
+
+    import torch
+    import blacklight_amd as bl
+    from blacklight_amd import mock
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if distributed:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    res = args.resolution
+    params_dict = dict(WORKLOAD)
+    params_dict["camera_resolution"] = res
+    if distributed and args.mode == "frames":
+        params_dict["camera_ph"] = 360.0 * rank / world
+    params = bl.Params.from_dict(params_dict)
+    grid = mock.generate(n_r=args.grid, n_th=args.grid, n_ph=args.grid)
+
+    ctx = bl.Context(params, device=local_rank)
+    ctx.set_grid(grid)          # staged into HBM once, outside the timed region
+
+    if args.mode == "tiled" and distributed:
+        pixels = tile_pixels(res, rank, world)
+        n_rays = int(pixels.size)
+    else:
+        pixels = None
+        n_rays = res * res
+    image = torch.empty((1, n_rays), dtype=torch.float64, device=device)
+    sample_num = torch.empty(n_rays, dtype=torch.int32, device=device)
+    flags = torch.empty(n_rays, dtype=torch.uint8, device=device)
+
+    def step():
+        return ctx.render_device(image.data_ptr(), n_rays, pixel_map=pixels,
+                                 sample_num_ptr=sample_num.data_ptr(), sample_flags_ptr=flags.data_ptr())
+
+    def gather_image():
+        """Final image(s) to rank 0 over RCCL (part of the job, inside the timed region)."""
+        if not distributed:
+            return None
+        if rank == 0:
+            parts = [torch.empty_like(image) for _ in range(world)]
+            dist.gather(image, parts, dst=0)
+            return parts
+        dist.gather(image, None, dst=0)
+        return None
+
+    for _ in range(args.warmup):
+        step()
+        gather_image()
+
+    def fence():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    ms = dict(geodesic=0.0, shade=0.0, transfer=0.0)
+    launches_shade = 0
+    stats = None
+    for _ in range(args.steps):
+        stats = step()
+        ms["geodesic"] += stats.ms_geodesic
+        ms["shade"] += stats.ms_shade
+        ms["transfer"] += stats.ms_transfer
+        launches_shade += stats.launches_shade
+        parts = gather_image()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        counts = torch.tensor([float(n_rays), float(stats.n_gathers), float(stats.n_samples)], dtype=torch.float64, device=device)
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+        total_rays, total_gathers, total_samples = (float(x) for x in counts.tolist())
+    else:
+        total_rays, total_gathers, total_samples = float(n_rays), float(stats.n_gathers), float(stats.n_samples)
+
+    if rank == 0:
+        ms_per_step = 1000.0 * elapsed / args.steps
+        value = total_rays / (elapsed / args.steps) / 1.0e6
+        # roofline of the dominant kernel, this rank's launches
+        shade_ms_per_launch = ms["shade"] / max(launches_shade, 1)
+        bytes_per_launch = stats.algorithmic_bytes / max(stats.launches_shade, 1)
+        achieved = bytes_per_launch / (shade_ms_per_launch * 1.0e-3) / 1.0e9
+        traffic = None
+        traffic_file = os.path.join(REPO, "profiles", "hbm_traffic.json")
+        if os.path.exists(traffic_file):
+            with open(traffic_file) as f:
+                traffic = json.load(f).get("bl_shade_kernel_bytes_per_launch")
+        line = {
+            "metric": "Mrays/sec + achieved HBM GB/s, 1024^2 camera over 256^3 GRMHD grid",
+            "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "strong" if (args.mode == "tiled" and distributed) else "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {
+                "workload": f"{res}x{res} plane camera (example_simulation.input) over {args.grid}^3 mock Athena++ GRMHD "
+                            "snapshot, DP integrator, trilinear sampling, thermal synchrotron 230 GHz, unpolarized",
+                "rays_per_step": total_rays, "samples_per_ray": total_samples / total_rays,
+                "parallelism": ("1 GPU" if not distributed else
+                                (f"{world} GPUs, one {res}^2 frame per GPU (views at 360/N deg), grid replicated, frames gathered over RCCL"
+                                 if args.mode == "frames" else
+                                 f"{world} GPUs, one {res}^2 frame in {TILE}x{TILE} tiles dealt block-cyclically, grid replicated, image gathered over RCCL")),
+                "chunks_per_step": stats.n_chunks,
+            },
+            "kernel_ms_per_step": {k: v / args.steps for k, v in ms.items()},
+            "hbm_gbs_algorithmic_whole_pipeline": (256.0 * total_gathers + 13.0 * total_rays) / (elapsed / args.steps) / 1.0e9,
+            "roofline": {"bound": "hbm", "kernel": "bl_shade_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": bytes_per_launch, "ms_per_launch": shade_ms_per_launch},
+        }
+        if not distributed and not args.no_cpu_baseline:
+            pixels_cpu, cpu, cores = cpu_baseline(params_dict, grid, res, args.cpu_stride)
+            line["cpu_baseline"] = {
+                "value": pixels_cpu.size / cpu["seconds"] / 1.0e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+                "sample": f"every {args.cpu_stride}th pixel per axis of the same {res}^2 camera "
+                          f"({pixels_cpu.size} rays, {cpu['seconds']:.1f} s), same grid, OpenMP over all host threads",
+            }
+            # cross-check while we are here: the GPU frame agrees with the oracle on those pixels
+            gpu_img = image[0].cpu().numpy()[pixels_cpu]
+            gpu_num = sample_num.cpu().numpy()[pixels_cpu]
+            same = (gpu_img == cpu["image"][0]) | (np.isnan(gpu_img) & np.isnan(cpu["image"][0]))
+            line["parity_vs_oracle_on_sample"] = {
+                "pixels": int(pixels_cpu.size), "image_bit_exact": bool(same.all()),
+                "sample_num_bit_exact": bool(np.array_equal(gpu_num, cpu["sample_num"])),
+            }
+        print(json.dumps(line), flush=True)
+
+    ctx.close()
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
