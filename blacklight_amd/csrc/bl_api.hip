@@ -21,7 +21,7 @@
 
 extern "C" hipError_t bl_launch_geodesic(const BlTraceArgs *args, int integrator, int grid, hipStream_t stream);
 extern "C" int bl_geodesic_occupancy(int integrator);
-extern "C" hipError_t bl_launch_shade(const BlShadeArgs *args, int model, int grid, hipStream_t stream);
+extern "C" hipError_t bl_launch_shade(const BlShadeArgs *args, int model, int grid, int lds_bytes, hipStream_t stream);
 extern "C" hipError_t bl_launch_transfer(const BlTransferArgs *args, hipStream_t stream);
 
 namespace {
@@ -87,6 +87,7 @@ struct bl_ctx {
   DeviceBuffer<double> d_coords;   // x1f x1v x2f x2v x3f x3v packed
   DeviceBuffer<int> d_buckets;
   BlGridDevice grid_dev{};
+  int lds_table_bytes = 0;
 
   // per-chunk scratch
   DeviceBuffer<BlSampleRecord> d_records;
@@ -97,6 +98,7 @@ struct bl_ctx {
   DeviceBuffer<long long> d_ray_out_index;
   DeviceBuffer<unsigned long long> d_counters;   // BL_CNT_COUNT + 4 stats
   DeviceBuffer<int> d_pixel_map, d_block_locs;
+  DeviceBuffer<BlShadeArgs> d_shade_args;
   // host-output staging
   DeviceBuffer<double> d_image, d_camera_pos, d_camera_dir;
   DeviceBuffer<int> d_out_sample_num;
@@ -427,7 +429,7 @@ int bl_set_grid(bl_ctx *ctx, const bl_grid_desc *g) {
     size_t off_b[3];
     BlGridDevice dev{};
     for (int a = 0; a < 3; a++) {
-      int n_bucket = std::max(1024, 16 * n[a]);
+      int n_bucket = std::max(512, 8 * n[a]);
       std::vector<int> table;
       BuildBuckets(xf[a], n[a], n_bucket, &table, &dev.bucket_x0[a], &dev.bucket_inv_w[a]);
       dev.n_bucket[a] = n_bucket;
@@ -444,6 +446,13 @@ int bl_set_grid(bl_ctx *ctx, const bl_grid_desc *g) {
       dev.n[a] = n[a];
     }
     ctx->grid_dev = dev;
+    {
+      size_t bytes = 0;
+      for (int a = 0; a < 3; a++) bytes += (2 * static_cast<size_t>(n[a]) + 1) * sizeof(double) + static_cast<size_t>(dev.n_bucket[a]) * sizeof(unsigned short);
+      if (bytes > 60 * 1024 || n_i > 65535 || n_j > 65535 || n_k > 65535)
+        throw Failure{BL_E_UNSUPPORTED, "Grid coordinate tables do not fit the 60 KiB LDS budget of the shading kernel."};
+      ctx->lds_table_bytes = static_cast<int>((bytes + 15) / 16 * 16);
+    }
     ctx->grid_meta = *g;
     ctx->n_i = n_i;
     ctx->n_j = n_j;
@@ -605,6 +614,8 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
     sa.cuts.plane_normal[2] = p.cut_plane_normal_z;
     sa.cuts.camera_r = p.camera_r;
     for (int mu = 0; mu < 4; mu++) sa.cuts.cam_x[mu] = ctx->frame.cam_x[mu];
+    sa.cuts.any_optional = (p.cut_omit_near || p.cut_omit_far || p.cut_omit_in >= 0.0 || p.cut_omit_out >= 0.0
+                            || p.cut_midplane_theta != 0.0 || p.cut_midplane_z != 0.0 || p.cut_plane) ? 1 : 0;
     if (simulation) {
       BlPlasmaDevice &pl = sa.plasma;
       pl.d_unit = p.simulation_rho_cgs;                       // simulation_coefficients.cpp:237-239
@@ -631,6 +642,10 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
       pl.cut_b_min = p.cut_b_min; pl.cut_b_max = p.cut_b_max;
       pl.cut_sigma_min = p.cut_sigma_min; pl.cut_sigma_max = p.cut_sigma_max;
       pl.cut_beta_inverse_min = p.cut_beta_inverse_min; pl.cut_beta_inverse_max = p.cut_beta_inverse_max;
+      pl.any_cell_cut = (p.cut_rho_min >= 0.0 || p.cut_rho_max >= 0.0 || p.cut_n_e_min >= 0.0 || p.cut_n_e_max >= 0.0
+                         || p.cut_p_gas_min >= 0.0 || p.cut_p_gas_max >= 0.0 || p.cut_theta_e_min >= 0.0
+                         || p.cut_theta_e_max >= 0.0 || p.cut_b_min >= 0.0 || p.cut_b_max >= 0.0 || p.cut_sigma_min >= 0.0
+                         || p.cut_sigma_max >= 0.0 || p.cut_beta_inverse_min >= 0.0 || p.cut_beta_inverse_max >= 0.0) ? 1 : 0;
       sa.grid = ctx->grid_dev;
     } else {
       BlFormulaDevice &fm = sa.formula;
@@ -647,6 +662,9 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
     sa.ray_max_steps = max_steps;
     sa.x_unit = kGGMsun * ctx->frame.mass_msun / (kC * kC);   // unpolarized.cpp:42
     sa.transfer = ctx->d_transfer.ptr;
+
+    ctx->d_shade_args.Ensure(1);
+    Check(hipMemcpyAsync(ctx->d_shade_args.ptr, &sa, sizeof(BlShadeArgs), hipMemcpyHostToDevice, stream), "shade args upload");
 
     BlTransferArgs xa{};
     xa.transfer = ctx->d_transfer.ptr;
@@ -685,7 +703,7 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
       Check(hipEventRecord(ctx->ev[0], stream), "event");
       Check(bl_launch_geodesic(&ta, p.ray_integrator, std::min(geo_grid, (rays + 63) / 64), stream), "geodesic kernel launch");
       Check(hipEventRecord(ctx->ev[1], stream), "event");
-      Check(bl_launch_shade(&sa, p.model_type, shade_grid, stream), "shade kernel launch");
+      Check(bl_launch_shade(ctx->d_shade_args.ptr, p.model_type, shade_grid, ctx->lds_table_bytes, stream), "shade kernel launch");
       Check(hipEventRecord(ctx->ev[2], stream), "event");
       Check(bl_launch_transfer(&xa, stream), "transfer kernel launch");
       Check(hipEventRecord(ctx->ev[3], stream), "event");
@@ -751,7 +769,7 @@ void bl_free(bl_ctx *ctx) {
   ctx->d_cells.Free(); ctx->d_coords.Free(); ctx->d_buckets.Free(); ctx->d_records.Free(); ctx->d_transfer.Free();
   ctx->d_ray_kt.Free(); ctx->d_ray_factor.Free(); ctx->d_freq.Free(); ctx->d_ray_sample_num.Free();
   ctx->d_ray_flags.Free(); ctx->d_ray_out_index.Free(); ctx->d_counters.Free(); ctx->d_pixel_map.Free();
-  ctx->d_block_locs.Free(); ctx->d_image.Free(); ctx->d_camera_pos.Free(); ctx->d_camera_dir.Free();
+  ctx->d_block_locs.Free(); ctx->d_shade_args.Free(); ctx->d_image.Free(); ctx->d_camera_pos.Free(); ctx->d_camera_dir.Free();
   ctx->d_out_sample_num.Free(); ctx->d_out_flags.Free();
   for (auto &e : ctx->ev)
     if (e != nullptr) (void)hipEventDestroy(e);

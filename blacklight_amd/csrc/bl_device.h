@@ -69,6 +69,7 @@ struct BlPlasmaDevice {
   double cut_rho_min, cut_rho_max, cut_n_e_min, cut_n_e_max, cut_p_gas_min, cut_p_gas_max;
   double cut_theta_e_min, cut_theta_e_max, cut_b_min, cut_b_max, cut_sigma_min, cut_sigma_max;
   double cut_beta_inverse_min, cut_beta_inverse_max;
+  int any_cell_cut;          // some cell cut threshold is >= 0
 };
 
 struct BlFormulaDevice {
@@ -77,6 +78,7 @@ struct BlFormulaDevice {
 
 struct BlCutsDevice {
   int omit_near, omit_far, plane;
+  int any_optional;          // any cut besides r > camera_r is active
   double omit_in, omit_out, midplane_theta, midplane_z;
   double plane_origin[3], plane_normal[3];
   double camera_r;

@@ -100,6 +100,44 @@ BL_HD void bl_gcon(const BlSpacetime &st, double x, double y, double z, double g
   }
 }
 
+// Metric components from already-computed Kerr-Schild scalars (same values as bl_gcov / bl_gcon;
+// lets a caller evaluate bl_kerr_schild once per point instead of once per tensor).
+BL_HD void bl_gcov_ks(const BlKerrSchild &ks, double g[4][4]) {
+  g[0][0] = ks.f - 1.0;
+  for (int i = 0; i < 3; i++) {
+    g[0][i + 1] = ks.fl[i];
+    g[i + 1][0] = ks.fl[i];
+    for (int j = 0; j < 3; j++) g[i + 1][j + 1] = ks.fl[i] * ks.l[j];
+    g[i + 1][i + 1] = ks.fl[i] * ks.l[i] + 1.0;
+  }
+}
+BL_HD void bl_gcon_ks(const BlKerrSchild &ks, double g[4][4]) {
+  g[0][0] = -ks.f - 1.0;
+  for (int i = 0; i < 3; i++) {
+    g[0][i + 1] = ks.fl[i];
+    g[i + 1][0] = ks.fl[i];
+    for (int j = 0; j < 3; j++) g[i + 1][j + 1] = -(ks.fl[i] * ks.l[j]);
+    g[i + 1][i + 1] = -(ks.fl[i] * ks.l[i]) + 1.0;
+  }
+}
+BL_HD void bl_minkowski(double g[4][4]) {
+  for (int mu = 0; mu < 4; mu++)
+    for (int nu = 0; nu < 4; nu++) g[mu][nu] = mu == nu ? (mu == 0 ? -1.0 : 1.0) : 0.0;
+}
+
+// bl_renormalization_factor with the contravariant metric supplied by the caller
+BL_HD double bl_renormalization_factor_g(const double gcon[4][4], double k0, double k1, double k2, double k3) {
+  double k[4] = {k0, k1, k2, k3};
+  double temp_a = 0.0;
+  for (int a = 1; a < 4; a++)
+    for (int b = 1; b < 4; b++) temp_a += gcon[a][b] * k[a] * k[b];
+  double temp_b = 0.0;
+  for (int a = 1; a < 4; a++) temp_b += 2.0 * gcon[0][a] * k[0] * k[a];
+  double temp_c = gcon[0][0] * k[0] * k[0];
+  double temp_d = blm_sqrt(temp_b * temp_b - 4.0 * temp_a * temp_c);
+  return temp_b < 0.0 ? (temp_d - temp_b) / (2.0 * temp_a) : -2.0 * temp_c / (temp_b + temp_d);
+}
+
 // Null-condition renormalisation factor for the spatial covariant momentum
 // (geodesics.cpp:296-309 and :352-371): solves g^{mu nu} k_mu k_nu = 0 for a common factor on k_i.
 BL_HD double bl_renormalization_factor(const BlSpacetime &st, double x, double y, double z,

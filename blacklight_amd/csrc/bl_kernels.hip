@@ -467,22 +467,36 @@ __global__ void __launch_bounds__(64, 1) bl_geodesic_kernel(BlTraceArgs P) {
 // =================================================================================================
 namespace {
 
-// simulation_sampling.cpp:458-466: first cell index c with xf[c+1] >= x, started from a bucket table
-__device__ __forceinline__ int find_cell(const BlGridDevice &g, int axis, double x) {
-  int n = g.n[axis];
-  double t = (x - g.bucket_x0[axis]) * g.bucket_inv_w[axis];
-  int b = (int)t;
+// Coordinate tables of the (single-block) grid staged in LDS: faces and centres of the three axes
+// plus one bucket table per axis. The reference finds a cell by a linear scan over faces
+// (simulation_sampling.cpp:458-466: first c with xf[c+1] >= x); the bucket table gives a start
+// index that is never beyond that result, so a short forward scan lands on the same cell.
+struct GridTables {
+  const double *xf[3];
+  const double *xv[3];
+  const unsigned short *bucket[3];
+};
+
+__device__ __forceinline__ int find_cell(const BlGridDevice &g, const GridTables &t, int axis, double x) {
+  const int n = g.n[axis];
+  double u = (x - g.bucket_x0[axis]) * g.bucket_inv_w[axis];
+  int b = (int)u;
   b = b < 0 ? 0 : (b >= g.n_bucket[axis] ? g.n_bucket[axis] - 1 : b);
-  int c = g.bucket[axis][b];
-  const double *xf = g.xf[axis];
-  while (c < n - 1 && !(xf[c + 1] >= x)) c++;
-  if (!(xf[c + 1] >= x)) c = n;   // loop ran off the end (cannot happen after the block test)
+  int c = t.bucket[axis][b];
+  const double *xf = t.xf[axis];
+  // straight-line common case (the answer is c or c + 1), then the general forward scan
+  double f1 = xf[c + 1];
+  double f2 = xf[(c + 2 <= n) ? c + 2 : n];
+  if (!(f1 >= x)) {
+    c += 1;
+    if (!(f2 >= x)) {
+      c += 1;
+      while (c < n - 1 && !(xf[c + 1] >= x)) c++;
+    }
+  }
+  if (c > n - 1) c = n - 1;
   return c;
 }
-
-struct Prims {
-  float rho, pgas, uu1, uu2, uu3, bb1, bb2, bb3;
-};
 
 __device__ __forceinline__ void load_cell(const BlGridDevice &g, int k, int j, int i, float v[8]) {
   size_t idx = (((size_t)k * g.n[1] + j) * g.n[0] + i) * 8;
@@ -534,9 +548,9 @@ __device__ __forceinline__ void tetrad_build(const double ucon[4], const double 
   }
 }
 
-// Geometric cuts (simulation_sampling.cpp:237-292, formula_coefficients.cpp:73-116)
-__device__ __forceinline__ bool geometric_cut(const BlCutsDevice &c, double x1, double x2, double x3, double r) {
-  if (r > c.camera_r) return true;
+// Optional geometric cuts (simulation_sampling.cpp:246-292, formula_coefficients.cpp:78-116); the
+// unconditional r > camera_r cut (:238-243) is applied by the caller.
+__device__ __forceinline__ bool optional_cuts(const BlCutsDevice &c, double x1, double x2, double x3, double r) {
   if (c.omit_near || c.omit_far) {
     double dot_product = x1 * c.cam_x[1] + x2 * c.cam_x[2] + x3 * c.cam_x[3];
     if ((c.omit_near && dot_product > 0.0) || (c.omit_far && dot_product < 0.0)) return true;
@@ -578,14 +592,376 @@ __device__ __forceinline__ double2 transfer_record(double j, double alpha, doubl
   return rec;
 }
 
+// Everything the per-frequency loop needs from the per-sample (frequency independent) work
+struct SampleShade {
+  bool have_coefficients;      // false: j = alpha = 0 at every frequency
+  double nu_fluid_over_nu;     // -k_mu u^mu (fluid-frame frequency per unit camera frequency*factor)
+  double n_e_cgs, nu_c_cgs, theta_e, sin_theta_b, kb_tt_e_cgs;   // simulation
+  double n_n0_fluid, fu[4];                                       // formula
+};
+
+// Simulation mode, one sample: CKS -> SKS, cell search, gather + trilinear interpolation
+// (simulation_sampling.cpp:295-575, :666-1033) and the frequency-independent part of
+// CalculateSimulationCoefficients (simulation_coefficients.cpp:253-455).
+__device__ __forceinline__ void shade_simulation(const BlShadeArgs &P, const GridTables &tab, const BlSpacetime &st,
+                                                 const BlKerrSchild &ks, double x1, double x2, double x3,
+                                                 const double kcov[4], unsigned long long *gathers,
+                                                 SampleShade *out) {
+  const BlPlasmaDevice &pl = P.plasma;
+  const BlGridDevice &g = P.grid;
+  const double bh_a = st.bh_a, bh_m = st.bh_m;
+  const double r = ks.r, r2 = ks.r2, a2 = ks.a2;
+  const bool sks = pl.simulation_coord == BL_COORD_SKS;
+
+  // ConvertFromCKS (radiation_geometry.cpp:37-57); z / r is also cos(theta) of the SKS metric and
+  // of the Jacobian below (same expression there)
+  const double cth = x3 / r;
+  double s1 = x1, s2 = x2, s3 = x3;
+  double ph_unwrapped = 0.0;
+  if (sks) {
+    double th = bl_acos(cth);
+    ph_unwrapped = bl_atan2(x2, x1) - bl_atan(bh_a / r);
+    double ph = ph_unwrapped;
+    ph += ph < 0.0 ? 2.0 * kPi : 0.0;
+    ph -= ph >= 2.0 * kPi ? 2.0 * kPi : 0.0;
+    s1 = r;
+    s2 = th;
+    s3 = ph;
+  }
+
+  float pr[8];   // rho, pgas, uu1, uu2, uu3, bb1, bb2, bb3
+  const int n_i = g.n[0], n_j = g.n[1], n_k = g.n[2];
+  // block test (simulation_sampling.cpp:352-394), single block
+  if (s1 < tab.xf[0][0] || s1 > tab.xf[0][n_i] || s2 < tab.xf[1][0] || s2 > tab.xf[1][n_j]
+      || s3 < tab.xf[2][0] || s3 > tab.xf[2][n_k]) {
+    const float fnan = __int_as_float(0x7fc00000);
+    pr[0] = pl.fallback_nan ? fnan : pl.fallback_rho;    // :377-384, :678-706
+    pr[1] = pl.fallback_nan ? fnan : pl.fallback_pgas;
+    for (int v = 2; v < 8; v++) pr[v] = pl.fallback_nan ? fnan : 0.0f;
+  } else {
+    int i = find_cell(g, tab, 0, s1);
+    int j = find_cell(g, tab, 1, s2);
+    int k = find_cell(g, tab, 2, s3);
+    *gathers += 1ull;
+    if (!pl.simulation_interp) {   // :710-734
+      load_cell(g, k, j, i, pr);
+    } else {                       // :485-490, :809-839
+      int i_m = (i == 0 || (i != n_i - 1 && s1 >= tab.xv[0][i])) ? i : i - 1;
+      int j_m = (j == 0 || (j != n_j - 1 && s2 >= tab.xv[1][j])) ? j : j - 1;
+      int k_m = (k == 0 || (k != n_k - 1 && s3 >= tab.xv[2][k])) ? k : k - 1;
+      double f_i = (s1 - tab.xv[0][i_m]) / (tab.xv[0][i_m + 1] - tab.xv[0][i_m]);
+      double f_j = (s2 - tab.xv[1][j_m]) / (tab.xv[1][j_m + 1] - tab.xv[1][j_m]);
+      double f_k = (s3 - tab.xv[2][k_m]) / (tab.xv[2][k_m + 1] - tab.xv[2][k_m]);
+      // InterpolateSimple sums w_c * v_c over the corners in the order mmm, mmp, mpm, mpp, pmm,
+      // pmp, ppm, ppp (:1345-1349); accumulating corner by corner keeps that order.
+      double w_k[2] = {1.0 - f_k, f_k}, w_j[2] = {1.0 - f_j, f_j}, w_i[2] = {1.0 - f_i, f_i};
+      double val[8];
+      float first[8];
+#pragma unroll
+      for (int corner = 0; corner < 8; corner++) {
+        const int dk = corner >> 2, dj = (corner >> 1) & 1, di = corner & 1;
+        float c[8];
+        load_cell(g, k_m + dk, j_m + dj, i_m + di, c);
+        double w = w_k[dk] * w_j[dj] * w_i[di];
+#pragma unroll
+        for (int v = 0; v < 8; v++) {
+          if (corner == 0) {
+            val[v] = w * (double)c[v];
+            first[v] = c[v];
+          } else {
+            val[v] += w * (double)c[v];
+          }
+        }
+      }
+      if (val[0] <= 0.0) val[0] = (double)first[0];   // :822-825
+      if (val[1] <= 0.0) val[1] = (double)first[1];
+#pragma unroll
+      for (int v = 0; v < 8; v++) pr[v] = (float)val[v];   // :830-839
+    }
+  }
+
+  // ---------------- coefficients (simulation_coefficients.cpp:274-455)
+  const double rho = pr[0], pgas = pr[1];
+  const double uu1 = pr[2], uu2 = pr[3], uu3 = pr[4];
+  const double bb1 = pr[5], bb2 = pr[6], bb3 = pr[7];
+  const double rho_cgs = rho * pl.d_unit;
+  const double pgas_cgs = pgas * pl.e_unit;
+  const double n_cgs = rho_cgs / (pl.plasma_mu * kMp);
+  const double n_e_cgs = n_cgs / (1.0 + 1.0 / pl.plasma_ne_ni);
+
+  // Velocity and field in simulation coordinates (:292-330). In SKS the metric is sparse
+  // (radiation_geometry.cpp:462-489, :543-571); sums that the reference runs over all 16 entries
+  // are evaluated over the non-zero ones, which is exact (the dropped terms are 0 * finite = +-0).
+  double ucon_sim[4], bcon_sim[4], b_sq;
+  if (sks) {
+    const double cth2 = cth * cth;
+    const double sth2 = 1.0 - cth2;
+    const double delta = r2 - 2.0 * bh_m * r + a2;
+    const double sigma = r2 + a2 * cth2;
+    const double g00 = -(1.0 - 2.0 * bh_m * r / sigma);
+    const double g01 = 2.0 * bh_m * r / sigma;
+    const double g03 = -2.0 * bh_m * bh_a * r * sth2 / sigma;
+    const double g11 = 1.0 + 2.0 * bh_m * r / sigma;
+    const double g13 = -(1.0 + 2.0 * bh_m * r / sigma) * bh_a * sth2;
+    const double g22 = sigma;
+    const double g33 = (r2 + a2 + 2.0 * bh_m * a2 * r * sth2 / sigma) * sth2;
+    const double gc00 = -(1.0 + 2.0 * bh_m * r / sigma);
+    const double gc01 = 2.0 * bh_m * r / sigma;
+    (void)delta;
+    // uu0 (:297-300): gcov_sim[1][2] = gcov_sim[2][3] = 0
+    const double uu0 = blm_sqrt(1.0 + g11 * uu1 * uu1 + 2.0 * 0.0 * uu1 * uu2 + 2.0 * g13 * uu1 * uu3
+        + g22 * uu2 * uu2 + 2.0 * 0.0 * uu2 * uu3 + g33 * uu3 * uu3);
+    const double lapse = 1.0 / blm_sqrt(-gc00);
+    const double shift1 = -gc01 / gc00;
+    const double shift2 = -0.0 / gc00;
+    const double shift3 = -0.0 / gc00;
+    ucon_sim[0] = uu0 / lapse;
+    ucon_sim[1] = uu1 - shift1 * uu0 / lapse;
+    ucon_sim[2] = uu2 - shift2 * uu0 / lapse;
+    ucon_sim[3] = uu3 - shift3 * uu0 / lapse;
+    // ucov_sim[mu] = sum_nu gcov_sim[mu][nu] ucon_sim[nu] (:310-313), non-zero entries only
+    const double ucov1 = (g01 * ucon_sim[0] + g11 * ucon_sim[1]) + g13 * ucon_sim[3];
+    const double ucov2 = g22 * ucon_sim[2];
+    const double ucov3 = (g03 * ucon_sim[0] + g13 * ucon_sim[1]) + g33 * ucon_sim[3];
+    bcon_sim[0] = ucov1 * bb1 + ucov2 * bb2 + ucov3 * bb3;
+    bcon_sim[1] = (bb1 + bcon_sim[0] * ucon_sim[1]) / ucon_sim[0];
+    bcon_sim[2] = (bb2 + bcon_sim[0] * ucon_sim[2]) / ucon_sim[0];
+    bcon_sim[3] = (bb3 + bcon_sim[0] * ucon_sim[3]) / ucon_sim[0];
+    const double bcov0 = (g00 * bcon_sim[0] + g01 * bcon_sim[1]) + g03 * bcon_sim[3];
+    const double bcov1 = (g01 * bcon_sim[0] + g11 * bcon_sim[1]) + g13 * bcon_sim[3];
+    const double bcov2 = g22 * bcon_sim[2];
+    const double bcov3 = (g03 * bcon_sim[0] + g13 * bcon_sim[1]) + g33 * bcon_sim[3];
+    b_sq = bcov0 * bcon_sim[0] + bcov1 * bcon_sim[1] + bcov2 * bcon_sim[2] + bcov3 * bcon_sim[3];
+  } else {
+    // Cartesian Kerr-Schild simulation: same metric as the geodesic one, never flat
+    double gs_cov[4][4], gs_con[4][4];
+    bl_gcov_ks(ks, gs_cov);
+    bl_gcon_ks(ks, gs_con);
+    const double uu0 = blm_sqrt(1.0 + gs_cov[1][1] * uu1 * uu1 + 2.0 * gs_cov[1][2] * uu1 * uu2
+        + 2.0 * gs_cov[1][3] * uu1 * uu3 + gs_cov[2][2] * uu2 * uu2 + 2.0 * gs_cov[2][3] * uu2 * uu3
+        + gs_cov[3][3] * uu3 * uu3);
+    const double lapse = 1.0 / blm_sqrt(-gs_con[0][0]);
+    const double shift1 = -gs_con[0][1] / gs_con[0][0];
+    const double shift2 = -gs_con[0][2] / gs_con[0][0];
+    const double shift3 = -gs_con[0][3] / gs_con[0][0];
+    ucon_sim[0] = uu0 / lapse;
+    ucon_sim[1] = uu1 - shift1 * uu0 / lapse;
+    ucon_sim[2] = uu2 - shift2 * uu0 / lapse;
+    ucon_sim[3] = uu3 - shift3 * uu0 / lapse;
+    double ucov_sim[4];
+    for (int mu = 0; mu < 4; mu++) {
+      double acc = 0.0;
+      for (int nu = 0; nu < 4; nu++) acc += gs_cov[mu][nu] * ucon_sim[nu];
+      ucov_sim[mu] = acc;
+    }
+    bcon_sim[0] = ucov_sim[1] * bb1 + ucov_sim[2] * bb2 + ucov_sim[3] * bb3;
+    bcon_sim[1] = (bb1 + bcon_sim[0] * ucon_sim[1]) / ucon_sim[0];
+    bcon_sim[2] = (bb2 + bcon_sim[0] * ucon_sim[2]) / ucon_sim[0];
+    bcon_sim[3] = (bb3 + bcon_sim[0] * ucon_sim[3]) / ucon_sim[0];
+    b_sq = 0.0;
+    for (int mu = 0; mu < 4; mu++) {
+      double acc = 0.0;
+      for (int nu = 0; nu < 4; nu++) acc += gs_cov[mu][nu] * bcon_sim[nu];
+      b_sq += acc * bcon_sim[mu];
+    }
+  }
+  const double bb_cgs = blm_sqrt(b_sq) * pl.b_unit;
+  const double sigma_cut = b_sq / rho;
+  const double beta_inv = b_sq / (2.0 * pgas);
+
+  // electron temperature, T_i/T_e(beta) model (:333-348)
+  double theta_e = __longlong_as_double(0x7ff8000000000000ll);
+  double kb_tt_e_cgs = theta_e;
+  if (pl.plasma_thermal_frac != 0.0) {
+    double tti_tte = (pl.plasma_rat_high + pl.plasma_rat_low * beta_inv * beta_inv) / (1.0 + beta_inv * beta_inv);
+    double kb_tt_tot_cgs = pl.plasma_mu * kMp * pgas_cgs / rho_cgs;
+    if (pl.plasma_use_p) {
+      kb_tt_e_cgs = (1.0 + pl.plasma_ne_ni) / (tti_tte + pl.plasma_ne_ni) * kb_tt_tot_cgs;
+    } else {
+      kb_tt_e_cgs = (1.0 + pl.plasma_ne_ni) * kb_tt_tot_cgs / (pl.plasma_gamma - 1.0);
+      kb_tt_e_cgs /= tti_tte / (pl.plasma_gamma_i - 1.0) + pl.plasma_ne_ni / (pl.plasma_gamma_e - 1.0);
+    }
+    theta_e = kb_tt_e_cgs / (kMe * kC * kC);
+  }
+
+  // cell cuts (:361-375); all thresholds negative = disabled is the common case
+  bool cell_cut = false;
+  if (pl.any_cell_cut) {
+    cell_cut = (pl.cut_rho_min >= 0.0 && rho_cgs < pl.cut_rho_min)
+        || (pl.cut_rho_max >= 0.0 && rho_cgs > pl.cut_rho_max)
+        || (pl.cut_n_e_min >= 0.0 && n_e_cgs < pl.cut_n_e_min)
+        || (pl.cut_n_e_max >= 0.0 && n_e_cgs > pl.cut_n_e_max)
+        || (pl.cut_p_gas_min >= 0.0 && pgas_cgs < pl.cut_p_gas_min)
+        || (pl.cut_p_gas_max >= 0.0 && pgas_cgs > pl.cut_p_gas_max)
+        || (pl.cut_theta_e_min >= 0.0 && theta_e < pl.cut_theta_e_min)
+        || (pl.cut_theta_e_max >= 0.0 && theta_e > pl.cut_theta_e_max)
+        || (pl.cut_b_min >= 0.0 && bb_cgs < pl.cut_b_min)
+        || (pl.cut_b_max >= 0.0 && bb_cgs > pl.cut_b_max)
+        || (pl.cut_sigma_min >= 0.0 && sigma_cut < pl.cut_sigma_min)
+        || (pl.cut_sigma_max >= 0.0 && sigma_cut > pl.cut_sigma_max)
+        || (pl.cut_beta_inverse_min >= 0.0 && beta_inv < pl.cut_beta_inverse_min)
+        || (pl.cut_beta_inverse_max >= 0.0 && beta_inv > pl.cut_beta_inverse_max);
+  }
+  const bool no_field = bb1 == 0.0 && bb2 == 0.0 && bb3 == 0.0;   // :394
+  out->have_coefficients = false;
+  if (cell_cut || no_field) return;
+
+  // Transform u and b to geodesic (CKS) coordinates (:398-408). The Jacobian of
+  // radiation_geometry.cpp:69-126 has row/column 0 = identity and jacobian[3][3] = 0; the products
+  // with those 0 / 1 entries are dropped (exact).
+  double ucon[4], bcon[4];
+  if (sks) {
+    const double sth = blm_sqrt(1.0 - cth * cth);
+    double sph, cph;
+    bl_sincos(ph_unwrapped, &sph, &cph);
+    const double j11 = sth * cph;
+    const double j12 = cth * (r * cph - bh_a * sph);
+    const double j13 = sth * (-r * sph - bh_a * cph);
+    const double j21 = sth * sph;
+    const double j22 = cth * (r * sph + bh_a * cph);
+    const double j23 = sth * (r * cph - bh_a * sph);
+    const double j31 = cth;
+    const double j32 = -r * sth;
+    ucon[0] = ucon_sim[0];
+    ucon[1] = (j11 * ucon_sim[1] + j12 * ucon_sim[2]) + j13 * ucon_sim[3];
+    ucon[2] = (j21 * ucon_sim[1] + j22 * ucon_sim[2]) + j23 * ucon_sim[3];
+    ucon[3] = j31 * ucon_sim[1] + j32 * ucon_sim[2];
+    bcon[0] = bcon_sim[0];
+    bcon[1] = (j11 * bcon_sim[1] + j12 * bcon_sim[2]) + j13 * bcon_sim[3];
+    bcon[2] = (j21 * bcon_sim[1] + j22 * bcon_sim[2]) + j23 * bcon_sim[3];
+    bcon[3] = j31 * bcon_sim[1] + j32 * bcon_sim[2];
+  } else {
+    for (int mu = 0; mu < 4; mu++) {
+      ucon[mu] = ucon_sim[mu];
+      bcon[mu] = bcon_sim[mu];
+    }
+  }
+  // kcon, ucov, bcov in the geodesic metric (:411-428); the metric is rebuilt from the Kerr-Schild
+  // scalars here (a dozen multiplies) rather than kept live across the gather
+  double gcov[4][4], gcon[4][4];
+  if (st.ray_flat) {
+    bl_minkowski(gcov);
+    bl_minkowski(gcon);
+  } else {
+    bl_gcov_ks(ks, gcov);
+    bl_gcon_ks(ks, gcon);
+  }
+  double kcon[4], ucov[4], bcov[4];
+  for (int mu = 0; mu < 4; mu++) {
+    double ak = 0.0, au = 0.0, ab = 0.0;
+    for (int nu = 0; nu < 4; nu++) {
+      ak += gcon[mu][nu] * kcov[nu];
+      au += gcov[mu][nu] * ucon[nu];
+      ab += gcov[mu][nu] * bcon[nu];
+    }
+    kcon[mu] = ak;
+    ucov[mu] = au;
+    bcov[mu] = ab;
+  }
+  double tetrad[4][4];
+  tetrad_build(ucon, ucov, kcon, kcov, bcon, gcov, gcon, tetrad);
+  double k_tet[3] = {0.0, 0.0, 0.0}, b_tet[3] = {0.0, 0.0, 0.0};   // :434-455
+  for (int mu = 0; mu < 4; mu++)
+    for (int a = 0; a < 3; a++) {
+      k_tet[a] += tetrad[a + 1][mu] * kcov[mu];
+      b_tet[a] += tetrad[a + 1][mu] * bcov[mu];
+    }
+  const double k_sq_tet = k_tet[0] * k_tet[0] + k_tet[1] * k_tet[1] + k_tet[2] * k_tet[2];
+  const double b_sq_tet = b_tet[0] * b_tet[0] + b_tet[1] * b_tet[1] + b_tet[2] * b_tet[2];
+  const double k_b_tet = k_tet[0] * b_tet[0] + k_tet[1] * b_tet[1] + k_tet[2] * b_tet[2];
+  const double cos2_theta_b = std_min(k_b_tet * k_b_tet / (k_sq_tet * b_sq_tet), 1.0);
+  const double sin2_theta_b = 1.0 - cos2_theta_b;
+  double nu_sum = 0.0;   // :461-463
+  for (int mu = 0; mu < 4; mu++) nu_sum -= kcov[mu] * ucon[mu];
+  out->have_coefficients = true;
+  out->nu_fluid_over_nu = nu_sum;
+  out->n_e_cgs = n_e_cgs;
+  out->nu_c_cgs = kE * bb_cgs / (2.0 * kPi * kMe * kC);
+  out->theta_e = theta_e;
+  out->sin_theta_b = blm_sqrt(sin2_theta_b);
+  out->kb_tt_e_cgs = kb_tt_e_cgs;
+}
+
+// Formula mode, one sample (formula_coefficients.cpp:118-161)
+__device__ __forceinline__ void shade_formula(const BlShadeArgs &P, const BlSpacetime &st, double r, double x1,
+                                              double x2, double x3, SampleShade *out) {
+  const BlFormulaDevice &fm = P.formula;
+  const double bh_a = st.bh_a, bh_m = st.bh_m;
+  double rr = blm_sqrt(r * r - x3 * x3);
+  double cth = x3 / r;
+  double sth = blm_sqrt(1.0 - cth * cth);
+  double ph = bl_atan2(x2, x1) - bl_atan(bh_a / r);
+  double sph, cph;
+  bl_sincos(ph, &sph, &cph);
+  double delta = r * r - 2.0 * bh_m * r + bh_a * bh_a;
+  double sigma = r * r + bh_a * bh_a * cth * cth;
+  double gtt_bl = -(1.0 + 2.0 * bh_m * r * (r * r + bh_a * bh_a) / (delta * sigma));
+  double gtph_bl = -2.0 * bh_m * bh_a * r / (delta * sigma);
+  double grr_bl = delta / sigma;
+  double gthth_bl = 1.0 / sigma;
+  double gphph_bl = (sigma - 2.0 * bh_m * r) / (delta * sigma * sth * sth);
+  double ll = fm.l0 / (1.0 + rr) * bl_pow(rr, 1.0 + fm.q);
+  double u_norm = 1.0 / blm_sqrt(-gtt_bl + 2.0 * gtph_bl * ll - gphph_bl * ll * ll);
+  double u_t_bl = -u_norm;
+  double u_r_bl = 0.0;
+  double u_th_bl = 0.0;
+  double u_ph_bl = u_norm * ll;
+  double ut_bl = gtt_bl * u_t_bl + gtph_bl * u_ph_bl;
+  double ur_bl = grr_bl * u_r_bl;
+  double uth_bl = gthth_bl * u_th_bl;
+  double uph_bl = gtph_bl * u_t_bl + gphph_bl * u_ph_bl;
+  double ut = ut_bl + 2.0 * bh_m * r / delta * ur_bl;
+  double ur = ur_bl;
+  double uth = uth_bl;
+  double uph = uph_bl + bh_a / delta * ur_bl;
+  out->fu[0] = ut;
+  out->fu[1] = sth * cph * ur + cth * (r * cph - bh_a * sph) * uth + sth * (-r * sph - bh_a * cph) * uph;
+  out->fu[2] = sth * sph * ur + cth * (r * sph + bh_a * cph) * uth + sth * (r * cph - bh_a * sph) * uph;
+  out->fu[3] = cth * ur - r * sth * uth;
+  out->n_n0_fluid = bl_exp(-0.5 * (r * r / (fm.r0 * fm.r0) + fm.h * fm.h * cth * cth));
+  out->have_coefficients = true;
+}
+
 }  // namespace
 
 template <int kModel>
-__global__ void __launch_bounds__(256) bl_shade_kernel(BlShadeArgs P) {
+__global__ void __launch_bounds__(256, 1) bl_shade_kernel(const BlShadeArgs *__restrict__ args) {
+  // Arguments live in HBM / scalar cache and are fetched with s_load where they are used: by value
+  // they would all be pinned in SGPRs for the whole kernel (and spilled to VGPR lanes).
+  const BlShadeArgs &P = *args;
   const BlSpacetime st = P.st;
+
+  // ---- stage the grid's coordinate tables in LDS (simulation mode)
+  extern __shared__ double lds_tables[];
+  GridTables tab;
+  if (kModel == BL_MODEL_SIMULATION) {
+    const BlGridDevice &g = P.grid;
+    double *dst = lds_tables;
+    for (int a = 0; a < 3; a++) {
+      tab.xf[a] = dst;
+      for (int i = threadIdx.x; i <= g.n[a]; i += blockDim.x) dst[i] = g.xf[a][i];
+      dst += g.n[a] + 1;
+      tab.xv[a] = dst;
+      for (int i = threadIdx.x; i < g.n[a]; i += blockDim.x) dst[i] = g.xv[a][i];
+      dst += g.n[a];
+    }
+    unsigned short *bdst = reinterpret_cast<unsigned short *>(dst);
+    for (int a = 0; a < 3; a++) {
+      tab.bucket[a] = bdst;
+      for (int i = threadIdx.x; i < g.n_bucket[a]; i += blockDim.x) bdst[i] = (unsigned short)g.bucket[a][i];
+      bdst += g.n_bucket[a];
+    }
+    __syncthreads();
+  } else {
+    for (int a = 0; a < 3; a++) {
+      tab.xf[a] = nullptr;
+      tab.xv[a] = nullptr;
+      tab.bucket[a] = nullptr;
+    }
+  }
+
   const unsigned long long n_records = P.counters_in[BL_CNT_RECORDS];
   unsigned long long gathers_local = 0ull;
-  const double bh_a = st.bh_a, bh_m = st.bh_m;
 
   for (unsigned long long idx = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; idx < n_records;
        idx += (unsigned long long)gridDim.x * blockDim.x) {
@@ -595,374 +971,85 @@ __global__ void __launch_bounds__(256) bl_shade_kernel(BlShadeArgs P) {
     uint32_t ray = (uint32_t)__double_as_longlong(q3.y);
     uint32_t n = (uint32_t)(((unsigned long long)__double_as_longlong(q3.y)) >> 32);
     if (ray == BL_DEAD_RAY) continue;
-    double x1 = q0.x, x2 = q0.y, x3 = q1.x;
+    const double x1 = q0.x, x2 = q0.y, x3 = q1.x;
     double kcov[4];
     kcov[0] = P.ray_kt[ray];
     kcov[1] = q1.y;
     kcov[2] = q2.x;
     kcov[3] = q2.y;
-    double len = q3.x;
-    double momentum_factor = P.ray_factor[ray];
+    const double delta_lambda = -q3.x;   // ReverseGeodesics: sample_len = -geodesic_len (:840)
+    const double momentum_factor = P.ray_factor[ray];
     double2 *out = P.transfer + ((size_t)ray * P.ray_max_steps + n) * P.n_nu;
 
+    // Kerr-Schild scalars at the sample: evaluated once, shared by the renormalisation, the cuts,
+    // the coordinate conversion, the simulation metric and the geodesic metric (the reference
+    // recomputes them in each of those functions; identical inputs, identical bits)
+    BlKerrSchild ks;
+    bl_kerr_schild(st, x1, x2, x3, &ks);
     // per-sample renormalisation of the stored momentum (geodesics.cpp:352-371)
     {
-      double factor = bl_renormalization_factor(st, x1, x2, x3, kcov[0], kcov[1], kcov[2], kcov[3]);
+      double gcon[4][4];
+      if (st.ray_flat)
+        bl_minkowski(gcon);
+      else
+        bl_gcon_ks(ks, gcon);
+      double factor = bl_renormalization_factor_g(gcon, kcov[0], kcov[1], kcov[2], kcov[3]);
       kcov[1] *= factor;
       kcov[2] *= factor;
       kcov[3] *= factor;
     }
-    double delta_lambda = -len;   // ReverseGeodesics: sample_len = -geodesic_len (:840)
 
-    double r = bl_radial_coordinate(st, x1, x2, x3);
-    bool skip = geometric_cut(P.cuts, x1, x2, x3, r);
-    bool have_coefficients = false;   // false -> j = alpha = 0 for every frequency
-    // quantities shared by all frequencies
-    double nu_fluid_over_nu = 0.0;    // -k_mu u^mu * factor
-    // simulation
-    double n_e_cgs = 0.0, nu_c_cgs = 0.0, theta_e = 0.0, sin_theta_b = 0.0, kb_tt_e_cgs = 0.0;
-    // formula
-    double n_n0_fluid = 0.0;
+    const double r = ks.r;
+    bool skip = r > P.cuts.camera_r;                                   // simulation_sampling.cpp:238-243
+    if (!skip && P.cuts.any_optional) skip = optional_cuts(P.cuts, x1, x2, x3, r);
 
-    if (!skip && kModel == BL_MODEL_SIMULATION) {
-      const BlPlasmaDevice &pl = P.plasma;
-      const BlGridDevice &g = P.grid;
-      // ConvertFromCKS (radiation_geometry.cpp:37-57)
-      double s1 = x1, s2 = x2, s3 = x3;
-      double atan2_yx = 0.0, atan_ar = 0.0;
-      if (pl.simulation_coord == BL_COORD_SKS) {
-        double th = bl_acos(x3 / r);
-        atan2_yx = bl_atan2(x2, x1);
-        atan_ar = bl_atan(bh_a / r);
-        double ph = atan2_yx - atan_ar;
-        ph += ph < 0.0 ? 2.0 * kPi : 0.0;
-        ph -= ph >= 2.0 * kPi ? 2.0 * kPi : 0.0;
-        s1 = r;
-        s2 = th;
-        s3 = ph;
-      }
-      Prims pr;
-      bool valid = true;
-      // block test (simulation_sampling.cpp:352-394), single block
-      if (s1 < g.xf[0][0] || s1 > g.xf[0][g.n[0]] || s2 < g.xf[1][0] || s2 > g.xf[1][g.n[1]]
-          || s3 < g.xf[2][0] || s3 > g.xf[2][g.n[2]]) {
-        if (pl.fallback_nan) {
-          float fnan = __int_as_float(0x7fc00000);
-          pr = Prims{fnan, fnan, fnan, fnan, fnan, fnan, fnan, fnan};
-        } else {
-          pr = Prims{pl.fallback_rho, pl.fallback_pgas, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-        }
-      } else {
-        int i = find_cell(g, 0, s1);
-        int j = find_cell(g, 1, s2);
-        int k = find_cell(g, 2, s3);
-        gathers_local++;
-        if (!pl.simulation_interp) {   // :710-734
-          float v[8];
-          load_cell(g, k, j, i, v);
-          pr = Prims{v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
-        } else {                       // :485-490, :809-839, InterpolateSimple :1334-1351
-          int n_i = g.n[0], n_j = g.n[1], n_k = g.n[2];
-          int i_m = (i == 0 || (i != n_i - 1 && s1 >= g.xv[0][i])) ? i : i - 1;
-          int j_m = (j == 0 || (j != n_j - 1 && s2 >= g.xv[1][j])) ? j : j - 1;
-          int k_m = (k == 0 || (k != n_k - 1 && s3 >= g.xv[2][k])) ? k : k - 1;
-          double f_i = (s1 - g.xv[0][i_m]) / (g.xv[0][i_m + 1] - g.xv[0][i_m]);
-          double f_j = (s2 - g.xv[1][j_m]) / (g.xv[1][j_m + 1] - g.xv[1][j_m]);
-          double f_k = (s3 - g.xv[2][k_m]) / (g.xv[2][k_m + 1] - g.xv[2][k_m]);
-          float c[8][8];   // corner order mmm, mmp, mpm, mpp, pmm, pmp, ppm, ppp
-          load_cell(g, k_m, j_m, i_m, c[0]);
-          load_cell(g, k_m, j_m, i_m + 1, c[1]);
-          load_cell(g, k_m, j_m + 1, i_m, c[2]);
-          load_cell(g, k_m, j_m + 1, i_m + 1, c[3]);
-          load_cell(g, k_m + 1, j_m, i_m, c[4]);
-          load_cell(g, k_m + 1, j_m, i_m + 1, c[5]);
-          load_cell(g, k_m + 1, j_m + 1, i_m, c[6]);
-          load_cell(g, k_m + 1, j_m + 1, i_m + 1, c[7]);
-          double w[8];
-          w[0] = (1.0 - f_k) * (1.0 - f_j) * (1.0 - f_i);
-          w[1] = (1.0 - f_k) * (1.0 - f_j) * f_i;
-          w[2] = (1.0 - f_k) * f_j * (1.0 - f_i);
-          w[3] = (1.0 - f_k) * f_j * f_i;
-          w[4] = f_k * (1.0 - f_j) * (1.0 - f_i);
-          w[5] = f_k * (1.0 - f_j) * f_i;
-          w[6] = f_k * f_j * (1.0 - f_i);
-          w[7] = f_k * f_j * f_i;
-          double val[8];
-#pragma unroll
-          for (int v = 0; v < 8; v++) {
-            double acc = w[0] * (double)c[0][v];
-#pragma unroll
-            for (int corner = 1; corner < 8; corner++) acc += w[corner] * (double)c[corner][v];
-            val[v] = acc;
-          }
-          if (val[0] <= 0.0) val[0] = (double)c[0][0];   // :822-825
-          if (val[1] <= 0.0) val[1] = (double)c[0][1];
-          pr = Prims{(float)val[0], (float)val[1], (float)val[2], (float)val[3],
-                     (float)val[4], (float)val[5], (float)val[6], (float)val[7]};
-        }
-      }
-      (void)valid;
-
-      // ---------------- coefficients (simulation_coefficients.cpp:253-455)
-      double rho = pr.rho, pgas = pr.pgas;
-      double uu1_sim = pr.uu1, uu2_sim = pr.uu2, uu3_sim = pr.uu3;
-      double bb1_sim = pr.bb1, bb2_sim = pr.bb2, bb3_sim = pr.bb3;
-      double rho_cgs = rho * pl.d_unit;
-      double pgas_cgs = pgas * pl.e_unit;
-      double n_cgs = rho_cgs / (pl.plasma_mu * kMp);
-      n_e_cgs = n_cgs / (1.0 + 1.0 / pl.plasma_ne_ni);
-
-      // simulation metric (radiation_geometry.cpp:421-573)
-      double gcov_sim[4][4], gcon_sim[4][4];
-      if (pl.simulation_coord == BL_COORD_CKS) {
-        bl_gcov(BlSpacetime{bh_m, bh_a, 0}, x1, x2, x3, gcov_sim);
-        bl_gcon(BlSpacetime{bh_m, bh_a, 0}, x1, x2, x3, gcon_sim);
-      } else {
-        double a2 = bh_a * bh_a;
-        double r2 = r * r;   // placeholder, recomputed below exactly as the reference does
-        {
-          double rr2 = x1 * x1 + x2 * x2 + x3 * x3;
-          r2 = 0.5 * (rr2 - a2 + bl_hypot(rr2 - a2, 2.0 * bh_a * x3));
-        }
-        double rs = blm_sqrt(r2);
-        double cth = x3 / rs;
-        double cth2 = cth * cth;
-        double sth2 = 1.0 - cth2;
-        double delta = r2 - 2.0 * bh_m * rs + a2;
-        double sigma = r2 + a2 * cth2;
-        for (int mu = 0; mu < 4; mu++)
-          for (int nu = 0; nu < 4; nu++) {
-            gcov_sim[mu][nu] = 0.0;
-            gcon_sim[mu][nu] = 0.0;
-          }
-        gcov_sim[0][0] = -(1.0 - 2.0 * bh_m * rs / sigma);
-        gcov_sim[0][1] = 2.0 * bh_m * rs / sigma;
-        gcov_sim[0][3] = -2.0 * bh_m * bh_a * rs * sth2 / sigma;
-        gcov_sim[1][0] = 2.0 * bh_m * rs / sigma;
-        gcov_sim[1][1] = 1.0 + 2.0 * bh_m * rs / sigma;
-        gcov_sim[1][3] = -(1.0 + 2.0 * bh_m * rs / sigma) * bh_a * sth2;
-        gcov_sim[2][2] = sigma;
-        gcov_sim[3][0] = -2.0 * bh_m * bh_a * rs * sth2 / sigma;
-        gcov_sim[3][1] = -(1.0 + 2.0 * bh_m * rs / sigma) * bh_a * sth2;
-        gcov_sim[3][3] = (r2 + a2 + 2.0 * bh_m * a2 * rs * sth2 / sigma) * sth2;
-        gcon_sim[0][0] = -(1.0 + 2.0 * bh_m * rs / sigma);
-        gcon_sim[0][1] = 2.0 * bh_m * rs / sigma;
-        gcon_sim[1][0] = 2.0 * bh_m * rs / sigma;
-        gcon_sim[1][1] = delta / sigma;
-        gcon_sim[1][3] = bh_a / sigma;
-        gcon_sim[2][2] = 1.0 / sigma;
-        gcon_sim[3][1] = bh_a / sigma;
-        gcon_sim[3][3] = 1.0 / (sigma * sth2);
-      }
-
-      // simulation velocity (:297-313)
-      double uu0_sim = blm_sqrt(1.0 + gcov_sim[1][1] * uu1_sim * uu1_sim
-          + 2.0 * gcov_sim[1][2] * uu1_sim * uu2_sim + 2.0 * gcov_sim[1][3] * uu1_sim * uu3_sim
-          + gcov_sim[2][2] * uu2_sim * uu2_sim + 2.0 * gcov_sim[2][3] * uu2_sim * uu3_sim
-          + gcov_sim[3][3] * uu3_sim * uu3_sim);
-      double lapse_sim = 1.0 / blm_sqrt(-gcon_sim[0][0]);
-      double shift1_sim = -gcon_sim[0][1] / gcon_sim[0][0];
-      double shift2_sim = -gcon_sim[0][2] / gcon_sim[0][0];
-      double shift3_sim = -gcon_sim[0][3] / gcon_sim[0][0];
-      double ucon_sim[4];
-      ucon_sim[0] = uu0_sim / lapse_sim;
-      ucon_sim[1] = uu1_sim - shift1_sim * uu0_sim / lapse_sim;
-      ucon_sim[2] = uu2_sim - shift2_sim * uu0_sim / lapse_sim;
-      ucon_sim[3] = uu3_sim - shift3_sim * uu0_sim / lapse_sim;
-      double ucov_sim[4];
-      for (int mu = 0; mu < 4; mu++) {
-        double acc = 0.0;
-        for (int nu = 0; nu < 4; nu++) acc += gcov_sim[mu][nu] * ucon_sim[nu];
-        ucov_sim[mu] = acc;
-      }
-      // simulation magnetic field (:316-330)
-      double bcon_sim[4];
-      bcon_sim[0] = ucov_sim[1] * bb1_sim + ucov_sim[2] * bb2_sim + ucov_sim[3] * bb3_sim;
-      bcon_sim[1] = (bb1_sim + bcon_sim[0] * ucon_sim[1]) / ucon_sim[0];
-      bcon_sim[2] = (bb2_sim + bcon_sim[0] * ucon_sim[2]) / ucon_sim[0];
-      bcon_sim[3] = (bb3_sim + bcon_sim[0] * ucon_sim[3]) / ucon_sim[0];
-      double b_sq = 0.0;
-      for (int mu = 0; mu < 4; mu++) {
-        double acc = 0.0;
-        for (int nu = 0; nu < 4; nu++) acc += gcov_sim[mu][nu] * bcon_sim[nu];
-        b_sq += acc * bcon_sim[mu];
-      }
-      double bb_cgs = blm_sqrt(b_sq) * pl.b_unit;
-      double sigma_cut = b_sq / rho;
-      double beta_inv = b_sq / (2.0 * pgas);
-
-      // electron temperature, T_i/T_e(beta) model (:333-348)
-      theta_e = __longlong_as_double(0x7ff8000000000000ll);
-      kb_tt_e_cgs = theta_e;
-      if (pl.plasma_thermal_frac != 0.0) {
-        double tti_tte = (pl.plasma_rat_high + pl.plasma_rat_low * beta_inv * beta_inv) / (1.0 + beta_inv * beta_inv);
-        double kb_tt_tot_cgs = pl.plasma_mu * kMp * pgas_cgs / rho_cgs;
-        if (pl.plasma_use_p) {
-          kb_tt_e_cgs = (1.0 + pl.plasma_ne_ni) / (tti_tte + pl.plasma_ne_ni) * kb_tt_tot_cgs;
-        } else {
-          kb_tt_e_cgs = (1.0 + pl.plasma_ne_ni) * kb_tt_tot_cgs / (pl.plasma_gamma - 1.0);
-          kb_tt_e_cgs /= tti_tte / (pl.plasma_gamma_i - 1.0) + pl.plasma_ne_ni / (pl.plasma_gamma_e - 1.0);
-        }
-        theta_e = kb_tt_e_cgs / (kMe * kC * kC);
-      }
-
-      // cell cuts (:361-375)
-      bool cell_cut = (pl.cut_rho_min >= 0.0 && rho_cgs < pl.cut_rho_min)
-          || (pl.cut_rho_max >= 0.0 && rho_cgs > pl.cut_rho_max)
-          || (pl.cut_n_e_min >= 0.0 && n_e_cgs < pl.cut_n_e_min)
-          || (pl.cut_n_e_max >= 0.0 && n_e_cgs > pl.cut_n_e_max)
-          || (pl.cut_p_gas_min >= 0.0 && pgas_cgs < pl.cut_p_gas_min)
-          || (pl.cut_p_gas_max >= 0.0 && pgas_cgs > pl.cut_p_gas_max)
-          || (pl.cut_theta_e_min >= 0.0 && theta_e < pl.cut_theta_e_min)
-          || (pl.cut_theta_e_max >= 0.0 && theta_e > pl.cut_theta_e_max)
-          || (pl.cut_b_min >= 0.0 && bb_cgs < pl.cut_b_min)
-          || (pl.cut_b_max >= 0.0 && bb_cgs > pl.cut_b_max)
-          || (pl.cut_sigma_min >= 0.0 && sigma_cut < pl.cut_sigma_min)
-          || (pl.cut_sigma_max >= 0.0 && sigma_cut > pl.cut_sigma_max)
-          || (pl.cut_beta_inverse_min >= 0.0 && beta_inv < pl.cut_beta_inverse_min)
-          || (pl.cut_beta_inverse_max >= 0.0 && beta_inv > pl.cut_beta_inverse_max);
-      bool no_field = bb1_sim == 0.0 && bb2_sim == 0.0 && bb3_sim == 0.0;   // :394
-      if (!cell_cut && !no_field) {
-        // Jacobian to geodesic (CKS) coordinates (radiation_geometry.cpp:69-126)
-        double jac[4][4];
-        for (int mu = 0; mu < 4; mu++)
-          for (int nu = 0; nu < 4; nu++) jac[mu][nu] = mu == nu ? 1.0 : 0.0;
-        if (pl.simulation_coord == BL_COORD_SKS) {
-          double cth = x3 / r;
-          double sth = blm_sqrt(1.0 - cth * cth);
-          double ph = atan2_yx - atan_ar;
-          double sph, cph;
-          bl_sincos(ph, &sph, &cph);
-          jac[1][1] = sth * cph;
-          jac[1][2] = cth * (r * cph - bh_a * sph);
-          jac[1][3] = sth * (-r * sph - bh_a * cph);
-          jac[2][1] = sth * sph;
-          jac[2][2] = cth * (r * sph + bh_a * cph);
-          jac[2][3] = sth * (r * cph - bh_a * sph);
-          jac[3][1] = cth;
-          jac[3][2] = -r * sth;
-          jac[3][3] = 0.0;
-        }
-        double ucon[4], bcon[4];
-        for (int mu = 0; mu < 4; mu++) {
-          double au = 0.0, ab = 0.0;
-          for (int nu = 0; nu < 4; nu++) {
-            au += jac[mu][nu] * ucon_sim[nu];
-            ab += jac[mu][nu] * bcon_sim[nu];
-          }
-          ucon[mu] = au;
-          bcon[mu] = ab;
-        }
-        double gcov[4][4], gcon[4][4];
-        bl_gcov(st, x1, x2, x3, gcov);
-        bl_gcon(st, x1, x2, x3, gcon);
-        double kcon[4], ucov[4], bcov[4];
-        for (int mu = 0; mu < 4; mu++) {
-          double ak = 0.0, au = 0.0, ab = 0.0;
-          for (int nu = 0; nu < 4; nu++) {
-            ak += gcon[mu][nu] * kcov[nu];
-            au += gcov[mu][nu] * ucon[nu];
-            ab += gcov[mu][nu] * bcon[nu];
-          }
-          kcon[mu] = ak;
-          ucov[mu] = au;
-          bcov[mu] = ab;
-        }
-        double tetrad[4][4];
-        tetrad_build(ucon, ucov, kcon, kcov, bcon, gcov, gcon, tetrad);
-        double k_tet[3] = {0.0, 0.0, 0.0}, b_tet[3] = {0.0, 0.0, 0.0};   // :434-455
-        for (int mu = 0; mu < 4; mu++)
-          for (int a = 0; a < 3; a++) {
-            k_tet[a] += tetrad[a + 1][mu] * kcov[mu];
-            b_tet[a] += tetrad[a + 1][mu] * bcov[mu];
-          }
-        double k_sq_tet = k_tet[0] * k_tet[0] + k_tet[1] * k_tet[1] + k_tet[2] * k_tet[2];
-        double b_sq_tet = b_tet[0] * b_tet[0] + b_tet[1] * b_tet[1] + b_tet[2] * b_tet[2];
-        double k_b_tet = k_tet[0] * b_tet[0] + k_tet[1] * b_tet[1] + k_tet[2] * b_tet[2];
-        double cos2_theta_b = std_min(k_b_tet * k_b_tet / (k_sq_tet * b_sq_tet), 1.0);
-        double sin2_theta_b = 1.0 - cos2_theta_b;
-        sin_theta_b = blm_sqrt(sin2_theta_b);
-        double nu_sum = 0.0;   // :461-463
-        for (int mu = 0; mu < 4; mu++) nu_sum -= kcov[mu] * ucon[mu];
-        nu_fluid_over_nu = nu_sum;
-        nu_c_cgs = kE * bb_cgs / (2.0 * kPi * kMe * kC);
-        have_coefficients = true;
-      }
-    }
-
-    // formula model geometry (formula_coefficients.cpp:118-161)
-    double fu[4] = {0.0, 0.0, 0.0, 0.0};
-    if (!skip && kModel == BL_MODEL_FORMULA) {
-      const BlFormulaDevice &fm = P.formula;
-      double rr = blm_sqrt(r * r - x3 * x3);
-      double cth = x3 / r;
-      double sth = blm_sqrt(1.0 - cth * cth);
-      double ph = bl_atan2(x2, x1) - bl_atan(bh_a / r);
-      double sph, cph;
-      bl_sincos(ph, &sph, &cph);
-      double delta = r * r - 2.0 * bh_m * r + bh_a * bh_a;
-      double sigma = r * r + bh_a * bh_a * cth * cth;
-      double gtt_bl = -(1.0 + 2.0 * bh_m * r * (r * r + bh_a * bh_a) / (delta * sigma));
-      double gtph_bl = -2.0 * bh_m * bh_a * r / (delta * sigma);
-      double grr_bl = delta / sigma;
-      double gthth_bl = 1.0 / sigma;
-      double gphph_bl = (sigma - 2.0 * bh_m * r) / (delta * sigma * sth * sth);
-      double ll = fm.l0 / (1.0 + rr) * bl_pow(rr, 1.0 + fm.q);
-      double u_norm = 1.0 / blm_sqrt(-gtt_bl + 2.0 * gtph_bl * ll - gphph_bl * ll * ll);
-      double u_t_bl = -u_norm;
-      double u_r_bl = 0.0;
-      double u_th_bl = 0.0;
-      double u_ph_bl = u_norm * ll;
-      double ut_bl = gtt_bl * u_t_bl + gtph_bl * u_ph_bl;
-      double ur_bl = grr_bl * u_r_bl;
-      double uth_bl = gthth_bl * u_th_bl;
-      double uph_bl = gtph_bl * u_t_bl + gphph_bl * u_ph_bl;
-      double ut = ut_bl + 2.0 * bh_m * r / delta * ur_bl;
-      double ur = ur_bl;
-      double uth = uth_bl;
-      double uph = uph_bl + bh_a / delta * ur_bl;
-      fu[0] = ut;
-      fu[1] = sth * cph * ur + cth * (r * cph - bh_a * sph) * uth + sth * (-r * sph - bh_a * cph) * uph;
-      fu[2] = sth * sph * ur + cth * (r * sph + bh_a * cph) * uth + sth * (r * cph - bh_a * sph) * uph;
-      fu[3] = cth * ur - r * sth * uth;
-      n_n0_fluid = bl_exp(-0.5 * (r * r / (fm.r0 * fm.r0) + fm.h * fm.h * cth * cth));
-      have_coefficients = true;
+    SampleShade sh;
+    sh.have_coefficients = false;
+    sh.nu_fluid_over_nu = 0.0;
+    sh.n_e_cgs = sh.nu_c_cgs = sh.theta_e = sh.sin_theta_b = sh.kb_tt_e_cgs = 0.0;
+    sh.n_n0_fluid = 0.0;
+    sh.fu[0] = sh.fu[1] = sh.fu[2] = sh.fu[3] = 0.0;
+    if (!skip) {
+      if (kModel == BL_MODEL_SIMULATION)
+        shade_simulation(P, tab, st, ks, x1, x2, x3, kcov, &gathers_local, &sh);
+      else
+        shade_formula(P, st, r, x1, x2, x3, &sh);
     }
 
     // ---------------- per-frequency coefficients and transfer records
     for (int l = 0; l < P.n_nu; l++) {
-      double freq = P.frequencies[l];
+      const double freq = P.frequencies[l];
       double j_val = 0.0, alpha_val = 0.0;
-      if (have_coefficients && kModel == BL_MODEL_SIMULATION) {
+      if (sh.have_coefficients && kModel == BL_MODEL_SIMULATION) {
         // simulation_coefficients.cpp:464-523, thermal electrons, unpolarized
-        const BlPlasmaDevice &pl = P.plasma;
-        double nu_cgs = nu_fluid_over_nu * (freq * momentum_factor);
-        double nu_2_cgs = nu_cgs * nu_cgs;
-        double nu_s_cgs = 2.0 / 9.0 * nu_c_cgs * theta_e * theta_e * sin_theta_b;
-        if (pl.plasma_thermal_frac != 0.0) {
-          double xx = nu_cgs / nu_s_cgs;
-          double xx_1_2 = blm_sqrt(xx);
-          double xx_1_3 = bl_cbrt(xx);
-          double xx_1_6 = blm_sqrt(xx_1_3);
-          double coefficient = pl.plasma_thermal_frac * n_e_cgs * kE * kE * nu_c_cgs / (kC * nu_2_cgs) * bl_exp(-xx_1_3);
-          double var_a = kSqrt2 * kPi / 27.0 * sin_theta_b;
-          double var_b = kPow2_11_12;
-          double var_c = xx_1_2 + var_b * xx_1_6;
+        const double thermal_frac = P.plasma.plasma_thermal_frac;
+        const double nu_cgs = sh.nu_fluid_over_nu * (freq * momentum_factor);
+        const double nu_2_cgs = nu_cgs * nu_cgs;
+        const double nu_s_cgs = 2.0 / 9.0 * sh.nu_c_cgs * sh.theta_e * sh.theta_e * sh.sin_theta_b;
+        if (thermal_frac != 0.0) {
+          const double xx = nu_cgs / nu_s_cgs;
+          const double xx_1_2 = blm_sqrt(xx);
+          const double xx_1_3 = bl_cbrt(xx);
+          const double xx_1_6 = blm_sqrt(xx_1_3);
+          const double coefficient = thermal_frac * sh.n_e_cgs * kE * kE * sh.nu_c_cgs / (kC * nu_2_cgs) * bl_exp(-xx_1_3);
+          const double var_a = kSqrt2 * kPi / 27.0 * sh.sin_theta_b;
+          const double var_b = kPow2_11_12;
+          const double var_c = xx_1_2 + var_b * xx_1_6;
           j_val = coefficient * var_a * var_c * var_c;
-          double b_nu_nu_3_cgs = 2.0 * kH / (kC * kC) / bl_expm1(kH * nu_cgs / kb_tt_e_cgs);
+          const double b_nu_nu_3_cgs = 2.0 * kH / (kC * kC) / bl_expm1(kH * nu_cgs / sh.kb_tt_e_cgs);
           alpha_val = j_val / b_nu_nu_3_cgs;
           if (1.0 / (alpha_val * alpha_val) == __longlong_as_double(0x7ff0000000000000ll)) alpha_val = 0.0;   // :513-523
         }
-      } else if (have_coefficients && kModel == BL_MODEL_FORMULA) {
+      } else if (sh.have_coefficients && kModel == BL_MODEL_FORMULA) {
         // formula_coefficients.cpp:164-179
         const BlFormulaDevice &fm = P.formula;
-        double nu_fluid_cgs = -(fu[0] * kcov[0] + fu[1] * kcov[1] + fu[2] * kcov[2] + fu[3] * kcov[3]) * freq * momentum_factor;
-        double j_nu_fluid_cgs = fm.cn0 * n_n0_fluid * bl_pow(nu_fluid_cgs / fm.nup, -fm.alpha);
+        const double nu_fluid_cgs = -(sh.fu[0] * kcov[0] + sh.fu[1] * kcov[1] + sh.fu[2] * kcov[2] + sh.fu[3] * kcov[3]) * freq * momentum_factor;
+        const double j_nu_fluid_cgs = fm.cn0 * sh.n_n0_fluid * bl_pow(nu_fluid_cgs / fm.nup, -fm.alpha);
         j_val = j_nu_fluid_cgs / (nu_fluid_cgs * nu_fluid_cgs);
-        double alpha_nu_fluid_cgs = fm.a * fm.cn0 * n_n0_fluid * bl_pow(nu_fluid_cgs / fm.nup, -fm.beta - fm.alpha);
+        const double alpha_nu_fluid_cgs = fm.a * fm.cn0 * sh.n_n0_fluid * bl_pow(nu_fluid_cgs / fm.nup, -fm.beta - fm.alpha);
         alpha_val = alpha_nu_fluid_cgs * nu_fluid_cgs;
       }
-      double delta_lambda_cgs = delta_lambda * P.x_unit / (freq * momentum_factor);   // unpolarized.cpp:75-76
+      const double delta_lambda_cgs = delta_lambda * P.x_unit / (freq * momentum_factor);   // unpolarized.cpp:75-76
       out[l] = transfer_record(j_val, alpha_val, delta_lambda_cgs);
     }
   }
@@ -1060,11 +1147,12 @@ extern "C" int bl_geodesic_occupancy(int integrator) {
   return blocks;
 }
 
-extern "C" hipError_t bl_launch_shade(const BlShadeArgs *args, int model, int grid, hipStream_t stream) {
+// args: DEVICE pointer; lds_bytes: size of the coordinate tables staged in LDS (simulation mode)
+extern "C" hipError_t bl_launch_shade(const BlShadeArgs *args, int model, int grid, int lds_bytes, hipStream_t stream) {
   if (model == BL_MODEL_SIMULATION)
-    hipLaunchKernelGGL(bl_shade_kernel<BL_MODEL_SIMULATION>, dim3(grid), dim3(256), 0, stream, *args);
+    hipLaunchKernelGGL(bl_shade_kernel<BL_MODEL_SIMULATION>, dim3(grid), dim3(256), lds_bytes, stream, args);
   else
-    hipLaunchKernelGGL(bl_shade_kernel<BL_MODEL_FORMULA>, dim3(grid), dim3(256), 0, stream, *args);
+    hipLaunchKernelGGL(bl_shade_kernel<BL_MODEL_FORMULA>, dim3(grid), dim3(256), 0, stream, args);
   return hipGetLastError();
 }
 

@@ -178,10 +178,9 @@ BLM_FN double bl_expm1(double x) {
   double tail = blm_fma(r2 * r, q, 0.5 * r2);
   tail += blm_fma(c, r, c);
   double e = r + tail;
-  if (k == 0) return e;
-  if (k == -1) return 0.5 * e - 0.5;
-  if (k == 1) return 1.0 + 2.0 * e;
   if (k >= 54) return blm_scalbn(1.0 + e, k) - 1.0;
+  /* (2^k - 1) + 2^k e: 2^k - 1 and 2^k e are exact, one rounding. For k = 0, -1, +1 this is
+     e, 0.5 e - 0.5 and 1 + 2 e bit for bit, so no special cases (and no lane divergence). */
   double t = blm_pow2i(k);
   return (t - 1.0) + t * e;
 }
@@ -344,7 +343,6 @@ BLM_FN double bl_cbrt(double x) {
 /* argument reduction: x = n*(pi/2) + (r.hi + r.lo), |r| <= ~pi/4; returns n mod 4.
    pi/2 is carried as three full doubles (~159 bits); products are exact via fma. */
 BLM_FN int blm_rem_pio2(double x, blm_dd *r) {
-  if (blm_abs(x) <= 0x1.921fb54442d18p-1) { r->hi = x; r->lo = 0.0; return 0; }
   double fn = blm_rint(x * 0x1.45f306dc9c883p-1);
   blm_dd p1 = blm_two_prod(-fn, 0x1.921fb54442d18p+0);
   blm_dd p2 = blm_two_prod(-fn, 0x1.1a62633145c07p-54);
@@ -420,21 +418,15 @@ BLM_FN void bl_sincos(double x, double *s, double *c) {
 BLM_FN double bl_atan(double x) {
   if (blm_isnan(x)) return x;
   double ax = blm_abs(x);
-  double hi, lo, t;
-  int direct = 0;
   if (ax >= 0x1p66) return blm_copysign(BLM_PIO2_HI + BLM_PIO2_LO, x);
-  if (ax < 0.4375) {
-    if (ax < 0x1p-27) return x;
-    direct = 1; t = ax; hi = 0.0; lo = 0.0;
-  } else if (ax < 0.6875) {
-    t = (2.0 * ax - 1.0) / (2.0 + ax); hi = 0x1.dac670561bb4fp-2; lo = 0x1.a2b7f222f65e2p-56;
-  } else if (ax < 1.1875) {
-    t = (ax - 1.0) / (ax + 1.0); hi = 0x1.921fb54442d18p-1; lo = 0x1.1a62633145c07p-55;
-  } else if (ax < 2.4375) {
-    t = (ax - 1.5) / (1.0 + 1.5 * ax); hi = 0x1.f730bd281f69bp-1; lo = 0x1.007887af0cbbdp-56;
-  } else {
-    t = -1.0 / ax; hi = BLM_PIO2_HI; lo = BLM_PIO2_LO;
-  }
+  if (ax < 0x1p-27) return x;
+  /* range selection without divergent branches: t = num / den, atan(ax) = hi + lo + atan(t) */
+  double num = ax, den = 1.0, hi = 0.0, lo = 0.0;          /* ax < 7/16: t = ax / 1 = ax exactly */
+  if (ax >= 0.4375) { num = 2.0 * ax - 1.0; den = 2.0 + ax; hi = 0x1.dac670561bb4fp-2; lo = 0x1.a2b7f222f65e2p-56; }
+  if (ax >= 0.6875) { num = ax - 1.0; den = ax + 1.0; hi = 0x1.921fb54442d18p-1; lo = 0x1.1a62633145c07p-55; }
+  if (ax >= 1.1875) { num = ax - 1.5; den = 1.0 + 1.5 * ax; hi = 0x1.f730bd281f69bp-1; lo = 0x1.007887af0cbbdp-56; }
+  if (ax >= 2.4375) { num = -1.0; den = ax; hi = BLM_PIO2_HI; lo = BLM_PIO2_LO; }
+  double t = num / den;
   double z = t * t;
   double a = -0x1.9a0e3d8214a3cp-7;
   a = blm_fma(a, z, 0x1.dde84abd3489ap-6);
@@ -450,7 +442,7 @@ BLM_FN double bl_atan(double x) {
   a = blm_fma(a, z, 0x1.999999999998fp-3);
   a = blm_fma(a, z, -0x1.5555555555555p-2);
   double tp = t * (z * a);                    /* atan(t) = t + tp */
-  double res = direct ? (t + tp) : (hi + ((tp + lo) + t));
+  double res = hi + ((tp + lo) + t);          /* hi = lo = 0 in the direct range: exactly t + tp */
   return blm_copysign(res, x);
 }
 BLM_FN double bl_atan2(double y, double x) {
@@ -496,24 +488,22 @@ BLM_FN double bl_acos(double x) {
   double ax = blm_abs(x);
   if (ax > 1.0) return BLM_NAN;
   if (ax == 1.0) return x > 0.0 ? 0.0 : BLM_PI_HI + BLM_PI_LO;
-  if (ax < 0.5) {
-    if (ax < 0x1p-57) return BLM_PIO2_HI + BLM_PIO2_LO;
-    double z = x * x;
-    double r = z * blm_asin_r(z);
-    return BLM_PIO2_HI - (x - (BLM_PIO2_LO - x * r));
-  }
-  if (x < 0.0) {
-    double z = (1.0 + x) * 0.5;
-    double s = blm_sqrt(z);
-    double r = z * blm_asin_r(z);
-    double w = r * s - BLM_PIO2_LO;
-    return BLM_PI_HI - 2.0 * (s + w);
-  }
-  double z = (1.0 - x) * 0.5;
-  double s = blm_sqrt(z);
-  double c = blm_fma(-s, s, z) / (s + s);      /* sqrt(z) = s + c */
+  if (ax < 0x1p-57) return BLM_PIO2_HI + BLM_PIO2_LO;
+  /* Three ranges, evaluated without divergent branches (a wave usually holds lanes of all three):
+       |x| < 0.5 : pi/2 - (x + x^3 R(x^2))
+       x <= -0.5 : pi - 2 (s + s^3 R(z)),  z = (1 + x)/2, s = sqrt(z)
+       x >=  0.5 : 2 (s + s^3 R(z)),       z = (1 - x)/2, with s split as s + c exactly
+     1 + x = 1 - |x| exactly for x < 0, so z has a single expression in the outer ranges. */
+  int small = ax < 0.5;
+  double z = small ? x * x : (1.0 - ax) * 0.5;
   double r = z * blm_asin_r(z);
-  return 2.0 * (s + (r * s + c));
+  double s = blm_sqrt(z);
+  double res_small = BLM_PIO2_HI - (x - (BLM_PIO2_LO - x * r));
+  double w = r * s - BLM_PIO2_LO;
+  double res_neg = BLM_PI_HI - 2.0 * (s + w);
+  double c = blm_fma(-s, s, z) / (s + s);      /* sqrt(z) = s + c */
+  double res_pos = 2.0 * (s + (r * s + c));
+  return small ? res_small : (x < 0.0 ? res_neg : res_pos);
 }
 
 /* ---------------------------------------------------------------- hyperbolic (polarized path) */
