@@ -663,9 +663,6 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
     sa.x_unit = kGGMsun * ctx->frame.mass_msun / (kC * kC);   // unpolarized.cpp:42
     sa.transfer = ctx->d_transfer.ptr;
 
-    ctx->d_shade_args.Ensure(1);
-    Check(hipMemcpyAsync(ctx->d_shade_args.ptr, &sa, sizeof(BlShadeArgs), hipMemcpyHostToDevice, stream), "shade args upload");
-
     BlTransferArgs xa{};
     xa.transfer = ctx->d_transfer.ptr;
     xa.ray_sample_num = ctx->d_ray_sample_num.ptr;
@@ -703,7 +700,7 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
       Check(hipEventRecord(ctx->ev[0], stream), "event");
       Check(bl_launch_geodesic(&ta, p.ray_integrator, std::min(geo_grid, (rays + 63) / 64), stream), "geodesic kernel launch");
       Check(hipEventRecord(ctx->ev[1], stream), "event");
-      Check(bl_launch_shade(ctx->d_shade_args.ptr, p.model_type, shade_grid, ctx->lds_table_bytes, stream), "shade kernel launch");
+      Check(bl_launch_shade(&sa, p.model_type, shade_grid, ctx->lds_table_bytes, stream), "shade kernel launch");
       Check(hipEventRecord(ctx->ev[2], stream), "event");
       Check(bl_launch_transfer(&xa, stream), "transfer kernel launch");
       Check(hipEventRecord(ctx->ev[3], stream), "event");
