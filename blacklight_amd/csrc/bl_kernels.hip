@@ -1195,8 +1195,19 @@ __global__ void __launch_bounds__(256) bl_transfer_kernel(BlTransferArgs P) {
         intensity = (num > 0 && nan_row) ? nan : 0.0;
       } else {
         const double2 *rec = P.transfer + (size_t)slot * P.ray_max_steps * P.n_nu + l;
-        // reference sample order is reversed integration order (geodesics.cpp:832-840)
-        for (int n = num - 1; n >= 0; n--) {
+        // reference sample order is reversed integration order (geodesics.cpp:832-840). The
+        // recurrence is sequential but the loads are not: fetch 8 records (one 128-byte line of
+        // this ray's row when n_nu = 1) at a time so 8 loads are in flight per lane.
+        int n = num - 1;
+        for (; n >= 7; n -= 8) {
+          double2 ab[8];
+#pragma unroll
+          for (int u = 0; u < 8; u++) ab[u] = rec[(size_t)(n - u) * P.n_nu];
+#pragma unroll
+          for (int u = 0; u < 8; u++)
+            intensity = (ab[u].x == BL_THICK_MARK) ? ab[u].y : ab[u].x * (intensity + ab[u].y);
+        }
+        for (; n >= 0; n--) {
           double2 ab = rec[(size_t)n * P.n_nu];
           intensity = (ab.x == BL_THICK_MARK) ? ab.y : ab.x * (intensity + ab.y);
         }
