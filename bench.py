@@ -65,18 +65,6 @@ WORKLOAD = dict(
 )
 
 
-def tile_pixels(resolution, rank, world, tile=TILE):
-    """Pixels of the tiles dealt block-cyclically to `rank` (tile t -> rank t % world), tile-major,
-    row-major inside a tile: the order the geodesic kernel wants (compact 2-D patches per wave)."""
-    tiles_per_side = resolution // tile
-    ids = np.arange(rank, tiles_per_side * tiles_per_side, world)
-    ty, tx = ids // tiles_per_side, ids % tiles_per_side
-    yy, xx = np.meshgrid(np.arange(tile), np.arange(tile), indexing="ij")
-    m2 = (ty[:, None, None] * tile + yy[None]).reshape(-1)
-    m1 = (tx[:, None, None] * tile + xx[None]).reshape(-1)
-    return (m2 * resolution + m1).astype(np.int32)
-
-
 def cpu_baseline(params_dict, grid, resolution, stride):
     """Time the CPU oracle (port of the reference algorithm) on a regular sub-lattice of the camera."""
     sys.path.insert(0, os.path.join(REPO, "tests"))
@@ -107,6 +95,7 @@ def main():
 
     import torch
     import blacklight_amd as bl
+    from blacklight_amd import distributed as bd
     from blacklight_amd import mock
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -133,7 +122,7 @@ def main():
     ctx.set_grid(grid)          # staged into HBM once, outside the timed region
 
     if args.mode == "tiled" and distributed:
-        pixels = tile_pixels(res, rank, world)
+        pixels = bd.tile_pixels(res, rank, world, TILE)
         n_rays = int(pixels.size)
     else:
         pixels = None
@@ -150,12 +139,10 @@ def main():
         """Final image(s) to rank 0 over RCCL (part of the job, inside the timed region)."""
         if not distributed:
             return None
-        if rank == 0:
-            parts = [torch.empty_like(image) for _ in range(world)]
-            dist.gather(image, parts, dst=0)
-            return parts
-        dist.gather(image, None, dst=0)
-        return None
+        parts = bd.gather_rows(image, dst=0)
+        if parts is not None and args.mode == "tiled":
+            return bd.assemble(parts, res, TILE)      # rank 0 de-tiles into (n_q, res*res)
+        return parts
 
     for _ in range(args.warmup):
         step()

@@ -1,0 +1,57 @@
+"""The C-ABI library loads (no GPU needed) and exports every entry point that
+include/blacklight_amd.h declares; the product tree never refers to the oracle."""
+import ctypes
+import os
+import re
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_every_declared_symbol_is_exported(built_library):
+    header = open(os.path.join(REPO, "include", "blacklight_amd.h")).read()
+    declared = re.findall(r"BL_API\s+[\w\s\*]+?\b(bl_\w+)\s*\(", header)
+    assert len(declared) >= 18
+    lib = ctypes.CDLL(built_library)
+    missing = [name for name in declared if not hasattr(lib, name)]
+    assert not missing, missing
+    lib.bl_build_info.restype = ctypes.c_char_p
+    info = lib.bl_build_info().decode()
+    assert "gfx950" in info and "hip" in info and "fp-contract=off" in info
+
+
+def test_params_block_size_is_consistent(built_library):
+    lib = ctypes.CDLL(built_library)
+    lib.bl_params_sizeof.restype = ctypes.c_size_t
+    assert 4096 < lib.bl_params_sizeof() < 16384
+
+
+def test_no_gpu_means_loud_failure_not_fallback(built_library):
+    """Without a HIP device bl_init must fail with BL_E_DEVICE: there is no CPU path in the product."""
+    import torch
+    import blacklight_amd as bl
+    import golden_util as gu
+    if torch.cuda.is_available():
+        return
+    fx, params, _ = gu.load_case("formula_flat")
+    try:
+        bl.Context(bl.Params.from_dict(params))
+    except bl.BlacklightError as err:
+        assert err.code == 4 and "no CPU fallback" in str(err)
+    else:
+        raise AssertionError("bl_init succeeded without a GPU")
+
+
+def test_product_does_not_use_the_oracle():
+    offenders = []
+    for root in ("blacklight_amd", "include"):
+        for dirpath, _, files in os.walk(os.path.join(REPO, root)):
+            if "_obj" in dirpath or "__pycache__" in dirpath:
+                continue
+            for name in files:
+                if not name.endswith((".py", ".h", ".hip", ".cpp")):
+                    continue
+                text = open(os.path.join(dirpath, name)).read()
+                if re.search(r"#include\s+\"[^\"]*oracle|import\s+oracle_api|from\s+oracle|CDLL\([^)]*oracle|"
+                             r"dlopen\([^)]*oracle|blo_render", text):
+                    offenders.append(os.path.join(dirpath, name))
+    assert not offenders, offenders
