@@ -41,6 +41,18 @@ class RenderDesc(C.Structure):
     ]
 
 
+BL_MAX_LEVELS = 16
+
+
+class OutputLevel(C.Structure):
+    _fields_ = [("n_blocks", C.c_int32), ("block_locs", C.c_void_p), ("image", C.c_void_p), ("camera", C.c_void_p)]
+
+
+class OutputDesc(C.Structure):
+    _fields_ = [("adaptive_num_levels", C.c_int32), ("level", OutputLevel * (BL_MAX_LEVELS + 1)),
+                ("snapshot", C.c_int32)]
+
+
 class Stats(C.Structure):
     _fields_ = [
         ("n_rays", C.c_int64), ("n_samples", C.c_int64), ("n_samples_emitted", C.c_int64),
@@ -85,6 +97,9 @@ def lib():
     L.bl_last_global_error.restype = C.c_char_p
     L.bl_warnings.argtypes = [C.c_void_p]
     L.bl_warnings.restype = C.c_char_p
+    L.bl_adaptive_refine.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.POINTER(C.c_int32), C.c_void_p]
+    L.bl_write_output.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(OutputDesc)]
     L.bl_free.argtypes = [C.c_void_p]
     L.bl_build_info.restype = C.c_char_p
     _lib = L

@@ -15,9 +15,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libblacklight_amd.so")
+EXE = os.path.join(HERE, "bin", "blacklight_amd")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 
-SOURCES = ["bl_kernels.hip", "bl_api.hip", "bl_params.cpp"]
+SOURCES = ["bl_kernels.hip", "bl_api.hip", "bl_params.cpp", "bl_host.cpp"]
 ARCH = "gfx950"
 COMMON = ["-std=c++17", "-O3", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden", f"-I{INCLUDE}", f"-I{CSRC}"]
 
@@ -67,6 +68,15 @@ def build(force=False, verbose=False):
         result = subprocess.run(cmd, capture_output=True, text=True)
         if result.returncode != 0:
             raise RuntimeError(f"link failed:\n{result.stdout}\n{result.stderr}")
+    # command-line driver with the reference's outer contract (blacklight_amd/bin/blacklight_amd)
+    os.makedirs(os.path.dirname(EXE), exist_ok=True)
+    main_src = os.path.join(CSRC, "bl_main.cpp")
+    if force or rebuilt or not os.path.exists(EXE) or os.path.getmtime(EXE) < os.path.getmtime(main_src):
+        cmd = ["g++", "-std=c++17", "-O2", f"-I{INCLUDE}", main_src, "-o", EXE, f"-L{HERE}", "-lblacklight_amd",
+               "-Wl,-rpath,$ORIGIN/.."]
+        result = subprocess.run(cmd, capture_output=True, text=True)
+        if result.returncode != 0:
+            raise RuntimeError(f"g++ failed on bl_main.cpp:\n{result.stdout}\n{result.stderr}")
     return LIB
 
 

@@ -129,6 +129,69 @@ class Context:
         return dict(image=image, sample_num=sample_num, sample_flags=sample_flags,
                     camera_pos=camera_pos, camera_dir=camera_dir, stats=self.stats)
 
+    # ------------------------------------------------------------------ host steps of the reference loop
+    def adaptive_refine(self, level, image, block_locs=None):
+        """CheckAdaptiveRefinement for the level just rendered (reference radiation_adaptive.cpp:19-139)
+        plus AugmentCamera's block list of the next level (camera.cpp:445-458).
+        Returns (refine_flags, next_block_locs); an empty next list ends the adaptive loop."""
+        image = np.ascontiguousarray(image, dtype=np.float64)
+        if level == 0:
+            bs = int(self.params.get("adaptive_block_size"))
+            n_blocks = (self.resolution // bs) ** 2
+            locs_ptr = None
+        else:
+            bl = np.ascontiguousarray(block_locs, dtype=np.int32).reshape(-1, 2)
+            n_blocks = bl.shape[0]
+            locs_ptr = bl.ctypes.data_as(C.c_void_p)
+        flags = np.zeros(n_blocks, dtype=np.uint8)
+        nxt = np.zeros((4 * n_blocks, 2), dtype=np.int32)
+        count = C.c_int32(0)
+        self._check(self._lib.bl_adaptive_refine(self._ctx, level, n_blocks, locs_ptr, image.ctypes.data_as(C.c_void_p),
+                                                 flags.ctypes.data_as(C.c_void_p), C.byref(count),
+                                                 nxt.ctypes.data_as(C.c_void_p)))
+        return flags.astype(bool), nxt[: 4 * count.value].copy()
+
+    def render_adaptive(self, want_camera=False):
+        """The reference's do { Integrate; AddGeodesics } while (!done) loop (blacklight.cpp:196-233).
+        Returns a list of per-level dicts (level 0 first), each with image / block_locs / ..."""
+        levels = [self.render(want_camera=want_camera)]
+        levels[0]["block_locs"] = None
+        if int(self.params.get("adaptive_max_level") or 0) <= 0:
+            return levels
+        level = 0
+        while True:
+            flags, nxt = self.adaptive_refine(level, levels[level]["image"], levels[level]["block_locs"])
+            levels[level]["refinement_flags"] = flags
+            if nxt.shape[0] == 0:
+                return levels
+            level += 1
+            out = self.render(level=level, block_locs=nxt, want_camera=want_camera)
+            out["block_locs"] = nxt
+            levels.append(out)
+
+    def write_output(self, levels, path=None, snapshot=0):
+        """OutputWriter::Write (reference output_writer.cpp:169-274); `levels` as from render_adaptive."""
+        d = _capi.OutputDesc()
+        d.adaptive_num_levels = len(levels) - 1
+        d.snapshot = snapshot
+        keep = []
+        plane = int(self.params.get("camera_type")) == 0
+        for index, lv in enumerate(levels):
+            image = np.ascontiguousarray(lv["image"], dtype=np.float64)
+            keep.append(image)
+            d.level[index].image = image.ctypes.data_as(C.c_void_p)
+            if index > 0:
+                bl = np.ascontiguousarray(lv["block_locs"], dtype=np.int32)
+                keep.append(bl)
+                d.level[index].n_blocks = bl.shape[0]
+                d.level[index].block_locs = bl.ctypes.data_as(C.c_void_p)
+            camera = lv.get("camera_pos") if plane else lv.get("camera_dir")
+            if camera is not None:
+                camera = np.ascontiguousarray(camera, dtype=np.float64)
+                keep.append(camera)
+                d.level[index].camera = camera.ctypes.data_as(C.c_void_p)
+        self._check(self._lib.bl_write_output(self._ctx, None if path is None else str(path).encode(), C.byref(d)))
+
     def render_device(self, image_ptr, n_rays, level=0, pixel_map=None, sample_num_ptr=0, sample_flags_ptr=0,
                       block_locs=None):
         """Trace into caller-owned HBM (raw device pointers, e.g. torch.Tensor.data_ptr())."""

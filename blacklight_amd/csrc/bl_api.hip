@@ -18,6 +18,7 @@
 #include "../../include/blacklight_amd.h"
 #include "bl_camera.h"
 #include "bl_device.h"
+#include "bl_internal.h"
 
 extern "C" hipError_t bl_launch_geodesic(const BlTraceArgs *args, int integrator, int grid, hipStream_t stream);
 extern "C" int bl_geodesic_occupancy(int integrator);
@@ -284,7 +285,28 @@ void ValidateRadiation(bl_ctx *ctx) {
     Require(p, {BL_P_slow_light_on}, kRadMissing);
     if (p.slow_light_on) throw Failure{BL_E_UNSUPPORTED, "slow_light_on = true is not built yet."};
   }
-  if (p.adaptive_max_level > 0 && !p.image_light) throw Failure{BL_E_INPUT, "Adaptive ray tracing requires image_light."};
+  if (p.adaptive_max_level > 0) {   // radiation_integrator.cpp:218-270
+    if (!p.image_light) throw Failure{BL_E_INPUT, "Adaptive ray tracing requires image_light."};
+    if (p.adaptive_max_level > BL_MAX_LEVELS) throw Failure{BL_E_UNSUPPORTED, "adaptive_max_level exceeds BL_MAX_LEVELS."};
+    if (p.image_num_frequencies > 1) {
+      Require(p, {BL_P_adaptive_frequency_num}, kRadMissing);
+      if (p.adaptive_frequency_num - 1 < 0 || p.adaptive_frequency_num - 1 >= p.image_num_frequencies)
+        throw Failure{BL_E_INPUT, "Must choose adaptive_frequency_num from 1 to image_num_frequencies."};
+    }
+    Require(p, {BL_P_adaptive_val_frac}, kRadMissing);
+    if (p.adaptive_val_frac >= 0.0) Require(p, {BL_P_adaptive_val_cut}, kRadMissing);
+    Require(p, {BL_P_adaptive_abs_grad_frac}, kRadMissing);
+    if (p.adaptive_abs_grad_frac >= 0.0) Require(p, {BL_P_adaptive_abs_grad_cut}, kRadMissing);
+    Require(p, {BL_P_adaptive_rel_grad_frac}, kRadMissing);
+    if (p.adaptive_rel_grad_frac >= 0.0) Require(p, {BL_P_adaptive_rel_grad_cut}, kRadMissing);
+    Require(p, {BL_P_adaptive_abs_lapl_frac}, kRadMissing);
+    if (p.adaptive_abs_lapl_frac >= 0.0) Require(p, {BL_P_adaptive_abs_lapl_cut}, kRadMissing);
+    Require(p, {BL_P_adaptive_rel_lapl_frac}, kRadMissing);
+    if (p.adaptive_rel_lapl_frac >= 0.0) Require(p, {BL_P_adaptive_rel_lapl_cut}, kRadMissing);
+    Require(p, {BL_P_adaptive_num_regions}, kRadMissing);
+    for (int r = 0; r < p.adaptive_num_regions; r++)
+      if (p.adaptive_region_has[r] != 31) throw Failure{BL_E_MISSING, kRadMissing};
+  }
   if (simulation) {
     Require(p, {BL_P_plasma_mu, BL_P_plasma_ne_ni, BL_P_plasma_model}, kRadMissing);
     if (p.plasma_model == BL_PLASMA_TI_TE_BETA)
@@ -368,6 +390,11 @@ int bl_init(const bl_params *p, int device, bl_ctx **out) {
     ValidateRadiation(ctx);
     BuildFrequencies(ctx);
     bl_camera_frame_build(ctx->params, ctx->st, &ctx->frame);
+    if (device == BL_DEVICE_NONE) {   // host-only context: validation, camera frame, refinement, writer
+      ctx->device = BL_DEVICE_NONE;
+      *out = ctx;
+      return BL_OK;
+    }
     int count = 0;
     hipError_t err = hipGetDeviceCount(&count);
     if (err != hipSuccess || count <= 0)
@@ -392,6 +419,7 @@ int bl_init(const bl_params *p, int device, bl_ctx **out) {
 int bl_set_grid(bl_ctx *ctx, const bl_grid_desc *g) {
   if (ctx == nullptr || g == nullptr) return BL_E_ARG;
   try {
+    if (ctx->device == BL_DEVICE_NONE) throw Failure{BL_E_DEVICE, "Host-only context: no HIP device selected (the hot path has no CPU fallback)."};
     if (ctx->params.model_type != BL_MODEL_SIMULATION) throw Failure{BL_E_STATE, "bl_set_grid called in formula mode."};
     if (g->n_blocks != 1)
       throw Failure{BL_E_UNSUPPORTED, "Multi-block (mesh-refined) grids are not built yet; single-block grids only."};
@@ -489,6 +517,7 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
   try {
     const bl_params &p = ctx->params;
     const bool simulation = p.model_type == BL_MODEL_SIMULATION;
+    if (ctx->device == BL_DEVICE_NONE) throw Failure{BL_E_DEVICE, "Host-only context: no HIP device selected (the hot path has no CPU fallback)."};
     if (simulation && !ctx->have_grid) throw Failure{BL_E_STATE, "bl_render called before bl_set_grid."};
     if (d->n_rays <= 0 || d->image == nullptr) throw Failure{BL_E_ARG, "bl_render needs n_rays > 0 and an image buffer."};
     if (d->n_rays > 0x7fffffffll) throw Failure{BL_E_ARG, "Too many rays in one bl_render call."};
@@ -762,6 +791,10 @@ const char *bl_warnings(const bl_ctx *ctx) { return ctx != nullptr ? ctx->warnin
 
 void bl_free(bl_ctx *ctx) {
   if (ctx == nullptr) return;
+  if (ctx->device == BL_DEVICE_NONE) {
+    delete ctx;
+    return;
+  }
   (void)hipSetDevice(ctx->device);
   ctx->d_cells.Free(); ctx->d_coords.Free(); ctx->d_buckets.Free(); ctx->d_records.Free(); ctx->d_transfer.Free();
   ctx->d_ray_kt.Free(); ctx->d_ray_factor.Free(); ctx->d_freq.Free(); ctx->d_ray_sample_num.Free();
@@ -777,3 +810,14 @@ void bl_free(bl_ctx *ctx) {
 const char *bl_build_info(void) { return "blacklight_amd;hip;gfx950;fp-contract=off"; }
 
 }  // extern "C"
+
+const bl_params *bl_internal_params(const bl_ctx *ctx) { return &ctx->params; }
+const bl_camera_frame *bl_internal_frame(const bl_ctx *ctx) { return &ctx->frame; }
+const double *bl_internal_frequencies(const bl_ctx *ctx, int *count) {
+  *count = static_cast<int>(ctx->frequencies.size());
+  return ctx->frequencies.data();
+}
+int bl_internal_fail(bl_ctx *ctx, int code, const char *message) {
+  ctx->last_error = std::string("Error: ") + message + "\n";
+  return code;
+}

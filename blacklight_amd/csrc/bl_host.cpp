@@ -1,0 +1,405 @@
+// bl_host.cpp - the two host-side steps that sit between and after GPU renders, kept on the host as
+// in the reference: the adaptive refinement decision (src/radiation_integrator/
+// radiation_adaptive.cpp:19-312 + the block bookkeeping of camera.cpp:445-458) and the output writer
+// (src/output_writer/output_writer.cpp:169-316, numpy_format.cpp, zip_format.cpp, raw_format.cpp).
+// The .npy / ZIP byte layout is the reference's (NumPy .npy v1.0 with a 128-byte header, ZIP 2.0
+// stored entries with CRC-32), so its plotting scripts read the files unchanged.
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <ctime>
+#include <fstream>
+#include <string>
+#include <vector>
+
+#include "bl_internal.h"
+#include "blmath.h"
+
+namespace {
+
+// ------------------------------------------------------------------ adaptive refinement
+// EvaluateBlock (radiation_adaptive.cpp:163-312). q(row, col) = intensity of the block.
+bool EvaluateBlock(const bl_params &p, const double *block, int bs) {
+  auto q_at = [&](int i, int j) { return block[i * bs + j]; };
+  auto exceeds = [](int num_exceeded, int num_examined, double frac_cut) {
+    double frac = static_cast<double>(num_exceeded) / static_cast<double>(num_examined);
+    return frac > frac_cut;
+  };
+  if (p.adaptive_val_frac >= 0.0) {
+    int num_examined = 0, num_exceeded = 0;
+    for (int i = 0; i < bs; i++)
+      for (int j = 0; j < bs; j++) {
+        double q = std::abs(q_at(i, j));
+        if (!std::isfinite(q)) continue;
+        num_examined++;
+        if (q > p.adaptive_val_cut) num_exceeded++;
+      }
+    if (exceeds(num_exceeded, num_examined, p.adaptive_val_frac)) return true;
+  }
+  if (p.adaptive_abs_grad_frac >= 0.0) {
+    int num_examined = 0, num_exceeded = 0;
+    for (int i = 0; i < bs; i++)
+      for (int j = 0; j < bs; j++) {
+        double q_x = j == 0 ? q_at(i, j + 1) - q_at(i, j)
+            : (j == bs - 1 ? q_at(i, j) - q_at(i, j - 1) : 0.5 * (q_at(i, j + 1) - q_at(i, j - 1)));
+        double q_y = i == 0 ? q_at(i + 1, j) - q_at(i, j)
+            : (i == bs - 1 ? q_at(i, j) - q_at(i - 1, j) : 0.5 * (q_at(i + 1, j) - q_at(i - 1, j)));
+        double q = bl_hypot(q_x, q_y);
+        if (!std::isfinite(q)) continue;
+        num_examined++;
+        if (q > p.adaptive_abs_grad_cut) num_exceeded++;
+      }
+    if (exceeds(num_exceeded, num_examined, p.adaptive_abs_grad_frac)) return true;
+  }
+  if (p.adaptive_rel_grad_frac >= 0.0) {
+    int num_examined = 0, num_exceeded = 0;
+    for (int i = 0; i < bs; i++)
+      for (int j = 0; j < bs; j++) {
+        double q_x;
+        if (j == 0)
+          q_x = 2.0 * (q_at(i, j + 1) - q_at(i, j)) / (q_at(i, j) + q_at(i, j + 1));
+        else if (j == bs - 1)
+          q_x = 2.0 * (q_at(i, j) - q_at(i, j - 1)) / (q_at(i, j - 1) + q_at(i, j));
+        else
+          q_x = 2.0 * (q_at(i, j + 1) - q_at(i, j - 1)) / (q_at(i, j - 1) + 2.0 * q_at(i, j) + q_at(i, j + 1));
+        double q_y;
+        if (i == 0)
+          q_y = 2.0 * (q_at(i + 1, j) - q_at(i, j)) / (q_at(i, j) + q_at(i + 1, j));
+        else if (i == bs - 1)
+          q_y = 2.0 * (q_at(i, j) - q_at(i - 1, j)) / (q_at(i - 1, j) + q_at(i, j));
+        else
+          q_y = 2.0 * (q_at(i + 1, j) - q_at(i - 1, j)) / (q_at(i - 1, j) + 2.0 * q_at(i, j) + q_at(i + 1, j));
+        double q = bl_hypot(q_x, q_y);
+        if (!std::isfinite(q)) continue;
+        num_examined++;
+        if (q > p.adaptive_rel_grad_cut) num_exceeded++;
+      }
+    if (exceeds(num_exceeded, num_examined, p.adaptive_rel_grad_frac)) return true;
+  }
+  if (p.adaptive_abs_lapl_frac >= 0.0) {
+    int num_examined = 0, num_exceeded = 0;
+    for (int i = 1; i < bs - 1; i++)
+      for (int j = 1; j < bs - 1; j++) {
+        double q_x = q_at(i, j - 1) - 2.0 * q_at(i, j) + q_at(i, j + 1);
+        double q_y = q_at(i - 1, j) - 2.0 * q_at(i, j) + q_at(i + 1, j);
+        double q = std::abs(q_x + q_y);
+        if (!std::isfinite(q)) continue;
+        num_examined++;
+        if (q > p.adaptive_abs_lapl_cut) num_exceeded++;
+      }
+    if (exceeds(num_exceeded, num_examined, p.adaptive_abs_lapl_frac)) return true;
+  }
+  if (p.adaptive_rel_lapl_frac >= 0.0) {
+    int num_examined = 0, num_exceeded = 0;
+    for (int i = 1; i < bs - 1; i++)
+      for (int j = 1; j < bs - 1; j++) {
+        double q_x = 4.0 * (q_at(i, j - 1) - 2.0 * q_at(i, j) + q_at(i, j + 1))
+            / (q_at(i, j - 1) + 2.0 * q_at(i, j) + q_at(i, j + 1));
+        double q_y = 4.0 * (q_at(i - 1, j) - 2.0 * q_at(i, j) + q_at(i + 1, j))
+            / (q_at(i - 1, j) + 2.0 * q_at(i, j) + q_at(i + 1, j));
+        double q = std::abs(q_x + q_y);
+        if (!std::isfinite(q)) continue;
+        num_examined++;
+        if (q > p.adaptive_rel_lapl_cut) num_exceeded++;
+      }
+    if (exceeds(num_exceeded, num_examined, p.adaptive_rel_lapl_frac)) return true;
+  }
+  return false;
+}
+
+// ------------------------------------------------------------------ .npy / ZIP
+using Bytes = std::vector<uint8_t>;
+
+// NumPy .npy v1.0 with the reference's fixed 128-byte header (numpy_format.cpp:604-664)
+Bytes MakeNpy(const char *descr, const std::vector<int> &shape, const void *data, size_t data_bytes) {
+  const size_t header_length = 128;
+  Bytes out(header_length + data_bytes);
+  std::memcpy(out.data(), "\x93NUMPY\x01\x00", 8);
+  uint16_t header_len = static_cast<uint16_t>(header_length - 10);
+  std::memcpy(out.data() + 8, &header_len, 2);
+  std::string dict = std::string("{'descr': '") + descr + "', 'fortran_order': False, 'shape': (";
+  for (size_t i = 0; i < shape.size(); i++) {
+    dict += std::to_string(shape[i]);
+    if (shape.size() == 1) dict += ",";
+    else if (i + 1 < shape.size()) dict += ", ";
+  }
+  dict += ")}";
+  if (dict.size() > header_length - 11) return Bytes();
+  std::memset(out.data() + 10, ' ', header_length - 11);
+  std::memcpy(out.data() + 10, dict.data(), dict.size());
+  out[header_length - 1] = '\n';
+  if (data_bytes > 0) std::memcpy(out.data() + header_length, data, data_bytes);
+  return out;
+}
+
+// Standard CRC-32 (what zip_format.cpp:284-360 computes with its bit-reversed tables)
+uint32_t Crc32(const uint8_t *data, size_t n) {
+  static uint32_t table[256];
+  static bool ready = false;
+  if (!ready) {
+    for (uint32_t i = 0; i < 256; i++) {
+      uint32_t c = i;
+      for (int k = 0; k < 8; k++) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+      table[i] = c;
+    }
+    ready = true;
+  }
+  uint32_t crc = 0xFFFFFFFFu;
+  for (size_t i = 0; i < n; i++) crc = table[(crc ^ data[i]) & 0xFFu] ^ (crc >> 8);
+  return crc ^ 0xFFFFFFFFu;
+}
+
+struct ZipEntry {
+  Bytes local_header;
+  Bytes data;
+};
+
+template <typename T>
+void Put(Bytes *b, T v) {
+  const uint8_t *p = reinterpret_cast<const uint8_t *>(&v);
+  b->insert(b->end(), p, p + sizeof(T));
+}
+
+// zip_format.cpp:26-110
+bool MakeLocalHeader(const std::string &name, const Bytes &record, Bytes *header) {
+  if (record.size() > UINT32_MAX) return false;
+  std::string full = name + ".npy";
+  header->clear();
+  header->insert(header->end(), {0x50, 0x4b, 0x03, 0x04});
+  Put<uint8_t>(header, 20);   // version needed 2.0
+  Put<uint8_t>(header, 0);
+  Put<uint16_t>(header, 0);   // flags
+  Put<uint16_t>(header, 0);   // stored
+  std::time_t now = std::time(nullptr);
+  std::tm *lt = std::localtime(&now);
+  uint16_t time = static_cast<uint16_t>(lt->tm_hour << 11);
+  time |= static_cast<uint16_t>((lt->tm_min & 0x1F) << 5);
+  time |= static_cast<uint16_t>(lt->tm_sec / 2 & 0x1F);
+  uint16_t date = static_cast<uint16_t>((lt->tm_year - 80) << 9);
+  date |= static_cast<uint16_t>(((lt->tm_mon + 1) & 0xF) << 5);
+  date |= static_cast<uint16_t>(lt->tm_mday & 0x1F);
+  Put<uint16_t>(header, time);
+  Put<uint16_t>(header, date);
+  Put<uint32_t>(header, Crc32(record.data(), record.size()));
+  Put<uint32_t>(header, static_cast<uint32_t>(record.size()));
+  Put<uint32_t>(header, static_cast<uint32_t>(record.size()));
+  Put<uint16_t>(header, static_cast<uint16_t>(full.size()));
+  Put<uint16_t>(header, 0);
+  header->insert(header->end(), full.begin(), full.end());
+  return true;
+}
+
+// zip_format.cpp:122-190
+Bytes MakeCentralHeader(const Bytes &local, size_t offset) {
+  Bytes out = {0x50, 0x4b, 0x01, 0x02};
+  Put<uint8_t>(&out, 20);   // version made by 2.0
+  Put<uint8_t>(&out, 3);    // unix
+  out.insert(out.end(), local.begin() + 4, local.begin() + 30);
+  Put<uint16_t>(&out, 0);   // comment length
+  Put<uint16_t>(&out, 0);   // disk number
+  Put<uint16_t>(&out, 0);   // internal attributes
+  Put<uint32_t>(&out, 0x81800000u);
+  Put<uint32_t>(&out, static_cast<uint32_t>(offset));
+  out.insert(out.end(), local.begin() + 30, local.end());
+  return out;
+}
+
+// output_writer.cpp:283-316
+bool FormatFilename(const std::string &pattern, int file_number, std::string *out) {
+  std::string::size_type open = pattern.find_first_of('{');
+  if (open == std::string::npos) return false;
+  std::string::size_type close = pattern.find_first_of('}', open);
+  if (close == std::string::npos) return false;
+  if (pattern[close - 1] != 'd') return false;
+  int field_length = 0;
+  if (close - open > 2) field_length = std::atoi(pattern.substr(open + 1, close - open - 2).c_str());
+  std::string number = std::to_string(file_number);
+  std::string zeros;
+  if (static_cast<int>(number.size()) < field_length) zeros.assign(field_length - number.size(), '0');
+  *out = pattern.substr(0, open) + zeros + number + pattern.substr(close + 1);
+  return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bl_adaptive_refine(const bl_ctx *ctx_const, int level, int n_blocks, const int32_t *block_locs,
+                       const double *image, uint8_t *refine_flags, int32_t *n_refined, int32_t *next_locs) {
+  bl_ctx *ctx = const_cast<bl_ctx *>(ctx_const);
+  if (ctx == nullptr || image == nullptr || refine_flags == nullptr || n_refined == nullptr) return BL_E_ARG;
+  const bl_params &p = *bl_internal_params(ctx);
+  *n_refined = 0;
+  if (p.adaptive_max_level <= 0 || level >= p.adaptive_max_level) {   // radiation_adaptive.cpp:22-23
+    for (int b = 0; b < n_blocks; b++) refine_flags[b] = 0;
+    return BL_OK;
+  }
+  const int bs = p.adaptive_block_size;
+  const int linear_root_blocks = p.camera_resolution / bs;
+  if (level == 0 && n_blocks != linear_root_blocks * linear_root_blocks)
+    return bl_internal_fail(ctx, BL_E_ARG, "Level 0 must be evaluated with all root blocks.");
+  if (level > 0 && block_locs == nullptr) return bl_internal_fail(ctx, BL_E_ARG, "Refined levels need block_locs.");
+  int linear_num_blocks = linear_root_blocks;
+  for (int n = 1; n <= level; n++) linear_num_blocks *= 2;
+  const int block_num_pix = bs * bs;
+  const long long n_pix = level == 0 ? static_cast<long long>(p.camera_resolution) * p.camera_resolution
+                                     : static_cast<long long>(n_blocks) * block_num_pix;
+  // row of I_nu at the chosen frequency (polarization is outside the built scope: stride 1)
+  const int freq_index = p.image_num_frequencies > 1 ? p.adaptive_frequency_num - 1 : 0;
+  const double *row = image + static_cast<size_t>(freq_index) * n_pix;
+  std::vector<double> block(block_num_pix);
+  int count = 0;
+  for (int b = 0; b < n_blocks; b++) {
+    const int loc_v = level == 0 ? b / linear_root_blocks : block_locs[2 * b + 0];
+    const int loc_u = level == 0 ? b % linear_root_blocks : block_locs[2 * b + 1];
+    bool flag = false;
+    bool decided = false;
+    if (p.adaptive_num_regions > 0) {   // forced regions (:52-69, :96-113)
+      double y = ((loc_v + 0.5) / linear_num_blocks - 0.5) * p.camera_width;
+      double x = ((loc_u + 0.5) / linear_num_blocks - 0.5) * p.camera_width;
+      for (int r = 0; r < p.adaptive_num_regions; r++)
+        if (level < p.adaptive_region_level[r] && x > p.adaptive_region_x_min[r] && x < p.adaptive_region_x_max[r]
+            && y > p.adaptive_region_y_min[r] && y < p.adaptive_region_y_max[r]) {
+          flag = true;
+          decided = true;
+          break;
+        }
+    }
+    if (!decided) {
+      if (level == 0) {
+        const int j0 = loc_v * bs, i0 = loc_u * bs;
+        for (int j = 0; j < bs; j++)
+          for (int i = 0; i < bs; i++) block[j * bs + i] = row[static_cast<size_t>(j0 + j) * p.camera_resolution + i0 + i];
+      } else {
+        std::memcpy(block.data(), row + static_cast<size_t>(b) * block_num_pix, sizeof(double) * block_num_pix);
+      }
+      flag = EvaluateBlock(p, block.data(), bs);
+    }
+    refine_flags[b] = flag ? 1 : 0;
+    if (flag) {
+      if (next_locs != nullptr) {   // camera.cpp:453-458
+        int32_t *dst = next_locs + static_cast<size_t>(count) * 8;
+        int k = 0;
+        for (int v = 2 * loc_v; v <= 2 * loc_v + 1; v++)
+          for (int u = 2 * loc_u; u <= 2 * loc_u + 1; u++) {
+            dst[2 * k + 0] = v;
+            dst[2 * k + 1] = u;
+            k++;
+          }
+      }
+      count++;
+    }
+  }
+  *n_refined = count;
+  return BL_OK;
+}
+
+int bl_write_output(bl_ctx *ctx, const char *path_override, const bl_output_desc *d) {
+  if (ctx == nullptr || d == nullptr || d->level[0].image == nullptr) return BL_E_ARG;
+  const bl_params &p = *bl_internal_params(ctx);
+  const bl_camera_frame &frame = *bl_internal_frame(ctx);
+  int n_nu = 0;
+  const double *frequencies = bl_internal_frequencies(ctx, &n_nu);
+  const int res = p.camera_resolution;
+  const int n_q = bl_image_num_quantities(ctx);
+  const size_t n_pix = static_cast<size_t>(res) * res;
+
+  std::string path;
+  if (path_override != nullptr && path_override[0] != '\0') {
+    path = path_override;
+  } else {
+    if (!p.has[BL_P_output_file]) return bl_internal_fail(ctx, BL_E_MISSING, "OutputWriter unable to find all needed values in input file.");
+    path = p.output_file.s;
+    if (p.model_type == BL_MODEL_SIMULATION && p.simulation_multiple) {
+      int file_number = d->snapshot + (p.slow_light_on ? p.slow_offset : p.simulation_start);
+      if (!FormatFilename(p.output_file.s, file_number, &path))
+        return bl_internal_fail(ctx, BL_E_INPUT, "Invalid output_file for multiple runs.");
+    }
+  }
+  std::ofstream stream(path, std::ios_base::out | std::ios_base::binary);
+  if (!stream.is_open()) return bl_internal_fail(ctx, BL_E_INPUT, "Could not open output file.");
+
+  const double *image0 = d->level[0].image;
+  if (p.output_format == BL_OUTPUT_RAW) {   // raw_format.cpp: the bytes of image[0]
+    stream.write(reinterpret_cast<const char *>(image0), static_cast<std::streamsize>(sizeof(double) * n_q * n_pix));
+    return BL_OK;
+  }
+  if (p.output_format == BL_OUTPUT_NPY) {   // numpy_format.cpp:19-32: image[0] as (n_q, res, res)
+    Bytes npy = MakeNpy("<f8", {n_q, res, res}, image0, sizeof(double) * n_q * n_pix);
+    stream.write(reinterpret_cast<const char *>(npy.data()), static_cast<std::streamsize>(npy.size()));
+    return BL_OK;
+  }
+
+  // npz (numpy_format.cpp:46-584), records in the reference's order
+  std::vector<std::pair<std::string, Bytes>> records;
+  auto add = [&](const std::string &name, Bytes bytes) { records.emplace_back(name, std::move(bytes)); };
+  double mass_msun = frame.mass_msun;
+  double width = p.camera_width;
+  int32_t num_levels = d->adaptive_num_levels;
+  add("mass_msun", MakeNpy("<f8", {1}, &mass_msun, 8));
+  add("width", MakeNpy("<f8", {1}, &width, 8));
+  add("frequency", MakeNpy("<f8", {n_nu}, frequencies, sizeof(double) * n_nu));
+  add("adaptive_num_levels", MakeNpy("<i4", {1}, &num_levels, 4));
+  if (p.adaptive_max_level > 0) {
+    std::vector<int32_t> counts(num_levels + 1);
+    counts[0] = (res / p.adaptive_block_size) * (res / p.adaptive_block_size);
+    for (int l = 1; l <= num_levels; l++) counts[l] = d->level[l].n_blocks;
+    add("adaptive_num_blocks", MakeNpy("<i4", {num_levels + 1}, counts.data(), 4 * counts.size()));
+  }
+  const char *camera_name = p.camera_type == BL_CAMERA_PLANE ? "positions" : "directions";
+  if (p.output_camera) {
+    if (d->level[0].camera == nullptr) return bl_internal_fail(ctx, BL_E_ARG, "output_camera needs camera data.");
+    add(camera_name, MakeNpy("<f8", {res, res, 4}, d->level[0].camera, sizeof(double) * n_pix * 4));
+  }
+  if (p.image_light) {
+    std::vector<int> shape = n_nu == 1 ? std::vector<int>{res, res} : std::vector<int>{n_nu, res, res};
+    add("I_nu", MakeNpy("<f8", shape, image0, sizeof(double) * n_nu * n_pix));
+  }
+  const int bs = p.adaptive_max_level > 0 ? p.adaptive_block_size : 1;
+  for (int l = 1; l <= num_levels; l++) {
+    const bl_output_level &lv = d->level[l];
+    if (lv.image == nullptr || lv.block_locs == nullptr) return bl_internal_fail(ctx, BL_E_ARG, "Missing adaptive level data.");
+    const std::string suffix = "_" + std::to_string(l);
+    const size_t level_pix = static_cast<size_t>(lv.n_blocks) * bs * bs;
+    add("adaptive_block_locs" + suffix, MakeNpy("<i4", {lv.n_blocks, 2}, lv.block_locs, 8 * static_cast<size_t>(lv.n_blocks)));
+    if (p.output_camera) {
+      if (lv.camera == nullptr) return bl_internal_fail(ctx, BL_E_ARG, "output_camera needs camera data.");
+      add(std::string("adaptive_") + camera_name + suffix, MakeNpy("<f8", {lv.n_blocks, bs, bs, 4}, lv.camera, sizeof(double) * level_pix * 4));
+    }
+    if (p.image_light) {
+      std::vector<int> shape = n_nu == 1 ? std::vector<int>{lv.n_blocks, bs, bs} : std::vector<int>{n_nu, lv.n_blocks, bs, bs};
+      add("adaptive_I_nu" + suffix, MakeNpy("<f8", shape, lv.image, sizeof(double) * n_nu * level_pix));
+    }
+  }
+
+  std::vector<Bytes> local_headers(records.size()), central_headers(records.size());
+  size_t offset = 0;
+  for (size_t n = 0; n < records.size(); n++) {
+    if (records[n].second.empty() || !MakeLocalHeader(records[n].first, records[n].second, &local_headers[n]))
+      return bl_internal_fail(ctx, BL_E_INPUT, "Array and metadata too large for ZIP record.");
+    central_headers[n] = MakeCentralHeader(local_headers[n], offset);
+    offset += local_headers[n].size() + records[n].second.size();
+  }
+  size_t central_length = 0;
+  for (const Bytes &h : central_headers) central_length += h.size();
+  if (offset > UINT32_MAX || central_length > UINT32_MAX)
+    return bl_internal_fail(ctx, BL_E_INPUT, "File contents too large for ZIP format.");
+  Bytes end = {0x50, 0x4b, 0x05, 0x06};
+  Put<uint16_t>(&end, 0);
+  Put<uint16_t>(&end, 0);
+  Put<uint16_t>(&end, static_cast<uint16_t>(records.size()));
+  Put<uint16_t>(&end, static_cast<uint16_t>(records.size()));
+  Put<uint32_t>(&end, static_cast<uint32_t>(central_length));
+  Put<uint32_t>(&end, static_cast<uint32_t>(offset));
+  Put<uint16_t>(&end, 0);
+  for (size_t n = 0; n < records.size(); n++) {
+    stream.write(reinterpret_cast<const char *>(local_headers[n].data()), static_cast<std::streamsize>(local_headers[n].size()));
+    stream.write(reinterpret_cast<const char *>(records[n].second.data()), static_cast<std::streamsize>(records[n].second.size()));
+  }
+  for (const Bytes &h : central_headers) stream.write(reinterpret_cast<const char *>(h.data()), static_cast<std::streamsize>(h.size()));
+  stream.write(reinterpret_cast<const char *>(end.data()), static_cast<std::streamsize>(end.size()));
+  return stream.good() ? BL_OK : bl_internal_fail(ctx, BL_E_INPUT, "Could not write output file.");
+}
+
+}  // extern "C"

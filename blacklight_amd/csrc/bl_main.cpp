@@ -1,0 +1,211 @@
+// bl_main.cpp - command-line driver with the reference's outer contract (src/blacklight.cpp:31-273):
+// exactly one argument, the .input file; errors on stdout as "Error: ...\n", warnings on stderr as
+// "Warning: ...\n", exit code 0 / 1, the same timing block at the end. Everything between reading the
+// parameters and writing the image goes through the C-ABI (include/blacklight_amd.h) to the GPU.
+//
+// Snapshot input: the reference's own HDF5 / AthenaK / iharm readers are outside the hot-path scope
+// (SURVEY.md 8f); simulation_file must be a raw single-block grid file as written by
+// blacklight_amd.mock.Grid.save_raw (magic "BLGRID1", dimensions, coordinates, primitives), i.e. the
+// arrays SimulationReader would have produced.
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iomanip>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include "../../include/blacklight_amd.h"
+
+namespace {
+
+double Now() {
+  using clock = std::chrono::steady_clock;
+  return std::chrono::duration<double>(clock::now().time_since_epoch()).count();
+}
+
+struct RawGrid {
+  int32_t n_i = 0, n_j = 0, n_k = 0, n_var = 0;
+  std::vector<double> coords[6];   // x1f x2f x3f x1v x2v x3v
+  std::vector<float> prim;
+};
+
+bool ReadRawGrid(const std::string &path, RawGrid *g, std::string *error) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f.is_open()) {
+    *error = "Could not open file: " + path;
+    return false;
+  }
+  char magic[8] = {};
+  f.read(magic, 8);
+  if (std::memcmp(magic, "BLGRID1\0", 8) != 0) {
+    *error = "simulation_file is not a raw BLGRID1 grid (the HDF5 / AthenaK / iharm readers are outside the "
+             "scope of the MI355X hot path; convert the snapshot with blacklight_amd.mock.Grid.save_raw).";
+    return false;
+  }
+  int32_t dims[4];
+  f.read(reinterpret_cast<char *>(dims), sizeof dims);
+  g->n_i = dims[0];
+  g->n_j = dims[1];
+  g->n_k = dims[2];
+  g->n_var = dims[3];
+  const int counts[6] = {g->n_i + 1, g->n_j + 1, g->n_k + 1, g->n_i, g->n_j, g->n_k};
+  for (int c = 0; c < 6; c++) {
+    g->coords[c].resize(counts[c]);
+    f.read(reinterpret_cast<char *>(g->coords[c].data()), sizeof(double) * counts[c]);
+  }
+  size_t n = static_cast<size_t>(g->n_var) * g->n_k * g->n_j * g->n_i;
+  g->prim.resize(n);
+  f.read(reinterpret_cast<char *>(g->prim.data()), sizeof(float) * n);
+  if (!f) {
+    *error = "Could not read file: " + path;
+    return false;
+  }
+  return true;
+}
+
+}  // namespace
+
+int main(int argc, char *argv[]) {
+  double time_start = Now();
+  double time_geodesic = 0.0, time_read = 0.0, time_sample = 0.0, time_image = 0.0, time_render = 0.0;
+  if (argc != 2) {
+    std::cout << "Error: Must give a single input file.\n";
+    return 1;
+  }
+  static bl_params params;
+  char err[1024] = "";
+  int num_runs = 1;
+  if (bl_params_read_file(&params, argv[1], &num_runs, err, sizeof err) != BL_OK) {
+    std::cout << err;
+    return 1;
+  }
+  if (!params.has[BL_P_num_threads]) {
+    std::cout << "Error: num_threads not specified in input file.\n";
+    return 1;
+  }
+  bl_ctx *ctx = nullptr;
+  if (bl_init(&params, -1, &ctx) != BL_OK) {
+    std::cout << bl_last_global_error();
+    return 1;
+  }
+  const bool simulation = params.model_type == BL_MODEL_SIMULATION;
+  const int res = params.camera_resolution;
+  const int n_q = bl_image_num_quantities(ctx);
+  const int bs = params.adaptive_max_level > 0 ? params.adaptive_block_size : 1;
+  const bool want_camera = params.has[BL_P_output_camera] && params.output_camera && params.output_format == BL_OUTPUT_NPZ;
+
+  for (int run = 0; run < num_runs; run++) {
+    if (simulation) {
+      double t0 = Now();
+      if (params.simulation_multiple) {
+        std::cout << "Error: simulation_multiple needs the reference's file-series reader, which is outside the scope of the MI355X hot path.\n";
+        return 1;
+      }
+      RawGrid raw;
+      std::string message;
+      if (!params.has[BL_P_simulation_file] || !ReadRawGrid(params.simulation_file.s, &raw, &message)) {
+        std::cout << "Error: " << (message.empty() ? "SimulationReader unable to find all needed values in input file." : message) << "\n";
+        return 1;
+      }
+      bl_grid_desc g = {};
+      g.n_blocks = 1;
+      g.n_i = raw.n_i; g.n_j = raw.n_j; g.n_k = raw.n_k; g.n_var = raw.n_var;
+      g.prim = raw.prim.data();
+      g.x1f = raw.coords[0].data(); g.x2f = raw.coords[1].data(); g.x3f = raw.coords[2].data();
+      g.x1v = raw.coords[3].data(); g.x2v = raw.coords[4].data(); g.x3v = raw.coords[5].data();
+      g.ind_rho = 0; g.ind_pgas = 1; g.ind_uu1 = 2; g.ind_uu2 = 3; g.ind_uu3 = 4;
+      g.ind_bb1 = 5; g.ind_bb2 = 6; g.ind_bb3 = 7;
+      g.plasma_gamma = params.has[BL_P_plasma_gamma] ? params.plasma_gamma : 0.0;
+      g.plasma_gamma_i = params.has[BL_P_plasma_gamma_i] ? params.plasma_gamma_i : 0.0;
+      g.plasma_gamma_e = params.has[BL_P_plasma_gamma_e] ? params.plasma_gamma_e : 0.0;
+      if (bl_set_grid(ctx, &g) != BL_OK) {
+        std::cout << bl_last_error(ctx);
+        return 1;
+      }
+      time_read += Now() - t0;
+    }
+
+    // do { Integrate; if (!done) AddGeodesics } while (!done)   (blacklight.cpp:196-233)
+    std::vector<std::vector<double>> images, cameras;
+    std::vector<std::vector<int32_t>> locs(1);
+    std::vector<int32_t> counts = {bs > 0 && params.adaptive_max_level > 0 ? (res / bs) * (res / bs) : 0};
+    int level = 0;
+    while (true) {
+      const long long n_rays = level == 0 ? static_cast<long long>(res) * res
+                                          : static_cast<long long>(counts[level]) * bs * bs;
+      images.emplace_back(static_cast<size_t>(n_q) * n_rays);
+      cameras.emplace_back(want_camera ? static_cast<size_t>(n_rays) * 4 : 0);
+      bl_render_desc d = {};
+      d.level = level;
+      d.n_blocks = level == 0 ? 0 : counts[level];
+      d.block_locs = level == 0 ? nullptr : locs[level].data();
+      d.n_rays = n_rays;
+      d.image = images.back().data();
+      if (want_camera) {
+        if (params.camera_type == BL_CAMERA_PLANE) d.camera_pos = cameras.back().data();
+        else d.camera_dir = cameras.back().data();
+      }
+      double t0 = Now();
+      if (bl_render(ctx, &d) != BL_OK) {
+        std::cout << bl_last_error(ctx);
+        return 1;
+      }
+      bl_stats st;
+      bl_get_stats(ctx, &st);
+      double elapsed = Now() - t0;
+      // attribute wall time to the reference's three timers in proportion to kernel time
+      double kernel = st.ms_total > 0.0f ? st.ms_total : 1.0;
+      time_geodesic += elapsed * st.ms_geodesic / kernel;
+      (simulation ? time_sample : time_image) += elapsed * st.ms_shade / kernel * (simulation ? 0.5 : 1.0);
+      time_image += elapsed * (st.ms_transfer + (simulation ? 0.5 * st.ms_shade : 0.0)) / kernel;
+
+      if (params.adaptive_max_level <= 0) break;
+      double t1 = Now();
+      std::vector<uint8_t> flags(counts[level]);
+      std::vector<int32_t> next(static_cast<size_t>(counts[level]) * 8);
+      int32_t n_refined = 0;
+      if (bl_adaptive_refine(ctx, level, counts[level], level == 0 ? nullptr : locs[level].data(),
+                             images.back().data(), flags.data(), &n_refined, next.data()) != BL_OK) {
+        std::cout << bl_last_error(ctx);
+        return 1;
+      }
+      time_image += Now() - t1;
+      if (n_refined == 0) break;
+      next.resize(static_cast<size_t>(n_refined) * 8);
+      locs.push_back(next);
+      counts.push_back(n_refined * 4);
+      level++;
+    }
+    std::cerr << bl_warnings(ctx);
+
+    bl_output_desc out = {};
+    out.adaptive_num_levels = level;
+    out.snapshot = run;
+    for (int l = 0; l <= level; l++) {
+      out.level[l].n_blocks = l == 0 ? 0 : counts[l];
+      out.level[l].block_locs = l == 0 ? nullptr : locs[l].data();
+      out.level[l].image = images[l].data();
+      out.level[l].camera = want_camera ? cameras[l].data() : nullptr;
+    }
+    if (bl_write_output(ctx, nullptr, &out) != BL_OK) {
+      std::cout << bl_last_error(ctx);
+      return 1;
+    }
+  }
+  bl_free(ctx);
+
+  double time_full = Now() - time_start;   // blacklight.cpp:259-269
+  std::cout << std::setprecision(7);
+  std::cout << "\nCalculation completed.";
+  std::cout << "\nElapsed time:            " << time_full << " s";
+  std::cout << "\n  Integrating geodesics: " << time_geodesic << " s";
+  std::cout << "\n  Reading simulation:    " << time_read << " s";
+  std::cout << "\n  Sampling simulation:   " << time_sample << " s";
+  std::cout << "\n  Integrating image:     " << time_image << " s";
+  std::cout << "\n  Rendering:             " << time_render << " s";
+  std::cout << "\n\n";
+  return 0;
+}

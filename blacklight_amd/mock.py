@@ -61,6 +61,18 @@ class Grid:
     def shape(self):
         return self.prim.shape[2:]
 
+    def save_raw(self, path):
+        """Raw single-block grid file read by the command-line driver (bl_main.cpp): magic "BLGRID1",
+        int32 n_i, n_j, n_k, n_var, float64 x1f x2f x3f x1v x2v x3v, float32 prim[n_var][n_k][n_j][n_i]."""
+        n_var, n_b, n_k, n_j, n_i = self.prim.shape
+        assert n_b == 1
+        with open(path, "wb") as f:
+            f.write(b"BLGRID1\0")
+            np.array([n_i, n_j, n_k, n_var], dtype=np.int32).tofile(f)
+            for name in ("x1f", "x2f", "x3f", "x1v", "x2v", "x3v"):
+                np.ascontiguousarray(getattr(self, name)[0], dtype=np.float64).tofile(f)
+            np.ascontiguousarray(self.prim, dtype=np.float32).tofile(f)
+
     def desc(self):
         """bl_grid_desc borrowing this object's arrays (keep `self` alive while it is used)."""
         d = _capi.GridDesc()

@@ -211,8 +211,10 @@ typedef struct bl_stats {
 typedef struct bl_ctx bl_ctx;
 
 /* Validate parameters exactly like the two reference constructors, compute the camera frame and
- * frequency list on the host, select the device (device < 0: current device) and allocate
- * nothing large yet. */
+ * frequency list on the host, select the device (device = -1: current device) and allocate
+ * nothing large yet. device = BL_DEVICE_NONE gives a host-only context (parameter validation, camera
+ * frame, bl_adaptive_refine, bl_write_output); bl_set_grid / bl_render on it fail with BL_E_DEVICE. */
+#define BL_DEVICE_NONE (-2)
 BL_API int bl_init(const bl_params *p, int device, bl_ctx **out);
 /* Repack the grid into the HBM layout ([k][j][i][8 floats]) and upload it; once per snapshot. */
 BL_API int bl_set_grid(bl_ctx *ctx, const bl_grid_desc *g);
@@ -231,6 +233,38 @@ BL_API const char *bl_last_global_error(void);
 /* Warnings raised by the last call, newline separated, reference wording ("Warning: ...\n") */
 BL_API const char *bl_warnings(const bl_ctx *ctx);
 BL_API void bl_free(bl_ctx *ctx);
+
+/* ------------------------------------------------------------------ host steps between / after renders
+ * Kept on the host exactly like the reference does (tiny, serial per block). */
+#define BL_MAX_LEVELS 16
+
+/* RadiationIntegrator::CheckAdaptiveRefinement + EvaluateBlock (radiation_adaptive.cpp:19-312) for the
+ * level just rendered, followed by the block bookkeeping of GeodesicIntegrator::AugmentCamera
+ * (camera.cpp:445-458): which blocks refine, and the (block_v, block_u) list of the next level in the
+ * reference's order (parents in order, children (2v,2u), (2v,2u+1), (2v+1,2u), (2v+1,2u+1)).
+ *   block_locs    [n_blocks][2] of this level; NULL at level 0 (root blocks, row-major)
+ *   image         host [n_q][n_pix of this level] as filled by bl_render
+ *   refine_flags  out [n_blocks]
+ *   next_locs     out [4 * n_refined][2], may be NULL
+ * Returns BL_OK; *n_refined = 0 means the adaptive loop is complete. */
+BL_API int bl_adaptive_refine(const bl_ctx *ctx, int level, int n_blocks, const int32_t *block_locs,
+                              const double *image, uint8_t *refine_flags, int32_t *n_refined,
+                              int32_t *next_locs);
+
+/* OutputWriter::Write (output_writer.cpp:169-274): npz / npy / raw exactly in the reference's layout
+ * (numpy_format.cpp, zip_format.cpp, raw_format.cpp), format and array selection from the parameters. */
+typedef struct bl_output_level {
+  int32_t n_blocks;            /* levels > 0 */
+  const int32_t *block_locs;   /* levels > 0: [n_blocks][2] */
+  const double *image;         /* host [n_q][n_pix of the level] */
+  const double *camera;        /* output_camera: positions (plane) or directions (pinhole) [n_pix][4] */
+} bl_output_level;
+typedef struct bl_output_desc {
+  int32_t adaptive_num_levels; /* levels beyond the root that were rendered */
+  bl_output_level level[BL_MAX_LEVELS + 1];
+  int32_t snapshot;            /* run index, for output_file with {Nd} when simulation_multiple */
+} bl_output_desc;
+BL_API int bl_write_output(bl_ctx *ctx, const char *path_override, const bl_output_desc *d);
 
 /* Library self-description: "gfx950;hip" etc. Lets a loader verify the HIP path is the one built. */
 BL_API const char *bl_build_info(void);

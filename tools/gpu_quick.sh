@@ -1,7 +1,7 @@
-# quick iteration on the GPU box: parity subset + short bench (no CPU baseline)
+# quick iteration on the GPU box: GPU tests + short bench (no CPU baseline)
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q 2>&1 | tail -3
+timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -5
 timeout 900 python bench.py --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.read())

@@ -102,6 +102,22 @@ CASES = {
                                       image_lambda="true", image_emission="true", image_tau="true",
                                       image_lambda_ave="true", image_emission_ave="true", image_tau_int="true",
                                       image_crossings="true"), SMALL_MOCK, [136]),
+    "sim_adaptive": (SIM_BASE, dict(camera_resolution=32, adaptive_max_level=2, adaptive_block_size=8,
+                                    adaptive_val_cut=0.0, adaptive_val_frac=-1.0, adaptive_abs_grad_cut=0.0,
+                                    adaptive_abs_grad_frac=-1.0, adaptive_rel_grad_cut=0.5, adaptive_rel_grad_frac=0.25,
+                                    adaptive_abs_lapl_cut=0.0, adaptive_abs_lapl_frac=-1.0, adaptive_rel_lapl_cut=1.0,
+                                    adaptive_rel_lapl_frac=0.25, adaptive_num_regions=1, adaptive_region_1_level=1,
+                                    adaptive_region_1_x_min=-11.0, adaptive_region_1_x_max=-5.0,
+                                    adaptive_region_1_y_min=2.0, adaptive_region_1_y_max=9.0, output_camera="true"),
+                     SMALL_MOCK, [495]),
+    "formula_adaptive_multifreq": (FORMULA_BASE, dict(camera_resolution=16, adaptive_max_level=1, adaptive_block_size=4,
+                                    image_num_frequencies=2, image_frequency_start=1.0e11, image_frequency_end=3.0e11,
+                                    image_frequency_spacing="lin_wave", adaptive_frequency_num=2,
+                                    adaptive_val_cut=1.0e-5, adaptive_val_frac=0.5, adaptive_abs_grad_cut=1.0e-6,
+                                    adaptive_abs_grad_frac=0.3, adaptive_rel_grad_cut=0.5, adaptive_rel_grad_frac=-1.0,
+                                    adaptive_abs_lapl_cut=1.0e-6, adaptive_abs_lapl_frac=0.3, adaptive_rel_lapl_cut=1.0,
+                                    adaptive_rel_lapl_frac=-1.0, adaptive_num_regions=0, camera_type="pinhole",
+                                    camera_r=100.0, output_camera="true"), None, [136]),
     "formula_dp": (FORMULA_BASE, dict(camera_resolution=32), None, [0, 528, 1023]),
     "formula_absorb": (FORMULA_BASE, dict(camera_resolution=16, formula_a=1.0e6, formula_l0=1.0, formula_h=3.33,
                                           formula_alpha=0.0, camera_type="pinhole", camera_r=100.0), None, [136]),
