@@ -22,7 +22,8 @@
 
 extern "C" hipError_t bl_launch_geodesic(const BlTraceArgs *args, int integrator, int grid, hipStream_t stream);
 extern "C" int bl_geodesic_occupancy(int integrator);
-extern "C" hipError_t bl_launch_shade(const BlShadeArgs *args, int model, int grid, int lds_bytes, hipStream_t stream);
+extern "C" hipError_t bl_launch_shade(const BlShadeArgs *args, int model, int locate_grid, int shade_grid, int lds_bytes,
+                                      hipStream_t stream);
 extern "C" hipError_t bl_launch_transfer(const BlTransferArgs *args, hipStream_t stream);
 
 namespace {
@@ -74,7 +75,7 @@ struct bl_ctx {
   int num_cus = 256;
   hipStream_t stream = nullptr;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-  uint64_t scratch_limit = 48ull << 30;
+  uint64_t scratch_limit = 80ull << 30;
 
   // image rows (radiation_integrator.cpp:436-520)
   int image_num_quantities = 0;
@@ -92,6 +93,7 @@ struct bl_ctx {
 
   // per-chunk scratch
   DeviceBuffer<BlSampleRecord> d_records;
+  DeviceBuffer<BlLocated> d_located;
   DeviceBuffer<double2> d_transfer;
   DeviceBuffer<double> d_ray_kt, d_ray_factor, d_freq;
   DeviceBuffer<int> d_ray_sample_num;
@@ -99,7 +101,7 @@ struct bl_ctx {
   DeviceBuffer<long long> d_ray_out_index;
   DeviceBuffer<unsigned long long> d_counters;   // BL_CNT_COUNT + 4 stats
   DeviceBuffer<int> d_pixel_map, d_block_locs;
-  DeviceBuffer<BlShadeArgs> d_shade_args;
+  DeviceBuffer<BlShadeCold> d_shade_cold;
   // host-output staging
   DeviceBuffer<double> d_image, d_camera_pos, d_camera_dir;
   DeviceBuffer<int> d_out_sample_num;
@@ -536,8 +538,10 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
     if (d->level > 0) level_pixels = static_cast<long long>(d->n_blocks) * p.adaptive_block_size * p.adaptive_block_size;
     if (d->pixel_map == nullptr && n_rays > level_pixels) throw Failure{BL_E_ARG, "n_rays exceeds the pixels of this level."};
 
-    // chunk size from the scratch budget: per ray max_steps * (64 B record + 16 B * n_nu transfer)
-    const uint64_t per_ray = static_cast<uint64_t>(max_steps) * (sizeof(BlSampleRecord) + sizeof(double2) * n_nu) + 64;
+    // chunk size from the scratch budget: per ray max_steps * (64 B record + 48 B located sample
+    // (simulation mode) + 16 B * n_nu transfer)
+    const uint64_t per_ray = static_cast<uint64_t>(max_steps)
+        * (sizeof(BlSampleRecord) + (simulation ? sizeof(BlLocated) : 0) + sizeof(double2) * n_nu) + 64;
     long long chunk = static_cast<long long>(ctx->scratch_limit / per_ray);
     chunk = std::max<long long>(chunk, 64);
     chunk = std::min<long long>(chunk, n_rays);
@@ -545,6 +549,7 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
     const int n_chunks = static_cast<int>((n_rays + chunk - 1) / chunk);
 
     ctx->d_records.Ensure(static_cast<size_t>(chunk) * max_steps);
+    if (simulation) ctx->d_located.Ensure(static_cast<size_t>(chunk) * max_steps);
     ctx->d_transfer.Ensure(static_cast<size_t>(chunk) * max_steps * n_nu);
     ctx->d_ray_kt.Ensure(chunk);
     ctx->d_ray_factor.Ensure(chunk);
@@ -628,21 +633,22 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
 
     BlShadeArgs sa{};
     sa.st = ctx->st;
-    sa.cuts.omit_near = p.cut_omit_near;
-    sa.cuts.omit_far = p.cut_omit_far;
-    sa.cuts.plane = p.cut_plane;
-    sa.cuts.omit_in = p.cut_omit_in;
-    sa.cuts.omit_out = p.cut_omit_out;
-    sa.cuts.midplane_theta = p.cut_midplane_theta;
-    sa.cuts.midplane_z = p.cut_midplane_z;
-    sa.cuts.plane_origin[0] = p.cut_plane_origin_x;
-    sa.cuts.plane_origin[1] = p.cut_plane_origin_y;
-    sa.cuts.plane_origin[2] = p.cut_plane_origin_z;
-    sa.cuts.plane_normal[0] = p.cut_plane_normal_x;
-    sa.cuts.plane_normal[1] = p.cut_plane_normal_y;
-    sa.cuts.plane_normal[2] = p.cut_plane_normal_z;
+    BlShadeCold cold{};
+    cold.omit_near = p.cut_omit_near;
+    cold.omit_far = p.cut_omit_far;
+    cold.plane = p.cut_plane;
+    cold.omit_in = p.cut_omit_in;
+    cold.omit_out = p.cut_omit_out;
+    cold.midplane_theta = p.cut_midplane_theta;
+    cold.midplane_z = p.cut_midplane_z;
+    cold.plane_origin[0] = p.cut_plane_origin_x;
+    cold.plane_origin[1] = p.cut_plane_origin_y;
+    cold.plane_origin[2] = p.cut_plane_origin_z;
+    cold.plane_normal[0] = p.cut_plane_normal_x;
+    cold.plane_normal[1] = p.cut_plane_normal_y;
+    cold.plane_normal[2] = p.cut_plane_normal_z;
+    for (int mu = 0; mu < 4; mu++) cold.cam_x[mu] = ctx->frame.cam_x[mu];
     sa.cuts.camera_r = p.camera_r;
-    for (int mu = 0; mu < 4; mu++) sa.cuts.cam_x[mu] = ctx->frame.cam_x[mu];
     sa.cuts.any_optional = (p.cut_omit_near || p.cut_omit_far || p.cut_omit_in >= 0.0 || p.cut_omit_out >= 0.0
                             || p.cut_midplane_theta != 0.0 || p.cut_midplane_z != 0.0 || p.cut_plane) ? 1 : 0;
     if (simulation) {
@@ -655,22 +661,22 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
       pl.plasma_rat_low = p.plasma_rat_low;
       pl.plasma_rat_high = p.plasma_rat_high;
       pl.plasma_thermal_frac = ctx->plasma_thermal_frac;
-      pl.plasma_gamma = ctx->grid_meta.plasma_gamma;
-      pl.plasma_gamma_i = ctx->grid_meta.plasma_gamma_i;
-      pl.plasma_gamma_e = ctx->grid_meta.plasma_gamma_e;
+      cold.plasma_gamma = ctx->grid_meta.plasma_gamma;
+      cold.plasma_gamma_i = ctx->grid_meta.plasma_gamma_i;
+      cold.plasma_gamma_e = ctx->grid_meta.plasma_gamma_e;
       pl.plasma_use_p = p.plasma_use_p;
       pl.simulation_interp = p.simulation_interp;
       pl.simulation_coord = p.simulation_coord;
       pl.fallback_nan = p.fallback_nan;
-      pl.fallback_rho = p.fallback_nan ? 0.0f : p.fallback_rho;
-      pl.fallback_pgas = p.fallback_nan ? 0.0f : p.fallback_pgas;
-      pl.cut_rho_min = p.cut_rho_min; pl.cut_rho_max = p.cut_rho_max;
-      pl.cut_n_e_min = p.cut_n_e_min; pl.cut_n_e_max = p.cut_n_e_max;
-      pl.cut_p_gas_min = p.cut_p_gas_min; pl.cut_p_gas_max = p.cut_p_gas_max;
-      pl.cut_theta_e_min = p.cut_theta_e_min; pl.cut_theta_e_max = p.cut_theta_e_max;
-      pl.cut_b_min = p.cut_b_min; pl.cut_b_max = p.cut_b_max;
-      pl.cut_sigma_min = p.cut_sigma_min; pl.cut_sigma_max = p.cut_sigma_max;
-      pl.cut_beta_inverse_min = p.cut_beta_inverse_min; pl.cut_beta_inverse_max = p.cut_beta_inverse_max;
+      cold.fallback_rho = p.fallback_nan ? 0.0f : p.fallback_rho;
+      cold.fallback_pgas = p.fallback_nan ? 0.0f : p.fallback_pgas;
+      cold.cut_rho_min = p.cut_rho_min; cold.cut_rho_max = p.cut_rho_max;
+      cold.cut_n_e_min = p.cut_n_e_min; cold.cut_n_e_max = p.cut_n_e_max;
+      cold.cut_p_gas_min = p.cut_p_gas_min; cold.cut_p_gas_max = p.cut_p_gas_max;
+      cold.cut_theta_e_min = p.cut_theta_e_min; cold.cut_theta_e_max = p.cut_theta_e_max;
+      cold.cut_b_min = p.cut_b_min; cold.cut_b_max = p.cut_b_max;
+      cold.cut_sigma_min = p.cut_sigma_min; cold.cut_sigma_max = p.cut_sigma_max;
+      cold.cut_beta_inverse_min = p.cut_beta_inverse_min; cold.cut_beta_inverse_max = p.cut_beta_inverse_max;
       pl.any_cell_cut = (p.cut_rho_min >= 0.0 || p.cut_rho_max >= 0.0 || p.cut_n_e_min >= 0.0 || p.cut_n_e_max >= 0.0
                          || p.cut_p_gas_min >= 0.0 || p.cut_p_gas_max >= 0.0 || p.cut_theta_e_min >= 0.0
                          || p.cut_theta_e_max >= 0.0 || p.cut_b_min >= 0.0 || p.cut_b_max >= 0.0 || p.cut_sigma_min >= 0.0
@@ -681,7 +687,11 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
       fm.r0 = p.formula_r0; fm.h = p.formula_h; fm.l0 = p.formula_l0; fm.q = p.formula_q; fm.nup = p.formula_nup;
       fm.cn0 = p.formula_cn0; fm.alpha = p.formula_alpha; fm.a = p.formula_a; fm.beta = p.formula_beta;
     }
+    ctx->d_shade_cold.Ensure(1);
+    Check(hipMemcpyAsync(ctx->d_shade_cold.ptr, &cold, sizeof(BlShadeCold), hipMemcpyHostToDevice, stream), "shade parameter upload");
+    sa.cold = ctx->d_shade_cold.ptr;
     sa.records = ctx->d_records.ptr;
+    sa.located = simulation ? ctx->d_located.ptr : nullptr;
     sa.counters_in = ctx->d_counters.ptr;
     sa.counters = ctx->d_counters.ptr;
     sa.ray_kt = ctx->d_ray_kt.ptr;
@@ -710,7 +720,8 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
 
     const int geo_blocks_per_cu = bl_geodesic_occupancy(p.ray_integrator);
     const int geo_grid = ctx->num_cus * geo_blocks_per_cu;
-    const int shade_grid = ctx->num_cus * 8;
+    const int locate_grid = ctx->num_cus * 2 * 4;  // 256-thread workgroups, 2 waves per SIMD, x4 for tail balance
+    const int shade_grid = ctx->num_cus * 2 * 4;  // 256-thread workgroups, 2 waves per SIMD, x4 for tail balance
 
     bl_stats st{};
     st.n_rays = n_rays;
@@ -729,7 +740,7 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
       Check(hipEventRecord(ctx->ev[0], stream), "event");
       Check(bl_launch_geodesic(&ta, p.ray_integrator, std::min(geo_grid, (rays + 63) / 64), stream), "geodesic kernel launch");
       Check(hipEventRecord(ctx->ev[1], stream), "event");
-      Check(bl_launch_shade(&sa, p.model_type, shade_grid, ctx->lds_table_bytes, stream), "shade kernel launch");
+      Check(bl_launch_shade(&sa, p.model_type, locate_grid, shade_grid, ctx->lds_table_bytes, stream), "shade kernel launch");
       Check(hipEventRecord(ctx->ev[2], stream), "event");
       Check(bl_launch_transfer(&xa, stream), "transfer kernel launch");
       Check(hipEventRecord(ctx->ev[3], stream), "event");
@@ -796,10 +807,10 @@ void bl_free(bl_ctx *ctx) {
     return;
   }
   (void)hipSetDevice(ctx->device);
-  ctx->d_cells.Free(); ctx->d_coords.Free(); ctx->d_buckets.Free(); ctx->d_records.Free(); ctx->d_transfer.Free();
+  ctx->d_cells.Free(); ctx->d_coords.Free(); ctx->d_buckets.Free(); ctx->d_records.Free(); ctx->d_located.Free(); ctx->d_transfer.Free();
   ctx->d_ray_kt.Free(); ctx->d_ray_factor.Free(); ctx->d_freq.Free(); ctx->d_ray_sample_num.Free();
   ctx->d_ray_flags.Free(); ctx->d_ray_out_index.Free(); ctx->d_counters.Free(); ctx->d_pixel_map.Free();
-  ctx->d_block_locs.Free(); ctx->d_shade_args.Free(); ctx->d_image.Free(); ctx->d_camera_pos.Free(); ctx->d_camera_dir.Free();
+  ctx->d_block_locs.Free(); ctx->d_shade_cold.Free(); ctx->d_image.Free(); ctx->d_camera_pos.Free(); ctx->d_camera_dir.Free();
   ctx->d_out_sample_num.Free(); ctx->d_out_flags.Free();
   for (auto &e : ctx->ev)
     if (e != nullptr) (void)hipEventDestroy(e);

@@ -8,8 +8,10 @@
 //                                                trilinear fetch are four 64-B segments
 //   face / centre double x{1,2,3}f[n+1], x{1,2,3}v[n]  + per-axis bucket tables for the cell search
 //   records       BlSampleRecord [<= C*S]        64 B per emitted sample, written by the geodesic
-//                                                kernel in wave-contiguous runs, read once by the
-//                                                shading kernel (coalesced 4 KiB per wave)
+//                                                kernel in wave-contiguous runs, read by the locate
+//                                                and coefficient kernels (coalesced 4 KiB per wave)
+//   located       BlLocated [<= C*S]             48 B per sample: interpolated primitives + azimuth +
+//                                                status, locate kernel -> coefficient kernel
 //   transfer      double2 [C][S][n_nu]           (a, b) of the per-sample affine update
 //                                                I <- a * (I + b), written by the shading kernel,
 //                                                replayed far -> near by the transfer kernel
@@ -32,6 +34,17 @@ struct alignas(16) BlSampleRecord {
   uint32_t n;         // sample index along the ray in integration order
 };
 static_assert(sizeof(BlSampleRecord) == 64, "record must be 64 bytes");
+
+// One located sample, written by the locate kernel at the index of its sample record and read once
+// by the coefficient kernel (simulation mode): the primitives after nearest / trilinear / fallback
+// sampling, the unwrapped spherical Kerr-Schild azimuth (needed again by the Jacobian) and the status.
+struct alignas(16) BlLocated {
+  float pr[8];        // rho, pgas, uu1, uu2, uu3, bb1, bb2, bb3
+  double ph;
+  uint32_t status;    // SampleStatus
+  uint32_t pad;
+};
+static_assert(sizeof(BlLocated) == 48, "located sample must be 48 bytes");
 
 #define BL_DEAD_RAY 0xFFFFFFFFu
 // Marker for "optically thick: I <- b" in the transfer record (exp(-dtau) is never negative)
@@ -59,17 +72,26 @@ struct BlPlasmaDevice {
   // units (simulation_coefficients.cpp:237-239)
   double d_unit, e_unit, b_unit;
   double plasma_mu, plasma_ne_ni, plasma_rat_low, plasma_rat_high, plasma_thermal_frac;
-  double plasma_gamma, plasma_gamma_i, plasma_gamma_e;
   int plasma_use_p;
   int simulation_interp;
   int simulation_coord;
   int fallback_nan;
-  float fallback_rho, fallback_pgas;
-  // cell cuts (:361-375); negative = disabled
+  int any_cell_cut;          // some cell cut threshold (simulation_coefficients.cpp:361-375) is >= 0
+};
+
+// Rarely used parameters of the shading kernel (optional geometric cuts, cell cut thresholds,
+// fallback primitives): kept in HBM behind one pointer and read under wave-uniform flags, so they do
+// not occupy SGPRs in the common case where they are all disabled.
+struct BlShadeCold {
+  int omit_near, omit_far, plane;
+  double omit_in, omit_out, midplane_theta, midplane_z;
+  double plane_origin[3], plane_normal[3];
+  double cam_x[4];
   double cut_rho_min, cut_rho_max, cut_n_e_min, cut_n_e_max, cut_p_gas_min, cut_p_gas_max;
   double cut_theta_e_min, cut_theta_e_max, cut_b_min, cut_b_max, cut_sigma_min, cut_sigma_max;
   double cut_beta_inverse_min, cut_beta_inverse_max;
-  int any_cell_cut;          // some cell cut threshold is >= 0
+  float fallback_rho, fallback_pgas;
+  double plasma_gamma, plasma_gamma_i, plasma_gamma_e;
 };
 
 struct BlFormulaDevice {
@@ -77,12 +99,8 @@ struct BlFormulaDevice {
 };
 
 struct BlCutsDevice {
-  int omit_near, omit_far, plane;
-  int any_optional;          // any cut besides r > camera_r is active
-  double omit_in, omit_out, midplane_theta, midplane_z;
-  double plane_origin[3], plane_normal[3];
+  int any_optional;          // any cut besides r > camera_r is active (details in BlShadeCold)
   double camera_r;
-  double cam_x[4];
 };
 
 // Kernel arguments: geodesic kernel
@@ -115,7 +133,9 @@ struct BlShadeArgs {
   BlPlasmaDevice plasma;
   BlFormulaDevice formula;
   BlGridDevice grid;
+  const BlShadeCold *cold;    // device pointer
   const BlSampleRecord *records;
+  BlLocated *located;         // [record capacity], simulation mode
   const unsigned long long *counters_in;
   unsigned long long *counters;
   const double *ray_kt, *ray_factor;

@@ -550,7 +550,7 @@ __device__ __forceinline__ void tetrad_build(const double ucon[4], const double 
 
 // Optional geometric cuts (simulation_sampling.cpp:246-292, formula_coefficients.cpp:78-116); the
 // unconditional r > camera_r cut (:238-243) is applied by the caller.
-__device__ __forceinline__ bool optional_cuts(const BlCutsDevice &c, double x1, double x2, double x3, double r) {
+__device__ __forceinline__ bool optional_cuts(const BlShadeCold &c, double x1, double x2, double x3, double r) {
   if (c.omit_near || c.omit_far) {
     double dot_product = x1 * c.cam_x[1] + x2 * c.cam_x[2] + x3 * c.cam_x[3];
     if ((c.omit_near && dot_product > 0.0) || (c.omit_far && dot_product < 0.0)) return true;
@@ -600,50 +600,37 @@ struct SampleShade {
   double n_n0_fluid, fu[4];                                       // formula
 };
 
-// One sample between the two pipeline phases of the shading kernel. Phase 1 (sample_prepare) does the
-// geometry, the cell search and ISSUES the loads of the 8 corner cells; phase 2 (sample_finish) runs
-// one loop iteration later, when those loads have landed, and does the interpolation and all the
-// coefficient arithmetic. The struct is carried in registers across the loop back-edge, so the
-// corner loads of sample i+1 are in flight during the ~2000 fp64 instructions of sample i.
+// Status of a located sample (BlLocated::status)
 enum SampleStatus { kSampleNone = 0, kSampleCut = 1, kSampleOffGrid = 2, kSampleNearest = 3, kSampleInterp = 4,
                     kSampleFormula = 5 };
-struct SamplePre {
-  int status;
-  uint32_t ray, n;
-  double x1, x2, x3;
-  double kx, ky, kz;          // covariant spatial momentum as stored (not yet renormalised)
-  double delta_lambda;
-  double kt, factor;          // per-ray k_t and 1/nu_local (loads in flight)
-  BlKerrSchild ks;
-  double cth, ph;             // z / r and the unwrapped SKS azimuth
-  double f_i, f_j, f_k;       // trilinear fractions
-  float4 c[16];               // corner cells (two float4 per cell), loads in flight
-};
 
-__device__ __forceinline__ void load_cell4(const BlGridDevice &g, int k, int j, int i, float4 *lo, float4 *hi) {
-  size_t idx = (((size_t)k * g.n[1] + j) * g.n[0] + i) * 8;
-  const float4 *p = reinterpret_cast<const float4 *>(g.cells + idx);
-  *lo = p[0];
-  *hi = p[1];
+__device__ __forceinline__ void unpack_cell(const float4 &lo, const float4 &hi, float v[8]) {
+  v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w;
+  v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
 }
 
-// Phase 1, simulation mode: ConvertFromCKS (radiation_geometry.cpp:37-57), block test and cell
-// search (simulation_sampling.cpp:352-394, :458-490), corner loads issued.
-__device__ __forceinline__ void sample_prepare_simulation(const BlShadeArgs &P, const GridTables &tab,
-                                                          const BlSpacetime &st, unsigned long long *gathers,
-                                                          SamplePre *s) {
+__device__ __forceinline__ const float4 *cell_ptr(const BlGridDevice &g, int k, int j, int i) {
+  size_t idx = (((size_t)k * g.n[1] + j) * g.n[0] + i) * 8;
+  return reinterpret_cast<const float4 *>(g.cells + idx);
+}
+
+// Locate one sample on the simulation grid and produce its primitives: ConvertFromCKS
+// (radiation_geometry.cpp:37-57), block test and cell search (simulation_sampling.cpp:352-394,
+// :458-490), then SampleSimulation's nearest / trilinear read (:666-1033, InterpolateSimple
+// :1334-1351). Returns the status; pr = rho, pgas, uu1..3, bb1..3 as float; *ph_out = unwrapped azimuth.
+__device__ __forceinline__ int locate_sample(const BlShadeArgs &P, const GridTables &tab, const BlSpacetime &st,
+                                             double x1, double x2, double x3, double r, float pr[8], double *ph_out,
+                                             unsigned long long *gathers) {
   const BlPlasmaDevice &pl = P.plasma;
   const BlGridDevice &g = P.grid;
-  const double r = s->ks.r;
   const bool sks = pl.simulation_coord == BL_COORD_SKS;
-  // z / r is cos(theta) in ConvertFromCKS, in the SKS metric and in the Jacobian (same expression)
-  s->cth = s->x3 / r;
-  double s1 = s->x1, s2 = s->x2, s3 = s->x3;
-  s->ph = 0.0;
+  double s1 = x1, s2 = x2, s3 = x3;
+  *ph_out = 0.0;
   if (sks) {
-    double th = bl_acos(s->cth);
-    s->ph = bl_atan2(s->x2, s->x1) - bl_atan(st.bh_a / r);
-    double ph = s->ph;
+    // z / r is cos(theta) in ConvertFromCKS, in the SKS metric and in the Jacobian (same expression)
+    double th = bl_acos(x3 / r);
+    double ph = bl_atan2(x2, x1) - bl_atan(st.bh_a / r);
+    *ph_out = ph;
     ph += ph < 0.0 ? 2.0 * kPi : 0.0;
     ph -= ph >= 2.0 * kPi ? 2.0 * kPi : 0.0;
     s1 = r;
@@ -653,78 +640,66 @@ __device__ __forceinline__ void sample_prepare_simulation(const BlShadeArgs &P, 
   const int n_i = g.n[0], n_j = g.n[1], n_k = g.n[2];
   if (s1 < tab.xf[0][0] || s1 > tab.xf[0][n_i] || s2 < tab.xf[1][0] || s2 > tab.xf[1][n_j]
       || s3 < tab.xf[2][0] || s3 > tab.xf[2][n_k]) {
-    s->status = kSampleOffGrid;
-    return;
+    const float fnan = __int_as_float(0x7fc00000);
+    pr[0] = pl.fallback_nan ? fnan : P.cold->fallback_rho;    // :377-384, :678-706
+    pr[1] = pl.fallback_nan ? fnan : P.cold->fallback_pgas;
+    for (int v = 2; v < 8; v++) pr[v] = pl.fallback_nan ? fnan : 0.0f;
+    return kSampleOffGrid;
   }
   int i = find_cell(g, tab, 0, s1);
   int j = find_cell(g, tab, 1, s2);
   int k = find_cell(g, tab, 2, s3);
   *gathers += 1ull;
   if (!pl.simulation_interp) {   // :710-734
-    s->status = kSampleNearest;
-    load_cell4(g, k, j, i, &s->c[0], &s->c[1]);
-    return;
+    const float4 *p = cell_ptr(g, k, j, i);
+    unpack_cell(p[0], p[1], pr);
+    return kSampleNearest;
   }
-  s->status = kSampleInterp;     // :485-490
+  // :485-490
   int i_m = (i == 0 || (i != n_i - 1 && s1 >= tab.xv[0][i])) ? i : i - 1;
   int j_m = (j == 0 || (j != n_j - 1 && s2 >= tab.xv[1][j])) ? j : j - 1;
   int k_m = (k == 0 || (k != n_k - 1 && s3 >= tab.xv[2][k])) ? k : k - 1;
-  s->f_i = (s1 - tab.xv[0][i_m]) / (tab.xv[0][i_m + 1] - tab.xv[0][i_m]);
-  s->f_j = (s2 - tab.xv[1][j_m]) / (tab.xv[1][j_m + 1] - tab.xv[1][j_m]);
-  s->f_k = (s3 - tab.xv[2][k_m]) / (tab.xv[2][k_m + 1] - tab.xv[2][k_m]);
+  // the 8 corner cells: 16 independent 16-byte loads in flight per lane
+  float4 lo[8], hi[8];
 #pragma unroll
   for (int corner = 0; corner < 8; corner++) {
     const int dk = corner >> 2, dj = (corner >> 1) & 1, di = corner & 1;
-    load_cell4(g, k_m + dk, j_m + dj, i_m + di, &s->c[2 * corner], &s->c[2 * corner + 1]);
+    const float4 *p = cell_ptr(g, k_m + dk, j_m + dj, i_m + di);
+    lo[corner] = p[0];
+    hi[corner] = p[1];
   }
-}
-
-__device__ __forceinline__ void unpack_cell(const float4 &lo, const float4 &hi, float v[8]) {
-  v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w;
-  v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
-}
-
-// Phase 2a, simulation mode: SampleSimulation's interpolation (simulation_sampling.cpp:666-1033,
-// InterpolateSimple :1334-1351). Consumes the corner cells; pr = rho, pgas, uu1..3, bb1..3 as float.
-__device__ __forceinline__ void sample_interpolate(const BlShadeArgs &P, const SamplePre &s, float pr[8]) {
-  const BlPlasmaDevice &pl = P.plasma;
-  if (s.status == kSampleOffGrid) {
-    const float fnan = __int_as_float(0x7fc00000);
-    pr[0] = pl.fallback_nan ? fnan : pl.fallback_rho;    // :377-384, :678-706
-    pr[1] = pl.fallback_nan ? fnan : pl.fallback_pgas;
-    for (int v = 2; v < 8; v++) pr[v] = pl.fallback_nan ? fnan : 0.0f;
-  } else if (s.status == kSampleNearest) {
-    unpack_cell(s.c[0], s.c[1], pr);
-  } else {
-    // InterpolateSimple sums w_c * v_c over the corners in the order mmm, mmp, mpm, mpp, pmm,
-    // pmp, ppm, ppp (:1345-1349); accumulating corner by corner keeps that order.
-    const double w_k[2] = {1.0 - s.f_k, s.f_k}, w_j[2] = {1.0 - s.f_j, s.f_j}, w_i[2] = {1.0 - s.f_i, s.f_i};
-    double val[8];
-    float first[8];
+  const double f_i = (s1 - tab.xv[0][i_m]) / (tab.xv[0][i_m + 1] - tab.xv[0][i_m]);
+  const double f_j = (s2 - tab.xv[1][j_m]) / (tab.xv[1][j_m + 1] - tab.xv[1][j_m]);
+  const double f_k = (s3 - tab.xv[2][k_m]) / (tab.xv[2][k_m + 1] - tab.xv[2][k_m]);
+  // InterpolateSimple sums w_c * v_c over the corners in the order mmm, mmp, mpm, mpp, pmm, pmp,
+  // ppm, ppp (:1345-1349); accumulating corner by corner keeps that order.
+  const double w_k[2] = {1.0 - f_k, f_k}, w_j[2] = {1.0 - f_j, f_j}, w_i[2] = {1.0 - f_i, f_i};
+  double val[8];
+  float first[8];
 #pragma unroll
-    for (int corner = 0; corner < 8; corner++) {
-      const int dk = corner >> 2, dj = (corner >> 1) & 1, di = corner & 1;
-      float c[8];
-      unpack_cell(s.c[2 * corner], s.c[2 * corner + 1], c);
-      double w = w_k[dk] * w_j[dj] * w_i[di];
+  for (int corner = 0; corner < 8; corner++) {
+    const int dk = corner >> 2, dj = (corner >> 1) & 1, di = corner & 1;
+    float c[8];
+    unpack_cell(lo[corner], hi[corner], c);
+    double w = w_k[dk] * w_j[dj] * w_i[di];
 #pragma unroll
-      for (int v = 0; v < 8; v++) {
-        if (corner == 0) {
-          val[v] = w * (double)c[v];
-          first[v] = c[v];
-        } else {
-          val[v] += w * (double)c[v];
-        }
+    for (int v = 0; v < 8; v++) {
+      if (corner == 0) {
+        val[v] = w * (double)c[v];
+        first[v] = c[v];
+      } else {
+        val[v] += w * (double)c[v];
       }
     }
-    if (val[0] <= 0.0) val[0] = (double)first[0];   // :822-825
-    if (val[1] <= 0.0) val[1] = (double)first[1];
-#pragma unroll
-    for (int v = 0; v < 8; v++) pr[v] = (float)val[v];   // :830-839
   }
+  if (val[0] <= 0.0) val[0] = (double)first[0];   // :822-825
+  if (val[1] <= 0.0) val[1] = (double)first[1];
+#pragma unroll
+  for (int v = 0; v < 8; v++) pr[v] = (float)val[v];   // :830-839
+  return kSampleInterp;
 }
 
-// Phase 2b, simulation mode: the frequency-independent part of CalculateSimulationCoefficients
+// Simulation mode: the frequency-independent part of CalculateSimulationCoefficients
 // (simulation_coefficients.cpp:253-455).
 __device__ __forceinline__ void sample_finish_simulation(const BlShadeArgs &P, const BlSpacetime &st,
                                                          const BlKerrSchild &ks, double cth, double ph_unwrapped,
@@ -833,8 +808,8 @@ __device__ __forceinline__ void sample_finish_simulation(const BlShadeArgs &P, c
     if (pl.plasma_use_p) {
       kb_tt_e_cgs = (1.0 + pl.plasma_ne_ni) / (tti_tte + pl.plasma_ne_ni) * kb_tt_tot_cgs;
     } else {
-      kb_tt_e_cgs = (1.0 + pl.plasma_ne_ni) * kb_tt_tot_cgs / (pl.plasma_gamma - 1.0);
-      kb_tt_e_cgs /= tti_tte / (pl.plasma_gamma_i - 1.0) + pl.plasma_ne_ni / (pl.plasma_gamma_e - 1.0);
+      kb_tt_e_cgs = (1.0 + pl.plasma_ne_ni) * kb_tt_tot_cgs / (P.cold->plasma_gamma - 1.0);
+      kb_tt_e_cgs /= tti_tte / (P.cold->plasma_gamma_i - 1.0) + pl.plasma_ne_ni / (P.cold->plasma_gamma_e - 1.0);
     }
     theta_e = kb_tt_e_cgs / (kMe * kC * kC);
   }
@@ -842,20 +817,21 @@ __device__ __forceinline__ void sample_finish_simulation(const BlShadeArgs &P, c
   // cell cuts (:361-375); all thresholds negative = disabled is the common case
   bool cell_cut = false;
   if (pl.any_cell_cut) {
-    cell_cut = (pl.cut_rho_min >= 0.0 && rho_cgs < pl.cut_rho_min)
-        || (pl.cut_rho_max >= 0.0 && rho_cgs > pl.cut_rho_max)
-        || (pl.cut_n_e_min >= 0.0 && n_e_cgs < pl.cut_n_e_min)
-        || (pl.cut_n_e_max >= 0.0 && n_e_cgs > pl.cut_n_e_max)
-        || (pl.cut_p_gas_min >= 0.0 && pgas_cgs < pl.cut_p_gas_min)
-        || (pl.cut_p_gas_max >= 0.0 && pgas_cgs > pl.cut_p_gas_max)
-        || (pl.cut_theta_e_min >= 0.0 && theta_e < pl.cut_theta_e_min)
-        || (pl.cut_theta_e_max >= 0.0 && theta_e > pl.cut_theta_e_max)
-        || (pl.cut_b_min >= 0.0 && bb_cgs < pl.cut_b_min)
-        || (pl.cut_b_max >= 0.0 && bb_cgs > pl.cut_b_max)
-        || (pl.cut_sigma_min >= 0.0 && sigma_cut < pl.cut_sigma_min)
-        || (pl.cut_sigma_max >= 0.0 && sigma_cut > pl.cut_sigma_max)
-        || (pl.cut_beta_inverse_min >= 0.0 && beta_inv < pl.cut_beta_inverse_min)
-        || (pl.cut_beta_inverse_max >= 0.0 && beta_inv > pl.cut_beta_inverse_max);
+    const BlShadeCold &cc = *P.cold;
+    cell_cut = (cc.cut_rho_min >= 0.0 && rho_cgs < cc.cut_rho_min)
+        || (cc.cut_rho_max >= 0.0 && rho_cgs > cc.cut_rho_max)
+        || (cc.cut_n_e_min >= 0.0 && n_e_cgs < cc.cut_n_e_min)
+        || (cc.cut_n_e_max >= 0.0 && n_e_cgs > cc.cut_n_e_max)
+        || (cc.cut_p_gas_min >= 0.0 && pgas_cgs < cc.cut_p_gas_min)
+        || (cc.cut_p_gas_max >= 0.0 && pgas_cgs > cc.cut_p_gas_max)
+        || (cc.cut_theta_e_min >= 0.0 && theta_e < cc.cut_theta_e_min)
+        || (cc.cut_theta_e_max >= 0.0 && theta_e > cc.cut_theta_e_max)
+        || (cc.cut_b_min >= 0.0 && bb_cgs < cc.cut_b_min)
+        || (cc.cut_b_max >= 0.0 && bb_cgs > cc.cut_b_max)
+        || (cc.cut_sigma_min >= 0.0 && sigma_cut < cc.cut_sigma_min)
+        || (cc.cut_sigma_max >= 0.0 && sigma_cut > cc.cut_sigma_max)
+        || (cc.cut_beta_inverse_min >= 0.0 && beta_inv < cc.cut_beta_inverse_min)
+        || (cc.cut_beta_inverse_max >= 0.0 && beta_inv > cc.cut_beta_inverse_max);
   }
   const bool no_field = bb1 == 0.0 && bb2 == 0.0 && bb3 == 0.0;   // :394
   out->have_coefficients = false;
@@ -979,17 +955,14 @@ __device__ __forceinline__ void shade_formula(const BlShadeArgs &P, const BlSpac
 
 }  // namespace
 
-template <int kModel>
-__global__ void __launch_bounds__(256, 1) bl_shade_kernel(const BlShadeArgs P) {
-  // Arguments by value: they are loaded from the kernarg segment once, before the loop. (Passed by
-  // pointer the compiler re-fetched them with s_load inside the loop, and at one wave per SIMD every
-  // scalar-load wait is exposed.)
+// ---- locate kernel (simulation mode): one sample record per lane, many waves per SIMD. Everything
+// here waits on memory - LDS table walks, then 16 gathered 16-byte loads - and has few live values,
+// so it runs at 4 waves per SIMD and leaves the hiding of those latencies to the hardware.
+__global__ void __launch_bounds__(256, 2) bl_locate_kernel(const BlShadeArgs P) {
   const BlSpacetime st = P.st;
-
-  // ---- stage the grid's coordinate tables in LDS (simulation mode)
   extern __shared__ double lds_tables[];
   GridTables tab;
-  if (kModel == BL_MODEL_SIMULATION) {
+  {
     const BlGridDevice &g = P.grid;
     double *dst = lds_tables;
     for (int a = 0; a < 3; a++) {
@@ -1007,165 +980,139 @@ __global__ void __launch_bounds__(256, 1) bl_shade_kernel(const BlShadeArgs P) {
       bdst += g.n_bucket[a];
     }
     __syncthreads();
-  } else {
-    for (int a = 0; a < 3; a++) {
-      tab.xf[a] = nullptr;
-      tab.xv[a] = nullptr;
-      tab.bucket[a] = nullptr;
-    }
   }
-
   const unsigned long long n_records = P.counters_in[BL_CNT_RECORDS];
   const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
   unsigned long long gathers_local = 0ull;
-
-  // Software pipeline, three stages deep, all state in registers:
-  //   iteration i   loads the 64-byte record of sample i+2            (coalesced 4 KiB per wave)
-  //                 runs phase 2a of sample i   (interpolation: consumes its corner cells)
-  //                 runs phase 1 of sample i+1  (geometry, search, issue corner + per-ray loads)
-  //                 runs phase 2b of sample i   (coefficients, transfer record)
-  // so the corner loads of sample i+1 have all of phase 2b (~1800 fp64 instructions) to land, and
-  // the corner registers of samples i and i+1 are never live at the same time.
-  unsigned long long idx_load = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-  double2 rq[4];
-  bool rec_valid = idx_load < n_records;
-  {
-    const double2 *src = reinterpret_cast<const double2 *>(P.records + (rec_valid ? idx_load : 0ull));
-    rq[0] = src[0]; rq[1] = src[1]; rq[2] = src[2]; rq[3] = src[3];
-  }
-  SamplePre cur;
-  cur.status = kSampleNone;
-
-  for (int stage = 0;; stage++) {
-    // ---- issue the record loads two samples ahead
-    idx_load += stride;
-    const bool rec2_valid = idx_load < n_records;
-    double2 rq2[4];
-    {
-      const double2 *src = reinterpret_cast<const double2 *>(P.records + (rec2_valid ? idx_load : 0ull));
-      rq2[0] = src[0]; rq2[1] = src[1]; rq2[2] = src[2]; rq2[3] = src[3];
-    }
-
-    // ---- phase 2a of the current sample: consume its corner cells (interpolation), so that their
-    //      registers are free before the next sample's loads are issued
+  for (unsigned long long idx = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; idx < n_records; idx += stride) {
+    const double2 *src = reinterpret_cast<const double2 *>(P.records + idx);
+    const double2 q0 = src[0], q1 = src[1], q3 = src[3];
+    const uint32_t ray = (uint32_t)__double_as_longlong(q3.y);
+    if (ray == BL_DEAD_RAY) continue;
+    const double x1 = q0.x, x2 = q0.y, x3 = q1.x;
+    const double r = bl_radial_coordinate(st, x1, x2, x3);
+    bool skip = r > P.cuts.camera_r;                                 // simulation_sampling.cpp:238-243
+    if (!skip && P.cuts.any_optional) skip = optional_cuts(*P.cold, x1, x2, x3, r);
     float pr[8];
-    if (kModel == BL_MODEL_SIMULATION && cur.status >= kSampleOffGrid && cur.status <= kSampleInterp)
-      sample_interpolate(P, cur, pr);
-    else
+    double ph = 0.0;
+    int status = kSampleCut;
+    if (skip) {
       for (int v = 0; v < 8; v++) pr[v] = 0.0f;
-    // what phase 2b still needs of the current sample
-    const int cur_status = cur.status;
-    const uint32_t cur_ray = cur.ray, cur_n = cur.n;
-    const double cur_x1 = cur.x1, cur_x2 = cur.x2, cur_x3 = cur.x3;
-    const double cur_delta_lambda = cur.delta_lambda, cur_factor = cur.factor;
-    const double cur_cth = cur.cth, cur_ph = cur.ph;
-    const BlKerrSchild cur_ks = cur.ks;
-    double kcov[4] = {cur.kt, cur.kx, cur.ky, cur.kz};
-
-    // ---- phase 1 of the next sample
-    SamplePre nxt;
-    nxt.status = kSampleNone;
-    if (rec_valid) {
-      nxt.ray = (uint32_t)__double_as_longlong(rq[3].y);
-      nxt.n = (uint32_t)(((unsigned long long)__double_as_longlong(rq[3].y)) >> 32);
-      if (nxt.ray != BL_DEAD_RAY) {
-        nxt.x1 = rq[0].x; nxt.x2 = rq[0].y; nxt.x3 = rq[1].x;
-        nxt.kx = rq[1].y; nxt.ky = rq[2].x; nxt.kz = rq[2].y;
-        nxt.delta_lambda = -rq[3].x;   // ReverseGeodesics: sample_len = -geodesic_len (:840)
-        nxt.kt = P.ray_kt[nxt.ray];
-        nxt.factor = P.ray_factor[nxt.ray];
-        // Kerr-Schild scalars at the sample: evaluated once, shared by the renormalisation, the
-        // cuts, the coordinate conversion, the simulation metric and the geodesic metric (the
-        // reference recomputes them in each of those functions; identical inputs, identical bits)
-        bl_kerr_schild(st, nxt.x1, nxt.x2, nxt.x3, &nxt.ks);
-        bool skip = nxt.ks.r > P.cuts.camera_r;                          // simulation_sampling.cpp:238-243
-        if (!skip && P.cuts.any_optional) skip = optional_cuts(P.cuts, nxt.x1, nxt.x2, nxt.x3, nxt.ks.r);
-        if (skip) {
-          nxt.status = kSampleCut;
-        } else if (kModel == BL_MODEL_SIMULATION) {
-          sample_prepare_simulation(P, tab, st, &gathers_local, &nxt);
-        } else {
-          nxt.status = kSampleFormula;
-        }
-      }
+    } else {
+      status = locate_sample(P, tab, st, x1, x2, x3, r, pr, &ph, &gathers_local);
     }
-
-    // ---- phase 2b of the current sample (the next sample's loads are in flight meanwhile)
-    if (cur_status != kSampleNone) {
-      {   // per-sample renormalisation of the stored momentum (geodesics.cpp:352-371)
-        double gcon[4][4];
-        if (st.ray_flat)
-          bl_minkowski(gcon);
-        else
-          bl_gcon_ks(cur_ks, gcon);
-        double factor = bl_renormalization_factor_g(gcon, kcov[0], kcov[1], kcov[2], kcov[3]);
-        kcov[1] *= factor;
-        kcov[2] *= factor;
-        kcov[3] *= factor;
-      }
-      SampleShade sh;
-      sh.have_coefficients = false;
-      sh.nu_fluid_over_nu = 0.0;
-      sh.n_e_cgs = sh.nu_c_cgs = sh.theta_e = sh.sin_theta_b = sh.kb_tt_e_cgs = 0.0;
-      sh.n_n0_fluid = 0.0;
-      sh.fu[0] = sh.fu[1] = sh.fu[2] = sh.fu[3] = 0.0;
-      if (cur_status != kSampleCut) {
-        if (kModel == BL_MODEL_SIMULATION)
-          sample_finish_simulation(P, st, cur_ks, cur_cth, cur_ph, pr, kcov, &sh);
-        else
-          shade_formula(P, st, cur_ks.r, cur_x1, cur_x2, cur_x3, &sh);
-      }
-      const double momentum_factor = cur_factor;
-      double2 *out = P.transfer + ((size_t)cur_ray * P.ray_max_steps + cur_n) * P.n_nu;
-      // ---------------- per-frequency coefficients and transfer records
-      for (int l = 0; l < P.n_nu; l++) {
-        const double freq = P.frequencies[l];
-        double j_val = 0.0, alpha_val = 0.0;
-        if (sh.have_coefficients && kModel == BL_MODEL_SIMULATION) {
-          // simulation_coefficients.cpp:464-523, thermal electrons, unpolarized
-          const double thermal_frac = P.plasma.plasma_thermal_frac;
-          const double nu_cgs = sh.nu_fluid_over_nu * (freq * momentum_factor);
-          const double nu_2_cgs = nu_cgs * nu_cgs;
-          const double nu_s_cgs = 2.0 / 9.0 * sh.nu_c_cgs * sh.theta_e * sh.theta_e * sh.sin_theta_b;
-          if (thermal_frac != 0.0) {
-            const double xx = nu_cgs / nu_s_cgs;
-            const double xx_1_2 = blm_sqrt(xx);
-            const double xx_1_3 = bl_cbrt(xx);
-            const double xx_1_6 = blm_sqrt(xx_1_3);
-            const double coefficient = thermal_frac * sh.n_e_cgs * kE * kE * sh.nu_c_cgs / (kC * nu_2_cgs) * bl_exp(-xx_1_3);
-            const double var_a = kSqrt2 * kPi / 27.0 * sh.sin_theta_b;
-            const double var_b = kPow2_11_12;
-            const double var_c = xx_1_2 + var_b * xx_1_6;
-            j_val = coefficient * var_a * var_c * var_c;
-            const double b_nu_nu_3_cgs = 2.0 * kH / (kC * kC) / bl_expm1(kH * nu_cgs / sh.kb_tt_e_cgs);
-            alpha_val = j_val / b_nu_nu_3_cgs;
-            if (1.0 / (alpha_val * alpha_val) == __longlong_as_double(0x7ff0000000000000ll)) alpha_val = 0.0;   // :513-523
-          }
-        } else if (sh.have_coefficients && kModel == BL_MODEL_FORMULA) {
-          // formula_coefficients.cpp:164-179
-          const BlFormulaDevice &fm = P.formula;
-          const double nu_fluid_cgs = -(sh.fu[0] * kcov[0] + sh.fu[1] * kcov[1] + sh.fu[2] * kcov[2] + sh.fu[3] * kcov[3]) * freq * momentum_factor;
-          const double j_nu_fluid_cgs = fm.cn0 * sh.n_n0_fluid * bl_pow(nu_fluid_cgs / fm.nup, -fm.alpha);
-          j_val = j_nu_fluid_cgs / (nu_fluid_cgs * nu_fluid_cgs);
-          const double alpha_nu_fluid_cgs = fm.a * fm.cn0 * sh.n_n0_fluid * bl_pow(nu_fluid_cgs / fm.nup, -fm.beta - fm.alpha);
-          alpha_val = alpha_nu_fluid_cgs * nu_fluid_cgs;
-        }
-        const double delta_lambda_cgs = cur_delta_lambda * P.x_unit / (freq * momentum_factor);   // unpolarized.cpp:75-76
-        out[l] = transfer_record(j_val, alpha_val, delta_lambda_cgs);
-      }
-    }
-
-    // ---- advance the pipeline; a lane is done when nothing is pending and nothing is being loaded
-    cur = nxt;
-    rq[0] = rq2[0]; rq[1] = rq2[1]; rq[2] = rq2[2]; rq[3] = rq2[3];
-    const bool was_valid = rec_valid;
-    rec_valid = rec2_valid;
-    if (!was_valid && !rec_valid) break;   // cur (if any) was produced from a valid record, so it is kSampleNone here
+    float4 *dst = reinterpret_cast<float4 *>(P.located + idx);
+    dst[0] = make_float4(pr[0], pr[1], pr[2], pr[3]);
+    dst[1] = make_float4(pr[4], pr[5], pr[6], pr[7]);
+    const unsigned long long ph_bits = (unsigned long long)__double_as_longlong(ph);
+    dst[2] = make_float4(__uint_as_float((uint32_t)ph_bits), __uint_as_float((uint32_t)(ph_bits >> 32)),
+                         __uint_as_float((uint32_t)status), 0.0f);
   }
-
   // S_in accounting: one atomic per wave
   for (int offset = 32; offset > 0; offset >>= 1) gathers_local += __shfl_xor(gathers_local, offset, 64);
   if ((threadIdx.x & 63) == 0 && gathers_local != 0ull) atomicAdd(&P.counters[BL_CNT_GATHERS], gathers_local);
+}
+
+// ---- coefficient kernel: one sample record per lane, pure fp64 arithmetic between one coalesced
+// read (record + located sample) and one 16-byte store per frequency. Two waves per SIMD so that one
+// wave's scalar work, dependent-issue bubbles and load waits overlap the other's VALU work.
+template <int kModel>
+__global__ void __launch_bounds__(256, 2) bl_shade_kernel(const BlShadeArgs P) {
+  const BlSpacetime st = P.st;
+  const unsigned long long n_records = P.counters_in[BL_CNT_RECORDS];
+  const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+  for (unsigned long long idx = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; idx < n_records; idx += stride) {
+    const double2 *src = reinterpret_cast<const double2 *>(P.records + idx);
+    const double2 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
+    const uint32_t ray = (uint32_t)__double_as_longlong(q3.y);
+    if (ray == BL_DEAD_RAY) continue;
+    const uint32_t n = (uint32_t)(((unsigned long long)__double_as_longlong(q3.y)) >> 32);
+    const double x1 = q0.x, x2 = q0.y, x3 = q1.x;
+    const double delta_lambda = -q3.x;   // ReverseGeodesics: sample_len = -geodesic_len (:840)
+    double kcov[4] = {P.ray_kt[ray], q1.y, q2.x, q2.y};
+    const double momentum_factor = P.ray_factor[ray];
+    float pr[8];
+    double ph = 0.0;
+    int status;
+    if (kModel == BL_MODEL_SIMULATION) {
+      const float4 *loc = reinterpret_cast<const float4 *>(P.located + idx);
+      const float4 l0 = loc[0], l1 = loc[1], l2 = loc[2];
+      unpack_cell(l0, l1, pr);
+      ph = __longlong_as_double((long long)(((unsigned long long)__float_as_uint(l2.y) << 32) | __float_as_uint(l2.x)));
+      status = (int)__float_as_uint(l2.z);
+    }
+    // Kerr-Schild scalars at the sample: evaluated once, shared by the renormalisation, the cuts, the
+    // simulation metric and the geodesic metric (the reference recomputes them in each of those
+    // functions; identical inputs, identical bits)
+    BlKerrSchild ks;
+    bl_kerr_schild(st, x1, x2, x3, &ks);
+    if (kModel == BL_MODEL_FORMULA) {
+      bool skip = ks.r > P.cuts.camera_r;                              // formula_coefficients.cpp:78-116
+      if (!skip && P.cuts.any_optional) skip = optional_cuts(*P.cold, x1, x2, x3, ks.r);
+      status = skip ? kSampleCut : kSampleFormula;
+      for (int v = 0; v < 8; v++) pr[v] = 0.0f;
+    }
+    {   // per-sample renormalisation of the stored momentum (geodesics.cpp:352-371)
+      double gcon[4][4];
+      if (st.ray_flat)
+        bl_minkowski(gcon);
+      else
+        bl_gcon_ks(ks, gcon);
+      double factor = bl_renormalization_factor_g(gcon, kcov[0], kcov[1], kcov[2], kcov[3]);
+      kcov[1] *= factor;
+      kcov[2] *= factor;
+      kcov[3] *= factor;
+    }
+    SampleShade sh;
+    sh.have_coefficients = false;
+    sh.nu_fluid_over_nu = 0.0;
+    sh.n_e_cgs = sh.nu_c_cgs = sh.theta_e = sh.sin_theta_b = sh.kb_tt_e_cgs = 0.0;
+    sh.n_n0_fluid = 0.0;
+    sh.fu[0] = sh.fu[1] = sh.fu[2] = sh.fu[3] = 0.0;
+    if (status != kSampleCut) {
+      if (kModel == BL_MODEL_SIMULATION)
+        sample_finish_simulation(P, st, ks, x3 / ks.r, ph, pr, kcov, &sh);
+      else
+        shade_formula(P, st, ks.r, x1, x2, x3, &sh);
+    }
+    double2 *out = P.transfer + ((size_t)ray * P.ray_max_steps + n) * P.n_nu;
+    // ---------------- per-frequency coefficients and transfer records
+    for (int l = 0; l < P.n_nu; l++) {
+      const double freq = P.frequencies[l];
+      double j_val = 0.0, alpha_val = 0.0;
+      if (sh.have_coefficients && kModel == BL_MODEL_SIMULATION) {
+        // simulation_coefficients.cpp:464-523, thermal electrons, unpolarized
+        const double thermal_frac = P.plasma.plasma_thermal_frac;
+        const double nu_cgs = sh.nu_fluid_over_nu * (freq * momentum_factor);
+        const double nu_2_cgs = nu_cgs * nu_cgs;
+        const double nu_s_cgs = 2.0 / 9.0 * sh.nu_c_cgs * sh.theta_e * sh.theta_e * sh.sin_theta_b;
+        if (thermal_frac != 0.0) {
+          const double xx = nu_cgs / nu_s_cgs;
+          const double xx_1_2 = blm_sqrt(xx);
+          const double xx_1_3 = bl_cbrt(xx);
+          const double xx_1_6 = blm_sqrt(xx_1_3);
+          const double coefficient = thermal_frac * sh.n_e_cgs * kE * kE * sh.nu_c_cgs / (kC * nu_2_cgs) * bl_exp(-xx_1_3);
+          const double var_a = kSqrt2 * kPi / 27.0 * sh.sin_theta_b;
+          const double var_b = kPow2_11_12;
+          const double var_c = xx_1_2 + var_b * xx_1_6;
+          j_val = coefficient * var_a * var_c * var_c;
+          const double b_nu_nu_3_cgs = 2.0 * kH / (kC * kC) / bl_expm1(kH * nu_cgs / sh.kb_tt_e_cgs);
+          alpha_val = j_val / b_nu_nu_3_cgs;
+          if (1.0 / (alpha_val * alpha_val) == __longlong_as_double(0x7ff0000000000000ll)) alpha_val = 0.0;   // :513-523
+        }
+      } else if (sh.have_coefficients && kModel == BL_MODEL_FORMULA) {
+        // formula_coefficients.cpp:164-179
+        const BlFormulaDevice &fm = P.formula;
+        const double nu_fluid_cgs = -(sh.fu[0] * kcov[0] + sh.fu[1] * kcov[1] + sh.fu[2] * kcov[2] + sh.fu[3] * kcov[3]) * freq * momentum_factor;
+        const double j_nu_fluid_cgs = fm.cn0 * sh.n_n0_fluid * bl_pow(nu_fluid_cgs / fm.nup, -fm.alpha);
+        j_val = j_nu_fluid_cgs / (nu_fluid_cgs * nu_fluid_cgs);
+        const double alpha_nu_fluid_cgs = fm.a * fm.cn0 * sh.n_n0_fluid * bl_pow(nu_fluid_cgs / fm.nup, -fm.beta - fm.alpha);
+        alpha_val = alpha_nu_fluid_cgs * nu_fluid_cgs;
+      }
+      const double delta_lambda_cgs = delta_lambda * P.x_unit / (freq * momentum_factor);   // unpolarized.cpp:75-76
+      out[l] = transfer_record(j_val, alpha_val, delta_lambda_cgs);
+    }
+  }
 }
 
 // =================================================================================================
@@ -1267,12 +1214,18 @@ extern "C" int bl_geodesic_occupancy(int integrator) {
   return blocks;
 }
 
-// lds_bytes: size of the coordinate tables staged in LDS (simulation mode)
-extern "C" hipError_t bl_launch_shade(const BlShadeArgs *args, int model, int grid, int lds_bytes, hipStream_t stream) {
-  if (model == BL_MODEL_SIMULATION)
-    hipLaunchKernelGGL(bl_shade_kernel<BL_MODEL_SIMULATION>, dim3(grid), dim3(256), lds_bytes, stream, *args);
-  else
-    hipLaunchKernelGGL(bl_shade_kernel<BL_MODEL_FORMULA>, dim3(grid), dim3(256), 0, stream, *args);
+// Shading = locate kernel (simulation mode only; lds_bytes = size of the coordinate tables it stages in
+// LDS) followed by the coefficient kernel, back to back on the same stream.
+extern "C" hipError_t bl_launch_shade(const BlShadeArgs *args, int model, int locate_grid, int shade_grid, int lds_bytes,
+                                      hipStream_t stream) {
+  if (model == BL_MODEL_SIMULATION) {
+    hipLaunchKernelGGL(bl_locate_kernel, dim3(locate_grid), dim3(256), lds_bytes, stream, *args);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return err;
+    hipLaunchKernelGGL(bl_shade_kernel<BL_MODEL_SIMULATION>, dim3(shade_grid), dim3(256), 0, stream, *args);
+  } else {
+    hipLaunchKernelGGL(bl_shade_kernel<BL_MODEL_FORMULA>, dim3(shade_grid), dim3(256), 0, stream, *args);
+  }
   return hipGetLastError();
 }
 

@@ -222,7 +222,7 @@ BL_API int bl_set_grid(bl_ctx *ctx, const bl_grid_desc *g);
 BL_API int bl_image_num_quantities(const bl_ctx *ctx);
 BL_API int bl_camera_frame_get(const bl_ctx *ctx, bl_camera_frame *out);
 BL_API int bl_frequencies(const bl_ctx *ctx, double *out, int n);
-/* Cap on scratch HBM (bytes) used for per-sample records; default 48 GiB. */
+/* Cap on scratch HBM (bytes) used for per-sample records; default 80 GiB. */
 BL_API int bl_set_scratch_limit(bl_ctx *ctx, uint64_t bytes);
 BL_API int bl_render(bl_ctx *ctx, const bl_render_desc *d);
 BL_API int bl_get_stats(const bl_ctx *ctx, bl_stats *out);
