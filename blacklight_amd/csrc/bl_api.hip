@@ -720,7 +720,7 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
 
     const int geo_blocks_per_cu = bl_geodesic_occupancy(p.ray_integrator);
     const int geo_grid = ctx->num_cus * geo_blocks_per_cu;
-    const int locate_grid = ctx->num_cus * 2 * 4;  // 256-thread workgroups, 2 waves per SIMD, x4 for tail balance
+    const int locate_grid = ctx->num_cus * 4 * 4;  // 256-thread workgroups, 4 waves per SIMD, x4 for tail balance
     const int shade_grid = ctx->num_cus * 2 * 4;  // 256-thread workgroups, 2 waves per SIMD, x4 for tail balance
 
     bl_stats st{};

@@ -10,8 +10,8 @@
 //   records       BlSampleRecord [<= C*S]        64 B per emitted sample, written by the geodesic
 //                                                kernel in wave-contiguous runs, read by the locate
 //                                                and coefficient kernels (coalesced 4 KiB per wave)
-//   located       BlLocated [<= C*S]             48 B per sample: interpolated primitives + azimuth +
-//                                                status, locate kernel -> coefficient kernel
+//   located       BlLocated [<= C*S]             48 B per sample: first cell + trilinear fractions +
+//                                                azimuth + status, locate kernel -> coefficient kernel
 //   transfer      double2 [C][S][n_nu]           (a, b) of the per-sample affine update
 //                                                I <- a * (I + b), written by the shading kernel,
 //                                                replayed far -> near by the transfer kernel
@@ -36,13 +36,15 @@ struct alignas(16) BlSampleRecord {
 static_assert(sizeof(BlSampleRecord) == 64, "record must be 64 bytes");
 
 // One located sample, written by the locate kernel at the index of its sample record and read once
-// by the coefficient kernel (simulation mode): the primitives after nearest / trilinear / fallback
-// sampling, the unwrapped spherical Kerr-Schild azimuth (needed again by the Jacobian) and the status.
+// by the coefficient kernel (simulation mode): where the sample sits on the grid - the first of the
+// (up to) 8 cells it reads and the trilinear fractions - plus the unwrapped spherical Kerr-Schild
+// azimuth (needed again by the Jacobian) and the status.
 struct alignas(16) BlLocated {
-  float pr[8];        // rho, pgas, uu1, uu2, uu3, bb1, bb2, bb3
+  double f_i, f_j, f_k;   // trilinear fractions (kSampleInterp)
   double ph;
-  uint32_t status;    // SampleStatus
-  uint32_t pad;
+  uint32_t cell;          // linear index of cell (k_m, j_m, i_m) resp. of the nearest cell
+  uint32_t status;        // SampleStatus
+  uint32_t pad[2];
 };
 static_assert(sizeof(BlLocated) == 48, "located sample must be 48 bytes");
 

@@ -614,23 +614,23 @@ __device__ __forceinline__ const float4 *cell_ptr(const BlGridDevice &g, int k, 
   return reinterpret_cast<const float4 *>(g.cells + idx);
 }
 
-// Locate one sample on the simulation grid and produce its primitives: ConvertFromCKS
-// (radiation_geometry.cpp:37-57), block test and cell search (simulation_sampling.cpp:352-394,
-// :458-490), then SampleSimulation's nearest / trilinear read (:666-1033, InterpolateSimple
-// :1334-1351). Returns the status; pr = rho, pgas, uu1..3, bb1..3 as float; *ph_out = unwrapped azimuth.
-__device__ __forceinline__ int locate_sample(const BlShadeArgs &P, const GridTables &tab, const BlSpacetime &st,
-                                             double x1, double x2, double x3, double r, float pr[8], double *ph_out,
-                                             unsigned long long *gathers) {
+// Locate one sample on the simulation grid: ConvertFromCKS (radiation_geometry.cpp:37-57), block test
+// and cell search (simulation_sampling.cpp:352-394, :458-490), trilinear fractions (:736-760).
+__device__ __forceinline__ void locate_sample(const BlShadeArgs &P, const GridTables &tab, const BlSpacetime &st,
+                                              double x1, double x2, double x3, double r, BlLocated *out,
+                                              unsigned long long *gathers) {
   const BlPlasmaDevice &pl = P.plasma;
   const BlGridDevice &g = P.grid;
   const bool sks = pl.simulation_coord == BL_COORD_SKS;
   double s1 = x1, s2 = x2, s3 = x3;
-  *ph_out = 0.0;
+  out->ph = 0.0;
+  out->f_i = out->f_j = out->f_k = 0.0;
+  out->cell = 0u;
   if (sks) {
     // z / r is cos(theta) in ConvertFromCKS, in the SKS metric and in the Jacobian (same expression)
     double th = bl_acos(x3 / r);
     double ph = bl_atan2(x2, x1) - bl_atan(st.bh_a / r);
-    *ph_out = ph;
+    out->ph = ph;
     ph += ph < 0.0 ? 2.0 * kPi : 0.0;
     ph -= ph >= 2.0 * kPi ? 2.0 * kPi : 0.0;
     s1 = r;
@@ -640,63 +640,83 @@ __device__ __forceinline__ int locate_sample(const BlShadeArgs &P, const GridTab
   const int n_i = g.n[0], n_j = g.n[1], n_k = g.n[2];
   if (s1 < tab.xf[0][0] || s1 > tab.xf[0][n_i] || s2 < tab.xf[1][0] || s2 > tab.xf[1][n_j]
       || s3 < tab.xf[2][0] || s3 > tab.xf[2][n_k]) {
-    const float fnan = __int_as_float(0x7fc00000);
-    pr[0] = pl.fallback_nan ? fnan : P.cold->fallback_rho;    // :377-384, :678-706
-    pr[1] = pl.fallback_nan ? fnan : P.cold->fallback_pgas;
-    for (int v = 2; v < 8; v++) pr[v] = pl.fallback_nan ? fnan : 0.0f;
-    return kSampleOffGrid;
+    out->status = kSampleOffGrid;
+    return;
   }
   int i = find_cell(g, tab, 0, s1);
   int j = find_cell(g, tab, 1, s2);
   int k = find_cell(g, tab, 2, s3);
   *gathers += 1ull;
   if (!pl.simulation_interp) {   // :710-734
-    const float4 *p = cell_ptr(g, k, j, i);
-    unpack_cell(p[0], p[1], pr);
-    return kSampleNearest;
+    out->status = kSampleNearest;
+    out->cell = (uint32_t)((k * n_j + j) * n_i + i);
+    return;
   }
   // :485-490
   int i_m = (i == 0 || (i != n_i - 1 && s1 >= tab.xv[0][i])) ? i : i - 1;
   int j_m = (j == 0 || (j != n_j - 1 && s2 >= tab.xv[1][j])) ? j : j - 1;
   int k_m = (k == 0 || (k != n_k - 1 && s3 >= tab.xv[2][k])) ? k : k - 1;
-  // the 8 corner cells: 16 independent 16-byte loads in flight per lane
-  float4 lo[8], hi[8];
+  out->f_i = (s1 - tab.xv[0][i_m]) / (tab.xv[0][i_m + 1] - tab.xv[0][i_m]);
+  out->f_j = (s2 - tab.xv[1][j_m]) / (tab.xv[1][j_m + 1] - tab.xv[1][j_m]);
+  out->f_k = (s3 - tab.xv[2][k_m]) / (tab.xv[2][k_m + 1] - tab.xv[2][k_m]);
+  out->status = kSampleInterp;
+  out->cell = (uint32_t)((k_m * n_j + j_m) * n_i + i_m);
+}
+
+// SampleSimulation's nearest / trilinear read (simulation_sampling.cpp:666-1033, InterpolateSimple
+// :1334-1351) for a located sample: pr = rho, pgas, uu1..3, bb1..3 as float.
+__device__ __forceinline__ void sample_primitives(const BlShadeArgs &P, int status, uint32_t cell, double f_i,
+                                                  double f_j, double f_k, float pr[8]) {
+  const BlPlasmaDevice &pl = P.plasma;
+  const BlGridDevice &g = P.grid;
+  const float4 *base = reinterpret_cast<const float4 *>(g.cells) + (size_t)cell * 2;
+  if (status == kSampleInterp) {
+    // the 8 corner cells: 16 independent 16-byte loads in flight per lane; the two cells of an
+    // i-pair are one contiguous 64-byte segment
+    const size_t row = (size_t)g.n[0] * 2, plane = (size_t)g.n[1] * row;
+    float4 lo[8], hi[8];
 #pragma unroll
-  for (int corner = 0; corner < 8; corner++) {
-    const int dk = corner >> 2, dj = (corner >> 1) & 1, di = corner & 1;
-    const float4 *p = cell_ptr(g, k_m + dk, j_m + dj, i_m + di);
-    lo[corner] = p[0];
-    hi[corner] = p[1];
-  }
-  const double f_i = (s1 - tab.xv[0][i_m]) / (tab.xv[0][i_m + 1] - tab.xv[0][i_m]);
-  const double f_j = (s2 - tab.xv[1][j_m]) / (tab.xv[1][j_m + 1] - tab.xv[1][j_m]);
-  const double f_k = (s3 - tab.xv[2][k_m]) / (tab.xv[2][k_m + 1] - tab.xv[2][k_m]);
-  // InterpolateSimple sums w_c * v_c over the corners in the order mmm, mmp, mpm, mpp, pmm, pmp,
-  // ppm, ppp (:1345-1349); accumulating corner by corner keeps that order.
-  const double w_k[2] = {1.0 - f_k, f_k}, w_j[2] = {1.0 - f_j, f_j}, w_i[2] = {1.0 - f_i, f_i};
-  double val[8];
-  float first[8];
+    for (int corner = 0; corner < 8; corner++) {
+      const int dk = corner >> 2, dj = (corner >> 1) & 1, di = corner & 1;
+      const float4 *p = base + dk * plane + dj * row + di * 2;
+      lo[corner] = p[0];
+      hi[corner] = p[1];
+    }
+    // InterpolateSimple sums w_c * v_c over the corners in the order mmm, mmp, mpm, mpp, pmm, pmp,
+    // ppm, ppp (:1345-1349); accumulating corner by corner keeps that order.
+    const double w_k[2] = {1.0 - f_k, f_k}, w_j[2] = {1.0 - f_j, f_j}, w_i[2] = {1.0 - f_i, f_i};
+    double val[8];
+    float first[8];
 #pragma unroll
-  for (int corner = 0; corner < 8; corner++) {
-    const int dk = corner >> 2, dj = (corner >> 1) & 1, di = corner & 1;
-    float c[8];
-    unpack_cell(lo[corner], hi[corner], c);
-    double w = w_k[dk] * w_j[dj] * w_i[di];
+    for (int corner = 0; corner < 8; corner++) {
+      const int dk = corner >> 2, dj = (corner >> 1) & 1, di = corner & 1;
+      float c[8];
+      unpack_cell(lo[corner], hi[corner], c);
+      double w = w_k[dk] * w_j[dj] * w_i[di];
 #pragma unroll
-    for (int v = 0; v < 8; v++) {
-      if (corner == 0) {
-        val[v] = w * (double)c[v];
-        first[v] = c[v];
-      } else {
-        val[v] += w * (double)c[v];
+      for (int v = 0; v < 8; v++) {
+        if (corner == 0) {
+          val[v] = w * (double)c[v];
+          first[v] = c[v];
+        } else {
+          val[v] += w * (double)c[v];
+        }
       }
     }
-  }
-  if (val[0] <= 0.0) val[0] = (double)first[0];   // :822-825
-  if (val[1] <= 0.0) val[1] = (double)first[1];
+    if (val[0] <= 0.0) val[0] = (double)first[0];   // :822-825
+    if (val[1] <= 0.0) val[1] = (double)first[1];
 #pragma unroll
-  for (int v = 0; v < 8; v++) pr[v] = (float)val[v];   // :830-839
-  return kSampleInterp;
+    for (int v = 0; v < 8; v++) pr[v] = (float)val[v];   // :830-839
+  } else if (status == kSampleNearest) {
+    unpack_cell(base[0], base[1], pr);
+  } else if (status == kSampleOffGrid) {
+    const float fnan = __int_as_float(0x7fc00000);
+    pr[0] = pl.fallback_nan ? fnan : P.cold->fallback_rho;    // :377-384, :678-706
+    pr[1] = pl.fallback_nan ? fnan : P.cold->fallback_pgas;
+    for (int v = 2; v < 8; v++) pr[v] = pl.fallback_nan ? fnan : 0.0f;
+  } else {
+    for (int v = 0; v < 8; v++) pr[v] = 0.0f;
+  }
 }
 
 // Simulation mode: the frequency-independent part of CalculateSimulationCoefficients
@@ -955,10 +975,10 @@ __device__ __forceinline__ void shade_formula(const BlShadeArgs &P, const BlSpac
 
 }  // namespace
 
-// ---- locate kernel (simulation mode): one sample record per lane, many waves per SIMD. Everything
-// here waits on memory - LDS table walks, then 16 gathered 16-byte loads - and has few live values,
-// so it runs at 4 waves per SIMD and leaves the hiding of those latencies to the hardware.
-__global__ void __launch_bounds__(256, 2) bl_locate_kernel(const BlShadeArgs P) {
+// ---- locate kernel (simulation mode): one sample record per lane. Coordinate conversion and the
+// LDS table walks of the cell search; no grid reads (the coefficient kernel issues those, where they
+// overlap its arithmetic instead of saturating the texture addresser here).
+__global__ void __launch_bounds__(256, 4) bl_locate_kernel(const BlShadeArgs P) {
   const BlSpacetime st = P.st;
   extern __shared__ double lds_tables[];
   GridTables tab;
@@ -993,20 +1013,15 @@ __global__ void __launch_bounds__(256, 2) bl_locate_kernel(const BlShadeArgs P) 
     const double r = bl_radial_coordinate(st, x1, x2, x3);
     bool skip = r > P.cuts.camera_r;                                 // simulation_sampling.cpp:238-243
     if (!skip && P.cuts.any_optional) skip = optional_cuts(*P.cold, x1, x2, x3, r);
-    float pr[8];
-    double ph = 0.0;
-    int status = kSampleCut;
-    if (skip) {
-      for (int v = 0; v < 8; v++) pr[v] = 0.0f;
-    } else {
-      status = locate_sample(P, tab, st, x1, x2, x3, r, pr, &ph, &gathers_local);
-    }
-    float4 *dst = reinterpret_cast<float4 *>(P.located + idx);
-    dst[0] = make_float4(pr[0], pr[1], pr[2], pr[3]);
-    dst[1] = make_float4(pr[4], pr[5], pr[6], pr[7]);
-    const unsigned long long ph_bits = (unsigned long long)__double_as_longlong(ph);
-    dst[2] = make_float4(__uint_as_float((uint32_t)ph_bits), __uint_as_float((uint32_t)(ph_bits >> 32)),
-                         __uint_as_float((uint32_t)status), 0.0f);
+    BlLocated loc;
+    loc.f_i = loc.f_j = loc.f_k = loc.ph = 0.0;
+    loc.cell = 0u;
+    loc.status = kSampleCut;
+    if (!skip) locate_sample(P, tab, st, x1, x2, x3, r, &loc, &gathers_local);
+    double2 *dst = reinterpret_cast<double2 *>(P.located + idx);
+    dst[0] = make_double2(loc.f_i, loc.f_j);
+    dst[1] = make_double2(loc.f_k, loc.ph);
+    dst[2] = make_double2(__longlong_as_double((long long)(((unsigned long long)loc.status << 32) | loc.cell)), 0.0);
   }
   // S_in accounting: one atomic per wave
   for (int offset = 32; offset > 0; offset >>= 1) gathers_local += __shfl_xor(gathers_local, offset, 64);
@@ -1021,26 +1036,52 @@ __global__ void __launch_bounds__(256, 2) bl_shade_kernel(const BlShadeArgs P) {
   const BlSpacetime st = P.st;
   const unsigned long long n_records = P.counters_in[BL_CNT_RECORDS];
   const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
-  for (unsigned long long idx = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; idx < n_records; idx += stride) {
+  // The record and the located sample of the next iteration are requested at the top of this one, behind
+  // this sample's grid reads, so they arrive while the arithmetic runs.
+  unsigned long long idx = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n_records) return;
+  double2 nq0, nq1, nq2, nq3, nl0 = make_double2(0.0, 0.0), nl1 = nl0, nl2 = nl0;
+  {
     const double2 *src = reinterpret_cast<const double2 *>(P.records + idx);
-    const double2 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
+    nq0 = src[0]; nq1 = src[1]; nq2 = src[2]; nq3 = src[3];
+    if (kModel == BL_MODEL_SIMULATION) {
+      const double2 *loc = reinterpret_cast<const double2 *>(P.located + idx);
+      nl0 = loc[0]; nl1 = loc[1]; nl2 = loc[2];
+    }
+  }
+  for (bool more = true; more;) {
+    const double2 q0 = nq0, q1 = nq1, q2 = nq2, q3 = nq3, l0 = nl0, l1 = nl1, l2 = nl2;
     const uint32_t ray = (uint32_t)__double_as_longlong(q3.y);
-    if (ray == BL_DEAD_RAY) continue;
+    const bool live = ray != BL_DEAD_RAY;
     const uint32_t n = (uint32_t)(((unsigned long long)__double_as_longlong(q3.y)) >> 32);
     const double x1 = q0.x, x2 = q0.y, x3 = q1.x;
     const double delta_lambda = -q3.x;   // ReverseGeodesics: sample_len = -geodesic_len (:840)
-    double kcov[4] = {P.ray_kt[ray], q1.y, q2.x, q2.y};
-    const double momentum_factor = P.ray_factor[ray];
+    double kcov[4] = {0.0, q1.y, q2.x, q2.y};
+    double momentum_factor = 0.0;
+    if (live) {
+      kcov[0] = P.ray_kt[ray];
+      momentum_factor = P.ray_factor[ray];
+    }
     float pr[8];
     double ph = 0.0;
-    int status;
-    if (kModel == BL_MODEL_SIMULATION) {
-      const float4 *loc = reinterpret_cast<const float4 *>(P.located + idx);
-      const float4 l0 = loc[0], l1 = loc[1], l2 = loc[2];
-      unpack_cell(l0, l1, pr);
-      ph = __longlong_as_double((long long)(((unsigned long long)__float_as_uint(l2.y) << 32) | __float_as_uint(l2.x)));
-      status = (int)__float_as_uint(l2.z);
+    int status = kSampleNone;
+    if (kModel == BL_MODEL_SIMULATION && live) {
+      const unsigned long long tag = (unsigned long long)__double_as_longlong(l2.x);
+      ph = l1.y;
+      status = (int)(tag >> 32);
+      sample_primitives(P, status, (uint32_t)tag, l0.x, l0.y, l1.x, pr);
     }
+    idx += stride;
+    more = idx < n_records;
+    if (more) {
+      const double2 *src = reinterpret_cast<const double2 *>(P.records + idx);
+      nq0 = src[0]; nq1 = src[1]; nq2 = src[2]; nq3 = src[3];
+      if (kModel == BL_MODEL_SIMULATION) {
+        const double2 *loc = reinterpret_cast<const double2 *>(P.located + idx);
+        nl0 = loc[0]; nl1 = loc[1]; nl2 = loc[2];
+      }
+    }
+    if (!live) continue;
     // Kerr-Schild scalars at the sample: evaluated once, shared by the renormalisation, the cuts, the
     // simulation metric and the geodesic metric (the reference recomputes them in each of those
     // functions; identical inputs, identical bits)
