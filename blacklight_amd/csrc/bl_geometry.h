@@ -23,6 +23,51 @@
 #define BL_HD inline
 #endif
 
+// ---- division by a shared denominator ----------------------------------------------------------
+// IEEE-754 division a / b, correctly rounded, organised so that several numerators over the same
+// denominator share the reciprocal. On gfx950 the compiler expands every fp64 `/` into
+//   v_div_scale x2, v_rcp, 2 Newton steps (4 fma), mul, fma, v_div_fmas, v_div_fixup
+// where the two v_div_scale and the scaling half of v_div_fmas only act when an exponent is close to
+// the edge of the fp64 range. bl_recip()/bl_div_r() issue the same rcp + Newton + residual sequence
+// without the scaling (5 instructions per denominator + 4 per numerator instead of 11 per quotient)
+// and keep v_div_fixup, which restores the exact IEEE result for zeros, infinities and NaNs.
+// Bit-identical to `/` whenever no scaling would have happened, i.e. for
+//   2^-1000 < |b| < 2^1000,  a == 0 or 2^-900 < |a| < 2^1000,  2^-1000 < |a / b| < 2^1000.
+// Used ONLY where both operands are built from coordinates, metric components and O(1) velocities /
+// field components (all within 2^+-200 for any ray the reference itself can integrate); quantities in
+// cgs units that can under- or overflow (emissivities, optical depths) keep the plain `/`.
+// On the host both functions are a plain division.
+struct BlRecip {
+  double d;   // the denominator
+  double y;   // its reciprocal after two Newton steps (device only)
+};
+BL_HD BlRecip bl_recip(double b) {
+  BlRecip rc;
+  rc.d = b;
+#if defined(__HIP_DEVICE_COMPILE__)
+  double y = __builtin_amdgcn_rcp(b);
+  double e = __builtin_fma(-b, y, 1.0);
+  y = __builtin_fma(y, e, y);
+  e = __builtin_fma(-b, y, 1.0);
+  y = __builtin_fma(y, e, y);
+  rc.y = y;
+#else
+  rc.y = 0.0;
+#endif
+  return rc;
+}
+BL_HD double bl_div_r(double a, const BlRecip &rc) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double q = a * rc.y;
+  double r = __builtin_fma(-rc.d, q, a);
+  q = __builtin_fma(r, rc.y, q);
+  return __builtin_amdgcn_div_fixup(q, rc.d, a);
+#else
+  return a / rc.d;
+#endif
+}
+BL_HD double bl_div_g(double a, double b) { return bl_div_r(a, bl_recip(b)); }
+
 struct BlSpacetime {
   double bh_m;
   double bh_a;
@@ -36,6 +81,10 @@ struct BlKerrSchild {
   double fl[3];   // f * l_i
   double a2, rr2;
 };
+// Reciprocals of the two denominators that the metric shares with its derivatives
+struct BlKerrSchildRecip {
+  BlRecip r, ra;  // 1 / r, 1 / (r^2 + a^2)
+};
 
 // geodesic_geometry.cpp:19-26
 BL_HD double bl_radial_coordinate(const BlSpacetime &st, double x, double y, double z) {
@@ -45,22 +94,29 @@ BL_HD double bl_radial_coordinate(const BlSpacetime &st, double x, double y, dou
   return blm_sqrt(r2);
 }
 
-BL_HD void bl_kerr_schild(const BlSpacetime &st, double x, double y, double z, BlKerrSchild *ks) {
+BL_HD void bl_kerr_schild_r(const BlSpacetime &st, double x, double y, double z, BlKerrSchild *ks,
+                            BlKerrSchildRecip *rc) {
   double bh_a = st.bh_a;
   double a2 = bh_a * bh_a;
   double rr2 = x * x + y * y + z * z;
   double r2 = 0.5 * (rr2 - a2 + bl_hypot(rr2 - a2, 2.0 * bh_a * z));
   double r = blm_sqrt(r2);
-  double f = 2.0 * st.bh_m * r2 * r / (r2 * r2 + a2 * z * z);
+  double f = bl_div_g(2.0 * st.bh_m * r2 * r, r2 * r2 + a2 * z * z);
+  rc->r = bl_recip(r);
+  rc->ra = bl_recip(r2 + a2);
   ks->a2 = a2;
   ks->rr2 = rr2;
   ks->r2 = r2;
   ks->r = r;
   ks->f = f;
-  ks->l[0] = (r * x + bh_a * y) / (r2 + a2);
-  ks->l[1] = (r * y - bh_a * x) / (r2 + a2);
-  ks->l[2] = z / r;
+  ks->l[0] = bl_div_r(r * x + bh_a * y, rc->ra);
+  ks->l[1] = bl_div_r(r * y - bh_a * x, rc->ra);
+  ks->l[2] = bl_div_r(z, rc->r);
   for (int i = 0; i < 3; i++) ks->fl[i] = f * ks->l[i];
+}
+BL_HD void bl_kerr_schild(const BlSpacetime &st, double x, double y, double z, BlKerrSchild *ks) {
+  BlKerrSchildRecip rc;
+  bl_kerr_schild_r(st, x, y, z, ks, &rc);
 }
 
 // Full covariant metric g_{mu nu} (geodesic_geometry.cpp:38-93). Used by the camera set-up and
@@ -135,7 +191,7 @@ BL_HD double bl_renormalization_factor_g(const double gcon[4][4], double k0, dou
   for (int a = 1; a < 4; a++) temp_b += 2.0 * gcon[0][a] * k[0] * k[a];
   double temp_c = gcon[0][0] * k[0] * k[0];
   double temp_d = blm_sqrt(temp_b * temp_b - 4.0 * temp_a * temp_c);
-  return temp_b < 0.0 ? (temp_d - temp_b) / (2.0 * temp_a) : -2.0 * temp_c / (temp_b + temp_d);
+  return temp_b < 0.0 ? bl_div_g(temp_d - temp_b, 2.0 * temp_a) : bl_div_g(-2.0 * temp_c, temp_b + temp_d);
 }
 
 // Null-condition renormalisation factor for the spatial covariant momentum
@@ -152,7 +208,7 @@ BL_HD double bl_renormalization_factor(const BlSpacetime &st, double x, double y
   for (int a = 1; a < 4; a++) temp_b += 2.0 * gcon[0][a] * k[0] * k[a];
   double temp_c = gcon[0][0] * k[0] * k[0];
   double temp_d = blm_sqrt(temp_b * temp_b - 4.0 * temp_a * temp_c);
-  return temp_b < 0.0 ? (temp_d - temp_b) / (2.0 * temp_a) : -2.0 * temp_c / (temp_b + temp_d);
+  return temp_b < 0.0 ? bl_div_g(temp_d - temp_b, 2.0 * temp_a) : bl_div_g(-2.0 * temp_c, temp_b + temp_d);
 }
 
 // Right-hand side of the geodesic equations (geodesics.cpp:867-893 with distance, :909-925
@@ -183,7 +239,8 @@ BL_HD void bl_geodesic_rhs(const BlSpacetime &st, const double pos[3], const dou
   double x = pos[0], y = pos[1], z = pos[2];
   double bh_a = st.bh_a;
   BlKerrSchild ks;
-  bl_kerr_schild(st, x, y, z, &ks);
+  BlKerrSchildRecip rc;
+  bl_kerr_schild_r(st, x, y, z, &ks, &rc);
   double r = ks.r, r2 = ks.r2, f = ks.f, a2 = ks.a2, rr2 = ks.rr2;
   const double *l = ks.l;
   const double *fl = ks.fl;
@@ -212,28 +269,28 @@ BL_HD void bl_geodesic_rhs(const BlSpacetime &st, const double pos[3], const dou
 
   // Scalar and vector derivatives (geodesic_geometry.cpp:199-220)
   double dr[3], df[3], dl[3][3];  // dl[i][a] = d l_{i+1} / d x^a
-  double denom = 2.0 * r2 - rr2 + a2;
-  dr[0] = r * x / denom;
-  dr[1] = r * y / denom;
-  dr[2] = (r * z + a2 * z / r) / denom;
+  // all quotients below are over four denominators (denom, den_f, r^2 + a^2, r), each inverted once
+  const BlRecip rc_denom = bl_recip(2.0 * r2 - rr2 + a2);
+  dr[0] = bl_div_r(r * x, rc_denom);
+  dr[1] = bl_div_r(r * y, rc_denom);
+  dr[2] = bl_div_r(r * z + bl_div_r(a2 * z, rc.r), rc_denom);
   double num_f = r2 * r2 - 3.0 * a2 * z * z;
-  double den_f = r * (r2 * r2 + a2 * z * z);
-  df[0] = -num_f * dr[0] / den_f * f;
-  df[1] = -num_f * dr[1] / den_f * f;
-  df[2] = -(num_f * dr[2] + 2.0 * a2 * r * z) / den_f * f;
+  const BlRecip rc_den_f = bl_recip(r * (r2 * r2 + a2 * z * z));
+  df[0] = bl_div_r(-num_f * dr[0], rc_den_f) * f;
+  df[1] = bl_div_r(-num_f * dr[1], rc_den_f) * f;
+  df[2] = bl_div_r(-(num_f * dr[2] + 2.0 * a2 * r * z), rc_den_f) * f;
   double xl = x - 2.0 * r * l[0];
   double yl = y - 2.0 * r * l[1];
-  double ra = r2 + a2;
-  dl[0][0] = (xl * dr[0] + r) / ra;
-  dl[0][1] = (xl * dr[1] + bh_a) / ra;
-  dl[0][2] = xl * dr[2] / ra;
-  dl[1][0] = (yl * dr[0] - bh_a) / ra;
-  dl[1][1] = (yl * dr[1] + r) / ra;
-  dl[1][2] = yl * dr[2] / ra;
-  double mz_r2 = -z / r2;
+  dl[0][0] = bl_div_r(xl * dr[0] + r, rc.ra);
+  dl[0][1] = bl_div_r(xl * dr[1] + bh_a, rc.ra);
+  dl[0][2] = bl_div_r(xl * dr[2], rc.ra);
+  dl[1][0] = bl_div_r(yl * dr[0] - bh_a, rc.ra);
+  dl[1][1] = bl_div_r(yl * dr[1] + r, rc.ra);
+  dl[1][2] = bl_div_r(yl * dr[2], rc.ra);
+  double mz_r2 = bl_div_g(-z, r2);
   dl[2][0] = mz_r2 * dr[0];
   dl[2][1] = mz_r2 * dr[1];
-  dl[2][2] = mz_r2 * dr[2] + 1.0 / r;
+  dl[2][2] = mz_r2 * dr[2] + bl_div_r(1.0, rc.r);
 
   // k[4+a] -= 0.5 * dgcon[a-1][mu][nu] * y[4+mu] * y[4+nu], (mu, nu) row-major (:880-883), with
   // dgcon[a][mu][nu] = -(df_a l_mu l_nu + f dl_mu,a l_nu + f l_mu dl_nu,a) (geodesic_geometry.cpp:223-274)

@@ -515,19 +515,21 @@ __device__ __forceinline__ void tetrad_build(const double ucon[4], const double 
   for (int mu = 0; mu < 4; mu++) omega -= kcov[mu] * ucon[mu];
   double k_up_over_omega = 0.0;
   for (int mu = 0; mu < 4; mu++) k_up_over_omega += kcov[mu] * up_con[mu];
-  k_up_over_omega /= omega;
+  const BlRecip rc_omega = bl_recip(omega);   // six quotients over omega
+  k_up_over_omega = bl_div_r(k_up_over_omega, rc_omega);
   double u_up_over_omega = 0.0;
   for (int mu = 0; mu < 4; mu++) u_up_over_omega += ucov[mu] * up_con[mu];
-  u_up_over_omega /= omega;
+  u_up_over_omega = bl_div_r(u_up_over_omega, rc_omega);
   for (int mu = 0; mu < 4; mu++) tetrad[0][mu] = ucon[mu];
-  for (int mu = 0; mu < 4; mu++) tetrad[3][mu] = kcon[mu] / omega - ucon[mu];
+  for (int mu = 0; mu < 4; mu++) tetrad[3][mu] = bl_div_r(kcon[mu], rc_omega) - ucon[mu];
   for (int mu = 0; mu < 4; mu++)
     tetrad[2][mu] = up_con[mu] - k_up_over_omega * tetrad[3][mu] + u_up_over_omega * kcon[mu];
   double norm = 0.0;
   for (int mu = 0; mu < 4; mu++)
     for (int nu = 0; nu < 4; nu++) norm += gcov[mu][nu] * tetrad[2][mu] * tetrad[2][nu];
   norm = blm_sqrt(norm);
-  for (int mu = 0; mu < 4; mu++) tetrad[2][mu] /= norm;
+  const BlRecip rc_norm = bl_recip(norm);
+  for (int mu = 0; mu < 4; mu++) tetrad[2][mu] = bl_div_r(tetrad[2][mu], rc_norm);
   double t1[4];
   t1[0] = tetrad[0][1] * (tetrad[2][3] * tetrad[3][2] - tetrad[2][2] * tetrad[3][3])
       + tetrad[0][2] * (tetrad[2][1] * tetrad[3][3] - tetrad[2][3] * tetrad[3][1])
@@ -748,35 +750,41 @@ __device__ __forceinline__ void sample_finish_simulation(const BlShadeArgs &P, c
     const double sth2 = 1.0 - cth2;
     const double delta = r2 - 2.0 * bh_m * r + a2;
     const double sigma = r2 + a2 * cth2;
-    const double g00 = -(1.0 - 2.0 * bh_m * r / sigma);
-    const double g01 = 2.0 * bh_m * r / sigma;
-    const double g03 = -2.0 * bh_m * bh_a * r * sth2 / sigma;
-    const double g11 = 1.0 + 2.0 * bh_m * r / sigma;
-    const double g13 = -(1.0 + 2.0 * bh_m * r / sigma) * bh_a * sth2;
+    // three quotients over sigma (2 m r / sigma is one expression in the reference, used six times)
+    const BlRecip rc_sigma = bl_recip(sigma);
+    const double two_mr_sigma = bl_div_r(2.0 * bh_m * r, rc_sigma);
+    const double g00 = -(1.0 - two_mr_sigma);
+    const double g01 = two_mr_sigma;
+    const double g03 = bl_div_r(-2.0 * bh_m * bh_a * r * sth2, rc_sigma);
+    const double g11 = 1.0 + two_mr_sigma;
+    const double g13 = -(1.0 + two_mr_sigma) * bh_a * sth2;
     const double g22 = sigma;
-    const double g33 = (r2 + a2 + 2.0 * bh_m * a2 * r * sth2 / sigma) * sth2;
-    const double gc00 = -(1.0 + 2.0 * bh_m * r / sigma);
-    const double gc01 = 2.0 * bh_m * r / sigma;
+    const double g33 = (r2 + a2 + bl_div_r(2.0 * bh_m * a2 * r * sth2, rc_sigma)) * sth2;
+    const double gc00 = -(1.0 + two_mr_sigma);
+    const double gc01 = two_mr_sigma;
     (void)delta;
     // uu0 (:297-300): gcov_sim[1][2] = gcov_sim[2][3] = 0
     const double uu0 = blm_sqrt(1.0 + g11 * uu1 * uu1 + 2.0 * 0.0 * uu1 * uu2 + 2.0 * g13 * uu1 * uu3
         + g22 * uu2 * uu2 + 2.0 * 0.0 * uu2 * uu3 + g33 * uu3 * uu3);
-    const double lapse = 1.0 / blm_sqrt(-gc00);
-    const double shift1 = -gc01 / gc00;
-    const double shift2 = -0.0 / gc00;
-    const double shift3 = -0.0 / gc00;
-    ucon_sim[0] = uu0 / lapse;
-    ucon_sim[1] = uu1 - shift1 * uu0 / lapse;
-    ucon_sim[2] = uu2 - shift2 * uu0 / lapse;
-    ucon_sim[3] = uu3 - shift3 * uu0 / lapse;
+    const double lapse = bl_div_g(1.0, blm_sqrt(-gc00));
+    const double shift1 = bl_div_g(-gc01, gc00);
+    // shift2 = shift3 = -gcon_sim[0][2,3] / gcon_sim[0][0] = -0 / gc00 = +0 (gc00 <= -1, or NaN and then
+    // uu0 is NaN too), so the reference's  uu_a - shift_a * uu0 / lapse  subtracts (+0 * uu0) / lapse:
+    // +0 when uu0 is finite (lapse is in (0, 1]), NaN when uu0 is not. 0.0 * uu0 is exactly that.
+    const BlRecip rc_lapse = bl_recip(lapse);
+    ucon_sim[0] = bl_div_r(uu0, rc_lapse);
+    ucon_sim[1] = uu1 - bl_div_r(shift1 * uu0, rc_lapse);
+    ucon_sim[2] = uu2 - 0.0 * uu0;
+    ucon_sim[3] = uu3 - 0.0 * uu0;
     // ucov_sim[mu] = sum_nu gcov_sim[mu][nu] ucon_sim[nu] (:310-313), non-zero entries only
     const double ucov1 = (g01 * ucon_sim[0] + g11 * ucon_sim[1]) + g13 * ucon_sim[3];
     const double ucov2 = g22 * ucon_sim[2];
     const double ucov3 = (g03 * ucon_sim[0] + g13 * ucon_sim[1]) + g33 * ucon_sim[3];
     bcon_sim[0] = ucov1 * bb1 + ucov2 * bb2 + ucov3 * bb3;
-    bcon_sim[1] = (bb1 + bcon_sim[0] * ucon_sim[1]) / ucon_sim[0];
-    bcon_sim[2] = (bb2 + bcon_sim[0] * ucon_sim[2]) / ucon_sim[0];
-    bcon_sim[3] = (bb3 + bcon_sim[0] * ucon_sim[3]) / ucon_sim[0];
+    const BlRecip rc_u0 = bl_recip(ucon_sim[0]);
+    bcon_sim[1] = bl_div_r(bb1 + bcon_sim[0] * ucon_sim[1], rc_u0);
+    bcon_sim[2] = bl_div_r(bb2 + bcon_sim[0] * ucon_sim[2], rc_u0);
+    bcon_sim[3] = bl_div_r(bb3 + bcon_sim[0] * ucon_sim[3], rc_u0);
     const double bcov0 = (g00 * bcon_sim[0] + g01 * bcon_sim[1]) + g03 * bcon_sim[3];
     const double bcov1 = (g01 * bcon_sim[0] + g11 * bcon_sim[1]) + g13 * bcon_sim[3];
     const double bcov2 = g22 * bcon_sim[2];
