@@ -548,8 +548,11 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
     if (chunk < n_rays) chunk = (chunk / 64) * 64;   // keep 8x8 tiles whole
     const int n_chunks = static_cast<int>((n_rays + chunk - 1) / chunk);
 
-    ctx->d_records.Ensure(static_cast<size_t>(chunk) * max_steps);
-    if (simulation) ctx->d_located.Ensure(static_cast<size_t>(chunk) * max_steps);
+    const int geo_blocks_per_cu = bl_geodesic_occupancy(p.ray_integrator);
+    const int geo_grid = ctx->num_cus * geo_blocks_per_cu;   // persistent waves of the geodesic kernel
+    const size_t record_capacity = static_cast<size_t>(chunk) * max_steps + static_cast<size_t>(geo_grid) * BL_RECORD_BLOCK;
+    ctx->d_records.Ensure(record_capacity);
+    if (simulation) ctx->d_located.Ensure(record_capacity);
     ctx->d_transfer.Ensure(static_cast<size_t>(chunk) * max_steps * n_nu);
     ctx->d_ray_kt.Ensure(chunk);
     ctx->d_ray_factor.Ensure(chunk);
@@ -621,7 +624,7 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
     ta.pixel_map = d_pixel_map;
     ta.block_locs = d_block_locs;
     ta.records = ctx->d_records.ptr;
-    ta.record_capacity = static_cast<long long>(chunk) * max_steps;
+    ta.record_capacity = static_cast<long long>(record_capacity);
     ta.counters = ctx->d_counters.ptr;
     ta.ray_kt = ctx->d_ray_kt.ptr;
     ta.ray_factor = ctx->d_ray_factor.ptr;
@@ -718,8 +721,6 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
     xa.out_flags = out_flags;
     xa.stats = ctx->d_counters.ptr + BL_CNT_COUNT;
 
-    const int geo_blocks_per_cu = bl_geodesic_occupancy(p.ray_integrator);
-    const int geo_grid = ctx->num_cus * geo_blocks_per_cu;
     const int locate_grid = ctx->num_cus * 4 * 4;  // 256-thread workgroups, 4 waves per SIMD, x4 for tail balance
     const int shade_grid = ctx->num_cus * 2 * 4;  // 256-thread workgroups, 2 waves per SIMD, x4 for tail balance
 

@@ -301,26 +301,30 @@ BL_HD void bl_geodesic_rhs(const BlSpacetime &st, const double pos[3], const dou
       dfl[i] = df[a] * l[i];
       fdl[i] = f * dl[i][a];
     }
+    // Every term of the reference's sum carries the factor 0.5 as its first multiplication. Scaling
+    // by a power of two commutes with rounding (nothing here is near the underflow threshold), so
+    // summing the unscaled terms in the same order and halving once gives the same bits.
     double acc = 0.0;
-    acc -= 0.5 * (-df[a]) * kcov[0] * kcov[0];
-    for (int j = 0; j < 3; j++) acc -= 0.5 * (dfl[j] + fdl[j]) * kcov[0] * kcov[j + 1];
+    acc -= (-df[a]) * kcov[0] * kcov[0];
+    for (int j = 0; j < 3; j++) acc -= (dfl[j] + fdl[j]) * kcov[0] * kcov[j + 1];
     for (int i = 0; i < 3; i++) {
-      acc -= 0.5 * (dfl[i] + fdl[i]) * kcov[i + 1] * kcov[0];
+      acc -= (dfl[i] + fdl[i]) * kcov[i + 1] * kcov[0];
       for (int j = 0; j < 3; j++) {
         double dg = -(dfl[i] * l[j] + fdl[i] * l[j] + fl[i] * dl[j][a]);
-        acc -= 0.5 * dg * kcov[i + 1] * kcov[j + 1];
+        acc -= dg * kcov[i + 1] * kcov[j + 1];
       }
     }
-    dk[a] = acc;
+    dk[a] = 0.5 * acc;
   }
 
   if (kWithDistance) {
     // temp_a[a] += (gcon[a][mu] - gcon[0][a] * gcon[0][mu] / gcon[0][0]) * y[4+mu] (:884-887)
     double temp_a[3];
+    const BlRecip rc_g00 = bl_recip(g00);   // twelve quotients over g^{00}
     for (int a = 0; a < 3; a++) {
       double g0a = fl[a];
-      double acc = (fl[a] - g0a * g00 / g00) * kcov[0];
-      for (int j = 0; j < 3; j++) acc += (gij[a][j] - g0a * fl[j] / g00) * kcov[j + 1];
+      double acc = (fl[a] - bl_div_r(g0a * g00, rc_g00)) * kcov[0];
+      for (int j = 0; j < 3; j++) acc += (gij[a][j] - bl_div_r(g0a * fl[j], rc_g00)) * kcov[j + 1];
       temp_a[a] = acc;
     }
     // k[8] += gcov[a][b] * temp_a[a] * temp_a[b] (:888-891); gcov[i][j] = (f l_i) l_j (+1 diag)

@@ -68,15 +68,43 @@ __device__ __forceinline__ double std_min(double a, double b) { return (b < a) ?
 
 __device__ __forceinline__ int wave_lane() { return threadIdx.x & 63; }
 
-// Inclusive wave scan of non-negative ints (64 lanes), via ds_bpermute-free shuffles
+// Wave-level scan / reduction with DPP row shifts and row broadcasts (VALU only: a ds_bpermute
+// shuffle costs an LDS round trip that nothing hides at one wave per SIMD).
+//   row_shr:n = 0x110 + n, row_bcast:15 = 0x142 (rows 1 and 3 take lane 15 of the row below),
+//   row_bcast:31 = 0x143 (rows 2 and 3 take lane 31). Lanes without a source keep `old` = identity.
+#define BL_DPP(old, src, ctrl, row_mask) __builtin_amdgcn_update_dpp((old), (src), (ctrl), (row_mask), 0xf, false)
+
+// Inclusive wave scan of ints (64 lanes)
 __device__ __forceinline__ int wave_inclusive_scan(int v) {
-  const int lane = wave_lane();
-#pragma unroll
-  for (int offset = 1; offset < 64; offset <<= 1) {
-    int up = __shfl_up(v, offset, 64);
-    if (lane >= offset) v += up;
-  }
+  v += BL_DPP(0, v, 0x111, 0xf);
+  v += BL_DPP(0, v, 0x112, 0xf);
+  v += BL_DPP(0, v, 0x114, 0xf);
+  v += BL_DPP(0, v, 0x118, 0xf);
+  v += BL_DPP(0, v, 0x142, 0xa);
+  v += BL_DPP(0, v, 0x143, 0xc);
   return v;
+}
+
+// Maximum of non-negative ints over the wave (uniform result)
+__device__ __forceinline__ int wave_max_nonneg(int v) {
+  int t;
+  t = BL_DPP(0, v, 0x111, 0xf); v = t > v ? t : v;
+  t = BL_DPP(0, v, 0x112, 0xf); v = t > v ? t : v;
+  t = BL_DPP(0, v, 0x114, 0xf); v = t > v ? t : v;
+  t = BL_DPP(0, v, 0x118, 0xf); v = t > v ? t : v;
+  t = BL_DPP(0, v, 0x142, 0xa); v = t > v ? t : v;
+  t = BL_DPP(0, v, 0x143, 0xc); v = t > v ? t : v;
+  return __builtin_amdgcn_readlane(v, 63);
+}
+
+__device__ __forceinline__ long long std_max_ll(long long a, long long b) { return a > b ? a : b; }
+
+// Mark the record slots [first, last) as dead (only the id word is written)
+__device__ __forceinline__ void retire_record_slots(BlSampleRecord *records, long long first, long long last, int lane) {
+  for (long long at = first + lane; at < last; at += 64) {
+    records[at].ray = BL_DEAD_RAY;
+    records[at].n = 0u;
+  }
 }
 
 // State vector component order used in the geodesic kernel:
@@ -141,6 +169,7 @@ __global__ void __launch_bounds__(64, 1) bl_geodesic_kernel(BlTraceArgs P) {
     k0[p] = 0.0;
   }
   s.kt = 0.0;
+  long long block_next = 0, block_end = 0;   // this wave's block of record slots (wave-uniform)
 
   while (true) {
     // ------------------------------------------------------------------ refill idle lanes
@@ -151,7 +180,8 @@ __global__ void __launch_bounds__(64, 1) bl_geodesic_kernel(BlTraceArgs P) {
       int leader = __ffsll((long long)need_mask) - 1;
       unsigned long long base = 0ull;
       if (lane == leader) base = atomicAdd(&P.counters[BL_CNT_NEXT_RAY], (unsigned long long)count);
-      base = __shfl(base, leader, 64);
+      base = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(base >> 32), leader) << 32)
+          | (unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)base, leader);
       if (need) {
         int rank = __popcll(need_mask & ((1ull << lane) - 1ull));
         unsigned long long q = base + (unsigned long long)rank;
@@ -198,7 +228,10 @@ __global__ void __launch_bounds__(64, 1) bl_geodesic_kernel(BlTraceArgs P) {
         }
       }
     }
-    if (__ballot(have_ray) == 0ull) break;
+    if (__ballot(have_ray) == 0ull) {
+      retire_record_slots(P.records, block_next, block_end, lane);   // unused rest of the last block
+      break;
+    }
 
     // ------------------------------------------------------------------ one step attempt
     int emit = 0;               // samples this lane writes in this iteration
@@ -357,28 +390,44 @@ __global__ void __launch_bounds__(64, 1) bl_geodesic_kernel(BlTraceArgs P) {
     }
 
     // ------------------------------------------------------------------ allocate sample slots
-    // One wave scan + one atomic for the whole wave-step; each lane's samples are contiguous.
+    // Each wave owns a block of BL_RECORD_BLOCK consecutive record slots and hands them out with one
+    // wave scan per step; the global atomic (whose return has to be waited for, with nothing else to
+    // run at one wave per SIMD) is only needed when a block runs out, about once in a dozen steps.
+    // Each lane's samples are contiguous. When the step does not fit in what is left of the block,
+    // the leading lanes that do fit use it up and the others start the next block; the few slots in
+    // between are marked dead for the shading kernels.
     int scan = wave_inclusive_scan(emit);
-    int total = __shfl(scan, 63, 64);
-    unsigned long long wave_base = 0ull;
+    int total = __builtin_amdgcn_readlane(scan, 63);
+    long long my_base = 0;
     if (total > 0) {
-      if (lane == 63) wave_base = atomicAdd(&P.counters[BL_CNT_RECORDS], (unsigned long long)total);
-      wave_base = __shfl(wave_base, 63, 64);
-    }
-    long long my_base = (long long)wave_base + (long long)(scan - emit);
-    if (emit > 0 && my_base + emit > P.record_capacity) {
-      // cannot happen when capacity = chunk_rays * ray_max_steps; flagged for the host if it does
-      atomicExch(&P.counters[BL_CNT_OVERFLOW], 1ull);
-      emit = 0;
+      const long long remaining = block_end - block_next;
+      const unsigned long long fit_mask = __ballot((long long)scan <= remaining);   // a prefix of the lanes (scan is monotonic)
+      const int n_fit = __popcll(fit_mask);
+      const int used_old = n_fit > 0 ? __builtin_amdgcn_readlane(scan, n_fit - 1) : 0;
+      if (n_fit == 64) {
+        my_base = block_next + (long long)(scan - emit);
+        block_next += total;
+      } else {
+        retire_record_slots(P.records, block_next + used_old, block_end, lane);
+        const unsigned long long grab = (unsigned long long)std_max_ll(total - used_old, BL_RECORD_BLOCK);
+        unsigned long long new_base = 0ull;
+        if (lane == 63) new_base = atomicAdd(&P.counters[BL_CNT_RECORDS], grab);
+        new_base = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(new_base >> 32), 63) << 32)
+            | (unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)new_base, 63);
+        my_base = lane < n_fit ? block_next + (long long)(scan - emit) : (long long)new_base + (long long)(scan - emit - used_old);
+        block_next = (long long)new_base + (long long)(total - used_old);
+        block_end = (long long)(new_base + grab);
+        if (block_end > P.record_capacity) {
+          // cannot happen when capacity = chunk_rays * ray_max_steps + one block per wave; flagged for the host
+          atomicExch(&P.counters[BL_CNT_OVERFLOW], 1ull);
+          block_end = block_next = 0;
+          emit = 0;
+        }
+      }
     }
 
     // ------------------------------------------------------------------ emit samples
-    int max_emit = emit;
-#pragma unroll
-    for (int offset = 32; offset > 0; offset >>= 1) {
-      int other = __shfl_xor(max_emit, offset, 64);
-      max_emit = other > max_emit ? other : max_emit;
-    }
+    const int max_emit = wave_max_nonneg(emit);
     for (int nn = 0; nn < max_emit; nn++) {
       if (nn < emit) {
         double smp[7];
