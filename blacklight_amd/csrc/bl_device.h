@@ -51,7 +51,7 @@ static_assert(sizeof(BlLocated) == 48, "located sample must be 48 bytes");
 #define BL_DEAD_RAY 0xFFFFFFFFu
 // Record slots a wave of the geodesic kernel reserves at a time (one global atomic per block); the
 // record buffers hold one spare block per launched wave on top of chunk_rays * ray_max_steps.
-#define BL_RECORD_BLOCK 4096
+#define BL_RECORD_BLOCK 1024
 // Marker for "optically thick: I <- b" in the transfer record (exp(-dtau) is never negative)
 #define BL_THICK_MARK (-1.0)
 

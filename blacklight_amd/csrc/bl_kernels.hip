@@ -1061,12 +1061,31 @@ __global__ void __launch_bounds__(256, 4) bl_locate_kernel(const BlShadeArgs P) 
   const unsigned long long n_records = P.counters_in[BL_CNT_RECORDS];
   const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
   unsigned long long gathers_local = 0ull;
-  for (unsigned long long idx = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; idx < n_records; idx += stride) {
-    const double2 *src = reinterpret_cast<const double2 *>(P.records + idx);
-    const double2 q0 = src[0], q1 = src[1], q3 = src[3];
-    const uint32_t ray = (uint32_t)__double_as_longlong(q3.y);
+  // Position and id of the next record are requested one iteration ahead (all three pieces together:
+  // left to the compiler, the position loads sink below the dead-record test and pay a second latency).
+  unsigned long long idx = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  bool more = idx < n_records;
+  double2 nq0 = make_double2(0.0, 0.0);
+  double nz = 0.0, nid = 0.0;
+  if (more) {
+    const double *src = reinterpret_cast<const double *>(P.records + idx);
+    nq0 = *reinterpret_cast<const double2 *>(src);
+    nz = src[2];
+    nid = src[7];
+  }
+  while (more) {
+    const unsigned long long at = idx;
+    const double x1 = nq0.x, x2 = nq0.y, x3 = nz;
+    const uint32_t ray = (uint32_t)__double_as_longlong(nid);
+    idx += stride;
+    more = idx < n_records;
+    if (more) {
+      const double *src = reinterpret_cast<const double *>(P.records + idx);
+      nq0 = *reinterpret_cast<const double2 *>(src);
+      nz = src[2];
+      nid = src[7];
+    }
     if (ray == BL_DEAD_RAY) continue;
-    const double x1 = q0.x, x2 = q0.y, x3 = q1.x;
     const double r = bl_radial_coordinate(st, x1, x2, x3);
     bool skip = r > P.cuts.camera_r;                                 // simulation_sampling.cpp:238-243
     if (!skip && P.cuts.any_optional) skip = optional_cuts(*P.cold, x1, x2, x3, r);
@@ -1075,7 +1094,7 @@ __global__ void __launch_bounds__(256, 4) bl_locate_kernel(const BlShadeArgs P) 
     loc.cell = 0u;
     loc.status = kSampleCut;
     if (!skip) locate_sample(P, tab, st, x1, x2, x3, r, &loc, &gathers_local);
-    double2 *dst = reinterpret_cast<double2 *>(P.located + idx);
+    double2 *dst = reinterpret_cast<double2 *>(P.located + at);
     dst[0] = make_double2(loc.f_i, loc.f_j);
     dst[1] = make_double2(loc.f_k, loc.ph);
     dst[2] = make_double2(__longlong_as_double((long long)(((unsigned long long)loc.status << 32) | loc.cell)), 0.0);
