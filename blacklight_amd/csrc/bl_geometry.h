@@ -68,6 +68,48 @@ BL_HD double bl_div_r(double a, const BlRecip &rc) {
 }
 BL_HD double bl_div_g(double a, double b) { return bl_div_r(a, bl_recip(b)); }
 
+// ---- square root and hypot for geometric operands -----------------------------------------------
+// bl_sqrt_g: the compiler's correctly rounded fp64 square root (v_rsq + two coupled Newton steps)
+// without the 2^256 pre-scaling it applies to arguments below 2^-767; zeros and +inf pass through,
+// negative arguments and NaN give NaN. Bit-identical to sqrt() for x >= 2^-767.
+// bl_hypot_g: bl_hypot() of blmath.h - same operations in the same order - without its range
+// scaling and its infinity tests: bit-identical for finite arguments with max <= 2^510 and
+// min >= 2^-450 (or zero); NaN in, NaN out. Host builds call the general functions.
+BL_HD double bl_sqrt_g(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double y = __builtin_amdgcn_rsq(x);
+  double g = x * y;
+  double h = y * 0.5;
+  double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  double d = __builtin_fma(-g, g, x);
+  g = __builtin_fma(d, h, g);
+  d = __builtin_fma(-g, g, x);
+  g = __builtin_fma(d, h, g);
+  return __builtin_amdgcn_class(x, 0x260) ? x : g;   // +-0, +inf
+#else
+  return blm_sqrt(x);
+#endif
+}
+BL_HD double bl_hypot_g(double x, double y) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double ax = blm_abs(x), ay = blm_abs(y);
+  const bool swap = ax < ay;
+  const double big = swap ? ay : ax, small = swap ? ax : ay;
+  double p = big * big, pe = __builtin_fma(big, big, -p);
+  double q = small * small, qe = __builtin_fma(small, small, -q);
+  double hi = p + q;
+  double lo = (q - (hi - p)) + (pe + qe);
+  double h = bl_sqrt_g(hi);
+  double r = __builtin_fma(-h, h, hi) + lo;
+  h = h + bl_div_g(r, h + h);
+  return (small == 0.0 || small < big * 0x1p-54) ? big : h;
+#else
+  return bl_hypot(x, y);
+#endif
+}
+
 struct BlSpacetime {
   double bh_m;
   double bh_a;
@@ -90,8 +132,8 @@ struct BlKerrSchildRecip {
 BL_HD double bl_radial_coordinate(const BlSpacetime &st, double x, double y, double z) {
   double a2 = st.bh_a * st.bh_a;
   double rr2 = x * x + y * y + z * z;
-  double r2 = 0.5 * (rr2 - a2 + bl_hypot(rr2 - a2, 2.0 * st.bh_a * z));
-  return blm_sqrt(r2);
+  double r2 = 0.5 * (rr2 - a2 + bl_hypot_g(rr2 - a2, 2.0 * st.bh_a * z));
+  return bl_sqrt_g(r2);
 }
 
 BL_HD void bl_kerr_schild_r(const BlSpacetime &st, double x, double y, double z, BlKerrSchild *ks,
@@ -99,8 +141,8 @@ BL_HD void bl_kerr_schild_r(const BlSpacetime &st, double x, double y, double z,
   double bh_a = st.bh_a;
   double a2 = bh_a * bh_a;
   double rr2 = x * x + y * y + z * z;
-  double r2 = 0.5 * (rr2 - a2 + bl_hypot(rr2 - a2, 2.0 * bh_a * z));
-  double r = blm_sqrt(r2);
+  double r2 = 0.5 * (rr2 - a2 + bl_hypot_g(rr2 - a2, 2.0 * bh_a * z));
+  double r = bl_sqrt_g(r2);
   double f = bl_div_g(2.0 * st.bh_m * r2 * r, r2 * r2 + a2 * z * z);
   rc->r = bl_recip(r);
   rc->ra = bl_recip(r2 + a2);
@@ -190,7 +232,7 @@ BL_HD double bl_renormalization_factor_g(const double gcon[4][4], double k0, dou
   double temp_b = 0.0;
   for (int a = 1; a < 4; a++) temp_b += 2.0 * gcon[0][a] * k[0] * k[a];
   double temp_c = gcon[0][0] * k[0] * k[0];
-  double temp_d = blm_sqrt(temp_b * temp_b - 4.0 * temp_a * temp_c);
+  double temp_d = bl_sqrt_g(temp_b * temp_b - 4.0 * temp_a * temp_c);
   return temp_b < 0.0 ? bl_div_g(temp_d - temp_b, 2.0 * temp_a) : bl_div_g(-2.0 * temp_c, temp_b + temp_d);
 }
 
@@ -207,7 +249,7 @@ BL_HD double bl_renormalization_factor(const BlSpacetime &st, double x, double y
   double temp_b = 0.0;
   for (int a = 1; a < 4; a++) temp_b += 2.0 * gcon[0][a] * k[0] * k[a];
   double temp_c = gcon[0][0] * k[0] * k[0];
-  double temp_d = blm_sqrt(temp_b * temp_b - 4.0 * temp_a * temp_c);
+  double temp_d = bl_sqrt_g(temp_b * temp_b - 4.0 * temp_a * temp_c);
   return temp_b < 0.0 ? bl_div_g(temp_d - temp_b, 2.0 * temp_a) : bl_div_g(-2.0 * temp_c, temp_b + temp_d);
 }
 
@@ -230,7 +272,7 @@ BL_HD void bl_geodesic_rhs(const BlSpacetime &st, const double pos[3], const dou
       // temp_a[a] = sum_mu (g^{a mu} - g^{0a} g^{0 mu}/g^{00}) k_mu = k_a ; k[8] = -sqrt(sum k_a^2)
       double acc = 0.0;
       for (int a = 1; a < 4; a++) acc += kcov[a] * kcov[a];
-      *ds = -blm_sqrt(acc);
+      *ds = -bl_sqrt_g(acc);
     }
     // RadialGeodesicCoordinate ignores ray_flat (geodesic_geometry.cpp:19-26)
     *r_out = bl_radial_coordinate(st, pos[0], pos[1], pos[2]);
@@ -334,7 +376,7 @@ BL_HD void bl_geodesic_rhs(const BlSpacetime &st, const double pos[3], const dou
         double gab = a == b ? fl[a] * l[b] + 1.0 : fl[a] * l[b];
         acc += gab * temp_a[a] * temp_a[b];
       }
-    *ds = -blm_sqrt(acc);
+    *ds = -bl_sqrt_g(acc);
   }
 }
 

@@ -256,16 +256,28 @@ __global__ void __launch_bounds__(64, 1) bl_geodesic_kernel(BlTraceArgs P) {
           h = h_new;
           double k1[8], k2[8], k3[8], k4[8], k5[8];
           double yt[8], r_stage;
+          // Coordinate time (component 0) and proper distance (component 7) never enter a right-hand
+          // side: their stage derivatives are only ever used in the b-weighted sums of the 5th / 4th
+          // order solutions, whose terms are added in stage order. Those sums are advanced as soon as
+          // each stage is known, so 2 x 6 stage values need not stay live through the later stages.
+          double t5 = s.y[0], t4 = s.y[0], s5 = s.y[7];
+#define BL_FOLD(Q, K)                     \
+          t5 += kB5[Q] * h * K[0];        \
+          t4 += kB4[Q] * h * K[0];        \
+          s5 += kB5[Q] * h * K[7];
+          BL_FOLD(0, k0)
           // stages 1..6 (:162-170): y_temp = y + sum_{q<s} a[s][q] * h * k[q], terms added in q order
 #define BL_STAGE(S, KOUT, ...)                                                  \
           {                                                                      \
             const double *kq[6] = {__VA_ARGS__};                                 \
-            _Pragma("unroll") for (int p = 0; p < 8; p++) {                      \
+            _Pragma("unroll") for (int p = 1; p < 7; p++) {                      \
               double acc = s.y[p];                                               \
               _Pragma("unroll") for (int q = 0; q < S; q++) acc += kA[S][q] * h * kq[q][p]; \
               yt[p] = acc;                                                       \
             }                                                                    \
+            yt[0] = 0.0; yt[7] = 0.0;                                            \
             rhs<true>(st, yt, s.kt, KOUT, &r_stage);                             \
+            BL_FOLD(S, KOUT)                                                     \
           }
           BL_STAGE(1, k1, k0, k0, k0, k0, k0, k0)
           BL_STAGE(2, k2, k0, k1, k0, k0, k0, k0)
@@ -274,6 +286,7 @@ __global__ void __launch_bounds__(64, 1) bl_geodesic_kernel(BlTraceArgs P) {
           BL_STAGE(5, k5, k0, k1, k2, k3, k4, k0)
           BL_STAGE(6, k6, k0, k1, k2, k3, k4, k5)
 #undef BL_STAGE
+#undef BL_FOLD
           // 5th / 4th order solutions and error (:173-194). y_vals_5 equals the stage-6 argument
           // bit for bit (same coefficients, same order, the extra b5[6] = 0 term adds +-0), so
           // r_new = RadialGeodesicCoordinate(y_vals_5) is the r of stage 6.
@@ -282,10 +295,17 @@ __global__ void __launch_bounds__(64, 1) bl_geodesic_kernel(BlTraceArgs P) {
 #pragma unroll
           for (int p = 0; p < 8; p++) {
             double a5 = s.y[p], a4 = s.y[p];
+            if (p == 0) {
+              a5 = t5;
+              a4 = t4;
+            } else if (p == 7) {
+              a5 = s5;
+            } else {
 #pragma unroll
-            for (int q = 0; q < 7; q++) {
-              a5 += kB5[q] * h * kk[q][p];
-              a4 += kB4[q] * h * kk[q][p];
+              for (int q = 0; q < 7; q++) {
+                a5 += kB5[q] * h * kk[q][p];
+                a4 += kB4[q] * h * kk[q][p];
+              }
             }
             y5[p] = a5;
             if (p < 7) {   // reference p < 8 covers t, x, y, z, k_t (zero difference), k_x, k_y, k_z
@@ -319,9 +339,9 @@ __global__ void __launch_bounds__(64, 1) bl_geodesic_kernel(BlTraceArgs P) {
             previous_fail = false;
             accepted = true;
 
-            // midpoint (:227-231), subdivision (:234-245)
+            // midpoint (:227-231), subdivision (:234-245); component 0 (t) of the samples is never stored
 #pragma unroll
-            for (int p = 0; p < 7; p++) {
+            for (int p = 1; p < 7; p++) {
               double acc = s.y[p];
 #pragma unroll
               for (int q = 0; q < 7; q++) acc += kB4m[q] * h * kk[q][p];
@@ -340,7 +360,7 @@ __global__ void __launch_bounds__(64, 1) bl_geodesic_kernel(BlTraceArgs P) {
             emit = num_steps;
             if (num_steps_ideal > 1) {   // :262-274
 #pragma unroll
-              for (int p = 0; p < 7; p++) {
+              for (int p = 1; p < 7; p++) {
                 rv0[p] = y5[p] - s.y[p];
                 rv1[p] = s.y[p] - y5[p] + h * k0[p];
                 rv2[p] = 2.0 * (y5[p] - s.y[p]) - h * (k0[p] + k6[p]);
@@ -434,12 +454,12 @@ __global__ void __launch_bounds__(64, 1) bl_geodesic_kernel(BlTraceArgs P) {
         double len;
         if (num_steps_ideal == 1) {   // :248-259 (and the RK4 / RK2 stored state)
 #pragma unroll
-          for (int p = 0; p < 7; p++) smp[p] = y4m[p];
+          for (int p = 1; p < 7; p++) smp[p] = y4m[p];
           len = h;
         } else {                      // :277-293
           double frac = (nn + 0.5) / num_steps_ideal;
 #pragma unroll
-          for (int p = 0; p < 7; p++)
+          for (int p = 1; p < 7; p++)
             smp[p] = s.y[p] + frac * (rv0[p] + (1.0 - frac) * (rv1[p] + frac * (rv2[p] + (1.0 - frac) * rv3[p])));
           len = h / num_steps_ideal;
         }
@@ -576,7 +596,7 @@ __device__ __forceinline__ void tetrad_build(const double ucon[4], const double 
   double norm = 0.0;
   for (int mu = 0; mu < 4; mu++)
     for (int nu = 0; nu < 4; nu++) norm += gcov[mu][nu] * tetrad[2][mu] * tetrad[2][nu];
-  norm = blm_sqrt(norm);
+  norm = bl_sqrt_g(norm);
   const BlRecip rc_norm = bl_recip(norm);
   for (int mu = 0; mu < 4; mu++) tetrad[2][mu] = bl_div_r(tetrad[2][mu], rc_norm);
   double t1[4];
@@ -813,9 +833,9 @@ __device__ __forceinline__ void sample_finish_simulation(const BlShadeArgs &P, c
     const double gc01 = two_mr_sigma;
     (void)delta;
     // uu0 (:297-300): gcov_sim[1][2] = gcov_sim[2][3] = 0
-    const double uu0 = blm_sqrt(1.0 + g11 * uu1 * uu1 + 2.0 * 0.0 * uu1 * uu2 + 2.0 * g13 * uu1 * uu3
+    const double uu0 = bl_sqrt_g(1.0 + g11 * uu1 * uu1 + 2.0 * 0.0 * uu1 * uu2 + 2.0 * g13 * uu1 * uu3
         + g22 * uu2 * uu2 + 2.0 * 0.0 * uu2 * uu3 + g33 * uu3 * uu3);
-    const double lapse = bl_div_g(1.0, blm_sqrt(-gc00));
+    const double lapse = bl_div_g(1.0, bl_sqrt_g(-gc00));
     const double shift1 = bl_div_g(-gc01, gc00);
     // shift2 = shift3 = -gcon_sim[0][2,3] / gcon_sim[0][0] = -0 / gc00 = +0 (gc00 <= -1, or NaN and then
     // uu0 is NaN too), so the reference's  uu_a - shift_a * uu0 / lapse  subtracts (+0 * uu0) / lapse:
@@ -844,10 +864,10 @@ __device__ __forceinline__ void sample_finish_simulation(const BlShadeArgs &P, c
     double gs_cov[4][4], gs_con[4][4];
     bl_gcov_ks(ks, gs_cov);
     bl_gcon_ks(ks, gs_con);
-    const double uu0 = blm_sqrt(1.0 + gs_cov[1][1] * uu1 * uu1 + 2.0 * gs_cov[1][2] * uu1 * uu2
+    const double uu0 = bl_sqrt_g(1.0 + gs_cov[1][1] * uu1 * uu1 + 2.0 * gs_cov[1][2] * uu1 * uu2
         + 2.0 * gs_cov[1][3] * uu1 * uu3 + gs_cov[2][2] * uu2 * uu2 + 2.0 * gs_cov[2][3] * uu2 * uu3
         + gs_cov[3][3] * uu3 * uu3);
-    const double lapse = 1.0 / blm_sqrt(-gs_con[0][0]);
+    const double lapse = 1.0 / bl_sqrt_g(-gs_con[0][0]);
     const double shift1 = -gs_con[0][1] / gs_con[0][0];
     const double shift2 = -gs_con[0][2] / gs_con[0][0];
     const double shift3 = -gs_con[0][3] / gs_con[0][0];
@@ -872,7 +892,7 @@ __device__ __forceinline__ void sample_finish_simulation(const BlShadeArgs &P, c
       b_sq += acc * bcon_sim[mu];
     }
   }
-  const double bb_cgs = blm_sqrt(b_sq) * pl.b_unit;
+  const double bb_cgs = bl_sqrt_g(b_sq) * pl.b_unit;
   const double sigma_cut = b_sq / rho;
   const double beta_inv = b_sq / (2.0 * pgas);
 
@@ -919,7 +939,7 @@ __device__ __forceinline__ void sample_finish_simulation(const BlShadeArgs &P, c
   // with those 0 / 1 entries are dropped (exact).
   double ucon[4], bcon[4];
   if (sks) {
-    const double sth = blm_sqrt(1.0 - cth * cth);
+    const double sth = bl_sqrt_g(1.0 - cth * cth);
     double sph, cph;
     bl_sincos(ph_unwrapped, &sph, &cph);
     const double j11 = sth * cph;
@@ -986,7 +1006,7 @@ __device__ __forceinline__ void sample_finish_simulation(const BlShadeArgs &P, c
   out->n_e_cgs = n_e_cgs;
   out->nu_c_cgs = kE * bb_cgs / (2.0 * kPi * kMe * kC);
   out->theta_e = theta_e;
-  out->sin_theta_b = blm_sqrt(sin2_theta_b);
+  out->sin_theta_b = bl_sqrt_g(sin2_theta_b);
   out->kb_tt_e_cgs = kb_tt_e_cgs;
 }
 
@@ -1205,9 +1225,9 @@ __global__ void __launch_bounds__(256, 2) bl_shade_kernel(const BlShadeArgs P) {
         const double nu_s_cgs = 2.0 / 9.0 * sh.nu_c_cgs * sh.theta_e * sh.theta_e * sh.sin_theta_b;
         if (thermal_frac != 0.0) {
           const double xx = nu_cgs / nu_s_cgs;
-          const double xx_1_2 = blm_sqrt(xx);
+          const double xx_1_2 = bl_sqrt_g(xx);
           const double xx_1_3 = bl_cbrt(xx);
-          const double xx_1_6 = blm_sqrt(xx_1_3);
+          const double xx_1_6 = bl_sqrt_g(xx_1_3);
           const double coefficient = thermal_frac * sh.n_e_cgs * kE * kE * sh.nu_c_cgs / (kC * nu_2_cgs) * bl_exp(-xx_1_3);
           const double var_a = kSqrt2 * kPi / 27.0 * sh.sin_theta_b;
           const double var_b = kPow2_11_12;
