@@ -155,13 +155,15 @@ def main():
 
     fence()
     t0 = time.perf_counter()
-    ms = dict(geodesic=0.0, shade=0.0, transfer=0.0)
+    ms = dict(geodesic=0.0, locate=0.0, shade=0.0, transfer=0.0, wall=0.0)
     launches_shade = 0
     stats = None
     for _ in range(args.steps):
         stats = step()
         ms["geodesic"] += stats.ms_geodesic
+        ms["locate"] += stats.ms_locate
         ms["shade"] += stats.ms_shade
+        ms["wall"] += stats.ms_wall
         ms["transfer"] += stats.ms_transfer
         launches_shade += stats.launches_shade
         parts = gather_image()

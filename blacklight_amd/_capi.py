@@ -62,6 +62,7 @@ class Stats(C.Structure):
         ("ms_total", C.c_float),
         ("launches_geodesic", C.c_int32), ("launches_shade", C.c_int32),
         ("launches_transfer", C.c_int32),
+        ("ms_locate", C.c_float), ("ms_wall", C.c_float), ("launches_locate", C.c_int32),
     ]
 
 
@@ -90,6 +91,7 @@ def lib():
     L.bl_camera_frame_get.argtypes = [C.c_void_p, C.POINTER(CameraFrame)]
     L.bl_frequencies.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int]
     L.bl_set_scratch_limit.argtypes = [C.c_void_p, C.c_uint64]
+    L.bl_set_overlap.argtypes = [C.c_void_p, C.c_int]
     L.bl_render.argtypes = [C.c_void_p, C.POINTER(RenderDesc)]
     L.bl_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
     L.bl_last_error.argtypes = [C.c_void_p]

@@ -77,6 +77,10 @@ class Context:
     def set_scratch_limit(self, nbytes):
         self._check(self._lib.bl_set_scratch_limit(self._ctx, int(nbytes)))
 
+    def set_overlap(self, on):
+        """Overlap the geodesic kernel of the next chunk with the shading of the current one."""
+        self._check(self._lib.bl_set_overlap(self._ctx, 1 if on else 0))
+
     # ------------------------------------------------------------------ grid
     def set_grid(self, grid):
         """grid: blacklight_amd.mock.Grid (or anything with .desc())."""

@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -22,8 +23,8 @@
 
 extern "C" hipError_t bl_launch_geodesic(const BlTraceArgs *args, int integrator, int grid, hipStream_t stream);
 extern "C" int bl_geodesic_occupancy(int integrator);
-extern "C" hipError_t bl_launch_shade(const BlShadeArgs *args, int model, int locate_grid, int shade_grid, int lds_bytes,
-                                      hipStream_t stream);
+extern "C" hipError_t bl_launch_locate(const BlShadeArgs *args, int grid, int lds_bytes, hipStream_t stream);
+extern "C" hipError_t bl_launch_shade(const BlShadeArgs *args, int model, int grid, hipStream_t stream);
 extern "C" hipError_t bl_launch_transfer(const BlTransferArgs *args, hipStream_t stream);
 
 namespace {
@@ -73,9 +74,13 @@ struct bl_ctx {
   std::string last_error, warnings;
   int device = 0;
   int num_cus = 256;
-  hipStream_t stream = nullptr;
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipStream_t stream = nullptr;       // shading stream: locate, coefficient and transfer kernels, uploads
+  hipStream_t stream_geo = nullptr;   // geodesic kernel of the next chunk, concurrent with the above
+  std::vector<hipEvent_t> events;     // kEventsPerChunk per chunk of the last render + one set-up event
+  unsigned long long *host_counters = nullptr;   // pinned, (BL_CNT_COUNT + 4) per chunk
+  size_t host_counters_chunks = 0;
   uint64_t scratch_limit = 80ull << 30;
+  int overlap_chunks = 0;             // bl_set_overlap(): geodesic kernel of chunk c + 1 beside the shading of chunk c
 
   // image rows (radiation_integrator.cpp:436-520)
   int image_num_quantities = 0;
@@ -91,15 +96,23 @@ struct bl_ctx {
   BlGridDevice grid_dev{};
   int lds_table_bytes = 0;
 
-  // per-chunk scratch
-  DeviceBuffer<BlSampleRecord> d_records;
-  DeviceBuffer<BlLocated> d_located;
-  DeviceBuffer<double2> d_transfer;
-  DeviceBuffer<double> d_ray_kt, d_ray_factor, d_freq;
-  DeviceBuffer<int> d_ray_sample_num;
-  DeviceBuffer<unsigned char> d_ray_flags;
-  DeviceBuffer<long long> d_ray_out_index;
-  DeviceBuffer<unsigned long long> d_counters;   // BL_CNT_COUNT + 4 stats
+  // per-chunk scratch, two sets: the geodesic kernel fills one while the shading kernels drain the other
+  struct ChunkSlot {
+    DeviceBuffer<BlSampleRecord> d_records;
+    DeviceBuffer<BlLocated> d_located;
+    DeviceBuffer<double2> d_transfer;
+    DeviceBuffer<double> d_ray_kt, d_ray_factor;
+    DeviceBuffer<int> d_ray_sample_num;
+    DeviceBuffer<unsigned char> d_ray_flags;
+    DeviceBuffer<long long> d_ray_out_index;
+    DeviceBuffer<unsigned long long> d_counters;   // BL_CNT_COUNT + 4 stats
+    void Free() {
+      d_records.Free(); d_located.Free(); d_transfer.Free(); d_ray_kt.Free(); d_ray_factor.Free();
+      d_ray_sample_num.Free(); d_ray_flags.Free(); d_ray_out_index.Free(); d_counters.Free();
+    }
+  };
+  ChunkSlot slot[2];
+  DeviceBuffer<double> d_freq;
   DeviceBuffer<int> d_pixel_map, d_block_locs;
   DeviceBuffer<BlShadeCold> d_shade_cold;
   // host-output staging
@@ -363,10 +376,28 @@ void BuildBuckets(const double *xf, int n, int n_bucket, std::vector<int> *table
   }
 }
 
-void EnsureEvents(bl_ctx *ctx) {
+constexpr int kEventsPerChunk = 6;   // geodesic start / end, locate start, coefficient start, transfer start, end
+
+void EnsureStreams(bl_ctx *ctx) {
   if (ctx->stream == nullptr) Check(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking), "hipStreamCreate");
-  for (auto &e : ctx->ev)
-    if (e == nullptr) Check(hipEventCreate(&e), "hipEventCreate");
+  if (ctx->stream_geo == nullptr) Check(hipStreamCreateWithFlags(&ctx->stream_geo, hipStreamNonBlocking), "hipStreamCreate");
+}
+
+void EnsureChunkResources(bl_ctx *ctx, int n_chunks) {
+  const size_t need = static_cast<size_t>(n_chunks) * kEventsPerChunk + 1;
+  while (ctx->events.size() < need) {
+    hipEvent_t e = nullptr;
+    Check(hipEventCreate(&e), "hipEventCreate");
+    ctx->events.push_back(e);
+  }
+  if (ctx->host_counters_chunks < static_cast<size_t>(n_chunks)) {
+    if (ctx->host_counters != nullptr) (void)hipHostFree(ctx->host_counters);
+    ctx->host_counters = nullptr;
+    Check(hipHostMalloc(reinterpret_cast<void **>(&ctx->host_counters),
+                        static_cast<size_t>(n_chunks) * (BL_CNT_COUNT + 4) * sizeof(unsigned long long), hipHostMallocDefault),
+          "hipHostMalloc");
+    ctx->host_counters_chunks = n_chunks;
+  }
 }
 
 int Fail(bl_ctx *ctx, const Failure &failure) {
@@ -408,7 +439,7 @@ int bl_init(const bl_params *p, int device, bl_ctx **out) {
     hipDeviceProp_t prop;
     Check(hipGetDeviceProperties(&prop, device), "hipGetDeviceProperties");
     ctx->num_cus = prop.multiProcessorCount;
-    EnsureEvents(ctx);
+    EnsureStreams(ctx);
   } catch (const Failure &failure) {
     int code = Fail(nullptr, failure);
     delete ctx;
@@ -508,6 +539,12 @@ int bl_frequencies(const bl_ctx *ctx, double *out, int n) {
   return BL_OK;
 }
 
+int bl_set_overlap(bl_ctx *ctx, int on) {
+  if (ctx == nullptr) return BL_E_ARG;
+  ctx->overlap_chunks = on ? 1 : 0;
+  return BL_OK;
+}
+
 int bl_set_scratch_limit(bl_ctx *ctx, uint64_t bytes) {
   if (ctx == nullptr || bytes < (1ull << 20)) return BL_E_ARG;
   ctx->scratch_limit = bytes;
@@ -526,8 +563,9 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
     if (d->level < 0 || d->level > p.adaptive_max_level) throw Failure{BL_E_ARG, "Adaptive level out of range."};
     if (d->level > 0 && (d->block_locs == nullptr || d->n_blocks <= 0)) throw Failure{BL_E_ARG, "Refined level needs block_locs."};
     Check(hipSetDevice(ctx->device), "hipSetDevice");
-    EnsureEvents(ctx);
-    hipStream_t stream = ctx->stream;
+    EnsureStreams(ctx);
+    hipStream_t stream = ctx->stream, stream_geo = ctx->stream_geo;
+    if (!ctx->overlap_chunks) stream_geo = stream;   // default: one stream, chunks back to back
     const int n_nu = p.image_num_frequencies;
     const int n_q = ctx->image_num_quantities;
     const int max_steps = p.ray_max_steps;
@@ -542,24 +580,32 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
     // (simulation mode) + 16 B * n_nu transfer)
     const uint64_t per_ray = static_cast<uint64_t>(max_steps)
         * (sizeof(BlSampleRecord) + (simulation ? sizeof(BlLocated) : 0) + sizeof(double2) * n_nu) + 64;
+    // One chunk if the whole call fits the budget. With bl_set_overlap(): two scratch sets of half the budget
+    // each, so that the geodesic kernel of chunk c + 1 runs while chunk c is being shaded.
     long long chunk = static_cast<long long>(ctx->scratch_limit / per_ray);
+    if (chunk < n_rays && ctx->overlap_chunks) chunk = static_cast<long long>(ctx->scratch_limit / (2 * per_ray));
     chunk = std::max<long long>(chunk, 64);
     chunk = std::min<long long>(chunk, n_rays);
     if (chunk < n_rays) chunk = (chunk / 64) * 64;   // keep 8x8 tiles whole
     const int n_chunks = static_cast<int>((n_rays + chunk - 1) / chunk);
+    const int n_slots = (n_chunks > 1 && ctx->overlap_chunks) ? 2 : 1;
 
     const int geo_blocks_per_cu = bl_geodesic_occupancy(p.ray_integrator);
     const int geo_grid = ctx->num_cus * geo_blocks_per_cu;   // persistent waves of the geodesic kernel
     const size_t record_capacity = static_cast<size_t>(chunk) * max_steps + static_cast<size_t>(geo_grid) * BL_RECORD_BLOCK;
-    ctx->d_records.Ensure(record_capacity);
-    if (simulation) ctx->d_located.Ensure(record_capacity);
-    ctx->d_transfer.Ensure(static_cast<size_t>(chunk) * max_steps * n_nu);
-    ctx->d_ray_kt.Ensure(chunk);
-    ctx->d_ray_factor.Ensure(chunk);
-    ctx->d_ray_sample_num.Ensure(chunk);
-    ctx->d_ray_flags.Ensure(chunk);
-    ctx->d_ray_out_index.Ensure(chunk);
-    ctx->d_counters.Ensure(BL_CNT_COUNT + 4);
+    for (int k = 0; k < n_slots; k++) {
+      bl_ctx::ChunkSlot &sl = ctx->slot[k];
+      sl.d_records.Ensure(record_capacity);
+      if (simulation) sl.d_located.Ensure(record_capacity);
+      sl.d_transfer.Ensure(static_cast<size_t>(chunk) * max_steps * n_nu);
+      sl.d_ray_kt.Ensure(chunk);
+      sl.d_ray_factor.Ensure(chunk);
+      sl.d_ray_sample_num.Ensure(chunk);
+      sl.d_ray_flags.Ensure(chunk);
+      sl.d_ray_out_index.Ensure(chunk);
+      sl.d_counters.Ensure(BL_CNT_COUNT + 4);
+    }
+    EnsureChunkResources(ctx, n_chunks);
     ctx->d_freq.Ensure(n_nu);
     Check(hipMemcpyAsync(ctx->d_freq.ptr, ctx->frequencies.data(), n_nu * sizeof(double), hipMemcpyHostToDevice, stream), "freq upload");
 
@@ -623,14 +669,7 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
         ? p.camera_resolution : 0;
     ta.pixel_map = d_pixel_map;
     ta.block_locs = d_block_locs;
-    ta.records = ctx->d_records.ptr;
     ta.record_capacity = static_cast<long long>(record_capacity);
-    ta.counters = ctx->d_counters.ptr;
-    ta.ray_kt = ctx->d_ray_kt.ptr;
-    ta.ray_factor = ctx->d_ray_factor.ptr;
-    ta.ray_sample_num = ctx->d_ray_sample_num.ptr;
-    ta.ray_flags = ctx->d_ray_flags.ptr;
-    ta.ray_out_index = ctx->d_ray_out_index.ptr;
     ta.camera_pos = cam_pos;
     ta.camera_dir = cam_dir;
 
@@ -693,23 +732,12 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
     ctx->d_shade_cold.Ensure(1);
     Check(hipMemcpyAsync(ctx->d_shade_cold.ptr, &cold, sizeof(BlShadeCold), hipMemcpyHostToDevice, stream), "shade parameter upload");
     sa.cold = ctx->d_shade_cold.ptr;
-    sa.records = ctx->d_records.ptr;
-    sa.located = simulation ? ctx->d_located.ptr : nullptr;
-    sa.counters_in = ctx->d_counters.ptr;
-    sa.counters = ctx->d_counters.ptr;
-    sa.ray_kt = ctx->d_ray_kt.ptr;
-    sa.ray_factor = ctx->d_ray_factor.ptr;
     sa.frequencies = ctx->d_freq.ptr;
     sa.n_nu = n_nu;
     sa.ray_max_steps = max_steps;
     sa.x_unit = kGGMsun * ctx->frame.mass_msun / (kC * kC);   // unpolarized.cpp:42
-    sa.transfer = ctx->d_transfer.ptr;
 
     BlTransferArgs xa{};
-    xa.transfer = ctx->d_transfer.ptr;
-    xa.ray_sample_num = ctx->d_ray_sample_num.ptr;
-    xa.ray_flags = ctx->d_ray_flags.ptr;
-    xa.ray_out_index = ctx->d_ray_out_index.ptr;
     xa.frequencies = ctx->d_freq.ptr;
     xa.n_nu = n_nu;
     xa.ray_max_steps = max_steps;
@@ -719,48 +747,104 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
     xa.image = image;
     xa.out_sample_num = out_num;
     xa.out_flags = out_flags;
-    xa.stats = ctx->d_counters.ptr + BL_CNT_COUNT;
 
-    const int locate_grid = ctx->num_cus * 4 * 4;  // 256-thread workgroups, 4 waves per SIMD, x4 for tail balance
+    // Locate kernel: 256-thread workgroups. Alone (single chunk) it runs 4 waves per SIMD; when chunks are
+    // pipelined it shares each SIMD with one 328-register wave of the next chunk's geodesic kernel, which
+    // leaves room for exactly one 128-register locate wave - one workgroup per CU, so that whichever of the
+    // two kernels is dispatched first cannot fill the register file and lock the other out.
+    const int locate_grid_alone = ctx->num_cus * 4 * 4;
+    const int locate_grid_shared = ctx->num_cus;
     const int shade_grid = ctx->num_cus * 2 * 4;  // 256-thread workgroups, 2 waves per SIMD, x4 for tail balance
 
     bl_stats st{};
     st.n_rays = n_rays;
     st.n_chunks = n_chunks;
-    float ms_geo = 0.0f, ms_shade = 0.0f, ms_transfer = 0.0f;
-    std::vector<unsigned long long> host_counters(BL_CNT_COUNT + 4);
-    unsigned long long total_samples = 0, total_flagged = 0, total_records = 0, total_gathers = 0, max_num = 0;
 
+    // Chunk c uses scratch set c % 2. Two streams:
+    //   stream_geo: [wait until set c % 2 was drained by chunk c - 2]  geodesic(c)
+    //   stream:     [wait for geodesic(c)]  locate(c)  coefficients(c)  transfer(c)  counters -> host
+    // so geodesic(c + 1) overlaps the shading of chunk c. The geodesic kernel holds one 328-register
+    // wave per SIMD; a 128-register locate wave fits beside it and issues into the slots its dependent
+    // fp64 chains leave idle, and the coefficient / transfer waves take over SIMDs as geodesic waves retire.
+    hipEvent_t *ev = ctx->events.data();
+    hipEvent_t ev_setup = ev[static_cast<size_t>(n_chunks) * kEventsPerChunk];
+    Check(hipEventRecord(ev_setup, stream), "event");            // uploads above were queued on `stream`
+    Check(hipStreamWaitEvent(stream_geo, ev_setup, 0), "stream wait");
+    const size_t n_counters = BL_CNT_COUNT + 4;
     for (int c = 0; c < n_chunks; c++) {
       const long long begin = static_cast<long long>(c) * chunk;
       const int rays = static_cast<int>(std::min<long long>(chunk, n_rays - begin));
-      Check(hipMemsetAsync(ctx->d_counters.ptr, 0, (BL_CNT_COUNT + 4) * sizeof(unsigned long long), stream), "counter reset");
+      bl_ctx::ChunkSlot &sl = ctx->slot[c % n_slots];
+      hipEvent_t *e = ev + static_cast<size_t>(c) * kEventsPerChunk;
       ta.chunk_begin = begin;
       ta.chunk_rays = rays;
+      ta.records = sl.d_records.ptr;
+      ta.counters = sl.d_counters.ptr;
+      ta.ray_kt = sl.d_ray_kt.ptr;
+      ta.ray_factor = sl.d_ray_factor.ptr;
+      ta.ray_sample_num = sl.d_ray_sample_num.ptr;
+      ta.ray_flags = sl.d_ray_flags.ptr;
+      ta.ray_out_index = sl.d_ray_out_index.ptr;
+      sa.records = sl.d_records.ptr;
+      sa.located = simulation ? sl.d_located.ptr : nullptr;
+      sa.counters_in = sl.d_counters.ptr;
+      sa.counters = sl.d_counters.ptr;
+      sa.ray_kt = sl.d_ray_kt.ptr;
+      sa.ray_factor = sl.d_ray_factor.ptr;
+      sa.transfer = sl.d_transfer.ptr;
       xa.chunk_rays = rays;
-      Check(hipEventRecord(ctx->ev[0], stream), "event");
-      Check(bl_launch_geodesic(&ta, p.ray_integrator, std::min(geo_grid, (rays + 63) / 64), stream), "geodesic kernel launch");
-      Check(hipEventRecord(ctx->ev[1], stream), "event");
-      Check(bl_launch_shade(&sa, p.model_type, locate_grid, shade_grid, ctx->lds_table_bytes, stream), "shade kernel launch");
-      Check(hipEventRecord(ctx->ev[2], stream), "event");
+      xa.transfer = sl.d_transfer.ptr;
+      xa.ray_sample_num = sl.d_ray_sample_num.ptr;
+      xa.ray_flags = sl.d_ray_flags.ptr;
+      xa.ray_out_index = sl.d_ray_out_index.ptr;
+      xa.stats = sl.d_counters.ptr + BL_CNT_COUNT;
+
+      // ---- geodesic stream
+      if (c >= n_slots) Check(hipStreamWaitEvent(stream_geo, (e - n_slots * kEventsPerChunk)[5], 0), "stream wait");
+      Check(hipMemsetAsync(sl.d_counters.ptr, 0, n_counters * sizeof(unsigned long long), stream_geo), "counter reset");
+      Check(hipEventRecord(e[0], stream_geo), "event");
+      Check(bl_launch_geodesic(&ta, p.ray_integrator, std::min(geo_grid, (rays + 63) / 64), stream_geo), "geodesic kernel launch");
+      Check(hipEventRecord(e[1], stream_geo), "event");
+      // ---- shading stream
+      Check(hipStreamWaitEvent(stream, e[1], 0), "stream wait");
+      Check(hipEventRecord(e[2], stream), "event");
+      if (simulation) {
+        const bool shares_gpu = stream_geo != stream && c + 1 < n_chunks;   // geodesic(c + 1) is running beside it
+        Check(bl_launch_locate(&sa, shares_gpu ? locate_grid_shared : locate_grid_alone, ctx->lds_table_bytes, stream), "locate kernel launch");
+      }
+      Check(hipEventRecord(e[3], stream), "event");
+      Check(bl_launch_shade(&sa, p.model_type, shade_grid, stream), "coefficient kernel launch");
+      Check(hipEventRecord(e[4], stream), "event");
       Check(bl_launch_transfer(&xa, stream), "transfer kernel launch");
-      Check(hipEventRecord(ctx->ev[3], stream), "event");
-      Check(hipMemcpyAsync(host_counters.data(), ctx->d_counters.ptr, host_counters.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream), "counter download");
-      Check(hipStreamSynchronize(stream), "kernel execution");
+      Check(hipEventRecord(e[5], stream), "event");
+      Check(hipMemcpyAsync(ctx->host_counters + static_cast<size_t>(c) * n_counters, sl.d_counters.ptr,
+                           n_counters * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream), "counter download");
+    }
+    Check(hipStreamSynchronize(stream_geo), "kernel execution");
+    Check(hipStreamSynchronize(stream), "kernel execution");
+
+    float ms_geo = 0.0f, ms_locate = 0.0f, ms_shade = 0.0f, ms_transfer = 0.0f, ms_wall = 0.0f;
+    unsigned long long total_samples = 0, total_flagged = 0, total_records = 0, total_gathers = 0, max_num = 0;
+    for (int c = 0; c < n_chunks; c++) {
+      hipEvent_t *e = ev + static_cast<size_t>(c) * kEventsPerChunk;
+      const unsigned long long *hc = ctx->host_counters + static_cast<size_t>(c) * n_counters;
       float ms = 0.0f;
-      Check(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]), "event time"); ms_geo += ms;
-      Check(hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]), "event time"); ms_shade += ms;
-      Check(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]), "event time"); ms_transfer += ms;
-      if (host_counters[BL_CNT_OVERFLOW] != 0) throw Failure{BL_E_DEVICE, "Sample record buffer overflow."};
-      total_records += host_counters[BL_CNT_RECORDS];
-      total_gathers += host_counters[BL_CNT_GATHERS];
-      total_samples += host_counters[BL_CNT_COUNT + 0];
-      total_flagged += host_counters[BL_CNT_COUNT + 1];
-      max_num = std::max(max_num, host_counters[BL_CNT_COUNT + 2]);
+      Check(hipEventElapsedTime(&ms, e[0], e[1]), "event time"); ms_geo += ms;
+      Check(hipEventElapsedTime(&ms, e[2], e[3]), "event time"); ms_locate += ms;
+      Check(hipEventElapsedTime(&ms, e[3], e[4]), "event time"); ms_shade += ms;
+      Check(hipEventElapsedTime(&ms, e[4], e[5]), "event time"); ms_transfer += ms;
+      if (hc[BL_CNT_OVERFLOW] != 0) throw Failure{BL_E_DEVICE, "Sample record buffer overflow."};
+      total_records += hc[BL_CNT_RECORDS];
+      total_gathers += hc[BL_CNT_GATHERS];
+      total_samples += hc[BL_CNT_COUNT + 0];
+      total_flagged += hc[BL_CNT_COUNT + 1];
+      max_num = std::max<unsigned long long>(max_num, hc[BL_CNT_COUNT + 2]);
       st.launches_geodesic++;
+      if (simulation) st.launches_locate++;
       st.launches_shade++;
       st.launches_transfer++;
     }
+    Check(hipEventElapsedTime(&ms_wall, ev[0], (ev + static_cast<size_t>(n_chunks - 1) * kEventsPerChunk)[5]), "event time");
 
     if (!d->outputs_on_device) {
       Check(hipMemcpy(d->image, image, static_cast<size_t>(n_q) * n_rays * sizeof(double), hipMemcpyDeviceToHost), "image download");
@@ -778,9 +862,11 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
     const double bytes_per_gather = (simulation && !p.simulation_interp) ? 32.0 : 256.0;
     st.algorithmic_bytes = bytes_per_gather * static_cast<double>(total_gathers) + 13.0 * static_cast<double>(n_rays);
     st.ms_geodesic = ms_geo;
+    st.ms_locate = ms_locate;
     st.ms_shade = ms_shade;
     st.ms_transfer = ms_transfer;
-    st.ms_total = ms_geo + ms_shade + ms_transfer;
+    st.ms_total = ms_geo + ms_locate + ms_shade + ms_transfer;
+    st.ms_wall = ms_wall;
     ctx->stats = st;
     // Warning text of the reference (geodesics.cpp:389-394)
     if (total_flagged > 0)
@@ -808,14 +894,15 @@ void bl_free(bl_ctx *ctx) {
     return;
   }
   (void)hipSetDevice(ctx->device);
-  ctx->d_cells.Free(); ctx->d_coords.Free(); ctx->d_buckets.Free(); ctx->d_records.Free(); ctx->d_located.Free(); ctx->d_transfer.Free();
-  ctx->d_ray_kt.Free(); ctx->d_ray_factor.Free(); ctx->d_freq.Free(); ctx->d_ray_sample_num.Free();
-  ctx->d_ray_flags.Free(); ctx->d_ray_out_index.Free(); ctx->d_counters.Free(); ctx->d_pixel_map.Free();
+  ctx->d_cells.Free(); ctx->d_coords.Free(); ctx->d_buckets.Free(); ctx->slot[0].Free(); ctx->slot[1].Free();
+  ctx->d_freq.Free(); ctx->d_pixel_map.Free();
   ctx->d_block_locs.Free(); ctx->d_shade_cold.Free(); ctx->d_image.Free(); ctx->d_camera_pos.Free(); ctx->d_camera_dir.Free();
   ctx->d_out_sample_num.Free(); ctx->d_out_flags.Free();
-  for (auto &e : ctx->ev)
+  for (auto &e : ctx->events)
     if (e != nullptr) (void)hipEventDestroy(e);
+  if (ctx->host_counters != nullptr) (void)hipHostFree(ctx->host_counters);
   if (ctx->stream != nullptr) (void)hipStreamDestroy(ctx->stream);
+  if (ctx->stream_geo != nullptr) (void)hipStreamDestroy(ctx->stream_geo);
   delete ctx;
 }
 

@@ -1351,18 +1351,18 @@ extern "C" int bl_geodesic_occupancy(int integrator) {
   return blocks;
 }
 
-// Shading = locate kernel (simulation mode only; lds_bytes = size of the coordinate tables it stages in
-// LDS) followed by the coefficient kernel, back to back on the same stream.
-extern "C" hipError_t bl_launch_shade(const BlShadeArgs *args, int model, int locate_grid, int shade_grid, int lds_bytes,
-                                      hipStream_t stream) {
-  if (model == BL_MODEL_SIMULATION) {
-    hipLaunchKernelGGL(bl_locate_kernel, dim3(locate_grid), dim3(256), lds_bytes, stream, *args);
-    hipError_t err = hipGetLastError();
-    if (err != hipSuccess) return err;
-    hipLaunchKernelGGL(bl_shade_kernel<BL_MODEL_SIMULATION>, dim3(shade_grid), dim3(256), 0, stream, *args);
-  } else {
-    hipLaunchKernelGGL(bl_shade_kernel<BL_MODEL_FORMULA>, dim3(shade_grid), dim3(256), 0, stream, *args);
-  }
+// Locate kernel (simulation mode only); lds_bytes = size of the coordinate tables it stages in LDS
+extern "C" hipError_t bl_launch_locate(const BlShadeArgs *args, int grid, int lds_bytes, hipStream_t stream) {
+  hipLaunchKernelGGL(bl_locate_kernel, dim3(grid), dim3(256), lds_bytes, stream, *args);
+  return hipGetLastError();
+}
+
+// Coefficient kernel
+extern "C" hipError_t bl_launch_shade(const BlShadeArgs *args, int model, int grid, hipStream_t stream) {
+  if (model == BL_MODEL_SIMULATION)
+    hipLaunchKernelGGL(bl_shade_kernel<BL_MODEL_SIMULATION>, dim3(grid), dim3(256), 0, stream, *args);
+  else
+    hipLaunchKernelGGL(bl_shade_kernel<BL_MODEL_FORMULA>, dim3(grid), dim3(256), 0, stream, *args);
   return hipGetLastError();
 }
 

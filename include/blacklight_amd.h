@@ -204,8 +204,13 @@ typedef struct bl_stats {
   int32_t max_sample_num;     /* geodesic_num_steps                                                */
   int32_t n_chunks;
   double algorithmic_bytes;   /* 256 (or 32) * n_gathers + 13 * n_rays                */
-  float ms_geodesic, ms_shade, ms_transfer, ms_total; /* HIP-event kernel time, last bl_render     */
+  float ms_geodesic, ms_shade, ms_transfer, ms_total; /* HIP-event kernel time, last bl_render: geodesic,
+                                 coefficient (bl_shade_kernel) and transfer kernels; ms_total = sum of all four    */
   int32_t launches_geodesic, launches_shade, launches_transfer;
+  float ms_locate;            /* locate kernel (simulation mode)                                      */
+  float ms_wall;              /* first kernel start to last kernel end; less than ms_total when the geodesic
+                                 kernel of one chunk overlaps the shading of the previous one          */
+  int32_t launches_locate;
 } bl_stats;
 
 typedef struct bl_ctx bl_ctx;
@@ -224,6 +229,10 @@ BL_API int bl_camera_frame_get(const bl_ctx *ctx, bl_camera_frame *out);
 BL_API int bl_frequencies(const bl_ctx *ctx, double *out, int n);
 /* Cap on scratch HBM (bytes) used for per-sample records; default 80 GiB. */
 BL_API int bl_set_scratch_limit(bl_ctx *ctx, uint64_t bytes);
+/* on != 0: when a render needs several chunks, run the geodesic kernel of chunk c + 1 on a second stream
+ * beside the shading kernels of chunk c (two scratch sets of half the budget). Off by default: measured
+ * on MI355X it changes the frame time by less than 1 %, and per-kernel times are cleaner off. */
+BL_API int bl_set_overlap(bl_ctx *ctx, int on);
 BL_API int bl_render(bl_ctx *ctx, const bl_render_desc *d);
 BL_API int bl_get_stats(const bl_ctx *ctx, bl_stats *out);
 /* Text of the last failure on this context ("Error: ...\n"), or "" */

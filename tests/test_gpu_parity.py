@@ -72,9 +72,11 @@ def test_tier_a_tolerance(case, built_library):
         assert np.nanmax(np.abs(got - want)) / scale < 1.0e-6
 
 
+@pytest.mark.parametrize("overlap", [False, True])
 @pytest.mark.parametrize("case", ["sim_dp_interp", "formula_dp"])
-def test_pixel_map_and_chunking(case, built_library):
-    """A shuffled pixel subset rendered in several small chunks gives the same bits per pixel."""
+def test_pixel_map_and_chunking(case, overlap, built_library):
+    """A shuffled pixel subset rendered in several small chunks gives the same bits per pixel, with the
+    chunks back to back on one stream and with the geodesic kernel of the next chunk overlapped."""
     import blacklight_amd as bl
     fx, params, mock_args = gu.load_case(case)
     p = bl.Params.from_dict(params)
@@ -85,8 +87,9 @@ def test_pixel_map_and_chunking(case, built_library):
         rng = np.random.default_rng(7)
         n_pix = full["sample_num"].size
         subset = rng.permutation(n_pix)[: n_pix // 3].astype(np.int32)
-        per_ray = int(p.get("ray_max_steps")) * 80 + 64
+        per_ray = int(p.get("ray_max_steps")) * 160 + 64
         ctx.set_scratch_limit(max(per_ray * 100, 1 << 20))   # forces several chunks
+        ctx.set_overlap(overlap)
         part = ctx.render(pixel_map=subset)
         assert part["stats"].n_chunks > 1
     assert np.array_equal(part["sample_num"], full["sample_num"][subset])
