@@ -38,13 +38,13 @@ static_assert(sizeof(BlSampleRecord) == 64, "record must be 64 bytes");
 // One located sample, written by the locate kernel at the index of its sample record and read once
 // by the coefficient kernel (simulation mode): where the sample sits on the grid - the first of the
 // (up to) 8 cells it reads and the trilinear fractions - plus the unwrapped spherical Kerr-Schild
-// azimuth (needed again by the Jacobian) and the status.
+// azimuth (needed again by the Jacobian), the status and r^2.
 struct alignas(16) BlLocated {
   double f_i, f_j, f_k;   // trilinear fractions (kSampleInterp)
   double ph;
   uint32_t cell;          // linear index of cell (k_m, j_m, i_m) resp. of the nearest cell
   uint32_t status;        // SampleStatus
-  uint32_t pad[2];
+  double r2;              // squared Kerr-Schild radius of the sample (the coefficient kernel needs it again)
 };
 static_assert(sizeof(BlLocated) == 48, "located sample must be 48 bytes");
 

@@ -128,20 +128,25 @@ struct BlKerrSchildRecip {
   BlRecip r, ra;  // 1 / r, 1 / (r^2 + a^2)
 };
 
-// geodesic_geometry.cpp:19-26
-BL_HD double bl_radial_coordinate(const BlSpacetime &st, double x, double y, double z) {
+// geodesic_geometry.cpp:19-26; bl_radial_coordinate2 also returns r^2
+BL_HD double bl_radial_coordinate2(const BlSpacetime &st, double x, double y, double z, double *r2_out) {
   double a2 = st.bh_a * st.bh_a;
   double rr2 = x * x + y * y + z * z;
   double r2 = 0.5 * (rr2 - a2 + bl_hypot_g(rr2 - a2, 2.0 * st.bh_a * z));
+  *r2_out = r2;
   return bl_sqrt_g(r2);
 }
+BL_HD double bl_radial_coordinate(const BlSpacetime &st, double x, double y, double z) {
+  double r2;
+  return bl_radial_coordinate2(st, x, y, z, &r2);
+}
 
-BL_HD void bl_kerr_schild_r(const BlSpacetime &st, double x, double y, double z, BlKerrSchild *ks,
-                            BlKerrSchildRecip *rc) {
+// The Kerr-Schild scalars given r^2 = the value bl_radial_coordinate2() returned for the same point
+BL_HD void bl_kerr_schild_r2(const BlSpacetime &st, double x, double y, double z, double r2, BlKerrSchild *ks,
+                             BlKerrSchildRecip *rc) {
   double bh_a = st.bh_a;
   double a2 = bh_a * bh_a;
   double rr2 = x * x + y * y + z * z;
-  double r2 = 0.5 * (rr2 - a2 + bl_hypot_g(rr2 - a2, 2.0 * bh_a * z));
   double r = bl_sqrt_g(r2);
   double f = bl_div_g(2.0 * st.bh_m * r2 * r, r2 * r2 + a2 * z * z);
   rc->r = bl_recip(r);
@@ -155,6 +160,13 @@ BL_HD void bl_kerr_schild_r(const BlSpacetime &st, double x, double y, double z,
   ks->l[1] = bl_div_r(r * y - bh_a * x, rc->ra);
   ks->l[2] = bl_div_r(z, rc->r);
   for (int i = 0; i < 3; i++) ks->fl[i] = f * ks->l[i];
+}
+BL_HD void bl_kerr_schild_r(const BlSpacetime &st, double x, double y, double z, BlKerrSchild *ks,
+                            BlKerrSchildRecip *rc) {
+  double a2 = st.bh_a * st.bh_a;
+  double rr2 = x * x + y * y + z * z;
+  double r2 = 0.5 * (rr2 - a2 + bl_hypot_g(rr2 - a2, 2.0 * st.bh_a * z));
+  bl_kerr_schild_r2(st, x, y, z, r2, ks, rc);
 }
 BL_HD void bl_kerr_schild(const BlSpacetime &st, double x, double y, double z, BlKerrSchild *ks) {
   BlKerrSchildRecip rc;

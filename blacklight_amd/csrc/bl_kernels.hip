@@ -807,8 +807,11 @@ __device__ __forceinline__ void sample_finish_simulation(const BlShadeArgs &P, c
   const double bb1 = pr[5], bb2 = pr[6], bb3 = pr[7];
   const double rho_cgs = rho * pl.d_unit;
   const double pgas_cgs = pgas * pl.e_unit;
-  const double n_cgs = rho_cgs / (pl.plasma_mu * kMp);
-  const double n_e_cgs = n_cgs / (1.0 + 1.0 / pl.plasma_ne_ni);
+  // The quotients below have operands that are products of single-precision grid values (zero, or
+  // 1e-45 .. 3e38 in magnitude) and unit constants: far inside the range where bl_div_g() is the IEEE
+  // quotient (bl_geometry.h). Quotients that involve results of exp() keep the plain division.
+  const double n_cgs = bl_div_g(rho_cgs, pl.plasma_mu * kMp);
+  const double n_e_cgs = bl_div_g(n_cgs, 1.0 + 1.0 / pl.plasma_ne_ni);
 
   // Velocity and field in simulation coordinates (:292-330). In SKS the metric is sparse
   // (radiation_geometry.cpp:462-489, :543-571); sums that the reference runs over all 16 entries
@@ -894,21 +897,21 @@ __device__ __forceinline__ void sample_finish_simulation(const BlShadeArgs &P, c
   }
   const double bb_cgs = bl_sqrt_g(b_sq) * pl.b_unit;
   const double sigma_cut = b_sq / rho;
-  const double beta_inv = b_sq / (2.0 * pgas);
+  const double beta_inv = bl_div_g(b_sq, 2.0 * pgas);
 
   // electron temperature, T_i/T_e(beta) model (:333-348)
   double theta_e = __longlong_as_double(0x7ff8000000000000ll);
   double kb_tt_e_cgs = theta_e;
   if (pl.plasma_thermal_frac != 0.0) {
-    double tti_tte = (pl.plasma_rat_high + pl.plasma_rat_low * beta_inv * beta_inv) / (1.0 + beta_inv * beta_inv);
-    double kb_tt_tot_cgs = pl.plasma_mu * kMp * pgas_cgs / rho_cgs;
+    double tti_tte = bl_div_g(pl.plasma_rat_high + pl.plasma_rat_low * beta_inv * beta_inv, 1.0 + beta_inv * beta_inv);
+    double kb_tt_tot_cgs = bl_div_g(pl.plasma_mu * kMp * pgas_cgs, rho_cgs);
     if (pl.plasma_use_p) {
-      kb_tt_e_cgs = (1.0 + pl.plasma_ne_ni) / (tti_tte + pl.plasma_ne_ni) * kb_tt_tot_cgs;
+      kb_tt_e_cgs = bl_div_g(1.0 + pl.plasma_ne_ni, tti_tte + pl.plasma_ne_ni) * kb_tt_tot_cgs;
     } else {
       kb_tt_e_cgs = (1.0 + pl.plasma_ne_ni) * kb_tt_tot_cgs / (P.cold->plasma_gamma - 1.0);
       kb_tt_e_cgs /= tti_tte / (P.cold->plasma_gamma_i - 1.0) + pl.plasma_ne_ni / (P.cold->plasma_gamma_e - 1.0);
     }
-    theta_e = kb_tt_e_cgs / (kMe * kC * kC);
+    theta_e = bl_div_g(kb_tt_e_cgs, kMe * kC * kC);
   }
 
   // cell cuts (:361-375); all thresholds negative = disabled is the common case
@@ -997,14 +1000,14 @@ __device__ __forceinline__ void sample_finish_simulation(const BlShadeArgs &P, c
   const double k_sq_tet = k_tet[0] * k_tet[0] + k_tet[1] * k_tet[1] + k_tet[2] * k_tet[2];
   const double b_sq_tet = b_tet[0] * b_tet[0] + b_tet[1] * b_tet[1] + b_tet[2] * b_tet[2];
   const double k_b_tet = k_tet[0] * b_tet[0] + k_tet[1] * b_tet[1] + k_tet[2] * b_tet[2];
-  const double cos2_theta_b = std_min(k_b_tet * k_b_tet / (k_sq_tet * b_sq_tet), 1.0);
+  const double cos2_theta_b = std_min(bl_div_g(k_b_tet * k_b_tet, k_sq_tet * b_sq_tet), 1.0);
   const double sin2_theta_b = 1.0 - cos2_theta_b;
   double nu_sum = 0.0;   // :461-463
   for (int mu = 0; mu < 4; mu++) nu_sum -= kcov[mu] * ucon[mu];
   out->have_coefficients = true;
   out->nu_fluid_over_nu = nu_sum;
   out->n_e_cgs = n_e_cgs;
-  out->nu_c_cgs = kE * bb_cgs / (2.0 * kPi * kMe * kC);
+  out->nu_c_cgs = bl_div_g(kE * bb_cgs, 2.0 * kPi * kMe * kC);
   out->theta_e = theta_e;
   out->sin_theta_b = bl_sqrt_g(sin2_theta_b);
   out->kb_tt_e_cgs = kb_tt_e_cgs;
@@ -1106,7 +1109,8 @@ __global__ void __launch_bounds__(256, 4) bl_locate_kernel(const BlShadeArgs P) 
       nid = src[7];
     }
     if (ray == BL_DEAD_RAY) continue;
-    const double r = bl_radial_coordinate(st, x1, x2, x3);
+    double r2;
+    const double r = bl_radial_coordinate2(st, x1, x2, x3, &r2);
     bool skip = r > P.cuts.camera_r;                                 // simulation_sampling.cpp:238-243
     if (!skip && P.cuts.any_optional) skip = optional_cuts(*P.cold, x1, x2, x3, r);
     BlLocated loc;
@@ -1117,7 +1121,7 @@ __global__ void __launch_bounds__(256, 4) bl_locate_kernel(const BlShadeArgs P) 
     double2 *dst = reinterpret_cast<double2 *>(P.located + at);
     dst[0] = make_double2(loc.f_i, loc.f_j);
     dst[1] = make_double2(loc.f_k, loc.ph);
-    dst[2] = make_double2(__longlong_as_double((long long)(((unsigned long long)loc.status << 32) | loc.cell)), 0.0);
+    dst[2] = make_double2(__longlong_as_double((long long)(((unsigned long long)loc.status << 32) | loc.cell)), r2);
   }
   // S_in accounting: one atomic per wave
   for (int offset = 32; offset > 0; offset >>= 1) gathers_local += __shfl_xor(gathers_local, offset, 64);
@@ -1182,7 +1186,12 @@ __global__ void __launch_bounds__(256, 2) bl_shade_kernel(const BlShadeArgs P) {
     // simulation metric and the geodesic metric (the reference recomputes them in each of those
     // functions; identical inputs, identical bits)
     BlKerrSchild ks;
-    bl_kerr_schild(st, x1, x2, x3, &ks);
+    if (kModel == BL_MODEL_SIMULATION) {
+      BlKerrSchildRecip rc;
+      bl_kerr_schild_r2(st, x1, x2, x3, l2.y, &ks, &rc);   // r^2 as the locate kernel computed it (same bits)
+    } else {
+      bl_kerr_schild(st, x1, x2, x3, &ks);
+    }
     if (kModel == BL_MODEL_FORMULA) {
       bool skip = ks.r > P.cuts.camera_r;                              // formula_coefficients.cpp:78-116
       if (!skip && P.cuts.any_optional) skip = optional_cuts(*P.cold, x1, x2, x3, ks.r);
@@ -1228,14 +1237,17 @@ __global__ void __launch_bounds__(256, 2) bl_shade_kernel(const BlShadeArgs P) {
           const double xx_1_2 = bl_sqrt_g(xx);
           const double xx_1_3 = bl_cbrt(xx);
           const double xx_1_6 = bl_sqrt_g(xx_1_3);
-          const double coefficient = thermal_frac * sh.n_e_cgs * kE * kE * sh.nu_c_cgs / (kC * nu_2_cgs) * bl_exp(-xx_1_3);
+          const double coefficient = bl_div_g(thermal_frac * sh.n_e_cgs * kE * kE * sh.nu_c_cgs, kC * nu_2_cgs) * bl_exp(-xx_1_3);
           const double var_a = kSqrt2 * kPi / 27.0 * sh.sin_theta_b;
           const double var_b = kPow2_11_12;
           const double var_c = xx_1_2 + var_b * xx_1_6;
           j_val = coefficient * var_a * var_c * var_c;
           const double b_nu_nu_3_cgs = 2.0 * kH / (kC * kC) / bl_expm1(kH * nu_cgs / sh.kb_tt_e_cgs);
           alpha_val = j_val / b_nu_nu_3_cgs;
-          if (1.0 / (alpha_val * alpha_val) == __longlong_as_double(0x7ff0000000000000ll)) alpha_val = 0.0;   // :513-523
+          // :513-523 zero alpha when 1 / alpha^2 overflows. 1 / x (x >= 0) rounds to +inf exactly when
+          // x <= 2^-1024 (the next double above, 2^-1024 + 2^-1074, gives 2^1024 - 2^974 < DBL_MAX + ulp/2);
+          // NaN fails both tests. One compare instead of a division.
+          if (alpha_val * alpha_val <= 0x1p-1024) alpha_val = 0.0;
         }
       } else if (sh.have_coefficients && kModel == BL_MODEL_FORMULA) {
         // formula_coefficients.cpp:164-179
@@ -1246,7 +1258,7 @@ __global__ void __launch_bounds__(256, 2) bl_shade_kernel(const BlShadeArgs P) {
         const double alpha_nu_fluid_cgs = fm.a * fm.cn0 * sh.n_n0_fluid * bl_pow(nu_fluid_cgs / fm.nup, -fm.beta - fm.alpha);
         alpha_val = alpha_nu_fluid_cgs * nu_fluid_cgs;
       }
-      const double delta_lambda_cgs = delta_lambda * P.x_unit / (freq * momentum_factor);   // unpolarized.cpp:75-76
+      const double delta_lambda_cgs = bl_div_g(delta_lambda * P.x_unit, freq * momentum_factor);   // unpolarized.cpp:75-76
       out[l] = transfer_record(j_val, alpha_val, delta_lambda_cgs);
     }
   }
