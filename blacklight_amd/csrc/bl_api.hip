@@ -26,6 +26,7 @@ extern "C" int bl_geodesic_occupancy(int integrator);
 extern "C" hipError_t bl_launch_locate(const BlShadeArgs *args, int grid, int lds_bytes, hipStream_t stream);
 extern "C" hipError_t bl_launch_shade(const BlShadeArgs *args, int model, int grid, hipStream_t stream);
 extern "C" hipError_t bl_launch_transfer(const BlTransferArgs *args, hipStream_t stream);
+extern "C" hipError_t bl_launch_transfer_aux(const BlTransferArgs *args, hipStream_t stream);
 
 namespace {
 
@@ -84,6 +85,7 @@ struct bl_ctx {
 
   // image rows (radiation_integrator.cpp:436-520)
   int image_num_quantities = 0;
+  BlAuxImages aux_images{};          // which image rows exist; .any = an auxiliary image is requested
   double plasma_thermal_frac = 0.0;
 
   // grid
@@ -106,7 +108,10 @@ struct bl_ctx {
     DeviceBuffer<unsigned char> d_ray_flags;
     DeviceBuffer<long long> d_ray_out_index;
     DeviceBuffer<unsigned long long> d_counters;   // BL_CNT_COUNT + 4 stats
+    DeviceBuffer<BlAuxSample> d_aux;               // auxiliary-image mode
+    DeviceBuffer<double> d_sample_t;               // image_time
     void Free() {
+      d_aux.Free(); d_sample_t.Free();
       d_records.Free(); d_located.Free(); d_transfer.Free(); d_ray_kt.Free(); d_ray_factor.Free();
       d_ray_sample_num.Free(); d_ray_flags.Free(); d_ray_out_index.Free(); d_counters.Free();
     }
@@ -293,9 +298,6 @@ void ValidateRadiation(bl_ctx *ctx) {
     throw Failure{BL_E_UNSUPPORTED, "False-colour rendering (render_num_images > 0) is outside the hot-path scope."};
   if (polarization)
     throw Failure{BL_E_UNSUPPORTED, "image_polarization = true (polarized transfer) is not built yet."};
-  if (p.image_time || p.image_length || p.image_lambda || p.image_emission || p.image_tau || p.image_lambda_ave
-      || p.image_emission_ave || p.image_tau_int || p.image_crossings)
-    throw Failure{BL_E_UNSUPPORTED, "Auxiliary images (image_time ... image_crossings) are not built yet; only image_light."};
   if (simulation) {
     Require(p, {BL_P_slow_light_on}, kRadMissing);
     if (p.slow_light_on) throw Failure{BL_E_UNSUPPORTED, "slow_light_on = true is not built yet."};
@@ -353,9 +355,43 @@ void ValidateRadiation(bl_ctx *ctx) {
 
   // geometry data and image rows (:419-520)
   ctx->frame.mass_msun = simulation ? p.simulation_m_msun : p.formula_mass * kC * kC / kGGMsun;
+  // image rows and their offsets (radiation_integrator.cpp:436-520); polarization is rejected above
+  BlAuxImages &A = ctx->aux_images;
+  A = BlAuxImages{};
+  const int nf = p.image_num_frequencies;
+  A.image_light = p.image_light;
+  A.image_time = p.image_time;
+  A.image_length = p.image_length;
+  A.image_lambda = p.image_lambda;
+  A.image_emission = p.image_emission;
+  A.image_tau = p.image_tau;
+  A.image_lambda_ave = simulation && p.image_lambda_ave;
+  A.image_emission_ave = simulation && p.image_emission_ave;
+  A.image_tau_int = simulation && p.image_tau_int;
+  A.image_crossings = p.image_crossings;
   int n_q = 0;
-  if (p.image_light) n_q += p.image_num_frequencies;
-  (void)kNumCellValues;
+  if (A.image_light) n_q += nf;
+  A.offset_time = n_q;
+  if (A.image_time) n_q += 1;
+  A.offset_length = n_q;
+  if (A.image_length) n_q += 1;
+  A.offset_lambda = n_q;
+  if (A.image_lambda) n_q += nf;
+  A.offset_emission = n_q;
+  if (A.image_emission) n_q += nf;
+  A.offset_tau = n_q;
+  if (A.image_tau) n_q += nf;
+  A.offset_lambda_ave = n_q;
+  if (A.image_lambda_ave) n_q += nf * kNumCellValues;
+  A.offset_emission_ave = n_q;
+  if (A.image_emission_ave) n_q += nf * kNumCellValues;
+  A.offset_tau_int = n_q;
+  if (A.image_tau_int) n_q += nf * kNumCellValues;
+  A.offset_crossings = n_q;
+  if (A.image_crossings) n_q += 1;
+  A.n_q = n_q;
+  A.any = (A.image_time || A.image_length || A.image_lambda || A.image_emission || A.image_tau || A.image_lambda_ave
+           || A.image_emission_ave || A.image_tau_int || A.image_crossings) ? 1 : 0;
   ctx->image_num_quantities = n_q;
 }
 
@@ -570,6 +606,7 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
     const int n_q = ctx->image_num_quantities;
     const int max_steps = p.ray_max_steps;
     const long long n_rays = d->n_rays;
+    const bool aux = ctx->aux_images.any != 0;
 
     // level pixel count check
     long long level_pixels = static_cast<long long>(p.camera_resolution) * p.camera_resolution;
@@ -579,7 +616,8 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
     // chunk size from the scratch budget: per ray max_steps * (64 B record + 48 B located sample
     // (simulation mode) + 16 B * n_nu transfer)
     const uint64_t per_ray = static_cast<uint64_t>(max_steps)
-        * (sizeof(BlSampleRecord) + (simulation ? sizeof(BlLocated) : 0) + sizeof(double2) * n_nu) + 64;
+        * (sizeof(BlSampleRecord) + (simulation ? sizeof(BlLocated) : 0) + sizeof(double2) * n_nu
+           + (aux ? sizeof(BlAuxSample) + sizeof(double) : 0)) + 64;
     // One chunk if the whole call fits the budget. With bl_set_overlap(): two scratch sets of half the budget
     // each, so that the geodesic kernel of chunk c + 1 runs while chunk c is being shaded.
     long long chunk = static_cast<long long>(ctx->scratch_limit / per_ray);
@@ -604,6 +642,8 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
       sl.d_ray_flags.Ensure(chunk);
       sl.d_ray_out_index.Ensure(chunk);
       sl.d_counters.Ensure(BL_CNT_COUNT + 4);
+      if (aux) sl.d_aux.Ensure(static_cast<size_t>(chunk) * max_steps);
+      if (aux && ctx->aux_images.image_time) sl.d_sample_t.Ensure(record_capacity);
     }
     EnsureChunkResources(ctx, n_chunks);
     ctx->d_freq.Ensure(n_nu);
@@ -736,6 +776,10 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
     sa.n_nu = n_nu;
     sa.ray_max_steps = max_steps;
     sa.x_unit = kGGMsun * ctx->frame.mass_msun / (kC * kC);   // unpolarized.cpp:42
+    sa.aux_need_coefficients = (p.image_light || p.image_emission || p.image_tau || ctx->aux_images.image_emission_ave
+                                || ctx->aux_images.image_tau_int) ? 1 : 0;   // simulation_coefficients.cpp:389
+    sa.aux_need_length = ctx->aux_images.image_length;
+    for (int mu = 0; mu < 4; mu++) sa.cam_x[mu] = ctx->frame.cam_x[mu];
 
     BlTransferArgs xa{};
     xa.frequencies = ctx->d_freq.ptr;
@@ -747,6 +791,9 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
     xa.image = image;
     xa.out_sample_num = out_num;
     xa.out_flags = out_flags;
+    xa.aux_images = ctx->aux_images;
+    xa.x_unit = kGGMsun * ctx->frame.mass_msun / (kC * kC);
+    xa.t_unit = xa.x_unit / kC;   // unpolarized.cpp:43
 
     // Locate kernel: 256-thread workgroups. Alone (single chunk) it runs 4 waves per SIMD; when chunks are
     // pipelined it shares each SIMD with one 328-register wave of the next chunk's geodesic kernel, which
@@ -798,6 +845,12 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
       xa.ray_flags = sl.d_ray_flags.ptr;
       xa.ray_out_index = sl.d_ray_out_index.ptr;
       xa.stats = sl.d_counters.ptr + BL_CNT_COUNT;
+      ta.sample_t = (aux && ctx->aux_images.image_time) ? sl.d_sample_t.ptr : nullptr;
+      sa.aux = aux ? sl.d_aux.ptr : nullptr;
+      sa.sample_t = ta.sample_t;
+      sa.ray_flags = sl.d_ray_flags.ptr;
+      xa.aux = sa.aux;
+      xa.ray_factor = sl.d_ray_factor.ptr;
 
       // ---- geodesic stream
       if (c >= n_slots) Check(hipStreamWaitEvent(stream_geo, (e - n_slots * kEventsPerChunk)[5], 0), "stream wait");
@@ -815,7 +868,7 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
       Check(hipEventRecord(e[3], stream), "event");
       Check(bl_launch_shade(&sa, p.model_type, shade_grid, stream), "coefficient kernel launch");
       Check(hipEventRecord(e[4], stream), "event");
-      Check(bl_launch_transfer(&xa, stream), "transfer kernel launch");
+      Check(aux ? bl_launch_transfer_aux(&xa, stream) : bl_launch_transfer(&xa, stream), "transfer kernel launch");
       Check(hipEventRecord(e[5], stream), "event");
       Check(hipMemcpyAsync(ctx->host_counters + static_cast<size_t>(c) * n_counters, sl.d_counters.ptr,
                            n_counters * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream), "counter download");

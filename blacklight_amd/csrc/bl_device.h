@@ -108,6 +108,30 @@ struct BlCutsDevice {
   double camera_r;
 };
 
+// Per-sample inputs of the auxiliary images (unpolarized.cpp:113-173), stored [ray][n] like the transfer
+// records. Only written and read when an auxiliary image is requested; in that mode the transfer buffer
+// holds (j_nu, alpha_nu) per sample and frequency instead of (a, b).
+#define BL_NUM_CELL_VALUES 7   // blacklight.hpp:30-33: rho, n_e, p_gas, theta_e, bb, sigma, beta_inv
+struct alignas(16) BlAuxSample {
+  double delta_lambda;               // sample_len in geometric units
+  double length_term;                // sqrt(dl_dlambda_sq) * delta_lambda * x_unit (image_length)
+  double t;                          // coordinate time of the sample (image_time)
+  double plane;                      // camera_x . x (image_crossings compares its sign between samples)
+  double cell[BL_NUM_CELL_VALUES];   // cell_values, NaN when not recorded
+  double pad;
+};
+static_assert(sizeof(BlAuxSample) == 96, "aux sample must be 96 bytes");
+
+// Which auxiliary images are requested, and where their rows start (radiation_integrator.cpp:436-520)
+struct BlAuxImages {
+  int any;
+  int image_light, image_time, image_length, image_lambda, image_emission, image_tau;
+  int image_lambda_ave, image_emission_ave, image_tau_int, image_crossings;
+  int offset_time, offset_length, offset_lambda, offset_emission, offset_tau;
+  int offset_lambda_ave, offset_emission_ave, offset_tau_int, offset_crossings;
+  int n_q;
+};
+
 // Kernel arguments: geodesic kernel
 struct BlTraceArgs {
   BlSpacetime st;
@@ -122,6 +146,7 @@ struct BlTraceArgs {
   const int *pixel_map;       // device, or null
   const int *block_locs;      // device, or null
   BlSampleRecord *records;
+  double *sample_t;           // optional [record capacity]: coordinate time of each sample (image_time)
   long long record_capacity;
   unsigned long long *counters;
   double *ray_kt, *ray_factor;
@@ -148,7 +173,14 @@ struct BlShadeArgs {
   int n_nu;
   int ray_max_steps;
   double x_unit;              // GM/c^2 in cm (unpolarized.cpp:42)
-  double2 *transfer;          // [chunk_rays][ray_max_steps][n_nu]
+  double2 *transfer;          // [chunk_rays][ray_max_steps][n_nu]; (a, b), or (j, alpha) in auxiliary mode
+  // auxiliary-image mode only
+  BlAuxSample *aux;           // [chunk_rays][ray_max_steps]
+  const double *sample_t;     // [record capacity] or null
+  const unsigned char *ray_flags;
+  int aux_need_coefficients;  // image_light || image_emission || image_tau || image_emission_ave || image_tau_int (:389)
+  int aux_need_length;
+  double cam_x[4];
 };
 
 // Kernel arguments: transfer kernel
@@ -165,6 +197,11 @@ struct BlTransferArgs {
   int *out_sample_num;        // [n_rays_total] or null
   unsigned char *out_flags;   // [n_rays_total] or null
   unsigned long long *stats;  // [0] sum sample_num, [1] flagged rays, [2] max sample_num
+  // auxiliary-image mode only
+  BlAuxImages aux_images;
+  const BlAuxSample *aux;
+  const double *ray_factor;
+  double x_unit, t_unit;
 };
 
 #endif  // BLACKLIGHT_AMD_BL_DEVICE_H_

@@ -3,22 +3,26 @@
 // Pipeline per chunk of rays (fp64 throughout, grid primitives fp32 in HBM; no MFMA: the work is
 // per-ray ODE integration and gathers, not a contraction):
 //
-//   bl_geodesic_kernel   one ray per lane, wave64, persistent waves. Camera pixel -> (x^mu, k_mu),
-//                        Dormand-Prince 5(4) / RK4 / RK2 stepping in Kerr-Schild coordinates with the
-//                        reference's controller, dense-output sampling, online truncation test.
-//                        Lanes whose ray has terminated are refilled from a global work queue
-//                        (ballot + popcount prefix, one atomic per wave); sample slots for a whole
-//                        wave-step are allocated with one wave scan + one atomic and written as
-//                        64-byte records.   (reference geodesics.cpp:39-396, camera.cpp:528-671)
-//   bl_shade_kernel      one SAMPLE per lane (no ray divergence, high occupancy to hide gather
-//                        latency): per-sample momentum renormalisation, cuts, CKS->SKS, cell search,
-//                        8-variable trilinear gather from the interleaved grid, thermal-synchrotron
-//                        j_nu / alpha_nu, and the per-sample transfer coefficients (a, b) of
-//                        I <- a (I + b).   (simulation_sampling.cpp:201-575, :666-1033,
+//   bl_geodesic_kernel   one ray per lane, wave64, persistent waves (1 per SIMD). Camera pixel ->
+//                        (x^mu, k_mu), Dormand-Prince 5(4) / RK4 / RK2 stepping in Kerr-Schild
+//                        coordinates with the reference's controller, dense-output sampling, online
+//                        truncation test. Lanes whose ray has terminated are refilled from a global work
+//                        queue (ballot + popcount prefix, one atomic per wave); samples go to 64-byte
+//                        records in per-wave blocks of slots.   (geodesics.cpp:39-396, camera.cpp:528-671)
+//   bl_locate_kernel     one SAMPLE per lane, 4 waves per SIMD (simulation mode): cuts, CKS->SKS, cell
+//                        search on LDS tables, trilinear fractions -> 48-byte located sample.
+//                        (simulation_sampling.cpp:201-575)
+//   bl_shade_kernel      one SAMPLE per lane, 2 waves per SIMD ("coefficient kernel"): the 8-variable
+//                        trilinear read from the interleaved grid, per-sample momentum renormalisation,
+//                        thermal-synchrotron j_nu / alpha_nu (or the formula model), and the per-sample
+//                        transfer coefficients (a, b) of I <- a (I + b).   (simulation_sampling.cpp:666-1033,
 //                        simulation_coefficients.cpp:253-524, formula_coefficients.cpp:62-180,
 //                        unpolarized.cpp:74-110)
 //   bl_transfer_kernel   one ray per lane: replays the (a, b) records far -> near in the reference's
 //                        order and scales by nu^3.   (unpolarized.cpp:71-110, :200-208)
+//   auxiliary images     bl_geodesic_kernel<., true> also emits sample times, bl_shade_kernel<., true>
+//                        writes (j, alpha) and a BlAuxSample per sample, bl_transfer_aux_kernel integrates
+//                        image_light and the nine auxiliary images.   (unpolarized.cpp:113-196)
 //
 // The reference integrates camera -> source but evaluates the transfer equation source -> camera
 // (ReverseGeodesics, geodesics.cpp:808-849); recording (a, b) per sample in the forward pass keeps
@@ -150,7 +154,9 @@ __device__ __forceinline__ long long traversal_to_ray(long long q, int res) {
 // =================================================================================================
 // Geodesic kernel
 // =================================================================================================
-template <int kIntegrator>
+// kTime: also emit the coordinate time of every sample (P.sample_t, for image_time). Without it the time
+// component is only advanced, never sampled, which keeps its six stage derivatives out of the registers.
+template <int kIntegrator, bool kTime>
 __global__ void __launch_bounds__(64, 1) bl_geodesic_kernel(BlTraceArgs P) {
   const int lane = wave_lane();
   const BlSpacetime st = P.st;
@@ -295,7 +301,7 @@ __global__ void __launch_bounds__(64, 1) bl_geodesic_kernel(BlTraceArgs P) {
 #pragma unroll
           for (int p = 0; p < 8; p++) {
             double a5 = s.y[p], a4 = s.y[p];
-            if (p == 0) {
+            if (p == 0 && !kTime) {
               a5 = t5;
               a4 = t4;
             } else if (p == 7) {
@@ -339,9 +345,9 @@ __global__ void __launch_bounds__(64, 1) bl_geodesic_kernel(BlTraceArgs P) {
             previous_fail = false;
             accepted = true;
 
-            // midpoint (:227-231), subdivision (:234-245); component 0 (t) of the samples is never stored
+            // midpoint (:227-231), subdivision (:234-245); component 0 (t) of the samples only with kTime
 #pragma unroll
-            for (int p = 1; p < 7; p++) {
+            for (int p = kTime ? 0 : 1; p < 7; p++) {
               double acc = s.y[p];
 #pragma unroll
               for (int q = 0; q < 7; q++) acc += kB4m[q] * h * kk[q][p];
@@ -360,7 +366,7 @@ __global__ void __launch_bounds__(64, 1) bl_geodesic_kernel(BlTraceArgs P) {
             emit = num_steps;
             if (num_steps_ideal > 1) {   // :262-274
 #pragma unroll
-              for (int p = 1; p < 7; p++) {
+              for (int p = kTime ? 0 : 1; p < 7; p++) {
                 rv0[p] = y5[p] - s.y[p];
                 rv1[p] = s.y[p] - y5[p] + h * k0[p];
                 rv2[p] = 2.0 * (y5[p] - s.y[p]) - h * (k0[p] + k6[p]);
@@ -454,12 +460,12 @@ __global__ void __launch_bounds__(64, 1) bl_geodesic_kernel(BlTraceArgs P) {
         double len;
         if (num_steps_ideal == 1) {   // :248-259 (and the RK4 / RK2 stored state)
 #pragma unroll
-          for (int p = 1; p < 7; p++) smp[p] = y4m[p];
+          for (int p = kTime ? 0 : 1; p < 7; p++) smp[p] = y4m[p];
           len = h;
         } else {                      // :277-293
           double frac = (nn + 0.5) / num_steps_ideal;
 #pragma unroll
-          for (int p = 1; p < 7; p++)
+          for (int p = kTime ? 0 : 1; p < 7; p++)
             smp[p] = s.y[p] + frac * (rv0[p] + (1.0 - frac) * (rv1[p] + frac * (rv2[p] + (1.0 - frac) * rv3[p])));
           len = h / num_steps_ideal;
         }
@@ -490,6 +496,7 @@ __global__ void __launch_bounds__(64, 1) bl_geodesic_kernel(BlTraceArgs P) {
         rec.ray = dead ? BL_DEAD_RAY : slot;
         rec.n = (unsigned int)index;
         P.records[my_base + nn] = rec;
+        if (kTime) P.sample_t[my_base + nn] = smp[0];
       }
     }
 
@@ -669,6 +676,8 @@ struct SampleShade {
   double nu_fluid_over_nu;     // -k_mu u^mu (fluid-frame frequency per unit camera frequency*factor)
   double n_e_cgs, nu_c_cgs, theta_e, sin_theta_b, kb_tt_e_cgs;   // simulation
   double n_n0_fluid, fu[4];                                       // formula
+  bool have_cell;              // cell_values recorded (simulation_coefficients.cpp:377-387)
+  double cell[BL_NUM_CELL_VALUES];
 };
 
 // Status of a located sample (BlLocated::status)
@@ -795,7 +804,7 @@ __device__ __forceinline__ void sample_primitives(const BlShadeArgs &P, int stat
 __device__ __forceinline__ void sample_finish_simulation(const BlShadeArgs &P, const BlSpacetime &st,
                                                          const BlKerrSchild &ks, double cth, double ph_unwrapped,
                                                          const float pr[8], const double kcov[4],
-                                                         SampleShade *out) {
+                                                         int need_coefficients, SampleShade *out) {
   const BlPlasmaDevice &pl = P.plasma;
   const double bh_a = st.bh_a, bh_m = st.bh_m;
   const double r = ks.r, r2 = ks.r2, a2 = ks.a2;
@@ -935,7 +944,17 @@ __device__ __forceinline__ void sample_finish_simulation(const BlShadeArgs &P, c
   }
   const bool no_field = bb1 == 0.0 && bb2 == 0.0 && bb3 == 0.0;   // :394
   out->have_coefficients = false;
-  if (cell_cut || no_field) return;
+  out->have_cell = false;
+  if (cell_cut) return;
+  out->have_cell = true;   // :377-387 (used in auxiliary-image mode only)
+  out->cell[0] = rho_cgs;
+  out->cell[1] = n_e_cgs;
+  out->cell[2] = pgas_cgs;
+  out->cell[3] = theta_e;
+  out->cell[4] = bb_cgs;
+  out->cell[5] = sigma_cut;
+  out->cell[6] = beta_inv;
+  if (need_coefficients == 0 || no_field) return;   // :389-395
 
   // Transform u and b to geodesic (CKS) coordinates (:398-408). The Jacobian of
   // radiation_geometry.cpp:69-126 has row/column 0 = identity and jacobian[3][3] = 0; the products
@@ -1131,7 +1150,10 @@ __global__ void __launch_bounds__(256, 4) bl_locate_kernel(const BlShadeArgs P) 
 // ---- coefficient kernel: one sample record per lane, pure fp64 arithmetic between one coalesced
 // read (record + located sample) and one 16-byte store per frequency. Two waves per SIMD so that one
 // wave's scalar work, dependent-issue bubbles and load waits overlap the other's VALU work.
-template <int kModel>
+// kAux (any auxiliary image requested, unpolarized.cpp:113-173): the per-frequency pairs written are
+// (j_nu, alpha_nu) instead of (a, b), and one BlAuxSample per sample goes with them; the auxiliary
+// transfer kernel integrates everything. Kept out of the instantiations the benchmark path runs.
+template <int kModel, bool kAux>
 __global__ void __launch_bounds__(256, 2) bl_shade_kernel(const BlShadeArgs P) {
   const BlSpacetime st = P.st;
   const unsigned long long n_records = P.counters_in[BL_CNT_RECORDS];
@@ -1150,6 +1172,7 @@ __global__ void __launch_bounds__(256, 2) bl_shade_kernel(const BlShadeArgs P) {
     }
   }
   for (bool more = true; more;) {
+    const unsigned long long idx_cur = idx;
     const double2 q0 = nq0, q1 = nq1, q2 = nq2, q3 = nq3, l0 = nl0, l1 = nl1, l2 = nl2;
     const uint32_t ray = (uint32_t)__double_as_longlong(q3.y);
     const bool live = ray != BL_DEAD_RAY;
@@ -1215,13 +1238,55 @@ __global__ void __launch_bounds__(256, 2) bl_shade_kernel(const BlShadeArgs P) {
     sh.n_e_cgs = sh.nu_c_cgs = sh.theta_e = sh.sin_theta_b = sh.kb_tt_e_cgs = 0.0;
     sh.n_n0_fluid = 0.0;
     sh.fu[0] = sh.fu[1] = sh.fu[2] = sh.fu[3] = 0.0;
+    sh.have_cell = false;
+    bool nan_ray = false;
+    if (kAux) {
+      // rays that ended on ray_max_steps / retries with fallback_nan: simulation mode samples NaN
+      // primitives at every sample, cuts not applied (simulation_sampling.cpp:211-216); formula mode
+      // fills frequency 0 with NaN coefficients (formula_coefficients.cpp:51-59)
+      nan_ray = P.plasma.fallback_nan && P.ray_flags[ray] != 0;
+      if (nan_ray && kModel == BL_MODEL_SIMULATION) {
+        const float fnan = __int_as_float(0x7fc00000);
+        for (int v = 0; v < 8; v++) pr[v] = fnan;
+        status = kSampleOffGrid;
+      }
+    }
     if (status != kSampleCut) {
       if (kModel == BL_MODEL_SIMULATION)
-        sample_finish_simulation(P, st, ks, x3 / ks.r, ph, pr, kcov, &sh);
-      else
+        sample_finish_simulation(P, st, ks, x3 / ks.r, ph, pr, kcov, kAux ? P.aux_need_coefficients : 1, &sh);
+      else if (!(kAux && nan_ray))
         shade_formula(P, st, ks.r, x1, x2, x3, &sh);
     }
     double2 *out = P.transfer + ((size_t)ray * P.ray_max_steps + n) * P.n_nu;
+    if (kAux) {
+      BlAuxSample aux;
+      aux.delta_lambda = delta_lambda;
+      aux.t = P.sample_t != nullptr ? P.sample_t[idx_cur] : 0.0;
+      aux.plane = P.cam_x[1] * x1 + P.cam_x[2] * x2 + P.cam_x[3] * x3;
+      aux.length_term = 0.0;
+      aux.pad = 0.0;
+      if (P.aux_need_length) {
+        // unpolarized.cpp:115-129 with the renormalised sample momentum
+        double gcov[4][4], gcon[4][4];
+        if (st.ray_flat) {
+          bl_minkowski(gcov);
+          bl_minkowski(gcon);
+        } else {
+          bl_gcov_ks(ks, gcov);
+          bl_gcon_ks(ks, gcon);
+        }
+        double temp_a[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int a = 1; a < 4; a++)
+          for (int mu = 0; mu < 4; mu++) temp_a[a] += (gcon[a][mu] - gcon[0][a] * gcon[0][mu] / gcon[0][0]) * kcov[mu];
+        double dl_dlambda_sq = 0.0;
+        for (int a = 1; a < 4; a++)
+          for (int b = 1; b < 4; b++) dl_dlambda_sq += gcov[a][b] * temp_a[a] * temp_a[b];
+        aux.length_term = blm_sqrt(dl_dlambda_sq) * delta_lambda * P.x_unit;
+      }
+      const double nan = __longlong_as_double(0x7ff8000000000000ll);
+      for (int a = 0; a < BL_NUM_CELL_VALUES; a++) aux.cell[a] = sh.have_cell ? sh.cell[a] : nan;
+      P.aux[(size_t)ray * P.ray_max_steps + n] = aux;
+    }
     // ---------------- per-frequency coefficients and transfer records
     for (int l = 0; l < P.n_nu; l++) {
       const double freq = P.frequencies[l];
@@ -1258,8 +1323,13 @@ __global__ void __launch_bounds__(256, 2) bl_shade_kernel(const BlShadeArgs P) {
         const double alpha_nu_fluid_cgs = fm.a * fm.cn0 * sh.n_n0_fluid * bl_pow(nu_fluid_cgs / fm.nup, -fm.beta - fm.alpha);
         alpha_val = alpha_nu_fluid_cgs * nu_fluid_cgs;
       }
-      const double delta_lambda_cgs = bl_div_g(delta_lambda * P.x_unit, freq * momentum_factor);   // unpolarized.cpp:75-76
-      out[l] = transfer_record(j_val, alpha_val, delta_lambda_cgs);
+      if (kAux) {
+        if (kModel == BL_MODEL_FORMULA && nan_ray && l == 0) j_val = alpha_val = __longlong_as_double(0x7ff8000000000000ll);
+        out[l] = make_double2(j_val, alpha_val);
+      } else {
+        const double delta_lambda_cgs = bl_div_g(delta_lambda * P.x_unit, freq * momentum_factor);   // unpolarized.cpp:75-76
+        out[l] = transfer_record(j_val, alpha_val, delta_lambda_cgs);
+      }
     }
   }
 }
@@ -1327,21 +1397,129 @@ __global__ void __launch_bounds__(256) bl_transfer_kernel(BlTransferArgs P) {
   }
 }
 
+// Auxiliary-image transfer kernel (unpolarized.cpp:53-196 for one pixel per lane): integrates image_light
+// and every requested auxiliary image from the (j, alpha) pairs and the BlAuxSample records, far -> near,
+// in the reference's order. Not on the benchmark path.
+__global__ void __launch_bounds__(64) bl_transfer_aux_kernel(BlTransferArgs P) {
+  int slot = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long samples = 0ull, flagged = 0ull;
+  int max_num = 0;
+  if (slot < P.chunk_rays) {
+    const BlAuxImages &A = P.aux_images;
+    const int num = P.ray_sample_num[slot];
+    const bool flag = P.ray_flags[slot] != 0;
+    const long long out_index = P.ray_out_index[slot];
+    samples = (unsigned long long)num;
+    flagged = flag ? 1ull : 0ull;
+    max_num = num;
+    if (P.out_sample_num != nullptr) P.out_sample_num[out_index] = num;
+    if (P.out_flags != nullptr) P.out_flags[out_index] = flag ? 1 : 0;
+    const double nan = __longlong_as_double(0x7ff8000000000000ll);
+    const double momentum_factor = P.ray_factor[slot];
+    const size_t row = (size_t)P.n_rays_total;
+    double *img = P.image + out_index;   // img[q * row] = image(q, pixel)
+    for (int q = 0; q < A.n_q; q++) img[(size_t)q * row] = 0.0;
+    const BlAuxSample *aux = P.aux + (size_t)slot * P.ray_max_steps;
+    const double2 *ja = P.transfer + (size_t)slot * P.ray_max_steps * P.n_nu;
+    const bool use_j = A.image_light || A.image_emission || A.image_emission_ave;
+    const bool use_alpha = A.image_light || A.image_tau || A.image_tau_int;
+    for (int l = 0; l < P.n_nu; l++) {
+      const double freq = P.frequencies[l];
+      double intensity = 0.0, integrated_lambda = 0.0, integrated_emission = 0.0, tau = 0.0;
+      double time_min = 0.0, length = 0.0;
+      double lambda_ave[BL_NUM_CELL_VALUES], emission_ave[BL_NUM_CELL_VALUES], tau_int[BL_NUM_CELL_VALUES];
+      for (int a = 0; a < BL_NUM_CELL_VALUES; a++) lambda_ave[a] = emission_ave[a] = tau_int[a] = 0.0;
+      bool plane_sign = num > 0 ? aux[num - 1].plane > 0.0 : false;   // first (farthest) sample, :63-67
+      int crossings = 0;
+      // reference sample order is reversed integration order (geodesics.cpp:832-840)
+      for (int n = num - 1; n >= 0; n--) {
+        const BlAuxSample s = aux[n];
+        const double2 c = ja[(size_t)n * P.n_nu + l];
+        const double delta_lambda = s.delta_lambda;
+        const double delta_lambda_cgs = delta_lambda * P.x_unit / (freq * momentum_factor);
+        const double t_cgs = s.t * P.t_unit;
+        const double j = use_j ? c.x : nan;
+        const double alpha = use_alpha ? c.y : nan;
+        const double ss = j / alpha;
+        const double delta_tau = alpha * delta_lambda_cgs;
+        const double exp_neg = bl_exp(-delta_tau);
+        const double expm1 = bl_expm1(delta_tau);
+        const bool optically_thin = delta_tau <= kDeltaTauMax;
+        if (A.image_light) {
+          if (alpha > 0.0) {
+            if (optically_thin)
+              intensity = exp_neg * (intensity + ss * expm1);
+            else
+              intensity = ss;
+          } else {
+            intensity += j * delta_lambda_cgs;
+          }
+        }
+        if (A.image_time && l == 0) time_min = std_min(time_min, t_cgs);
+        if (A.image_length && l == 0) length += s.length_term;
+        if (A.image_lambda || A.image_lambda_ave) integrated_lambda += delta_lambda_cgs;
+        if (A.image_emission || A.image_emission_ave) integrated_emission += j * delta_lambda_cgs;
+        if (A.image_tau) tau += delta_tau;
+        const bool have_cell = !(s.cell[0] != s.cell[0]);
+        if (A.image_lambda_ave && have_cell)
+          for (int a = 0; a < BL_NUM_CELL_VALUES; a++) lambda_ave[a] += s.cell[a] * delta_lambda_cgs;
+        if (A.image_emission_ave && have_cell)
+          for (int a = 0; a < BL_NUM_CELL_VALUES; a++) emission_ave[a] += s.cell[a] * j * delta_lambda_cgs;
+        if (A.image_tau_int && have_cell) {
+          if (optically_thin)
+            for (int a = 0; a < BL_NUM_CELL_VALUES; a++) tau_int[a] = exp_neg * (tau_int[a] + s.cell[a] * expm1);
+          else
+            for (int a = 0; a < BL_NUM_CELL_VALUES; a++) tau_int[a] = s.cell[a];
+        }
+        if (A.image_crossings && l == 0) {
+          const bool plane_sign_new = s.plane > 0.0;
+          if (plane_sign_new != plane_sign) crossings++;
+          plane_sign = plane_sign_new;
+        }
+      }
+      if (A.image_light) img[(size_t)l * row] = intensity * (freq * freq * freq);   // :200-208
+      if (A.image_time && l == 0) img[(size_t)A.offset_time * row] = time_min;
+      if (A.image_length && l == 0) img[(size_t)A.offset_length * row] = length;
+      if (A.image_lambda) img[(size_t)(A.offset_lambda + l) * row] = integrated_lambda;
+      if (A.image_emission) img[(size_t)(A.offset_emission + l) * row] = integrated_emission;
+      if (A.image_tau) img[(size_t)(A.offset_tau + l) * row] = tau;
+      if (A.image_crossings && l == 0) img[(size_t)A.offset_crossings * row] = (double)crossings;
+      for (int a = 0; a < BL_NUM_CELL_VALUES; a++) {
+        if (A.image_lambda_ave) img[(size_t)(A.offset_lambda_ave + l * BL_NUM_CELL_VALUES + a) * row] = lambda_ave[a] / integrated_lambda;
+        if (A.image_emission_ave) img[(size_t)(A.offset_emission_ave + l * BL_NUM_CELL_VALUES + a) * row] = emission_ave[a] / integrated_emission;
+        if (A.image_tau_int) img[(size_t)(A.offset_tau_int + l * BL_NUM_CELL_VALUES + a) * row] = tau_int[a];
+      }
+    }
+  }
+  for (int offset = 32; offset > 0; offset >>= 1) {
+    samples += __shfl_xor(samples, offset, 64);
+    flagged += __shfl_xor(flagged, offset, 64);
+    int other = __shfl_xor(max_num, offset, 64);
+    max_num = other > max_num ? other : max_num;
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (samples) atomicAdd(&P.stats[0], samples);
+    if (flagged) atomicAdd(&P.stats[1], flagged);
+    atomicMax(&P.stats[2], (unsigned long long)max_num);
+  }
+}
+
 // =================================================================================================
 // Launch wrappers (called from bl_api.hip)
 // =================================================================================================
 extern "C" hipError_t bl_launch_geodesic(const BlTraceArgs *args, int integrator, int grid, hipStream_t stream) {
+  const bool with_time = args->sample_t != nullptr;
+#define BL_LAUNCH_G(I)                                                                                      \
+  do {                                                                                                      \
+    if (with_time) hipLaunchKernelGGL((bl_geodesic_kernel<I, true>), dim3(grid), dim3(64), 0, stream, *args); \
+    else hipLaunchKernelGGL((bl_geodesic_kernel<I, false>), dim3(grid), dim3(64), 0, stream, *args);        \
+  } while (0)
   switch (integrator) {
-    case BL_INTEGRATOR_DP:
-      hipLaunchKernelGGL(bl_geodesic_kernel<BL_INTEGRATOR_DP>, dim3(grid), dim3(64), 0, stream, *args);
-      break;
-    case BL_INTEGRATOR_RK4:
-      hipLaunchKernelGGL(bl_geodesic_kernel<BL_INTEGRATOR_RK4>, dim3(grid), dim3(64), 0, stream, *args);
-      break;
-    default:
-      hipLaunchKernelGGL(bl_geodesic_kernel<BL_INTEGRATOR_RK2>, dim3(grid), dim3(64), 0, stream, *args);
-      break;
+    case BL_INTEGRATOR_DP: BL_LAUNCH_G(BL_INTEGRATOR_DP); break;
+    case BL_INTEGRATOR_RK4: BL_LAUNCH_G(BL_INTEGRATOR_RK4); break;
+    default: BL_LAUNCH_G(BL_INTEGRATOR_RK2); break;
   }
+#undef BL_LAUNCH_G
   return hipGetLastError();
 }
 
@@ -1350,13 +1528,13 @@ extern "C" int bl_geodesic_occupancy(int integrator) {
   hipError_t err;
   switch (integrator) {
     case BL_INTEGRATOR_DP:
-      err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, bl_geodesic_kernel<BL_INTEGRATOR_DP>, 64, 0);
+      err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, bl_geodesic_kernel<BL_INTEGRATOR_DP, false>, 64, 0);
       break;
     case BL_INTEGRATOR_RK4:
-      err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, bl_geodesic_kernel<BL_INTEGRATOR_RK4>, 64, 0);
+      err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, bl_geodesic_kernel<BL_INTEGRATOR_RK4, false>, 64, 0);
       break;
     default:
-      err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, bl_geodesic_kernel<BL_INTEGRATOR_RK2>, 64, 0);
+      err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, bl_geodesic_kernel<BL_INTEGRATOR_RK2, false>, 64, 0);
       break;
   }
   if (err != hipSuccess || blocks < 1) blocks = 4;
@@ -1371,10 +1549,20 @@ extern "C" hipError_t bl_launch_locate(const BlShadeArgs *args, int grid, int ld
 
 // Coefficient kernel
 extern "C" hipError_t bl_launch_shade(const BlShadeArgs *args, int model, int grid, hipStream_t stream) {
-  if (model == BL_MODEL_SIMULATION)
-    hipLaunchKernelGGL(bl_shade_kernel<BL_MODEL_SIMULATION>, dim3(grid), dim3(256), 0, stream, *args);
-  else
-    hipLaunchKernelGGL(bl_shade_kernel<BL_MODEL_FORMULA>, dim3(grid), dim3(256), 0, stream, *args);
+  const bool aux = args->aux != nullptr;
+  if (model == BL_MODEL_SIMULATION) {
+    if (aux) hipLaunchKernelGGL((bl_shade_kernel<BL_MODEL_SIMULATION, true>), dim3(grid), dim3(256), 0, stream, *args);
+    else hipLaunchKernelGGL((bl_shade_kernel<BL_MODEL_SIMULATION, false>), dim3(grid), dim3(256), 0, stream, *args);
+  } else {
+    if (aux) hipLaunchKernelGGL((bl_shade_kernel<BL_MODEL_FORMULA, true>), dim3(grid), dim3(256), 0, stream, *args);
+    else hipLaunchKernelGGL((bl_shade_kernel<BL_MODEL_FORMULA, false>), dim3(grid), dim3(256), 0, stream, *args);
+  }
+  return hipGetLastError();
+}
+
+extern "C" hipError_t bl_launch_transfer_aux(const BlTransferArgs *args, hipStream_t stream) {
+  int grid = (args->chunk_rays + 63) / 64;
+  hipLaunchKernelGGL(bl_transfer_aux_kernel, dim3(grid), dim3(64), 0, stream, *args);
   return hipGetLastError();
 }
 

@@ -11,7 +11,7 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 CASES = sorted(f[:-4] for f in os.listdir(GOLDEN_DIR)
                if f.endswith(".npz") and not f.startswith("mock_") and not f.startswith("window_"))
 # cases whose parameters are inside the scope of the HIP path today
-GPU_CASES = [c for c in CASES if c != "sim_aux_images"]
+GPU_CASES = list(CASES)
 
 FRAME_KEYS = ("cam_x", "u_con", "u_cov", "norm_con", "norm_con_c", "hor_con_c", "vert_con_c")
 
@@ -38,10 +38,21 @@ def golden_grid(mock_args):
                 x1v=coord("x1v"), x2v=coord("x2v"), x3v=coord("x3v"))
 
 
+IMAGE_ROW_NAMES = ["I_nu", "time", "length", "lambda", "emission", "tau", "lambda_ave_rho", "lambda_ave_n_e",
+                   "lambda_ave_p_gas", "lambda_ave_Theta_e", "lambda_ave_B", "lambda_ave_sigma", "lambda_ave_beta_inverse",
+                   "emission_ave_rho", "emission_ave_n_e", "emission_ave_p_gas", "emission_ave_Theta_e", "emission_ave_B",
+                   "emission_ave_sigma", "emission_ave_beta_inverse", "tau_int_rho", "tau_int_n_e", "tau_int_p_gas",
+                   "tau_int_Theta_e", "tau_int_B", "tau_int_sigma", "tau_int_beta_inverse", "crossings"]
+
+
 def expected_image(fx, tier, n_pix):
-    """Rows of image[0] in reference order for the light-only cases: (n_nu, n_pix)."""
-    arr = fx[f"{tier}_npz_I_nu"]
-    return arr.reshape(-1, n_pix)
+    """All image rows in the reference's row order (radiation_integrator.cpp:436-520): (n_q, n_pix)."""
+    rows = []
+    for name in IMAGE_ROW_NAMES:
+        key = f"{tier}_npz_{name}"
+        if key in fx.files:
+            rows.append(fx[key].reshape(-1, n_pix))
+    return np.concatenate(rows, axis=0)
 
 
 def same_bits(a, b):

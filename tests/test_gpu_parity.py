@@ -97,6 +97,48 @@ def test_pixel_map_and_chunking(case, overlap, built_library):
     assert gu.same_bits(part["image"], full["image"][:, subset]).all()
 
 
+AUX_ALL = dict(image_time="true", image_length="true", image_lambda="true", image_emission="true", image_tau="true",
+               image_crossings="true")
+AUX_SIM = dict(AUX_ALL, image_lambda_ave="true", image_emission_ave="true", image_tau_int="true")
+
+
+@pytest.mark.parametrize("case,extra", [
+    ("sim_multifreq", AUX_SIM),                                    # three frequencies, every auxiliary image
+    ("sim_few_steps", AUX_SIM),                                    # flagged rays: NaN primitives along the whole ray
+    ("sim_cuts", dict(AUX_SIM, image_light="false")),              # no image_light: j, alpha read as NaN where unused
+    ("sim_spin_fallback", dict(image_lambda_ave="true", image_crossings="true")),   # no coefficients needed at all
+    ("sim_rk4", AUX_SIM),
+    ("formula_dp", AUX_ALL),
+    ("formula_absorb", dict(AUX_ALL, image_light="false", image_time="false")),
+    ("formula_flat", AUX_ALL),
+])
+def test_auxiliary_images_against_oracle(case, extra, built_library):
+    """Auxiliary images (unpolarized.cpp:113-196) on configurations beyond the golden one: HIP vs the CPU
+    oracle (itself bit-exact against the reference on the golden auxiliary case), every row bit-exact."""
+    import blacklight_amd as bl
+    from blacklight_amd import _capi
+    import oracle_api
+    fx, params, mock_args = gu.load_case(case)
+    params = dict(params)
+    params.update(extra)
+    p = bl.Params.from_dict(params)
+    grid = gu.golden_grid(mock_args) if mock_args is not None else None
+    with bl.Context(p) as ctx:
+        if grid is not None:
+            ctx.set_grid(grid)
+        got = ctx.render()
+    res = int(p.get("camera_resolution"))
+    want = oracle_api.render(p.ptr, grid.desc() if grid is not None else None, _capi.RenderDesc, _capi.CameraFrame,
+                             n_rays=res * res, max_steps=int(p.get("ray_max_steps")),
+                             n_freq=int(p.get("image_num_frequencies")))
+    assert np.array_equal(got["sample_num"], want["sample_num"])
+    assert np.array_equal(got["sample_flags"], want["sample_flags"])
+    assert got["image"].shape == want["image"].shape
+    same = gu.same_bits(got["image"], want["image"])
+    bad_rows = sorted(set(np.nonzero(~same)[0].tolist()))
+    assert same.all(), f"{(~same).sum()} values differ in rows {bad_rows}"
+
+
 def test_oracle_agreement_other_configuration(built_library):
     """Seeded variation away from the golden cases: HIP vs CPU oracle, bit-exact."""
     import blacklight_amd as bl

@@ -30,7 +30,7 @@ def test_camera_frame_and_frequencies(case, built_library):
         assert np.array_equal(np.array(getattr(frame, key)), fx[f"B_{key}"]), key
     assert np.array_equal(ctx.frequencies, fx["B_image_frequencies"])
     assert frame.mass_msun == float(fx["B_npz_mass_msun"][0])
-    assert ctx.num_quantities == int(p.get("image_num_frequencies"))
+    assert ctx.num_quantities == gu.expected_image(fx, "B", int(p.get("camera_resolution")) ** 2).shape[0]
 
 
 def test_host_only_context_cannot_render(built_library):

@@ -34,19 +34,7 @@ def _run(case, variant):
     return fx, p, out, res * res
 
 
-def _expected_rows(fx, tier, n_pix):
-    """All image rows in the reference's row order (radiation_integrator.cpp:436-520)."""
-    names = ["I_nu", "time", "length", "lambda", "emission", "tau", "lambda_ave_rho", "lambda_ave_n_e",
-             "lambda_ave_p_gas", "lambda_ave_Theta_e", "lambda_ave_B", "lambda_ave_sigma", "lambda_ave_beta_inverse",
-             "emission_ave_rho", "emission_ave_n_e", "emission_ave_p_gas", "emission_ave_Theta_e", "emission_ave_B",
-             "emission_ave_sigma", "emission_ave_beta_inverse", "tau_int_rho", "tau_int_n_e", "tau_int_p_gas",
-             "tau_int_Theta_e", "tau_int_B", "tau_int_sigma", "tau_int_beta_inverse", "crossings"]
-    rows = []
-    for name in names:
-        key = f"{tier}_npz_{name}"
-        if key in fx.files:
-            rows.append(fx[key].reshape(-1, n_pix))
-    return np.concatenate(rows, axis=0)
+_expected_rows = gu.expected_image
 
 
 @pytest.mark.parametrize("case", gu.CASES)
