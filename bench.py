@@ -90,6 +90,7 @@ def main():
     ap.add_argument("--resolution", type=int, default=1024)
     ap.add_argument("--grid", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scratch-gib", type=float, default=0.0, help="override the library's scratch budget (GiB); 0 = default")
     ap.add_argument("--cpu-stride", type=int, default=4, help="CPU baseline traces every stride-th pixel per axis")
     args = ap.parse_args()
 
@@ -120,6 +121,8 @@ def main():
 
     ctx = bl.Context(params, device=local_rank)
     ctx.set_grid(grid)          # staged into HBM once, outside the timed region
+    if args.scratch_gib > 0.0:
+        ctx.set_scratch_limit(int(args.scratch_gib * (1 << 30)))
 
     if args.mode == "tiled" and distributed:
         pixels = bd.tile_pixels(res, rank, world, TILE)

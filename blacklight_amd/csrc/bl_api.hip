@@ -80,7 +80,7 @@ struct bl_ctx {
   std::vector<hipEvent_t> events;     // kEventsPerChunk per chunk of the last render + one set-up event
   unsigned long long *host_counters = nullptr;   // pinned, (BL_CNT_COUNT + 4) per chunk
   size_t host_counters_chunks = 0;
-  uint64_t scratch_limit = 80ull << 30;
+  uint64_t scratch_limit = 144ull << 30;
   int overlap_chunks = 0;             // bl_set_overlap(): geodesic kernel of chunk c + 1 beside the shading of chunk c
 
   // image rows (radiation_integrator.cpp:436-520)
@@ -118,7 +118,8 @@ struct bl_ctx {
   };
   ChunkSlot slot[2];
   DeviceBuffer<double> d_freq;
-  DeviceBuffer<int> d_pixel_map, d_block_locs;
+  DeviceBuffer<int> d_pixel_map, d_block_locs, d_tile_order;
+  int tile_order_res = 0;
   DeviceBuffer<BlShadeCold> d_shade_cold;
   // host-output staging
   DeviceBuffer<double> d_image, d_camera_pos, d_camera_dir;
@@ -707,6 +708,29 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
     ta.n_rays_total = n_rays;
     ta.swizzle_tiles = (d->level == 0 && d->pixel_map == nullptr && p.camera_resolution % 8 == 0 && n_rays == level_pixels)
         ? p.camera_resolution : 0;
+    // Order in which the 8x8 pixel tiles of a full frame are traced: centre of the image first. Rays near
+    // the centre (photon ring, disc) are the long ones, the periphery is short; a chunk that ends on short
+    // rays drains its persistent waves quickly (measured: geodesic kernel 33.9 -> 29.4 ms per frame at four
+    // chunks), and waves of similar ray lengths also diverge less in the transfer kernel.
+    ta.tile_order = nullptr;
+    if (ta.swizzle_tiles > 0) {
+      if (ctx->tile_order_res != p.camera_resolution) {
+        const int tiles_per_row = p.camera_resolution / 8;
+        const int n_tiles = tiles_per_row * tiles_per_row;
+        std::vector<int> order(n_tiles);
+        for (int t = 0; t < n_tiles; t++) order[t] = t;
+        const double centre = 0.5 * (tiles_per_row - 1);
+        auto dist2 = [&](int t) {
+          double dy = t / tiles_per_row - centre, dx = t % tiles_per_row - centre;
+          return dx * dx + dy * dy;
+        };
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return dist2(a) < dist2(b); });
+        ctx->d_tile_order.Ensure(n_tiles);
+        Check(hipMemcpy(ctx->d_tile_order.ptr, order.data(), n_tiles * sizeof(int), hipMemcpyHostToDevice), "tile order upload");
+        ctx->tile_order_res = p.camera_resolution;
+      }
+      ta.tile_order = ctx->d_tile_order.ptr;
+    }
     ta.pixel_map = d_pixel_map;
     ta.block_locs = d_block_locs;
     ta.record_capacity = static_cast<long long>(record_capacity);
@@ -949,7 +973,7 @@ void bl_free(bl_ctx *ctx) {
   (void)hipSetDevice(ctx->device);
   ctx->d_cells.Free(); ctx->d_coords.Free(); ctx->d_buckets.Free(); ctx->slot[0].Free(); ctx->slot[1].Free();
   ctx->d_freq.Free(); ctx->d_pixel_map.Free();
-  ctx->d_block_locs.Free(); ctx->d_shade_cold.Free(); ctx->d_image.Free(); ctx->d_camera_pos.Free(); ctx->d_camera_dir.Free();
+  ctx->d_block_locs.Free(); ctx->d_tile_order.Free(); ctx->d_shade_cold.Free(); ctx->d_image.Free(); ctx->d_camera_pos.Free(); ctx->d_camera_dir.Free();
   ctx->d_out_sample_num.Free(); ctx->d_out_flags.Free();
   for (auto &e : ctx->events)
     if (e != nullptr) (void)hipEventDestroy(e);

@@ -143,6 +143,7 @@ struct BlTraceArgs {
   int chunk_rays;
   long long n_rays_total;
   int swizzle_tiles;          // >0: traversal order walks 8x8 pixel tiles of a swizzle_tiles-wide image
+  const int *tile_order;      // device [tiles of the image] or null: order in which the 8x8 tiles are traced
   const int *pixel_map;       // device, or null
   const int *block_locs;      // device, or null
   BlSampleRecord *records;

@@ -137,10 +137,10 @@ __device__ __forceinline__ void rhs(const BlSpacetime &st, const double y[8], do
 
 // Map a traversal index to the output (ray) index: walk 8x8 pixel tiles so that the 64 lanes of a
 // wave start as a compact patch of the image (similar path lengths, shared grid cells).
-__device__ __forceinline__ long long traversal_to_ray(long long q, int res) {
+__device__ __forceinline__ long long traversal_to_ray(long long q, int res, const int *tile_order) {
   if (res <= 0) return q;
   int tiles_per_row = res >> 3;
-  long long tile = q >> 6;
+  long long tile = tile_order != nullptr ? (long long)tile_order[q >> 6] : (q >> 6);
   int within = (int)(q & 63);
   long long tile_row = tile / tiles_per_row;
   int tile_col = (int)(tile % tiles_per_row);
@@ -196,7 +196,7 @@ __global__ void __launch_bounds__(64, 1) bl_geodesic_kernel(BlTraceArgs P) {
         } else {
           have_ray = true;
           slot = (unsigned int)q;
-          long long ray = traversal_to_ray(P.chunk_begin + (long long)q, P.swizzle_tiles);
+          long long ray = traversal_to_ray(P.chunk_begin + (long long)q, P.swizzle_tiles, P.tile_order);
           long long pixel = P.pixel_map != nullptr ? (long long)P.pixel_map[ray] : ray;
           double u_ind, v_ind, position[4], direction[4], factor;
           bl_pixel_indices(P.cam, pixel, P.block_locs, &u_ind, &v_ind);

@@ -227,7 +227,7 @@ BL_API int bl_set_grid(bl_ctx *ctx, const bl_grid_desc *g);
 BL_API int bl_image_num_quantities(const bl_ctx *ctx);
 BL_API int bl_camera_frame_get(const bl_ctx *ctx, bl_camera_frame *out);
 BL_API int bl_frequencies(const bl_ctx *ctx, double *out, int n);
-/* Cap on scratch HBM (bytes) used for per-sample records; default 80 GiB. */
+/* Cap on scratch HBM (bytes) used for per-sample records; default 144 GiB (half of the MI355X HBM). */
 BL_API int bl_set_scratch_limit(bl_ctx *ctx, uint64_t bytes);
 /* on != 0: when a render needs several chunks, run the geodesic kernel of chunk c + 1 on a second stream
  * beside the shading kernels of chunk c (two scratch sets of half the budget). Off by default: measured
