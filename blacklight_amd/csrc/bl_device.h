@@ -28,10 +28,11 @@
 // geodesics.cpp:250-293), before the per-sample momentum renormalisation of :352-371.
 struct alignas(16) BlSampleRecord {
   double x, y, z;     // position (CKS)
-  double kx, ky, kz;  // covariant spatial momentum, not yet renormalised
-  double len;         // affine step length as stored by the integrator (negative: camera -> source)
   uint32_t ray;       // chunk-local ray slot, 0xFFFFFFFF = dead slot (sample dropped by truncation)
   uint32_t n;         // sample index along the ray in integration order
+                      // (position and id are the first 32 bytes: all the locate kernel reads)
+  double kx, ky, kz;  // covariant spatial momentum, not yet renormalised
+  double len;         // affine step length as stored by the integrator (negative: camera -> source)
 };
 static_assert(sizeof(BlSampleRecord) == 64, "record must be 64 bytes");
 

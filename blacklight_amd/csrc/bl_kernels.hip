@@ -1113,7 +1113,7 @@ __global__ void __launch_bounds__(256, 4) bl_locate_kernel(const BlShadeArgs P) 
     const double *src = reinterpret_cast<const double *>(P.records + idx);
     nq0 = *reinterpret_cast<const double2 *>(src);
     nz = src[2];
-    nid = src[7];
+    nid = src[3];
   }
   while (more) {
     const unsigned long long at = idx;
@@ -1125,7 +1125,7 @@ __global__ void __launch_bounds__(256, 4) bl_locate_kernel(const BlShadeArgs P) 
       const double *src = reinterpret_cast<const double *>(P.records + idx);
       nq0 = *reinterpret_cast<const double2 *>(src);
       nz = src[2];
-      nid = src[7];
+      nid = src[3];
     }
     if (ray == BL_DEAD_RAY) continue;
     double r2;
@@ -1174,12 +1174,12 @@ __global__ void __launch_bounds__(256, 2) bl_shade_kernel(const BlShadeArgs P) {
   for (bool more = true; more;) {
     const unsigned long long idx_cur = idx;
     const double2 q0 = nq0, q1 = nq1, q2 = nq2, q3 = nq3, l0 = nl0, l1 = nl1, l2 = nl2;
-    const uint32_t ray = (uint32_t)__double_as_longlong(q3.y);
+    const uint32_t ray = (uint32_t)__double_as_longlong(q1.y);
     const bool live = ray != BL_DEAD_RAY;
-    const uint32_t n = (uint32_t)(((unsigned long long)__double_as_longlong(q3.y)) >> 32);
+    const uint32_t n = (uint32_t)(((unsigned long long)__double_as_longlong(q1.y)) >> 32);
     const double x1 = q0.x, x2 = q0.y, x3 = q1.x;
-    const double delta_lambda = -q3.x;   // ReverseGeodesics: sample_len = -geodesic_len (:840)
-    double kcov[4] = {0.0, q1.y, q2.x, q2.y};
+    const double delta_lambda = -q3.y;   // ReverseGeodesics: sample_len = -geodesic_len (:840)
+    double kcov[4] = {0.0, q2.x, q2.y, q3.x};
     double momentum_factor = 0.0;
     if (live) {
       kcov[0] = P.ray_kt[ray];
