@@ -621,8 +621,22 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
            + (aux ? sizeof(BlAuxSample) + sizeof(double) : 0)) + 64;
     // One chunk if the whole call fits the budget. With bl_set_overlap(): two scratch sets of half the budget
     // each, so that the geodesic kernel of chunk c + 1 runs while chunk c is being shaded.
-    long long chunk = static_cast<long long>(ctx->scratch_limit / per_ray);
-    if (chunk < n_rays && ctx->overlap_chunks) chunk = static_cast<long long>(ctx->scratch_limit / (2 * per_ray));
+    // The budget is also capped by what the device can actually give: 90 % of (free memory + the scratch
+    // this context already holds from earlier renders).
+    uint64_t budget = ctx->scratch_limit;
+    {
+      size_t free_bytes = 0, total_bytes = 0;
+      if (hipMemGetInfo(&free_bytes, &total_bytes) == hipSuccess) {
+        uint64_t held = 0;
+        for (const bl_ctx::ChunkSlot &sl : ctx->slot)
+          held += sl.d_records.count * sizeof(BlSampleRecord) + sl.d_located.count * sizeof(BlLocated)
+              + sl.d_transfer.count * sizeof(double2) + sl.d_aux.count * sizeof(BlAuxSample) + sl.d_sample_t.count * sizeof(double);
+        const uint64_t available = static_cast<uint64_t>(0.9 * static_cast<double>(free_bytes + held));
+        if (available < budget) budget = available;
+      }
+    }
+    long long chunk = static_cast<long long>(budget / per_ray);
+    if (chunk < n_rays && ctx->overlap_chunks) chunk = static_cast<long long>(budget / (2 * per_ray));
     chunk = std::max<long long>(chunk, 64);
     chunk = std::min<long long>(chunk, n_rays);
     if (chunk < n_rays) chunk = (chunk / 64) * 64;   // keep 8x8 tiles whole
