@@ -335,8 +335,10 @@ void ValidateRadiation(bl_ctx *ctx) {
     if (p.plasma_power_frac < 0.0 || p.plasma_power_frac > 1.0) Warn(ctx, "Fraction of power-law electrons outside [0, 1].");
     Require(p, {BL_P_plasma_kappa_frac}, kRadMissing);
     if (p.plasma_kappa_frac < 0.0 || p.plasma_kappa_frac > 1.0) Warn(ctx, "Fraction of kappa-distribution electrons outside [0, 1].");
-    if (p.plasma_power_frac != 0.0 || p.plasma_kappa_frac != 0.0)
-      throw Failure{BL_E_UNSUPPORTED, "Non-thermal electrons (plasma_power_frac / plasma_kappa_frac != 0) are not built yet."};
+    if (p.plasma_power_frac != 0.0) Require(p, {BL_P_plasma_p, BL_P_plasma_gamma_min, BL_P_plasma_gamma_max}, kRadMissing);
+    if (p.plasma_kappa_frac != 0.0)
+      throw Failure{BL_E_UNSUPPORTED, "Kappa-distribution electrons (plasma_kappa_frac != 0) are not built: the reference's unpolarized "
+                                      "absorptivity reads kappa_aa_high_i, which it only initialises for polarized runs."};
     ctx->plasma_thermal_frac = 1.0 - (p.plasma_power_frac + p.plasma_kappa_frac);
     if (ctx->plasma_thermal_frac < 0.0 || ctx->plasma_thermal_frac > 1.0) Warn(ctx, "Fraction of thermal electrons outside [0, 1].");
     Require(p, {BL_P_cut_rho_min, BL_P_cut_rho_max, BL_P_cut_n_e_min, BL_P_cut_n_e_max, BL_P_cut_p_gas_min,
@@ -781,6 +783,24 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
       pl.plasma_rat_low = p.plasma_rat_low;
       pl.plasma_rat_high = p.plasma_rat_high;
       pl.plasma_thermal_frac = ctx->plasma_thermal_frac;
+      pl.power_frac = p.plasma_power_frac;
+      pl.plasma_p = 0.0;
+      pl.power_jj = pl.power_aa = 0.0;
+      if (p.plasma_power_frac != 0.0) {
+        // simulation_coefficients.cpp:54-66 (unpolarized part); pow is the pinned one, tgamma the host libm's
+        const double plasma_p = p.plasma_p;
+        const double var_a = bl_pow(3.0, plasma_p / 2.0) * (plasma_p - 1.0);
+        const double var_b = 2.0 * (plasma_p + 1.0);
+        const double var_c = bl_pow(p.plasma_gamma_min, 1.0 - plasma_p) - bl_pow(p.plasma_gamma_max, 1.0 - plasma_p);
+        const double var_d = std::tgamma((3.0 * plasma_p - 1.0) / 12.0);
+        const double var_e = std::tgamma((3.0 * plasma_p + 19.0) / 12.0);
+        const double var_f = bl_pow(3.0, (plasma_p + 1.0) / 2.0) * (plasma_p - 1.0) / 4.0;
+        const double var_g = std::tgamma((3.0 * plasma_p + 2.0) / 12.0);
+        const double var_h = std::tgamma((3.0 * plasma_p + 22.0) / 12.0);
+        pl.plasma_p = plasma_p;
+        pl.power_jj = var_a / var_b / var_c * var_d * var_e;
+        pl.power_aa = var_f / var_c * var_g * var_h;
+      }
       cold.plasma_gamma = ctx->grid_meta.plasma_gamma;
       cold.plasma_gamma_i = ctx->grid_meta.plasma_gamma_i;
       cold.plasma_gamma_e = ctx->grid_meta.plasma_gamma_e;

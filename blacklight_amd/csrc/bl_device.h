@@ -83,6 +83,8 @@ struct BlPlasmaDevice {
   int simulation_coord;
   int fallback_nan;
   int any_cell_cut;          // some cell cut threshold (simulation_coefficients.cpp:361-375) is >= 0
+  // power-law electrons (simulation_coefficients.cpp:54-66, :556-584); power_frac = 0: none
+  double power_frac, plasma_p, power_jj, power_aa;
 };
 
 // Rarely used parameters of the shading kernel (optional geometric cuts, cell cut thresholds,

@@ -1153,7 +1153,9 @@ __global__ void __launch_bounds__(256, 4) bl_locate_kernel(const BlShadeArgs P) 
 // kAux (any auxiliary image requested, unpolarized.cpp:113-173): the per-frequency pairs written are
 // (j_nu, alpha_nu) instead of (a, b), and one BlAuxSample per sample goes with them; the auxiliary
 // transfer kernel integrates everything. Kept out of the instantiations the benchmark path runs.
-template <int kModel, bool kAux>
+// kPowerLaw: power-law electrons present (simulation_coefficients.cpp:556-584): two more pow() per
+// sample and frequency; its own instantiation so that the thermal-only kernel keeps its registers.
+template <int kModel, bool kAux, bool kPowerLaw>
 __global__ void __launch_bounds__(256, 2) bl_shade_kernel(const BlShadeArgs P) {
   const BlSpacetime st = P.st;
   const unsigned long long n_records = P.counters_in[BL_CNT_RECORDS];
@@ -1313,6 +1315,15 @@ __global__ void __launch_bounds__(256, 2) bl_shade_kernel(const BlShadeArgs P) {
           // x <= 2^-1024 (the next double above, 2^-1024 + 2^-1074, gives 2^1024 - 2^974 < DBL_MAX + ulp/2);
           // NaN fails both tests. One compare instead of a division.
           if (alpha_val * alpha_val <= 0x1p-1024) alpha_val = 0.0;
+        }
+        if (kPowerLaw && P.plasma.power_frac != 0.0) {
+          // power-law electrons, unpolarized (simulation_coefficients.cpp:556-584)
+          const double ratio = nu_cgs / (sh.nu_c_cgs * sh.sin_theta_b);
+          const double var_a_j = bl_pow(ratio, -(P.plasma.plasma_p - 1.0) / 2.0);
+          j_val += P.plasma.power_frac * sh.n_e_cgs * kE * kE * sh.nu_c_cgs / (kC * nu_2_cgs) * P.plasma.power_jj
+              * sh.sin_theta_b * var_a_j;
+          const double var_a_a = bl_pow(ratio, -(P.plasma.plasma_p + 2.0) / 2.0);
+          alpha_val += P.plasma.power_frac * sh.n_e_cgs * kE * kE / (kMe * kC) * P.plasma.power_aa * var_a_a;
         }
       } else if (sh.have_coefficients && kModel == BL_MODEL_FORMULA) {
         // formula_coefficients.cpp:164-179
@@ -1550,13 +1561,18 @@ extern "C" hipError_t bl_launch_locate(const BlShadeArgs *args, int grid, int ld
 // Coefficient kernel
 extern "C" hipError_t bl_launch_shade(const BlShadeArgs *args, int model, int grid, hipStream_t stream) {
   const bool aux = args->aux != nullptr;
+  const bool power = args->plasma.power_frac != 0.0;
+#define BL_LAUNCH_S(M, A, W) hipLaunchKernelGGL((bl_shade_kernel<M, A, W>), dim3(grid), dim3(256), 0, stream, *args)
   if (model == BL_MODEL_SIMULATION) {
-    if (aux) hipLaunchKernelGGL((bl_shade_kernel<BL_MODEL_SIMULATION, true>), dim3(grid), dim3(256), 0, stream, *args);
-    else hipLaunchKernelGGL((bl_shade_kernel<BL_MODEL_SIMULATION, false>), dim3(grid), dim3(256), 0, stream, *args);
+    if (aux && power) BL_LAUNCH_S(BL_MODEL_SIMULATION, true, true);
+    else if (aux) BL_LAUNCH_S(BL_MODEL_SIMULATION, true, false);
+    else if (power) BL_LAUNCH_S(BL_MODEL_SIMULATION, false, true);
+    else BL_LAUNCH_S(BL_MODEL_SIMULATION, false, false);
   } else {
-    if (aux) hipLaunchKernelGGL((bl_shade_kernel<BL_MODEL_FORMULA, true>), dim3(grid), dim3(256), 0, stream, *args);
-    else hipLaunchKernelGGL((bl_shade_kernel<BL_MODEL_FORMULA, false>), dim3(grid), dim3(256), 0, stream, *args);
+    if (aux) BL_LAUNCH_S(BL_MODEL_FORMULA, true, false);
+    else BL_LAUNCH_S(BL_MODEL_FORMULA, false, false);
   }
+#undef BL_LAUNCH_S
   return hipGetLastError();
 }
 

@@ -95,6 +95,7 @@ struct Oracle {
       image_offset_crossings;
   bool image_polarization;  // forced false in formula mode
   double plasma_thermal_frac;
+  double power_jj = 0.0, power_aa = 0.0;   // simulation_coefficients.cpp:54-66
 };
 
 bool need(const bl_params *p, int index) { return p->has[index] != 0; }
@@ -1429,6 +1430,19 @@ void SimulationCoefficientsOne(const Oracle &o, const double pos[4], const doubl
           and 1.0 / (alpha[l * stride] * alpha[l * stride]) == std::numeric_limits<double>::infinity())
         alpha[l * stride] = 0.0;
     }
+    // power-law electrons (:556-584, unpolarized part)
+    if (p.plasma_power_frac != 0.0 and (p.image_light or p.image_emission or p.image_emission_ave)) {
+      double var_a = M::pow(nu_cgs / (nu_c_cgs * sin_theta_b), -(p.plasma_p - 1.0) / 2.0);
+      double coefficient = p.plasma_power_frac * n_e_cgs * Physics::e * Physics::e * nu_c_cgs
+          / (Physics::c * nu_2_cgs) * o.power_jj * sin_theta_b * var_a;
+      j[l * stride] += coefficient;
+    }
+    if (p.plasma_power_frac != 0.0 and (p.image_light or p.image_tau or p.image_tau_int)) {
+      double var_a = M::pow(nu_cgs / (nu_c_cgs * sin_theta_b), -(p.plasma_p + 2.0) / 2.0);
+      double coefficient = p.plasma_power_frac * n_e_cgs * Physics::e * Physics::e
+          / (Physics::m_e * Physics::c) * o.power_aa * var_a;
+      alpha[l * stride] += coefficient;
+    }
   }
 }
 
@@ -1638,9 +1652,22 @@ int Setup(Oracle &o, const bl_params *p, const bl_grid_desc *g, char *err, size_
     if (g->n_blocks != 1) return Fail(err, err_len, "oracle: multi-block grids not restated yet", BL_E_UNSUPPORTED);
     if (p->slow_light_on) return Fail(err, err_len, "oracle: slow light not restated yet", BL_E_UNSUPPORTED);
     if (p->simulation_coord == BL_COORD_FMKS) return Fail(err, err_len, "oracle: fmks not restated yet", BL_E_UNSUPPORTED);
-    if (p->plasma_power_frac != 0.0 or p->plasma_kappa_frac != 0.0)
-      return Fail(err, err_len, "oracle: non-thermal electrons not restated yet", BL_E_UNSUPPORTED);
+    if (p->plasma_kappa_frac != 0.0)
+      return Fail(err, err_len, "oracle: kappa-distribution electrons not restated (the reference reads the uninitialised kappa_aa_high_i)", BL_E_UNSUPPORTED);
     o.plasma_thermal_frac = 1.0 - (p->plasma_power_frac + p->plasma_kappa_frac);
+    if (p->plasma_power_frac != 0.0) {  // simulation_coefficients.cpp:54-66 (unpolarized part)
+      double plasma_p = p->plasma_p;
+      double var_a = M::pow(3.0, plasma_p / 2.0) * (plasma_p - 1.0);
+      double var_b = 2.0 * (plasma_p + 1.0);
+      double var_c = M::pow(p->plasma_gamma_min, 1.0 - plasma_p) - M::pow(p->plasma_gamma_max, 1.0 - plasma_p);
+      double var_d = std::tgamma((3.0 * plasma_p - 1.0) / 12.0);
+      double var_e = std::tgamma((3.0 * plasma_p + 19.0) / 12.0);
+      double var_f = M::pow(3.0, (plasma_p + 1.0) / 2.0) * (plasma_p - 1.0) / 4.0;
+      double var_g = std::tgamma((3.0 * plasma_p + 2.0) / 12.0);
+      double var_h = std::tgamma((3.0 * plasma_p + 22.0) / 12.0);
+      o.power_jj = var_a / var_b / var_c * var_d * var_e;
+      o.power_aa = var_f / var_c * var_g * var_h;
+    }
   } else
     o.plasma_thermal_frac = 0.0;
   ImageOffsets(o);

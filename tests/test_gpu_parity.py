@@ -108,6 +108,10 @@ AUX_SIM = dict(AUX_ALL, image_lambda_ave="true", image_emission_ave="true", imag
     ("sim_cuts", dict(AUX_SIM, image_light="false")),              # no image_light: j, alpha read as NaN where unused
     ("sim_spin_fallback", dict(image_lambda_ave="true", image_crossings="true")),   # no coefficients needed at all
     ("sim_rk4", AUX_SIM),
+    ("sim_powerlaw", AUX_SIM),                                     # thermal + power-law electrons
+    ("sim_powerlaw", dict(plasma_power_frac=1.0)),                 # power-law electrons only (no thermal part, theta_e NaN)
+    ("sim_powerlaw", dict(plasma_power_frac=0.5, plasma_p=3.5, plasma_gamma_min=10.0, plasma_gamma_max=1.0e5,
+                          image_tau="true", image_light="false")),
     ("formula_dp", AUX_ALL),
     ("formula_absorb", dict(AUX_ALL, image_light="false", image_time="false")),
     ("formula_flat", AUX_ALL),

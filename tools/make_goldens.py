@@ -98,6 +98,8 @@ CASES = {
                                 cut_rho_min=1.0e-19, cut_b_max=1.0e3, cut_beta_inverse_max=5.0), SMALL_MOCK, [300]),
     "sim_few_steps": (SIM_BASE, dict(camera_resolution=16, ray_max_steps=450), SMALL_MOCK, [136]),
     "sim_pole": (SIM_BASE, dict(camera_resolution=16, camera_th=0.0), SMALL_MOCK, [136]),
+    "sim_powerlaw": (SIM_BASE, dict(camera_resolution=24, plasma_power_frac=0.3, plasma_p=2.5, plasma_gamma_min=1.0,
+                                    plasma_gamma_max=1000.0), SMALL_MOCK, [300]),
     "sim_aux_images": (SIM_BASE, dict(camera_resolution=16, image_time="true", image_length="true",
                                       image_lambda="true", image_emission="true", image_tau="true",
                                       image_lambda_ave="true", image_emission_ave="true", image_tau_int="true",
