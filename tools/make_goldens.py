@@ -278,10 +278,67 @@ def make_mock_fixture():
     print("mock fixtures written")
 
 
+# Windows of the 1024^2 benchmark frame (bench.py WORKLOAD = SIM_BASE at camera_resolution = 1024 over the
+# 256^3 mock) computed by the unmodified reference: a 256^2 base camera with forced adaptive refinement to
+# level 2 (adaptive_region_*, radiation_adaptive.cpp:52-69) evaluates exactly the pixels of the 1024^2
+# lattice that lie in the refined blocks. A block is refined when its CENTRE lies inside a
+# region; level-0 block b (16 px of 256) is centred at -11.25 + 1.5 b, its level-1 children at +-0.375 from
+# that. Each region below holds one level-0 centre and one of its level-1 children, i.e. it yields four
+# level-2 blocks = a 32 x 32 window of the 1024^2 lattice. Three windows: photon ring, disc, periphery.
+def _window(bx, by):
+    cx, cy = -11.25 + 1.5 * bx, -11.25 + 1.5 * by
+    return (cx - 0.1, cx + 0.5, cy - 0.1, cy + 0.5)
+
+
+WINDOW_REGIONS = [_window(10, 10), _window(3, 7), _window(14, 14)]
+
+
+def make_window_fixture():
+    name = "window_1024"
+    mock = dict(n_r=256, n_th=256, n_ph=256)
+    params = dict(SIM_BASE)
+    params.update(camera_resolution=256, checkpoint_geodesic_save="false", adaptive_max_level=2, adaptive_block_size=16,
+                  adaptive_frequency_num=0, adaptive_val_cut=0.0, adaptive_val_frac=-1.0, adaptive_abs_grad_cut=0.0,
+                  adaptive_abs_grad_frac=-1.0, adaptive_rel_grad_cut=0.0, adaptive_rel_grad_frac=-1.0,
+                  adaptive_abs_lapl_cut=0.0, adaptive_abs_lapl_frac=-1.0, adaptive_rel_lapl_cut=0.0,
+                  adaptive_rel_lapl_frac=-1.0, adaptive_num_regions=len(WINDOW_REGIONS), output_camera="false")
+    for r, (x0, x1, y0, y1) in enumerate(WINDOW_REGIONS, start=1):
+        params[f"adaptive_region_{r}_level"] = 2
+        params[f"adaptive_region_{r}_x_min"] = x0
+        params[f"adaptive_region_{r}_x_max"] = x1
+        params[f"adaptive_region_{r}_y_min"] = y0
+        params[f"adaptive_region_{r}_y_max"] = y1
+    workdir = os.path.join(WORK, name)
+    os.makedirs(os.path.join(workdir, "data"), exist_ok=True)
+    os.makedirs(os.path.join(workdir, "output"), exist_ok=True)
+    mock_path = os.path.join(workdir, "data", "mock.athdf")
+    if not os.path.exists(mock_path):
+        args = [sys.executable, "-W", "ignore", MOCK_SCRIPT, mock_path]
+        for key, value in mock.items():
+            args += [f"--{key}", str(value)]
+        subprocess.run(args, check=True)
+    write_input(os.path.join(workdir, "case.input"), params)
+    bench_params = {k: v for k, v in SIM_BASE.items() if k not in ("checkpoint_geodesic_save", "checkpoint_geodesic_file")}
+    bench_params.update(camera_resolution=1024, checkpoint_geodesic_save="false")
+    fixture = dict(mock_args=json.dumps(mock), params=json.dumps(bench_params), reference_params=json.dumps(params))
+    for tier, preload in (("A", False), ("B", True)):
+        fixture[f"{tier}_warnings"] = run_reference(workdir, "case.input", preload)
+        npz = np.load(os.path.join(workdir, "output", "out.npz"))
+        fixture[f"{tier}_block_locs"] = npz["adaptive_block_locs_2"]
+        fixture[f"{tier}_I_nu"] = npz["adaptive_I_nu_2"]
+        print(tier, "level-2 blocks", npz["adaptive_block_locs_2"].shape, "I_nu", npz["adaptive_I_nu_2"].shape)
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **fixture)
+    a, b = fixture["A_I_nu"], fixture["B_I_nu"]
+    print(f"{name}: A-vs-B max rel {np.nanmax(np.abs(a - b)) / np.nanmax(np.abs(b)):.2e}, blocks equal "
+          f"{np.array_equal(fixture['A_block_locs'], fixture['B_block_locs'])}")
+
+
 if __name__ == "__main__":
     names = sys.argv[1:] or (["mock"] + list(CASES))
     for case_name in names:
         if case_name == "mock":
             make_mock_fixture()
+        elif case_name == "window_1024":
+            make_window_fixture()
         else:
             make_case(case_name)
