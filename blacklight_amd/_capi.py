@@ -92,6 +92,7 @@ def lib():
     L.bl_frequencies.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int]
     L.bl_set_scratch_limit.argtypes = [C.c_void_p, C.c_uint64]
     L.bl_set_overlap.argtypes = [C.c_void_p, C.c_int]
+    L.bl_debug_math.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
     L.bl_render.argtypes = [C.c_void_p, C.POINTER(RenderDesc)]
     L.bl_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
     L.bl_last_error.argtypes = [C.c_void_p]

@@ -77,6 +77,18 @@ class Context:
     def set_scratch_limit(self, nbytes):
         self._check(self._lib.bl_set_scratch_limit(self._ctx, int(nbytes)))
 
+    def debug_math(self, op, x, y=None):
+        """Apply device math function `op` (see bl_debug_math in the header) element-wise; returns float64 array."""
+        import numpy as np
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        out = np.empty_like(x)
+        yp = None
+        if y is not None:
+            y = np.ascontiguousarray(y, dtype=np.float64)
+            yp = y.ctypes.data
+        self._check(self._lib.bl_debug_math(self._ctx, int(op), x.size, x.ctypes.data, yp, out.ctypes.data))
+        return out
+
     def set_overlap(self, on):
         """Overlap the geodesic kernel of the next chunk with the shading of the current one."""
         self._check(self._lib.bl_set_overlap(self._ctx, 1 if on else 0))

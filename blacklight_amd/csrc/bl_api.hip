@@ -27,6 +27,7 @@ extern "C" hipError_t bl_launch_locate(const BlShadeArgs *args, int grid, int ld
 extern "C" hipError_t bl_launch_shade(const BlShadeArgs *args, int model, int grid, hipStream_t stream);
 extern "C" hipError_t bl_launch_transfer(const BlTransferArgs *args, hipStream_t stream);
 extern "C" hipError_t bl_launch_transfer_aux(const BlTransferArgs *args, hipStream_t stream);
+extern "C" hipError_t bl_launch_debug_math(int op, long long n, const double *x, const double *y, double *out, hipStream_t stream);
 
 namespace {
 
@@ -982,6 +983,31 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
     // Warning text of the reference (geodesics.cpp:389-394)
     if (total_flagged > 0)
       Warn(ctx, std::to_string(total_flagged) + " out of " + std::to_string(n_rays) + " geodesics terminate unexpectedly.");
+  } catch (const Failure &failure) {
+    return Fail(ctx, failure);
+  }
+  return BL_OK;
+}
+
+int bl_debug_math(bl_ctx *ctx, int op, int64_t n, const double *x, const double *y, double *out) {
+  if (ctx == nullptr || x == nullptr || out == nullptr || n <= 0) return BL_E_ARG;
+  try {
+    if (ctx->device == BL_DEVICE_NONE) throw Failure{BL_E_DEVICE, "Host-only context: no HIP device selected."};
+    Check(hipSetDevice(ctx->device), "hipSetDevice");
+    EnsureStreams(ctx);
+    DeviceBuffer<double> dx, dy, dout;
+    dx.Ensure(n);
+    dout.Ensure(n);
+    Check(hipMemcpy(dx.ptr, x, n * sizeof(double), hipMemcpyHostToDevice), "upload");
+    if (y != nullptr) {
+      dy.Ensure(n);
+      Check(hipMemcpy(dy.ptr, y, n * sizeof(double), hipMemcpyHostToDevice), "upload");
+    }
+    hipError_t err = bl_launch_debug_math(op, n, dx.ptr, y != nullptr ? dy.ptr : nullptr, dout.ptr, ctx->stream);
+    if (err == hipSuccess) err = hipStreamSynchronize(ctx->stream);
+    if (err == hipSuccess) err = hipMemcpy(out, dout.ptr, n * sizeof(double), hipMemcpyDeviceToHost);
+    dx.Free(); dy.Free(); dout.Free();
+    Check(err, "bl_debug_math");
   } catch (const Failure &failure) {
     return Fail(ctx, failure);
   }

@@ -1515,6 +1515,37 @@ __global__ void __launch_bounds__(64) bl_transfer_aux_kernel(BlTransferArgs P) {
   }
 }
 
+// Diagnostics: apply one device math function element-wise (bl_debug_math). Lets the tests compare the
+// device build of blmath.h and the exact-arithmetic devices of bl_geometry.h with the host, bit for bit.
+__global__ void bl_debug_math_kernel(int op, long long n, const double *x, const double *y, double *out) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double a = x[i], b = y != nullptr ? y[i] : 0.0;
+  double r = 0.0, s_unused, c_unused;
+  switch (op) {
+    case 0: r = bl_exp(a); break;
+    case 1: r = bl_expm1(a); break;
+    case 2: r = bl_log(a); break;
+    case 3: r = bl_cbrt(a); break;
+    case 4: r = bl_sin(a); break;
+    case 5: r = bl_cos(a); break;
+    case 6: r = bl_acos(a); break;
+    case 7: r = bl_atan(a); break;
+    case 8: r = bl_atan2(a, b); break;
+    case 9: r = bl_pow(a, b); break;
+    case 10: r = bl_hypot(a, b); break;
+    case 11: r = bl_hypot_g(a, b); break;
+    case 12: r = bl_sqrt_g(a); break;
+    case 13: r = bl_div_g(a, b); break;
+    case 14: r = blm_sqrt(a); break;
+    case 15: r = a / b; break;
+    case 16: bl_sincos(a, &r, &c_unused); break;
+    case 17: bl_sincos(a, &s_unused, &r); break;
+    default: break;
+  }
+  out[i] = r;
+}
+
 // =================================================================================================
 // Launch wrappers (called from bl_api.hip)
 // =================================================================================================
@@ -1573,6 +1604,12 @@ extern "C" hipError_t bl_launch_shade(const BlShadeArgs *args, int model, int gr
     else BL_LAUNCH_S(BL_MODEL_FORMULA, false, false);
   }
 #undef BL_LAUNCH_S
+  return hipGetLastError();
+}
+
+extern "C" hipError_t bl_launch_debug_math(int op, long long n, const double *x, const double *y, double *out, hipStream_t stream) {
+  int grid = (int)((n + 255) / 256);
+  hipLaunchKernelGGL(bl_debug_math_kernel, dim3(grid), dim3(256), 0, stream, op, n, x, y, out);
   return hipGetLastError();
 }
 

@@ -234,6 +234,12 @@ BL_API int bl_set_scratch_limit(bl_ctx *ctx, uint64_t bytes);
  * on MI355X it changes the frame time by less than 1 %, and per-kernel times are cleaner off. */
 BL_API int bl_set_overlap(bl_ctx *ctx, int on);
 BL_API int bl_render(bl_ctx *ctx, const bl_render_desc *d);
+/* Diagnostics (not part of the reference's interface): apply one device math function element-wise to
+ * host arrays x (and y for two-argument functions; may be NULL otherwise) and return the results in out.
+ * op: 0 exp, 1 expm1, 2 log, 3 cbrt, 4 sin, 5 cos, 6 acos, 7 atan, 8 atan2(x, y), 9 pow(x, y),
+ * 10 hypot (blmath.h), 11 bl_hypot_g, 12 bl_sqrt_g, 13 bl_div_g(x, y) (bl_geometry.h), 14 sqrt, 15 x / y,
+ * 16 sincos -> sin, 17 sincos -> cos. Used by the tests to compare the device arithmetic with the host's. */
+BL_API int bl_debug_math(bl_ctx *ctx, int op, int64_t n, const double *x, const double *y, double *out);
 BL_API int bl_get_stats(const bl_ctx *ctx, bl_stats *out);
 /* Text of the last failure on this context ("Error: ...\n"), or "" */
 BL_API const char *bl_last_error(const bl_ctx *ctx);
