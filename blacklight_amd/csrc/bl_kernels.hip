@@ -1349,20 +1349,26 @@ __global__ void __launch_bounds__(256, 2) bl_shade_kernel(const BlShadeArgs P) {
 // Transfer kernel
 // =================================================================================================
 __global__ void __launch_bounds__(256) bl_transfer_kernel(BlTransferArgs P) {
-  int slot = blockIdx.x * blockDim.x + threadIdx.x;
+  // One lane per (ray, frequency): consecutive lanes are the frequencies of one ray, whose records of a
+  // sample are contiguous, so multi-frequency loads coalesce and the parallelism grows with n_nu.
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int slot = (int)(t / P.n_nu);
+  const int l = (int)(t % P.n_nu);
   unsigned long long samples = 0ull, flagged = 0ull;
   int max_num = 0;
   if (slot < P.chunk_rays) {
     int num = P.ray_sample_num[slot];
     bool flag = P.ray_flags[slot] != 0;
     long long out_index = P.ray_out_index[slot];
-    samples = (unsigned long long)num;
-    flagged = flag ? 1ull : 0ull;
-    max_num = num;
-    if (P.out_sample_num != nullptr) P.out_sample_num[out_index] = num;
-    if (P.out_flags != nullptr) P.out_flags[out_index] = flag ? 1 : 0;
+    if (l == 0) {
+      samples = (unsigned long long)num;
+      flagged = flag ? 1ull : 0ull;
+      max_num = num;
+      if (P.out_sample_num != nullptr) P.out_sample_num[out_index] = num;
+      if (P.out_flags != nullptr) P.out_flags[out_index] = flag ? 1 : 0;
+    }
     const double nan = __longlong_as_double(0x7ff8000000000000ll);
-    for (int l = 0; l < P.n_nu; l++) {
+    {
       double intensity = 0.0;
       if (P.fallback_nan && flag) {
         // simulation: every sample of a flagged ray carries NaN primitives
@@ -1620,7 +1626,7 @@ extern "C" hipError_t bl_launch_transfer_aux(const BlTransferArgs *args, hipStre
 }
 
 extern "C" hipError_t bl_launch_transfer(const BlTransferArgs *args, hipStream_t stream) {
-  int grid = (args->chunk_rays + 255) / 256;
+  int grid = (int)(((long long)args->chunk_rays * args->n_nu + 255) / 256);
   hipLaunchKernelGGL(bl_transfer_kernel, dim3(grid), dim3(256), 0, stream, *args);
   return hipGetLastError();
 }
