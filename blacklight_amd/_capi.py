@@ -37,7 +37,7 @@ class RenderDesc(C.Structure):
         ("level", C.c_int32), ("n_blocks", C.c_int32), ("block_locs", C.c_void_p),
         ("n_rays", C.c_int64), ("pixel_map", C.c_void_p), ("outputs_on_device", C.c_int32),
         ("image", C.c_void_p), ("sample_num", C.c_void_p), ("sample_flags", C.c_void_p),
-        ("camera_pos", C.c_void_p), ("camera_dir", C.c_void_p),
+        ("camera_pos", C.c_void_p), ("camera_dir", C.c_void_p), ("render", C.c_void_p),
     ]
 
 
@@ -45,7 +45,8 @@ BL_MAX_LEVELS = 16
 
 
 class OutputLevel(C.Structure):
-    _fields_ = [("n_blocks", C.c_int32), ("block_locs", C.c_void_p), ("image", C.c_void_p), ("camera", C.c_void_p)]
+    _fields_ = [("n_blocks", C.c_int32), ("block_locs", C.c_void_p), ("image", C.c_void_p), ("camera", C.c_void_p),
+                ("render", C.c_void_p)]
 
 
 class OutputDesc(C.Structure):

@@ -53,6 +53,10 @@ class Context:
         return self._lib.bl_image_num_quantities(self._ctx)
 
     @property
+    def num_render_images(self):
+        return self._lib.bl_render_num_images(self._ctx)
+
+    @property
     def camera_frame(self):
         frame = _capi.CameraFrame()
         self._check(self._lib.bl_camera_frame_get(self._ctx, C.byref(frame)))
@@ -141,9 +145,14 @@ class Context:
             camera_dir = np.empty((n_rays, 4))
             d.camera_pos = camera_pos.ctypes.data_as(C.c_void_p)
             d.camera_dir = camera_dir.ctypes.data_as(C.c_void_p)
+        rendering = None
+        n_render = self.num_render_images
+        if n_render > 0:
+            rendering = np.empty((n_render, 3, n_rays))
+            d.render = rendering.ctypes.data_as(C.c_void_p)
         self._check(self._lib.bl_render(self._ctx, C.byref(d)))
         return dict(image=image, sample_num=sample_num, sample_flags=sample_flags,
-                    camera_pos=camera_pos, camera_dir=camera_dir, stats=self.stats)
+                    camera_pos=camera_pos, camera_dir=camera_dir, rendering=rendering, stats=self.stats)
 
     # ------------------------------------------------------------------ host steps of the reference loop
     def adaptive_refine(self, level, image, block_locs=None):
@@ -201,6 +210,10 @@ class Context:
                 keep.append(bl)
                 d.level[index].n_blocks = bl.shape[0]
                 d.level[index].block_locs = bl.ctypes.data_as(C.c_void_p)
+            if lv.get("rendering") is not None:
+                rendering = np.ascontiguousarray(lv["rendering"], dtype=np.float64)
+                keep.append(rendering)
+                d.level[index].render = rendering.ctypes.data_as(C.c_void_p)
             camera = lv.get("camera_pos") if plane else lv.get("camera_dir")
             if camera is not None:
                 camera = np.ascontiguousarray(camera, dtype=np.float64)

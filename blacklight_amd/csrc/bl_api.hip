@@ -86,7 +86,10 @@ struct bl_ctx {
 
   // image rows (radiation_integrator.cpp:436-520)
   int image_num_quantities = 0;
-  BlAuxImages aux_images{};          // which image rows exist; .any = an auxiliary image is requested
+  BlAuxImages aux_images{};          // which image rows exist; .any = an auxiliary image or a rendering is requested
+  int render_num_images = 0;         // false-colour renderings (0 in formula mode)
+  DeviceBuffer<BlRenderDevice> d_render_params;
+  DeviceBuffer<double> d_render;     // staging for host output
   double plasma_thermal_frac = 0.0;
 
   // grid
@@ -296,8 +299,24 @@ void ValidateRadiation(bl_ctx *ctx) {
   if (!(p.image_light || p.image_time || p.image_length || p.image_lambda || p.image_emission || p.image_tau
         || p.image_lambda_ave || p.image_emission_ave || p.image_tau_int || p.image_crossings || render_num_images > 0))
     throw Failure{BL_E_INPUT, "No image or rendering selected."};
-  if (render_num_images > 0)
-    throw Failure{BL_E_UNSUPPORTED, "False-colour rendering (render_num_images > 0) is outside the hot-path scope."};
+  // rendering parameters (radiation_integrator.cpp:146-197): every value the features need must be present
+  ctx->render_num_images = render_num_images;
+  for (int n_i = 0; n_i < render_num_images; n_i++) {
+    if (!p.render_num_features_has[n_i]) throw Failure{BL_E_MISSING, kRadMissing};
+    const int num_features = p.render_num_features[n_i];
+    if (num_features <= 0) throw Failure{BL_E_INPUT, "Must have positive number of features for each rendered image."};
+    for (int n_f = 0; n_f < num_features; n_f++) {
+      const int has = p.render_has[n_i][n_f];
+      int need = BL_RENDER_HAS_QUANTITY | BL_RENDER_HAS_TYPE | BL_RENDER_HAS_XYZ;
+      if ((has & BL_RENDER_HAS_TYPE) != 0) {
+        if (p.render_type[n_i][n_f] == BL_RENDER_FILL)
+          need |= BL_RENDER_HAS_MIN | BL_RENDER_HAS_MAX | BL_RENDER_HAS_TAU_SCALE;
+        else
+          need |= BL_RENDER_HAS_THRESH | BL_RENDER_HAS_OPACITY;
+      }
+      if ((has & need) != need) throw Failure{BL_E_MISSING, kRadMissing};
+    }
+  }
   if (polarization)
     throw Failure{BL_E_UNSUPPORTED, "image_polarization = true (polarized transfer) is not built yet."};
   if (simulation) {
@@ -395,7 +414,7 @@ void ValidateRadiation(bl_ctx *ctx) {
   if (A.image_crossings) n_q += 1;
   A.n_q = n_q;
   A.any = (A.image_time || A.image_length || A.image_lambda || A.image_emission || A.image_tau || A.image_lambda_ave
-           || A.image_emission_ave || A.image_tau_int || A.image_crossings) ? 1 : 0;
+           || A.image_emission_ave || A.image_tau_int || A.image_crossings || ctx->render_num_images > 0) ? 1 : 0;
   ctx->image_num_quantities = n_q;
 }
 
@@ -565,6 +584,8 @@ int bl_set_grid(bl_ctx *ctx, const bl_grid_desc *g) {
   return BL_OK;
 }
 
+int bl_render_num_images(const bl_ctx *ctx) { return ctx != nullptr ? ctx->render_num_images : 0; }
+
 int bl_image_num_quantities(const bl_ctx *ctx) { return ctx != nullptr ? ctx->image_num_quantities : -1; }
 
 int bl_camera_frame_get(const bl_ctx *ctx, bl_camera_frame *out) {
@@ -598,7 +619,9 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
     const bool simulation = p.model_type == BL_MODEL_SIMULATION;
     if (ctx->device == BL_DEVICE_NONE) throw Failure{BL_E_DEVICE, "Host-only context: no HIP device selected (the hot path has no CPU fallback)."};
     if (simulation && !ctx->have_grid) throw Failure{BL_E_STATE, "bl_render called before bl_set_grid."};
-    if (d->n_rays <= 0 || d->image == nullptr) throw Failure{BL_E_ARG, "bl_render needs n_rays > 0 and an image buffer."};
+    if (d->n_rays <= 0 || (d->image == nullptr && ctx->image_num_quantities > 0))
+      throw Failure{BL_E_ARG, "bl_render needs n_rays > 0 and an image buffer."};
+    if (ctx->render_num_images > 0 && d->render == nullptr) throw Failure{BL_E_ARG, "bl_render needs a render buffer when render_num_images > 0."};
     if (d->n_rays > 0x7fffffffll) throw Failure{BL_E_ARG, "Too many rays in one bl_render call."};
     if (d->level < 0 || d->level > p.adaptive_max_level) throw Failure{BL_E_ARG, "Adaptive level out of range."};
     if (d->level > 0 && (d->block_locs == nullptr || d->n_blocks <= 0)) throw Failure{BL_E_ARG, "Refined level needs block_locs."};
@@ -690,6 +713,37 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
       if (d->sample_flags != nullptr) { ctx->d_out_flags.Ensure(n_rays); out_flags = ctx->d_out_flags.ptr; }
       if (d->camera_pos != nullptr) { ctx->d_camera_pos.Ensure(static_cast<size_t>(n_rays) * 4); cam_pos = ctx->d_camera_pos.ptr; }
       if (d->camera_dir != nullptr) { ctx->d_camera_dir.Ensure(static_cast<size_t>(n_rays) * 4); cam_dir = ctx->d_camera_dir.ptr; }
+    }
+    double *render_out = nullptr;
+    bool fill_present = false;
+    if (ctx->render_num_images > 0) {
+      BlRenderDevice rp{};
+      rp.n_images = ctx->render_num_images;
+      for (int n_i = 0; n_i < rp.n_images; n_i++) {
+        rp.n_features[n_i] = p.render_num_features[n_i];
+        for (int n_f = 0; n_f < rp.n_features[n_i]; n_f++) {
+          rp.quantity[n_i][n_f] = p.render_quantity[n_i][n_f];
+          rp.type[n_i][n_f] = p.render_type[n_i][n_f];
+          rp.min_val[n_i][n_f] = p.render_min[n_i][n_f];
+          rp.max_val[n_i][n_f] = p.render_max[n_i][n_f];
+          rp.thresh[n_i][n_f] = p.render_thresh[n_i][n_f];
+          rp.tau_scale[n_i][n_f] = p.render_tau_scale[n_i][n_f];
+          rp.opacity[n_i][n_f] = p.render_opacity[n_i][n_f];
+          rp.xyz[n_i][n_f][0] = p.render_x[n_i][n_f];
+          rp.xyz[n_i][n_f][1] = p.render_y[n_i][n_f];
+          rp.xyz[n_i][n_f][2] = p.render_z[n_i][n_f];
+          if (rp.type[n_i][n_f] == BL_RENDER_FILL) fill_present = true;
+        }
+      }
+      rp.fill_present = fill_present ? 1 : 0;
+      ctx->d_render_params.Ensure(1);
+      Check(hipMemcpyAsync(ctx->d_render_params.ptr, &rp, sizeof(BlRenderDevice), hipMemcpyHostToDevice, stream), "render parameter upload");
+      Check(hipStreamSynchronize(stream), "render parameter upload");   // rp is a local
+      render_out = d->render;
+      if (!d->outputs_on_device) {
+        ctx->d_render.Ensure(static_cast<size_t>(ctx->render_num_images) * 3 * n_rays);
+        render_out = ctx->d_render.ptr;
+      }
     }
 
     // ---- kernel arguments common to all chunks
@@ -837,7 +891,7 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
     sa.x_unit = kGGMsun * ctx->frame.mass_msun / (kC * kC);   // unpolarized.cpp:42
     sa.aux_need_coefficients = (p.image_light || p.image_emission || p.image_tau || ctx->aux_images.image_emission_ave
                                 || ctx->aux_images.image_tau_int) ? 1 : 0;   // simulation_coefficients.cpp:389
-    sa.aux_need_length = ctx->aux_images.image_length;
+    sa.aux_need_length = (ctx->aux_images.image_length || fill_present) ? 1 : 0;
     for (int mu = 0; mu < 4; mu++) sa.cam_x[mu] = ctx->frame.cam_x[mu];
 
     BlTransferArgs xa{};
@@ -853,6 +907,8 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
     xa.aux_images = ctx->aux_images;
     xa.x_unit = kGGMsun * ctx->frame.mass_msun / (kC * kC);
     xa.t_unit = xa.x_unit / kC;   // unpolarized.cpp:43
+    xa.render_params = ctx->render_num_images > 0 ? ctx->d_render_params.ptr : nullptr;
+    xa.render = render_out;
 
     // Locate kernel: 256-thread workgroups. Alone (single chunk) it runs 4 waves per SIMD; when chunks are
     // pipelined it shares each SIMD with one 328-register wave of the next chunk's geodesic kernel, which
@@ -959,11 +1015,13 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
     Check(hipEventElapsedTime(&ms_wall, ev[0], (ev + static_cast<size_t>(n_chunks - 1) * kEventsPerChunk)[5]), "event time");
 
     if (!d->outputs_on_device) {
-      Check(hipMemcpy(d->image, image, static_cast<size_t>(n_q) * n_rays * sizeof(double), hipMemcpyDeviceToHost), "image download");
+      if (n_q > 0) Check(hipMemcpy(d->image, image, static_cast<size_t>(n_q) * n_rays * sizeof(double), hipMemcpyDeviceToHost), "image download");
       if (d->sample_num != nullptr) Check(hipMemcpy(d->sample_num, out_num, n_rays * sizeof(int), hipMemcpyDeviceToHost), "sample_num download");
       if (d->sample_flags != nullptr) Check(hipMemcpy(d->sample_flags, out_flags, n_rays, hipMemcpyDeviceToHost), "flags download");
       if (d->camera_pos != nullptr) Check(hipMemcpy(d->camera_pos, cam_pos, static_cast<size_t>(n_rays) * 32, hipMemcpyDeviceToHost), "camera_pos download");
       if (d->camera_dir != nullptr) Check(hipMemcpy(d->camera_dir, cam_dir, static_cast<size_t>(n_rays) * 32, hipMemcpyDeviceToHost), "camera_dir download");
+      if (ctx->render_num_images > 0)
+        Check(hipMemcpy(d->render, render_out, static_cast<size_t>(ctx->render_num_images) * 3 * n_rays * sizeof(double), hipMemcpyDeviceToHost), "render download");
     }
 
     st.n_samples = static_cast<int64_t>(total_samples);
@@ -1033,7 +1091,7 @@ void bl_free(bl_ctx *ctx) {
   (void)hipSetDevice(ctx->device);
   ctx->d_cells.Free(); ctx->d_coords.Free(); ctx->d_buckets.Free(); ctx->slot[0].Free(); ctx->slot[1].Free();
   ctx->d_freq.Free(); ctx->d_pixel_map.Free();
-  ctx->d_block_locs.Free(); ctx->d_tile_order.Free(); ctx->d_shade_cold.Free(); ctx->d_image.Free(); ctx->d_camera_pos.Free(); ctx->d_camera_dir.Free();
+  ctx->d_block_locs.Free(); ctx->d_tile_order.Free(); ctx->d_render_params.Free(); ctx->d_render.Free(); ctx->d_shade_cold.Free(); ctx->d_image.Free(); ctx->d_camera_pos.Free(); ctx->d_camera_dir.Free();
   ctx->d_out_sample_num.Free(); ctx->d_out_flags.Free();
   for (auto &e : ctx->events)
     if (e != nullptr) (void)hipEventDestroy(e);

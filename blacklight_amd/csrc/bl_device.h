@@ -135,6 +135,19 @@ struct BlAuxImages {
   int n_q;
 };
 
+// False-colour rendering parameters (rendering.cpp; a device buffer, too large for kernel arguments)
+struct BlRenderDevice {
+  int n_images;
+  int fill_present;
+  int n_features[BL_MAX_RENDER_IMAGES];
+  int quantity[BL_MAX_RENDER_IMAGES][BL_MAX_RENDER_FEATURES];
+  int type[BL_MAX_RENDER_IMAGES][BL_MAX_RENDER_FEATURES];
+  double min_val[BL_MAX_RENDER_IMAGES][BL_MAX_RENDER_FEATURES], max_val[BL_MAX_RENDER_IMAGES][BL_MAX_RENDER_FEATURES];
+  double thresh[BL_MAX_RENDER_IMAGES][BL_MAX_RENDER_FEATURES], tau_scale[BL_MAX_RENDER_IMAGES][BL_MAX_RENDER_FEATURES];
+  double opacity[BL_MAX_RENDER_IMAGES][BL_MAX_RENDER_FEATURES];
+  double xyz[BL_MAX_RENDER_IMAGES][BL_MAX_RENDER_FEATURES][3];
+};
+
 // Kernel arguments: geodesic kernel
 struct BlTraceArgs {
   BlSpacetime st;
@@ -206,6 +219,8 @@ struct BlTransferArgs {
   const BlAuxSample *aux;
   const double *ray_factor;
   double x_unit, t_unit;
+  const BlRenderDevice *render_params;   // device, or null
+  double *render;                        // [n_images][3][n_rays_total], or null
 };
 
 #endif  // BLACKLIGHT_AMD_BL_DEVICE_H_

@@ -296,7 +296,8 @@ int bl_adaptive_refine(const bl_ctx *ctx_const, int level, int n_blocks, const i
 }
 
 int bl_write_output(bl_ctx *ctx, const char *path_override, const bl_output_desc *d) {
-  if (ctx == nullptr || d == nullptr || d->level[0].image == nullptr) return BL_E_ARG;
+  if (ctx == nullptr || d == nullptr) return BL_E_ARG;
+  if (d->level[0].image == nullptr && bl_image_num_quantities(ctx) > 0) return bl_internal_fail(ctx, BL_E_ARG, "bl_write_output needs the root image.");
   const bl_params &p = *bl_internal_params(ctx);
   const bl_camera_frame &frame = *bl_internal_frame(ctx);
   int n_nu = 0;
@@ -320,6 +321,8 @@ int bl_write_output(bl_ctx *ctx, const char *path_override, const bl_output_desc
   std::ofstream stream(path, std::ios_base::out | std::ios_base::binary);
   if (!stream.is_open()) return bl_internal_fail(ctx, BL_E_INPUT, "Could not open output file.");
 
+  if (bl_render_num_images(ctx) > 0 && p.output_format != BL_OUTPUT_NPZ)
+    return bl_internal_fail(ctx, BL_E_INPUT, "Only npz outputs support rendering.");
   const double *image0 = d->level[0].image;
   if (p.output_format == BL_OUTPUT_RAW) {   // raw_format.cpp: the bytes of image[0]
     stream.write(reinterpret_cast<const char *>(image0), static_cast<std::streamsize>(sizeof(double) * n_q * n_pix));
@@ -356,6 +359,56 @@ int bl_write_output(bl_ctx *ctx, const char *path_override, const bl_output_desc
     std::vector<int> shape = n_nu == 1 ? std::vector<int>{res, res} : std::vector<int>{n_nu, res, res};
     add("I_nu", MakeNpy("<f8", shape, image0, sizeof(double) * n_nu * n_pix));
   }
+  // alternate images (numpy_format.cpp:167-281) and renderings (:282-289), root level
+  const bool simulation = p.model_type == BL_MODEL_SIMULATION;
+  const int n_render = bl_render_num_images(ctx);
+  struct RowSet { const char *name; bool on; int offset; bool per_frequency; bool per_cell; };
+  int row = p.image_light ? n_nu : 0;
+  auto take = [&](bool on, int count) { int at = row; if (on) row += count; return at; };
+  const int off_time = take(p.image_time, 1), off_length = take(p.image_length, 1), off_lambda = take(p.image_lambda, n_nu);
+  const int off_emission = take(p.image_emission, n_nu), off_tau = take(p.image_tau, n_nu);
+  const int off_lambda_ave = take(simulation && p.image_lambda_ave, 7 * n_nu);
+  const int off_emission_ave = take(simulation && p.image_emission_ave, 7 * n_nu);
+  const int off_tau_int = take(simulation && p.image_tau_int, 7 * n_nu);
+  const int off_crossings = take(p.image_crossings, 1);
+  static const char *const cell_names[7] = {"rho", "n_e", "p_gas", "Theta_e", "B", "sigma", "beta_inverse"};
+  // level_shape: the trailing dimensions of one image of the level ({res, res} or {n_blocks, bs, bs})
+  auto add_alternates = [&](const double *image, size_t level_pix, const std::vector<int> &level_shape, const std::string &prefix,
+                            const std::string &suffix, const double *render) {
+    auto shaped = [&](bool per_frequency) {
+      std::vector<int> shape;
+      if (per_frequency && n_nu > 1) shape.push_back(n_nu);
+      shape.insert(shape.end(), level_shape.begin(), level_shape.end());
+      return shape;
+    };
+    auto rows = [&](const std::string &name, int offset, int count, bool per_frequency) {
+      add(prefix + name + suffix, MakeNpy("<f8", shaped(per_frequency), image + static_cast<size_t>(offset) * level_pix, sizeof(double) * count * level_pix));
+    };
+    auto cells = [&](const char *stem, int offset) {
+      std::vector<double> copy(static_cast<size_t>(n_nu) * level_pix);
+      for (int n = 0; n < 7; n++) {
+        for (int l = 0; l < n_nu; l++)
+          std::memcpy(&copy[static_cast<size_t>(l) * level_pix], image + static_cast<size_t>(offset + l * 7 + n) * level_pix, sizeof(double) * level_pix);
+        add(prefix + stem + cell_names[n] + suffix, MakeNpy("<f8", shaped(true), copy.data(), sizeof(double) * copy.size()));
+      }
+    };
+    if (p.image_time) rows("time", off_time, 1, false);
+    if (p.image_length) rows("length", off_length, 1, false);
+    if (p.image_lambda) rows("lambda", off_lambda, n_nu, true);
+    if (p.image_emission) rows("emission", off_emission, n_nu, true);
+    if (p.image_tau) rows("tau", off_tau, n_nu, true);
+    if (simulation && p.image_lambda_ave) cells("lambda_ave_", off_lambda_ave);
+    if (simulation && p.image_emission_ave) cells("emission_ave_", off_emission_ave);
+    if (simulation && p.image_tau_int) cells("tau_int_", off_tau_int);
+    if (p.image_crossings) rows("crossings", off_crossings, 1, false);
+    if (n_render > 0) {
+      std::vector<int> shape = {n_render, 3};
+      shape.insert(shape.end(), level_shape.begin(), level_shape.end());
+      add(prefix + "rendering" + suffix, MakeNpy("<f8", shape, render, sizeof(double) * n_render * 3 * level_pix));
+    }
+  };
+  if (n_render > 0 && d->level[0].render == nullptr) return bl_internal_fail(ctx, BL_E_ARG, "render_num_images > 0 needs render data.");
+  add_alternates(image0, n_pix, {res, res}, "", "", d->level[0].render);
   const int bs = p.adaptive_max_level > 0 ? p.adaptive_block_size : 1;
   for (int l = 1; l <= num_levels; l++) {
     const bl_output_level &lv = d->level[l];
@@ -371,6 +424,8 @@ int bl_write_output(bl_ctx *ctx, const char *path_override, const bl_output_desc
       std::vector<int> shape = n_nu == 1 ? std::vector<int>{lv.n_blocks, bs, bs} : std::vector<int>{n_nu, lv.n_blocks, bs, bs};
       add("adaptive_I_nu" + suffix, MakeNpy("<f8", shape, lv.image, sizeof(double) * n_nu * level_pix));
     }
+    if (n_render > 0 && lv.render == nullptr) return bl_internal_fail(ctx, BL_E_ARG, "render_num_images > 0 needs render data.");
+    add_alternates(lv.image, level_pix, {lv.n_blocks, bs, bs}, "adaptive_", suffix, lv.render);
   }
 
   std::vector<Bytes> local_headers(records.size()), central_headers(records.size());

@@ -1440,7 +1440,61 @@ __global__ void __launch_bounds__(64) bl_transfer_aux_kernel(BlTransferArgs P) {
     const double2 *ja = P.transfer + (size_t)slot * P.ray_max_steps * P.n_nu;
     const bool use_j = A.image_light || A.image_emission || A.image_emission_ave;
     const bool use_alpha = A.image_light || A.image_tau || A.image_tau_int;
-    for (int l = 0; l < P.n_nu; l++) {
+    if (P.render_params != nullptr) {
+      // RadiationIntegrator::Render (rendering.cpp:25-179): false-colour composition along the ray from the
+      // recorded cell values, far -> near
+      const BlRenderDevice &R = *P.render_params;
+      double rgb[BL_MAX_RENDER_IMAGES][3];
+      for (int n_i = 0; n_i < BL_MAX_RENDER_IMAGES; n_i++) rgb[n_i][0] = rgb[n_i][1] = rgb[n_i][2] = 0.0;
+      double previous_values[BL_NUM_CELL_VALUES];
+      for (int a = 0; a < BL_NUM_CELL_VALUES; a++) previous_values[a] = nan;
+      for (int n = num - 1; n >= 0; n--) {
+        const BlAuxSample s = aux[n];
+        const double delta_length = s.length_term;   // 0 unless a fill feature is present
+        for (int n_i = 0; n_i < R.n_images; n_i++) {
+          for (int n_f = 0; n_f < R.n_features[n_i]; n_f++) {
+            const int n_v = R.quantity[n_i][n_f];
+            const int type = R.type[n_i][n_f];
+            double previous_value = 0.0, current_value = 0.0;
+            for (int a = 0; a < BL_NUM_CELL_VALUES; a++)   // register arrays: select instead of indexing
+              if (a == n_v) {
+                previous_value = previous_values[a];
+                current_value = s.cell[a];
+              }
+            const double cx = R.xyz[n_i][n_f][0], cy = R.xyz[n_i][n_f][1], cz = R.xyz[n_i][n_f][2];
+            if (type == BL_RENDER_FILL && current_value >= R.min_val[n_i][n_f] && current_value <= R.max_val[n_i][n_f]) {
+              const double delta_tau = delta_length / R.tau_scale[n_i][n_f];
+              if (delta_tau <= kDeltaTauMax) {
+                const double exp_neg = bl_exp(-delta_tau);
+                const double expm1 = bl_expm1(delta_tau);
+                rgb[n_i][0] = exp_neg * (rgb[n_i][0] + cx * expm1);
+                rgb[n_i][1] = exp_neg * (rgb[n_i][1] + cy * expm1);
+                rgb[n_i][2] = exp_neg * (rgb[n_i][2] + cz * expm1);
+              } else {
+                rgb[n_i][0] = cx;
+                rgb[n_i][1] = cy;
+                rgb[n_i][2] = cz;
+              }
+            }
+            bool threshold_crossed = false;
+            const bool rise_search = type == BL_RENDER_THRESH || type == BL_RENDER_RISE;
+            if (rise_search && previous_value < R.thresh[n_i][n_f] && current_value >= R.thresh[n_i][n_f]) threshold_crossed = true;
+            const bool fall_search = type == BL_RENDER_THRESH || type == BL_RENDER_FALL;
+            if (fall_search && previous_value > R.thresh[n_i][n_f] && current_value <= R.thresh[n_i][n_f]) threshold_crossed = true;
+            if (threshold_crossed) {
+              const double opacity = R.opacity[n_i][n_f];
+              rgb[n_i][0] = (1.0 - opacity) * rgb[n_i][0] + opacity * cx;
+              rgb[n_i][1] = (1.0 - opacity) * rgb[n_i][1] + opacity * cy;
+              rgb[n_i][2] = (1.0 - opacity) * rgb[n_i][2] + opacity * cz;
+            }
+          }
+        }
+        for (int a = 0; a < BL_NUM_CELL_VALUES; a++) previous_values[a] = s.cell[a];
+      }
+      for (int n_i = 0; n_i < R.n_images; n_i++)
+        for (int c = 0; c < 3; c++) P.render[(size_t)(n_i * 3 + c) * row + out_index] = rgb[n_i][c];
+    }
+    for (int l = 0; l < (A.n_q > 0 ? P.n_nu : 0); l++) {
       const double freq = P.frequencies[l];
       double intensity = 0.0, integrated_lambda = 0.0, integrated_emission = 0.0, tau = 0.0;
       double time_min = 0.0, length = 0.0;

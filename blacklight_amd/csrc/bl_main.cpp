@@ -129,7 +129,8 @@ int main(int argc, char *argv[]) {
     }
 
     // do { Integrate; if (!done) AddGeodesics } while (!done)   (blacklight.cpp:196-233)
-    std::vector<std::vector<double>> images, cameras;
+    std::vector<std::vector<double>> images, cameras, renders;
+    const int n_render = bl_render_num_images(ctx);
     std::vector<std::vector<int32_t>> locs(1);
     std::vector<int32_t> counts = {bs > 0 && params.adaptive_max_level > 0 ? (res / bs) * (res / bs) : 0};
     int level = 0;
@@ -138,12 +139,14 @@ int main(int argc, char *argv[]) {
                                           : static_cast<long long>(counts[level]) * bs * bs;
       images.emplace_back(static_cast<size_t>(n_q) * n_rays);
       cameras.emplace_back(want_camera ? static_cast<size_t>(n_rays) * 4 : 0);
+      renders.emplace_back(static_cast<size_t>(n_render) * 3 * n_rays);
       bl_render_desc d = {};
       d.level = level;
       d.n_blocks = level == 0 ? 0 : counts[level];
       d.block_locs = level == 0 ? nullptr : locs[level].data();
       d.n_rays = n_rays;
       d.image = images.back().data();
+      d.render = n_render > 0 ? renders.back().data() : nullptr;
       if (want_camera) {
         if (params.camera_type == BL_CAMERA_PLANE) d.camera_pos = cameras.back().data();
         else d.camera_dir = cameras.back().data();
@@ -189,6 +192,7 @@ int main(int argc, char *argv[]) {
       out.level[l].block_locs = l == 0 ? nullptr : locs[l].data();
       out.level[l].image = images[l].data();
       out.level[l].camera = want_camera ? cameras[l].data() : nullptr;
+      out.level[l].render = n_render > 0 ? renders[l].data() : nullptr;
     }
     if (bl_write_output(ctx, nullptr, &out) != BL_OK) {
       std::cout << bl_last_error(ctx);

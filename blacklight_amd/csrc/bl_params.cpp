@@ -14,6 +14,7 @@
 #include <string>
 
 #include "../../include/blacklight_amd.h"
+#include "blmath.h"
 
 namespace {
 
@@ -54,11 +55,12 @@ double ToDouble(const std::string &val, size_t *consumed = nullptr) {
   if (consumed != nullptr) *consumed = static_cast<size_t>(end - begin);
   return x;
 }
-int ToInt(const std::string &val) {
+int ToInt(const std::string &val, size_t *consumed = nullptr) {
   const char *begin = val.c_str();
   char *end = nullptr;
   long x = std::strtol(begin, &end, 10);
   if (end == begin) throw ParseFailure{"Could not read input file."};
+  if (consumed != nullptr) *consumed = static_cast<size_t>(end - begin);
   return static_cast<int>(x);
 }
 float ToFloat(const std::string &val) {
@@ -169,16 +171,128 @@ void ReadAdaptiveRegion(bl_params *p, const std::string &key, const std::string 
   throw ParseFailure{"Unknown key (adaptive_region_" + key + ") in input file."};
 }
 
+// RGBToXYZ (src/utils/colors.cpp:24-39): sRGB255 -> XYZ1 under D65. pow is the pinned one, like every
+// other libm call of the path.
+void RgbToXyz(double r, double g, double b, double *x, double *y, double *z) {
+  double r1 = r / 255.0;
+  double g1 = g / 255.0;
+  double b1 = b / 255.0;
+  double lr = r1 <= 0.040449936 ? r1 / 12.92 : bl_pow((r1 + 0.055) / 1.055, 2.4);
+  double lg = g1 <= 0.040449936 ? g1 / 12.92 : bl_pow((g1 + 0.055) / 1.055, 2.4);
+  double lb = b1 <= 0.040449936 ? b1 / 12.92 : bl_pow((b1 + 0.055) / 1.055, 2.4);
+  *x = 0.4123955889674142 * lr + 0.3575834307637148 * lg + 0.18049264738170154 * lb;
+  *y = 0.21258623078559552 * lr + 0.715170303703411 * lg + 0.0722004986433362 * lb;
+  *z = 0.019297215491746938 * lr + 0.11918386458084851 * lg + 0.9504971251315798 * lb;
+}
+
+// "x,y,z" into three doubles (input_reader.cpp:468-482)
+void ReadTripleValues(const std::string &val, double *x, double *y, double *z) {
+  size_t pos_1 = 0, pos_2 = 0;
+  *x = ToDouble(val, &pos_1);
+  if (pos_1 + 1 > val.size()) throw ParseFailure{"Could not read input file."};
+  std::string rest_1 = val.substr(pos_1 + 1);
+  *y = ToDouble(rest_1, &pos_2);
+  if (pos_1 + pos_2 + 2 > val.size()) throw ParseFailure{"Could not read input file."};
+  *z = ToDouble(val.substr(pos_1 + pos_2 + 2));
+  if (val[pos_1] != ',' || val[pos_1 + pos_2 + 1] != ',')
+    throw ParseFailure{"Invalid triple (" + val + ") in input file."};
+}
+
+bool EndsWith(const std::string &key, const char *suffix, size_t min_size) {
+  const size_t n = std::strlen(suffix);
+  return key.size() >= min_size && key.compare(key.size() - n, std::string::npos, suffix) == 0;
+}
+
+// render_<...> keys without the leading "render_" (render_reader.cpp:27-224): same order of tests, same
+// silent dropping of indices beyond what render_num_images / render_<i>_num_features declared.
+void ReadRender(bl_params *p, const std::string &key, const std::string &val) {
+  auto need_images = [&]() {
+    if (!p->has[BL_P_render_num_images]) throw ParseFailure{"Could not read input file."};   // bad_optional_access
+  };
+  if (EndsWith(key, "_num_features", 14)) {
+    need_images();
+    int image = ToInt(key.substr(0, key.size() - 13)) - 1;
+    if (image >= p->render_num_images) return;
+    if (image < 0 || image >= BL_MAX_RENDER_IMAGES) throw ParseFailure{"Too many rendered images for this build."};
+    int num_features = ToInt(val);
+    if (num_features > BL_MAX_RENDER_FEATURES) throw ParseFailure{"Too many render features for this build."};
+    p->render_num_features[image] = num_features;
+    p->render_num_features_has[image] = 1;
+    for (int f = 0; f < BL_MAX_RENDER_FEATURES; f++) p->render_has[image][f] = 0;
+    return;
+  }
+  // <image>_<feature>_<field>
+  auto indices = [&](int *image, int *feature) -> bool {
+    need_images();
+    size_t pos = 0;
+    *image = ToInt(key, &pos) - 1;
+    if (pos + 1 > key.size()) throw ParseFailure{"Could not read input file."};
+    *feature = ToInt(key.substr(pos + 1)) - 1;
+    if (*image >= p->render_num_images) return false;
+    if (*image < 0 || *image >= BL_MAX_RENDER_IMAGES) throw ParseFailure{"Too many rendered images for this build."};
+    if (!p->render_num_features_has[*image]) throw ParseFailure{"Could not read input file."};   // bad_optional_access
+    if (*feature >= p->render_num_features[*image]) return false;
+    if (*feature < 0) throw ParseFailure{"Could not read input file."};
+    return true;
+  };
+  int im = 0, fe = 0;
+  if (EndsWith(key, "_quantity", 12)) {
+    if (!indices(&im, &fe)) return;
+    static const char *const names[7] = {"rho", "n_e", "p_gas", "Theta_e", "B", "sigma", "beta_inverse"};
+    for (int q = 0; q < 7; q++)
+      if (val == names[q]) {
+        p->render_quantity[im][fe] = q;
+        p->render_has[im][fe] |= BL_RENDER_HAS_QUANTITY;
+        return;
+      }
+    throw ParseFailure{"Invalid render quantity (" + val + ") in input file."};
+  }
+  if (EndsWith(key, "_type", 8)) {
+    if (!indices(&im, &fe)) return;
+    static const char *const names[4] = {"fill", "thresh", "rise", "fall"};
+    for (int t = 0; t < 4; t++)
+      if (val == names[t]) {
+        p->render_type[im][fe] = t;
+        p->render_has[im][fe] |= BL_RENDER_HAS_TYPE;
+        return;
+      }
+    throw ParseFailure{"Invalid render type (" + val + ") in input file."};
+  }
+  struct Scalar { const char *suffix; size_t min_size; double (*field)[BL_MAX_RENDER_FEATURES]; int bit; };
+  const Scalar scalars[5] = {{"_min", 7, p->render_min, BL_RENDER_HAS_MIN}, {"_max", 7, p->render_max, BL_RENDER_HAS_MAX},
+                             {"_thresh", 10, p->render_thresh, BL_RENDER_HAS_THRESH},
+                             {"_tau_scale", 13, p->render_tau_scale, BL_RENDER_HAS_TAU_SCALE},
+                             {"_opacity", 11, p->render_opacity, BL_RENDER_HAS_OPACITY}};
+  for (const Scalar &sc : scalars)
+    if (EndsWith(key, sc.suffix, sc.min_size)) {
+      if (!indices(&im, &fe)) return;
+      sc.field[im][fe] = ToDouble(val);
+      p->render_has[im][fe] |= sc.bit;
+      return;
+    }
+  if (EndsWith(key, "_rgb", 7)) {
+    if (!indices(&im, &fe)) return;
+    double r, g, b;
+    ReadTripleValues(val, &r, &g, &b);
+    RgbToXyz(r, g, b, &p->render_x[im][fe], &p->render_y[im][fe], &p->render_z[im][fe]);
+    p->render_has[im][fe] |= BL_RENDER_HAS_XYZ;
+    return;
+  }
+  if (EndsWith(key, "_xyz", 7)) {
+    if (!indices(&im, &fe)) return;
+    ReadTripleValues(val, &p->render_x[im][fe], &p->render_y[im][fe], &p->render_z[im][fe]);
+    p->render_has[im][fe] |= BL_RENDER_HAS_XYZ;
+    return;
+  }
+  throw ParseFailure{"Unknown key (render_" + key + ") in input file."};
+}
+
 void SetKeyValue(bl_params *p, const std::string &key, const std::string &val) {
   // Compound keys first
   if (key == "cut_plane_origin") return ReadTriple(val, p, BL_P_cut_plane_origin_x);
   if (key == "cut_plane_normal") return ReadTriple(val, p, BL_P_cut_plane_normal_x);
   if (key.compare(0, 16, "adaptive_region_") == 0) return ReadAdaptiveRegion(p, key.substr(16), val);
-  if (key.compare(0, 7, "render_") == 0 && key != "render_num_images") {
-    // Per-feature rendering keys (render_reader.cpp) belong to Render(), which is outside the
-    // hot-path scope; they are accepted and ignored so that reference input files still parse.
-    return;
-  }
+  if (key.compare(0, 7, "render_") == 0 && key != "render_num_images") return ReadRender(p, key.substr(7), val);
 
   for (int index = 0; index < BL_P_COUNT; index++) {
     const FieldInfo &f = kFields[index];
@@ -207,6 +321,10 @@ void SetKeyValue(bl_params *p, const std::string &key, const std::string &val) {
       }
     }
     p->has[index] = 1;
+    if (index == BL_P_render_num_images) {
+      if (p->render_num_images > BL_MAX_RENDER_IMAGES) throw ParseFailure{"Too many rendered images for this build."};
+      for (int i = 0; i < BL_MAX_RENDER_IMAGES; i++) p->render_num_features_has[i] = 0;
+    }
     if (index == BL_P_adaptive_num_regions) {
       if (p->adaptive_num_regions > BL_MAX_REGIONS)
         throw ParseFailure{"Too many adaptive regions for this build."};

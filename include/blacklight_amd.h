@@ -124,6 +124,13 @@ typedef struct bl_str { char s[BL_STR_LEN]; } bl_str;
 
 enum { BL_PARAM_LIST(BL_X_INDEX) BL_P_COUNT };
 
+/* False-colour rendering (rendering.cpp): bounds of this build and enumerations */
+#define BL_MAX_RENDER_IMAGES 4
+#define BL_MAX_RENDER_FEATURES 16
+enum { BL_RENDER_FILL = 0, BL_RENDER_THRESH = 1, BL_RENDER_RISE = 2, BL_RENDER_FALL = 3 };
+enum { BL_RENDER_HAS_QUANTITY = 1, BL_RENDER_HAS_TYPE = 2, BL_RENDER_HAS_MIN = 4, BL_RENDER_HAS_MAX = 8,
+       BL_RENDER_HAS_THRESH = 16, BL_RENDER_HAS_TAU_SCALE = 32, BL_RENDER_HAS_OPACITY = 64, BL_RENDER_HAS_XYZ = 128 };
+
 typedef struct bl_params {
   /* has[i] != 0 iff field i (enum BL_P_*) was given: the std::optional of the reference */
   uint8_t has[((BL_P_COUNT + 7) / 8) * 8];
@@ -135,6 +142,22 @@ typedef struct bl_params {
   double adaptive_region_x_max[BL_MAX_REGIONS];
   double adaptive_region_y_min[BL_MAX_REGIONS];
   double adaptive_region_y_max[BL_MAX_REGIONS];
+  /* render_<i>_num_features, render_<i>_<f>_{quantity,type,min,max,thresh,tau_scale,opacity,rgb|xyz}
+   * (src/input_reader/render_reader.cpp); indices beyond render_num_images / num_features are ignored
+   * as there, indices beyond BL_MAX_RENDER_* are an error of this build */
+  int32_t render_num_features_has[BL_MAX_RENDER_IMAGES];
+  int32_t render_num_features[BL_MAX_RENDER_IMAGES];
+  int32_t render_has[BL_MAX_RENDER_IMAGES][BL_MAX_RENDER_FEATURES];   /* BL_RENDER_HAS_* bits */
+  int32_t render_quantity[BL_MAX_RENDER_IMAGES][BL_MAX_RENDER_FEATURES];   /* cell value index 0..6 */
+  int32_t render_type[BL_MAX_RENDER_IMAGES][BL_MAX_RENDER_FEATURES];       /* BL_RENDER_* */
+  double render_min[BL_MAX_RENDER_IMAGES][BL_MAX_RENDER_FEATURES];
+  double render_max[BL_MAX_RENDER_IMAGES][BL_MAX_RENDER_FEATURES];
+  double render_thresh[BL_MAX_RENDER_IMAGES][BL_MAX_RENDER_FEATURES];
+  double render_tau_scale[BL_MAX_RENDER_IMAGES][BL_MAX_RENDER_FEATURES];
+  double render_opacity[BL_MAX_RENDER_IMAGES][BL_MAX_RENDER_FEATURES];
+  double render_x[BL_MAX_RENDER_IMAGES][BL_MAX_RENDER_FEATURES];      /* XYZ colour (D65), rgb keys converted */
+  double render_y[BL_MAX_RENDER_IMAGES][BL_MAX_RENDER_FEATURES];
+  double render_z[BL_MAX_RENDER_IMAGES][BL_MAX_RENDER_FEATURES];
 } bl_params;
 
 /* Zero a parameter block (nothing present). */
@@ -193,6 +216,8 @@ typedef struct bl_render_desc {
   uint8_t *sample_flags;      /* [n_rays] or NULL                                                  */
   double *camera_pos;         /* [n_rays][4] or NULL                                               */
   double *camera_dir;         /* [n_rays][4] or NULL                                               */
+  double *render;             /* render_num_images > 0: [render_num_images][3][n_rays] XYZ, else NULL
+                                 (RadiationIntegrator::Render, rendering.cpp:25-179)                  */
 } bl_render_desc;
 
 typedef struct bl_stats {
@@ -225,6 +250,8 @@ BL_API int bl_init(const bl_params *p, int device, bl_ctx **out);
 BL_API int bl_set_grid(bl_ctx *ctx, const bl_grid_desc *g);
 /* Number of image rows n_q and their offsets (radiation_integrator.cpp:436-520). */
 BL_API int bl_image_num_quantities(const bl_ctx *ctx);
+/* Number of false-colour renderings bl_render produces (render_num_images; 0 in formula mode). */
+BL_API int bl_render_num_images(const bl_ctx *ctx);
 BL_API int bl_camera_frame_get(const bl_ctx *ctx, bl_camera_frame *out);
 BL_API int bl_frequencies(const bl_ctx *ctx, double *out, int n);
 /* Cap on scratch HBM (bytes) used for per-sample records; default 144 GiB (half of the MI355X HBM). */
@@ -273,6 +300,7 @@ typedef struct bl_output_level {
   const int32_t *block_locs;   /* levels > 0: [n_blocks][2] */
   const double *image;         /* host [n_q][n_pix of the level] */
   const double *camera;        /* output_camera: positions (plane) or directions (pinhole) [n_pix][4] */
+  const double *render;        /* render_num_images > 0: host [render_num_images][3][n_pix of the level] */
 } bl_output_level;
 typedef struct bl_output_desc {
   int32_t adaptive_num_levels; /* levels beyond the root that were rendered */

@@ -96,6 +96,7 @@ struct Oracle {
   bool image_polarization;  // forced false in formula mode
   double plasma_thermal_frac;
   double power_jj = 0.0, power_aa = 0.0;   // simulation_coefficients.cpp:54-66
+  int render_num_images = 0;               // 0 in formula mode (radiation_integrator.cpp:136-145)
 };
 
 bool need(const bl_params *p, int index) { return p->has[index] != 0; }
@@ -1351,7 +1352,7 @@ void SimulationCoefficientsOne(const Oracle &o, const double pos[4], const doubl
       or (p.cut_beta_inverse_max >= 0.0 and beta_inv > p.cut_beta_inverse_max))
     return;
 
-  if (p.image_lambda_ave or p.image_emission_ave or p.image_tau_int) {  // :378-387
+  if (p.image_lambda_ave or p.image_emission_ave or p.image_tau_int or o.render_num_images > 0) {  // :378-387
     cell[0] = rho_cgs;
     cell[1] = n_e_cgs;
     cell[2] = pgas_cgs;
@@ -1597,6 +1598,71 @@ void IntegrateUnpolarizedOne(const Oracle &o, const RayBuffers &b, int num_steps
     }
 }
 
+// rendering.cpp:25-179 for one pixel. render_col[3 * n_i + c] = render(n_i, c, m).
+void RenderOne(const Oracle &o, const RayBuffers &b, int num_steps, int max_steps, double *render_col) {
+  const bl_params &p = *o.p;
+  constexpr double delta_tau_max = 100.0;
+  bool fill_present = false;
+  for (int n_i = 0; n_i < o.render_num_images; n_i++)
+    for (int n_f = 0; n_f < p.render_num_features[n_i]; n_f++)
+      if (p.render_type[n_i][n_f] == BL_RENDER_FILL) fill_present = true;
+  double x_unit = Physics::gg_msun * o.mass_msun / (Physics::c * Physics::c);
+  for (int q = 0; q < 3 * o.render_num_images; q++) render_col[q] = 0.0;
+  double previous_values[num_cell_values], current_values[num_cell_values];
+  for (int n_v = 0; n_v < num_cell_values; n_v++) previous_values[n_v] = std::numeric_limits<double>::quiet_NaN();
+  for (int n = 0; n < num_steps; n++) {
+    double delta_lambda = b.sample_len[n];
+    double x1 = b.sample_pos[4 * n + 1], x2 = b.sample_pos[4 * n + 2], x3 = b.sample_pos[4 * n + 3];
+    double kcov[4] = {b.sample_dir[4 * n + 0], b.sample_dir[4 * n + 1], b.sample_dir[4 * n + 2], b.sample_dir[4 * n + 3]};
+    for (int n_v = 0; n_v < num_cell_values; n_v++) current_values[n_v] = b.cell_values[n_v * static_cast<size_t>(max_steps) + n];
+    double delta_length = 0.0;
+    if (fill_present) {
+      double gcov[4][4], gcon[4][4];
+      CovariantGeodesicMetric(o, x1, x2, x3, gcov);
+      ContravariantGeodesicMetric(o, x1, x2, x3, gcon);
+      double temp_a[4] = {};
+      for (int a = 1; a < 4; a++)
+        for (int mu = 0; mu < 4; mu++) temp_a[a] += (gcon[a][mu] - gcon[0][a] * gcon[0][mu] / gcon[0][0]) * kcov[mu];
+      double dl_dlambda_sq = 0.0;
+      for (int a = 1; a < 4; a++)
+        for (int bb = 1; bb < 4; bb++) dl_dlambda_sq += gcov[a][bb] * temp_a[a] * temp_a[bb];
+      delta_length = std::sqrt(dl_dlambda_sq) * delta_lambda * x_unit;
+    }
+    for (int n_i = 0; n_i < o.render_num_images; n_i++) {
+      double *rgb = render_col + 3 * n_i;
+      for (int n_f = 0; n_f < p.render_num_features[n_i]; n_f++) {
+        int n_v = p.render_quantity[n_i][n_f];
+        int type = p.render_type[n_i][n_f];
+        double previous_value = previous_values[n_v];
+        double current_value = current_values[n_v];
+        const double xyz[3] = {p.render_x[n_i][n_f], p.render_y[n_i][n_f], p.render_z[n_i][n_f]};
+        if (type == BL_RENDER_FILL and current_value >= p.render_min[n_i][n_f] and current_value <= p.render_max[n_i][n_f]) {
+          double delta_tau = delta_length / p.render_tau_scale[n_i][n_f];
+          if (delta_tau <= delta_tau_max) {
+            double exp_neg = M::exp(-delta_tau);
+            double expm1 = M::expm1(delta_tau);
+            for (int c = 0; c < 3; c++) rgb[c] = exp_neg * (rgb[c] + xyz[c] * expm1);
+          } else {
+            for (int c = 0; c < 3; c++) rgb[c] = xyz[c];
+          }
+        }
+        bool threshold_crossed = false;
+        bool rise_search = type == BL_RENDER_THRESH or type == BL_RENDER_RISE;
+        if (rise_search and previous_value < p.render_thresh[n_i][n_f] and current_value >= p.render_thresh[n_i][n_f])
+          threshold_crossed = true;
+        bool fall_search = type == BL_RENDER_THRESH or type == BL_RENDER_FALL;
+        if (fall_search and previous_value > p.render_thresh[n_i][n_f] and current_value <= p.render_thresh[n_i][n_f])
+          threshold_crossed = true;
+        if (threshold_crossed) {
+          double opacity = p.render_opacity[n_i][n_f];
+          for (int c = 0; c < 3; c++) rgb[c] = (1.0 - opacity) * rgb[c] + opacity * xyz[c];
+        }
+      }
+    }
+    for (int n_v = 0; n_v < num_cell_values; n_v++) previous_values[n_v] = current_values[n_v];
+  }
+}
+
 // radiation_integrator.cpp:436-520
 void ImageOffsets(Oracle &o) {
   const bl_params &p = *o.p;
@@ -1655,6 +1721,7 @@ int Setup(Oracle &o, const bl_params *p, const bl_grid_desc *g, char *err, size_
     if (p->plasma_kappa_frac != 0.0)
       return Fail(err, err_len, "oracle: kappa-distribution electrons not restated (the reference reads the uninitialised kappa_aa_high_i)", BL_E_UNSUPPORTED);
     o.plasma_thermal_frac = 1.0 - (p->plasma_power_frac + p->plasma_kappa_frac);
+    o.render_num_images = p->render_num_images;   // radiation_integrator.cpp:136-139
     if (p->plasma_power_frac != 0.0) {  // simulation_coefficients.cpp:54-66 (unpolarized part)
       double plasma_p = p->plasma_p;
       double var_a = M::pow(3.0, plasma_p / 2.0) * (plasma_p - 1.0);
@@ -1822,6 +1889,11 @@ int blo_render(const bl_params *p, const bl_grid_desc *g, const bl_render_desc *
       IntegrateUnpolarizedOne(o, b, sample_num, max_steps, factor, image_col.data());
       if (d->image != nullptr)
         for (int q = 0; q < n_q; q++) d->image[static_cast<size_t>(q) * n_rays + ray] = image_col[q];
+      if (o.render_num_images > 0 && d->render != nullptr) {
+        double render_col[3 * BL_MAX_RENDER_IMAGES];
+        RenderOne(o, b, sample_num, max_steps, render_col);
+        for (int q = 0; q < 3 * o.render_num_images; q++) d->render[static_cast<size_t>(q) * n_rays + ray] = render_col[q];
+      }
     }
   }
   if (extra != nullptr) {

@@ -52,7 +52,18 @@ def expected_image(fx, tier, n_pix):
         key = f"{tier}_npz_{name}"
         if key in fx.files:
             rows.append(fx[key].reshape(-1, n_pix))
+    if not rows:
+        return np.zeros((0, n_pix))
     return np.concatenate(rows, axis=0)
+
+
+def expected_rendering(fx, tier, n_pix):
+    """False-colour renderings (n_images, 3, n_pix), or None."""
+    key = f"{tier}_npz_rendering"
+    if key not in fx.files:
+        return None
+    arr = fx[key]
+    return arr.reshape(arr.shape[0], 3, n_pix)
 
 
 def same_bits(a, b):

@@ -54,8 +54,9 @@ def load(variant="blmath"):
 
 def render(params_ptr, grid_desc, desc_cls, camera_frame_cls, *, n_rays, level=0, block_locs=None,
            pixel_map=None, variant="blmath", num_threads=0, dump_ray=-1, max_steps=0, n_freq=1,
-           want_camera=False):
-    """Run the oracle. Returns dict(image, sample_num, sample_flags, frame, frequencies, extra...)."""
+           want_camera=False, n_render=0):
+    """Run the oracle. Returns dict(image, sample_num, sample_flags, frame, frequencies, extra...).
+    n_render > 0: also the false-colour renderings, (n_render, 3, n_rays)."""
     L = load(variant)
     n_q = L.blo_image_num_quantities(params_ptr)
     image = np.zeros((max(n_q, 1), n_rays), dtype=np.float64)
@@ -84,6 +85,10 @@ def render(params_ptr, grid_desc, desc_cls, camera_frame_cls, *, n_rays, level=0
         camera_dir = np.zeros((n_rays, 4))
         d.camera_pos = camera_pos.ctypes.data_as(C.c_void_p)
         d.camera_dir = camera_dir.ctypes.data_as(C.c_void_p)
+    rendering = None
+    if n_render > 0:
+        rendering = np.zeros((n_render, 3, n_rays))
+        d.render = rendering.ctypes.data_as(C.c_void_p)
     frame = camera_frame_cls()
     freqs = np.zeros(max(n_freq, 1))
     extra = Extra()
@@ -104,7 +109,7 @@ def render(params_ptr, grid_desc, desc_cls, camera_frame_cls, *, n_rays, level=0
     out = dict(image=image[:n_q], sample_num=sample_num, sample_flags=sample_flags, frame=frame,
                frequencies=freqs, n_samples=extra.n_samples, n_gathers=extra.n_gathers,
                n_flagged=extra.n_flagged, max_sample_num=extra.max_sample_num, seconds=extra.seconds,
-               camera_pos=camera_pos, camera_dir=camera_dir)
+               camera_pos=camera_pos, camera_dir=camera_dir, rendering=rendering)
     if dump is not None:
         n = extra.dump_num
         out["dump"] = dict(pos=dump["pos"][:n], dir=dump["dir"][:n], len=dump["len"][:n])

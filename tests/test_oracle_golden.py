@@ -28,9 +28,10 @@ def _run(case, variant):
     grid = gu.golden_grid(mock_args) if mock_args is not None else None
     desc = grid.desc() if grid is not None else None
     res = int(p.get("camera_resolution"))
+    n_render = int(p.get("render_num_images") or 0) if grid is not None else 0
     out = oracle_api.render(p.ptr, desc, _capi.RenderDesc, _capi.CameraFrame, n_rays=res * res, variant=variant,
                             max_steps=int(p.get("ray_max_steps")), n_freq=int(p.get("image_num_frequencies")),
-                            dump_ray=int(fx["dump_rays"][0]), want_camera=True)
+                            dump_ray=int(fx["dump_rays"][0]), want_camera=True, n_render=n_render)
     return fx, p, out, res * res
 
 
@@ -52,6 +53,9 @@ def test_tier_b_bit_exact(case, built_library):
     want = _expected_rows(fx, "B", n_pix)
     assert out["image"].shape == want.shape
     assert gu.same_bits(out["image"], want).all()
+    want_render = gu.expected_rendering(fx, "B", n_pix)
+    if want_render is not None:
+        assert gu.same_bits(out["rendering"], want_render).all()
     ray = int(fx["dump_rays"][0])
     assert np.array_equal(out["dump"]["pos"], fx[f"B_ray{ray}_pos"])
     assert np.array_equal(out["dump"]["dir"], fx[f"B_ray{ray}_dir"])

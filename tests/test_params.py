@@ -122,4 +122,5 @@ def test_context_validation_messages(bl):
         "Error: Must have adaptive_block_size divide camera_resolution."
     # reference configurations outside the hot-path scope are refused loudly, never approximated
     assert "not built yet" in failing(image_polarization="true", image_rotation_split="false")
-    assert "outside the hot-path scope" in failing(render_num_images=1)
+    # a rendering without its features: bad_optional_access in the reference constructor (radiation_integrator.cpp:161)
+    assert failing(render_num_images=1) == "Error: RadiationIntegrator unable to find all needed values in input file."

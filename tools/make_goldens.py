@@ -100,6 +100,25 @@ CASES = {
     "sim_pole": (SIM_BASE, dict(camera_resolution=16, camera_th=0.0), SMALL_MOCK, [136]),
     "sim_powerlaw": (SIM_BASE, dict(camera_resolution=24, plasma_power_frac=0.3, plasma_p=2.5, plasma_gamma_min=1.0,
                                     plasma_gamma_max=1000.0), SMALL_MOCK, [300]),
+    # false-colour renderings (rendering.cpp): the features of the reference's example_render.input, without
+    # and with images of light next to them; the second has two renderings and rise / fall features
+    "sim_render": (SIM_BASE, dict(camera_resolution=24, image_light="false", render_num_images=1, render_1_num_features=3,
+                                  render_1_1_quantity="rho", render_1_1_type="fill", render_1_1_min=1.5e-17, render_1_1_max="inf",
+                                  render_1_1_tau_scale=1.5e13, render_1_1_rgb="106,121,247",
+                                  render_1_2_quantity="sigma", render_1_2_type="fill", render_1_2_min=1.0, render_1_2_max="inf",
+                                  render_1_2_tau_scale=1.0e13, render_1_2_rgb="214,76.5,66.7",
+                                  render_1_3_quantity="beta_inverse", render_1_3_type="thresh", render_1_3_thresh=0.15,
+                                  render_1_3_opacity=0.2, render_1_3_xyz="0.12,0.246,0.089"), SMALL_MOCK, [300]),
+    "sim_render_light": (SIM_BASE, dict(camera_resolution=16, image_tau="true", render_num_images=2, render_1_num_features=2,
+                                        render_1_1_quantity="Theta_e", render_1_1_type="rise", render_1_1_thresh=0.5,
+                                        render_1_1_opacity=0.5, render_1_1_rgb="250,10,20",
+                                        render_1_2_quantity="B", render_1_2_type="fall", render_1_2_thresh=2.0,
+                                        render_1_2_opacity=0.3, render_1_2_xyz="0.2,0.3,0.4",
+                                        render_2_num_features=2,
+                                        render_2_1_quantity="n_e", render_2_1_type="fill", render_2_1_min=1.0e4, render_2_1_max=1.0e7,
+                                        render_2_1_tau_scale=3.0e13, render_2_1_rgb="30,200,90",
+                                        render_2_2_quantity="p_gas", render_2_2_type="thresh", render_2_2_thresh=1.0e-6,
+                                        render_2_2_opacity=1.0, render_2_2_xyz="0.9,0.8,0.1"), SMALL_MOCK, [136]),
     "sim_aux_images": (SIM_BASE, dict(camera_resolution=16, image_time="true", image_length="true",
                                       image_lambda="true", image_emission="true", image_tau="true",
                                       image_lambda_ave="true", image_emission_ave="true", image_tau_int="true",
@@ -240,9 +259,10 @@ def make_case(name):
         os.remove(os.path.join(workdir, "data", "geo.dat"))
     os.makedirs(OUT, exist_ok=True)
     np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **fixture)
-    a, b = fixture["A_npz_I_nu"], fixture["B_npz_I_nu"]
+    key = "I_nu" if "A_npz_I_nu" in fixture else "rendering"
+    a, b = fixture[f"A_npz_{key}"], fixture[f"B_npz_{key}"]
     same_num = np.array_equal(fixture["A_sample_num"], fixture["B_sample_num"])
-    print(f"{name}: I_nu {a.shape} nan={int(np.isnan(b).sum())} A-vs-B max rel "
+    print(f"{name}: {key} {a.shape} nan={int(np.isnan(b).sum())} A-vs-B max rel "
           f"{np.nanmax(np.abs(a - b) / np.nanmax(np.abs(b))):.2e} sample_num equal A/B: {same_num} "
           f"flags B: {int(fixture['B_sample_flags'].sum())}")
 
