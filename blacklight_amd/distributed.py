@@ -13,12 +13,18 @@ TILE = 32
 
 def tile_pixels(resolution, rank, world, tile=TILE):
     """Pixel indices (m = m2 * resolution + m1, as the reference's camera, camera.cpp:393-396) of the
-    tiles owned by `rank`: tile t -> rank t % world. Tile-major, row-major inside a tile, which is
-    also the order the geodesic kernel wants (each wave starts as a compact 2-D patch)."""
+    tiles owned by `rank`. Tile-major, row-major inside a tile, which is also the order the geodesic
+    kernel wants (each wave starts as a compact 2-D patch)."""
     if resolution % tile != 0:
         raise ValueError("camera_resolution must be a multiple of the tile size")
     tiles_per_side = resolution // tile
-    ids = np.arange(rank, tiles_per_side * tiles_per_side, world)
+    # All tiles sorted by distance from the image centre, then dealt round-robin: every rank gets the same
+    # mix of long (central) and short (peripheral) rays, and traces its long ones first, so that its
+    # persistent geodesic waves end on short rays (same reason as the library's centre-first tile order).
+    all_ids = np.arange(tiles_per_side * tiles_per_side)
+    centre = 0.5 * (tiles_per_side - 1)
+    dist2 = (all_ids // tiles_per_side - centre) ** 2 + (all_ids % tiles_per_side - centre) ** 2
+    ids = all_ids[np.argsort(dist2, kind="stable")][rank::world]
     ty, tx = ids // tiles_per_side, ids % tiles_per_side
     yy, xx = np.meshgrid(np.arange(tile), np.arange(tile), indexing="ij")
     m2 = (ty[:, None, None] * tile + yy[None]).reshape(-1)

@@ -60,4 +60,9 @@ def test_tiles_partition_the_image():
         seen = np.concatenate([bd.tile_pixels(128, r, world, 32) for r in range(world)])
         assert np.array_equal(np.sort(seen), np.arange(128 * 128))
         first = bd.tile_pixels(128, 0, world, 32)[:32 * 32].reshape(32, 32)
-        assert np.array_equal(first[0], np.arange(32)) and first[1, 0] == 128   # row-major inside a tile
+        # row-major inside a tile; rank 0's first tile is one of the four central ones (centre first)
+        assert np.array_equal(first[0], first[0, 0] + np.arange(32)) and first[1, 0] == first[0, 0] + 128
+        assert first[0, 0] // 128 in (32, 64) and first[0, 0] % 128 in (32, 64)
+        # every rank gets the same number of tiles (+-1), dealt so that each holds central and peripheral ones
+        counts = [bd.tile_pixels(128, r, world, 32).size // (32 * 32) for r in range(world)]
+        assert max(counts) - min(counts) <= 1
