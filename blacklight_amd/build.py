@@ -50,7 +50,7 @@ def build(force=False, verbose=False):
                  or os.path.getmtime(obj_path) < max(os.path.getmtime(src_path), header_time))
         if not stale:
             continue
-        cmd = [cc, "-c", src_path, "-o", obj_path] + COMMON
+        cmd = [cc, "-c", src_path, "-o", obj_path] + COMMON + os.environ.get("BLACKLIGHT_AMD_EXTRA_FLAGS", "").split()
         if src.endswith(".hip"):
             cmd += [f"--offload-arch={ARCH}", "-Rpass-analysis=kernel-resource-usage"] if verbose else [f"--offload-arch={ARCH}"]
         else:
