@@ -513,27 +513,95 @@ int bl_set_grid(bl_ctx *ctx, const bl_grid_desc *g) {
   try {
     if (ctx->device == BL_DEVICE_NONE) throw Failure{BL_E_DEVICE, "Host-only context: no HIP device selected (the hot path has no CPU fallback)."};
     if (ctx->params.model_type != BL_MODEL_SIMULATION) throw Failure{BL_E_STATE, "bl_set_grid called in formula mode."};
-    if (g->n_blocks != 1)
-      throw Failure{BL_E_UNSUPPORTED, "Multi-block (mesh-refined) grids are not built yet; single-block grids only."};
+    if (g->n_blocks < 1) throw Failure{BL_E_ARG, "Bad grid description."};
     if (g->n_i < 2 || g->n_j < 2 || g->n_k < 2 || g->prim == nullptr) throw Failure{BL_E_ARG, "Bad grid description."};
     Check(hipSetDevice(ctx->device), "hipSetDevice");
-    const int n_i = g->n_i, n_j = g->n_j, n_k = g->n_k;
+    // Several blocks (simulation_sampling.cpp:352-394 searches them per sample): supported when they are
+    // equal blocks at one refinement level tiling a box, in any order. They are merged into one global
+    // array at upload; the locate kernel keeps the reference's per-block anchor rules through the block
+    // size. Mesh refinement (blocks of different levels) is not built.
+    const int nb_cells[3] = {g->n_i, g->n_j, g->n_k};
+    const double *block_xf[3] = {g->x1f, g->x2f, g->x3f};
+    const double *block_xv[3] = {g->x1v, g->x2v, g->x3v};
+    const int n_b = g->n_blocks;
+    std::vector<double> starts[3];          // distinct first faces along each axis, ascending
+    std::vector<int> block_pos[3];          // position of every block along each axis
+    for (int a = 0; a < 3; a++) {
+      for (int blk = 0; blk < n_b; blk++) starts[a].push_back(block_xf[a][static_cast<size_t>(blk) * (nb_cells[a] + 1)]);
+      std::sort(starts[a].begin(), starts[a].end());
+      starts[a].erase(std::unique(starts[a].begin(), starts[a].end()), starts[a].end());
+      block_pos[a].resize(n_b);
+      for (int blk = 0; blk < n_b; blk++) {
+        const double first = block_xf[a][static_cast<size_t>(blk) * (nb_cells[a] + 1)];
+        block_pos[a][blk] = static_cast<int>(std::lower_bound(starts[a].begin(), starts[a].end(), first) - starts[a].begin());
+      }
+    }
+    const int nbl[3] = {static_cast<int>(starts[0].size()), static_cast<int>(starts[1].size()), static_cast<int>(starts[2].size())};
+    const char *kIrregular = "Multi-block grid is not a regular tiling by equal blocks of one level (mesh refinement is not built).";
+    if (static_cast<long long>(nbl[0]) * nbl[1] * nbl[2] != n_b) throw Failure{BL_E_UNSUPPORTED, kIrregular};
+    std::vector<int> block_at(n_b, -1);     // lattice position -> block
+    for (int blk = 0; blk < n_b; blk++) {
+      const int at = (block_pos[2][blk] * nbl[1] + block_pos[1][blk]) * nbl[0] + block_pos[0][blk];
+      if (block_at[at] != -1) throw Failure{BL_E_UNSUPPORTED, kIrregular};
+      block_at[at] = blk;
+    }
+    // global coordinate tables; every block at the same position along an axis must carry the same rows,
+    // and neighbouring rows must meet bit for bit (no gaps, no overlaps)
+    const int n_i = nbl[0] * nb_cells[0], n_j = nbl[1] * nb_cells[1], n_k = nbl[2] * nb_cells[2];
+    const int n[3] = {n_i, n_j, n_k};
+    std::vector<double> global_xf[3], global_xv[3];
+    for (int a = 0; a < 3; a++) {
+      global_xf[a].assign(n[a] + 1, 0.0);
+      global_xv[a].assign(n[a], 0.0);
+      std::vector<char> seen(nbl[a], 0);
+      for (int blk = 0; blk < n_b; blk++) {
+        const int pos = block_pos[a][blk];
+        const double *f = block_xf[a] + static_cast<size_t>(blk) * (nb_cells[a] + 1);
+        const double *v = block_xv[a] + static_cast<size_t>(blk) * nb_cells[a];
+        double *gf = global_xf[a].data() + static_cast<size_t>(pos) * nb_cells[a];
+        double *gv = global_xv[a].data() + static_cast<size_t>(pos) * nb_cells[a];
+        if (!seen[pos]) {
+          if (pos > 0 && seen[pos - 1] && std::memcmp(gf, f, sizeof(double)) != 0) throw Failure{BL_E_UNSUPPORTED, kIrregular};
+          std::memcpy(gf, f, sizeof(double) * (nb_cells[a] + 1));
+          std::memcpy(gv, v, sizeof(double) * nb_cells[a]);
+          seen[pos] = 1;
+        } else if (std::memcmp(gf, f, sizeof(double) * (nb_cells[a] + 1)) != 0 || std::memcmp(gv, v, sizeof(double) * nb_cells[a]) != 0) {
+          throw Failure{BL_E_UNSUPPORTED, kIrregular};
+        }
+      }
+      // joins written by a later block: the first face of block pos must equal the last face of pos - 1
+      for (int blk = 0; blk < n_b; blk++) {
+        const int pos = block_pos[a][blk];
+        const double *f = block_xf[a] + static_cast<size_t>(blk) * (nb_cells[a] + 1);
+        if (std::memcmp(global_xf[a].data() + static_cast<size_t>(pos) * nb_cells[a], f, sizeof(double)) != 0
+            || std::memcmp(global_xf[a].data() + static_cast<size_t>(pos + 1) * nb_cells[a], f + nb_cells[a], sizeof(double)) != 0)
+          throw Failure{BL_E_UNSUPPORTED, kIrregular};
+      }
+    }
     const size_t n_cells = static_cast<size_t>(n_i) * n_j * n_k;
-    // Repack [var][k][j][i] -> [k][j][i][8]: rho, pgas, uu1, uu2, uu3, bb1, bb2, bb3
+    const size_t block_cells = static_cast<size_t>(nb_cells[0]) * nb_cells[1] * nb_cells[2];
+    // Repack [var][block][k][j][i] -> global [k][j][i][8]: rho, pgas, uu1, uu2, uu3, bb1, bb2, bb3
     const int order[8] = {g->ind_rho, g->ind_pgas, g->ind_uu1, g->ind_uu2, g->ind_uu3, g->ind_bb1, g->ind_bb2, g->ind_bb3};
     for (int v : order)
       if (v < 0 || v >= g->n_var) throw Failure{BL_E_ARG, "Grid variable index out of range."};
     std::vector<float> cells(n_cells * 8);
-    for (int v = 0; v < 8; v++) {
-      const float *src = g->prim + static_cast<size_t>(order[v]) * n_cells;
-      for (size_t c = 0; c < n_cells; c++) cells[c * 8 + v] = src[c];
+    for (int blk = 0; blk < n_b; blk++) {
+      const int pi = block_pos[0][blk], pj = block_pos[1][blk], pk = block_pos[2][blk];
+      for (int v = 0; v < 8; v++) {
+        const float *src = g->prim + (static_cast<size_t>(order[v]) * n_b + blk) * block_cells;
+        for (int k = 0; k < nb_cells[2]; k++)
+          for (int j = 0; j < nb_cells[1]; j++) {
+            const size_t row = (static_cast<size_t>(pk * nb_cells[2] + k) * n_j + (pj * nb_cells[1] + j)) * n_i + static_cast<size_t>(pi) * nb_cells[0];
+            const float *line = src + (static_cast<size_t>(k) * nb_cells[1] + j) * nb_cells[0];
+            for (int i = 0; i < nb_cells[0]; i++) cells[(row + i) * 8 + v] = line[i];
+          }
+      }
     }
     ctx->d_cells.Ensure(cells.size());
     Check(hipMemcpy(ctx->d_cells.ptr, cells.data(), cells.size() * sizeof(float), hipMemcpyHostToDevice), "grid upload");
     // coordinates
-    const int n[3] = {n_i, n_j, n_k};
-    const double *xf[3] = {g->x1f, g->x2f, g->x3f};
-    const double *xv[3] = {g->x1v, g->x2v, g->x3v};
+    const double *xf[3] = {global_xf[0].data(), global_xf[1].data(), global_xf[2].data()};
+    const double *xv[3] = {global_xv[0].data(), global_xv[1].data(), global_xv[2].data()};
     std::vector<double> coords;
     size_t off_f[3], off_v[3];
     for (int a = 0; a < 3; a++) {
@@ -564,6 +632,7 @@ int bl_set_grid(bl_ctx *ctx, const bl_grid_desc *g) {
       dev.xv[a] = ctx->d_coords.ptr + off_v[a];
       dev.bucket[a] = ctx->d_buckets.ptr + off_b[a];
       dev.n[a] = n[a];
+      dev.nb[a] = nb_cells[a];
     }
     ctx->grid_dev = dev;
     {

@@ -71,7 +71,8 @@ struct BlGridDevice {
   const int *bucket[3];      // bucket -> first candidate cell
   double bucket_x0[3], bucket_inv_w[3];
   int n_bucket[3];
-  int n[3];                  // n_i, n_j, n_k
+  int n[3];                  // n_i, n_j, n_k of the (merged) global grid
+  int nb[3];                 // cells per block along each axis (= n for a single block)
 };
 
 struct BlPlasmaDevice {

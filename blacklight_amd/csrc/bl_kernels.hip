@@ -733,9 +733,12 @@ __device__ __forceinline__ void locate_sample(const BlShadeArgs &P, const GridTa
     return;
   }
   // :485-490
-  int i_m = (i == 0 || (i != n_i - 1 && s1 >= tab.xv[0][i])) ? i : i - 1;
-  int j_m = (j == 0 || (j != n_j - 1 && s2 >= tab.xv[1][j])) ? j : j - 1;
-  int k_m = (k == 0 || (k != n_k - 1 && s3 >= tab.xv[2][k])) ? k : k - 1;
+  // the anchor rule is per block (the indices of :485-487 are block-local): several equal blocks live in one
+  // merged array here, g.nb is the block size
+  const int i_b = i % g.nb[0], j_b = j % g.nb[1], k_b = k % g.nb[2];
+  int i_m = (i_b == 0 || (i_b != g.nb[0] - 1 && s1 >= tab.xv[0][i])) ? i : i - 1;
+  int j_m = (j_b == 0 || (j_b != g.nb[1] - 1 && s2 >= tab.xv[1][j])) ? j : j - 1;
+  int k_m = (k_b == 0 || (k_b != g.nb[2] - 1 && s3 >= tab.xv[2][k])) ? k : k - 1;
   out->f_i = (s1 - tab.xv[0][i_m]) / (tab.xv[0][i_m + 1] - tab.xv[0][i_m]);
   out->f_j = (s2 - tab.xv[1][j_m]) / (tab.xv[1][j_m + 1] - tab.xv[1][j_m]);
   out->f_k = (s3 - tab.xv[2][k_m]) / (tab.xv[2][k_m + 1] - tab.xv[2][k_m]);

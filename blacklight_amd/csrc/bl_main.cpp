@@ -4,9 +4,9 @@
 // parameters and writing the image goes through the C-ABI (include/blacklight_amd.h) to the GPU.
 //
 // Snapshot input: the reference's own HDF5 / AthenaK / iharm readers are outside the hot-path scope
-// (SURVEY.md 8f); simulation_file must be a raw single-block grid file as written by
-// blacklight_amd.mock.Grid.save_raw (magic "BLGRID1", dimensions, coordinates, primitives), i.e. the
-// arrays SimulationReader would have produced.
+// (SURVEY.md 8f); simulation_file must be a raw grid file as written by blacklight_amd.mock.Grid.save_raw
+// (magic "BLGRID1" for one block, "BLGRID2" for several equal blocks; dimensions, coordinates,
+// primitives), i.e. the arrays SimulationReader would have produced.
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
@@ -27,11 +27,12 @@ double Now() {
 }
 
 struct RawGrid {
-  int32_t n_i = 0, n_j = 0, n_k = 0, n_var = 0;
-  std::vector<double> coords[6];   // x1f x2f x3f x1v x2v x3v
-  std::vector<float> prim;
+  int32_t n_b = 1, n_i = 0, n_j = 0, n_k = 0, n_var = 0;
+  std::vector<double> coords[6];   // x1f x2f x3f x1v x2v x3v, each [n_b][...]
+  std::vector<float> prim;         // [n_var][n_b][n_k][n_j][n_i]
 };
 
+// "BLGRID1": int32 n_i, n_j, n_k, n_var (one block); "BLGRID2": int32 n_b, n_i, n_j, n_k, n_var (n_b equal blocks)
 bool ReadRawGrid(const std::string &path, RawGrid *g, std::string *error) {
   std::ifstream f(path, std::ios::binary);
   if (!f.is_open()) {
@@ -40,23 +41,29 @@ bool ReadRawGrid(const std::string &path, RawGrid *g, std::string *error) {
   }
   char magic[8] = {};
   f.read(magic, 8);
-  if (std::memcmp(magic, "BLGRID1\0", 8) != 0) {
-    *error = "simulation_file is not a raw BLGRID1 grid (the HDF5 / AthenaK / iharm readers are outside the "
+  const bool v1 = std::memcmp(magic, "BLGRID1\0", 8) == 0, v2 = std::memcmp(magic, "BLGRID2\0", 8) == 0;
+  if (!v1 && !v2) {
+    *error = "simulation_file is not a raw BLGRID1 / BLGRID2 grid (the HDF5 / AthenaK / iharm readers are outside the "
              "scope of the MI355X hot path; convert the snapshot with blacklight_amd.mock.Grid.save_raw).";
     return false;
   }
+  if (v2) f.read(reinterpret_cast<char *>(&g->n_b), sizeof(int32_t));
   int32_t dims[4];
   f.read(reinterpret_cast<char *>(dims), sizeof dims);
   g->n_i = dims[0];
   g->n_j = dims[1];
   g->n_k = dims[2];
   g->n_var = dims[3];
+  if (!f || g->n_b < 1 || g->n_i < 1 || g->n_j < 1 || g->n_k < 1 || g->n_var < 1) {
+    *error = "Could not read file: " + path;
+    return false;
+  }
   const int counts[6] = {g->n_i + 1, g->n_j + 1, g->n_k + 1, g->n_i, g->n_j, g->n_k};
   for (int c = 0; c < 6; c++) {
-    g->coords[c].resize(counts[c]);
-    f.read(reinterpret_cast<char *>(g->coords[c].data()), sizeof(double) * counts[c]);
+    g->coords[c].resize(static_cast<size_t>(g->n_b) * counts[c]);
+    f.read(reinterpret_cast<char *>(g->coords[c].data()), sizeof(double) * g->coords[c].size());
   }
-  size_t n = static_cast<size_t>(g->n_var) * g->n_k * g->n_j * g->n_i;
+  size_t n = static_cast<size_t>(g->n_var) * g->n_b * g->n_k * g->n_j * g->n_i;
   g->prim.resize(n);
   f.read(reinterpret_cast<char *>(g->prim.data()), sizeof(float) * n);
   if (!f) {
@@ -111,7 +118,7 @@ int main(int argc, char *argv[]) {
         return 1;
       }
       bl_grid_desc g = {};
-      g.n_blocks = 1;
+      g.n_blocks = raw.n_b;
       g.n_i = raw.n_i; g.n_j = raw.n_j; g.n_k = raw.n_k; g.n_var = raw.n_var;
       g.prim = raw.prim.data();
       g.x1f = raw.coords[0].data(); g.x2f = raw.coords[1].data(); g.x3f = raw.coords[2].data();

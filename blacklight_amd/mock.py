@@ -45,9 +45,9 @@ def _default_uph_amp(uph_r_power):
 
 @dataclass
 class Grid:
-    """Single-block grid in the reference reader's layout (see bl_grid_desc)."""
-    prim: np.ndarray   # float32 [8][1][n_k][n_j][n_i]
-    x1f: np.ndarray    # float64 [1][n_i+1]
+    """Grid in the reference reader's layout (see bl_grid_desc): n_b equal blocks."""
+    prim: np.ndarray   # float32 [8][n_b][n_k][n_j][n_i]
+    x1f: np.ndarray    # float64 [n_b][n_i+1]
     x2f: np.ndarray
     x3f: np.ndarray
     x1v: np.ndarray    # float64 [1][n_i]
@@ -62,15 +62,19 @@ class Grid:
         return self.prim.shape[2:]
 
     def save_raw(self, path):
-        """Raw single-block grid file read by the command-line driver (bl_main.cpp): magic "BLGRID1",
-        int32 n_i, n_j, n_k, n_var, float64 x1f x2f x3f x1v x2v x3v, float32 prim[n_var][n_k][n_j][n_i]."""
+        """Raw grid file read by the command-line driver (bl_main.cpp). One block: magic "BLGRID1", int32 n_i,
+        n_j, n_k, n_var; several equal blocks: magic "BLGRID2", int32 n_b, n_i, n_j, n_k, n_var. Then float64
+        x1f x2f x3f x1v x2v x3v (each [n_b][...]) and float32 prim[n_var][n_b][n_k][n_j][n_i]."""
         n_var, n_b, n_k, n_j, n_i = self.prim.shape
-        assert n_b == 1
         with open(path, "wb") as f:
-            f.write(b"BLGRID1\0")
-            np.array([n_i, n_j, n_k, n_var], dtype=np.int32).tofile(f)
+            if n_b == 1:
+                f.write(b"BLGRID1\0")
+                np.array([n_i, n_j, n_k, n_var], dtype=np.int32).tofile(f)
+            else:
+                f.write(b"BLGRID2\0")
+                np.array([n_b, n_i, n_j, n_k, n_var], dtype=np.int32).tofile(f)
             for name in ("x1f", "x2f", "x3f", "x1v", "x2v", "x3v"):
-                np.ascontiguousarray(getattr(self, name)[0], dtype=np.float64).tofile(f)
+                np.ascontiguousarray(getattr(self, name), dtype=np.float64).tofile(f)
             np.ascontiguousarray(self.prim, dtype=np.float32).tofile(f)
 
     def desc(self):

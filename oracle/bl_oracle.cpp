@@ -1159,22 +1159,22 @@ bool GeometricCut(const Oracle &o, double x1, double x2, double x3, double r) {
   return false;
 }
 
-inline float GridVal(const bl_grid_desc &g, int var, int k, int j, int i) {
-  // Array<float>(n_var, n_b, n_k, n_j, n_i), block 0 (utils/array.cpp:317-325)
-  size_t idx = ((static_cast<size_t>(var) * g.n_blocks + 0) * g.n_k + k) * g.n_j + j;
+inline float GridVal(const bl_grid_desc &g, int var, int b, int k, int j, int i) {
+  // Array<float>(n_var, n_b, n_k, n_j, n_i) (utils/array.cpp:317-325)
+  size_t idx = ((static_cast<size_t>(var) * g.n_blocks + b) * g.n_k + k) * g.n_j + j;
   return g.prim[idx * g.n_i + i];
 }
 
 // simulation_sampling.cpp:1334-1351
-double InterpolateSimple(const bl_grid_desc &g, int var, int k, int j, int i, double f_k, double f_j, double f_i) {
-  double val_mmm = static_cast<double>(GridVal(g, var, k, j, i));
-  double val_mmp = static_cast<double>(GridVal(g, var, k, j, i + 1));
-  double val_mpm = static_cast<double>(GridVal(g, var, k, j + 1, i));
-  double val_mpp = static_cast<double>(GridVal(g, var, k, j + 1, i + 1));
-  double val_pmm = static_cast<double>(GridVal(g, var, k + 1, j, i));
-  double val_pmp = static_cast<double>(GridVal(g, var, k + 1, j, i + 1));
-  double val_ppm = static_cast<double>(GridVal(g, var, k + 1, j + 1, i));
-  double val_ppp = static_cast<double>(GridVal(g, var, k + 1, j + 1, i + 1));
+double InterpolateSimple(const bl_grid_desc &g, int var, int b, int k, int j, int i, double f_k, double f_j, double f_i) {
+  double val_mmm = static_cast<double>(GridVal(g, var, b, k, j, i));
+  double val_mmp = static_cast<double>(GridVal(g, var, b, k, j, i + 1));
+  double val_mpm = static_cast<double>(GridVal(g, var, b, k, j + 1, i));
+  double val_mpp = static_cast<double>(GridVal(g, var, b, k, j + 1, i + 1));
+  double val_pmm = static_cast<double>(GridVal(g, var, b, k + 1, j, i));
+  double val_pmp = static_cast<double>(GridVal(g, var, b, k + 1, j, i + 1));
+  double val_ppm = static_cast<double>(GridVal(g, var, b, k + 1, j + 1, i));
+  double val_ppp = static_cast<double>(GridVal(g, var, b, k + 1, j + 1, i + 1));
   double val = (1.0 - f_k) * (1.0 - f_j) * (1.0 - f_i) * val_mmm
       + (1.0 - f_k) * (1.0 - f_j) * f_i * val_mmp + (1.0 - f_k) * f_j * (1.0 - f_i) * val_mpm
       + (1.0 - f_k) * f_j * f_i * val_mpp + f_k * (1.0 - f_j) * (1.0 - f_i) * val_pmm
@@ -1187,9 +1187,16 @@ struct Prims {
   float rho, pgas, kappa, uu1, uu2, uu3, bb1, bb2, bb3;
 };
 
-// simulation_sampling.cpp:201-575 + :666-1033 for one sample (single block, no slow light).
+// The block a thread is looking at (simulation_sampling.cpp:205-214): the reference keeps it from one
+// sample to the next and only searches again, from block 0, when the point leaves it.
+struct BlockState {
+  int b = 0;
+  bool valid = false;
+};
+
+// simulation_sampling.cpp:201-575 + :666-1033 for one sample (no slow light).
 // Returns: 0 = sampled, 1 = cut, 2 = NaN, 3 = fallback values. *gathered set if the grid was read.
-int SampleOne(const Oracle &o, const double pos[4], Prims *out, bool *gathered) {
+int SampleOne(const Oracle &o, const double pos[4], Prims *out, bool *gathered, BlockState *state) {
   const bl_params &p = *o.p;
   const bl_grid_desc &g = *o.g;
   *gathered = false;
@@ -1197,13 +1204,32 @@ int SampleOne(const Oracle &o, const double pos[4], Prims *out, bool *gathered) 
   double r = RadialGeodesicCoordinate(o, x1, x2, x3);
   if (GeometricCut(o, x1, x2, x3, r)) return 1;
   ConvertFromCKS(o, &x1, &x2, &x3);
-  int n_i = g.n_i, n_j = g.n_j, n_k = g.n_k;
-  const double *x1f = g.x1f, *x2f = g.x2f, *x3f = g.x3f, *x1v = g.x1v, *x2v = g.x2v, *x3v = g.x3v;
-  // block test (:352-394), n_b = 1
-  if (x1 < x1f[0] or x1 > x1f[n_i] or x2 < x2f[0] or x2 > x2f[n_j] or x3 < x3f[0] or x3 > x3f[n_k]) {
-    if (p.fallback_nan) return 2;
-    return 3;
+  int n_i = g.n_i, n_j = g.n_j, n_k = g.n_k, n_b = g.n_blocks;
+  // block test and search (:352-394)
+  if (!state->valid) {   // :205-214: block 0 to start with
+    state->b = 0;
+    state->valid = true;
   }
+  int b = state->b;
+  auto inside = [&](int bb) {
+    return x1 >= g.x1f[static_cast<size_t>(bb) * (n_i + 1)] and x1 <= g.x1f[static_cast<size_t>(bb) * (n_i + 1) + n_i]
+        and x2 >= g.x2f[static_cast<size_t>(bb) * (n_j + 1)] and x2 <= g.x2f[static_cast<size_t>(bb) * (n_j + 1) + n_j]
+        and x3 >= g.x3f[static_cast<size_t>(bb) * (n_k + 1)] and x3 <= g.x3f[static_cast<size_t>(bb) * (n_k + 1) + n_k];
+  };
+  if (!inside(b)) {
+    int b_new;
+    for (b_new = 0; b_new < n_b; b_new++)
+      if (inside(b_new)) break;
+    if (b_new == n_b) {
+      if (p.fallback_nan) return 2;
+      return 3;
+    }
+    b = b_new;
+    state->b = b;
+  }
+  const double *x1f = g.x1f + static_cast<size_t>(b) * (n_i + 1), *x2f = g.x2f + static_cast<size_t>(b) * (n_j + 1);
+  const double *x3f = g.x3f + static_cast<size_t>(b) * (n_k + 1);
+  const double *x1v = g.x1v + static_cast<size_t>(b) * n_i, *x2v = g.x2v + static_cast<size_t>(b) * n_j, *x3v = g.x3v + static_cast<size_t>(b) * n_k;
   int i, j, k;  // :458-466
   for (i = 0; i < n_i; i++)
     if (x1f[i + 1] >= x1) break;
@@ -1214,15 +1240,15 @@ int SampleOne(const Oracle &o, const double pos[4], Prims *out, bool *gathered) 
   bool code_kappa = p.plasma_model == BL_PLASMA_CODE_KAPPA;
   *gathered = true;
   if (not p.simulation_interp) {  // :710-734
-    out->rho = GridVal(g, g.ind_rho, k, j, i);
-    out->pgas = GridVal(g, g.ind_pgas, k, j, i);
-    out->kappa = code_kappa ? GridVal(g, g.ind_kappa, k, j, i) : 0.0f;
-    out->uu1 = GridVal(g, g.ind_uu1, k, j, i);
-    out->uu2 = GridVal(g, g.ind_uu2, k, j, i);
-    out->uu3 = GridVal(g, g.ind_uu3, k, j, i);
-    out->bb1 = GridVal(g, g.ind_bb1, k, j, i);
-    out->bb2 = GridVal(g, g.ind_bb2, k, j, i);
-    out->bb3 = GridVal(g, g.ind_bb3, k, j, i);
+    out->rho = GridVal(g, g.ind_rho, b, k, j, i);
+    out->pgas = GridVal(g, g.ind_pgas, b, k, j, i);
+    out->kappa = code_kappa ? GridVal(g, g.ind_kappa, b, k, j, i) : 0.0f;
+    out->uu1 = GridVal(g, g.ind_uu1, b, k, j, i);
+    out->uu2 = GridVal(g, g.ind_uu2, b, k, j, i);
+    out->uu3 = GridVal(g, g.ind_uu3, b, k, j, i);
+    out->bb1 = GridVal(g, g.ind_bb1, b, k, j, i);
+    out->bb2 = GridVal(g, g.ind_bb2, b, k, j, i);
+    out->bb3 = GridVal(g, g.ind_bb3, b, k, j, i);
     return 0;
   }
   // intrablock interpolation (:485-490, :809-839)
@@ -1232,19 +1258,19 @@ int SampleOne(const Oracle &o, const double pos[4], Prims *out, bool *gathered) 
   double f_i = (x1 - x1v[i_m]) / (x1v[i_m + 1] - x1v[i_m]);
   double f_j = (x2 - x2v[j_m]) / (x2v[j_m + 1] - x2v[j_m]);
   double f_k = (x3 - x3v[k_m]) / (x3v[k_m + 1] - x3v[k_m]);
-  double rho = InterpolateSimple(g, g.ind_rho, k_m, j_m, i_m, f_k, f_j, f_i);
-  double pgas = InterpolateSimple(g, g.ind_pgas, k_m, j_m, i_m, f_k, f_j, f_i);
+  double rho = InterpolateSimple(g, g.ind_rho, b, k_m, j_m, i_m, f_k, f_j, f_i);
+  double pgas = InterpolateSimple(g, g.ind_pgas, b, k_m, j_m, i_m, f_k, f_j, f_i);
   double kappa = 0.0;
-  if (code_kappa) kappa = InterpolateSimple(g, g.ind_kappa, k_m, j_m, i_m, f_k, f_j, f_i);
-  double uu1 = InterpolateSimple(g, g.ind_uu1, k_m, j_m, i_m, f_k, f_j, f_i);
-  double uu2 = InterpolateSimple(g, g.ind_uu2, k_m, j_m, i_m, f_k, f_j, f_i);
-  double uu3 = InterpolateSimple(g, g.ind_uu3, k_m, j_m, i_m, f_k, f_j, f_i);
-  double bb1 = InterpolateSimple(g, g.ind_bb1, k_m, j_m, i_m, f_k, f_j, f_i);
-  double bb2 = InterpolateSimple(g, g.ind_bb2, k_m, j_m, i_m, f_k, f_j, f_i);
-  double bb3 = InterpolateSimple(g, g.ind_bb3, k_m, j_m, i_m, f_k, f_j, f_i);
-  if (rho <= 0.0) rho = static_cast<double>(GridVal(g, g.ind_rho, k_m, j_m, i_m));
-  if (pgas <= 0.0) pgas = static_cast<double>(GridVal(g, g.ind_pgas, k_m, j_m, i_m));
-  if (code_kappa and kappa <= 0.0) kappa = static_cast<double>(GridVal(g, g.ind_kappa, k_m, j_m, i_m));
+  if (code_kappa) kappa = InterpolateSimple(g, g.ind_kappa, b, k_m, j_m, i_m, f_k, f_j, f_i);
+  double uu1 = InterpolateSimple(g, g.ind_uu1, b, k_m, j_m, i_m, f_k, f_j, f_i);
+  double uu2 = InterpolateSimple(g, g.ind_uu2, b, k_m, j_m, i_m, f_k, f_j, f_i);
+  double uu3 = InterpolateSimple(g, g.ind_uu3, b, k_m, j_m, i_m, f_k, f_j, f_i);
+  double bb1 = InterpolateSimple(g, g.ind_bb1, b, k_m, j_m, i_m, f_k, f_j, f_i);
+  double bb2 = InterpolateSimple(g, g.ind_bb2, b, k_m, j_m, i_m, f_k, f_j, f_i);
+  double bb3 = InterpolateSimple(g, g.ind_bb3, b, k_m, j_m, i_m, f_k, f_j, f_i);
+  if (rho <= 0.0) rho = static_cast<double>(GridVal(g, g.ind_rho, b, k_m, j_m, i_m));
+  if (pgas <= 0.0) pgas = static_cast<double>(GridVal(g, g.ind_pgas, b, k_m, j_m, i_m));
+  if (code_kappa and kappa <= 0.0) kappa = static_cast<double>(GridVal(g, g.ind_kappa, b, k_m, j_m, i_m));
   out->rho = static_cast<float>(rho);
   out->pgas = static_cast<float>(pgas);
   out->kappa = static_cast<float>(kappa);
@@ -1715,7 +1741,7 @@ int Setup(Oracle &o, const bl_params *p, const bl_grid_desc *g, char *err, size_
   if (o.image_polarization) return Fail(err, err_len, "oracle: polarized transfer not restated yet", BL_E_UNSUPPORTED);
   if (p->model_type == BL_MODEL_SIMULATION) {
     if (g == nullptr) return Fail(err, err_len, "oracle: simulation mode needs a grid", BL_E_ARG);
-    if (g->n_blocks != 1) return Fail(err, err_len, "oracle: multi-block grids not restated yet", BL_E_UNSUPPORTED);
+    if (p->simulation_block_interp) return Fail(err, err_len, "oracle: inter-block interpolation not restated (out-of-bounds read in the reference)", BL_E_UNSUPPORTED);
     if (p->slow_light_on) return Fail(err, err_len, "oracle: slow light not restated yet", BL_E_UNSUPPORTED);
     if (p->simulation_coord == BL_COORD_FMKS) return Fail(err, err_len, "oracle: fmks not restated yet", BL_E_UNSUPPORTED);
     if (p->plasma_kappa_frac != 0.0)
@@ -1804,6 +1830,8 @@ int blo_render(const bl_params *p, const bl_grid_desc *g, const bl_render_desc *
   #pragma omp parallel num_threads(num_threads) reduction(+: total_samples, total_gathers, total_flagged) reduction(max: max_sample_num)
   {
     RayBuffers b(max_steps, nf);
+    BlockState block_state;   // per thread, kept across rays like the reference's (which rays share a thread
+                              // differs, and only matters for a sample exactly on a face shared by two blocks)
     std::vector<double> image_col(std::max(n_q, 1));
     #pragma omp for schedule(dynamic, 16)
     for (int64_t ray = 0; ray < n_rays; ray++) {
@@ -1858,7 +1886,7 @@ int blo_render(const bl_params *p, const bl_grid_desc *g, const bl_render_desc *
           if (nan_ray)
             status = 2;
           else
-            status = SampleOne(o, &b.sample_pos[4 * n], &s, &gathered);
+            status = SampleOne(o, &b.sample_pos[4 * n], &s, &gathered, &block_state);
           if (gathered) total_gathers++;
           if (status == 1) continue;  // cut: simulation_coefficients.cpp:260-261
           if (status == 2) {

@@ -28,14 +28,37 @@ def golden_grid(mock_args):
     build's generator, so that parity tests do not depend on blacklight_amd.mock."""
     from blacklight_amd.mock import Grid
     fx = np.load(os.path.join(GOLDEN_DIR, "mock_small.npz"), allow_pickle=False)
+    mock_args = dict(mock_args)
+    blocks = mock_args.pop("_blocks", None)
     assert json.loads(str(fx["mock_args"])) == mock_args
     prim = np.ascontiguousarray(fx["prim"], dtype=np.float32)
 
     def coord(name):
         return np.ascontiguousarray(fx[name].astype(np.float32).astype(np.float64).reshape(1, -1))
 
-    return Grid(prim=prim, x1f=coord("x1f"), x2f=coord("x2f"), x3f=coord("x3f"),
+    grid = Grid(prim=prim, x1f=coord("x1f"), x2f=coord("x2f"), x3f=coord("x3f"),
                 x1v=coord("x1v"), x2v=coord("x2v"), x3v=coord("x3v"))
+    return split_grid(grid, *blocks) if blocks is not None else grid
+
+
+def split_grid(grid, nbi, nbj, nbk):
+    """The single-block grid as nbi x nbj x nbk equal blocks in the scrambled order that
+    tools/make_goldens.py split_into_blocks wrote for the reference (same permutation)."""
+    from blacklight_amd.mock import Grid
+    n_var, _, n_k, n_j, n_i = grid.prim.shape
+    ni, nj, nk = n_i // nbi, n_j // nbj, n_k // nbk
+    blocks = [(bk, bj, bi) for bk in range(nbk) for bj in range(nbj) for bi in range(nbi)]
+    order = np.random.default_rng(3).permutation(len(blocks))
+    blocks = [blocks[o] for o in order]
+    prim = np.empty((n_var, len(blocks), nk, nj, ni), dtype=np.float32)
+    for n, (bk, bj, bi) in enumerate(blocks):
+        prim[:, n] = grid.prim[:, 0, bk * nk:(bk + 1) * nk, bj * nj:(bj + 1) * nj, bi * ni:(bi + 1) * ni]
+
+    def cut(arr, n, sel, extra):
+        return np.ascontiguousarray(np.array([arr[0, b[sel] * n: b[sel] * n + n + extra] for b in blocks]))
+
+    return Grid(prim=prim, x1f=cut(grid.x1f, ni, 2, 1), x2f=cut(grid.x2f, nj, 1, 1), x3f=cut(grid.x3f, nk, 0, 1),
+                x1v=cut(grid.x1v, ni, 2, 0), x2v=cut(grid.x2v, nj, 1, 0), x3v=cut(grid.x3v, nk, 0, 0))
 
 
 IMAGE_ROW_NAMES = ["I_nu", "time", "length", "lambda", "emission", "tau", "lambda_ave_rho", "lambda_ave_n_e",

@@ -98,6 +98,10 @@ CASES = {
                                 cut_rho_min=1.0e-19, cut_b_max=1.0e3, cut_beta_inverse_max=5.0), SMALL_MOCK, [300]),
     "sim_few_steps": (SIM_BASE, dict(camera_resolution=16, ray_max_steps=450), SMALL_MOCK, [136]),
     "sim_pole": (SIM_BASE, dict(camera_resolution=16, camera_th=0.0), SMALL_MOCK, [136]),
+    # eight equal MeshBlocks in scrambled order (the mock script writes one block; the file is split afterwards)
+    "sim_multiblock": (SIM_BASE, dict(camera_resolution=32), dict(SMALL_MOCK, _blocks=[2, 2, 2]), [528]),
+    "sim_multiblock_nearest": (SIM_BASE, dict(camera_resolution=24, simulation_interp="false", simulation_a=0.5),
+                               dict(SMALL_MOCK, _blocks=[4, 2, 2]), [300]),
     "sim_powerlaw": (SIM_BASE, dict(camera_resolution=24, plasma_power_frac=0.3, plasma_p=2.5, plasma_gamma_min=1.0,
                                     plasma_gamma_max=1000.0), SMALL_MOCK, [300]),
     # false-colour renderings (rendering.cpp): the features of the reference's example_render.input, without
@@ -218,6 +222,41 @@ def mock_arrays(path):
     return prim, coords
 
 
+def split_into_blocks(src, dst, nbi, nbj, nbk):
+    """Rewrite the single-block athdf `src` as nbi x nbj x nbk equal MeshBlocks (same level), in a scrambled
+    block order (the reader accepts any). Same decomposition as tests/golden_util.split_grid."""
+    import h5py
+    with h5py.File(src, "r") as f:
+        attrs = {k: f.attrs[k] for k in f.attrs}
+        xf = [f["x1f"][0], f["x2f"][0], f["x3f"][0]]
+        xv = [f["x1v"][0], f["x2v"][0], f["x3v"][0]]
+        prim, bfield = f["prim"][:, 0], f["B"][:, 0]
+    ni, nj, nk = len(xv[0]) // nbi, len(xv[1]) // nbj, len(xv[2]) // nbk
+    blocks = [(bk, bj, bi) for bk in range(nbk) for bj in range(nbj) for bi in range(nbi)]
+    order = np.random.default_rng(3).permutation(len(blocks))
+    blocks = [blocks[o] for o in order]
+    nb = len(blocks)
+    with h5py.File(dst, "w") as g:
+        for k, v in attrs.items():
+            if k not in ("NumMeshBlocks", "MeshBlockSize"):
+                g.attrs.create(k, v, dtype=v.dtype)
+        g.attrs.create("NumMeshBlocks", nb, dtype=np.int32)
+        g.attrs.create("MeshBlockSize", (ni, nj, nk), dtype=np.int32)
+        g.create_dataset("Levels", data=np.zeros(nb), dtype=np.int32)
+        g.create_dataset("LogicalLocations", data=np.array([(bi, bj, bk) for bk, bj, bi in blocks]), shape=(nb, 3), dtype=np.int64)
+        for axis, (name, n, sel) in enumerate((("x1", ni, 2), ("x2", nj, 1), ("x3", nk, 0))):
+            g.create_dataset(name + "f", data=np.array([xf[axis][b[sel] * n: b[sel] * n + n + 1] for b in blocks], dtype=np.float32))
+            g.create_dataset(name + "v", data=np.array([xv[axis][b[sel] * n: b[sel] * n + n] for b in blocks], dtype=np.float32))
+
+        def cut(a):
+            out = np.empty((a.shape[0], nb, nk, nj, ni), dtype=np.float32)
+            for n, (bk, bj, bi) in enumerate(blocks):
+                out[:, n] = a[:, bk * nk:(bk + 1) * nk, bj * nj:(bj + 1) * nj, bi * ni:(bi + 1) * ni]
+            return out
+        g.create_dataset("prim", data=cut(prim))
+        g.create_dataset("B", data=cut(bfield))
+
+
 def make_case(name):
     base, overrides, mock, dump_rays = CASES[name]
     params = dict(base)
@@ -230,8 +269,13 @@ def make_case(name):
         mock_path = os.path.join(workdir, "data", "mock.athdf")
         args = [sys.executable, "-W", "ignore", MOCK_SCRIPT, mock_path]
         for key, value in mock.items():
-            args += [f"--{key}", str(value)]
+            if not key.startswith("_"):
+                args += [f"--{key}", str(value)]
         subprocess.run(args, check=True)
+        if "_blocks" in mock:   # several MeshBlocks: split the script's single block
+            single = os.path.join(workdir, "data", "mock_single.athdf")
+            os.replace(mock_path, single)
+            split_into_blocks(single, mock_path, *mock["_blocks"])
         fixture["mock_args"] = json.dumps(mock)
     write_input(os.path.join(workdir, "case.input"), params)
     # what the test feeds to the build: same keys without file plumbing
