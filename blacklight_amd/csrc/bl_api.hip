@@ -97,6 +97,7 @@ struct bl_ctx {
   int n_i = 0, n_j = 0, n_k = 0;
   bl_grid_desc grid_meta{};
   DeviceBuffer<float> d_cells;
+  DeviceBuffer<float> d_kappa;   // electron entropy per cell (plasma_model = code_kappa)
   DeviceBuffer<double> d_coords;   // x1f x1v x2f x2v x3f x3v packed
   DeviceBuffer<int> d_buckets;
   BlGridDevice grid_dev{};
@@ -349,8 +350,6 @@ void ValidateRadiation(bl_ctx *ctx) {
     Require(p, {BL_P_plasma_mu, BL_P_plasma_ne_ni, BL_P_plasma_model}, kRadMissing);
     if (p.plasma_model == BL_PLASMA_TI_TE_BETA)
       Require(p, {BL_P_plasma_use_p, BL_P_plasma_rat_low, BL_P_plasma_rat_high}, kRadMissing);
-    else
-      throw Failure{BL_E_UNSUPPORTED, "plasma_model = code_kappa is not built yet."};
     Require(p, {BL_P_plasma_power_frac}, kRadMissing);
     if (p.plasma_power_frac < 0.0 || p.plasma_power_frac > 1.0) Warn(ctx, "Fraction of power-law electrons outside [0, 1].");
     Require(p, {BL_P_plasma_kappa_frac}, kRadMissing);
@@ -375,6 +374,7 @@ void ValidateRadiation(bl_ctx *ctx) {
             kRadMissing);
   Require(p, {BL_P_fallback_nan}, kRadMissing);
   if (simulation && !p.fallback_nan) Require(p, {BL_P_fallback_rho, BL_P_fallback_pgas}, kRadMissing);
+  if (simulation && !p.fallback_nan && p.plasma_model == BL_PLASMA_CODE_KAPPA) Require(p, {BL_P_fallback_kappa}, kRadMissing);
 
   // geometry data and image rows (:419-520)
   ctx->frame.mass_msun = simulation ? p.simulation_m_msun : p.formula_mass * kC * kC / kGGMsun;
@@ -599,6 +599,24 @@ int bl_set_grid(bl_ctx *ctx, const bl_grid_desc *g) {
     }
     ctx->d_cells.Ensure(cells.size());
     Check(hipMemcpy(ctx->d_cells.ptr, cells.data(), cells.size() * sizeof(float), hipMemcpyHostToDevice), "grid upload");
+    const bool code_kappa = ctx->params.plasma_model == BL_PLASMA_CODE_KAPPA;
+    if (code_kappa) {
+      // the ninth value of a cell (simulation_reader.cpp:1164-1172) in its own [k][j][i] array: only the
+      // extended coefficient kernel reads it
+      if (g->ind_kappa < 0 || g->ind_kappa >= g->n_var) throw Failure{BL_E_ARG, "Grid variable index out of range."};
+      std::vector<float> kappa(n_cells);
+      for (int blk = 0; blk < n_b; blk++) {
+        const int pi = block_pos[0][blk], pj = block_pos[1][blk], pk = block_pos[2][blk];
+        const float *src = g->prim + (static_cast<size_t>(g->ind_kappa) * n_b + blk) * block_cells;
+        for (int k = 0; k < nb_cells[2]; k++)
+          for (int j = 0; j < nb_cells[1]; j++) {
+            const size_t row = (static_cast<size_t>(pk * nb_cells[2] + k) * n_j + (pj * nb_cells[1] + j)) * n_i + static_cast<size_t>(pi) * nb_cells[0];
+            std::memcpy(kappa.data() + row, src + (static_cast<size_t>(k) * nb_cells[1] + j) * nb_cells[0], sizeof(float) * nb_cells[0]);
+          }
+      }
+      ctx->d_kappa.Ensure(kappa.size());
+      Check(hipMemcpy(ctx->d_kappa.ptr, kappa.data(), kappa.size() * sizeof(float), hipMemcpyHostToDevice), "grid upload");
+    }
     // coordinates
     const double *xf[3] = {global_xf[0].data(), global_xf[1].data(), global_xf[2].data()};
     const double *xv[3] = {global_xv[0].data(), global_xv[1].data(), global_xv[2].data()};
@@ -627,6 +645,7 @@ int bl_set_grid(bl_ctx *ctx, const bl_grid_desc *g) {
     ctx->d_buckets.Ensure(buckets.size());
     Check(hipMemcpy(ctx->d_buckets.ptr, buckets.data(), buckets.size() * sizeof(int), hipMemcpyHostToDevice), "bucket upload");
     dev.cells = ctx->d_cells.ptr;
+    dev.kappa = code_kappa ? ctx->d_kappa.ptr : nullptr;
     for (int a = 0; a < 3; a++) {
       dev.xf[a] = ctx->d_coords.ptr + off_f[a];
       dev.xv[a] = ctx->d_coords.ptr + off_v[a];
@@ -934,6 +953,8 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
       pl.fallback_nan = p.fallback_nan;
       cold.fallback_rho = p.fallback_nan ? 0.0f : p.fallback_rho;
       cold.fallback_pgas = p.fallback_nan ? 0.0f : p.fallback_pgas;
+      cold.fallback_kappa = p.fallback_nan ? 0.0f : p.fallback_kappa;
+      pl.code_kappa = p.plasma_model == BL_PLASMA_CODE_KAPPA ? 1 : 0;
       cold.cut_rho_min = p.cut_rho_min; cold.cut_rho_max = p.cut_rho_max;
       cold.cut_n_e_min = p.cut_n_e_min; cold.cut_n_e_max = p.cut_n_e_max;
       cold.cut_p_gas_min = p.cut_p_gas_min; cold.cut_p_gas_max = p.cut_p_gas_max;
@@ -1158,7 +1179,7 @@ void bl_free(bl_ctx *ctx) {
     return;
   }
   (void)hipSetDevice(ctx->device);
-  ctx->d_cells.Free(); ctx->d_coords.Free(); ctx->d_buckets.Free(); ctx->slot[0].Free(); ctx->slot[1].Free();
+  ctx->d_cells.Free(); ctx->d_kappa.Free(); ctx->d_coords.Free(); ctx->d_buckets.Free(); ctx->slot[0].Free(); ctx->slot[1].Free();
   ctx->d_freq.Free(); ctx->d_pixel_map.Free();
   ctx->d_block_locs.Free(); ctx->d_tile_order.Free(); ctx->d_render_params.Free(); ctx->d_render.Free(); ctx->d_shade_cold.Free(); ctx->d_image.Free(); ctx->d_camera_pos.Free(); ctx->d_camera_dir.Free();
   ctx->d_out_sample_num.Free(); ctx->d_out_flags.Free();

@@ -66,6 +66,7 @@ enum BlCounter {
 
 struct BlGridDevice {
   const float *cells;        // [n_k][n_j][n_i][8]
+  const float *kappa;        // [n_k][n_j][n_i] electron entropy (plasma_model = code_kappa), else null
   const double *xf[3];       // faces  (r, theta, phi)
   const double *xv[3];       // centres
   const int *bucket[3];      // bucket -> first candidate cell
@@ -86,6 +87,7 @@ struct BlPlasmaDevice {
   int any_cell_cut;          // some cell cut threshold (simulation_coefficients.cpp:361-375) is >= 0
   // power-law electrons (simulation_coefficients.cpp:54-66, :556-584); power_frac = 0: none
   double power_frac, plasma_p, power_jj, power_aa;
+  int code_kappa;            // plasma_model = code_kappa: theta_e from the simulation's electron entropy (:351-358)
 };
 
 // Rarely used parameters of the shading kernel (optional geometric cuts, cell cut thresholds,
@@ -99,7 +101,7 @@ struct BlShadeCold {
   double cut_rho_min, cut_rho_max, cut_n_e_min, cut_n_e_max, cut_p_gas_min, cut_p_gas_max;
   double cut_theta_e_min, cut_theta_e_max, cut_b_min, cut_b_max, cut_sigma_min, cut_sigma_max;
   double cut_beta_inverse_min, cut_beta_inverse_max;
-  float fallback_rho, fallback_pgas;
+  float fallback_rho, fallback_pgas, fallback_kappa;
   double plasma_gamma, plasma_gamma_i, plasma_gamma_e;
 };
 

@@ -802,11 +802,39 @@ __device__ __forceinline__ void sample_primitives(const BlShadeArgs &P, int stat
   }
 }
 
+// The electron entropy of a located sample (plasma_model = code_kappa; simulation_sampling.cpp:726-727,
+// :812-833): same nearest / trilinear rule as the other primitives, from its own array.
+__device__ __forceinline__ float sample_kappa(const BlShadeArgs &P, int status, uint32_t cell, double f_i, double f_j,
+                                              double f_k) {
+  const BlGridDevice &g = P.grid;
+  const float *base = g.kappa + cell;
+  if (status == kSampleInterp) {
+    const size_t row = (size_t)g.n[0], plane = (size_t)g.n[1] * row;
+    float c[8];
+#pragma unroll
+    for (int corner = 0; corner < 8; corner++)
+      c[corner] = base[(corner >> 2) * plane + ((corner >> 1) & 1) * row + (corner & 1)];
+    const double w_k[2] = {1.0 - f_k, f_k}, w_j[2] = {1.0 - f_j, f_j}, w_i[2] = {1.0 - f_i, f_i};
+    double val = 0.0;
+#pragma unroll
+    for (int corner = 0; corner < 8; corner++) {
+      const double w = w_k[corner >> 2] * w_j[(corner >> 1) & 1] * w_i[corner & 1];
+      val = corner == 0 ? w * (double)c[0] : val + w * (double)c[corner];
+    }
+    if (val <= 0.0) val = (double)c[0];   // :826-827
+    return (float)val;
+  }
+  if (status == kSampleNearest) return base[0];
+  if (status == kSampleOffGrid) return P.plasma.fallback_nan ? __int_as_float(0x7fc00000) : P.cold->fallback_kappa;
+  return 0.0f;
+}
+
 // Simulation mode: the frequency-independent part of CalculateSimulationCoefficients
-// (simulation_coefficients.cpp:253-455).
+// (simulation_coefficients.cpp:253-455). kExtended: the instantiation that also knows plasma_model = code_kappa.
+template <bool kExtended>
 __device__ __forceinline__ void sample_finish_simulation(const BlShadeArgs &P, const BlSpacetime &st,
                                                          const BlKerrSchild &ks, double cth, double ph_unwrapped,
-                                                         const float pr[8], const double kcov[4],
+                                                         const float pr[8], float kappa_f, const double kcov[4],
                                                          int need_coefficients, SampleShade *out) {
   const BlPlasmaDevice &pl = P.plasma;
   const double bh_a = st.bh_a, bh_m = st.bh_m;
@@ -914,7 +942,17 @@ __device__ __forceinline__ void sample_finish_simulation(const BlShadeArgs &P, c
   // electron temperature, T_i/T_e(beta) model (:333-348)
   double theta_e = __longlong_as_double(0x7ff8000000000000ll);
   double kb_tt_e_cgs = theta_e;
-  if (pl.plasma_thermal_frac != 0.0) {
+  if (kExtended && pl.code_kappa) {
+    // electron entropy model (:351-358)
+    if (pl.plasma_thermal_frac != 0.0) {
+      const double kappa = kappa_f;
+      const double mu_e = pl.plasma_mu * (1.0 + 1.0 / pl.plasma_ne_ni);
+      const double rho_e = rho * kMe / (mu_e * kMp);
+      const double rho_kappa_e_cbrt = bl_cbrt(rho_e * kappa);
+      theta_e = 1.0 / 5.0 * (blm_sqrt(1.0 + 25.0 * rho_kappa_e_cbrt * rho_kappa_e_cbrt) - 1.0);
+      kb_tt_e_cgs = theta_e * kMe * kC * kC;
+    }
+  } else if (pl.plasma_thermal_frac != 0.0) {
     double tti_tte = bl_div_g(pl.plasma_rat_high + pl.plasma_rat_low * beta_inv * beta_inv, 1.0 + beta_inv * beta_inv);
     double kb_tt_tot_cgs = bl_div_g(pl.plasma_mu * kMp * pgas_cgs, rho_cgs);
     if (pl.plasma_use_p) {
@@ -1156,9 +1194,10 @@ __global__ void __launch_bounds__(256, 4) bl_locate_kernel(const BlShadeArgs P) 
 // kAux (any auxiliary image requested, unpolarized.cpp:113-173): the per-frequency pairs written are
 // (j_nu, alpha_nu) instead of (a, b), and one BlAuxSample per sample goes with them; the auxiliary
 // transfer kernel integrates everything. Kept out of the instantiations the benchmark path runs.
-// kPowerLaw: power-law electrons present (simulation_coefficients.cpp:556-584): two more pow() per
-// sample and frequency; its own instantiation so that the thermal-only kernel keeps its registers.
-template <int kModel, bool kAux, bool kPowerLaw>
+// kExtended: power-law electrons present (simulation_coefficients.cpp:556-584: two more pow() per
+// sample and frequency) or plasma_model = code_kappa (:351-358: a ninth grid value per cell); its own
+// instantiation so that the thermal-only T_i/T_e(beta) kernel keeps its registers.
+template <int kModel, bool kAux, bool kExtended>
 __global__ void __launch_bounds__(256, 2) bl_shade_kernel(const BlShadeArgs P) {
   const BlSpacetime st = P.st;
   const unsigned long long n_records = P.counters_in[BL_CNT_RECORDS];
@@ -1191,6 +1230,7 @@ __global__ void __launch_bounds__(256, 2) bl_shade_kernel(const BlShadeArgs P) {
       momentum_factor = P.ray_factor[ray];
     }
     float pr[8];
+    float kappa_f = 0.0f;
     double ph = 0.0;
     int status = kSampleNone;
     if (kModel == BL_MODEL_SIMULATION && live) {
@@ -1198,6 +1238,7 @@ __global__ void __launch_bounds__(256, 2) bl_shade_kernel(const BlShadeArgs P) {
       ph = l1.y;
       status = (int)(tag >> 32);
       sample_primitives(P, status, (uint32_t)tag, l0.x, l0.y, l1.x, pr);
+      if (kExtended && P.plasma.code_kappa) kappa_f = sample_kappa(P, status, (uint32_t)tag, l0.x, l0.y, l1.x);
     }
     idx += stride;
     more = idx < n_records;
@@ -1253,12 +1294,14 @@ __global__ void __launch_bounds__(256, 2) bl_shade_kernel(const BlShadeArgs P) {
       if (nan_ray && kModel == BL_MODEL_SIMULATION) {
         const float fnan = __int_as_float(0x7fc00000);
         for (int v = 0; v < 8; v++) pr[v] = fnan;
+        kappa_f = fnan;
         status = kSampleOffGrid;
       }
     }
     if (status != kSampleCut) {
       if (kModel == BL_MODEL_SIMULATION)
-        sample_finish_simulation(P, st, ks, x3 / ks.r, ph, pr, kcov, kAux ? P.aux_need_coefficients : 1, &sh);
+        sample_finish_simulation<kExtended>(P, st, ks, x3 / ks.r, ph, pr, kappa_f, kcov,
+                                            kAux ? P.aux_need_coefficients : 1, &sh);
       else if (!(kAux && nan_ray))
         shade_formula(P, st, ks.r, x1, x2, x3, &sh);
     }
@@ -1319,7 +1362,7 @@ __global__ void __launch_bounds__(256, 2) bl_shade_kernel(const BlShadeArgs P) {
           // NaN fails both tests. One compare instead of a division.
           if (alpha_val * alpha_val <= 0x1p-1024) alpha_val = 0.0;
         }
-        if (kPowerLaw && P.plasma.power_frac != 0.0) {
+        if (kExtended && P.plasma.power_frac != 0.0) {
           // power-law electrons, unpolarized (simulation_coefficients.cpp:556-584)
           const double ratio = nu_cgs / (sh.nu_c_cgs * sh.sin_theta_b);
           const double var_a_j = bl_pow(ratio, -(P.plasma.plasma_p - 1.0) / 2.0);
@@ -1655,7 +1698,7 @@ extern "C" hipError_t bl_launch_locate(const BlShadeArgs *args, int grid, int ld
 // Coefficient kernel
 extern "C" hipError_t bl_launch_shade(const BlShadeArgs *args, int model, int grid, hipStream_t stream) {
   const bool aux = args->aux != nullptr;
-  const bool power = args->plasma.power_frac != 0.0;
+  const bool power = args->plasma.power_frac != 0.0 || args->plasma.code_kappa != 0;
 #define BL_LAUNCH_S(M, A, W) hipLaunchKernelGGL((bl_shade_kernel<M, A, W>), dim3(grid), dim3(256), 0, stream, *args)
   if (model == BL_MODEL_SIMULATION) {
     if (aux && power) BL_LAUNCH_S(BL_MODEL_SIMULATION, true, true);

@@ -125,6 +125,7 @@ int main(int argc, char *argv[]) {
       g.x1v = raw.coords[3].data(); g.x2v = raw.coords[4].data(); g.x3v = raw.coords[5].data();
       g.ind_rho = 0; g.ind_pgas = 1; g.ind_uu1 = 2; g.ind_uu2 = 3; g.ind_uu3 = 4;
       g.ind_bb1 = 5; g.ind_bb2 = 6; g.ind_bb3 = 7;
+      g.ind_kappa = raw.n_var > 8 ? 8 : 0;   // a ninth variable is the electron entropy (plasma_model = code_kappa)
       g.plasma_gamma = params.has[BL_P_plasma_gamma] ? params.plasma_gamma : 0.0;
       g.plasma_gamma_i = params.has[BL_P_plasma_gamma_i] ? params.plasma_gamma_i : 0.0;
       g.plasma_gamma_e = params.has[BL_P_plasma_gamma_e] ? params.plasma_gamma_e : 0.0;

@@ -56,6 +56,7 @@ class Grid:
     plasma_gamma: float = 0.0
     plasma_gamma_i: float = 0.0
     plasma_gamma_e: float = 0.0
+    ind_kappa: int = -1   # index of the electron entropy in prim (plasma_model = code_kappa), -1: none
 
     @property
     def shape(self):
@@ -89,10 +90,30 @@ class Grid:
         # VerifyVariablesAthena (simulation_reader.cpp:1141-1216) for the order written above
         d.ind_rho, d.ind_pgas, d.ind_uu1, d.ind_uu2, d.ind_uu3 = 0, 1, 2, 3, 4
         d.ind_bb1, d.ind_bb2, d.ind_bb3 = 5, 6, 7
-        d.ind_kappa = 0
+        d.ind_kappa = max(self.ind_kappa, 0)
         d.plasma_gamma, d.plasma_gamma_i, d.plasma_gamma_e = (
             self.plasma_gamma, self.plasma_gamma_i, self.plasma_gamma_e)
         return d
+
+
+ENTROPY_SCALE = np.float32(2.0 ** 26)
+
+
+def electron_entropy(rho, pgas):
+    """A stand-in electron entropy variable for plasma_model = code_kappa (the reference's mock script writes
+    none): 2^26 p / rho^(3/2) in single precision - only correctly rounded operations, so that any host
+    reproduces it bit for bit. Gives Theta_e of order 1..10 on the mock torus."""
+    rho = np.asarray(rho, dtype=np.float32)
+    pgas = np.asarray(pgas, dtype=np.float32)
+    return (ENTROPY_SCALE * (pgas / (rho * np.sqrt(rho)))).astype(np.float32)
+
+
+def with_entropy(grid):
+    """The grid with electron_entropy() appended as a ninth variable."""
+    import dataclasses
+    kappa = electron_entropy(grid.prim[0], grid.prim[1])
+    prim = np.ascontiguousarray(np.concatenate([grid.prim[:8], kappa[None]], axis=0), dtype=np.float32)
+    return dataclasses.replace(grid, prim=prim, ind_kappa=8)
 
 
 def generate(**overrides):

@@ -30,6 +30,7 @@ def golden_grid(mock_args):
     fx = np.load(os.path.join(GOLDEN_DIR, "mock_small.npz"), allow_pickle=False)
     mock_args = dict(mock_args)
     blocks = mock_args.pop("_blocks", None)
+    entropy = mock_args.pop("_entropy", None)
     assert json.loads(str(fx["mock_args"])) == mock_args
     prim = np.ascontiguousarray(fx["prim"], dtype=np.float32)
 
@@ -38,6 +39,9 @@ def golden_grid(mock_args):
 
     grid = Grid(prim=prim, x1f=coord("x1f"), x2f=coord("x2f"), x3f=coord("x3f"),
                 x1v=coord("x1v"), x2v=coord("x2v"), x3v=coord("x3v"))
+    if entropy:
+        from blacklight_amd.mock import with_entropy
+        grid = with_entropy(grid)
     return split_grid(grid, *blocks) if blocks is not None else grid
 
 
@@ -58,7 +62,8 @@ def split_grid(grid, nbi, nbj, nbk):
         return np.ascontiguousarray(np.array([arr[0, b[sel] * n: b[sel] * n + n + extra] for b in blocks]))
 
     return Grid(prim=prim, x1f=cut(grid.x1f, ni, 2, 1), x2f=cut(grid.x2f, nj, 1, 1), x3f=cut(grid.x3f, nk, 0, 1),
-                x1v=cut(grid.x1v, ni, 2, 0), x2v=cut(grid.x2v, nj, 1, 0), x3v=cut(grid.x3v, nk, 0, 0))
+                x1v=cut(grid.x1v, ni, 2, 0), x2v=cut(grid.x2v, nj, 1, 0), x3v=cut(grid.x3v, nk, 0, 0),
+                ind_kappa=grid.ind_kappa)
 
 
 IMAGE_ROW_NAMES = ["I_nu", "time", "length", "lambda", "emission", "tau", "lambda_ave_rho", "lambda_ave_n_e",

@@ -102,6 +102,13 @@ CASES = {
     "sim_multiblock": (SIM_BASE, dict(camera_resolution=32), dict(SMALL_MOCK, _blocks=[2, 2, 2]), [528]),
     "sim_multiblock_nearest": (SIM_BASE, dict(camera_resolution=24, simulation_interp="false", simulation_a=0.5),
                                dict(SMALL_MOCK, _blocks=[4, 2, 2]), [300]),
+    # electron temperature from an entropy variable in the file (the script's output plus a variable "r0")
+    "sim_code_kappa": (SIM_BASE, dict(camera_resolution=24, plasma_model="code_kappa", simulation_kappa_name="r0",
+                                      image_lambda_ave="true", image_tau="true"), dict(SMALL_MOCK, _entropy=1), [300]),
+    "sim_code_kappa_fallback": (SIM_BASE, dict(camera_resolution=16, plasma_model="code_kappa", simulation_kappa_name="r0",
+                                               simulation_interp="false", simulation_a=0.9, fallback_nan="false",
+                                               fallback_rho=1.0e-6, fallback_pgas=1.0e-8, fallback_kappa=3.0e6,
+                                               cut_theta_e_max=20.0), dict(SMALL_MOCK, _entropy=1, _blocks=[2, 2, 2]), [136]),
     "sim_powerlaw": (SIM_BASE, dict(camera_resolution=24, plasma_power_frac=0.3, plasma_p=2.5, plasma_gamma_min=1.0,
                                     plasma_gamma_max=1000.0), SMALL_MOCK, [300]),
     # false-colour renderings (rendering.cpp): the features of the reference's example_render.input, without
@@ -222,6 +229,22 @@ def mock_arrays(path):
     return prim, coords
 
 
+def add_entropy(path):
+    """Append the variable "r0" = blacklight_amd.mock.electron_entropy(rho, press) to the prim dataset of the
+    script's athdf output (what an Athena++ run with an electron-entropy scalar would hold)."""
+    import h5py
+    sys.path.insert(0, REPO)
+    from blacklight_amd.mock import electron_entropy
+    with h5py.File(path, "r+") as f:
+        prim = f["prim"][...]
+        kappa = electron_entropy(prim[0], prim[1])
+        del f["prim"]
+        f.create_dataset("prim", data=np.concatenate([prim, kappa[None]], axis=0).astype(np.float32))
+        del f.attrs["NumVariables"], f.attrs["VariableNames"]
+        f.attrs.create("NumVariables", [6, 3], dtype=np.int32)
+        f.attrs.create("VariableNames", ["rho", "press", "vel1", "vel2", "vel3", "r0", "Bcc1", "Bcc2", "Bcc3"], dtype="|S21")
+
+
 def split_into_blocks(src, dst, nbi, nbj, nbk):
     """Rewrite the single-block athdf `src` as nbi x nbj x nbk equal MeshBlocks (same level), in a scrambled
     block order (the reader accepts any). Same decomposition as tests/golden_util.split_grid."""
@@ -272,6 +295,8 @@ def make_case(name):
             if not key.startswith("_"):
                 args += [f"--{key}", str(value)]
         subprocess.run(args, check=True)
+        if "_entropy" in mock:
+            add_entropy(mock_path)
         if "_blocks" in mock:   # several MeshBlocks: split the script's single block
             single = os.path.join(workdir, "data", "mock_single.athdf")
             os.replace(mock_path, single)
