@@ -7,5 +7,6 @@ from . import mock  # noqa: F401
 from ._capi import BlacklightError, LIB_PATH  # noqa: F401
 from .context import Context  # noqa: F401
 from .params import Params  # noqa: F401
+from .snapshot import Snapshot  # noqa: F401
 
-__all__ = ["Params", "Context", "BlacklightError", "mock", "LIB_PATH"]
+__all__ = ["Params", "Context", "Snapshot", "BlacklightError", "mock", "LIB_PATH"]

@@ -105,6 +105,17 @@ def lib():
                                      C.POINTER(C.c_int32), C.c_void_p]
     L.bl_write_output.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(OutputDesc)]
     L.bl_free.argtypes = [C.c_void_p]
+    L.bl_snapshot_open.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_char_p, C.c_size_t]
+    L.bl_snapshot_grid.argtypes = [C.c_void_p]
+    L.bl_snapshot_grid.restype = C.POINTER(GridDesc)
+    L.bl_snapshot_time.argtypes = [C.c_void_p]
+    L.bl_snapshot_time.restype = C.c_double
+    L.bl_snapshot_warnings.argtypes = [C.c_void_p]
+    L.bl_snapshot_warnings.restype = C.c_char_p
+    L.bl_snapshot_file.argtypes = [C.c_void_p]
+    L.bl_snapshot_file.restype = C.c_char_p
+    L.bl_snapshot_blocks.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.POINTER(C.c_int32))]
+    L.bl_snapshot_close.argtypes = [C.c_void_p]
     L.bl_build_info.restype = C.c_char_p
     _lib = L
     return L

@@ -3,10 +3,11 @@
 // "Warning: ...\n", exit code 0 / 1, the same timing block at the end. Everything between reading the
 // parameters and writing the image goes through the C-ABI (include/blacklight_amd.h) to the GPU.
 //
-// Snapshot input: the reference's own HDF5 / AthenaK / iharm readers are outside the hot-path scope
-// (SURVEY.md 8f); simulation_file must be a raw grid file as written by blacklight_amd.mock.Grid.save_raw
-// (magic "BLGRID1" for one block, "BLGRID2" for several equal blocks; dimensions, coordinates,
-// primitives), i.e. the arrays SimulationReader would have produced.
+// Snapshot input: Athena++ .athdf files (simulation_format = athena, single file or a numbered series
+// with simulation_multiple) through bl_snapshot_open(), as the reference's SimulationReader reads them.
+// As an extension, a simulation_file that starts with the magic "BLGRID1" (one block) or "BLGRID2"
+// (several equal blocks) is taken as a raw grid written by blacklight_amd.mock.Grid.save_raw (dimensions,
+// coordinates, primitives: the arrays SimulationReader would have produced), whatever simulation_format says.
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
@@ -43,8 +44,7 @@ bool ReadRawGrid(const std::string &path, RawGrid *g, std::string *error) {
   f.read(magic, 8);
   const bool v1 = std::memcmp(magic, "BLGRID1\0", 8) == 0, v2 = std::memcmp(magic, "BLGRID2\0", 8) == 0;
   if (!v1 && !v2) {
-    *error = "simulation_file is not a raw BLGRID1 / BLGRID2 grid (the HDF5 / AthenaK / iharm readers are outside the "
-             "scope of the MI355X hot path; convert the snapshot with blacklight_amd.mock.Grid.save_raw).";
+    *error = "not a raw grid";
     return false;
   }
   if (v2) f.read(reinterpret_cast<char *>(&g->n_b), sizeof(int32_t));
@@ -71,6 +71,13 @@ bool ReadRawGrid(const std::string &path, RawGrid *g, std::string *error) {
     return false;
   }
   return true;
+}
+
+bool IsRawGrid(const std::string &path) {
+  std::ifstream f(path, std::ios::binary);
+  char magic[8] = {};
+  f.read(magic, 8);
+  return f && (std::memcmp(magic, "BLGRID1\0", 8) == 0 || std::memcmp(magic, "BLGRID2\0", 8) == 0);
 }
 
 }  // namespace
@@ -107,29 +114,37 @@ int main(int argc, char *argv[]) {
   for (int run = 0; run < num_runs; run++) {
     if (simulation) {
       double t0 = Now();
-      if (params.simulation_multiple) {
-        std::cout << "Error: simulation_multiple needs the reference's file-series reader, which is outside the scope of the MI355X hot path.\n";
-        return 1;
-      }
       RawGrid raw;
       std::string message;
-      if (!params.has[BL_P_simulation_file] || !ReadRawGrid(params.simulation_file.s, &raw, &message)) {
-        std::cout << "Error: " << (message.empty() ? "SimulationReader unable to find all needed values in input file." : message) << "\n";
-        return 1;
-      }
+      bl_snapshot *snap = nullptr;
       bl_grid_desc g = {};
-      g.n_blocks = raw.n_b;
-      g.n_i = raw.n_i; g.n_j = raw.n_j; g.n_k = raw.n_k; g.n_var = raw.n_var;
-      g.prim = raw.prim.data();
-      g.x1f = raw.coords[0].data(); g.x2f = raw.coords[1].data(); g.x3f = raw.coords[2].data();
-      g.x1v = raw.coords[3].data(); g.x2v = raw.coords[4].data(); g.x3v = raw.coords[5].data();
-      g.ind_rho = 0; g.ind_pgas = 1; g.ind_uu1 = 2; g.ind_uu2 = 3; g.ind_uu3 = 4;
-      g.ind_bb1 = 5; g.ind_bb2 = 6; g.ind_bb3 = 7;
-      g.ind_kappa = raw.n_var > 8 ? 8 : 0;   // a ninth variable is the electron entropy (plasma_model = code_kappa)
-      g.plasma_gamma = params.has[BL_P_plasma_gamma] ? params.plasma_gamma : 0.0;
-      g.plasma_gamma_i = params.has[BL_P_plasma_gamma_i] ? params.plasma_gamma_i : 0.0;
-      g.plasma_gamma_e = params.has[BL_P_plasma_gamma_e] ? params.plasma_gamma_e : 0.0;
-      if (bl_set_grid(ctx, &g) != BL_OK) {
+      if (params.has[BL_P_simulation_file] && !params.simulation_multiple && IsRawGrid(params.simulation_file.s)) {
+        if (!ReadRawGrid(params.simulation_file.s, &raw, &message)) {
+          std::cout << "Error: " << message << "\n";
+          return 1;
+        }
+        g.n_blocks = raw.n_b;
+        g.n_i = raw.n_i; g.n_j = raw.n_j; g.n_k = raw.n_k; g.n_var = raw.n_var;
+        g.prim = raw.prim.data();
+        g.x1f = raw.coords[0].data(); g.x2f = raw.coords[1].data(); g.x3f = raw.coords[2].data();
+        g.x1v = raw.coords[3].data(); g.x2v = raw.coords[4].data(); g.x3v = raw.coords[5].data();
+        g.ind_rho = 0; g.ind_pgas = 1; g.ind_uu1 = 2; g.ind_uu2 = 3; g.ind_uu3 = 4;
+        g.ind_bb1 = 5; g.ind_bb2 = 6; g.ind_bb3 = 7;
+        g.ind_kappa = raw.n_var > 8 ? 8 : 0;   // a ninth variable is the electron entropy (plasma_model = code_kappa)
+        g.plasma_gamma = params.has[BL_P_plasma_gamma] ? params.plasma_gamma : 0.0;
+        g.plasma_gamma_i = params.has[BL_P_plasma_gamma_i] ? params.plasma_gamma_i : 0.0;
+        g.plasma_gamma_e = params.has[BL_P_plasma_gamma_e] ? params.plasma_gamma_e : 0.0;
+      } else {
+        if (bl_snapshot_open(&params, run, &snap, err, sizeof err) != BL_OK) {
+          std::cout << err;
+          return 1;
+        }
+        if (run == 0) std::cerr << bl_snapshot_warnings(snap);
+        g = *bl_snapshot_grid(snap);
+      }
+      const int rc = bl_set_grid(ctx, &g);
+      bl_snapshot_close(snap);
+      if (rc != BL_OK) {
         std::cout << bl_last_error(ctx);
         return 1;
       }

@@ -1,0 +1,733 @@
+// bl_snapshot.cpp - host-side snapshot reader for simulation_format = athena (Athena++ .athdf).
+//
+// Replaces, for that format, SimulationReader's constructor and Read() (reference
+// src/simulation_reader/simulation_reader.cpp:36-159, :211-861, :870-904, :1141-1216) together with the
+// subset of the HDF5 file format the reference implements by hand (hdf5_format_structure.cpp,
+// hdf5_format_metadata.cpp, hdf5_format_arrays.cpp): superblock version 0 with 8-byte offsets and lengths,
+// version-1 B-trees / symbol-table nodes / local heaps, version-1 object headers with continuation blocks,
+// version-1 attribute, datatype and dataspace messages, version-3 contiguous data layouts. The result is
+// the bl_grid_desc that bl_set_grid() takes. Error texts are the reference's where the condition is the same.
+//
+// Organisation (not the reference's): the file is memory-mapped once and every structure is decoded from
+// bounds-checked views of the mapping; an object header is walked as a queue of message blocks, a group as a
+// recursive descent through its B-tree.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../include/blacklight_amd.h"
+
+namespace {
+
+struct ReadFailure {
+  int code;
+  std::string message;
+};
+
+[[noreturn]] void Fail(const char *message, int code = BL_E_INPUT) { throw ReadFailure{code, message}; }
+
+constexpr uint64_t kUndefinedAddress = ~0ull;
+
+// ------------------------------------------------------------------------------------------------
+// Bounds-checked little-endian view of the mapped file
+
+class FileMap {
+ public:
+  FileMap() = default;
+  FileMap(const FileMap &) = delete;
+  FileMap &operator=(const FileMap &) = delete;
+  ~FileMap() {
+    if (base_ != nullptr && size_ > 0) munmap(const_cast<uint8_t *>(base_), size_);
+  }
+  void Open(const std::string &path) {
+    int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) Fail("Could not open file for reading.");
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) {
+      close(fd);
+      Fail("Could not open file for reading.");
+    }
+    size_ = static_cast<size_t>(st.st_size);
+    if (size_ > 0) {
+      void *p = mmap(nullptr, size_, PROT_READ, MAP_PRIVATE, fd, 0);
+      if (p == MAP_FAILED) {
+        close(fd);
+        Fail("Could not open file for reading.");
+      }
+      base_ = static_cast<const uint8_t *>(p);
+    }
+    close(fd);
+  }
+  const uint8_t *At(uint64_t offset, uint64_t length) const {
+    if (offset > size_ || length > size_ - offset) Fail("Unexpected end of HDF5 file.");
+    return base_ + offset;
+  }
+  template <typename T>
+  T Get(uint64_t offset) const {
+    T value;
+    std::memcpy(&value, At(offset, sizeof(T)), sizeof(T));
+    return value;
+  }
+  uint8_t Byte(uint64_t offset) const { return *At(offset, 1); }
+
+ private:
+  const uint8_t *base_ = nullptr;
+  size_t size_ = 0;
+};
+
+// A message (or attribute payload) inside the mapping
+struct Span {
+  const uint8_t *data = nullptr;
+  uint64_t size = 0;
+  const uint8_t *At(uint64_t offset, uint64_t length) const {
+    if (offset > size || length > size - offset) Fail("Unexpected end of HDF5 file.");
+    return data + offset;
+  }
+  template <typename T>
+  T Get(uint64_t offset) const {
+    T value;
+    std::memcpy(&value, At(offset, sizeof(T)), sizeof(T));
+    return value;
+  }
+};
+
+struct Message {
+  uint16_t type;
+  Span body;
+};
+
+// What describes a stored array: datatype message, dataspace message, element bytes
+struct RawArray {
+  Span datatype, dataspace, data;
+};
+
+struct GroupRef {
+  uint64_t btree = kUndefinedAddress, heap = kUndefinedAddress;
+};
+
+inline uint64_t PadTo8(uint64_t n) { return (n + 7) & ~7ull; }
+
+// ------------------------------------------------------------------------------------------------
+// HDF5 structures
+
+class Hdf5File {
+ public:
+  explicit Hdf5File(const std::string &path) {
+    map_.Open(path);
+    ReadSuperblock();
+  }
+
+  // All messages of a version-1 object header, continuation blocks followed in file order
+  std::vector<Message> ObjectHeader(uint64_t address) const {
+    if (map_.Byte(address) != 1) Fail("Unexpected HDF5 object header version.");
+    const uint16_t num_messages = map_.Get<uint16_t>(address + 2);
+    const uint32_t header_size = map_.Get<uint32_t>(address + 8);
+    std::deque<std::pair<uint64_t, uint64_t>> blocks;   // (offset, length)
+    blocks.emplace_back(address + 16, header_size);     // messages start on the 8-byte boundary after 12 bytes
+    std::vector<Message> messages;
+    messages.reserve(num_messages);
+    while (!blocks.empty() && messages.size() < num_messages) {
+      uint64_t pos = blocks.front().first;
+      const uint64_t end = pos + blocks.front().second;
+      blocks.pop_front();
+      while (pos + 8 <= end && messages.size() < num_messages) {
+        const uint16_t type = map_.Get<uint16_t>(pos);
+        const uint16_t size = map_.Get<uint16_t>(pos + 2);
+        const uint8_t flags = map_.Byte(pos + 4);
+        if (flags & 0x02) Fail("Unexpected HDF5 header message flag.");   // shared message
+        Message m;
+        m.type = type;
+        m.body.data = map_.At(pos + 8, size);
+        m.body.size = size;
+        if (type == 0x0010) blocks.emplace_back(m.body.Get<uint64_t>(0), m.body.Get<uint64_t>(8));
+        messages.push_back(m);
+        pos += 8 + static_cast<uint64_t>(size);
+      }
+    }
+    return messages;
+  }
+
+  // Address of the object header of `path` ("a/b/c", no leading slash) below the root group
+  uint64_t Locate(const std::string &path) const {
+    GroupRef group = root_;
+    uint64_t header = root_header_;
+    size_t begin = 0;
+    while (begin <= path.size()) {
+      size_t slash = path.find('/', begin);
+      const bool last = slash == std::string::npos;
+      const std::string name = path.substr(begin, last ? std::string::npos : slash - begin);
+      GroupRef child;
+      if (group.btree == kUndefinedAddress || !FindInTree(group.btree, HeapData(group.heap), name, &header, &child, 0))
+        Fail("Could not find HDF5 dataset in file.");
+      if (last) return header;
+      if (child.btree == kUndefinedAddress) child = SymbolTableOf(header);
+      group = child;
+      begin = slash + 1;
+    }
+    Fail("Could not find HDF5 dataset in file.");
+  }
+
+  RawArray Dataset(const std::string &path) const {
+    RawArray raw;
+    bool have_type = false, have_space = false, have_layout = false;
+    for (const Message &m : ObjectHeader(Locate(path))) {
+      if (m.type == 0x0003) {
+        if (have_type) Fail("Too many HDF5 datatypes for dataset.");
+        have_type = true;
+        raw.datatype = m.body;
+      } else if (m.type == 0x0001) {
+        if (have_space) Fail("Too many HDF5 dataspaces for dataset.");
+        have_space = true;
+        raw.dataspace = m.body;
+      } else if (m.type == 0x0008) {
+        if (have_layout) Fail("Too many HDF5 data layouts for dataset.");
+        have_layout = true;
+        if (m.body.Get<uint8_t>(0) != 3) Fail("Unexpected HDF5 data layout message version.");
+        if (m.body.Get<uint8_t>(1) != 1) Fail("Unexpected HDF5 data layout class.");   // contiguous only
+        const uint64_t address = m.body.Get<uint64_t>(2), size = m.body.Get<uint64_t>(10);
+        raw.data.size = size;
+        raw.data.data = size > 0 ? map_.At(address, size) : nullptr;
+      }
+    }
+    if (!(have_type && have_space && have_layout)) Fail("Could not find needed dataset properties.");
+    return raw;
+  }
+
+  // File-level attribute by name; false if absent
+  bool RootAttribute(const std::string &name, RawArray *out) const {
+    for (const Message &m : ObjectHeader(root_header_)) {
+      if (m.type != 0x000C) continue;
+      if (m.body.Get<uint8_t>(0) != 1) Fail("Unexpected HDF5 attribute message version.");
+      const uint16_t name_size = m.body.Get<uint16_t>(2);
+      const uint16_t type_size = m.body.Get<uint16_t>(4);
+      const uint16_t space_size = m.body.Get<uint16_t>(6);
+      uint64_t offset = 8;
+      const char *raw_name = reinterpret_cast<const char *>(m.body.At(offset, name_size));
+      const std::string found(raw_name, name_size > 0 ? strnlen(raw_name, name_size) : 0);
+      offset += PadTo8(name_size);
+      if (found != name) continue;
+      out->datatype.data = m.body.At(offset, type_size);
+      out->datatype.size = type_size;
+      offset += PadTo8(type_size);
+      out->dataspace.data = m.body.At(offset, space_size);
+      out->dataspace.size = space_size;
+      offset += PadTo8(space_size);
+      if (offset > m.body.size) Fail("Unexpected end of HDF5 file.");
+      out->data.data = m.body.data + offset;
+      out->data.size = m.body.size - offset;
+      return true;
+    }
+    return false;
+  }
+
+ private:
+  void ReadSuperblock() {
+    static const uint8_t signature[8] = {0x89, 'H', 'D', 'F', '\r', '\n', 0x1a, '\n'};
+    if (std::memcmp(map_.At(0, 8), signature, 8) != 0) Fail("Unexpected HDF5 format signature.");
+    if (map_.Byte(8) != 0) Fail("Unexpected HDF5 superblock version.");
+    if (map_.Byte(9) != 0) Fail("Unexpected HDF5 file free space storage version.");
+    if (map_.Byte(10) != 0) Fail("Unexpected HDF5 root group symbol table entry version.");
+    if (map_.Byte(12) != 0) Fail("Unexpected HDF5 shared header message format version.");
+    if (map_.Byte(13) != 8) Fail("Unexpected HDF5 size of offsets.");
+    if (map_.Byte(14) != 8) Fail("Unexpected HDF5 size of lengths.");
+    // 16..23 tree ranks and consistency flags, 24..55 base / free-space / end-of-file / driver addresses,
+    // 56.. root group symbol table entry: name offset, header address, cache type, reserved, scratch
+    root_header_ = map_.Get<uint64_t>(56 + 8);
+    if (map_.Get<uint32_t>(56 + 16) != 1) Fail("Unexpected HDF5 root group symbol table entry cache type.");
+    root_.btree = map_.Get<uint64_t>(56 + 24);
+    root_.heap = map_.Get<uint64_t>(56 + 32);
+  }
+
+  // Address of the data segment of a local heap
+  uint64_t HeapData(uint64_t heap) const {
+    if (std::memcmp(map_.At(heap, 4), "HEAP", 4) != 0) Fail("Unexpected HDF5 heap signature.");
+    if (map_.Byte(heap + 4) != 0) Fail("Unexpected HDF5 heap version.");
+    return map_.Get<uint64_t>(heap + 24);
+  }
+
+  std::string HeapString(uint64_t heap_data, uint64_t offset) const {
+    std::string s;
+    for (uint64_t pos = heap_data + offset;; pos++) {
+      const char c = static_cast<char>(map_.Byte(pos));
+      if (c == '\0') return s;
+      s.push_back(c);
+    }
+  }
+
+  GroupRef SymbolTableOf(uint64_t header) const {
+    for (const Message &m : ObjectHeader(header))
+      if (m.type == 0x0011) {
+        GroupRef g;
+        g.btree = m.body.Get<uint64_t>(0);
+        g.heap = m.body.Get<uint64_t>(8);
+        return g;
+      }
+    Fail("Could not find HDF5 dataset in file.");
+  }
+
+  // Depth-first search of a version-1 group B-tree for a link name
+  bool FindInTree(uint64_t node, uint64_t heap_data, const std::string &name, uint64_t *header, GroupRef *child,
+                  int depth) const {
+    if (depth > 64) Fail("Unexpected HDF5 B-tree signature.");
+    if (std::memcmp(map_.At(node, 4), "TREE", 4) != 0) Fail("Unexpected HDF5 B-tree signature.");
+    if (map_.Byte(node + 4) != 0) Fail("Unexpected HDF5 node type.");
+    const uint8_t level = map_.Byte(node + 5);
+    const uint16_t entries = map_.Get<uint16_t>(node + 6);
+    // keys and child pointers alternate after the two sibling addresses: key 0, child 0, key 1, ...
+    for (uint16_t e = 0; e < entries; e++) {
+      const uint64_t child_address = map_.Get<uint64_t>(node + 24 + 8 + 16ull * e);
+      if (level > 0) {
+        if (FindInTree(child_address, heap_data, name, header, child, depth + 1)) return true;
+        continue;
+      }
+      if (std::memcmp(map_.At(child_address, 4), "SNOD", 4) != 0) Fail("Unexpected HDF5 symbol table node signature.");
+      if (map_.Byte(child_address + 4) != 1) Fail("Unexpected HDF5 symbol table node version.");
+      const uint16_t symbols = map_.Get<uint16_t>(child_address + 6);
+      for (uint16_t s = 0; s < symbols; s++) {
+        const uint64_t entry = child_address + 8 + 40ull * s;
+        if (HeapString(heap_data, map_.Get<uint64_t>(entry)) != name) continue;
+        const uint32_t cache_type = map_.Get<uint32_t>(entry + 16);
+        if (cache_type > 1) Fail("Unexpected HDF5 symbol table entry cache type.");
+        *header = map_.Get<uint64_t>(entry + 8);
+        *child = GroupRef{};
+        if (cache_type == 1) {
+          child->btree = map_.Get<uint64_t>(entry + 24);
+          child->heap = map_.Get<uint64_t>(entry + 32);
+        }
+        return true;
+      }
+    }
+    return false;
+  }
+
+  FileMap map_;
+  uint64_t root_header_ = 0;
+  GroupRef root_;
+};
+
+// ------------------------------------------------------------------------------------------------
+// Array decoding
+
+std::vector<uint64_t> Dimensions(const Span &dataspace) {
+  if (dataspace.Get<uint8_t>(0) != 1) Fail("Unexpected HDF5 dataspace version.");
+  const int rank = dataspace.Get<uint8_t>(1);
+  if (dataspace.Get<uint8_t>(2) & 0x02) Fail("Unexpected HDF5 dataspace permutation indices.");
+  std::vector<uint64_t> dims(rank);
+  for (int d = 0; d < rank; d++) dims[d] = dataspace.Get<uint64_t>(8 + 8ull * d);
+  return dims;
+}
+
+uint64_t Product(const std::vector<uint64_t> &dims) {
+  uint64_t n = 1;
+  for (uint64_t d : dims) {
+    if (d != 0 && n > (1ull << 40) / d) Fail("Array dimension mismatch.");
+    n *= d;
+  }
+  return n;
+}
+
+struct TypeHeader {
+  int version, type_class;
+  uint8_t bits0, bits1;
+  uint32_t size;
+};
+
+TypeHeader ReadTypeHeader(const Span &datatype) {
+  TypeHeader t;
+  const uint8_t version_class = datatype.Get<uint8_t>(0);
+  t.version = version_class >> 4;
+  t.type_class = version_class & 0x0f;
+  t.bits0 = datatype.Get<uint8_t>(1);
+  t.bits1 = datatype.Get<uint8_t>(2);
+  t.size = datatype.Get<uint32_t>(4);
+  if (t.version != 1) Fail("Unexpected HDF5 datatype version.");
+  return t;
+}
+
+// Element `n` of `size` bytes, byte-swapped into host order if the file order is big-endian
+template <typename T>
+T Element(const Span &data, uint64_t n, bool big_endian) {
+  uint8_t bytes[sizeof(T)];
+  std::memcpy(bytes, data.At(n * sizeof(T), sizeof(T)), sizeof(T));
+  if (big_endian)
+    for (size_t b = 0; b < sizeof(T) / 2; b++) std::swap(bytes[b], bytes[sizeof(T) - 1 - b]);
+  T value;
+  std::memcpy(&value, bytes, sizeof(T));
+  return value;
+}
+
+// Fixed-point arrays of 4 or 8 bytes; 8-byte values are truncated to int32 as the reference does
+std::vector<int32_t> DecodeInts(const RawArray &raw, std::vector<uint64_t> *dims_out) {
+  const TypeHeader t = ReadTypeHeader(raw.datatype);
+  if (t.type_class != 0) Fail("Unexpected HDF5 datatype class.");
+  if (t.size != 4 && t.size != 8) Fail("Unexpected int size.");
+  const bool big_endian = t.bits0 & 0x01;
+  if (t.bits0 & 0x06) Fail("Unexpected HDF5 fixed-point padding.");
+  if (raw.datatype.Get<uint16_t>(8) != 0 || raw.datatype.Get<uint16_t>(10) != 8 * t.size)
+    Fail("Unexpected HDF5 fixed-point bit layout.");
+  std::vector<uint64_t> dims = Dimensions(raw.dataspace);
+  if (dims.size() > 2) Fail("Unexpected HDF5 fixed-point array size.");
+  const uint64_t count = Product(dims);
+  std::vector<int32_t> values(count);
+  for (uint64_t n = 0; n < count; n++)
+    values[n] = t.size == 4 ? Element<int32_t>(raw.data, n, big_endian)
+                            : static_cast<int32_t>(Element<int64_t>(raw.data, n, big_endian));
+  if (dims_out != nullptr) *dims_out = dims;
+  return values;
+}
+
+std::vector<float> DecodeFloats(const RawArray &raw, std::vector<uint64_t> *dims_out, float *into = nullptr,
+                                uint64_t expect = 0) {
+  const TypeHeader t = ReadTypeHeader(raw.datatype);
+  if (t.type_class != 1) Fail("Unexpected HDF5 datatype class.");
+  if (t.size != 4) Fail("Unexpected float size.");
+  const bool big_endian = t.bits0 & 0x01;
+  if (t.bits0 & 0x40) Fail("Unexpected HDF5 floating-point byte order.");
+  if (t.bits0 & 0x0e) Fail("Unexpected HDF5 floating-point padding.");
+  if ((t.bits0 & 0x30) != 0x20) Fail("Unexpected HDF5 floating-point mantissa normalization.");
+  const Span &d = raw.datatype;
+  if (t.bits1 != 31 || d.Get<uint16_t>(8) != 0 || d.Get<uint16_t>(10) != 32 || d.Get<uint8_t>(12) != 23
+      || d.Get<uint8_t>(13) != 8 || d.Get<uint8_t>(14) != 0 || d.Get<uint8_t>(15) != 23 || d.Get<uint32_t>(16) != 127)
+    Fail("Unexpected HDF5 single-precision floating-point bit layout.");
+  std::vector<uint64_t> dims = Dimensions(raw.dataspace);
+  if (!(dims.empty() || dims.size() == 1 || dims.size() == 2 || dims.size() == 4 || dims.size() == 5))
+    Fail("Unexpected HDF5 floating-point array size.");
+  const uint64_t count = Product(dims);
+  if (dims_out != nullptr) *dims_out = dims;
+  std::vector<float> owned;
+  float *dst = into;
+  if (into == nullptr) {
+    owned.resize(count);
+    dst = owned.data();
+  } else if (count != expect) {
+    Fail("Array dimension mismatch.");
+  }
+  if (!big_endian) {
+    if (count > 0) std::memcpy(dst, raw.data.At(0, count * 4), count * 4);
+  } else {
+    for (uint64_t n = 0; n < count; n++) dst[n] = Element<float>(raw.data, n, true);
+  }
+  return owned;
+}
+
+std::vector<std::string> DecodeStrings(const RawArray &raw) {
+  const TypeHeader t = ReadTypeHeader(raw.datatype);
+  if (t.type_class != 3) Fail("Unexpected HDF5 datatype class.");
+  if ((t.bits0 >> 4) != 0) Fail("Unexpected HDF5 string encoding.");   // ASCII
+  std::vector<uint64_t> dims = Dimensions(raw.dataspace);
+  if (dims.size() != 1) Fail("Unexpected HDF5 string array size.");
+  std::vector<std::string> strings(dims[0]);
+  for (uint64_t n = 0; n < dims[0]; n++) {
+    const char *s = reinterpret_cast<const char *>(raw.data.At(n * t.size, t.size));
+    strings[n].assign(s, strnlen(s, t.size));
+  }
+  return strings;
+}
+
+// ------------------------------------------------------------------------------------------------
+// SimulationReader::FormatFilename (simulation_reader.cpp:870-904): "{Nd}" -> zero-padded file number
+
+std::string FormatFilename(const std::string &pattern, int file_number) {
+  const size_t open = pattern.find_first_of('{');
+  if (open == std::string::npos) Fail("Invalid simulation_file for multiple runs.");
+  const size_t close = pattern.find_first_of('}', open);
+  if (close == std::string::npos) Fail("Invalid simulation_file for multiple runs.");
+  if (pattern[close - 1] != 'd') Fail("Invalid simulation_file for multiple runs.");
+  int field_length = 0;
+  if (close - open > 2) {
+    try {
+      field_length = std::stoi(pattern.substr(open + 1, close - open - 2));
+    } catch (...) {
+      Fail("Invalid simulation_file for multiple runs.");
+    }
+  }
+  const std::string number = std::to_string(file_number);
+  std::string out = pattern.substr(0, open);
+  if (static_cast<int>(number.size()) < field_length) out.append(field_length - number.size(), '0');
+  return out + number + pattern.substr(close + 1);
+}
+
+constexpr double kPi = 3.141592653589793;               // blacklight.hpp Math::pi
+constexpr double kAngularDomainTolerance = 0.1;         // simulation_reader.hpp:100
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+
+struct bl_snapshot {
+  bl_grid_desc desc{};
+  std::vector<float> prim;
+  std::vector<double> coords[6];   // x1f x2f x3f x1v x2v x3v
+  std::vector<int32_t> levels, locations;
+  double time = 0.0;
+  std::string warnings, file;
+};
+
+namespace {
+
+void Warn(bl_snapshot *s, const std::string &text) { s->warnings += "Warning: " + text + "\n"; }
+
+constexpr const char *kMissing = "SimulationReader unable to find all needed values in input file.";
+
+void Require(const bl_params &p, std::initializer_list<int> keys) {
+  for (int k : keys)
+    if (!p.has[k]) Fail(kMissing, BL_E_MISSING);
+}
+
+// Constructor part (simulation_reader.cpp:36-159): presence checks, range checks, adiabatic indices
+void ReaderSetup(const bl_params &p, bl_snapshot *s) {
+  Require(p, {BL_P_model_type});
+  if (p.model_type != BL_MODEL_SIMULATION) Fail("Snapshots are only read in simulation mode.", BL_E_STATE);
+  Require(p, {BL_P_simulation_format, BL_P_simulation_file, BL_P_simulation_multiple});
+  if (p.simulation_multiple) {
+    Require(p, {BL_P_simulation_start});
+    if (p.simulation_start < 0) Fail("Must have nonnegative index simulation_start.");
+    Require(p, {BL_P_simulation_end});
+    if (p.simulation_end < p.simulation_start) Fail("Must have simulation_end at least as large as simulation_start.");
+  }
+  Require(p, {BL_P_simulation_coord, BL_P_simulation_a, BL_P_simulation_m_msun, BL_P_simulation_rho_cgs, BL_P_slow_light_on});
+  if (p.slow_light_on)
+    Fail("slow_light_on = true (time interpolation between snapshots) is not built.", BL_E_UNSUPPORTED);
+  if (p.simulation_format != BL_SIMFMT_ATHENA)
+    Fail("Only simulation_format = athena has a native reader; other formats must be handed over through bl_set_grid().",
+         BL_E_UNSUPPORTED);
+  Require(p, {BL_P_plasma_mu, BL_P_plasma_model});
+  double gamma = 0.0, gamma_i = 0.0, gamma_e = 0.0;
+  if (p.plasma_model == BL_PLASMA_TI_TE_BETA) {
+    Require(p, {BL_P_plasma_use_p});
+    if (p.plasma_use_p) {
+      if (p.has[BL_P_plasma_gamma]) gamma = p.plasma_gamma;
+      if (p.has[BL_P_plasma_gamma_i]) Warn(s, "Ignoring plasma_gamma_i selection.");
+      if (p.has[BL_P_plasma_gamma_e]) Warn(s, "Ignoring plasma_gamma_e selection.");
+    } else {
+      Require(p, {BL_P_plasma_gamma, BL_P_plasma_gamma_i, BL_P_plasma_gamma_e});   // athena: all three from the input
+      gamma = p.plasma_gamma;
+      gamma_i = p.plasma_gamma_i;
+      gamma_e = p.plasma_gamma_e;
+    }
+  } else {
+    Require(p, {BL_P_simulation_kappa_name});
+    if (p.has[BL_P_plasma_gamma]) gamma = p.plasma_gamma;
+    if (p.has[BL_P_plasma_gamma_i]) Warn(s, "Ignoring plasma_gamma_i selection.");
+    if (p.has[BL_P_plasma_gamma_e]) Warn(s, "Ignoring plasma_gamma_e selection.");
+  }
+  s->desc.plasma_gamma = gamma;
+  s->desc.plasma_gamma_i = gamma_i;
+  s->desc.plasma_gamma_e = gamma_e;
+}
+
+// Variable lookup with the reference's index arithmetic (VerifyVariablesAthena, :1141-1216): indices
+// count through VariableNames over all datasets, while the primitive array holds "prim" then "B".
+void LocateVariables(const bl_params &p, const std::vector<std::string> &dataset_names,
+                     const std::vector<std::string> &variable_names, const std::vector<int32_t> &num_variables,
+                     int *ind_hydro_out, int *ind_bb_out, bl_grid_desc *d) {
+  const int num_datasets = static_cast<int>(dataset_names.size());
+  const int num_names = static_cast<int>(variable_names.size());
+  auto find_dataset = [&](const char *name, int *offset) {
+    int index = 0;
+    *offset = 0;
+    for (; index < num_datasets; index++) {
+      if (dataset_names[index] == name) break;
+      *offset += num_variables[index];
+    }
+    return index;
+  };
+  auto find_variable = [&](const std::string &name, int offset, int count) {
+    int index = offset;
+    for (; index < offset + count; index++)
+      if (index < num_names && variable_names[index] == name) break;
+    return index;
+  };
+  int prim_offset = 0, bb_offset = 0;
+  const int ind_hydro = find_dataset("prim", &prim_offset);
+  if (ind_hydro == num_datasets) Fail("Unable to locate array \"prim\" in data file.");
+  const int n_hydro = num_variables[ind_hydro];
+  auto hydro = [&](const std::string &name, const char *error) {
+    const int index = find_variable(name, prim_offset, n_hydro);
+    if (index == prim_offset + n_hydro) Fail(error);
+    return index;
+  };
+  d->ind_rho = hydro("rho", "Unable to locate \"rho\" slice of \"prim\" in data file.");
+  d->ind_pgas = hydro("press", "Unable to locate \"press\" slice of \"prim\" in data file.");
+  d->ind_kappa = 0;
+  if (p.plasma_model == BL_PLASMA_CODE_KAPPA)
+    d->ind_kappa = hydro(p.simulation_kappa_name.s, "Unable to locate electron entropy slice of \"prim\" in data file.");
+  d->ind_uu1 = hydro("vel1", "Unable to locate \"vel1\" slice of \"prim\" in data file.");
+  d->ind_uu2 = hydro("vel2", "Unable to locate \"vel2\" slice of \"prim\" in data file.");
+  d->ind_uu3 = hydro("vel3", "Unable to locate \"vel3\" slice of \"prim\" in data file.");
+  const int ind_bb = find_dataset("B", &bb_offset);
+  if (ind_bb == num_datasets) Fail("Unable to locate array \"B\" in data file.");
+  const int n_bb = num_variables[ind_bb];
+  auto field = [&](const std::string &name, const char *error) {
+    const int index = find_variable(name, bb_offset, n_bb);
+    if (index == bb_offset + n_bb) Fail(error);
+    return index;
+  };
+  d->ind_bb1 = field("Bcc1", "Unable to locate \"Bcc1\" slice of \"prim\" in data file.");
+  d->ind_bb2 = field("Bcc2", "Unable to locate \"Bcc2\" slice of \"prim\" in data file.");
+  d->ind_bb3 = field("Bcc3", "Unable to locate \"Bcc3\" slice of \"prim\" in data file.");
+  *ind_hydro_out = ind_hydro;
+  *ind_bb_out = ind_bb;
+}
+
+std::string Scientific16(double value) {
+  std::ostringstream text;
+  text.setf(std::ios_base::scientific);
+  text.precision(16);
+  text << value;
+  return text.str();
+}
+
+void ReadAthena(const bl_params &p, int snapshot, bl_snapshot *s) {
+  // which file (:305-319)
+  s->file = p.simulation_file.s;
+  if (p.simulation_multiple) s->file = FormatFilename(s->file, p.simulation_start + snapshot);
+  const Hdf5File file(s->file);
+
+  // file-level attributes (hdf5_format_structure.cpp:145-289)
+  RawArray root_grid_size, dataset_attr, variable_attr, count_attr, time_attr;
+  if (!file.RootAttribute("RootGridSize", &root_grid_size) || !file.RootAttribute("DatasetNames", &dataset_attr)
+      || !file.RootAttribute("VariableNames", &variable_attr) || !file.RootAttribute("NumVariables", &count_attr))
+    Fail("Could not find needed file-level attributes.");
+  DecodeInts(root_grid_size, nullptr);
+  const std::vector<std::string> dataset_names = DecodeStrings(dataset_attr);
+  const std::vector<std::string> variable_names = DecodeStrings(variable_attr);
+  const std::vector<int32_t> num_variables = DecodeInts(count_attr, nullptr);
+  if (num_variables.size() != dataset_names.size()) Fail("DatasetNames and NumVariables file-level attribute mismatch.");
+  if (!file.RootAttribute("Time", &time_attr)) Fail("Could not find needed file-level attributes.");
+  {
+    std::vector<float> t = DecodeFloats(time_attr, nullptr);
+    if (t.empty()) Fail("Array dimension mismatch.");
+    s->time = t[0];
+  }
+
+  // block layout and coordinates (:590-620)
+  std::vector<uint64_t> dims;
+  s->levels = DecodeInts(file.Dataset("Levels"), &dims);
+  s->locations = DecodeInts(file.Dataset("LogicalLocations"), &dims);
+  const size_t n_blocks = s->levels.size();
+  if (n_blocks == 0 || s->locations.size() != 3 * n_blocks) Fail("Array dimension mismatch.");
+  static const char *const kCoordNames[6] = {"x1f", "x2f", "x3f", "x1v", "x2v", "x3v"};
+  size_t per_block[6];
+  for (int c = 0; c < 6; c++) {
+    const std::vector<float> values = DecodeFloats(file.Dataset(kCoordNames[c]), &dims);
+    if (dims.size() != 2 || dims[0] != n_blocks) Fail("Array dimension mismatch.");
+    per_block[c] = dims[1];
+    s->coords[c].assign(values.begin(), values.end());   // float32 promoted to double (:615-620)
+  }
+  for (int a = 0; a < 3; a++)
+    if (per_block[a + 3] == 0 || per_block[a] != per_block[a + 3] + 1) Fail("Array dimension mismatch.");
+  const size_t n_i = per_block[3], n_j = per_block[4], n_k = per_block[5];
+
+  // angular ranges of single-block spherical grids (:722-758)
+  if (n_blocks == 1 && p.simulation_coord == BL_COORD_SKS) {
+    std::vector<double> &x2f = s->coords[1];
+    const size_t last = x2f.size() - 1;
+    const bool low = std::abs(x2f[0]) > (x2f[1] - x2f[0]) * kAngularDomainTolerance;
+    const bool high = std::abs(x2f[last] - kPi) > (x2f[last] - x2f[last - 1]) * kAngularDomainTolerance;
+    if (low || high) {
+      Warn(s, "Changing theta range from [" + Scientific16(x2f[0]) + ", " + Scientific16(x2f[last]) + "] to [0, pi].");
+      x2f[0] = 0.0;
+      x2f[last] = kPi;
+    }
+  }
+  if (n_blocks == 1 && (p.simulation_coord == BL_COORD_SKS || p.simulation_coord == BL_COORD_FMKS)) {
+    std::vector<double> &x3f = s->coords[2];
+    const size_t last = x3f.size() - 1;
+    const bool low = std::abs(x3f[0]) > (x3f[1] - x3f[0]) * kAngularDomainTolerance;
+    const bool high = std::abs(x3f[last] - 2.0 * kPi) > (x3f[last] - x3f[last - 1]) * kAngularDomainTolerance;
+    if (low || high) {
+      Warn(s, "Changing phi range from [" + Scientific16(x3f[0]) + ", " + Scientific16(x3f[last]) + "] to [0, 2*pi].");
+      x3f[0] = 0.0;
+      x3f[last] = 2.0 * kPi;
+    }
+  }
+
+  // cell data (:761-781): "prim" variables first, then "B", whatever their order in the file
+  int ind_hydro = 0, ind_bb = 0;
+  LocateVariables(p, dataset_names, variable_names, num_variables, &ind_hydro, &ind_bb, &s->desc);
+  const int n_hydro = num_variables[ind_hydro], n_bb = num_variables[ind_bb];
+  if (n_hydro < 0 || n_bb < 0) Fail("Array dimension mismatch.");
+  const size_t cells = n_blocks * n_k * n_j * n_i;
+  s->prim.resize(static_cast<size_t>(n_hydro + n_bb) * cells);
+  auto read_cells = [&](const char *name, int count, float *into) {
+    const RawArray raw = file.Dataset(name);
+    const std::vector<uint64_t> d = Dimensions(raw.dataspace);
+    if (d.size() != 5 || d[0] != static_cast<uint64_t>(count) || d[1] != n_blocks || d[2] != n_k || d[3] != n_j || d[4] != n_i)
+      Fail("Array dimension mismatch.");
+    DecodeFloats(raw, nullptr, into, static_cast<uint64_t>(count) * cells);
+  };
+  read_cells("prim", n_hydro, s->prim.data());
+  read_cells("B", n_bb, s->prim.data() + static_cast<size_t>(n_hydro) * cells);
+
+  bl_grid_desc &d = s->desc;
+  d.n_blocks = static_cast<int32_t>(n_blocks);
+  d.n_i = static_cast<int32_t>(n_i);
+  d.n_j = static_cast<int32_t>(n_j);
+  d.n_k = static_cast<int32_t>(n_k);
+  d.n_var = n_hydro + n_bb;
+  d.prim = s->prim.data();
+  d.x1f = s->coords[0].data(); d.x2f = s->coords[1].data(); d.x3f = s->coords[2].data();
+  d.x1v = s->coords[3].data(); d.x2v = s->coords[4].data(); d.x3v = s->coords[5].data();
+}
+
+void SetError(char *err, size_t err_len, const std::string &message) {
+  if (err != nullptr && err_len > 0) std::snprintf(err, err_len, "Error: %s\n", message.c_str());
+}
+
+}  // namespace
+
+extern "C" {
+
+int bl_snapshot_open(const bl_params *p, int snapshot, bl_snapshot **out, char *err, size_t err_len) {
+  if (p == nullptr || out == nullptr || snapshot < 0) {
+    SetError(err, err_len, "bl_snapshot_open: bad argument.");
+    return BL_E_ARG;
+  }
+  *out = nullptr;
+  bl_snapshot *s = nullptr;
+  try {
+    s = new bl_snapshot;
+    ReaderSetup(*p, s);
+    ReadAthena(*p, snapshot, s);
+    *out = s;
+    return BL_OK;
+  } catch (const ReadFailure &f) {
+    delete s;
+    SetError(err, err_len, f.message);
+    return f.code;
+  } catch (const std::exception &e) {
+    delete s;
+    SetError(err, err_len, std::string("Could not read simulation file (") + e.what() + ").");
+    return BL_E_INPUT;
+  }
+}
+
+const bl_grid_desc *bl_snapshot_grid(const bl_snapshot *s) { return s != nullptr ? &s->desc : nullptr; }
+
+double bl_snapshot_time(const bl_snapshot *s) { return s != nullptr ? s->time : 0.0; }
+
+const char *bl_snapshot_warnings(const bl_snapshot *s) { return s != nullptr ? s->warnings.c_str() : ""; }
+
+const char *bl_snapshot_file(const bl_snapshot *s) { return s != nullptr ? s->file.c_str() : ""; }
+
+int bl_snapshot_blocks(const bl_snapshot *s, const int32_t **levels, const int32_t **locations) {
+  if (s == nullptr) return 0;
+  if (levels != nullptr) *levels = s->levels.data();
+  if (locations != nullptr) *locations = s->locations.data();
+  return static_cast<int>(s->levels.size());
+}
+
+void bl_snapshot_close(bl_snapshot *s) { delete s; }
+
+}  // extern "C"

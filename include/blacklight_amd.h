@@ -190,6 +190,26 @@ typedef struct bl_grid_desc {
   double plasma_gamma, plasma_gamma_i, plasma_gamma_e; /* possibly modified by the reader */
 } bl_grid_desc;
 
+/* ------------------------------------------------------------------ snapshot reader (host only)
+ * SimulationReader for simulation_format = athena: constructor checks (simulation_reader.cpp:36-159),
+ * Read() (:211-861: file name for `snapshot` via FormatFilename :870-904, Time, Levels, LogicalLocations,
+ * coordinates with the angular-range fix :722-758, VerifyVariablesAthena :1141-1216, "prim" + "B" cell
+ * data :761-781) over the subset of HDF5 the reference decodes by hand (hdf5_format_*.cpp: superblock 0,
+ * version-1 B-trees / heaps / object headers / attributes, contiguous version-3 layouts). The snapshot
+ * owns the arrays bl_snapshot_grid() points to; hand that view to bl_set_grid(), then close the snapshot.
+ * err receives "Error: ...\n" (reference texts). Each call reads its file completely; the reference
+ * re-uses block layout and coordinates of the first file for later files of a series.
+ * slow_light_on and the other simulation formats return BL_E_UNSUPPORTED. */
+typedef struct bl_snapshot bl_snapshot;
+BL_API int bl_snapshot_open(const bl_params *p, int snapshot, bl_snapshot **out, char *err, size_t err_len);
+BL_API const bl_grid_desc *bl_snapshot_grid(const bl_snapshot *s);
+BL_API double bl_snapshot_time(const bl_snapshot *s);              /* file attribute "Time"           */
+BL_API const char *bl_snapshot_warnings(const bl_snapshot *s);     /* "Warning: ...\n" lines           */
+BL_API const char *bl_snapshot_file(const bl_snapshot *s);         /* file name actually opened       */
+/* MeshBlock table: returns n_blocks; *levels -> [n_blocks], *locations -> [n_blocks][3] */
+BL_API int bl_snapshot_blocks(const bl_snapshot *s, const int32_t **levels, const int32_t **locations);
+BL_API void bl_snapshot_close(bl_snapshot *s);
+
 /* ------------------------------------------------------------------ camera frame
  * The seven 4-vectors GeodesicIntegrator::InitializeCamera() derives (camera.cpp:61-380,
  * geodesic_integrator.hpp) and the frequency list (:30-50). Filled by bl_init. */

@@ -422,6 +422,73 @@ def make_window_fixture():
           f"{np.array_equal(fixture['A_block_locs'], fixture['B_block_locs'])}")
 
 
+# ------------------------------------------------------------------------------------------------
+# Snapshot-reader fixtures (tests/golden/reader/): small .athdf files exactly as h5py wrote them, the arrays
+# h5py reads back from them, and the reference's images for a two-file series (simulation_multiple) of them.
+READER_MOCKS = {
+    # file name: (mock arguments, Time attribute, post-processing)
+    "series_0003.athdf": (dict(n_r=16, n_th=12, n_ph=16), 3.5, None),
+    "series_0004.athdf": (dict(n_r=16, n_th=12, n_ph=16, pert_amp=0.4, pert_n_ph=3, rho_amp=1.5, Bph_amp=0.3), 4.75, None),
+    "blocks_entropy.athdf": (dict(n_r=8, n_th=6, n_ph=8), 11.0, "blocks_entropy"),
+}
+
+
+def set_time(path, value):
+    import h5py
+    with h5py.File(path, "r+") as f:
+        del f.attrs["Time"]
+        f.attrs.create("Time", value, dtype=np.float32)
+
+
+def make_reader_fixtures():
+    import h5py
+    out_dir = os.path.join(OUT, "reader")
+    workdir = os.path.join(WORK, "reader")
+    for sub in (out_dir, os.path.join(workdir, "data"), os.path.join(workdir, "output")):
+        os.makedirs(sub, exist_ok=True)
+    expected = {}
+    for name, (mock, time, post) in READER_MOCKS.items():
+        path = os.path.join(workdir, "data", name)
+        args = [sys.executable, "-W", "ignore", MOCK_SCRIPT, path]
+        for key, value in mock.items():
+            args += [f"--{key}", str(value)]
+        subprocess.run(args, check=True)
+        set_time(path, time)
+        if post == "blocks_entropy":
+            add_entropy(path)
+            single = path + ".single"
+            os.replace(path, single)
+            split_into_blocks(single, path, 2, 1, 2)
+            os.remove(single)
+        with open(path, "rb") as src, open(os.path.join(out_dir, name), "wb") as dst:
+            dst.write(src.read())
+        stem = name.split(".")[0]
+        with h5py.File(path, "r") as f:   # what an independent HDF5 implementation reads from the same bytes
+            expected[f"{stem}_prim"] = np.concatenate([f["prim"][...], f["B"][...]], axis=0).astype(np.float32)
+            for key in ("x1f", "x2f", "x3f", "x1v", "x2v", "x3v"):
+                expected[f"{stem}_{key}"] = f[key][...].astype(np.float32)
+            expected[f"{stem}_levels"] = f["Levels"][...].astype(np.int32)
+            expected[f"{stem}_locations"] = f["LogicalLocations"][...].astype(np.int32)
+            expected[f"{stem}_time"] = np.float32(f.attrs["Time"])
+            expected[f"{stem}_variable_names"] = json.dumps([v.decode() for v in f.attrs["VariableNames"]])
+    # the reference on the two-file series
+    params = dict(SIM_BASE)
+    params.update(camera_resolution=16, checkpoint_geodesic_save="false", simulation_multiple="true", simulation_start=3,
+                  simulation_end=4, simulation_file="data/series_{04d}.athdf", output_file="output/out_{02d}.npz",
+                  image_tau="true")
+    write_input(os.path.join(workdir, "case.input"), params)
+    expected["series_params"] = json.dumps(params)
+    for tier, preload in (("A", False), ("B", True)):
+        expected[f"series_{tier}_warnings"] = run_reference(workdir, "case.input", preload)
+        for number in (3, 4):
+            npz = np.load(os.path.join(workdir, "output", f"out_{number:02d}.npz"))
+            for key in npz.files:
+                expected[f"series_{tier}_{number}_{key}"] = npz[key]
+    np.savez_compressed(os.path.join(out_dir, "expected.npz"), **expected)
+    a, b = expected["series_B_3_I_nu"], expected["series_B_4_I_nu"]
+    print("reader fixtures written; series images differ:", not np.array_equal(a, b), "max", a.max(), b.max())
+
+
 if __name__ == "__main__":
     names = sys.argv[1:] or (["mock"] + list(CASES))
     for case_name in names:
@@ -429,5 +496,7 @@ if __name__ == "__main__":
             make_mock_fixture()
         elif case_name == "window_1024":
             make_window_fixture()
+        elif case_name == "reader":
+            make_reader_fixtures()
         else:
             make_case(case_name)
