@@ -508,14 +508,15 @@ int bl_init(const bl_params *p, int device, bl_ctx **out) {
   return BL_OK;
 }
 
-int bl_set_grid(bl_ctx *ctx, const bl_grid_desc *g) {
-  if (ctx == nullptr || g == nullptr) return BL_E_ARG;
-  try {
-    if (ctx->device == BL_DEVICE_NONE) throw Failure{BL_E_DEVICE, "Host-only context: no HIP device selected (the hot path has no CPU fallback)."};
-    if (ctx->params.model_type != BL_MODEL_SIMULATION) throw Failure{BL_E_STATE, "bl_set_grid called in formula mode."};
-    if (g->n_blocks < 1) throw Failure{BL_E_ARG, "Bad grid description."};
-    if (g->n_i < 2 || g->n_j < 2 || g->n_k < 2 || g->prim == nullptr) throw Failure{BL_E_ARG, "Bad grid description."};
-    Check(hipSetDevice(ctx->device), "hipSetDevice");
+namespace {
+
+// Grid of equal blocks at one refinement level tiling a box, in any order (simulation_sampling.cpp:352-394
+// searches the blocks per sample): merged into one global array at upload; the locate kernel keeps the
+// reference's per-block anchor rules through the block size. Throws kIrregular when the blocks are not such
+// a tiling (bl_set_grid then takes the refined-mesh path).
+const char *const kIrregular = "Multi-block grid is not a regular tiling by equal blocks of one level.";
+
+void UploadMergedGrid(bl_ctx *ctx, const bl_grid_desc *g) {
     // Several blocks (simulation_sampling.cpp:352-394 searches them per sample): supported when they are
     // equal blocks at one refinement level tiling a box, in any order. They are merged into one global
     // array at upload; the locate kernel keeps the reference's per-block anchor rules through the block
@@ -537,7 +538,6 @@ int bl_set_grid(bl_ctx *ctx, const bl_grid_desc *g) {
       }
     }
     const int nbl[3] = {static_cast<int>(starts[0].size()), static_cast<int>(starts[1].size()), static_cast<int>(starts[2].size())};
-    const char *kIrregular = "Multi-block grid is not a regular tiling by equal blocks of one level (mesh refinement is not built).";
     if (static_cast<long long>(nbl[0]) * nbl[1] * nbl[2] != n_b) throw Failure{BL_E_UNSUPPORTED, kIrregular};
     std::vector<int> block_at(n_b, -1);     // lattice position -> block
     for (int blk = 0; blk < n_b; blk++) {
@@ -646,6 +646,9 @@ int bl_set_grid(bl_ctx *ctx, const bl_grid_desc *g) {
     Check(hipMemcpy(ctx->d_buckets.ptr, buckets.data(), buckets.size() * sizeof(int), hipMemcpyHostToDevice), "bucket upload");
     dev.cells = ctx->d_cells.ptr;
     dev.kappa = code_kappa ? ctx->d_kappa.ptr : nullptr;
+    dev.n_blocks = 0;
+    dev.stride_row = n_i;
+    dev.stride_plane = n_i * n_j;
     for (int a = 0; a < 3; a++) {
       dev.xf[a] = ctx->d_coords.ptr + off_f[a];
       dev.xv[a] = ctx->d_coords.ptr + off_v[a];
@@ -661,10 +664,128 @@ int bl_set_grid(bl_ctx *ctx, const bl_grid_desc *g) {
         throw Failure{BL_E_UNSUPPORTED, "Grid coordinate tables do not fit the 60 KiB LDS budget of the shading kernel."};
       ctx->lds_table_bytes = static_cast<int>((bytes + 15) / 16 * 16);
     }
-    ctx->grid_meta = *g;
     ctx->n_i = n_i;
     ctx->n_j = n_j;
     ctx->n_k = n_k;
+}
+
+// Mesh with refinement (blocks of several levels), or any other set of non-overlapping equal-sized blocks:
+// cells stay block by block; the distinct block boundaries along each axis span a lattice of boxes, each
+// covered by at most one block, from which the locate kernel finds the block of a sample (the reference
+// scans all blocks per sample, simulation_sampling.cpp:352-394), then the cell from the block's own rows.
+void UploadRefinedGrid(bl_ctx *ctx, const bl_grid_desc *g) {
+  const int nb[3] = {g->n_i, g->n_j, g->n_k};
+  const double *block_xf[3] = {g->x1f, g->x2f, g->x3f};
+  const double *block_xv[3] = {g->x1v, g->x2v, g->x3v};
+  const int n_b = g->n_blocks;
+  const char *kBadMesh = "Multi-block grid has blocks that overlap or faces that do not ascend.";
+  std::vector<double> edge[3];
+  for (int a = 0; a < 3; a++) {
+    if (block_xf[a] == nullptr || block_xv[a] == nullptr) throw Failure{BL_E_ARG, "Bad grid description."};
+    for (int blk = 0; blk < n_b; blk++) {
+      const double *f = block_xf[a] + static_cast<size_t>(blk) * (nb[a] + 1);
+      for (int i = 0; i < nb[a]; i++)
+        if (!(f[i] < f[i + 1])) throw Failure{BL_E_UNSUPPORTED, kBadMesh};
+      edge[a].push_back(f[0]);
+      edge[a].push_back(f[nb[a]]);
+    }
+    std::sort(edge[a].begin(), edge[a].end());
+    edge[a].erase(std::unique(edge[a].begin(), edge[a].end()), edge[a].end());
+  }
+  const int n_edge[3] = {static_cast<int>(edge[0].size()) - 1, static_cast<int>(edge[1].size()) - 1,
+                         static_cast<int>(edge[2].size()) - 1};
+  const size_t n_boxes = static_cast<size_t>(n_edge[0]) * n_edge[1] * n_edge[2];
+  const size_t block_cells = static_cast<size_t>(nb[0]) * nb[1] * nb[2];
+  const size_t n_cells = block_cells * n_b;
+  if (n_boxes > (1ull << 28) || n_cells >= (1ull << 32))
+    throw Failure{BL_E_UNSUPPORTED, "Multi-block grid too large for the block lattice of this build."};
+  std::vector<int> lattice(n_boxes, -1);
+  for (int blk = 0; blk < n_b; blk++) {
+    int lo[3], hi[3];
+    for (int a = 0; a < 3; a++) {
+      const double *f = block_xf[a] + static_cast<size_t>(blk) * (nb[a] + 1);
+      lo[a] = static_cast<int>(std::lower_bound(edge[a].begin(), edge[a].end(), f[0]) - edge[a].begin());
+      hi[a] = static_cast<int>(std::lower_bound(edge[a].begin(), edge[a].end(), f[nb[a]]) - edge[a].begin());
+    }
+    for (int kk = lo[2]; kk < hi[2]; kk++)
+      for (int jj = lo[1]; jj < hi[1]; jj++)
+        for (int ii = lo[0]; ii < hi[0]; ii++) {
+          int &slot = lattice[(static_cast<size_t>(kk) * n_edge[1] + jj) * n_edge[0] + ii];
+          if (slot != -1) throw Failure{BL_E_UNSUPPORTED, kBadMesh};
+          slot = blk;
+        }
+  }
+  // cells: [var][block][k][j][i] -> [block][k][j][i][8]
+  const int order[8] = {g->ind_rho, g->ind_pgas, g->ind_uu1, g->ind_uu2, g->ind_uu3, g->ind_bb1, g->ind_bb2, g->ind_bb3};
+  for (int v : order)
+    if (v < 0 || v >= g->n_var) throw Failure{BL_E_ARG, "Grid variable index out of range."};
+  std::vector<float> cells(n_cells * 8);
+  for (int v = 0; v < 8; v++) {
+    const float *src = g->prim + static_cast<size_t>(order[v]) * n_cells;
+    for (size_t c = 0; c < n_cells; c++) cells[c * 8 + v] = src[c];
+  }
+  ctx->d_cells.Ensure(cells.size());
+  Check(hipMemcpy(ctx->d_cells.ptr, cells.data(), cells.size() * sizeof(float), hipMemcpyHostToDevice), "grid upload");
+  const bool code_kappa = ctx->params.plasma_model == BL_PLASMA_CODE_KAPPA;
+  if (code_kappa) {
+    if (g->ind_kappa < 0 || g->ind_kappa >= g->n_var) throw Failure{BL_E_ARG, "Grid variable index out of range."};
+    ctx->d_kappa.Ensure(n_cells);
+    Check(hipMemcpy(ctx->d_kappa.ptr, g->prim + static_cast<size_t>(g->ind_kappa) * n_cells, n_cells * sizeof(float),
+                    hipMemcpyHostToDevice), "grid upload");
+  }
+  // coordinate rows of every block, then the block boundaries
+  std::vector<double> coords;
+  size_t off_f[3], off_v[3], off_e[3];
+  for (int a = 0; a < 3; a++) {
+    off_f[a] = coords.size();
+    coords.insert(coords.end(), block_xf[a], block_xf[a] + static_cast<size_t>(n_b) * (nb[a] + 1));
+    off_v[a] = coords.size();
+    coords.insert(coords.end(), block_xv[a], block_xv[a] + static_cast<size_t>(n_b) * nb[a]);
+    off_e[a] = coords.size();
+    coords.insert(coords.end(), edge[a].begin(), edge[a].end());
+  }
+  ctx->d_coords.Ensure(coords.size());
+  Check(hipMemcpy(ctx->d_coords.ptr, coords.data(), coords.size() * sizeof(double), hipMemcpyHostToDevice), "coordinate upload");
+  ctx->d_buckets.Ensure(lattice.size());
+  Check(hipMemcpy(ctx->d_buckets.ptr, lattice.data(), lattice.size() * sizeof(int), hipMemcpyHostToDevice), "lattice upload");
+  BlGridDevice dev{};
+  dev.cells = ctx->d_cells.ptr;
+  dev.kappa = code_kappa ? ctx->d_kappa.ptr : nullptr;
+  dev.n_blocks = n_b;
+  dev.lattice = ctx->d_buckets.ptr;
+  dev.stride_row = nb[0];
+  dev.stride_plane = nb[0] * nb[1];
+  for (int a = 0; a < 3; a++) {
+    dev.bxf[a] = ctx->d_coords.ptr + off_f[a];
+    dev.bxv[a] = ctx->d_coords.ptr + off_v[a];
+    dev.edge[a] = ctx->d_coords.ptr + off_e[a];
+    dev.n_edge[a] = n_edge[a];
+    dev.n[a] = nb[a];
+    dev.nb[a] = nb[a];
+  }
+  ctx->grid_dev = dev;
+  ctx->lds_table_bytes = 0;
+  ctx->n_i = nb[0];
+  ctx->n_j = nb[1];
+  ctx->n_k = nb[2];
+}
+}  // namespace
+
+int bl_set_grid(bl_ctx *ctx, const bl_grid_desc *g) {
+  if (ctx == nullptr || g == nullptr) return BL_E_ARG;
+  try {
+    if (ctx->device == BL_DEVICE_NONE) throw Failure{BL_E_DEVICE, "Host-only context: no HIP device selected (the hot path has no CPU fallback)."};
+    if (ctx->params.model_type != BL_MODEL_SIMULATION) throw Failure{BL_E_STATE, "bl_set_grid called in formula mode."};
+    if (g->n_blocks < 1) throw Failure{BL_E_ARG, "Bad grid description."};
+    if (g->n_i < 2 || g->n_j < 2 || g->n_k < 2 || g->prim == nullptr) throw Failure{BL_E_ARG, "Bad grid description."};
+    Check(hipSetDevice(ctx->device), "hipSetDevice");
+    try {
+      UploadMergedGrid(ctx, g);
+    } catch (const Failure &failure) {
+      if (failure.message != kIrregular) throw;
+      UploadRefinedGrid(ctx, g);   // blocks of several levels, or a tiling with holes
+    }
+    ctx->grid_meta = *g;
     ctx->have_grid = true;
   } catch (const Failure &failure) {
     return Fail(ctx, failure);

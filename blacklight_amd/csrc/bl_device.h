@@ -74,6 +74,15 @@ struct BlGridDevice {
   int n_bucket[3];
   int n[3];                  // n_i, n_j, n_k of the (merged) global grid
   int nb[3];                 // cells per block along each axis (= n for a single block)
+  int stride_row, stride_plane;   // cells between j- and k-neighbours in `cells` / `kappa`
+  // Mesh refinement (blocks of several levels, simulation_sampling.cpp:352-394): `cells` is then
+  // [block][n_k][n_j][n_i][8] with nb = block size, and the tables above are unused. n_blocks = 0: merged grid.
+  int n_blocks;
+  const double *edge[3];     // ascending distinct block boundaries per axis, n_edge[a] + 1 values
+  int n_edge[3];
+  const int *lattice;        // [n_edge[2]][n_edge[1]][n_edge[0]] -> block covering that box, -1: none
+  const double *bxf[3];      // [n_blocks][nb[a] + 1] faces of every block
+  const double *bxv[3];      // [n_blocks][nb[a]] centres
 };
 
 struct BlPlasmaDevice {

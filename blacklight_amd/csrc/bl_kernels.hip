@@ -694,8 +694,74 @@ __device__ __forceinline__ const float4 *cell_ptr(const BlGridDevice &g, int k, 
   return reinterpret_cast<const float4 *>(g.cells + idx);
 }
 
+// First index i in [0, n) with table[i + 1] >= x, for x in [table[0], table[n]] (the rule of the reference's
+// linear scans, simulation_sampling.cpp:458-466), by bisection.
+__device__ __forceinline__ int first_upper_face(const double *table, int n, double x) {
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (table[mid + 1] >= x) hi = mid; else lo = mid + 1;
+  }
+  return lo;
+}
+
+// The same on a mesh with refinement: the block from the lattice of block boundaries, then the cell inside
+// it from the block's own coordinate rows (global memory; this path is not the benchmark's).
+__device__ __forceinline__ void locate_sample_refined(const BlShadeArgs &P, double s1, double s2, double s3,
+                                                      BlLocated *out, unsigned long long *gathers) {
+  const BlPlasmaDevice &pl = P.plasma;
+  const BlGridDevice &g = P.grid;
+  const double s[3] = {s1, s2, s3};
+  int box[3];
+  for (int a = 0; a < 3; a++) {
+    if (s[a] < g.edge[a][0] || s[a] > g.edge[a][g.n_edge[a]]) {
+      out->status = kSampleOffGrid;
+      return;
+    }
+    box[a] = first_upper_face(g.edge[a], g.n_edge[a], s[a]);
+  }
+  const int b = g.lattice[((size_t)box[2] * g.n_edge[1] + box[1]) * g.n_edge[0] + box[0]];
+  if (b < 0) {
+    out->status = kSampleOffGrid;
+    return;
+  }
+  int c[3];
+  const double *xv[3];
+  for (int a = 0; a < 3; a++) {
+    const int n = g.nb[a];
+    const double *xf = g.bxf[a] + (size_t)b * (n + 1);
+    xv[a] = g.bxv[a] + (size_t)b * n;
+    // start from the position in a uniform block, then walk to the first cell whose upper face is >= s
+    int i = (int)((s[a] - xf[0]) / (xf[n] - xf[0]) * (double)n);
+    i = i < 0 ? 0 : (i > n - 1 ? n - 1 : i);
+    while (i < n - 1 && xf[i + 1] < s[a]) i++;
+    while (i > 0 && xf[i] >= s[a]) i--;
+    c[a] = i;
+  }
+  *gathers += 1ull;
+  const size_t block_base = (size_t)b * g.nb[2] * g.stride_plane;
+  if (!pl.simulation_interp) {
+    out->status = kSampleNearest;
+    out->cell = (uint32_t)(block_base + (size_t)c[2] * g.stride_plane + (size_t)c[1] * g.stride_row + c[0]);
+    return;
+  }
+  int m[3];
+  double f[3];
+  for (int a = 0; a < 3; a++) {   // :485-490 with the block's own centres
+    const int i = c[a];
+    m[a] = (i == 0 || (i != g.nb[a] - 1 && s[a] >= xv[a][i])) ? i : i - 1;
+    f[a] = (s[a] - xv[a][m[a]]) / (xv[a][m[a] + 1] - xv[a][m[a]]);
+  }
+  out->f_i = f[0];
+  out->f_j = f[1];
+  out->f_k = f[2];
+  out->status = kSampleInterp;
+  out->cell = (uint32_t)(block_base + (size_t)m[2] * g.stride_plane + (size_t)m[1] * g.stride_row + m[0]);
+}
+
 // Locate one sample on the simulation grid: ConvertFromCKS (radiation_geometry.cpp:37-57), block test
 // and cell search (simulation_sampling.cpp:352-394, :458-490), trilinear fractions (:736-760).
+template <bool kRefined>
 __device__ __forceinline__ void locate_sample(const BlShadeArgs &P, const GridTables &tab, const BlSpacetime &st,
                                               double x1, double x2, double x3, double r, BlLocated *out,
                                               unsigned long long *gathers) {
@@ -716,6 +782,10 @@ __device__ __forceinline__ void locate_sample(const BlShadeArgs &P, const GridTa
     s1 = r;
     s2 = th;
     s3 = ph;
+  }
+  if (kRefined) {
+    locate_sample_refined(P, s1, s2, s3, out, gathers);
+    return;
   }
   const int n_i = g.n[0], n_j = g.n[1], n_k = g.n[2];
   if (s1 < tab.xf[0][0] || s1 > tab.xf[0][n_i] || s2 < tab.xf[1][0] || s2 > tab.xf[1][n_j]
@@ -756,7 +826,7 @@ __device__ __forceinline__ void sample_primitives(const BlShadeArgs &P, int stat
   if (status == kSampleInterp) {
     // the 8 corner cells: 16 independent 16-byte loads in flight per lane; the two cells of an
     // i-pair are one contiguous 64-byte segment
-    const size_t row = (size_t)g.n[0] * 2, plane = (size_t)g.n[1] * row;
+    const size_t row = (size_t)g.stride_row * 2, plane = (size_t)g.stride_plane * 2;
     float4 lo[8], hi[8];
 #pragma unroll
     for (int corner = 0; corner < 8; corner++) {
@@ -809,7 +879,7 @@ __device__ __forceinline__ float sample_kappa(const BlShadeArgs &P, int status, 
   const BlGridDevice &g = P.grid;
   const float *base = g.kappa + cell;
   if (status == kSampleInterp) {
-    const size_t row = (size_t)g.n[0], plane = (size_t)g.n[1] * row;
+    const size_t row = (size_t)g.stride_row, plane = (size_t)g.stride_plane;
     float c[8];
 #pragma unroll
     for (int corner = 0; corner < 8; corner++)
@@ -1118,11 +1188,18 @@ __device__ __forceinline__ void shade_formula(const BlShadeArgs &P, const BlSpac
 // ---- locate kernel (simulation mode): one sample record per lane. Coordinate conversion and the
 // LDS table walks of the cell search; no grid reads (the coefficient kernel issues those, where they
 // overlap its arithmetic instead of saturating the texture addresser here).
+// kRefined: mesh with refinement; block and cell come from tables in global memory, no LDS staging.
+template <bool kRefined>
 __global__ void __launch_bounds__(256, 4) bl_locate_kernel(const BlShadeArgs P) {
   const BlSpacetime st = P.st;
   extern __shared__ double lds_tables[];
   GridTables tab;
-  {
+  if (kRefined) {
+    for (int a = 0; a < 3; a++) {
+      tab.xf[a] = tab.xv[a] = nullptr;
+      tab.bucket[a] = nullptr;
+    }
+  } else {
     const BlGridDevice &g = P.grid;
     double *dst = lds_tables;
     for (int a = 0; a < 3; a++) {
@@ -1177,7 +1254,7 @@ __global__ void __launch_bounds__(256, 4) bl_locate_kernel(const BlShadeArgs P) 
     loc.f_i = loc.f_j = loc.f_k = loc.ph = 0.0;
     loc.cell = 0u;
     loc.status = kSampleCut;
-    if (!skip) locate_sample(P, tab, st, x1, x2, x3, r, &loc, &gathers_local);
+    if (!skip) locate_sample<kRefined>(P, tab, st, x1, x2, x3, r, &loc, &gathers_local);
     double2 *dst = reinterpret_cast<double2 *>(P.located + at);
     dst[0] = make_double2(loc.f_i, loc.f_j);
     dst[1] = make_double2(loc.f_k, loc.ph);
@@ -1691,7 +1768,10 @@ extern "C" int bl_geodesic_occupancy(int integrator) {
 
 // Locate kernel (simulation mode only); lds_bytes = size of the coordinate tables it stages in LDS
 extern "C" hipError_t bl_launch_locate(const BlShadeArgs *args, int grid, int lds_bytes, hipStream_t stream) {
-  hipLaunchKernelGGL(bl_locate_kernel, dim3(grid), dim3(256), lds_bytes, stream, *args);
+  if (args->grid.n_blocks > 0)
+    hipLaunchKernelGGL(bl_locate_kernel<true>, dim3(grid), dim3(256), 0, stream, *args);
+  else
+    hipLaunchKernelGGL(bl_locate_kernel<false>, dim3(grid), dim3(256), lds_bytes, stream, *args);
   return hipGetLastError();
 }
 

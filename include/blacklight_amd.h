@@ -266,7 +266,9 @@ typedef struct bl_ctx bl_ctx;
  * frame, bl_adaptive_refine, bl_write_output); bl_set_grid / bl_render on it fail with BL_E_DEVICE. */
 #define BL_DEVICE_NONE (-2)
 BL_API int bl_init(const bl_params *p, int device, bl_ctx **out);
-/* Repack the grid into the HBM layout ([k][j][i][8 floats]) and upload it; once per snapshot. */
+/* Repack the grid into the HBM layout and upload it; once per snapshot. Equal blocks of one level tiling a
+ * box are merged into one [k][j][i][8 floats] array; other sets of non-overlapping equal-sized blocks (mesh
+ * refinement) stay [block][k][j][i][8] behind a lattice of block boundaries. Overlapping blocks are refused. */
 BL_API int bl_set_grid(bl_ctx *ctx, const bl_grid_desc *g);
 /* Number of image rows n_q and their offsets (radiation_integrator.cpp:436-520). */
 BL_API int bl_image_num_quantities(const bl_ctx *ctx);

@@ -31,6 +31,7 @@ def golden_grid(mock_args):
     mock_args = dict(mock_args)
     blocks = mock_args.pop("_blocks", None)
     entropy = mock_args.pop("_entropy", None)
+    refined = mock_args.pop("_refined", None)
     assert json.loads(str(fx["mock_args"])) == mock_args
     prim = np.ascontiguousarray(fx["prim"], dtype=np.float32)
 
@@ -42,6 +43,8 @@ def golden_grid(mock_args):
     if entropy:
         from blacklight_amd.mock import with_entropy
         grid = with_entropy(grid)
+    if refined:
+        return refined_grid(grid)
     return split_grid(grid, *blocks) if blocks is not None else grid
 
 
@@ -64,6 +67,70 @@ def split_grid(grid, nbi, nbj, nbk):
     return Grid(prim=prim, x1f=cut(grid.x1f, ni, 2, 1), x2f=cut(grid.x2f, nj, 1, 1), x3f=cut(grid.x3f, nk, 0, 1),
                 x1v=cut(grid.x1v, ni, 2, 0), x2v=cut(grid.x2v, nj, 1, 0), x3v=cut(grid.x3v, nk, 0, 0),
                 ind_kappa=grid.ind_kappa)
+
+
+REFINED_BLOCK = (8, 6, 8)   # cells per block (i, j, k) of the refined version of the 32 x 24 x 32 mock
+
+
+def refined_blocks(prim, xf, xv):
+    """A two-level mesh from one block of data: prim [n_var][n_k][n_j][n_i] float32, xf / xv = three float32
+    face / centre rows. The domain is cut into 2 x 2 x 2 octants; octants with an odd index sum become one
+    coarse block each (level 0: pairwise averages of the fine cells in single precision, every second face),
+    the others eight fine blocks each (level 1), all of REFINED_BLOCK cells, in a scrambled order. Only
+    correctly rounded single-precision operations, so that tools/make_goldens.py (which writes the result as
+    an .athdf for the reference) and the tests build the same bits. Returns a dict of arrays."""
+    bi, bj, bk = REFINED_BLOCK
+    n_var, n_k, n_j, n_i = prim.shape
+    assert (n_i, n_j, n_k) == (4 * bi, 4 * bj, 4 * bk)
+    f32 = np.float32
+    prim = prim.astype(f32)
+    xf = [np.asarray(a, dtype=f32) for a in xf]
+    xv = [np.asarray(a, dtype=f32) for a in xv]
+    c = prim
+    pairs_i = (c[..., 0::2] + c[..., 1::2]).astype(f32)
+    pairs_j = (pairs_i[..., 0::2, :] + pairs_i[..., 1::2, :]).astype(f32)
+    coarse = ((pairs_j[:, 0::2] + pairs_j[:, 1::2]).astype(f32) * f32(0.125)).astype(f32)
+    cxf = [a[0::2] for a in xf]
+    cxv = [(0.5 * (a[:-1].astype(np.float64) + a[1:].astype(np.float64))).astype(f32) for a in cxf]
+    blocks = []   # (level, (li, lj, lk), source arrays, cell offsets)
+    for ok in range(2):
+        for oj in range(2):
+            for oi in range(2):
+                if (oi + oj + ok) % 2 == 1:
+                    blocks.append((0, (oi, oj, ok), coarse, cxf, cxv, (oi * bi, oj * bj, ok * bk)))
+                else:
+                    for fk in range(2):
+                        for fj in range(2):
+                            for fi in range(2):
+                                loc = (2 * oi + fi, 2 * oj + fj, 2 * ok + fk)
+                                blocks.append((1, loc, prim, xf, xv, (loc[0] * bi, loc[1] * bj, loc[2] * bk)))
+    order = np.random.default_rng(5).permutation(len(blocks))
+    blocks = [blocks[o] for o in order]
+    n_b = len(blocks)
+    out = dict(prim=np.empty((n_var, n_b, bk, bj, bi), dtype=f32), levels=np.empty(n_b, dtype=np.int32),
+               locations=np.empty((n_b, 3), dtype=np.int64))
+    for name, n in (("x1f", bi + 1), ("x2f", bj + 1), ("x3f", bk + 1), ("x1v", bi), ("x2v", bj), ("x3v", bk)):
+        out[name] = np.empty((n_b, n), dtype=f32)
+    for n, (level, loc, data, faces, centres, (i0, j0, k0)) in enumerate(blocks):
+        out["prim"][:, n] = data[:, k0:k0 + bk, j0:j0 + bj, i0:i0 + bi]
+        out["levels"][n] = level
+        out["locations"][n] = loc
+        for axis, (start, size) in enumerate(((i0, bi), (j0, bj), (k0, bk))):
+            out[f"x{axis + 1}f"][n] = faces[axis][start:start + size + 1]
+            out[f"x{axis + 1}v"][n] = centres[axis][start:start + size]
+    return out
+
+
+def refined_grid(grid):
+    """The single-block Grid as the two-level mesh of refined_blocks()."""
+    from blacklight_amd.mock import Grid
+    blocks = refined_blocks(grid.prim[:, 0], [grid.x1f[0], grid.x2f[0], grid.x3f[0]], [grid.x1v[0], grid.x2v[0], grid.x3v[0]])
+
+    def row(name):
+        return np.ascontiguousarray(blocks[name].astype(np.float64))
+
+    return Grid(prim=np.ascontiguousarray(blocks["prim"]), x1f=row("x1f"), x2f=row("x2f"), x3f=row("x3f"),
+                x1v=row("x1v"), x2v=row("x2v"), x3v=row("x3v"), ind_kappa=grid.ind_kappa)
 
 
 IMAGE_ROW_NAMES = ["I_nu", "time", "length", "lambda", "emission", "tau", "lambda_ave_rho", "lambda_ave_n_e",

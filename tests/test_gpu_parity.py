@@ -225,21 +225,34 @@ def _random_configuration(seed):
             over["formula_spin"] = 0.0
     if rng.integers(0, 3) == 0:
         over.update(image_tau="true", image_lambda="true", image_crossings="true")
-    return base, over
+    # mesh layout and electron model (drawn last, so that earlier seeds keep their other parameters)
+    mesh = {}
+    if simulation:
+        layout = int(rng.integers(0, 4))
+        if layout == 1:
+            mesh["_blocks"] = [2, 2, 2]
+        elif layout >= 2:
+            mesh["_refined"] = 1
+        if layout == 3:
+            mesh["_entropy"] = 1
+            over.update(plasma_model="code_kappa", simulation_kappa_name="r0", fallback_kappa=2.0e6)
+    return base, over, mesh
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", range(24))
 def test_randomised_configurations_against_oracle(seed, built_library):
     """Seeded draws from the supported parameter space (cameras, spins, integrators, termination rules,
-    frequency lists, plasma / formula parameters, cuts, power-law electrons, auxiliary images): HIP vs the
-    CPU oracle, every output bit-exact."""
+    frequency lists, plasma / formula parameters, cuts, power-law electrons, auxiliary images, single-block /
+    multi-block / refined meshes, electron entropy): HIP vs the CPU oracle, every output bit-exact."""
     import blacklight_amd as bl
     from blacklight_amd import _capi
     import oracle_api
-    base, over = _random_configuration(seed)
+    base, over, mesh = _random_configuration(seed)
     fx, params, mock_args = gu.load_case(base)
     params = dict(params)
     params.update(over)
+    if mock_args is not None:
+        mock_args = dict(mock_args, **mesh)
     p = bl.Params.from_dict(params)
     grid = gu.golden_grid(mock_args) if mock_args is not None else None
     with bl.Context(p) as ctx:
@@ -255,3 +268,32 @@ def test_randomised_configurations_against_oracle(seed, built_library):
     assert got["image"].shape == want["image"].shape
     same = gu.same_bits(got["image"], want["image"])
     assert same.all(), f"{(~same).sum()} of {same.size} values differ for {over}"
+
+
+def test_refined_mesh_holes_and_overlaps(built_library):
+    """A mesh with a block missing is still a mesh (samples in the hole are off the grid, as in the reference's
+    scan over blocks): HIP vs oracle bit-exact. Blocks that overlap are refused."""
+    import dataclasses
+    import blacklight_amd as bl
+    from blacklight_amd import _capi
+    import oracle_api
+    fx, params, mock_args = gu.load_case("sim_refined")
+    params = dict(params, camera_resolution=16, fallback_nan="false", fallback_rho=1.0e-6, fallback_pgas=1.0e-8)
+    p = bl.Params.from_dict(params)
+    full = gu.golden_grid(mock_args)
+
+    def subset(keep):
+        return dataclasses.replace(full, prim=np.ascontiguousarray(full.prim[:, keep]),
+                                   **{n: np.ascontiguousarray(getattr(full, n)[keep]) for n in ("x1f", "x2f", "x3f", "x1v", "x2v", "x3v")})
+
+    n_b = full.prim.shape[1]
+    holed = subset([b for b in range(n_b) if b not in (3, 17)])
+    with bl.Context(p) as ctx:
+        ctx.set_grid(holed)
+        got = ctx.render()
+        want = oracle_api.render(p.ptr, holed.desc(), _capi.RenderDesc, _capi.CameraFrame, n_rays=256,
+                                 max_steps=int(p.get("ray_max_steps")), n_freq=1)
+        assert np.array_equal(got["sample_num"], want["sample_num"])
+        assert gu.same_bits(got["image"], want["image"]).all()
+        with pytest.raises(bl.BlacklightError, match="overlap"):
+            ctx.set_grid(subset(list(range(n_b)) + [5]))

@@ -109,6 +109,11 @@ CASES = {
                                                simulation_interp="false", simulation_a=0.9, fallback_nan="false",
                                                fallback_rho=1.0e-6, fallback_pgas=1.0e-8, fallback_kappa=3.0e6,
                                                cut_theta_e_max=20.0), dict(SMALL_MOCK, _entropy=1, _blocks=[2, 2, 2]), [136]),
+    # mesh refinement: 4 coarse + 32 fine blocks in scrambled order (tests/golden_util.refined_blocks)
+    "sim_refined": (SIM_BASE, dict(camera_resolution=32), dict(SMALL_MOCK, _refined=1), [528]),
+    "sim_refined_nearest": (SIM_BASE, dict(camera_resolution=24, simulation_interp="false", simulation_a=0.5,
+                                           plasma_model="code_kappa", simulation_kappa_name="r0"),
+                            dict(SMALL_MOCK, _entropy=1, _refined=1), [300]),
     "sim_powerlaw": (SIM_BASE, dict(camera_resolution=24, plasma_power_frac=0.3, plasma_p=2.5, plasma_gamma_min=1.0,
                                     plasma_gamma_max=1000.0), SMALL_MOCK, [300]),
     # false-colour renderings (rendering.cpp): the features of the reference's example_render.input, without
@@ -280,6 +285,34 @@ def split_into_blocks(src, dst, nbi, nbj, nbk):
         g.create_dataset("B", data=cut(bfield))
 
 
+def split_refined(src, dst):
+    """Rewrite the single-block athdf `src` as the two-level mesh of tests/golden_util.refined_blocks."""
+    import h5py
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    sys.path.insert(0, REPO)
+    from golden_util import REFINED_BLOCK, refined_blocks
+    with h5py.File(src, "r") as f:
+        attrs = {k: f.attrs[k] for k in f.attrs}
+        n_hydro = f["prim"].shape[0]
+        prim = np.concatenate([f["prim"][:, 0], f["B"][:, 0]], axis=0)
+        blocks = refined_blocks(prim, [f["x1f"][0], f["x2f"][0], f["x3f"][0]], [f["x1v"][0], f["x2v"][0], f["x3v"][0]])
+    bi, bj, bk = REFINED_BLOCK
+    with h5py.File(dst, "w") as g:
+        for k, v in attrs.items():
+            if k not in ("NumMeshBlocks", "MeshBlockSize", "RootGridSize", "MaxLevel"):
+                g.attrs.create(k, v, dtype=v.dtype)
+        g.attrs.create("NumMeshBlocks", len(blocks["levels"]), dtype=np.int32)
+        g.attrs.create("MeshBlockSize", (bi, bj, bk), dtype=np.int32)
+        g.attrs.create("RootGridSize", (2 * bi, 2 * bj, 2 * bk), dtype=np.int32)
+        g.attrs.create("MaxLevel", 1, dtype=np.int32)
+        g.create_dataset("Levels", data=blocks["levels"], dtype=np.int32)
+        g.create_dataset("LogicalLocations", data=blocks["locations"], dtype=np.int64)
+        for name in ("x1f", "x2f", "x3f", "x1v", "x2v", "x3v"):
+            g.create_dataset(name, data=blocks[name], dtype=np.float32)
+        g.create_dataset("prim", data=blocks["prim"][:n_hydro], dtype=np.float32)
+        g.create_dataset("B", data=blocks["prim"][n_hydro:], dtype=np.float32)
+
+
 def make_case(name):
     base, overrides, mock, dump_rays = CASES[name]
     params = dict(base)
@@ -297,6 +330,10 @@ def make_case(name):
         subprocess.run(args, check=True)
         if "_entropy" in mock:
             add_entropy(mock_path)
+        if "_refined" in mock:   # two refinement levels
+            single = os.path.join(workdir, "data", "mock_single.athdf")
+            os.replace(mock_path, single)
+            split_refined(single, mock_path)
         if "_blocks" in mock:   # several MeshBlocks: split the script's single block
             single = os.path.join(workdir, "data", "mock_single.athdf")
             os.replace(mock_path, single)
