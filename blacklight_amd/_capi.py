@@ -116,6 +116,12 @@ def lib():
     L.bl_snapshot_file.restype = C.c_char_p
     L.bl_snapshot_blocks.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.POINTER(C.c_int32))]
     L.bl_snapshot_close.argtypes = [C.c_void_p]
+    L.bl_snapshot_open_number.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_char_p, C.c_size_t]
+    L.bl_slow_light_read.argtypes = [C.c_void_p, C.c_int]
+    L.bl_set_grid_slice.argtypes = [C.c_void_p, C.c_int, C.POINTER(GridDesc), C.c_double]
+    L.bl_shift_grid_slices.argtypes = [C.c_void_p, C.c_int]
+    L.bl_set_snapshot.argtypes = [C.c_void_p, C.c_int]
+    L.bl_warnings_clear.argtypes = [C.c_void_p]
     L.bl_build_info.restype = C.c_char_p
     _lib = L
     return L

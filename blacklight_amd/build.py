@@ -52,14 +52,15 @@ def build(force=False, verbose=False):
             continue
         cmd = [cc, "-c", src_path, "-o", obj_path] + COMMON + os.environ.get("BLACKLIGHT_AMD_EXTRA_FLAGS", "").split()
         if src.endswith(".hip"):
-            cmd += [f"--offload-arch={ARCH}", "-Rpass-analysis=kernel-resource-usage"] if verbose else [f"--offload-arch={ARCH}"]
-        else:
-            cmd += ["-x", "c++"] if False else []
+            cmd += [f"--offload-arch={ARCH}", "-Rpass-analysis=kernel-resource-usage"]
         if verbose:
             print(" ".join(cmd), flush=True)
         result = subprocess.run(cmd, capture_output=True, text=True)
         if result.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{result.stdout}\n{result.stderr}")
+        if src.endswith(".hip"):   # registers, scratch and occupancy of every kernel (tests/test_kernel_resources.py)
+            with open(obj_path[:-2] + ".resources.txt", "w") as f:
+                f.write(result.stderr)
         if verbose and result.stderr:
             print(result.stderr)
         rebuilt = True

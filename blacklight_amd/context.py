@@ -104,6 +104,26 @@ class Context:
         self._grid_keepalive = grid
         self._check(self._lib.bl_set_grid(self._ctx, C.byref(desc)))
 
+    # ------------------------------------------------------------------ slow light
+    def slow_light_read(self, snapshot):
+        """SimulationReader::Read(snapshot) with slow_light_on: advance the window of files to the camera time of
+        image `snapshot` (reads .athdf files itself) and select that image for the next render()."""
+        self._check(self._lib.bl_slow_light_read(self._ctx, int(snapshot)))
+
+    def set_grid_slice(self, n, grid, time):
+        """Slice n of the slow-light window (n = 0: latest file) from a caller-side reader."""
+        desc = grid.desc()
+        self._check(self._lib.bl_set_grid_slice(self._ctx, int(n), C.byref(desc), float(time)))
+
+    def shift_grid_slices(self, count):
+        self._check(self._lib.bl_shift_grid_slices(self._ctx, int(count)))
+
+    def set_snapshot(self, snapshot):
+        self._check(self._lib.bl_set_snapshot(self._ctx, int(snapshot)))
+
+    def clear_warnings(self):
+        self._lib.bl_warnings_clear(self._ctx)
+
     # ------------------------------------------------------------------ render
     def level_pixels(self, level=0, n_blocks=0):
         if level == 0:

@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <sstream>
 #include <string>
 #include <vector>
 
@@ -102,6 +103,21 @@ struct bl_ctx {
   DeviceBuffer<int> d_buckets;
   BlGridDevice grid_dev{};
   int lds_table_bytes = 0;
+  DeviceBuffer<float> *cells_target = nullptr, *kappa_target = nullptr;   // where the grid upload puts the cells
+
+  // slow light: the reader's window of time slices (prim[n], time[n]; n = 0 latest) on one geometry
+  struct SlowSlice {
+    DeviceBuffer<float> cells, kappa;
+    double time = 0.0;
+    bool set = false;
+  };
+  std::vector<SlowSlice> slow_slices;
+  bl_slow_state slow_state{};            // reader-side bookkeeping of bl_slow_light_read (bl_snapshot.cpp)
+  int snapshot = 0;                      // index of the image being rendered (warning texts, camera time)
+  long long stats_slow_count[4] = {0, 0, 0, 0};    // pixels needing extrapolation in the last render, by kind
+  double stats_slow_val[4] = {0.0, 0.0, 0.0, 0.0};
+  DeviceBuffer<unsigned long long> d_slow_table;   // cells pointers, kappa pointers, times, extrapolation maxima
+  DeviceBuffer<unsigned int> d_ray_extrap;
 
   // per-chunk scratch, two sets: the geodesic kernel fills one while the shading kernels drain the other
   struct ChunkSlot {
@@ -114,9 +130,10 @@ struct bl_ctx {
     DeviceBuffer<long long> d_ray_out_index;
     DeviceBuffer<unsigned long long> d_counters;   // BL_CNT_COUNT + 4 stats
     DeviceBuffer<BlAuxSample> d_aux;               // auxiliary-image mode
-    DeviceBuffer<double> d_sample_t;               // image_time
+    DeviceBuffer<double> d_sample_t;               // image_time, slow light
+    DeviceBuffer<double> d_slow_frac;              // slow light: t_frac of every located sample
     void Free() {
-      d_aux.Free(); d_sample_t.Free();
+      d_aux.Free(); d_sample_t.Free(); d_slow_frac.Free();
       d_records.Free(); d_located.Free(); d_transfer.Free(); d_ray_kt.Free(); d_ray_factor.Free();
       d_ray_sample_num.Free(); d_ray_flags.Free(); d_ray_out_index.Free(); d_counters.Free();
     }
@@ -322,7 +339,12 @@ void ValidateRadiation(bl_ctx *ctx) {
     throw Failure{BL_E_UNSUPPORTED, "image_polarization = true (polarized transfer) is not built yet."};
   if (simulation) {
     Require(p, {BL_P_slow_light_on}, kRadMissing);
-    if (p.slow_light_on) throw Failure{BL_E_UNSUPPORTED, "slow_light_on = true is not built yet."};
+    if (p.slow_light_on) {   // radiation_integrator.cpp:206-215
+      if ((p.has[BL_P_checkpoint_sample_save] && p.checkpoint_sample_save) || (p.has[BL_P_checkpoint_sample_load] && p.checkpoint_sample_load))
+        throw Failure{BL_E_INPUT, "Cannot use sample checkpoints with slow light."};
+      Require(p, {BL_P_slow_interp, BL_P_slow_chunk_size, BL_P_slow_t_start, BL_P_slow_dt}, kRadMissing);
+      if (p.slow_chunk_size < 2) throw Failure{BL_E_INPUT, "Must have slow_chunk_size be at least 2."};   // simulation_reader.cpp:77
+    }
   }
   if (p.adaptive_max_level > 0) {   // radiation_integrator.cpp:218-270
     if (!p.image_light) throw Failure{BL_E_INPUT, "Adaptive ray tracing requires image_light."};
@@ -597,8 +619,10 @@ void UploadMergedGrid(bl_ctx *ctx, const bl_grid_desc *g) {
           }
       }
     }
-    ctx->d_cells.Ensure(cells.size());
-    Check(hipMemcpy(ctx->d_cells.ptr, cells.data(), cells.size() * sizeof(float), hipMemcpyHostToDevice), "grid upload");
+    DeviceBuffer<float> &d_cells = ctx->cells_target != nullptr ? *ctx->cells_target : ctx->d_cells;
+    DeviceBuffer<float> &d_kappa = ctx->kappa_target != nullptr ? *ctx->kappa_target : ctx->d_kappa;
+    d_cells.Ensure(cells.size());
+    Check(hipMemcpy(d_cells.ptr, cells.data(), cells.size() * sizeof(float), hipMemcpyHostToDevice), "grid upload");
     const bool code_kappa = ctx->params.plasma_model == BL_PLASMA_CODE_KAPPA;
     if (code_kappa) {
       // the ninth value of a cell (simulation_reader.cpp:1164-1172) in its own [k][j][i] array: only the
@@ -614,8 +638,8 @@ void UploadMergedGrid(bl_ctx *ctx, const bl_grid_desc *g) {
             std::memcpy(kappa.data() + row, src + (static_cast<size_t>(k) * nb_cells[1] + j) * nb_cells[0], sizeof(float) * nb_cells[0]);
           }
       }
-      ctx->d_kappa.Ensure(kappa.size());
-      Check(hipMemcpy(ctx->d_kappa.ptr, kappa.data(), kappa.size() * sizeof(float), hipMemcpyHostToDevice), "grid upload");
+      d_kappa.Ensure(kappa.size());
+      Check(hipMemcpy(d_kappa.ptr, kappa.data(), kappa.size() * sizeof(float), hipMemcpyHostToDevice), "grid upload");
     }
     // coordinates
     const double *xf[3] = {global_xf[0].data(), global_xf[1].data(), global_xf[2].data()};
@@ -644,8 +668,8 @@ void UploadMergedGrid(bl_ctx *ctx, const bl_grid_desc *g) {
     }
     ctx->d_buckets.Ensure(buckets.size());
     Check(hipMemcpy(ctx->d_buckets.ptr, buckets.data(), buckets.size() * sizeof(int), hipMemcpyHostToDevice), "bucket upload");
-    dev.cells = ctx->d_cells.ptr;
-    dev.kappa = code_kappa ? ctx->d_kappa.ptr : nullptr;
+    dev.cells = d_cells.ptr;
+    dev.kappa = code_kappa ? d_kappa.ptr : nullptr;
     dev.n_blocks = 0;
     dev.stride_row = n_i;
     dev.stride_plane = n_i * n_j;
@@ -724,13 +748,15 @@ void UploadRefinedGrid(bl_ctx *ctx, const bl_grid_desc *g) {
     const float *src = g->prim + static_cast<size_t>(order[v]) * n_cells;
     for (size_t c = 0; c < n_cells; c++) cells[c * 8 + v] = src[c];
   }
-  ctx->d_cells.Ensure(cells.size());
-  Check(hipMemcpy(ctx->d_cells.ptr, cells.data(), cells.size() * sizeof(float), hipMemcpyHostToDevice), "grid upload");
+  DeviceBuffer<float> &d_cells = ctx->cells_target != nullptr ? *ctx->cells_target : ctx->d_cells;
+  DeviceBuffer<float> &d_kappa = ctx->kappa_target != nullptr ? *ctx->kappa_target : ctx->d_kappa;
+  d_cells.Ensure(cells.size());
+  Check(hipMemcpy(d_cells.ptr, cells.data(), cells.size() * sizeof(float), hipMemcpyHostToDevice), "grid upload");
   const bool code_kappa = ctx->params.plasma_model == BL_PLASMA_CODE_KAPPA;
   if (code_kappa) {
     if (g->ind_kappa < 0 || g->ind_kappa >= g->n_var) throw Failure{BL_E_ARG, "Grid variable index out of range."};
-    ctx->d_kappa.Ensure(n_cells);
-    Check(hipMemcpy(ctx->d_kappa.ptr, g->prim + static_cast<size_t>(g->ind_kappa) * n_cells, n_cells * sizeof(float),
+    d_kappa.Ensure(n_cells);
+    Check(hipMemcpy(d_kappa.ptr, g->prim + static_cast<size_t>(g->ind_kappa) * n_cells, n_cells * sizeof(float),
                     hipMemcpyHostToDevice), "grid upload");
   }
   // coordinate rows of every block, then the block boundaries
@@ -749,8 +775,8 @@ void UploadRefinedGrid(bl_ctx *ctx, const bl_grid_desc *g) {
   ctx->d_buckets.Ensure(lattice.size());
   Check(hipMemcpy(ctx->d_buckets.ptr, lattice.data(), lattice.size() * sizeof(int), hipMemcpyHostToDevice), "lattice upload");
   BlGridDevice dev{};
-  dev.cells = ctx->d_cells.ptr;
-  dev.kappa = code_kappa ? ctx->d_kappa.ptr : nullptr;
+  dev.cells = d_cells.ptr;
+  dev.kappa = code_kappa ? d_kappa.ptr : nullptr;
   dev.n_blocks = n_b;
   dev.lattice = ctx->d_buckets.ptr;
   dev.stride_row = nb[0];
@@ -776,6 +802,8 @@ int bl_set_grid(bl_ctx *ctx, const bl_grid_desc *g) {
   try {
     if (ctx->device == BL_DEVICE_NONE) throw Failure{BL_E_DEVICE, "Host-only context: no HIP device selected (the hot path has no CPU fallback)."};
     if (ctx->params.model_type != BL_MODEL_SIMULATION) throw Failure{BL_E_STATE, "bl_set_grid called in formula mode."};
+    if (ctx->params.slow_light_on && ctx->cells_target == nullptr)
+      throw Failure{BL_E_STATE, "slow_light_on = true: hand the time slices over with bl_set_grid_slice (or bl_slow_light_read)."};
     if (g->n_blocks < 1) throw Failure{BL_E_ARG, "Bad grid description."};
     if (g->n_i < 2 || g->n_j < 2 || g->n_k < 2 || g->prim == nullptr) throw Failure{BL_E_ARG, "Bad grid description."};
     Check(hipSetDevice(ctx->device), "hipSetDevice");
@@ -790,6 +818,45 @@ int bl_set_grid(bl_ctx *ctx, const bl_grid_desc *g) {
   } catch (const Failure &failure) {
     return Fail(ctx, failure);
   }
+  return BL_OK;
+}
+
+int bl_set_grid_slice(bl_ctx *ctx, int slice, const bl_grid_desc *g, double time) {
+  if (ctx == nullptr || g == nullptr) return BL_E_ARG;
+  try {
+    const bl_params &p = ctx->params;
+    if (p.model_type != BL_MODEL_SIMULATION || !p.slow_light_on) throw Failure{BL_E_STATE, "bl_set_grid_slice needs slow_light_on = true."};
+    if (slice < 0 || slice >= p.slow_chunk_size) throw Failure{BL_E_ARG, "Time slice index outside slow_chunk_size."};
+    ctx->slow_slices.resize(p.slow_chunk_size);
+    bl_ctx::SlowSlice &target = ctx->slow_slices[slice];
+    ctx->cells_target = &target.cells;
+    ctx->kappa_target = &target.kappa;
+    const int rc = bl_set_grid(ctx, g);
+    ctx->cells_target = nullptr;
+    ctx->kappa_target = nullptr;
+    if (rc != BL_OK) return rc;
+    target.time = time;
+    target.set = true;
+  } catch (const Failure &failure) {
+    ctx->cells_target = nullptr;
+    ctx->kappa_target = nullptr;
+    return Fail(ctx, failure);
+  }
+  return BL_OK;
+}
+
+int bl_shift_grid_slices(bl_ctx *ctx, int count) {
+  if (ctx == nullptr) return BL_E_ARG;
+  const int chunk = static_cast<int>(ctx->slow_slices.size());
+  if (count < 0 || count > chunk) return Fail(ctx, Failure{BL_E_ARG, "Bad slice shift."});
+  // prim[n].Swap(prim[n - count]) for n = chunk - 1 ... count (simulation_reader.cpp:289-296)
+  for (int n = chunk - 1; n >= count && count > 0; n--) std::swap(ctx->slow_slices[n], ctx->slow_slices[n - count]);
+  return BL_OK;
+}
+
+int bl_set_snapshot(bl_ctx *ctx, int snapshot) {
+  if (ctx == nullptr || snapshot < 0) return BL_E_ARG;
+  ctx->snapshot = snapshot;
   return BL_OK;
 }
 
@@ -843,6 +910,13 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
     const int max_steps = p.ray_max_steps;
     const long long n_rays = d->n_rays;
     const bool aux = ctx->aux_images.any != 0;
+    const bool slow = simulation && p.slow_light_on;
+    if (slow) {
+      if (static_cast<int>(ctx->slow_slices.size()) != p.slow_chunk_size) throw Failure{BL_E_STATE, "Slow light: time slices not set."};
+      for (const bl_ctx::SlowSlice &slice : ctx->slow_slices)
+        if (!slice.set) throw Failure{BL_E_STATE, "Slow light: time slices not set."};
+    }
+    const bool need_time = (aux && ctx->aux_images.image_time) || slow;
 
     // level pixel count check
     long long level_pixels = static_cast<long long>(p.camera_resolution) * p.camera_resolution;
@@ -853,7 +927,7 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
     // (simulation mode) + 16 B * n_nu transfer)
     const uint64_t per_ray = static_cast<uint64_t>(max_steps)
         * (sizeof(BlSampleRecord) + (simulation ? sizeof(BlLocated) : 0) + sizeof(double2) * n_nu
-           + (aux ? sizeof(BlAuxSample) + sizeof(double) : 0)) + 64;
+           + (aux ? sizeof(BlAuxSample) + sizeof(double) : 0) + (slow ? 2 * sizeof(double) : 0)) + 64;
     // One chunk if the whole call fits the budget. With bl_set_overlap(): two scratch sets of half the budget
     // each, so that the geodesic kernel of chunk c + 1 runs while chunk c is being shaded.
     // The budget is also capped by what the device can actually give: 90 % of (free memory + the scratch
@@ -865,7 +939,8 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
         uint64_t held = 0;
         for (const bl_ctx::ChunkSlot &sl : ctx->slot)
           held += sl.d_records.count * sizeof(BlSampleRecord) + sl.d_located.count * sizeof(BlLocated)
-              + sl.d_transfer.count * sizeof(double2) + sl.d_aux.count * sizeof(BlAuxSample) + sl.d_sample_t.count * sizeof(double);
+              + sl.d_transfer.count * sizeof(double2) + sl.d_aux.count * sizeof(BlAuxSample)
+              + (sl.d_sample_t.count + sl.d_slow_frac.count) * sizeof(double);
         const uint64_t available = static_cast<uint64_t>(0.9 * static_cast<double>(free_bytes + held));
         if (available < budget) budget = available;
       }
@@ -893,7 +968,8 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
       sl.d_ray_out_index.Ensure(chunk);
       sl.d_counters.Ensure(BL_CNT_COUNT + 4);
       if (aux) sl.d_aux.Ensure(static_cast<size_t>(chunk) * max_steps);
-      if (aux && ctx->aux_images.image_time) sl.d_sample_t.Ensure(record_capacity);
+      if (need_time) sl.d_sample_t.Ensure(record_capacity);
+      if (slow) sl.d_slow_frac.Ensure(record_capacity);
     }
     EnsureChunkResources(ctx, n_chunks);
     ctx->d_freq.Ensure(n_nu);
@@ -1105,6 +1181,29 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
     sa.aux_need_length = (ctx->aux_images.image_length || fill_present) ? 1 : 0;
     for (int mu = 0; mu < 4; mu++) sa.cam_x[mu] = ctx->frame.cam_x[mu];
 
+    const double snapshot_time = slow ? p.slow_t_start + p.slow_dt * ctx->snapshot : 0.0;   // simulation_reader.cpp:214
+    if (slow) {
+      const int chunk_size = p.slow_chunk_size;
+      std::vector<unsigned long long> table(3 * static_cast<size_t>(chunk_size) + 4, 0ull);
+      for (int n = 0; n < chunk_size; n++) {
+        const bl_ctx::SlowSlice &slice = ctx->slow_slices[n];
+        table[n] = reinterpret_cast<unsigned long long>(slice.cells.ptr);
+        table[chunk_size + n] = reinterpret_cast<unsigned long long>(slice.kappa.ptr);
+        std::memcpy(&table[2 * static_cast<size_t>(chunk_size) + n], &slice.time, sizeof(double));
+      }
+      ctx->d_slow_table.Ensure(table.size());
+      Check(hipMemcpyAsync(ctx->d_slow_table.ptr, table.data(), table.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, stream), "slow-light table upload");
+      ctx->d_ray_extrap.Ensure(n_rays);
+      Check(hipMemsetAsync(ctx->d_ray_extrap.ptr, 0, n_rays * sizeof(unsigned int), stream), "slow-light flags reset");
+      sa.slow.n = chunk_size;
+      sa.slow.interp = p.slow_interp ? 1 : 0;
+      sa.slow.snapshot_time = snapshot_time;
+      sa.slow.cells = reinterpret_cast<const float *const *>(ctx->d_slow_table.ptr);
+      sa.slow.kappa = reinterpret_cast<const float *const *>(ctx->d_slow_table.ptr + chunk_size);
+      sa.slow.times = reinterpret_cast<const double *>(ctx->d_slow_table.ptr + 2 * static_cast<size_t>(chunk_size));
+      sa.slow.extrap_max = ctx->d_slow_table.ptr + 3 * static_cast<size_t>(chunk_size);
+    }
+
     BlTransferArgs xa{};
     xa.frequencies = ctx->d_freq.ptr;
     xa.n_nu = n_nu;
@@ -1171,9 +1270,13 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
       xa.ray_flags = sl.d_ray_flags.ptr;
       xa.ray_out_index = sl.d_ray_out_index.ptr;
       xa.stats = sl.d_counters.ptr + BL_CNT_COUNT;
-      ta.sample_t = (aux && ctx->aux_images.image_time) ? sl.d_sample_t.ptr : nullptr;
+      ta.sample_t = need_time ? sl.d_sample_t.ptr : nullptr;
       sa.aux = aux ? sl.d_aux.ptr : nullptr;
       sa.sample_t = ta.sample_t;
+      if (slow) {
+        sa.slow.frac = sl.d_slow_frac.ptr;
+        sa.slow.ray_extrap = ctx->d_ray_extrap.ptr + begin;
+      }
       sa.ray_flags = sl.d_ray_flags.ptr;
       xa.aux = sa.aux;
       xa.ray_factor = sl.d_ray_factor.ptr;
@@ -1252,6 +1355,31 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
     // Warning text of the reference (geodesics.cpp:389-394)
     if (total_flagged > 0)
       Warn(ctx, std::to_string(total_flagged) + " out of " + std::to_string(n_rays) + " geodesics terminate unexpectedly.");
+    if (slow) {   // simulation_sampling.cpp:553-617: pixels whose samples fall outside the window of files
+      std::vector<unsigned int> flags(n_rays);
+      unsigned long long maxima[4];
+      Check(hipMemcpy(flags.data(), ctx->d_ray_extrap.ptr, n_rays * sizeof(unsigned int), hipMemcpyDeviceToHost), "slow-light flags download");
+      Check(hipMemcpy(maxima, ctx->d_slow_table.ptr + 3 * static_cast<size_t>(p.slow_chunk_size), sizeof maxima, hipMemcpyDeviceToHost), "slow-light maxima download");
+      long long count[4] = {0, 0, 0, 0};
+      for (unsigned int f : flags)
+        for (int e = 0; e < 4; e++) count[e] += (f >> e) & 1u;
+      auto text = [&](int kind, const char *degree, const char *direction) {
+        double by;
+        std::memcpy(&by, &maxima[kind], sizeof(double));
+        std::ostringstream message;
+        message << "Snapshot " << ctx->snapshot << " at time " << snapshot_time << " requires " << degree << " extrapolation "
+                << direction << " in time (" << count[kind] << "/" << n_rays << " pixels, by up to " << by << " gravitational times).";
+        return message.str();
+      };
+      for (int e = 0; e < 4; e++) {
+        ctx->stats_slow_count[e] = count[e];
+        std::memcpy(&ctx->stats_slow_val[e], &maxima[e], sizeof(double));
+      }
+      if (count[1] > 0) throw Failure{BL_E_INPUT, text(1, "significant", "forward")};
+      if (count[3] > 0) throw Failure{BL_E_INPUT, text(3, "significant", "backward")};
+      if (count[0] > 0) Warn(ctx, text(0, "moderate", "forward"));
+      if (count[2] > 0) Warn(ctx, text(2, "moderate", "backward"));
+    }
   } catch (const Failure &failure) {
     return Fail(ctx, failure);
   }
@@ -1293,6 +1421,10 @@ const char *bl_last_error(const bl_ctx *ctx) { return ctx != nullptr ? ctx->last
 const char *bl_last_global_error(void) { return g_global_error.c_str(); }
 const char *bl_warnings(const bl_ctx *ctx) { return ctx != nullptr ? ctx->warnings.c_str() : ""; }
 
+void bl_warnings_clear(bl_ctx *ctx) {
+  if (ctx != nullptr) ctx->warnings.clear();
+}
+
 void bl_free(bl_ctx *ctx) {
   if (ctx == nullptr) return;
   if (ctx->device == BL_DEVICE_NONE) {
@@ -1317,6 +1449,8 @@ const char *bl_build_info(void) { return "blacklight_amd;hip;gfx950;fp-contract=
 }  // extern "C"
 
 const bl_params *bl_internal_params(const bl_ctx *ctx) { return &ctx->params; }
+bl_slow_state *bl_internal_slow_state(bl_ctx *ctx) { return &ctx->slow_state; }
+void bl_internal_warn(bl_ctx *ctx, const char *message) { Warn(ctx, message); }
 const bl_camera_frame *bl_internal_frame(const bl_ctx *ctx) { return &ctx->frame; }
 const double *bl_internal_frequencies(const bl_ctx *ctx, int *count) {
   *count = static_cast<int>(ctx->frequencies.size());

@@ -186,12 +186,27 @@ struct BlTraceArgs {
 };
 
 // Kernel arguments: shading kernel
+// Slow light (slow_light_on): the time slices the reader holds (simulation_reader.cpp:211-303), latest
+// first, all on the geometry of BlGridDevice. n = 0: off.
+struct BlSlowDevice {
+  int n;                           // slow_chunk_size
+  int interp;                      // slow_interp: linear in time between two slices, else the nearest slice
+  double snapshot_time;            // camera time of this image
+  const double *times;             // device [n], descending
+  const float *const *cells;       // device [n]: cell array of every slice (layout of BlGridDevice::cells)
+  const float *const *kappa;       // device [n] or null
+  unsigned int *ray_extrap;        // [chunk rays]: bit e set = some sample needed extrapolation of kind e
+  unsigned long long *extrap_max;  // [4]: bit pattern of the largest extrapolation of each kind (doubles >= 0)
+  double *frac;                    // [record capacity]: t_frac of a located sample
+};
+
 struct BlShadeArgs {
   BlSpacetime st;
   BlCutsDevice cuts;
   BlPlasmaDevice plasma;
   BlFormulaDevice formula;
   BlGridDevice grid;
+  BlSlowDevice slow;
   const BlShadeCold *cold;    // device pointer
   const BlSampleRecord *records;
   BlLocated *located;         // [record capacity], simulation mode

@@ -761,6 +761,46 @@ __device__ __forceinline__ void locate_sample_refined(const BlShadeArgs &P, doub
 
 // Locate one sample on the simulation grid: ConvertFromCKS (radiation_geometry.cpp:37-57), block test
 // and cell search (simulation_sampling.cpp:352-394, :458-490), trilinear fractions (:736-760).
+// Slow light: which time slice(s) a sample at coordinate time x0 reads (simulation_sampling.cpp:296-349).
+// Returns t_ind; *t_frac for slow_interp. Extrapolation beyond the window is recorded per ray and as maxima.
+__device__ __forceinline__ int locate_time(const BlSlowDevice &sl, double x0, uint32_t ray, double *t_frac) {
+  const double *time = sl.times;
+  const int chunk = sl.n;
+  const double tolerance = 1.0;   // simulation_reader.hpp:99
+  int t_ind = 0;
+  *t_frac = 0.0;
+  int kind = -1;
+  double by = 0.0;
+  if (x0 >= time[0]) {
+    by = x0 - time[0];
+    if (x0 > time[0] + tolerance) kind = 1;
+    else if (x0 > time[0]) kind = 0;
+  } else if (x0 <= time[chunk - 1]) {
+    by = time[chunk - 1] - x0;
+    if (x0 < time[chunk - 1] - tolerance) kind = 3;
+    else if (x0 < time[chunk - 1]) kind = 2;
+    if (sl.interp) {
+      t_ind = chunk - 2;
+      *t_frac = 1.0;
+    } else {
+      t_ind = chunk - 1;
+    }
+  } else {
+    while (time[t_ind] > x0) t_ind++;   // first slice not later than the sample (exists: x0 > time[chunk - 1])
+    if (sl.interp) {
+      t_ind--;
+      *t_frac = (x0 - time[t_ind]) / (time[t_ind + 1] - time[t_ind]);
+    } else if (time[t_ind - 1] - x0 <= x0 - time[t_ind]) {
+      t_ind--;
+    }
+  }
+  if (kind >= 0) {
+    atomicOr(&sl.ray_extrap[ray], 1u << kind);
+    atomicMax(&sl.extrap_max[kind], (unsigned long long)__double_as_longlong(by));
+  }
+  return t_ind;
+}
+
 template <bool kRefined>
 __device__ __forceinline__ void locate_sample(const BlShadeArgs &P, const GridTables &tab, const BlSpacetime &st,
                                               double x1, double x2, double x3, double r, BlLocated *out,
@@ -897,6 +937,71 @@ __device__ __forceinline__ float sample_kappa(const BlShadeArgs &P, int status, 
   if (status == kSampleNearest) return base[0];
   if (status == kSampleOffGrid) return P.plasma.fallback_nan ? __int_as_float(0x7fc00000) : P.cold->fallback_kappa;
   return 0.0f;
+}
+
+// Slow light: the nine values of a located sample from time slice t_ind, or blended linearly in time with
+// slice t_ind + 1 (simulation_sampling.cpp:710-786 nearest, :809-912 trilinear). Spatial interpolation and the
+// "<= 0 -> anchor cell" rule of rho, pgas, kappa apply per slice, before the blend; values stay double until the
+// final conversion to float. Not on the benchmark path: plain loops, the extended instantiation only.
+__device__ __forceinline__ void sample_slice_values(const BlShadeArgs &P, const float *cells, const float *kappa,
+                                                    int status, uint32_t cell, double f_i, double f_j, double f_k,
+                                                    double val[9]) {
+  const BlGridDevice &g = P.grid;
+  const size_t row = (size_t)g.stride_row, plane = (size_t)g.stride_plane;
+  if (status == kSampleNearest) {
+    const float *c = cells + (size_t)cell * 8;
+    for (int v = 0; v < 8; v++) val[v] = (double)c[v];
+    val[8] = kappa != nullptr ? (double)kappa[cell] : 0.0;
+    return;
+  }
+  const double w_k[2] = {1.0 - f_k, f_k}, w_j[2] = {1.0 - f_j, f_j}, w_i[2] = {1.0 - f_i, f_i};
+  double first[9];
+  for (int corner = 0; corner < 8; corner++) {
+    const int dk = corner >> 2, dj = (corner >> 1) & 1, di = corner & 1;
+    const size_t at = (size_t)cell + dk * plane + dj * row + di;
+    const double w = w_k[dk] * w_j[dj] * w_i[di];
+    const float *c = cells + at * 8;
+    for (int v = 0; v < 9; v++) {
+      const double x = v < 8 ? (double)c[v] : (kappa != nullptr ? (double)kappa[at] : 0.0);
+      if (corner == 0) {
+        val[v] = w * x;
+        first[v] = x;
+      } else {
+        val[v] += w * x;
+      }
+    }
+  }
+  if (val[0] <= 0.0) val[0] = first[0];
+  if (val[1] <= 0.0) val[1] = first[1];
+  if (kappa != nullptr && val[8] <= 0.0) val[8] = first[8];
+}
+
+__device__ __forceinline__ void sample_primitives_slow(const BlShadeArgs &P, int status, uint32_t cell, int t_ind,
+                                                       double t_frac, double f_i, double f_j, double f_k, float pr[8],
+                                                       float *kappa_out) {
+  const BlPlasmaDevice &pl = P.plasma;
+  const BlSlowDevice &sl = P.slow;
+  if (status == kSampleInterp || status == kSampleNearest) {
+    const bool entropy = pl.code_kappa != 0;
+    double val[9];
+    sample_slice_values(P, sl.cells[t_ind], entropy ? sl.kappa[t_ind] : nullptr, status, cell, f_i, f_j, f_k, val);
+    if (sl.interp) {
+      double next[9];
+      sample_slice_values(P, sl.cells[t_ind + 1], entropy ? sl.kappa[t_ind + 1] : nullptr, status, cell, f_i, f_j, f_k, next);
+      for (int v = 0; v < 9; v++) val[v] = (1.0 - t_frac) * val[v] + t_frac * next[v];
+    }
+    for (int v = 0; v < 8; v++) pr[v] = (float)val[v];
+    *kappa_out = entropy ? (float)val[8] : 0.0f;
+  } else if (status == kSampleOffGrid) {
+    const float fnan = __int_as_float(0x7fc00000);
+    pr[0] = pl.fallback_nan ? fnan : P.cold->fallback_rho;
+    pr[1] = pl.fallback_nan ? fnan : P.cold->fallback_pgas;
+    for (int v = 2; v < 8; v++) pr[v] = pl.fallback_nan ? fnan : 0.0f;
+    *kappa_out = pl.fallback_nan ? fnan : P.cold->fallback_kappa;
+  } else {
+    for (int v = 0; v < 8; v++) pr[v] = 0.0f;
+    *kappa_out = 0.0f;
+  }
 }
 
 // Simulation mode: the frequency-independent part of CalculateSimulationCoefficients
@@ -1189,7 +1294,8 @@ __device__ __forceinline__ void shade_formula(const BlShadeArgs &P, const BlSpac
 // LDS table walks of the cell search; no grid reads (the coefficient kernel issues those, where they
 // overlap its arithmetic instead of saturating the texture addresser here).
 // kRefined: mesh with refinement; block and cell come from tables in global memory, no LDS staging.
-template <bool kRefined>
+// kSlow: slow light; the time slice of every sample that passed the cuts is found first (:296-349).
+template <bool kRefined, bool kSlow>
 __global__ void __launch_bounds__(256, 4) bl_locate_kernel(const BlShadeArgs P) {
   const BlSpacetime st = P.st;
   extern __shared__ double lds_tables[];
@@ -1254,11 +1360,17 @@ __global__ void __launch_bounds__(256, 4) bl_locate_kernel(const BlShadeArgs P) 
     loc.f_i = loc.f_j = loc.f_k = loc.ph = 0.0;
     loc.cell = 0u;
     loc.status = kSampleCut;
+    unsigned long long t_ind = 0ull;
+    if (kSlow && !skip && !(P.plasma.fallback_nan && P.ray_flags[ray] != 0)) {   // NaN rays are not sampled (:211-216)
+      double t_frac;
+      t_ind = (unsigned long long)locate_time(P.slow, P.sample_t[at] + P.slow.snapshot_time, ray, &t_frac);
+      P.slow.frac[at] = t_frac;
+    }
     if (!skip) locate_sample<kRefined>(P, tab, st, x1, x2, x3, r, &loc, &gathers_local);
     double2 *dst = reinterpret_cast<double2 *>(P.located + at);
     dst[0] = make_double2(loc.f_i, loc.f_j);
     dst[1] = make_double2(loc.f_k, loc.ph);
-    dst[2] = make_double2(__longlong_as_double((long long)(((unsigned long long)loc.status << 32) | loc.cell)), r2);
+    dst[2] = make_double2(__longlong_as_double((long long)((t_ind << 40) | ((unsigned long long)loc.status << 32) | loc.cell)), r2);
   }
   // S_in accounting: one atomic per wave
   for (int offset = 32; offset > 0; offset >>= 1) gathers_local += __shfl_xor(gathers_local, offset, 64);
@@ -1313,9 +1425,13 @@ __global__ void __launch_bounds__(256, 2) bl_shade_kernel(const BlShadeArgs P) {
     if (kModel == BL_MODEL_SIMULATION && live) {
       const unsigned long long tag = (unsigned long long)__double_as_longlong(l2.x);
       ph = l1.y;
-      status = (int)(tag >> 32);
-      sample_primitives(P, status, (uint32_t)tag, l0.x, l0.y, l1.x, pr);
-      if (kExtended && P.plasma.code_kappa) kappa_f = sample_kappa(P, status, (uint32_t)tag, l0.x, l0.y, l1.x);
+      status = kExtended ? ((int)(tag >> 32) & 0xff) : (int)(tag >> 32);   // bits 40..: time slice (slow light only)
+      if (kExtended && P.slow.n > 0) {
+        sample_primitives_slow(P, status, (uint32_t)tag, (int)(tag >> 40), P.slow.frac[idx_cur], l0.x, l0.y, l1.x, pr, &kappa_f);
+      } else {
+        sample_primitives(P, status, (uint32_t)tag, l0.x, l0.y, l1.x, pr);
+        if (kExtended && P.plasma.code_kappa) kappa_f = sample_kappa(P, status, (uint32_t)tag, l0.x, l0.y, l1.x);
+      }
     }
     idx += stride;
     more = idx < n_records;
@@ -1768,17 +1884,18 @@ extern "C" int bl_geodesic_occupancy(int integrator) {
 
 // Locate kernel (simulation mode only); lds_bytes = size of the coordinate tables it stages in LDS
 extern "C" hipError_t bl_launch_locate(const BlShadeArgs *args, int grid, int lds_bytes, hipStream_t stream) {
-  if (args->grid.n_blocks > 0)
-    hipLaunchKernelGGL(bl_locate_kernel<true>, dim3(grid), dim3(256), 0, stream, *args);
-  else
-    hipLaunchKernelGGL(bl_locate_kernel<false>, dim3(grid), dim3(256), lds_bytes, stream, *args);
+  const bool refined = args->grid.n_blocks > 0, slow = args->slow.n > 0;
+  if (refined && slow) hipLaunchKernelGGL((bl_locate_kernel<true, true>), dim3(grid), dim3(256), 0, stream, *args);
+  else if (refined) hipLaunchKernelGGL((bl_locate_kernel<true, false>), dim3(grid), dim3(256), 0, stream, *args);
+  else if (slow) hipLaunchKernelGGL((bl_locate_kernel<false, true>), dim3(grid), dim3(256), lds_bytes, stream, *args);
+  else hipLaunchKernelGGL((bl_locate_kernel<false, false>), dim3(grid), dim3(256), lds_bytes, stream, *args);
   return hipGetLastError();
 }
 
 // Coefficient kernel
 extern "C" hipError_t bl_launch_shade(const BlShadeArgs *args, int model, int grid, hipStream_t stream) {
   const bool aux = args->aux != nullptr;
-  const bool power = args->plasma.power_frac != 0.0 || args->plasma.code_kappa != 0;
+  const bool power = args->plasma.power_frac != 0.0 || args->plasma.code_kappa != 0 || args->slow.n > 0;
 #define BL_LAUNCH_S(M, A, W) hipLaunchKernelGGL((bl_shade_kernel<M, A, W>), dim3(grid), dim3(256), 0, stream, *args)
   if (model == BL_MODEL_SIMULATION) {
     if (aux && power) BL_LAUNCH_S(BL_MODEL_SIMULATION, true, true);

@@ -15,6 +15,7 @@
 #include <fstream>
 #include <iomanip>
 #include <iostream>
+#include <sstream>
 #include <string>
 #include <vector>
 
@@ -118,6 +119,16 @@ int main(int argc, char *argv[]) {
       std::string message;
       bl_snapshot *snap = nullptr;
       bl_grid_desc g = {};
+      if (params.slow_light_on) {
+        // the window of files around this image's camera time (SimulationReader::Read with slow light)
+        if (bl_slow_light_read(ctx, run) != BL_OK) {
+          std::cout << bl_last_error(ctx);
+          return 1;
+        }
+        std::cerr << bl_warnings(ctx);
+        bl_warnings_clear(ctx);
+        time_read += Now() - t0;
+      } else {
       if (params.has[BL_P_simulation_file] && !params.simulation_multiple && IsRawGrid(params.simulation_file.s)) {
         if (!ReadRawGrid(params.simulation_file.s, &raw, &message)) {
           std::cout << "Error: " << message << "\n";
@@ -149,6 +160,7 @@ int main(int argc, char *argv[]) {
         return 1;
       }
       time_read += Now() - t0;
+      }
     }
 
     // do { Integrate; if (!done) AddGeodesics } while (!done)   (blacklight.cpp:196-233)
@@ -205,7 +217,15 @@ int main(int argc, char *argv[]) {
       counts.push_back(n_refined * 4);
       level++;
     }
-    std::cerr << bl_warnings(ctx);
+    {
+      // the reference integrates the geodesics once, before the first image: its count of badly terminated
+      // geodesics is reported once, not per image
+      std::istringstream lines(bl_warnings(ctx));
+      std::string line;
+      while (std::getline(lines, line))
+        if (run == 0 || line.find("geodesics terminate unexpectedly") == std::string::npos) std::cerr << line << "\n";
+      bl_warnings_clear(ctx);
+    }
 
     bl_output_desc out = {};
     out.adaptive_num_levels = level;

@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "../../include/blacklight_amd.h"
+#include "bl_internal.h"
 
 namespace {
 
@@ -496,8 +497,14 @@ void ReaderSetup(const bl_params &p, bl_snapshot *s) {
     if (p.simulation_end < p.simulation_start) Fail("Must have simulation_end at least as large as simulation_start.");
   }
   Require(p, {BL_P_simulation_coord, BL_P_simulation_a, BL_P_simulation_m_msun, BL_P_simulation_rho_cgs, BL_P_slow_light_on});
-  if (p.slow_light_on)
-    Fail("slow_light_on = true (time interpolation between snapshots) is not built.", BL_E_UNSUPPORTED);
+  if (p.slow_light_on) {   // :66-82
+    if (!p.simulation_multiple) Fail("Must enable simulation_multiple to use slow light.");
+    Require(p, {BL_P_slow_chunk_size});
+    if (p.slow_chunk_size < 2) Fail("Must have slow_chunk_size be at least 2.");
+    if (p.slow_chunk_size > p.simulation_end - p.simulation_start + 1) Fail("Not enough simulation files for given slow_chunk_size.");
+    Require(p, {BL_P_slow_t_start, BL_P_slow_dt});
+    if (p.slow_dt <= 0.0) Fail("Must have positive time interval slow_dt.");
+  }
   if (p.simulation_format != BL_SIMFMT_ATHENA)
     Fail("Only simulation_format = athena has a native reader; other formats must be handed over through bl_set_grid().",
          BL_E_UNSUPPORTED);
@@ -588,10 +595,10 @@ std::string Scientific16(double value) {
   return text.str();
 }
 
-void ReadAthena(const bl_params &p, int snapshot, bl_snapshot *s) {
-  // which file (:305-319)
+// file_number < 0: simulation_file as it is
+void ReadAthena(const bl_params &p, int file_number, bl_snapshot *s) {
   s->file = p.simulation_file.s;
-  if (p.simulation_multiple) s->file = FormatFilename(s->file, p.simulation_start + snapshot);
+  if (file_number >= 0) s->file = FormatFilename(s->file, file_number);
   const Hdf5File file(s->file);
 
   // file-level attributes (hdf5_format_structure.cpp:145-289)
@@ -699,7 +706,8 @@ int bl_snapshot_open(const bl_params *p, int snapshot, bl_snapshot **out, char *
   try {
     s = new bl_snapshot;
     ReaderSetup(*p, s);
-    ReadAthena(*p, snapshot, s);
+    if (p->slow_light_on) Fail("slow_light_on = true: the window of files is read by bl_slow_light_read().", BL_E_STATE);
+    ReadAthena(*p, p->simulation_multiple ? p->simulation_start + snapshot : -1, s);   // :305-319
     *out = s;
     return BL_OK;
   } catch (const ReadFailure &f) {
@@ -711,6 +719,148 @@ int bl_snapshot_open(const bl_params *p, int snapshot, bl_snapshot **out, char *
     SetError(err, err_len, std::string("Could not read simulation file (") + e.what() + ").");
     return BL_E_INPUT;
   }
+}
+
+int bl_snapshot_open_number(const bl_params *p, int file_number, bl_snapshot **out, char *err, size_t err_len) {
+  if (p == nullptr || out == nullptr || file_number < 0) {
+    SetError(err, err_len, "bl_snapshot_open_number: bad argument.");
+    return BL_E_ARG;
+  }
+  *out = nullptr;
+  bl_snapshot *s = nullptr;
+  try {
+    s = new bl_snapshot;
+    ReaderSetup(*p, s);
+    ReadAthena(*p, file_number, s);
+    *out = s;
+    return BL_OK;
+  } catch (const ReadFailure &f) {
+    delete s;
+    SetError(err, err_len, f.message);
+    return f.code;
+  } catch (const std::exception &e) {
+    delete s;
+    SetError(err, err_len, std::string("Could not read simulation file (") + e.what() + ").");
+    return BL_E_INPUT;
+  }
+}
+
+// SimulationReader::Read(snapshot) with slow light (simulation_reader.cpp:211-303, :313-861): advance the
+// window of slow_chunk_size files until its latest file is not earlier than the camera time.
+int bl_slow_light_read(bl_ctx *ctx, int snapshot) {
+  if (ctx == nullptr || snapshot < 0) return BL_E_ARG;
+  const bl_params &p = *bl_internal_params(ctx);
+  bl_slow_state &state = *bl_internal_slow_state(ctx);
+  constexpr double kExtrapolationTolerance = 1.0;   // simulation_reader.hpp:99
+  char err[1024] = "";
+  auto fail_text = [&](int code) {   // err holds "Error: ...\n"
+    std::string text(err);
+    if (text.rfind("Error: ", 0) == 0) text = text.substr(7);
+    while (!text.empty() && text.back() == '\n') text.pop_back();
+    return bl_internal_fail(ctx, code, text.c_str());
+  };
+  if (p.model_type != BL_MODEL_SIMULATION || !p.slow_light_on) return bl_internal_fail(ctx, BL_E_STATE, "bl_slow_light_read needs slow_light_on = true.");
+  if (state.first_time) {   // the constructor's checks come before any file is touched
+    try {
+      bl_snapshot scratch;
+      ReaderSetup(p, &scratch);
+    } catch (const ReadFailure &f) {
+      return bl_internal_fail(ctx, f.code, f.message.c_str());
+    }
+  }
+  const double snapshot_time = p.slow_t_start + p.slow_dt * snapshot;
+  double latest_time = snapshot_time - 2.0 * kExtrapolationTolerance;
+  int latest_old = -1;
+  if (state.first_time) {
+    state.latest_file_number = p.simulation_start + p.slow_chunk_size - 2;
+  } else {
+    latest_time = state.latest_time;
+    latest_old = state.latest_file_number;
+  }
+  // find the first file not earlier than the camera time (only its Time attribute matters here; the file is
+  // read once more below if it enters the window, like the reference does)
+  std::vector<bl_snapshot *> opened;   // files read while searching, by file number - latest_start
+  const int search_start = state.latest_file_number + 1;
+  auto close_all = [&]() {
+    for (bl_snapshot *s : opened) bl_snapshot_close(s);
+    opened.clear();
+  };
+  while (latest_time < snapshot_time && state.latest_file_number < p.simulation_end) {
+    state.latest_file_number++;
+    bl_snapshot *s = nullptr;
+    const int rc = bl_snapshot_open_number(&p, state.latest_file_number, &s, err, sizeof err);
+    if (rc != BL_OK) {
+      close_all();
+      return fail_text(rc);
+    }
+    opened.push_back(s);
+    latest_time = bl_snapshot_time(s);
+  }
+  if (latest_time < snapshot_time - kExtrapolationTolerance) {
+    close_all();
+    std::ostringstream message;
+    message << "Snapshot " << snapshot << " at time " << snapshot_time << " would require significant extrapolation beyond file "
+            << p.simulation_end << ".";
+    return bl_internal_fail(ctx, BL_E_INPUT, message.str().c_str());
+  }
+  if (latest_time < snapshot_time) {
+    std::ostringstream message;
+    message << "Snapshot " << snapshot << " at time " << snapshot_time << " requires moderate extrapolation.";
+    bl_internal_warn(ctx, message.str().c_str());
+  }
+  // how many slices are new (:281-302)
+  int num_read;
+  if (state.latest_file_number == latest_old) {
+    num_read = 0;
+  } else if (state.latest_file_number - p.slow_chunk_size + 1 <= latest_old) {
+    num_read = state.latest_file_number - latest_old;
+    const int rc = bl_shift_grid_slices(ctx, num_read);
+    if (rc != BL_OK) {
+      close_all();
+      return rc;
+    }
+  } else {
+    num_read = p.slow_chunk_size;
+  }
+  // slice n <- file latest_file_number - n (:313-320)
+  for (int n = 0; n < num_read; n++) {
+    const int number = state.latest_file_number - n;
+    bl_snapshot *s = nullptr;
+    const int held = number - search_start;
+    if (held >= 0 && held < static_cast<int>(opened.size())) {
+      s = opened[held];
+      opened[held] = nullptr;
+    } else {
+      const int rc = bl_snapshot_open_number(&p, number, &s, err, sizeof err);
+      if (rc != BL_OK) {
+        close_all();
+        return fail_text(rc);
+      }
+    }
+    if (state.first_time && n == 0) {
+      const char *w = bl_snapshot_warnings(s);   // constructor and angular-range warnings, once
+      std::string all(w);
+      size_t at = 0;
+      while (at < all.size()) {
+        size_t end = all.find('\n', at);
+        if (end == std::string::npos) end = all.size();
+        std::string line = all.substr(at, end - at);
+        if (line.rfind("Warning: ", 0) == 0) line = line.substr(9);
+        if (!line.empty()) bl_internal_warn(ctx, line.c_str());
+        at = end + 1;
+      }
+    }
+    const int rc = bl_set_grid_slice(ctx, n, bl_snapshot_grid(s), bl_snapshot_time(s));
+    bl_snapshot_close(s);
+    if (rc != BL_OK) {
+      close_all();
+      return rc;
+    }
+  }
+  close_all();
+  if (num_read > 0 || state.first_time) state.latest_time = latest_time;
+  state.first_time = 0;
+  return bl_set_snapshot(ctx, snapshot);
 }
 
 const bl_grid_desc *bl_snapshot_grid(const bl_snapshot *s) { return s != nullptr ? &s->desc : nullptr; }

@@ -199,7 +199,7 @@ typedef struct bl_grid_desc {
  * owns the arrays bl_snapshot_grid() points to; hand that view to bl_set_grid(), then close the snapshot.
  * err receives "Error: ...\n" (reference texts). Each call reads its file completely; the reference
  * re-uses block layout and coordinates of the first file for later files of a series.
- * slow_light_on and the other simulation formats return BL_E_UNSUPPORTED. */
+ * The other simulation formats return BL_E_UNSUPPORTED. With slow_light_on use bl_slow_light_read(). */
 typedef struct bl_snapshot bl_snapshot;
 BL_API int bl_snapshot_open(const bl_params *p, int snapshot, bl_snapshot **out, char *err, size_t err_len);
 BL_API const bl_grid_desc *bl_snapshot_grid(const bl_snapshot *s);
@@ -209,6 +209,9 @@ BL_API const char *bl_snapshot_file(const bl_snapshot *s);         /* file name 
 /* MeshBlock table: returns n_blocks; *levels -> [n_blocks], *locations -> [n_blocks][3] */
 BL_API int bl_snapshot_blocks(const bl_snapshot *s, const int32_t **levels, const int32_t **locations);
 BL_API void bl_snapshot_close(bl_snapshot *s);
+/* Open file number `file_number` of the series (simulation_file with its {Nd} field filled in), whatever
+ * simulation_multiple / slow_light_on say: the building block of bl_slow_light_read(). */
+BL_API int bl_snapshot_open_number(const bl_params *p, int file_number, bl_snapshot **out, char *err, size_t err_len);
 
 /* ------------------------------------------------------------------ camera frame
  * The seven 4-vectors GeodesicIntegrator::InitializeCamera() derives (camera.cpp:61-380,
@@ -270,6 +273,22 @@ BL_API int bl_init(const bl_params *p, int device, bl_ctx **out);
  * box are merged into one [k][j][i][8 floats] array; other sets of non-overlapping equal-sized blocks (mesh
  * refinement) stay [block][k][j][i][8] behind a lattice of block boundaries. Overlapping blocks are refused. */
 BL_API int bl_set_grid(bl_ctx *ctx, const bl_grid_desc *g);
+/* ---- slow light (slow_light_on = true): the reader keeps a window of slow_chunk_size files, latest first
+ * (simulation_reader.cpp:211-303), all on the geometry of the first; every sample reads the slice(s) around
+ * its own coordinate time (simulation_sampling.cpp:296-349, :736-786, :840-912).
+ * bl_slow_light_read(ctx, snapshot): SimulationReader::Read(snapshot) for slow light - advances the window to
+ *   cover camera time slow_t_start + snapshot * slow_dt, reading only new files (bl_snapshot_open_number),
+ *   shifting the slices already in HBM, and selects `snapshot` for the next bl_render. Reference error and
+ *   warning texts ("... would require significant extrapolation beyond file N.").
+ * The three calls below are what it is made of, for callers with their own reader:
+ * bl_set_grid_slice(ctx, n, g, time): slice n of the window (prim[n], time[n]).
+ * bl_shift_grid_slices(ctx, count): slice n <- slice n - count for n >= count (device pointers move, no copy).
+ * bl_set_snapshot(ctx, snapshot): image index; camera time and the texts of bl_render's extrapolation
+ *   warnings / errors (simulation_sampling.cpp:577-617) follow from it. */
+BL_API int bl_slow_light_read(bl_ctx *ctx, int snapshot);
+BL_API int bl_set_grid_slice(bl_ctx *ctx, int slice, const bl_grid_desc *g, double time);
+BL_API int bl_shift_grid_slices(bl_ctx *ctx, int count);
+BL_API int bl_set_snapshot(bl_ctx *ctx, int snapshot);
 /* Number of image rows n_q and their offsets (radiation_integrator.cpp:436-520). */
 BL_API int bl_image_num_quantities(const bl_ctx *ctx);
 /* Number of false-colour renderings bl_render produces (render_num_images; 0 in formula mode). */
@@ -296,6 +315,7 @@ BL_API const char *bl_last_error(const bl_ctx *ctx);
 BL_API const char *bl_last_global_error(void);
 /* Warnings raised by the last call, newline separated, reference wording ("Warning: ...\n") */
 BL_API const char *bl_warnings(const bl_ctx *ctx);
+BL_API void bl_warnings_clear(bl_ctx *ctx);   /* forget the warnings collected so far */
 BL_API void bl_free(bl_ctx *ctx);
 
 /* ------------------------------------------------------------------ host steps between / after renders

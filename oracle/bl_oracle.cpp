@@ -97,6 +97,11 @@ struct Oracle {
   double plasma_thermal_frac;
   double power_jj = 0.0, power_aa = 0.0;   // simulation_coefficients.cpp:54-66
   int render_num_images = 0;               // 0 in formula mode (radiation_integrator.cpp:136-145)
+  // slow light: time slices held by the reader, latest first (simulation_reader.cpp:211-303)
+  int slow_n = 0;
+  const bl_grid_desc *const *slow_grids = nullptr;
+  const double *slow_times = nullptr;
+  double snapshot_time = 0.0;
 };
 
 bool need(const bl_params *p, int index) { return p->has[index] != 0; }
@@ -1192,9 +1197,14 @@ struct Prims {
 struct BlockState {
   int b = 0;
   bool valid = false;
+  // slow light, per ray (simulation_sampling.cpp:218-226): which extrapolations its samples needed
+  bool extrap[4] = {false, false, false, false};   // camera small, camera large, source small, source large
+  double extrap_val[4] = {0.0, 0.0, 0.0, 0.0};
 };
 
-// simulation_sampling.cpp:201-575 + :666-1033 for one sample (no slow light).
+constexpr double extrapolation_tolerance = 1.0;   // simulation_reader.hpp:99
+
+// simulation_sampling.cpp:201-575 + :666-1033 for one sample.
 // Returns: 0 = sampled, 1 = cut, 2 = NaN, 3 = fallback values. *gathered set if the grid was read.
 int SampleOne(const Oracle &o, const double pos[4], Prims *out, bool *gathered, BlockState *state) {
   const bl_params &p = *o.p;
@@ -1204,6 +1214,46 @@ int SampleOne(const Oracle &o, const double pos[4], Prims *out, bool *gathered, 
   double r = RadialGeodesicCoordinate(o, x1, x2, x3);
   if (GeometricCut(o, x1, x2, x3, r)) return 1;
   ConvertFromCKS(o, &x1, &x2, &x3);
+  // time interpolation (:296-349)
+  const bool slow = p.slow_light_on != 0;
+  const bool slow_interp = slow and p.slow_interp;
+  int t_ind = 0;
+  double t_frac = 0.0;
+  if (slow) {
+    const double *time = o.slow_times;
+    const int chunk = o.slow_n;
+    double x0 = pos[0] + o.snapshot_time;   // :231
+    if (x0 >= time[0]) {
+      if (x0 > time[0] + extrapolation_tolerance) {
+        state->extrap[1] = true;
+        state->extrap_val[1] = std::max(state->extrap_val[1], x0 - time[0]);
+      } else if (x0 > time[0]) {
+        state->extrap[0] = true;
+        state->extrap_val[0] = std::max(state->extrap_val[0], x0 - time[0]);
+      }
+    } else if (x0 <= time[chunk - 1]) {
+      if (x0 < time[chunk - 1] - extrapolation_tolerance) {
+        state->extrap[3] = true;
+        state->extrap_val[3] = std::max(state->extrap_val[3], time[chunk - 1] - x0);
+      } else if (x0 < time[chunk - 1]) {
+        state->extrap[2] = true;
+        state->extrap_val[2] = std::max(state->extrap_val[2], time[chunk - 1] - x0);
+      }
+      if (slow_interp) {
+        t_ind = chunk - 2;
+        t_frac = 1.0;
+      } else
+        t_ind = chunk - 1;
+    } else {
+      while (time[t_ind++] > x0);
+      t_ind--;
+      if (slow_interp) {
+        t_ind--;
+        t_frac = (x0 - time[t_ind]) / (time[t_ind + 1] - time[t_ind]);
+      } else if (time[t_ind - 1] - x0 <= x0 - time[t_ind])
+        t_ind--;
+    }
+  }
   int n_i = g.n_i, n_j = g.n_j, n_k = g.n_k, n_b = g.n_blocks;
   // block test and search (:352-394)
   if (!state->valid) {   // :205-214: block 0 to start with
@@ -1239,47 +1289,51 @@ int SampleOne(const Oracle &o, const double pos[4], Prims *out, bool *gathered, 
     if (x3f[k + 1] >= x3) break;
   bool code_kappa = p.plasma_model == BL_PLASMA_CODE_KAPPA;
   *gathered = true;
-  if (not p.simulation_interp) {  // :710-734
-    out->rho = GridVal(g, g.ind_rho, b, k, j, i);
-    out->pgas = GridVal(g, g.ind_pgas, b, k, j, i);
-    out->kappa = code_kappa ? GridVal(g, g.ind_kappa, b, k, j, i) : 0.0f;
-    out->uu1 = GridVal(g, g.ind_uu1, b, k, j, i);
-    out->uu2 = GridVal(g, g.ind_uu2, b, k, j, i);
-    out->uu3 = GridVal(g, g.ind_uu3, b, k, j, i);
-    out->bb1 = GridVal(g, g.ind_bb1, b, k, j, i);
-    out->bb2 = GridVal(g, g.ind_bb2, b, k, j, i);
-    out->bb3 = GridVal(g, g.ind_bb3, b, k, j, i);
+  // the nine variables in the order of Prims; without code_kappa the entropy stays 0
+  const int vars[9] = {g.ind_rho, g.ind_pgas, g.ind_kappa, g.ind_uu1, g.ind_uu2, g.ind_uu3, g.ind_bb1, g.ind_bb2, g.ind_bb3};
+  float *dst[9] = {&out->rho, &out->pgas, &out->kappa, &out->uu1, &out->uu2, &out->uu3, &out->bb1, &out->bb2, &out->bb3};
+  auto slice = [&](int t) -> const bl_grid_desc & { return slow ? *o.slow_grids[t] : g; };
+  if (not p.simulation_interp) {  // :710-786
+    for (int v = 0; v < 9; v++) {
+      if (v == 2 and not code_kappa) {
+        *dst[v] = 0.0f;
+        continue;
+      }
+      if (not slow_interp)
+        *dst[v] = GridVal(slice(t_ind), vars[v], b, k, j, i);
+      else {
+        double val_1 = static_cast<double>(GridVal(slice(t_ind), vars[v], b, k, j, i));
+        double val_2 = static_cast<double>(GridVal(slice(t_ind + 1), vars[v], b, k, j, i));
+        *dst[v] = static_cast<float>((1.0 - t_frac) * val_1 + t_frac * val_2);
+      }
+    }
     return 0;
   }
-  // intrablock interpolation (:485-490, :809-839)
+  // intrablock interpolation (:485-490, :809-912)
   int i_m = i == 0 or (i != n_i - 1 and x1 >= x1v[i]) ? i : i - 1;
   int j_m = j == 0 or (j != n_j - 1 and x2 >= x2v[j]) ? j : j - 1;
   int k_m = k == 0 or (k != n_k - 1 and x3 >= x3v[k]) ? k : k - 1;
   double f_i = (x1 - x1v[i_m]) / (x1v[i_m + 1] - x1v[i_m]);
   double f_j = (x2 - x2v[j_m]) / (x2v[j_m + 1] - x2v[j_m]);
   double f_k = (x3 - x3v[k_m]) / (x3v[k_m + 1] - x3v[k_m]);
-  double rho = InterpolateSimple(g, g.ind_rho, b, k_m, j_m, i_m, f_k, f_j, f_i);
-  double pgas = InterpolateSimple(g, g.ind_pgas, b, k_m, j_m, i_m, f_k, f_j, f_i);
-  double kappa = 0.0;
-  if (code_kappa) kappa = InterpolateSimple(g, g.ind_kappa, b, k_m, j_m, i_m, f_k, f_j, f_i);
-  double uu1 = InterpolateSimple(g, g.ind_uu1, b, k_m, j_m, i_m, f_k, f_j, f_i);
-  double uu2 = InterpolateSimple(g, g.ind_uu2, b, k_m, j_m, i_m, f_k, f_j, f_i);
-  double uu3 = InterpolateSimple(g, g.ind_uu3, b, k_m, j_m, i_m, f_k, f_j, f_i);
-  double bb1 = InterpolateSimple(g, g.ind_bb1, b, k_m, j_m, i_m, f_k, f_j, f_i);
-  double bb2 = InterpolateSimple(g, g.ind_bb2, b, k_m, j_m, i_m, f_k, f_j, f_i);
-  double bb3 = InterpolateSimple(g, g.ind_bb3, b, k_m, j_m, i_m, f_k, f_j, f_i);
-  if (rho <= 0.0) rho = static_cast<double>(GridVal(g, g.ind_rho, b, k_m, j_m, i_m));
-  if (pgas <= 0.0) pgas = static_cast<double>(GridVal(g, g.ind_pgas, b, k_m, j_m, i_m));
-  if (code_kappa and kappa <= 0.0) kappa = static_cast<double>(GridVal(g, g.ind_kappa, b, k_m, j_m, i_m));
-  out->rho = static_cast<float>(rho);
-  out->pgas = static_cast<float>(pgas);
-  out->kappa = static_cast<float>(kappa);
-  out->uu1 = static_cast<float>(uu1);
-  out->uu2 = static_cast<float>(uu2);
-  out->uu3 = static_cast<float>(uu3);
-  out->bb1 = static_cast<float>(bb1);
-  out->bb2 = static_cast<float>(bb2);
-  out->bb3 = static_cast<float>(bb3);
+  auto spatial = [&](const bl_grid_desc &gs, int v) {   // InterpolateSimple + the <= 0 rule of rho, pgas, kappa
+    double val = InterpolateSimple(gs, vars[v], b, k_m, j_m, i_m, f_k, f_j, f_i);
+    if (v < 3 and val <= 0.0) val = static_cast<double>(GridVal(gs, vars[v], b, k_m, j_m, i_m));
+    return val;
+  };
+  for (int v = 0; v < 9; v++) {
+    if (v == 2 and not code_kappa) {
+      *dst[v] = 0.0f;
+      continue;
+    }
+    if (not slow_interp)
+      *dst[v] = static_cast<float>(spatial(slice(t_ind), v));
+    else {
+      double val_1 = spatial(slice(t_ind), v);
+      double val_2 = spatial(slice(t_ind + 1), v);
+      *dst[v] = static_cast<float>((1.0 - t_frac) * val_1 + t_frac * val_2);
+    }
+  }
   return 0;
 }
 
@@ -1742,7 +1796,8 @@ int Setup(Oracle &o, const bl_params *p, const bl_grid_desc *g, char *err, size_
   if (p->model_type == BL_MODEL_SIMULATION) {
     if (g == nullptr) return Fail(err, err_len, "oracle: simulation mode needs a grid", BL_E_ARG);
     if (p->simulation_block_interp) return Fail(err, err_len, "oracle: inter-block interpolation not restated (out-of-bounds read in the reference)", BL_E_UNSUPPORTED);
-    if (p->slow_light_on) return Fail(err, err_len, "oracle: slow light not restated yet", BL_E_UNSUPPORTED);
+    if (p->slow_light_on and (o.slow_n < 2 or o.slow_n != p->slow_chunk_size or o.slow_grids == nullptr or o.slow_times == nullptr))
+      return Fail(err, err_len, "oracle: slow light needs slow_chunk_size time slices in blo_extra", BL_E_ARG);
     if (p->simulation_coord == BL_COORD_FMKS) return Fail(err, err_len, "oracle: fmks not restated yet", BL_E_UNSUPPORTED);
     if (p->plasma_kappa_frac != 0.0)
       return Fail(err, err_len, "oracle: kappa-distribution electrons not restated (the reference reads the uninitialised kappa_aa_high_i)", BL_E_UNSUPPORTED);
@@ -1795,6 +1850,12 @@ int blo_render(const bl_params *p, const bl_grid_desc *g, const bl_render_desc *
   if (p == nullptr || d == nullptr) return BL_E_ARG;
   if (d->outputs_on_device) return Fail(err, err_len, "oracle works on host memory only", BL_E_ARG);
   Oracle o{};
+  if (extra != nullptr and p->model_type == BL_MODEL_SIMULATION and p->slow_light_on) {
+    o.slow_n = extra->slow_n;
+    o.slow_grids = extra->slow_grids;
+    o.slow_times = extra->slow_times;
+    o.snapshot_time = extra->slow_snapshot_time;
+  }
   int rc = Setup(o, p, g, err, err_len);
   if (rc != BL_OK) return rc;
   if (frame != nullptr) {
@@ -1826,8 +1887,10 @@ int blo_render(const bl_params *p, const bl_grid_desc *g, const bl_render_desc *
   int max_sample_num = 0;
   if (extra != nullptr) extra->dump_num = 0;
   double time_start = omp_get_wtime();
+  int64_t count_0 = 0, count_1 = 0, count_2 = 0, count_3 = 0;   // simulation_sampling.cpp:160-168
+  double val_0 = 0.0, val_1 = 0.0, val_2 = 0.0, val_3 = 0.0;
 
-  #pragma omp parallel num_threads(num_threads) reduction(+: total_samples, total_gathers, total_flagged) reduction(max: max_sample_num)
+  #pragma omp parallel num_threads(num_threads) reduction(+: total_samples, total_gathers, total_flagged, count_0, count_1, count_2, count_3) reduction(max: max_sample_num, val_0, val_1, val_2, val_3)
   {
     RayBuffers b(max_steps, nf);
     BlockState block_state;   // per thread, kept across rays like the reference's (which rays share a thread
@@ -1879,6 +1942,10 @@ int blo_render(const bl_params *p, const bl_grid_desc *g, const bl_render_desc *
       const double nan = std::numeric_limits<double>::quiet_NaN();
       if (simulation) {
         bool nan_ray = p->fallback_nan and flag;  // simulation_sampling.cpp:211-216
+        for (int e = 0; e < 4; e++) {
+          block_state.extrap[e] = false;
+          block_state.extrap_val[e] = 0.0;
+        }
         for (int n = 0; n < sample_num; n++) {
           Prims s;
           bool gathered = false;
@@ -1903,6 +1970,10 @@ int blo_render(const bl_params *p, const bl_grid_desc *g, const bl_render_desc *
                                     &b.j_i[n], &b.alpha_i[n], max_steps, cell);
           for (int a = 0; a < num_cell_values; a++) b.cell_values[a * static_cast<size_t>(max_steps) + n] = cell[a];
         }
+        if (block_state.extrap[0]) { count_0++; val_0 = std::max(val_0, block_state.extrap_val[0]); }   // :553-575
+        if (block_state.extrap[1]) { count_1++; val_1 = std::max(val_1, block_state.extrap_val[1]); }
+        if (block_state.extrap[2]) { count_2++; val_2 = std::max(val_2, block_state.extrap_val[2]); }
+        if (block_state.extrap[3]) { count_3++; val_3 = std::max(val_3, block_state.extrap_val[3]); }
       } else if (sample_num > 0) {
         if (p->fallback_nan and flag) {  // formula_coefficients.cpp:51-59 (only frequency 0 is filled)
           for (int n = 0; n < sample_num; n++) {
@@ -1930,6 +2001,8 @@ int blo_render(const bl_params *p, const bl_grid_desc *g, const bl_render_desc *
     extra->n_flagged = total_flagged;
     extra->max_sample_num = max_sample_num;
     extra->seconds = omp_get_wtime() - time_start;
+    extra->slow_count[0] = count_0; extra->slow_count[1] = count_1; extra->slow_count[2] = count_2; extra->slow_count[3] = count_3;
+    extra->slow_val[0] = val_0; extra->slow_val[1] = val_1; extra->slow_val[2] = val_2; extra->slow_val[3] = val_3;
   }
   return BL_OK;
 }

@@ -33,6 +33,16 @@ typedef struct blo_extra {
   int64_t n_samples, n_gathers, n_flagged;
   int32_t max_sample_num;
   double seconds;             /* wall time of the ray loop                                         */
+  /* slow light (slow_light_on; simulation_sampling.cpp:296-349, :736-786, :840-912): in: the time slices the
+     reader holds, slow_grids[0] the latest (simulation_reader.cpp:211-303), and the camera time of this
+     snapshot; g of blo_render gives the coordinates (= slow_grids[0]'s). out: pixels needing extrapolation
+     and by how much: [0] forward small, [1] forward large, [2] backward small, [3] backward large          */
+  int32_t slow_n;
+  const bl_grid_desc *const *slow_grids;
+  const double *slow_times;
+  double slow_snapshot_time;
+  int64_t slow_count[4];
+  double slow_val[4];
 } blo_extra;
 
 /* Same contract as bl_render() with host pointers (d->outputs_on_device must be 0). g may be NULL

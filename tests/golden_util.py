@@ -9,7 +9,7 @@ import numpy as np
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 CASES = sorted(f[:-4] for f in os.listdir(GOLDEN_DIR)
-               if f.endswith(".npz") and not f.startswith("mock_") and not f.startswith("window_"))
+               if f.endswith(".npz") and not f.startswith(("mock_", "window_", "slow_")))
 # cases whose parameters are inside the scope of the HIP path today
 GPU_CASES = list(CASES)
 
@@ -131,6 +131,41 @@ def refined_grid(grid):
 
     return Grid(prim=np.ascontiguousarray(blocks["prim"]), x1f=row("x1f"), x2f=row("x2f"), x3f=row("x3f"),
                 x1v=row("x1v"), x2v=row("x2v"), x3v=row("x3v"), ind_kappa=grid.ind_kappa)
+
+
+SLOW_CASES = ["slow_interp", "slow_nearest"]
+
+
+def slow_light_grids(fx):
+    """The eleven snapshots of a slow-light fixture, regenerated (blacklight_amd.mock.generate restates the
+    reference's generator bit for bit; checked here against the hashes of the files the reference read)."""
+    import hashlib
+    from blacklight_amd import mock
+    grids = []
+    for args, want in zip(json.loads(str(fx["mock_args"])), json.loads(str(fx["prim_sha256"]))):
+        grid = mock.generate(**args)
+        assert hashlib.sha256(np.ascontiguousarray(grid.prim[:8, 0]).tobytes()).hexdigest() == want
+        grids.append(grid)
+    return grids
+
+
+def slow_light_windows(params, file_times):
+    """Test-side restatement of the reader's sliding window (simulation_reader.cpp:211-303): for every
+    snapshot, (camera time, file numbers held, latest first)."""
+    start, end, chunk = int(params["simulation_start"]), int(params["simulation_end"]), int(params["slow_chunk_size"])
+    latest_number, windows = None, []
+    for snapshot in range(int(params["slow_num_images"])):
+        t = float(params["slow_t_start"]) + float(params["slow_dt"]) * snapshot
+        if latest_number is None:
+            latest_time, latest_number = t - 2.0, start + chunk - 2
+        else:
+            latest_time = file_times[latest_number]
+        while latest_time < t and latest_number < end:
+            latest_number += 1
+            latest_time = file_times[latest_number]
+        assert latest_time >= t - 1.0
+        windows.append((t, [latest_number - n for n in range(chunk)]))
+    return windows
 
 
 IMAGE_ROW_NAMES = ["I_nu", "time", "length", "lambda", "emission", "tau", "lambda_ave_rho", "lambda_ave_n_e",

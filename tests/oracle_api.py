@@ -19,6 +19,8 @@ class Extra(C.Structure):
         ("dump_num", C.c_int32),
         ("n_samples", C.c_int64), ("n_gathers", C.c_int64), ("n_flagged", C.c_int64),
         ("max_sample_num", C.c_int32), ("seconds", C.c_double),
+        ("slow_n", C.c_int32), ("slow_grids", C.c_void_p), ("slow_times", C.c_void_p),
+        ("slow_snapshot_time", C.c_double), ("slow_count", C.c_int64 * 4), ("slow_val", C.c_double * 4),
     ]
 
 
@@ -54,9 +56,10 @@ def load(variant="blmath"):
 
 def render(params_ptr, grid_desc, desc_cls, camera_frame_cls, *, n_rays, level=0, block_locs=None,
            pixel_map=None, variant="blmath", num_threads=0, dump_ray=-1, max_steps=0, n_freq=1,
-           want_camera=False, n_render=0):
+           want_camera=False, n_render=0, slow=None):
     """Run the oracle. Returns dict(image, sample_num, sample_flags, frame, frequencies, extra...).
-    n_render > 0: also the false-colour renderings, (n_render, 3, n_rays)."""
+    n_render > 0: also the false-colour renderings, (n_render, 3, n_rays).
+    slow = dict(grids=[bl_grid_desc, ...] latest first, times=[...], snapshot_time=t): slow light."""
     L = load(variant)
     n_q = L.blo_image_num_quantities(params_ptr)
     image = np.zeros((max(n_q, 1), n_rays), dtype=np.float64)
@@ -100,6 +103,14 @@ def render(params_ptr, grid_desc, desc_cls, camera_frame_cls, *, n_rays, level=0
         extra.dump_pos = dump["pos"].ctypes.data_as(C.c_void_p)
         extra.dump_dir = dump["dir"].ctypes.data_as(C.c_void_p)
         extra.dump_len = dump["len"].ctypes.data_as(C.c_void_p)
+    if slow is not None:
+        grid_ptrs = (C.c_void_p * len(slow["grids"]))(*[C.addressof(g) for g in slow["grids"]])
+        times = np.ascontiguousarray(slow["times"], dtype=np.float64)
+        keep += [grid_ptrs, times]
+        extra.slow_n = len(slow["grids"])
+        extra.slow_grids = C.cast(grid_ptrs, C.c_void_p)
+        extra.slow_times = times.ctypes.data_as(C.c_void_p)
+        extra.slow_snapshot_time = float(slow["snapshot_time"])
     err = C.create_string_buffer(1024)
     grid_ptr = C.byref(grid_desc) if grid_desc is not None else None
     rc = L.blo_render(params_ptr, grid_ptr, C.byref(d), C.byref(frame),
@@ -109,7 +120,8 @@ def render(params_ptr, grid_desc, desc_cls, camera_frame_cls, *, n_rays, level=0
     out = dict(image=image[:n_q], sample_num=sample_num, sample_flags=sample_flags, frame=frame,
                frequencies=freqs, n_samples=extra.n_samples, n_gathers=extra.n_gathers,
                n_flagged=extra.n_flagged, max_sample_num=extra.max_sample_num, seconds=extra.seconds,
-               camera_pos=camera_pos, camera_dir=camera_dir, rendering=rendering)
+               camera_pos=camera_pos, camera_dir=camera_dir, rendering=rendering,
+               slow_count=list(extra.slow_count), slow_val=list(extra.slow_val))
     if dump is not None:
         n = extra.dump_num
         out["dump"] = dict(pos=dump["pos"][:n], dir=dump["dir"][:n], len=dump["len"][:n])

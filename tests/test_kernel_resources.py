@@ -1,0 +1,46 @@
+"""The register budget the measured numbers rest on: the kernels of the benchmark path
+must compile without scratch at their intended occupancy. Read from the compiler's own resource remarks,
+which blacklight_amd.build keeps next to the objects."""
+import os
+import re
+
+import pytest
+
+from blacklight_amd import build as bl_build
+
+RESOURCES = os.path.join(bl_build.OBJ, "bl_kernels.resources.txt")
+
+# mangled name -> (waves per SIMD, largest scratch in bytes per lane)
+BENCHMARK_KERNELS = {
+    "_Z18bl_geodesic_kernelILi0ELb0EEv11BlTraceArgs": (1, 0),        # Dormand-Prince, no sample times
+    "_Z16bl_locate_kernelILb0ELb0EEv11BlShadeArgs": (4, 0),          # merged grid, no slow light
+    "_Z15bl_shade_kernelILi0ELb0ELb0EEv11BlShadeArgs": (2, 0),       # simulation, thermal electrons
+    "_Z18bl_transfer_kernel14BlTransferArgs": (None, 0),
+}
+
+
+def _parse():
+    text = open(RESOURCES).read()
+    kernels = {}
+    current = None
+    for line in text.splitlines():
+        m = re.search(r"remark: Function Name: (\S+)", line)
+        if m:
+            current = kernels.setdefault(m.group(1), {})
+            continue
+        m = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[bytes/lane\]| \[waves/SIMD\])?: (\d+)", line)
+        if m and current is not None:
+            current[m.group(1).strip()] = int(m.group(2))
+    return kernels
+
+
+def test_benchmark_kernels_fit_their_registers(built_library):
+    if not os.path.exists(RESOURCES):
+        bl_build.build(force=True)
+    kernels = _parse()
+    for name, (occupancy, scratch) in BENCHMARK_KERNELS.items():
+        assert name in kernels, (name, sorted(kernels))
+        usage = kernels[name]
+        assert usage["ScratchSize"] <= scratch, (name, usage)
+        if occupancy is not None:
+            assert usage["Occupancy"] == occupancy, (name, usage)

@@ -9,6 +9,7 @@ bit-for-bit by the restatement -
 image rows (all auxiliary images too), sample_num, sample_flags, the camera frame, the frequency
 list, per-pixel initial conditions, and full per-sample position / momentum / length of the dumped
 rays."""
+import json
 import platform
 
 import numpy as np
@@ -84,3 +85,36 @@ def test_tier_a_stock_reference(case, built_library):
         finite = np.isfinite(want) & np.isfinite(out["image"])
         scale = np.nanmax(np.abs(want[0]))
         assert np.max(np.abs(out["image"][0] - want[0])[finite[0]]) / scale < 1e-5
+
+
+@pytest.mark.parametrize("variant,tier", [("blmath", "B"), ("libm", "A")])
+@pytest.mark.parametrize("case", gu.SLOW_CASES)
+def test_slow_light(case, variant, tier, built_library):
+    """slow_light_on: every camera time the reference rendered through its sliding window of files, with time
+    interpolation (slow_interp) or the nearest file; images bit-exact, extrapolation counts as in its warnings."""
+    import os
+    import blacklight_amd as bl
+    from blacklight_amd import _capi
+    if tier == "A" and _generating_host_class() is False:
+        pytest.skip("tier A bit-exactness needs the host class the goldens were generated on")
+    fx = np.load(os.path.join(gu.GOLDEN_DIR, f"{case}.npz"), allow_pickle=False)
+    params = json.loads(str(fx["params"]))
+    p = bl.Params.from_dict(params)
+    grids = gu.slow_light_grids(fx)
+    file_times = [float(t) for t in fx["file_times"]]
+    res = int(params["camera_resolution"])
+    rows = [name for name in ("I_nu", "tau") if f"{tier}_0_{name}" in fx.files]
+    for image, (t_cam, files) in enumerate(gu.slow_light_windows(params, file_times)):
+        descs = [grids[f].desc() for f in files]
+        out = oracle_api.render(p.ptr, descs[0], _capi.RenderDesc, _capi.CameraFrame, n_rays=res * res, variant=variant,
+                                max_steps=int(params["ray_max_steps"]), n_freq=1,
+                                slow=dict(grids=descs, times=[file_times[f] for f in files], snapshot_time=t_cam))
+        want = np.stack([fx[f"{tier}_{image}_{name}"].reshape(-1) for name in rows])
+        assert gu.same_bits(out["image"], want).all(), (image, t_cam)
+        if case == "slow_nearest":
+            # "(52/256 pixels, by up to 0.37249 gravitational times)" on the last camera time only
+            assert out["slow_count"] == ([52, 0, 0, 0] if image == 2 else [0, 0, 0, 0])
+            if image == 2:
+                assert f"{out['slow_val'][0]:.6g}" == "0.37249"
+        else:
+            assert out["slow_count"] == [0, 0, 0, 0]

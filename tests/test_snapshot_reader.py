@@ -96,9 +96,21 @@ def test_adiabatic_indices_and_constructor_rules(built_library, expected):
         assert (d.plasma_gamma, d.plasma_gamma_i, d.plasma_gamma_e) == (1.5, 1.6, 1.3) and s.warnings == ""
     with pytest.raises(BlacklightError, match="SimulationReader unable to find all needed values in input file."):
         Snapshot(_params(expected, plasma_use_p="false", plasma_gamma=1.5))
-    with pytest.raises(BlacklightError, match="not built") as info:
-        Snapshot(_params(expected, simulation_multiple="true", simulation_start=3, simulation_end=4, slow_light_on="true"))
-    assert info.value.code == 3
+    # slow light: the constructor's rules (simulation_reader.cpp:66-82); its window of files is read by
+    # bl_slow_light_read (GPU tests), a single bl_snapshot_open refuses
+    slow = dict(simulation_multiple="true", simulation_start=3, simulation_end=4, slow_light_on="true", slow_chunk_size=2,
+                slow_t_start=4.0, slow_dt=0.5, simulation_file=os.path.join(READER_DIR, "series_{04d}.athdf"))
+    with pytest.raises(BlacklightError, match="read by bl_slow_light_read") as info:
+        Snapshot(_params(expected, **slow))
+    assert info.value.code == 6
+    for change, message in ((dict(simulation_multiple="false"), "Must enable simulation_multiple to use slow light."),
+                            (dict(slow_chunk_size=1), "Must have slow_chunk_size be at least 2."),
+                            (dict(slow_chunk_size=3), "Not enough simulation files for given slow_chunk_size."),
+                            (dict(slow_dt=0.0), "Must have positive time interval slow_dt."),
+                            (dict(slow_dt=None), "SimulationReader unable to find all needed values in input file.")):
+        with pytest.raises(BlacklightError) as info:
+            Snapshot(_params(expected, **dict(slow, **change)))
+        assert str(info.value) == "Error: " + message
     with pytest.raises(BlacklightError, match="Only simulation_format = athena") as info:
         Snapshot(_params(expected, simulation_format="iharm3d"))
     assert info.value.code == 3

@@ -526,6 +526,100 @@ def make_reader_fixtures():
     print("reader fixtures written; series images differ:", not np.array_equal(a, b), "max", a.max(), b.max())
 
 
+# ------------------------------------------------------------------------------------------------
+# Slow light (tests/golden/slow_*.npz): eleven small mocks with file times 0, 20, ..., 200 and varying
+# perturbations; the reference renders a few camera times through a sliding window of slow_chunk_size files.
+def slow_mock_args(index):
+    return dict(SMALL_MOCK, pert_amp=round(0.05 + 0.03 * index, 4), pert_n_ph=2 + index % 3, Bph_amp=round(0.15 + 0.01 * index, 4),
+                rho_amp=round(1.0 + 0.05 * ((index * 7) % 5), 4))
+
+
+SLOW_CASES = {
+    # trilinear in space, linear in time; no extrapolation
+    "slow_interp": dict(slow_interp="true", simulation_interp="true", slow_t_start=150.0, slow_dt=15.0, slow_num_images=4,
+                        image_tau="true"),
+    # nearest in space and time; the last camera time lies 0.5 beyond the last file (moderate forward extrapolation)
+    "slow_nearest": dict(slow_interp="false", simulation_interp="false", slow_t_start=170.5, slow_dt=15.0, slow_num_images=3,
+                         simulation_a=0.5),
+}
+
+
+def make_slow_fixture(name):
+    import hashlib
+    workdir = os.path.join(WORK, "slow")
+    os.makedirs(os.path.join(workdir, "data"), exist_ok=True)
+    os.makedirs(os.path.join(workdir, "output"), exist_ok=True)
+    n_files = 11
+    fixture = {}
+    hashes = []
+    for index in range(n_files):
+        path = os.path.join(workdir, "data", f"slow_{index:02d}.athdf")
+        mock = slow_mock_args(index)
+        if not os.path.exists(path):
+            args = [sys.executable, "-W", "ignore", MOCK_SCRIPT, path]
+            for key, value in mock.items():
+                args += [f"--{key}", str(value)]
+            subprocess.run(args, check=True)
+            set_time(path, 20.0 * index)
+        prim, _ = mock_arrays(path)
+        hashes.append(hashlib.sha256(np.ascontiguousarray(prim).tobytes()).hexdigest())
+    params = dict(SIM_BASE)
+    params.update(camera_resolution=16, checkpoint_geodesic_save="false", simulation_multiple="true", simulation_start=0,
+                  simulation_end=n_files - 1, simulation_file="data/slow_{02d}.athdf", output_file="output/" + name + "_{02d}.npz",
+                  slow_light_on="true", slow_chunk_size=9, slow_offset=5)
+    params.update(SLOW_CASES[name])
+    write_input(os.path.join(workdir, name + ".input"), params)
+    fixture["params"] = json.dumps(params)
+    fixture["mock_args"] = json.dumps([slow_mock_args(i) for i in range(n_files)])
+    fixture["file_times"] = np.array([20.0 * i for i in range(n_files)])
+    fixture["prim_sha256"] = json.dumps(hashes)
+    for tier, preload in (("A", False), ("B", True)):
+        fixture[f"{tier}_warnings"] = run_reference(workdir, name + ".input", preload)
+        for image in range(params["slow_num_images"]):
+            npz = np.load(os.path.join(workdir, "output", f"{name}_{image + 5:02d}.npz"))
+            for key in npz.files:
+                fixture[f"{tier}_{image}_{key}"] = npz[key]
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **fixture)
+    imgs = [fixture[f"B_{i}_I_nu"] for i in range(params["slow_num_images"])]
+    print(name, "max I_nu per image", [float(np.nanmax(i)) for i in imgs], "warnings:", repr(fixture["B_warnings"]))
+
+
+# Slow light end to end (tests/golden/reader/slowcli_*.athdf + slowcli.npz): twelve 8 x 6 x 8 files 12.5 time
+# units apart, a close camera, a window of 10 files; the reference's outputs for the command-line test.
+def make_slow_cli_fixture():
+    out_dir = os.path.join(OUT, "reader")
+    workdir = os.path.join(WORK, "slowcli")
+    for sub in (out_dir, os.path.join(workdir, "data"), os.path.join(workdir, "output")):
+        os.makedirs(sub, exist_ok=True)
+    n_files = 12
+    for index in range(n_files):
+        path = os.path.join(workdir, "data", f"slowcli_{index:02d}.athdf")
+        mock = dict(slow_mock_args(index), n_r=8, n_th=6, n_ph=8)
+        args = [sys.executable, "-W", "ignore", MOCK_SCRIPT, path]
+        for key, value in mock.items():
+            args += [f"--{key}", str(value)]
+        subprocess.run(args, check=True)
+        set_time(path, 12.5 * index)
+        with open(path, "rb") as src, open(os.path.join(out_dir, os.path.basename(path)), "wb") as dst:
+            dst.write(src.read())
+    params = dict(SIM_BASE)
+    params.update(camera_resolution=16, camera_r=20.0, camera_width=16.0, checkpoint_geodesic_save="false",
+                  simulation_multiple="true", simulation_start=0, simulation_end=n_files - 1,
+                  simulation_file="data/slowcli_{02d}.athdf", output_file="output/slowcli_{03d}.npz", slow_light_on="true",
+                  slow_interp="true", slow_chunk_size=10, slow_offset=40, slow_t_start=101.0, slow_dt=9.0, slow_num_images=4,
+                  simulation_a=0.3, fallback_nan="false", fallback_rho=1.0e-6, fallback_pgas=1.0e-8)
+    write_input(os.path.join(workdir, "slowcli.input"), params)
+    fixture = dict(params=json.dumps(params))
+    for tier, preload in (("A", False), ("B", True)):
+        fixture[f"{tier}_warnings"] = run_reference(workdir, "slowcli.input", preload)
+        for image in range(params["slow_num_images"]):
+            npz = np.load(os.path.join(workdir, "output", f"slowcli_{image + 40:03d}.npz"))
+            for key in npz.files:
+                fixture[f"{tier}_{image}_{key}"] = npz[key]
+    np.savez_compressed(os.path.join(OUT, "slow_cli.npz"), **fixture)
+    print("slowcli: max I_nu", [float(np.nanmax(fixture[f"B_{i}_I_nu"])) for i in range(4)], repr(fixture["B_warnings"]))
+
+
 if __name__ == "__main__":
     names = sys.argv[1:] or (["mock"] + list(CASES))
     for case_name in names:
@@ -535,5 +629,9 @@ if __name__ == "__main__":
             make_window_fixture()
         elif case_name == "reader":
             make_reader_fixtures()
+        elif case_name == "slowcli":
+            make_slow_cli_fixture()
+        elif case_name in SLOW_CASES:
+            make_slow_fixture(case_name)
         else:
             make_case(case_name)
