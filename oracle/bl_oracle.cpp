@@ -11,6 +11,7 @@
 // stages for one ray at a time, so memory is O(ray_max_steps) per thread.
 #include <algorithm>
 #include <cmath>
+#include <complex>
 #include <cstdio>
 #include <cstring>
 #include <limits>
@@ -40,6 +41,9 @@ inline double cos(double x) { return std::cos(x); }
 inline double acos(double x) { return std::acos(x); }
 inline double atan(double x) { return std::atan(x); }
 inline double atan2(double y, double x) { return std::atan2(y, x); }
+inline double sinh(double x) { return std::sinh(x); }
+inline double cosh(double x) { return std::cosh(x); }
+inline double tanh(double x) { return std::tanh(x); }
 }  // namespace M
 #else
 namespace M {
@@ -55,6 +59,9 @@ inline double cos(double x) { return bl_cos(x); }
 inline double acos(double x) { return bl_acos(x); }
 inline double atan(double x) { return bl_atan(x); }
 inline double atan2(double y, double x) { return bl_atan2(y, x); }
+inline double sinh(double x) { return bl_sinh(x); }
+inline double cosh(double x) { return bl_cosh(x); }
+inline double tanh(double x) { return bl_tanh(x); }
 }  // namespace M
 #endif
 
@@ -96,6 +103,7 @@ struct Oracle {
   bool image_polarization;  // forced false in formula mode
   double plasma_thermal_frac;
   double power_jj = 0.0, power_aa = 0.0;   // simulation_coefficients.cpp:54-66
+  double power_pol[7] = {};                // :67-80: jj_q, jj_v, aa_q, aa_v, rho, rho_q, rho_v
   int render_num_images = 0;               // 0 in formula mode (radiation_integrator.cpp:136-145)
   // slow light: time slices held by the reader, latest first (simulation_reader.cpp:211-303)
   int slow_n = 0;
@@ -653,6 +661,14 @@ struct RayBuffers {
   std::vector<double> j_i, alpha_i;                              // [n_nu][n]
   std::vector<double> cell_values;                               // [7][n]
   std::vector<unsigned char> sample_cut;
+  // polarized transfer: j_Q, j_V, alpha_Q, alpha_V, rho_Q, rho_V [n_nu][max_steps] and the sampled
+  // velocity / field of every sample (sample_uu1..bb3, zero where the sample was cut)
+  std::vector<double> pol[6];
+  std::vector<float> sample_ub;
+  void EnablePolarization(int max_steps, int n_nu) {
+    for (auto &v : pol) v.assign(static_cast<size_t>(n_nu) * max_steps, 0.0);
+    sample_ub.assign(6 * static_cast<size_t>(max_steps), 0.0f);
+  }
   explicit RayBuffers(int max_steps, int n_nu)
       : geodesic_pos(4 * static_cast<size_t>(max_steps)), geodesic_dir(4 * static_cast<size_t>(max_steps)),
         geodesic_len(max_steps), sample_pos(4 * static_cast<size_t>(max_steps)),
@@ -1337,11 +1353,156 @@ int SampleOne(const Oracle &o, const double pos[4], Prims *out, bool *gathered, 
   return 0;
 }
 
+// std::cyl_bessel_k(n, x) for n = 0, 1, 2 as libstdc++ 11 evaluates it (GCC 11.4,
+// <tr1/modified_bessel_func.tcc> __bessel_ik:75-258 through __cyl_bessel_k:305-318; the reference calls it at
+// simulation_coefficients.cpp:537-539): Temme's series for x < 2, Steed's continued fraction otherwise, then
+// upward recurrence. Only the K branch is restated: the continued fraction and recurrences for I_nu, which
+// the header evaluates in the same call, do not enter K_nu. For integer order mu = nu - nl = 0, so
+// __gamma_temme (bessel_function.tcc:100-119) gives gampl = gammi = 1 / tgamma(1) = 1, gam1 = -Euler's
+// constant, gam2 = 1. libm calls (log, sinh, cosh, exp) go through M:: like everywhere else.
+double CylBesselK(int nl, double x) {
+  if (std::isnan(x)) return std::numeric_limits<double>::quiet_NaN();
+  if (x == 0.0) return std::numeric_limits<double>::infinity();
+  const double eps = std::numeric_limits<double>::epsilon();
+  const int max_iter = 15000;
+  const double mu = 0.0, mu2 = 0.0;
+  const double xi = 1.0 / x;
+  const double xi2 = 2.0 * xi;
+  double kmu, knu1;
+  if (x < 2.0) {
+    const double x2 = x / 2.0;
+    const double pimu = Math::pi * mu;
+    const double fact = std::abs(pimu) < eps ? 1.0 : pimu / M::sin(pimu);
+    double d = -M::log(x2);
+    double e = mu * d;
+    const double fact2 = std::abs(e) < eps ? 1.0 : M::sinh(e) / e;
+    const double gam1 = -0.5772156649015328606065120900824024L, gam2 = 1.0, gampl = 1.0, gammi = 1.0;
+    double ff = fact * (gam1 * M::cosh(e) + gam2 * fact2 * d);
+    double sum = ff;
+    e = M::exp(e);
+    double pp = e / (2.0 * gampl);
+    double q = 1.0 / (2.0 * e * gammi);
+    double c = 1.0;
+    d = x2 * x2;
+    double sum1 = pp;
+    for (int i = 1; i <= max_iter; ++i) {
+      ff = (i * ff + pp + q) / (i * i - mu2);
+      c *= d / i;
+      pp /= i - mu;
+      q /= i + mu;
+      const double del = c * ff;
+      sum += del;
+      const double del1 = c * (pp - i * ff);
+      sum1 += del1;
+      if (std::abs(del) < eps * std::abs(sum)) break;
+    }
+    kmu = sum;
+    knu1 = sum1 * xi2;
+  } else {
+    double b = 2.0 * (1.0 + x);
+    double d = 1.0 / b;
+    double delh = d;
+    double h = delh;
+    double q1 = 0.0;
+    double q2 = 1.0;
+    double a1 = 0.25 - mu2;
+    double c = a1;
+    double q = c;
+    double a = -a1;
+    double s = 1.0 + q * delh;
+    for (int i = 2; i <= max_iter; ++i) {
+      a -= 2 * (i - 1);
+      c = -a * c / i;
+      const double qnew = (q1 - b * q2) / a;
+      q1 = q2;
+      q2 = qnew;
+      q += c * qnew;
+      b += 2.0;
+      d = 1.0 / (b + a * d);
+      delh = (b * d - 1.0) * delh;
+      h += delh;
+      const double dels = q * delh;
+      s += dels;
+      if (std::abs(dels / s) < eps) break;
+    }
+    h = a1 * h;
+    kmu = std::sqrt(Math::pi / (2.0 * x)) * M::exp(-x) / s;
+    knu1 = kmu * (mu + x + 0.5 - h) * xi;
+  }
+  for (int i = 1; i <= nl; ++i) {
+    const double knutemp = (mu + i) * xi2 * knu1 + kmu;
+    kmu = knu1;
+    knu1 = knutemp;
+  }
+  return kmu;
+}
+
+// radiation_geometry.cpp:274-412: Christoffel symbols of the Cartesian Kerr-Schild geodesic metric
+void GeodesicConnection(const Oracle &o, double x, double y, double z, double connection[4][4][4]) {
+  if (o.ray_flat) {
+    for (int mu = 0; mu < 4; mu++)
+      for (int alpha = 0; alpha < 4; alpha++)
+        for (int beta = 0; beta < 4; beta++) connection[mu][alpha][beta] = 0.0;
+    return;
+  }
+  double bh_a = o.bh_a, bh_m = o.bh_m;
+  double a2 = bh_a * bh_a;
+  double rr2 = x * x + y * y + z * z;
+  double r2 = 0.5 * (rr2 - a2 + M::hypot(rr2 - a2, 2.0 * bh_a * z));
+  double r = std::sqrt(r2);
+  double f = 2.0 * bh_m * r2 * r / (r2 * r2 + a2 * z * z);
+  double l[4] = {-1.0, (r * x + bh_a * y) / (r2 + a2), (r * y - bh_a * x) / (r2 + a2), z / r};
+  double gcon[4][4];
+  for (int mu = 0; mu < 4; mu++)
+    for (int nu = 0; nu < 4; nu++) gcon[mu][nu] = -f * l[mu] * l[nu] + (mu == nu ? (mu == 0 ? -1.0 : 1.0) : 0.0);
+  // the reference writes the off-diagonal entries without the "+ 0": same bits
+  for (int mu = 0; mu < 4; mu++)
+    for (int nu = 0; nu < 4; nu++)
+      if (mu != nu) gcon[mu][nu] = -f * l[mu] * l[nu];
+  gcon[0][0] = -f * l[0] * l[0] - 1.0;
+  double dr[4], df[4], dl[4][4];   // dr[a] = d r / d x^a, dl[mu][a] = d l_mu / d x^a (a = 1..3)
+  dr[1] = r * x / (2.0 * r2 - rr2 + a2);
+  dr[2] = r * y / (2.0 * r2 - rr2 + a2);
+  dr[3] = (r * z + a2 * z / r) / (2.0 * r2 - rr2 + a2);
+  df[1] = -(r2 * r2 - 3.0 * a2 * z * z) * dr[1] / (r * (r2 * r2 + a2 * z * z)) * f;
+  df[2] = -(r2 * r2 - 3.0 * a2 * z * z) * dr[2] / (r * (r2 * r2 + a2 * z * z)) * f;
+  df[3] = -((r2 * r2 - 3.0 * a2 * z * z) * dr[3] + 2.0 * a2 * r * z) / (r * (r2 * r2 + a2 * z * z)) * f;
+  for (int a = 1; a < 4; a++) dl[0][a] = 0.0;
+  dl[1][1] = ((x - 2.0 * r * l[1]) * dr[1] + r) / (r2 + a2);
+  dl[1][2] = ((x - 2.0 * r * l[1]) * dr[2] + bh_a) / (r2 + a2);
+  dl[1][3] = (x - 2.0 * r * l[1]) * dr[3] / (r2 + a2);
+  dl[2][1] = ((y - 2.0 * r * l[2]) * dr[1] - bh_a) / (r2 + a2);
+  dl[2][2] = ((y - 2.0 * r * l[2]) * dr[2] + r) / (r2 + a2);
+  dl[2][3] = (y - 2.0 * r * l[2]) * dr[3] / (r2 + a2);
+  dl[3][1] = -z / r2 * dr[1];
+  dl[3][2] = -z / r2 * dr[2];
+  dl[3][3] = -z / r2 * dr[3] + 1.0 / r;
+  // dgcov[a][mu][nu] = d g_{mu nu} / d x^a = +-(df l_mu l_nu + f dl_mu l_nu + f l_mu dl_nu): minus exactly when
+  // one of mu, nu is 0 (l_0 of the covariant null vector is +1, the table above holds the contravariant -1)
+  double dgcov[4][4][4] = {};
+  for (int a = 1; a < 4; a++)
+    for (int mu = 0; mu < 4; mu++)
+      for (int nu = 0; nu < 4; nu++) {
+        double val = df[a] * l[mu] * l[nu] + f * dl[mu][a] * l[nu] + f * l[mu] * dl[nu][a];
+        dgcov[a][mu][nu] = ((mu == 0) != (nu == 0)) ? -val : +val;
+      }
+  for (int mu = 0; mu < 4; mu++)
+    for (int alpha = 0; alpha < 4; alpha++)
+      for (int beta = 0; beta < 4; beta++) {
+        connection[mu][alpha][beta] = 0.0;
+        for (int nu = 0; nu < 4; nu++)
+          connection[mu][alpha][beta] +=
+              0.5 * gcon[mu][nu] * (dgcov[alpha][beta][nu] + dgcov[beta][alpha][nu] - dgcov[nu][alpha][beta]);
+      }
+}
+
 // simulation_coefficients.cpp:253-700 for one sample (thermal electrons, unpolarized outputs).
 // j[l], alpha[l] must be zero on entry (as after Array::Zero(), :226-229); cell[7] NaN on entry.
+// pol (polarized transfer only): the six arrays j_Q, j_V, alpha_Q, alpha_V, rho_Q, rho_V of this sample, same
+// stride between frequencies, zero on entry.
 void SimulationCoefficientsOne(const Oracle &o, const double pos[4], const double kcov_in[4],
                                const Prims &s, double momentum_factor, double *j, double *alpha,
-                               int stride, double cell[num_cell_values]) {
+                               int stride, double cell[num_cell_values], double *const pol[6] = nullptr) {
   const bl_params &p = *o.p;
   double d_unit = p.simulation_rho_cgs;  // :237-239
   double e_unit = d_unit * Physics::c * Physics::c;
@@ -1480,9 +1641,11 @@ void SimulationCoefficientsOne(const Oracle &o, const double pos[4], const doubl
   double cos2_theta_b = std::min(k_b_tet * k_b_tet / (k_sq_tet * b_sq_tet), 1.0);
   double sin2_theta_b = 1.0 - cos2_theta_b;
   double sin_theta_b = std::sqrt(sin2_theta_b);
+  double cos_theta_b = std::sqrt(cos2_theta_b) * (k_b_tet >= 0.0 ? 1.0 : -1.0);
+  const bool polarized = o.image_polarization and pol != nullptr;   // image_light and image_polarization
 
   int nf = p.image_num_frequencies;
-  for (int l = 0; l < nf; l++) {  // :458-524 (thermal, unpolarized)
+  for (int l = 0; l < nf; l++) {  // :458-605 (thermal and power-law electrons)
     double nu_cgs = 0.0;
     for (int mu = 0; mu < 4; mu++) nu_cgs -= kcov[mu] * ucon[mu];
     nu_cgs *= o.image_frequencies[l] * momentum_factor;
@@ -1502,14 +1665,60 @@ void SimulationCoefficientsOne(const Oracle &o, const double pos[4], const doubl
       double var_c = xx_1_2 + var_b * xx_1_6;
       j_i_val = coefficient * var_a * var_c * var_c;
       if (p.image_light or p.image_emission or p.image_emission_ave) j[l * stride] = j_i_val;
+      if (polarized) {  // :485-495
+        double var_d = (7.0 * M::pow(theta_e, 0.96) + 35.0) / (10.0 * M::pow(theta_e, 0.96) + 75.0) * var_b;
+        double var_e = xx_1_2 + var_d * xx_1_6;
+        double var_f = cos_theta_b / theta_e;
+        double var_g = Math::pi / 3.0 + Math::pi / 3.0 * xx_1_3 + 2.0 / 300.0 * xx_1_2
+            + 2.0 / 19.0 * Math::pi * xx_1_3 * xx_1_3;
+        pol[0][l * stride] = -coefficient * var_a * var_e * var_e;
+        pol[1][l * stride] = coefficient * var_f * var_g;
+      }
     }
     if (o.plasma_thermal_frac != 0.0) {
       double b_nu_nu_3_cgs = 2.0 * Physics::h / (Physics::c * Physics::c)
           / M::expm1(Physics::h * nu_cgs / kb_tt_e_cgs);
       if (p.image_light or p.image_tau or p.image_tau_int) alpha[l * stride] = j_i_val / b_nu_nu_3_cgs;
+      if (polarized) {
+        pol[2][l * stride] = pol[0][l * stride] / b_nu_nu_3_cgs;
+        pol[3][l * stride] = pol[1][l * stride] / b_nu_nu_3_cgs;
+      }
       if ((p.image_light or p.image_tau or p.image_tau_int)
-          and 1.0 / (alpha[l * stride] * alpha[l * stride]) == std::numeric_limits<double>::infinity())
+          and 1.0 / (alpha[l * stride] * alpha[l * stride]) == std::numeric_limits<double>::infinity()) {
         alpha[l * stride] = 0.0;
+        if (polarized) {
+          pol[2][l * stride] = 0.0;
+          pol[3][l * stride] = 0.0;
+        }
+      }
+    }
+    if (o.plasma_thermal_frac != 0.0 and polarized) {  // rotativities, :527-553
+      double coefficient_q = -o.plasma_thermal_frac * n_e_cgs * Physics::e * Physics::e * nu_c_cgs * nu_c_cgs
+          * sin2_theta_b / (Physics::m_e * Physics::c * nu_2_cgs);
+      double coefficient_v = o.plasma_thermal_frac * 2.0 * n_e_cgs * Physics::e * Physics::e * nu_c_cgs
+          * cos_theta_b / (Physics::m_e * Physics::c * nu_cgs);
+      double factor_q = 0.0;
+      double factor_v = 1.0;
+      if (theta_e >= 0.01) {   // theta_e_zero, radiation_integrator.hpp:190
+        double kk_0 = CylBesselK(0, 1.0 / theta_e);
+        double kk_1 = CylBesselK(1, 1.0 / theta_e);
+        double kk_2 = CylBesselK(2, 1.0 / theta_e);
+        double xx = nu_cgs / nu_s_cgs;
+        double xx_neg_1_2 = 1.0 / std::sqrt(xx);
+        double var_a = 2.011 * M::exp(-19.78 * M::pow(xx, -0.5175));
+        double var_b = M::cos(39.89 * xx_neg_1_2) * M::exp(-70.16 * M::pow(xx, -0.6));
+        double var_c = 0.011 * M::exp(-1.69 * xx_neg_1_2);
+        double var_d = 0.003135 * M::pow(xx, 4.0 / 3.0);
+        double var_e = 0.5 * (1.0 + M::tanh(10.0 * M::log(0.6648 * xx_neg_1_2)));
+        double f_0 = var_a - var_b - var_c;
+        double f_m = f_0 + (var_c - var_d) * var_e;
+        double delta_jj_5 = 0.4379 * M::log(1.0 + 1.3414 * M::pow(xx, -0.7515));
+        factor_q = f_m * (kk_1 / kk_2 + 6.0 * theta_e);
+        factor_v = (kk_0 - delta_jj_5) / kk_2;
+        factor_v = factor_v < 0.0 or factor_v > 1.0 ? 1.0 : factor_v;
+      }
+      pol[4][l * stride] = coefficient_q * factor_q;
+      pol[5][l * stride] = coefficient_v * factor_v;
     }
     // power-law electrons (:556-584, unpolarized part)
     if (p.plasma_power_frac != 0.0 and (p.image_light or p.image_emission or p.image_emission_ave)) {
@@ -1517,12 +1726,37 @@ void SimulationCoefficientsOne(const Oracle &o, const double pos[4], const doubl
       double coefficient = p.plasma_power_frac * n_e_cgs * Physics::e * Physics::e * nu_c_cgs
           / (Physics::c * nu_2_cgs) * o.power_jj * sin_theta_b * var_a;
       j[l * stride] += coefficient;
+      if (polarized) {
+        double var_b = cos_theta_b / sin_theta_b;
+        double var_c = 1.0 / std::sqrt(nu_cgs / (3.0 * nu_c_cgs * sin_theta_b));
+        pol[0][l * stride] += coefficient * o.power_pol[0];
+        pol[1][l * stride] += coefficient * o.power_pol[1] * var_b * var_c;
+      }
     }
     if (p.plasma_power_frac != 0.0 and (p.image_light or p.image_tau or p.image_tau_int)) {
       double var_a = M::pow(nu_cgs / (nu_c_cgs * sin_theta_b), -(p.plasma_p + 2.0) / 2.0);
       double coefficient = p.plasma_power_frac * n_e_cgs * Physics::e * Physics::e
           / (Physics::m_e * Physics::c) * o.power_aa * var_a;
       alpha[l * stride] += coefficient;
+      if (polarized) {
+        double var_b = M::pow(3.1 * M::pow(sin_theta_b, -1.92) - 3.1, 0.512);
+        double var_c = 1.0 / std::sqrt(nu_cgs / (nu_c_cgs * sin_theta_b));
+        double var_d = cos_theta_b >= 0.0 ? 1.0 : -1.0;
+        pol[2][l * stride] += coefficient * o.power_pol[2];
+        pol[3][l * stride] += coefficient * o.power_pol[3] * var_b * var_c * var_d;
+      }
+    }
+    if (p.plasma_power_frac != 0.0 and polarized) {  // :587-605
+      double var_a = n_e_cgs * Physics::e * Physics::e * nu_cgs / (Physics::m_e * Physics::c * nu_c_cgs * sin_theta_b);
+      double var_b = nu_c_cgs * sin_theta_b / nu_cgs;
+      double var_c = var_b * var_b;
+      double var_d = var_c * var_b;
+      double var_e = 1.0 - M::pow(2.0 * nu_c_cgs * p.plasma_gamma_min * p.plasma_gamma_min * sin_theta_b / (3.0 * nu_cgs),
+                                  p.plasma_p / 2.0 - 1.0);
+      double var_f = cos_theta_b / sin_theta_b;
+      double coefficient = p.plasma_power_frac * o.power_pol[4] * var_a;
+      pol[4][l * stride] += coefficient * o.power_pol[5] * var_d * var_e;
+      pol[5][l * stride] += coefficient * o.power_pol[6] * var_c * var_f;
     }
   }
 }
@@ -1678,6 +1912,444 @@ void IntegrateUnpolarizedOne(const Oracle &o, const RayBuffers &b, int num_steps
     }
 }
 
+// polarized.cpp:51-949 for one ray: the coherency tensor N^{mu nu} is parallel-transported along the ray
+// (half a step before and after every sample, connection and k^mu averaged with the previous sample's),
+// taken into the fluid's orthonormal tetrad, turned into Stokes parameters, coupled to the plasma over the
+// sample's length (rotation split from emission / absorption, or the joint analytic solution), put back, and
+// finally projected on the camera's tetrad. image_col as in IntegrateUnpolarizedOne; rows 4 l + {0..3} =
+// I, Q, U, V of frequency l. camera_pos / camera_dir: the pixel's initial position and momentum.
+void IntegratePolarizedOne(const Oracle &o, const RayBuffers &b, int num_steps, int max_steps,
+                           double momentum_factor, const double camera_pos[4], const double camera_dir[4],
+                           double *image_col) {
+  typedef std::complex<double> cplx;
+  const bl_params &p = *o.p;
+  const cplx imag_unit(0.0, 1.0);
+  constexpr double delta_tau_max = 100.0;  // radiation_integrator.hpp:191
+  int nf = p.image_num_frequencies;
+  double x_unit = Physics::gg_msun * o.mass_msun / (Physics::c * Physics::c);
+  double t_unit = x_unit / Physics::c;
+  for (int q = 0; q < o.image_num_quantities; q++) image_col[q] = 0.0;
+  if (num_steps <= 0) return;   // :94-96 (the image stays zero, also after the camera projection of a zero N)
+  for (int l = 0; l < nf; l++) {
+    double delta_lambda_old = 0.0;
+    double kcon_old[4];
+    double gcov[4][4], gcon[4][4], gcov_sim[4][4], gcon_sim[4][4], connection[4][4][4], connection_old[4][4][4];
+    double tetrad[4][4], jacobian[4][4];
+    cplx nn_con[4][4], nn_con_temp[4][4], nn_tet_cov[4][4], nn_tet_con[4][4];
+    for (int mu = 0; mu < 4; mu++)
+      for (int nu = 0; nu < 4; nu++) {
+        nn_con[mu][nu] = 0.0;
+        nn_con_temp[mu][nu] = 0.0;
+      }
+    double integrated_lambda = 0.0;
+    double integrated_emission = 0.0;
+    bool plane_sign = o.cam_x[1] * b.sample_pos[1] + o.cam_x[2] * b.sample_pos[2] + o.cam_x[3] * b.sample_pos[3] > 0.0;
+    int crossings_count = 0;
+    for (int n = 0; n < num_steps; n++) {
+      double delta_lambda = b.sample_len[n];
+      double delta_lambda_new = delta_lambda;
+      if (n < num_steps - 1) delta_lambda_new = b.sample_len[n + 1];
+      double delta_lambda_cgs = delta_lambda * x_unit / (o.image_frequencies[l] * momentum_factor);
+      double t_cgs = b.sample_pos[4 * n + 0] * t_unit;
+      double x1 = b.sample_pos[4 * n + 1], x2 = b.sample_pos[4 * n + 2], x3 = b.sample_pos[4 * n + 3];
+      double kcov[4] = {b.sample_dir[4 * n + 0], b.sample_dir[4 * n + 1], b.sample_dir[4 * n + 2], b.sample_dir[4 * n + 3]};
+      double uu1_sim = b.sample_ub[6 * n + 0], uu2_sim = b.sample_ub[6 * n + 1], uu3_sim = b.sample_ub[6 * n + 2];
+      double bb1_sim = b.sample_ub[6 * n + 3], bb2_sim = b.sample_ub[6 * n + 4], bb3_sim = b.sample_ub[6 * n + 5];
+
+      CovariantGeodesicMetric(o, x1, x2, x3, gcov);  // :152-166
+      ContravariantGeodesicMetric(o, x1, x2, x3, gcon);
+      GeodesicConnection(o, x1, x2, x3, connection);
+      for (int mu = 0; mu < 4; mu++)
+        for (int alpha = 0; alpha < 4; alpha++)
+          for (int beta = 0; beta < 4; beta++)
+            connection_old[mu][alpha][beta] = n == 0 ? connection[mu][alpha][beta]
+                : 0.5 * (connection_old[mu][alpha][beta] + connection[mu][alpha][beta]);
+      double kcon[4] = {};  // :169-178
+      for (int mu = 0; mu < 4; mu++)
+        for (int nu = 0; nu < 4; nu++) kcon[mu] += gcon[mu][nu] * kcov[nu];
+      for (int mu = 0; mu < 4; mu++) kcon_old[mu] = n == 0 ? kcon[mu] : 0.5 * (kcon_old[mu] + kcon[mu]);
+
+      double temp_a[4][4] = {};  // first half step of the transport, :181-198
+      for (int mu = 0; mu < 4; mu++)
+        for (int beta = 0; beta < 4; beta++)
+          for (int alpha = 0; alpha < 4; alpha++) temp_a[mu][beta] += kcon_old[alpha] * connection_old[mu][alpha][beta];
+      double delta_lambda_local = (delta_lambda_old + delta_lambda) / 2.0;
+      for (int mu = 0; mu < 4; mu++)
+        for (int nu = 0; nu < 4; nu++) {
+          cplx dnn_dlambda = 0.0;
+          for (int beta = 0; beta < 4; beta++)
+            dnn_dlambda -= temp_a[mu][beta] * nn_con[beta][nu] + temp_a[nu][beta] * nn_con[mu][beta];
+          nn_con_temp[mu][nu] += dnn_dlambda * delta_lambda_local;
+        }
+      for (int mu = 0; mu < 4; mu++)
+        for (int nu = 0; nu < 4; nu++) nn_con[mu][nu] = nn_con_temp[mu][nu];
+
+      CovariantSimulationMetric(o, x1, x2, x3, gcov_sim);  // :201-229
+      ContravariantSimulationMetric(o, x1, x2, x3, gcon_sim);
+      double uu0_sim = std::sqrt(1.0 + gcov_sim[1][1] * uu1_sim * uu1_sim
+          + 2.0 * gcov_sim[1][2] * uu1_sim * uu2_sim + 2.0 * gcov_sim[1][3] * uu1_sim * uu3_sim
+          + gcov_sim[2][2] * uu2_sim * uu2_sim + 2.0 * gcov_sim[2][3] * uu2_sim * uu3_sim
+          + gcov_sim[3][3] * uu3_sim * uu3_sim);
+      double lapse_sim = 1.0 / std::sqrt(-gcon_sim[0][0]);
+      double shift1_sim = -gcon_sim[0][1] / gcon_sim[0][0];
+      double shift2_sim = -gcon_sim[0][2] / gcon_sim[0][0];
+      double shift3_sim = -gcon_sim[0][3] / gcon_sim[0][0];
+      double ucon_sim[4];
+      ucon_sim[0] = uu0_sim / lapse_sim;
+      ucon_sim[1] = uu1_sim - shift1_sim * uu0_sim / lapse_sim;
+      ucon_sim[2] = uu2_sim - shift2_sim * uu0_sim / lapse_sim;
+      ucon_sim[3] = uu3_sim - shift3_sim * uu0_sim / lapse_sim;
+      double ucov_sim[4] = {};
+      for (int mu = 0; mu < 4; mu++)
+        for (int nu = 0; nu < 4; nu++) ucov_sim[mu] += gcov_sim[mu][nu] * ucon_sim[nu];
+      double bcon_sim[4];
+      bcon_sim[0] = ucov_sim[1] * bb1_sim + ucov_sim[2] * bb2_sim + ucov_sim[3] * bb3_sim;
+      bcon_sim[1] = (bb1_sim + bcon_sim[0] * ucon_sim[1]) / ucon_sim[0];
+      bcon_sim[2] = (bb2_sim + bcon_sim[0] * ucon_sim[2]) / ucon_sim[0];
+      bcon_sim[3] = (bb3_sim + bcon_sim[0] * ucon_sim[3]) / ucon_sim[0];
+
+      CoordinateJacobian(o, x1, x2, x3, jacobian);  // :232-256
+      double ucon[4] = {}, bcon[4] = {}, ucov[4] = {}, bcov[4] = {};
+      for (int mu = 0; mu < 4; mu++)
+        for (int nu = 0; nu < 4; nu++) ucon[mu] += jacobian[mu][nu] * ucon_sim[nu];
+      for (int mu = 0; mu < 4; mu++)
+        for (int nu = 0; nu < 4; nu++) bcon[mu] += jacobian[mu][nu] * bcon_sim[nu];
+      for (int mu = 0; mu < 4; mu++)
+        for (int nu = 0; nu < 4; nu++) ucov[mu] += gcov[mu][nu] * ucon[nu];
+      for (int mu = 0; mu < 4; mu++)
+        for (int nu = 0; nu < 4; nu++) bcov[mu] += gcov[mu][nu] * bcon[nu];
+      (void)bcov;
+      double upcon[4] = {};  // :259-265
+      if (bb1_sim == 0.0 and bb2_sim == 0.0 and bb3_sim == 0.0)
+        upcon[3] = 1.0;
+      else
+        for (int mu = 0; mu < 4; mu++) upcon[mu] = bcon[mu];
+      Tetrad(ucon, ucov, kcon, kcov, upcon, gcov, gcon, tetrad);
+
+      cplx temp_b[4][4] = {}, temp_c[4][4] = {}, temp_d[4][4] = {};  // N into the tetrad, :268-292
+      for (int nu = 0; nu < 4; nu++)
+        for (int alpha = 0; alpha < 4; alpha++)
+          for (int beta = 0; beta < 4; beta++) temp_b[nu][alpha] += gcov[nu][beta] * nn_con[alpha][beta];
+      for (int mu = 0; mu < 4; mu++)
+        for (int nu = 0; nu < 4; nu++)
+          for (int alpha = 0; alpha < 4; alpha++) temp_c[mu][nu] += gcov[mu][alpha] * temp_b[nu][alpha];
+      for (int bb = 0; bb < 4; bb++)
+        for (int mu = 0; mu < 4; mu++)
+          for (int nu = 0; nu < 4; nu++) temp_d[bb][mu] += tetrad[bb][nu] * temp_c[mu][nu];
+      for (int a = 0; a < 4; a++)
+        for (int bb = 0; bb < 4; bb++) {
+          nn_tet_cov[a][bb] = 0.0;
+          for (int mu = 0; mu < 4; mu++) nn_tet_cov[a][bb] += tetrad[a][mu] * temp_d[bb][mu];
+        }
+      double ss_start[4];
+      ss_start[0] = 0.5 * (nn_tet_cov[1][1] + nn_tet_cov[2][2]).real();
+      ss_start[1] = 0.5 * (nn_tet_cov[1][1] - nn_tet_cov[2][2]).real();
+      ss_start[2] = 0.5 * (nn_tet_cov[1][2] + nn_tet_cov[2][1]).real();
+      ss_start[3] = 0.5 * (nn_tet_cov[2][1] - nn_tet_cov[1][2]).imag();
+
+      size_t at = static_cast<size_t>(l) * max_steps + n;  // :295-315
+      double j_s[4] = {b.j_i[at], b.pol[0][at], 0.0, b.pol[1][at]};
+      double alpha_s[4] = {b.alpha_i[at], b.pol[2][at], 0.0, b.pol[3][at]};
+      double rho_s[4] = {0.0, b.pol[4][at], 0.0, b.pol[5][at]};
+      double delta_tau = alpha_s[0] * delta_lambda_cgs;
+      bool optically_thin = delta_tau <= delta_tau_max;
+
+      // alternative image quantities, :318-381
+      if (p.image_time and l == 0) image_col[o.image_offset_time] = std::min(image_col[o.image_offset_time], t_cgs);
+      if (p.image_length and l == 0) {
+        double temp_e[4] = {};
+        for (int a = 1; a < 4; a++)
+          for (int mu = 0; mu < 4; mu++) temp_e[a] += (gcon[a][mu] - gcon[0][a] * gcon[0][mu] / gcon[0][0]) * kcov[mu];
+        double dl_dlambda_sq = 0.0;
+        for (int a = 1; a < 4; a++)
+          for (int bb = 1; bb < 4; bb++) dl_dlambda_sq += gcov[a][bb] * temp_e[a] * temp_e[bb];
+        image_col[o.image_offset_length] += std::sqrt(dl_dlambda_sq) * delta_lambda * x_unit;
+      }
+      if (p.image_lambda or p.image_lambda_ave) integrated_lambda += delta_lambda_cgs;
+      if (p.image_emission or p.image_emission_ave) integrated_emission += j_s[0] * delta_lambda_cgs;
+      if (p.image_tau) image_col[o.image_offset_tau + l] += delta_tau;
+      const double *cell = &b.cell_values[n];
+      bool have_cell = not std::isnan(cell[0]);
+      if (p.image_lambda_ave and have_cell)
+        for (int a = 0; a < num_cell_values; a++)
+          image_col[o.image_offset_lambda_ave + l * num_cell_values + a] += cell[a * static_cast<size_t>(max_steps)] * delta_lambda_cgs;
+      if (p.image_emission_ave and have_cell)
+        for (int a = 0; a < num_cell_values; a++)
+          image_col[o.image_offset_emission_ave + l * num_cell_values + a] +=
+              cell[a * static_cast<size_t>(max_steps)] * j_s[0] * delta_lambda_cgs;
+      if (p.image_tau_int and have_cell) {
+        if (optically_thin) {
+          double exp_neg = M::exp(-delta_tau);
+          double expm1 = M::expm1(delta_tau);
+          for (int a = 0; a < num_cell_values; a++) {
+            int index = o.image_offset_tau_int + l * num_cell_values + a;
+            image_col[index] = exp_neg * (image_col[index] + cell[a * static_cast<size_t>(max_steps)] * expm1);
+          }
+        } else
+          for (int a = 0; a < num_cell_values; a++)
+            image_col[o.image_offset_tau_int + l * num_cell_values + a] = cell[a * static_cast<size_t>(max_steps)];
+      }
+      if (p.image_crossings and l == 0) {
+        bool plane_sign_new = o.cam_x[1] * x1 + o.cam_x[2] * x2 + o.cam_x[3] * x3 > 0.0;
+        if (plane_sign_new != plane_sign) crossings_count++;
+        plane_sign = plane_sign_new;
+      }
+
+      // coupling to the plasma, :384-790
+      double alpha_sq = alpha_s[1] * alpha_s[1] + alpha_s[3] * alpha_s[3];
+      double alpha_p = std::sqrt(alpha_sq);
+      double rho_sq = rho_s[1] * rho_s[1] + rho_s[3] * rho_s[3];
+      double rho_p = std::sqrt(rho_sq);
+      double ss_end[4] = {};
+      // emission and absorption over a length dl (I A14-A17 and its limits); shared by the split halves
+      // (dl = half the step) and the unsplit case without rotation (dl = the step)
+      auto absorb = [&](double dl, double dtau) {
+        if (alpha_s[0] == 0.0) {
+          for (int a = 0; a < 4; a++) ss_end[a] = ss_start[a] + j_s[a] * dl;
+        } else if (alpha_p == 0.0) {
+          if (optically_thin) {
+            double exp_neg = M::exp(-dtau);
+            double expm1 = M::expm1(dtau);
+            for (int a = 0; a < 4; a++) ss_end[a] = exp_neg * (ss_start[a] + j_s[a] / alpha_s[0] * expm1);
+          } else
+            for (int a = 0; a < 4; a++) ss_end[a] = j_s[a] / alpha_s[0];
+        } else if (optically_thin) {
+          double exp_neg_i = M::exp(-dtau);
+          double exp_neg_p = M::exp(-alpha_p * dl);
+          double sinh_p = M::sinh(alpha_p * dl);
+          double cosh_p = M::cosh(alpha_p * dl);
+          double coshm1_p = 0.5 * (M::expm1(alpha_p * dl) + exp_neg_p - 1.0);
+          double alpha_ss = alpha_s[1] * ss_start[1] + alpha_s[3] * ss_start[3];
+          double alpha_j = alpha_s[1] * j_s[1] + alpha_s[3] * j_s[3];
+          double alpha_i_p_factor = 1.0 / (alpha_s[0] * alpha_s[0] - alpha_sq);
+          ss_end[0] = (ss_start[0] * cosh_p - alpha_ss / alpha_p * sinh_p) * exp_neg_i
+              + alpha_j * alpha_i_p_factor * (-1.0 + (alpha_s[0] * sinh_p + alpha_p * cosh_p) / alpha_p * exp_neg_p)
+              + alpha_s[0] * j_s[0] * alpha_i_p_factor * (1.0 - (alpha_s[0] * cosh_p + alpha_p * sinh_p) / alpha_s[0] * exp_neg_p);
+          for (int a = 1; a < 4; a++) {
+            double term_1 = (ss_start[a] + alpha_s[a] * alpha_ss / alpha_sq * coshm1_p
+                - ss_start[0] * alpha_s[a] / alpha_p * sinh_p) * exp_neg_i;
+            double term_2 = j_s[a] * (1.0 - exp_neg_i) / alpha_s[0];
+            double term_3 = alpha_j * alpha_s[a] / alpha_s[0] * alpha_i_p_factor * (1.0 - (1.0
+                - alpha_s[0] * alpha_s[0] / alpha_sq - alpha_s[0] / alpha_sq * (alpha_s[0] * cosh_p + alpha_p * sinh_p)) * exp_neg_i);
+            double term_4 = j_s[0] * alpha_s[a] / alpha_p * alpha_i_p_factor * (-alpha_p
+                + (alpha_p * cosh_p + alpha_s[0] * sinh_p) * exp_neg_i);
+            ss_end[a] = term_1 + term_2 + term_3 + term_4;
+          }
+        } else {
+          double alpha_j = alpha_s[1] * j_s[1] + alpha_s[3] * j_s[3];
+          ss_end[0] = (alpha_s[0] * j_s[0] - alpha_j) / (alpha_s[0] * alpha_s[0] - alpha_sq);
+          for (int a = 1; a < 4; a++) ss_end[a] = (j_s[a] - alpha_s[a] * ss_end[0]) / alpha_s[0];
+        }
+      };
+      // Faraday rotation and conversion over the whole step without absorption (I A2-A5)
+      auto rotate = [&]() {
+        double cos_rho = M::cos(rho_p * delta_lambda_cgs);
+        double sin_rho = M::sin(rho_p * delta_lambda_cgs);
+        double sin_sq_rho = M::sin(rho_p * delta_lambda_cgs / 2.0);
+        sin_sq_rho = sin_sq_rho * sin_sq_rho;
+        double rho_ss = rho_s[1] * ss_start[1] + rho_s[3] * ss_start[3];
+        ss_end[0] = ss_start[0];
+        ss_end[1] = ss_start[1] * cos_rho + 2.0 * rho_s[1] * rho_ss / rho_sq * sin_sq_rho - rho_s[3] * ss_start[2] / rho_p * sin_rho;
+        ss_end[2] = ss_start[2] * cos_rho + (rho_s[3] * ss_start[1] - rho_s[1] * ss_start[3]) / rho_p * sin_rho;
+        ss_end[3] = ss_start[3] * cos_rho + 2.0 * rho_s[3] * rho_ss / rho_sq * sin_sq_rho + rho_s[1] * ss_start[2] / rho_p * sin_rho;
+      };
+      auto limit_polarization = [&]() {
+        double ss_pol = ss_end[1] * ss_end[1] + ss_end[2] * ss_end[2] + ss_end[3] * ss_end[3];
+        if (ss_pol > ss_end[0] * ss_end[0]) {
+          double factor = std::sqrt(ss_end[0] * ss_end[0] / ss_pol);
+          ss_end[1] *= factor;
+          ss_end[2] *= factor;
+          ss_end[3] *= factor;
+        }
+      };
+      if (p.image_rotation_split) {  // :388-568
+        absorb(delta_lambda_cgs / 2.0, delta_tau / 2.0);
+        ss_end[0] = std::max(ss_end[0], 0.0);
+        limit_polarization();
+        for (int a = 0; a < 4; a++) ss_start[a] = ss_end[a];
+        if (rho_p != 0.0) rotate();
+        limit_polarization();
+        for (int a = 0; a < 4; a++) ss_start[a] = ss_end[a];
+        absorb(delta_lambda_cgs / 2.0, delta_tau / 2.0);
+      } else if (alpha_s[0] == 0.0 and rho_p == 0.0) {  // :571-577
+        for (int a = 0; a < 4; a++) ss_end[a] = ss_start[a] + j_s[a] * delta_lambda_cgs;
+      } else if (alpha_p == 0.0 and rho_p == 0.0) {
+        absorb(delta_lambda_cgs, delta_tau);
+      } else if (alpha_s[0] == 0.0) {  // :598-615
+        rotate();
+        for (int a = 0; a < 4; a++) ss_end[a] += j_s[a] * delta_lambda_cgs;
+      } else if (rho_p == 0.0) {
+        absorb(delta_lambda_cgs, delta_tau);
+      } else {  // absorption and rotation together (L 10, I 24), :657-778
+        double alpha_rho = alpha_s[1] * rho_s[1] + alpha_s[3] * rho_s[3];
+        double alpha_sq_rho_sq = alpha_sq - rho_sq;
+        double lambda_a = std::sqrt(alpha_sq_rho_sq * alpha_sq_rho_sq / 4.0 + alpha_rho * alpha_rho);
+        double lambda_b = alpha_sq_rho_sq / 2.0;
+        double lambda_1 = std::sqrt(lambda_a + lambda_b);
+        double lambda_2 = std::sqrt(lambda_a - lambda_b);
+        double coefficient_theta = lambda_1 * lambda_1 + lambda_2 * lambda_2;
+        double sg = alpha_rho >= 0.0 ? 1.0 : -1.0;
+        double mm_1[4][4] = {}, mm_2[4][4] = {}, mm_3[4][4] = {}, mm_4[4][4] = {};
+        for (int a = 0; a < 4; a++) mm_1[a][a] = 1.0;
+        // as written in the reference: [1][2] is assigned twice and [1][3], [0][2], [2][3] stay zero
+        mm_2[0][1] = lambda_2 * alpha_s[1] - sg * lambda_1 * rho_s[1];
+        mm_2[0][3] = lambda_2 * alpha_s[3] - sg * lambda_1 * rho_s[3];
+        mm_2[1][2] = sg * lambda_1 * alpha_s[3] + lambda_2 * rho_s[3];
+        mm_2[1][2] = sg * lambda_1 * alpha_s[1] + lambda_2 * rho_s[1];
+        mm_2[1][0] = mm_2[0][1];
+        mm_2[2][0] = mm_2[0][2];
+        mm_2[3][0] = mm_2[0][3];
+        mm_2[2][1] = -mm_2[1][2];
+        mm_2[3][1] = -mm_2[1][3];
+        mm_2[3][2] = -mm_2[2][3];
+        for (int a = 0; a < 4; a++)
+          for (int bb = 0; bb < 4; bb++) mm_2[a][bb] *= 1.0 / coefficient_theta;
+        mm_3[0][1] = lambda_1 * alpha_s[1] + sg * lambda_2 * rho_s[1];
+        mm_3[0][3] = lambda_1 * alpha_s[3] + sg * lambda_2 * rho_s[3];
+        mm_3[1][2] = -(sg * lambda_2 * alpha_s[3] - lambda_1 * rho_s[3]);
+        mm_3[1][2] = -(sg * lambda_2 * alpha_s[1] - lambda_1 * rho_s[1]);
+        mm_3[1][0] = mm_3[0][1];
+        mm_3[2][0] = mm_3[0][2];
+        mm_3[3][0] = mm_3[0][3];
+        mm_3[2][1] = -mm_3[1][2];
+        mm_3[3][1] = -mm_3[1][3];
+        mm_3[3][2] = -mm_3[2][3];
+        for (int a = 0; a < 4; a++)
+          for (int bb = 0; bb < 4; bb++) mm_3[a][bb] *= 1.0 / coefficient_theta;
+        mm_4[0][0] = (alpha_sq + rho_sq) / 2.0;
+        mm_4[1][1] = alpha_s[1] * alpha_s[1] + rho_s[1] * rho_s[1] - (alpha_sq + rho_sq) / 2.0;
+        mm_4[2][2] = -(alpha_sq + rho_sq) / 2.0;
+        mm_4[3][3] = alpha_s[3] * alpha_s[3] + rho_s[3] * rho_s[3] - (alpha_sq + rho_sq) / 2.0;
+        mm_4[0][2] = alpha_s[1] * rho_s[3] - alpha_s[3] * rho_s[1];
+        mm_4[1][3] = alpha_s[3] * alpha_s[1] + rho_s[3] * rho_s[1];
+        mm_4[1][0] = -mm_4[0][1];
+        mm_4[2][0] = -mm_4[0][2];
+        mm_4[3][0] = -mm_4[0][3];
+        mm_4[2][1] = mm_4[1][2];
+        mm_4[3][1] = mm_4[1][3];
+        mm_4[3][2] = mm_4[2][3];
+        for (int a = 0; a < 4; a++)
+          for (int bb = 0; bb < 4; bb++) mm_4[a][bb] *= 2.0 / coefficient_theta;
+        double exp_v = 0.0, sin_v = 0.0, cos_v = 0.0, sinh_v = 0.0, cosh_v = 0.0;
+        double oo[4][4] = {}, pp[4][4] = {};
+        if (optically_thin) {
+          exp_v = M::exp(-delta_tau);
+          sin_v = M::sin(lambda_2 * delta_lambda_cgs);
+          cos_v = M::cos(lambda_2 * delta_lambda_cgs);
+          sinh_v = M::sinh(lambda_1 * delta_lambda_cgs);
+          cosh_v = M::cosh(lambda_1 * delta_lambda_cgs);
+          for (int a = 0; a < 4; a++)
+            for (int bb = 0; bb < 4; bb++)
+              oo[a][bb] = exp_v * (0.5 * (mm_1[a][bb] + mm_4[a][bb]) * cosh_v + 0.5 * (mm_1[a][bb] - mm_4[a][bb]) * cos_v
+                  - mm_2[a][bb] * sin_v - mm_3[a][bb] * sinh_v);
+        }
+        double f_1 = 1.0 / (alpha_s[0] * alpha_s[0] - lambda_1 * lambda_1);
+        double f_2 = 1.0 / (alpha_s[0] * alpha_s[0] + lambda_2 * lambda_2);
+        for (int a = 0; a < 4; a++)
+          for (int bb = 0; bb < 4; bb++) {
+            double cosh_term = -lambda_1 * f_1 * mm_3[a][bb] + 0.5 * alpha_s[0] * f_1 * (mm_1[a][bb] + mm_4[a][bb]);
+            double cos_term = -lambda_2 * f_2 * mm_2[a][bb] + 0.5 * alpha_s[0] * f_2 * (mm_1[a][bb] - mm_4[a][bb]);
+            pp[a][bb] = cosh_term + cos_term;
+            if (optically_thin) {
+              double sin_term = -alpha_s[0] * f_2 * mm_2[a][bb] - 0.5 * lambda_2 * f_2 * (mm_1[a][bb] - mm_4[a][bb]);
+              double sinh_term = -alpha_s[0] * f_1 * mm_3[a][bb] + 0.5 * lambda_1 * f_1 * (mm_1[a][bb] + mm_4[a][bb]);
+              pp[a][bb] -= exp_v * (cosh_term * cosh_v + cos_term * cos_v + sin_term * sin_v + sinh_term * sinh_v);
+            }
+          }
+        if (optically_thin) {
+          for (int a = 0; a < 4; a++)
+            for (int bb = 0; bb < 4; bb++) ss_end[a] += pp[a][bb] * j_s[bb] + oo[a][bb] * ss_start[bb];
+        } else
+          for (int a = 0; a < 4; a++)
+            for (int bb = 0; bb < 4; bb++) ss_end[a] += pp[a][bb] * j_s[bb];
+      }
+      ss_end[0] = std::max(ss_end[0], 0.0);  // :781-790
+      limit_polarization();
+
+      for (int mu = 0; mu < 4; mu++)  // back to coordinates, :793-813
+        for (int nu = 0; nu < 4; nu++) nn_tet_con[mu][nu] = 0.0;
+      nn_tet_con[1][1] = ss_end[0] + ss_end[1];
+      nn_tet_con[2][2] = ss_end[0] - ss_end[1];
+      nn_tet_con[1][2] = ss_end[2] - imag_unit * ss_end[3];
+      nn_tet_con[2][1] = ss_end[2] + imag_unit * ss_end[3];
+      cplx temp_f[4][4] = {};
+      for (int nu = 0; nu < 4; nu++)
+        for (int a = 0; a < 4; a++)
+          for (int bb = 0; bb < 4; bb++) temp_f[nu][a] += tetrad[bb][nu] * nn_tet_con[a][bb];
+      for (int mu = 0; mu < 4; mu++)
+        for (int nu = 0; nu < 4; nu++) {
+          nn_con[mu][nu] = 0.0;
+          for (int a = 0; a < 4; a++) nn_con[mu][nu] += tetrad[a][mu] * temp_f[nu][a];
+        }
+
+      for (int mu = 0; mu < 4; mu++)  // second half step, :816-833
+        for (int nu = 0; nu < 4; nu++) nn_con_temp[mu][nu] = nn_con[mu][nu];
+      double temp_g[4][4] = {};
+      for (int mu = 0; mu < 4; mu++)
+        for (int beta = 0; beta < 4; beta++)
+          for (int alpha = 0; alpha < 4; alpha++) temp_g[mu][beta] += kcon[alpha] * connection[mu][alpha][beta];
+      delta_lambda_local = (delta_lambda + delta_lambda_new) / 4.0;
+      for (int mu = 0; mu < 4; mu++)
+        for (int nu = 0; nu < 4; nu++) {
+          cplx dnn_dlambda = 0.0;
+          for (int beta = 0; beta < 4; beta++)
+            dnn_dlambda -= temp_g[mu][beta] * nn_con_temp[beta][nu] + temp_g[nu][beta] * nn_con_temp[mu][beta];
+          nn_con[mu][nu] += dnn_dlambda * delta_lambda_local;
+        }
+      delta_lambda_old = delta_lambda;  // :836-843
+      for (int mu = 0; mu < 4; mu++) kcon_old[mu] = kcon[mu];
+      for (int mu = 0; mu < 4; mu++)
+        for (int alpha = 0; alpha < 4; alpha++)
+          for (int beta = 0; beta < 4; beta++) connection_old[mu][alpha][beta] = connection[mu][alpha][beta];
+    }
+
+    if (p.image_lambda) image_col[o.image_offset_lambda + l] = integrated_lambda;  // :852-872
+    if (p.image_emission) image_col[o.image_offset_emission + l] = integrated_emission;
+    if (p.image_crossings and l == 0) image_col[o.image_offset_crossings] = static_cast<double>(crossings_count);
+    if (p.image_lambda_ave)
+      for (int a = 0; a < num_cell_values; a++) image_col[o.image_offset_lambda_ave + l * num_cell_values + a] /= integrated_lambda;
+    if (p.image_emission_ave)
+      for (int a = 0; a < num_cell_values; a++) image_col[o.image_offset_emission_ave + l * num_cell_values + a] /= integrated_emission;
+
+    // projection on the camera's tetrad, :875-949
+    double x = camera_pos[1], y = camera_pos[2], z = camera_pos[3];
+    double kcov[4] = {camera_dir[0], camera_dir[1], camera_dir[2], camera_dir[3]};
+    CovariantGeodesicMetric(o, x, y, z, gcov);
+    ContravariantGeodesicMetric(o, x, y, z, gcon);
+    double kcon[4] = {};
+    for (int mu = 0; mu < 4; mu++)
+      for (int nu = 0; nu < 4; nu++) kcon[mu] += gcon[mu][nu] * kcov[nu];
+    double up_con[4];
+    up_con[0] = o.u_con[0] * o.vert_con_c[0]
+        - (o.u_cov[1] * o.vert_con_c[1] + o.u_cov[2] * o.vert_con_c[2] + o.u_cov[3] * o.vert_con_c[3]) / o.u_cov[0];
+    up_con[1] = o.vert_con_c[1] + o.u_con[1] * o.vert_con_c[0];
+    up_con[2] = o.vert_con_c[2] + o.u_con[2] * o.vert_con_c[0];
+    up_con[3] = o.vert_con_c[3] + o.u_con[3] * o.vert_con_c[0];
+    Tetrad(o.u_con, o.u_cov, kcon, kcov, up_con, gcov, gcon, tetrad);
+    cplx temp_a[4][4] = {}, temp_b[4][4] = {}, temp_c[4][4] = {};
+    for (int nu = 0; nu < 4; nu++)
+      for (int alpha = 0; alpha < 4; alpha++)
+        for (int beta = 0; beta < 4; beta++) temp_a[nu][alpha] += gcov[nu][beta] * nn_con[alpha][beta];
+    for (int mu = 0; mu < 4; mu++)
+      for (int nu = 0; nu < 4; nu++)
+        for (int alpha = 0; alpha < 4; alpha++) temp_b[mu][nu] += gcov[mu][alpha] * temp_a[nu][alpha];
+    for (int bb = 0; bb < 4; bb++)
+      for (int mu = 0; mu < 4; mu++)
+        for (int nu = 0; nu < 4; nu++) temp_c[bb][mu] += tetrad[bb][nu] * temp_b[mu][nu];
+    for (int a = 0; a < 4; a++)
+      for (int bb = 0; bb < 4; bb++) {
+        nn_tet_cov[a][bb] = 0.0;
+        for (int mu = 0; mu < 4; mu++) nn_tet_cov[a][bb] += tetrad[a][mu] * temp_c[bb][mu];
+      }
+    double nu_cu = o.image_frequencies[l] * o.image_frequencies[l] * o.image_frequencies[l];
+    image_col[l * 4 + 0] = 0.5 * (nn_tet_cov[1][1] + nn_tet_cov[2][2]).real() * nu_cu;
+    image_col[l * 4 + 1] = 0.5 * (nn_tet_cov[1][1] - nn_tet_cov[2][2]).real() * nu_cu;
+    image_col[l * 4 + 2] = 0.5 * (nn_tet_cov[1][2] + nn_tet_cov[2][1]).real() * nu_cu;
+    image_col[l * 4 + 3] = 0.5 * (nn_tet_cov[2][1] - nn_tet_cov[1][2]).imag() * nu_cu;
+  }
+}
+
+
 // rendering.cpp:25-179 for one pixel. render_col[3 * n_i + c] = render(n_i, c, m).
 void RenderOne(const Oracle &o, const RayBuffers &b, int num_steps, int max_steps, double *render_col) {
   const bl_params &p = *o.p;
@@ -1792,7 +2464,6 @@ int Setup(Oracle &o, const bl_params *p, const bl_grid_desc *g, char *err, size_
   else
     o.r_terminate = o.r_horizon + p->ray_factor;
   o.image_polarization = p->model_type == BL_MODEL_SIMULATION and p->image_light and p->image_polarization;
-  if (o.image_polarization) return Fail(err, err_len, "oracle: polarized transfer not restated yet", BL_E_UNSUPPORTED);
   if (p->model_type == BL_MODEL_SIMULATION) {
     if (g == nullptr) return Fail(err, err_len, "oracle: simulation mode needs a grid", BL_E_ARG);
     if (p->simulation_block_interp) return Fail(err, err_len, "oracle: inter-block interpolation not restated (out-of-bounds read in the reference)", BL_E_UNSUPPORTED);
@@ -1815,6 +2486,18 @@ int Setup(Oracle &o, const bl_params *p, const bl_grid_desc *g, char *err, size_
       double var_h = std::tgamma((3.0 * plasma_p + 22.0) / 12.0);
       o.power_jj = var_a / var_b / var_c * var_d * var_e;
       o.power_aa = var_f / var_c * var_g * var_h;
+      if (o.image_polarization) {
+        double var_i = 2.0 * (plasma_p + 2.0) / (plasma_p + 1.0);
+        double var_j = M::pow(p->plasma_gamma_min, -(plasma_p + 1.0));
+        double var_k = M::log(p->plasma_gamma_min);
+        o.power_pol[0] = -(plasma_p + 1.0) / (plasma_p + 7.0 / 3.0);
+        o.power_pol[1] = 0.684 * M::pow(plasma_p, 0.49);
+        o.power_pol[2] = -M::pow(0.034 * plasma_p - 0.0344, 0.086);
+        o.power_pol[3] = M::pow(0.71 * plasma_p + 0.0352, 0.394);
+        o.power_pol[4] = (plasma_p - 1.0) / var_c;
+        o.power_pol[5] = -M::pow(p->plasma_gamma_min, 2.0 - plasma_p) / (plasma_p / 2.0 - 1.0);
+        o.power_pol[6] = var_i * var_j * var_k;
+      }
     }
   } else
     o.plasma_thermal_frac = 0.0;
@@ -1893,6 +2576,7 @@ int blo_render(const bl_params *p, const bl_grid_desc *g, const bl_render_desc *
   #pragma omp parallel num_threads(num_threads) reduction(+: total_samples, total_gathers, total_flagged, count_0, count_1, count_2, count_3) reduction(max: max_sample_num, val_0, val_1, val_2, val_3)
   {
     RayBuffers b(max_steps, nf);
+    if (o.image_polarization) b.EnablePolarization(max_steps, nf);
     BlockState block_state;   // per thread, kept across rays like the reference's (which rays share a thread
                               // differs, and only matters for a sample exactly on a face shared by two blocks)
     std::vector<double> image_col(std::max(n_q, 1));
@@ -1940,6 +2624,12 @@ int blo_render(const bl_params *p, const bl_grid_desc *g, const bl_render_desc *
         for (int n = 0; n < sample_num; n++)
           b.cell_values[a * static_cast<size_t>(max_steps) + n] = std::numeric_limits<double>::quiet_NaN();
       const double nan = std::numeric_limits<double>::quiet_NaN();
+      if (o.image_polarization) {   // Zero() of the polarized coefficient and sample arrays
+        for (auto &v : b.pol)
+          for (int l = 0; l < nf; l++)
+            for (int n = 0; n < sample_num; n++) v[static_cast<size_t>(l) * max_steps + n] = 0.0;
+        for (int n = 0; n < 6 * sample_num; n++) b.sample_ub[n] = 0.0f;
+      }
       if (simulation) {
         bool nan_ray = p->fallback_nan and flag;  // simulation_sampling.cpp:211-216
         for (int e = 0; e < 4; e++) {
@@ -1966,8 +2656,14 @@ int blo_render(const bl_params *p, const bl_grid_desc *g, const bl_render_desc *
           }
           double cell[num_cell_values];
           for (int a = 0; a < num_cell_values; a++) cell[a] = nan;
+          double *pol[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+          if (o.image_polarization) {
+            for (int c = 0; c < 6; c++) pol[c] = &b.pol[c][n];
+            const float ub[6] = {s.uu1, s.uu2, s.uu3, s.bb1, s.bb2, s.bb3};
+            for (int c = 0; c < 6; c++) b.sample_ub[6 * n + c] = ub[c];
+          }
           SimulationCoefficientsOne(o, &b.sample_pos[4 * n], &b.sample_dir[4 * n], s, factor,
-                                    &b.j_i[n], &b.alpha_i[n], max_steps, cell);
+                                    &b.j_i[n], &b.alpha_i[n], max_steps, cell, o.image_polarization ? pol : nullptr);
           for (int a = 0; a < num_cell_values; a++) b.cell_values[a * static_cast<size_t>(max_steps) + n] = cell[a];
         }
         if (block_state.extrap[0]) { count_0++; val_0 = std::max(val_0, block_state.extrap_val[0]); }   // :553-575
@@ -1985,7 +2681,10 @@ int blo_render(const bl_params *p, const bl_grid_desc *g, const bl_render_desc *
             FormulaCoefficientsOne(o, &b.sample_pos[4 * n], &b.sample_dir[4 * n], factor, &b.j_i[n],
                                    &b.alpha_i[n], max_steps);
       }
-      IntegrateUnpolarizedOne(o, b, sample_num, max_steps, factor, image_col.data());
+      if (o.image_polarization)
+        IntegratePolarizedOne(o, b, sample_num, max_steps, factor, cpos, cdir, image_col.data());
+      else
+        IntegrateUnpolarizedOne(o, b, sample_num, max_steps, factor, image_col.data());
       if (d->image != nullptr)
         for (int q = 0; q < n_q; q++) d->image[static_cast<size_t>(q) * n_rays + ray] = image_col[q];
       if (o.render_num_images > 0 && d->render != nullptr) {

@@ -180,7 +180,12 @@ def expected_image(fx, tier, n_pix):
     rows = []
     for name in IMAGE_ROW_NAMES:
         key = f"{tier}_npz_{name}"
-        if key in fx.files:
+        if key not in fx.files:
+            continue
+        if name == "I_nu" and f"{tier}_npz_Q_nu" in fx.files:   # polarized: rows 4 l + (I, Q, U, V)
+            stokes = [fx[f"{tier}_npz_{s}_nu"].reshape(-1, n_pix) for s in "IQUV"]
+            rows.append(np.stack(stokes, axis=1).reshape(-1, n_pix))
+        else:
             rows.append(fx[key].reshape(-1, n_pix))
     if not rows:
         return np.zeros((0, n_pix))

@@ -114,6 +114,30 @@ CASES = {
     "sim_refined_nearest": (SIM_BASE, dict(camera_resolution=24, simulation_interp="false", simulation_a=0.5,
                                            plasma_model="code_kappa", simulation_kappa_name="r0"),
                             dict(SMALL_MOCK, _entropy=1, _refined=1), [300]),
+    # polarized transfer (polarized.cpp): joint analytic coupling, rotation split (two frequencies, spin),
+    # power-law electrons next to thermal ones with every auxiliary image, and refined levels
+    "sim_polarized": (SIM_BASE, dict(camera_resolution=24, image_polarization="true", image_tau="true"), SMALL_MOCK, [300]),
+    "sim_polarized_split": (SIM_BASE, dict(camera_resolution=16, image_polarization="true", image_rotation_split="true",
+                                           simulation_a=0.5, image_num_frequencies=2, image_frequency_start=1.0e11,
+                                           image_frequency_end=3.0e11, image_frequency_spacing="log",
+                                           camera_type="pinhole", camera_r=40.0, camera_width=20.0,
+                                           image_normalization="camera", camera_urn=-0.03, camera_uphn=0.004,
+                                           camera_rotation=20.0), SMALL_MOCK, [136]),
+    "sim_polarized_powerlaw": (SIM_BASE, dict(camera_resolution=16, image_polarization="true", plasma_power_frac=0.3,
+                                              plasma_p=2.5, plasma_gamma_min=2.0, plasma_gamma_max=1000.0,
+                                              image_time="true", image_length="true", image_lambda="true",
+                                              image_emission="true", image_tau="true", image_lambda_ave="true",
+                                              image_emission_ave="true", image_tau_int="true", image_crossings="true",
+                                              simulation_interp="false", fallback_nan="false", fallback_rho=1.0e-6,
+                                              fallback_pgas=1.0e-8, simulation_a=0.9), SMALL_MOCK, [136]),
+    "sim_polarized_adaptive": (SIM_BASE, dict(camera_resolution=16, image_polarization="true", adaptive_max_level=1,
+                                              adaptive_block_size=4, adaptive_val_cut=0.0, adaptive_val_frac=-1.0,
+                                              adaptive_abs_grad_cut=0.0, adaptive_abs_grad_frac=-1.0,
+                                              adaptive_rel_grad_cut=0.0, adaptive_rel_grad_frac=-1.0,
+                                              adaptive_abs_lapl_cut=0.0, adaptive_abs_lapl_frac=-1.0,
+                                              adaptive_rel_lapl_cut=1.0, adaptive_rel_lapl_frac=0.25,
+                                              adaptive_num_regions=0, image_tau="true", output_camera="true"),
+                               SMALL_MOCK, [136]),
     "sim_powerlaw": (SIM_BASE, dict(camera_resolution=24, plasma_power_frac=0.3, plasma_p=2.5, plasma_gamma_min=1.0,
                                     plasma_gamma_max=1000.0), SMALL_MOCK, [300]),
     # false-colour renderings (rendering.cpp): the features of the reference's example_render.input, without
