@@ -28,6 +28,7 @@ extern "C" hipError_t bl_launch_locate(const BlShadeArgs *args, int grid, int ld
 extern "C" hipError_t bl_launch_shade(const BlShadeArgs *args, int model, int grid, hipStream_t stream);
 extern "C" hipError_t bl_launch_transfer(const BlTransferArgs *args, hipStream_t stream);
 extern "C" hipError_t bl_launch_transfer_aux(const BlTransferArgs *args, hipStream_t stream);
+extern "C" hipError_t bl_launch_transfer_polarized(const BlTransferArgs *args, hipStream_t stream);
 extern "C" hipError_t bl_launch_debug_math(int op, long long n, const double *x, const double *y, double *out, hipStream_t stream);
 
 namespace {
@@ -113,6 +114,8 @@ struct bl_ctx {
   };
   std::vector<SlowSlice> slow_slices;
   bl_slow_state slow_state{};            // reader-side bookkeeping of bl_slow_light_read (bl_snapshot.cpp)
+  bool polarized = false;                // image_light and image_polarization in simulation mode
+  double power_pol[7] = {};              // polarized power-law constants (simulation_coefficients.cpp:67-80)
   int snapshot = 0;                      // index of the image being rendered (warning texts, camera time)
   long long stats_slow_count[4] = {0, 0, 0, 0};    // pixels needing extrapolation in the last render, by kind
   double stats_slow_val[4] = {0.0, 0.0, 0.0, 0.0};
@@ -132,8 +135,10 @@ struct bl_ctx {
     DeviceBuffer<BlAuxSample> d_aux;               // auxiliary-image mode
     DeviceBuffer<double> d_sample_t;               // image_time, slow light
     DeviceBuffer<double> d_slow_frac;              // slow light: t_frac of every located sample
+    DeviceBuffer<BlPolSample> d_pol_samples;       // polarized transfer
+    DeviceBuffer<double2> d_pol_coeffs;
     void Free() {
-      d_aux.Free(); d_sample_t.Free(); d_slow_frac.Free();
+      d_aux.Free(); d_sample_t.Free(); d_slow_frac.Free(); d_pol_samples.Free(); d_pol_coeffs.Free();
       d_records.Free(); d_located.Free(); d_transfer.Free(); d_ray_kt.Free(); d_ray_factor.Free();
       d_ray_sample_num.Free(); d_ray_flags.Free(); d_ray_out_index.Free(); d_counters.Free();
     }
@@ -335,8 +340,7 @@ void ValidateRadiation(bl_ctx *ctx) {
       if ((has & need) != need) throw Failure{BL_E_MISSING, kRadMissing};
     }
   }
-  if (polarization)
-    throw Failure{BL_E_UNSUPPORTED, "image_polarization = true (polarized transfer) is not built yet."};
+  ctx->polarized = polarization;
   if (simulation) {
     Require(p, {BL_P_slow_light_on}, kRadMissing);
     if (p.slow_light_on) {   // radiation_integrator.cpp:206-215
@@ -415,7 +419,8 @@ void ValidateRadiation(bl_ctx *ctx) {
   A.image_tau_int = simulation && p.image_tau_int;
   A.image_crossings = p.image_crossings;
   int n_q = 0;
-  if (A.image_light) n_q += nf;
+  A.polarized = ctx->polarized ? 1 : 0;
+  if (A.image_light) n_q += nf * (ctx->polarized ? 4 : 1);
   A.offset_time = n_q;
   if (A.image_time) n_q += 1;
   A.offset_length = n_q;
@@ -436,7 +441,8 @@ void ValidateRadiation(bl_ctx *ctx) {
   if (A.image_crossings) n_q += 1;
   A.n_q = n_q;
   A.any = (A.image_time || A.image_length || A.image_lambda || A.image_emission || A.image_tau || A.image_lambda_ave
-           || A.image_emission_ave || A.image_tau_int || A.image_crossings || ctx->render_num_images > 0) ? 1 : 0;
+           || A.image_emission_ave || A.image_tau_int || A.image_crossings || ctx->render_num_images > 0
+           || ctx->polarized) ? 1 : 0;   // polarized transfer runs in auxiliary-image mode
   ctx->image_num_quantities = n_q;
 }
 
@@ -927,7 +933,8 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
     // (simulation mode) + 16 B * n_nu transfer)
     const uint64_t per_ray = static_cast<uint64_t>(max_steps)
         * (sizeof(BlSampleRecord) + (simulation ? sizeof(BlLocated) : 0) + sizeof(double2) * n_nu
-           + (aux ? sizeof(BlAuxSample) + sizeof(double) : 0) + (slow ? 2 * sizeof(double) : 0)) + 64;
+           + (aux ? sizeof(BlAuxSample) + sizeof(double) : 0) + (slow ? 2 * sizeof(double) : 0)
+           + (ctx->polarized ? sizeof(BlPolSample) + 3 * sizeof(double2) * n_nu : 0)) + 64;
     // One chunk if the whole call fits the budget. With bl_set_overlap(): two scratch sets of half the budget
     // each, so that the geodesic kernel of chunk c + 1 runs while chunk c is being shaded.
     // The budget is also capped by what the device can actually give: 90 % of (free memory + the scratch
@@ -940,7 +947,8 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
         for (const bl_ctx::ChunkSlot &sl : ctx->slot)
           held += sl.d_records.count * sizeof(BlSampleRecord) + sl.d_located.count * sizeof(BlLocated)
               + sl.d_transfer.count * sizeof(double2) + sl.d_aux.count * sizeof(BlAuxSample)
-              + (sl.d_sample_t.count + sl.d_slow_frac.count) * sizeof(double);
+              + (sl.d_sample_t.count + sl.d_slow_frac.count) * sizeof(double)
+              + sl.d_pol_samples.count * sizeof(BlPolSample) + sl.d_pol_coeffs.count * sizeof(double2);
         const uint64_t available = static_cast<uint64_t>(0.9 * static_cast<double>(free_bytes + held));
         if (available < budget) budget = available;
       }
@@ -970,6 +978,10 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
       if (aux) sl.d_aux.Ensure(static_cast<size_t>(chunk) * max_steps);
       if (need_time) sl.d_sample_t.Ensure(record_capacity);
       if (slow) sl.d_slow_frac.Ensure(record_capacity);
+      if (ctx->polarized) {
+        sl.d_pol_samples.Ensure(static_cast<size_t>(chunk) * max_steps);
+        sl.d_pol_coeffs.Ensure(static_cast<size_t>(chunk) * max_steps * n_nu * 3);
+      }
     }
     EnsureChunkResources(ctx, n_chunks);
     ctx->d_freq.Ensure(n_nu);
@@ -998,6 +1010,10 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
       if (d->sample_flags != nullptr) { ctx->d_out_flags.Ensure(n_rays); out_flags = ctx->d_out_flags.ptr; }
       if (d->camera_pos != nullptr) { ctx->d_camera_pos.Ensure(static_cast<size_t>(n_rays) * 4); cam_pos = ctx->d_camera_pos.ptr; }
       if (d->camera_dir != nullptr) { ctx->d_camera_dir.Ensure(static_cast<size_t>(n_rays) * 4); cam_dir = ctx->d_camera_dir.ptr; }
+    }
+    if (ctx->polarized) {   // the camera tetrad projection needs every ray's initial position and momentum
+      if (cam_pos == nullptr) { ctx->d_camera_pos.Ensure(static_cast<size_t>(n_rays) * 4); cam_pos = ctx->d_camera_pos.ptr; }
+      if (cam_dir == nullptr) { ctx->d_camera_dir.Ensure(static_cast<size_t>(n_rays) * 4); cam_dir = ctx->d_camera_dir.ptr; }
     }
     double *render_out = nullptr;
     bool fill_present = false;
@@ -1140,6 +1156,18 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
         pl.plasma_p = plasma_p;
         pl.power_jj = var_a / var_b / var_c * var_d * var_e;
         pl.power_aa = var_f / var_c * var_g * var_h;
+        if (ctx->polarized) {   // simulation_coefficients.cpp:67-80
+          const double var_i = 2.0 * (plasma_p + 2.0) / (plasma_p + 1.0);
+          const double var_j = bl_pow(p.plasma_gamma_min, -(plasma_p + 1.0));
+          const double var_k = bl_log(p.plasma_gamma_min);
+          ctx->power_pol[0] = -(plasma_p + 1.0) / (plasma_p + 7.0 / 3.0);
+          ctx->power_pol[1] = 0.684 * bl_pow(plasma_p, 0.49);
+          ctx->power_pol[2] = -bl_pow(0.034 * plasma_p - 0.0344, 0.086);
+          ctx->power_pol[3] = bl_pow(0.71 * plasma_p + 0.0352, 0.394);
+          ctx->power_pol[4] = (plasma_p - 1.0) / var_c;
+          ctx->power_pol[5] = -bl_pow(p.plasma_gamma_min, 2.0 - plasma_p) / (plasma_p / 2.0 - 1.0);
+          ctx->power_pol[6] = var_i * var_j * var_k;
+        }
       }
       cold.plasma_gamma = ctx->grid_meta.plasma_gamma;
       cold.plasma_gamma_i = ctx->grid_meta.plasma_gamma_i;
@@ -1219,6 +1247,20 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
     xa.t_unit = xa.x_unit / kC;   // unpolarized.cpp:43
     xa.render_params = ctx->render_num_images > 0 ? ctx->d_render_params.ptr : nullptr;
     xa.render = render_out;
+    if (ctx->polarized) {
+      xa.camera_pos = cam_pos;
+      xa.camera_dir = cam_dir;
+      xa.st = ctx->st;
+      xa.simulation_coord = p.simulation_coord;
+      xa.rotation_split = p.image_rotation_split ? 1 : 0;
+      for (int mu = 0; mu < 4; mu++) {
+        xa.cam_u_con[mu] = ctx->frame.u_con[mu];
+        xa.cam_u_cov[mu] = ctx->frame.u_cov[mu];
+        xa.cam_vert_con_c[mu] = ctx->frame.vert_con_c[mu];
+      }
+      for (int c = 0; c < 7; c++) sa.power_pol[c] = ctx->power_pol[c];
+      sa.plasma_gamma_min = p.plasma_power_frac != 0.0 ? p.plasma_gamma_min : 0.0;
+    }
 
     // Locate kernel: 256-thread workgroups. Alone (single chunk) it runs 4 waves per SIMD; when chunks are
     // pipelined it shares each SIMD with one 328-register wave of the next chunk's geodesic kernel, which
@@ -1273,6 +1315,12 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
       ta.sample_t = need_time ? sl.d_sample_t.ptr : nullptr;
       sa.aux = aux ? sl.d_aux.ptr : nullptr;
       sa.sample_t = ta.sample_t;
+      if (ctx->polarized) {
+        sa.pol_samples = sl.d_pol_samples.ptr;
+        sa.pol_coeffs = sl.d_pol_coeffs.ptr;
+        xa.pol_samples = sl.d_pol_samples.ptr;
+        xa.pol_coeffs = sl.d_pol_coeffs.ptr;
+      }
       if (slow) {
         sa.slow.frac = sl.d_slow_frac.ptr;
         sa.slow.ray_extrap = ctx->d_ray_extrap.ptr + begin;
@@ -1298,6 +1346,7 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
       Check(bl_launch_shade(&sa, p.model_type, shade_grid, stream), "coefficient kernel launch");
       Check(hipEventRecord(e[4], stream), "event");
       Check(aux ? bl_launch_transfer_aux(&xa, stream) : bl_launch_transfer(&xa, stream), "transfer kernel launch");
+      if (ctx->polarized) Check(bl_launch_transfer_polarized(&xa, stream), "polarized transfer kernel launch");
       Check(hipEventRecord(e[5], stream), "event");
       Check(hipMemcpyAsync(ctx->host_counters + static_cast<size_t>(c) * n_counters, sl.d_counters.ptr,
                            n_counters * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream), "counter download");

@@ -145,6 +145,7 @@ struct BlAuxImages {
   int offset_time, offset_length, offset_lambda, offset_emission, offset_tau;
   int offset_lambda_ave, offset_emission_ave, offset_tau_int, offset_crossings;
   int n_q;
+  int polarized;   // rows 4 l + (I, Q, U, V) written by the polarized transfer kernel instead of row l
 };
 
 // False-colour rendering parameters (rendering.cpp; a device buffer, too large for kernel arguments)
@@ -186,6 +187,17 @@ struct BlTraceArgs {
 };
 
 // Kernel arguments: shading kernel
+// Polarized transfer (image_polarization): what the polarized transfer kernel needs of every sample besides the
+// eight coefficients - position, renormalised covariant momentum (sample_dir of the reference), affine length
+// and the sampled velocity / field (sample_uu1..bb3, zero where the sample was cut). 96 bytes.
+struct BlPolSample {
+  double x[3];
+  double k[4];
+  double delta_lambda;
+  float uu[3], bb[3];
+  double pad;
+};
+
 // Slow light (slow_light_on): the time slices the reader holds (simulation_reader.cpp:211-303), latest
 // first, all on the geometry of BlGridDevice. n = 0: off.
 struct BlSlowDevice {
@@ -222,6 +234,11 @@ struct BlShadeArgs {
   BlAuxSample *aux;           // [chunk_rays][ray_max_steps]
   const double *sample_t;     // [record capacity] or null
   const unsigned char *ray_flags;
+  // polarized transfer only (runs in auxiliary-image mode): null otherwise
+  BlPolSample *pol_samples;   // [chunk_rays][ray_max_steps]
+  double2 *pol_coeffs;        // [chunk_rays][ray_max_steps][n_nu][3]: (j_Q, j_V), (alpha_Q, alpha_V), (rho_Q, rho_V)
+  double power_pol[7];        // simulation_coefficients.cpp:67-80: jj_q, jj_v, aa_q, aa_v, rho, rho_q, rho_v
+  double plasma_gamma_min;
   int aux_need_coefficients;  // image_light || image_emission || image_tau || image_emission_ave || image_tau_int (:389)
   int aux_need_length;
   double cam_x[4];
@@ -229,6 +246,13 @@ struct BlShadeArgs {
 
 // Kernel arguments: transfer kernel
 struct BlTransferArgs {
+  // polarized transfer only
+  const BlPolSample *pol_samples;
+  const double2 *pol_coeffs;
+  const double *camera_pos, *camera_dir;   // [n_rays_total][4] by output index: initial position, momentum
+  BlSpacetime st;
+  int simulation_coord, rotation_split;
+  double cam_u_con[4], cam_u_cov[4], cam_vert_con_c[4];
   const double2 *transfer;
   const int *ray_sample_num;
   const unsigned char *ray_flags;

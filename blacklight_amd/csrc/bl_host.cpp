@@ -245,9 +245,10 @@ int bl_adaptive_refine(const bl_ctx *ctx_const, int level, int n_blocks, const i
   const int block_num_pix = bs * bs;
   const long long n_pix = level == 0 ? static_cast<long long>(p.camera_resolution) * p.camera_resolution
                                      : static_cast<long long>(n_blocks) * block_num_pix;
-  // row of I_nu at the chosen frequency (polarization is outside the built scope: stride 1)
+  // row of I_nu at the chosen frequency (radiation_adaptive.cpp:166-167): rows 4 l + (I, Q, U, V) when polarized
   const int freq_index = p.image_num_frequencies > 1 ? p.adaptive_frequency_num - 1 : 0;
-  const double *row = image + static_cast<size_t>(freq_index) * n_pix;
+  const bool polarized = p.model_type == BL_MODEL_SIMULATION && p.image_light && p.has[BL_P_image_polarization] && p.image_polarization;
+  const double *row = image + static_cast<size_t>(freq_index) * (polarized ? 4 : 1) * n_pix;
   std::vector<double> block(block_num_pix);
   int count = 0;
   for (int b = 0; b < n_blocks; b++) {
@@ -324,6 +325,9 @@ int bl_write_output(bl_ctx *ctx, const char *path_override, const bl_output_desc
   if (bl_render_num_images(ctx) > 0 && p.output_format != BL_OUTPUT_NPZ)
     return bl_internal_fail(ctx, BL_E_INPUT, "Only npz outputs support rendering.");
   const double *image0 = d->level[0].image;
+  if (p.output_format == BL_OUTPUT_RAW && p.model_type == BL_MODEL_SIMULATION && p.image_light && p.has[BL_P_image_polarization]
+      && p.image_polarization)   // output_writer.cpp:64-70
+    return bl_internal_fail(ctx, BL_E_INPUT, "Only npz or npy outputs support polarization.");
   if (p.output_format == BL_OUTPUT_RAW) {   // raw_format.cpp: the bytes of image[0]
     stream.write(reinterpret_cast<const char *>(image0), static_cast<std::streamsize>(sizeof(double) * n_q * n_pix));
     return BL_OK;
@@ -355,15 +359,29 @@ int bl_write_output(bl_ctx *ctx, const char *path_override, const bl_output_desc
     if (d->level[0].camera == nullptr) return bl_internal_fail(ctx, BL_E_ARG, "output_camera needs camera data.");
     add(camera_name, MakeNpy("<f8", {res, res, 4}, d->level[0].camera, sizeof(double) * n_pix * 4));
   }
-  if (p.image_light) {
-    std::vector<int> shape = n_nu == 1 ? std::vector<int>{res, res} : std::vector<int>{n_nu, res, res};
-    add("I_nu", MakeNpy("<f8", shape, image0, sizeof(double) * n_nu * n_pix));
-  }
+  // Stokes rows (numpy_format.cpp:128-165): row (l * stride + a) of the image -> record a, slice l
+  const bool polarized = p.model_type == BL_MODEL_SIMULATION && p.image_light && p.has[BL_P_image_polarization] && p.image_polarization;
+  const int stokes_stride = polarized ? 4 : 1;
+  static const char *const kStokesNames[4] = {"I_nu", "Q_nu", "U_nu", "V_nu"};
+  std::vector<double> stokes;
+  auto add_stokes = [&](const double *image, size_t pixels, const std::vector<int> &pixel_shape, const std::string &prefix,
+                        const std::string &suffix) {
+    std::vector<int> shape = pixel_shape;
+    if (n_nu > 1) shape.insert(shape.begin(), n_nu);
+    for (int a = 0; a < stokes_stride; a++) {
+      stokes.resize(static_cast<size_t>(n_nu) * pixels);
+      for (int l = 0; l < n_nu; l++)
+        std::memcpy(stokes.data() + static_cast<size_t>(l) * pixels, image + static_cast<size_t>(l * stokes_stride + a) * pixels,
+                    sizeof(double) * pixels);
+      add(prefix + kStokesNames[a] + suffix, MakeNpy("<f8", shape, stokes.data(), sizeof(double) * n_nu * pixels));
+    }
+  };
+  if (p.image_light) add_stokes(image0, n_pix, {res, res}, "", "");
   // alternate images (numpy_format.cpp:167-281) and renderings (:282-289), root level
   const bool simulation = p.model_type == BL_MODEL_SIMULATION;
   const int n_render = bl_render_num_images(ctx);
   struct RowSet { const char *name; bool on; int offset; bool per_frequency; bool per_cell; };
-  int row = p.image_light ? n_nu : 0;
+  int row = p.image_light ? n_nu * stokes_stride : 0;
   auto take = [&](bool on, int count) { int at = row; if (on) row += count; return at; };
   const int off_time = take(p.image_time, 1), off_length = take(p.image_length, 1), off_lambda = take(p.image_lambda, n_nu);
   const int off_emission = take(p.image_emission, n_nu), off_tau = take(p.image_tau, n_nu);
@@ -420,10 +438,7 @@ int bl_write_output(bl_ctx *ctx, const char *path_override, const bl_output_desc
       if (lv.camera == nullptr) return bl_internal_fail(ctx, BL_E_ARG, "output_camera needs camera data.");
       add(std::string("adaptive_") + camera_name + suffix, MakeNpy("<f8", {lv.n_blocks, bs, bs, 4}, lv.camera, sizeof(double) * level_pix * 4));
     }
-    if (p.image_light) {
-      std::vector<int> shape = n_nu == 1 ? std::vector<int>{lv.n_blocks, bs, bs} : std::vector<int>{n_nu, lv.n_blocks, bs, bs};
-      add("adaptive_I_nu" + suffix, MakeNpy("<f8", shape, lv.image, sizeof(double) * n_nu * level_pix));
-    }
+    if (p.image_light) add_stokes(lv.image, level_pix, {lv.n_blocks, bs, bs}, "adaptive_", suffix);
     if (n_render > 0 && lv.render == nullptr) return bl_internal_fail(ctx, BL_E_ARG, "render_num_images > 0 needs render data.");
     add_alternates(lv.image, level_pix, {lv.n_blocks, bs, bs}, "adaptive_", suffix, lv.render);
   }

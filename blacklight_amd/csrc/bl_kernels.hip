@@ -32,6 +32,7 @@
 #include <hip/hip_runtime.h>
 
 #include "bl_device.h"
+#include "bl_bessel.h"
 
 namespace {
 
@@ -675,6 +676,7 @@ struct SampleShade {
   bool have_coefficients;      // false: j = alpha = 0 at every frequency
   double nu_fluid_over_nu;     // -k_mu u^mu (fluid-frame frequency per unit camera frequency*factor)
   double n_e_cgs, nu_c_cgs, theta_e, sin_theta_b, kb_tt_e_cgs;   // simulation
+  double cos_theta_b, sin2_theta_b;                               // polarized coefficients only
   double n_n0_fluid, fu[4];                                       // formula
   bool have_cell;              // cell_values recorded (simulation_coefficients.cpp:377-387)
   double cell[BL_NUM_CELL_VALUES];
@@ -1246,6 +1248,8 @@ __device__ __forceinline__ void sample_finish_simulation(const BlShadeArgs &P, c
   out->theta_e = theta_e;
   out->sin_theta_b = bl_sqrt_g(sin2_theta_b);
   out->kb_tt_e_cgs = kb_tt_e_cgs;
+  out->sin2_theta_b = sin2_theta_b;
+  out->cos_theta_b = bl_sqrt_g(cos2_theta_b) * (k_b_tet >= 0.0 ? 1.0 : -1.0);   // :455
 }
 
 // Formula mode, one sample (formula_coefficients.cpp:118-161)
@@ -1475,6 +1479,7 @@ __global__ void __launch_bounds__(256, 2) bl_shade_kernel(const BlShadeArgs P) {
     sh.have_coefficients = false;
     sh.nu_fluid_over_nu = 0.0;
     sh.n_e_cgs = sh.nu_c_cgs = sh.theta_e = sh.sin_theta_b = sh.kb_tt_e_cgs = 0.0;
+    sh.cos_theta_b = sh.sin2_theta_b = 0.0;
     sh.n_n0_fluid = 0.0;
     sh.fu[0] = sh.fu[1] = sh.fu[2] = sh.fu[3] = 0.0;
     sh.have_cell = false;
@@ -1527,6 +1532,18 @@ __global__ void __launch_bounds__(256, 2) bl_shade_kernel(const BlShadeArgs P) {
       const double nan = __longlong_as_double(0x7ff8000000000000ll);
       for (int a = 0; a < BL_NUM_CELL_VALUES; a++) aux.cell[a] = sh.have_cell ? sh.cell[a] : nan;
       P.aux[(size_t)ray * P.ray_max_steps + n] = aux;
+      if (kExtended && P.pol_samples != nullptr) {
+        BlPolSample ps;
+        ps.x[0] = x1; ps.x[1] = x2; ps.x[2] = x3;
+        for (int mu = 0; mu < 4; mu++) ps.k[mu] = kcov[mu];
+        ps.delta_lambda = delta_lambda;
+        for (int c = 0; c < 3; c++) {
+          ps.uu[c] = pr[2 + c];
+          ps.bb[c] = pr[5 + c];
+        }
+        ps.pad = 0.0;
+        P.pol_samples[(size_t)ray * P.ray_max_steps + n] = ps;
+      }
     }
     // ---------------- per-frequency coefficients and transfer records
     for (int l = 0; l < P.n_nu; l++) {
@@ -1572,6 +1589,101 @@ __global__ void __launch_bounds__(256, 2) bl_shade_kernel(const BlShadeArgs P) {
         j_val = j_nu_fluid_cgs / (nu_fluid_cgs * nu_fluid_cgs);
         const double alpha_nu_fluid_cgs = fm.a * fm.cn0 * sh.n_n0_fluid * bl_pow(nu_fluid_cgs / fm.nup, -fm.beta - fm.alpha);
         alpha_val = alpha_nu_fluid_cgs * nu_fluid_cgs;
+      }
+      if (kAux && kExtended && kModel == BL_MODEL_SIMULATION && P.pol_coeffs != nullptr) {
+        // polarized coefficients (simulation_coefficients.cpp:485-495, :506-523, :527-553, :567-605), plain
+        // IEEE operations in the reference's order
+        double j_q = 0.0, j_v = 0.0, alpha_q = 0.0, alpha_v = 0.0, rho_q = 0.0, rho_v = 0.0;
+        if (sh.have_coefficients) {
+          const double thermal_frac = P.plasma.plasma_thermal_frac;
+          const double nu_cgs = sh.nu_fluid_over_nu * (freq * momentum_factor);
+          const double nu_2_cgs = nu_cgs * nu_cgs;
+          const double nu_c_cgs = sh.nu_c_cgs, theta_e = sh.theta_e, sin_theta_b = sh.sin_theta_b, cos_theta_b = sh.cos_theta_b;
+          const double n_e_cgs = sh.n_e_cgs;
+          const double nu_s_cgs = 2.0 / 9.0 * nu_c_cgs * theta_e * theta_e * sin_theta_b;
+          if (thermal_frac != 0.0) {
+            const double xx = nu_cgs / nu_s_cgs;
+            const double xx_1_2 = blm_sqrt(xx);
+            const double xx_1_3 = bl_cbrt(xx);
+            const double xx_1_6 = blm_sqrt(xx_1_3);
+            const double coefficient = thermal_frac * n_e_cgs * kE * kE * nu_c_cgs / (kC * nu_2_cgs) * bl_exp(-xx_1_3);
+            const double var_a = kSqrt2 * kPi / 27.0 * sin_theta_b;
+            const double var_b = kPow2_11_12;
+            const double var_d = (7.0 * bl_pow(theta_e, 0.96) + 35.0) / (10.0 * bl_pow(theta_e, 0.96) + 75.0) * var_b;
+            const double var_e = xx_1_2 + var_d * xx_1_6;
+            const double var_f = cos_theta_b / theta_e;
+            const double var_g = kPi / 3.0 + kPi / 3.0 * xx_1_3 + 2.0 / 300.0 * xx_1_2 + 2.0 / 19.0 * kPi * xx_1_3 * xx_1_3;
+            j_q = -coefficient * var_a * var_e * var_e;
+            j_v = coefficient * var_f * var_g;
+            const double b_nu_nu_3_cgs = 2.0 * kH / (kC * kC) / bl_expm1(kH * nu_cgs / sh.kb_tt_e_cgs);
+            alpha_q = j_q / b_nu_nu_3_cgs;
+            alpha_v = j_v / b_nu_nu_3_cgs;
+            // :513-523 with the thermal alpha_I (alpha_val holds it, possibly already zeroed, before the
+            // power-law term is added - recompute the test on the thermal value)
+            {
+              const double var_c = xx_1_2 + var_b * xx_1_6;
+              const double alpha_thermal = coefficient * var_a * var_c * var_c / b_nu_nu_3_cgs;
+              if (alpha_thermal * alpha_thermal <= 0x1p-1024) alpha_q = alpha_v = 0.0;
+            }
+            const double coefficient_q = -thermal_frac * n_e_cgs * kE * kE * nu_c_cgs * nu_c_cgs * sh.sin2_theta_b / (kMe * kC * nu_2_cgs);
+            const double coefficient_v = thermal_frac * 2.0 * n_e_cgs * kE * kE * nu_c_cgs * cos_theta_b / (kMe * kC * nu_cgs);
+            double factor_q = 0.0, factor_v = 1.0;
+            if (theta_e >= 0.01) {   // theta_e_zero, radiation_integrator.hpp:190
+              const double kk_0 = bl_cyl_bessel_k(0, 1.0 / theta_e);
+              const double kk_1 = bl_cyl_bessel_k(1, 1.0 / theta_e);
+              const double kk_2 = bl_cyl_bessel_k(2, 1.0 / theta_e);
+              const double xx_neg_1_2 = 1.0 / blm_sqrt(xx);
+              const double f_a = 2.011 * bl_exp(-19.78 * bl_pow(xx, -0.5175));
+              const double f_b = bl_cos(39.89 * xx_neg_1_2) * bl_exp(-70.16 * bl_pow(xx, -0.6));
+              const double f_c = 0.011 * bl_exp(-1.69 * xx_neg_1_2);
+              const double f_d = 0.003135 * bl_pow(xx, 4.0 / 3.0);
+              const double f_e = 0.5 * (1.0 + bl_tanh(10.0 * bl_log(0.6648 * xx_neg_1_2)));
+              const double f_0 = f_a - f_b - f_c;
+              const double f_m = f_0 + (f_c - f_d) * f_e;
+              const double delta_jj_5 = 0.4379 * bl_log(1.0 + 1.3414 * bl_pow(xx, -0.7515));
+              factor_q = f_m * (kk_1 / kk_2 + 6.0 * theta_e);
+              factor_v = (kk_0 - delta_jj_5) / kk_2;
+              factor_v = (factor_v < 0.0 || factor_v > 1.0) ? 1.0 : factor_v;
+            }
+            rho_q = coefficient_q * factor_q;
+            rho_v = coefficient_v * factor_v;
+          }
+          if (P.plasma.power_frac != 0.0) {
+            const double plasma_p = P.plasma.plasma_p;
+            {
+              const double var_a = bl_pow(nu_cgs / (nu_c_cgs * sin_theta_b), -(plasma_p - 1.0) / 2.0);
+              const double coefficient = P.plasma.power_frac * n_e_cgs * kE * kE * nu_c_cgs / (kC * nu_2_cgs) * P.plasma.power_jj * sin_theta_b * var_a;
+              const double var_b = cos_theta_b / sin_theta_b;
+              const double var_c = 1.0 / blm_sqrt(nu_cgs / (3.0 * nu_c_cgs * sin_theta_b));
+              j_q += coefficient * P.power_pol[0];
+              j_v += coefficient * P.power_pol[1] * var_b * var_c;
+            }
+            {
+              const double var_a = bl_pow(nu_cgs / (nu_c_cgs * sin_theta_b), -(plasma_p + 2.0) / 2.0);
+              const double coefficient = P.plasma.power_frac * n_e_cgs * kE * kE / (kMe * kC) * P.plasma.power_aa * var_a;
+              const double var_b = bl_pow(3.1 * bl_pow(sin_theta_b, -1.92) - 3.1, 0.512);
+              const double var_c = 1.0 / blm_sqrt(nu_cgs / (nu_c_cgs * sin_theta_b));
+              const double var_d = cos_theta_b >= 0.0 ? 1.0 : -1.0;
+              alpha_q += coefficient * P.power_pol[2];
+              alpha_v += coefficient * P.power_pol[3] * var_b * var_c * var_d;
+            }
+            {
+              const double var_a = n_e_cgs * kE * kE * nu_cgs / (kMe * kC * nu_c_cgs * sin_theta_b);
+              const double var_b = nu_c_cgs * sin_theta_b / nu_cgs;
+              const double var_c = var_b * var_b;
+              const double var_d = var_c * var_b;
+              const double var_e = 1.0 - bl_pow(2.0 * nu_c_cgs * P.plasma_gamma_min * P.plasma_gamma_min * sin_theta_b / (3.0 * nu_cgs), plasma_p / 2.0 - 1.0);
+              const double var_f = cos_theta_b / sin_theta_b;
+              const double coefficient = P.plasma.power_frac * P.power_pol[4] * var_a;
+              rho_q += coefficient * P.power_pol[5] * var_d * var_e;
+              rho_v += coefficient * P.power_pol[6] * var_c * var_f;
+            }
+          }
+        }
+        double2 *pc = P.pol_coeffs + (((size_t)ray * P.ray_max_steps + n) * P.n_nu + l) * 3;
+        pc[0] = make_double2(j_q, j_v);
+        pc[1] = make_double2(alpha_q, alpha_v);
+        pc[2] = make_double2(rho_q, rho_v);
       }
       if (kAux) {
         if (kModel == BL_MODEL_FORMULA && nan_ray && l == 0) j_val = alpha_val = __longlong_as_double(0x7ff8000000000000ll);
@@ -1787,7 +1899,7 @@ __global__ void __launch_bounds__(64) bl_transfer_aux_kernel(BlTransferArgs P) {
           plane_sign = plane_sign_new;
         }
       }
-      if (A.image_light) img[(size_t)l * row] = intensity * (freq * freq * freq);   // :200-208
+      if (A.image_light && !A.polarized) img[(size_t)l * row] = intensity * (freq * freq * freq);   // :200-208
       if (A.image_time && l == 0) img[(size_t)A.offset_time * row] = time_min;
       if (A.image_length && l == 0) img[(size_t)A.offset_length * row] = length;
       if (A.image_lambda) img[(size_t)(A.offset_lambda + l) * row] = integrated_lambda;
@@ -1895,7 +2007,7 @@ extern "C" hipError_t bl_launch_locate(const BlShadeArgs *args, int grid, int ld
 // Coefficient kernel
 extern "C" hipError_t bl_launch_shade(const BlShadeArgs *args, int model, int grid, hipStream_t stream) {
   const bool aux = args->aux != nullptr;
-  const bool power = args->plasma.power_frac != 0.0 || args->plasma.code_kappa != 0 || args->slow.n > 0;
+  const bool power = args->plasma.power_frac != 0.0 || args->plasma.code_kappa != 0 || args->slow.n > 0 || args->pol_samples != nullptr;
 #define BL_LAUNCH_S(M, A, W) hipLaunchKernelGGL((bl_shade_kernel<M, A, W>), dim3(grid), dim3(256), 0, stream, *args)
   if (model == BL_MODEL_SIMULATION) {
     if (aux && power) BL_LAUNCH_S(BL_MODEL_SIMULATION, true, true);
