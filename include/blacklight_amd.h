@@ -224,7 +224,8 @@ typedef struct bl_camera_frame {
 /* ------------------------------------------------------------------ one render call
  * Replaces, for one adaptive level, InitializeCamera/AugmentCamera + IntegrateGeodesics* +
  * ReverseGeodesics + CalculateSimulationSampling + SampleSimulation + Calculate*Coefficients +
- * IntegrateUnpolarizedRadiation. The refinement decision between levels
+ * IntegrateUnpolarizedRadiation / IntegratePolarizedRadiation (image rows 4 l + (I, Q, U, V) with
+ * image_polarization). The refinement decision between levels
  * (radiation_adaptive.cpp) stays with the caller, as in blacklight.cpp:196-233. */
 typedef struct bl_render_desc {
   int32_t level;              /* 0 = root camera; L>0 = refined blocks at res * 2^L              */
