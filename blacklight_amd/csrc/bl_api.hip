@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "../../include/blacklight_amd.h"
+#include "bl_bessel.h"
 #include "bl_camera.h"
 #include "bl_device.h"
 #include "bl_internal.h"
@@ -159,6 +160,24 @@ struct bl_ctx {
 namespace {
 
 void Warn(bl_ctx *ctx, const std::string &message) { ctx->warnings += "Warning: " + message + "\n"; }
+
+// RadiationIntegrator::Hypergeometric (simulation_coefficients.cpp:740-773): 2F1 for z < 0 through its Pfaff
+// transformation, ten terms of the series
+double Hypergeometric(double alpha, double beta, double gamma, double z) {
+  const double a = alpha, b = gamma - beta, c = gamma;
+  const double x = z / (z - 1.0);
+  double result = 1.0, a_k = 1.0, b_k = 1.0, c_k = 1.0, xk = 1.0, k_factorial = 1.0;
+  for (int k = 1; k <= 10; k++) {
+    a_k *= a + k - 1.0;
+    b_k *= b + k - 1.0;
+    c_k *= c + k - 1.0;
+    xk *= x;
+    k_factorial *= k;
+    result += a_k * b_k * xk / (c_k * k_factorial);
+  }
+  result *= bl_pow(1.0 - z, -alpha);
+  return result;
+}
 
 bool Has(const bl_params &p, int index) { return p.has[index] != 0; }
 
@@ -381,9 +400,18 @@ void ValidateRadiation(bl_ctx *ctx) {
     Require(p, {BL_P_plasma_kappa_frac}, kRadMissing);
     if (p.plasma_kappa_frac < 0.0 || p.plasma_kappa_frac > 1.0) Warn(ctx, "Fraction of kappa-distribution electrons outside [0, 1].");
     if (p.plasma_power_frac != 0.0) Require(p, {BL_P_plasma_p, BL_P_plasma_gamma_min, BL_P_plasma_gamma_max}, kRadMissing);
-    if (p.plasma_kappa_frac != 0.0)
-      throw Failure{BL_E_UNSUPPORTED, "Kappa-distribution electrons (plasma_kappa_frac != 0) are not built: the reference's unpolarized "
-                                      "absorptivity reads kappa_aa_high_i, which it only initialises for polarized runs."};
+    if (p.plasma_kappa_frac != 0.0) {   // radiation_integrator.cpp:296-308
+      Require(p, {BL_P_plasma_kappa}, kRadMissing);
+      if (p.image_light && p.image_polarization) {
+        if (p.plasma_kappa < 3.5 || p.plasma_kappa > 5.0) throw Failure{BL_E_INPUT, "Polarized transport only supports kappa in [3.5, 5]."};
+        if (p.plasma_kappa != 3.5 && p.plasma_kappa != 4.0 && p.plasma_kappa != 4.5 && p.plasma_kappa != 5.0)
+          Warn(ctx, "Polarized transport will interpolate formulas based on kappa.");
+      }
+      Require(p, {BL_P_plasma_w}, kRadMissing);
+      if (!(p.image_light && p.image_polarization))
+        throw Failure{BL_E_UNSUPPORTED, "Kappa-distribution electrons (plasma_kappa_frac != 0) are built for polarized runs only: the reference's "
+                                        "unpolarized absorptivity reads kappa_aa_high_i, which it only initialises for polarized runs."};
+    }
     ctx->plasma_thermal_frac = 1.0 - (p.plasma_power_frac + p.plasma_kappa_frac);
     if (ctx->plasma_thermal_frac < 0.0 || ctx->plasma_thermal_frac > 1.0) Warn(ctx, "Fraction of thermal electrons outside [0, 1].");
     Require(p, {BL_P_cut_rho_min, BL_P_cut_rho_max, BL_P_cut_n_e_min, BL_P_cut_n_e_max, BL_P_cut_p_gas_min,
@@ -1167,6 +1195,77 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
           ctx->power_pol[4] = (plasma_p - 1.0) / var_c;
           ctx->power_pol[5] = -bl_pow(p.plasma_gamma_min, 2.0 - plasma_p) / (plasma_p / 2.0 - 1.0);
           ctx->power_pol[6] = var_i * var_j * var_k;
+        }
+      }
+      cold.kappa = BlKappaDevice{};
+      if (p.plasma_kappa_frac != 0.0) {
+        // simulation_coefficients.cpp:82-193 for a polarized run; pow / exp / log and K_nu are the pinned ones,
+        // tgamma the host libm's
+        BlKappaDevice &kk = cold.kappa;
+        const double plasma_kappa = p.plasma_kappa, plasma_w = p.plasma_w;
+        kk.frac = p.plasma_kappa_frac;
+        kk.kappa = plasma_kappa;
+        kk.w = plasma_w;
+        const double var_a = 4.0 * kPi * std::tgamma(plasma_kappa - 4.0 / 3.0);
+        const double var_b = bl_pow(3.0, 7.0 / 3.0) * std::tgamma(plasma_kappa - 2.0);
+        const double var_c = bl_pow(3.0, (plasma_kappa - 1.0) / 2.0);
+        const double var_d = (plasma_kappa - 2.0) * (plasma_kappa - 1.0) / 4.0;
+        const double var_e = std::tgamma(plasma_kappa / 4.0 - 1.0 / 3.0);
+        const double var_f = std::tgamma(plasma_kappa / 4.0 + 4.0 / 3.0);
+        const double var_g = bl_pow(3.0, 1.0 / 6.0) * 10.0 / 41.0;
+        const double var_h = plasma_w * plasma_kappa;
+        const double var_i = 2.0 * kPi * bl_pow(var_h, plasma_kappa - 10.0 / 3.0);
+        const double var_j = (plasma_kappa - 2.0) * (plasma_kappa - 1.0) * plasma_kappa;
+        const double var_k = 3.0 * plasma_kappa - 1.0;
+        const double var_l = std::tgamma(5.0 / 3.0);
+        const double var_m = Hypergeometric(plasma_kappa - 1.0 / 3.0, plasma_kappa + 1.0, plasma_kappa + 2.0 / 3.0, -var_h);
+        const double var_n = bl_pow(kPi, 1.5) / 3.0;
+        const double var_o = var_j / (var_h * var_h * var_h);
+        const double var_p = 2.0 * std::tgamma(2.0 + plasma_kappa / 2.0) / (2.0 + plasma_kappa) - 1.0;
+        kk.jj_low = var_a / var_b;
+        kk.jj_high = var_c * var_d * var_e * var_f;
+        kk.jj_x_i = 3.0 * bl_pow(plasma_kappa, -1.5);
+        kk.aa_low = var_g * var_i * var_j / var_k * var_l * var_m;
+        kk.aa_high = var_n * var_o * var_p;
+        kk.aa_x_i = bl_pow(-1.75 + 1.6 * plasma_kappa, -0.86);
+        const double var_q = 14.3 * bl_pow(plasma_w, -0.928);
+        const double var_r = 169.0 * bl_pow(plasma_kappa, -8.0) + 0.0052 * plasma_kappa - 0.0526 + 47.0 / (200.0 * plasma_kappa);
+        kk.jj_low_q = 0.5;
+        kk.jj_low_v = 0.5625 * bl_pow(plasma_kappa, -0.528) / plasma_w;
+        kk.jj_high_q = 0.64 + 0.02 * plasma_kappa;
+        kk.jj_high_v = 0.765625 * bl_pow(plasma_kappa, -0.44) / plasma_w;
+        kk.jj_x_q = 3.7 * bl_pow(plasma_kappa, -1.6);
+        kk.jj_x_v = kk.jj_x_i;
+        kk.aa_low_q = 25.0 / 48.0;
+        kk.aa_low_v = 77.0 / (100.0 * plasma_w) * bl_pow(plasma_kappa, -0.7);
+        kk.aa_high_i = bl_pow(3.0 / plasma_kappa, 4.75) + 0.6;
+        kk.aa_high_q = 441.0 * bl_pow(plasma_kappa, -5.76) + 0.55;
+        kk.aa_high_v = var_q * var_r;
+        kk.aa_x_q = 1.4 * bl_pow(plasma_kappa, -1.15);
+        kk.aa_x_v = 1.22 * bl_pow(plasma_kappa, -1.136) + 0.007;
+        kk.rho_v = bl_cyl_bessel_k(0, 1.0 / plasma_w) / bl_cyl_bessel_k(2, 1.0 / plasma_w);
+        // rotativity fits at kappa = 3.5, 4, 4.5, 5 (:128-192); kappa is bracketed by two of them
+        const double sqrt_w = blm_sqrt(plasma_w), exp_w = bl_exp(-5.0 * plasma_w), w2 = plasma_w * plasma_w;
+        const double fit_q[4][5] = {
+            {17.0 * plasma_w + sqrt_w * (-3.0 + 7.0 * exp_w), -1.0 / 30.0, 0.1, -1.5, 0.471},
+            {46.0 / 3.0 * plasma_w + sqrt_w * (-5.0 / 3.0 + 17.0 / 3.0 * exp_w), -1.0 / 18.0, 1.0 / 6.0, -1.75, 0.5},
+            {14.0 * plasma_w + sqrt_w * (-1.625 + 4.5 * exp_w), -1.0 / 12.0, 0.25, -2.0, 0.525},
+            {12.5 * plasma_w + sqrt_w * (-1.0 + 5.0 * exp_w), -0.125, 0.375, -2.25, 0.541}};
+        const double fit_v[4][2] = {
+            {(w2 + 2.0 * plasma_w + 1.0) / (3.125 * w2 + 4.0 * plasma_w + 1.0), 0.447},
+            {(w2 + 54.0 * plasma_w + 50.0) / (30.0 / 11.0 * w2 + 134.0 * plasma_w + 50.0), 0.391},
+            {(w2 + 43.0 * plasma_w + 38.0) / (7.0 / 3.0 * w2 + 92.5 * plasma_w + 38.0), 0.348},
+            {(plasma_w + 13.0 / 14.0) / (2.0 * plasma_w + 13.0 / 14.0), 0.313}};
+        const int lo = plasma_kappa < 4.0 ? 0 : (plasma_kappa < 4.5 ? 1 : 2);
+        const double k_lo = 3.5 + 0.5 * lo, k_hi = 4.0 + 0.5 * lo;
+        kk.rho_frac = (plasma_kappa - k_lo) / (k_hi - k_lo);
+        for (int c = 0; c < 5; c++) {
+          kk.rho_q_low[c] = fit_q[lo][c];
+          kk.rho_q_high[c] = fit_q[lo + 1][c];
+        }
+        for (int c = 0; c < 2; c++) {
+          kk.rho_v_low[c] = fit_v[lo][c];
+          kk.rho_v_high[c] = fit_v[lo + 1][c];
         }
       }
       cold.plasma_gamma = ctx->grid_meta.plasma_gamma;

@@ -13,9 +13,8 @@
 
 #include "blmath.h"
 
-BLM_FN double bl_cyl_bessel_k(int nl, double x) {
-  if (x != x) return x;
-  if (x == 0.0) return blm_from_bits(0x7ff0000000000000ull);
+/* K_mu and K_{mu+1} for mu = 0 (the part of __bessel_ik every integer order shares); x is finite, non-zero */
+BLM_FN void bl_bessel_k_core(double x, double *kmu_out, double *knu1_out) {
   const double eps = 0x1p-52;
   const int max_iter = 15000;
   const double mu = 0.0, mu2 = 0.0;
@@ -81,12 +80,36 @@ BLM_FN double bl_cyl_bessel_k(int nl, double x) {
     kmu = blm_sqrt(3.141592653589793 / (2.0 * x)) * bl_exp(-x) / s;
     knu1 = kmu * (mu + x + 0.5 - h) * xi;
   }
+  *kmu_out = kmu;
+  *knu1_out = knu1;
+}
+
+BLM_FN double bl_cyl_bessel_k(int nl, double x) {
+  if (x != x) return x;
+  if (x == 0.0) return blm_from_bits(0x7ff0000000000000ull);
+  const double mu = 0.0;
+  const double xi2 = 2.0 * (1.0 / x);
+  double kmu, knu1;
+  bl_bessel_k_core(x, &kmu, &knu1);
   for (int i = 1; i <= nl; ++i) {
     const double knutemp = (mu + i) * xi2 * knu1 + kmu;
     kmu = knu1;
     knu1 = knutemp;
   }
   return kmu;
+}
+
+/* K_0, K_1, K_2 of one argument: what three calls of bl_cyl_bessel_k(0 / 1 / 2, x) return, bit for bit - each of
+ * them starts from the same (K_0, K_1) pair and the upward recurrence only reads it - for a third of the work. */
+BLM_FN void bl_cyl_bessel_k012(double x, double *k0, double *k1, double *k2) {
+  if (x != x) { *k0 = *k1 = *k2 = x; return; }
+  if (x == 0.0) { *k0 = *k1 = *k2 = blm_from_bits(0x7ff0000000000000ull); return; }
+  const double xi2 = 2.0 * (1.0 / x);
+  double kmu, knu1;
+  bl_bessel_k_core(x, &kmu, &knu1);
+  *k0 = kmu;
+  *k1 = knu1;
+  *k2 = (0.0 + 1) * xi2 * knu1 + kmu;
 }
 
 #endif

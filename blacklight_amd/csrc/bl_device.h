@@ -99,6 +99,18 @@ struct BlPlasmaDevice {
   int code_kappa;            // plasma_model = code_kappa: theta_e from the simulation's electron entropy (:351-358)
 };
 
+// Kappa-distribution electrons (simulation_coefficients.cpp:82-193; the reference's names without the prefix).
+// frac = 0: none. Built for polarized runs, where the reference defines every constant (bl_init refuses otherwise).
+struct BlKappaDevice {
+  double frac, kappa, w;
+  double jj_low, jj_high, jj_x_i, aa_low, aa_high, aa_x_i;
+  double jj_low_q, jj_low_v, jj_high_q, jj_high_v, jj_x_q, jj_x_v;
+  double aa_low_q, aa_low_v, aa_high_i, aa_high_q, aa_high_v, aa_x_q, aa_x_v;
+  double rho_v, rho_frac;
+  double rho_q_low[5], rho_q_high[5];   // a, b, c, d, e of the two fits that bracket kappa
+  double rho_v_low[2], rho_v_high[2];   // a, b
+};
+
 // Rarely used parameters of the shading kernel (optional geometric cuts, cell cut thresholds,
 // fallback primitives): kept in HBM behind one pointer and read under wave-uniform flags, so they do
 // not occupy SGPRs in the common case where they are all disabled.
@@ -112,6 +124,7 @@ struct BlShadeCold {
   double cut_beta_inverse_min, cut_beta_inverse_max;
   float fallback_rho, fallback_pgas, fallback_kappa;
   double plasma_gamma, plasma_gamma_i, plasma_gamma_e;
+  BlKappaDevice kappa;
 };
 
 struct BlFormulaDevice {

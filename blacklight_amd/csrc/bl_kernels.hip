@@ -1629,9 +1629,8 @@ __global__ void __launch_bounds__(256, 2) bl_shade_kernel(const BlShadeArgs P) {
             const double coefficient_v = thermal_frac * 2.0 * n_e_cgs * kE * kE * nu_c_cgs * cos_theta_b / (kMe * kC * nu_cgs);
             double factor_q = 0.0, factor_v = 1.0;
             if (theta_e >= 0.01) {   // theta_e_zero, radiation_integrator.hpp:190
-              const double kk_0 = bl_cyl_bessel_k(0, 1.0 / theta_e);
-              const double kk_1 = bl_cyl_bessel_k(1, 1.0 / theta_e);
-              const double kk_2 = bl_cyl_bessel_k(2, 1.0 / theta_e);
+              double kk_0, kk_1, kk_2;   // three std::cyl_bessel_k calls in the reference (:537-539)
+              bl_cyl_bessel_k012(1.0 / theta_e, &kk_0, &kk_1, &kk_2);
               const double xx_neg_1_2 = 1.0 / blm_sqrt(xx);
               const double f_a = 2.011 * bl_exp(-19.78 * bl_pow(xx, -0.5175));
               const double f_b = bl_cos(39.89 * xx_neg_1_2) * bl_exp(-70.16 * bl_pow(xx, -0.6));
@@ -1677,6 +1676,64 @@ __global__ void __launch_bounds__(256, 2) bl_shade_kernel(const BlShadeArgs P) {
               const double coefficient = P.plasma.power_frac * P.power_pol[4] * var_a;
               rho_q += coefficient * P.power_pol[5] * var_d * var_e;
               rho_v += coefficient * P.power_pol[6] * var_c * var_f;
+            }
+          }
+          if (P.cold->kappa.frac != 0.0) {
+            // kappa-distribution electrons (simulation_coefficients.cpp:607-698): every term is the harmonic-like
+            // bridge (low^-x + high^-x)^(-1/x) between a low- and a high-frequency fit. Only polarized runs get
+            // here (bl_init), so the intensity terms are added to j_val / alpha_val in this block as well.
+            const BlKappaDevice &kk = P.cold->kappa;
+            const double nu_kappa_cgs = nu_c_cgs * kk.w * kk.w * kk.kappa * kk.kappa * sin_theta_b;
+            const double xx = nu_cgs / nu_kappa_cgs;
+            const double var_g = 1.0 / blm_sqrt(xx);
+            const double var_h = cos_theta_b >= 0.0 ? 1.0 : -1.0;
+            const double var_e = bl_pow(xx, -0.35);
+            {   // emissivities (:608-637)
+              const double var_a = kk.frac * n_e_cgs * kE * kE * nu_c_cgs / (kC * nu_2_cgs);
+              const double var_b = bl_cbrt(xx) * sin_theta_b;
+              const double var_c = bl_pow(xx, -(kk.kappa - 2.0) / 2.0) * sin_theta_b;
+              const double coefficient_low = kk.jj_low * var_a * var_b;
+              const double coefficient_high = kk.jj_high * var_a * var_c;
+              j_val += bl_pow(bl_pow(coefficient_low, -kk.jj_x_i) + bl_pow(coefficient_high, -kk.jj_x_i), -1.0 / kk.jj_x_i);
+              const double var_d = bl_pow(bl_pow(sin_theta_b, -2.4) - 1.0, 0.48);
+              const double var_f = bl_pow(bl_pow(sin_theta_b, -2.5) - 1.0, 0.44);
+              const double jj_q_low = coefficient_low * kk.jj_low_q;
+              const double jj_v_low = coefficient_low * kk.jj_low_v * var_d * var_e;
+              const double jj_q_high = coefficient_high * kk.jj_high_q;
+              const double jj_v_high = coefficient_high * kk.jj_high_v * var_f * var_g;
+              j_q -= bl_pow(bl_pow(jj_q_low, -kk.jj_x_q) + bl_pow(jj_q_high, -kk.jj_x_q), -1.0 / kk.jj_x_q);
+              j_v += bl_pow(bl_pow(jj_v_low, -kk.jj_x_v) + bl_pow(jj_v_high, -kk.jj_x_v), -1.0 / kk.jj_x_v) * var_h;
+            }
+            {   // absorptivities (:640-667)
+              const double var_a = kk.frac * n_e_cgs * kE * kE / (kMe * kC);
+              const double var_b = bl_pow(xx, -2.0 / 3.0);
+              const double var_c = bl_pow(xx, -(1.0 + kk.kappa) / 2.0);
+              const double coefficient_low = kk.aa_low * var_a * var_b;
+              const double coefficient_high = kk.aa_high * var_a * var_c;
+              const double aa_i_low = coefficient_low;
+              const double aa_i_high = coefficient_high * kk.aa_high_i;
+              alpha_val += bl_pow(bl_pow(aa_i_low, -kk.aa_x_i) + bl_pow(aa_i_high, -kk.aa_x_i), -1.0 / kk.aa_x_i);
+              const double var_d = bl_pow(bl_pow(sin_theta_b, -2.28) - 1.0, 0.446);
+              const double var_f = blm_sqrt(bl_pow(sin_theta_b, -2.05) - 1.0);
+              const double aa_q_low = coefficient_low * kk.aa_low_q;
+              const double aa_v_low = coefficient_low * kk.aa_low_v * var_d * var_e;
+              const double aa_q_high = coefficient_high * kk.aa_high_q;
+              const double aa_v_high = coefficient_high * kk.aa_high_v * var_f * var_g;
+              alpha_q -= bl_pow(bl_pow(aa_q_low, -kk.aa_x_q) + bl_pow(aa_q_high, -kk.aa_x_q), -1.0 / kk.aa_x_q);
+              alpha_v += bl_pow(bl_pow(aa_v_low, -kk.aa_x_v) + bl_pow(aa_v_high, -kk.aa_x_v), -1.0 / kk.aa_x_v) * var_h;
+            }
+            {   // rotativities (:670-698): linear blend of the fits at the two ends of kappa's bracket
+              const double var_a = -kk.frac * n_e_cgs * kE * kE * nu_c_cgs * nu_c_cgs * sh.sin2_theta_b / (kMe * kC * nu_2_cgs);
+              const double var_b = kk.frac * 2.0 * n_e_cgs * kE * kE * nu_c_cgs * cos_theta_b / (kMe * kC * nu_cgs);
+              const double xx_084 = bl_pow(xx, 0.84);
+              const double rho_q_low = var_a * kk.rho_q_low[0] * (1.0 - bl_exp(kk.rho_q_low[1] * xx_084)
+                  - bl_sin(kk.rho_q_low[2] * xx) * bl_exp(kk.rho_q_low[3] * bl_pow(xx, kk.rho_q_low[4])));
+              const double rho_q_high = var_a * kk.rho_q_high[0] * (1.0 - bl_exp(kk.rho_q_high[1] * xx_084)
+                  - bl_sin(kk.rho_q_high[2] * xx) * bl_exp(kk.rho_q_high[3] * bl_pow(xx, kk.rho_q_high[4])));
+              const double rho_v_low = kk.rho_v * var_b * kk.rho_v_low[0] * (1.0 - 0.17 * bl_log(1.0 + kk.rho_v_low[1] * var_g));
+              const double rho_v_high = kk.rho_v * var_b * kk.rho_v_high[0] * (1.0 - 0.17 * bl_log(1.0 + kk.rho_v_high[1] * var_g));
+              rho_q += (1.0 - kk.rho_frac) * rho_q_low + kk.rho_frac * rho_q_high;
+              rho_v += (1.0 - kk.rho_frac) * rho_v_low + kk.rho_frac * rho_v_high;
             }
           }
         }

@@ -104,6 +104,16 @@ struct Oracle {
   double plasma_thermal_frac;
   double power_jj = 0.0, power_aa = 0.0;   // simulation_coefficients.cpp:54-66
   double power_pol[7] = {};                // :67-80: jj_q, jj_v, aa_q, aa_v, rho, rho_q, rho_v
+  // kappa-distribution electrons (simulation_coefficients.cpp:82-193), same names without the prefix
+  struct {
+    double jj_low, jj_high, jj_x_i, aa_low, aa_high, aa_x_i;
+    double jj_low_q, jj_low_v, jj_high_q, jj_high_v, jj_x_q, jj_x_v;
+    double aa_low_q, aa_low_v, aa_high_i, aa_high_q, aa_high_v, aa_x_q, aa_x_v;
+    double rho_v, rho_frac;
+    double rho_q_low_a, rho_q_low_b, rho_q_low_c, rho_q_low_d, rho_q_low_e;
+    double rho_q_high_a, rho_q_high_b, rho_q_high_c, rho_q_high_d, rho_q_high_e;
+    double rho_v_low_a, rho_v_low_b, rho_v_high_a, rho_v_high_b;
+  } kappa = {};
   int render_num_images = 0;               // 0 in formula mode (radiation_integrator.cpp:136-145)
   // slow light: time slices held by the reader, latest first (simulation_reader.cpp:211-303)
   int slow_n = 0;
@@ -1360,6 +1370,27 @@ int SampleOne(const Oracle &o, const double pos[4], Prims *out, bool *gathered, 
 // the header evaluates in the same call, do not enter K_nu. For integer order mu = nu - nl = 0, so
 // __gamma_temme (bessel_function.tcc:100-119) gives gampl = gammi = 1 / tgamma(1) = 1, gam1 = -Euler's
 // constant, gam2 = 1. libm calls (log, sinh, cosh, exp) go through M:: like everywhere else.
+// simulation_coefficients.cpp:740-773: 2F1 through its Pfaff transformation, ten terms of the series
+double Hypergeometric(double alpha, double beta, double gamma, double z) {
+  const int k_max = 10;
+  double a = alpha;
+  double b = gamma - beta;
+  double c = gamma;
+  double x = z / (z - 1.0);
+  double result = 1.0;
+  double a_k = 1.0, b_k = 1.0, c_k = 1.0, xk = 1.0, k_factorial = 1.0;
+  for (int k = 1; k <= k_max; k++) {
+    a_k *= a + k - 1.0;
+    b_k *= b + k - 1.0;
+    c_k *= c + k - 1.0;
+    xk *= x;
+    k_factorial *= k;
+    result += a_k * b_k * xk / (c_k * k_factorial);
+  }
+  result *= M::pow(1.0 - z, -alpha);
+  return result;
+}
+
 double CylBesselK(int nl, double x) {
   if (std::isnan(x)) return std::numeric_limits<double>::quiet_NaN();
   if (x == 0.0) return std::numeric_limits<double>::infinity();
@@ -1757,6 +1788,75 @@ void SimulationCoefficientsOne(const Oracle &o, const double pos[4], const doubl
       double coefficient = p.plasma_power_frac * o.power_pol[4] * var_a;
       pol[4][l * stride] += coefficient * o.power_pol[5] * var_d * var_e;
       pol[5][l * stride] += coefficient * o.power_pol[6] * var_c * var_f;
+    }
+    // kappa-distribution electrons (:607-698); only reached in polarized runs (image_light is then set)
+    if (p.plasma_kappa_frac != 0.0 and (p.image_light or p.image_emission or p.image_emission_ave)) {
+      const auto &kk = o.kappa;
+      double nu_kappa_cgs = nu_c_cgs * p.plasma_w * p.plasma_w * p.plasma_kappa * p.plasma_kappa * sin_theta_b;
+      double xx = nu_cgs / nu_kappa_cgs;
+      double var_a = p.plasma_kappa_frac * n_e_cgs * Physics::e * Physics::e * nu_c_cgs / (Physics::c * nu_2_cgs);
+      double var_b = M::cbrt(xx) * sin_theta_b;
+      double var_c = M::pow(xx, -(p.plasma_kappa - 2.0) / 2.0) * sin_theta_b;
+      double coefficient_low = kk.jj_low * var_a * var_b;
+      double coefficient_high = kk.jj_high * var_a * var_c;
+      j[l * stride] += M::pow(M::pow(coefficient_low, -kk.jj_x_i) + M::pow(coefficient_high, -kk.jj_x_i), -1.0 / kk.jj_x_i);
+      if (polarized) {
+        double var_d = M::pow(M::pow(sin_theta_b, -2.4) - 1.0, 0.48);
+        double var_e = M::pow(xx, -0.35);
+        double var_f = M::pow(M::pow(sin_theta_b, -2.5) - 1.0, 0.44);
+        double var_g = 1.0 / std::sqrt(xx);
+        double var_h = cos_theta_b >= 0.0 ? 1.0 : -1.0;
+        double jj_q_low = coefficient_low * kk.jj_low_q;
+        double jj_v_low = coefficient_low * kk.jj_low_v * var_d * var_e;
+        double jj_q_high = coefficient_high * kk.jj_high_q;
+        double jj_v_high = coefficient_high * kk.jj_high_v * var_f * var_g;
+        pol[0][l * stride] -= M::pow(M::pow(jj_q_low, -kk.jj_x_q) + M::pow(jj_q_high, -kk.jj_x_q), -1.0 / kk.jj_x_q);
+        pol[1][l * stride] += M::pow(M::pow(jj_v_low, -kk.jj_x_v) + M::pow(jj_v_high, -kk.jj_x_v), -1.0 / kk.jj_x_v) * var_h;
+      }
+    }
+    if (p.plasma_kappa_frac != 0.0 and (p.image_light or p.image_tau or p.image_tau_int)) {
+      const auto &kk = o.kappa;
+      double nu_kappa_cgs = nu_c_cgs * p.plasma_w * p.plasma_w * p.plasma_kappa * p.plasma_kappa * sin_theta_b;
+      double xx = nu_cgs / nu_kappa_cgs;
+      double var_a = p.plasma_kappa_frac * n_e_cgs * Physics::e * Physics::e / (Physics::m_e * Physics::c);
+      double var_b = M::pow(xx, -2.0 / 3.0);
+      double var_c = M::pow(xx, -(1.0 + p.plasma_kappa) / 2.0);
+      double coefficient_low = kk.aa_low * var_a * var_b;
+      double coefficient_high = kk.aa_high * var_a * var_c;
+      double aa_i_low = coefficient_low;
+      double aa_i_high = coefficient_high * kk.aa_high_i;
+      alpha[l * stride] += M::pow(M::pow(aa_i_low, -kk.aa_x_i) + M::pow(aa_i_high, -kk.aa_x_i), -1.0 / kk.aa_x_i);
+      if (polarized) {
+        double var_d = M::pow(M::pow(sin_theta_b, -2.28) - 1.0, 0.446);
+        double var_e = M::pow(xx, -0.35);
+        double var_f = std::sqrt(M::pow(sin_theta_b, -2.05) - 1.0);
+        double var_g = 1.0 / std::sqrt(xx);
+        double var_h = cos_theta_b >= 0.0 ? 1.0 : -1.0;
+        double aa_q_low = coefficient_low * kk.aa_low_q;
+        double aa_v_low = coefficient_low * kk.aa_low_v * var_d * var_e;
+        double aa_q_high = coefficient_high * kk.aa_high_q;
+        double aa_v_high = coefficient_high * kk.aa_high_v * var_f * var_g;
+        pol[2][l * stride] -= M::pow(M::pow(aa_q_low, -kk.aa_x_q) + M::pow(aa_q_high, -kk.aa_x_q), -1.0 / kk.aa_x_q);
+        pol[3][l * stride] += M::pow(M::pow(aa_v_low, -kk.aa_x_v) + M::pow(aa_v_high, -kk.aa_x_v), -1.0 / kk.aa_x_v) * var_h;
+      }
+    }
+    if (p.plasma_kappa_frac != 0.0 and polarized) {  // rotativities, :670-698
+      const auto &kk = o.kappa;
+      double nu_kappa_cgs = nu_c_cgs * p.plasma_w * p.plasma_w * p.plasma_kappa * p.plasma_kappa * sin_theta_b;
+      double xx = nu_cgs / nu_kappa_cgs;
+      double var_a = -p.plasma_kappa_frac * n_e_cgs * Physics::e * Physics::e * nu_c_cgs * nu_c_cgs * sin2_theta_b
+          / (Physics::m_e * Physics::c * nu_2_cgs);
+      double var_b = p.plasma_kappa_frac * 2.0 * n_e_cgs * Physics::e * Physics::e * nu_c_cgs * cos_theta_b
+          / (Physics::m_e * Physics::c * nu_cgs);
+      double var_c = 1.0 / std::sqrt(xx);
+      double rho_q_low = var_a * kk.rho_q_low_a * (1.0 - M::exp(kk.rho_q_low_b * M::pow(xx, 0.84))
+          - M::sin(kk.rho_q_low_c * xx) * M::exp(kk.rho_q_low_d * M::pow(xx, kk.rho_q_low_e)));
+      double rho_q_high = var_a * kk.rho_q_high_a * (1.0 - M::exp(kk.rho_q_high_b * M::pow(xx, 0.84))
+          - M::sin(kk.rho_q_high_c * xx) * M::exp(kk.rho_q_high_d * M::pow(xx, kk.rho_q_high_e)));
+      double rho_v_low = kk.rho_v * var_b * kk.rho_v_low_a * (1.0 - 0.17 * M::log(1.0 + kk.rho_v_low_b * var_c));
+      double rho_v_high = kk.rho_v * var_b * kk.rho_v_high_a * (1.0 - 0.17 * M::log(1.0 + kk.rho_v_high_b * var_c));
+      pol[4][l * stride] += (1.0 - kk.rho_frac) * rho_q_low + kk.rho_frac * rho_q_high;
+      pol[5][l * stride] += (1.0 - kk.rho_frac) * rho_v_low + kk.rho_frac * rho_v_high;
     }
   }
 }
@@ -2470,8 +2570,8 @@ int Setup(Oracle &o, const bl_params *p, const bl_grid_desc *g, char *err, size_
     if (p->slow_light_on and (o.slow_n < 2 or o.slow_n != p->slow_chunk_size or o.slow_grids == nullptr or o.slow_times == nullptr))
       return Fail(err, err_len, "oracle: slow light needs slow_chunk_size time slices in blo_extra", BL_E_ARG);
     if (p->simulation_coord == BL_COORD_FMKS) return Fail(err, err_len, "oracle: fmks not restated yet", BL_E_UNSUPPORTED);
-    if (p->plasma_kappa_frac != 0.0)
-      return Fail(err, err_len, "oracle: kappa-distribution electrons not restated (the reference reads the uninitialised kappa_aa_high_i)", BL_E_UNSUPPORTED);
+    if (p->plasma_kappa_frac != 0.0 and not o.image_polarization)
+      return Fail(err, err_len, "oracle: kappa-distribution electrons are restated for polarized runs only (in unpolarized runs the reference reads the uninitialised kappa_aa_high_i)", BL_E_UNSUPPORTED);
     o.plasma_thermal_frac = 1.0 - (p->plasma_power_frac + p->plasma_kappa_frac);
     o.render_num_images = p->render_num_images;   // radiation_integrator.cpp:136-139
     if (p->plasma_power_frac != 0.0) {  // simulation_coefficients.cpp:54-66 (unpolarized part)
@@ -2498,6 +2598,75 @@ int Setup(Oracle &o, const bl_params *p, const bl_grid_desc *g, char *err, size_
         o.power_pol[5] = -M::pow(p->plasma_gamma_min, 2.0 - plasma_p) / (plasma_p / 2.0 - 1.0);
         o.power_pol[6] = var_i * var_j * var_k;
       }
+    }
+    if (p->plasma_kappa_frac != 0.0) {  // simulation_coefficients.cpp:82-193 (a polarized run: see above)
+      auto &kk = o.kappa;
+      double plasma_kappa = p->plasma_kappa, plasma_w = p->plasma_w;
+      double var_a = 4.0 * Math::pi * std::tgamma(plasma_kappa - 4.0 / 3.0);
+      double var_b = M::pow(3.0, 7.0 / 3.0) * std::tgamma(plasma_kappa - 2.0);
+      double var_c = M::pow(3.0, (plasma_kappa - 1.0) / 2.0);
+      double var_d = (plasma_kappa - 2.0) * (plasma_kappa - 1.0) / 4.0;
+      double var_e = std::tgamma(plasma_kappa / 4.0 - 1.0 / 3.0);
+      double var_f = std::tgamma(plasma_kappa / 4.0 + 4.0 / 3.0);
+      double var_g = M::pow(3.0, 1.0 / 6.0) * 10.0 / 41.0;
+      double var_h = plasma_w * plasma_kappa;
+      double var_i = 2.0 * Math::pi * M::pow(var_h, plasma_kappa - 10.0 / 3.0);
+      double var_j = (plasma_kappa - 2.0) * (plasma_kappa - 1.0) * plasma_kappa;
+      double var_k = 3.0 * plasma_kappa - 1.0;
+      double var_l = std::tgamma(5.0 / 3.0);
+      double var_m = Hypergeometric(plasma_kappa - 1.0 / 3.0, plasma_kappa + 1.0, plasma_kappa + 2.0 / 3.0, -var_h);
+      double var_n = M::pow(Math::pi, 1.5) / 3.0;
+      double var_o = var_j / (var_h * var_h * var_h);
+      double var_p = 2.0 * std::tgamma(2.0 + plasma_kappa / 2.0) / (2.0 + plasma_kappa) - 1.0;
+      kk.jj_low = var_a / var_b;
+      kk.jj_high = var_c * var_d * var_e * var_f;
+      kk.jj_x_i = 3.0 * M::pow(plasma_kappa, -1.5);
+      kk.aa_low = var_g * var_i * var_j / var_k * var_l * var_m;
+      kk.aa_high = var_n * var_o * var_p;
+      kk.aa_x_i = M::pow(-1.75 + 1.6 * plasma_kappa, -0.86);
+      double var_q = 14.3 * M::pow(plasma_w, -0.928);
+      double var_r = 169.0 * M::pow(plasma_kappa, -8.0) + 0.0052 * plasma_kappa - 0.0526 + 47.0 / (200.0 * plasma_kappa);
+      kk.jj_low_q = 0.5;
+      kk.jj_low_v = 0.5625 * M::pow(plasma_kappa, -0.528) / plasma_w;
+      kk.jj_high_q = 0.64 + 0.02 * plasma_kappa;
+      kk.jj_high_v = 0.765625 * M::pow(plasma_kappa, -0.44) / plasma_w;
+      kk.jj_x_q = 3.7 * M::pow(plasma_kappa, -1.6);
+      kk.jj_x_v = kk.jj_x_i;
+      kk.aa_low_q = 25.0 / 48.0;
+      kk.aa_low_v = 77.0 / (100.0 * plasma_w) * M::pow(plasma_kappa, -0.7);
+      kk.aa_high_i = M::pow(3.0 / plasma_kappa, 4.75) + 0.6;
+      kk.aa_high_q = 441.0 * M::pow(plasma_kappa, -5.76) + 0.55;
+      kk.aa_high_v = var_q * var_r;
+      kk.aa_x_q = 1.4 * M::pow(plasma_kappa, -1.15);
+      kk.aa_x_v = 1.22 * M::pow(plasma_kappa, -1.136) + 0.007;
+      kk.rho_v = CylBesselK(0, 1.0 / plasma_w) / CylBesselK(2, 1.0 / plasma_w);
+      // the three brackets of kappa (:128-192): each interpolates between the fits for its two ends
+      auto rho_q_a = [&](double c_w, double c_0, double c_1) {
+        return c_w * plasma_w + std::sqrt(plasma_w) * (c_0 + c_1 * M::exp(-5.0 * plasma_w));
+      };
+      auto rho_v_a = [&](int which) {
+        switch (which) {
+          case 0: return (plasma_w * plasma_w + 2.0 * plasma_w + 1.0) / (3.125 * plasma_w * plasma_w + 4.0 * plasma_w + 1.0);
+          case 1: return (plasma_w * plasma_w + 54.0 * plasma_w + 50.0) / (30.0 / 11.0 * plasma_w * plasma_w + 134.0 * plasma_w + 50.0);
+          case 2: return (plasma_w * plasma_w + 43.0 * plasma_w + 38.0) / (7.0 / 3.0 * plasma_w * plasma_w + 92.5 * plasma_w + 38.0);
+          default: return (plasma_w + 13.0 / 14.0) / (2.0 * plasma_w + 13.0 / 14.0);
+        }
+      };
+      // fits at kappa = 3.5, 4, 4.5, 5 (rho_q: a, b, c, d, e; rho_v: a, b)
+      const double fit_q[4][5] = {
+          {rho_q_a(17.0, -3.0, 7.0), -1.0 / 30.0, 0.1, -1.5, 0.471},
+          {rho_q_a(46.0 / 3.0, -5.0 / 3.0, 17.0 / 3.0), -1.0 / 18.0, 1.0 / 6.0, -1.75, 0.5},
+          {rho_q_a(14.0, -1.625, 4.5), -1.0 / 12.0, 0.25, -2.0, 0.525},
+          {rho_q_a(12.5, -1.0, 5.0), -0.125, 0.375, -2.25, 0.541}};
+      const double fit_v_b[4] = {0.447, 0.391, 0.348, 0.313};
+      int lo = plasma_kappa < 4.0 ? 0 : (plasma_kappa < 4.5 ? 1 : 2);
+      kk.rho_frac = (plasma_kappa - (3.5 + 0.5 * lo)) / ((4.0 + 0.5 * lo) - (3.5 + 0.5 * lo));
+      kk.rho_q_low_a = fit_q[lo][0]; kk.rho_q_low_b = fit_q[lo][1]; kk.rho_q_low_c = fit_q[lo][2];
+      kk.rho_q_low_d = fit_q[lo][3]; kk.rho_q_low_e = fit_q[lo][4];
+      kk.rho_q_high_a = fit_q[lo + 1][0]; kk.rho_q_high_b = fit_q[lo + 1][1]; kk.rho_q_high_c = fit_q[lo + 1][2];
+      kk.rho_q_high_d = fit_q[lo + 1][3]; kk.rho_q_high_e = fit_q[lo + 1][4];
+      kk.rho_v_low_a = rho_v_a(lo); kk.rho_v_low_b = fit_v_b[lo];
+      kk.rho_v_high_a = rho_v_a(lo + 1); kk.rho_v_high_b = fit_v_b[lo + 1];
     }
   } else
     o.plasma_thermal_frac = 0.0;

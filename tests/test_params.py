@@ -121,7 +121,13 @@ def test_context_validation_messages(bl):
     assert failing(adaptive_max_level=1, adaptive_block_size=5) == \
         "Error: Must have adaptive_block_size divide camera_resolution."
     # reference configurations outside the hot-path scope are refused loudly, never approximated
-    assert "are not built" in failing(plasma_kappa_frac=0.2, plasma_kappa=4.0, plasma_w=1.0)
+    # kappa-distribution electrons: the constructor's checks (radiation_integrator.cpp:296-308); unpolarized runs are
+    # refused (the reference reads an uninitialised constant there), never approximated
+    assert "built for polarized runs only" in failing(plasma_kappa_frac=0.2, plasma_kappa=4.0, plasma_w=1.0)
+    assert failing(plasma_kappa_frac=0.2, plasma_w=1.0) == "Error: RadiationIntegrator unable to find all needed values in input file."
+    assert failing(plasma_kappa_frac=0.2, plasma_kappa=4.0) == "Error: RadiationIntegrator unable to find all needed values in input file."
+    assert failing(plasma_kappa_frac=0.2, plasma_kappa=5.5, plasma_w=1.0, image_polarization="true",
+                   image_rotation_split="false") == "Error: Polarized transport only supports kappa in [3.5, 5]."
     assert failing(image_polarization="true", image_rotation_split=None) == "Error: RadiationIntegrator unable to find all needed values in input file."
     # a rendering without its features: bad_optional_access in the reference constructor (radiation_integrator.cpp:161)
     assert failing(render_num_images=1) == "Error: RadiationIntegrator unable to find all needed values in input file."

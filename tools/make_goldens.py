@@ -138,6 +138,17 @@ CASES = {
                                               adaptive_rel_lapl_cut=1.0, adaptive_rel_lapl_frac=0.25,
                                               adaptive_num_regions=0, image_tau="true", output_camera="true"),
                                SMALL_MOCK, [136]),
+    # kappa-distribution electrons (simulation_coefficients.cpp:82-193, :607-698), defined in polarized runs only:
+    # next to thermal electrons at kappa = 4 (an end of a bracket of the rotativity fits), and next to thermal and
+    # power-law electrons at kappa = 4.3 (interpolated fits, its warning) with the rotation split, spin and tau
+    "sim_polarized_kappa": (SIM_BASE, dict(camera_resolution=16, image_polarization="true", plasma_kappa_frac=0.4,
+                                           plasma_kappa=4.0, plasma_w=1.5, image_tau="true"), SMALL_MOCK, [136]),
+    "sim_polarized_kappa_mix": (SIM_BASE, dict(camera_resolution=16, image_polarization="true", image_rotation_split="true",
+                                               plasma_kappa_frac=0.25, plasma_kappa=4.3, plasma_w=2.5, plasma_power_frac=0.2,
+                                               plasma_p=3.0, plasma_gamma_min=3.0, plasma_gamma_max=500.0,
+                                               simulation_a=0.9, image_tau="true", image_emission="true",
+                                               image_num_frequencies=2, image_frequency_start=1.0e11,
+                                               image_frequency_end=3.0e11, image_frequency_spacing="log"), SMALL_MOCK, [136]),
     "sim_powerlaw": (SIM_BASE, dict(camera_resolution=24, plasma_power_frac=0.3, plasma_p=2.5, plasma_gamma_min=1.0,
                                     plasma_gamma_max=1000.0), SMALL_MOCK, [300]),
     # false-colour renderings (rendering.cpp): the features of the reference's example_render.input, without
