@@ -1245,16 +1245,16 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
         kk.aa_x_v = 1.22 * bl_pow(plasma_kappa, -1.136) + 0.007;
         kk.rho_v = bl_cyl_bessel_k(0, 1.0 / plasma_w) / bl_cyl_bessel_k(2, 1.0 / plasma_w);
         // rotativity fits at kappa = 3.5, 4, 4.5, 5 (:128-192); kappa is bracketed by two of them
-        const double sqrt_w = blm_sqrt(plasma_w), exp_w = bl_exp(-5.0 * plasma_w), w2 = plasma_w * plasma_w;
+        const double sqrt_w = blm_sqrt(plasma_w), exp_w = bl_exp(-5.0 * plasma_w);
         const double fit_q[4][5] = {
             {17.0 * plasma_w + sqrt_w * (-3.0 + 7.0 * exp_w), -1.0 / 30.0, 0.1, -1.5, 0.471},
             {46.0 / 3.0 * plasma_w + sqrt_w * (-5.0 / 3.0 + 17.0 / 3.0 * exp_w), -1.0 / 18.0, 1.0 / 6.0, -1.75, 0.5},
             {14.0 * plasma_w + sqrt_w * (-1.625 + 4.5 * exp_w), -1.0 / 12.0, 0.25, -2.0, 0.525},
             {12.5 * plasma_w + sqrt_w * (-1.0 + 5.0 * exp_w), -0.125, 0.375, -2.25, 0.541}};
         const double fit_v[4][2] = {
-            {(w2 + 2.0 * plasma_w + 1.0) / (3.125 * w2 + 4.0 * plasma_w + 1.0), 0.447},
-            {(w2 + 54.0 * plasma_w + 50.0) / (30.0 / 11.0 * w2 + 134.0 * plasma_w + 50.0), 0.391},
-            {(w2 + 43.0 * plasma_w + 38.0) / (7.0 / 3.0 * w2 + 92.5 * plasma_w + 38.0), 0.348},
+            {(plasma_w * plasma_w + 2.0 * plasma_w + 1.0) / (3.125 * plasma_w * plasma_w + 4.0 * plasma_w + 1.0), 0.447},
+            {(plasma_w * plasma_w + 54.0 * plasma_w + 50.0) / (30.0 / 11.0 * plasma_w * plasma_w + 134.0 * plasma_w + 50.0), 0.391},
+            {(plasma_w * plasma_w + 43.0 * plasma_w + 38.0) / (7.0 / 3.0 * plasma_w * plasma_w + 92.5 * plasma_w + 38.0), 0.348},
             {(plasma_w + 13.0 / 14.0) / (2.0 * plasma_w + 13.0 / 14.0), 0.313}};
         const int lo = plasma_kappa < 4.0 ? 0 : (plasma_kappa < 4.5 ? 1 : 2);
         const double k_lo = 3.5 + 0.5 * lo, k_hi = 4.0 + 0.5 * lo;

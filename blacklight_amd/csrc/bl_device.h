@@ -201,14 +201,15 @@ struct BlTraceArgs {
 
 // Kernel arguments: shading kernel
 // Polarized transfer (image_polarization): what the polarized transfer kernel needs of every sample besides the
-// eight coefficients - position, renormalised covariant momentum (sample_dir of the reference), affine length
-// and the sampled velocity / field (sample_uu1..bb3, zero where the sample was cut). 96 bytes.
-struct BlPolSample {
+// eight coefficients - position (for the metric and the connection), affine length, k^mu = g^{mu nu} k_nu with the
+// renormalised momentum, and rows 1 and 2 of the fluid tetrad (the only rows the Stokes projection and its inverse
+// read: polarized.cpp:268-292, :793-813). The coefficient kernel has all of it at hand (simulation_coefficients.cpp:
+// 398-431 builds the same tetrad from the same inputs as polarized.cpp:201-265). 128 bytes.
+struct alignas(16) BlPolSample {
   double x[3];
-  double k[4];
   double delta_lambda;
-  float uu[3], bb[3];
-  double pad;
+  double kcon[4];
+  double e1[4], e2[4];
 };
 
 // Slow light (slow_light_on): the time slices the reader holds (simulation_reader.cpp:211-303), latest

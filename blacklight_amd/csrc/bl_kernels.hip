@@ -32,6 +32,7 @@
 #include <hip/hip_runtime.h>
 
 #include "bl_device.h"
+#include "bl_pol_frame.h"
 #include "bl_bessel.h"
 
 namespace {
@@ -1012,7 +1013,7 @@ template <bool kExtended>
 __device__ __forceinline__ void sample_finish_simulation(const BlShadeArgs &P, const BlSpacetime &st,
                                                          const BlKerrSchild &ks, double cth, double ph_unwrapped,
                                                          const float pr[8], float kappa_f, const double kcov[4],
-                                                         int need_coefficients, SampleShade *out) {
+                                                         int need_coefficients, SampleShade *out, BlPolSample *pol_out) {
   const BlPlasmaDevice &pl = P.plasma;
   const double bh_a = st.bh_a, bh_m = st.bh_m;
   const double r = ks.r, r2 = ks.r2, a2 = ks.a2;
@@ -1250,6 +1251,14 @@ __device__ __forceinline__ void sample_finish_simulation(const BlShadeArgs &P, c
   out->kb_tt_e_cgs = kb_tt_e_cgs;
   out->sin2_theta_b = sin2_theta_b;
   out->cos_theta_b = bl_sqrt_g(cos2_theta_b) * (k_b_tet >= 0.0 ? 1.0 : -1.0);   // :455
+  if (kExtended && pol_out != nullptr) {
+    // polarized.cpp:163-265 rebuilds k^mu and this tetrad from the same sampled values: hand them over
+    for (int mu = 0; mu < 4; mu++) {
+      pol_out->kcon[mu] = kcon[mu];
+      pol_out->e1[mu] = tetrad[1][mu];
+      pol_out->e2[mu] = tetrad[2][mu];
+    }
+  }
 }
 
 // Formula mode, one sample (formula_coefficients.cpp:118-161)
@@ -1499,7 +1508,9 @@ __global__ void __launch_bounds__(256, 2) bl_shade_kernel(const BlShadeArgs P) {
     if (status != kSampleCut) {
       if (kModel == BL_MODEL_SIMULATION)
         sample_finish_simulation<kExtended>(P, st, ks, x3 / ks.r, ph, pr, kappa_f, kcov,
-                                            kAux ? P.aux_need_coefficients : 1, &sh);
+                                            kAux ? P.aux_need_coefficients : 1, &sh,
+                                            (kAux && kExtended && P.pol_samples != nullptr)
+                                                ? P.pol_samples + ((size_t)ray * P.ray_max_steps + n) : nullptr);
       else if (!(kAux && nan_ray))
         shade_formula(P, st, ks.r, x1, x2, x3, &sh);
     }
@@ -1533,16 +1544,19 @@ __global__ void __launch_bounds__(256, 2) bl_shade_kernel(const BlShadeArgs P) {
       for (int a = 0; a < BL_NUM_CELL_VALUES; a++) aux.cell[a] = sh.have_cell ? sh.cell[a] : nan;
       P.aux[(size_t)ray * P.ray_max_steps + n] = aux;
       if (kExtended && P.pol_samples != nullptr) {
-        BlPolSample ps;
-        ps.x[0] = x1; ps.x[1] = x2; ps.x[2] = x3;
-        for (int mu = 0; mu < 4; mu++) ps.k[mu] = kcov[mu];
-        ps.delta_lambda = delta_lambda;
-        for (int c = 0; c < 3; c++) {
-          ps.uu[c] = pr[2 + c];
-          ps.bb[c] = pr[5 + c];
+        BlPolSample *ps = P.pol_samples + ((size_t)ray * P.ray_max_steps + n);
+        ps->x[0] = x1; ps->x[1] = x2; ps->x[2] = x3;
+        ps->delta_lambda = delta_lambda;
+        if (!sh.have_coefficients) {
+          // cut samples, cells cut or without field: the coefficient code never reached its tetrad, the polarized
+          // transfer still needs the frame (with zero velocity / field where the sample was cut)
+          float uu[3], bb[3];
+          for (int c = 0; c < 3; c++) {
+            uu[c] = pr[2 + c];
+            bb[c] = pr[5 + c];
+          }
+          bl_pol::sample_frame(st, P.plasma.simulation_coord, x1, x2, x3, kcov, uu, bb, ps);
         }
-        ps.pad = 0.0;
-        P.pol_samples[(size_t)ray * P.ray_max_steps + n] = ps;
       }
     }
     // ---------------- per-frequency coefficients and transfer records

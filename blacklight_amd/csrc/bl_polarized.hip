@@ -10,16 +10,25 @@
 // projected on the camera's tetrad (:875-939) and scaled by nu^3 (:942-949): image rows 4 l + (I, Q, U, V).
 //
 // Inputs are what the coefficient kernel left in HBM in auxiliary-image mode: (j_I, alpha_I) pairs, the three
-// polarized coefficient pairs, and one BlPolSample per sample (position, renormalised k_mu, length, sampled
-// velocity and field). The other image rows of a polarized run come from bl_transfer_aux_kernel.
+// polarized coefficient pairs, and one BlPolSample per sample: position, length, k^mu and rows 1 and 2 of the fluid
+// tetrad - the frame is sample-parallel work and the coefficient kernel has already built it, so the sequential
+// part of a ray keeps only what depends on N. The other image rows of a polarized run come from
+// bl_transfer_aux_kernel.
+//
+// What is sequential, per sample: the connection at the sample (it enters through its average with the previous
+// sample's, element by element, so the previous one is carried: 64 doubles), two half-step transports, the
+// projection on the tetrad, the coupling, the way back. Projection and its inverse only read rows 1 and 2 of the
+// tetrad and only produce / consume the (1,1), (1,2), (2,1), (2,2) tetrad components (:288-292, :795-798); the
+// sums the reference runs over the other rows add products with exact zeros, which change nothing (see
+// from_stokes). State per ray: N and N_temp (32 doubles each, see transport), the previous connection (64), the previous k^mu (4).
 //
 // Arithmetic: plain IEEE double operations in the reference's order (no contraction: -ffp-contract=off), the
 // pinned elementary functions of blmath.h; complex numbers as (re, im) pairs with the component-wise
-// semantics libstdc++ gives real x complex and complex + complex. Not the benchmark path: the state of a ray
-// (N, the previous connection: ~100 doubles) plus the temporaries of a step live in scratch.
+// semantics libstdc++ gives real x complex and complex + complex.
 #include <hip/hip_runtime.h>
 
 #include "bl_device.h"
+#include "bl_pol_frame.h"
 
 namespace {
 
@@ -34,34 +43,34 @@ __device__ __forceinline__ Cplx cscale(double a, Cplx z) { return Cplx{a * z.re,
 __device__ __forceinline__ Cplx cadd(Cplx a, Cplx b) { return Cplx{a.re + b.re, a.im + b.im}; }
 __device__ __forceinline__ Cplx csub(Cplx a, Cplx b) { return Cplx{a.re - b.re, a.im - b.im}; }
 
-// radiation_geometry.cpp:138-262 through the shared Kerr-Schild scalars of bl_geometry.h
-__device__ void geodesic_metric(const BlSpacetime &st, double x, double y, double z, double gcov[4][4], double gcon[4][4]) {
+// GeodesicConnection (radiation_geometry.cpp:274-412) from the Kerr-Schild scalars of the point (r, r^2, f, l_i:
+// the expressions of :283-292 are those of bl_kerr_schild). The connection is not materialised on its own: every
+// component, as soon as it is known, (1) enters gk_new[mu][beta] += k[alpha] Gamma[mu][alpha][beta], the contraction
+// the second half step uses (:816-822), (2) is averaged with the previous sample's component and enters
+// gk_avg[mu][beta] += k_avg[alpha] Gamma_avg[mu][alpha][beta] of the first half step (:150-180), and (3) replaces the
+// previous sample's component. For fixed (mu, beta) the alpha terms arrive in ascending order, as in the reference.
+__device__ __forceinline__ void connection_contractions(const BlSpacetime &st, double x, double y, double z, const BlKerrSchild &ks,
+                                                        const double kcon[4], const double kcon_avg[4],
+                                                        double connection_old[4][4][4], double gk_avg[4][4], double gk_new[4][4]) {
+  for (int mu = 0; mu < 4; mu++)
+    for (int beta = 0; beta < 4; beta++) gk_avg[mu][beta] = gk_new[mu][beta] = 0.0;
   if (st.ray_flat) {
-    bl_minkowski(gcov);
-    bl_minkowski(gcon);
-    return;
-  }
-  BlKerrSchild ks;
-  bl_kerr_schild(st, x, y, z, &ks);
-  bl_gcov_ks(ks, gcov);
-  bl_gcon_ks(ks, gcon);
-}
-
-// radiation_geometry.cpp:274-412
-__device__ void geodesic_connection(const BlSpacetime &st, double x, double y, double z, double connection[4][4][4]) {
-  if (st.ray_flat) {
+#pragma unroll
     for (int mu = 0; mu < 4; mu++)
+#pragma unroll
       for (int alpha = 0; alpha < 4; alpha++)
-        for (int beta = 0; beta < 4; beta++) connection[mu][alpha][beta] = 0.0;
+#pragma unroll
+        for (int beta = 0; beta < 4; beta++) {
+          const double g = 0.0;
+          gk_new[mu][beta] += kcon[alpha] * g;
+          gk_avg[mu][beta] += kcon_avg[alpha] * (0.5 * (connection_old[mu][alpha][beta] + g));
+          connection_old[mu][alpha][beta] = g;
+        }
     return;
   }
-  const double bh_a = st.bh_a, bh_m = st.bh_m;
-  const double a2 = bh_a * bh_a;
-  const double rr2 = x * x + y * y + z * z;
-  const double r2 = 0.5 * (rr2 - a2 + bl_hypot(rr2 - a2, 2.0 * bh_a * z));
-  const double r = blm_sqrt(r2);
-  const double f = 2.0 * bh_m * r2 * r / (r2 * r2 + a2 * z * z);
-  const double l[4] = {-1.0, (r * x + bh_a * y) / (r2 + a2), (r * y - bh_a * x) / (r2 + a2), z / r};
+  const double bh_a = st.bh_a;
+  const double a2 = ks.a2, rr2 = ks.rr2, r2 = ks.r2, r = ks.r, f = ks.f;
+  const double l[4] = {-1.0, ks.l[0], ks.l[1], ks.l[2]};
   double gcon[4][4];
   for (int mu = 0; mu < 4; mu++)
     for (int nu = 0; nu < 4; nu++) gcon[mu][nu] = -f * l[mu] * l[nu];
@@ -90,191 +99,141 @@ __device__ void geodesic_connection(const BlSpacetime &st, double x, double y, d
   double dgcov[4][4][4];
   for (int mu = 0; mu < 4; mu++)
     for (int nu = 0; nu < 4; nu++) dgcov[0][mu][nu] = 0.0;
+#pragma unroll
   for (int a = 1; a < 4; a++)
+#pragma unroll
     for (int mu = 0; mu < 4; mu++)
+#pragma unroll
       for (int nu = 0; nu < 4; nu++) {
         const double val = df[a] * l[mu] * l[nu] + f * dl[mu][a] * l[nu] + f * l[mu] * dl[nu][a];
         dgcov[a][mu][nu] = ((mu == 0) != (nu == 0)) ? -val : val;
       }
+#pragma unroll
+  for (int mu = 0; mu < 4; mu++)
+#pragma unroll
+    for (int alpha = 0; alpha < 4; alpha++)
+#pragma unroll
+      for (int beta = 0; beta < 4; beta++) {
+        double g = 0.0;
+#pragma unroll
+        for (int nu = 0; nu < 4; nu++)
+          g += 0.5 * gcon[mu][nu] * (dgcov[alpha][beta][nu] + dgcov[beta][alpha][nu] - dgcov[nu][alpha][beta]);
+        gk_new[mu][beta] += kcon[alpha] * g;
+        gk_avg[mu][beta] += kcon_avg[alpha] * (0.5 * (connection_old[mu][alpha][beta] + g));
+        connection_old[mu][alpha][beta] = g;
+      }
+}
+
+// The connection alone, for the first sample of a ray (its "previous" connection is its own: :150-154)
+__device__ __forceinline__ void connection_first(const BlSpacetime &st, double x, double y, double z, const BlKerrSchild &ks,
+                                                 double connection_old[4][4][4]) {
+  const double zero[4] = {0.0, 0.0, 0.0, 0.0};
+  double gk_a[4][4], gk_b[4][4];
   for (int mu = 0; mu < 4; mu++)
     for (int alpha = 0; alpha < 4; alpha++)
-      for (int beta = 0; beta < 4; beta++) {
-        double acc = 0.0;
-        for (int nu = 0; nu < 4; nu++)
-          acc += 0.5 * gcon[mu][nu] * (dgcov[alpha][beta][nu] + dgcov[beta][alpha][nu] - dgcov[nu][alpha][beta]);
-        connection[mu][alpha][beta] = acc;
-      }
+      for (int beta = 0; beta < 4; beta++) connection_old[mu][alpha][beta] = 0.0;
+  connection_contractions(st, x, y, z, ks, zero, zero, connection_old, gk_a, gk_b);
 }
 
-// radiation_geometry.cpp:421-573: metric of the simulation's coordinates at a CKS point
-__device__ void simulation_metric(const BlSpacetime &st, int coord, double x, double y, double z, double gcov[4][4],
-                                  double gcon[4][4]) {
-  const double bh_a = st.bh_a, bh_m = st.bh_m;
-  const double a2 = bh_a * bh_a;
-  const double rr2 = x * x + y * y + z * z;
-  const double r2 = 0.5 * (rr2 - a2 + bl_hypot(rr2 - a2, 2.0 * bh_a * z));
-  const double r = blm_sqrt(r2);
-  if (coord == BL_COORD_CKS) {
-    const double f = 2.0 * bh_m * r2 * r / (r2 * r2 + a2 * z * z);
-    const double l1 = (r * x + bh_a * y) / (r2 + a2), l2 = (r * y - bh_a * x) / (r2 + a2), l3 = z / r;
-    const double lcov[4] = {1.0, l1, l2, l3}, lcon[4] = {-1.0, l1, l2, l3};
-    for (int mu = 0; mu < 4; mu++)
-      for (int nu = 0; nu < 4; nu++) {
-        gcov[mu][nu] = f * lcov[mu] * lcov[nu];
-        gcon[mu][nu] = -f * lcon[mu] * lcon[nu];
-      }
-    gcov[0][0] = f * lcov[0] * lcov[0] - 1.0;
-    gcon[0][0] = -f * lcon[0] * lcon[0] - 1.0;
-    for (int a = 1; a < 4; a++) {
-      gcov[a][a] = f * lcov[a] * lcov[a] + 1.0;
-      gcon[a][a] = -f * lcon[a] * lcon[a] + 1.0;
-    }
-    return;
-  }
-  const double cth = z / r;
-  const double cth2 = cth * cth;
-  const double sth2 = 1.0 - cth2;
-  const double delta = r2 - 2.0 * bh_m * r + a2;
-  const double sigma = r2 + a2 * cth2;
-  for (int mu = 0; mu < 4; mu++)
-    for (int nu = 0; nu < 4; nu++) gcov[mu][nu] = gcon[mu][nu] = 0.0;
-  gcov[0][0] = -(1.0 - 2.0 * bh_m * r / sigma);
-  gcov[0][1] = gcov[1][0] = 2.0 * bh_m * r / sigma;
-  gcov[0][3] = gcov[3][0] = -2.0 * bh_m * bh_a * r * sth2 / sigma;
-  gcov[1][1] = 1.0 + 2.0 * bh_m * r / sigma;
-  gcov[1][3] = gcov[3][1] = -(1.0 + 2.0 * bh_m * r / sigma) * bh_a * sth2;
-  gcov[2][2] = sigma;
-  gcov[3][3] = (r2 + a2 + 2.0 * bh_m * a2 * r * sth2 / sigma) * sth2;
-  gcon[0][0] = -(1.0 + 2.0 * bh_m * r / sigma);
-  gcon[0][1] = gcon[1][0] = 2.0 * bh_m * r / sigma;
-  gcon[1][1] = delta / sigma;
-  gcon[1][3] = gcon[3][1] = bh_a / sigma;
-  gcon[2][2] = 1.0 / sigma;
-  gcon[3][3] = 1.0 / (sigma * sth2);
-}
-
-// radiation_geometry.cpp:69-126
-__device__ void coordinate_jacobian(const BlSpacetime &st, int coord, double x, double y, double z, double jacobian[4][4]) {
-  for (int mu = 0; mu < 4; mu++)
-    for (int nu = 0; nu < 4; nu++) jacobian[mu][nu] = mu == nu ? 1.0 : 0.0;
-  if (coord == BL_COORD_CKS) return;
-  const double bh_a = st.bh_a;
-  const double a2 = bh_a * bh_a;
-  const double rr2 = x * x + y * y + z * z;
-  const double r2 = 0.5 * (rr2 - a2 + bl_hypot(rr2 - a2, 2.0 * bh_a * z));
-  const double r = blm_sqrt(r2);
-  const double cth = z / r;
-  const double sth = blm_sqrt(1.0 - cth * cth);
-  const double ph = bl_atan2(y, x) - bl_atan(bh_a / r);
-  const double sph = bl_sin(ph);
-  const double cph = bl_cos(ph);
-  jacobian[1][1] = sth * cph;
-  jacobian[1][2] = cth * (r * cph - bh_a * sph);
-  jacobian[1][3] = sth * (-r * sph - bh_a * cph);
-  jacobian[2][1] = sth * sph;
-  jacobian[2][2] = cth * (r * sph + bh_a * cph);
-  jacobian[2][3] = sth * (r * cph - bh_a * sph);
-  jacobian[3][1] = cth;
-  jacobian[3][2] = -r * sth;
-  jacobian[3][3] = 0.0;
-}
-
-// radiation_geometry.cpp:597-658
-__device__ void tetrad_frame(const double ucon[4], const double ucov[4], const double kcon[4], const double kcov[4],
-                             const double up_con[4], const double gcov[4][4], const double gcon[4][4], double tetrad[4][4]) {
-  double omega = 0.0;
-  for (int mu = 0; mu < 4; mu++) omega -= kcov[mu] * ucon[mu];
-  double k_up_over_omega = 0.0;
-  for (int mu = 0; mu < 4; mu++) k_up_over_omega += kcov[mu] * up_con[mu];
-  k_up_over_omega /= omega;
-  double u_up_over_omega = 0.0;
-  for (int mu = 0; mu < 4; mu++) u_up_over_omega += ucov[mu] * up_con[mu];
-  u_up_over_omega /= omega;
-  for (int mu = 0; mu < 4; mu++) tetrad[0][mu] = ucon[mu];
-  for (int mu = 0; mu < 4; mu++) tetrad[3][mu] = kcon[mu] / omega - ucon[mu];
-  for (int mu = 0; mu < 4; mu++) tetrad[2][mu] = up_con[mu] - k_up_over_omega * tetrad[3][mu] + u_up_over_omega * kcon[mu];
-  double norm = 0.0;
-  for (int mu = 0; mu < 4; mu++)
-    for (int nu = 0; nu < 4; nu++) norm += gcov[mu][nu] * tetrad[2][mu] * tetrad[2][nu];
-  norm = blm_sqrt(norm);
-  for (int mu = 0; mu < 4; mu++) tetrad[2][mu] /= norm;
-  double t1[4];
-  t1[0] = tetrad[0][1] * (tetrad[2][3] * tetrad[3][2] - tetrad[2][2] * tetrad[3][3])
-      + tetrad[0][2] * (tetrad[2][1] * tetrad[3][3] - tetrad[2][3] * tetrad[3][1])
-      + tetrad[0][3] * (tetrad[2][2] * tetrad[3][1] - tetrad[2][1] * tetrad[3][2]);
-  t1[1] = tetrad[0][0] * (tetrad[2][2] * tetrad[3][3] - tetrad[2][3] * tetrad[3][2])
-      + tetrad[0][2] * (tetrad[2][3] * tetrad[3][0] - tetrad[2][0] * tetrad[3][3])
-      + tetrad[0][3] * (tetrad[2][0] * tetrad[3][2] - tetrad[2][2] * tetrad[3][0]);
-  t1[2] = tetrad[0][0] * (tetrad[2][3] * tetrad[3][1] - tetrad[2][1] * tetrad[3][3])
-      + tetrad[0][1] * (tetrad[2][0] * tetrad[3][3] - tetrad[2][3] * tetrad[3][0])
-      + tetrad[0][3] * (tetrad[2][1] * tetrad[3][0] - tetrad[2][0] * tetrad[3][1]);
-  t1[3] = tetrad[0][0] * (tetrad[2][1] * tetrad[3][2] - tetrad[2][2] * tetrad[3][1])
-      + tetrad[0][1] * (tetrad[2][2] * tetrad[3][0] - tetrad[2][0] * tetrad[3][2])
-      + tetrad[0][2] * (tetrad[2][0] * tetrad[3][1] - tetrad[2][1] * tetrad[3][0]);
-  for (int mu = 0; mu < 4; mu++) {
-    double acc = 0.0;
-    for (int nu = 0; nu < 4; nu++) acc += gcon[mu][nu] * t1[nu];
-    tetrad[1][mu] = acc;
-  }
-}
-
-// N^{mu nu} -> covariant components in a tetrad (:268-285, :904-925): N_{(a)(b)} = e_(a)^mu e_(b)^nu g g N
-__device__ void to_tetrad(const double gcov[4][4], const double tetrad[4][4], const Cplx nn_con[4][4], Cplx nn_tet_cov[4][4]) {
-  Cplx temp_b[4][4], temp_c[4][4], temp_d[4][4];
-  for (int nu = 0; nu < 4; nu++)
-    for (int alpha = 0; alpha < 4; alpha++) {
-      Cplx acc = {0.0, 0.0};
-      for (int beta = 0; beta < 4; beta++) acc = cadd(acc, cscale(gcov[nu][beta], nn_con[alpha][beta]));
-      temp_b[nu][alpha] = acc;
-    }
-  for (int mu = 0; mu < 4; mu++)
-    for (int nu = 0; nu < 4; nu++) {
-      Cplx acc = {0.0, 0.0};
-      for (int alpha = 0; alpha < 4; alpha++) acc = cadd(acc, cscale(gcov[mu][alpha], temp_b[nu][alpha]));
-      temp_c[mu][nu] = acc;
-    }
-  for (int b = 0; b < 4; b++)
-    for (int mu = 0; mu < 4; mu++) {
-      Cplx acc = {0.0, 0.0};
-      for (int nu = 0; nu < 4; nu++) acc = cadd(acc, cscale(tetrad[b][nu], temp_c[mu][nu]));
-      temp_d[b][mu] = acc;
-    }
-  for (int a = 0; a < 4; a++)
-    for (int b = 0; b < 4; b++) {
-      Cplx acc = {0.0, 0.0};
-      for (int mu = 0; mu < 4; mu++) acc = cadd(acc, cscale(tetrad[a][mu], temp_d[b][mu]));
-      nn_tet_cov[a][b] = acc;
-    }
-}
-
-__device__ void stokes_from(const Cplx nn_tet_cov[4][4], double ss[4]) {   // I 14
-  ss[0] = 0.5 * cadd(nn_tet_cov[1][1], nn_tet_cov[2][2]).re;
-  ss[1] = 0.5 * csub(nn_tet_cov[1][1], nn_tet_cov[2][2]).re;
-  ss[2] = 0.5 * cadd(nn_tet_cov[1][2], nn_tet_cov[2][1]).re;
-  ss[3] = 0.5 * csub(nn_tet_cov[2][1], nn_tet_cov[1][2]).im;
-}
-
-// Half a step of dN/dlambda = -(Gamma^mu_{alpha beta} k^alpha N^{beta nu} + (mu <-> nu)) (:181-198, :816-833):
-// target += dN/dlambda(source) * dl
-__device__ void transport(const double kcon[4], const double connection[4][4][4], const Cplx source[4][4], double dl,
-                          Cplx target[4][4]) {
-  double gk[4][4];
-  for (int mu = 0; mu < 4; mu++)
-    for (int beta = 0; beta < 4; beta++) {
-      double acc = 0.0;
-      for (int alpha = 0; alpha < 4; alpha++) acc += kcon[alpha] * connection[mu][alpha][beta];
-      gk[mu][beta] = acc;
-    }
+// Half a step of dN/dlambda = -(Gamma^mu_{alpha beta} k^alpha N^{beta nu} + (mu <-> nu)) (:181-198, :816-833), with
+// gk[mu][beta] = k^alpha Gamma^mu_{alpha beta}: target += dN/dlambda(source) dl. The reference's two half steps are
+// not symmetric: the first adds the derivative at the current N to N_temp - which still holds N as it was before
+// the previous sample's second half step - and then sets N = N_temp; the second copies N to N_temp and adds the
+// derivative to N. Both N and N_temp are therefore carried from sample to sample.
+__device__ __forceinline__ void transport(const double gk[4][4], double dl, const Cplx nn[4][4], Cplx target[4][4]) {
   Cplx delta[4][4];
+#pragma unroll
   for (int mu = 0; mu < 4; mu++)
+#pragma unroll
     for (int nu = 0; nu < 4; nu++) {
       Cplx d = {0.0, 0.0};
+#pragma unroll
       for (int beta = 0; beta < 4; beta++)
-        d = csub(d, cadd(cscale(gk[mu][beta], source[beta][nu]), cscale(gk[nu][beta], source[mu][beta])));
+        d = csub(d, cadd(cscale(gk[mu][beta], nn[beta][nu]), cscale(gk[nu][beta], nn[mu][beta])));
       delta[mu][nu] = cscale(dl, d);   // complex * real: component-wise
     }
+#pragma unroll
   for (int mu = 0; mu < 4; mu++)
+#pragma unroll
     for (int nu = 0; nu < 4; nu++) target[mu][nu] = cadd(target[mu][nu], delta[mu][nu]);
+}
+
+// Stokes parameters of N^{mu nu} in a tetrad (:268-292, :904-932). N_{(a)(b)} = e_(a)^mu e_(b)^nu g g N is evaluated in
+// the reference's nesting; only a, b in {1, 2} enter I, Q, U, V, so the last two contractions run over rows 1 and 2 of
+// the tetrad only (the entries they skip are never read).
+__device__ __forceinline__ void to_stokes(const double gcov[4][4], const double e1[4], const double e2[4], const Cplx nn_con[4][4],
+                                          double ss[4]) {
+  Cplx temp_c[4][4];
+  {
+    Cplx temp_b[4][4];
+#pragma unroll
+    for (int nu = 0; nu < 4; nu++)
+#pragma unroll
+      for (int alpha = 0; alpha < 4; alpha++) {
+        Cplx acc = {0.0, 0.0};
+#pragma unroll
+        for (int beta = 0; beta < 4; beta++) acc = cadd(acc, cscale(gcov[nu][beta], nn_con[alpha][beta]));
+        temp_b[nu][alpha] = acc;
+      }
+#pragma unroll
+    for (int mu = 0; mu < 4; mu++)
+#pragma unroll
+      for (int nu = 0; nu < 4; nu++) {
+        Cplx acc = {0.0, 0.0};
+#pragma unroll
+        for (int alpha = 0; alpha < 4; alpha++) acc = cadd(acc, cscale(gcov[mu][alpha], temp_b[nu][alpha]));
+        temp_c[mu][nu] = acc;
+      }
+  }
+  Cplx d1[4], d2[4];   // temp_d[b][mu] for b = 1, 2
+#pragma unroll
+  for (int mu = 0; mu < 4; mu++) {
+    Cplx a1 = {0.0, 0.0}, a2 = {0.0, 0.0};
+#pragma unroll
+    for (int nu = 0; nu < 4; nu++) {
+      a1 = cadd(a1, cscale(e1[nu], temp_c[mu][nu]));
+      a2 = cadd(a2, cscale(e2[nu], temp_c[mu][nu]));
+    }
+    d1[mu] = a1;
+    d2[mu] = a2;
+  }
+  Cplx n11 = {0.0, 0.0}, n12 = {0.0, 0.0}, n21 = {0.0, 0.0}, n22 = {0.0, 0.0};   // nn_tet_cov[a][b] = sum e_a[mu] temp_d[b][mu]
+#pragma unroll
+  for (int mu = 0; mu < 4; mu++) {
+    n11 = cadd(n11, cscale(e1[mu], d1[mu]));
+    n12 = cadd(n12, cscale(e1[mu], d2[mu]));
+    n21 = cadd(n21, cscale(e2[mu], d1[mu]));
+    n22 = cadd(n22, cscale(e2[mu], d2[mu]));
+  }
+  ss[0] = 0.5 * cadd(n11, n22).re;   // I 14
+  ss[1] = 0.5 * csub(n11, n22).re;
+  ss[2] = 0.5 * cadd(n12, n21).re;
+  ss[3] = 0.5 * csub(n21, n12).im;
+}
+
+// Back to coordinates (:793-813): N^{mu nu} = e_(a)^mu e_(b)^nu N^{(a)(b)} with N^{(a)(b)} non-zero for a, b in {1, 2}
+// only. The reference sums over all four a and b; its extra terms are products of a tetrad component with an exact
+// (0, 0): +-0, which leave a sum that started at +0 unchanged (x + (+-0) = x, and (+0) + (-0) = +0), or NaN when that
+// tetrad component is not finite - and then rows 1 and 2, which are built from rows 0 and 3, are NaN throughout and
+// N is NaN throughout either way. "0.0 +" below is the reference's zero-initialised accumulator.
+__device__ __forceinline__ void from_stokes(const double e1[4], const double e2[4], const double ss[4], Cplx nn_con[4][4]) {
+  const Cplx t11 = {ss[0] + ss[1], 0.0};
+  const Cplx t22 = {ss[0] - ss[1], 0.0};
+  // ss_2 -+ i ss_3 with libstdc++'s real -+ complex: i * ss_3 = (0 * ss_3, 1 * ss_3)
+  const Cplx t12 = {-(0.0 * ss[3]) + ss[2], -(1.0 * ss[3])};
+  const Cplx t21 = {0.0 * ss[3] + ss[2], 1.0 * ss[3]};
+  const Cplx zero = {0.0, 0.0};
+  Cplx f1[4], f2[4];   // temp_f[nu][a] = sum_b e_b[nu] N^{(a)(b)} for a = 1, 2
+#pragma unroll
+  for (int nu = 0; nu < 4; nu++) {
+    f1[nu] = cadd(cadd(zero, cscale(e1[nu], t11)), cscale(e2[nu], t12));
+    f2[nu] = cadd(cadd(zero, cscale(e1[nu], t21)), cscale(e2[nu], t22));
+  }
+#pragma unroll
+  for (int mu = 0; mu < 4; mu++)
+#pragma unroll
+    for (int nu = 0; nu < 4; nu++)
+      nn_con[mu][nu] = cadd(cadd(zero, cscale(e1[mu], f1[nu])), cscale(e2[mu], f2[nu]));
 }
 
 struct Coupling {
@@ -455,98 +414,28 @@ __global__ void __launch_bounds__(64) bl_transfer_polarized_kernel(BlTransferArg
       for (int a = 0; a < 4; a++) img[(size_t)(4 * l + a) * row] = 0.0;
       continue;
     }
-    double delta_lambda_old = 0.0;
-    double kcon_old[4] = {0.0, 0.0, 0.0, 0.0};
-    double connection_old[4][4][4];
     Cplx nn_con[4][4], nn_con_temp[4][4];
     for (int mu = 0; mu < 4; mu++)
       for (int nu = 0; nu < 4; nu++) nn_con[mu][nu] = nn_con_temp[mu][nu] = Cplx{0.0, 0.0};
-    // reference sample order is reversed integration order (geodesics.cpp:832-840): its n = 0 is record num - 1
+    // reference sample order is reversed integration order (geodesics.cpp:832-840): its n = 0 is record num - 1.
+    // At n = 0 the "previous" connection and k^mu are the sample's own (:150-154, :167-169); averaging a value
+    // with itself returns it, so the loop below needs no first-sample case.
+    double delta_lambda_old = 0.0;
+    double kcon_old[4];
+    double connection_old[4][4][4];
+    {
+      const BlPolSample s = samples[num - 1];
+      BlKerrSchild ks;
+      bl_kerr_schild(st, s.x[0], s.x[1], s.x[2], &ks);
+      connection_first(st, s.x[0], s.x[1], s.x[2], ks, connection_old);
+      for (int mu = 0; mu < 4; mu++) kcon_old[mu] = s.kcon[mu];
+    }
     for (int rec = num - 1; rec >= 0; rec--) {
-      const bool first = rec == num - 1;
       const BlPolSample s = samples[rec];
       const double delta_lambda = s.delta_lambda;
       const double delta_lambda_new = rec > 0 ? samples[rec - 1].delta_lambda : delta_lambda;
       const double delta_lambda_cgs = delta_lambda * P.x_unit / (freq * momentum_factor);
       const double x1 = s.x[0], x2 = s.x[1], x3 = s.x[2];
-      const double kcov[4] = {s.k[0], s.k[1], s.k[2], s.k[3]};
-      const double uu1 = s.uu[0], uu2 = s.uu[1], uu3 = s.uu[2], bb1 = s.bb[0], bb2 = s.bb[1], bb3 = s.bb[2];
-
-      double gcov[4][4], gcon[4][4], connection[4][4][4];
-      geodesic_metric(st, x1, x2, x3, gcov, gcon);
-      geodesic_connection(st, x1, x2, x3, connection);
-      for (int mu = 0; mu < 4; mu++)
-        for (int alpha = 0; alpha < 4; alpha++)
-          for (int beta = 0; beta < 4; beta++)
-            connection_old[mu][alpha][beta] = first ? connection[mu][alpha][beta]
-                : 0.5 * (connection_old[mu][alpha][beta] + connection[mu][alpha][beta]);
-      double kcon[4];
-      for (int mu = 0; mu < 4; mu++) {
-        double acc = 0.0;
-        for (int nu = 0; nu < 4; nu++) acc += gcon[mu][nu] * kcov[nu];
-        kcon[mu] = acc;
-      }
-      for (int mu = 0; mu < 4; mu++) kcon_old[mu] = first ? kcon[mu] : 0.5 * (kcon_old[mu] + kcon[mu]);
-
-      // first half step: N_temp += dN/dlambda(N) dl, N = N_temp
-      transport(kcon_old, connection_old, nn_con, (delta_lambda_old + delta_lambda) / 2.0, nn_con_temp);
-      for (int mu = 0; mu < 4; mu++)
-        for (int nu = 0; nu < 4; nu++) nn_con[mu][nu] = nn_con_temp[mu][nu];
-
-      // fluid frame (:201-265)
-      double tetrad[4][4];
-      {
-        double gcov_sim[4][4], gcon_sim[4][4], jacobian[4][4];
-        simulation_metric(st, P.simulation_coord, x1, x2, x3, gcov_sim, gcon_sim);
-        const double uu0 = blm_sqrt(1.0 + gcov_sim[1][1] * uu1 * uu1 + 2.0 * gcov_sim[1][2] * uu1 * uu2
-            + 2.0 * gcov_sim[1][3] * uu1 * uu3 + gcov_sim[2][2] * uu2 * uu2 + 2.0 * gcov_sim[2][3] * uu2 * uu3
-            + gcov_sim[3][3] * uu3 * uu3);
-        const double lapse = 1.0 / blm_sqrt(-gcon_sim[0][0]);
-        const double shift1 = -gcon_sim[0][1] / gcon_sim[0][0];
-        const double shift2 = -gcon_sim[0][2] / gcon_sim[0][0];
-        const double shift3 = -gcon_sim[0][3] / gcon_sim[0][0];
-        double ucon_sim[4], ucov_sim[4], bcon_sim[4];
-        ucon_sim[0] = uu0 / lapse;
-        ucon_sim[1] = uu1 - shift1 * uu0 / lapse;
-        ucon_sim[2] = uu2 - shift2 * uu0 / lapse;
-        ucon_sim[3] = uu3 - shift3 * uu0 / lapse;
-        for (int mu = 0; mu < 4; mu++) {
-          double acc = 0.0;
-          for (int nu = 0; nu < 4; nu++) acc += gcov_sim[mu][nu] * ucon_sim[nu];
-          ucov_sim[mu] = acc;
-        }
-        bcon_sim[0] = ucov_sim[1] * bb1 + ucov_sim[2] * bb2 + ucov_sim[3] * bb3;
-        bcon_sim[1] = (bb1 + bcon_sim[0] * ucon_sim[1]) / ucon_sim[0];
-        bcon_sim[2] = (bb2 + bcon_sim[0] * ucon_sim[2]) / ucon_sim[0];
-        bcon_sim[3] = (bb3 + bcon_sim[0] * ucon_sim[3]) / ucon_sim[0];
-        coordinate_jacobian(st, P.simulation_coord, x1, x2, x3, jacobian);
-        double ucon[4], bcon[4], ucov[4], upcon[4];
-        for (int mu = 0; mu < 4; mu++) {
-          double au = 0.0, ab = 0.0;
-          for (int nu = 0; nu < 4; nu++) {
-            au += jacobian[mu][nu] * ucon_sim[nu];
-            ab += jacobian[mu][nu] * bcon_sim[nu];
-          }
-          ucon[mu] = au;
-          bcon[mu] = ab;
-        }
-        for (int mu = 0; mu < 4; mu++) {
-          double acc = 0.0;
-          for (int nu = 0; nu < 4; nu++) acc += gcov[mu][nu] * ucon[nu];
-          ucov[mu] = acc;
-        }
-        const bool no_field = bb1 == 0.0 && bb2 == 0.0 && bb3 == 0.0;
-        for (int mu = 0; mu < 4; mu++) upcon[mu] = no_field ? (mu == 3 ? 1.0 : 0.0) : bcon[mu];
-        tetrad_frame(ucon, ucov, kcon, kcov, upcon, gcov, gcon, tetrad);
-      }
-
-      double ss_start[4], ss_end[4] = {0.0, 0.0, 0.0, 0.0};
-      {
-        Cplx nn_tet_cov[4][4];
-        to_tetrad(gcov, tetrad, nn_con, nn_tet_cov);
-        stokes_from(nn_tet_cov, ss_start);
-      }
-
       Coupling c;
       {
         const size_t at = (size_t)rec * P.n_nu + l;
@@ -555,6 +444,33 @@ __global__ void __launch_bounds__(64) bl_transfer_polarized_kernel(BlTransferArg
         c.alpha_s[0] = c0.y; c.alpha_s[1] = c2.x; c.alpha_s[2] = 0.0; c.alpha_s[3] = c2.y;
         c.rho_s[0] = 0.0; c.rho_s[1] = c3.x; c.rho_s[2] = 0.0; c.rho_s[3] = c3.y;
       }
+
+      BlKerrSchild ks;
+      bl_kerr_schild(st, x1, x2, x3, &ks);
+      double kcon[4], kcon_avg[4];
+      for (int mu = 0; mu < 4; mu++) {
+        kcon[mu] = s.kcon[mu];
+        kcon_avg[mu] = 0.5 * (kcon_old[mu] + kcon[mu]);
+      }
+      double gk_avg[4][4], gk_new[4][4];
+      connection_contractions(st, x1, x2, x3, ks, kcon, kcon_avg, connection_old, gk_avg, gk_new);
+
+      // first half step (:171-198)
+      transport(gk_avg, (delta_lambda_old + delta_lambda) / 2.0, nn_con, nn_con_temp);
+      for (int mu = 0; mu < 4; mu++)
+        for (int nu = 0; nu < 4; nu++) nn_con[mu][nu] = nn_con_temp[mu][nu];
+
+      // fluid frame: Stokes parameters before the coupling (:268-292)
+      double ss_start[4], ss_end[4] = {0.0, 0.0, 0.0, 0.0};
+      {
+        double gcov[4][4];
+        if (st.ray_flat)
+          bl_minkowski(gcov);
+        else
+          bl_gcov_ks(ks, gcov);
+        to_stokes(gcov, s.e1, s.e2, nn_con, ss_start);
+      }
+
       c.delta_lambda_cgs = delta_lambda_cgs;
       c.delta_tau = c.alpha_s[0] * delta_lambda_cgs;
       c.optically_thin = c.delta_tau <= kDeltaTauMax;
@@ -587,41 +503,14 @@ __global__ void __launch_bounds__(64) bl_transfer_polarized_kernel(BlTransferArg
       ss_end[0] = (ss_end[0] < 0.0) ? 0.0 : ss_end[0];
       limit_polarization(ss_end);
 
-      // back to coordinates (:793-813)
-      {
-        Cplx nn_tet_con[4][4];
-        for (int mu = 0; mu < 4; mu++)
-          for (int nu = 0; nu < 4; nu++) nn_tet_con[mu][nu] = Cplx{0.0, 0.0};
-        nn_tet_con[1][1] = Cplx{ss_end[0] + ss_end[1], 0.0};
-        nn_tet_con[2][2] = Cplx{ss_end[0] - ss_end[1], 0.0};
-        // ss_2 -+ i ss_3 with libstdc++'s real -+ complex: i * ss_3 = (0 * ss_3, 1 * ss_3)
-        nn_tet_con[1][2] = Cplx{-(0.0 * ss_end[3]) + ss_end[2], -(1.0 * ss_end[3])};
-        nn_tet_con[2][1] = Cplx{0.0 * ss_end[3] + ss_end[2], 1.0 * ss_end[3]};
-        Cplx temp_f[4][4];
-        for (int nu = 0; nu < 4; nu++)
-          for (int a = 0; a < 4; a++) {
-            Cplx acc = {0.0, 0.0};
-            for (int b = 0; b < 4; b++) acc = cadd(acc, cscale(tetrad[b][nu], nn_tet_con[a][b]));
-            temp_f[nu][a] = acc;
-          }
-        for (int mu = 0; mu < 4; mu++)
-          for (int nu = 0; nu < 4; nu++) {
-            Cplx acc = {0.0, 0.0};
-            for (int a = 0; a < 4; a++) acc = cadd(acc, cscale(tetrad[a][mu], temp_f[nu][a]));
-            nn_con[mu][nu] = acc;
-          }
-      }
-
-      // second half step: N_temp = N, N += dN/dlambda(N_temp) dl
+      // back to coordinates (:793-813), second half step (:816-833)
+      from_stokes(s.e1, s.e2, ss_end, nn_con);
       for (int mu = 0; mu < 4; mu++)
         for (int nu = 0; nu < 4; nu++) nn_con_temp[mu][nu] = nn_con[mu][nu];
-      transport(kcon, connection, nn_con_temp, (delta_lambda + delta_lambda_new) / 4.0, nn_con);
+      transport(gk_new, (delta_lambda + delta_lambda_new) / 4.0, nn_con_temp, nn_con);
 
       delta_lambda_old = delta_lambda;
       for (int mu = 0; mu < 4; mu++) kcon_old[mu] = kcon[mu];
-      for (int mu = 0; mu < 4; mu++)
-        for (int alpha = 0; alpha < 4; alpha++)
-          for (int beta = 0; beta < 4; beta++) connection_old[mu][alpha][beta] = connection[mu][alpha][beta];
     }
 
     // camera frame (:875-939) and nu^3 (:942-949)
@@ -629,7 +518,7 @@ __global__ void __launch_bounds__(64) bl_transfer_polarized_kernel(BlTransferArg
       const double *cp = P.camera_pos + 4 * out_index, *cd = P.camera_dir + 4 * out_index;
       const double kcov[4] = {cd[0], cd[1], cd[2], cd[3]};
       double gcov[4][4], gcon[4][4], kcon[4], up_con[4], tetrad[4][4];
-      geodesic_metric(st, cp[1], cp[2], cp[3], gcov, gcon);
+      bl_pol::geodesic_metric(st, cp[1], cp[2], cp[3], gcov, gcon);
       for (int mu = 0; mu < 4; mu++) {
         double acc = 0.0;
         for (int nu = 0; nu < 4; nu++) acc += gcon[mu][nu] * kcov[nu];
@@ -640,11 +529,9 @@ __global__ void __launch_bounds__(64) bl_transfer_polarized_kernel(BlTransferArg
       up_con[1] = vert[1] + u_con[1] * vert[0];
       up_con[2] = vert[2] + u_con[2] * vert[0];
       up_con[3] = vert[3] + u_con[3] * vert[0];
-      tetrad_frame(u_con, u_cov, kcon, kcov, up_con, gcov, gcon, tetrad);
-      Cplx nn_tet_cov[4][4];
-      to_tetrad(gcov, tetrad, nn_con, nn_tet_cov);
+      bl_pol::tetrad_frame(u_con, u_cov, kcon, kcov, up_con, gcov, gcon, tetrad);
       double ss[4];
-      stokes_from(nn_tet_cov, ss);
+      to_stokes(gcov, tetrad[1], tetrad[2], nn_con, ss);
       const double nu_cu = freq * freq * freq;
       for (int a = 0; a < 4; a++) img[(size_t)(4 * l + a) * row] = ss[a] * nu_cu;
     }

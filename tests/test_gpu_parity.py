@@ -273,6 +273,46 @@ def test_randomised_configurations_against_oracle(seed, built_library):
     assert same.all(), f"{(~same).sum()} of {same.size} values differ for {over}"
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_randomised_polarized_configurations_against_oracle(seed, built_library):
+    """Seeded draws of polarized runs (joint coupling / rotation split, spins, one or two frequencies, nearest or
+    trilinear sampling, thermal + power-law + kappa-distribution electron mixes, kappa on and between the fitted
+    values): every Stokes row and every auxiliary row, HIP vs the CPU oracle, bit-exact."""
+    import blacklight_amd as bl
+    from blacklight_amd import _capi
+    import oracle_api
+    rng = np.random.default_rng(5000 + seed)
+    fx, params, mock_args = gu.load_case("sim_polarized")
+    over = dict(camera_resolution=12, image_rotation_split=str(rng.choice(["true", "false"])),
+                simulation_a=float(rng.choice([0.0, 0.5, 0.9])), simulation_interp=str(rng.choice(["true", "false"])),
+                camera_th=float(rng.uniform(20.0, 160.0)), image_tau=str(rng.choice(["true", "false"])),
+                image_num_frequencies=int(rng.choice([1, 2])))
+    if over["image_num_frequencies"] > 1:
+        over.update(image_frequency_start=float(10.0 ** rng.uniform(10.5, 11.2)), image_frequency_end=float(10.0 ** rng.uniform(11.3, 12.0)),
+                    image_frequency_spacing="log")
+    else:
+        over["image_frequency"] = float(10.0 ** rng.uniform(10.8, 11.8))
+    if rng.integers(0, 2) == 0:
+        over.update(plasma_power_frac=float(rng.uniform(0.05, 0.4)), plasma_p=float(rng.uniform(2.2, 3.8)),
+                    plasma_gamma_min=float(rng.uniform(1.5, 30.0)), plasma_gamma_max=float(10.0 ** rng.uniform(3.0, 6.0)))
+    if seed % 5 != 4:
+        over.update(plasma_kappa_frac=float(rng.uniform(0.05, 0.5)), plasma_w=float(rng.uniform(1.0, 3.0)),
+                    plasma_kappa=float(rng.choice([3.5, 4.0, 4.5, 5.0, float(rng.uniform(3.5, 5.0))])))
+    params = dict(params)
+    params.update(over)
+    p = bl.Params.from_dict(params)
+    grid = gu.golden_grid(mock_args)
+    with bl.Context(p) as ctx:
+        ctx.set_grid(grid)
+        got = ctx.render()
+    want = oracle_api.render(p.ptr, grid.desc(), _capi.RenderDesc, _capi.CameraFrame, n_rays=144,
+                             max_steps=int(p.get("ray_max_steps")), n_freq=int(p.get("image_num_frequencies")))
+    assert np.array_equal(got["sample_num"], want["sample_num"]), over
+    assert got["image"].shape == want["image"].shape
+    same = gu.same_bits(got["image"], want["image"])
+    assert same.all(), f"{(~same).sum()} of {same.size} values differ for {over}"
+
+
 def test_refined_mesh_holes_and_overlaps(built_library):
     """A mesh with a block missing is still a mesh (samples in the hole are off the grid, as in the reference's
     scan over blocks): HIP vs oracle bit-exact. Blocks that overlap are refused."""

@@ -149,6 +149,10 @@ CASES = {
                                                simulation_a=0.9, image_tau="true", image_emission="true",
                                                image_num_frequencies=2, image_frequency_start=1.0e11,
                                                image_frequency_end=3.0e11, image_frequency_spacing="log"), SMALL_MOCK, [136]),
+    # kappa = 3.5 (the lower end of the fits) with an inexact width
+    "sim_polarized_kappa_low": (SIM_BASE, dict(camera_resolution=12, image_polarization="true", plasma_kappa_frac=0.49,
+                                               plasma_kappa=3.5, plasma_w=1.919106339654944, simulation_a=0.5,
+                                               simulation_interp="false"), SMALL_MOCK, [78]),
     "sim_powerlaw": (SIM_BASE, dict(camera_resolution=24, plasma_power_frac=0.3, plasma_p=2.5, plasma_gamma_min=1.0,
                                     plasma_gamma_max=1000.0), SMALL_MOCK, [300]),
     # false-colour renderings (rendering.cpp): the features of the reference's example_render.input, without
