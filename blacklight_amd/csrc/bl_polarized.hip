@@ -16,7 +16,7 @@
 // bl_transfer_aux_kernel.
 //
 // What is sequential, per sample: the connection at the sample (it enters through its average with the previous
-// sample's, element by element, so the previous one is carried: 64 doubles), two half-step transports, the
+// sample's, element by element, so the previous one is carried: 64 doubles per ray, kept in LDS), two half-step transports, the
 // projection on the tetrad, the coupling, the way back. Projection and its inverse only read rows 1 and 2 of the
 // tetrad and only produce / consume the (1,1), (1,2), (2,1), (2,2) tetrad components (:288-292, :795-798); the
 // sums the reference runs over the other rows add products with exact zeros, which change nothing (see
@@ -51,7 +51,7 @@ __device__ __forceinline__ Cplx csub(Cplx a, Cplx b) { return Cplx{a.re - b.re, 
 // previous sample's component. For fixed (mu, beta) the alpha terms arrive in ascending order, as in the reference.
 __device__ __forceinline__ void connection_contractions(const BlSpacetime &st, double x, double y, double z, const BlKerrSchild &ks,
                                                         const double kcon[4], const double kcon_avg[4],
-                                                        double connection_old[4][4][4], double gk_avg[4][4], double gk_new[4][4]) {
+                                                        double *connection_old, double gk_avg[4][4], double gk_new[4][4]) {
   for (int mu = 0; mu < 4; mu++)
     for (int beta = 0; beta < 4; beta++) gk_avg[mu][beta] = gk_new[mu][beta] = 0.0;
   if (st.ray_flat) {
@@ -62,9 +62,10 @@ __device__ __forceinline__ void connection_contractions(const BlSpacetime &st, d
 #pragma unroll
         for (int beta = 0; beta < 4; beta++) {
           const double g = 0.0;
+          double *old = connection_old + ((mu * 4 + alpha) * 4 + beta) * 64;
           gk_new[mu][beta] += kcon[alpha] * g;
-          gk_avg[mu][beta] += kcon_avg[alpha] * (0.5 * (connection_old[mu][alpha][beta] + g));
-          connection_old[mu][alpha][beta] = g;
+          gk_avg[mu][beta] += kcon_avg[alpha] * (0.5 * (*old + g));
+          *old = g;
         }
     return;
   }
@@ -118,20 +119,19 @@ __device__ __forceinline__ void connection_contractions(const BlSpacetime &st, d
 #pragma unroll
         for (int nu = 0; nu < 4; nu++)
           g += 0.5 * gcon[mu][nu] * (dgcov[alpha][beta][nu] + dgcov[beta][alpha][nu] - dgcov[nu][alpha][beta]);
+        double *old = connection_old + ((mu * 4 + alpha) * 4 + beta) * 64;
         gk_new[mu][beta] += kcon[alpha] * g;
-        gk_avg[mu][beta] += kcon_avg[alpha] * (0.5 * (connection_old[mu][alpha][beta] + g));
-        connection_old[mu][alpha][beta] = g;
+        gk_avg[mu][beta] += kcon_avg[alpha] * (0.5 * (*old + g));
+        *old = g;
       }
 }
 
 // The connection alone, for the first sample of a ray (its "previous" connection is its own: :150-154)
 __device__ __forceinline__ void connection_first(const BlSpacetime &st, double x, double y, double z, const BlKerrSchild &ks,
-                                                 double connection_old[4][4][4]) {
+                                                 double *connection_old) {
   const double zero[4] = {0.0, 0.0, 0.0, 0.0};
   double gk_a[4][4], gk_b[4][4];
-  for (int mu = 0; mu < 4; mu++)
-    for (int alpha = 0; alpha < 4; alpha++)
-      for (int beta = 0; beta < 4; beta++) connection_old[mu][alpha][beta] = 0.0;
+  for (int c = 0; c < 64; c++) connection_old[c * 64] = 0.0;
   connection_contractions(st, x, y, z, ks, zero, zero, connection_old, gk_a, gk_b);
 }
 
@@ -397,6 +397,10 @@ __device__ void couple_jointly(const Coupling &c, const double ss_start[4], doub
 }  // namespace
 
 __global__ void __launch_bounds__(64) bl_transfer_polarized_kernel(BlTransferArgs P) {
+  // The previous sample's connection, one column of 64 components per lane ([component][lane]: every access of a
+  // wave touches 64 consecutive doubles): 32 KiB per wave, which leaves the registers to N, N_temp and the step
+  __shared__ double connection_lds[64 * 64];
+  double *connection_old = connection_lds + threadIdx.x;
   const int slot = blockIdx.x * blockDim.x + threadIdx.x;
   if (slot >= P.chunk_rays) return;
   const BlSpacetime st = P.st;
@@ -422,7 +426,6 @@ __global__ void __launch_bounds__(64) bl_transfer_polarized_kernel(BlTransferArg
     // with itself returns it, so the loop below needs no first-sample case.
     double delta_lambda_old = 0.0;
     double kcon_old[4];
-    double connection_old[4][4][4];
     {
       const BlPolSample s = samples[num - 1];
       BlKerrSchild ks;
