@@ -27,6 +27,7 @@ extern "C" hipError_t bl_launch_geodesic(const BlTraceArgs *args, int integrator
 extern "C" int bl_geodesic_occupancy(int integrator);
 extern "C" hipError_t bl_launch_locate(const BlShadeArgs *args, int grid, int lds_bytes, hipStream_t stream);
 extern "C" hipError_t bl_launch_shade(const BlShadeArgs *args, int model, int grid, hipStream_t stream);
+extern "C" hipError_t bl_launch_polarized_coefficients(const BlShadeArgs *args, int grid, hipStream_t stream);
 extern "C" hipError_t bl_launch_transfer(const BlTransferArgs *args, hipStream_t stream);
 extern "C" hipError_t bl_launch_transfer_aux(const BlTransferArgs *args, hipStream_t stream);
 extern "C" hipError_t bl_launch_transfer_polarized(const BlTransferArgs *args, hipStream_t stream);
@@ -138,8 +139,9 @@ struct bl_ctx {
     DeviceBuffer<double> d_slow_frac;              // slow light: t_frac of every located sample
     DeviceBuffer<BlPolSample> d_pol_samples;       // polarized transfer
     DeviceBuffer<double2> d_pol_coeffs;
+    DeviceBuffer<BlCoefInputs> d_coef_inputs;      // polarized runs: coefficient kernel -> polarized coefficient kernel
     void Free() {
-      d_aux.Free(); d_sample_t.Free(); d_slow_frac.Free(); d_pol_samples.Free(); d_pol_coeffs.Free();
+      d_aux.Free(); d_sample_t.Free(); d_slow_frac.Free(); d_pol_samples.Free(); d_pol_coeffs.Free(); d_coef_inputs.Free();
       d_records.Free(); d_located.Free(); d_transfer.Free(); d_ray_kt.Free(); d_ray_factor.Free();
       d_ray_sample_num.Free(); d_ray_flags.Free(); d_ray_out_index.Free(); d_counters.Free();
     }
@@ -962,7 +964,7 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
     const uint64_t per_ray = static_cast<uint64_t>(max_steps)
         * (sizeof(BlSampleRecord) + (simulation ? sizeof(BlLocated) : 0) + sizeof(double2) * n_nu
            + (aux ? sizeof(BlAuxSample) + sizeof(double) : 0) + (slow ? 2 * sizeof(double) : 0)
-           + (ctx->polarized ? sizeof(BlPolSample) + 3 * sizeof(double2) * n_nu : 0)) + 64;
+           + (ctx->polarized ? sizeof(BlPolSample) + sizeof(BlCoefInputs) + 3 * sizeof(double2) * n_nu : 0)) + 64;
     // One chunk if the whole call fits the budget. With bl_set_overlap(): two scratch sets of half the budget
     // each, so that the geodesic kernel of chunk c + 1 runs while chunk c is being shaded.
     // The budget is also capped by what the device can actually give: 90 % of (free memory + the scratch
@@ -976,7 +978,8 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
           held += sl.d_records.count * sizeof(BlSampleRecord) + sl.d_located.count * sizeof(BlLocated)
               + sl.d_transfer.count * sizeof(double2) + sl.d_aux.count * sizeof(BlAuxSample)
               + (sl.d_sample_t.count + sl.d_slow_frac.count) * sizeof(double)
-              + sl.d_pol_samples.count * sizeof(BlPolSample) + sl.d_pol_coeffs.count * sizeof(double2);
+              + sl.d_pol_samples.count * sizeof(BlPolSample) + sl.d_pol_coeffs.count * sizeof(double2)
+              + sl.d_coef_inputs.count * sizeof(BlCoefInputs);
         const uint64_t available = static_cast<uint64_t>(0.9 * static_cast<double>(free_bytes + held));
         if (available < budget) budget = available;
       }
@@ -1009,6 +1012,7 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
       if (ctx->polarized) {
         sl.d_pol_samples.Ensure(static_cast<size_t>(chunk) * max_steps);
         sl.d_pol_coeffs.Ensure(static_cast<size_t>(chunk) * max_steps * n_nu * 3);
+        sl.d_coef_inputs.Ensure(record_capacity);
       }
     }
     EnsureChunkResources(ctx, n_chunks);
@@ -1417,6 +1421,7 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
       if (ctx->polarized) {
         sa.pol_samples = sl.d_pol_samples.ptr;
         sa.pol_coeffs = sl.d_pol_coeffs.ptr;
+        sa.coef_inputs = sl.d_coef_inputs.ptr;
         xa.pol_samples = sl.d_pol_samples.ptr;
         xa.pol_coeffs = sl.d_pol_coeffs.ptr;
       }
@@ -1443,6 +1448,7 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
       }
       Check(hipEventRecord(e[3], stream), "event");
       Check(bl_launch_shade(&sa, p.model_type, shade_grid, stream), "coefficient kernel launch");
+      if (ctx->polarized) Check(bl_launch_polarized_coefficients(&sa, ctx->num_cus * 8, stream), "polarized coefficient kernel launch");
       Check(hipEventRecord(e[4], stream), "event");
       Check(aux ? bl_launch_transfer_aux(&xa, stream) : bl_launch_transfer(&xa, stream), "transfer kernel launch");
       if (ctx->polarized) Check(bl_launch_transfer_polarized(&xa, stream), "polarized transfer kernel launch");

@@ -212,6 +212,16 @@ struct alignas(16) BlPolSample {
   double e1[4], e2[4];
 };
 
+// Polarized runs: what the per-frequency coefficient formulas need of a sample (simulation_coefficients.cpp:458-698),
+// left by the coefficient kernel for bl_polarized_coefficients_kernel, one per sample record. 64 bytes.
+struct alignas(16) BlCoefInputs {
+  double nu_fluid_over_nu;   // -k_mu u^mu
+  double n_e_cgs, nu_c_cgs, theta_e, kb_tt_e_cgs;
+  double cos2_theta_b;       // min(cos^2, 1) (:449-452)
+  double cos_sign;           // +-1: sign of k.b in the fluid frame (:455)
+  double have_coefficients;  // 1: the sample has coefficients; 0: j = alpha = rho = 0 at every frequency
+};
+
 // Slow light (slow_light_on): the time slices the reader holds (simulation_reader.cpp:211-303), latest
 // first, all on the geometry of BlGridDevice. n = 0: off.
 struct BlSlowDevice {
@@ -251,6 +261,7 @@ struct BlShadeArgs {
   // polarized transfer only (runs in auxiliary-image mode): null otherwise
   BlPolSample *pol_samples;   // [chunk_rays][ray_max_steps]
   double2 *pol_coeffs;        // [chunk_rays][ray_max_steps][n_nu][3]: (j_Q, j_V), (alpha_Q, alpha_V), (rho_Q, rho_V)
+  BlCoefInputs *coef_inputs;  // [record capacity]: coefficient kernel -> polarized coefficient kernel
   double power_pol[7];        // simulation_coefficients.cpp:67-80: jj_q, jj_v, aa_q, aa_v, rho, rho_q, rho_v
   double plasma_gamma_min;
   int aux_need_coefficients;  // image_light || image_emission || image_tau || image_emission_ave || image_tau_int (:389)

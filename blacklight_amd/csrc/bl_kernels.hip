@@ -677,7 +677,7 @@ struct SampleShade {
   bool have_coefficients;      // false: j = alpha = 0 at every frequency
   double nu_fluid_over_nu;     // -k_mu u^mu (fluid-frame frequency per unit camera frequency*factor)
   double n_e_cgs, nu_c_cgs, theta_e, sin_theta_b, kb_tt_e_cgs;   // simulation
-  double cos_theta_b, sin2_theta_b;                               // polarized coefficients only
+  double cos_theta_b, sin2_theta_b, cos2_theta_b, cos_sign;       // polarized coefficients only
   double n_n0_fluid, fu[4];                                       // formula
   bool have_cell;              // cell_values recorded (simulation_coefficients.cpp:377-387)
   double cell[BL_NUM_CELL_VALUES];
@@ -1250,6 +1250,8 @@ __device__ __forceinline__ void sample_finish_simulation(const BlShadeArgs &P, c
   out->sin_theta_b = bl_sqrt_g(sin2_theta_b);
   out->kb_tt_e_cgs = kb_tt_e_cgs;
   out->sin2_theta_b = sin2_theta_b;
+  out->cos2_theta_b = cos2_theta_b;
+  out->cos_sign = k_b_tet >= 0.0 ? 1.0 : -1.0;
   out->cos_theta_b = bl_sqrt_g(cos2_theta_b) * (k_b_tet >= 0.0 ? 1.0 : -1.0);   // :455
   if (kExtended && pol_out != nullptr) {
     // polarized.cpp:163-265 rebuilds k^mu and this tetrad from the same sampled values: hand them over
@@ -1259,6 +1261,204 @@ __device__ __forceinline__ void sample_finish_simulation(const BlShadeArgs &P, c
       pol_out->e2[mu] = tetrad[2][mu];
     }
   }
+}
+
+// Unpolarized emissivity and absorptivity of one sample at one frequency (simulation_coefficients.cpp:464-523,
+// :556-584): thermal electrons, plus power-law electrons in the extended instantiation. The sample has coefficients
+// (SampleShade::have_coefficients).
+template <bool kExtended>
+__device__ __forceinline__ void simulation_coefficients(const BlShadeArgs &P, const SampleShade &sh, double freq,
+                                                        double momentum_factor, double *j_out, double *alpha_out) {
+  double j_val = 0.0, alpha_val = 0.0;
+  // simulation_coefficients.cpp:464-523, thermal electrons, unpolarized
+  const double thermal_frac = P.plasma.plasma_thermal_frac;
+  const double nu_cgs = sh.nu_fluid_over_nu * (freq * momentum_factor);
+  const double nu_2_cgs = nu_cgs * nu_cgs;
+  const double nu_s_cgs = 2.0 / 9.0 * sh.nu_c_cgs * sh.theta_e * sh.theta_e * sh.sin_theta_b;
+  if (thermal_frac != 0.0) {
+    const double xx = nu_cgs / nu_s_cgs;
+    const double xx_1_2 = bl_sqrt_g(xx);
+    const double xx_1_3 = bl_cbrt(xx);
+    const double xx_1_6 = bl_sqrt_g(xx_1_3);
+    const double coefficient = bl_div_g(thermal_frac * sh.n_e_cgs * kE * kE * sh.nu_c_cgs, kC * nu_2_cgs) * bl_exp(-xx_1_3);
+    const double var_a = kSqrt2 * kPi / 27.0 * sh.sin_theta_b;
+    const double var_b = kPow2_11_12;
+    const double var_c = xx_1_2 + var_b * xx_1_6;
+    j_val = coefficient * var_a * var_c * var_c;
+    const double b_nu_nu_3_cgs = 2.0 * kH / (kC * kC) / bl_expm1(kH * nu_cgs / sh.kb_tt_e_cgs);
+    alpha_val = j_val / b_nu_nu_3_cgs;
+    // :513-523 zero alpha when 1 / alpha^2 overflows. 1 / x (x >= 0) rounds to +inf exactly when
+    // x <= 2^-1024 (the next double above, 2^-1024 + 2^-1074, gives 2^1024 - 2^974 < DBL_MAX + ulp/2);
+    // NaN fails both tests. One compare instead of a division.
+    if (alpha_val * alpha_val <= 0x1p-1024) alpha_val = 0.0;
+  }
+  if (kExtended && P.plasma.power_frac != 0.0) {
+    // power-law electrons, unpolarized (simulation_coefficients.cpp:556-584)
+    const double ratio = nu_cgs / (sh.nu_c_cgs * sh.sin_theta_b);
+    const double var_a_j = bl_pow(ratio, -(P.plasma.plasma_p - 1.0) / 2.0);
+    j_val += P.plasma.power_frac * sh.n_e_cgs * kE * kE * sh.nu_c_cgs / (kC * nu_2_cgs) * P.plasma.power_jj
+        * sh.sin_theta_b * var_a_j;
+    const double var_a_a = bl_pow(ratio, -(P.plasma.plasma_p + 2.0) / 2.0);
+    alpha_val += P.plasma.power_frac * sh.n_e_cgs * kE * kE / (kMe * kC) * P.plasma.power_aa * var_a_a;
+  }
+  *j_out = j_val;
+  *alpha_out = alpha_val;
+}
+
+// Polarized coefficients of one sample at one frequency: (j_Q, j_V), (alpha_Q, alpha_V), (rho_Q, rho_V); the
+// kappa-distribution terms also add to the intensity pair (j_val, alpha_val), which simulation_coefficients() has
+// filled before.
+__device__ __forceinline__ void polarized_coefficients(const BlShadeArgs &P, const SampleShade &sh, double freq,
+                                                       double momentum_factor, double &j_val, double &alpha_val, double2 pc[3]) {
+  // polarized coefficients (simulation_coefficients.cpp:485-495, :506-523, :527-553, :567-605), plain
+  // IEEE operations in the reference's order
+  double j_q = 0.0, j_v = 0.0, alpha_q = 0.0, alpha_v = 0.0, rho_q = 0.0, rho_v = 0.0;
+  if (sh.have_coefficients) {
+    const double thermal_frac = P.plasma.plasma_thermal_frac;
+    const double nu_cgs = sh.nu_fluid_over_nu * (freq * momentum_factor);
+    const double nu_2_cgs = nu_cgs * nu_cgs;
+    const double nu_c_cgs = sh.nu_c_cgs, theta_e = sh.theta_e, sin_theta_b = sh.sin_theta_b, cos_theta_b = sh.cos_theta_b;
+    const double n_e_cgs = sh.n_e_cgs;
+    const double nu_s_cgs = 2.0 / 9.0 * nu_c_cgs * theta_e * theta_e * sin_theta_b;
+    if (thermal_frac != 0.0) {
+      const double xx = nu_cgs / nu_s_cgs;
+      const double xx_1_2 = blm_sqrt(xx);
+      const double xx_1_3 = bl_cbrt(xx);
+      const double xx_1_6 = blm_sqrt(xx_1_3);
+      const double coefficient = thermal_frac * n_e_cgs * kE * kE * nu_c_cgs / (kC * nu_2_cgs) * bl_exp(-xx_1_3);
+      const double var_a = kSqrt2 * kPi / 27.0 * sin_theta_b;
+      const double var_b = kPow2_11_12;
+      const double var_d = (7.0 * bl_pow(theta_e, 0.96) + 35.0) / (10.0 * bl_pow(theta_e, 0.96) + 75.0) * var_b;
+      const double var_e = xx_1_2 + var_d * xx_1_6;
+      const double var_f = cos_theta_b / theta_e;
+      const double var_g = kPi / 3.0 + kPi / 3.0 * xx_1_3 + 2.0 / 300.0 * xx_1_2 + 2.0 / 19.0 * kPi * xx_1_3 * xx_1_3;
+      j_q = -coefficient * var_a * var_e * var_e;
+      j_v = coefficient * var_f * var_g;
+      const double b_nu_nu_3_cgs = 2.0 * kH / (kC * kC) / bl_expm1(kH * nu_cgs / sh.kb_tt_e_cgs);
+      alpha_q = j_q / b_nu_nu_3_cgs;
+      alpha_v = j_v / b_nu_nu_3_cgs;
+      // :513-523 with the thermal alpha_I (alpha_val holds it, possibly already zeroed, before the
+      // power-law term is added - recompute the test on the thermal value)
+      {
+        const double var_c = xx_1_2 + var_b * xx_1_6;
+        const double alpha_thermal = coefficient * var_a * var_c * var_c / b_nu_nu_3_cgs;
+        if (alpha_thermal * alpha_thermal <= 0x1p-1024) alpha_q = alpha_v = 0.0;
+      }
+      const double coefficient_q = -thermal_frac * n_e_cgs * kE * kE * nu_c_cgs * nu_c_cgs * sh.sin2_theta_b / (kMe * kC * nu_2_cgs);
+      const double coefficient_v = thermal_frac * 2.0 * n_e_cgs * kE * kE * nu_c_cgs * cos_theta_b / (kMe * kC * nu_cgs);
+      double factor_q = 0.0, factor_v = 1.0;
+      if (theta_e >= 0.01) {   // theta_e_zero, radiation_integrator.hpp:190
+        double kk_0, kk_1, kk_2;   // three std::cyl_bessel_k calls in the reference (:537-539)
+        bl_cyl_bessel_k012(1.0 / theta_e, &kk_0, &kk_1, &kk_2);
+        const double xx_neg_1_2 = 1.0 / blm_sqrt(xx);
+        const double f_a = 2.011 * bl_exp(-19.78 * bl_pow(xx, -0.5175));
+        const double f_b = bl_cos(39.89 * xx_neg_1_2) * bl_exp(-70.16 * bl_pow(xx, -0.6));
+        const double f_c = 0.011 * bl_exp(-1.69 * xx_neg_1_2);
+        const double f_d = 0.003135 * bl_pow(xx, 4.0 / 3.0);
+        const double f_e = 0.5 * (1.0 + bl_tanh(10.0 * bl_log(0.6648 * xx_neg_1_2)));
+        const double f_0 = f_a - f_b - f_c;
+        const double f_m = f_0 + (f_c - f_d) * f_e;
+        const double delta_jj_5 = 0.4379 * bl_log(1.0 + 1.3414 * bl_pow(xx, -0.7515));
+        factor_q = f_m * (kk_1 / kk_2 + 6.0 * theta_e);
+        factor_v = (kk_0 - delta_jj_5) / kk_2;
+        factor_v = (factor_v < 0.0 || factor_v > 1.0) ? 1.0 : factor_v;
+      }
+      rho_q = coefficient_q * factor_q;
+      rho_v = coefficient_v * factor_v;
+    }
+    if (P.plasma.power_frac != 0.0) {
+      const double plasma_p = P.plasma.plasma_p;
+      {
+        const double var_a = bl_pow(nu_cgs / (nu_c_cgs * sin_theta_b), -(plasma_p - 1.0) / 2.0);
+        const double coefficient = P.plasma.power_frac * n_e_cgs * kE * kE * nu_c_cgs / (kC * nu_2_cgs) * P.plasma.power_jj * sin_theta_b * var_a;
+        const double var_b = cos_theta_b / sin_theta_b;
+        const double var_c = 1.0 / blm_sqrt(nu_cgs / (3.0 * nu_c_cgs * sin_theta_b));
+        j_q += coefficient * P.power_pol[0];
+        j_v += coefficient * P.power_pol[1] * var_b * var_c;
+      }
+      {
+        const double var_a = bl_pow(nu_cgs / (nu_c_cgs * sin_theta_b), -(plasma_p + 2.0) / 2.0);
+        const double coefficient = P.plasma.power_frac * n_e_cgs * kE * kE / (kMe * kC) * P.plasma.power_aa * var_a;
+        const double var_b = bl_pow(3.1 * bl_pow(sin_theta_b, -1.92) - 3.1, 0.512);
+        const double var_c = 1.0 / blm_sqrt(nu_cgs / (nu_c_cgs * sin_theta_b));
+        const double var_d = cos_theta_b >= 0.0 ? 1.0 : -1.0;
+        alpha_q += coefficient * P.power_pol[2];
+        alpha_v += coefficient * P.power_pol[3] * var_b * var_c * var_d;
+      }
+      {
+        const double var_a = n_e_cgs * kE * kE * nu_cgs / (kMe * kC * nu_c_cgs * sin_theta_b);
+        const double var_b = nu_c_cgs * sin_theta_b / nu_cgs;
+        const double var_c = var_b * var_b;
+        const double var_d = var_c * var_b;
+        const double var_e = 1.0 - bl_pow(2.0 * nu_c_cgs * P.plasma_gamma_min * P.plasma_gamma_min * sin_theta_b / (3.0 * nu_cgs), plasma_p / 2.0 - 1.0);
+        const double var_f = cos_theta_b / sin_theta_b;
+        const double coefficient = P.plasma.power_frac * P.power_pol[4] * var_a;
+        rho_q += coefficient * P.power_pol[5] * var_d * var_e;
+        rho_v += coefficient * P.power_pol[6] * var_c * var_f;
+      }
+    }
+    if (P.cold->kappa.frac != 0.0) {
+      // kappa-distribution electrons (simulation_coefficients.cpp:607-698): every term is the harmonic-like
+      // bridge (low^-x + high^-x)^(-1/x) between a low- and a high-frequency fit. Only polarized runs get
+      // here (bl_init), so the intensity terms are added to j_val / alpha_val in this block as well.
+      const BlKappaDevice &kk = P.cold->kappa;
+      const double nu_kappa_cgs = nu_c_cgs * kk.w * kk.w * kk.kappa * kk.kappa * sin_theta_b;
+      const double xx = nu_cgs / nu_kappa_cgs;
+      const double var_g = 1.0 / blm_sqrt(xx);
+      const double var_h = cos_theta_b >= 0.0 ? 1.0 : -1.0;
+      const double var_e = bl_pow(xx, -0.35);
+      {   // emissivities (:608-637)
+        const double var_a = kk.frac * n_e_cgs * kE * kE * nu_c_cgs / (kC * nu_2_cgs);
+        const double var_b = bl_cbrt(xx) * sin_theta_b;
+        const double var_c = bl_pow(xx, -(kk.kappa - 2.0) / 2.0) * sin_theta_b;
+        const double coefficient_low = kk.jj_low * var_a * var_b;
+        const double coefficient_high = kk.jj_high * var_a * var_c;
+        j_val += bl_pow(bl_pow(coefficient_low, -kk.jj_x_i) + bl_pow(coefficient_high, -kk.jj_x_i), -1.0 / kk.jj_x_i);
+        const double var_d = bl_pow(bl_pow(sin_theta_b, -2.4) - 1.0, 0.48);
+        const double var_f = bl_pow(bl_pow(sin_theta_b, -2.5) - 1.0, 0.44);
+        const double jj_q_low = coefficient_low * kk.jj_low_q;
+        const double jj_v_low = coefficient_low * kk.jj_low_v * var_d * var_e;
+        const double jj_q_high = coefficient_high * kk.jj_high_q;
+        const double jj_v_high = coefficient_high * kk.jj_high_v * var_f * var_g;
+        j_q -= bl_pow(bl_pow(jj_q_low, -kk.jj_x_q) + bl_pow(jj_q_high, -kk.jj_x_q), -1.0 / kk.jj_x_q);
+        j_v += bl_pow(bl_pow(jj_v_low, -kk.jj_x_v) + bl_pow(jj_v_high, -kk.jj_x_v), -1.0 / kk.jj_x_v) * var_h;
+      }
+      {   // absorptivities (:640-667)
+        const double var_a = kk.frac * n_e_cgs * kE * kE / (kMe * kC);
+        const double var_b = bl_pow(xx, -2.0 / 3.0);
+        const double var_c = bl_pow(xx, -(1.0 + kk.kappa) / 2.0);
+        const double coefficient_low = kk.aa_low * var_a * var_b;
+        const double coefficient_high = kk.aa_high * var_a * var_c;
+        const double aa_i_low = coefficient_low;
+        const double aa_i_high = coefficient_high * kk.aa_high_i;
+        alpha_val += bl_pow(bl_pow(aa_i_low, -kk.aa_x_i) + bl_pow(aa_i_high, -kk.aa_x_i), -1.0 / kk.aa_x_i);
+        const double var_d = bl_pow(bl_pow(sin_theta_b, -2.28) - 1.0, 0.446);
+        const double var_f = blm_sqrt(bl_pow(sin_theta_b, -2.05) - 1.0);
+        const double aa_q_low = coefficient_low * kk.aa_low_q;
+        const double aa_v_low = coefficient_low * kk.aa_low_v * var_d * var_e;
+        const double aa_q_high = coefficient_high * kk.aa_high_q;
+        const double aa_v_high = coefficient_high * kk.aa_high_v * var_f * var_g;
+        alpha_q -= bl_pow(bl_pow(aa_q_low, -kk.aa_x_q) + bl_pow(aa_q_high, -kk.aa_x_q), -1.0 / kk.aa_x_q);
+        alpha_v += bl_pow(bl_pow(aa_v_low, -kk.aa_x_v) + bl_pow(aa_v_high, -kk.aa_x_v), -1.0 / kk.aa_x_v) * var_h;
+      }
+      {   // rotativities (:670-698): linear blend of the fits at the two ends of kappa's bracket
+        const double var_a = -kk.frac * n_e_cgs * kE * kE * nu_c_cgs * nu_c_cgs * sh.sin2_theta_b / (kMe * kC * nu_2_cgs);
+        const double var_b = kk.frac * 2.0 * n_e_cgs * kE * kE * nu_c_cgs * cos_theta_b / (kMe * kC * nu_cgs);
+        const double xx_084 = bl_pow(xx, 0.84);
+        const double rho_q_low = var_a * kk.rho_q_low[0] * (1.0 - bl_exp(kk.rho_q_low[1] * xx_084)
+            - bl_sin(kk.rho_q_low[2] * xx) * bl_exp(kk.rho_q_low[3] * bl_pow(xx, kk.rho_q_low[4])));
+        const double rho_q_high = var_a * kk.rho_q_high[0] * (1.0 - bl_exp(kk.rho_q_high[1] * xx_084)
+            - bl_sin(kk.rho_q_high[2] * xx) * bl_exp(kk.rho_q_high[3] * bl_pow(xx, kk.rho_q_high[4])));
+        const double rho_v_low = kk.rho_v * var_b * kk.rho_v_low[0] * (1.0 - 0.17 * bl_log(1.0 + kk.rho_v_low[1] * var_g));
+        const double rho_v_high = kk.rho_v * var_b * kk.rho_v_high[0] * (1.0 - 0.17 * bl_log(1.0 + kk.rho_v_high[1] * var_g));
+        rho_q += (1.0 - kk.rho_frac) * rho_q_low + kk.rho_frac * rho_q_high;
+        rho_v += (1.0 - kk.rho_frac) * rho_v_low + kk.rho_frac * rho_v_high;
+      }
+    }
+  }
+  pc[0] = make_double2(j_q, j_v);
+  pc[1] = make_double2(alpha_q, alpha_v);
+  pc[2] = make_double2(rho_q, rho_v);
 }
 
 // Formula mode, one sample (formula_coefficients.cpp:118-161)
@@ -1488,7 +1688,8 @@ __global__ void __launch_bounds__(256, 2) bl_shade_kernel(const BlShadeArgs P) {
     sh.have_coefficients = false;
     sh.nu_fluid_over_nu = 0.0;
     sh.n_e_cgs = sh.nu_c_cgs = sh.theta_e = sh.sin_theta_b = sh.kb_tt_e_cgs = 0.0;
-    sh.cos_theta_b = sh.sin2_theta_b = 0.0;
+    sh.cos_theta_b = sh.sin2_theta_b = sh.cos2_theta_b = 0.0;
+    sh.cos_sign = 1.0;
     sh.n_n0_fluid = 0.0;
     sh.fu[0] = sh.fu[1] = sh.fu[2] = sh.fu[3] = 0.0;
     sh.have_cell = false;
@@ -1559,42 +1760,27 @@ __global__ void __launch_bounds__(256, 2) bl_shade_kernel(const BlShadeArgs P) {
         }
       }
     }
+    if (kAux && kExtended && kModel == BL_MODEL_SIMULATION && P.pol_coeffs != nullptr) {
+      // polarized run: the per-frequency formulas (Bessel functions, a dozen powers and exponentials) need few
+      // registers and many waves - bl_polarized_coefficients_kernel evaluates them from these scalars
+      BlCoefInputs ci;
+      ci.nu_fluid_over_nu = sh.nu_fluid_over_nu;
+      ci.n_e_cgs = sh.n_e_cgs;
+      ci.nu_c_cgs = sh.nu_c_cgs;
+      ci.theta_e = sh.theta_e;
+      ci.kb_tt_e_cgs = sh.kb_tt_e_cgs;
+      ci.cos2_theta_b = sh.cos2_theta_b;
+      ci.cos_sign = sh.cos_sign;
+      ci.have_coefficients = sh.have_coefficients ? 1.0 : 0.0;
+      P.coef_inputs[idx_cur] = ci;
+      continue;
+    }
     // ---------------- per-frequency coefficients and transfer records
     for (int l = 0; l < P.n_nu; l++) {
       const double freq = P.frequencies[l];
       double j_val = 0.0, alpha_val = 0.0;
       if (sh.have_coefficients && kModel == BL_MODEL_SIMULATION) {
-        // simulation_coefficients.cpp:464-523, thermal electrons, unpolarized
-        const double thermal_frac = P.plasma.plasma_thermal_frac;
-        const double nu_cgs = sh.nu_fluid_over_nu * (freq * momentum_factor);
-        const double nu_2_cgs = nu_cgs * nu_cgs;
-        const double nu_s_cgs = 2.0 / 9.0 * sh.nu_c_cgs * sh.theta_e * sh.theta_e * sh.sin_theta_b;
-        if (thermal_frac != 0.0) {
-          const double xx = nu_cgs / nu_s_cgs;
-          const double xx_1_2 = bl_sqrt_g(xx);
-          const double xx_1_3 = bl_cbrt(xx);
-          const double xx_1_6 = bl_sqrt_g(xx_1_3);
-          const double coefficient = bl_div_g(thermal_frac * sh.n_e_cgs * kE * kE * sh.nu_c_cgs, kC * nu_2_cgs) * bl_exp(-xx_1_3);
-          const double var_a = kSqrt2 * kPi / 27.0 * sh.sin_theta_b;
-          const double var_b = kPow2_11_12;
-          const double var_c = xx_1_2 + var_b * xx_1_6;
-          j_val = coefficient * var_a * var_c * var_c;
-          const double b_nu_nu_3_cgs = 2.0 * kH / (kC * kC) / bl_expm1(kH * nu_cgs / sh.kb_tt_e_cgs);
-          alpha_val = j_val / b_nu_nu_3_cgs;
-          // :513-523 zero alpha when 1 / alpha^2 overflows. 1 / x (x >= 0) rounds to +inf exactly when
-          // x <= 2^-1024 (the next double above, 2^-1024 + 2^-1074, gives 2^1024 - 2^974 < DBL_MAX + ulp/2);
-          // NaN fails both tests. One compare instead of a division.
-          if (alpha_val * alpha_val <= 0x1p-1024) alpha_val = 0.0;
-        }
-        if (kExtended && P.plasma.power_frac != 0.0) {
-          // power-law electrons, unpolarized (simulation_coefficients.cpp:556-584)
-          const double ratio = nu_cgs / (sh.nu_c_cgs * sh.sin_theta_b);
-          const double var_a_j = bl_pow(ratio, -(P.plasma.plasma_p - 1.0) / 2.0);
-          j_val += P.plasma.power_frac * sh.n_e_cgs * kE * kE * sh.nu_c_cgs / (kC * nu_2_cgs) * P.plasma.power_jj
-              * sh.sin_theta_b * var_a_j;
-          const double var_a_a = bl_pow(ratio, -(P.plasma.plasma_p + 2.0) / 2.0);
-          alpha_val += P.plasma.power_frac * sh.n_e_cgs * kE * kE / (kMe * kC) * P.plasma.power_aa * var_a_a;
-        }
+        simulation_coefficients<kExtended>(P, sh, freq, momentum_factor, &j_val, &alpha_val);
       } else if (sh.have_coefficients && kModel == BL_MODEL_FORMULA) {
         // formula_coefficients.cpp:164-179
         const BlFormulaDevice &fm = P.formula;
@@ -1604,158 +1790,6 @@ __global__ void __launch_bounds__(256, 2) bl_shade_kernel(const BlShadeArgs P) {
         const double alpha_nu_fluid_cgs = fm.a * fm.cn0 * sh.n_n0_fluid * bl_pow(nu_fluid_cgs / fm.nup, -fm.beta - fm.alpha);
         alpha_val = alpha_nu_fluid_cgs * nu_fluid_cgs;
       }
-      if (kAux && kExtended && kModel == BL_MODEL_SIMULATION && P.pol_coeffs != nullptr) {
-        // polarized coefficients (simulation_coefficients.cpp:485-495, :506-523, :527-553, :567-605), plain
-        // IEEE operations in the reference's order
-        double j_q = 0.0, j_v = 0.0, alpha_q = 0.0, alpha_v = 0.0, rho_q = 0.0, rho_v = 0.0;
-        if (sh.have_coefficients) {
-          const double thermal_frac = P.plasma.plasma_thermal_frac;
-          const double nu_cgs = sh.nu_fluid_over_nu * (freq * momentum_factor);
-          const double nu_2_cgs = nu_cgs * nu_cgs;
-          const double nu_c_cgs = sh.nu_c_cgs, theta_e = sh.theta_e, sin_theta_b = sh.sin_theta_b, cos_theta_b = sh.cos_theta_b;
-          const double n_e_cgs = sh.n_e_cgs;
-          const double nu_s_cgs = 2.0 / 9.0 * nu_c_cgs * theta_e * theta_e * sin_theta_b;
-          if (thermal_frac != 0.0) {
-            const double xx = nu_cgs / nu_s_cgs;
-            const double xx_1_2 = blm_sqrt(xx);
-            const double xx_1_3 = bl_cbrt(xx);
-            const double xx_1_6 = blm_sqrt(xx_1_3);
-            const double coefficient = thermal_frac * n_e_cgs * kE * kE * nu_c_cgs / (kC * nu_2_cgs) * bl_exp(-xx_1_3);
-            const double var_a = kSqrt2 * kPi / 27.0 * sin_theta_b;
-            const double var_b = kPow2_11_12;
-            const double var_d = (7.0 * bl_pow(theta_e, 0.96) + 35.0) / (10.0 * bl_pow(theta_e, 0.96) + 75.0) * var_b;
-            const double var_e = xx_1_2 + var_d * xx_1_6;
-            const double var_f = cos_theta_b / theta_e;
-            const double var_g = kPi / 3.0 + kPi / 3.0 * xx_1_3 + 2.0 / 300.0 * xx_1_2 + 2.0 / 19.0 * kPi * xx_1_3 * xx_1_3;
-            j_q = -coefficient * var_a * var_e * var_e;
-            j_v = coefficient * var_f * var_g;
-            const double b_nu_nu_3_cgs = 2.0 * kH / (kC * kC) / bl_expm1(kH * nu_cgs / sh.kb_tt_e_cgs);
-            alpha_q = j_q / b_nu_nu_3_cgs;
-            alpha_v = j_v / b_nu_nu_3_cgs;
-            // :513-523 with the thermal alpha_I (alpha_val holds it, possibly already zeroed, before the
-            // power-law term is added - recompute the test on the thermal value)
-            {
-              const double var_c = xx_1_2 + var_b * xx_1_6;
-              const double alpha_thermal = coefficient * var_a * var_c * var_c / b_nu_nu_3_cgs;
-              if (alpha_thermal * alpha_thermal <= 0x1p-1024) alpha_q = alpha_v = 0.0;
-            }
-            const double coefficient_q = -thermal_frac * n_e_cgs * kE * kE * nu_c_cgs * nu_c_cgs * sh.sin2_theta_b / (kMe * kC * nu_2_cgs);
-            const double coefficient_v = thermal_frac * 2.0 * n_e_cgs * kE * kE * nu_c_cgs * cos_theta_b / (kMe * kC * nu_cgs);
-            double factor_q = 0.0, factor_v = 1.0;
-            if (theta_e >= 0.01) {   // theta_e_zero, radiation_integrator.hpp:190
-              double kk_0, kk_1, kk_2;   // three std::cyl_bessel_k calls in the reference (:537-539)
-              bl_cyl_bessel_k012(1.0 / theta_e, &kk_0, &kk_1, &kk_2);
-              const double xx_neg_1_2 = 1.0 / blm_sqrt(xx);
-              const double f_a = 2.011 * bl_exp(-19.78 * bl_pow(xx, -0.5175));
-              const double f_b = bl_cos(39.89 * xx_neg_1_2) * bl_exp(-70.16 * bl_pow(xx, -0.6));
-              const double f_c = 0.011 * bl_exp(-1.69 * xx_neg_1_2);
-              const double f_d = 0.003135 * bl_pow(xx, 4.0 / 3.0);
-              const double f_e = 0.5 * (1.0 + bl_tanh(10.0 * bl_log(0.6648 * xx_neg_1_2)));
-              const double f_0 = f_a - f_b - f_c;
-              const double f_m = f_0 + (f_c - f_d) * f_e;
-              const double delta_jj_5 = 0.4379 * bl_log(1.0 + 1.3414 * bl_pow(xx, -0.7515));
-              factor_q = f_m * (kk_1 / kk_2 + 6.0 * theta_e);
-              factor_v = (kk_0 - delta_jj_5) / kk_2;
-              factor_v = (factor_v < 0.0 || factor_v > 1.0) ? 1.0 : factor_v;
-            }
-            rho_q = coefficient_q * factor_q;
-            rho_v = coefficient_v * factor_v;
-          }
-          if (P.plasma.power_frac != 0.0) {
-            const double plasma_p = P.plasma.plasma_p;
-            {
-              const double var_a = bl_pow(nu_cgs / (nu_c_cgs * sin_theta_b), -(plasma_p - 1.0) / 2.0);
-              const double coefficient = P.plasma.power_frac * n_e_cgs * kE * kE * nu_c_cgs / (kC * nu_2_cgs) * P.plasma.power_jj * sin_theta_b * var_a;
-              const double var_b = cos_theta_b / sin_theta_b;
-              const double var_c = 1.0 / blm_sqrt(nu_cgs / (3.0 * nu_c_cgs * sin_theta_b));
-              j_q += coefficient * P.power_pol[0];
-              j_v += coefficient * P.power_pol[1] * var_b * var_c;
-            }
-            {
-              const double var_a = bl_pow(nu_cgs / (nu_c_cgs * sin_theta_b), -(plasma_p + 2.0) / 2.0);
-              const double coefficient = P.plasma.power_frac * n_e_cgs * kE * kE / (kMe * kC) * P.plasma.power_aa * var_a;
-              const double var_b = bl_pow(3.1 * bl_pow(sin_theta_b, -1.92) - 3.1, 0.512);
-              const double var_c = 1.0 / blm_sqrt(nu_cgs / (nu_c_cgs * sin_theta_b));
-              const double var_d = cos_theta_b >= 0.0 ? 1.0 : -1.0;
-              alpha_q += coefficient * P.power_pol[2];
-              alpha_v += coefficient * P.power_pol[3] * var_b * var_c * var_d;
-            }
-            {
-              const double var_a = n_e_cgs * kE * kE * nu_cgs / (kMe * kC * nu_c_cgs * sin_theta_b);
-              const double var_b = nu_c_cgs * sin_theta_b / nu_cgs;
-              const double var_c = var_b * var_b;
-              const double var_d = var_c * var_b;
-              const double var_e = 1.0 - bl_pow(2.0 * nu_c_cgs * P.plasma_gamma_min * P.plasma_gamma_min * sin_theta_b / (3.0 * nu_cgs), plasma_p / 2.0 - 1.0);
-              const double var_f = cos_theta_b / sin_theta_b;
-              const double coefficient = P.plasma.power_frac * P.power_pol[4] * var_a;
-              rho_q += coefficient * P.power_pol[5] * var_d * var_e;
-              rho_v += coefficient * P.power_pol[6] * var_c * var_f;
-            }
-          }
-          if (P.cold->kappa.frac != 0.0) {
-            // kappa-distribution electrons (simulation_coefficients.cpp:607-698): every term is the harmonic-like
-            // bridge (low^-x + high^-x)^(-1/x) between a low- and a high-frequency fit. Only polarized runs get
-            // here (bl_init), so the intensity terms are added to j_val / alpha_val in this block as well.
-            const BlKappaDevice &kk = P.cold->kappa;
-            const double nu_kappa_cgs = nu_c_cgs * kk.w * kk.w * kk.kappa * kk.kappa * sin_theta_b;
-            const double xx = nu_cgs / nu_kappa_cgs;
-            const double var_g = 1.0 / blm_sqrt(xx);
-            const double var_h = cos_theta_b >= 0.0 ? 1.0 : -1.0;
-            const double var_e = bl_pow(xx, -0.35);
-            {   // emissivities (:608-637)
-              const double var_a = kk.frac * n_e_cgs * kE * kE * nu_c_cgs / (kC * nu_2_cgs);
-              const double var_b = bl_cbrt(xx) * sin_theta_b;
-              const double var_c = bl_pow(xx, -(kk.kappa - 2.0) / 2.0) * sin_theta_b;
-              const double coefficient_low = kk.jj_low * var_a * var_b;
-              const double coefficient_high = kk.jj_high * var_a * var_c;
-              j_val += bl_pow(bl_pow(coefficient_low, -kk.jj_x_i) + bl_pow(coefficient_high, -kk.jj_x_i), -1.0 / kk.jj_x_i);
-              const double var_d = bl_pow(bl_pow(sin_theta_b, -2.4) - 1.0, 0.48);
-              const double var_f = bl_pow(bl_pow(sin_theta_b, -2.5) - 1.0, 0.44);
-              const double jj_q_low = coefficient_low * kk.jj_low_q;
-              const double jj_v_low = coefficient_low * kk.jj_low_v * var_d * var_e;
-              const double jj_q_high = coefficient_high * kk.jj_high_q;
-              const double jj_v_high = coefficient_high * kk.jj_high_v * var_f * var_g;
-              j_q -= bl_pow(bl_pow(jj_q_low, -kk.jj_x_q) + bl_pow(jj_q_high, -kk.jj_x_q), -1.0 / kk.jj_x_q);
-              j_v += bl_pow(bl_pow(jj_v_low, -kk.jj_x_v) + bl_pow(jj_v_high, -kk.jj_x_v), -1.0 / kk.jj_x_v) * var_h;
-            }
-            {   // absorptivities (:640-667)
-              const double var_a = kk.frac * n_e_cgs * kE * kE / (kMe * kC);
-              const double var_b = bl_pow(xx, -2.0 / 3.0);
-              const double var_c = bl_pow(xx, -(1.0 + kk.kappa) / 2.0);
-              const double coefficient_low = kk.aa_low * var_a * var_b;
-              const double coefficient_high = kk.aa_high * var_a * var_c;
-              const double aa_i_low = coefficient_low;
-              const double aa_i_high = coefficient_high * kk.aa_high_i;
-              alpha_val += bl_pow(bl_pow(aa_i_low, -kk.aa_x_i) + bl_pow(aa_i_high, -kk.aa_x_i), -1.0 / kk.aa_x_i);
-              const double var_d = bl_pow(bl_pow(sin_theta_b, -2.28) - 1.0, 0.446);
-              const double var_f = blm_sqrt(bl_pow(sin_theta_b, -2.05) - 1.0);
-              const double aa_q_low = coefficient_low * kk.aa_low_q;
-              const double aa_v_low = coefficient_low * kk.aa_low_v * var_d * var_e;
-              const double aa_q_high = coefficient_high * kk.aa_high_q;
-              const double aa_v_high = coefficient_high * kk.aa_high_v * var_f * var_g;
-              alpha_q -= bl_pow(bl_pow(aa_q_low, -kk.aa_x_q) + bl_pow(aa_q_high, -kk.aa_x_q), -1.0 / kk.aa_x_q);
-              alpha_v += bl_pow(bl_pow(aa_v_low, -kk.aa_x_v) + bl_pow(aa_v_high, -kk.aa_x_v), -1.0 / kk.aa_x_v) * var_h;
-            }
-            {   // rotativities (:670-698): linear blend of the fits at the two ends of kappa's bracket
-              const double var_a = -kk.frac * n_e_cgs * kE * kE * nu_c_cgs * nu_c_cgs * sh.sin2_theta_b / (kMe * kC * nu_2_cgs);
-              const double var_b = kk.frac * 2.0 * n_e_cgs * kE * kE * nu_c_cgs * cos_theta_b / (kMe * kC * nu_cgs);
-              const double xx_084 = bl_pow(xx, 0.84);
-              const double rho_q_low = var_a * kk.rho_q_low[0] * (1.0 - bl_exp(kk.rho_q_low[1] * xx_084)
-                  - bl_sin(kk.rho_q_low[2] * xx) * bl_exp(kk.rho_q_low[3] * bl_pow(xx, kk.rho_q_low[4])));
-              const double rho_q_high = var_a * kk.rho_q_high[0] * (1.0 - bl_exp(kk.rho_q_high[1] * xx_084)
-                  - bl_sin(kk.rho_q_high[2] * xx) * bl_exp(kk.rho_q_high[3] * bl_pow(xx, kk.rho_q_high[4])));
-              const double rho_v_low = kk.rho_v * var_b * kk.rho_v_low[0] * (1.0 - 0.17 * bl_log(1.0 + kk.rho_v_low[1] * var_g));
-              const double rho_v_high = kk.rho_v * var_b * kk.rho_v_high[0] * (1.0 - 0.17 * bl_log(1.0 + kk.rho_v_high[1] * var_g));
-              rho_q += (1.0 - kk.rho_frac) * rho_q_low + kk.rho_frac * rho_q_high;
-              rho_v += (1.0 - kk.rho_frac) * rho_v_low + kk.rho_frac * rho_v_high;
-            }
-          }
-        }
-        double2 *pc = P.pol_coeffs + (((size_t)ray * P.ray_max_steps + n) * P.n_nu + l) * 3;
-        pc[0] = make_double2(j_q, j_v);
-        pc[1] = make_double2(alpha_q, alpha_v);
-        pc[2] = make_double2(rho_q, rho_v);
-      }
       if (kAux) {
         if (kModel == BL_MODEL_FORMULA && nan_ray && l == 0) j_val = alpha_val = __longlong_as_double(0x7ff8000000000000ll);
         out[l] = make_double2(j_val, alpha_val);
@@ -1763,6 +1797,49 @@ __global__ void __launch_bounds__(256, 2) bl_shade_kernel(const BlShadeArgs P) {
         const double delta_lambda_cgs = bl_div_g(delta_lambda * P.x_unit, freq * momentum_factor);   // unpolarized.cpp:75-76
         out[l] = transfer_record(j_val, alpha_val, delta_lambda_cgs);
       }
+    }
+  }
+}
+
+// =================================================================================================
+// Polarized coefficient kernel: the per-frequency part of CalculateSimulationCoefficients (simulation_coefficients.cpp:
+// 458-698) for polarized runs, one sample record per lane from the scalars the coefficient kernel left
+// (BlCoefInputs). Writes (j_I, alpha_I) and the three polarized pairs, [ray][n][frequency].
+// =================================================================================================
+__global__ void __launch_bounds__(256, 2) bl_polarized_coefficients_kernel(const BlShadeArgs P) {
+  const unsigned long long n_records = P.counters_in[BL_CNT_RECORDS];
+  const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+  for (unsigned long long idx = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; idx < n_records; idx += stride) {
+    const unsigned long long tag = reinterpret_cast<const unsigned long long *>(P.records + idx)[3];   // (ray, n)
+    const uint32_t ray = (uint32_t)tag;
+    if (ray == BL_DEAD_RAY) continue;
+    const uint32_t n = (uint32_t)(tag >> 32);
+    const BlCoefInputs ci = P.coef_inputs[idx];
+    const double momentum_factor = P.ray_factor[ray];
+    SampleShade sh;
+    sh.have_coefficients = ci.have_coefficients != 0.0;
+    sh.nu_fluid_over_nu = ci.nu_fluid_over_nu;
+    sh.n_e_cgs = ci.n_e_cgs;
+    sh.nu_c_cgs = ci.nu_c_cgs;
+    sh.theta_e = ci.theta_e;
+    sh.kb_tt_e_cgs = ci.kb_tt_e_cgs;
+    // :453-455 from cos^2: the same operations the coefficient kernel applies to the same value
+    sh.cos2_theta_b = ci.cos2_theta_b;
+    sh.sin2_theta_b = 1.0 - ci.cos2_theta_b;
+    sh.sin_theta_b = bl_sqrt_g(sh.sin2_theta_b);
+    sh.cos_theta_b = bl_sqrt_g(ci.cos2_theta_b) * ci.cos_sign;
+    const size_t at = ((size_t)ray * P.ray_max_steps + n) * P.n_nu;
+    for (int l = 0; l < P.n_nu; l++) {
+      const double freq = P.frequencies[l];
+      double j_val = 0.0, alpha_val = 0.0;
+      double2 pc[3] = {make_double2(0.0, 0.0), make_double2(0.0, 0.0), make_double2(0.0, 0.0)};
+      if (sh.have_coefficients) simulation_coefficients<true>(P, sh, freq, momentum_factor, &j_val, &alpha_val);
+      polarized_coefficients(P, sh, freq, momentum_factor, j_val, alpha_val, pc);
+      P.transfer[at + l] = make_double2(j_val, alpha_val);
+      double2 *out = P.pol_coeffs + (at + l) * 3;
+      out[0] = pc[0];
+      out[1] = pc[1];
+      out[2] = pc[2];
     }
   }
 }
@@ -2090,6 +2167,11 @@ extern "C" hipError_t bl_launch_shade(const BlShadeArgs *args, int model, int gr
     else BL_LAUNCH_S(BL_MODEL_FORMULA, false, false);
   }
 #undef BL_LAUNCH_S
+  return hipGetLastError();
+}
+
+extern "C" hipError_t bl_launch_polarized_coefficients(const BlShadeArgs *args, int grid, hipStream_t stream) {
+  hipLaunchKernelGGL(bl_polarized_coefficients_kernel, dim3(grid), dim3(256), 0, stream, *args);
   return hipGetLastError();
 }
 
