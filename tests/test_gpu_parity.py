@@ -239,6 +239,8 @@ def _random_configuration(seed):
         if layout == 3:
             mesh["_entropy"] = 1
             over.update(plasma_model="code_kappa", simulation_kappa_name="r0", fallback_kappa=2.0e6)
+        if int(rng.integers(0, 4)) == 0:   # the same arrays read as a Cartesian Kerr-Schild box, looked at along x
+            over.update(simulation_coord="cks", camera_th=float(rng.uniform(75.0, 100.0)), camera_ph=float(rng.uniform(-15.0, 15.0)))
     return base, over, mesh
 
 

@@ -153,6 +153,13 @@ CASES = {
     "sim_polarized_kappa_low": (SIM_BASE, dict(camera_resolution=12, image_polarization="true", plasma_kappa_frac=0.49,
                                                plasma_kappa=3.5, plasma_w=1.919106339654944, simulation_a=0.5,
                                                simulation_interp="false"), SMALL_MOCK, [78]),
+    # Cartesian Kerr-Schild simulation coordinates: the mock's arrays read as a box in (x, y, z), looked at along x
+    "sim_cks": (SIM_BASE, dict(camera_resolution=24, simulation_coord="cks", simulation_a=0.5, camera_th=85.0, camera_width=12.0,
+                               image_tau="true", image_lambda_ave="true", fallback_nan="false", fallback_rho=1.0e-6,
+                               fallback_pgas=1.0e-8), SMALL_MOCK, [300]),
+    "sim_polarized_cks": (SIM_BASE, dict(camera_resolution=16, simulation_coord="cks", image_polarization="true",
+                                         simulation_interp="false", camera_th=80.0, camera_ph=10.0, camera_width=14.0, fallback_nan="false",
+                                         fallback_rho=1.0e-6, fallback_pgas=1.0e-8), SMALL_MOCK, [136]),
     "sim_powerlaw": (SIM_BASE, dict(camera_resolution=24, plasma_power_frac=0.3, plasma_p=2.5, plasma_gamma_min=1.0,
                                     plasma_gamma_max=1000.0), SMALL_MOCK, [300]),
     # false-colour renderings (rendering.cpp): the features of the reference's example_render.input, without
