@@ -1601,7 +1601,7 @@ __global__ void __launch_bounds__(256, 4) bl_locate_kernel(const BlShadeArgs P) 
 // kExtended: power-law electrons present (simulation_coefficients.cpp:556-584: two more pow() per
 // sample and frequency) or plasma_model = code_kappa (:351-358: a ninth grid value per cell); its own
 // instantiation so that the thermal-only T_i/T_e(beta) kernel keeps its registers.
-template <int kModel, bool kAux, bool kExtended, bool kSksCurved>
+template <int kModel, bool kAux, bool kExtended, bool kSksCurved, bool kPolarized>
 __global__ void __launch_bounds__(256, 2) bl_shade_kernel(const BlShadeArgs P) {
   const BlSpacetime st = P.st;
   const unsigned long long n_records = P.counters_in[BL_CNT_RECORDS];
@@ -1712,8 +1712,7 @@ __global__ void __launch_bounds__(256, 2) bl_shade_kernel(const BlShadeArgs P) {
       if (kModel == BL_MODEL_SIMULATION)
         sample_finish_simulation<kExtended, kSksCurved>(P, st, ks, x3 / ks.r, ph, pr, kappa_f, kcov,
                                             kAux ? P.aux_need_coefficients : 1, &sh,
-                                            (kAux && kExtended && P.pol_samples != nullptr)
-                                                ? P.pol_samples + ((size_t)ray * P.ray_max_steps + n) : nullptr);
+                                            kPolarized ? P.pol_samples + ((size_t)ray * P.ray_max_steps + n) : nullptr);
       else if (!(kAux && nan_ray))
         shade_formula(P, st, ks.r, x1, x2, x3, &sh);
     }
@@ -1746,7 +1745,7 @@ __global__ void __launch_bounds__(256, 2) bl_shade_kernel(const BlShadeArgs P) {
       const double nan = __longlong_as_double(0x7ff8000000000000ll);
       for (int a = 0; a < BL_NUM_CELL_VALUES; a++) aux.cell[a] = sh.have_cell ? sh.cell[a] : nan;
       P.aux[(size_t)ray * P.ray_max_steps + n] = aux;
-      if (kExtended && P.pol_samples != nullptr) {
+      if (kPolarized) {
         BlPolSample *ps = P.pol_samples + ((size_t)ray * P.ray_max_steps + n);
         ps->x[0] = x1; ps->x[1] = x2; ps->x[2] = x3;
         ps->delta_lambda = delta_lambda;
@@ -1762,8 +1761,8 @@ __global__ void __launch_bounds__(256, 2) bl_shade_kernel(const BlShadeArgs P) {
         }
       }
     }
-    if (kAux && kExtended && kModel == BL_MODEL_SIMULATION && P.pol_coeffs != nullptr) {
-      // polarized run: the per-frequency formulas (Bessel functions, a dozen powers and exponentials) need few
+    if (kPolarized) {
+      // polarized run (an auxiliary-image, extended, simulation-mode instantiation): the per-frequency formulas (Bessel functions, a dozen powers and exponentials) need few
       // registers and many waves - bl_polarized_coefficients_kernel evaluates them from these scalars
       BlCoefInputs ci;
       ci.nu_fluid_over_nu = sh.nu_fluid_over_nu;
@@ -2161,12 +2160,16 @@ extern "C" hipError_t bl_launch_shade(const BlShadeArgs *args, int model, int gr
   // the benchmark path - plain image of a spherical Kerr-Schild simulation in a curved spacetime - has its own
   // instantiation with those two facts known at compile time (62.4 instead of 64.4 ms per 1024^2 frame)
   const bool sks_curved = args->plasma.simulation_coord == BL_COORD_SKS && !args->st.ray_flat;
-#define BL_LAUNCH_S(M, A, W) hipLaunchKernelGGL((bl_shade_kernel<M, A, W, false>), dim3(grid), dim3(256), 0, stream, *args)
+#define BL_LAUNCH_S(M, A, W) hipLaunchKernelGGL((bl_shade_kernel<M, A, W, false, false>), dim3(grid), dim3(256), 0, stream, *args)
   if (model == BL_MODEL_SIMULATION) {
-    if (aux && power) BL_LAUNCH_S(BL_MODEL_SIMULATION, true, true);
+    if (aux && args->pol_samples != nullptr && sks_curved)   // polarized run: frame and coefficient inputs per sample, no frequency loop
+      hipLaunchKernelGGL((bl_shade_kernel<BL_MODEL_SIMULATION, true, true, true, true>), dim3(grid), dim3(256), 0, stream, *args);
+    else if (aux && args->pol_samples != nullptr)
+      hipLaunchKernelGGL((bl_shade_kernel<BL_MODEL_SIMULATION, true, true, false, true>), dim3(grid), dim3(256), 0, stream, *args);
+    else if (aux && power) BL_LAUNCH_S(BL_MODEL_SIMULATION, true, true);
     else if (aux) BL_LAUNCH_S(BL_MODEL_SIMULATION, true, false);
     else if (power) BL_LAUNCH_S(BL_MODEL_SIMULATION, false, true);
-    else if (sks_curved) hipLaunchKernelGGL((bl_shade_kernel<BL_MODEL_SIMULATION, false, false, true>), dim3(grid), dim3(256), 0, stream, *args);
+    else if (sks_curved) hipLaunchKernelGGL((bl_shade_kernel<BL_MODEL_SIMULATION, false, false, true, false>), dim3(grid), dim3(256), 0, stream, *args);
     else BL_LAUNCH_S(BL_MODEL_SIMULATION, false, false);
   } else {
     if (aux) BL_LAUNCH_S(BL_MODEL_FORMULA, true, false);
