@@ -1330,7 +1330,8 @@ __device__ __forceinline__ void polarized_coefficients(const BlShadeArgs &P, con
       const double coefficient = thermal_frac * n_e_cgs * kE * kE * nu_c_cgs / (kC * nu_2_cgs) * bl_exp(-xx_1_3);
       const double var_a = kSqrt2 * kPi / 27.0 * sin_theta_b;
       const double var_b = kPow2_11_12;
-      const double var_d = (7.0 * bl_pow(theta_e, 0.96) + 35.0) / (10.0 * bl_pow(theta_e, 0.96) + 75.0) * var_b;
+      const double theta_e_096 = bl_pow(theta_e, 0.96);   // evaluated twice in the reference: same value
+      const double var_d = (7.0 * theta_e_096 + 35.0) / (10.0 * theta_e_096 + 75.0) * var_b;
       const double var_e = xx_1_2 + var_d * xx_1_6;
       const double var_f = cos_theta_b / theta_e;
       const double var_g = kPi / 3.0 + kPi / 3.0 * xx_1_3 + 2.0 / 300.0 * xx_1_2 + 2.0 / 19.0 * kPi * xx_1_3 * xx_1_3;
@@ -1353,14 +1354,15 @@ __device__ __forceinline__ void polarized_coefficients(const BlShadeArgs &P, con
         double kk_0, kk_1, kk_2;   // three std::cyl_bessel_k calls in the reference (:537-539)
         bl_cyl_bessel_k012(1.0 / theta_e, &kk_0, &kk_1, &kk_2);
         const double xx_neg_1_2 = 1.0 / blm_sqrt(xx);
-        const double f_a = 2.011 * bl_exp(-19.78 * bl_pow(xx, -0.5175));
-        const double f_b = bl_cos(39.89 * xx_neg_1_2) * bl_exp(-70.16 * bl_pow(xx, -0.6));
+        const blm_powbase xx_base = bl_pow_base(xx);   // four powers of xx below: one logarithm (blmath.h)
+        const double f_a = 2.011 * bl_exp(-19.78 * bl_pow_of(xx_base, -0.5175));
+        const double f_b = bl_cos(39.89 * xx_neg_1_2) * bl_exp(-70.16 * bl_pow_of(xx_base, -0.6));
         const double f_c = 0.011 * bl_exp(-1.69 * xx_neg_1_2);
-        const double f_d = 0.003135 * bl_pow(xx, 4.0 / 3.0);
+        const double f_d = 0.003135 * bl_pow_of(xx_base, 4.0 / 3.0);
         const double f_e = 0.5 * (1.0 + bl_tanh(10.0 * bl_log(0.6648 * xx_neg_1_2)));
         const double f_0 = f_a - f_b - f_c;
         const double f_m = f_0 + (f_c - f_d) * f_e;
-        const double delta_jj_5 = 0.4379 * bl_log(1.0 + 1.3414 * bl_pow(xx, -0.7515));
+        const double delta_jj_5 = 0.4379 * bl_log(1.0 + 1.3414 * bl_pow_of(xx_base, -0.7515));
         factor_q = f_m * (kk_1 / kk_2 + 6.0 * theta_e);
         factor_v = (kk_0 - delta_jj_5) / kk_2;
         factor_v = (factor_v < 0.0 || factor_v > 1.0) ? 1.0 : factor_v;
@@ -1408,16 +1410,17 @@ __device__ __forceinline__ void polarized_coefficients(const BlShadeArgs &P, con
       const double xx = nu_cgs / nu_kappa_cgs;
       const double var_g = 1.0 / blm_sqrt(xx);
       const double var_h = cos_theta_b >= 0.0 ? 1.0 : -1.0;
-      const double var_e = bl_pow(xx, -0.35);
+      const blm_powbase xx_base = bl_pow_base(xx), sin_base = bl_pow_base(sin_theta_b);   // 8 + 5 powers: two logarithms
+      const double var_e = bl_pow_of(xx_base, -0.35);
       {   // emissivities (:608-637)
         const double var_a = kk.frac * n_e_cgs * kE * kE * nu_c_cgs / (kC * nu_2_cgs);
         const double var_b = bl_cbrt(xx) * sin_theta_b;
-        const double var_c = bl_pow(xx, -(kk.kappa - 2.0) / 2.0) * sin_theta_b;
+        const double var_c = bl_pow_of(xx_base, -(kk.kappa - 2.0) / 2.0) * sin_theta_b;
         const double coefficient_low = kk.jj_low * var_a * var_b;
         const double coefficient_high = kk.jj_high * var_a * var_c;
         j_val += bl_pow(bl_pow(coefficient_low, -kk.jj_x_i) + bl_pow(coefficient_high, -kk.jj_x_i), -1.0 / kk.jj_x_i);
-        const double var_d = bl_pow(bl_pow(sin_theta_b, -2.4) - 1.0, 0.48);
-        const double var_f = bl_pow(bl_pow(sin_theta_b, -2.5) - 1.0, 0.44);
+        const double var_d = bl_pow(bl_pow_of(sin_base, -2.4) - 1.0, 0.48);
+        const double var_f = bl_pow(bl_pow_of(sin_base, -2.5) - 1.0, 0.44);
         const double jj_q_low = coefficient_low * kk.jj_low_q;
         const double jj_v_low = coefficient_low * kk.jj_low_v * var_d * var_e;
         const double jj_q_high = coefficient_high * kk.jj_high_q;
@@ -1427,15 +1430,15 @@ __device__ __forceinline__ void polarized_coefficients(const BlShadeArgs &P, con
       }
       {   // absorptivities (:640-667)
         const double var_a = kk.frac * n_e_cgs * kE * kE / (kMe * kC);
-        const double var_b = bl_pow(xx, -2.0 / 3.0);
-        const double var_c = bl_pow(xx, -(1.0 + kk.kappa) / 2.0);
+        const double var_b = bl_pow_of(xx_base, -2.0 / 3.0);
+        const double var_c = bl_pow_of(xx_base, -(1.0 + kk.kappa) / 2.0);
         const double coefficient_low = kk.aa_low * var_a * var_b;
         const double coefficient_high = kk.aa_high * var_a * var_c;
         const double aa_i_low = coefficient_low;
         const double aa_i_high = coefficient_high * kk.aa_high_i;
         alpha_val += bl_pow(bl_pow(aa_i_low, -kk.aa_x_i) + bl_pow(aa_i_high, -kk.aa_x_i), -1.0 / kk.aa_x_i);
-        const double var_d = bl_pow(bl_pow(sin_theta_b, -2.28) - 1.0, 0.446);
-        const double var_f = blm_sqrt(bl_pow(sin_theta_b, -2.05) - 1.0);
+        const double var_d = bl_pow(bl_pow_of(sin_base, -2.28) - 1.0, 0.446);
+        const double var_f = blm_sqrt(bl_pow_of(sin_base, -2.05) - 1.0);
         const double aa_q_low = coefficient_low * kk.aa_low_q;
         const double aa_v_low = coefficient_low * kk.aa_low_v * var_d * var_e;
         const double aa_q_high = coefficient_high * kk.aa_high_q;
@@ -1446,11 +1449,11 @@ __device__ __forceinline__ void polarized_coefficients(const BlShadeArgs &P, con
       {   // rotativities (:670-698): linear blend of the fits at the two ends of kappa's bracket
         const double var_a = -kk.frac * n_e_cgs * kE * kE * nu_c_cgs * nu_c_cgs * sh.sin2_theta_b / (kMe * kC * nu_2_cgs);
         const double var_b = kk.frac * 2.0 * n_e_cgs * kE * kE * nu_c_cgs * cos_theta_b / (kMe * kC * nu_cgs);
-        const double xx_084 = bl_pow(xx, 0.84);
+        const double xx_084 = bl_pow_of(xx_base, 0.84);
         const double rho_q_low = var_a * kk.rho_q_low[0] * (1.0 - bl_exp(kk.rho_q_low[1] * xx_084)
-            - bl_sin(kk.rho_q_low[2] * xx) * bl_exp(kk.rho_q_low[3] * bl_pow(xx, kk.rho_q_low[4])));
+            - bl_sin(kk.rho_q_low[2] * xx) * bl_exp(kk.rho_q_low[3] * bl_pow_of(xx_base, kk.rho_q_low[4])));
         const double rho_q_high = var_a * kk.rho_q_high[0] * (1.0 - bl_exp(kk.rho_q_high[1] * xx_084)
-            - bl_sin(kk.rho_q_high[2] * xx) * bl_exp(kk.rho_q_high[3] * bl_pow(xx, kk.rho_q_high[4])));
+            - bl_sin(kk.rho_q_high[2] * xx) * bl_exp(kk.rho_q_high[3] * bl_pow_of(xx_base, kk.rho_q_high[4])));
         const double rho_v_low = kk.rho_v * var_b * kk.rho_v_low[0] * (1.0 - 0.17 * bl_log(1.0 + kk.rho_v_low[1] * var_g));
         const double rho_v_high = kk.rho_v * var_b * kk.rho_v_high[0] * (1.0 - 0.17 * bl_log(1.0 + kk.rho_v_high[1] * var_g));
         rho_q += (1.0 - kk.rho_frac) * rho_q_low + kk.rho_frac * rho_q_high;

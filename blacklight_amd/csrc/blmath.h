@@ -307,6 +307,31 @@ BLM_FN double bl_pow(double x, double y) {
   return sign * blm_exp_dd(a);
 }
 
+/* Several powers of one base: bl_pow(x, y) spends a third of its work on log(x). bl_pow_base() takes that
+   logarithm once; bl_pow_of(base, y) is bl_pow(x, y) bit for bit - for a finite positive x other than 1 it is the
+   tail of bl_pow on the same double-double logarithm, for every other x it calls bl_pow. */
+typedef struct { double x; blm_dd l; int regular; } blm_powbase;
+BLM_FN blm_powbase bl_pow_base(double x) {
+  blm_powbase b;
+  b.x = x;
+  b.regular = x > 0.0 && !blm_isinf(x) && x != 1.0;   /* false for NaN */
+  b.l.hi = b.l.lo = 0.0;
+  if (b.regular) b.l = blm_log_dd(x);
+  return b;
+}
+BLM_FN double bl_pow_of(blm_powbase b, double y) {
+  if (!b.regular) return bl_pow(b.x, y);
+  if (y == 0.0) return 1.0;
+  if (blm_isnan(y)) return b.x + y;
+  if (blm_isinf(y)) return ((b.x > 1.0) == (y > 0.0)) ? BLM_INF : 0.0;
+  blm_dd a = blm_two_prod(b.l.hi, y);
+  a.lo = blm_fma(b.l.lo, y, a.lo);
+  a = blm_fast_two_sum(a.hi, a.lo);
+  if (a.hi > 709.79) return BLM_INF;
+  if (a.hi < -745.2) return 0.0;
+  return blm_exp_dd(a);
+}
+
 /* ---------------------------------------------------------------- cbrt */
 BLM_FN double bl_cbrt(double x) {
   if (x == 0.0 || blm_isnan(x) || blm_isinf(x)) return x;

@@ -32,6 +32,8 @@ EXPORT double tanh(double x) { return bl_tanh(x); }
 #define VEC2(name, fn) EXPORT void name(const double *x, const double *y, double *out, long n) { for (long i = 0; i < n; i++) out[i] = fn(x[i], y[i]); }
 VEC2(blv_hypot, bl_hypot)
 VEC2(blv_pow, bl_pow)
+static double pow_through_base(double x, double y) { return bl_pow_of(bl_pow_base(x), y); }
+VEC2(blv_pow_of, pow_through_base)
 VEC2(blv_atan2, bl_atan2)
 VEC1(blv_exp, bl_exp)
 VEC1(blv_expm1, bl_expm1)

@@ -106,6 +106,21 @@ def test_pow_general_and_special(lib):
     assert np.array_equal(res[~np.isnan(want)], want[~np.isnan(want)])
 
 
+def test_pow_through_shared_logarithm(lib):
+    """bl_pow_of(bl_pow_base(x), y) - several powers of one base from one logarithm - is bl_pow(x, y) bit for bit:
+    200 000 random operand pairs and every pairing of the special values."""
+    rng = np.random.default_rng(77)
+    x = np.concatenate([10.0 ** rng.uniform(-300, 300, 100000), rng.uniform(0.0, 4.0, 100000)])
+    y = np.concatenate([rng.uniform(-8, 8, 100000), rng.uniform(-400, 400, 100000)])
+    special = np.array([0.0, -0.0, 1.0, -1.0, 2.0, 0.5, -2.0, -0.5, np.inf, -np.inf, np.nan, 5e-324, 1.7976931348623157e308, 3.0, -3.0])
+    xs, ys = np.meshgrid(special, special)
+    x = np.concatenate([x, xs.ravel()])
+    y = np.concatenate([y, ys.ravel()])
+    a = _call2(lib, "pow", x, y)
+    b = _call2(lib, "pow_of", x, y)
+    assert np.array_equal(a.view(np.uint64), b.view(np.uint64))
+
+
 def test_atan2_quadrants(lib):
     y = RNG.uniform(-5, 5, N)
     x = RNG.uniform(-5, 5, N)
