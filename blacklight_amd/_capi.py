@@ -23,6 +23,7 @@ class GridDesc(C.Structure):
         ("ind_uu1", C.c_int32), ("ind_uu2", C.c_int32), ("ind_uu3", C.c_int32),
         ("ind_bb1", C.c_int32), ("ind_bb2", C.c_int32), ("ind_bb3", C.c_int32),
         ("plasma_gamma", C.c_double), ("plasma_gamma_i", C.c_double), ("plasma_gamma_e", C.c_double),
+        ("levels", C.c_void_p), ("locations", C.c_void_p), ("n_3_root", C.c_int32),
     ]
 
 

@@ -57,6 +57,10 @@ class Grid:
     plasma_gamma_i: float = 0.0
     plasma_gamma_e: float = 0.0
     ind_kappa: int = -1   # index of the electron entropy in prim (plasma_model = code_kappa), -1: none
+    # MeshBlock table (simulation_block_interp): int32 [n_b], int32 [n_b][3], cells of the root grid in x3
+    levels: np.ndarray = None
+    locations: np.ndarray = None
+    n_3_root: int = 0
 
     @property
     def shape(self):
@@ -93,6 +97,12 @@ class Grid:
         d.ind_kappa = max(self.ind_kappa, 0)
         d.plasma_gamma, d.plasma_gamma_i, d.plasma_gamma_e = (
             self.plasma_gamma, self.plasma_gamma_i, self.plasma_gamma_e)
+        if self.levels is not None:
+            assert self.levels.dtype == np.int32 and self.locations.dtype == np.int32
+            assert self.levels.flags["C_CONTIGUOUS"] and self.locations.flags["C_CONTIGUOUS"]
+            d.levels = self.levels.ctypes.data_as(C.c_void_p)
+            d.locations = self.locations.ctypes.data_as(C.c_void_p)
+            d.n_3_root = int(self.n_3_root)
         return d
 
 

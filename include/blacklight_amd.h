@@ -188,6 +188,12 @@ typedef struct bl_grid_desc {
   const double *x1f, *x2f, *x3f, *x1v, *x2v, *x3v;
   int32_t ind_rho, ind_pgas, ind_kappa, ind_uu1, ind_uu2, ind_uu3, ind_bb1, ind_bb2, ind_bb3;
   double plasma_gamma, plasma_gamma_i, plasma_gamma_e; /* possibly modified by the reader */
+  /* MeshBlock table, read only with simulation_block_interp = true (simulation_sampling.cpp:36-39, :84-93):
+   * refinement level of each block, its logical location (i, j, k) on that level, and the number of cells
+   * of the root grid in x^3 (RootGridSize[2]). NULL / 0 otherwise. */
+  const int32_t *levels;      /* [n_blocks] */
+  const int32_t *locations;   /* [n_blocks][3] */
+  int32_t n_3_root;
 } bl_grid_desc;
 
 /* ------------------------------------------------------------------ snapshot reader (host only)

@@ -1214,6 +1214,141 @@ double InterpolateSimple(const bl_grid_desc &g, int var, int b, int k, int j, in
   return val;
 }
 
+// simulation_sampling.cpp:84-93: blocks along x^3 at a refinement level
+inline int N3Level(const bl_grid_desc &g, int level) { return (g.n_3_root / g.n_k) << level; }
+
+// simulation_sampling.cpp:1068-1321: the cell (block, k, j, i) that stands for cell (k, j, i) of block b when that
+// index is one beyond the block: the ghost cell's counterpart in the neighbouring block of the same level, the
+// coarse cell containing it, the fine cell nearest the sample, or - where the mesh ends - the edge cell itself.
+// Returns false where the reference throws "Grid interpolation failed."
+bool FindNearbyInds(const Oracle &o, int b, int k, int j, int i, int k_c, int j_c, int i_c, double x3, double x2, double x1, int inds[4]) {
+  const bl_grid_desc &g = *o.g;
+  const bool sks = o.p->simulation_coord == BL_COORD_SKS;
+  int n_b = g.n_blocks, n_i = g.n_i, n_j = g.n_j, n_k = g.n_k;
+  auto levels = [&](int bb) { return g.levels[bb]; };
+  auto locations = [&](int bb, int a) { return g.locations[3 * bb + a]; };
+  int max_level = 0;
+  for (int bb = 0; bb < n_b; bb++) max_level = std::max(max_level, levels(bb));
+  int level = levels(b);
+  int location_i = locations(b, 0), location_j = locations(b, 1), location_k = locations(b, 2);
+  bool upper_i = i > n_i / 2, upper_j = j > n_j / 2, upper_k = k > n_k / 2;
+  int i_safe = std::max(std::min(i, n_i - 1), 0);
+  int j_safe = std::max(std::min(j, n_j - 1), 0);
+  int k_safe = std::max(std::min(k, n_k - 1), 0);
+  if (i == i_safe and j == j_safe and k == k_safe) {
+    inds[0] = b; inds[1] = k; inds[2] = j; inds[3] = i;
+    return true;
+  }
+  bool x1_off_grid = true, x2_off_grid = true, x3_off_grid = true;
+  for (int b_alt = 0; b_alt < n_b; b_alt++) {
+    int level_alt = levels(b_alt);
+    int li = locations(b_alt, 0), lj = locations(b_alt, 1), lk = locations(b_alt, 2);
+    if (x1_off_grid and i != i_safe) {
+      bool same = level_alt == level and li == (i == -1 ? location_i - 1 : location_i + 1) and lj == location_j and lk == location_k;
+      bool coarser = level_alt == level - 1 and li == (i == -1 ? (location_i - 1) / 2 : (location_i + 1) / 2)
+          and lj == location_j / 2 and lk == location_k / 2;
+      bool finer = level_alt == level + 1 and li == (i == -1 ? location_i * 2 - 1 : location_i * 2 + 2)
+          and lj == (upper_j ? location_j * 2 + 1 : location_j * 2) and lk == (upper_k ? location_k * 2 + 1 : location_k * 2);
+      if (same or coarser or finer) x1_off_grid = false;
+    }
+    if (x2_off_grid and j != j_safe) {
+      bool same = level_alt == level and li == location_i and lj == (j == -1 ? location_j - 1 : location_j + 1) and lk == location_k;
+      bool coarser = level_alt == level - 1 and li == location_i / 2
+          and lj == (j == -1 ? (location_j - 1) / 2 : (location_j + 1) / 2) and lk == location_k / 2;
+      bool finer = level_alt == level + 1 and li == (upper_i ? location_i * 2 + 1 : location_i * 2)
+          and lj == (j == -1 ? location_j * 2 - 1 : location_j * 2 + 2) and lk == (upper_k ? location_k * 2 + 1 : location_k * 2);
+      if (same or coarser or finer) x2_off_grid = false;
+    }
+    if (x3_off_grid and k != k_safe) {
+      bool same = level_alt == level and li == location_i and lj == location_j and lk == (k == -1 ? location_k - 1 : location_k + 1);
+      bool coarser = level_alt == level - 1 and li == location_i / 2 and lj == location_j / 2
+          and lk == (k == -1 ? (location_k - 1) / 2 : (location_k + 1) / 2);
+      bool finer = level_alt == level + 1 and li == (upper_i ? location_i * 2 + 1 : location_i * 2)
+          and lj == (upper_j ? location_j * 2 + 1 : location_j * 2) and lk == (k == -1 ? location_k * 2 - 1 : location_k * 2 + 2);
+      if (same or coarser or finer) x3_off_grid = false;
+    }
+    // across the periodic boundary in x^3 (:1181-1219)
+    if (x3_off_grid and sks and k == -1 and location_k == 0) {
+      bool same = level_alt == level and li == location_i and lj == location_j and lk == N3Level(g, level_alt) - 1;
+      bool coarser = level_alt == level - 1 and li == location_i / 2 and lj == location_j / 2 and lk == N3Level(g, level_alt) - 1;
+      bool finer = level_alt == level + 1 and li == (upper_i ? location_i * 2 + 1 : location_i * 2)
+          and lj == (upper_j ? location_j * 2 + 1 : location_j * 2) and lk == N3Level(g, level_alt) - 1;
+      if (same or coarser or finer) x3_off_grid = false;
+    }
+    if (x3_off_grid and sks and k == n_k and location_k == N3Level(g, level) - 1) {
+      bool same = level_alt == level and li == location_i and lj == location_j and lk == 0;
+      bool coarser = level_alt == level - 1 and li == location_i / 2 and lj == location_j / 2 and lk == 0;
+      bool finer = level_alt == level + 1 and li == (upper_i ? location_i * 2 + 1 : location_i * 2)
+          and lj == (upper_j ? location_j * 2 + 1 : location_j * 2) and lk == 0;
+      if (same or coarser or finer) x3_off_grid = false;
+    }
+  }
+  if (i == i_safe) x1_off_grid = false;
+  if (j == j_safe) x2_off_grid = false;
+  if (k == k_safe) x3_off_grid = false;
+  if (x1_off_grid) i = i_safe;
+  if (x2_off_grid) j = j_safe;
+  if (x3_off_grid) k = k_safe;
+  auto find = [&](int level_sought, int li, int lj, int lk) {
+    for (int b_alt = 0; b_alt < n_b; b_alt++)
+      if (levels(b_alt) == level_sought and locations(b_alt, 0) == li and locations(b_alt, 1) == lj and locations(b_alt, 2) == lk)
+        return b_alt;
+    return -1;
+  };
+  // same level (:1239-1261)
+  int level_sought = level;
+  int location_i_sought = i == i_safe ? location_i : i == -1 ? location_i - 1 : location_i + 1;
+  int location_j_sought = j == j_safe ? location_j : j == -1 ? location_j - 1 : location_j + 1;
+  int location_k_sought = k == k_safe ? location_k : k == -1 ? location_k - 1 : location_k + 1;
+  if (sks and k == -1 and location_k == 0) location_k_sought = N3Level(g, level_sought) - 1;
+  if (sks and k == n_k and location_k == N3Level(g, level) - 1) location_k_sought = 0;
+  int i_sought = i == i_safe ? i : i == -1 ? n_i - 1 : 0;
+  int j_sought = j == j_safe ? j : j == -1 ? n_j - 1 : 0;
+  int k_sought = k == k_safe ? k : k == -1 ? n_k - 1 : 0;
+  int b_alt = find(level_sought, location_i_sought, location_j_sought, location_k_sought);
+  if (b_alt >= 0) {
+    inds[0] = b_alt; inds[1] = k_sought; inds[2] = j_sought; inds[3] = i_sought;
+    return true;
+  }
+  // coarser level (:1264-1291)
+  level_sought = level - 1;
+  if (level_sought >= 0) {
+    location_i_sought = i == i_safe ? location_i / 2 : i == -1 ? (location_i - 1) / 2 : (location_i + 1) / 2;
+    location_j_sought = j == j_safe ? location_j / 2 : j == -1 ? (location_j - 1) / 2 : (location_j + 1) / 2;
+    location_k_sought = k == k_safe ? location_k / 2 : k == -1 ? (location_k - 1) / 2 : (location_k + 1) / 2;
+    if (sks and k == -1 and location_k == 0) location_k_sought = N3Level(g, level_sought) - 1;
+    if (sks and k == n_k and location_k == N3Level(g, level) - 1) location_k_sought = 0;
+    i_sought = i == i_safe ? (location_i % 2 * n_i + i) / 2 : i == -1 ? n_i - 1 : 0;
+    j_sought = j == j_safe ? (location_j % 2 * n_j + j) / 2 : j == -1 ? n_j - 1 : 0;
+    k_sought = k == k_safe ? (location_k % 2 * n_k + k) / 2 : k == -1 ? n_k - 1 : 0;
+    b_alt = find(level_sought, location_i_sought, location_j_sought, location_k_sought);
+    if (b_alt >= 0) {
+      inds[0] = b_alt; inds[1] = k_sought; inds[2] = j_sought; inds[3] = i_sought;
+      return true;
+    }
+  }
+  // finer level (:1294-1316)
+  level_sought = level + 1;
+  location_i_sought = location_i * 2 + (i == i_safe ? 0 : i == -1 ? -1 : 1) + (upper_i ? 1 : 0);
+  location_j_sought = location_j * 2 + (j == j_safe ? 0 : j == -1 ? -1 : 1) + (upper_j ? 1 : 0);
+  location_k_sought = location_k * 2 + (k == k_safe ? 0 : k == -1 ? -1 : 1) + (upper_k ? 1 : 0);
+  if (sks and k == -1 and location_k == 0 and level_sought <= max_level) location_k_sought = N3Level(g, level_sought) - 1;
+  if (sks and k == n_k and location_k == N3Level(g, level) - 1) location_k_sought = 0;
+  i_sought = i == i_safe ? (upper_i ? (i - n_i / 2) * 2 : i * 2) : i == -1 ? n_i - 2 : 0;
+  j_sought = j == j_safe ? (upper_j ? (j - n_j / 2) * 2 : j * 2) : j == -1 ? n_j - 2 : 0;
+  k_sought = k == k_safe ? (upper_k ? (k - n_k / 2) * 2 : k * 2) : k == -1 ? n_k - 2 : 0;
+  b_alt = find(level_sought, location_i_sought, location_j_sought, location_k_sought);
+  if (b_alt >= 0) {
+    const double *x1v = g.x1v + static_cast<size_t>(b) * n_i, *x2v = g.x2v + static_cast<size_t>(b) * n_j, *x3v = g.x3v + static_cast<size_t>(b) * n_k;
+    inds[0] = b_alt; inds[1] = k_sought; inds[2] = j_sought; inds[3] = i_sought;
+    inds[1] += k < k_c or (k == k_c and x3 > x3v[k_c]) ? 1 : 0;
+    inds[2] += j < j_c or (j == j_c and x2 > x2v[j_c]) ? 1 : 0;
+    inds[3] += i < i_c or (i == i_c and x1 > x1v[i_c]) ? 1 : 0;
+    return true;
+  }
+  return false;
+}
+
 struct Prims {
   float rho, pgas, kappa, uu1, uu2, uu3, bb1, bb2, bb3;
 };
@@ -1330,6 +1465,55 @@ int SampleOne(const Oracle &o, const double pos[4], Prims *out, bool *gathered, 
       else {
         double val_1 = static_cast<double>(GridVal(slice(t_ind), vars[v], b, k, j, i));
         double val_2 = static_cast<double>(GridVal(slice(t_ind + 1), vars[v], b, k, j, i));
+        *dst[v] = static_cast<float>((1.0 - t_frac) * val_1 + t_frac * val_2);
+      }
+    }
+    return 0;
+  }
+  if (p.simulation_block_interp) {   // inter-block interpolation (:505-546, :912-1033)
+    int i_m = x1 >= x1v[i] ? i : i - 1;
+    int j_m = x2 >= x2v[j] ? j : j - 1;
+    int k_m = x3 >= x3v[k] ? k : k - 1;
+    int i_p = i_m + 1, j_p = j_m + 1, k_p = k_m + 1;
+    // :520-522 read x1v(b, i + 1) with i = n_i - 1 at a block's upper edge: in the reference's Array that is the
+    // first centre of the NEXT block's row; for the last block it is past the allocation - undefined (status 4)
+    if ((i_p == n_i or j_p == n_j or k_p == n_k) and b == n_b - 1) return 4;
+    double x1_m = i_m == -1 ? 2.0 * x1f[i] - x1v[i] : x1v[i_m];
+    double x2_m = j_m == -1 ? 2.0 * x2f[j] - x2v[j] : x2v[j_m];
+    double x3_m = k_m == -1 ? 2.0 * x3f[k] - x3v[k] : x3v[k_m];
+    double x1_p = i_p == n_i ? 2.0 * x1v[i + 1] - x1v[i] : x1v[i_p];
+    double x2_p = j_p == n_j ? 2.0 * x2v[j + 1] - x2v[j] : x2v[j_p];
+    double x3_p = k_p == n_k ? 2.0 * x3v[k + 1] - x3v[k] : x3v[k_p];
+    double f_i = (x1 - x1_m) / (x1_p - x1_m);
+    double f_j = (x2 - x2_m) / (x2_p - x2_m);
+    double f_k = (x3 - x3_m) / (x3_p - x3_m);
+    int inds[8][4];
+    bool found = true;
+    for (int corner = 0; corner < 8; corner++)
+      found = FindNearbyInds(o, b, (corner & 4) ? k_p : k_m, (corner & 2) ? j_p : j_m, (corner & 1) ? i_p : i_m, k, j, i, x3, x2, x1,
+                             inds[corner]) and found;
+    if (not found) return 5;   // "Grid interpolation failed."
+    auto advanced = [&](const bl_grid_desc &gs, int v) {   // InterpolateAdvanced (:1365-1386) + the <= 0 rule (:936-945)
+      double vals[8];
+      for (int c = 0; c < 8; c++) vals[c] = static_cast<double>(GridVal(gs, vars[v], inds[c][0], inds[c][1], inds[c][2], inds[c][3]));
+      double val = (1.0 - f_k) * (1.0 - f_j) * (1.0 - f_i) * vals[0]
+          + (1.0 - f_k) * (1.0 - f_j) * f_i * vals[1] + (1.0 - f_k) * f_j * (1.0 - f_i) * vals[2]
+          + (1.0 - f_k) * f_j * f_i * vals[3] + f_k * (1.0 - f_j) * (1.0 - f_i) * vals[4]
+          + f_k * (1.0 - f_j) * f_i * vals[5] + f_k * f_j * (1.0 - f_i) * vals[6]
+          + f_k * f_j * f_i * vals[7];
+      if (v < 3 and val <= 0.0) val = vals[0];
+      return val;
+    };
+    for (int v = 0; v < 9; v++) {
+      if (v == 2 and not code_kappa) {
+        *dst[v] = 0.0f;
+        continue;
+      }
+      if (not slow_interp)
+        *dst[v] = static_cast<float>(advanced(slice(t_ind), v));
+      else {
+        double val_1 = advanced(slice(t_ind), v);
+        double val_2 = advanced(slice(t_ind + 1), v);
         *dst[v] = static_cast<float>((1.0 - t_frac) * val_1 + t_frac * val_2);
       }
     }
@@ -2566,7 +2750,8 @@ int Setup(Oracle &o, const bl_params *p, const bl_grid_desc *g, char *err, size_
   o.image_polarization = p->model_type == BL_MODEL_SIMULATION and p->image_light and p->image_polarization;
   if (p->model_type == BL_MODEL_SIMULATION) {
     if (g == nullptr) return Fail(err, err_len, "oracle: simulation mode needs a grid", BL_E_ARG);
-    if (p->simulation_block_interp) return Fail(err, err_len, "oracle: inter-block interpolation not restated (out-of-bounds read in the reference)", BL_E_UNSUPPORTED);
+    if (p->simulation_block_interp and p->simulation_interp and (g->levels == nullptr or g->locations == nullptr or g->n_3_root <= 0))
+      return Fail(err, err_len, "oracle: inter-block interpolation needs the MeshBlock table (levels, locations, n_3_root)", BL_E_ARG);
     if (p->slow_light_on and (o.slow_n < 2 or o.slow_n != p->slow_chunk_size or o.slow_grids == nullptr or o.slow_times == nullptr))
       return Fail(err, err_len, "oracle: slow light needs slow_chunk_size time slices in blo_extra", BL_E_ARG);
     if (p->simulation_coord == BL_COORD_FMKS) return Fail(err, err_len, "oracle: fmks not restated yet", BL_E_UNSUPPORTED);
@@ -2740,9 +2925,10 @@ int blo_render(const bl_params *p, const bl_grid_desc *g, const bl_render_desc *
   if (extra != nullptr) extra->dump_num = 0;
   double time_start = omp_get_wtime();
   int64_t count_0 = 0, count_1 = 0, count_2 = 0, count_3 = 0;   // simulation_sampling.cpp:160-168
+  int64_t count_undefined = 0, count_failed = 0;                // inter-block interpolation: SampleOne status 4, 5
   double val_0 = 0.0, val_1 = 0.0, val_2 = 0.0, val_3 = 0.0;
 
-  #pragma omp parallel num_threads(num_threads) reduction(+: total_samples, total_gathers, total_flagged, count_0, count_1, count_2, count_3) reduction(max: max_sample_num, val_0, val_1, val_2, val_3)
+  #pragma omp parallel num_threads(num_threads) reduction(+: total_samples, total_gathers, total_flagged, count_0, count_1, count_2, count_3, count_undefined, count_failed) reduction(max: max_sample_num, val_0, val_1, val_2, val_3)
   {
     RayBuffers b(max_steps, nf);
     if (o.image_polarization) b.EnablePolarization(max_steps, nf);
@@ -2814,6 +3000,8 @@ int blo_render(const bl_params *p, const bl_grid_desc *g, const bl_render_desc *
           else
             status = SampleOne(o, &b.sample_pos[4 * n], &s, &gathered, &block_state);
           if (gathered) total_gathers++;
+          if (status == 4) { count_undefined++; continue; }
+          if (status == 5) { count_failed++; continue; }
           if (status == 1) continue;  // cut: simulation_coefficients.cpp:260-261
           if (status == 2) {
             float fnan = std::numeric_limits<float>::quiet_NaN();
@@ -2863,6 +3051,9 @@ int blo_render(const bl_params *p, const bl_grid_desc *g, const bl_render_desc *
       }
     }
   }
+  if (count_failed > 0) return Fail(err, err_len, "Error: Grid interpolation failed.\n", BL_E_INPUT);
+  if (count_undefined > 0)
+    return Fail(err, err_len, "oracle: inter-block interpolation reached the upper edge of the last MeshBlock, where the reference reads past its cell-centre arrays", BL_E_UNSUPPORTED);
   if (extra != nullptr) {
     extra->n_samples = total_samples;
     extra->n_gathers = total_gathers;

@@ -11,7 +11,7 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 CASES = sorted(f[:-4] for f in os.listdir(GOLDEN_DIR)
                if f.endswith(".npz") and not f.startswith(("mock_", "window_", "slow_")))
 # cases whose parameters are inside the scope of the HIP path today
-GPU_CASES = list(CASES)
+GPU_CASES = [c for c in CASES if "blockinterp" not in c]   # TEMPORARY until the device path of a15 lands
 
 FRAME_KEYS = ("cam_x", "u_con", "u_cov", "norm_con", "norm_con_c", "hor_con_c", "vert_con_c")
 
@@ -32,6 +32,7 @@ def golden_grid(mock_args):
     blocks = mock_args.pop("_blocks", None)
     entropy = mock_args.pop("_entropy", None)
     refined = mock_args.pop("_refined", None)
+    last = mock_args.pop("_last", None)   # block to move to the end of the list: see move_last
     assert json.loads(str(fx["mock_args"])) == mock_args
     prim = np.ascontiguousarray(fx["prim"], dtype=np.float32)
 
@@ -44,11 +45,29 @@ def golden_grid(mock_args):
         from blacklight_amd.mock import with_entropy
         grid = with_entropy(grid)
     if refined:
-        return refined_grid(grid)
-    return split_grid(grid, *blocks) if blocks is not None else grid
+        return refined_grid(grid, last)
+    return split_grid(grid, *blocks, last=last) if blocks is not None else single_block_table(grid)
 
 
-def split_grid(grid, nbi, nbj, nbk):
+def single_block_table(grid):
+    import dataclasses
+    return dataclasses.replace(grid, levels=np.zeros(1, dtype=np.int32), locations=np.zeros((1, 3), dtype=np.int32),
+                               n_3_root=int(grid.prim.shape[2]))
+
+
+def move_last(blocks, last, key):
+    """Put the block for which key(block) == tuple(last) at the end of the list. With inter-block interpolation the
+    reference reads one element past a block's cell-centre rows at its upper edges - the first element of the next
+    block's row, or, for the last block of the file, whatever follows the array - so the goldens for it keep a block
+    the rays never reach in last place (tools/make_goldens.py applies the same move)."""
+    if last is None:
+        return blocks
+    at = [n for n, b in enumerate(blocks) if key(b) == tuple(last)]
+    assert len(at) == 1
+    return blocks[:at[0]] + blocks[at[0] + 1:] + [blocks[at[0]]]
+
+
+def split_grid(grid, nbi, nbj, nbk, last=None):
     """The single-block grid as nbi x nbj x nbk equal blocks in the scrambled order that
     tools/make_goldens.py split_into_blocks wrote for the reference (same permutation)."""
     from blacklight_amd.mock import Grid
@@ -56,7 +75,7 @@ def split_grid(grid, nbi, nbj, nbk):
     ni, nj, nk = n_i // nbi, n_j // nbj, n_k // nbk
     blocks = [(bk, bj, bi) for bk in range(nbk) for bj in range(nbj) for bi in range(nbi)]
     order = np.random.default_rng(3).permutation(len(blocks))
-    blocks = [blocks[o] for o in order]
+    blocks = move_last([blocks[o] for o in order], last, lambda b: (b[2], b[1], b[0]))   # last = (bi, bj, bk)
     prim = np.empty((n_var, len(blocks), nk, nj, ni), dtype=np.float32)
     for n, (bk, bj, bi) in enumerate(blocks):
         prim[:, n] = grid.prim[:, 0, bk * nk:(bk + 1) * nk, bj * nj:(bj + 1) * nj, bi * ni:(bi + 1) * ni]
@@ -66,13 +85,14 @@ def split_grid(grid, nbi, nbj, nbk):
 
     return Grid(prim=prim, x1f=cut(grid.x1f, ni, 2, 1), x2f=cut(grid.x2f, nj, 1, 1), x3f=cut(grid.x3f, nk, 0, 1),
                 x1v=cut(grid.x1v, ni, 2, 0), x2v=cut(grid.x2v, nj, 1, 0), x3v=cut(grid.x3v, nk, 0, 0),
-                ind_kappa=grid.ind_kappa)
+                ind_kappa=grid.ind_kappa, levels=np.zeros(len(blocks), dtype=np.int32),
+                locations=np.ascontiguousarray([(bi, bj, bk) for bk, bj, bi in blocks], dtype=np.int32), n_3_root=int(n_k))
 
 
 REFINED_BLOCK = (8, 6, 8)   # cells per block (i, j, k) of the refined version of the 32 x 24 x 32 mock
 
 
-def refined_blocks(prim, xf, xv):
+def refined_blocks(prim, xf, xv, last=None):
     """A two-level mesh from one block of data: prim [n_var][n_k][n_j][n_i] float32, xf / xv = three float32
     face / centre rows. The domain is cut into 2 x 2 x 2 octants; octants with an odd index sum become one
     coarse block each (level 0: pairwise averages of the fine cells in single precision, every second face),
@@ -105,7 +125,7 @@ def refined_blocks(prim, xf, xv):
                                 loc = (2 * oi + fi, 2 * oj + fj, 2 * ok + fk)
                                 blocks.append((1, loc, prim, xf, xv, (loc[0] * bi, loc[1] * bj, loc[2] * bk)))
     order = np.random.default_rng(5).permutation(len(blocks))
-    blocks = [blocks[o] for o in order]
+    blocks = move_last([blocks[o] for o in order], last, lambda b: (b[0],) + tuple(b[1]))   # last = (level, li, lj, lk)
     n_b = len(blocks)
     out = dict(prim=np.empty((n_var, n_b, bk, bj, bi), dtype=f32), levels=np.empty(n_b, dtype=np.int32),
                locations=np.empty((n_b, 3), dtype=np.int64))
@@ -121,16 +141,18 @@ def refined_blocks(prim, xf, xv):
     return out
 
 
-def refined_grid(grid):
+def refined_grid(grid, last=None):
     """The single-block Grid as the two-level mesh of refined_blocks()."""
     from blacklight_amd.mock import Grid
-    blocks = refined_blocks(grid.prim[:, 0], [grid.x1f[0], grid.x2f[0], grid.x3f[0]], [grid.x1v[0], grid.x2v[0], grid.x3v[0]])
+    blocks = refined_blocks(grid.prim[:, 0], [grid.x1f[0], grid.x2f[0], grid.x3f[0]], [grid.x1v[0], grid.x2v[0], grid.x3v[0]], last)
 
     def row(name):
         return np.ascontiguousarray(blocks[name].astype(np.float64))
 
     return Grid(prim=np.ascontiguousarray(blocks["prim"]), x1f=row("x1f"), x2f=row("x2f"), x3f=row("x3f"),
-                x1v=row("x1v"), x2v=row("x2v"), x3v=row("x3v"), ind_kappa=grid.ind_kappa)
+                x1v=row("x1v"), x2v=row("x2v"), x3v=row("x3v"), ind_kappa=grid.ind_kappa,
+                levels=np.ascontiguousarray(blocks["levels"], dtype=np.int32),
+                locations=np.ascontiguousarray(blocks["locations"], dtype=np.int32), n_3_root=2 * REFINED_BLOCK[2])
 
 
 SLOW_CASES = ["slow_interp", "slow_nearest"]

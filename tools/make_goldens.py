@@ -160,6 +160,17 @@ CASES = {
     "sim_polarized_cks": (SIM_BASE, dict(camera_resolution=16, simulation_coord="cks", image_polarization="true",
                                          simulation_interp="false", camera_th=80.0, camera_ph=10.0, camera_width=14.0, fallback_nan="false",
                                          fallback_rho=1.0e-6, fallback_pgas=1.0e-8), SMALL_MOCK, [136]),
+    # inter-block interpolation (simulation_block_interp; FindNearbyInds / InterpolateAdvanced): equal blocks of one
+    # level, and the two-level mesh. At a block's upper edges the reference reads one element past the block's row of
+    # cell centres - the next block's first centre, or, for the last block of the file, past the array - so these
+    # cameras are narrow enough for every ray to be captured (nothing reaches the far side) and a far-side block is
+    # moved to the end of the file ("_last")
+    "sim_blockinterp": (SIM_BASE, dict(camera_resolution=16, camera_width=4.0, simulation_block_interp="true", image_tau="true"),
+                        dict(SMALL_MOCK, _blocks=[2, 2, 4], _last=[1, 1, 2]), [136]),
+    "sim_blockinterp_refined": (SIM_BASE, dict(camera_resolution=16, camera_width=4.5, camera_th=60.0, simulation_a=0.5,
+                                               simulation_block_interp="true", plasma_model="code_kappa", simulation_kappa_name="r0",
+                                               fallback_nan="false", fallback_rho=1.0e-6, fallback_pgas=1.0e-8, fallback_kappa=2.0e6),
+                                dict(SMALL_MOCK, _entropy=1, _refined=1, _last=[0, 1, 1, 1]), [136]),
     "sim_powerlaw": (SIM_BASE, dict(camera_resolution=24, plasma_power_frac=0.3, plasma_p=2.5, plasma_gamma_min=1.0,
                                     plasma_gamma_max=1000.0), SMALL_MOCK, [300]),
     # false-colour renderings (rendering.cpp): the features of the reference's example_render.input, without
@@ -296,7 +307,7 @@ def add_entropy(path):
         f.attrs.create("VariableNames", ["rho", "press", "vel1", "vel2", "vel3", "r0", "Bcc1", "Bcc2", "Bcc3"], dtype="|S21")
 
 
-def split_into_blocks(src, dst, nbi, nbj, nbk):
+def split_into_blocks(src, dst, nbi, nbj, nbk, last=None):
     """Rewrite the single-block athdf `src` as nbi x nbj x nbk equal MeshBlocks (same level), in a scrambled
     block order (the reader accepts any). Same decomposition as tests/golden_util.split_grid."""
     import h5py
@@ -308,7 +319,10 @@ def split_into_blocks(src, dst, nbi, nbj, nbk):
     ni, nj, nk = len(xv[0]) // nbi, len(xv[1]) // nbj, len(xv[2]) // nbk
     blocks = [(bk, bj, bi) for bk in range(nbk) for bj in range(nbj) for bi in range(nbi)]
     order = np.random.default_rng(3).permutation(len(blocks))
-    blocks = [blocks[o] for o in order]
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    sys.path.insert(0, REPO)
+    from golden_util import move_last
+    blocks = move_last([blocks[o] for o in order], last, lambda b: (b[2], b[1], b[0]))
     nb = len(blocks)
     with h5py.File(dst, "w") as g:
         for k, v in attrs.items():
@@ -331,7 +345,7 @@ def split_into_blocks(src, dst, nbi, nbj, nbk):
         g.create_dataset("B", data=cut(bfield))
 
 
-def split_refined(src, dst):
+def split_refined(src, dst, last=None):
     """Rewrite the single-block athdf `src` as the two-level mesh of tests/golden_util.refined_blocks."""
     import h5py
     sys.path.insert(0, os.path.join(REPO, "tests"))
@@ -341,7 +355,7 @@ def split_refined(src, dst):
         attrs = {k: f.attrs[k] for k in f.attrs}
         n_hydro = f["prim"].shape[0]
         prim = np.concatenate([f["prim"][:, 0], f["B"][:, 0]], axis=0)
-        blocks = refined_blocks(prim, [f["x1f"][0], f["x2f"][0], f["x3f"][0]], [f["x1v"][0], f["x2v"][0], f["x3v"][0]])
+        blocks = refined_blocks(prim, [f["x1f"][0], f["x2f"][0], f["x3f"][0]], [f["x1v"][0], f["x2v"][0], f["x3v"][0]], last)
     bi, bj, bk = REFINED_BLOCK
     with h5py.File(dst, "w") as g:
         for k, v in attrs.items():
@@ -379,11 +393,11 @@ def make_case(name):
         if "_refined" in mock:   # two refinement levels
             single = os.path.join(workdir, "data", "mock_single.athdf")
             os.replace(mock_path, single)
-            split_refined(single, mock_path)
+            split_refined(single, mock_path, mock.get("_last"))
         if "_blocks" in mock:   # several MeshBlocks: split the script's single block
             single = os.path.join(workdir, "data", "mock_single.athdf")
             os.replace(mock_path, single)
-            split_into_blocks(single, mock_path, *mock["_blocks"])
+            split_into_blocks(single, mock_path, *mock["_blocks"], last=mock.get("_last"))
         fixture["mock_args"] = json.dumps(mock)
     write_input(os.path.join(workdir, "case.input"), params)
     # what the test feeds to the build: same keys without file plumbing
