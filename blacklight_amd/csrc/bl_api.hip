@@ -104,6 +104,8 @@ struct bl_ctx {
   DeviceBuffer<float> d_kappa;   // electron entropy per cell (plasma_model = code_kappa)
   DeviceBuffer<double> d_coords;   // x1f x1v x2f x2v x3f x3v packed
   DeviceBuffer<int> d_buckets;
+  DeviceBuffer<int> d_block_table;                  // inter-block interpolation: levels, locations, hash blocks
+  DeviceBuffer<unsigned long long> d_block_keys;    // ... and hash keys
   BlGridDevice grid_dev{};
   int lds_table_bytes = 0;
   DeviceBuffer<float> *cells_target = nullptr, *kappa_target = nullptr;   // where the grid upload puts the cells
@@ -139,9 +141,10 @@ struct bl_ctx {
     DeviceBuffer<double> d_slow_frac;              // slow light: t_frac of every located sample
     DeviceBuffer<BlPolSample> d_pol_samples;       // polarized transfer
     DeviceBuffer<double2> d_pol_coeffs;
+    DeviceBuffer<unsigned int> d_anchors;          // inter-block interpolation: eight anchor cells per record
     DeviceBuffer<BlCoefInputs> d_coef_inputs;      // polarized runs: coefficient kernel -> polarized coefficient kernel
     void Free() {
-      d_aux.Free(); d_sample_t.Free(); d_slow_frac.Free(); d_pol_samples.Free(); d_pol_coeffs.Free(); d_coef_inputs.Free();
+      d_aux.Free(); d_sample_t.Free(); d_slow_frac.Free(); d_pol_samples.Free(); d_pol_coeffs.Free(); d_coef_inputs.Free(); d_anchors.Free();
       d_records.Free(); d_located.Free(); d_transfer.Free(); d_ray_kt.Free(); d_ray_factor.Free();
       d_ray_sample_num.Free(); d_ray_flags.Free(); d_ray_out_index.Free(); d_counters.Free();
     }
@@ -296,8 +299,8 @@ void ValidateRadiation(bl_ctx *ctx) {
             kRadMissing);
     if ((p.simulation_format == BL_SIMFMT_ATHENA || p.simulation_format == BL_SIMFMT_ATHENAK) && p.simulation_interp) {
       Require(p, {BL_P_simulation_block_interp}, kRadMissing);
-      if (p.simulation_block_interp)
-        throw Failure{BL_E_UNSUPPORTED, "simulation_block_interp = true (inter-block interpolation) is not built yet."};
+      if (p.simulation_block_interp && Has(p, BL_P_slow_light_on) && p.slow_light_on)
+        throw Failure{BL_E_UNSUPPORTED, "simulation_block_interp = true together with slow_light_on = true is not built."};
     } else if (Has(p, BL_P_simulation_block_interp)) {
       Warn(ctx, "Ignoring simulation_block_interp selection.");
     }
@@ -825,6 +828,48 @@ void UploadRefinedGrid(bl_ctx *ctx, const bl_grid_desc *g) {
     dev.n[a] = nb[a];
     dev.nb[a] = nb[a];
   }
+  if (ctx->params.simulation_interp && ctx->params.simulation_block_interp) {
+    // MeshBlock table for FindNearbyInds (simulation_sampling.cpp:36-39, :84-93) and a hash from (level, location)
+    // to block in place of its scans over all blocks
+    if (g->levels == nullptr || g->locations == nullptr || g->n_3_root <= 0)
+      throw Failure{BL_E_ARG, "simulation_block_interp = true needs the MeshBlock table (levels, locations, n_3_root) in bl_grid_desc."};
+    int max_level = 0;
+    for (int blk = 0; blk < n_b; blk++) {
+      if (g->levels[blk] < 0 || g->levels[blk] > 30) throw Failure{BL_E_ARG, "Bad MeshBlock level."};
+      max_level = std::max(max_level, g->levels[blk]);
+      for (int a = 0; a < 3; a++)
+        if (g->locations[3 * blk + a] < 0 || g->locations[3 * blk + a] >= (1 << 19)) throw Failure{BL_E_UNSUPPORTED, "MeshBlock location outside the range of this build."};
+    }
+    unsigned int slots = 16;
+    while (slots < 2u * static_cast<unsigned int>(n_b)) slots *= 2;
+    std::vector<unsigned long long> keys(slots, ~0ull);
+    std::vector<int> table(static_cast<size_t>(n_b) * 4 + slots, -1);
+    for (int blk = 0; blk < n_b; blk++) {
+      table[blk] = g->levels[blk];
+      for (int a = 0; a < 3; a++) table[n_b + 3 * blk + a] = g->locations[3 * blk + a];
+      const unsigned long long key = (static_cast<unsigned long long>(g->levels[blk]) << 57) | (static_cast<unsigned long long>(g->locations[3 * blk]) << 38)
+          | (static_cast<unsigned long long>(g->locations[3 * blk + 1]) << 19) | static_cast<unsigned long long>(g->locations[3 * blk + 2]);
+      unsigned int slot = static_cast<unsigned int>((key * 0x9e3779b97f4a7c15ull) >> 32) & (slots - 1);
+      while (keys[slot] != ~0ull) {
+        if (keys[slot] == key) throw Failure{BL_E_UNSUPPORTED, kBadMesh};   // two blocks at one place
+        slot = (slot + 1) & (slots - 1);
+      }
+      keys[slot] = key;
+      table[static_cast<size_t>(n_b) * 4 + slot] = blk;
+    }
+    ctx->d_block_table.Ensure(table.size());
+    ctx->d_block_keys.Ensure(keys.size());
+    Check(hipMemcpy(ctx->d_block_table.ptr, table.data(), table.size() * sizeof(int), hipMemcpyHostToDevice), "block table upload");
+    Check(hipMemcpy(ctx->d_block_keys.ptr, keys.data(), keys.size() * sizeof(unsigned long long), hipMemcpyHostToDevice), "block table upload");
+    dev.block_interp = 1;
+    dev.levels = ctx->d_block_table.ptr;
+    dev.locations = ctx->d_block_table.ptr + n_b;
+    dev.hash_blocks = ctx->d_block_table.ptr + static_cast<size_t>(n_b) * 4;
+    dev.hash_keys = ctx->d_block_keys.ptr;
+    dev.hash_mask = slots - 1;
+    dev.max_level = max_level;
+    dev.n_3_level0 = g->n_3_root / nb[2];
+  }
   ctx->grid_dev = dev;
   ctx->lds_table_bytes = 0;
   ctx->n_i = nb[0];
@@ -843,11 +888,15 @@ int bl_set_grid(bl_ctx *ctx, const bl_grid_desc *g) {
     if (g->n_blocks < 1) throw Failure{BL_E_ARG, "Bad grid description."};
     if (g->n_i < 2 || g->n_j < 2 || g->n_k < 2 || g->prim == nullptr) throw Failure{BL_E_ARG, "Bad grid description."};
     Check(hipSetDevice(ctx->device), "hipSetDevice");
-    try {
-      UploadMergedGrid(ctx, g);
-    } catch (const Failure &failure) {
-      if (failure.message != kIrregular) throw;
-      UploadRefinedGrid(ctx, g);   // blocks of several levels, or a tiling with holes
+    if (ctx->params.simulation_interp && ctx->params.simulation_block_interp) {
+      UploadRefinedGrid(ctx, g);   // inter-block interpolation works on the MeshBlocks as they are
+    } else {
+      try {
+        UploadMergedGrid(ctx, g);
+      } catch (const Failure &failure) {
+        if (failure.message != kIrregular) throw;
+        UploadRefinedGrid(ctx, g);   // blocks of several levels, or a tiling with holes
+      }
     }
     ctx->grid_meta = *g;
     ctx->have_grid = true;
@@ -959,12 +1008,14 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
     if (d->level > 0) level_pixels = static_cast<long long>(d->n_blocks) * p.adaptive_block_size * p.adaptive_block_size;
     if (d->pixel_map == nullptr && n_rays > level_pixels) throw Failure{BL_E_ARG, "n_rays exceeds the pixels of this level."};
 
+    const bool block_interp = simulation && ctx->grid_dev.block_interp != 0;
     // chunk size from the scratch budget: per ray max_steps * (64 B record + 48 B located sample
     // (simulation mode) + 16 B * n_nu transfer)
     const uint64_t per_ray = static_cast<uint64_t>(max_steps)
         * (sizeof(BlSampleRecord) + (simulation ? sizeof(BlLocated) : 0) + sizeof(double2) * n_nu
            + (aux ? sizeof(BlAuxSample) + sizeof(double) : 0) + (slow ? 2 * sizeof(double) : 0)
-           + (ctx->polarized ? sizeof(BlPolSample) + sizeof(BlCoefInputs) + 3 * sizeof(double2) * n_nu : 0)) + 64;
+           + (ctx->polarized ? sizeof(BlPolSample) + sizeof(BlCoefInputs) + 3 * sizeof(double2) * n_nu : 0)
+           + (block_interp ? 8 * sizeof(unsigned int) : 0)) + 64;
     // One chunk if the whole call fits the budget. With bl_set_overlap(): two scratch sets of half the budget
     // each, so that the geodesic kernel of chunk c + 1 runs while chunk c is being shaded.
     // The budget is also capped by what the device can actually give: 90 % of (free memory + the scratch
@@ -979,7 +1030,7 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
               + sl.d_transfer.count * sizeof(double2) + sl.d_aux.count * sizeof(BlAuxSample)
               + (sl.d_sample_t.count + sl.d_slow_frac.count) * sizeof(double)
               + sl.d_pol_samples.count * sizeof(BlPolSample) + sl.d_pol_coeffs.count * sizeof(double2)
-              + sl.d_coef_inputs.count * sizeof(BlCoefInputs);
+              + sl.d_coef_inputs.count * sizeof(BlCoefInputs) + sl.d_anchors.count * sizeof(unsigned int);
         const uint64_t available = static_cast<uint64_t>(0.9 * static_cast<double>(free_bytes + held));
         if (available < budget) budget = available;
       }
@@ -1014,6 +1065,7 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
         sl.d_pol_coeffs.Ensure(static_cast<size_t>(chunk) * max_steps * n_nu * 3);
         sl.d_coef_inputs.Ensure(record_capacity);
       }
+      if (block_interp) sl.d_anchors.Ensure(record_capacity * 8);
     }
     EnsureChunkResources(ctx, n_chunks);
     ctx->d_freq.Ensure(n_nu);
@@ -1425,6 +1477,7 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
         xa.pol_samples = sl.d_pol_samples.ptr;
         xa.pol_coeffs = sl.d_pol_coeffs.ptr;
       }
+      sa.anchors = block_interp ? sl.d_anchors.ptr : nullptr;
       if (slow) {
         sa.slow.frac = sl.d_slow_frac.ptr;
         sa.slow.ray_extrap = ctx->d_ray_extrap.ptr + begin;
@@ -1470,6 +1523,10 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
       Check(hipEventElapsedTime(&ms, e[3], e[4]), "event time"); ms_shade += ms;
       Check(hipEventElapsedTime(&ms, e[4], e[5]), "event time"); ms_transfer += ms;
       if (hc[BL_CNT_OVERFLOW] != 0) throw Failure{BL_E_DEVICE, "Sample record buffer overflow."};
+      if (hc[BL_CNT_INTERP_FAILED] != 0) throw Failure{BL_E_INPUT, "Grid interpolation failed."};   // simulation_sampling.cpp:1319
+      if (hc[BL_CNT_UNDEFINED] != 0)
+        throw Failure{BL_E_UNSUPPORTED, "Inter-block interpolation reached an upper edge of the last MeshBlock, where the reference reads past the end "
+                                        "of its cell-centre arrays (simulation_sampling.cpp:520-522): no defined result to reproduce."};
       total_records += hc[BL_CNT_RECORDS];
       total_gathers += hc[BL_CNT_GATHERS];
       total_samples += hc[BL_CNT_COUNT + 0];

@@ -61,6 +61,8 @@ enum BlCounter {
   BL_CNT_RECORDS = 1,       // sample records allocated
   BL_CNT_GATHERS = 2,       // samples that read the grid (S_in)
   BL_CNT_OVERFLOW = 3,      // record buffer overflow flag
+  BL_CNT_UNDEFINED = 4,     // inter-block interpolation: samples at an upper edge of the last MeshBlock
+  BL_CNT_INTERP_FAILED = 5, // inter-block interpolation: samples for which no anchor block exists
   BL_CNT_COUNT = 8
 };
 
@@ -83,6 +85,15 @@ struct BlGridDevice {
   const int *lattice;        // [n_edge[2]][n_edge[1]][n_edge[0]] -> block covering that box, -1: none
   const double *bxf[3];      // [n_blocks][nb[a] + 1] faces of every block
   const double *bxv[3];      // [n_blocks][nb[a]] centres
+  // Inter-block interpolation (simulation_block_interp; simulation_sampling.cpp:505-546, :1068-1321): the MeshBlock
+  // table and a hash from (level, location) to block - the reference scans all blocks for every such lookup
+  int block_interp;
+  const int *levels;             // [n_blocks]
+  const int *locations;          // [n_blocks][3]
+  const unsigned long long *hash_keys;   // open addressing, hash_mask + 1 slots, ~0ull = empty
+  const int *hash_blocks;
+  unsigned int hash_mask;
+  int max_level, n_3_level0;     // n_3_level(level) = n_3_level0 << level (:84-93)
 };
 
 struct BlPlasmaDevice {
@@ -262,6 +273,7 @@ struct BlShadeArgs {
   BlPolSample *pol_samples;   // [chunk_rays][ray_max_steps]
   double2 *pol_coeffs;        // [chunk_rays][ray_max_steps][n_nu][3]: (j_Q, j_V), (alpha_Q, alpha_V), (rho_Q, rho_V)
   BlCoefInputs *coef_inputs;  // [record capacity]: coefficient kernel -> polarized coefficient kernel
+  unsigned int *anchors;      // inter-block interpolation: [record capacity][8] cells of the eight anchors, else null
   double power_pol[7];        // simulation_coefficients.cpp:67-80: jj_q, jj_v, aa_q, aa_v, rho, rho_q, rho_v
   double plasma_gamma_min;
   int aux_need_coefficients;  // image_light || image_emission || image_tau || image_emission_ave || image_tau_int (:389)

@@ -685,7 +685,7 @@ struct SampleShade {
 
 // Status of a located sample (BlLocated::status)
 enum SampleStatus { kSampleNone = 0, kSampleCut = 1, kSampleOffGrid = 2, kSampleNearest = 3, kSampleInterp = 4,
-                    kSampleFormula = 5 };
+                    kSampleFormula = 5, kSampleAdvanced = 6 };
 
 __device__ __forceinline__ void unpack_cell(const float4 &lo, const float4 &hi, float v[8]) {
   v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w;
@@ -708,9 +708,124 @@ __device__ __forceinline__ int first_upper_face(const double *table, int n, doub
   return lo;
 }
 
+// ---- inter-block interpolation (simulation_block_interp = true)
+
+// Block of a refinement level at a logical location, -1: none. The reference finds it by scanning all blocks
+// (simulation_sampling.cpp:1246-1256 and alike); blocks do not overlap, so the key is unique.
+__device__ __forceinline__ unsigned long long block_key(int level, int li, int lj, int lk) {
+  return ((unsigned long long)(unsigned)level << 57) | ((unsigned long long)(unsigned)li << 38) | ((unsigned long long)(unsigned)lj << 19)
+      | (unsigned long long)(unsigned)lk;
+}
+__device__ __forceinline__ int find_block(const BlGridDevice &g, int level, int li, int lj, int lk) {
+  if (level < 0 || level > g.max_level || li < 0 || lj < 0 || lk < 0 || li >= (1 << 19) || lj >= (1 << 19) || lk >= (1 << 19)) return -1;
+  const unsigned long long key = block_key(level, li, lj, lk);
+  unsigned int slot = (unsigned int)((key * 0x9e3779b97f4a7c15ull) >> 32) & g.hash_mask;
+  while (true) {
+    const unsigned long long found = g.hash_keys[slot];
+    if (found == key) return g.hash_blocks[slot];
+    if (found == ~0ull) return -1;
+    slot = (slot + 1) & g.hash_mask;
+  }
+}
+
+// FindNearbyInds (simulation_sampling.cpp:1068-1321): the cell that stands for cell (k, j, i) of block b when an
+// index is one beyond the block. c[] = cell closest to the sample, s[] = the sample. Returns the cell's position
+// in the [block][k][j][i] array, or -1 where the reference throws "Grid interpolation failed."
+__device__ long long find_nearby(const BlGridDevice &g, bool sks, int b, int k, int j, int i, const int c[3], const double s[3]) {
+  const int n_i = g.nb[0], n_j = g.nb[1], n_k = g.nb[2];
+  const size_t block_cells = (size_t)g.nb[2] * g.stride_plane;
+  const int i_safe = max(min(i, n_i - 1), 0), j_safe = max(min(j, n_j - 1), 0), k_safe = max(min(k, n_k - 1), 0);
+  if (i == i_safe && j == j_safe && k == k_safe)
+    return (long long)(b * block_cells + (size_t)k * g.stride_plane + (size_t)j * g.stride_row + i);
+  const int level = g.levels[b];
+  const int li = g.locations[3 * b], lj = g.locations[3 * b + 1], lk = g.locations[3 * b + 2];
+  const bool upper_i = i > n_i / 2, upper_j = j > n_j / 2, upper_k = k > n_k / 2;
+  const int n3 = g.n_3_level0 << level;
+  const int fi = upper_i ? li * 2 + 1 : li * 2, fj = upper_j ? lj * 2 + 1 : lj * 2, fk = upper_k ? lk * 2 + 1 : lk * 2;
+  // does the mesh continue beyond the block in each direction (:1098-1221)?
+  bool x1_off_grid = i != i_safe, x2_off_grid = j != j_safe, x3_off_grid = k != k_safe;
+  if (x1_off_grid) {
+    const int d = i == -1 ? -1 : 1;
+    if (find_block(g, level, li + d, lj, lk) >= 0
+        || find_block(g, level - 1, i == -1 ? (li - 1) / 2 : (li + 1) / 2, lj / 2, lk / 2) >= 0
+        || find_block(g, level + 1, i == -1 ? li * 2 - 1 : li * 2 + 2, fj, fk) >= 0)
+      x1_off_grid = false;
+  }
+  if (x2_off_grid) {
+    const int d = j == -1 ? -1 : 1;
+    if (find_block(g, level, li, lj + d, lk) >= 0
+        || find_block(g, level - 1, li / 2, j == -1 ? (lj - 1) / 2 : (lj + 1) / 2, lk / 2) >= 0
+        || find_block(g, level + 1, fi, j == -1 ? lj * 2 - 1 : lj * 2 + 2, fk) >= 0)
+      x2_off_grid = false;
+  }
+  if (x3_off_grid) {
+    const int d = k == -1 ? -1 : 1;
+    if (find_block(g, level, li, lj, lk + d) >= 0
+        || find_block(g, level - 1, li / 2, lj / 2, k == -1 ? (lk - 1) / 2 : (lk + 1) / 2) >= 0
+        || find_block(g, level + 1, fi, fj, k == -1 ? lk * 2 - 1 : lk * 2 + 2) >= 0)
+      x3_off_grid = false;
+    // across the periodic boundary in x^3 (:1181-1219)
+    if (x3_off_grid && sks && k == -1 && lk == 0
+        && (find_block(g, level, li, lj, n3 - 1) >= 0 || find_block(g, level - 1, li / 2, lj / 2, (g.n_3_level0 << (level - 1)) - 1) >= 0
+            || find_block(g, level + 1, fi, fj, (g.n_3_level0 << (level + 1)) - 1) >= 0))
+      x3_off_grid = false;
+    if (x3_off_grid && sks && k == n_k && lk == n3 - 1
+        && (find_block(g, level, li, lj, 0) >= 0 || find_block(g, level - 1, li / 2, lj / 2, 0) >= 0 || find_block(g, level + 1, fi, fj, 0) >= 0))
+      x3_off_grid = false;
+  }
+  if (x1_off_grid) i = i_safe;
+  if (x2_off_grid) j = j_safe;
+  if (x3_off_grid) k = k_safe;
+  const bool wrap_low = sks && k == -1 && lk == 0, wrap_high = sks && k == n_k && lk == n3 - 1;
+  // same level (:1239-1261)
+  {
+    int lks = k == k_safe ? lk : k == -1 ? lk - 1 : lk + 1;
+    if (wrap_low) lks = n3 - 1;
+    if (wrap_high) lks = 0;
+    const int b_alt = find_block(g, level, i == i_safe ? li : i == -1 ? li - 1 : li + 1, j == j_safe ? lj : j == -1 ? lj - 1 : lj + 1, lks);
+    if (b_alt >= 0) {
+      const int is = i == i_safe ? i : i == -1 ? n_i - 1 : 0, js = j == j_safe ? j : j == -1 ? n_j - 1 : 0, ks = k == k_safe ? k : k == -1 ? n_k - 1 : 0;
+      return (long long)(b_alt * block_cells + (size_t)ks * g.stride_plane + (size_t)js * g.stride_row + is);
+    }
+  }
+  // coarser level (:1264-1291)
+  if (level - 1 >= 0) {
+    int lks = k == k_safe ? lk / 2 : k == -1 ? (lk - 1) / 2 : (lk + 1) / 2;
+    if (wrap_low) lks = (g.n_3_level0 << (level - 1)) - 1;
+    if (wrap_high) lks = 0;
+    const int b_alt = find_block(g, level - 1, i == i_safe ? li / 2 : i == -1 ? (li - 1) / 2 : (li + 1) / 2,
+                                 j == j_safe ? lj / 2 : j == -1 ? (lj - 1) / 2 : (lj + 1) / 2, lks);
+    if (b_alt >= 0) {
+      const int is = i == i_safe ? (li % 2 * n_i + i) / 2 : i == -1 ? n_i - 1 : 0;
+      const int js = j == j_safe ? (lj % 2 * n_j + j) / 2 : j == -1 ? n_j - 1 : 0;
+      const int ks = k == k_safe ? (lk % 2 * n_k + k) / 2 : k == -1 ? n_k - 1 : 0;
+      return (long long)(b_alt * block_cells + (size_t)ks * g.stride_plane + (size_t)js * g.stride_row + is);
+    }
+  }
+  // finer level (:1294-1316)
+  {
+    int lks = lk * 2 + (k == k_safe ? 0 : k == -1 ? -1 : 1) + (upper_k ? 1 : 0);
+    if (wrap_low && level + 1 <= g.max_level) lks = (g.n_3_level0 << (level + 1)) - 1;
+    if (wrap_high) lks = 0;
+    const int b_alt = find_block(g, level + 1, li * 2 + (i == i_safe ? 0 : i == -1 ? -1 : 1) + (upper_i ? 1 : 0),
+                                 lj * 2 + (j == j_safe ? 0 : j == -1 ? -1 : 1) + (upper_j ? 1 : 0), lks);
+    if (b_alt >= 0) {
+      int is = i == i_safe ? (upper_i ? (i - n_i / 2) * 2 : i * 2) : i == -1 ? n_i - 2 : 0;
+      int js = j == j_safe ? (upper_j ? (j - n_j / 2) * 2 : j * 2) : j == -1 ? n_j - 2 : 0;
+      int ks = k == k_safe ? (upper_k ? (k - n_k / 2) * 2 : k * 2) : k == -1 ? n_k - 2 : 0;
+      const double *x1v = g.bxv[0] + (size_t)b * n_i, *x2v = g.bxv[1] + (size_t)b * n_j, *x3v = g.bxv[2] + (size_t)b * n_k;
+      ks += (k < c[2] || (k == c[2] && s[2] > x3v[c[2]])) ? 1 : 0;
+      js += (j < c[1] || (j == c[1] && s[1] > x2v[c[1]])) ? 1 : 0;
+      is += (i < c[0] || (i == c[0] && s[0] > x1v[c[0]])) ? 1 : 0;
+      return (long long)(b_alt * block_cells + (size_t)ks * g.stride_plane + (size_t)js * g.stride_row + is);
+    }
+  }
+  return -1;
+}
+
 // The same on a mesh with refinement: the block from the lattice of block boundaries, then the cell inside
 // it from the block's own coordinate rows (global memory; this path is not the benchmark's).
-__device__ __forceinline__ void locate_sample_refined(const BlShadeArgs &P, double s1, double s2, double s3,
+__device__ __forceinline__ void locate_sample_refined(const BlShadeArgs &P, unsigned int *anchors, double s1, double s2, double s3,
                                                       BlLocated *out, unsigned long long *gathers) {
   const BlPlasmaDevice &pl = P.plasma;
   const BlGridDevice &g = P.grid;
@@ -746,6 +861,46 @@ __device__ __forceinline__ void locate_sample_refined(const BlShadeArgs &P, doub
   if (!pl.simulation_interp) {
     out->status = kSampleNearest;
     out->cell = (uint32_t)(block_base + (size_t)c[2] * g.stride_plane + (size_t)c[1] * g.stride_row + c[0]);
+    return;
+  }
+  if (g.block_interp) {   // inter-block interpolation (:505-546)
+    int m[3], pp[3];
+    double f[3];
+    bool undefined = false;
+    for (int a = 0; a < 3; a++) {
+      const int n = g.nb[a], i = c[a];
+      const double *xf = g.bxf[a] + (size_t)b * (n + 1);
+      m[a] = s[a] >= xv[a][i] ? i : i - 1;
+      pp[a] = m[a] + 1;
+      // :520-522 read x1v(b, i + 1) at a block's upper edge: the next block's first centre in the reference's
+      // Array (xv[a][i + 1] here as well: rows are contiguous); past the array for the last block - undefined
+      if (pp[a] == n && b == g.n_blocks - 1) undefined = true;
+      const double x_m = m[a] == -1 ? 2.0 * xf[i] - xv[a][i] : xv[a][m[a]];
+      const double x_p = (pp[a] == n) ? (undefined ? 0.0 : 2.0 * xv[a][i + 1] - xv[a][i]) : xv[a][pp[a]];
+      f[a] = (s[a] - x_m) / (x_p - x_m);
+    }
+    if (undefined) {
+      atomicAdd(&P.counters[BL_CNT_UNDEFINED], 1ull);
+      out->status = kSampleCut;
+      return;
+    }
+    const bool sks = pl.simulation_coord == BL_COORD_SKS;
+    bool failed = false;
+    for (int corner = 0; corner < 8; corner++) {
+      const long long cell = find_nearby(g, sks, b, (corner & 4) ? pp[2] : m[2], (corner & 2) ? pp[1] : m[1], (corner & 1) ? pp[0] : m[0], c, s);
+      failed = failed || cell < 0;
+      anchors[corner] = (unsigned int)cell;
+    }
+    if (failed) {
+      atomicAdd(&P.counters[BL_CNT_INTERP_FAILED], 1ull);
+      out->status = kSampleCut;
+      return;
+    }
+    out->f_i = f[0];
+    out->f_j = f[1];
+    out->f_k = f[2];
+    out->status = kSampleAdvanced;
+    out->cell = anchors[0];
     return;
   }
   int m[3];
@@ -807,7 +962,7 @@ __device__ __forceinline__ int locate_time(const BlSlowDevice &sl, double x0, ui
 template <bool kRefined>
 __device__ __forceinline__ void locate_sample(const BlShadeArgs &P, const GridTables &tab, const BlSpacetime &st,
                                               double x1, double x2, double x3, double r, BlLocated *out,
-                                              unsigned long long *gathers) {
+                                              unsigned long long *gathers, unsigned int *anchors) {
   const BlPlasmaDevice &pl = P.plasma;
   const BlGridDevice &g = P.grid;
   const bool sks = pl.simulation_coord == BL_COORD_SKS;
@@ -827,7 +982,7 @@ __device__ __forceinline__ void locate_sample(const BlShadeArgs &P, const GridTa
     s3 = ph;
   }
   if (kRefined) {
-    locate_sample_refined(P, s1, s2, s3, out, gathers);
+    locate_sample_refined(P, anchors, s1, s2, s3, out, gathers);
     return;
   }
   const int n_i = g.n[0], n_j = g.n[1], n_k = g.n[2];
@@ -913,6 +1068,37 @@ __device__ __forceinline__ void sample_primitives(const BlShadeArgs &P, int stat
   } else {
     for (int v = 0; v < 8; v++) pr[v] = 0.0f;
   }
+}
+
+// Inter-block interpolation: the nine values of a sample from its eight anchor cells (InterpolateAdvanced,
+// simulation_sampling.cpp:1365-1386: the weights and order of InterpolateSimple; "<= 0 -> first anchor", :936-945)
+__device__ __forceinline__ void sample_primitives_advanced(const BlShadeArgs &P, const unsigned int *anchors, double f_i, double f_j,
+                                                           double f_k, float pr[8], float *kappa_out) {
+  const BlGridDevice &g = P.grid;
+  const double w_k[2] = {1.0 - f_k, f_k}, w_j[2] = {1.0 - f_j, f_j}, w_i[2] = {1.0 - f_i, f_i};
+  double val[9];
+  float first[9];
+  for (int corner = 0; corner < 8; corner++) {
+    const unsigned int cell = anchors[corner];
+    const float4 *p = reinterpret_cast<const float4 *>(g.cells) + (size_t)cell * 2;
+    float c[9];
+    unpack_cell(p[0], p[1], c);
+    c[8] = g.kappa != nullptr ? g.kappa[cell] : 0.0f;
+    const double w = w_k[corner >> 2] * w_j[(corner >> 1) & 1] * w_i[corner & 1];
+    for (int v = 0; v < 9; v++) {
+      if (corner == 0) {
+        val[v] = w * (double)c[v];
+        first[v] = c[v];
+      } else {
+        val[v] += w * (double)c[v];
+      }
+    }
+  }
+  if (val[0] <= 0.0) val[0] = (double)first[0];
+  if (val[1] <= 0.0) val[1] = (double)first[1];
+  if (val[8] <= 0.0) val[8] = (double)first[8];
+  for (int v = 0; v < 8; v++) pr[v] = (float)val[v];
+  *kappa_out = (float)val[8];
 }
 
 // The electron entropy of a located sample (plasma_model = code_kappa; simulation_sampling.cpp:726-727,
@@ -1584,7 +1770,7 @@ __global__ void __launch_bounds__(256, 4) bl_locate_kernel(const BlShadeArgs P) 
       t_ind = (unsigned long long)locate_time(P.slow, P.sample_t[at] + P.slow.snapshot_time, ray, &t_frac);
       P.slow.frac[at] = t_frac;
     }
-    if (!skip) locate_sample<kRefined>(P, tab, st, x1, x2, x3, r, &loc, &gathers_local);
+    if (!skip) locate_sample<kRefined>(P, tab, st, x1, x2, x3, r, &loc, &gathers_local, P.anchors != nullptr ? P.anchors + at * 8 : nullptr);
     double2 *dst = reinterpret_cast<double2 *>(P.located + at);
     dst[0] = make_double2(loc.f_i, loc.f_j);
     dst[1] = make_double2(loc.f_k, loc.ph);
@@ -1646,6 +1832,8 @@ __global__ void __launch_bounds__(256, 2) bl_shade_kernel(const BlShadeArgs P) {
       status = kExtended ? ((int)(tag >> 32) & 0xff) : (int)(tag >> 32);   // bits 40..: time slice (slow light only)
       if (kExtended && P.slow.n > 0) {
         sample_primitives_slow(P, status, (uint32_t)tag, (int)(tag >> 40), P.slow.frac[idx_cur], l0.x, l0.y, l1.x, pr, &kappa_f);
+      } else if (kExtended && status == kSampleAdvanced) {
+        sample_primitives_advanced(P, P.anchors + idx_cur * 8, l0.x, l0.y, l1.x, pr, &kappa_f);
       } else {
         sample_primitives(P, status, (uint32_t)tag, l0.x, l0.y, l1.x, pr);
         if (kExtended && P.plasma.code_kappa) kappa_f = sample_kappa(P, status, (uint32_t)tag, l0.x, l0.y, l1.x);
@@ -2159,7 +2347,8 @@ extern "C" hipError_t bl_launch_locate(const BlShadeArgs *args, int grid, int ld
 // Coefficient kernel
 extern "C" hipError_t bl_launch_shade(const BlShadeArgs *args, int model, int grid, hipStream_t stream) {
   const bool aux = args->aux != nullptr;
-  const bool power = args->plasma.power_frac != 0.0 || args->plasma.code_kappa != 0 || args->slow.n > 0 || args->pol_samples != nullptr;
+  const bool power = args->plasma.power_frac != 0.0 || args->plasma.code_kappa != 0 || args->slow.n > 0 || args->pol_samples != nullptr
+      || args->anchors != nullptr;
   // the benchmark path - plain image of a spherical Kerr-Schild simulation in a curved spacetime - has its own
   // instantiation with those two facts known at compile time (62.4 instead of 64.4 ms per 1024^2 frame)
   const bool sks_curved = args->plasma.simulation_coord == BL_COORD_SKS && !args->st.ray_flat;

@@ -606,7 +606,8 @@ void ReadAthena(const bl_params &p, int file_number, bl_snapshot *s) {
   if (!file.RootAttribute("RootGridSize", &root_grid_size) || !file.RootAttribute("DatasetNames", &dataset_attr)
       || !file.RootAttribute("VariableNames", &variable_attr) || !file.RootAttribute("NumVariables", &count_attr))
     Fail("Could not find needed file-level attributes.");
-  DecodeInts(root_grid_size, nullptr);
+  const std::vector<int32_t> root_grid = DecodeInts(root_grid_size, nullptr);
+  if (root_grid.size() != 3) Fail("Array dimension mismatch.");
   const std::vector<std::string> dataset_names = DecodeStrings(dataset_attr);
   const std::vector<std::string> variable_names = DecodeStrings(variable_attr);
   const std::vector<int32_t> num_variables = DecodeInts(count_attr, nullptr);
@@ -686,6 +687,10 @@ void ReadAthena(const bl_params &p, int file_number, bl_snapshot *s) {
   d.prim = s->prim.data();
   d.x1f = s->coords[0].data(); d.x2f = s->coords[1].data(); d.x3f = s->coords[2].data();
   d.x1v = s->coords[3].data(); d.x2v = s->coords[4].data(); d.x3v = s->coords[5].data();
+  // MeshBlock table for inter-block interpolation (hdf5_format_structure.cpp:245, simulation_reader.cpp:593-611)
+  d.levels = s->levels.data();
+  d.locations = s->locations.data();
+  d.n_3_root = root_grid[2];
 }
 
 void SetError(char *err, size_t err_len, const std::string &message) {

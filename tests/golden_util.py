@@ -11,7 +11,7 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 CASES = sorted(f[:-4] for f in os.listdir(GOLDEN_DIR)
                if f.endswith(".npz") and not f.startswith(("mock_", "window_", "slow_")))
 # cases whose parameters are inside the scope of the HIP path today
-GPU_CASES = [c for c in CASES if "blockinterp" not in c]   # TEMPORARY until the device path of a15 lands
+GPU_CASES = list(CASES)
 
 FRAME_KEYS = ("cam_x", "u_con", "u_cov", "norm_con", "norm_con_c", "hor_con_c", "vert_con_c")
 

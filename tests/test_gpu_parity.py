@@ -315,6 +315,60 @@ def test_randomised_polarized_configurations_against_oracle(seed, built_library)
     assert same.all(), f"{(~same).sum()} of {same.size} values differ for {over}"
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_block_interpolation_against_oracle(seed, built_library):
+    """simulation_block_interp = true (FindNearbyInds / InterpolateAdvanced) on equal blocks and on the two-level mesh,
+    narrow cameras whose rays are all captured so that the far-side block kept last in the list is never reached
+    (tests/golden_util.move_last): anchors across block faces, refinement levels and the periodic seam, GPU vs the
+    CPU oracle, bit-exact; auxiliary rows, an entropy variable and polarized transfer among the draws."""
+    import blacklight_amd as bl
+    from blacklight_amd import _capi
+    import oracle_api
+    rng = np.random.default_rng(9000 + seed)
+    fx, params, mock_args = gu.load_case("sim_dp_interp")
+    layouts = [dict(_blocks=[2, 2, 4], _last=[1, 1, 2]), dict(_blocks=[4, 2, 2], _last=[3, 1, 1]), dict(_blocks=[2, 3, 8], _last=[1, 2, 4]),
+               dict(_refined=1, _last=[0, 1, 1, 1]), dict(_refined=1, _entropy=1, _last=[0, 1, 1, 1])]
+    mesh = layouts[seed % len(layouts)]
+    over = dict(camera_resolution=12, simulation_block_interp="true", simulation_interp="true",
+                camera_th=float(rng.uniform(35.0, 80.0)), camera_ph=float(rng.uniform(-20.0, 20.0)),
+                camera_width=float(rng.uniform(1.5, 4.5)), image_tau=str(rng.choice(["true", "false"])),
+                fallback_nan=str(rng.choice(["true", "false"])), fallback_rho=1.0e-6, fallback_pgas=1.0e-8, fallback_kappa=2.0e6)
+    if "_entropy" in mesh:
+        over.update(plasma_model="code_kappa", simulation_kappa_name="r0")
+    if seed % 4 == 3:
+        over.update(image_polarization="true", image_rotation_split="false")
+    params = dict(params)
+    params.update(over)
+    p = bl.Params.from_dict(params)
+    grid = gu.golden_grid(dict(mock_args, **mesh))
+    with bl.Context(p) as ctx:
+        ctx.set_grid(grid)
+        got = ctx.render()
+    want = oracle_api.render(p.ptr, grid.desc(), _capi.RenderDesc, _capi.CameraFrame, n_rays=144,
+                             max_steps=int(p.get("ray_max_steps")), n_freq=1)
+    assert np.array_equal(got["sample_num"], want["sample_num"]), over
+    assert got["image"].shape == want["image"].shape
+    same = gu.same_bits(got["image"], want["image"])
+    assert same.all(), f"{(~same).sum()} of {same.size} values differ for {over} on {mesh}"
+
+
+def test_block_interpolation_refuses_undefined_reads(built_library):
+    """A camera that sees the whole grid reaches the upper edges of the last MeshBlock, where the reference reads past
+    its cell-centre arrays: refused (never approximated). Without the MeshBlock table bl_set_grid fails."""
+    import dataclasses
+    import blacklight_amd as bl
+    fx, params, mock_args = gu.load_case("sim_blockinterp")
+    params = dict(params, camera_width=24.0)
+    p = bl.Params.from_dict(params)
+    grid = gu.golden_grid(mock_args)
+    with bl.Context(p) as ctx:
+        ctx.set_grid(grid)
+        with pytest.raises(bl.BlacklightError, match="last MeshBlock"):
+            ctx.render()
+        with pytest.raises(bl.BlacklightError, match="MeshBlock table"):
+            ctx.set_grid(dataclasses.replace(grid, levels=None, locations=None, n_3_root=0))
+
+
 def test_refined_mesh_holes_and_overlaps(built_library):
     """A mesh with a block missing is still a mesh (samples in the hole are off the grid, as in the reference's
     scan over blocks): HIP vs oracle bit-exact. Blocks that overlap are refused."""

@@ -38,6 +38,14 @@ def _check_arrays(snapshot, expected, stem):
     assert np.array_equal(levels, expected[f"{stem}_levels"])
     assert np.array_equal(locations, expected[f"{stem}_locations"])
     assert snapshot.time == float(expected[f"{stem}_time"])
+    # the MeshBlock table travels in the grid description too (inter-block interpolation reads it): same arrays,
+    # and the root grid's cells along x3 (one level here: blocks along x3 times cells per block)
+    d = snapshot.desc()
+    import ctypes
+    assert np.array_equal(np.ctypeslib.as_array(ctypes.cast(d.levels, ctypes.POINTER(ctypes.c_int32)), (d.n_blocks,)), levels)
+    assert np.array_equal(np.ctypeslib.as_array(ctypes.cast(d.locations, ctypes.POINTER(ctypes.c_int32)), (d.n_blocks, 3)), locations)
+    if levels.max() == 0:
+        assert d.n_3_root == (int(locations[:, 2].max()) + 1) * d.n_k
     return arrays
 
 
