@@ -42,3 +42,46 @@ def test_reference_windows_of_the_benchmark_frame(built_library):
     # stock glibc reference: a = 0, stated tolerance
     want_a = fx["A_I_nu"].reshape(-1)
     assert np.nanmax(np.abs(got - want_a)) / np.nanmax(np.abs(want_a)) < 1.0e-6
+
+
+def test_full_size_frame_is_independent_of_how_it_is_split(built_library):
+    """Size-independent properties at the benchmark's own size (1024^2 camera, 256^3 grid): every ray is independent,
+    so the frame rendered in one call, the frame assembled from the 32 x 32-pixel tiles of eight emulated ranks
+    (blacklight_amd.distributed, the strong-scaling mode of bench.py), and the frame rendered in many small chunks
+    must agree bit for bit - image, sample counts and flags. Also: the gather counter of the whole frame equals
+    the sum over the ranks, and no pixel of the plain frame is NaN except along flagged rays."""
+    import blacklight_amd as bl
+    from blacklight_amd import distributed as bd, mock
+    import bench
+    grid = mock.generate(n_r=256, n_th=256, n_ph=256)
+    p = bl.Params.from_dict(dict(bench.WORKLOAD))
+    res, world = 1024, 8
+    with bl.Context(p) as ctx:
+        ctx.set_grid(grid)
+        full = ctx.render()
+        assert full["image"].shape == (1, res * res)
+        assembled = np.full(res * res, np.nan)
+        counts = np.full(res * res, -1, dtype=np.int32)
+        gathers = 0
+        seen = 0
+        for rank in range(world):
+            pixels = bd.tile_pixels(res, rank, world, bench.TILE)
+            part = ctx.render(pixel_map=pixels)
+            assembled[pixels] = part["image"][0]
+            counts[pixels] = part["sample_num"]
+            gathers += part["stats"].n_gathers
+            seen += pixels.size
+        assert seen == res * res and (counts >= 0).all()
+        assert gu.same_bits(assembled, full["image"][0]).all()
+        assert np.array_equal(counts, full["sample_num"])
+        assert gathers == full["stats"].n_gathers
+        ctx.set_scratch_limit(8 << 30)   # ~ 40 chunks instead of 2
+        chunked = ctx.render()
+        assert chunked["stats"].n_chunks > 10
+        assert gu.same_bits(chunked["image"][0], full["image"][0]).all()
+        assert np.array_equal(chunked["sample_num"], full["sample_num"])
+        assert np.array_equal(chunked["sample_flags"], full["sample_flags"])
+    nan = np.isnan(full["image"][0])
+    assert np.array_equal(nan, full["sample_flags"].astype(bool) & nan) and nan.sum() <= full["sample_flags"].sum()
+    # algorithmic bytes of the roofline (SURVEY.md 8d): 256 B per gathered sample + 13 B per ray
+    assert full["stats"].algorithmic_bytes == 256 * full["stats"].n_gathers + 13 * res * res
