@@ -831,7 +831,8 @@ void UploadRefinedGrid(bl_ctx *ctx, const bl_grid_desc *g) {
   if (ctx->params.simulation_interp && ctx->params.simulation_block_interp) {
     // MeshBlock table for FindNearbyInds (simulation_sampling.cpp:36-39, :84-93) and a hash from (level, location)
     // to block in place of its scans over all blocks
-    if (g->levels == nullptr || g->locations == nullptr || g->n_3_root <= 0)
+    // n_3_root only enters through the periodic seam of spherical coordinates (simulation_sampling.cpp:1181-1219)
+    if (g->levels == nullptr || g->locations == nullptr || (g->n_3_root <= 0 && ctx->params.simulation_coord == BL_COORD_SKS))
       throw Failure{BL_E_ARG, "simulation_block_interp = true needs the MeshBlock table (levels, locations, n_3_root) in bl_grid_desc."};
     int max_level = 0;
     for (int blk = 0; blk < n_b; blk++) {

@@ -16,6 +16,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -80,6 +81,7 @@ class FileMap {
     return value;
   }
   uint8_t Byte(uint64_t offset) const { return *At(offset, 1); }
+  size_t Size() const { return size_; }
 
  private:
   const uint8_t *base_ = nullptr;
@@ -505,8 +507,8 @@ void ReaderSetup(const bl_params &p, bl_snapshot *s) {
     Require(p, {BL_P_slow_t_start, BL_P_slow_dt});
     if (p.slow_dt <= 0.0) Fail("Must have positive time interval slow_dt.");
   }
-  if (p.simulation_format != BL_SIMFMT_ATHENA)
-    Fail("Only simulation_format = athena has a native reader; other formats must be handed over through bl_set_grid().",
+  if (p.simulation_format != BL_SIMFMT_ATHENA && p.simulation_format != BL_SIMFMT_ATHENAK)
+    Fail("Only simulation_format = athena and athenak have native readers; other formats must be handed over through bl_set_grid().",
          BL_E_UNSUPPORTED);
   Require(p, {BL_P_plasma_mu, BL_P_plasma_model});
   double gamma = 0.0, gamma_i = 0.0, gamma_e = 0.0;
@@ -517,8 +519,10 @@ void ReaderSetup(const bl_params &p, bl_snapshot *s) {
       if (p.has[BL_P_plasma_gamma_i]) Warn(s, "Ignoring plasma_gamma_i selection.");
       if (p.has[BL_P_plasma_gamma_e]) Warn(s, "Ignoring plasma_gamma_e selection.");
     } else {
-      Require(p, {BL_P_plasma_gamma, BL_P_plasma_gamma_i, BL_P_plasma_gamma_e});   // athena: all three from the input
-      gamma = p.plasma_gamma;
+      // :108-134: athena needs all three from the input; athenak may take plasma_gamma from the file
+      if (p.simulation_format == BL_SIMFMT_ATHENA) Require(p, {BL_P_plasma_gamma});
+      Require(p, {BL_P_plasma_gamma_i, BL_P_plasma_gamma_e});
+      if (p.has[BL_P_plasma_gamma]) gamma = p.plasma_gamma;
       gamma_i = p.plasma_gamma_i;
       gamma_e = p.plasma_gamma_e;
     }
@@ -693,6 +697,192 @@ void ReadAthena(const bl_params &p, int file_number, bl_snapshot *s) {
   d.n_3_root = root_grid[2];
 }
 
+// ------------------------------------------------------------------------------------------------
+// AthenaK binary dumps (simulation_format = athenak): ReadAthenaKHeader (simulation_reader.cpp:915-1012),
+// VerifyVariablesAthenaK (:1226-1287), ReadAthenaKInputs (:1027-1131) and the block loop of Read (:434-589).
+// Layout: a text header (version line, one line skipped, "  time=", one line skipped, "  size of location=",
+// "  size of variable=", "  number of variables=", "  variables:", "  header offset="), `header offset` bytes of
+// the run's input file, then one record per MeshBlock: six int32 cell-index bounds, logical location (3 x int32),
+// level (int32), six face coordinates (float or double), then every variable over the block's cells.
+// The reference counts the blocks with `while (!eof) { ignore(block); count++; }`, which ends one past the last
+// block (ignore() only raises eof when it runs short), and then reads that phantom block into uninitialised arrays;
+// this reader takes the blocks the file holds.
+void ReadAthenaK(const bl_params &p, int file_number, bl_snapshot *s) {
+  s->file = p.simulation_file.s;
+  if (file_number >= 0) s->file = FormatFilename(s->file, file_number);
+  FileMap map;
+  map.Open(s->file);
+  const size_t size = map.Size();
+  const char *text = size > 0 ? reinterpret_cast<const char *>(map.At(0, size)) : "";
+  size_t pos = 0;
+  auto next_line = [&](bool *terminated) {   // std::istream::getline: up to, not including, the newline
+    const size_t begin = pos;
+    while (pos < size && text[pos] != '\n') pos++;
+    std::string line(text + begin, pos - begin);
+    *terminated = pos < size;
+    if (pos < size) pos++;
+    return line;
+  };
+  bool ended;
+  if (next_line(&ended) != "Athena binary output version=1.1" || !ended) Fail("Unknown AthenaK file format.");
+  next_line(&ended);
+  auto value_after = [&](const char *label) {   // the text after `label` on the next line
+    const std::string line = next_line(&ended);
+    const size_t n = std::strlen(label);
+    if (line.compare(0, n, label) != 0) Fail("Invalid AthenaK file header.");
+    return line.substr(n);
+  };
+  s->time = std::strtod(value_after("  time=").c_str(), nullptr);
+  next_line(&ended);
+  const int location_size = std::atoi(value_after("  size of location=").c_str());
+  if (location_size != 4 && location_size != 8) Fail("Unsupported size of location.");
+  const int variable_size = std::atoi(value_after("  size of variable=").c_str());
+  if (variable_size != 4 && variable_size != 8) Fail("Unsupported size of variables.");
+  const int num_variables = std::atoi(value_after("  number of variables=").c_str());
+  std::vector<std::string> names;
+  {
+    std::istringstream tokens(value_after("  variables:"));
+    std::string name;
+    while (tokens >> name) names.push_back(name);
+    if (num_variables <= 0 || static_cast<int>(names.size()) < num_variables) Fail("Invalid AthenaK file header.");
+    names.resize(num_variables);
+  }
+  const long header_offset = std::atol(value_after("  header offset=").c_str());
+  if (header_offset < 0 || pos + static_cast<size_t>(header_offset) > size) Fail("Invalid AthenaK file header.");
+  const size_t data_offset = pos + static_cast<size_t>(header_offset);
+
+  // VerifyVariablesAthenaK
+  const bool code_kappa = p.plasma_model == BL_PLASMA_CODE_KAPPA;
+  auto locate = [&](const std::string &name, const char *message) {
+    for (int n = 0; n < num_variables; n++)
+      if (names[n] == name) return n;
+    Fail(message);
+  };
+  const int in_rho = locate("dens", "Unable to locate \"dens\" values in data file.");
+  const int in_pgas = locate("eint", "Unable to locate \"eint\" values in data file.");
+  const int in_kappa = code_kappa ? locate(p.simulation_kappa_name.s, "Unable to locate electron entropy values in data file.") : -1;
+  const int in_uu1 = locate("velx", "Unable to locate \"velx\" values in data file.");
+  const int in_uu2 = locate("vely", "Unable to locate \"vely\" values in data file.");
+  const int in_uu3 = locate("velz", "Unable to locate \"velz\" values in data file.");
+  const int in_bb1 = locate("bcc1", "Unable to locate \"bcc1\" values in data file.");
+  const int in_bb2 = locate("bcc2", "Unable to locate \"bcc2\" values in data file.");
+  const int in_bb3 = locate("bcc3", "Unable to locate \"bcc3\" values in data file.");
+
+  // ReadAthenaKInputs: the run's input file, up to the data
+  const bool gamma_set = p.has[BL_P_plasma_gamma] != 0;   // every branch of the constructor that reads it sets gamma_set (:96-150)
+  bool gamma_found = false;
+  std::string section;
+  auto mismatch = [&](const char *what, double given, double in_file) {
+    std::ostringstream message;
+    message << "Given " << what << " of " << given << " does not match file value of " << in_file << "; ignoring the latter.";
+    Warn(s, message.str());
+  };
+  while (pos < data_offset) {
+    const std::string line = next_line(&ended);
+    if (!line.empty() && line[0] == '#') continue;
+    if (!line.empty() && line.front() == '<' && line.back() == '>') {
+      section = line.substr(1, line.size() - 2);
+      continue;
+    }
+    const size_t eq = line.find('=');
+    if (eq == std::string::npos) Fail("Error parsing inputs in AthenaK file.");
+    std::string variable = line.substr(0, eq);
+    variable.erase(std::remove(variable.begin(), variable.end(), ' '), variable.end());
+    const double value = std::strtod(line.c_str() + eq + 1, nullptr);
+    if (section == "coord" && variable == "a" && value != p.simulation_a) mismatch("spin", p.simulation_a, value);
+    if (section == "units" && variable == "bhmass_msun" && value != p.simulation_m_msun) mismatch("mass", p.simulation_m_msun, value);
+    if (section == "units" && variable == "density_cgs" && value != p.simulation_rho_cgs) mismatch("density scale", p.simulation_rho_cgs, value);
+    if (section == "units" && variable == "mu" && value != p.plasma_mu) mismatch("density scale", p.plasma_mu, value);   // the reference's wording
+    if (section == "mhd" && variable == "gamma") {
+      if (!gamma_set)
+        s->desc.plasma_gamma = value;
+      else if (s->desc.plasma_gamma != value)
+        mismatch("total adiabatic index", s->desc.plasma_gamma, value);
+      gamma_found = true;
+    }
+  }
+  if (!gamma_found) Fail("Missing adiabatic index.");
+  pos = data_offset;
+
+  // blocks
+  const int32_t *bounds = reinterpret_cast<const int32_t *>(map.At(data_offset, 24));
+  int32_t first[6];
+  std::memcpy(first, bounds, 24);
+  const long n_i = first[1] - first[0] + 1, n_j = first[3] - first[2] + 1, n_k = first[5] - first[4] + 1;
+  if (n_i < 1 || n_j < 1 || n_k < 1 || n_i > 65536 || n_j > 65536 || n_k > 65536) Fail("Invalid AthenaK file header.");
+  const size_t cells = static_cast<size_t>(n_i) * n_j * n_k;
+  const size_t block_bytes = 24 + 16 + 6 * static_cast<size_t>(location_size) + static_cast<size_t>(num_variables) * cells * variable_size;
+  const size_t n_blocks = (size - data_offset) / block_bytes;
+  if (n_blocks == 0) Fail("Unexpected end of AthenaK file.");
+  const int n_var = code_kappa ? 9 : 8;
+  s->levels.assign(n_blocks, 0);
+  s->locations.assign(3 * n_blocks, 0);
+  const long n_axis[3] = {n_i, n_j, n_k};
+  for (int a = 0; a < 3; a++) {
+    s->coords[a].assign(n_blocks * (n_axis[a] + 1), 0.0);
+    s->coords[3 + a].assign(n_blocks * n_axis[a], 0.0);
+  }
+  s->prim.assign(static_cast<size_t>(n_var) * n_blocks * cells, 0.0f);
+  const int source[9] = {in_rho, in_uu1, in_uu2, in_uu3, in_pgas, in_bb1, in_bb2, in_bb3, in_kappa};   // prim order :1277-1285
+  const float gamma_minus_one = static_cast<float>(s->desc.plasma_gamma - 1.0);
+  for (size_t block = 0; block < n_blocks; block++) {
+    const size_t begin = data_offset + block * block_bytes;
+    std::memcpy(&s->locations[3 * block], map.At(begin + 24, 12), 12);
+    std::memcpy(&s->levels[block], map.At(begin + 36, 4), 4);
+    double faces[6];
+    for (int c = 0; c < 6; c++)
+      faces[c] = location_size == 4 ? static_cast<double>(map.Get<float>(begin + 40 + 4 * c)) : map.Get<double>(begin + 40 + 8 * c);
+    for (int a = 0; a < 3; a++) {   // uniform faces between the block's bounds, centres midway (:508-529)
+      const long n = n_axis[a];
+      double *xf = &s->coords[a][block * (n + 1)], *xv = &s->coords[3 + a][block * n];
+      xf[0] = faces[2 * a];
+      xf[n] = faces[2 * a + 1];
+      const double dx = (faces[2 * a + 1] - faces[2 * a]) / static_cast<double>(n);
+      for (long i = 1; i < n; i++) xf[i] = faces[2 * a] + static_cast<double>(i) * dx;
+      for (long i = 0; i < n; i++) xv[i] = 0.5 * (xf[i] + xf[i + 1]);
+    }
+    const size_t cell_data = begin + 40 + 6 * static_cast<size_t>(location_size);
+    for (int v = 0; v < n_var; v++) {
+      float *dst = &s->prim[(static_cast<size_t>(v) * n_blocks + block) * cells];
+      const size_t from = cell_data + static_cast<size_t>(source[v]) * cells * variable_size;
+      if (variable_size == 4) {
+        std::memcpy(dst, map.At(from, cells * 4), cells * 4);
+      } else {
+        const uint8_t *src = map.At(from, cells * 8);
+        for (size_t c = 0; c < cells; c++) {
+          double value;
+          std::memcpy(&value, src + 8 * c, 8);
+          dst[c] = static_cast<float>(value);
+        }
+      }
+      if (v == 4)   // internal energy to pressure (:584-589)
+        for (size_t c = 0; c < cells; c++) dst[c] *= gamma_minus_one;
+    }
+  }
+  bl_grid_desc &d = s->desc;
+  d.n_blocks = static_cast<int32_t>(n_blocks);
+  d.n_i = static_cast<int32_t>(n_i);
+  d.n_j = static_cast<int32_t>(n_j);
+  d.n_k = static_cast<int32_t>(n_k);
+  d.n_var = n_var;
+  d.prim = s->prim.data();
+  d.x1f = s->coords[0].data(); d.x2f = s->coords[1].data(); d.x3f = s->coords[2].data();
+  d.x1v = s->coords[3].data(); d.x2v = s->coords[4].data(); d.x3v = s->coords[5].data();
+  d.ind_rho = 0; d.ind_uu1 = 1; d.ind_uu2 = 2; d.ind_uu3 = 3; d.ind_pgas = 4;
+  d.ind_bb1 = 5; d.ind_bb2 = 6; d.ind_bb3 = 7; d.ind_kappa = code_kappa ? 8 : 0;
+  d.levels = s->levels.data();
+  d.locations = s->locations.data();
+  d.n_3_root = 0;   // the reference sets it for HDF5 files only; it is read for spherical coordinates alone
+}
+
+// Either format
+void ReadSnapshot(const bl_params &p, int file_number, bl_snapshot *s) {
+  if (p.simulation_format == BL_SIMFMT_ATHENAK)
+    ReadAthenaK(p, file_number, s);
+  else
+    ReadAthena(p, file_number, s);
+}
+
 void SetError(char *err, size_t err_len, const std::string &message) {
   if (err != nullptr && err_len > 0) std::snprintf(err, err_len, "Error: %s\n", message.c_str());
 }
@@ -712,7 +902,7 @@ int bl_snapshot_open(const bl_params *p, int snapshot, bl_snapshot **out, char *
     s = new bl_snapshot;
     ReaderSetup(*p, s);
     if (p->slow_light_on) Fail("slow_light_on = true: the window of files is read by bl_slow_light_read().", BL_E_STATE);
-    ReadAthena(*p, p->simulation_multiple ? p->simulation_start + snapshot : -1, s);   // :305-319
+    ReadSnapshot(*p, p->simulation_multiple ? p->simulation_start + snapshot : -1, s);   // :305-319
     *out = s;
     return BL_OK;
   } catch (const ReadFailure &f) {
@@ -736,7 +926,7 @@ int bl_snapshot_open_number(const bl_params *p, int file_number, bl_snapshot **o
   try {
     s = new bl_snapshot;
     ReaderSetup(*p, s);
-    ReadAthena(*p, file_number, s);
+    ReadSnapshot(*p, file_number, s);
     *out = s;
     return BL_OK;
   } catch (const ReadFailure &f) {

@@ -205,7 +205,8 @@ typedef struct bl_grid_desc {
  * owns the arrays bl_snapshot_grid() points to; hand that view to bl_set_grid(), then close the snapshot.
  * err receives "Error: ...\n" (reference texts). Each call reads its file completely; the reference
  * re-uses block layout and coordinates of the first file for later files of a series.
- * The other simulation formats return BL_E_UNSUPPORTED. With slow_light_on use bl_slow_light_read(). */
+ * simulation_format = athenak: the AthenaK binary dump reader (simulation_reader.cpp:915-1131, :434-589) behind the same calls.
+ * iharm3d / harm3d return BL_E_UNSUPPORTED. With slow_light_on use bl_slow_light_read(). */
 typedef struct bl_snapshot bl_snapshot;
 BL_API int bl_snapshot_open(const bl_params *p, int snapshot, bl_snapshot **out, char *err, size_t err_len);
 BL_API const bl_grid_desc *bl_snapshot_grid(const bl_snapshot *s);

@@ -2750,7 +2750,7 @@ int Setup(Oracle &o, const bl_params *p, const bl_grid_desc *g, char *err, size_
   o.image_polarization = p->model_type == BL_MODEL_SIMULATION and p->image_light and p->image_polarization;
   if (p->model_type == BL_MODEL_SIMULATION) {
     if (g == nullptr) return Fail(err, err_len, "oracle: simulation mode needs a grid", BL_E_ARG);
-    if (p->simulation_block_interp and p->simulation_interp and (g->levels == nullptr or g->locations == nullptr or g->n_3_root <= 0))
+    if (p->simulation_block_interp and p->simulation_interp and (g->levels == nullptr or g->locations == nullptr or (g->n_3_root <= 0 and p->simulation_coord == BL_COORD_SKS)))
       return Fail(err, err_len, "oracle: inter-block interpolation needs the MeshBlock table (levels, locations, n_3_root)", BL_E_ARG);
     if (p->slow_light_on and (o.slow_n < 2 or o.slow_n != p->slow_chunk_size or o.slow_grids == nullptr or o.slow_times == nullptr))
       return Fail(err, err_len, "oracle: slow light needs slow_chunk_size time slices in blo_extra", BL_E_ARG);

@@ -184,3 +184,85 @@ def test_malformed_files(built_library, expected, tmp_path):
     empty.write_bytes(b"")
     with pytest.raises(BlacklightError, match="Unexpected end of HDF5 file."):
         Snapshot(_params(expected, simulation_file=str(empty)))
+
+
+# ---------------------------------------------------------------------------------------------- AthenaK dumps
+@pytest.fixture(scope="module")
+def athenak():
+    return np.load(os.path.join(READER_DIR, "expected_athenak.npz"), allow_pickle=False)
+
+
+def _athenak_params(athenak, stem, **overrides):
+    params = json.loads(str(athenak[f"{stem}_params"]))
+    params["simulation_file"] = os.path.join(READER_DIR, stem + ".bin")
+    params.update(overrides)
+    return Params.from_dict({k: v for k, v in params.items() if v is not None})
+
+
+@pytest.mark.parametrize("stem", ["athenak_single", "athenak_blocks"])
+def test_athenak_files(built_library, athenak, stem):
+    """simulation_format = athenak (simulation_reader.cpp:915-1131, :434-589): 4- and 8-byte locations and variables,
+    variables in any order, an entropy variable, several MeshBlocks; the arrays the reader hands over against what
+    tools/make_goldens.py put into the file, in the reference's internal order (rho, v, p = (gamma - 1) e_int, B, kappa)."""
+    names = json.loads(str(athenak[f"{stem}_names"]))
+    order = athenak[f"{stem}_order"]
+    nbi, nbj, nbk = (int(v) for v in athenak[f"{stem}_blocks"])
+    bounds = athenak[f"{stem}_bounds"]
+    gamma = float(athenak[f"{stem}_gamma"])
+    with Snapshot(_athenak_params(athenak, stem)) as s:
+        arrays = s.arrays()
+        d = s.desc()
+        assert s.time == float(athenak[f"{stem}_time"])
+        assert s.warnings == str(athenak[f"{stem}_B_warnings"])
+        assert d.plasma_gamma == gamma
+        levels, locations = s.blocks
+    assert np.array_equal(levels, np.zeros(len(order), dtype=np.int32)) and np.array_equal(locations, order)
+    n_k, n_j, n_i = athenak["source_dens"].shape
+    ni, nj, nk = n_i // nbi, n_j // nbj, n_k // nbk
+    internal = ["dens", "velx", "vely", "velz", "eint", "bcc1", "bcc2", "bcc3"] + (["s_00"] if "s_00" in names else [])
+    assert arrays["prim"].shape == (len(internal), len(order), nk, nj, ni)
+    assert arrays["indices"] == dict(ind_rho=0, ind_uu1=1, ind_uu2=2, ind_uu3=3, ind_pgas=4, ind_bb1=5, ind_bb2=6, ind_bb3=7,
+                                     ind_kappa=8 if "s_00" in names else 0)
+    for b, (bi, bj, bk) in enumerate(order):
+        for v, name in enumerate(internal):
+            want = athenak[f"source_{name}"][bk * nk:(bk + 1) * nk, bj * nj:(bj + 1) * nj, bi * ni:(bi + 1) * ni]
+            if name == "eint":
+                want = (want * np.float32(gamma - 1.0)).astype(np.float32)
+            assert np.array_equal(arrays["prim"][v, b].view(np.uint32), want.view(np.uint32)), (name, b)
+        for axis, (n_blocks_axis, n, index) in enumerate(((nbi, ni, bi), (nbj, nj, bj), (nbk, nk, bk))):
+            edges = np.linspace(bounds[2 * axis], bounds[2 * axis + 1], n_blocks_axis + 1)
+            lo, hi = edges[index], edges[index + 1]
+            if stem == "athenak_single":   # 4-byte locations
+                lo, hi = float(np.float32(lo)), float(np.float32(hi))
+            faces = arrays[f"x{axis + 1}f"][b]
+            dx = (hi - lo) / n
+            want_faces = np.array([lo] + [lo + i * dx for i in range(1, n)] + [hi])
+            assert np.array_equal(faces, want_faces)
+            assert np.array_equal(arrays[f"x{axis + 1}v"][b], 0.5 * (want_faces[:-1] + want_faces[1:]))
+
+
+def test_athenak_malformed_files(built_library, athenak, tmp_path):
+    """The reference's error texts for files it rejects."""
+    good = open(os.path.join(READER_DIR, "athenak_single.bin"), "rb").read()
+
+    def failing(data, **overrides):
+        path = tmp_path / "bad.bin"
+        path.write_bytes(data)
+        with pytest.raises(BlacklightError) as err:
+            Snapshot(_athenak_params(athenak, "athenak_single", simulation_file=str(path), **overrides))
+        return str(err.value)
+
+    assert failing(good.replace(b"version=1.1", b"version=1.0", 1)) == "Error: Unknown AthenaK file format."
+    assert failing(good.replace(b"  time=", b"  tyme=", 1)) == "Error: Invalid AthenaK file header."
+    assert failing(good.replace(b"size of location=4", b"size of location=2", 1)) == "Error: Unsupported size of location."
+    assert failing(good.replace(b" eint ", b" etot ", 1)) == "Error: Unable to locate \"eint\" values in data file."
+    assert failing(good.replace(b"gamma = ", b"gamna = ", 1)) == "Error: Missing adiabatic index."
+    assert failing(good.replace(b"eos = ideal", b"eos : ideal", 1)) == "Error: Error parsing inputs in AthenaK file."
+    assert failing(good, plasma_model="code_kappa", simulation_kappa_name="s_00") == \
+        "Error: Unable to locate electron entropy values in data file."
+    header_end = good.index(b"gamma = ")
+    assert "Error:" in failing(good[:header_end + 40])   # data cut off
+    # a mismatch between the input's adiabatic index and the file's: the reference's warning, the input's value kept
+    with Snapshot(_athenak_params(athenak, "athenak_single", plasma_gamma=1.5)) as s:
+        assert "Warning: Given total adiabatic index of 1.5 does not match file value of 1.66667; ignoring the latter.\n" in s.warnings
+        assert s.desc().plasma_gamma == 1.5

@@ -587,6 +587,114 @@ def make_reader_fixtures():
 
 
 # ------------------------------------------------------------------------------------------------
+# AthenaK dumps (tests/golden/reader/athenak_*.bin): the format has no generator in the reference, so these files
+# are written here, following what its reader parses (simulation_reader.cpp:915-1131, :434-589), from the arrays of a
+# small mock read as a Cartesian box; the reference then images them (simulation_format = athenak, cks).
+def write_athenak(path, prim, names, bounds, blocks, time, inputs, location_size, variable_size):
+    """prim [n_var][n_k][n_j][n_i] float32 over the whole box, names of the variables in file order, bounds
+    (x1min, x1max, x2min, x2max, x3min, x3max), blocks (nbi, nbj, nbk): equal blocks written in a scrambled order."""
+    n_var, n_k, n_j, n_i = prim.shape
+    nbi, nbj, nbk = blocks
+    ni, nj, nk = n_i // nbi, n_j // nbj, n_k // nbk
+    order = [(bk, bj, bi) for bk in range(nbk) for bj in range(nbj) for bi in range(nbi)]
+    order = [order[o] for o in np.random.default_rng(11).permutation(len(order))]
+    loc_type = np.float32 if location_size == 4 else np.float64
+    var_type = np.float32 if variable_size == 4 else np.float64
+    text = inputs.encode()
+    with open(path, "wb") as f:
+        f.write(b"Athena binary output version=1.1\n")
+        f.write(b"  size of preheader=5\n")
+        f.write(f"  time={time!r}\n".encode())
+        f.write(b"  cycle=1234\n")
+        f.write(f"  size of location={location_size}\n".encode())
+        f.write(f"  size of variable={variable_size}\n".encode())
+        f.write(f"  number of variables={n_var}\n".encode())
+        f.write(("  variables:  " + "  ".join(names) + "  \n").encode())
+        f.write(f"  header offset={len(text)}\n".encode())
+        f.write(text)
+        edges = [np.linspace(bounds[2 * a], bounds[2 * a + 1], n + 1) for a, n in enumerate((nbi, nbj, nbk))]
+        for bk, bj, bi in order:
+            np.array([2, 2 + ni - 1, 2, 2 + nj - 1, 2, 2 + nk - 1], dtype=np.int32).tofile(f)   # cell-index bounds with ghost offset
+            np.array([bi, bj, bk, 0], dtype=np.int32).tofile(f)
+            np.array([edges[0][bi], edges[0][bi + 1], edges[1][bj], edges[1][bj + 1], edges[2][bk], edges[2][bk + 1]], dtype=loc_type).tofile(f)
+            prim[:, bk * nk:(bk + 1) * nk, bj * nj:(bj + 1) * nj, bi * ni:(bi + 1) * ni].astype(var_type).tofile(f)
+    return order
+
+
+ATHENAK_INPUTS = """# File produced by tools/make_goldens.py
+<comment>
+problem = mock torus read as a Cartesian box
+<mesh>
+nx1 = 16
+x1min = 2.0
+<coord>
+general_rel = true
+a = {a}
+<units>
+bhmass_msun = 4.152e6
+density_cgs = {rho}
+mu = 0.5
+<mhd>
+eos = ideal
+gamma = {gamma}
+"""
+
+
+def make_athenak_fixtures():
+    import h5py
+    out_dir = os.path.join(OUT, "reader")
+    workdir = os.path.join(WORK, "athenak")
+    for sub in (out_dir, os.path.join(workdir, "data"), os.path.join(workdir, "output")):
+        os.makedirs(sub, exist_ok=True)
+    mock_path = os.path.join(workdir, "data", "mock.athdf")
+    subprocess.run([sys.executable, "-W", "ignore", MOCK_SCRIPT, mock_path, "--n_r", "16", "--n_th", "12", "--n_ph", "16"], check=True)
+    with h5py.File(mock_path, "r") as f:
+        hydro, bfield = f["prim"][:, 0].astype(np.float32), f["B"][:, 0].astype(np.float32)
+    rho, pgas, vel = hydro[0], hydro[1], hydro[2:5]
+    entropy = (np.float32(2.0 ** 26) * (pgas / (rho * np.sqrt(rho)))).astype(np.float32)
+    eint = (pgas * np.float32(1.5)).astype(np.float32)
+    expected = {}
+    files = {
+        # name: (variables in file order, blocks, location size, variable size, gamma in the file, spin in the file, time)
+        "athenak_single.bin": (["dens", "velx", "vely", "velz", "eint", "bcc1", "bcc2", "bcc3"], (1, 1, 1), 4, 4, 1.6666666666666667, 0.0, 7.25),
+        "athenak_blocks.bin": (["bcc1", "bcc2", "bcc3", "s_00", "eint", "dens", "velz", "vely", "velx"], (2, 1, 2), 8, 8, 1.4444444444444444, 0.3, 8.5),
+    }
+    arrays = dict(dens=rho, eint=eint, velx=vel[0], vely=vel[1], velz=vel[2], bcc1=bfield[0], bcc2=bfield[1], bcc3=bfield[2], s_00=entropy)
+    bounds = (2.0, 40.0, -1.5, 4.5, -3.0, 9.0)
+    for name, (names, blocks, loc, var, gamma, spin, time) in files.items():
+        prim = np.stack([arrays[n] for n in names])
+        path = os.path.join(workdir, "data", name)
+        order = write_athenak(path, prim, names, bounds, blocks, time, ATHENAK_INPUTS.format(a=spin, rho=1.0e-16, gamma=gamma), loc, var)
+        with open(path, "rb") as src, open(os.path.join(out_dir, name), "wb") as dst:
+            dst.write(src.read())
+        stem = name.split(".")[0]
+        expected[f"{stem}_order"] = np.array([(bi, bj, bk) for bk, bj, bi in order], dtype=np.int32)
+        expected[f"{stem}_names"] = json.dumps(names)
+        expected[f"{stem}_gamma"] = gamma
+        expected[f"{stem}_time"] = time
+        expected[f"{stem}_blocks"] = np.array(blocks, dtype=np.int32)
+        expected[f"{stem}_bounds"] = np.array(bounds)
+        for key, value in arrays.items():
+            expected[f"source_{key}"] = value
+        params = dict(SIM_BASE)
+        params.update(camera_resolution=16, checkpoint_geodesic_save="false", simulation_format="athenak", simulation_coord="cks",
+                      simulation_file="data/" + name, simulation_a=0.3, camera_th=80.0, camera_ph=5.0, camera_width=14.0,
+                      fallback_nan="false", fallback_rho=1.0e-6, fallback_pgas=1.0e-8, fallback_kappa=2.0e6, image_tau="true")
+        if "s_00" in names:
+            params.update(plasma_model="code_kappa", simulation_kappa_name="s_00", simulation_block_interp="false")
+        write_input(os.path.join(workdir, "case.input"), params)
+        expected[f"{stem}_params"] = json.dumps(params)
+        for tier, preload in (("A", False), ("B", True)):
+            expected[f"{stem}_{tier}_warnings"] = run_reference(workdir, "case.input", preload)
+            npz = np.load(os.path.join(workdir, "output", "out.npz"))
+            for key in npz.files:
+                expected[f"{stem}_{tier}_{key}"] = npz[key]
+        print(name, "I_nu max", float(np.nanmax(expected[f"{stem}_B_I_nu"])), "nonzero", int(np.count_nonzero(expected[f"{stem}_B_I_nu"])),
+              repr(expected[f"{stem}_B_warnings"]))
+    np.savez_compressed(os.path.join(out_dir, "expected_athenak.npz"), **expected)
+
+
+# ------------------------------------------------------------------------------------------------
 # Slow light (tests/golden/slow_*.npz): eleven small mocks with file times 0, 20, ..., 200 and varying
 # perturbations; the reference renders a few camera times through a sliding window of slow_chunk_size files.
 def slow_mock_args(index):
@@ -689,6 +797,8 @@ if __name__ == "__main__":
             make_window_fixture()
         elif case_name == "reader":
             make_reader_fixtures()
+        elif case_name == "athenak":
+            make_athenak_fixtures()
         elif case_name == "slowcli":
             make_slow_cli_fixture()
         elif case_name in SLOW_CASES:
