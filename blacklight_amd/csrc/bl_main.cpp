@@ -150,7 +150,12 @@ int main(int argc, char *argv[]) {
           std::cout << err;
           return 1;
         }
-        if (run == 0) std::cerr << bl_snapshot_warnings(snap);
+        if (run == 0) {   // the reference's order: reader constructor, the integrators' constructors, then the file
+          const std::string warnings = bl_snapshot_warnings(snap);
+          const size_t setup = bl_snapshot_setup_warning_bytes(snap);
+          std::cerr << warnings.substr(0, setup) << bl_warnings(ctx) << warnings.substr(setup);
+          bl_warnings_clear(ctx);
+        }
         g = *bl_snapshot_grid(snap);
       }
       const int rc = bl_set_grid(ctx, &g);

@@ -17,6 +17,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <cctype>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -28,6 +29,7 @@
 
 #include "../../include/blacklight_amd.h"
 #include "bl_internal.h"
+#include "blmath.h"
 
 namespace {
 
@@ -423,6 +425,25 @@ std::vector<float> DecodeFloats(const RawArray &raw, std::vector<uint64_t> *dims
   return owned;
 }
 
+// IEEE double-precision scalars / arrays (the header values of iharm3d files)
+std::vector<double> DecodeDoubles(const RawArray &raw) {
+  const TypeHeader t = ReadTypeHeader(raw.datatype);
+  if (t.type_class != 1) Fail("Unexpected HDF5 datatype class.");
+  if (t.size != 8) Fail("Unexpected double size.");
+  const bool big_endian = t.bits0 & 0x01;
+  if (t.bits0 & 0x40) Fail("Unexpected HDF5 floating-point byte order.");
+  if (t.bits0 & 0x0e) Fail("Unexpected HDF5 floating-point padding.");
+  if ((t.bits0 & 0x30) != 0x20) Fail("Unexpected HDF5 floating-point mantissa normalization.");
+  const Span &d = raw.datatype;
+  if (t.bits1 != 63 || d.Get<uint16_t>(8) != 0 || d.Get<uint16_t>(10) != 64 || d.Get<uint8_t>(12) != 52
+      || d.Get<uint8_t>(13) != 11 || d.Get<uint8_t>(14) != 0 || d.Get<uint8_t>(15) != 52 || d.Get<uint32_t>(16) != 1023)
+    Fail("Unexpected HDF5 double-precision floating-point bit layout.");
+  const uint64_t count = Product(Dimensions(raw.dataspace));
+  std::vector<double> values(count);
+  for (uint64_t n = 0; n < count; n++) values[n] = Element<double>(raw.data, n, big_endian);
+  return values;
+}
+
 std::vector<std::string> DecodeStrings(const RawArray &raw) {
   const TypeHeader t = ReadTypeHeader(raw.datatype);
   if (t.type_class != 3) Fail("Unexpected HDF5 datatype class.");
@@ -474,6 +495,7 @@ struct bl_snapshot {
   std::vector<int32_t> levels, locations;
   double time = 0.0;
   std::string warnings, file;
+  size_t setup_warning_bytes = 0;   // leading part of `warnings` that comes from the constructor's checks
 };
 
 namespace {
@@ -507,9 +529,8 @@ void ReaderSetup(const bl_params &p, bl_snapshot *s) {
     Require(p, {BL_P_slow_t_start, BL_P_slow_dt});
     if (p.slow_dt <= 0.0) Fail("Must have positive time interval slow_dt.");
   }
-  if (p.simulation_format != BL_SIMFMT_ATHENA && p.simulation_format != BL_SIMFMT_ATHENAK)
-    Fail("Only simulation_format = athena and athenak have native readers; other formats must be handed over through bl_set_grid().",
-         BL_E_UNSUPPORTED);
+  if (p.simulation_format != BL_SIMFMT_ATHENA && p.simulation_format != BL_SIMFMT_ATHENAK && p.simulation_format != BL_SIMFMT_IHARM3D)
+    Fail("simulation_format = harm3d has no native reader; hand its arrays over through bl_set_grid().", BL_E_UNSUPPORTED);
   Require(p, {BL_P_plasma_mu, BL_P_plasma_model});
   double gamma = 0.0, gamma_i = 0.0, gamma_e = 0.0;
   if (p.plasma_model == BL_PLASMA_TI_TE_BETA) {
@@ -521,10 +542,15 @@ void ReaderSetup(const bl_params &p, bl_snapshot *s) {
     } else {
       // :108-134: athena needs all three from the input; athenak may take plasma_gamma from the file
       if (p.simulation_format == BL_SIMFMT_ATHENA) Require(p, {BL_P_plasma_gamma});
-      Require(p, {BL_P_plasma_gamma_i, BL_P_plasma_gamma_e});
       if (p.has[BL_P_plasma_gamma]) gamma = p.plasma_gamma;
-      gamma_i = p.plasma_gamma_i;
-      gamma_e = p.plasma_gamma_e;
+      if (p.simulation_format == BL_SIMFMT_IHARM3D) {   // may come from the file (header/gam_p, header/gam_e)
+        if (p.has[BL_P_plasma_gamma_i]) gamma_i = p.plasma_gamma_i;
+        if (p.has[BL_P_plasma_gamma_e]) gamma_e = p.plasma_gamma_e;
+      } else {
+        Require(p, {BL_P_plasma_gamma_i, BL_P_plasma_gamma_e});
+        gamma_i = p.plasma_gamma_i;
+        gamma_e = p.plasma_gamma_e;
+      }
     }
   } else {
     Require(p, {BL_P_simulation_kappa_name});
@@ -875,10 +901,221 @@ void ReadAthenaK(const bl_params &p, int file_number, bl_snapshot *s) {
   d.n_3_root = 0;   // the reference sets it for HDF5 files only; it is read for spherical coordinates alone
 }
 
+// ------------------------------------------------------------------------------------------------
+// iharm3d dumps (simulation_format = iharm3d) in modified Kerr-Schild coordinates (header/metric = MKS, read with
+// simulation_coord = sks): Read (simulation_reader.cpp:354-428, :598-657, :782-807), VerifyVariablesHarm
+// (:1302-1413), ConvertCoordinates and ConvertPrimitives3 (simulation_geometry.cpp:29-83, :95-230). One block:
+// x^1 = log r, x^2 in [0, 1] with theta = pi x^2 + (1 - h) / 2 sin(2 pi x^2), x^3 = phi, all uniform;
+// "prims" [n1][n2][n3][n_prim] with internal energy in place of pressure and velocity / field components on the
+// modified coordinates' basis. The reader hands over a standard spherical Kerr-Schild grid: coordinates converted,
+// p = (gamma - 1) u, vectors re-expressed (normal-frame velocity, lab-frame field) cell by cell.
+// FMKS / MMKS grids (simulation_coord = fmks) are not built.
+void ReadIharm3d(const bl_params &p, int file_number, bl_snapshot *s) {
+  s->file = p.simulation_file.s;
+  if (file_number >= 0) s->file = FormatFilename(s->file, file_number);
+  const Hdf5File file(s->file);
+  auto scalar = [&](const std::string &path) {
+    const std::vector<double> v = DecodeDoubles(file.Dataset(path));
+    if (v.empty()) Fail("Array dimension mismatch.");
+    return v[0];
+  };
+  auto integer = [&](const std::string &path) {
+    const std::vector<int32_t> v = DecodeInts(file.Dataset(path), nullptr);
+    if (v.empty()) Fail("Array dimension mismatch.");
+    return v[0];
+  };
+  s->time = scalar("t");
+  // metric (:364-428)
+  const std::vector<std::string> metric_names = DecodeStrings(file.Dataset("header/metric"));
+  if (metric_names.empty()) Fail("Array dimension mismatch.");
+  const std::string metric = metric_names[0];
+  if (p.simulation_coord != BL_COORD_SKS && p.simulation_coord != BL_COORD_FMKS) Fail("Invalid simulation_coord for Harm format.");
+  std::string metric_lower = metric;
+  for (char &c : metric_lower) c = static_cast<char>(std::tolower(static_cast<unsigned char>(c)));
+  if (metric != "MKS" && metric != "MMKS" && metric != "FMKS")
+    Warn(s, "Given metric mks does not match file value of " + metric + "; ignoring the latter.");
+  const double metric_a = scalar("header/geom/" + metric_lower + "/a");
+  const double metric_h = scalar("header/geom/" + metric_lower + "/hslope");
+  if (metric_a != p.simulation_a) {
+    std::ostringstream message;
+    message << "Given spin of " << p.simulation_a << " does not match file value of " << metric_a << "; ignoring the latter.";
+    Warn(s, message.str());
+  }
+  if (p.simulation_coord == BL_COORD_FMKS)
+    Fail("simulation_coord = fmks (FMKS / MMKS grids of iharm3d) is not built.", BL_E_UNSUPPORTED);
+
+  // coordinates (:622-656) and their conversion to r, theta (simulation_geometry.cpp:62-81)
+  const long n[3] = {integer("header/n1"), integer("header/n2"), integer("header/n3")};
+  std::vector<double> x2v_alt;
+  for (int a = 0; a < 3; a++) {
+    if (n[a] < 1 || n[a] > 65536) Fail("Array dimension mismatch.");
+    const double start = scalar("header/geom/startx" + std::to_string(a + 1)), dx = scalar("header/geom/dx" + std::to_string(a + 1));
+    std::vector<double> &xf = s->coords[a], &xv = s->coords[3 + a];
+    xf.assign(n[a] + 1, 0.0);
+    xv.assign(n[a], 0.0);
+    xf[0] = start;
+    for (long i = 0; i < n[a]; i++) {
+      xf[i + 1] = start + static_cast<double>(i + 1) * dx;
+      xv[i] = 0.5 * (xf[i] + xf[i + 1]);
+    }
+  }
+  x2v_alt = s->coords[4];
+  for (double &x : s->coords[0]) x = bl_exp(x);
+  for (double &x : s->coords[3]) x = bl_exp(x);
+  for (double &x : s->coords[1]) x = kPi * x + (1.0 - metric_h) / 2.0 * bl_sin(2.0 * kPi * x);
+  for (double &x : s->coords[4]) x = kPi * x + (1.0 - metric_h) / 2.0 * bl_sin(2.0 * kPi * x);
+
+  // VerifyVariablesHarm
+  const int n_prim = integer("header/n_prim");
+  const std::vector<std::string> names = DecodeStrings(file.Dataset("header/prim_names"));
+  if (n_prim != static_cast<int>(names.size())) Fail("Inconsistency in number of primitive variables.");
+  auto locate = [&](const std::string &name, const char *message) {
+    for (int v = 0; v < n_prim; v++)
+      if (names[v] == name) return v;
+    Fail(message);
+  };
+  bl_grid_desc &d = s->desc;
+  d.ind_rho = locate("RHO", "Unable to locate \"RHO\" slice of \"prims\" in data file.");
+  d.ind_pgas = locate("UU", "Unable to locate \"UU\" slice of \"prims\" in data file.");
+  d.ind_kappa = 0;
+  if (p.plasma_model == BL_PLASMA_CODE_KAPPA)
+    d.ind_kappa = locate(p.simulation_kappa_name.s, "Unable to locate electron entropy slice of \"prims\" in data file.");
+  d.ind_uu1 = locate("U1", "Unable to locate \"U1\" slice of \"prims\" in data file.");
+  d.ind_uu2 = locate("U2", "Unable to locate \"U2\" slice of \"prims\" in data file.");
+  d.ind_uu3 = locate("U3", "Unable to locate \"U3\" slice of \"prims\" in data file.");
+  d.ind_bb1 = locate("B1", "Unable to locate \"B1\" slice of \"prims\" in data file.");
+  d.ind_bb2 = locate("B2", "Unable to locate \"B2\" slice of \"prims\" in data file.");
+  d.ind_bb3 = locate("B3", "Unable to locate \"B3\" slice of \"prims\" in data file.");
+  auto adiabatic_index = [&](const char *path, bool given, double *value, const char *what, const char *missing) {
+    bool found = true;
+    double in_file = 0.0;
+    try {
+      in_file = scalar(path);
+    } catch (const ReadFailure &) {
+      found = false;
+    }
+    if (!found) {
+      if (!given) Fail(missing);
+      return;
+    }
+    if (!given) {
+      *value = in_file;
+    } else if (*value != in_file) {
+      std::ostringstream message;
+      message << "Given " << what << " adiabatic index of " << *value << " does not match file value of " << in_file << "; ignoring the latter.";
+      Warn(s, message.str());
+    }
+  };
+  adiabatic_index("header/gam", p.has[BL_P_plasma_gamma] != 0, &d.plasma_gamma, "total", "Could not find total adiabatic index in input or data file.");
+  if (p.plasma_model == BL_PLASMA_TI_TE_BETA && !p.plasma_use_p) {
+    adiabatic_index("header/gam_p", p.has[BL_P_plasma_gamma_i] != 0, &d.plasma_gamma_i, "ion", "Could not find ion adiabatic index in input or data file.");
+    adiabatic_index("header/gam_e", p.has[BL_P_plasma_gamma_e] != 0, &d.plasma_gamma_e, "electron", "Could not find electron adiabatic index in input or data file.");
+  }
+
+  // cell data: [n1][n2][n3][n_prim] -> [n_prim][1][n3][n2][n1], u -> p (:792-805)
+  const size_t cells = static_cast<size_t>(n[0]) * n[1] * n[2];
+  std::vector<float> transposed(cells * n_prim);
+  std::vector<uint64_t> dims;
+  DecodeFloats(file.Dataset("prims"), &dims, transposed.data(), transposed.size());
+  if (dims.size() != 4 || dims[0] != static_cast<uint64_t>(n[0]) || dims[1] != static_cast<uint64_t>(n[1])
+      || dims[2] != static_cast<uint64_t>(n[2]) || dims[3] != static_cast<uint64_t>(n_prim))
+    Fail("Array dimension mismatch.");
+  s->prim.assign(cells * n_prim, 0.0f);
+  auto at = [&](int v, long k, long j, long i) -> float & { return s->prim[((static_cast<size_t>(v) * n[2] + k) * n[1] + j) * n[0] + i]; };
+  for (int v = 0; v < n_prim; v++)
+    for (long k = 0; k < n[2]; k++)
+      for (long j = 0; j < n[1]; j++)
+        for (long i = 0; i < n[0]; i++) at(v, k, j, i) = transposed[((static_cast<size_t>(i) * n[1] + j) * n[2] + k) * n_prim + v];
+  const float gamma_minus_one = static_cast<float>(d.plasma_gamma - 1.0);
+  for (size_t c = 0; c < cells; c++) s->prim[static_cast<size_t>(d.ind_pgas) * cells + c] *= gamma_minus_one;
+
+  // ConvertPrimitives3 (simulation_geometry.cpp:95-230) for modified Kerr-Schild coordinates: the Jacobian is
+  // dr/dx1 = exp(x1), dtheta/dx1 = 0, dtheta/dx2 = pi + (1 - h) pi cos(2 pi x2) (:440-468)
+  const double a = p.simulation_a;
+  for (long k = 0; k < n[2]; k++)
+    for (long j = 0; j < n[1]; j++)
+      for (long i = 0; i < n[0]; i++) {
+        const double r = s->coords[3][i], th = s->coords[4][j];
+        const double x1 = bl_log(r), x2 = x2v_alt[j];
+        const double sth = bl_sin(th), cth = bl_cos(th);
+        const double uu1 = at(d.ind_uu1, k, j, i), uu2 = at(d.ind_uu2, k, j, i), uu3 = at(d.ind_uu3, k, j, i);
+        const double bb1 = at(d.ind_bb1, k, j, i), bb2 = at(d.ind_bb2, k, j, i), bb3 = at(d.ind_bb3, k, j, i);
+        const double dr_dx1 = bl_exp(x1), dth_dx1 = 0.0;
+        const double dth_dx2 = kPi + (1.0 - metric_h) * kPi * bl_cos(2.0 * kPi * x2);
+        const double sigma = r * r + a * a * cth * cth;
+        const double f = 2.0 * r / sigma;
+        const double g_tr = f, g_tth = 0.0, g_tph = -a * f * sth * sth;
+        const double g_rr = 1.0 + f, g_rth = 0.0, g_rph = -a * (1.0 + f) * sth * sth;
+        const double g_thth = sigma, g_thph = 0.0;
+        const double g_phph = (r * r + a * a + a * a * f * sth * sth) * sth * sth;
+        const double gtt = -(1.0 + f), gtr = f, gtth = 0.0, gtph = 0.0;
+        const double alpha = 1.0 / std::sqrt(-gtt);
+        const double g_01 = dr_dx1 * g_tr + dth_dx1 * g_tth;
+        const double g_02 = dth_dx2 * g_tth;
+        const double g_03 = g_tph;
+        const double g_11 = dr_dx1 * dr_dx1 * g_rr + 2.0 * dr_dx1 * dth_dx1 * g_rth + dth_dx1 * dth_dx1 * g_thth;
+        const double g_12 = dr_dx1 * dth_dx2 * g_rth + dth_dx1 * dth_dx2 * g_thth;
+        const double g_13 = dr_dx1 * g_rph + dth_dx1 * g_thph;
+        const double g_22 = dth_dx2 * dth_dx2 * g_thth;
+        const double g_23 = dth_dx2 * g_thph;
+        const double g_33 = g_phph;
+        const double g00 = gtt;
+        const double g01 = gtr / dr_dx1;
+        const double g02 = g_tth / dth_dx2 - dth_dx1 * g_tr / (dr_dx1 * dth_dx2);
+        const double g03 = gtph;
+        const double alpha_mod = 1.0 / std::sqrt(-g00);
+        const double uu0 = std::sqrt(1.0 + g_11 * uu1 * uu1 + 2.0 * g_12 * uu1 * uu2 + 2.0 * g_13 * uu1 * uu3 + g_22 * uu2 * uu2
+                                     + 2.0 * g_23 * uu2 * uu3 + g_33 * uu3 * uu3);
+        const double u0 = uu0 / alpha_mod;
+        const double u1 = uu1 - alpha_mod * g01 * uu0;
+        const double u2 = uu2 - alpha_mod * g02 * uu0;
+        const double u3 = uu3 - alpha_mod * g03 * uu0;
+        const double u_1 = g_01 * u0 + g_11 * u1 + g_12 * u2 + g_13 * u3;
+        const double u_2 = g_02 * u0 + g_12 * u1 + g_22 * u2 + g_23 * u3;
+        const double u_3 = g_03 * u0 + g_13 * u1 + g_23 * u2 + g_33 * u3;
+        const double ut = u0;
+        const double ur = dr_dx1 * u1;
+        const double uth = dth_dx1 * u1 + dth_dx2 * u2;
+        const double uph = u3;
+        const double uur = ur + alpha * alpha * gtr * ut;
+        const double uuth = uth + alpha * alpha * gtth * ut;
+        const double uuph = uph + alpha * alpha * gtph * ut;
+        const double b0 = u_1 * bb1 + u_2 * bb2 + u_3 * bb3;
+        const double b1 = (bb1 + b0 * u1) / u0;
+        const double b2 = (bb2 + b0 * u2) / u0;
+        const double b3 = (bb3 + b0 * u3) / u0;
+        const double bt = b0;
+        const double br = dr_dx1 * b1;
+        const double bth = dth_dx1 * b1 + dth_dx2 * b2;
+        const double bph = b3;
+        at(d.ind_uu1, k, j, i) = static_cast<float>(uur);
+        at(d.ind_uu2, k, j, i) = static_cast<float>(uuth);
+        at(d.ind_uu3, k, j, i) = static_cast<float>(uuph);
+        at(d.ind_bb1, k, j, i) = static_cast<float>(br * ut - bt * ur);
+        at(d.ind_bb2, k, j, i) = static_cast<float>(bth * ut - bt * uth);
+        at(d.ind_bb3, k, j, i) = static_cast<float>(bph * ut - bt * uph);
+      }
+  s->levels.assign(1, 0);
+  s->locations.assign(3, 0);
+  d.n_blocks = 1;
+  d.n_i = static_cast<int32_t>(n[0]);
+  d.n_j = static_cast<int32_t>(n[1]);
+  d.n_k = static_cast<int32_t>(n[2]);
+  d.n_var = n_prim;
+  d.prim = s->prim.data();
+  d.x1f = s->coords[0].data(); d.x2f = s->coords[1].data(); d.x3f = s->coords[2].data();
+  d.x1v = s->coords[3].data(); d.x2v = s->coords[4].data(); d.x3v = s->coords[5].data();
+  d.levels = s->levels.data();
+  d.locations = s->locations.data();
+  d.n_3_root = 0;
+}
+
 // Either format
 void ReadSnapshot(const bl_params &p, int file_number, bl_snapshot *s) {
   if (p.simulation_format == BL_SIMFMT_ATHENAK)
     ReadAthenaK(p, file_number, s);
+  else if (p.simulation_format == BL_SIMFMT_IHARM3D)
+    ReadIharm3d(p, file_number, s);
   else
     ReadAthena(p, file_number, s);
 }
@@ -901,6 +1138,7 @@ int bl_snapshot_open(const bl_params *p, int snapshot, bl_snapshot **out, char *
   try {
     s = new bl_snapshot;
     ReaderSetup(*p, s);
+    s->setup_warning_bytes = s->warnings.size();
     if (p->slow_light_on) Fail("slow_light_on = true: the window of files is read by bl_slow_light_read().", BL_E_STATE);
     ReadSnapshot(*p, p->simulation_multiple ? p->simulation_start + snapshot : -1, s);   // :305-319
     *out = s;
@@ -926,6 +1164,7 @@ int bl_snapshot_open_number(const bl_params *p, int file_number, bl_snapshot **o
   try {
     s = new bl_snapshot;
     ReaderSetup(*p, s);
+    s->setup_warning_bytes = s->warnings.size();
     ReadSnapshot(*p, file_number, s);
     *out = s;
     return BL_OK;
@@ -1063,6 +1302,7 @@ const bl_grid_desc *bl_snapshot_grid(const bl_snapshot *s) { return s != nullptr
 double bl_snapshot_time(const bl_snapshot *s) { return s != nullptr ? s->time : 0.0; }
 
 const char *bl_snapshot_warnings(const bl_snapshot *s) { return s != nullptr ? s->warnings.c_str() : ""; }
+size_t bl_snapshot_setup_warning_bytes(const bl_snapshot *s) { return s != nullptr ? s->setup_warning_bytes : 0; }
 
 const char *bl_snapshot_file(const bl_snapshot *s) { return s != nullptr ? s->file.c_str() : ""; }
 

@@ -206,12 +206,17 @@ typedef struct bl_grid_desc {
  * err receives "Error: ...\n" (reference texts). Each call reads its file completely; the reference
  * re-uses block layout and coordinates of the first file for later files of a series.
  * simulation_format = athenak: the AthenaK binary dump reader (simulation_reader.cpp:915-1131, :434-589) behind the same calls.
- * iharm3d / harm3d return BL_E_UNSUPPORTED. With slow_light_on use bl_slow_light_read(). */
+ * simulation_format = iharm3d: modified Kerr-Schild (MKS) dumps read with simulation_coord = sks (coordinates and vector
+ * components converted like SimulationReader does); fmks grids and simulation_format = harm3d return BL_E_UNSUPPORTED. With slow_light_on use bl_slow_light_read(). */
 typedef struct bl_snapshot bl_snapshot;
 BL_API int bl_snapshot_open(const bl_params *p, int snapshot, bl_snapshot **out, char *err, size_t err_len);
 BL_API const bl_grid_desc *bl_snapshot_grid(const bl_snapshot *s);
 BL_API double bl_snapshot_time(const bl_snapshot *s);              /* file attribute "Time"           */
 BL_API const char *bl_snapshot_warnings(const bl_snapshot *s);     /* "Warning: ...\n" lines           */
+/* How many leading bytes of bl_snapshot_warnings() stem from SimulationReader's constructor checks (the reference
+ * prints those before RadiationIntegrator's constructor warnings - bl_warnings() after bl_init() - and the file's
+ * own warnings after them). */
+BL_API size_t bl_snapshot_setup_warning_bytes(const bl_snapshot *s);
 BL_API const char *bl_snapshot_file(const bl_snapshot *s);         /* file name actually opened       */
 /* MeshBlock table: returns n_blocks; *levels -> [n_blocks], *locations -> [n_blocks][3] */
 BL_API int bl_snapshot_blocks(const bl_snapshot *s, const int32_t **levels, const int32_t **locations);

@@ -119,8 +119,8 @@ def test_adiabatic_indices_and_constructor_rules(built_library, expected):
         with pytest.raises(BlacklightError) as info:
             Snapshot(_params(expected, **dict(slow, **change)))
         assert str(info.value) == "Error: " + message
-    with pytest.raises(BlacklightError, match="Only simulation_format = athena") as info:
-        Snapshot(_params(expected, simulation_format="iharm3d"))
+    with pytest.raises(BlacklightError, match="simulation_format = harm3d has no native reader") as info:
+        Snapshot(_params(expected, simulation_format="harm3d"))
     assert info.value.code == 3
 
 
@@ -266,3 +266,61 @@ def test_athenak_malformed_files(built_library, athenak, tmp_path):
     with Snapshot(_athenak_params(athenak, "athenak_single", plasma_gamma=1.5)) as s:
         assert "Warning: Given total adiabatic index of 1.5 does not match file value of 1.66667; ignoring the latter.\n" in s.warnings
         assert s.desc().plasma_gamma == 1.5
+
+
+# ---------------------------------------------------------------------------------------------- iharm3d dumps
+@pytest.fixture(scope="module")
+def iharm3d():
+    return np.load(os.path.join(READER_DIR, "expected_iharm3d.npz"), allow_pickle=False)
+
+
+def _iharm3d_params(iharm3d, case, **overrides):
+    params = json.loads(str(iharm3d[f"{case}_params"]))
+    params["simulation_file"] = os.path.join(READER_DIR, "iharm3d_mock.h5")
+    params.update(overrides)
+    return Params.from_dict({k: v for k, v in params.items() if v is not None})
+
+
+def test_iharm3d_file_against_its_athena_twin(built_library, iharm3d):
+    """simulation_format = iharm3d, modified Kerr-Schild coordinates (simulation_reader.cpp:354-428, :622-656, :782-807;
+    simulation_geometry.cpp:29-83, :95-230). The reference's mock script writes the same fields once as an Athena++ file
+    (normal-frame velocity and field on the spherical Kerr-Schild basis) and once as an iharm3d dump (internal energy,
+    components on the log-r / x2 basis): after the reader's conversions the two must agree to single precision. The
+    bit-level pin is the reference's image of this file (tests/test_gpu_adaptive_cli.py)."""
+    with Snapshot(_iharm3d_params(iharm3d, "plain")) as s:
+        arrays = s.arrays()
+        d = s.desc()
+        assert s.time == 0.0 and s.warnings == ""
+        assert d.plasma_gamma == 13.0 / 9.0
+        levels, locations = s.blocks
+    assert np.array_equal(levels, [0]) and np.array_equal(locations, [[0, 0, 0]])
+    assert arrays["indices"] == dict(ind_rho=0, ind_pgas=1, ind_kappa=0, ind_uu1=2, ind_uu2=3, ind_uu3=4, ind_bb1=5, ind_bb2=6, ind_bb3=7)
+    twin = iharm3d["twin_prim"]
+    assert arrays["prim"].shape == (8, 1) + twin.shape[1:]
+    for name in ("x1f", "x2f", "x3f", "x1v", "x2v", "x3v"):
+        # the twin holds float32 coordinates, the iharm3d header doubles: agreement to single precision
+        # (cell centres of the log-spaced radial grid are geometric means here, arithmetic ones in the twin)
+        tolerance = 1.0e-2 if name == "x1v" else 1.0e-6
+        assert np.allclose(arrays[name][0], iharm3d[f"twin_{name}"], rtol=tolerance, atol=1.0e-6), name
+    # scalars are the same numbers; vector components pass through the radial Jacobian at the reader's cell centres
+    # (geometric means of the faces, the script's are arithmetic: 0.5 % apart on this coarse grid)
+    scale = np.abs(twin).reshape(8, -1).max(axis=1)
+    for v in range(8):
+        tolerance = 2.0e-6 if v < 2 else 1.0e-2
+        assert np.abs(arrays["prim"][v, 0] - twin[v]).max() <= tolerance * scale[v] + 1.0e-12, v
+
+
+def test_iharm3d_messages(built_library, iharm3d, tmp_path):
+    with Snapshot(_iharm3d_params(iharm3d, "spin")) as s:   # the reader's part of the reference's stderr for this case
+        assert s.warnings == ("Warning: Given spin of 0.5 does not match file value of 0; ignoring the latter.\n"
+                              "Warning: Given total adiabatic index of 1.5 does not match file value of 1.44444; ignoring the latter.\n")
+        d = s.desc()
+        assert (d.plasma_gamma, d.plasma_gamma_i, d.plasma_gamma_e) == (1.5, 1.6666666666666667, 1.3333333333333333)
+    with pytest.raises(BlacklightError, match="Could not find ion adiabatic index in input or data file."):
+        Snapshot(_iharm3d_params(iharm3d, "spin", plasma_gamma_i=None))
+    with pytest.raises(BlacklightError, match="Invalid simulation_coord for Harm format."):
+        Snapshot(_iharm3d_params(iharm3d, "plain", simulation_coord="cks"))
+    with pytest.raises(BlacklightError, match="fmks"):
+        Snapshot(_iharm3d_params(iharm3d, "plain", simulation_coord="fmks"))
+    with pytest.raises(BlacklightError, match="electron entropy slice"):
+        Snapshot(_iharm3d_params(iharm3d, "plain", plasma_model="code_kappa", simulation_kappa_name="KEL"))

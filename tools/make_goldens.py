@@ -695,6 +695,49 @@ def make_athenak_fixtures():
 
 
 # ------------------------------------------------------------------------------------------------
+# iharm3d dumps (tests/golden/reader/iharm3d_*.h5): written by the reference's own mock script (--format iharm3d:
+# modified Kerr-Schild coordinates, header/metric = MKS), imaged by the reference with simulation_coord = sks.
+def make_iharm3d_fixtures():
+    import h5py
+    out_dir = os.path.join(OUT, "reader")
+    workdir = os.path.join(WORK, "iharm3d")
+    for sub in (out_dir, os.path.join(workdir, "data"), os.path.join(workdir, "output")):
+        os.makedirs(sub, exist_ok=True)
+    expected = {}
+    mock = dict(n_r=16, n_th=12, n_ph=16, pert_amp=0.3, pert_n_ph=3, Bph_amp=0.25)
+    args = []
+    for key, value in mock.items():
+        args += [f"--{key}", str(value)]
+    name = "iharm3d_mock.h5"
+    path = os.path.join(workdir, "data", name)
+    subprocess.run([sys.executable, "-W", "ignore", MOCK_SCRIPT, path, "--format", "iharm3d"] + args, check=True)
+    twin = os.path.join(workdir, "data", "twin.athdf")   # the same fields as the script writes them for Athena++
+    subprocess.run([sys.executable, "-W", "ignore", MOCK_SCRIPT, twin] + args, check=True)
+    with open(path, "rb") as src, open(os.path.join(out_dir, name), "wb") as dst:
+        dst.write(src.read())
+    with h5py.File(twin, "r") as f:
+        expected["twin_prim"] = np.concatenate([f["prim"][:, 0], f["B"][:, 0]], axis=0).astype(np.float32)
+        for key in ("x1f", "x2f", "x3f", "x1v", "x2v", "x3v"):
+            expected[f"twin_{key}"] = f[key][0].astype(np.float64)
+    for case, overrides in (("plain", dict(image_tau="true")),
+                            ("spin", dict(simulation_a=0.5, plasma_use_p="false", plasma_gamma=1.5, plasma_gamma_i=1.6666666666666667,
+                                          plasma_gamma_e=1.3333333333333333, simulation_interp="false"))):
+        params = dict(SIM_BASE)
+        params.update(camera_resolution=16, checkpoint_geodesic_save="false", simulation_format="iharm3d", simulation_coord="sks",
+                      simulation_file="data/" + name)
+        params.update(overrides)
+        write_input(os.path.join(workdir, "case.input"), params)
+        expected[f"{case}_params"] = json.dumps(params)
+        for tier, preload in (("A", False), ("B", True)):
+            expected[f"{case}_{tier}_warnings"] = run_reference(workdir, "case.input", preload)
+            npz = np.load(os.path.join(workdir, "output", "out.npz"))
+            for key in npz.files:
+                expected[f"{case}_{tier}_{key}"] = npz[key]
+        print("iharm3d", case, "I_nu max", float(np.nanmax(expected[f"{case}_B_I_nu"])), repr(expected[f"{case}_B_warnings"]))
+    np.savez_compressed(os.path.join(out_dir, "expected_iharm3d.npz"), **expected)
+
+
+# ------------------------------------------------------------------------------------------------
 # Slow light (tests/golden/slow_*.npz): eleven small mocks with file times 0, 20, ..., 200 and varying
 # perturbations; the reference renders a few camera times through a sliding window of slow_chunk_size files.
 def slow_mock_args(index):
@@ -799,6 +842,8 @@ if __name__ == "__main__":
             make_reader_fixtures()
         elif case_name == "athenak":
             make_athenak_fixtures()
+        elif case_name == "iharm3d":
+            make_iharm3d_fixtures()
         elif case_name == "slowcli":
             make_slow_cli_fixture()
         elif case_name in SLOW_CASES:
