@@ -529,8 +529,6 @@ void ReaderSetup(const bl_params &p, bl_snapshot *s) {
     Require(p, {BL_P_slow_t_start, BL_P_slow_dt});
     if (p.slow_dt <= 0.0) Fail("Must have positive time interval slow_dt.");
   }
-  if (p.simulation_format != BL_SIMFMT_ATHENA && p.simulation_format != BL_SIMFMT_ATHENAK && p.simulation_format != BL_SIMFMT_IHARM3D)
-    Fail("simulation_format = harm3d has no native reader; hand its arrays over through bl_set_grid().", BL_E_UNSUPPORTED);
   Require(p, {BL_P_plasma_mu, BL_P_plasma_model});
   double gamma = 0.0, gamma_i = 0.0, gamma_e = 0.0;
   if (p.plasma_model == BL_PLASMA_TI_TE_BETA) {
@@ -1110,12 +1108,137 @@ void ReadIharm3d(const bl_params &p, int file_number, bl_snapshot *s) {
   d.n_3_root = 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// harm3d dumps (simulation_format = harm3d; Read simulation_reader.cpp:360-361, :661-716, :808-846; ConvertCoordinates
+// and ConvertPrimitives4 simulation_geometry.cpp:29-83, :242-311): one line of text - time, n1 n2 n3, start and spacing
+// of (log r, x2, phi), spin, adiabatic index, a radius, h-slope, a count - then float32 records of 16 (17 with an
+// electron entropy) values per cell, [n1][n2][n3][...]: six coordinates, rho, u, u^mu, b^mu on the modified basis.
+void ReadHarm3d(const bl_params &p, int file_number, bl_snapshot *s) {
+  s->file = p.simulation_file.s;
+  if (file_number >= 0) s->file = FormatFilename(s->file, file_number);
+  if (p.simulation_coord != BL_COORD_SKS) Fail("Invalid simulation_coord for Harm format.");
+  FileMap map;
+  map.Open(s->file);
+  const size_t size = map.Size();
+  const char *text = size > 0 ? reinterpret_cast<const char *>(map.At(0, size)) : "";
+  size_t pos = 0;
+  auto number = [&]() {   // operator>> on the stream: skip white space, parse one number
+    while (pos < size && std::isspace(static_cast<unsigned char>(text[pos]))) pos++;
+    const size_t begin = pos;
+    while (pos < size && !std::isspace(static_cast<unsigned char>(text[pos]))) pos++;
+    if (begin == pos) Fail("Unexpected end of harm3d file.");
+    return std::strtod(std::string(text + begin, pos - begin).c_str(), nullptr);
+  };
+  s->time = number();
+  long n[3];
+  for (int a = 0; a < 3; a++) {
+    n[a] = static_cast<long>(number());
+    if (n[a] < 1 || n[a] > 65536) Fail("Array dimension mismatch.");
+  }
+  double start[3], dx[3];
+  for (int a = 0; a < 3; a++) start[a] = number();
+  for (int a = 0; a < 3; a++) dx[a] = number();
+  const double metric_a = number();
+  if (metric_a != p.simulation_a) {
+    std::ostringstream message;
+    message << "Given spin of " << p.simulation_a << " does not match file value of " << metric_a << "; ignoring the latter.";
+    Warn(s, message.str());
+  }
+  bl_grid_desc &d = s->desc;
+  const double file_gamma = number();
+  if (!p.has[BL_P_plasma_gamma]) {
+    d.plasma_gamma = file_gamma;
+  } else if (d.plasma_gamma != file_gamma) {
+    std::ostringstream message;
+    message << "Given total adiabatic index of " << d.plasma_gamma << " does not match file value of " << file_gamma << "; ignoring the latter.";
+    Warn(s, message.str());
+  }
+  number();
+  const double metric_h = number();
+  number();
+  pos += 1;   // the newline
+  for (int a = 0; a < 3; a++) {
+    std::vector<double> &xf = s->coords[a], &xv = s->coords[3 + a];
+    xf.assign(n[a] + 1, 0.0);
+    xv.assign(n[a], 0.0);
+    xf[0] = start[a];
+    for (long i = 0; i < n[a]; i++) {
+      xf[i + 1] = start[a] + static_cast<double>(i + 1) * dx[a];
+      xv[i] = 0.5 * (xf[i] + xf[i + 1]);
+    }
+  }
+  const std::vector<double> x2v_alt = s->coords[4];
+  for (double &x : s->coords[0]) x = bl_exp(x);
+  for (double &x : s->coords[3]) x = bl_exp(x);
+  for (double &x : s->coords[1]) x = kPi * x + (1.0 - metric_h) / 2.0 * bl_sin(2.0 * kPi * x);
+  for (double &x : s->coords[4]) x = kPi * x + (1.0 - metric_h) / 2.0 * bl_sin(2.0 * kPi * x);
+
+  const int n_var = p.plasma_model == BL_PLASMA_CODE_KAPPA ? 11 : 10;   // rho, u, u^0..3, b^0..3 (, kappa)
+  const int record = n_var + 6;
+  const size_t cells = static_cast<size_t>(n[0]) * n[1] * n[2];
+  const uint8_t *data = map.At(pos, cells * record * 4);
+  s->prim.assign(cells * n_var, 0.0f);
+  auto at = [&](int v, long k, long j, long i) -> float & { return s->prim[((static_cast<size_t>(v) * n[2] + k) * n[1] + j) * n[0] + i]; };
+  for (int v = 0; v < n_var; v++)
+    for (long k = 0; k < n[2]; k++)
+      for (long j = 0; j < n[1]; j++)
+        for (long i = 0; i < n[0]; i++)
+          std::memcpy(&at(v, k, j, i), data + 4 * (((static_cast<size_t>(i) * n[1] + j) * n[2] + k) * record + v + 6), 4);
+  const float gamma_minus_one = static_cast<float>(d.plasma_gamma - 1.0);
+  for (size_t c = 0; c < cells; c++) s->prim[cells + c] *= gamma_minus_one;
+  // ConvertPrimitives4 (simulation_geometry.cpp:242-311)
+  const double a = p.simulation_a;
+  for (long k = 0; k < n[2]; k++)
+    for (long j = 0; j < n[1]; j++)
+      for (long i = 0; i < n[0]; i++) {
+        const double r = s->coords[3][i], th = s->coords[4][j];
+        const double cth = bl_cos(th);
+        const double x2 = x2v_alt[j];
+        const double u0 = at(2, k, j, i), u1 = at(3, k, j, i), u2 = at(4, k, j, i), u3 = at(5, k, j, i);
+        const double b0 = at(6, k, j, i), b1 = at(7, k, j, i), b2 = at(8, k, j, i), b3 = at(9, k, j, i);
+        const double dr_dx1 = r;
+        const double dth_dx2 = kPi + (1.0 - metric_h) * kPi * bl_cos(2.0 * kPi * x2);
+        const double sigma = r * r + a * a * cth * cth;
+        const double f = 2.0 * r / sigma;
+        const double gtt = -(1.0 + f), gtr = f, gtth = 0.0, gtph = 0.0;
+        const double alpha = 1.0 / std::sqrt(-gtt);
+        const double ut = u0, ur = dr_dx1 * u1, uth = dth_dx2 * u2, uph = u3;
+        const double uur = ur + alpha * alpha * gtr * ut;
+        const double uuth = uth + alpha * alpha * gtth * ut;
+        const double uuph = uph + alpha * alpha * gtph * ut;
+        const double bt = b0, br = dr_dx1 * b1, bth = dth_dx2 * b2, bph = b3;
+        at(3, k, j, i) = static_cast<float>(uur);
+        at(4, k, j, i) = static_cast<float>(uuth);
+        at(5, k, j, i) = static_cast<float>(uuph);
+        at(7, k, j, i) = static_cast<float>(br * ut - bt * ur);
+        at(8, k, j, i) = static_cast<float>(bth * ut - bt * uth);
+        at(9, k, j, i) = static_cast<float>(bph * ut - bt * uph);
+      }
+  s->levels.assign(1, 0);
+  s->locations.assign(3, 0);
+  d.n_blocks = 1;
+  d.n_i = static_cast<int32_t>(n[0]);
+  d.n_j = static_cast<int32_t>(n[1]);
+  d.n_k = static_cast<int32_t>(n[2]);
+  d.n_var = n_var;
+  d.prim = s->prim.data();
+  d.x1f = s->coords[0].data(); d.x2f = s->coords[1].data(); d.x3f = s->coords[2].data();
+  d.x1v = s->coords[3].data(); d.x2v = s->coords[4].data(); d.x3v = s->coords[5].data();
+  d.ind_rho = 0; d.ind_pgas = 1; d.ind_uu1 = 3; d.ind_uu2 = 4; d.ind_uu3 = 5; d.ind_bb1 = 7; d.ind_bb2 = 8; d.ind_bb3 = 9;
+  d.ind_kappa = n_var == 11 ? 10 : 0;
+  d.levels = s->levels.data();
+  d.locations = s->locations.data();
+  d.n_3_root = 0;
+}
+
 // Either format
 void ReadSnapshot(const bl_params &p, int file_number, bl_snapshot *s) {
   if (p.simulation_format == BL_SIMFMT_ATHENAK)
     ReadAthenaK(p, file_number, s);
   else if (p.simulation_format == BL_SIMFMT_IHARM3D)
     ReadIharm3d(p, file_number, s);
+  else if (p.simulation_format == BL_SIMFMT_HARM3D)
+    ReadHarm3d(p, file_number, s);
   else
     ReadAthena(p, file_number, s);
 }

@@ -206,8 +206,8 @@ typedef struct bl_grid_desc {
  * err receives "Error: ...\n" (reference texts). Each call reads its file completely; the reference
  * re-uses block layout and coordinates of the first file for later files of a series.
  * simulation_format = athenak: the AthenaK binary dump reader (simulation_reader.cpp:915-1131, :434-589) behind the same calls.
- * simulation_format = iharm3d: modified Kerr-Schild (MKS) dumps read with simulation_coord = sks (coordinates and vector
- * components converted like SimulationReader does); fmks grids and simulation_format = harm3d return BL_E_UNSUPPORTED. With slow_light_on use bl_slow_light_read(). */
+ * simulation_format = iharm3d / harm3d: modified Kerr-Schild (MKS) dumps read with simulation_coord = sks (coordinates and
+ * vector components converted like SimulationReader does); fmks grids return BL_E_UNSUPPORTED. With slow_light_on use bl_slow_light_read(). */
 typedef struct bl_snapshot bl_snapshot;
 BL_API int bl_snapshot_open(const bl_params *p, int snapshot, bl_snapshot **out, char *err, size_t err_len);
 BL_API const bl_grid_desc *bl_snapshot_grid(const bl_snapshot *s);

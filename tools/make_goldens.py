@@ -737,6 +737,47 @@ def make_iharm3d_fixtures():
     np.savez_compressed(os.path.join(out_dir, "expected_iharm3d.npz"), **expected)
 
 
+# harm3d dumps: the same, --format harm3d (one line of text, then float32 records)
+def make_harm3d_fixtures():
+    import h5py
+    out_dir = os.path.join(OUT, "reader")
+    workdir = os.path.join(WORK, "harm3d")
+    for sub in (out_dir, os.path.join(workdir, "data"), os.path.join(workdir, "output")):
+        os.makedirs(sub, exist_ok=True)
+    expected = {}
+    mock = dict(n_r=16, n_th=12, n_ph=16, pert_amp=0.2, pert_n_ph=5, Bph_amp=0.15, rho_amp=1.3)
+    args = []
+    for key, value in mock.items():
+        args += [f"--{key}", str(value)]
+    name = "harm3d_mock.bin"
+    path = os.path.join(workdir, "data", name)
+    subprocess.run([sys.executable, "-W", "ignore", MOCK_SCRIPT, path, "--format", "harm3d"] + args, check=True)
+    twin = os.path.join(workdir, "data", "twin.athdf")   # the same fields as the script writes them for Athena++
+    subprocess.run([sys.executable, "-W", "ignore", MOCK_SCRIPT, twin] + args, check=True)
+    with open(path, "rb") as src, open(os.path.join(out_dir, name), "wb") as dst:
+        dst.write(src.read())
+    with h5py.File(twin, "r") as f:
+        expected["twin_prim"] = np.concatenate([f["prim"][:, 0], f["B"][:, 0]], axis=0).astype(np.float32)
+        for key in ("x1f", "x2f", "x3f", "x1v", "x2v", "x3v"):
+            expected[f"twin_{key}"] = f[key][0].astype(np.float64)
+    for case, overrides in (("plain", dict(image_tau="true")),
+                            ("spin", dict(simulation_a=0.5, plasma_use_p="false", plasma_gamma=1.5, plasma_gamma_i=1.6666666666666667,
+                                          plasma_gamma_e=1.3333333333333333, simulation_interp="false"))):
+        params = dict(SIM_BASE)
+        params.update(camera_resolution=16, checkpoint_geodesic_save="false", simulation_format="harm3d", simulation_coord="sks",
+                      simulation_file="data/" + name)
+        params.update(overrides)
+        write_input(os.path.join(workdir, "case.input"), params)
+        expected[f"{case}_params"] = json.dumps(params)
+        for tier, preload in (("A", False), ("B", True)):
+            expected[f"{case}_{tier}_warnings"] = run_reference(workdir, "case.input", preload)
+            npz = np.load(os.path.join(workdir, "output", "out.npz"))
+            for key in npz.files:
+                expected[f"{case}_{tier}_{key}"] = npz[key]
+        print("harm3d", case, "I_nu max", float(np.nanmax(expected[f"{case}_B_I_nu"])), repr(expected[f"{case}_B_warnings"]))
+    np.savez_compressed(os.path.join(out_dir, "expected_harm3d.npz"), **expected)
+
+
 # ------------------------------------------------------------------------------------------------
 # Slow light (tests/golden/slow_*.npz): eleven small mocks with file times 0, 20, ..., 200 and varying
 # perturbations; the reference renders a few camera times through a sliding window of slow_chunk_size files.
@@ -844,6 +885,8 @@ if __name__ == "__main__":
             make_athenak_fixtures()
         elif case_name == "iharm3d":
             make_iharm3d_fixtures()
+        elif case_name == "harm3d":
+            make_harm3d_fixtures()
         elif case_name == "slowcli":
             make_slow_cli_fixture()
         elif case_name in SLOW_CASES:
