@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -1336,13 +1337,19 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
       cold.fallback_pgas = p.fallback_nan ? 0.0f : p.fallback_pgas;
       cold.fallback_kappa = p.fallback_nan ? 0.0f : p.fallback_kappa;
       pl.code_kappa = p.plasma_model == BL_PLASMA_CODE_KAPPA ? 1 : 0;
-      cold.cut_rho_min = p.cut_rho_min; cold.cut_rho_max = p.cut_rho_max;
-      cold.cut_n_e_min = p.cut_n_e_min; cold.cut_n_e_max = p.cut_n_e_max;
-      cold.cut_p_gas_min = p.cut_p_gas_min; cold.cut_p_gas_max = p.cut_p_gas_max;
-      cold.cut_theta_e_min = p.cut_theta_e_min; cold.cut_theta_e_max = p.cut_theta_e_max;
-      cold.cut_b_min = p.cut_b_min; cold.cut_b_max = p.cut_b_max;
-      cold.cut_sigma_min = p.cut_sigma_min; cold.cut_sigma_max = p.cut_sigma_max;
-      cold.cut_beta_inverse_min = p.cut_beta_inverse_min; cold.cut_beta_inverse_max = p.cut_beta_inverse_max;
+      // cell cuts (simulation_coefficients.cpp:361-375): "cut >= 0 and value < cut". A disabled threshold goes to the
+      // device as -inf (lower) / +inf (upper), against which no value - NaN included - compares true: same
+      // decisions, one compare per threshold
+      const double kInf = std::numeric_limits<double>::infinity();
+      auto lower = [&](double cut) { return cut >= 0.0 ? cut : -kInf; };
+      auto upper = [&](double cut) { return cut >= 0.0 ? cut : kInf; };
+      cold.cut_rho_min = lower(p.cut_rho_min); cold.cut_rho_max = upper(p.cut_rho_max);
+      cold.cut_n_e_min = lower(p.cut_n_e_min); cold.cut_n_e_max = upper(p.cut_n_e_max);
+      cold.cut_p_gas_min = lower(p.cut_p_gas_min); cold.cut_p_gas_max = upper(p.cut_p_gas_max);
+      cold.cut_theta_e_min = lower(p.cut_theta_e_min); cold.cut_theta_e_max = upper(p.cut_theta_e_max);
+      cold.cut_b_min = lower(p.cut_b_min); cold.cut_b_max = upper(p.cut_b_max);
+      cold.cut_sigma_min = lower(p.cut_sigma_min); cold.cut_sigma_max = upper(p.cut_sigma_max);
+      cold.cut_beta_inverse_min = lower(p.cut_beta_inverse_min); cold.cut_beta_inverse_max = upper(p.cut_beta_inverse_max);
       pl.any_cell_cut = (p.cut_rho_min >= 0.0 || p.cut_rho_max >= 0.0 || p.cut_n_e_min >= 0.0 || p.cut_n_e_max >= 0.0
                          || p.cut_p_gas_min >= 0.0 || p.cut_p_gas_max >= 0.0 || p.cut_theta_e_min >= 0.0
                          || p.cut_theta_e_max >= 0.0 || p.cut_b_min >= 0.0 || p.cut_b_max >= 0.0 || p.cut_sigma_min >= 0.0

@@ -1334,20 +1334,11 @@ __device__ __forceinline__ void sample_finish_simulation(const BlShadeArgs &P, c
   bool cell_cut = false;
   if (pl.any_cell_cut) {
     const BlShadeCold &cc = *P.cold;
-    cell_cut = (cc.cut_rho_min >= 0.0 && rho_cgs < cc.cut_rho_min)
-        || (cc.cut_rho_max >= 0.0 && rho_cgs > cc.cut_rho_max)
-        || (cc.cut_n_e_min >= 0.0 && n_e_cgs < cc.cut_n_e_min)
-        || (cc.cut_n_e_max >= 0.0 && n_e_cgs > cc.cut_n_e_max)
-        || (cc.cut_p_gas_min >= 0.0 && pgas_cgs < cc.cut_p_gas_min)
-        || (cc.cut_p_gas_max >= 0.0 && pgas_cgs > cc.cut_p_gas_max)
-        || (cc.cut_theta_e_min >= 0.0 && theta_e < cc.cut_theta_e_min)
-        || (cc.cut_theta_e_max >= 0.0 && theta_e > cc.cut_theta_e_max)
-        || (cc.cut_b_min >= 0.0 && bb_cgs < cc.cut_b_min)
-        || (cc.cut_b_max >= 0.0 && bb_cgs > cc.cut_b_max)
-        || (cc.cut_sigma_min >= 0.0 && sigma_cut < cc.cut_sigma_min)
-        || (cc.cut_sigma_max >= 0.0 && sigma_cut > cc.cut_sigma_max)
-        || (cc.cut_beta_inverse_min >= 0.0 && beta_inv < cc.cut_beta_inverse_min)
-        || (cc.cut_beta_inverse_max >= 0.0 && beta_inv > cc.cut_beta_inverse_max);
+    // disabled thresholds are -inf / +inf (bl_api.hip): one compare each, same decisions as "cut >= 0 and ..."
+    cell_cut = rho_cgs < cc.cut_rho_min || rho_cgs > cc.cut_rho_max || n_e_cgs < cc.cut_n_e_min || n_e_cgs > cc.cut_n_e_max
+        || pgas_cgs < cc.cut_p_gas_min || pgas_cgs > cc.cut_p_gas_max || theta_e < cc.cut_theta_e_min || theta_e > cc.cut_theta_e_max
+        || bb_cgs < cc.cut_b_min || bb_cgs > cc.cut_b_max || sigma_cut < cc.cut_sigma_min || sigma_cut > cc.cut_sigma_max
+        || beta_inv < cc.cut_beta_inverse_min || beta_inv > cc.cut_beta_inverse_max;
   }
   const bool no_field = bb1 == 0.0 && bb2 == 0.0 && bb3 == 0.0;   // :394
   out->have_coefficients = false;
