@@ -300,8 +300,6 @@ void ValidateRadiation(bl_ctx *ctx) {
             kRadMissing);
     if ((p.simulation_format == BL_SIMFMT_ATHENA || p.simulation_format == BL_SIMFMT_ATHENAK) && p.simulation_interp) {
       Require(p, {BL_P_simulation_block_interp}, kRadMissing);
-      if (p.simulation_block_interp && Has(p, BL_P_slow_light_on) && p.slow_light_on)
-        throw Failure{BL_E_UNSUPPORTED, "simulation_block_interp = true together with slow_light_on = true is not built."};
     } else if (Has(p, BL_P_simulation_block_interp)) {
       Warn(ctx, "Ignoring simulation_block_interp selection.");
     }

@@ -1165,12 +1165,49 @@ __device__ __forceinline__ void sample_slice_values(const BlShadeArgs &P, const 
   if (kappa != nullptr && val[8] <= 0.0) val[8] = first[8];
 }
 
-__device__ __forceinline__ void sample_primitives_slow(const BlShadeArgs &P, int status, uint32_t cell, int t_ind,
-                                                       double t_frac, double f_i, double f_j, double f_k, float pr[8],
+// Slow light with inter-block interpolation: the nine values of one time slice from the eight anchor cells, double,
+// with the "<= 0 -> first anchor" rule per slice (simulation_sampling.cpp:960-1033)
+__device__ __forceinline__ void sample_slice_values_advanced(const BlShadeArgs &P, const float *cells, const float *kappa,
+                                                             const unsigned int *anchors, double f_i, double f_j, double f_k,
+                                                             double val[9]) {
+  const double w_k[2] = {1.0 - f_k, f_k}, w_j[2] = {1.0 - f_j, f_j}, w_i[2] = {1.0 - f_i, f_i};
+  double first[9];
+  for (int corner = 0; corner < 8; corner++) {
+    const unsigned int cell = anchors[corner];
+    const float *c = cells + (size_t)cell * 8;
+    const double w = w_k[corner >> 2] * w_j[(corner >> 1) & 1] * w_i[corner & 1];
+    for (int v = 0; v < 9; v++) {
+      const double x = v < 8 ? (double)c[v] : (kappa != nullptr ? (double)kappa[cell] : 0.0);
+      if (corner == 0) {
+        val[v] = w * x;
+        first[v] = x;
+      } else {
+        val[v] += w * x;
+      }
+    }
+  }
+  if (val[0] <= 0.0) val[0] = first[0];
+  if (val[1] <= 0.0) val[1] = first[1];
+  if (val[8] <= 0.0) val[8] = first[8];
+}
+
+__device__ __forceinline__ void sample_primitives_slow(const BlShadeArgs &P, int status, uint32_t cell, const unsigned int *anchors,
+                                                       int t_ind, double t_frac, double f_i, double f_j, double f_k, float pr[8],
                                                        float *kappa_out) {
   const BlPlasmaDevice &pl = P.plasma;
   const BlSlowDevice &sl = P.slow;
-  if (status == kSampleInterp || status == kSampleNearest) {
+  if (status == kSampleAdvanced) {
+    const bool entropy = pl.code_kappa != 0;
+    double val[9];
+    sample_slice_values_advanced(P, sl.cells[t_ind], entropy ? sl.kappa[t_ind] : nullptr, anchors, f_i, f_j, f_k, val);
+    if (sl.interp) {
+      double next[9];
+      sample_slice_values_advanced(P, sl.cells[t_ind + 1], entropy ? sl.kappa[t_ind + 1] : nullptr, anchors, f_i, f_j, f_k, next);
+      for (int v = 0; v < 9; v++) val[v] = (1.0 - t_frac) * val[v] + t_frac * next[v];
+    }
+    for (int v = 0; v < 8; v++) pr[v] = (float)val[v];
+    *kappa_out = entropy ? (float)val[8] : 0.0f;
+  } else if (status == kSampleInterp || status == kSampleNearest) {
     const bool entropy = pl.code_kappa != 0;
     double val[9];
     sample_slice_values(P, sl.cells[t_ind], entropy ? sl.kappa[t_ind] : nullptr, status, cell, f_i, f_j, f_k, val);
@@ -1822,7 +1859,8 @@ __global__ void __launch_bounds__(256, 2) bl_shade_kernel(const BlShadeArgs P) {
       ph = l1.y;
       status = kExtended ? ((int)(tag >> 32) & 0xff) : (int)(tag >> 32);   // bits 40..: time slice (slow light only)
       if (kExtended && P.slow.n > 0) {
-        sample_primitives_slow(P, status, (uint32_t)tag, (int)(tag >> 40), P.slow.frac[idx_cur], l0.x, l0.y, l1.x, pr, &kappa_f);
+        sample_primitives_slow(P, status, (uint32_t)tag, P.anchors != nullptr ? P.anchors + idx_cur * 8 : nullptr, (int)(tag >> 40),
+                               P.slow.frac[idx_cur], l0.x, l0.y, l1.x, pr, &kappa_f);
       } else if (kExtended && status == kSampleAdvanced) {
         sample_primitives_advanced(P, P.anchors + idx_cur * 8, l0.x, l0.y, l1.x, pr, &kappa_f);
       } else {
