@@ -678,6 +678,7 @@ struct SampleShade {
   double nu_fluid_over_nu;     // -k_mu u^mu (fluid-frame frequency per unit camera frequency*factor)
   double n_e_cgs, nu_c_cgs, theta_e, sin_theta_b, kb_tt_e_cgs;   // simulation
   double cos_theta_b, sin2_theta_b, cos2_theta_b, cos_sign;       // polarized coefficients only
+  double theta_e_096, kk_0, kk_1, kk_2;   // polarized, thermal: theta_e^0.96 and K_0,1,2(1 / theta_e) - the same at every frequency
   double n_n0_fluid, fu[4];                                       // formula
   bool have_cell;              // cell_values recorded (simulation_coefficients.cpp:377-387)
   double cell[BL_NUM_CELL_VALUES];
@@ -1544,7 +1545,7 @@ __device__ __forceinline__ void polarized_coefficients(const BlShadeArgs &P, con
       const double coefficient = thermal_frac * n_e_cgs * kE * kE * nu_c_cgs / (kC * nu_2_cgs) * bl_exp(-xx_1_3);
       const double var_a = kSqrt2 * kPi / 27.0 * sin_theta_b;
       const double var_b = kPow2_11_12;
-      const double theta_e_096 = bl_pow(theta_e, 0.96);   // evaluated twice in the reference: same value
+      const double theta_e_096 = sh.theta_e_096;   // bl_pow(theta_e, 0.96), evaluated twice per frequency in the reference: same value
       const double var_d = (7.0 * theta_e_096 + 35.0) / (10.0 * theta_e_096 + 75.0) * var_b;
       const double var_e = xx_1_2 + var_d * xx_1_6;
       const double var_f = cos_theta_b / theta_e;
@@ -1565,8 +1566,7 @@ __device__ __forceinline__ void polarized_coefficients(const BlShadeArgs &P, con
       const double coefficient_v = thermal_frac * 2.0 * n_e_cgs * kE * kE * nu_c_cgs * cos_theta_b / (kMe * kC * nu_cgs);
       double factor_q = 0.0, factor_v = 1.0;
       if (theta_e >= 0.01) {   // theta_e_zero, radiation_integrator.hpp:190
-        double kk_0, kk_1, kk_2;   // three std::cyl_bessel_k calls in the reference (:537-539)
-        bl_cyl_bessel_k012(1.0 / theta_e, &kk_0, &kk_1, &kk_2);
+        const double kk_0 = sh.kk_0, kk_1 = sh.kk_1, kk_2 = sh.kk_2;   // three std::cyl_bessel_k calls per frequency in the reference (:537-539)
         const double xx_neg_1_2 = 1.0 / blm_sqrt(xx);
         const blm_powbase xx_base = bl_pow_base(xx);   // four powers of xx below: one logarithm (blmath.h)
         const double f_a = 2.011 * bl_exp(-19.78 * bl_pow_of(xx_base, -0.5175));
@@ -2049,6 +2049,12 @@ __global__ void __launch_bounds__(256, 2) bl_polarized_coefficients_kernel(const
     sh.sin2_theta_b = 1.0 - ci.cos2_theta_b;
     sh.sin_theta_b = bl_sqrt_g(sh.sin2_theta_b);
     sh.cos_theta_b = bl_sqrt_g(ci.cos2_theta_b) * ci.cos_sign;
+    // what does not depend on the frequency, once per sample (the reference recomputes it for every frequency)
+    sh.theta_e_096 = sh.kk_0 = sh.kk_1 = sh.kk_2 = 0.0;
+    if (sh.have_coefficients && P.plasma.plasma_thermal_frac != 0.0) {
+      sh.theta_e_096 = bl_pow(sh.theta_e, 0.96);
+      if (sh.theta_e >= 0.01) bl_cyl_bessel_k012(1.0 / sh.theta_e, &sh.kk_0, &sh.kk_1, &sh.kk_2);   // theta_e_zero, radiation_integrator.hpp:190
+    }
     const size_t at = ((size_t)ray * P.ray_max_steps + n) * P.n_nu;
     for (int l = 0; l < P.n_nu; l++) {
       const double freq = P.frequencies[l];
