@@ -1,0 +1,98 @@
+"""BASELINE.json configuration 5: the multi-frequency render of input/example_true_color.input (simulation mode,
+frequencies equally spaced in wavelength between 1.5e11 and 3.3e11 Hz, camera.cpp:30-50; the per-frequency loop of
+simulation_coefficients.cpp:458). The reference's own ten-frequency golden (tests/golden/sim_true_color.npz) runs with
+the other goldens in test_gpu_parity.py; here: the 64-frequency regime (1 KiB of transfer records per sample, one lane
+per (ray, frequency) in the transfer kernel) against the CPU oracle, and at the configuration's full width - 64
+frequencies over the 256^3 grid at 1024^2 - the size-independent split property."""
+import numpy as np
+import pytest
+
+import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+
+def _true_color(n_freq, **extra):
+    fx, params, mock_args = gu.load_case("sim_true_color")
+    params = dict(params, image_num_frequencies=n_freq)
+    params.update(extra)
+    return params, mock_args
+
+
+@pytest.mark.parametrize("n_freq,res,extra", [
+    (64, 16, {}),
+    (64, 12, dict(simulation_a=0.5, image_normalization="camera", camera_urn=-0.05)),
+    (33, 16, dict(simulation_interp="false", image_frequency_spacing="lin_freq")),
+])
+def test_many_frequencies_against_oracle(n_freq, res, extra, built_library):
+    import blacklight_amd as bl
+    from blacklight_amd import _capi
+    import oracle_api
+    params, mock_args = _true_color(n_freq, camera_resolution=res, **extra)
+    p = bl.Params.from_dict(params)
+    grid = gu.golden_grid(mock_args)
+    with bl.Context(p) as ctx:
+        ctx.set_grid(grid)
+        got = ctx.render()
+        freqs = ctx.frequencies
+    want = oracle_api.render(p.ptr, grid.desc(), _capi.RenderDesc, _capi.CameraFrame, n_rays=res * res,
+                             max_steps=int(p.get("ray_max_steps")), n_freq=n_freq)
+    assert got["image"].shape == (n_freq, res * res) == want["image"].shape
+    assert np.array_equal(freqs, want["frequencies"])
+    if "image_frequency_spacing" not in extra:   # lin_wave: equal steps in wavelength, descending (camera.cpp:39-45)
+        wavelength = 1.0 / freqs
+        assert np.allclose(np.diff(wavelength), (1.0 / 3.3e11 - 1.0 / 1.5e11) / (n_freq - 1), rtol=1e-12)
+    assert np.array_equal(got["sample_num"], want["sample_num"])
+    assert np.array_equal(got["sample_flags"], want["sample_flags"])
+    same = gu.same_bits(got["image"], want["image"])
+    assert same.all(), f"{(~same).sum()} of {same.size} values differ"
+
+
+def test_true_color_at_size_is_independent_of_how_it_is_split(built_library):
+    """1024^2 x 64 frequencies over the 256^3 mock (a quarter of configuration 5's 4096^2 pixels - one GPU's share of
+    the frame twice over): the frame in one call (16 chunks of the default scratch budget), the frame assembled from
+    the tiles of eight emulated ranks, and a window of it in many small chunks agree bit for bit; row l of the 64-row
+    image equals the single-frequency render at frequency l for a sample of rows."""
+    import blacklight_amd as bl
+    from blacklight_amd import distributed as bd, mock
+    import bench
+    n_freq, res, world = 64, 1024, 8
+    params = dict(bench.WORKLOAD, image_num_frequencies=n_freq, image_frequency_start=1.5e11, image_frequency_end=3.3e11,
+                  image_frequency_spacing="lin_wave")
+    params.pop("image_frequency", None)
+    grid = mock.generate(n_r=256, n_th=256, n_ph=256)
+    p = bl.Params.from_dict(params)
+    with bl.Context(p) as ctx:
+        ctx.set_grid(grid)
+        full = ctx.render()
+        freqs = ctx.frequencies
+        assert full["image"].shape == (n_freq, res * res)
+        assert full["stats"].n_chunks >= 8          # 1 KiB of transfer records per sample
+        assembled = np.empty_like(full["image"])
+        counts = np.full(res * res, -1, dtype=np.int32)
+        for rank in range(world):
+            pixels = bd.tile_pixels(res, rank, world, bench.TILE)
+            part = ctx.render(pixel_map=pixels)
+            assembled[:, pixels] = part["image"]
+            counts[pixels] = part["sample_num"]
+        assert np.array_equal(counts, full["sample_num"])
+        same = gu.same_bits(assembled, full["image"])
+        assert same.all(), f"{(~same).sum()} values differ between the tiled and the plain frame"
+        del assembled
+        # a 64 x 64 window through the photon ring in ~30 chunks
+        iv, iu = np.mgrid[480:544, 400:464]
+        window = (iv * res + iu).reshape(-1).astype(np.int32)
+        ctx.set_scratch_limit(256 << 20)
+        chunked = ctx.render(pixel_map=window)
+        assert chunked["stats"].n_chunks > 10
+        assert gu.same_bits(chunked["image"], full["image"][:, window]).all()
+        assert np.array_equal(chunked["sample_num"], full["sample_num"][window])
+    # single-frequency renders of the same window reproduce their rows
+    for l in (0, 31, 63):
+        single = dict(bench.WORKLOAD, image_frequency=float(freqs[l]))
+        with bl.Context(bl.Params.from_dict(single)) as ctx:
+            ctx.set_grid(grid)
+            one = ctx.render(pixel_map=window)
+        assert gu.same_bits(one["image"][0], full["image"][l, window]).all(), l
+    nan = np.isnan(full["image"])
+    assert not nan[:, full["sample_flags"] == 0].any()

@@ -92,6 +92,10 @@ CASES = {
                                                camera_ph=30.0, camera_rotation=15.0), SMALL_MOCK, [300]),
     "sim_multifreq": (SIM_BASE, dict(camera_resolution=16, image_num_frequencies=3, image_frequency_start=1.0e11,
                                      image_frequency_end=4.0e11, image_frequency_spacing="log"), SMALL_MOCK, [136]),
+    # example_true_color.input's parameter set (input/example_true_color.input:55-58: ten frequencies equally spaced
+    # in wavelength, 1.5e11 - 3.3e11 Hz; camera.cpp:30-50) on the small mock: BASELINE.json's configuration 5
+    "sim_true_color": (SIM_BASE, dict(camera_resolution=24, image_num_frequencies=10, image_frequency_start=1.5e11,
+                                      image_frequency_end=3.3e11, image_frequency_spacing="lin_wave"), SMALL_MOCK, [300]),
     "sim_cuts": (SIM_BASE, dict(camera_resolution=24, cut_omit_near="true", cut_omit_in=3.0, cut_omit_out=30.0,
                                 cut_midplane_theta=50.0, cut_midplane_z=20.0, cut_plane="true",
                                 cut_plane_origin="0.0,0.0,0.0", cut_plane_normal="1.0,0.2,0.1",
