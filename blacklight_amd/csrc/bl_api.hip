@@ -48,10 +48,31 @@ struct Failure {
   std::string message;
 };
 
+// Owning HBM allocation. Freed by the destructor (bl_free selects the context's device before it deletes the
+// context, so every buffer a context holds - scratch sets, grid, time slices, block tables - goes back to the
+// device); movable (the slow-light window swaps slices), not copyable.
 template <typename T>
 struct DeviceBuffer {
   T *ptr = nullptr;
   size_t count = 0;
+  DeviceBuffer() = default;
+  DeviceBuffer(const DeviceBuffer &) = delete;
+  DeviceBuffer &operator=(const DeviceBuffer &) = delete;
+  DeviceBuffer(DeviceBuffer &&other) noexcept : ptr(other.ptr), count(other.count) {
+    other.ptr = nullptr;
+    other.count = 0;
+  }
+  DeviceBuffer &operator=(DeviceBuffer &&other) noexcept {
+    if (this != &other) {
+      Free();
+      ptr = other.ptr;
+      count = other.count;
+      other.ptr = nullptr;
+      other.count = 0;
+    }
+    return *this;
+  }
+  ~DeviceBuffer() { Free(); }
   void Free() {
     if (ptr != nullptr) (void)hipFree(ptr);
     ptr = nullptr;
@@ -104,7 +125,8 @@ struct bl_ctx {
   DeviceBuffer<float> d_cells;
   DeviceBuffer<float> d_kappa;   // electron entropy per cell (plasma_model = code_kappa)
   DeviceBuffer<double> d_coords;   // x1f x1v x2f x2v x3f x3v packed
-  DeviceBuffer<int> d_buckets;
+  DeviceBuffer<unsigned short> d_buckets;
+  DeviceBuffer<int> d_lattice;   // refined mesh: box of the block-boundary lattice -> block
   DeviceBuffer<int> d_block_table;                  // inter-block interpolation: levels, locations, hash blocks
   DeviceBuffer<unsigned long long> d_block_keys;    // ... and hash keys
   BlGridDevice grid_dev{};
@@ -129,8 +151,10 @@ struct bl_ctx {
 
   // per-chunk scratch, two sets: the geodesic kernel fills one while the shading kernels drain the other
   struct ChunkSlot {
-    DeviceBuffer<BlSampleRecord> d_records;
+    DeviceBuffer<BlSampleHot> d_records_hot;
+    DeviceBuffer<BlSampleCold> d_records_cold;
     DeviceBuffer<BlLocated> d_located;
+    DeviceBuffer<unsigned long long> d_located_tag;
     DeviceBuffer<double2> d_transfer;
     DeviceBuffer<double> d_ray_kt, d_ray_factor;
     DeviceBuffer<int> d_ray_sample_num;
@@ -146,7 +170,7 @@ struct bl_ctx {
     DeviceBuffer<BlCoefInputs> d_coef_inputs;      // polarized runs: coefficient kernel -> polarized coefficient kernel
     void Free() {
       d_aux.Free(); d_sample_t.Free(); d_slow_frac.Free(); d_pol_samples.Free(); d_pol_coeffs.Free(); d_coef_inputs.Free(); d_anchors.Free();
-      d_records.Free(); d_located.Free(); d_transfer.Free(); d_ray_kt.Free(); d_ray_factor.Free();
+      d_records_hot.Free(); d_records_cold.Free(); d_located.Free(); d_located_tag.Free(); d_transfer.Free(); d_ray_kt.Free(); d_ray_factor.Free();
       d_ray_sample_num.Free(); d_ray_flags.Free(); d_ray_out_index.Free(); d_counters.Free();
     }
   };
@@ -495,7 +519,8 @@ void BuildBuckets(const double *xf, int n, int n_bucket, std::vector<int> *table
   }
 }
 
-constexpr int kEventsPerChunk = 6;   // geodesic start / end, locate start, coefficient start, transfer start, end
+// geodesic start / end, locate start, coefficient start, transfer start, end, counters copied to the host
+constexpr int kEventsPerChunk = 7;
 
 void EnsureStreams(bl_ctx *ctx) {
   if (ctx->stream == nullptr) Check(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking), "hipStreamCreate");
@@ -693,7 +718,9 @@ void UploadMergedGrid(bl_ctx *ctx, const bl_grid_desc *g) {
     ctx->d_coords.Ensure(coords.size());
     Check(hipMemcpy(ctx->d_coords.ptr, coords.data(), coords.size() * sizeof(double), hipMemcpyHostToDevice), "coordinate upload");
     // bucket tables for the cell search
-    std::vector<int> buckets;
+    if (n_i > 65535 || n_j > 65535 || n_k > 65535)
+      throw Failure{BL_E_UNSUPPORTED, "More than 65535 cells along an axis of the merged grid."};
+    std::vector<unsigned short> buckets;
     size_t off_b[3];
     BlGridDevice dev{};
     for (int a = 0; a < 3; a++) {
@@ -705,7 +732,7 @@ void UploadMergedGrid(bl_ctx *ctx, const bl_grid_desc *g) {
       buckets.insert(buckets.end(), table.begin(), table.end());
     }
     ctx->d_buckets.Ensure(buckets.size());
-    Check(hipMemcpy(ctx->d_buckets.ptr, buckets.data(), buckets.size() * sizeof(int), hipMemcpyHostToDevice), "bucket upload");
+    Check(hipMemcpy(ctx->d_buckets.ptr, buckets.data(), buckets.size() * sizeof(unsigned short), hipMemcpyHostToDevice), "bucket upload");
     dev.cells = d_cells.ptr;
     dev.kappa = code_kappa ? d_kappa.ptr : nullptr;
     dev.n_blocks = 0;
@@ -720,11 +747,11 @@ void UploadMergedGrid(bl_ctx *ctx, const bl_grid_desc *g) {
     }
     ctx->grid_dev = dev;
     {
+      // The locate kernel stages the tables in LDS when they fit 60 KiB (up to ~640 cells per axis); larger grids
+      // are searched in the same tables where they lie in HBM (lds_table_bytes = 0).
       size_t bytes = 0;
       for (int a = 0; a < 3; a++) bytes += (2 * static_cast<size_t>(n[a]) + 1) * sizeof(double) + static_cast<size_t>(dev.n_bucket[a]) * sizeof(unsigned short);
-      if (bytes > 60 * 1024 || n_i > 65535 || n_j > 65535 || n_k > 65535)
-        throw Failure{BL_E_UNSUPPORTED, "Grid coordinate tables do not fit the 60 KiB LDS budget of the shading kernel."};
-      ctx->lds_table_bytes = static_cast<int>((bytes + 15) / 16 * 16);
+      ctx->lds_table_bytes = bytes > 60 * 1024 ? 0 : static_cast<int>((bytes + 15) / 16 * 16);
     }
     ctx->n_i = n_i;
     ctx->n_j = n_j;
@@ -810,13 +837,13 @@ void UploadRefinedGrid(bl_ctx *ctx, const bl_grid_desc *g) {
   }
   ctx->d_coords.Ensure(coords.size());
   Check(hipMemcpy(ctx->d_coords.ptr, coords.data(), coords.size() * sizeof(double), hipMemcpyHostToDevice), "coordinate upload");
-  ctx->d_buckets.Ensure(lattice.size());
-  Check(hipMemcpy(ctx->d_buckets.ptr, lattice.data(), lattice.size() * sizeof(int), hipMemcpyHostToDevice), "lattice upload");
+  ctx->d_lattice.Ensure(lattice.size());
+  Check(hipMemcpy(ctx->d_lattice.ptr, lattice.data(), lattice.size() * sizeof(int), hipMemcpyHostToDevice), "lattice upload");
   BlGridDevice dev{};
   dev.cells = d_cells.ptr;
   dev.kappa = code_kappa ? d_kappa.ptr : nullptr;
   dev.n_blocks = n_b;
-  dev.lattice = ctx->d_buckets.ptr;
+  dev.lattice = ctx->d_lattice.ptr;
   dev.stride_row = nb[0];
   dev.stride_plane = nb[0] * nb[1];
   for (int a = 0; a < 3; a++) {
@@ -888,6 +915,7 @@ int bl_set_grid(bl_ctx *ctx, const bl_grid_desc *g) {
     if (g->n_blocks < 1) throw Failure{BL_E_ARG, "Bad grid description."};
     if (g->n_i < 2 || g->n_j < 2 || g->n_k < 2 || g->prim == nullptr) throw Failure{BL_E_ARG, "Bad grid description."};
     Check(hipSetDevice(ctx->device), "hipSetDevice");
+    ctx->have_grid = false;   // a failed upload leaves no grid behind (the previous one may be half overwritten)
     if (ctx->params.simulation_interp && ctx->params.simulation_block_interp) {
       UploadRefinedGrid(ctx, g);   // inter-block interpolation works on the MeshBlocks as they are
     } else {
@@ -1009,10 +1037,10 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
     if (d->pixel_map == nullptr && n_rays > level_pixels) throw Failure{BL_E_ARG, "n_rays exceeds the pixels of this level."};
 
     const bool block_interp = simulation && ctx->grid_dev.block_interp != 0;
-    // chunk size from the scratch budget: per ray max_steps * (64 B record + 48 B located sample
+    // chunk size from the scratch budget: per ray max_steps * (2 x 32 B record + 40 B located sample
     // (simulation mode) + 16 B * n_nu transfer)
     const uint64_t per_ray = static_cast<uint64_t>(max_steps)
-        * (sizeof(BlSampleRecord) + (simulation ? sizeof(BlLocated) : 0) + sizeof(double2) * n_nu
+        * (sizeof(BlSampleHot) + sizeof(BlSampleCold) + (simulation ? sizeof(BlLocated) + sizeof(unsigned long long) : 0) + sizeof(double2) * n_nu
            + (aux ? sizeof(BlAuxSample) + sizeof(double) : 0) + (slow ? 2 * sizeof(double) : 0)
            + (ctx->polarized ? sizeof(BlPolSample) + sizeof(BlCoefInputs) + 3 * sizeof(double2) * n_nu : 0)
            + (block_interp ? 8 * sizeof(unsigned int) : 0)) + 64;
@@ -1026,7 +1054,8 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
       if (hipMemGetInfo(&free_bytes, &total_bytes) == hipSuccess) {
         uint64_t held = 0;
         for (const bl_ctx::ChunkSlot &sl : ctx->slot)
-          held += sl.d_records.count * sizeof(BlSampleRecord) + sl.d_located.count * sizeof(BlLocated)
+          held += sl.d_records_hot.count * (sizeof(BlSampleHot) + sizeof(BlSampleCold))
+              + sl.d_located.count * (sizeof(BlLocated) + sizeof(unsigned long long))
               + sl.d_transfer.count * sizeof(double2) + sl.d_aux.count * sizeof(BlAuxSample)
               + (sl.d_sample_t.count + sl.d_slow_frac.count) * sizeof(double)
               + sl.d_pol_samples.count * sizeof(BlPolSample) + sl.d_pol_coeffs.count * sizeof(double2)
@@ -1048,8 +1077,12 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
     const size_t record_capacity = static_cast<size_t>(chunk) * max_steps + static_cast<size_t>(geo_grid) * BL_RECORD_BLOCK;
     for (int k = 0; k < n_slots; k++) {
       bl_ctx::ChunkSlot &sl = ctx->slot[k];
-      sl.d_records.Ensure(record_capacity);
-      if (simulation) sl.d_located.Ensure(record_capacity);
+      sl.d_records_hot.Ensure(record_capacity);
+      sl.d_records_cold.Ensure(record_capacity);
+      if (simulation) {
+        sl.d_located.Ensure(record_capacity);
+        sl.d_located_tag.Ensure(record_capacity);
+      }
       sl.d_transfer.Ensure(static_cast<size_t>(chunk) * max_steps * n_nu);
       sl.d_ray_kt.Ensure(chunk);
       sl.d_ray_factor.Ensure(chunk);
@@ -1353,6 +1386,7 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
                          || p.cut_theta_e_max >= 0.0 || p.cut_b_min >= 0.0 || p.cut_b_max >= 0.0 || p.cut_sigma_min >= 0.0
                          || p.cut_sigma_max >= 0.0 || p.cut_beta_inverse_min >= 0.0 || p.cut_beta_inverse_max >= 0.0) ? 1 : 0;
       sa.grid = ctx->grid_dev;
+      sa.lds_table_bytes = ctx->lds_table_bytes;
     } else {
       BlFormulaDevice &fm = sa.formula;
       fm.r0 = p.formula_r0; fm.h = p.formula_h; fm.l0 = p.formula_l0; fm.q = p.formula_q; fm.nup = p.formula_nup;
@@ -1453,15 +1487,18 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
       hipEvent_t *e = ev + static_cast<size_t>(c) * kEventsPerChunk;
       ta.chunk_begin = begin;
       ta.chunk_rays = rays;
-      ta.records = sl.d_records.ptr;
+      ta.records_hot = sl.d_records_hot.ptr;
+      ta.records_cold = sl.d_records_cold.ptr;
       ta.counters = sl.d_counters.ptr;
       ta.ray_kt = sl.d_ray_kt.ptr;
       ta.ray_factor = sl.d_ray_factor.ptr;
       ta.ray_sample_num = sl.d_ray_sample_num.ptr;
       ta.ray_flags = sl.d_ray_flags.ptr;
       ta.ray_out_index = sl.d_ray_out_index.ptr;
-      sa.records = sl.d_records.ptr;
+      sa.records_hot = sl.d_records_hot.ptr;
+      sa.records_cold = sl.d_records_cold.ptr;
       sa.located = simulation ? sl.d_located.ptr : nullptr;
+      sa.located_tag = simulation ? sl.d_located_tag.ptr : nullptr;
       sa.counters_in = sl.d_counters.ptr;
       sa.counters = sl.d_counters.ptr;
       sa.ray_kt = sl.d_ray_kt.ptr;
@@ -1493,7 +1530,9 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
       xa.ray_factor = sl.d_ray_factor.ptr;
 
       // ---- geodesic stream
-      if (c >= n_slots) Check(hipStreamWaitEvent(stream_geo, (e - n_slots * kEventsPerChunk)[5], 0), "stream wait");
+      // the scratch set (and its counters) is free again once the chunk that used it before has had its
+      // counters copied out - event 6, recorded behind that copy, not event 5 in front of it
+      if (c >= n_slots) Check(hipStreamWaitEvent(stream_geo, (e - n_slots * kEventsPerChunk)[6], 0), "stream wait");
       Check(hipMemsetAsync(sl.d_counters.ptr, 0, n_counters * sizeof(unsigned long long), stream_geo), "counter reset");
       Check(hipEventRecord(e[0], stream_geo), "event");
       Check(bl_launch_geodesic(&ta, p.ray_integrator, std::min(geo_grid, (rays + 63) / 64), stream_geo), "geodesic kernel launch");
@@ -1514,6 +1553,7 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
       Check(hipEventRecord(e[5], stream), "event");
       Check(hipMemcpyAsync(ctx->host_counters + static_cast<size_t>(c) * n_counters, sl.d_counters.ptr,
                            n_counters * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream), "counter download");
+      Check(hipEventRecord(e[6], stream), "event");
     }
     Check(hipStreamSynchronize(stream_geo), "kernel execution");
     Check(hipStreamSynchronize(stream), "kernel execution");

@@ -7,11 +7,12 @@
 //                                                bb3 interleaved, i fastest, so the 8 corners of a
 //                                                trilinear fetch are four 64-B segments
 //   face / centre double x{1,2,3}f[n+1], x{1,2,3}v[n]  + per-axis bucket tables for the cell search
-//   records       BlSampleRecord [<= C*S]        64 B per emitted sample, written by the geodesic
-//                                                kernel in wave-contiguous runs, read by the locate
-//                                                and coefficient kernels (coalesced 4 KiB per wave)
-//   located       BlLocated [<= C*S]             48 B per sample: first cell + trilinear fractions +
-//                                                azimuth + status, locate kernel -> coefficient kernel
+//   records       BlSampleHot, BlSampleCold [<= C*S]  2 x 32 B per emitted sample (position + id | momentum +
+//                                                length), written by the geodesic kernel in wave-contiguous
+//                                                runs; the locate kernel reads the first, the coefficient
+//                                                kernel both (coalesced)
+//   located       BlLocated [<= C*S] + tag [<= C*S]   32 + 8 B per sample: trilinear fractions + azimuth | first
+//                                                cell + status, locate kernel -> coefficient kernel
 //   transfer      double2 [C][S][n_nu]           (a, b) of the per-sample affine update
 //                                                I <- a * (I + b), written by the shading kernel,
 //                                                replayed far -> near by the transfer kernel
@@ -24,30 +25,31 @@
 #include "bl_camera.h"
 #include "bl_geometry.h"
 
-// One emitted geodesic sample (geodesic_pos/dir/len entries of the reference,
-// geodesics.cpp:250-293), before the per-sample momentum renormalisation of :352-371.
-struct alignas(16) BlSampleRecord {
+// One emitted geodesic sample (geodesic_pos/dir/len entries of the reference, geodesics.cpp:250-293), before the
+// per-sample momentum renormalisation of :352-371, in two 32-byte halves kept in two arrays: the locate kernel
+// reads positions and ids only, and with the halves interleaved in one 64-byte record it fetched the whole line
+// for half of it (24 GB instead of 12 GB per launch of the benchmark).
+struct alignas(16) BlSampleHot {
   double x, y, z;     // position (CKS)
   uint32_t ray;       // chunk-local ray slot, 0xFFFFFFFF = dead slot (sample dropped by truncation)
   uint32_t n;         // sample index along the ray in integration order
-                      // (position and id are the first 32 bytes: all the locate kernel reads)
+};
+struct alignas(16) BlSampleCold {
   double kx, ky, kz;  // covariant spatial momentum, not yet renormalised
   double len;         // affine step length as stored by the integrator (negative: camera -> source)
 };
-static_assert(sizeof(BlSampleRecord) == 64, "record must be 64 bytes");
+static_assert(sizeof(BlSampleHot) == 32 && sizeof(BlSampleCold) == 32, "record halves must be 32 bytes");
 
-// One located sample, written by the locate kernel at the index of its sample record and read once
-// by the coefficient kernel (simulation mode): where the sample sits on the grid - the first of the
-// (up to) 8 cells it reads and the trilinear fractions - plus the unwrapped spherical Kerr-Schild
-// azimuth (needed again by the Jacobian), the status and r^2.
+// One located sample, written by the locate kernel at the index of its sample record and read once by the
+// coefficient kernel (simulation mode): where the sample sits on the grid. 32 bytes of fractions and azimuth
+// (BlLocated) plus an 8-byte tag in its own array: bits 0..31 linear index of cell (k_m, j_m, i_m) resp. of the
+// nearest cell, bits 32..39 SampleStatus, bits 40.. time slice (slow light). r^2, which the coefficient kernel
+// needs again, is not handed over: with zero spin it is x^2 + y^2 + z^2, otherwise one hypot.
 struct alignas(16) BlLocated {
   double f_i, f_j, f_k;   // trilinear fractions (kSampleInterp)
-  double ph;
-  uint32_t cell;          // linear index of cell (k_m, j_m, i_m) resp. of the nearest cell
-  uint32_t status;        // SampleStatus
-  double r2;              // squared Kerr-Schild radius of the sample (the coefficient kernel needs it again)
+  double ph;              // unwrapped spherical Kerr-Schild azimuth (needed again by the Jacobian)
 };
-static_assert(sizeof(BlLocated) == 48, "located sample must be 48 bytes");
+static_assert(sizeof(BlLocated) == 32, "located sample must be 32 bytes");
 
 #define BL_DEAD_RAY 0xFFFFFFFFu
 // Record slots a wave of the geodesic kernel reserves at a time (one global atomic per block); the
@@ -71,7 +73,7 @@ struct BlGridDevice {
   const float *kappa;        // [n_k][n_j][n_i] electron entropy (plasma_model = code_kappa), else null
   const double *xf[3];       // faces  (r, theta, phi)
   const double *xv[3];       // centres
-  const int *bucket[3];      // bucket -> first candidate cell
+  const unsigned short *bucket[3];   // bucket -> first candidate cell
   double bucket_x0[3], bucket_inv_w[3];
   int n_bucket[3];
   int n[3];                  // n_i, n_j, n_k of the (merged) global grid
@@ -199,7 +201,8 @@ struct BlTraceArgs {
   const int *tile_order;      // device [tiles of the image] or null: order in which the 8x8 tiles are traced
   const int *pixel_map;       // device, or null
   const int *block_locs;      // device, or null
-  BlSampleRecord *records;
+  BlSampleHot *records_hot;
+  BlSampleCold *records_cold;
   double *sample_t;           // optional [record capacity]: coordinate time of each sample (image_time)
   long long record_capacity;
   unsigned long long *counters;
@@ -255,8 +258,11 @@ struct BlShadeArgs {
   BlGridDevice grid;
   BlSlowDevice slow;
   const BlShadeCold *cold;    // device pointer
-  const BlSampleRecord *records;
+  const BlSampleHot *records_hot;
+  const BlSampleCold *records_cold;
   BlLocated *located;         // [record capacity], simulation mode
+  unsigned long long *located_tag;   // [record capacity]: cell | status << 32 | time slice << 40
+  int lds_table_bytes;        // size of the coordinate tables the locate kernel stages in LDS; 0: searched in HBM
   const unsigned long long *counters_in;
   unsigned long long *counters;
   const double *ray_kt, *ray_factor;

@@ -128,49 +128,74 @@ struct BlKerrSchildRecip {
   BlRecip r, ra;  // 1 / r, 1 / (r^2 + a^2)
 };
 
+// ---- zero spin -------------------------------------------------------------------------------------
+// kSpinZero instantiations (selected by the host when bh_a == 0.0, which the benchmark and every a = 0 input use)
+// drop the operations whose result is fixed by a = 0. Bit-identical to the general code evaluated at a = 0:
+//   a^2 = 0 * 0 = +0, and every product with it (a^2 z, a^2 z^2, 2 a z, a x, a y, 2 a^2 r z) is +-0 for the finite
+//   coordinates of a ray; x + (+-0) = x and x - (+-0) = x for x != 0 (the reference is built with
+//   -fno-signed-zeros, so the sign of a zero sum is not part of its contract either);
+//   hypot(R^2 - 0, +-0) = |R^2| = R^2 (bl_hypot_g returns the larger argument when the smaller is zero), so
+//   r^2 = 0.5 * (R^2 + R^2) = R^2 exactly, and 2 r^2 - R^2 + 0 = r^2 exactly: the denominators 2 r^2 - R^2 + a^2 and
+//   r^2 + a^2 of geodesic_geometry.cpp:199-214 are both r^2 and share one reciprocal;
+//   quotients keep their operands: f = (2 m r^2 r) / (r^2 r^2), l_1 = (r x) / r^2 - not 2 m / r, x / r.
+// tests/test_gpu_math.py compares both instantiations on random points through bl_debug_geometry.
+
 // geodesic_geometry.cpp:19-26; bl_radial_coordinate2 also returns r^2
+template <bool kSpinZero = false>
 BL_HD double bl_radial_coordinate2(const BlSpacetime &st, double x, double y, double z, double *r2_out) {
-  double a2 = st.bh_a * st.bh_a;
   double rr2 = x * x + y * y + z * z;
+  if (kSpinZero) {
+    *r2_out = rr2;
+    return bl_sqrt_g(rr2);
+  }
+  double a2 = st.bh_a * st.bh_a;
   double r2 = 0.5 * (rr2 - a2 + bl_hypot_g(rr2 - a2, 2.0 * st.bh_a * z));
   *r2_out = r2;
   return bl_sqrt_g(r2);
 }
+template <bool kSpinZero = false>
 BL_HD double bl_radial_coordinate(const BlSpacetime &st, double x, double y, double z) {
   double r2;
-  return bl_radial_coordinate2(st, x, y, z, &r2);
+  return bl_radial_coordinate2<kSpinZero>(st, x, y, z, &r2);
 }
 
 // The Kerr-Schild scalars given r^2 = the value bl_radial_coordinate2() returned for the same point
+template <bool kSpinZero = false>
 BL_HD void bl_kerr_schild_r2(const BlSpacetime &st, double x, double y, double z, double r2, BlKerrSchild *ks,
                              BlKerrSchildRecip *rc) {
   double bh_a = st.bh_a;
-  double a2 = bh_a * bh_a;
+  double a2 = kSpinZero ? 0.0 : bh_a * bh_a;
   double rr2 = x * x + y * y + z * z;
   double r = bl_sqrt_g(r2);
-  double f = bl_div_g(2.0 * st.bh_m * r2 * r, r2 * r2 + a2 * z * z);
+  double f = kSpinZero ? bl_div_g(2.0 * st.bh_m * r2 * r, r2 * r2) : bl_div_g(2.0 * st.bh_m * r2 * r, r2 * r2 + a2 * z * z);
   rc->r = bl_recip(r);
-  rc->ra = bl_recip(r2 + a2);
+  rc->ra = kSpinZero ? bl_recip(r2) : bl_recip(r2 + a2);
   ks->a2 = a2;
   ks->rr2 = rr2;
   ks->r2 = r2;
   ks->r = r;
   ks->f = f;
-  ks->l[0] = bl_div_r(r * x + bh_a * y, rc->ra);
-  ks->l[1] = bl_div_r(r * y - bh_a * x, rc->ra);
+  ks->l[0] = kSpinZero ? bl_div_r(r * x, rc->ra) : bl_div_r(r * x + bh_a * y, rc->ra);
+  ks->l[1] = kSpinZero ? bl_div_r(r * y, rc->ra) : bl_div_r(r * y - bh_a * x, rc->ra);
   ks->l[2] = bl_div_r(z, rc->r);
   for (int i = 0; i < 3; i++) ks->fl[i] = f * ks->l[i];
 }
+template <bool kSpinZero = false>
 BL_HD void bl_kerr_schild_r(const BlSpacetime &st, double x, double y, double z, BlKerrSchild *ks,
                             BlKerrSchildRecip *rc) {
-  double a2 = st.bh_a * st.bh_a;
   double rr2 = x * x + y * y + z * z;
+  if (kSpinZero) {
+    bl_kerr_schild_r2<true>(st, x, y, z, rr2, ks, rc);
+    return;
+  }
+  double a2 = st.bh_a * st.bh_a;
   double r2 = 0.5 * (rr2 - a2 + bl_hypot_g(rr2 - a2, 2.0 * st.bh_a * z));
-  bl_kerr_schild_r2(st, x, y, z, r2, ks, rc);
+  bl_kerr_schild_r2<false>(st, x, y, z, r2, ks, rc);
 }
+template <bool kSpinZero = false>
 BL_HD void bl_kerr_schild(const BlSpacetime &st, double x, double y, double z, BlKerrSchild *ks) {
   BlKerrSchildRecip rc;
-  bl_kerr_schild_r(st, x, y, z, ks, &rc);
+  bl_kerr_schild_r<kSpinZero>(st, x, y, z, ks, &rc);
 }
 
 // Full covariant metric g_{mu nu} (geodesic_geometry.cpp:38-93). Used by the camera set-up and
@@ -250,10 +275,17 @@ BL_HD double bl_renormalization_factor_g(const double gcon[4][4], double k0, dou
 
 // Null-condition renormalisation factor for the spatial covariant momentum
 // (geodesics.cpp:296-309 and :352-371): solves g^{mu nu} k_mu k_nu = 0 for a common factor on k_i.
+template <bool kSpinZero = false>
 BL_HD double bl_renormalization_factor(const BlSpacetime &st, double x, double y, double z,
                                        double k0, double k1, double k2, double k3) {
   double gcon[4][4];
-  bl_gcon(st, x, y, z, gcon);
+  if (kSpinZero && !st.ray_flat) {
+    BlKerrSchild ks;
+    bl_kerr_schild<true>(st, x, y, z, &ks);
+    bl_gcon_ks(ks, gcon);
+  } else {
+    bl_gcon(st, x, y, z, gcon);
+  }
   double k[4] = {k0, k1, k2, k3};
   double temp_a = 0.0;
   for (int a = 1; a < 4; a++)
@@ -271,7 +303,7 @@ BL_HD double bl_renormalization_factor(const BlSpacetime &st, double x, double y
 //   dk[0..2]   = d(k_x, k_y, k_z)/d lambda = -1/2 d_i g^{mu nu} k_mu k_nu      (d k_t = 0)
 //   *ds        = d s / d lambda (proper distance), only if kWithDistance
 // Returns r at the evaluation point through *r_out.
-template <bool kWithDistance>
+template <bool kWithDistance, bool kSpinZero = false>
 BL_HD void bl_geodesic_rhs(const BlSpacetime &st, const double pos[3], const double kcov[4],
                            double dpos[4], double dk[3], double *ds, double *r_out) {
   if (st.ray_flat) {
@@ -287,14 +319,14 @@ BL_HD void bl_geodesic_rhs(const BlSpacetime &st, const double pos[3], const dou
       *ds = -bl_sqrt_g(acc);
     }
     // RadialGeodesicCoordinate ignores ray_flat (geodesic_geometry.cpp:19-26)
-    *r_out = bl_radial_coordinate(st, pos[0], pos[1], pos[2]);
+    *r_out = bl_radial_coordinate<kSpinZero>(st, pos[0], pos[1], pos[2]);
     return;
   }
   double x = pos[0], y = pos[1], z = pos[2];
   double bh_a = st.bh_a;
   BlKerrSchild ks;
   BlKerrSchildRecip rc;
-  bl_kerr_schild_r(st, x, y, z, &ks, &rc);
+  bl_kerr_schild_r<kSpinZero>(st, x, y, z, &ks, &rc);
   double r = ks.r, r2 = ks.r2, f = ks.f, a2 = ks.a2, rr2 = ks.rr2;
   const double *l = ks.l;
   const double *fl = ks.fl;
@@ -324,27 +356,52 @@ BL_HD void bl_geodesic_rhs(const BlSpacetime &st, const double pos[3], const dou
   // Scalar and vector derivatives (geodesic_geometry.cpp:199-220)
   double dr[3], df[3], dl[3][3];  // dl[i][a] = d l_{i+1} / d x^a
   // all quotients below are over four denominators (denom, den_f, r^2 + a^2, r), each inverted once
-  const BlRecip rc_denom = bl_recip(2.0 * r2 - rr2 + a2);
-  dr[0] = bl_div_r(r * x, rc_denom);
-  dr[1] = bl_div_r(r * y, rc_denom);
-  dr[2] = bl_div_r(r * z + bl_div_r(a2 * z, rc.r), rc_denom);
-  double num_f = r2 * r2 - 3.0 * a2 * z * z;
-  const BlRecip rc_den_f = bl_recip(r * (r2 * r2 + a2 * z * z));
-  df[0] = bl_div_r(-num_f * dr[0], rc_den_f) * f;
-  df[1] = bl_div_r(-num_f * dr[1], rc_den_f) * f;
-  df[2] = bl_div_r(-(num_f * dr[2] + 2.0 * a2 * r * z), rc_den_f) * f;
-  double xl = x - 2.0 * r * l[0];
-  double yl = y - 2.0 * r * l[1];
-  dl[0][0] = bl_div_r(xl * dr[0] + r, rc.ra);
-  dl[0][1] = bl_div_r(xl * dr[1] + bh_a, rc.ra);
-  dl[0][2] = bl_div_r(xl * dr[2], rc.ra);
-  dl[1][0] = bl_div_r(yl * dr[0] - bh_a, rc.ra);
-  dl[1][1] = bl_div_r(yl * dr[1] + r, rc.ra);
-  dl[1][2] = bl_div_r(yl * dr[2], rc.ra);
-  double mz_r2 = bl_div_g(-z, r2);
-  dl[2][0] = mz_r2 * dr[0];
-  dl[2][1] = mz_r2 * dr[1];
-  dl[2][2] = mz_r2 * dr[2] + bl_div_r(1.0, rc.r);
+  if (kSpinZero) {
+    // 2 r^2 - R^2 + a^2 = r^2 = r^2 + a^2 exactly (see "zero spin" above): one reciprocal serves both
+    const BlRecip &rc_denom = rc.ra;
+    dr[0] = bl_div_r(r * x, rc_denom);
+    dr[1] = bl_div_r(r * y, rc_denom);
+    dr[2] = bl_div_r(r * z, rc_denom);
+    double num_f = r2 * r2;
+    const BlRecip rc_den_f = bl_recip(r * (r2 * r2));
+    df[0] = bl_div_r(-num_f * dr[0], rc_den_f) * f;
+    df[1] = bl_div_r(-num_f * dr[1], rc_den_f) * f;
+    df[2] = bl_div_r(-(num_f * dr[2]), rc_den_f) * f;
+    double xl = x - 2.0 * r * l[0];
+    double yl = y - 2.0 * r * l[1];
+    dl[0][0] = bl_div_r(xl * dr[0] + r, rc.ra);
+    dl[0][1] = bl_div_r(xl * dr[1], rc.ra);
+    dl[0][2] = bl_div_r(xl * dr[2], rc.ra);
+    dl[1][0] = bl_div_r(yl * dr[0], rc.ra);
+    dl[1][1] = bl_div_r(yl * dr[1] + r, rc.ra);
+    dl[1][2] = bl_div_r(yl * dr[2], rc.ra);
+    double mz_r2 = bl_div_r(-z, rc.ra);   // -z / r^2
+    dl[2][0] = mz_r2 * dr[0];
+    dl[2][1] = mz_r2 * dr[1];
+    dl[2][2] = mz_r2 * dr[2] + bl_div_r(1.0, rc.r);
+  } else {
+    const BlRecip rc_denom = bl_recip(2.0 * r2 - rr2 + a2);
+    dr[0] = bl_div_r(r * x, rc_denom);
+    dr[1] = bl_div_r(r * y, rc_denom);
+    dr[2] = bl_div_r(r * z + bl_div_r(a2 * z, rc.r), rc_denom);
+    double num_f = r2 * r2 - 3.0 * a2 * z * z;
+    const BlRecip rc_den_f = bl_recip(r * (r2 * r2 + a2 * z * z));
+    df[0] = bl_div_r(-num_f * dr[0], rc_den_f) * f;
+    df[1] = bl_div_r(-num_f * dr[1], rc_den_f) * f;
+    df[2] = bl_div_r(-(num_f * dr[2] + 2.0 * a2 * r * z), rc_den_f) * f;
+    double xl = x - 2.0 * r * l[0];
+    double yl = y - 2.0 * r * l[1];
+    dl[0][0] = bl_div_r(xl * dr[0] + r, rc.ra);
+    dl[0][1] = bl_div_r(xl * dr[1] + bh_a, rc.ra);
+    dl[0][2] = bl_div_r(xl * dr[2], rc.ra);
+    dl[1][0] = bl_div_r(yl * dr[0] - bh_a, rc.ra);
+    dl[1][1] = bl_div_r(yl * dr[1] + r, rc.ra);
+    dl[1][2] = bl_div_r(yl * dr[2], rc.ra);
+    double mz_r2 = bl_div_g(-z, r2);
+    dl[2][0] = mz_r2 * dr[0];
+    dl[2][1] = mz_r2 * dr[1];
+    dl[2][2] = mz_r2 * dr[2] + bl_div_r(1.0, rc.r);
+  }
 
   // k[4+a] -= 0.5 * dgcon[a-1][mu][nu] * y[4+mu] * y[4+nu], (mu, nu) row-major (:880-883), with
   // dgcon[a][mu][nu] = -(df_a l_mu l_nu + f dl_mu,a l_nu + f l_mu dl_nu,a) (geodesic_geometry.cpp:223-274)
