@@ -3,23 +3,29 @@
 Mrays/s (+ achieved HBM GB/s) for a 1024^2 camera over a 256^3 mock GRMHD snapshot.
 
     python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one complete render (camera -> geodesics -> sampling -> coefficients -> transfer ->
 image in HBM) of the 1024^2 example_simulation camera over the 256^3 mock snapshot, both synthetic
 and generated natively (blacklight_amd.mock restates the reference's generator). The grid is staged
 into HBM once, before the timed region.
 
-Multi-GPU (one process per GPU, torch.distributed nccl = RCCL): the path shards over independent
-rays, so by default every rank renders its own full 1024^2 frame of the replicated snapshot (a
-multi-view job: rank r looks from azimuth 360 r / N degrees) and the frames are gathered on rank 0
-over RCCL - weak scaling, value = all rays of all ranks / max-over-ranks time. `--mode tiled`
-instead splits ONE 1024^2 frame into 32x32-pixel tiles dealt block-cyclically to the ranks and
-gathers the image (strong scaling).
+Multi-GPU: one process per GPU over torch.distributed (nccl = RCCL). Started as the driver does
+(`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`) the ranks come from the environment;
+started plainly (`python bench.py --gpus N`, no WORLD_SIZE) the parent starts that same launcher as a child process
+BEFORE anything touches the GPU and exits with its code. --gpus must equal the number of ranks, and a box with fewer
+GPUs than that fails loudly. For N > 1 the job is north_star's: ONE 1024^2 frame cut into 32 x 32-pixel tiles dealt
+centre-first round-robin to the ranks (every rank gets the same mix of long and short rays), grid replicated, the
+image RCCL-gathered on rank 0 inside the timed region, rank 0 de-tiles - strong scaling, value = rays of the frame /
+max-over-ranks time. `--mode frames` is the weak-scaling variant (one full frame per rank, views at 360 r / N degrees).
+
+Arithmetic tiers (include/blacklight_amd.h, bl_set_arithmetic): `value` is measured in the TOLERANT tier - the fp64
+tolerance north_star grants for intensities (per-pixel L-infinity < 1e-6; measured ~1e-14), ray-step counts, flags and
+cut decisions bit-exact - and the same K steps are then timed in the EXACT tier (bit-identical to the reference with
+the pinned math library) and reported beside it as "exact_tier". `--arithmetic exact` times only that tier as `value`.
 
 The JSON line also carries
-  roofline     HBM-read roofline of the dominant kernel (bl_shade_kernel): algorithmic bytes
-               (256 B per gathered sample + 13 B per ray) over its HIP-event time
+  roofline     HBM-read roofline of the dominant kernel (the coefficient kernel, which issues the grid reads):
+               algorithmic bytes (256 B per gathered sample + 13 B per ray) over its HIP-event time
   cpu_baseline the CPU oracle (a port of the reference's algorithm, oracle/) timed on this host's
                cores on a bounded sample of the same workload (rank 0, N = 1 only)
 """
@@ -27,6 +33,8 @@ import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -81,40 +89,70 @@ def cpu_baseline(params_dict, grid, resolution, stride):
     return pixels, out, cores
 
 
+def launch_ranks(n_gpus, argv):
+    """`python bench.py --gpus N` without a launcher: start torch.distributed.run as a CHILD process (this process has
+    not touched the GPU and never will) and return its exit code. torch.cuda.device_count() does not initialise HIP."""
+    import torch
+    visible = torch.cuda.device_count()
+    if visible < n_gpus:
+        raise SystemExit(f"bench.py --gpus {n_gpus}: only {visible} GPU(s) visible on this box - refusing to run a smaller job "
+                         "under that name")
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    return subprocess.call(cmd)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--mode", choices=["frames", "tiled"], default="frames")
+    ap.add_argument("--mode", choices=["frames", "tiled"], default="tiled", help="N > 1: one frame tiled over the ranks (default) or one frame per rank")
+    ap.add_argument("--arithmetic", choices=["tolerant", "exact"], default="tolerant",
+                    help="tier `value` is measured in; with tolerant the exact tier is timed afterwards and reported as exact_tier")
     ap.add_argument("--resolution", type=int, default=1024)
     ap.add_argument("--grid", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--scratch-gib", type=float, default=0.0, help="override the library's scratch budget (GiB); 0 = default")
     ap.add_argument("--cpu-stride", type=int, default=2, help="CPU baseline traces every stride-th pixel per axis")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be positive")
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} was started with WORLD_SIZE = {world}: the two must agree")
 
     import torch
     import blacklight_amd as bl
     from blacklight_amd import distributed as bd
     from blacklight_amd import mock
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    if torch.cuda.device_count() < (world if distributed else 1):
+        raise SystemExit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if distributed:
         import torch.distributed as dist
         dist.init_process_group(backend="nccl", device_id=device)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"RCCL sees {dist.get_world_size()} ranks, --gpus says {args.gpus}")
 
     res = args.resolution
+    tiled = distributed and args.mode == "tiled"
     params_dict = dict(WORKLOAD)
     params_dict["camera_resolution"] = res
-    if distributed and args.mode == "frames":
+    if distributed and not tiled:
         params_dict["camera_ph"] = 360.0 * rank / world
     params = bl.Params.from_dict(params_dict)
     grid = mock.generate(n_r=args.grid, n_th=args.grid, n_ph=args.grid)
@@ -124,15 +162,16 @@ def main():
     if args.scratch_gib > 0.0:
         ctx.set_scratch_limit(int(args.scratch_gib * (1 << 30)))
 
-    if args.mode == "tiled" and distributed:
+    if tiled:
         pixels = bd.tile_pixels(res, rank, world, TILE)
         n_rays = int(pixels.size)
+        n_padded = bd.padded_count(res, world, TILE)   # equal shares for the gather, whatever the world size
     else:
         pixels = None
-        n_rays = res * res
-    image = torch.empty((1, n_rays), dtype=torch.float64, device=device)
-    sample_num = torch.empty(n_rays, dtype=torch.int32, device=device)
-    flags = torch.empty(n_rays, dtype=torch.uint8, device=device)
+        n_rays = n_padded = res * res
+    image = torch.zeros((1, n_padded), dtype=torch.float64, device=device)
+    sample_num = torch.zeros(n_padded, dtype=torch.int32, device=device)
+    flags = torch.zeros(n_padded, dtype=torch.uint8, device=device)
 
     def step():
         return ctx.render_device(image.data_ptr(), n_rays, pixel_map=pixels,
@@ -143,79 +182,114 @@ def main():
         if not distributed:
             return None
         parts = bd.gather_rows(image, dst=0)
-        if parts is not None and args.mode == "tiled":
+        if parts is not None and tiled:
             return bd.assemble(parts, res, TILE)      # rank 0 de-tiles into (n_q, res*res)
         return parts
-
-    for _ in range(args.warmup):
-        step()
-        gather_image()
 
     def fence():
         if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
-    fence()
-    t0 = time.perf_counter()
-    ms = dict(geodesic=0.0, locate=0.0, shade=0.0, transfer=0.0, wall=0.0)
-    launches_shade = 0
-    stats = None
-    for _ in range(args.steps):
-        stats = step()
-        ms["geodesic"] += stats.ms_geodesic
-        ms["locate"] += stats.ms_locate
-        ms["shade"] += stats.ms_shade
-        ms["wall"] += stats.ms_wall
-        ms["transfer"] += stats.ms_transfer
-        launches_shade += stats.launches_shade
-        parts = gather_image()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        counts = torch.tensor([float(n_rays), float(stats.n_gathers), float(stats.n_samples)], dtype=torch.float64, device=device)
-        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
-        total_rays, total_gathers, total_samples = (float(x) for x in counts.tolist())
-    else:
-        total_rays, total_gathers, total_samples = float(n_rays), float(stats.n_gathers), float(stats.n_samples)
+    def timed(tier):
+        """W warm-up steps, then exactly K steps between two fences; max over ranks."""
+        ctx.set_arithmetic(tier)
+        for _ in range(args.warmup):
+            step()
+            gather_image()
+        fence()
+        t0 = time.perf_counter()
+        ms = dict(geodesic=0.0, locate=0.0, shade=0.0, transfer=0.0, wall=0.0)
+        launches = 0
+        stats = None
+        for _ in range(args.steps):
+            stats = step()
+            ms["geodesic"] += stats.ms_geodesic
+            ms["locate"] += stats.ms_locate
+            ms["shade"] += stats.ms_shade
+            ms["wall"] += stats.ms_wall
+            ms["transfer"] += stats.ms_transfer
+            launches += stats.launches_shade
+            gather_image()
+        fence()
+        elapsed = time.perf_counter() - t0
+        per_rank = [elapsed]
+        if distributed:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+            every = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(every, t)
+            per_rank = [float(x.item()) for x in every]
+            elapsed = max(per_rank)
+            counts = torch.tensor([float(n_rays), float(stats.n_gathers), float(stats.n_samples)], dtype=torch.float64, device=device)
+            dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+            totals = [float(x) for x in counts.tolist()]
+        else:
+            totals = [float(n_rays), float(stats.n_gathers), float(stats.n_samples)]
+        shade_ms_per_launch = ms["shade"] / max(launches, 1)
+        bytes_per_launch = stats.algorithmic_bytes / max(stats.launches_shade, 1)
+        return dict(elapsed=elapsed, per_rank=per_rank, ms=ms, stats=stats, totals=totals, shade_ms_per_launch=shade_ms_per_launch,
+                    bytes_per_launch=bytes_per_launch, tier_ran="tolerant" if stats.arithmetic == 1 else "exact")
+
+    main_run = timed(args.arithmetic)
+    exact_run = timed("exact") if args.arithmetic == "tolerant" else None
+    if exact_run is not None:
+        ctx.set_arithmetic("tolerant")
+        step()   # leave the headline tier's frame in `image` for the parity cross-check below
+        torch.cuda.synchronize()
 
     if rank == 0:
+        stats = main_run["stats"]
+        total_rays, total_gathers, total_samples = main_run["totals"]
+        elapsed = main_run["elapsed"]
         ms_per_step = 1000.0 * elapsed / args.steps
         value = total_rays / (elapsed / args.steps) / 1.0e6
-        # roofline of the dominant kernel, this rank's launches
-        shade_ms_per_launch = ms["shade"] / max(launches_shade, 1)
-        bytes_per_launch = stats.algorithmic_bytes / max(stats.launches_shade, 1)
-        achieved = bytes_per_launch / (shade_ms_per_launch * 1.0e-3) / 1.0e9
-        traffic = None
+        achieved = main_run["bytes_per_launch"] / (main_run["shade_ms_per_launch"] * 1.0e-3) / 1.0e9
+        traffic, traffic_source = None, None
         traffic_file = os.path.join(REPO, "profiles", "hbm_traffic.json")
-        if os.path.exists(traffic_file):
+        if os.path.exists(traffic_file) and not distributed:
             with open(traffic_file) as f:
-                traffic = json.load(f).get("bl_shade_kernel_bytes_per_launch")
+                recorded = json.load(f)
+            entry = recorded.get(main_run["tier_ran"], {})
+            traffic = entry.get("coefficient_kernel_bytes_per_launch")
+            traffic_source = entry.get("source")
+        tier_text = {"tolerant": "tolerant arithmetic tier (intensities within north_star's fp64 tolerance, counts / flags / cuts bit-exact)",
+                     "exact": "exact arithmetic tier (bit-identical to the reference with the pinned math library)"}
         line = {
             "metric": "Mrays/sec + achieved HBM GB/s, 1024^2 camera over 256^3 GRMHD grid",
             "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "strong" if (args.mode == "tiled" and distributed) else "weak",
+            "scaling": "strong" if tiled else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {
                 "workload": f"{res}x{res} plane camera (example_simulation.input) over {args.grid}^3 mock Athena++ GRMHD "
-                            "snapshot, DP integrator, trilinear sampling, thermal synchrotron 230 GHz, unpolarized",
+                            "snapshot, DP integrator, trilinear sampling, thermal synchrotron 230 GHz, unpolarized; "
+                            + tier_text[main_run["tier_ran"]],
+                "arithmetic": main_run["tier_ran"],
                 "rays_per_step": total_rays, "samples_per_ray": total_samples / total_rays,
                 "parallelism": ("1 GPU" if not distributed else
-                                (f"{world} GPUs, one {res}^2 frame per GPU (views at 360/N deg), grid replicated, frames gathered over RCCL"
-                                 if args.mode == "frames" else
-                                 f"{world} GPUs, one {res}^2 frame in {TILE}x{TILE} tiles dealt block-cyclically, grid replicated, image gathered over RCCL")),
+                                (f"{world} GPUs, one {res}^2 frame in {TILE}x{TILE} tiles dealt centre-first round-robin, grid replicated, image gathered over RCCL"
+                                 if tiled else
+                                 f"{world} GPUs, one {res}^2 frame per GPU (views at 360/N deg), grid replicated, frames gathered over RCCL")),
                 "chunks_per_step": stats.n_chunks,
             },
-            "kernel_ms_per_step": {k: v / args.steps for k, v in ms.items()},
+            "ranks_seen_by_rccl": world,
+            "ms_per_step_per_rank": {"min": 1000.0 * min(main_run["per_rank"]) / args.steps, "max": 1000.0 * max(main_run["per_rank"]) / args.steps},
+            "kernel_ms_per_step": {k: v / args.steps for k, v in main_run["ms"].items()},
             "hbm_gbs_algorithmic_whole_pipeline": (256.0 * total_gathers + 13.0 * total_rays) / (elapsed / args.steps) / 1.0e9,
-            "roofline": {"bound": "hbm", "kernel": "bl_shade_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": bytes_per_launch, "ms_per_launch": shade_ms_per_launch},
+            "roofline": {"bound": "hbm", "kernel": "bl_shade_fast_kernel" if main_run["tier_ran"] == "tolerant" else "bl_shade_kernel",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                         "algorithmic_bytes_per_launch": main_run["bytes_per_launch"], "ms_per_launch": main_run["shade_ms_per_launch"]},
         }
+        if exact_run is not None:
+            e_elapsed = exact_run["elapsed"]
+            e_achieved = exact_run["bytes_per_launch"] / (exact_run["shade_ms_per_launch"] * 1.0e-3) / 1.0e9
+            line["exact_tier"] = {
+                "value": exact_run["totals"][0] / (e_elapsed / args.steps) / 1.0e6, "unit": "Mrays/s", "ms_per_step": 1000.0 * e_elapsed / args.steps,
+                "kernel_ms_per_step": {k: v / args.steps for k, v in exact_run["ms"].items()},
+                "roofline": {"kernel": "bl_shade_kernel", "achieved": e_achieved, "frac": e_achieved / HBM_PEAK_GBS,
+                             "ms_per_launch": exact_run["shade_ms_per_launch"]},
+            }
         if not distributed and not args.no_cpu_baseline:
             pixels_cpu, cpu, cores = cpu_baseline(params_dict, grid, res, args.cpu_stride)
             line["cpu_baseline"] = {
@@ -223,12 +297,15 @@ def main():
                 "sample": f"one pixel in {args.cpu_stride} per axis of the same {res}^2 camera "
                           f"({pixels_cpu.size} rays, {cpu['seconds']:.1f} s), same grid, OpenMP over all host threads",
             }
-            # cross-check while we are here: the GPU frame agrees with the oracle on those pixels
+            # cross-check while we are here: the GPU frame (of the tier `value` was measured in) against the oracle
             gpu_img = image[0].cpu().numpy()[pixels_cpu]
             gpu_num = sample_num.cpu().numpy()[pixels_cpu]
             same = (gpu_img == cpu["image"][0]) | (np.isnan(gpu_img) & np.isnan(cpu["image"][0]))
+            with np.errstate(invalid="ignore"):
+                distance = float(np.nanmax(np.abs(gpu_img - cpu["image"][0])) / np.nanmax(np.abs(cpu["image"][0])))
             line["parity_vs_oracle_on_sample"] = {
-                "pixels": int(pixels_cpu.size), "image_bit_exact": bool(same.all()),
+                "pixels": int(pixels_cpu.size), "image_bit_exact": bool(same.all()), "image_linf_over_max": distance,
+                "nan_mask_equal": bool(np.array_equal(np.isnan(gpu_img), np.isnan(cpu["image"][0]))),
                 "sample_num_bit_exact": bool(np.array_equal(gpu_num, cpu["sample_num"])),
             }
         print(json.dumps(line), flush=True)

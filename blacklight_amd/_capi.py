@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libblacklight_amd.so")
+# BLACKLIGHT_AMD_LIB: another build of the same library (kernel A/B runs, tools/gpu_variants.sh)
+LIB_PATH = os.environ.get("BLACKLIGHT_AMD_LIB") or os.path.join(_HERE, "libblacklight_amd.so")
 
 BL_OK, BL_E_INPUT, BL_E_MISSING, BL_E_UNSUPPORTED, BL_E_DEVICE, BL_E_ARG, BL_E_STATE = range(7)
 
@@ -65,6 +66,7 @@ class Stats(C.Structure):
         ("launches_geodesic", C.c_int32), ("launches_shade", C.c_int32),
         ("launches_transfer", C.c_int32),
         ("ms_locate", C.c_float), ("ms_wall", C.c_float), ("launches_locate", C.c_int32),
+        ("arithmetic", C.c_int32), ("n_deferred", C.c_int64),
     ]
 
 
@@ -94,6 +96,8 @@ def lib():
     L.bl_frequencies.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int]
     L.bl_set_scratch_limit.argtypes = [C.c_void_p, C.c_uint64]
     L.bl_set_overlap.argtypes = [C.c_void_p, C.c_int]
+    L.bl_set_arithmetic.argtypes = [C.c_void_p, C.c_int]
+    L.bl_debug_set_guard_band.argtypes = [C.c_void_p, C.c_double]
     L.bl_debug_math.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
     L.bl_render.argtypes = [C.c_void_p, C.POINTER(RenderDesc)]
     L.bl_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]

@@ -93,6 +93,13 @@ class Context:
         self._check(self._lib.bl_debug_math(self._ctx, int(op), x.size, x.ctypes.data, yp, out.ctypes.data))
         return out
 
+    def set_arithmetic(self, mode):
+        """"exact" (default) or "tolerant": arithmetic tier of the coefficient kernel (bl_set_arithmetic)."""
+        self._check(self._lib.bl_set_arithmetic(self._ctx, {"exact": 0, "tolerant": 1}[mode]))
+
+    def debug_set_guard_band(self, relative_width):
+        self._check(self._lib.bl_debug_set_guard_band(self._ctx, float(relative_width)))
+
     def set_overlap(self, on):
         """Overlap the geodesic kernel of the next chunk with the shading of the current one."""
         self._check(self._lib.bl_set_overlap(self._ctx, 1 if on else 0))
@@ -196,9 +203,25 @@ class Context:
                                                  nxt.ctypes.data_as(C.c_void_p)))
         return flags.astype(bool), nxt[: 4 * count.value].copy()
 
-    def render_adaptive(self, want_camera=False):
+    def render_template(self, want_camera=False):
+        """The per-pixel outputs of render() for zero rays: which rows a level has and their leading shapes
+        (blacklight_amd.distributed uses it on a rank that holds no rays of a level)."""
+        n_render = self.num_render_images
+        return dict(image=np.empty((self.num_quantities, 0)), sample_num=np.empty(0, dtype=np.int32),
+                    sample_flags=np.empty(0, dtype=np.uint8),
+                    camera_pos=np.empty((0, 4)) if want_camera else None, camera_dir=np.empty((0, 4)) if want_camera else None,
+                    rendering=np.empty((n_render, 3, 0)) if n_render > 0 else None)
+
+    def render_adaptive(self, want_camera=False, distributed=False, comm=None):
         """The reference's do { Integrate; AddGeodesics } while (!done) loop (blacklight.cpp:196-233).
-        Returns a list of per-level dicts (level 0 first), each with image / block_locs / ..."""
+        Returns a list of per-level dicts (level 0 first), each with image / block_locs / ...
+        distributed=True: every rank of torch.distributed's default group calls this; the camera is tiled over the
+        ranks level by level (blacklight_amd.distributed.render_adaptive) and rank 0 gets the same list a single
+        GPU returns (the other ranks get None); warnings with the levels' totals are in .distributed_warnings."""
+        if distributed:
+            from . import distributed as bd
+            levels, self.distributed_warnings = bd.render_adaptive(self, comm, want_camera)
+            return levels
         levels = [self.render(want_camera=want_camera)]
         levels[0]["block_locs"] = None
         if int(self.params.get("adaptive_max_level") or 0) <= 0:

@@ -28,6 +28,7 @@ extern "C" hipError_t bl_launch_geodesic(const BlTraceArgs *args, int integrator
 extern "C" int bl_geodesic_occupancy(int integrator);
 extern "C" hipError_t bl_launch_locate(const BlShadeArgs *args, int grid, int lds_bytes, hipStream_t stream);
 extern "C" hipError_t bl_launch_shade(const BlShadeArgs *args, int model, int grid, hipStream_t stream);
+extern "C" hipError_t bl_launch_shade_fast(const BlShadeArgs *args, int grid, hipStream_t stream);
 extern "C" hipError_t bl_launch_polarized_coefficients(const BlShadeArgs *args, int grid, hipStream_t stream);
 extern "C" hipError_t bl_launch_transfer(const BlTransferArgs *args, hipStream_t stream);
 extern "C" hipError_t bl_launch_transfer_aux(const BlTransferArgs *args, hipStream_t stream);
@@ -39,6 +40,7 @@ namespace {
 constexpr double kPi = 3.141592653589793;
 constexpr double kC = 2.99792458e10;
 constexpr double kGGMsun = 1.32712440018e26;
+constexpr double kMp = 1.67262192369e-24;
 constexpr int kNumCellValues = 7;
 
 thread_local std::string g_global_error;
@@ -109,6 +111,8 @@ struct bl_ctx {
   size_t host_counters_chunks = 0;
   uint64_t scratch_limit = 144ull << 30;
   int overlap_chunks = 0;             // bl_set_overlap(): geodesic kernel of chunk c + 1 beside the shading of chunk c
+  int arithmetic = BL_ARITH_EXACT;    // bl_set_arithmetic()
+  double guard_band = 1.0e-9;         // tolerant tier: relative half-width around a cut threshold left to the exact kernel
 
   // image rows (radiation_integrator.cpp:436-520)
   int image_num_quantities = 0;
@@ -168,8 +172,9 @@ struct bl_ctx {
     DeviceBuffer<double2> d_pol_coeffs;
     DeviceBuffer<unsigned int> d_anchors;          // inter-block interpolation: eight anchor cells per record
     DeviceBuffer<BlCoefInputs> d_coef_inputs;      // polarized runs: coefficient kernel -> polarized coefficient kernel
+    DeviceBuffer<unsigned long long> d_redo;       // tolerant tier: records left to the exact coefficient kernel
     void Free() {
-      d_aux.Free(); d_sample_t.Free(); d_slow_frac.Free(); d_pol_samples.Free(); d_pol_coeffs.Free(); d_coef_inputs.Free(); d_anchors.Free();
+      d_redo.Free(); d_aux.Free(); d_sample_t.Free(); d_slow_frac.Free(); d_pol_samples.Free(); d_pol_coeffs.Free(); d_coef_inputs.Free(); d_anchors.Free();
       d_records_hot.Free(); d_records_cold.Free(); d_located.Free(); d_located_tag.Free(); d_transfer.Free(); d_ray_kt.Free(); d_ray_factor.Free();
       d_ray_sample_num.Free(); d_ray_flags.Free(); d_ray_out_index.Free(); d_counters.Free();
     }
@@ -995,6 +1000,18 @@ int bl_set_overlap(bl_ctx *ctx, int on) {
   return BL_OK;
 }
 
+int bl_debug_set_guard_band(bl_ctx *ctx, double relative_width) {
+  if (ctx == nullptr || !(relative_width >= 0.0)) return BL_E_ARG;
+  ctx->guard_band = relative_width;
+  return BL_OK;
+}
+
+int bl_set_arithmetic(bl_ctx *ctx, int mode) {
+  if (ctx == nullptr || (mode != BL_ARITH_EXACT && mode != BL_ARITH_TOLERANT)) return BL_E_ARG;
+  ctx->arithmetic = mode;
+  return BL_OK;
+}
+
 int bl_set_scratch_limit(bl_ctx *ctx, uint64_t bytes) {
   if (ctx == nullptr || bytes < (1ull << 20)) return BL_E_ARG;
   ctx->scratch_limit = bytes;
@@ -1037,6 +1054,13 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
     if (d->pixel_map == nullptr && n_rays > level_pixels) throw Failure{BL_E_ARG, "n_rays exceeds the pixels of this level."};
 
     const bool block_interp = simulation && ctx->grid_dev.block_interp != 0;
+    // Tolerant tier: plain unpolarized images of a spherical Kerr-Schild simulation with thermal electrons in a curved
+    // spacetime have the fast coefficient kernel; every other configuration is rendered in exact arithmetic whatever
+    // bl_set_arithmetic() asked for (bl_stats.arithmetic says which tier ran)
+    const bool fast = ctx->arithmetic == BL_ARITH_TOLERANT && simulation && !aux && !ctx->polarized && !slow && !block_interp
+        && p.plasma_power_frac == 0.0 && p.plasma_kappa_frac == 0.0 && p.plasma_model != BL_PLASMA_CODE_KAPPA
+        && p.simulation_coord == BL_COORD_SKS && !p.ray_flat && ctx->plasma_thermal_frac != 0.0;
+    const size_t redo_capacity = 1u << 20;
     // chunk size from the scratch budget: per ray max_steps * (2 x 32 B record + 40 B located sample
     // (simulation mode) + 16 B * n_nu transfer)
     const uint64_t per_ray = static_cast<uint64_t>(max_steps)
@@ -1099,6 +1123,7 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
         sl.d_coef_inputs.Ensure(record_capacity);
       }
       if (block_interp) sl.d_anchors.Ensure(record_capacity * 8);
+      if (fast) sl.d_redo.Ensure(redo_capacity);
     }
     EnsureChunkResources(ctx, n_chunks);
     ctx->d_freq.Ensure(n_nu);
@@ -1381,6 +1406,23 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
       cold.cut_b_min = lower(p.cut_b_min); cold.cut_b_max = upper(p.cut_b_max);
       cold.cut_sigma_min = lower(p.cut_sigma_min); cold.cut_sigma_max = upper(p.cut_sigma_max);
       cold.cut_beta_inverse_min = lower(p.cut_beta_inverse_min); cold.cut_beta_inverse_max = upper(p.cut_beta_inverse_max);
+      {
+        const double cuts[14] = {p.cut_rho_min, p.cut_rho_max, p.cut_n_e_min, p.cut_n_e_max, p.cut_p_gas_min, p.cut_p_gas_max,
+                                 p.cut_theta_e_min, p.cut_theta_e_max, p.cut_b_min, p.cut_b_max, p.cut_sigma_min, p.cut_sigma_max,
+                                 p.cut_beta_inverse_min, p.cut_beta_inverse_max};
+        pl.cut_mask = 0;
+        for (int c = 0; c < 14; c++) {
+          const bool active = cuts[c] >= 0.0;
+          if (active) pl.cut_mask |= 1 << c;
+          cold.fast_cut[c] = active ? cuts[c] : 0.0;
+          cold.fast_cut_lo[c] = active ? cuts[c] * (1.0 - ctx->guard_band) : 0.0;
+          cold.fast_cut_hi[c] = active ? cuts[c] * (1.0 + ctx->guard_band) : 0.0;
+        }
+        sa.fast_n_e_factor = 1.0 / (p.plasma_mu * kMp * (1.0 + 1.0 / p.plasma_ne_ni));
+        sa.fast_gamma[0] = 1.0 / (ctx->grid_meta.plasma_gamma - 1.0);
+        sa.fast_gamma[1] = 1.0 / (ctx->grid_meta.plasma_gamma_i - 1.0);
+        sa.fast_gamma[2] = 1.0 / (ctx->grid_meta.plasma_gamma_e - 1.0);
+      }
       pl.any_cell_cut = (p.cut_rho_min >= 0.0 || p.cut_rho_max >= 0.0 || p.cut_n_e_min >= 0.0 || p.cut_n_e_max >= 0.0
                          || p.cut_p_gas_min >= 0.0 || p.cut_p_gas_max >= 0.0 || p.cut_theta_e_min >= 0.0
                          || p.cut_theta_e_max >= 0.0 || p.cut_b_min >= 0.0 || p.cut_b_max >= 0.0 || p.cut_sigma_min >= 0.0
@@ -1433,6 +1475,7 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
     xa.ray_max_steps = max_steps;
     xa.fallback_nan = p.fallback_nan;
     xa.model_type = p.model_type;
+    xa.affine = fast ? 1 : 0;
     xa.n_rays_total = n_rays;
     xa.image = image;
     xa.out_sample_num = out_num;
@@ -1521,6 +1564,8 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
         xa.pol_coeffs = sl.d_pol_coeffs.ptr;
       }
       sa.anchors = block_interp ? sl.d_anchors.ptr : nullptr;
+      sa.redo_list = fast ? sl.d_redo.ptr : nullptr;
+      sa.redo_capacity = fast ? redo_capacity : 0;
       if (slow) {
         sa.slow.frac = sl.d_slow_frac.ptr;
         sa.slow.ray_extrap = ctx->d_ray_extrap.ptr + begin;
@@ -1545,7 +1590,8 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
         Check(bl_launch_locate(&sa, shares_gpu ? locate_grid_shared : locate_grid_alone, ctx->lds_table_bytes, stream), "locate kernel launch");
       }
       Check(hipEventRecord(e[3], stream), "event");
-      Check(bl_launch_shade(&sa, p.model_type, shade_grid, stream), "coefficient kernel launch");
+      if (fast) Check(bl_launch_shade_fast(&sa, shade_grid, stream), "coefficient kernel launch");
+      else Check(bl_launch_shade(&sa, p.model_type, shade_grid, stream), "coefficient kernel launch");
       if (ctx->polarized) Check(bl_launch_polarized_coefficients(&sa, ctx->num_cus * 8, stream), "polarized coefficient kernel launch");
       Check(hipEventRecord(e[4], stream), "event");
       Check(aux ? bl_launch_transfer_aux(&xa, stream) : bl_launch_transfer(&xa, stream), "transfer kernel launch");
@@ -1559,7 +1605,7 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
     Check(hipStreamSynchronize(stream), "kernel execution");
 
     float ms_geo = 0.0f, ms_locate = 0.0f, ms_shade = 0.0f, ms_transfer = 0.0f, ms_wall = 0.0f;
-    unsigned long long total_samples = 0, total_flagged = 0, total_records = 0, total_gathers = 0, max_num = 0;
+    unsigned long long total_samples = 0, total_flagged = 0, total_records = 0, total_gathers = 0, total_redo = 0, max_num = 0;
     for (int c = 0; c < n_chunks; c++) {
       hipEvent_t *e = ev + static_cast<size_t>(c) * kEventsPerChunk;
       const unsigned long long *hc = ctx->host_counters + static_cast<size_t>(c) * n_counters;
@@ -1575,6 +1621,7 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
                                         "of its cell-centre arrays (simulation_sampling.cpp:520-522): no defined result to reproduce."};
       total_records += hc[BL_CNT_RECORDS];
       total_gathers += hc[BL_CNT_GATHERS];
+      total_redo += hc[BL_CNT_REDO];
       total_samples += hc[BL_CNT_COUNT + 0];
       total_flagged += hc[BL_CNT_COUNT + 1];
       max_num = std::max<unsigned long long>(max_num, hc[BL_CNT_COUNT + 2]);
@@ -1608,6 +1655,8 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
     st.ms_transfer = ms_transfer;
     st.ms_total = ms_geo + ms_locate + ms_shade + ms_transfer;
     st.ms_wall = ms_wall;
+    st.arithmetic = fast ? BL_ARITH_TOLERANT : BL_ARITH_EXACT;
+    st.n_deferred = static_cast<int64_t>(total_redo);
     ctx->stats = st;
     // Warning text of the reference (geodesics.cpp:389-394)
     if (total_flagged > 0)

@@ -65,6 +65,7 @@ enum BlCounter {
   BL_CNT_OVERFLOW = 3,      // record buffer overflow flag
   BL_CNT_UNDEFINED = 4,     // inter-block interpolation: samples at an upper edge of the last MeshBlock
   BL_CNT_INTERP_FAILED = 5, // inter-block interpolation: samples for which no anchor block exists
+  BL_CNT_REDO = 6,          // tolerant tier: samples left to the exact coefficient kernel (redo list entries)
   BL_CNT_COUNT = 8
 };
 
@@ -110,6 +111,7 @@ struct BlPlasmaDevice {
   // power-law electrons (simulation_coefficients.cpp:54-66, :556-584); power_frac = 0: none
   double power_frac, plasma_p, power_jj, power_aa;
   int code_kappa;            // plasma_model = code_kappa: theta_e from the simulation's electron entropy (:351-358)
+  int cut_mask;              // bit c set: cell cut threshold c (BlShadeCold::fast_cut order) is active
 };
 
 // Kappa-distribution electrons (simulation_coefficients.cpp:82-193; the reference's names without the prefix).
@@ -138,6 +140,10 @@ struct BlShadeCold {
   float fallback_rho, fallback_pgas, fallback_kappa;
   double plasma_gamma, plasma_gamma_i, plasma_gamma_e;
   BlKappaDevice kappa;
+  // Tolerant tier: the active cell cut thresholds in the order rho, n_e, p_gas, theta_e, B, sigma, 1 / beta, each
+  // (min, max), and the guard band around each (threshold * (1 -+ 1e-9)) inside which the decision is left to the
+  // exact kernel
+  double fast_cut[14], fast_cut_lo[14], fast_cut_hi[14];
 };
 
 struct BlFormulaDevice {
@@ -282,6 +288,11 @@ struct BlShadeArgs {
   unsigned int *anchors;      // inter-block interpolation: [record capacity][8] cells of the eight anchors, else null
   double power_pol[7];        // simulation_coefficients.cpp:67-80: jj_q, jj_v, aa_q, aa_v, rho, rho_q, rho_v
   double plasma_gamma_min;
+  // tolerant arithmetic tier (bl_shade_fast_kernel) only
+  double fast_n_e_factor;     // 1 / (mu m_p (1 + 1 / ne_ni))
+  double fast_gamma[3];       // 1 / (gamma - 1), 1 / (gamma_i - 1), 1 / (gamma_e - 1) (plasma_use_p = false)
+  unsigned long long *redo_list;       // record indices left to the exact kernel, BL_CNT_REDO entries
+  unsigned long long redo_capacity;    // entries the list holds; more than that: the exact kernel shades every record
   int aux_need_coefficients;  // image_light || image_emission || image_tau || image_emission_ave || image_tau_int (:389)
   int aux_need_length;
   double cam_x[4];
@@ -303,6 +314,7 @@ struct BlTransferArgs {
   const double *frequencies;
   int n_nu, ray_max_steps, chunk_rays;
   int fallback_nan, model_type;
+  int affine;                 // tolerant tier: records are (a, c) of I <- a I + c instead of (a, b) of I <- a (I + b)
   long long n_rays_total;
   double *image;              // [n_q][n_rays_total]; rows 0..n_nu-1 = I_nu
   int *out_sample_num;        // [n_rays_total] or null

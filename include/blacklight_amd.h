@@ -272,6 +272,8 @@ typedef struct bl_stats {
   float ms_wall;              /* first kernel start to last kernel end; less than ms_total when the geodesic
                                  kernel of one chunk overlaps the shading of the previous one          */
   int32_t launches_locate;
+  int32_t arithmetic;         /* BL_ARITH_EXACT or BL_ARITH_TOLERANT: the tier the last bl_render ran in          */
+  int64_t n_deferred;         /* tolerant tier: samples whose cut decision was left to the exact kernel           */
 } bl_stats;
 
 typedef struct bl_ctx bl_ctx;
@@ -308,6 +310,18 @@ BL_API int bl_image_num_quantities(const bl_ctx *ctx);
 BL_API int bl_render_num_images(const bl_ctx *ctx);
 BL_API int bl_camera_frame_get(const bl_ctx *ctx, bl_camera_frame *out);
 BL_API int bl_frequencies(const bl_ctx *ctx, double *out, int n);
+/* Arithmetic tier of the coefficient kernel. BL_ARITH_EXACT (default): every operation in the reference's order with
+ * the pinned math library - images equal the reference's bit for bit (tier-B goldens). BL_ARITH_TOLERANT: the tolerance
+ * north_star grants for intensities ("within a stated fp64 tolerance", per-pixel L-infinity < 1e-6 of the image
+ * maximum; measured ~1e-13) is used between the sampled primitives and the transfer record of a sample - fused
+ * multiply-adds, faster exp / expm1 / cbrt, the fluid-frame angle and frequency as invariants instead of through
+ * the tetrad of simulation_coefficients.cpp:398-455. Ray-step counts, flags, cell indices, NaN masks and every cut
+ * decision stay those of the exact tier. Built for plain unpolarized images of spherical Kerr-Schild simulations
+ * with thermal electrons (the benchmark and the many-frequency renders); other configurations run in exact
+ * arithmetic regardless - bl_stats.arithmetic reports the tier that ran. */
+#define BL_ARITH_EXACT 0
+#define BL_ARITH_TOLERANT 1
+BL_API int bl_set_arithmetic(bl_ctx *ctx, int mode);
 /* Cap on scratch HBM (bytes) used for per-sample records; default 144 GiB (half of the MI355X HBM). */
 BL_API int bl_set_scratch_limit(bl_ctx *ctx, uint64_t bytes);
 /* on != 0: when a render needs several chunks, run the geodesic kernel of chunk c + 1 on a second stream
@@ -321,6 +335,11 @@ BL_API int bl_render(bl_ctx *ctx, const bl_render_desc *d);
  * 10 hypot (blmath.h), 11 bl_hypot_g, 12 bl_sqrt_g, 13 bl_div_g(x, y) (bl_geometry.h), 14 sqrt, 15 x / y,
  * 16 sincos -> sin, 17 sincos -> cos. Used by the tests to compare the device arithmetic with the host's. */
 BL_API int bl_debug_math(bl_ctx *ctx, int op, int64_t n, const double *x, const double *y, double *out);
+/* Tolerant tier, tests only: relative half-width of the band around an active cell cut threshold inside which the cut
+ * decision of a sample is left to the exact kernel (default 1e-9; the tolerant arithmetic is good to ~1e-13). A wide band
+ * defers many samples, which exercises the list and its overflow path. ops 20-24 of bl_debug_math are the tolerant
+ * tier's exp, expm1, cbrt, reciprocal and reciprocal square root. */
+BL_API int bl_debug_set_guard_band(bl_ctx *ctx, double relative_width);
 BL_API int bl_get_stats(const bl_ctx *ctx, bl_stats *out);
 /* Text of the last failure on this context ("Error: ...\n"), or "" */
 BL_API const char *bl_last_error(const bl_ctx *ctx);

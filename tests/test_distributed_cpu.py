@@ -66,3 +66,68 @@ def test_tiles_partition_the_image():
         # every rank gets the same number of tiles (+-1), dealt so that each holds central and peripheral ones
         counts = [bd.tile_pixels(128, r, world, 32).size // (32 * 32) for r in range(world)]
         assert max(counts) - min(counts) <= 1
+
+
+ADAPTIVE_STUB = dict(
+    model_type="formula", num_threads=1, output_format="npz", output_file="stub.npz", output_camera="true",
+    checkpoint_geodesic_save="false", checkpoint_geodesic_load="false", formula_mass=6.0e11, formula_spin=0.9, formula_r0=10.0,
+    formula_h=0.0, formula_l0=0.0, formula_q=0.5, formula_nup=2.3e11, formula_cn0=3.0e-18, formula_alpha=-3.0, formula_a=0.0,
+    formula_beta=2.5, camera_type="plane", camera_r=100.0, camera_th=60.0, camera_ph=0.0, camera_urn=0.0, camera_uthn=0.0,
+    camera_uphn=0.0, camera_k_r=1.0, camera_k_th=0.0, camera_k_ph=0.0, camera_rotation=0.0, camera_width=30.0,
+    camera_resolution=48, ray_flat="false", ray_terminate="additive", ray_factor=5.0e-4, ray_integrator="dp", ray_step=0.01,
+    ray_max_steps=2000, ray_max_retries=20, ray_tol_abs=1.0e-8, ray_tol_rel=1.0e-8, image_light="true",
+    image_num_frequencies=2, image_frequency_start=1.0e11, image_frequency_end=3.0e11, image_frequency_spacing="log",
+    image_normalization="camera", image_time="false", image_length="false", image_lambda="false", image_emission="false",
+    image_tau="false", image_lambda_ave="false", image_emission_ave="false", image_tau_int="false", image_crossings="false",
+    render_num_images=0, adaptive_max_level=2, adaptive_block_size=8, adaptive_frequency_num=1, adaptive_val_cut=0.0,
+    adaptive_val_frac=-1.0, adaptive_abs_grad_cut=0.0, adaptive_abs_grad_frac=-1.0, adaptive_rel_grad_cut=0.25,
+    adaptive_rel_grad_frac=0.2, adaptive_abs_lapl_cut=0.0, adaptive_abs_lapl_frac=-1.0, adaptive_rel_lapl_cut=0.5,
+    adaptive_rel_lapl_frac=0.2, adaptive_num_regions=0, cut_omit_near="false", cut_omit_far="false", cut_omit_in=-1.0,
+    cut_omit_out=-1.0, cut_midplane_theta=0.0, cut_midplane_z=0.0, cut_plane="false", fallback_nan="true",
+)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_adaptive_orchestration_world(tmp_path, world, built_library):
+    """blacklight_amd.distributed.render_adaptive - the code a multi-GPU run executes: per-level tiling, gathers of
+    image / counts / flags / camera rows, max / sum reductions, refinement on rank 0 (the real bl_adaptive_refine on a
+    host-only context), broadcast of the next block list - on 2 and 3 gloo ranks with a stub renderer, against the
+    same loop on one rank. 3 ranks: shares of unequal size (36 tiles, block counts not divisible by 3)."""
+    import dist_worker
+    out_path = str(tmp_path / "levels.npz")
+    mp.spawn(dist_worker.worker, args=(world, _free_port(), "stub", ADAPTIVE_STUB, None, True, out_path), nprocs=world, join=True)
+    got = np.load(out_path)
+    ctx = dist_worker.StubContext(ADAPTIVE_STUB)
+    want = dist_worker.serial_adaptive(ctx, True)
+    assert int(got["n_levels"]) == len(want) == 3          # the ring refines twice
+    total_flagged = 0
+    for n, level in enumerate(want):
+        for key in ("image", "sample_num", "sample_flags", "camera_pos", "camera_dir"):
+            assert np.array_equal(got[f"{key}_{n}"], level[key]), (n, key)
+        if n > 0:
+            assert np.array_equal(got[f"block_locs_{n}"], level["block_locs"])
+            assert level["block_locs"].shape[0] % world != 0 or world == 2
+        if n < len(want) - 1:
+            assert np.array_equal(got[f"refinement_flags_{n}"], level["refinement_flags"])
+        assert int(got[f"count_max_sample_num_{n}"]) == level["stats"].max_sample_num
+        assert int(got[f"count_n_flagged_{n}"]) == level["stats"].n_flagged
+        assert int(got[f"count_n_rays_{n}"]) == level["sample_num"].size
+        total_flagged += level["stats"].n_flagged
+    # one warning per level with the level's totals, in the reference's words (geodesics.cpp:389-394)
+    expected = "".join(f"Warning: {lv['stats'].n_flagged} out of {lv['sample_num'].size} geodesics terminate unexpectedly.\n"
+                       for lv in want if lv["stats"].n_flagged > 0)
+    assert str(got["warnings"]) == expected and total_flagged > 0
+
+
+def test_launcher_refuses_a_mismatched_world(tmp_path):
+    """bench.py --gpus N must equal the number of ranks it was started with, and without a launcher it must not run a
+    smaller job under that name: both fail before anything touches a GPU."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    run = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "4"], env=env, capture_output=True, text=True)
+    assert run.returncode != 0 and "must agree" in run.stderr
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    run = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "64"], env=env, capture_output=True, text=True)
+    assert run.returncode != 0 and "GPU(s) visible" in run.stderr

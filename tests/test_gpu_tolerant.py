@@ -1,0 +1,215 @@
+"""The tolerant arithmetic tier (bl_set_arithmetic, include/blacklight_amd.h): north_star's parity bar for intensities
+is a tolerance - per-pixel L-infinity < 1e-6 of the image maximum - while ray-step counts and termination masks are
+bit-exact. The tolerant coefficient kernel uses that room (fused multiply-adds, lighter exp / expm1 / cbrt, the
+fluid-frame angle and frequency as invariants). Checked here, on every golden case it applies to and at the
+benchmark's size:
+  * sample_num, sample_flags, NaN masks: identical to the exact tier and to the reference;
+  * intensities: within TOLERANCE of the exact tier, of the reference run with the pinned math library (tier B) and
+    of the stock reference (tier A) - measured distances are ~1e-13, printed with -s;
+  * configurations outside its scope run in exact arithmetic and stay bit-exact;
+  * the cut decisions it defers (guard band around active thresholds, list and list overflow) change nothing."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+TOLERANCE = 1.0e-6      # north_star: per-pixel L-infinity relative to the image maximum
+EXPECTED = 1.0e-11      # what rounding-level differences amount to; a regression beyond this is a bug, not noise
+
+
+def _applies(params):
+    """Scope of bl_shade_fast_kernel (bl_api.hip: `fast`)."""
+    def on(key):
+        return str(params.get(key, "false")) == "true"
+    aux = any(on(k) for k in ("image_time", "image_length", "image_lambda", "image_emission", "image_tau", "image_lambda_ave",
+                              "image_emission_ave", "image_tau_int", "image_crossings")) or int(params.get("render_num_images", 0)) > 0
+    return (params["model_type"] == "simulation" and not aux and not on("image_polarization") and not on("slow_light_on")
+            and not on("simulation_block_interp") and float(params.get("plasma_power_frac", 0.0)) == 0.0
+            and float(params.get("plasma_kappa_frac", 0.0)) == 0.0 and params.get("plasma_model", "ti_te_beta") == "ti_te_beta"
+            and params.get("simulation_coord", "sks") == "sks" and not on("ray_flat") and on("image_light"))
+
+
+def _both(params, mock_args, **render_args):
+    import blacklight_amd as bl
+    p = bl.Params.from_dict(params)
+    grid = gu.golden_grid(mock_args) if mock_args is not None else None
+    out = {}
+    with bl.Context(p) as ctx:
+        if grid is not None:
+            ctx.set_grid(grid)
+        for tier in ("exact", "tolerant"):
+            ctx.set_arithmetic(tier)
+            out[tier] = ctx.render(**render_args)
+    return out
+
+
+def _distance(a, b):
+    scale = np.nanmax(np.abs(b), axis=-1, keepdims=True)
+    scale = np.where(scale > 0, scale, 1.0)
+    with np.errstate(invalid="ignore"):
+        d = np.abs(a - b) / scale
+    return float(np.nanmax(d)) if np.isfinite(d).any() else 0.0
+
+
+ADAPTIVE = [c for c in gu.GPU_CASES if "adaptive" in c]
+
+
+@pytest.mark.parametrize("case", [c for c in gu.GPU_CASES if c not in ADAPTIVE])
+def test_tolerant_tier_on_the_goldens(case, built_library):
+    fx, params, mock_args = gu.load_case(case)
+    out = _both(params, mock_args)
+    exact, tol = out["exact"], out["tolerant"]
+    n_pix = exact["sample_num"].size
+    assert exact["stats"].arithmetic == 0
+    assert np.array_equal(tol["sample_num"], exact["sample_num"])
+    assert np.array_equal(tol["sample_flags"], exact["sample_flags"])
+    assert np.array_equal(np.isnan(tol["image"]), np.isnan(exact["image"]))
+    if not _applies(params):
+        assert tol["stats"].arithmetic == 0
+        assert gu.same_bits(tol["image"], exact["image"]).all()
+        return
+    assert tol["stats"].arithmetic == 1
+    d_exact = _distance(tol["image"], exact["image"])
+    d_b = _distance(tol["image"], gu.expected_image(fx, "B", n_pix))
+    d_a = _distance(tol["image"], gu.expected_image(fx, "A", n_pix))
+    print(f"{case}: tolerant vs exact {d_exact:.2e}, vs reference (pinned math) {d_b:.2e}, vs stock reference {d_a:.2e}, "
+          f"deferred {tol['stats'].n_deferred}")
+    assert d_exact < EXPECTED and d_b < EXPECTED
+    if float(params.get("simulation_a", 0.0)) == 0.0:   # spinning cases: glibc's hypot / pow move sample counts
+        assert np.array_equal(tol["sample_num"], fx["A_sample_num"])
+        assert d_a < TOLERANCE
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_tolerant_tier_on_seeded_configurations(seed, built_library):
+    """Cameras, spins, sampling modes, temperature models, cuts and frequency lists drawn inside the tier's scope."""
+    rng = np.random.default_rng(7000 + seed)
+    fx, params, mock_args = gu.load_case("sim_dp_interp")
+    over = dict(camera_resolution=20, camera_th=float(rng.uniform(5.0, 175.0)), camera_ph=float(rng.uniform(0.0, 360.0)),
+                camera_r=float(rng.uniform(30.0, 100.0)), camera_width=float(rng.uniform(8.0, 40.0)),
+                camera_type=str(rng.choice(["plane", "pinhole"])),
+                simulation_a=float(rng.choice([0.0, 0.0, 0.3, 0.9])), simulation_interp=str(rng.choice(["true", "false"])),
+                plasma_use_p=str(rng.choice(["true", "false"])), plasma_rat_high=float(rng.uniform(3.0, 40.0)),
+                fallback_rho=1.0e-6, fallback_pgas=1.0e-8,
+                cut_sigma_max=float(rng.choice([-1.0, 1.0, 10.0])), cut_theta_e_max=float(rng.choice([-1.0, 50.0])),
+                cut_beta_inverse_min=float(rng.choice([-1.0, 1.0e-3])), image_num_frequencies=int(rng.choice([1, 4])))
+    # NaN for off-grid samples only where the rays stay inside the grid's outer edge (r = 52): a camera beyond it with
+    # fallback_nan would make the whole image NaN and test nothing but the mask
+    over["fallback_nan"] = str(rng.choice(["true", "false"])) if over["camera_r"] < 50.0 else "false"
+    if over["camera_type"] == "pinhole":
+        over["camera_width"] = float(rng.uniform(0.05, 0.4)) * over["camera_r"]
+    if over["image_num_frequencies"] > 1:
+        over.update(image_frequency_start=1.0e11, image_frequency_end=float(10.0 ** rng.uniform(11.3, 12.0)), image_frequency_spacing="log")
+    mesh = [{}, dict(_blocks=[2, 2, 2]), dict(_refined=1)][seed % 3]
+    params = dict(params, **over)
+    assert _applies(params)
+    out = _both(params, dict(mock_args, **mesh))
+    exact, tol = out["exact"], out["tolerant"]
+    assert tol["stats"].arithmetic == 1
+    assert np.array_equal(tol["sample_num"], exact["sample_num"]) and np.array_equal(tol["sample_flags"], exact["sample_flags"])
+    assert np.array_equal(np.isnan(tol["image"]), np.isnan(exact["image"])), over
+    d = _distance(tol["image"], exact["image"])
+    print(f"seed {seed}: {d:.2e}, deferred {tol['stats'].n_deferred}, NaN pixels {int(np.isnan(exact['image']).sum())} of {exact['image'].size}")
+    assert d < EXPECTED, over
+    assert np.isfinite(exact["image"]).mean() > 0.5
+
+
+@pytest.mark.parametrize("band,resolution", [(1.0e30, 24), (1.0e30, 56)])
+def test_deferred_cut_decisions(band, resolution, built_library):
+    """An unbounded guard band defers every sample that reaches the cell cuts to the exact kernel: through the list
+    (24^2 rays), and past its capacity (56^2 rays x ~700 samples > 2^20 entries: every record is then shaded by the
+    exact kernel). Same image either way."""
+    import blacklight_amd as bl
+    # sim_cuts: rho, B and 1 / beta thresholds behind geometric cuts; sim_dp_interp (sigma < 1 only) keeps nearly every sample
+    fx, params, mock_args = gu.load_case("sim_cuts" if resolution < 40 else "sim_dp_interp")
+    params = dict(params, camera_resolution=resolution)
+    p = bl.Params.from_dict(params)
+    with bl.Context(p) as ctx:
+        ctx.set_grid(gu.golden_grid(mock_args))
+        exact = ctx.render()
+        ctx.set_arithmetic("tolerant")
+        plain = ctx.render()
+        ctx.debug_set_guard_band(band)
+        wide = ctx.render()
+    assert wide["stats"].arithmetic == 1 and wide["stats"].n_deferred > 10 * max(plain["stats"].n_deferred, 1)
+    if resolution > 40:
+        assert wide["stats"].n_deferred > (1 << 20)
+    assert np.array_equal(wide["sample_num"], exact["sample_num"])
+    assert np.array_equal(np.isnan(wide["image"]), np.isnan(exact["image"]))
+    assert _distance(wide["image"], exact["image"]) < EXPECTED
+    assert _distance(plain["image"], exact["image"]) < EXPECTED
+
+
+def test_tolerant_functions_are_accurate(built_library):
+    """exp, expm1, cbrt, reciprocal and reciprocal square root of the tolerant tier against numpy's long double."""
+    import blacklight_amd as bl
+    fx, params, _ = gu.load_case("formula_flat")
+    rng = np.random.default_rng(3)
+    ld = np.longdouble
+    with bl.Context(bl.Params.from_dict(params)) as ctx:
+        def worst(op, x, ref):
+            got = ctx.debug_math(op, x)
+            want = ref(x.astype(ld))
+            ok = np.isfinite(want.astype(np.float64)) & (want != 0)
+            return float(np.max(np.abs((got[ok].astype(ld) - want[ok]) / want[ok])))
+        x = np.concatenate([rng.uniform(-700.0, 700.0, 200000), rng.uniform(-1.0, 1.0, 200000), 10.0 ** rng.uniform(-300, -1, 1000)])
+        assert worst(20, x, np.exp) < 4.0e-16
+        xm = np.concatenate([rng.uniform(-40.0, 700.0, 200000), rng.uniform(-1.0, 1.0, 200000),
+                             10.0 ** rng.uniform(-300, -1, 1000), -(10.0 ** rng.uniform(-300, -1, 1000))])
+        assert worst(21, xm, np.expm1) < 6.0e-16
+        xp = 10.0 ** rng.uniform(-300.0, 300.0, 400000)
+        assert worst(22, xp, np.cbrt) < 4.0e-16
+        assert worst(23, xp, lambda v: 1 / v) < 3.0e-16
+        xq = 10.0 ** rng.uniform(-290.0, 300.0, 400000)
+        assert worst(24, xq, lambda v: 1 / np.sqrt(v)) < 4.0e-16
+        special = np.array([0.0, np.inf, np.nan, 5e-324, 1.0, 8.0, 27.0e300])
+        got = ctx.debug_math(22, special)
+        assert got[0] == 0.0 and got[1] == np.inf and np.isnan(got[2]) and got[4] == 1.0 and abs(got[5] - 2.0) < 1e-15
+        assert abs(got[3] / np.cbrt(ld(5e-324)) - 1) < 1e-15
+        sat = ctx.debug_math(20, np.array([-800.0, 800.0, np.nan]))
+        assert sat[0] == 0.0 and sat[1] == np.inf and np.isnan(sat[2])
+        sat = ctx.debug_math(21, np.array([-800.0, 800.0, np.nan, 0.0]))
+        assert sat[0] == -1.0 and sat[1] == np.inf and np.isnan(sat[2]) and sat[3] == 0.0
+        rc = ctx.debug_math(23, np.array([0.0, np.inf, -np.inf, np.nan]))
+        assert rc[0] == np.inf and rc[1] == 0.0 and rc[2] == 0.0 and np.isnan(rc[3])
+
+
+WINDOWS = os.path.join(gu.GOLDEN_DIR, "window_1024.npz")
+
+
+def test_tolerant_tier_at_the_benchmark_size(built_library):
+    """The 1024^2 frame over the 256^3 grid that bench.py times: tolerant vs exact over the whole frame, and the three
+    windows the unmodified reference computed (tests/golden/window_1024.npz) in the tolerant tier."""
+    import blacklight_amd as bl
+    from blacklight_amd import mock
+    import bench
+    grid = mock.generate(n_r=256, n_th=256, n_ph=256)
+    p = bl.Params.from_dict(dict(bench.WORKLOAD))
+    res, bs = 1024, 16
+    with bl.Context(p) as ctx:
+        ctx.set_grid(grid)
+        exact = ctx.render()
+        ctx.set_arithmetic("tolerant")
+        tol = ctx.render()
+        assert tol["stats"].arithmetic == 1
+        assert np.array_equal(tol["sample_num"], exact["sample_num"]) and np.array_equal(tol["sample_flags"], exact["sample_flags"])
+        assert np.array_equal(np.isnan(tol["image"]), np.isnan(exact["image"]))
+        assert tol["stats"].n_gathers == exact["stats"].n_gathers
+        d = _distance(tol["image"], exact["image"])
+        print(f"1024^2 frame: tolerant vs exact {d:.2e}, deferred {tol['stats'].n_deferred} of {tol['stats'].n_samples_emitted}")
+        assert d < EXPECTED
+        if os.path.exists(WINDOWS):
+            fx = np.load(WINDOWS, allow_pickle=False)
+            iv, iu = np.mgrid[0:bs, 0:bs]
+            pixels = np.concatenate([((bv * bs + iv) * res + (bu * bs + iu)).reshape(-1) for bv, bu in fx["B_block_locs"]]).astype(np.int32)
+            got = tol["image"][0][pixels]
+            for tier in ("B", "A"):
+                want = fx[f"{tier}_I_nu"].reshape(-1)
+                dist = np.nanmax(np.abs(got - want)) / np.nanmax(np.abs(want))
+                print(f"windows vs reference tier {tier}: {dist:.2e}")
+                assert dist < (EXPECTED if tier == "B" else TOLERANCE)

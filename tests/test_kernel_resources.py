@@ -16,10 +16,14 @@ BENCHMARK_KERNELS = {
     "_Z18bl_geodesic_kernelILi0ELb0ELb0EEv11BlTraceArgs": (1, 0),        # ... any spin
     "_Z16bl_locate_kernelILb0ELb0ELb1EEv11BlShadeArgs": (4, 0),          # merged grid, no slow light, zero spin
     "_Z16bl_locate_kernelILb0ELb0ELb0EEv11BlShadeArgs": (4, 0),
-    "_Z15bl_shade_kernelILi0ELb0ELb0ELb1ELb0ELb1EEv11BlShadeArgs": (2, 0),   # simulation, thermal electrons, SKS + curved, zero spin
-    "_Z15bl_shade_kernelILi0ELb0ELb0ELb1ELb0ELb0EEv11BlShadeArgs": (2, 0),   # ... any spin
-    "_Z15bl_shade_kernelILi0ELb0ELb0ELb0ELb0ELb0EEv11BlShadeArgs": (2, 0),   # the same for any coordinates
-    "_Z18bl_transfer_kernel14BlTransferArgs": (None, 0),
+    "_Z15bl_shade_kernelILi0ELb0ELb0ELb1ELb0ELb1ELb0EEv11BlShadeArgs": (2, 0),   # simulation, thermal electrons, SKS + curved, zero spin
+    "_Z15bl_shade_kernelILi0ELb0ELb0ELb1ELb0ELb0ELb0EEv11BlShadeArgs": (2, 0),   # ... any spin
+    "_Z15bl_shade_kernelILi0ELb0ELb0ELb0ELb0ELb0ELb0EEv11BlShadeArgs": (2, 0),   # the same for any coordinates
+    "_Z20bl_shade_fast_kernelILb1EEv11BlShadeArgs": (None, 0),               # tolerant tier, zero spin
+    "_Z20bl_shade_fast_kernelILb0EEv11BlShadeArgs": (None, 0),
+    "_Z15bl_shade_kernelILi0ELb0ELb0ELb1ELb0ELb1ELb1EEv11BlShadeArgs": (2, 0),   # ... its exact second pass
+    "_Z18bl_transfer_kernelILb0EEv14BlTransferArgs": (None, 0),
+    "_Z18bl_transfer_kernelILb1EEv14BlTransferArgs": (None, 0),
 }
 
 
