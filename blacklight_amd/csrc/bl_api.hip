@@ -757,6 +757,8 @@ void UploadMergedGrid(bl_ctx *ctx, const bl_grid_desc *g) {
       size_t bytes = 0;
       for (int a = 0; a < 3; a++) bytes += (2 * static_cast<size_t>(n[a]) + 1) * sizeof(double) + static_cast<size_t>(dev.n_bucket[a]) * sizeof(unsigned short);
       ctx->lds_table_bytes = bytes > 60 * 1024 ? 0 : static_cast<int>((bytes + 15) / 16 * 16);
+      if (ctx->lds_table_bytes == 0 && ctx->params.slow_light_on)
+        throw Failure{BL_E_UNSUPPORTED, "Slow light on a grid whose coordinate tables exceed the 60 KiB LDS budget is not built."};
     }
     ctx->n_i = n_i;
     ctx->n_j = n_j;

@@ -31,6 +31,8 @@
 // Compile with -ffp-contract=off: bit-exact sample counts depend on it (see blmath.h).
 #include <hip/hip_runtime.h>
 
+#include <cstddef>
+
 #include "bl_device.h"
 #include "bl_pol_frame.h"
 #include "bl_bessel.h"
@@ -1737,7 +1739,10 @@ __device__ __forceinline__ void shade_formula(const BlShadeArgs &P, const BlSpac
 // overlap its arithmetic instead of saturating the texture addresser here).
 // kRefined: mesh with refinement; block and cell come from tables in global memory, no LDS staging.
 // kSlow: slow light; the time slice of every sample that passed the cuts is found first (:296-349).
-template <bool kRefined, bool kSlow, bool kSpinZero>
+// kTablesInHbm: the coordinate tables of a merged grid are too large for LDS and are searched where they lie (a
+// compile-time choice: table pointers that may be either LDS or global become flat loads, each of which waits on both
+// memory counters).
+template <bool kRefined, bool kSlow, bool kSpinZero, bool kTablesInHbm = false>
 __global__ void __launch_bounds__(256, 4) bl_locate_kernel(const BlShadeArgs P) {
   const BlSpacetime st = P.st;
   extern __shared__ double lds_tables[];
@@ -1747,7 +1752,7 @@ __global__ void __launch_bounds__(256, 4) bl_locate_kernel(const BlShadeArgs P) 
       tab.xf[a] = tab.xv[a] = nullptr;
       tab.bucket[a] = nullptr;
     }
-  } else if (P.lds_table_bytes == 0) {   // tables too large for LDS: search them in HBM
+  } else if (kTablesInHbm) {
     const BlGridDevice &g = P.grid;
     for (int a = 0; a < 3; a++) {
       tab.xf[a] = g.xf[a];
@@ -2096,30 +2101,10 @@ __device__ __forceinline__ double rsqrt(double x) {
   e = __builtin_fma(-h * y, y, 0.5);
   return __builtin_fma(y, e, y);
 }
-// exp(x): the polynomial of bl_exp (blmath.h), hardware rounding and ldexp; x beyond the range of doubles saturates
-__device__ __forceinline__ double exp(double x) {
-  x = x > 710.0 ? 710.0 : (x < -746.0 ? -746.0 : x);
-  const double kd = __builtin_rint(x * BLM_INV_LN2);
-  double r = __builtin_fma(-kd, BLM_LN2_HI, x);
-  r = __builtin_fma(-kd, BLM_LN2_LO, r);
-  double p = 0x1.61bfaa228dde5p-33;
-  p = __builtin_fma(p, r, 0x1.1f7f2776cfaf2p-29);
-  p = __builtin_fma(p, r, 0x1.ae642c82e33d5p-26);
-  p = __builtin_fma(p, r, 0x1.27e4d41966f2fp-22);
-  p = __builtin_fma(p, r, 0x1.71de3a5aa7bb7p-19);
-  p = __builtin_fma(p, r, 0x1.a01a01a9e991bp-16);
-  p = __builtin_fma(p, r, 0x1.a01a01a0196acp-13);
-  p = __builtin_fma(p, r, 0x1.6c16c16c15a68p-10);
-  p = __builtin_fma(p, r, 0x1.1111111111111p-7);
-  p = __builtin_fma(p, r, 0x1.5555555555557p-5);
-  p = __builtin_fma(p, r, 0x1.5555555555555p-3);
-  p = __builtin_fma(p, r, 0x1.0000000000000p-1);
-  const double e = __builtin_fma(r * r, p, r) + 1.0;
-  return __builtin_amdgcn_ldexp(e, (int)kd);
-}
-// expm1(x): the polynomial of bl_expm1; accurate for tiny |x| (k = 0: r + r^2 / 2 + r^3 q(r))
-__device__ __forceinline__ double expm1(double x) {
-  x = x > 710.0 ? 710.0 : (x < -40.0 ? -40.0 : x);
+// exp(x) and expm1(x) share one core: x = k ln 2 + r, |r| <= ln 2 / 2, and e = expm1(r) = r + r^2 / 2 + r^3 q(r) with the
+// polynomial of bl_expm1 (blmath.h); hardware rounding and ldexp. One set of coefficients for both keeps two dozen
+// scalar registers free (a v_fma_f64 cannot take a 64-bit literal: every coefficient is a register pair).
+__device__ __forceinline__ double expm1_core(double x, int *k) {
   const double kd = __builtin_rint(x * BLM_INV_LN2);
   double r = __builtin_fma(-kd, BLM_LN2_HI, x);
   r = __builtin_fma(-kd, BLM_LN2_LO, r);
@@ -2136,8 +2121,22 @@ __device__ __forceinline__ double expm1(double x) {
   q = __builtin_fma(q, r, 0x1.5555555555555p-5);
   q = __builtin_fma(q, r, 0x1.5555555555555p-3);
   const double r2 = r * r;
-  const double e = r + __builtin_fma(r2 * r, q, 0.5 * r2);
-  const double t = __builtin_amdgcn_ldexp(1.0, (int)kd);   // 2^k; inf for k = 1024 (x > 709.78)
+  *k = (int)kd;
+  return r + __builtin_fma(r2 * r, q, 0.5 * r2);
+}
+// exp(x); x beyond the range of doubles saturates to 0 / inf
+__device__ __forceinline__ double exp(double x) {
+  x = x > 710.0 ? 710.0 : (x < -746.0 ? -746.0 : x);
+  int k;
+  const double e = expm1_core(x, &k);
+  return __builtin_amdgcn_ldexp(1.0 + e, k);
+}
+// expm1(x); accurate for tiny |x| (k = 0: the core itself)
+__device__ __forceinline__ double expm1(double x) {
+  x = x > 710.0 ? 710.0 : (x < -40.0 ? -40.0 : x);
+  int k;
+  const double e = expm1_core(x, &k);
+  const double t = __builtin_amdgcn_ldexp(1.0, k);   // 2^k; inf for k = 1024 (x > 709.78)
   return (t - 1.0) + t * e;
 }
 // cbrt(x) for x >= 0 (0, inf and NaN pass through): x = m 2^(3q), m in [0.5, 4); m^(-1/3) from a single-precision
@@ -2862,6 +2861,10 @@ extern "C" hipError_t bl_launch_locate(const BlShadeArgs *args, int grid, int ld
   } while (0)
   if (refined && slow) BL_LAUNCH_L(true, true, 0);
   else if (refined) BL_LAUNCH_L(true, false, 0);
+  else if (lds_bytes == 0) {   // merged grid with tables beyond the LDS budget (not with slow light: its instantiation needs them in LDS)
+    if (spin_zero) hipLaunchKernelGGL((bl_locate_kernel<false, false, true, true>), dim3(grid), dim3(256), 0, stream, *args);
+    else hipLaunchKernelGGL((bl_locate_kernel<false, false, false, true>), dim3(grid), dim3(256), 0, stream, *args);
+  }
   else if (slow) BL_LAUNCH_L(false, true, lds_bytes);
   else BL_LAUNCH_L(false, false, lds_bytes);
 #undef BL_LAUNCH_L
