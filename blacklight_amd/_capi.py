@@ -25,6 +25,9 @@ class GridDesc(C.Structure):
         ("ind_bb1", C.c_int32), ("ind_bb2", C.c_int32), ("ind_bb3", C.c_int32),
         ("plasma_gamma", C.c_double), ("plasma_gamma_i", C.c_double), ("plasma_gamma_e", C.c_double),
         ("levels", C.c_void_p), ("locations", C.c_void_p), ("n_3_root", C.c_int32),
+        ("sks_map", C.c_void_p), ("sks_map_n1", C.c_int32), ("sks_map_n2", C.c_int32),
+        ("sks_map_r_in", C.c_double), ("sks_map_dr", C.c_double), ("sks_map_dtheta", C.c_double),
+        ("simulation_bounds", C.c_double * 6),
     ]
 
 
@@ -97,6 +100,8 @@ def lib():
     L.bl_set_scratch_limit.argtypes = [C.c_void_p, C.c_uint64]
     L.bl_set_overlap.argtypes = [C.c_void_p, C.c_int]
     L.bl_set_arithmetic.argtypes = [C.c_void_p, C.c_int]
+    L.bl_device_count.restype = C.c_int
+    L.bl_set_undefined_policy.argtypes = [C.c_void_p, C.c_int]
     L.bl_debug_set_guard_band.argtypes = [C.c_void_p, C.c_double]
     L.bl_debug_math.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
     L.bl_render.argtypes = [C.c_void_p, C.POINTER(RenderDesc)]

@@ -73,7 +73,7 @@ def build(force=False, verbose=False):
     os.makedirs(os.path.dirname(EXE), exist_ok=True)
     main_src = os.path.join(CSRC, "bl_main.cpp")
     if force or rebuilt or not os.path.exists(EXE) or os.path.getmtime(EXE) < os.path.getmtime(main_src):
-        cmd = ["g++", "-std=c++17", "-O2", f"-I{INCLUDE}", main_src, "-o", EXE, f"-L{HERE}", "-lblacklight_amd",
+        cmd = ["g++", "-std=c++17", "-O2", "-pthread", f"-I{INCLUDE}", main_src, "-o", EXE, f"-L{HERE}", "-lblacklight_amd",
                "-Wl,-rpath,$ORIGIN/.."]
         result = subprocess.run(cmd, capture_output=True, text=True)
         if result.returncode != 0:

@@ -93,6 +93,10 @@ class Context:
         self._check(self._lib.bl_debug_math(self._ctx, int(op), x.size, x.ctypes.data, yp, out.ctypes.data))
         return out
 
+    def set_undefined_policy(self, policy):
+        """"refuse" (default) or "edge": samples where the reference reads past its arrays (bl_set_undefined_policy)."""
+        self._check(self._lib.bl_set_undefined_policy(self._ctx, {"refuse": 0, "edge": 1}[policy]))
+
     def set_arithmetic(self, mode):
         """"exact" (default) or "tolerant": arithmetic tier of the coefficient kernel (bl_set_arithmetic)."""
         self._check(self._lib.bl_set_arithmetic(self._ctx, {"exact": 0, "tolerant": 1}[mode]))

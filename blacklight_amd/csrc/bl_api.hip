@@ -112,6 +112,7 @@ struct bl_ctx {
   uint64_t scratch_limit = 144ull << 30;
   int overlap_chunks = 0;             // bl_set_overlap(): geodesic kernel of chunk c + 1 beside the shading of chunk c
   int arithmetic = BL_ARITH_EXACT;    // bl_set_arithmetic()
+  int undefined_policy = BL_UNDEFINED_REFUSE;   // bl_set_undefined_policy()
   double guard_band = 1.0e-9;         // tolerant tier: relative half-width around a cut threshold left to the exact kernel
 
   // image rows (radiation_integrator.cpp:436-520)
@@ -131,6 +132,7 @@ struct bl_ctx {
   DeviceBuffer<double> d_coords;   // x1f x1v x2f x2v x3f x3v packed
   DeviceBuffer<unsigned short> d_buckets;
   DeviceBuffer<int> d_lattice;   // refined mesh: box of the block-boundary lattice -> block
+  DeviceBuffer<double> d_sks_map;   // simulation_coord = fmks: the reader's SKS -> FMKS look-up table
   DeviceBuffer<int> d_block_table;                  // inter-block interpolation: levels, locations, hash blocks
   DeviceBuffer<unsigned long long> d_block_keys;    // ... and hash keys
   BlGridDevice grid_dev{};
@@ -332,8 +334,8 @@ void ValidateRadiation(bl_ctx *ctx) {
     } else if (Has(p, BL_P_simulation_block_interp)) {
       Warn(ctx, "Ignoring simulation_block_interp selection.");
     }
-    if (p.simulation_coord == BL_COORD_FMKS)
-      throw Failure{BL_E_UNSUPPORTED, "simulation_coord = fmks is not built yet."};
+    if (p.simulation_coord == BL_COORD_FMKS && p.slow_light_on)
+      throw Failure{BL_E_UNSUPPORTED, "simulation_coord = fmks with slow light is not built."};
   } else {
     if (Has(p, BL_P_checkpoint_sample_save) && p.checkpoint_sample_save) Warn(ctx, "Ignoring checkpoint_sample_save selection.");
     if (Has(p, BL_P_checkpoint_sample_load) && p.checkpoint_sample_load) Warn(ctx, "Ignoring checkpoint_sample_load selection.");
@@ -750,6 +752,25 @@ void UploadMergedGrid(bl_ctx *ctx, const bl_grid_desc *g) {
       dev.n[a] = n[a];
       dev.nb[a] = nb_cells[a];
     }
+    if (ctx->params.simulation_coord == BL_COORD_FMKS) {
+      // FMKS grid (simulation_sampling.cpp:66-73): native coordinates above, plus the reader's map and bounds
+      if (n_b != 1 || g->sks_map == nullptr || g->sks_map_n1 < 2 || g->sks_map_n2 < 2)
+        throw Failure{BL_E_ARG, "simulation_coord = fmks needs a single block and the reader's sks_map in bl_grid_desc."};
+      const size_t map_count = static_cast<size_t>(2) * g->sks_map_n1 * g->sks_map_n2;
+      ctx->d_sks_map.Ensure(map_count);
+      Check(hipMemcpy(ctx->d_sks_map.ptr, g->sks_map, map_count * sizeof(double), hipMemcpyHostToDevice), "sks_map upload");
+      dev.fmks = 1;
+      dev.sks_map = ctx->d_sks_map.ptr;
+      dev.sks_map_n1 = g->sks_map_n1;
+      dev.sks_map_n2 = g->sks_map_n2;
+      dev.sks_map_r_in = g->sks_map_r_in;
+      dev.sks_map_dr = g->sks_map_dr;
+      dev.sks_map_dtheta = g->sks_map_dtheta;
+      for (int c = 0; c < 6; c++) dev.fmks_bounds[c] = g->simulation_bounds[c];
+      dev.fmks_x1_0 = xf[0][0];
+      dev.fmks_dx1 = xf[0][1] - xf[0][0];
+      dev.fmks_dx2 = xf[1][1] - xf[1][0];
+    }
     ctx->grid_dev = dev;
     {
       // The locate kernel stages the tables in LDS when they fit 60 KiB (up to ~640 cells per axis); larger grids
@@ -1008,6 +1029,17 @@ int bl_debug_set_guard_band(bl_ctx *ctx, double relative_width) {
   return BL_OK;
 }
 
+int bl_device_count(void) {
+  int count = 0;
+  return hipGetDeviceCount(&count) == hipSuccess ? count : 0;
+}
+
+int bl_set_undefined_policy(bl_ctx *ctx, int policy) {
+  if (ctx == nullptr || (policy != BL_UNDEFINED_REFUSE && policy != BL_UNDEFINED_EDGE)) return BL_E_ARG;
+  ctx->undefined_policy = policy;
+  return BL_OK;
+}
+
 int bl_set_arithmetic(bl_ctx *ctx, int mode) {
   if (ctx == nullptr || (mode != BL_ARITH_EXACT && mode != BL_ARITH_TOLERANT)) return BL_E_ARG;
   ctx->arithmetic = mode;
@@ -1061,7 +1093,7 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
     // bl_set_arithmetic() asked for (bl_stats.arithmetic says which tier ran)
     const bool fast = ctx->arithmetic == BL_ARITH_TOLERANT && simulation && !aux && !ctx->polarized && !slow && !block_interp
         && p.plasma_power_frac == 0.0 && p.plasma_kappa_frac == 0.0 && p.plasma_model != BL_PLASMA_CODE_KAPPA
-        && p.simulation_coord == BL_COORD_SKS && !p.ray_flat && ctx->plasma_thermal_frac != 0.0;
+        && (p.simulation_coord == BL_COORD_SKS || p.simulation_coord == BL_COORD_FMKS) && !p.ray_flat && ctx->plasma_thermal_frac != 0.0;
     const size_t redo_capacity = 1u << 20;
     // chunk size from the scratch budget: per ray max_steps * (2 x 32 B record + 40 B located sample
     // (simulation mode) + 16 B * n_nu transfer)
@@ -1389,7 +1421,9 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
       cold.plasma_gamma_e = ctx->grid_meta.plasma_gamma_e;
       pl.plasma_use_p = p.plasma_use_p;
       pl.simulation_interp = p.simulation_interp;
-      pl.simulation_coord = p.simulation_coord;
+      // fmks: the reader has put vectors on the spherical Kerr-Schild basis; everything but the cell search treats the
+      // grid as sks (radiation_geometry.cpp:39, :94, :460, :541)
+      pl.simulation_coord = p.simulation_coord == BL_COORD_FMKS ? BL_COORD_SKS : p.simulation_coord;
       pl.fallback_nan = p.fallback_nan;
       cold.fallback_rho = p.fallback_nan ? 0.0f : p.fallback_rho;
       cold.fallback_pgas = p.fallback_nan ? 0.0f : p.fallback_pgas;
@@ -1431,6 +1465,7 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
                          || p.cut_sigma_max >= 0.0 || p.cut_beta_inverse_min >= 0.0 || p.cut_beta_inverse_max >= 0.0) ? 1 : 0;
       sa.grid = ctx->grid_dev;
       sa.lds_table_bytes = ctx->lds_table_bytes;
+      sa.undefined_edge = ctx->undefined_policy == BL_UNDEFINED_EDGE ? 1 : 0;
     } else {
       BlFormulaDevice &fm = sa.formula;
       fm.r0 = p.formula_r0; fm.h = p.formula_h; fm.l0 = p.formula_l0; fm.q = p.formula_q; fm.nup = p.formula_nup;
@@ -1491,7 +1526,7 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
       xa.camera_pos = cam_pos;
       xa.camera_dir = cam_dir;
       xa.st = ctx->st;
-      xa.simulation_coord = p.simulation_coord;
+      xa.simulation_coord = p.simulation_coord == BL_COORD_FMKS ? BL_COORD_SKS : p.simulation_coord;
       xa.rotation_split = p.image_rotation_split ? 1 : 0;
       for (int mu = 0; mu < 4; mu++) {
         xa.cam_u_con[mu] = ctx->frame.u_con[mu];
@@ -1607,7 +1642,7 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
     Check(hipStreamSynchronize(stream), "kernel execution");
 
     float ms_geo = 0.0f, ms_locate = 0.0f, ms_shade = 0.0f, ms_transfer = 0.0f, ms_wall = 0.0f;
-    unsigned long long total_samples = 0, total_flagged = 0, total_records = 0, total_gathers = 0, total_redo = 0, max_num = 0;
+    unsigned long long total_samples = 0, total_flagged = 0, total_records = 0, total_gathers = 0, total_redo = 0, total_undefined = 0, max_num = 0;
     for (int c = 0; c < n_chunks; c++) {
       hipEvent_t *e = ev + static_cast<size_t>(c) * kEventsPerChunk;
       const unsigned long long *hc = ctx->host_counters + static_cast<size_t>(c) * n_counters;
@@ -1618,9 +1653,16 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
       Check(hipEventElapsedTime(&ms, e[4], e[5]), "event time"); ms_transfer += ms;
       if (hc[BL_CNT_OVERFLOW] != 0) throw Failure{BL_E_DEVICE, "Sample record buffer overflow."};
       if (hc[BL_CNT_INTERP_FAILED] != 0) throw Failure{BL_E_INPUT, "Grid interpolation failed."};   // simulation_sampling.cpp:1319
-      if (hc[BL_CNT_UNDEFINED] != 0)
+      if (hc[BL_CNT_UNDEFINED] != 0 && ctx->undefined_policy != BL_UNDEFINED_EDGE) {
+        if (p.simulation_coord == BL_COORD_FMKS)
+          throw Failure{BL_E_UNSUPPORTED, "FMKS sampling reached the last polar zone of the last azimuthal plane (or the last entry of the "
+                                          "coordinate table), where the reference reads past its arrays (simulation_sampling.cpp:405-415, "
+                                          ":809-819): no defined result to reproduce. bl_set_undefined_policy(BL_UNDEFINED_EDGE) uses the edge cell instead."};
         throw Failure{BL_E_UNSUPPORTED, "Inter-block interpolation reached an upper edge of the last MeshBlock, where the reference reads past the end "
-                                        "of its cell-centre arrays (simulation_sampling.cpp:520-522): no defined result to reproduce."};
+                                        "of its cell-centre arrays (simulation_sampling.cpp:520-522): no defined result to reproduce. "
+                                        "bl_set_undefined_policy(BL_UNDEFINED_EDGE) mirrors the last cell centre about the block's face instead."};
+      }
+      total_undefined += hc[BL_CNT_UNDEFINED];
       total_records += hc[BL_CNT_RECORDS];
       total_gathers += hc[BL_CNT_GATHERS];
       total_redo += hc[BL_CNT_REDO];
@@ -1663,6 +1705,8 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
     // Warning text of the reference (geodesics.cpp:389-394)
     if (total_flagged > 0)
       Warn(ctx, std::to_string(total_flagged) + " out of " + std::to_string(n_rays) + " geodesics terminate unexpectedly.");
+    if (total_undefined > 0)   // BL_UNDEFINED_EDGE (this text has no counterpart in the reference)
+      Warn(ctx, std::to_string(total_undefined) + " samples lie where the reference reads past its arrays; the edge cell was used for them.");
     if (slow) {   // simulation_sampling.cpp:553-617: pixels whose samples fall outside the window of files
       std::vector<unsigned int> flags(n_rays);
       unsigned long long maxima[4];

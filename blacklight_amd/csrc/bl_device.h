@@ -97,6 +97,14 @@ struct BlGridDevice {
   const int *hash_blocks;
   unsigned int hash_mask;
   int max_level, n_3_level0;     // n_3_level(level) = n_3_level0 << level (:84-93)
+  // FMKS grids (simulation_coord = fmks; simulation_sampling.cpp:190-198, :396-456): one block in native coordinates
+  // (tables above: only x^3 is searched in them), position in x^1, x^2 from the reader's look-up table
+  int fmks;
+  const double *sks_map;         // [2][sks_map_n2][sks_map_n1]
+  int sks_map_n1, sks_map_n2;
+  double sks_map_r_in, sks_map_dr, sks_map_dtheta;
+  double fmks_bounds[6];         // r, theta, phi limits of the grid
+  double fmks_x1_0, fmks_dx1, fmks_dx2;
 };
 
 struct BlPlasmaDevice {
@@ -269,6 +277,7 @@ struct BlShadeArgs {
   BlLocated *located;         // [record capacity], simulation mode
   unsigned long long *located_tag;   // [record capacity]: cell | status << 32 | time slice << 40
   int lds_table_bytes;        // size of the coordinate tables the locate kernel stages in LDS; 0: searched in HBM
+  int undefined_edge;         // bl_set_undefined_policy(BL_UNDEFINED_EDGE): samples where the reference reads past its arrays use the edge
   const unsigned long long *counters_in;
   unsigned long long *counters;
   const double *ray_kt, *ray_factor;

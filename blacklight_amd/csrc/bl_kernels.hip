@@ -886,15 +886,19 @@ __device__ __forceinline__ void locate_sample_refined(const BlShadeArgs &P, unsi
       pp[a] = m[a] + 1;
       // :520-522 read x1v(b, i + 1) at a block's upper edge: the next block's first centre in the reference's
       // Array (xv[a][i + 1] here as well: rows are contiguous); past the array for the last block - undefined
-      if (pp[a] == n && b == g.n_blocks - 1) undefined = true;
+      const bool past_the_array = pp[a] == n && b == g.n_blocks - 1;
+      if (past_the_array) undefined = true;
       const double x_m = m[a] == -1 ? 2.0 * xf[i] - xv[a][i] : xv[a][m[a]];
-      const double x_p = (pp[a] == n) ? (undefined ? 0.0 : 2.0 * xv[a][i + 1] - xv[a][i]) : xv[a][pp[a]];
+      // BL_UNDEFINED_EDGE: the centre mirrored about the block's upper face, the rule the lower edge has (x_m above)
+      const double x_p = (pp[a] == n) ? (past_the_array ? 2.0 * xf[i + 1] - xv[a][i] : 2.0 * xv[a][i + 1] - xv[a][i]) : xv[a][pp[a]];
       f[a] = (s[a] - x_m) / (x_p - x_m);
     }
     if (undefined) {
       atomicAdd(&P.counters[BL_CNT_UNDEFINED], 1ull);
-      out->status = kSampleCut;
-      return;
+      if (!P.undefined_edge) {
+        out->status = kSampleCut;
+        return;
+      }
     }
     const bool sks = pl.simulation_coord == BL_COORD_SKS;
     bool failed = false;
@@ -999,6 +1003,77 @@ __device__ __forceinline__ void locate_sample(const BlShadeArgs &P, const GridTa
     return;
   }
   const int n_i = g.n[0], n_j = g.n[1], n_k = g.n[2];
+  if (g.fmks) {
+    // FMKS grid (simulation_sampling.cpp:190-198, :396-456): bounds in (r, theta, phi); (r, theta) -> (x^1, x^2) from the
+    // reader's table by plain scaling (its x^2 read at row j + 1 in both terms, as written there); zone and fraction from
+    // the lower FACE in x^1 and x^2 (no half-cell shift), the usual centre rule in x^3. The reference reads cells
+    // (k_m .. k_m + 1, j_m .. j_m + 1, i_m .. i_m + 1) of an array without bounds: one beyond a row is the next row's
+    // cell - reproduced (the gather steps through the same linear order) - but beyond the block it is another variable's
+    // data: no value to reproduce, counted as undefined.
+    if (!(s1 >= g.fmks_bounds[0] && s1 <= g.fmks_bounds[1] && s2 >= g.fmks_bounds[2] && s2 <= g.fmks_bounds[3]
+          && s3 >= g.fmks_bounds[4] && s3 <= g.fmks_bounds[5])) {
+      out->status = kSampleOffGrid;
+      return;
+    }
+    const size_t m1 = (size_t)g.sks_map_n1, m2 = (size_t)g.sks_map_n2;
+    double i_ind, j_ind;
+    double f_i = bl_modf((s1 - g.sks_map_r_in) / g.sks_map_dr, &i_ind);
+    double f_j = bl_modf(s2 / g.sks_map_dtheta, &j_ind);
+    size_t mi = (size_t)(int)i_ind, mj = (size_t)(int)j_ind;
+    if (mi + 1 >= m1 || mj + 1 >= m2) {   // r = r_out or theta = pi exactly: the reference reads past the table
+      atomicAdd(&P.counters[BL_CNT_UNDEFINED], 1ull);
+      if (!P.undefined_edge) {
+        out->status = kSampleCut;
+        return;
+      }
+      if (mi + 1 >= m1) { mi = m1 - 2; f_i = 1.0; }   // BL_UNDEFINED_EDGE: the table's last entry
+      if (mj + 1 >= m2) { mj = m2 - 2; f_j = 1.0; }
+    }
+    const double fmks_x1 = (1.0 - f_i) * g.sks_map[mj * m1 + mi] + f_i * g.sks_map[mj * m1 + mi + 1];
+    const double map_x2 = g.sks_map[(m2 + mj + 1) * m1 + mi];
+    const double fmks_x2 = (1.0 - f_j) * map_x2 + f_j * map_x2;
+    f_i = bl_modf((fmks_x1 - g.fmks_x1_0) / g.fmks_dx1, &i_ind);
+    f_j = bl_modf(fmks_x2 / g.fmks_dx2, &j_ind);
+    int i_m = (int)i_ind, j_m = (int)j_ind;
+    const int k = find_cell(g, tab, 2, s3);
+    const int k_m = (k == 0 || (k != n_k - 1 && s3 >= tab.xv[2][k])) ? k : k - 1;
+    const double f_k = (s3 - tab.xv[2][k_m]) / (tab.xv[2][k_m + 1] - tab.xv[2][k_m]);
+    const long long n_cells = (long long)n_k * n_j * n_i;
+    long long first, last;
+    if (!pl.simulation_interp) {
+      first = last = ((long long)k * n_j + (f_j >= 0.5 ? j_m + 1 : j_m)) * n_i + (f_i >= 0.5 ? i_m + 1 : i_m);
+    } else {
+      first = ((long long)k_m * n_j + j_m) * n_i + i_m;
+      last = ((long long)(k_m + 1) * n_j + (j_m + 1)) * n_i + (i_m + 1);
+    }
+    if (first < 0 || last >= n_cells) {
+      atomicAdd(&P.counters[BL_CNT_UNDEFINED], 1ull);
+      if (!P.undefined_edge) {
+        out->status = kSampleCut;
+        return;
+      }
+      // BL_UNDEFINED_EDGE: the zone's own row / column stands for the missing one
+      if (pl.simulation_interp) {
+        if (j_m + 1 >= n_j) { j_m = n_j - 2; f_j = 1.0; }
+        if (i_m + 1 >= n_i) { i_m = n_i - 2; f_i = 1.0; }
+        first = ((long long)k_m * n_j + j_m) * n_i + i_m;
+      } else {
+        const int jn = min(f_j >= 0.5 ? j_m + 1 : j_m, n_j - 1), in = min(f_i >= 0.5 ? i_m + 1 : i_m, n_i - 1);
+        first = ((long long)k * n_j + jn) * n_i + in;
+      }
+    }
+    *gathers += 1ull;
+    out->cell = (uint32_t)first;
+    if (!pl.simulation_interp) {
+      out->status = kSampleNearest;
+    } else {
+      out->f_i = f_i;
+      out->f_j = f_j;
+      out->f_k = f_k;
+      out->status = kSampleInterp;
+    }
+    return;
+  }
   if (s1 < tab.xf[0][0] || s1 > tab.xf[0][n_i] || s2 < tab.xf[1][0] || s2 > tab.xf[1][n_j]
       || s3 < tab.xf[2][0] || s3 > tab.xf[2][n_k]) {
     out->status = kSampleOffGrid;

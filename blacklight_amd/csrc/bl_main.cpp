@@ -17,6 +17,10 @@
 #include <iostream>
 #include <sstream>
 #include <string>
+#include <thread>
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
 #include <vector>
 
 #include "../../include/blacklight_amd.h"
@@ -81,6 +85,48 @@ bool IsRawGrid(const std::string &path) {
   return f && (std::memcmp(magic, "BLGRID1\0", 8) == 0 || std::memcmp(magic, "BLGRID2\0", 8) == 0);
 }
 
+// ---- several GPUs from one process (BLACKLIGHT_AMD_DEVICES = N or "all"; one host thread per GPU, grid replicated).
+// Rays are independent: level 0 is cut into square tiles dealt centre-first round-robin to the devices (the same
+// partition as blacklight_amd/distributed.py tile_pixels: cost per ray varies ~4x across the image), refined levels
+// give device d the blocks d, d + N, ... of the level's list; every device renders its share through the same
+// bl_render call (pixel_map / block_locs) into its own buffer, and the shares are put back in the level's order.
+
+// Pixels (m = m2 * res + m1) of the tiles device `rank` of `world` owns, tile-major, row-major inside a tile
+std::vector<int32_t> TilePixels(int res, int rank, int world, int tile) {
+  const int per_side = res / tile;
+  std::vector<int> ids(static_cast<size_t>(per_side) * per_side);
+  for (size_t t = 0; t < ids.size(); t++) ids[t] = static_cast<int>(t);
+  const double centre = 0.5 * (per_side - 1);
+  auto dist2 = [&](int t) {
+    const double dy = t / per_side - centre, dx = t % per_side - centre;
+    return dx * dx + dy * dy;
+  };
+  std::stable_sort(ids.begin(), ids.end(), [&](int a, int b) { return dist2(a) < dist2(b); });
+  std::vector<int32_t> pixels;
+  for (size_t t = rank; t < ids.size(); t += world) {
+    const int ty = ids[t] / per_side, tx = ids[t] % per_side;
+    for (int y = 0; y < tile; y++)
+      for (int x = 0; x < tile; x++) pixels.push_back((ty * tile + y) * res + tx * tile + x);
+  }
+  return pixels;
+}
+
+// Largest of 32, 16, 8, ... that divides the camera and is a multiple of the adaptive block
+int DefaultTile(int res, int block) {
+  int tile = 32;
+  while (tile > 1 && (res % tile != 0 || tile % block != 0)) tile /= 2;
+  return (res % tile == 0 && tile % block == 0) ? tile : res;
+}
+
+struct LevelShare {
+  std::vector<int32_t> pixels;       // level 0: this device's pixels
+  std::vector<int32_t> block_locs;   // refined levels: this device's blocks (v, u)
+  std::vector<int64_t> where;        // position of each of its rays in the level's arrays
+  std::vector<double> image, camera, render;
+  bl_stats stats{};
+  int rc = BL_OK;
+};
+
 }  // namespace
 
 int main(int argc, char *argv[]) {
@@ -101,11 +147,34 @@ int main(int argc, char *argv[]) {
     std::cout << "Error: num_threads not specified in input file.\n";
     return 1;
   }
-  bl_ctx *ctx = nullptr;
-  if (bl_init(&params, -1, &ctx) != BL_OK) {
-    std::cout << bl_last_global_error();
-    return 1;
+  // Options that the reference's command line has no place for come from the environment:
+  //   BLACKLIGHT_AMD_DEVICES    = N | all   GPUs to spread every image over (default 1; N may exceed the GPUs present:
+  //                                         device d % present, which is how one GPU rehearses several)
+  //   BLACKLIGHT_AMD_ARITHMETIC = tolerant  bl_set_arithmetic(BL_ARITH_TOLERANT)
+  //   BLACKLIGHT_AMD_UNDEFINED  = edge      bl_set_undefined_policy(BL_UNDEFINED_EDGE)
+  int n_devices = 1;
+  if (const char *text = std::getenv("BLACKLIGHT_AMD_DEVICES")) {
+    const int present = bl_device_count();
+    n_devices = std::string(text) == "all" ? present : std::atoi(text);
+    if (n_devices < 1 || present < 1) {
+      std::cout << "Error: BLACKLIGHT_AMD_DEVICES must be a positive number or \"all\", with a GPU present.\n";
+      return 1;
+    }
+    if (params.has[BL_P_slow_light_on] && params.slow_light_on) n_devices = 1;   // the window of files lives in one context
   }
+  std::vector<bl_ctx *> contexts(n_devices, nullptr);
+  for (int dev = 0; dev < n_devices; dev++) {
+    const int present = n_devices > 1 ? bl_device_count() : 1;
+    if (bl_init(&params, n_devices > 1 ? dev % present : -1, &contexts[dev]) != BL_OK) {
+      std::cout << bl_last_global_error();
+      return 1;
+    }
+    if (const char *text = std::getenv("BLACKLIGHT_AMD_ARITHMETIC"))
+      if (std::string(text) == "tolerant") bl_set_arithmetic(contexts[dev], BL_ARITH_TOLERANT);
+    if (const char *text = std::getenv("BLACKLIGHT_AMD_UNDEFINED"))
+      if (std::string(text) == "edge") bl_set_undefined_policy(contexts[dev], BL_UNDEFINED_EDGE);
+  }
+  bl_ctx *ctx = contexts[0];
   const bool simulation = params.model_type == BL_MODEL_SIMULATION;
   const int res = params.camera_resolution;
   const int n_q = bl_image_num_quantities(ctx);
@@ -158,7 +227,19 @@ int main(int argc, char *argv[]) {
         }
         g = *bl_snapshot_grid(snap);
       }
-      const int rc = bl_set_grid(ctx, &g);
+      int rc = BL_OK;
+      {   // grid replicated: every device stages its own copy, concurrently
+        std::vector<int> results(n_devices, BL_OK);
+        std::vector<std::thread> workers;
+        for (int dev = 0; dev < n_devices; dev++)
+          workers.emplace_back([&, dev]() { results[dev] = bl_set_grid(contexts[dev], &g); });
+        for (std::thread &w : workers) w.join();
+        for (int dev = 0; dev < n_devices; dev++)
+          if (results[dev] != BL_OK && rc == BL_OK) {
+            rc = results[dev];
+            ctx = contexts[dev];   // whose error text is reported
+          }
+      }
       bl_snapshot_close(snap);
       if (rc != BL_OK) {
         std::cout << bl_last_error(ctx);
@@ -174,6 +255,7 @@ int main(int argc, char *argv[]) {
     std::vector<std::vector<int32_t>> locs(1);
     std::vector<int32_t> counts = {bs > 0 && params.adaptive_max_level > 0 ? (res / bs) * (res / bs) : 0};
     int level = 0;
+    std::string shared_warnings;   // several devices: the levels' warnings with their totals
     while (true) {
       const long long n_rays = level == 0 ? static_cast<long long>(res) * res
                                           : static_cast<long long>(counts[level]) * bs * bs;
@@ -192,12 +274,97 @@ int main(int argc, char *argv[]) {
         else d.camera_dir = cameras.back().data();
       }
       double t0 = Now();
-      if (bl_render(ctx, &d) != BL_OK) {
-        std::cout << bl_last_error(ctx);
-        return 1;
-      }
       bl_stats st;
-      bl_get_stats(ctx, &st);
+      if (n_devices == 1) {
+        if (bl_render(ctx, &d) != BL_OK) {
+          std::cout << bl_last_error(ctx);
+          return 1;
+        }
+        bl_get_stats(ctx, &st);
+      } else {
+        // this level's rays over the devices
+        const int tile = DefaultTile(res, bs);
+        std::vector<LevelShare> shares(n_devices);
+        for (int dev = 0; dev < n_devices; dev++) {
+          LevelShare &sh = shares[dev];
+          if (level == 0) {
+            sh.pixels = TilePixels(res, dev, n_devices, tile);
+            sh.where.assign(sh.pixels.begin(), sh.pixels.end());
+          } else {
+            for (int b = dev; b < counts[level]; b += n_devices) {
+              sh.block_locs.push_back(locs[level][2 * b]);
+              sh.block_locs.push_back(locs[level][2 * b + 1]);
+              for (int q = 0; q < bs * bs; q++) sh.where.push_back(static_cast<int64_t>(b) * bs * bs + q);
+            }
+          }
+          const size_t n_local = sh.where.size();
+          sh.image.resize(static_cast<size_t>(n_q) * n_local);
+          sh.camera.resize(want_camera ? n_local * 4 : 0);
+          sh.render.resize(static_cast<size_t>(n_render) * 3 * n_local);
+        }
+        std::vector<std::thread> workers;
+        for (int dev = 0; dev < n_devices; dev++)
+          workers.emplace_back([&, dev]() {
+            LevelShare &sh = shares[dev];
+            if (sh.where.empty()) return;
+            bl_render_desc dd = {};
+            dd.level = level;
+            dd.n_rays = static_cast<int64_t>(sh.where.size());
+            if (level == 0) {
+              dd.pixel_map = sh.pixels.data();
+            } else {
+              dd.n_blocks = static_cast<int32_t>(sh.block_locs.size() / 2);
+              dd.block_locs = sh.block_locs.data();
+            }
+            dd.image = sh.image.data();
+            dd.render = n_render > 0 ? sh.render.data() : nullptr;
+            if (want_camera) {
+              if (params.camera_type == BL_CAMERA_PLANE) dd.camera_pos = sh.camera.data();
+              else dd.camera_dir = sh.camera.data();
+            }
+            sh.rc = bl_render(contexts[dev], &dd);
+            bl_get_stats(contexts[dev], &sh.stats);
+          });
+        for (std::thread &w : workers) w.join();
+        st = bl_stats{};
+        for (int dev = 0; dev < n_devices; dev++) {
+          const LevelShare &sh = shares[dev];
+          if (sh.rc != BL_OK) {
+            std::cout << bl_last_error(contexts[dev]);
+            return 1;
+          }
+          const size_t n_local = sh.where.size();
+          for (size_t i = 0; i < n_local; i++) {
+            const size_t at = static_cast<size_t>(sh.where[i]);
+            for (int q = 0; q < n_q; q++) images.back()[static_cast<size_t>(q) * n_rays + at] = sh.image[static_cast<size_t>(q) * n_local + i];
+            for (int q = 0; q < 3 * n_render; q++) renders.back()[static_cast<size_t>(q) * n_rays + at] = sh.render[static_cast<size_t>(q) * n_local + i];
+            if (want_camera)
+              for (int c = 0; c < 4; c++) cameras.back()[4 * at + c] = sh.camera[4 * i + c];
+          }
+          if (n_local == 0) continue;
+          // kernel times add up over devices that worked side by side: keep the slowest device's, sum the counts
+          if (sh.stats.ms_total > st.ms_total) {
+            st.ms_total = sh.stats.ms_total;
+            st.ms_geodesic = sh.stats.ms_geodesic;
+            st.ms_shade = sh.stats.ms_shade;
+            st.ms_transfer = sh.stats.ms_transfer;
+          }
+          st.n_flagged += sh.stats.n_flagged;
+          st.max_sample_num = std::max(st.max_sample_num, sh.stats.max_sample_num);
+        }
+        // one warning with the level's totals, in the reference's words (geodesics.cpp:389-394), instead of one per device
+        std::string others;
+        for (int dev = 0; dev < n_devices; dev++) {
+          std::istringstream lines(bl_warnings(contexts[dev]));
+          std::string line;
+          while (std::getline(lines, line))
+            if (line.find("geodesics terminate unexpectedly") == std::string::npos && dev == 0) others += line + "\n";
+          bl_warnings_clear(contexts[dev]);
+        }
+        if (st.n_flagged > 0)
+          shared_warnings += "Warning: " + std::to_string(st.n_flagged) + " out of " + std::to_string(n_rays) + " geodesics terminate unexpectedly.\n";
+        shared_warnings += others;
+      }
       double elapsed = Now() - t0;
       // attribute wall time to the reference's three timers in proportion to kernel time
       double kernel = st.ms_total > 0.0f ? st.ms_total : 1.0;
@@ -225,11 +392,11 @@ int main(int argc, char *argv[]) {
     {
       // the reference integrates the geodesics once, before the first image: its count of badly terminated
       // geodesics is reported once, not per image
-      std::istringstream lines(bl_warnings(ctx));
+      std::istringstream lines(std::string(bl_warnings(contexts[0])) + shared_warnings);
       std::string line;
       while (std::getline(lines, line))
         if (run == 0 || line.find("geodesics terminate unexpectedly") == std::string::npos) std::cerr << line << "\n";
-      bl_warnings_clear(ctx);
+      bl_warnings_clear(contexts[0]);
     }
 
     bl_output_desc out = {};
@@ -247,7 +414,7 @@ int main(int argc, char *argv[]) {
       return 1;
     }
   }
-  bl_free(ctx);
+  for (bl_ctx *c : contexts) bl_free(c);
 
   double time_full = Now() - time_start;   // blacklight.cpp:259-269
   std::cout << std::setprecision(7);

@@ -25,6 +25,7 @@
 #include <deque>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/blacklight_amd.h"
@@ -492,6 +493,7 @@ struct bl_snapshot {
   bl_grid_desc desc{};
   std::vector<float> prim;
   std::vector<double> coords[6];   // x1f x2f x3f x1v x2v x3v
+  std::vector<double> sks_map;     // simulation_coord = fmks: [2][2048][2048]
   std::vector<int32_t> levels, locations;
   double time = 0.0;
   std::string warnings, file;
@@ -907,7 +909,9 @@ void ReadAthenaK(const bl_params &p, int file_number, bl_snapshot *s) {
 // "prims" [n1][n2][n3][n_prim] with internal energy in place of pressure and velocity / field components on the
 // modified coordinates' basis. The reader hands over a standard spherical Kerr-Schild grid: coordinates converted,
 // p = (gamma - 1) u, vectors re-expressed (normal-frame velocity, lab-frame field) cell by cell.
-// FMKS / MMKS grids (simulation_coord = fmks) are not built.
+// FMKS / MMKS dumps read with simulation_coord = fmks keep their native coordinates and get the reader's SKS -> FMKS
+// look-up table and bounds instead (ConvertCoordinates, GenerateSKSMap, GetSKSCoordinates, SetJacobianFactors:
+// simulation_geometry.cpp:36-57, :321-419, :427-483).
 void ReadIharm3d(const bl_params &p, int file_number, bl_snapshot *s) {
   s->file = p.simulation_file.s;
   if (file_number >= 0) s->file = FormatFilename(s->file, file_number);
@@ -939,8 +943,55 @@ void ReadIharm3d(const bl_params &p, int file_number, bl_snapshot *s) {
     message << "Given spin of " << p.simulation_a << " does not match file value of " << metric_a << "; ignoring the latter.";
     Warn(s, message.str());
   }
-  if (p.simulation_coord == BL_COORD_FMKS)
-    Fail("simulation_coord = fmks (FMKS / MMKS grids of iharm3d) is not built.", BL_E_UNSUPPORTED);
+  // FMKS / MMKS geometry (:396-427)
+  const bool fmks = p.simulation_coord == BL_COORD_FMKS;
+  if (fmks && metric != "MMKS" && metric != "FMKS")   // the reference would build its map from uninitialised parameters
+    Fail("simulation_coord = fmks needs a file whose header/metric is FMKS or MMKS.", BL_E_UNSUPPORTED);
+  double metric_r_in = 0.0, metric_poly_xt = 0.0, metric_poly_alpha = 0.0, metric_mks_smooth = 0.0, metric_derived_poly_norm = 0.0;
+  if (metric == "MMKS" || metric == "FMKS") {
+    bool found = true;
+    try {
+      metric_r_in = scalar("header/geom/" + metric_lower + "/r_in");
+    } catch (const ReadFailure &) {
+      found = false;
+    }
+    if (!found) {
+      try {
+        metric_r_in = scalar("header/geom/" + metric_lower + "/Rin");
+      } catch (const ReadFailure &) {
+        Fail("Unable to identify r_in parameter for iharm3d-format file.");
+      }
+    }
+    metric_poly_xt = scalar("header/geom/" + metric_lower + "/poly_xt");
+    metric_poly_alpha = scalar("header/geom/" + metric_lower + "/poly_alpha");
+    metric_mks_smooth = scalar("header/geom/" + metric_lower + "/mks_smooth");
+    metric_derived_poly_norm = (metric_poly_alpha + 1.0) * bl_pow(metric_poly_xt, metric_poly_alpha);
+    metric_derived_poly_norm = 0.5 * kPi * metric_derived_poly_norm / (metric_derived_poly_norm + 1.0);
+  }
+  // SimulationReader::GetSKSCoordinates (simulation_geometry.cpp:427-443) and SetJacobianFactors (:451-483), FMKS branches
+  auto sks_coordinates = [&](double x1, double x2, double *r, double *theta) {
+    *r = bl_exp(x1);
+    const double y = 2.0 * x2 - 1.0;
+    const double theta_g = kPi * x2 + (1.0 - metric_h) / 2.0 * bl_sin(2.0 * kPi * x2);
+    const double theta_j = 0.5 * kPi + metric_derived_poly_norm * y * (1.0 + bl_pow(y / metric_poly_xt, metric_poly_alpha) / (metric_poly_alpha + 1.0));
+    *theta = theta_g + bl_exp(metric_mks_smooth * (bl_log(metric_r_in) - x1)) * (theta_j - theta_g);
+  };
+  auto fmks_jacobian = [&](double x1, double x2, double *dr_dx1, double *dth_dx1, double *dth_dx2) {
+    *dr_dx1 = bl_exp(x1);
+    const double var_a = bl_exp(metric_mks_smooth * (bl_log(metric_r_in) - x1));
+    const double var_b = kPi * (0.5 - x2);
+    const double var_c = bl_pow((2.0 * x2 - 1.0) / metric_poly_xt, metric_poly_alpha);
+    const double var_d = 1.0 + metric_poly_alpha;
+    const double var_e = metric_derived_poly_norm * (1.0 + var_c / var_d);
+    const double var_f = var_e * (2.0 * x2 - 1.0);
+    const double var_g = -0.5 * (1.0 - metric_h) * bl_sin(2.0 * kPi * x2);
+    *dth_dx1 = -metric_mks_smooth * var_a * (var_b + var_f + var_g);
+    const double var_h = kPi + (1.0 - metric_h) * kPi * bl_cos(2.0 * kPi * x2);
+    const double var_i = -kPi + 2.0 * var_e;
+    const double var_j = 2.0 * metric_derived_poly_norm * metric_poly_alpha * var_c / var_d;
+    const double var_k = -(1.0 - metric_h) * kPi * bl_cos(2.0 * kPi * x2);
+    *dth_dx2 = var_h + var_a * (var_i + var_j + var_k);
+  };
 
   // coordinates (:622-656) and their conversion to r, theta (simulation_geometry.cpp:62-81)
   const long n[3] = {integer("header/n1"), integer("header/n2"), integer("header/n3")};
@@ -958,10 +1009,83 @@ void ReadIharm3d(const bl_params &p, int file_number, bl_snapshot *s) {
     }
   }
   x2v_alt = s->coords[4];
-  for (double &x : s->coords[0]) x = bl_exp(x);
-  for (double &x : s->coords[3]) x = bl_exp(x);
-  for (double &x : s->coords[1]) x = kPi * x + (1.0 - metric_h) / 2.0 * bl_sin(2.0 * kPi * x);
-  for (double &x : s->coords[4]) x = kPi * x + (1.0 - metric_h) / 2.0 * bl_sin(2.0 * kPi * x);
+  if (fmks) {
+    // ConvertCoordinates, FMKS case (simulation_geometry.cpp:36-57): the coordinates stay native; the map from (r, theta)
+    // to (x^1, x^2) and the grid's bounds in (r, theta, phi) are what the sampler works with. GenerateSKSMap (:321-419):
+    // 2048 x 2048 points, x^2 by bisection on theta(x^1, x^2) to 1e-8.
+    const int map_n1 = 2048, map_n2 = 2048, max_iter = 1000;
+    const double tol = 1.0e-8;
+    const double r_in = bl_exp(s->coords[0][0]), r_out = bl_exp(s->coords[0][n[0]]);
+    const double dr = (r_out - r_in) / (map_n1 - 1), dtheta = kPi / (map_n2 - 1);
+    s->sks_map.assign(static_cast<size_t>(2) * map_n2 * map_n1, 0.0);
+    double *map_x1 = s->sks_map.data(), *map_x2 = s->sks_map.data() + static_cast<size_t>(map_n2) * map_n1;
+    // (columns are independent: spread over the host's threads; the reference fills the map serially)
+    auto fill_columns = [&](int i_begin, int i_end) {
+    for (int i = i_begin; i < i_end; ++i) {
+      const double r = r_in + i * dr;
+      const double x1 = bl_log(r);
+      for (int j = 0; j < map_n2; ++j) {
+        const double theta = std::min(j * dtheta, kPi);
+        double x2 = 0.5;
+        if (theta > tol && std::abs(kPi - theta) > tol) {
+          double x2_a = 0.0, x2_b = 1.0;
+          x2 = (x2_b + x2_a) / 2.0;
+          double temp_r, theta_a = 0.0, theta_b = kPi, theta_c = kPi / 2.0;
+          sks_coordinates(x1, x2_a, &temp_r, &theta_a);
+          sks_coordinates(x1, x2_b, &temp_r, &theta_b);
+          for (int iter = 0; iter < max_iter; iter++) {
+            sks_coordinates(x1, x2, &temp_r, &theta_c);
+            if ((theta_c - theta) * (theta_b - theta) < 0.0) {
+              theta_a = theta_c;
+              x2_a = x2;
+            } else {
+              theta_b = theta_c;
+              x2_b = x2;
+            }
+            x2 = (x2_a + x2_b) / 2.0;
+            if (std::abs(theta - theta_c) < tol) break;
+          }
+          (void)theta_a;
+        } else if (theta < tol) {
+          x2 = 0.0;
+        } else if (theta > kPi - tol) {
+          x2 = 1.0;
+        }
+        map_x1[static_cast<size_t>(j) * map_n1 + i] = x1;
+        map_x2[static_cast<size_t>(j) * map_n1 + i] = x2;
+      }
+    }
+    };
+    {
+      const int n_threads = std::max(1, std::min(64, static_cast<int>(std::thread::hardware_concurrency())));
+      std::vector<std::thread> workers;
+      for (int t = 0; t < n_threads; t++)
+        workers.emplace_back(fill_columns, static_cast<int>(static_cast<long>(map_n1) * t / n_threads),
+                             static_cast<int>(static_cast<long>(map_n1) * (t + 1) / n_threads));
+      for (std::thread &w : workers) w.join();
+    }
+    bl_grid_desc &gd = s->desc;
+    gd.sks_map = s->sks_map.data();
+    gd.sks_map_n1 = map_n1;
+    gd.sks_map_n2 = map_n2;
+    gd.sks_map_r_in = r_in;
+    gd.sks_map_dr = dr;
+    gd.sks_map_dtheta = dtheta;
+    double r_val, theta_val;
+    sks_coordinates(s->coords[0][0], 0.0, &r_val, &theta_val);
+    gd.simulation_bounds[0] = r_val;
+    gd.simulation_bounds[2] = theta_val;
+    gd.simulation_bounds[4] = 0.0;
+    sks_coordinates(s->coords[0][n[0]], 1.0, &r_val, &theta_val);
+    gd.simulation_bounds[1] = r_val;
+    gd.simulation_bounds[3] = theta_val;
+    gd.simulation_bounds[5] = 2.0 * kPi;
+  } else {
+    for (double &x : s->coords[0]) x = bl_exp(x);
+    for (double &x : s->coords[3]) x = bl_exp(x);
+    for (double &x : s->coords[1]) x = kPi * x + (1.0 - metric_h) / 2.0 * bl_sin(2.0 * kPi * x);
+    for (double &x : s->coords[4]) x = kPi * x + (1.0 - metric_h) / 2.0 * bl_sin(2.0 * kPi * x);
+  }
 
   // VerifyVariablesHarm
   const int n_prim = integer("header/n_prim");
@@ -1033,13 +1157,23 @@ void ReadIharm3d(const bl_params &p, int file_number, bl_snapshot *s) {
   for (long k = 0; k < n[2]; k++)
     for (long j = 0; j < n[1]; j++)
       for (long i = 0; i < n[0]; i++) {
-        const double r = s->coords[3][i], th = s->coords[4][j];
-        const double x1 = bl_log(r), x2 = x2v_alt[j];
+        double r = s->coords[3][i], th = s->coords[4][j];
+        double x1, x2, dr_dx1, dth_dx1, dth_dx2;
+        if (fmks) {   // the cell centres are native coordinates (:118-124); Jacobian of the FMKS map (:463-475)
+          x1 = r;
+          x2 = th;
+          sks_coordinates(x1, x2, &r, &th);
+          fmks_jacobian(x1, x2, &dr_dx1, &dth_dx1, &dth_dx2);
+        } else {
+          x1 = bl_log(r);
+          x2 = x2v_alt[j];
+          dr_dx1 = bl_exp(x1);
+          dth_dx1 = 0.0;
+          dth_dx2 = kPi + (1.0 - metric_h) * kPi * bl_cos(2.0 * kPi * x2);
+        }
         const double sth = bl_sin(th), cth = bl_cos(th);
         const double uu1 = at(d.ind_uu1, k, j, i), uu2 = at(d.ind_uu2, k, j, i), uu3 = at(d.ind_uu3, k, j, i);
         const double bb1 = at(d.ind_bb1, k, j, i), bb2 = at(d.ind_bb2, k, j, i), bb3 = at(d.ind_bb3, k, j, i);
-        const double dr_dx1 = bl_exp(x1), dth_dx1 = 0.0;
-        const double dth_dx2 = kPi + (1.0 - metric_h) * kPi * bl_cos(2.0 * kPi * x2);
         const double sigma = r * r + a * a * cth * cth;
         const double f = 2.0 * r / sigma;
         const double g_tr = f, g_tth = 0.0, g_tph = -a * f * sth * sth;

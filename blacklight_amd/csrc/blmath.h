@@ -60,6 +60,14 @@ BLM_FN double blm_scalbn(double x, int k) {
   return x * blm_pow2i(k);
 }
 
+/* modf: integral part through *ip (truncation towards zero), fractional part returned, both with the sign of x; exact */
+BLM_FN double bl_modf(double x, double *ip) {
+  if (blm_isinf(x)) { *ip = x; return blm_copysign(0.0, x); }
+  double t = __builtin_trunc(x);
+  *ip = t;
+  return blm_copysign(x - t, x);
+}
+
 /* ---------------------------------------------------------------- double-double toolkit */
 BLM_FN blm_dd blm_two_sum(double a, double b) {
   blm_dd r; r.hi = a + b; double bb = r.hi - a; r.lo = (a - (r.hi - bb)) + (b - bb); return r;

@@ -194,6 +194,15 @@ typedef struct bl_grid_desc {
   const int32_t *levels;      /* [n_blocks] */
   const int32_t *locations;   /* [n_blocks][3] */
   int32_t n_3_root;
+  /* simulation_coord = fmks (iharm3d FMKS / MMKS grids; simulation_sampling.cpp:66-73, :190-198, :396-456): x1f ... x3v
+   * stay in the file's native coordinates (x^1 = log r, x^2 in [0, 1], x^3 = phi, one block, uniform), and a sample's
+   * position on them comes from the reader's look-up table from spherical Kerr-Schild (r, theta) to (x^1, x^2)
+   * (SimulationReader::GenerateSKSMap, simulation_geometry.cpp:321-419) within the grid's bounds in (r, theta, phi)
+   * (simulation_bounds, :46-57). NULL / 0 for every other coordinate system. */
+  const double *sks_map;      /* [2][sks_map_n2][sks_map_n1]: x^1, then x^2 */
+  int32_t sks_map_n1, sks_map_n2;
+  double sks_map_r_in, sks_map_dr, sks_map_dtheta;
+  double simulation_bounds[6];   /* r_min, r_max, theta_min, theta_max, phi_min, phi_max */
 } bl_grid_desc;
 
 /* ------------------------------------------------------------------ snapshot reader (host only)
@@ -207,7 +216,8 @@ typedef struct bl_grid_desc {
  * re-uses block layout and coordinates of the first file for later files of a series.
  * simulation_format = athenak: the AthenaK binary dump reader (simulation_reader.cpp:915-1131, :434-589) behind the same calls.
  * simulation_format = iharm3d / harm3d: modified Kerr-Schild (MKS) dumps read with simulation_coord = sks (coordinates and
- * vector components converted like SimulationReader does); fmks grids return BL_E_UNSUPPORTED. With slow_light_on use bl_slow_light_read(). */
+ * vector components converted like SimulationReader does); iharm3d FMKS / MMKS dumps read with simulation_coord = fmks
+ * (native coordinates kept, bl_grid_desc::sks_map built). With slow_light_on use bl_slow_light_read(). */
 typedef struct bl_snapshot bl_snapshot;
 BL_API int bl_snapshot_open(const bl_params *p, int snapshot, bl_snapshot **out, char *err, size_t err_len);
 BL_API const bl_grid_desc *bl_snapshot_grid(const bl_snapshot *s);
@@ -284,6 +294,9 @@ typedef struct bl_ctx bl_ctx;
  * frame, bl_adaptive_refine, bl_write_output); bl_set_grid / bl_render on it fail with BL_E_DEVICE. */
 #define BL_DEVICE_NONE (-2)
 BL_API int bl_init(const bl_params *p, int device, bl_ctx **out);
+/* HIP devices visible to this process (0: none). One context per device and one host thread per context is how one process
+ * drives several GPUs: bl_render is thread-safe across contexts (bin/blacklight_amd with BLACKLIGHT_AMD_DEVICES does that). */
+BL_API int bl_device_count(void);
 /* Repack the grid into the HBM layout and upload it; once per snapshot. Equal blocks of one level tiling a
  * box are merged into one [k][j][i][8 floats] array; other sets of non-overlapping equal-sized blocks (mesh
  * refinement) stay [block][k][j][i][8] behind a lattice of block boundaries. Overlapping blocks are refused. */
@@ -319,6 +332,15 @@ BL_API int bl_frequencies(const bl_ctx *ctx, double *out, int n);
  * decision stay those of the exact tier. Built for plain unpolarized images of spherical Kerr-Schild simulations
  * with thermal electrons (the benchmark and the many-frequency renders); other configurations run in exact
  * arithmetic regardless - bl_stats.arithmetic reports the tier that ran. */
+/* What to do with a sample for which the reference reads past the end of one of its arrays (no bounds checks in its Array):
+ * inter-block interpolation at an upper edge of the file's last MeshBlock (simulation_sampling.cpp:520-522), FMKS sampling in
+ * the last polar zone of the last azimuthal plane (:412-415 with :809-819). BL_UNDEFINED_REFUSE (default): bl_render fails with
+ * BL_E_UNSUPPORTED - there is no defined result to reproduce. BL_UNDEFINED_EDGE: such samples use the edge of the data that
+ * exists (block centre mirrored about the upper face; the zone's own row), and bl_render warns with their number. Every
+ * sample the reference defines is unaffected by the choice. */
+#define BL_UNDEFINED_REFUSE 0
+#define BL_UNDEFINED_EDGE 1
+BL_API int bl_set_undefined_policy(bl_ctx *ctx, int policy);
 #define BL_ARITH_EXACT 0
 #define BL_ARITH_TOLERANT 1
 BL_API int bl_set_arithmetic(bl_ctx *ctx, int mode);

@@ -1416,6 +1416,65 @@ int SampleOne(const Oracle &o, const double pos[4], Prims *out, bool *gathered, 
     }
   }
   int n_i = g.n_i, n_j = g.n_j, n_k = g.n_k, n_b = g.n_blocks;
+  if (p.simulation_coord == BL_COORD_FMKS) {
+    // FMKS grids (:190-198, :352-394 with the grid's bounds in r, theta, phi; :396-456): one block in native coordinates,
+    // position from the reader's SKS -> FMKS look-up table by plain scaling - no half-cell shift in x^1, x^2, the map's
+    // x^2 read at row j + 1 in both terms, and no bounds on i_m + 1 / j_m + 1: exactly as written there. One thing is
+    // not restated: the reference's per-thread "current block" bounds (:184-198, :362-392) start as these SKS bounds
+    // and turn into the NATIVE coordinate box after the first off-grid sample that lies inside that box, so that its
+    // image depends on the OpenMP schedule from then on. Here (and on the GPU) a sample outside the grid's SKS bounds
+    // is off the grid, and nothing else changes.
+    const double *bounds = g.simulation_bounds;
+    if (not (x1 >= bounds[0] and x1 <= bounds[1] and x2 >= bounds[2] and x2 <= bounds[3] and x3 >= bounds[4] and x3 <= bounds[5])) {
+      if (p.fallback_nan) return 2;
+      return 3;
+    }
+    const size_t m1 = g.sks_map_n1, m2 = g.sks_map_n2;
+    auto sks_map = [&](int v, long j, long i) { return g.sks_map[(static_cast<size_t>(v) * m2 + j) * m1 + i]; };
+    double i_ind, j_ind;
+    double f_i = std::modf((x1 - g.sks_map_r_in) / g.sks_map_dr, &i_ind);
+    double f_j = std::modf(x2 / g.sks_map_dtheta, &j_ind);
+    int i = static_cast<int>(i_ind), j = static_cast<int>(j_ind);
+    double fmks_x1 = (1.0 - f_i) * sks_map(0, j, i) + f_i * sks_map(0, j, i + 1);
+    double fmks_x2 = (1.0 - f_j) * sks_map(1, j + 1, i) + f_j * sks_map(1, j + 1, i);
+    double x1_0 = g.x1f[0];
+    double dx1 = g.x1f[1] - g.x1f[0];
+    double dx2 = g.x2f[1] - g.x2f[0];
+    f_i = std::modf((fmks_x1 - x1_0) / dx1, &i_ind);
+    f_j = std::modf(fmks_x2 / dx2, &j_ind);
+    int i_m = static_cast<int>(i_ind), j_m = static_cast<int>(j_ind);
+    int k;
+    for (k = 0; k < n_k; k++)
+      if (g.x3f[k + 1] >= x3) break;
+    int k_m = k == 0 or (k != n_k - 1 and x3 >= g.x3v[k]) ? k : k - 1;
+    double f_k = (x3 - g.x3v[k_m]) / (g.x3v[k_m + 1] - g.x3v[k_m]);
+    bool code_kappa = p.plasma_model == BL_PLASMA_CODE_KAPPA;
+    *gathered = true;
+    const int vars[9] = {g.ind_rho, g.ind_pgas, g.ind_kappa, g.ind_uu1, g.ind_uu2, g.ind_uu3, g.ind_bb1, g.ind_bb2, g.ind_bb3};
+    float *dst[9] = {&out->rho, &out->pgas, &out->kappa, &out->uu1, &out->uu2, &out->uu3, &out->bb1, &out->bb2, &out->bb3};
+    // The reference's Array has no bounds: a cell index beyond a row is the next row's cell, and a cell beyond the block
+    // is the next VARIABLE's data (or, for the last variable, memory past the array). The first is reproduced as it is;
+    // the second has no value to reproduce (status 4, like the upper edges of the last MeshBlock above).
+    const long n_cells = static_cast<long>(n_k) * n_j * n_i;
+    auto beyond = [&](long kk, long jj, long ii) { return (kk * n_j + jj) * n_i + ii >= n_cells or (kk * n_j + jj) * n_i + ii < 0; };
+    if (not p.simulation_interp) {
+      int jn = f_j >= 0.5 ? j_m + 1 : j_m, in = f_i >= 0.5 ? i_m + 1 : i_m;
+      if (beyond(k, jn, in)) return 4;
+      for (int v = 0; v < 9; v++) *dst[v] = (v == 2 and not code_kappa) ? 0.0f : GridVal(g, vars[v], 0, k, jn, in);
+      return 0;
+    }
+    if (beyond(k_m + 1, j_m + 1, i_m + 1) or beyond(k_m, j_m, i_m)) return 4;
+    for (int v = 0; v < 9; v++) {
+      if (v == 2 and not code_kappa) {
+        *dst[v] = 0.0f;
+        continue;
+      }
+      double val = InterpolateSimple(g, vars[v], 0, k_m, j_m, i_m, f_k, f_j, f_i);
+      if (v < 3 and val <= 0.0) val = static_cast<double>(GridVal(g, vars[v], 0, k_m, j_m, i_m));
+      *dst[v] = static_cast<float>(val);
+    }
+    return 0;
+  }
   // block test and search (:352-394)
   if (!state->valid) {   // :205-214: block 0 to start with
     state->b = 0;
@@ -2754,7 +2813,8 @@ int Setup(Oracle &o, const bl_params *p, const bl_grid_desc *g, char *err, size_
       return Fail(err, err_len, "oracle: inter-block interpolation needs the MeshBlock table (levels, locations, n_3_root)", BL_E_ARG);
     if (p->slow_light_on and (o.slow_n < 2 or o.slow_n != p->slow_chunk_size or o.slow_grids == nullptr or o.slow_times == nullptr))
       return Fail(err, err_len, "oracle: slow light needs slow_chunk_size time slices in blo_extra", BL_E_ARG);
-    if (p->simulation_coord == BL_COORD_FMKS) return Fail(err, err_len, "oracle: fmks not restated yet", BL_E_UNSUPPORTED);
+    if (p->simulation_coord == BL_COORD_FMKS and (g->sks_map == nullptr or g->n_blocks != 1 or p->slow_light_on))
+      return Fail(err, err_len, "oracle: fmks needs the reader's sks_map, one block and no slow light", BL_E_UNSUPPORTED);
     if (p->plasma_kappa_frac != 0.0 and not o.image_polarization)
       return Fail(err, err_len, "oracle: kappa-distribution electrons are restated for polarized runs only (in unpolarized runs the reference reads the uninitialised kappa_aa_high_i)", BL_E_UNSUPPORTED);
     o.plasma_thermal_frac = 1.0 - (p->plasma_power_frac + p->plasma_kappa_frac);

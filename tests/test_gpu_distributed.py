@@ -42,3 +42,28 @@ def test_warning_carries_the_totals_of_the_level(built_library, tmp_path):
     assert open(out_path + ".warnings").read() == str(fx["B_warnings"]) == "Warning: 252 out of 256 geodesics terminate unexpectedly.\n"
     counts = np.load(out_path + ".counts.npy")
     assert counts[0] == int(fx["B_geodesic_num_steps"]) and counts[1] == 252
+
+
+@pytest.mark.parametrize("case,devices", [("sim_adaptive", 2), ("sim_polarized_adaptive", 3), ("sim_few_steps", 2), ("sim_render_light", 2)])
+def test_command_line_driver_over_several_devices(case, devices, built_library, tmp_path):
+    """bin/blacklight_amd with BLACKLIGHT_AMD_DEVICES = N: one process, one host thread and one context per device (here N
+    contexts on the one GPU of the box), every level cut over them and put back together. Output files and warnings are
+    the single-device ones, i.e. the reference's."""
+    import subprocess
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(repo, "blacklight_amd", "bin", "blacklight_amd")
+    fx, params, mock_args = gu.load_case(case)
+    params = dict(params)
+    params["output_file"] = str(tmp_path / "image.npz")
+    grid_path = tmp_path / "grid.blgrid"
+    gu.golden_grid(mock_args).save_raw(grid_path)
+    params["simulation_file"] = str(grid_path)
+    input_path = tmp_path / "case.input"
+    with open(input_path, "w") as f:
+        for key, value in params.items():
+            f.write(f"{key} = {value}\n")
+    run = subprocess.run([exe, str(input_path)], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, BLACKLIGHT_AMD_DEVICES=str(devices)))
+    assert run.returncode == 0, run.stdout + run.stderr
+    _assert_npz_equals_golden(np.load(params["output_file"]), fx)
+    assert run.stderr == str(fx["B_warnings"])

@@ -365,6 +365,10 @@ def test_block_interpolation_refuses_undefined_reads(built_library):
         ctx.set_grid(grid)
         with pytest.raises(bl.BlacklightError, match="last MeshBlock"):
             ctx.render()
+        ctx.set_undefined_policy("edge")   # usable for a camera that sees the whole grid: edge rule + a warning
+        out = ctx.render()
+        assert np.isfinite(out["image"]).all() and "where the reference reads past its arrays" in ctx.warnings
+        ctx.set_undefined_policy("refuse")
         with pytest.raises(bl.BlacklightError, match="MeshBlock table"):
             ctx.set_grid(dataclasses.replace(grid, levels=None, locations=None, n_3_root=0))
 

@@ -2,6 +2,7 @@
 files written by h5py with the reference's mock script (tests/golden/reader/*.athdf, made by
 tools/make_goldens.py reader) and the arrays h5py itself reads back from them (expected.npz). The reference
 reads the same files: its images of the two-file series are the GPU test in test_gpu_adaptive_cli.py."""
+import ctypes as C
 import json
 import os
 
@@ -319,7 +320,7 @@ def test_iharm3d_messages(built_library, iharm3d, tmp_path):
         Snapshot(_iharm3d_params(iharm3d, "spin", plasma_gamma_i=None))
     with pytest.raises(BlacklightError, match="Invalid simulation_coord for Harm format."):
         Snapshot(_iharm3d_params(iharm3d, "plain", simulation_coord="cks"))
-    with pytest.raises(BlacklightError, match="fmks"):
+    with pytest.raises(BlacklightError, match="header/metric is FMKS or MMKS"):
         Snapshot(_iharm3d_params(iharm3d, "plain", simulation_coord="fmks"))
     with pytest.raises(BlacklightError, match="electron entropy slice"):
         Snapshot(_iharm3d_params(iharm3d, "plain", plasma_model="code_kappa", simulation_kappa_name="KEL"))
@@ -350,3 +351,85 @@ def test_harm3d_file_against_its_athena_twin(built_library):
     params["simulation_coord"] = "cks"
     with pytest.raises(BlacklightError, match="Invalid simulation_coord for Harm format."):
         Snapshot(Params.from_dict(params))
+
+
+# ---------------------------------------------------------------------------------------------- FMKS iharm3d dumps
+FMKS_FILE = os.path.join(READER_DIR, "iharm3d_fmks.h5")
+
+
+@pytest.fixture(scope="module")
+def fmks():
+    return np.load(os.path.join(READER_DIR, "expected_fmks.npz"), allow_pickle=False)
+
+
+def _fmks_params(fmks, case, **overrides):
+    params = json.loads(str(fmks[f"{case}_params"]))
+    params["simulation_file"] = FMKS_FILE
+    params.update(overrides)
+    return Params.from_dict({k: v for k, v in params.items() if v is not None})
+
+
+def test_fmks_reader(built_library, fmks):
+    """simulation_coord = fmks on an iharm3d FMKS dump (simulation_reader.cpp:371-427; ConvertCoordinates, GenerateSKSMap,
+    GetSKSCoordinates, SetJacobianFactors: simulation_geometry.cpp:36-57, :321-483): native coordinates kept, the SKS ->
+    FMKS table and the grid's SKS bounds built."""
+    with Snapshot(_fmks_params(fmks, "interp")) as s:
+        d = s.desc()
+        arrays = s.arrays()
+        assert s.warnings == ""
+        n1, n2 = d.sks_map_n1, d.sks_map_n2
+        assert (n1, n2) == (2048, 2048) and d.sks_map
+        table = np.ctypeslib.as_array(C.cast(d.sks_map, C.POINTER(C.c_double)), shape=(2, n2, n1)).copy()
+        bounds = np.array(d.simulation_bounds)
+        r_in, dr, dtheta = d.sks_map_r_in, d.sks_map_dr, d.sks_map_dtheta
+    # native coordinates: uniform in log r and in x^2 from 0 to 1
+    assert np.allclose(np.diff(arrays["x1f"][0]), arrays["x1f"][0][1] - arrays["x1f"][0][0], rtol=1e-12)
+    assert arrays["x2f"][0][0] == 0.0 and abs(arrays["x2f"][0][-1] - 1.0) < 1e-14
+    assert abs(np.exp(arrays["x1f"][0][0]) - r_in) < 1e-12 and abs(bounds[0] - r_in) < 1e-12
+    assert abs(bounds[1] - np.exp(arrays["x1f"][0][-1])) < 1e-9 and abs(dr * (n1 - 1) - (bounds[1] - bounds[0])) < 1e-9
+    assert abs(bounds[2]) < 1e-12 and abs(bounds[3] - np.pi) < 1e-12 and bounds[4] == 0.0 and bounds[5] == 2.0 * np.pi
+    assert abs(dtheta * (n2 - 1) - np.pi) < 1e-14
+    # x^1 = log r along a row; x^2 from 0 at the north pole to 1 at the south pole, monotonic, and the FMKS theta of
+    # (x^1, x^2) is the row's theta to the bisection's tolerance
+    assert np.allclose(table[0, 7], np.log(r_in + dr * np.arange(n1)), rtol=1e-13)
+    assert np.all(table[1, 0] == 0.0) and np.all(table[1, -1] == 1.0) and np.all(np.diff(table[1, :, 100]) > 0)
+    hslope, xt, alpha, smooth = 0.3, 0.82, 14.0, 0.5
+    norm = 0.5 * np.pi * ((alpha + 1) * xt ** alpha) / ((alpha + 1) * xt ** alpha + 1)
+    j = np.arange(5, n2 - 5, 37)
+    x1, x2 = table[0, j, 900], table[1, j, 900]
+    y = 2 * x2 - 1
+    theta_g = np.pi * x2 + (1 - hslope) / 2 * np.sin(2 * np.pi * x2)
+    theta_j = 0.5 * np.pi + norm * y * (1 + (y / xt) ** alpha / (alpha + 1))
+    theta = theta_g + np.exp(smooth * (np.log(r_in) - x1)) * (theta_j - theta_g)
+    assert np.max(np.abs(theta - j * dtheta)) < 2e-5   # the bisection stops at 1e-8 in theta, then takes one more midpoint in x^2
+
+
+@pytest.mark.parametrize("case", ["interp", "nearest"])
+def test_fmks_oracle_against_the_reference(built_library, fmks, case):
+    """Reader + FMKS sampler of the oracle (simulation_sampling.cpp:190-198, :396-456) against the reference's images of
+    the FMKS fixture: bit-exact with the pinned math library (tier B), within 1e-6 of the stock reference (whose reader
+    builds the table with glibc's exp / sin / pow / log)."""
+    import oracle_api
+    from blacklight_amd import _capi
+    p = _fmks_params(fmks, case)
+    with Snapshot(p) as s:
+        assert s.warnings + "Warning: Ignoring simulation_block_interp selection.\n" == str(fmks[f"{case}_B_warnings"]) \
+            or "Warning: Ignoring simulation_block_interp selection.\n" + s.warnings == str(fmks[f"{case}_B_warnings"])
+        out = oracle_api.render(p.ptr, s.desc(), _capi.RenderDesc, _capi.CameraFrame, n_rays=256, max_steps=2000, n_freq=1)
+        out_a = oracle_api.render(p.ptr, s.desc(), _capi.RenderDesc, _capi.CameraFrame, n_rays=256, max_steps=2000, n_freq=1, variant="libm")
+    rows = ["I_nu"] + (["tau"] if f"{case}_B_tau" in fmks.files else [])
+    want = np.stack([fmks[f"{case}_B_{name}"].reshape(-1) for name in rows])
+    assert gu.same_bits(out["image"], want).all()
+    want_a = np.stack([fmks[f"{case}_A_{name}"].reshape(-1) for name in rows])
+    assert np.max(np.abs(out_a["image"] - want_a) / np.max(np.abs(want_a), axis=1, keepdims=True)) < 1.0e-6
+
+
+def test_fmks_undefined_reads_are_refused(built_library, fmks):
+    """Without the polar cut of the goldens the camera sees the last polar zone of the last azimuthal plane, where the
+    reference's unbounded Array hands back another variable's data: the oracle (like the GPU path) refuses."""
+    import oracle_api
+    from blacklight_amd import _capi
+    p = _fmks_params(fmks, "interp", cut_midplane_theta=0.0)
+    with Snapshot(p) as s:
+        with pytest.raises(RuntimeError, match="reads past"):
+            oracle_api.render(p.ptr, s.desc(), _capi.RenderDesc, _capi.CameraFrame, n_rays=256, max_steps=2000, n_freq=1)

@@ -37,14 +37,15 @@ with bl.Context(bl.Params.from_dict(params)) as ctx:
     out["formula_512"] = dict(seconds=sec, mrays_per_s=512 * 512 / sec / 1e6, samples_per_ray=st.n_samples / (512 * 512),
                               ms_geodesic=st.ms_geodesic, ms_shade=st.ms_shade, ms_transfer=st.ms_transfer, chunks=st.n_chunks)
 grid = mock.generate(n_r=256, n_th=256, n_ph=256)
-for nf in (10, 64):
+for nf, tier in ((10, "exact"), (10, "tolerant"), (64, "exact"), (64, "tolerant")):
     p = dict(bench.WORKLOAD)
     p.update(image_num_frequencies=nf, image_frequency_start=1.5e11, image_frequency_end=3.3e11, image_frequency_spacing="lin_wave")
     with bl.Context(bl.Params.from_dict(p)) as ctx:
         ctx.set_grid(grid)
+        ctx.set_arithmetic(tier)
         res, sec = timed(ctx, n=2)
         st = res["stats"]
-        out[f"true_color_1024_{nf}freq"] = dict(seconds=sec, mrays_per_s=1024 * 1024 / sec / 1e6, ms_geodesic=st.ms_geodesic,
+        out[f"true_color_1024_{nf}freq_{tier}"] = dict(seconds=sec, mrays_per_s=1024 * 1024 / sec / 1e6, ms_geodesic=st.ms_geodesic,
                                                 ms_locate=st.ms_locate, ms_shade=st.ms_shade, ms_transfer=st.ms_transfer, chunks=st.n_chunks,
                                                 finite_fraction=float(np.isfinite(res["image"]).mean()))
 print(json.dumps(out, indent=1))

@@ -741,6 +741,72 @@ def make_iharm3d_fixtures():
     np.savez_compressed(os.path.join(out_dir, "expected_iharm3d.npz"), **expected)
 
 
+# FMKS ("funky" modified Kerr-Schild) iharm3d dumps, simulation_coord = fmks. The reference's mock script writes MKS files
+# only; this rewrites its iharm3d file with header/metric = FMKS and the geometry group iharm3d writes for that metric
+# (header/geom/fmks/{a, hslope, r_in, poly_xt, poly_alpha, mks_smooth}; simulation_reader.cpp:371-427). The cell data are
+# the script's, now read as components on the FMKS basis - a test of the reader and sampler, not a physical disc.
+def make_fmks_fixtures():
+    import h5py
+    out_dir = os.path.join(OUT, "reader")
+    workdir = os.path.join(WORK, "fmks")
+    for sub in (out_dir, os.path.join(workdir, "data"), os.path.join(workdir, "output")):
+        os.makedirs(sub, exist_ok=True)
+    expected = {}
+    mock = dict(n_r=16, n_th=12, n_ph=16, pert_amp=0.3, pert_n_ph=3, Bph_amp=0.25)
+    args = []
+    for key, value in mock.items():
+        args += [f"--{key}", str(value)]
+    source = os.path.join(workdir, "data", "mks.h5")
+    subprocess.run([sys.executable, "-W", "ignore", MOCK_SCRIPT, source, "--format", "iharm3d"] + args, check=True)
+    name = "iharm3d_fmks.h5"
+    path = os.path.join(workdir, "data", name)
+    with h5py.File(source, "r") as f, h5py.File(path, "w") as g:
+        def copy(group_in, prefix):
+            for key, item in group_in.items():
+                full = prefix + key
+                if isinstance(item, h5py.Group):
+                    if full != "header/geom/mks":
+                        copy(item, full + "/")
+                elif full == "header/metric":
+                    g.create_dataset(full, data=("FMKS",), dtype="|S20")
+                else:
+                    g.create_dataset(full, data=item[...], dtype=item.dtype)
+        copy(f, "")
+        r_in = float(np.exp(f["header/geom/startx1"][()]))
+        for key, value in (("a", 0.5), ("hslope", 0.3), ("r_in", r_in), ("r_out", float(f["header/geom/mks/r_out"][()])),
+                           ("poly_xt", 0.82), ("poly_alpha", 14.0), ("mks_smooth", 0.5), ("r_eh", 2.0)):
+            g.create_dataset("header/geom/fmks/" + key, data=value, dtype=np.float64)
+    with open(path, "rb") as src, open(os.path.join(out_dir, name), "wb") as dst:
+        dst.write(src.read())
+    # The reference's FMKS sampler reads cells (k_m .. k_m + 1, j_m .. j_m + 1, i_m .. i_m + 1) from the zone a sample is in,
+    # without bounds (simulation_sampling.cpp:412-415, :809-819): in the outermost radial zone that is the next row's first
+    # cell (kept: part of what is pinned here), in the last polar zone of the last azimuthal plane it is ANOTHER VARIABLE's
+    # data (or memory past the array) - the samples there are kept out by cut_midplane_theta, as the far-side block is
+    # for inter-block interpolation. ray_factor = 1.05 ends the rays at r = 1.96, outside the grid's inner edge (1.916): the
+    # reference keeps its "current block" bounds per OpenMP thread (:184-198), starts them at the SKS bounds of the grid, and
+    # after the first sample that leaves those bounds but lies inside the NATIVE coordinate box (log r, x^2, phi read as
+    # r, theta, phi: r in [0.65, 3.95], theta < 1) it tests every later sample of that thread against the native box
+    # (:362-392) - the image then depends on the thread schedule. Not reproduced; the goldens never leave the grid.
+    for case, overrides in (("interp", dict(image_tau="true")),
+                            ("nearest", dict(simulation_interp="false", plasma_use_p="false", plasma_gamma=1.5,
+                                             plasma_gamma_i=1.6666666666666667, plasma_gamma_e=1.3333333333333333, camera_th=70.0))):
+        params = dict(SIM_BASE)
+        params.update(camera_resolution=16, checkpoint_geodesic_save="false", simulation_format="iharm3d", simulation_coord="fmks",
+                      simulation_a=0.5, simulation_file="data/" + name, cut_midplane_theta=40.0, ray_factor=1.05)
+        params.update(overrides)
+        write_input(os.path.join(workdir, "case.input"), params)
+        expected[f"{case}_params"] = json.dumps(params)
+        for tier, preload in (("A", False), ("B", True)):
+            expected[f"{case}_{tier}_warnings"] = run_reference(workdir, "case.input", preload)
+            npz = np.load(os.path.join(workdir, "output", "out.npz"))
+            for key in npz.files:
+                expected[f"{case}_{tier}_{key}"] = npz[key]
+        a, b = expected[f"{case}_A_I_nu"], expected[f"{case}_B_I_nu"]
+        print("fmks", case, "I_nu max", float(np.nanmax(b)), "nan", int(np.isnan(b).sum()), "A-vs-B", float(np.nanmax(np.abs(a - b)) / np.nanmax(np.abs(b))),
+              repr(expected[f"{case}_B_warnings"]))
+    np.savez_compressed(os.path.join(out_dir, "expected_fmks.npz"), **expected)
+
+
 # harm3d dumps: the same, --format harm3d (one line of text, then float32 records)
 def make_harm3d_fixtures():
     import h5py
@@ -889,6 +955,8 @@ if __name__ == "__main__":
             make_athenak_fixtures()
         elif case_name == "iharm3d":
             make_iharm3d_fixtures()
+        elif case_name == "fmks":
+            make_fmks_fixtures()
         elif case_name == "harm3d":
             make_harm3d_fixtures()
         elif case_name == "slowcli":
