@@ -424,32 +424,31 @@ __global__ void __launch_bounds__(64, 1) bl_geodesic_kernel(BlTraceArgs P) {
     // Each wave owns a block of BL_RECORD_BLOCK consecutive record slots and hands them out with one
     // wave scan per step; the global atomic (whose return has to be waited for, with nothing else to
     // run at one wave per SIMD) is only needed when a block runs out, about once in a dozen steps.
-    // Each lane's samples are contiguous. When the step does not fit in what is left of the block,
-    // the leading lanes that do fit use it up and the others start the next block; the few slots in
-    // between are marked dead for the shading kernels.
-    int scan = wave_inclusive_scan(emit);
-    int total = __builtin_amdgcn_readlane(scan, 63);
-    long long my_base = 0;
+    // The samples of the step are laid end to end in lane order; when they do not fit in what is left of the
+    // block, they fill it to its last slot and continue at the start of the next block (a lane's run of samples
+    // may straddle the two), so no slot is lost at a switch and chunk_rays * ray_max_steps slots plus one block
+    // per wave always suffice. Only the unused tail of a wave's last block is marked dead.
+    const int scan = wave_inclusive_scan(emit);
+    const int total = __builtin_amdgcn_readlane(scan, 63);
+    const int excl = scan - emit;               // this lane's first sample among the step's
+    long long old_base = block_next, new_base = 0;
+    int old_room = 0x7fffffff;                   // samples of this step that go to the current block
     if (total > 0) {
       const long long remaining = block_end - block_next;
-      const unsigned long long fit_mask = __ballot((long long)scan <= remaining);   // a prefix of the lanes (scan is monotonic)
-      const int n_fit = __popcll(fit_mask);
-      const int used_old = n_fit > 0 ? __builtin_amdgcn_readlane(scan, n_fit - 1) : 0;
-      if (n_fit == 64) {
-        my_base = block_next + (long long)(scan - emit);
+      if ((long long)total <= remaining) {
         block_next += total;
       } else {
-        retire_record_slots(P.records_hot, block_next + used_old, block_end, lane);
-        const unsigned long long grab = (unsigned long long)std_max_ll(total - used_old, BL_RECORD_BLOCK);
-        unsigned long long new_base = 0ull;
-        if (lane == 63) new_base = atomicAdd(&P.counters[BL_CNT_RECORDS], grab);
-        new_base = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(new_base >> 32), 63) << 32)
-            | (unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)new_base, 63);
-        my_base = lane < n_fit ? block_next + (long long)(scan - emit) : (long long)new_base + (long long)(scan - emit - used_old);
-        block_next = (long long)new_base + (long long)(total - used_old);
-        block_end = (long long)(new_base + grab);
+        old_room = (int)remaining;
+        const unsigned long long grab = (unsigned long long)std_max_ll((long long)total - remaining, BL_RECORD_BLOCK);
+        unsigned long long fetched = 0ull;
+        if (lane == 63) fetched = atomicAdd(&P.counters[BL_CNT_RECORDS], grab);
+        fetched = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(fetched >> 32), 63) << 32)
+            | (unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)fetched, 63);
+        new_base = (long long)fetched;
+        block_next = new_base + ((long long)total - remaining);
+        block_end = (long long)(fetched + grab);
         if (block_end > P.record_capacity) {
-          // cannot happen when capacity = chunk_rays * ray_max_steps + one block per wave; flagged for the host
+          // cannot happen with capacity = chunk_rays * ray_max_steps + one block per wave; flagged for the host
           atomicExch(&P.counters[BL_CNT_OVERFLOW], 1ull);
           block_end = block_next = 0;
           emit = 0;
@@ -496,14 +495,16 @@ __global__ void __launch_bounds__(64, 1) bl_geodesic_kernel(BlTraceArgs P) {
         hot.z = smp[3];
         hot.ray = dead ? BL_DEAD_RAY : slot;
         hot.n = (unsigned int)index;
-        P.records_hot[my_base + nn] = hot;
+        const int place = excl + nn;
+        const long long at = place < old_room ? old_base + place : new_base + (place - old_room);
+        P.records_hot[at] = hot;
         BlSampleCold cold;
         cold.kx = smp[4];
         cold.ky = smp[5];
         cold.kz = smp[6];
         cold.len = len;
-        P.records_cold[my_base + nn] = cold;
-        if (kTime) P.sample_t[my_base + nn] = smp[0];
+        P.records_cold[at] = cold;
+        if (kTime) P.sample_t[at] = smp[0];
       }
     }
 

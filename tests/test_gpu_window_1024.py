@@ -85,3 +85,20 @@ def test_full_size_frame_is_independent_of_how_it_is_split(built_library):
     assert np.array_equal(nan, full["sample_flags"].astype(bool) & nan) and nan.sum() <= full["sample_flags"].sum()
     # algorithmic bytes of the roofline: 256 B per gathered sample + 13 B per ray
     assert full["stats"].algorithmic_bytes == 256 * full["stats"].n_gathers + 13 * res * res
+
+
+def test_saturated_rays_fill_the_record_buffer_exactly(built_library):
+    """Every ray of a 1024^2 camera runs into a low ray_max_steps: the sample records then need all of
+    chunk_rays * ray_max_steps slots. The geodesic kernel hands slots out without losing any at a block switch, so
+    that bound (plus one block per wave) holds - the reference only warns in this situation, and so does bl_render."""
+    import blacklight_amd as bl
+    fx, params, _ = gu.load_case("formula_dp")
+    for steps in (96, 257):
+        p = bl.Params.from_dict(dict(params, camera_resolution=1024, ray_max_steps=steps, fallback_nan="false"))
+        with bl.Context(p) as ctx:
+            out = ctx.render()
+            st = out["stats"]
+            assert st.n_flagged == 1024 * 1024 and (out["sample_num"] == steps).all() and out["sample_flags"].all()
+            assert st.n_samples == 1024 * 1024 * steps
+            assert "1048576 out of 1048576 geodesics terminate unexpectedly." in ctx.warnings
+            assert np.isfinite(out["image"]).all()
