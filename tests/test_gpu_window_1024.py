@@ -102,3 +102,57 @@ def test_saturated_rays_fill_the_record_buffer_exactly(built_library):
             assert st.n_samples == 1024 * 1024 * steps
             assert "1048576 out of 1048576 geodesics terminate unexpectedly." in ctx.warnings
             assert np.isfinite(out["image"]).all()
+
+
+def _split_property(ctx, res, world, tile, rows=None):
+    """Frame in one call == frame assembled from the tiles of `world` emulated ranks == frame in many chunks."""
+    from blacklight_amd import distributed as bd
+    full = ctx.render()
+    n_q = full["image"].shape[0]
+    assembled = np.full((n_q, res * res), np.nan)
+    counts = np.full(res * res, -1, dtype=np.int32)
+    for rank in range(world):
+        pixels = bd.tile_pixels(res, rank, world, tile)
+        part = ctx.render(pixel_map=pixels)
+        assembled[:, pixels] = part["image"]
+        counts[pixels] = part["sample_num"]
+    assert np.array_equal(counts, full["sample_num"])
+    assert gu.same_bits(assembled, full["image"]).all()
+    return full
+
+
+def test_config_2_at_size_is_independent_of_how_it_is_split(built_library):
+    """BASELINE.json configuration 2 - example_formula.input at 512^2 (formula mode, a = 0.9, camera at r = 1000,
+    ray_max_steps = 7000) - at its own size: split independence, flags only where rays ran out of steps."""
+    import blacklight_amd as bl
+    fx, params, _ = gu.load_case("formula_dp")
+    p = bl.Params.from_dict(dict(params, camera_resolution=512))
+    with bl.Context(p) as ctx:
+        full = _split_property(ctx, 512, 4, 32)
+        ctx.set_scratch_limit(12 << 30)
+        chunked = ctx.render()
+        assert chunked["stats"].n_chunks > 4
+        assert gu.same_bits(chunked["image"], full["image"]).all() and np.array_equal(chunked["sample_num"], full["sample_num"])
+    flagged = full["sample_flags"].astype(bool)
+    assert np.array_equal(np.isnan(full["image"][0]), flagged) and 0 < flagged.sum() < 4096
+    assert (full["sample_num"][~flagged] < 7000).all() and full["sample_num"].mean() > 1000
+
+
+def test_polarized_frame_at_size_is_independent_of_how_it_is_split(built_library):
+    """Configuration 4's physics - full-Stokes polarized transfer with image_tau - on one 1024^2 frame over the 256^3 mock:
+    the frame in one call equals the frame assembled from the tiles of three emulated ranks (unequal shares), row by row
+    (I, Q, U, V, tau), and |Q|, |U|, |V| never exceed I."""
+    import blacklight_amd as bl
+    from blacklight_amd import mock
+    import bench
+    grid = mock.generate(n_r=256, n_th=256, n_ph=256)
+    p = bl.Params.from_dict(dict(bench.WORKLOAD, image_polarization=True, image_rotation_split=False, image_tau=True))
+    with bl.Context(p) as ctx:
+        ctx.set_grid(grid)
+        full = _split_property(ctx, 1024, 3, 32)
+    image = full["image"]
+    assert image.shape == (5, 1024 * 1024)
+    ok = np.isfinite(image[0])
+    assert ok.mean() > 0.999
+    polarized = np.sqrt(image[1] ** 2 + image[2] ** 2 + image[3] ** 2)
+    assert (polarized[ok] <= image[0][ok] * (1.0 + 1.0e-12) + 1.0e-300).all() and polarized[ok].max() > 0.0
