@@ -1094,6 +1094,8 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
     const bool fast = ctx->arithmetic == BL_ARITH_TOLERANT && simulation && !aux && !ctx->polarized && !slow && !block_interp
         && p.plasma_power_frac == 0.0 && p.plasma_kappa_frac == 0.0 && p.plasma_model != BL_PLASMA_CODE_KAPPA
         && (p.simulation_coord == BL_COORD_SKS || p.simulation_coord == BL_COORD_FMKS) && !p.ray_flat && ctx->plasma_thermal_frac != 0.0;
+    // ... and the per-frequency coefficient kernel of polarized runs (frame, transport and coupling stay exact)
+    const bool tolerant_polarized = ctx->arithmetic == BL_ARITH_TOLERANT && ctx->polarized;
     const size_t redo_capacity = 1u << 20;
     // chunk size from the scratch budget: per ray max_steps * (2 x 32 B record + 40 B located sample
     // (simulation mode) + 16 B * n_nu transfer)
@@ -1466,6 +1468,7 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
       sa.grid = ctx->grid_dev;
       sa.lds_table_bytes = ctx->lds_table_bytes;
       sa.undefined_edge = ctx->undefined_policy == BL_UNDEFINED_EDGE ? 1 : 0;
+      sa.tolerant = (fast || tolerant_polarized) ? 1 : 0;
     } else {
       BlFormulaDevice &fm = sa.formula;
       fm.r0 = p.formula_r0; fm.h = p.formula_h; fm.l0 = p.formula_l0; fm.q = p.formula_q; fm.nup = p.formula_nup;
@@ -1699,7 +1702,7 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
     st.ms_transfer = ms_transfer;
     st.ms_total = ms_geo + ms_locate + ms_shade + ms_transfer;
     st.ms_wall = ms_wall;
-    st.arithmetic = fast ? BL_ARITH_TOLERANT : BL_ARITH_EXACT;
+    st.arithmetic = (fast || tolerant_polarized) ? BL_ARITH_TOLERANT : BL_ARITH_EXACT;
     st.n_deferred = static_cast<int64_t>(total_redo);
     ctx->stats = st;
     // Warning text of the reference (geodesics.cpp:389-394)

@@ -1568,205 +1568,38 @@ __device__ __forceinline__ void sample_finish_simulation(const BlShadeArgs &P, c
   }
 }
 
-// Unpolarized emissivity and absorptivity of one sample at one frequency (simulation_coefficients.cpp:464-523,
-// :556-584): thermal electrons, plus power-law electrons in the extended instantiation. The sample has coefficients
-// (SampleShade::have_coefficients).
-template <bool kExtended>
-__device__ __forceinline__ void simulation_coefficients(const BlShadeArgs &P, const SampleShade &sh, double freq,
-                                                        double momentum_factor, double *j_out, double *alpha_out) {
-  double j_val = 0.0, alpha_val = 0.0;
-  // simulation_coefficients.cpp:464-523, thermal electrons, unpolarized
-  const double thermal_frac = P.plasma.plasma_thermal_frac;
-  const double nu_cgs = sh.nu_fluid_over_nu * (freq * momentum_factor);
-  const double nu_2_cgs = nu_cgs * nu_cgs;
-  const double nu_s_cgs = 2.0 / 9.0 * sh.nu_c_cgs * sh.theta_e * sh.theta_e * sh.sin_theta_b;
-  if (thermal_frac != 0.0) {
-    const double xx = nu_cgs / nu_s_cgs;
-    const double xx_1_2 = bl_sqrt_g(xx);
-    const double xx_1_3 = bl_cbrt(xx);
-    const double xx_1_6 = bl_sqrt_g(xx_1_3);
-    const double coefficient = bl_div_g(thermal_frac * sh.n_e_cgs * kE * kE * sh.nu_c_cgs, kC * nu_2_cgs) * bl_exp(-xx_1_3);
-    const double var_a = kSqrt2 * kPi / 27.0 * sh.sin_theta_b;
-    const double var_b = kPow2_11_12;
-    const double var_c = xx_1_2 + var_b * xx_1_6;
-    j_val = coefficient * var_a * var_c * var_c;
-    const double b_nu_nu_3_cgs = 2.0 * kH / (kC * kC) / bl_expm1(kH * nu_cgs / sh.kb_tt_e_cgs);
-    alpha_val = j_val / b_nu_nu_3_cgs;
-    // :513-523 zero alpha when 1 / alpha^2 overflows. 1 / x (x >= 0) rounds to +inf exactly when
-    // x <= 2^-1024 (the next double above, 2^-1024 + 2^-1074, gives 2^1024 - 2^974 < DBL_MAX + ulp/2);
-    // NaN fails both tests. One compare instead of a division.
-    if (alpha_val * alpha_val <= 0x1p-1024) alpha_val = 0.0;
-  }
-  if (kExtended && P.plasma.power_frac != 0.0) {
-    // power-law electrons, unpolarized (simulation_coefficients.cpp:556-584)
-    const double ratio = nu_cgs / (sh.nu_c_cgs * sh.sin_theta_b);
-    const double var_a_j = bl_pow(ratio, -(P.plasma.plasma_p - 1.0) / 2.0);
-    j_val += P.plasma.power_frac * sh.n_e_cgs * kE * kE * sh.nu_c_cgs / (kC * nu_2_cgs) * P.plasma.power_jj
-        * sh.sin_theta_b * var_a_j;
-    const double var_a_a = bl_pow(ratio, -(P.plasma.plasma_p + 2.0) / 2.0);
-    alpha_val += P.plasma.power_frac * sh.n_e_cgs * kE * kE / (kMe * kC) * P.plasma.power_aa * var_a_a;
-  }
-  *j_out = j_val;
-  *alpha_out = alpha_val;
-}
-
-// Polarized coefficients of one sample at one frequency: (j_Q, j_V), (alpha_Q, alpha_V), (rho_Q, rho_V); the
-// kappa-distribution terms also add to the intensity pair (j_val, alpha_val), which simulation_coefficients() has
-// filled before.
-__device__ __forceinline__ void polarized_coefficients(const BlShadeArgs &P, const SampleShade &sh, double freq,
-                                                       double momentum_factor, double &j_val, double &alpha_val, double2 pc[3]) {
-  // polarized coefficients (simulation_coefficients.cpp:485-495, :506-523, :527-553, :567-605), plain
-  // IEEE operations in the reference's order
-  double j_q = 0.0, j_v = 0.0, alpha_q = 0.0, alpha_v = 0.0, rho_q = 0.0, rho_v = 0.0;
-  if (sh.have_coefficients) {
-    const double thermal_frac = P.plasma.plasma_thermal_frac;
-    const double nu_cgs = sh.nu_fluid_over_nu * (freq * momentum_factor);
-    const double nu_2_cgs = nu_cgs * nu_cgs;
-    const double nu_c_cgs = sh.nu_c_cgs, theta_e = sh.theta_e, sin_theta_b = sh.sin_theta_b, cos_theta_b = sh.cos_theta_b;
-    const double n_e_cgs = sh.n_e_cgs;
-    const double nu_s_cgs = 2.0 / 9.0 * nu_c_cgs * theta_e * theta_e * sin_theta_b;
-    if (thermal_frac != 0.0) {
-      const double xx = nu_cgs / nu_s_cgs;
-      const double xx_1_2 = blm_sqrt(xx);
-      const double xx_1_3 = bl_cbrt(xx);
-      const double xx_1_6 = blm_sqrt(xx_1_3);
-      const double coefficient = thermal_frac * n_e_cgs * kE * kE * nu_c_cgs / (kC * nu_2_cgs) * bl_exp(-xx_1_3);
-      const double var_a = kSqrt2 * kPi / 27.0 * sin_theta_b;
-      const double var_b = kPow2_11_12;
-      const double theta_e_096 = sh.theta_e_096;   // bl_pow(theta_e, 0.96), evaluated twice per frequency in the reference: same value
-      const double var_d = (7.0 * theta_e_096 + 35.0) / (10.0 * theta_e_096 + 75.0) * var_b;
-      const double var_e = xx_1_2 + var_d * xx_1_6;
-      const double var_f = cos_theta_b / theta_e;
-      const double var_g = kPi / 3.0 + kPi / 3.0 * xx_1_3 + 2.0 / 300.0 * xx_1_2 + 2.0 / 19.0 * kPi * xx_1_3 * xx_1_3;
-      j_q = -coefficient * var_a * var_e * var_e;
-      j_v = coefficient * var_f * var_g;
-      const double b_nu_nu_3_cgs = 2.0 * kH / (kC * kC) / bl_expm1(kH * nu_cgs / sh.kb_tt_e_cgs);
-      alpha_q = j_q / b_nu_nu_3_cgs;
-      alpha_v = j_v / b_nu_nu_3_cgs;
-      // :513-523 with the thermal alpha_I (alpha_val holds it, possibly already zeroed, before the
-      // power-law term is added - recompute the test on the thermal value)
-      {
-        const double var_c = xx_1_2 + var_b * xx_1_6;
-        const double alpha_thermal = coefficient * var_a * var_c * var_c / b_nu_nu_3_cgs;
-        if (alpha_thermal * alpha_thermal <= 0x1p-1024) alpha_q = alpha_v = 0.0;
-      }
-      const double coefficient_q = -thermal_frac * n_e_cgs * kE * kE * nu_c_cgs * nu_c_cgs * sh.sin2_theta_b / (kMe * kC * nu_2_cgs);
-      const double coefficient_v = thermal_frac * 2.0 * n_e_cgs * kE * kE * nu_c_cgs * cos_theta_b / (kMe * kC * nu_cgs);
-      double factor_q = 0.0, factor_v = 1.0;
-      if (theta_e >= 0.01) {   // theta_e_zero, radiation_integrator.hpp:190
-        const double kk_0 = sh.kk_0, kk_1 = sh.kk_1, kk_2 = sh.kk_2;   // three std::cyl_bessel_k calls per frequency in the reference (:537-539)
-        const double xx_neg_1_2 = 1.0 / blm_sqrt(xx);
-        const blm_powbase xx_base = bl_pow_base(xx);   // four powers of xx below: one logarithm (blmath.h)
-        const double f_a = 2.011 * bl_exp(-19.78 * bl_pow_of(xx_base, -0.5175));
-        const double f_b = bl_cos(39.89 * xx_neg_1_2) * bl_exp(-70.16 * bl_pow_of(xx_base, -0.6));
-        const double f_c = 0.011 * bl_exp(-1.69 * xx_neg_1_2);
-        const double f_d = 0.003135 * bl_pow_of(xx_base, 4.0 / 3.0);
-        const double f_e = 0.5 * (1.0 + bl_tanh(10.0 * bl_log(0.6648 * xx_neg_1_2)));
-        const double f_0 = f_a - f_b - f_c;
-        const double f_m = f_0 + (f_c - f_d) * f_e;
-        const double delta_jj_5 = 0.4379 * bl_log(1.0 + 1.3414 * bl_pow_of(xx_base, -0.7515));
-        factor_q = f_m * (kk_1 / kk_2 + 6.0 * theta_e);
-        factor_v = (kk_0 - delta_jj_5) / kk_2;
-        factor_v = (factor_v < 0.0 || factor_v > 1.0) ? 1.0 : factor_v;
-      }
-      rho_q = coefficient_q * factor_q;
-      rho_v = coefficient_v * factor_v;
-    }
-    if (P.plasma.power_frac != 0.0) {
-      const double plasma_p = P.plasma.plasma_p;
-      {
-        const double var_a = bl_pow(nu_cgs / (nu_c_cgs * sin_theta_b), -(plasma_p - 1.0) / 2.0);
-        const double coefficient = P.plasma.power_frac * n_e_cgs * kE * kE * nu_c_cgs / (kC * nu_2_cgs) * P.plasma.power_jj * sin_theta_b * var_a;
-        const double var_b = cos_theta_b / sin_theta_b;
-        const double var_c = 1.0 / blm_sqrt(nu_cgs / (3.0 * nu_c_cgs * sin_theta_b));
-        j_q += coefficient * P.power_pol[0];
-        j_v += coefficient * P.power_pol[1] * var_b * var_c;
-      }
-      {
-        const double var_a = bl_pow(nu_cgs / (nu_c_cgs * sin_theta_b), -(plasma_p + 2.0) / 2.0);
-        const double coefficient = P.plasma.power_frac * n_e_cgs * kE * kE / (kMe * kC) * P.plasma.power_aa * var_a;
-        const double var_b = bl_pow(3.1 * bl_pow(sin_theta_b, -1.92) - 3.1, 0.512);
-        const double var_c = 1.0 / blm_sqrt(nu_cgs / (nu_c_cgs * sin_theta_b));
-        const double var_d = cos_theta_b >= 0.0 ? 1.0 : -1.0;
-        alpha_q += coefficient * P.power_pol[2];
-        alpha_v += coefficient * P.power_pol[3] * var_b * var_c * var_d;
-      }
-      {
-        const double var_a = n_e_cgs * kE * kE * nu_cgs / (kMe * kC * nu_c_cgs * sin_theta_b);
-        const double var_b = nu_c_cgs * sin_theta_b / nu_cgs;
-        const double var_c = var_b * var_b;
-        const double var_d = var_c * var_b;
-        const double var_e = 1.0 - bl_pow(2.0 * nu_c_cgs * P.plasma_gamma_min * P.plasma_gamma_min * sin_theta_b / (3.0 * nu_cgs), plasma_p / 2.0 - 1.0);
-        const double var_f = cos_theta_b / sin_theta_b;
-        const double coefficient = P.plasma.power_frac * P.power_pol[4] * var_a;
-        rho_q += coefficient * P.power_pol[5] * var_d * var_e;
-        rho_v += coefficient * P.power_pol[6] * var_c * var_f;
-      }
-    }
-    if (P.cold->kappa.frac != 0.0) {
-      // kappa-distribution electrons (simulation_coefficients.cpp:607-698): every term is the harmonic-like
-      // bridge (low^-x + high^-x)^(-1/x) between a low- and a high-frequency fit. Only polarized runs get
-      // here (bl_init), so the intensity terms are added to j_val / alpha_val in this block as well.
-      const BlKappaDevice &kk = P.cold->kappa;
-      const double nu_kappa_cgs = nu_c_cgs * kk.w * kk.w * kk.kappa * kk.kappa * sin_theta_b;
-      const double xx = nu_cgs / nu_kappa_cgs;
-      const double var_g = 1.0 / blm_sqrt(xx);
-      const double var_h = cos_theta_b >= 0.0 ? 1.0 : -1.0;
-      const blm_powbase xx_base = bl_pow_base(xx), sin_base = bl_pow_base(sin_theta_b);   // 8 + 5 powers: two logarithms
-      const double var_e = bl_pow_of(xx_base, -0.35);
-      {   // emissivities (:608-637)
-        const double var_a = kk.frac * n_e_cgs * kE * kE * nu_c_cgs / (kC * nu_2_cgs);
-        const double var_b = bl_cbrt(xx) * sin_theta_b;
-        const double var_c = bl_pow_of(xx_base, -(kk.kappa - 2.0) / 2.0) * sin_theta_b;
-        const double coefficient_low = kk.jj_low * var_a * var_b;
-        const double coefficient_high = kk.jj_high * var_a * var_c;
-        j_val += bl_pow(bl_pow(coefficient_low, -kk.jj_x_i) + bl_pow(coefficient_high, -kk.jj_x_i), -1.0 / kk.jj_x_i);
-        const double var_d = bl_pow(bl_pow_of(sin_base, -2.4) - 1.0, 0.48);
-        const double var_f = bl_pow(bl_pow_of(sin_base, -2.5) - 1.0, 0.44);
-        const double jj_q_low = coefficient_low * kk.jj_low_q;
-        const double jj_v_low = coefficient_low * kk.jj_low_v * var_d * var_e;
-        const double jj_q_high = coefficient_high * kk.jj_high_q;
-        const double jj_v_high = coefficient_high * kk.jj_high_v * var_f * var_g;
-        j_q -= bl_pow(bl_pow(jj_q_low, -kk.jj_x_q) + bl_pow(jj_q_high, -kk.jj_x_q), -1.0 / kk.jj_x_q);
-        j_v += bl_pow(bl_pow(jj_v_low, -kk.jj_x_v) + bl_pow(jj_v_high, -kk.jj_x_v), -1.0 / kk.jj_x_v) * var_h;
-      }
-      {   // absorptivities (:640-667)
-        const double var_a = kk.frac * n_e_cgs * kE * kE / (kMe * kC);
-        const double var_b = bl_pow_of(xx_base, -2.0 / 3.0);
-        const double var_c = bl_pow_of(xx_base, -(1.0 + kk.kappa) / 2.0);
-        const double coefficient_low = kk.aa_low * var_a * var_b;
-        const double coefficient_high = kk.aa_high * var_a * var_c;
-        const double aa_i_low = coefficient_low;
-        const double aa_i_high = coefficient_high * kk.aa_high_i;
-        alpha_val += bl_pow(bl_pow(aa_i_low, -kk.aa_x_i) + bl_pow(aa_i_high, -kk.aa_x_i), -1.0 / kk.aa_x_i);
-        const double var_d = bl_pow(bl_pow_of(sin_base, -2.28) - 1.0, 0.446);
-        const double var_f = blm_sqrt(bl_pow_of(sin_base, -2.05) - 1.0);
-        const double aa_q_low = coefficient_low * kk.aa_low_q;
-        const double aa_v_low = coefficient_low * kk.aa_low_v * var_d * var_e;
-        const double aa_q_high = coefficient_high * kk.aa_high_q;
-        const double aa_v_high = coefficient_high * kk.aa_high_v * var_f * var_g;
-        alpha_q -= bl_pow(bl_pow(aa_q_low, -kk.aa_x_q) + bl_pow(aa_q_high, -kk.aa_x_q), -1.0 / kk.aa_x_q);
-        alpha_v += bl_pow(bl_pow(aa_v_low, -kk.aa_x_v) + bl_pow(aa_v_high, -kk.aa_x_v), -1.0 / kk.aa_x_v) * var_h;
-      }
-      {   // rotativities (:670-698): linear blend of the fits at the two ends of kappa's bracket
-        const double var_a = -kk.frac * n_e_cgs * kE * kE * nu_c_cgs * nu_c_cgs * sh.sin2_theta_b / (kMe * kC * nu_2_cgs);
-        const double var_b = kk.frac * 2.0 * n_e_cgs * kE * kE * nu_c_cgs * cos_theta_b / (kMe * kC * nu_cgs);
-        const double xx_084 = bl_pow_of(xx_base, 0.84);
-        const double rho_q_low = var_a * kk.rho_q_low[0] * (1.0 - bl_exp(kk.rho_q_low[1] * xx_084)
-            - bl_sin(kk.rho_q_low[2] * xx) * bl_exp(kk.rho_q_low[3] * bl_pow_of(xx_base, kk.rho_q_low[4])));
-        const double rho_q_high = var_a * kk.rho_q_high[0] * (1.0 - bl_exp(kk.rho_q_high[1] * xx_084)
-            - bl_sin(kk.rho_q_high[2] * xx) * bl_exp(kk.rho_q_high[3] * bl_pow_of(xx_base, kk.rho_q_high[4])));
-        const double rho_v_low = kk.rho_v * var_b * kk.rho_v_low[0] * (1.0 - 0.17 * bl_log(1.0 + kk.rho_v_low[1] * var_g));
-        const double rho_v_high = kk.rho_v * var_b * kk.rho_v_high[0] * (1.0 - 0.17 * bl_log(1.0 + kk.rho_v_high[1] * var_g));
-        rho_q += (1.0 - kk.rho_frac) * rho_q_low + kk.rho_frac * rho_q_high;
-        rho_v += (1.0 - kk.rho_frac) * rho_v_low + kk.rho_frac * rho_v_high;
-      }
-    }
-  }
-  pc[0] = make_double2(j_q, j_v);
-  pc[1] = make_double2(alpha_q, alpha_v);
-  pc[2] = make_double2(rho_q, rho_v);
-}
+// exact arithmetic tier of the coefficient formulas
+#define BLC_NAME(f) f
+#define BLC_SQRT bl_sqrt_g
+#define BLC_SQRT_M blm_sqrt
+#define BLC_CBRT bl_cbrt
+#define BLC_EXP bl_exp
+#define BLC_EXPM1 bl_expm1
+#define BLC_LOG bl_log
+#define BLC_POW bl_pow
+#define BLC_POWBASE_T blm_powbase
+#define BLC_POW_BASE bl_pow_base
+#define BLC_POW_OF bl_pow_of
+#define BLC_DIV_G bl_div_g
+#define BLC_SIN bl_sin
+#define BLC_COS bl_cos
+#define BLC_TANH bl_tanh
+#include "bl_coefficients.inc"
+#undef BLC_NAME
+#undef BLC_SQRT
+#undef BLC_SQRT_M
+#undef BLC_CBRT
+#undef BLC_EXP
+#undef BLC_EXPM1
+#undef BLC_LOG
+#undef BLC_POW
+#undef BLC_POWBASE_T
+#undef BLC_POW_BASE
+#undef BLC_POW_OF
+#undef BLC_DIV_G
+#undef BLC_SIN
+#undef BLC_COS
+#undef BLC_TANH
 
 // Formula mode, one sample (formula_coefficients.cpp:118-161)
 __device__ __forceinline__ void shade_formula(const BlShadeArgs &P, const BlSpacetime &st, double r, double x1,
@@ -2234,7 +2067,85 @@ __device__ __forceinline__ double cbrt(double x) {
   return __builtin_amdgcn_class(x, 0x263) ? x : res;               // NaN, +-0, +inf
 }
 
+// log(x): x = m 2^e, m in [sqrt(1/2), sqrt(2)); log m = 2 s (1 + z / 3 + z^2 / 5 + ...), s = (m - 1) / (m + 1), z = s^2 <= 0.0295
+// (ten terms: 1e-17). Zero gives -inf, negative arguments NaN, +inf and NaN pass through.
+__device__ __forceinline__ double log(double x) {
+  int e = __builtin_amdgcn_frexp_exp(x);
+  double m = __builtin_amdgcn_frexp_mant(x);   // [0.5, 1)
+  const bool low = m < 0x1.6a09e667f3bcdp-1;
+  m = low ? 2.0 * m : m;
+  e = low ? e - 1 : e;
+  const double s = (m - 1.0) * rcp(m + 1.0);
+  const double z = s * s;
+  double p = 1.0 / 19.0;
+  p = __builtin_fma(p, z, 1.0 / 17.0);
+  p = __builtin_fma(p, z, 1.0 / 15.0);
+  p = __builtin_fma(p, z, 1.0 / 13.0);
+  p = __builtin_fma(p, z, 1.0 / 11.0);
+  p = __builtin_fma(p, z, 1.0 / 9.0);
+  p = __builtin_fma(p, z, 1.0 / 7.0);
+  p = __builtin_fma(p, z, 1.0 / 5.0);
+  p = __builtin_fma(p, z, 1.0 / 3.0);
+  const double ed = (double)e;
+  const double small = __builtin_fma(2.0 * s * z, p, ed * BLM_LN2_LO);   // 2 s (z / 3 + ...) + e ln2_lo
+  const double res = __builtin_fma(ed, BLM_LN2_HI, 2.0 * s + small);
+  // special arguments: +-0 -> -inf, negative -> NaN, +inf / NaN -> themselves
+  if (__builtin_amdgcn_class(x, 0x060)) return -__builtin_inf();
+  if (__builtin_amdgcn_class(x, 0x01c)) return __builtin_nan("");
+  if (__builtin_amdgcn_class(x, 0x203)) return x;
+  return res;
+}
+// pow(x, y) = exp(y log x) for x >= 0 (the coefficient formulas raise positive quantities to real powers); relative error
+// ~|y log x| 2^-52. pow(x, 0) = 1 and pow(1, y) = 1 whatever the other argument, as std::pow has it.
+__device__ __forceinline__ double pow(double x, double y) {
+  const double r = exp(y * log(x));
+  return (y == 0.0 || x == 1.0) ? 1.0 : r;
+}
+struct PowBase {
+  double x, l;
+};
+__device__ __forceinline__ PowBase pow_base(double x) { return PowBase{x, log(x)}; }
+__device__ __forceinline__ double pow_of(PowBase b, double y) {
+  const double r = exp(y * b.l);
+  return (y == 0.0 || b.x == 1.0) ? 1.0 : r;
+}
+__device__ __forceinline__ double div(double a, double b) { return a * rcp(b); }
+
 }  // namespace fastmath
+
+// tolerant arithmetic tier of the coefficient formulas (sin, cos, tanh keep the pinned versions: few calls, and their
+// arguments need a real range reduction)
+#define BLC_NAME(f) f##_fast
+#define BLC_SQRT bl_sqrt_g
+#define BLC_SQRT_M bl_sqrt_g
+#define BLC_CBRT fastmath::cbrt
+#define BLC_EXP fastmath::exp
+#define BLC_EXPM1 fastmath::expm1
+#define BLC_LOG fastmath::log
+#define BLC_POW fastmath::pow
+#define BLC_POWBASE_T fastmath::PowBase
+#define BLC_POW_BASE fastmath::pow_base
+#define BLC_POW_OF fastmath::pow_of
+#define BLC_DIV_G fastmath::div
+#define BLC_SIN bl_sin
+#define BLC_COS bl_cos
+#define BLC_TANH bl_tanh
+#include "bl_coefficients.inc"
+#undef BLC_NAME
+#undef BLC_SQRT
+#undef BLC_SQRT_M
+#undef BLC_CBRT
+#undef BLC_EXP
+#undef BLC_EXPM1
+#undef BLC_LOG
+#undef BLC_POW
+#undef BLC_POWBASE_T
+#undef BLC_POW_BASE
+#undef BLC_POW_OF
+#undef BLC_DIV_G
+#undef BLC_SIN
+#undef BLC_COS
+#undef BLC_TANH
 
 // One redo-list entry per sample whose cut decision the tolerant tier leaves to the exact kernel
 __device__ __forceinline__ void fast_defer(const BlShadeArgs &P, unsigned long long idx) {
@@ -2570,6 +2481,9 @@ __global__ void __launch_bounds__(256, BL_FAST_WAVES) bl_shade_fast_kernel(const
 // 458-698) for polarized runs, one sample record per lane from the scalars the coefficient kernel left
 // (BlCoefInputs). Writes (j_I, alpha_I) and the three polarized pairs, [ray][n][frequency].
 // =================================================================================================
+// kTolerant: the tolerant arithmetic tier's functions and fused multiply-adds in the formulas (bl_coefficients.inc,
+// second inclusion) - the kernel is almost entirely the double-double pow / log of the pinned library otherwise.
+template <bool kTolerant>
 __global__ void __launch_bounds__(256, 2) bl_polarized_coefficients_kernel(const BlShadeArgs P) {
   const unsigned long long n_records = P.counters_in[BL_CNT_RECORDS];
   const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
@@ -2595,7 +2509,7 @@ __global__ void __launch_bounds__(256, 2) bl_polarized_coefficients_kernel(const
     // what does not depend on the frequency, once per sample (the reference recomputes it for every frequency)
     sh.theta_e_096 = sh.kk_0 = sh.kk_1 = sh.kk_2 = 0.0;
     if (sh.have_coefficients && P.plasma.plasma_thermal_frac != 0.0) {
-      sh.theta_e_096 = bl_pow(sh.theta_e, 0.96);
+      sh.theta_e_096 = kTolerant ? fastmath::pow(sh.theta_e, 0.96) : bl_pow(sh.theta_e, 0.96);
       if (sh.theta_e >= 0.01) bl_cyl_bessel_k012(1.0 / sh.theta_e, &sh.kk_0, &sh.kk_1, &sh.kk_2);   // theta_e_zero, radiation_integrator.hpp:190
     }
     const size_t at = ((size_t)ray * P.ray_max_steps + n) * P.n_nu;
@@ -2603,8 +2517,13 @@ __global__ void __launch_bounds__(256, 2) bl_polarized_coefficients_kernel(const
       const double freq = P.frequencies[l];
       double j_val = 0.0, alpha_val = 0.0;
       double2 pc[3] = {make_double2(0.0, 0.0), make_double2(0.0, 0.0), make_double2(0.0, 0.0)};
-      if (sh.have_coefficients) simulation_coefficients<true>(P, sh, freq, momentum_factor, &j_val, &alpha_val);
-      polarized_coefficients(P, sh, freq, momentum_factor, j_val, alpha_val, pc);
+      if (kTolerant) {
+        if (sh.have_coefficients) simulation_coefficients_fast<true>(P, sh, freq, momentum_factor, &j_val, &alpha_val);
+        polarized_coefficients_fast(P, sh, freq, momentum_factor, j_val, alpha_val, pc);
+      } else {
+        if (sh.have_coefficients) simulation_coefficients<true>(P, sh, freq, momentum_factor, &j_val, &alpha_val);
+        polarized_coefficients(P, sh, freq, momentum_factor, j_val, alpha_val, pc);
+      }
       P.transfer[at + l] = make_double2(j_val, alpha_val);
       double2 *out = P.pol_coeffs + (at + l) * 3;
       out[0] = pc[0];
@@ -2991,7 +2910,8 @@ extern "C" hipError_t bl_launch_shade_fast(const BlShadeArgs *args, int grid, hi
 }
 
 extern "C" hipError_t bl_launch_polarized_coefficients(const BlShadeArgs *args, int grid, hipStream_t stream) {
-  hipLaunchKernelGGL(bl_polarized_coefficients_kernel, dim3(grid), dim3(256), 0, stream, *args);
+  if (args->tolerant) hipLaunchKernelGGL(bl_polarized_coefficients_kernel<true>, dim3(grid), dim3(256), 0, stream, *args);
+  else hipLaunchKernelGGL(bl_polarized_coefficients_kernel<false>, dim3(grid), dim3(256), 0, stream, *args);
   return hipGetLastError();
 }
 

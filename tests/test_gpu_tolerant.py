@@ -70,8 +70,19 @@ def test_tolerant_tier_on_the_goldens(case, built_library):
     assert np.array_equal(tol["sample_flags"], exact["sample_flags"])
     assert np.array_equal(np.isnan(tol["image"]), np.isnan(exact["image"]))
     if not _applies(params):
-        assert tol["stats"].arithmetic == 0
-        assert gu.same_bits(tol["image"], exact["image"]).all()
+        polarized = params["model_type"] == "simulation" and str(params.get("image_polarization", "false")) == "true"
+        if not polarized:
+            assert tol["stats"].arithmetic == 0
+            assert gu.same_bits(tol["image"], exact["image"]).all()
+            return
+        # polarized runs: the per-frequency coefficient formulas (bl_polarized_coefficients_kernel) have a tolerant
+        # instantiation - fused multiply-adds, exp / log / pow / cbrt of the tolerant tier; frame, transport and coupling
+        # stay exact. pow(x, y) = exp(y log x) carries |y log x| ulps, hence the wider (still rounding-level) bound.
+        assert tol["stats"].arithmetic == 1
+        d_exact = _distance(tol["image"], exact["image"])
+        d_b = _distance(tol["image"], gu.expected_image(fx, "B", n_pix))
+        print(f"{case}: polarized, tolerant vs exact {d_exact:.2e}, vs reference (pinned math) {d_b:.2e}")
+        assert d_exact < 1.0e-9 and d_b < 1.0e-9
         return
     assert tol["stats"].arithmetic == 1
     d_exact = _distance(tol["image"], exact["image"])

@@ -19,6 +19,7 @@ p = dict(bench.WORKLOAD)
 p.update(camera_resolution=res, image_polarization=True, image_tau=True)
 with bl.Context(bl.Params.from_dict(p)) as ctx:
     ctx.set_grid(grid)
+    ctx.set_arithmetic(os.environ.get("ARITH", "exact"))
     ctx.render()
     t0 = time.perf_counter()
     out = ctx.render()

@@ -20,6 +20,7 @@ p = dict(bench.WORKLOAD)
 out = {}
 with bl.Context(bl.Params.from_dict(p)) as ctx:
     ctx.set_grid(grid)
+    ctx.set_arithmetic(os.environ.get("ARITH", "tolerant"))
     for world in (1, 2, 4, 8):
         times = []
         for rank in range(world):
