@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <fstream>
 #include <limits>
 #include <sstream>
 #include <string>
@@ -191,6 +192,16 @@ struct bl_ctx {
   DeviceBuffer<int> d_out_sample_num;
   DeviceBuffer<unsigned char> d_out_flags;
 
+  // geodesic checkpoint of the root level (geodesic_checkpoint.cpp:28-108): what LoadGeodesics() read, by pixel
+  struct Checkpoint {
+    bool loaded = false;
+    int num_steps = 0;
+    std::vector<double> camera_pos, camera_dir, factors;   // [n_pix][4], [n_pix][4], [n_pix]
+    std::vector<uint8_t> flags;
+    std::vector<int32_t> sample_num;
+    std::vector<double> pos, dir, len;   // [n_pix][num_steps][4] x 2, [n_pix][num_steps]: reference order (far -> near)
+  } checkpoint;
+
   bl_stats stats{};
 };
 
@@ -234,8 +245,7 @@ void ValidateGeodesic(bl_ctx *ctx) {
   Require(p, {BL_P_model_type, BL_P_checkpoint_geodesic_save, BL_P_checkpoint_geodesic_load}, kGeoMissing);
   if (p.checkpoint_geodesic_save && p.checkpoint_geodesic_load)
     throw Failure{BL_E_INPUT, "Cannot both save and load a geodesic checkpoint."};
-  if (p.checkpoint_geodesic_save || p.checkpoint_geodesic_load)
-    throw Failure{BL_E_UNSUPPORTED, "Geodesic checkpoints are outside the scope of the MI355X hot path."};
+  if (p.checkpoint_geodesic_save || p.checkpoint_geodesic_load) Require(p, {BL_P_checkpoint_geodesic_file}, kGeoMissing);
   Require(p, {BL_P_camera_type, BL_P_camera_r, BL_P_camera_th, BL_P_camera_ph, BL_P_camera_urn, BL_P_camera_uthn,
               BL_P_camera_uphn, BL_P_camera_k_r, BL_P_camera_k_th, BL_P_camera_k_ph, BL_P_camera_rotation,
               BL_P_camera_width, BL_P_camera_resolution, BL_P_camera_pole},
@@ -558,6 +568,59 @@ int Fail(bl_ctx *ctx, const Failure &failure) {
   else
     g_global_error = text;
   return failure.code;
+}
+
+// ---- geodesic checkpoints (geodesic_checkpoint.cpp:28-108, file_io.cpp:65-127): 7 x 4 doubles of camera frame, then Arrays
+// - five int32 dimensions n1 ... n5 (fastest first) followed by the data - of camera_pos (n_pix, 4), camera_dir (n_pix, 4),
+// image_frequencies, momentum_factors (n_pix), the int geodesic_num_steps, sample_flags (n_pix, bool), sample_num (n_pix, int),
+// sample_pos (n_pix, n_steps, 4), sample_dir (n_pix, n_steps, 4), sample_len (n_pix, n_steps); root level only.
+template <typename T>
+void ReadCheckpointArray(std::ifstream &in, std::vector<T> *data, int dims[5]) {
+  in.read(reinterpret_cast<char *>(dims), 5 * sizeof(int));
+  size_t count = 1;
+  for (int a = 0; a < 5; a++) count *= static_cast<size_t>(std::max(dims[a], 1));
+  if (!in || count > (1ull << 36) / sizeof(T)) throw Failure{BL_E_INPUT, "Geodesic checkpoint file is damaged."};
+  data->resize(count);
+  in.read(reinterpret_cast<char *>(data->data()), static_cast<std::streamsize>(count * sizeof(T)));
+  if (!in) throw Failure{BL_E_INPUT, "Geodesic checkpoint file is damaged."};
+}
+
+void LoadGeodesicCheckpoint(bl_ctx *ctx) {
+  const bl_params &p = ctx->params;
+  std::ifstream in(p.checkpoint_geodesic_file.s, std::ios_base::in | std::ios_base::binary);
+  if (!in.is_open()) throw Failure{BL_E_INPUT, "Could not open geodesic checkpoint file."};
+  bl_camera_frame &f = ctx->frame;
+  double *vectors[7] = {f.cam_x, f.u_con, f.u_cov, f.norm_con, f.norm_con_c, f.hor_con_c, f.vert_con_c};
+  for (double *v : vectors) in.read(reinterpret_cast<char *>(v), 4 * sizeof(double));
+  bl_ctx::Checkpoint &c = ctx->checkpoint;
+  const size_t n_pix = static_cast<size_t>(p.camera_resolution) * p.camera_resolution;
+  int dims[5];
+  std::vector<double> frequencies;
+  ReadCheckpointArray(in, &c.camera_pos, dims);
+  ReadCheckpointArray(in, &c.camera_dir, dims);
+  ReadCheckpointArray(in, &frequencies, dims);
+  ReadCheckpointArray(in, &c.factors, dims);
+  in.read(reinterpret_cast<char *>(&c.num_steps), sizeof(int));
+  ReadCheckpointArray(in, &c.flags, dims);
+  ReadCheckpointArray(in, &c.sample_num, dims);
+  ReadCheckpointArray(in, &c.pos, dims);
+  ReadCheckpointArray(in, &c.dir, dims);
+  ReadCheckpointArray(in, &c.len, dims);
+  const size_t steps = static_cast<size_t>(std::max(c.num_steps, 0));
+  if (c.camera_pos.size() != 4 * n_pix || c.camera_dir.size() != 4 * n_pix || c.factors.size() != n_pix || c.flags.size() != n_pix
+      || c.sample_num.size() != n_pix || c.pos.size() != n_pix * steps * 4 || c.dir.size() != n_pix * steps * 4
+      || c.len.size() != n_pix * steps || static_cast<int>(frequencies.size()) != p.image_num_frequencies || c.num_steps > p.ray_max_steps)
+    throw Failure{BL_E_INPUT, "Geodesic checkpoint does not match this camera (resolution, frequencies or ray_max_steps)."};
+  for (size_t m = 0; m < n_pix; m++)
+    if (c.sample_num[m] < 0 || c.sample_num[m] > c.num_steps) throw Failure{BL_E_INPUT, "Geodesic checkpoint file is damaged."};
+  ctx->frequencies = frequencies;   // LoadGeodesics() replaces what InitializeCamera() would have computed
+  c.loaded = true;
+}
+
+template <typename T>
+void WriteCheckpointHeader(std::ofstream &out, int n1, int n2, int n3) {
+  const int dims[5] = {n1, n2, n3, 1, 1};
+  out.write(reinterpret_cast<const char *>(dims), sizeof dims);
 }
 
 }  // namespace
@@ -1080,13 +1143,20 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
       for (const bl_ctx::SlowSlice &slice : ctx->slow_slices)
         if (!slice.set) throw Failure{BL_E_STATE, "Slow light: time slices not set."};
     }
-    const bool need_time = (aux && ctx->aux_images.image_time) || slow;
+    // geodesic checkpoints (root level only, like the reference's): load replaces the geodesic kernel by the file's
+    // samples, save writes what the geodesic kernel produced in the reference's layout
+    const bool geo_load = p.checkpoint_geodesic_load && d->level == 0;
+    const bool geo_save = p.checkpoint_geodesic_save && d->level == 0;
+    if (geo_load && !ctx->checkpoint.loaded) LoadGeodesicCheckpoint(ctx);
+    const bool need_time = (aux && ctx->aux_images.image_time) || slow || geo_load || geo_save;
 
     // level pixel count check
     long long level_pixels = static_cast<long long>(p.camera_resolution) * p.camera_resolution;
     if (d->level > 0) level_pixels = static_cast<long long>(d->n_blocks) * p.adaptive_block_size * p.adaptive_block_size;
     if (d->pixel_map == nullptr && n_rays > level_pixels) throw Failure{BL_E_ARG, "n_rays exceeds the pixels of this level."};
 
+    if (geo_save && (d->pixel_map != nullptr || n_rays != level_pixels))
+      throw Failure{BL_E_ARG, "checkpoint_geodesic_save needs the whole root camera in one bl_render call."};
     const bool block_interp = simulation && ctx->grid_dev.block_interp != 0;
     // Tolerant tier: plain unpolarized images of a spherical Kerr-Schild simulation with thermal electrons in a curved
     // spacetime have the fast coefficient kernel; every other configuration is rendered in exact arithmetic whatever
@@ -1189,9 +1259,22 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
       if (d->camera_pos != nullptr) { ctx->d_camera_pos.Ensure(static_cast<size_t>(n_rays) * 4); cam_pos = ctx->d_camera_pos.ptr; }
       if (d->camera_dir != nullptr) { ctx->d_camera_dir.Ensure(static_cast<size_t>(n_rays) * 4); cam_dir = ctx->d_camera_dir.ptr; }
     }
-    if (ctx->polarized) {   // the camera tetrad projection needs every ray's initial position and momentum
+    if (ctx->polarized || geo_save) {   // the camera tetrad projection (and the checkpoint) need every ray's initial position and momentum
       if (cam_pos == nullptr) { ctx->d_camera_pos.Ensure(static_cast<size_t>(n_rays) * 4); cam_pos = ctx->d_camera_pos.ptr; }
       if (cam_dir == nullptr) { ctx->d_camera_dir.Ensure(static_cast<size_t>(n_rays) * 4); cam_dir = ctx->d_camera_dir.ptr; }
+    }
+    if (geo_load && (cam_pos != nullptr || cam_dir != nullptr)) {   // camera_pos / camera_dir come from the file as well
+      std::vector<double> rows(static_cast<size_t>(n_rays) * 4);
+      for (int which = 0; which < 2; which++) {
+        double *target = which == 0 ? cam_pos : cam_dir;
+        if (target == nullptr) continue;
+        const std::vector<double> &source = which == 0 ? ctx->checkpoint.camera_pos : ctx->checkpoint.camera_dir;
+        for (long long ray = 0; ray < n_rays; ray++) {
+          const size_t m = d->pixel_map != nullptr ? static_cast<size_t>(d->pixel_map[ray]) : static_cast<size_t>(ray);
+          for (int mu = 0; mu < 4; mu++) rows[4 * ray + mu] = source[4 * m + mu];
+        }
+        Check(hipMemcpy(target, rows.data(), rows.size() * sizeof(double), hipMemcpyHostToDevice), "checkpoint upload");
+      }
     }
     double *render_out = nullptr;
     bool fill_present = false;
@@ -1469,11 +1552,13 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
       sa.lds_table_bytes = ctx->lds_table_bytes;
       sa.undefined_edge = ctx->undefined_policy == BL_UNDEFINED_EDGE ? 1 : 0;
       sa.tolerant = (fast || tolerant_polarized) ? 1 : 0;
+      sa.samples_renormalised = geo_load ? 1 : 0;
     } else {
       BlFormulaDevice &fm = sa.formula;
       fm.r0 = p.formula_r0; fm.h = p.formula_h; fm.l0 = p.formula_l0; fm.q = p.formula_q; fm.nup = p.formula_nup;
       fm.cn0 = p.formula_cn0; fm.alpha = p.formula_alpha; fm.a = p.formula_a; fm.beta = p.formula_beta;
     }
+    sa.samples_renormalised = geo_load ? 1 : 0;
     ctx->d_shade_cold.Ensure(1);
     Check(hipMemcpyAsync(ctx->d_shade_cold.ptr, &cold, sizeof(BlShadeCold), hipMemcpyHostToDevice, stream), "shade parameter upload");
     sa.cold = ctx->d_shade_cold.ptr;
@@ -1558,6 +1643,12 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
     // so geodesic(c + 1) overlaps the shading of chunk c. The geodesic kernel holds one 328-register
     // wave per SIMD; a 128-register locate wave fits beside it and issues into the slots its dependent
     // fp64 chains leave idle, and the coefficient / transfer waves take over SIMDs as geodesic waves retire.
+    struct {   // geodesic checkpoint being assembled: samples of every pixel, far -> near, packed
+      std::vector<int32_t> sample_num;
+      std::vector<uint8_t> flags;
+      std::vector<double> factors, pos, dir, len;
+      std::vector<size_t> offset;
+    } save;
     hipEvent_t *ev = ctx->events.data();
     hipEvent_t ev_setup = ev[static_cast<size_t>(n_chunks) * kEventsPerChunk];
     Check(hipEventRecord(ev_setup, stream), "event");            // uploads above were queued on `stream`
@@ -1620,7 +1711,59 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
       if (c >= n_slots) Check(hipStreamWaitEvent(stream_geo, (e - n_slots * kEventsPerChunk)[6], 0), "stream wait");
       Check(hipMemsetAsync(sl.d_counters.ptr, 0, n_counters * sizeof(unsigned long long), stream_geo), "counter reset");
       Check(hipEventRecord(e[0], stream_geo), "event");
-      Check(bl_launch_geodesic(&ta, p.ray_integrator, std::min(geo_grid, (rays + 63) / 64), stream_geo), "geodesic kernel launch");
+      if (geo_load) {
+        // LoadGeodesics(): the chunk's sample records come from the file instead of the geodesic kernel. The file holds
+        // them far -> near (ReverseGeodesics) with the renormalised momentum; records are near -> far, so sample n of a ray
+        // is entry num - 1 - n, and len = -sample_len.
+        Check(hipStreamSynchronize(stream), "kernel execution");       // the scratch set may still be in use
+        Check(hipStreamSynchronize(stream_geo), "kernel execution");
+        const bl_ctx::Checkpoint &ck = ctx->checkpoint;
+        const size_t steps = static_cast<size_t>(ck.num_steps);
+        std::vector<BlSampleHot> hot;
+        std::vector<BlSampleCold> cold;
+        std::vector<double> sample_t, ray_kt(rays), ray_factor(rays);
+        std::vector<int> ray_num(rays);
+        std::vector<unsigned char> ray_flags(rays);
+        std::vector<long long> ray_out(rays);
+        for (int q = 0; q < rays; q++) {
+          const long long ray = begin + q;
+          const size_t m = d->pixel_map != nullptr ? static_cast<size_t>(d->pixel_map[ray]) : static_cast<size_t>(ray);
+          if (m >= ck.sample_num.size()) throw Failure{BL_E_ARG, "pixel_map names a pixel the geodesic checkpoint does not hold."};
+          const int num = ck.sample_num[m];
+          ray_kt[q] = ck.camera_dir[4 * m];
+          ray_factor[q] = ck.factors[m];
+          ray_num[q] = num;
+          ray_flags[q] = ck.flags[m];
+          ray_out[q] = ray;
+          for (int n = 0; n < num; n++) {
+            const size_t at = m * steps + static_cast<size_t>(num - 1 - n);
+            BlSampleHot h;
+            h.x = ck.pos[4 * at + 1]; h.y = ck.pos[4 * at + 2]; h.z = ck.pos[4 * at + 3];
+            h.ray = static_cast<uint32_t>(q);
+            h.n = static_cast<uint32_t>(n);
+            BlSampleCold c;
+            c.kx = ck.dir[4 * at + 1]; c.ky = ck.dir[4 * at + 2]; c.kz = ck.dir[4 * at + 3];
+            c.len = -ck.len[at];
+            hot.push_back(h);
+            cold.push_back(c);
+            sample_t.push_back(ck.pos[4 * at]);
+          }
+        }
+        const unsigned long long n_loaded = hot.size();
+        if (n_loaded > 0) {
+          Check(hipMemcpy(sl.d_records_hot.ptr, hot.data(), n_loaded * sizeof(BlSampleHot), hipMemcpyHostToDevice), "checkpoint upload");
+          Check(hipMemcpy(sl.d_records_cold.ptr, cold.data(), n_loaded * sizeof(BlSampleCold), hipMemcpyHostToDevice), "checkpoint upload");
+          Check(hipMemcpy(sl.d_sample_t.ptr, sample_t.data(), n_loaded * sizeof(double), hipMemcpyHostToDevice), "checkpoint upload");
+        }
+        Check(hipMemcpy(sl.d_ray_kt.ptr, ray_kt.data(), rays * sizeof(double), hipMemcpyHostToDevice), "checkpoint upload");
+        Check(hipMemcpy(sl.d_ray_factor.ptr, ray_factor.data(), rays * sizeof(double), hipMemcpyHostToDevice), "checkpoint upload");
+        Check(hipMemcpy(sl.d_ray_sample_num.ptr, ray_num.data(), rays * sizeof(int), hipMemcpyHostToDevice), "checkpoint upload");
+        Check(hipMemcpy(sl.d_ray_flags.ptr, ray_flags.data(), rays, hipMemcpyHostToDevice), "checkpoint upload");
+        Check(hipMemcpy(sl.d_ray_out_index.ptr, ray_out.data(), rays * sizeof(long long), hipMemcpyHostToDevice), "checkpoint upload");
+        Check(hipMemcpy(sl.d_counters.ptr + BL_CNT_RECORDS, &n_loaded, sizeof n_loaded, hipMemcpyHostToDevice), "checkpoint upload");
+      } else {
+        Check(bl_launch_geodesic(&ta, p.ray_integrator, std::min(geo_grid, (rays + 63) / 64), stream_geo), "geodesic kernel launch");
+      }
       Check(hipEventRecord(e[1], stream_geo), "event");
       // ---- shading stream
       Check(hipStreamWaitEvent(stream, e[1], 0), "stream wait");
@@ -1640,10 +1783,111 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
       Check(hipMemcpyAsync(ctx->host_counters + static_cast<size_t>(c) * n_counters, sl.d_counters.ptr,
                            n_counters * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream), "counter download");
       Check(hipEventRecord(e[6], stream), "event");
+      if (geo_save) {
+        // SaveGeodesics(): bring this chunk's records back while its scratch set still holds them
+        Check(hipStreamSynchronize(stream_geo), "kernel execution");
+        Check(hipStreamSynchronize(stream), "kernel execution");
+        unsigned long long n_written = 0;
+        Check(hipMemcpy(&n_written, sl.d_counters.ptr + BL_CNT_RECORDS, sizeof n_written, hipMemcpyDeviceToHost), "checkpoint download");
+        std::vector<BlSampleHot> hot(n_written);
+        std::vector<BlSampleCold> cold(n_written);
+        std::vector<double> sample_t(n_written), ray_kt(rays), ray_factor(rays);
+        std::vector<int> ray_num(rays);
+        std::vector<unsigned char> ray_flags(rays);
+        std::vector<long long> ray_out(rays);
+        if (n_written > 0) {
+          Check(hipMemcpy(hot.data(), sl.d_records_hot.ptr, n_written * sizeof(BlSampleHot), hipMemcpyDeviceToHost), "checkpoint download");
+          Check(hipMemcpy(cold.data(), sl.d_records_cold.ptr, n_written * sizeof(BlSampleCold), hipMemcpyDeviceToHost), "checkpoint download");
+          Check(hipMemcpy(sample_t.data(), sl.d_sample_t.ptr, n_written * sizeof(double), hipMemcpyDeviceToHost), "checkpoint download");
+        }
+        Check(hipMemcpy(ray_kt.data(), sl.d_ray_kt.ptr, rays * sizeof(double), hipMemcpyDeviceToHost), "checkpoint download");
+        Check(hipMemcpy(ray_factor.data(), sl.d_ray_factor.ptr, rays * sizeof(double), hipMemcpyDeviceToHost), "checkpoint download");
+        Check(hipMemcpy(ray_num.data(), sl.d_ray_sample_num.ptr, rays * sizeof(int), hipMemcpyDeviceToHost), "checkpoint download");
+        Check(hipMemcpy(ray_flags.data(), sl.d_ray_flags.ptr, rays, hipMemcpyDeviceToHost), "checkpoint download");
+        Check(hipMemcpy(ray_out.data(), sl.d_ray_out_index.ptr, rays * sizeof(long long), hipMemcpyDeviceToHost), "checkpoint download");
+        if (save.sample_num.empty()) {
+          save.sample_num.assign(n_rays, 0);
+          save.flags.assign(n_rays, 0);
+          save.factors.assign(n_rays, 0.0);
+          save.offset.assign(n_rays, 0);
+        }
+        std::vector<size_t> slot_offset(rays);
+        for (int q = 0; q < rays; q++) {
+          const size_t m = static_cast<size_t>(ray_out[q]);
+          save.sample_num[m] = ray_num[q];
+          save.flags[m] = ray_flags[q];
+          save.factors[m] = ray_factor[q];
+          save.offset[m] = save.len.size();
+          slot_offset[q] = save.len.size();
+          save.pos.resize(save.pos.size() + 4 * static_cast<size_t>(ray_num[q]));
+          save.dir.resize(save.dir.size() + 4 * static_cast<size_t>(ray_num[q]));
+          save.len.resize(save.len.size() + static_cast<size_t>(ray_num[q]));
+        }
+        for (unsigned long long r = 0; r < n_written; r++) {
+          const BlSampleHot &h = hot[r];
+          if (h.ray == BL_DEAD_RAY) continue;
+          const int num = ray_num[h.ray];
+          if (static_cast<int>(h.n) >= num) continue;
+          const BlSampleCold &c = cold[r];
+          // ReverseGeodesics (geodesics.cpp:820-842) behind the per-sample renormalisation (:352-371)
+          const size_t at = slot_offset[h.ray] + static_cast<size_t>(num - 1 - static_cast<int>(h.n));
+          const double kt = ray_kt[h.ray];
+          const double factor = bl_renormalization_factor(ctx->st, h.x, h.y, h.z, kt, c.kx, c.ky, c.kz);
+          save.pos[4 * at] = sample_t[r]; save.pos[4 * at + 1] = h.x; save.pos[4 * at + 2] = h.y; save.pos[4 * at + 3] = h.z;
+          save.dir[4 * at] = kt; save.dir[4 * at + 1] = c.kx * factor; save.dir[4 * at + 2] = c.ky * factor; save.dir[4 * at + 3] = c.kz * factor;
+          save.len[at] = -c.len;
+        }
+      }
     }
     Check(hipStreamSynchronize(stream_geo), "kernel execution");
     Check(hipStreamSynchronize(stream), "kernel execution");
 
+    if (geo_save) {   // SaveGeodesics() (geodesic_checkpoint.cpp:28-59)
+      std::vector<double> camera_pos(static_cast<size_t>(n_rays) * 4), camera_dir(static_cast<size_t>(n_rays) * 4);
+      Check(hipMemcpy(camera_pos.data(), cam_pos, camera_pos.size() * sizeof(double), hipMemcpyDeviceToHost), "checkpoint download");
+      Check(hipMemcpy(camera_dir.data(), cam_dir, camera_dir.size() * sizeof(double), hipMemcpyDeviceToHost), "checkpoint download");
+      std::ofstream out(p.checkpoint_geodesic_file.s, std::ios_base::out | std::ios_base::binary);
+      if (!out.is_open()) throw Failure{BL_E_INPUT, "Could not open geodesic checkpoint file."};
+      const bl_camera_frame &f = ctx->frame;
+      const double *vectors[7] = {f.cam_x, f.u_con, f.u_cov, f.norm_con, f.norm_con_c, f.hor_con_c, f.vert_con_c};
+      for (const double *v : vectors) out.write(reinterpret_cast<const char *>(v), 4 * sizeof(double));
+      const int n_pix = static_cast<int>(n_rays);
+      int num_steps = 0;
+      for (int32_t num : save.sample_num) num_steps = std::max(num_steps, static_cast<int>(num));
+      WriteCheckpointHeader<double>(out, 4, n_pix, 1);
+      out.write(reinterpret_cast<const char *>(camera_pos.data()), static_cast<std::streamsize>(camera_pos.size() * sizeof(double)));
+      WriteCheckpointHeader<double>(out, 4, n_pix, 1);
+      out.write(reinterpret_cast<const char *>(camera_dir.data()), static_cast<std::streamsize>(camera_dir.size() * sizeof(double)));
+      WriteCheckpointHeader<double>(out, n_nu, 1, 1);
+      out.write(reinterpret_cast<const char *>(ctx->frequencies.data()), static_cast<std::streamsize>(n_nu * sizeof(double)));
+      WriteCheckpointHeader<double>(out, n_pix, 1, 1);
+      out.write(reinterpret_cast<const char *>(save.factors.data()), static_cast<std::streamsize>(save.factors.size() * sizeof(double)));
+      out.write(reinterpret_cast<const char *>(&num_steps), sizeof(int));
+      WriteCheckpointHeader<uint8_t>(out, n_pix, 1, 1);
+      out.write(reinterpret_cast<const char *>(save.flags.data()), static_cast<std::streamsize>(save.flags.size()));
+      WriteCheckpointHeader<int32_t>(out, n_pix, 1, 1);
+      out.write(reinterpret_cast<const char *>(save.sample_num.data()), static_cast<std::streamsize>(save.sample_num.size() * sizeof(int32_t)));
+      // sample_pos, sample_dir (n_pix, n_steps, 4) and sample_len (n_pix, n_steps): a pixel's samples, then zeros (the
+      // reference leaves the tail of sample_pos / sample_dir as allocated; nothing reads it)
+      std::vector<double> row(static_cast<size_t>(num_steps) * 4);
+      for (int which = 0; which < 2; which++) {
+        const std::vector<double> &source = which == 0 ? save.pos : save.dir;
+        WriteCheckpointHeader<double>(out, 4, num_steps, n_pix);
+        for (int m = 0; m < n_pix; m++) {
+          std::fill(row.begin(), row.end(), 0.0);
+          std::copy(source.begin() + 4 * save.offset[m], source.begin() + 4 * (save.offset[m] + save.sample_num[m]), row.begin());
+          out.write(reinterpret_cast<const char *>(row.data()), static_cast<std::streamsize>(row.size() * sizeof(double)));
+        }
+      }
+      WriteCheckpointHeader<double>(out, num_steps, n_pix, 1);
+      row.resize(num_steps);
+      for (int m = 0; m < n_pix; m++) {
+        std::fill(row.begin(), row.end(), 0.0);
+        std::copy(save.len.begin() + save.offset[m], save.len.begin() + save.offset[m] + save.sample_num[m], row.begin());
+        out.write(reinterpret_cast<const char *>(row.data()), static_cast<std::streamsize>(row.size() * sizeof(double)));
+      }
+      if (!out) throw Failure{BL_E_INPUT, "Could not write geodesic checkpoint file."};
+    }
     float ms_geo = 0.0f, ms_locate = 0.0f, ms_shade = 0.0f, ms_transfer = 0.0f, ms_wall = 0.0f;
     unsigned long long total_samples = 0, total_flagged = 0, total_records = 0, total_gathers = 0, total_redo = 0, total_undefined = 0, max_num = 0;
     for (int c = 0; c < n_chunks; c++) {
@@ -1696,7 +1940,7 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
     st.max_sample_num = static_cast<int32_t>(max_num);
     const double bytes_per_gather = (simulation && !p.simulation_interp) ? 32.0 : 256.0;
     st.algorithmic_bytes = bytes_per_gather * static_cast<double>(total_gathers) + 13.0 * static_cast<double>(n_rays);
-    st.ms_geodesic = ms_geo;
+    st.ms_geodesic = geo_load ? 0.0f : ms_geo;   // nothing was integrated
     st.ms_locate = ms_locate;
     st.ms_shade = ms_shade;
     st.ms_transfer = ms_transfer;

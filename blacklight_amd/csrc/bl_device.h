@@ -277,6 +277,7 @@ struct BlShadeArgs {
   BlLocated *located;         // [record capacity], simulation mode
   unsigned long long *located_tag;   // [record capacity]: cell | status << 32 | time slice << 40
   int lds_table_bytes;        // size of the coordinate tables the locate kernel stages in LDS; 0: searched in HBM
+  int samples_renormalised;   // records come from a geodesic checkpoint: momenta as stored, no renormalisation per sample
   int tolerant;               // bl_set_arithmetic(BL_ARITH_TOLERANT): kernels that have a tolerant instantiation use it
   int undefined_edge;         // bl_set_undefined_policy(BL_UNDEFINED_EDGE): samples where the reference reads past its arrays use the edge
   const unsigned long long *counters_in;

@@ -1833,8 +1833,8 @@ __global__ void __launch_bounds__(256, 2) bl_shade_kernel(const BlShadeArgs P) {
       status = skip ? kSampleCut : kSampleFormula;
       for (int v = 0; v < 8; v++) pr[v] = 0.0f;
     }
-    {   // per-sample renormalisation of the stored momentum (geodesics.cpp:352-371)
-      double gcon[4][4];
+    if (!P.samples_renormalised) {   // per-sample renormalisation of the stored momentum (geodesics.cpp:352-371); samples
+      double gcon[4][4];             // loaded from a geodesic checkpoint carry the renormalised momentum already
       if (!kSksCurved && st.ray_flat)
         bl_minkowski(gcon);
       else
@@ -2199,7 +2199,8 @@ __device__ __forceinline__ bool fast_shade_sample(const BlShadeArgs &P, const do
       const double tb = 2.0 * kt * f * lk;                 // 2 g^0i k_0 k_i
       const double tc = -(1.0 + f) * kt * kt;              // g^00 k_0 k_0
       const double td = bl_sqrt_g(tb * tb - 4.0 * ta * tc);
-      const double factor = tb < 0.0 ? (td - tb) * fastmath::rcp(2.0 * ta) : -2.0 * tc * fastmath::rcp(tb + td);
+      double factor = tb < 0.0 ? (td - tb) * fastmath::rcp(2.0 * ta) : -2.0 * tc * fastmath::rcp(tb + td);
+      if (P.samples_renormalised) factor = 1.0;   // geodesic checkpoint: done before the samples were saved
       kx *= factor;
       ky *= factor;
       kz *= factor;

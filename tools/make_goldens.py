@@ -807,6 +807,51 @@ def make_fmks_fixtures():
     np.savez_compressed(os.path.join(out_dir, "expected_fmks.npz"), **expected)
 
 
+# Geodesic checkpoints (geodesic_checkpoint.cpp): the file the reference writes with checkpoint_geodesic_save (kept whole as a
+# fixture: it is what checkpoint_geodesic_load has to read; the tails of sample_pos / sample_dir beyond a pixel's samples are
+# whatever the reference's allocator held) and its image, for a simulation and a formula case on 8 x 8 cameras.
+CHECKPOINT_CASES = {
+    "sim": (SIM_BASE, dict(camera_resolution=8, ray_step=0.05, simulation_a=0.5, image_tau="true", image_time="true",
+                           camera_type="pinhole", camera_r=40.0, camera_width=18.0, image_normalization="camera", camera_urn=-0.04), SMALL_MOCK),
+    "formula": (FORMULA_BASE, dict(camera_resolution=8, ray_step=0.1, ray_max_steps=600, camera_r=100.0), None),
+}
+
+
+def make_checkpoint_fixtures():
+    out_dir = os.path.join(OUT, "reader")
+    expected = {}
+    for name, (base, overrides, mock) in CHECKPOINT_CASES.items():
+        workdir = os.path.join(WORK, "checkpoint_" + name)
+        for sub in (out_dir, os.path.join(workdir, "data"), os.path.join(workdir, "output")):
+            os.makedirs(sub, exist_ok=True)
+        params = dict(base)
+        params.update(overrides)
+        params.update(checkpoint_geodesic_save="true", checkpoint_geodesic_load="false", checkpoint_geodesic_file="data/geo.dat")
+        if mock is not None:
+            args = [sys.executable, "-W", "ignore", MOCK_SCRIPT, os.path.join(workdir, "data", "mock.athdf")]
+            for key, value in mock.items():
+                args += [f"--{key}", str(value)]
+            subprocess.run(args, check=True)
+            expected[f"{name}_mock_args"] = json.dumps(mock)
+        write_input(os.path.join(workdir, "case.input"), params)
+        expected[f"{name}_warnings"] = run_reference(workdir, "case.input", True)     # pinned math library (tier B)
+        npz = np.load(os.path.join(workdir, "output", "out.npz"))
+        for key in npz.files:
+            expected[f"{name}_npz_{key}"] = npz[key]
+        test_params = {k: v for k, v in params.items() if k not in ("checkpoint_geodesic_save", "checkpoint_geodesic_load", "checkpoint_geodesic_file")}
+        expected[f"{name}_params"] = json.dumps(test_params)
+        with open(os.path.join(workdir, "data", "geo.dat"), "rb") as src, open(os.path.join(out_dir, f"geodesic_{name}.ckpt"), "wb") as dst:
+            dst.write(src.read())
+        # the reference reading its own file back gives the same image
+        params.update(checkpoint_geodesic_save="false", checkpoint_geodesic_load="true")
+        write_input(os.path.join(workdir, "load.input"), params)
+        run_reference(workdir, "load.input", True)
+        again = np.load(os.path.join(workdir, "output", "out.npz"))
+        assert all(np.array_equal(again[k], npz[k], equal_nan=True) for k in npz.files)
+        print("checkpoint", name, os.path.getsize(os.path.join(out_dir, f"geodesic_{name}.ckpt")), "bytes")
+    np.savez_compressed(os.path.join(out_dir, "expected_checkpoint.npz"), **expected)
+
+
 # harm3d dumps: the same, --format harm3d (one line of text, then float32 records)
 def make_harm3d_fixtures():
     import h5py
@@ -957,6 +1002,8 @@ if __name__ == "__main__":
             make_iharm3d_fixtures()
         elif case_name == "fmks":
             make_fmks_fixtures()
+        elif case_name == "checkpoint":
+            make_checkpoint_fixtures()
         elif case_name == "harm3d":
             make_harm3d_fixtures()
         elif case_name == "slowcli":
