@@ -335,7 +335,13 @@ void ValidateRadiation(bl_ctx *ctx) {
     if (p.checkpoint_sample_save && p.checkpoint_sample_load)
       throw Failure{BL_E_INPUT, "Cannot both save and load a sample checkpoint."};
     if (p.checkpoint_sample_save || p.checkpoint_sample_load)
-      throw Failure{BL_E_UNSUPPORTED, "Sample checkpoints are outside the scope of the MI355X hot path."};
+      // The reference cannot read these files itself: LoadSampling() (sample_checkpoint.cpp:49-63) restores sample_inds,
+      // sample_fracs, sample_nan and sample_fallback but not sample_cut, which only CalculateSimulationSampling() allocates
+      // (simulation_sampling.cpp:155) and SampleSimulation() reads for every sample (:691) - the reference binary built
+      // from /root/reference ends in a segmentation fault on checkpoint_sample_load = true. A file nobody can read back has
+      // no defined result to match, so neither direction is offered; geodesic checkpoints are (LoadGeodesicCheckpoint).
+      throw Failure{BL_E_UNSUPPORTED, "Sample checkpoints are not offered: the reference cannot load them (its LoadSampling() "
+                                      "leaves sample_cut unallocated); use geodesic checkpoints."};
     Require(p, {BL_P_simulation_format, BL_P_simulation_coord, BL_P_simulation_m_msun, BL_P_simulation_rho_cgs,
                 BL_P_simulation_interp},
             kRadMissing);

@@ -101,7 +101,7 @@ def test_context_validation_messages(bl):
         q = dict(params)
         for key, value in changes.items():
             if value is None:
-                q.pop(key)
+                q.pop(key, None)
             else:
                 q[key] = value
         with pytest.raises(bl.BlacklightError) as err:
@@ -115,8 +115,13 @@ def test_context_validation_messages(bl):
     assert failing(image_num_frequencies=0) == "Error: Must have positive image_num_frequencies."
     assert failing(checkpoint_geodesic_save="true", checkpoint_geodesic_load="true") == \
         "Error: Cannot both save and load a geodesic checkpoint."
+    assert failing(checkpoint_geodesic_save="true", checkpoint_geodesic_file=None) == \
+        "Error: GeodesicIntegrator unable to find all needed values in input file."
     assert failing(camera_r=None) == "Error: GeodesicIntegrator unable to find all needed values in input file."
     assert failing(plasma_mu=None) == "Error: RadiationIntegrator unable to find all needed values in input file."
+    assert failing(checkpoint_sample_save="true", checkpoint_sample_load="true") == "Error: Cannot both save and load a sample checkpoint."
+    # sample checkpoints: the reference segfaults reading its own file (sample_cut is never restored), so there is nothing to match
+    assert "the reference cannot load them" in failing(checkpoint_sample_save="true", checkpoint_sample_file="s.dat")
     assert failing(image_light="false") == "Error: No image or rendering selected."
     assert failing(adaptive_max_level=1, adaptive_block_size=5) == \
         "Error: Must have adaptive_block_size divide camera_resolution."
