@@ -4,7 +4,9 @@
 // (src/output_writer/output_writer.cpp:169-316, numpy_format.cpp, zip_format.cpp, raw_format.cpp).
 // The .npy / ZIP byte layout is the reference's (NumPy .npy v1.0 with a 128-byte header, ZIP 2.0
 // stored entries with CRC-32), so its plotting scripts read the files unchanged.
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -111,10 +113,10 @@ bool EvaluateBlock(const bl_params &p, const double *block, int bs) {
 // ------------------------------------------------------------------ .npy / ZIP
 using Bytes = std::vector<uint8_t>;
 
-// NumPy .npy v1.0 with the reference's fixed 128-byte header (numpy_format.cpp:604-664)
-Bytes MakeNpy(const char *descr, const std::vector<int> &shape, const void *data, size_t data_bytes) {
+// NumPy .npy v1.0 with the reference's fixed 128-byte header (numpy_format.cpp:604-664); empty if the shape does not fit
+Bytes MakeNpyHeader(const char *descr, const std::vector<int> &shape) {
   const size_t header_length = 128;
-  Bytes out(header_length + data_bytes);
+  Bytes out(header_length);
   std::memcpy(out.data(), "\x93NUMPY\x01\x00", 8);
   uint16_t header_len = static_cast<uint16_t>(header_length - 10);
   std::memcpy(out.data() + 8, &header_len, 2);
@@ -129,31 +131,50 @@ Bytes MakeNpy(const char *descr, const std::vector<int> &shape, const void *data
   std::memset(out.data() + 10, ' ', header_length - 11);
   std::memcpy(out.data() + 10, dict.data(), dict.size());
   out[header_length - 1] = '\n';
-  if (data_bytes > 0) std::memcpy(out.data() + header_length, data, data_bytes);
   return out;
 }
 
-// Standard CRC-32 (what zip_format.cpp:284-360 computes with its bit-reversed tables)
-uint32_t Crc32(const uint8_t *data, size_t n) {
-  static uint32_t table[256];
+// One array on its way into a file: the .npy header and the data where they lie (the caller's image rows) or, where the
+// reference reorders them (Stokes components, cell averages) or they are locals, a copy. Nothing is assembled in memory:
+// a 4096^2 x 64-frequency I_nu record (8.6 GB) is checksummed and written straight from the image.
+struct NpyRecord {
+  std::string name;
+  Bytes head;
+  const uint8_t *data = nullptr;
+  size_t data_bytes = 0;
+  Bytes owned;
+  size_t size() const { return head.size() + data_bytes; }
+};
+
+// Standard CRC-32 (what zip_format.cpp:284-360 computes with its bit-reversed tables), eight bytes per step
+uint32_t Crc32Update(uint32_t crc, const uint8_t *data, size_t n) {
+  static uint32_t table[8][256];
   static bool ready = false;
   if (!ready) {
     for (uint32_t i = 0; i < 256; i++) {
       uint32_t c = i;
       for (int k = 0; k < 8; k++) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
-      table[i] = c;
+      table[0][i] = c;
     }
+    for (uint32_t i = 0; i < 256; i++)
+      for (int t = 1; t < 8; t++) table[t][i] = table[0][table[t - 1][i] & 0xFFu] ^ (table[t - 1][i] >> 8);
     ready = true;
   }
-  uint32_t crc = 0xFFFFFFFFu;
-  for (size_t i = 0; i < n; i++) crc = table[(crc ^ data[i]) & 0xFFu] ^ (crc >> 8);
+  crc ^= 0xFFFFFFFFu;
+  size_t i = 0;
+  for (; i + 8 <= n; i += 8) {
+    uint32_t lo, hi;
+    std::memcpy(&lo, data + i, 4);
+    std::memcpy(&hi, data + i + 4, 4);
+    lo ^= crc;
+    crc = table[7][lo & 0xFFu] ^ table[6][(lo >> 8) & 0xFFu] ^ table[5][(lo >> 16) & 0xFFu] ^ table[4][lo >> 24]
+        ^ table[3][hi & 0xFFu] ^ table[2][(hi >> 8) & 0xFFu] ^ table[1][(hi >> 16) & 0xFFu] ^ table[0][hi >> 24];
+  }
+  for (; i < n; i++) crc = table[0][(crc ^ data[i]) & 0xFFu] ^ (crc >> 8);
   return crc ^ 0xFFFFFFFFu;
 }
 
-struct ZipEntry {
-  Bytes local_header;
-  Bytes data;
-};
+uint32_t Crc32(const NpyRecord &r) { return Crc32Update(Crc32Update(0, r.head.data(), r.head.size()), r.data, r.data_bytes); }
 
 template <typename T>
 void Put(Bytes *b, T v) {
@@ -162,12 +183,14 @@ void Put(Bytes *b, T v) {
 }
 
 // zip_format.cpp:26-110
-bool MakeLocalHeader(const std::string &name, const Bytes &record, Bytes *header) {
-  if (record.size() > UINT32_MAX) return false;
+// zip64: the record carries its sizes in a ZIP64 extended-information field (APPNOTE 4.5.3) - beyond the reference, which
+// stops at 4 GiB (numpy_format.cpp:44-45); used only where 32 bits do not hold the size (or when forced, for the tests)
+bool MakeLocalHeader(const std::string &name, const NpyRecord &record, bool zip64, Bytes *header) {
+  if (record.size() > UINT32_MAX && !zip64) return false;
   std::string full = name + ".npy";
   header->clear();
   header->insert(header->end(), {0x50, 0x4b, 0x03, 0x04});
-  Put<uint8_t>(header, 20);   // version needed 2.0
+  Put<uint8_t>(header, zip64 ? 45 : 20);   // version needed 2.0 (4.5 with ZIP64 fields)
   Put<uint8_t>(header, 0);
   Put<uint16_t>(header, 0);   // flags
   Put<uint16_t>(header, 0);   // stored
@@ -181,27 +204,47 @@ bool MakeLocalHeader(const std::string &name, const Bytes &record, Bytes *header
   date |= static_cast<uint16_t>(lt->tm_mday & 0x1F);
   Put<uint16_t>(header, time);
   Put<uint16_t>(header, date);
-  Put<uint32_t>(header, Crc32(record.data(), record.size()));
-  Put<uint32_t>(header, static_cast<uint32_t>(record.size()));
-  Put<uint32_t>(header, static_cast<uint32_t>(record.size()));
+  Put<uint32_t>(header, Crc32(record));
+  Put<uint32_t>(header, zip64 ? 0xFFFFFFFFu : static_cast<uint32_t>(record.size()));
+  Put<uint32_t>(header, zip64 ? 0xFFFFFFFFu : static_cast<uint32_t>(record.size()));
   Put<uint16_t>(header, static_cast<uint16_t>(full.size()));
-  Put<uint16_t>(header, 0);
+  Put<uint16_t>(header, zip64 ? 20 : 0);
   header->insert(header->end(), full.begin(), full.end());
+  if (zip64) {
+    Put<uint16_t>(header, 0x0001);
+    Put<uint16_t>(header, 16);
+    Put<uint64_t>(header, record.size());   // uncompressed, then compressed
+    Put<uint64_t>(header, record.size());
+  }
   return true;
 }
 
 // zip_format.cpp:122-190
-Bytes MakeCentralHeader(const Bytes &local, size_t offset) {
+Bytes MakeCentralHeader(const Bytes &local, size_t offset, bool zip64, size_t record_size) {
   Bytes out = {0x50, 0x4b, 0x01, 0x02};
-  Put<uint8_t>(&out, 20);   // version made by 2.0
+  Put<uint8_t>(&out, zip64 ? 45 : 20);   // version made by 2.0 (4.5 with ZIP64 fields)
   Put<uint8_t>(&out, 3);    // unix
-  out.insert(out.end(), local.begin() + 4, local.begin() + 30);
+  if (!zip64) {
+    out.insert(out.end(), local.begin() + 4, local.begin() + 30);
+  } else {
+    out.insert(out.end(), local.begin() + 4, local.begin() + 28);   // ... up to the name length
+    Put<uint16_t>(&out, 28);                                           // extra: sizes and the offset of the local header
+  }
   Put<uint16_t>(&out, 0);   // comment length
   Put<uint16_t>(&out, 0);   // disk number
   Put<uint16_t>(&out, 0);   // internal attributes
   Put<uint32_t>(&out, 0x81800000u);
-  Put<uint32_t>(&out, static_cast<uint32_t>(offset));
-  out.insert(out.end(), local.begin() + 30, local.end());
+  Put<uint32_t>(&out, zip64 ? 0xFFFFFFFFu : static_cast<uint32_t>(offset));
+  uint16_t name_length;
+  std::memcpy(&name_length, local.data() + 26, 2);
+  out.insert(out.end(), local.begin() + 30, local.begin() + 30 + name_length);
+  if (zip64) {
+    Put<uint16_t>(&out, 0x0001);
+    Put<uint16_t>(&out, 24);
+    Put<uint64_t>(&out, record_size);
+    Put<uint64_t>(&out, record_size);
+    Put<uint64_t>(&out, offset);
+  }
   return out;
 }
 
@@ -333,31 +376,41 @@ int bl_write_output(bl_ctx *ctx, const char *path_override, const bl_output_desc
     return BL_OK;
   }
   if (p.output_format == BL_OUTPUT_NPY) {   // numpy_format.cpp:19-32: image[0] as (n_q, res, res)
-    Bytes npy = MakeNpy("<f8", {n_q, res, res}, image0, sizeof(double) * n_q * n_pix);
-    stream.write(reinterpret_cast<const char *>(npy.data()), static_cast<std::streamsize>(npy.size()));
+    Bytes head = MakeNpyHeader("<f8", {n_q, res, res});
+    stream.write(reinterpret_cast<const char *>(head.data()), static_cast<std::streamsize>(head.size()));
+    stream.write(reinterpret_cast<const char *>(image0), static_cast<std::streamsize>(sizeof(double) * n_q * n_pix));
     return BL_OK;
   }
 
   // npz (numpy_format.cpp:46-584), records in the reference's order
-  std::vector<std::pair<std::string, Bytes>> records;
-  auto add = [&](const std::string &name, Bytes bytes) { records.emplace_back(name, std::move(bytes)); };
+  std::vector<NpyRecord> records;
+  // copy: the data are a local or a reordered temporary; otherwise they stay where the caller holds them
+  auto add = [&](const std::string &name, const char *descr, const std::vector<int> &shape, const void *data, size_t bytes, bool copy) {
+    NpyRecord r;
+    r.name = name;
+    r.head = MakeNpyHeader(descr, shape);
+    r.data_bytes = bytes;
+    if (copy) r.owned.assign(static_cast<const uint8_t *>(data), static_cast<const uint8_t *>(data) + bytes);
+    else r.data = static_cast<const uint8_t *>(data);
+    records.push_back(std::move(r));
+  };
   double mass_msun = frame.mass_msun;
   double width = p.camera_width;
   int32_t num_levels = d->adaptive_num_levels;
-  add("mass_msun", MakeNpy("<f8", {1}, &mass_msun, 8));
-  add("width", MakeNpy("<f8", {1}, &width, 8));
-  add("frequency", MakeNpy("<f8", {n_nu}, frequencies, sizeof(double) * n_nu));
-  add("adaptive_num_levels", MakeNpy("<i4", {1}, &num_levels, 4));
+  add("mass_msun", "<f8", {1}, &mass_msun, 8, true);
+  add("width", "<f8", {1}, &width, 8, true);
+  add("frequency", "<f8", {n_nu}, frequencies, sizeof(double) * n_nu, true);
+  add("adaptive_num_levels", "<i4", {1}, &num_levels, 4, true);
   if (p.adaptive_max_level > 0) {
     std::vector<int32_t> counts(num_levels + 1);
     counts[0] = (res / p.adaptive_block_size) * (res / p.adaptive_block_size);
     for (int l = 1; l <= num_levels; l++) counts[l] = d->level[l].n_blocks;
-    add("adaptive_num_blocks", MakeNpy("<i4", {num_levels + 1}, counts.data(), 4 * counts.size()));
+    add("adaptive_num_blocks", "<i4", {num_levels + 1}, counts.data(), 4 * counts.size(), true);
   }
   const char *camera_name = p.camera_type == BL_CAMERA_PLANE ? "positions" : "directions";
   if (p.output_camera) {
     if (d->level[0].camera == nullptr) return bl_internal_fail(ctx, BL_E_ARG, "output_camera needs camera data.");
-    add(camera_name, MakeNpy("<f8", {res, res, 4}, d->level[0].camera, sizeof(double) * n_pix * 4));
+    add(camera_name, "<f8", {res, res, 4}, d->level[0].camera, sizeof(double) * n_pix * 4, false);
   }
   // Stokes rows (numpy_format.cpp:128-165): row (l * stride + a) of the image -> record a, slice l
   const bool polarized = p.model_type == BL_MODEL_SIMULATION && p.image_light && p.has[BL_P_image_polarization] && p.image_polarization;
@@ -368,12 +421,16 @@ int bl_write_output(bl_ctx *ctx, const char *path_override, const bl_output_desc
                         const std::string &suffix) {
     std::vector<int> shape = pixel_shape;
     if (n_nu > 1) shape.insert(shape.begin(), n_nu);
+    if (stokes_stride == 1) {   // unpolarized: the rows are the record
+      add(prefix + kStokesNames[0] + suffix, "<f8", shape, image, sizeof(double) * n_nu * pixels, false);
+      return;
+    }
     for (int a = 0; a < stokes_stride; a++) {
       stokes.resize(static_cast<size_t>(n_nu) * pixels);
       for (int l = 0; l < n_nu; l++)
         std::memcpy(stokes.data() + static_cast<size_t>(l) * pixels, image + static_cast<size_t>(l * stokes_stride + a) * pixels,
                     sizeof(double) * pixels);
-      add(prefix + kStokesNames[a] + suffix, MakeNpy("<f8", shape, stokes.data(), sizeof(double) * n_nu * pixels));
+      add(prefix + kStokesNames[a] + suffix, "<f8", shape, stokes.data(), sizeof(double) * n_nu * pixels, true);
     }
   };
   if (p.image_light) add_stokes(image0, n_pix, {res, res}, "", "");
@@ -400,14 +457,14 @@ int bl_write_output(bl_ctx *ctx, const char *path_override, const bl_output_desc
       return shape;
     };
     auto rows = [&](const std::string &name, int offset, int count, bool per_frequency) {
-      add(prefix + name + suffix, MakeNpy("<f8", shaped(per_frequency), image + static_cast<size_t>(offset) * level_pix, sizeof(double) * count * level_pix));
+      add(prefix + name + suffix, "<f8", shaped(per_frequency), image + static_cast<size_t>(offset) * level_pix, sizeof(double) * count * level_pix, false);
     };
     auto cells = [&](const char *stem, int offset) {
       std::vector<double> copy(static_cast<size_t>(n_nu) * level_pix);
       for (int n = 0; n < 7; n++) {
         for (int l = 0; l < n_nu; l++)
           std::memcpy(&copy[static_cast<size_t>(l) * level_pix], image + static_cast<size_t>(offset + l * 7 + n) * level_pix, sizeof(double) * level_pix);
-        add(prefix + stem + cell_names[n] + suffix, MakeNpy("<f8", shaped(true), copy.data(), sizeof(double) * copy.size()));
+        add(prefix + stem + cell_names[n] + suffix, "<f8", shaped(true), copy.data(), sizeof(double) * copy.size(), true);
       }
     };
     if (p.image_time) rows("time", off_time, 1, false);
@@ -422,7 +479,7 @@ int bl_write_output(bl_ctx *ctx, const char *path_override, const bl_output_desc
     if (n_render > 0) {
       std::vector<int> shape = {n_render, 3};
       shape.insert(shape.end(), level_shape.begin(), level_shape.end());
-      add(prefix + "rendering" + suffix, MakeNpy("<f8", shape, render, sizeof(double) * n_render * 3 * level_pix));
+      add(prefix + "rendering" + suffix, "<f8", shape, render, sizeof(double) * n_render * 3 * level_pix, false);
     }
   };
   if (n_render > 0 && d->level[0].render == nullptr) return bl_internal_fail(ctx, BL_E_ARG, "render_num_images > 0 needs render data.");
@@ -433,39 +490,72 @@ int bl_write_output(bl_ctx *ctx, const char *path_override, const bl_output_desc
     if (lv.image == nullptr || lv.block_locs == nullptr) return bl_internal_fail(ctx, BL_E_ARG, "Missing adaptive level data.");
     const std::string suffix = "_" + std::to_string(l);
     const size_t level_pix = static_cast<size_t>(lv.n_blocks) * bs * bs;
-    add("adaptive_block_locs" + suffix, MakeNpy("<i4", {lv.n_blocks, 2}, lv.block_locs, 8 * static_cast<size_t>(lv.n_blocks)));
+    add("adaptive_block_locs" + suffix, "<i4", {lv.n_blocks, 2}, lv.block_locs, 8 * static_cast<size_t>(lv.n_blocks), false);
     if (p.output_camera) {
       if (lv.camera == nullptr) return bl_internal_fail(ctx, BL_E_ARG, "output_camera needs camera data.");
-      add(std::string("adaptive_") + camera_name + suffix, MakeNpy("<f8", {lv.n_blocks, bs, bs, 4}, lv.camera, sizeof(double) * level_pix * 4));
+      add(std::string("adaptive_") + camera_name + suffix, "<f8", {lv.n_blocks, bs, bs, 4}, lv.camera, sizeof(double) * level_pix * 4, false);
     }
     if (p.image_light) add_stokes(lv.image, level_pix, {lv.n_blocks, bs, bs}, "adaptive_", suffix);
     if (n_render > 0 && lv.render == nullptr) return bl_internal_fail(ctx, BL_E_ARG, "render_num_images > 0 needs render data.");
     add_alternates(lv.image, level_pix, {lv.n_blocks, bs, bs}, "adaptive_", suffix, lv.render);
   }
 
+  // ZIP64 (beyond the reference, whose writer ends with "too large for ZIP" there - numpy_format.cpp:44-45,
+  // zip_format.cpp:83-85): records of 4 GiB and more, and records behind the first 4 GiB of the file, carry 64-bit sizes
+  // and offsets, and the file ends with the ZIP64 end-of-central-directory record and locator (APPNOTE 4.3.14-15), which
+  // numpy.load reads. Files within the 32-bit limits are byte for byte what the reference writes.
+  // BLACKLIGHT_AMD_ZIP64 = never keeps the reference's error, = always writes the 64-bit fields whatever the size.
+  const char *zip64_env = std::getenv("BLACKLIGHT_AMD_ZIP64");
+  const bool zip64_never = zip64_env != nullptr && std::strcmp(zip64_env, "never") == 0;
+  const bool zip64_always = zip64_env != nullptr && std::strcmp(zip64_env, "always") == 0;
   std::vector<Bytes> local_headers(records.size()), central_headers(records.size());
   size_t offset = 0;
+  bool any_zip64 = zip64_always;
+  for (NpyRecord &r : records)
+    if (!r.owned.empty()) r.data = r.owned.data();   // (set here: the vector of records has stopped moving)
   for (size_t n = 0; n < records.size(); n++) {
-    if (records[n].second.empty() || !MakeLocalHeader(records[n].first, records[n].second, &local_headers[n]))
+    const size_t size = records[n].size();
+    const bool zip64 = !zip64_never && (zip64_always || size > UINT32_MAX || offset > UINT32_MAX);
+    if (records[n].head.empty() || !MakeLocalHeader(records[n].name, records[n], zip64, &local_headers[n]))
       return bl_internal_fail(ctx, BL_E_INPUT, "Array and metadata too large for ZIP record.");
-    central_headers[n] = MakeCentralHeader(local_headers[n], offset);
-    offset += local_headers[n].size() + records[n].second.size();
+    central_headers[n] = MakeCentralHeader(local_headers[n], offset, zip64, size);
+    any_zip64 = any_zip64 || zip64;
+    offset += local_headers[n].size() + size;
   }
   size_t central_length = 0;
   for (const Bytes &h : central_headers) central_length += h.size();
-  if (offset > UINT32_MAX || central_length > UINT32_MAX)
+  const bool end_zip64 = !zip64_never && (any_zip64 || offset > UINT32_MAX || central_length > UINT32_MAX || records.size() > 0xFFFE);
+  if (!end_zip64 && (offset > UINT32_MAX || central_length > UINT32_MAX))
     return bl_internal_fail(ctx, BL_E_INPUT, "File contents too large for ZIP format.");
-  Bytes end = {0x50, 0x4b, 0x05, 0x06};
+  Bytes end;
+  if (end_zip64) {
+    end = {0x50, 0x4b, 0x06, 0x06};
+    Put<uint64_t>(&end, 44);             // size of the rest of this record
+    Put<uint16_t>(&end, 45 | (3 << 8));  // made by 4.5, unix
+    Put<uint16_t>(&end, 45);
+    Put<uint32_t>(&end, 0);
+    Put<uint32_t>(&end, 0);
+    Put<uint64_t>(&end, records.size());
+    Put<uint64_t>(&end, records.size());
+    Put<uint64_t>(&end, central_length);
+    Put<uint64_t>(&end, offset);
+    end.insert(end.end(), {0x50, 0x4b, 0x06, 0x07});   // locator
+    Put<uint32_t>(&end, 0);
+    Put<uint64_t>(&end, offset + central_length);
+    Put<uint32_t>(&end, 1);
+  }
+  end.insert(end.end(), {0x50, 0x4b, 0x05, 0x06});
   Put<uint16_t>(&end, 0);
   Put<uint16_t>(&end, 0);
-  Put<uint16_t>(&end, static_cast<uint16_t>(records.size()));
-  Put<uint16_t>(&end, static_cast<uint16_t>(records.size()));
-  Put<uint32_t>(&end, static_cast<uint32_t>(central_length));
-  Put<uint32_t>(&end, static_cast<uint32_t>(offset));
+  Put<uint16_t>(&end, static_cast<uint16_t>(std::min<size_t>(records.size(), 0xFFFF)));
+  Put<uint16_t>(&end, static_cast<uint16_t>(std::min<size_t>(records.size(), 0xFFFF)));
+  Put<uint32_t>(&end, static_cast<uint32_t>(std::min<size_t>(central_length, UINT32_MAX)));
+  Put<uint32_t>(&end, static_cast<uint32_t>(std::min<size_t>(offset, UINT32_MAX)));
   Put<uint16_t>(&end, 0);
   for (size_t n = 0; n < records.size(); n++) {
     stream.write(reinterpret_cast<const char *>(local_headers[n].data()), static_cast<std::streamsize>(local_headers[n].size()));
-    stream.write(reinterpret_cast<const char *>(records[n].second.data()), static_cast<std::streamsize>(records[n].second.size()));
+    stream.write(reinterpret_cast<const char *>(records[n].head.data()), static_cast<std::streamsize>(records[n].head.size()));
+    stream.write(reinterpret_cast<const char *>(records[n].data), static_cast<std::streamsize>(records[n].data_bytes));
   }
   for (const Bytes &h : central_headers) stream.write(reinterpret_cast<const char *>(h.data()), static_cast<std::streamsize>(h.size()));
   stream.write(reinterpret_cast<const char *>(end.data()), static_cast<std::streamsize>(end.size()));

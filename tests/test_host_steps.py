@@ -4,6 +4,7 @@ the reference's adaptive_block_locs, and the .npz / .npy / raw writer against th
 output files (record names, order, shapes, bytes of every array; 128-byte .npy headers; stored ZIP
 entries with valid CRC-32)."""
 import io
+import os
 import struct
 import zipfile
 
@@ -122,3 +123,70 @@ def test_output_file_pattern_for_multiple_runs(built_library, tmp_path):
     ctx = bl.Context(bl.Params.from_dict(q), device=BL_DEVICE_NONE)
     ctx.write_output([dict(image=fx["B_npz_I_nu"].reshape(1, -1), block_locs=None)], snapshot=2)
     assert (tmp_path / "img_0009.npz").exists()
+
+
+def test_npz_zip64_fields_read_back(built_library, tmp_path, monkeypatch):
+    """BLACKLIGHT_AMD_ZIP64=always: every record carries the ZIP64 extended-information field and the file ends with the ZIP64
+    end-of-central-directory record + locator; zipfile and numpy read the reference's arrays out of it unchanged."""
+    fx, p, ctx = _host_context("sim_adaptive")
+    levels = _levels_from_golden(fx, int(p.get("image_num_frequencies")))
+    plain, forced = tmp_path / "plain.npz", tmp_path / "zip64.npz"
+    ctx.write_output(levels, path=plain)
+    monkeypatch.setenv("BLACKLIGHT_AMD_ZIP64", "always")
+    ctx.write_output(levels, path=forced)
+    monkeypatch.delenv("BLACKLIGHT_AMD_ZIP64")
+    raw = forced.read_bytes()
+    assert raw.count(b"PK\x06\x06") >= 1 and raw.count(b"PK\x06\x07") >= 1 and raw[-22:-18] == b"PK\x05\x06"
+    with zipfile.ZipFile(forced) as z:
+        assert z.testzip() is None
+        for info in z.infolist():
+            assert info.extract_version == 45 and info.extra[:4] == struct.pack("<HH", 1, 24)
+    a, b = np.load(plain), np.load(forced)
+    assert a.files == b.files
+    for name in a.files:
+        assert a[name].dtype == b[name].dtype and a[name].shape == b[name].shape and a[name].tobytes() == b[name].tobytes(), name
+
+
+def test_npz_record_beyond_4_gib(built_library, tmp_path, monkeypatch):
+    """A 33-frequency 4100^2 image (4.4 GB in one I_nu record; config 5's 4096^2 x 64 is twice that): the reference stops
+    with "too large for ZIP" (numpy_format.cpp:44-45) - kept under BLACKLIGHT_AMD_ZIP64=never - and the ZIP64 writer hands
+    numpy the array. The writer checksums and writes the rows where they lie, so the only large thing here is the file
+    (the image is untouched zero pages with a few marked values)."""
+    import blacklight_amd as bl
+    if os.statvfs(tmp_path).f_bavail * os.statvfs(tmp_path).f_frsize < 6 << 30:
+        pytest.skip("needs 6 GiB of disk")
+    fx, params, _ = gu.load_case("formula_dp")
+    res, n_nu = 4100, 33
+    q = dict(params, camera_resolution=res, image_num_frequencies=n_nu, image_frequency_start=1.0e11, image_frequency_end=1.0e12,
+             image_frequency_spacing="log", adaptive_max_level=0)
+    ctx = bl.Context(bl.Params.from_dict(q), device=BL_DEVICE_NONE)
+    image = np.zeros((n_nu, res * res))
+    marks = [(0, 0, 1.5), (0, res * res - 1, -2.25), (16, 12345, 3.0e-7), (n_nu - 1, 7, 42.0), (n_nu - 1, res * res - 1, -1.0e300)]
+    for l, m, value in marks:
+        image[l, m] = value
+    path = tmp_path / "big.npz"
+    monkeypatch.setenv("BLACKLIGHT_AMD_ZIP64", "never")
+    with pytest.raises(bl.BlacklightError, match="too large for ZIP"):
+        ctx.write_output([dict(image=image, block_locs=None)], path=path)
+    monkeypatch.delenv("BLACKLIGHT_AMD_ZIP64")
+    ctx.write_output([dict(image=image, block_locs=None)], path=path)
+    assert os.path.getsize(path) > 1 << 32
+    with zipfile.ZipFile(path) as z:
+        info = z.getinfo("I_nu.npy")
+        assert info.file_size == 128 + 8 * n_nu * res * res and info.CRC != 0
+        assert [i.filename for i in z.infolist()] == ["mass_msun.npy", "width.npy", "frequency.npy", "adaptive_num_levels.npy", "I_nu.npy"]
+    with np.load(path, mmap_mode=None) as got:
+        assert got["frequency"].shape == (n_nu,) and got["width"].shape == (1,)
+    # numpy's own reader on the big member, without holding 4.4 GB: header through numpy, values by position
+    with zipfile.ZipFile(path) as z, z.open("I_nu.npy") as member:
+        version = np.lib.format.read_magic(member)
+        shape, fortran, dtype = np.lib.format.read_array_header_1_0(member)
+        assert version == (1, 0) and shape == (n_nu, res, res) and not fortran and dtype == np.dtype("<f8")
+        for l, m, value in marks:
+            member.seek(128 + 8 * (l * res * res + m))
+            assert struct.unpack("<d", member.read(8))[0] == value
+        member.seek(128 + 8 * (5 * res * res))
+        assert member.read(1 << 20) == bytes(1 << 20)
+    with zipfile.ZipFile(path) as z, z.open("I_nu.npy") as member:
+        while member.read(1 << 26):     # read to the end: zipfile compares the CRC-32 of 4.4 GB with the header's
+            pass
