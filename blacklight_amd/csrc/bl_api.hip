@@ -34,6 +34,7 @@ extern "C" hipError_t bl_launch_polarized_coefficients(const BlShadeArgs *args, 
 extern "C" hipError_t bl_launch_transfer(const BlTransferArgs *args, hipStream_t stream);
 extern "C" hipError_t bl_launch_transfer_aux(const BlTransferArgs *args, hipStream_t stream);
 extern "C" hipError_t bl_launch_transfer_polarized(const BlTransferArgs *args, hipStream_t stream);
+extern "C" hipError_t bl_launch_transfer_polarized_matrix(const BlTransferArgs *args, int num_cus, hipStream_t stream);
 extern "C" hipError_t bl_launch_debug_math(int op, long long n, const double *x, const double *y, double *out, hipStream_t stream);
 
 namespace {
@@ -172,12 +173,13 @@ struct bl_ctx {
     DeviceBuffer<double> d_sample_t;               // image_time, slow light
     DeviceBuffer<double> d_slow_frac;              // slow light: t_frac of every located sample
     DeviceBuffer<BlPolSample> d_pol_samples;       // polarized transfer
+    DeviceBuffer<double> d_pol_matrix;             // tolerant tier: 10 doubles per sample
     DeviceBuffer<double2> d_pol_coeffs;
     DeviceBuffer<unsigned int> d_anchors;          // inter-block interpolation: eight anchor cells per record
     DeviceBuffer<BlCoefInputs> d_coef_inputs;      // polarized runs: coefficient kernel -> polarized coefficient kernel
     DeviceBuffer<unsigned long long> d_redo;       // tolerant tier: records left to the exact coefficient kernel
     void Free() {
-      d_redo.Free(); d_aux.Free(); d_sample_t.Free(); d_slow_frac.Free(); d_pol_samples.Free(); d_pol_coeffs.Free(); d_coef_inputs.Free(); d_anchors.Free();
+      d_redo.Free(); d_aux.Free(); d_sample_t.Free(); d_slow_frac.Free(); d_pol_samples.Free(); d_pol_matrix.Free(); d_pol_coeffs.Free(); d_coef_inputs.Free(); d_anchors.Free();
       d_records_hot.Free(); d_records_cold.Free(); d_located.Free(); d_located_tag.Free(); d_transfer.Free(); d_ray_kt.Free(); d_ray_factor.Free();
       d_ray_sample_num.Free(); d_ray_flags.Free(); d_ray_out_index.Free(); d_counters.Free();
     }
@@ -1172,6 +1174,8 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
         && (p.simulation_coord == BL_COORD_SKS || p.simulation_coord == BL_COORD_FMKS) && !p.ray_flat && ctx->plasma_thermal_frac != 0.0;
     // ... and the per-frequency coefficient kernel of polarized runs (frame, transport and coupling stay exact)
     const bool tolerant_polarized = ctx->arithmetic == BL_ARITH_TOLERANT && ctx->polarized;
+    // ... and transport matrices (bl_transport_matrix_kernel) instead of the ray-sequential tensor transport, in curved spacetimes
+    const bool matrix_transport = tolerant_polarized && !p.ray_flat;
     const size_t redo_capacity = 1u << 20;
     // chunk size from the scratch budget: per ray max_steps * (2 x 32 B record + 40 B located sample
     // (simulation mode) + 16 B * n_nu transfer)
@@ -1179,6 +1183,7 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
         * (sizeof(BlSampleHot) + sizeof(BlSampleCold) + (simulation ? sizeof(BlLocated) + sizeof(unsigned long long) : 0) + sizeof(double2) * n_nu
            + (aux ? sizeof(BlAuxSample) + sizeof(double) : 0) + (slow ? 2 * sizeof(double) : 0)
            + (ctx->polarized ? sizeof(BlPolSample) + sizeof(BlCoefInputs) + 3 * sizeof(double2) * n_nu : 0)
+           + (matrix_transport ? BL_POL_MATRIX_DOUBLES * sizeof(double) : 0)
            + (block_interp ? 8 * sizeof(unsigned int) : 0)) + 64;
     // One chunk if the whole call fits the budget. With bl_set_overlap(): two scratch sets of half the budget
     // each, so that the geodesic kernel of chunk c + 1 runs while chunk c is being shaded.
@@ -1194,7 +1199,7 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
               + sl.d_located.count * (sizeof(BlLocated) + sizeof(unsigned long long))
               + sl.d_transfer.count * sizeof(double2) + sl.d_aux.count * sizeof(BlAuxSample)
               + (sl.d_sample_t.count + sl.d_slow_frac.count) * sizeof(double)
-              + sl.d_pol_samples.count * sizeof(BlPolSample) + sl.d_pol_coeffs.count * sizeof(double2)
+              + sl.d_pol_samples.count * sizeof(BlPolSample) + (sl.d_pol_coeffs.count) * sizeof(double2) + sl.d_pol_matrix.count * sizeof(double)
               + sl.d_coef_inputs.count * sizeof(BlCoefInputs) + sl.d_anchors.count * sizeof(unsigned int);
         const uint64_t available = static_cast<uint64_t>(0.9 * static_cast<double>(free_bytes + held));
         if (available < budget) budget = available;
@@ -1231,6 +1236,7 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
       if (slow) sl.d_slow_frac.Ensure(record_capacity);
       if (ctx->polarized) {
         sl.d_pol_samples.Ensure(static_cast<size_t>(chunk) * max_steps);
+        if (matrix_transport) sl.d_pol_matrix.Ensure(static_cast<size_t>(chunk) * max_steps * BL_POL_MATRIX_DOUBLES);
         sl.d_pol_coeffs.Ensure(static_cast<size_t>(chunk) * max_steps * n_nu * 3);
         sl.d_coef_inputs.Ensure(record_capacity);
       }
@@ -1699,6 +1705,7 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
         sa.coef_inputs = sl.d_coef_inputs.ptr;
         xa.pol_samples = sl.d_pol_samples.ptr;
         xa.pol_coeffs = sl.d_pol_coeffs.ptr;
+        xa.pol_matrix = matrix_transport ? sl.d_pol_matrix.ptr : nullptr;
       }
       sa.anchors = block_interp ? sl.d_anchors.ptr : nullptr;
       sa.redo_list = fast ? sl.d_redo.ptr : nullptr;
@@ -1784,7 +1791,9 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
       if (ctx->polarized) Check(bl_launch_polarized_coefficients(&sa, ctx->num_cus * 8, stream), "polarized coefficient kernel launch");
       Check(hipEventRecord(e[4], stream), "event");
       Check(aux ? bl_launch_transfer_aux(&xa, stream) : bl_launch_transfer(&xa, stream), "transfer kernel launch");
-      if (ctx->polarized) Check(bl_launch_transfer_polarized(&xa, stream), "polarized transfer kernel launch");
+      if (ctx->polarized)
+        Check(matrix_transport ? bl_launch_transfer_polarized_matrix(&xa, ctx->num_cus, stream) : bl_launch_transfer_polarized(&xa, stream),
+              "polarized transfer kernel launch");
       Check(hipEventRecord(e[5], stream), "event");
       Check(hipMemcpyAsync(ctx->host_counters + static_cast<size_t>(c) * n_counters, sl.d_counters.ptr,
                            n_counters * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream), "counter download");

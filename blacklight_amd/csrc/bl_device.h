@@ -233,6 +233,8 @@ struct BlTraceArgs {
 // renormalised momentum, and rows 1 and 2 of the fluid tetrad (the only rows the Stokes projection and its inverse
 // read: polarized.cpp:268-292, :793-813). The coefficient kernel has all of it at hand (simulation_coefficients.cpp:
 // 398-431 builds the same tetrad from the same inputs as polarized.cpp:201-265). 128 bytes.
+// Tolerant tier, per sample: the transport matrix (3 x 3 block of I, Q, U by rows, then the V number), the sample's length, a spare
+#define BL_POL_MATRIX_DOUBLES 12
 struct alignas(16) BlPolSample {
   double x[3];
   double delta_lambda;
@@ -314,6 +316,7 @@ struct BlTransferArgs {
   // polarized transfer only
   const BlPolSample *pol_samples;
   const double2 *pol_coeffs;
+  double *pol_matrix;                      // tolerant tier: [chunk_rays][ray_max_steps][BL_POL_MATRIX_DOUBLES] (bl_polarized.hip)
   const double *camera_pos, *camera_dir;   // [n_rays_total][4] by output index: initial position, momentum
   BlSpacetime st;
   int simulation_coord, rotation_split;

@@ -394,6 +394,43 @@ __device__ void couple_jointly(const Coupling &c, const double ss_start[4], doub
     }
 }
 
+// The coupling of one sample (:388-779) with its guards (:781-790): rotation split from emission / absorption, or the
+// analytic cases. c holds the coefficients on entry; the derived quantities are filled in here.
+__device__ __forceinline__ void couple_sample(Coupling *cp, bool rotation_split, double delta_lambda_cgs, double ss_start[4], double ss_end[4]) {
+  Coupling &c = *cp;
+  c.delta_lambda_cgs = delta_lambda_cgs;
+  c.delta_tau = c.alpha_s[0] * delta_lambda_cgs;
+  c.optically_thin = c.delta_tau <= kDeltaTauMax;
+  c.alpha_sq = c.alpha_s[1] * c.alpha_s[1] + c.alpha_s[3] * c.alpha_s[3];
+  c.alpha_p = blm_sqrt(c.alpha_sq);
+  c.rho_sq = c.rho_s[1] * c.rho_s[1] + c.rho_s[3] * c.rho_s[3];
+  c.rho_p = blm_sqrt(c.rho_sq);
+  if (rotation_split) {   // :388-568
+    absorb(c, delta_lambda_cgs / 2.0, c.delta_tau / 2.0, ss_start, ss_end);
+    ss_end[0] = (ss_end[0] < 0.0) ? 0.0 : ss_end[0];   // std::max(ss_end[0], 0.0)
+    limit_polarization(ss_end);
+    for (int a = 0; a < 4; a++) ss_start[a] = ss_end[a];
+    if (c.rho_p != 0.0) rotate(c, ss_start, ss_end);
+    limit_polarization(ss_end);
+    for (int a = 0; a < 4; a++) ss_start[a] = ss_end[a];
+    absorb(c, delta_lambda_cgs / 2.0, c.delta_tau / 2.0, ss_start, ss_end);
+  } else if (c.alpha_s[0] == 0.0 && c.rho_p == 0.0) {
+    for (int a = 0; a < 4; a++) ss_end[a] = ss_start[a] + c.j_s[a] * delta_lambda_cgs;
+  } else if (c.alpha_p == 0.0 && c.rho_p == 0.0) {
+    absorb(c, delta_lambda_cgs, c.delta_tau, ss_start, ss_end);
+  } else if (c.alpha_s[0] == 0.0) {
+    rotate(c, ss_start, ss_end);
+    for (int a = 0; a < 4; a++) ss_end[a] += c.j_s[a] * delta_lambda_cgs;
+  } else if (c.rho_p == 0.0) {
+    absorb(c, delta_lambda_cgs, c.delta_tau, ss_start, ss_end);
+  } else {
+    couple_jointly(c, ss_start, ss_end);
+  }
+  // std::max(ss_end[0], 0.0) (:781): (a < b) ? b : a, so a NaN intensity stays NaN
+  ss_end[0] = (ss_end[0] < 0.0) ? 0.0 : ss_end[0];
+  limit_polarization(ss_end);
+}
+
 }  // namespace
 
 __global__ void __launch_bounds__(64) bl_transfer_polarized_kernel(BlTransferArgs P) {
@@ -474,37 +511,7 @@ __global__ void __launch_bounds__(64) bl_transfer_polarized_kernel(BlTransferArg
         to_stokes(gcov, s.e1, s.e2, nn_con, ss_start);
       }
 
-      c.delta_lambda_cgs = delta_lambda_cgs;
-      c.delta_tau = c.alpha_s[0] * delta_lambda_cgs;
-      c.optically_thin = c.delta_tau <= kDeltaTauMax;
-      c.alpha_sq = c.alpha_s[1] * c.alpha_s[1] + c.alpha_s[3] * c.alpha_s[3];
-      c.alpha_p = blm_sqrt(c.alpha_sq);
-      c.rho_sq = c.rho_s[1] * c.rho_s[1] + c.rho_s[3] * c.rho_s[3];
-      c.rho_p = blm_sqrt(c.rho_sq);
-      if (P.rotation_split) {   // :388-568
-        absorb(c, delta_lambda_cgs / 2.0, c.delta_tau / 2.0, ss_start, ss_end);
-        ss_end[0] = (ss_end[0] < 0.0) ? 0.0 : ss_end[0];   // std::max(ss_end[0], 0.0)
-        limit_polarization(ss_end);
-        for (int a = 0; a < 4; a++) ss_start[a] = ss_end[a];
-        if (c.rho_p != 0.0) rotate(c, ss_start, ss_end);
-        limit_polarization(ss_end);
-        for (int a = 0; a < 4; a++) ss_start[a] = ss_end[a];
-        absorb(c, delta_lambda_cgs / 2.0, c.delta_tau / 2.0, ss_start, ss_end);
-      } else if (c.alpha_s[0] == 0.0 && c.rho_p == 0.0) {
-        for (int a = 0; a < 4; a++) ss_end[a] = ss_start[a] + c.j_s[a] * delta_lambda_cgs;
-      } else if (c.alpha_p == 0.0 && c.rho_p == 0.0) {
-        absorb(c, delta_lambda_cgs, c.delta_tau, ss_start, ss_end);
-      } else if (c.alpha_s[0] == 0.0) {
-        rotate(c, ss_start, ss_end);
-        for (int a = 0; a < 4; a++) ss_end[a] += c.j_s[a] * delta_lambda_cgs;
-      } else if (c.rho_p == 0.0) {
-        absorb(c, delta_lambda_cgs, c.delta_tau, ss_start, ss_end);
-      } else {
-        couple_jointly(c, ss_start, ss_end);
-      }
-      // std::max(ss_end[0], 0.0) (:781): (a < b) ? b : a, so a NaN intensity stays NaN
-      ss_end[0] = (ss_end[0] < 0.0) ? 0.0 : ss_end[0];
-      limit_polarization(ss_end);
+      couple_sample(&c, P.rotation_split != 0, delta_lambda_cgs, ss_start, ss_end);
 
       // back to coordinates (:793-813), second half step (:816-833)
       from_stokes(s.e1, s.e2, ss_end, nn_con);
@@ -544,5 +551,425 @@ __global__ void __launch_bounds__(64) bl_transfer_polarized_kernel(BlTransferArg
 extern "C" hipError_t bl_launch_transfer_polarized(const BlTransferArgs *args, hipStream_t stream) {
   const int grid = (args->chunk_rays + 63) / 64;
   hipLaunchKernelGGL(bl_transfer_polarized_kernel, dim3(grid), dim3(64), 0, stream, *args);
+  return hipGetLastError();
+}
+
+// =====================================================================================================================
+// Tolerant arithmetic tier (bl_set_arithmetic(BL_ARITH_TOLERANT)): transport matrices.
+//
+// Between two couplings everything the reference does to a ray's state is linear in the four Stokes parameters the
+// previous coupling left: from_stokes with the previous sample's tetrad (N0 = E_p T E_p^T, T the 2 x 2 Hermitian matrix of
+// I, Q, U, V), the previous sample's second half step (N1 = N0 + a D_1(N0), D(N) = -(G N + N G^T), G_1 = k^alpha Gamma at
+// the previous sample), this sample's first half step, which adds to N_temp = N0 (N2 = N0 + b D_2(N1), G_2 from the
+// averaged connection and momentum), and to_stokes with this sample's metric and tetrad. So
+//     ss_start(n) = M_n ss_end(n - 1)
+// with a real 4 x 4 matrix M_n that depends on the geometry of samples n - 1 and n only: sample-parallel work. M_n is built
+// without ever forming N: with covectors c_a = g e'_a, u_a = G_2^T c_a and the projections P(x) = (x . e_1, x . e_2),
+// R(x) = P(G_1^T x) onto the previous tetrad, x^T N1 y = P(x)^T T P(y) - a [R(x)^T T P(y) + P(x)^T T R(y)], and
+// n_ab = c_a^T N2 c_b = sum_cd K_ab^cd t_cd with K_ab = P(c_a) P(c_b)^T - b [X(u_a, c_b) + X(c_a, u_b)]. K is real, so
+// (I, Q, U) and V decouple: M is a 3 x 3 block and one number (10 doubles per sample). The contraction
+// G^mu_beta = k^alpha Gamma^mu_{alpha beta} of the Kerr-Schild metric g = eta + f l l is evaluated in closed form
+// (s = k.df, v = (k.d) l, w_beta = k^alpha d_beta l_alpha, lambda = l.k; Q = s l l^T + f (v l^T + l v^T) + T2 - T2^T with
+// T2 = lambda (df l^T + f dl) + f l w^T; G = (eta Q - f l^up (l^up Q)) / 2) instead of through the 64 components, and only
+// ever applied to covectors (apply_transposed), never stored.
+// bl_transport_matrix_kernel does that for every sample at full occupancy; what stays sequential per ray
+// (bl_transfer_polarized_matrix_kernel) is ss = M ss, the coupling and its guards - the same coupling code as the exact tier.
+// The same mathematics as polarized.cpp:150-198, :259-292, :793-833 in another association of the floating-point
+// operations: images agree with the exact tier to ~1e-13 of the peak intensity (tests/test_gpu_tolerant.py), NaN masks and
+// all integer results are the exact tier's. Not used with ray_flat (the exact kernel serves that).
+#pragma clang fp contract(fast)
+
+namespace {
+namespace fastpol {
+
+// 1 / b: v_rcp_f64 + two Newton steps (~1 ulp); v_div_fixup restores 1 / 0, 1 / inf and NaN
+__device__ __forceinline__ double rcp(double b) {
+  double y = __builtin_amdgcn_rcp(b);
+  double e = __builtin_fma(-b, y, 1.0);
+  y = __builtin_fma(y, e, y);
+  e = __builtin_fma(-b, y, 1.0);
+  y = __builtin_fma(y, e, y);
+  return __builtin_amdgcn_div_fixup(y, b, 1.0);
+}
+
+// f, l_i and their spatial derivatives at a point (radiation_geometry.cpp:283-330 in closed form with shared reciprocals)
+struct PointGeometry {
+  double f;
+  double l[3];       // l_1..l_3 (l_0 = 1 covariant, -1 contravariant)
+  double df[3];      // d f / d x^a
+  double dl[3][3];   // dl[i][a] = d l_{i+1} / d x^{a+1}
+};
+
+__device__ __forceinline__ PointGeometry point_geometry(const BlSpacetime &st, double x, double y, double z) {
+  BlKerrSchild ks;
+  bl_kerr_schild(st, x, y, z, &ks);
+  PointGeometry g;
+  const double a = st.bh_a, a2 = ks.a2, r = ks.r, r2 = ks.r2;
+  g.f = ks.f;
+  g.l[0] = ks.l[0]; g.l[1] = ks.l[1]; g.l[2] = ks.l[2];
+  const double inv_d = rcp(2.0 * r2 - ks.rr2 + a2), inv_r = rcp(r), inv_ra = rcp(r2 + a2);
+  const double q = r2 * r2, az2 = a2 * z * z;
+  const double inv_f = rcp(r * (q + az2));
+  const double dr[3] = {r * x * inv_d, r * y * inv_d, (r * z + a2 * z * inv_r) * inv_d};
+  const double c1 = -(q - 3.0 * az2) * g.f * inv_f;
+  g.df[0] = c1 * dr[0];
+  g.df[1] = c1 * dr[1];
+  g.df[2] = c1 * dr[2] - 2.0 * a2 * r * z * g.f * inv_f;
+  const double px = x - 2.0 * r * g.l[0], py = y - 2.0 * r * g.l[1], mz = -z * inv_r * inv_r;
+  g.dl[0][0] = (px * dr[0] + r) * inv_ra;
+  g.dl[0][1] = (px * dr[1] + a) * inv_ra;
+  g.dl[0][2] = px * dr[2] * inv_ra;
+  g.dl[1][0] = (py * dr[0] - a) * inv_ra;
+  g.dl[1][1] = (py * dr[1] + r) * inv_ra;
+  g.dl[1][2] = py * dr[2] * inv_ra;
+  g.dl[2][0] = mz * dr[0];
+  g.dl[2][1] = mz * dr[1];
+  g.dl[2][2] = mz * dr[2] + inv_r;
+  return g;
+}
+
+// G[mu][beta] = k^alpha Gamma^mu_{alpha beta} at a point is never formed: only y = G^T x is needed, for a handful of covectors
+// x. With z = g^{-1} x (z^0 = -x_0 + f (l^up . x), z^i = x_i - f l_i (l^up . x)) and the scalars of the momentum
+// (s = k . df, lambda = l . k, v_i = k^a d_a l_i, w_b = k^i d_b l_i):
+//   h = s (z.l) + f (z.v) - lambda (z.df) - f (z.w),   y_0 = h / 2,
+//   y_i = (l_i h + f (z.l) (v_i + w_i) + lambda (df_i (z.l) + f ((z.dl)_i - (dl z)_i))) / 2.
+struct Contracted {
+  double s, lambda, v[3], w[3];
+};
+__device__ __forceinline__ Contracted contract_momentum(const PointGeometry &g, const double k[4]) {
+  Contracted c;
+  c.s = k[1] * g.df[0] + k[2] * g.df[1] + k[3] * g.df[2];
+  c.lambda = k[0] + k[1] * g.l[0] + k[2] * g.l[1] + k[3] * g.l[2];
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    c.v[i] = k[1] * g.dl[i][0] + k[2] * g.dl[i][1] + k[3] * g.dl[i][2];
+    c.w[i] = k[1] * g.dl[0][i] + k[2] * g.dl[1][i] + k[3] * g.dl[2][i];
+  }
+  return c;
+}
+__device__ __forceinline__ void apply_transposed(const PointGeometry &g, const Contracted &c, const double x[4], double y[4]) {
+  const double lux = -x[0] + g.l[0] * x[1] + g.l[1] * x[2] + g.l[2] * x[3];
+  const double flux = g.f * lux;
+  const double z0 = flux - x[0];
+  const double z[3] = {x[1] - flux * g.l[0], x[2] - flux * g.l[1], x[3] - flux * g.l[2]};
+  const double zl = z0 + z[0] * g.l[0] + z[1] * g.l[1] + z[2] * g.l[2];
+  const double zv = z[0] * c.v[0] + z[1] * c.v[1] + z[2] * c.v[2];
+  const double zw = z[0] * c.w[0] + z[1] * c.w[1] + z[2] * c.w[2];
+  const double zdf = z[0] * g.df[0] + z[1] * g.df[1] + z[2] * g.df[2];
+  const double h = c.s * zl + g.f * (zv - zw) - c.lambda * zdf;
+  y[0] = 0.5 * h;
+  const double fzl = g.f * zl;
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    const double zdl = z[0] * g.dl[0][i] + z[1] * g.dl[1][i] + z[2] * g.dl[2][i];
+    const double dlz = g.dl[i][0] * z[0] + g.dl[i][1] * z[1] + g.dl[i][2] * z[2];
+    y[i + 1] = 0.5 * (g.l[i] * h + fzl * (c.v[i] + c.w[i]) + c.lambda * (g.df[i] * zl + g.f * (zdl - dlz)));
+  }
+}
+
+// P(x) and R(x) = P(G1^T x) of a covector x for the previous sample's tetrad rows e1, e2
+struct Projected {
+  double p[2], r[2];
+};
+__device__ __forceinline__ Projected project(const double x[4], const double e1[4], const double e2[4], const PointGeometry &g1,
+                                             const Contracted &c1) {
+  Projected o;
+  o.p[0] = x[0] * e1[0] + x[1] * e1[1] + x[2] * e1[2] + x[3] * e1[3];
+  o.p[1] = x[0] * e2[0] + x[1] * e2[1] + x[2] * e2[2] + x[3] * e2[3];
+  double gx[4];
+  apply_transposed(g1, c1, x, gx);
+  o.r[0] = gx[0] * e1[0] + gx[1] * e1[1] + gx[2] * e1[2] + gx[3] * e1[3];
+  o.r[1] = gx[0] * e2[0] + gx[1] * e2[1] + gx[2] * e2[2] + gx[3] * e2[3];
+  return o;
+}
+// X(x, y)^{cd}: the coefficients of t_cd in x^T N1 y, N1 = N0 + a D_1(N0)
+__device__ __forceinline__ void after_first_transport(const Projected &x, const Projected &y, double a, double X[2][2]) {
+#pragma unroll
+  for (int c = 0; c < 2; c++)
+#pragma unroll
+    for (int d = 0; d < 2; d++) X[c][d] = x.p[c] * y.p[d] - a * (x.r[c] * y.p[d] + x.p[c] * y.r[d]);
+}
+// K_ab^{cd} (coefficients of t_cd in n_ab) -> the 3 x 3 (I, Q, U) block, rows first, and the V number: m[0..8], m[9]
+__device__ __forceinline__ void stokes_matrix(const double K[2][2][2][2], double m[10]) {
+  double A[2][2], B[2][2], C[2][2], D[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int b = 0; b < 2; b++) {
+      A[a][b] = K[a][b][0][0] + K[a][b][1][1];
+      B[a][b] = K[a][b][0][0] - K[a][b][1][1];
+      C[a][b] = K[a][b][0][1] + K[a][b][1][0];
+      D[a][b] = K[a][b][1][0] - K[a][b][0][1];
+    }
+  m[0] = 0.5 * (A[0][0] + A[1][1]); m[1] = 0.5 * (B[0][0] + B[1][1]); m[2] = 0.5 * (C[0][0] + C[1][1]);
+  m[3] = 0.5 * (A[0][0] - A[1][1]); m[4] = 0.5 * (B[0][0] - B[1][1]); m[5] = 0.5 * (C[0][0] - C[1][1]);
+  m[6] = 0.5 * (A[0][1] + A[1][0]); m[7] = 0.5 * (B[0][1] + B[1][0]); m[8] = 0.5 * (C[0][1] + C[1][0]);
+  m[9] = 0.5 * (D[1][0] - D[0][1]);
+}
+
+__device__ __forceinline__ void load_sample(const BlPolSample *s, double x[3], double *delta_lambda, double k[4], double e1[4], double e2[4]) {
+  const double2 *q = reinterpret_cast<const double2 *>(s);
+  const double2 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4], q5 = q[5], q6 = q[6], q7 = q[7];
+  x[0] = q0.x; x[1] = q0.y; x[2] = q1.x; *delta_lambda = q1.y;
+  k[0] = q2.x; k[1] = q2.y; k[2] = q3.x; k[3] = q3.y;
+  e1[0] = q4.x; e1[1] = q4.y; e1[2] = q5.x; e1[3] = q5.y;
+  e2[0] = q6.x; e2[1] = q6.y; e2[2] = q7.x; e2[3] = q7.y;
+}
+
+}  // namespace fastpol
+}  // namespace
+
+// One lane per sample, ray by ray: a wave takes 64 consecutive samples of one ray (persistent waves over the rays). A lane
+// reading its own 128-byte record straight from memory makes every load instruction touch 64 different lines, and two waves
+// per SIMD do not hide a trip to memory on their own; so the records of a segment (64 + the first of the next segment: the
+// previous sample of lane i is lane i + 1's) travel as coalesced 16-byte units by LDS-DMA (global_load_lds_dwordx4: no
+// registers in between) into one of two wave-private LDS tiles while the arithmetic of the segment before runs out of the
+// other. The DMA writes LDS lane-linearly, so the tile is swizzled on the source side: unit r of sample i sits in slot
+// 8 i + ((r + i) & 7), which spreads the 16-byte LDS reads of consecutive lanes over all banks. The 96-byte results go back
+// through the tile they came from (rows padded to 112 bytes) and leave as coalesced 16-byte stores.
+constexpr int kMkTileBytes = 9 * 1024;      // nine DMA instructions of 64 x 16 bytes: 65 records and slack
+constexpr int kMkOutStride = 112;           // bytes per result row in the tile (96 + 16)
+
+__device__ __forceinline__ void mk_wave_sync() {   // LDS traffic of this wave before / after: ordered and complete
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ void mk_read_sample(const unsigned char *tile, int index, double x[3], double *delta_lambda, double k[4],
+                                               double e1[4], double e2[4]) {
+  double2 q[8];
+#pragma unroll
+  for (int r = 0; r < 8; r++) q[r] = *reinterpret_cast<const double2 *>(tile + (index * 8 + ((r + index) & 7)) * 16);
+  x[0] = q[0].x; x[1] = q[0].y; x[2] = q[1].x; *delta_lambda = q[1].y;
+  k[0] = q[2].x; k[1] = q[2].y; k[2] = q[3].x; k[3] = q[3].y;
+  e1[0] = q[4].x; e1[1] = q[4].y; e1[2] = q[5].x; e1[3] = q[5].y;
+  e2[0] = q[6].x; e2[1] = q[6].y; e2[2] = q[7].x; e2[3] = q[7].y;
+}
+
+__global__ void __launch_bounds__(256, 2) bl_transport_matrix_kernel(BlTransferArgs P) {
+  using namespace fastpol;
+  __shared__ __attribute__((aligned(16))) unsigned char tiles_even[4 * kMkTileBytes];
+  __shared__ __attribute__((aligned(16))) unsigned char tiles_odd[4 * kMkTileBytes];
+  const BlSpacetime st = P.st;
+  const int lane = threadIdx.x & 63;
+  const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  unsigned char *const tile_even = tiles_even + wave_in_block * kMkTileBytes;
+  unsigned char *const tile_odd = tiles_odd + wave_in_block * kMkTileBytes;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int n_waves = (gridDim.x * blockDim.x) >> 6;
+  int slot = __builtin_amdgcn_readfirstlane(wave), base = 0, num = 0;   // wave-uniform: scalar registers, scalar branches
+  auto settle = [&]() {   // first segment at or after (slot, base) that holds samples; false when the rays are used up
+    for (;;) {
+      if (slot >= P.chunk_rays) return false;
+      if (base == 0) num = __builtin_amdgcn_readfirstlane(P.ray_sample_num[slot]);
+      if (base < num) return true;
+      slot += n_waves;
+      base = 0;
+    }
+  };
+  // slot q = lane + 64 j of the tile receives unit 8 i + ((r - i) & 7) of the segment, i = q / 8, r = q % 8 (clamped to the
+  // ray's last record: always a valid address, never under a branch)
+  auto request = [&](unsigned char *tile, int slot_r, int base_r, int num_r) {
+    const double2 *samples = reinterpret_cast<const double2 *>(P.pol_samples + (size_t)slot_r * P.ray_max_steps);
+#pragma unroll
+    for (int j = 0; j < 9; j++) {
+      const int q = lane + 64 * j, i = q >> 3;
+      const int unit = min(base_r * 8 + i * 8 + ((q - i) & 7), num_r * 8 - 1);
+      // (as assembly: the compiler would otherwise wait for every LDS-DMA in flight before any LDS read it cannot prove
+      // disjoint from the DMA's target, which is every read of the other tile; M0 carries the LDS address)
+      const unsigned lds_address = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)(tile + j * 1024);
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(samples + unit), "s"(lds_address) : "memory");
+    }
+  };
+  if (!settle()) return;
+  request(tile_even, slot, base, num);
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the first tile has landed
+  // one segment: arithmetic out of `tile` while the next segment travels into `tile_next`; returns false after the last one
+  auto segment = [&](unsigned char *tile, unsigned char *tile_next) {
+    const int slot_cur = slot, base_cur = base, num_cur = num;
+    double2 *matrices = reinterpret_cast<double2 *>(P.pol_matrix + (size_t)slot_cur * P.ray_max_steps * BL_POL_MATRIX_DOUBLES);
+    bool live;
+    {
+      mk_wave_sync();
+      base += 64;
+      live = settle();
+      // the next segment into the other tile (after the last segment: the current one again, into a tile nobody reads)
+      request(tile_next, live ? slot : slot_cur, live ? base : base_cur, live ? num : num_cur);
+      const int rec = base_cur + lane;
+      double m[10], dn = 0.0;
+      if (rec < num_cur) {
+        // previous sample in integration order of the transfer: record rec + 1 (the far end is its own predecessor, :150-154)
+        const int prev = rec + 1 < num_cur ? lane + 1 : lane;
+        double xn[3], xp[3], dp, kn[4], kp[4], e1n[4], e2n[4], e1p[4], e2p[4];
+        mk_read_sample(tile, lane, xn, &dn, kn, e1n, e2n);
+        mk_read_sample(tile, prev, xp, &dp, kp, e1p, e2p);
+        const PointGeometry gn = point_geometry(st, xn[0], xn[1], xn[2]);
+        const PointGeometry gp = point_geometry(st, xp[0], xp[1], xp[2]);
+        const double kavg[4] = {0.5 * (kp[0] + kn[0]), 0.5 * (kp[1] + kn[1]), 0.5 * (kp[2] + kn[2]), 0.5 * (kp[3] + kn[3])};
+        const Contracted cp_own = contract_momentum(gp, kp);     // second half step of the previous sample (:816-822)
+        const Contracted cp_avg = contract_momentum(gp, kavg);   // first half step: connection and momentum averaged over the
+        const Contracted cn_avg = contract_momentum(gn, kavg);   // two samples (:150-180)
+        const double a = (dp + dn) * 0.25, b = (dp + dn) * 0.5;
+        // c_a = g e'_a with g = eta + f l l (covariant l_0 = 1); u_a = G_2^T c_a
+        double c[2][4], u[2][4];
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+          const double *e = t == 0 ? e1n : e2n;
+          const double le = gn.f * (e[0] + gn.l[0] * e[1] + gn.l[1] * e[2] + gn.l[2] * e[3]);
+          c[t][0] = le - e[0];
+          c[t][1] = e[1] + le * gn.l[0];
+          c[t][2] = e[2] + le * gn.l[1];
+          c[t][3] = e[3] + le * gn.l[2];
+          double ya[4], yb[4];
+          apply_transposed(gp, cp_avg, c[t], ya);
+          apply_transposed(gn, cn_avg, c[t], yb);
+#pragma unroll
+          for (int be = 0; be < 4; be++) u[t][be] = 0.5 * (ya[be] + yb[be]);
+        }
+        const Projected pc[2] = {project(c[0], e1p, e2p, gp, cp_own), project(c[1], e1p, e2p, gp, cp_own)};
+        const Projected pu[2] = {project(u[0], e1p, e2p, gp, cp_own), project(u[1], e1p, e2p, gp, cp_own)};
+        double K[2][2][2][2];
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+          for (int j = 0; j < 2; j++) {
+            double X1[2][2], X2[2][2];
+            after_first_transport(pu[i], pc[j], a, X1);
+            after_first_transport(pc[i], pu[j], a, X2);
+#pragma unroll
+            for (int cc = 0; cc < 2; cc++)
+#pragma unroll
+              for (int d = 0; d < 2; d++) K[i][j][cc][d] = pc[i].p[cc] * pc[j].p[d] - b * (X1[cc][d] + X2[cc][d]);
+          }
+        stokes_matrix(K, m);
+      }
+      mk_wave_sync();   // every lane has read its records: the tile takes the results
+      if (rec < num_cur) {
+        double2 *out = reinterpret_cast<double2 *>(tile + lane * kMkOutStride);
+#pragma unroll
+        for (int t = 0; t < 5; t++) out[t] = make_double2(m[2 * t], m[2 * t + 1]);
+        out[5] = make_double2(dn, 0.0);   // the sample's length rides along: the sequential kernel reads one stream
+      }
+      mk_wave_sync();
+      // vmcnt(0): the next tile has landed (requested a segment's arithmetic ago), and so have the stores of the segment
+      // before; placed here, ahead of this segment's stores, so that those stay in flight during the next segment
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+#pragma unroll
+      for (int j = 0; j < 6; j++) {
+        const int unit = lane + 64 * j;
+        const int sample = unit / 6;
+        if (base_cur + sample < num_cur)
+          matrices[(size_t)base_cur * 6 + unit] = *reinterpret_cast<const double2 *>(tile + sample * kMkOutStride + (unit - sample * 6) * 16);
+      }
+    }
+    return live;
+  };
+  for (;;) {
+    if (!segment(tile_even, tile_odd)) break;
+    if (!segment(tile_odd, tile_even)) break;
+  }
+}
+
+// One ray per lane, frequencies in sequence: ss = M ss, the coupling, its guards; at the end the last half step and the
+// camera's tetrad (:875-939) through the same projection algebra, and nu^3 (:942-949).
+__global__ void __launch_bounds__(64, 2) bl_transfer_polarized_matrix_kernel(BlTransferArgs P) {
+  using namespace fastpol;
+  const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot >= P.chunk_rays) return;
+  const BlSpacetime st = P.st;
+  const int num = P.ray_sample_num[slot];
+  const long long out_index = P.ray_out_index[slot];
+  const double momentum_factor = P.ray_factor[slot];
+  const size_t row = (size_t)P.n_rays_total;
+  double *img = P.image + out_index;
+  const BlPolSample *samples = P.pol_samples + (size_t)slot * P.ray_max_steps;
+  const double *matrices = P.pol_matrix + (size_t)slot * P.ray_max_steps * BL_POL_MATRIX_DOUBLES;
+  const double2 *ja = P.transfer + (size_t)slot * P.ray_max_steps * P.n_nu;
+  const double2 *pc = P.pol_coeffs + (size_t)slot * P.ray_max_steps * P.n_nu * 3;
+  // the last sample's second half step and the camera projection do not depend on the frequency
+  double m_cam[10];
+  if (num > 0) {
+    double x0[3], d0, k0[4], e1[4], e2[4];
+    load_sample(samples, x0, &d0, k0, e1, e2);
+    const PointGeometry g0 = point_geometry(st, x0[0], x0[1], x0[2]);
+    const Contracted c0 = contract_momentum(g0, k0);
+    const double *cp = P.camera_pos + 4 * out_index, *cd = P.camera_dir + 4 * out_index;
+    const double kcov[4] = {cd[0], cd[1], cd[2], cd[3]};
+    double gcov[4][4], gcon[4][4], kcon[4], up_con[4], tetrad[4][4];
+    bl_pol::geodesic_metric(st, cp[1], cp[2], cp[3], gcov, gcon);
+    for (int mu = 0; mu < 4; mu++) {
+      double acc = 0.0;
+      for (int nu = 0; nu < 4; nu++) acc += gcon[mu][nu] * kcov[nu];
+      kcon[mu] = acc;
+    }
+    const double *u_con = P.cam_u_con, *u_cov = P.cam_u_cov, *vert = P.cam_vert_con_c;
+    up_con[0] = u_con[0] * vert[0] - (u_cov[1] * vert[1] + u_cov[2] * vert[2] + u_cov[3] * vert[3]) / u_cov[0];
+    up_con[1] = vert[1] + u_con[1] * vert[0];
+    up_con[2] = vert[2] + u_con[2] * vert[0];
+    up_con[3] = vert[3] + u_con[3] * vert[0];
+    bl_pol::tetrad_frame(u_con, u_cov, kcon, kcov, up_con, gcov, gcon, tetrad);
+    double c[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+      for (int mu = 0; mu < 4; mu++)
+        c[t][mu] = gcov[mu][0] * tetrad[1 + t][0] + gcov[mu][1] * tetrad[1 + t][1] + gcov[mu][2] * tetrad[1 + t][2] + gcov[mu][3] * tetrad[1 + t][3];
+    const Projected pcam[2] = {project(c[0], e1, e2, g0, c0), project(c[1], e1, e2, g0, c0)};
+    double K[2][2][2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int j = 0; j < 2; j++) after_first_transport(pcam[i], pcam[j], (d0 + d0) * 0.25, K[i][j]);
+    stokes_matrix(K, m_cam);
+  }
+  for (int l = 0; l < P.n_nu; l++) {
+    const double freq = P.frequencies[l];
+    if (num <= 0) {   // :94-96
+      for (int a = 0; a < 4; a++) img[(size_t)(4 * l + a) * row] = 0.0;
+      continue;
+    }
+    double ss_end[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int rec = num - 1; rec >= 0; rec--) {
+      const double2 *mq = reinterpret_cast<const double2 *>(matrices + (size_t)rec * BL_POL_MATRIX_DOUBLES);
+      const double2 m0 = mq[0], m1 = mq[1], m2 = mq[2], m3 = mq[3], m4 = mq[4];
+      const double delta_lambda = mq[5].x;
+      Coupling c;
+      {
+        const size_t at = (size_t)rec * P.n_nu + l;
+        const double2 c0 = ja[at], c1 = pc[at * 3 + 0], c2 = pc[at * 3 + 1], c3 = pc[at * 3 + 2];
+        c.j_s[0] = c0.x; c.j_s[1] = c1.x; c.j_s[2] = 0.0; c.j_s[3] = c1.y;
+        c.alpha_s[0] = c0.y; c.alpha_s[1] = c2.x; c.alpha_s[2] = 0.0; c.alpha_s[3] = c2.y;
+        c.rho_s[0] = 0.0; c.rho_s[1] = c3.x; c.rho_s[2] = 0.0; c.rho_s[3] = c3.y;
+      }
+      double ss_start[4];
+      ss_start[0] = m0.x * ss_end[0] + m0.y * ss_end[1] + m1.x * ss_end[2];
+      ss_start[1] = m1.y * ss_end[0] + m2.x * ss_end[1] + m2.y * ss_end[2];
+      ss_start[2] = m3.x * ss_end[0] + m3.y * ss_end[1] + m4.x * ss_end[2];
+      ss_start[3] = m4.y * ss_end[3];
+      const double delta_lambda_cgs = delta_lambda * P.x_unit / (freq * momentum_factor);
+      ss_end[0] = ss_end[1] = ss_end[2] = ss_end[3] = 0.0;
+#ifdef BL_TPS_NOCOUPLE
+      for (int a = 0; a < 4; a++) ss_end[a] = ss_start[a] + c.j_s[a] * delta_lambda_cgs + c.alpha_s[a] + c.rho_s[a];
+#else
+      couple_sample(&c, P.rotation_split != 0, delta_lambda_cgs, ss_start, ss_end);
+#endif
+    }
+    const double nu_cu = freq * freq * freq;
+    img[(size_t)(4 * l + 0) * row] = (m_cam[0] * ss_end[0] + m_cam[1] * ss_end[1] + m_cam[2] * ss_end[2]) * nu_cu;
+    img[(size_t)(4 * l + 1) * row] = (m_cam[3] * ss_end[0] + m_cam[4] * ss_end[1] + m_cam[5] * ss_end[2]) * nu_cu;
+    img[(size_t)(4 * l + 2) * row] = (m_cam[6] * ss_end[0] + m_cam[7] * ss_end[1] + m_cam[8] * ss_end[2]) * nu_cu;
+    img[(size_t)(4 * l + 3) * row] = (m_cam[9] * ss_end[3]) * nu_cu;
+  }
+}
+
+extern "C" hipError_t bl_launch_transfer_polarized_matrix(const BlTransferArgs *args, int num_cus, hipStream_t stream) {
+  hipLaunchKernelGGL(bl_transport_matrix_kernel, dim3(num_cus * 2 * 4), dim3(256), 0, stream, *args);
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return err;
+  const int grid = (args->chunk_rays + 63) / 64;
+  hipLaunchKernelGGL(bl_transfer_polarized_matrix_kernel, dim3(grid), dim3(64), 0, stream, *args);
   return hipGetLastError();
 }

@@ -20,6 +20,8 @@ p.update(camera_resolution=res, image_polarization=True, image_tau=True)
 with bl.Context(bl.Params.from_dict(p)) as ctx:
     ctx.set_grid(grid)
     ctx.set_arithmetic(os.environ.get("ARITH", "exact"))
+    if "SCRATCH_GB" in os.environ:
+        ctx.set_scratch_limit(int(float(os.environ["SCRATCH_GB"]) * 1e9))
     ctx.render()
     t0 = time.perf_counter()
     out = ctx.render()
