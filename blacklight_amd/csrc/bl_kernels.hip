@@ -1907,30 +1907,35 @@ __global__ void __launch_bounds__(256, 2) bl_shade_kernel(const BlShadeArgs P) {
         BlPolSample *ps = P.pol_samples + ((size_t)ray * P.ray_max_steps + n);
         ps->x[0] = x1; ps->x[1] = x2; ps->x[2] = x3;
         ps->delta_lambda = delta_lambda;
-        if (!sh.have_coefficients) {
-          // cut samples, cells cut or without field: the coefficient code never reached its tetrad, the polarized
-          // transfer still needs the frame (with zero velocity / field where the sample was cut)
-          float uu[3], bb[3];
-          for (int c = 0; c < 3; c++) {
-            uu[c] = pr[2 + c];
-            bb[c] = pr[5 + c];
-          }
-          bl_pol::sample_frame(st, P.plasma.simulation_coord, x1, x2, x3, kcov, uu, bb, ps);
-        }
       }
     }
     if (kPolarized) {
       // polarized run (an auxiliary-image, extended, simulation-mode instantiation): the per-frequency formulas (Bessel functions, a dozen powers and exponentials) need few
       // registers and many waves - bl_polarized_coefficients_kernel evaluates them from these scalars
       BlCoefInputs ci;
-      ci.nu_fluid_over_nu = sh.nu_fluid_over_nu;
-      ci.n_e_cgs = sh.n_e_cgs;
-      ci.nu_c_cgs = sh.nu_c_cgs;
-      ci.theta_e = sh.theta_e;
-      ci.kb_tt_e_cgs = sh.kb_tt_e_cgs;
-      ci.cos2_theta_b = sh.cos2_theta_b;
-      ci.cos_sign = sh.cos_sign;
-      ci.have_coefficients = sh.have_coefficients ? 1.0 : 0.0;
+      if (sh.have_coefficients) {
+        ci.nu_fluid_over_nu = sh.nu_fluid_over_nu;
+        ci.n_e_cgs = sh.n_e_cgs;
+        ci.nu_c_cgs = sh.nu_c_cgs;
+        ci.theta_e = sh.theta_e;
+        ci.kb_tt_e_cgs = sh.kb_tt_e_cgs;
+        ci.cos2_theta_b = sh.cos2_theta_b;
+        ci.cos_sign = sh.cos_sign;
+        ci.have_coefficients = 1.0;
+      } else {
+        // cut samples, cells cut or without field: the coefficient code never reached its tetrad, but the polarized transfer
+        // needs the frame (with zero velocity / field where the sample was cut). Rare, and a frame's worth of registers:
+        // bl_polarized_frame_kernel builds it from what is parked here in the fields nobody reads for such a sample -
+        // the renormalised k_mu and the sampled velocity and field.
+        ci.nu_fluid_over_nu = kcov[0];
+        ci.n_e_cgs = kcov[1];
+        ci.nu_c_cgs = kcov[2];
+        ci.theta_e = kcov[3];
+        ci.kb_tt_e_cgs = __hiloint2double(__float_as_int(pr[3]), __float_as_int(pr[2]));
+        ci.cos2_theta_b = __hiloint2double(__float_as_int(pr[5]), __float_as_int(pr[4]));
+        ci.cos_sign = __hiloint2double(__float_as_int(pr[7]), __float_as_int(pr[6]));
+        ci.have_coefficients = 0.0;
+      }
       P.coef_inputs[idx_cur] = ci;
       continue;
     }
@@ -2534,6 +2539,29 @@ __global__ void __launch_bounds__(256, 2) bl_polarized_coefficients_kernel(const
   }
 }
 
+// The fluid frame of the samples without coefficients (polarized.cpp:163-265 at cut samples and cut or field-free cells):
+// k^mu and tetrad rows 1, 2 into their BlPolSample, from what the coefficient kernel parked in BlCoefInputs.
+__global__ void __launch_bounds__(256) bl_polarized_frame_kernel(const BlShadeArgs P) {
+  const unsigned long long n_records = P.counters_in[BL_CNT_RECORDS];
+  const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+  for (unsigned long long idx = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; idx < n_records; idx += stride) {
+    const double2 *hot = reinterpret_cast<const double2 *>(P.records_hot + idx);
+    const double2 q1 = hot[1];
+    const unsigned long long tag = (unsigned long long)__double_as_longlong(q1.y);   // (ray, n)
+    const uint32_t ray = (uint32_t)tag;
+    if (ray == BL_DEAD_RAY) continue;
+    const double2 *in = reinterpret_cast<const double2 *>(P.coef_inputs + idx);
+    const double2 c3 = in[3];
+    if (c3.y != 0.0) continue;   // have_coefficients: the coefficient kernel wrote the frame
+    const uint32_t n = (uint32_t)(tag >> 32);
+    const double2 q0 = hot[0], c0 = in[0], c1 = in[1], c2 = in[2];
+    const double kcov[4] = {c0.x, c0.y, c1.x, c1.y};
+    const float uu[3] = {__int_as_float(__double2loint(c2.x)), __int_as_float(__double2hiint(c2.x)), __int_as_float(__double2loint(c2.y))};
+    const float bb[3] = {__int_as_float(__double2hiint(c2.y)), __int_as_float(__double2loint(c3.x)), __int_as_float(__double2hiint(c3.x))};
+    bl_pol::sample_frame(P.st, P.plasma.simulation_coord, q0.x, q0.y, q1.x, kcov, uu, bb, P.pol_samples + ((size_t)ray * P.ray_max_steps + n));
+  }
+}
+
 // =================================================================================================
 // Transfer kernel
 // =================================================================================================
@@ -2913,6 +2941,7 @@ extern "C" hipError_t bl_launch_shade_fast(const BlShadeArgs *args, int grid, hi
 extern "C" hipError_t bl_launch_polarized_coefficients(const BlShadeArgs *args, int grid, hipStream_t stream) {
   if (args->tolerant) hipLaunchKernelGGL(bl_polarized_coefficients_kernel<true>, dim3(grid), dim3(256), 0, stream, *args);
   else hipLaunchKernelGGL(bl_polarized_coefficients_kernel<false>, dim3(grid), dim3(256), 0, stream, *args);
+  hipLaunchKernelGGL(bl_polarized_frame_kernel, dim3(grid), dim3(256), 0, stream, *args);
   return hipGetLastError();
 }
 

@@ -139,9 +139,8 @@ __device__ inline void tetrad_frame(const double ucon[4], const double ucov[4], 
   }
 }
 
-// polarized.cpp:163-265 for one sample: k^mu = g^{mu nu} k_nu and rows 1, 2 of the fluid tetrad. Kept out of line:
-// the coefficient kernel calls it on a rare branch only.
-static __device__ __noinline__ void sample_frame(const BlSpacetime &st, int coord, double x1, double x2, double x3, const double kcov[4],
+// polarized.cpp:163-265 for one sample: k^mu = g^{mu nu} k_nu and rows 1, 2 of the fluid tetrad (bl_polarized_frame_kernel)
+static __device__ __forceinline__ void sample_frame(const BlSpacetime &st, int coord, double x1, double x2, double x3, const double kcov[4],
                                           const float uu[3], const float bb[3], BlPolSample *out) {
   double gcov[4][4], gcon[4][4];
   geodesic_metric(st, x1, x2, x3, gcov, gcon);

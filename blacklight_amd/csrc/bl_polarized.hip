@@ -752,7 +752,7 @@ __global__ void __launch_bounds__(256, 2) bl_transport_matrix_kernel(BlTransferA
   __shared__ __attribute__((aligned(16))) unsigned char tiles_even[4 * kMkTileBytes];
   __shared__ __attribute__((aligned(16))) unsigned char tiles_odd[4 * kMkTileBytes];
   const BlSpacetime st = P.st;
-  const int lane = threadIdx.x & 63;
+  const int lane_fixed = threadIdx.x & 63;
   const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   unsigned char *const tile_even = tiles_even + wave_in_block * kMkTileBytes;
   unsigned char *const tile_odd = tiles_odd + wave_in_block * kMkTileBytes;
@@ -770,7 +770,7 @@ __global__ void __launch_bounds__(256, 2) bl_transport_matrix_kernel(BlTransferA
   };
   // slot q = lane + 64 j of the tile receives unit 8 i + ((r - i) & 7) of the segment, i = q / 8, r = q % 8 (clamped to the
   // ray's last record: always a valid address, never under a branch)
-  auto request = [&](unsigned char *tile, int slot_r, int base_r, int num_r) {
+  auto request = [&](unsigned char *tile, int lane, int slot_r, int base_r, int num_r) {
     const double2 *samples = reinterpret_cast<const double2 *>(P.pol_samples + (size_t)slot_r * P.ray_max_steps);
 #pragma unroll
     for (int j = 0; j < 9; j++) {
@@ -785,11 +785,15 @@ __global__ void __launch_bounds__(256, 2) bl_transport_matrix_kernel(BlTransferA
     }
   };
   if (!settle()) return;
-  request(tile_even, slot, base, num);
+  request(tile_even, lane_fixed, slot, base, num);
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the first tile has landed
   // one segment: arithmetic out of `tile` while the next segment travels into `tile_next`; returns false after the last one
   auto segment = [&](unsigned char *tile, unsigned char *tile_next) {
     const int slot_cur = slot, base_cur = base, num_cur = num;
+    // the lane number as the loop sees it: opaque, so that the two dozen tile offsets derived from it are recomputed (three
+    // integer instructions each) every segment instead of being hoisted out of the loop into registers that then spill
+    int lane = lane_fixed;
+    asm volatile("" : "+v"(lane));
     double2 *matrices = reinterpret_cast<double2 *>(P.pol_matrix + (size_t)slot_cur * P.ray_max_steps * BL_POL_MATRIX_DOUBLES);
     bool live;
     {
@@ -797,7 +801,7 @@ __global__ void __launch_bounds__(256, 2) bl_transport_matrix_kernel(BlTransferA
       base += 64;
       live = settle();
       // the next segment into the other tile (after the last segment: the current one again, into a tile nobody reads)
-      request(tile_next, live ? slot : slot_cur, live ? base : base_cur, live ? num : num_cur);
+      request(tile_next, lane, live ? slot : slot_cur, live ? base : base_cur, live ? num : num_cur);
       const int rec = base_cur + lane;
       double m[10], dn = 0.0;
       if (rec < num_cur) {
