@@ -1581,6 +1581,11 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
     sa.aux_need_coefficients = (p.image_light || p.image_emission || p.image_tau || ctx->aux_images.image_emission_ave
                                 || ctx->aux_images.image_tau_int) ? 1 : 0;   // simulation_coefficients.cpp:389
     sa.aux_need_length = (ctx->aux_images.image_length || fill_present) ? 1 : 0;
+    // polarized run with no per-sample row but tau and no rendering: tau is integrated by the polarized transfer kernel
+    const BlAuxImages &AI = ctx->aux_images;
+    const bool rows_only = ctx->polarized && ctx->render_num_images == 0 && !fill_present && !(AI.image_time || AI.image_length || AI.image_lambda
+        || AI.image_emission || AI.image_lambda_ave || AI.image_emission_ave || AI.image_tau_int || AI.image_crossings);
+    sa.aux_record_unused = rows_only ? 1 : 0;
     for (int mu = 0; mu < 4; mu++) sa.cam_x[mu] = ctx->frame.cam_x[mu];
 
     const double snapshot_time = slow ? p.slow_t_start + p.slow_dt * ctx->snapshot : 0.0;   // simulation_reader.cpp:214
@@ -1618,6 +1623,7 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
     xa.out_sample_num = out_num;
     xa.out_flags = out_flags;
     xa.aux_images = ctx->aux_images;
+    xa.aux_images.polarized_rows_only = rows_only ? 1 : 0;
     xa.x_unit = kGGMsun * ctx->frame.mass_msun / (kC * kC);
     xa.t_unit = xa.x_unit / kC;   // unpolarized.cpp:43
     xa.render_params = ctx->render_num_images > 0 ? ctx->d_render_params.ptr : nullptr;

@@ -186,6 +186,9 @@ struct BlAuxImages {
   int offset_lambda_ave, offset_emission_ave, offset_tau_int, offset_crossings;
   int n_q;
   int polarized;   // rows 4 l + (I, Q, U, V) written by the polarized transfer kernel instead of row l
+  int polarized_rows_only;   // polarized run whose only other row is tau (or none), no rendering: the polarized transfer kernel
+                             // accumulates tau beside the Stokes parameters, the auxiliary kernel keeps its bookkeeping only
+                             // and the coefficient kernel writes no BlAuxSample
 };
 
 // False-colour rendering parameters (rendering.cpp; a device buffer, too large for kernel arguments)
@@ -308,6 +311,7 @@ struct BlShadeArgs {
   unsigned long long redo_capacity;    // entries the list holds; more than that: the exact kernel shades every record
   int aux_need_coefficients;  // image_light || image_emission || image_tau || image_emission_ave || image_tau_int (:389)
   int aux_need_length;
+  int aux_record_unused;      // BlAuxImages::polarized_rows_only: nobody reads the BlAuxSample records
   double cam_x[4];
 };
 

@@ -1875,7 +1875,7 @@ __global__ void __launch_bounds__(256, 2) bl_shade_kernel(const BlShadeArgs P) {
         shade_formula(P, st, ks.r, x1, x2, x3, &sh);
     }
     double2 *out = P.transfer + ((size_t)ray * P.ray_max_steps + n) * P.n_nu;
-    if (kAux) {
+    if (kAux && !(kPolarized && P.aux_record_unused)) {
       BlAuxSample aux;
       aux.delta_lambda = delta_lambda;
       aux.t = P.sample_t != nullptr ? P.sample_t[idx_cur] : 0.0;
@@ -1903,11 +1903,11 @@ __global__ void __launch_bounds__(256, 2) bl_shade_kernel(const BlShadeArgs P) {
       const double nan = __longlong_as_double(0x7ff8000000000000ll);
       for (int a = 0; a < BL_NUM_CELL_VALUES; a++) aux.cell[a] = sh.have_cell ? sh.cell[a] : nan;
       P.aux[(size_t)ray * P.ray_max_steps + n] = aux;
-      if (kPolarized) {
-        BlPolSample *ps = P.pol_samples + ((size_t)ray * P.ray_max_steps + n);
-        ps->x[0] = x1; ps->x[1] = x2; ps->x[2] = x3;
-        ps->delta_lambda = delta_lambda;
-      }
+    }
+    if (kPolarized) {
+      BlPolSample *ps = P.pol_samples + ((size_t)ray * P.ray_max_steps + n);
+      ps->x[0] = x1; ps->x[1] = x2; ps->x[2] = x3;
+      ps->delta_lambda = delta_lambda;
     }
     if (kPolarized) {
       // polarized run (an auxiliary-image, extended, simulation-mode instantiation): the per-frequency formulas (Bessel functions, a dozen powers and exponentials) need few
@@ -2716,7 +2716,7 @@ __global__ void __launch_bounds__(64) bl_transfer_aux_kernel(BlTransferArgs P) {
       for (int n_i = 0; n_i < R.n_images; n_i++)
         for (int c = 0; c < 3; c++) P.render[(size_t)(n_i * 3 + c) * row + out_index] = rgb[n_i][c];
     }
-    for (int l = 0; l < (A.n_q > 0 ? P.n_nu : 0); l++) {
+    for (int l = 0; l < ((A.n_q > 0 && !A.polarized_rows_only) ? P.n_nu : 0); l++) {
       const double freq = P.frequencies[l];
       double intensity = 0.0, integrated_lambda = 0.0, integrated_emission = 0.0, tau = 0.0;
       double time_min = 0.0, length = 0.0;
@@ -2735,10 +2735,12 @@ __global__ void __launch_bounds__(64) bl_transfer_aux_kernel(BlTransferArgs P) {
         const double alpha = use_alpha ? c.y : nan;
         const double ss = j / alpha;
         const double delta_tau = alpha * delta_lambda_cgs;
-        const double exp_neg = bl_exp(-delta_tau);
-        const double expm1 = bl_expm1(delta_tau);
+        // (consumers: the intensity of an unpolarized run and tau_int; a polarized run integrates its Stokes rows elsewhere)
+        const bool need_exp = (A.image_light && !A.polarized) || A.image_tau_int;
+        const double exp_neg = need_exp ? bl_exp(-delta_tau) : 0.0;
+        const double expm1 = need_exp ? bl_expm1(delta_tau) : 0.0;
         const bool optically_thin = delta_tau <= kDeltaTauMax;
-        if (A.image_light) {
+        if (A.image_light && !A.polarized) {
           if (alpha > 0.0) {
             if (optically_thin)
               intensity = exp_neg * (intensity + ss * expm1);

@@ -461,7 +461,7 @@ __global__ void __launch_bounds__(64) bl_transfer_polarized_kernel(BlTransferArg
     // reference sample order is reversed integration order (geodesics.cpp:832-840): its n = 0 is record num - 1.
     // At n = 0 the "previous" connection and k^mu are the sample's own (:150-154, :167-169); averaging a value
     // with itself returns it, so the loop below needs no first-sample case.
-    double delta_lambda_old = 0.0;
+    double delta_lambda_old = 0.0, tau = 0.0;
     double kcon_old[4];
     {
       const BlPolSample s = samples[num - 1];
@@ -512,6 +512,7 @@ __global__ void __launch_bounds__(64) bl_transfer_polarized_kernel(BlTransferArg
       }
 
       couple_sample(&c, P.rotation_split != 0, delta_lambda_cgs, ss_start, ss_end);
+      tau += c.delta_tau;   // unpolarized.cpp:139-140 (BlAuxImages::polarized_rows_only: written below)
 
       // back to coordinates (:793-813), second half step (:816-833)
       from_stokes(s.e1, s.e2, ss_end, nn_con);
@@ -544,6 +545,7 @@ __global__ void __launch_bounds__(64) bl_transfer_polarized_kernel(BlTransferArg
       to_stokes(gcov, tetrad[1], tetrad[2], nn_con, ss);
       const double nu_cu = freq * freq * freq;
       for (int a = 0; a < 4; a++) img[(size_t)(4 * l + a) * row] = ss[a] * nu_cu;
+      if (P.aux_images.polarized_rows_only && P.aux_images.image_tau) img[(size_t)(P.aux_images.offset_tau + l) * row] = tau;
     }
   }
 }
@@ -935,7 +937,7 @@ __global__ void __launch_bounds__(64, 2) bl_transfer_polarized_matrix_kernel(BlT
       for (int a = 0; a < 4; a++) img[(size_t)(4 * l + a) * row] = 0.0;
       continue;
     }
-    double ss_end[4] = {0.0, 0.0, 0.0, 0.0};
+    double ss_end[4] = {0.0, 0.0, 0.0, 0.0}, tau = 0.0;
     for (int rec = num - 1; rec >= 0; rec--) {
       const double2 *mq = reinterpret_cast<const double2 *>(matrices + (size_t)rec * BL_POL_MATRIX_DOUBLES);
       const double2 m0 = mq[0], m1 = mq[1], m2 = mq[2], m3 = mq[3], m4 = mq[4];
@@ -960,12 +962,14 @@ __global__ void __launch_bounds__(64, 2) bl_transfer_polarized_matrix_kernel(BlT
 #else
       couple_sample(&c, P.rotation_split != 0, delta_lambda_cgs, ss_start, ss_end);
 #endif
+      tau += c.delta_tau;   // unpolarized.cpp:139-140 (BlAuxImages::polarized_rows_only: written below)
     }
     const double nu_cu = freq * freq * freq;
     img[(size_t)(4 * l + 0) * row] = (m_cam[0] * ss_end[0] + m_cam[1] * ss_end[1] + m_cam[2] * ss_end[2]) * nu_cu;
     img[(size_t)(4 * l + 1) * row] = (m_cam[3] * ss_end[0] + m_cam[4] * ss_end[1] + m_cam[5] * ss_end[2]) * nu_cu;
     img[(size_t)(4 * l + 2) * row] = (m_cam[6] * ss_end[0] + m_cam[7] * ss_end[1] + m_cam[8] * ss_end[2]) * nu_cu;
     img[(size_t)(4 * l + 3) * row] = (m_cam[9] * ss_end[3]) * nu_cu;
+    if (P.aux_images.polarized_rows_only && P.aux_images.image_tau) img[(size_t)(P.aux_images.offset_tau + l) * row] = tau;
   }
 }
 
