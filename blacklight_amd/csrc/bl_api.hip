@@ -1176,7 +1176,8 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
     const bool tolerant_polarized = ctx->arithmetic == BL_ARITH_TOLERANT && ctx->polarized;
     // ... and transport matrices (bl_transport_matrix_kernel) instead of the ray-sequential tensor transport, in curved spacetimes
     const bool matrix_transport = tolerant_polarized && !p.ray_flat;
-    const size_t redo_capacity = 1u << 20;
+    // (polarized runs list the samples without coefficients there - cut samples, cut cells - which are many more)
+    const size_t redo_capacity = ctx->polarized ? (1u << 24) : (1u << 20);
     // chunk size from the scratch budget: per ray max_steps * (2 x 32 B record + 40 B located sample
     // (simulation mode) + 16 B * n_nu transfer)
     const uint64_t per_ray = static_cast<uint64_t>(max_steps)
@@ -1241,7 +1242,7 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
         sl.d_coef_inputs.Ensure(record_capacity);
       }
       if (block_interp) sl.d_anchors.Ensure(record_capacity * 8);
-      if (fast) sl.d_redo.Ensure(redo_capacity);
+      if (fast || ctx->polarized) sl.d_redo.Ensure(redo_capacity);   // polarized runs: the samples whose frame bl_polarized_frame_kernel builds
     }
     EnsureChunkResources(ctx, n_chunks);
     ctx->d_freq.Ensure(n_nu);
@@ -1714,8 +1715,8 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
         xa.pol_matrix = matrix_transport ? sl.d_pol_matrix.ptr : nullptr;
       }
       sa.anchors = block_interp ? sl.d_anchors.ptr : nullptr;
-      sa.redo_list = fast ? sl.d_redo.ptr : nullptr;
-      sa.redo_capacity = fast ? redo_capacity : 0;
+      sa.redo_list = (fast || ctx->polarized) ? sl.d_redo.ptr : nullptr;
+      sa.redo_capacity = (fast || ctx->polarized) ? redo_capacity : 0;
       if (slow) {
         sa.slow.frac = sl.d_slow_frac.ptr;
         sa.slow.ray_extrap = ctx->d_ray_extrap.ptr + begin;
@@ -1933,7 +1934,7 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
       total_undefined += hc[BL_CNT_UNDEFINED];
       total_records += hc[BL_CNT_RECORDS];
       total_gathers += hc[BL_CNT_GATHERS];
-      total_redo += hc[BL_CNT_REDO];
+      if (fast) total_redo += hc[BL_CNT_REDO];   // (polarized runs use the list for something else: bl_polarized_frame_kernel)
       total_samples += hc[BL_CNT_COUNT + 0];
       total_flagged += hc[BL_CNT_COUNT + 1];
       max_num = std::max<unsigned long long>(max_num, hc[BL_CNT_COUNT + 2]);

@@ -1935,6 +1935,17 @@ __global__ void __launch_bounds__(256, 2) bl_shade_kernel(const BlShadeArgs P) {
         ci.cos2_theta_b = __hiloint2double(__float_as_int(pr[5]), __float_as_int(pr[4]));
         ci.cos_sign = __hiloint2double(__float_as_int(pr[7]), __float_as_int(pr[6]));
         ci.have_coefficients = 0.0;
+        // ... and listed for that kernel (the list of the tolerant tier's deferred records, unused in polarized runs): one
+        // atomic per wave for the lanes that are here; a full list makes the frame kernel scan every record instead
+        if (P.redo_list != nullptr) {
+          const unsigned long long here = __ballot(1);
+          const unsigned int rank = __builtin_amdgcn_mbcnt_hi((unsigned int)(here >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)here, 0u));
+          unsigned long long first = 0ull;
+          if (rank == 0u) first = atomicAdd(&P.counters[BL_CNT_REDO], (unsigned long long)__popcll(here));
+          const unsigned long long at = (((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(first >> 32)) << 32)
+                                         | (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)first)) + rank;
+          if (at < P.redo_capacity) P.redo_list[at] = idx_cur;
+        }
       }
       P.coef_inputs[idx_cur] = ci;
       continue;
@@ -2542,9 +2553,13 @@ __global__ void __launch_bounds__(256, 2) bl_polarized_coefficients_kernel(const
 // The fluid frame of the samples without coefficients (polarized.cpp:163-265 at cut samples and cut or field-free cells):
 // k^mu and tetrad rows 1, 2 into their BlPolSample, from what the coefficient kernel parked in BlCoefInputs.
 __global__ void __launch_bounds__(256) bl_polarized_frame_kernel(const BlShadeArgs P) {
-  const unsigned long long n_records = P.counters_in[BL_CNT_RECORDS];
+  const unsigned long long n_all = P.counters_in[BL_CNT_RECORDS];
+  const unsigned long long n_listed = P.redo_list != nullptr ? P.counters_in[BL_CNT_REDO] : ~0ull;
+  const bool listed = n_listed <= P.redo_capacity;   // else: more such samples than the list holds - look at every record
+  const unsigned long long n_items = listed ? n_listed : n_all;
   const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
-  for (unsigned long long idx = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; idx < n_records; idx += stride) {
+  for (unsigned long long pos = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; pos < n_items; pos += stride) {
+    const unsigned long long idx = listed ? P.redo_list[pos] : pos;
     const double2 *hot = reinterpret_cast<const double2 *>(P.records_hot + idx);
     const double2 q1 = hot[1];
     const unsigned long long tag = (unsigned long long)__double_as_longlong(q1.y);   // (ray, n)

@@ -23,10 +23,12 @@ p.update(camera_resolution=res, image_polarization=True, image_tau=True, adaptiv
          adaptive_abs_lapl_frac=-1.0, adaptive_rel_lapl_cut=1.0, adaptive_rel_lapl_frac=0.25, adaptive_num_regions=0)
 with bl.Context(bl.Params.from_dict(p)) as ctx:
     ctx.set_grid(grid)
+    ctx.set_arithmetic(os.environ.get("ARITH", "exact"))
+    ctx.render_adaptive()                      # first run: allocations
     t0 = time.perf_counter()
     levels = ctx.render_adaptive()
     sec = time.perf_counter() - t0
     rays = sum(int(lv["image"].shape[1]) for lv in levels)
-    print(json.dumps(dict(root_resolution=res, seconds=sec, levels=len(levels), rays=rays, mrays_per_s=rays / sec / 1e6,
+    print(json.dumps(dict(root_resolution=res, arithmetic=os.environ.get("ARITH", "exact"), seconds=sec, levels=len(levels), rays=rays, mrays_per_s=rays / sec / 1e6,
                           blocks_per_level=[int(lv["image"].shape[1]) // 64 for lv in levels],
                           finite_fraction=[float(np.isfinite(lv["image"]).mean()) for lv in levels]), indent=1))
