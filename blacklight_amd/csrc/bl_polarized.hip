@@ -455,9 +455,14 @@ __global__ void __launch_bounds__(64) bl_transfer_polarized_kernel(BlTransferArg
       for (int a = 0; a < 4; a++) img[(size_t)(4 * l + a) * row] = 0.0;
       continue;
     }
-    Cplx nn_con[4][4], nn_con_temp[4][4];
+    // N is carried from sample to sample. N_temp is not: after a sample it is what from_stokes made of that sample's final
+    // Stokes parameters and tetrad (the second half step copies N to N_temp before it advances N), so it is rebuilt from
+    // those twelve numbers - the same operations on the same operands, the same bits - instead of living in 64 registers.
+    Cplx nn_con[4][4];
     for (int mu = 0; mu < 4; mu++)
-      for (int nu = 0; nu < 4; nu++) nn_con[mu][nu] = nn_con_temp[mu][nu] = Cplx{0.0, 0.0};
+      for (int nu = 0; nu < 4; nu++) nn_con[mu][nu] = Cplx{0.0, 0.0};
+    double ss_carried[4] = {0.0, 0.0, 0.0, 0.0}, e1_carried[4] = {0.0, 0.0, 0.0, 0.0}, e2_carried[4] = {0.0, 0.0, 0.0, 0.0};
+    bool first_sample = true;
     // reference sample order is reversed integration order (geodesics.cpp:832-840): its n = 0 is record num - 1.
     // At n = 0 the "previous" connection and k^mu are the sample's own (:150-154, :167-169); averaging a value
     // with itself returns it, so the loop below needs no first-sample case.
@@ -496,9 +501,18 @@ __global__ void __launch_bounds__(64) bl_transfer_polarized_kernel(BlTransferArg
       connection_contractions(st, x1, x2, x3, ks, kcon, kcon_avg, connection_old, gk_avg, gk_new);
 
       // first half step (:171-198)
-      transport(gk_avg, (delta_lambda_old + delta_lambda) / 2.0, nn_con, nn_con_temp);
-      for (int mu = 0; mu < 4; mu++)
-        for (int nu = 0; nu < 4; nu++) nn_con[mu][nu] = nn_con_temp[mu][nu];
+      {
+        Cplx nn_con_temp[4][4];
+        if (first_sample) {
+          for (int mu = 0; mu < 4; mu++)
+            for (int nu = 0; nu < 4; nu++) nn_con_temp[mu][nu] = Cplx{0.0, 0.0};
+        } else {
+          from_stokes(e1_carried, e2_carried, ss_carried, nn_con_temp);
+        }
+        transport(gk_avg, (delta_lambda_old + delta_lambda) / 2.0, nn_con, nn_con_temp);
+        for (int mu = 0; mu < 4; mu++)
+          for (int nu = 0; nu < 4; nu++) nn_con[mu][nu] = nn_con_temp[mu][nu];
+      }
 
       // fluid frame: Stokes parameters before the coupling (:268-292)
       double ss_start[4], ss_end[4] = {0.0, 0.0, 0.0, 0.0};
@@ -515,10 +529,19 @@ __global__ void __launch_bounds__(64) bl_transfer_polarized_kernel(BlTransferArg
       tau += c.delta_tau;   // unpolarized.cpp:139-140 (BlAuxImages::polarized_rows_only: written below)
 
       // back to coordinates (:793-813), second half step (:816-833)
-      from_stokes(s.e1, s.e2, ss_end, nn_con);
-      for (int mu = 0; mu < 4; mu++)
-        for (int nu = 0; nu < 4; nu++) nn_con_temp[mu][nu] = nn_con[mu][nu];
-      transport(gk_new, (delta_lambda + delta_lambda_new) / 4.0, nn_con_temp, nn_con);
+      {
+        Cplx nn_con_temp[4][4];
+        from_stokes(s.e1, s.e2, ss_end, nn_con_temp);
+        for (int mu = 0; mu < 4; mu++)
+          for (int nu = 0; nu < 4; nu++) nn_con[mu][nu] = nn_con_temp[mu][nu];
+        transport(gk_new, (delta_lambda + delta_lambda_new) / 4.0, nn_con_temp, nn_con);
+      }
+      for (int a = 0; a < 4; a++) {
+        ss_carried[a] = ss_end[a];
+        e1_carried[a] = s.e1[a];
+        e2_carried[a] = s.e2[a];
+      }
+      first_sample = false;
 
       delta_lambda_old = delta_lambda;
       for (int mu = 0; mu < 4; mu++) kcon_old[mu] = kcon[mu];
