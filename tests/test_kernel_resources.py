@@ -14,7 +14,7 @@ RESOURCES = os.path.join(bl_build.OBJ, "bl_kernels.resources.txt")
 BENCHMARK_KERNELS = {
     "_Z18bl_geodesic_kernelILi0ELb0ELb1EEv11BlTraceArgs": (1, 0),        # Dormand-Prince, no sample times, zero spin
     "_Z18bl_geodesic_kernelILi0ELb0ELb0EEv11BlTraceArgs": (1, 0),        # ... any spin
-    "_Z16bl_locate_kernelILb0ELb0ELb1ELb0EEv11BlShadeArgs": (4, 0),          # merged grid, no slow light, zero spin
+    "_Z16bl_locate_kernelILb0ELb0ELb1ELb0EEv11BlShadeArgs": (4, 0),          # merged grid, no slow light, zero spin (at least 4)
     "_Z16bl_locate_kernelILb0ELb0ELb0ELb0EEv11BlShadeArgs": (4, 0),
     "_Z15bl_shade_kernelILi0ELb0ELb0ELb1ELb0ELb1ELb0EEv11BlShadeArgs": (2, 0),   # simulation, thermal electrons, SKS + curved, zero spin
     "_Z15bl_shade_kernelILi0ELb0ELb0ELb1ELb0ELb0ELb0EEv11BlShadeArgs": (2, 0),   # ... any spin
@@ -51,4 +51,17 @@ def test_benchmark_kernels_fit_their_registers(built_library):
         usage = kernels[name]
         assert usage["ScratchSize"] <= scratch, (name, usage)
         if occupancy is not None:
-            assert usage["Occupancy"] == occupancy, (name, usage)
+            assert usage["Occupancy"] >= occupancy, (name, usage)
+
+
+def test_no_kernel_needs_scratch_memory(built_library):
+    """Every kernel of both device translation units - all instantiations, polarized and slow-light ones included - keeps its
+    state in registers (and LDS): no private-segment memory, so no hidden memory traffic behind the measured numbers."""
+    if not os.path.exists(RESOURCES):
+        bl_build.build(force=True)
+    for path in (RESOURCES, os.path.join(bl_build.OBJ, "bl_polarized.resources.txt")):
+        text = open(path).read()
+        names = re.findall(r"remark: Function Name: (\S+)", text)
+        scratch = [int(v) for v in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", text)]
+        assert len(names) == len(scratch) and len(names) > 2
+        assert not any(scratch), {n: s for n, s in zip(names, scratch) if s}

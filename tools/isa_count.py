@@ -13,7 +13,7 @@ asm = os.path.join(OUT, "bl_kernels.s")
 src = os.path.join(REPO, "blacklight_amd", "csrc", "bl_kernels.hip")
 if not os.path.exists(asm) or os.path.getmtime(asm) < max(os.path.getmtime(os.path.join(REPO, "blacklight_amd", "csrc", f))
                                                           for f in os.listdir(os.path.join(REPO, "blacklight_amd", "csrc")) if f.endswith((".hip", ".h"))):
-    subprocess.run(["hipcc", "-S", "--offload-device-only", "--offload-arch=gfx950", "-std=c++17", "-O3", "-ffp-contract=off",
+    subprocess.run(["hipcc", "-S", "--offload-device-only", "--offload-arch=gfx950", "-std=c++17", "-O3", "-ffp-contract=off", "-mllvm", "-disable-machine-licm",
                     f"-I{REPO}/include", f"-I{REPO}/blacklight_amd/csrc", src, "-o", asm], check=True, capture_output=True)
 lines = open(asm).read().split("\n")
 filters = sys.argv[1:] or ["shade", "locate_kernelILb0ELb0", "geodesic_kernelILi0ELb0", "transfer_kernel"]
