@@ -26,7 +26,7 @@
 #include "bl_internal.h"
 
 extern "C" hipError_t bl_launch_geodesic(const BlTraceArgs *args, int integrator, int grid, hipStream_t stream);
-extern "C" int bl_geodesic_occupancy(int integrator);
+extern "C" int bl_geodesic_occupancy(int integrator, int with_time, int spin_zero);
 extern "C" hipError_t bl_launch_locate(const BlShadeArgs *args, int grid, int lds_bytes, hipStream_t stream);
 extern "C" hipError_t bl_launch_shade(const BlShadeArgs *args, int model, int grid, hipStream_t stream);
 extern "C" hipError_t bl_launch_shade_fast(const BlShadeArgs *args, int grid, hipStream_t stream);
@@ -1214,7 +1214,7 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
     const int n_chunks = static_cast<int>((n_rays + chunk - 1) / chunk);
     const int n_slots = (n_chunks > 1 && ctx->overlap_chunks) ? 2 : 1;
 
-    const int geo_blocks_per_cu = bl_geodesic_occupancy(p.ray_integrator);
+    const int geo_blocks_per_cu = bl_geodesic_occupancy(p.ray_integrator, need_time ? 1 : 0, ctx->st.bh_a == 0.0 ? 1 : 0);
     const int geo_grid = ctx->num_cus * geo_blocks_per_cu;   // persistent waves of the geodesic kernel
     const size_t record_capacity = static_cast<size_t>(chunk) * max_steps + static_cast<size_t>(geo_grid) * BL_RECORD_BLOCK;
     for (int k = 0; k < n_slots; k++) {

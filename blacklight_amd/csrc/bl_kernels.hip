@@ -161,8 +161,22 @@ __device__ __forceinline__ long long traversal_to_ray(long long q, int res, cons
 // kTime: also emit the coordinate time of every sample (P.sample_t, for image_time). Without it the time
 // component is only advanced, never sampled, which keeps its six stage derivatives out of the registers.
 // kSpinZero: bh_a == 0.0 known at compile time (bl_geometry.h, "zero spin"): same bits, no hypot.
+#ifndef BL_GEO_WAVES
+#define BL_GEO_WAVES 2
+#endif
+// A wave-uniform value the optimiser cannot see through (an empty instruction that claims to rewrite its scalar register)
+__device__ __forceinline__ int opaque_uniform(int v) {
+  asm volatile("" : "+s"(v));
+  return v;
+}
+__device__ __forceinline__ double opaque_uniform(double v) {
+  asm volatile("" : "+s"(v));
+  return v;
+}
 template <int kIntegrator, bool kTime, bool kSpinZero>
-__global__ void __launch_bounds__(64, 1) bl_geodesic_kernel(BlTraceArgs P) {
+// Two waves per SIMD where the state fits 256 registers (Dormand-Prince without sample times at zero spin - the benchmark's
+// instantiation - and the Runge-Kutta steppers); one wave with accumulation registers behind it where it does not.
+__global__ void __launch_bounds__(64, (kIntegrator == BL_INTEGRATOR_DP && (kTime || !kSpinZero)) ? 1 : BL_GEO_WAVES) bl_geodesic_kernel(BlTraceArgs P) {
   const int lane = wave_lane();
   const BlSpacetime st = P.st;
 
@@ -204,8 +218,16 @@ __global__ void __launch_bounds__(64, 1) bl_geodesic_kernel(BlTraceArgs P) {
           long long ray = traversal_to_ray(P.chunk_begin + (long long)q, P.swizzle_tiles, P.tile_order);
           long long pixel = P.pixel_map != nullptr ? (long long)P.pixel_map[ray] : ray;
           double u_ind, v_ind, position[4], direction[4], factor;
-          bl_pixel_indices(P.cam, pixel, P.block_locs, &u_ind, &v_ind);
-          bl_pixel_ray(st, P.cam, u_ind, v_ind, position, direction, &factor);
+          // The camera's resolution and the spin as this branch sees them: opaque copies, so that what depends on them alone
+          // ((double)resolution, resolution / 2, a^2) is computed here, where a ray starts, instead of before the loop and
+          // kept in registers through every step of every ray (same operations on the same values: same bits).
+          BlCameraDevice cam = P.cam;
+          cam.camera_resolution = opaque_uniform(cam.camera_resolution);
+          cam.effective_resolution = opaque_uniform(cam.effective_resolution);
+          BlSpacetime st_start = st;
+          st_start.bh_a = opaque_uniform(st.bh_a);
+          bl_pixel_indices(cam, pixel, P.block_locs, &u_ind, &v_ind);
+          bl_pixel_ray(st_start, cam, u_ind, v_ind, position, direction, &factor);
           P.ray_kt[slot] = direction[0];
           P.ray_factor[slot] = factor;
           P.ray_out_index[slot] = ray;
@@ -2873,20 +2895,23 @@ extern "C" hipError_t bl_launch_geodesic(const BlTraceArgs *args, int integrator
   return hipGetLastError();
 }
 
-extern "C" int bl_geodesic_occupancy(int integrator) {
+// Workgroups (= waves) of the geodesic kernel one CU holds: the persistent grid is this many per CU
+extern "C" int bl_geodesic_occupancy(int integrator, int with_time, int spin_zero) {
   int blocks = 0;
-  hipError_t err;
+  hipError_t err = hipSuccess;
+#define BL_OCCUPANCY_G(I)                                                                                                        \
+  do {                                                                                                                           \
+    if (with_time && spin_zero) err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, bl_geodesic_kernel<I, true, true>, 64, 0);   \
+    else if (with_time) err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, bl_geodesic_kernel<I, true, false>, 64, 0);          \
+    else if (spin_zero) err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, bl_geodesic_kernel<I, false, true>, 64, 0);          \
+    else err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, bl_geodesic_kernel<I, false, false>, 64, 0);                        \
+  } while (0)
   switch (integrator) {
-    case BL_INTEGRATOR_DP:
-      err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, bl_geodesic_kernel<BL_INTEGRATOR_DP, false, false>, 64, 0);
-      break;
-    case BL_INTEGRATOR_RK4:
-      err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, bl_geodesic_kernel<BL_INTEGRATOR_RK4, false, false>, 64, 0);
-      break;
-    default:
-      err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, bl_geodesic_kernel<BL_INTEGRATOR_RK2, false, false>, 64, 0);
-      break;
+    case BL_INTEGRATOR_DP: BL_OCCUPANCY_G(BL_INTEGRATOR_DP); break;
+    case BL_INTEGRATOR_RK4: BL_OCCUPANCY_G(BL_INTEGRATOR_RK4); break;
+    default: BL_OCCUPANCY_G(BL_INTEGRATOR_RK2); break;
   }
+#undef BL_OCCUPANCY_G
   if (err != hipSuccess || blocks < 1) blocks = 4;
   return blocks;
 }
