@@ -76,8 +76,10 @@ def test_tolerant_tier_on_the_goldens(case, built_library):
             assert gu.same_bits(tol["image"], exact["image"]).all()
             return
         # polarized runs: the per-frequency coefficient formulas (bl_polarized_coefficients_kernel) have a tolerant
-        # instantiation - fused multiply-adds, exp / log / pow / cbrt of the tolerant tier; frame, transport and coupling
-        # stay exact. pow(x, y) = exp(y log x) carries |y log x| ulps, hence the wider (still rounding-level) bound.
+        # instantiation - fused multiply-adds, exp / log / pow / cbrt of the tolerant tier - and the transport between two
+        # couplings is one 4 x 4 matrix per sample, built sample-parallel in closed form (bl_transport_matrix_kernel,
+        # DESIGN.md 5d), instead of the tensor walked along the ray; frame and coupling stay exact. pow(x, y) = exp(y log x)
+        # carries |y log x| ulps, hence the wider (still rounding-level) bound.
         assert tol["stats"].arithmetic == 1
         d_exact = _distance(tol["image"], exact["image"])
         d_b = _distance(tol["image"], gu.expected_image(fx, "B", n_pix))
