@@ -150,7 +150,19 @@ def test_polarized_frame_at_size_is_independent_of_how_it_is_split(built_library
     with bl.Context(p) as ctx:
         ctx.set_grid(grid)
         full = _split_property(ctx, 1024, 3, 32)
+        # the tolerant tier on the same frame - transport matrices instead of the tensor transport, rays of
+        # every length across the 64-sample segments of bl_transport_matrix_kernel: north_star's tolerance row by row
+        ctx.set_arithmetic("tolerant")
+        tolerant = ctx.render()
+        assert tolerant["stats"].arithmetic == 1
     image = full["image"]
+    assert np.array_equal(tolerant["sample_num"], full["sample_num"]) and np.array_equal(tolerant["sample_flags"], full["sample_flags"])
+    assert np.array_equal(np.isnan(tolerant["image"]), np.isnan(image))
+    for row, name in enumerate(["I", "Q", "U", "V", "tau"]):
+        scale = np.nanmax(np.abs(image[row]))
+        distance = np.nanmax(np.abs(tolerant["image"][row] - image[row])) / scale
+        print(f"polarized 1024^2, tolerant vs exact, row {name}: {distance:.2e} of the row's peak")
+        assert distance < 1.0e-6, name
     assert image.shape == (5, 1024 * 1024)
     ok = np.isfinite(image[0])
     assert ok.mean() > 0.999
