@@ -961,17 +961,29 @@ __global__ void __launch_bounds__(64, 2) bl_transfer_polarized_matrix_kernel(BlT
       continue;
     }
     double ss_end[4] = {0.0, 0.0, 0.0, 0.0}, tau = 0.0;
+    // the next sample's matrix and coefficients are requested before this sample's coupling (a lane walks its own ray: every
+    // load is a cache line of its own, and two waves per SIMD do not hide that on their own); clamped at the ray's near end
+    // so that the request is never under a branch
+    double2 n0, n1, n2, n3, n4, n5, nc0, nc1, nc2, nc3;
+    {
+      const double2 *mq = reinterpret_cast<const double2 *>(matrices + (size_t)(num - 1) * BL_POL_MATRIX_DOUBLES);
+      n0 = mq[0]; n1 = mq[1]; n2 = mq[2]; n3 = mq[3]; n4 = mq[4]; n5 = mq[5];
+      const size_t at = (size_t)(num - 1) * P.n_nu + l;
+      nc0 = ja[at]; nc1 = pc[at * 3 + 0]; nc2 = pc[at * 3 + 1]; nc3 = pc[at * 3 + 2];
+    }
     for (int rec = num - 1; rec >= 0; rec--) {
-      const double2 *mq = reinterpret_cast<const double2 *>(matrices + (size_t)rec * BL_POL_MATRIX_DOUBLES);
-      const double2 m0 = mq[0], m1 = mq[1], m2 = mq[2], m3 = mq[3], m4 = mq[4];
-      const double delta_lambda = mq[5].x;
+      const double2 m0 = n0, m1 = n1, m2 = n2, m3 = n3, m4 = n4;
+      const double delta_lambda = n5.x;
       Coupling c;
+      c.j_s[0] = nc0.x; c.j_s[1] = nc1.x; c.j_s[2] = 0.0; c.j_s[3] = nc1.y;
+      c.alpha_s[0] = nc0.y; c.alpha_s[1] = nc2.x; c.alpha_s[2] = 0.0; c.alpha_s[3] = nc2.y;
+      c.rho_s[0] = 0.0; c.rho_s[1] = nc3.x; c.rho_s[2] = 0.0; c.rho_s[3] = nc3.y;
       {
-        const size_t at = (size_t)rec * P.n_nu + l;
-        const double2 c0 = ja[at], c1 = pc[at * 3 + 0], c2 = pc[at * 3 + 1], c3 = pc[at * 3 + 2];
-        c.j_s[0] = c0.x; c.j_s[1] = c1.x; c.j_s[2] = 0.0; c.j_s[3] = c1.y;
-        c.alpha_s[0] = c0.y; c.alpha_s[1] = c2.x; c.alpha_s[2] = 0.0; c.alpha_s[3] = c2.y;
-        c.rho_s[0] = 0.0; c.rho_s[1] = c3.x; c.rho_s[2] = 0.0; c.rho_s[3] = c3.y;
+        const int next = rec > 0 ? rec - 1 : 0;
+        const double2 *mq = reinterpret_cast<const double2 *>(matrices + (size_t)next * BL_POL_MATRIX_DOUBLES);
+        n0 = mq[0]; n1 = mq[1]; n2 = mq[2]; n3 = mq[3]; n4 = mq[4]; n5 = mq[5];
+        const size_t at = (size_t)next * P.n_nu + l;
+        nc0 = ja[at]; nc1 = pc[at * 3 + 0]; nc2 = pc[at * 3 + 1]; nc3 = pc[at * 3 + 2];
       }
       double ss_start[4];
       ss_start[0] = m0.x * ss_end[0] + m0.y * ss_end[1] + m1.x * ss_end[2];
