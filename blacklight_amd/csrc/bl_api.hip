@@ -1692,6 +1692,7 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
       sa.records_cold = sl.d_records_cold.ptr;
       sa.located = simulation ? sl.d_located.ptr : nullptr;
       sa.located_tag = simulation ? sl.d_located_tag.ptr : nullptr;
+      sa.tag_in_record = fast ? 1 : 0;
       sa.counters_in = sl.d_counters.ptr;
       sa.counters = sl.d_counters.ptr;
       sa.ray_kt = sl.d_ray_kt.ptr;

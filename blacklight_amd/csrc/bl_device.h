@@ -281,6 +281,7 @@ struct BlShadeArgs {
   const BlSampleCold *records_cold;
   BlLocated *located;         // [record capacity], simulation mode
   unsigned long long *located_tag;   // [record capacity]: cell | status << 32 | time slice << 40
+  int tag_in_record;                 // tolerant tier: the tag is written into BlLocated::ph instead (32 bytes per sample, one stream)
   int lds_table_bytes;        // size of the coordinate tables the locate kernel stages in LDS; 0: searched in HBM
   int samples_renormalised;   // records come from a geodesic checkpoint: momenta as stored, no renormalisation per sample
   int tolerant;               // bl_set_arithmetic(BL_ARITH_TOLERANT): kernels that have a tolerant instantiation use it

@@ -1733,7 +1733,9 @@ __global__ void __launch_bounds__(256, 4) bl_locate_kernel(const BlShadeArgs P) 
       nq1 = src[1];
     }
     if (ray == BL_DEAD_RAY) {
-      P.located_tag[at] = 0ull;   // kSampleNone: the tolerant coefficient kernel requests corner cells from the tag alone
+      // kSampleNone: the tolerant coefficient kernel requests corner cells from the tag alone
+      if (P.tag_in_record) reinterpret_cast<double2 *>(P.located + at)[1] = make_double2(0.0, 0.0);
+      else P.located_tag[at] = 0ull;
       continue;
     }
     double r2;
@@ -1752,9 +1754,14 @@ __global__ void __launch_bounds__(256, 4) bl_locate_kernel(const BlShadeArgs P) 
     }
     if (!skip) locate_sample<kRefined, kSpinZero>(P, tab, st, x1, x2, x3, r, &loc, &gathers_local, P.anchors != nullptr ? P.anchors + at * 8 : nullptr);
     double2 *dst = reinterpret_cast<double2 *>(P.located + at);
+    const unsigned long long tag = (t_ind << 40) | ((unsigned long long)loc.status << 32) | loc.cell;
     dst[0] = make_double2(loc.f_i, loc.f_j);
-    dst[1] = make_double2(loc.f_k, loc.ph);
-    P.located_tag[at] = (t_ind << 40) | ((unsigned long long)loc.status << 32) | loc.cell;
+    if (P.tag_in_record) {   // tolerant tier: the tag rides in the azimuth's slot (the few samples the exact kernel re-does
+      dst[1] = make_double2(loc.f_k, __longlong_as_double((long long)tag));   // recompute the azimuth): 32 bytes, one stream
+    } else {
+      dst[1] = make_double2(loc.f_k, loc.ph);
+      P.located_tag[at] = tag;
+    }
   }
   // S_in accounting: one atomic per wave
   for (int offset = 32; offset > 0; offset >>= 1) gathers_local += __shfl_xor(gathers_local, offset, 64);
@@ -1795,7 +1802,7 @@ __global__ void __launch_bounds__(256, 2) bl_shade_kernel(const BlShadeArgs P) {
     if (kModel == BL_MODEL_SIMULATION) {
       const double2 *loc = reinterpret_cast<const double2 *>(P.located + idx);
       nl0 = loc[0]; nl1 = loc[1];
-      ntag = P.located_tag[idx];
+      ntag = kRedo ? (unsigned long long)__double_as_longlong(nl1.y) : P.located_tag[idx];
     }
   }
   for (bool more = true; more;) {
@@ -1840,7 +1847,7 @@ __global__ void __launch_bounds__(256, 2) bl_shade_kernel(const BlShadeArgs P) {
       if (kModel == BL_MODEL_SIMULATION) {
         const double2 *loc = reinterpret_cast<const double2 *>(P.located + idx);
         nl0 = loc[0]; nl1 = loc[1];
-        ntag = P.located_tag[idx];
+        ntag = kRedo ? (unsigned long long)__double_as_longlong(nl1.y) : P.located_tag[idx];
       }
     }
     if (!live) continue;
@@ -1849,6 +1856,9 @@ __global__ void __launch_bounds__(256, 2) bl_shade_kernel(const BlShadeArgs P) {
     // functions; identical inputs, identical bits)
     BlKerrSchild ks;
     bl_kerr_schild<kSpinZero>(st, x1, x2, x3, &ks);   // r^2 as the locate kernel computed it: same operations, same bits
+    // second pass of the tolerant tier: the record carries the tag where the azimuth would be; the azimuth as the locate
+    // kernel computes it (locate_sample: same functions of the same x, y, r - same bits)
+    if (kRedo && kModel == BL_MODEL_SIMULATION) ph = kSpinZero ? bl_atan2(x2, x1) : bl_atan2(x2, x1) - bl_atan(st.bh_a / ks.r);
     if (kModel == BL_MODEL_FORMULA) {
       bool skip = ks.r > P.cuts.camera_r;                              // formula_coefficients.cpp:78-116
       if (!skip && P.cuts.any_optional) skip = optional_cuts(*P.cold, x1, x2, x3, ks.r);
@@ -2370,13 +2380,11 @@ struct FastRay {
   double2 q0, q1, q2, q3;
 };
 __device__ __forceinline__ void fast_load_located(const BlShadeArgs &P, unsigned long long idx, FastLocated &r) {
-  // f_i, f_j, f_k only: the azimuth is not used in this tier, and a load into a register nobody reads is worse than
-  // wasted - the allocator reuses the register at once, and that write has to wait for the load (and every load before it)
-  const double *loc = reinterpret_cast<const double *>(P.located + idx);
-  r.l0 = *reinterpret_cast<const double2 *>(loc);
-  r.l1.x = loc[2];
-  r.l1.y = 0.0;
-  r.tag = P.located_tag[idx];
+  // f_i, f_j | f_k, tag: the locate kernel writes the tag where the exact tier keeps the azimuth (BlShadeArgs::tag_in_record)
+  const double2 *loc = reinterpret_cast<const double2 *>(P.located + idx);
+  r.l0 = loc[0];
+  r.l1 = loc[1];
+  r.tag = (unsigned long long)__double_as_longlong(r.l1.y);
 }
 __device__ __forceinline__ void fast_load_ray(const BlShadeArgs &P, unsigned long long idx, FastRay &r) {
   const double2 *hot = reinterpret_cast<const double2 *>(P.records_hot + idx);
