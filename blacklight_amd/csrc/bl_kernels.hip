@@ -164,6 +164,12 @@ __device__ __forceinline__ long long traversal_to_ray(long long q, int res, cons
 #ifndef BL_GEO_WAVES
 #define BL_GEO_WAVES 2
 #endif
+// Instantiations held at one wave per SIMD (none: the Dormand-Prince stepper with spin or sample times needs 36-88 bytes of
+// scratch per lane at two waves - four to eleven doubles reloaded inside a ~6 000-instruction step - and is still 8 %
+// faster there than with one wave and accumulation registers: 33.8 -> 31.2 ms for the benchmark frame at a = 0.94)
+#ifndef BL_GEO_ONE_WAVE
+#define BL_GEO_ONE_WAVE(integrator, with_time, spin_zero) false
+#endif
 // A wave-uniform value the optimiser cannot see through (an empty instruction that claims to rewrite its scalar register)
 __device__ __forceinline__ int opaque_uniform(int v) {
   asm volatile("" : "+s"(v));
@@ -174,9 +180,9 @@ __device__ __forceinline__ double opaque_uniform(double v) {
   return v;
 }
 template <int kIntegrator, bool kTime, bool kSpinZero>
-// Two waves per SIMD where the state fits 256 registers (Dormand-Prince without sample times at zero spin - the benchmark's
-// instantiation - and the Runge-Kutta steppers); one wave with accumulation registers behind it where it does not.
-__global__ void __launch_bounds__(64, (kIntegrator == BL_INTEGRATOR_DP && (kTime || !kSpinZero)) ? 1 : BL_GEO_WAVES) bl_geodesic_kernel(BlTraceArgs P) {
+// Two waves per SIMD: the benchmark's instantiation (Dormand-Prince, no sample times, zero spin) and the Runge-Kutta steppers
+// fit 256 registers; see BL_GEO_ONE_WAVE for the others.
+__global__ void __launch_bounds__(64, BL_GEO_ONE_WAVE(kIntegrator, kTime, kSpinZero) ? 1 : BL_GEO_WAVES) bl_geodesic_kernel(BlTraceArgs P) {
   const int lane = wave_lane();
   const BlSpacetime st = P.st;
 
