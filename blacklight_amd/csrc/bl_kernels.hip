@@ -2165,6 +2165,63 @@ __device__ __forceinline__ double pow_of(PowBase b, double y) {
 }
 __device__ __forceinline__ double div(double a, double b) { return a * rcp(b); }
 
+// K_0, K_1, K_2 of one argument: bl_cyl_bessel_k012's algorithm (Temme's series below 2, Steed's continued fraction above,
+// the same stopping rules) with the tier's logarithm, exponential and reciprocals in place of the pinned functions and the
+// IEEE divisions (a dozen per term there). x finite and positive (1 / Theta_e with Theta_e >= 0.01).
+__device__ __forceinline__ void bessel_k012(double x, double *k0, double *k1, double *k2) {
+  const double eps = 0x1p-52;
+  const double xi = rcp(x);
+  double kmu, knu1;
+  if (x < 2.0) {
+    const double x2 = 0.5 * x;
+    const double d = -log(x2);
+    double ff = -0.57721566490153286 + d;
+    double sum = ff, p = 0.5, q = 0.5, c = 1.0, sum1 = 0.5;
+    const double dd = x2 * x2;
+    for (int i = 1; i <= 15000; ++i) {
+      const double di = (double)i, inv_i = rcp(di);
+      ff = (di * ff + p + q) * (inv_i * inv_i);
+      c *= dd * inv_i;
+      p *= inv_i;
+      q *= inv_i;
+      const double del = c * ff;
+      sum += del;
+      sum1 += c * (p - di * ff);
+      if (__builtin_fabs(del) < eps * __builtin_fabs(sum)) break;
+    }
+    kmu = sum;
+    knu1 = sum1 * (2.0 * xi);
+  } else {
+    double b = 2.0 * (1.0 + x);
+    double d = rcp(b);
+    double delh = d, h = d, q1 = 0.0, q2 = 1.0;
+    const double a1 = 0.25;
+    double c = a1, q = a1, a = -a1;
+    double s = 1.0 + q * delh;
+    for (int i = 2; i <= 15000; ++i) {
+      a -= (double)(2 * (i - 1));
+      c = -a * c * rcp((double)i);
+      const double qnew = (q1 - b * q2) * rcp(a);
+      q1 = q2;
+      q2 = qnew;
+      q += c * qnew;
+      b += 2.0;
+      d = rcp(b + a * d);
+      delh = (b * d - 1.0) * delh;
+      h += delh;
+      const double dels = q * delh;
+      s += dels;
+      if (__builtin_fabs(dels) < eps * __builtin_fabs(s)) break;
+    }
+    h = a1 * h;
+    kmu = bl_sqrt_g(3.141592653589793 * 0.5 * xi) * exp(-x) * rcp(s);
+    knu1 = kmu * (x + 0.5 - h) * xi;
+  }
+  *k0 = kmu;
+  *k1 = knu1;
+  *k2 = 2.0 * xi * knu1 + kmu;
+}
+
 }  // namespace fastmath
 
 // tolerant arithmetic tier of the coefficient formulas (sin, cos, tanh keep the pinned versions: few calls, and their
@@ -2563,7 +2620,10 @@ __global__ void __launch_bounds__(256, 2) bl_polarized_coefficients_kernel(const
     sh.theta_e_096 = sh.kk_0 = sh.kk_1 = sh.kk_2 = 0.0;
     if (sh.have_coefficients && P.plasma.plasma_thermal_frac != 0.0) {
       sh.theta_e_096 = kTolerant ? fastmath::pow(sh.theta_e, 0.96) : bl_pow(sh.theta_e, 0.96);
-      if (sh.theta_e >= 0.01) bl_cyl_bessel_k012(1.0 / sh.theta_e, &sh.kk_0, &sh.kk_1, &sh.kk_2);   // theta_e_zero, radiation_integrator.hpp:190
+      if (sh.theta_e >= 0.01) {   // theta_e_zero, radiation_integrator.hpp:190
+        if (kTolerant) fastmath::bessel_k012(1.0 / sh.theta_e, &sh.kk_0, &sh.kk_1, &sh.kk_2);
+        else bl_cyl_bessel_k012(1.0 / sh.theta_e, &sh.kk_0, &sh.kk_1, &sh.kk_2);
+      }
     }
     const size_t at = ((size_t)ray * P.ray_max_steps + n) * P.n_nu;
     for (int l = 0; l < P.n_nu; l++) {
@@ -2877,6 +2937,12 @@ __global__ void bl_debug_math_kernel(int op, long long n, const double *x, const
     case 16: bl_sincos(a, &r, &c_unused); break;
     case 17: bl_sincos(a, &s_unused, &r); break;
     // tolerant tier's functions (not bit-reproducible by contract; accuracy is what the tests check)
+    case 25: case 26: case 27: {
+      double k0, k1, k2;
+      fastmath::bessel_k012(a, &k0, &k1, &k2);
+      r = op == 25 ? k0 : (op == 26 ? k1 : k2);
+      break;
+    }
     case 20: r = fastmath::exp(a); break;
     case 21: r = fastmath::expm1(a); break;
     case 22: r = fastmath::cbrt(a); break;

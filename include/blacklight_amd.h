@@ -359,8 +359,8 @@ BL_API int bl_render(bl_ctx *ctx, const bl_render_desc *d);
 BL_API int bl_debug_math(bl_ctx *ctx, int op, int64_t n, const double *x, const double *y, double *out);
 /* Tolerant tier, tests only: relative half-width of the band around an active cell cut threshold inside which the cut
  * decision of a sample is left to the exact kernel (default 1e-9; the tolerant arithmetic is good to ~1e-13). A wide band
- * defers many samples, which exercises the list and its overflow path. ops 20-24 of bl_debug_math are the tolerant
- * tier's exp, expm1, cbrt, reciprocal and reciprocal square root. */
+ * defers many samples, which exercises the list and its overflow path. ops 20-27 of bl_debug_math are the tolerant
+ * tier's exp, expm1, cbrt, reciprocal, reciprocal square root and K_0, K_1, K_2. */
 BL_API int bl_debug_set_guard_band(bl_ctx *ctx, double relative_width);
 BL_API int bl_get_stats(const bl_ctx *ctx, bl_stats *out);
 /* Text of the last failure on this context ("Error: ...\n"), or "" */

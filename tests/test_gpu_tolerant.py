@@ -159,7 +159,8 @@ def test_deferred_cut_decisions(band, resolution, built_library):
 
 
 def test_tolerant_functions_are_accurate(built_library):
-    """exp, expm1, cbrt, reciprocal and reciprocal square root of the tolerant tier against numpy's long double."""
+    """exp, expm1, cbrt, reciprocal and reciprocal square root of the tolerant tier against numpy's long double, its Bessel
+    functions against scipy."""
     import blacklight_amd as bl
     fx, params, _ = gu.load_case("formula_flat")
     rng = np.random.default_rng(3)
@@ -190,6 +191,14 @@ def test_tolerant_functions_are_accurate(built_library):
         assert sat[0] == -1.0 and sat[1] == np.inf and np.isnan(sat[2]) and sat[3] == 0.0
         rc = ctx.debug_math(23, np.array([0.0, np.inf, -np.inf, np.nan]))
         assert rc[0] == np.inf and rc[1] == 0.0 and rc[2] == 0.0 and np.isnan(rc[3])
+        # K_0, K_1, K_2 (ops 25-27) over the arguments 1 / Theta_e takes (Theta_e from 0.01 to 1e4), against scipy
+        from scipy import special as sp
+        xb = np.concatenate([10.0 ** rng.uniform(-4.0, 2.0, 100000), rng.uniform(1.5, 2.5, 20000)])
+        for op, order in ((25, 0), (26, 1), (27, 2)):
+            got = ctx.debug_math(op, xb)
+            want = sp.kn(order, xb)
+            ok = want > 1.0e-300
+            assert np.max(np.abs(got[ok] / want[ok] - 1.0)) < 5.0e-14, order
 
 
 WINDOWS = os.path.join(gu.GOLDEN_DIR, "window_1024.npz")
