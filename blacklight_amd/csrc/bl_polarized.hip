@@ -243,26 +243,38 @@ struct Coupling {
   bool optically_thin;
 };
 
+// The elementary functions of the coupling: the pinned library in the exact tier, the tolerant tier's in its sequential kernel
+// (CouplingMathTolerant, further down). The formulas around them are the same text for both.
+struct CouplingMathExact {
+  static __device__ __forceinline__ double exp(double x) { return bl_exp(x); }
+  static __device__ __forceinline__ double expm1(double x) { return bl_expm1(x); }
+  static __device__ __forceinline__ double sinh(double x) { return bl_sinh(x); }
+  static __device__ __forceinline__ double cosh(double x) { return bl_cosh(x); }
+  static __device__ __forceinline__ double sin(double x) { return bl_sin(x); }
+  static __device__ __forceinline__ double cos(double x) { return bl_cos(x); }
+};
+
 // Emission and absorption over a length dl without rotation (I A14-A17 and its limits; :391-451, :580-654)
+template <typename M>
 __device__ void absorb(const Coupling &c, double dl, double dtau, const double ss_start[4], double ss_end[4]) {
   const double *j_s = c.j_s, *alpha_s = c.alpha_s;
   if (alpha_s[0] == 0.0) {
     for (int a = 0; a < 4; a++) ss_end[a] = ss_start[a] + j_s[a] * dl;
   } else if (c.alpha_p == 0.0) {
     if (c.optically_thin) {
-      const double exp_neg = bl_exp(-dtau);
-      const double expm1 = bl_expm1(dtau);
+      const double exp_neg = M::exp(-dtau);
+      const double expm1 = M::expm1(dtau);
       for (int a = 0; a < 4; a++) ss_end[a] = exp_neg * (ss_start[a] + j_s[a] / alpha_s[0] * expm1);
     } else {
       for (int a = 0; a < 4; a++) ss_end[a] = j_s[a] / alpha_s[0];
     }
   } else if (c.optically_thin) {
     const double alpha_p = c.alpha_p, alpha_sq = c.alpha_sq;
-    const double exp_neg_i = bl_exp(-dtau);
-    const double exp_neg_p = bl_exp(-alpha_p * dl);
-    const double sinh_p = bl_sinh(alpha_p * dl);
-    const double cosh_p = bl_cosh(alpha_p * dl);
-    const double coshm1_p = 0.5 * (bl_expm1(alpha_p * dl) + exp_neg_p - 1.0);
+    const double exp_neg_i = M::exp(-dtau);
+    const double exp_neg_p = M::exp(-alpha_p * dl);
+    const double sinh_p = M::sinh(alpha_p * dl);
+    const double cosh_p = M::cosh(alpha_p * dl);
+    const double coshm1_p = 0.5 * (M::expm1(alpha_p * dl) + exp_neg_p - 1.0);
     const double alpha_ss = alpha_s[1] * ss_start[1] + alpha_s[3] * ss_start[3];
     const double alpha_j = alpha_s[1] * j_s[1] + alpha_s[3] * j_s[3];
     const double alpha_i_p_factor = 1.0 / (alpha_s[0] * alpha_s[0] - alpha_sq);
@@ -287,11 +299,12 @@ __device__ void absorb(const Coupling &c, double dl, double dtau, const double s
 }
 
 // Faraday rotation and conversion over the whole step without absorption (I A2-A5; :470-486, :598-612)
+template <typename M>
 __device__ void rotate(const Coupling &c, const double ss_start[4], double ss_end[4]) {
   const double *rho_s = c.rho_s;
-  const double cos_rho = bl_cos(c.rho_p * c.delta_lambda_cgs);
-  const double sin_rho = bl_sin(c.rho_p * c.delta_lambda_cgs);
-  double sin_sq_rho = bl_sin(c.rho_p * c.delta_lambda_cgs / 2.0);
+  const double cos_rho = M::cos(c.rho_p * c.delta_lambda_cgs);
+  const double sin_rho = M::sin(c.rho_p * c.delta_lambda_cgs);
+  double sin_sq_rho = M::sin(c.rho_p * c.delta_lambda_cgs / 2.0);
   sin_sq_rho = sin_sq_rho * sin_sq_rho;
   const double rho_ss = rho_s[1] * ss_start[1] + rho_s[3] * ss_start[3];
   ss_end[0] = ss_start[0];
@@ -312,6 +325,7 @@ __device__ void limit_polarization(double ss[4]) {
 
 // Absorption and rotation together (L 10, I 24; :657-778). The coupling matrices are built exactly as the
 // reference writes them: entry [1][2] of matrices 2 and 3 is assigned twice and [0][2], [1][3], [2][3] stay zero.
+template <typename M>
 __device__ void couple_jointly(const Coupling &c, const double ss_start[4], double ss_end[4]) {
   const double *j_s = c.j_s, *alpha_s = c.alpha_s, *rho_s = c.rho_s;
   const double alpha_sq = c.alpha_sq, rho_sq = c.rho_sq;
@@ -367,11 +381,11 @@ __device__ void couple_jointly(const Coupling &c, const double ss_start[4], doub
     for (int b = 0; b < 4; b++) mm_4[a][b] *= 2.0 / coefficient_theta;
   double exp_v = 0.0, sin_v = 0.0, cos_v = 0.0, sinh_v = 0.0, cosh_v = 0.0;
   if (c.optically_thin) {
-    exp_v = bl_exp(-c.delta_tau);
-    sin_v = bl_sin(lambda_2 * c.delta_lambda_cgs);
-    cos_v = bl_cos(lambda_2 * c.delta_lambda_cgs);
-    sinh_v = bl_sinh(lambda_1 * c.delta_lambda_cgs);
-    cosh_v = bl_cosh(lambda_1 * c.delta_lambda_cgs);
+    exp_v = M::exp(-c.delta_tau);
+    sin_v = M::sin(lambda_2 * c.delta_lambda_cgs);
+    cos_v = M::cos(lambda_2 * c.delta_lambda_cgs);
+    sinh_v = M::sinh(lambda_1 * c.delta_lambda_cgs);
+    cosh_v = M::cosh(lambda_1 * c.delta_lambda_cgs);
   }
   const double f_1 = 1.0 / (alpha_s[0] * alpha_s[0] - lambda_1 * lambda_1);
   const double f_2 = 1.0 / (alpha_s[0] * alpha_s[0] + lambda_2 * lambda_2);
@@ -396,6 +410,7 @@ __device__ void couple_jointly(const Coupling &c, const double ss_start[4], doub
 
 // The coupling of one sample (:388-779) with its guards (:781-790): rotation split from emission / absorption, or the
 // analytic cases. c holds the coefficients on entry; the derived quantities are filled in here.
+template <typename M>
 __device__ __forceinline__ void couple_sample(Coupling *cp, bool rotation_split, double delta_lambda_cgs, double ss_start[4], double ss_end[4]) {
   Coupling &c = *cp;
   c.delta_lambda_cgs = delta_lambda_cgs;
@@ -406,25 +421,25 @@ __device__ __forceinline__ void couple_sample(Coupling *cp, bool rotation_split,
   c.rho_sq = c.rho_s[1] * c.rho_s[1] + c.rho_s[3] * c.rho_s[3];
   c.rho_p = blm_sqrt(c.rho_sq);
   if (rotation_split) {   // :388-568
-    absorb(c, delta_lambda_cgs / 2.0, c.delta_tau / 2.0, ss_start, ss_end);
+    absorb<M>(c, delta_lambda_cgs / 2.0, c.delta_tau / 2.0, ss_start, ss_end);
     ss_end[0] = (ss_end[0] < 0.0) ? 0.0 : ss_end[0];   // std::max(ss_end[0], 0.0)
     limit_polarization(ss_end);
     for (int a = 0; a < 4; a++) ss_start[a] = ss_end[a];
-    if (c.rho_p != 0.0) rotate(c, ss_start, ss_end);
+    if (c.rho_p != 0.0) rotate<M>(c, ss_start, ss_end);
     limit_polarization(ss_end);
     for (int a = 0; a < 4; a++) ss_start[a] = ss_end[a];
-    absorb(c, delta_lambda_cgs / 2.0, c.delta_tau / 2.0, ss_start, ss_end);
+    absorb<M>(c, delta_lambda_cgs / 2.0, c.delta_tau / 2.0, ss_start, ss_end);
   } else if (c.alpha_s[0] == 0.0 && c.rho_p == 0.0) {
     for (int a = 0; a < 4; a++) ss_end[a] = ss_start[a] + c.j_s[a] * delta_lambda_cgs;
   } else if (c.alpha_p == 0.0 && c.rho_p == 0.0) {
-    absorb(c, delta_lambda_cgs, c.delta_tau, ss_start, ss_end);
+    absorb<M>(c, delta_lambda_cgs, c.delta_tau, ss_start, ss_end);
   } else if (c.alpha_s[0] == 0.0) {
-    rotate(c, ss_start, ss_end);
+    rotate<M>(c, ss_start, ss_end);
     for (int a = 0; a < 4; a++) ss_end[a] += c.j_s[a] * delta_lambda_cgs;
   } else if (c.rho_p == 0.0) {
-    absorb(c, delta_lambda_cgs, c.delta_tau, ss_start, ss_end);
+    absorb<M>(c, delta_lambda_cgs, c.delta_tau, ss_start, ss_end);
   } else {
-    couple_jointly(c, ss_start, ss_end);
+    couple_jointly<M>(c, ss_start, ss_end);
   }
   // std::max(ss_end[0], 0.0) (:781): (a < b) ? b : a, so a NaN intensity stays NaN
   ss_end[0] = (ss_end[0] < 0.0) ? 0.0 : ss_end[0];
@@ -525,7 +540,7 @@ __global__ void __launch_bounds__(64) bl_transfer_polarized_kernel(BlTransferArg
         to_stokes(gcov, s.e1, s.e2, nn_con, ss_start);
       }
 
-      couple_sample(&c, P.rotation_split != 0, delta_lambda_cgs, ss_start, ss_end);
+      couple_sample<CouplingMathExact>(&c, P.rotation_split != 0, delta_lambda_cgs, ss_start, ss_end);
       tau += c.delta_tau;   // unpolarized.cpp:139-140 (BlAuxImages::polarized_rows_only: written below)
 
       // back to coordinates (:793-813), second half step (:816-833)
@@ -605,17 +620,28 @@ extern "C" hipError_t bl_launch_transfer_polarized(const BlTransferArgs *args, h
 #pragma clang fp contract(fast)
 
 namespace {
-namespace fastpol {
+#include "bl_fastmath.h"
 
-// 1 / b: v_rcp_f64 + two Newton steps (~1 ulp); v_div_fixup restores 1 / 0, 1 / inf and NaN
-__device__ __forceinline__ double rcp(double b) {
-  double y = __builtin_amdgcn_rcp(b);
-  double e = __builtin_fma(-b, y, 1.0);
-  y = __builtin_fma(y, e, y);
-  e = __builtin_fma(-b, y, 1.0);
-  y = __builtin_fma(y, e, y);
-  return __builtin_amdgcn_div_fixup(y, b, 1.0);
-}
+// exp, expm1 and the hyperbolic functions of the coupling from the tier's exponential core; sine and cosine stay the pinned
+// ones (Faraday-thick samples hand them arguments of any size: they need the real range reduction)
+struct CouplingMathTolerant {
+  static __device__ __forceinline__ double exp(double x) { return fastmath::exp(x); }
+  static __device__ __forceinline__ double expm1(double x) { return fastmath::expm1(x); }
+  static __device__ __forceinline__ double sinh(double x) {   // (e^x - e^-x) / 2 through expm1: no cancellation near 0
+    const double em = fastmath::expm1(x);
+    const double inv = fastmath::rcp(em + 1.0);                     // e^-x; 0 once e^x has overflowed
+    return 0.5 * (em + (inv == 0.0 ? 1.0 : em * inv));              // (e^x - 1) + (1 - e^-x)
+  }
+  static __device__ __forceinline__ double cosh(double x) {
+    const double e = fastmath::exp(x);
+    return 0.5 * (e + fastmath::rcp(e));
+  }
+  static __device__ __forceinline__ double sin(double x) { return bl_sin(x); }
+  static __device__ __forceinline__ double cos(double x) { return bl_cos(x); }
+};
+
+namespace fastpol {
+using fastmath::rcp;
 
 // f, l_i and their spatial derivatives at a point (radiation_geometry.cpp:283-330 in closed form with shared reciprocals)
 struct PointGeometry {
@@ -995,7 +1021,7 @@ __global__ void __launch_bounds__(64, 2) bl_transfer_polarized_matrix_kernel(BlT
 #ifdef BL_TPS_NOCOUPLE
       for (int a = 0; a < 4; a++) ss_end[a] = ss_start[a] + c.j_s[a] * delta_lambda_cgs + c.alpha_s[a] + c.rho_s[a];
 #else
-      couple_sample(&c, P.rotation_split != 0, delta_lambda_cgs, ss_start, ss_end);
+      couple_sample<CouplingMathTolerant>(&c, P.rotation_split != 0, delta_lambda_cgs, ss_start, ss_end);
 #endif
       tau += c.delta_tau;   // unpolarized.cpp:139-140 (BlAuxImages::polarized_rows_only: written below)
     }
