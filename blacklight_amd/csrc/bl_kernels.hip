@@ -164,11 +164,12 @@ __device__ __forceinline__ long long traversal_to_ray(long long q, int res, cons
 #ifndef BL_GEO_WAVES
 #define BL_GEO_WAVES 2
 #endif
-// Instantiations held at one wave per SIMD (none: the Dormand-Prince stepper with spin or sample times needs 36-88 bytes of
-// scratch per lane at two waves - four to eleven doubles reloaded inside a ~6 000-instruction step - and is still 8 %
-// faster there than with one wave and accumulation registers: 33.8 -> 31.2 ms for the benchmark frame at a = 0.94)
+// Instantiations held at one wave per SIMD: the Dormand-Prince stepper with spin or sample times. At two waves it needs 36-88
+// bytes of scratch per lane, and although a frame with many rays per lane still gains (benchmark frame at a = 0.94: 33.8 ->
+// 31.2 ms), the 512^2 formula frame (BASELINE configuration 2: four rays per lane, time set by its longest rays) loses more
+// (72 -> 87 ms): a wave that shares its SIMD steps a long ray more slowly.
 #ifndef BL_GEO_ONE_WAVE
-#define BL_GEO_ONE_WAVE(integrator, with_time, spin_zero) false
+#define BL_GEO_ONE_WAVE(integrator, with_time, spin_zero) ((integrator) == BL_INTEGRATOR_DP && ((with_time) || !(spin_zero)))
 #endif
 // A wave-uniform value the optimiser cannot see through (an empty instruction that claims to rewrite its scalar register)
 __device__ __forceinline__ int opaque_uniform(int v) {

@@ -33,6 +33,20 @@
 #define BLM_FN static inline
 #endif
 
+/* BLM_K(c): a 64-bit literal operand. The device compiler would put it in a vector register pair with two v_mov_b32 at
+ * every use - as dear as the fused multiply-add that consumes it, which triples the cost of a Horner step; handed through
+ * an empty scalar-register instruction it is two s_mov_b32 on the scalar unit (which runs beside the vector unit) and a
+ * scalar operand of the vector instruction. Same value, same arithmetic. Host: the literal itself. */
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BLM_NO_SCALAR_LITERALS)
+static inline __device__ double blm_scalar_literal(double v) {
+  asm volatile("" : "+s"(v));
+  return v;
+}
+#define BLM_K(c) blm_scalar_literal(c)
+#else
+#define BLM_K(c) (c)
+#endif
+
 #define BLM_INF (__builtin_inf())
 #define BLM_NAN (__builtin_nan(""))
 
@@ -50,7 +64,7 @@ BLM_FN double blm_copysign(double mag, double sgn) {
   return blm_from_bits((blm_bits(mag) & 0x7fffffffffffffffull) | (blm_bits(sgn) & 0x8000000000000000ull));
 }
 /* round to nearest integer (ties to even) for |v| < 2^51, without a libm call */
-BLM_FN double blm_rint(double v) { return (v + 0x1.8p52) - 0x1.8p52; }
+BLM_FN double blm_rint(double v) { return (v + BLM_K(0x1.8p52)) - BLM_K(0x1.8p52); }
 /* 2^k for -1022 <= k <= 1023 */
 BLM_FN double blm_pow2i(int k) { return blm_from_bits((uint64_t)(k + 1023) << 52); }
 /* x * 2^k, any int k (results in the subnormal range are rounded once more; never on our path) */
@@ -129,31 +143,31 @@ BLM_FN double bl_hypot3(double x, double y, double z) {
 }
 
 /* ---------------------------------------------------------------- exp */
-#define BLM_LN2_HI 0x1.62e42feep-1          /* 32 significant bits: k*LN2_HI exact for |k| < 2^21 */
-#define BLM_LN2_LO 0x1.a39ef35793c76p-33
-#define BLM_LN2_TAIL 0x1.cc01f97b57a08p-87
-#define BLM_INV_LN2 0x1.71547652b82fep+0
+#define BLM_LN2_HI BLM_K(0x1.62e42feep-1)          /* 32 significant bits: k*LN2_HI exact for |k| < 2^21 */
+#define BLM_LN2_LO BLM_K(0x1.a39ef35793c76p-33)
+#define BLM_LN2_TAIL BLM_K(0x1.cc01f97b57a08p-87)
+#define BLM_INV_LN2 BLM_K(0x1.71547652b82fep+0)
 
 BLM_FN double bl_exp(double x) {
   if (blm_isnan(x)) return x;
-  if (x > 0x1.62e42fefa39efp+9) return BLM_INF;
-  if (x < -0x1.74910d52d3051p+9) return 0.0;
+  if (x > BLM_K(0x1.62e42fefa39efp+9)) return BLM_INF;
+  if (x < -BLM_K(0x1.74910d52d3051p+9)) return 0.0;
   double kd = blm_rint(x * BLM_INV_LN2);
   int k = (int)kd;
   double r = blm_fma(-kd, BLM_LN2_HI, x);
   r = blm_fma(-kd, BLM_LN2_LO, r);
-  double p = 0x1.61bfaa228dde5p-33;
-  p = blm_fma(p, r, 0x1.1f7f2776cfaf2p-29);
-  p = blm_fma(p, r, 0x1.ae642c82e33d5p-26);
-  p = blm_fma(p, r, 0x1.27e4d41966f2fp-22);
-  p = blm_fma(p, r, 0x1.71de3a5aa7bb7p-19);
-  p = blm_fma(p, r, 0x1.a01a01a9e991bp-16);
-  p = blm_fma(p, r, 0x1.a01a01a0196acp-13);
-  p = blm_fma(p, r, 0x1.6c16c16c15a68p-10);
-  p = blm_fma(p, r, 0x1.1111111111111p-7);
-  p = blm_fma(p, r, 0x1.5555555555557p-5);
-  p = blm_fma(p, r, 0x1.5555555555555p-3);
-  p = blm_fma(p, r, 0x1.0000000000000p-1);
+  double p = BLM_K(0x1.61bfaa228dde5p-33);
+  p = blm_fma(p, r, BLM_K(0x1.1f7f2776cfaf2p-29));
+  p = blm_fma(p, r, BLM_K(0x1.ae642c82e33d5p-26));
+  p = blm_fma(p, r, BLM_K(0x1.27e4d41966f2fp-22));
+  p = blm_fma(p, r, BLM_K(0x1.71de3a5aa7bb7p-19));
+  p = blm_fma(p, r, BLM_K(0x1.a01a01a9e991bp-16));
+  p = blm_fma(p, r, BLM_K(0x1.a01a01a0196acp-13));
+  p = blm_fma(p, r, BLM_K(0x1.6c16c16c15a68p-10));
+  p = blm_fma(p, r, BLM_K(0x1.1111111111111p-7));
+  p = blm_fma(p, r, BLM_K(0x1.5555555555557p-5));
+  p = blm_fma(p, r, BLM_K(0x1.5555555555555p-3));
+  p = blm_fma(p, r, BLM_K(0x1.0000000000000p-1));
   blm_dd s1 = blm_fast_two_sum(1.0, r);            /* 1 + r exactly */
   double e = s1.hi + blm_fma(r * r, p, s1.lo);
   return blm_scalbn(e, k);
@@ -162,7 +176,7 @@ BLM_FN double bl_exp(double x) {
 /* ---------------------------------------------------------------- expm1 */
 BLM_FN double bl_expm1(double x) {
   if (blm_isnan(x)) return x;
-  if (x > 0x1.62e42fefa39efp+9) return BLM_INF;
+  if (x > BLM_K(0x1.62e42fefa39efp+9)) return BLM_INF;
   if (x < -38.0) return -1.0;
   if (blm_abs(x) < 0x1p-54) return x;
   double kd = blm_rint(x * BLM_INV_LN2);
@@ -170,18 +184,18 @@ BLM_FN double bl_expm1(double x) {
   double rh = blm_fma(-kd, BLM_LN2_HI, x);
   double r = blm_fma(-kd, BLM_LN2_LO, rh);
   double c = blm_fma(-kd, BLM_LN2_LO, rh - r);   /* r + c == rh - kd*LN2_LO to ~2^-106 */
-  double q = 0x1.94328fcb8199cp-37;
-  q = blm_fma(q, r, 0x1.61bfaa228dde5p-33);
-  q = blm_fma(q, r, 0x1.1eed7a01fc8b7p-29);
-  q = blm_fma(q, r, 0x1.ae642c82e33d5p-26);
-  q = blm_fma(q, r, 0x1.27e4fb7a2782ap-22);
-  q = blm_fma(q, r, 0x1.71de3a5aa7bb7p-19);
-  q = blm_fma(q, r, 0x1.a01a01a019b63p-16);
-  q = blm_fma(q, r, 0x1.a01a01a0196acp-13);
-  q = blm_fma(q, r, 0x1.6c16c16c16c17p-10);
-  q = blm_fma(q, r, 0x1.1111111111111p-7);
-  q = blm_fma(q, r, 0x1.5555555555555p-5);
-  q = blm_fma(q, r, 0x1.5555555555555p-3);
+  double q = BLM_K(0x1.94328fcb8199cp-37);
+  q = blm_fma(q, r, BLM_K(0x1.61bfaa228dde5p-33));
+  q = blm_fma(q, r, BLM_K(0x1.1eed7a01fc8b7p-29));
+  q = blm_fma(q, r, BLM_K(0x1.ae642c82e33d5p-26));
+  q = blm_fma(q, r, BLM_K(0x1.27e4fb7a2782ap-22));
+  q = blm_fma(q, r, BLM_K(0x1.71de3a5aa7bb7p-19));
+  q = blm_fma(q, r, BLM_K(0x1.a01a01a019b63p-16));
+  q = blm_fma(q, r, BLM_K(0x1.a01a01a0196acp-13));
+  q = blm_fma(q, r, BLM_K(0x1.6c16c16c16c17p-10));
+  q = blm_fma(q, r, BLM_K(0x1.1111111111111p-7));
+  q = blm_fma(q, r, BLM_K(0x1.5555555555555p-5));
+  q = blm_fma(q, r, BLM_K(0x1.5555555555555p-3));
   double r2 = r * r;
   double tail = blm_fma(r2 * r, q, 0.5 * r2);
   tail += blm_fma(c, r, c);
@@ -200,7 +214,7 @@ BLM_FN blm_dd blm_log_dd(double x) { /* x finite, > 0 */
   if (u < 0x0010000000000000ull) { x *= 0x1p54; e = -54; u = blm_bits(x); }
   e += (int)(u >> 52) - 1023;
   double m = blm_from_bits((u & 0x000fffffffffffffull) | 0x3ff0000000000000ull);
-  if (m > 0x1.6a09e667f3bcdp+0) { m *= 0.5; e += 1; }
+  if (m > BLM_K(0x1.6a09e667f3bcdp+0)) { m *= 0.5; e += 1; }
   double f = m - 1.0;
   blm_dd den = blm_two_sum(m, 1.0);
   blm_dd s;
@@ -210,20 +224,20 @@ BLM_FN blm_dd blm_log_dd(double x) { /* x finite, > 0 */
   z.hi = s.hi * s.hi;
   z.lo = blm_fma(s.hi, s.hi, -z.hi) + 2.0 * s.hi * s.lo;
   double zz = z.hi;
-  double l = 0x1.615a2da208f78p-5;
-  l = blm_fma(l, zz, 0x1.441667b6cb80dp-5);
-  l = blm_fma(l, zz, 0x1.64515e682719ap-5);
-  l = blm_fma(l, zz, 0x1.861778358d1c4p-5);
-  l = blm_fma(l, zz, 0x1.af286f7c52d6ep-5);
-  l = blm_fma(l, zz, 0x1.e1e1e1d845c7ap-5);
-  l = blm_fma(l, zz, 0x1.1111111118d87p-4);
-  l = blm_fma(l, zz, 0x1.3b13b13b13a9ep-4);
-  l = blm_fma(l, zz, 0x1.745d1745d1746p-4);
-  l = blm_fma(l, zz, 0x1.c71c71c71c71cp-4);
-  l = blm_fma(l, zz, 0x1.2492492492492p-3);
+  double l = BLM_K(0x1.615a2da208f78p-5);
+  l = blm_fma(l, zz, BLM_K(0x1.441667b6cb80dp-5));
+  l = blm_fma(l, zz, BLM_K(0x1.64515e682719ap-5));
+  l = blm_fma(l, zz, BLM_K(0x1.861778358d1c4p-5));
+  l = blm_fma(l, zz, BLM_K(0x1.af286f7c52d6ep-5));
+  l = blm_fma(l, zz, BLM_K(0x1.e1e1e1d845c7ap-5));
+  l = blm_fma(l, zz, BLM_K(0x1.1111111118d87p-4));
+  l = blm_fma(l, zz, BLM_K(0x1.3b13b13b13a9ep-4));
+  l = blm_fma(l, zz, BLM_K(0x1.745d1745d1746p-4));
+  l = blm_fma(l, zz, BLM_K(0x1.c71c71c71c71cp-4));
+  l = blm_fma(l, zz, BLM_K(0x1.2492492492492p-3));
   double tail = zz * zz * zz * l;
-  blm_dd third = {0x1.5555555555555p-2, 0x1.5555555555555p-56};
-  blm_dd fifth = {0x1.999999999999ap-3, -0x1.999999999999ap-57};
+  blm_dd third = {BLM_K(0x1.5555555555555p-2), BLM_K(0x1.5555555555555p-56)};
+  blm_dd fifth = {BLM_K(0x1.999999999999ap-3), -BLM_K(0x1.999999999999ap-57)};
   blm_dd t1 = blm_dd_mul(z, third);
   blm_dd t2 = blm_dd_mul(blm_dd_mul(z, z), fifth);
   blm_dd sum = blm_dd_add_d(t2, tail);
@@ -259,20 +273,20 @@ BLM_FN double blm_exp_dd(blm_dd a) {
   r = blm_dd_add_d(r, -kd * BLM_LN2_TAIL);
   r = blm_dd_scale(r, 0.125);
   double rr = r.hi;
-  double ep = 0x1.1eef4361593cbp-29;
-  ep = blm_fma(ep, rr, 0x1.ae67522acca97p-26);
-  ep = blm_fma(ep, rr, 0x1.27e4fb764f679p-22);
-  ep = blm_fma(ep, rr, 0x1.71de3a5345fa0p-19);
-  ep = blm_fma(ep, rr, 0x1.a01a01a01a025p-16);
-  ep = blm_fma(ep, rr, 0x1.a01a01a01a02cp-13);
-  ep = blm_fma(ep, rr, 0x1.6c16c16c16c17p-10);
-  ep = blm_fma(ep, rr, 0x1.1111111111111p-7);
-  ep = blm_fma(ep, rr, 0x1.5555555555555p-5);
+  double ep = BLM_K(0x1.1eef4361593cbp-29);
+  ep = blm_fma(ep, rr, BLM_K(0x1.ae67522acca97p-26));
+  ep = blm_fma(ep, rr, BLM_K(0x1.27e4fb764f679p-22));
+  ep = blm_fma(ep, rr, BLM_K(0x1.71de3a5345fa0p-19));
+  ep = blm_fma(ep, rr, BLM_K(0x1.a01a01a01a025p-16));
+  ep = blm_fma(ep, rr, BLM_K(0x1.a01a01a01a02cp-13));
+  ep = blm_fma(ep, rr, BLM_K(0x1.6c16c16c16c17p-10));
+  ep = blm_fma(ep, rr, BLM_K(0x1.1111111111111p-7));
+  ep = blm_fma(ep, rr, BLM_K(0x1.5555555555555p-5));
   double r2d = rr * rr;
   double tail = r2d * r2d * ep;
   blm_dd r2 = blm_dd_mul(r, r);
   blm_dd r3 = blm_dd_mul(r2, r);
-  blm_dd sixth = {0x1.5555555555555p-3, 0x1.5555555555555p-57};
+  blm_dd sixth = {BLM_K(0x1.5555555555555p-3), BLM_K(0x1.5555555555555p-57)};
   blm_dd e = blm_dd_add_d(blm_dd_mul(r3, sixth), tail);
   e = blm_dd_add(blm_dd_scale(r2, 0.5), e);
   e = blm_dd_add(r, e);
@@ -352,13 +366,13 @@ BLM_FN double bl_cbrt(double x) {
   int q = (e >= 0) ? e / 3 : -((2 - e) / 3);
   int rem = e - 3 * q;                       /* 0, 1, 2 */
   double xs = rem == 0 ? m : (rem == 1 ? m * 2.0 : m * 4.0);   /* in [1, 8) */
-  double t = 0x1.4c7608a04eba1p-8;
-  t = blm_fma(t, m, -0x1.8bd2dce403128p-5);
-  t = blm_fma(t, m, 0x1.92bfc00e33108p-3);
-  t = blm_fma(t, m, -0x1.d758498b983bcp-2);
-  t = blm_fma(t, m, 0x1.a9da3cc66f245p-1);
-  t = blm_fma(t, m, 0x1.e68ceb1fc3429p-2);
-  t *= rem == 0 ? 1.0 : (rem == 1 ? 0x1.428a2f98d728bp+0 : 0x1.965fea53d6e3dp+0);
+  double t = BLM_K(0x1.4c7608a04eba1p-8);
+  t = blm_fma(t, m, -BLM_K(0x1.8bd2dce403128p-5));
+  t = blm_fma(t, m, BLM_K(0x1.92bfc00e33108p-3));
+  t = blm_fma(t, m, -BLM_K(0x1.d758498b983bcp-2));
+  t = blm_fma(t, m, BLM_K(0x1.a9da3cc66f245p-1));
+  t = blm_fma(t, m, BLM_K(0x1.e68ceb1fc3429p-2));
+  t *= rem == 0 ? 1.0 : (rem == 1 ? BLM_K(0x1.428a2f98d728bp+0) : BLM_K(0x1.965fea53d6e3dp+0));
   double t3 = t * t * t;
   t = t * (t3 + 2.0 * xs) / (2.0 * t3 + xs);            /* Halley */
   double t2 = t * t, t2e = blm_fma(t, t, -t2);
@@ -368,18 +382,18 @@ BLM_FN double bl_cbrt(double x) {
 }
 
 /* ---------------------------------------------------------------- sin / cos */
-#define BLM_PIO2_HI 0x1.921fb54442d18p+0
-#define BLM_PIO2_LO 0x1.1a62633145c07p-54
-#define BLM_PI_HI 0x1.921fb54442d18p+1
-#define BLM_PI_LO 0x1.1a62633145c07p-53
+#define BLM_PIO2_HI BLM_K(0x1.921fb54442d18p+0)
+#define BLM_PIO2_LO BLM_K(0x1.1a62633145c07p-54)
+#define BLM_PI_HI BLM_K(0x1.921fb54442d18p+1)
+#define BLM_PI_LO BLM_K(0x1.1a62633145c07p-53)
 
 /* argument reduction: x = n*(pi/2) + (r.hi + r.lo), |r| <= ~pi/4; returns n mod 4.
    pi/2 is carried as three full doubles (~159 bits); products are exact via fma. */
 BLM_FN int blm_rem_pio2(double x, blm_dd *r) {
-  double fn = blm_rint(x * 0x1.45f306dc9c883p-1);
-  blm_dd p1 = blm_two_prod(-fn, 0x1.921fb54442d18p+0);
-  blm_dd p2 = blm_two_prod(-fn, 0x1.1a62633145c07p-54);
-  double p3 = -fn * -0x1.f1976b7ed8fbcp-110;
+  double fn = blm_rint(x * BLM_K(0x1.45f306dc9c883p-1));
+  blm_dd p1 = blm_two_prod(-fn, BLM_K(0x1.921fb54442d18p+0));
+  blm_dd p2 = blm_two_prod(-fn, BLM_K(0x1.1a62633145c07p-54));
+  double p3 = -fn * -BLM_K(0x1.f1976b7ed8fbcp-110);
   blm_dd acc = blm_two_sum(x, p1.hi);
   blm_dd t = blm_two_sum(p1.lo, p2.hi);
   acc = blm_dd_add(acc, t);
@@ -391,25 +405,25 @@ BLM_FN int blm_rem_pio2(double x, blm_dd *r) {
 }
 BLM_FN double blm_ksin(double r, double lo) {
   double z = r * r;
-  double s = -0x1.ab17a79237a19p-41;
-  s = blm_fma(s, z, 0x1.61217ec01749dp-33);
-  s = blm_fma(s, z, -0x1.ae64541266378p-26);
-  s = blm_fma(s, z, 0x1.71de3a54605eep-19);
-  s = blm_fma(s, z, -0x1.a01a01a019936p-13);
-  s = blm_fma(s, z, 0x1.1111111111110p-7);
-  s = blm_fma(s, z, -0x1.5555555555555p-3);
+  double s = -BLM_K(0x1.ab17a79237a19p-41);
+  s = blm_fma(s, z, BLM_K(0x1.61217ec01749dp-33));
+  s = blm_fma(s, z, -BLM_K(0x1.ae64541266378p-26));
+  s = blm_fma(s, z, BLM_K(0x1.71de3a54605eep-19));
+  s = blm_fma(s, z, -BLM_K(0x1.a01a01a019936p-13));
+  s = blm_fma(s, z, BLM_K(0x1.1111111111110p-7));
+  s = blm_fma(s, z, -BLM_K(0x1.5555555555555p-3));
   double corr = lo * (1.0 - 0.5 * z);
   return r + blm_fma(r * z, s, corr);
 }
 BLM_FN double blm_kcos(double r, double lo) {
   double z = r * r;
-  double c = 0x1.ab783376962cfp-45;
-  c = blm_fma(c, z, -0x1.9394b9c9c20a4p-37);
-  c = blm_fma(c, z, 0x1.1eed8deb6d561p-29);
-  c = blm_fma(c, z, -0x1.27e4fb7712bdfp-22);
-  c = blm_fma(c, z, 0x1.a01a01a019d0ap-16);
-  c = blm_fma(c, z, -0x1.6c16c16c16c16p-10);
-  c = blm_fma(c, z, 0x1.5555555555555p-5);
+  double c = BLM_K(0x1.ab783376962cfp-45);
+  c = blm_fma(c, z, -BLM_K(0x1.9394b9c9c20a4p-37));
+  c = blm_fma(c, z, BLM_K(0x1.1eed8deb6d561p-29));
+  c = blm_fma(c, z, -BLM_K(0x1.27e4fb7712bdfp-22));
+  c = blm_fma(c, z, BLM_K(0x1.a01a01a019d0ap-16));
+  c = blm_fma(c, z, -BLM_K(0x1.6c16c16c16c16p-10));
+  c = blm_fma(c, z, BLM_K(0x1.5555555555555p-5));
   double hz = 0.5 * z;
   double w = 1.0 - hz;
   double tail = ((1.0 - w) - hz) + blm_fma(z * z, c, -r * lo);
@@ -455,25 +469,25 @@ BLM_FN double bl_atan(double x) {
   if (ax < 0x1p-27) return x;
   /* range selection without divergent branches: t = num / den, atan(ax) = hi + lo + atan(t) */
   double num = ax, den = 1.0, hi = 0.0, lo = 0.0;          /* ax < 7/16: t = ax / 1 = ax exactly */
-  if (ax >= 0.4375) { num = 2.0 * ax - 1.0; den = 2.0 + ax; hi = 0x1.dac670561bb4fp-2; lo = 0x1.a2b7f222f65e2p-56; }
-  if (ax >= 0.6875) { num = ax - 1.0; den = ax + 1.0; hi = 0x1.921fb54442d18p-1; lo = 0x1.1a62633145c07p-55; }
-  if (ax >= 1.1875) { num = ax - 1.5; den = 1.0 + 1.5 * ax; hi = 0x1.f730bd281f69bp-1; lo = 0x1.007887af0cbbdp-56; }
+  if (ax >= 0.4375) { num = 2.0 * ax - 1.0; den = 2.0 + ax; hi = BLM_K(0x1.dac670561bb4fp-2); lo = BLM_K(0x1.a2b7f222f65e2p-56); }
+  if (ax >= 0.6875) { num = ax - 1.0; den = ax + 1.0; hi = BLM_K(0x1.921fb54442d18p-1); lo = BLM_K(0x1.1a62633145c07p-55); }
+  if (ax >= 1.1875) { num = ax - 1.5; den = 1.0 + 1.5 * ax; hi = BLM_K(0x1.f730bd281f69bp-1); lo = BLM_K(0x1.007887af0cbbdp-56); }
   if (ax >= 2.4375) { num = -1.0; den = ax; hi = BLM_PIO2_HI; lo = BLM_PIO2_LO; }
   double t = num / den;
   double z = t * t;
-  double a = -0x1.9a0e3d8214a3cp-7;
-  a = blm_fma(a, z, 0x1.dde84abd3489ap-6);
-  a = blm_fma(a, z, -0x1.4ac01ab40659fp-5);
-  a = blm_fma(a, z, 0x1.812cf294b38a9p-5);
-  a = blm_fma(a, z, -0x1.ae800c7915a0cp-5);
-  a = blm_fma(a, z, 0x1.e1d239c838f12p-5);
-  a = blm_fma(a, z, -0x1.1110907ae84ccp-4);
-  a = blm_fma(a, z, 0x1.3b13abac1919fp-4);
-  a = blm_fma(a, z, -0x1.745d171e2e854p-4);
-  a = blm_fma(a, z, 0x1.c71c71c673bd9p-4);
-  a = blm_fma(a, z, -0x1.24924924918e2p-3);
-  a = blm_fma(a, z, 0x1.999999999998fp-3);
-  a = blm_fma(a, z, -0x1.5555555555555p-2);
+  double a = -BLM_K(0x1.9a0e3d8214a3cp-7);
+  a = blm_fma(a, z, BLM_K(0x1.dde84abd3489ap-6));
+  a = blm_fma(a, z, -BLM_K(0x1.4ac01ab40659fp-5));
+  a = blm_fma(a, z, BLM_K(0x1.812cf294b38a9p-5));
+  a = blm_fma(a, z, -BLM_K(0x1.ae800c7915a0cp-5));
+  a = blm_fma(a, z, BLM_K(0x1.e1d239c838f12p-5));
+  a = blm_fma(a, z, -BLM_K(0x1.1110907ae84ccp-4));
+  a = blm_fma(a, z, BLM_K(0x1.3b13abac1919fp-4));
+  a = blm_fma(a, z, -BLM_K(0x1.745d171e2e854p-4));
+  a = blm_fma(a, z, BLM_K(0x1.c71c71c673bd9p-4));
+  a = blm_fma(a, z, -BLM_K(0x1.24924924918e2p-3));
+  a = blm_fma(a, z, BLM_K(0x1.999999999998fp-3));
+  a = blm_fma(a, z, -BLM_K(0x1.5555555555555p-2));
   double tp = t * (z * a);                    /* atan(t) = t + tp */
   double res = hi + ((tp + lo) + t);          /* hi = lo = 0 in the direct range: exactly t + tp */
   return blm_copysign(res, x);
@@ -485,7 +499,7 @@ BLM_FN double bl_atan2(double y, double x) {
   if (y == 0.0) return sx ? (sy ? -pi : pi) : y;
   if (x == 0.0) return sy ? -pio2 : pio2;
   if (blm_isinf(x)) {
-    if (blm_isinf(y)) { double v = sx ? 3.0 * 0x1.921fb54442d18p-1 : 0x1.921fb54442d18p-1; return sy ? -v : v; }
+    if (blm_isinf(y)) { double v = sx ? 3.0 * BLM_K(0x1.921fb54442d18p-1) : BLM_K(0x1.921fb54442d18p-1); return sy ? -v : v; }
     return sx ? (sy ? -pi : pi) : (sy ? -0.0 : 0.0);
   }
   if (blm_isinf(y)) return sy ? -pio2 : pio2;
@@ -500,20 +514,20 @@ BLM_FN double bl_atan2(double y, double x) {
 
 /* ---------------------------------------------------------------- acos */
 BLM_FN double blm_asin_r(double z) { /* (asin(x)-x)/x^3 with z = x^2 <= 0.25 */
-  double r = 0x1.e58a4f278e007p-6;
-  r = blm_fma(r, z, -0x1.3bd7e353ddbc2p-6);
-  r = blm_fma(r, z, 0x1.40c91fa8deb7ep-6);
-  r = blm_fma(r, z, 0x1.8dcdf11997e0fp-9);
-  r = blm_fma(r, z, 0x1.31777489dfd29p-7);
-  r = blm_fma(r, z, 0x1.3b462d121c5d2p-7);
-  r = blm_fma(r, z, 0x1.7b02ef007d23ep-7);
-  r = blm_fma(r, z, 0x1.c990a42b32b03p-7);
-  r = blm_fma(r, z, 0x1.1c4efd20ebb99p-6);
-  r = blm_fma(r, z, 0x1.6e8ba121b9d5fp-6);
-  r = blm_fma(r, z, 0x1.f1c71c7a5e151p-6);
-  r = blm_fma(r, z, 0x1.6db6db6dac0eap-5);
-  r = blm_fma(r, z, 0x1.3333333333389p-4);
-  r = blm_fma(r, z, 0x1.5555555555555p-3);
+  double r = BLM_K(0x1.e58a4f278e007p-6);
+  r = blm_fma(r, z, -BLM_K(0x1.3bd7e353ddbc2p-6));
+  r = blm_fma(r, z, BLM_K(0x1.40c91fa8deb7ep-6));
+  r = blm_fma(r, z, BLM_K(0x1.8dcdf11997e0fp-9));
+  r = blm_fma(r, z, BLM_K(0x1.31777489dfd29p-7));
+  r = blm_fma(r, z, BLM_K(0x1.3b462d121c5d2p-7));
+  r = blm_fma(r, z, BLM_K(0x1.7b02ef007d23ep-7));
+  r = blm_fma(r, z, BLM_K(0x1.c990a42b32b03p-7));
+  r = blm_fma(r, z, BLM_K(0x1.1c4efd20ebb99p-6));
+  r = blm_fma(r, z, BLM_K(0x1.6e8ba121b9d5fp-6));
+  r = blm_fma(r, z, BLM_K(0x1.f1c71c7a5e151p-6));
+  r = blm_fma(r, z, BLM_K(0x1.6db6db6dac0eap-5));
+  r = blm_fma(r, z, BLM_K(0x1.3333333333389p-4));
+  r = blm_fma(r, z, BLM_K(0x1.5555555555555p-3));
   return r;
 }
 BLM_FN double bl_acos(double x) {
