@@ -21,7 +21,11 @@ out = {}
 with bl.Context(bl.Params.from_dict(p)) as ctx:
     ctx.set_grid(grid)
     ctx.set_arithmetic(os.environ.get("ARITH", "tolerant"))
-    for world in (1, 2, 4, 8):
+    if os.environ.get("OVERLAP"):
+        ctx.set_overlap(True)
+    if os.environ.get("SCRATCH_GB"):
+        ctx.set_scratch_limit(int(float(os.environ["SCRATCH_GB"]) * 1e9))
+    for world in [int(w) for w in os.environ.get("WORLDS", "1,2,4,8").split(",")]:
         times = []
         for rank in range(world):
             pixels = bd.tile_pixels(res, rank, world, bench.TILE) if world > 1 else None
