@@ -428,3 +428,31 @@ def test_refined_mesh_holes_and_overlaps(built_library):
         assert gu.same_bits(got["image"], want["image"]).all()
         with pytest.raises(bl.BlacklightError, match="overlap"):
             ctx.set_grid(subset(list(range(n_b)) + [5]))
+
+
+def test_contexts_give_their_memory_back(built_library):
+    """bl_free releases everything a context allocated (records, grids, block tables, polarized scratch, redo lists): device
+    memory after a series of contexts - plain, polarized + tolerant, refined mesh with inter-block interpolation - is back
+    where it was (DeviceBuffer owns its allocation)."""
+    import torch
+    import blacklight_amd as bl
+
+    def free_bytes():
+        torch.cuda.synchronize()
+        return torch.cuda.mem_get_info()[0]
+
+    def run(case, arithmetic):
+        fx, params, mock_args = gu.load_case(case)
+        with bl.Context(bl.Params.from_dict(params)) as ctx:
+            if mock_args is not None:
+                ctx.set_grid(gu.golden_grid(mock_args))
+            ctx.set_arithmetic(arithmetic)
+            ctx.render()
+
+    run("sim_dp_interp", "exact")            # first use: the runtime's own one-off allocations
+    before = free_bytes()
+    for case, arithmetic in (("sim_dp_interp", "tolerant"), ("sim_polarized", "tolerant"), ("sim_polarized", "exact"),
+                             ("sim_blockinterp_refined", "exact"), ("formula_dp", "exact")):
+        run(case, arithmetic)
+    after = free_bytes()
+    assert abs(before - after) <= 64 << 20, (before, after)
