@@ -2218,27 +2218,33 @@ __device__ __forceinline__ bool fast_shade_sample(const BlShadeArgs &P, const do
     return true;
   }
   // ---- per-frequency coefficients (simulation_coefficients.cpp:464-523) and transfer records (unpolarized.cpp:74-110)
+  // Every frequency-dependent quantity factors into a part of the sample and a part of the frequency: with nu = s_nu f_l
+  // (s_nu = -k.u x momentum factor), x = nu / nu_s = s_x f_l, so x^(1/2), x^(1/3), x^(1/6) are products of one square / cube
+  // root per sample with the frequency's roots from the table (table[44 + n_nu ...], filled once per workgroup) - what is
+  // left per sample AND frequency is one exp, two expm1, one reciprocal and two dozen multiplications.
   const double thermal_frac = pl.plasma_thermal_frac;
   const double nu_s_cgs = 2.0 / 9.0 * nu_c_cgs * theta_e * theta_e * sin_theta_b;
-  const double nu_s_inv = have ? fastmath::rcp(nu_s_cgs) : 0.0;
-  const double kt_inv = have ? fastmath::rcp(kb_tt_e_cgs) : 0.0;
-  const double j_scale = thermal_frac * n_e_cgs * kE * kE * nu_c_cgs * (1.0 / kC) * (kSqrt2 * kPi / 27.0) * sin_theta_b;
-  for (int l = 0; l < P.n_nu; l++) {
+  const double s_nu = nu_ratio * momentum_factor;
+  const double s_x = have ? s_nu * fastmath::rcp(nu_s_cgs) : 0.0;
+  const double s_1_2 = bl_sqrt_g(s_x), s_1_3 = fastmath::cbrt(s_x);
+  const double s_1_6 = bl_sqrt_g(s_1_3);
+  const double s_planck = have ? kH * s_nu * fastmath::rcp(kb_tt_e_cgs) : 0.0;                    // h nu / (k T_e) = s_planck f_l
+  const double s_nu_inv = have ? fastmath::rcp(s_nu) : 0.0;
+  const double s_j = thermal_frac * n_e_cgs * kE * kE * nu_c_cgs * (1.0 / kC) * (kSqrt2 * kPi / 27.0) * sin_theta_b * s_nu_inv * s_nu_inv;
+  const double s_length = delta_lambda * P.x_unit * fastmath::rcp(momentum_factor);               // unpolarized.cpp:75-76
+  const int n_nu = P.n_nu;
+  for (int l = 0; l < n_nu; l++) {
     double2 rec = make_double2(1.0, 0.0);
     if (have) {
-      const double nu_factor = table[44 + l] * momentum_factor;
-      const double nu_cgs = nu_ratio * nu_factor;
-      const double xx = nu_cgs * nu_s_inv;
-      const double xx_1_2 = bl_sqrt_g(xx);
-      const double xx_1_3 = fastmath::cbrt(xx);
-      const double xx_1_6 = bl_sqrt_g(xx_1_3);
-      const double var_c = xx_1_2 + kPow2_11_12 * xx_1_6;
-      const double nu_inv = fastmath::rcp(nu_cgs);
-      const double j_val = j_scale * nu_inv * nu_inv * fastmath::exp(-xx_1_3) * var_c * var_c;
-      const double inv_b_nu = fastmath::expm1(kH * nu_cgs * kt_inv) * (kC * kC / (2.0 * kH));   // 1 / (B_nu / nu^3)
+      const double f = table[44 + l], f_1_2 = table[44 + n_nu + l], f_1_3 = table[44 + 2 * n_nu + l], f_1_6 = table[44 + 3 * n_nu + l];
+      const double f_inv = table[44 + 4 * n_nu + l];
+      const double xx_1_3 = s_1_3 * f_1_3;
+      const double var_c = s_1_2 * f_1_2 + kPow2_11_12 * (s_1_6 * f_1_6);
+      const double j_val = s_j * (f_inv * f_inv) * fastmath::exp(-xx_1_3) * var_c * var_c;
+      const double inv_b_nu = fastmath::expm1(s_planck * f) * (kC * kC / (2.0 * kH));   // 1 / (B_nu / nu^3)
       double alpha_val = j_val * inv_b_nu;
       if (alpha_val * alpha_val <= 0x1p-1024) alpha_val = 0.0;                                // :513-523
-      const double delta_lambda_cgs = delta_lambda * P.x_unit * fastmath::rcp(nu_factor);     // unpolarized.cpp:75-76
+      const double delta_lambda_cgs = s_length * f_inv;
       if (alpha_val > 0.0) {
         const double ss = j_val * fastmath::rcp(alpha_val);
         const double delta_tau = alpha_val * delta_lambda_cgs;
@@ -2347,12 +2353,21 @@ __global__ void __launch_bounds__(256, BL_FAST_WAVES) bl_shade_fast_kernel(const
   const unsigned long long n_records = P.counters_in[BL_CNT_RECORDS];
   const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
   unsigned long long idx = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;   // record of `next`
-  // LDS: 3 x 14 cut thresholds / guard bands, the two fallback primitives, the frequencies
+  // LDS: 3 x 14 cut thresholds / guard bands, the two fallback primitives, the frequencies and their roots / reciprocals
   extern __shared__ double fast_table[];
-  for (int i = threadIdx.x; i < 44 + P.n_nu; i += blockDim.x) {
+  for (int i = threadIdx.x; i < 44 + 5 * P.n_nu; i += blockDim.x) {
     const BlShadeCold &cc = *P.cold;
-    fast_table[i] = i < 14 ? cc.fast_cut[i] : (i < 28 ? cc.fast_cut_lo[i - 14] : (i < 42 ? cc.fast_cut_hi[i - 28]
-        : (i == 42 ? (double)cc.fallback_rho : (i == 43 ? (double)cc.fallback_pgas : P.frequencies[i - 44]))));
+    double value;
+    if (i < 44) {
+      value = i < 14 ? cc.fast_cut[i] : (i < 28 ? cc.fast_cut_lo[i - 14] : (i < 42 ? cc.fast_cut_hi[i - 28]
+          : (i == 42 ? (double)cc.fallback_rho : (double)cc.fallback_pgas)));
+    } else {   // f, f^(1/2), f^(1/3), f^(1/6), 1 / f of every frequency (fast_shade_sample)
+      const int which = (i - 44) / P.n_nu;
+      const double f = P.frequencies[(i - 44) - which * P.n_nu];
+      const double f_1_3 = fastmath::cbrt(f);
+      value = which == 0 ? f : (which == 1 ? bl_sqrt_g(f) : (which == 2 ? f_1_3 : (which == 3 ? bl_sqrt_g(f_1_3) : fastmath::rcp(f))));
+    }
+    fast_table[i] = value;
   }
   __syncthreads();
   if (n_records == 0ull) return;
@@ -2874,10 +2889,10 @@ extern "C" hipError_t bl_launch_shade(const BlShadeArgs *args, int model, int gr
 // Tolerant tier: the fast coefficient kernel, then the exact kernel over the records it deferred
 extern "C" hipError_t bl_launch_shade_fast(const BlShadeArgs *args, int grid, hipStream_t stream) {
   if (args->st.bh_a == 0.0) {
-    hipLaunchKernelGGL((bl_shade_fast_kernel<true>), dim3(grid), dim3(256), (44 + args->n_nu) * sizeof(double), stream, *args);
+    hipLaunchKernelGGL((bl_shade_fast_kernel<true>), dim3(grid), dim3(256), (44 + 5 * args->n_nu) * sizeof(double), stream, *args);
     hipLaunchKernelGGL((bl_shade_kernel<BL_MODEL_SIMULATION, false, false, true, false, true, true>), dim3(grid), dim3(256), 0, stream, *args);
   } else {
-    hipLaunchKernelGGL((bl_shade_fast_kernel<false>), dim3(grid), dim3(256), (44 + args->n_nu) * sizeof(double), stream, *args);
+    hipLaunchKernelGGL((bl_shade_fast_kernel<false>), dim3(grid), dim3(256), (44 + 5 * args->n_nu) * sizeof(double), stream, *args);
     hipLaunchKernelGGL((bl_shade_kernel<BL_MODEL_SIMULATION, false, false, true, false, false, true>), dim3(grid), dim3(256), 0, stream, *args);
   }
   return hipGetLastError();
