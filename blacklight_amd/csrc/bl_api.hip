@@ -32,6 +32,7 @@ extern "C" hipError_t bl_launch_shade(const BlShadeArgs *args, int model, int gr
 extern "C" hipError_t bl_launch_shade_fast(const BlShadeArgs *args, int grid, hipStream_t stream);
 extern "C" hipError_t bl_launch_polarized_coefficients(const BlShadeArgs *args, int grid, hipStream_t stream);
 extern "C" hipError_t bl_launch_transfer(const BlTransferArgs *args, hipStream_t stream);
+extern "C" hipError_t bl_launch_transfer_freq(const BlTransferArgs *args, hipStream_t stream);
 extern "C" hipError_t bl_launch_transfer_aux(const BlTransferArgs *args, hipStream_t stream);
 extern "C" hipError_t bl_launch_transfer_polarized(const BlTransferArgs *args, hipStream_t stream);
 extern "C" hipError_t bl_launch_transfer_polarized_matrix(const BlTransferArgs *args, int num_cus, hipStream_t stream);
@@ -174,12 +175,13 @@ struct bl_ctx {
     DeviceBuffer<double> d_slow_frac;              // slow light: t_frac of every located sample
     DeviceBuffer<BlPolSample> d_pol_samples;       // polarized transfer
     DeviceBuffer<double> d_pol_matrix;             // tolerant tier: 10 doubles per sample
+    DeviceBuffer<BlFreqInputs> d_freq_inputs;      // tolerant tier, several frequencies
     DeviceBuffer<double2> d_pol_coeffs;
     DeviceBuffer<unsigned int> d_anchors;          // inter-block interpolation: eight anchor cells per record
     DeviceBuffer<BlCoefInputs> d_coef_inputs;      // polarized runs: coefficient kernel -> polarized coefficient kernel
     DeviceBuffer<unsigned long long> d_redo;       // tolerant tier: records left to the exact coefficient kernel
     void Free() {
-      d_redo.Free(); d_aux.Free(); d_sample_t.Free(); d_slow_frac.Free(); d_pol_samples.Free(); d_pol_matrix.Free(); d_pol_coeffs.Free(); d_coef_inputs.Free(); d_anchors.Free();
+      d_redo.Free(); d_aux.Free(); d_sample_t.Free(); d_slow_frac.Free(); d_pol_samples.Free(); d_pol_matrix.Free(); d_freq_inputs.Free(); d_pol_coeffs.Free(); d_coef_inputs.Free(); d_anchors.Free();
       d_records_hot.Free(); d_records_cold.Free(); d_located.Free(); d_located_tag.Free(); d_transfer.Free(); d_ray_kt.Free(); d_ray_factor.Free();
       d_ray_sample_num.Free(); d_ray_flags.Free(); d_ray_out_index.Free(); d_counters.Free();
     }
@@ -1176,6 +1178,9 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
     const bool tolerant_polarized = ctx->arithmetic == BL_ARITH_TOLERANT && ctx->polarized;
     // ... and transport matrices (bl_transport_matrix_kernel) instead of the ray-sequential tensor transport, in curved spacetimes
     const bool matrix_transport = tolerant_polarized && !p.ray_flat;
+    // Several frequencies in the fast path: per-sample factors (BlFreqInputs) instead of per-frequency transfer records,
+    // evaluated by bl_transfer_freq_kernel with one lane per ray and frequency
+    const bool freq_split = fast && n_nu >= 4;
     // (polarized runs list the samples without coefficients there - cut samples, cut cells - which are many more)
     const size_t redo_capacity = ctx->polarized ? (1u << 24) : (1u << 20);
     // chunk size from the scratch budget: per ray max_steps * (2 x 32 B record + 40 B located sample
@@ -1184,7 +1189,7 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
         * (sizeof(BlSampleHot) + sizeof(BlSampleCold) + (simulation ? sizeof(BlLocated) + sizeof(unsigned long long) : 0) + sizeof(double2) * n_nu
            + (aux ? sizeof(BlAuxSample) + sizeof(double) : 0) + (slow ? 2 * sizeof(double) : 0)
            + (ctx->polarized ? sizeof(BlPolSample) + sizeof(BlCoefInputs) + 3 * sizeof(double2) * n_nu : 0)
-           + (matrix_transport ? BL_POL_MATRIX_DOUBLES * sizeof(double) : 0)
+           + (matrix_transport ? BL_POL_MATRIX_DOUBLES * sizeof(double) : 0) + (freq_split ? sizeof(BlFreqInputs) : 0)
            + (block_interp ? 8 * sizeof(unsigned int) : 0)) + 64;
     // One chunk if the whole call fits the budget. With bl_set_overlap(): two scratch sets of half the budget
     // each, so that the geodesic kernel of chunk c + 1 runs while chunk c is being shaded.
@@ -1201,7 +1206,8 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
               + sl.d_transfer.count * sizeof(double2) + sl.d_aux.count * sizeof(BlAuxSample)
               + (sl.d_sample_t.count + sl.d_slow_frac.count) * sizeof(double)
               + sl.d_pol_samples.count * sizeof(BlPolSample) + (sl.d_pol_coeffs.count) * sizeof(double2) + sl.d_pol_matrix.count * sizeof(double)
-              + sl.d_coef_inputs.count * sizeof(BlCoefInputs) + sl.d_anchors.count * sizeof(unsigned int);
+              + sl.d_coef_inputs.count * sizeof(BlCoefInputs) + sl.d_anchors.count * sizeof(unsigned int)
+              + sl.d_freq_inputs.count * sizeof(BlFreqInputs);
         const uint64_t available = static_cast<uint64_t>(0.9 * static_cast<double>(free_bytes + held));
         if (available < budget) budget = available;
       }
@@ -1226,6 +1232,7 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
         sl.d_located_tag.Ensure(record_capacity);
       }
       sl.d_transfer.Ensure(static_cast<size_t>(chunk) * max_steps * n_nu);
+      if (freq_split) sl.d_freq_inputs.Ensure(static_cast<size_t>(chunk) * max_steps);
       sl.d_ray_kt.Ensure(chunk);
       sl.d_ray_factor.Ensure(chunk);
       sl.d_ray_sample_num.Ensure(chunk);
@@ -1693,6 +1700,11 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
       sa.located = simulation ? sl.d_located.ptr : nullptr;
       sa.located_tag = simulation ? sl.d_located_tag.ptr : nullptr;
       sa.tag_in_record = fast ? 1 : 0;
+      sa.freq_split = freq_split ? 1 : 0;
+      sa.freq_inputs = freq_split ? sl.d_freq_inputs.ptr : nullptr;
+      xa.freq_inputs = sa.freq_inputs;
+      xa.redo_counter = sl.d_counters.ptr + BL_CNT_REDO;
+      xa.redo_capacity = redo_capacity;
       sa.counters_in = sl.d_counters.ptr;
       sa.counters = sl.d_counters.ptr;
       sa.ray_kt = sl.d_ray_kt.ptr;
@@ -1798,7 +1810,8 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
       else Check(bl_launch_shade(&sa, p.model_type, shade_grid, stream), "coefficient kernel launch");
       if (ctx->polarized) Check(bl_launch_polarized_coefficients(&sa, ctx->num_cus * 8, stream), "polarized coefficient kernel launch");
       Check(hipEventRecord(e[4], stream), "event");
-      Check(aux ? bl_launch_transfer_aux(&xa, stream) : bl_launch_transfer(&xa, stream), "transfer kernel launch");
+      Check(aux ? bl_launch_transfer_aux(&xa, stream) : (freq_split ? bl_launch_transfer_freq(&xa, stream) : bl_launch_transfer(&xa, stream)),
+            "transfer kernel launch");
       if (ctx->polarized)
         Check(matrix_transport ? bl_launch_transfer_polarized_matrix(&xa, ctx->num_cus, stream) : bl_launch_transfer_polarized(&xa, stream),
               "polarized transfer kernel launch");

@@ -245,6 +245,20 @@ struct alignas(16) BlPolSample {
   double e1[4], e2[4];
 };
 
+// Tolerant tier with several frequencies (BlShadeArgs::freq_split): what is left of a sample once everything that does not
+// depend on the frequency has been evaluated - the factors of bl_shade_fast_kernel's frequency loop. bl_transfer_freq_kernel
+// (one lane per ray and frequency) turns them into the sample's (a, c) and applies it on the spot: no transfer records.
+// flag: 0 nothing to add (cut sample, cut cell, no field), 1 coefficients follow, 2 NaN (off the grid with fallback_nan),
+// 3 the exact second pass wrote this sample's records (deferred cut decision). 64 bytes.
+struct alignas(16) BlFreqInputs {
+  double flag;
+  double s_1_2, s_1_3, s_1_6;   // x^(1/2), x^(1/3), x^(1/6) of x = nu / nu_s at unit frequency
+  double s_planck;              // h nu / (k T_e) at unit frequency
+  double s_j;                   // j_nu nu^2 e^(x^(1/3)) / var_c^2
+  double s_length;              // delta lambda in cm at unit frequency
+  double pad;
+};
+
 // Polarized runs: what the per-frequency coefficient formulas need of a sample (simulation_coefficients.cpp:458-698),
 // left by the coefficient kernel for bl_polarized_coefficients_kernel, one per sample record. 64 bytes.
 struct alignas(16) BlCoefInputs {
@@ -281,6 +295,8 @@ struct BlShadeArgs {
   const BlSampleCold *records_cold;
   BlLocated *located;         // [record capacity], simulation mode
   unsigned long long *located_tag;   // [record capacity]: cell | status << 32 | time slice << 40
+  BlFreqInputs *freq_inputs;         // [chunk_rays][ray_max_steps] when freq_split
+  int freq_split;                    // tolerant tier, n_nu >= 4: per-sample factors instead of per-frequency transfer records
   int tag_in_record;                 // tolerant tier: the tag is written into BlLocated::ph instead (32 bytes per sample, one stream)
   int lds_table_bytes;        // size of the coordinate tables the locate kernel stages in LDS; 0: searched in HBM
   int samples_renormalised;   // records come from a geodesic checkpoint: momenta as stored, no renormalisation per sample
@@ -334,6 +350,9 @@ struct BlTransferArgs {
   int n_nu, ray_max_steps, chunk_rays;
   int fallback_nan, model_type;
   int affine;                 // tolerant tier: records are (a, c) of I <- a I + c instead of (a, b) of I <- a (I + b)
+  const BlFreqInputs *freq_inputs;            // bl_transfer_freq_kernel
+  const unsigned long long *redo_counter;     // ... number of deferred samples (device), and what the list holds:
+  unsigned long long redo_capacity;           //     beyond it the exact pass has written every sample's records
   long long n_rays_total;
   double *image;              // [n_q][n_rays_total]; rows 0..n_nu-1 = I_nu
   int *out_sample_num;        // [n_rays_total] or null

@@ -2214,6 +2214,10 @@ __device__ __forceinline__ bool fast_shade_sample(const BlShadeArgs &P, const do
   }
   if (status == kSampleOffGrid && pl.fallback_nan) {
     // primitives are NaN (simulation_sampling.cpp:377-384): j and alpha are NaN at every frequency, I <- I + NaN
+    if (P.freq_split) {
+      reinterpret_cast<double2 *>(P.freq_inputs + ((size_t)ray * P.ray_max_steps + n))[0] = make_double2(2.0, 0.0);
+      return true;
+    }
     for (int l = 0; l < P.n_nu; l++) out[l] = make_double2(1.0, nan);
     return true;
   }
@@ -2232,6 +2236,14 @@ __device__ __forceinline__ bool fast_shade_sample(const BlShadeArgs &P, const do
   const double s_nu_inv = have ? fastmath::rcp(s_nu) : 0.0;
   const double s_j = thermal_frac * n_e_cgs * kE * kE * nu_c_cgs * (1.0 / kC) * (kSqrt2 * kPi / 27.0) * sin_theta_b * s_nu_inv * s_nu_inv;
   const double s_length = delta_lambda * P.x_unit * fastmath::rcp(momentum_factor);               // unpolarized.cpp:75-76
+  if (P.freq_split) {   // several frequencies: the factors go to bl_transfer_freq_kernel, one lane per ray and frequency
+    double2 *dst = reinterpret_cast<double2 *>(P.freq_inputs + ((size_t)ray * P.ray_max_steps + n));
+    dst[0] = make_double2(have ? 1.0 : 0.0, s_1_2);
+    dst[1] = make_double2(s_1_3, s_1_6);
+    dst[2] = make_double2(s_planck, s_j);
+    dst[3] = make_double2(s_length, 0.0);
+    return true;
+  }
   const int n_nu = P.n_nu;
   for (int l = 0; l < n_nu; l++) {
     double2 rec = make_double2(1.0, 0.0);
@@ -2417,9 +2429,96 @@ __global__ void __launch_bounds__(256, BL_FAST_WAVES) bl_shade_fast_kernel(const
     if (live) {
       // ReverseGeodesics: sample_len = -geodesic_len (geodesics.cpp:840)
       if (!fast_shade_sample<kSpinZero>(P, fast_table, pr, status, ray, n, rec.q0.x, rec.q0.y, rec.q1.x, rec.q2.x, rec.q2.y, rec.q3.x, kt,
-                                        momentum_factor, -rec.q3.y))
+                                        momentum_factor, -rec.q3.y)) {
+        if (P.freq_split) reinterpret_cast<double2 *>(P.freq_inputs + ((size_t)ray * P.ray_max_steps + n))[0] = make_double2(3.0, 0.0);
         fast_defer(P, idx_rec);
+      }
     }
+  }
+}
+
+// Several frequencies in the tolerant tier: one lane per (ray, frequency) walks the ray far -> near, builds each sample's
+// (a, c) from the sample's factors (BlFreqInputs; the lanes of one ray read the same 64 bytes) and the lane's own frequency,
+// and applies I <- a I + c at once. The per-frequency transfer records (16 bytes per sample and frequency: 1.5 TB written
+// and read per 1024^2 x 64-frequency frame) exist only for the samples the exact second pass shaded.
+__global__ void __launch_bounds__(256) bl_transfer_freq_kernel(BlTransferArgs P) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int slot = (int)(t / P.n_nu);
+  const int l = (int)(t % P.n_nu);
+  unsigned long long samples = 0ull, flagged = 0ull;
+  int max_num = 0;
+  if (slot < P.chunk_rays) {
+    const int num = P.ray_sample_num[slot];
+    const bool flag = P.ray_flags[slot] != 0;
+    const long long out_index = P.ray_out_index[slot];
+    if (l == 0) {
+      samples = (unsigned long long)num;
+      flagged = flag ? 1ull : 0ull;
+      max_num = num;
+      if (P.out_sample_num != nullptr) P.out_sample_num[out_index] = num;
+      if (P.out_flags != nullptr) P.out_flags[out_index] = flag ? 1 : 0;
+    }
+    const double nan = __longlong_as_double(0x7ff8000000000000ll);
+    const double f = P.frequencies[l];
+    double intensity = 0.0;
+    if (P.fallback_nan && flag) {
+      intensity = num > 0 ? nan : 0.0;   // every sample of a flagged ray carries NaN primitives (simulation_sampling.cpp:211-216)
+    } else {
+      const double f_1_2 = bl_sqrt_g(f), f_1_3 = fastmath::cbrt(f);
+      const double f_1_6 = bl_sqrt_g(f_1_3), f_inv = fastmath::rcp(f);
+      const double f_inv2 = f_inv * f_inv;
+      const bool every_record = *P.redo_counter > P.redo_capacity;   // the exact pass shaded every sample
+      const double2 *in = reinterpret_cast<const double2 *>(P.freq_inputs + (size_t)slot * P.ray_max_steps);
+      const double2 *rec = P.transfer + (size_t)slot * P.ray_max_steps * P.n_nu + l;
+      for (int n = num - 1; n >= 0; n--) {   // reference sample order is reversed integration order (geodesics.cpp:832-840)
+        const double2 q0 = in[4 * (size_t)n], q1 = in[4 * (size_t)n + 1], q2 = in[4 * (size_t)n + 2], q3 = in[4 * (size_t)n + 3];
+        double a = 1.0, c = 0.0;
+        if (every_record || q0.x == 3.0) {
+          const double2 ac = rec[(size_t)n * P.n_nu];
+          a = ac.x;
+          c = ac.y;
+        } else if (q0.x == 2.0) {
+          c = nan;
+        } else if (q0.x == 1.0) {
+          // bl_shade_fast_kernel's frequency loop (simulation_coefficients.cpp:464-523, unpolarized.cpp:74-110)
+          const double xx_1_3 = q1.x * f_1_3;
+          const double var_c = q0.y * f_1_2 + kPow2_11_12 * (q1.y * f_1_6);
+          const double j_val = q2.y * f_inv2 * fastmath::exp(-xx_1_3) * var_c * var_c;
+          const double inv_b_nu = fastmath::expm1(q2.x * f) * (kC * kC / (2.0 * kH));
+          double alpha_val = j_val * inv_b_nu;
+          if (alpha_val * alpha_val <= 0x1p-1024) alpha_val = 0.0;
+          const double delta_lambda_cgs = q3.x * f_inv;
+          if (alpha_val > 0.0) {
+            const double ss = j_val * fastmath::rcp(alpha_val);
+            const double delta_tau = alpha_val * delta_lambda_cgs;
+            if (delta_tau <= kDeltaTauMax) {
+              const double e1 = fastmath::expm1(-delta_tau);
+              a = 1.0 + e1;
+              c = -ss * e1;
+            } else {
+              a = 0.0;
+              c = ss;
+            }
+          } else {
+            c = j_val * delta_lambda_cgs;
+          }
+        }
+        intensity = __builtin_fma(a, intensity, c);
+      }
+    }
+    P.image[(size_t)l * P.n_rays_total + out_index] = intensity * (f * f * f);   // unpolarized.cpp:206-207
+  }
+  // statistics: wave reduce, one atomic per wave
+  for (int offset = 32; offset > 0; offset >>= 1) {
+    samples += __shfl_xor(samples, offset, 64);
+    flagged += __shfl_xor(flagged, offset, 64);
+    int other = __shfl_xor(max_num, offset, 64);
+    max_num = other > max_num ? other : max_num;
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (samples) atomicAdd(&P.stats[0], samples);
+    if (flagged) atomicAdd(&P.stats[1], flagged);
+    atomicMax(&P.stats[2], (unsigned long long)max_num);
   }
 }
 #pragma clang fp contract(off)
@@ -2908,6 +3007,12 @@ extern "C" hipError_t bl_launch_polarized_coefficients(const BlShadeArgs *args, 
 extern "C" hipError_t bl_launch_debug_math(int op, long long n, const double *x, const double *y, double *out, hipStream_t stream) {
   int grid = (int)((n + 255) / 256);
   hipLaunchKernelGGL(bl_debug_math_kernel, dim3(grid), dim3(256), 0, stream, op, n, x, y, out);
+  return hipGetLastError();
+}
+
+extern "C" hipError_t bl_launch_transfer_freq(const BlTransferArgs *args, hipStream_t stream) {
+  const long long lanes = (long long)args->chunk_rays * args->n_nu;
+  hipLaunchKernelGGL(bl_transfer_freq_kernel, dim3((unsigned int)((lanes + 255) / 256)), dim3(256), 0, stream, *args);
   return hipGetLastError();
 }
 
