@@ -1186,7 +1186,7 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
     // chunk size from the scratch budget: per ray max_steps * (2 x 32 B record + 40 B located sample
     // (simulation mode) + 16 B * n_nu transfer)
     const uint64_t per_ray = static_cast<uint64_t>(max_steps)
-        * (sizeof(BlSampleHot) + sizeof(BlSampleCold) + (simulation ? sizeof(BlLocated) + sizeof(unsigned long long) : 0) + sizeof(double2) * n_nu
+        * (sizeof(BlSampleHot) + sizeof(BlSampleCold) + (simulation ? sizeof(BlLocated) + sizeof(unsigned long long) : 0) + (freq_split ? 0 : sizeof(double2) * n_nu)
            + (aux ? sizeof(BlAuxSample) + sizeof(double) : 0) + (slow ? 2 * sizeof(double) : 0)
            + (ctx->polarized ? sizeof(BlPolSample) + sizeof(BlCoefInputs) + 3 * sizeof(double2) * n_nu : 0)
            + (matrix_transport ? BL_POL_MATRIX_DOUBLES * sizeof(double) : 0) + (freq_split ? sizeof(BlFreqInputs) : 0)
@@ -1231,8 +1231,8 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
         sl.d_located.Ensure(record_capacity);
         sl.d_located_tag.Ensure(record_capacity);
       }
-      sl.d_transfer.Ensure(static_cast<size_t>(chunk) * max_steps * n_nu);
-      if (freq_split) sl.d_freq_inputs.Ensure(static_cast<size_t>(chunk) * max_steps);
+      if (freq_split) sl.d_freq_inputs.Ensure(static_cast<size_t>(chunk) * max_steps);   // instead of the transfer records
+      else sl.d_transfer.Ensure(static_cast<size_t>(chunk) * max_steps * n_nu);
       sl.d_ray_kt.Ensure(chunk);
       sl.d_ray_factor.Ensure(chunk);
       sl.d_ray_sample_num.Ensure(chunk);
@@ -1703,8 +1703,6 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
       sa.freq_split = freq_split ? 1 : 0;
       sa.freq_inputs = freq_split ? sl.d_freq_inputs.ptr : nullptr;
       xa.freq_inputs = sa.freq_inputs;
-      xa.redo_counter = sl.d_counters.ptr + BL_CNT_REDO;
-      xa.redo_capacity = redo_capacity;
       sa.counters_in = sl.d_counters.ptr;
       sa.counters = sl.d_counters.ptr;
       sa.ray_kt = sl.d_ray_kt.ptr;

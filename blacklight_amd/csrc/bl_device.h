@@ -248,8 +248,8 @@ struct alignas(16) BlPolSample {
 // Tolerant tier with several frequencies (BlShadeArgs::freq_split): what is left of a sample once everything that does not
 // depend on the frequency has been evaluated - the factors of bl_shade_fast_kernel's frequency loop. bl_transfer_freq_kernel
 // (one lane per ray and frequency) turns them into the sample's (a, c) and applies it on the spot: no transfer records.
-// flag: 0 nothing to add (cut sample, cut cell, no field), 1 coefficients follow, 2 NaN (off the grid with fallback_nan),
-// 3 the exact second pass wrote this sample's records (deferred cut decision). 64 bytes.
+// flag: 0 nothing to add (cut sample, cut cell, no field), 1 coefficients follow, 2 NaN (off the grid with fallback_nan).
+// A sample whose cut decision is deferred gets its factors from the exact second pass (bl_shade_kernel<..., kRedo>). 64 bytes.
 struct alignas(16) BlFreqInputs {
   double flag;
   double s_1_2, s_1_3, s_1_6;   // x^(1/2), x^(1/3), x^(1/6) of x = nu / nu_s at unit frequency
@@ -351,8 +351,6 @@ struct BlTransferArgs {
   int fallback_nan, model_type;
   int affine;                 // tolerant tier: records are (a, c) of I <- a I + c instead of (a, b) of I <- a (I + b)
   const BlFreqInputs *freq_inputs;            // bl_transfer_freq_kernel
-  const unsigned long long *redo_counter;     // ... number of deferred samples (device), and what the list holds:
-  unsigned long long redo_capacity;           //     beyond it the exact pass has written every sample's records
   long long n_rays_total;
   double *image;              // [n_q][n_rays_total]; rows 0..n_nu-1 = I_nu
   int *out_sample_num;        // [n_rays_total] or null

@@ -1989,6 +1989,26 @@ __global__ void __launch_bounds__(256, 2) bl_shade_kernel(const BlShadeArgs P) {
       P.coef_inputs[idx_cur] = ci;
       continue;
     }
+    if (kRedo && kModel == BL_MODEL_SIMULATION && P.freq_split) {
+      // second pass of the tolerant tier with several frequencies: the cut decisions above were the point; what goes to
+      // bl_transfer_freq_kernel are the same per-sample factors the fast kernel leaves (BlFreqInputs), from this sample's
+      // exactly computed state - thermal electrons only, as everywhere in that tier
+      double2 *dst = reinterpret_cast<double2 *>(P.freq_inputs + ((size_t)ray * P.ray_max_steps + n));
+      if (!sh.have_coefficients) {
+        dst[0] = make_double2(0.0, 0.0);
+      } else {
+        const double nu_s_cgs = 2.0 / 9.0 * sh.nu_c_cgs * sh.theta_e * sh.theta_e * sh.sin_theta_b;
+        const double s_nu = sh.nu_fluid_over_nu * momentum_factor;
+        const double s_x = s_nu / nu_s_cgs;
+        const double s_1_3 = bl_cbrt(s_x);
+        dst[0] = make_double2(1.0, bl_sqrt_g(s_x));
+        dst[1] = make_double2(s_1_3, bl_sqrt_g(s_1_3));
+        dst[2] = make_double2(kH * s_nu / sh.kb_tt_e_cgs, P.plasma.plasma_thermal_frac * sh.n_e_cgs * kE * kE * sh.nu_c_cgs * (1.0 / kC)
+                                  * (kSqrt2 * kPi / 27.0) * sh.sin_theta_b / (s_nu * s_nu));
+        dst[3] = make_double2(delta_lambda * P.x_unit / momentum_factor, 0.0);
+      }
+      continue;
+    }
     // ---------------- per-frequency coefficients and transfer records
     for (int l = 0; l < P.n_nu; l++) {
       const double freq = P.frequencies[l];
@@ -2430,7 +2450,6 @@ __global__ void __launch_bounds__(256, BL_FAST_WAVES) bl_shade_fast_kernel(const
       // ReverseGeodesics: sample_len = -geodesic_len (geodesics.cpp:840)
       if (!fast_shade_sample<kSpinZero>(P, fast_table, pr, status, ray, n, rec.q0.x, rec.q0.y, rec.q1.x, rec.q2.x, rec.q2.y, rec.q3.x, kt,
                                         momentum_factor, -rec.q3.y)) {
-        if (P.freq_split) reinterpret_cast<double2 *>(P.freq_inputs + ((size_t)ray * P.ray_max_steps + n))[0] = make_double2(3.0, 0.0);
         fast_defer(P, idx_rec);
       }
     }
@@ -2440,7 +2459,7 @@ __global__ void __launch_bounds__(256, BL_FAST_WAVES) bl_shade_fast_kernel(const
 // Several frequencies in the tolerant tier: one lane per (ray, frequency) walks the ray far -> near, builds each sample's
 // (a, c) from the sample's factors (BlFreqInputs; the lanes of one ray read the same 64 bytes) and the lane's own frequency,
 // and applies I <- a I + c at once. The per-frequency transfer records (16 bytes per sample and frequency: 1.5 TB written
-// and read per 1024^2 x 64-frequency frame) exist only for the samples the exact second pass shaded.
+// and read per 1024^2 x 64-frequency frame) do not exist on this path; the exact second pass leaves the same factors.
 __global__ void __launch_bounds__(256) bl_transfer_freq_kernel(BlTransferArgs P) {
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const int slot = (int)(t / P.n_nu);
@@ -2467,17 +2486,11 @@ __global__ void __launch_bounds__(256) bl_transfer_freq_kernel(BlTransferArgs P)
       const double f_1_2 = bl_sqrt_g(f), f_1_3 = fastmath::cbrt(f);
       const double f_1_6 = bl_sqrt_g(f_1_3), f_inv = fastmath::rcp(f);
       const double f_inv2 = f_inv * f_inv;
-      const bool every_record = *P.redo_counter > P.redo_capacity;   // the exact pass shaded every sample
       const double2 *in = reinterpret_cast<const double2 *>(P.freq_inputs + (size_t)slot * P.ray_max_steps);
-      const double2 *rec = P.transfer + (size_t)slot * P.ray_max_steps * P.n_nu + l;
       for (int n = num - 1; n >= 0; n--) {   // reference sample order is reversed integration order (geodesics.cpp:832-840)
         const double2 q0 = in[4 * (size_t)n], q1 = in[4 * (size_t)n + 1], q2 = in[4 * (size_t)n + 2], q3 = in[4 * (size_t)n + 3];
         double a = 1.0, c = 0.0;
-        if (every_record || q0.x == 3.0) {
-          const double2 ac = rec[(size_t)n * P.n_nu];
-          a = ac.x;
-          c = ac.y;
-        } else if (q0.x == 2.0) {
+        if (q0.x == 2.0) {
           c = nan;
         } else if (q0.x == 1.0) {
           // bl_shade_fast_kernel's frequency loop (simulation_coefficients.cpp:464-523, unpolarized.cpp:74-110)
@@ -2492,7 +2505,10 @@ __global__ void __launch_bounds__(256) bl_transfer_freq_kernel(BlTransferArgs P)
             const double ss = j_val * fastmath::rcp(alpha_val);
             const double delta_tau = alpha_val * delta_lambda_cgs;
             if (delta_tau <= kDeltaTauMax) {
-              const double e1 = fastmath::expm1(-delta_tau);
+              // optically thin step (nearly every sample): expm1(-t) = -t (1 - t/2 (1 - t/3 (1 - t/4))) to 2^-53 below t = 2^-10
+              const double e1 = delta_tau < 0x1p-10
+                  ? -delta_tau * (1.0 - 0.5 * delta_tau * (1.0 - (1.0 / 3.0) * delta_tau * (1.0 - 0.25 * delta_tau)))
+                  : fastmath::expm1(-delta_tau);
               a = 1.0 + e1;
               c = -ss * e1;
             } else {

@@ -132,15 +132,19 @@ def test_tolerant_tier_on_seeded_configurations(seed, built_library):
     assert np.isfinite(exact["image"]).mean() > 0.5
 
 
-@pytest.mark.parametrize("band,resolution", [(1.0e30, 24), (1.0e30, 56)])
-def test_deferred_cut_decisions(band, resolution, built_library):
+@pytest.mark.parametrize("band,resolution,frequencies", [(1.0e30, 24, 1), (1.0e30, 56, 1), (1.0e30, 24, 5), (1.0e30, 56, 5)])
+def test_deferred_cut_decisions(band, resolution, frequencies, built_library):
     """An unbounded guard band defers every sample that reaches the cell cuts to the exact kernel: through the list
     (24^2 rays), and past its capacity (56^2 rays x ~700 samples > 2^20 entries: every record is then shaded by the
-    exact kernel). Same image either way."""
+    exact kernel). Same image either way - with one frequency (transfer records) and with five (per-sample factors for
+    bl_transfer_freq_kernel, which the exact pass then has to leave as well)."""
     import blacklight_amd as bl
     # sim_cuts: rho, B and 1 / beta thresholds behind geometric cuts; sim_dp_interp (sigma < 1 only) keeps nearly every sample
     fx, params, mock_args = gu.load_case("sim_cuts" if resolution < 40 else "sim_dp_interp")
     params = dict(params, camera_resolution=resolution)
+    if frequencies > 1:
+        params.update(image_num_frequencies=frequencies, image_frequency_start=1.0e11, image_frequency_end=8.0e11, image_frequency_spacing="log")
+        params.pop("image_frequency", None)
     p = bl.Params.from_dict(params)
     with bl.Context(p) as ctx:
         ctx.set_grid(gu.golden_grid(mock_args))
