@@ -2497,23 +2497,31 @@ __global__ void __launch_bounds__(256) bl_transfer_freq_kernel(BlTransferArgs P)
           const double xx_1_3 = q1.x * f_1_3;
           const double var_c = q0.y * f_1_2 + kPow2_11_12 * (q1.y * f_1_6);
           const double j_val = q2.y * f_inv2 * fastmath::exp(-xx_1_3) * var_c * var_c;
-          const double inv_b_nu = fastmath::expm1(q2.x * f) * (kC * kC / (2.0 * kH));
+          // h nu / (k T_e) is tiny for the hot plasma that shines (Rayleigh-Jeans): the same four-term form as for the thin step
+          const double xp = q2.x * f;
+          const double planck = xp < 0x1p-10 ? xp * (1.0 + 0.5 * xp * (1.0 + (1.0 / 3.0) * xp * (1.0 + 0.25 * xp))) : fastmath::expm1(xp);
+          const double inv_b_nu = planck * (kC * kC / (2.0 * kH));
           double alpha_val = j_val * inv_b_nu;
           if (alpha_val * alpha_val <= 0x1p-1024) alpha_val = 0.0;
           const double delta_lambda_cgs = q3.x * f_inv;
           if (alpha_val > 0.0) {
-            const double ss = j_val * fastmath::rcp(alpha_val);
             const double delta_tau = alpha_val * delta_lambda_cgs;
-            if (delta_tau <= kDeltaTauMax) {
-              // optically thin step (nearly every sample): expm1(-t) = -t (1 - t/2 (1 - t/3 (1 - t/4))) to 2^-53 below t = 2^-10
-              const double e1 = delta_tau < 0x1p-10
-                  ? -delta_tau * (1.0 - 0.5 * delta_tau * (1.0 - (1.0 / 3.0) * delta_tau * (1.0 - 0.25 * delta_tau)))
-                  : fastmath::expm1(-delta_tau);
-              a = 1.0 + e1;
-              c = -ss * e1;
+            if (delta_tau < 0x1p-10) {
+              // optically thin step (nearly every sample): expm1(-t) = -t p(t), p = 1 - t/2 (1 - t/3 (1 - t/4)) to 2^-53, so
+              // a = 1 - t p and c = -(j / alpha) expm1(-t) = j dl p: no exponential and no division
+              const double p = 1.0 - 0.5 * delta_tau * (1.0 - (1.0 / 3.0) * delta_tau * (1.0 - 0.25 * delta_tau));
+              a = 1.0 - delta_tau * p;
+              c = j_val * delta_lambda_cgs * p;
             } else {
-              a = 0.0;
-              c = ss;
+              const double ss = j_val * fastmath::rcp(alpha_val);
+              if (delta_tau <= kDeltaTauMax) {
+                const double e1 = fastmath::expm1(-delta_tau);
+                a = 1.0 + e1;
+                c = -ss * e1;
+              } else {
+                a = 0.0;
+                c = ss;
+              }
             }
           } else {
             c = j_val * delta_lambda_cgs;
