@@ -2273,18 +2273,23 @@ __device__ __forceinline__ bool fast_shade_sample(const BlShadeArgs &P, const do
       const double xx_1_3 = s_1_3 * f_1_3;
       const double var_c = s_1_2 * f_1_2 + kPow2_11_12 * (s_1_6 * f_1_6);
       const double j_val = s_j * (f_inv * f_inv) * fastmath::exp(-xx_1_3) * var_c * var_c;
-      const double inv_b_nu = fastmath::expm1(s_planck * f) * (kC * kC / (2.0 * kH));   // 1 / (B_nu / nu^3)
+      // (thin steps in Rayleigh-Jeans plasma - nearly every sample - need neither expm1 nor a division: bl_transfer_freq_kernel)
+      const double xp = s_planck * f;
+      const double planck = xp < 0x1p-10 ? xp * (1.0 + 0.5 * xp * (1.0 + (1.0 / 3.0) * xp * (1.0 + 0.25 * xp))) : fastmath::expm1(xp);
+      const double inv_b_nu = planck * (kC * kC / (2.0 * kH));   // 1 / (B_nu / nu^3)
       double alpha_val = j_val * inv_b_nu;
       if (alpha_val * alpha_val <= 0x1p-1024) alpha_val = 0.0;                                // :513-523
       const double delta_lambda_cgs = s_length * f_inv;
       if (alpha_val > 0.0) {
-        const double ss = j_val * fastmath::rcp(alpha_val);
         const double delta_tau = alpha_val * delta_lambda_cgs;
-        if (delta_tau <= kDeltaTauMax) {
+        if (delta_tau < 0x1p-10) {
+          const double p = 1.0 - 0.5 * delta_tau * (1.0 - (1.0 / 3.0) * delta_tau * (1.0 - 0.25 * delta_tau));
+          rec = make_double2(1.0 - delta_tau * p, j_val * delta_lambda_cgs * p);
+        } else if (delta_tau <= kDeltaTauMax) {
           const double e1 = fastmath::expm1(-delta_tau);
-          rec = make_double2(1.0 + e1, -ss * e1);
+          rec = make_double2(1.0 + e1, -(j_val * fastmath::rcp(alpha_val)) * e1);
         } else {
-          rec = make_double2(0.0, ss);
+          rec = make_double2(0.0, j_val * fastmath::rcp(alpha_val));
         }
       } else {
         rec = make_double2(1.0, j_val * delta_lambda_cgs);
