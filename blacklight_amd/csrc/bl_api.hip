@@ -1173,7 +1173,8 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
     // bl_set_arithmetic() asked for (bl_stats.arithmetic says which tier ran)
     const bool fast = ctx->arithmetic == BL_ARITH_TOLERANT && simulation && !aux && !ctx->polarized && !slow && !block_interp
         && p.plasma_power_frac == 0.0 && p.plasma_kappa_frac == 0.0 && p.plasma_model != BL_PLASMA_CODE_KAPPA
-        && (p.simulation_coord == BL_COORD_SKS || p.simulation_coord == BL_COORD_FMKS) && !p.ray_flat && ctx->plasma_thermal_frac != 0.0;
+        && (p.simulation_coord == BL_COORD_SKS || p.simulation_coord == BL_COORD_FMKS) && !p.ray_flat && ctx->plasma_thermal_frac != 0.0
+        && n_nu <= 1024;   // (its LDS table holds five numbers per frequency)
     // ... and the per-frequency coefficient kernel of polarized runs (frame, transport and coupling stay exact)
     const bool tolerant_polarized = ctx->arithmetic == BL_ARITH_TOLERANT && ctx->polarized;
     // ... and transport matrices (bl_transport_matrix_kernel) instead of the ray-sequential tensor transport, in curved spacetimes
