@@ -33,6 +33,7 @@ extern "C" hipError_t bl_launch_shade_fast(const BlShadeArgs *args, int grid, hi
 extern "C" hipError_t bl_launch_polarized_coefficients(const BlShadeArgs *args, int grid, hipStream_t stream);
 extern "C" hipError_t bl_launch_transfer(const BlTransferArgs *args, hipStream_t stream);
 extern "C" hipError_t bl_launch_transfer_freq(const BlTransferArgs *args, hipStream_t stream);
+extern "C" hipError_t bl_launch_coefficients_freq(const BlShadeArgs *args, int grid, hipStream_t stream);
 extern "C" hipError_t bl_launch_transfer_aux(const BlTransferArgs *args, hipStream_t stream);
 extern "C" hipError_t bl_launch_transfer_polarized(const BlTransferArgs *args, hipStream_t stream);
 extern "C" hipError_t bl_launch_transfer_polarized_matrix(const BlTransferArgs *args, int num_cus, hipStream_t stream);
@@ -1182,6 +1183,8 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
     // Several frequencies in the fast path: per-sample factors (BlFreqInputs) instead of per-frequency transfer records,
     // evaluated by bl_transfer_freq_kernel with one lane per ray and frequency
     const bool freq_split = fast && n_nu >= 4;
+    // ... and in the exact coefficient kernel (plain images): the frequency loop as lanes of bl_coefficients_freq_kernel
+    const bool coef_split = !fast && simulation && !aux && !ctx->polarized && n_nu >= 4;
     // (polarized runs list the samples without coefficients there - cut samples, cut cells - which are many more)
     const size_t redo_capacity = ctx->polarized ? (1u << 24) : (1u << 20);
     // chunk size from the scratch budget: per ray max_steps * (2 x 32 B record + 40 B located sample
@@ -1190,6 +1193,7 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
         * (sizeof(BlSampleHot) + sizeof(BlSampleCold) + (simulation ? sizeof(BlLocated) + sizeof(unsigned long long) : 0) + (freq_split ? 0 : sizeof(double2) * n_nu)
            + (aux ? sizeof(BlAuxSample) + sizeof(double) : 0) + (slow ? 2 * sizeof(double) : 0)
            + (ctx->polarized ? sizeof(BlPolSample) + sizeof(BlCoefInputs) + 3 * sizeof(double2) * n_nu : 0)
+           + (coef_split ? sizeof(BlCoefInputs) : 0)
            + (matrix_transport ? BL_POL_MATRIX_DOUBLES * sizeof(double) : 0) + (freq_split ? sizeof(BlFreqInputs) : 0)
            + (block_interp ? 8 * sizeof(unsigned int) : 0)) + 64;
     // One chunk if the whole call fits the budget. With bl_set_overlap(): two scratch sets of half the budget
@@ -1249,6 +1253,7 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
         sl.d_pol_coeffs.Ensure(static_cast<size_t>(chunk) * max_steps * n_nu * 3);
         sl.d_coef_inputs.Ensure(record_capacity);
       }
+      if (coef_split) sl.d_coef_inputs.Ensure(record_capacity);
       if (block_interp) sl.d_anchors.Ensure(record_capacity * 8);
       if (fast || ctx->polarized) sl.d_redo.Ensure(redo_capacity);   // polarized runs: the samples whose frame bl_polarized_frame_kernel builds
     }
@@ -1702,6 +1707,7 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
       sa.located_tag = simulation ? sl.d_located_tag.ptr : nullptr;
       sa.tag_in_record = fast ? 1 : 0;
       sa.freq_split = freq_split ? 1 : 0;
+      sa.coef_split = coef_split ? 1 : 0;
       sa.freq_inputs = freq_split ? sl.d_freq_inputs.ptr : nullptr;
       xa.freq_inputs = sa.freq_inputs;
       sa.counters_in = sl.d_counters.ptr;
@@ -1718,6 +1724,7 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
       ta.sample_t = need_time ? sl.d_sample_t.ptr : nullptr;
       sa.aux = aux ? sl.d_aux.ptr : nullptr;
       sa.sample_t = ta.sample_t;
+      if (coef_split) sa.coef_inputs = sl.d_coef_inputs.ptr;
       if (ctx->polarized) {
         sa.pol_samples = sl.d_pol_samples.ptr;
         sa.pol_coeffs = sl.d_pol_coeffs.ptr;
@@ -1808,6 +1815,7 @@ int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
       if (fast) Check(bl_launch_shade_fast(&sa, shade_grid, stream), "coefficient kernel launch");
       else Check(bl_launch_shade(&sa, p.model_type, shade_grid, stream), "coefficient kernel launch");
       if (ctx->polarized) Check(bl_launch_polarized_coefficients(&sa, ctx->num_cus * 8, stream), "polarized coefficient kernel launch");
+      if (coef_split) Check(bl_launch_coefficients_freq(&sa, ctx->num_cus * 16, stream), "per-frequency coefficient kernel launch");
       Check(hipEventRecord(e[4], stream), "event");
       Check(aux ? bl_launch_transfer_aux(&xa, stream) : (freq_split ? bl_launch_transfer_freq(&xa, stream) : bl_launch_transfer(&xa, stream)),
             "transfer kernel launch");

@@ -296,6 +296,7 @@ struct BlShadeArgs {
   BlLocated *located;         // [record capacity], simulation mode
   unsigned long long *located_tag;   // [record capacity]: cell | status << 32 | time slice << 40
   BlFreqInputs *freq_inputs;         // [chunk_rays][ray_max_steps] when freq_split
+  int coef_split;                    // exact tier, plain images, n_nu >= 4: BlCoefInputs for bl_coefficients_freq_kernel instead of the frequency loop
   int freq_split;                    // tolerant tier, n_nu >= 4: per-sample factors instead of per-frequency transfer records
   int tag_in_record;                 // tolerant tier: the tag is written into BlLocated::ph instead (32 bytes per sample, one stream)
   int lds_table_bytes;        // size of the coordinate tables the locate kernel stages in LDS; 0: searched in HBM

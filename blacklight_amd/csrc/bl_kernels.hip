@@ -1989,6 +1989,21 @@ __global__ void __launch_bounds__(256, 2) bl_shade_kernel(const BlShadeArgs P) {
       P.coef_inputs[idx_cur] = ci;
       continue;
     }
+    if (!kAux && !kPolarized && !kRedo && kModel == BL_MODEL_SIMULATION && P.coef_split) {
+      // exact tier with several frequencies: the per-frequency formulas and transfer records are bl_coefficients_freq_kernel's,
+      // one lane per (record, frequency); it gets the six numbers they need, the sample's length in the sign's slot
+      BlCoefInputs ci;
+      ci.nu_fluid_over_nu = sh.nu_fluid_over_nu;
+      ci.n_e_cgs = sh.n_e_cgs;
+      ci.nu_c_cgs = sh.nu_c_cgs;
+      ci.theta_e = sh.theta_e;
+      ci.kb_tt_e_cgs = sh.kb_tt_e_cgs;
+      ci.cos2_theta_b = sh.sin_theta_b;   // (sin theta_B itself: nothing here needs the cosine)
+      ci.cos_sign = delta_lambda;
+      ci.have_coefficients = sh.have_coefficients ? 1.0 : 0.0;
+      P.coef_inputs[idx_cur] = ci;
+      continue;
+    }
     if (kRedo && kModel == BL_MODEL_SIMULATION && P.freq_split) {
       // second pass of the tolerant tier with several frequencies: the cut decisions above were the point; what goes to
       // bl_transfer_freq_kernel are the same per-sample factors the fast kernel leaves (BlFreqInputs), from this sample's
@@ -2612,6 +2627,42 @@ __global__ void __launch_bounds__(256, 2) bl_polarized_coefficients_kernel(const
   }
 }
 
+// Exact tier, plain images with several frequencies: one lane per (sample record, frequency). The coefficient kernel's frequency
+// loop (simulation_coefficients.cpp:464-523, :556-584; unpolarized.cpp:74-110) with the loop turned into lanes: the lanes of a
+// record read the same 64 bytes of inputs, evaluate the pinned formulas at their own frequency - the same operations on the
+// same operands as in the loop, so the same bits - and write the record's transfer records side by side (one contiguous
+// kilobyte per sample at 64 frequencies instead of 64 scattered 16-byte stores per lane), at four waves per SIMD.
+template <bool kExtended>
+__global__ void __launch_bounds__(256, 4) bl_coefficients_freq_kernel(const BlShadeArgs P) {
+  const unsigned long long n_records = P.counters_in[BL_CNT_RECORDS];
+  const unsigned long long total = n_records * (unsigned long long)P.n_nu;
+  const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+  for (unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const unsigned long long idx = t / (unsigned long long)P.n_nu;
+    const int l = (int)(t - idx * (unsigned long long)P.n_nu);
+    const unsigned long long tag = reinterpret_cast<const unsigned long long *>(P.records_hot + idx)[3];   // (ray, n)
+    const uint32_t ray = (uint32_t)tag;
+    if (ray == BL_DEAD_RAY) continue;
+    const uint32_t n = (uint32_t)(tag >> 32);
+    const BlCoefInputs ci = P.coef_inputs[idx];
+    const double momentum_factor = P.ray_factor[ray];
+    SampleShade sh;
+    sh.have_coefficients = ci.have_coefficients != 0.0;
+    sh.nu_fluid_over_nu = ci.nu_fluid_over_nu;
+    sh.n_e_cgs = ci.n_e_cgs;
+    sh.nu_c_cgs = ci.nu_c_cgs;
+    sh.theta_e = ci.theta_e;
+    sh.kb_tt_e_cgs = ci.kb_tt_e_cgs;
+    sh.sin_theta_b = ci.cos2_theta_b;
+    const double delta_lambda = ci.cos_sign;
+    const double freq = P.frequencies[l];
+    double j_val = 0.0, alpha_val = 0.0;
+    if (sh.have_coefficients) simulation_coefficients<kExtended>(P, sh, freq, momentum_factor, &j_val, &alpha_val);
+    const double delta_lambda_cgs = bl_div_g(delta_lambda * P.x_unit, freq * momentum_factor);   // unpolarized.cpp:75-76
+    P.transfer[((size_t)ray * P.ray_max_steps + n) * P.n_nu + l] = transfer_record(j_val, alpha_val, delta_lambda_cgs);
+  }
+}
+
 // The fluid frame of the samples without coefficients (polarized.cpp:163-265 at cut samples and cut or field-free cells):
 // k^mu and tetrad rows 1, 2 into their BlPolSample, from what the coefficient kernel parked in BlCoefInputs.
 __global__ void __launch_bounds__(256) bl_polarized_frame_kernel(const BlShadeArgs P) {
@@ -3036,6 +3087,14 @@ extern "C" hipError_t bl_launch_polarized_coefficients(const BlShadeArgs *args, 
 extern "C" hipError_t bl_launch_debug_math(int op, long long n, const double *x, const double *y, double *out, hipStream_t stream) {
   int grid = (int)((n + 255) / 256);
   hipLaunchKernelGGL(bl_debug_math_kernel, dim3(grid), dim3(256), 0, stream, op, n, x, y, out);
+  return hipGetLastError();
+}
+
+extern "C" hipError_t bl_launch_coefficients_freq(const BlShadeArgs *args, int grid, hipStream_t stream) {
+  // (the instantiation bl_launch_shade chose for the coefficient kernel: power-law electrons only in the extended one)
+  const bool extended = args->plasma.power_frac != 0.0 || args->plasma.code_kappa != 0 || args->slow.n > 0 || args->anchors != nullptr;
+  if (extended) hipLaunchKernelGGL(bl_coefficients_freq_kernel<true>, dim3(grid), dim3(256), 0, stream, *args);
+  else hipLaunchKernelGGL(bl_coefficients_freq_kernel<false>, dim3(grid), dim3(256), 0, stream, *args);
   return hipGetLastError();
 }
 

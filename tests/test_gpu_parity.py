@@ -434,12 +434,14 @@ def test_contexts_give_their_memory_back(built_library):
     """bl_free releases everything a context allocated (records, grids, block tables, polarized scratch, redo lists): device
     memory after a series of contexts - plain, polarized + tolerant, refined mesh with inter-block interpolation - is back
     where it was (DeviceBuffer owns its allocation)."""
-    import torch
+    import ctypes
     import blacklight_amd as bl
+    hip = ctypes.CDLL("libamdhip64.so")
 
     def free_bytes():
-        torch.cuda.synchronize()
-        return torch.cuda.mem_get_info()[0]
+        free, total = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        assert hip.hipDeviceSynchronize() == 0 and hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)) == 0
+        return free.value
 
     def run(case, arithmetic):
         fx, params, mock_args = gu.load_case(case)
