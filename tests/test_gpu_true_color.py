@@ -68,6 +68,19 @@ def test_true_color_at_size_is_independent_of_how_it_is_split(built_library):
         freqs = ctx.frequencies
         assert full["image"].shape == (n_freq, res * res)
         assert full["stats"].n_chunks >= 8          # 1 KiB of transfer records per sample
+        # the tolerant tier on the same frame: per-sample factors and one lane per (ray, frequency), no transfer records
+        #  - every row within north_star's tolerance of the exact tier's, integer results identical
+        ctx.set_arithmetic("tolerant")
+        tolerant = ctx.render()
+        ctx.set_arithmetic("exact")
+        assert tolerant["stats"].arithmetic == 1 and tolerant["stats"].n_chunks < full["stats"].n_chunks
+        assert np.array_equal(tolerant["sample_num"], full["sample_num"])
+        assert np.array_equal(np.isnan(tolerant["image"]), np.isnan(full["image"]))
+        scale = np.nanmax(np.abs(full["image"]), axis=1, keepdims=True)
+        worst = float(np.nanmax(np.abs(tolerant["image"] - full["image"]) / scale))
+        print(f"1024^2 x 64 frequencies, tolerant vs exact: {worst:.2e} of each row's peak")
+        assert worst < 1.0e-6
+        del tolerant
         assembled = np.empty_like(full["image"])
         counts = np.full(res * res, -1, dtype=np.int32)
         for rank in range(world):
