@@ -67,9 +67,10 @@ def test_significant_extrapolation_is_an_error(built_library):
         assert text.endswith(" gravitational times).") and "(64/64 pixels, by up to 150." in text
 
 
+@pytest.mark.parametrize("n_freq", [1, 5])
 @pytest.mark.parametrize("case", gu.SLOW_CASES)
-def test_slow_light_with_block_interpolation_against_oracle(case, built_library):
-    """slow_light_on together with simulation_block_interp (simulation_sampling.cpp:960-1033: InterpolateAdvanced per time
+def test_slow_light_with_block_interpolation_against_oracle(case, n_freq, built_library):
+    """(With one frequency and with five.) slow_light_on together with simulation_block_interp (simulation_sampling.cpp:960-1033: InterpolateAdvanced per time
     slice, "<= 0 -> first anchor" per slice, then the blend in time): GPU vs the CPU oracle, bit-exact, on the slow-light
     fixtures' snapshots. These are single blocks - the file's last block - so the camera keeps clear of its upper
     half-cells in r and phi (where the reference reads past its centre rows): it sits at r = 40, phi = 180 degrees, and is
@@ -81,6 +82,9 @@ def test_slow_light_with_block_interpolation_against_oracle(case, built_library)
     fx = np.load(os.path.join(gu.GOLDEN_DIR, f"{case}.npz"), allow_pickle=False)
     params = dict(json.loads(str(fx["params"])), simulation_block_interp="true", simulation_interp="true", camera_resolution=10,
                   camera_r=40.0, camera_ph=180.0, camera_width=3.0, slow_num_images=2, simulation_a=0.0)
+    if n_freq > 1:   # several frequencies: the exact tier's frequency loop runs as lanes of bl_coefficients_freq_kernel
+        params.update(image_num_frequencies=n_freq, image_frequency_start=1.0e11, image_frequency_end=6.0e11, image_frequency_spacing="log")
+        params.pop("image_frequency", None)
     p = bl.Params.from_dict(params)
     grids = [gu.single_block_table(g) for g in gu.slow_light_grids(fx)]
     file_times = [float(t) for t in fx["file_times"]]
@@ -92,7 +96,7 @@ def test_slow_light_with_block_interpolation_against_oracle(case, built_library)
             got = ctx.render()
             descs = [grids[f].desc() for f in files]
             want = oracle_api.render(p.ptr, descs[0], _capi.RenderDesc, _capi.CameraFrame, n_rays=100, max_steps=int(params["ray_max_steps"]),
-                                     n_freq=1, slow=dict(grids=descs, times=[file_times[f] for f in files], snapshot_time=t_cam))
+                                     n_freq=n_freq, slow=dict(grids=descs, times=[file_times[f] for f in files], snapshot_time=t_cam))
             assert np.array_equal(got["sample_num"], want["sample_num"])
             assert gu.same_bits(got["image"], want["image"]).all(), (image, t_cam)
             assert np.nanmax(got["image"][0]) > 0.0
