@@ -23,6 +23,8 @@ def _true_color(n_freq, **extra):
     (64, 16, {}),
     (64, 12, dict(simulation_a=0.5, image_normalization="camera", camera_urn=-0.05)),
     (33, 16, dict(simulation_interp="false", image_frequency_spacing="lin_freq")),
+    # thermal + power-law electrons: the extended instantiation of the per-frequency kernel (bl_coefficients_freq_kernel<true>)
+    (12, 14, dict(plasma_power_frac=0.3, plasma_p=2.5, plasma_gamma_min=1.0, plasma_gamma_max=1000.0)),
 ])
 def test_many_frequencies_against_oracle(n_freq, res, extra, built_library):
     import blacklight_amd as bl
