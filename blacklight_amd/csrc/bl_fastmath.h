@@ -10,12 +10,12 @@
 
 namespace fastmath {
 
-// 1 / b (v_rcp_f64 + two Newton steps, ~1 ulp; v_div_fixup restores 1 / 0 = inf, 1 / inf = 0 and NaN)
+// 1 / b: v_rcp_f64 (about 26 good bits) + one Newton step, relative error <= 2.1e-15 - far inside the tier's 1e-6 and
+// six orders inside the guard band of the cut decisions; a second step (1.1e-16) costs two more multiply-adds per
+// reciprocal, 0.7 ms of the benchmark frame. v_div_fixup restores 1 / 0 = inf, 1 / inf = 0 and NaN.
 __device__ __forceinline__ double rcp(double b) {
   double y = __builtin_amdgcn_rcp(b);
-  double e = __builtin_fma(-b, y, 1.0);
-  y = __builtin_fma(y, e, y);
-  e = __builtin_fma(-b, y, 1.0);
+  const double e = __builtin_fma(-b, y, 1.0);
   y = __builtin_fma(y, e, y);
   return __builtin_amdgcn_div_fixup(y, b, 1.0);
 }
