@@ -69,7 +69,7 @@ class Stats(C.Structure):
         ("launches_geodesic", C.c_int32), ("launches_shade", C.c_int32),
         ("launches_transfer", C.c_int32),
         ("ms_locate", C.c_float), ("ms_wall", C.c_float), ("launches_locate", C.c_int32),
-        ("arithmetic", C.c_int32), ("n_deferred", C.c_int64),
+        ("arithmetic", C.c_int32), ("n_deferred", C.c_int64), ("n_undefined", C.c_int64),
     ]
 
 

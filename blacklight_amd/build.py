@@ -18,7 +18,7 @@ LIB = os.path.join(HERE, "libblacklight_amd.so")
 EXE = os.path.join(HERE, "bin", "blacklight_amd")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 
-SOURCES = ["bl_kernels.hip", "bl_polarized.hip", "bl_api.hip", "bl_params.cpp", "bl_host.cpp", "bl_snapshot.cpp"]
+SOURCES = ["bl_kernels.hip", "bl_polarized.hip", "bl_api.hip", "bl_render.hip", "bl_params.cpp", "bl_host.cpp", "bl_snapshot.cpp"]
 ARCH = "gfx950"
 DEVICE_FLAGS = ["-mllvm", "-disable-machine-licm"]
 COMMON = ["-std=c++17", "-O3", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden", f"-I{INCLUDE}", f"-I{CSRC}"]

@@ -1,0 +1,229 @@
+// bl_ctx.h - the context behind the C-ABI handle (include/blacklight_amd.h) and the few helpers the host-side
+// translation units of the HIP path share: bl_api.hip (construction, validation, grid upload, settings) and
+// bl_render.hip (bl_render: chunk planning, kernel pipeline, geodesic checkpoints, statistics). Internal, hidden visibility.
+#ifndef BLACKLIGHT_AMD_BL_CTX_H_
+#define BLACKLIGHT_AMD_BL_CTX_H_
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <limits>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../include/blacklight_amd.h"
+#include "bl_bessel.h"
+#include "bl_camera.h"
+#include "bl_device.h"
+#include "bl_internal.h"
+
+extern "C" hipError_t bl_launch_ray_init(const BlTraceArgs *args, int integrator, hipStream_t stream);
+extern "C" hipError_t bl_launch_geodesic(const BlTraceArgs *args, int integrator, int grid, hipStream_t stream);
+extern "C" int bl_geodesic_occupancy(int integrator, int with_time, int spin_zero);
+extern "C" hipError_t bl_launch_locate(const BlShadeArgs *args, int grid, int lds_bytes, hipStream_t stream);
+extern "C" hipError_t bl_launch_shade(const BlShadeArgs *args, int model, int grid, hipStream_t stream);
+extern "C" hipError_t bl_launch_shade_fast(const BlShadeArgs *args, int grid, hipStream_t stream);
+extern "C" hipError_t bl_launch_polarized_coefficients(const BlShadeArgs *args, int grid, hipStream_t stream);
+extern "C" hipError_t bl_launch_transfer(const BlTransferArgs *args, hipStream_t stream);
+extern "C" hipError_t bl_launch_transfer_freq(const BlTransferArgs *args, hipStream_t stream);
+extern "C" hipError_t bl_launch_coefficients_freq(const BlShadeArgs *args, int grid, hipStream_t stream);
+extern "C" hipError_t bl_launch_transfer_aux(const BlTransferArgs *args, hipStream_t stream);
+extern "C" hipError_t bl_launch_transfer_polarized(const BlTransferArgs *args, hipStream_t stream);
+extern "C" hipError_t bl_launch_transfer_polarized_matrix(const BlTransferArgs *args, int num_cus, hipStream_t stream);
+extern "C" hipError_t bl_launch_debug_math(int op, long long n, const double *x, const double *y, double *out, hipStream_t stream);
+
+namespace blhost {
+
+constexpr double kPi = 3.141592653589793;
+constexpr double kC = 2.99792458e10;
+constexpr double kGGMsun = 1.32712440018e26;
+constexpr double kMp = 1.67262192369e-24;
+constexpr int kNumCellValues = 7;
+
+struct Failure {
+  int code;
+  std::string message;
+};
+
+// Owning HBM allocation. Freed by the destructor (bl_free selects the context's device before it deletes the
+// context, so every buffer a context holds - scratch sets, grid, time slices, block tables - goes back to the
+// device); movable (the slow-light window swaps slices), not copyable.
+template <typename T>
+struct DeviceBuffer {
+  T *ptr = nullptr;
+  size_t count = 0;
+  DeviceBuffer() = default;
+  DeviceBuffer(const DeviceBuffer &) = delete;
+  DeviceBuffer &operator=(const DeviceBuffer &) = delete;
+  DeviceBuffer(DeviceBuffer &&other) noexcept : ptr(other.ptr), count(other.count) {
+    other.ptr = nullptr;
+    other.count = 0;
+  }
+  DeviceBuffer &operator=(DeviceBuffer &&other) noexcept {
+    if (this != &other) {
+      Free();
+      ptr = other.ptr;
+      count = other.count;
+      other.ptr = nullptr;
+      other.count = 0;
+    }
+    return *this;
+  }
+  ~DeviceBuffer() { Free(); }
+  void Free() {
+    if (ptr != nullptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    count = 0;
+  }
+  void Ensure(size_t n) {
+    if (n <= count) return;
+    Free();
+    hipError_t err = hipMalloc(reinterpret_cast<void **>(&ptr), n * sizeof(T));
+    if (err != hipSuccess)
+      throw Failure{BL_E_DEVICE, std::string("hipMalloc of ") + std::to_string(n * sizeof(T)) + " bytes failed: " + hipGetErrorString(err)};
+    count = n;
+  }
+};
+
+inline void Check(hipError_t err, const char *what) {
+  if (err != hipSuccess) throw Failure{BL_E_DEVICE, std::string(what) + ": " + hipGetErrorString(err)};
+}
+
+}  // namespace blhost
+using namespace blhost;
+
+struct bl_ctx {
+  bl_params params;
+  bl_camera_frame frame;
+  BlSpacetime st;
+  std::vector<double> frequencies;
+  std::string last_error, warnings;
+  int device = 0;
+  int num_cus = 256;
+  hipStream_t stream = nullptr;       // shading stream: locate, coefficient and transfer kernels, uploads
+  hipStream_t stream_geo = nullptr;   // geodesic kernel of the next chunk, concurrent with the above
+  std::vector<hipEvent_t> events;     // kEventsPerChunk per scratch set + begin / end of the render
+  unsigned long long *host_counters = nullptr;   // pinned, BL_CNT_TOTAL per scratch set
+  uint64_t scratch_limit = 144ull << 30;
+  int overlap_chunks = 0;             // bl_set_overlap(): geodesic kernel of chunk c + 1 beside the shading of chunk c
+  int arithmetic = BL_ARITH_EXACT;    // bl_set_arithmetic()
+  int undefined_policy = BL_UNDEFINED_REFUSE;   // bl_set_undefined_policy()
+  double guard_band = 1.0e-9;         // tolerant tier: relative half-width around a cut threshold left to the exact kernel
+
+  // image rows (radiation_integrator.cpp:436-520)
+  int image_num_quantities = 0;
+  BlAuxImages aux_images{};          // which image rows exist; .any = an auxiliary image or a rendering is requested
+  int render_num_images = 0;         // false-colour renderings (0 in formula mode)
+  DeviceBuffer<BlRenderDevice> d_render_params;
+  DeviceBuffer<double> d_render;     // staging for host output
+  double plasma_thermal_frac = 0.0;
+
+  // grid
+  bool have_grid = false;
+  int n_i = 0, n_j = 0, n_k = 0;
+  bl_grid_desc grid_meta{};
+  DeviceBuffer<float> d_cells;
+  DeviceBuffer<float> d_kappa;   // electron entropy per cell (plasma_model = code_kappa)
+  DeviceBuffer<double> d_coords;   // x1f x1v x2f x2v x3f x3v packed
+  DeviceBuffer<unsigned short> d_buckets;
+  DeviceBuffer<int> d_lattice;   // refined mesh: box of the block-boundary lattice -> block
+  DeviceBuffer<double> d_sks_map;   // simulation_coord = fmks: the reader's SKS -> FMKS look-up table
+  DeviceBuffer<int> d_block_table;                  // inter-block interpolation: levels, locations, hash blocks
+  DeviceBuffer<unsigned long long> d_block_keys;    // ... and hash keys
+  BlGridDevice grid_dev{};
+  int lds_table_bytes = 0;
+  DeviceBuffer<float> *cells_target = nullptr, *kappa_target = nullptr;   // where the grid upload puts the cells
+
+  // slow light: the reader's window of time slices (prim[n], time[n]; n = 0 latest) on one geometry
+  struct SlowSlice {
+    DeviceBuffer<float> cells, kappa;
+    double time = 0.0;
+    bool set = false;
+  };
+  std::vector<SlowSlice> slow_slices;
+  bl_slow_state slow_state{};            // reader-side bookkeeping of bl_slow_light_read (bl_snapshot.cpp)
+  bool polarized = false;                // image_light and image_polarization in simulation mode
+  double power_pol[7] = {};              // polarized power-law constants (simulation_coefficients.cpp:67-80)
+  int snapshot = 0;                      // index of the image being rendered (warning texts, camera time)
+  long long stats_slow_count[4] = {0, 0, 0, 0};    // pixels needing extrapolation in the last render, by kind
+  double stats_slow_val[4] = {0.0, 0.0, 0.0, 0.0};
+  DeviceBuffer<unsigned long long> d_slow_table;   // cells pointers, kappa pointers, times, extrapolation maxima
+  DeviceBuffer<unsigned int> d_ray_extrap;
+
+  // Per-chunk scratch, two sets (the geodesic kernel fills one while the shading kernels drain the other when bl_set_overlap is
+  // on). Every array has one entry per sample record or per kept sample, so a set holds `record_capacity` of each and a chunk
+  // is as many rays as the geodesic kernel fits into it (BlTraceArgs::record_gate).
+  struct ChunkSlot {
+    DeviceBuffer<BlSampleHot> d_records_hot;
+    DeviceBuffer<BlSampleCold> d_records_cold;
+    DeviceBuffer<BlLocated> d_located;
+    DeviceBuffer<unsigned long long> d_located_tag;
+    DeviceBuffer<double2> d_transfer;
+    DeviceBuffer<unsigned long long> d_counters;   // BL_CNT_TOTAL
+    DeviceBuffer<BlAuxSample> d_aux;               // auxiliary-image mode
+    DeviceBuffer<double> d_sample_t;               // image_time, slow light
+    DeviceBuffer<double> d_slow_frac;              // slow light: t_frac of every located sample
+    DeviceBuffer<BlPolSample> d_pol_samples;       // polarized transfer
+    DeviceBuffer<double> d_pol_matrix;             // tolerant tier: 12 doubles per sample
+    DeviceBuffer<BlFreqInputs> d_freq_inputs;      // tolerant tier, several frequencies
+    DeviceBuffer<double2> d_pol_coeffs;
+    DeviceBuffer<unsigned int> d_anchors;          // inter-block interpolation: eight anchor cells per record
+    DeviceBuffer<BlCoefInputs> d_coef_inputs;      // polarized runs: coefficient kernel -> polarized coefficient kernel
+    DeviceBuffer<unsigned long long> d_redo;       // tolerant tier: records left to the exact coefficient kernel
+    uint64_t Bytes() const {
+      return d_records_hot.count * sizeof(BlSampleHot) + d_records_cold.count * sizeof(BlSampleCold) + d_located.count * sizeof(BlLocated)
+          + d_located_tag.count * sizeof(unsigned long long) + d_transfer.count * sizeof(double2) + d_aux.count * sizeof(BlAuxSample)
+          + (d_sample_t.count + d_slow_frac.count + d_pol_matrix.count) * sizeof(double) + d_pol_samples.count * sizeof(BlPolSample)
+          + d_freq_inputs.count * sizeof(BlFreqInputs) + d_pol_coeffs.count * sizeof(double2) + d_anchors.count * sizeof(unsigned int)
+          + d_coef_inputs.count * sizeof(BlCoefInputs) + d_redo.count * sizeof(unsigned long long);
+    }
+    void Free() {
+      d_redo.Free(); d_aux.Free(); d_sample_t.Free(); d_slow_frac.Free(); d_pol_samples.Free(); d_pol_matrix.Free(); d_freq_inputs.Free(); d_pol_coeffs.Free(); d_coef_inputs.Free(); d_anchors.Free();
+      d_records_hot.Free(); d_records_cold.Free(); d_located.Free(); d_located_tag.Free(); d_transfer.Free(); d_counters.Free();
+    }
+  };
+  ChunkSlot slot[2];
+  // per ray of a bl_render call (indexed by traversal position; a chunk's kernels get pointers to its first ray)
+  DeviceBuffer<double> d_ray_kt, d_ray_factor;
+  DeviceBuffer<double> d_ray_start;              // BL_RAY_START_FIELDS rows: start state of every ray (bl_ray_init_kernel -> geodesic kernel)
+  DeviceBuffer<int> d_ray_sample_num;
+  DeviceBuffer<unsigned char> d_ray_flags;
+  DeviceBuffer<long long> d_ray_out_index, d_ray_offset;
+  uint64_t RayBytes() const {
+    return (d_ray_kt.count + d_ray_factor.count + d_ray_start.count) * sizeof(double) + d_ray_sample_num.count * sizeof(int) + d_ray_flags.count
+        + (d_ray_out_index.count + d_ray_offset.count) * sizeof(long long);
+  }
+  DeviceBuffer<double> d_freq;
+  DeviceBuffer<int> d_pixel_map, d_block_locs, d_tile_order;
+  int tile_order_res = 0;
+  DeviceBuffer<BlShadeCold> d_shade_cold;
+  // host-output staging
+  DeviceBuffer<double> d_image, d_camera_pos, d_camera_dir;
+  DeviceBuffer<int> d_out_sample_num;
+  DeviceBuffer<unsigned char> d_out_flags;
+
+  // geodesic checkpoint of the root level (geodesic_checkpoint.cpp:28-108): what LoadGeodesics() read, by pixel
+  struct Checkpoint {
+    bool loaded = false;
+    int num_steps = 0;
+    std::vector<double> camera_pos, camera_dir, factors;   // [n_pix][4], [n_pix][4], [n_pix]
+    std::vector<uint8_t> flags;
+    std::vector<int32_t> sample_num;
+    std::vector<double> pos, dir, len;   // [n_pix][num_steps][4] x 2, [n_pix][num_steps]: reference order (far -> near)
+  } checkpoint;
+
+  bl_stats stats{};
+};
+
+namespace blhost {
+inline void Warn(bl_ctx *ctx, const std::string &message) { ctx->warnings += "Warning: " + message + "\n"; }
+int Fail(bl_ctx *ctx, const Failure &failure);   // sets bl_last_error (or the global error when ctx is null), returns the code
+void EnsureStreams(bl_ctx *ctx);
+}  // namespace blhost
+
+#endif  // BLACKLIGHT_AMD_BL_CTX_H_

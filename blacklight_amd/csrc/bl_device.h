@@ -66,8 +66,13 @@ enum BlCounter {
   BL_CNT_UNDEFINED = 4,     // inter-block interpolation: samples at an upper edge of the last MeshBlock
   BL_CNT_INTERP_FAILED = 5, // inter-block interpolation: samples for which no anchor block exists
   BL_CNT_REDO = 6,          // tolerant tier: samples left to the exact coefficient kernel (redo list entries)
-  BL_CNT_COUNT = 8
+  BL_CNT_COMMITTED = 7,     // geodesic kernel: record slots spoken for - ray_max_steps per ray in flight, what it emitted per finished ray
+  BL_CNT_SAMPLES = 8,       // kept samples of the finished rays: where the next ray's per-sample rows start (BlTraceArgs::ray_offset)
+  BL_CNT_COUNT = 10
 };
+// per scratch set: the counters above, four transfer statistics, eight debug counters (kernels built with -DBL_GEO_STATS)
+#define BL_CNT_DEBUG (BL_CNT_COUNT + 4)
+#define BL_CNT_TOTAL (BL_CNT_COUNT + 12)
 
 struct BlGridDevice {
   const float *cells;        // [n_k][n_j][n_i][8]
@@ -222,13 +227,24 @@ struct BlTraceArgs {
   BlSampleCold *records_cold;
   double *sample_t;           // optional [record capacity]: coordinate time of each sample (image_time)
   long long record_capacity;
+  // The geodesic kernel hands a ray to a lane only while BL_CNT_COMMITTED + ray_max_steps <= record_gate (= capacity minus one
+  // block per wave): a chunk is the rays that fit the record buffers as they turn out, not as the worst case would have them.
+  // Rays it did not get to (BL_CNT_NEXT_RAY < chunk_rays at the end) are the next chunk's.
+  long long record_gate;
   unsigned long long *counters;
   double *ray_kt, *ray_factor;
   int *ray_sample_num;
   unsigned char *ray_flags;
   long long *ray_out_index;
+  long long *ray_offset;      // [chunk_rays]: first row of the ray's kept samples in the per-sample arrays (transfer records, ...)
   double *camera_pos, *camera_dir;  // optional [n_rays][4] indexed by output index
+  // Start state of every ray of the chunk, written by bl_ray_init_kernel (one ray per lane, every lane busy) and read by the
+  // persistent geodesic kernel when it hands a ray to an idle lane: BL_RAY_START_FIELDS rows of ray_start_stride doubles,
+  // [field][chunk slot] - t, x, y, z, k_x, k_y, k_z | k_t | r | first-stage derivatives (Dormand-Prince only)
+  double *ray_start;
+  long long ray_start_stride;
 };
+#define BL_RAY_START_FIELDS 17
 
 // Kernel arguments: shading kernel
 // Polarized transfer (image_polarization): what the polarized transfer kernel needs of every sample besides the
@@ -295,7 +311,7 @@ struct BlShadeArgs {
   const BlSampleCold *records_cold;
   BlLocated *located;         // [record capacity], simulation mode
   unsigned long long *located_tag;   // [record capacity]: cell | status << 32 | time slice << 40
-  BlFreqInputs *freq_inputs;         // [chunk_rays][ray_max_steps] when freq_split
+  BlFreqInputs *freq_inputs;         // [sample row] when freq_split
   int coef_split;                    // exact tier, plain images, n_nu >= 4: BlCoefInputs for bl_coefficients_freq_kernel instead of the frequency loop
   int freq_split;                    // tolerant tier, n_nu >= 4: per-sample factors instead of per-frequency transfer records
   int tag_in_record;                 // tolerant tier: the tag is written into BlLocated::ph instead (32 bytes per sample, one stream)
@@ -306,18 +322,19 @@ struct BlShadeArgs {
   const unsigned long long *counters_in;
   unsigned long long *counters;
   const double *ray_kt, *ray_factor;
+  const long long *ray_offset;   // [chunk_rays]: sample n of ray q has row ray_offset[q] + n in transfer, aux, pol_samples, freq_inputs, ...
   const double *frequencies;  // device [n_nu]
   int n_nu;
   int ray_max_steps;
   double x_unit;              // GM/c^2 in cm (unpolarized.cpp:42)
-  double2 *transfer;          // [chunk_rays][ray_max_steps][n_nu]; (a, b), or (j, alpha) in auxiliary mode
+  double2 *transfer;          // [sample row][n_nu]; (a, b), or (j, alpha) in auxiliary mode
   // auxiliary-image mode only
-  BlAuxSample *aux;           // [chunk_rays][ray_max_steps]
+  BlAuxSample *aux;           // [sample row]
   const double *sample_t;     // [record capacity] or null
   const unsigned char *ray_flags;
   // polarized transfer only (runs in auxiliary-image mode): null otherwise
-  BlPolSample *pol_samples;   // [chunk_rays][ray_max_steps]
-  double2 *pol_coeffs;        // [chunk_rays][ray_max_steps][n_nu][3]: (j_Q, j_V), (alpha_Q, alpha_V), (rho_Q, rho_V)
+  BlPolSample *pol_samples;   // [sample row]
+  double2 *pol_coeffs;        // [sample row][n_nu][3]: (j_Q, j_V), (alpha_Q, alpha_V), (rho_Q, rho_V)
   BlCoefInputs *coef_inputs;  // [record capacity]: coefficient kernel -> polarized coefficient kernel
   unsigned int *anchors;      // inter-block interpolation: [record capacity][8] cells of the eight anchors, else null
   double power_pol[7];        // simulation_coefficients.cpp:67-80: jj_q, jj_v, aa_q, aa_v, rho, rho_q, rho_v
@@ -338,15 +355,17 @@ struct BlTransferArgs {
   // polarized transfer only
   const BlPolSample *pol_samples;
   const double2 *pol_coeffs;
-  double *pol_matrix;                      // tolerant tier: [chunk_rays][ray_max_steps][BL_POL_MATRIX_DOUBLES] (bl_polarized.hip)
+  double *pol_matrix;                      // tolerant tier: [sample row][BL_POL_MATRIX_DOUBLES] (bl_polarized.hip)
   const double *camera_pos, *camera_dir;   // [n_rays_total][4] by output index: initial position, momentum
   BlSpacetime st;
   int simulation_coord, rotation_split;
   double cam_u_con[4], cam_u_cov[4], cam_vert_con_c[4];
   const double2 *transfer;
+  const unsigned long long *counters;      // BL_CNT_NEXT_RAY: rays of the chunk the geodesic kernel traced (bl_rays_done)
   const int *ray_sample_num;
   const unsigned char *ray_flags;
   const long long *ray_out_index;
+  const long long *ray_offset;             // [chunk_rays]: first sample row of each ray
   const double *frequencies;
   int n_nu, ray_max_steps, chunk_rays;
   int fallback_nan, model_type;
@@ -365,5 +384,13 @@ struct BlTransferArgs {
   const BlRenderDevice *render_params;   // device, or null
   double *render;                        // [n_images][3][n_rays_total], or null
 };
+
+#if defined(__HIPCC__) || defined(__HIP__)
+// Rays of a chunk the geodesic kernel traced: the rays after them did not fit the record buffers and go to the next chunk
+__device__ __forceinline__ int bl_rays_done(const unsigned long long *counters, int chunk_rays) {
+  const unsigned long long taken = counters[BL_CNT_NEXT_RAY];
+  return taken < (unsigned long long)chunk_rays ? (int)taken : chunk_rays;
+}
+#endif
 
 #endif  // BLACKLIGHT_AMD_BL_DEVICE_H_

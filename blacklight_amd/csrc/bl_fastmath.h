@@ -10,6 +10,13 @@
 
 namespace fastmath {
 
+// FMK(c): a 64-bit literal of this header. BL_FAST_SCALAR_LITERALS: as a scalar operand (blmath.h BLM_K) instead of two v_mov_b32
+#ifdef BL_FAST_SCALAR_LITERALS
+#define FMK(c) blm_scalar_literal(c)
+#else
+#define FMK(c) (c)
+#endif
+
 // 1 / b: v_rcp_f64 (about 26 good bits) + one Newton step, relative error <= 2.1e-15 - far inside the tier's 1e-6 and
 // six orders inside the guard band of the cut decisions; a second step (1.1e-16) costs two more multiply-adds per
 // reciprocal, 0.7 ms of the benchmark frame. v_div_fixup restores 1 / 0 = inf, 1 / inf = 0 and NaN.
@@ -32,21 +39,21 @@ __device__ __forceinline__ double rsqrt(double x) {
 // polynomial of bl_expm1 (blmath.h); hardware rounding and ldexp. One set of coefficients for both keeps two dozen
 // scalar registers free (a v_fma_f64 cannot take a 64-bit literal: every coefficient is a register pair).
 __device__ __forceinline__ double expm1_core(double x, int *k) {
-  const double kd = __builtin_rint(x * BLM_INV_LN2);
-  double r = __builtin_fma(-kd, BLM_LN2_HI, x);
-  r = __builtin_fma(-kd, BLM_LN2_LO, r);
-  double q = 0x1.94328fcb8199cp-37;
-  q = __builtin_fma(q, r, 0x1.61bfaa228dde5p-33);
-  q = __builtin_fma(q, r, 0x1.1eed7a01fc8b7p-29);
-  q = __builtin_fma(q, r, 0x1.ae642c82e33d5p-26);
-  q = __builtin_fma(q, r, 0x1.27e4fb7a2782ap-22);
-  q = __builtin_fma(q, r, 0x1.71de3a5aa7bb7p-19);
-  q = __builtin_fma(q, r, 0x1.a01a01a019b63p-16);
-  q = __builtin_fma(q, r, 0x1.a01a01a0196acp-13);
-  q = __builtin_fma(q, r, 0x1.6c16c16c16c17p-10);
-  q = __builtin_fma(q, r, 0x1.1111111111111p-7);
-  q = __builtin_fma(q, r, 0x1.5555555555555p-5);
-  q = __builtin_fma(q, r, 0x1.5555555555555p-3);
+  const double kd = __builtin_rint(x * FMK(0x1.71547652b82fep+0));
+  double r = __builtin_fma(-kd, FMK(0x1.62e42feep-1), x);
+  r = __builtin_fma(-kd, FMK(0x1.a39ef35793c76p-33), r);
+  double q = FMK(0x1.94328fcb8199cp-37);
+  q = __builtin_fma(q, r, FMK(0x1.61bfaa228dde5p-33));
+  q = __builtin_fma(q, r, FMK(0x1.1eed7a01fc8b7p-29));
+  q = __builtin_fma(q, r, FMK(0x1.ae642c82e33d5p-26));
+  q = __builtin_fma(q, r, FMK(0x1.27e4fb7a2782ap-22));
+  q = __builtin_fma(q, r, FMK(0x1.71de3a5aa7bb7p-19));
+  q = __builtin_fma(q, r, FMK(0x1.a01a01a019b63p-16));
+  q = __builtin_fma(q, r, FMK(0x1.a01a01a0196acp-13));
+  q = __builtin_fma(q, r, FMK(0x1.6c16c16c16c17p-10));
+  q = __builtin_fma(q, r, FMK(0x1.1111111111111p-7));
+  q = __builtin_fma(q, r, FMK(0x1.5555555555555p-5));
+  q = __builtin_fma(q, r, FMK(0x1.5555555555555p-3));
   const double r2 = r * r;
   *k = (int)kd;
   return r + __builtin_fma(r2 * r, q, 0.5 * r2);
@@ -76,11 +83,11 @@ __device__ __forceinline__ double cbrt(double x) {
   const float seed = __builtin_amdgcn_exp2f(__builtin_amdgcn_logf((float)m) * -0.33333334f);
   double z = (double)seed;
   double h = __builtin_fma(-m, z * z * z, 1.0);
-  z = __builtin_fma(z * h, 0x1.5555555555555p-2, z);
+  z = __builtin_fma(z * h, FMK(0x1.5555555555555p-2), z);
   h = __builtin_fma(-m, z * z * z, 1.0);
-  z = __builtin_fma(z * h, 0x1.5555555555555p-2, z);
+  z = __builtin_fma(z * h, FMK(0x1.5555555555555p-2), z);
   double c = m * z * z;                                             // m^(1/3), ~2 ulp
-  c = __builtin_fma(__builtin_fma(-c * c, c, m), z * z * 0x1.5555555555555p-2, c);   // c + (m - c^3) / (3 c^2)
+  c = __builtin_fma(__builtin_fma(-c * c, c, m), z * z * FMK(0x1.5555555555555p-2), c);   // c + (m - c^3) / (3 c^2)
   const double res = __builtin_amdgcn_ldexp(c, q);
   return __builtin_amdgcn_class(x, 0x263) ? x : res;               // NaN, +-0, +inf
 }
@@ -90,23 +97,23 @@ __device__ __forceinline__ double cbrt(double x) {
 __device__ __forceinline__ double log(double x) {
   int e = __builtin_amdgcn_frexp_exp(x);
   double m = __builtin_amdgcn_frexp_mant(x);   // [0.5, 1)
-  const bool low = m < 0x1.6a09e667f3bcdp-1;
+  const bool low = m < FMK(0x1.6a09e667f3bcdp-1);
   m = low ? 2.0 * m : m;
   e = low ? e - 1 : e;
   const double s = (m - 1.0) * rcp(m + 1.0);
   const double z = s * s;
-  double p = 1.0 / 19.0;
-  p = __builtin_fma(p, z, 1.0 / 17.0);
-  p = __builtin_fma(p, z, 1.0 / 15.0);
-  p = __builtin_fma(p, z, 1.0 / 13.0);
-  p = __builtin_fma(p, z, 1.0 / 11.0);
-  p = __builtin_fma(p, z, 1.0 / 9.0);
-  p = __builtin_fma(p, z, 1.0 / 7.0);
-  p = __builtin_fma(p, z, 1.0 / 5.0);
-  p = __builtin_fma(p, z, 1.0 / 3.0);
+  double p = FMK(1.0 / 19.0);
+  p = __builtin_fma(p, z, FMK(1.0 / 17.0));
+  p = __builtin_fma(p, z, FMK(1.0 / 15.0));
+  p = __builtin_fma(p, z, FMK(1.0 / 13.0));
+  p = __builtin_fma(p, z, FMK(1.0 / 11.0));
+  p = __builtin_fma(p, z, FMK(1.0 / 9.0));
+  p = __builtin_fma(p, z, FMK(1.0 / 7.0));
+  p = __builtin_fma(p, z, FMK(1.0 / 5.0));
+  p = __builtin_fma(p, z, FMK(1.0 / 3.0));
   const double ed = (double)e;
-  const double small = __builtin_fma(2.0 * s * z, p, ed * BLM_LN2_LO);   // 2 s (z / 3 + ...) + e ln2_lo
-  const double res = __builtin_fma(ed, BLM_LN2_HI, 2.0 * s + small);
+  const double small = __builtin_fma(2.0 * s * z, p, ed * FMK(0x1.a39ef35793c76p-33));   // 2 s (z / 3 + ...) + e ln2_lo
+  const double res = __builtin_fma(ed, FMK(0x1.62e42feep-1), 2.0 * s + small);
   // special arguments: +-0 -> -inf, negative -> NaN, +inf / NaN -> themselves
   if (__builtin_amdgcn_class(x, 0x060)) return -__builtin_inf();
   if (__builtin_amdgcn_class(x, 0x01c)) return __builtin_nan("");

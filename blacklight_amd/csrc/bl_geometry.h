@@ -75,23 +75,7 @@ BL_HD double bl_div_g(double a, double b) { return bl_div_r(a, bl_recip(b)); }
 // bl_hypot_g: bl_hypot() of blmath.h - same operations in the same order - without its range
 // scaling and its infinity tests: bit-identical for finite arguments with max <= 2^510 and
 // min >= 2^-450 (or zero); NaN in, NaN out. Host builds call the general functions.
-BL_HD double bl_sqrt_g(double x) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  double y = __builtin_amdgcn_rsq(x);
-  double g = x * y;
-  double h = y * 0.5;
-  double r = __builtin_fma(-h, g, 0.5);
-  g = __builtin_fma(g, r, g);
-  h = __builtin_fma(h, r, h);
-  double d = __builtin_fma(-g, g, x);
-  g = __builtin_fma(d, h, g);
-  d = __builtin_fma(-g, g, x);
-  g = __builtin_fma(d, h, g);
-  return __builtin_amdgcn_class(x, 0x260) ? x : g;   // +-0, +inf
-#else
-  return blm_sqrt(x);
-#endif
-}
+BL_HD double bl_sqrt_g(double x) { return blm_sqrt_n(x); }
 BL_HD double bl_hypot_g(double x, double y) {
 #if defined(__HIP_DEVICE_COMPILE__)
   double ax = blm_abs(x), ay = blm_abs(y);

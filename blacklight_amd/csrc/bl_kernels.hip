@@ -32,6 +32,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstddef>
+#include <cstdlib>
 
 #include "bl_device.h"
 #include "bl_pol_frame.h"
@@ -156,6 +157,55 @@ __device__ __forceinline__ long long traversal_to_ray(long long q, int res, cons
 }  // namespace
 
 // =================================================================================================
+// Ray start kernel
+// =================================================================================================
+// One ray of the chunk per lane: pixel -> position, momentum, momentum factor (camera.cpp:393-396, :465-479, :528-671), the
+// radial coordinate of the start point and, for the Dormand-Prince stepper, the first stage of the first step
+// (geodesics.cpp:113-133, :155-156). This used to be the refill branch of the persistent geodesic kernel, where it ran with
+// one or two active lanes almost every time a ray ended (~2 000 instructions per refill, a seventh of that kernel's
+// instruction stream) and kept the camera frame - 28 doubles - in scalar registers through every step of every ray. Here
+// every lane is busy, and the stepping kernel fetches 17 doubles per new ray instead. Same functions of the same inputs:
+// same bits.
+template <bool kDormandPrince, bool kSpinZero>
+__global__ void __launch_bounds__(256) bl_ray_init_kernel(BlTraceArgs P) {
+  const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= (long long)P.chunk_rays) return;
+  const BlSpacetime st = P.st;
+  const long long ray = traversal_to_ray(P.chunk_begin + q, P.swizzle_tiles, P.tile_order);
+  const long long pixel = P.pixel_map != nullptr ? (long long)P.pixel_map[ray] : ray;
+  double u_ind, v_ind, position[4], direction[4], factor;
+  bl_pixel_indices(P.cam, pixel, P.block_locs, &u_ind, &v_ind);
+  bl_pixel_ray(st, P.cam, u_ind, v_ind, position, direction, &factor);
+  P.ray_kt[q] = direction[0];
+  P.ray_factor[q] = factor;
+  P.ray_out_index[q] = ray;
+  if (P.camera_pos != nullptr)
+    for (int mu = 0; mu < 4; mu++) P.camera_pos[4 * ray + mu] = position[mu];
+  if (P.camera_dir != nullptr)
+    for (int mu = 0; mu < 4; mu++) P.camera_dir[4 * ray + mu] = direction[mu];
+  double *start = P.ray_start + q;
+  const long long stride = P.ray_start_stride;
+  RayState s;
+  s.y[0] = position[0];
+  s.y[1] = position[1];
+  s.y[2] = position[2];
+  s.y[3] = position[3];
+  s.kt = direction[0];
+  s.y[4] = direction[1];
+  s.y[5] = direction[2];
+  s.y[6] = direction[3];
+  s.y[7] = 0.0;
+  for (int p = 0; p < 7; p++) start[p * stride] = s.y[p];
+  start[7 * stride] = s.kt;
+  start[8 * stride] = bl_radial_coordinate<kSpinZero>(st, s.y[1], s.y[2], s.y[3]);
+  if (kDormandPrince) {
+    double k0[8], r_unused;
+    rhs<true, kSpinZero>(st, s.y, s.kt, k0, &r_unused);
+    for (int p = 0; p < 8; p++) start[(9 + p) * stride] = k0[p];
+  }
+}
+
+// =================================================================================================
 // Geodesic kernel
 // =================================================================================================
 // kTime: also emit the coordinate time of every sample (P.sample_t, for image_time). Without it the time
@@ -202,57 +252,75 @@ __global__ void __launch_bounds__(64, BL_GEO_ONE_WAVE(kIntegrator, kTime, kSpinZ
   }
   s.kt = 0.0;
   long long block_next = 0, block_end = 0;   // this wave's block of record slots (wave-uniform)
+  int retry_wait = 0;                        // steps until the wave asks for rays again after a refusal (wave-uniform)
+#ifdef BL_GEO_STATS
+  // per lane: step attempts, accepted steps, samples emitted; per wave (lane 0): loop iterations, emission iterations, refills,
+  // lane-iterations with a ray
+  unsigned long long st_attempt = 0, st_accept = 0, st_emit = 0, st_iter = 0, st_emit_iter = 0, st_refill = 0, st_busy = 0;
+#endif
 
   while (true) {
     // ------------------------------------------------------------------ refill idle lanes
+    // A ray is handed out only while the record buffers can take its worst case: the leader reserves ray_max_steps slots per
+    // idle lane in BL_CNT_COMMITTED and gives back what does not fit under the gate; a finished ray gives back what it did not
+    // emit. So the buffers never overflow, and a chunk is as many rays as fit them as the rays turn out (704 of 2 000 steps
+    // on the benchmark frame: one chunk where the worst case needed two). Lanes that were refused ask again a few steps
+    // later - slots come back as rays finish - and a wave with no ray left that is refused ends; the rays nobody took
+    // (BL_CNT_NEXT_RAY < chunk_rays) are the next chunk's.
     bool need = !have_ray && !exhausted;
     unsigned long long need_mask = __ballot(need);
-    if (need_mask != 0ull) {
-      int count = __popcll(need_mask);
-      int leader = __ffsll((long long)need_mask) - 1;
+    if (need_mask != 0ull && retry_wait > 0 && __ballot(have_ray) != 0ull) {
+      retry_wait -= 1;
+    } else if (need_mask != 0ull) {
+#ifdef BL_GEO_STATS
+      st_refill += 1;
+#endif
+      const int count = __popcll(need_mask);
+      const int leader = __ffsll((long long)need_mask) - 1;
       unsigned long long base = 0ull;
-      if (lane == leader) base = atomicAdd(&P.counters[BL_CNT_NEXT_RAY], (unsigned long long)count);
+      int admitted = 0;
+      if (lane == leader) {
+        const unsigned long long per_ray = (unsigned long long)P.ray_max_steps;
+        const unsigned long long want = (unsigned long long)count * per_ray;
+        const long long over = (long long)(atomicAdd(&P.counters[BL_CNT_COMMITTED], want) + want) - P.record_gate;
+        long long refused = over > 0 ? (over + (long long)per_ray - 1) / (long long)per_ray : 0;
+        refused = refused < (long long)count ? refused : (long long)count;
+        admitted = count - (int)refused;
+        if (admitted > 0) {
+          base = atomicAdd(&P.counters[BL_CNT_NEXT_RAY], (unsigned long long)admitted);
+          long long beyond = (long long)(base + (unsigned long long)admitted) - (long long)P.chunk_rays;   // past the end of the queue
+          beyond = beyond < 0 ? 0 : (beyond < (long long)admitted ? beyond : (long long)admitted);
+          refused += beyond;
+        }
+        if (refused > 0) atomicAdd(&P.counters[BL_CNT_COMMITTED], (unsigned long long)(-(refused * (long long)per_ray)));
+      }
       base = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(base >> 32), leader) << 32)
           | (unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)base, leader);
+      admitted = __builtin_amdgcn_readlane(admitted, leader);
+      retry_wait = admitted < count ? 4 : 0;
       if (need) {
-        int rank = __popcll(need_mask & ((1ull << lane) - 1ull));
-        unsigned long long q = base + (unsigned long long)rank;
-        if (q >= (unsigned long long)P.chunk_rays) {
+        const int rank = __popcll(need_mask & ((1ull << lane) - 1ull));
+        const unsigned long long q = base + (unsigned long long)rank;
+        if (rank >= admitted) {
+          // no slots for this lane's ray now; once the queue is known to be empty there is nothing to wait for
+          if (admitted > 0 && base + (unsigned long long)admitted >= (unsigned long long)P.chunk_rays) exhausted = true;
+        } else if (q >= (unsigned long long)P.chunk_rays) {
           exhausted = true;
         } else {
           have_ray = true;
           slot = (unsigned int)q;
-          long long ray = traversal_to_ray(P.chunk_begin + (long long)q, P.swizzle_tiles, P.tile_order);
-          long long pixel = P.pixel_map != nullptr ? (long long)P.pixel_map[ray] : ray;
-          double u_ind, v_ind, position[4], direction[4], factor;
-          // The camera's resolution and the spin as this branch sees them: opaque copies, so that what depends on them alone
-          // ((double)resolution, resolution / 2, a^2) is computed here, where a ray starts, instead of before the loop and
-          // kept in registers through every step of every ray (same operations on the same values: same bits).
-          BlCameraDevice cam = P.cam;
-          cam.camera_resolution = opaque_uniform(cam.camera_resolution);
-          cam.effective_resolution = opaque_uniform(cam.effective_resolution);
-          BlSpacetime st_start = st;
-          st_start.bh_a = opaque_uniform(st.bh_a);
-          bl_pixel_indices(cam, pixel, P.block_locs, &u_ind, &v_ind);
-          bl_pixel_ray(st_start, cam, u_ind, v_ind, position, direction, &factor);
-          P.ray_kt[slot] = direction[0];
-          P.ray_factor[slot] = factor;
-          P.ray_out_index[slot] = ray;
-          if (P.camera_pos != nullptr)
-            for (int mu = 0; mu < 4; mu++) P.camera_pos[4 * ray + mu] = position[mu];
-          if (P.camera_dir != nullptr)
-            for (int mu = 0; mu < 4; mu++) P.camera_dir[4 * ray + mu] = direction[mu];
-          // geodesics.cpp:113-133
-          s.y[0] = position[0];
-          s.y[1] = position[1];
-          s.y[2] = position[2];
-          s.y[3] = position[3];
-          s.kt = direction[0];
-          s.y[4] = direction[1];
-          s.y[5] = direction[2];
-          s.y[6] = direction[3];
+          // the ray's start state as bl_ray_init_kernel left it (geodesics.cpp:113-133, :155-156)
+          const double *start = P.ray_start + q;
+          const long long stride = P.ray_start_stride;
+#pragma unroll
+          for (int p = 0; p < 7; p++) s.y[p] = start[p * stride];
           s.y[7] = 0.0;
-          r_cur = bl_radial_coordinate<kSpinZero>(st, s.y[1], s.y[2], s.y[3]);
+          s.kt = start[7 * stride];
+          r_cur = start[8 * stride];
+          if (kIntegrator == BL_INTEGRATOR_DP) {
+#pragma unroll
+            for (int p = 0; p < 8; p++) k0[p] = start[(9 + p) * stride];
+          }
           h_new = -P.ray_step * r_cur;
           num_retry = 0;
           previous_fail = false;
@@ -261,10 +329,6 @@ __global__ void __launch_bounds__(64, BL_GEO_ONE_WAVE(kIntegrator, kTime, kSpinZ
           sample_num = 0;
           trunc_at = -1;
           r_prev_sample = 0.0;
-          if (kIntegrator == BL_INTEGRATOR_DP) {
-            double r_unused;
-            rhs<true, kSpinZero>(st, s.y, s.kt, k0, &r_unused);  // :155-156 (first stage of the first step)
-          }
         }
       }
     }
@@ -272,6 +336,11 @@ __global__ void __launch_bounds__(64, BL_GEO_ONE_WAVE(kIntegrator, kTime, kSpinZ
       retire_record_slots(P.records_hot, block_next, block_end, lane);   // unused rest of the last block
       break;
     }
+#ifdef BL_GEO_STATS
+    st_iter += 1;
+    st_busy += have_ray ? 1 : 0;
+    st_attempt += (have_ray && (kIntegrator != BL_INTEGRATOR_DP || num_retry <= P.ray_max_retries)) ? 1 : 0;
+#endif
 
     // ------------------------------------------------------------------ one step attempt
     int emit = 0;               // samples this lane writes in this iteration
@@ -487,7 +556,17 @@ __global__ void __launch_bounds__(64, BL_GEO_ONE_WAVE(kIntegrator, kTime, kSpinZ
 
     // ------------------------------------------------------------------ emit samples
     const int max_emit = wave_max_nonneg(emit);
-    for (int nn = 0; nn < max_emit; nn++) {
+#ifdef BL_GEO_STATS
+    st_emit_iter += max_emit;
+    st_emit += emit;
+    st_accept += accepted ? 1 : 0;
+#endif
+    // the two quotients of the dense output, (nn + 0.5) / num_steps_ideal and h / num_steps_ideal (:277-293), over one
+    // reciprocal per step instead of a division per sample (small integers and step lengths: the IEEE quotients, bl_geometry.h)
+    const BlRecip rc_steps = bl_recip((double)num_steps_ideal);
+    const double len_dense = bl_div_r(h, rc_steps);
+    double position = 0.5;   // nn + 0.5, exact
+    for (int nn = 0; nn < max_emit; nn++, position += 1.0) {
       if (nn < emit) {
         double smp[7];
         double len;
@@ -496,11 +575,11 @@ __global__ void __launch_bounds__(64, BL_GEO_ONE_WAVE(kIntegrator, kTime, kSpinZ
           for (int p = kTime ? 0 : 1; p < 7; p++) smp[p] = y4m[p];
           len = h;
         } else {                      // :277-293
-          double frac = (nn + 0.5) / num_steps_ideal;
+          double frac = bl_div_r(position, rc_steps);
 #pragma unroll
           for (int p = kTime ? 0 : 1; p < 7; p++)
             smp[p] = s.y[p] + frac * (rv0[p] + (1.0 - frac) * (rv1[p] + frac * (rv2[p] + (1.0 - frac) * rv3[p])));
-          len = h / num_steps_ideal;
+          len = len_dense;
         }
         // online form of the truncation pass (:327-349): the first sample (index >= 1) that moves
         // outward beyond the camera radius or falls inside r_terminate ends the kept part of the ray
@@ -526,12 +605,12 @@ __global__ void __launch_bounds__(64, BL_GEO_ONE_WAVE(kIntegrator, kTime, kSpinZ
         hot.n = (unsigned int)index;
         const int place = excl + nn;
         const long long at = place < old_room ? old_base + place : new_base + (place - old_room);
-        P.records_hot[at] = hot;
         BlSampleCold cold;
         cold.kx = smp[4];
         cold.ky = smp[5];
         cold.kz = smp[6];
         cold.len = len;
+        P.records_hot[at] = hot;
         P.records_cold[at] = cold;
         if (kTime) P.sample_t[at] = smp[0];
       }
@@ -570,9 +649,23 @@ __global__ void __launch_bounds__(64, BL_GEO_ONE_WAVE(kIntegrator, kTime, kSpinZ
       int final_num = (trunc_at >= 0) ? trunc_at : sample_num;
       P.ray_sample_num[slot] = final_num;
       P.ray_flags[slot] = flag ? 1 : 0;
+      // rows of the kept samples in the per-sample arrays, in the order in which rays finish; slots not emitted go back
+      P.ray_offset[slot] = (long long)atomicAdd(&P.counters[BL_CNT_SAMPLES], (unsigned long long)final_num);
+      atomicAdd(&P.counters[BL_CNT_COMMITTED], (unsigned long long)(-(long long)(P.ray_max_steps - sample_num)));
       have_ray = false;
     }
   }
+#ifdef BL_GEO_STATS
+  atomicAdd(&P.counters[BL_CNT_DEBUG + 0], st_attempt);
+  atomicAdd(&P.counters[BL_CNT_DEBUG + 1], st_accept);
+  atomicAdd(&P.counters[BL_CNT_DEBUG + 2], st_emit);
+  atomicAdd(&P.counters[BL_CNT_DEBUG + 6], st_busy);
+  if (lane == 0) {
+    atomicAdd(&P.counters[BL_CNT_DEBUG + 3], st_iter);
+    atomicAdd(&P.counters[BL_CNT_DEBUG + 4], st_emit_iter);
+    atomicAdd(&P.counters[BL_CNT_DEBUG + 5], st_refill);
+  }
+#endif
 }
 
 // =================================================================================================
@@ -1018,9 +1111,9 @@ __device__ __forceinline__ void locate_sample(const BlShadeArgs &P, const GridTa
   out->cell = 0u;
   if (sks) {
     // z / r is cos(theta) in ConvertFromCKS, in the SKS metric and in the Jacobian (same expression)
-    double th = bl_acos(x3 / r);
+    double th = bl_acos(blm_div(x3, r));   // (|z| <= r, both of the order of the coordinates: ordinary operands)
     // zero spin: atan(0 / r) = +0 and atan2(y, x) - 0 = atan2(y, x)
-    double ph = kSpinZero ? bl_atan2(x2, x1) : bl_atan2(x2, x1) - bl_atan(st.bh_a / r);
+    double ph = kSpinZero ? bl_atan2(x2, x1) : bl_atan2(x2, x1) - bl_atan(blm_div(st.bh_a, r));
     out->ph = ph;
     ph += ph < 0.0 ? 2.0 * kPi : 0.0;
     ph -= ph >= 2.0 * kPi ? 2.0 * kPi : 0.0;
@@ -1121,13 +1214,16 @@ __device__ __forceinline__ void locate_sample(const BlShadeArgs &P, const GridTa
   // :485-490
   // the anchor rule is per block (the indices of :485-487 are block-local): several equal blocks live in one
   // merged array here, g.nb is the block size
-  const int i_b = i % g.nb[0], j_b = j % g.nb[1], k_b = k % g.nb[2];
+  // (one block - the usual case, known to the whole launch - needs no remainders: three integer divisions per sample)
+  const bool one_block = g.nb[0] == n_i && g.nb[1] == n_j && g.nb[2] == n_k;
+  const int i_b = one_block ? i : i % g.nb[0], j_b = one_block ? j : j % g.nb[1], k_b = one_block ? k : k % g.nb[2];
   int i_m = (i_b == 0 || (i_b != g.nb[0] - 1 && s1 >= tab.xv[0][i])) ? i : i - 1;
   int j_m = (j_b == 0 || (j_b != g.nb[1] - 1 && s2 >= tab.xv[1][j])) ? j : j - 1;
   int k_m = (k_b == 0 || (k_b != g.nb[2] - 1 && s3 >= tab.xv[2][k])) ? k : k - 1;
-  out->f_i = (s1 - tab.xv[0][i_m]) / (tab.xv[0][i_m + 1] - tab.xv[0][i_m]);
-  out->f_j = (s2 - tab.xv[1][j_m]) / (tab.xv[1][j_m + 1] - tab.xv[1][j_m]);
-  out->f_k = (s3 - tab.xv[2][k_m]) / (tab.xv[2][k_m + 1] - tab.xv[2][k_m]);
+  // (fractions of cell widths: ordinary operands for the short division; a sample exactly on a centre gives 0 / width = 0)
+  out->f_i = blm_div(s1 - tab.xv[0][i_m], tab.xv[0][i_m + 1] - tab.xv[0][i_m]);
+  out->f_j = blm_div(s2 - tab.xv[1][j_m], tab.xv[1][j_m + 1] - tab.xv[1][j_m]);
+  out->f_k = blm_div(s3 - tab.xv[2][k_m], tab.xv[2][k_m + 1] - tab.xv[2][k_m]);
   out->status = kSampleInterp;
   out->cell = (uint32_t)((k_m * n_j + j_m) * n_i + i_m);
 }
@@ -1775,6 +1871,110 @@ __global__ void __launch_bounds__(256, 4) bl_locate_kernel(const BlShadeArgs P) 
   if ((threadIdx.x & 63) == 0 && gathers_local != 0ull) atomicAdd(&P.counters[BL_CNT_GATHERS], gathers_local);
 }
 
+// ---- locate kernel of the common case: one grid (or equal blocks merged into one) in spherical Kerr-Schild coordinates with
+// its coordinate tables in LDS, trilinear sampling, no optional geometric cut, no slow light. The same functions of the same
+// values as bl_locate_kernel<false, false, ...> - bit-identical located samples - as one straight line per sample: every
+// lane runs the whole search (a dead slot, a cut or an off-grid sample on clamped inputs) and the status is selected at
+// the end, where the general kernel nests a dozen divergent branches whose masks, merges and live scalars cost it more
+// instructions than the arithmetic they skip (555 vector instructions per sample there, two thirds of them not arithmetic).
+template <bool kSpinZero>
+__global__ void __launch_bounds__(256, 4) bl_locate_plain_kernel(const BlShadeArgs P) {
+  const BlSpacetime st = P.st;
+  extern __shared__ double lds_tables[];
+  GridTables tab;
+  const int n_i = P.grid.n[0], n_j = P.grid.n[1], n_k = P.grid.n[2];
+  {
+    const BlGridDevice &g = P.grid;
+    double *dst = lds_tables;
+    for (int a = 0; a < 3; a++) {
+      tab.xf[a] = dst;
+      for (int i = threadIdx.x; i <= g.n[a]; i += blockDim.x) dst[i] = g.xf[a][i];
+      dst += g.n[a] + 1;
+      tab.xv[a] = dst;
+      for (int i = threadIdx.x; i < g.n[a]; i += blockDim.x) dst[i] = g.xv[a][i];
+      dst += g.n[a];
+    }
+    unsigned short *bdst = reinterpret_cast<unsigned short *>(dst);
+    for (int a = 0; a < 3; a++) {
+      tab.bucket[a] = bdst;
+      for (int i = threadIdx.x; i < g.n_bucket[a]; i += blockDim.x) bdst[i] = g.bucket[a][i];
+      bdst += g.n_bucket[a];
+    }
+    __syncthreads();
+  }
+  // what the search needs of the grid, once per wave instead of once per use
+  const double lo_i = tab.xf[0][0], hi_i = tab.xf[0][n_i], lo_j = tab.xf[1][0], hi_j = tab.xf[1][n_j], lo_k = tab.xf[2][0], hi_k = tab.xf[2][n_k];
+  const int nb_i = P.grid.nb[0], nb_j = P.grid.nb[1], nb_k = P.grid.nb[2];
+  const bool one_block = nb_i == n_i && nb_j == n_j && nb_k == n_k;
+  const double camera_r = P.cuts.camera_r;
+  const bool tag_in_record = P.tag_in_record != 0;
+  const unsigned long long n_records = P.counters_in[BL_CNT_RECORDS];
+  const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+  unsigned long long gathers_local = 0ull;
+  unsigned long long idx = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  bool more = idx < n_records;
+  double2 nq0 = make_double2(1.0, 1.0), nq1 = make_double2(1.0, __longlong_as_double((long long)BL_DEAD_RAY));
+  if (more) {
+    const double2 *src = reinterpret_cast<const double2 *>(P.records_hot + idx);
+    nq0 = src[0];
+    nq1 = src[1];
+  }
+  while (more) {
+    const unsigned long long at = idx;
+    const uint32_t ray = (uint32_t)__double_as_longlong(nq1.y);
+    const bool live = ray != BL_DEAD_RAY;
+    // a dead slot may hold anything: the search runs on a harmless point instead
+    const double x1 = live ? nq0.x : 1.0, x2 = live ? nq0.y : 1.0, x3 = live ? nq1.x : 1.0;
+    idx += stride;
+    more = idx < n_records;
+    if (more) {
+      const double2 *src = reinterpret_cast<const double2 *>(P.records_hot + idx);
+      nq0 = src[0];
+      nq1 = src[1];
+    }
+    double r2;
+    const double r = bl_radial_coordinate2<kSpinZero>(st, x1, x2, x3, &r2);
+    const bool cut = r > camera_r;                                   // simulation_sampling.cpp:238-243
+    // ConvertFromCKS (radiation_geometry.cpp:37-57), as in locate_sample()
+    const double th = bl_acos(blm_div(x3, r));
+    const double ph_unwrapped = kSpinZero ? bl_atan2(x2, x1) : bl_atan2(x2, x1) - bl_atan(blm_div(st.bh_a, r));
+    double ph = ph_unwrapped;
+    ph += ph < 0.0 ? 2.0 * kPi : 0.0;
+    ph -= ph >= 2.0 * kPi ? 2.0 * kPi : 0.0;
+    const double s1 = r, s2 = th, s3 = ph;
+    const bool off_grid = s1 < lo_i || s1 > hi_i || s2 < lo_j || s2 > hi_j || s3 < lo_k || s3 > hi_k;   // :352-394
+    const int i = find_cell(P.grid, tab, 0, s1), j = find_cell(P.grid, tab, 1, s2), k = find_cell(P.grid, tab, 2, s3);
+    // :485-490, per block of a merged grid
+    const int i_b = one_block ? i : i % nb_i, j_b = one_block ? j : j % nb_j, k_b = one_block ? k : k % nb_k;
+    const int i_m = (i_b == 0 || (i_b != nb_i - 1 && s1 >= tab.xv[0][i])) ? i : i - 1;
+    const int j_m = (j_b == 0 || (j_b != nb_j - 1 && s2 >= tab.xv[1][j])) ? j : j - 1;
+    const int k_m = (k_b == 0 || (k_b != nb_k - 1 && s3 >= tab.xv[2][k])) ? k : k - 1;
+    const double xv_i = tab.xv[0][i_m], xv_j = tab.xv[1][j_m], xv_k = tab.xv[2][k_m];
+    const double f_i = blm_div(s1 - xv_i, tab.xv[0][i_m + 1] - xv_i);
+    const double f_j = blm_div(s2 - xv_j, tab.xv[1][j_m + 1] - xv_j);
+    const double f_k = blm_div(s3 - xv_k, tab.xv[2][k_m + 1] - xv_k);
+    const bool sampled = live && !cut && !off_grid;
+    const uint32_t status = !live ? (uint32_t)kSampleNone : (cut ? (uint32_t)kSampleCut : (off_grid ? (uint32_t)kSampleOffGrid : (uint32_t)kSampleInterp));
+    const uint32_t cell = sampled ? (uint32_t)((k_m * n_j + j_m) * n_i + i_m) : 0u;
+    gathers_local += sampled ? 1ull : 0ull;
+    const unsigned long long tag = ((unsigned long long)status << 32) | cell;
+    double2 *dst = reinterpret_cast<double2 *>(P.located + at);
+    if (tag_in_record) {
+      // (a dead slot gets its tag alone in the general kernel; the fractions nobody reads are written here as zeros)
+      dst[0] = make_double2(sampled ? f_i : 0.0, sampled ? f_j : 0.0);
+      dst[1] = make_double2(sampled ? f_k : 0.0, __longlong_as_double((long long)tag));
+    } else if (live) {
+      dst[0] = make_double2(sampled ? f_i : 0.0, sampled ? f_j : 0.0);
+      dst[1] = make_double2(sampled ? f_k : 0.0, cut ? 0.0 : ph_unwrapped);
+      P.located_tag[at] = tag;
+    } else {
+      P.located_tag[at] = 0ull;
+    }
+  }
+  for (int offset = 32; offset > 0; offset >>= 1) gathers_local += __shfl_xor(gathers_local, offset, 64);
+  if ((threadIdx.x & 63) == 0 && gathers_local != 0ull) atomicAdd(&P.counters[BL_CNT_GATHERS], gathers_local);
+}
+
 // ---- coefficient kernel: one sample record per lane, pure fp64 arithmetic between one coalesced
 // read (record + located sample) and one 16-byte store per frequency. Two waves per SIMD so that one
 // wave's scalar work, dependent-issue bubbles and load waits overlap the other's VALU work.
@@ -1823,9 +2023,11 @@ __global__ void __launch_bounds__(256, 2) bl_shade_kernel(const BlShadeArgs P) {
     const double delta_lambda = -q3.y;   // ReverseGeodesics: sample_len = -geodesic_len (:840)
     double kcov[4] = {0.0, q2.x, q2.y, q3.x};
     double momentum_factor = 0.0;
+    size_t row = 0;   // of this sample in the per-sample arrays: the ray's first row + n
     if (live) {
       kcov[0] = P.ray_kt[ray];
       momentum_factor = P.ray_factor[ray];
+      row = (size_t)P.ray_offset[ray] + n;
     }
     float pr[8];
     float kappa_f = 0.0f;
@@ -1909,11 +2111,11 @@ __global__ void __launch_bounds__(256, 2) bl_shade_kernel(const BlShadeArgs P) {
       if (kModel == BL_MODEL_SIMULATION)
         sample_finish_simulation<kExtended, kSksCurved>(P, st, ks, x3 / ks.r, ph, pr, kappa_f, kcov,
                                             kAux ? P.aux_need_coefficients : 1, &sh,
-                                            kPolarized ? P.pol_samples + ((size_t)ray * P.ray_max_steps + n) : nullptr);
+                                            kPolarized ? P.pol_samples + row : nullptr);
       else if (!(kAux && nan_ray))
         shade_formula(P, st, ks.r, x1, x2, x3, &sh);
     }
-    double2 *out = P.transfer + ((size_t)ray * P.ray_max_steps + n) * P.n_nu;
+    double2 *out = P.transfer + row * P.n_nu;
     if (kAux && !(kPolarized && P.aux_record_unused)) {
       BlAuxSample aux;
       aux.delta_lambda = delta_lambda;
@@ -1941,10 +2143,10 @@ __global__ void __launch_bounds__(256, 2) bl_shade_kernel(const BlShadeArgs P) {
       }
       const double nan = __longlong_as_double(0x7ff8000000000000ll);
       for (int a = 0; a < BL_NUM_CELL_VALUES; a++) aux.cell[a] = sh.have_cell ? sh.cell[a] : nan;
-      P.aux[(size_t)ray * P.ray_max_steps + n] = aux;
+      P.aux[row] = aux;
     }
     if (kPolarized) {
-      BlPolSample *ps = P.pol_samples + ((size_t)ray * P.ray_max_steps + n);
+      BlPolSample *ps = P.pol_samples + row;
       ps->x[0] = x1; ps->x[1] = x2; ps->x[2] = x3;
       ps->delta_lambda = delta_lambda;
     }
@@ -2008,7 +2210,7 @@ __global__ void __launch_bounds__(256, 2) bl_shade_kernel(const BlShadeArgs P) {
       // second pass of the tolerant tier with several frequencies: the cut decisions above were the point; what goes to
       // bl_transfer_freq_kernel are the same per-sample factors the fast kernel leaves (BlFreqInputs), from this sample's
       // exactly computed state - thermal electrons only, as everywhere in that tier
-      double2 *dst = reinterpret_cast<double2 *>(P.freq_inputs + ((size_t)ray * P.ray_max_steps + n));
+      double2 *dst = reinterpret_cast<double2 *>(P.freq_inputs + row);
       if (!sh.have_coefficients) {
         dst[0] = make_double2(0.0, 0.0);
       } else {
@@ -2127,8 +2329,8 @@ __device__ __forceinline__ void fast_defer(const BlShadeArgs &P, unsigned long l
 // `table` (LDS): the 3 x 14 cut thresholds and guard bands of BlShadeCold, then the frequencies. Read from LDS so that
 // nothing in here waits on the vector-memory counter, behind which the next sample's corner cells are in flight.
 template <bool kSpinZero>
-__device__ __forceinline__ bool fast_shade_sample(const BlShadeArgs &P, const double *table, const float pr[8], int status, uint32_t ray,
-                                                  uint32_t n, double x, double y, double z, double kx, double ky, double kz, double kt,
+__device__ __forceinline__ bool fast_shade_sample(const BlShadeArgs &P, const double *table, const float pr[8], int status, size_t row,
+                                                  double x, double y, double z, double kx, double ky, double kz, double kt,
                                                   double momentum_factor, double delta_lambda) {
   const BlSpacetime &st = P.st;
   const BlPlasmaDevice &pl = P.plasma;
@@ -2136,7 +2338,7 @@ __device__ __forceinline__ bool fast_shade_sample(const BlShadeArgs &P, const do
   const double bh_a = kSpinZero ? 0.0 : st.bh_a;
   const double a2 = bh_a * bh_a;
   const double nan = __longlong_as_double(0x7ff8000000000000ll);
-  double2 *out = P.transfer + ((size_t)ray * P.ray_max_steps + n) * P.n_nu;
+  double2 *out = P.transfer + row * P.n_nu;
   // what the loop over frequencies needs
   bool have = false;
   double nu_ratio = 0.0, n_e_cgs = 0.0, nu_c_cgs = 0.0, theta_e = 0.0, kb_tt_e_cgs = 0.0, sin_theta_b = 0.0;
@@ -2250,7 +2452,7 @@ __device__ __forceinline__ bool fast_shade_sample(const BlShadeArgs &P, const do
   if (status == kSampleOffGrid && pl.fallback_nan) {
     // primitives are NaN (simulation_sampling.cpp:377-384): j and alpha are NaN at every frequency, I <- I + NaN
     if (P.freq_split) {
-      reinterpret_cast<double2 *>(P.freq_inputs + ((size_t)ray * P.ray_max_steps + n))[0] = make_double2(2.0, 0.0);
+      reinterpret_cast<double2 *>(P.freq_inputs + row)[0] = make_double2(2.0, 0.0);
       return true;
     }
     for (int l = 0; l < P.n_nu; l++) out[l] = make_double2(1.0, nan);
@@ -2272,7 +2474,7 @@ __device__ __forceinline__ bool fast_shade_sample(const BlShadeArgs &P, const do
   const double s_j = thermal_frac * n_e_cgs * kE * kE * nu_c_cgs * (1.0 / kC) * (kSqrt2 * kPi / 27.0) * sin_theta_b * s_nu_inv * s_nu_inv;
   const double s_length = delta_lambda * P.x_unit * fastmath::rcp(momentum_factor);               // unpolarized.cpp:75-76
   if (P.freq_split) {   // several frequencies: the factors go to bl_transfer_freq_kernel, one lane per ray and frequency
-    double2 *dst = reinterpret_cast<double2 *>(P.freq_inputs + ((size_t)ray * P.ray_max_steps + n));
+    double2 *dst = reinterpret_cast<double2 *>(P.freq_inputs + row);
     dst[0] = make_double2(have ? 1.0 : 0.0, s_1_2);
     dst[1] = make_double2(s_1_3, s_1_6);
     dst[2] = make_double2(s_planck, s_j);
@@ -2344,7 +2546,11 @@ __device__ __forceinline__ void fast_load_ray(const BlShadeArgs &P, unsigned lon
 __device__ __forceinline__ void gather_issue(const BlShadeArgs &P, int status, uint32_t cell, float4 (&lo)[8], float4 (&hi)[8]) {
   const BlGridDevice &g = P.grid;
   const bool interp = status == kSampleInterp;
+#ifdef BL_EXP_GATHER0   // experiment: every gather reads the cells at (0, 0, 0): the kernel's time without grid traffic
+  const size_t first = 0;
+#else
   const size_t first = (interp || status == kSampleNearest) ? (size_t)cell : 0;
+#endif
   const float4 *base = reinterpret_cast<const float4 *>(g.cells) + first * 2;
   const size_t row = interp ? (size_t)g.stride_row * 2 : 0, plane = interp ? (size_t)g.stride_plane * 2 : 0, next = interp ? 2 : 0;
 #pragma unroll
@@ -2450,6 +2656,7 @@ __global__ void __launch_bounds__(256, BL_FAST_WAVES) bl_shade_fast_kernel(const
     const int status = (int)(loc_prev.tag >> 32) & 0xff;
     // per-ray constants of `prev`: requested before the next sample's cells, so that waiting for them does not wait for those
     const double kt = P.ray_kt[live ? ray : 0u], momentum_factor = P.ray_factor[live ? ray : 0u];
+    const size_t row = (size_t)P.ray_offset[live ? ray : 0u] + n;
     float pr[8];
     gather_finish(P, fast_table, live ? status : (int)kSampleNone, lo, hi, loc_prev.l0.x, loc_prev.l0.y, loc_prev.l1.x, pr);
     gather_issue(P, have_cur ? (int)(loc_cur.tag >> 32) & 0xff : (int)kSampleNone, (uint32_t)loc_cur.tag, lo, hi);
@@ -2468,7 +2675,7 @@ __global__ void __launch_bounds__(256, BL_FAST_WAVES) bl_shade_fast_kernel(const
     fast_load_located(P, have_next ? idx : last, loc_next);
     if (live) {
       // ReverseGeodesics: sample_len = -geodesic_len (geodesics.cpp:840)
-      if (!fast_shade_sample<kSpinZero>(P, fast_table, pr, status, ray, n, rec.q0.x, rec.q0.y, rec.q1.x, rec.q2.x, rec.q2.y, rec.q3.x, kt,
+      if (!fast_shade_sample<kSpinZero>(P, fast_table, pr, status, row, rec.q0.x, rec.q0.y, rec.q1.x, rec.q2.x, rec.q2.y, rec.q3.x, kt,
                                         momentum_factor, -rec.q3.y)) {
         fast_defer(P, idx_rec);
       }
@@ -2486,7 +2693,7 @@ __global__ void __launch_bounds__(256) bl_transfer_freq_kernel(BlTransferArgs P)
   const int l = (int)(t % P.n_nu);
   unsigned long long samples = 0ull, flagged = 0ull;
   int max_num = 0;
-  if (slot < P.chunk_rays) {
+  if (slot < bl_rays_done(P.counters, P.chunk_rays)) {
     const int num = P.ray_sample_num[slot];
     const bool flag = P.ray_flags[slot] != 0;
     const long long out_index = P.ray_out_index[slot];
@@ -2506,7 +2713,7 @@ __global__ void __launch_bounds__(256) bl_transfer_freq_kernel(BlTransferArgs P)
       const double f_1_2 = bl_sqrt_g(f), f_1_3 = fastmath::cbrt(f);
       const double f_1_6 = bl_sqrt_g(f_1_3), f_inv = fastmath::rcp(f);
       const double f_inv2 = f_inv * f_inv;
-      const double2 *in = reinterpret_cast<const double2 *>(P.freq_inputs + (size_t)slot * P.ray_max_steps);
+      const double2 *in = reinterpret_cast<const double2 *>(P.freq_inputs + (size_t)P.ray_offset[slot]);
       for (int n = num - 1; n >= 0; n--) {   // reference sample order is reversed integration order (geodesics.cpp:832-840)
         const double2 q0 = in[4 * (size_t)n], q1 = in[4 * (size_t)n + 1], q2 = in[4 * (size_t)n + 2], q3 = in[4 * (size_t)n + 3];
         double a = 1.0, c = 0.0;
@@ -2606,7 +2813,7 @@ __global__ void __launch_bounds__(256, 2) bl_polarized_coefficients_kernel(const
         else bl_cyl_bessel_k012(1.0 / sh.theta_e, &sh.kk_0, &sh.kk_1, &sh.kk_2);
       }
     }
-    const size_t at = ((size_t)ray * P.ray_max_steps + n) * P.n_nu;
+    const size_t at = ((size_t)P.ray_offset[ray] + n) * P.n_nu;
     for (int l = 0; l < P.n_nu; l++) {
       const double freq = P.frequencies[l];
       double j_val = 0.0, alpha_val = 0.0;
@@ -2659,7 +2866,7 @@ __global__ void __launch_bounds__(256, 4) bl_coefficients_freq_kernel(const BlSh
     double j_val = 0.0, alpha_val = 0.0;
     if (sh.have_coefficients) simulation_coefficients<kExtended>(P, sh, freq, momentum_factor, &j_val, &alpha_val);
     const double delta_lambda_cgs = bl_div_g(delta_lambda * P.x_unit, freq * momentum_factor);   // unpolarized.cpp:75-76
-    P.transfer[((size_t)ray * P.ray_max_steps + n) * P.n_nu + l] = transfer_record(j_val, alpha_val, delta_lambda_cgs);
+    P.transfer[((size_t)P.ray_offset[ray] + n) * P.n_nu + l] = transfer_record(j_val, alpha_val, delta_lambda_cgs);
   }
 }
 
@@ -2686,7 +2893,7 @@ __global__ void __launch_bounds__(256) bl_polarized_frame_kernel(const BlShadeAr
     const double kcov[4] = {c0.x, c0.y, c1.x, c1.y};
     const float uu[3] = {__int_as_float(__double2loint(c2.x)), __int_as_float(__double2hiint(c2.x)), __int_as_float(__double2loint(c2.y))};
     const float bb[3] = {__int_as_float(__double2hiint(c2.y)), __int_as_float(__double2loint(c3.x)), __int_as_float(__double2hiint(c3.x))};
-    bl_pol::sample_frame(P.st, P.plasma.simulation_coord, q0.x, q0.y, q1.x, kcov, uu, bb, P.pol_samples + ((size_t)ray * P.ray_max_steps + n));
+    bl_pol::sample_frame(P.st, P.plasma.simulation_coord, q0.x, q0.y, q1.x, kcov, uu, bb, P.pol_samples + ((size_t)P.ray_offset[ray] + n));
   }
 }
 
@@ -2703,7 +2910,7 @@ __global__ void __launch_bounds__(256) bl_transfer_kernel(BlTransferArgs P) {
   const int l = (int)(t % P.n_nu);
   unsigned long long samples = 0ull, flagged = 0ull;
   int max_num = 0;
-  if (slot < P.chunk_rays) {
+  if (slot < bl_rays_done(P.counters, P.chunk_rays)) {
     int num = P.ray_sample_num[slot];
     bool flag = P.ray_flags[slot] != 0;
     long long out_index = P.ray_out_index[slot];
@@ -2724,7 +2931,7 @@ __global__ void __launch_bounds__(256) bl_transfer_kernel(BlTransferArgs P) {
         bool nan_row = P.model_type == BL_MODEL_SIMULATION || l == 0;
         intensity = (num > 0 && nan_row) ? nan : 0.0;
       } else {
-        const double2 *rec = P.transfer + (size_t)slot * P.ray_max_steps * P.n_nu + l;
+        const double2 *rec = P.transfer + (size_t)P.ray_offset[slot] * P.n_nu + l;
         // reference sample order is reversed integration order (geodesics.cpp:832-840). The
         // recurrence is sequential but the loads are not: fetch 8 records (one 128-byte line of
         // this ray's row when n_nu = 1) at a time so 8 loads are in flight per lane.
@@ -2771,7 +2978,7 @@ __global__ void __launch_bounds__(64) bl_transfer_aux_kernel(BlTransferArgs P) {
   int slot = blockIdx.x * blockDim.x + threadIdx.x;
   unsigned long long samples = 0ull, flagged = 0ull;
   int max_num = 0;
-  if (slot < P.chunk_rays) {
+  if (slot < bl_rays_done(P.counters, P.chunk_rays)) {
     const BlAuxImages &A = P.aux_images;
     const int num = P.ray_sample_num[slot];
     const bool flag = P.ray_flags[slot] != 0;
@@ -2786,8 +2993,8 @@ __global__ void __launch_bounds__(64) bl_transfer_aux_kernel(BlTransferArgs P) {
     const size_t row = (size_t)P.n_rays_total;
     double *img = P.image + out_index;   // img[q * row] = image(q, pixel)
     for (int q = 0; q < A.n_q; q++) img[(size_t)q * row] = 0.0;
-    const BlAuxSample *aux = P.aux + (size_t)slot * P.ray_max_steps;
-    const double2 *ja = P.transfer + (size_t)slot * P.ray_max_steps * P.n_nu;
+    const BlAuxSample *aux = P.aux + (size_t)P.ray_offset[slot];
+    const double2 *ja = P.transfer + (size_t)P.ray_offset[slot] * P.n_nu;
     const bool use_j = A.image_light || A.image_emission || A.image_emission_ave;
     const bool use_alpha = A.image_light || A.image_tau || A.image_tau_int;
     if (P.render_params != nullptr) {
@@ -2973,6 +3180,18 @@ __global__ void bl_debug_math_kernel(int op, long long n, const double *x, const
 // =================================================================================================
 // Launch wrappers (called from bl_api.hip)
 // =================================================================================================
+// Start states of the rays [chunk_begin, chunk_begin + chunk_rays) (bl_ray_init_kernel)
+extern "C" hipError_t bl_launch_ray_init(const BlTraceArgs *args, int integrator, hipStream_t stream) {
+  const bool spin_zero = args->st.bh_a == 0.0;
+  const int grid = (args->chunk_rays + 255) / 256;
+  const bool dp = integrator == BL_INTEGRATOR_DP;
+  if (dp && spin_zero) hipLaunchKernelGGL((bl_ray_init_kernel<true, true>), dim3(grid), dim3(256), 0, stream, *args);
+  else if (dp) hipLaunchKernelGGL((bl_ray_init_kernel<true, false>), dim3(grid), dim3(256), 0, stream, *args);
+  else if (spin_zero) hipLaunchKernelGGL((bl_ray_init_kernel<false, true>), dim3(grid), dim3(256), 0, stream, *args);
+  else hipLaunchKernelGGL((bl_ray_init_kernel<false, false>), dim3(grid), dim3(256), 0, stream, *args);
+  return hipGetLastError();
+}
+
 extern "C" hipError_t bl_launch_geodesic(const BlTraceArgs *args, int integrator, int grid, hipStream_t stream) {
   const bool with_time = args->sample_t != nullptr;
   const bool spin_zero = args->st.bh_a == 0.0;   // also true for -0.0: the instantiation never reads bh_a
@@ -3017,6 +3236,14 @@ extern "C" int bl_geodesic_occupancy(int integrator, int with_time, int spin_zer
 extern "C" hipError_t bl_launch_locate(const BlShadeArgs *args, int grid, int lds_bytes, hipStream_t stream) {
   const bool refined = args->grid.n_blocks > 0, slow = args->slow.n > 0;
   const bool spin_zero = args->st.bh_a == 0.0;
+  // the common case has a kernel of its own (bl_locate_plain_kernel): same located samples
+  const bool plain = !refined && !slow && lds_bytes > 0 && !args->grid.fmks && args->plasma.simulation_interp && !args->cuts.any_optional
+      && args->plasma.simulation_coord == BL_COORD_SKS && args->anchors == nullptr && std::getenv("BLACKLIGHT_AMD_GENERAL_LOCATE") == nullptr;
+  if (plain) {
+    if (spin_zero) hipLaunchKernelGGL((bl_locate_plain_kernel<true>), dim3(grid), dim3(256), lds_bytes, stream, *args);
+    else hipLaunchKernelGGL((bl_locate_plain_kernel<false>), dim3(grid), dim3(256), lds_bytes, stream, *args);
+    return hipGetLastError();
+  }
 #define BL_LAUNCH_L(R, S, LDS)                                                                                        \
   do {                                                                                                                \
     if (spin_zero) hipLaunchKernelGGL((bl_locate_kernel<R, S, true>), dim3(grid), dim3(256), LDS, stream, *args);     \

@@ -454,16 +454,16 @@ __global__ void __launch_bounds__(64) bl_transfer_polarized_kernel(BlTransferArg
   __shared__ double connection_lds[64 * 64];
   double *connection_old = connection_lds + threadIdx.x;
   const int slot = blockIdx.x * blockDim.x + threadIdx.x;
-  if (slot >= P.chunk_rays) return;
+  if (slot >= bl_rays_done(P.counters, P.chunk_rays)) return;
   const BlSpacetime st = P.st;
   const int num = P.ray_sample_num[slot];
   const long long out_index = P.ray_out_index[slot];
   const double momentum_factor = P.ray_factor[slot];
   const size_t row = (size_t)P.n_rays_total;
   double *img = P.image + out_index;
-  const BlPolSample *samples = P.pol_samples + (size_t)slot * P.ray_max_steps;
-  const double2 *ja = P.transfer + (size_t)slot * P.ray_max_steps * P.n_nu;
-  const double2 *pc = P.pol_coeffs + (size_t)slot * P.ray_max_steps * P.n_nu * 3;
+  const BlPolSample *samples = P.pol_samples + (size_t)P.ray_offset[slot];
+  const double2 *ja = P.transfer + (size_t)P.ray_offset[slot] * P.n_nu;
+  const double2 *pc = P.pol_coeffs + (size_t)P.ray_offset[slot] * P.n_nu * 3;
   for (int l = 0; l < P.n_nu; l++) {
     const double freq = P.frequencies[l];
     if (num <= 0) {   // :94-96: nothing integrated; rows stay as the auxiliary kernel zeroed them
@@ -810,9 +810,10 @@ __global__ void __launch_bounds__(256, 2) bl_transport_matrix_kernel(BlTransferA
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int n_waves = (gridDim.x * blockDim.x) >> 6;
   int slot = __builtin_amdgcn_readfirstlane(wave), base = 0, num = 0;   // wave-uniform: scalar registers, scalar branches
+  const int rays_done = bl_rays_done(P.counters, P.chunk_rays);
   auto settle = [&]() {   // first segment at or after (slot, base) that holds samples; false when the rays are used up
     for (;;) {
-      if (slot >= P.chunk_rays) return false;
+      if (slot >= rays_done) return false;
       if (base == 0) num = __builtin_amdgcn_readfirstlane(P.ray_sample_num[slot]);
       if (base < num) return true;
       slot += n_waves;
@@ -822,7 +823,7 @@ __global__ void __launch_bounds__(256, 2) bl_transport_matrix_kernel(BlTransferA
   // slot q = lane + 64 j of the tile receives unit 8 i + ((r - i) & 7) of the segment, i = q / 8, r = q % 8 (clamped to the
   // ray's last record: always a valid address, never under a branch)
   auto request = [&](unsigned char *tile, int lane, int slot_r, int base_r, int num_r) {
-    const double2 *samples = reinterpret_cast<const double2 *>(P.pol_samples + (size_t)slot_r * P.ray_max_steps);
+    const double2 *samples = reinterpret_cast<const double2 *>(P.pol_samples + (size_t)P.ray_offset[slot_r]);
 #pragma unroll
     for (int j = 0; j < 9; j++) {
       const int q = lane + 64 * j, i = q >> 3;
@@ -845,7 +846,7 @@ __global__ void __launch_bounds__(256, 2) bl_transport_matrix_kernel(BlTransferA
     // integer instructions each) every segment instead of being hoisted out of the loop into registers that then spill
     int lane = lane_fixed;
     asm volatile("" : "+v"(lane));
-    double2 *matrices = reinterpret_cast<double2 *>(P.pol_matrix + (size_t)slot_cur * P.ray_max_steps * BL_POL_MATRIX_DOUBLES);
+    double2 *matrices = reinterpret_cast<double2 *>(P.pol_matrix + (size_t)P.ray_offset[slot_cur] * BL_POL_MATRIX_DOUBLES);
     bool live;
     {
       mk_wave_sync();
@@ -933,17 +934,17 @@ __global__ void __launch_bounds__(256, 2) bl_transport_matrix_kernel(BlTransferA
 __global__ void __launch_bounds__(64, 2) bl_transfer_polarized_matrix_kernel(BlTransferArgs P) {
   using namespace fastpol;
   const int slot = blockIdx.x * blockDim.x + threadIdx.x;
-  if (slot >= P.chunk_rays) return;
+  if (slot >= bl_rays_done(P.counters, P.chunk_rays)) return;
   const BlSpacetime st = P.st;
   const int num = P.ray_sample_num[slot];
   const long long out_index = P.ray_out_index[slot];
   const double momentum_factor = P.ray_factor[slot];
   const size_t row = (size_t)P.n_rays_total;
   double *img = P.image + out_index;
-  const BlPolSample *samples = P.pol_samples + (size_t)slot * P.ray_max_steps;
-  const double *matrices = P.pol_matrix + (size_t)slot * P.ray_max_steps * BL_POL_MATRIX_DOUBLES;
-  const double2 *ja = P.transfer + (size_t)slot * P.ray_max_steps * P.n_nu;
-  const double2 *pc = P.pol_coeffs + (size_t)slot * P.ray_max_steps * P.n_nu * 3;
+  const BlPolSample *samples = P.pol_samples + (size_t)P.ray_offset[slot];
+  const double *matrices = P.pol_matrix + (size_t)P.ray_offset[slot] * BL_POL_MATRIX_DOUBLES;
+  const double2 *ja = P.transfer + (size_t)P.ray_offset[slot] * P.n_nu;
+  const double2 *pc = P.pol_coeffs + (size_t)P.ray_offset[slot] * P.n_nu * 3;
   // the last sample's second half step and the camera projection do not depend on the frequency
   double m_cam[10];
   if (num > 0) {

@@ -1,0 +1,1268 @@
+// bl_render.hip - bl_render(): the reference's GeodesicIntegrator::Integrate() + RadiationIntegrator::Integrate() for one
+// level of rays (src/blacklight.cpp:93-94, 203-204) as a pipeline of HIP kernels over chunks of rays, and what hangs off
+// it: geodesic checkpoints (geodesic_checkpoint.cpp:28-108), statistics, the reference's warning texts.
+//
+// One call = plan (which kernels, what a sample costs in HBM) -> scratch -> kernel arguments -> chunks -> outputs.
+// A chunk is not sized on the host: every scratch array has one entry per sample record (or per kept sample), a scratch set
+// holds `record_capacity` of each, and the geodesic kernel hands out rays only while the records of the rays in flight
+// are sure to fit (BlTraceArgs::record_gate). What it did not get to is the next chunk. The benchmark frame - 704 samples
+// per ray where ray_max_steps allows 2 000 - is one chunk this way; sized for the worst case it was two.
+#include "bl_ctx.h"
+
+namespace {
+
+// geodesic start / end, locate start, coefficient start, transfer start, end, counters copied to the host
+constexpr int kEventsPerChunk = 7;
+
+// RadiationIntegrator::Hypergeometric (simulation_coefficients.cpp:740-773): 2F1 for z < 0 through its Pfaff
+// transformation, ten terms of the series
+double Hypergeometric(double alpha, double beta, double gamma, double z) {
+  const double a = alpha, b = gamma - beta, c = gamma;
+  const double x = z / (z - 1.0);
+  double result = 1.0, a_k = 1.0, b_k = 1.0, c_k = 1.0, xk = 1.0, k_factorial = 1.0;
+  for (int k = 1; k <= 10; k++) {
+    a_k *= a + k - 1.0;
+    b_k *= b + k - 1.0;
+    c_k *= c + k - 1.0;
+    xk *= x;
+    k_factorial *= k;
+    result += a_k * b_k * xk / (c_k * k_factorial);
+  }
+  result *= bl_pow(1.0 - z, -alpha);
+  return result;
+}
+
+void EnsureRenderResources(bl_ctx *ctx) {
+  const size_t need = 2 * kEventsPerChunk + 2;
+  while (ctx->events.size() < need) {
+    hipEvent_t e = nullptr;
+    Check(hipEventCreate(&e), "hipEventCreate");
+    ctx->events.push_back(e);
+  }
+  if (ctx->host_counters == nullptr)
+    Check(hipHostMalloc(reinterpret_cast<void **>(&ctx->host_counters), 2 * BL_CNT_TOTAL * sizeof(unsigned long long), hipHostMallocDefault),
+          "hipHostMalloc");
+}
+
+// ---- geodesic checkpoints (geodesic_checkpoint.cpp:28-108, file_io.cpp:65-127): 7 x 4 doubles of camera frame, then Arrays
+// - five int32 dimensions n1 ... n5 (fastest first) followed by the data - of camera_pos (n_pix, 4), camera_dir (n_pix, 4),
+// image_frequencies, momentum_factors (n_pix), the int geodesic_num_steps, sample_flags (n_pix, bool), sample_num (n_pix, int),
+// sample_pos (n_pix, n_steps, 4), sample_dir (n_pix, n_steps, 4), sample_len (n_pix, n_steps); root level only.
+template <typename T>
+void ReadCheckpointArray(std::ifstream &in, std::vector<T> *data, int dims[5]) {
+  in.read(reinterpret_cast<char *>(dims), 5 * sizeof(int));
+  size_t count = 1;
+  for (int a = 0; a < 5; a++) count *= static_cast<size_t>(std::max(dims[a], 1));
+  if (!in || count > (1ull << 36) / sizeof(T)) throw Failure{BL_E_INPUT, "Geodesic checkpoint file is damaged."};
+  data->resize(count);
+  in.read(reinterpret_cast<char *>(data->data()), static_cast<std::streamsize>(count * sizeof(T)));
+  if (!in) throw Failure{BL_E_INPUT, "Geodesic checkpoint file is damaged."};
+}
+
+void LoadGeodesicCheckpoint(bl_ctx *ctx) {
+  const bl_params &p = ctx->params;
+  std::ifstream in(p.checkpoint_geodesic_file.s, std::ios_base::in | std::ios_base::binary);
+  if (!in.is_open()) throw Failure{BL_E_INPUT, "Could not open geodesic checkpoint file."};
+  bl_camera_frame &f = ctx->frame;
+  double *vectors[7] = {f.cam_x, f.u_con, f.u_cov, f.norm_con, f.norm_con_c, f.hor_con_c, f.vert_con_c};
+  for (double *v : vectors) in.read(reinterpret_cast<char *>(v), 4 * sizeof(double));
+  bl_ctx::Checkpoint &c = ctx->checkpoint;
+  const size_t n_pix = static_cast<size_t>(p.camera_resolution) * p.camera_resolution;
+  int dims[5];
+  std::vector<double> frequencies;
+  ReadCheckpointArray(in, &c.camera_pos, dims);
+  ReadCheckpointArray(in, &c.camera_dir, dims);
+  ReadCheckpointArray(in, &frequencies, dims);
+  ReadCheckpointArray(in, &c.factors, dims);
+  in.read(reinterpret_cast<char *>(&c.num_steps), sizeof(int));
+  ReadCheckpointArray(in, &c.flags, dims);
+  ReadCheckpointArray(in, &c.sample_num, dims);
+  ReadCheckpointArray(in, &c.pos, dims);
+  ReadCheckpointArray(in, &c.dir, dims);
+  ReadCheckpointArray(in, &c.len, dims);
+  const size_t steps = static_cast<size_t>(std::max(c.num_steps, 0));
+  if (c.camera_pos.size() != 4 * n_pix || c.camera_dir.size() != 4 * n_pix || c.factors.size() != n_pix || c.flags.size() != n_pix
+      || c.sample_num.size() != n_pix || c.pos.size() != n_pix * steps * 4 || c.dir.size() != n_pix * steps * 4
+      || c.len.size() != n_pix * steps || static_cast<int>(frequencies.size()) != p.image_num_frequencies || c.num_steps > p.ray_max_steps)
+    throw Failure{BL_E_INPUT, "Geodesic checkpoint does not match this camera (resolution, frequencies or ray_max_steps)."};
+  for (size_t m = 0; m < n_pix; m++)
+    if (c.sample_num[m] < 0 || c.sample_num[m] > c.num_steps) throw Failure{BL_E_INPUT, "Geodesic checkpoint file is damaged."};
+  ctx->frequencies = frequencies;   // LoadGeodesics() replaces what InitializeCamera() would have computed
+  c.loaded = true;
+}
+
+template <typename T>
+void WriteCheckpointHeader(std::ofstream &out, int n1, int n2, int n3) {
+  const int dims[5] = {n1, n2, n3, 1, 1};
+  out.write(reinterpret_cast<const char *>(dims), sizeof dims);
+}
+
+// A geodesic checkpoint being assembled: samples of every pixel, far -> near, packed
+struct CheckpointSave {
+  std::vector<int32_t> sample_num;
+  std::vector<uint8_t> flags;
+  std::vector<double> factors, pos, dir, len;
+  std::vector<size_t> offset;
+};
+
+// Everything one bl_render call decides before its first kernel, and what its chunks add up to
+struct RenderJob {
+  bl_ctx *ctx = nullptr;
+  const bl_render_desc *d = nullptr;
+  // which path
+  bool simulation = false, aux = false, slow = false, geo_load = false, geo_save = false, need_time = false, block_interp = false;
+  bool fast = false, tolerant_polarized = false, matrix_transport = false, freq_split = false, coef_split = false;
+  bool rows_only = false, fill_present = false;
+  int n_nu = 0, n_q = 0, max_steps = 0;
+  long long n_rays = 0, level_pixels = 0;
+  size_t redo_capacity = 0;
+  // scratch
+  uint64_t bytes_per_record = 0;
+  size_t record_capacity = 0;
+  long long record_gate = 0;
+  int n_slots = 1, geo_grid = 1;
+  // outputs (device pointers: the caller's, or staging)
+  double *image = nullptr, *cam_pos = nullptr, *cam_dir = nullptr, *render_out = nullptr;
+  int *out_num = nullptr;
+  unsigned char *out_flags = nullptr;
+  const int *d_pixel_map = nullptr, *d_block_locs = nullptr;
+  double snapshot_time = 0.0;
+  // kernel arguments common to all chunks
+  BlTraceArgs ta{};
+  BlShadeArgs sa{};
+  BlTransferArgs xa{};
+  int locate_grid_alone = 0, locate_grid_shared = 0, shade_grid = 0;
+  // a chunk in flight on scratch set k
+  struct InFlight {
+    bool busy = false;
+    long long begin = 0;
+    int rays = 0;
+    long long done = -1;   // rays the chunk covered, once known
+  } in_flight[2];
+  // totals
+  int n_chunks = 0;
+  float ms_geo = 0.0f, ms_locate = 0.0f, ms_shade = 0.0f, ms_transfer = 0.0f;
+  unsigned long long total_samples = 0, total_flagged = 0, total_records = 0, total_gathers = 0, total_redo = 0, total_undefined = 0, max_num = 0;
+  unsigned long long debug_counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  CheckpointSave save;
+};
+
+hipEvent_t *SlotEvents(RenderJob &job, int k) { return job.ctx->events.data() + static_cast<size_t>(k) * kEventsPerChunk; }
+
+// ---- plan: validation of the call, the path it takes
+void PlanJob(RenderJob &job) {
+  bl_ctx *ctx = job.ctx;
+  const bl_render_desc *d = job.d;
+  const bl_params &p = ctx->params;
+  job.simulation = p.model_type == BL_MODEL_SIMULATION;
+  if (ctx->device == BL_DEVICE_NONE) throw Failure{BL_E_DEVICE, "Host-only context: no HIP device selected (the hot path has no CPU fallback)."};
+  if (job.simulation && !ctx->have_grid) throw Failure{BL_E_STATE, "bl_render called before bl_set_grid."};
+  if (d->n_rays <= 0 || (d->image == nullptr && ctx->image_num_quantities > 0))
+    throw Failure{BL_E_ARG, "bl_render needs n_rays > 0 and an image buffer."};
+  if (ctx->render_num_images > 0 && d->render == nullptr) throw Failure{BL_E_ARG, "bl_render needs a render buffer when render_num_images > 0."};
+  if (d->n_rays > 0x7fffffffll) throw Failure{BL_E_ARG, "Too many rays in one bl_render call."};
+  if (d->level < 0 || d->level > p.adaptive_max_level) throw Failure{BL_E_ARG, "Adaptive level out of range."};
+  if (d->level > 0 && (d->block_locs == nullptr || d->n_blocks <= 0)) throw Failure{BL_E_ARG, "Refined level needs block_locs."};
+  job.n_nu = p.image_num_frequencies;
+  job.n_q = ctx->image_num_quantities;
+  job.max_steps = p.ray_max_steps;
+  job.n_rays = d->n_rays;
+  job.aux = ctx->aux_images.any != 0;
+  job.slow = job.simulation && p.slow_light_on;
+  if (job.slow) {
+    if (static_cast<int>(ctx->slow_slices.size()) != p.slow_chunk_size) throw Failure{BL_E_STATE, "Slow light: time slices not set."};
+    for (const bl_ctx::SlowSlice &slice : ctx->slow_slices)
+      if (!slice.set) throw Failure{BL_E_STATE, "Slow light: time slices not set."};
+  }
+  // geodesic checkpoints (root level only, like the reference's): load replaces the geodesic kernel by the file's
+  // samples, save writes what the geodesic kernel produced in the reference's layout
+  job.geo_load = p.checkpoint_geodesic_load && d->level == 0;
+  job.geo_save = p.checkpoint_geodesic_save && d->level == 0;
+  if (job.geo_load && !ctx->checkpoint.loaded) LoadGeodesicCheckpoint(ctx);
+  job.need_time = (job.aux && ctx->aux_images.image_time) || job.slow || job.geo_load || job.geo_save;
+
+  job.level_pixels = static_cast<long long>(p.camera_resolution) * p.camera_resolution;
+  if (d->level > 0) job.level_pixels = static_cast<long long>(d->n_blocks) * p.adaptive_block_size * p.adaptive_block_size;
+  if (d->pixel_map == nullptr && job.n_rays > job.level_pixels) throw Failure{BL_E_ARG, "n_rays exceeds the pixels of this level."};
+  if (job.geo_save && (d->pixel_map != nullptr || job.n_rays != job.level_pixels))
+    throw Failure{BL_E_ARG, "checkpoint_geodesic_save needs the whole root camera in one bl_render call."};
+  if (job.geo_load && d->pixel_map != nullptr) {   // a rank's tiles can be served from the one file; the map must stay inside it
+    const size_t n_pix = ctx->checkpoint.sample_num.size();
+    for (long long ray = 0; ray < job.n_rays; ray++)
+      if (d->pixel_map[ray] < 0 || static_cast<size_t>(d->pixel_map[ray]) >= n_pix)
+        throw Failure{BL_E_ARG, "pixel_map names a pixel the geodesic checkpoint does not hold."};
+  }
+  job.block_interp = job.simulation && ctx->grid_dev.block_interp != 0;
+  // Tolerant tier: plain unpolarized images of a spherical Kerr-Schild simulation with thermal electrons in a curved
+  // spacetime have the fast coefficient kernel; every other configuration is rendered in exact arithmetic whatever
+  // bl_set_arithmetic() asked for (bl_stats.arithmetic says which tier ran)
+  job.fast = ctx->arithmetic == BL_ARITH_TOLERANT && job.simulation && !job.aux && !ctx->polarized && !job.slow && !job.block_interp
+      && p.plasma_power_frac == 0.0 && p.plasma_kappa_frac == 0.0 && p.plasma_model != BL_PLASMA_CODE_KAPPA
+      && (p.simulation_coord == BL_COORD_SKS || p.simulation_coord == BL_COORD_FMKS) && !p.ray_flat && ctx->plasma_thermal_frac != 0.0
+      && job.n_nu <= 1024;   // (its LDS table holds five numbers per frequency)
+  // ... and the per-frequency coefficient kernel of polarized runs (frame, transport and coupling stay exact)
+  job.tolerant_polarized = ctx->arithmetic == BL_ARITH_TOLERANT && ctx->polarized;
+  // ... and transport matrices (bl_transport_matrix_kernel) instead of the ray-sequential tensor transport, in curved spacetimes
+  job.matrix_transport = job.tolerant_polarized && !p.ray_flat;
+  // Several frequencies in the fast path: per-sample factors (BlFreqInputs) instead of per-frequency transfer records,
+  // evaluated by bl_transfer_freq_kernel with one lane per ray and frequency
+  job.freq_split = job.fast && job.n_nu >= 4;
+  // ... and in the exact coefficient kernel (plain images): the frequency loop as lanes of bl_coefficients_freq_kernel
+  job.coef_split = !job.fast && job.simulation && !job.aux && !ctx->polarized && job.n_nu >= 4;
+  // (polarized runs list the samples without coefficients there - cut samples, cut cells - which are many more)
+  job.redo_capacity = ctx->polarized ? (1u << 24) : (1u << 20);
+  // polarized run with no per-sample row but tau and no rendering: tau is integrated by the polarized transfer kernel
+  bool fill_present = false;
+  for (int n_i = 0; n_i < ctx->render_num_images; n_i++)
+    for (int n_f = 0; n_f < p.render_num_features[n_i]; n_f++)
+      if (p.render_type[n_i][n_f] == BL_RENDER_FILL) fill_present = true;
+  job.fill_present = fill_present;
+  const BlAuxImages &AI = ctx->aux_images;
+  job.rows_only = ctx->polarized && ctx->render_num_images == 0 && !fill_present && !(AI.image_time || AI.image_length || AI.image_lambda
+      || AI.image_emission || AI.image_lambda_ave || AI.image_emission_ave || AI.image_tau_int || AI.image_crossings);
+}
+
+// ---- scratch: what a sample record costs, how many fit, how many persistent waves trace rays into them
+void PlanScratch(RenderJob &job) {
+  bl_ctx *ctx = job.ctx;
+  const bl_params &p = ctx->params;
+  const int n_nu = job.n_nu;
+  // per sample record (the arrays indexed by record slot) and per kept sample (the arrays indexed by ray_offset + n: never
+  // more than records)
+  job.bytes_per_record = sizeof(BlSampleHot) + sizeof(BlSampleCold)
+      + (job.simulation ? sizeof(BlLocated) + sizeof(unsigned long long) : 0)
+      + (job.freq_split ? sizeof(BlFreqInputs) : sizeof(double2) * n_nu)
+      + (job.aux ? sizeof(BlAuxSample) : 0) + (job.need_time ? sizeof(double) : 0) + (job.slow ? sizeof(double) : 0)
+      + (ctx->polarized ? sizeof(BlPolSample) + sizeof(BlCoefInputs) + 3 * sizeof(double2) * n_nu : 0)
+      + (job.coef_split ? sizeof(BlCoefInputs) : 0)
+      + (job.matrix_transport ? BL_POL_MATRIX_DOUBLES * sizeof(double) : 0)
+      + (job.block_interp ? 8 * sizeof(unsigned int) : 0);
+  const uint64_t per_slot_fixed = ((job.fast || ctx->polarized) ? job.redo_capacity * sizeof(unsigned long long) : 0) + BL_CNT_TOTAL * sizeof(unsigned long long);
+  const uint64_t per_ray = (2 + (job.geo_load ? 0 : BL_RAY_START_FIELDS)) * sizeof(double) + sizeof(int) + 1 + 2 * sizeof(long long);
+  // The budget is capped by what the device can actually give: 90 % of (free memory + what this context already holds
+  // from earlier renders).
+  uint64_t budget = ctx->scratch_limit;
+  {
+    size_t free_bytes = 0, total_bytes = 0;
+    if (hipMemGetInfo(&free_bytes, &total_bytes) == hipSuccess) {
+      const uint64_t held = ctx->slot[0].Bytes() + ctx->slot[1].Bytes() + ctx->RayBytes();
+      const uint64_t available = static_cast<uint64_t>(0.9 * static_cast<double>(free_bytes + held));
+      if (available < budget) budget = available;
+    }
+  }
+  const int waves_per_cu = bl_geodesic_occupancy(p.ray_integrator, job.need_time ? 1 : 0, ctx->st.bh_a == 0.0 ? 1 : 0);
+  const long long max_grid = std::min<long long>(static_cast<long long>(ctx->num_cus) * waves_per_cu, (job.n_rays + 63) / 64);
+  const uint64_t worst_case = static_cast<uint64_t>(job.n_rays) * job.max_steps + static_cast<uint64_t>(max_grid) * BL_RECORD_BLOCK;
+  const uint64_t fixed = per_ray * static_cast<uint64_t>(job.n_rays);
+  auto capacity_for = [&](int n_slots) -> uint64_t {
+    const uint64_t overhead = fixed + n_slots * per_slot_fixed;
+    if (budget <= overhead) return 0;
+    return std::min<uint64_t>((budget - overhead) / (static_cast<uint64_t>(n_slots) * job.bytes_per_record), worst_case);
+  };
+  // One scratch set; two of half the size each under bl_set_overlap() when one set cannot be sure to take the whole call,
+  // so that the geodesic kernel of chunk c + 1 runs while chunk c is being shaded.
+  job.n_slots = 1;
+  uint64_t capacity = capacity_for(1);
+  if (ctx->overlap_chunks && capacity < worst_case) {
+    job.n_slots = 2;
+    capacity = capacity_for(2);
+  }
+  // Persistent waves: every lane in flight holds ray_max_steps record slots until its ray ends, so no more lanes than
+  // half the buffer can cover (a small budget then runs few waves and still finishes rays to make room for the next).
+  const uint64_t per_wave = BL_RECORD_BLOCK + 2ull * 64ull * static_cast<uint64_t>(job.max_steps);
+  const long long grid = std::max<long long>(1, std::min<long long>(max_grid, static_cast<long long>(capacity / per_wave)));
+  const long long gate = static_cast<long long>(capacity) - grid * BL_RECORD_BLOCK;
+  if (gate < job.max_steps)
+    throw Failure{BL_E_ARG, "Scratch budget too small: the sample records of a single ray (ray_max_steps of them) do not fit (bl_set_scratch_limit)."};
+  job.record_capacity = static_cast<size_t>(capacity);
+  job.record_gate = gate;
+  job.geo_grid = static_cast<int>(grid);
+}
+
+void EnsureScratch(RenderJob &job) {
+  bl_ctx *ctx = job.ctx;
+  const size_t cap = job.record_capacity;
+  const size_t n_nu = static_cast<size_t>(job.n_nu);
+  for (int k = 0; k < job.n_slots; k++) {
+    bl_ctx::ChunkSlot &sl = ctx->slot[k];
+    sl.d_records_hot.Ensure(cap);
+    sl.d_records_cold.Ensure(cap);
+    if (job.simulation) {
+      sl.d_located.Ensure(cap);
+      sl.d_located_tag.Ensure(cap);
+    }
+    if (job.freq_split) sl.d_freq_inputs.Ensure(cap);   // instead of the transfer records
+    else sl.d_transfer.Ensure(cap * n_nu);
+    sl.d_counters.Ensure(BL_CNT_TOTAL);
+    if (job.aux) sl.d_aux.Ensure(cap);
+    if (job.need_time) sl.d_sample_t.Ensure(cap);
+    if (job.slow) sl.d_slow_frac.Ensure(cap);
+    if (ctx->polarized) {
+      sl.d_pol_samples.Ensure(cap);
+      if (job.matrix_transport) sl.d_pol_matrix.Ensure(cap * BL_POL_MATRIX_DOUBLES);
+      sl.d_pol_coeffs.Ensure(cap * n_nu * 3);
+      sl.d_coef_inputs.Ensure(cap);
+    }
+    if (job.coef_split) sl.d_coef_inputs.Ensure(cap);
+    if (job.block_interp) sl.d_anchors.Ensure(cap * 8);
+    if (job.fast || ctx->polarized) sl.d_redo.Ensure(job.redo_capacity);   // polarized runs: the samples whose frame bl_polarized_frame_kernel builds
+  }
+  const size_t n_rays = static_cast<size_t>(job.n_rays);
+  ctx->d_ray_kt.Ensure(n_rays);
+  ctx->d_ray_factor.Ensure(n_rays);
+  ctx->d_ray_sample_num.Ensure(n_rays);
+  ctx->d_ray_flags.Ensure(n_rays);
+  ctx->d_ray_out_index.Ensure(n_rays);
+  ctx->d_ray_offset.Ensure(n_rays);
+  if (!job.geo_load) ctx->d_ray_start.Ensure(n_rays * BL_RAY_START_FIELDS);
+  EnsureRenderResources(ctx);
+}
+
+// ---- inputs of the call that live in HBM: frequencies, pixel map, block list; output buffers (the caller's, or staging)
+void StageInputsAndOutputs(RenderJob &job) {
+  bl_ctx *ctx = job.ctx;
+  const bl_render_desc *d = job.d;
+  const bl_params &p = ctx->params;
+  hipStream_t stream = ctx->stream;
+  const long long n_rays = job.n_rays;
+  ctx->d_freq.Ensure(job.n_nu);
+  Check(hipMemcpyAsync(ctx->d_freq.ptr, ctx->frequencies.data(), job.n_nu * sizeof(double), hipMemcpyHostToDevice, stream), "freq upload");
+  if (d->pixel_map != nullptr) {
+    ctx->d_pixel_map.Ensure(n_rays);
+    Check(hipMemcpyAsync(ctx->d_pixel_map.ptr, d->pixel_map, n_rays * sizeof(int), hipMemcpyHostToDevice, stream), "pixel_map upload");
+    job.d_pixel_map = ctx->d_pixel_map.ptr;
+  }
+  if (d->level > 0) {
+    ctx->d_block_locs.Ensure(static_cast<size_t>(d->n_blocks) * 2);
+    Check(hipMemcpyAsync(ctx->d_block_locs.ptr, d->block_locs, static_cast<size_t>(d->n_blocks) * 2 * sizeof(int), hipMemcpyHostToDevice, stream), "block_locs upload");
+    job.d_block_locs = ctx->d_block_locs.ptr;
+  }
+  job.image = d->image;
+  job.cam_pos = d->camera_pos;
+  job.cam_dir = d->camera_dir;
+  job.out_num = d->sample_num;
+  job.out_flags = d->sample_flags;
+  if (!d->outputs_on_device) {
+    ctx->d_image.Ensure(static_cast<size_t>(job.n_q) * n_rays);
+    job.image = ctx->d_image.ptr;
+    if (d->sample_num != nullptr) { ctx->d_out_sample_num.Ensure(n_rays); job.out_num = ctx->d_out_sample_num.ptr; }
+    if (d->sample_flags != nullptr) { ctx->d_out_flags.Ensure(n_rays); job.out_flags = ctx->d_out_flags.ptr; }
+    if (d->camera_pos != nullptr) { ctx->d_camera_pos.Ensure(static_cast<size_t>(n_rays) * 4); job.cam_pos = ctx->d_camera_pos.ptr; }
+    if (d->camera_dir != nullptr) { ctx->d_camera_dir.Ensure(static_cast<size_t>(n_rays) * 4); job.cam_dir = ctx->d_camera_dir.ptr; }
+  }
+  if (ctx->polarized || job.geo_save) {   // the camera tetrad projection (and the checkpoint) need every ray's initial position and momentum
+    if (job.cam_pos == nullptr) { ctx->d_camera_pos.Ensure(static_cast<size_t>(n_rays) * 4); job.cam_pos = ctx->d_camera_pos.ptr; }
+    if (job.cam_dir == nullptr) { ctx->d_camera_dir.Ensure(static_cast<size_t>(n_rays) * 4); job.cam_dir = ctx->d_camera_dir.ptr; }
+  }
+  if (job.geo_load && (job.cam_pos != nullptr || job.cam_dir != nullptr)) {   // camera_pos / camera_dir come from the file as well
+    std::vector<double> rows(static_cast<size_t>(n_rays) * 4);
+    for (int which = 0; which < 2; which++) {
+      double *target = which == 0 ? job.cam_pos : job.cam_dir;
+      if (target == nullptr) continue;
+      const std::vector<double> &source = which == 0 ? ctx->checkpoint.camera_pos : ctx->checkpoint.camera_dir;
+      for (long long ray = 0; ray < n_rays; ray++) {
+        const size_t m = d->pixel_map != nullptr ? static_cast<size_t>(d->pixel_map[ray]) : static_cast<size_t>(ray);
+        for (int mu = 0; mu < 4; mu++) rows[4 * ray + mu] = source[4 * m + mu];
+      }
+      Check(hipMemcpy(target, rows.data(), rows.size() * sizeof(double), hipMemcpyHostToDevice), "checkpoint upload");
+    }
+  }
+  if (ctx->render_num_images > 0) {
+    BlRenderDevice rp{};
+    rp.n_images = ctx->render_num_images;
+    for (int n_i = 0; n_i < rp.n_images; n_i++) {
+      rp.n_features[n_i] = p.render_num_features[n_i];
+      for (int n_f = 0; n_f < rp.n_features[n_i]; n_f++) {
+        rp.quantity[n_i][n_f] = p.render_quantity[n_i][n_f];
+        rp.type[n_i][n_f] = p.render_type[n_i][n_f];
+        rp.min_val[n_i][n_f] = p.render_min[n_i][n_f];
+        rp.max_val[n_i][n_f] = p.render_max[n_i][n_f];
+        rp.thresh[n_i][n_f] = p.render_thresh[n_i][n_f];
+        rp.tau_scale[n_i][n_f] = p.render_tau_scale[n_i][n_f];
+        rp.opacity[n_i][n_f] = p.render_opacity[n_i][n_f];
+        rp.xyz[n_i][n_f][0] = p.render_x[n_i][n_f];
+        rp.xyz[n_i][n_f][1] = p.render_y[n_i][n_f];
+        rp.xyz[n_i][n_f][2] = p.render_z[n_i][n_f];
+      }
+    }
+    rp.fill_present = job.fill_present ? 1 : 0;
+    ctx->d_render_params.Ensure(1);
+    Check(hipMemcpyAsync(ctx->d_render_params.ptr, &rp, sizeof(BlRenderDevice), hipMemcpyHostToDevice, stream), "render parameter upload");
+    Check(hipStreamSynchronize(stream), "render parameter upload");   // rp is a local
+    job.render_out = d->render;
+    if (!d->outputs_on_device) {
+      ctx->d_render.Ensure(static_cast<size_t>(ctx->render_num_images) * 3 * n_rays);
+      job.render_out = ctx->d_render.ptr;
+    }
+  }
+}
+
+// ---- kernel arguments common to all chunks: the geodesic kernel's
+void BuildTraceArgs(RenderJob &job) {
+  bl_ctx *ctx = job.ctx;
+  const bl_render_desc *d = job.d;
+  const bl_params &p = ctx->params;
+  BlTraceArgs &ta = job.ta;
+  ta.st = ctx->st;
+  BlCameraDevice &cam = ta.cam;
+  for (int mu = 0; mu < 4; mu++) {
+    cam.cam_x[mu] = ctx->frame.cam_x[mu];
+    cam.u_con[mu] = ctx->frame.u_con[mu];
+    cam.u_cov[mu] = ctx->frame.u_cov[mu];
+    cam.norm_con[mu] = ctx->frame.norm_con[mu];
+    cam.norm_con_c[mu] = ctx->frame.norm_con_c[mu];
+    cam.hor_con_c[mu] = ctx->frame.hor_con_c[mu];
+    cam.vert_con_c[mu] = ctx->frame.vert_con_c[mu];
+  }
+  cam.camera_width = p.camera_width;
+  cam.camera_r = p.camera_r;
+  cam.camera_type = p.camera_type;
+  cam.image_normalization = p.image_normalization;
+  cam.camera_resolution = p.camera_resolution;
+  cam.level = d->level;
+  cam.block_size = p.adaptive_max_level > 0 ? p.adaptive_block_size : 1;
+  cam.effective_resolution = p.camera_resolution;
+  for (int l = 1; l <= d->level; l++) cam.effective_resolution *= 2;
+  ta.r_terminate = ctx->frame.r_terminate;
+  ta.r_horizon = ctx->frame.r_horizon;
+  ta.camera_r = p.camera_r;
+  ta.ray_step = p.ray_step;
+  ta.ray_tol_abs = p.ray_integrator == BL_INTEGRATOR_DP ? p.ray_tol_abs : 0.0;
+  ta.ray_tol_rel = p.ray_integrator == BL_INTEGRATOR_DP ? p.ray_tol_rel : 0.0;
+  ta.ray_max_steps = job.max_steps;
+  ta.ray_max_retries = p.ray_integrator == BL_INTEGRATOR_DP ? p.ray_max_retries : 0;
+  ta.n_rays_total = job.n_rays;
+  ta.swizzle_tiles = (d->level == 0 && d->pixel_map == nullptr && p.camera_resolution % 8 == 0 && job.n_rays == job.level_pixels)
+      ? p.camera_resolution : 0;
+  // Order in which the 8x8 pixel tiles of a full frame are traced: centre of the image first. Rays near
+  // the centre (photon ring, disc) are the long ones, the periphery is short; a chunk that ends on short
+  // rays drains its persistent waves quickly (measured: geodesic kernel 33.9 -> 29.4 ms per frame at four
+  // chunks), and waves of similar ray lengths also diverge less in the transfer kernel.
+  ta.tile_order = nullptr;
+  if (ta.swizzle_tiles > 0) {
+    if (ctx->tile_order_res != p.camera_resolution) {
+      const int tiles_per_row = p.camera_resolution / 8;
+      const int n_tiles = tiles_per_row * tiles_per_row;
+      std::vector<int> order(n_tiles);
+      for (int t = 0; t < n_tiles; t++) order[t] = t;
+      const double centre = 0.5 * (tiles_per_row - 1);
+      auto dist2 = [&](int t) {
+        double dy = t / tiles_per_row - centre, dx = t % tiles_per_row - centre;
+        return dx * dx + dy * dy;
+      };
+      std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return dist2(a) < dist2(b); });
+      ctx->d_tile_order.Ensure(n_tiles);
+      Check(hipMemcpy(ctx->d_tile_order.ptr, order.data(), n_tiles * sizeof(int), hipMemcpyHostToDevice), "tile order upload");
+      ctx->tile_order_res = p.camera_resolution;
+    }
+    ta.tile_order = ctx->d_tile_order.ptr;
+  }
+  ta.pixel_map = job.d_pixel_map;
+  ta.block_locs = job.d_block_locs;
+  ta.record_capacity = static_cast<long long>(job.record_capacity);
+  ta.record_gate = job.record_gate;
+  ta.camera_pos = job.cam_pos;
+  ta.camera_dir = job.cam_dir;
+  ta.ray_start_stride = job.n_rays;
+}
+
+// Power-law and kappa-distribution constants of the coefficient formulas (simulation_coefficients.cpp:54-193); pow / exp / log
+// and K_nu are the pinned ones, tgamma the host libm's
+void FillElectronConstants(RenderJob &job, BlPlasmaDevice &pl, BlShadeCold &cold) {
+  bl_ctx *ctx = job.ctx;
+  const bl_params &p = ctx->params;
+  pl.power_frac = p.plasma_power_frac;
+  pl.plasma_p = 0.0;
+  pl.power_jj = pl.power_aa = 0.0;
+  if (p.plasma_power_frac != 0.0) {
+    // simulation_coefficients.cpp:54-66 (unpolarized part)
+    const double plasma_p = p.plasma_p;
+    const double var_a = bl_pow(3.0, plasma_p / 2.0) * (plasma_p - 1.0);
+    const double var_b = 2.0 * (plasma_p + 1.0);
+    const double var_c = bl_pow(p.plasma_gamma_min, 1.0 - plasma_p) - bl_pow(p.plasma_gamma_max, 1.0 - plasma_p);
+    const double var_d = std::tgamma((3.0 * plasma_p - 1.0) / 12.0);
+    const double var_e = std::tgamma((3.0 * plasma_p + 19.0) / 12.0);
+    const double var_f = bl_pow(3.0, (plasma_p + 1.0) / 2.0) * (plasma_p - 1.0) / 4.0;
+    const double var_g = std::tgamma((3.0 * plasma_p + 2.0) / 12.0);
+    const double var_h = std::tgamma((3.0 * plasma_p + 22.0) / 12.0);
+    pl.plasma_p = plasma_p;
+    pl.power_jj = var_a / var_b / var_c * var_d * var_e;
+    pl.power_aa = var_f / var_c * var_g * var_h;
+    if (ctx->polarized) {   // simulation_coefficients.cpp:67-80
+      const double var_i = 2.0 * (plasma_p + 2.0) / (plasma_p + 1.0);
+      const double var_j = bl_pow(p.plasma_gamma_min, -(plasma_p + 1.0));
+      const double var_k = bl_log(p.plasma_gamma_min);
+      ctx->power_pol[0] = -(plasma_p + 1.0) / (plasma_p + 7.0 / 3.0);
+      ctx->power_pol[1] = 0.684 * bl_pow(plasma_p, 0.49);
+      ctx->power_pol[2] = -bl_pow(0.034 * plasma_p - 0.0344, 0.086);
+      ctx->power_pol[3] = bl_pow(0.71 * plasma_p + 0.0352, 0.394);
+      ctx->power_pol[4] = (plasma_p - 1.0) / var_c;
+      ctx->power_pol[5] = -bl_pow(p.plasma_gamma_min, 2.0 - plasma_p) / (plasma_p / 2.0 - 1.0);
+      ctx->power_pol[6] = var_i * var_j * var_k;
+    }
+  }
+  cold.kappa = BlKappaDevice{};
+  if (p.plasma_kappa_frac != 0.0) {
+    // simulation_coefficients.cpp:82-193 for a polarized run
+    BlKappaDevice &kk = cold.kappa;
+    const double plasma_kappa = p.plasma_kappa, plasma_w = p.plasma_w;
+    kk.frac = p.plasma_kappa_frac;
+    kk.kappa = plasma_kappa;
+    kk.w = plasma_w;
+    const double var_a = 4.0 * kPi * std::tgamma(plasma_kappa - 4.0 / 3.0);
+    const double var_b = bl_pow(3.0, 7.0 / 3.0) * std::tgamma(plasma_kappa - 2.0);
+    const double var_c = bl_pow(3.0, (plasma_kappa - 1.0) / 2.0);
+    const double var_d = (plasma_kappa - 2.0) * (plasma_kappa - 1.0) / 4.0;
+    const double var_e = std::tgamma(plasma_kappa / 4.0 - 1.0 / 3.0);
+    const double var_f = std::tgamma(plasma_kappa / 4.0 + 4.0 / 3.0);
+    const double var_g = bl_pow(3.0, 1.0 / 6.0) * 10.0 / 41.0;
+    const double var_h = plasma_w * plasma_kappa;
+    const double var_i = 2.0 * kPi * bl_pow(var_h, plasma_kappa - 10.0 / 3.0);
+    const double var_j = (plasma_kappa - 2.0) * (plasma_kappa - 1.0) * plasma_kappa;
+    const double var_k = 3.0 * plasma_kappa - 1.0;
+    const double var_l = std::tgamma(5.0 / 3.0);
+    const double var_m = Hypergeometric(plasma_kappa - 1.0 / 3.0, plasma_kappa + 1.0, plasma_kappa + 2.0 / 3.0, -var_h);
+    const double var_n = bl_pow(kPi, 1.5) / 3.0;
+    const double var_o = var_j / (var_h * var_h * var_h);
+    const double var_p = 2.0 * std::tgamma(2.0 + plasma_kappa / 2.0) / (2.0 + plasma_kappa) - 1.0;
+    kk.jj_low = var_a / var_b;
+    kk.jj_high = var_c * var_d * var_e * var_f;
+    kk.jj_x_i = 3.0 * bl_pow(plasma_kappa, -1.5);
+    kk.aa_low = var_g * var_i * var_j / var_k * var_l * var_m;
+    kk.aa_high = var_n * var_o * var_p;
+    kk.aa_x_i = bl_pow(-1.75 + 1.6 * plasma_kappa, -0.86);
+    const double var_q = 14.3 * bl_pow(plasma_w, -0.928);
+    const double var_r = 169.0 * bl_pow(plasma_kappa, -8.0) + 0.0052 * plasma_kappa - 0.0526 + 47.0 / (200.0 * plasma_kappa);
+    kk.jj_low_q = 0.5;
+    kk.jj_low_v = 0.5625 * bl_pow(plasma_kappa, -0.528) / plasma_w;
+    kk.jj_high_q = 0.64 + 0.02 * plasma_kappa;
+    kk.jj_high_v = 0.765625 * bl_pow(plasma_kappa, -0.44) / plasma_w;
+    kk.jj_x_q = 3.7 * bl_pow(plasma_kappa, -1.6);
+    kk.jj_x_v = kk.jj_x_i;
+    kk.aa_low_q = 25.0 / 48.0;
+    kk.aa_low_v = 77.0 / (100.0 * plasma_w) * bl_pow(plasma_kappa, -0.7);
+    kk.aa_high_i = bl_pow(3.0 / plasma_kappa, 4.75) + 0.6;
+    kk.aa_high_q = 441.0 * bl_pow(plasma_kappa, -5.76) + 0.55;
+    kk.aa_high_v = var_q * var_r;
+    kk.aa_x_q = 1.4 * bl_pow(plasma_kappa, -1.15);
+    kk.aa_x_v = 1.22 * bl_pow(plasma_kappa, -1.136) + 0.007;
+    kk.rho_v = bl_cyl_bessel_k(0, 1.0 / plasma_w) / bl_cyl_bessel_k(2, 1.0 / plasma_w);
+    // rotativity fits at kappa = 3.5, 4, 4.5, 5 (:128-192); kappa is bracketed by two of them
+    const double sqrt_w = blm_sqrt(plasma_w), exp_w = bl_exp(-5.0 * plasma_w);
+    const double fit_q[4][5] = {
+        {17.0 * plasma_w + sqrt_w * (-3.0 + 7.0 * exp_w), -1.0 / 30.0, 0.1, -1.5, 0.471},
+        {46.0 / 3.0 * plasma_w + sqrt_w * (-5.0 / 3.0 + 17.0 / 3.0 * exp_w), -1.0 / 18.0, 1.0 / 6.0, -1.75, 0.5},
+        {14.0 * plasma_w + sqrt_w * (-1.625 + 4.5 * exp_w), -1.0 / 12.0, 0.25, -2.0, 0.525},
+        {12.5 * plasma_w + sqrt_w * (-1.0 + 5.0 * exp_w), -0.125, 0.375, -2.25, 0.541}};
+    const double fit_v[4][2] = {
+        {(plasma_w * plasma_w + 2.0 * plasma_w + 1.0) / (3.125 * plasma_w * plasma_w + 4.0 * plasma_w + 1.0), 0.447},
+        {(plasma_w * plasma_w + 54.0 * plasma_w + 50.0) / (30.0 / 11.0 * plasma_w * plasma_w + 134.0 * plasma_w + 50.0), 0.391},
+        {(plasma_w * plasma_w + 43.0 * plasma_w + 38.0) / (7.0 / 3.0 * plasma_w * plasma_w + 92.5 * plasma_w + 38.0), 0.348},
+        {(plasma_w + 13.0 / 14.0) / (2.0 * plasma_w + 13.0 / 14.0), 0.313}};
+    const int lo = plasma_kappa < 4.0 ? 0 : (plasma_kappa < 4.5 ? 1 : 2);
+    const double k_lo = 3.5 + 0.5 * lo, k_hi = 4.0 + 0.5 * lo;
+    kk.rho_frac = (plasma_kappa - k_lo) / (k_hi - k_lo);
+    for (int c = 0; c < 5; c++) {
+      kk.rho_q_low[c] = fit_q[lo][c];
+      kk.rho_q_high[c] = fit_q[lo + 1][c];
+    }
+    for (int c = 0; c < 2; c++) {
+      kk.rho_v_low[c] = fit_v[lo][c];
+      kk.rho_v_high[c] = fit_v[lo + 1][c];
+    }
+  }
+}
+
+// ---- the locate / coefficient kernels'
+void BuildShadeArgs(RenderJob &job) {
+  bl_ctx *ctx = job.ctx;
+  const bl_params &p = ctx->params;
+  hipStream_t stream = ctx->stream;
+  BlShadeArgs &sa = job.sa;
+  sa.st = ctx->st;
+  BlShadeCold cold{};
+  cold.omit_near = p.cut_omit_near;
+  cold.omit_far = p.cut_omit_far;
+  cold.plane = p.cut_plane;
+  cold.omit_in = p.cut_omit_in;
+  cold.omit_out = p.cut_omit_out;
+  cold.midplane_theta = p.cut_midplane_theta;
+  cold.midplane_z = p.cut_midplane_z;
+  cold.plane_origin[0] = p.cut_plane_origin_x;
+  cold.plane_origin[1] = p.cut_plane_origin_y;
+  cold.plane_origin[2] = p.cut_plane_origin_z;
+  cold.plane_normal[0] = p.cut_plane_normal_x;
+  cold.plane_normal[1] = p.cut_plane_normal_y;
+  cold.plane_normal[2] = p.cut_plane_normal_z;
+  for (int mu = 0; mu < 4; mu++) cold.cam_x[mu] = ctx->frame.cam_x[mu];
+  sa.cuts.camera_r = p.camera_r;
+  sa.cuts.any_optional = (p.cut_omit_near || p.cut_omit_far || p.cut_omit_in >= 0.0 || p.cut_omit_out >= 0.0
+                          || p.cut_midplane_theta != 0.0 || p.cut_midplane_z != 0.0 || p.cut_plane) ? 1 : 0;
+  if (job.simulation) {
+    BlPlasmaDevice &pl = sa.plasma;
+    pl.d_unit = p.simulation_rho_cgs;                       // simulation_coefficients.cpp:237-239
+    pl.e_unit = pl.d_unit * kC * kC;
+    pl.b_unit = blm_sqrt(4.0 * kPi * pl.e_unit);
+    pl.plasma_mu = p.plasma_mu;
+    pl.plasma_ne_ni = p.plasma_ne_ni;
+    pl.plasma_rat_low = p.plasma_rat_low;
+    pl.plasma_rat_high = p.plasma_rat_high;
+    pl.plasma_thermal_frac = ctx->plasma_thermal_frac;
+    FillElectronConstants(job, pl, cold);
+    cold.plasma_gamma = ctx->grid_meta.plasma_gamma;
+    cold.plasma_gamma_i = ctx->grid_meta.plasma_gamma_i;
+    cold.plasma_gamma_e = ctx->grid_meta.plasma_gamma_e;
+    pl.plasma_use_p = p.plasma_use_p;
+    pl.simulation_interp = p.simulation_interp;
+    // fmks: the reader has put vectors on the spherical Kerr-Schild basis; everything but the cell search treats the
+    // grid as sks (radiation_geometry.cpp:39, :94, :460, :541)
+    pl.simulation_coord = p.simulation_coord == BL_COORD_FMKS ? BL_COORD_SKS : p.simulation_coord;
+    pl.fallback_nan = p.fallback_nan;
+    cold.fallback_rho = p.fallback_nan ? 0.0f : p.fallback_rho;
+    cold.fallback_pgas = p.fallback_nan ? 0.0f : p.fallback_pgas;
+    cold.fallback_kappa = p.fallback_nan ? 0.0f : p.fallback_kappa;
+    pl.code_kappa = p.plasma_model == BL_PLASMA_CODE_KAPPA ? 1 : 0;
+    // cell cuts (simulation_coefficients.cpp:361-375): "cut >= 0 and value < cut". A disabled threshold goes to the
+    // device as -inf (lower) / +inf (upper), against which no value - NaN included - compares true: same
+    // decisions, one compare per threshold
+    const double kInf = std::numeric_limits<double>::infinity();
+    auto lower = [&](double cut) { return cut >= 0.0 ? cut : -kInf; };
+    auto upper = [&](double cut) { return cut >= 0.0 ? cut : kInf; };
+    cold.cut_rho_min = lower(p.cut_rho_min); cold.cut_rho_max = upper(p.cut_rho_max);
+    cold.cut_n_e_min = lower(p.cut_n_e_min); cold.cut_n_e_max = upper(p.cut_n_e_max);
+    cold.cut_p_gas_min = lower(p.cut_p_gas_min); cold.cut_p_gas_max = upper(p.cut_p_gas_max);
+    cold.cut_theta_e_min = lower(p.cut_theta_e_min); cold.cut_theta_e_max = upper(p.cut_theta_e_max);
+    cold.cut_b_min = lower(p.cut_b_min); cold.cut_b_max = upper(p.cut_b_max);
+    cold.cut_sigma_min = lower(p.cut_sigma_min); cold.cut_sigma_max = upper(p.cut_sigma_max);
+    cold.cut_beta_inverse_min = lower(p.cut_beta_inverse_min); cold.cut_beta_inverse_max = upper(p.cut_beta_inverse_max);
+    {
+      const double cuts[14] = {p.cut_rho_min, p.cut_rho_max, p.cut_n_e_min, p.cut_n_e_max, p.cut_p_gas_min, p.cut_p_gas_max,
+                               p.cut_theta_e_min, p.cut_theta_e_max, p.cut_b_min, p.cut_b_max, p.cut_sigma_min, p.cut_sigma_max,
+                               p.cut_beta_inverse_min, p.cut_beta_inverse_max};
+      pl.cut_mask = 0;
+      pl.any_cell_cut = 0;
+      for (int c = 0; c < 14; c++) {
+        const bool active = cuts[c] >= 0.0;
+        if (active) pl.cut_mask |= 1 << c;
+        if (active) pl.any_cell_cut = 1;
+        cold.fast_cut[c] = active ? cuts[c] : 0.0;
+        cold.fast_cut_lo[c] = active ? cuts[c] * (1.0 - ctx->guard_band) : 0.0;
+        cold.fast_cut_hi[c] = active ? cuts[c] * (1.0 + ctx->guard_band) : 0.0;
+      }
+      sa.fast_n_e_factor = 1.0 / (p.plasma_mu * kMp * (1.0 + 1.0 / p.plasma_ne_ni));
+      sa.fast_gamma[0] = 1.0 / (ctx->grid_meta.plasma_gamma - 1.0);
+      sa.fast_gamma[1] = 1.0 / (ctx->grid_meta.plasma_gamma_i - 1.0);
+      sa.fast_gamma[2] = 1.0 / (ctx->grid_meta.plasma_gamma_e - 1.0);
+    }
+    sa.grid = ctx->grid_dev;
+    sa.lds_table_bytes = ctx->lds_table_bytes;
+    sa.undefined_edge = ctx->undefined_policy == BL_UNDEFINED_EDGE ? 1 : 0;
+    sa.tolerant = (job.fast || job.tolerant_polarized) ? 1 : 0;
+  } else {
+    BlFormulaDevice &fm = sa.formula;
+    fm.r0 = p.formula_r0; fm.h = p.formula_h; fm.l0 = p.formula_l0; fm.q = p.formula_q; fm.nup = p.formula_nup;
+    fm.cn0 = p.formula_cn0; fm.alpha = p.formula_alpha; fm.a = p.formula_a; fm.beta = p.formula_beta;
+  }
+  sa.samples_renormalised = job.geo_load ? 1 : 0;
+  ctx->d_shade_cold.Ensure(1);
+  Check(hipMemcpyAsync(ctx->d_shade_cold.ptr, &cold, sizeof(BlShadeCold), hipMemcpyHostToDevice, stream), "shade parameter upload");
+  Check(hipStreamSynchronize(stream), "shade parameter upload");   // cold is a local
+  sa.cold = ctx->d_shade_cold.ptr;
+  sa.frequencies = ctx->d_freq.ptr;
+  sa.n_nu = job.n_nu;
+  sa.ray_max_steps = job.max_steps;
+  sa.x_unit = kGGMsun * ctx->frame.mass_msun / (kC * kC);   // unpolarized.cpp:42
+  sa.aux_need_coefficients = (p.image_light || p.image_emission || p.image_tau || ctx->aux_images.image_emission_ave
+                              || ctx->aux_images.image_tau_int) ? 1 : 0;   // simulation_coefficients.cpp:389
+  sa.aux_need_length = (ctx->aux_images.image_length || job.fill_present) ? 1 : 0;
+  sa.aux_record_unused = job.rows_only ? 1 : 0;
+  for (int mu = 0; mu < 4; mu++) sa.cam_x[mu] = ctx->frame.cam_x[mu];
+  sa.tag_in_record = job.fast ? 1 : 0;
+  sa.freq_split = job.freq_split ? 1 : 0;
+  sa.coef_split = job.coef_split ? 1 : 0;
+  sa.redo_capacity = (job.fast || ctx->polarized) ? job.redo_capacity : 0;
+
+  job.snapshot_time = job.slow ? p.slow_t_start + p.slow_dt * ctx->snapshot : 0.0;   // simulation_reader.cpp:214
+  if (job.slow) {
+    const int chunk_size = p.slow_chunk_size;
+    std::vector<unsigned long long> table(3 * static_cast<size_t>(chunk_size) + 4, 0ull);
+    for (int n = 0; n < chunk_size; n++) {
+      const bl_ctx::SlowSlice &slice = ctx->slow_slices[n];
+      table[n] = reinterpret_cast<unsigned long long>(slice.cells.ptr);
+      table[chunk_size + n] = reinterpret_cast<unsigned long long>(slice.kappa.ptr);
+      std::memcpy(&table[2 * static_cast<size_t>(chunk_size) + n], &slice.time, sizeof(double));
+    }
+    ctx->d_slow_table.Ensure(table.size());
+    Check(hipMemcpy(ctx->d_slow_table.ptr, table.data(), table.size() * sizeof(unsigned long long), hipMemcpyHostToDevice), "slow-light table upload");
+    ctx->d_ray_extrap.Ensure(job.n_rays);
+    Check(hipMemsetAsync(ctx->d_ray_extrap.ptr, 0, job.n_rays * sizeof(unsigned int), stream), "slow-light flags reset");
+    sa.slow.n = chunk_size;
+    sa.slow.interp = p.slow_interp ? 1 : 0;
+    sa.slow.snapshot_time = job.snapshot_time;
+    sa.slow.cells = reinterpret_cast<const float *const *>(ctx->d_slow_table.ptr);
+    sa.slow.kappa = reinterpret_cast<const float *const *>(ctx->d_slow_table.ptr + chunk_size);
+    sa.slow.times = reinterpret_cast<const double *>(ctx->d_slow_table.ptr + 2 * static_cast<size_t>(chunk_size));
+    sa.slow.extrap_max = ctx->d_slow_table.ptr + 3 * static_cast<size_t>(chunk_size);
+  }
+  if (ctx->polarized) {
+    for (int c = 0; c < 7; c++) sa.power_pol[c] = ctx->power_pol[c];
+    sa.plasma_gamma_min = p.plasma_power_frac != 0.0 ? p.plasma_gamma_min : 0.0;
+  }
+  // Locate kernel: 256-thread workgroups. Alone it runs 4 waves per SIMD; beside the next chunk's geodesic kernel
+  // (bl_set_overlap) one workgroup per CU, so that whichever of the two kernels is dispatched first cannot fill the
+  // register file and lock the other out.
+  job.locate_grid_alone = ctx->num_cus * 4 * 4;
+  job.locate_grid_shared = ctx->num_cus;
+  job.shade_grid = ctx->num_cus * 2 * 4;  // 256-thread workgroups, 2 waves per SIMD, x4 for tail balance
+}
+
+// ---- the transfer kernels'
+void BuildTransferArgs(RenderJob &job) {
+  bl_ctx *ctx = job.ctx;
+  const bl_params &p = ctx->params;
+  BlTransferArgs &xa = job.xa;
+  xa.frequencies = ctx->d_freq.ptr;
+  xa.n_nu = job.n_nu;
+  xa.ray_max_steps = job.max_steps;
+  xa.fallback_nan = p.fallback_nan;
+  xa.model_type = p.model_type;
+  xa.affine = job.fast ? 1 : 0;
+  xa.n_rays_total = job.n_rays;
+  xa.image = job.image;
+  xa.out_sample_num = job.out_num;
+  xa.out_flags = job.out_flags;
+  xa.aux_images = ctx->aux_images;
+  xa.aux_images.polarized_rows_only = job.rows_only ? 1 : 0;
+  xa.x_unit = kGGMsun * ctx->frame.mass_msun / (kC * kC);
+  xa.t_unit = xa.x_unit / kC;   // unpolarized.cpp:43
+  xa.render_params = ctx->render_num_images > 0 ? ctx->d_render_params.ptr : nullptr;
+  xa.render = job.render_out;
+  if (ctx->polarized) {
+    xa.camera_pos = job.cam_pos;
+    xa.camera_dir = job.cam_dir;
+    xa.st = ctx->st;
+    xa.simulation_coord = p.simulation_coord == BL_COORD_FMKS ? BL_COORD_SKS : p.simulation_coord;
+    xa.rotation_split = p.image_rotation_split ? 1 : 0;
+    for (int mu = 0; mu < 4; mu++) {
+      xa.cam_u_con[mu] = ctx->frame.u_con[mu];
+      xa.cam_u_cov[mu] = ctx->frame.u_cov[mu];
+      xa.cam_vert_con_c[mu] = ctx->frame.vert_con_c[mu];
+    }
+  }
+}
+
+// Point the three argument blocks at scratch set k and at the rays [begin, begin + rays)
+void BindChunk(RenderJob &job, int k, long long begin, int rays) {
+  bl_ctx *ctx = job.ctx;
+  bl_ctx::ChunkSlot &sl = ctx->slot[k];
+  BlTraceArgs &ta = job.ta;
+  BlShadeArgs &sa = job.sa;
+  BlTransferArgs &xa = job.xa;
+  ta.chunk_begin = begin;
+  ta.chunk_rays = rays;
+  ta.records_hot = sl.d_records_hot.ptr;
+  ta.records_cold = sl.d_records_cold.ptr;
+  ta.sample_t = job.need_time ? sl.d_sample_t.ptr : nullptr;
+  ta.counters = sl.d_counters.ptr;
+  ta.ray_kt = ctx->d_ray_kt.ptr + begin;
+  ta.ray_factor = ctx->d_ray_factor.ptr + begin;
+  ta.ray_sample_num = ctx->d_ray_sample_num.ptr + begin;
+  ta.ray_flags = ctx->d_ray_flags.ptr + begin;
+  ta.ray_out_index = ctx->d_ray_out_index.ptr + begin;
+  ta.ray_offset = ctx->d_ray_offset.ptr + begin;
+  ta.ray_start = job.geo_load ? nullptr : ctx->d_ray_start.ptr + begin;
+  sa.records_hot = sl.d_records_hot.ptr;
+  sa.records_cold = sl.d_records_cold.ptr;
+  sa.located = job.simulation ? sl.d_located.ptr : nullptr;
+  sa.located_tag = job.simulation ? sl.d_located_tag.ptr : nullptr;
+  sa.freq_inputs = job.freq_split ? sl.d_freq_inputs.ptr : nullptr;
+  sa.counters_in = sl.d_counters.ptr;
+  sa.counters = sl.d_counters.ptr;
+  sa.ray_kt = ta.ray_kt;
+  sa.ray_factor = ta.ray_factor;
+  sa.ray_offset = ta.ray_offset;
+  sa.ray_flags = ta.ray_flags;
+  sa.transfer = sl.d_transfer.ptr;
+  sa.aux = job.aux ? sl.d_aux.ptr : nullptr;
+  sa.sample_t = ta.sample_t;
+  sa.coef_inputs = (job.coef_split || ctx->polarized) ? sl.d_coef_inputs.ptr : nullptr;
+  sa.anchors = job.block_interp ? sl.d_anchors.ptr : nullptr;
+  sa.redo_list = (job.fast || ctx->polarized) ? sl.d_redo.ptr : nullptr;
+  if (job.slow) {
+    sa.slow.frac = sl.d_slow_frac.ptr;
+    sa.slow.ray_extrap = ctx->d_ray_extrap.ptr + begin;
+  }
+  xa.chunk_rays = rays;
+  xa.counters = sl.d_counters.ptr;
+  xa.transfer = sl.d_transfer.ptr;
+  xa.freq_inputs = sa.freq_inputs;
+  xa.ray_sample_num = ta.ray_sample_num;
+  xa.ray_flags = ta.ray_flags;
+  xa.ray_out_index = ta.ray_out_index;
+  xa.ray_offset = ta.ray_offset;
+  xa.ray_factor = ta.ray_factor;
+  xa.stats = sl.d_counters.ptr + BL_CNT_COUNT;
+  xa.aux = sa.aux;
+  if (ctx->polarized) {
+    sa.pol_samples = sl.d_pol_samples.ptr;
+    sa.pol_coeffs = sl.d_pol_coeffs.ptr;
+    xa.pol_samples = sl.d_pol_samples.ptr;
+    xa.pol_coeffs = sl.d_pol_coeffs.ptr;
+    xa.pol_matrix = job.matrix_transport ? sl.d_pol_matrix.ptr : nullptr;
+  }
+}
+
+// LoadGeodesics(): the chunk's sample records come from the file instead of the geodesic kernel. The file holds them
+// far -> near (ReverseGeodesics) with the renormalised momentum; records are near -> far, so sample n of a ray is entry
+// num - 1 - n, and len = -sample_len. Takes as many of the rays [begin, begin + rays) as the record buffers hold and
+// returns how many.
+long long LoadChunkFromCheckpoint(RenderJob &job, int k, long long begin, int rays) {
+  bl_ctx *ctx = job.ctx;
+  const bl_render_desc *d = job.d;
+  bl_ctx::ChunkSlot &sl = ctx->slot[k];
+  const bl_ctx::Checkpoint &ck = ctx->checkpoint;
+  const size_t steps = static_cast<size_t>(ck.num_steps);
+  size_t total = 0;
+  int taken = 0;
+  for (; taken < rays; taken++) {
+    const long long ray = begin + taken;
+    const size_t m = d->pixel_map != nullptr ? static_cast<size_t>(d->pixel_map[ray]) : static_cast<size_t>(ray);
+    const size_t num = static_cast<size_t>(ck.sample_num[m]);
+    if (total + num > static_cast<size_t>(job.record_gate)) break;
+    total += num;
+  }
+  if (taken == 0) throw Failure{BL_E_ARG, "Scratch budget too small for the samples of one checkpointed ray (bl_set_scratch_limit)."};
+  std::vector<BlSampleHot> hot;
+  std::vector<BlSampleCold> cold;
+  std::vector<double> sample_t, ray_kt(taken), ray_factor(taken);
+  std::vector<int> ray_num(taken);
+  std::vector<unsigned char> ray_flags(taken);
+  std::vector<long long> ray_out(taken), ray_offset(taken);
+  hot.reserve(total);
+  cold.reserve(total);
+  sample_t.reserve(total);
+  for (int q = 0; q < taken; q++) {
+    const long long ray = begin + q;
+    const size_t m = d->pixel_map != nullptr ? static_cast<size_t>(d->pixel_map[ray]) : static_cast<size_t>(ray);
+    const int num = ck.sample_num[m];
+    ray_kt[q] = ck.camera_dir[4 * m];
+    ray_factor[q] = ck.factors[m];
+    ray_num[q] = num;
+    ray_flags[q] = ck.flags[m];
+    ray_out[q] = ray;
+    ray_offset[q] = static_cast<long long>(hot.size());
+    for (int n = 0; n < num; n++) {
+      const size_t at = m * steps + static_cast<size_t>(num - 1 - n);
+      BlSampleHot h;
+      h.x = ck.pos[4 * at + 1]; h.y = ck.pos[4 * at + 2]; h.z = ck.pos[4 * at + 3];
+      h.ray = static_cast<uint32_t>(q);
+      h.n = static_cast<uint32_t>(n);
+      BlSampleCold c;
+      c.kx = ck.dir[4 * at + 1]; c.ky = ck.dir[4 * at + 2]; c.kz = ck.dir[4 * at + 3];
+      c.len = -ck.len[at];
+      hot.push_back(h);
+      cold.push_back(c);
+      sample_t.push_back(ck.pos[4 * at]);
+    }
+  }
+  const unsigned long long n_loaded = hot.size(), n_taken = static_cast<unsigned long long>(taken);
+  if (n_loaded > 0) {
+    Check(hipMemcpy(sl.d_records_hot.ptr, hot.data(), n_loaded * sizeof(BlSampleHot), hipMemcpyHostToDevice), "checkpoint upload");
+    Check(hipMemcpy(sl.d_records_cold.ptr, cold.data(), n_loaded * sizeof(BlSampleCold), hipMemcpyHostToDevice), "checkpoint upload");
+    Check(hipMemcpy(sl.d_sample_t.ptr, sample_t.data(), n_loaded * sizeof(double), hipMemcpyHostToDevice), "checkpoint upload");
+  }
+  Check(hipMemcpy(ctx->d_ray_kt.ptr + begin, ray_kt.data(), taken * sizeof(double), hipMemcpyHostToDevice), "checkpoint upload");
+  Check(hipMemcpy(ctx->d_ray_factor.ptr + begin, ray_factor.data(), taken * sizeof(double), hipMemcpyHostToDevice), "checkpoint upload");
+  Check(hipMemcpy(ctx->d_ray_sample_num.ptr + begin, ray_num.data(), taken * sizeof(int), hipMemcpyHostToDevice), "checkpoint upload");
+  Check(hipMemcpy(ctx->d_ray_flags.ptr + begin, ray_flags.data(), taken, hipMemcpyHostToDevice), "checkpoint upload");
+  Check(hipMemcpy(ctx->d_ray_out_index.ptr + begin, ray_out.data(), taken * sizeof(long long), hipMemcpyHostToDevice), "checkpoint upload");
+  Check(hipMemcpy(ctx->d_ray_offset.ptr + begin, ray_offset.data(), taken * sizeof(long long), hipMemcpyHostToDevice), "checkpoint upload");
+  Check(hipMemcpy(sl.d_counters.ptr + BL_CNT_RECORDS, &n_loaded, sizeof n_loaded, hipMemcpyHostToDevice), "checkpoint upload");
+  Check(hipMemcpy(sl.d_counters.ptr + BL_CNT_NEXT_RAY, &n_taken, sizeof n_taken, hipMemcpyHostToDevice), "checkpoint upload");
+  return taken;
+}
+
+// SaveGeodesics(), first half: bring a chunk's records back while its scratch set still holds them
+void SaveChunkRecords(RenderJob &job, int k, long long begin, int rays) {
+  bl_ctx *ctx = job.ctx;
+  bl_ctx::ChunkSlot &sl = ctx->slot[k];
+  CheckpointSave &save = job.save;
+  unsigned long long n_written = 0;
+  Check(hipMemcpy(&n_written, sl.d_counters.ptr + BL_CNT_RECORDS, sizeof n_written, hipMemcpyDeviceToHost), "checkpoint download");
+  std::vector<BlSampleHot> hot(n_written);
+  std::vector<BlSampleCold> cold(n_written);
+  std::vector<double> sample_t(n_written), ray_kt(rays), ray_factor(rays);
+  std::vector<int> ray_num(rays);
+  std::vector<unsigned char> ray_flags(rays);
+  std::vector<long long> ray_out(rays);
+  if (n_written > 0) {
+    Check(hipMemcpy(hot.data(), sl.d_records_hot.ptr, n_written * sizeof(BlSampleHot), hipMemcpyDeviceToHost), "checkpoint download");
+    Check(hipMemcpy(cold.data(), sl.d_records_cold.ptr, n_written * sizeof(BlSampleCold), hipMemcpyDeviceToHost), "checkpoint download");
+    Check(hipMemcpy(sample_t.data(), sl.d_sample_t.ptr, n_written * sizeof(double), hipMemcpyDeviceToHost), "checkpoint download");
+  }
+  Check(hipMemcpy(ray_kt.data(), ctx->d_ray_kt.ptr + begin, rays * sizeof(double), hipMemcpyDeviceToHost), "checkpoint download");
+  Check(hipMemcpy(ray_factor.data(), ctx->d_ray_factor.ptr + begin, rays * sizeof(double), hipMemcpyDeviceToHost), "checkpoint download");
+  Check(hipMemcpy(ray_num.data(), ctx->d_ray_sample_num.ptr + begin, rays * sizeof(int), hipMemcpyDeviceToHost), "checkpoint download");
+  Check(hipMemcpy(ray_flags.data(), ctx->d_ray_flags.ptr + begin, rays, hipMemcpyDeviceToHost), "checkpoint download");
+  Check(hipMemcpy(ray_out.data(), ctx->d_ray_out_index.ptr + begin, rays * sizeof(long long), hipMemcpyDeviceToHost), "checkpoint download");
+  if (save.sample_num.empty()) {
+    save.sample_num.assign(job.n_rays, 0);
+    save.flags.assign(job.n_rays, 0);
+    save.factors.assign(job.n_rays, 0.0);
+    save.offset.assign(job.n_rays, 0);
+  }
+  std::vector<size_t> slot_offset(rays);
+  for (int q = 0; q < rays; q++) {
+    const size_t m = static_cast<size_t>(ray_out[q]);
+    save.sample_num[m] = ray_num[q];
+    save.flags[m] = ray_flags[q];
+    save.factors[m] = ray_factor[q];
+    save.offset[m] = save.len.size();
+    slot_offset[q] = save.len.size();
+    save.pos.resize(save.pos.size() + 4 * static_cast<size_t>(ray_num[q]));
+    save.dir.resize(save.dir.size() + 4 * static_cast<size_t>(ray_num[q]));
+    save.len.resize(save.len.size() + static_cast<size_t>(ray_num[q]));
+  }
+  for (unsigned long long r = 0; r < n_written; r++) {
+    const BlSampleHot &h = hot[r];
+    if (h.ray == BL_DEAD_RAY) continue;
+    const int num = ray_num[h.ray];
+    if (static_cast<int>(h.n) >= num) continue;
+    const BlSampleCold &c = cold[r];
+    // ReverseGeodesics (geodesics.cpp:820-842) behind the per-sample renormalisation (:352-371)
+    const size_t at = slot_offset[h.ray] + static_cast<size_t>(num - 1 - static_cast<int>(h.n));
+    const double kt = ray_kt[h.ray];
+    const double factor = bl_renormalization_factor(ctx->st, h.x, h.y, h.z, kt, c.kx, c.ky, c.kz);
+    save.pos[4 * at] = sample_t[r]; save.pos[4 * at + 1] = h.x; save.pos[4 * at + 2] = h.y; save.pos[4 * at + 3] = h.z;
+    save.dir[4 * at] = kt; save.dir[4 * at + 1] = c.kx * factor; save.dir[4 * at + 2] = c.ky * factor; save.dir[4 * at + 3] = c.kz * factor;
+    save.len[at] = -c.len;
+  }
+}
+
+// SaveGeodesics(), second half (geodesic_checkpoint.cpp:28-59)
+void WriteGeodesicCheckpoint(RenderJob &job) {
+  bl_ctx *ctx = job.ctx;
+  const bl_params &p = ctx->params;
+  const CheckpointSave &save = job.save;
+  const long long n_rays = job.n_rays;
+  std::vector<double> camera_pos(static_cast<size_t>(n_rays) * 4), camera_dir(static_cast<size_t>(n_rays) * 4);
+  Check(hipMemcpy(camera_pos.data(), job.cam_pos, camera_pos.size() * sizeof(double), hipMemcpyDeviceToHost), "checkpoint download");
+  Check(hipMemcpy(camera_dir.data(), job.cam_dir, camera_dir.size() * sizeof(double), hipMemcpyDeviceToHost), "checkpoint download");
+  std::ofstream out(p.checkpoint_geodesic_file.s, std::ios_base::out | std::ios_base::binary);
+  if (!out.is_open()) throw Failure{BL_E_INPUT, "Could not open geodesic checkpoint file."};
+  const bl_camera_frame &f = ctx->frame;
+  const double *vectors[7] = {f.cam_x, f.u_con, f.u_cov, f.norm_con, f.norm_con_c, f.hor_con_c, f.vert_con_c};
+  for (const double *v : vectors) out.write(reinterpret_cast<const char *>(v), 4 * sizeof(double));
+  const int n_pix = static_cast<int>(n_rays);
+  const int n_nu = job.n_nu;
+  int num_steps = 0;
+  for (int32_t num : save.sample_num) num_steps = std::max(num_steps, static_cast<int>(num));
+  WriteCheckpointHeader<double>(out, 4, n_pix, 1);
+  out.write(reinterpret_cast<const char *>(camera_pos.data()), static_cast<std::streamsize>(camera_pos.size() * sizeof(double)));
+  WriteCheckpointHeader<double>(out, 4, n_pix, 1);
+  out.write(reinterpret_cast<const char *>(camera_dir.data()), static_cast<std::streamsize>(camera_dir.size() * sizeof(double)));
+  WriteCheckpointHeader<double>(out, n_nu, 1, 1);
+  out.write(reinterpret_cast<const char *>(ctx->frequencies.data()), static_cast<std::streamsize>(n_nu * sizeof(double)));
+  WriteCheckpointHeader<double>(out, n_pix, 1, 1);
+  out.write(reinterpret_cast<const char *>(save.factors.data()), static_cast<std::streamsize>(save.factors.size() * sizeof(double)));
+  out.write(reinterpret_cast<const char *>(&num_steps), sizeof(int));
+  WriteCheckpointHeader<uint8_t>(out, n_pix, 1, 1);
+  out.write(reinterpret_cast<const char *>(save.flags.data()), static_cast<std::streamsize>(save.flags.size()));
+  WriteCheckpointHeader<int32_t>(out, n_pix, 1, 1);
+  out.write(reinterpret_cast<const char *>(save.sample_num.data()), static_cast<std::streamsize>(save.sample_num.size() * sizeof(int32_t)));
+  // sample_pos, sample_dir (n_pix, n_steps, 4) and sample_len (n_pix, n_steps): a pixel's samples, then zeros (the
+  // reference leaves the tail of sample_pos / sample_dir as allocated; nothing reads it)
+  std::vector<double> row(static_cast<size_t>(num_steps) * 4);
+  for (int which = 0; which < 2; which++) {
+    const std::vector<double> &source = which == 0 ? save.pos : save.dir;
+    WriteCheckpointHeader<double>(out, 4, num_steps, n_pix);
+    for (int m = 0; m < n_pix; m++) {
+      std::fill(row.begin(), row.end(), 0.0);
+      std::copy(source.begin() + 4 * save.offset[m], source.begin() + 4 * (save.offset[m] + save.sample_num[m]), row.begin());
+      out.write(reinterpret_cast<const char *>(row.data()), static_cast<std::streamsize>(row.size() * sizeof(double)));
+    }
+  }
+  WriteCheckpointHeader<double>(out, num_steps, n_pix, 1);
+  row.resize(num_steps);
+  for (int m = 0; m < n_pix; m++) {
+    std::fill(row.begin(), row.end(), 0.0);
+    std::copy(save.len.begin() + save.offset[m], save.len.begin() + save.offset[m] + save.sample_num[m], row.begin());
+    out.write(reinterpret_cast<const char *>(row.data()), static_cast<std::streamsize>(row.size() * sizeof(double)));
+  }
+  if (!out) throw Failure{BL_E_INPUT, "Could not write geodesic checkpoint file."};
+}
+
+// ---- a chunk, first half: the geodesic stage on stream_geo into scratch set k (the set must be free)
+void LaunchGeodesicStage(RenderJob &job, int k, long long begin, int rays, hipStream_t stream_geo) {
+  bl_ctx *ctx = job.ctx;
+  bl_ctx::ChunkSlot &sl = ctx->slot[k];
+  hipEvent_t *e = SlotEvents(job, k);
+  BindChunk(job, k, begin, rays);
+  Check(hipMemsetAsync(sl.d_counters.ptr, 0, BL_CNT_TOTAL * sizeof(unsigned long long), stream_geo), "counter reset");
+  Check(hipEventRecord(e[0], stream_geo), "event");
+  job.in_flight[k].busy = true;
+  job.in_flight[k].begin = begin;
+  job.in_flight[k].rays = rays;
+  job.in_flight[k].done = -1;
+  if (job.geo_load) {
+    Check(hipStreamSynchronize(stream_geo), "kernel execution");   // the counters are reset before the host writes two of them
+    job.in_flight[k].done = LoadChunkFromCheckpoint(job, k, begin, rays);
+  } else {
+    Check(bl_launch_geodesic(&job.ta, ctx->params.ray_integrator, std::min(job.geo_grid, (rays + 63) / 64), stream_geo), "geodesic kernel launch");
+  }
+  Check(hipEventRecord(e[1], stream_geo), "event");
+}
+
+// ---- second half: locate, coefficients, transfer on the shading stream, counters to the host
+void LaunchShadingStage(RenderJob &job, int k, bool geodesic_beside, hipStream_t stream) {
+  bl_ctx *ctx = job.ctx;
+  const bl_params &p = ctx->params;
+  bl_ctx::ChunkSlot &sl = ctx->slot[k];
+  hipEvent_t *e = SlotEvents(job, k);
+  BindChunk(job, k, job.in_flight[k].begin, job.in_flight[k].rays);
+  BlShadeArgs &sa = job.sa;
+  BlTransferArgs &xa = job.xa;
+  Check(hipStreamWaitEvent(stream, e[1], 0), "stream wait");
+  Check(hipEventRecord(e[2], stream), "event");
+  if (job.simulation)
+    Check(bl_launch_locate(&sa, geodesic_beside ? job.locate_grid_shared : job.locate_grid_alone, ctx->lds_table_bytes, stream), "locate kernel launch");
+  Check(hipEventRecord(e[3], stream), "event");
+  if (job.fast) Check(bl_launch_shade_fast(&sa, job.shade_grid, stream), "coefficient kernel launch");
+  else Check(bl_launch_shade(&sa, p.model_type, job.shade_grid, stream), "coefficient kernel launch");
+  if (ctx->polarized) Check(bl_launch_polarized_coefficients(&sa, ctx->num_cus * 8, stream), "polarized coefficient kernel launch");
+  if (job.coef_split) Check(bl_launch_coefficients_freq(&sa, ctx->num_cus * 16, stream), "per-frequency coefficient kernel launch");
+  Check(hipEventRecord(e[4], stream), "event");
+  Check(job.aux ? bl_launch_transfer_aux(&xa, stream) : (job.freq_split ? bl_launch_transfer_freq(&xa, stream) : bl_launch_transfer(&xa, stream)),
+        "transfer kernel launch");
+  if (ctx->polarized)
+    Check(job.matrix_transport ? bl_launch_transfer_polarized_matrix(&xa, ctx->num_cus, stream) : bl_launch_transfer_polarized(&xa, stream),
+          "polarized transfer kernel launch");
+  Check(hipEventRecord(e[5], stream), "event");
+  Check(hipMemcpyAsync(ctx->host_counters + static_cast<size_t>(k) * BL_CNT_TOTAL, sl.d_counters.ptr, BL_CNT_TOTAL * sizeof(unsigned long long),
+                       hipMemcpyDeviceToHost, stream), "counter download");
+  Check(hipEventRecord(e[6], stream), "event");
+}
+
+// Rays of the chunk on scratch set k that the geodesic stage covered (waits for that stage)
+long long WaitGeodesicStage(RenderJob &job, int k, hipStream_t stream_geo) {
+  RenderJob::InFlight &fl = job.in_flight[k];
+  if (fl.done >= 0) return fl.done;
+  Check(hipStreamSynchronize(stream_geo), "kernel execution");
+  unsigned long long taken = 0;
+  Check(hipMemcpy(&taken, job.ctx->slot[k].d_counters.ptr + BL_CNT_NEXT_RAY, sizeof taken, hipMemcpyDeviceToHost), "counter download");
+  fl.done = static_cast<long long>(std::min<unsigned long long>(taken, static_cast<unsigned long long>(fl.rays)));
+  return fl.done;
+}
+
+// ---- wait for the chunk on scratch set k, add its counters and times to the totals, free the set
+void CollectChunk(RenderJob &job, int k) {
+  bl_ctx *ctx = job.ctx;
+  const bl_params &p = ctx->params;
+  RenderJob::InFlight &fl = job.in_flight[k];
+  if (!fl.busy) return;
+  hipEvent_t *e = SlotEvents(job, k);
+  Check(hipEventSynchronize(e[6]), "kernel execution");
+  const unsigned long long *hc = ctx->host_counters + static_cast<size_t>(k) * BL_CNT_TOTAL;
+  float ms = 0.0f;
+  Check(hipEventElapsedTime(&ms, e[0], e[1]), "event time"); job.ms_geo += ms;
+  Check(hipEventElapsedTime(&ms, e[2], e[3]), "event time"); job.ms_locate += ms;
+  Check(hipEventElapsedTime(&ms, e[3], e[4]), "event time"); job.ms_shade += ms;
+  Check(hipEventElapsedTime(&ms, e[4], e[5]), "event time"); job.ms_transfer += ms;
+  fl.busy = false;
+  if (fl.done < 0) fl.done = static_cast<long long>(std::min<unsigned long long>(hc[BL_CNT_NEXT_RAY], static_cast<unsigned long long>(fl.rays)));
+  if (hc[BL_CNT_OVERFLOW] != 0) throw Failure{BL_E_DEVICE, "Sample record buffer overflow."};
+  if (hc[BL_CNT_INTERP_FAILED] != 0) throw Failure{BL_E_INPUT, "Grid interpolation failed."};   // simulation_sampling.cpp:1319
+  if (hc[BL_CNT_UNDEFINED] != 0 && ctx->undefined_policy != BL_UNDEFINED_EDGE) {
+    if (p.simulation_coord == BL_COORD_FMKS)
+      throw Failure{BL_E_UNSUPPORTED, "FMKS sampling reached the last polar zone of the last azimuthal plane (or the last entry of the "
+                                      "coordinate table), where the reference reads past its arrays (simulation_sampling.cpp:405-415, "
+                                      ":809-819): no defined result to reproduce. bl_set_undefined_policy(BL_UNDEFINED_EDGE) uses the edge cell instead."};
+    throw Failure{BL_E_UNSUPPORTED, "Inter-block interpolation reached an upper edge of the last MeshBlock, where the reference reads past the end "
+                                    "of its cell-centre arrays (simulation_sampling.cpp:520-522): no defined result to reproduce. "
+                                    "bl_set_undefined_policy(BL_UNDEFINED_EDGE) mirrors the last cell centre about the block's face instead."};
+  }
+  job.total_undefined += hc[BL_CNT_UNDEFINED];
+  job.total_records += hc[BL_CNT_RECORDS];
+  job.total_gathers += hc[BL_CNT_GATHERS];
+  if (job.fast) job.total_redo += hc[BL_CNT_REDO];   // (polarized runs use the list for something else: bl_polarized_frame_kernel)
+  job.total_samples += hc[BL_CNT_COUNT + 0];
+  job.total_flagged += hc[BL_CNT_COUNT + 1];
+  job.max_num = std::max<unsigned long long>(job.max_num, hc[BL_CNT_COUNT + 2]);
+  for (int c = 0; c < 8; c++) job.debug_counters[c] += hc[BL_CNT_DEBUG + c];
+  job.n_chunks++;
+}
+
+// ---- all chunks of the call
+void RunChunks(RenderJob &job) {
+  bl_ctx *ctx = job.ctx;
+  hipStream_t stream = ctx->stream;
+  hipStream_t stream_geo = job.n_slots == 2 ? ctx->stream_geo : stream;   // one scratch set: one stream, chunks back to back
+  hipEvent_t ev_begin = ctx->events[2 * kEventsPerChunk], ev_end = ctx->events[2 * kEventsPerChunk + 1];
+  Check(hipEventRecord(ev_begin, stream), "event");                // the uploads above were queued on `stream`
+  if (stream_geo != stream) Check(hipStreamWaitEvent(stream_geo, ev_begin, 0), "stream wait");
+  if (!job.geo_load) {
+    // start states of every ray of the call, once (bl_ray_init_kernel; the geodesic kernel of each chunk reads its share)
+    BindChunk(job, 0, 0, static_cast<int>(job.n_rays));
+    Check(bl_launch_ray_init(&job.ta, ctx->params.ray_integrator, stream_geo), "ray start kernel launch");
+  }
+  const long long n_rays = job.n_rays;
+  auto no_progress = []() {
+    return Failure{BL_E_ARG, "Scratch budget too small: no ray fits the sample record buffers (bl_set_scratch_limit)."};
+  };
+  long long begin = 0;
+  for (int c = 0; begin < n_rays; c++) {
+    const int k = c % job.n_slots;
+    const int rays = static_cast<int>(n_rays - begin);
+    CollectChunk(job, k);   // the chunk that used this scratch set before (two chunks back when there are two sets)
+    LaunchGeodesicStage(job, k, begin, rays, stream_geo);
+    long long done;
+    if (job.n_slots == 2) {
+      // Two sets: chunk c + 1's geodesic kernel is to run beside chunk c's shading, so this chunk's extent is fetched as
+      // soon as its geodesic kernel ends, and its shading goes to the other stream without waiting for anything else.
+      done = WaitGeodesicStage(job, k, stream_geo);
+      LaunchShadingStage(job, k, begin + done < n_rays, stream);
+      if (job.geo_save) {
+        Check(hipStreamSynchronize(stream), "kernel execution");
+        SaveChunkRecords(job, k, begin, static_cast<int>(done));
+      }
+    } else {
+      LaunchShadingStage(job, k, false, stream);
+      if (job.geo_save) {
+        Check(hipStreamSynchronize(stream), "kernel execution");
+        SaveChunkRecords(job, k, begin, static_cast<int>(WaitGeodesicStage(job, k, stream_geo)));
+      }
+      CollectChunk(job, k);
+      done = job.in_flight[k].done;
+    }
+    if (done <= 0) throw no_progress();
+    begin += done;
+  }
+  const int oldest = job.n_chunks % job.n_slots;   // chunks are collected in order: the next one to collect sits on this set
+  for (int k = 0; k < job.n_slots; k++) CollectChunk(job, (oldest + k) % job.n_slots);
+  Check(hipEventRecord(ev_end, stream), "event");
+  Check(hipStreamSynchronize(stream_geo), "kernel execution");
+  Check(hipStreamSynchronize(stream), "kernel execution");
+}
+
+void DownloadOutputs(RenderJob &job) {
+  bl_ctx *ctx = job.ctx;
+  const bl_render_desc *d = job.d;
+  const long long n_rays = job.n_rays;
+  if (d->outputs_on_device) return;
+  if (job.n_q > 0) Check(hipMemcpy(d->image, job.image, static_cast<size_t>(job.n_q) * n_rays * sizeof(double), hipMemcpyDeviceToHost), "image download");
+  if (d->sample_num != nullptr) Check(hipMemcpy(d->sample_num, job.out_num, n_rays * sizeof(int), hipMemcpyDeviceToHost), "sample_num download");
+  if (d->sample_flags != nullptr) Check(hipMemcpy(d->sample_flags, job.out_flags, n_rays, hipMemcpyDeviceToHost), "flags download");
+  if (d->camera_pos != nullptr) Check(hipMemcpy(d->camera_pos, job.cam_pos, static_cast<size_t>(n_rays) * 32, hipMemcpyDeviceToHost), "camera_pos download");
+  if (d->camera_dir != nullptr) Check(hipMemcpy(d->camera_dir, job.cam_dir, static_cast<size_t>(n_rays) * 32, hipMemcpyDeviceToHost), "camera_dir download");
+  if (ctx->render_num_images > 0)
+    Check(hipMemcpy(d->render, job.render_out, static_cast<size_t>(ctx->render_num_images) * 3 * n_rays * sizeof(double), hipMemcpyDeviceToHost), "render download");
+}
+
+// bl_stats of the call, and the reference's warning about rays that ended unexpectedly (geodesics.cpp:389-394)
+void FinishStats(RenderJob &job) {
+  bl_ctx *ctx = job.ctx;
+  const bl_params &p = ctx->params;
+  bl_stats st{};
+  st.n_rays = job.n_rays;
+  st.n_chunks = job.n_chunks;
+  st.launches_geodesic = job.n_chunks;
+  st.launches_locate = job.simulation ? job.n_chunks : 0;
+  st.launches_shade = job.n_chunks;
+  st.launches_transfer = job.n_chunks;
+  st.n_samples = static_cast<int64_t>(job.total_samples);
+  st.n_samples_emitted = static_cast<int64_t>(job.total_records);
+  st.n_gathers = static_cast<int64_t>(job.total_gathers);
+  st.n_flagged = static_cast<int64_t>(job.total_flagged);
+  st.max_sample_num = static_cast<int32_t>(job.max_num);
+  const double bytes_per_gather = (job.simulation && !p.simulation_interp) ? 32.0 : 256.0;
+  st.algorithmic_bytes = bytes_per_gather * static_cast<double>(job.total_gathers) + 13.0 * static_cast<double>(job.n_rays);
+  st.ms_geodesic = job.geo_load ? 0.0f : job.ms_geo;   // nothing was integrated
+  st.ms_locate = job.ms_locate;
+  st.ms_shade = job.ms_shade;
+  st.ms_transfer = job.ms_transfer;
+  st.ms_total = job.ms_geo + job.ms_locate + job.ms_shade + job.ms_transfer;
+  float ms_wall = 0.0f;
+  Check(hipEventElapsedTime(&ms_wall, ctx->events[2 * kEventsPerChunk], ctx->events[2 * kEventsPerChunk + 1]), "event time");
+  st.ms_wall = ms_wall;
+  st.arithmetic = (job.fast || job.tolerant_polarized) ? BL_ARITH_TOLERANT : BL_ARITH_EXACT;
+  st.n_deferred = static_cast<int64_t>(job.total_redo);
+  st.n_undefined = static_cast<int64_t>(job.total_undefined);
+  ctx->stats = st;
+  if (std::getenv("BLACKLIGHT_AMD_DEBUG_COUNTERS") != nullptr) {   // kernels built with -DBL_GEO_STATS fill these
+    std::fprintf(stderr, "debug counters:");
+    for (int k = 0; k < 8; k++) std::fprintf(stderr, " %llu", job.debug_counters[k]);
+    std::fprintf(stderr, "\n");
+  }
+  if (job.total_flagged > 0)
+    Warn(ctx, std::to_string(job.total_flagged) + " out of " + std::to_string(job.n_rays) + " geodesics terminate unexpectedly.");
+  if (job.total_undefined > 0)   // BL_UNDEFINED_EDGE (this text has no counterpart in the reference)
+    Warn(ctx, std::to_string(job.total_undefined) + " samples lie where the reference reads past its arrays; the edge cell was used for them.");
+}
+
+// Slow light (simulation_sampling.cpp:553-617): pixels whose samples fall outside the window of files
+void SlowLightMessages(RenderJob &job) {
+  bl_ctx *ctx = job.ctx;
+  const bl_params &p = ctx->params;
+  const long long n_rays = job.n_rays;
+  std::vector<unsigned int> flags(n_rays);
+  unsigned long long maxima[4];
+  Check(hipMemcpy(flags.data(), ctx->d_ray_extrap.ptr, n_rays * sizeof(unsigned int), hipMemcpyDeviceToHost), "slow-light flags download");
+  Check(hipMemcpy(maxima, ctx->d_slow_table.ptr + 3 * static_cast<size_t>(p.slow_chunk_size), sizeof maxima, hipMemcpyDeviceToHost), "slow-light maxima download");
+  long long count[4] = {0, 0, 0, 0};
+  for (unsigned int f : flags)
+    for (int e = 0; e < 4; e++) count[e] += (f >> e) & 1u;
+  auto text = [&](int kind, const char *degree, const char *direction) {
+    double by;
+    std::memcpy(&by, &maxima[kind], sizeof(double));
+    std::ostringstream message;
+    message << "Snapshot " << ctx->snapshot << " at time " << job.snapshot_time << " requires " << degree << " extrapolation "
+            << direction << " in time (" << count[kind] << "/" << n_rays << " pixels, by up to " << by << " gravitational times).";
+    return message.str();
+  };
+  for (int e = 0; e < 4; e++) {
+    ctx->stats_slow_count[e] = count[e];
+    std::memcpy(&ctx->stats_slow_val[e], &maxima[e], sizeof(double));
+  }
+  if (count[1] > 0) throw Failure{BL_E_INPUT, text(1, "significant", "forward")};
+  if (count[3] > 0) throw Failure{BL_E_INPUT, text(3, "significant", "backward")};
+  if (count[0] > 0) Warn(ctx, text(0, "moderate", "forward"));
+  if (count[2] > 0) Warn(ctx, text(2, "moderate", "backward"));
+}
+
+}  // namespace
+
+namespace blhost {
+void EnsureStreams(bl_ctx *ctx) {
+  if (ctx->stream == nullptr) Check(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking), "hipStreamCreate");
+  if (ctx->stream_geo == nullptr) Check(hipStreamCreateWithFlags(&ctx->stream_geo, hipStreamNonBlocking), "hipStreamCreate");
+}
+}  // namespace blhost
+
+extern "C" int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
+  if (ctx == nullptr || d == nullptr) return BL_E_ARG;
+  try {
+    RenderJob job;
+    job.ctx = ctx;
+    job.d = d;
+    PlanJob(job);
+    Check(hipSetDevice(ctx->device), "hipSetDevice");
+    EnsureStreams(ctx);
+    PlanScratch(job);
+    EnsureScratch(job);
+    StageInputsAndOutputs(job);
+    BuildTraceArgs(job);
+    BuildShadeArgs(job);
+    BuildTransferArgs(job);
+    RunChunks(job);
+    if (job.geo_save) WriteGeodesicCheckpoint(job);
+    DownloadOutputs(job);
+    FinishStats(job);
+    if (job.slow) SlowLightMessages(job);
+  } catch (const Failure &failure) {
+    // leave no chunk half collected behind: a later call starts from idle streams
+    (void)hipStreamSynchronize(ctx->stream_geo);
+    (void)hipStreamSynchronize(ctx->stream);
+    return Fail(ctx, failure);
+  }
+  return BL_OK;
+}

@@ -47,6 +47,43 @@ static inline __device__ double blm_scalar_literal(double v) {
 #define BLM_K(c) (c)
 #endif
 
+/* blm_div(a, b), blm_sqrt_n(x): the IEEE quotient / square root for operands in the middle of the exponent range. The device
+ * compiler expands `/` into v_div_scale x2, v_rcp, two Newton steps, a multiplication, a residual step, v_div_fmas, v_div_fixup,
+ * where the scaling instructions only act when an exponent is near an end of the range (|b| or |a / b| beyond 2^+-1000,
+ * 0 < |a| < 2^-900); without them the same sequence is five instructions shorter and bit-identical wherever no scaling would
+ * have happened (tests/test_gpu_math.py). Likewise sqrt without its 2^256 pre-scaling of arguments below 2^-767. Used where the
+ * operands are known to be ordinary: ratios of coordinates, polynomial arguments of the inverse trigonometric functions. Host:
+ * the plain operations. */
+#if defined(__HIP_DEVICE_COMPILE__)
+static inline __device__ double blm_div(double a, double b) {
+  double y = __builtin_amdgcn_rcp(b);
+  double e = __builtin_fma(-b, y, 1.0);
+  y = __builtin_fma(y, e, y);
+  e = __builtin_fma(-b, y, 1.0);
+  y = __builtin_fma(y, e, y);
+  double q = a * y;
+  const double r = __builtin_fma(-b, q, a);
+  q = __builtin_fma(r, y, q);
+  return __builtin_amdgcn_div_fixup(q, b, a);
+}
+static inline __device__ double blm_sqrt_n(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  double g = x * y;
+  double h = y * 0.5;
+  double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  double d = __builtin_fma(-g, g, x);
+  g = __builtin_fma(d, h, g);
+  d = __builtin_fma(-g, g, x);
+  g = __builtin_fma(d, h, g);
+  return __builtin_amdgcn_class(x, 0x260) ? x : g;   /* +-0, +inf */
+}
+#else
+#define blm_div(a, b) ((a) / (b))
+#define blm_sqrt_n(x) __builtin_sqrt(x)
+#endif
+
 #define BLM_INF (__builtin_inf())
 #define BLM_NAN (__builtin_nan(""))
 
@@ -473,7 +510,7 @@ BLM_FN double bl_atan(double x) {
   if (ax >= 0.6875) { num = ax - 1.0; den = ax + 1.0; hi = BLM_K(0x1.921fb54442d18p-1); lo = BLM_K(0x1.1a62633145c07p-55); }
   if (ax >= 1.1875) { num = ax - 1.5; den = 1.0 + 1.5 * ax; hi = BLM_K(0x1.f730bd281f69bp-1); lo = BLM_K(0x1.007887af0cbbdp-56); }
   if (ax >= 2.4375) { num = -1.0; den = ax; hi = BLM_PIO2_HI; lo = BLM_PIO2_LO; }
-  double t = num / den;
+  double t = blm_div(num, den);             /* |num| <= 2 |x| + 1, 1 <= den: ordinary operands */
   double z = t * t;
   double a = -BLM_K(0x1.9a0e3d8214a3cp-7);
   a = blm_fma(a, z, BLM_K(0x1.dde84abd3489ap-6));
@@ -507,7 +544,12 @@ BLM_FN double bl_atan2(double y, double x) {
   double z;
   if (ay > ax * 0x1p64) z = BLM_PIO2_HI + 0.5 * BLM_PI_LO;
   else if (sx && ay < ax * 0x1p-64) z = 0.0;
-  else z = bl_atan(ay / ax);
+  else {
+    /* 2^-64 <= ay / ax <= 2^64 here; the short division needs both operands away from the ends of the exponent range */
+    const unsigned ex = (unsigned)(blm_bits(ax) >> 52), ey = (unsigned)(blm_bits(ay) >> 52);
+    const int ordinary = (ex - 223u) < 1600u && (ey - 223u) < 1600u;   /* 2^-800 <= |x|, |y| < 2^800 */
+    z = bl_atan(ordinary ? blm_div(ay, ax) : ay / ax);
+  }
   double res = sx ? (pi - (z - BLM_PI_LO)) : z;
   return sy ? -res : res;
 }
@@ -544,11 +586,11 @@ BLM_FN double bl_acos(double x) {
   int small = ax < 0.5;
   double z = small ? x * x : (1.0 - ax) * 0.5;
   double r = z * blm_asin_r(z);
-  double s = blm_sqrt(z);
+  double s = blm_sqrt_n(z);                    /* z >= 2^-114 */
   double res_small = BLM_PIO2_HI - (x - (BLM_PIO2_LO - x * r));
   double w = r * s - BLM_PIO2_LO;
   double res_neg = BLM_PI_HI - 2.0 * (s + w);
-  double c = blm_fma(-s, s, z) / (s + s);      /* sqrt(z) = s + c */
+  double c = blm_div(blm_fma(-s, s, z), s + s);   /* sqrt(z) = s + c; the numerator is zero or within 2^-54 of z */
   double res_pos = 2.0 * (s + (r * s + c));
   return small ? res_small : (x < 0.0 ? res_neg : res_pos);
 }

@@ -284,6 +284,7 @@ typedef struct bl_stats {
   int32_t launches_locate;
   int32_t arithmetic;         /* BL_ARITH_EXACT or BL_ARITH_TOLERANT: the tier the last bl_render ran in          */
   int64_t n_deferred;         /* tolerant tier: samples whose cut decision was left to the exact kernel           */
+  int64_t n_undefined;        /* BL_UNDEFINED_EDGE: samples where the reference reads past its arrays (edge cell used)     */
 } bl_stats;
 
 typedef struct bl_ctx bl_ctx;

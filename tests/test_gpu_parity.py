@@ -125,8 +125,8 @@ def test_pixel_map_and_chunking(case, overlap, built_library):
         rng = np.random.default_rng(7)
         n_pix = full["sample_num"].size
         subset = rng.permutation(n_pix)[: n_pix // 3].astype(np.int32)
-        per_ray = int(p.get("ray_max_steps")) * 160 + 64
-        ctx.set_scratch_limit(max(per_ray * 100, 1 << 20))   # forces several chunks
+        # a few rays' worth of sample records per scratch set (two sets when chunks overlap): several chunks
+        ctx.set_scratch_limit(max(1 << 20, int(p.get("ray_max_steps")) * 600))
         ctx.set_overlap(overlap)
         part = ctx.render(pixel_map=subset)
         assert part["stats"].n_chunks > 1

