@@ -225,6 +225,7 @@ struct BlTraceArgs {
   const int *block_locs;      // device, or null
   BlSampleHot *records_hot;
   BlSampleCold *records_cold;
+  int record_stride;          // 1: the two halves of a record in arrays of their own; 2: interleaved, 64 bytes per record (records_cold = records_hot + 1)
   double *sample_t;           // optional [record capacity]: coordinate time of each sample (image_time)
   long long record_capacity;
   // The geodesic kernel hands a ray to a lane only while BL_CNT_COMMITTED + ray_max_steps <= record_gate (= capacity minus one
@@ -309,6 +310,7 @@ struct BlShadeArgs {
   const BlShadeCold *cold;    // device pointer
   const BlSampleHot *records_hot;
   const BlSampleCold *records_cold;
+  int record_stride;          // as in BlTraceArgs
   BlLocated *located;         // [record capacity], simulation mode
   unsigned long long *located_tag;   // [record capacity]: cell | status << 32 | time slice << 40
   BlFreqInputs *freq_inputs;         // [sample row] when freq_split
@@ -341,6 +343,7 @@ struct BlShadeArgs {
   double plasma_gamma_min;
   // tolerant arithmetic tier (bl_shade_fast_kernel) only
   double fast_n_e_factor;     // 1 / (mu m_p (1 + 1 / ne_ni))
+  double fast_d_unit_inv;     // 1 / d_unit
   double fast_gamma[3];       // 1 / (gamma - 1), 1 / (gamma_i - 1), 1 / (gamma_e - 1) (plasma_use_p = false)
   unsigned long long *redo_list;       // record indices left to the exact kernel, BL_CNT_REDO entries
   unsigned long long redo_capacity;    // entries the list holds; more than that: the exact kernel shades every record

@@ -109,10 +109,10 @@ __device__ __forceinline__ int wave_max_nonneg(int v) {
 __device__ __forceinline__ long long std_max_ll(long long a, long long b) { return a > b ? a : b; }
 
 // Mark the record slots [first, last) as dead (only the id word is written)
-__device__ __forceinline__ void retire_record_slots(BlSampleHot *records, long long first, long long last, int lane) {
+__device__ __forceinline__ void retire_record_slots(BlSampleHot *records, int stride, long long first, long long last, int lane) {
   for (long long at = first + lane; at < last; at += 64) {
-    records[at].ray = BL_DEAD_RAY;
-    records[at].n = 0u;
+    records[at * stride].ray = BL_DEAD_RAY;
+    records[at * stride].n = 0u;
   }
 }
 
@@ -333,7 +333,7 @@ __global__ void __launch_bounds__(64, BL_GEO_ONE_WAVE(kIntegrator, kTime, kSpinZ
       }
     }
     if (__ballot(have_ray) == 0ull) {
-      retire_record_slots(P.records_hot, block_next, block_end, lane);   // unused rest of the last block
+      retire_record_slots(P.records_hot, P.record_stride, block_next, block_end, lane);   // unused rest of the last block
       break;
     }
 #ifdef BL_GEO_STATS
@@ -352,8 +352,11 @@ __global__ void __launch_bounds__(64, BL_GEO_ONE_WAVE(kIntegrator, kTime, kSpinZ
     double y5[8], k6[8], y4m[8];
     double rv0[8], rv1[8], rv2[8], rv3[8];   // dense-output coefficients (geodesics.cpp:264-273)
     double r_new = 0.0;
+    // (dense-output coefficients of -0: a step that stores its one midpoint sample runs the interpolation formula of the
+    // emission loop on them and gets that sample back bit for bit - every product and partial sum is -0, and x + (-0) = x
+    // for every x, a zero of either sign included)
     for (int p = 0; p < 8; p++) {
-      y5[p] = 0.0; k6[p] = 0.0; y4m[p] = 0.0; rv0[p] = 0.0; rv1[p] = 0.0; rv2[p] = 0.0; rv3[p] = 0.0;
+      y5[p] = 0.0; k6[p] = 0.0; y4m[p] = 0.0; rv0[p] = -0.0; rv1[p] = -0.0; rv2[p] = -0.0; rv3[p] = -0.0;
     }
 
     if (have_ray) {
@@ -561,48 +564,43 @@ __global__ void __launch_bounds__(64, BL_GEO_ONE_WAVE(kIntegrator, kTime, kSpinZ
     st_emit += emit;
     st_accept += accepted ? 1 : 0;
 #endif
-    // the two quotients of the dense output, (nn + 0.5) / num_steps_ideal and h / num_steps_ideal (:277-293), over one
-    // reciprocal per step instead of a division per sample (small integers and step lengths: the IEEE quotients, bl_geometry.h)
+    // The samples of the step. One midpoint sample (:248-259, and the stored state of RK4 / RK2) or num_steps_ideal samples of
+    // the dense output (:277-293): smp = y + frac (r0 + (1 - frac) (r1 + frac (r2 + (1 - frac) r3))), frac = (nn + 0.5) /
+    // num_steps_ideal, each of length h / num_steps_ideal. Both run the same formula: a midpoint step has base = the stored
+    // state and coefficients of -0 (above), frac = 0.5 / 1 and h / 1 = h. The two quotients share one reciprocal per step
+    // (small integers and step lengths: the IEEE quotients, bl_geometry.h).
+    const bool dense_output = num_steps_ideal > 1;
+    double base[7];
+#pragma unroll
+    for (int p = kTime ? 0 : 1; p < 7; p++) base[p] = dense_output ? s.y[p] : y4m[p];
     const BlRecip rc_steps = bl_recip((double)num_steps_ideal);
-    const double len_dense = bl_div_r(h, rc_steps);
+    const double len = bl_div_r(h, rc_steps);
     double position = 0.5;   // nn + 0.5, exact
     for (int nn = 0; nn < max_emit; nn++, position += 1.0) {
       if (nn < emit) {
         double smp[7];
-        double len;
-        if (num_steps_ideal == 1) {   // :248-259 (and the RK4 / RK2 stored state)
+        const double frac = bl_div_r(position, rc_steps);
 #pragma unroll
-          for (int p = kTime ? 0 : 1; p < 7; p++) smp[p] = y4m[p];
-          len = h;
-        } else {                      // :277-293
-          double frac = bl_div_r(position, rc_steps);
-#pragma unroll
-          for (int p = kTime ? 0 : 1; p < 7; p++)
-            smp[p] = s.y[p] + frac * (rv0[p] + (1.0 - frac) * (rv1[p] + frac * (rv2[p] + (1.0 - frac) * rv3[p])));
-          len = len_dense;
-        }
+        for (int p = kTime ? 0 : 1; p < 7; p++)
+          smp[p] = base[p] + frac * (rv0[p] + (1.0 - frac) * (rv1[p] + frac * (rv2[p] + (1.0 - frac) * rv3[p])));
         // online form of the truncation pass (:327-349): the first sample (index >= 1) that moves
         // outward beyond the camera radius or falls inside r_terminate ends the kept part of the ray
-        int index = n + nn;
-        bool dead = trunc_at >= 0;
-        if (!dead) {
-          double r_s = bl_radial_coordinate<kSpinZero>(st, smp[1], smp[2], smp[3]);
-          if (index >= 1) {
-            bool terminate_outer = r_s > P.camera_r && r_s > r_prev_sample;
-            bool terminate_inner = r_s < P.r_terminate;
-            if (terminate_outer || terminate_inner) {
-              trunc_at = index;
-              dead = true;
-            }
-          }
-          r_prev_sample = r_s;
-        }
+        // (evaluated for every sample, decided only while the ray is still whole: after the first hit nothing reads
+        // r_prev_sample again, and the ray ends with this step - its end test is the same comparison at the step's end)
+        const int index = n + nn;
+        const double r_s = bl_radial_coordinate<kSpinZero>(st, smp[1], smp[2], smp[3]);
+        const bool hit = index >= 1 && ((r_s > P.camera_r && r_s > r_prev_sample) || r_s < P.r_terminate);
+        const bool dead = trunc_at >= 0 || hit;
+        trunc_at = (trunc_at < 0 && hit) ? index : trunc_at;
+        r_prev_sample = r_s;
         BlSampleHot hot;
         hot.x = smp[1];
         hot.y = smp[2];
         hot.z = smp[3];
         hot.ray = dead ? BL_DEAD_RAY : slot;
         hot.n = (unsigned int)index;
+        // (a lane's samples side by side, the lanes' runs end to end: consecutive records are consecutive samples of a ray, which
+        // read the same grid cells - laid out row by row instead, the coefficient kernels take 4 ms longer per frame)
         const int place = excl + nn;
         const long long at = place < old_room ? old_base + place : new_base + (place - old_room);
         BlSampleCold cold;
@@ -610,8 +608,15 @@ __global__ void __launch_bounds__(64, BL_GEO_ONE_WAVE(kIntegrator, kTime, kSpinZ
         cold.ky = smp[5];
         cold.kz = smp[6];
         cold.len = len;
-        P.records_hot[at] = hot;
-        P.records_cold[at] = cold;
+#ifdef BL_EXP_NOSTORE   // experiment: the geodesic kernel without its record stores (one lane in 2^20 keeps the values alive)
+        if (at == 0x7ffffffffffll) {
+          P.records_hot[0] = hot;
+          P.records_cold[0] = cold;
+        }
+#else
+        P.records_hot[at * P.record_stride] = hot;
+        P.records_cold[at * P.record_stride] = cold;
+#endif
         if (kTime) P.sample_t[at] = smp[0];
       }
     }
@@ -1820,7 +1825,7 @@ __global__ void __launch_bounds__(256, 4) bl_locate_kernel(const BlShadeArgs P) 
   bool more = idx < n_records;
   double2 nq0 = make_double2(0.0, 0.0), nq1 = nq0;
   if (more) {
-    const double2 *src = reinterpret_cast<const double2 *>(P.records_hot + idx);
+    const double2 *src = reinterpret_cast<const double2 *>(P.records_hot + (idx) * P.record_stride);
     nq0 = src[0];
     nq1 = src[1];
   }
@@ -1831,7 +1836,7 @@ __global__ void __launch_bounds__(256, 4) bl_locate_kernel(const BlShadeArgs P) 
     idx += stride;
     more = idx < n_records;
     if (more) {
-      const double2 *src = reinterpret_cast<const double2 *>(P.records_hot + idx);
+      const double2 *src = reinterpret_cast<const double2 *>(P.records_hot + (idx) * P.record_stride);
       nq0 = src[0];
       nq1 = src[1];
     }
@@ -1871,41 +1876,91 @@ __global__ void __launch_bounds__(256, 4) bl_locate_kernel(const BlShadeArgs P) 
   if ((threadIdx.x & 63) == 0 && gathers_local != 0ull) atomicAdd(&P.counters[BL_CNT_GATHERS], gathers_local);
 }
 
-// ---- locate kernel of the common case: one grid (or equal blocks merged into one) in spherical Kerr-Schild coordinates with
-// its coordinate tables in LDS, trilinear sampling, no optional geometric cut, no slow light. The same functions of the same
-// values as bl_locate_kernel<false, false, ...> - bit-identical located samples - as one straight line per sample: every
-// lane runs the whole search (a dead slot, a cut or an off-grid sample on clamped inputs) and the status is selected at
-// the end, where the general kernel nests a dozen divergent branches whose masks, merges and live scalars cost it more
-// instructions than the arithmetic they skip (555 vector instructions per sample there, two thirds of them not arithmetic).
+// ---- locating a sample in the common case: one grid (or equal blocks merged into one) in spherical Kerr-Schild coordinates
+// with its coordinate tables in LDS, trilinear sampling, no optional geometric cut, no slow light. The same functions of the
+// same values as locate_sample() - bit-identical results - as one straight line: every lane runs the whole search (a dead
+// slot, a cut or an off-grid sample on clamped inputs) and the status is selected at the end, where the general kernel nests
+// a dozen divergent branches whose masks, merges and live scalars cost it more instructions than the arithmetic they skip
+// (555 vector instructions per sample there, 371 here).
+struct PlainGrid {   // what the search needs of the grid, fetched once per workgroup
+  GridTables tab;
+  int n_i, n_j, n_k, nb_i, nb_j, nb_k;
+  bool one_block;
+};
+__device__ __forceinline__ void stage_grid_tables(const BlGridDevice &g, double *lds, PlainGrid *pg) {
+  double *dst = lds;
+  for (int a = 0; a < 3; a++) {
+    pg->tab.xf[a] = dst;
+    for (int i = threadIdx.x; i <= g.n[a]; i += blockDim.x) dst[i] = g.xf[a][i];
+    dst += g.n[a] + 1;
+    pg->tab.xv[a] = dst;
+    for (int i = threadIdx.x; i < g.n[a]; i += blockDim.x) dst[i] = g.xv[a][i];
+    dst += g.n[a];
+  }
+  unsigned short *bdst = reinterpret_cast<unsigned short *>(dst);
+  for (int a = 0; a < 3; a++) {
+    pg->tab.bucket[a] = bdst;
+    for (int i = threadIdx.x; i < g.n_bucket[a]; i += blockDim.x) bdst[i] = g.bucket[a][i];
+    bdst += g.n_bucket[a];
+  }
+  pg->n_i = g.n[0]; pg->n_j = g.n[1]; pg->n_k = g.n[2];
+  pg->nb_i = g.nb[0]; pg->nb_j = g.nb[1]; pg->nb_k = g.nb[2];
+  pg->one_block = g.nb[0] == g.n[0] && g.nb[1] == g.n[1] && g.nb[2] == g.n[2];
+}
+struct PlainLocated {
+  double f_i, f_j, f_k, ph_unwrapped;
+  uint32_t status, cell;
+};
+template <bool kSpinZero>
+__device__ __forceinline__ PlainLocated locate_plain_sample(const BlSpacetime &st, const BlGridDevice &g, const PlainGrid &pg, double camera_r,
+                                                            bool live, double x1, double x2, double x3) {
+  const GridTables &tab = pg.tab;
+  // a dead slot may hold anything: the search runs on a harmless point instead
+  x1 = live ? x1 : 1.0;
+  x2 = live ? x2 : 1.0;
+  x3 = live ? x3 : 1.0;
+  double r2;
+  const double r = bl_radial_coordinate2<kSpinZero>(st, x1, x2, x3, &r2);
+  const bool cut = r > camera_r;                                   // simulation_sampling.cpp:238-243
+  // ConvertFromCKS (radiation_geometry.cpp:37-57), as in locate_sample()
+  const double th = bl_acos(blm_div(x3, r));
+  const double ph_unwrapped = kSpinZero ? bl_atan2(x2, x1) : bl_atan2(x2, x1) - bl_atan(blm_div(st.bh_a, r));
+  double ph = ph_unwrapped;
+  ph += ph < 0.0 ? 2.0 * kPi : 0.0;
+  ph -= ph >= 2.0 * kPi ? 2.0 * kPi : 0.0;
+  const double s1 = r, s2 = th, s3 = ph;
+  const bool off_grid = s1 < tab.xf[0][0] || s1 > tab.xf[0][pg.n_i] || s2 < tab.xf[1][0] || s2 > tab.xf[1][pg.n_j]
+      || s3 < tab.xf[2][0] || s3 > tab.xf[2][pg.n_k];             // :352-394
+  const int i = find_cell(g, tab, 0, s1), j = find_cell(g, tab, 1, s2), k = find_cell(g, tab, 2, s3);
+  // :485-490, per block of a merged grid (one block - the usual case - needs no remainders)
+  const int i_b = pg.one_block ? i : i % pg.nb_i, j_b = pg.one_block ? j : j % pg.nb_j, k_b = pg.one_block ? k : k % pg.nb_k;
+  const int i_m = (i_b == 0 || (i_b != pg.nb_i - 1 && s1 >= tab.xv[0][i])) ? i : i - 1;
+  const int j_m = (j_b == 0 || (j_b != pg.nb_j - 1 && s2 >= tab.xv[1][j])) ? j : j - 1;
+  const int k_m = (k_b == 0 || (k_b != pg.nb_k - 1 && s3 >= tab.xv[2][k])) ? k : k - 1;
+  const double xv_i = tab.xv[0][i_m], xv_j = tab.xv[1][j_m], xv_k = tab.xv[2][k_m];
+  const bool sampled = live && !cut && !off_grid;
+  PlainLocated out;
+  // (fractions of cell widths: ordinary operands for the short division)
+  const double f_i = blm_div(s1 - xv_i, tab.xv[0][i_m + 1] - xv_i);
+  const double f_j = blm_div(s2 - xv_j, tab.xv[1][j_m + 1] - xv_j);
+  const double f_k = blm_div(s3 - xv_k, tab.xv[2][k_m + 1] - xv_k);
+  out.f_i = sampled ? f_i : 0.0;
+  out.f_j = sampled ? f_j : 0.0;
+  out.f_k = sampled ? f_k : 0.0;
+  out.ph_unwrapped = (!live || cut) ? 0.0 : ph_unwrapped;
+  out.status = !live ? (uint32_t)kSampleNone : (cut ? (uint32_t)kSampleCut : (off_grid ? (uint32_t)kSampleOffGrid : (uint32_t)kSampleInterp));
+  out.cell = sampled ? (uint32_t)((k_m * pg.n_j + j_m) * pg.n_i + i_m) : 0u;
+  return out;
+}
+
+// The locate kernel of that case
 template <bool kSpinZero>
 __global__ void __launch_bounds__(256, 4) bl_locate_plain_kernel(const BlShadeArgs P) {
   const BlSpacetime st = P.st;
   extern __shared__ double lds_tables[];
-  GridTables tab;
-  const int n_i = P.grid.n[0], n_j = P.grid.n[1], n_k = P.grid.n[2];
-  {
-    const BlGridDevice &g = P.grid;
-    double *dst = lds_tables;
-    for (int a = 0; a < 3; a++) {
-      tab.xf[a] = dst;
-      for (int i = threadIdx.x; i <= g.n[a]; i += blockDim.x) dst[i] = g.xf[a][i];
-      dst += g.n[a] + 1;
-      tab.xv[a] = dst;
-      for (int i = threadIdx.x; i < g.n[a]; i += blockDim.x) dst[i] = g.xv[a][i];
-      dst += g.n[a];
-    }
-    unsigned short *bdst = reinterpret_cast<unsigned short *>(dst);
-    for (int a = 0; a < 3; a++) {
-      tab.bucket[a] = bdst;
-      for (int i = threadIdx.x; i < g.n_bucket[a]; i += blockDim.x) bdst[i] = g.bucket[a][i];
-      bdst += g.n_bucket[a];
-    }
-    __syncthreads();
-  }
-  // what the search needs of the grid, once per wave instead of once per use
-  const double lo_i = tab.xf[0][0], hi_i = tab.xf[0][n_i], lo_j = tab.xf[1][0], hi_j = tab.xf[1][n_j], lo_k = tab.xf[2][0], hi_k = tab.xf[2][n_k];
-  const int nb_i = P.grid.nb[0], nb_j = P.grid.nb[1], nb_k = P.grid.nb[2];
-  const bool one_block = nb_i == n_i && nb_j == n_j && nb_k == n_k;
+  PlainGrid pg;
+  stage_grid_tables(P.grid, lds_tables, &pg);
+  __syncthreads();
   const double camera_r = P.cuts.camera_r;
   const bool tag_in_record = P.tag_in_record != 0;
   const unsigned long long n_records = P.counters_in[BL_CNT_RECORDS];
@@ -1915,57 +1970,32 @@ __global__ void __launch_bounds__(256, 4) bl_locate_plain_kernel(const BlShadeAr
   bool more = idx < n_records;
   double2 nq0 = make_double2(1.0, 1.0), nq1 = make_double2(1.0, __longlong_as_double((long long)BL_DEAD_RAY));
   if (more) {
-    const double2 *src = reinterpret_cast<const double2 *>(P.records_hot + idx);
+    const double2 *src = reinterpret_cast<const double2 *>(P.records_hot + (idx) * P.record_stride);
     nq0 = src[0];
     nq1 = src[1];
   }
   while (more) {
     const unsigned long long at = idx;
-    const uint32_t ray = (uint32_t)__double_as_longlong(nq1.y);
-    const bool live = ray != BL_DEAD_RAY;
-    // a dead slot may hold anything: the search runs on a harmless point instead
-    const double x1 = live ? nq0.x : 1.0, x2 = live ? nq0.y : 1.0, x3 = live ? nq1.x : 1.0;
+    const bool live = (uint32_t)__double_as_longlong(nq1.y) != BL_DEAD_RAY;
+    const double x1 = nq0.x, x2 = nq0.y, x3 = nq1.x;
     idx += stride;
     more = idx < n_records;
     if (more) {
-      const double2 *src = reinterpret_cast<const double2 *>(P.records_hot + idx);
+      const double2 *src = reinterpret_cast<const double2 *>(P.records_hot + (idx) * P.record_stride);
       nq0 = src[0];
       nq1 = src[1];
     }
-    double r2;
-    const double r = bl_radial_coordinate2<kSpinZero>(st, x1, x2, x3, &r2);
-    const bool cut = r > camera_r;                                   // simulation_sampling.cpp:238-243
-    // ConvertFromCKS (radiation_geometry.cpp:37-57), as in locate_sample()
-    const double th = bl_acos(blm_div(x3, r));
-    const double ph_unwrapped = kSpinZero ? bl_atan2(x2, x1) : bl_atan2(x2, x1) - bl_atan(blm_div(st.bh_a, r));
-    double ph = ph_unwrapped;
-    ph += ph < 0.0 ? 2.0 * kPi : 0.0;
-    ph -= ph >= 2.0 * kPi ? 2.0 * kPi : 0.0;
-    const double s1 = r, s2 = th, s3 = ph;
-    const bool off_grid = s1 < lo_i || s1 > hi_i || s2 < lo_j || s2 > hi_j || s3 < lo_k || s3 > hi_k;   // :352-394
-    const int i = find_cell(P.grid, tab, 0, s1), j = find_cell(P.grid, tab, 1, s2), k = find_cell(P.grid, tab, 2, s3);
-    // :485-490, per block of a merged grid
-    const int i_b = one_block ? i : i % nb_i, j_b = one_block ? j : j % nb_j, k_b = one_block ? k : k % nb_k;
-    const int i_m = (i_b == 0 || (i_b != nb_i - 1 && s1 >= tab.xv[0][i])) ? i : i - 1;
-    const int j_m = (j_b == 0 || (j_b != nb_j - 1 && s2 >= tab.xv[1][j])) ? j : j - 1;
-    const int k_m = (k_b == 0 || (k_b != nb_k - 1 && s3 >= tab.xv[2][k])) ? k : k - 1;
-    const double xv_i = tab.xv[0][i_m], xv_j = tab.xv[1][j_m], xv_k = tab.xv[2][k_m];
-    const double f_i = blm_div(s1 - xv_i, tab.xv[0][i_m + 1] - xv_i);
-    const double f_j = blm_div(s2 - xv_j, tab.xv[1][j_m + 1] - xv_j);
-    const double f_k = blm_div(s3 - xv_k, tab.xv[2][k_m + 1] - xv_k);
-    const bool sampled = live && !cut && !off_grid;
-    const uint32_t status = !live ? (uint32_t)kSampleNone : (cut ? (uint32_t)kSampleCut : (off_grid ? (uint32_t)kSampleOffGrid : (uint32_t)kSampleInterp));
-    const uint32_t cell = sampled ? (uint32_t)((k_m * n_j + j_m) * n_i + i_m) : 0u;
-    gathers_local += sampled ? 1ull : 0ull;
-    const unsigned long long tag = ((unsigned long long)status << 32) | cell;
+    const PlainLocated loc = locate_plain_sample<kSpinZero>(st, P.grid, pg, camera_r, live, x1, x2, x3);
+    gathers_local += loc.status == kSampleInterp ? 1ull : 0ull;
+    const unsigned long long tag = ((unsigned long long)loc.status << 32) | loc.cell;
     double2 *dst = reinterpret_cast<double2 *>(P.located + at);
     if (tag_in_record) {
       // (a dead slot gets its tag alone in the general kernel; the fractions nobody reads are written here as zeros)
-      dst[0] = make_double2(sampled ? f_i : 0.0, sampled ? f_j : 0.0);
-      dst[1] = make_double2(sampled ? f_k : 0.0, __longlong_as_double((long long)tag));
+      dst[0] = make_double2(loc.f_i, loc.f_j);
+      dst[1] = make_double2(loc.f_k, __longlong_as_double((long long)tag));
     } else if (live) {
-      dst[0] = make_double2(sampled ? f_i : 0.0, sampled ? f_j : 0.0);
-      dst[1] = make_double2(sampled ? f_k : 0.0, cut ? 0.0 : ph_unwrapped);
+      dst[0] = make_double2(loc.f_i, loc.f_j);
+      dst[1] = make_double2(loc.f_k, loc.ph_unwrapped);
       P.located_tag[at] = tag;
     } else {
       P.located_tag[at] = 0ull;
@@ -2003,10 +2033,10 @@ __global__ void __launch_bounds__(256, 2) bl_shade_kernel(const BlShadeArgs P) {
   double2 nq0, nq1, nq2, nq3, nl0 = make_double2(0.0, 0.0), nl1 = nl0;
   unsigned long long ntag = 0ull;
   {
-    const double2 *hot = reinterpret_cast<const double2 *>(P.records_hot + idx);
-    const double2 *cold = reinterpret_cast<const double2 *>(P.records_cold + idx);
+    const double2 *hot = reinterpret_cast<const double2 *>(P.records_hot + (idx) * P.record_stride);
+    const double2 *cold = reinterpret_cast<const double2 *>(P.records_cold + (idx) * P.record_stride);
     nq0 = hot[0]; nq1 = hot[1]; nq2 = cold[0]; nq3 = cold[1];
-    if (kModel == BL_MODEL_SIMULATION) {
+    if (kModel == BL_MODEL_SIMULATION && !(kRedo && P.located == nullptr)) {
       const double2 *loc = reinterpret_cast<const double2 *>(P.located + idx);
       nl0 = loc[0]; nl1 = loc[1];
       ntag = kRedo ? (unsigned long long)__double_as_longlong(nl1.y) : P.located_tag[idx];
@@ -2014,12 +2044,34 @@ __global__ void __launch_bounds__(256, 2) bl_shade_kernel(const BlShadeArgs P) {
   }
   for (bool more = true; more;) {
     const unsigned long long idx_cur = idx;
-    const double2 q0 = nq0, q1 = nq1, q2 = nq2, q3 = nq3, l0 = nl0, l1 = nl1;
-    const unsigned long long tag = ntag;
+    const double2 q0 = nq0, q1 = nq1, q2 = nq2, q3 = nq3;
+    double2 l0 = nl0, l1 = nl1;
+    unsigned long long tag = ntag;
     const uint32_t ray = (uint32_t)__double_as_longlong(q1.y);
     const bool live = ray != BL_DEAD_RAY;
     const uint32_t n = (uint32_t)(((unsigned long long)__double_as_longlong(q1.y)) >> 32);
     const double x1 = q0.x, x2 = q0.y, x3 = q1.x;
+    if (kRedo && kModel == BL_MODEL_SIMULATION && P.located == nullptr && live) {
+      // second pass behind bl_shade_fused_kernel, which leaves no located samples: the few samples it deferred are located
+      // here, by the locate kernel's own code on the coordinate tables where they lie in HBM (the grid read was counted there)
+      GridTables tab;
+      for (int a = 0; a < 3; a++) {
+        tab.xf[a] = P.grid.xf[a];
+        tab.xv[a] = P.grid.xv[a];
+        tab.bucket[a] = P.grid.bucket[a];
+      }
+      double r2_unused;
+      const double r_here = bl_radial_coordinate2<kSpinZero>(st, x1, x2, x3, &r2_unused);
+      LocatedSample loc;
+      loc.f_i = loc.f_j = loc.f_k = loc.ph = 0.0;
+      loc.cell = 0u;
+      loc.status = kSampleCut;
+      unsigned long long counted_already = 0ull;
+      if (!(r_here > P.cuts.camera_r)) locate_sample<false, kSpinZero>(P, tab, st, x1, x2, x3, r_here, &loc, &counted_already, nullptr);
+      l0 = make_double2(loc.f_i, loc.f_j);
+      l1 = make_double2(loc.f_k, 0.0);
+      tag = ((unsigned long long)loc.status << 32) | loc.cell;
+    }
     const double delta_lambda = -q3.y;   // ReverseGeodesics: sample_len = -geodesic_len (:840)
     double kcov[4] = {0.0, q2.x, q2.y, q3.x};
     double momentum_factor = 0.0;
@@ -2050,10 +2102,10 @@ __global__ void __launch_bounds__(256, 2) bl_shade_kernel(const BlShadeArgs P) {
     more = pos < n_records;
     if (more) {
       idx = listed ? P.redo_list[pos] : pos;
-      const double2 *hot = reinterpret_cast<const double2 *>(P.records_hot + idx);
-      const double2 *cold = reinterpret_cast<const double2 *>(P.records_cold + idx);
+      const double2 *hot = reinterpret_cast<const double2 *>(P.records_hot + (idx) * P.record_stride);
+      const double2 *cold = reinterpret_cast<const double2 *>(P.records_cold + (idx) * P.record_stride);
       nq0 = hot[0]; nq1 = hot[1]; nq2 = cold[0]; nq3 = cold[1];
-      if (kModel == BL_MODEL_SIMULATION) {
+      if (kModel == BL_MODEL_SIMULATION && !(kRedo && P.located == nullptr)) {
         const double2 *loc = reinterpret_cast<const double2 *>(P.located + idx);
         nl0 = loc[0]; nl1 = loc[1];
         ntag = kRedo ? (unsigned long long)__double_as_longlong(nl1.y) : P.located_tag[idx];
@@ -2341,7 +2393,7 @@ __device__ __forceinline__ bool fast_shade_sample(const BlShadeArgs &P, const do
   double2 *out = P.transfer + row * P.n_nu;
   // what the loop over frequencies needs
   bool have = false;
-  double nu_ratio = 0.0, n_e_cgs = 0.0, nu_c_cgs = 0.0, theta_e = 0.0, kb_tt_e_cgs = 0.0, sin_theta_b = 0.0;
+  double nu_ratio = 0.0, n_e_cgs = 0.0, theta_e = 0.0, kb_tt_e_cgs = 0.0, k_u_inv = 0.0, b_sin = 0.0, b_sin_inv = 0.0;
   const double rho = pr[0], pgas = pr[1], uu1 = pr[2], uu2 = pr[3], uu3 = pr[4], bb1 = pr[5], bb2 = pr[6], bb3 = pr[7];
   if (status != kSampleCut) {
     // ---- Kerr-Schild scalars (radiation_geometry.cpp:18-25, :138-262)
@@ -2384,16 +2436,19 @@ __device__ __forceinline__ bool fast_shade_sample(const BlShadeArgs &P, const do
     const double g_tph = kSpinZero ? 0.0 : -hh * bh_a * sth2;
     const double g_rph = kSpinZero ? 0.0 : -g_rr * bh_a * sth2;
     const double g_phph = kSpinZero ? pp2 : (ra2 + hh * a2 * sth2) * sth2;
-    // ---- u^mu from the normal-frame velocities (simulation_coefficients.cpp:297-313)
-    const double u0n = bl_sqrt_g(1.0 + g_rr * uu1 * uu1 + 2.0 * g_rph * uu1 * uu3 + g_thth * uu2 * uu2 + g_phph * uu3 * uu3);
-    const double ut = u0n * bl_sqrt_g(g_rr);                       // u0n / lapse, lapse = 1 / sqrt(1 + 2 m r / Sigma)
+    // ---- u^mu from the normal-frame velocities (simulation_coefficients.cpp:297-313). u^t = u0n / lapse = sqrt(S (1 + 2 m r /
+    // Sigma)): one reciprocal square root gives u^t and 1 / u^t. (Square roots and reciprocals are a fifth of this function's
+    // issue time - a dozen instructions each, one of them at quarter rate - so quantities that share one are taken from one.)
+    const double u0n2 = 1.0 + g_rr * uu1 * uu1 + 2.0 * g_rph * uu1 * uu3 + g_thth * uu2 * uu2 + g_phph * uu3 * uu3;
+    const double ut2 = u0n2 * g_rr;
+    const double ut_inv = fastmath::rsqrt(ut2);
+    const double ut = ut2 * ut_inv;
     const double ur = uu1 - hh * fastmath::rcp(g_rr) * ut;         // shift^r = (2 m r / Sigma) / (1 + 2 m r / Sigma)
     const double u_r = hh * ut + g_rr * ur + g_rph * uu3;
     const double u_th = g_thth * uu2;
     const double u_ph = g_tph * ut + g_rph * ur + g_phph * uu3;
     // ---- b^mu (:316-330); b.b = (B.B + (u.B)^2) / (u^t)^2
     const double bt = u_r * bb1 + u_th * bb2 + u_ph * bb3;
-    const double ut_inv = fastmath::rcp(ut);
     const double br = (bb1 + bt * ur) * ut_inv;
     const double bth = (bb2 + bt * uu2) * ut_inv;
     const double bph = (bb3 + bt * uu3) * ut_inv;
@@ -2403,24 +2458,33 @@ __device__ __forceinline__ bool fast_shade_sample(const BlShadeArgs &P, const do
     const double rho_cgs = rho * pl.d_unit;
     const double pgas_cgs = pgas * pl.e_unit;
     n_e_cgs = rho_cgs * P.fast_n_e_factor;                         // / (mu m_p) / (1 + 1 / ne_ni)
-    const double bb_cgs = bl_sqrt_g(b_sq) * pl.b_unit;
-    const double rho_inv = fastmath::rcp(rho);
-    const double sigma_cut = b_sq * rho_inv;
-    const double beta_inv = b_sq * fastmath::rcp(2.0 * pgas);
+    // 1 / rho and 1 / p from one reciprocal where both are positive (single-precision values: the product is an ordinary double)
+    double rho_inv, pgas_inv;
     {
+      const double rp = rho * pgas;
+      const bool both = rho > 0.0 && rp > 0.0 && rp < __builtin_inf();
+      const double t = fastmath::rcp(both ? rp : rho);
+      rho_inv = both ? t * pgas : t;
+      pgas_inv = both ? t * rho : fastmath::rcp(pgas);
+    }
+    const double sigma_cut = b_sq * rho_inv;
+    const double beta_inv = 0.5 * b_sq * pgas_inv;
+    {
+      // T_i / T_e = N / D, N = rat_high + rat_low / beta^2, D = 1 + 1 / beta^2: k T_e = (1 + c) k T_tot D / (N + c D), one reciprocal
       const double bi2 = beta_inv * beta_inv;
-      const double tti_tte = (pl.plasma_rat_high + pl.plasma_rat_low * bi2) * fastmath::rcp(1.0 + bi2);
-      const double kb_tt_tot_cgs = pl.plasma_mu * kMp * pgas_cgs * fastmath::rcp(rho_cgs);
+      const double nn = pl.plasma_rat_high + pl.plasma_rat_low * bi2, dd = 1.0 + bi2;
+      const double kb_tt_tot_cgs = (pl.plasma_mu * kMp) * pgas_cgs * (rho_inv * P.fast_d_unit_inv);
       if (pl.plasma_use_p)
-        kb_tt_e_cgs = (1.0 + pl.plasma_ne_ni) * fastmath::rcp(tti_tte + pl.plasma_ne_ni) * kb_tt_tot_cgs;
+        kb_tt_e_cgs = (1.0 + pl.plasma_ne_ni) * kb_tt_tot_cgs * (dd * fastmath::rcp(nn + pl.plasma_ne_ni * dd));
       else
         kb_tt_e_cgs = (1.0 + pl.plasma_ne_ni) * kb_tt_tot_cgs * P.fast_gamma[0]
-            * fastmath::rcp(tti_tte * P.fast_gamma[1] + pl.plasma_ne_ni * P.fast_gamma[2]);
+            * (dd * fastmath::rcp(nn * P.fast_gamma[1] + pl.plasma_ne_ni * P.fast_gamma[2] * dd));
       theta_e = kb_tt_e_cgs * (1.0 / (kMe * kC * kC));
     }
     // ---- cell cuts (:361-375): decided here unless a value sits within the guard band of an active threshold
     bool cell_cut = false, undecided = pp2 == 0.0;
     if (pl.cut_mask != 0) {
+      const double bb_cgs = (pl.cut_mask & 0x300) ? bl_sqrt_g(b_sq) * pl.b_unit : 0.0;   // only the field-strength cuts need |b| itself
       const double value[7] = {rho_cgs, n_e_cgs, pgas_cgs, theta_e, bb_cgs, sigma_cut, beta_inv};
 #pragma unroll
       for (int c = 0; c < 14; c++)
@@ -2441,12 +2505,17 @@ __device__ __forceinline__ bool fast_shade_sample(const BlShadeArgs &P, const do
       const double k_ph = x * ky - y * kx;
       const double k_u = kt * ut + k_r * ur + k_th * uu2 + k_ph * uu3;
       const double k_b = kt * bt + k_r * br + k_th * bth + k_ph * bph;
-      double cos2 = k_b * k_b * fastmath::rcp(k_u * k_u * b_sq);      // :434-455 in invariant form
+      // cos^2 = (k.b)^2 / ((k.u)^2 b.b) (:434-455 in invariant form) and 1 / (k.u) from one reciprocal
+      const double t = fastmath::rcp(k_u * b_sq);
+      k_u_inv = t * b_sq;
+      double cos2 = k_b * k_b * (t * k_u_inv);
       cos2 = cos2 < 1.0 ? cos2 : 1.0;
       have = true;
       nu_ratio = -k_u;                                                // :461-463
-      nu_c_cgs = kE * bb_cgs * (1.0 / (2.0 * kPi * kMe * kC));
-      sin_theta_b = bl_sqrt_g(1.0 - cos2);
+      // |b| sin(theta_B) and its reciprocal from one reciprocal square root: nu_c sin(theta_B) and nu_s carry nothing else of the field
+      const double bs2 = b_sq * (1.0 - cos2);
+      b_sin_inv = fastmath::rsqrt(bs2);                               // (inf along the field: nu / nu_s = inf there, as from 1 / 0)
+      b_sin = bs2 > 0.0 ? bs2 * b_sin_inv : 0.0;
     }
   }
   if (status == kSampleOffGrid && pl.fallback_nan) {
@@ -2463,16 +2532,20 @@ __device__ __forceinline__ bool fast_shade_sample(const BlShadeArgs &P, const do
   // (s_nu = -k.u x momentum factor), x = nu / nu_s = s_x f_l, so x^(1/2), x^(1/3), x^(1/6) are products of one square / cube
   // root per sample with the frequency's roots from the table (table[44 + n_nu ...], filled once per workgroup) - what is
   // left per sample AND frequency is one exp, two expm1, one reciprocal and two dozen multiplications.
+  // nu_c = e |b| b_unit / (2 pi m_e c), nu_s = 2/9 nu_c Theta_e^2 sin(theta_B): nu / nu_s without another reciprocal
   const double thermal_frac = pl.plasma_thermal_frac;
-  const double nu_s_cgs = 2.0 / 9.0 * nu_c_cgs * theta_e * theta_e * sin_theta_b;
+  const double nu_c_over_b = kE * pl.b_unit * (1.0 / (2.0 * kPi * kMe * kC));
+  const double momentum_factor_inv = fastmath::rcp(momentum_factor);
+  const double kb_tt_e_inv = have ? fastmath::rcp(kb_tt_e_cgs) : 0.0;
+  const double theta_e_inv = kb_tt_e_inv * (kMe * kC * kC);
   const double s_nu = nu_ratio * momentum_factor;
-  const double s_x = have ? s_nu * fastmath::rcp(nu_s_cgs) : 0.0;
+  const double s_x = have ? s_nu * b_sin_inv * (theta_e_inv * theta_e_inv) * (4.5 / nu_c_over_b) : 0.0;
   const double s_1_2 = bl_sqrt_g(s_x), s_1_3 = fastmath::cbrt(s_x);
   const double s_1_6 = bl_sqrt_g(s_1_3);
-  const double s_planck = have ? kH * s_nu * fastmath::rcp(kb_tt_e_cgs) : 0.0;                    // h nu / (k T_e) = s_planck f_l
-  const double s_nu_inv = have ? fastmath::rcp(s_nu) : 0.0;
-  const double s_j = thermal_frac * n_e_cgs * kE * kE * nu_c_cgs * (1.0 / kC) * (kSqrt2 * kPi / 27.0) * sin_theta_b * s_nu_inv * s_nu_inv;
-  const double s_length = delta_lambda * P.x_unit * fastmath::rcp(momentum_factor);               // unpolarized.cpp:75-76
+  const double s_planck = have ? kH * s_nu * kb_tt_e_inv : 0.0;                                   // h nu / (k T_e) = s_planck f_l
+  const double s_nu_inv = have ? -k_u_inv * momentum_factor_inv : 0.0;
+  const double s_j = thermal_frac * n_e_cgs * kE * kE * (nu_c_over_b * b_sin) * (1.0 / kC) * (kSqrt2 * kPi / 27.0) * s_nu_inv * s_nu_inv;
+  const double s_length = delta_lambda * P.x_unit * momentum_factor_inv;                          // unpolarized.cpp:75-76
   if (P.freq_split) {   // several frequencies: the factors go to bl_transfer_freq_kernel, one lane per ray and frequency
     double2 *dst = reinterpret_cast<double2 *>(P.freq_inputs + row);
     dst[0] = make_double2(have ? 1.0 : 0.0, s_1_2);
@@ -2533,8 +2606,8 @@ __device__ __forceinline__ void fast_load_located(const BlShadeArgs &P, unsigned
   r.tag = (unsigned long long)__double_as_longlong(r.l1.y);
 }
 __device__ __forceinline__ void fast_load_ray(const BlShadeArgs &P, unsigned long long idx, FastRay &r) {
-  const double2 *hot = reinterpret_cast<const double2 *>(P.records_hot + idx);
-  const double2 *cold = reinterpret_cast<const double2 *>(P.records_cold + idx);
+  const double2 *hot = reinterpret_cast<const double2 *>(P.records_hot + (idx) * P.record_stride);
+  const double2 *cold = reinterpret_cast<const double2 *>(P.records_cold + (idx) * P.record_stride);
   r.q0 = hot[0]; r.q1 = hot[1]; r.q2 = cold[0]; r.q3 = cold[1];
 }
 
@@ -2683,6 +2756,128 @@ __global__ void __launch_bounds__(256, BL_FAST_WAVES) bl_shade_fast_kernel(const
   }
 }
 
+// Tolerant tier, common case of the grid (locate_plain_sample): the locate step inside the coefficient kernel. The located
+// samples - 32 bytes written and 32 read per sample, and the 32 bytes of record the locate kernel reads - never exist: the
+// locate kernel alone, at 371 vector instructions per sample, was bound by those 64 bytes per sample (10.9 ms per frame at
+// 4.4 TB/s). Three samples in flight per lane:
+//   next: its position record is requested before the arithmetic of `prev` and located after it (coordinate tables in LDS);
+//   cur:  located -> corner cells and momentum record requested at the top of the iteration;
+//   prev: cells and records arrived -> trilinear read, arithmetic.
+// One wait per iteration (before the search, on loads a whole sample's arithmetic old). Deferred cut decisions go to the
+// exact kernel's second pass, which locates those samples itself (BlShadeArgs::located == nullptr).
+template <bool kSpinZero>
+__global__ void __launch_bounds__(256, BL_FAST_WAVES) bl_shade_fused_kernel(const BlShadeArgs P) {
+  const BlSpacetime st = P.st;
+  const unsigned long long n_records = P.counters_in[BL_CNT_RECORDS];
+  const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+  unsigned long long idx = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  extern __shared__ double fast_table[];   // bl_shade_fast_kernel's table, then the grid's coordinate tables
+  const int table_doubles = 44 + 5 * P.n_nu;
+  for (int i = threadIdx.x; i < table_doubles; i += blockDim.x) {
+    const BlShadeCold &cc = *P.cold;
+    double value;
+    if (i < 44) {
+      value = i < 14 ? cc.fast_cut[i] : (i < 28 ? cc.fast_cut_lo[i - 14] : (i < 42 ? cc.fast_cut_hi[i - 28]
+          : (i == 42 ? (double)cc.fallback_rho : (double)cc.fallback_pgas)));
+    } else {
+      const int which = (i - 44) / P.n_nu;
+      const double f = P.frequencies[(i - 44) - which * P.n_nu];
+      const double f_1_3 = fastmath::cbrt(f);
+      value = which == 0 ? f : (which == 1 ? bl_sqrt_g(f) : (which == 2 ? f_1_3 : (which == 3 ? bl_sqrt_g(f_1_3) : fastmath::rcp(f))));
+    }
+    fast_table[i] = value;
+  }
+  PlainGrid pg;
+  stage_grid_tables(P.grid, fast_table + table_doubles, &pg);
+  __syncthreads();
+  if (n_records == 0ull) return;
+  const unsigned long long last = n_records - 1ull;
+  const double camera_r = P.cuts.camera_r;
+  unsigned long long gathers_local = 0ull;
+  auto load_position = [&](bool have, unsigned long long at, double2 &q0, double2 &q1) {
+    const double2 *hot = reinterpret_cast<const double2 *>(P.records_hot + (have ? at : last) * P.record_stride);
+    q0 = hot[0];
+    q1 = hot[1];
+  };
+  FastRay rec_prev;                        // q0, q1: position record; q2, q3: momentum record
+  double2 hot_cur0, hot_cur1, hot_next0, hot_next1;
+  PlainLocated loc_prev, loc_cur;
+  float4 lo[8], hi[8];
+  unsigned long long idx_prev = 0ull, idx_cur = idx;
+  bool have_prev = false, have_cur = idx < n_records;
+  rec_prev.q0 = rec_prev.q1 = rec_prev.q2 = rec_prev.q3 = make_double2(0.0, 0.0);
+  rec_prev.q1.y = __longlong_as_double((long long)BL_DEAD_RAY);
+  loc_prev.f_i = loc_prev.f_j = loc_prev.f_k = loc_prev.ph_unwrapped = 0.0;
+  loc_prev.status = kSampleNone;
+  loc_prev.cell = 0u;
+#pragma unroll
+  for (int c = 0; c < 8; c++) lo[c] = hi[c] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  load_position(have_cur, idx_cur, hot_cur0, hot_cur1);
+  idx += stride;
+  unsigned long long idx_next = idx;
+  bool have_next = have_cur && idx < n_records;
+  // (the position record of `next` is requested a whole iteration before its search, so that the wait in front of the search
+  // is for loads of the previous iteration, not for the cells and records requested in this one)
+  load_position(have_next, idx_next, hot_next0, hot_next1);
+  idx += stride;
+  bool have_after = have_next && idx < n_records;
+  {
+    const bool live = have_cur && (uint32_t)__double_as_longlong(hot_cur1.y) != BL_DEAD_RAY;
+    loc_cur = locate_plain_sample<kSpinZero>(st, P.grid, pg, camera_r, live, hot_cur0.x, hot_cur0.y, hot_cur1.x);
+  }
+  while (have_prev || have_cur) {
+    const uint32_t ray = have_prev ? (uint32_t)__double_as_longlong(rec_prev.q1.y) : BL_DEAD_RAY;
+    const bool live = ray != BL_DEAD_RAY;
+    const uint32_t n = (uint32_t)(((unsigned long long)__double_as_longlong(rec_prev.q1.y)) >> 32);
+    const int status = (int)loc_prev.status;
+    // per-ray constants of `prev`: requested before the next sample's cells
+    const double kt = P.ray_kt[live ? ray : 0u], momentum_factor = P.ray_factor[live ? ray : 0u];
+    const size_t row = (size_t)P.ray_offset[live ? ray : 0u] + n;
+    float pr[8];
+    gather_finish(P, fast_table, status, lo, hi, loc_prev.f_i, loc_prev.f_j, loc_prev.f_k, pr);
+    gathers_local += (live && status == kSampleInterp) ? 1ull : 0ull;
+    gather_issue(P, (int)loc_cur.status, loc_cur.cell, lo, hi);
+    double2 cold_cur0, cold_cur1;
+    {
+      const double2 *cold = reinterpret_cast<const double2 *>(P.records_cold + (have_cur ? idx_cur : last) * P.record_stride);
+      cold_cur0 = cold[0];
+      cold_cur1 = cold[1];
+    }
+    double2 hot_after0, hot_after1;
+    load_position(have_after, idx, hot_after0, hot_after1);
+    if (live) {
+      // ReverseGeodesics: sample_len = -geodesic_len (geodesics.cpp:840)
+      if (!fast_shade_sample<kSpinZero>(P, fast_table, pr, status, row, rec_prev.q0.x, rec_prev.q0.y, rec_prev.q1.x, rec_prev.q2.x, rec_prev.q2.y,
+                                        rec_prev.q3.x, kt, momentum_factor, -rec_prev.q3.y)) {
+        fast_defer(P, idx_prev);
+      }
+    }
+    // the search for `next`
+    const bool live_next = have_next && (uint32_t)__double_as_longlong(hot_next1.y) != BL_DEAD_RAY;
+    const PlainLocated loc_next = locate_plain_sample<kSpinZero>(st, P.grid, pg, camera_r, live_next, hot_next0.x, hot_next0.y, hot_next1.x);
+    rec_prev.q0 = hot_cur0;
+    rec_prev.q1 = hot_cur1;
+    rec_prev.q2 = cold_cur0;
+    rec_prev.q3 = cold_cur1;
+    loc_prev = loc_cur;
+    idx_prev = idx_cur;
+    have_prev = have_cur;
+    hot_cur0 = hot_next0;
+    hot_cur1 = hot_next1;
+    loc_cur = loc_next;
+    idx_cur = idx_next;
+    have_cur = have_next;
+    hot_next0 = hot_after0;
+    hot_next1 = hot_after1;
+    idx_next = idx;
+    have_next = have_after;
+    idx += stride;
+    have_after = have_after && idx < n_records;
+  }
+  for (int offset = 32; offset > 0; offset >>= 1) gathers_local += __shfl_xor(gathers_local, offset, 64);
+  if ((threadIdx.x & 63) == 0 && gathers_local != 0ull) atomicAdd(&P.counters[BL_CNT_GATHERS], gathers_local);
+}
+
 // Several frequencies in the tolerant tier: one lane per (ray, frequency) walks the ray far -> near, builds each sample's
 // (a, c) from the sample's factors (BlFreqInputs; the lanes of one ray read the same 64 bytes) and the lane's own frequency,
 // and applies I <- a I + c at once. The per-frequency transfer records (16 bytes per sample and frequency: 1.5 TB written
@@ -2786,7 +2981,7 @@ __global__ void __launch_bounds__(256, 2) bl_polarized_coefficients_kernel(const
   const unsigned long long n_records = P.counters_in[BL_CNT_RECORDS];
   const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
   for (unsigned long long idx = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; idx < n_records; idx += stride) {
-    const unsigned long long tag = reinterpret_cast<const unsigned long long *>(P.records_hot + idx)[3];   // (ray, n)
+    const unsigned long long tag = reinterpret_cast<const unsigned long long *>(P.records_hot + (idx) * P.record_stride)[3];   // (ray, n)
     const uint32_t ray = (uint32_t)tag;
     if (ray == BL_DEAD_RAY) continue;
     const uint32_t n = (uint32_t)(tag >> 32);
@@ -2847,7 +3042,7 @@ __global__ void __launch_bounds__(256, 4) bl_coefficients_freq_kernel(const BlSh
   for (unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
     const unsigned long long idx = t / (unsigned long long)P.n_nu;
     const int l = (int)(t - idx * (unsigned long long)P.n_nu);
-    const unsigned long long tag = reinterpret_cast<const unsigned long long *>(P.records_hot + idx)[3];   // (ray, n)
+    const unsigned long long tag = reinterpret_cast<const unsigned long long *>(P.records_hot + (idx) * P.record_stride)[3];   // (ray, n)
     const uint32_t ray = (uint32_t)tag;
     if (ray == BL_DEAD_RAY) continue;
     const uint32_t n = (uint32_t)(tag >> 32);
@@ -2880,7 +3075,7 @@ __global__ void __launch_bounds__(256) bl_polarized_frame_kernel(const BlShadeAr
   const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
   for (unsigned long long pos = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; pos < n_items; pos += stride) {
     const unsigned long long idx = listed ? P.redo_list[pos] : pos;
-    const double2 *hot = reinterpret_cast<const double2 *>(P.records_hot + idx);
+    const double2 *hot = reinterpret_cast<const double2 *>(P.records_hot + (idx) * P.record_stride);
     const double2 q1 = hot[1];
     const unsigned long long tag = (unsigned long long)__double_as_longlong(q1.y);   // (ray, n)
     const uint32_t ray = (uint32_t)tag;
@@ -3294,6 +3489,17 @@ extern "C" hipError_t bl_launch_shade(const BlShadeArgs *args, int model, int gr
 
 // Tolerant tier: the fast coefficient kernel, then the exact kernel over the records it deferred
 extern "C" hipError_t bl_launch_shade_fast(const BlShadeArgs *args, int grid, hipStream_t stream) {
+  if (args->located == nullptr) {   // no locate kernel ran: the fused kernel (coordinate tables in LDS behind its own table)
+    const size_t lds = (44 + 5 * args->n_nu) * sizeof(double) + args->lds_table_bytes;
+    if (args->st.bh_a == 0.0) {
+      hipLaunchKernelGGL((bl_shade_fused_kernel<true>), dim3(grid), dim3(256), lds, stream, *args);
+      hipLaunchKernelGGL((bl_shade_kernel<BL_MODEL_SIMULATION, false, false, true, false, true, true>), dim3(grid), dim3(256), 0, stream, *args);
+    } else {
+      hipLaunchKernelGGL((bl_shade_fused_kernel<false>), dim3(grid), dim3(256), lds, stream, *args);
+      hipLaunchKernelGGL((bl_shade_kernel<BL_MODEL_SIMULATION, false, false, true, false, false, true>), dim3(grid), dim3(256), 0, stream, *args);
+    }
+    return hipGetLastError();
+  }
   if (args->st.bh_a == 0.0) {
     hipLaunchKernelGGL((bl_shade_fast_kernel<true>), dim3(grid), dim3(256), (44 + 5 * args->n_nu) * sizeof(double), stream, *args);
     hipLaunchKernelGGL((bl_shade_kernel<BL_MODEL_SIMULATION, false, false, true, false, true, true>), dim3(grid), dim3(256), 0, stream, *args);

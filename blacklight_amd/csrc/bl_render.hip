@@ -113,6 +113,8 @@ struct RenderJob {
   bool simulation = false, aux = false, slow = false, geo_load = false, geo_save = false, need_time = false, block_interp = false;
   bool fast = false, tolerant_polarized = false, matrix_transport = false, freq_split = false, coef_split = false;
   bool rows_only = false, fill_present = false;
+  bool interleaved = false;   // sample records as one 64-byte array instead of two of 32-byte halves
+  bool fused = false;   // tolerant tier, common grid case: the locate step runs inside the coefficient kernel (bl_shade_fused_kernel)
   int n_nu = 0, n_q = 0, max_steps = 0;
   long long n_rays = 0, level_pixels = 0;
   size_t redo_capacity = 0;
@@ -207,6 +209,13 @@ void PlanJob(RenderJob &job) {
   // Several frequencies in the fast path: per-sample factors (BlFreqInputs) instead of per-frequency transfer records,
   // evaluated by bl_transfer_freq_kernel with one lane per ray and frequency
   job.freq_split = job.fast && job.n_nu >= 4;
+  // The fast path over one grid (or equal blocks merged into one) with its coordinate tables in LDS, trilinear sampling and no
+  // optional geometric cut locates its samples inside the coefficient kernel: no located samples in HBM at all
+  job.fused = job.fast && ctx->grid_dev.n_blocks == 0 && ctx->lds_table_bytes > 0 && !ctx->grid_dev.fmks && p.simulation_interp
+      && !(p.cut_omit_near || p.cut_omit_far || p.cut_omit_in >= 0.0 || p.cut_omit_out >= 0.0 || p.cut_midplane_theta != 0.0 || p.cut_midplane_z != 0.0 || p.cut_plane)
+      && static_cast<size_t>(ctx->lds_table_bytes) + (44 + 5 * static_cast<size_t>(job.n_nu)) * sizeof(double) <= 60u * 1024u
+      && std::getenv("BLACKLIGHT_AMD_NO_FUSED_LOCATE") == nullptr;
+  job.interleaved = (job.fused || !job.simulation) && !job.geo_load && !job.geo_save && std::getenv("BLACKLIGHT_AMD_SPLIT_RECORDS") == nullptr;
   // ... and in the exact coefficient kernel (plain images): the frequency loop as lanes of bl_coefficients_freq_kernel
   job.coef_split = !job.fast && job.simulation && !job.aux && !ctx->polarized && job.n_nu >= 4;
   // (polarized runs list the samples without coefficients there - cut samples, cut cells - which are many more)
@@ -230,7 +239,7 @@ void PlanScratch(RenderJob &job) {
   // per sample record (the arrays indexed by record slot) and per kept sample (the arrays indexed by ray_offset + n: never
   // more than records)
   job.bytes_per_record = sizeof(BlSampleHot) + sizeof(BlSampleCold)
-      + (job.simulation ? sizeof(BlLocated) + sizeof(unsigned long long) : 0)
+      + ((job.simulation && !job.fused) ? sizeof(BlLocated) + sizeof(unsigned long long) : 0)
       + (job.freq_split ? sizeof(BlFreqInputs) : sizeof(double2) * n_nu)
       + (job.aux ? sizeof(BlAuxSample) : 0) + (job.need_time ? sizeof(double) : 0) + (job.slow ? sizeof(double) : 0)
       + (ctx->polarized ? sizeof(BlPolSample) + sizeof(BlCoefInputs) + 3 * sizeof(double2) * n_nu : 0)
@@ -285,9 +294,13 @@ void EnsureScratch(RenderJob &job) {
   const size_t n_nu = static_cast<size_t>(job.n_nu);
   for (int k = 0; k < job.n_slots; k++) {
     bl_ctx::ChunkSlot &sl = ctx->slot[k];
-    sl.d_records_hot.Ensure(cap);
-    sl.d_records_cold.Ensure(cap);
-    if (job.simulation) {
+    if (job.interleaved) {
+      sl.d_records_hot.Ensure(2 * cap);
+    } else {
+      sl.d_records_hot.Ensure(cap);
+      sl.d_records_cold.Ensure(cap);
+    }
+    if (job.simulation && !job.fused) {
       sl.d_located.Ensure(cap);
       sl.d_located_tag.Ensure(cap);
     }
@@ -650,6 +663,7 @@ void BuildShadeArgs(RenderJob &job) {
         cold.fast_cut_hi[c] = active ? cuts[c] * (1.0 + ctx->guard_band) : 0.0;
       }
       sa.fast_n_e_factor = 1.0 / (p.plasma_mu * kMp * (1.0 + 1.0 / p.plasma_ne_ni));
+      sa.fast_d_unit_inv = 1.0 / p.simulation_rho_cgs;
       sa.fast_gamma[0] = 1.0 / (ctx->grid_meta.plasma_gamma - 1.0);
       sa.fast_gamma[1] = 1.0 / (ctx->grid_meta.plasma_gamma_i - 1.0);
       sa.fast_gamma[2] = 1.0 / (ctx->grid_meta.plasma_gamma_e - 1.0);
@@ -760,8 +774,12 @@ void BindChunk(RenderJob &job, int k, long long begin, int rays) {
   BlTransferArgs &xa = job.xa;
   ta.chunk_begin = begin;
   ta.chunk_rays = rays;
+  // The halves of a sample record (position + id | momentum + length): side by side in one array where every reader wants both
+  // (the fused tolerant kernel: 64 contiguous bytes per lane for the geodesic kernel's scattered stores), in two arrays where
+  // the locate kernel reads positions only
   ta.records_hot = sl.d_records_hot.ptr;
-  ta.records_cold = sl.d_records_cold.ptr;
+  ta.records_cold = job.interleaved ? reinterpret_cast<BlSampleCold *>(sl.d_records_hot.ptr + 1) : sl.d_records_cold.ptr;
+  ta.record_stride = job.interleaved ? 2 : 1;
   ta.sample_t = job.need_time ? sl.d_sample_t.ptr : nullptr;
   ta.counters = sl.d_counters.ptr;
   ta.ray_kt = ctx->d_ray_kt.ptr + begin;
@@ -771,10 +789,11 @@ void BindChunk(RenderJob &job, int k, long long begin, int rays) {
   ta.ray_out_index = ctx->d_ray_out_index.ptr + begin;
   ta.ray_offset = ctx->d_ray_offset.ptr + begin;
   ta.ray_start = job.geo_load ? nullptr : ctx->d_ray_start.ptr + begin;
-  sa.records_hot = sl.d_records_hot.ptr;
-  sa.records_cold = sl.d_records_cold.ptr;
-  sa.located = job.simulation ? sl.d_located.ptr : nullptr;
-  sa.located_tag = job.simulation ? sl.d_located_tag.ptr : nullptr;
+  sa.records_hot = ta.records_hot;
+  sa.records_cold = ta.records_cold;
+  sa.record_stride = ta.record_stride;
+  sa.located = (job.simulation && !job.fused) ? sl.d_located.ptr : nullptr;
+  sa.located_tag = (job.simulation && !job.fused) ? sl.d_located_tag.ptr : nullptr;
   sa.freq_inputs = job.freq_split ? sl.d_freq_inputs.ptr : nullptr;
   sa.counters_in = sl.d_counters.ptr;
   sa.counters = sl.d_counters.ptr;
@@ -1024,7 +1043,7 @@ void LaunchShadingStage(RenderJob &job, int k, bool geodesic_beside, hipStream_t
   BlTransferArgs &xa = job.xa;
   Check(hipStreamWaitEvent(stream, e[1], 0), "stream wait");
   Check(hipEventRecord(e[2], stream), "event");
-  if (job.simulation)
+  if (job.simulation && !job.fused)
     Check(bl_launch_locate(&sa, geodesic_beside ? job.locate_grid_shared : job.locate_grid_alone, ctx->lds_table_bytes, stream), "locate kernel launch");
   Check(hipEventRecord(e[3], stream), "event");
   if (job.fast) Check(bl_launch_shade_fast(&sa, job.shade_grid, stream), "coefficient kernel launch");
@@ -1166,7 +1185,7 @@ void FinishStats(RenderJob &job) {
   st.n_rays = job.n_rays;
   st.n_chunks = job.n_chunks;
   st.launches_geodesic = job.n_chunks;
-  st.launches_locate = job.simulation ? job.n_chunks : 0;
+  st.launches_locate = (job.simulation && !job.fused) ? job.n_chunks : 0;
   st.launches_shade = job.n_chunks;
   st.launches_transfer = job.n_chunks;
   st.n_samples = static_cast<int64_t>(job.total_samples);
