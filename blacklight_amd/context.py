@@ -269,8 +269,9 @@ class Context:
         self._check(self._lib.bl_write_output(self._ctx, None if path is None else str(path).encode(), C.byref(d)))
 
     def render_device(self, image_ptr, n_rays, level=0, pixel_map=None, sample_num_ptr=0, sample_flags_ptr=0,
-                      block_locs=None):
-        """Trace into caller-owned HBM (raw device pointers, e.g. torch.Tensor.data_ptr())."""
+                      block_locs=None, camera_pos_ptr=0, camera_dir_ptr=0, render_ptr=0):
+        """Trace into caller-owned HBM (raw device pointers, e.g. torch.Tensor.data_ptr()): image (n_q, n_rays), sample_num,
+        sample_flags (n_rays), camera_pos / camera_dir (n_rays, 4), renderings (n_images, 3, n_rays) - the layouts of render()."""
         d = _capi.RenderDesc()
         d.level = level
         keep = []
@@ -288,5 +289,8 @@ class Context:
         d.image = C.c_void_p(image_ptr)
         d.sample_num = C.c_void_p(sample_num_ptr) if sample_num_ptr else None
         d.sample_flags = C.c_void_p(sample_flags_ptr) if sample_flags_ptr else None
+        d.camera_pos = C.c_void_p(camera_pos_ptr) if camera_pos_ptr else None
+        d.camera_dir = C.c_void_p(camera_dir_ptr) if camera_dir_ptr else None
+        d.render = C.c_void_p(render_ptr) if render_ptr else None
         self._check(self._lib.bl_render(self._ctx, C.byref(d)))
         return self.stats

@@ -2633,7 +2633,7 @@ __device__ __forceinline__ void gather_issue(const BlShadeArgs &P, int status, u
     hi[corner] = p[1];
   }
 }
-__device__ __forceinline__ void gather_finish(const BlShadeArgs &P, const double *table, int status, const float4 (&lo)[8],
+__device__ __forceinline__ void gather_finish(const BlShadeArgs &P, float fallback_rho, float fallback_pgas, int status, const float4 (&lo)[8],
                                               const float4 (&hi)[8], double f_i, double f_j, double f_k, float pr[8]) {
 #pragma clang fp contract(off)
   const BlPlasmaDevice &pl = P.plasma;
@@ -2665,8 +2665,8 @@ __device__ __forceinline__ void gather_finish(const BlShadeArgs &P, const double
     unpack_cell(lo[0], hi[0], pr);
   } else if (status == kSampleOffGrid) {
     const float fnan = __int_as_float(0x7fc00000);
-    pr[0] = pl.fallback_nan ? fnan : (float)table[42];    // :377-384, :678-706
-    pr[1] = pl.fallback_nan ? fnan : (float)table[43];
+    pr[0] = pl.fallback_nan ? fnan : fallback_rho;    // :377-384, :678-706
+    pr[1] = pl.fallback_nan ? fnan : fallback_pgas;
     for (int q = 2; q < 8; q++) pr[q] = pl.fallback_nan ? fnan : 0.0f;
   } else {
     for (int q = 0; q < 8; q++) pr[q] = 0.0f;
@@ -2731,7 +2731,7 @@ __global__ void __launch_bounds__(256, BL_FAST_WAVES) bl_shade_fast_kernel(const
     const double kt = P.ray_kt[live ? ray : 0u], momentum_factor = P.ray_factor[live ? ray : 0u];
     const size_t row = (size_t)P.ray_offset[live ? ray : 0u] + n;
     float pr[8];
-    gather_finish(P, fast_table, live ? status : (int)kSampleNone, lo, hi, loc_prev.l0.x, loc_prev.l0.y, loc_prev.l1.x, pr);
+    gather_finish(P, (float)fast_table[42], (float)fast_table[43], live ? status : (int)kSampleNone, lo, hi, loc_prev.l0.x, loc_prev.l0.y, loc_prev.l1.x, pr);
     gather_issue(P, have_cur ? (int)(loc_cur.tag >> 32) & 0xff : (int)kSampleNone, (uint32_t)loc_cur.tag, lo, hi);
     fast_load_ray(P, have_cur ? idx_cur : last, ray_cur);
     const FastRay rec = ray_prev;
@@ -2834,7 +2834,7 @@ __global__ void __launch_bounds__(256, BL_FAST_WAVES) bl_shade_fused_kernel(cons
     const double kt = P.ray_kt[live ? ray : 0u], momentum_factor = P.ray_factor[live ? ray : 0u];
     const size_t row = (size_t)P.ray_offset[live ? ray : 0u] + n;
     float pr[8];
-    gather_finish(P, fast_table, status, lo, hi, loc_prev.f_i, loc_prev.f_j, loc_prev.f_k, pr);
+    gather_finish(P, (float)fast_table[42], (float)fast_table[43], status, lo, hi, loc_prev.f_i, loc_prev.f_j, loc_prev.f_k, pr);
     gathers_local += (live && status == kSampleInterp) ? 1ull : 0ull;
     gather_issue(P, (int)loc_cur.status, loc_cur.cell, lo, hi);
     double2 cold_cur0, cold_cur1;
@@ -2968,6 +2968,122 @@ __global__ void __launch_bounds__(256) bl_transfer_freq_kernel(BlTransferArgs P)
   }
 }
 #pragma clang fp contract(off)
+
+// ---- the exact tier's coefficient kernel for the benchmark's case (plain image of a spherical Kerr-Schild simulation in a
+// curved spacetime, thermal electrons): bl_shade_kernel<simulation, false, false, true, false, kSpinZero>'s arithmetic, call for
+// call, behind bl_shade_fast_kernel's software pipeline - located sample of `next` loading, corner cells and record of `cur`
+// requested, trilinear read and arithmetic of `prev` - with every load of the loop unconditional so that the waits are
+// exact. The unpipelined kernel waited for memory in 44 % of its wave cycles. No arithmetic changes: bit-identical.
+template <bool kSpinZero>
+__global__ void __launch_bounds__(256, 2) bl_shade_exact_kernel(const BlShadeArgs P) {
+  const BlSpacetime st = P.st;
+  // (record indices as 32-bit numbers: a scratch set holds fewer than 2^32 records, bl_render sees to that)
+  const uint32_t n_records = (uint32_t)P.counters_in[BL_CNT_RECORDS];
+  const uint32_t stride = gridDim.x * blockDim.x;
+  uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;   // record of `next`
+  if (n_records == 0u) return;
+  const float fallback_rho = P.cold->fallback_rho, fallback_pgas = P.cold->fallback_pgas;
+  const uint32_t last = n_records - 1u;
+  struct Located {
+    double2 l0, l1;   // f_i, f_j | f_k, unwrapped azimuth
+    unsigned long long tag;
+  };
+  auto load_located = [&](uint32_t at, Located &r) {
+    const double2 *loc = reinterpret_cast<const double2 *>(P.located + at);
+    r.l0 = loc[0];
+    r.l1 = loc[1];
+    r.tag = P.located_tag[at];
+  };
+  Located loc_prev, loc_cur, loc_next;
+  FastRay ray_prev, ray_cur;
+  float4 lo[8], hi[8];
+  uint32_t idx_prev = 0u, idx_cur = 0u;
+  bool have_prev = false, have_cur = false, have_next = idx < n_records;
+  loc_prev.tag = loc_cur.tag = 0ull;
+  loc_prev.l0 = loc_prev.l1 = loc_cur.l0 = loc_cur.l1 = make_double2(0.0, 0.0);
+  ray_prev.q0 = ray_prev.q1 = ray_prev.q2 = ray_prev.q3 = make_double2(0.0, 0.0);
+  ray_prev.q1.y = __longlong_as_double((long long)BL_DEAD_RAY);
+#pragma unroll
+  for (int c = 0; c < 8; c++) lo[c] = hi[c] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  load_located(have_next ? idx : last, loc_next);
+  while (have_prev || have_cur || have_next) {
+    const uint32_t ray = have_prev ? (uint32_t)__double_as_longlong(ray_prev.q1.y) : BL_DEAD_RAY;
+    const bool live = ray != BL_DEAD_RAY;
+    const uint32_t n = (uint32_t)(((unsigned long long)__double_as_longlong(ray_prev.q1.y)) >> 32);
+    // (a dead slot has tag 0 = kSampleNone from the locate kernel; a stage without a sample reads the last record's slot)
+    const int status = live ? (int)(loc_prev.tag >> 32) : (int)kSampleNone;
+    // per-ray constants of `prev`: requested before the next sample's cells
+    const double kt = P.ray_kt[live ? ray : 0u], momentum_factor = P.ray_factor[live ? ray : 0u];
+    const uint32_t row = (uint32_t)P.ray_offset[live ? ray : 0u] + n;   // (rows are record counts: 32 bits as well)
+    float pr[8];
+    gather_finish(P, fallback_rho, fallback_pgas, status, lo, hi, loc_prev.l0.x, loc_prev.l0.y, loc_prev.l1.x, pr);
+    gather_issue(P, have_cur ? (int)(loc_cur.tag >> 32) : (int)kSampleNone, (uint32_t)loc_cur.tag, lo, hi);
+    fast_load_ray(P, have_cur ? idx_cur : last, ray_cur);
+    const FastRay rec = ray_prev;
+    const double ph = loc_prev.l1.y;
+    const uint32_t idx_rec = idx_prev;
+    loc_prev = loc_cur;
+    ray_prev = ray_cur;
+    idx_prev = idx_cur;
+    have_prev = have_cur;
+    loc_cur = loc_next;
+    idx_cur = idx;
+    have_cur = have_next;
+    have_next = have_next && n_records > stride && idx < n_records - stride;   // (compared before the addition: no wrap-around)
+    idx += stride;
+    // (with spin the arithmetic below needs the ten registers of the located sample in flight: requested behind it instead)
+    if (kSpinZero) load_located(have_next ? idx : last, loc_next);
+    if (live) {
+    // ---- from here on: bl_shade_kernel's body for this instantiation
+    const double x1 = rec.q0.x, x2 = rec.q0.y, x3 = rec.q1.x;
+    const double delta_lambda = -rec.q3.y;   // ReverseGeodesics: sample_len = -geodesic_len (:840)
+    double kcov[4] = {kt, rec.q2.x, rec.q2.y, rec.q3.x};
+    BlKerrSchild ks;
+    bl_kerr_schild<kSpinZero>(st, x1, x2, x3, &ks);
+    if (!P.samples_renormalised) {   // per-sample renormalisation of the stored momentum (geodesics.cpp:352-371)
+      double gcon[4][4];
+      bl_gcon_ks(ks, gcon);
+      double factor = bl_renormalization_factor_g(gcon, kcov[0], kcov[1], kcov[2], kcov[3]);
+      kcov[1] *= factor;
+      kcov[2] *= factor;
+      kcov[3] *= factor;
+    }
+    SampleShade sh;
+    sh.have_coefficients = false;
+    sh.nu_fluid_over_nu = 0.0;
+    sh.n_e_cgs = sh.nu_c_cgs = sh.theta_e = sh.sin_theta_b = sh.kb_tt_e_cgs = 0.0;
+    sh.cos_theta_b = sh.sin2_theta_b = sh.cos2_theta_b = 0.0;
+    sh.cos_sign = 1.0;
+    sh.n_n0_fluid = 0.0;
+    sh.fu[0] = sh.fu[1] = sh.fu[2] = sh.fu[3] = 0.0;
+    sh.have_cell = false;
+    if (status != kSampleCut) sample_finish_simulation<false, true>(P, st, ks, x3 / ks.r, ph, pr, 0.0f, kcov, 1, &sh, nullptr);
+    double2 *out = P.transfer + (size_t)row * P.n_nu;
+    if (P.coef_split) {
+      // several frequencies: the per-frequency formulas and transfer records are bl_coefficients_freq_kernel's
+      BlCoefInputs ci;
+      ci.nu_fluid_over_nu = sh.nu_fluid_over_nu;
+      ci.n_e_cgs = sh.n_e_cgs;
+      ci.nu_c_cgs = sh.nu_c_cgs;
+      ci.theta_e = sh.theta_e;
+      ci.kb_tt_e_cgs = sh.kb_tt_e_cgs;
+      ci.cos2_theta_b = sh.sin_theta_b;   // (sin theta_B itself: nothing there needs the cosine)
+      ci.cos_sign = delta_lambda;
+      ci.have_coefficients = sh.have_coefficients ? 1.0 : 0.0;
+      P.coef_inputs[idx_rec] = ci;
+    } else {
+      for (int l = 0; l < P.n_nu; l++) {
+        const double freq = P.frequencies[l];
+        double j_val = 0.0, alpha_val = 0.0;
+        if (sh.have_coefficients) simulation_coefficients<false>(P, sh, freq, momentum_factor, &j_val, &alpha_val);
+        const double delta_lambda_cgs = bl_div_g(delta_lambda * P.x_unit, freq * momentum_factor);   // unpolarized.cpp:75-76
+        out[l] = transfer_record(j_val, alpha_val, delta_lambda_cgs);
+      }
+    }
+    }
+    if (!kSpinZero) load_located(have_next ? idx : last, loc_next);
+  }
+}
 
 // =================================================================================================
 // Polarized coefficient kernel: the per-frequency part of CalculateSimulationCoefficients (simulation_coefficients.cpp:
@@ -3476,6 +3592,10 @@ extern "C" hipError_t bl_launch_shade(const BlShadeArgs *args, int model, int gr
     else if (aux && power) BL_LAUNCH_S(BL_MODEL_SIMULATION, true, true);
     else if (aux) BL_LAUNCH_S(BL_MODEL_SIMULATION, true, false);
     else if (power) BL_LAUNCH_S(BL_MODEL_SIMULATION, false, true);
+    else if (sks_curved && std::getenv("BLACKLIGHT_AMD_UNPIPELINED_SHADE") == nullptr) {   // the benchmark's case: the software-pipelined kernel
+      if (spin_zero) hipLaunchKernelGGL((bl_shade_exact_kernel<true>), dim3(grid), dim3(256), 0, stream, *args);
+      else hipLaunchKernelGGL((bl_shade_exact_kernel<false>), dim3(grid), dim3(256), 0, stream, *args);
+    }
     else if (sks_curved && spin_zero) hipLaunchKernelGGL((bl_shade_kernel<BL_MODEL_SIMULATION, false, false, true, false, true>), dim3(grid), dim3(256), 0, stream, *args);
     else if (sks_curved) hipLaunchKernelGGL((bl_shade_kernel<BL_MODEL_SIMULATION, false, false, true, false, false>), dim3(grid), dim3(256), 0, stream, *args);
     else BL_LAUNCH_S(BL_MODEL_SIMULATION, false, false);

@@ -283,6 +283,7 @@ void PlanScratch(RenderJob &job) {
   const long long gate = static_cast<long long>(capacity) - grid * BL_RECORD_BLOCK;
   if (gate < job.max_steps)
     throw Failure{BL_E_ARG, "Scratch budget too small: the sample records of a single ray (ray_max_steps of them) do not fit (bl_set_scratch_limit)."};
+  if (capacity >= (1ull << 32)) capacity = (1ull << 32) - 1;   // (kernels may index a scratch set's records with 32 bits)
   job.record_capacity = static_cast<size_t>(capacity);
   job.record_gate = gate;
   job.geo_grid = static_cast<int>(grid);

@@ -82,8 +82,13 @@ def assemble(parts, resolution, tile=TILE):
     return image
 
 
+class RankError(RuntimeError):
+    """A rank's render failed: raised on EVERY rank (the others would otherwise block in the next collective until the
+    backend's timeout), with the failing ranks' messages."""
+
+
 class Comm:
-    """The three collectives of the protocol on torch.distributed's default group. `device`: where the tensors that
+    """The collectives of the protocol on torch.distributed's default group. `device`: where the tensors that
     travel live - the rank's GPU for nccl (RCCL over xGMI), the CPU for gloo."""
 
     def __init__(self, device=None):
@@ -95,15 +100,25 @@ class Comm:
             device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
         self.device = device
 
-    def gather_columns(self, local, n_padded):
-        """local: numpy (rows, n_local). Rank 0 gets the list of every rank's (rows, n_padded) array (zero padded)."""
-        torch = self.torch
-        rows = local.shape[0]
-        buf = torch.zeros((rows, n_padded), dtype=torch.from_numpy(local[:0].copy()).dtype, device=self.device)
-        if local.shape[1]:
-            buf[:, : local.shape[1]] = torch.from_numpy(np.ascontiguousarray(local)).to(self.device)
-        parts = gather_rows(buf, dst=0)
-        return None if parts is None else [p.cpu().numpy() for p in parts]
+    @property
+    def on_gpu(self):
+        return self.device.type == "cuda"
+
+    def agree(self, error):
+        """Every rank passes its error text (None: none). If any rank failed, every rank raises RankError with all
+        the texts - before any data collective, so that nobody waits for a rank that has left."""
+        torch, dist = self.torch, self.dist
+        flag = torch.tensor([0 if error is None else 1], dtype=torch.int32, device=self.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag.item()) == 0:
+            return
+        texts = [None] * self.world
+        dist.all_gather_object(texts, error)
+        raise RankError("; ".join(f"rank {r}: {t.strip()}" for r, t in enumerate(texts) if t is not None))
+
+    def gather_flat(self, local, dst=0):
+        """local: a tensor on self.device, the same shape on every rank. Rank dst gets the list of all of them."""
+        return gather_rows(local, dst=dst)
 
     def reduce_counts(self, max_value, sum_value):
         """(max over ranks of max_value, sum over ranks of sum_value), on every rank."""
@@ -122,90 +137,124 @@ class Comm:
         n = int(count.item())
         data = torch.zeros((max(n, 1), 2), dtype=torch.int32, device=self.device)
         if self.rank == 0 and n:
-            data[:] = torch.from_numpy(np.ascontiguousarray(block_locs, dtype=np.int32)).to(self.device)
+            data[:] = torch.as_tensor(np.ascontiguousarray(block_locs, dtype=np.int32), device=self.device)
         dist.broadcast(data, src=0)
         return data.cpu().numpy()[:n].copy()
 
 
-ROW_KEYS = ("image", "sample_num", "sample_flags", "camera_pos", "camera_dir", "rendering")
+# per-pixel outputs of a level, as flat (rows x rays) buffers: name, rows per ray as a function of the context, dtype
+def _row_specs(ctx, want_camera):
+    import torch
+    specs = [("image", ctx.num_quantities, torch.float64), ("sample_num", 1, torch.int32), ("sample_flags", 1, torch.uint8)]
+    if want_camera:
+        specs += [("camera_pos", 4, torch.float64), ("camera_dir", 4, torch.float64)]
+    if ctx.num_render_images > 0:
+        specs.append(("rendering", 3 * ctx.num_render_images, torch.float64))
+    return specs
 
 
-def _as_rows(key, value):
-    """Per-pixel outputs of Context.render as (rows, n_pixels) arrays."""
-    if key in ("sample_num", "sample_flags"):
-        return value.reshape(1, -1)
+def _render_into_buffers(ctx, comm, specs, n_local, n_padded, level, pixels, blocks, want_camera):
+    """This rank's share of a level into one flat buffer per output on comm.device, each rows x n_padded long with the
+    share's rows x n_local values in front. On a GPU the library writes straight into the buffers (bl_render with device
+    pointers): nothing crosses PCIe before the gather. Returns (buffers, stats)."""
+    import torch
+    buffers = {name: torch.zeros(rows * n_padded, dtype=dtype, device=comm.device) for name, rows, dtype in specs}
+    if n_local == 0:
+        return buffers, None
+    if comm.on_gpu and hasattr(ctx, "render_device"):
+        ptr = {name: buffers[name].data_ptr() for name in buffers}
+        stats = ctx.render_device(ptr["image"], n_local, level=level, pixel_map=pixels, block_locs=blocks,
+                                  sample_num_ptr=ptr["sample_num"], sample_flags_ptr=ptr["sample_flags"],
+                                  camera_pos_ptr=ptr.get("camera_pos", 0), camera_dir_ptr=ptr.get("camera_dir", 0),
+                                  render_ptr=ptr.get("rendering", 0))
+        return buffers, stats
+    out = ctx.render(level=level, block_locs=blocks, pixel_map=pixels, want_camera=want_camera)
+    for name, rows, dtype in specs:
+        value = out[name]
+        # the library's layouts: image / rendering rows x rays, camera rows rays x 4, counts and flags one row
+        flat = torch.from_numpy(np.ascontiguousarray(value).reshape(-1))
+        buffers[name][: flat.numel()] = flat
+    return buffers, out["stats"]
+
+
+def _level_layout(key, flat, n_local):
+    """A share's flat values as (rows, n_local) with rays along the columns."""
     if key in ("camera_pos", "camera_dir"):
-        return np.ascontiguousarray(value.T)                       # (n, 4) -> (4, n)
-    if key == "rendering":
-        return value.reshape(-1, value.shape[-1])                   # (n_images, 3, n) -> (3 n_images, n)
-    return value
-
-
-def _from_rows(key, rows, like):
-    if key in ("sample_num", "sample_flags"):
-        return rows[0]
-    if key in ("camera_pos", "camera_dir"):
-        return np.ascontiguousarray(rows.T)
-    if key == "rendering":
-        return rows.reshape(like.shape[0], 3, -1)
-    return rows
+        return flat[: 4 * n_local].reshape(n_local, 4).T          # the library writes rays x 4
+    rows = flat.size // max(n_local, 1) if n_local else 0
+    return flat.reshape(rows, n_local) if n_local else flat.reshape(0, 0)
 
 
 def render_level(ctx, comm, level=0, block_locs=None, want_camera=False, tile=None):
     """One adaptive level over all ranks. Level 0: the camera in tiles (tile_pixels); refined levels: blocks
     rank, rank + world, ... of `block_locs`. Returns on rank 0 the dict Context.render returns for the whole level
     (image, sample_num, sample_flags, camera rows, rendering) plus max_sample_num / n_flagged of the level; None on
-    the other ranks. The per-rank "geodesics terminate unexpectedly" warnings are replaced by one with the level's totals."""
+    the other ranks. The per-rank "geodesics terminate unexpectedly" warnings are replaced by one with the level's totals.
+    A failure on any rank (a refusal that depends on the rank's own rays, a full record buffer, no memory) is agreed on
+    before the first data collective and raised on every rank (RankError)."""
     rank, world = comm.rank, comm.world
     bs = int(ctx.params.get("adaptive_block_size") or 1) if int(ctx.params.get("adaptive_max_level") or 0) > 0 else 1
     if level == 0:
         res = ctx.resolution
         tile = tile or default_tile(res, bs)
-        pixels = tile_pixels(res, rank, world, tile)
+        counts = [int(tile_pixels(res, r, world, tile).size) for r in range(world)]
+        pixels, blocks = tile_pixels(res, rank, world, tile), None
         n_total = res * res
         n_padded = padded_count(res, world, tile)
-        out = ctx.render(pixel_map=pixels, want_camera=want_camera) if pixels.size else None
-        n_local = int(pixels.size)
     else:
-        mine = np.ascontiguousarray(block_locs[rank::world], dtype=np.int32)
         n_blocks = int(block_locs.shape[0])
+        counts = [len(range(r, n_blocks, world)) * bs * bs for r in range(world)]
+        pixels, blocks = None, np.ascontiguousarray(block_locs[rank::world], dtype=np.int32)
         n_total = n_blocks * bs * bs
         n_padded = ((n_blocks + world - 1) // world) * bs * bs
-        out = ctx.render(level=level, block_locs=mine, want_camera=want_camera) if mine.shape[0] else None
-        n_local = int(mine.shape[0]) * bs * bs
+    n_local = counts[rank]
+    specs = _row_specs(ctx, want_camera)
+    buffers, stats, error = None, None, None
+    try:
+        buffers, stats = _render_into_buffers(ctx, comm, specs, n_local, n_padded, level, pixels, blocks, want_camera)
+    except Exception as failure:   # agreed on below: every rank raises, none is left waiting in a collective
+        error = f"{type(failure).__name__}: {failure}"
+    comm.agree(error)
     if hasattr(ctx, "clear_warnings"):
         ctx.clear_warnings()   # per-rank counts; the level's totals are reported below
-    max_num = out["stats"].max_sample_num if out is not None else 0
-    n_flagged = out["stats"].n_flagged if out is not None else 0
+    max_num = stats.max_sample_num if stats is not None else 0
+    n_flagged = stats.n_flagged if stats is not None else 0
     max_num, n_flagged = comm.reduce_counts(max_num, n_flagged)
-    # which rows exist is the same on every rank (it follows from the parameters); a rank without rays sends zeros
-    template = out if out is not None else ctx.render_template(want_camera)
     result = dict(max_sample_num=max_num, n_flagged=n_flagged, n_rays=n_total) if rank == 0 else None
-    for key in ROW_KEYS:
-        if template.get(key) is None:
-            continue
-        like = template[key]
-        rows = _as_rows(key, like)
-        if out is None:
-            rows = np.zeros((rows.shape[0], 0), dtype=rows.dtype)
-        parts = comm.gather_columns(rows[:, :n_local], n_padded)
+    for name, rows, dtype in specs:
+        parts = comm.gather_flat(buffers[name])
         if rank != 0:
             continue
-        full = np.empty((rows.shape[0], n_total), dtype=rows.dtype)
+        full = None
         for r, part in enumerate(parts):
+            host = part.cpu().numpy()          # one download per rank's share, on rank 0 only
+            share = _level_layout(name, host[: rows * counts[r]], counts[r])
+            if full is None:
+                full = np.empty((rows, n_total), dtype=host.dtype)
             if level == 0:
                 where = tile_pixels(ctx.resolution, r, world, tile).astype(np.int64)
             else:
-                blocks = np.arange(r, n_total // (bs * bs), world, dtype=np.int64)
-                where = (blocks[:, None] * (bs * bs) + np.arange(bs * bs)[None, :]).reshape(-1)
-            full[:, where] = part[:, : where.size]
-        result[key] = _from_rows(key, full, like)
+                ids = np.arange(r, n_total // (bs * bs), world, dtype=np.int64)
+                where = (ids[:, None] * (bs * bs) + np.arange(bs * bs)[None, :]).reshape(-1)
+            if where.size:
+                full[:, where] = share
+        if name in ("sample_num", "sample_flags"):
+            result[name] = full[0]
+        elif name in ("camera_pos", "camera_dir"):
+            result[name] = np.ascontiguousarray(full.T)
+        elif name == "rendering":
+            result[name] = full.reshape(ctx.num_render_images, 3, -1)
+        else:
+            result[name] = full
     if rank == 0:
         for key in ROW_KEYS:
             result.setdefault(key, None)
         if n_flagged > 0:   # geodesics.cpp:389-394, with the totals of the level
             result["warning"] = f"Warning: {n_flagged} out of {n_total} geodesics terminate unexpectedly.\n"
     return result
+
+
+ROW_KEYS = ("image", "sample_num", "sample_flags", "camera_pos", "camera_dir", "rendering")
 
 
 def render_tiled(ctx, comm, want_camera=False, tile=None):

@@ -24,6 +24,8 @@ class StubContext:
     """Stands in for blacklight_amd.Context in render_level / render_adaptive: same render() contract, images from
     stub_value, refinement decisions and the writer from a host-only context (BL_DEVICE_NONE) of the real library."""
 
+    fail_on_level = None   # a level at which render() raises (one rank's refusal: test of the error agreement)
+
     def __init__(self, params_dict):
         import blacklight_amd as bl
         self.params = bl.Params.from_dict(params_dict)
@@ -46,6 +48,8 @@ class StubContext:
 
     def render(self, level=0, block_locs=None, pixel_map=None, want_camera=False):
         res, bs = self.resolution, self.block_size
+        if self.fail_on_level == level:
+            raise RuntimeError("Error: this rank's rays reach a place the reference reads past its arrays.")
         if level == 0:
             pixels = np.arange(res * res) if pixel_map is None else np.asarray(pixel_map, dtype=np.int64)
             iu, iv, eff = pixels % res, pixels // res, res
@@ -98,7 +102,22 @@ def worker(rank, world, port, mode, params_dict, mock_args, want_camera, out_pat
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from blacklight_amd import distributed as bd
     comm = bd.Comm(device=torch.device("cpu"))
-    if mode == "stub":
+    if mode == "stub_failing":
+        # rank 1 alone fails at level 1: every rank must raise, none may be left waiting in a collective
+        ctx = StubContext(params_dict)
+        if rank == 1:
+            ctx.fail_on_level = 1
+        try:
+            bd.render_adaptive(ctx, comm, want_camera)
+            outcome = "no error"
+        except bd.RankError as failure:
+            outcome = str(failure)
+        with open(f"{out_path}.rank{rank}", "w") as f:
+            f.write(outcome)
+    elif mode == "gpu_device":
+        # one rank, nccl: the device-resident path (bl_render into torch tensors, gather on the GPU, one download)
+        pass
+    elif mode == "stub":
         ctx = StubContext(params_dict)
         levels, warnings = bd.render_adaptive(ctx, comm, want_camera)
         if rank == 0:

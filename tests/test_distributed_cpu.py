@@ -119,6 +119,17 @@ def test_adaptive_orchestration_world(tmp_path, world, built_library):
     assert str(got["warnings"]) == expected and total_flagged > 0
 
 
+def test_a_failing_rank_fails_every_rank(tmp_path, built_library):
+    """One rank's render raises at level 1 (a refusal that depends on the rank's own rays): every rank raises RankError with
+    that rank's text before the level's first data collective - nobody hangs until the backend's timeout."""
+    import dist_worker
+    out_path = str(tmp_path / "outcome")
+    mp.spawn(dist_worker.worker, args=(3, _free_port(), "stub_failing", ADAPTIVE_STUB, None, False, out_path), nprocs=3, join=True)
+    for rank in range(3):
+        text = open(f"{out_path}.rank{rank}").read()
+        assert "rank 1: RuntimeError: Error: this rank's rays reach a place" in text and "rank 0" not in text and "rank 2" not in text
+
+
 def test_launcher_refuses_a_mismatched_world(tmp_path):
     """bench.py --gpus N must equal the number of ranks it was started with, and without a launcher it must not run a
     smaller job under that name: both fail before anything touches a GPU."""

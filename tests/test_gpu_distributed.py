@@ -67,3 +67,40 @@ def test_command_line_driver_over_several_devices(case, devices, built_library, 
     assert run.returncode == 0, run.stdout + run.stderr
     _assert_npz_equals_golden(np.load(params["output_file"]), fx)
     assert run.stderr == str(fx["B_warnings"])
+
+
+def _device_path_worker(rank, port, params, mock_args, out_path):
+    """One rank over nccl (RCCL): the product path of a multi-GPU run - bl_render into torch tensors in HBM, gather on the
+    device, one download on rank 0 - must give what the plain single-GPU loop gives."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    import blacklight_amd as bl
+    from blacklight_amd import distributed as bd
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    comm = bd.Comm()
+    assert comm.on_gpu
+    with bl.Context(bl.Params.from_dict(params), device=0) as ctx:
+        if mock_args is not None:
+            ctx.set_grid(gu.golden_grid(mock_args))
+        levels = ctx.render_adaptive(want_camera=True, distributed=True, comm=comm)
+        plain = ctx.render_adaptive(want_camera=True)
+        assert len(levels) == len(plain)
+        for got, want in zip(levels, plain):
+            for key in ("image", "sample_num", "sample_flags", "camera_pos", "camera_dir", "rendering"):
+                if want.get(key) is None:
+                    assert got.get(key) is None
+                else:
+                    assert gu.same_bits(np.asarray(got[key], dtype=np.float64), np.asarray(want[key], dtype=np.float64)).all(), key
+        ctx.write_output(levels, path=out_path)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", ["sim_adaptive", "sim_polarized_adaptive", "sim_render_light"])
+def test_device_resident_gather_over_rccl(case, built_library, tmp_path):
+    fx, params, mock_args = gu.load_case(case)
+    out_path = str(tmp_path / "out.npz")
+    mp.spawn(_device_path_worker, args=(_free_port(), params, mock_args, out_path), nprocs=1, join=True)
+    _assert_npz_equals_golden(np.load(out_path), fx)
