@@ -89,12 +89,30 @@ def cpu_baseline(params_dict, grid, resolution, stride):
     return pixels, out, cores
 
 
+def visible_gpus():
+    """GPUs of this box as the kernel driver lists them (KFD topology nodes with SIMDs), without initialising HIP or importing
+    torch in the launching process: 0 without the driver, None when the topology is there but cannot be read (the ranks
+    themselves then report a shortfall)."""
+    nodes = "/sys/class/kfd/kfd/topology/nodes"
+    if not os.path.isdir(nodes):
+        return 0
+    try:
+        count = 0
+        for node in os.listdir(nodes):
+            with open(os.path.join(nodes, node, "properties")) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            if int(props.get("simd_count", "0")) > 0:
+                count += 1
+        return count
+    except OSError:
+        return None
+
+
 def launch_ranks(n_gpus, argv):
-    """`python bench.py --gpus N` without a launcher: start torch.distributed.run as a CHILD process (this process has
-    not touched the GPU and never will) and return its exit code. torch.cuda.device_count() does not initialise HIP."""
-    import torch
-    visible = torch.cuda.device_count()
-    if visible < n_gpus:
+    """`python bench.py --gpus N` without a launcher: start torch.distributed.run as a CHILD process and return its exit
+    code. The launching process neither imports torch nor touches HIP: it holds no GPU context while the ranks run."""
+    visible = visible_gpus()
+    if visible is not None and visible < n_gpus:
         raise SystemExit(f"bench.py --gpus {n_gpus}: only {visible} GPU(s) visible on this box - refusing to run a smaller job "
                          "under that name")
     with socket.socket() as sock:
@@ -103,6 +121,19 @@ def launch_ranks(n_gpus, argv):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + argv
     return subprocess.call(cmd)
+
+
+def kernel_source_hash():
+    """Hash of the sources the library is built from (blacklight_amd/csrc): profiles/hbm_traffic.json carries the hash of
+    the tree its counters were measured on, and the bench line says when the two differ."""
+    import hashlib
+    csrc = os.path.join(REPO, "blacklight_amd", "csrc")
+    digest = hashlib.sha256()
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".h", ".inc", ".cpp")):
+            with open(os.path.join(csrc, name), "rb") as f:
+                digest.update(name.encode() + b"\0" + f.read())
+    return digest.hexdigest()[:16]
 
 
 def main():
@@ -244,7 +275,7 @@ def main():
         ms_per_step = 1000.0 * elapsed / args.steps
         value = total_rays / (elapsed / args.steps) / 1.0e6
         achieved = main_run["bytes_per_launch"] / (main_run["shade_ms_per_launch"] * 1.0e-3) / 1.0e9
-        traffic, traffic_source = None, None
+        traffic, traffic_source, traffic_stale = None, None, None
         traffic_file = os.path.join(REPO, "profiles", "hbm_traffic.json")
         if os.path.exists(traffic_file) and not distributed:
             with open(traffic_file) as f:
@@ -252,6 +283,7 @@ def main():
             entry = recorded.get(main_run["tier_ran"], {})
             traffic = entry.get("coefficient_kernel_bytes_per_launch")
             traffic_source = entry.get("source")
+            traffic_stale = recorded.get("csrc_sha256_16") != kernel_source_hash()
         tier_text = {"tolerant": "tolerant arithmetic tier (intensities within north_star's fp64 tolerance, counts / flags / cuts bit-exact)",
                      "exact": "exact arithmetic tier (bit-identical to the reference with the pinned math library)"}
         line = {
@@ -278,7 +310,7 @@ def main():
             "hbm_gbs_algorithmic_whole_pipeline": (256.0 * total_gathers + 13.0 * total_rays) / (elapsed / args.steps) / 1.0e9,
             "roofline": {"bound": "hbm", "kernel": "bl_shade_fast_kernel" if main_run["tier_ran"] == "tolerant" else "bl_shade_kernel",
                          "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source, "traffic_stale": traffic_stale,
                          "algorithmic_bytes_per_launch": main_run["bytes_per_launch"], "ms_per_launch": main_run["shade_ms_per_launch"]},
         }
         if exact_run is not None:

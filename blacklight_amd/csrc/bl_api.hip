@@ -119,14 +119,15 @@ void ValidateRadiation(bl_ctx *ctx) {
     Require(p, {BL_P_checkpoint_sample_save, BL_P_checkpoint_sample_load}, kRadMissing);
     if (p.checkpoint_sample_save && p.checkpoint_sample_load)
       throw Failure{BL_E_INPUT, "Cannot both save and load a sample checkpoint."};
-    if (p.checkpoint_sample_save || p.checkpoint_sample_load)
+    if (p.checkpoint_sample_save || p.checkpoint_sample_load) Require(p, {BL_P_checkpoint_sample_file}, kRadMissing);
+    if (p.checkpoint_sample_load)
       // The reference cannot read these files itself: LoadSampling() (sample_checkpoint.cpp:49-63) restores sample_inds,
       // sample_fracs, sample_nan and sample_fallback but not sample_cut, which only CalculateSimulationSampling() allocates
       // (simulation_sampling.cpp:155) and SampleSimulation() reads for every sample (:691) - the reference binary built
-      // from /root/reference ends in a segmentation fault on checkpoint_sample_load = true. A file nobody can read back has
-      // no defined result to match, so neither direction is offered; geodesic checkpoints are (LoadGeodesicCheckpoint).
-      throw Failure{BL_E_UNSUPPORTED, "Sample checkpoints are not offered: the reference cannot load them (its LoadSampling() "
-                                      "leaves sample_cut unallocated); use geodesic checkpoints."};
+      // from /root/reference ends in a segmentation fault on checkpoint_sample_load = true. Loading has no defined result to
+      // match and is refused; saving writes the reference's file (bl_render.hip, WriteSampleCheckpoint).
+      throw Failure{BL_E_UNSUPPORTED, "checkpoint_sample_load is not offered: the reference cannot load its own sample checkpoints (its "
+                                      "LoadSampling() leaves sample_cut unallocated); use geodesic checkpoints."};
     Require(p, {BL_P_simulation_format, BL_P_simulation_coord, BL_P_simulation_m_msun, BL_P_simulation_rho_cgs,
                 BL_P_simulation_interp},
             kRadMissing);
@@ -415,6 +416,8 @@ void UploadMergedGrid(bl_ctx *ctx, const bl_grid_desc *g) {
       if (block_at[at] != -1) throw Failure{BL_E_UNSUPPORTED, kIrregular};
       block_at[at] = blk;
     }
+    ctx->merged_block_at = block_at;        // (sample checkpoints name cells by MeshBlock and block-local indices)
+    for (int a = 0; a < 3; a++) ctx->merged_blocks[a] = nbl[a];
     // global coordinate tables; every block at the same position along an axis must carry the same rows,
     // and neighbouring rows must meet bit for bit (no gaps, no overlaps)
     const int n_i = nbl[0] * nb_cells[0], n_j = nbl[1] * nb_cells[1], n_k = nbl[2] * nb_cells[2];

@@ -136,6 +136,9 @@ struct bl_ctx {
   DeviceBuffer<int> d_block_table;                  // inter-block interpolation: levels, locations, hash blocks
   DeviceBuffer<unsigned long long> d_block_keys;    // ... and hash keys
   BlGridDevice grid_dev{};
+  std::vector<int> merged_block_at;   // merged grid: lattice position (k, j, i of the block) -> MeshBlock of the file
+  int merged_blocks[3] = {1, 1, 1};   // ... and the lattice's extent
+  bool sample_checkpoint_saved = false;   // checkpoint_sample_save: written with the first image only (radiation_integrator.cpp:699-704)
   int lds_table_bytes = 0;
   DeviceBuffer<float> *cells_target = nullptr, *kappa_target = nullptr;   // where the grid upload puts the cells
 

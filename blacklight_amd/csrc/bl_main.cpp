@@ -346,30 +346,40 @@ int main(int argc, char *argv[]) {
           if (sh.stats.ms_total > st.ms_total) {
             st.ms_total = sh.stats.ms_total;
             st.ms_geodesic = sh.stats.ms_geodesic;
+            st.ms_locate = sh.stats.ms_locate;
             st.ms_shade = sh.stats.ms_shade;
             st.ms_transfer = sh.stats.ms_transfer;
           }
           st.n_flagged += sh.stats.n_flagged;
+          st.n_undefined += sh.stats.n_undefined;
           st.max_sample_num = std::max(st.max_sample_num, sh.stats.max_sample_num);
         }
-        // one warning with the level's totals, in the reference's words (geodesics.cpp:389-394), instead of one per device
+        // Warnings of the level: the two that carry counts are rebuilt from the devices' totals - the reference's about
+        // geodesics that end unexpectedly (geodesics.cpp:389-394) and the library's about samples where the reference reads
+        // past its arrays - every other line is taken from whichever devices raised it, once
         std::string others;
         for (int dev = 0; dev < n_devices; dev++) {
           std::istringstream lines(bl_warnings(contexts[dev]));
           std::string line;
-          while (std::getline(lines, line))
-            if (line.find("geodesics terminate unexpectedly") == std::string::npos && dev == 0) others += line + "\n";
+          while (std::getline(lines, line)) {
+            if (line.find("geodesics terminate unexpectedly") != std::string::npos) continue;
+            if (line.find("samples lie where the reference reads past its arrays") != std::string::npos) continue;
+            if (others.find(line + "\n") == std::string::npos) others += line + "\n";
+          }
           bl_warnings_clear(contexts[dev]);
         }
         if (st.n_flagged > 0)
           shared_warnings += "Warning: " + std::to_string(st.n_flagged) + " out of " + std::to_string(n_rays) + " geodesics terminate unexpectedly.\n";
+        if (st.n_undefined > 0)
+          shared_warnings += "Warning: " + std::to_string(st.n_undefined) + " samples lie where the reference reads past its arrays; the edge cell was used for them.\n";
         shared_warnings += others;
       }
       double elapsed = Now() - t0;
       // attribute wall time to the reference's three timers in proportion to kernel time
       double kernel = st.ms_total > 0.0f ? st.ms_total : 1.0;
       time_geodesic += elapsed * st.ms_geodesic / kernel;
-      (simulation ? time_sample : time_image) += elapsed * st.ms_shade / kernel * (simulation ? 0.5 : 1.0);
+      // (simulation mode: the locate kernel and half of the coefficient kernel - the grid read - are the reference's sampling stage)
+      (simulation ? time_sample : time_image) += elapsed * (st.ms_shade * (simulation ? 0.5 : 1.0) + (simulation ? st.ms_locate : 0.0)) / kernel;
       time_image += elapsed * (st.ms_transfer + (simulation ? 0.5 * st.ms_shade : 0.0)) / kernel;
 
       if (params.adaptive_max_level <= 0) break;

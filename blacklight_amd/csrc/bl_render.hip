@@ -147,6 +147,16 @@ struct RenderJob {
   unsigned long long total_samples = 0, total_flagged = 0, total_records = 0, total_gathers = 0, total_redo = 0, total_undefined = 0, max_num = 0;
   unsigned long long debug_counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   CheckpointSave save;
+  // checkpoint_sample_save: where every kept sample of the level sits on the grid, by pixel and reversed sample index
+  bool sample_save = false;
+  struct SampleSave {
+    int per_sample = 4;                     // indices per sample: 4, or 8 x 4 with inter-block interpolation
+    std::vector<int32_t> sample_num;        // [pixel]
+    std::vector<size_t> offset;             // [pixel]: first entry of the pixel in the packed arrays below
+    std::vector<int32_t> inds;              // [sample][per_sample]
+    std::vector<double> fracs;              // [sample][3] (trilinear sampling)
+    std::vector<uint8_t> nan, fallback;     // [sample]
+  } sampling;
 };
 
 hipEvent_t *SlotEvents(RenderJob &job, int k) { return job.ctx->events.data() + static_cast<size_t>(k) * kEventsPerChunk; }
@@ -195,6 +205,10 @@ void PlanJob(RenderJob &job) {
         throw Failure{BL_E_ARG, "pixel_map names a pixel the geodesic checkpoint does not hold."};
   }
   job.block_interp = job.simulation && ctx->grid_dev.block_interp != 0;
+  // SaveSampling() (sample_checkpoint.cpp:22-46): with the first image of the root level only (radiation_integrator.cpp:693-704)
+  job.sample_save = job.simulation && p.checkpoint_sample_save && d->level == 0 && !ctx->sample_checkpoint_saved;
+  if (job.sample_save && (d->pixel_map != nullptr || job.n_rays != job.level_pixels))
+    throw Failure{BL_E_ARG, "checkpoint_sample_save needs the whole root camera in one bl_render call."};
   // Tolerant tier: plain unpolarized images of a spherical Kerr-Schild simulation with thermal electrons in a curved
   // spacetime have the fast coefficient kernel; every other configuration is rendered in exact arithmetic whatever
   // bl_set_arithmetic() asked for (bl_stats.arithmetic says which tier ran)
@@ -214,8 +228,8 @@ void PlanJob(RenderJob &job) {
   job.fused = job.fast && ctx->grid_dev.n_blocks == 0 && ctx->lds_table_bytes > 0 && !ctx->grid_dev.fmks && p.simulation_interp
       && !(p.cut_omit_near || p.cut_omit_far || p.cut_omit_in >= 0.0 || p.cut_omit_out >= 0.0 || p.cut_midplane_theta != 0.0 || p.cut_midplane_z != 0.0 || p.cut_plane)
       && static_cast<size_t>(ctx->lds_table_bytes) + (44 + 5 * static_cast<size_t>(job.n_nu)) * sizeof(double) <= 60u * 1024u
-      && std::getenv("BLACKLIGHT_AMD_NO_FUSED_LOCATE") == nullptr;
-  job.interleaved = (job.fused || !job.simulation) && !job.geo_load && !job.geo_save && std::getenv("BLACKLIGHT_AMD_SPLIT_RECORDS") == nullptr;
+      && !job.sample_save && std::getenv("BLACKLIGHT_AMD_NO_FUSED_LOCATE") == nullptr;   // (a sample checkpoint is made of the located samples)
+  job.interleaved = (job.fused || !job.simulation) && !job.geo_load && !job.geo_save && !job.sample_save && std::getenv("BLACKLIGHT_AMD_SPLIT_RECORDS") == nullptr;
   // ... and in the exact coefficient kernel (plain images): the frequency loop as lanes of bl_coefficients_freq_kernel
   job.coef_split = !job.fast && job.simulation && !job.aux && !ctx->polarized && job.n_nu >= 4;
   // (polarized runs list the samples without coefficients there - cut samples, cut cells - which are many more)
@@ -1012,6 +1026,138 @@ void WriteGeodesicCheckpoint(RenderJob &job) {
   if (!out) throw Failure{BL_E_INPUT, "Could not write geodesic checkpoint file."};
 }
 
+// SaveSampling(), first half: a chunk's located samples, while its scratch set still holds them, as the reference keeps them -
+// sample_inds (MeshBlock, k, j, i of the nearest cell or of the lower corner; eight of them with inter-block interpolation),
+// sample_fracs (f_k, f_j, f_i), sample_nan, sample_fallback (simulation_sampling.cpp:205-216, :377-384, :427-549) - by pixel
+// and by the reversed sample index of ReverseGeodesics.
+void SaveChunkSampling(RenderJob &job, int k, long long begin, int rays) {
+  bl_ctx *ctx = job.ctx;
+  const bl_params &p = ctx->params;
+  bl_ctx::ChunkSlot &sl = ctx->slot[k];
+  RenderJob::SampleSave &out = job.sampling;
+  const BlGridDevice &g = ctx->grid_dev;
+  unsigned long long n_written = 0;
+  Check(hipMemcpy(&n_written, sl.d_counters.ptr + BL_CNT_RECORDS, sizeof n_written, hipMemcpyDeviceToHost), "checkpoint download");
+  const size_t stride = static_cast<size_t>(job.interleaved ? 2 : 1);
+  std::vector<BlSampleHot> hot(n_written * stride);
+  std::vector<BlLocated> located(n_written);
+  std::vector<unsigned long long> tags(n_written);
+  std::vector<unsigned int> anchors(job.block_interp ? n_written * 8 : 0);
+  std::vector<int> ray_num(rays);
+  std::vector<unsigned char> ray_flags(rays);
+  std::vector<long long> ray_out(rays);
+  if (n_written > 0) {
+    Check(hipMemcpy(hot.data(), sl.d_records_hot.ptr, hot.size() * sizeof(BlSampleHot), hipMemcpyDeviceToHost), "checkpoint download");
+    Check(hipMemcpy(located.data(), sl.d_located.ptr, n_written * sizeof(BlLocated), hipMemcpyDeviceToHost), "checkpoint download");
+    if (!job.fast) Check(hipMemcpy(tags.data(), sl.d_located_tag.ptr, n_written * sizeof(unsigned long long), hipMemcpyDeviceToHost), "checkpoint download");
+    if (job.block_interp) Check(hipMemcpy(anchors.data(), sl.d_anchors.ptr, anchors.size() * sizeof(unsigned int), hipMemcpyDeviceToHost), "checkpoint download");
+  }
+  Check(hipMemcpy(ray_num.data(), ctx->d_ray_sample_num.ptr + begin, rays * sizeof(int), hipMemcpyDeviceToHost), "checkpoint download");
+  Check(hipMemcpy(ray_flags.data(), ctx->d_ray_flags.ptr + begin, rays, hipMemcpyDeviceToHost), "checkpoint download");
+  Check(hipMemcpy(ray_out.data(), ctx->d_ray_out_index.ptr + begin, rays * sizeof(long long), hipMemcpyDeviceToHost), "checkpoint download");
+  if (out.sample_num.empty()) {
+    out.per_sample = job.block_interp ? 32 : 4;
+    out.sample_num.assign(job.n_rays, 0);
+    out.offset.assign(job.n_rays, 0);
+  }
+  std::vector<size_t> slot_offset(rays);
+  for (int q = 0; q < rays; q++) {
+    const size_t m = static_cast<size_t>(ray_out[q]);
+    const size_t num = static_cast<size_t>(ray_num[q]);
+    out.sample_num[m] = ray_num[q];
+    out.offset[m] = slot_offset[q] = out.nan.size();
+    out.inds.resize(out.inds.size() + num * out.per_sample, 0);
+    if (p.simulation_interp) out.fracs.resize(out.fracs.size() + num * 3, 0.0);
+    out.nan.resize(out.nan.size() + num, 0);
+    out.fallback.resize(out.fallback.size() + num, 0);
+  }
+  // a cell of the HBM arrays as the reference names it: MeshBlock of the file, then k, j, i inside the block
+  const size_t block_cells = static_cast<size_t>(g.nb[0]) * g.nb[1] * g.nb[2];
+  auto name_cell = [&](unsigned int cell, int32_t *dst) {
+    if (g.n_blocks > 0) {   // cells kept by MeshBlock
+      const size_t b = cell / block_cells, rest = cell % block_cells;
+      dst[0] = static_cast<int32_t>(b);
+      dst[1] = static_cast<int32_t>(rest / g.stride_plane);
+      dst[2] = static_cast<int32_t>(rest % g.stride_plane / g.stride_row);
+      dst[3] = static_cast<int32_t>(rest % g.stride_row);
+    } else {                // equal blocks merged into one array (one block: itself)
+      const int i = static_cast<int>(cell % g.n[0]), j = static_cast<int>(cell / g.n[0] % g.n[1]), kk = static_cast<int>(cell / (static_cast<size_t>(g.n[0]) * g.n[1]));
+      const int at = ((kk / g.nb[2]) * ctx->merged_blocks[1] + j / g.nb[1]) * ctx->merged_blocks[0] + i / g.nb[0];
+      dst[0] = ctx->merged_block_at.empty() ? 0 : ctx->merged_block_at[at];
+      dst[1] = kk % g.nb[2];
+      dst[2] = j % g.nb[1];
+      dst[3] = i % g.nb[0];
+    }
+  };
+  for (unsigned long long r = 0; r < n_written; r++) {
+    const BlSampleHot &h = hot[r * stride];
+    if (h.ray == BL_DEAD_RAY) continue;
+    const int num = ray_num[h.ray];
+    if (static_cast<int>(h.n) >= num) continue;
+    const size_t at = slot_offset[h.ray] + static_cast<size_t>(num - 1 - static_cast<int>(h.n));
+    if (p.fallback_nan && ray_flags[h.ray] != 0) {   // a poorly terminated geodesic samples NaN everywhere (:211-216)
+      out.nan[at] = 1;
+      continue;
+    }
+    unsigned long long tag = tags[r];
+    if (job.fast) std::memcpy(&tag, &located[r].ph, sizeof tag);   // tolerant tier: the tag rides in the azimuth's slot
+    const int status = static_cast<int>(tag >> 32) & 0xff;
+    if (status == 2) {                 // off the grid (:377-384)
+      (p.fallback_nan ? out.nan : out.fallback)[at] = 1;
+    } else if (status == 3 || status == 4) {   // nearest cell | lower corner of the trilinear stencil
+      name_cell(static_cast<unsigned int>(tag), &out.inds[at * out.per_sample]);
+    } else if (status == 6) {          // inter-block interpolation: the eight anchors (:541)
+      for (int c = 0; c < 8; c++) name_cell(anchors[r * 8 + c], &out.inds[at * out.per_sample + 4 * c]);
+    }
+    if (p.simulation_interp && (status == 4 || status == 6)) {
+      out.fracs[3 * at] = located[r].f_k;
+      out.fracs[3 * at + 1] = located[r].f_j;
+      out.fracs[3 * at + 2] = located[r].f_i;
+    }
+  }
+}
+
+// SaveSampling(), second half (sample_checkpoint.cpp:22-46): four Arrays (file_io.cpp:65-76: five int32 extents, fastest first,
+// then the data). Entries the reference never writes - beyond a pixel's samples, cut samples, samples off the grid - are
+// whatever its allocator held there; zeros here.
+void WriteSampleCheckpoint(RenderJob &job) {
+  bl_ctx *ctx = job.ctx;
+  const bl_params &p = ctx->params;
+  const RenderJob::SampleSave &sv = job.sampling;
+  std::ofstream out(p.checkpoint_sample_file.s, std::ios_base::out | std::ios_base::binary);
+  if (!out.is_open()) throw Failure{BL_E_INPUT, "Could not open sample checkpoint file."};
+  const int n_pix = static_cast<int>(job.n_rays);
+  int num_steps = 0;
+  for (int32_t num : sv.sample_num) num_steps = std::max(num_steps, static_cast<int>(num));
+  auto write_rows = [&](const auto &packed, int per_sample) {
+    using T = typename std::decay<decltype(packed)>::type::value_type;
+    std::vector<T> row(static_cast<size_t>(num_steps) * per_sample);
+    for (int m = 0; m < n_pix; m++) {
+      std::fill(row.begin(), row.end(), T(0));
+      const size_t first = sv.offset[m] * per_sample, count = static_cast<size_t>(sv.sample_num[m]) * per_sample;
+      std::copy(packed.begin() + first, packed.begin() + first + count, row.begin());
+      out.write(reinterpret_cast<const char *>(row.data()), static_cast<std::streamsize>(row.size() * sizeof(T)));
+    }
+  };
+  if (job.block_interp) {
+    const int dims[5] = {4, 8, num_steps, n_pix, 1};
+    out.write(reinterpret_cast<const char *>(dims), sizeof dims);
+  } else {
+    WriteCheckpointHeader<int32_t>(out, 4, num_steps, n_pix);
+  }
+  write_rows(sv.inds, sv.per_sample);
+  if (p.simulation_interp) {
+    WriteCheckpointHeader<double>(out, 3, num_steps, n_pix);
+    write_rows(sv.fracs, 3);
+  }
+  WriteCheckpointHeader<uint8_t>(out, num_steps, n_pix, 1);
+  write_rows(sv.nan, 1);
+  WriteCheckpointHeader<uint8_t>(out, num_steps, n_pix, 1);
+  write_rows(sv.fallback, 1);
+  if (!out) throw Failure{BL_E_INPUT, "Could not write sample checkpoint file."};
+  ctx->sample_checkpoint_saved = true;
+}
+
 // ---- a chunk, first half: the geodesic stage on stream_geo into scratch set k (the set must be free)
 void LaunchGeodesicStage(RenderJob &job, int k, long long begin, int rays, hipStream_t stream_geo) {
   bl_ctx *ctx = job.ctx;
@@ -1141,16 +1287,14 @@ void RunChunks(RenderJob &job) {
       // soon as its geodesic kernel ends, and its shading goes to the other stream without waiting for anything else.
       done = WaitGeodesicStage(job, k, stream_geo);
       LaunchShadingStage(job, k, begin + done < n_rays, stream);
-      if (job.geo_save) {
-        Check(hipStreamSynchronize(stream), "kernel execution");
-        SaveChunkRecords(job, k, begin, static_cast<int>(done));
-      }
+      if (job.geo_save || job.sample_save) Check(hipStreamSynchronize(stream), "kernel execution");
+      if (job.geo_save) SaveChunkRecords(job, k, begin, static_cast<int>(done));
+      if (job.sample_save) SaveChunkSampling(job, k, begin, static_cast<int>(done));
     } else {
       LaunchShadingStage(job, k, false, stream);
-      if (job.geo_save) {
-        Check(hipStreamSynchronize(stream), "kernel execution");
-        SaveChunkRecords(job, k, begin, static_cast<int>(WaitGeodesicStage(job, k, stream_geo)));
-      }
+      if (job.geo_save || job.sample_save) Check(hipStreamSynchronize(stream), "kernel execution");
+      if (job.geo_save) SaveChunkRecords(job, k, begin, static_cast<int>(WaitGeodesicStage(job, k, stream_geo)));
+      if (job.sample_save) SaveChunkSampling(job, k, begin, static_cast<int>(WaitGeodesicStage(job, k, stream_geo)));
       CollectChunk(job, k);
       done = job.in_flight[k].done;
     }
@@ -1275,6 +1419,7 @@ extern "C" int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
     BuildTransferArgs(job);
     RunChunks(job);
     if (job.geo_save) WriteGeodesicCheckpoint(job);
+    if (job.sample_save) WriteSampleCheckpoint(job);
     DownloadOutputs(job);
     FinishStats(job);
     if (job.slow) SlowLightMessages(job);

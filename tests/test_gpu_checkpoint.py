@@ -174,3 +174,72 @@ def test_checkpoint_subsets_and_damaged_files(built_library, expected, tmp_path)
     with _context(expected, "formula", checkpoint_geodesic_load="true", checkpoint_geodesic_file=str(tmp_path / "none")) as ctx:
         with pytest.raises(BlacklightError, match="Could not open"):
             ctx.render()
+
+
+# ---- sample checkpoints (sample_checkpoint.cpp:22-46)
+def _read_sample_checkpoint(path, interp, block_interp=False):
+    data = open(path, "rb").read()
+    out, off = {}, 0
+    for name, dtype in [("inds", "<i4")] + ([("fracs", "<f8")] if interp else []) + [("nan", "u1"), ("fallback", "u1")]:
+        dims = [int(v) for v in np.frombuffer(data[off:off + 20], dtype="<i4")]
+        off += 20
+        shape = dims[::-1]
+        while len(shape) > 1 and shape[0] == 1:
+            shape = shape[1:]
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        out[name] = np.frombuffer(data[off:off + nbytes], dtype=dtype).reshape(shape)
+        off += nbytes
+    assert off == len(data)
+    return out
+
+
+@pytest.mark.parametrize("case", ["interp", "nearest_blocks_fallback", "few_steps_nan"])
+@pytest.mark.parametrize("tier,chunked", [("exact", False), ("exact", True), ("tolerant", False)])
+def test_sample_checkpoint_holds_what_the_reference_defines(built_library, case, tier, chunked, tmp_path):
+    """checkpoint_sample_save: the file has the reference's layout and, wherever the reference defines an entry (a kept sample
+    inside camera_r and on the grid: its MeshBlock and cell indices, its trilinear fractions), the reference's value bit for
+    bit; sample_nan and sample_fallback, which the reference zeroes first, are equal throughout. The image is the one a run
+    without the checkpoint gives, and the second image of a context does not write the file again."""
+    from blacklight_amd import Context, Params
+    fx = np.load(os.path.join(READER_DIR, "expected_sample_checkpoint.npz"), allow_pickle=False)
+    params = json.loads(str(fx[f"{case}_params"]))
+    mock_args = json.loads(str(fx[f"{case}_mock_args"]))
+    path = str(tmp_path / "sample.ckpt")
+    plain_params = dict(params, checkpoint_sample_save="false")
+    with Context(Params.from_dict(plain_params)) as ctx:
+        ctx.set_grid(gu.golden_grid(mock_args))
+        ctx.set_arithmetic(tier)
+        plain = ctx.render()
+    with Context(Params.from_dict(dict(params, checkpoint_sample_file=path))) as ctx:
+        ctx.set_grid(gu.golden_grid(mock_args))
+        ctx.set_arithmetic(tier)
+        if chunked:
+            ctx.set_scratch_limit(1 << 20)
+        saved = ctx.render()
+        assert (saved["stats"].n_chunks > 1) == chunked
+        assert gu.same_bits(saved["image"], plain["image"]).all() and np.array_equal(saved["sample_num"], plain["sample_num"])
+        assert np.array_equal(saved["sample_num"], fx[f"{case}_sample_num"])
+        stamp = os.path.getmtime(path)
+        size = os.path.getsize(path)
+        ctx.render()
+        assert os.path.getmtime(path) == stamp and os.path.getsize(path) == size
+    interp = params["simulation_interp"] == "true"
+    got = _read_sample_checkpoint(path, interp)
+    m, n = fx[f"{case}_pixels"].astype(np.int64), fx[f"{case}_steps"].astype(np.int64)
+    assert got["nan"].shape == fx[f"{case}_nan"].shape and got["inds"].shape == got["nan"].shape + (4,)
+    assert np.array_equal(got["nan"], fx[f"{case}_nan"]) and np.array_equal(got["fallback"], fx[f"{case}_fallback"])
+    assert np.array_equal(got["inds"][m, n], fx[f"{case}_inds"])
+    if interp:
+        assert gu.same_bits(got["fracs"][m, n], fx[f"{case}_fracs"]).all()
+    # what the reference leaves unset is zero here: nothing beyond a pixel's samples
+    beyond = np.arange(got["nan"].shape[1])[None, :] >= fx[f"{case}_sample_num"][:, None]
+    assert not got["inds"][beyond].any() and not got["nan"][beyond].any()
+
+
+def test_sample_checkpoint_load_is_refused_with_the_reason(built_library):
+    from blacklight_amd import Context, Params, BlacklightError
+    fx = np.load(os.path.join(READER_DIR, "expected_sample_checkpoint.npz"), allow_pickle=False)
+    params = json.loads(str(fx["interp_params"]))
+    params.update(checkpoint_sample_save="false", checkpoint_sample_load="true", checkpoint_sample_file="x.ckpt")
+    with pytest.raises(BlacklightError, match="cannot load its own sample checkpoints"):
+        Context(Params.from_dict(params))

@@ -120,8 +120,12 @@ def test_context_validation_messages(bl):
     assert failing(camera_r=None) == "Error: GeodesicIntegrator unable to find all needed values in input file."
     assert failing(plasma_mu=None) == "Error: RadiationIntegrator unable to find all needed values in input file."
     assert failing(checkpoint_sample_save="true", checkpoint_sample_load="true") == "Error: Cannot both save and load a sample checkpoint."
-    # sample checkpoints: the reference segfaults reading its own file (sample_cut is never restored), so there is nothing to match
-    assert "the reference cannot load them" in failing(checkpoint_sample_save="true", checkpoint_sample_file="s.dat")
+    # sample checkpoints: saving writes the reference's file; loading is refused - the reference segfaults reading its own
+    # file (sample_cut is never restored), so there is nothing to match
+    assert "cannot load its own sample checkpoints" in failing(checkpoint_sample_load="true", checkpoint_sample_file="s.dat")
+    assert failing(checkpoint_sample_save="true", checkpoint_sample_file=None) == \
+        "Error: RadiationIntegrator unable to find all needed values in input file."
+    bl.Context(bl.Params.from_dict(dict(params, checkpoint_sample_save="true", checkpoint_sample_file="s.dat")), device=-2).close()
     assert failing(image_light="false") == "Error: No image or rendering selected."
     assert failing(adaptive_max_level=1, adaptive_block_size=5) == \
         "Error: Must have adaptive_block_size divide camera_resolution."

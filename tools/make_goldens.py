@@ -852,6 +852,107 @@ def make_checkpoint_fixtures():
     np.savez_compressed(os.path.join(out_dir, "expected_checkpoint.npz"), **expected)
 
 
+# Sample checkpoints (sample_checkpoint.cpp:22-46): the file the reference writes with checkpoint_sample_save. It holds
+# sample_inds / sample_fracs as allocated - entries beyond a pixel's samples, of cut samples and of samples off the grid are
+# whatever the allocator held - so the fixture keeps the entries the reference DEFINES (pixel, reversed sample index, values)
+# and the two flag arrays, which it zeroes, whole. Which entries are defined follows from the geodesic checkpoint of the same
+# run (sample_num, sample_pos: a sample beyond camera_r is cut, simulation_sampling.cpp:238-243) and from the flags themselves.
+SAMPLE_CHECKPOINT_CASES = {
+    "interp": (dict(camera_resolution=8, ray_step=0.05), SMALL_MOCK),
+    "nearest_blocks_fallback": (dict(camera_resolution=8, ray_step=0.05, simulation_interp="false", simulation_a=0.5, fallback_nan="false",
+                                     fallback_rho=1.0e-6, fallback_pgas=1.0e-8), dict(SMALL_MOCK, _blocks=[2, 2, 2])),
+    "few_steps_nan": (dict(camera_resolution=8, ray_step=0.05, ray_max_steps=150), SMALL_MOCK),
+}
+
+
+def read_arrays(path, dtypes):
+    data = open(path, "rb").read()
+    out, off = [], 0
+    for dtype in dtypes:
+        dims = [int(v) for v in np.frombuffer(data[off:off + 20], dtype="<i4")]
+        off += 20
+        count = int(np.prod(dims))
+        nbytes = count * np.dtype(dtype).itemsize
+        shape = [v for v in dims[::-1]]
+        while len(shape) > 1 and shape[0] == 1:
+            shape = shape[1:]
+        out.append(np.frombuffer(data[off:off + nbytes], dtype=dtype).reshape(shape).copy())
+        off += nbytes
+    assert off == len(data)
+    return out
+
+
+def make_sample_checkpoint_fixtures():
+    out_dir = os.path.join(OUT, "reader")
+    expected = {}
+    for name, (overrides, mock) in SAMPLE_CHECKPOINT_CASES.items():
+        workdir = os.path.join(WORK, "sample_checkpoint_" + name)
+        for sub in (out_dir, os.path.join(workdir, "data"), os.path.join(workdir, "output")):
+            os.makedirs(sub, exist_ok=True)
+        params = dict(SIM_BASE)
+        params.update(overrides)
+        params.update(checkpoint_geodesic_save="true", checkpoint_geodesic_file="data/geo.dat", checkpoint_sample_save="true",
+                      checkpoint_sample_file="data/sample.dat")
+        mock_path = os.path.join(workdir, "data", "mock.athdf")
+        args = [sys.executable, "-W", "ignore", MOCK_SCRIPT, mock_path]
+        for key, value in mock.items():
+            if not key.startswith("_"):
+                args += [f"--{key}", str(value)]
+        subprocess.run(args, check=True)
+        if "_blocks" in mock:
+            single = os.path.join(workdir, "data", "mock_single.athdf")
+            os.replace(mock_path, single)
+            split_into_blocks(single, mock_path, *mock["_blocks"], last=mock.get("_last"))
+        expected[f"{name}_mock_args"] = json.dumps(mock)
+        write_input(os.path.join(workdir, "case.input"), params)
+        run_reference(workdir, "case.input", True)     # pinned math library (tier B)
+        interp = params["simulation_interp"] == "true"
+        arrays = read_arrays(os.path.join(workdir, "data", "sample.dat"), ["<i4"] + (["<f8"] if interp else []) + ["u1", "u1"])
+        inds, nan, fallback = arrays[0], arrays[-2], arrays[-1]
+        with open(os.path.join(workdir, "data", "geo.dat"), "rb") as f:   # geodesic_checkpoint.cpp:36-57: seven 4-vectors, then Arrays
+            f.seek(7 * 32)
+
+            def array(dtype):
+                dims = [int(v) for v in np.frombuffer(f.read(20), dtype="<i4")]
+                shape = dims[::-1]
+                while len(shape) > 1 and shape[0] == 1:
+                    shape = shape[1:]
+                return np.frombuffer(f.read(int(np.prod(shape)) * np.dtype(dtype).itemsize), dtype=dtype).reshape(shape).copy()
+
+            for _ in range(4):
+                array("<f8")
+            f.read(4)
+            array("u1")
+            sample_num = array("<i4")
+            pos = array("<f8")
+        n_pix, n_steps = nan.shape
+        assert inds.shape[:2] == (n_pix, n_steps) and pos.shape[:2] == (n_pix, n_steps)
+        x, y, z = pos[..., 1], pos[..., 2], pos[..., 3]
+        a = float(params["simulation_a"])
+        rr2 = x * x + y * y + z * z
+        r = np.sqrt(0.5 * (rr2 - a * a + np.hypot(rr2 - a * a, 2.0 * a * z)))
+        within = np.arange(n_steps)[None, :] < sample_num[:, None]
+        camera_r = float(params["camera_r"])
+        defined = within & (r < camera_r * (1.0 - 1.0e-9)) & (nan == 0) & (fallback == 0)
+        undecided = within & (np.abs(r - camera_r) <= camera_r * 1.0e-9)
+        assert not undecided.any()
+        m_idx, n_idx = np.nonzero(defined)
+        expected[f"{name}_pixels"] = m_idx.astype(np.int32)
+        expected[f"{name}_steps"] = n_idx.astype(np.int32)
+        expected[f"{name}_inds"] = inds[m_idx, n_idx]
+        if interp:
+            expected[f"{name}_fracs"] = arrays[1][m_idx, n_idx]
+        expected[f"{name}_nan"] = nan
+        expected[f"{name}_fallback"] = fallback
+        expected[f"{name}_sample_num"] = sample_num
+        test_params = {k: v for k, v in params.items() if k not in ("checkpoint_geodesic_save", "checkpoint_geodesic_file", "checkpoint_sample_file")}
+        test_params["checkpoint_geodesic_save"] = "false"
+        expected[f"{name}_params"] = json.dumps(test_params)
+        print("sample checkpoint", name, "defined", int(defined.sum()), "of", int(within.sum()), "nan", int(nan.sum()), "fallback", int(fallback.sum()),
+              "blocks", sorted(set(inds[m_idx, n_idx][:, 0].tolist())))
+    np.savez_compressed(os.path.join(out_dir, "expected_sample_checkpoint.npz"), **expected)
+
+
 # harm3d dumps: the same, --format harm3d (one line of text, then float32 records)
 def make_harm3d_fixtures():
     import h5py
@@ -1004,6 +1105,8 @@ if __name__ == "__main__":
             make_fmks_fixtures()
         elif case_name == "checkpoint":
             make_checkpoint_fixtures()
+        elif case_name == "sample_checkpoint":
+            make_sample_checkpoint_fixtures()
         elif case_name == "harm3d":
             make_harm3d_fixtures()
         elif case_name == "slowcli":
