@@ -51,6 +51,7 @@ constexpr double kE = 4.80320425e-10;
 // the correctly rounded value (the constant is in the reference binary; 11/12 is not)
 constexpr double kPow2_11_12 = 0x1.e3437e7101343p+0;
 constexpr double kDeltaTauMax = 100.0;       // radiation_integrator.hpp:191
+constexpr long long kGateClosed = 1ll << 46;   // added to BL_CNT_COMMITTED by the first refused reservation of a chunk
 
 // Dormand-Prince RK5(4)7M tableau exactly as written in geodesics.cpp:42-72
 constexpr double kA[7][6] = {
@@ -252,7 +253,6 @@ __global__ void __launch_bounds__(64, BL_GEO_ONE_WAVE(kIntegrator, kTime, kSpinZ
   }
   s.kt = 0.0;
   long long block_next = 0, block_end = 0;   // this wave's block of record slots (wave-uniform)
-  int retry_wait = 0;                        // steps until the wave asks for rays again after a refusal (wave-uniform)
 #ifdef BL_GEO_STATS
   // per lane: step attempts, accepted steps, samples emitted; per wave (lane 0): loop iterations, emission iterations, refills,
   // lane-iterations with a ray
@@ -264,14 +264,14 @@ __global__ void __launch_bounds__(64, BL_GEO_ONE_WAVE(kIntegrator, kTime, kSpinZ
     // A ray is handed out only while the record buffers can take its worst case: the leader reserves ray_max_steps slots per
     // idle lane in BL_CNT_COMMITTED and gives back what does not fit under the gate; a finished ray gives back what it did not
     // emit. So the buffers never overflow, and a chunk is as many rays as fit them as the rays turn out (704 of 2 000 steps
-    // on the benchmark frame: one chunk where the worst case needed two). Lanes that were refused ask again a few steps
-    // later - slots come back as rays finish - and a wave with no ray left that is refused ends; the rays nobody took
-    // (BL_CNT_NEXT_RAY < chunk_rays) are the next chunk's.
+    // on the benchmark frame: one chunk where the worst case needed two). The first refusal closes the gate for the whole
+    // chunk: every wave finishes the rays it has and ends, so the chunk drains within one ray's time. (Handing out the slots
+    // that come back - two thirds of a reservation per finished ray - admits ever fewer rays per generation of rays: 30 ms
+    // per chunk boundary. The persistent grid is sized so that its first fill always fits, bl_render.hip.) The rays nobody
+    // took (BL_CNT_NEXT_RAY < chunk_rays) are the next chunk's.
     bool need = !have_ray && !exhausted;
     unsigned long long need_mask = __ballot(need);
-    if (need_mask != 0ull && retry_wait > 0 && __ballot(have_ray) != 0ull) {
-      retry_wait -= 1;
-    } else if (need_mask != 0ull) {
+    if (need_mask != 0ull) {
 #ifdef BL_GEO_STATS
       st_refill += 1;
 #endif
@@ -286,26 +286,24 @@ __global__ void __launch_bounds__(64, BL_GEO_ONE_WAVE(kIntegrator, kTime, kSpinZ
         long long refused = over > 0 ? (over + (long long)per_ray - 1) / (long long)per_ray : 0;
         refused = refused < (long long)count ? refused : (long long)count;
         admitted = count - (int)refused;
+        // the first refusal closes the gate for every wave (a large constant on the counter: every later reservation is over)
+        long long give_back = -(refused * (long long)per_ray) + ((refused > 0 && over < kGateClosed / 2) ? kGateClosed : 0);
         if (admitted > 0) {
           base = atomicAdd(&P.counters[BL_CNT_NEXT_RAY], (unsigned long long)admitted);
           long long beyond = (long long)(base + (unsigned long long)admitted) - (long long)P.chunk_rays;   // past the end of the queue
           beyond = beyond < 0 ? 0 : (beyond < (long long)admitted ? beyond : (long long)admitted);
-          refused += beyond;
+          give_back -= beyond * (long long)per_ray;
         }
-        if (refused > 0) atomicAdd(&P.counters[BL_CNT_COMMITTED], (unsigned long long)(-(refused * (long long)per_ray)));
+        if (give_back != 0) atomicAdd(&P.counters[BL_CNT_COMMITTED], (unsigned long long)give_back);
       }
       base = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(base >> 32), leader) << 32)
           | (unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)base, leader);
       admitted = __builtin_amdgcn_readlane(admitted, leader);
-      retry_wait = admitted < count ? 4 : 0;
       if (need) {
         const int rank = __popcll(need_mask & ((1ull << lane) - 1ull));
         const unsigned long long q = base + (unsigned long long)rank;
-        if (rank >= admitted) {
-          // no slots for this lane's ray now; once the queue is known to be empty there is nothing to wait for
-          if (admitted > 0 && base + (unsigned long long)admitted >= (unsigned long long)P.chunk_rays) exhausted = true;
-        } else if (q >= (unsigned long long)P.chunk_rays) {
-          exhausted = true;
+        if (rank >= admitted || q >= (unsigned long long)P.chunk_rays) {
+          exhausted = true;   // no slots for this lane's ray, or no ray left in the queue
         } else {
           have_ray = true;
           slot = (unsigned int)q;
@@ -2878,6 +2876,112 @@ __global__ void __launch_bounds__(256, BL_FAST_WAVES) bl_shade_fused_kernel(cons
   if ((threadIdx.x & 63) == 0 && gathers_local != 0ull) atomicAdd(&P.counters[BL_CNT_GATHERS], gathers_local);
 }
 
+// Tolerant tier, formula mode (formula_coefficients.cpp:62-180; BASELINE configuration 2): one sample per lane, no grid. The
+// reference finds the azimuth with atan2 and atan, takes its sine and cosine, and builds u^mu through the Boyer-Lindquist
+// metric and the Jacobian to Cartesian Kerr-Schild coordinates; with u_r = u_theta = 0 that Jacobian collapses - r (sin
+// theta sin phi) + a (sin theta cos phi) = y and r (sin theta cos phi) - a (sin theta sin phi) = x identically - to
+// u^mu = (u^t, -y u^phi, x u^phi, 0): no trigonometric function at all. Powers share one logarithm. The cut at camera_r is
+// not decided within 1e-9 of it, nor anything on the polar axis: those samples go to the exact kernel's second pass.
+__global__ void __launch_bounds__(256, 4) bl_shade_formula_fast_kernel(const BlShadeArgs P) {
+  const BlFormulaDevice fm = P.formula;
+  const double bh_m = P.st.bh_m, bh_a = P.st.bh_a, a2 = bh_a * bh_a;
+  const bool flat = P.st.ray_flat != 0;
+  const unsigned long long n_records = P.counters_in[BL_CNT_RECORDS];
+  const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+  const double r0_inv2 = 1.0 / (fm.r0 * fm.r0), h2 = fm.h * fm.h, nup_inv = 1.0 / fm.nup;
+  const double band_lo = P.cuts.camera_r * (1.0 - 1.0e-9), band_hi = P.cuts.camera_r * (1.0 + 1.0e-9);
+  unsigned long long idx = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  bool more = idx < n_records;
+  FastRay next;
+  next.q0 = next.q1 = next.q2 = next.q3 = make_double2(0.0, 0.0);
+  if (more) fast_load_ray(P, idx, next);
+  while (more) {
+    const FastRay rec = next;
+    const unsigned long long idx_rec = idx;
+    idx += stride;
+    more = idx < n_records;
+    if (more) fast_load_ray(P, idx, next);
+    const uint32_t ray = (uint32_t)__double_as_longlong(rec.q1.y);
+    if (ray == BL_DEAD_RAY) continue;
+    const uint32_t n = (uint32_t)(((unsigned long long)__double_as_longlong(rec.q1.y)) >> 32);
+    const double x = rec.q0.x, y = rec.q0.y, z = rec.q1.x;
+    double kx = rec.q2.x, ky = rec.q2.y, kz = rec.q3.x;
+    const double delta_lambda = -rec.q3.y;   // ReverseGeodesics: sample_len = -geodesic_len (geodesics.cpp:840)
+    const double kt = P.ray_kt[ray], momentum_factor = P.ray_factor[ray];
+    double2 *out = P.transfer + ((size_t)P.ray_offset[ray] + n) * P.n_nu;
+    // ---- Kerr-Schild scalars
+    const double pp2 = x * x + y * y, rr2 = pp2 + z * z;
+    const double uu = rr2 - a2, vv = 2.0 * bh_a * z;
+    const double r2 = 0.5 * (uu + bl_sqrt_g(uu * uu + vv * vv));
+    const double r_inv = fastmath::rsqrt(r2);
+    const double r = r2 * r_inv;
+    if ((r >= band_lo && r <= band_hi) || pp2 == 0.0) {   // the exact kernel decides the cut / handles the axis
+      fast_defer(P, idx_rec);
+      continue;
+    }
+    if (r > P.cuts.camera_r) {                             // formula_coefficients.cpp:72-75: j = alpha = 0
+      for (int l = 0; l < P.n_nu; l++) out[l] = make_double2(1.0, 0.0);
+      continue;
+    }
+    // ---- null-condition renormalisation of the stored momentum (geodesics.cpp:352-371)
+    if (!P.samples_renormalised) {
+      double f = 0.0, lx = 0.0, ly = 0.0, lz = 0.0;
+      if (!flat) {
+        const double ra_inv = fastmath::rcp(r2 + a2);
+        lx = (r * x + bh_a * y) * ra_inv;
+        ly = (r * y - bh_a * x) * ra_inv;
+        lz = z * r_inv;
+        f = 2.0 * bh_m * r2 * r * fastmath::rcp(r2 * r2 + a2 * z * z);
+      }
+      const double lk = lx * kx + ly * ky + lz * kz;
+      const double kk = kx * kx + ky * ky + kz * kz;
+      const double ta = kk - f * lk * lk, tb = 2.0 * kt * f * lk, tc = -(1.0 + f) * kt * kt;
+      const double td = bl_sqrt_g(tb * tb - 4.0 * ta * tc);
+      const double factor = tb < 0.0 ? (td - tb) * fastmath::rcp(2.0 * ta) : -2.0 * tc * fastmath::rcp(tb + td);
+      kx *= factor;
+      ky *= factor;
+      kz *= factor;
+    }
+    // ---- Boyer-Lindquist metric at the sample and the model's rotation law (:121-147)
+    const double cth = z * r_inv, cth2 = cth * cth, sth2 = 1.0 - cth2;
+    const double rr = bl_sqrt_g(r2 - z * z);
+    const double delta = r2 - 2.0 * bh_m * r + a2, sigma = r2 + a2 * cth2;
+    const double ds_inv = fastmath::rcp(delta * sigma);
+    const double gtt = -(1.0 + 2.0 * bh_m * r * (r2 + a2) * ds_inv);
+    const double gtph = -2.0 * bh_m * bh_a * r * ds_inv;
+    const double gphph = (sigma - 2.0 * bh_m * r) * ds_inv * fastmath::rcp(sth2);
+    const double ll = fm.l0 * fastmath::rcp(1.0 + rr) * fastmath::pow(rr, 1.0 + fm.q);
+    const double u_norm = fastmath::rsqrt(-gtt + 2.0 * gtph * ll - gphph * ll * ll);
+    const double ut = u_norm * (gtph * ll - gtt);
+    const double uph = u_norm * (gphph * ll - gtph);
+    const double nu_ratio = -(ut * kt + uph * (x * ky - y * kx));   // -u^mu k_mu with u^mu = (u^t, -y u^phi, x u^phi, 0)
+    const double n_n0 = fastmath::exp(-0.5 * (r2 * r0_inv2 + h2 * cth2));
+    // ---- per frequency (:164-179) and the transfer record (unpolarized.cpp:74-110)
+    for (int l = 0; l < P.n_nu; l++) {
+      const double freq = P.frequencies[l];
+      const double nu = nu_ratio * freq * momentum_factor;
+      const fastmath::PowBase base = fastmath::pow_base(nu * nup_inv);
+      const double nu_inv = fastmath::rcp(nu);
+      const double j_val = fm.cn0 * n_n0 * fastmath::pow_of(base, -fm.alpha) * nu_inv * nu_inv;
+      const double alpha_val = fm.a * fm.cn0 * n_n0 * fastmath::pow_of(base, -fm.beta - fm.alpha) * nu;
+      const double delta_lambda_cgs = delta_lambda * P.x_unit * fastmath::rcp(freq * momentum_factor);
+      double2 rec_out;
+      if (alpha_val > 0.0) {
+        const double delta_tau = alpha_val * delta_lambda_cgs;
+        if (delta_tau <= kDeltaTauMax) {
+          const double e1 = fastmath::expm1(-delta_tau);
+          rec_out = make_double2(1.0 + e1, -(j_val * fastmath::rcp(alpha_val)) * e1);
+        } else {
+          rec_out = make_double2(0.0, j_val * fastmath::rcp(alpha_val));
+        }
+      } else {
+        rec_out = make_double2(1.0, j_val * delta_lambda_cgs);
+      }
+      out[l] = rec_out;
+    }
+  }
+}
+
 // Several frequencies in the tolerant tier: one lane per (ray, frequency) walks the ray far -> near, builds each sample's
 // (a, c) from the sample's factors (BlFreqInputs; the lanes of one ray read the same 64 bytes) and the lane's own frequency,
 // and applies I <- a I + c at once. The per-frequency transfer records (16 bytes per sample and frequency: 1.5 TB written
@@ -3608,6 +3712,13 @@ extern "C" hipError_t bl_launch_shade(const BlShadeArgs *args, int model, int gr
 }
 
 // Tolerant tier: the fast coefficient kernel, then the exact kernel over the records it deferred
+// Tolerant tier in formula mode: the fast kernel, then the exact kernel over the records it deferred
+extern "C" hipError_t bl_launch_shade_formula_fast(const BlShadeArgs *args, int grid, hipStream_t stream) {
+  hipLaunchKernelGGL(bl_shade_formula_fast_kernel, dim3(grid), dim3(256), 0, stream, *args);
+  hipLaunchKernelGGL((bl_shade_kernel<BL_MODEL_FORMULA, false, false, false, false, false, true>), dim3(grid), dim3(256), 0, stream, *args);
+  return hipGetLastError();
+}
+
 extern "C" hipError_t bl_launch_shade_fast(const BlShadeArgs *args, int grid, hipStream_t stream) {
   if (args->located == nullptr) {   // no locate kernel ran: the fused kernel (coordinate tables in LDS behind its own table)
     const size_t lds = (44 + 5 * args->n_nu) * sizeof(double) + args->lds_table_bytes;

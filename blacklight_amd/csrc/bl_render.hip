@@ -114,6 +114,7 @@ struct RenderJob {
   bool fast = false, tolerant_polarized = false, matrix_transport = false, freq_split = false, coef_split = false;
   bool rows_only = false, fill_present = false;
   bool interleaved = false;   // sample records as one 64-byte array instead of two of 32-byte halves
+  bool fast_formula = false;   // tolerant tier in formula mode: bl_shade_formula_fast_kernel
   bool fused = false;   // tolerant tier, common grid case: the locate step runs inside the coefficient kernel (bl_shade_fused_kernel)
   int n_nu = 0, n_q = 0, max_steps = 0;
   long long n_rays = 0, level_pixels = 0;
@@ -216,6 +217,9 @@ void PlanJob(RenderJob &job) {
       && p.plasma_power_frac == 0.0 && p.plasma_kappa_frac == 0.0 && p.plasma_model != BL_PLASMA_CODE_KAPPA
       && (p.simulation_coord == BL_COORD_SKS || p.simulation_coord == BL_COORD_FMKS) && !p.ray_flat && ctx->plasma_thermal_frac != 0.0
       && job.n_nu <= 1024;   // (its LDS table holds five numbers per frequency)
+  // ... formula mode has a fast kernel of its own (plain images, no optional geometric cut)
+  job.fast_formula = ctx->arithmetic == BL_ARITH_TOLERANT && !job.simulation && !job.aux
+      && !(p.cut_omit_near || p.cut_omit_far || p.cut_omit_in >= 0.0 || p.cut_omit_out >= 0.0 || p.cut_midplane_theta != 0.0 || p.cut_midplane_z != 0.0 || p.cut_plane);
   // ... and the per-frequency coefficient kernel of polarized runs (frame, transport and coupling stay exact)
   job.tolerant_polarized = ctx->arithmetic == BL_ARITH_TOLERANT && ctx->polarized;
   // ... and transport matrices (bl_transport_matrix_kernel) instead of the ray-sequential tensor transport, in curved spacetimes
@@ -260,7 +264,7 @@ void PlanScratch(RenderJob &job) {
       + (job.coef_split ? sizeof(BlCoefInputs) : 0)
       + (job.matrix_transport ? BL_POL_MATRIX_DOUBLES * sizeof(double) : 0)
       + (job.block_interp ? 8 * sizeof(unsigned int) : 0);
-  const uint64_t per_slot_fixed = ((job.fast || ctx->polarized) ? job.redo_capacity * sizeof(unsigned long long) : 0) + BL_CNT_TOTAL * sizeof(unsigned long long);
+  const uint64_t per_slot_fixed = ((job.fast || job.fast_formula || ctx->polarized) ? job.redo_capacity * sizeof(unsigned long long) : 0) + BL_CNT_TOTAL * sizeof(unsigned long long);
   const uint64_t per_ray = (2 + (job.geo_load ? 0 : BL_RAY_START_FIELDS)) * sizeof(double) + sizeof(int) + 1 + 2 * sizeof(long long);
   // The budget is capped by what the device can actually give: 90 % of (free memory + what this context already holds
   // from earlier renders).
@@ -290,9 +294,11 @@ void PlanScratch(RenderJob &job) {
     job.n_slots = 2;
     capacity = capacity_for(2);
   }
-  // Persistent waves: every lane in flight holds ray_max_steps record slots until its ray ends, so no more lanes than
-  // half the buffer can cover (a small budget then runs few waves and still finishes rays to make room for the next).
-  const uint64_t per_wave = BL_RECORD_BLOCK + 2ull * 64ull * static_cast<uint64_t>(job.max_steps);
+  // Persistent waves: every lane in flight holds ray_max_steps record slots until its ray ends, so no more lanes than the
+  // buffer can cover at once. (A chunk still takes about capacity / samples-per-ray rays: a finished ray gives back what it
+  // did not emit and the lanes that were refused ask again. Fewer waves than that would only trace the same rays more
+  // slowly - 500 instead of 2 048 waves took the 64-frequency exact frame's geodesic stage from 37 to 183 ms.)
+  const uint64_t per_wave = BL_RECORD_BLOCK + 64ull * static_cast<uint64_t>(job.max_steps);
   const long long grid = std::max<long long>(1, std::min<long long>(max_grid, static_cast<long long>(capacity / per_wave)));
   const long long gate = static_cast<long long>(capacity) - grid * BL_RECORD_BLOCK;
   if (gate < job.max_steps)
@@ -333,7 +339,7 @@ void EnsureScratch(RenderJob &job) {
     }
     if (job.coef_split) sl.d_coef_inputs.Ensure(cap);
     if (job.block_interp) sl.d_anchors.Ensure(cap * 8);
-    if (job.fast || ctx->polarized) sl.d_redo.Ensure(job.redo_capacity);   // polarized runs: the samples whose frame bl_polarized_frame_kernel builds
+    if (job.fast || job.fast_formula || ctx->polarized) sl.d_redo.Ensure(job.redo_capacity);   // polarized runs: the samples whose frame bl_polarized_frame_kernel builds
   }
   const size_t n_rays = static_cast<size_t>(job.n_rays);
   ctx->d_ray_kt.Ensure(n_rays);
@@ -709,7 +715,7 @@ void BuildShadeArgs(RenderJob &job) {
   sa.tag_in_record = job.fast ? 1 : 0;
   sa.freq_split = job.freq_split ? 1 : 0;
   sa.coef_split = job.coef_split ? 1 : 0;
-  sa.redo_capacity = (job.fast || ctx->polarized) ? job.redo_capacity : 0;
+  sa.redo_capacity = (job.fast || job.fast_formula || ctx->polarized) ? job.redo_capacity : 0;
 
   job.snapshot_time = job.slow ? p.slow_t_start + p.slow_dt * ctx->snapshot : 0.0;   // simulation_reader.cpp:214
   if (job.slow) {
@@ -755,7 +761,7 @@ void BuildTransferArgs(RenderJob &job) {
   xa.ray_max_steps = job.max_steps;
   xa.fallback_nan = p.fallback_nan;
   xa.model_type = p.model_type;
-  xa.affine = job.fast ? 1 : 0;
+  xa.affine = (job.fast || job.fast_formula) ? 1 : 0;
   xa.n_rays_total = job.n_rays;
   xa.image = job.image;
   xa.out_sample_num = job.out_num;
@@ -821,7 +827,7 @@ void BindChunk(RenderJob &job, int k, long long begin, int rays) {
   sa.sample_t = ta.sample_t;
   sa.coef_inputs = (job.coef_split || ctx->polarized) ? sl.d_coef_inputs.ptr : nullptr;
   sa.anchors = job.block_interp ? sl.d_anchors.ptr : nullptr;
-  sa.redo_list = (job.fast || ctx->polarized) ? sl.d_redo.ptr : nullptr;
+  sa.redo_list = (job.fast || job.fast_formula || ctx->polarized) ? sl.d_redo.ptr : nullptr;
   if (job.slow) {
     sa.slow.frac = sl.d_slow_frac.ptr;
     sa.slow.ray_extrap = ctx->d_ray_extrap.ptr + begin;
@@ -1194,6 +1200,7 @@ void LaunchShadingStage(RenderJob &job, int k, bool geodesic_beside, hipStream_t
     Check(bl_launch_locate(&sa, geodesic_beside ? job.locate_grid_shared : job.locate_grid_alone, ctx->lds_table_bytes, stream), "locate kernel launch");
   Check(hipEventRecord(e[3], stream), "event");
   if (job.fast) Check(bl_launch_shade_fast(&sa, job.shade_grid, stream), "coefficient kernel launch");
+  else if (job.fast_formula) Check(bl_launch_shade_formula_fast(&sa, ctx->num_cus * 4 * 4, stream), "coefficient kernel launch");
   else Check(bl_launch_shade(&sa, p.model_type, job.shade_grid, stream), "coefficient kernel launch");
   if (ctx->polarized) Check(bl_launch_polarized_coefficients(&sa, ctx->num_cus * 8, stream), "polarized coefficient kernel launch");
   if (job.coef_split) Check(bl_launch_coefficients_freq(&sa, ctx->num_cus * 16, stream), "per-frequency coefficient kernel launch");
@@ -1250,7 +1257,7 @@ void CollectChunk(RenderJob &job, int k) {
   job.total_undefined += hc[BL_CNT_UNDEFINED];
   job.total_records += hc[BL_CNT_RECORDS];
   job.total_gathers += hc[BL_CNT_GATHERS];
-  if (job.fast) job.total_redo += hc[BL_CNT_REDO];   // (polarized runs use the list for something else: bl_polarized_frame_kernel)
+  if (job.fast || job.fast_formula) job.total_redo += hc[BL_CNT_REDO];   // (polarized runs use the list for something else: bl_polarized_frame_kernel)
   job.total_samples += hc[BL_CNT_COUNT + 0];
   job.total_flagged += hc[BL_CNT_COUNT + 1];
   job.max_num = std::max<unsigned long long>(job.max_num, hc[BL_CNT_COUNT + 2]);
@@ -1348,7 +1355,7 @@ void FinishStats(RenderJob &job) {
   float ms_wall = 0.0f;
   Check(hipEventElapsedTime(&ms_wall, ctx->events[2 * kEventsPerChunk], ctx->events[2 * kEventsPerChunk + 1]), "event time");
   st.ms_wall = ms_wall;
-  st.arithmetic = (job.fast || job.tolerant_polarized) ? BL_ARITH_TOLERANT : BL_ARITH_EXACT;
+  st.arithmetic = (job.fast || job.fast_formula || job.tolerant_polarized) ? BL_ARITH_TOLERANT : BL_ARITH_EXACT;
   st.n_deferred = static_cast<int64_t>(job.total_redo);
   st.n_undefined = static_cast<int64_t>(job.total_undefined);
   ctx->stats = st;

@@ -142,6 +142,27 @@ class Comm:
         return data.cpu().numpy()[:n].copy()
 
 
+class EmulatedComm:
+    """`world` ranks emulated by ONE process on one GPU: render_level / render_adaptive run every rank's share one after
+    the other through the same tiling, padding, buffer layouts and reassembly as a real group, with the collectives
+    replaced by their serial meaning. For tests and strong-scaling estimates at sizes where a box allows no more than a
+    few processes on its GPU; nothing here touches torch.distributed."""
+    emulated = True
+
+    def __init__(self, world, device=None):
+        import torch
+        self.torch = torch
+        self.rank, self.world = 0, int(world)
+        self.device = device if device is not None else (torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu"))
+
+    @property
+    def on_gpu(self):
+        return self.device.type == "cuda"
+
+    def broadcast_blocks(self, block_locs):
+        return np.zeros((0, 2), dtype=np.int32) if block_locs is None else np.ascontiguousarray(block_locs, dtype=np.int32)
+
+
 # per-pixel outputs of a level, as flat (rows x rays) buffers: name, rows per ray as a function of the context, dtype
 def _row_specs(ctx, want_camera):
     import torch
@@ -207,22 +228,38 @@ def render_level(ctx, comm, level=0, block_locs=None, want_camera=False, tile=No
         pixels, blocks = None, np.ascontiguousarray(block_locs[rank::world], dtype=np.int32)
         n_total = n_blocks * bs * bs
         n_padded = ((n_blocks + world - 1) // world) * bs * bs
-    n_local = counts[rank]
     specs = _row_specs(ctx, want_camera)
-    buffers, stats, error = None, None, None
-    try:
-        buffers, stats = _render_into_buffers(ctx, comm, specs, n_local, n_padded, level, pixels, blocks, want_camera)
-    except Exception as failure:   # agreed on below: every rank raises, none is left waiting in a collective
-        error = f"{type(failure).__name__}: {failure}"
-    comm.agree(error)
-    if hasattr(ctx, "clear_warnings"):
-        ctx.clear_warnings()   # per-rank counts; the level's totals are reported below
-    max_num = stats.max_sample_num if stats is not None else 0
-    n_flagged = stats.n_flagged if stats is not None else 0
-    max_num, n_flagged = comm.reduce_counts(max_num, n_flagged)
+    emulated = getattr(comm, "emulated", False)
+    if emulated:
+        # every rank's share in turn, into buffers of its own: what the gathers below would deliver
+        shares, max_num, n_flagged = [], 0, 0
+        for r in range(world):
+            if level == 0:
+                pixels_r, blocks_r = tile_pixels(ctx.resolution, r, world, tile), None
+            else:
+                pixels_r, blocks_r = None, np.ascontiguousarray(block_locs[r::world], dtype=np.int32)
+            buffers_r, stats_r = _render_into_buffers(ctx, comm, specs, counts[r], n_padded, level, pixels_r, blocks_r, want_camera)
+            shares.append(buffers_r)
+            if stats_r is not None:
+                max_num, n_flagged = max(max_num, stats_r.max_sample_num), n_flagged + stats_r.n_flagged
+        if hasattr(ctx, "clear_warnings"):
+            ctx.clear_warnings()
+    else:
+        n_local = counts[rank]
+        buffers, stats, error = None, None, None
+        try:
+            buffers, stats = _render_into_buffers(ctx, comm, specs, n_local, n_padded, level, pixels, blocks, want_camera)
+        except Exception as failure:   # agreed on below: every rank raises, none is left waiting in a collective
+            error = f"{type(failure).__name__}: {failure}"
+        comm.agree(error)
+        if hasattr(ctx, "clear_warnings"):
+            ctx.clear_warnings()   # per-rank counts; the level's totals are reported below
+        max_num = stats.max_sample_num if stats is not None else 0
+        n_flagged = stats.n_flagged if stats is not None else 0
+        max_num, n_flagged = comm.reduce_counts(max_num, n_flagged)
     result = dict(max_sample_num=max_num, n_flagged=n_flagged, n_rays=n_total) if rank == 0 else None
     for name, rows, dtype in specs:
-        parts = comm.gather_flat(buffers[name])
+        parts = [share[name] for share in shares] if emulated else comm.gather_flat(buffers[name])
         if rank != 0:
             continue
         full = None

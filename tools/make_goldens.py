@@ -523,6 +523,65 @@ def make_window_fixture():
           f"{np.array_equal(fixture['A_block_locs'], fixture['B_block_locs'])}")
 
 
+# Reference windows of BASELINE's other at-size configurations over the 256^3 mock, by the same forced refinement: a
+# full-Stokes window of the 2048^2 lattice (configuration 4's physics) and a ten-frequency window of the 1024^2 lattice
+# (configuration 5's parameter set). Root cameras of 128^2 keep the reference inside this container's memory.
+def _window128(cx, cy):
+    """A region that holds the centre (cx, cy) of one 16-pixel block of the 128^2 root camera (centres at -10.5 + 3 b) and, level
+    by level, the centres of the children nearest to it: one block per level down to level 2, 2 x 2 at level 3, 4 x 4 at 4."""
+    return (cx - 0.1, cx + 0.8, cy - 0.1, cy + 0.8)
+
+
+WINDOW_VARIANTS = {
+    # name: (root resolution, forced level, lattice resolution, regions, overrides)
+    "window_2048_polarized": (128, 4, 2048, [_window128(1.5, 4.5)], dict(image_polarization="true", image_rotation_split="false")),
+    "window_1024_multifreq": (128, 3, 1024, [_window128(1.5, 4.5), _window128(-4.5, 1.5)],
+                              dict(image_num_frequencies=10, image_frequency_start=1.5e11, image_frequency_end=3.3e11,
+                                   image_frequency_spacing="lin_wave", adaptive_frequency_num=1)),
+}
+
+
+def make_window_variant(name):
+    root, level, lattice, regions, overrides = WINDOW_VARIANTS[name]
+    mock = dict(n_r=256, n_th=256, n_ph=256)
+    params = dict(SIM_BASE)
+    params.update(camera_resolution=root, checkpoint_geodesic_save="false", adaptive_max_level=level, adaptive_block_size=16,
+                  adaptive_frequency_num=0, adaptive_val_cut=0.0, adaptive_val_frac=-1.0, adaptive_abs_grad_cut=0.0,
+                  adaptive_abs_grad_frac=-1.0, adaptive_rel_grad_cut=0.0, adaptive_rel_grad_frac=-1.0,
+                  adaptive_abs_lapl_cut=0.0, adaptive_abs_lapl_frac=-1.0, adaptive_rel_lapl_cut=0.0,
+                  adaptive_rel_lapl_frac=-1.0, adaptive_num_regions=len(regions), output_camera="false")
+    params.update(overrides)
+    params.pop("image_frequency", None) if "image_frequency_start" in overrides else None
+    for r, (x0, x1, y0, y1) in enumerate(regions, start=1):
+        params[f"adaptive_region_{r}_level"] = level
+        params[f"adaptive_region_{r}_x_min"] = x0
+        params[f"adaptive_region_{r}_x_max"] = x1
+        params[f"adaptive_region_{r}_y_min"] = y0
+        params[f"adaptive_region_{r}_y_max"] = y1
+    workdir = os.path.join(WORK, "window_1024")   # shares the 256^3 mock file with window_1024
+    os.makedirs(os.path.join(workdir, "data"), exist_ok=True)
+    os.makedirs(os.path.join(workdir, "output"), exist_ok=True)
+    mock_path = os.path.join(workdir, "data", "mock.athdf")
+    if not os.path.exists(mock_path):
+        args = [sys.executable, "-W", "ignore", MOCK_SCRIPT, mock_path]
+        for key, value in mock.items():
+            args += [f"--{key}", str(value)]
+        subprocess.run(args, check=True)
+    write_input(os.path.join(workdir, name + ".input"), params)
+    skip = ("checkpoint_geodesic_save", "checkpoint_geodesic_file", "adaptive_max_level", "adaptive_block_size", "adaptive_num_regions")
+    plain = {k: v for k, v in params.items() if k not in skip and not k.startswith("adaptive_")}
+    plain.update(camera_resolution=lattice, checkpoint_geodesic_save="false", adaptive_max_level=0)
+    fixture = dict(mock_args=json.dumps(mock), params=json.dumps(plain), reference_params=json.dumps(params), lattice=lattice)
+    fixture["B_warnings"] = run_reference(workdir, name + ".input", True)   # pinned math library
+    npz = np.load(os.path.join(workdir, "output", "out.npz"))
+    fixture["B_block_locs"] = npz[f"adaptive_block_locs_{level}"]
+    for key in npz.files:
+        if key.startswith("adaptive_") and key.endswith(f"_{level}") and key != f"adaptive_block_locs_{level}":
+            fixture["B_" + key[len("adaptive_"):-len(f"_{level}")]] = npz[key]
+    print(name, "level", level, "blocks", fixture["B_block_locs"].shape, {k: v.shape for k, v in fixture.items() if k.startswith("B_") and hasattr(v, "shape")})
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **fixture)
+
+
 # ------------------------------------------------------------------------------------------------
 # Snapshot-reader fixtures (tests/golden/reader/): small .athdf files exactly as h5py wrote them, the arrays
 # h5py reads back from them, and the reference's images for a two-file series (simulation_multiple) of them.
@@ -1107,6 +1166,8 @@ if __name__ == "__main__":
             make_checkpoint_fixtures()
         elif case_name == "sample_checkpoint":
             make_sample_checkpoint_fixtures()
+        elif case_name in WINDOW_VARIANTS:
+            make_window_variant(case_name)
         elif case_name == "harm3d":
             make_harm3d_fixtures()
         elif case_name == "slowcli":
