@@ -606,15 +606,8 @@ __global__ void __launch_bounds__(64, BL_GEO_ONE_WAVE(kIntegrator, kTime, kSpinZ
         cold.ky = smp[5];
         cold.kz = smp[6];
         cold.len = len;
-#ifdef BL_EXP_NOSTORE   // experiment: the geodesic kernel without its record stores (one lane in 2^20 keeps the values alive)
-        if (at == 0x7ffffffffffll) {
-          P.records_hot[0] = hot;
-          P.records_cold[0] = cold;
-        }
-#else
         P.records_hot[at * P.record_stride] = hot;
         P.records_cold[at * P.record_stride] = cold;
-#endif
         if (kTime) P.sample_t[at] = smp[0];
       }
     }
@@ -2378,7 +2371,7 @@ __device__ __forceinline__ void fast_defer(const BlShadeArgs &P, unsigned long l
 // transfer records of every frequency. Returns false when a cut decision is left to the exact kernel (nothing written).
 // `table` (LDS): the 3 x 14 cut thresholds and guard bands of BlShadeCold, then the frequencies. Read from LDS so that
 // nothing in here waits on the vector-memory counter, behind which the next sample's corner cells are in flight.
-template <bool kSpinZero>
+template <bool kSpinZero, bool kGeneral = false>
 __device__ __forceinline__ bool fast_shade_sample(const BlShadeArgs &P, const double *table, const float pr[8], int status, size_t row,
                                                   double x, double y, double z, double kx, double ky, double kz, double kt,
                                                   double momentum_factor, double delta_lambda) {
@@ -2427,31 +2420,60 @@ __device__ __forceinline__ bool fast_shade_sample(const BlShadeArgs &P, const do
       kz *= factor;
       lk *= factor;
     }
-    // ---- simulation metric, spherical Kerr-Schild (radiation_geometry.cpp:421-573); x^2 + y^2 = (r^2 + a^2) sin^2
-    const double sth2 = pp2 * ra_inv;
-    const double g_rr = 1.0 + hh;
-    const double g_thth = sigma;
-    const double g_tph = kSpinZero ? 0.0 : -hh * bh_a * sth2;
-    const double g_rph = kSpinZero ? 0.0 : -g_rr * bh_a * sth2;
-    const double g_phph = kSpinZero ? pp2 : (ra2 + hh * a2 * sth2) * sth2;
-    // ---- u^mu from the normal-frame velocities (simulation_coefficients.cpp:297-313). u^t = u0n / lapse = sqrt(S (1 + 2 m r /
-    // Sigma)): one reciprocal square root gives u^t and 1 / u^t. (Square roots and reciprocals are a fifth of this function's
-    // issue time - a dozen instructions each, one of them at quarter rate - so quantities that share one are taken from one.)
-    const double u0n2 = 1.0 + g_rr * uu1 * uu1 + 2.0 * g_rph * uu1 * uu3 + g_thth * uu2 * uu2 + g_phph * uu3 * uu3;
-    const double ut2 = u0n2 * g_rr;
-    const double ut_inv = fastmath::rsqrt(ut2);
-    const double ut = ut2 * ut_inv;
-    const double ur = uu1 - hh * fastmath::rcp(g_rr) * ut;         // shift^r = (2 m r / Sigma) / (1 + 2 m r / Sigma)
-    const double u_r = hh * ut + g_rr * ur + g_rph * uu3;
-    const double u_th = g_thth * uu2;
-    const double u_ph = g_tph * ut + g_rph * ur + g_phph * uu3;
-    // ---- b^mu (:316-330); b.b = (B.B + (u.B)^2) / (u^t)^2
-    const double bt = u_r * bb1 + u_th * bb2 + u_ph * bb3;
-    const double br = (bb1 + bt * ur) * ut_inv;
-    const double bth = (bb2 + bt * uu2) * ut_inv;
-    const double bph = (bb3 + bt * uu3) * ut_inv;
-    const double bb_sq_lab = g_rr * bb1 * bb1 + 2.0 * g_rph * bb1 * bb3 + g_thth * bb2 * bb2 + g_phph * bb3 * bb3;
-    const double b_sq = (bb_sq_lab + bt * bt) * ut_inv * ut_inv;
+    double ut_inv, b_sq, k_u, k_b;
+    const bool cartesian = kGeneral && pl.simulation_coord == BL_COORD_CKS;
+    if (cartesian) {
+      // ---- Cartesian Kerr-Schild simulation (the geodesic's own coordinates): g_ij = delta_ij + f l_i l_j, lapse^-2 = 1 + f,
+      // shift^i = f l_i / (1 + f) (radiation_geometry.cpp:138-262 for both metrics); k_i needs no Jacobian
+      const double lu = lx * uu1 + ly * uu2 + lz * uu3;
+      const double u0n2 = 1.0 + (uu1 * uu1 + uu2 * uu2 + uu3 * uu3) + f * lu * lu;
+      const double ut2 = u0n2 * (1.0 + f);
+      ut_inv = fastmath::rsqrt(ut2);
+      const double ut = ut2 * ut_inv;
+      const double sh = f * fastmath::rcp(1.0 + f) * ut;
+      const double ux = uu1 - sh * lx, uy = uu2 - sh * ly, uz = uu3 - sh * lz;
+      const double flu = f * (ut + (lx * ux + ly * uy + lz * uz));
+      const double u_x = ux + flu * lx, u_y = uy + flu * ly, u_z = uz + flu * lz;
+      const double bt = u_x * bb1 + u_y * bb2 + u_z * bb3;
+      const double lb = lx * bb1 + ly * bb2 + lz * bb3;
+      b_sq = ((bb1 * bb1 + bb2 * bb2 + bb3 * bb3) + f * lb * lb + bt * bt) * ut_inv * ut_inv;
+      k_u = kt * ut + kx * ux + ky * uy + kz * uz;
+      k_b = kt * bt + (kx * (bb1 + bt * ux) + ky * (bb2 + bt * uy) + kz * (bb3 + bt * uz)) * ut_inv;
+    } else {
+      // ---- simulation metric, spherical Kerr-Schild (radiation_geometry.cpp:421-573); x^2 + y^2 = (r^2 + a^2) sin^2
+      const double sth2 = pp2 * ra_inv;
+      const double g_rr = 1.0 + hh;
+      const double g_thth = sigma;
+      const double g_tph = kSpinZero ? 0.0 : -hh * bh_a * sth2;
+      const double g_rph = kSpinZero ? 0.0 : -g_rr * bh_a * sth2;
+      const double g_phph = kSpinZero ? pp2 : (ra2 + hh * a2 * sth2) * sth2;
+      // ---- u^mu from the normal-frame velocities (simulation_coefficients.cpp:297-313). u^t = u0n / lapse = sqrt(S (1 + 2 m r /
+      // Sigma)): one reciprocal square root gives u^t and 1 / u^t. (Square roots and reciprocals are a fifth of this function's
+      // issue time - a dozen instructions each, one of them at quarter rate - so quantities that share one are taken from one.)
+      const double u0n2 = 1.0 + g_rr * uu1 * uu1 + 2.0 * g_rph * uu1 * uu3 + g_thth * uu2 * uu2 + g_phph * uu3 * uu3;
+      const double ut2 = u0n2 * g_rr;
+      ut_inv = fastmath::rsqrt(ut2);
+      const double ut = ut2 * ut_inv;
+      const double ur = uu1 - hh * fastmath::rcp(g_rr) * ut;         // shift^r = (2 m r / Sigma) / (1 + 2 m r / Sigma)
+      const double u_r = hh * ut + g_rr * ur + g_rph * uu3;
+      const double u_th = g_thth * uu2;
+      const double u_ph = g_tph * ut + g_rph * ur + g_phph * uu3;
+      // ---- b^mu (:316-330); b.b = (B.B + (u.B)^2) / (u^t)^2
+      const double bt = u_r * bb1 + u_th * bb2 + u_ph * bb3;
+      const double br = (bb1 + bt * ur) * ut_inv;
+      const double bth = (bb2 + bt * uu2) * ut_inv;
+      const double bph = (bb3 + bt * uu3) * ut_inv;
+      const double bb_sq_lab = g_rr * bb1 * bb1 + 2.0 * g_rph * bb1 * bb3 + g_thth * bb2 * bb2 + g_phph * bb3 * bb3;
+      b_sq = (bb_sq_lab + bt * bt) * ut_inv * ut_inv;
+      // ---- k_i in the simulation's coordinates: k'_a = k_i d x^i / d x'^a with the Jacobian of radiation_geometry.cpp:
+      // 69-126, whose columns are (l_x, l_y, l_z), (cot(theta) x, cot(theta) y, -r sin(theta)) and (-y, x, 0)
+      const double sth_inv = fastmath::rsqrt(sth2);
+      const double k_r = lk;
+      const double k_th = (lz * (x * kx + y * ky) - r * sth2 * kz) * sth_inv;
+      const double k_ph = x * ky - y * kx;
+      k_u = kt * ut + k_r * ur + k_th * uu2 + k_ph * uu3;
+      k_b = kt * bt + k_r * br + k_th * bth + k_ph * bph;
+    }
     // ---- plasma state (:274-358)
     const double rho_cgs = rho * pl.d_unit;
     const double pgas_cgs = pgas * pl.e_unit;
@@ -2480,7 +2502,7 @@ __device__ __forceinline__ bool fast_shade_sample(const BlShadeArgs &P, const do
       theta_e = kb_tt_e_cgs * (1.0 / (kMe * kC * kC));
     }
     // ---- cell cuts (:361-375): decided here unless a value sits within the guard band of an active threshold
-    bool cell_cut = false, undecided = pp2 == 0.0;
+    bool cell_cut = false, undecided = !cartesian && pp2 == 0.0;   // (on the polar axis of the spherical coordinates: the exact kernel's business)
     if (pl.cut_mask != 0) {
       const double bb_cgs = (pl.cut_mask & 0x300) ? bl_sqrt_g(b_sq) * pl.b_unit : 0.0;   // only the field-strength cuts need |b| itself
       const double value[7] = {rho_cgs, n_e_cgs, pgas_cgs, theta_e, bb_cgs, sigma_cut, beta_inv};
@@ -2495,14 +2517,6 @@ __device__ __forceinline__ bool fast_shade_sample(const BlShadeArgs &P, const do
     if (undecided) return false;   // bl_shade_kernel<..., kRedo> writes this sample's records
     const bool no_field = bb1 == 0.0 && bb2 == 0.0 && bb3 == 0.0;   // :394
     if (!cell_cut && !no_field) {
-      // ---- k_i in the simulation's coordinates: k'_a = k_i d x^i / d x'^a with the Jacobian of radiation_geometry.cpp:
-      // 69-126, whose columns are (l_x, l_y, l_z), (cot(theta) x, cot(theta) y, -r sin(theta)) and (-y, x, 0)
-      const double sth_inv = fastmath::rsqrt(sth2);
-      const double k_r = lk;
-      const double k_th = (lz * (x * kx + y * ky) - r * sth2 * kz) * sth_inv;
-      const double k_ph = x * ky - y * kx;
-      const double k_u = kt * ut + k_r * ur + k_th * uu2 + k_ph * uu3;
-      const double k_b = kt * bt + k_r * br + k_th * bth + k_ph * bph;
       // cos^2 = (k.b)^2 / ((k.u)^2 b.b) (:434-455 in invariant form) and 1 / (k.u) from one reciprocal
       const double t = fastmath::rcp(k_u * b_sq);
       k_u_inv = t * b_sq;
@@ -2531,7 +2545,7 @@ __device__ __forceinline__ bool fast_shade_sample(const BlShadeArgs &P, const do
   // root per sample with the frequency's roots from the table (table[44 + n_nu ...], filled once per workgroup) - what is
   // left per sample AND frequency is one exp, two expm1, one reciprocal and two dozen multiplications.
   // nu_c = e |b| b_unit / (2 pi m_e c), nu_s = 2/9 nu_c Theta_e^2 sin(theta_B): nu / nu_s without another reciprocal
-  const double thermal_frac = pl.plasma_thermal_frac;
+  const double thermal_frac = pl.plasma_thermal_frac, power_frac = pl.power_frac;
   const double nu_c_over_b = kE * pl.b_unit * (1.0 / (2.0 * kPi * kMe * kC));
   const double momentum_factor_inv = fastmath::rcp(momentum_factor);
   const double kb_tt_e_inv = have ? fastmath::rcp(kb_tt_e_cgs) : 0.0;
@@ -2567,20 +2581,31 @@ __device__ __forceinline__ bool fast_shade_sample(const BlShadeArgs &P, const do
       const double inv_b_nu = planck * (kC * kC / (2.0 * kH));   // 1 / (B_nu / nu^3)
       double alpha_val = j_val * inv_b_nu;
       if (alpha_val * alpha_val <= 0x1p-1024) alpha_val = 0.0;                                // :513-523
+      double j_total = j_val;
+      if (kGeneral && power_frac != 0.0) {
+        // power-law electrons (simulation_coefficients.cpp:556-584): nu / (nu_c sin theta_B) to two powers, one logarithm; the
+        // field enters through |b| sin theta_B alone here as well
+        const double nu_cgs = s_nu * f;
+        const fastmath::PowBase ratio = fastmath::pow_base(nu_cgs * b_sin_inv * (1.0 / nu_c_over_b));
+        const double common = power_frac * n_e_cgs * kE * kE;
+        j_total += common * (nu_c_over_b * b_sin) * (1.0 / kC) * (s_nu_inv * f_inv) * (s_nu_inv * f_inv) * pl.power_jj
+            * fastmath::pow_of(ratio, -(pl.plasma_p - 1.0) * 0.5);
+        alpha_val += common * (1.0 / (kMe * kC)) * pl.power_aa * fastmath::pow_of(ratio, -(pl.plasma_p + 2.0) * 0.5);
+      }
       const double delta_lambda_cgs = s_length * f_inv;
       if (alpha_val > 0.0) {
         const double delta_tau = alpha_val * delta_lambda_cgs;
         if (delta_tau < 0x1p-10) {
           const double p = 1.0 - 0.5 * delta_tau * (1.0 - (1.0 / 3.0) * delta_tau * (1.0 - 0.25 * delta_tau));
-          rec = make_double2(1.0 - delta_tau * p, j_val * delta_lambda_cgs * p);
+          rec = make_double2(1.0 - delta_tau * p, j_total * delta_lambda_cgs * p);
         } else if (delta_tau <= kDeltaTauMax) {
           const double e1 = fastmath::expm1(-delta_tau);
-          rec = make_double2(1.0 + e1, -(j_val * fastmath::rcp(alpha_val)) * e1);
+          rec = make_double2(1.0 + e1, -(j_total * fastmath::rcp(alpha_val)) * e1);
         } else {
-          rec = make_double2(0.0, j_val * fastmath::rcp(alpha_val));
+          rec = make_double2(0.0, j_total * fastmath::rcp(alpha_val));
         }
       } else {
-        rec = make_double2(1.0, j_val * delta_lambda_cgs);
+        rec = make_double2(1.0, j_total * delta_lambda_cgs);
       }
     }
     out[l] = rec;
@@ -2617,11 +2642,7 @@ __device__ __forceinline__ void fast_load_ray(const BlShadeArgs &P, unsigned lon
 __device__ __forceinline__ void gather_issue(const BlShadeArgs &P, int status, uint32_t cell, float4 (&lo)[8], float4 (&hi)[8]) {
   const BlGridDevice &g = P.grid;
   const bool interp = status == kSampleInterp;
-#ifdef BL_EXP_GATHER0   // experiment: every gather reads the cells at (0, 0, 0): the kernel's time without grid traffic
-  const size_t first = 0;
-#else
   const size_t first = (interp || status == kSampleNearest) ? (size_t)cell : 0;
-#endif
   const float4 *base = reinterpret_cast<const float4 *>(g.cells) + first * 2;
   const size_t row = interp ? (size_t)g.stride_row * 2 : 0, plane = interp ? (size_t)g.stride_plane * 2 : 0, next = interp ? 2 : 0;
 #pragma unroll
@@ -2677,7 +2698,7 @@ __device__ __forceinline__ void gather_finish(const BlShadeArgs &P, float fallba
 // ~1 700 instructions of arithmetic instead of in front of them (the unpipelined version waited for memory in 54 % of its
 // wave cycles). Nothing between the requests and the end of the arithmetic reads global memory: thresholds, fallback
 // values and frequencies sit in LDS, the per-ray constants are requested before the cells.
-template <bool kSpinZero>
+template <bool kSpinZero, bool kGeneral>
 __global__ void __launch_bounds__(256, BL_FAST_WAVES) bl_shade_fast_kernel(const BlShadeArgs P) {
   const unsigned long long n_records = P.counters_in[BL_CNT_RECORDS];
   const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
@@ -2746,8 +2767,8 @@ __global__ void __launch_bounds__(256, BL_FAST_WAVES) bl_shade_fast_kernel(const
     fast_load_located(P, have_next ? idx : last, loc_next);
     if (live) {
       // ReverseGeodesics: sample_len = -geodesic_len (geodesics.cpp:840)
-      if (!fast_shade_sample<kSpinZero>(P, fast_table, pr, status, row, rec.q0.x, rec.q0.y, rec.q1.x, rec.q2.x, rec.q2.y, rec.q3.x, kt,
-                                        momentum_factor, -rec.q3.y)) {
+      if (!fast_shade_sample<kSpinZero, kGeneral>(P, fast_table, pr, status, row, rec.q0.x, rec.q0.y, rec.q1.x, rec.q2.x, rec.q2.y, rec.q3.x,
+                                                   kt, momentum_factor, -rec.q3.y)) {
         fast_defer(P, idx_rec);
       }
     }
@@ -3731,13 +3752,24 @@ extern "C" hipError_t bl_launch_shade_fast(const BlShadeArgs *args, int grid, hi
     }
     return hipGetLastError();
   }
-  if (args->st.bh_a == 0.0) {
-    hipLaunchKernelGGL((bl_shade_fast_kernel<true>), dim3(grid), dim3(256), (44 + 5 * args->n_nu) * sizeof(double), stream, *args);
-    hipLaunchKernelGGL((bl_shade_kernel<BL_MODEL_SIMULATION, false, false, true, false, true, true>), dim3(grid), dim3(256), 0, stream, *args);
+  const size_t lds = (44 + 5 * args->n_nu) * sizeof(double);
+  const bool spin_zero = args->st.bh_a == 0.0;
+  const bool power_law = args->plasma.power_frac != 0.0, cartesian = args->plasma.simulation_coord == BL_COORD_CKS;
+  // (the records it defers go to the exact kernel: its extended instantiation knows power laws, its general one Cartesian grids)
+#define BL_FAST_PAIR(SPIN, GENERAL, EXTENDED, SKS)                                                                               \
+  do {                                                                                                                           \
+    hipLaunchKernelGGL((bl_shade_fast_kernel<SPIN, GENERAL>), dim3(grid), dim3(256), lds, stream, *args);                        \
+    hipLaunchKernelGGL((bl_shade_kernel<BL_MODEL_SIMULATION, false, EXTENDED, SKS, false, SPIN, true>), dim3(grid), dim3(256), 0, \
+                       stream, *args);                                                                                           \
+  } while (0)
+  if (cartesian) {
+    if (spin_zero) BL_FAST_PAIR(true, true, true, false); else BL_FAST_PAIR(false, true, true, false);
+  } else if (power_law) {
+    if (spin_zero) BL_FAST_PAIR(true, true, true, true); else BL_FAST_PAIR(false, true, true, true);
   } else {
-    hipLaunchKernelGGL((bl_shade_fast_kernel<false>), dim3(grid), dim3(256), (44 + 5 * args->n_nu) * sizeof(double), stream, *args);
-    hipLaunchKernelGGL((bl_shade_kernel<BL_MODEL_SIMULATION, false, false, true, false, false, true>), dim3(grid), dim3(256), 0, stream, *args);
+    if (spin_zero) BL_FAST_PAIR(true, false, false, true); else BL_FAST_PAIR(false, false, false, true);
   }
+#undef BL_FAST_PAIR
   return hipGetLastError();
 }
 

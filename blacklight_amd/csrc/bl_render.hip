@@ -210,12 +210,12 @@ void PlanJob(RenderJob &job) {
   job.sample_save = job.simulation && p.checkpoint_sample_save && d->level == 0 && !ctx->sample_checkpoint_saved;
   if (job.sample_save && (d->pixel_map != nullptr || job.n_rays != job.level_pixels))
     throw Failure{BL_E_ARG, "checkpoint_sample_save needs the whole root camera in one bl_render call."};
-  // Tolerant tier: plain unpolarized images of a spherical Kerr-Schild simulation with thermal electrons in a curved
+  // Tolerant tier: plain unpolarized images of a simulation with thermal (and power-law) electrons in a curved
   // spacetime have the fast coefficient kernel; every other configuration is rendered in exact arithmetic whatever
   // bl_set_arithmetic() asked for (bl_stats.arithmetic says which tier ran)
   job.fast = ctx->arithmetic == BL_ARITH_TOLERANT && job.simulation && !job.aux && !ctx->polarized && !job.slow && !job.block_interp
-      && p.plasma_power_frac == 0.0 && p.plasma_kappa_frac == 0.0 && p.plasma_model != BL_PLASMA_CODE_KAPPA
-      && (p.simulation_coord == BL_COORD_SKS || p.simulation_coord == BL_COORD_FMKS) && !p.ray_flat && ctx->plasma_thermal_frac != 0.0
+      && p.plasma_kappa_frac == 0.0 && p.plasma_model != BL_PLASMA_CODE_KAPPA
+      && !p.ray_flat && ctx->plasma_thermal_frac != 0.0
       && job.n_nu <= 1024;   // (its LDS table holds five numbers per frequency)
   // ... formula mode has a fast kernel of its own (plain images, no optional geometric cut)
   job.fast_formula = ctx->arithmetic == BL_ARITH_TOLERANT && !job.simulation && !job.aux
@@ -226,10 +226,10 @@ void PlanJob(RenderJob &job) {
   job.matrix_transport = job.tolerant_polarized && !p.ray_flat;
   // Several frequencies in the fast path: per-sample factors (BlFreqInputs) instead of per-frequency transfer records,
   // evaluated by bl_transfer_freq_kernel with one lane per ray and frequency
-  job.freq_split = job.fast && job.n_nu >= 4;
+  job.freq_split = job.fast && job.n_nu >= 4 && p.plasma_power_frac == 0.0;   // (the factors are the thermal formulas')
   // The fast path over one grid (or equal blocks merged into one) with its coordinate tables in LDS, trilinear sampling and no
   // optional geometric cut locates its samples inside the coefficient kernel: no located samples in HBM at all
-  job.fused = job.fast && ctx->grid_dev.n_blocks == 0 && ctx->lds_table_bytes > 0 && !ctx->grid_dev.fmks && p.simulation_interp
+  job.fused = job.fast && ctx->grid_dev.n_blocks == 0 && ctx->lds_table_bytes > 0 && !ctx->grid_dev.fmks && p.simulation_interp && p.plasma_power_frac == 0.0
       && !(p.cut_omit_near || p.cut_omit_far || p.cut_omit_in >= 0.0 || p.cut_omit_out >= 0.0 || p.cut_midplane_theta != 0.0 || p.cut_midplane_z != 0.0 || p.cut_plane)
       && static_cast<size_t>(ctx->lds_table_bytes) + (44 + 5 * static_cast<size_t>(job.n_nu)) * sizeof(double) <= 60u * 1024u
       && !job.sample_save && std::getenv("BLACKLIGHT_AMD_NO_FUSED_LOCATE") == nullptr;   // (a sample checkpoint is made of the located samples)

@@ -33,9 +33,9 @@ def _applies(params):
                 or float(params.get("cut_midplane_theta", 0.0)) != 0.0 or float(params.get("cut_midplane_z", 0.0)) != 0.0 or on("cut_plane"))
         return not aux and not cuts
     return (params["model_type"] == "simulation" and not aux and not on("image_polarization") and not on("slow_light_on")
-            and not on("simulation_block_interp") and float(params.get("plasma_power_frac", 0.0)) == 0.0
+            and not on("simulation_block_interp")
             and float(params.get("plasma_kappa_frac", 0.0)) == 0.0 and params.get("plasma_model", "ti_te_beta") == "ti_te_beta"
-            and params.get("simulation_coord", "sks") == "sks" and not on("ray_flat") and on("image_light"))
+            and not on("ray_flat") and on("image_light"))
 
 
 def _both(params, mock_args, **render_args):
@@ -136,8 +136,39 @@ def test_tolerant_tier_on_seeded_configurations(seed, built_library):
     assert np.isfinite(exact["image"]).mean() > 0.5
 
 
-@pytest.mark.parametrize("band,resolution,frequencies", [(1.0e30, 24, 1), (1.0e30, 56, 1), (1.0e30, 24, 5), (1.0e30, 56, 5)])
-def test_deferred_cut_decisions(band, resolution, frequencies, built_library):
+@pytest.mark.parametrize("seed", range(8))
+def test_tolerant_tier_with_power_laws_and_cartesian_grids(seed, built_library):
+    """The general instantiation of bl_shade_fast_kernel: power-law electrons beside the thermal ones
+    (simulation_coefficients.cpp:556-584) and simulations in Cartesian Kerr-Schild coordinates, separately and together."""
+    rng = np.random.default_rng(9100 + seed)
+    fx, params, mock_args = gu.load_case("sim_dp_interp")
+    over = dict(camera_resolution=24, camera_th=float(rng.uniform(10.0, 170.0)), camera_ph=float(rng.uniform(0.0, 360.0)),
+                simulation_a=float(rng.choice([0.0, 0.5, 0.9])), simulation_interp=str(rng.choice(["true", "false"])),
+                fallback_nan="false", fallback_rho=1.0e-6, fallback_pgas=1.0e-8, cut_sigma_max=float(rng.choice([-1.0, 5.0])),
+                image_num_frequencies=int(rng.choice([1, 3, 6])))   # (the mock grid read as Cartesian covers one octant: no NaN fallback)
+    if seed % 4 != 0:
+        over.update(plasma_power_frac=float(rng.uniform(0.05, 0.6)), plasma_p=float(rng.uniform(2.1, 3.5)),
+                    plasma_gamma_min=float(rng.uniform(1.0, 10.0)), plasma_gamma_max=float(rng.uniform(500.0, 5000.0)))
+    if seed % 2 == 0:
+        over["simulation_coord"] = "cks"
+    if over["image_num_frequencies"] > 1:
+        over.update(image_frequency_start=1.0e11, image_frequency_end=float(10.0 ** rng.uniform(11.3, 12.0)), image_frequency_spacing="log")
+    params = dict(params, **over)
+    assert _applies(params)
+    out = _both(params, mock_args)
+    exact, tol = out["exact"], out["tolerant"]
+    assert tol["stats"].arithmetic == 1 and exact["stats"].arithmetic == 0
+    assert np.array_equal(tol["sample_num"], exact["sample_num"]) and np.array_equal(tol["sample_flags"], exact["sample_flags"])
+    assert np.array_equal(np.isnan(tol["image"]), np.isnan(exact["image"])), over
+    d = _distance(tol["image"], exact["image"])
+    print(f"seed {seed}: {d:.2e}, deferred {tol['stats'].n_deferred}")
+    assert d < EXPECTED, over
+    assert np.isfinite(exact["image"]).mean() > 0.5 and np.nanmax(exact["image"]) > 0.0
+
+
+@pytest.mark.parametrize("band,resolution,frequencies,variant", [(1.0e30, 24, 1, ""), (1.0e30, 56, 1, ""), (1.0e30, 24, 5, ""), (1.0e30, 56, 5, ""),
+                                                                 (1.0e30, 24, 1, "power"), (1.0e30, 24, 3, "cks"), (1.0e30, 24, 3, "cks power")])
+def test_deferred_cut_decisions(band, resolution, frequencies, variant, built_library):
     """An unbounded guard band defers every sample that reaches the cell cuts to the exact kernel: through the list
     (24^2 rays), and past its capacity (56^2 rays x ~700 samples > 2^20 entries: every record is then shaded by the
     exact kernel). Same image either way - with one frequency (transfer records) and with five (per-sample factors for
@@ -146,6 +177,11 @@ def test_deferred_cut_decisions(band, resolution, frequencies, built_library):
     # sim_cuts: rho, B and 1 / beta thresholds behind geometric cuts; sim_dp_interp (sigma < 1 only) keeps nearly every sample
     fx, params, mock_args = gu.load_case("sim_cuts" if resolution < 40 else "sim_dp_interp")
     params = dict(params, camera_resolution=resolution)
+    # (the exact kernel's instantiations behind the general fast kernel: extended for power laws, general for Cartesian grids)
+    if "power" in variant:
+        params.update(plasma_power_frac=0.3, plasma_p=2.5, plasma_gamma_min=1.0, plasma_gamma_max=1000.0)
+    if "cks" in variant:
+        params.update(simulation_coord="cks", simulation_a=0.5, fallback_nan="false", fallback_rho=1.0e-6, fallback_pgas=1.0e-8)
     if frequencies > 1:
         params.update(image_num_frequencies=frequencies, image_frequency_start=1.0e11, image_frequency_end=8.0e11, image_frequency_spacing="log")
         params.pop("image_frequency", None)
