@@ -736,6 +736,9 @@ int bl_set_grid(bl_ctx *ctx, const bl_grid_desc *g) {
       }
     }
     ctx->grid_meta = *g;
+    ctx->grid_outer_x1 = g->x1f[g->n_i];
+    for (int blk = 1; blk < g->n_blocks; blk++)
+      ctx->grid_outer_x1 = std::max(ctx->grid_outer_x1, g->x1f[static_cast<size_t>(blk) * (g->n_i + 1) + g->n_i]);
     ctx->have_grid = true;
   } catch (const Failure &failure) {
     return Fail(ctx, failure);

@@ -137,6 +137,7 @@ struct bl_ctx {
   DeviceBuffer<int> d_block_table;                  // inter-block interpolation: levels, locations, hash blocks
   DeviceBuffer<unsigned long long> d_block_keys;    // ... and hash keys
   BlGridDevice grid_dev{};
+  double grid_outer_x1 = 0.0;   // largest outer x1 face of the grid's blocks (bl_set_grid)
   std::vector<int> merged_block_at;   // merged grid: lattice position (k, j, i of the block) -> MeshBlock of the file
   int merged_blocks[3] = {1, 1, 1};   // ... and the lattice's extent
   bool sample_checkpoint_saved = false;   // checkpoint_sample_save: written with the first image only (radiation_integrator.cpp:699-704)
@@ -195,11 +196,11 @@ struct bl_ctx {
   // per ray of a bl_render call (indexed by traversal position; a chunk's kernels get pointers to its first ray)
   DeviceBuffer<double> d_ray_kt, d_ray_factor;
   DeviceBuffer<double> d_ray_start;              // BL_RAY_START_FIELDS rows: start state of every ray (bl_ray_init_kernel -> geodesic kernel)
-  DeviceBuffer<int> d_ray_sample_num;
+  DeviceBuffer<int> d_ray_sample_num, d_ray_skipped;
   DeviceBuffer<unsigned char> d_ray_flags;
   DeviceBuffer<long long> d_ray_out_index, d_ray_offset;
   uint64_t RayBytes() const {
-    return (d_ray_kt.count + d_ray_factor.count + d_ray_start.count) * sizeof(double) + d_ray_sample_num.count * sizeof(int) + d_ray_flags.count
+    return (d_ray_kt.count + d_ray_factor.count + d_ray_start.count) * sizeof(double) + (d_ray_sample_num.count + d_ray_skipped.count) * sizeof(int) + d_ray_flags.count
         + (d_ray_out_index.count + d_ray_offset.count) * sizeof(long long);
   }
   DeviceBuffer<double> d_freq;

@@ -244,6 +244,14 @@ struct BlTraceArgs {
   // [field][chunk slot] - t, x, y, z, k_x, k_y, k_z | k_t | r | first-stage derivatives (Dormand-Prince only)
   double *ray_start;
   long long ray_start_stride;
+  // Steps in the empty shell between the grid's outer edge and the camera's sphere leave no records (plain images of a spherical
+  // Kerr-Schild simulation with fallback values: every sample there is off the grid, has no field and adds nothing, simulation_
+  // sampling.cpp:352-394, simulation_coefficients.cpp:394). A step is skipped when the bound |p - y| <= sum_q |r_q| on its dense
+  // output puts all its samples there: |y| - d > skip_low (= sqrt(r_out^2 (1 + 1e-9) + a^2); r_KS^2 >= R^2 - a^2) and
+  // |y| + d < skip_high (= camera_r (1 - 1e-9); r_KS <= R). skip_low = +inf: every step is recorded. The samples still count
+  // (sample_num, ray_max_steps); ray_skipped[slot] is how many of a ray's samples have no record.
+  double skip_low, skip_high;
+  int *ray_skipped;
 };
 #define BL_RAY_START_FIELDS 17
 
@@ -365,7 +373,8 @@ struct BlTransferArgs {
   double cam_u_con[4], cam_u_cov[4], cam_vert_con_c[4];
   const double2 *transfer;
   const unsigned long long *counters;      // BL_CNT_NEXT_RAY: rays of the chunk the geodesic kernel traced (bl_rays_done)
-  const int *ray_sample_num;
+  const int *ray_sample_num;               // [chunk_rays]: kept samples with a record (= rows) of each ray
+  const int *ray_skipped;                  // [chunk_rays] or null: its samples without a record (BlTraceArgs::skip_low)
   const unsigned char *ray_flags;
   const long long *ray_out_index;
   const long long *ray_offset;             // [chunk_rays]: first sample row of each ray

@@ -245,6 +245,7 @@ __global__ void __launch_bounds__(64, BL_GEO_ONE_WAVE(kIntegrator, kTime, kSpinZ
   double k0[8];
   double h_new = 0.0, r_cur = 0.0, r_prev_sample = 0.0;
   int num_retry = 0, n = 0, sample_num = 0, trunc_at = -1;
+  int skipped = 0;   // samples of the ray without a record (BlTraceArgs::skip_low)
   unsigned int slot = 0;
   bool previous_fail = false, flag = false;
   for (int p = 0; p < 8; p++) {
@@ -325,6 +326,7 @@ __global__ void __launch_bounds__(64, BL_GEO_ONE_WAVE(kIntegrator, kTime, kSpinZ
           flag = false;
           n = 0;
           sample_num = 0;
+          skipped = 0;
           trunc_at = -1;
           r_prev_sample = 0.0;
         }
@@ -519,6 +521,28 @@ __global__ void __launch_bounds__(64, BL_GEO_ONE_WAVE(kIntegrator, kTime, kSpinZ
       }
     }
 
+    // ------------------------------------------------------------------ steps that leave no records (BlTraceArgs::skip_low)
+    // Every sample of the step lies within d = sum over x, y, z of |r0| + |r1| + |r2| + |r3| of the base point (the weights of the
+    // dense output are products of numbers in [0, 1]; a midpoint step has coefficients of -0). Such a step cannot hold the
+    // sample that ends the ray either (r <= camera_r, r > r_terminate), and whatever sample follows it compares with a
+    // predecessor inside the camera's sphere: any r_prev_sample <= camera_r gives the same answer.
+    if (emit > 0 && P.skip_low < __builtin_inf()) {
+      const bool dense = num_steps_ideal > 1;
+      double d = 0.0, rr = 0.0;
+#pragma unroll
+      for (int p = 1; p < 4; p++) {
+        const double b = dense ? s.y[p] : y4m[p];
+        rr += b * b;
+        d += (blm_abs(rv0[p]) + blm_abs(rv1[p])) + (blm_abs(rv2[p]) + blm_abs(rv3[p]));
+      }
+      const double low = P.skip_low + d, high = P.skip_high - d;
+      if (rr > low * low && high > 0.0 && rr < high * high && trunc_at < 0) {
+        skipped += emit;
+        emit = 0;
+        r_prev_sample = 0.0;
+      }
+    }
+
     // ------------------------------------------------------------------ allocate sample slots
     // Each wave owns a block of BL_RECORD_BLOCK consecutive record slots and hands them out with one
     // wave scan per step; the global atomic (whose return has to be waited for, with nothing else to
@@ -596,7 +620,7 @@ __global__ void __launch_bounds__(64, BL_GEO_ONE_WAVE(kIntegrator, kTime, kSpinZ
         hot.y = smp[2];
         hot.z = smp[3];
         hot.ray = dead ? BL_DEAD_RAY : slot;
-        hot.n = (unsigned int)index;
+        hot.n = (unsigned int)(index - skipped);   // its row among the ray's records
         // (a lane's samples side by side, the lanes' runs end to end: consecutive records are consecutive samples of a ray, which
         // read the same grid cells - laid out row by row instead, the coefficient kernels take 4 ms longer per frame)
         const int place = excl + nn;
@@ -642,12 +666,13 @@ __global__ void __launch_bounds__(64, BL_GEO_ONE_WAVE(kIntegrator, kTime, kSpinZ
       r_cur = r_new;
     }
     if (have_ray && finish) {
-      int final_num = (trunc_at >= 0) ? trunc_at : sample_num;
+      const int final_num = ((trunc_at >= 0) ? trunc_at : sample_num) - skipped;   // kept samples with a record
       P.ray_sample_num[slot] = final_num;
+      if (P.ray_skipped != nullptr) P.ray_skipped[slot] = skipped;
       P.ray_flags[slot] = flag ? 1 : 0;
       // rows of the kept samples in the per-sample arrays, in the order in which rays finish; slots not emitted go back
       P.ray_offset[slot] = (long long)atomicAdd(&P.counters[BL_CNT_SAMPLES], (unsigned long long)final_num);
-      atomicAdd(&P.counters[BL_CNT_COMMITTED], (unsigned long long)(-(long long)(P.ray_max_steps - sample_num)));
+      atomicAdd(&P.counters[BL_CNT_COMMITTED], (unsigned long long)(-(long long)(P.ray_max_steps - (sample_num - skipped))));
       have_ray = false;
     }
   }
@@ -1914,8 +1939,13 @@ __device__ __forceinline__ PlainLocated locate_plain_sample(const BlSpacetime &s
   const double r = bl_radial_coordinate2<kSpinZero>(st, x1, x2, x3, &r2);
   const bool cut = r > camera_r;                                   // simulation_sampling.cpp:238-243
   // ConvertFromCKS (radiation_geometry.cpp:37-57), as in locate_sample()
+#ifdef BL_EXP_CHEAP_ANGLES   // experiment (wrong images): what the inverse trigonometric functions cost the fused kernel
+  const double th = 1.5707963 - 1.2 * blm_div(x3, r);
+  const double ph_unwrapped = 3.14159 + 3.0 * blm_div(x2, fabs(x1) + fabs(x2) + 1.0e-300) * (x1 < 0.0 ? 0.5 : 1.0);
+#else
   const double th = bl_acos(blm_div(x3, r));
   const double ph_unwrapped = kSpinZero ? bl_atan2(x2, x1) : bl_atan2(x2, x1) - bl_atan(blm_div(st.bh_a, r));
+#endif
   double ph = ph_unwrapped;
   ph += ph < 0.0 ? 2.0 * kPi : 0.0;
   ph -= ph >= 2.0 * kPi ? 2.0 * kPi : 0.0;
@@ -3018,10 +3048,11 @@ __global__ void __launch_bounds__(256) bl_transfer_freq_kernel(BlTransferArgs P)
     const bool flag = P.ray_flags[slot] != 0;
     const long long out_index = P.ray_out_index[slot];
     if (l == 0) {
-      samples = (unsigned long long)num;
+      const int all = num + (P.ray_skipped != nullptr ? P.ray_skipped[slot] : 0);
+      samples = (unsigned long long)all;
       flagged = flag ? 1ull : 0ull;
-      max_num = num;
-      if (P.out_sample_num != nullptr) P.out_sample_num[out_index] = num;
+      max_num = all;
+      if (P.out_sample_num != nullptr) P.out_sample_num[out_index] = all;
       if (P.out_flags != nullptr) P.out_flags[out_index] = flag ? 1 : 0;
     }
     const double nan = __longlong_as_double(0x7ff8000000000000ll);
@@ -3351,10 +3382,11 @@ __global__ void __launch_bounds__(256) bl_transfer_kernel(BlTransferArgs P) {
     bool flag = P.ray_flags[slot] != 0;
     long long out_index = P.ray_out_index[slot];
     if (l == 0) {
-      samples = (unsigned long long)num;
+      const int all = num + (P.ray_skipped != nullptr ? P.ray_skipped[slot] : 0);   // the ray's samples, with or without a record
+      samples = (unsigned long long)all;
       flagged = flag ? 1ull : 0ull;
-      max_num = num;
-      if (P.out_sample_num != nullptr) P.out_sample_num[out_index] = num;
+      max_num = all;
+      if (P.out_sample_num != nullptr) P.out_sample_num[out_index] = all;
       if (P.out_flags != nullptr) P.out_flags[out_index] = flag ? 1 : 0;
     }
     const double nan = __longlong_as_double(0x7ff8000000000000ll);

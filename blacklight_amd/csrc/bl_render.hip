@@ -115,6 +115,7 @@ struct RenderJob {
   bool rows_only = false, fill_present = false;
   bool interleaved = false;   // sample records as one 64-byte array instead of two of 32-byte halves
   bool fast_formula = false;   // tolerant tier in formula mode: bl_shade_formula_fast_kernel
+  bool skip_shell = false;   // steps between the grid's outer edge and the camera's sphere leave no records (BlTraceArgs::skip_low)
   bool fused = false;   // tolerant tier, common grid case: the locate step runs inside the coefficient kernel (bl_shade_fused_kernel)
   int n_nu = 0, n_q = 0, max_steps = 0;
   long long n_rays = 0, level_pixels = 0;
@@ -234,6 +235,11 @@ void PlanJob(RenderJob &job) {
       && static_cast<size_t>(ctx->lds_table_bytes) + (44 + 5 * static_cast<size_t>(job.n_nu)) * sizeof(double) <= 60u * 1024u
       && !job.sample_save && std::getenv("BLACKLIGHT_AMD_NO_FUSED_LOCATE") == nullptr;   // (a sample checkpoint is made of the located samples)
   job.interleaved = (job.fused || !job.simulation) && !job.geo_load && !job.geo_save && !job.sample_save && std::getenv("BLACKLIGHT_AMD_SPLIT_RECORDS") == nullptr;
+  // Plain images of a spherical Kerr-Schild simulation with fallback values beyond the grid: nothing is recorded of the steps that
+  // lie in the empty shell between the grid's outer edge and the camera's sphere (both tiers; the samples count as ever)
+  job.skip_shell = job.simulation && !job.aux && !ctx->polarized && !job.slow && !job.geo_load && !job.geo_save && !job.sample_save
+      && !job.need_time && p.simulation_coord == BL_COORD_SKS && !ctx->grid_dev.fmks && !p.fallback_nan && ctx->grid_outer_x1 > 0.0
+      && ctx->grid_outer_x1 < p.camera_r && std::getenv("BLACKLIGHT_AMD_RECORD_EVERY_STEP") == nullptr;
   // ... and in the exact coefficient kernel (plain images): the frequency loop as lanes of bl_coefficients_freq_kernel
   job.coef_split = !job.fast && job.simulation && !job.aux && !ctx->polarized && job.n_nu >= 4;
   // (polarized runs list the samples without coefficients there - cut samples, cut cells - which are many more)
@@ -345,6 +351,7 @@ void EnsureScratch(RenderJob &job) {
   ctx->d_ray_kt.Ensure(n_rays);
   ctx->d_ray_factor.Ensure(n_rays);
   ctx->d_ray_sample_num.Ensure(n_rays);
+  if (job.skip_shell) ctx->d_ray_skipped.Ensure(n_rays);
   ctx->d_ray_flags.Ensure(n_rays);
   ctx->d_ray_out_index.Ensure(n_rays);
   ctx->d_ray_offset.Ensure(n_rays);
@@ -460,6 +467,13 @@ void BuildTraceArgs(RenderJob &job) {
   ta.r_terminate = ctx->frame.r_terminate;
   ta.r_horizon = ctx->frame.r_horizon;
   ta.camera_r = p.camera_r;
+  ta.skip_low = std::numeric_limits<double>::infinity();
+  ta.skip_high = 0.0;
+  if (job.skip_shell) {
+    const double a = ctx->st.bh_a;
+    ta.skip_low = std::sqrt(ctx->grid_outer_x1 * ctx->grid_outer_x1 * (1.0 + 1.0e-9) + a * a) * (1.0 + 1.0e-12);
+    ta.skip_high = p.camera_r * (1.0 - 1.0e-9);
+  }
   ta.ray_step = p.ray_step;
   ta.ray_tol_abs = p.ray_integrator == BL_INTEGRATOR_DP ? p.ray_tol_abs : 0.0;
   ta.ray_tol_rel = p.ray_integrator == BL_INTEGRATOR_DP ? p.ray_tol_rel : 0.0;
@@ -806,6 +820,7 @@ void BindChunk(RenderJob &job, int k, long long begin, int rays) {
   ta.ray_kt = ctx->d_ray_kt.ptr + begin;
   ta.ray_factor = ctx->d_ray_factor.ptr + begin;
   ta.ray_sample_num = ctx->d_ray_sample_num.ptr + begin;
+  ta.ray_skipped = job.skip_shell ? ctx->d_ray_skipped.ptr + begin : nullptr;
   ta.ray_flags = ctx->d_ray_flags.ptr + begin;
   ta.ray_out_index = ctx->d_ray_out_index.ptr + begin;
   ta.ray_offset = ctx->d_ray_offset.ptr + begin;
@@ -837,6 +852,7 @@ void BindChunk(RenderJob &job, int k, long long begin, int rays) {
   xa.transfer = sl.d_transfer.ptr;
   xa.freq_inputs = sa.freq_inputs;
   xa.ray_sample_num = ta.ray_sample_num;
+  xa.ray_skipped = ta.ray_skipped;
   xa.ray_flags = ta.ray_flags;
   xa.ray_out_index = ta.ray_out_index;
   xa.ray_offset = ta.ray_offset;

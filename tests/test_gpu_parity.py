@@ -303,6 +303,55 @@ def test_randomised_configurations_against_oracle(seed, built_library):
     assert same.all(), f"{(~same).sum()} of {same.size} values differ for {over}"
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_empty_shell_steps_leave_no_records(seed, built_library, monkeypatch):
+    """Camera outside the grid, fallback values beyond it: the geodesic kernel records nothing of the steps that lie between the
+    grid's outer edge and the camera's sphere (BlTraceArgs::skip_low) - off the grid, no field, nothing added
+    (simulation_sampling.cpp:352-394, simulation_coefficients.cpp:394). Same image, counts and flags as the oracle and as the
+    same library recording every step, in both tiers; integrators, spins, cameras, meshes and frequency lists drawn."""
+    import blacklight_amd as bl
+    from blacklight_amd import _capi
+    import oracle_api
+    rng = np.random.default_rng(4400 + seed)
+    fx, params, mock_args = gu.load_case("sim_dp_interp")
+    over = dict(camera_resolution=20, camera_r=float(rng.uniform(60.0, 400.0)), camera_th=float(rng.uniform(5.0, 175.0)),
+                camera_ph=float(rng.uniform(0.0, 360.0)), camera_type=str(rng.choice(["plane", "pinhole"])),
+                camera_width=float(rng.uniform(20.0, 130.0)), simulation_a=float(rng.choice([0.0, 0.5, 0.95])),
+                ray_integrator=str(rng.choice(["dp", "dp", "rk4", "rk2"])), ray_step=float(rng.choice([0.01, 0.03])),
+                ray_terminate=str(rng.choice(["photon", "multiplicative"])), simulation_interp=str(rng.choice(["true", "false"])),
+                fallback_nan="false", fallback_rho=1.0e-6, fallback_pgas=1.0e-8, image_num_frequencies=int(rng.choice([1, 1, 5])))
+    if over["camera_type"] == "pinhole":
+        over["camera_width"] = float(rng.uniform(0.2, 0.8)) * over["camera_r"]
+    if over["image_num_frequencies"] > 1:
+        over.update(image_frequency_start=1.0e11, image_frequency_end=9.0e11, image_frequency_spacing="log")
+    mesh = [{}, dict(_blocks=[2, 2, 2]), dict(_refined=1)][seed % 3]
+    params = dict(params, **over)
+    p = bl.Params.from_dict(params)
+    grid = gu.golden_grid(dict(mock_args, **mesh))
+    out = {}
+    with bl.Context(p) as ctx:
+        ctx.set_grid(grid)
+        for tier in ("exact", "tolerant"):
+            ctx.set_arithmetic(tier)
+            out[tier] = ctx.render()
+            monkeypatch.setenv("BLACKLIGHT_AMD_RECORD_EVERY_STEP", "1")
+            out[tier + " all"] = ctx.render()
+            monkeypatch.delenv("BLACKLIGHT_AMD_RECORD_EVERY_STEP")
+    res = 20
+    want = oracle_api.render(p.ptr, grid.desc(), _capi.RenderDesc, _capi.CameraFrame, n_rays=res * res, max_steps=int(p.get("ray_max_steps")),
+                             n_freq=int(p.get("image_num_frequencies")))
+    for tier in ("exact", "tolerant"):
+        got, every = out[tier], out[tier + " all"]
+        assert np.array_equal(got["sample_num"], want["sample_num"]) and np.array_equal(got["sample_flags"], want["sample_flags"]), over
+        assert got["stats"].n_samples == want["n_samples"] == every["stats"].n_samples and got["stats"].n_gathers == want["n_gathers"]
+        assert got["stats"].max_sample_num == every["stats"].max_sample_num == int(want["sample_num"].max())
+        assert gu.same_bits(got["image"], every["image"]).all(), over     # (the skipped records are identities in either tier)
+        assert every["stats"].n_samples_emitted >= every["stats"].n_samples
+        assert got["stats"].n_samples_emitted < 0.9 * every["stats"].n_samples_emitted, over
+    assert gu.same_bits(out["exact"]["image"], want["image"]).all(), over
+    assert np.nanmax(want["image"]) > 0.0
+
+
 @pytest.mark.parametrize("seed", range(10))
 def test_randomised_polarized_configurations_against_oracle(seed, built_library):
     """Seeded draws of polarized runs (joint coupling / rotation split, spins, one or two frequencies, nearest or

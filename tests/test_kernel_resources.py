@@ -19,8 +19,17 @@ BENCHMARK_KERNELS = {
     "_Z15bl_shade_kernelILi0ELb0ELb0ELb1ELb0ELb1ELb0EEv11BlShadeArgs": (2, 0),   # simulation, thermal electrons, SKS + curved, zero spin
     "_Z15bl_shade_kernelILi0ELb0ELb0ELb1ELb0ELb0ELb0EEv11BlShadeArgs": (2, 0),   # ... any spin
     "_Z15bl_shade_kernelILi0ELb0ELb0ELb0ELb0ELb0ELb0EEv11BlShadeArgs": (2, 0),   # the same for any coordinates
-    "_Z20bl_shade_fast_kernelILb1EEv11BlShadeArgs": (None, 0),               # tolerant tier, zero spin
-    "_Z20bl_shade_fast_kernelILb0EEv11BlShadeArgs": (None, 0),
+    "_Z20bl_shade_fast_kernelILb1ELb0EEv11BlShadeArgs": (2, 0),              # tolerant tier, zero spin
+    "_Z20bl_shade_fast_kernelILb0ELb0EEv11BlShadeArgs": (2, 0),
+    "_Z20bl_shade_fast_kernelILb1ELb1EEv11BlShadeArgs": (2, 0),              # ... power laws / Cartesian grids
+    "_Z20bl_shade_fast_kernelILb0ELb1EEv11BlShadeArgs": (2, 0),
+    "_Z21bl_shade_fused_kernelILb1EEv11BlShadeArgs": (2, 0),                 # ... locate step inside (the benchmark's kernel)
+    "_Z21bl_shade_fused_kernelILb0EEv11BlShadeArgs": (2, 0),
+    "_Z21bl_shade_exact_kernelILb1EEv11BlShadeArgs": (2, 0),                 # exact tier, software-pipelined
+    "_Z21bl_shade_exact_kernelILb0EEv11BlShadeArgs": (2, 0),
+    "_Z22bl_locate_plain_kernelILb1EEv11BlShadeArgs": (4, 0),                # exact tier's locate step, common grid case
+    "_Z22bl_locate_plain_kernelILb0EEv11BlShadeArgs": (4, 0),
+    "_Z28bl_shade_formula_fast_kernel11BlShadeArgs": (None, 0),              # tolerant tier, formula mode
     "_Z15bl_shade_kernelILi0ELb0ELb0ELb1ELb0ELb1ELb1EEv11BlShadeArgs": (2, 0),   # ... its exact second pass
     "_Z18bl_transfer_kernelILb0EEv14BlTransferArgs": (None, 0),
     "_Z18bl_transfer_kernelILb1EEv14BlTransferArgs": (None, 0),

@@ -48,4 +48,22 @@ for nf, tier in ((10, "exact"), (10, "tolerant"), (64, "exact"), (64, "tolerant"
         out[f"true_color_1024_{nf}freq_{tier}"] = dict(seconds=sec, mrays_per_s=1024 * 1024 / sec / 1e6, ms_geodesic=st.ms_geodesic,
                                                 ms_locate=st.ms_locate, ms_shade=st.ms_shade, ms_transfer=st.ms_transfer, chunks=st.n_chunks,
                                                 finite_fraction=float(np.isfinite(res["image"]).mean()))
+# camera outside the grid (r = 100, the grid ends at 52; fallback values beyond it): the benchmark frame from farther away.
+# Steps in the empty shell leave no records (BlTraceArgs::skip_low); BLACKLIGHT_AMD_RECORD_EVERY_STEP = the same frame without that.
+for tier in ("exact", "tolerant"):
+    p = dict(bench.WORKLOAD)
+    p.update(camera_r=100.0, fallback_nan=False, fallback_rho=1.0e-6, fallback_pgas=1.0e-8)
+    with bl.Context(bl.Params.from_dict(p)) as ctx:
+        ctx.set_grid(grid)
+        ctx.set_arithmetic(tier)
+        for every in (False, True):
+            if every:
+                os.environ["BLACKLIGHT_AMD_RECORD_EVERY_STEP"] = "1"
+            res, sec = timed(ctx, n=2)
+            os.environ.pop("BLACKLIGHT_AMD_RECORD_EVERY_STEP", None)
+            st = res["stats"]
+            out[f"camera_at_100_{tier}" + ("_every_step_recorded" if every else "")] = dict(
+                seconds=sec, mrays_per_s=1024 * 1024 / sec / 1e6, samples_per_ray=st.n_samples / (1024 * 1024),
+                records_per_ray=st.n_samples_emitted / (1024 * 1024), ms_geodesic=st.ms_geodesic, ms_locate=st.ms_locate,
+                ms_shade=st.ms_shade, ms_transfer=st.ms_transfer, chunks=st.n_chunks, image_sum=float(np.nansum(res["image"])))
 print(json.dumps(out, indent=1))
