@@ -231,7 +231,8 @@ __device__ __forceinline__ double opaque_uniform(double v) {
   asm volatile("" : "+s"(v));
   return v;
 }
-template <int kIntegrator, bool kTime, bool kSpinZero>
+template <int kIntegrator, bool kTime, bool kSpinZero, bool kShell = false>
+// kShell: the instantiation that leaves no records of steps in the empty shell around the grid (BlTraceArgs::skip_low).
 // Two waves per SIMD: the benchmark's instantiation (Dormand-Prince, no sample times, zero spin) and the Runge-Kutta steppers
 // fit 256 registers; see BL_GEO_ONE_WAVE for the others.
 __global__ void __launch_bounds__(64, BL_GEO_ONE_WAVE(kIntegrator, kTime, kSpinZero) ? 1 : BL_GEO_WAVES) bl_geodesic_kernel(BlTraceArgs P) {
@@ -526,7 +527,7 @@ __global__ void __launch_bounds__(64, BL_GEO_ONE_WAVE(kIntegrator, kTime, kSpinZ
     // dense output are products of numbers in [0, 1]; a midpoint step has coefficients of -0). Such a step cannot hold the
     // sample that ends the ray either (r <= camera_r, r > r_terminate), and whatever sample follows it compares with a
     // predecessor inside the camera's sphere: any r_prev_sample <= camera_r gives the same answer.
-    if (emit > 0 && P.skip_low < __builtin_inf()) {
+    if (kShell && emit > 0) {
       const bool dense = num_steps_ideal > 1;
       double d = 0.0, rr = 0.0;
 #pragma unroll
@@ -620,7 +621,7 @@ __global__ void __launch_bounds__(64, BL_GEO_ONE_WAVE(kIntegrator, kTime, kSpinZ
         hot.y = smp[2];
         hot.z = smp[3];
         hot.ray = dead ? BL_DEAD_RAY : slot;
-        hot.n = (unsigned int)(index - skipped);   // its row among the ray's records
+        hot.n = (unsigned int)(kShell ? index - skipped : index);   // its row among the ray's records
         // (a lane's samples side by side, the lanes' runs end to end: consecutive records are consecutive samples of a ray, which
         // read the same grid cells - laid out row by row instead, the coefficient kernels take 4 ms longer per frame)
         const int place = excl + nn;
@@ -666,13 +667,13 @@ __global__ void __launch_bounds__(64, BL_GEO_ONE_WAVE(kIntegrator, kTime, kSpinZ
       r_cur = r_new;
     }
     if (have_ray && finish) {
-      const int final_num = ((trunc_at >= 0) ? trunc_at : sample_num) - skipped;   // kept samples with a record
+      const int final_num = ((trunc_at >= 0) ? trunc_at : sample_num) - (kShell ? skipped : 0);   // kept samples with a record
       P.ray_sample_num[slot] = final_num;
-      if (P.ray_skipped != nullptr) P.ray_skipped[slot] = skipped;
+      if (kShell) P.ray_skipped[slot] = skipped;
       P.ray_flags[slot] = flag ? 1 : 0;
       // rows of the kept samples in the per-sample arrays, in the order in which rays finish; slots not emitted go back
       P.ray_offset[slot] = (long long)atomicAdd(&P.counters[BL_CNT_SAMPLES], (unsigned long long)final_num);
-      atomicAdd(&P.counters[BL_CNT_COMMITTED], (unsigned long long)(-(long long)(P.ray_max_steps - (sample_num - skipped))));
+      atomicAdd(&P.counters[BL_CNT_COMMITTED], (unsigned long long)(-(long long)(P.ray_max_steps - (sample_num - (kShell ? skipped : 0)))));
       have_ray = false;
     }
   }
@@ -3660,42 +3661,46 @@ extern "C" hipError_t bl_launch_ray_init(const BlTraceArgs *args, int integrator
   return hipGetLastError();
 }
 
+// One expression per instantiation of the geodesic kernel (integrator x sample times x zero spin x empty shell; the last two
+// only without sample times)
+#define BL_GEODESIC_CASES(I, DO)                                                      \
+  do {                                                                                \
+    if (with_time && spin_zero) DO((bl_geodesic_kernel<I, true, true, false>));       \
+    else if (with_time) DO((bl_geodesic_kernel<I, true, false, false>));              \
+    else if (spin_zero && shell) DO((bl_geodesic_kernel<I, false, true, true>));      \
+    else if (spin_zero) DO((bl_geodesic_kernel<I, false, true, false>));              \
+    else if (shell) DO((bl_geodesic_kernel<I, false, false, true>));                  \
+    else DO((bl_geodesic_kernel<I, false, false, false>));                            \
+  } while (0)
+
 extern "C" hipError_t bl_launch_geodesic(const BlTraceArgs *args, int integrator, int grid, hipStream_t stream) {
   const bool with_time = args->sample_t != nullptr;
   const bool spin_zero = args->st.bh_a == 0.0;   // also true for -0.0: the instantiation never reads bh_a
-#define BL_LAUNCH_G(I)                                                                                             \
-  do {                                                                                                             \
-    if (with_time && spin_zero) hipLaunchKernelGGL((bl_geodesic_kernel<I, true, true>), dim3(grid), dim3(64), 0, stream, *args);    \
-    else if (with_time) hipLaunchKernelGGL((bl_geodesic_kernel<I, true, false>), dim3(grid), dim3(64), 0, stream, *args);           \
-    else if (spin_zero) hipLaunchKernelGGL((bl_geodesic_kernel<I, false, true>), dim3(grid), dim3(64), 0, stream, *args);           \
-    else hipLaunchKernelGGL((bl_geodesic_kernel<I, false, false>), dim3(grid), dim3(64), 0, stream, *args);        \
-  } while (0)
+  const bool shell = args->ray_skipped != nullptr;
+  if (shell && with_time) return hipErrorInvalidValue;
+#define BL_LAUNCH_G(K) hipLaunchKernelGGL(K, dim3(grid), dim3(64), 0, stream, *args)
   switch (integrator) {
-    case BL_INTEGRATOR_DP: BL_LAUNCH_G(BL_INTEGRATOR_DP); break;
-    case BL_INTEGRATOR_RK4: BL_LAUNCH_G(BL_INTEGRATOR_RK4); break;
-    default: BL_LAUNCH_G(BL_INTEGRATOR_RK2); break;
+    case BL_INTEGRATOR_DP: BL_GEODESIC_CASES(BL_INTEGRATOR_DP, BL_LAUNCH_G); break;
+    case BL_INTEGRATOR_RK4: BL_GEODESIC_CASES(BL_INTEGRATOR_RK4, BL_LAUNCH_G); break;
+    default: BL_GEODESIC_CASES(BL_INTEGRATOR_RK2, BL_LAUNCH_G); break;
   }
 #undef BL_LAUNCH_G
   return hipGetLastError();
 }
 
 // Workgroups (= waves) of the geodesic kernel one CU holds: the persistent grid is this many per CU
-extern "C" int bl_geodesic_occupancy(int integrator, int with_time, int spin_zero) {
+extern "C" int bl_geodesic_occupancy(int integrator, int with_time_flag, int spin_zero_flag, int shell_flag) {
   int blocks = 0;
   hipError_t err = hipSuccess;
-#define BL_OCCUPANCY_G(I)                                                                                                        \
-  do {                                                                                                                           \
-    if (with_time && spin_zero) err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, bl_geodesic_kernel<I, true, true>, 64, 0);   \
-    else if (with_time) err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, bl_geodesic_kernel<I, true, false>, 64, 0);          \
-    else if (spin_zero) err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, bl_geodesic_kernel<I, false, true>, 64, 0);          \
-    else err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, bl_geodesic_kernel<I, false, false>, 64, 0);                        \
-  } while (0)
+  const bool with_time = with_time_flag != 0, spin_zero = spin_zero_flag != 0, shell = shell_flag != 0;
+#define BL_OCCUPANCY_G(K) err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, K, 64, 0)
   switch (integrator) {
-    case BL_INTEGRATOR_DP: BL_OCCUPANCY_G(BL_INTEGRATOR_DP); break;
-    case BL_INTEGRATOR_RK4: BL_OCCUPANCY_G(BL_INTEGRATOR_RK4); break;
-    default: BL_OCCUPANCY_G(BL_INTEGRATOR_RK2); break;
+    case BL_INTEGRATOR_DP: BL_GEODESIC_CASES(BL_INTEGRATOR_DP, BL_OCCUPANCY_G); break;
+    case BL_INTEGRATOR_RK4: BL_GEODESIC_CASES(BL_INTEGRATOR_RK4, BL_OCCUPANCY_G); break;
+    default: BL_GEODESIC_CASES(BL_INTEGRATOR_RK2, BL_OCCUPANCY_G); break;
   }
 #undef BL_OCCUPANCY_G
+#undef BL_GEODESIC_CASES
   if (err != hipSuccess || blocks < 1) blocks = 4;
   return blocks;
 }

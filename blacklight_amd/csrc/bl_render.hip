@@ -283,7 +283,7 @@ void PlanScratch(RenderJob &job) {
       if (available < budget) budget = available;
     }
   }
-  const int waves_per_cu = bl_geodesic_occupancy(p.ray_integrator, job.need_time ? 1 : 0, ctx->st.bh_a == 0.0 ? 1 : 0);
+  const int waves_per_cu = bl_geodesic_occupancy(p.ray_integrator, job.need_time ? 1 : 0, ctx->st.bh_a == 0.0 ? 1 : 0, job.skip_shell ? 1 : 0);
   const long long max_grid = std::min<long long>(static_cast<long long>(ctx->num_cus) * waves_per_cu, (job.n_rays + 63) / 64);
   const uint64_t worst_case = static_cast<uint64_t>(job.n_rays) * job.max_steps + static_cast<uint64_t>(max_grid) * BL_RECORD_BLOCK;
   const uint64_t fixed = per_ray * static_cast<uint64_t>(job.n_rays);

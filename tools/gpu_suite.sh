@@ -1,5 +1,10 @@
-# the whole -m gpu suite, log under gpurun_out/
+# the whole -m gpu suite, log under gpurun_out/, then one short bench line
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 timeout 1100 python -m pytest tests -m gpu -q -x --timeout 900 > gpurun_out/r3_gpu_suite.log 2>&1
-tail -15 gpurun_out/r3_gpu_suite.log
+tail -8 gpurun_out/r3_gpu_suite.log
+timeout 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "
+import sys, json
+d = json.loads(sys.stdin.read())
+print('Mrays/s', round(d['value'],3), 'ms/step', round(d['ms_per_step'],1), {k: round(v,1) for k,v in d['kernel_ms_per_step'].items()})
+"
