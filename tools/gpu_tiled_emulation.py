@@ -37,7 +37,7 @@ with bl.Context(bl.Params.from_dict(p)) as ctx:
                 st = ctx.render_device(image.data_ptr(), n_rays, pixel_map=pixels)
                 torch.cuda.synchronize()
                 dt = time.perf_counter() - t0
-            times.append(dict(rank=rank, ms=1e3 * dt, geodesic=st.ms_geodesic, locate=st.ms_locate, shade=st.ms_shade, transfer=st.ms_transfer))
+            times.append(dict(rank=rank, ms=1e3 * dt, geodesic=st.ms_geodesic, locate=st.ms_locate, shade=st.ms_shade, transfer=st.ms_transfer, wall=st.ms_wall, chunks=st.n_chunks, emitted=st.n_samples_emitted, samples=st.n_samples))
         worst = max(t["ms"] for t in times)
         out[f"world_{world}"] = dict(max_ms=worst, mrays_per_s=res * res / worst / 1e3, ranks=times)
 print(json.dumps(out, indent=1))
