@@ -136,8 +136,6 @@ void ValidateRadiation(bl_ctx *ctx) {
     } else if (Has(p, BL_P_simulation_block_interp)) {
       Warn(ctx, "Ignoring simulation_block_interp selection.");
     }
-    if (p.simulation_coord == BL_COORD_FMKS && p.slow_light_on)
-      throw Failure{BL_E_UNSUPPORTED, "simulation_coord = fmks with slow light is not built."};
   } else {
     if (Has(p, BL_P_checkpoint_sample_save) && p.checkpoint_sample_save) Warn(ctx, "Ignoring checkpoint_sample_save selection.");
     if (Has(p, BL_P_checkpoint_sample_load) && p.checkpoint_sample_load) Warn(ctx, "Ignoring checkpoint_sample_load selection.");

@@ -25,6 +25,7 @@
 #include <deque>
 #include <sstream>
 #include <string>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -488,6 +489,10 @@ constexpr double kAngularDomainTolerance = 0.1;         // simulation_reader.hpp
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
+
+// The last FMKS look-up table built in this process and what it was built from (ReadIharm3d)
+static std::mutex g_sks_map_mutex;
+static std::vector<double> g_sks_map_key, g_sks_map;
 
 struct bl_snapshot {
   bl_grid_desc desc{};
@@ -1017,7 +1022,18 @@ void ReadIharm3d(const bl_params &p, int file_number, bl_snapshot *s) {
     const double tol = 1.0e-8;
     const double r_in = bl_exp(s->coords[0][0]), r_out = bl_exp(s->coords[0][n[0]]);
     const double dr = (r_out - r_in) / (map_n1 - 1), dtheta = kPi / (map_n2 - 1);
-    s->sks_map.assign(static_cast<size_t>(2) * map_n2 * map_n1, 0.0);
+    // (The files of a series share their geometry - slow light opens a window of them - and the map is 4 million bisections:
+    // the last map built in this process is kept with everything it was built from, and copied when those numbers come again.)
+    const std::vector<double> map_key = {r_in, r_out, metric_h, metric_r_in, metric_poly_xt, metric_poly_alpha, metric_mks_smooth};
+    bool map_cached = false;
+    {
+      std::lock_guard<std::mutex> lock(g_sks_map_mutex);
+      if (g_sks_map_key == map_key && !g_sks_map.empty()) {
+        s->sks_map = g_sks_map;
+        map_cached = true;
+      }
+    }
+    if (!map_cached) s->sks_map.assign(static_cast<size_t>(2) * map_n2 * map_n1, 0.0);
     double *map_x1 = s->sks_map.data(), *map_x2 = s->sks_map.data() + static_cast<size_t>(map_n2) * map_n1;
     // (columns are independent: spread over the host's threads; the reference fills the map serially)
     auto fill_columns = [&](int i_begin, int i_end) {
@@ -1056,13 +1072,16 @@ void ReadIharm3d(const bl_params &p, int file_number, bl_snapshot *s) {
       }
     }
     };
-    {
+    if (!map_cached) {
       const int n_threads = std::max(1, std::min(64, static_cast<int>(std::thread::hardware_concurrency())));
       std::vector<std::thread> workers;
       for (int t = 0; t < n_threads; t++)
         workers.emplace_back(fill_columns, static_cast<int>(static_cast<long>(map_n1) * t / n_threads),
                              static_cast<int>(static_cast<long>(map_n1) * (t + 1) / n_threads));
       for (std::thread &w : workers) w.join();
+      std::lock_guard<std::mutex> lock(g_sks_map_mutex);
+      g_sks_map_key = map_key;
+      g_sks_map = s->sks_map;
     }
     bl_grid_desc &gd = s->desc;
     gd.sks_map = s->sks_map.data();

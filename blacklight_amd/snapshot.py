@@ -12,15 +12,19 @@ from .params import Params
 
 
 class Snapshot:
-    """One file of the run: `Snapshot(params, snapshot=0)`; pass it to Context.set_grid()."""
+    """One file of the run: `Snapshot(params, snapshot=0)`; pass it to Context.set_grid(). `file_number`: that file of a
+    numbered series instead (bl_snapshot_open_number - what the slow-light window reads, simulation_reader.cpp:225-232)."""
 
-    def __init__(self, params: Params, snapshot: int = 0):
+    def __init__(self, params: Params, snapshot: int = 0, file_number: int = None):
         L = _capi.lib()
         self._lib = L
         self._params = params   # keeps simulation_kappa_name etc. alive
         handle = C.c_void_p()
         err = C.create_string_buffer(1024)
-        rc = L.bl_snapshot_open(params.ptr, int(snapshot), C.byref(handle), err, len(err))
+        if file_number is None:
+            rc = L.bl_snapshot_open(params.ptr, int(snapshot), C.byref(handle), err, len(err))
+        else:
+            rc = L.bl_snapshot_open_number(params.ptr, int(file_number), C.byref(handle), err, len(err))
         if rc != 0:
             raise _capi.BlacklightError(rc, err.value.decode())
         self._h = handle

@@ -1457,21 +1457,45 @@ int SampleOne(const Oracle &o, const double pos[4], Prims *out, bool *gathered, 
     // the second has no value to reproduce (status 4, like the upper edges of the last MeshBlock above).
     const long n_cells = static_cast<long>(n_k) * n_j * n_i;
     auto beyond = [&](long kk, long jj, long ii) { return (kk * n_j + jj) * n_i + ii >= n_cells or (kk * n_j + jj) * n_i + ii < 0; };
+    // the values: from the time slice(s) of the sample as everywhere else (:710-786, :809-912 - the FMKS branch only finds
+    // indices and fractions, :396-456)
+    auto fmks_slice = [&](int t) -> const bl_grid_desc & { return slow ? *o.slow_grids[t] : g; };
     if (not p.simulation_interp) {
       int jn = f_j >= 0.5 ? j_m + 1 : j_m, in = f_i >= 0.5 ? i_m + 1 : i_m;
       if (beyond(k, jn, in)) return 4;
-      for (int v = 0; v < 9; v++) *dst[v] = (v == 2 and not code_kappa) ? 0.0f : GridVal(g, vars[v], 0, k, jn, in);
+      for (int v = 0; v < 9; v++) {
+        if (v == 2 and not code_kappa) {
+          *dst[v] = 0.0f;
+          continue;
+        }
+        if (not slow_interp)
+          *dst[v] = GridVal(fmks_slice(t_ind), vars[v], 0, k, jn, in);
+        else {
+          double val_1 = static_cast<double>(GridVal(fmks_slice(t_ind), vars[v], 0, k, jn, in));
+          double val_2 = static_cast<double>(GridVal(fmks_slice(t_ind + 1), vars[v], 0, k, jn, in));
+          *dst[v] = static_cast<float>((1.0 - t_frac) * val_1 + t_frac * val_2);
+        }
+      }
       return 0;
     }
     if (beyond(k_m + 1, j_m + 1, i_m + 1) or beyond(k_m, j_m, i_m)) return 4;
+    auto fmks_spatial = [&](const bl_grid_desc &gs, int v) {
+      double val = InterpolateSimple(gs, vars[v], 0, k_m, j_m, i_m, f_k, f_j, f_i);
+      if (v < 3 and val <= 0.0) val = static_cast<double>(GridVal(gs, vars[v], 0, k_m, j_m, i_m));
+      return val;
+    };
     for (int v = 0; v < 9; v++) {
       if (v == 2 and not code_kappa) {
         *dst[v] = 0.0f;
         continue;
       }
-      double val = InterpolateSimple(g, vars[v], 0, k_m, j_m, i_m, f_k, f_j, f_i);
-      if (v < 3 and val <= 0.0) val = static_cast<double>(GridVal(g, vars[v], 0, k_m, j_m, i_m));
-      *dst[v] = static_cast<float>(val);
+      if (not slow_interp)
+        *dst[v] = static_cast<float>(fmks_spatial(fmks_slice(t_ind), v));
+      else {
+        double val_1 = fmks_spatial(fmks_slice(t_ind), v);
+        double val_2 = fmks_spatial(fmks_slice(t_ind + 1), v);
+        *dst[v] = static_cast<float>((1.0 - t_frac) * val_1 + t_frac * val_2);
+      }
     }
     return 0;
   }
@@ -2813,8 +2837,8 @@ int Setup(Oracle &o, const bl_params *p, const bl_grid_desc *g, char *err, size_
       return Fail(err, err_len, "oracle: inter-block interpolation needs the MeshBlock table (levels, locations, n_3_root)", BL_E_ARG);
     if (p->slow_light_on and (o.slow_n < 2 or o.slow_n != p->slow_chunk_size or o.slow_grids == nullptr or o.slow_times == nullptr))
       return Fail(err, err_len, "oracle: slow light needs slow_chunk_size time slices in blo_extra", BL_E_ARG);
-    if (p->simulation_coord == BL_COORD_FMKS and (g->sks_map == nullptr or g->n_blocks != 1 or p->slow_light_on))
-      return Fail(err, err_len, "oracle: fmks needs the reader's sks_map, one block and no slow light", BL_E_UNSUPPORTED);
+    if (p->simulation_coord == BL_COORD_FMKS and (g->sks_map == nullptr or g->n_blocks != 1))
+      return Fail(err, err_len, "oracle: fmks needs the reader's sks_map and one block", BL_E_UNSUPPORTED);
     if (p->plasma_kappa_frac != 0.0 and not o.image_polarization)
       return Fail(err, err_len, "oracle: kappa-distribution electrons are restated for polarized runs only (in unpolarized runs the reference reads the uninitialised kappa_aa_high_i)", BL_E_UNSUPPORTED);
     o.plasma_thermal_frac = 1.0 - (p->plasma_power_frac + p->plasma_kappa_frac);

@@ -95,3 +95,51 @@ def test_fmks_command_line(built_library, fmks, case, tmp_path):
         want, got = fmks[prefix + name], npz[name]
         assert got.shape == want.shape and got.dtype == want.dtype, name
         assert gu.same_bits(got, want).all() if want.dtype.kind == "f" else np.array_equal(got, want), name
+
+
+@pytest.fixture(scope="module")
+def fmks_slow():
+    return np.load(os.path.join(READER_DIR, "expected_fmks_slow.npz"), allow_pickle=False)
+
+
+@pytest.mark.parametrize("case", ["interp", "nearest"])
+def test_fmks_slow_light_against_the_reference(built_library, fmks_slow, case, tmp_path):
+    """slow_light_on over a series of FMKS dumps (tests/golden/reader/fmksslow_*.h5): the time-slice lookup
+    (simulation_sampling.cpp:296-349) in front of the locate kernel's FMKS branch (:396-456), values blended from the slices
+    (:710-786, :809-912). Through the library's own window of files (bl_slow_light_read) and through the command-line
+    driver, against the reference's images of every camera time: bit-exact."""
+    from blacklight_amd import Context, Params
+    fx = fmks_slow
+    params = json.loads(str(fx[f"{case}_params"]))
+    params["simulation_file"] = os.path.join(READER_DIR, "fmksslow_{02d}.h5")
+    rows = ["I_nu"] + (["tau"] if f"{case}_B_0_tau" in fx.files else [])
+    p = Params.from_dict({k: v for k, v in params.items() if k != "output_file"})
+    with Context(p) as ctx:
+        for image in range(int(params["slow_num_images"])):
+            ctx.slow_light_read(image)
+            out = ctx.render()
+            want = np.stack([fx[f"{case}_B_{image}_{name}"].reshape(-1) for name in rows])
+            assert gu.same_bits(out["image"], want).all(), image
+            want_a = np.stack([fx[f"{case}_A_{image}_{name}"].reshape(-1) for name in rows])
+            assert np.max(np.abs(out["image"] - want_a) / np.max(np.abs(want_a), axis=1, keepdims=True)) < 1.0e-6
+            ctx.set_arithmetic("tolerant")   # (slow light is rendered in exact arithmetic whatever was asked for)
+            again = ctx.render()
+            assert again["stats"].arithmetic == 0 and gu.same_bits(again["image"], want).all()
+            ctx.set_arithmetic("exact")
+    params["output_file"] = str(tmp_path / "image_{02d}.npz")
+    input_path = tmp_path / "fmks_slow.input"
+    with open(input_path, "w") as f:
+        for key, value in params.items():
+            f.write(f"{key} = {value}\n")
+    run = subprocess.run([EXE, str(input_path)], capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert run.stderr == str(fx[f"{case}_B_warnings"])
+    for image in range(int(params["slow_num_images"])):
+        npz = np.load(tmp_path / f"image_{image + int(params['slow_offset']):02d}.npz")
+        prefix = f"{case}_B_{image}_"
+        names = [k[len(prefix):] for k in fx.files if k.startswith(prefix)]
+        assert sorted(npz.files) == sorted(names)
+        for name in names:
+            want, got = fx[prefix + name], npz[name]
+            assert got.shape == want.shape and got.dtype == want.dtype, name
+            assert gu.same_bits(got, want).all() if want.dtype.kind == "f" else np.array_equal(got, want), name

@@ -424,6 +424,37 @@ def test_fmks_oracle_against_the_reference(built_library, fmks, case):
     assert np.max(np.abs(out_a["image"] - want_a) / np.max(np.abs(want_a), axis=1, keepdims=True)) < 1.0e-6
 
 
+@pytest.mark.parametrize("case", ["interp", "nearest"])
+def test_fmks_slow_light_oracle_against_the_reference(built_library, case):
+    """slow_light_on over a series of FMKS dumps (tests/golden/reader/fmksslow_*.h5, tools/make_goldens.py fmks_slow): the
+    time-slice lookup (simulation_sampling.cpp:296-349) in front of the FMKS branch (:396-456), values from the slice(s)
+    (:710-786, :809-912). The oracle on the reader's slices against the reference's images of every camera time: bit-exact
+    with the pinned math library."""
+    import oracle_api
+    from blacklight_amd import _capi
+    fx = np.load(os.path.join(READER_DIR, "expected_fmks_slow.npz"), allow_pickle=False)
+    params = json.loads(str(fx[f"{case}_params"]))
+    params["simulation_file"] = os.path.join(READER_DIR, "fmksslow_{02d}.h5")
+    p = Params.from_dict(params)
+    file_times = [float(t) for t in fx["file_times"]]
+    res = int(params["camera_resolution"])
+    rows = ["I_nu"] + (["tau"] if f"{case}_B_0_tau" in fx.files else [])
+    for image, (t_cam, files) in enumerate(gu.slow_light_windows(params, file_times)):
+        snaps = [Snapshot(p, file_number=f) for f in files]
+        try:
+            assert [s.time for s in snaps] == [file_times[f] for f in files]
+            descs = [s.desc() for s in snaps]
+            out = oracle_api.render(p.ptr, descs[0], _capi.RenderDesc, _capi.CameraFrame, n_rays=res * res, max_steps=int(params["ray_max_steps"]),
+                                    n_freq=1, slow=dict(grids=descs, times=[file_times[f] for f in files], snapshot_time=t_cam))
+        finally:
+            for s in snaps:
+                s.close()
+        want = np.stack([fx[f"{case}_B_{image}_{name}"].reshape(-1) for name in rows])
+        assert gu.same_bits(out["image"], want).all(), (image, t_cam)
+        assert out["slow_count"] == [0, 0, 0, 0]
+    assert not gu.same_bits(fx[f"{case}_B_0_I_nu"], fx[f"{case}_B_2_I_nu"]).all()   # (the slices do differ)
+
+
 def test_fmks_undefined_reads_are_refused(built_library, fmks):
     """Without the polar cut of the goldens the camera sees the last polar zone of the last azimuthal plane, where the
     reference's unbounded Array hands back another variable's data: the oracle (like the GPU path) refuses."""

@@ -1147,6 +1147,74 @@ def make_slow_cli_fixture():
     print("slowcli: max I_nu", [float(np.nanmax(fixture[f"B_{i}_I_nu"])) for i in range(4)], repr(fixture["B_warnings"]))
 
 
+# Slow light on an FMKS grid (tests/golden/reader/fmksslow_*.h5 + expected_fmks_slow.npz): seven iharm3d FMKS dumps 20 time
+# units apart (the fmks fixture's geometry and cuts, different perturbations, "t" set per file), a window of six; the
+# reference's images with interpolation in space and time and with the nearest cell of the nearest slice.
+FMKS_SLOW_CASES = {
+    "interp": dict(slow_interp="true", simulation_interp="true", slow_t_start=100.0, slow_dt=9.0, slow_num_images=3, image_tau="true"),
+    "nearest": dict(slow_interp="false", simulation_interp="false", slow_t_start=91.5, slow_dt=8.0, slow_num_images=3, camera_th=70.0),
+}
+
+
+def make_fmks_slow_fixture():
+    import h5py
+    out_dir = os.path.join(OUT, "reader")
+    workdir = os.path.join(WORK, "fmksslow")
+    for sub in (out_dir, os.path.join(workdir, "data"), os.path.join(workdir, "output")):
+        os.makedirs(sub, exist_ok=True)
+    n_files = 7
+    expected = {"file_times": np.array([20.0 * i for i in range(n_files)])}
+    for index in range(n_files):
+        mock = dict(n_r=16, n_th=12, n_ph=16, pert_amp=round(0.2 + 0.04 * index, 4), pert_n_ph=2 + index % 3, Bph_amp=round(0.2 + 0.02 * index, 4),
+                    rho_amp=round(1.0 + 0.05 * ((index * 7) % 5), 4))
+        args = []
+        for key, value in mock.items():
+            args += [f"--{key}", str(value)]
+        source = os.path.join(workdir, "data", "mks.h5")
+        subprocess.run([sys.executable, "-W", "ignore", MOCK_SCRIPT, source, "--format", "iharm3d"] + args, check=True)
+        name = f"fmksslow_{index:02d}.h5"
+        path = os.path.join(workdir, "data", name)
+        with h5py.File(source, "r") as f, h5py.File(path, "w") as g:
+            def copy(group_in, prefix):
+                for key, item in group_in.items():
+                    full = prefix + key
+                    if isinstance(item, h5py.Group):
+                        if full != "header/geom/mks":
+                            copy(item, full + "/")
+                    elif full == "header/metric":
+                        g.create_dataset(full, data=("FMKS",), dtype="|S20")
+                    elif full == "t":
+                        g.create_dataset(full, data=20.0 * index, dtype=np.float64)
+                    else:
+                        g.create_dataset(full, data=item[...], dtype=item.dtype)
+            copy(f, "")
+            r_in = float(np.exp(f["header/geom/startx1"][()]))
+            for key, value in (("a", 0.5), ("hslope", 0.3), ("r_in", r_in), ("r_out", float(f["header/geom/mks/r_out"][()])),
+                               ("poly_xt", 0.82), ("poly_alpha", 14.0), ("mks_smooth", 0.5), ("r_eh", 2.0)):
+                g.create_dataset("header/geom/fmks/" + key, data=value, dtype=np.float64)
+        with open(path, "rb") as src, open(os.path.join(out_dir, name), "wb") as dst:
+            dst.write(src.read())
+    for case, overrides in FMKS_SLOW_CASES.items():
+        params = dict(SIM_BASE)
+        params.update(camera_resolution=12, checkpoint_geodesic_save="false", simulation_format="iharm3d", simulation_coord="fmks",
+                      simulation_a=0.5, cut_midplane_theta=40.0, ray_factor=1.05, camera_r=20.0, camera_width=16.0,
+                      simulation_multiple="true", simulation_start=0, simulation_end=n_files - 1, simulation_file="data/fmksslow_{02d}.h5",
+                      output_file="output/" + case + "_{02d}.npz", slow_light_on="true", slow_chunk_size=6, slow_offset=3)
+        params.update(overrides)
+        write_input(os.path.join(workdir, case + ".input"), params)
+        expected[f"{case}_params"] = json.dumps(params)
+        for tier, preload in (("A", False), ("B", True)):
+            expected[f"{case}_{tier}_warnings"] = run_reference(workdir, case + ".input", preload)
+            for image in range(params["slow_num_images"]):
+                npz = np.load(os.path.join(workdir, "output", f"{case}_{image + 3:02d}.npz"))
+                for key in npz.files:
+                    expected[f"{case}_{tier}_{image}_{key}"] = npz[key]
+        imgs = [expected[f"{case}_B_{i}_I_nu"] for i in range(params["slow_num_images"])]
+        print("fmks slow", case, "max I_nu per image", [float(np.nanmax(i)) for i in imgs], "nan", [int(np.isnan(i).sum()) for i in imgs],
+              "warnings:", repr(expected[f"{case}_B_warnings"]))
+    np.savez_compressed(os.path.join(out_dir, "expected_fmks_slow.npz"), **expected)
+
+
 if __name__ == "__main__":
     names = sys.argv[1:] or (["mock"] + list(CASES))
     for case_name in names:
@@ -1162,6 +1230,8 @@ if __name__ == "__main__":
             make_iharm3d_fixtures()
         elif case_name == "fmks":
             make_fmks_fixtures()
+        elif case_name == "fmks_slow":
+            make_fmks_slow_fixture()
         elif case_name == "checkpoint":
             make_checkpoint_fixtures()
         elif case_name == "sample_checkpoint":
