@@ -31,6 +31,7 @@ extern "C" hipError_t bl_launch_shade_fast(const BlShadeArgs *args, int grid, hi
 extern "C" hipError_t bl_launch_shade_formula_fast(const BlShadeArgs *args, int grid, hipStream_t stream);
 extern "C" hipError_t bl_launch_polarized_coefficients(const BlShadeArgs *args, int grid, hipStream_t stream);
 extern "C" hipError_t bl_launch_transfer(const BlTransferArgs *args, hipStream_t stream);
+extern "C" hipError_t bl_launch_tau(const BlTransferArgs *args, hipStream_t stream);
 extern "C" hipError_t bl_launch_transfer_freq(const BlTransferArgs *args, hipStream_t stream);
 extern "C" hipError_t bl_launch_coefficients_freq(const BlShadeArgs *args, int grid, hipStream_t stream);
 extern "C" hipError_t bl_launch_transfer_aux(const BlTransferArgs *args, hipStream_t stream);
@@ -180,15 +181,16 @@ struct bl_ctx {
     DeviceBuffer<unsigned int> d_anchors;          // inter-block interpolation: eight anchor cells per record
     DeviceBuffer<BlCoefInputs> d_coef_inputs;      // polarized runs: coefficient kernel -> polarized coefficient kernel
     DeviceBuffer<unsigned long long> d_redo;       // tolerant tier: records left to the exact coefficient kernel
+    DeviceBuffer<double> d_tau_inc;                // tolerant tier with an optical-depth image: alpha x length per sample and frequency
     uint64_t Bytes() const {
       return d_records_hot.count * sizeof(BlSampleHot) + d_records_cold.count * sizeof(BlSampleCold) + d_located.count * sizeof(BlLocated)
           + d_located_tag.count * sizeof(unsigned long long) + d_transfer.count * sizeof(double2) + d_aux.count * sizeof(BlAuxSample)
-          + (d_sample_t.count + d_slow_frac.count + d_pol_matrix.count) * sizeof(double) + d_pol_samples.count * sizeof(BlPolSample)
+          + (d_sample_t.count + d_slow_frac.count + d_pol_matrix.count + d_tau_inc.count) * sizeof(double) + d_pol_samples.count * sizeof(BlPolSample)
           + d_freq_inputs.count * sizeof(BlFreqInputs) + d_pol_coeffs.count * sizeof(double2) + d_anchors.count * sizeof(unsigned int)
           + d_coef_inputs.count * sizeof(BlCoefInputs) + d_redo.count * sizeof(unsigned long long);
     }
     void Free() {
-      d_redo.Free(); d_aux.Free(); d_sample_t.Free(); d_slow_frac.Free(); d_pol_samples.Free(); d_pol_matrix.Free(); d_freq_inputs.Free(); d_pol_coeffs.Free(); d_coef_inputs.Free(); d_anchors.Free();
+      d_redo.Free(); d_tau_inc.Free(); d_aux.Free(); d_sample_t.Free(); d_slow_frac.Free(); d_pol_samples.Free(); d_pol_matrix.Free(); d_freq_inputs.Free(); d_pol_coeffs.Free(); d_coef_inputs.Free(); d_anchors.Free();
       d_records_hot.Free(); d_records_cold.Free(); d_located.Free(); d_located_tag.Free(); d_transfer.Free(); d_counters.Free();
     }
   };

@@ -338,6 +338,7 @@ struct BlShadeArgs {
   int ray_max_steps;
   double x_unit;              // GM/c^2 in cm (unpolarized.cpp:42)
   double2 *transfer;          // [sample row][n_nu]; (a, b), or (j, alpha) in auxiliary mode
+  double *tau_inc;            // tolerant tier with an optical-depth image: [sample row][n_nu] alpha x length of every sample, or null
   // auxiliary-image mode only
   BlAuxSample *aux;           // [sample row]
   const double *sample_t;     // [record capacity] or null
@@ -372,6 +373,8 @@ struct BlTransferArgs {
   int simulation_coord, rotation_split;
   double cam_u_con[4], cam_u_cov[4], cam_vert_con_c[4];
   const double2 *transfer;
+  const double *tau_inc;                   // bl_tau_kernel: [sample row][n_nu], rows summed into image row tau_row + l
+  int tau_row;
   const unsigned long long *counters;      // BL_CNT_NEXT_RAY: rays of the chunk the geodesic kernel traced (bl_rays_done)
   const int *ray_sample_num;               // [chunk_rays]: kept samples with a record (= rows) of each ray
   const int *ray_skipped;                  // [chunk_rays] or null: its samples without a record (BlTraceArgs::skip_low)

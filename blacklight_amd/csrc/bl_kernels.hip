@@ -2323,6 +2323,7 @@ __global__ void __launch_bounds__(256, 2) bl_shade_kernel(const BlShadeArgs P) {
         double2 rec = transfer_record(j_val, alpha_val, delta_lambda_cgs);
         if (kRedo) rec = rec.x == BL_THICK_MARK ? make_double2(0.0, rec.y) : make_double2(rec.x, rec.x * rec.y);   // (a, b) -> (a, c)
         out[l] = rec;
+        if (kRedo && P.tau_inc != nullptr) P.tau_inc[(out - P.transfer) + l] = alpha_val * delta_lambda_cgs;   // unpolarized.cpp:150-151
       }
     }
   }
@@ -2568,6 +2569,8 @@ __device__ __forceinline__ bool fast_shade_sample(const BlShadeArgs &P, const do
       return true;
     }
     for (int l = 0; l < P.n_nu; l++) out[l] = make_double2(1.0, nan);
+    if (kGeneral && P.tau_inc != nullptr)
+      for (int l = 0; l < P.n_nu; l++) P.tau_inc[row * P.n_nu + l] = nan;
     return true;
   }
   // ---- per-frequency coefficients (simulation_coefficients.cpp:464-523) and transfer records (unpolarized.cpp:74-110)
@@ -2600,6 +2603,7 @@ __device__ __forceinline__ bool fast_shade_sample(const BlShadeArgs &P, const do
   const int n_nu = P.n_nu;
   for (int l = 0; l < n_nu; l++) {
     double2 rec = make_double2(1.0, 0.0);
+    double delta_tau_out = 0.0;   // what the sample adds to an optical-depth image (unpolarized.cpp:150-151)
     if (have) {
       const double f = table[44 + l], f_1_2 = table[44 + n_nu + l], f_1_3 = table[44 + 2 * n_nu + l], f_1_6 = table[44 + 3 * n_nu + l];
       const double f_inv = table[44 + 4 * n_nu + l];
@@ -2624,6 +2628,7 @@ __device__ __forceinline__ bool fast_shade_sample(const BlShadeArgs &P, const do
         alpha_val += common * (1.0 / (kMe * kC)) * pl.power_aa * fastmath::pow_of(ratio, -(pl.plasma_p + 2.0) * 0.5);
       }
       const double delta_lambda_cgs = s_length * f_inv;
+      delta_tau_out = alpha_val * delta_lambda_cgs;
       if (alpha_val > 0.0) {
         const double delta_tau = alpha_val * delta_lambda_cgs;
         if (delta_tau < 0x1p-10) {
@@ -2640,6 +2645,7 @@ __device__ __forceinline__ bool fast_shade_sample(const BlShadeArgs &P, const do
       }
     }
     out[l] = rec;
+    if (kGeneral && P.tau_inc != nullptr) P.tau_inc[row * n_nu + l] = delta_tau_out;
   }
   return true;
 }
@@ -3791,7 +3797,8 @@ extern "C" hipError_t bl_launch_shade_fast(const BlShadeArgs *args, int grid, hi
   }
   const size_t lds = (44 + 5 * args->n_nu) * sizeof(double);
   const bool spin_zero = args->st.bh_a == 0.0;
-  const bool power_law = args->plasma.power_frac != 0.0, cartesian = args->plasma.simulation_coord == BL_COORD_CKS;
+  const bool power_law = args->plasma.power_frac != 0.0 || args->tau_inc != nullptr, cartesian = args->plasma.simulation_coord == BL_COORD_CKS;
+  // (an optical-depth image goes through the general instantiation as well)
   // (the records it defers go to the exact kernel: its extended instantiation knows power laws, its general one Cartesian grids)
 #define BL_FAST_PAIR(SPIN, GENERAL, EXTENDED, SKS)                                                                               \
   do {                                                                                                                           \
@@ -3840,6 +3847,38 @@ extern "C" hipError_t bl_launch_transfer_freq(const BlTransferArgs *args, hipStr
 extern "C" hipError_t bl_launch_transfer_aux(const BlTransferArgs *args, hipStream_t stream) {
   int grid = (args->chunk_rays + 63) / 64;
   hipLaunchKernelGGL(bl_transfer_aux_kernel, dim3(grid), dim3(64), 0, stream, *args);
+  return hipGetLastError();
+}
+
+// Optical depth beside the intensities in the tolerant tier: tau(ray, frequency) = sum of alpha x length over the ray's samples, far
+// -> near as the reference adds them (unpolarized.cpp:63-151), from the increments the fast coefficient kernel left
+__global__ void __launch_bounds__(256) bl_tau_kernel(BlTransferArgs P) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int slot = (int)(t / P.n_nu);
+  const int l = (int)(t % P.n_nu);
+  if (slot >= bl_rays_done(P.counters, P.chunk_rays)) return;
+  const int num = P.ray_sample_num[slot];
+  const double *inc = P.tau_inc + (size_t)P.ray_offset[slot] * P.n_nu + l;
+  double tau = 0.0;
+  int n = num - 1;
+  if (P.fallback_nan && P.ray_flags[slot] != 0) {   // every sample of a flagged ray carries NaN primitives (simulation_sampling.cpp:211-216)
+    tau = num > 0 ? __longlong_as_double(0x7ff8000000000000ll) : 0.0;
+    n = -1;
+  }
+  for (; n >= 7; n -= 8) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) v[u] = inc[(size_t)(n - u) * P.n_nu];
+#pragma unroll
+    for (int u = 0; u < 8; u++) tau += v[u];
+  }
+  for (; n >= 0; n--) tau += inc[(size_t)n * P.n_nu];
+  P.image[(size_t)(P.tau_row + l) * P.n_rays_total + P.ray_out_index[slot]] = tau;
+}
+
+extern "C" hipError_t bl_launch_tau(const BlTransferArgs *args, hipStream_t stream) {
+  const int grid = (int)(((long long)args->chunk_rays * args->n_nu + 255) / 256);
+  hipLaunchKernelGGL(bl_tau_kernel, dim3(grid), dim3(256), 0, stream, *args);
   return hipGetLastError();
 }
 

@@ -115,6 +115,7 @@ struct RenderJob {
   bool rows_only = false, fill_present = false;
   bool interleaved = false;   // sample records as one 64-byte array instead of two of 32-byte halves
   bool fast_formula = false;   // tolerant tier in formula mode: bl_shade_formula_fast_kernel
+  bool tau_row = false;   // tolerant tier: an optical-depth image beside the intensities on the plain path (bl_tau_kernel)
   bool skip_shell = false;   // steps between the grid's outer edge and the camera's sphere leave no records (BlTraceArgs::skip_low)
   bool fused = false;   // tolerant tier, common grid case: the locate step runs inside the coefficient kernel (bl_shade_fused_kernel)
   int n_nu = 0, n_q = 0, max_steps = 0;
@@ -214,10 +215,19 @@ void PlanJob(RenderJob &job) {
   // Tolerant tier: plain unpolarized images of a simulation with thermal (and power-law) electrons in a curved
   // spacetime have the fast coefficient kernel; every other configuration is rendered in exact arithmetic whatever
   // bl_set_arithmetic() asked for (bl_stats.arithmetic says which tier ran)
-  job.fast = ctx->arithmetic == BL_ARITH_TOLERANT && job.simulation && !job.aux && !ctx->polarized && !job.slow && !job.block_interp
+  // (an optical-depth image as the only auxiliary row is the plain path plus one sum per ray: not an auxiliary run below)
+  const BlAuxImages &rows = ctx->aux_images;
+  const bool tau_only = job.aux && !ctx->polarized && p.image_light && rows.image_tau && ctx->render_num_images == 0 && !job.geo_load && !job.geo_save
+      && !(rows.image_time || rows.image_length || rows.image_lambda || rows.image_emission || rows.image_lambda_ave || rows.image_emission_ave
+           || rows.image_tau_int || rows.image_crossings);
+  job.fast = ctx->arithmetic == BL_ARITH_TOLERANT && job.simulation && (!job.aux || tau_only) && !ctx->polarized && !job.slow && !job.block_interp
       && p.plasma_kappa_frac == 0.0 && p.plasma_model != BL_PLASMA_CODE_KAPPA
       && !p.ray_flat && ctx->plasma_thermal_frac != 0.0
       && job.n_nu <= 1024;   // (its LDS table holds five numbers per frequency)
+  if (job.fast && job.aux) {
+    job.tau_row = true;
+    job.aux = false;
+  }
   // ... formula mode has a fast kernel of its own (plain images, no optional geometric cut)
   job.fast_formula = ctx->arithmetic == BL_ARITH_TOLERANT && !job.simulation && !job.aux
       && !(p.cut_omit_near || p.cut_omit_far || p.cut_omit_in >= 0.0 || p.cut_omit_out >= 0.0 || p.cut_midplane_theta != 0.0 || p.cut_midplane_z != 0.0 || p.cut_plane);
@@ -227,10 +237,10 @@ void PlanJob(RenderJob &job) {
   job.matrix_transport = job.tolerant_polarized && !p.ray_flat;
   // Several frequencies in the fast path: per-sample factors (BlFreqInputs) instead of per-frequency transfer records,
   // evaluated by bl_transfer_freq_kernel with one lane per ray and frequency
-  job.freq_split = job.fast && job.n_nu >= 4 && p.plasma_power_frac == 0.0;   // (the factors are the thermal formulas')
+  job.freq_split = job.fast && job.n_nu >= 4 && p.plasma_power_frac == 0.0 && !job.tau_row;   // (the factors are the thermal formulas')
   // The fast path over one grid (or equal blocks merged into one) with its coordinate tables in LDS, trilinear sampling and no
   // optional geometric cut locates its samples inside the coefficient kernel: no located samples in HBM at all
-  job.fused = job.fast && ctx->grid_dev.n_blocks == 0 && ctx->lds_table_bytes > 0 && !ctx->grid_dev.fmks && p.simulation_interp && p.plasma_power_frac == 0.0
+  job.fused = job.fast && !job.tau_row && ctx->grid_dev.n_blocks == 0 && ctx->lds_table_bytes > 0 && !ctx->grid_dev.fmks && p.simulation_interp && p.plasma_power_frac == 0.0
       && !(p.cut_omit_near || p.cut_omit_far || p.cut_omit_in >= 0.0 || p.cut_omit_out >= 0.0 || p.cut_midplane_theta != 0.0 || p.cut_midplane_z != 0.0 || p.cut_plane)
       && static_cast<size_t>(ctx->lds_table_bytes) + (44 + 5 * static_cast<size_t>(job.n_nu)) * sizeof(double) <= 60u * 1024u
       && !job.sample_save && std::getenv("BLACKLIGHT_AMD_NO_FUSED_LOCATE") == nullptr;   // (a sample checkpoint is made of the located samples)
@@ -264,7 +274,7 @@ void PlanScratch(RenderJob &job) {
   // more than records)
   job.bytes_per_record = sizeof(BlSampleHot) + sizeof(BlSampleCold)
       + ((job.simulation && !job.fused) ? sizeof(BlLocated) + sizeof(unsigned long long) : 0)
-      + (job.freq_split ? sizeof(BlFreqInputs) : sizeof(double2) * n_nu)
+      + (job.freq_split ? sizeof(BlFreqInputs) : sizeof(double2) * n_nu) + (job.tau_row ? sizeof(double) * n_nu : 0)
       + (job.aux ? sizeof(BlAuxSample) : 0) + (job.need_time ? sizeof(double) : 0) + (job.slow ? sizeof(double) : 0)
       + (ctx->polarized ? sizeof(BlPolSample) + sizeof(BlCoefInputs) + 3 * sizeof(double2) * n_nu : 0)
       + (job.coef_split ? sizeof(BlCoefInputs) : 0)
@@ -336,6 +346,7 @@ void EnsureScratch(RenderJob &job) {
     }
     if (job.freq_split) sl.d_freq_inputs.Ensure(cap);   // instead of the transfer records
     else sl.d_transfer.Ensure(cap * n_nu);
+    if (job.tau_row) sl.d_tau_inc.Ensure(cap * n_nu);
     sl.d_counters.Ensure(BL_CNT_TOTAL);
     if (job.aux) sl.d_aux.Ensure(cap);
     if (job.need_time) sl.d_sample_t.Ensure(cap);
@@ -841,6 +852,7 @@ void BindChunk(RenderJob &job, int k, long long begin, int rays) {
   sa.ray_offset = ta.ray_offset;
   sa.ray_flags = ta.ray_flags;
   sa.transfer = sl.d_transfer.ptr;
+  sa.tau_inc = job.tau_row ? sl.d_tau_inc.ptr : nullptr;
   sa.aux = job.aux ? sl.d_aux.ptr : nullptr;
   sa.sample_t = ta.sample_t;
   sa.coef_inputs = (job.coef_split || ctx->polarized) ? sl.d_coef_inputs.ptr : nullptr;
@@ -853,6 +865,8 @@ void BindChunk(RenderJob &job, int k, long long begin, int rays) {
   xa.chunk_rays = rays;
   xa.counters = sl.d_counters.ptr;
   xa.transfer = sl.d_transfer.ptr;
+  xa.tau_inc = sa.tau_inc;
+  xa.tau_row = ctx->aux_images.offset_tau;
   xa.freq_inputs = sa.freq_inputs;
   xa.ray_sample_num = ta.ray_sample_num;
   xa.ray_skipped = ta.ray_skipped;
@@ -1226,6 +1240,7 @@ void LaunchShadingStage(RenderJob &job, int k, bool geodesic_beside, hipStream_t
   Check(hipEventRecord(e[4], stream), "event");
   Check(job.aux ? bl_launch_transfer_aux(&xa, stream) : (job.freq_split ? bl_launch_transfer_freq(&xa, stream) : bl_launch_transfer(&xa, stream)),
         "transfer kernel launch");
+  if (job.tau_row) Check(bl_launch_tau(&xa, stream), "optical-depth kernel launch");
   if (ctx->polarized)
     Check(job.matrix_transport ? bl_launch_transfer_polarized_matrix(&xa, ctx->num_cus, stream) : bl_launch_transfer_polarized(&xa, stream),
           "polarized transfer kernel launch");

@@ -26,8 +26,10 @@ def _applies(params):
     """Scope of bl_shade_fast_kernel (bl_api.hip: `fast`)."""
     def on(key):
         return str(params.get(key, "false")) == "true"
-    aux = any(on(k) for k in ("image_time", "image_length", "image_lambda", "image_emission", "image_tau", "image_lambda_ave",
+    aux = any(on(k) for k in ("image_time", "image_length", "image_lambda", "image_emission", "image_lambda_ave",
                               "image_emission_ave", "image_tau_int", "image_crossings")) or int(params.get("render_num_images", 0)) > 0
+    if on("image_tau") and params["model_type"] == "formula":   # (simulation mode: an optical-depth image rides along, bl_tau_kernel)
+        aux = True
     if params["model_type"] == "formula":   # bl_shade_formula_fast_kernel: plain images, no optional geometric cut
         cuts = (on("cut_omit_near") or on("cut_omit_far") or float(params.get("cut_omit_in", -1.0)) >= 0.0 or float(params.get("cut_omit_out", -1.0)) >= 0.0
                 or float(params.get("cut_midplane_theta", 0.0)) != 0.0 or float(params.get("cut_midplane_z", 0.0)) != 0.0 or on("cut_plane"))
@@ -164,6 +166,59 @@ def test_tolerant_tier_with_power_laws_and_cartesian_grids(seed, built_library):
     print(f"seed {seed}: {d:.2e}, deferred {tol['stats'].n_deferred}")
     assert d < EXPECTED, over
     assert np.isfinite(exact["image"]).mean() > 0.5 and np.nanmax(exact["image"]) > 0.0
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_tolerant_tier_with_an_optical_depth_image(seed, built_library):
+    """image_tau as the only auxiliary row: the fast coefficient kernel leaves alpha x length of every sample beside its
+    transfer records and bl_tau_kernel sums them far -> near (unpolarized.cpp:63-151); every other auxiliary row still
+    sends the run to the exact kernels. Rows I_nu and tau against the exact tier, NaN pixels (flagged rays with
+    fallback_nan) in the same places; cameras, spins, frequency lists, power laws, Cartesian grids, few-step rays and
+    an unbounded guard band (every sample through the exact second pass) among the draws."""
+    import blacklight_amd as bl
+    rng = np.random.default_rng(5200 + seed)
+    fx, params, mock_args = gu.load_case("sim_dp_interp")
+    over = dict(camera_resolution=24, camera_th=float(rng.uniform(10.0, 170.0)), camera_ph=float(rng.uniform(0.0, 360.0)),
+                simulation_a=float(rng.choice([0.0, 0.5, 0.9])), simulation_interp=str(rng.choice(["true", "false"])),
+                fallback_nan=str(rng.choice(["true", "false"])), fallback_rho=1.0e-6, fallback_pgas=1.0e-8,
+                cut_sigma_max=float(rng.choice([-1.0, 5.0])), image_num_frequencies=int(rng.choice([1, 3, 6])), image_tau="true")
+    if seed >= 4:
+        over["cut_sigma_max"] = 5.0   # (a threshold for the guard band to act on)
+    if seed % 4 == 1:
+        over.update(plasma_power_frac=0.3, plasma_p=2.8, plasma_gamma_min=2.0, plasma_gamma_max=2000.0)
+    if seed % 4 == 2:
+        over.update(simulation_coord="cks", fallback_nan="false")
+    if seed % 4 == 3:
+        over.update(ray_max_steps=560, fallback_nan="true")   # rays that run into the step limit: NaN pixels in both rows
+    if over["image_num_frequencies"] > 1:
+        over.update(image_frequency_start=1.0e11, image_frequency_end=float(10.0 ** rng.uniform(11.3, 12.0)), image_frequency_spacing="log")
+    params = dict(params, **over)
+    n_nu = over["image_num_frequencies"]
+    with bl.Context(bl.Params.from_dict(params)) as ctx:
+        ctx.set_grid(gu.golden_grid(mock_args))
+        exact = ctx.render()
+        ctx.set_arithmetic("tolerant")
+        tol = ctx.render()
+        if seed >= 4:
+            ctx.debug_set_guard_band(1.0e30)
+            wide = ctx.render()
+            assert wide["stats"].n_deferred > 10 * max(tol["stats"].n_deferred, 1)
+            tol = wide
+    assert exact["stats"].arithmetic == 0 and tol["stats"].arithmetic == 1
+    assert exact["image"].shape == tol["image"].shape == (2 * n_nu, 24 * 24)
+    assert np.array_equal(tol["sample_num"], exact["sample_num"]) and np.array_equal(tol["sample_flags"], exact["sample_flags"])
+    assert np.array_equal(np.isnan(tol["image"]), np.isnan(exact["image"])), over
+    d = _distance(tol["image"], exact["image"])   # (every row against its own maximum)
+    print(f"seed {seed}: {d:.2e}, NaN pixels {int(np.isnan(exact['image'][0]).sum())}, deferred {tol['stats'].n_deferred}")
+    assert d < EXPECTED, over
+    assert np.nanmax(exact["image"][n_nu:]) > 0.0 and np.nanmax(exact["image"][:n_nu]) > 0.0
+    if seed % 4 == 3:
+        assert np.isnan(exact["image"]).any()
+    # any other auxiliary row: exact arithmetic, as before
+    with bl.Context(bl.Params.from_dict(dict(params, image_lambda="true"))) as ctx:
+        ctx.set_grid(gu.golden_grid(mock_args))
+        ctx.set_arithmetic("tolerant")
+        assert ctx.render()["stats"].arithmetic == 0
 
 
 @pytest.mark.parametrize("band,resolution,frequencies,variant", [(1.0e30, 24, 1, ""), (1.0e30, 56, 1, ""), (1.0e30, 24, 5, ""), (1.0e30, 56, 5, ""),
