@@ -94,8 +94,12 @@ class Context:
         return out
 
     def set_undefined_policy(self, policy):
-        """"refuse" (default) or "edge": samples where the reference reads past its arrays (bl_set_undefined_policy)."""
-        self._check(self._lib.bl_set_undefined_policy(self._ctx, {"refuse": 0, "edge": 1}[policy]))
+        """"refuse" (default), "edge" (samples where the reference reads past its arrays), "kappa" (unpolarized kappa-distribution
+        electrons, whose absorptivity the reference computes from an uninitialised constant), or "edge,kappa" (bl_set_undefined_policy)."""
+        flags = 0
+        for word in str(policy).replace("|", ",").split(","):
+            flags |= {"refuse": 0, "edge": 1, "kappa": 2}[word.strip()]
+        self._check(self._lib.bl_set_undefined_policy(self._ctx, flags))
 
     def set_arithmetic(self, mode):
         """"exact" (default) or "tolerant": arithmetic tier of the coefficient kernel (bl_set_arithmetic)."""

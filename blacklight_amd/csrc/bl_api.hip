@@ -243,9 +243,7 @@ void ValidateRadiation(bl_ctx *ctx) {
           Warn(ctx, "Polarized transport will interpolate formulas based on kappa.");
       }
       Require(p, {BL_P_plasma_w}, kRadMissing);
-      if (!(p.image_light && p.image_polarization))
-        throw Failure{BL_E_UNSUPPORTED, "Kappa-distribution electrons (plasma_kappa_frac != 0) are built for polarized runs only: the reference's "
-                                        "unpolarized absorptivity reads kappa_aa_high_i, which it only initialises for polarized runs."};
+      // (an unpolarized run with such electrons: bl_render refuses it unless bl_set_undefined_policy(BL_UNDEFINED_KAPPA) was called)
     }
     ctx->plasma_thermal_frac = 1.0 - (p.plasma_power_frac + p.plasma_kappa_frac);
     if (ctx->plasma_thermal_frac < 0.0 || ctx->plasma_thermal_frac > 1.0) Warn(ctx, "Fraction of thermal electrons outside [0, 1].");
@@ -817,7 +815,7 @@ int bl_device_count(void) {
 }
 
 int bl_set_undefined_policy(bl_ctx *ctx, int policy) {
-  if (ctx == nullptr || (policy != BL_UNDEFINED_REFUSE && policy != BL_UNDEFINED_EDGE)) return BL_E_ARG;
+  if (ctx == nullptr || policy < 0 || policy > (BL_UNDEFINED_EDGE | BL_UNDEFINED_KAPPA)) return BL_E_ARG;
   ctx->undefined_policy = policy;
   return BL_OK;
 }

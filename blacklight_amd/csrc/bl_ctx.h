@@ -114,7 +114,8 @@ struct bl_ctx {
   uint64_t scratch_limit = 144ull << 30;
   int overlap_chunks = 0;             // bl_set_overlap(): geodesic kernel of chunk c + 1 beside the shading of chunk c
   int arithmetic = BL_ARITH_EXACT;    // bl_set_arithmetic()
-  int undefined_policy = BL_UNDEFINED_REFUSE;   // bl_set_undefined_policy()
+  int undefined_policy = BL_UNDEFINED_REFUSE;   // bl_set_undefined_policy(): BL_UNDEFINED_EDGE | BL_UNDEFINED_KAPPA
+  bool kappa_warned = false;
   double guard_band = 1.0e-9;         // tolerant tier: relative half-width around a cut threshold left to the exact kernel
 
   // image rows (radiation_integrator.cpp:436-520)

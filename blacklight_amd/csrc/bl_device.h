@@ -125,10 +125,12 @@ struct BlPlasmaDevice {
   double power_frac, plasma_p, power_jj, power_aa;
   int code_kappa;            // plasma_model = code_kappa: theta_e from the simulation's electron entropy (:351-358)
   int cut_mask;              // bit c set: cell cut threshold c (BlShadeCold::fast_cut order) is active
+  int kappa_unpolarized;     // kappa-distribution electrons in an unpolarized run (BL_UNDEFINED_KAPPA): BlShadeCold::kappa's intensity terms
 };
 
 // Kappa-distribution electrons (simulation_coefficients.cpp:82-193; the reference's names without the prefix).
-// frac = 0: none. Built for polarized runs, where the reference defines every constant (bl_init refuses otherwise).
+// frac = 0: none. The reference defines every constant in polarized runs only: an unpolarized run reads aa_high_i without ever
+// setting it, and is rendered here only under bl_set_undefined_policy(BL_UNDEFINED_KAPPA), with the polarized definition.
 struct BlKappaDevice {
   double frac, kappa, w;
   double jj_low, jj_high, jj_x_i, aa_low, aa_high, aa_x_i;

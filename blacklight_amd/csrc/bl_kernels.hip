@@ -3744,7 +3744,7 @@ extern "C" hipError_t bl_launch_locate(const BlShadeArgs *args, int grid, int ld
 extern "C" hipError_t bl_launch_shade(const BlShadeArgs *args, int model, int grid, hipStream_t stream) {
   const bool aux = args->aux != nullptr;
   const bool power = args->plasma.power_frac != 0.0 || args->plasma.code_kappa != 0 || args->slow.n > 0 || args->pol_samples != nullptr
-      || args->anchors != nullptr;
+      || args->anchors != nullptr || args->plasma.kappa_unpolarized != 0;
   // the benchmark path - plain image of a spherical Kerr-Schild simulation in a curved spacetime - has its own
   // instantiation with those two facts known at compile time (62.4 instead of 64.4 ms per 1024^2 frame)
   const bool sks_curved = args->plasma.simulation_coord == BL_COORD_SKS && !args->st.ray_flat;
@@ -3832,7 +3832,8 @@ extern "C" hipError_t bl_launch_debug_math(int op, long long n, const double *x,
 
 extern "C" hipError_t bl_launch_coefficients_freq(const BlShadeArgs *args, int grid, hipStream_t stream) {
   // (the instantiation bl_launch_shade chose for the coefficient kernel: power-law electrons only in the extended one)
-  const bool extended = args->plasma.power_frac != 0.0 || args->plasma.code_kappa != 0 || args->slow.n > 0 || args->anchors != nullptr;
+  const bool extended = args->plasma.power_frac != 0.0 || args->plasma.code_kappa != 0 || args->slow.n > 0 || args->anchors != nullptr
+      || args->plasma.kappa_unpolarized != 0;
   if (extended) hipLaunchKernelGGL(bl_coefficients_freq_kernel<true>, dim3(grid), dim3(256), 0, stream, *args);
   else hipLaunchKernelGGL(bl_coefficients_freq_kernel<false>, dim3(grid), dim3(256), 0, stream, *args);
   return hipGetLastError();

@@ -151,7 +151,7 @@ int main(int argc, char *argv[]) {
   //   BLACKLIGHT_AMD_DEVICES    = N | all   GPUs to spread every image over (default 1; N may exceed the GPUs present:
   //                                         device d % present, which is how one GPU rehearses several)
   //   BLACKLIGHT_AMD_ARITHMETIC = tolerant  bl_set_arithmetic(BL_ARITH_TOLERANT)
-  //   BLACKLIGHT_AMD_UNDEFINED  = edge      bl_set_undefined_policy(BL_UNDEFINED_EDGE)
+  //   BLACKLIGHT_AMD_UNDEFINED  = edge | kappa | edge,kappa   bl_set_undefined_policy(BL_UNDEFINED_EDGE / BL_UNDEFINED_KAPPA)
   int n_devices = 1;
   if (const char *text = std::getenv("BLACKLIGHT_AMD_DEVICES")) {
     const int present = bl_device_count();
@@ -171,8 +171,11 @@ int main(int argc, char *argv[]) {
     }
     if (const char *text = std::getenv("BLACKLIGHT_AMD_ARITHMETIC"))
       if (std::string(text) == "tolerant") bl_set_arithmetic(contexts[dev], BL_ARITH_TOLERANT);
-    if (const char *text = std::getenv("BLACKLIGHT_AMD_UNDEFINED"))
-      if (std::string(text) == "edge") bl_set_undefined_policy(contexts[dev], BL_UNDEFINED_EDGE);
+    if (const char *text = std::getenv("BLACKLIGHT_AMD_UNDEFINED")) {
+      const std::string chosen(text);
+      const int policy = (chosen.find("edge") != std::string::npos ? BL_UNDEFINED_EDGE : 0) | (chosen.find("kappa") != std::string::npos ? BL_UNDEFINED_KAPPA : 0);
+      bl_set_undefined_policy(contexts[dev], policy);
+    }
   }
   bl_ctx *ctx = contexts[0];
   const bool simulation = params.model_type == BL_MODEL_SIMULATION;

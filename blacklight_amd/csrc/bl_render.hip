@@ -178,6 +178,15 @@ void PlanJob(RenderJob &job) {
   if (d->n_rays > 0x7fffffffll) throw Failure{BL_E_ARG, "Too many rays in one bl_render call."};
   if (d->level < 0 || d->level > p.adaptive_max_level) throw Failure{BL_E_ARG, "Adaptive level out of range."};
   if (d->level > 0 && (d->block_locs == nullptr || d->n_blocks <= 0)) throw Failure{BL_E_ARG, "Refined level needs block_locs."};
+  if (job.simulation && p.plasma_kappa_frac != 0.0 && !ctx->polarized) {
+    if (!(ctx->undefined_policy & BL_UNDEFINED_KAPPA))
+      throw Failure{BL_E_UNSUPPORTED, "Kappa-distribution electrons (plasma_kappa_frac != 0) in an unpolarized run: the reference's absorptivity reads "
+                                      "kappa_aa_high_i, which it only initialises for polarized runs - no defined result to reproduce. "
+                                      "bl_set_undefined_policy(BL_UNDEFINED_KAPPA) uses the polarized definition instead."};
+    if (!ctx->kappa_warned)
+      Warn(ctx, "Unpolarized kappa-distribution electrons: kappa_aa_high_i, which the reference leaves uninitialised here, is (3 / kappa)^4.75 + 0.6.");
+    ctx->kappa_warned = true;
+  }
   job.n_nu = p.image_num_frequencies;
   job.n_q = ctx->image_num_quantities;
   job.max_steps = p.ray_max_steps;
@@ -684,6 +693,7 @@ void BuildShadeArgs(RenderJob &job) {
     cold.fallback_pgas = p.fallback_nan ? 0.0f : p.fallback_pgas;
     cold.fallback_kappa = p.fallback_nan ? 0.0f : p.fallback_kappa;
     pl.code_kappa = p.plasma_model == BL_PLASMA_CODE_KAPPA ? 1 : 0;
+    pl.kappa_unpolarized = (p.plasma_kappa_frac != 0.0 && !ctx->polarized) ? 1 : 0;
     // cell cuts (simulation_coefficients.cpp:361-375): "cut >= 0 and value < cut". A disabled threshold goes to the
     // device as -inf (lower) / +inf (upper), against which no value - NaN included - compares true: same
     // decisions, one compare per threshold
@@ -719,7 +729,7 @@ void BuildShadeArgs(RenderJob &job) {
     }
     sa.grid = ctx->grid_dev;
     sa.lds_table_bytes = ctx->lds_table_bytes;
-    sa.undefined_edge = ctx->undefined_policy == BL_UNDEFINED_EDGE ? 1 : 0;
+    sa.undefined_edge = (ctx->undefined_policy & BL_UNDEFINED_EDGE) ? 1 : 0;
     sa.tolerant = (job.fast || job.tolerant_polarized) ? 1 : 0;
   } else {
     BlFormulaDevice &fm = sa.formula;
@@ -1279,7 +1289,7 @@ void CollectChunk(RenderJob &job, int k) {
   if (fl.done < 0) fl.done = static_cast<long long>(std::min<unsigned long long>(hc[BL_CNT_NEXT_RAY], static_cast<unsigned long long>(fl.rays)));
   if (hc[BL_CNT_OVERFLOW] != 0) throw Failure{BL_E_DEVICE, "Sample record buffer overflow."};
   if (hc[BL_CNT_INTERP_FAILED] != 0) throw Failure{BL_E_INPUT, "Grid interpolation failed."};   // simulation_sampling.cpp:1319
-  if (hc[BL_CNT_UNDEFINED] != 0 && ctx->undefined_policy != BL_UNDEFINED_EDGE) {
+  if (hc[BL_CNT_UNDEFINED] != 0 && !(ctx->undefined_policy & BL_UNDEFINED_EDGE)) {
     if (p.simulation_coord == BL_COORD_FMKS)
       throw Failure{BL_E_UNSUPPORTED, "FMKS sampling reached the last polar zone of the last azimuthal plane (or the last entry of the "
                                       "coordinate table), where the reference reads past its arrays (simulation_sampling.cpp:405-415, "

@@ -341,6 +341,12 @@ BL_API int bl_frequencies(const bl_ctx *ctx, double *out, int n);
  * sample the reference defines is unaffected by the choice. */
 #define BL_UNDEFINED_REFUSE 0
 #define BL_UNDEFINED_EDGE 1
+/* BL_UNDEFINED_KAPPA (may be or-ed with BL_UNDEFINED_EDGE): kappa-distribution electrons (plasma_kappa_frac != 0) in an unpolarized
+ * run. The reference's absorptivity reads kappa_aa_high_i (simulation_coefficients.cpp:652), which it sets for polarized runs only
+ * (:108-121): whatever its allocator left there decides its image. Without this flag bl_render refuses such a run (BL_E_UNSUPPORTED);
+ * with it the constant has its polarized definition, (3 / kappa)^4.75 + 0.6, and bl_render says so in a warning. No reference image
+ * exists to compare with: the checker is the oracle under the same definition. */
+#define BL_UNDEFINED_KAPPA 2
 BL_API int bl_set_undefined_policy(bl_ctx *ctx, int policy);
 #define BL_ARITH_EXACT 0
 #define BL_ARITH_TOLERANT 1

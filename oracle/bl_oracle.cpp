@@ -116,6 +116,7 @@ struct Oracle {
   } kappa = {};
   int render_num_images = 0;               // 0 in formula mode (radiation_integrator.cpp:136-145)
   // slow light: time slices held by the reader, latest first (simulation_reader.cpp:211-303)
+  bool define_kappa_aa_high_i = false;   // blo_extra: unpolarized kappa-distribution electrons allowed
   int slow_n = 0;
   const bl_grid_desc *const *slow_grids = nullptr;
   const double *slow_times = nullptr;
@@ -2839,8 +2840,8 @@ int Setup(Oracle &o, const bl_params *p, const bl_grid_desc *g, char *err, size_
       return Fail(err, err_len, "oracle: slow light needs slow_chunk_size time slices in blo_extra", BL_E_ARG);
     if (p->simulation_coord == BL_COORD_FMKS and (g->sks_map == nullptr or g->n_blocks != 1))
       return Fail(err, err_len, "oracle: fmks needs the reader's sks_map and one block", BL_E_UNSUPPORTED);
-    if (p->plasma_kappa_frac != 0.0 and not o.image_polarization)
-      return Fail(err, err_len, "oracle: kappa-distribution electrons are restated for polarized runs only (in unpolarized runs the reference reads the uninitialised kappa_aa_high_i)", BL_E_UNSUPPORTED);
+    if (p->plasma_kappa_frac != 0.0 and not o.image_polarization and not o.define_kappa_aa_high_i)
+      return Fail(err, err_len, "oracle: in unpolarized runs with kappa-distribution electrons the reference reads the uninitialised kappa_aa_high_i (blo_extra::define_kappa_aa_high_i gives it its polarized definition)", BL_E_UNSUPPORTED);
     o.plasma_thermal_frac = 1.0 - (p->plasma_power_frac + p->plasma_kappa_frac);
     o.render_num_images = p->render_num_images;   // radiation_integrator.cpp:136-139
     if (p->plasma_power_frac != 0.0) {  // simulation_coefficients.cpp:54-66 (unpolarized part)
@@ -2971,6 +2972,7 @@ int blo_render(const bl_params *p, const bl_grid_desc *g, const bl_render_desc *
   if (p == nullptr || d == nullptr) return BL_E_ARG;
   if (d->outputs_on_device) return Fail(err, err_len, "oracle works on host memory only", BL_E_ARG);
   Oracle o{};
+  o.define_kappa_aa_high_i = extra != nullptr and extra->define_kappa_aa_high_i != 0;
   if (extra != nullptr and p->model_type == BL_MODEL_SIMULATION and p->slow_light_on) {
     o.slow_n = extra->slow_n;
     o.slow_grids = extra->slow_grids;

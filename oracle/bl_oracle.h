@@ -43,6 +43,10 @@ typedef struct blo_extra {
   double slow_snapshot_time;
   int64_t slow_count[4];
   double slow_val[4];
+  /* in: != 0 renders kappa-distribution electrons in an unpolarized run with kappa_aa_high_i = (3 / kappa)^4.75 + 0.6, the value
+     the reference gives it in polarized runs (simulation_coefficients.cpp:121) and leaves uninitialised otherwise (read at :652);
+     0: such a run is refused. The library's BL_UNDEFINED_KAPPA. No reference image can pin this configuration. */
+  int32_t define_kappa_aa_high_i;
 } blo_extra;
 
 /* Same contract as bl_render() with host pointers (d->outputs_on_device must be 0). g may be NULL

@@ -21,6 +21,7 @@ class Extra(C.Structure):
         ("max_sample_num", C.c_int32), ("seconds", C.c_double),
         ("slow_n", C.c_int32), ("slow_grids", C.c_void_p), ("slow_times", C.c_void_p),
         ("slow_snapshot_time", C.c_double), ("slow_count", C.c_int64 * 4), ("slow_val", C.c_double * 4),
+        ("define_kappa_aa_high_i", C.c_int32),
     ]
 
 
@@ -56,10 +57,11 @@ def load(variant="blmath"):
 
 def render(params_ptr, grid_desc, desc_cls, camera_frame_cls, *, n_rays, level=0, block_locs=None,
            pixel_map=None, variant="blmath", num_threads=0, dump_ray=-1, max_steps=0, n_freq=1,
-           want_camera=False, n_render=0, slow=None):
+           want_camera=False, n_render=0, slow=None, define_kappa=False):
     """Run the oracle. Returns dict(image, sample_num, sample_flags, frame, frequencies, extra...).
     n_render > 0: also the false-colour renderings, (n_render, 3, n_rays).
-    slow = dict(grids=[bl_grid_desc, ...] latest first, times=[...], snapshot_time=t): slow light."""
+    slow = dict(grids=[bl_grid_desc, ...] latest first, times=[...], snapshot_time=t): slow light.
+    define_kappa: unpolarized kappa-distribution electrons with kappa_aa_high_i as in polarized runs (blo_extra)."""
     L = load(variant)
     n_q = L.blo_image_num_quantities(params_ptr)
     image = np.zeros((max(n_q, 1), n_rays), dtype=np.float64)
@@ -96,6 +98,7 @@ def render(params_ptr, grid_desc, desc_cls, camera_frame_cls, *, n_rays, level=0
     freqs = np.zeros(max(n_freq, 1))
     extra = Extra()
     extra.num_threads = num_threads
+    extra.define_kappa_aa_high_i = 1 if define_kappa else 0
     extra.dump_ray = dump_ray
     dump = None
     if dump_ray >= 0:

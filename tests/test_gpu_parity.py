@@ -352,6 +352,57 @@ def test_empty_shell_steps_leave_no_records(seed, built_library, monkeypatch):
     assert np.nanmax(want["image"]) > 0.0
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_unpolarized_kappa_electrons_under_the_opt_in_policy(seed, built_library):
+    """plasma_kappa_frac != 0 without polarization: the reference's absorptivity reads kappa_aa_high_i (simulation_coefficients.
+    cpp:652), set for polarized runs only (:108-121) - no image of its to compare with. Refused by default; under
+    bl_set_undefined_policy(BL_UNDEFINED_KAPPA) rendered with the polarized definition and a warning, bit-identical to the
+    oracle under the same definition - plain images, auxiliary rows and frequency lists (the exact tier's per-frequency
+    kernel), with thermal and power-law electrons beside them."""
+    import blacklight_amd as bl
+    from blacklight_amd import _capi
+    import oracle_api
+    rng = np.random.default_rng(8800 + seed)
+    fx, params, mock_args = gu.load_case("sim_dp_interp")
+    over = dict(camera_resolution=16, camera_th=float(rng.uniform(20.0, 160.0)), camera_ph=float(rng.uniform(0.0, 360.0)),
+                simulation_a=float(rng.choice([0.0, 0.6])), plasma_kappa_frac=float(rng.uniform(0.1, 0.7)),
+                plasma_kappa=float(rng.choice([3.5, 4.2, 5.0, 7.0])), plasma_w=float(rng.uniform(5.0, 40.0)),
+                image_num_frequencies=int(rng.choice([1, 5])), simulation_interp=str(rng.choice(["true", "false"])))
+    if seed % 3 == 1:
+        over.update(plasma_power_frac=0.2, plasma_p=3.0, plasma_gamma_min=1.0, plasma_gamma_max=1000.0)
+    if seed % 3 == 2:
+        over.update(image_tau="true", image_emission="true", image_tau_int="true")
+    if over["image_num_frequencies"] > 1:
+        over.update(image_frequency_start=1.0e11, image_frequency_end=8.0e11, image_frequency_spacing="log")
+    params = dict(params, **over)
+    p = bl.Params.from_dict(params)
+    grid = gu.golden_grid(mock_args)
+    with bl.Context(p) as ctx:
+        ctx.set_grid(grid)
+        with pytest.raises(bl.BlacklightError, match="BL_UNDEFINED_KAPPA"):
+            ctx.render()
+        ctx.set_undefined_policy("kappa")
+        ctx.clear_warnings()
+        got = ctx.render()
+        assert ctx.warnings.count("kappa_aa_high_i") == 1 and "(3 / kappa)^4.75 + 0.6" in ctx.warnings
+        ctx.set_arithmetic("tolerant")
+        again = ctx.render()
+        assert again["stats"].arithmetic == 0 and gu.same_bits(again["image"], got["image"]).all()
+    want = oracle_api.render(p.ptr, grid.desc(), _capi.RenderDesc, _capi.CameraFrame, n_rays=256, max_steps=int(p.get("ray_max_steps")),
+                             n_freq=over["image_num_frequencies"], define_kappa=True)
+    with pytest.raises(RuntimeError, match="uninitialised kappa_aa_high_i"):
+        oracle_api.render(p.ptr, grid.desc(), _capi.RenderDesc, _capi.CameraFrame, n_rays=256, max_steps=int(p.get("ray_max_steps")),
+                          n_freq=over["image_num_frequencies"])
+    assert np.array_equal(got["sample_num"], want["sample_num"])
+    assert got["image"].shape == want["image"].shape
+    same = gu.same_bits(got["image"], want["image"])
+    assert same.all(), f"{(~same).sum()} of {same.size} values differ for {over}"
+    # the electrons are seen: the same run without them gives another image
+    with bl.Context(bl.Params.from_dict(dict(params, plasma_kappa_frac=0.0))) as ctx:
+        ctx.set_grid(grid)
+        assert not gu.same_bits(ctx.render()["image"], got["image"]).all()
+
+
 @pytest.mark.parametrize("seed", range(10))
 def test_randomised_polarized_configurations_against_oracle(seed, built_library):
     """Seeded draws of polarized runs (joint coupling / rotation split, spins, one or two frequencies, nearest or

@@ -130,9 +130,9 @@ def test_context_validation_messages(bl):
     assert failing(adaptive_max_level=1, adaptive_block_size=5) == \
         "Error: Must have adaptive_block_size divide camera_resolution."
     # reference configurations outside the hot-path scope are refused loudly, never approximated
-    # kappa-distribution electrons: the constructor's checks (radiation_integrator.cpp:296-308); unpolarized runs are
-    # refused (the reference reads an uninitialised constant there), never approximated
-    assert "built for polarized runs only" in failing(plasma_kappa_frac=0.2, plasma_kappa=4.0, plasma_w=1.0)
+    # kappa-distribution electrons: the constructor's checks (radiation_integrator.cpp:296-308). An unpolarized run passes them,
+    # as in the reference; bl_render refuses it without BL_UNDEFINED_KAPPA (the reference reads an uninitialised constant
+    # there: tests/test_gpu_parity.py::test_unpolarized_kappa_electrons_under_the_opt_in_policy)
     assert failing(plasma_kappa_frac=0.2, plasma_w=1.0) == "Error: RadiationIntegrator unable to find all needed values in input file."
     assert failing(plasma_kappa_frac=0.2, plasma_kappa=4.0) == "Error: RadiationIntegrator unable to find all needed values in input file."
     assert failing(plasma_kappa_frac=0.2, plasma_kappa=5.5, plasma_w=1.0, image_polarization="true",
