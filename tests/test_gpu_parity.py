@@ -140,6 +140,48 @@ AUX_ALL = dict(image_time="true", image_length="true", image_lambda="true", imag
 AUX_SIM = dict(AUX_ALL, image_lambda_ave="true", image_emission_ave="true", image_tau_int="true")
 
 
+@pytest.mark.parametrize("overlap", [False, True])
+@pytest.mark.parametrize("mode", ["empty shell", "optical depth", "kappa", "power law cks"])
+def test_round_three_paths_in_several_chunks(mode, overlap, built_library):
+    """The paths added in round 3 under a scratch budget that forces several chunks (rays the record gate refused go to the next
+    chunk; with bl_set_overlap two scratch sets alternate): same bits as the unconstrained render, in both tiers."""
+    import blacklight_amd as bl
+    fx, params, mock_args = gu.load_case("sim_dp_interp")
+    params = dict(params, camera_resolution=48, fallback_nan="false", fallback_rho=1.0e-6, fallback_pgas=1.0e-8, image_num_frequencies=3,
+                  image_frequency_start=1.0e11, image_frequency_end=6.0e11, image_frequency_spacing="log")
+    params.pop("image_frequency", None)
+    if mode == "empty shell":
+        params.update(camera_r=150.0, camera_width=60.0)
+    elif mode == "optical depth":
+        params.update(image_tau="true", simulation_a=0.5)
+    elif mode == "kappa":
+        params.update(plasma_kappa_frac=0.3, plasma_kappa=4.0, plasma_w=10.0, image_num_frequencies=5)
+    else:
+        params.update(simulation_coord="cks", plasma_power_frac=0.2, plasma_p=3.0, plasma_gamma_min=1.0, plasma_gamma_max=1000.0, simulation_a=0.5)
+    p = bl.Params.from_dict(params)
+    with bl.Context(p) as ctx:
+        ctx.set_grid(gu.golden_grid(mock_args))
+        if mode == "kappa":
+            ctx.set_undefined_policy("kappa")
+        for tier in ("exact", "tolerant"):
+            ctx.set_arithmetic(tier)
+            ctx.set_scratch_limit(1 << 40)
+            ctx.set_overlap(False)
+            whole = ctx.render()
+            assert whole["stats"].n_chunks == 1
+            ctx.set_scratch_limit(int(p.get("ray_max_steps")) * 16384)
+            ctx.set_overlap(overlap)
+            split = ctx.render()
+            assert split["stats"].n_chunks >= 4, split["stats"].n_chunks
+            assert split["stats"].arithmetic == whole["stats"].arithmetic == (0 if (mode == "kappa" or tier == "exact") else 1)
+            assert gu.same_bits(split["image"], whole["image"]).all(), (mode, tier)
+            assert np.array_equal(split["sample_num"], whole["sample_num"]) and np.array_equal(split["sample_flags"], whole["sample_flags"])
+            assert split["stats"].n_samples == whole["stats"].n_samples and split["stats"].n_gathers == whole["stats"].n_gathers
+            if mode == "empty shell":
+                assert whole["stats"].n_samples_emitted < 0.9 * whole["stats"].n_samples
+    assert np.nanmax(whole["image"]) > 0.0
+
+
 @pytest.mark.parametrize("case,extra", [
     ("sim_multifreq", AUX_SIM),                                    # three frequencies, every auxiliary image
     ("sim_few_steps", AUX_SIM),                                    # flagged rays: NaN primitives along the whole ray
