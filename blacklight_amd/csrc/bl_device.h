@@ -355,6 +355,7 @@ struct BlShadeArgs {
   // tolerant arithmetic tier (bl_shade_fast_kernel) only
   double fast_n_e_factor;     // 1 / (mu m_p (1 + 1 / ne_ni))
   double fast_d_unit_inv;     // 1 / d_unit
+  double fast_angle_band;     // tolerant locate step: theta / phi closer than this to a decision are the exact kernel's (1e-12; wider under bl_debug_set_guard_band)
   double fast_gamma[3];       // 1 / (gamma - 1), 1 / (gamma_i - 1), 1 / (gamma_e - 1) (plasma_use_p = false)
   unsigned long long *redo_list;       // record indices left to the exact kernel, BL_CNT_REDO entries
   unsigned long long redo_capacity;    // entries the list holds; more than that: the exact kernel shades every record

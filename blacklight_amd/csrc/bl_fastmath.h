@@ -136,6 +136,66 @@ __device__ __forceinline__ double pow_of(PowBase b, double y) {
 }
 __device__ __forceinline__ double div(double a, double b) { return a * rcp(b); }
 
+// acos(x) for |x| <= 1 and atan2(y, x) for finite arguments, as the locate step of the tolerant tier uses them: the pinned
+// library's polynomials (blmath.h: (asin(s) - s) / s^3 on s^2 <= 1/4; atan on |u| < 7/16) without its double-double corrections,
+// with the tier's reciprocal and reciprocal square root, and one quotient in atan2 where bl_atan2 has two. Absolute error
+// below 1e-15 (measured 6e-16 / 7e-16, tests/test_gpu_tolerant.py); the caller keeps away from decisions closer than that (locate_plain_sample).
+__device__ __forceinline__ double acos(double x) {
+  const double ax = __builtin_fabs(x);
+  const bool small = ax < 0.5;
+  const double z = small ? x * x : (1.0 - ax) * 0.5;
+  double r = 0x1.e58a4f278e007p-6;
+  r = __builtin_fma(r, z, -0x1.3bd7e353ddbc2p-6);
+  r = __builtin_fma(r, z, 0x1.40c91fa8deb7ep-6);
+  r = __builtin_fma(r, z, 0x1.8dcdf11997e0fp-9);
+  r = __builtin_fma(r, z, 0x1.31777489dfd29p-7);
+  r = __builtin_fma(r, z, 0x1.3b462d121c5d2p-7);
+  r = __builtin_fma(r, z, 0x1.7b02ef007d23ep-7);
+  r = __builtin_fma(r, z, 0x1.c990a42b32b03p-7);
+  r = __builtin_fma(r, z, 0x1.1c4efd20ebb99p-6);
+  r = __builtin_fma(r, z, 0x1.6e8ba121b9d5fp-6);
+  r = __builtin_fma(r, z, 0x1.f1c71c7a5e151p-6);
+  r = __builtin_fma(r, z, 0x1.6db6db6dac0eap-5);
+  r = __builtin_fma(r, z, 0x1.3333333333389p-4);
+  r = __builtin_fma(r, z, 0x1.5555555555555p-3);
+  r *= z;                                                     // asin(s) = s + s r
+  const double s = small ? x : (z > 0.0 ? z * rsqrt(z) : 0.0);
+  const double asin_s = __builtin_fma(s, r, s);
+  const double pio2 = 0x1.921fb54442d18p+0, pio2_lo = 0x1.1a62633145c07p-54;
+  const double res_small = (pio2 - asin_s) + pio2_lo;
+  const double res_neg = __builtin_fma(-2.0, asin_s, 2.0 * pio2) + 2.0 * pio2_lo;
+  return small ? res_small : (x < 0.0 ? res_neg : 2.0 * asin_s);
+}
+__device__ __forceinline__ double atan2(double y, double x) {
+  const double ax = __builtin_fabs(x), ay = __builtin_fabs(y);
+  const double mx = ax > ay ? ax : ay, mn = ax > ay ? ay : ax;
+  // t = mn / mx in [0, 1]: atan(t) = atan(c) + atan((t - c) / (1 + c t)) with c = 0, 1/2, 1 by t < 7/16, < 11/16, else
+  const bool low = 16.0 * mn <= 7.0 * mx, mid = 16.0 * mn < 11.0 * mx;   // (<=: the origin itself gives 0)
+  const double c = low ? 0.0 : (mid ? 0.5 : 1.0);
+  const double hi = low ? 0.0 : (mid ? 0x1.dac670561bb4fp-2 : 0x1.921fb54442d18p-1);
+  const double num = __builtin_fma(-c, mx, mn), den = __builtin_fma(c, mn, mx);
+  const double u = den > 0.0 ? num * rcp(den) : 0.0;
+  const double w = u * u;
+  double a = -0x1.9a0e3d8214a3cp-7;
+  a = __builtin_fma(a, w, 0x1.dde84abd3489ap-6);
+  a = __builtin_fma(a, w, -0x1.4ac01ab40659fp-5);
+  a = __builtin_fma(a, w, 0x1.812cf294b38a9p-5);
+  a = __builtin_fma(a, w, -0x1.ae800c7915a0cp-5);
+  a = __builtin_fma(a, w, 0x1.e1d239c838f12p-5);
+  a = __builtin_fma(a, w, -0x1.1110907ae84ccp-4);
+  a = __builtin_fma(a, w, 0x1.3b13abac1919fp-4);
+  a = __builtin_fma(a, w, -0x1.745d171e2e854p-4);
+  a = __builtin_fma(a, w, 0x1.c71c71c673bd9p-4);
+  a = __builtin_fma(a, w, -0x1.24924924918e2p-3);
+  a = __builtin_fma(a, w, 0x1.999999999998fp-3);
+  a = __builtin_fma(a, w, -0x1.5555555555555p-2);
+  double res = hi + __builtin_fma(u * w, a, u);               // atan(mn / mx)
+  const double pio2 = 0x1.921fb54442d18p+0, pi = 0x1.921fb54442d18p+1;
+  res = ay > ax ? pio2 - res : res;
+  res = x < 0.0 ? pi - res : res;
+  return y < 0.0 ? -res : res;
+}
+
 // K_0, K_1, K_2 of one argument: bl_cyl_bessel_k012's algorithm (Temme's series below 2, Steed's continued fraction above,
 // the same stopping rules) with the tier's logarithm, exponential and reciprocals in place of the pinned functions and the
 // IEEE divisions (a dozen per term there). x finite and positive (1 / Theta_e with Theta_e >= 0.01).

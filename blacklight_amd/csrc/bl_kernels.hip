@@ -1926,29 +1926,17 @@ __device__ __forceinline__ void stage_grid_tables(const BlGridDevice &g, double 
 }
 struct PlainLocated {
   double f_i, f_j, f_k, ph_unwrapped;
-  uint32_t status, cell;
+  uint32_t status, cell;   // status: kSample...; | kPlainUndecided from locate_plain_sample_tolerant()
 };
-template <bool kSpinZero>
-__device__ __forceinline__ PlainLocated locate_plain_sample(const BlSpacetime &st, const BlGridDevice &g, const PlainGrid &pg, double camera_r,
-                                                            bool live, double x1, double x2, double x3) {
+constexpr uint32_t kPlainUndecided = 0x100u;
+// From (r, theta, unwrapped phi) to status, cell and fractions. margin (if asked for): how far theta and phi are from the nearest
+// value they are compared with on the way - the faces and the centre of their cells, the ends of the azimuth's range.
+__device__ __forceinline__ PlainLocated locate_plain_from_angles(const BlGridDevice &g, const PlainGrid &pg, bool live, bool cut, double r, double th,
+                                                                 double ph_unwrapped, double *margin) {
   const GridTables &tab = pg.tab;
-  // a dead slot may hold anything: the search runs on a harmless point instead
-  x1 = live ? x1 : 1.0;
-  x2 = live ? x2 : 1.0;
-  x3 = live ? x3 : 1.0;
-  double r2;
-  const double r = bl_radial_coordinate2<kSpinZero>(st, x1, x2, x3, &r2);
-  const bool cut = r > camera_r;                                   // simulation_sampling.cpp:238-243
-  // ConvertFromCKS (radiation_geometry.cpp:37-57), as in locate_sample()
-#ifdef BL_EXP_CHEAP_ANGLES   // experiment (wrong images): what the inverse trigonometric functions cost the fused kernel
-  const double th = 1.5707963 - 1.2 * blm_div(x3, r);
-  const double ph_unwrapped = 3.14159 + 3.0 * blm_div(x2, fabs(x1) + fabs(x2) + 1.0e-300) * (x1 < 0.0 ? 0.5 : 1.0);
-#else
-  const double th = bl_acos(blm_div(x3, r));
-  const double ph_unwrapped = kSpinZero ? bl_atan2(x2, x1) : bl_atan2(x2, x1) - bl_atan(blm_div(st.bh_a, r));
-#endif
   double ph = ph_unwrapped;
   ph += ph < 0.0 ? 2.0 * kPi : 0.0;
+  const double ph_once = ph;
   ph -= ph >= 2.0 * kPi ? 2.0 * kPi : 0.0;
   const double s1 = r, s2 = th, s3 = ph;
   const bool off_grid = s1 < tab.xf[0][0] || s1 > tab.xf[0][pg.n_i] || s2 < tab.xf[1][0] || s2 > tab.xf[1][pg.n_j]
@@ -1956,9 +1944,10 @@ __device__ __forceinline__ PlainLocated locate_plain_sample(const BlSpacetime &s
   const int i = find_cell(g, tab, 0, s1), j = find_cell(g, tab, 1, s2), k = find_cell(g, tab, 2, s3);
   // :485-490, per block of a merged grid (one block - the usual case - needs no remainders)
   const int i_b = pg.one_block ? i : i % pg.nb_i, j_b = pg.one_block ? j : j % pg.nb_j, k_b = pg.one_block ? k : k % pg.nb_k;
+  const double xv_at_j = tab.xv[1][j], xv_at_k = tab.xv[2][k];
   const int i_m = (i_b == 0 || (i_b != pg.nb_i - 1 && s1 >= tab.xv[0][i])) ? i : i - 1;
-  const int j_m = (j_b == 0 || (j_b != pg.nb_j - 1 && s2 >= tab.xv[1][j])) ? j : j - 1;
-  const int k_m = (k_b == 0 || (k_b != pg.nb_k - 1 && s3 >= tab.xv[2][k])) ? k : k - 1;
+  const int j_m = (j_b == 0 || (j_b != pg.nb_j - 1 && s2 >= xv_at_j)) ? j : j - 1;
+  const int k_m = (k_b == 0 || (k_b != pg.nb_k - 1 && s3 >= xv_at_k)) ? k : k - 1;
   const double xv_i = tab.xv[0][i_m], xv_j = tab.xv[1][j_m], xv_k = tab.xv[2][k_m];
   const bool sampled = live && !cut && !off_grid;
   PlainLocated out;
@@ -1972,7 +1961,30 @@ __device__ __forceinline__ PlainLocated locate_plain_sample(const BlSpacetime &s
   out.ph_unwrapped = (!live || cut) ? 0.0 : ph_unwrapped;
   out.status = !live ? (uint32_t)kSampleNone : (cut ? (uint32_t)kSampleCut : (off_grid ? (uint32_t)kSampleOffGrid : (uint32_t)kSampleInterp));
   out.cell = sampled ? (uint32_t)((k_m * pg.n_j + j_m) * pg.n_i + i_m) : 0u;
+  if (margin != nullptr) {
+    double m = std_min(blm_abs(s2 - tab.xf[1][j]), blm_abs(s2 - tab.xf[1][j + 1]));
+    m = std_min(m, blm_abs(s2 - xv_at_j));
+    m = std_min(m, std_min(blm_abs(s3 - tab.xf[2][k]), blm_abs(s3 - tab.xf[2][k + 1])));
+    m = std_min(m, blm_abs(s3 - xv_at_k));
+    m = std_min(m, std_min(blm_abs(ph_unwrapped), blm_abs(ph_once - 2.0 * kPi)));
+    *margin = m;
+  }
   return out;
+}
+template <bool kSpinZero>
+__device__ __forceinline__ PlainLocated locate_plain_sample(const BlSpacetime &st, const BlGridDevice &g, const PlainGrid &pg, double camera_r,
+                                                            bool live, double x1, double x2, double x3) {
+  // a dead slot may hold anything: the search runs on a harmless point instead
+  x1 = live ? x1 : 1.0;
+  x2 = live ? x2 : 1.0;
+  x3 = live ? x3 : 1.0;
+  double r2;
+  const double r = bl_radial_coordinate2<kSpinZero>(st, x1, x2, x3, &r2);
+  const bool cut = r > camera_r;                                   // simulation_sampling.cpp:238-243
+  // ConvertFromCKS (radiation_geometry.cpp:37-57), as in locate_sample()
+  const double th = bl_acos(blm_div(x3, r));
+  const double ph_unwrapped = kSpinZero ? bl_atan2(x2, x1) : bl_atan2(x2, x1) - bl_atan(blm_div(st.bh_a, r));
+  return locate_plain_from_angles(g, pg, live, cut, r, th, ph_unwrapped, nullptr);
 }
 
 // The locate kernel of that case
@@ -2358,6 +2370,28 @@ __global__ void __launch_bounds__(256, 2) bl_shade_kernel(const BlShadeArgs P) {
 
 #pragma clang fp contract(fast)
 #include "bl_fastmath.h"
+
+// locate_plain_sample() with the tolerant tier's inverse trigonometric functions (bl_fastmath.h: below 1e-15) where the exact tier has
+// the pinned ones. Radius, cut at the camera's sphere, cell search and fractions are the same code on the same tables; a sample
+// whose theta or phi comes within `band` (1e-12) of anything it is compared with - a face or centre of its cell, the ends of the azimuth's
+// range - is marked kPlainUndecided and left to the exact kernel's second pass, so status and cell are the exact tier's everywhere
+// else (and the fractions within 1e-13 of a cell width).
+template <bool kSpinZero>
+__device__ __forceinline__ PlainLocated locate_plain_sample_tolerant(const BlSpacetime &st, const BlGridDevice &g, const PlainGrid &pg, double camera_r,
+                                                                     double band, bool live, double x1, double x2, double x3) {
+  x1 = live ? x1 : 1.0;
+  x2 = live ? x2 : 1.0;
+  x3 = live ? x3 : 1.0;
+  double r2;
+  const double r = bl_radial_coordinate2<kSpinZero>(st, x1, x2, x3, &r2);
+  const bool cut = r > camera_r;
+  const double th = fastmath::acos(blm_div(x3, r));
+  const double ph_unwrapped = kSpinZero ? fastmath::atan2(x2, x1) : fastmath::atan2(x2, x1) - fastmath::atan2(st.bh_a, r);
+  double margin;
+  PlainLocated out = locate_plain_from_angles(g, pg, live, cut, r, th, ph_unwrapped, &margin);
+  if (live && !cut && !(margin > band)) out.status |= kPlainUndecided;
+  return out;
+}
 
 // tolerant arithmetic tier of the coefficient formulas (sin, cos, tanh keep the pinned versions: few calls, and their
 // arguments need a real range reduction)
@@ -2849,6 +2883,7 @@ __global__ void __launch_bounds__(256, BL_FAST_WAVES) bl_shade_fused_kernel(cons
   if (n_records == 0ull) return;
   const unsigned long long last = n_records - 1ull;
   const double camera_r = P.cuts.camera_r;
+  const double angle_band = P.fast_angle_band;
   unsigned long long gathers_local = 0ull;
   auto load_position = [&](bool have, unsigned long long at, double2 &q0, double2 &q1) {
     const double2 *hot = reinterpret_cast<const double2 *>(P.records_hot + (have ? at : last) * P.record_stride);
@@ -2879,20 +2914,21 @@ __global__ void __launch_bounds__(256, BL_FAST_WAVES) bl_shade_fused_kernel(cons
   bool have_after = have_next && idx < n_records;
   {
     const bool live = have_cur && (uint32_t)__double_as_longlong(hot_cur1.y) != BL_DEAD_RAY;
-    loc_cur = locate_plain_sample<kSpinZero>(st, P.grid, pg, camera_r, live, hot_cur0.x, hot_cur0.y, hot_cur1.x);
+    loc_cur = locate_plain_sample_tolerant<kSpinZero>(st, P.grid, pg, camera_r, angle_band, live, hot_cur0.x, hot_cur0.y, hot_cur1.x);
   }
   while (have_prev || have_cur) {
     const uint32_t ray = have_prev ? (uint32_t)__double_as_longlong(rec_prev.q1.y) : BL_DEAD_RAY;
     const bool live = ray != BL_DEAD_RAY;
     const uint32_t n = (uint32_t)(((unsigned long long)__double_as_longlong(rec_prev.q1.y)) >> 32);
-    const int status = (int)loc_prev.status;
+    const int status = (int)(loc_prev.status & 0xffu);
+    const bool undecided = (loc_prev.status & kPlainUndecided) != 0u;   // theta or phi too close to a decision: the exact kernel's sample
     // per-ray constants of `prev`: requested before the next sample's cells
     const double kt = P.ray_kt[live ? ray : 0u], momentum_factor = P.ray_factor[live ? ray : 0u];
     const size_t row = (size_t)P.ray_offset[live ? ray : 0u] + n;
     float pr[8];
     gather_finish(P, (float)fast_table[42], (float)fast_table[43], status, lo, hi, loc_prev.f_i, loc_prev.f_j, loc_prev.f_k, pr);
     gathers_local += (live && status == kSampleInterp) ? 1ull : 0ull;
-    gather_issue(P, (int)loc_cur.status, loc_cur.cell, lo, hi);
+    gather_issue(P, (int)(loc_cur.status & 0xffu), loc_cur.cell, lo, hi);
     double2 cold_cur0, cold_cur1;
     {
       const double2 *cold = reinterpret_cast<const double2 *>(P.records_cold + (have_cur ? idx_cur : last) * P.record_stride);
@@ -2903,14 +2939,14 @@ __global__ void __launch_bounds__(256, BL_FAST_WAVES) bl_shade_fused_kernel(cons
     load_position(have_after, idx, hot_after0, hot_after1);
     if (live) {
       // ReverseGeodesics: sample_len = -geodesic_len (geodesics.cpp:840)
-      if (!fast_shade_sample<kSpinZero>(P, fast_table, pr, status, row, rec_prev.q0.x, rec_prev.q0.y, rec_prev.q1.x, rec_prev.q2.x, rec_prev.q2.y,
-                                        rec_prev.q3.x, kt, momentum_factor, -rec_prev.q3.y)) {
+      if (undecided || !fast_shade_sample<kSpinZero>(P, fast_table, pr, status, row, rec_prev.q0.x, rec_prev.q0.y, rec_prev.q1.x, rec_prev.q2.x,
+                                                     rec_prev.q2.y, rec_prev.q3.x, kt, momentum_factor, -rec_prev.q3.y)) {
         fast_defer(P, idx_prev);
       }
     }
     // the search for `next`
     const bool live_next = have_next && (uint32_t)__double_as_longlong(hot_next1.y) != BL_DEAD_RAY;
-    const PlainLocated loc_next = locate_plain_sample<kSpinZero>(st, P.grid, pg, camera_r, live_next, hot_next0.x, hot_next0.y, hot_next1.x);
+    const PlainLocated loc_next = locate_plain_sample_tolerant<kSpinZero>(st, P.grid, pg, camera_r, angle_band, live_next, hot_next0.x, hot_next0.y, hot_next1.x);
     rec_prev.q0 = hot_cur0;
     rec_prev.q1 = hot_cur1;
     rec_prev.q2 = cold_cur0;
@@ -3647,6 +3683,8 @@ __global__ void bl_debug_math_kernel(int op, long long n, const double *x, const
     case 22: r = fastmath::cbrt(a); break;
     case 23: r = fastmath::rcp(a); break;
     case 24: r = fastmath::rsqrt(a); break;
+    case 28: r = fastmath::acos(a); break;
+    case 29: r = fastmath::atan2(a, b); break;
     default: break;
   }
   out[i] = r;

@@ -258,8 +258,8 @@ def test_deferred_cut_decisions(band, resolution, frequencies, variant, built_li
 
 
 def test_tolerant_functions_are_accurate(built_library):
-    """exp, expm1, cbrt, reciprocal and reciprocal square root of the tolerant tier against numpy's long double, its Bessel
-    functions against scipy."""
+    """exp, expm1, cbrt, reciprocal, reciprocal square root, acos and atan2 of the tolerant tier against numpy's long double, its
+    Bessel functions against scipy."""
     import blacklight_amd as bl
     fx, params, _ = gu.load_case("formula_flat")
     rng = np.random.default_rng(3)
@@ -290,6 +290,18 @@ def test_tolerant_functions_are_accurate(built_library):
         assert sat[0] == -1.0 and sat[1] == np.inf and np.isnan(sat[2]) and sat[3] == 0.0
         rc = ctx.debug_math(23, np.array([0.0, np.inf, -np.inf, np.nan]))
         assert rc[0] == np.inf and rc[1] == 0.0 and rc[2] == 0.0 and np.isnan(rc[3])
+        # acos and atan2 of the tolerant locate step (ops 28, 29): absolute error, against long double
+        xa = np.concatenate([rng.uniform(-1.0, 1.0, 300000), 1.0 - 10.0 ** rng.uniform(-16, 0, 50000), -1.0 + 10.0 ** rng.uniform(-16, 0, 50000),
+                             np.array([0.0, 1.0, -1.0, 0.5, -0.5, 0.4999999999999999, 1e-300])])
+        got = ctx.debug_math(28, xa)
+        assert float(np.max(np.abs(got.astype(ld) - np.arccos(xa.astype(ld))))) < 1.0e-15
+        ya = np.concatenate([rng.uniform(-60.0, 60.0, 300000), 10.0 ** rng.uniform(-12, 2, 100000) * rng.choice([-1.0, 1.0], 100000)])
+        xb2 = np.concatenate([rng.uniform(-60.0, 60.0, 300000), 10.0 ** rng.uniform(-12, 2, 100000) * rng.choice([-1.0, 1.0], 100000)])
+        got = ctx.debug_math(29, ya, xb2)
+        assert float(np.max(np.abs(got.astype(ld) - np.arctan2(ya.astype(ld), xb2.astype(ld))))) < 1.0e-15
+        edge = ctx.debug_math(29, np.array([0.0, 0.0, 1.0, -1.0, 0.0, 7.0, -7.0]), np.array([1.0, -1.0, 0.0, 0.0, 0.0, 7.0, -7.0]))
+        assert edge[0] == 0.0 and abs(edge[1] - np.pi) < 5e-16 and abs(edge[2] - np.pi / 2) < 5e-16 and abs(edge[3] + np.pi / 2) < 5e-16
+        assert edge[4] == 0.0 and abs(edge[5] - np.pi / 4) < 5e-16 and abs(edge[6] + 3 * np.pi / 4) < 5e-16
         # K_0, K_1, K_2 (ops 25-27) over the arguments 1 / Theta_e takes (Theta_e from 0.01 to 1e4), against scipy
         from scipy import special as sp
         xb = np.concatenate([10.0 ** rng.uniform(-4.0, 2.0, 100000), rng.uniform(1.5, 2.5, 20000)])
