@@ -1903,6 +1903,7 @@ struct PlainGrid {   // what the search needs of the grid, fetched once per work
   GridTables tab;
   int n_i, n_j, n_k, nb_i, nb_j, nb_k;
   bool one_block;
+  const double *inv_w[3];   // tolerant tier: 1 / (xv[c + 1] - xv[c]) per axis (LDS), or null: the fractions are IEEE quotients
 };
 __device__ __forceinline__ void stage_grid_tables(const BlGridDevice &g, double *lds, PlainGrid *pg) {
   double *dst = lds;
@@ -1923,6 +1924,16 @@ __device__ __forceinline__ void stage_grid_tables(const BlGridDevice &g, double 
   pg->n_i = g.n[0]; pg->n_j = g.n[1]; pg->n_k = g.n[2];
   pg->nb_i = g.nb[0]; pg->nb_j = g.nb[1]; pg->nb_k = g.nb[2];
   pg->one_block = g.nb[0] == g.n[0] && g.nb[1] == g.n[1] && g.nb[2] == g.n[2];
+  pg->inv_w[0] = pg->inv_w[1] = pg->inv_w[2] = nullptr;
+}
+// ... and the reciprocal widths between cell centres behind them (call after a barrier: reads the staged centres)
+__device__ __forceinline__ void stage_reciprocal_widths(const BlGridDevice &g, double *lds, PlainGrid *pg) {
+  double *dst = lds;
+  for (int a = 0; a < 3; a++) {
+    pg->inv_w[a] = dst;
+    for (int i = threadIdx.x; i + 1 < g.n[a]; i += blockDim.x) dst[i] = 1.0 / (pg->tab.xv[a][i + 1] - pg->tab.xv[a][i]);
+    dst += g.n[a];
+  }
 }
 struct PlainLocated {
   double f_i, f_j, f_k, ph_unwrapped;
@@ -1952,9 +1963,16 @@ __device__ __forceinline__ PlainLocated locate_plain_from_angles(const BlGridDev
   const bool sampled = live && !cut && !off_grid;
   PlainLocated out;
   // (fractions of cell widths: ordinary operands for the short division)
-  const double f_i = blm_div(s1 - xv_i, tab.xv[0][i_m + 1] - xv_i);
-  const double f_j = blm_div(s2 - xv_j, tab.xv[1][j_m + 1] - xv_j);
-  const double f_k = blm_div(s3 - xv_k, tab.xv[2][k_m + 1] - xv_k);
+  double f_i, f_j, f_k;
+  if (pg.inv_w[0] != nullptr) {   // tolerant tier: one multiplication by the width's reciprocal (2e-16 of the fraction)
+    f_i = (s1 - xv_i) * pg.inv_w[0][i_m];
+    f_j = (s2 - xv_j) * pg.inv_w[1][j_m];
+    f_k = (s3 - xv_k) * pg.inv_w[2][k_m];
+  } else {
+    f_i = blm_div(s1 - xv_i, tab.xv[0][i_m + 1] - xv_i);
+    f_j = blm_div(s2 - xv_j, tab.xv[1][j_m + 1] - xv_j);
+    f_k = blm_div(s3 - xv_k, tab.xv[2][k_m + 1] - xv_k);
+  }
   out.f_i = sampled ? f_i : 0.0;
   out.f_j = sampled ? f_j : 0.0;
   out.f_k = sampled ? f_k : 0.0;
@@ -2879,6 +2897,8 @@ __global__ void __launch_bounds__(256, BL_FAST_WAVES) bl_shade_fused_kernel(cons
   }
   PlainGrid pg;
   stage_grid_tables(P.grid, fast_table + table_doubles, &pg);
+  __syncthreads();
+  stage_reciprocal_widths(P.grid, fast_table + table_doubles + P.lds_table_bytes / sizeof(double), &pg);
   __syncthreads();
   if (n_records == 0ull) return;
   const unsigned long long last = n_records - 1ull;
@@ -3823,7 +3843,8 @@ extern "C" hipError_t bl_launch_shade_formula_fast(const BlShadeArgs *args, int 
 
 extern "C" hipError_t bl_launch_shade_fast(const BlShadeArgs *args, int grid, hipStream_t stream) {
   if (args->located == nullptr) {   // no locate kernel ran: the fused kernel (coordinate tables in LDS behind its own table)
-    const size_t lds = (44 + 5 * args->n_nu) * sizeof(double) + args->lds_table_bytes;
+    const size_t lds = (44 + 5 * args->n_nu) * sizeof(double) + args->lds_table_bytes
+        + (size_t)(args->grid.n[0] + args->grid.n[1] + args->grid.n[2]) * sizeof(double);   // (+ the reciprocal widths)
     if (args->st.bh_a == 0.0) {
       hipLaunchKernelGGL((bl_shade_fused_kernel<true>), dim3(grid), dim3(256), lds, stream, *args);
       hipLaunchKernelGGL((bl_shade_kernel<BL_MODEL_SIMULATION, false, false, true, false, true, true>), dim3(grid), dim3(256), 0, stream, *args);
