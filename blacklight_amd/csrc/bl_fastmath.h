@@ -35,6 +35,8 @@ __device__ __forceinline__ double rsqrt(double x) {
   e = __builtin_fma(-h * y, y, 0.5);
   return __builtin_fma(y, e, y);
 }
+// sqrt(x) for finite x >= 0 (a few units in the last place; 0 for 0)
+__device__ __forceinline__ double sqrt(double x) { return x > 0.0 ? x * rsqrt(x) : 0.0; }
 // exp(x) and expm1(x) share one core: x = k ln 2 + r, |r| <= ln 2 / 2, and e = expm1(r) = r + r^2 / 2 + r^3 q(r) with the
 // polynomial of bl_expm1 (blmath.h); hardware rounding and ldexp. One set of coefficients for both keeps two dozen
 // scalar registers free (a v_fma_f64 cannot take a 64-bit literal: every coefficient is a register pair).

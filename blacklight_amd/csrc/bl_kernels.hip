@@ -2496,8 +2496,9 @@ __device__ __forceinline__ bool fast_shade_sample(const BlShadeArgs &P, const do
       const double ta = kk - f * lk * lk;                  // g^ij k_i k_j
       const double tb = 2.0 * kt * f * lk;                 // 2 g^0i k_0 k_i
       const double tc = -(1.0 + f) * kt * kt;              // g^00 k_0 k_0
-      const double td = bl_sqrt_g(tb * tb - 4.0 * ta * tc);
-      double factor = tb < 0.0 ? (td - tb) * fastmath::rcp(2.0 * ta) : -2.0 * tc * fastmath::rcp(tb + td);
+      const double td = fastmath::sqrt(tb * tb - 4.0 * ta * tc);
+      // (the root that avoids cancellation, one reciprocal for either)
+      double factor = (tb < 0.0 ? td - tb : -2.0 * tc) * fastmath::rcp(tb < 0.0 ? 2.0 * ta : tb + td);
       if (P.samples_renormalised) factor = 1.0;   // geodesic checkpoint: done before the samples were saved
       kx *= factor;
       ky *= factor;
@@ -2638,8 +2639,10 @@ __device__ __forceinline__ bool fast_shade_sample(const BlShadeArgs &P, const do
   const double theta_e_inv = kb_tt_e_inv * (kMe * kC * kC);
   const double s_nu = nu_ratio * momentum_factor;
   const double s_x = have ? s_nu * b_sin_inv * (theta_e_inv * theta_e_inv) * (4.5 / nu_c_over_b) : 0.0;
-  const double s_1_2 = bl_sqrt_g(s_x), s_1_3 = fastmath::cbrt(s_x);
-  const double s_1_6 = bl_sqrt_g(s_1_3);
+  // x^(1/3) by the cube root, x^(1/6) as its square root, x^(1/2) as the cube of that
+  const double s_1_3 = fastmath::cbrt(s_x);
+  const double s_1_6 = fastmath::sqrt(s_1_3);
+  const double s_1_2 = s_1_6 * s_1_3;
   const double s_planck = have ? kH * s_nu * kb_tt_e_inv : 0.0;                                   // h nu / (k T_e) = s_planck f_l
   const double s_nu_inv = have ? -k_u_inv * momentum_factor_inv : 0.0;
   const double s_j = thermal_frac * n_e_cgs * kE * kE * (nu_c_over_b * b_sin) * (1.0 / kC) * (kSqrt2 * kPi / 27.0) * s_nu_inv * s_nu_inv;
@@ -2779,6 +2782,59 @@ __device__ __forceinline__ void gather_finish(const BlShadeArgs &P, float fallba
   } else {
     for (int q = 0; q < 8; q++) pr[q] = 0.0f;
   }
+}
+
+// The tolerant tier's form of gather_finish(): the same weights, the eight products summed with fused multiply-adds (56 additions
+// fewer per sample). The sums differ from the reference's by a few units in the last place of a double, which the conversion to
+// float hides - unless a sum lies that close to the midpoint of two floats, where the two could round apart and move a primitive by
+// 6e-8: then the function returns true and the sample is left to the exact kernel. The midpoint is where the 29 bits below a
+// float's precision read 2^28; the window around it is 64 units for the positive sums of density and pressure, 4 096 for the
+// components of velocity and field, whose terms may cancel (a sum that is a 500th of its terms or less is a component that small
+// beside the others: a unit of its float precision is 1e-10 of the vector).
+__device__ __forceinline__ bool gather_finish_tolerant(const BlShadeArgs &P, float fallback_rho, float fallback_pgas, int status, const float4 (&lo)[8],
+                                                       const float4 (&hi)[8], double f_i, double f_j, double f_k, float pr[8]) {
+  const BlPlasmaDevice &pl = P.plasma;
+  bool near_midpoint = false;
+  if (status == kSampleInterp) {
+    const double w_k[2] = {1.0 - f_k, f_k}, w_j[2] = {1.0 - f_j, f_j}, w_i[2] = {1.0 - f_i, f_i};
+    double val[8];
+    float first[8];
+#pragma unroll
+    for (int corner = 0; corner < 8; corner++) {
+      float v[8];
+      unpack_cell(lo[corner], hi[corner], v);
+      const double w = w_k[corner >> 2] * w_j[(corner >> 1) & 1] * w_i[corner & 1];
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        if (corner == 0) {
+          val[q] = w * (double)v[q];
+          first[q] = v[q];
+        } else {
+          val[q] = __builtin_fma(w, (double)v[q], val[q]);
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const uint32_t below = (uint32_t)__double_as_longlong(val[q]) & 0x1fffffffu;
+      const uint32_t window = q < 2 ? 64u : 4096u;
+      near_midpoint = near_midpoint || (below - (0x10000000u - window)) <= 2u * window;
+    }
+    if (val[0] <= 0.0) val[0] = (double)first[0];   // :822-825
+    if (val[1] <= 0.0) val[1] = (double)first[1];
+#pragma unroll
+    for (int q = 0; q < 8; q++) pr[q] = (float)val[q];   // :830-839
+  } else if (status == kSampleNearest) {
+    unpack_cell(lo[0], hi[0], pr);
+  } else if (status == kSampleOffGrid) {
+    const float fnan = __int_as_float(0x7fc00000);
+    pr[0] = pl.fallback_nan ? fnan : fallback_rho;    // :377-384, :678-706
+    pr[1] = pl.fallback_nan ? fnan : fallback_pgas;
+    for (int q = 2; q < 8; q++) pr[q] = pl.fallback_nan ? fnan : 0.0f;
+  } else {
+    for (int q = 0; q < 8; q++) pr[q] = 0.0f;
+  }
+  return near_midpoint;
 }
 
 // Tolerant tier's coefficient kernel, one sample per lane, software-pipelined over the samples of a lane: the corner
@@ -2946,7 +3002,8 @@ __global__ void __launch_bounds__(256, BL_FAST_WAVES) bl_shade_fused_kernel(cons
     const double kt = P.ray_kt[live ? ray : 0u], momentum_factor = P.ray_factor[live ? ray : 0u];
     const size_t row = (size_t)P.ray_offset[live ? ray : 0u] + n;
     float pr[8];
-    gather_finish(P, (float)fast_table[42], (float)fast_table[43], status, lo, hi, loc_prev.f_i, loc_prev.f_j, loc_prev.f_k, pr);
+    const bool near_midpoint = gather_finish_tolerant(P, (float)fast_table[42], (float)fast_table[43], status, lo, hi, loc_prev.f_i, loc_prev.f_j,
+                                                      loc_prev.f_k, pr);
     gathers_local += (live && status == kSampleInterp) ? 1ull : 0ull;
     gather_issue(P, (int)(loc_cur.status & 0xffu), loc_cur.cell, lo, hi);
     double2 cold_cur0, cold_cur1;
@@ -2959,7 +3016,7 @@ __global__ void __launch_bounds__(256, BL_FAST_WAVES) bl_shade_fused_kernel(cons
     load_position(have_after, idx, hot_after0, hot_after1);
     if (live) {
       // ReverseGeodesics: sample_len = -geodesic_len (geodesics.cpp:840)
-      if (undecided || !fast_shade_sample<kSpinZero>(P, fast_table, pr, status, row, rec_prev.q0.x, rec_prev.q0.y, rec_prev.q1.x, rec_prev.q2.x,
+      if (undecided || near_midpoint || !fast_shade_sample<kSpinZero>(P, fast_table, pr, status, row, rec_prev.q0.x, rec_prev.q0.y, rec_prev.q1.x, rec_prev.q2.x,
                                                      rec_prev.q2.y, rec_prev.q3.x, kt, momentum_factor, -rec_prev.q3.y)) {
         fast_defer(P, idx_prev);
       }
