@@ -511,6 +511,14 @@ void UploadMergedGrid(bl_ctx *ctx, const bl_grid_desc *g) {
       int n_bucket = std::max(512, 8 * n[a]);
       std::vector<int> table;
       BuildBuckets(xf[a], n[a], n_bucket, &table, &dev.bucket_x0[a], &dev.bucket_inv_w[a]);
+      {   // evenly spaced faces?
+        const double width = (xf[a][n[a]] - xf[a][0]) / n[a];
+        bool even = width > 0.0;
+        for (int c = 0; c <= n[a] && even; c++) even = std::abs(xf[a][c] - (xf[a][0] + c * width)) <= 1.0e-4 * width;
+        dev.cell_x0[a] = xf[a][0];
+        dev.cell_inv_w[a] = even ? 1.0 / width : 0.0;
+        if (even) dev.uniform_mask |= 1 << a;
+      }
       dev.n_bucket[a] = n_bucket;
       off_b[a] = buckets.size();
       buckets.insert(buckets.end(), table.begin(), table.end());

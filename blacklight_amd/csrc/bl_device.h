@@ -82,6 +82,10 @@ struct BlGridDevice {
   const unsigned short *bucket[3];   // bucket -> first candidate cell
   double bucket_x0[3], bucket_inv_w[3];
   int n_bucket[3];
+  // axes whose faces are evenly spaced to 1e-4 of a cell (bit a of uniform_mask): cell = floor((x - cell_x0) * cell_inv_w), which the
+  // tolerant locate step takes as its guess and checks against the faces (locate_plain_from_angles)
+  int uniform_mask;
+  double cell_x0[3], cell_inv_w[3];
   int n[3];                  // n_i, n_j, n_k of the (merged) global grid
   int nb[3];                 // cells per block along each axis (= n for a single block)
   int stride_row, stride_plane;   // cells between j- and k-neighbours in `cells` / `kappa`

@@ -1942,8 +1942,10 @@ struct PlainLocated {
 constexpr uint32_t kPlainUndecided = 0x100u;
 // From (r, theta, unwrapped phi) to status, cell and fractions. margin (if asked for): how far theta and phi are from the nearest
 // value they are compared with on the way - the faces and the centre of their cells, the ends of the azimuth's range.
+// guess_mask (tolerant tier): axes whose cell is guessed as floor((x - x0) / width) instead of searched (evenly spaced faces); a guess
+// the faces do not confirm comes back as margin = 0.
 __device__ __forceinline__ PlainLocated locate_plain_from_angles(const BlGridDevice &g, const PlainGrid &pg, bool live, bool cut, double r, double th,
-                                                                 double ph_unwrapped, double *margin) {
+                                                                 double ph_unwrapped, double *margin, int guess_mask = 0) {
   const GridTables &tab = pg.tab;
   double ph = ph_unwrapped;
   ph += ph < 0.0 ? 2.0 * kPi : 0.0;
@@ -1952,7 +1954,20 @@ __device__ __forceinline__ PlainLocated locate_plain_from_angles(const BlGridDev
   const double s1 = r, s2 = th, s3 = ph;
   const bool off_grid = s1 < tab.xf[0][0] || s1 > tab.xf[0][pg.n_i] || s2 < tab.xf[1][0] || s2 > tab.xf[1][pg.n_j]
       || s3 < tab.xf[2][0] || s3 > tab.xf[2][pg.n_k];             // :352-394
-  const int i = find_cell(g, tab, 0, s1), j = find_cell(g, tab, 1, s2), k = find_cell(g, tab, 2, s3);
+  const int i = find_cell(g, tab, 0, s1);
+  int j, k;
+  if (guess_mask & 2) {
+    j = (int)((s2 - g.cell_x0[1]) * g.cell_inv_w[1]);
+    j = j < 0 ? 0 : (j > pg.n_j - 1 ? pg.n_j - 1 : j);
+  } else {
+    j = find_cell(g, tab, 1, s2);
+  }
+  if (guess_mask & 4) {
+    k = (int)((s3 - g.cell_x0[2]) * g.cell_inv_w[2]);
+    k = k < 0 ? 0 : (k > pg.n_k - 1 ? pg.n_k - 1 : k);
+  } else {
+    k = find_cell(g, tab, 2, s3);
+  }
   // :485-490, per block of a merged grid (one block - the usual case - needs no remainders)
   const int i_b = pg.one_block ? i : i % pg.nb_i, j_b = pg.one_block ? j : j % pg.nb_j, k_b = pg.one_block ? k : k % pg.nb_k;
   const double xv_at_j = tab.xv[1][j], xv_at_k = tab.xv[2][k];
@@ -1980,11 +1995,16 @@ __device__ __forceinline__ PlainLocated locate_plain_from_angles(const BlGridDev
   out.status = !live ? (uint32_t)kSampleNone : (cut ? (uint32_t)kSampleCut : (off_grid ? (uint32_t)kSampleOffGrid : (uint32_t)kSampleInterp));
   out.cell = sampled ? (uint32_t)((k_m * pg.n_j + j_m) * pg.n_i + i_m) : 0u;
   if (margin != nullptr) {
-    double m = std_min(blm_abs(s2 - tab.xf[1][j]), blm_abs(s2 - tab.xf[1][j + 1]));
+    const double fj0 = tab.xf[1][j], fj1 = tab.xf[1][j + 1], fk0 = tab.xf[2][k], fk1 = tab.xf[2][k + 1];
+    double m = std_min(blm_abs(s2 - fj0), blm_abs(s2 - fj1));
     m = std_min(m, blm_abs(s2 - xv_at_j));
-    m = std_min(m, std_min(blm_abs(s3 - tab.xf[2][k]), blm_abs(s3 - tab.xf[2][k + 1])));
+    m = std_min(m, std_min(blm_abs(s3 - fk0), blm_abs(s3 - fk1)));
     m = std_min(m, blm_abs(s3 - xv_at_k));
     m = std_min(m, std_min(blm_abs(ph_unwrapped), blm_abs(ph_once - 2.0 * kPi)));
+    // a guessed cell has to hold the coordinate (the search's "first upper face >= x" then names the same cell: the margin above
+    // keeps x off the faces); off the grid the guess is the clamped end cell, as the search's
+    if ((guess_mask & 2) && !off_grid && !(s2 >= fj0 && s2 <= fj1)) m = 0.0;
+    if ((guess_mask & 4) && !off_grid && !(s3 >= fk0 && s3 <= fk1)) m = 0.0;
     *margin = m;
   }
   return out;
@@ -2406,7 +2426,7 @@ __device__ __forceinline__ PlainLocated locate_plain_sample_tolerant(const BlSpa
   const double th = fastmath::acos(blm_div(x3, r));
   const double ph_unwrapped = kSpinZero ? fastmath::atan2(x2, x1) : fastmath::atan2(x2, x1) - fastmath::atan2(st.bh_a, r);
   double margin;
-  PlainLocated out = locate_plain_from_angles(g, pg, live, cut, r, th, ph_unwrapped, &margin);
+  PlainLocated out = locate_plain_from_angles(g, pg, live, cut, r, th, ph_unwrapped, &margin, pg.one_block ? (g.uniform_mask & 6) : 0);
   if (live && !cut && !(margin > band)) out.status |= kPlainUndecided;
   return out;
 }
