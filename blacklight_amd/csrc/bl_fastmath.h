@@ -168,6 +168,32 @@ __device__ __forceinline__ double acos(double x) {
   const double res_neg = __builtin_fma(-2.0, asin_s, 2.0 * pio2) + 2.0 * pio2_lo;
   return small ? res_small : (x < 0.0 ? res_neg : 2.0 * asin_s);
 }
+// ... with the polynomial's coefficients handed in: a kernel that keeps them in registers across its sample loop (kAcosCoefficients
+// through opaque_register(), bl_shade_fused_kernel) saves the two moves per coefficient that a literal costs at every use
+constexpr double kAcosCoefficients[14] = {0x1.e58a4f278e007p-6, -0x1.3bd7e353ddbc2p-6, 0x1.40c91fa8deb7ep-6, 0x1.8dcdf11997e0fp-9,
+                                          0x1.31777489dfd29p-7, 0x1.3b462d121c5d2p-7, 0x1.7b02ef007d23ep-7, 0x1.c990a42b32b03p-7,
+                                          0x1.1c4efd20ebb99p-6, 0x1.6e8ba121b9d5fp-6, 0x1.f1c71c7a5e151p-6, 0x1.6db6db6dac0eap-5,
+                                          0x1.3333333333389p-4, 0x1.5555555555555p-3};
+__device__ __forceinline__ double opaque_register(double v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+template <int N>
+__device__ __forceinline__ double acos(double x, const double (&c)[N]) {
+  const double ax = __builtin_fabs(x);
+  const bool small = ax < 0.5;
+  const double z = small ? x * x : (1.0 - ax) * 0.5;
+  double r = c[0];
+#pragma unroll
+  for (int i = 1; i < 14; i++) r = __builtin_fma(r, z, c[i]);
+  r *= z;
+  const double s = small ? x : (z > 0.0 ? z * rsqrt(z) : 0.0);
+  const double asin_s = __builtin_fma(s, r, s);
+  const double pio2 = 0x1.921fb54442d18p+0, pio2_lo = 0x1.1a62633145c07p-54;
+  const double res_small = (pio2 - asin_s) + pio2_lo;
+  const double res_neg = __builtin_fma(-2.0, asin_s, 2.0 * pio2) + 2.0 * pio2_lo;
+  return small ? res_small : (x < 0.0 ? res_neg : 2.0 * asin_s);
+}
 __device__ __forceinline__ double atan2(double y, double x) {
   const double ax = __builtin_fabs(x), ay = __builtin_fabs(y);
   const double mx = ax > ay ? ax : ay, mn = ax > ay ? ay : ax;

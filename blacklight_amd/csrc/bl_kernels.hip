@@ -2416,14 +2416,15 @@ __global__ void __launch_bounds__(256, 2) bl_shade_kernel(const BlShadeArgs P) {
 // else (and the fractions within 1e-13 of a cell width).
 template <bool kSpinZero>
 __device__ __forceinline__ PlainLocated locate_plain_sample_tolerant(const BlSpacetime &st, const BlGridDevice &g, const PlainGrid &pg, double camera_r,
-                                                                     double band, bool live, double x1, double x2, double x3) {
+                                                                     double band, const double (&acos_c)[14], bool live, double x1, double x2,
+                                                                     double x3) {
   x1 = live ? x1 : 1.0;
   x2 = live ? x2 : 1.0;
   x3 = live ? x3 : 1.0;
   double r2;
   const double r = bl_radial_coordinate2<kSpinZero>(st, x1, x2, x3, &r2);
   const bool cut = r > camera_r;
-  const double th = fastmath::acos(blm_div(x3, r));
+  const double th = fastmath::acos(blm_div(x3, r), acos_c);
   const double ph_unwrapped = kSpinZero ? fastmath::atan2(x2, x1) : fastmath::atan2(x2, x1) - fastmath::atan2(st.bh_a, r);
   double margin;
   PlainLocated out = locate_plain_from_angles(g, pg, live, cut, r, th, ph_unwrapped, &margin, pg.one_block ? (g.uniform_mask & 6) : 0);
@@ -2980,6 +2981,9 @@ __global__ void __launch_bounds__(256, BL_FAST_WAVES) bl_shade_fused_kernel(cons
   const unsigned long long last = n_records - 1ull;
   const double camera_r = P.cuts.camera_r;
   const double angle_band = P.fast_angle_band;
+  double acos_c[14];   // (in registers for the whole loop: bl_fastmath.h)
+#pragma unroll
+  for (int t = 0; t < 14; t++) acos_c[t] = fastmath::opaque_register(fastmath::kAcosCoefficients[t]);
   unsigned long long gathers_local = 0ull;
   auto load_position = [&](bool have, unsigned long long at, double2 &q0, double2 &q1) {
     const double2 *hot = reinterpret_cast<const double2 *>(P.records_hot + (have ? at : last) * P.record_stride);
@@ -3010,7 +3014,7 @@ __global__ void __launch_bounds__(256, BL_FAST_WAVES) bl_shade_fused_kernel(cons
   bool have_after = have_next && idx < n_records;
   {
     const bool live = have_cur && (uint32_t)__double_as_longlong(hot_cur1.y) != BL_DEAD_RAY;
-    loc_cur = locate_plain_sample_tolerant<kSpinZero>(st, P.grid, pg, camera_r, angle_band, live, hot_cur0.x, hot_cur0.y, hot_cur1.x);
+    loc_cur = locate_plain_sample_tolerant<kSpinZero>(st, P.grid, pg, camera_r, angle_band, acos_c, live, hot_cur0.x, hot_cur0.y, hot_cur1.x);
   }
   while (have_prev || have_cur) {
     const uint32_t ray = have_prev ? (uint32_t)__double_as_longlong(rec_prev.q1.y) : BL_DEAD_RAY;
@@ -3043,7 +3047,7 @@ __global__ void __launch_bounds__(256, BL_FAST_WAVES) bl_shade_fused_kernel(cons
     }
     // the search for `next`
     const bool live_next = have_next && (uint32_t)__double_as_longlong(hot_next1.y) != BL_DEAD_RAY;
-    const PlainLocated loc_next = locate_plain_sample_tolerant<kSpinZero>(st, P.grid, pg, camera_r, angle_band, live_next, hot_next0.x, hot_next0.y, hot_next1.x);
+    const PlainLocated loc_next = locate_plain_sample_tolerant<kSpinZero>(st, P.grid, pg, camera_r, angle_band, acos_c, live_next, hot_next0.x, hot_next0.y, hot_next1.x);
     rec_prev.q0 = hot_cur0;
     rec_prev.q1 = hot_cur1;
     rec_prev.q2 = cold_cur0;
