@@ -2612,12 +2612,21 @@ __device__ __forceinline__ bool fast_shade_sample(const BlShadeArgs &P, const do
     if (pl.cut_mask != 0) {
       const double bb_cgs = (pl.cut_mask & 0x300) ? bl_sqrt_g(b_sq) * pl.b_unit : 0.0;   // only the field-strength cuts need |b| itself
       const double value[7] = {rho_cgs, n_e_cgs, pgas_cgs, theta_e, bb_cgs, sigma_cut, beta_inv};
+      // (one scalar test per quantity, then per bound; the three table values of a bound are read together and combined without
+      // short-circuit branches)
 #pragma unroll
-      for (int c = 0; c < 14; c++)
-        if ((pl.cut_mask >> c) & 1) {
-          const double q = value[c >> 1];
-          cell_cut = cell_cut || ((c & 1) ? q > table[c] : q < table[c]);
-          undecided = undecided || (q >= table[14 + c] && q <= table[28 + c]);
+      for (int v = 0; v < 7; v++)
+        if ((pl.cut_mask >> (2 * v)) & 3) {
+          const double q = value[v];
+#pragma unroll
+          for (int upper = 0; upper < 2; upper++) {
+            const int c = 2 * v + upper;
+            if ((pl.cut_mask >> c) & 1) {
+              const double threshold = table[c], band_lo = table[14 + c], band_hi = table[28 + c];
+              cell_cut = cell_cut | (upper ? q > threshold : q < threshold);
+              undecided = undecided | ((q >= band_lo) & (q <= band_hi));
+            }
+          }
         }
     }
     if (undecided) return false;   // bl_shade_kernel<..., kRedo> writes this sample's records
