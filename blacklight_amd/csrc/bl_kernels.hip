@@ -2990,9 +2990,9 @@ __global__ void __launch_bounds__(256, BL_FAST_WAVES) bl_shade_fused_kernel(cons
   const unsigned long long last = n_records - 1ull;
   const double camera_r = P.cuts.camera_r;
   const double angle_band = P.fast_angle_band;
-  double acos_c[14];   // (in registers for the whole loop: bl_fastmath.h)
+  double acos_c[14];   // in registers for the whole loop (bl_fastmath.h) where there is room: the spinning instantiation keeps literals
 #pragma unroll
-  for (int t = 0; t < 14; t++) acos_c[t] = fastmath::opaque_register(fastmath::kAcosCoefficients[t]);
+  for (int t = 0; t < 14; t++) acos_c[t] = kSpinZero ? fastmath::opaque_register(fastmath::kAcosCoefficients[t]) : fastmath::kAcosCoefficients[t];
   unsigned long long gathers_local = 0ull;
   auto load_position = [&](bool have, unsigned long long at, double2 &q0, double2 &q1) {
     const double2 *hot = reinterpret_cast<const double2 *>(P.records_hot + (have ? at : last) * P.record_stride);
