@@ -221,6 +221,51 @@ def test_tolerant_tier_with_an_optical_depth_image(seed, built_library):
         assert ctx.render()["stats"].arithmetic == 0
 
 
+@pytest.mark.parametrize("warp", ["theta", "phi", "both"])
+def test_tolerant_locate_on_unevenly_spaced_axes(warp, built_library):
+    """The fused kernel guesses the cell along evenly spaced axes and searches the others (BlGridDevice::uniform_mask). The mock's
+    polar and azimuthal faces are even; here they are warped smoothly (cell data unchanged - a test of the search, not a disc), so
+    that the tolerant locate step takes its search path: counts, NaN mask and S_in equal to the exact tier's and the oracle's,
+    image at rounding level."""
+    import dataclasses
+    import blacklight_amd as bl
+    from blacklight_amd import _capi
+    import oracle_api
+    fx, params, mock_args = gu.load_case("sim_dp_interp")
+    params = dict(params, camera_resolution=32, simulation_a=0.5, camera_th=70.0, fallback_nan="false", fallback_rho=1.0e-6, fallback_pgas=1.0e-8)
+    grid = gu.golden_grid(mock_args)
+
+    def warped(faces, amplitude):
+        lo, hi = faces[0, 0], faces[0, -1]
+        u = (faces - lo) / (hi - lo)
+        out = lo + (hi - lo) * (u + amplitude * np.sin(2.0 * np.pi * u) / (2.0 * np.pi))
+        out = out.astype(np.float32).astype(np.float64)
+        out[0, 0], out[0, -1] = lo, hi
+        return np.ascontiguousarray(out)
+
+    changes = {}
+    if warp in ("theta", "both"):
+        x2f = warped(grid.x2f, 0.6)
+        changes.update(x2f=x2f, x2v=np.ascontiguousarray((0.5 * (x2f[:, :-1] + x2f[:, 1:])).astype(np.float32).astype(np.float64)))
+    if warp in ("phi", "both"):
+        x3f = warped(grid.x3f, -0.5)
+        changes.update(x3f=x3f, x3v=np.ascontiguousarray((0.5 * (x3f[:, :-1] + x3f[:, 1:])).astype(np.float32).astype(np.float64)))
+    grid = dataclasses.replace(grid, **changes)
+    p = bl.Params.from_dict(params)
+    with bl.Context(p) as ctx:
+        ctx.set_grid(grid)
+        exact = ctx.render()
+        ctx.set_arithmetic("tolerant")
+        tol = ctx.render()
+    want = oracle_api.render(p.ptr, grid.desc(), _capi.RenderDesc, _capi.CameraFrame, n_rays=32 * 32, max_steps=int(p.get("ray_max_steps")))
+    assert gu.same_bits(exact["image"], want["image"]).all() and exact["stats"].n_gathers == want["n_gathers"]
+    assert tol["stats"].arithmetic == 1 and tol["stats"].n_gathers == exact["stats"].n_gathers
+    assert np.array_equal(tol["sample_num"], exact["sample_num"]) and np.array_equal(np.isnan(tol["image"]), np.isnan(exact["image"]))
+    d = _distance(tol["image"], exact["image"])
+    print(f"{warp}: {d:.2e}, deferred {tol['stats'].n_deferred}")
+    assert d < EXPECTED
+
+
 @pytest.mark.parametrize("band,resolution,frequencies,variant", [(1.0e30, 24, 1, ""), (1.0e30, 56, 1, ""), (1.0e30, 24, 5, ""), (1.0e30, 56, 5, ""),
                                                                  (1.0e30, 24, 1, "power"), (1.0e30, 24, 3, "cks"), (1.0e30, 24, 3, "cks power")])
 def test_deferred_cut_decisions(band, resolution, frequencies, variant, built_library):
