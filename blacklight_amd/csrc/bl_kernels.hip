@@ -2925,7 +2925,8 @@ __global__ void __launch_bounds__(256, BL_FAST_WAVES) bl_shade_fast_kernel(const
     const double kt = P.ray_kt[live ? ray : 0u], momentum_factor = P.ray_factor[live ? ray : 0u];
     const size_t row = (size_t)P.ray_offset[live ? ray : 0u] + n;
     float pr[8];
-    gather_finish(P, (float)fast_table[42], (float)fast_table[43], live ? status : (int)kSampleNone, lo, hi, loc_prev.l0.x, loc_prev.l0.y, loc_prev.l1.x, pr);
+    const bool near_midpoint = gather_finish_tolerant(P, (float)fast_table[42], (float)fast_table[43], live ? status : (int)kSampleNone, lo, hi,
+                                                      loc_prev.l0.x, loc_prev.l0.y, loc_prev.l1.x, pr);
     gather_issue(P, have_cur ? (int)(loc_cur.tag >> 32) & 0xff : (int)kSampleNone, (uint32_t)loc_cur.tag, lo, hi);
     fast_load_ray(P, have_cur ? idx_cur : last, ray_cur);
     const FastRay rec = ray_prev;
@@ -2942,8 +2943,8 @@ __global__ void __launch_bounds__(256, BL_FAST_WAVES) bl_shade_fast_kernel(const
     fast_load_located(P, have_next ? idx : last, loc_next);
     if (live) {
       // ReverseGeodesics: sample_len = -geodesic_len (geodesics.cpp:840)
-      if (!fast_shade_sample<kSpinZero, kGeneral>(P, fast_table, pr, status, row, rec.q0.x, rec.q0.y, rec.q1.x, rec.q2.x, rec.q2.y, rec.q3.x,
-                                                   kt, momentum_factor, -rec.q3.y)) {
+      if (near_midpoint || !fast_shade_sample<kSpinZero, kGeneral>(P, fast_table, pr, status, row, rec.q0.x, rec.q0.y, rec.q1.x, rec.q2.x, rec.q2.y,
+                                                                    rec.q3.x, kt, momentum_factor, -rec.q3.y)) {
         fast_defer(P, idx_rec);
       }
     }

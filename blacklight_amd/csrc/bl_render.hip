@@ -290,7 +290,7 @@ void PlanScratch(RenderJob &job) {
       + (job.matrix_transport ? BL_POL_MATRIX_DOUBLES * sizeof(double) : 0)
       + (job.block_interp ? 8 * sizeof(unsigned int) : 0);
   const uint64_t per_slot_fixed = ((job.fast || job.fast_formula || ctx->polarized) ? job.redo_capacity * sizeof(unsigned long long) : 0) + BL_CNT_TOTAL * sizeof(unsigned long long);
-  const uint64_t per_ray = (2 + (job.geo_load ? 0 : BL_RAY_START_FIELDS)) * sizeof(double) + sizeof(int) + 1 + 2 * sizeof(long long);
+  const uint64_t per_ray = (2 + (job.geo_load ? 0 : BL_RAY_START_FIELDS)) * sizeof(double) + (job.skip_shell ? 2 : 1) * sizeof(int) + 1 + 2 * sizeof(long long);
   // The budget is capped by what the device can actually give: 90 % of (free memory + what this context already holds
   // from earlier renders).
   uint64_t budget = ctx->scratch_limit;
