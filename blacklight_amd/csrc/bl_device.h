@@ -357,6 +357,10 @@ struct BlShadeArgs {
   double power_pol[7];        // simulation_coefficients.cpp:67-80: jj_q, jj_v, aa_q, aa_v, rho, rho_q, rho_v
   double plasma_gamma_min;
   // tolerant arithmetic tier (bl_shade_fast_kernel) only
+  // fast_shade_sample's constants, folded on the host (BuildShadeArgs): [0] k T_e = [0] p / rho x D / ([1] + [2] / beta^2 + [3] D) in code
+  // units of p and rho; [4] x = nu / nu_s at unit frequency = s_nu / (|b| sin) / (k T_e)^2 x [4]; [5] j at unit frequency =
+  // [5] rho |b| sin / s_nu^2; [6] n_e = [6] rho; [7] nu_c / |b|
+  double fast_k[8];
   double fast_n_e_factor;     // 1 / (mu m_p (1 + 1 / ne_ni))
   double fast_d_unit_inv;     // 1 / d_unit
   double fast_angle_band;     // tolerant locate step: theta / phi closer than this to a decision are the exact kernel's (1e-12; wider under bl_debug_set_guard_band)

@@ -2580,10 +2580,9 @@ __device__ __forceinline__ bool fast_shade_sample(const BlShadeArgs &P, const do
       k_u = kt * ut + k_r * ur + k_th * uu2 + k_ph * uu3;
       k_b = kt * bt + k_r * br + k_th * bth + k_ph * bph;
     }
-    // ---- plasma state (:274-358)
-    const double rho_cgs = rho * pl.d_unit;
-    const double pgas_cgs = pgas * pl.e_unit;
-    n_e_cgs = rho_cgs * P.fast_n_e_factor;                         // / (mu m_p) / (1 + 1 / ne_ni)
+    // ---- plasma state (:274-358). Everything that is a product of units and parameters is one constant from the host
+    // (BlShadeArgs::fast_k), and the cut thresholds come scaled to code units (BuildShadeArgs): no cgs value of rho, p, n_e or
+    // Theta_e is formed per sample.
     // 1 / rho and 1 / p from one reciprocal where both are positive (single-precision values: the product is an ordinary double)
     double rho_inv, pgas_inv;
     {
@@ -2597,21 +2596,16 @@ __device__ __forceinline__ bool fast_shade_sample(const BlShadeArgs &P, const do
     const double beta_inv = 0.5 * b_sq * pgas_inv;
     {
       // T_i / T_e = N / D, N = rat_high + rat_low / beta^2, D = 1 + 1 / beta^2: k T_e = (1 + c) k T_tot D / (N + c D), one reciprocal
+      // (with plasma_use_p = false the three 1 / (gamma - 1) ride in the constants)
       const double bi2 = beta_inv * beta_inv;
-      const double nn = pl.plasma_rat_high + pl.plasma_rat_low * bi2, dd = 1.0 + bi2;
-      const double kb_tt_tot_cgs = (pl.plasma_mu * kMp) * pgas_cgs * (rho_inv * P.fast_d_unit_inv);
-      if (pl.plasma_use_p)
-        kb_tt_e_cgs = (1.0 + pl.plasma_ne_ni) * kb_tt_tot_cgs * (dd * fastmath::rcp(nn + pl.plasma_ne_ni * dd));
-      else
-        kb_tt_e_cgs = (1.0 + pl.plasma_ne_ni) * kb_tt_tot_cgs * P.fast_gamma[0]
-            * (dd * fastmath::rcp(nn * P.fast_gamma[1] + pl.plasma_ne_ni * P.fast_gamma[2] * dd));
-      theta_e = kb_tt_e_cgs * (1.0 / (kMe * kC * kC));
+      const double dd = 1.0 + bi2;
+      kb_tt_e_cgs = P.fast_k[0] * (pgas * rho_inv) * (dd * fastmath::rcp(P.fast_k[1] + P.fast_k[2] * bi2 + P.fast_k[3] * dd));
     }
     // ---- cell cuts (:361-375): decided here unless a value sits within the guard band of an active threshold
     bool cell_cut = false, undecided = !cartesian && pp2 == 0.0;   // (on the polar axis of the spherical coordinates: the exact kernel's business)
     if (pl.cut_mask != 0) {
-      const double bb_cgs = (pl.cut_mask & 0x300) ? bl_sqrt_g(b_sq) * pl.b_unit : 0.0;   // only the field-strength cuts need |b| itself
-      const double value[7] = {rho_cgs, n_e_cgs, pgas_cgs, theta_e, bb_cgs, sigma_cut, beta_inv};
+      const double bb = (pl.cut_mask & 0x300) ? fastmath::sqrt(b_sq) : 0.0;   // only the field-strength cuts need |b| itself
+      const double value[7] = {rho, rho, pgas, kb_tt_e_cgs, bb, sigma_cut, beta_inv};   // against thresholds in these units
       // (one scalar test per quantity, then per bound; the three table values of a bound are read together and combined without
       // short-circuit branches)
 #pragma unroll
@@ -2662,20 +2656,20 @@ __device__ __forceinline__ bool fast_shade_sample(const BlShadeArgs &P, const do
   // root per sample with the frequency's roots from the table (table[44 + n_nu ...], filled once per workgroup) - what is
   // left per sample AND frequency is one exp, two expm1, one reciprocal and two dozen multiplications.
   // nu_c = e |b| b_unit / (2 pi m_e c), nu_s = 2/9 nu_c Theta_e^2 sin(theta_B): nu / nu_s without another reciprocal
-  const double thermal_frac = pl.plasma_thermal_frac, power_frac = pl.power_frac;
-  const double nu_c_over_b = kE * pl.b_unit * (1.0 / (2.0 * kPi * kMe * kC));
+  const double power_frac = pl.power_frac;
+  const double nu_c_over_b = P.fast_k[7];
   const double momentum_factor_inv = fastmath::rcp(momentum_factor);
   const double kb_tt_e_inv = have ? fastmath::rcp(kb_tt_e_cgs) : 0.0;
-  const double theta_e_inv = kb_tt_e_inv * (kMe * kC * kC);
   const double s_nu = nu_ratio * momentum_factor;
-  const double s_x = have ? s_nu * b_sin_inv * (theta_e_inv * theta_e_inv) * (4.5 / nu_c_over_b) : 0.0;
+  const double s_x = have ? s_nu * b_sin_inv * (kb_tt_e_inv * kb_tt_e_inv) * P.fast_k[4] : 0.0;
   // x^(1/3) by the cube root, x^(1/6) as its square root, x^(1/2) as the cube of that
   const double s_1_3 = fastmath::cbrt(s_x);
   const double s_1_6 = fastmath::sqrt(s_1_3);
   const double s_1_2 = s_1_6 * s_1_3;
   const double s_planck = have ? kH * s_nu * kb_tt_e_inv : 0.0;                                   // h nu / (k T_e) = s_planck f_l
   const double s_nu_inv = have ? -k_u_inv * momentum_factor_inv : 0.0;
-  const double s_j = thermal_frac * n_e_cgs * kE * kE * (nu_c_over_b * b_sin) * (1.0 / kC) * (kSqrt2 * kPi / 27.0) * s_nu_inv * s_nu_inv;
+  const double s_j = P.fast_k[5] * (rho * b_sin) * (s_nu_inv * s_nu_inv);
+  if (kGeneral) n_e_cgs = P.fast_k[6] * rho;   // (the power-law terms below)
   const double s_length = delta_lambda * P.x_unit * momentum_factor_inv;                          // unpolarized.cpp:75-76
   if (P.freq_split) {   // several frequencies: the factors go to bl_transfer_freq_kernel, one lane per ray and frequency
     double2 *dst = reinterpret_cast<double2 *>(P.freq_inputs + row);

@@ -717,9 +717,30 @@ void BuildShadeArgs(RenderJob &job) {
         const bool active = cuts[c] >= 0.0;
         if (active) pl.cut_mask |= 1 << c;
         if (active) pl.any_cell_cut = 1;
-        cold.fast_cut[c] = active ? cuts[c] : 0.0;
-        cold.fast_cut_lo[c] = active ? cuts[c] * (1.0 - ctx->guard_band) : 0.0;
-        cold.fast_cut_hi[c] = active ? cuts[c] * (1.0 + ctx->guard_band) : 0.0;
+        // the fast kernels compare in code units (rho, rho for n_e, p, k T_e for Theta_e, |b| in code units; sigma and 1 / beta have
+        // none): the thresholds are scaled once here, the guard band is relative and scales with them
+        const double n_e_per_rho = pl.d_unit / (p.plasma_mu * kMp * (1.0 + 1.0 / p.plasma_ne_ni));
+        const double to_code[7] = {1.0 / pl.d_unit, 1.0 / n_e_per_rho, 1.0 / pl.e_unit, kMe * kC * kC, 1.0 / pl.b_unit, 1.0, 1.0};
+        const double scaled = cuts[c] * to_code[c >> 1];
+        cold.fast_cut[c] = active ? scaled : 0.0;
+        cold.fast_cut_lo[c] = active ? scaled * (1.0 - ctx->guard_band) : 0.0;
+        cold.fast_cut_hi[c] = active ? scaled * (1.0 + ctx->guard_band) : 0.0;
+      }
+      {
+        const bool use_p = p.plasma_use_p != 0;
+        const double g0 = use_p ? 1.0 : 1.0 / (ctx->grid_meta.plasma_gamma - 1.0);
+        const double g1 = use_p ? 1.0 : 1.0 / (ctx->grid_meta.plasma_gamma_i - 1.0);
+        const double g2 = use_p ? 1.0 : 1.0 / (ctx->grid_meta.plasma_gamma_e - 1.0);
+        const double n_e_per_rho = pl.d_unit / (p.plasma_mu * kMp * (1.0 + 1.0 / p.plasma_ne_ni));
+        const double nu_c_over_b = kE * pl.b_unit / (2.0 * kPi * kMe * kC);
+        sa.fast_k[0] = (1.0 + p.plasma_ne_ni) * p.plasma_mu * kMp * pl.e_unit / pl.d_unit * g0;
+        sa.fast_k[1] = p.plasma_rat_high * g1;
+        sa.fast_k[2] = p.plasma_rat_low * g1;
+        sa.fast_k[3] = p.plasma_ne_ni * g2;
+        sa.fast_k[4] = (kMe * kC * kC) * (kMe * kC * kC) * 4.5 / nu_c_over_b;
+        sa.fast_k[5] = ctx->plasma_thermal_frac * n_e_per_rho * kE * kE * nu_c_over_b / kC * (kSqrt2 * kPi / 27.0);
+        sa.fast_k[6] = n_e_per_rho;
+        sa.fast_k[7] = nu_c_over_b;
       }
       sa.fast_n_e_factor = 1.0 / (p.plasma_mu * kMp * (1.0 + 1.0 / p.plasma_ne_ni));
       sa.fast_d_unit_inv = 1.0 / p.simulation_rho_cgs;
