@@ -361,10 +361,7 @@ struct BlShadeArgs {
   // units of p and rho; [4] x = nu / nu_s at unit frequency = s_nu / (|b| sin) / (k T_e)^2 x [4]; [5] j at unit frequency =
   // [5] rho |b| sin / s_nu^2; [6] n_e = [6] rho; [7] nu_c / |b|
   double fast_k[8];
-  double fast_n_e_factor;     // 1 / (mu m_p (1 + 1 / ne_ni))
-  double fast_d_unit_inv;     // 1 / d_unit
   double fast_angle_band;     // tolerant locate step: theta / phi closer than this to a decision are the exact kernel's (1e-12; wider under bl_debug_set_guard_band)
-  double fast_gamma[3];       // 1 / (gamma - 1), 1 / (gamma_i - 1), 1 / (gamma_e - 1) (plasma_use_p = false)
   unsigned long long *redo_list;       // record indices left to the exact kernel, BL_CNT_REDO entries
   unsigned long long redo_capacity;    // entries the list holds; more than that: the exact kernel shades every record
   int aux_need_coefficients;  // image_light || image_emission || image_tau || image_emission_ave || image_tau_int (:389)

@@ -2489,7 +2489,7 @@ __device__ __forceinline__ bool fast_shade_sample(const BlShadeArgs &P, const do
   double2 *out = P.transfer + row * P.n_nu;
   // what the loop over frequencies needs
   bool have = false;
-  double nu_ratio = 0.0, n_e_cgs = 0.0, theta_e = 0.0, kb_tt_e_cgs = 0.0, k_u_inv = 0.0, b_sin = 0.0, b_sin_inv = 0.0;
+  double nu_ratio = 0.0, n_e_cgs = 0.0, kb_tt_e_cgs = 0.0, k_u_inv = 0.0, b_sin = 0.0, b_sin_inv = 0.0;
   const double rho = pr[0], pgas = pr[1], uu1 = pr[2], uu2 = pr[3], uu3 = pr[4], bb1 = pr[5], bb2 = pr[6], bb3 = pr[7];
   if (status != kSampleCut) {
     // ---- Kerr-Schild scalars (radiation_geometry.cpp:18-25, :138-262)

@@ -742,12 +742,7 @@ void BuildShadeArgs(RenderJob &job) {
         sa.fast_k[6] = n_e_per_rho;
         sa.fast_k[7] = nu_c_over_b;
       }
-      sa.fast_n_e_factor = 1.0 / (p.plasma_mu * kMp * (1.0 + 1.0 / p.plasma_ne_ni));
-      sa.fast_d_unit_inv = 1.0 / p.simulation_rho_cgs;
       sa.fast_angle_band = std::max(1.0e-12, ctx->guard_band > 1.0e-8 ? ctx->guard_band : 0.0);   // (the debug switch widens both kinds of band)
-      sa.fast_gamma[0] = 1.0 / (ctx->grid_meta.plasma_gamma - 1.0);
-      sa.fast_gamma[1] = 1.0 / (ctx->grid_meta.plasma_gamma_i - 1.0);
-      sa.fast_gamma[2] = 1.0 / (ctx->grid_meta.plasma_gamma_e - 1.0);
     }
     sa.grid = ctx->grid_dev;
     sa.lds_table_bytes = ctx->lds_table_bytes;
