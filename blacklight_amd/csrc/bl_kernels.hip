@@ -2989,17 +2989,20 @@ __global__ void __launch_bounds__(256, BL_FAST_WAVES) bl_shade_fused_kernel(cons
 #pragma unroll
   for (int t = 0; t < 14; t++) acos_c[t] = kSpinZero ? fastmath::opaque_register(fastmath::kAcosCoefficients[t]) : fastmath::kAcosCoefficients[t];
   unsigned long long gathers_local = 0ull;
-  auto load_position = [&](bool have, unsigned long long at, double2 &q0, double2 &q1) {
+  // (a position beyond the last record reads the last record and comes back marked dead: whether a slot of the pipeline holds a
+  // sample is then a property of its record, not a flag carried beside it - four lane masks fewer across the loop)
+  auto load_position = [&](unsigned long long at, double2 &q0, double2 &q1) {
+    const bool have = at < n_records;
     const double2 *hot = reinterpret_cast<const double2 *>(P.records_hot + (have ? at : last) * P.record_stride);
     q0 = hot[0];
     q1 = hot[1];
+    q1.y = have ? q1.y : __longlong_as_double((long long)BL_DEAD_RAY);
   };
   FastRay rec_prev;                        // q0, q1: position record; q2, q3: momentum record
   double2 hot_cur0, hot_cur1, hot_next0, hot_next1;
   PlainLocated loc_prev, loc_cur;
   float4 lo[8], hi[8];
-  unsigned long long idx_prev = 0ull, idx_cur = idx;
-  bool have_prev = false, have_cur = idx < n_records;
+  unsigned long long idx_prev = ~0ull, idx_cur = idx;
   rec_prev.q0 = rec_prev.q1 = rec_prev.q2 = rec_prev.q3 = make_double2(0.0, 0.0);
   rec_prev.q1.y = __longlong_as_double((long long)BL_DEAD_RAY);
   loc_prev.f_i = loc_prev.f_j = loc_prev.f_k = loc_prev.ph_unwrapped = 0.0;
@@ -3007,21 +3010,19 @@ __global__ void __launch_bounds__(256, BL_FAST_WAVES) bl_shade_fused_kernel(cons
   loc_prev.cell = 0u;
 #pragma unroll
   for (int c = 0; c < 8; c++) lo[c] = hi[c] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-  load_position(have_cur, idx_cur, hot_cur0, hot_cur1);
+  load_position(idx_cur, hot_cur0, hot_cur1);
   idx += stride;
   unsigned long long idx_next = idx;
-  bool have_next = have_cur && idx < n_records;
   // (the position record of `next` is requested a whole iteration before its search, so that the wait in front of the search
   // is for loads of the previous iteration, not for the cells and records requested in this one)
-  load_position(have_next, idx_next, hot_next0, hot_next1);
+  load_position(idx_next, hot_next0, hot_next1);
   idx += stride;
-  bool have_after = have_next && idx < n_records;
   {
-    const bool live = have_cur && (uint32_t)__double_as_longlong(hot_cur1.y) != BL_DEAD_RAY;
+    const bool live = (uint32_t)__double_as_longlong(hot_cur1.y) != BL_DEAD_RAY;
     loc_cur = locate_plain_sample_tolerant<kSpinZero>(st, P.grid, pg, camera_r, angle_band, acos_c, live, hot_cur0.x, hot_cur0.y, hot_cur1.x);
   }
-  while (have_prev || have_cur) {
-    const uint32_t ray = have_prev ? (uint32_t)__double_as_longlong(rec_prev.q1.y) : BL_DEAD_RAY;
+  while (idx_prev < n_records || idx_cur < n_records) {   // (idx_prev starts beyond every record)
+    const uint32_t ray = (uint32_t)__double_as_longlong(rec_prev.q1.y);
     const bool live = ray != BL_DEAD_RAY;
     const uint32_t n = (uint32_t)(((unsigned long long)__double_as_longlong(rec_prev.q1.y)) >> 32);
     const int status = (int)(loc_prev.status & 0xffu);
@@ -3036,12 +3037,12 @@ __global__ void __launch_bounds__(256, BL_FAST_WAVES) bl_shade_fused_kernel(cons
     gather_issue(P, (int)(loc_cur.status & 0xffu), loc_cur.cell, lo, hi);
     double2 cold_cur0, cold_cur1;
     {
-      const double2 *cold = reinterpret_cast<const double2 *>(P.records_cold + (have_cur ? idx_cur : last) * P.record_stride);
+      const double2 *cold = reinterpret_cast<const double2 *>(P.records_cold + (idx_cur < n_records ? idx_cur : last) * P.record_stride);
       cold_cur0 = cold[0];
       cold_cur1 = cold[1];
     }
     double2 hot_after0, hot_after1;
-    load_position(have_after, idx, hot_after0, hot_after1);
+    load_position(idx, hot_after0, hot_after1);
     if (live) {
       // ReverseGeodesics: sample_len = -geodesic_len (geodesics.cpp:840)
       if (undecided || near_midpoint || !fast_shade_sample<kSpinZero>(P, fast_table, pr, status, row, rec_prev.q0.x, rec_prev.q0.y, rec_prev.q1.x, rec_prev.q2.x,
@@ -3050,7 +3051,7 @@ __global__ void __launch_bounds__(256, BL_FAST_WAVES) bl_shade_fused_kernel(cons
       }
     }
     // the search for `next`
-    const bool live_next = have_next && (uint32_t)__double_as_longlong(hot_next1.y) != BL_DEAD_RAY;
+    const bool live_next = (uint32_t)__double_as_longlong(hot_next1.y) != BL_DEAD_RAY;
     const PlainLocated loc_next = locate_plain_sample_tolerant<kSpinZero>(st, P.grid, pg, camera_r, angle_band, acos_c, live_next, hot_next0.x, hot_next0.y, hot_next1.x);
     rec_prev.q0 = hot_cur0;
     rec_prev.q1 = hot_cur1;
@@ -3058,18 +3059,14 @@ __global__ void __launch_bounds__(256, BL_FAST_WAVES) bl_shade_fused_kernel(cons
     rec_prev.q3 = cold_cur1;
     loc_prev = loc_cur;
     idx_prev = idx_cur;
-    have_prev = have_cur;
     hot_cur0 = hot_next0;
     hot_cur1 = hot_next1;
     loc_cur = loc_next;
     idx_cur = idx_next;
-    have_cur = have_next;
     hot_next0 = hot_after0;
     hot_next1 = hot_after1;
     idx_next = idx;
-    have_next = have_after;
     idx += stride;
-    have_after = have_after && idx < n_records;
   }
   for (int offset = 32; offset > 0; offset >>= 1) gathers_local += __shfl_xor(gathers_local, offset, 64);
   if ((threadIdx.x & 63) == 0 && gathers_local != 0ull) atomicAdd(&P.counters[BL_CNT_GATHERS], gathers_local);
