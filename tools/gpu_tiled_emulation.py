@@ -31,12 +31,14 @@ with bl.Context(bl.Params.from_dict(p)) as ctx:
             pixels = bd.tile_pixels(res, rank, world, bench.TILE) if world > 1 else None
             n_rays = res * res if pixels is None else int(pixels.size)
             image = torch.empty((1, n_rays), dtype=torch.float64, device="cuda")
-            for rep in range(3):
+            dt = 1.0e30
+            for rep in range(6):   # the fastest of six: a rank's share is a few milliseconds, and the clock takes a render or two to settle
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                st = ctx.render_device(image.data_ptr(), n_rays, pixel_map=pixels)
+                st_rep = ctx.render_device(image.data_ptr(), n_rays, pixel_map=pixels)
                 torch.cuda.synchronize()
-                dt = time.perf_counter() - t0
+                if time.perf_counter() - t0 < dt:
+                    dt, st = time.perf_counter() - t0, st_rep
             times.append(dict(rank=rank, ms=1e3 * dt, geodesic=st.ms_geodesic, locate=st.ms_locate, shade=st.ms_shade, transfer=st.ms_transfer, wall=st.ms_wall, chunks=st.n_chunks, emitted=st.n_samples_emitted, samples=st.n_samples))
         worst = max(t["ms"] for t in times)
         out[f"world_{world}"] = dict(max_ms=worst, mrays_per_s=res * res / worst / 1e3, ranks=times)
