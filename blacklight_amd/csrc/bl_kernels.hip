@@ -4024,8 +4024,84 @@ extern "C" hipError_t bl_launch_tau(const BlTransferArgs *args, hipStream_t stre
   return hipGetLastError();
 }
 
+// Tolerant tier, one frequency: four lanes per ray. I <- a I + c is an affine map and maps compose - (a2, c2) after (a1, c1) is
+// (a2 a1, a2 c1 + c2) - so the four lanes of a quad take four consecutive records (64 contiguous bytes where a lane per ray reads
+// 16 from each of 64 different lines), compose them in order by two steps of a scan inside the quad, and the quad's map is applied to
+// the running intensity. Same records, same order of application; the association differs (rounding level: the tier's tolerance).
+// (Measured on the benchmark frame: 2.4 ms against the lane-per-ray kernel's 2.9; two lanes per ray 2.8, eight 3.6, sixteen 6.7 - beyond
+// a quad the scan's moves go through the LDS crossbar instead of DPP; 4, 8 or 16 records per lane in flight make no difference.)
+__global__ void __launch_bounds__(256) bl_transfer_quad_kernel(BlTransferArgs P) {
+  constexpr int kLanes = 4, kShift = 2;
+  constexpr int kBatch = 8;   // records per lane in flight
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int slot = (int)(t >> kShift);
+  const int q = (int)(t & (kLanes - 1));
+  unsigned long long samples = 0ull, flagged = 0ull;
+  int max_num = 0;
+  if (slot < bl_rays_done(P.counters, P.chunk_rays)) {
+    const int num = P.ray_sample_num[slot];
+    const bool flag = P.ray_flags[slot] != 0;
+    const long long out_index = P.ray_out_index[slot];
+    const int all = num + (P.ray_skipped != nullptr ? P.ray_skipped[slot] : 0);
+    if (q == 0) {
+      samples = (unsigned long long)all;
+      flagged = flag ? 1ull : 0ull;
+      max_num = all;
+      if (P.out_sample_num != nullptr) P.out_sample_num[out_index] = all;
+      if (P.out_flags != nullptr) P.out_flags[out_index] = flag ? 1 : 0;
+    }
+    double intensity = 0.0;
+    if (P.fallback_nan && flag) {
+      intensity = num > 0 ? __longlong_as_double(0x7ff8000000000000ll) : 0.0;   // simulation_sampling.cpp:211-216
+    } else {
+      const double2 *rec = P.transfer + (size_t)P.ray_offset[slot];
+      for (int top = num - 1; top >= 0; top -= kLanes * kBatch) {   // far -> near (geodesics.cpp:832-840)
+        double2 m[kBatch];
+#pragma unroll
+        for (int u = 0; u < kBatch; u++) {
+          const int n = top - kLanes * u - q;
+          m[u] = n >= 0 ? rec[n] : make_double2(1.0, 0.0);
+        }
+#pragma unroll
+        for (int u = 0; u < kBatch; u++) {
+          double a = m[u].x, c = m[u].y;
+#pragma unroll
+          for (int d = 1; d < kLanes; d <<= 1) {
+            const double pa = __shfl_up(a, d, kLanes), pc = __shfl_up(c, d, kLanes);   // the map of the d records before this lane's segment
+            if (q >= d) {
+              c = __builtin_fma(a, pc, c);
+              a *= pa;
+            }
+          }
+          const double block_a = __shfl(a, kLanes - 1, kLanes), block_c = __shfl(c, kLanes - 1, kLanes);
+          intensity = __builtin_fma(block_a, intensity, block_c);
+        }
+      }
+    }
+    if (q == 0) {
+      const double freq = P.frequencies[0];
+      P.image[out_index] = intensity * (freq * freq * freq);   // unpolarized.cpp:206-207
+    }
+  }
+  for (int offset = 32; offset > 0; offset >>= 1) {
+    samples += __shfl_xor(samples, offset, 64);
+    flagged += __shfl_xor(flagged, offset, 64);
+    const int other = __shfl_xor(max_num, offset, 64);
+    max_num = other > max_num ? other : max_num;
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (samples) atomicAdd(&P.stats[0], samples);
+    if (flagged) atomicAdd(&P.stats[1], flagged);
+    atomicMax(&P.stats[2], (unsigned long long)max_num);
+  }
+}
+
 extern "C" hipError_t bl_launch_transfer(const BlTransferArgs *args, hipStream_t stream) {
   int grid = (int)(((long long)args->chunk_rays * args->n_nu + 255) / 256);
+  if (args->affine && args->n_nu == 1 && std::getenv("BLACKLIGHT_AMD_LANE_TRANSFER") == nullptr) {
+    hipLaunchKernelGGL(bl_transfer_quad_kernel, dim3((int)(((long long)args->chunk_rays * 4 + 255) / 256)), dim3(256), 0, stream, *args);
+    return hipGetLastError();
+  }
   if (args->affine) hipLaunchKernelGGL(bl_transfer_kernel<true>, dim3(grid), dim3(256), 0, stream, *args);
   else hipLaunchKernelGGL(bl_transfer_kernel<false>, dim3(grid), dim3(256), 0, stream, *args);
   return hipGetLastError();

@@ -387,7 +387,12 @@ def test_empty_shell_steps_leave_no_records(seed, built_library, monkeypatch):
         assert np.array_equal(got["sample_num"], want["sample_num"]) and np.array_equal(got["sample_flags"], want["sample_flags"]), over
         assert got["stats"].n_samples == want["n_samples"] == every["stats"].n_samples and got["stats"].n_gathers == want["n_gathers"]
         assert got["stats"].max_sample_num == every["stats"].max_sample_num == int(want["sample_num"].max())
-        assert gu.same_bits(got["image"], every["image"]).all(), over     # (the skipped records are identities in either tier)
+        if tier == "exact":
+            assert gu.same_bits(got["image"], every["image"]).all(), over     # (the skipped records are identities)
+        else:   # the tolerant tier composes a ray's records four at a time (bl_transfer_quad_kernel): without the identities the groups differ
+            with np.errstate(invalid="ignore"):
+                assert np.nanmax(np.abs(got["image"] - every["image"])) <= 1.0e-13 * np.nanmax(np.abs(every["image"])), over
+            assert np.array_equal(np.isnan(got["image"]), np.isnan(every["image"]))
         assert every["stats"].n_samples_emitted >= every["stats"].n_samples
         assert got["stats"].n_samples_emitted < 0.9 * every["stats"].n_samples_emitted, over
     assert gu.same_bits(out["exact"]["image"], want["image"]).all(), over

@@ -35,6 +35,7 @@ BENCHMARK_KERNELS = {
     "_Z15bl_shade_kernelILi0ELb0ELb0ELb1ELb0ELb1ELb1EEv11BlShadeArgs": (2, 0),   # ... its exact second pass
     "_Z18bl_transfer_kernelILb0EEv14BlTransferArgs": (None, 0),
     "_Z18bl_transfer_kernelILb1EEv14BlTransferArgs": (None, 0),
+    "_Z23bl_transfer_quad_kernel14BlTransferArgs": (None, 0),               # tolerant tier, one frequency: four lanes per ray
 }
 
 
