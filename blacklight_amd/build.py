@@ -6,6 +6,7 @@ Objects are cached under blacklight_amd/csrc/_obj and rebuilt when a source or h
 -ffp-contract=off is mandatory: bit-exact ray-step counts depend on no implicit FMA contraction
 (blmath.h); the only fused operations are the explicit fma calls of the math library.
 """
+import concurrent.futures
 import os
 import shutil
 import subprocess
@@ -18,7 +19,8 @@ LIB = os.path.join(HERE, "libblacklight_amd.so")
 EXE = os.path.join(HERE, "bin", "blacklight_amd")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 
-SOURCES = ["bl_kernels.hip", "bl_polarized.hip", "bl_api.hip", "bl_render.hip", "bl_params.cpp", "bl_host.cpp", "bl_snapshot.cpp"]
+SOURCES = ["bl_shade.hip", "bl_shade_fast.hip", "bl_geodesic.hip", "bl_coefficients_freq.hip", "bl_transfer.hip", "bl_polarized.hip", "bl_api.hip",
+           "bl_render.hip", "bl_params.cpp", "bl_host.cpp", "bl_snapshot.cpp"]   # (slowest first: they are compiled side by side)
 ARCH = "gfx950"
 DEVICE_FLAGS = ["-mllvm", "-disable-machine-licm"]
 COMMON = ["-std=c++17", "-O3", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden", f"-I{INCLUDE}", f"-I{CSRC}"]
@@ -42,15 +44,18 @@ def build(force=False, verbose=False):
     cc = hipcc()
     header_time = _newest_header()
     objects = []
-    rebuilt = False
+    stale_sources = []
     for src in SOURCES:
         src_path = os.path.join(CSRC, src)
         obj_path = os.path.join(OBJ, src.rsplit(".", 1)[0] + ".o")
         objects.append(obj_path)
-        stale = (force or not os.path.exists(obj_path)
-                 or os.path.getmtime(obj_path) < max(os.path.getmtime(src_path), header_time))
-        if not stale:
-            continue
+        if (force or not os.path.exists(obj_path)
+                or os.path.getmtime(obj_path) < max(os.path.getmtime(src_path), header_time)):
+            stale_sources.append(src)
+
+    def compile_one(src):
+        src_path = os.path.join(CSRC, src)
+        obj_path = os.path.join(OBJ, src.rsplit(".", 1)[0] + ".o")
         cmd = [cc, "-c", src_path, "-o", obj_path] + COMMON + os.environ.get("BLACKLIGHT_AMD_EXTRA_FLAGS", "").split()
         if src.endswith(".hip"):
             # -disable-machine-licm: left on, the back end hoists the dozens of 64-bit literals of the math library (each a
@@ -69,7 +74,14 @@ def build(force=False, verbose=False):
                 f.write(result.stderr)
         if verbose and result.stderr:
             print(result.stderr)
-        rebuilt = True
+
+    # the translation units side by side (one per stage of the pipeline: the slowest takes ~20 s)
+    workers = max(1, min(len(stale_sources), os.cpu_count() or 1, 8))
+    if stale_sources:
+        with concurrent.futures.ThreadPoolExecutor(max_workers=workers) as pool:
+            for future in [pool.submit(compile_one, src) for src in stale_sources]:
+                future.result()
+    rebuilt = bool(stale_sources)
     if rebuilt or force or not os.path.exists(LIB):
         cmd = [cc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objects
         result = subprocess.run(cmd, capture_output=True, text=True)

@@ -45,7 +45,7 @@ constexpr double kPi = 3.141592653589793;
 constexpr double kC = 2.99792458e10;
 constexpr double kGGMsun = 1.32712440018e26;
 constexpr double kMp = 1.67262192369e-24;
-constexpr double kMe = 9.1093837015e-28;   // (the kernels' values: bl_kernels.hip)
+constexpr double kMe = 9.1093837015e-28;   // (the kernels' values: bl_kernel_util.h)
 constexpr double kE = 4.80320425e-10;
 constexpr double kSqrt2 = 1.4142135623730951;
 constexpr int kNumCellValues = 7;

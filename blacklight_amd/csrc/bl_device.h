@@ -1,4 +1,4 @@
-// bl_device.h - data layout shared by the HIP kernels (bl_kernels.hip) and their host driver
+// bl_device.h - data layout shared by the HIP kernels (bl_geodesic.hip, bl_shade.hip, bl_shade_fast.hip, bl_coefficients_freq.hip, bl_transfer.hip, bl_polarized.hip) and their host driver
 // (bl_api.hip).
 //
 // HBM layout of one render chunk (all sizes for C rays, ray_max_steps = S, n_nu frequencies):

@@ -2,7 +2,7 @@
  * reciprocal / reciprocal square root with Newton steps, one exponential core for exp and expm1, cube root, logarithm, powers
  * of one base, K_0 / K_1 / K_2. Accurate to a few ulp (tests/test_gpu_tolerant.py::test_tolerant_functions_are_accurate), not
  * bit-reproducible by contract. Device only; to be included INSIDE a `#pragma clang fp contract(fast)` region of the including
- * file (bl_kernels.hip, bl_polarized.hip): the fused multiply-adds are part of the design. */
+ * file (bl_sampling_fast.h, bl_shade_fast.hip, bl_transfer.hip, bl_polarized.hip): the fused multiply-adds are part of the design. */
 #ifndef BLACKLIGHT_AMD_BL_FASTMATH_H_
 #define BLACKLIGHT_AMD_BL_FASTMATH_H_
 

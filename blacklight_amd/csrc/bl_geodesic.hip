@@ -1,0 +1,675 @@
+// bl_geodesic.hip - the geodesic stage of the hot path (gfx950).
+//
+//   bl_ray_init_kernel   one ray per lane: camera pixel -> (x^mu, k_mu), the start state of a ray.   (camera.cpp:528-671)
+//   bl_geodesic_kernel   one ray per lane, wave64, persistent waves. Dormand-Prince 5(4) / RK4 / RK2 stepping in Kerr-Schild
+//                        coordinates with the reference's controller, dense-output sampling, online truncation test. Lanes
+//                        whose ray has terminated are refilled from a global work queue (ballot + popcount prefix, one atomic
+//                        per wave); samples go to 64-byte records in per-wave blocks of slots.   (geodesics.cpp:39-396)
+//
+// The reference integrates camera -> source but evaluates the transfer equation source -> camera (ReverseGeodesics,
+// geodesics.cpp:808-849); the coefficient kernels record the transfer coefficients per sample in the forward pass, which keeps
+// the recurrence the reference's while never materialising its per-sample arrays.
+#include "bl_kernel_util.h"
+
+namespace {
+
+// Dormand-Prince RK5(4)7M tableau exactly as written in geodesics.cpp:42-72
+constexpr double kA[7][6] = {
+    {0.0, 0.0, 0.0, 0.0, 0.0, 0.0},
+    {1.0 / 5.0, 0.0, 0.0, 0.0, 0.0, 0.0},
+    {3.0 / 40.0, 9.0 / 40.0, 0.0, 0.0, 0.0, 0.0},
+    {44.0 / 45.0, -56.0 / 15.0, 32.0 / 9.0, 0.0, 0.0, 0.0},
+    {19372.0 / 6561.0, -25360.0 / 2187.0, 64448.0 / 6561.0, -212.0 / 729.0, 0.0, 0.0},
+    {9017.0 / 3168.0, -355.0 / 33.0, 46732.0 / 5247.0, 49.0 / 176.0, -5103.0 / 18656.0, 0.0},
+    {35.0 / 384.0, 0.0, 500.0 / 1113.0, 125.0 / 192.0, -2187.0 / 6784.0, 11.0 / 84.0}};
+constexpr double kB5[7] = {35.0 / 384.0, 0.0, 500.0 / 1113.0, 125.0 / 192.0, -2187.0 / 6784.0, 11.0 / 84.0, 0.0};
+constexpr double kB4[7] = {5179.0 / 57600.0, 0.0, 7571.0 / 16695.0, 393.0 / 640.0, -92097.0 / 339200.0,
+                           187.0 / 2100.0, 1.0 / 40.0};
+constexpr double kB4m[7] = {6025192743.0 / 30085553152.0, 0.0, 51252292925.0 / 65400821598.0,
+                            -2691868925.0 / 45128329728.0, 187940372067.0 / 1594534317056.0,
+                            -1776094331.0 / 19743644256.0, 11237099.0 / 235043384.0};
+constexpr double kD[7] = {-12715105075.0 / 11282082432.0, 0.0, 87487479700.0 / 32700410799.0,
+                          -10690763975.0 / 1880347072.0, 701980252875.0 / 199316789632.0,
+                          -1453857185.0 / 822651844.0, 69997945.0 / 29380423.0};
+
+// Mark the record slots [first, last) as dead (only the id word is written)
+__device__ __forceinline__ void retire_record_slots(BlSampleHot *records, int stride, long long first, long long last, int lane) {
+  for (long long at = first + lane; at < last; at += 64) {
+    records[at * stride].ray = BL_DEAD_RAY;
+    records[at * stride].n = 0u;
+  }
+}
+
+// State vector component order used in the geodesic kernel:
+//   0 t, 1 x, 2 y, 3 z, 4 k_x, 5 k_y, 6 k_z, 7 s      (k_t is constant along the ray: d k_t = 0)
+// which is the reference's y_vals[0..8] without y_vals[4].
+struct RayState {
+  double y[8];
+  double kt;
+};
+
+template <bool kWithDistance, bool kSpinZero>
+__device__ __forceinline__ void rhs(const BlSpacetime &st, const double y[8], double kt, double k[8], double *r) {
+  double pos[3] = {y[1], y[2], y[3]};
+  double kcov[4] = {kt, y[4], y[5], y[6]};
+  double dpos[4], dk[3], ds = 0.0;
+  bl_geodesic_rhs<kWithDistance, kSpinZero>(st, pos, kcov, dpos, dk, &ds, r);
+  k[0] = dpos[0];
+  k[1] = dpos[1];
+  k[2] = dpos[2];
+  k[3] = dpos[3];
+  k[4] = dk[0];
+  k[5] = dk[1];
+  k[6] = dk[2];
+  k[7] = ds;
+}
+
+// Map a traversal index to the output (ray) index: walk 8x8 pixel tiles so that the 64 lanes of a
+// wave start as a compact patch of the image (similar path lengths, shared grid cells).
+__device__ __forceinline__ long long traversal_to_ray(long long q, int res, const int *tile_order) {
+  if (res <= 0) return q;
+  int tiles_per_row = res >> 3;
+  long long tile = tile_order != nullptr ? (long long)tile_order[q >> 6] : (q >> 6);
+  int within = (int)(q & 63);
+  long long tile_row = tile / tiles_per_row;
+  int tile_col = (int)(tile % tiles_per_row);
+  long long m2 = tile_row * 8 + (within >> 3);
+  int m1 = tile_col * 8 + (within & 7);
+  return m2 * res + m1;
+}
+
+}  // namespace
+
+// =================================================================================================
+// Ray start kernel
+// =================================================================================================
+// One ray of the chunk per lane: pixel -> position, momentum, momentum factor (camera.cpp:393-396, :465-479, :528-671), the
+// radial coordinate of the start point and, for the Dormand-Prince stepper, the first stage of the first step
+// (geodesics.cpp:113-133, :155-156). This used to be the refill branch of the persistent geodesic kernel, where it ran with
+// one or two active lanes almost every time a ray ended (~2 000 instructions per refill, a seventh of that kernel's
+// instruction stream) and kept the camera frame - 28 doubles - in scalar registers through every step of every ray. Here
+// every lane is busy, and the stepping kernel fetches 17 doubles per new ray instead. Same functions of the same inputs:
+// same bits.
+template <bool kDormandPrince, bool kSpinZero>
+__global__ void __launch_bounds__(256) bl_ray_init_kernel(BlTraceArgs P) {
+  const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= (long long)P.chunk_rays) return;
+  const BlSpacetime st = P.st;
+  const long long ray = traversal_to_ray(P.chunk_begin + q, P.swizzle_tiles, P.tile_order);
+  const long long pixel = P.pixel_map != nullptr ? (long long)P.pixel_map[ray] : ray;
+  double u_ind, v_ind, position[4], direction[4], factor;
+  bl_pixel_indices(P.cam, pixel, P.block_locs, &u_ind, &v_ind);
+  bl_pixel_ray(st, P.cam, u_ind, v_ind, position, direction, &factor);
+  P.ray_kt[q] = direction[0];
+  P.ray_factor[q] = factor;
+  P.ray_out_index[q] = ray;
+  if (P.camera_pos != nullptr)
+    for (int mu = 0; mu < 4; mu++) P.camera_pos[4 * ray + mu] = position[mu];
+  if (P.camera_dir != nullptr)
+    for (int mu = 0; mu < 4; mu++) P.camera_dir[4 * ray + mu] = direction[mu];
+  double *start = P.ray_start + q;
+  const long long stride = P.ray_start_stride;
+  RayState s;
+  s.y[0] = position[0];
+  s.y[1] = position[1];
+  s.y[2] = position[2];
+  s.y[3] = position[3];
+  s.kt = direction[0];
+  s.y[4] = direction[1];
+  s.y[5] = direction[2];
+  s.y[6] = direction[3];
+  s.y[7] = 0.0;
+  for (int p = 0; p < 7; p++) start[p * stride] = s.y[p];
+  start[7 * stride] = s.kt;
+  start[8 * stride] = bl_radial_coordinate<kSpinZero>(st, s.y[1], s.y[2], s.y[3]);
+  if (kDormandPrince) {
+    double k0[8], r_unused;
+    rhs<true, kSpinZero>(st, s.y, s.kt, k0, &r_unused);
+    for (int p = 0; p < 8; p++) start[(9 + p) * stride] = k0[p];
+  }
+}
+
+// =================================================================================================
+// Geodesic kernel
+// =================================================================================================
+// kTime: also emit the coordinate time of every sample (P.sample_t, for image_time). Without it the time
+// component is only advanced, never sampled, which keeps its six stage derivatives out of the registers.
+// kSpinZero: bh_a == 0.0 known at compile time (bl_geometry.h, "zero spin"): same bits, no hypot.
+#ifndef BL_GEO_WAVES
+#define BL_GEO_WAVES 2
+#endif
+// Instantiations held at one wave per SIMD: the Dormand-Prince stepper with spin or sample times. At two waves it needs 36-88
+// bytes of scratch per lane, and although a frame with many rays per lane still gains (benchmark frame at a = 0.94: 33.8 ->
+// 31.2 ms), the 512^2 formula frame (BASELINE configuration 2: four rays per lane, time set by its longest rays) loses more
+// (72 -> 87 ms): a wave that shares its SIMD steps a long ray more slowly.
+#ifndef BL_GEO_ONE_WAVE
+#define BL_GEO_ONE_WAVE(integrator, with_time, spin_zero) ((integrator) == BL_INTEGRATOR_DP && ((with_time) || !(spin_zero)))
+#endif
+// A wave-uniform value the optimiser cannot see through (an empty instruction that claims to rewrite its scalar register)
+__device__ __forceinline__ int opaque_uniform(int v) {
+  asm volatile("" : "+s"(v));
+  return v;
+}
+__device__ __forceinline__ double opaque_uniform(double v) {
+  asm volatile("" : "+s"(v));
+  return v;
+}
+template <int kIntegrator, bool kTime, bool kSpinZero, bool kShell = false>
+// kShell: the instantiation that leaves no records of steps in the empty shell around the grid (BlTraceArgs::skip_low).
+// Two waves per SIMD: the benchmark's instantiation (Dormand-Prince, no sample times, zero spin) and the Runge-Kutta steppers
+// fit 256 registers; see BL_GEO_ONE_WAVE for the others.
+__global__ void __launch_bounds__(64, BL_GEO_ONE_WAVE(kIntegrator, kTime, kSpinZero) ? 1 : BL_GEO_WAVES) bl_geodesic_kernel(BlTraceArgs P) {
+  const int lane = wave_lane();
+  const BlSpacetime st = P.st;
+
+  bool have_ray = false;
+  bool exhausted = false;
+  // per-ray persistent state
+  RayState s;
+  double k0[8];
+  double h_new = 0.0, r_cur = 0.0, r_prev_sample = 0.0;
+  int num_retry = 0, n = 0, sample_num = 0, trunc_at = -1;
+  int skipped = 0;   // samples of the ray without a record (BlTraceArgs::skip_low)
+  unsigned int slot = 0;
+  bool previous_fail = false, flag = false;
+  for (int p = 0; p < 8; p++) {
+    s.y[p] = 0.0;
+    k0[p] = 0.0;
+  }
+  s.kt = 0.0;
+  long long block_next = 0, block_end = 0;   // this wave's block of record slots (wave-uniform)
+#ifdef BL_GEO_STATS
+  // per lane: step attempts, accepted steps, samples emitted; per wave (lane 0): loop iterations, emission iterations, refills,
+  // lane-iterations with a ray
+  unsigned long long st_attempt = 0, st_accept = 0, st_emit = 0, st_iter = 0, st_emit_iter = 0, st_refill = 0, st_busy = 0;
+#endif
+
+  while (true) {
+    // ------------------------------------------------------------------ refill idle lanes
+    // A ray is handed out only while the record buffers can take its worst case: the leader reserves ray_max_steps slots per
+    // idle lane in BL_CNT_COMMITTED and gives back what does not fit under the gate; a finished ray gives back what it did not
+    // emit. So the buffers never overflow, and a chunk is as many rays as fit them as the rays turn out (704 of 2 000 steps
+    // on the benchmark frame: one chunk where the worst case needed two). The first refusal closes the gate for the whole
+    // chunk: every wave finishes the rays it has and ends, so the chunk drains within one ray's time. (Handing out the slots
+    // that come back - two thirds of a reservation per finished ray - admits ever fewer rays per generation of rays: 30 ms
+    // per chunk boundary. The persistent grid is sized so that its first fill always fits, bl_render.hip.) The rays nobody
+    // took (BL_CNT_NEXT_RAY < chunk_rays) are the next chunk's.
+    bool need = !have_ray && !exhausted;
+    unsigned long long need_mask = __ballot(need);
+    if (need_mask != 0ull) {
+#ifdef BL_GEO_STATS
+      st_refill += 1;
+#endif
+      const int count = __popcll(need_mask);
+      const int leader = __ffsll((long long)need_mask) - 1;
+      unsigned long long base = 0ull;
+      int admitted = 0;
+      if (lane == leader) {
+        const unsigned long long per_ray = (unsigned long long)P.ray_max_steps;
+        const unsigned long long want = (unsigned long long)count * per_ray;
+        const long long over = (long long)(atomicAdd(&P.counters[BL_CNT_COMMITTED], want) + want) - P.record_gate;
+        long long refused = over > 0 ? (over + (long long)per_ray - 1) / (long long)per_ray : 0;
+        refused = refused < (long long)count ? refused : (long long)count;
+        admitted = count - (int)refused;
+        // the first refusal closes the gate for every wave (a large constant on the counter: every later reservation is over)
+        long long give_back = -(refused * (long long)per_ray) + ((refused > 0 && over < kGateClosed / 2) ? kGateClosed : 0);
+        if (admitted > 0) {
+          base = atomicAdd(&P.counters[BL_CNT_NEXT_RAY], (unsigned long long)admitted);
+          long long beyond = (long long)(base + (unsigned long long)admitted) - (long long)P.chunk_rays;   // past the end of the queue
+          beyond = beyond < 0 ? 0 : (beyond < (long long)admitted ? beyond : (long long)admitted);
+          give_back -= beyond * (long long)per_ray;
+        }
+        if (give_back != 0) atomicAdd(&P.counters[BL_CNT_COMMITTED], (unsigned long long)give_back);
+      }
+      base = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(base >> 32), leader) << 32)
+          | (unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)base, leader);
+      admitted = __builtin_amdgcn_readlane(admitted, leader);
+      if (need) {
+        const int rank = __popcll(need_mask & ((1ull << lane) - 1ull));
+        const unsigned long long q = base + (unsigned long long)rank;
+        if (rank >= admitted || q >= (unsigned long long)P.chunk_rays) {
+          exhausted = true;   // no slots for this lane's ray, or no ray left in the queue
+        } else {
+          have_ray = true;
+          slot = (unsigned int)q;
+          // the ray's start state as bl_ray_init_kernel left it (geodesics.cpp:113-133, :155-156)
+          const double *start = P.ray_start + q;
+          const long long stride = P.ray_start_stride;
+#pragma unroll
+          for (int p = 0; p < 7; p++) s.y[p] = start[p * stride];
+          s.y[7] = 0.0;
+          s.kt = start[7 * stride];
+          r_cur = start[8 * stride];
+          if (kIntegrator == BL_INTEGRATOR_DP) {
+#pragma unroll
+            for (int p = 0; p < 8; p++) k0[p] = start[(9 + p) * stride];
+          }
+          h_new = -P.ray_step * r_cur;
+          num_retry = 0;
+          previous_fail = false;
+          flag = false;
+          n = 0;
+          sample_num = 0;
+          skipped = 0;
+          trunc_at = -1;
+          r_prev_sample = 0.0;
+        }
+      }
+    }
+    if (__ballot(have_ray) == 0ull) {
+      retire_record_slots(P.records_hot, P.record_stride, block_next, block_end, lane);   // unused rest of the last block
+      break;
+    }
+#ifdef BL_GEO_STATS
+    st_iter += 1;
+    st_busy += have_ray ? 1 : 0;
+    st_attempt += (have_ray && (kIntegrator != BL_INTEGRATOR_DP || num_retry <= P.ray_max_retries)) ? 1 : 0;
+#endif
+
+    // ------------------------------------------------------------------ one step attempt
+    int emit = 0;               // samples this lane writes in this iteration
+    int num_steps = 0;          // samples the step contributes to sample_num
+    int num_steps_ideal = 1;
+    bool accepted = false;
+    bool finish = false;
+    double h = 0.0;
+    double y5[8], k6[8], y4m[8];
+    double rv0[8], rv1[8], rv2[8], rv3[8];   // dense-output coefficients (geodesics.cpp:264-273)
+    double r_new = 0.0;
+    // (dense-output coefficients of -0: a step that stores its one midpoint sample runs the interpolation formula of the
+    // emission loop on them and gets that sample back bit for bit - every product and partial sum is -0, and x + (-0) = x
+    // for every x, a zero of either sign included)
+    for (int p = 0; p < 8; p++) {
+      y5[p] = 0.0; k6[p] = 0.0; y4m[p] = 0.0; rv0[p] = -0.0; rv1[p] = -0.0; rv2[p] = -0.0; rv3[p] = -0.0;
+    }
+
+    if (have_ray) {
+      if (kIntegrator == BL_INTEGRATOR_DP) {
+        if (num_retry > P.ray_max_retries) {   // :139-143
+          flag = true;
+          finish = true;
+        } else {
+          h = h_new;
+          double k1[8], k2[8], k3[8], k4[8], k5[8];
+          double yt[8], r_stage;
+          // Coordinate time (component 0) and proper distance (component 7) never enter a right-hand
+          // side: their stage derivatives are only ever used in the b-weighted sums of the 5th / 4th
+          // order solutions, whose terms are added in stage order. Those sums are advanced as soon as
+          // each stage is known, so 2 x 6 stage values need not stay live through the later stages.
+          double t5 = s.y[0], t4 = s.y[0], s5 = s.y[7];
+#define BL_FOLD(Q, K)                     \
+          t5 += kB5[Q] * h * K[0];        \
+          t4 += kB4[Q] * h * K[0];        \
+          s5 += kB5[Q] * h * K[7];
+          BL_FOLD(0, k0)
+          // stages 1..6 (:162-170): y_temp = y + sum_{q<s} a[s][q] * h * k[q], terms added in q order
+#define BL_STAGE(S, KOUT, ...)                                                  \
+          {                                                                      \
+            const double *kq[6] = {__VA_ARGS__};                                 \
+            _Pragma("unroll") for (int p = 1; p < 7; p++) {                      \
+              double acc = s.y[p];                                               \
+              _Pragma("unroll") for (int q = 0; q < S; q++) acc += kA[S][q] * h * kq[q][p]; \
+              yt[p] = acc;                                                       \
+            }                                                                    \
+            yt[0] = 0.0; yt[7] = 0.0;                                            \
+            rhs<true, kSpinZero>(st, yt, s.kt, KOUT, &r_stage);                             \
+            BL_FOLD(S, KOUT)                                                     \
+          }
+          BL_STAGE(1, k1, k0, k0, k0, k0, k0, k0)
+          BL_STAGE(2, k2, k0, k1, k0, k0, k0, k0)
+          BL_STAGE(3, k3, k0, k1, k2, k0, k0, k0)
+          BL_STAGE(4, k4, k0, k1, k2, k3, k0, k0)
+          BL_STAGE(5, k5, k0, k1, k2, k3, k4, k0)
+          BL_STAGE(6, k6, k0, k1, k2, k3, k4, k5)
+#undef BL_STAGE
+#undef BL_FOLD
+          // 5th / 4th order solutions and error (:173-194). y_vals_5 equals the stage-6 argument
+          // bit for bit (same coefficients, same order, the extra b5[6] = 0 term adds +-0), so
+          // r_new = RadialGeodesicCoordinate(y_vals_5) is the r of stage 6.
+          const double *kk[7] = {k0, k1, k2, k3, k4, k5, k6};
+          double error = 0.0;
+#pragma unroll
+          for (int p = 0; p < 8; p++) {
+            double a5 = s.y[p], a4 = s.y[p];
+            if (p == 0 && !kTime) {
+              a5 = t5;
+              a4 = t4;
+            } else if (p == 7) {
+              a5 = s5;
+            } else {
+#pragma unroll
+              for (int q = 0; q < 7; q++) {
+                a5 += kB5[q] * h * kk[q][p];
+                a4 += kB4[q] * h * kk[q][p];
+              }
+            }
+            y5[p] = a5;
+            if (p < 7) {   // reference p < 8 covers t, x, y, z, k_t (zero difference), k_x, k_y, k_z
+              double y_abs = std_max(blm_abs(s.y[p]), blm_abs(a5));
+              double error_scale = P.ray_tol_abs + P.ray_tol_rel * y_abs;
+              double delta_y = blm_abs(a5 - a4);
+              error = std_max(error, delta_y / error_scale);
+            }
+          }
+          r_new = r_stage;
+
+          if (!(error <= 1.0)) {   // :197-209
+            double h_factor = 0.2;
+            if (error - error == 0.0) {   // std::isfinite
+              double h_factor_ideal = 0.9 * bl_pow(error, -0.2);
+              h_factor = std_max(h_factor_ideal, 0.2);
+            }
+            h_new = h * h_factor;
+            num_retry += 1;
+            previous_fail = true;
+          } else {                 // :210-224
+            double h_factor = 10.0;
+            if (error > 0.0) {
+              h_factor = 0.9 * bl_pow(error, -0.2);
+              h_factor = std_max(h_factor, 0.2);
+              h_factor = std_min(h_factor, 10.0);
+            }
+            if (previous_fail) h_factor = std_min(h_factor, 1.0);
+            h_new = h * h_factor;
+            num_retry = 0;
+            previous_fail = false;
+            accepted = true;
+
+            // midpoint (:227-231), subdivision (:234-245); component 0 (t) of the samples only with kTime
+#pragma unroll
+            for (int p = kTime ? 0 : 1; p < 7; p++) {
+              double acc = s.y[p];
+#pragma unroll
+              for (int q = 0; q < 7; q++) acc += kB4m[q] * h * kk[q][p];
+              y4m[p] = acc;
+            }
+            double r_mid = bl_radial_coordinate<kSpinZero>(st, y4m[1], y4m[2], y4m[3]);
+            double delta_s_step = P.ray_step * r_mid;
+            double delta_s_full = y5[7] - s.y[7];
+            num_steps_ideal = (int)ceil(delta_s_full / delta_s_step);
+            int num_steps_max = P.ray_max_steps - n;
+            num_steps = num_steps_ideal;
+            if (num_steps > num_steps_max) {
+              num_steps = num_steps_max;
+              flag = true;
+            }
+            emit = num_steps;
+            if (num_steps_ideal > 1) {   // :262-274
+#pragma unroll
+              for (int p = kTime ? 0 : 1; p < 7; p++) {
+                rv0[p] = y5[p] - s.y[p];
+                rv1[p] = s.y[p] - y5[p] + h * k0[p];
+                rv2[p] = 2.0 * (y5[p] - s.y[p]) - h * (k0[p] + k6[p]);
+                double acc = 0.0;
+#pragma unroll
+                for (int q = 0; q < 7; q++) acc += kD[q] * h * kk[q][p];
+                rv3[p] = acc;
+              }
+            }
+          }
+        }
+      } else {
+        // RK4 (:463-533) / RK2 (:670-722): one sample per step, fixed step rule
+        double r = r_cur;
+        h = -P.ray_step * (r - P.r_horizon);
+        double kv[8], ysub[8], yacc[8], r_unused;
+        if (kIntegrator == BL_INTEGRATOR_RK4) {
+          rhs<false, kSpinZero>(st, s.y, s.kt, kv, &r_unused);
+          for (int p = 0; p < 7; p++) yacc[p] = s.y[p] + 1.0 / 6.0 * h * kv[p];
+          for (int p = 0; p < 7; p++) ysub[p] = s.y[p] + 0.5 * h * kv[p];
+          ysub[7] = 0.0;
+          rhs<false, kSpinZero>(st, ysub, s.kt, kv, &r_unused);
+          for (int p = 0; p < 7; p++) yacc[p] += 1.0 / 3.0 * h * kv[p];
+          for (int p = 0; p < 7; p++) ysub[p] = s.y[p] + 0.5 * h * kv[p];
+          rhs<false, kSpinZero>(st, ysub, s.kt, kv, &r_unused);
+          for (int p = 0; p < 7; p++) yacc[p] += 1.0 / 3.0 * h * kv[p];
+          for (int p = 0; p < 7; p++) ysub[p] = s.y[p] + h * kv[p];
+          rhs<false, kSpinZero>(st, ysub, s.kt, kv, &r_unused);
+          for (int p = 0; p < 7; p++) yacc[p] += 1.0 / 6.0 * h * kv[p];
+          for (int p = 0; p < 7; p++) y4m[p] = 0.5 * (s.y[p] + yacc[p]);   // stored midpoint (:496-500)
+          for (int p = 0; p < 7; p++) y5[p] = yacc[p];
+        } else {
+          rhs<false, kSpinZero>(st, s.y, s.kt, kv, &r_unused);
+          for (int p = 0; p < 7; p++) ysub[p] = s.y[p] + h * kv[p];
+          ysub[7] = 0.0;
+          for (int p = 0; p < 7; p++) yacc[p] = s.y[p] + 1.0 / 2.0 * h * kv[p];
+          for (int p = 0; p < 7; p++) y4m[p] = yacc[p];                    // stored half-step state (:684-688)
+          rhs<false, kSpinZero>(st, ysub, s.kt, kv, &r_unused);
+          for (int p = 0; p < 7; p++) y5[p] = yacc[p] + 1.0 / 2.0 * h * kv[p];
+        }
+        y5[7] = 0.0;
+        accepted = true;
+        num_steps_ideal = 1;
+        num_steps = 1;
+        emit = 1;
+      }
+    }
+
+    // ------------------------------------------------------------------ steps that leave no records (BlTraceArgs::skip_low)
+    // Every sample of the step lies within d = sum over x, y, z of |r0| + |r1| + |r2| + |r3| of the base point (the weights of the
+    // dense output are products of numbers in [0, 1]; a midpoint step has coefficients of -0). Such a step cannot hold the
+    // sample that ends the ray either (r <= camera_r, r > r_terminate), and whatever sample follows it compares with a
+    // predecessor inside the camera's sphere: any r_prev_sample <= camera_r gives the same answer.
+    if (kShell && emit > 0) {
+      const bool dense = num_steps_ideal > 1;
+      double d = 0.0, rr = 0.0;
+#pragma unroll
+      for (int p = 1; p < 4; p++) {
+        const double b = dense ? s.y[p] : y4m[p];
+        rr += b * b;
+        d += (blm_abs(rv0[p]) + blm_abs(rv1[p])) + (blm_abs(rv2[p]) + blm_abs(rv3[p]));
+      }
+      const double low = P.skip_low + d, high = P.skip_high - d;
+      if (rr > low * low && high > 0.0 && rr < high * high && trunc_at < 0) {
+        skipped += emit;
+        emit = 0;
+        r_prev_sample = 0.0;
+      }
+    }
+
+    // ------------------------------------------------------------------ allocate sample slots
+    // Each wave owns a block of BL_RECORD_BLOCK consecutive record slots and hands them out with one
+    // wave scan per step; the global atomic (whose return has to be waited for, with nothing else to
+    // run at one wave per SIMD) is only needed when a block runs out, about once in a dozen steps.
+    // The samples of the step are laid end to end in lane order; when they do not fit in what is left of the
+    // block, they fill it to its last slot and continue at the start of the next block (a lane's run of samples
+    // may straddle the two), so no slot is lost at a switch and chunk_rays * ray_max_steps slots plus one block
+    // per wave always suffice. Only the unused tail of a wave's last block is marked dead.
+    const int scan = wave_inclusive_scan(emit);
+    const int total = __builtin_amdgcn_readlane(scan, 63);
+    const int excl = scan - emit;               // this lane's first sample among the step's
+    long long old_base = block_next, new_base = 0;
+    int old_room = 0x7fffffff;                   // samples of this step that go to the current block
+    if (total > 0) {
+      const long long remaining = block_end - block_next;
+      if ((long long)total <= remaining) {
+        block_next += total;
+      } else {
+        old_room = (int)remaining;
+        const unsigned long long grab = (unsigned long long)std_max_ll((long long)total - remaining, BL_RECORD_BLOCK);
+        unsigned long long fetched = 0ull;
+        if (lane == 63) fetched = atomicAdd(&P.counters[BL_CNT_RECORDS], grab);
+        fetched = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(fetched >> 32), 63) << 32)
+            | (unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)fetched, 63);
+        new_base = (long long)fetched;
+        block_next = new_base + ((long long)total - remaining);
+        block_end = (long long)(fetched + grab);
+        if (block_end > P.record_capacity) {
+          // cannot happen with capacity = chunk_rays * ray_max_steps + one block per wave; flagged for the host
+          atomicExch(&P.counters[BL_CNT_OVERFLOW], 1ull);
+          block_end = block_next = 0;
+          emit = 0;
+        }
+      }
+    }
+
+    // ------------------------------------------------------------------ emit samples
+    const int max_emit = wave_max_nonneg(emit);
+#ifdef BL_GEO_STATS
+    st_emit_iter += max_emit;
+    st_emit += emit;
+    st_accept += accepted ? 1 : 0;
+#endif
+    // The samples of the step. One midpoint sample (:248-259, and the stored state of RK4 / RK2) or num_steps_ideal samples of
+    // the dense output (:277-293): smp = y + frac (r0 + (1 - frac) (r1 + frac (r2 + (1 - frac) r3))), frac = (nn + 0.5) /
+    // num_steps_ideal, each of length h / num_steps_ideal. Both run the same formula: a midpoint step has base = the stored
+    // state and coefficients of -0 (above), frac = 0.5 / 1 and h / 1 = h. The two quotients share one reciprocal per step
+    // (small integers and step lengths: the IEEE quotients, bl_geometry.h).
+    const bool dense_output = num_steps_ideal > 1;
+    double base[7];
+#pragma unroll
+    for (int p = kTime ? 0 : 1; p < 7; p++) base[p] = dense_output ? s.y[p] : y4m[p];
+    const BlRecip rc_steps = bl_recip((double)num_steps_ideal);
+    const double len = bl_div_r(h, rc_steps);
+    double position = 0.5;   // nn + 0.5, exact
+    for (int nn = 0; nn < max_emit; nn++, position += 1.0) {
+      if (nn < emit) {
+        double smp[7];
+        const double frac = bl_div_r(position, rc_steps);
+#pragma unroll
+        for (int p = kTime ? 0 : 1; p < 7; p++)
+          smp[p] = base[p] + frac * (rv0[p] + (1.0 - frac) * (rv1[p] + frac * (rv2[p] + (1.0 - frac) * rv3[p])));
+        // online form of the truncation pass (:327-349): the first sample (index >= 1) that moves
+        // outward beyond the camera radius or falls inside r_terminate ends the kept part of the ray
+        // (evaluated for every sample, decided only while the ray is still whole: after the first hit nothing reads
+        // r_prev_sample again, and the ray ends with this step - its end test is the same comparison at the step's end)
+        const int index = n + nn;
+        const double r_s = bl_radial_coordinate<kSpinZero>(st, smp[1], smp[2], smp[3]);
+        const bool hit = index >= 1 && ((r_s > P.camera_r && r_s > r_prev_sample) || r_s < P.r_terminate);
+        const bool dead = trunc_at >= 0 || hit;
+        trunc_at = (trunc_at < 0 && hit) ? index : trunc_at;
+        r_prev_sample = r_s;
+        BlSampleHot hot;
+        hot.x = smp[1];
+        hot.y = smp[2];
+        hot.z = smp[3];
+        hot.ray = dead ? BL_DEAD_RAY : slot;
+        hot.n = (unsigned int)(kShell ? index - skipped : index);   // its row among the ray's records
+        // (a lane's samples side by side, the lanes' runs end to end: consecutive records are consecutive samples of a ray, which
+        // read the same grid cells - laid out row by row instead, the coefficient kernels take 4 ms longer per frame)
+        const int place = excl + nn;
+        const long long at = place < old_room ? old_base + place : new_base + (place - old_room);
+        BlSampleCold cold;
+        cold.kx = smp[4];
+        cold.ky = smp[5];
+        cold.kz = smp[6];
+        cold.len = len;
+        P.records_hot[at * P.record_stride] = hot;
+        P.records_cold[at * P.record_stride] = cold;
+        if (kTime) P.sample_t[at] = smp[0];
+      }
+    }
+
+    // ------------------------------------------------------------------ finish the step
+    if (have_ray && accepted) {
+      // renormalise the spatial momentum at the new point (:296-309 / :507-521 / :696-710)
+      double factor = bl_renormalization_factor<kSpinZero>(st, y5[1], y5[2], y5[3], s.kt, y5[4], y5[5], y5[6]);
+      y5[4] *= factor;
+      y5[5] *= factor;
+      y5[6] *= factor;
+      double r_before = r_cur;
+      if (kIntegrator != BL_INTEGRATOR_DP) r_new = bl_radial_coordinate<kSpinZero>(st, y5[1], y5[2], y5[3]);
+      sample_num += num_steps;
+      bool terminate_outer = r_new > P.camera_r && r_new > r_before;
+      bool terminate_inner = r_new < P.r_terminate;
+      if (terminate_outer || terminate_inner) {
+        finish = true;
+      } else {
+        bool last_step = n + num_steps >= P.ray_max_steps;
+        if (last_step) flag = true;
+        n += num_steps;
+        if (n >= P.ray_max_steps) finish = true;
+      }
+      // FSAL: next step starts from y_vals_5 with k_vals[0] = k_vals[6], the latter evaluated
+      // BEFORE the renormalisation above (:149-154)
+#pragma unroll
+      for (int p = 0; p < 8; p++) {
+        s.y[p] = y5[p];
+        k0[p] = k6[p];
+      }
+      r_cur = r_new;
+    }
+    if (have_ray && finish) {
+      const int final_num = ((trunc_at >= 0) ? trunc_at : sample_num) - (kShell ? skipped : 0);   // kept samples with a record
+      P.ray_sample_num[slot] = final_num;
+      if (kShell) P.ray_skipped[slot] = skipped;
+      P.ray_flags[slot] = flag ? 1 : 0;
+      // rows of the kept samples in the per-sample arrays, in the order in which rays finish; slots not emitted go back
+      P.ray_offset[slot] = (long long)atomicAdd(&P.counters[BL_CNT_SAMPLES], (unsigned long long)final_num);
+      atomicAdd(&P.counters[BL_CNT_COMMITTED], (unsigned long long)(-(long long)(P.ray_max_steps - (sample_num - (kShell ? skipped : 0)))));
+      have_ray = false;
+    }
+  }
+#ifdef BL_GEO_STATS
+  atomicAdd(&P.counters[BL_CNT_DEBUG + 0], st_attempt);
+  atomicAdd(&P.counters[BL_CNT_DEBUG + 1], st_accept);
+  atomicAdd(&P.counters[BL_CNT_DEBUG + 2], st_emit);
+  atomicAdd(&P.counters[BL_CNT_DEBUG + 6], st_busy);
+  if (lane == 0) {
+    atomicAdd(&P.counters[BL_CNT_DEBUG + 3], st_iter);
+    atomicAdd(&P.counters[BL_CNT_DEBUG + 4], st_emit_iter);
+    atomicAdd(&P.counters[BL_CNT_DEBUG + 5], st_refill);
+  }
+#endif
+}
+
+
+// =================================================================================================
+// Launch wrappers (called from bl_api.hip)
+// =================================================================================================
+// Start states of the rays [chunk_begin, chunk_begin + chunk_rays) (bl_ray_init_kernel)
+extern "C" hipError_t bl_launch_ray_init(const BlTraceArgs *args, int integrator, hipStream_t stream) {
+  const bool spin_zero = args->st.bh_a == 0.0;
+  const int grid = (args->chunk_rays + 255) / 256;
+  const bool dp = integrator == BL_INTEGRATOR_DP;
+  if (dp && spin_zero) hipLaunchKernelGGL((bl_ray_init_kernel<true, true>), dim3(grid), dim3(256), 0, stream, *args);
+  else if (dp) hipLaunchKernelGGL((bl_ray_init_kernel<true, false>), dim3(grid), dim3(256), 0, stream, *args);
+  else if (spin_zero) hipLaunchKernelGGL((bl_ray_init_kernel<false, true>), dim3(grid), dim3(256), 0, stream, *args);
+  else hipLaunchKernelGGL((bl_ray_init_kernel<false, false>), dim3(grid), dim3(256), 0, stream, *args);
+  return hipGetLastError();
+}
+
+// One expression per instantiation of the geodesic kernel (integrator x sample times x zero spin x empty shell; the last two
+// only without sample times)
+#define BL_GEODESIC_CASES(I, DO)                                                      \
+  do {                                                                                \
+    if (with_time && spin_zero) DO((bl_geodesic_kernel<I, true, true, false>));       \
+    else if (with_time) DO((bl_geodesic_kernel<I, true, false, false>));              \
+    else if (spin_zero && shell) DO((bl_geodesic_kernel<I, false, true, true>));      \
+    else if (spin_zero) DO((bl_geodesic_kernel<I, false, true, false>));              \
+    else if (shell) DO((bl_geodesic_kernel<I, false, false, true>));                  \
+    else DO((bl_geodesic_kernel<I, false, false, false>));                            \
+  } while (0)
+
+extern "C" hipError_t bl_launch_geodesic(const BlTraceArgs *args, int integrator, int grid, hipStream_t stream) {
+  const bool with_time = args->sample_t != nullptr;
+  const bool spin_zero = args->st.bh_a == 0.0;   // also true for -0.0: the instantiation never reads bh_a
+  const bool shell = args->ray_skipped != nullptr;
+  if (shell && with_time) return hipErrorInvalidValue;
+#define BL_LAUNCH_G(K) hipLaunchKernelGGL(K, dim3(grid), dim3(64), 0, stream, *args)
+  switch (integrator) {
+    case BL_INTEGRATOR_DP: BL_GEODESIC_CASES(BL_INTEGRATOR_DP, BL_LAUNCH_G); break;
+    case BL_INTEGRATOR_RK4: BL_GEODESIC_CASES(BL_INTEGRATOR_RK4, BL_LAUNCH_G); break;
+    default: BL_GEODESIC_CASES(BL_INTEGRATOR_RK2, BL_LAUNCH_G); break;
+  }
+#undef BL_LAUNCH_G
+  return hipGetLastError();
+}
+
+// Workgroups (= waves) of the geodesic kernel one CU holds: the persistent grid is this many per CU
+extern "C" int bl_geodesic_occupancy(int integrator, int with_time_flag, int spin_zero_flag, int shell_flag) {
+  int blocks = 0;
+  hipError_t err = hipSuccess;
+  const bool with_time = with_time_flag != 0, spin_zero = spin_zero_flag != 0, shell = shell_flag != 0;
+#define BL_OCCUPANCY_G(K) err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, K, 64, 0)
+  switch (integrator) {
+    case BL_INTEGRATOR_DP: BL_GEODESIC_CASES(BL_INTEGRATOR_DP, BL_OCCUPANCY_G); break;
+    case BL_INTEGRATOR_RK4: BL_GEODESIC_CASES(BL_INTEGRATOR_RK4, BL_OCCUPANCY_G); break;
+    default: BL_GEODESIC_CASES(BL_INTEGRATOR_RK2, BL_OCCUPANCY_G); break;
+  }
+#undef BL_OCCUPANCY_G
+#undef BL_GEODESIC_CASES
+  if (err != hipSuccess || blocks < 1) blocks = 4;
+  return blocks;
+}
+

@@ -8,7 +8,8 @@ import pytest
 
 from blacklight_amd import build as bl_build
 
-RESOURCES = os.path.join(bl_build.OBJ, "bl_kernels.resources.txt")
+RESOURCES = [os.path.join(bl_build.OBJ, name + ".resources.txt")
+             for name in ("bl_geodesic", "bl_shade", "bl_shade_fast", "bl_transfer")]   # one translation unit per stage of the pipeline
 
 # mangled name -> (waves per SIMD, largest scratch in bytes per lane)
 BENCHMARK_KERNELS = {
@@ -40,7 +41,7 @@ BENCHMARK_KERNELS = {
 
 
 def _parse():
-    text = open(RESOURCES).read()
+    text = "".join(open(path).read() for path in RESOURCES)
     kernels = {}
     current = None
     for line in text.splitlines():
@@ -55,7 +56,7 @@ def _parse():
 
 
 def test_benchmark_kernels_fit_their_registers(built_library):
-    if not os.path.exists(RESOURCES):
+    if not all(os.path.exists(path) for path in RESOURCES):
         bl_build.build(force=True)
     kernels = _parse()
     for name, (occupancy, scratch) in BENCHMARK_KERNELS.items():
@@ -70,11 +71,12 @@ SCRATCH_ALLOWED = {}
 
 
 def test_no_kernel_needs_scratch_memory(built_library):
-    """Every kernel of both device translation units - all instantiations, polarized and slow-light ones included - keeps its
+    """Every kernel of every device translation unit - all instantiations, polarized and slow-light ones included - keeps its
     state in registers (and LDS): no private-segment memory, so no hidden memory traffic behind the measured numbers."""
-    if not os.path.exists(RESOURCES):
+    everything = RESOURCES + [os.path.join(bl_build.OBJ, name + ".resources.txt") for name in ("bl_coefficients_freq", "bl_polarized")]
+    if not all(os.path.exists(path) for path in everything):
         bl_build.build(force=True)
-    for path in (RESOURCES, os.path.join(bl_build.OBJ, "bl_polarized.resources.txt")):
+    for path in everything:
         text = open(path).read()
         names = re.findall(r"remark: Function Name: (\S+)", text)
         scratch = [int(v) for v in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", text)]

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Static instruction counts per kernel from the gfx950 assembly of blacklight_amd/csrc/bl_kernels.hip
+"""Static instruction counts per kernel from the gfx950 assembly of the kernel files of blacklight_amd/csrc
 (tools only; a proxy for the dynamic counts rocprofv3 reports).  python tools/isa_count.py [filter ...]"""
 import os
 import re
@@ -9,12 +9,16 @@ import sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = "/tmp/bl_isa"
 os.makedirs(OUT, exist_ok=True)
-asm = os.path.join(OUT, "bl_kernels.s")
-src = os.path.join(REPO, "blacklight_amd", "csrc", "bl_kernels.hip")
+asm = os.path.join(OUT, "kernels.s")
+sources = [os.path.join(REPO, "blacklight_amd", "csrc", f + ".hip") for f in ("bl_geodesic", "bl_shade", "bl_shade_fast", "bl_transfer")]
 if not os.path.exists(asm) or os.path.getmtime(asm) < max(os.path.getmtime(os.path.join(REPO, "blacklight_amd", "csrc", f))
                                                           for f in os.listdir(os.path.join(REPO, "blacklight_amd", "csrc")) if f.endswith((".hip", ".h"))):
-    subprocess.run(["hipcc", "-S", "--offload-device-only", "--offload-arch=gfx950", "-std=c++17", "-O3", "-ffp-contract=off", "-mllvm", "-disable-machine-licm",
-                    f"-I{REPO}/include", f"-I{REPO}/blacklight_amd/csrc", src, "-o", asm], check=True, capture_output=True)
+    with open(asm, "w") as out:
+        for src in sources:
+            part = os.path.join(OUT, os.path.basename(src)[:-4] + ".s")
+            subprocess.run(["hipcc", "-S", "--offload-device-only", "--offload-arch=gfx950", "-std=c++17", "-O3", "-ffp-contract=off", "-mllvm",
+                            "-disable-machine-licm", f"-I{REPO}/include", f"-I{REPO}/blacklight_amd/csrc", src, "-o", part], check=True, capture_output=True)
+            out.write(open(part).read())
 lines = open(asm).read().split("\n")
 filters = sys.argv[1:] or ["shade", "locate_kernelILb0ELb0", "geodesic_kernelILi0ELb0", "transfer_kernel"]
 name = None
