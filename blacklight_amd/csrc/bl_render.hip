@@ -250,6 +250,7 @@ void PlanJob(RenderJob &job) {
   // The fast path over one grid (or equal blocks merged into one) with its coordinate tables in LDS, trilinear sampling and no
   // optional geometric cut locates its samples inside the coefficient kernel: no located samples in HBM at all
   job.fused = job.fast && !job.tau_row && ctx->grid_dev.n_blocks == 0 && ctx->lds_table_bytes > 0 && !ctx->grid_dev.fmks && p.simulation_interp && p.plasma_power_frac == 0.0
+      && p.simulation_coord == BL_COORD_SKS   // (its locate step is the spherical one: Cartesian grids go through the locate kernel)
       && !(p.cut_omit_near || p.cut_omit_far || p.cut_omit_in >= 0.0 || p.cut_omit_out >= 0.0 || p.cut_midplane_theta != 0.0 || p.cut_midplane_z != 0.0 || p.cut_plane)
       && static_cast<size_t>(ctx->lds_table_bytes) + (44 + 5 * static_cast<size_t>(job.n_nu) + ctx->n_i + ctx->n_j + ctx->n_k) * sizeof(double) <= 60u * 1024u
       && !job.sample_save && std::getenv("BLACKLIGHT_AMD_NO_FUSED_LOCATE") == nullptr;   // (a sample checkpoint is made of the located samples)

@@ -2958,6 +2958,9 @@ int blo_image_num_quantities(const bl_params *p) {
   return o.image_num_quantities;
 }
 
+// Length of the frequency list blo_render() writes to its `frequencies` argument
+int blo_image_num_frequencies(const bl_params *p) { return p->image_num_frequencies; }
+
 const char *blo_build_info(void) {
 #ifdef BLO_LIBM
   return "oracle;libm";

@@ -57,6 +57,7 @@ int blo_render(const bl_params *p, const bl_grid_desc *g, const bl_render_desc *
 
 /* number of image rows for these parameters (radiation_integrator.cpp:436-520) */
 int blo_image_num_quantities(const bl_params *p);
+int blo_image_num_frequencies(const bl_params *p);
 
 const char *blo_build_info(void);
 

@@ -51,6 +51,7 @@ def load(variant="blmath"):
     L = C.CDLL(path)
     L.blo_build_info.restype = C.c_char_p
     L.blo_image_num_quantities.argtypes = [C.c_void_p]
+    L.blo_image_num_frequencies.argtypes = [C.c_void_p]
     _libs[variant] = L
     return L
 
@@ -95,7 +96,9 @@ def render(params_ptr, grid_desc, desc_cls, camera_frame_cls, *, n_rays, level=0
         rendering = np.zeros((n_render, 3, n_rays))
         d.render = rendering.ctypes.data_as(C.c_void_p)
     frame = camera_frame_cls()
-    freqs = np.zeros(max(n_freq, 1))
+    # (the oracle writes the whole frequency list: sized from the parameters, whatever the caller said - a sweep with several
+    # frequencies and the default n_freq once wrote past an 8-byte buffer, found by tools/gpu_fuzz_tiers.py under ASan)
+    freqs = np.zeros(max(n_freq, L.blo_image_num_frequencies(params_ptr), 1))
     extra = Extra()
     extra.num_threads = num_threads
     extra.define_kappa_aa_high_i = 1 if define_kappa else 0

@@ -168,6 +168,29 @@ def test_tolerant_tier_with_power_laws_and_cartesian_grids(seed, built_library):
     assert np.isfinite(exact["image"]).mean() > 0.5 and np.nanmax(exact["image"]) > 0.0
 
 
+@pytest.mark.parametrize("frequencies,spin", [(1, 0.0), (1, 0.9), (5, 0.0)])
+def test_tolerant_tier_on_a_cartesian_grid_with_thermal_electrons(frequencies, spin, built_library):
+    """One block, trilinear sampling, thermal electrons, no auxiliary row - everything the fused kernel asks for except the
+    coordinates: a Cartesian Kerr-Schild grid has to go through the locate kernel (the fused kernel's locate step is the spherical
+    one; a randomised sweep, tools/gpu_fuzz_tiers.py, found such runs sent to it). Counts, S_in and NaN mask equal, image at
+    rounding level."""
+    fx, params, mock_args = gu.load_case("sim_dp_interp")
+    params = dict(params, camera_resolution=24, camera_th=75.0, camera_ph=40.0, simulation_a=spin, simulation_interp="true", simulation_coord="cks",
+                  fallback_nan="false", fallback_rho=1.0e-6, fallback_pgas=1.0e-8, image_num_frequencies=frequencies)
+    if frequencies > 1:
+        params.update(image_frequency_start=1.0e11, image_frequency_end=6.0e11, image_frequency_spacing="log")
+    assert _applies(params)
+    out = _both(params, mock_args)
+    exact, tol = out["exact"], out["tolerant"]
+    assert tol["stats"].arithmetic == 1 and exact["stats"].arithmetic == 0
+    assert tol["stats"].launches_locate == exact["stats"].launches_locate > 0
+    assert tol["stats"].n_gathers == exact["stats"].n_gathers
+    assert np.array_equal(tol["sample_num"], exact["sample_num"]) and np.array_equal(np.isnan(tol["image"]), np.isnan(exact["image"]))
+    d = _distance(tol["image"], exact["image"])
+    print(f"cks, thermal, {frequencies} frequencies, a = {spin}: {d:.2e}")
+    assert d < EXPECTED and np.nanmax(exact["image"]) > 0.0
+
+
 @pytest.mark.parametrize("seed", range(8))
 def test_tolerant_tier_with_an_optical_depth_image(seed, built_library):
     """image_tau as the only auxiliary row: the fast coefficient kernel leaves alpha x length of every sample beside its
