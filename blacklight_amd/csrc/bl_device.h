@@ -57,6 +57,11 @@ static_assert(sizeof(BlLocated) == 32, "located sample must be 32 bytes");
 #define BL_RECORD_BLOCK 1024
 // Marker for "optically thick: I <- b" in the transfer record (exp(-dtau) is never negative)
 #define BL_THICK_MARK (-1.0)
+// ... and in the tolerant tier's affine records (a, c) of I <- a I + c: a = -0.0. An optically thick step's intensity REPLACES what lies
+// behind it (unpolarized.cpp:103-104), a NaN included, so the transfer kernels must tell it from a thin step whose a = 1 + expm1(-tau)
+// has rounded to +0 (tau > 37.4), behind which a NaN stays a NaN as in the exact tier (NaN x exp(-tau)). No other a is negative.
+#define BL_AFFINE_THICK (-0.0)
+#define BL_IS_AFFINE_THICK(a) (__double2hiint(a) < 0)
 
 enum BlCounter {
   BL_CNT_NEXT_RAY = 0,      // work queue head of the geodesic kernel

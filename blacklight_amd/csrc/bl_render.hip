@@ -670,6 +670,7 @@ void BuildShadeArgs(RenderJob &job) {
   sa.cuts.camera_r = p.camera_r;
   sa.cuts.any_optional = (p.cut_omit_near || p.cut_omit_far || p.cut_omit_in >= 0.0 || p.cut_omit_out >= 0.0
                           || p.cut_midplane_theta != 0.0 || p.cut_midplane_z != 0.0 || p.cut_plane) ? 1 : 0;
+  sa.plasma.fallback_nan = p.fallback_nan;   // (formula mode too: a flagged ray's coefficients are NaN there as well, formula_coefficients.cpp:51-59)
   if (job.simulation) {
     BlPlasmaDevice &pl = sa.plasma;
     pl.d_unit = p.simulation_rho_cgs;                       // simulation_coefficients.cpp:237-239

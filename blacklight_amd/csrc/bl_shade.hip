@@ -460,7 +460,7 @@ __global__ void __launch_bounds__(256, 2) bl_shade_kernel(const BlShadeArgs P) {
       } else {
         const double delta_lambda_cgs = bl_div_g(delta_lambda * P.x_unit, freq * momentum_factor);   // unpolarized.cpp:75-76
         double2 rec = transfer_record(j_val, alpha_val, delta_lambda_cgs);
-        if (kRedo) rec = rec.x == BL_THICK_MARK ? make_double2(0.0, rec.y) : make_double2(rec.x, rec.x * rec.y);   // (a, b) -> (a, c)
+        if (kRedo) rec = rec.x == BL_THICK_MARK ? make_double2(BL_AFFINE_THICK, rec.y) : make_double2(rec.x, rec.x * rec.y);   // (a, b) -> (a, c)
         out[l] = rec;
         if (kRedo && P.tau_inc != nullptr) P.tau_inc[(out - P.transfer) + l] = alpha_val * delta_lambda_cgs;   // unpolarized.cpp:150-151
       }

@@ -256,7 +256,7 @@ __device__ __forceinline__ bool fast_shade_sample(const BlShadeArgs &P, const do
           const double e1 = fastmath::expm1(-delta_tau);
           rec = make_double2(1.0 + e1, -(j_total * fastmath::rcp(alpha_val)) * e1);
         } else {
-          rec = make_double2(0.0, j_total * fastmath::rcp(alpha_val));
+          rec = make_double2(BL_AFFINE_THICK, j_total * fastmath::rcp(alpha_val));
         }
       } else {
         rec = make_double2(1.0, j_total * delta_lambda_cgs);
@@ -628,7 +628,7 @@ __global__ void __launch_bounds__(256, 4) bl_shade_formula_fast_kernel(const BlS
           const double e1 = fastmath::expm1(-delta_tau);
           rec_out = make_double2(1.0 + e1, -(j_val * fastmath::rcp(alpha_val)) * e1);
         } else {
-          rec_out = make_double2(0.0, j_val * fastmath::rcp(alpha_val));
+          rec_out = make_double2(BL_AFFINE_THICK, j_val * fastmath::rcp(alpha_val));
         }
       } else {
         rec_out = make_double2(1.0, j_val * delta_lambda_cgs);

@@ -77,6 +77,7 @@ __global__ void __launch_bounds__(256) bl_transfer_freq_kernel(BlTransferArgs P)
               } else {
                 a = 0.0;
                 c = ss;
+                intensity = 0.0;   // the thick step's intensity replaces what lies behind it, a NaN included (unpolarized.cpp:103-104)
               }
             }
           } else {
@@ -149,13 +150,15 @@ __global__ void __launch_bounds__(256) bl_transfer_kernel(BlTransferArgs P) {
           for (int u = 0; u < 8; u++) ab[u] = rec[(size_t)(n - u) * P.n_nu];
 #pragma unroll
           for (int u = 0; u < 8; u++) {
-            if (kAffine) intensity = __builtin_fma(ab[u].x, intensity, ab[u].y);
+            if (kAffine) intensity = BL_IS_AFFINE_THICK(ab[u].x) ? ab[u].y : __builtin_fma(ab[u].x, intensity, ab[u].y);   // (the thick step, see below)
             else intensity = (ab[u].x == BL_THICK_MARK) ? ab[u].y : ab[u].x * (intensity + ab[u].y);
           }
         }
         for (; n >= 0; n--) {
           double2 ab = rec[(size_t)n * P.n_nu];
-          if (kAffine) intensity = __builtin_fma(ab.x, intensity, ab.y);
+          // (a = -0.0 marks an optically thick step, whose intensity replaces what lies behind it - a NaN included,
+          // unpolarized.cpp:103-104; behind a thin step a NaN stays one, BL_AFFINE_THICK in bl_device.h)
+          if (kAffine) intensity = BL_IS_AFFINE_THICK(ab.x) ? ab.y : __builtin_fma(ab.x, intensity, ab.y);
           else intensity = (ab.x == BL_THICK_MARK) ? ab.y : ab.x * (intensity + ab.y);
         }
       }
@@ -426,16 +429,24 @@ __global__ void __launch_bounds__(256) bl_transfer_quad_kernel(BlTransferArgs P)
 #pragma unroll
         for (int u = 0; u < kBatch; u++) {
           double a = m[u].x, c = m[u].y;
+          // a = -0.0 marks an optically thick step, whose intensity replaces whatever lies behind it - a NaN included (unpolarized.cpp:
+          // 103-104, BL_AFFINE_THICK; a thin step's a may round to +0 and a product of them underflow, behind which a NaN stays a
+          // NaN: hence a flag of its own). A segment that holds a thick step keeps its map; one that does not takes the flag of
+          // what it is composed with.
+          int thick = BL_IS_AFFINE_THICK(a) ? 1 : 0;
 #pragma unroll
           for (int d = 1; d < kLanes; d <<= 1) {
             const double pa = __shfl_up(a, d, kLanes), pc = __shfl_up(c, d, kLanes);   // the map of the d records before this lane's segment
-            if (q >= d) {
+            const int pt = __shfl_up(thick, d, kLanes);
+            if (q >= d && !thick) {
               c = __builtin_fma(a, pc, c);
               a *= pa;
+              thick = pt;
             }
           }
           const double block_a = __shfl(a, kLanes - 1, kLanes), block_c = __shfl(c, kLanes - 1, kLanes);
-          intensity = __builtin_fma(block_a, intensity, block_c);
+          const int block_thick = __shfl(thick, kLanes - 1, kLanes);
+          intensity = block_thick ? block_c : __builtin_fma(block_a, intensity, block_c);
         }
       }
     }

@@ -168,6 +168,27 @@ def test_tolerant_tier_with_power_laws_and_cartesian_grids(seed, built_library):
     assert np.isfinite(exact["image"]).mean() > 0.5 and np.nanmax(exact["image"]) > 0.0
 
 
+@pytest.mark.parametrize("seed", [235, 355, 427, 462, 3, 11])
+def test_tolerant_tier_keeps_the_nan_mask_behind_thick_steps(seed, built_library):
+    """An optically thick step replaces the intensity behind it (unpolarized.cpp:103-104) - a NaN from an off-grid sample farther
+    along the ray included. The tolerant tier's records are affine maps I <- a I + c with a = 0 for such a step, and 0 x NaN is NaN:
+    its transfer kernels (lane per ray, four lanes per ray with composed maps, per-frequency) have to treat a = 0 as the
+    replacement it stands for. Configurations with fallback_nan and thick steps in front of off-grid samples, found by
+    tools/gpu_fuzz_wide.py (its generator is the parity test's); counts, flags and NaN mask against the exact tier."""
+    from test_gpu_parity import _random_configuration
+    base, over, mesh = _random_configuration(seed)
+    fx, params, mock_args = gu.load_case(base)
+    params = dict(params, **over)
+    out = _both(params, dict(mock_args, **mesh) if mock_args is not None else None)
+    exact, tol = out["exact"], out["tolerant"]
+    assert np.array_equal(tol["sample_num"], exact["sample_num"]) and np.array_equal(tol["sample_flags"], exact["sample_flags"])
+    assert np.array_equal(np.isnan(tol["image"]), np.isnan(exact["image"])), over
+    if tol["stats"].arithmetic == 1:
+        assert _distance(tol["image"], exact["image"]) < EXPECTED, over
+    else:
+        assert gu.same_bits(tol["image"], exact["image"]).all()
+
+
 @pytest.mark.parametrize("frequencies,spin", [(1, 0.0), (1, 0.9), (5, 0.0)])
 def test_tolerant_tier_on_a_cartesian_grid_with_thermal_electrons(frequencies, spin, built_library):
     """One block, trilinear sampling, thermal electrons, no auxiliary row - everything the fused kernel asks for except the
