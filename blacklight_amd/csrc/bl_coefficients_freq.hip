@@ -168,6 +168,20 @@ __global__ void bl_debug_math_kernel(int op, long long n, const double *x, const
     case 24: r = fastmath::rsqrt(a); break;
     case 28: r = fastmath::acos(a); break;
     case 29: r = fastmath::atan2(a, b); break;
+    case 30: case 31: case 32: {   // the tolerant tier's Bessel functions K_0, K_1, K_2
+      double k[3];
+      fastmath::bessel_k012(a, &k[0], &k[1], &k[2]);
+      r = k[op - 30];
+      break;
+    }
+    case 33: case 34: case 35: {   // the exact tier's
+      double k[3];
+      bl_cyl_bessel_k012(a, &k[0], &k[1], &k[2]);
+      r = k[op - 33];
+      break;
+    }
+    case 36: r = fastmath::log(a); break;
+    case 37: r = fastmath::pow(a, b); break;
     default: break;
   }
   out[i] = r;

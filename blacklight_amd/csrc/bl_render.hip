@@ -243,7 +243,7 @@ void PlanJob(RenderJob &job) {
   // ... and the per-frequency coefficient kernel of polarized runs (frame, transport and coupling stay exact)
   job.tolerant_polarized = ctx->arithmetic == BL_ARITH_TOLERANT && ctx->polarized;
   // ... and transport matrices (bl_transport_matrix_kernel) instead of the ray-sequential tensor transport, in curved spacetimes
-  job.matrix_transport = job.tolerant_polarized && !p.ray_flat;
+  job.matrix_transport = job.tolerant_polarized && !p.ray_flat && std::getenv("BLACKLIGHT_AMD_TENSOR_TRANSPORT") == nullptr;
   // Several frequencies in the fast path: per-sample factors (BlFreqInputs) instead of per-frequency transfer records,
   // evaluated by bl_transfer_freq_kernel with one lane per ray and frequency
   job.freq_split = job.fast && job.n_nu >= 4 && p.plasma_power_frac == 0.0 && !job.tau_row;   // (the factors are the thermal formulas')
@@ -749,7 +749,7 @@ void BuildShadeArgs(RenderJob &job) {
     sa.grid = ctx->grid_dev;
     sa.lds_table_bytes = ctx->lds_table_bytes;
     sa.undefined_edge = (ctx->undefined_policy & BL_UNDEFINED_EDGE) ? 1 : 0;
-    sa.tolerant = (job.fast || job.tolerant_polarized) ? 1 : 0;
+    sa.tolerant = (job.fast || (job.tolerant_polarized && std::getenv("BLACKLIGHT_AMD_EXACT_POLARIZED_COEFFICIENTS") == nullptr)) ? 1 : 0;
   } else {
     BlFormulaDevice &fm = sa.formula;
     fm.r0 = p.formula_r0; fm.h = p.formula_h; fm.l0 = p.formula_l0; fm.q = p.formula_q; fm.nup = p.formula_nup;

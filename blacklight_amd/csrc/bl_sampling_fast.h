@@ -31,7 +31,9 @@
 #define BL_FAST_WAVES 2
 #endif
 
+#ifndef BLV_NOCONTRACT
 #pragma clang fp contract(fast)
+#endif
 #include "bl_fastmath.h"
 
 // locate_plain_sample() with the tolerant tier's inverse trigonometric functions (bl_fastmath.h: below 1e-15) where the exact tier has
@@ -62,15 +64,43 @@ __device__ __forceinline__ PlainLocated locate_plain_sample_tolerant(const BlSpa
 #define BLC_NAME(f) f##_fast
 #define BLC_SQRT bl_sqrt_g
 #define BLC_SQRT_M bl_sqrt_g
+// (BLV_*: variants for A/B runs that put the exact tier's function back, one at a time - tools/build_variant.sh)
+#ifdef BLV_CBRT
+#define BLC_CBRT bl_cbrt
+#else
 #define BLC_CBRT fastmath::cbrt
+#endif
+#ifdef BLV_EXP
+#define BLC_EXP bl_exp
+#else
 #define BLC_EXP fastmath::exp
+#endif
+#ifdef BLV_EXPM1
+#define BLC_EXPM1 bl_expm1
+#else
 #define BLC_EXPM1 fastmath::expm1
+#endif
+#ifdef BLV_LOG
+#define BLC_LOG bl_log
+#else
 #define BLC_LOG fastmath::log
+#endif
+#ifdef BLV_POW
+#define BLC_POW bl_pow
+#define BLC_POWBASE_T blm_powbase
+#define BLC_POW_BASE bl_pow_base
+#define BLC_POW_OF bl_pow_of
+#else
 #define BLC_POW fastmath::pow
 #define BLC_POWBASE_T fastmath::PowBase
 #define BLC_POW_BASE fastmath::pow_base
 #define BLC_POW_OF fastmath::pow_of
+#endif
+#ifdef BLV_DIV
+#define BLC_DIV_G bl_div_g
+#else
 #define BLC_DIV_G fastmath::div
+#endif
 #define BLC_SIN bl_sin
 #define BLC_COS bl_cos
 #define BLC_TANH bl_tanh

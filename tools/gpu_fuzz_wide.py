@@ -40,12 +40,21 @@ def distance(a, b):
 def main():
     n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 300
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+    polarized = os.environ.get("FUZZ_POLARIZED") is not None   # simulation draws with full-Stokes transfer (tolerant tier: 1e-9)
     bad = []
     worst = 0.0
-    tolerant_ran = chunked = 0
+    tolerant_ran = chunked = amplified = 0
+    spread_ratio = 0.0
     t0 = time.time()
     for seed in range(first, first + n_seeds):
         base, over, mesh = _random_configuration(seed)
+        if polarized:
+            if base != "sim_dp_interp" or over.get("plasma_model") == "code_kappa":
+                continue
+            rng = np.random.default_rng(77000 + seed)
+            over = dict(over, image_polarization="true", image_rotation_split=str(rng.choice(["true", "false"])), camera_resolution=12)
+            if rng.integers(0, 3) == 0:
+                over.update(plasma_kappa_frac=float(rng.uniform(0.05, 0.5)), plasma_kappa=float(rng.uniform(3.55, 4.95)), plasma_w=float(rng.uniform(1.0, 30.0)))
         try:
             fx, params, mock_args = gu.load_case(base)
             params = dict(params, **over)
@@ -78,7 +87,7 @@ def main():
                     chunked += int(again["stats"].launches_shade > exact["stats"].launches_shade)
                     if not (gu.same_bits(again["image"], exact["image"]).all() and np.array_equal(again["sample_num"], exact["sample_num"])):
                         problems.append(f"chunked exact differs ({again['stats'].launches_shade} launches)")
-                    if not np.array_equal(again_tol["sample_num"], tol["sample_num"]) or not distance(again_tol["image"], tol["image"]) < EXPECTED:
+                    if not np.array_equal(again_tol["sample_num"], tol["sample_num"]) or not distance(again_tol["image"], tol["image"]) < (1.0e-9 if polarized else EXPECTED):
                         problems.append(f"chunked tolerant differs {distance(again_tol['image'], tol['image']):.2e}")
             want = oracle_api.render(p.ptr, grid.desc() if grid is not None else None, _capi.RenderDesc, _capi.CameraFrame, n_rays=res * res,
                                      max_steps=int(p.get("ray_max_steps")), n_freq=int(p.get("image_num_frequencies")))
@@ -94,7 +103,23 @@ def main():
                 tolerant_ran += 1
                 d = distance(tol["image"], exact["image"])
                 worst = max(worst, d)
-                if not d < EXPECTED:
+                if polarized and not d < 1.0e-9:
+                    # The reference's polarized step amplifies last-place differences of its elementary functions in some
+                    # configurations (optically and Faraday thick steps): measured here as the distance between the oracle with the
+                    # pinned math library and the same oracle with the host's libm - the reference against itself. The tolerant
+                    # tier has to stay within a small multiple of that, row by row.
+                    other = oracle_api.render(p.ptr, grid.desc(), _capi.RenderDesc, _capi.CameraFrame, n_rays=res * res, variant="libm",
+                                              max_steps=int(p.get("ray_max_steps")), n_freq=int(p.get("image_num_frequencies")))
+                    if np.array_equal(other["sample_num"], want["sample_num"]):
+                        rows_tol = [distance(tol["image"][r:r + 1], exact["image"][r:r + 1]) for r in range(exact["image"].shape[0])]
+                        rows_ref = [distance(other["image"][r:r + 1], want["image"][r:r + 1]) for r in range(exact["image"].shape[0])]
+                        ratio = max(t / max(f, 1.0e-11) for t, f in zip(rows_tol, rows_ref))
+                        spread_ratio = max(spread_ratio, ratio)
+                        amplified += 1
+                        if ratio > 30.0:
+                            problems.append(f"tolerant distance {d:.2e}, {ratio:.1f} x the reference's own spread between math libraries")
+                    # (different sample counts between the two oracles: glibc's hypot / pow move steps of spinning rays - no measure)
+                elif not polarized and not d < EXPECTED:
                     problems.append(f"tolerant distance {d:.2e}")
             elif not gu.same_bits(tol["image"], exact["image"]).all():
                 problems.append("tolerant tier fell back to exact kernels but differs")
@@ -106,7 +131,7 @@ def main():
             print(f"seed {seed}: raised {type(exc).__name__}: {exc} base {base} mesh {mesh} {json.dumps(over)}", flush=True)
         if (seed - first) % 25 == 24:
             print(f"... {seed - first + 1} seeds, {len(bad)} findings, worst tolerant distance {worst:.2e}, {time.time() - t0:.0f} s", flush=True)
-    print(json.dumps(dict(seeds=n_seeds, first=first, findings=bad, worst_tolerant_distance=worst, tolerant_ran=tolerant_ran, chunked=chunked,
+    print(json.dumps(dict(seeds=n_seeds, first=first, findings=bad, worst_tolerant_distance=worst, tolerant_ran=tolerant_ran, chunked=chunked, amplified=amplified, worst_ratio_to_reference_spread=spread_ratio,
                           seconds=round(time.time() - t0, 1))))
 
 
