@@ -431,22 +431,18 @@ __global__ void __launch_bounds__(256) bl_transfer_quad_kernel(BlTransferArgs P)
           double a = m[u].x, c = m[u].y;
           // a = -0.0 marks an optically thick step, whose intensity replaces whatever lies behind it - a NaN included (unpolarized.cpp:
           // 103-104, BL_AFFINE_THICK; a thin step's a may round to +0 and a product of them underflow, behind which a NaN stays a
-          // NaN: hence a flag of its own). A segment that holds a thick step keeps its map; one that does not takes the flag of
-          // what it is composed with.
-          int thick = BL_IS_AFFINE_THICK(a) ? 1 : 0;
+          // NaN). A segment that holds a thick step keeps its map; the sign of a product carries the mark of what a segment without
+          // one is composed with (every other a is positive or +0), so the sign bit of a is the flag at every stage of the scan.
 #pragma unroll
           for (int d = 1; d < kLanes; d <<= 1) {
             const double pa = __shfl_up(a, d, kLanes), pc = __shfl_up(c, d, kLanes);   // the map of the d records before this lane's segment
-            const int pt = __shfl_up(thick, d, kLanes);
-            if (q >= d && !thick) {
+            if (q >= d && !BL_IS_AFFINE_THICK(a)) {
               c = __builtin_fma(a, pc, c);
               a *= pa;
-              thick = pt;
             }
           }
           const double block_a = __shfl(a, kLanes - 1, kLanes), block_c = __shfl(c, kLanes - 1, kLanes);
-          const int block_thick = __shfl(thick, kLanes - 1, kLanes);
-          intensity = block_thick ? block_c : __builtin_fma(block_a, intensity, block_c);
+          intensity = BL_IS_AFFINE_THICK(block_a) ? block_c : __builtin_fma(block_a, intensity, block_c);
         }
       }
     }
