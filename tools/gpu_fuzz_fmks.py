@@ -1,0 +1,98 @@
+#!/usr/bin/env python3
+"""Randomised cameras over the FMKS fixture (tests/golden/reader/iharm3d_fmks.h5): reader, the FMKS branch of the locate kernel
+and the rest of the path in both tiers, the exact tier against the CPU oracle bit for bit (a tool, not a test).
+The fixture's polar cut stays on - without it the reference reads past its arrays in the last polar zone -
+with its angle drawn.     python3 tools/gpu_fuzz_fmks.py [n_seeds] [first_seed]"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tests"))
+
+import blacklight_amd as bl          # noqa: E402
+from blacklight_amd import _capi     # noqa: E402
+import golden_util as gu             # noqa: E402
+import oracle_api                    # noqa: E402
+
+READER_DIR = os.path.join(gu.GOLDEN_DIR, "reader")
+
+
+def main():
+    n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    fx = np.load(os.path.join(READER_DIR, "expected_fmks.npz"), allow_pickle=False)
+    bad = []
+    worst = 0.0
+    refused = 0
+    t0 = time.time()
+    for seed in range(first, first + n_seeds):
+        rng = np.random.default_rng(616000 + seed)
+        params = json.loads(str(fx[str(rng.choice(["interp", "nearest"])) + "_params"]))
+        params["simulation_file"] = os.path.join(READER_DIR, "iharm3d_fmks.h5")
+        res = int(rng.choice([12, 16, 20]))
+        params.update(camera_resolution=res, camera_th=float(rng.uniform(20.0, 160.0)), camera_ph=float(rng.uniform(0.0, 360.0)),
+                      camera_r=float(rng.uniform(20.0, 80.0)), camera_width=float(rng.uniform(8.0, 40.0)), camera_rotation=float(rng.uniform(-90.0, 90.0)),
+                      camera_type=str(rng.choice(["plane", "pinhole"])), cut_midplane_theta=float(rng.uniform(20.0, 45.0)),
+                      image_tau=str(rng.choice(["true", "false"])), image_num_frequencies=int(rng.choice([1, 1, 3])),
+                      cut_sigma_max=float(rng.choice([-1.0, 1.0])), plasma_rat_high=float(rng.uniform(3.0, 40.0)),
+                      fallback_nan=str(rng.choice(["true", "false"])), fallback_rho=1.0e-6, fallback_pgas=1.0e-8)
+        if params["camera_type"] == "pinhole":
+            params["camera_width"] = float(rng.uniform(0.05, 0.4)) * params["camera_r"]
+        if params["image_num_frequencies"] > 1:
+            params.update(image_frequency_start=1.0e11, image_frequency_end=float(10.0 ** rng.uniform(11.3, 12.0)), image_frequency_spacing="log")
+        try:
+            p = bl.Params.from_dict(params)
+            problems = []
+            with bl.Context(p) as ctx:
+                with bl.Snapshot(p) as snap:
+                    ctx.set_grid(snap)
+                    try:
+                        want = oracle_api.render(p.ptr, snap.desc(), _capi.RenderDesc, _capi.CameraFrame, n_rays=res * res, max_steps=int(p.get("ray_max_steps")),
+                                                 n_freq=int(p.get("image_num_frequencies")))
+                    except RuntimeError as exc:
+                        if "reads past" not in str(exc):
+                            raise
+                        want = None   # a sample where the reference reads past its arrays: the library has to refuse as well
+                try:
+                    exact = ctx.render()
+                except bl.BlacklightError as exc:
+                    if "no defined result" in str(exc) and want is None:
+                        refused += 1
+                        continue
+                    raise
+                if want is None:
+                    raise RuntimeError("the oracle refused an undefined read, the library rendered the frame")
+                ctx.set_arithmetic("tolerant")
+                tol = ctx.render()
+            if not (np.array_equal(exact["sample_num"], want["sample_num"]) and np.array_equal(exact["sample_flags"], want["sample_flags"])):
+                problems.append("oracle counts / flags")
+            if not gu.same_bits(exact["image"], want["image"]).all():
+                problems.append("oracle image")
+            if not np.array_equal(tol["sample_num"], exact["sample_num"]) or not np.array_equal(np.isnan(tol["image"]), np.isnan(exact["image"])):
+                problems.append("tolerant counts / NaN mask")
+            with np.errstate(invalid="ignore"):
+                scale = np.nanmax(np.abs(np.where(np.isfinite(exact["image"]), exact["image"], np.nan)), axis=-1, keepdims=True)
+                scale = np.where(np.isfinite(scale) & (scale > 0), scale, 1.0)
+                d = np.abs(tol["image"] - exact["image"]) / scale
+            d = float(np.nanmax(d)) if np.isfinite(d).any() else 0.0
+            worst = max(worst, d)
+            if not d < 1.0e-11:
+                problems.append(f"tolerant distance {d:.2e}")
+            if problems:
+                bad.append(seed)
+                print(f"seed {seed}: {problems} " + json.dumps({k: params[k] for k in params if k.startswith(("camera", "cut_mid", "image_tau", "image_num", "fallback_nan", "simulation_interp"))}), flush=True)
+        except Exception as exc:   # noqa: BLE001
+            bad.append(seed)
+            print(f"seed {seed}: raised {type(exc).__name__}: {exc}", flush=True)
+        if (seed - first) % 10 == 9:
+            print(f"... {seed - first + 1} seeds, {len(bad)} findings, {refused} refused, {time.time() - t0:.0f} s", flush=True)
+    print(json.dumps(dict(seeds=n_seeds, first=first, findings=bad, refused=refused, worst_tolerant_distance=worst, seconds=round(time.time() - t0, 1))))
+
+
+if __name__ == "__main__":
+    main()

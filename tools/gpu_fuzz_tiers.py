@@ -124,7 +124,21 @@ def main():
                 exact = ctx.render()
                 ctx.set_arithmetic("tolerant")
                 tol = ctx.render()
+                subset = None
+                if seed % 4 == 0:   # a shuffled subset of the pixels (what a rank of a tiled job renders): the same bits, pixel by pixel
+                    rng = np.random.default_rng(99000 + seed)
+                    n_all = exact["sample_num"].size
+                    subset = rng.permutation(n_all)[: int(rng.integers(1, n_all + 1))].astype(np.int32)
+                    part_tol = ctx.render(pixel_map=subset)
+                    ctx.set_arithmetic("exact")
+                    part = ctx.render(pixel_map=subset)
             problems = []
+            if subset is not None:
+                for name, got, full in (("exact", part, exact), ("tolerant", part_tol, tol)):
+                    if not (gu.same_bits(got["image"], full["image"][:, subset]).all() and np.array_equal(got["sample_num"], full["sample_num"][subset])
+                            and np.array_equal(got["sample_flags"], full["sample_flags"][subset])):
+                        problems.append(f"{name} tier: a subset of {subset.size} pixels differs from the full frame "
+                                        f"({distance(got['image'], full['image'][:, subset]):.2e})")
             if not np.array_equal(tol["sample_num"], exact["sample_num"]):
                 problems.append("sample_num")
             if not np.array_equal(tol["sample_flags"], exact["sample_flags"]):
