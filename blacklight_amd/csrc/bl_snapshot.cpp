@@ -385,6 +385,7 @@ std::vector<int32_t> DecodeInts(const RawArray &raw, std::vector<uint64_t> *dims
   std::vector<uint64_t> dims = Dimensions(raw.dataspace);
   if (dims.size() > 2) Fail("Unexpected HDF5 fixed-point array size.");
   const uint64_t count = Product(dims);
+  raw.data.At(0, count * t.size);   // the elements have to be there before anything is sized after them
   std::vector<int32_t> values(count);
   for (uint64_t n = 0; n < count; n++)
     values[n] = t.size == 4 ? Element<int32_t>(raw.data, n, big_endian)
@@ -413,6 +414,7 @@ std::vector<float> DecodeFloats(const RawArray &raw, std::vector<uint64_t> *dims
   if (dims_out != nullptr) *dims_out = dims;
   std::vector<float> owned;
   float *dst = into;
+  raw.data.At(0, count * sizeof(float));   // (as in DecodeInts)
   if (into == nullptr) {
     owned.resize(count);
     dst = owned.data();
@@ -441,6 +443,7 @@ std::vector<double> DecodeDoubles(const RawArray &raw) {
       || d.Get<uint8_t>(13) != 11 || d.Get<uint8_t>(14) != 0 || d.Get<uint8_t>(15) != 52 || d.Get<uint32_t>(16) != 1023)
     Fail("Unexpected HDF5 double-precision floating-point bit layout.");
   const uint64_t count = Product(Dimensions(raw.dataspace));
+  raw.data.At(0, count * sizeof(double));   // (as in DecodeInts)
   std::vector<double> values(count);
   for (uint64_t n = 0; n < count; n++) values[n] = Element<double>(raw.data, n, big_endian);
   return values;
@@ -452,6 +455,7 @@ std::vector<std::string> DecodeStrings(const RawArray &raw) {
   if ((t.bits0 >> 4) != 0) Fail("Unexpected HDF5 string encoding.");   // ASCII
   std::vector<uint64_t> dims = Dimensions(raw.dataspace);
   if (dims.size() != 1) Fail("Unexpected HDF5 string array size.");
+  if (t.size == 0 || dims[0] > raw.data.size / t.size) Fail("Unexpected end of HDF5 file.");   // (sized after what is stored)
   std::vector<std::string> strings(dims[0]);
   for (uint64_t n = 0; n < dims[0]; n++) {
     const char *s = reinterpret_cast<const char *>(raw.data.At(n * t.size, t.size));

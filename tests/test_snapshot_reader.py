@@ -186,6 +186,36 @@ def test_malformed_files(built_library, expected, tmp_path):
         Snapshot(_params(expected, simulation_file=str(empty)))
 
 
+def test_athdf_reader_sizes_nothing_after_a_damaged_count(expected, tmp_path):
+    """Every 8-byte field of the file's first 12 KiB (superblock, object headers, dataspace dimensions, attribute counts) in turn
+    replaced by 2^40 + 5: the file is read as before or refused with an error text - the decoder sizes its arrays after what
+    the file holds, never after a count alone (a robustness sweep over mutated files, tools/fuzz_snapshot_reader.py under
+    AddressSanitizer, found two counts that were allocated first and checked afterwards)."""
+    import resource
+    import time
+    data = np.fromfile(os.path.join(READER_DIR, "series_0003.athdf"), dtype=np.uint8)
+    path = str(tmp_path / "damaged.athdf")
+    soft, hard = resource.getrlimit(resource.RLIMIT_AS)
+    resource.setrlimit(resource.RLIMIT_AS, (8 << 30, hard))   # a terabyte-sized request fails at once instead of being tried
+    try:
+        refused = read = 0
+        t0 = time.time()
+        for at in range(0, 12 * 1024, 8):
+            damaged = data.copy()
+            damaged[at:at + 8] = np.frombuffer(((1 << 40) + 5).to_bytes(8, "little"), dtype=np.uint8)
+            damaged.tofile(path)
+            try:
+                with Snapshot(_params(expected, simulation_file=path)):
+                    read += 1
+            except BlacklightError as exc:
+                assert str(exc).startswith("Error: "), str(exc)
+                assert "alloc" not in str(exc).lower(), (at, str(exc))
+                refused += 1
+        assert refused > 20 and read > 20 and time.time() - t0 < 120.0
+    finally:
+        resource.setrlimit(resource.RLIMIT_AS, (soft, hard))
+
+
 # ---------------------------------------------------------------------------------------------- AthenaK dumps
 @pytest.fixture(scope="module")
 def athenak():
