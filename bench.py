@@ -124,13 +124,15 @@ def launch_ranks(n_gpus, argv):
 
 
 def kernel_source_hash():
-    """Hash of the sources the library is built from (blacklight_amd/csrc): profiles/hbm_traffic.json carries the hash of
-    the tree its counters were measured on, and the bench line says when the two differ."""
+    """Hash of the sources the kernels and their launches are built from (blacklight_amd/csrc: every .hip file - kernels, planning
+    and launch code - and every header; not the host-only readers, parser, writers and command line, which cannot move a kernel's
+    traffic): profiles/hbm_traffic.json carries the hash of the tree its counters were measured on, and the bench line says when
+    the two differ."""
     import hashlib
     csrc = os.path.join(REPO, "blacklight_amd", "csrc")
     digest = hashlib.sha256()
     for name in sorted(os.listdir(csrc)):
-        if name.endswith((".hip", ".h", ".inc", ".cpp")):
+        if name.endswith((".hip", ".h", ".inc")):
             with open(os.path.join(csrc, name), "rb") as f:
                 digest.update(name.encode() + b"\0" + f.read())
     return digest.hexdigest()[:16]
