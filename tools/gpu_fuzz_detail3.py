@@ -17,8 +17,8 @@ for seed in [int(s) for s in sys.argv[1:]]:
     fx, params, mock_args = gu.load_case(base)
     params = dict(params, **over)
     p = bl.Params.from_dict(params)
-    for switch in ("", "BLACKLIGHT_AMD_TENSOR_TRANSPORT", "BLACKLIGHT_AMD_EXACT_POLARIZED_COEFFICIENTS"):
-        for name in ("BLACKLIGHT_AMD_TENSOR_TRANSPORT", "BLACKLIGHT_AMD_EXACT_POLARIZED_COEFFICIENTS"):
+    for switch in ("", "BLACKLIGHT_AMD_TENSOR_TRANSPORT", "BLACKLIGHT_AMD_TOLERANT_POLARIZED_COEFFICIENTS"):
+        for name in ("BLACKLIGHT_AMD_TENSOR_TRANSPORT", "BLACKLIGHT_AMD_TOLERANT_POLARIZED_COEFFICIENTS"):
             os.environ.pop(name, None)
         if switch:
             os.environ[switch] = "1"
