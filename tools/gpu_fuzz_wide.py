@@ -43,7 +43,7 @@ def main():
     polarized = os.environ.get("FUZZ_POLARIZED") is not None   # simulation draws with full-Stokes transfer (tolerant tier: 1e-9)
     bad = []
     worst = 0.0
-    tolerant_ran = chunked = amplified = 0
+    tolerant_ran = chunked = amplified = refined = 0
     spread_ratio = 0.0
     t0 = time.time()
     for seed in range(first, first + n_seeds):
@@ -55,6 +55,14 @@ def main():
             over = dict(over, image_polarization="true", image_rotation_split=str(rng.choice(["true", "false"])), camera_resolution=12)
             if rng.integers(0, 3) == 0:
                 over.update(plasma_kappa_frac=float(rng.uniform(0.05, 0.5)), plasma_kappa=float(rng.uniform(3.55, 4.95)), plasma_w=float(rng.uniform(1.0, 30.0)))
+        adaptive = os.environ.get("FUZZ_ADAPTIVE") is not None and not polarized
+        if adaptive:
+            rng_a = np.random.default_rng(55000 + seed)
+            over = dict(over, camera_resolution=int(rng_a.choice([16, 24])), adaptive_max_level=int(rng_a.integers(1, 3)), adaptive_block_size=int(rng_a.choice([4, 8])),
+                        adaptive_frequency_num=1, adaptive_val_cut=0.0, adaptive_val_frac=-1.0, adaptive_abs_grad_cut=0.0, adaptive_abs_grad_frac=-1.0,
+                        adaptive_rel_grad_cut=float(rng_a.uniform(0.05, 0.5)), adaptive_rel_grad_frac=float(rng_a.choice([0.1, 0.25, 0.5])),
+                        adaptive_abs_lapl_cut=0.0, adaptive_abs_lapl_frac=-1.0, adaptive_rel_lapl_cut=float(rng_a.uniform(0.2, 2.0)),
+                        adaptive_rel_lapl_frac=float(rng_a.choice([-1.0, 0.25])), adaptive_num_regions=0)
         try:
             fx, params, mock_args = gu.load_case(base)
             params = dict(params, **over)
@@ -89,6 +97,18 @@ def main():
                         problems.append(f"chunked exact differs ({again['stats'].launches_shade} launches)")
                     if not np.array_equal(again_tol["sample_num"], tol["sample_num"]) or not distance(again_tol["image"], tol["image"]) < (1.0e-9 if polarized else EXPECTED):
                         problems.append(f"chunked tolerant differs {distance(again_tol['image'], tol['image']):.2e}")
+                if adaptive:   # refined levels (exact tier): every level's rays against the oracle's for the same block list
+                    ctx.set_arithmetic("exact")
+                    ctx.set_scratch_limit(144 << 30)
+                    levels = ctx.render_adaptive()
+                    refined += int(len(levels) > 1)
+                    bs = int(p.get("adaptive_block_size"))
+                    for level, lv in enumerate(levels[1:], start=1):
+                        w = oracle_api.render(p.ptr, grid.desc() if grid is not None else None, _capi.RenderDesc, _capi.CameraFrame,
+                                              n_rays=lv["block_locs"].shape[0] * bs * bs, level=level, block_locs=lv["block_locs"],
+                                              max_steps=int(p.get("ray_max_steps")), n_freq=int(p.get("image_num_frequencies")))
+                        if not (np.array_equal(lv["sample_num"], w["sample_num"]) and gu.same_bits(lv["image"], w["image"]).all()):
+                            problems.append(f"adaptive level {level} ({lv['block_locs'].shape[0]} blocks) differs from the oracle")
             want = oracle_api.render(p.ptr, grid.desc() if grid is not None else None, _capi.RenderDesc, _capi.CameraFrame, n_rays=res * res,
                                      max_steps=int(p.get("ray_max_steps")), n_freq=int(p.get("image_num_frequencies")))
             if not np.array_equal(exact["sample_num"], want["sample_num"]) or not np.array_equal(exact["sample_flags"], want["sample_flags"]):
@@ -131,7 +151,7 @@ def main():
             print(f"seed {seed}: raised {type(exc).__name__}: {exc} base {base} mesh {mesh} {json.dumps(over)}", flush=True)
         if (seed - first) % 25 == 24:
             print(f"... {seed - first + 1} seeds, {len(bad)} findings, worst tolerant distance {worst:.2e}, {time.time() - t0:.0f} s", flush=True)
-    print(json.dumps(dict(seeds=n_seeds, first=first, findings=bad, worst_tolerant_distance=worst, tolerant_ran=tolerant_ran, chunked=chunked, amplified=amplified, worst_ratio_to_reference_spread=spread_ratio,
+    print(json.dumps(dict(seeds=n_seeds, first=first, findings=bad, worst_tolerant_distance=worst, tolerant_ran=tolerant_ran, chunked=chunked, amplified=amplified, refined=refined, worst_ratio_to_reference_spread=spread_ratio,
                           seconds=round(time.time() - t0, 1))))
 
 
