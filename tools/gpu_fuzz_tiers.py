@@ -54,6 +54,8 @@ def draw(seed):
     rng = np.random.default_rng(424200 + seed)
     _, params, _ = gu.load_case("sim_dp_interp")
     res = int(rng.choice([16, 24, 33]))
+    if os.environ.get("FUZZ_RES"):   # larger frames: many waves, refills of the persistent kernel, record blocks, the reservation gate
+        res = int(rng.choice([int(v) for v in os.environ["FUZZ_RES"].split(",")]))
     over = dict(camera_resolution=res, camera_th=float(rng.uniform(3.0, 177.0)), camera_ph=float(rng.uniform(0.0, 360.0)),
                 camera_r=float(rng.uniform(25.0, 110.0)), camera_width=float(rng.uniform(6.0, 45.0)),
                 camera_type=str(rng.choice(["plane", "pinhole"])),
@@ -119,11 +121,33 @@ def main():
             continue
         try:
             p = bl.Params.from_dict(params)
+            chunk_problems = []
             with bl.Context(p) as ctx:
                 ctx.set_grid(grid)
                 exact = ctx.render()
                 ctx.set_arithmetic("tolerant")
                 tol = ctx.render()
+                if os.environ.get("FUZZ_CHUNKS") and seed % 2 == 0:   # the same frames under a scratch limit of several chunks: same bits
+                    limit = int(max(exact["stats"].n_samples, 1) * 40 + (1 << 20))
+                    while True:
+                        ctx.set_scratch_limit(limit)
+                        try:
+                            tol_chunked = ctx.render()
+                            ctx.set_arithmetic("exact")
+                            exact_chunked = ctx.render()
+                            break
+                        except bl.BlacklightError as exc:
+                            if "Scratch budget too small" not in str(exc):
+                                raise
+                            ctx.set_arithmetic("tolerant")
+                            limit *= 4
+                    ctx.set_scratch_limit(144 << 30)
+                    ctx.set_arithmetic("tolerant")
+                    if not (gu.same_bits(exact_chunked["image"], exact["image"]).all() and np.array_equal(exact_chunked["sample_num"], exact["sample_num"])):
+                        chunk_problems.append(f"exact tier in {exact_chunked['stats'].n_chunks} chunks differs")
+                    if not (np.array_equal(tol_chunked["sample_num"], tol["sample_num"]) and distance(tol_chunked["image"], tol["image"]) < EXPECTED
+                            and np.array_equal(np.isnan(tol_chunked["image"]), np.isnan(tol["image"]))):
+                        chunk_problems.append(f"tolerant tier in {tol_chunked['stats'].n_chunks} chunks differs {distance(tol_chunked['image'], tol['image']):.2e}")
                 subset = None
                 if seed % 4 == 0:   # a shuffled subset of the pixels (what a rank of a tiled job renders): the same bits, pixel by pixel
                     rng = np.random.default_rng(99000 + seed)
@@ -132,7 +156,7 @@ def main():
                     part_tol = ctx.render(pixel_map=subset)
                     ctx.set_arithmetic("exact")
                     part = ctx.render(pixel_map=subset)
-            problems = []
+            problems = list(chunk_problems)
             if subset is not None:
                 for name, got, full in (("exact", part, exact), ("tolerant", part_tol, tol)):
                     if not (gu.same_bits(got["image"], full["image"][:, subset]).all() and np.array_equal(got["sample_num"], full["sample_num"][subset])
