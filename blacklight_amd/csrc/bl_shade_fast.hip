@@ -274,9 +274,12 @@ __device__ __forceinline__ bool fast_shade_sample(const BlShadeArgs &P, const do
 // against the interpolated value (large next to empty cells) - which the conversion to float hides, unless a sum lies that close to
 // the midpoint of two floats, where the two could round apart and move a primitive by 6e-8: then the function returns true and the
 // sample is left to the exact kernel. The midpoint is where the 29 bits below a float's precision read 2^28; the window around it
-// is 8 192 units = 9e-13 of the value (3e-5 of all values: a few 1e-4 of the samples go to the exact pass). A randomised sweep at
-// 256^2 ... 512^2 (tools/gpu_fuzz_tiers.py) found one pixel in 6.5 million at 1.3e-10 with the earlier window of 64 units for
-// density and pressure; what remains possible beyond the window is that same effect, one float's last place in one sample.
+// is 2 048 units (2e-13 of the value) for the positive sums of density and pressure, 4 096 for the components of velocity and field,
+// whose terms may cancel (a sum that is a 500th of its terms or less is a component that small beside the others: a unit of its float
+// precision is 1e-10 of the vector); 1e-4 of the samples go to the exact pass. A randomised sweep at 256^2 ... 512^2
+// (tools/gpu_fuzz_tiers.py) found one pixel in 6.5 million at 1.3e-10 with the earlier 64 units for density and pressure; 8 192 units
+// for everything cost 0.35 ms per frame in the exact pass and found nothing more. What remains possible beyond the window is that
+// same effect: one float's last place in one sample.
 __device__ __forceinline__ bool gather_finish_tolerant(const BlShadeArgs &P, float fallback_rho, float fallback_pgas, int status, const float4 (&lo)[8],
                                                        const float4 (&hi)[8], double f_i, double f_j, double f_k, float pr[8]) {
   const BlPlasmaDevice &pl = P.plasma;
@@ -303,7 +306,7 @@ __device__ __forceinline__ bool gather_finish_tolerant(const BlShadeArgs &P, flo
 #pragma unroll
     for (int q = 0; q < 8; q++) {
       const uint32_t below = (uint32_t)__double_as_longlong(val[q]) & 0x1fffffffu;
-      const uint32_t window = 8192u;
+      const uint32_t window = q < 2 ? 2048u : 4096u;
       near_midpoint = near_midpoint || (below - (0x10000000u - window)) <= 2u * window;
     }
     if (val[0] <= 0.0) val[0] = (double)first[0];   // :822-825
