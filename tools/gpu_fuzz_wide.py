@@ -55,6 +55,8 @@ def main():
             over = dict(over, image_polarization="true", image_rotation_split=str(rng.choice(["true", "false"])), camera_resolution=12)
             if rng.integers(0, 3) == 0:
                 over.update(plasma_kappa_frac=float(rng.uniform(0.05, 0.5)), plasma_kappa=float(rng.uniform(3.55, 4.95)), plasma_w=float(rng.uniform(1.0, 30.0)))
+        if os.environ.get("FUZZ_RES") and not polarized:   # larger frames: many waves, several chunks, refills of the persistent kernel
+            over = dict(over, camera_resolution=int(np.random.default_rng(66000 + seed).choice([int(v) for v in os.environ["FUZZ_RES"].split(",")])))
         adaptive = os.environ.get("FUZZ_ADAPTIVE") is not None and not polarized
         if adaptive:
             rng_a = np.random.default_rng(55000 + seed)
