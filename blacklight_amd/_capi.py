@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# BLACKLIGHT_AMD_LIB: another build of the same library (kernel A/B runs, tools/gpu_variants.sh)
+# BLACKLIGHT_AMD_LIB: another build of the same library (kernel A/B runs, tools/gpu_ab.sh)
 LIB_PATH = os.environ.get("BLACKLIGHT_AMD_LIB") or os.path.join(_HERE, "libblacklight_amd.so")
 
 BL_OK, BL_E_INPUT, BL_E_MISSING, BL_E_UNSUPPORTED, BL_E_DEVICE, BL_E_ARG, BL_E_STATE = range(7)
@@ -46,6 +46,11 @@ class RenderDesc(C.Structure):
     ]
 
 
+# BL_SWITCH_* of include/blacklight_amd.h: measurement switches (bl_stats.switches, bl_debug_set_switches)
+SWITCHES = {name: 1 << bit for bit, name in enumerate(
+    ["TENSOR_TRANSPORT", "SPLIT_RECORDS", "RECORD_EVERY_STEP", "TOLERANT_POLARIZED_COEFFICIENTS", "GENERAL_LOCATE", "LANE_TRANSFER",
+     "NO_FUSED_LOCATE", "GENERAL_FUSED", "SAMPLE_RECORDS"])}
+
 BL_MAX_LEVELS = 16
 
 
@@ -70,6 +75,7 @@ class Stats(C.Structure):
         ("launches_transfer", C.c_int32),
         ("ms_locate", C.c_float), ("ms_wall", C.c_float), ("launches_locate", C.c_int32),
         ("arithmetic", C.c_int32), ("n_deferred", C.c_int64), ("n_undefined", C.c_int64),
+        ("switches", C.c_uint32), ("fused_variant", C.c_int32),
     ]
 
 
@@ -103,6 +109,7 @@ def lib():
     L.bl_device_count.restype = C.c_int
     L.bl_set_undefined_policy.argtypes = [C.c_void_p, C.c_int]
     L.bl_debug_set_guard_band.argtypes = [C.c_void_p, C.c_double]
+    L.bl_debug_set_switches.argtypes = [C.c_void_p, C.c_uint32]
     L.bl_debug_math.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
     L.bl_render.argtypes = [C.c_void_p, C.POINTER(RenderDesc)]
     L.bl_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]

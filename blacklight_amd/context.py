@@ -105,6 +105,14 @@ class Context:
         """"exact" (default) or "tolerant": arithmetic tier of the coefficient kernel (bl_set_arithmetic)."""
         self._check(self._lib.bl_set_arithmetic(self._ctx, {"exact": 0, "tolerant": 1}[mode]))
 
+    def debug_set_switches(self, *names):
+        """Measurement switches of this context by name (_capi.SWITCHES: "RECORD_EVERY_STEP", "GENERAL_FUSED", ...); none: all off.
+        They select another kernel or layout with the same results (bl_stats.switches echoes them)."""
+        mask = 0
+        for name in names:
+            mask |= _capi.SWITCHES[name]
+        self._check(self._lib.bl_debug_set_switches(self._ctx, mask))
+
     def debug_set_guard_band(self, relative_width):
         self._check(self._lib.bl_debug_set_guard_band(self._ctx, float(relative_width)))
 

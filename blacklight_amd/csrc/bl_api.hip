@@ -344,6 +344,18 @@ int bl_init(const bl_params *p, int device, bl_ctx **out) {
   *out = nullptr;
   bl_ctx *ctx = new bl_ctx();
   ctx->params = *p;
+  {   // measurement switches: the environment is read here and nowhere else (getenv is not safe beside a setenv in another thread)
+    const struct { const char *name; unsigned int bit; } kSwitches[] = {
+        {"BLACKLIGHT_AMD_TENSOR_TRANSPORT", BL_SWITCH_TENSOR_TRANSPORT}, {"BLACKLIGHT_AMD_SPLIT_RECORDS", BL_SWITCH_SPLIT_RECORDS},
+        {"BLACKLIGHT_AMD_RECORD_EVERY_STEP", BL_SWITCH_RECORD_EVERY_STEP},
+        {"BLACKLIGHT_AMD_TOLERANT_POLARIZED_COEFFICIENTS", BL_SWITCH_TOLERANT_POLARIZED_COEFFICIENTS},
+        {"BLACKLIGHT_AMD_GENERAL_LOCATE", BL_SWITCH_GENERAL_LOCATE}, {"BLACKLIGHT_AMD_LANE_TRANSFER", BL_SWITCH_LANE_TRANSFER},
+        {"BLACKLIGHT_AMD_NO_FUSED_LOCATE", BL_SWITCH_NO_FUSED_LOCATE}, {"BLACKLIGHT_AMD_GENERAL_FUSED", BL_SWITCH_GENERAL_FUSED},
+        {"BLACKLIGHT_AMD_SAMPLE_RECORDS", BL_SWITCH_SAMPLE_RECORDS}};
+    for (const auto &sw : kSwitches)
+      if (std::getenv(sw.name) != nullptr) ctx->switches |= sw.bit;
+    ctx->debug_counters = std::getenv("BLACKLIGHT_AMD_DEBUG_COUNTERS") != nullptr;
+  }
   try {
     ValidateGeodesic(ctx);
     ValidateRadiation(ctx);
@@ -519,10 +531,22 @@ void UploadMergedGrid(bl_ctx *ctx, const bl_grid_desc *g) {
         dev.cell_inv_w[a] = even ? 1.0 / width : 0.0;
         if (even) dev.uniform_mask |= 1 << a;
       }
+      if (a == 0) {   // radial faces evenly spaced in log r? (bl_shade_fused2_kernel guesses the cell from log2 r and confirms it by the faces)
+        dev.r_face_in = xf[0][0];
+        dev.r_face_out = xf[0][n[0]];
+        bool even = xf[0][0] > 0.0 && xf[0][n[0]] > xf[0][0];
+        const double l0 = even ? std::log2(xf[0][0]) : 0.0, width = even ? (std::log2(xf[0][n[0]]) - l0) / n[0] : 1.0;
+        for (int c = 0; c <= n[0] && even; c++) even = std::abs(std::log2(xf[0][c]) - (l0 + c * width)) <= 1.0e-4 * width;
+        dev.log_uniform = even ? 1 : 0;
+        dev.log_l0 = static_cast<float>(l0);
+        dev.log_inv_w = static_cast<float>(1.0 / width);
+      }
       dev.n_bucket[a] = n_bucket;
       off_b[a] = buckets.size();
       buckets.insert(buckets.end(), table.begin(), table.end());
     }
+    // theta from pole to pole and phi all the way round: no sample is off the grid in angle
+    dev.full_sphere = (xf[1][0] <= 0.0 && xf[1][n[1]] >= kPi && xf[2][0] <= 0.0 && xf[2][n[2]] >= 2.0 * kPi) ? 1 : 0;
     ctx->d_buckets.Ensure(buckets.size());
     Check(hipMemcpy(ctx->d_buckets.ptr, buckets.data(), buckets.size() * sizeof(unsigned short), hipMemcpyHostToDevice), "bucket upload");
     dev.cells = d_cells.ptr;
@@ -831,6 +855,12 @@ int bl_set_undefined_policy(bl_ctx *ctx, int policy) {
 int bl_set_arithmetic(bl_ctx *ctx, int mode) {
   if (ctx == nullptr || (mode != BL_ARITH_EXACT && mode != BL_ARITH_TOLERANT)) return BL_E_ARG;
   ctx->arithmetic = mode;
+  return BL_OK;
+}
+
+int bl_debug_set_switches(bl_ctx *ctx, uint32_t switches) {
+  if (ctx == nullptr) return BL_E_ARG;
+  ctx->switches = switches;
   return BL_OK;
 }
 

@@ -28,6 +28,8 @@ extern "C" int bl_geodesic_occupancy(int integrator, int with_time, int spin_zer
 extern "C" hipError_t bl_launch_locate(const BlShadeArgs *args, int grid, int lds_bytes, hipStream_t stream);
 extern "C" hipError_t bl_launch_shade(const BlShadeArgs *args, int model, int grid, hipStream_t stream);
 extern "C" hipError_t bl_launch_shade_fast(const BlShadeArgs *args, int grid, hipStream_t stream);
+extern "C" int bl_fused2_applicable(const BlGridDevice *grid, int n_nu, long long n_rays);
+extern "C" hipError_t bl_launch_transfer_composed(const BlTransferArgs *args, hipStream_t stream);
 extern "C" hipError_t bl_launch_shade_formula_fast(const BlShadeArgs *args, int grid, hipStream_t stream);
 extern "C" hipError_t bl_launch_polarized_coefficients(const BlShadeArgs *args, int grid, hipStream_t stream);
 extern "C" hipError_t bl_launch_transfer(const BlTransferArgs *args, hipStream_t stream);
@@ -119,6 +121,8 @@ struct bl_ctx {
   int arithmetic = BL_ARITH_EXACT;    // bl_set_arithmetic()
   int undefined_policy = BL_UNDEFINED_REFUSE;   // bl_set_undefined_policy(): BL_UNDEFINED_EDGE | BL_UNDEFINED_KAPPA
   bool kappa_warned = false;
+  bool debug_counters = false;        // BLACKLIGHT_AMD_DEBUG_COUNTERS (bl_init): print the -DBL_GEO_STATS counters after a render
+  unsigned int switches = 0;          // BL_SWITCH_* (include/blacklight_amd.h): the environment as bl_init found it, never read again
   double guard_band = 1.0e-9;         // tolerant tier: relative half-width around a cut threshold left to the exact kernel
 
   // image rows (radiation_integrator.cpp:436-520)
@@ -174,6 +178,7 @@ struct bl_ctx {
     DeviceBuffer<BlLocated> d_located;
     DeviceBuffer<unsigned long long> d_located_tag;
     DeviceBuffer<double2> d_transfer;
+    DeviceBuffer<double2> d_composed;              // tolerant tier: one affine map per ray segment (BlShadeArgs::composed)
     DeviceBuffer<unsigned long long> d_counters;   // BL_CNT_TOTAL
     DeviceBuffer<BlAuxSample> d_aux;               // auxiliary-image mode
     DeviceBuffer<double> d_sample_t;               // image_time, slow light
@@ -188,25 +193,25 @@ struct bl_ctx {
     DeviceBuffer<double> d_tau_inc;                // tolerant tier with an optical-depth image: alpha x length per sample and frequency
     uint64_t Bytes() const {
       return d_records_hot.count * sizeof(BlSampleHot) + d_records_cold.count * sizeof(BlSampleCold) + d_located.count * sizeof(BlLocated)
-          + d_located_tag.count * sizeof(unsigned long long) + d_transfer.count * sizeof(double2) + d_aux.count * sizeof(BlAuxSample)
+          + d_located_tag.count * sizeof(unsigned long long) + (d_transfer.count + d_composed.count) * sizeof(double2) + d_aux.count * sizeof(BlAuxSample)
           + (d_sample_t.count + d_slow_frac.count + d_pol_matrix.count + d_tau_inc.count) * sizeof(double) + d_pol_samples.count * sizeof(BlPolSample)
           + d_freq_inputs.count * sizeof(BlFreqInputs) + d_pol_coeffs.count * sizeof(double2) + d_anchors.count * sizeof(unsigned int)
           + d_coef_inputs.count * sizeof(BlCoefInputs) + d_redo.count * sizeof(unsigned long long);
     }
     void Free() {
       d_redo.Free(); d_tau_inc.Free(); d_aux.Free(); d_sample_t.Free(); d_slow_frac.Free(); d_pol_samples.Free(); d_pol_matrix.Free(); d_freq_inputs.Free(); d_pol_coeffs.Free(); d_coef_inputs.Free(); d_anchors.Free();
-      d_records_hot.Free(); d_records_cold.Free(); d_located.Free(); d_located_tag.Free(); d_transfer.Free(); d_counters.Free();
+      d_records_hot.Free(); d_records_cold.Free(); d_located.Free(); d_located_tag.Free(); d_transfer.Free(); d_composed.Free(); d_counters.Free();
     }
   };
   ChunkSlot slot[2];
   // per ray of a bl_render call (indexed by traversal position; a chunk's kernels get pointers to its first ray)
   DeviceBuffer<double> d_ray_kt, d_ray_factor;
   DeviceBuffer<double> d_ray_start;              // BL_RAY_START_FIELDS rows: start state of every ray (bl_ray_init_kernel -> geodesic kernel)
-  DeviceBuffer<int> d_ray_sample_num, d_ray_skipped;
+  DeviceBuffer<int> d_ray_sample_num, d_ray_skipped, d_ray_rows;
   DeviceBuffer<unsigned char> d_ray_flags;
   DeviceBuffer<long long> d_ray_out_index, d_ray_offset;
   uint64_t RayBytes() const {
-    return (d_ray_kt.count + d_ray_factor.count + d_ray_start.count) * sizeof(double) + (d_ray_sample_num.count + d_ray_skipped.count) * sizeof(int) + d_ray_flags.count
+    return (d_ray_kt.count + d_ray_factor.count + d_ray_start.count) * sizeof(double) + (d_ray_sample_num.count + d_ray_skipped.count + d_ray_rows.count) * sizeof(int) + d_ray_flags.count
         + (d_ray_out_index.count + d_ray_offset.count) * sizeof(long long);
   }
   DeviceBuffer<double> d_freq;

@@ -62,6 +62,10 @@ static_assert(sizeof(BlLocated) == 32, "located sample must be 32 bytes");
 // has rounded to +0 (tau > 37.4), behind which a NaN stays a NaN as in the exact tier (NaN x exp(-tau)). No other a is negative.
 #define BL_AFFINE_THICK (-0.0)
 #define BL_IS_AFFINE_THICK(a) (__double2hiint(a) < 0)
+// A row of composed maps (BlShadeArgs::composed) that stands for per-sample records instead: a = -(number of samples) <= -1 (no
+// map has such an a: a composed a lies in [0, 1], the thick mark is -0.0), c = the bit pattern of the first sample's record index;
+// the transfer kernel replays transfer[first ... first + number) in its place.
+#define BL_COMPOSED_EXPANDED(a) ((a) <= -1.0)
 
 enum BlCounter {
   BL_CNT_NEXT_RAY = 0,      // work queue head of the geodesic kernel
@@ -91,6 +95,12 @@ struct BlGridDevice {
   // tolerant locate step takes as its guess and checks against the faces (locate_plain_from_angles)
   int uniform_mask;
   double cell_x0[3], cell_inv_w[3];
+  // what bl_shade_fused2_kernel (bl_shade_fused.hip) asks of a grid: radial faces evenly spaced in log r to 1e-4 of a cell
+  // (log_uniform; cell = floor((log2 r - log_l0) * log_inv_w), a guess the faces confirm), theta and phi covering the sphere
+  // (full_sphere: no sample is off the grid in angle), and the first and last radial face
+  int log_uniform, full_sphere;
+  float log_l0, log_inv_w;
+  double r_face_in, r_face_out;
   int n[3];                  // n_i, n_j, n_k of the (merged) global grid
   int nb[3];                 // cells per block along each axis (= n for a single block)
   int stride_row, stride_plane;   // cells between j- and k-neighbours in `cells` / `kappa`
@@ -263,6 +273,10 @@ struct BlTraceArgs {
   // (sample_num, ray_max_steps); ray_skipped[slot] is how many of a ray's samples have no record.
   double skip_low, skip_high;
   int *ray_skipped;
+  // Composed transfer maps (tolerant tier, bl_shade_fused2_kernel with one map per segment): records carry segment numbers instead
+  // of sample numbers, ray_offset counts segments, ray_rows[slot] = the ray's segments (bl_geodesic_kernel's emission loop)
+  int segment_rows;
+  int *ray_rows;
 };
 #define BL_RAY_START_FIELDS 17
 
@@ -339,6 +353,12 @@ struct BlShadeArgs {
   int lds_table_bytes;        // size of the coordinate tables the locate kernel stages in LDS; 0: searched in HBM
   int samples_renormalised;   // records come from a geodesic checkpoint: momenta as stored, no renormalisation per sample
   int tolerant;               // bl_set_arithmetic(BL_ARITH_TOLERANT): kernels that have a tolerant instantiation use it
+  int fused_variant;          // tolerant tier, locate step inside: 1 = bl_shade_fused2_kernel (bl_fused2_applicable), 0 = bl_shade_fused_kernel
+  // Composed transfer maps (bl_shade_fused2_kernel): one (a, c) per SEGMENT of a ray (BlTraceArgs::segment_rows) in row
+  // ray_offset[ray] + segment of `composed`; `transfer` is then indexed by RECORD and written only for the samples of a wave that
+  // holds a deferred sample or an optically thick step (the segment's row then says where they are: BL_COMPOSED_EXPANDED)
+  double2 *composed;          // [segment row], or null: one transfer record per sample
+  int general_locate;         // measurement switch (bl_stats.switches): the general locate kernel where the plain one applies
   int undefined_edge;         // bl_set_undefined_policy(BL_UNDEFINED_EDGE): samples where the reference reads past its arrays use the edge
   const unsigned long long *counters_in;
   unsigned long long *counters;
@@ -398,6 +418,9 @@ struct BlTransferArgs {
   int n_nu, ray_max_steps, chunk_rays;
   int fallback_nan, model_type;
   int affine;                 // tolerant tier: records are (a, c) of I <- a I + c instead of (a, b) of I <- a (I + b)
+  int lane_transfer;          // measurement switch (bl_stats.switches): one lane per ray where four lanes per ray apply
+  const double2 *composed;    // composed transfer maps (BlShadeArgs::composed): [ray_offset + segment], ray_rows[ray] of them per ray; `transfer` by record
+  const int *ray_rows;
   const BlFreqInputs *freq_inputs;            // bl_transfer_freq_kernel
   long long n_rays_total;
   double *image;              // [n_q][n_rays_total]; rows 0..n_nu-1 = I_nu

@@ -168,8 +168,10 @@ __global__ void __launch_bounds__(64, BL_GEO_ONE_WAVE(kIntegrator, kTime, kSpinZ
   RayState s;
   double k0[8];
   double h_new = 0.0, r_cur = 0.0, r_prev_sample = 0.0;
-  int num_retry = 0, n = 0, sample_num = 0, trunc_at = -1;
+  // (sample_num doubles as the index of the step's first sample: a ray that goes on has had every accepted step's samples added)
+  int num_retry = 0, sample_num = 0, trunc_at = -1;
   int skipped = 0;   // samples of the ray without a record (BlTraceArgs::skip_low)
+  int seg = 0;       // BlTraceArgs::segment_rows: segments of kept samples so far (the rows of the ray's composed transfer maps)
   unsigned int slot = 0;
   bool previous_fail = false, flag = false;
   for (int p = 0; p < 8; p++) {
@@ -248,9 +250,9 @@ __global__ void __launch_bounds__(64, BL_GEO_ONE_WAVE(kIntegrator, kTime, kSpinZ
           num_retry = 0;
           previous_fail = false;
           flag = false;
-          n = 0;
           sample_num = 0;
           skipped = 0;
+          seg = 0;
           trunc_at = -1;
           r_prev_sample = 0.0;
         }
@@ -387,7 +389,7 @@ __global__ void __launch_bounds__(64, BL_GEO_ONE_WAVE(kIntegrator, kTime, kSpinZ
             double delta_s_step = P.ray_step * r_mid;
             double delta_s_full = y5[7] - s.y[7];
             num_steps_ideal = (int)ceil(delta_s_full / delta_s_step);
-            int num_steps_max = P.ray_max_steps - n;
+            int num_steps_max = P.ray_max_steps - sample_num;
             num_steps = num_steps_ideal;
             if (num_steps > num_steps_max) {
               num_steps = num_steps_max;
@@ -522,6 +524,7 @@ __global__ void __launch_bounds__(64, BL_GEO_ONE_WAVE(kIntegrator, kTime, kSpinZ
     const BlRecip rc_steps = bl_recip((double)num_steps_ideal);
     const double len = bl_div_r(h, rc_steps);
     double position = 0.5;   // nn + 0.5, exact
+    unsigned int window_prev = 0xffffffffu;   // segment_rows: the 16-record window of the lane's previous sample of this step (none yet)
     for (int nn = 0; nn < max_emit; nn++, position += 1.0) {
       if (nn < emit) {
         double smp[7];
@@ -533,7 +536,7 @@ __global__ void __launch_bounds__(64, BL_GEO_ONE_WAVE(kIntegrator, kTime, kSpinZ
         // outward beyond the camera radius or falls inside r_terminate ends the kept part of the ray
         // (evaluated for every sample, decided only while the ray is still whole: after the first hit nothing reads
         // r_prev_sample again, and the ray ends with this step - its end test is the same comparison at the step's end)
-        const int index = n + nn;
+        const int index = sample_num + nn;
         const double r_s = bl_radial_coordinate<kSpinZero>(st, smp[1], smp[2], smp[3]);
         const bool hit = index >= 1 && ((r_s > P.camera_r && r_s > r_prev_sample) || r_s < P.r_terminate);
         const bool dead = trunc_at >= 0 || hit;
@@ -549,6 +552,17 @@ __global__ void __launch_bounds__(64, BL_GEO_ONE_WAVE(kIntegrator, kTime, kSpinZ
         // read the same grid cells - laid out row by row instead, the coefficient kernels take 4 ms longer per frame)
         const int place = excl + nn;
         const long long at = place < old_room ? old_base + place : new_base + (place - old_room);
+        if (P.segment_rows) {
+          // Composed transfer maps (bl_shade_fused2_kernel): the kept samples of a ray that lie side by side within one aligned
+          // group of 16 records - a lane's run of a step, cut where it crosses such a boundary - are one SEGMENT, numbered along the
+          // ray; the record carries the segment's number instead of the sample's, and the coefficient kernel, whose lanes of a
+          // DPP row hold exactly such a group, composes a segment's affine maps and stores one map per segment in row
+          // ray_offset + number.
+          const unsigned int window = (unsigned int)(at >> 4);
+          seg += (!dead && window != window_prev) ? 1 : 0;
+          window_prev = window;
+          hot.n = (unsigned int)(seg - 1);
+        }
         BlSampleCold cold;
         cold.kx = smp[4];
         cold.ky = smp[5];
@@ -574,11 +588,9 @@ __global__ void __launch_bounds__(64, BL_GEO_ONE_WAVE(kIntegrator, kTime, kSpinZ
       bool terminate_inner = r_new < P.r_terminate;
       if (terminate_outer || terminate_inner) {
         finish = true;
-      } else {
-        bool last_step = n + num_steps >= P.ray_max_steps;
-        if (last_step) flag = true;
-        n += num_steps;
-        if (n >= P.ray_max_steps) finish = true;
+      } else if (sample_num >= P.ray_max_steps) {   // :311-321: the step that reaches ray_max_steps flags the ray and ends it
+        flag = true;
+        finish = true;
       }
       // FSAL: next step starts from y_vals_5 with k_vals[0] = k_vals[6], the latter evaluated
       // BEFORE the renormalisation above (:149-154)
@@ -595,7 +607,9 @@ __global__ void __launch_bounds__(64, BL_GEO_ONE_WAVE(kIntegrator, kTime, kSpinZ
       if (kShell) P.ray_skipped[slot] = skipped;
       P.ray_flags[slot] = flag ? 1 : 0;
       // rows of the kept samples in the per-sample arrays, in the order in which rays finish; slots not emitted go back
-      P.ray_offset[slot] = (long long)atomicAdd(&P.counters[BL_CNT_SAMPLES], (unsigned long long)final_num);
+      const int rows = P.segment_rows ? seg : final_num;
+      if (P.segment_rows) P.ray_rows[slot] = rows;
+      P.ray_offset[slot] = (long long)atomicAdd(&P.counters[BL_CNT_SAMPLES], (unsigned long long)rows);
       atomicAdd(&P.counters[BL_CNT_COMMITTED], (unsigned long long)(-(long long)(P.ray_max_steps - (sample_num - (kShell ? skipped : 0)))));
       have_ray = false;
     }

@@ -118,6 +118,8 @@ struct RenderJob {
   bool tau_row = false;   // tolerant tier: an optical-depth image beside the intensities on the plain path (bl_tau_kernel)
   bool skip_shell = false;   // steps between the grid's outer edge and the camera's sphere leave no records (BlTraceArgs::skip_low)
   bool fused = false;   // tolerant tier, common grid case: the locate step runs inside the coefficient kernel (bl_shade_fused_kernel)
+  bool fused2 = false;  // ... the benchmark's case of it: bl_shade_fused2_kernel (bl_shade_fused.hip)
+  bool composed = false;   // ... writing one affine transfer map per ray segment instead of one per sample (BlShadeArgs::composed)
   int n_nu = 0, n_q = 0, max_steps = 0;
   long long n_rays = 0, level_pixels = 0;
   size_t redo_capacity = 0;
@@ -243,7 +245,7 @@ void PlanJob(RenderJob &job) {
   // ... and the per-frequency coefficient kernel of polarized runs (frame, transport and coupling stay exact)
   job.tolerant_polarized = ctx->arithmetic == BL_ARITH_TOLERANT && ctx->polarized;
   // ... and transport matrices (bl_transport_matrix_kernel) instead of the ray-sequential tensor transport, in curved spacetimes
-  job.matrix_transport = job.tolerant_polarized && !p.ray_flat && std::getenv("BLACKLIGHT_AMD_TENSOR_TRANSPORT") == nullptr;
+  job.matrix_transport = job.tolerant_polarized && !p.ray_flat && !(ctx->switches & BL_SWITCH_TENSOR_TRANSPORT);
   // Several frequencies in the fast path: per-sample factors (BlFreqInputs) instead of per-frequency transfer records,
   // evaluated by bl_transfer_freq_kernel with one lane per ray and frequency
   job.freq_split = job.fast && job.n_nu >= 4 && p.plasma_power_frac == 0.0 && !job.tau_row;   // (the factors are the thermal formulas')
@@ -253,13 +255,18 @@ void PlanJob(RenderJob &job) {
       && p.simulation_coord == BL_COORD_SKS   // (its locate step is the spherical one: Cartesian grids go through the locate kernel)
       && !(p.cut_omit_near || p.cut_omit_far || p.cut_omit_in >= 0.0 || p.cut_omit_out >= 0.0 || p.cut_midplane_theta != 0.0 || p.cut_midplane_z != 0.0 || p.cut_plane)
       && static_cast<size_t>(ctx->lds_table_bytes) + (44 + 5 * static_cast<size_t>(job.n_nu) + ctx->n_i + ctx->n_j + ctx->n_k) * sizeof(double) <= 60u * 1024u
-      && !job.sample_save && std::getenv("BLACKLIGHT_AMD_NO_FUSED_LOCATE") == nullptr;   // (a sample checkpoint is made of the located samples)
-  job.interleaved = (job.fused || !job.simulation) && !job.geo_load && !job.geo_save && !job.sample_save && std::getenv("BLACKLIGHT_AMD_SPLIT_RECORDS") == nullptr;
+      && !job.sample_save && !(ctx->switches & BL_SWITCH_NO_FUSED_LOCATE);   // (a sample checkpoint is made of the located samples)
+  job.interleaved = (job.fused || !job.simulation) && !job.geo_load && !job.geo_save && !job.sample_save && !(ctx->switches & BL_SWITCH_SPLIT_RECORDS);
+  // One frequency over a single block with evenly spaced faces: the benchmark's kernel, which also composes the affine maps of a
+  // ray's neighbouring samples before they leave it (the geodesic kernel numbers the segments: BlTraceArgs::segment_rows)
+  job.fused2 = job.fused && job.interleaved && !job.freq_split && !(ctx->switches & BL_SWITCH_GENERAL_FUSED)
+      && bl_fused2_applicable(&ctx->grid_dev, job.n_nu, job.n_rays) != 0;
+  job.composed = job.fused2 && !(ctx->switches & BL_SWITCH_SAMPLE_RECORDS);
   // Plain images of a spherical Kerr-Schild simulation with fallback values beyond the grid: nothing is recorded of the steps that
   // lie in the empty shell between the grid's outer edge and the camera's sphere (both tiers; the samples count as ever)
   job.skip_shell = job.simulation && !job.aux && !ctx->polarized && !job.slow && !job.geo_load && !job.geo_save && !job.sample_save
       && !job.need_time && p.simulation_coord == BL_COORD_SKS && !ctx->grid_dev.fmks && !p.fallback_nan && ctx->grid_outer_x1 > 0.0
-      && ctx->grid_outer_x1 < p.camera_r && std::getenv("BLACKLIGHT_AMD_RECORD_EVERY_STEP") == nullptr;
+      && ctx->grid_outer_x1 < p.camera_r && !(ctx->switches & BL_SWITCH_RECORD_EVERY_STEP);
   // ... and in the exact coefficient kernel (plain images): the frequency loop as lanes of bl_coefficients_freq_kernel
   job.coef_split = !job.fast && job.simulation && !job.aux && !ctx->polarized && job.n_nu >= 4;
   // (polarized runs list the samples without coefficients there - cut samples, cut cells - which are many more)
@@ -285,6 +292,7 @@ void PlanScratch(RenderJob &job) {
   job.bytes_per_record = sizeof(BlSampleHot) + sizeof(BlSampleCold)
       + ((job.simulation && !job.fused) ? sizeof(BlLocated) + sizeof(unsigned long long) : 0)
       + (job.freq_split ? sizeof(BlFreqInputs) : sizeof(double2) * n_nu) + (job.tau_row ? sizeof(double) * n_nu : 0)
+      + (job.composed ? sizeof(double2) : 0)
       + (job.aux ? sizeof(BlAuxSample) : 0) + (job.need_time ? sizeof(double) : 0) + (job.slow ? sizeof(double) : 0)
       + (ctx->polarized ? sizeof(BlPolSample) + sizeof(BlCoefInputs) + 3 * sizeof(double2) * n_nu : 0)
       + (job.coef_split ? sizeof(BlCoefInputs) : 0)
@@ -323,6 +331,10 @@ void PlanScratch(RenderJob &job) {
     job.n_slots = 2;
     capacity = capacity_for(2);
   }
+  // Kernels index a scratch set's records with 32 bits, and a grid-stride loop runs a few strides past the last record: the
+  // capacity stays 2^22 records below 2^32. Clamped BEFORE the persistent grid and the reservation gate are derived from it
+  // (they were once computed from the unclamped value: a gate beyond the buffers EnsureScratch allocates).
+  capacity = std::min<uint64_t>(capacity, (1ull << 32) - (1ull << 22));
   // Persistent waves: every lane in flight holds ray_max_steps record slots until its ray ends, so no more lanes than the
   // buffer can cover at once. (A chunk still takes about capacity / samples-per-ray rays: a finished ray gives back what it
   // did not emit and the lanes that were refused ask again. Fewer waves than that would only trace the same rays more
@@ -332,7 +344,6 @@ void PlanScratch(RenderJob &job) {
   const long long gate = static_cast<long long>(capacity) - grid * BL_RECORD_BLOCK;
   if (gate < job.max_steps)
     throw Failure{BL_E_ARG, "Scratch budget too small: the sample records of a single ray (ray_max_steps of them) do not fit (bl_set_scratch_limit)."};
-  if (capacity >= (1ull << 32)) capacity = (1ull << 32) - 1;   // (kernels may index a scratch set's records with 32 bits)
   job.record_capacity = static_cast<size_t>(capacity);
   job.record_gate = gate;
   job.geo_grid = static_cast<int>(grid);
@@ -356,6 +367,7 @@ void EnsureScratch(RenderJob &job) {
     }
     if (job.freq_split) sl.d_freq_inputs.Ensure(cap);   // instead of the transfer records
     else sl.d_transfer.Ensure(cap * n_nu);
+    if (job.composed) sl.d_composed.Ensure(cap);
     if (job.tau_row) sl.d_tau_inc.Ensure(cap * n_nu);
     sl.d_counters.Ensure(BL_CNT_TOTAL);
     if (job.aux) sl.d_aux.Ensure(cap);
@@ -376,6 +388,7 @@ void EnsureScratch(RenderJob &job) {
   ctx->d_ray_factor.Ensure(n_rays);
   ctx->d_ray_sample_num.Ensure(n_rays);
   if (job.skip_shell) ctx->d_ray_skipped.Ensure(n_rays);
+  if (job.composed) ctx->d_ray_rows.Ensure(n_rays);
   ctx->d_ray_flags.Ensure(n_rays);
   ctx->d_ray_out_index.Ensure(n_rays);
   ctx->d_ray_offset.Ensure(n_rays);
@@ -753,13 +766,14 @@ void BuildShadeArgs(RenderJob &job) {
     // amplifies last-place differences of the coefficients by up to ten orders of magnitude in optically and Faraday thick
     // configurations, so only bit-identical coefficients keep Stokes V within the tier's tolerance
     // everywhere. The tolerant coefficient kernel (106 -> 59 ms per 1024^2 frame) is there for the asking.
-    sa.tolerant = (job.fast || (job.tolerant_polarized && std::getenv("BLACKLIGHT_AMD_TOLERANT_POLARIZED_COEFFICIENTS") != nullptr)) ? 1 : 0;
+    sa.tolerant = (job.fast || (job.tolerant_polarized && (ctx->switches & BL_SWITCH_TOLERANT_POLARIZED_COEFFICIENTS) != 0)) ? 1 : 0;
   } else {
     BlFormulaDevice &fm = sa.formula;
     fm.r0 = p.formula_r0; fm.h = p.formula_h; fm.l0 = p.formula_l0; fm.q = p.formula_q; fm.nup = p.formula_nup;
     fm.cn0 = p.formula_cn0; fm.alpha = p.formula_alpha; fm.a = p.formula_a; fm.beta = p.formula_beta;
   }
   sa.samples_renormalised = job.geo_load ? 1 : 0;
+  sa.general_locate = (ctx->switches & BL_SWITCH_GENERAL_LOCATE) ? 1 : 0;
   ctx->d_shade_cold.Ensure(1);
   Check(hipMemcpyAsync(ctx->d_shade_cold.ptr, &cold, sizeof(BlShadeCold), hipMemcpyHostToDevice, stream), "shade parameter upload");
   Check(hipStreamSynchronize(stream), "shade parameter upload");   // cold is a local
@@ -823,6 +837,7 @@ void BuildTransferArgs(RenderJob &job) {
   xa.fallback_nan = p.fallback_nan;
   xa.model_type = p.model_type;
   xa.affine = (job.fast || job.fast_formula) ? 1 : 0;
+  xa.lane_transfer = (ctx->switches & BL_SWITCH_LANE_TRANSFER) ? 1 : 0;
   xa.n_rays_total = job.n_rays;
   xa.image = job.image;
   xa.out_sample_num = job.out_num;
@@ -868,6 +883,8 @@ void BindChunk(RenderJob &job, int k, long long begin, int rays) {
   ta.ray_factor = ctx->d_ray_factor.ptr + begin;
   ta.ray_sample_num = ctx->d_ray_sample_num.ptr + begin;
   ta.ray_skipped = job.skip_shell ? ctx->d_ray_skipped.ptr + begin : nullptr;
+  ta.segment_rows = job.composed ? 1 : 0;
+  ta.ray_rows = job.composed ? ctx->d_ray_rows.ptr + begin : nullptr;
   ta.ray_flags = ctx->d_ray_flags.ptr + begin;
   ta.ray_out_index = ctx->d_ray_out_index.ptr + begin;
   ta.ray_offset = ctx->d_ray_offset.ptr + begin;
@@ -885,6 +902,8 @@ void BindChunk(RenderJob &job, int k, long long begin, int rays) {
   sa.ray_offset = ta.ray_offset;
   sa.ray_flags = ta.ray_flags;
   sa.transfer = sl.d_transfer.ptr;
+  sa.composed = job.composed ? sl.d_composed.ptr : nullptr;
+  sa.fused_variant = job.fused2 ? 1 : 0;
   sa.tau_inc = job.tau_row ? sl.d_tau_inc.ptr : nullptr;
   sa.aux = job.aux ? sl.d_aux.ptr : nullptr;
   sa.sample_t = ta.sample_t;
@@ -898,6 +917,8 @@ void BindChunk(RenderJob &job, int k, long long begin, int rays) {
   xa.chunk_rays = rays;
   xa.counters = sl.d_counters.ptr;
   xa.transfer = sl.d_transfer.ptr;
+  xa.composed = sa.composed;
+  xa.ray_rows = ta.ray_rows;
   xa.tau_inc = sa.tau_inc;
   xa.tau_row = ctx->aux_images.offset_tau;
   xa.freq_inputs = sa.freq_inputs;
@@ -1271,7 +1292,8 @@ void LaunchShadingStage(RenderJob &job, int k, bool geodesic_beside, hipStream_t
   if (ctx->polarized) Check(bl_launch_polarized_coefficients(&sa, ctx->num_cus * 8, stream), "polarized coefficient kernel launch");
   if (job.coef_split) Check(bl_launch_coefficients_freq(&sa, ctx->num_cus * 16, stream), "per-frequency coefficient kernel launch");
   Check(hipEventRecord(e[4], stream), "event");
-  Check(job.aux ? bl_launch_transfer_aux(&xa, stream) : (job.freq_split ? bl_launch_transfer_freq(&xa, stream) : bl_launch_transfer(&xa, stream)),
+  Check(job.aux ? bl_launch_transfer_aux(&xa, stream)
+                : (job.freq_split ? bl_launch_transfer_freq(&xa, stream) : (job.composed ? bl_launch_transfer_composed(&xa, stream) : bl_launch_transfer(&xa, stream))),
         "transfer kernel launch");
   if (job.tau_row) Check(bl_launch_tau(&xa, stream), "optical-depth kernel launch");
   if (ctx->polarized)
@@ -1425,8 +1447,10 @@ void FinishStats(RenderJob &job) {
   st.arithmetic = (job.fast || job.fast_formula || job.tolerant_polarized) ? BL_ARITH_TOLERANT : BL_ARITH_EXACT;
   st.n_deferred = static_cast<int64_t>(job.total_redo);
   st.n_undefined = static_cast<int64_t>(job.total_undefined);
+  st.switches = ctx->switches;
+  st.fused_variant = job.fused ? (job.fused2 ? 2 : 1) : 0;
   ctx->stats = st;
-  if (std::getenv("BLACKLIGHT_AMD_DEBUG_COUNTERS") != nullptr) {   // kernels built with -DBL_GEO_STATS fill these
+  if (ctx->debug_counters) {   // kernels built with -DBL_GEO_STATS fill these
     std::fprintf(stderr, "debug counters:");
     for (int k = 0; k < 8; k++) std::fprintf(stderr, " %llu", job.debug_counters[k]);
     std::fprintf(stderr, "\n");

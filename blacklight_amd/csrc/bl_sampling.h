@@ -1178,7 +1178,13 @@ __device__ __forceinline__ PlainLocated locate_plain_from_angles(const BlGridDev
     k = find_cell(g, tab, 2, s3);
   }
   // :485-490, per block of a merged grid (one block - the usual case - needs no remainders)
-  const int i_b = pg.one_block ? i : i % pg.nb_i, j_b = pg.one_block ? j : j % pg.nb_j, k_b = pg.one_block ? k : k % pg.nb_k;
+  // (a wave-uniform branch, not a select: three integer remainders are ~120 vector instructions the one-block case never needs)
+  int i_b = i, j_b = j, k_b = k;
+  if (__builtin_expect(!pg.one_block, 0)) {
+    i_b = i % pg.nb_i;
+    j_b = j % pg.nb_j;
+    k_b = k % pg.nb_k;
+  }
   const double xv_at_j = tab.xv[1][j], xv_at_k = tab.xv[2][k];
   const int i_m = (i_b == 0 || (i_b != pg.nb_i - 1 && s1 >= tab.xv[0][i])) ? i : i - 1;
   const int j_m = (j_b == 0 || (j_b != pg.nb_j - 1 && s2 >= xv_at_j)) ? j : j - 1;

@@ -241,6 +241,7 @@ __global__ void __launch_bounds__(256, 2) bl_shade_kernel(const BlShadeArgs P) {
       kcov[0] = P.ray_kt[ray];
       momentum_factor = P.ray_factor[ray];
       row = (size_t)P.ray_offset[ray] + n;
+      if (kRedo && P.composed != nullptr) row = (size_t)idx_cur;   // composed transfer maps: per-sample records lie by record index
     }
     float pr[8];
     float kappa_f = 0.0f;
@@ -595,7 +596,7 @@ extern "C" hipError_t bl_launch_locate(const BlShadeArgs *args, int grid, int ld
   const bool spin_zero = args->st.bh_a == 0.0;
   // the common case has a kernel of its own (bl_locate_plain_kernel): same located samples
   const bool plain = !refined && !slow && lds_bytes > 0 && !args->grid.fmks && args->plasma.simulation_interp && !args->cuts.any_optional
-      && args->plasma.simulation_coord == BL_COORD_SKS && args->anchors == nullptr && std::getenv("BLACKLIGHT_AMD_GENERAL_LOCATE") == nullptr;
+      && args->plasma.simulation_coord == BL_COORD_SKS && args->anchors == nullptr && !args->general_locate;
   if (plain) {
     if (spin_zero) hipLaunchKernelGGL((bl_locate_plain_kernel<true>), dim3(grid), dim3(256), lds_bytes, stream, *args);
     else hipLaunchKernelGGL((bl_locate_plain_kernel<false>), dim3(grid), dim3(256), lds_bytes, stream, *args);

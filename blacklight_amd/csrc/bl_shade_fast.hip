@@ -649,6 +649,7 @@ __global__ void __launch_bounds__(256, 4) bl_shade_formula_fast_kernel(const BlS
 // =================================================================================================
 // The exact tier's kernel over the records a tolerant kernel deferred (bl_shade.hip)
 extern "C" hipError_t bl_launch_shade_redo(const BlShadeArgs *args, int model, int grid, hipStream_t stream);
+extern "C" hipError_t bl_launch_shade_fused2(const BlShadeArgs *args, int grid, hipStream_t stream);   // bl_shade_fused.hip
 
 // Tolerant tier in formula mode: the fast kernel, then the exact kernel over the records it deferred
 extern "C" hipError_t bl_launch_shade_formula_fast(const BlShadeArgs *args, int grid, hipStream_t stream) {
@@ -659,6 +660,11 @@ extern "C" hipError_t bl_launch_shade_formula_fast(const BlShadeArgs *args, int 
 // Tolerant tier, simulations: the fast coefficient kernel, then the exact kernel over the records it deferred
 extern "C" hipError_t bl_launch_shade_fast(const BlShadeArgs *args, int grid, hipStream_t stream) {
   const bool spin_zero = args->st.bh_a == 0.0;
+  if (args->located == nullptr && args->fused_variant == 1) {   // the benchmark's case has a kernel of its own (bl_shade_fused.hip)
+    const hipError_t err = bl_launch_shade_fused2(args, grid, stream);
+    if (err != hipSuccess) return err;
+    return bl_launch_shade_redo(args, BL_MODEL_SIMULATION, grid, stream);
+  }
   if (args->located == nullptr) {   // no locate kernel ran: the fused kernel (coordinate tables in LDS behind its own table)
     const size_t lds = (44 + 5 * args->n_nu) * sizeof(double) + args->lds_table_bytes
         + (size_t)(args->grid.n[0] + args->grid.n[1] + args->grid.n[2]) * sizeof(double);   // (+ the reciprocal widths)

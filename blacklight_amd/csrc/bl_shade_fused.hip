@@ -1,0 +1,782 @@
+// bl_shade_fused.hip - the benchmark's coefficient kernel (gfx950): tolerant arithmetic tier, locate step inside, ONE frequency,
+// one grid block whose faces are evenly spaced in log r, theta and phi and cover the whole sphere (what Athena++ / the mock write
+// for a spherical Kerr-Schild run). Everything else the tier covers stays on bl_shade_fused_kernel / bl_shade_fast_kernel
+// (bl_shade_fast.hip), whose arithmetic this kernel restates; what is different here is everything around the arithmetic:
+//
+//   * the loop body is one straight line. Every lane runs the whole sample - a dead slot, a cut or an off-grid sample on harmless
+//     inputs - and the record is selected at the end; the only branches left are wave-uniform ones around things that almost never
+//     happen (cell-cut thresholds that are switched off, a step that is not optically thin, a deferred sample). The general
+//     kernel's nest of divergent branches cost more scalar and mask instructions than the arithmetic they skipped, and made the
+//     compiler spill 109 scalar registers through v_writelane / v_readlane (round-3 ISA mix: 36 % of the loop's vector
+//     instructions were fp64 arithmetic).
+//   * what a cell search needs of an axis is ONE 64-byte row in LDS per cell (faces, centre, the centre and reciprocal width the
+//     fraction is taken against on either side, the anchor shift), at a fixed place: one address computation and three 16-byte
+//     reads per axis instead of five 8-byte reads from five tables with five address computations.
+//   * cells are guessed arithmetically on every axis - floor((x - x0) / w) in theta and phi, floor((log2 r - l0) / w) with the
+//     hardware's single-precision log2 in r - and confirmed against the row's faces: theta and phi with the guard band of the
+//     tier's own angles, r exactly (radius, cut at the camera's sphere and radial cell are the exact tier's decisions, as before).
+//     A guess its faces do not confirm is left to the exact kernel's second pass, like every other undecided sample.
+//   * grid reads and per-ray constants are addressed by 32-bit offsets from scalar base pointers (a cell index x 32 bytes and a
+//     ray slot x 8 bytes fit 32 bits), records by one running 64-bit pointer: no 64-bit address arithmetic per load.
+//   * rarely used arguments are read from the kernel-argument segment where they are used (through a pointer the optimiser
+//     cannot see through), not held in scalar registers across the loop.
+//
+// Parity contract unchanged (bl_sampling_fast.h): sample_num, flags, status, cell and every cut decision are the exact tier's;
+// intensities within the tier's tolerance (tests/test_gpu_tolerant.py asserts 1e-11 of the image maximum against the exact tier).
+// Reference arithmetic restated: simulation_sampling.cpp:201-575, :806-839; simulation_coefficients.cpp:253-701; unpolarized.cpp:74-110.
+#include "bl_sampling_fast.h"
+
+#pragma clang fp contract(fast)
+
+namespace fused2 {
+
+// One cell of one axis, as the search wants it (LDS, 64 bytes)
+struct alignas(16) AxisRow {
+  double xf_lo, xf_hi;   // faces of cell c
+  double xv;             // centre of cell c: the anchor is c when x >= xv, else c - 1 (simulation_sampling.cpp:485-490) ...
+  uint32_t dj_ge, dj_lt; // ... except at the block's ends: anchor = c - dj
+  double xv_ge, w_ge;    // centre of the anchor cell and 1 / (distance to the next centre) when x >= xv
+  double xv_lt, w_lt;    // ... and when x < xv
+};
+static_assert(sizeof(AxisRow) == 64, "axis row must be 64 bytes");
+
+typedef const __attribute__((address_space(4))) BlShadeArgs *KernArgs;
+// The kernel-argument segment through a pointer the optimiser cannot trace: fields read through it are loaded (s_load) where
+// they are used instead of being kept in scalar registers from the kernel's entry on
+__device__ __forceinline__ KernArgs kernargs() {
+  KernArgs p = (KernArgs)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+  return p;
+}
+__device__ __forceinline__ double uniform_value(double v) {   // a wave-uniform double into a scalar register pair
+  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+
+// ---- 64-bit constants as scalar operands. No fp64 vector instruction takes a 64-bit literal: a constant has to sit in a register
+// pair, and the compiler's choice is two v_mov_b32 into vector registers in front of every use - for the addend of a Horner step
+// always, because it prefers the two-address v_fmac_f64 and copies the constant into the destination first. Those moves were a
+// fifth of this kernel's vector instructions. KS(c) hands a literal through a scalar register pair (two s_mov_b32 on the scalar
+// unit, which issues beside the vector unit); fma_k / add_k are the three-address forms with the constant as the scalar operand.
+#if defined(BLV_VECTOR_LITERALS) || !defined(__HIP_DEVICE_COMPILE__)   // (A/B variant: the compiler's own choice)
+#define KS(c) (c)
+__device__ __forceinline__ double fma_k(double a, double b, double c_uniform) { return __builtin_fma(a, b, c_uniform); }
+__device__ __forceinline__ double add_k(double a, double c_uniform) { return a + c_uniform; }
+#else
+#define KS(c) BLM_K(c)
+__device__ __forceinline__ double fma_k(double a, double b, double c_uniform) {   // a * b + c
+  double d;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c_uniform));
+  return d;
+}
+__device__ __forceinline__ double add_k(double a, double c_uniform) {   // a + c
+  double d;
+  asm("v_add_f64 %0, %1, %2" : "=v"(d) : "v"(a), "s"(c_uniform));
+  return d;
+}
+#endif
+// The tier's elementary functions (bl_fastmath.h: same polynomials, same reductions, same accuracy) with their coefficients as
+// scalar operands
+__device__ __forceinline__ double expm1_core_k(double x, int *k) {
+  const double kd = __builtin_rint(x * KS(0x1.71547652b82fep+0));
+  double r = __builtin_fma(-kd, KS(0x1.62e42feep-1), x);
+  r = __builtin_fma(-kd, KS(0x1.a39ef35793c76p-33), r);
+  double q = add_k(r * KS(0x1.94328fcb8199cp-37), 0x1.61bfaa228dde5p-33);
+  q = fma_k(q, r, 0x1.1eed7a01fc8b7p-29);
+  q = fma_k(q, r, 0x1.ae642c82e33d5p-26);
+  q = fma_k(q, r, 0x1.27e4fb7a2782ap-22);
+  q = fma_k(q, r, 0x1.71de3a5aa7bb7p-19);
+  q = fma_k(q, r, 0x1.a01a01a019b63p-16);
+  q = fma_k(q, r, 0x1.a01a01a0196acp-13);
+  q = fma_k(q, r, 0x1.6c16c16c16c17p-10);
+  q = fma_k(q, r, 0x1.1111111111111p-7);
+  q = fma_k(q, r, 0x1.5555555555555p-5);
+  q = fma_k(q, r, 0x1.5555555555555p-3);
+  const double r2 = r * r;
+  *k = (int)kd;
+  return r + __builtin_fma(r2 * r, q, 0.5 * r2);
+}
+__device__ __forceinline__ double exp_k(double x) {
+  x = x > KS(710.0) ? KS(710.0) : (x < KS(-746.0) ? KS(-746.0) : x);
+  int k;
+  const double e = expm1_core_k(x, &k);
+  return __builtin_amdgcn_ldexp(1.0 + e, k);
+}
+__device__ __forceinline__ double expm1_k(double x) {
+  x = x > KS(710.0) ? KS(710.0) : (x < KS(-40.0) ? KS(-40.0) : x);
+  int k;
+  const double e = expm1_core_k(x, &k);
+  const double t = __builtin_amdgcn_ldexp(1.0, k);
+  return (t - 1.0) + t * e;
+}
+__device__ __forceinline__ double cbrt_k(double x) {
+  const int e = __builtin_amdgcn_frexp_exp(x);
+  const double mant = __builtin_amdgcn_frexp_mant(x);
+  const int q = (int)(((unsigned int)(e + 3072) * 43691u) >> 17) - 1024;
+  const double m = __builtin_amdgcn_ldexp(mant, e - 3 * q);
+  const float seed = __builtin_amdgcn_exp2f(__builtin_amdgcn_logf((float)m) * -0.33333334f);
+  const double third = KS(0x1.5555555555555p-2);
+  double z = (double)seed;
+  double h = __builtin_fma(-m, z * z * z, 1.0);
+  z = __builtin_fma(z * h, third, z);
+  h = __builtin_fma(-m, z * z * z, 1.0);
+  z = __builtin_fma(z * h, third, z);
+  double c = m * z * z;
+  c = __builtin_fma(__builtin_fma(-c * c, c, m), z * z * third, c);
+  const double res = __builtin_amdgcn_ldexp(c, q);
+  return __builtin_amdgcn_class(x, 0x263) ? x : res;
+}
+__device__ __forceinline__ double acos_k(double x) {
+  const double ax = __builtin_fabs(x);
+  const bool small = ax < 0.5;
+  const double z = small ? x * x : (1.0 - ax) * 0.5;
+  double r = add_k(z * KS(0x1.e58a4f278e007p-6), -0x1.3bd7e353ddbc2p-6);
+  r = fma_k(r, z, 0x1.40c91fa8deb7ep-6);
+  r = fma_k(r, z, 0x1.8dcdf11997e0fp-9);
+  r = fma_k(r, z, 0x1.31777489dfd29p-7);
+  r = fma_k(r, z, 0x1.3b462d121c5d2p-7);
+  r = fma_k(r, z, 0x1.7b02ef007d23ep-7);
+  r = fma_k(r, z, 0x1.c990a42b32b03p-7);
+  r = fma_k(r, z, 0x1.1c4efd20ebb99p-6);
+  r = fma_k(r, z, 0x1.6e8ba121b9d5fp-6);
+  r = fma_k(r, z, 0x1.f1c71c7a5e151p-6);
+  r = fma_k(r, z, 0x1.6db6db6dac0eap-5);
+  r = fma_k(r, z, 0x1.3333333333389p-4);
+  r = fma_k(r, z, 0x1.5555555555555p-3);
+  r *= z;
+  const double s = small ? x : (z > 0.0 ? z * fastmath::rsqrt(z) : 0.0);
+  const double asin_s = __builtin_fma(s, r, s);
+  const double pio2 = KS(0x1.921fb54442d18p+0), pio2_lo = KS(0x1.1a62633145c07p-54);
+  const double res_small = (pio2 - asin_s) + pio2_lo;
+  const double res_neg = __builtin_fma(-2.0, asin_s, 2.0 * pio2) + 2.0 * pio2_lo;
+  return small ? res_small : (x < 0.0 ? res_neg : 2.0 * asin_s);
+}
+__device__ __forceinline__ double atan2_k(double y, double x) {
+  const double ax = __builtin_fabs(x), ay = __builtin_fabs(y);
+  const double mx = ax > ay ? ax : ay, mn = ax > ay ? ay : ax;
+  const bool low = 16.0 * mn <= KS(7.0) * mx, mid = 16.0 * mn < KS(11.0) * mx;
+  const double c = low ? 0.0 : (mid ? 0.5 : 1.0);
+  const double hi = low ? 0.0 : (mid ? KS(0x1.dac670561bb4fp-2) : KS(0x1.921fb54442d18p-1));
+  const double num = __builtin_fma(-c, mx, mn), den = __builtin_fma(c, mn, mx);
+  const double u = den > 0.0 ? num * fastmath::rcp(den) : 0.0;
+  const double w = u * u;
+  double a = add_k(w * KS(-0x1.9a0e3d8214a3cp-7), 0x1.dde84abd3489ap-6);
+  a = fma_k(a, w, -0x1.4ac01ab40659fp-5);
+  a = fma_k(a, w, 0x1.812cf294b38a9p-5);
+  a = fma_k(a, w, -0x1.ae800c7915a0cp-5);
+  a = fma_k(a, w, 0x1.e1d239c838f12p-5);
+  a = fma_k(a, w, -0x1.1110907ae84ccp-4);
+  a = fma_k(a, w, 0x1.3b13abac1919fp-4);
+  a = fma_k(a, w, -0x1.745d171e2e854p-4);
+  a = fma_k(a, w, 0x1.c71c71c673bd9p-4);
+  a = fma_k(a, w, -0x1.24924924918e2p-3);
+  a = fma_k(a, w, 0x1.999999999998fp-3);
+  a = fma_k(a, w, -0x1.5555555555555p-2);
+  double res = hi + __builtin_fma(u * w, a, u);               // atan(mn / mx)
+  const double pio2 = KS(0x1.921fb54442d18p+0), pi = KS(0x1.921fb54442d18p+1);
+  res = ay > ax ? pio2 - res : res;
+  res = x < 0.0 ? pi - res : res;
+  return y < 0.0 ? -res : res;
+}
+
+// sqrt(x) correctly rounded (blm_sqrt_n's operations, bit for bit) together with 1 / sqrt(x) to ~2e-16 (what the Newton step
+// leaves behind): the exact radius for the decisions and its reciprocal for the tolerant angle from one v_rsq
+__device__ __forceinline__ double sqrt_with_reciprocal(double x, double *inv) {
+#pragma clang fp contract(off)
+  double y = __builtin_amdgcn_rsq(x);
+  double g = x * y;
+  double h = y * 0.5;
+  double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  double d = __builtin_fma(-g, g, x);
+  g = __builtin_fma(d, h, g);
+  d = __builtin_fma(-g, g, x);
+  g = __builtin_fma(d, h, g);
+  *inv = h + h;
+  return g;   // (callers pass finite x > 0)
+}
+
+struct Located {
+  double f_i, f_j, f_k;
+  uint32_t status;        // kSample... | kPlainUndecided
+  uint32_t cell_bytes;    // byte offset of cell (k_m, j_m, i_m) in the cell array; 0 without a cell to read
+};
+
+// What the loop keeps of the grid in scalar registers
+struct GridScalars {
+  double th_x0, th_inv_w, ph_x0, ph_inv_w;   // theta, phi: cell = floor((x - x0) * inv_w)
+  float r_l0, r_linv;                        // r: cell = floor((log2 r - l0) * linv)
+  double r_in, r_out;                        // first and last radial face
+  int n_i1, n_j1, n_k1;                      // n - 1 per axis
+  uint32_t n_i, n_j;                         // cell index = (k n_j + j) n_i + i
+  uint32_t lds_r, lds_th, lds_ph;            // LDS byte addresses of the three row tables
+};
+
+// LDS reads by byte address (the row tables live behind the kernel's extern array; LDS addresses are 32-bit numbers, which is
+// what lets a row's address be computed with one shift-and-add). Device code only; the host pass sees stubs.
+typedef double v2d __attribute__((ext_vector_type(2)));
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ v2d lds_read2(uint32_t addr) { return *(const __attribute__((address_space(3))) v2d *)addr; }
+__device__ __forceinline__ v4u lds_read_bits(uint32_t addr) { return *(const __attribute__((address_space(3))) v4u *)addr; }
+__device__ __forceinline__ uint32_t lds_address(const void *p) { return (uint32_t)(const __attribute__((address_space(3))) char *)p; }
+#else
+__device__ __forceinline__ v2d lds_read2(uint32_t) { return v2d{0.0, 0.0}; }
+__device__ __forceinline__ v4u lds_read_bits(uint32_t) { return v4u{0u, 0u, 0u, 0u}; }
+__device__ __forceinline__ uint32_t lds_address(const void *) { return 0u; }
+#endif
+
+// One axis: row of the guessed cell -> anchor shift, fraction, signed distance to the nearest face (negative: the guess is wrong
+// or the coordinate lies beyond the grid) and distance to the centre
+__device__ __forceinline__ void axis_lookup(uint32_t row_addr, double s, double *frac, uint32_t *dj, double *face_margin, double *centre_margin) {
+  const v2d faces = lds_read2(row_addr);
+  const v4u mid = lds_read_bits(row_addr + 16u);
+  const double xv = __hiloint2double((int)mid.y, (int)mid.x);
+  const bool ge = s >= xv;
+  const v2d anchor = lds_read2(row_addr + (ge ? 32u : 48u));
+  *dj = ge ? mid.z : mid.w;
+  *frac = (s - anchor.x) * anchor.y;
+  const double d_lo = s - faces.x, d_hi = faces.y - s;
+  *face_margin = d_lo < d_hi ? d_lo : d_hi;
+  *centre_margin = __builtin_fabs(s - xv);
+}
+
+// The locate step (locate_plain_sample_tolerant's results; bl_sampling_fast.h) for the grids this kernel takes
+template <bool kSpinZero>
+__device__ __forceinline__ Located locate(const BlSpacetime &st, const GridScalars &G, double camera_r, double band, bool live, double x, double y, double z) {
+  x = live ? x : 1.0;
+  y = live ? y : 1.0;
+  z = live ? z : 1.0;
+  double r2;
+  {
+#pragma clang fp contract(off)
+    const double rr2 = x * x + y * y + z * z;   // (the exact tier's operations: bl_radial_coordinate2)
+    r2 = rr2;
+    if (!kSpinZero) {
+      const double a2 = st.bh_a * st.bh_a;
+      r2 = 0.5 * (rr2 - a2 + bl_hypot_g(rr2 - a2, 2.0 * st.bh_a * z));
+    }
+  }
+  double r_inv;
+  const double r = sqrt_with_reciprocal(r2, &r_inv);
+  const bool cut = r > camera_r;                                   // simulation_sampling.cpp:238-243
+  const bool off_grid = r < G.r_in || r > G.r_out;                 // :352-394 (theta and phi cover the sphere)
+  // ConvertFromCKS (radiation_geometry.cpp:37-57) with the tier's inverse trigonometric functions
+  // (cos theta = z / r: the product with the reciprocal, corrected once by its residual, is the correctly rounded quotient - the
+  // exact tier's argument bit for bit - in all but a few cases in a million; the arccosine amplifies what is left by 1 / sin theta)
+  double cth = z * r_inv;
+  cth = __builtin_fma(__builtin_fma(-r, cth, z), r_inv, cth);
+  const double th = acos_k(cth);
+  double ph = kSpinZero ? atan2_k(y, x) : atan2_k(y, x) - atan2_k(st.bh_a, r);
+  const double ph_unwrapped = ph;
+  const double two_pi = KS(2.0 * kPi);
+  ph += ph < 0.0 ? two_pi : 0.0;
+  const double ph_once = ph;
+  ph -= ph >= two_pi ? two_pi : 0.0;
+  // guessed cells
+  int gi = (int)((__builtin_amdgcn_logf((float)r) - G.r_l0) * G.r_linv);
+  int gj = (int)((th - G.th_x0) * G.th_inv_w);
+  int gk = (int)((ph - G.ph_x0) * G.ph_inv_w);
+  gi = gi < 0 ? 0 : (gi > G.n_i1 ? G.n_i1 : gi);
+  gj = gj < 0 ? 0 : (gj > G.n_j1 ? G.n_j1 : gj);
+  gk = gk < 0 ? 0 : (gk > G.n_k1 ? G.n_k1 : gk);
+  double f_i, f_j, f_k, m_i, m_j, m_k, c_i, c_j, c_k;
+  uint32_t di, dj, dk;
+  axis_lookup(G.lds_r + ((uint32_t)gi << 6), r, &f_i, &di, &m_i, &c_i);
+  axis_lookup(G.lds_th + ((uint32_t)gj << 6), th, &f_j, &dj, &m_j, &c_j);
+  axis_lookup(G.lds_ph + ((uint32_t)gk << 6), ph, &f_k, &dk, &m_k, &c_k);
+  // r is the exact tier's r: its cell is confirmed exactly (first c with xf[c + 1] >= r: xf[c] < r <= xf[c + 1]; m_i is
+  // min(r - xf[c], xf[c + 1] - r)) - except on a face itself, where the signed minimum is zero either way: left to the exact pass
+  // theta, phi: the tier's own angles, so every value they are compared with must be further away than the band
+  double m = m_j < m_k ? m_j : m_k;
+  m = m < c_j ? m : c_j;
+  m = m < c_k ? m : c_k;
+  const double e0 = __builtin_fabs(ph_unwrapped), e1 = __builtin_fabs(ph_once - two_pi);
+  m = m < e0 ? m : e0;
+  m = m < e1 ? m : e1;
+  const bool sampled = live && !cut && !off_grid;
+  const bool undecided = sampled && (!(m > band) || !(m_i > 0.0));
+  Located out;
+  out.f_i = f_i;
+  out.f_j = f_j;
+  out.f_k = f_k;
+  const uint32_t cell = __umul24(__umul24((uint32_t)gk - dk, G.n_j) + ((uint32_t)gj - dj), G.n_i) + ((uint32_t)gi - di);
+  out.cell_bytes = sampled ? cell << 5 : 0u;
+  out.status = (!live ? (uint32_t)kSampleNone : (cut ? (uint32_t)kSampleCut : (off_grid ? (uint32_t)kSampleOffGrid : (uint32_t)kSampleInterp)))
+      | (undecided ? kPlainUndecided : 0u);
+  return out;
+}
+
+// The eight corner cells of a located sample: sixteen 16-byte loads at 32-bit offsets from the scalar base pointer
+__device__ __forceinline__ void gather_issue(const char *cells, uint32_t cell_bytes, bool interp, uint32_t row_bytes, uint32_t plane_bytes, float4 (&lo)[8],
+                                             float4 (&hi)[8]) {
+  const uint32_t row = interp ? row_bytes : 0u, plane = interp ? plane_bytes : 0u, next = interp ? 32u : 0u;
+#pragma unroll
+  for (int corner = 0; corner < 8; corner++) {
+    const uint32_t off = cell_bytes + ((corner >> 2) ? plane : 0u) + (((corner >> 1) & 1) ? row : 0u) + ((corner & 1) ? next : 0u);
+    const float4 *p = reinterpret_cast<const float4 *>(cells + (size_t)off);
+    lo[corner] = p[0];
+    hi[corner] = p[1];
+  }
+}
+
+// gather_finish_tolerant() for an interpolated sample (bl_shade_fast.hip): the trilinear read with fused multiply-adds, the <= 0
+// rule, the rounding to float; true when a sum lies too close to the midpoint of two floats for the tier to decide the rounding
+__device__ __forceinline__ bool trilinear(const float4 (&lo)[8], const float4 (&hi)[8], double f_i, double f_j, double f_k, float pr[8]) {
+  const double w_k[2] = {1.0 - f_k, f_k}, w_j[2] = {1.0 - f_j, f_j}, w_i[2] = {1.0 - f_i, f_i};
+  double val[8];
+  float first[2];
+#pragma unroll
+  for (int corner = 0; corner < 8; corner++) {
+    float v[8];
+    unpack_cell(lo[corner], hi[corner], v);
+    const double w = w_k[corner >> 2] * w_j[(corner >> 1) & 1] * w_i[corner & 1];
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      if (corner == 0) {
+        val[q] = w * (double)v[q];
+        if (q < 2) first[q] = v[q];
+      } else {
+        val[q] = __builtin_fma(w, (double)v[q], val[q]);
+      }
+    }
+  }
+  bool near_midpoint = false;
+#pragma unroll
+  for (int q = 0; q < 8; q++) {
+    const uint32_t below = (uint32_t)__double_as_longlong(val[q]) & 0x1fffffffu;
+    const uint32_t window = q < 2 ? 2048u : 4096u;
+    near_midpoint = near_midpoint | ((below - (0x10000000u - window)) <= 2u * window);
+  }
+  if (val[0] <= 0.0) val[0] = (double)first[0];   // simulation_sampling.cpp:822-825
+  if (val[1] <= 0.0) val[1] = (double)first[1];
+#pragma unroll
+  for (int q = 0; q < 8; q++) pr[q] = (float)val[q];   // :830-839
+  return near_midpoint;
+}
+
+// fast_shade_sample() (bl_shade_fast.hip) for one frequency, thermal electrons, spherical Kerr-Schild simulation, as one straight
+// line: every lane computes, `have` says whether the lane's sample has coefficients. Returns the record (a, c) of I <- a I + c for
+// a sample with coefficients (anything else: the caller's selection) and *undecided when a cut decision is the exact kernel's.
+// cut_table (LDS): per cut quantity (rho, n_e, p_gas, Theta_e, B, sigma, 1 / beta) six numbers: lower and upper threshold, the
+// guard band around the lower one (lo, hi), the guard band around the upper one (lo, hi); a switched-off threshold is -inf / +inf
+// with an empty band.
+template <bool kSpinZero>
+__device__ __forceinline__ double2 shade(const BlSpacetime &st, const double (&K)[6], double freq, double freq_inv, double x_unit, int cut_mask,
+                                         uint32_t cut_table, const float pr[8], double x, double y, double z, double kx, double ky, double kz, double kt,
+                                         double momentum_factor, double delta_lambda, bool *have_out, bool *undecided_out) {
+  const double bh_m = st.bh_m;
+  const double bh_a = kSpinZero ? 0.0 : st.bh_a;
+  const double a2 = bh_a * bh_a;
+  const double rho = pr[0], pgas = pr[1], uu1 = pr[2], uu2 = pr[3], uu3 = pr[4], bb1 = pr[5], bb2 = pr[6], bb3 = pr[7];
+  // ---- Kerr-Schild scalars (radiation_geometry.cpp:18-25, :138-262)
+  const double pp2 = x * x + y * y;
+  const double rr2 = pp2 + z * z;
+  double r2 = rr2;
+  if (!kSpinZero) {
+    const double u = rr2 - a2, v = 2.0 * bh_a * z;
+    r2 = 0.5 * (u + bl_sqrt_g(u * u + v * v));
+  }
+  const double r_inv = fastmath::rsqrt(r2);
+  const double r = r2 * r_inv;
+  const double ra2 = r2 + a2;
+  const double ra_inv = kSpinZero ? r_inv * r_inv : fastmath::rcp(ra2);
+  const double lx = kSpinZero ? x * r_inv : (r * x + bh_a * y) * ra_inv;
+  const double ly = kSpinZero ? y * r_inv : (r * y - bh_a * x) * ra_inv;
+  const double lz = z * r_inv;                     // also cos(theta)
+  const double sigma = kSpinZero ? r2 : r2 + a2 * lz * lz;
+  const double hh = kSpinZero ? 2.0 * bh_m * r_inv : 2.0 * bh_m * r * fastmath::rcp(sigma);   // 2 m r / Sigma
+  const double f = kSpinZero ? hh : 2.0 * bh_m * r2 * r * fastmath::rcp(r2 * r2 + a2 * z * z);
+  // ---- null-condition renormalisation of the stored momentum (geodesics.cpp:352-371)
+  double lk = lx * kx + ly * ky + lz * kz;
+  {
+    const double kk = kx * kx + ky * ky + kz * kz;
+    const double ta = kk - f * lk * lk;                  // g^ij k_i k_j
+    const double tb = 2.0 * kt * f * lk;                 // 2 g^0i k_0 k_i
+    const double tc = -(1.0 + f) * kt * kt;              // g^00 k_0 k_0
+    const double td = fastmath::sqrt(tb * tb - 4.0 * ta * tc);
+    const double factor = (tb < 0.0 ? td - tb : -2.0 * tc) * fastmath::rcp(tb < 0.0 ? 2.0 * ta : tb + td);
+    kx *= factor;
+    ky *= factor;
+    kz *= factor;
+    lk *= factor;
+  }
+  // ---- simulation metric, spherical Kerr-Schild (radiation_geometry.cpp:421-573); x^2 + y^2 = (r^2 + a^2) sin^2
+  const double sth2 = pp2 * ra_inv;
+  const double g_rr = 1.0 + hh;
+  const double g_thth = sigma;
+  const double g_tph = kSpinZero ? 0.0 : -hh * bh_a * sth2;
+  const double g_rph = kSpinZero ? 0.0 : -g_rr * bh_a * sth2;
+  const double g_phph = kSpinZero ? pp2 : (ra2 + hh * a2 * sth2) * sth2;
+  // ---- u^mu from the normal-frame velocities (simulation_coefficients.cpp:297-313): u^t and 1 / u^t from one reciprocal square root
+  const double u0n2 = 1.0 + g_rr * uu1 * uu1 + 2.0 * g_rph * uu1 * uu3 + g_thth * uu2 * uu2 + g_phph * uu3 * uu3;
+  const double ut2 = u0n2 * g_rr;
+  const double ut_inv = fastmath::rsqrt(ut2);
+  const double ut = ut2 * ut_inv;
+  const double ur = uu1 - hh * fastmath::rcp(g_rr) * ut;         // shift^r = (2 m r / Sigma) / (1 + 2 m r / Sigma)
+  const double u_r = hh * ut + g_rr * ur + g_rph * uu3;
+  const double u_th = g_thth * uu2;
+  const double u_ph = g_tph * ut + g_rph * ur + g_phph * uu3;
+  // ---- b^mu (:316-330); b.b = (B.B + (u.B)^2) / (u^t)^2
+  const double bt = u_r * bb1 + u_th * bb2 + u_ph * bb3;
+  const double br = (bb1 + bt * ur) * ut_inv;
+  const double bth = (bb2 + bt * uu2) * ut_inv;
+  const double bph = (bb3 + bt * uu3) * ut_inv;
+  const double bb_sq_lab = g_rr * bb1 * bb1 + 2.0 * g_rph * bb1 * bb3 + g_thth * bb2 * bb2 + g_phph * bb3 * bb3;
+  const double b_sq = (bb_sq_lab + bt * bt) * ut_inv * ut_inv;
+  // ---- k_i in the simulation's coordinates (Jacobian of radiation_geometry.cpp:69-126)
+  const double sth_inv = fastmath::rsqrt(sth2);
+  const double k_r = lk;
+  const double k_th = (lz * (x * kx + y * ky) - r * sth2 * kz) * sth_inv;
+  const double k_ph = x * ky - y * kx;
+  const double k_u = kt * ut + k_r * ur + k_th * uu2 + k_ph * uu3;
+  const double k_b = kt * bt + k_r * br + k_th * bth + k_ph * bph;
+  // ---- plasma state (:274-358), constants folded on the host (BlShadeArgs::fast_k)
+  double rho_inv, pgas_inv;
+  {
+    const double rp = rho * pgas;
+    const bool both = rho > 0.0 && rp > 0.0 && rp < __builtin_inf();
+    const double t = fastmath::rcp(both ? rp : rho);
+    rho_inv = both ? t * pgas : t;
+    pgas_inv = both ? t * rho : fastmath::rcp(pgas);
+  }
+  const double sigma_cut = b_sq * rho_inv;
+  const double beta_inv = 0.5 * b_sq * pgas_inv;
+  const double bi2 = beta_inv * beta_inv;
+  const double dd = 1.0 + bi2;
+  const double kb_tt_e = K[0] * (pgas * rho_inv) * (dd * fastmath::rcp(K[1] + K[2] * bi2 + K[3] * dd));
+  // ---- cell cuts (:361-375): decided here unless a value sits within the guard band of an active threshold
+  bool cell_cut = false, undecided = pp2 == 0.0;   // (on the polar axis: the exact kernel's business)
+  if (cut_mask != 0) {
+    const double bb = (cut_mask & 0x300) ? fastmath::sqrt(b_sq) : 0.0;   // only the field-strength cuts need |b| itself
+    const double value[7] = {rho, rho, pgas, kb_tt_e, bb, sigma_cut, beta_inv};   // against thresholds in these units
+#pragma unroll
+    for (int v = 0; v < 7; v++)
+      if ((cut_mask >> (2 * v)) & 3) {   // (wave-uniform)
+        const double q = value[v];
+        const v2d t = lds_read2(cut_table + 48u * v), b_lo = lds_read2(cut_table + 48u * v + 16u), b_hi = lds_read2(cut_table + 48u * v + 32u);
+        cell_cut = cell_cut | (q < t.x) | (q > t.y);
+        undecided = undecided | ((q >= b_lo.x) & (q <= b_lo.y)) | ((q >= b_hi.x) & (q <= b_hi.y));
+      }
+  }
+  const bool no_field = bb1 == 0.0 && bb2 == 0.0 && bb3 == 0.0;   // :394
+  const bool have = !cell_cut && !no_field;
+  *have_out = have;
+  *undecided_out = undecided;
+  // cos^2 = (k.b)^2 / ((k.u)^2 b.b) (:434-455 in invariant form) and 1 / (k.u) from one reciprocal
+  const double t_ku = fastmath::rcp(k_u * b_sq);
+  const double k_u_inv = t_ku * b_sq;
+  double cos2 = k_b * k_b * (t_ku * k_u_inv);
+  cos2 = cos2 < 1.0 ? cos2 : 1.0;
+  // |b| sin(theta_B) and its reciprocal from one reciprocal square root
+  const double bs2 = b_sq * (1.0 - cos2);
+  const double b_sin_inv = fastmath::rsqrt(bs2);                   // (inf along the field: nu / nu_s = inf there, as from 1 / 0)
+  const double b_sin = bs2 > 0.0 ? bs2 * b_sin_inv : 0.0;
+  // ---- coefficients at the one frequency (simulation_coefficients.cpp:464-523) and the transfer record (unpolarized.cpp:74-110)
+  const double mf_inv = fastmath::rcp(momentum_factor);
+  const double kte_inv = fastmath::rcp(kb_tt_e);
+  const double nu = -k_u * momentum_factor * freq;                 // :461-463 times the camera frequency
+  const double nu_inv = -k_u_inv * mf_inv * freq_inv;
+  const double xx = nu * b_sin_inv * (kte_inv * kte_inv) * K[4];   // nu / nu_s
+  const double x_1_3 = cbrt_k(xx);
+  const double x_1_6 = fastmath::sqrt(x_1_3);
+  const double x_1_2 = x_1_6 * x_1_3;
+  const double var_c = x_1_2 + KS(kPow2_11_12) * x_1_6;
+  const double j_val = K[5] * (rho * b_sin) * (nu_inv * nu_inv) * exp_k(-x_1_3) * var_c * var_c;
+  const double xp = KS(kH) * nu * kte_inv;                             // h nu / (k T_e)
+  double planck = xp * (1.0 + 0.5 * xp * (1.0 + KS(1.0 / 3.0) * xp * (1.0 + 0.25 * xp)));
+  if (__builtin_expect(have && !(xp < KS(0x1p-10)), 0)) planck = expm1_k(xp);
+  double alpha_val = j_val * (planck * KS(kC * kC / (2.0 * kH)));    // j / B_nu
+  if (alpha_val * alpha_val <= KS(0x1p-1024)) alpha_val = 0.0;         // :513-523
+  const double dl_cgs = delta_lambda * x_unit * mf_inv * freq_inv; // unpolarized.cpp:75-76
+  const double delta_tau = alpha_val * dl_cgs;
+  // optically thin step: neither expm1 nor a division
+  const double p = 1.0 - 0.5 * delta_tau * (1.0 - KS(1.0 / 3.0) * delta_tau * (1.0 - 0.25 * delta_tau));
+  const bool absorbing = alpha_val > 0.0;
+  double2 rec = make_double2(absorbing ? 1.0 - delta_tau * p : 1.0, j_val * dl_cgs * (absorbing ? p : 1.0));
+  if (__builtin_expect(have && absorbing && !(delta_tau < KS(0x1p-10)), 0)) {
+    const double source = j_val * fastmath::rcp(alpha_val);
+    if (delta_tau <= KS(kDeltaTauMax)) {
+      const double e1 = expm1_k(-delta_tau);
+      rec = make_double2(1.0 + e1, -source * e1);
+    } else {
+      rec = make_double2(BL_AFFINE_THICK, source);
+    }
+  }
+  return rec;
+}
+
+}  // namespace fused2
+
+// Three samples in flight per lane, as in bl_shade_fused_kernel:
+//   next: its position record was requested an iteration ago and is located at the end of this one (row tables in LDS);
+//   cur:  located -> corner cells and momentum record requested after the trilinear read has freed the landing registers;
+//   prev: cells and records arrived -> trilinear read, arithmetic, record.
+// kComposed: the affine maps I <- a I + c of a ray's samples that sit side by side in one DPP row - a SEGMENT, numbered by the
+// geodesic kernel (BlTraceArgs::segment_rows; the record carries the segment's number where it otherwise carries the sample's) -
+// are composed near -> far by a scan over the row, and the segment's last lane stores ONE map in row ray_offset + segment
+// (BlShadeArgs::composed): a seventh of the records a sample-by-sample kernel writes, and as many fewer for the transfer kernel to
+// read. A wave that holds a sample left to the exact kernel, or an optically thick step (whose map replaces what lies behind it,
+// a NaN included: not a product of numbers), writes its samples' own records instead, by record index, and marks its segments'
+// rows as standing for those (BL_COMPOSED_EXPANDED).
+template <bool kSpinZero, bool kComposed>
+__global__ void __launch_bounds__(256, BL_FAST_WAVES) bl_shade_fused2_kernel(const BlShadeArgs P) {
+  using namespace fused2;
+  extern __shared__ double lds[];
+  // ---- LDS: the cut table (7 x 6 doubles), then one row per cell for r, theta, phi
+  const uint32_t lds_base = lds_address(lds);
+  {
+    const BlShadeCold &cc = *P.cold;
+    const double inf = __builtin_inf();
+    for (int i = threadIdx.x; i < 42; i += blockDim.x) {
+      const int v = i / 6, w = i - 6 * v;
+      const bool lower_on = (P.plasma.cut_mask >> (2 * v)) & 1, upper_on = (P.plasma.cut_mask >> (2 * v + 1)) & 1;
+      double value;
+      if (w == 0) value = lower_on ? cc.fast_cut[2 * v] : -inf;
+      else if (w == 1) value = upper_on ? cc.fast_cut[2 * v + 1] : inf;
+      else if (w == 2) value = lower_on ? cc.fast_cut_lo[2 * v] : inf;
+      else if (w == 3) value = lower_on ? cc.fast_cut_hi[2 * v] : -inf;
+      else if (w == 4) value = upper_on ? cc.fast_cut_lo[2 * v + 1] : inf;
+      else value = upper_on ? cc.fast_cut_hi[2 * v + 1] : -inf;
+      lds[i] = value;
+    }
+    AxisRow *rows = reinterpret_cast<AxisRow *>(lds + 48);
+    for (int a = 0; a < 3; a++) {
+      const int n = P.grid.n[a];
+      const double *xf = P.grid.xf[a], *xv = P.grid.xv[a];
+      for (int c = threadIdx.x; c < n; c += blockDim.x) {
+        const int c_ge = c == n - 1 ? c - 1 : c, c_lt = c == 0 ? 0 : c - 1;
+        AxisRow row;
+        row.xf_lo = xf[c];
+        row.xf_hi = xf[c + 1];
+        row.xv = xv[c];
+        row.dj_ge = (uint32_t)(c - c_ge);
+        row.dj_lt = (uint32_t)(c - c_lt);
+        row.xv_ge = xv[c_ge];
+        row.w_ge = 1.0 / (xv[c_ge + 1] - xv[c_ge]);
+        row.xv_lt = xv[c_lt];
+        row.w_lt = 1.0 / (xv[c_lt + 1] - xv[c_lt]);
+        rows[c] = row;
+      }
+      rows += n;
+    }
+  }
+  __syncthreads();
+  const uint32_t n_records = (uint32_t)P.counters_in[BL_CNT_RECORDS];   // (a scratch set holds fewer than 2^32 records)
+  if (n_records == 0u) return;
+  const uint32_t stride = gridDim.x * blockDim.x;
+  const uint32_t last = n_records - 1u;
+  const BlSpacetime st = P.st;
+  GridScalars G;
+  G.th_x0 = P.grid.cell_x0[1];
+  G.th_inv_w = P.grid.cell_inv_w[1];
+  G.ph_x0 = P.grid.cell_x0[2];
+  G.ph_inv_w = P.grid.cell_inv_w[2];
+  G.r_l0 = P.grid.log_l0;
+  G.r_linv = P.grid.log_inv_w;
+  G.r_in = P.grid.r_face_in;
+  G.r_out = P.grid.r_face_out;
+  G.n_i1 = P.grid.n[0] - 1;
+  G.n_j1 = P.grid.n[1] - 1;
+  G.n_k1 = P.grid.n[2] - 1;
+  G.n_i = (uint32_t)P.grid.n[0];
+  G.n_j = (uint32_t)P.grid.n[1];
+  G.lds_r = lds_base + 48u * 8u;
+  G.lds_th = G.lds_r + 64u * (uint32_t)P.grid.n[0];
+  G.lds_ph = G.lds_th + 64u * (uint32_t)P.grid.n[1];
+  const uint32_t cut_table = lds_base;
+  const int cut_mask = P.plasma.cut_mask;
+  const double camera_r = P.cuts.camera_r;
+  const double band = P.fast_angle_band;
+  const double K[6] = {P.fast_k[0], P.fast_k[1], P.fast_k[2], P.fast_k[3], P.fast_k[4], P.fast_k[5]};
+  const double freq = uniform_value(P.frequencies[0]);
+  const double freq_inv = uniform_value(fastmath::rcp(freq));
+  const double x_unit = P.x_unit;
+  const bool fallback_nan = P.plasma.fallback_nan != 0;
+  const char *cells = reinterpret_cast<const char *>(P.grid.cells);
+  const uint32_t row_bytes = (uint32_t)P.grid.stride_row * 32u, plane_bytes = (uint32_t)P.grid.stride_plane * 32u;
+  const char *ray_kt = reinterpret_cast<const char *>(P.ray_kt), *ray_factor = reinterpret_cast<const char *>(P.ray_factor);
+  const char *ray_offset = reinterpret_cast<const char *>(P.ray_offset);
+  const double nan = __longlong_as_double(0x7ff8000000000000ll);
+  unsigned long long gathers_wave = 0ull;   // (wave-uniform: counted with ballots)
+
+  // Records are addressed from a wave-uniform base that advances by one grid stride per iteration (scalar arithmetic) plus the
+  // lane's own constant 32-bit offset; a position beyond the last record reads the base's record and comes back dead.
+  const char *records = reinterpret_cast<const char *>(P.records_hot);
+  const uint32_t lane_index = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t lane_bytes = lane_index << 6;
+  uint32_t base_index = 0u;   // record index of lane 0 of block 0 for the sample `prev` ... (wave-uniform)
+  auto record_base = [&](uint32_t first) { return records + ((size_t)(first < last ? first : last) << 6); };
+  double2 prev0 = make_double2(0.0, 0.0), prev1 = make_double2(0.0, __longlong_as_double((long long)BL_DEAD_RAY)), prev2 = prev0, prev3 = prev0;
+  double2 cur0, cur1;
+  double kt_prev = 0.0, factor_prev = 1.0;   // per-ray constants of `prev`, requested an iteration ago with its cells
+  long long row_prev = 0;
+  Located loc_prev, loc_cur;
+  loc_prev.f_i = loc_prev.f_j = loc_prev.f_k = 0.0;
+  loc_prev.status = kSampleNone;
+  loc_prev.cell_bytes = 0u;
+  float4 lo[8], hi[8];
+#pragma unroll
+  for (int c = 0; c < 8; c++) lo[c] = hi[c] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  // (32-bit record indices: the launcher keeps n_records + 3 strides below 2^32)
+  bool cur_in = lane_index < n_records;
+  {
+    const double2 *rec = reinterpret_cast<const double2 *>(record_base(0u) + (size_t)(cur_in ? lane_bytes : 0u));
+    cur0 = rec[0];
+    cur1 = rec[1];
+    cur1.y = cur_in ? cur1.y : __longlong_as_double((long long)BL_DEAD_RAY);
+  }
+  loc_cur = locate<kSpinZero>(st, G, camera_r, band, (uint32_t)__double_as_longlong(cur1.y) != BL_DEAD_RAY, cur0.x, cur0.y, cur1.x);
+  // `prev` is sample base_index - stride + lane_index (none in the first iteration), `cur` base_index + lane_index, `next` one stride on
+  bool prev_in = false;
+  while (__any(prev_in || cur_in)) {
+    const uint32_t ray = (uint32_t)__double_as_longlong(prev1.y);
+    const bool live = ray != BL_DEAD_RAY;
+    const uint32_t n = (uint32_t)(((unsigned long long)__double_as_longlong(prev1.y)) >> 32);
+    const uint32_t status = loc_prev.status & 0xffu;
+    const bool interp = status == (uint32_t)kSampleInterp;
+    // the position record of `next`: the oldest request of the iteration, used at its end
+    const uint32_t next_first = base_index + stride;
+    const bool next_in = next_first + lane_index < n_records;
+    double2 next0, next1;
+    {
+      const double2 *rec = reinterpret_cast<const double2 *>(record_base(next_first) + (size_t)(next_in ? lane_bytes : 0u));
+      next0 = rec[0];
+      next1 = rec[1];
+    }
+    const double kt = kt_prev, momentum_factor = factor_prev;
+    const long long row_first = row_prev;
+    float pr[8];
+    const bool near_midpoint = trilinear(lo, hi, loc_prev.f_i, loc_prev.f_j, loc_prev.f_k, pr);
+    gathers_wave += (unsigned long long)__popcll(__ballot(interp));
+    fused2::gather_issue(cells, loc_cur.cell_bytes, (loc_cur.status & 0xffu) == (uint32_t)kSampleInterp, row_bytes, plane_bytes, lo, hi);
+    double2 cold0, cold1;
+    {
+      const double2 *rec = reinterpret_cast<const double2 *>(record_base(base_index) + (size_t)(cur_in ? lane_bytes : 0u));
+      cold0 = rec[2];
+      cold1 = rec[3];
+    }
+    // ... and its per-ray constants (random 8-byte reads: a whole iteration ahead of their use, like the cells)
+    {
+      const uint32_t ray_cur = (uint32_t)__double_as_longlong(cur1.y);
+      const uint32_t ray_bytes = (ray_cur != BL_DEAD_RAY ? ray_cur : 0u) << 3;
+      kt_prev = *reinterpret_cast<const double *>(ray_kt + (size_t)ray_bytes);
+      factor_prev = *reinterpret_cast<const double *>(ray_factor + (size_t)ray_bytes);
+      row_prev = *reinterpret_cast<const long long *>(ray_offset + (size_t)ray_bytes);
+    }
+    // ---- arithmetic of `prev` (ReverseGeodesics: sample_len = -geodesic_len, geodesics.cpp:840)
+    // (Inside a branch - taken by every wave that holds a sample on the grid - not for the lanes it skips: a basic block is the
+    // unit the instruction scheduler arranges, and with the arithmetic in one block with the trilinear read, the requests and the
+    // search it interleaves all of them and needs 277 vector registers; as a block of its own the kernel fits 220.)
+    bool have = false, undecided_cut = false;
+    double2 rec = make_double2(1.0, 0.0);
+    if (interp)
+      rec = shade<kSpinZero>(st, K, freq, freq_inv, x_unit, cut_mask, cut_table, pr, prev0.x, prev0.y, prev1.x, prev2.x, prev2.y, prev3.x, kt, momentum_factor,
+                             -prev3.y, &have, &undecided_cut);
+    // a sample off the grid has fallback primitives without a field (no coefficients: I <- I) or NaN ones (I <- I + NaN,
+    // simulation_sampling.cpp:377-384); a cut sample has none either
+    const bool defer = interp && (undecided_cut || near_midpoint || (loc_prev.status & kPlainUndecided) != 0u);
+    if (!(interp && have)) rec = make_double2(1.0, (status == (uint32_t)kSampleOffGrid && fallback_nan) ? nan : 0.0);
+    if (!kComposed) {
+      if (live && !defer) {
+        double2 *out = P.transfer + (size_t)(row_first + (long long)n);
+        *out = rec;
+      }
+    } else {
+      // ---- one map per segment. `n` is the segment's number; lanes of one segment are neighbours within a DPP row and carry
+      // the same (ray, segment) word. first: lanes that begin a segment (or a row).
+      const uint32_t key_lo = ray, key_hi = n;
+      const uint32_t below_lo = (uint32_t)BL_DPP((int)~key_lo, (int)key_lo, 0x111, 0xf), below_hi = (uint32_t)BL_DPP((int)key_hi, (int)key_hi, 0x111, 0xf);
+      const unsigned long long first = __ballot(below_lo != key_lo || below_hi != key_hi) | 0x0001000100010001ull;
+      const bool expand = __any(live && (defer || BL_IS_AFFINE_THICK(rec.x)));
+      if (__builtin_expect(!expand, 1)) {
+        // inclusive scan of the maps over the lanes of a segment, nearer sample first: (a', c') o (a, c) = (a' a, a' c + c').
+        // Whether the lane d below belongs to the same segment is a matter of where segments begin: scalar masks.
+        const unsigned long long g2 = first | (first << 1), g4 = g2 | (g2 << 2), g8 = g4 | (g4 << 4);
+        double a = rec.x, c = rec.y;
+#define BL_COMPOSE_STEP(CTRL, STARTS)                                                                                          \
+        {                                                                                                                      \
+          const double a_below = __hiloint2double(BL_DPP(0, __double2hiint(a), CTRL, 0xf), BL_DPP(0, __double2loint(a), CTRL, 0xf)); \
+          const double c_below = __hiloint2double(BL_DPP(0, __double2hiint(c), CTRL, 0xf), BL_DPP(0, __double2loint(c), CTRL, 0xf)); \
+          if (__builtin_amdgcn_inverse_ballot_w64(~(STARTS))) {                                                                \
+            c = __builtin_fma(a_below, c, c_below);                                                                            \
+            a = a_below * a;                                                                                                   \
+          }                                                                                                                    \
+        }
+        BL_COMPOSE_STEP(0x111, first)
+        BL_COMPOSE_STEP(0x112, g2)
+        BL_COMPOSE_STEP(0x114, g4)
+        BL_COMPOSE_STEP(0x118, g8)
+#undef BL_COMPOSE_STEP
+        // the last lane of a segment holds its map
+        const unsigned long long last_lanes = (first >> 1) | 0x8000800080008000ull;
+        if (__builtin_amdgcn_inverse_ballot_w64(last_lanes) && live) P.composed[(size_t)(row_first + (long long)n)] = make_double2(a, c);
+      } else {
+        // a wave with a sample for the exact kernel or a thick step: its samples' own records, by record index, and rows that say so
+        const uint32_t record = base_index - stride + lane_index;
+        if (live && !defer) P.transfer[record] = rec;
+        const unsigned long long last_lanes = (first >> 1) | 0x8000800080008000ull;
+        const uint32_t lane = threadIdx.x & 63u;
+        if (((last_lanes >> lane) & 1ull) != 0ull && live) {
+          const unsigned long long starts_below = first & ((2ull << lane) - 1ull);   // (bit 0 of every row is set: never empty)
+          const uint32_t length = lane - (63u - (uint32_t)__builtin_clzll(starts_below)) + 1u;
+          P.composed[(size_t)(row_first + (long long)n)] =
+              make_double2(-(double)length, __longlong_as_double((long long)(unsigned long long)(record - (length - 1u))));
+        }
+      }
+    }
+    if (__builtin_expect(live && defer, 0)) {
+      KernArgs A = kernargs();
+      unsigned long long *counters = A->counters;
+      const unsigned long long at = atomicAdd(&counters[BL_CNT_REDO], 1ull);
+      if (at < A->redo_capacity) A->redo_list[at] = (unsigned long long)(base_index - stride + lane_index);
+    }
+    // ---- the search for `next`
+    const Located loc_next = locate<kSpinZero>(st, G, camera_r, band, next_in && (uint32_t)__double_as_longlong(next1.y) != BL_DEAD_RAY, next0.x, next0.y, next1.x);
+    prev0 = cur0;
+    prev1 = cur1;
+    prev2 = cold0;
+    prev3 = cold1;
+    loc_prev = loc_cur;
+    prev_in = cur_in;
+    cur0 = next0;
+    cur1 = next1;
+    cur1.y = next_in ? next1.y : __longlong_as_double((long long)BL_DEAD_RAY);
+    loc_cur = loc_next;
+    cur_in = next_in;
+    base_index = next_first;
+  }
+  if ((threadIdx.x & 63) == 0 && gathers_wave != 0ull) atomicAdd(&P.counters[BL_CNT_GATHERS], gathers_wave);
+}
+#pragma clang fp contract(off)
+
+// Whether a render can take this kernel (the caller has checked what bl_shade_fused_kernel needs, one frequency without the
+// per-frequency split, interleaved records whose momenta are not renormalised yet): one block, faces evenly spaced in log r / theta
+// / phi with the angles covering the sphere, at least two cells per axis, a cell array and ray slots that 32-bit byte offsets cover
+// (record indices always do: PlanScratch), room in LDS for the row tables.
+extern "C" int bl_fused2_applicable(const BlGridDevice *grid, int n_nu, long long n_rays) {
+  const BlGridDevice &g = *grid;
+  if (n_nu != 1 || n_rays >= (1ll << 29)) return 0;   // (ray slot x 8 bytes as a 32-bit offset)
+  if (g.n_blocks != 0 || g.fmks || g.nb[0] != g.n[0] || g.nb[1] != g.n[1] || g.nb[2] != g.n[2]) return 0;
+  if ((g.uniform_mask & 6) != 6 || !g.log_uniform || !g.full_sphere) return 0;
+  if (g.n[0] < 2 || g.n[1] < 2 || g.n[2] < 2) return 0;
+  const unsigned long long n_cells = (unsigned long long)g.n[0] * g.n[1] * g.n[2];
+  if (n_cells * 32ull >= (1ull << 32) || (unsigned long long)g.n[1] * g.n[2] >= (1ull << 24) || g.n[0] >= (1 << 24)) return 0;
+  if (g.stride_row != g.n[0] || g.stride_plane != g.n[0] * g.n[1]) return 0;
+  const size_t lds = 48 * sizeof(double) + 64 * (size_t)(g.n[0] + g.n[1] + g.n[2]);
+  return lds <= 64u * 1024u ? 1 : 0;
+}
+
+extern "C" hipError_t bl_launch_shade_fused2(const BlShadeArgs *args, int grid, hipStream_t stream) {
+  const BlGridDevice &g = args->grid;
+  const size_t lds = 48 * sizeof(double) + 64 * (size_t)(g.n[0] + g.n[1] + g.n[2]);
+  const bool spin_zero = args->st.bh_a == 0.0, composed = args->composed != nullptr;
+#define BL_LAUNCH_F2(S, C) hipLaunchKernelGGL((bl_shade_fused2_kernel<S, C>), dim3(grid), dim3(256), lds, stream, *args)
+  if (spin_zero && composed) BL_LAUNCH_F2(true, true);
+  else if (spin_zero) BL_LAUNCH_F2(true, false);
+  else if (composed) BL_LAUNCH_F2(false, true);
+  else BL_LAUNCH_F2(false, false);
+#undef BL_LAUNCH_F2
+  return hipGetLastError();
+}

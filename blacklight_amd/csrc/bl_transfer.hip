@@ -464,9 +464,75 @@ __global__ void __launch_bounds__(256) bl_transfer_quad_kernel(BlTransferArgs P)
   }
 }
 
+// Tolerant tier, composed maps (BlShadeArgs::composed; one frequency): one lane per ray applies the ray's segment maps far -> near -
+// about a seventh of the per-sample records, already composed by the coefficient kernel. A row that stands for per-sample
+// records (BL_COMPOSED_EXPANDED: its wave held a sample for the exact kernel or a thick step) is replayed from those.
+__global__ void __launch_bounds__(256) bl_transfer_composed_kernel(BlTransferArgs P) {
+  const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long samples = 0ull, flagged = 0ull;
+  int max_num = 0;
+  if (slot < bl_rays_done(P.counters, P.chunk_rays)) {
+    const int num = P.ray_sample_num[slot];
+    const bool flag = P.ray_flags[slot] != 0;
+    const long long out_index = P.ray_out_index[slot];
+    const int all = num + (P.ray_skipped != nullptr ? P.ray_skipped[slot] : 0);   // the ray's samples, with or without a record
+    samples = (unsigned long long)all;
+    flagged = flag ? 1ull : 0ull;
+    max_num = all;
+    if (P.out_sample_num != nullptr) P.out_sample_num[out_index] = all;
+    if (P.out_flags != nullptr) P.out_flags[out_index] = flag ? 1 : 0;
+    const double nan = __longlong_as_double(0x7ff8000000000000ll);
+    double intensity = 0.0;
+    if (P.fallback_nan && flag) {
+      intensity = num > 0 ? nan : 0.0;   // every sample of a flagged ray carries NaN primitives (simulation_sampling.cpp:211-216)
+    } else {
+      const double2 *rows = P.composed + (size_t)P.ray_offset[slot];
+      auto apply = [&](const double2 map) {
+        if (__builtin_expect(BL_COMPOSED_EXPANDED(map.x), 0)) {
+          const int length = (int)(-map.x);
+          const double2 *rec = P.transfer + (size_t)(unsigned long long)__double_as_longlong(map.y);
+          for (int i = length - 1; i >= 0; i--) {
+            const double2 ac = rec[i];
+            intensity = BL_IS_AFFINE_THICK(ac.x) ? ac.y : __builtin_fma(ac.x, intensity, ac.y);   // (unpolarized.cpp:103-104: see bl_transfer_kernel)
+          }
+        } else {
+          intensity = BL_IS_AFFINE_THICK(map.x) ? map.y : __builtin_fma(map.x, intensity, map.y);
+        }
+      };
+      int s = P.ray_rows[slot] - 1;
+      for (; s >= 7; s -= 8) {   // eight loads in flight per lane
+        double2 maps[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) maps[u] = rows[s - u];
+#pragma unroll
+        for (int u = 0; u < 8; u++) apply(maps[u]);
+      }
+      for (; s >= 0; s--) apply(rows[s]);
+    }
+    const double freq = P.frequencies[0];
+    P.image[out_index] = intensity * (freq * freq * freq);   // unpolarized.cpp:206-207
+  }
+  for (int offset = 32; offset > 0; offset >>= 1) {
+    samples += __shfl_xor(samples, offset, 64);
+    flagged += __shfl_xor(flagged, offset, 64);
+    int other = __shfl_xor(max_num, offset, 64);
+    max_num = other > max_num ? other : max_num;
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (samples) atomicAdd(&P.stats[0], samples);
+    if (flagged) atomicAdd(&P.stats[1], flagged);
+    atomicMax(&P.stats[2], (unsigned long long)max_num);
+  }
+}
+
+extern "C" hipError_t bl_launch_transfer_composed(const BlTransferArgs *args, hipStream_t stream) {
+  hipLaunchKernelGGL(bl_transfer_composed_kernel, dim3((args->chunk_rays + 255) / 256), dim3(256), 0, stream, *args);
+  return hipGetLastError();
+}
+
 extern "C" hipError_t bl_launch_transfer(const BlTransferArgs *args, hipStream_t stream) {
   int grid = (int)(((long long)args->chunk_rays * args->n_nu + 255) / 256);
-  if (args->affine && args->n_nu == 1 && std::getenv("BLACKLIGHT_AMD_LANE_TRANSFER") == nullptr) {
+  if (args->affine && args->n_nu == 1 && !args->lane_transfer) {
     hipLaunchKernelGGL(bl_transfer_quad_kernel, dim3((int)(((long long)args->chunk_rays * 4 + 255) / 256)), dim3(256), 0, stream, *args);
     return hipGetLastError();
   }

@@ -183,6 +183,10 @@ def _render_into_buffers(ctx, comm, specs, n_local, n_padded, level, pixels, blo
     if n_local == 0:
         return buffers, None
     if comm.on_gpu and hasattr(ctx, "render_device"):
+        # torch.zeros queued its fill kernels on torch's current stream; the library renders on non-blocking streams of its own,
+        # which nothing orders behind that one - a fill still pending could wipe what bl_ray_init_kernel writes at the very start
+        # of the render. Wait for the fills before handing the pointers over.
+        torch.cuda.current_stream(comm.device).synchronize()
         ptr = {name: buffers[name].data_ptr() for name in buffers}
         stats = ctx.render_device(ptr["image"], n_local, level=level, pixel_map=pixels, block_locs=blocks,
                                   sample_num_ptr=ptr["sample_num"], sample_flags_ptr=ptr["sample_flags"],

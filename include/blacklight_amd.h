@@ -285,7 +285,23 @@ typedef struct bl_stats {
   int32_t arithmetic;         /* BL_ARITH_EXACT or BL_ARITH_TOLERANT: the tier the last bl_render ran in          */
   int64_t n_deferred;         /* tolerant tier: samples whose cut decision was left to the exact kernel           */
   int64_t n_undefined;        /* BL_UNDEFINED_EDGE: samples where the reference reads past its arrays (edge cell used)     */
+  uint32_t switches;          /* BL_SWITCH_* bits active in this context (measurement switches, below); 0 in production  */
+  int32_t fused_variant;      /* tolerant tier with the locate step inside the coefficient kernel: 2 = bl_shade_fused2_kernel,
+                                 1 = bl_shade_fused_kernel, 0 = neither ran                                               */
 } bl_stats;
+
+/* Measurement switches: environment variables BLACKLIGHT_AMD_<NAME>, read ONCE by bl_init (never during a render) and echoed in
+ * bl_stats.switches, so that a benchmark line says which kernels it timed. They select an alternative kernel or layout with the
+ * same results (A/B runs, tests of the general paths); none of them changes an image. */
+#define BL_SWITCH_TENSOR_TRANSPORT (1u << 0)                /* polarized, tolerant tier: the exact tier's tensor transport      */
+#define BL_SWITCH_SPLIT_RECORDS (1u << 1)                   /* sample records as two arrays of 32-byte halves                   */
+#define BL_SWITCH_RECORD_EVERY_STEP (1u << 2)               /* steps in the empty shell around the grid leave records too       */
+#define BL_SWITCH_TOLERANT_POLARIZED_COEFFICIENTS (1u << 3) /* polarized, tolerant tier: the tolerant per-frequency kernel      */
+#define BL_SWITCH_GENERAL_LOCATE (1u << 4)                  /* bl_locate_kernel where bl_locate_plain_kernel applies            */
+#define BL_SWITCH_LANE_TRANSFER (1u << 5)                   /* one lane per ray where bl_transfer_quad_kernel applies           */
+#define BL_SWITCH_NO_FUSED_LOCATE (1u << 6)                 /* tolerant tier: locate kernel + bl_shade_fast_kernel              */
+#define BL_SWITCH_GENERAL_FUSED (1u << 7)                   /* bl_shade_fused_kernel where bl_shade_fused2_kernel applies       */
+#define BL_SWITCH_SAMPLE_RECORDS (1u << 8)                  /* tolerant tier: one transfer record per sample where composed maps apply */
 
 typedef struct bl_ctx bl_ctx;
 
@@ -369,6 +385,9 @@ BL_API int bl_debug_math(bl_ctx *ctx, int op, int64_t n, const double *x, const 
  * defers many samples, which exercises the list and its overflow path. ops 20-27 of bl_debug_math are the tolerant
  * tier's exp, expm1, cbrt, reciprocal, reciprocal square root and K_0, K_1, K_2. */
 BL_API int bl_debug_set_guard_band(bl_ctx *ctx, double relative_width);
+/* The measurement switches of this context (BL_SWITCH_*, above) set by the program instead of the environment bl_init read:
+ * what tests and A/B tools use between two renders of one context. */
+BL_API int bl_debug_set_switches(bl_ctx *ctx, uint32_t switches);
 BL_API int bl_get_stats(const bl_ctx *ctx, bl_stats *out);
 /* Text of the last failure on this context ("Error: ...\n"), or "" */
 BL_API const char *bl_last_error(const bl_ctx *ctx);

@@ -114,9 +114,6 @@ def worker(rank, world, port, mode, params_dict, mock_args, want_camera, out_pat
             outcome = str(failure)
         with open(f"{out_path}.rank{rank}", "w") as f:
             f.write(outcome)
-    elif mode == "gpu_device":
-        # one rank, nccl: the device-resident path (bl_render into torch tensors, gather on the GPU, one download)
-        pass
     elif mode == "stub":
         ctx = StubContext(params_dict)
         levels, warnings = bd.render_adaptive(ctx, comm, want_camera)

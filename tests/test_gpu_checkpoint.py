@@ -217,7 +217,14 @@ def test_sample_checkpoint_holds_what_the_reference_defines(built_library, case,
             ctx.set_scratch_limit(1 << 20)
         saved = ctx.render()
         assert (saved["stats"].n_chunks > 1) == chunked
-        assert gu.same_bits(saved["image"], plain["image"]).all() and np.array_equal(saved["sample_num"], plain["sample_num"])
+        if tier == "exact":
+            assert gu.same_bits(saved["image"], plain["image"]).all()
+        else:   # a run that saves located samples takes the locate kernel + bl_shade_fast_kernel, the plain one a fused kernel: the
+            # tier's arithmetic in another association of its operations (rounding level), the same NaN mask
+            assert np.array_equal(np.isnan(saved["image"]), np.isnan(plain["image"]))
+            with np.errstate(invalid="ignore"):
+                assert np.nanmax(np.abs(saved["image"] - plain["image"])) <= 1.0e-13 * np.nanmax(np.abs(plain["image"]))
+        assert np.array_equal(saved["sample_num"], plain["sample_num"])
         assert np.array_equal(saved["sample_num"], fx[f"{case}_sample_num"])
         stamp = os.path.getmtime(path)
         size = os.path.getsize(path)

@@ -377,9 +377,9 @@ def test_empty_shell_steps_leave_no_records(seed, built_library, monkeypatch):
         for tier in ("exact", "tolerant"):
             ctx.set_arithmetic(tier)
             out[tier] = ctx.render()
-            monkeypatch.setenv("BLACKLIGHT_AMD_RECORD_EVERY_STEP", "1")
+            ctx.debug_set_switches("RECORD_EVERY_STEP")
             out[tier + " all"] = ctx.render()
-            monkeypatch.delenv("BLACKLIGHT_AMD_RECORD_EVERY_STEP")
+            ctx.debug_set_switches()
     res = 20
     want = oracle_api.render(p.ptr, grid.desc(), _capi.RenderDesc, _capi.CameraFrame, n_rays=res * res, max_steps=int(p.get("ray_max_steps")),
                              n_freq=int(p.get("image_num_frequencies")))

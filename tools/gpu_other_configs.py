@@ -49,7 +49,7 @@ for nf, tier in ((10, "exact"), (10, "tolerant"), (64, "exact"), (64, "tolerant"
                                                 ms_locate=st.ms_locate, ms_shade=st.ms_shade, ms_transfer=st.ms_transfer, chunks=st.n_chunks,
                                                 finite_fraction=float(np.isfinite(res["image"]).mean()))
 # camera outside the grid (r = 100, the grid ends at 52; fallback values beyond it): the benchmark frame from farther away.
-# Steps in the empty shell leave no records (BlTraceArgs::skip_low); BLACKLIGHT_AMD_RECORD_EVERY_STEP = the same frame without that.
+# Steps in the empty shell leave no records (BlTraceArgs::skip_low); the RECORD_EVERY_STEP switch = the same frame without that.
 for tier in ("exact", "tolerant"):
     p = dict(bench.WORKLOAD)
     p.update(camera_r=100.0, fallback_nan=False, fallback_rho=1.0e-6, fallback_pgas=1.0e-8)
@@ -58,9 +58,9 @@ for tier in ("exact", "tolerant"):
         ctx.set_arithmetic(tier)
         for every in (False, True):
             if every:
-                os.environ["BLACKLIGHT_AMD_RECORD_EVERY_STEP"] = "1"
+                ctx.debug_set_switches("RECORD_EVERY_STEP")
             res, sec = timed(ctx, n=2)
-            os.environ.pop("BLACKLIGHT_AMD_RECORD_EVERY_STEP", None)
+            ctx.debug_set_switches()
             st = res["stats"]
             out[f"camera_at_100_{tier}" + ("_every_step_recorded" if every else "")] = dict(
                 seconds=sec, mrays_per_s=1024 * 1024 / sec / 1e6, samples_per_ray=st.n_samples / (1024 * 1024),
