@@ -89,6 +89,85 @@ def cpu_baseline(params_dict, grid, resolution, stride):
     return pixels, out, cores
 
 
+# BASELINE.json's configurations 2, 4 and 5 at size on ONE GPU (`--workload`): parity for them is in tests/ (reference windows and split
+# properties at these sizes); these lines say how fast they run and what bounds them. Parameters: the reference's example inputs as
+# the golden cases hold them (tests/golden), or the benchmark's workload with that configuration's physics switched on.
+OTHER_WORKLOADS = {
+    "formula512": "configuration 2: example_formula.input (formula mode, a = 0.9, camera at r = 1000, ray_max_steps = 7000), 512^2 camera",
+    "polarized1024": "configuration 4's physics: full-Stokes polarized transfer + image_tau, 1024^2 plane camera over the 256^3 mock",
+    "adaptive2048": "configuration 4: example_adaptive.input's refinement (8 x 8 blocks, one level, relative Laplacian) over a 2048^2 root camera, "
+                    "full-Stokes polarized transfer + image_tau, 256^3 mock, whole adaptive loop",
+    "truecolor1024x64": "configuration 5's physics: example_true_color.input's 64 frequencies (lin_wave, 1.5e11 ... 3.3e11 Hz), 1024^2 camera, 256^3 mock",
+}
+
+
+def other_workload(args):
+    """One of OTHER_WORKLOADS on one GPU: W warm-up renders, K timed ones, one JSON line in bench.py's schema."""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import blacklight_amd as bl
+    from blacklight_amd import mock
+    name = args.workload
+    grid = None
+    if name == "formula512":
+        import golden_util as gu
+        params = dict(gu.load_case("formula_dp")[1], camera_resolution=512)
+    else:
+        params = dict(WORKLOAD)
+        grid = mock.generate(n_r=args.grid, n_th=args.grid, n_ph=args.grid)
+        if name in ("polarized1024", "adaptive2048"):
+            params.update(image_polarization=True, image_tau=True)
+        if name == "adaptive2048":
+            params.update(camera_resolution=2048, adaptive_max_level=1, adaptive_block_size=8, adaptive_frequency_num=1, adaptive_val_cut=0.0,
+                          adaptive_val_frac=-1.0, adaptive_abs_grad_cut=0.0, adaptive_abs_grad_frac=-1.0, adaptive_rel_grad_cut=0.0,
+                          adaptive_rel_grad_frac=-1.0, adaptive_abs_lapl_cut=0.0, adaptive_abs_lapl_frac=-1.0, adaptive_rel_lapl_cut=1.0,
+                          adaptive_rel_lapl_frac=0.25, adaptive_num_regions=0)
+        if name == "truecolor1024x64":
+            params.update(image_num_frequencies=64, image_frequency_start=1.5e11, image_frequency_end=3.3e11, image_frequency_spacing="lin_wave")
+    with bl.Context(bl.Params.from_dict(params)) as ctx:
+        if grid is not None:
+            ctx.set_grid(grid)
+        ctx.set_arithmetic(args.arithmetic)
+        render = ctx.render_adaptive if name == "adaptive2048" else ctx.render
+        for _ in range(args.warmup):
+            render()
+        ms = dict(geodesic=0.0, locate=0.0, shade=0.0, transfer=0.0, wall=0.0)
+        rays = gathers = samples = 0
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = render()
+            for st in ([lv["stats"] for lv in out] if name == "adaptive2048" else [out["stats"]]):
+                ms["geodesic"] += st.ms_geodesic
+                ms["locate"] += st.ms_locate
+                ms["shade"] += st.ms_shade
+                ms["transfer"] += st.ms_transfer
+                ms["wall"] += st.ms_wall
+                rays += st.n_rays
+                gathers += st.n_gathers
+                samples += st.n_samples
+        elapsed = time.perf_counter() - t0
+        st = (out[0] if name == "adaptive2048" else out)["stats"]
+    rays_per_step = rays / args.steps
+    line = {
+        "metric": "Mrays/sec + achieved HBM GB/s", "value": rays / elapsed / 1.0e6, "unit": "Mrays/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": OTHER_WORKLOADS[name] + "; results on the host (PCIe download of the image rows inside the time)",
+                   "arithmetic": "tolerant" if st.arithmetic == 1 else "exact", "rays_per_step": rays_per_step,
+                   "samples_per_ray": samples / max(rays, 1), "parallelism": "1 GPU", "chunks_per_step": st.n_chunks},
+        "kernel_ms_per_step": {k: v / args.steps for k, v in ms.items()},
+        "switches": int(st.switches),
+    }
+    if gathers > 0 and ms["shade"] > 0.0:
+        algorithmic = 256.0 * gathers + 13.0 * rays
+        line["hbm_gbs_algorithmic_whole_pipeline"] = algorithmic / elapsed / 1.0e9
+        line["roofline"] = {"bound": "hbm", "kernel": "coefficient kernels of the run (see profiles/ for the kernel trace)",
+                            "achieved": algorithmic / (ms["shade"] * 1.0e-3) / 1.0e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": algorithmic / (ms["shade"] * 1.0e-3) / 1.0e9 / HBM_PEAK_GBS, "traffic": None}
+    else:
+        line["roofline"] = None   # no grid is read (formula mode): what bounds the frame is instruction issue, see profiles/README.md
+    print(json.dumps(line), flush=True)
+
+
 def visible_gpus():
     """GPUs of this box as the kernel driver lists them (KFD topology nodes with SIMDs), without initialising HIP or importing
     torch in the launching process: 0 without the driver, None when the topology is there but cannot be read (the ranks
@@ -112,6 +191,8 @@ def launch_ranks(n_gpus, argv):
     """`python bench.py --gpus N` without a launcher: start torch.distributed.run as a CHILD process and return its exit
     code. The launching process neither imports torch nor touches HIP: it holds no GPU context while the ranks run."""
     visible = visible_gpus()
+    if "--rehearse" in argv:
+        visible = None
     if visible is not None and visible < n_gpus:
         raise SystemExit(f"bench.py --gpus {n_gpus}: only {visible} GPU(s) visible on this box - refusing to run a smaller job "
                          "under that name")
@@ -151,7 +232,16 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--scratch-gib", type=float, default=0.0, help="override the library's scratch budget (GiB); 0 = default")
     ap.add_argument("--cpu-stride", type=int, default=2, help="CPU baseline traces every stride-th pixel per axis")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="N > 1 without N GPUs: the ranks share GPU 0 and gather over gloo (CPU tensors); rank 0 also renders the whole frame "
+                         "alone and reports whether the assembled frame equals it bit for bit. A rehearsal of the code path, not a measurement")
+    ap.add_argument("--workload", choices=["benchmark"] + sorted(OTHER_WORKLOADS), default="benchmark",
+                    help="BASELINE.json's other configurations at their own sizes on one GPU (same JSON schema, not the driver's line)")
     args = ap.parse_args()
+    if args.workload != "benchmark":
+        if args.gpus != 1:
+            raise SystemExit("bench.py --workload: the other configurations are timed on one GPU")
+        return other_workload(args)
     if args.gpus < 1:
         raise SystemExit("--gpus must be positive")
 
@@ -171,15 +261,21 @@ def main():
     distributed = world > 1
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
-    if torch.cuda.device_count() < (world if distributed else 1):
+    rehearse = distributed and args.rehearse
+    if rehearse:
+        local_rank = 0   # every rank on the one GPU
+    if torch.cuda.device_count() < (world if distributed and not rehearse else 1):
         raise SystemExit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if distributed:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=device)
+        if rehearse:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=device)
         if dist.get_world_size() != args.gpus:
-            raise SystemExit(f"RCCL sees {dist.get_world_size()} ranks, --gpus says {args.gpus}")
+            raise SystemExit(f"the process group has {dist.get_world_size()} ranks, --gpus says {args.gpus}")
 
     res = args.resolution
     tiled = distributed and args.mode == "tiled"
@@ -215,7 +311,7 @@ def main():
         """Final image(s) to rank 0 over RCCL (part of the job, inside the timed region)."""
         if not distributed:
             return None
-        parts = bd.gather_rows(image, dst=0)
+        parts = bd.gather_rows(image.cpu() if rehearse else image, dst=0)
         if parts is not None and tiled:
             return bd.assemble(parts, res, TILE)      # rank 0 de-tiles into (n_q, res*res)
         return parts
@@ -249,12 +345,12 @@ def main():
         elapsed = time.perf_counter() - t0
         per_rank = [elapsed]
         if distributed:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else device)
             every = [torch.zeros_like(t) for _ in range(world)]
             dist.all_gather(every, t)
             per_rank = [float(x.item()) for x in every]
             elapsed = max(per_rank)
-            counts = torch.tensor([float(n_rays), float(stats.n_gathers), float(stats.n_samples)], dtype=torch.float64, device=device)
+            counts = torch.tensor([float(n_rays), float(stats.n_gathers), float(stats.n_samples)], dtype=torch.float64, device="cpu" if rehearse else device)
             dist.all_reduce(counts, op=dist.ReduceOp.SUM)
             totals = [float(x) for x in counts.tolist()]
         else:
@@ -282,6 +378,32 @@ def main():
                          "nan_mask_equal": bool((torch.isnan(image) == torch.isnan(exact_image)).all().item()),
                          "sample_num_equal": bool((sample_num == exact_num).all().item()), "pixels": int(n_rays)}
 
+    rehearsal = None
+    if rehearse and tiled:
+        # the frame the ranks put together against the frame one rank renders alone: same bits, or the tiling / padding /
+        # gather / de-tiling of this very code path is wrong somewhere
+        ctx.set_arithmetic(args.arithmetic)
+        step()
+        torch.cuda.synchronize()
+        assembled = gather_image()
+        gathered_nums = bd.gather_rows(sample_num.cpu(), dst=0)
+        if rank == 0:
+            alone = torch.zeros((1, res * res), dtype=torch.float64, device=device)
+            num_alone = torch.zeros(res * res, dtype=torch.int32, device=device)
+            torch.cuda.synchronize()
+            ctx.render_device(alone.data_ptr(), res * res, sample_num_ptr=num_alone.data_ptr())
+            torch.cuda.synchronize()
+            nums = bd.assemble([part.reshape(1, -1) for part in gathered_nums], res, TILE).reshape(-1)
+            x, y = assembled.cpu().numpy(), alone.cpu().numpy()
+            a, b = x.view(np.uint64), y.view(np.uint64)
+            with np.errstate(invalid="ignore"):
+                distance = float(np.nanmax(np.where(np.isnan(x) & np.isnan(y), 0.0, np.abs(x - y))) / np.nanmax(np.abs(y)))
+            rehearsal = {"assembled_frame_equals_single_rank_frame_bit_for_bit": bool(np.array_equal(a, b)), "pixels": int(res * res),
+                         "differing_pixels": int((a != b).sum()), "image_linf_over_max": distance,
+                         "nan_mask_equal": bool(np.array_equal(np.isnan(x), np.isnan(y))),
+                         "sample_num_equal": bool(np.array_equal(nums.cpu().numpy(), num_alone.cpu().numpy())),
+                         "ranks_on_one_gpu": world, "collectives": "gloo"}
+        dist.barrier()
     if rank == 0:
         stats = main_run["stats"]
         total_rays, total_gathers, total_samples = main_run["totals"]
@@ -330,6 +452,9 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source, "traffic_stale": traffic_stale,
                          "algorithmic_bytes_per_launch": main_run["bytes_per_launch"], "ms_per_launch": main_run["shade_ms_per_launch"]},
         }
+        if rehearsal is not None:
+            line["rehearsal"] = rehearsal
+            line["data"] = "synthetic; REHEARSAL: the ranks shared one GPU and gathered over gloo - times mean nothing"
         line["switches"] = int(stats.switches)   # BL_SWITCH_* measurement switches active in this run (0: none)
         if tier_distance is not None:
             line["tolerant_vs_exact"] = tier_distance

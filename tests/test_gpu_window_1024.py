@@ -44,6 +44,45 @@ def test_reference_windows_of_the_benchmark_frame(built_library):
     assert np.nanmax(np.abs(got - want_a)) / np.nanmax(np.abs(want_a)) < 1.0e-6
 
 
+FORMULA_FIXTURE = os.path.join(gu.GOLDEN_DIR, "window_512_formula.npz")
+
+
+@pytest.mark.skipif(not os.path.exists(FORMULA_FIXTURE), reason="window_512_formula fixture not generated")
+def test_reference_windows_of_configuration_2_at_its_own_lattice(built_library):
+    """BASELINE's configuration 2 (example_formula.input, a = 0.9, 512^2) against the reference at that lattice: two 32 x 32 windows
+    - the edge of the shadow, where rays orbit for thousands of samples, and the periphery - which the unmodified reference computed
+    through forced refinement of a 128^2 root camera (tools/make_goldens.py window_512_formula; radiation_adaptive.cpp:50-69). The HIP
+    path renders those pixels of the plain 512^2 camera: bit for bit in the exact tier (pinned math library), 1e-6 from the stock
+    reference, and the tolerant tier within 1e-9 of it with the same counts and NaN mask."""
+    import blacklight_amd as bl
+    fx = np.load(FORMULA_FIXTURE, allow_pickle=False)
+    p = bl.Params.from_dict(json.loads(str(fx["params"])))
+    res, bs = int(p.get("camera_resolution")), 16
+    assert res == 512 == int(fx["lattice"])
+    locs = fx["B_block_locs"]
+    assert np.array_equal(locs, fx["A_block_locs"]) and locs.shape[0] == 8
+    iv, iu = np.mgrid[0:bs, 0:bs]
+    pixels = np.concatenate([((bv * bs + iv) * res + (bu * bs + iu)).reshape(-1) for bv, bu in locs]).astype(np.int32)
+    with bl.Context(p) as ctx:
+        exact = ctx.render(pixel_map=pixels)
+        # one ray of the window runs into ray_max_steps (NaN with fallback_nan): the reference's warning, with its count
+        assert str(fx["B_warnings"]) == "Warning: 1 out of 2048 geodesics terminate unexpectedly.\n" and str(fx["B_warnings"]) in ctx.warnings
+        ctx.set_arithmetic("tolerant")
+        tolerant = ctx.render(pixel_map=pixels)
+        assert tolerant["stats"].arithmetic == 1
+    assert exact["sample_flags"].sum() == 1 and np.isnan(exact["image"][0]).sum() == 1
+    want_b, want_a = fx["B_I_nu"].reshape(-1), fx["A_I_nu"].reshape(-1)
+    got = exact["image"][0]
+    same = gu.same_bits(got, want_b)
+    assert same.all(), f"{(~same).sum()} of {same.size} window pixels differ from the reference (pinned math)"
+    assert exact["sample_num"].max() > 5000   # (the window does hold the long orbits)
+    peak = np.nanmax(np.abs(want_b))
+    assert np.nanmax(np.abs(got - want_a)) / np.nanmax(np.abs(want_a)) < 1.0e-5   # (a = 0.9: the envelope SURVEY.md 7 measured between math libraries)
+    assert np.array_equal(np.isnan(tolerant["image"][0]), np.isnan(want_b))
+    assert np.nanmax(np.abs(tolerant["image"][0] - want_b)) / peak < 1.0e-9
+    assert np.array_equal(tolerant["sample_num"], exact["sample_num"]) and np.array_equal(tolerant["sample_flags"], exact["sample_flags"])
+
+
 def test_full_size_frame_is_independent_of_how_it_is_split(built_library):
     """Size-independent properties at the benchmark's own size (1024^2 camera, 256^3 grid): every ray is independent,
     so the frame rendered in one call, the frame assembled from the 32 x 32-pixel tiles of eight emulated ranks

@@ -38,6 +38,22 @@ def test_default_mock_hash(built_library, label, args):
     assert sum(same) >= 6, same
 
 
+def test_benchmark_grid_is_the_reference_generators(built_library):
+    """The 256^3 grid of bench.py and of the reference windows at the benchmark's size (tests/test_gpu_window_1024.py, which are
+    bit-exact assertions): every variable's SHA-256 equals that of the reference script's own arrays
+    (tests/golden/mock_hashes.json["n256"]). blacklight_amd.mock evaluates the analytic profiles with numpy's exp / power / cos; a
+    numpy whose vector functions differ by an ulp in a 1-D factor would move a few stored floats by one place - and every bit-exact
+    window test with them. This test names that cause."""
+    from blacklight_amd import mock
+    with open(os.path.join(gu.GOLDEN_DIR, "mock_hashes.json")) as f:
+        hashes = json.load(f)["n256"]
+    grid = mock.generate(n_r=256, n_th=256, n_ph=256)
+    assert list(grid.prim.shape) == hashes["shape"]
+    differing = [v for v in range(8) if hashlib.sha256(grid.prim[v].tobytes()).hexdigest() != hashes["per_var_sha256"][v]]
+    assert not differing, (f"variables {differing} of the 256^3 mock differ from the reference generator's: numpy {np.__version__}'s elementary functions "
+                           "are not the ones the fixtures were made with; the reference windows of the benchmark frame will not be bit-exact")
+
+
 def test_grid_desc_layout(built_library):
     from blacklight_amd import mock
     grid = mock.generate(n_r=6, n_th=4, n_ph=5)

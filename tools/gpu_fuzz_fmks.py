@@ -81,7 +81,7 @@ def main():
                 d = np.abs(tol["image"] - exact["image"]) / scale
             d = float(np.nanmax(d)) if np.isfinite(d).any() else 0.0
             worst = max(worst, d)
-            if not d < 3.0e-11:   # (the fixture's steep gradients near its polar cut: up to 1.4e-11 seen, rounding level)
+            if not d < 5.0e-11:   # (the fixture's steep gradients near its polar cut: up to 1.4e-11 seen, rounding level; the test's bound)
                 problems.append(f"tolerant distance {d:.2e}")
             if problems:
                 bad.append(seed)

@@ -582,6 +582,48 @@ def make_window_variant(name):
     np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **fixture)
 
 
+# Reference windows of BASELINE's configuration 2 at its own lattice: example_formula.input (a = 0.9, camera at r = 1000,
+# ray_max_steps = 7000) at 512^2, by forced refinement of a 128^2 root camera to level 2 (radiation_adaptive.cpp:50-69). Root blocks
+# of 16 pixels are 3.75 wide, centred at -13.125 + 3.75 b; a region that holds one root centre and the centre of one of its level-1
+# children (+-0.9375 from it) yields 2 x 2 level-2 blocks = a 32 x 32 window of the 512^2 lattice. Two windows: the edge of the
+# shadow where rays orbit longest (root pixel (59, 91) has 6 794 of the 7 000 possible samples), and the periphery.
+FORMULA_WINDOW_REGIONS = [(5.5, 6.7, -2.0, -0.8), (-9.5, -8.3, 9.25, 10.45)]
+
+
+def make_formula_window():
+    name = "window_512_formula"
+    root, level, lattice = 128, 2, 512
+    params = dict(FORMULA_BASE)
+    params.update(camera_resolution=root, checkpoint_geodesic_save="false", adaptive_max_level=level, adaptive_block_size=16,
+                  adaptive_frequency_num=0, adaptive_val_cut=0.0, adaptive_val_frac=-1.0, adaptive_abs_grad_cut=0.0,
+                  adaptive_abs_grad_frac=-1.0, adaptive_rel_grad_cut=0.0, adaptive_rel_grad_frac=-1.0,
+                  adaptive_abs_lapl_cut=0.0, adaptive_abs_lapl_frac=-1.0, adaptive_rel_lapl_cut=0.0,
+                  adaptive_rel_lapl_frac=-1.0, adaptive_num_regions=len(FORMULA_WINDOW_REGIONS), output_camera="false")
+    for r, (x0, x1, y0, y1) in enumerate(FORMULA_WINDOW_REGIONS, start=1):
+        params[f"adaptive_region_{r}_level"] = level
+        params[f"adaptive_region_{r}_x_min"] = x0
+        params[f"adaptive_region_{r}_x_max"] = x1
+        params[f"adaptive_region_{r}_y_min"] = y0
+        params[f"adaptive_region_{r}_y_max"] = y1
+    workdir = os.path.join(WORK, name)
+    os.makedirs(os.path.join(workdir, "data"), exist_ok=True)
+    os.makedirs(os.path.join(workdir, "output"), exist_ok=True)
+    write_input(os.path.join(workdir, "case.input"), params)
+    plain = {k: v for k, v in FORMULA_BASE.items() if k not in ("checkpoint_geodesic_save", "checkpoint_geodesic_file")}
+    plain.update(camera_resolution=lattice, checkpoint_geodesic_save="false")
+    fixture = dict(params=json.dumps(plain), reference_params=json.dumps(params), lattice=lattice)
+    for tier, preload in (("A", False), ("B", True)):
+        fixture[f"{tier}_warnings"] = run_reference(workdir, "case.input", preload)
+        npz = np.load(os.path.join(workdir, "output", "out.npz"))
+        fixture[f"{tier}_block_locs"] = npz[f"adaptive_block_locs_{level}"]
+        fixture[f"{tier}_I_nu"] = npz[f"adaptive_I_nu_{level}"]
+        print(tier, "level-2 blocks", npz[f"adaptive_block_locs_{level}"].tolist(), "I_nu", npz[f"adaptive_I_nu_{level}"].shape, "warnings", repr(fixture[f"{tier}_warnings"]))
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **fixture)
+    a, b = fixture["A_I_nu"], fixture["B_I_nu"]
+    print(f"{name}: A-vs-B max rel {np.nanmax(np.abs(a - b)) / np.nanmax(np.abs(b)):.2e}, blocks equal {np.array_equal(fixture['A_block_locs'], fixture['B_block_locs'])}, "
+          f"NaN {int(np.isnan(b).sum())}")
+
+
 # ------------------------------------------------------------------------------------------------
 # Snapshot-reader fixtures (tests/golden/reader/): small .athdf files exactly as h5py wrote them, the arrays
 # h5py reads back from them, and the reference's images for a two-file series (simulation_multiple) of them.
@@ -1236,6 +1278,8 @@ if __name__ == "__main__":
             make_checkpoint_fixtures()
         elif case_name == "sample_checkpoint":
             make_sample_checkpoint_fixtures()
+        elif case_name == "window_512_formula":
+            make_formula_window()
         elif case_name in WINDOW_VARIANTS:
             make_window_variant(case_name)
         elif case_name == "harm3d":
