@@ -181,6 +181,7 @@ __global__ void bl_debug_math_kernel(int op, long long n, const double *x, const
       break;
     }
     case 36: r = fastmath::log(a); break;
+    case 38: r = bl_pow_neg_fifth(a); break;
     case 37: r = fastmath::pow(a, b); break;
     default: break;
   }

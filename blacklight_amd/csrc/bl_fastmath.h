@@ -60,6 +60,53 @@ __device__ __forceinline__ double expm1_core(double x, int *k) {
   *k = (int)kd;
   return r + __builtin_fma(r2 * r, q, 0.5 * r2);
 }
+// ---- 64-bit constants as scalar operands. No fp64 vector instruction takes a 64-bit literal: a constant has to sit in a register
+// pair, and the compiler's choice is two v_mov_b32 into vector registers in front of every use - for the addend of a Horner step
+// always, because it prefers the two-address v_fmac_f64 and copies the constant into the destination first. fma_k / add_k are the
+// three-address forms with the constant as the scalar operand (a literal handed in becomes two s_mov_b32; a value the caller keeps
+// in scalar registers across a loop - resident_constant() - costs nothing per use).
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ double fma_k(double a, double b, double c_uniform) {   // a * b + c
+  double d;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c_uniform));
+  return d;
+}
+__device__ __forceinline__ double add_k(double a, double c_uniform) {   // a + c
+  double d;
+  asm("v_add_f64 %0, %1, %2" : "=v"(d) : "v"(a), "s"(c_uniform));
+  return d;
+}
+__device__ __forceinline__ double resident_constant(double v) {   // a literal the optimiser can neither fold nor rematerialise
+  asm volatile("" : "+s"(v));
+  return v;
+}
+#else
+__device__ __forceinline__ double fma_k(double a, double b, double c_uniform) { return __builtin_fma(a, b, c_uniform); }
+__device__ __forceinline__ double add_k(double a, double c_uniform) { return a + c_uniform; }
+__device__ __forceinline__ double resident_constant(double v) { return v; }
+#endif
+// expm1_core() with its fifteen constants handed in (kExpConstants through resident_constant(): a loop that evaluates one
+// exponential per iteration keeps them in scalar registers): the same operations, bit-identical results
+constexpr double kExpConstants[15] = {0x1.71547652b82fep+0, 0x1.62e42feep-1, 0x1.a39ef35793c76p-33, 0x1.94328fcb8199cp-37, 0x1.61bfaa228dde5p-33,
+                                      0x1.1eed7a01fc8b7p-29, 0x1.ae642c82e33d5p-26, 0x1.27e4fb7a2782ap-22, 0x1.71de3a5aa7bb7p-19, 0x1.a01a01a019b63p-16,
+                                      0x1.a01a01a0196acp-13, 0x1.6c16c16c16c17p-10, 0x1.1111111111111p-7, 0x1.5555555555555p-5, 0x1.5555555555555p-3};
+__device__ __forceinline__ double expm1_core(double x, int *k, const double (&c)[15]) {
+  const double kd = __builtin_rint(x * c[0]);
+  double r = __builtin_fma(-kd, c[1], x);
+  r = __builtin_fma(-kd, c[2], r);
+  double q = add_k(r * c[3], c[4]);
+#pragma unroll
+  for (int i = 5; i < 15; i++) q = fma_k(q, r, c[i]);
+  const double r2 = r * r;
+  *k = (int)kd;
+  return r + __builtin_fma(r2 * r, q, 0.5 * r2);
+}
+__device__ __forceinline__ double exp(double x, const double (&c)[15]) {
+  x = x > 710.0 ? 710.0 : (x < -746.0 ? -746.0 : x);
+  int k;
+  const double e = expm1_core(x, &k, c);
+  return __builtin_amdgcn_ldexp(1.0 + e, k);
+}
 // exp(x); x beyond the range of doubles saturates to 0 / inf
 __device__ __forceinline__ double exp(double x) {
   x = x > 710.0 ? 710.0 : (x < -746.0 ? -746.0 : x);

@@ -358,7 +358,7 @@ __global__ void __launch_bounds__(64, BL_GEO_ONE_WAVE(kIntegrator, kTime, kSpinZ
           if (!(error <= 1.0)) {   // :197-209
             double h_factor = 0.2;
             if (error - error == 0.0) {   // std::isfinite
-              double h_factor_ideal = 0.9 * bl_pow(error, -0.2);
+              double h_factor_ideal = 0.9 * bl_pow_neg_fifth(error);
               h_factor = std_max(h_factor_ideal, 0.2);
             }
             h_new = h * h_factor;
@@ -367,7 +367,7 @@ __global__ void __launch_bounds__(64, BL_GEO_ONE_WAVE(kIntegrator, kTime, kSpinZ
           } else {                 // :210-224
             double h_factor = 10.0;
             if (error > 0.0) {
-              h_factor = 0.9 * bl_pow(error, -0.2);
+              h_factor = 0.9 * bl_pow_neg_fifth(error);
               h_factor = std_max(h_factor, 0.2);
               h_factor = std_min(h_factor, 10.0);
             }
@@ -524,7 +524,6 @@ __global__ void __launch_bounds__(64, BL_GEO_ONE_WAVE(kIntegrator, kTime, kSpinZ
     const BlRecip rc_steps = bl_recip((double)num_steps_ideal);
     const double len = bl_div_r(h, rc_steps);
     double position = 0.5;   // nn + 0.5, exact
-    unsigned int window_prev = 0xffffffffu;   // segment_rows: the 16-record window of the lane's previous sample of this step (none yet)
     for (int nn = 0; nn < max_emit; nn++, position += 1.0) {
       if (nn < emit) {
         double smp[7];
@@ -552,15 +551,16 @@ __global__ void __launch_bounds__(64, BL_GEO_ONE_WAVE(kIntegrator, kTime, kSpinZ
         // read the same grid cells - laid out row by row instead, the coefficient kernels take 4 ms longer per frame)
         const int place = excl + nn;
         const long long at = place < old_room ? old_base + place : new_base + (place - old_room);
-        if (P.segment_rows) {
+        if (!kShell && P.segment_rows) {   // (the instantiation that skips the empty shell has no register left for it: bl_render.hip does not ask)
           // Composed transfer maps (bl_shade_fused2_kernel): the kept samples of a ray that lie side by side within one aligned
           // group of 16 records - a lane's run of a step, cut where it crosses such a boundary - are one SEGMENT, numbered along the
           // ray; the record carries the segment's number instead of the sample's, and the coefficient kernel, whose lanes of a
           // DPP row hold exactly such a group, composes a segment's affine maps and stores one map per segment in row
           // ray_offset + number.
-          const unsigned int window = (unsigned int)(at >> 4);
-          seg += (!dead && window != window_prev) ? 1 : 0;
-          window_prev = window;
+          // (the lane's previous sample of this step sits one slot below, or at the end of the old block: a new group of 16
+          // either way when this slot's index is a multiple of 16 or the first of the new block)
+          const bool first_of_group = nn == 0 || ((unsigned int)at & 15u) == 0u || place == old_room;
+          seg += (!dead && first_of_group) ? 1 : 0;
           hot.n = (unsigned int)(seg - 1);
         }
         BlSampleCold cold;
@@ -607,8 +607,8 @@ __global__ void __launch_bounds__(64, BL_GEO_ONE_WAVE(kIntegrator, kTime, kSpinZ
       if (kShell) P.ray_skipped[slot] = skipped;
       P.ray_flags[slot] = flag ? 1 : 0;
       // rows of the kept samples in the per-sample arrays, in the order in which rays finish; slots not emitted go back
-      const int rows = P.segment_rows ? seg : final_num;
-      if (P.segment_rows) P.ray_rows[slot] = rows;
+      const int rows = (!kShell && P.segment_rows) ? seg : final_num;
+      if (!kShell && P.segment_rows) P.ray_rows[slot] = rows;
       P.ray_offset[slot] = (long long)atomicAdd(&P.counters[BL_CNT_SAMPLES], (unsigned long long)rows);
       atomicAdd(&P.counters[BL_CNT_COMMITTED], (unsigned long long)(-(long long)(P.ray_max_steps - (sample_num - (kShell ? skipped : 0)))));
       have_ray = false;

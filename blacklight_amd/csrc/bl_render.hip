@@ -267,6 +267,8 @@ void PlanJob(RenderJob &job) {
   job.skip_shell = job.simulation && !job.aux && !ctx->polarized && !job.slow && !job.geo_load && !job.geo_save && !job.sample_save
       && !job.need_time && p.simulation_coord == BL_COORD_SKS && !ctx->grid_dev.fmks && !p.fallback_nan && ctx->grid_outer_x1 > 0.0
       && ctx->grid_outer_x1 < p.camera_r && !(ctx->switches & BL_SWITCH_RECORD_EVERY_STEP);
+  // (the geodesic kernel's instantiation that skips the shell has no register to number segments with: per-sample records there)
+  if (job.skip_shell) job.composed = false;
   // ... and in the exact coefficient kernel (plain images): the frequency loop as lanes of bl_coefficients_freq_kernel
   job.coef_split = !job.fast && job.simulation && !job.aux && !ctx->polarized && job.n_nu >= 4;
   // (polarized runs list the samples without coefficients there - cut samples, cut cells - which are many more)

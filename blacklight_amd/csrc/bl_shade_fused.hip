@@ -53,27 +53,17 @@ __device__ __forceinline__ double uniform_value(double v) {   // a wave-uniform 
   return __hiloint2double(hi, lo);
 }
 
-// ---- 64-bit constants as scalar operands. No fp64 vector instruction takes a 64-bit literal: a constant has to sit in a register
-// pair, and the compiler's choice is two v_mov_b32 into vector registers in front of every use - for the addend of a Horner step
-// always, because it prefers the two-address v_fmac_f64 and copies the constant into the destination first. Those moves were a
-// fifth of this kernel's vector instructions. KS(c) hands a literal through a scalar register pair (two s_mov_b32 on the scalar
-// unit, which issues beside the vector unit); fma_k / add_k are the three-address forms with the constant as the scalar operand.
+// ---- 64-bit constants as scalar operands (bl_fastmath.h: fma_k, add_k). KS(c) hands a literal through a scalar register pair - two
+// s_mov_b32 where the compiler would put two v_mov_b32: the same instruction count, but on the scalar unit and, more to the point,
+// none at all for the addends of the Horner steps, which fma_k takes as scalar operands.
 #if defined(BLV_VECTOR_LITERALS) || !defined(__HIP_DEVICE_COMPILE__)   // (A/B variant: the compiler's own choice)
 #define KS(c) (c)
 __device__ __forceinline__ double fma_k(double a, double b, double c_uniform) { return __builtin_fma(a, b, c_uniform); }
 __device__ __forceinline__ double add_k(double a, double c_uniform) { return a + c_uniform; }
 #else
 #define KS(c) BLM_K(c)
-__device__ __forceinline__ double fma_k(double a, double b, double c_uniform) {   // a * b + c
-  double d;
-  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c_uniform));
-  return d;
-}
-__device__ __forceinline__ double add_k(double a, double c_uniform) {   // a + c
-  double d;
-  asm("v_add_f64 %0, %1, %2" : "=v"(d) : "v"(a), "s"(c_uniform));
-  return d;
-}
+using fastmath::add_k;
+using fastmath::fma_k;
 #endif
 // The tier's elementary functions (bl_fastmath.h: same polynomials, same reductions, same accuracy) with their coefficients as
 // scalar operands

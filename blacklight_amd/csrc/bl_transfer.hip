@@ -42,6 +42,10 @@ __global__ void __launch_bounds__(256) bl_transfer_freq_kernel(BlTransferArgs P)
       const double f_1_2 = bl_sqrt_g(f), f_1_3 = fastmath::cbrt(f);
       const double f_1_6 = bl_sqrt_g(f_1_3), f_inv = fastmath::rcp(f);
       const double f_inv2 = f_inv * f_inv;
+      // (one exponential per sample and frequency is most of this loop: its constants stay in scalar registers across it)
+      double exp_c[15];
+#pragma unroll
+      for (int i = 0; i < 15; i++) exp_c[i] = fastmath::resident_constant(fastmath::kExpConstants[i]);
       const double2 *in = reinterpret_cast<const double2 *>(P.freq_inputs + (size_t)P.ray_offset[slot]);
       for (int n = num - 1; n >= 0; n--) {   // reference sample order is reversed integration order (geodesics.cpp:832-840)
         const double2 q0 = in[4 * (size_t)n], q1 = in[4 * (size_t)n + 1], q2 = in[4 * (size_t)n + 2], q3 = in[4 * (size_t)n + 3];
@@ -52,7 +56,7 @@ __global__ void __launch_bounds__(256) bl_transfer_freq_kernel(BlTransferArgs P)
           // bl_shade_fast_kernel's frequency loop (simulation_coefficients.cpp:464-523, unpolarized.cpp:74-110)
           const double xx_1_3 = q1.x * f_1_3;
           const double var_c = q0.y * f_1_2 + kPow2_11_12 * (q1.y * f_1_6);
-          const double j_val = q2.y * f_inv2 * fastmath::exp(-xx_1_3) * var_c * var_c;
+          const double j_val = q2.y * f_inv2 * fastmath::exp(-xx_1_3, exp_c) * var_c * var_c;
           // h nu / (k T_e) is tiny for the hot plasma that shines (Rayleigh-Jeans): the same four-term form as for the thin step
           const double xp = q2.x * f;
           const double planck = xp < 0x1p-10 ? xp * (1.0 + 0.5 * xp * (1.0 + (1.0 / 3.0) * xp * (1.0 + 0.25 * xp))) : fastmath::expm1(xp);

@@ -366,6 +366,56 @@ BLM_FN double bl_pow(double x, double y) {
   return sign * blm_exp_dd(a);
 }
 
+/* bl_pow(x, -0.2) - the Dormand-Prince step controller's only power (geodesics.cpp:202, :215), once per step attempt - by a
+   routine of its own on the device: a power correctly rounded is one number, so any routine that rounds correctly returns
+   bl_pow's bits. The exponent is the DOUBLE -0.2 = -(1 + 2^-54) / 5, not -1/5: the result is Y^(1 + 2^-54) with Y = x^(-1/5).
+   x = m 2^(5q) with m in [1, 32); y ~ m^(-1/5) from a single-precision seed and two Newton steps on 1 - m y^5 in double; one more
+   step with m y^5 in double-double arithmetic leaves y + delta within 2^-98 of the root; the factor Y^(2^-54) = 1 + 2^-54 ln Y
+   enters delta with ln Y from the hardware's single-precision logarithm (1e-7 absolute, i.e. 2^-77 of the result). The sum
+   is rounded once, and the rounding is accepted only when the exact remainder t of that sum keeps 2^-12 half-units (2^-66 of the
+   result) away from a rounding boundary. That band is set by bl_pow, not by this routine: the contract is bl_pow's bits, and
+   bl_pow is NOT correctly rounded everywhere - the tail of its logarithm's series is summed in plain double, which leaves it
+   ~2^-71 of the result in the worst cases seen (x = 5.853689088059315: the true power lies 2.3e-6 units above a midpoint and
+   bl_pow rounds down) - so this routine only answers where a 2^-66 error cannot change the rounding, and asks bl_pow itself
+   otherwise (2^-12 of the calls, and arguments outside 2^+-900). ~80 instructions where bl_pow takes ~520 (7 % of a step).
+   Host builds: bl_pow. tests/test_gpu_math.py compares the two on 10^8 arguments. */
+#if defined(__HIP_DEVICE_COMPILE__)
+static inline __device__ double bl_pow_neg_fifth(double x) {
+  const uint64_t u = blm_bits(x);
+  const int e_biased = (int)(u >> 52);                       /* sign bit set (x < 0) lands far outside the window below */
+  double result = 0.0;
+  bool fast = (unsigned)(e_biased - 123) < 1800u;            /* x finite, positive, exponent in [-900, 899] */
+  if (fast) {
+    const int e = e_biased - 1023;
+    const int q = (int)(((unsigned)(e + 5000) * 52429u) >> 18) - 1000;   /* floor(e / 5) */
+    const int r = e - 5 * q;                                 /* 0 ... 4 */
+    const double m = blm_from_bits((u & 0x000fffffffffffffull) | ((uint64_t)(1023 + r) << 52));   /* [1, 32) */
+    double y = (double)__builtin_amdgcn_exp2f(-0.2f * __builtin_amdgcn_logf((float)m));        /* ~2^-21 */
+    for (int step = 0; step < 2; step++) {                   /* y <- y + y (1 - m y^5) / 5 */
+      const double y2 = y * y, y4 = y2 * y2;
+      const double rho = __builtin_fma(-(y4 * y), m, 1.0);
+      y = __builtin_fma(y * 0.2, rho, y);
+    }
+    blm_dd p = blm_two_prod(y, y);                           /* y^2 exactly */
+    p = blm_dd_mul(p, p);                                    /* y^4 */
+    p = blm_dd_mul_d(p, y);                                  /* y^5 */
+    p = blm_dd_mul_d(p, m);                                  /* m y^5 = 1 + O(2^-51) */
+    const double rho = (1.0 - p.hi) - p.lo;
+    /* ln Y = ln y - q ln 2 */
+    const double ln_y = __builtin_fma(-(double)q, 0x1.62e42fefa39efp-1, (double)__builtin_amdgcn_logf((float)y) * 0x1.62e42fefa39efp-1);
+    const double delta = __builtin_fma(y * 0x1p-54, ln_y, (y * 0.2) * rho);
+    const double s = y + delta;
+    const double t = (y - s) + delta;                        /* y + delta = s + t exactly (|delta| << |y|) */
+    /* s lies in [1/2, 1]: half a unit in its last place is 2^-54 (2^-53 above 1, which m >= 1 never reaches) */
+    fast = !(blm_abs(t) >= 0x1p-54 * (1.0 - 0x1p-12));
+    result = s * blm_pow2i(-q);                              /* exact: |q| <= 180 */
+  }
+  return fast ? result : bl_pow(x, -0.2);
+}
+#else
+#define bl_pow_neg_fifth(x) bl_pow((x), -0.2)
+#endif
+
 /* Several powers of one base: bl_pow(x, y) spends a third of its work on log(x). bl_pow_base() takes that
    logarithm once; bl_pow_of(base, y) is bl_pow(x, y) bit for bit - for a finite positive x other than 1 it is the
    tail of bl_pow on the same double-double logarithm, for every other x it calls bl_pow. */

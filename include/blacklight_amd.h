@@ -378,7 +378,8 @@ BL_API int bl_render(bl_ctx *ctx, const bl_render_desc *d);
  * host arrays x (and y for two-argument functions; may be NULL otherwise) and return the results in out.
  * op: 0 exp, 1 expm1, 2 log, 3 cbrt, 4 sin, 5 cos, 6 acos, 7 atan, 8 atan2(x, y), 9 pow(x, y),
  * 10 hypot (blmath.h), 11 bl_hypot_g, 12 bl_sqrt_g, 13 bl_div_g(x, y) (bl_geometry.h), 14 sqrt, 15 x / y,
- * 16 sincos -> sin, 17 sincos -> cos. Used by the tests to compare the device arithmetic with the host's. */
+ * 16 sincos -> sin, 17 sincos -> cos; 38 bl_pow_neg_fifth (the step controller's x^(-1/5), blmath.h). Used by the tests to compare the
+ * device arithmetic with the host's. */
 BL_API int bl_debug_math(bl_ctx *ctx, int op, int64_t n, const double *x, const double *y, double *out);
 /* Tolerant tier, tests only: relative half-width of the band around an active cell cut threshold inside which the cut
  * decision of a sample is left to the exact kernel (default 1e-9; the tolerant arithmetic is good to ~1e-13). A wide band

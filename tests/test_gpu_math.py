@@ -141,3 +141,35 @@ def test_exact_devices_inside_their_stated_domain(host, device):
     u = rng.uniform(-2500.0, 2500.0, N)
     v = rng.uniform(-100.0, 100.0, N) * rng.choice([1.0, 1e-8, 1e-16], N)
     assert _bits_equal(device.debug_math(11, u, v), _host2(host, "hypot", u, v)).all()
+
+
+def test_step_controller_power_equals_bl_pow(device):
+    """bl_pow_neg_fifth(x) - the Dormand-Prince controller's x^(-1/5) by Newton steps and a Ziv rounding test (blmath.h) - against
+    bl_pow(x, -0.2) on the device, bit for bit, on 10^8 arguments: the error norms a controller meets (1e-12 ... 1e3, most of them
+    between 1e-3 and 10), the whole window of the fast path and beyond it, exact fifth powers of two, neighbours of 1, specials.
+    Sample counts hang on the last bit of this number; the goldens check it through real rays, this checks the function."""
+    rng = np.random.default_rng(20261004)
+    total = 0
+    for batch in range(10):
+        n = 10_000_000
+        kind = batch % 5
+        if kind == 0:
+            x = np.exp(rng.uniform(np.log(1.0e-3), np.log(10.0), n))
+        elif kind == 1:
+            x = np.exp(rng.uniform(np.log(1.0e-12), np.log(1.0e3), n))
+        elif kind == 2:
+            x = np.ldexp(rng.uniform(0.5, 1.0, n), rng.integers(-1000, 1001, n))
+        elif kind == 3:
+            # neighbours of the exact cases 2^(5 q) and of 1, where a result sits next to a power of two
+            q = rng.integers(-150, 151, n)
+            x = np.ldexp(1.0, 5 * q) * (1.0 + rng.integers(-40, 41, n) * 2.0 ** -52)
+        else:
+            x = rng.uniform(0.0, 2.0, n)
+        if batch == 0:
+            x[:12] = [0.0, -0.0, np.inf, -np.inf, np.nan, -1.0, 5e-324, 2.2250738585072014e-308, 1.7976931348623157e308, 1.0, 32.0, 2.0 ** -900]
+        fast = device.debug_math(38, x)
+        slow = device.debug_math(9, x, np.full(n, -0.2))
+        same = gu.same_bits(fast, slow)
+        assert same.all(), f"batch {batch}: {(~same).sum()} differ, first at x = {x[~same][0]!r}: {fast[~same][0]!r} vs {slow[~same][0]!r}"
+        total += n
+    assert total == 100_000_000
