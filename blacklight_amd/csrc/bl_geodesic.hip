@@ -350,7 +350,9 @@ __global__ void __launch_bounds__(64, BL_GEO_ONE_WAVE(kIntegrator, kTime, kSpinZ
               double y_abs = std_max(blm_abs(s.y[p]), blm_abs(a5));
               double error_scale = P.ray_tol_abs + P.ray_tol_rel * y_abs;
               double delta_y = blm_abs(a5 - a4);
-              error = std_max(error, delta_y / error_scale);
+              // (the IEEE quotient without the range scaling of the compiler's sequence, bl_geometry.h: the scale is >= ray_tol_abs,
+              // the difference of two solutions zero or an ordinary number)
+              error = std_max(error, bl_div_g(delta_y, error_scale));
             }
           }
           r_new = r_stage;

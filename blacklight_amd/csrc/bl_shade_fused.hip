@@ -423,23 +423,28 @@ __device__ __forceinline__ double2 shade(const BlSpacetime &st, const double (&K
   const double k_u = kt * ut + k_r * ur + k_th * uu2 + k_ph * uu3;
   const double k_b = kt * bt + k_r * br + k_th * bth + k_ph * bph;
   // ---- plasma state (:274-358), constants folded on the host (BlShadeArgs::fast_k)
+  // 1 / rho and 1 / p from one reciprocal where both are positive (single-precision values: the product is an ordinary double)
   double rho_inv, pgas_inv;
   {
     const double rp = rho * pgas;
     const bool both = rho > 0.0 && rp > 0.0 && rp < __builtin_inf();
     const double t = fastmath::rcp(both ? rp : rho);
     rho_inv = both ? t * pgas : t;
-    pgas_inv = both ? t * rho : fastmath::rcp(pgas);
+    pgas_inv = t * rho;
+    if (__builtin_expect(!both, 0)) pgas_inv = fastmath::rcp(pgas);
   }
   const double sigma_cut = b_sq * rho_inv;
   const double beta_inv = 0.5 * b_sq * pgas_inv;
   const double bi2 = beta_inv * beta_inv;
   const double dd = 1.0 + bi2;
-  const double kb_tt_e = K[0] * (pgas * rho_inv) * (dd * fastmath::rcp(K[1] + K[2] * bi2 + K[3] * dd));
+  // T_i / T_e = N / D, N = rat_high + rat_low / beta^2, D = 1 + 1 / beta^2: k T_e = (1 + c) k T_tot D / (N + c D). What the
+  // coefficients need is 1 / (k T_e): one reciprocal; k T_e itself only where a Theta_e cut looks at it
+  const double kte_inv = (K[1] + K[2] * bi2 + K[3] * dd) * fastmath::rcp(K[0] * (pgas * rho_inv) * dd);
   // ---- cell cuts (:361-375): decided here unless a value sits within the guard band of an active threshold
   bool cell_cut = false, undecided = pp2 == 0.0;   // (on the polar axis: the exact kernel's business)
   if (cut_mask != 0) {
     const double bb = (cut_mask & 0x300) ? fastmath::sqrt(b_sq) : 0.0;   // only the field-strength cuts need |b| itself
+    const double kb_tt_e = (cut_mask & 0xc0) ? fastmath::rcp(kte_inv) : 0.0;
     const double value[7] = {rho, rho, pgas, kb_tt_e, bb, sigma_cut, beta_inv};   // against thresholds in these units
 #pragma unroll
     for (int v = 0; v < 7; v++)
@@ -465,7 +470,6 @@ __device__ __forceinline__ double2 shade(const BlSpacetime &st, const double (&K
   const double b_sin = bs2 > 0.0 ? bs2 * b_sin_inv : 0.0;
   // ---- coefficients at the one frequency (simulation_coefficients.cpp:464-523) and the transfer record (unpolarized.cpp:74-110)
   const double mf_inv = fastmath::rcp(momentum_factor);
-  const double kte_inv = fastmath::rcp(kb_tt_e);
   const double nu = -k_u * momentum_factor * freq;                 // :461-463 times the camera frequency
   const double nu_inv = -k_u_inv * mf_inv * freq_inv;
   const double xx = nu * b_sin_inv * (kte_inv * kte_inv) * K[4];   // nu / nu_s

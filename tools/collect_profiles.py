@@ -1,5 +1,5 @@
-"""Copy the summaries of tools/gpu_profile_r3.sh (gpurun_out/prof_r3) to profiles/r03_* and write profiles/hbm_traffic.json
-(what bench.py's roofline.traffic reads) with the hash of the kernel sources the numbers were measured on."""
+"""Copy the summaries of tools/gpu_profile_r4.sh (gpurun_out/prof_r4) to profiles/r04_* and write profiles/hbm_traffic.json (what
+bench.py's roofline.traffic reads) with the hash of the kernel sources the numbers were measured on.   python3 tools/collect_profiles.py [r04]"""
 import json
 import os
 import shutil
@@ -9,24 +9,22 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 import bench
 
-src = os.path.join(REPO, "gpurun_out", "prof_r3")
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+src = os.path.join(REPO, "gpurun_out", "prof_r" + tag[1:].lstrip("0"))
 dst = os.path.join(REPO, "profiles")
-for name in ("bench_default.json", "bench_under_rocprof.json", "kernel_stats.csv", "kernel_trace_summary.txt", "pmc_summary.txt", "hbm_traffic_raw.json",
-             "formula_tolerant_kernel_trace_summary.txt", "formula_exact_kernel_trace_summary.txt", "formula_pmc_summary.txt",
-             "formula_tolerant.json", "formula_exact.json", "tiled_emulation.json"):
-    if os.path.exists(os.path.join(src, name)):
-        shutil.copy(os.path.join(src, name), os.path.join(dst, "r03_" + name))
-    else:
-        print("missing", name)
+for name in sorted(os.listdir(src)):
+    path = os.path.join(src, name)
+    if os.path.isfile(path) and name.endswith((".json", ".txt", ".csv")) and os.path.getsize(path) > 0 and not name.endswith(".err"):
+        shutil.copy(path, os.path.join(dst, f"{tag}_{name}"))
 raw = json.load(open(os.path.join(src, "hbm_traffic_raw.json")))
 line = json.loads(open(os.path.join(src, "bench_default.json")).read().strip().splitlines()[-1])
-source = ("profiles/r03_hbm_traffic_raw.json: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE of `python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline` "
-          "in separate passes (tools/gpu_profile_r3.sh); FETCH_SIZE (KiB) x 1024 x 2 (gfx950 tallies 64 B per 128-B request), WRITE_SIZE (KiB) x 1024; "
+source = (f"profiles/{tag}_hbm_traffic_raw.json: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE of `python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline` "
+          f"in separate passes (tools/gpu_profile_{tag[0]}{tag[1:].lstrip('0')}.sh); FETCH_SIZE (KiB) x 1024 x 2 (gfx950 tallies 64 B per 128-B request), WRITE_SIZE (KiB) x 1024; "
           "L2-to-fabric traffic, Infinity-Cache hits included")
 record = {"csrc_sha256_16": bench.kernel_source_hash(),
           "launch": f"one launch per frame of the 1024^2 / 256^3 benchmark; {line['roofline']['algorithmic_bytes_per_launch'] / 1e9:.2f} GB algorithmic "
                     "per launch (256 B x gathered samples + 13 B x rays)"}
-for tier, prefix in (("tolerant", "void bl_shade_fused_kernel"), ("exact", "void bl_shade_exact_kernel")):
+for tier, prefix in (("tolerant", "void " + line["roofline"]["kernel"]), ("exact", "void bl_shade_exact_kernel")):
     for k, v in raw.items():
         if k.startswith(prefix):
             record[tier] = {"kernel": k, "coefficient_kernel_bytes_per_launch": v["fetch_bytes_per_launch_x2_corrected"] + v["write_bytes_per_launch"],
