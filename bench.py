@@ -447,7 +447,7 @@ def main():
             "hbm_frac_algorithmic_whole_pipeline": (256.0 * total_gathers + 13.0 * total_rays) / (elapsed / args.steps) / 1.0e9 / HBM_PEAK_GBS,
             # the coefficient kernel of the tier that ran: with no launch of a locate kernel it is the one that locates as well
             "roofline": {"bound": "hbm", "kernel": (({2: "bl_shade_fused2_kernel", 1: "bl_shade_fused_kernel"}.get(stats.fused_variant, "bl_shade_fast_kernel"))
-                                                    if main_run["tier_ran"] == "tolerant" else "bl_shade_exact_kernel"),
+                                                    if main_run["tier_ran"] == "tolerant" else ("bl_shade_exact2_kernel" if stats.fused_variant == 3 else "bl_shade_exact_kernel")),
                          "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source, "traffic_stale": traffic_stale,
                          "algorithmic_bytes_per_launch": main_run["bytes_per_launch"], "ms_per_launch": main_run["shade_ms_per_launch"]},
@@ -464,7 +464,7 @@ def main():
             line["exact_tier"] = {
                 "value": exact_run["totals"][0] / (e_elapsed / args.steps) / 1.0e6, "unit": "Mrays/s", "ms_per_step": 1000.0 * e_elapsed / args.steps,
                 "kernel_ms_per_step": {k: v / args.steps for k, v in exact_run["ms"].items()},
-                "roofline": {"kernel": "bl_shade_exact_kernel", "achieved": e_achieved, "frac": e_achieved / HBM_PEAK_GBS,
+                "roofline": {"kernel": "bl_shade_exact2_kernel" if exact_run["stats"].fused_variant == 3 else "bl_shade_exact_kernel", "achieved": e_achieved, "frac": e_achieved / HBM_PEAK_GBS,
                              "ms_per_launch": exact_run["shade_ms_per_launch"]},
             }
         if not distributed and not args.no_cpu_baseline:

@@ -120,6 +120,8 @@ struct RenderJob {
   bool fused = false;   // tolerant tier, common grid case: the locate step runs inside the coefficient kernel (bl_shade_fused_kernel)
   bool fused2 = false;  // ... the benchmark's case of it: bl_shade_fused2_kernel (bl_shade_fused.hip)
   bool composed = false;   // ... writing one affine transfer map per ray segment instead of one per sample (BlShadeArgs::composed)
+  bool exact_fused = false;   // exact tier, the same grids, plain image at one frequency: bl_shade_exact2_kernel locates its samples itself
+  bool locate_inside = false; // fused || exact_fused: no locate kernel, no located samples in HBM
   int n_nu = 0, n_q = 0, max_steps = 0;
   long long n_rays = 0, level_pixels = 0;
   size_t redo_capacity = 0;
@@ -256,7 +258,16 @@ void PlanJob(RenderJob &job) {
       && !(p.cut_omit_near || p.cut_omit_far || p.cut_omit_in >= 0.0 || p.cut_omit_out >= 0.0 || p.cut_midplane_theta != 0.0 || p.cut_midplane_z != 0.0 || p.cut_plane)
       && static_cast<size_t>(ctx->lds_table_bytes) + (44 + 5 * static_cast<size_t>(job.n_nu) + ctx->n_i + ctx->n_j + ctx->n_k) * sizeof(double) <= 60u * 1024u
       && !job.sample_save && !(ctx->switches & BL_SWITCH_NO_FUSED_LOCATE);   // (a sample checkpoint is made of the located samples)
-  job.interleaved = (job.fused || !job.simulation) && !job.geo_load && !job.geo_save && !job.sample_save && !(ctx->switches & BL_SWITCH_SPLIT_RECORDS);
+  // The exact tier's plain image at one frequency over such a grid: the locate step inside bl_shade_exact2_kernel (bit-identical
+  // to bl_locate_plain_kernel + bl_shade_exact_kernel, whose conditions these are)
+  job.exact_fused = !job.fast && job.simulation && !job.aux && !ctx->polarized && !job.slow && !job.block_interp && job.n_nu == 1
+      && p.plasma_kappa_frac == 0.0 && p.plasma_power_frac == 0.0 && p.plasma_model != BL_PLASMA_CODE_KAPPA && !p.ray_flat
+      && ctx->plasma_thermal_frac != 0.0 && ctx->grid_dev.n_blocks == 0 && !ctx->grid_dev.fmks && p.simulation_interp && p.simulation_coord == BL_COORD_SKS
+      && !(p.cut_omit_near || p.cut_omit_far || p.cut_omit_in >= 0.0 || p.cut_omit_out >= 0.0 || p.cut_midplane_theta != 0.0 || p.cut_midplane_z != 0.0 || p.cut_plane)
+      && !job.geo_load && !job.geo_save && !job.sample_save && !(ctx->switches & (BL_SWITCH_NO_FUSED_LOCATE | BL_SWITCH_SPLIT_RECORDS))
+      && bl_fused2_applicable(&ctx->grid_dev, job.n_nu, job.n_rays) != 0;
+  job.interleaved = (job.fused || job.exact_fused || !job.simulation) && !job.geo_load && !job.geo_save && !job.sample_save && !(ctx->switches & BL_SWITCH_SPLIT_RECORDS);
+  job.locate_inside = job.fused || job.exact_fused;
   // One frequency over a single block with evenly spaced faces: the benchmark's kernel, which also composes the affine maps of a
   // ray's neighbouring samples before they leave it (the geodesic kernel numbers the segments: BlTraceArgs::segment_rows)
   job.fused2 = job.fused && job.interleaved && !job.freq_split && !(ctx->switches & BL_SWITCH_GENERAL_FUSED)
@@ -292,7 +303,7 @@ void PlanScratch(RenderJob &job) {
   // per sample record (the arrays indexed by record slot) and per kept sample (the arrays indexed by ray_offset + n: never
   // more than records)
   job.bytes_per_record = sizeof(BlSampleHot) + sizeof(BlSampleCold)
-      + ((job.simulation && !job.fused) ? sizeof(BlLocated) + sizeof(unsigned long long) : 0)
+      + ((job.simulation && !job.locate_inside) ? sizeof(BlLocated) + sizeof(unsigned long long) : 0)
       + (job.freq_split ? sizeof(BlFreqInputs) : sizeof(double2) * n_nu) + (job.tau_row ? sizeof(double) * n_nu : 0)
       + (job.composed ? sizeof(double2) : 0)
       + (job.aux ? sizeof(BlAuxSample) : 0) + (job.need_time ? sizeof(double) : 0) + (job.slow ? sizeof(double) : 0)
@@ -363,7 +374,7 @@ void EnsureScratch(RenderJob &job) {
       sl.d_records_hot.Ensure(cap);
       sl.d_records_cold.Ensure(cap);
     }
-    if (job.simulation && !job.fused) {
+    if (job.simulation && !job.locate_inside) {
       sl.d_located.Ensure(cap);
       sl.d_located_tag.Ensure(cap);
     }
@@ -894,8 +905,8 @@ void BindChunk(RenderJob &job, int k, long long begin, int rays) {
   sa.records_hot = ta.records_hot;
   sa.records_cold = ta.records_cold;
   sa.record_stride = ta.record_stride;
-  sa.located = (job.simulation && !job.fused) ? sl.d_located.ptr : nullptr;
-  sa.located_tag = (job.simulation && !job.fused) ? sl.d_located_tag.ptr : nullptr;
+  sa.located = (job.simulation && !job.locate_inside) ? sl.d_located.ptr : nullptr;
+  sa.located_tag = (job.simulation && !job.locate_inside) ? sl.d_located_tag.ptr : nullptr;
   sa.freq_inputs = job.freq_split ? sl.d_freq_inputs.ptr : nullptr;
   sa.counters_in = sl.d_counters.ptr;
   sa.counters = sl.d_counters.ptr;
@@ -1285,11 +1296,12 @@ void LaunchShadingStage(RenderJob &job, int k, bool geodesic_beside, hipStream_t
   BlTransferArgs &xa = job.xa;
   Check(hipStreamWaitEvent(stream, e[1], 0), "stream wait");
   Check(hipEventRecord(e[2], stream), "event");
-  if (job.simulation && !job.fused)
+  if (job.simulation && !job.locate_inside)
     Check(bl_launch_locate(&sa, geodesic_beside ? job.locate_grid_shared : job.locate_grid_alone, ctx->lds_table_bytes, stream), "locate kernel launch");
   Check(hipEventRecord(e[3], stream), "event");
   if (job.fast) Check(bl_launch_shade_fast(&sa, job.shade_grid, stream), "coefficient kernel launch");
   else if (job.fast_formula) Check(bl_launch_shade_formula_fast(&sa, ctx->num_cus * 4 * 4, stream), "coefficient kernel launch");
+  else if (job.exact_fused) Check(bl_launch_shade_exact2(&sa, job.shade_grid, stream), "coefficient kernel launch");
   else Check(bl_launch_shade(&sa, p.model_type, job.shade_grid, stream), "coefficient kernel launch");
   if (ctx->polarized) Check(bl_launch_polarized_coefficients(&sa, ctx->num_cus * 8, stream), "polarized coefficient kernel launch");
   if (job.coef_split) Check(bl_launch_coefficients_freq(&sa, ctx->num_cus * 16, stream), "per-frequency coefficient kernel launch");
@@ -1428,7 +1440,7 @@ void FinishStats(RenderJob &job) {
   st.n_rays = job.n_rays;
   st.n_chunks = job.n_chunks;
   st.launches_geodesic = job.n_chunks;
-  st.launches_locate = (job.simulation && !job.fused) ? job.n_chunks : 0;
+  st.launches_locate = (job.simulation && !job.locate_inside) ? job.n_chunks : 0;
   st.launches_shade = job.n_chunks;
   st.launches_transfer = job.n_chunks;
   st.n_samples = static_cast<int64_t>(job.total_samples);
@@ -1450,7 +1462,7 @@ void FinishStats(RenderJob &job) {
   st.n_deferred = static_cast<int64_t>(job.total_redo);
   st.n_undefined = static_cast<int64_t>(job.total_undefined);
   st.switches = ctx->switches;
-  st.fused_variant = job.fused ? (job.fused2 ? 2 : 1) : 0;
+  st.fused_variant = job.fused ? (job.fused2 ? 2 : 1) : (job.exact_fused ? 3 : 0);
   ctx->stats = st;
   if (ctx->debug_counters) {   // kernels built with -DBL_GEO_STATS fill these
     std::fprintf(stderr, "debug counters:");

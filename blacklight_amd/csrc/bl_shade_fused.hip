@@ -217,6 +217,53 @@ __device__ __forceinline__ v4u lds_read_bits(uint32_t) { return v4u{0u, 0u, 0u, 
 __device__ __forceinline__ uint32_t lds_address(const void *) { return 0u; }
 #endif
 
+// The row tables of the three axes, one after the other (r, theta, phi), built by the workgroup from the grid's face and centre
+// tables. kReciprocal: the anchor's width enters as its reciprocal (tolerant tier: the fraction is one multiplication); otherwise
+// as the width itself, xv[c + 1] - xv[c] - the divisor of the exact tier's quotient, from the same subtraction.
+template <bool kReciprocal>
+__device__ __forceinline__ void stage_axis_rows(const BlGridDevice &g, AxisRow *rows) {
+  for (int a = 0; a < 3; a++) {
+    const int n = g.n[a];
+    const double *xf = g.xf[a], *xv = g.xv[a];
+    for (int c = threadIdx.x; c < n; c += blockDim.x) {
+      const int c_ge = c == n - 1 ? c - 1 : c, c_lt = c == 0 ? 0 : c - 1;
+      AxisRow row;
+      row.xf_lo = xf[c];
+      row.xf_hi = xf[c + 1];
+      row.xv = xv[c];
+      row.dj_ge = (uint32_t)(c - c_ge);
+      row.dj_lt = (uint32_t)(c - c_lt);
+      row.xv_ge = xv[c_ge];
+      row.xv_lt = xv[c_lt];
+      const double width_ge = xv[c_ge + 1] - xv[c_ge], width_lt = xv[c_lt + 1] - xv[c_lt];
+      row.w_ge = kReciprocal ? 1.0 / width_ge : width_ge;
+      row.w_lt = kReciprocal ? 1.0 / width_lt : width_lt;
+      rows[c] = row;
+    }
+    rows += n;
+  }
+}
+__device__ __forceinline__ GridScalars grid_scalars(const BlGridDevice &g, uint32_t lds_rows) {
+  GridScalars G;
+  G.th_x0 = g.cell_x0[1];
+  G.th_inv_w = g.cell_inv_w[1];
+  G.ph_x0 = g.cell_x0[2];
+  G.ph_inv_w = g.cell_inv_w[2];
+  G.r_l0 = g.log_l0;
+  G.r_linv = g.log_inv_w;
+  G.r_in = g.r_face_in;
+  G.r_out = g.r_face_out;
+  G.n_i1 = g.n[0] - 1;
+  G.n_j1 = g.n[1] - 1;
+  G.n_k1 = g.n[2] - 1;
+  G.n_i = (uint32_t)g.n[0];
+  G.n_j = (uint32_t)g.n[1];
+  G.lds_r = lds_rows;
+  G.lds_th = G.lds_r + 64u * (uint32_t)g.n[0];
+  G.lds_ph = G.lds_th + 64u * (uint32_t)g.n[1];
+  return G;
+}
+
 // One axis: row of the guessed cell -> anchor shift, fraction, signed distance to the nearest face (negative: the guess is wrong
 // or the coordinate lies beyond the grid) and distance to the centre
 __device__ __forceinline__ void axis_lookup(uint32_t row_addr, double s, double *frac, uint32_t *dj, double *face_margin, double *centre_margin) {
@@ -535,26 +582,7 @@ __global__ void __launch_bounds__(256, BL_FAST_WAVES) bl_shade_fused2_kernel(con
       else value = upper_on ? cc.fast_cut_hi[2 * v + 1] : -inf;
       lds[i] = value;
     }
-    AxisRow *rows = reinterpret_cast<AxisRow *>(lds + 48);
-    for (int a = 0; a < 3; a++) {
-      const int n = P.grid.n[a];
-      const double *xf = P.grid.xf[a], *xv = P.grid.xv[a];
-      for (int c = threadIdx.x; c < n; c += blockDim.x) {
-        const int c_ge = c == n - 1 ? c - 1 : c, c_lt = c == 0 ? 0 : c - 1;
-        AxisRow row;
-        row.xf_lo = xf[c];
-        row.xf_hi = xf[c + 1];
-        row.xv = xv[c];
-        row.dj_ge = (uint32_t)(c - c_ge);
-        row.dj_lt = (uint32_t)(c - c_lt);
-        row.xv_ge = xv[c_ge];
-        row.w_ge = 1.0 / (xv[c_ge + 1] - xv[c_ge]);
-        row.xv_lt = xv[c_lt];
-        row.w_lt = 1.0 / (xv[c_lt + 1] - xv[c_lt]);
-        rows[c] = row;
-      }
-      rows += n;
-    }
+    stage_axis_rows<true>(P.grid, reinterpret_cast<AxisRow *>(lds + 48));
   }
   __syncthreads();
   const uint32_t n_records = (uint32_t)P.counters_in[BL_CNT_RECORDS];   // (a scratch set holds fewer than 2^32 records)
@@ -562,23 +590,7 @@ __global__ void __launch_bounds__(256, BL_FAST_WAVES) bl_shade_fused2_kernel(con
   const uint32_t stride = gridDim.x * blockDim.x;
   const uint32_t last = n_records - 1u;
   const BlSpacetime st = P.st;
-  GridScalars G;
-  G.th_x0 = P.grid.cell_x0[1];
-  G.th_inv_w = P.grid.cell_inv_w[1];
-  G.ph_x0 = P.grid.cell_x0[2];
-  G.ph_inv_w = P.grid.cell_inv_w[2];
-  G.r_l0 = P.grid.log_l0;
-  G.r_linv = P.grid.log_inv_w;
-  G.r_in = P.grid.r_face_in;
-  G.r_out = P.grid.r_face_out;
-  G.n_i1 = P.grid.n[0] - 1;
-  G.n_j1 = P.grid.n[1] - 1;
-  G.n_k1 = P.grid.n[2] - 1;
-  G.n_i = (uint32_t)P.grid.n[0];
-  G.n_j = (uint32_t)P.grid.n[1];
-  G.lds_r = lds_base + 48u * 8u;
-  G.lds_th = G.lds_r + 64u * (uint32_t)P.grid.n[0];
-  G.lds_ph = G.lds_th + 64u * (uint32_t)P.grid.n[1];
+  const GridScalars G = grid_scalars(P.grid, lds_base + 48u * 8u);
   const uint32_t cut_table = lds_base;
   const int cut_mask = P.plasma.cut_mask;
   const double camera_r = P.cuts.camera_r;
@@ -744,6 +756,231 @@ __global__ void __launch_bounds__(256, BL_FAST_WAVES) bl_shade_fused2_kernel(con
   if ((threadIdx.x & 63) == 0 && gathers_wave != 0ull) atomicAdd(&P.counters[BL_CNT_GATHERS], gathers_wave);
 }
 #pragma clang fp contract(off)
+
+// =================================================================================================
+// Exact tier, locate step inside (bl_shade_exact2_kernel): the same pipeline around the exact tier's own arithmetic - every
+// operation of bl_locate_plain_kernel and bl_shade_exact_kernel (bl_shade.hip) on the same operands, so the same bits - without
+// the 40 bytes of located sample per record that the two-kernel path writes and reads back (54 GB per benchmark frame). Compiled
+// with contraction off like everything exact.
+// =================================================================================================
+namespace fused2 {
+
+struct LocatedExact {
+  double f_i, f_j, f_k, ph_unwrapped;
+  uint32_t status, cell_bytes;
+};
+
+// One axis of the exact search: the cell find_cell() returns (the first c whose upper face is >= s, simulation_sampling.cpp:
+// 458-466) is the guessed one when s <= its upper face and, unless it is the first cell, s > its lower face; any other guess - a
+// coordinate within rounding of a face of an unevenly rounded table - is searched for in the tables where they lie in HBM. Then
+// the anchor (:485-490) and the fraction, an IEEE quotient by the distance between the centres (row.w = that distance).
+__device__ __forceinline__ bool guess_confirmed(uint32_t table, int guess, double s) {
+  const v2d faces = lds_read2(table + ((uint32_t)guess << 6));
+  return s <= faces.y && (guess == 0 || s > faces.x);
+}
+__device__ __forceinline__ void axis_lookup_exact(uint32_t table, int cell, double s, double *frac, uint32_t *anchor) {
+  const uint32_t row_addr = table + ((uint32_t)cell << 6);
+  const v4u mid = lds_read_bits(row_addr + 16u);
+  const bool ge = s >= __hiloint2double((int)mid.y, (int)mid.x);
+  const v2d centre = lds_read2(row_addr + (ge ? 32u : 48u));
+  *anchor = (uint32_t)cell - (ge ? mid.z : mid.w);
+  *frac = blm_div(s - centre.x, centre.y);
+}
+
+// locate_plain_sample() (bl_sampling.h) on the row tables
+template <bool kSpinZero>
+__device__ __forceinline__ LocatedExact locate_exact(const BlSpacetime &st, const BlGridDevice &g, const GridScalars &G, double camera_r, bool live, double x1, double x2,
+                                                     double x3) {
+  x1 = live ? x1 : 1.0;
+  x2 = live ? x2 : 1.0;
+  x3 = live ? x3 : 1.0;
+  double r2;
+  const double r = bl_radial_coordinate2<kSpinZero>(st, x1, x2, x3, &r2);
+  const bool cut = r > camera_r;                                   // simulation_sampling.cpp:238-243
+  const double th = bl_acos(blm_div(x3, r));                       // ConvertFromCKS (radiation_geometry.cpp:37-57)
+  const double ph_unwrapped = kSpinZero ? bl_atan2(x2, x1) : bl_atan2(x2, x1) - bl_atan(blm_div(st.bh_a, r));
+  double ph = ph_unwrapped;
+  ph += ph < 0.0 ? 2.0 * kPi : 0.0;
+  ph -= ph >= 2.0 * kPi ? 2.0 * kPi : 0.0;
+  const bool off_grid = r < G.r_in || r > G.r_out;                 // :352-394 (theta and phi cover the sphere: bl_fused2_applicable)
+  int gi = (int)((__builtin_amdgcn_logf((float)r) - G.r_l0) * G.r_linv);
+  int gj = (int)((th - G.th_x0) * G.th_inv_w);
+  int gk = (int)((ph - G.ph_x0) * G.ph_inv_w);
+  gi = gi < 0 ? 0 : (gi > G.n_i1 ? G.n_i1 : gi);
+  gj = gj < 0 ? 0 : (gj > G.n_j1 ? G.n_j1 : gj);
+  gk = gk < 0 ? 0 : (gk > G.n_k1 ? G.n_k1 : gk);
+  // (one copy of the search for all three axes, behind one branch that is almost never taken)
+  const bool ok_i = guess_confirmed(G.lds_r, gi, r), ok_j = guess_confirmed(G.lds_th, gj, th), ok_k = guess_confirmed(G.lds_ph, gk, ph);
+  if (__builtin_expect(!(ok_i && ok_j && ok_k), 0)) {
+    // find_cell() (bl_sampling.h) over the tables where they lie in HBM: the bucket's first candidate, then the forward scan
+    // (its tables and scales are read from the kernel arguments here, where they are needed: kernargs())
+    KernArgs A = kernargs();
+    auto search = [&](int a, double x) {
+      const int n_bucket = A->grid.n_bucket[a], n = A->grid.n[a];
+      int bucket = (int)((x - A->grid.bucket_x0[a]) * A->grid.bucket_inv_w[a]);
+      bucket = bucket < 0 ? 0 : (bucket >= n_bucket ? n_bucket - 1 : bucket);
+      int c = A->grid.bucket[a][bucket];
+      const double *xf = A->grid.xf[a];
+      while (c < n - 1 && !(xf[c + 1] >= x)) c++;
+      return c;
+    };
+    if (!ok_i) gi = search(0, r);
+    if (!ok_j) gj = search(1, th);
+    if (!ok_k) gk = search(2, ph);
+  }
+  LocatedExact out;
+  uint32_t i_m, j_m, k_m;
+  axis_lookup_exact(G.lds_r, gi, r, &out.f_i, &i_m);
+  axis_lookup_exact(G.lds_th, gj, th, &out.f_j, &j_m);
+  axis_lookup_exact(G.lds_ph, gk, ph, &out.f_k, &k_m);
+  const bool sampled = live && !cut && !off_grid;
+  out.f_i = sampled ? out.f_i : 0.0;
+  out.f_j = sampled ? out.f_j : 0.0;
+  out.f_k = sampled ? out.f_k : 0.0;
+  out.ph_unwrapped = (!live || cut) ? 0.0 : ph_unwrapped;
+  out.status = !live ? (uint32_t)kSampleNone : (cut ? (uint32_t)kSampleCut : (off_grid ? (uint32_t)kSampleOffGrid : (uint32_t)kSampleInterp));
+  out.cell_bytes = sampled ? (__umul24(__umul24(k_m, G.n_j) + j_m, G.n_i) + i_m) << 5 : 0u;
+  return out;
+}
+
+}  // namespace fused2
+
+template <bool kSpinZero>
+__global__ void __launch_bounds__(256, 2) bl_shade_exact2_kernel(const BlShadeArgs P) {
+  using namespace fused2;
+  extern __shared__ double lds[];
+  const uint32_t lds_base = lds_address(lds);
+  stage_axis_rows<false>(P.grid, reinterpret_cast<AxisRow *>(lds));
+  __syncthreads();
+  const uint32_t n_records = (uint32_t)P.counters_in[BL_CNT_RECORDS];
+  if (n_records == 0u) return;
+  const uint32_t stride = gridDim.x * blockDim.x;
+  const uint32_t last = n_records - 1u;
+  const BlSpacetime st = P.st;
+  const GridScalars G = grid_scalars(P.grid, lds_base);
+  const double camera_r = P.cuts.camera_r;
+  const float fallback_rho = P.cold->fallback_rho, fallback_pgas = P.cold->fallback_pgas;
+  const char *cells = reinterpret_cast<const char *>(P.grid.cells);
+  const uint32_t row_bytes = (uint32_t)P.grid.stride_row * 32u, plane_bytes = (uint32_t)P.grid.stride_plane * 32u;
+  const char *ray_kt = reinterpret_cast<const char *>(P.ray_kt), *ray_factor = reinterpret_cast<const char *>(P.ray_factor);
+  const char *ray_offset = reinterpret_cast<const char *>(P.ray_offset);
+  unsigned long long gathers_wave = 0ull;
+  const double freq = uniform_value(P.frequencies[0]);
+  const char *records = reinterpret_cast<const char *>(P.records_hot);
+  const uint32_t lane_index = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t lane_bytes = lane_index << 6;
+  uint32_t base_index = 0u;
+  auto record_base = [&](uint32_t first) { return records + ((size_t)(first < last ? first : last) << 6); };
+  double2 prev0 = make_double2(0.0, 0.0), prev1 = make_double2(0.0, __longlong_as_double((long long)BL_DEAD_RAY)), prev2 = prev0, prev3 = prev0;
+  double2 cur0, cur1;
+  double kt_prev = 0.0, factor_prev = 1.0;
+  long long row_prev = 0;
+  LocatedExact loc_prev, loc_cur;
+  loc_prev.f_i = loc_prev.f_j = loc_prev.f_k = loc_prev.ph_unwrapped = 0.0;
+  loc_prev.status = kSampleNone;
+  loc_prev.cell_bytes = 0u;
+  float4 lo[8], hi[8];
+#pragma unroll
+  for (int c = 0; c < 8; c++) lo[c] = hi[c] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  bool cur_in = lane_index < n_records;
+  {
+    const double2 *rec = reinterpret_cast<const double2 *>(record_base(0u) + (size_t)(cur_in ? lane_bytes : 0u));
+    cur0 = rec[0];
+    cur1 = rec[1];
+    cur1.y = cur_in ? cur1.y : __longlong_as_double((long long)BL_DEAD_RAY);
+  }
+  loc_cur = locate_exact<kSpinZero>(st, P.grid, G, camera_r, (uint32_t)__double_as_longlong(cur1.y) != BL_DEAD_RAY, cur0.x, cur0.y, cur1.x);
+  bool prev_in = false;
+  while (__any(prev_in || cur_in)) {
+    const uint32_t ray = (uint32_t)__double_as_longlong(prev1.y);
+    const bool live = ray != BL_DEAD_RAY;
+    const uint32_t n = (uint32_t)(((unsigned long long)__double_as_longlong(prev1.y)) >> 32);
+    const int status = (int)loc_prev.status;
+    const uint32_t next_first = base_index + stride;
+    const bool next_in = next_first + lane_index < n_records;
+    double2 next0, next1;
+    {
+      const double2 *rec = reinterpret_cast<const double2 *>(record_base(next_first) + (size_t)(next_in ? lane_bytes : 0u));
+      next0 = rec[0];
+      next1 = rec[1];
+    }
+    const double kt = kt_prev, momentum_factor = factor_prev;
+    const long long row_first = row_prev;
+    float pr[8];
+    gather_finish(P, fallback_rho, fallback_pgas, status, lo, hi, loc_prev.f_i, loc_prev.f_j, loc_prev.f_k, pr);
+    gathers_wave += (unsigned long long)__popcll(__ballot(status == (int)kSampleInterp));
+    fused2::gather_issue(cells, loc_cur.cell_bytes, loc_cur.status == (uint32_t)kSampleInterp, row_bytes, plane_bytes, lo, hi);
+    double2 cold0, cold1;
+    {
+      const double2 *rec = reinterpret_cast<const double2 *>(record_base(base_index) + (size_t)(cur_in ? lane_bytes : 0u));
+      cold0 = rec[2];
+      cold1 = rec[3];
+    }
+    {
+      const uint32_t ray_cur = (uint32_t)__double_as_longlong(cur1.y);
+      const uint32_t ray_bytes = (ray_cur != BL_DEAD_RAY ? ray_cur : 0u) << 3;
+      kt_prev = *reinterpret_cast<const double *>(ray_kt + (size_t)ray_bytes);
+      factor_prev = *reinterpret_cast<const double *>(ray_factor + (size_t)ray_bytes);
+      row_prev = *reinterpret_cast<const long long *>(ray_offset + (size_t)ray_bytes);
+    }
+    if (live) {
+      // ---- bl_shade_exact_kernel's body (bl_shade.hip), call for call
+      const double x1 = prev0.x, x2 = prev0.y, x3 = prev1.x;
+      const double delta_lambda = -prev3.y;   // ReverseGeodesics: sample_len = -geodesic_len (geodesics.cpp:840)
+      double kcov[4] = {kt, prev2.x, prev2.y, prev3.x};
+      BlKerrSchild ks;
+      bl_kerr_schild<kSpinZero>(st, x1, x2, x3, &ks);
+      {   // per-sample renormalisation of the stored momentum (geodesics.cpp:352-371)
+        double gcon[4][4];
+        bl_gcon_ks(ks, gcon);
+        const double factor = bl_renormalization_factor_g(gcon, kcov[0], kcov[1], kcov[2], kcov[3]);
+        kcov[1] *= factor;
+        kcov[2] *= factor;
+        kcov[3] *= factor;
+      }
+      SampleShade sh;
+      sh.have_coefficients = false;
+      sh.nu_fluid_over_nu = 0.0;
+      sh.n_e_cgs = sh.nu_c_cgs = sh.theta_e = sh.sin_theta_b = sh.kb_tt_e_cgs = 0.0;
+      sh.cos_theta_b = sh.sin2_theta_b = sh.cos2_theta_b = 0.0;
+      sh.cos_sign = 1.0;
+      sh.n_n0_fluid = 0.0;
+      sh.fu[0] = sh.fu[1] = sh.fu[2] = sh.fu[3] = 0.0;
+      sh.have_cell = false;
+      if (status != kSampleCut) sample_finish_simulation<false, true>(P, st, ks, x3 / ks.r, loc_prev.ph_unwrapped, pr, 0.0f, kcov, 1, &sh, nullptr);
+      double j_val = 0.0, alpha_val = 0.0;
+      if (sh.have_coefficients) simulation_coefficients<false>(P, sh, freq, momentum_factor, &j_val, &alpha_val);
+      const double delta_lambda_cgs = bl_div_g(delta_lambda * P.x_unit, freq * momentum_factor);   // unpolarized.cpp:75-76
+      P.transfer[(size_t)(row_first + (long long)n)] = transfer_record(j_val, alpha_val, delta_lambda_cgs);
+    }
+    const bool live_next = next_in && (uint32_t)__double_as_longlong(next1.y) != BL_DEAD_RAY;
+    LocatedExact loc_next = loc_cur;
+    if (__any(live_next)) loc_next = locate_exact<kSpinZero>(st, P.grid, G, camera_r, live_next, next0.x, next0.y, next1.x);
+    else loc_next.status = kSampleNone, loc_next.cell_bytes = 0u;
+    prev0 = cur0;
+    prev1 = cur1;
+    prev2 = cold0;
+    prev3 = cold1;
+    loc_prev = loc_cur;
+    prev_in = cur_in;
+    cur0 = next0;
+    cur1 = next1;
+    cur1.y = next_in ? next1.y : __longlong_as_double((long long)BL_DEAD_RAY);
+    loc_cur = loc_next;
+    cur_in = next_in;
+    base_index = next_first;
+  }
+  if ((threadIdx.x & 63) == 0 && gathers_wave != 0ull) atomicAdd(&P.counters[BL_CNT_GATHERS], gathers_wave);
+}
+
+// (the exact tier's use of the fused kernel: one frequency, plain image; bl_render.hip checks the rest with bl_fused2_applicable)
+extern "C" hipError_t bl_launch_shade_exact2(const BlShadeArgs *args, int grid, hipStream_t stream) {
+  const BlGridDevice &g = args->grid;
+  const size_t lds = 64 * (size_t)(g.n[0] + g.n[1] + g.n[2]);
+  if (args->st.bh_a == 0.0) hipLaunchKernelGGL((bl_shade_exact2_kernel<true>), dim3(grid), dim3(256), lds, stream, *args);
+  else hipLaunchKernelGGL((bl_shade_exact2_kernel<false>), dim3(grid), dim3(256), lds, stream, *args);
+  return hipGetLastError();
+}
 
 // Whether a render can take this kernel (the caller has checked what bl_shade_fused_kernel needs, one frequency without the
 // per-frequency split, interleaved records whose momenta are not renormalised yet): one block, faces evenly spaced in log r / theta

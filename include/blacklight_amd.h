@@ -286,8 +286,8 @@ typedef struct bl_stats {
   int64_t n_deferred;         /* tolerant tier: samples whose cut decision was left to the exact kernel           */
   int64_t n_undefined;        /* BL_UNDEFINED_EDGE: samples where the reference reads past its arrays (edge cell used)     */
   uint32_t switches;          /* BL_SWITCH_* bits active in this context (measurement switches, below); 0 in production  */
-  int32_t fused_variant;      /* tolerant tier with the locate step inside the coefficient kernel: 2 = bl_shade_fused2_kernel,
-                                 1 = bl_shade_fused_kernel, 0 = neither ran                                               */
+  int32_t fused_variant;      /* the locate step inside the coefficient kernel: 2 = bl_shade_fused2_kernel, 1 = bl_shade_fused_kernel
+                                 (tolerant tier), 3 = bl_shade_exact2_kernel (exact tier), 0 = a locate kernel of its own ran  */
 } bl_stats;
 
 /* Measurement switches: environment variables BLACKLIGHT_AMD_<NAME>, read ONCE by bl_init (never during a render) and echoed in
@@ -299,7 +299,7 @@ typedef struct bl_stats {
 #define BL_SWITCH_TOLERANT_POLARIZED_COEFFICIENTS (1u << 3) /* polarized, tolerant tier: the tolerant per-frequency kernel      */
 #define BL_SWITCH_GENERAL_LOCATE (1u << 4)                  /* bl_locate_kernel where bl_locate_plain_kernel applies            */
 #define BL_SWITCH_LANE_TRANSFER (1u << 5)                   /* one lane per ray where bl_transfer_quad_kernel applies           */
-#define BL_SWITCH_NO_FUSED_LOCATE (1u << 6)                 /* tolerant tier: locate kernel + bl_shade_fast_kernel              */
+#define BL_SWITCH_NO_FUSED_LOCATE (1u << 6)                 /* a locate kernel + bl_shade_fast_kernel / bl_shade_exact_kernel   */
 #define BL_SWITCH_GENERAL_FUSED (1u << 7)                   /* bl_shade_fused_kernel where bl_shade_fused2_kernel applies       */
 #define BL_SWITCH_SAMPLE_RECORDS (1u << 8)                  /* tolerant tier: one transfer record per sample where composed maps apply */
 

@@ -32,7 +32,9 @@ BENCHMARK_KERNELS = {
     "_Z22bl_shade_fused2_kernelILb0ELb0EEv11BlShadeArgs": (2, 0),
     "_Z21bl_shade_fused_kernelILb1EEv11BlShadeArgs": (2, 0),                 # ... locate step inside, general grids / up to three frequencies
     "_Z21bl_shade_fused_kernelILb0EEv11BlShadeArgs": (2, 0),
-    "_Z21bl_shade_exact_kernelILb1EEv11BlShadeArgs": (2, 0),                 # exact tier, software-pipelined
+    "_Z22bl_shade_exact2_kernelILb1EEv11BlShadeArgs": (2, 0),                # exact tier, locate step inside (the benchmark's exact kernel)
+    "_Z22bl_shade_exact2_kernelILb0EEv11BlShadeArgs": (2, 0),
+    "_Z21bl_shade_exact_kernelILb1EEv11BlShadeArgs": (2, 0),                 # exact tier behind a locate kernel, software-pipelined
     "_Z21bl_shade_exact_kernelILb0EEv11BlShadeArgs": (2, 0),
     "_Z22bl_locate_plain_kernelILb1EEv11BlShadeArgs": (4, 0),                # exact tier's locate step, common grid case
     "_Z22bl_locate_plain_kernelILb0EEv11BlShadeArgs": (4, 0),
