@@ -1,5 +1,7 @@
 # Every sweep tool once, seeds from $1 (default 100000): a final check of a library before a release.
-cd $GRAFT_REPO_ROOT
+set -u
+: "${GRAFT_REPO_ROOT:?run through gpurun}"
+cd "$GRAFT_REPO_ROOT"
 S=${1:-100000}
 run() { name=$1; shift; "$@" > gpurun_out/fuzz_all_$name.log 2>&1; echo "$name rc=$? $(tail -1 gpurun_out/fuzz_all_$name.log | cut -c1-330)"; }
 run tiers timeout -k 10 300 python3 tools/gpu_fuzz_tiers.py 1500 $S 10

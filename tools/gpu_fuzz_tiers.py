@@ -149,7 +149,7 @@ def main():
                             and np.array_equal(np.isnan(tol_chunked["image"]), np.isnan(tol["image"]))):
                         chunk_problems.append(f"tolerant tier in {tol_chunked['stats'].n_chunks} chunks differs {distance(tol_chunked['image'], tol['image']):.2e}")
                 subset = None
-                if seed % 4 == 0:   # a shuffled subset of the pixels (what a rank of a tiled job renders): the same bits, pixel by pixel
+                if seed % 4 == 0:   # a shuffled subset of the pixels (what a rank of a tiled job renders): the same pixels
                     rng = np.random.default_rng(99000 + seed)
                     n_all = exact["sample_num"].size
                     subset = rng.permutation(n_all)[: int(rng.integers(1, n_all + 1))].astype(np.int32)
@@ -159,7 +159,11 @@ def main():
             problems = list(chunk_problems)
             if subset is not None:
                 for name, got, full in (("exact", part, exact), ("tolerant", part_tol, tol)):
-                    if not (gu.same_bits(got["image"], full["image"][:, subset]).all() and np.array_equal(got["sample_num"], full["sample_num"][subset])
+                    # (the exact tier bit for bit; the tolerant tier to rounding level since round 4: which of a ray's affine maps are
+                    # composed with which follows the order in which the persistent geodesic kernel emitted the records)
+                    same_image = (gu.same_bits(got["image"], full["image"][:, subset]).all() if name == "exact" else
+                                  (np.array_equal(np.isnan(got["image"]), np.isnan(full["image"][:, subset])) and distance(got["image"], full["image"][:, subset]) < 1.0e-13))
+                    if not (same_image and np.array_equal(got["sample_num"], full["sample_num"][subset])
                             and np.array_equal(got["sample_flags"], full["sample_flags"][subset])):
                         problems.append(f"{name} tier: a subset of {subset.size} pixels differs from the full frame "
                                         f"({distance(got['image'], full['image'][:, subset]):.2e})")
