@@ -351,7 +351,7 @@ int bl_init(const bl_params *p, int device, bl_ctx **out) {
         {"BLACKLIGHT_AMD_TOLERANT_POLARIZED_COEFFICIENTS", BL_SWITCH_TOLERANT_POLARIZED_COEFFICIENTS},
         {"BLACKLIGHT_AMD_GENERAL_LOCATE", BL_SWITCH_GENERAL_LOCATE}, {"BLACKLIGHT_AMD_LANE_TRANSFER", BL_SWITCH_LANE_TRANSFER},
         {"BLACKLIGHT_AMD_NO_FUSED_LOCATE", BL_SWITCH_NO_FUSED_LOCATE}, {"BLACKLIGHT_AMD_GENERAL_FUSED", BL_SWITCH_GENERAL_FUSED},
-        {"BLACKLIGHT_AMD_SAMPLE_RECORDS", BL_SWITCH_SAMPLE_RECORDS}};
+        {"BLACKLIGHT_AMD_SAMPLE_RECORDS", BL_SWITCH_SAMPLE_RECORDS}, {"BLACKLIGHT_AMD_UNPIPELINED_SHADE", BL_SWITCH_UNPIPELINED_SHADE}};
     for (const auto &sw : kSwitches)
       if (std::getenv(sw.name) != nullptr) ctx->switches |= sw.bit;
     ctx->debug_counters = std::getenv("BLACKLIGHT_AMD_DEBUG_COUNTERS") != nullptr;

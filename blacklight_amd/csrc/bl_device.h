@@ -359,6 +359,7 @@ struct BlShadeArgs {
   // holds a deferred sample or an optically thick step (the segment's row then says where they are: BL_COMPOSED_EXPANDED)
   double2 *composed;          // [segment row], or null: one transfer record per sample
   int general_locate;         // measurement switch (bl_stats.switches): the general locate kernel where the plain one applies
+  int unpipelined_shade;      // ... the general exact coefficient kernel where the software-pipelined one applies
   int undefined_edge;         // bl_set_undefined_policy(BL_UNDEFINED_EDGE): samples where the reference reads past its arrays use the edge
   const unsigned long long *counters_in;
   unsigned long long *counters;

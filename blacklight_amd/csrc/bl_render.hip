@@ -787,6 +787,7 @@ void BuildShadeArgs(RenderJob &job) {
   }
   sa.samples_renormalised = job.geo_load ? 1 : 0;
   sa.general_locate = (ctx->switches & BL_SWITCH_GENERAL_LOCATE) ? 1 : 0;
+  sa.unpipelined_shade = (ctx->switches & BL_SWITCH_UNPIPELINED_SHADE) ? 1 : 0;
   ctx->d_shade_cold.Ensure(1);
   Check(hipMemcpyAsync(ctx->d_shade_cold.ptr, &cold, sizeof(BlShadeCold), hipMemcpyHostToDevice, stream), "shade parameter upload");
   Check(hipStreamSynchronize(stream), "shade parameter upload");   // cold is a local

@@ -639,7 +639,7 @@ extern "C" hipError_t bl_launch_shade(const BlShadeArgs *args, int model, int gr
     else if (aux && power) BL_LAUNCH_S(BL_MODEL_SIMULATION, true, true);
     else if (aux) BL_LAUNCH_S(BL_MODEL_SIMULATION, true, false);
     else if (power) BL_LAUNCH_S(BL_MODEL_SIMULATION, false, true);
-    else if (sks_curved && std::getenv("BLACKLIGHT_AMD_UNPIPELINED_SHADE") == nullptr) {   // the benchmark's case: the software-pipelined kernel
+    else if (sks_curved && !args->unpipelined_shade) {   // the benchmark's case: the software-pipelined kernel
       if (spin_zero) hipLaunchKernelGGL((bl_shade_exact_kernel<true>), dim3(grid), dim3(256), 0, stream, *args);
       else hipLaunchKernelGGL((bl_shade_exact_kernel<false>), dim3(grid), dim3(256), 0, stream, *args);
     }

@@ -302,6 +302,7 @@ typedef struct bl_stats {
 #define BL_SWITCH_NO_FUSED_LOCATE (1u << 6)                 /* a locate kernel + bl_shade_fast_kernel / bl_shade_exact_kernel   */
 #define BL_SWITCH_GENERAL_FUSED (1u << 7)                   /* bl_shade_fused_kernel where bl_shade_fused2_kernel applies       */
 #define BL_SWITCH_SAMPLE_RECORDS (1u << 8)                  /* tolerant tier: one transfer record per sample where composed maps apply */
+#define BL_SWITCH_UNPIPELINED_SHADE (1u << 9)               /* bl_shade_kernel where bl_shade_exact_kernel applies              */
 
 typedef struct bl_ctx bl_ctx;
 

@@ -55,3 +55,21 @@ def test_product_does_not_use_the_oracle():
                              r"dlopen\([^)]*oracle|blo_render", text):
                     offenders.append(os.path.join(dirpath, name))
     assert not offenders, offenders
+
+
+def test_the_environment_is_read_in_bl_init_only():
+    """Measurement switches are resolved once, when a context is made (bl_init, bl_api.hip), and echoed in bl_stats.switches: no
+    render, launch wrapper or kernel file calls getenv (not thread-safe beside a setenv, and invisible in a benchmark line). The
+    command-line driver and the .npz writer read their own options (BLACKLIGHT_AMD_DEVICES / _ARITHMETIC / _UNDEFINED, _ZIP64)."""
+    import glob
+    import re
+    csrc = os.path.join(REPO, "blacklight_amd", "csrc")
+    offenders = []
+    for path in sorted(glob.glob(os.path.join(csrc, "*"))):
+        name = os.path.basename(path)
+        if not name.endswith((".hip", ".h", ".inc", ".cpp")) or name in ("bl_api.hip", "bl_main.cpp", "bl_host.cpp"):
+            continue
+        for number, line in enumerate(open(path, errors="replace"), 1):
+            if re.search(r"\bgetenv\s*\(", line):
+                offenders.append(f"{name}:{number}")
+    assert not offenders, offenders
