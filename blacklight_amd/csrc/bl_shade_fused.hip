@@ -99,6 +99,14 @@ __device__ __forceinline__ double expm1_k(double x) {
   const double t = __builtin_amdgcn_ldexp(1.0, k);
   return (t - 1.0) + t * e;
 }
+// 1 / sqrt(x) for finite x > 0 from v_rsq_f64 (2^-26) and ONE Newton step: 4e-16, which is what the tier's reciprocal has as well
+// (bl_fastmath.h's rsqrt takes two: a quarter of its instructions for a last place this kernel's results never show)
+__device__ __forceinline__ double rsqrt_k(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  const double e = __builtin_fma(-0.5 * x * y, y, 0.5);
+  return __builtin_fma(y, e, y);
+}
+__device__ __forceinline__ double sqrt_k(double x) { return x > 0.0 ? x * rsqrt_k(x) : 0.0; }
 __device__ __forceinline__ double cbrt_k(double x) {
   const int e = __builtin_amdgcn_frexp_exp(x);
   const double mant = __builtin_amdgcn_frexp_mant(x);
@@ -106,11 +114,9 @@ __device__ __forceinline__ double cbrt_k(double x) {
   const double m = __builtin_amdgcn_ldexp(mant, e - 3 * q);
   const float seed = __builtin_amdgcn_exp2f(__builtin_amdgcn_logf((float)m) * -0.33333334f);
   const double third = KS(0x1.5555555555555p-2);
-  double z = (double)seed;
-  double h = __builtin_fma(-m, z * z * z, 1.0);
-  z = __builtin_fma(z * h, third, z);
-  h = __builtin_fma(-m, z * z * z, 1.0);
-  z = __builtin_fma(z * h, third, z);
+  double z = (double)seed;                                           // m^(-1/3) to 2^-21
+  const double h = __builtin_fma(-m, z * z * z, 1.0);
+  z = __builtin_fma(z * h, third, z);                                // 2^-41 (one Newton step; the correction below squares it again)
   double c = m * z * z;
   c = __builtin_fma(__builtin_fma(-c * c, c, m), z * z * third, c);
   const double res = __builtin_amdgcn_ldexp(c, q);
@@ -415,7 +421,7 @@ __device__ __forceinline__ double2 shade(const BlSpacetime &st, const double (&K
     const double u = rr2 - a2, v = 2.0 * bh_a * z;
     r2 = 0.5 * (u + bl_sqrt_g(u * u + v * v));
   }
-  const double r_inv = fastmath::rsqrt(r2);
+  const double r_inv = rsqrt_k(r2);
   const double r = r2 * r_inv;
   const double ra2 = r2 + a2;
   const double ra_inv = kSpinZero ? r_inv * r_inv : fastmath::rcp(ra2);
@@ -432,7 +438,7 @@ __device__ __forceinline__ double2 shade(const BlSpacetime &st, const double (&K
     const double ta = kk - f * lk * lk;                  // g^ij k_i k_j
     const double tb = 2.0 * kt * f * lk;                 // 2 g^0i k_0 k_i
     const double tc = -(1.0 + f) * kt * kt;              // g^00 k_0 k_0
-    const double td = fastmath::sqrt(tb * tb - 4.0 * ta * tc);
+    const double td = sqrt_k(tb * tb - 4.0 * ta * tc);
     const double factor = (tb < 0.0 ? td - tb : -2.0 * tc) * fastmath::rcp(tb < 0.0 ? 2.0 * ta : tb + td);
     kx *= factor;
     ky *= factor;
@@ -449,7 +455,7 @@ __device__ __forceinline__ double2 shade(const BlSpacetime &st, const double (&K
   // ---- u^mu from the normal-frame velocities (simulation_coefficients.cpp:297-313): u^t and 1 / u^t from one reciprocal square root
   const double u0n2 = 1.0 + g_rr * uu1 * uu1 + 2.0 * g_rph * uu1 * uu3 + g_thth * uu2 * uu2 + g_phph * uu3 * uu3;
   const double ut2 = u0n2 * g_rr;
-  const double ut_inv = fastmath::rsqrt(ut2);
+  const double ut_inv = rsqrt_k(ut2);
   const double ut = ut2 * ut_inv;
   const double ur = uu1 - hh * fastmath::rcp(g_rr) * ut;         // shift^r = (2 m r / Sigma) / (1 + 2 m r / Sigma)
   const double u_r = hh * ut + g_rr * ur + g_rph * uu3;
@@ -463,7 +469,7 @@ __device__ __forceinline__ double2 shade(const BlSpacetime &st, const double (&K
   const double bb_sq_lab = g_rr * bb1 * bb1 + 2.0 * g_rph * bb1 * bb3 + g_thth * bb2 * bb2 + g_phph * bb3 * bb3;
   const double b_sq = (bb_sq_lab + bt * bt) * ut_inv * ut_inv;
   // ---- k_i in the simulation's coordinates (Jacobian of radiation_geometry.cpp:69-126)
-  const double sth_inv = fastmath::rsqrt(sth2);
+  const double sth_inv = rsqrt_k(sth2);
   const double k_r = lk;
   const double k_th = (lz * (x * kx + y * ky) - r * sth2 * kz) * sth_inv;
   const double k_ph = x * ky - y * kx;
@@ -490,7 +496,7 @@ __device__ __forceinline__ double2 shade(const BlSpacetime &st, const double (&K
   // ---- cell cuts (:361-375): decided here unless a value sits within the guard band of an active threshold
   bool cell_cut = false, undecided = pp2 == 0.0;   // (on the polar axis: the exact kernel's business)
   if (cut_mask != 0) {
-    const double bb = (cut_mask & 0x300) ? fastmath::sqrt(b_sq) : 0.0;   // only the field-strength cuts need |b| itself
+    const double bb = (cut_mask & 0x300) ? sqrt_k(b_sq) : 0.0;   // only the field-strength cuts need |b| itself
     const double kb_tt_e = (cut_mask & 0xc0) ? fastmath::rcp(kte_inv) : 0.0;
     const double value[7] = {rho, rho, pgas, kb_tt_e, bb, sigma_cut, beta_inv};   // against thresholds in these units
 #pragma unroll
@@ -513,7 +519,7 @@ __device__ __forceinline__ double2 shade(const BlSpacetime &st, const double (&K
   cos2 = cos2 < 1.0 ? cos2 : 1.0;
   // |b| sin(theta_B) and its reciprocal from one reciprocal square root
   const double bs2 = b_sq * (1.0 - cos2);
-  const double b_sin_inv = fastmath::rsqrt(bs2);                   // (inf along the field: nu / nu_s = inf there, as from 1 / 0)
+  const double b_sin_inv = rsqrt_k(bs2);                   // (inf along the field: nu / nu_s = inf there, as from 1 / 0)
   const double b_sin = bs2 > 0.0 ? bs2 * b_sin_inv : 0.0;
   // ---- coefficients at the one frequency (simulation_coefficients.cpp:464-523) and the transfer record (unpolarized.cpp:74-110)
   const double mf_inv = fastmath::rcp(momentum_factor);
@@ -521,7 +527,7 @@ __device__ __forceinline__ double2 shade(const BlSpacetime &st, const double (&K
   const double nu_inv = -k_u_inv * mf_inv * freq_inv;
   const double xx = nu * b_sin_inv * (kte_inv * kte_inv) * K[4];   // nu / nu_s
   const double x_1_3 = cbrt_k(xx);
-  const double x_1_6 = fastmath::sqrt(x_1_3);
+  const double x_1_6 = sqrt_k(x_1_3);
   const double x_1_2 = x_1_6 * x_1_3;
   const double var_c = x_1_2 + KS(kPow2_11_12) * x_1_6;
   const double j_val = K[5] * (rho * b_sin) * (nu_inv * nu_inv) * exp_k(-x_1_3) * var_c * var_c;

@@ -47,47 +47,42 @@ __global__ void __launch_bounds__(256) bl_transfer_freq_kernel(BlTransferArgs P)
 #pragma unroll
       for (int i = 0; i < 15; i++) exp_c[i] = fastmath::resident_constant(fastmath::kExpConstants[i]);
       const double2 *in = reinterpret_cast<const double2 *>(P.freq_inputs + (size_t)P.ray_offset[slot]);
+      const double kThird = fastmath::resident_constant(1.0 / 3.0), kInvPlanck = fastmath::resident_constant(kC * kC / (2.0 * kH));
+      const double kRoot = fastmath::resident_constant(kPow2_11_12), kThin = fastmath::resident_constant(0x1p-10);
       for (int n = num - 1; n >= 0; n--) {   // reference sample order is reversed integration order (geodesics.cpp:832-840)
         const double2 q0 = in[4 * (size_t)n], q1 = in[4 * (size_t)n + 1], q2 = in[4 * (size_t)n + 2], q3 = in[4 * (size_t)n + 3];
-        double a = 1.0, c = 0.0;
-        if (q0.x == 2.0) {
-          c = nan;
-        } else if (q0.x == 1.0) {
-          // bl_shade_fast_kernel's frequency loop (simulation_coefficients.cpp:464-523, unpolarized.cpp:74-110)
-          const double xx_1_3 = q1.x * f_1_3;
-          const double var_c = q0.y * f_1_2 + kPow2_11_12 * (q1.y * f_1_6);
-          const double j_val = q2.y * f_inv2 * fastmath::exp(-xx_1_3, exp_c) * var_c * var_c;
-          // h nu / (k T_e) is tiny for the hot plasma that shines (Rayleigh-Jeans): the same four-term form as for the thin step
-          const double xp = q2.x * f;
-          const double planck = xp < 0x1p-10 ? xp * (1.0 + 0.5 * xp * (1.0 + (1.0 / 3.0) * xp * (1.0 + 0.25 * xp))) : fastmath::expm1(xp);
-          const double inv_b_nu = planck * (kC * kC / (2.0 * kH));
-          double alpha_val = j_val * inv_b_nu;
-          if (alpha_val * alpha_val <= 0x1p-1024) alpha_val = 0.0;
-          const double delta_lambda_cgs = q3.x * f_inv;
-          if (alpha_val > 0.0) {
-            const double delta_tau = alpha_val * delta_lambda_cgs;
-            if (delta_tau < 0x1p-10) {
-              // optically thin step (nearly every sample): expm1(-t) = -t p(t), p = 1 - t/2 (1 - t/3 (1 - t/4)) to 2^-53, so
-              // a = 1 - t p and c = -(j / alpha) expm1(-t) = j dl p: no exponential and no division
-              const double p = 1.0 - 0.5 * delta_tau * (1.0 - (1.0 / 3.0) * delta_tau * (1.0 - 0.25 * delta_tau));
-              a = 1.0 - delta_tau * p;
-              c = j_val * delta_lambda_cgs * p;
-            } else {
-              const double ss = j_val * fastmath::rcp(alpha_val);
-              if (delta_tau <= kDeltaTauMax) {
-                const double e1 = fastmath::expm1(-delta_tau);
-                a = 1.0 + e1;
-                c = -ss * e1;
-              } else {
-                a = 0.0;
-                c = ss;
-                intensity = 0.0;   // the thick step's intensity replaces what lies behind it, a NaN included (unpolarized.cpp:103-104)
-              }
-            }
+        // bl_shade_fast_kernel's frequency loop (simulation_coefficients.cpp:464-523, unpolarized.cpp:74-110) as one straight line for
+        // the sample that has coefficients, a thin step and h nu << k T_e - nearly every one: no expm1, no division, no branch; the
+        // rest is selected or, where it needs an exponential of its own, redone behind a branch
+        const bool have = q0.x == 1.0;
+        const double xx_1_3 = q1.x * f_1_3;
+        const double var_c = q0.y * f_1_2 + kRoot * (q1.y * f_1_6);
+        const double j_val = q2.y * f_inv2 * fastmath::exp(-xx_1_3, exp_c) * var_c * var_c;
+        const double xp = q2.x * f;
+        double planck = xp * (1.0 + 0.5 * xp * (1.0 + kThird * xp * (1.0 + 0.25 * xp)));
+        if (__builtin_expect(have && !(xp < kThin), 0)) planck = fastmath::expm1(xp);
+        double alpha_val = j_val * (planck * kInvPlanck);
+        if (alpha_val * alpha_val <= 0x1p-1024) alpha_val = 0.0;
+        const double delta_lambda_cgs = q3.x * f_inv;
+        const double delta_tau = alpha_val * delta_lambda_cgs;
+        // optically thin step: expm1(-t) = -t p(t), p = 1 - t/2 (1 - t/3 (1 - t/4)) to 2^-53: a = 1 - t p, c = j dl p
+        const double p = 1.0 - 0.5 * delta_tau * (1.0 - kThird * delta_tau * (1.0 - 0.25 * delta_tau));
+        const bool absorbing = alpha_val > 0.0;
+        double a = absorbing ? 1.0 - delta_tau * p : 1.0, c = j_val * delta_lambda_cgs * (absorbing ? p : 1.0);
+        if (__builtin_expect(have && absorbing && !(delta_tau < kThin), 0)) {
+          const double ss = j_val * fastmath::rcp(alpha_val);
+          if (delta_tau <= kDeltaTauMax) {
+            const double e1 = fastmath::expm1(-delta_tau);
+            a = 1.0 + e1;
+            c = -ss * e1;
           } else {
-            c = j_val * delta_lambda_cgs;
+            a = 0.0;
+            c = ss;
+            intensity = 0.0;   // the thick step's intensity replaces what lies behind it, a NaN included (unpolarized.cpp:103-104)
           }
         }
+        a = have ? a : 1.0;
+        c = have ? c : (q0.x == 2.0 ? nan : 0.0);   // (2: NaN primitives off the grid, simulation_sampling.cpp:377-384; 0: nothing to add)
         intensity = __builtin_fma(a, intensity, c);
       }
     }
