@@ -320,9 +320,17 @@ def render_adaptive(ctx, comm=None, want_camera=False, tile=None):
     block_locs = None
     while max_level > 0:
         nxt = None
+        error = None
         if rank == 0:
-            flags, nxt = ctx.adaptive_refine(level, levels[level]["image"], levels[level]["block_locs"])
-            levels[level]["refinement_flags"] = flags
+            try:
+                flags, nxt = ctx.adaptive_refine(level, levels[level]["image"], levels[level]["block_locs"])
+                levels[level]["refinement_flags"] = flags
+            except Exception as failure:   # (a bad image, out of memory, a library error: every rank has to hear of it)
+                error = f"{type(failure).__name__}: {failure}"
+        if hasattr(comm, "agree"):   # (rank 0 alone refines: the others would wait in the broadcast below for a rank that has left)
+            comm.agree(error)
+        elif error is not None:
+            raise RankError(f"rank 0: {error}")
         block_locs = comm.broadcast_blocks(nxt)
         if block_locs.shape[0] == 0:
             break

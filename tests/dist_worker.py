@@ -25,6 +25,7 @@ class StubContext:
     stub_value, refinement decisions and the writer from a host-only context (BL_DEVICE_NONE) of the real library."""
 
     fail_on_level = None   # a level at which render() raises (one rank's refusal: test of the error agreement)
+    fail_refine = False    # adaptive_refine() raises (rank 0's own step between two levels)
 
     def __init__(self, params_dict):
         import blacklight_amd as bl
@@ -71,6 +72,8 @@ class StubContext:
                     camera_dir=None if cam is None else -cam, rendering=None, stats=stats)
 
     def adaptive_refine(self, level, image, block_locs=None):
+        if self.fail_refine:
+            raise MemoryError("no room for the next level's block list")
         return self.host.adaptive_refine(level, image, block_locs)
 
     def clear_warnings(self):
@@ -102,11 +105,14 @@ def worker(rank, world, port, mode, params_dict, mock_args, want_camera, out_pat
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from blacklight_amd import distributed as bd
     comm = bd.Comm(device=torch.device("cpu"))
-    if mode == "stub_failing":
-        # rank 1 alone fails at level 1: every rank must raise, none may be left waiting in a collective
+    if mode in ("stub_failing", "stub_failing_refine"):
+        # rank 1 alone fails at level 1 - or rank 0 in the refinement step, which it runs alone: every rank must raise, none may be
+        # left waiting in a collective
         ctx = StubContext(params_dict)
-        if rank == 1:
+        if mode == "stub_failing" and rank == 1:
             ctx.fail_on_level = 1
+        if mode == "stub_failing_refine":
+            ctx.fail_refine = True
         try:
             bd.render_adaptive(ctx, comm, want_camera)
             outcome = "no error"

@@ -130,6 +130,17 @@ def test_a_failing_rank_fails_every_rank(tmp_path, built_library):
         assert "rank 1: RuntimeError: Error: this rank's rays reach a place" in text and "rank 0" not in text and "rank 2" not in text
 
 
+def test_rank_0_failing_between_levels_fails_every_rank(tmp_path, built_library):
+    """Rank 0 alone runs the refinement decision between two levels; an exception there (a bad image, out of memory) reaches every
+    rank as RankError before the broadcast of the next block list, in which the others would otherwise wait for a rank that has left."""
+    import dist_worker
+    out_path = str(tmp_path / "outcome")
+    mp.spawn(dist_worker.worker, args=(3, _free_port(), "stub_failing_refine", ADAPTIVE_STUB, None, False, out_path), nprocs=3, join=True)
+    for rank in range(3):
+        text = open(f"{out_path}.rank{rank}").read()
+        assert "rank 0: MemoryError: no room for the next level's block list" in text and "rank 1" not in text
+
+
 def test_launcher_refuses_a_mismatched_world(tmp_path):
     """bench.py --gpus N must equal the number of ranks it was started with, and without a launcher it must not run a
     smaller job under that name: both fail before anything touches a GPU."""
