@@ -12,6 +12,9 @@
 #include <cstring>
 #include <fstream>
 #include <limits>
+#include <map>
+#include <memory>
+#include <mutex>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -226,13 +229,17 @@ struct bl_ctx {
 
   // geodesic checkpoint of the root level (geodesic_checkpoint.cpp:28-108): what LoadGeodesics() read, by pixel
   struct Checkpoint {
-    bool loaded = false;
     int num_steps = 0;
+    double frame[7][4] = {};              // cam_x, u_con, u_cov, norm_con, norm_con_c, hor_con_c, vert_con_c as the file has them
+    std::vector<double> frequencies;
     std::vector<double> camera_pos, camera_dir, factors;   // [n_pix][4], [n_pix][4], [n_pix]
     std::vector<uint8_t> flags;
     std::vector<int32_t> sample_num;
     std::vector<double> pos, dir, len;   // [n_pix][num_steps][4] x 2, [n_pix][num_steps]: reference order (far -> near)
-  } checkpoint;
+  };
+  // One loaded file serves every context of the process that names it (the command-line driver's one context per GPU: 67 GB at
+  // 1024^2 once, not once per device): LoadGeodesicCheckpoint() keeps a process-wide table of weak references.
+  std::shared_ptr<const Checkpoint> checkpoint;
 
   bl_stats stats{};
 };

@@ -7,6 +7,8 @@
 // holds `record_capacity` of each, and the geodesic kernel hands out rays only while the records of the rays in flight
 // are sure to fit (BlTraceArgs::record_gate). What it did not get to is the next chunk. The benchmark frame - 704 samples
 // per ray where ray_max_steps allows 2 000 - is one chunk this way; sized for the worst case it was two.
+#include <sys/stat.h>
+
 #include "bl_ctx.h"
 
 namespace {
@@ -59,17 +61,15 @@ void ReadCheckpointArray(std::ifstream &in, std::vector<T> *data, int dims[5]) {
   if (!in) throw Failure{BL_E_INPUT, "Geodesic checkpoint file is damaged."};
 }
 
-void LoadGeodesicCheckpoint(bl_ctx *ctx) {
-  const bl_params &p = ctx->params;
+std::shared_ptr<const bl_ctx::Checkpoint> ReadGeodesicCheckpoint(const bl_params &p) {
   std::ifstream in(p.checkpoint_geodesic_file.s, std::ios_base::in | std::ios_base::binary);
   if (!in.is_open()) throw Failure{BL_E_INPUT, "Could not open geodesic checkpoint file."};
-  bl_camera_frame &f = ctx->frame;
-  double *vectors[7] = {f.cam_x, f.u_con, f.u_cov, f.norm_con, f.norm_con_c, f.hor_con_c, f.vert_con_c};
-  for (double *v : vectors) in.read(reinterpret_cast<char *>(v), 4 * sizeof(double));
-  bl_ctx::Checkpoint &c = ctx->checkpoint;
+  auto loaded = std::make_shared<bl_ctx::Checkpoint>();
+  bl_ctx::Checkpoint &c = *loaded;
+  for (double (&v)[4] : c.frame) in.read(reinterpret_cast<char *>(v), 4 * sizeof(double));
   const size_t n_pix = static_cast<size_t>(p.camera_resolution) * p.camera_resolution;
   int dims[5];
-  std::vector<double> frequencies;
+  std::vector<double> &frequencies = c.frequencies;
   ReadCheckpointArray(in, &c.camera_pos, dims);
   ReadCheckpointArray(in, &c.camera_dir, dims);
   ReadCheckpointArray(in, &frequencies, dims);
@@ -87,8 +87,36 @@ void LoadGeodesicCheckpoint(bl_ctx *ctx) {
     throw Failure{BL_E_INPUT, "Geodesic checkpoint does not match this camera (resolution, frequencies or ray_max_steps)."};
   for (size_t m = 0; m < n_pix; m++)
     if (c.sample_num[m] < 0 || c.sample_num[m] > c.num_steps) throw Failure{BL_E_INPUT, "Geodesic checkpoint file is damaged."};
-  ctx->frequencies = frequencies;   // LoadGeodesics() replaces what InitializeCamera() would have computed
-  c.loaded = true;
+  return loaded;
+}
+
+// LoadGeodesics() for this context. The file's contents are shared between the contexts of a process that load the same file for the
+// same camera (path, size, modification time, resolution, frequencies, ray_max_steps): the table holds weak references, so the
+// memory goes when the last context that uses it does.
+void LoadGeodesicCheckpoint(bl_ctx *ctx) {
+  static std::mutex table_lock;
+  static std::map<std::string, std::weak_ptr<const bl_ctx::Checkpoint>> table;
+  const bl_params &p = ctx->params;
+  struct stat info {};
+  std::string key = p.checkpoint_geodesic_file.s;
+  if (stat(p.checkpoint_geodesic_file.s, &info) == 0)
+    key += "|" + std::to_string(static_cast<long long>(info.st_size)) + "|" + std::to_string(static_cast<long long>(info.st_mtime)) + "|"
+        + std::to_string(static_cast<long long>(info.st_ino));
+  key += "|" + std::to_string(p.camera_resolution) + "|" + std::to_string(p.image_num_frequencies) + "|" + std::to_string(p.ray_max_steps);
+  std::shared_ptr<const bl_ctx::Checkpoint> loaded;
+  {
+    std::lock_guard<std::mutex> guard(table_lock);
+    loaded = table[key].lock();
+    if (!loaded) {   // (read under the lock: a second context asking for the same file waits for the first one's read instead of repeating it)
+      loaded = ReadGeodesicCheckpoint(p);
+      table[key] = loaded;
+    }
+  }
+  bl_camera_frame &f = ctx->frame;
+  double *vectors[7] = {f.cam_x, f.u_con, f.u_cov, f.norm_con, f.norm_con_c, f.hor_con_c, f.vert_con_c};
+  for (int v = 0; v < 7; v++) std::memcpy(vectors[v], loaded->frame[v], 4 * sizeof(double));
+  ctx->frequencies = loaded->frequencies;   // LoadGeodesics() replaces what InitializeCamera() would have computed
+  ctx->checkpoint = loaded;
 }
 
 template <typename T>
@@ -206,7 +234,7 @@ void PlanJob(RenderJob &job) {
   // samples, save writes what the geodesic kernel produced in the reference's layout
   job.geo_load = p.checkpoint_geodesic_load && d->level == 0;
   job.geo_save = p.checkpoint_geodesic_save && d->level == 0;
-  if (job.geo_load && !ctx->checkpoint.loaded) LoadGeodesicCheckpoint(ctx);
+  if (job.geo_load && !ctx->checkpoint) LoadGeodesicCheckpoint(ctx);
   job.need_time = (job.aux && ctx->aux_images.image_time) || job.slow || job.geo_load || job.geo_save;
 
   job.level_pixels = static_cast<long long>(p.camera_resolution) * p.camera_resolution;
@@ -215,7 +243,7 @@ void PlanJob(RenderJob &job) {
   if (job.geo_save && (d->pixel_map != nullptr || job.n_rays != job.level_pixels))
     throw Failure{BL_E_ARG, "checkpoint_geodesic_save needs the whole root camera in one bl_render call."};
   if (job.geo_load && d->pixel_map != nullptr) {   // a rank's tiles can be served from the one file; the map must stay inside it
-    const size_t n_pix = ctx->checkpoint.sample_num.size();
+    const size_t n_pix = ctx->checkpoint->sample_num.size();
     for (long long ray = 0; ray < job.n_rays; ray++)
       if (d->pixel_map[ray] < 0 || static_cast<size_t>(d->pixel_map[ray]) >= n_pix)
         throw Failure{BL_E_ARG, "pixel_map names a pixel the geodesic checkpoint does not hold."};
@@ -450,7 +478,7 @@ void StageInputsAndOutputs(RenderJob &job) {
     for (int which = 0; which < 2; which++) {
       double *target = which == 0 ? job.cam_pos : job.cam_dir;
       if (target == nullptr) continue;
-      const std::vector<double> &source = which == 0 ? ctx->checkpoint.camera_pos : ctx->checkpoint.camera_dir;
+      const std::vector<double> &source = which == 0 ? ctx->checkpoint->camera_pos : ctx->checkpoint->camera_dir;
       for (long long ray = 0; ray < n_rays; ray++) {
         const size_t m = d->pixel_map != nullptr ? static_cast<size_t>(d->pixel_map[ray]) : static_cast<size_t>(ray);
         for (int mu = 0; mu < 4; mu++) rows[4 * ray + mu] = source[4 * m + mu];
@@ -961,7 +989,7 @@ long long LoadChunkFromCheckpoint(RenderJob &job, int k, long long begin, int ra
   bl_ctx *ctx = job.ctx;
   const bl_render_desc *d = job.d;
   bl_ctx::ChunkSlot &sl = ctx->slot[k];
-  const bl_ctx::Checkpoint &ck = ctx->checkpoint;
+  const bl_ctx::Checkpoint &ck = *ctx->checkpoint;
   const size_t steps = static_cast<size_t>(ck.num_steps);
   size_t total = 0;
   int taken = 0;
