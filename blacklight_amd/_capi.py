@@ -49,7 +49,7 @@ class RenderDesc(C.Structure):
 # BL_SWITCH_* of include/blacklight_amd.h: measurement switches (bl_stats.switches, bl_debug_set_switches)
 SWITCHES = {name: 1 << bit for bit, name in enumerate(
     ["TENSOR_TRANSPORT", "SPLIT_RECORDS", "RECORD_EVERY_STEP", "TOLERANT_POLARIZED_COEFFICIENTS", "GENERAL_LOCATE", "LANE_TRANSFER",
-     "NO_FUSED_LOCATE", "GENERAL_FUSED", "SAMPLE_RECORDS", "UNPIPELINED_SHADE"])}
+     "NO_FUSED_LOCATE", "GENERAL_FUSED", "SAMPLE_RECORDS", "UNPIPELINED_SHADE", "QUAD_TAIL", "QUAD_EVERY_RAY"])}
 
 BL_MAX_LEVELS = 16
 
@@ -75,7 +75,7 @@ class Stats(C.Structure):
         ("launches_transfer", C.c_int32),
         ("ms_locate", C.c_float), ("ms_wall", C.c_float), ("launches_locate", C.c_int32),
         ("arithmetic", C.c_int32), ("n_deferred", C.c_int64), ("n_undefined", C.c_int64),
-        ("switches", C.c_uint32), ("fused_variant", C.c_int32),
+        ("switches", C.c_uint32), ("fused_variant", C.c_int32), ("n_parked", C.c_int64),
     ]
 
 

@@ -27,6 +27,7 @@
 
 extern "C" hipError_t bl_launch_ray_init(const BlTraceArgs *args, int integrator, hipStream_t stream);
 extern "C" hipError_t bl_launch_geodesic(const BlTraceArgs *args, int integrator, int grid, hipStream_t stream);
+extern "C" hipError_t bl_launch_geodesic_quad(const BlTraceArgs *args, int grid, hipStream_t stream);
 extern "C" int bl_geodesic_occupancy(int integrator, int with_time, int spin_zero, int shell);
 extern "C" hipError_t bl_launch_locate(const BlShadeArgs *args, int grid, int lds_bytes, hipStream_t stream);
 extern "C" hipError_t bl_launch_shade(const BlShadeArgs *args, int model, int grid, hipStream_t stream);
@@ -127,6 +128,7 @@ struct bl_ctx {
   bool kappa_warned = false;
   bool debug_counters = false;        // BLACKLIGHT_AMD_DEBUG_COUNTERS (bl_init): print the -DBL_GEO_STATS counters after a render
   unsigned int switches = 0;          // BL_SWITCH_* (include/blacklight_amd.h): the environment as bl_init found it, never read again
+  int park_below = 32, park_after = 32;   // BlTraceArgs::park_below, ::park_after (BLACKLIGHT_AMD_PARK_BELOW, _PARK_AFTER in bl_init's environment: measurement knobs)
   double guard_band = 1.0e-9;         // tolerant tier: relative half-width around a cut threshold left to the exact kernel
 
   // image rows (radiation_integrator.cpp:436-520)
@@ -183,6 +185,7 @@ struct bl_ctx {
     DeviceBuffer<unsigned long long> d_located_tag;
     DeviceBuffer<double2> d_transfer;
     DeviceBuffer<double2> d_composed;              // tolerant tier: one affine map per ray segment (BlShadeArgs::composed)
+    DeviceBuffer<double> d_parked;                 // rays bl_geodesic_kernel leaves to bl_geodesic_quad_kernel (BlTraceArgs::parked)
     DeviceBuffer<unsigned long long> d_counters;   // BL_CNT_TOTAL
     DeviceBuffer<BlAuxSample> d_aux;               // auxiliary-image mode
     DeviceBuffer<double> d_sample_t;               // image_time, slow light
@@ -197,14 +200,14 @@ struct bl_ctx {
     DeviceBuffer<double> d_tau_inc;                // tolerant tier with an optical-depth image: alpha x length per sample and frequency
     uint64_t Bytes() const {
       return d_records_hot.count * sizeof(BlSampleHot) + d_records_cold.count * sizeof(BlSampleCold) + d_located.count * sizeof(BlLocated)
-          + d_located_tag.count * sizeof(unsigned long long) + (d_transfer.count + d_composed.count) * sizeof(double2) + d_aux.count * sizeof(BlAuxSample)
+          + d_located_tag.count * sizeof(unsigned long long) + (d_transfer.count + d_composed.count) * sizeof(double2) + d_parked.count * sizeof(double) + d_aux.count * sizeof(BlAuxSample)
           + (d_sample_t.count + d_slow_frac.count + d_pol_matrix.count + d_tau_inc.count) * sizeof(double) + d_pol_samples.count * sizeof(BlPolSample)
           + d_freq_inputs.count * sizeof(BlFreqInputs) + d_pol_coeffs.count * sizeof(double2) + d_anchors.count * sizeof(unsigned int)
           + d_coef_inputs.count * sizeof(BlCoefInputs) + d_redo.count * sizeof(unsigned long long);
     }
     void Free() {
       d_redo.Free(); d_tau_inc.Free(); d_aux.Free(); d_sample_t.Free(); d_slow_frac.Free(); d_pol_samples.Free(); d_pol_matrix.Free(); d_freq_inputs.Free(); d_pol_coeffs.Free(); d_coef_inputs.Free(); d_anchors.Free();
-      d_records_hot.Free(); d_records_cold.Free(); d_located.Free(); d_located_tag.Free(); d_transfer.Free(); d_composed.Free(); d_counters.Free();
+      d_records_hot.Free(); d_records_cold.Free(); d_located.Free(); d_located_tag.Free(); d_transfer.Free(); d_composed.Free(); d_parked.Free(); d_counters.Free();
     }
   };
   ChunkSlot slot[2];

@@ -77,11 +77,13 @@ enum BlCounter {
   BL_CNT_REDO = 6,          // tolerant tier: samples left to the exact coefficient kernel (redo list entries)
   BL_CNT_COMMITTED = 7,     // geodesic kernel: record slots spoken for - ray_max_steps per ray in flight, what it emitted per finished ray
   BL_CNT_SAMPLES = 8,       // kept samples of the finished rays: where the next ray's per-sample rows start (BlTraceArgs::ray_offset)
+  BL_CNT_PARKED = 9,        // rays bl_geodesic_kernel parked for bl_geodesic_quad_kernel (BlTraceArgs::parked)
   BL_CNT_COUNT = 10
 };
 // per scratch set: the counters above, four transfer statistics, eight debug counters (kernels built with -DBL_GEO_STATS)
 #define BL_CNT_DEBUG (BL_CNT_COUNT + 4)
-#define BL_CNT_TOTAL (BL_CNT_COUNT + 12)
+#define BL_CNT_QUAD_NEXT (BL_CNT_COUNT + 12)   // work queue head of bl_geodesic_quad_kernel: parked rays handed out
+#define BL_CNT_TOTAL (BL_CNT_COUNT + 13)
 
 struct BlGridDevice {
   const float *cells;        // [n_k][n_j][n_i][8]
@@ -277,8 +279,26 @@ struct BlTraceArgs {
   // of sample numbers, ray_offset counts segments, ray_rows[slot] = the ray's segments (bl_geodesic_kernel's emission loop)
   int segment_rows;
   int *ray_rows;
+  // Parked rays (Dormand-Prince, no sample times, no skipped shell; BL_SWITCH_QUAD_TAIL - a measured experiment, off by default).
+  // A ray advances one step per pass of its wave through ~6 000 instructions however few of the wave's lanes still hold one, so
+  // the last rays of a chunk - a wave with nothing left to refill its idle lanes from - set the kernel's time. Such a wave, once
+  // park_below or fewer of its lanes hold a ray, writes those rays to parked[] (BL_PARK_DOUBLES doubles each, below; BL_CNT_PARKED
+  // counts them) and ends; bl_geodesic_quad_kernel, launched behind it, finishes them with a ray per QUAD of lanes in two thirds
+  // of the instructions per step - the same operations on the same operands, so the same bits; slower all the same
+  // (bl_geodesic_quad.hip). park_always: every wave parks every ray it is handed before its first step (tests: the whole frame
+  // goes through the quad kernel). parked == nullptr: no ray is parked.
+  double *parked;
+  int park_capacity;
+  int park_below;
+  int park_after;    // ... or, however many lanes hold one, park_after passes of the wave after it first had nothing to refill a lane from
+  int park_always;
 };
 #define BL_RAY_START_FIELDS 17
+// A parked ray (BlTraceArgs::parked): everything bl_geodesic_kernel holds of a ray between two steps, BL_PARK_DOUBLES doubles
+//   0..7 the state t, x, y, z, k_x, k_y, k_z, s | 8..15 the first stage of the next step (FSAL) | 16 k_t | 17 the next step's
+//   length | 18 r at the state | 19 r of the last sample | 20 (chunk slot, samples so far) | 21 (retries, index of the
+//   truncating sample or -1) | 22 (segments so far, bit 0 previous step failed + bit 1 flagged) | 23 unused
+#define BL_PARK_DOUBLES 24
 
 // Kernel arguments: shading kernel
 // Polarized transfer (image_polarization): what the polarized transfer kernel needs of every sample besides the

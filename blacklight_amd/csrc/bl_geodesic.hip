@@ -10,35 +10,9 @@
 // geodesics.cpp:808-849); the coefficient kernels record the transfer coefficients per sample in the forward pass, which keeps
 // the recurrence the reference's while never materialising its per-sample arrays.
 #include "bl_kernel_util.h"
+#include "bl_geodesic_common.h"
 
 namespace {
-
-// Dormand-Prince RK5(4)7M tableau exactly as written in geodesics.cpp:42-72
-constexpr double kA[7][6] = {
-    {0.0, 0.0, 0.0, 0.0, 0.0, 0.0},
-    {1.0 / 5.0, 0.0, 0.0, 0.0, 0.0, 0.0},
-    {3.0 / 40.0, 9.0 / 40.0, 0.0, 0.0, 0.0, 0.0},
-    {44.0 / 45.0, -56.0 / 15.0, 32.0 / 9.0, 0.0, 0.0, 0.0},
-    {19372.0 / 6561.0, -25360.0 / 2187.0, 64448.0 / 6561.0, -212.0 / 729.0, 0.0, 0.0},
-    {9017.0 / 3168.0, -355.0 / 33.0, 46732.0 / 5247.0, 49.0 / 176.0, -5103.0 / 18656.0, 0.0},
-    {35.0 / 384.0, 0.0, 500.0 / 1113.0, 125.0 / 192.0, -2187.0 / 6784.0, 11.0 / 84.0}};
-constexpr double kB5[7] = {35.0 / 384.0, 0.0, 500.0 / 1113.0, 125.0 / 192.0, -2187.0 / 6784.0, 11.0 / 84.0, 0.0};
-constexpr double kB4[7] = {5179.0 / 57600.0, 0.0, 7571.0 / 16695.0, 393.0 / 640.0, -92097.0 / 339200.0,
-                           187.0 / 2100.0, 1.0 / 40.0};
-constexpr double kB4m[7] = {6025192743.0 / 30085553152.0, 0.0, 51252292925.0 / 65400821598.0,
-                            -2691868925.0 / 45128329728.0, 187940372067.0 / 1594534317056.0,
-                            -1776094331.0 / 19743644256.0, 11237099.0 / 235043384.0};
-constexpr double kD[7] = {-12715105075.0 / 11282082432.0, 0.0, 87487479700.0 / 32700410799.0,
-                          -10690763975.0 / 1880347072.0, 701980252875.0 / 199316789632.0,
-                          -1453857185.0 / 822651844.0, 69997945.0 / 29380423.0};
-
-// Mark the record slots [first, last) as dead (only the id word is written)
-__device__ __forceinline__ void retire_record_slots(BlSampleHot *records, int stride, long long first, long long last, int lane) {
-  for (long long at = first + lane; at < last; at += 64) {
-    records[at * stride].ray = BL_DEAD_RAY;
-    records[at * stride].n = 0u;
-  }
-}
 
 // State vector component order used in the geodesic kernel:
 //   0 t, 1 x, 2 y, 3 z, 4 k_x, 5 k_y, 6 k_z, 7 s      (k_t is constant along the ray: d k_t = 0)
@@ -145,6 +119,13 @@ __global__ void __launch_bounds__(256) bl_ray_init_kernel(BlTraceArgs P) {
 #ifndef BL_GEO_ONE_WAVE
 #define BL_GEO_ONE_WAVE(integrator, with_time, spin_zero) ((integrator) == BL_INTEGRATOR_DP && ((with_time) || !(spin_zero)))
 #endif
+// The lane's index recomputed on the spot (two instructions the optimiser cannot merge with another copy): where the index is
+// needed once in a while - a refill, a new block of slots - this costs less than a register that holds it through every step
+__device__ __forceinline__ int lane_here() {
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
 // A wave-uniform value the optimiser cannot see through (an empty instruction that claims to rewrite its scalar register)
 __device__ __forceinline__ int opaque_uniform(int v) {
   asm volatile("" : "+s"(v));
@@ -159,7 +140,6 @@ template <int kIntegrator, bool kTime, bool kSpinZero, bool kShell = false>
 // Two waves per SIMD: the benchmark's instantiation (Dormand-Prince, no sample times, zero spin) and the Runge-Kutta steppers
 // fit 256 registers; see BL_GEO_ONE_WAVE for the others.
 __global__ void __launch_bounds__(64, BL_GEO_ONE_WAVE(kIntegrator, kTime, kSpinZero) ? 1 : BL_GEO_WAVES) bl_geodesic_kernel(BlTraceArgs P) {
-  const int lane = wave_lane();
   const BlSpacetime st = P.st;
 
   bool have_ray = false;
@@ -180,6 +160,23 @@ __global__ void __launch_bounds__(64, BL_GEO_ONE_WAVE(kIntegrator, kTime, kSpinZ
   }
   s.kt = 0.0;
   long long block_next = 0, block_end = 0;   // this wave's block of record slots (wave-uniform)
+  // BlTraceArgs::parked as the loop reads it - from LDS: a scalar register held through the steps is one more spilled, and the
+  // benchmark's instantiation has no vector register left to spill it to. Words: [0] the buffer, [1] its capacity, [2] low half
+  // park_below (-1: no ray is parked, 64: every ray at once), high half park_after, [3] the passes this wave has made since it
+  // first found nothing to refill a lane from. Read through the LDS address space, volatile: a flat load would wait for the
+  // sample stores in flight (s_waitcnt vmcnt(0)) in every pass, which a wave alone on its SIMD cannot afford (an eighth of the
+  // benchmark frame: 4.1 -> 5.6 ms); a plain load would be hoisted into a register.
+  constexpr bool kPark = kIntegrator == BL_INTEGRATOR_DP && !kTime && !kShell;
+  __shared__ long long park_lds[4];
+  typedef volatile __attribute__((address_space(3))) long long *ParkWord;
+  const ParkWord park_word = (ParkWord)park_lds;
+  if (kPark && lane_here() == 0) {
+    park_lds[0] = reinterpret_cast<long long>(P.parked);
+    park_lds[1] = (long long)P.park_capacity;
+    const int below = P.parked == nullptr ? -1 : (P.park_always != 0 ? 64 : (P.park_below < 63 ? P.park_below : 63));
+    park_lds[2] = (long long)(((unsigned long long)(unsigned int)P.park_after << 32) | (unsigned long long)(unsigned int)below);
+    park_lds[3] = 0;
+  }
 #ifdef BL_GEO_STATS
   // per lane: step attempts, accepted steps, samples emitted; per wave (lane 0): loop iterations, emission iterations, refills,
   // lane-iterations with a ray
@@ -206,6 +203,7 @@ __global__ void __launch_bounds__(64, BL_GEO_ONE_WAVE(kIntegrator, kTime, kSpinZ
       const int leader = __ffsll((long long)need_mask) - 1;
       unsigned long long base = 0ull;
       int admitted = 0;
+      const int lane = lane_here();
       if (lane == leader) {
         const unsigned long long per_ray = (unsigned long long)P.ray_max_steps;
         const unsigned long long want = (unsigned long long)count * per_ray;
@@ -258,8 +256,49 @@ __global__ void __launch_bounds__(64, BL_GEO_ONE_WAVE(kIntegrator, kTime, kSpinZ
         }
       }
     }
+    // ------------------------------------------------------------------ park the last rays (BlTraceArgs::parked)
+    // A wave that has nothing left to refill its idle lanes from, and few lanes still holding a ray, hands those rays to
+    // bl_geodesic_quad_kernel as they stand between two steps and ends.
+    if (kPark) {
+      const long long word = park_word[2];
+      const int park_below = __builtin_amdgcn_readfirstlane((int)word), park_after = __builtin_amdgcn_readfirstlane((int)(word >> 32));
+      const unsigned long long holding = __ballot(have_ray);
+      bool park = park_below >= 64;
+      if (park_below >= 0 && !park && __ballot(exhausted) != 0ull) {
+        const int passes = __builtin_amdgcn_readfirstlane((int)park_word[3]);
+        park_word[3] = (long long)(passes + 1);   // (every lane writes the same number)
+        park = __popcll(holding) <= park_below || passes >= park_after;
+      }
+      if (park && holding != 0ull) {
+        double *const parked = reinterpret_cast<double *>(park_word[0]);
+        const long long park_capacity = park_word[1];
+        const int leader = __ffsll((long long)holding) - 1;
+        const int lane = lane_here();
+        unsigned long long base = 0ull;
+        if (lane == leader) base = atomicAdd(&P.counters[BL_CNT_PARKED], (unsigned long long)__popcll(holding));
+        base = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(base >> 32), leader) << 32)
+            | (unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)base, leader);
+        const long long at = (long long)base + __popcll(holding & ((1ull << lane) - 1ull));
+        if (have_ray && at < park_capacity) {
+          double *pk = parked + at * BL_PARK_DOUBLES;
+#pragma unroll
+          for (int p = 0; p < 8; p++) {
+            pk[p] = s.y[p];
+            pk[8 + p] = k0[p];
+          }
+          pk[16] = s.kt;
+          pk[17] = h_new;
+          pk[18] = r_cur;
+          pk[19] = r_prev_sample;
+          pk[20] = __longlong_as_double((long long)(((unsigned long long)(unsigned int)sample_num << 32) | (unsigned long long)slot));
+          pk[21] = __longlong_as_double((long long)(((unsigned long long)(unsigned int)trunc_at << 32) | (unsigned long long)(unsigned int)num_retry));
+          pk[22] = __longlong_as_double((long long)(((unsigned long long)((previous_fail ? 1u : 0u) | (flag ? 2u : 0u)) << 32) | (unsigned long long)(unsigned int)seg));
+          have_ray = false;
+        }
+      }
+    }
     if (__ballot(have_ray) == 0ull) {
-      retire_record_slots(P.records_hot, P.record_stride, block_next, block_end, lane);   // unused rest of the last block
+      retire_record_slots(P.records_hot, P.record_stride, block_next, block_end, lane_here());   // unused rest of the last block
       break;
     }
 #ifdef BL_GEO_STATS
@@ -357,10 +396,14 @@ __global__ void __launch_bounds__(64, BL_GEO_ONE_WAVE(kIntegrator, kTime, kSpinZ
           }
           r_new = r_stage;
 
+          // (one evaluation of error^-0.2 for the two places that use it, :200 and :214: a rejected step needs it when the error
+          // is finite - it is > 1 then -, an accepted one when the error is > 0 - it is finite then; the function is ~500
+          // instructions with its fallback, and the loop's code is what the instruction cache has to hold)
+          const double error_power = (error - error == 0.0 && error > 0.0) ? bl_pow_neg_fifth(error) : 0.0;
           if (!(error <= 1.0)) {   // :197-209
             double h_factor = 0.2;
             if (error - error == 0.0) {   // std::isfinite
-              double h_factor_ideal = 0.9 * bl_pow_neg_fifth(error);
+              double h_factor_ideal = 0.9 * error_power;
               h_factor = std_max(h_factor_ideal, 0.2);
             }
             h_new = h * h_factor;
@@ -369,7 +412,7 @@ __global__ void __launch_bounds__(64, BL_GEO_ONE_WAVE(kIntegrator, kTime, kSpinZ
           } else {                 // :210-224
             double h_factor = 10.0;
             if (error > 0.0) {
-              h_factor = 0.9 * bl_pow_neg_fifth(error);
+              h_factor = 0.9 * error_power;
               h_factor = std_max(h_factor, 0.2);
               h_factor = std_min(h_factor, 10.0);
             }
@@ -492,7 +535,7 @@ __global__ void __launch_bounds__(64, BL_GEO_ONE_WAVE(kIntegrator, kTime, kSpinZ
         old_room = (int)remaining;
         const unsigned long long grab = (unsigned long long)std_max_ll((long long)total - remaining, BL_RECORD_BLOCK);
         unsigned long long fetched = 0ull;
-        if (lane == 63) fetched = atomicAdd(&P.counters[BL_CNT_RECORDS], grab);
+        if (lane_here() == 63) fetched = atomicAdd(&P.counters[BL_CNT_RECORDS], grab);
         fetched = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(fetched >> 32), 63) << 32)
             | (unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)fetched, 63);
         new_base = (long long)fetched;
@@ -621,7 +664,7 @@ __global__ void __launch_bounds__(64, BL_GEO_ONE_WAVE(kIntegrator, kTime, kSpinZ
   atomicAdd(&P.counters[BL_CNT_DEBUG + 1], st_accept);
   atomicAdd(&P.counters[BL_CNT_DEBUG + 2], st_emit);
   atomicAdd(&P.counters[BL_CNT_DEBUG + 6], st_busy);
-  if (lane == 0) {
+  if (lane_here() == 0) {
     atomicAdd(&P.counters[BL_CNT_DEBUG + 3], st_iter);
     atomicAdd(&P.counters[BL_CNT_DEBUG + 4], st_emit_iter);
     atomicAdd(&P.counters[BL_CNT_DEBUG + 5], st_refill);

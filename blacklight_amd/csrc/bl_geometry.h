@@ -281,6 +281,52 @@ BL_HD double bl_renormalization_factor(const BlSpacetime &st, double x, double y
   return temp_b < 0.0 ? bl_div_g(temp_d - temp_b, 2.0 * temp_a) : bl_div_g(-2.0 * temp_c, temp_b + temp_d);
 }
 
+// d k_a / d lambda = -1/2 d_a g^{mu nu} k_mu k_nu from the derivatives along x^a, df = d_a f and dl[i] = d_a l_{i+1}:
+// k[4+a] -= 0.5 * dgcon[a-1][mu][nu] * y[4+mu] * y[4+nu], (mu, nu) row-major (geodesics.cpp:880-883), with
+// dgcon[a][mu][nu] = -(df_a l_mu l_nu + f dl_mu,a l_nu + f l_mu dl_nu,a) (geodesic_geometry.cpp:223-274)
+//   [0][0] = -df_a ; [0][j] = [j][0] = df_a l_j + f dl_j,a ; [i][j] as written.
+// (One function for the kernel with a ray per lane, which calls it three times, and the one with a ray per quad of lanes,
+// whose lanes call it once each: the same operations in the same order either way.)
+BL_HD double bl_momentum_rhs(double df, const double dl[3], double f, const double l[3], const double fl[3], const double kcov[4]) {
+  double dfl[3], fdl[3];
+  for (int i = 0; i < 3; i++) {
+    dfl[i] = df * l[i];
+    fdl[i] = f * dl[i];
+  }
+  // Every term of the reference's sum carries the factor 0.5 as its first multiplication. Scaling
+  // by a power of two commutes with rounding (nothing here is near the underflow threshold), so
+  // summing the unscaled terms in the same order and halving once gives the same bits.
+  double acc = 0.0;
+  acc -= (-df) * kcov[0] * kcov[0];
+  for (int j = 0; j < 3; j++) acc -= (dfl[j] + fdl[j]) * kcov[0] * kcov[j + 1];
+  for (int i = 0; i < 3; i++) {
+    acc -= (dfl[i] + fdl[i]) * kcov[i + 1] * kcov[0];
+    for (int j = 0; j < 3; j++) {
+      double dg = -(dfl[i] * l[j] + fdl[i] * l[j] + fl[i] * dl[j]);
+      acc -= dg * kcov[i + 1] * kcov[j + 1];
+    }
+  }
+  return 0.5 * acc;
+}
+
+// The proper-distance derivative (geodesics.cpp:884-891), in the two pieces the kernel with a ray per quad of lanes needs:
+//   temp_a[a] += (gcon[a][mu] - gcon[0][a] * gcon[0][mu] / gcon[0][0]) * y[4+mu] (:884-887), from row a of g^{ij}
+BL_HD double bl_distance_row(double g0a, const double gia[3], const double fl[3], double g00, const BlRecip &rc_g00, const double kcov[4]) {
+  double acc = (g0a - bl_div_r(g0a * g00, rc_g00)) * kcov[0];
+  for (int j = 0; j < 3; j++) acc += (gia[j] - bl_div_r(g0a * fl[j], rc_g00)) * kcov[j + 1];
+  return acc;
+}
+//   k[8] += gcov[a][b] * temp_a[a] * temp_a[b] (:888-891); gcov[i][j] = (f l_i) l_j (+1 diag); k[8] = -sqrt of this
+BL_HD double bl_distance_norm(const double fl[3], const double l[3], const double temp_a[3]) {
+  double acc = 0.0;
+  for (int a = 0; a < 3; a++)
+    for (int b = 0; b < 3; b++) {
+      double gab = a == b ? fl[a] * l[b] + 1.0 : fl[a] * l[b];
+      acc += gab * temp_a[a] * temp_a[b];
+    }
+  return acc;
+}
+
 // Right-hand side of the geodesic equations (geodesics.cpp:867-893 with distance, :909-925
 // without). State: pos = (x, y, z); kcov = (k_t, k_x, k_y, k_z).
 //   dpos[0..3] = d(t, x, y, z)/d lambda = g^{mu nu} k_nu
@@ -387,48 +433,16 @@ BL_HD void bl_geodesic_rhs(const BlSpacetime &st, const double pos[3], const dou
     dl[2][2] = mz_r2 * dr[2] + bl_div_r(1.0, rc.r);
   }
 
-  // k[4+a] -= 0.5 * dgcon[a-1][mu][nu] * y[4+mu] * y[4+nu], (mu, nu) row-major (:880-883), with
-  // dgcon[a][mu][nu] = -(df_a l_mu l_nu + f dl_mu,a l_nu + f l_mu dl_nu,a) (geodesic_geometry.cpp:223-274)
-  //   [0][0] = -df_a ; [0][j] = [j][0] = df_a l_j + f dl_j,a ; [i][j] as written.
   for (int a = 0; a < 3; a++) {
-    double dfl[3], fdl[3];
-    for (int i = 0; i < 3; i++) {
-      dfl[i] = df[a] * l[i];
-      fdl[i] = f * dl[i][a];
-    }
-    // Every term of the reference's sum carries the factor 0.5 as its first multiplication. Scaling
-    // by a power of two commutes with rounding (nothing here is near the underflow threshold), so
-    // summing the unscaled terms in the same order and halving once gives the same bits.
-    double acc = 0.0;
-    acc -= (-df[a]) * kcov[0] * kcov[0];
-    for (int j = 0; j < 3; j++) acc -= (dfl[j] + fdl[j]) * kcov[0] * kcov[j + 1];
-    for (int i = 0; i < 3; i++) {
-      acc -= (dfl[i] + fdl[i]) * kcov[i + 1] * kcov[0];
-      for (int j = 0; j < 3; j++) {
-        double dg = -(dfl[i] * l[j] + fdl[i] * l[j] + fl[i] * dl[j][a]);
-        acc -= dg * kcov[i + 1] * kcov[j + 1];
-      }
-    }
-    dk[a] = 0.5 * acc;
+    const double dla[3] = {dl[0][a], dl[1][a], dl[2][a]};
+    dk[a] = bl_momentum_rhs(df[a], dla, f, l, fl, kcov);
   }
 
   if (kWithDistance) {
-    // temp_a[a] += (gcon[a][mu] - gcon[0][a] * gcon[0][mu] / gcon[0][0]) * y[4+mu] (:884-887)
     double temp_a[3];
     const BlRecip rc_g00 = bl_recip(g00);   // twelve quotients over g^{00}
-    for (int a = 0; a < 3; a++) {
-      double g0a = fl[a];
-      double acc = (fl[a] - bl_div_r(g0a * g00, rc_g00)) * kcov[0];
-      for (int j = 0; j < 3; j++) acc += (gij[a][j] - bl_div_r(g0a * fl[j], rc_g00)) * kcov[j + 1];
-      temp_a[a] = acc;
-    }
-    // k[8] += gcov[a][b] * temp_a[a] * temp_a[b] (:888-891); gcov[i][j] = (f l_i) l_j (+1 diag)
-    double acc = 0.0;
-    for (int a = 0; a < 3; a++)
-      for (int b = 0; b < 3; b++) {
-        double gab = a == b ? fl[a] * l[b] + 1.0 : fl[a] * l[b];
-        acc += gab * temp_a[a] * temp_a[b];
-      }
+    for (int a = 0; a < 3; a++) temp_a[a] = bl_distance_row(fl[a], gij[a], fl, g00, rc_g00, kcov);
+    const double acc = bl_distance_norm(fl, l, temp_a);
     *ds = -bl_sqrt_g(acc);
   }
 }

@@ -150,6 +150,9 @@ struct RenderJob {
   bool composed = false;   // ... writing one affine transfer map per ray segment instead of one per sample (BlShadeArgs::composed)
   bool exact_fused = false;   // exact tier, the same grids, plain image at one frequency: bl_shade_exact2_kernel locates its samples itself
   bool locate_inside = false; // fused || exact_fused: no locate kernel, no located samples in HBM
+  bool park = false;          // the last rays of a chunk go to bl_geodesic_quad_kernel (BlTraceArgs::parked)
+  size_t park_capacity = 0;
+  int quad_grid = 0;          // waves of bl_geodesic_quad_kernel
   int n_nu = 0, n_q = 0, max_steps = 0;
   long long n_rays = 0, level_pixels = 0;
   size_t redo_capacity = 0;
@@ -179,7 +182,7 @@ struct RenderJob {
   // totals
   int n_chunks = 0;
   float ms_geo = 0.0f, ms_locate = 0.0f, ms_shade = 0.0f, ms_transfer = 0.0f;
-  unsigned long long total_samples = 0, total_flagged = 0, total_records = 0, total_gathers = 0, total_redo = 0, total_undefined = 0, max_num = 0;
+  unsigned long long total_samples = 0, total_flagged = 0, total_records = 0, total_gathers = 0, total_redo = 0, total_undefined = 0, total_parked = 0, max_num = 0;
   unsigned long long debug_counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   CheckpointSave save;
   // checkpoint_sample_save: where every kept sample of the level sits on the grid, by pixel and reversed sample index
@@ -308,6 +311,10 @@ void PlanJob(RenderJob &job) {
       && ctx->grid_outer_x1 < p.camera_r && !(ctx->switches & BL_SWITCH_RECORD_EVERY_STEP);
   // (the geodesic kernel's instantiation that skips the shell has no register to number segments with: per-sample records there)
   if (job.skip_shell) job.composed = false;
+  // On request (a measurement switch: it does not pay) the last rays of a chunk are finished with a ray per
+  // quad of lanes (Dormand-Prince stepper without sample times; the instantiation that skips the shell has no register for it)
+  job.park = p.ray_integrator == BL_INTEGRATOR_DP && !job.need_time && !job.skip_shell && !job.geo_load
+      && (ctx->switches & (BL_SWITCH_QUAD_TAIL | BL_SWITCH_QUAD_EVERY_RAY)) != 0;
   // ... and in the exact coefficient kernel (plain images): the frequency loop as lanes of bl_coefficients_freq_kernel
   job.coef_split = !job.fast && job.simulation && !job.aux && !ctx->polarized && job.n_nu >= 4;
   // (polarized runs list the samples without coefficients there - cut samples, cut cells - which are many more)
@@ -340,7 +347,8 @@ void PlanScratch(RenderJob &job) {
       + (job.matrix_transport ? BL_POL_MATRIX_DOUBLES * sizeof(double) : 0)
       + (job.block_interp ? 8 * sizeof(unsigned int) : 0);
   const uint64_t per_slot_fixed = ((job.fast || job.fast_formula || ctx->polarized) ? job.redo_capacity * sizeof(unsigned long long) : 0) + BL_CNT_TOTAL * sizeof(unsigned long long);
-  const uint64_t per_ray = (2 + (job.geo_load ? 0 : BL_RAY_START_FIELDS)) * sizeof(double) + (job.skip_shell ? 2 : 1) * sizeof(int) + 1 + 2 * sizeof(long long);
+  const bool park_every_ray = job.park && (ctx->switches & BL_SWITCH_QUAD_EVERY_RAY) != 0;
+  const uint64_t per_ray = (2 + (job.geo_load ? 0 : BL_RAY_START_FIELDS) + (park_every_ray ? BL_PARK_DOUBLES : 0)) * sizeof(double) + (job.skip_shell ? 2 : 1) * sizeof(int) + 1 + 2 * sizeof(long long);
   // The budget is capped by what the device can actually give: 90 % of (free memory + what this context already holds
   // from earlier renders).
   uint64_t budget = ctx->scratch_limit;
@@ -357,7 +365,9 @@ void PlanScratch(RenderJob &job) {
   // with fewer waves per SIMD each of them is faster - an eighth of the benchmark frame (131 072 rays) takes 4.3 ms on 1 024 waves,
   // 4.7 to 5.3 ms on 2 048 (and the coefficient kernel 5.0 instead of 5.2 ms over the more compact records)
   const long long max_grid = std::min<long long>(static_cast<long long>(ctx->num_cus) * waves_per_cu, std::max<long long>(1, (job.n_rays + 127) / 128));
-  const uint64_t worst_case = static_cast<uint64_t>(job.n_rays) * job.max_steps + static_cast<uint64_t>(max_grid) * BL_RECORD_BLOCK;
+  // (the waves of bl_geodesic_quad_kernel take blocks of record slots as well: a wave per SIMD)
+  const long long quad_waves = job.park ? static_cast<long long>(ctx->num_cus) * 4 : 0;
+  const uint64_t worst_case = static_cast<uint64_t>(job.n_rays) * job.max_steps + static_cast<uint64_t>(max_grid + quad_waves) * BL_RECORD_BLOCK;
   const uint64_t fixed = per_ray * static_cast<uint64_t>(job.n_rays);
   auto capacity_for = [&](int n_slots) -> uint64_t {
     const uint64_t overhead = fixed + n_slots * per_slot_fixed;
@@ -381,13 +391,16 @@ void PlanScratch(RenderJob &job) {
   // did not emit and the lanes that were refused ask again. Fewer waves than that would only trace the same rays more
   // slowly - 500 instead of 2 048 waves took the 64-frequency exact frame's geodesic stage from 37 to 183 ms.)
   const uint64_t per_wave = BL_RECORD_BLOCK + 64ull * static_cast<uint64_t>(job.max_steps);
-  const long long grid = std::max<long long>(1, std::min<long long>(max_grid, static_cast<long long>(capacity / per_wave)));
-  const long long gate = static_cast<long long>(capacity) - grid * BL_RECORD_BLOCK;
+  const long long grid = std::max<long long>(1, std::min<long long>(max_grid, static_cast<long long>((capacity - std::min<uint64_t>(capacity, static_cast<uint64_t>(quad_waves) * BL_RECORD_BLOCK)) / per_wave)));
+  const long long gate = static_cast<long long>(capacity) - (grid + quad_waves) * BL_RECORD_BLOCK;
   if (gate < job.max_steps)
     throw Failure{BL_E_ARG, "Scratch budget too small: the sample records of a single ray (ray_max_steps of them) do not fit (bl_set_scratch_limit)."};
   job.record_capacity = static_cast<size_t>(capacity);
   job.record_gate = gate;
   job.geo_grid = static_cast<int>(grid);
+  job.quad_grid = static_cast<int>(quad_waves);
+  // a lane parks at most one ray (its wave ends), unless every ray is parked
+  job.park_capacity = job.park ? (park_every_ray ? static_cast<size_t>(job.n_rays) : static_cast<size_t>(grid) * 64) : 0;
 }
 
 void EnsureScratch(RenderJob &job) {
@@ -409,6 +422,7 @@ void EnsureScratch(RenderJob &job) {
     if (job.freq_split) sl.d_freq_inputs.Ensure(cap);   // instead of the transfer records
     else sl.d_transfer.Ensure(cap * n_nu);
     if (job.composed) sl.d_composed.Ensure(cap);
+    if (job.park) sl.d_parked.Ensure(job.park_capacity * BL_PARK_DOUBLES);
     if (job.tau_row) sl.d_tau_inc.Ensure(cap * n_nu);
     sl.d_counters.Ensure(BL_CNT_TOTAL);
     if (job.aux) sl.d_aux.Ensure(cap);
@@ -927,6 +941,11 @@ void BindChunk(RenderJob &job, int k, long long begin, int rays) {
   ta.ray_skipped = job.skip_shell ? ctx->d_ray_skipped.ptr + begin : nullptr;
   ta.segment_rows = job.composed ? 1 : 0;
   ta.ray_rows = job.composed ? ctx->d_ray_rows.ptr + begin : nullptr;
+  ta.parked = job.park ? sl.d_parked.ptr : nullptr;
+  ta.park_capacity = static_cast<int>(std::min<size_t>(job.park_capacity, 0x7fffffff));
+  ta.park_below = ctx->park_below;
+  ta.park_after = ctx->park_after;
+  ta.park_always = (job.park && (ctx->switches & BL_SWITCH_QUAD_EVERY_RAY)) ? 1 : 0;
   ta.ray_flags = ctx->d_ray_flags.ptr + begin;
   ta.ray_out_index = ctx->d_ray_out_index.ptr + begin;
   ta.ray_offset = ctx->d_ray_offset.ptr + begin;
@@ -1310,6 +1329,8 @@ void LaunchGeodesicStage(RenderJob &job, int k, long long begin, int rays, hipSt
     job.in_flight[k].done = LoadChunkFromCheckpoint(job, k, begin, rays);
   } else {
     Check(bl_launch_geodesic(&job.ta, ctx->params.ray_integrator, std::min(job.geo_grid, (rays + 63) / 64), stream_geo), "geodesic kernel launch");
+    // the rays it parked, sixteen to a wave, a wave per SIMD (waves that find none end at once)
+    if (job.park) Check(bl_launch_geodesic_quad(&job.ta, job.quad_grid, stream_geo), "geodesic quad kernel launch");
   }
   Check(hipEventRecord(e[1], stream_geo), "event");
 }
@@ -1389,6 +1410,7 @@ void CollectChunk(RenderJob &job, int k) {
   job.total_undefined += hc[BL_CNT_UNDEFINED];
   job.total_records += hc[BL_CNT_RECORDS];
   job.total_gathers += hc[BL_CNT_GATHERS];
+  job.total_parked += std::min<unsigned long long>(hc[BL_CNT_PARKED], job.park_capacity);
   if (job.fast || job.fast_formula) job.total_redo += hc[BL_CNT_REDO];   // (polarized runs use the list for something else: bl_polarized_frame_kernel)
   job.total_samples += hc[BL_CNT_COUNT + 0];
   job.total_flagged += hc[BL_CNT_COUNT + 1];
@@ -1492,6 +1514,7 @@ void FinishStats(RenderJob &job) {
   st.n_undefined = static_cast<int64_t>(job.total_undefined);
   st.switches = ctx->switches;
   st.fused_variant = job.fused ? (job.fused2 ? 2 : 1) : (job.exact_fused ? 3 : 0);
+  st.n_parked = static_cast<int64_t>(job.total_parked);
   ctx->stats = st;
   if (ctx->debug_counters) {   // kernels built with -DBL_GEO_STATS fill these
     std::fprintf(stderr, "debug counters:");

@@ -288,6 +288,7 @@ typedef struct bl_stats {
   uint32_t switches;          /* BL_SWITCH_* bits active in this context (measurement switches, below); 0 in production  */
   int32_t fused_variant;      /* the locate step inside the coefficient kernel: 2 = bl_shade_fused2_kernel, 1 = bl_shade_fused_kernel
                                  (tolerant tier), 3 = bl_shade_exact2_kernel (exact tier), 0 = a locate kernel of its own ran  */
+  int64_t n_parked;           /* rays whose last steps ran with a ray per quad of lanes (bl_geodesic_quad_kernel)                 */
 } bl_stats;
 
 /* Measurement switches: environment variables BLACKLIGHT_AMD_<NAME>, read ONCE by bl_init (never during a render) and echoed in
@@ -303,6 +304,8 @@ typedef struct bl_stats {
 #define BL_SWITCH_GENERAL_FUSED (1u << 7)                   /* bl_shade_fused_kernel where bl_shade_fused2_kernel applies       */
 #define BL_SWITCH_SAMPLE_RECORDS (1u << 8)                  /* tolerant tier: one transfer record per sample where composed maps apply */
 #define BL_SWITCH_UNPIPELINED_SHADE (1u << 9)               /* bl_shade_kernel where bl_shade_exact_kernel applies              */
+#define BL_SWITCH_QUAD_TAIL (1u << 10)                      /* the last rays of a chunk finished by bl_geodesic_quad_kernel (a ray per quad of lanes) */
+#define BL_SWITCH_QUAD_EVERY_RAY (1u << 11)                 /* every ray parked before its first step: all stepping in bl_geodesic_quad_kernel */
 
 typedef struct bl_ctx bl_ctx;
 
