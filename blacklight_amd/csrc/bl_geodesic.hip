@@ -320,8 +320,11 @@ __global__ void __launch_bounds__(64, BL_GEO_ONE_WAVE(kIntegrator, kTime, kSpinZ
     // (dense-output coefficients of -0: a step that stores its one midpoint sample runs the interpolation formula of the
     // emission loop on them and gets that sample back bit for bit - every product and partial sum is -0, and x + (-0) = x
     // for every x, a zero of either sign included)
+    // (all of these are read only in lanes that have set them in this pass - the coefficients of a midpoint step are set where
+    // the step is accepted; the zeros are what a lane without a step holds: constants the compiler rematerialises, where values
+    // left over from the last pass would occupy their registers through the six stages)
     for (int p = 0; p < 8; p++) {
-      y5[p] = 0.0; k6[p] = 0.0; y4m[p] = 0.0; rv0[p] = -0.0; rv1[p] = -0.0; rv2[p] = -0.0; rv3[p] = -0.0;
+      y5[p] = 0.0; k6[p] = 0.0; y4m[p] = 0.0; rv0[p] = 0.0; rv1[p] = 0.0; rv2[p] = 0.0; rv3[p] = 0.0;
     }
 
     if (have_ray) {
@@ -452,6 +455,11 @@ __global__ void __launch_bounds__(64, BL_GEO_ONE_WAVE(kIntegrator, kTime, kSpinZ
                 for (int q = 0; q < 7; q++) acc += kD[q] * h * kk[q][p];
                 rv3[p] = acc;
               }
+            } else {
+#pragma unroll
+              for (int p = kTime ? 0 : 1; p < 7; p++) {
+                rv0[p] = -0.0; rv1[p] = -0.0; rv2[p] = -0.0; rv3[p] = -0.0;
+              }
             }
           }
         }
@@ -485,6 +493,9 @@ __global__ void __launch_bounds__(64, BL_GEO_ONE_WAVE(kIntegrator, kTime, kSpinZ
           for (int p = 0; p < 7; p++) y5[p] = yacc[p] + 1.0 / 2.0 * h * kv[p];
         }
         y5[7] = 0.0;
+        for (int p = 0; p < 7; p++) {
+          rv0[p] = -0.0; rv1[p] = -0.0; rv2[p] = -0.0; rv3[p] = -0.0;
+        }
         accepted = true;
         num_steps_ideal = 1;
         num_steps = 1;
