@@ -352,7 +352,8 @@ int bl_init(const bl_params *p, int device, bl_ctx **out) {
         {"BLACKLIGHT_AMD_GENERAL_LOCATE", BL_SWITCH_GENERAL_LOCATE}, {"BLACKLIGHT_AMD_LANE_TRANSFER", BL_SWITCH_LANE_TRANSFER},
         {"BLACKLIGHT_AMD_NO_FUSED_LOCATE", BL_SWITCH_NO_FUSED_LOCATE}, {"BLACKLIGHT_AMD_GENERAL_FUSED", BL_SWITCH_GENERAL_FUSED},
         {"BLACKLIGHT_AMD_SAMPLE_RECORDS", BL_SWITCH_SAMPLE_RECORDS}, {"BLACKLIGHT_AMD_UNPIPELINED_SHADE", BL_SWITCH_UNPIPELINED_SHADE},
-        {"BLACKLIGHT_AMD_QUAD_TAIL", BL_SWITCH_QUAD_TAIL}, {"BLACKLIGHT_AMD_QUAD_EVERY_RAY", BL_SWITCH_QUAD_EVERY_RAY}};
+        {"BLACKLIGHT_AMD_QUAD_TAIL", BL_SWITCH_QUAD_TAIL}, {"BLACKLIGHT_AMD_QUAD_EVERY_RAY", BL_SWITCH_QUAD_EVERY_RAY},
+        {"BLACKLIGHT_AMD_TAIL_OVERLAP", BL_SWITCH_TAIL_OVERLAP}};
     for (const auto &sw : kSwitches)
       if (std::getenv(sw.name) != nullptr) ctx->switches |= sw.bit;
     ctx->debug_counters = std::getenv("BLACKLIGHT_AMD_DEBUG_COUNTERS") != nullptr;

@@ -28,6 +28,7 @@
 extern "C" hipError_t bl_launch_ray_init(const BlTraceArgs *args, int integrator, hipStream_t stream);
 extern "C" hipError_t bl_launch_geodesic(const BlTraceArgs *args, int integrator, int grid, hipStream_t stream);
 extern "C" hipError_t bl_launch_geodesic_quad(const BlTraceArgs *args, int grid, hipStream_t stream);
+extern "C" hipError_t bl_launch_geodesic_resume(const BlTraceArgs *args, int grid, hipStream_t stream);
 extern "C" int bl_geodesic_occupancy(int integrator, int with_time, int spin_zero, int shell);
 extern "C" hipError_t bl_launch_locate(const BlShadeArgs *args, int grid, int lds_bytes, hipStream_t stream);
 extern "C" hipError_t bl_launch_shade(const BlShadeArgs *args, int model, int grid, hipStream_t stream);

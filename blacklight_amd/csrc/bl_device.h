@@ -82,8 +82,9 @@ enum BlCounter {
 };
 // per scratch set: the counters above, four transfer statistics, eight debug counters (kernels built with -DBL_GEO_STATS)
 #define BL_CNT_DEBUG (BL_CNT_COUNT + 4)
-#define BL_CNT_QUAD_NEXT (BL_CNT_COUNT + 12)   // work queue head of bl_geodesic_quad_kernel: parked rays handed out
-#define BL_CNT_TOTAL (BL_CNT_COUNT + 13)
+#define BL_CNT_QUAD_NEXT (BL_CNT_COUNT + 12)   // work queue head of the launch that finishes the parked rays: parked rays handed out
+#define BL_CNT_RECORDS_FIRST (BL_CNT_COUNT + 13)   // BL_CNT_RECORDS as the first geodesic launch of a chunk left it (BlShadeArgs::record_range)
+#define BL_CNT_TOTAL (BL_CNT_COUNT + 14)
 
 struct BlGridDevice {
   const float *cells;        // [n_k][n_j][n_i][8]
@@ -382,6 +383,12 @@ struct BlShadeArgs {
   int unpipelined_shade;      // ... the general exact coefficient kernel where the software-pipelined one applies
   int undefined_edge;         // bl_set_undefined_policy(BL_UNDEFINED_EDGE): samples where the reference reads past its arrays use the edge
   const unsigned long long *counters_in;
+  // Which records a coefficient kernel covers: 0 all of the chunk's, [0, BL_CNT_RECORDS); 1 those of the chunk's first geodesic
+  // launch, [0, BL_CNT_RECORDS_FIRST) - shaded while the launch that finishes the parked rays still runs; 2 the rest,
+  // [BL_CNT_RECORDS_FIRST, BL_CNT_RECORDS). (bl_shade_fused2_kernel, bl_shade_exact2_kernel, bl_shade_formula_fast_kernel,
+  // bl_shade_kernel; the boundary is a multiple of 64.) skip_redo: the launcher leaves the exact second pass to a later call.
+  int record_range;
+  int skip_redo;
   unsigned long long *counters;
   const double *ray_kt, *ray_factor;
   const long long *ray_offset;   // [chunk_rays]: sample n of ray q has row ray_offset[q] + n in transfer, aux, pol_samples, freq_inputs, ...

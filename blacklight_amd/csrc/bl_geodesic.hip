@@ -135,11 +135,17 @@ __device__ __forceinline__ double opaque_uniform(double v) {
   asm volatile("" : "+s"(v));
   return v;
 }
-template <int kIntegrator, bool kTime, bool kSpinZero, bool kShell = false>
+template <int kIntegrator, bool kTime, bool kSpinZero, bool kShell = false, bool kResume = false>
+// kResume: the launch that finishes the rays an earlier launch parked (BlTraceArgs::parked) - its lanes are refilled from the
+// parked rays, as they stood between two steps, instead of the chunk's queue; it parks nothing itself.
 // kShell: the instantiation that leaves no records of steps in the empty shell around the grid (BlTraceArgs::skip_low).
 // Two waves per SIMD: the benchmark's instantiation (Dormand-Prince, no sample times, zero spin) and the Runge-Kutta steppers
 // fit 256 registers; see BL_GEO_ONE_WAVE for the others.
 __global__ void __launch_bounds__(64, BL_GEO_ONE_WAVE(kIntegrator, kTime, kSpinZero) ? 1 : BL_GEO_WAVES) bl_geodesic_kernel(BlTraceArgs P) {
+  // The launch that finishes the parked rays runs beside the coefficient kernel (bl_render.hip: tail_overlap), and the frame waits
+  // for its longest ray: its waves go first when a SIMD's vector unit is asked for by two (an eighth of the benchmark frame: the
+  // geodesic stage took 5.7 ms beside the coefficient kernel at equal priority, 4.1 alone)
+  if (kResume) __builtin_amdgcn_s_setprio(3);
   const BlSpacetime st = P.st;
 
   bool have_ray = false;
@@ -166,7 +172,8 @@ __global__ void __launch_bounds__(64, BL_GEO_ONE_WAVE(kIntegrator, kTime, kSpinZ
   // first found nothing to refill a lane from. Read through the LDS address space, volatile: a flat load would wait for the
   // sample stores in flight (s_waitcnt vmcnt(0)) in every pass, which a wave alone on its SIMD cannot afford (an eighth of the
   // benchmark frame: 4.1 -> 5.6 ms); a plain load would be hoisted into a register.
-  constexpr bool kPark = kIntegrator == BL_INTEGRATOR_DP && !kTime && !kShell;
+  constexpr bool kPark = kIntegrator == BL_INTEGRATOR_DP && !kTime && !kShell && !kResume;
+  const long long n_parked = kResume ? (long long)(P.counters[BL_CNT_PARKED] < (unsigned long long)P.park_capacity ? P.counters[BL_CNT_PARKED] : (unsigned long long)P.park_capacity) : 0;
   __shared__ long long park_lds[4];
   typedef volatile __attribute__((address_space(3))) long long *ParkWord;
   const ParkWord park_word = (ParkWord)park_lds;
@@ -195,7 +202,43 @@ __global__ void __launch_bounds__(64, BL_GEO_ONE_WAVE(kIntegrator, kTime, kSpinZ
     // took (BL_CNT_NEXT_RAY < chunk_rays) are the next chunk's.
     bool need = !have_ray && !exhausted;
     unsigned long long need_mask = __ballot(need);
-    if (need_mask != 0ull) {
+    if (kResume && need_mask != 0ull) {
+      // the parked rays, in the order in which they were parked (bl_device.h: BL_PARK_DOUBLES)
+      const int leader = __ffsll((long long)need_mask) - 1;
+      const int lane = lane_here();
+      unsigned long long base = 0ull;
+      if (lane == leader) base = atomicAdd(&P.counters[BL_CNT_QUAD_NEXT], (unsigned long long)__popcll(need_mask));
+      base = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(base >> 32), leader) << 32)
+          | (unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)base, leader);
+      if (need) {
+        const long long at = (long long)base + __popcll(need_mask & ((1ull << lane) - 1ull));
+        if (at >= n_parked) {
+          exhausted = true;
+        } else {
+          have_ray = true;
+          const double *pk = P.parked + at * BL_PARK_DOUBLES;
+#pragma unroll
+          for (int p = 0; p < 8; p++) {
+            s.y[p] = pk[p];
+            k0[p] = pk[8 + p];
+          }
+          s.kt = pk[16];
+          h_new = pk[17];
+          r_cur = pk[18];
+          r_prev_sample = pk[19];
+          const long long w0 = __double_as_longlong(pk[20]), w1 = __double_as_longlong(pk[21]), w2 = __double_as_longlong(pk[22]);
+          slot = (unsigned int)w0;
+          sample_num = (int)(w0 >> 32);
+          num_retry = (int)(unsigned int)w1;
+          trunc_at = (int)(w1 >> 32);
+          seg = (int)(unsigned int)w2;
+          previous_fail = ((w2 >> 32) & 1) != 0;
+          flag = ((w2 >> 32) & 2) != 0;
+          skipped = 0;
+        }
+      }
+    }
+    if (!kResume && need_mask != 0ull) {
 #ifdef BL_GEO_STATS
       st_refill += 1;
 #endif
@@ -293,6 +336,9 @@ __global__ void __launch_bounds__(64, BL_GEO_ONE_WAVE(kIntegrator, kTime, kSpinZ
           pk[20] = __longlong_as_double((long long)(((unsigned long long)(unsigned int)sample_num << 32) | (unsigned long long)slot));
           pk[21] = __longlong_as_double((long long)(((unsigned long long)(unsigned int)trunc_at << 32) | (unsigned long long)(unsigned int)num_retry));
           pk[22] = __longlong_as_double((long long)(((unsigned long long)((previous_fail ? 1u : 0u) | (flag ? 2u : 0u)) << 32) | (unsigned long long)(unsigned int)seg));
+          // The rows of the ray's kept samples are set aside now - ray_max_steps of them, its reservation in BL_CNT_COMMITTED -
+          // so that the coefficient kernel can place the records the ray has left so far before the ray has ended.
+          P.ray_offset[slot] = (long long)atomicAdd(&P.counters[BL_CNT_SAMPLES], (unsigned long long)P.ray_max_steps);
           have_ray = false;
         }
       }
@@ -544,7 +590,9 @@ __global__ void __launch_bounds__(64, BL_GEO_ONE_WAVE(kIntegrator, kTime, kSpinZ
         block_next += total;
       } else {
         old_room = (int)remaining;
-        const unsigned long long grab = (unsigned long long)std_max_ll((long long)total - remaining, BL_RECORD_BLOCK);
+        // (whole multiples of 64: the number of records allocated so far - where a second pass of a coefficient kernel starts,
+        // BlShadeArgs::record_begin_counter - stays aligned with the groups of 16 that the composed maps are cut at)
+        const unsigned long long grab = ((unsigned long long)std_max_ll((long long)total - remaining, BL_RECORD_BLOCK) + 63ull) & ~63ull;
         unsigned long long fetched = 0ull;
         if (lane_here() == 63) fetched = atomicAdd(&P.counters[BL_CNT_RECORDS], grab);
         fetched = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(fetched >> 32), 63) << 32)
@@ -665,7 +713,7 @@ __global__ void __launch_bounds__(64, BL_GEO_ONE_WAVE(kIntegrator, kTime, kSpinZ
       // rows of the kept samples in the per-sample arrays, in the order in which rays finish; slots not emitted go back
       const int rows = (!kShell && P.segment_rows) ? seg : final_num;
       if (!kShell && P.segment_rows) P.ray_rows[slot] = rows;
-      P.ray_offset[slot] = (long long)atomicAdd(&P.counters[BL_CNT_SAMPLES], (unsigned long long)rows);
+      if (!kResume) P.ray_offset[slot] = (long long)atomicAdd(&P.counters[BL_CNT_SAMPLES], (unsigned long long)rows);   // (a parked ray has its rows)
       atomicAdd(&P.counters[BL_CNT_COMMITTED], (unsigned long long)(-(long long)(P.ray_max_steps - (sample_num - (kShell ? skipped : 0)))));
       have_ray = false;
     }
@@ -723,6 +771,15 @@ extern "C" hipError_t bl_launch_geodesic(const BlTraceArgs *args, int integrator
     default: BL_GEODESIC_CASES(BL_INTEGRATOR_RK2, BL_LAUNCH_G); break;
   }
 #undef BL_LAUNCH_G
+  return hipGetLastError();
+}
+
+// The rays the launch above parked (BlTraceArgs::parked; Dormand-Prince, no sample times, every step recorded), finished by
+// the same stepper: what bl_render.hip launches behind it when the coefficient kernel is to run beside the last rays of a chunk
+extern "C" hipError_t bl_launch_geodesic_resume(const BlTraceArgs *args, int grid, hipStream_t stream) {
+  if (args->parked == nullptr || args->sample_t != nullptr || args->ray_skipped != nullptr) return hipErrorInvalidValue;
+  if (args->st.bh_a == 0.0) hipLaunchKernelGGL((bl_geodesic_kernel<BL_INTEGRATOR_DP, false, true, false, true>), dim3(grid), dim3(64), 0, stream, *args);
+  else hipLaunchKernelGGL((bl_geodesic_kernel<BL_INTEGRATOR_DP, false, false, false, true>), dim3(grid), dim3(64), 0, stream, *args);
   return hipGetLastError();
 }
 

@@ -369,7 +369,7 @@ __global__ void __launch_bounds__(64, 2) bl_geodesic_quad_kernel(BlTraceArgs P) 
         block_next += total;
       } else {
         old_room = (int)remaining;
-        const unsigned long long grab = (unsigned long long)std_max_ll((long long)total - remaining, BL_RECORD_BLOCK);
+        const unsigned long long grab = ((unsigned long long)std_max_ll((long long)total - remaining, BL_RECORD_BLOCK) + 63ull) & ~63ull;
         unsigned long long fetched = 0ull;
         if (lane == 63) fetched = atomicAdd(&P.counters[BL_CNT_RECORDS], grab);
         fetched = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(fetched >> 32), 63) << 32)
@@ -451,7 +451,7 @@ __global__ void __launch_bounds__(64, 2) bl_geodesic_quad_kernel(BlTraceArgs P) 
         P.ray_flags[slot] = flag ? 1 : 0;
         const int rows = P.segment_rows ? seg : final_num;
         if (P.segment_rows) P.ray_rows[slot] = rows;
-        P.ray_offset[slot] = (long long)atomicAdd(&P.counters[BL_CNT_SAMPLES], (unsigned long long)rows);
+        // (the ray's rows were set aside when it was parked: ray_offset[slot])
         atomicAdd(&P.counters[BL_CNT_COMMITTED], (unsigned long long)(-(long long)(P.ray_max_steps - sample_num)));
       }
       have_ray = false;

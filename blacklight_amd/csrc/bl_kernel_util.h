@@ -43,6 +43,14 @@ __device__ __forceinline__ double std_min(double a, double b) { return (b < a) ?
 
 __device__ __forceinline__ int wave_lane() { return threadIdx.x & 63; }
 
+// The records a coefficient kernel covers (BlShadeArgs::record_range): [record_range_first, record_range_end)
+__device__ __forceinline__ unsigned long long record_range_first(const BlShadeArgs &P) {
+  return P.record_range == 2 ? P.counters_in[BL_CNT_RECORDS_FIRST] : 0ull;
+}
+__device__ __forceinline__ unsigned long long record_range_end(const BlShadeArgs &P) {
+  return P.record_range == 1 ? P.counters_in[BL_CNT_RECORDS_FIRST] : P.counters_in[BL_CNT_RECORDS];
+}
+
 // Wave-level scan / reduction with DPP row shifts and row broadcasts (VALU only: a ds_bpermute
 // shuffle costs an LDS round trip that nothing hides at one wave per SIMD).
 //   row_shr:n = 0x110 + n, row_bcast:15 = 0x142 (rows 1 and 3 take lane 15 of the row below),

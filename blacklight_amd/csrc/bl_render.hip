@@ -14,7 +14,7 @@
 namespace {
 
 // geodesic start / end, locate start, coefficient start, transfer start, end, counters copied to the host
-constexpr int kEventsPerChunk = 7;
+constexpr int kEventsPerChunk = 10;
 
 // RadiationIntegrator::Hypergeometric (simulation_coefficients.cpp:740-773): 2F1 for z < 0 through its Pfaff
 // transformation, ten terms of the series
@@ -150,7 +150,9 @@ struct RenderJob {
   bool composed = false;   // ... writing one affine transfer map per ray segment instead of one per sample (BlShadeArgs::composed)
   bool exact_fused = false;   // exact tier, the same grids, plain image at one frequency: bl_shade_exact2_kernel locates its samples itself
   bool locate_inside = false; // fused || exact_fused: no locate kernel, no located samples in HBM
-  bool park = false;          // the last rays of a chunk go to bl_geodesic_quad_kernel (BlTraceArgs::parked)
+  bool park = false;          // the last rays of a chunk go to bl_geodesic_quad_kernel (BlTraceArgs::parked): a measurement switch
+  bool tail_overlap = false;  // the last rays of a chunk are parked and finished by a second launch of the geodesic kernel, beside
+                              // which the coefficient kernel covers the records of the first (BlShadeArgs::record_range)
   size_t park_capacity = 0;
   int quad_grid = 0;          // waves of bl_geodesic_quad_kernel
   int n_nu = 0, n_q = 0, max_steps = 0;
@@ -313,8 +315,13 @@ void PlanJob(RenderJob &job) {
   if (job.skip_shell) job.composed = false;
   // On request (a measurement switch: it does not pay) the last rays of a chunk are finished with a ray per
   // quad of lanes (Dormand-Prince stepper without sample times; the instantiation that skips the shell has no register for it)
-  job.park = p.ray_integrator == BL_INTEGRATOR_DP && !job.need_time && !job.skip_shell && !job.geo_load
-      && (ctx->switches & (BL_SWITCH_QUAD_TAIL | BL_SWITCH_QUAD_EVERY_RAY)) != 0;
+  const bool parkable = p.ray_integrator == BL_INTEGRATOR_DP && !job.need_time && !job.skip_shell && !job.geo_load;
+  job.park = parkable && (ctx->switches & (BL_SWITCH_QUAD_TAIL | BL_SWITCH_QUAD_EVERY_RAY)) != 0;
+  // On request (a measurement switch: it does not pay either) the coefficient kernel runs beside the last rays
+  // of a chunk: plain images whose coefficient kernel takes a range of records
+  job.tail_overlap = parkable && !job.park && (ctx->switches & BL_SWITCH_TAIL_OVERLAP) != 0 && !job.aux && !ctx->polarized && !job.slow
+      && !job.block_interp && !job.tau_row && !job.freq_split && !job.geo_save && !job.sample_save && job.n_nu < 4
+      && (job.fused2 || job.exact_fused || !job.simulation);
   // ... and in the exact coefficient kernel (plain images): the frequency loop as lanes of bl_coefficients_freq_kernel
   job.coef_split = !job.fast && job.simulation && !job.aux && !ctx->polarized && job.n_nu >= 4;
   // (polarized runs list the samples without coefficients there - cut samples, cut cells - which are many more)
@@ -366,7 +373,7 @@ void PlanScratch(RenderJob &job) {
   // 4.7 to 5.3 ms on 2 048 (and the coefficient kernel 5.0 instead of 5.2 ms over the more compact records)
   const long long max_grid = std::min<long long>(static_cast<long long>(ctx->num_cus) * waves_per_cu, std::max<long long>(1, (job.n_rays + 127) / 128));
   // (the waves of bl_geodesic_quad_kernel take blocks of record slots as well: a wave per SIMD)
-  const long long quad_waves = job.park ? static_cast<long long>(ctx->num_cus) * 4 : 0;
+  const long long quad_waves = job.park ? static_cast<long long>(ctx->num_cus) * 4 : (job.tail_overlap ? max_grid : 0);
   const uint64_t worst_case = static_cast<uint64_t>(job.n_rays) * job.max_steps + static_cast<uint64_t>(max_grid + quad_waves) * BL_RECORD_BLOCK;
   const uint64_t fixed = per_ray * static_cast<uint64_t>(job.n_rays);
   auto capacity_for = [&](int n_slots) -> uint64_t {
@@ -399,8 +406,10 @@ void PlanScratch(RenderJob &job) {
   job.record_gate = gate;
   job.geo_grid = static_cast<int>(grid);
   job.quad_grid = static_cast<int>(quad_waves);
+  // (the last rays beside the coefficient kernel: one scratch set - with two, the next chunk's rays run there already)
+  if (job.n_slots != 1) job.tail_overlap = false;
   // a lane parks at most one ray (its wave ends), unless every ray is parked
-  job.park_capacity = job.park ? (park_every_ray ? static_cast<size_t>(job.n_rays) : static_cast<size_t>(grid) * 64) : 0;
+  job.park_capacity = (job.park || job.tail_overlap) ? (park_every_ray ? static_cast<size_t>(job.n_rays) : static_cast<size_t>(grid) * 64) : 0;
 }
 
 void EnsureScratch(RenderJob &job) {
@@ -422,7 +431,7 @@ void EnsureScratch(RenderJob &job) {
     if (job.freq_split) sl.d_freq_inputs.Ensure(cap);   // instead of the transfer records
     else sl.d_transfer.Ensure(cap * n_nu);
     if (job.composed) sl.d_composed.Ensure(cap);
-    if (job.park) sl.d_parked.Ensure(job.park_capacity * BL_PARK_DOUBLES);
+    if (job.park || job.tail_overlap) sl.d_parked.Ensure(job.park_capacity * BL_PARK_DOUBLES);
     if (job.tau_row) sl.d_tau_inc.Ensure(cap * n_nu);
     sl.d_counters.Ensure(BL_CNT_TOTAL);
     if (job.aux) sl.d_aux.Ensure(cap);
@@ -941,7 +950,7 @@ void BindChunk(RenderJob &job, int k, long long begin, int rays) {
   ta.ray_skipped = job.skip_shell ? ctx->d_ray_skipped.ptr + begin : nullptr;
   ta.segment_rows = job.composed ? 1 : 0;
   ta.ray_rows = job.composed ? ctx->d_ray_rows.ptr + begin : nullptr;
-  ta.parked = job.park ? sl.d_parked.ptr : nullptr;
+  ta.parked = (job.park || job.tail_overlap) ? sl.d_parked.ptr : nullptr;
   ta.park_capacity = static_cast<int>(std::min<size_t>(job.park_capacity, 0x7fffffff));
   ta.park_below = ctx->park_below;
   ta.park_after = ctx->park_after;
@@ -965,6 +974,8 @@ void BindChunk(RenderJob &job, int k, long long begin, int rays) {
   sa.transfer = sl.d_transfer.ptr;
   sa.composed = job.composed ? sl.d_composed.ptr : nullptr;
   sa.fused_variant = job.fused2 ? 1 : 0;
+  sa.record_range = 0;
+  sa.skip_redo = 0;
   sa.tau_inc = job.tau_row ? sl.d_tau_inc.ptr : nullptr;
   sa.aux = job.aux ? sl.d_aux.ptr : nullptr;
   sa.sample_t = ta.sample_t;
@@ -1331,6 +1342,14 @@ void LaunchGeodesicStage(RenderJob &job, int k, long long begin, int rays, hipSt
     Check(bl_launch_geodesic(&job.ta, ctx->params.ray_integrator, std::min(job.geo_grid, (rays + 63) / 64), stream_geo), "geodesic kernel launch");
     // the rays it parked, sixteen to a wave, a wave per SIMD (waves that find none end at once)
     if (job.park) Check(bl_launch_geodesic_quad(&job.ta, job.quad_grid, stream_geo), "geodesic quad kernel launch");
+    if (job.tail_overlap) {
+      // what the first launch left: the number of its records, for the coefficient kernel that starts now on the other stream;
+      // then the parked rays, by the same stepper
+      Check(hipMemcpyAsync(sl.d_counters.ptr + BL_CNT_RECORDS_FIRST, sl.d_counters.ptr + BL_CNT_RECORDS, sizeof(unsigned long long), hipMemcpyDeviceToDevice,
+                           stream_geo), "counter copy");
+      Check(hipEventRecord(e[7], stream_geo), "event");
+      Check(bl_launch_geodesic_resume(&job.ta, std::min(job.geo_grid, (rays + 63) / 64), stream_geo), "geodesic kernel launch");
+    }
   }
   Check(hipEventRecord(e[1], stream_geo), "event");
 }
@@ -1344,15 +1363,36 @@ void LaunchShadingStage(RenderJob &job, int k, bool geodesic_beside, hipStream_t
   BindChunk(job, k, job.in_flight[k].begin, job.in_flight[k].rays);
   BlShadeArgs &sa = job.sa;
   BlTransferArgs &xa = job.xa;
+  auto coefficient_kernel = [&]() {
+    if (job.fast) Check(bl_launch_shade_fast(&sa, job.shade_grid, stream), "coefficient kernel launch");
+    else if (job.fast_formula) Check(bl_launch_shade_formula_fast(&sa, ctx->num_cus * 4 * 4, stream), "coefficient kernel launch");
+    else if (job.exact_fused) Check(bl_launch_shade_exact2(&sa, job.shade_grid, stream), "coefficient kernel launch");
+    else Check(bl_launch_shade(&sa, p.model_type, job.shade_grid, stream), "coefficient kernel launch");
+  };
+  if (job.tail_overlap) {
+    // The records of the chunk's first geodesic launch while the second, which finishes the parked rays, runs on the other
+    // stream; then the records of the second and whatever the tolerant kernel left to the exact one in either pass.
+    Check(hipStreamWaitEvent(stream, e[7], 0), "stream wait");
+    Check(hipEventRecord(e[2], stream), "event");
+    Check(hipEventRecord(e[3], stream), "event");
+    sa.record_range = 1;
+    sa.skip_redo = 1;
+    coefficient_kernel();
+    Check(hipEventRecord(e[8], stream), "event");
+    Check(hipStreamWaitEvent(stream, e[1], 0), "stream wait");
+    Check(hipEventRecord(e[9], stream), "event");
+    sa.record_range = 2;
+    sa.skip_redo = 0;
+    coefficient_kernel();
+    sa.record_range = 0;
+  } else {
   Check(hipStreamWaitEvent(stream, e[1], 0), "stream wait");
   Check(hipEventRecord(e[2], stream), "event");
   if (job.simulation && !job.locate_inside)
     Check(bl_launch_locate(&sa, geodesic_beside ? job.locate_grid_shared : job.locate_grid_alone, ctx->lds_table_bytes, stream), "locate kernel launch");
   Check(hipEventRecord(e[3], stream), "event");
-  if (job.fast) Check(bl_launch_shade_fast(&sa, job.shade_grid, stream), "coefficient kernel launch");
-  else if (job.fast_formula) Check(bl_launch_shade_formula_fast(&sa, ctx->num_cus * 4 * 4, stream), "coefficient kernel launch");
-  else if (job.exact_fused) Check(bl_launch_shade_exact2(&sa, job.shade_grid, stream), "coefficient kernel launch");
-  else Check(bl_launch_shade(&sa, p.model_type, job.shade_grid, stream), "coefficient kernel launch");
+  coefficient_kernel();
+  }
   if (ctx->polarized) Check(bl_launch_polarized_coefficients(&sa, ctx->num_cus * 8, stream), "polarized coefficient kernel launch");
   if (job.coef_split) Check(bl_launch_coefficients_freq(&sa, ctx->num_cus * 16, stream), "per-frequency coefficient kernel launch");
   Check(hipEventRecord(e[4], stream), "event");
@@ -1392,7 +1432,25 @@ void CollectChunk(RenderJob &job, int k) {
   float ms = 0.0f;
   Check(hipEventElapsedTime(&ms, e[0], e[1]), "event time"); job.ms_geo += ms;
   Check(hipEventElapsedTime(&ms, e[2], e[3]), "event time"); job.ms_locate += ms;
-  Check(hipEventElapsedTime(&ms, e[3], e[4]), "event time"); job.ms_shade += ms;
+  if (job.tail_overlap && ctx->debug_counters) {
+    float a = 0, b = 0, c = 0, d = 0, f = 0;
+    (void)hipEventElapsedTime(&a, e[0], e[7]);
+    (void)hipEventElapsedTime(&b, e[7], e[1]);
+    (void)hipEventElapsedTime(&c, e[0], e[3]);
+    (void)hipEventElapsedTime(&d, e[0], e[8]);
+    (void)hipEventElapsedTime(&f, e[0], e[9]);
+    float g = 0, h = 0;
+    (void)hipEventElapsedTime(&g, e[0], e[4]);
+    (void)hipEventElapsedTime(&h, e[0], e[5]);
+    std::fprintf(stderr, "tail overlap: first launch %.2f ms, second +%.2f; pass A %.2f ... %.2f, pass B %.2f ... %.2f, transfer ... %.2f; parked %llu, records %llu of %llu\n", a, b, c, d, f, g, h,
+                 hc[BL_CNT_PARKED], hc[BL_CNT_RECORDS_FIRST], hc[BL_CNT_RECORDS]);
+  }
+  if (job.tail_overlap) {   // the two passes of the coefficient kernel, not the wait for the last rays between them
+    Check(hipEventElapsedTime(&ms, e[3], e[8]), "event time"); job.ms_shade += ms;
+    Check(hipEventElapsedTime(&ms, e[9], e[4]), "event time"); job.ms_shade += ms;
+  } else {
+    Check(hipEventElapsedTime(&ms, e[3], e[4]), "event time"); job.ms_shade += ms;
+  }
   Check(hipEventElapsedTime(&ms, e[4], e[5]), "event time"); job.ms_transfer += ms;
   fl.busy = false;
   if (fl.done < 0) fl.done = static_cast<long long>(std::min<unsigned long long>(hc[BL_CNT_NEXT_RAY], static_cast<unsigned long long>(fl.rays)));
@@ -1423,7 +1481,8 @@ void CollectChunk(RenderJob &job, int k) {
 void RunChunks(RenderJob &job) {
   bl_ctx *ctx = job.ctx;
   hipStream_t stream = ctx->stream;
-  hipStream_t stream_geo = job.n_slots == 2 ? ctx->stream_geo : stream;   // one scratch set: one stream, chunks back to back
+  // one scratch set: one stream, chunks back to back - unless the coefficient kernel is to run beside the last rays of a chunk
+  hipStream_t stream_geo = (job.n_slots == 2 || job.tail_overlap) ? ctx->stream_geo : stream;
   hipEvent_t ev_begin = ctx->events[2 * kEventsPerChunk], ev_end = ctx->events[2 * kEventsPerChunk + 1];
   Check(hipEventRecord(ev_begin, stream), "event");                // the uploads above were queued on `stream`
   if (stream_geo != stream) Check(hipStreamWaitEvent(stream_geo, ev_begin, 0), "stream wait");

@@ -181,7 +181,9 @@ __global__ void __launch_bounds__(256, 4) bl_locate_plain_kernel(const BlShadeAr
 template <int kModel, bool kAux, bool kExtended, bool kSksCurved, bool kPolarized, bool kSpinZero, bool kRedo = false>
 __global__ void __launch_bounds__(256, 2) bl_shade_kernel(const BlShadeArgs P) {
   const BlSpacetime st = P.st;
-  const unsigned long long n_all = P.counters_in[BL_CNT_RECORDS];
+  // (the second pass covers the whole list, or every record, whatever range the pass before it covered: BlShadeArgs::record_range)
+  const unsigned long long first_record = kRedo ? 0ull : record_range_first(P);
+  const unsigned long long n_all = (kRedo ? P.counters_in[BL_CNT_RECORDS] : record_range_end(P)) - first_record;
   const unsigned long long n_listed = kRedo ? P.counters_in[BL_CNT_REDO] : 0ull;
   const bool listed = kRedo && n_listed <= P.redo_capacity;
   const unsigned long long n_records = listed ? n_listed : n_all;   // work items: list entries or records
@@ -190,7 +192,7 @@ __global__ void __launch_bounds__(256, 2) bl_shade_kernel(const BlShadeArgs P) {
   // this sample's grid reads, so they arrive while the arithmetic runs.
   unsigned long long pos = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (pos >= n_records) return;
-  unsigned long long idx = listed ? P.redo_list[pos] : pos;
+  unsigned long long idx = listed ? P.redo_list[pos] : first_record + pos;
   double2 nq0, nq1, nq2, nq3, nl0 = make_double2(0.0, 0.0), nl1 = nl0;
   unsigned long long ntag = 0ull;
   {
@@ -263,7 +265,7 @@ __global__ void __launch_bounds__(256, 2) bl_shade_kernel(const BlShadeArgs P) {
     pos += stride;
     more = pos < n_records;
     if (more) {
-      idx = listed ? P.redo_list[pos] : pos;
+      idx = listed ? P.redo_list[pos] : first_record + pos;
       const double2 *hot = reinterpret_cast<const double2 *>(P.records_hot + (idx) * P.record_stride);
       const double2 *cold = reinterpret_cast<const double2 *>(P.records_cold + (idx) * P.record_stride);
       nq0 = hot[0]; nq1 = hot[1]; nq2 = cold[0]; nq3 = cold[1];

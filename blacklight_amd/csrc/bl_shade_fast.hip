@@ -547,11 +547,11 @@ __global__ void __launch_bounds__(256, 4) bl_shade_formula_fast_kernel(const BlS
   const BlFormulaDevice fm = P.formula;
   const double bh_m = P.st.bh_m, bh_a = P.st.bh_a, a2 = bh_a * bh_a;
   const bool flat = P.st.ray_flat != 0;
-  const unsigned long long n_records = P.counters_in[BL_CNT_RECORDS];
+  const unsigned long long n_records = record_range_end(P);
   const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
   const double r0_inv2 = 1.0 / (fm.r0 * fm.r0), h2 = fm.h * fm.h, nup_inv = 1.0 / fm.nup;
   const double band_lo = P.cuts.camera_r * (1.0 - 1.0e-9), band_hi = P.cuts.camera_r * (1.0 + 1.0e-9);
-  unsigned long long idx = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long idx = record_range_first(P) + (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
   bool more = idx < n_records;
   FastRay next;
   next.q0 = next.q1 = next.q2 = next.q3 = make_double2(0.0, 0.0);
@@ -654,6 +654,7 @@ extern "C" hipError_t bl_launch_shade_fused2(const BlShadeArgs *args, int grid, 
 // Tolerant tier in formula mode: the fast kernel, then the exact kernel over the records it deferred
 extern "C" hipError_t bl_launch_shade_formula_fast(const BlShadeArgs *args, int grid, hipStream_t stream) {
   hipLaunchKernelGGL(bl_shade_formula_fast_kernel, dim3(grid), dim3(256), 0, stream, *args);
+  if (args->skip_redo) return hipGetLastError();
   return bl_launch_shade_redo(args, BL_MODEL_FORMULA, grid, stream);
 }
 
@@ -662,7 +663,7 @@ extern "C" hipError_t bl_launch_shade_fast(const BlShadeArgs *args, int grid, hi
   const bool spin_zero = args->st.bh_a == 0.0;
   if (args->located == nullptr && args->fused_variant == 1) {   // the benchmark's case has a kernel of its own (bl_shade_fused.hip)
     const hipError_t err = bl_launch_shade_fused2(args, grid, stream);
-    if (err != hipSuccess) return err;
+    if (err != hipSuccess || args->skip_redo) return err;
     return bl_launch_shade_redo(args, BL_MODEL_SIMULATION, grid, stream);
   }
   if (args->located == nullptr) {   // no locate kernel ran: the fused kernel (coordinate tables in LDS behind its own table)

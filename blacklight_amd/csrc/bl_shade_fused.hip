@@ -591,8 +591,9 @@ __global__ void __launch_bounds__(256, BL_FAST_WAVES) bl_shade_fused2_kernel(con
     stage_axis_rows<true>(P.grid, reinterpret_cast<AxisRow *>(lds + 48));
   }
   __syncthreads();
-  const uint32_t n_records = (uint32_t)P.counters_in[BL_CNT_RECORDS];   // (a scratch set holds fewer than 2^32 records)
-  if (n_records == 0u) return;
+  const uint32_t n_records = (uint32_t)record_range_end(P);   // (a scratch set holds fewer than 2^32 records)
+  const uint32_t first_record = (uint32_t)record_range_first(P);   // (a multiple of 64: BlShadeArgs::record_range)
+  if (n_records <= first_record) return;
   const uint32_t stride = gridDim.x * blockDim.x;
   const uint32_t last = n_records - 1u;
   const BlSpacetime st = P.st;
@@ -618,7 +619,7 @@ __global__ void __launch_bounds__(256, BL_FAST_WAVES) bl_shade_fused2_kernel(con
   const char *records = reinterpret_cast<const char *>(P.records_hot);
   const uint32_t lane_index = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t lane_bytes = lane_index << 6;
-  uint32_t base_index = 0u;   // record index of lane 0 of block 0 for the sample `prev` ... (wave-uniform)
+  uint32_t base_index = first_record;   // record index of lane 0 of block 0 for the sample `prev` ... (wave-uniform)
   auto record_base = [&](uint32_t first) { return records + ((size_t)(first < last ? first : last) << 6); };
   double2 prev0 = make_double2(0.0, 0.0), prev1 = make_double2(0.0, __longlong_as_double((long long)BL_DEAD_RAY)), prev2 = prev0, prev3 = prev0;
   double2 cur0, cur1;
@@ -632,9 +633,9 @@ __global__ void __launch_bounds__(256, BL_FAST_WAVES) bl_shade_fused2_kernel(con
 #pragma unroll
   for (int c = 0; c < 8; c++) lo[c] = hi[c] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   // (32-bit record indices: the launcher keeps n_records + 3 strides below 2^32)
-  bool cur_in = lane_index < n_records;
+  bool cur_in = first_record + lane_index < n_records;
   {
-    const double2 *rec = reinterpret_cast<const double2 *>(record_base(0u) + (size_t)(cur_in ? lane_bytes : 0u));
+    const double2 *rec = reinterpret_cast<const double2 *>(record_base(first_record) + (size_t)(cur_in ? lane_bytes : 0u));
     cur0 = rec[0];
     cur1 = rec[1];
     cur1.y = cur_in ? cur1.y : __longlong_as_double((long long)BL_DEAD_RAY);
@@ -858,8 +859,9 @@ __global__ void __launch_bounds__(256, 2) bl_shade_exact2_kernel(const BlShadeAr
   const uint32_t lds_base = lds_address(lds);
   stage_axis_rows<false>(P.grid, reinterpret_cast<AxisRow *>(lds));
   __syncthreads();
-  const uint32_t n_records = (uint32_t)P.counters_in[BL_CNT_RECORDS];
-  if (n_records == 0u) return;
+  const uint32_t n_records = (uint32_t)record_range_end(P);
+  const uint32_t first_record = (uint32_t)record_range_first(P);
+  if (n_records <= first_record) return;
   const uint32_t stride = gridDim.x * blockDim.x;
   const uint32_t last = n_records - 1u;
   const BlSpacetime st = P.st;
@@ -875,7 +877,7 @@ __global__ void __launch_bounds__(256, 2) bl_shade_exact2_kernel(const BlShadeAr
   const char *records = reinterpret_cast<const char *>(P.records_hot);
   const uint32_t lane_index = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t lane_bytes = lane_index << 6;
-  uint32_t base_index = 0u;
+  uint32_t base_index = first_record;
   auto record_base = [&](uint32_t first) { return records + ((size_t)(first < last ? first : last) << 6); };
   double2 prev0 = make_double2(0.0, 0.0), prev1 = make_double2(0.0, __longlong_as_double((long long)BL_DEAD_RAY)), prev2 = prev0, prev3 = prev0;
   double2 cur0, cur1;
@@ -888,9 +890,9 @@ __global__ void __launch_bounds__(256, 2) bl_shade_exact2_kernel(const BlShadeAr
   float4 lo[8], hi[8];
 #pragma unroll
   for (int c = 0; c < 8; c++) lo[c] = hi[c] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-  bool cur_in = lane_index < n_records;
+  bool cur_in = first_record + lane_index < n_records;
   {
-    const double2 *rec = reinterpret_cast<const double2 *>(record_base(0u) + (size_t)(cur_in ? lane_bytes : 0u));
+    const double2 *rec = reinterpret_cast<const double2 *>(record_base(first_record) + (size_t)(cur_in ? lane_bytes : 0u));
     cur0 = rec[0];
     cur1 = rec[1];
     cur1.y = cur_in ? cur1.y : __longlong_as_double((long long)BL_DEAD_RAY);

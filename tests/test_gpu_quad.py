@@ -96,3 +96,69 @@ def test_the_last_rays_of_a_frame_are_parked():
         out = _three_ways(ctx)
     _assert_same_frames(out, "exact", "formula_dp at 96^2")
     assert 0 < out["tail"]["stats"].n_parked < out["tail"]["stats"].n_rays
+
+
+# ---- the coefficient kernel beside the last rays of a chunk (BL_SWITCH_TAIL_OVERLAP; bl_render.hip: tail_overlap)
+
+def _overlap_on_off(ctx, extra=()):
+    out = {}
+    for name, switches in (("off", ()), ("on", ("TAIL_OVERLAP",))):
+        ctx.debug_set_switches(*switches, *extra)
+        out[name] = ctx.render()
+    ctx.debug_set_switches()
+    return out
+
+
+def _assert_overlap_equal(out, tier, what, expect_parked=True):
+    off, on = out["off"], out["on"]
+    assert off["stats"].n_parked == 0
+    if expect_parked:
+        assert 0 < on["stats"].n_parked <= on["stats"].n_rays, what
+    assert np.array_equal(on["sample_num"], off["sample_num"]) and np.array_equal(on["sample_flags"], off["sample_flags"]), what
+    assert on["stats"].n_samples == off["stats"].n_samples and on["stats"].n_gathers == off["stats"].n_gathers, what
+    assert on["stats"].n_deferred == off["stats"].n_deferred, what
+    if tier == "exact":
+        assert gu.same_bits(on["image"], off["image"]).all(), what
+    else:
+        assert np.array_equal(np.isnan(on["image"]), np.isnan(off["image"])), what
+        with np.errstate(invalid="ignore"):
+            assert np.nanmax(np.abs(on["image"] - off["image"])) <= 1.0e-13 * np.nanmax(np.abs(off["image"])), what
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_formula_frames_with_the_coefficient_kernel_beside_the_last_rays(seed):
+    import blacklight_amd as bl
+    rng = np.random.default_rng(7300 + seed)
+    fx, params, _ = gu.load_case("formula_dp")
+    over = dict(camera_resolution=int(rng.choice([48, 96])), camera_r=float(rng.uniform(60.0, 1000.0)), camera_th=float(rng.uniform(5.0, 175.0)),
+                camera_width=float(rng.uniform(12.0, 40.0)), formula_spin=float([0.0, 0.9, 0.5, 0.99][seed]),
+                ray_max_steps=int(rng.choice([2500, 7000])))
+    p = bl.Params.from_dict(dict(params, **over))
+    with bl.Context(p) as ctx:
+        for tier in ("exact", "tolerant"):
+            ctx.set_arithmetic(tier)
+            out = _overlap_on_off(ctx)
+            _assert_overlap_equal(out, tier, over)
+            assert np.isfinite(out["off"]["image"]).any(), over
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_simulation_frames_with_the_coefficient_kernel_beside_the_last_rays(seed):
+    """The benchmark's kernels (bl_shade_fused2_kernel with composed maps, bl_shade_exact2_kernel) over a range of records"""
+    import blacklight_amd as bl
+    from blacklight_amd import mock
+    rng = np.random.default_rng(7400 + seed)
+    fx, params, mock_args = gu.load_case("sim_dp_interp")
+    over = dict(camera_resolution=int(rng.choice([64, 128])), camera_r=float(rng.uniform(60.0, 300.0)), camera_th=float(rng.uniform(10.0, 170.0)),
+                camera_ph=float(rng.uniform(0.0, 360.0)), camera_width=float(rng.uniform(20.0, 60.0)), simulation_a=0.0 if seed % 2 == 0 else 0.9,
+                ray_integrator="dp", fallback_nan="false", fallback_rho=1.0e-6, fallback_pgas=1.0e-8)
+    p = bl.Params.from_dict(dict(params, **over))
+    grid = mock.generate(n_r=32, n_th=32, n_ph=32) if seed < 2 else gu.golden_grid(mock_args)
+    with bl.Context(p) as ctx:
+        ctx.set_grid(grid)
+        for tier in ("exact", "tolerant"):
+            ctx.set_arithmetic(tier)
+            out = _overlap_on_off(ctx, extra=("RECORD_EVERY_STEP",))
+            _assert_overlap_equal(out, tier, over)
+            if seed < 2:
+                assert out["on"]["stats"].fused_variant == (3 if tier == "exact" else 2), out["on"]["stats"].fused_variant

@@ -13,10 +13,12 @@ RESOURCES = [os.path.join(bl_build.OBJ, name + ".resources.txt")
 
 # mangled name -> (waves per SIMD, largest scratch in bytes per lane)
 BENCHMARK_KERNELS = {
-    "_Z18bl_geodesic_kernelILi0ELb0ELb1ELb0EEv11BlTraceArgs": (2, 0),      # Dormand-Prince, no sample times, zero spin
-    "_Z18bl_geodesic_kernelILi0ELb0ELb0ELb0EEv11BlTraceArgs": (1, 0),      # ... any spin: one wave, accumulation registers behind it
-    "_Z18bl_geodesic_kernelILi0ELb0ELb1ELb1EEv11BlTraceArgs": (2, 0),    # ... leaving no records of the empty shell around the grid
-    "_Z18bl_geodesic_kernelILi0ELb0ELb0ELb1EEv11BlTraceArgs": (1, 0),
+    "_Z18bl_geodesic_kernelILi0ELb0ELb1ELb0ELb0EEv11BlTraceArgs": (2, 0),      # Dormand-Prince, no sample times, zero spin
+    "_Z18bl_geodesic_kernelILi0ELb0ELb0ELb0ELb0EEv11BlTraceArgs": (1, 0),      # ... any spin: one wave, accumulation registers behind it
+    "_Z18bl_geodesic_kernelILi0ELb0ELb1ELb1ELb0EEv11BlTraceArgs": (2, 0),    # ... leaving no records of the empty shell around the grid
+    "_Z18bl_geodesic_kernelILi0ELb0ELb0ELb1ELb0EEv11BlTraceArgs": (1, 0),
+    "_Z18bl_geodesic_kernelILi0ELb0ELb1ELb0ELb1EEv11BlTraceArgs": (2, 0),    # ... finishing parked rays (BL_SWITCH_TAIL_OVERLAP: a measured experiment)
+    "_Z18bl_geodesic_kernelILi0ELb0ELb0ELb0ELb1EEv11BlTraceArgs": (1, 0),
     "_Z23bl_geodesic_quad_kernelILb1EEv11BlTraceArgs": (2, 0),             # a ray per quad of lanes (BL_SWITCH_QUAD_TAIL: a measured experiment)
     "_Z23bl_geodesic_quad_kernelILb0EEv11BlTraceArgs": (2, 0),
     "_Z16bl_locate_kernelILb0ELb0ELb1ELb0EEv11BlShadeArgs": (4, 0),          # merged grid, no slow light, zero spin (at least 4)

@@ -1,6 +1,7 @@
 #!/bin/bash
 # The quad tail (bl_geodesic_quad_kernel) measured on one box: configuration 2, the benchmark frame and the emulated eight-rank
-# share - without it, with it (BLACKLIGHT_AMD_QUAD_TAIL), and for every library under variants/*.so.
+# share - as shipped, with the quad tail (BLACKLIGHT_AMD_QUAD_TAIL), with the coefficient kernel beside the last rays
+# (BLACKLIGHT_AMD_TAIL_OVERLAP), and for every library under variants/*.so.
 #   gpurun -- 'bash tools/gpu_quad_tail.sh [ENV=VALUE ...]'      e.g. BLACKLIGHT_AMD_PARK_BELOW=32 AFTER="0 8 32" (values of BLACKLIGHT_AMD_PARK_AFTER)
 set -eu
 : "${GRAFT_REPO_ROOT:?run through gpurun}"
@@ -33,7 +34,8 @@ all() {
 }
 all "no-tail"
 for after in ${AFTER:-32}; do
-  BLACKLIGHT_AMD_QUAD_TAIL=1 BLACKLIGHT_AMD_PARK_AFTER=$after all "tail after=$after"
+  BLACKLIGHT_AMD_QUAD_TAIL=1 BLACKLIGHT_AMD_PARK_AFTER=$after all "quad tail after=$after"
+  BLACKLIGHT_AMD_TAIL_OVERLAP=1 BLACKLIGHT_AMD_PARK_AFTER=$after all "overlap after=$after"
 done
 for lib in variants/*.so; do
   [ -e "$lib" ] || continue
