@@ -702,8 +702,17 @@ __global__ void __launch_bounds__(256, BL_FAST_WAVES) bl_shade_fused2_kernel(con
       const uint32_t key_lo = ray, key_hi = n;
       const uint32_t below_lo = (uint32_t)BL_DPP((int)~key_lo, (int)key_lo, 0x111, 0xf), below_hi = (uint32_t)BL_DPP((int)key_hi, (int)key_hi, 0x111, 0xf);
       const unsigned long long first = __ballot(below_lo != key_lo || below_hi != key_hi) | 0x0001000100010001ull;
-      const bool expand = __any(live && (defer || BL_IS_AFFINE_THICK(rec.x)));
-      if (__builtin_expect(!expand, 1)) {
+      // Rows of 16 lanes that hold a sample for the exact kernel or an optically thick step keep their samples' own records
+      // (below); the other rows of the wave compose. (By the wave it was 14 % of the samples of the benchmark frame - one
+      // deferred sample in 300 - by the row it is 5 %.)
+      const unsigned long long needs_records = __ballot(live && (defer || BL_IS_AFFINE_THICK(rec.x)));
+      bool expand = false;
+      if (__builtin_expect(needs_records != 0ull, 0)) {
+        unsigned long long m = needs_records;
+        m |= m >> 1; m |= m >> 2; m |= m >> 4; m |= m >> 8;   // bit 0 of every row: any lane of the row
+        expand = __builtin_amdgcn_inverse_ballot_w64((m & 0x0001000100010001ull) * 0xffffull);
+      }
+      if (!expand) {
         // inclusive scan of the maps over the lanes of a segment, nearer sample first: (a', c') o (a, c) = (a' a, a' c + c').
         // Whether the lane d below belongs to the same segment is a matter of where segments begin: scalar masks.
         const unsigned long long g2 = first | (first << 1), g4 = g2 | (g2 << 2), g8 = g4 | (g4 << 4);
@@ -726,7 +735,7 @@ __global__ void __launch_bounds__(256, BL_FAST_WAVES) bl_shade_fused2_kernel(con
         const unsigned long long last_lanes = (first >> 1) | 0x8000800080008000ull;
         if (__builtin_amdgcn_inverse_ballot_w64(last_lanes) && live) P.composed[(size_t)(row_first + (long long)n)] = make_double2(a, c);
       } else {
-        // a wave with a sample for the exact kernel or a thick step: its samples' own records, by record index, and rows that say so
+        // a row with a sample for the exact kernel or a thick step: its samples' own records, by record index, and rows that say so
         const uint32_t record = base_index - stride + lane_index;
         if (live && !defer) P.transfer[record] = rec;
         const unsigned long long last_lanes = (first >> 1) | 0x8000800080008000ull;
