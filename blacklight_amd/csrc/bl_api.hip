@@ -353,12 +353,15 @@ int bl_init(const bl_params *p, int device, bl_ctx **out) {
         {"BLACKLIGHT_AMD_NO_FUSED_LOCATE", BL_SWITCH_NO_FUSED_LOCATE}, {"BLACKLIGHT_AMD_GENERAL_FUSED", BL_SWITCH_GENERAL_FUSED},
         {"BLACKLIGHT_AMD_SAMPLE_RECORDS", BL_SWITCH_SAMPLE_RECORDS}, {"BLACKLIGHT_AMD_UNPIPELINED_SHADE", BL_SWITCH_UNPIPELINED_SHADE},
         {"BLACKLIGHT_AMD_QUAD_TAIL", BL_SWITCH_QUAD_TAIL}, {"BLACKLIGHT_AMD_QUAD_EVERY_RAY", BL_SWITCH_QUAD_EVERY_RAY},
-        {"BLACKLIGHT_AMD_TAIL_OVERLAP", BL_SWITCH_TAIL_OVERLAP}};
+        {"BLACKLIGHT_AMD_TAIL_OVERLAP", BL_SWITCH_TAIL_OVERLAP}, {"BLACKLIGHT_AMD_TAIL_REPACKED", BL_SWITCH_TAIL_REPACKED}};
     for (const auto &sw : kSwitches)
       if (std::getenv(sw.name) != nullptr) ctx->switches |= sw.bit;
     ctx->debug_counters = std::getenv("BLACKLIGHT_AMD_DEBUG_COUNTERS") != nullptr;
     if (const char *below = std::getenv("BLACKLIGHT_AMD_PARK_BELOW")) ctx->park_below = std::max(0, std::min(64, std::atoi(below)));
     if (const char *after = std::getenv("BLACKLIGHT_AMD_PARK_AFTER")) ctx->park_after = std::max(0, std::atoi(after));
+    if (const char *quiet = std::getenv("BLACKLIGHT_AMD_PARK_QUIET")) ctx->park_quiet = std::max(1, std::atoi(quiet));
+    if (const char *age = std::getenv("BLACKLIGHT_AMD_PARK_AGE")) ctx->park_age = std::max(0, std::atoi(age));
+    if (const char *waves = std::getenv("BLACKLIGHT_AMD_QUAD_WAVES")) ctx->quad_waves_per_simd = std::max(1, std::min(3, std::atoi(waves)));
   }
   try {
     ValidateGeodesic(ctx);

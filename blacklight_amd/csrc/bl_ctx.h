@@ -129,7 +129,10 @@ struct bl_ctx {
   bool kappa_warned = false;
   bool debug_counters = false;        // BLACKLIGHT_AMD_DEBUG_COUNTERS (bl_init): print the -DBL_GEO_STATS counters after a render
   unsigned int switches = 0;          // BL_SWITCH_* (include/blacklight_amd.h): the environment as bl_init found it, never read again
-  int park_below = 32, park_after = 32;   // BlTraceArgs::park_below, ::park_after (BLACKLIGHT_AMD_PARK_BELOW, _PARK_AFTER in bl_init's environment: measurement knobs)
+  int quad_waves_per_simd = 1;        // waves of bl_geodesic_quad_kernel per SIMD (BLACKLIGHT_AMD_QUAD_WAVES: a measurement knob)
+  int park_age = -1;                  // BlTraceArgs::park_age; -1: an eighth of ray_max_steps (BLACKLIGHT_AMD_PARK_AGE)
+  int park_quiet = 1 << 30;           // BlTraceArgs::park_quiet (BLACKLIGHT_AMD_PARK_QUIET)
+  int park_below = 0, park_after = 0; // BlTraceArgs::park_below, ::park_after (BLACKLIGHT_AMD_PARK_BELOW, _PARK_AFTER): every wave parks its rays once the queue is dry   // BlTraceArgs::park_below, ::park_after (BLACKLIGHT_AMD_PARK_BELOW, _PARK_AFTER in bl_init's environment: measurement knobs)
   double guard_band = 1.0e-9;         // tolerant tier: relative half-width around a cut threshold left to the exact kernel
 
   // image rows (radiation_integrator.cpp:436-520)

@@ -84,7 +84,8 @@ enum BlCounter {
 #define BL_CNT_DEBUG (BL_CNT_COUNT + 4)
 #define BL_CNT_QUAD_NEXT (BL_CNT_COUNT + 12)   // work queue head of the launch that finishes the parked rays: parked rays handed out
 #define BL_CNT_RECORDS_FIRST (BL_CNT_COUNT + 13)   // BL_CNT_RECORDS as the first geodesic launch of a chunk left it (BlShadeArgs::record_range)
-#define BL_CNT_TOTAL (BL_CNT_COUNT + 14)
+#define BL_CNT_PARKED_YOUNG (BL_CNT_COUNT + 14)   // parked rays with fewer than BlTraceArgs::park_age samples so far (BL_CNT_PARKED: the others)
+#define BL_CNT_TOTAL (BL_CNT_COUNT + 15)
 
 struct BlGridDevice {
   const float *cells;        // [n_k][n_j][n_i][8]
@@ -285,13 +286,19 @@ struct BlTraceArgs {
   // the last rays of a chunk - a wave with nothing left to refill its idle lanes from - set the kernel's time. Such a wave, once
   // park_below or fewer of its lanes hold a ray, writes those rays to parked[] (BL_PARK_DOUBLES doubles each, below; BL_CNT_PARKED
   // counts them) and ends; bl_geodesic_quad_kernel, launched behind it, finishes them with a ray per QUAD of lanes in two thirds
-  // of the instructions per step - the same operations on the same operands, so the same bits; slower all the same
-  // (bl_geodesic_quad.hip). park_always: every wave parks every ray it is handed before its first step (tests: the whole frame
+  // of the instructions per step - the same operations on the same operands, so the same bits (bl_geodesic_quad.hip: what it
+  // gains and costs). park_always: every wave parks every ray it is handed before its first step (tests: the whole frame
   // goes through the quad kernel). parked == nullptr: no ray is parked.
   double *parked;
   int park_capacity;
   int park_below;
   int park_after;    // ... or, however many lanes hold one, park_after passes of the wave after it first had nothing to refill a lane from
+  // Parked rays are taken up again oldest first: those with park_age samples or more fill parked[] from the front (BL_CNT_PARKED),
+  // the others from the back (BL_CNT_PARKED_YOUNG) - a ray that is long so far is likely to be long, and the launch that finishes
+  // them ends with its longest ray, which should not be the last to get a quad.
+  int park_quiet;    // ... or park_quiet passes without a ray of the wave finishing (its rays are long ones)
+  int park_age;
+  int quad_first_round;   // bl_geodesic_quad_kernel: its first this many waves (one per SIMD) run at raised priority
   int park_always;
 };
 #define BL_RAY_START_FIELDS 17

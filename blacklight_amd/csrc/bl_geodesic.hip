@@ -169,12 +169,13 @@ __global__ void __launch_bounds__(64, BL_GEO_ONE_WAVE(kIntegrator, kTime, kSpinZ
   // BlTraceArgs::parked as the loop reads it - from LDS: a scalar register held through the steps is one more spilled, and the
   // benchmark's instantiation has no vector register left to spill it to. Words: [0] the buffer, [1] its capacity, [2] low half
   // park_below (-1: no ray is parked, 64: every ray at once), high half park_after, [3] the passes this wave has made since it
-  // first found nothing to refill a lane from. Read through the LDS address space, volatile: a flat load would wait for the
+  // first found the queue dry (low half) and before (high half). Read through the LDS address space, volatile: a flat load would wait for the
   // sample stores in flight (s_waitcnt vmcnt(0)) in every pass, which a wave alone on its SIMD cannot afford (an eighth of the
   // benchmark frame: 4.1 -> 5.6 ms); a plain load would be hoisted into a register.
   constexpr bool kPark = kIntegrator == BL_INTEGRATOR_DP && !kTime && !kShell && !kResume;
-  const long long n_parked = kResume ? (long long)(P.counters[BL_CNT_PARKED] < (unsigned long long)P.park_capacity ? P.counters[BL_CNT_PARKED] : (unsigned long long)P.park_capacity) : 0;
-  __shared__ long long park_lds[4];
+  const long long n_parked_old = kResume ? (long long)(P.counters[BL_CNT_PARKED] < (unsigned long long)P.park_capacity ? P.counters[BL_CNT_PARKED] : (unsigned long long)P.park_capacity) : 0;
+  const long long n_parked = kResume ? n_parked_old + (long long)P.counters[BL_CNT_PARKED_YOUNG] : 0;   // (together no more than park_capacity)
+  __shared__ long long park_lds[5];
   typedef volatile __attribute__((address_space(3))) long long *ParkWord;
   const ParkWord park_word = (ParkWord)park_lds;
   if (kPark && lane_here() == 0) {
@@ -183,6 +184,7 @@ __global__ void __launch_bounds__(64, BL_GEO_ONE_WAVE(kIntegrator, kTime, kSpinZ
     const int below = P.parked == nullptr ? -1 : (P.park_always != 0 ? 64 : (P.park_below < 63 ? P.park_below : 63));
     park_lds[2] = (long long)(((unsigned long long)(unsigned int)P.park_after << 32) | (unsigned long long)(unsigned int)below);
     park_lds[3] = 0;
+    park_lds[4] = 0;
   }
 #ifdef BL_GEO_STATS
   // per lane: step attempts, accepted steps, samples emitted; per wave (lane 0): loop iterations, emission iterations, refills,
@@ -216,7 +218,7 @@ __global__ void __launch_bounds__(64, BL_GEO_ONE_WAVE(kIntegrator, kTime, kSpinZ
           exhausted = true;
         } else {
           have_ray = true;
-          const double *pk = P.parked + at * BL_PARK_DOUBLES;
+          const double *pk = P.parked + (at < n_parked_old ? at : (long long)P.park_capacity - 1 - (at - n_parked_old)) * BL_PARK_DOUBLES;
 #pragma unroll
           for (int p = 0; p < 8; p++) {
             s.y[p] = pk[p];
@@ -307,22 +309,46 @@ __global__ void __launch_bounds__(64, BL_GEO_ONE_WAVE(kIntegrator, kTime, kSpinZ
       const int park_below = __builtin_amdgcn_readfirstlane((int)word), park_after = __builtin_amdgcn_readfirstlane((int)(word >> 32));
       const unsigned long long holding = __ballot(have_ray);
       bool park = park_below >= 64;
-      if (park_below >= 0 && !park && __ballot(exhausted) != 0ull) {
-        const int passes = __builtin_amdgcn_readfirstlane((int)park_word[3]);
-        park_word[3] = (long long)(passes + 1);   // (every lane writes the same number)
-        park = __popcll(holding) <= park_below || passes >= park_after;
+      if (park_below >= 0 && !park) {
+        // Whether the queue has run dry: a wave sees it when one of its lanes asks in vain - or, a wave whose lanes all hold
+        // long rays (configuration 2: such waves went 48 ms without noticing), by looking at the queue's head every sixteenth
+        // pass. That load is dear - the wave waits for it behind all its sample stores, s_waitcnt vmcnt(0): 4 ms of the
+        // benchmark frame's 20 when parking is switched on, none when it is off. [3]: low half the passes since the queue ran
+        // dry, high half the passes before.
+        const long long seen = park_word[3];
+        int passes = __builtin_amdgcn_readfirstlane((int)seen);
+        const int before = __builtin_amdgcn_readfirstlane((int)(seen >> 32));
+        bool dry = passes > 0 || __ballot(exhausted) != 0ull;
+        if (!dry && (before & 15) == 15)
+          dry = __hip_atomic_load(&P.counters[BL_CNT_NEXT_RAY], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned long long)P.chunk_rays;
+        dry = __builtin_amdgcn_readfirstlane(dry ? 1 : 0) != 0;
+        park_word[3] = dry ? (long long)(((unsigned long long)(unsigned int)before << 32) | (unsigned int)(passes + 1))
+                           : (long long)((unsigned long long)(unsigned int)(before + 1) << 32);   // (every lane writes the same number)
+        // [4]: the passes since a lane of this wave last finished a ray (a lane that asked for a new one at the top of this
+        // pass has). A wave that goes park_quiet passes without finishing any holds long rays only - a frame's photon-ring rays
+        // of thousands of steps, not the benchmark's, whose longest take ~350.
+        const int quiet = need_mask != 0ull ? 0 : __builtin_amdgcn_readfirstlane((int)park_word[4]) + 1;
+        park_word[4] = (long long)quiet;
+        park = dry && (__popcll(holding) <= park_below || passes >= park_after || quiet >= P.park_quiet);
       }
       if (park && holding != 0ull) {
         double *const parked = reinterpret_cast<double *>(park_word[0]);
         const long long park_capacity = park_word[1];
+        // (rays that are long so far from the front of the buffer, the others from its back: BlTraceArgs::park_age)
+        const bool old_ray = have_ray && sample_num >= P.park_age;
+        const unsigned long long old_mask = __ballot(old_ray), young_mask = holding & ~old_mask;
         const int leader = __ffsll((long long)holding) - 1;
         const int lane = lane_here();
-        unsigned long long base = 0ull;
-        if (lane == leader) base = atomicAdd(&P.counters[BL_CNT_PARKED], (unsigned long long)__popcll(holding));
-        base = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(base >> 32), leader) << 32)
-            | (unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)base, leader);
-        const long long at = (long long)base + __popcll(holding & ((1ull << lane) - 1ull));
-        if (have_ray && at < park_capacity) {
+        unsigned long long base_old = 0ull, base_young = 0ull;
+        if (lane == leader) {
+          if (old_mask != 0ull) base_old = atomicAdd(&P.counters[BL_CNT_PARKED], (unsigned long long)__popcll(old_mask));
+          if (young_mask != 0ull) base_young = atomicAdd(&P.counters[BL_CNT_PARKED_YOUNG], (unsigned long long)__popcll(young_mask));
+        }
+        const int old_first = __builtin_amdgcn_readlane((int)base_old, leader), young_first = __builtin_amdgcn_readlane((int)base_young, leader);   // (fewer than 2^31 rays)
+        const unsigned long long below = (1ull << lane) - 1ull;
+        const long long at = old_ray ? (long long)old_first + __popcll(old_mask & below)
+                                     : park_capacity - 1 - ((long long)young_first + __popcll(young_mask & below));
+        if (have_ray && at >= 0 && at < park_capacity) {
           double *pk = parked + at * BL_PARK_DOUBLES;
 #pragma unroll
           for (int p = 0; p < 8; p++) {

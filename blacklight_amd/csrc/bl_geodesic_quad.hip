@@ -2,8 +2,8 @@
 //
 //   bl_geodesic_quad_kernel   finishes the rays bl_geodesic_kernel parked (BlTraceArgs::parked, bl_device.h).
 //
-// A MEASURED EXPERIMENT, off by default (BL_SWITCH_QUAD_TAIL / BL_SWITCH_QUAD_EVERY_RAY): bit-identical to the ray-per-lane
-// kernel, and slower than it - see the end of this comment and DESIGN.md section 5j.
+// Behind a measurement switch (BL_SWITCH_QUAD_TAIL / BL_SWITCH_QUAD_EVERY_RAY): bit-identical to the ray-per-lane kernel, 1.5 - 1.65
+// times faster for a ray alone, 2.6 times dearer per ray-step in issue slots - see the end of this comment and DESIGN.md section 5j.
 //
 // A ray is a chain of steps, a step a chain of six right-hand sides, and a wave issues its instructions one after the other
 // however few of its lanes hold a ray: with a ray per lane the last rays of a chunk - the long rays of the 512^2 formula frame,
@@ -22,12 +22,11 @@
 //
 // What it costs: 4 306 vector instructions in the kernel against 6 660 with zero spin, 4 854 against 7 277 with spin (static; the
 // Kerr-Schild scalars with their square roots and reciprocals are evaluated by all four lanes alike, and selecting a lane's operands
-// costs 300 - 430 v_cndmask) - two thirds, not the half hoped for - and they form long dependent chains: a lone wave of the
-// ray-per-lane kernel, whose six components are independent streams, issues an instruction every ~5.3 cycles, a lone wave of this
-// one - measured on configuration 2's long rays - about every 11. Per step of a ray it is 1.2 - 1.4 times SLOWER (configuration 2:
-// 66 ms geodesic stage without it, 90 - 100 ms with it for any parking rule; an eighth of the benchmark frame: 4.1 - 4.2 ms
-// either way). A version that pays would have to split the scalar part over lanes as well and be scheduled by hand for the
-// latency of dependent fp64 instructions; the dependency chain of a step is ~1 400 instructions long.
+// costs 300 - 430 v_cndmask) - two thirds, not the half hoped for. A wave alone on its SIMD issues ~one instruction per 5.3
+// cycles whatever it holds, so a lone ray is stepped 1.5 - 1.65 times faster (tools/gpu_quad_latency.py: 49.8 -> 33.3 ms for 64
+// rays around the photon ring at a = 0.9); but a wave holds 16 rays instead of 64, so where SIMDs are not idle it is 2.6 times
+// dearer per ray-step. With every wave parking its rays once the queue is dry, configuration 2 takes 67 ms instead of 77 and the
+// benchmark frame 55.6 instead of 49.2; an eighth of the benchmark frame is unchanged (DESIGN.md section 5j has the table).
 #include "bl_geodesic_common.h"
 
 namespace {
@@ -157,6 +156,10 @@ __device__ __forceinline__ void rhs_quad(const BlSpacetime &st, const QuadRole &
 // =================================================================================================
 template <bool kSpinZero>
 __global__ void __launch_bounds__(64, 2) bl_geodesic_quad_kernel(BlTraceArgs P) {
+  // With more than one wave per SIMD (BLACKLIGHT_AMD_QUAD_WAVES) the first round of waves - which takes the oldest parked rays,
+  // the likely longest - goes first where two waves want the vector unit; the others fill the slots it leaves (a wave of this
+  // kernel waits for a dependent result most of the time)
+  if ((int)blockIdx.x < P.quad_first_round) __builtin_amdgcn_s_setprio(3);
   const int lane = wave_lane();
   const int role = lane & 3;
   const int quad_first = lane & ~3;
@@ -167,8 +170,10 @@ __global__ void __launch_bounds__(64, 2) bl_geodesic_quad_kernel(BlTraceArgs P) 
   q.is3 = role == 3;
   const int own1 = q.is0 ? 7 : 3 + role;   // the lane's second component in the ray-per-lane kernel's order t, x, y, z, k_x, k_y, k_z, s
   const BlSpacetime st = P.st;
+  // the parked rays: the old ones from the front of the buffer, then the young ones from its back (BlTraceArgs::park_age)
   const unsigned long long n_parked_all = P.counters[BL_CNT_PARKED];
-  const long long n_parked = (long long)(n_parked_all < (unsigned long long)P.park_capacity ? n_parked_all : (unsigned long long)P.park_capacity);
+  const long long n_parked_old = (long long)(n_parked_all < (unsigned long long)P.park_capacity ? n_parked_all : (unsigned long long)P.park_capacity);
+  const long long n_parked = n_parked_old + (long long)P.counters[BL_CNT_PARKED_YOUNG];   // (together no more than park_capacity)
 
   bool have_ray = false;
   bool exhausted = false;
@@ -198,7 +203,7 @@ __global__ void __launch_bounds__(64, 2) bl_geodesic_quad_kernel(BlTraceArgs P) 
           exhausted = true;
         } else {
           have_ray = true;
-          const double *pk = P.parked + at * BL_PARK_DOUBLES;
+          const double *pk = P.parked + (at < n_parked_old ? at : (long long)P.park_capacity - 1 - (at - n_parked_old)) * BL_PARK_DOUBLES;
           y0 = pk[role];
           y1 = pk[own1];
           kd0 = pk[8 + role];

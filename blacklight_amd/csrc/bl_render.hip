@@ -151,6 +151,7 @@ struct RenderJob {
   bool exact_fused = false;   // exact tier, the same grids, plain image at one frequency: bl_shade_exact2_kernel locates its samples itself
   bool locate_inside = false; // fused || exact_fused: no locate kernel, no located samples in HBM
   bool park = false;          // the last rays of a chunk go to bl_geodesic_quad_kernel (BlTraceArgs::parked): a measurement switch
+  bool tail_beside = false;   // tail_overlap, and the coefficient kernel's first pass runs beside the second launch (else after it)
   bool tail_overlap = false;  // the last rays of a chunk are parked and finished by a second launch of the geodesic kernel, beside
                               // which the coefficient kernel covers the records of the first (BlShadeArgs::record_range)
   size_t park_capacity = 0;
@@ -313,13 +314,13 @@ void PlanJob(RenderJob &job) {
       && ctx->grid_outer_x1 < p.camera_r && !(ctx->switches & BL_SWITCH_RECORD_EVERY_STEP);
   // (the geodesic kernel's instantiation that skips the shell has no register to number segments with: per-sample records there)
   if (job.skip_shell) job.composed = false;
-  // On request (a measurement switch: it does not pay) the last rays of a chunk are finished with a ray per
-  // quad of lanes (Dormand-Prince stepper without sample times; the instantiation that skips the shell has no register for it)
+  // On request (a measurement switch: it pays on frames whose last rays run for thousands of steps and costs the others, DESIGN.md
+  // section 5j) the last rays of a chunk are finished with a ray per quad of lanes (Dormand-Prince stepper without sample times; the instantiation that skips the shell has no register for it)
   const bool parkable = p.ray_integrator == BL_INTEGRATOR_DP && !job.need_time && !job.skip_shell && !job.geo_load;
   job.park = parkable && (ctx->switches & (BL_SWITCH_QUAD_TAIL | BL_SWITCH_QUAD_EVERY_RAY)) != 0;
-  // On request (a measurement switch: it does not pay either) the coefficient kernel runs beside the last rays
+  // On request (a measurement switch: it does not pay) the coefficient kernel runs beside the last rays
   // of a chunk: plain images whose coefficient kernel takes a range of records
-  job.tail_overlap = parkable && !job.park && (ctx->switches & BL_SWITCH_TAIL_OVERLAP) != 0 && !job.aux && !ctx->polarized && !job.slow
+  job.tail_overlap = parkable && !job.park && (ctx->switches & (BL_SWITCH_TAIL_OVERLAP | BL_SWITCH_TAIL_REPACKED)) != 0 && !job.aux && !ctx->polarized && !job.slow
       && !job.block_interp && !job.tau_row && !job.freq_split && !job.geo_save && !job.sample_save && job.n_nu < 4
       && (job.fused2 || job.exact_fused || !job.simulation);
   // ... and in the exact coefficient kernel (plain images): the frequency loop as lanes of bl_coefficients_freq_kernel
@@ -373,7 +374,9 @@ void PlanScratch(RenderJob &job) {
   // 4.7 to 5.3 ms on 2 048 (and the coefficient kernel 5.0 instead of 5.2 ms over the more compact records)
   const long long max_grid = std::min<long long>(static_cast<long long>(ctx->num_cus) * waves_per_cu, std::max<long long>(1, (job.n_rays + 127) / 128));
   // (the waves of bl_geodesic_quad_kernel take blocks of record slots as well: a wave per SIMD)
-  const long long quad_waves = job.park ? static_cast<long long>(ctx->num_cus) * 4 : (job.tail_overlap ? max_grid : 0);
+  // (one to a SIMD: with three - as many as fit its registers - every ray runs at a third of the speed, the longest ones too, and
+  // configuration 2 takes 94 ms instead of 67)
+  const long long quad_waves = job.park ? static_cast<long long>(ctx->num_cus) * 4 * ctx->quad_waves_per_simd : (job.tail_overlap ? max_grid : 0);
   const uint64_t worst_case = static_cast<uint64_t>(job.n_rays) * job.max_steps + static_cast<uint64_t>(max_grid + quad_waves) * BL_RECORD_BLOCK;
   const uint64_t fixed = per_ray * static_cast<uint64_t>(job.n_rays);
   auto capacity_for = [&](int n_slots) -> uint64_t {
@@ -408,6 +411,7 @@ void PlanScratch(RenderJob &job) {
   job.quad_grid = static_cast<int>(quad_waves);
   // (the last rays beside the coefficient kernel: one scratch set - with two, the next chunk's rays run there already)
   if (job.n_slots != 1) job.tail_overlap = false;
+  job.tail_beside = job.tail_overlap && (ctx->switches & BL_SWITCH_TAIL_OVERLAP) != 0;
   // a lane parks at most one ray (its wave ends), unless every ray is parked
   job.park_capacity = (job.park || job.tail_overlap) ? (park_every_ray ? static_cast<size_t>(job.n_rays) : static_cast<size_t>(grid) * 64) : 0;
 }
@@ -954,6 +958,9 @@ void BindChunk(RenderJob &job, int k, long long begin, int rays) {
   ta.park_capacity = static_cast<int>(std::min<size_t>(job.park_capacity, 0x7fffffff));
   ta.park_below = ctx->park_below;
   ta.park_after = ctx->park_after;
+  ta.park_quiet = ctx->park_quiet;
+  ta.park_age = ctx->park_age >= 0 ? ctx->park_age : job.max_steps / 8;
+  ta.quad_first_round = ctx->num_cus * 4;
   ta.park_always = (job.park && (ctx->switches & BL_SWITCH_QUAD_EVERY_RAY)) ? 1 : 0;
   ta.ray_flags = ctx->d_ray_flags.ptr + begin;
   ta.ray_out_index = ctx->d_ray_out_index.ptr + begin;
@@ -1369,7 +1376,7 @@ void LaunchShadingStage(RenderJob &job, int k, bool geodesic_beside, hipStream_t
     else if (job.exact_fused) Check(bl_launch_shade_exact2(&sa, job.shade_grid, stream), "coefficient kernel launch");
     else Check(bl_launch_shade(&sa, p.model_type, job.shade_grid, stream), "coefficient kernel launch");
   };
-  if (job.tail_overlap) {
+  if (job.tail_beside) {
     // The records of the chunk's first geodesic launch while the second, which finishes the parked rays, runs on the other
     // stream; then the records of the second and whatever the tolerant kernel left to the exact one in either pass.
     Check(hipStreamWaitEvent(stream, e[7], 0), "stream wait");
@@ -1432,7 +1439,7 @@ void CollectChunk(RenderJob &job, int k) {
   float ms = 0.0f;
   Check(hipEventElapsedTime(&ms, e[0], e[1]), "event time"); job.ms_geo += ms;
   Check(hipEventElapsedTime(&ms, e[2], e[3]), "event time"); job.ms_locate += ms;
-  if (job.tail_overlap && ctx->debug_counters) {
+  if (job.tail_beside && ctx->debug_counters) {
     float a = 0, b = 0, c = 0, d = 0, f = 0;
     (void)hipEventElapsedTime(&a, e[0], e[7]);
     (void)hipEventElapsedTime(&b, e[7], e[1]);
@@ -1445,7 +1452,7 @@ void CollectChunk(RenderJob &job, int k) {
     std::fprintf(stderr, "tail overlap: first launch %.2f ms, second +%.2f; pass A %.2f ... %.2f, pass B %.2f ... %.2f, transfer ... %.2f; parked %llu, records %llu of %llu\n", a, b, c, d, f, g, h,
                  hc[BL_CNT_PARKED], hc[BL_CNT_RECORDS_FIRST], hc[BL_CNT_RECORDS]);
   }
-  if (job.tail_overlap) {   // the two passes of the coefficient kernel, not the wait for the last rays between them
+  if (job.tail_beside) {   // the two passes of the coefficient kernel, not the wait for the last rays between them
     Check(hipEventElapsedTime(&ms, e[3], e[8]), "event time"); job.ms_shade += ms;
     Check(hipEventElapsedTime(&ms, e[9], e[4]), "event time"); job.ms_shade += ms;
   } else {
@@ -1468,7 +1475,7 @@ void CollectChunk(RenderJob &job, int k) {
   job.total_undefined += hc[BL_CNT_UNDEFINED];
   job.total_records += hc[BL_CNT_RECORDS];
   job.total_gathers += hc[BL_CNT_GATHERS];
-  job.total_parked += std::min<unsigned long long>(hc[BL_CNT_PARKED], job.park_capacity);
+  job.total_parked += std::min<unsigned long long>(hc[BL_CNT_PARKED] + hc[BL_CNT_PARKED_YOUNG], job.park_capacity);
   if (job.fast || job.fast_formula) job.total_redo += hc[BL_CNT_REDO];   // (polarized runs use the list for something else: bl_polarized_frame_kernel)
   job.total_samples += hc[BL_CNT_COUNT + 0];
   job.total_flagged += hc[BL_CNT_COUNT + 1];

@@ -307,6 +307,7 @@ typedef struct bl_stats {
 #define BL_SWITCH_QUAD_TAIL (1u << 10)                      /* the last rays of a chunk finished by bl_geodesic_quad_kernel (a ray per quad of lanes) */
 #define BL_SWITCH_QUAD_EVERY_RAY (1u << 11)                 /* every ray parked before its first step: all stepping in bl_geodesic_quad_kernel */
 #define BL_SWITCH_TAIL_OVERLAP (1u << 12)                   /* the coefficient kernel beside the last rays of a chunk (a second geodesic launch)  */
+#define BL_SWITCH_TAIL_REPACKED (1u << 13)                  /* the last rays of a chunk repacked into full waves by a second geodesic launch, nothing beside it */
 
 typedef struct bl_ctx bl_ctx;
 

@@ -3,7 +3,7 @@
 The quad kernel performs the operations of the ray-per-lane kernel on the same operands, spread over four lanes: positions, step
 lengths, sample counts and flags must be the same bits. BL_SWITCH_QUAD_EVERY_RAY parks every ray before its first step - the
 whole frame is stepped by the quad kernel -, BL_SWITCH_QUAD_TAIL parks the last rays of a chunk, each somewhere along its way;
-the default parks none (the quad kernel is a measured experiment that does not pay: DESIGN.md section 5j). All three must give the same frame, and the oracle's (geodesics.cpp:39-396).
+the default parks none (what the quad kernel gains and where it costs). All three must give the same frame, and the oracle's (geodesics.cpp:39-396).
 """
 import numpy as np
 import pytest
