@@ -227,6 +227,9 @@ def main():
     ap.add_argument("--mode", choices=["frames", "tiled"], default="tiled", help="N > 1: one frame tiled over the ranks (default) or one frame per rank")
     ap.add_argument("--arithmetic", choices=["tolerant", "exact"], default="tolerant",
                     help="tier `value` is measured in; with tolerant the exact tier is timed afterwards and reported as exact_tier")
+    ap.add_argument("--reproducible", action="store_true",
+                    help="tolerant tier: bl_set_reproducible (one transfer record per sample: images bit-identical from run to run and between a "
+                         "frame and its tiles) instead of composed maps")
     ap.add_argument("--resolution", type=int, default=1024)
     ap.add_argument("--grid", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -288,33 +291,40 @@ def main():
 
     ctx = bl.Context(params, device=local_rank)
     ctx.set_grid(grid)          # staged into HBM once, outside the timed region
+    ctx.set_reproducible(args.reproducible)
     if args.scratch_gib > 0.0:
         ctx.set_scratch_limit(int(args.scratch_gib * (1 << 30)))
 
     if tiled:
-        pixels = bd.tile_pixels(res, rank, world, TILE)
+        layout = bd.frame_layout(res, world, TILE)     # built once: per-rank pixel lists and, on rank 0's GPU, the way back
+        pixels = layout.pixels[rank]
         n_rays = int(pixels.size)
-        n_padded = bd.padded_count(res, world, TILE)   # equal shares for the gather, whatever the world size
+        n_padded = layout.n_padded                     # equal shares for the gather, whatever the world size
     else:
-        pixels = None
+        layout, pixels = None, None
         n_rays = n_padded = res * res
     image = torch.zeros((1, n_padded), dtype=torch.float64, device=device)
     sample_num = torch.zeros(n_padded, dtype=torch.int32, device=device)
     flags = torch.zeros(n_padded, dtype=torch.uint8, device=device)
-    torch.cuda.synchronize()   # the fills run on torch's stream, the library's kernels on its own: order them once, here
+    # The library renders on streams of its own. bl_set_caller_stream orders every render behind what torch's current stream
+    # holds at the call - the fills above, and the RCCL gather of the previous frame (torch makes its current stream wait for a
+    # collective it has issued): a rank's next frame cannot write `image` while the gather still reads it. Waits on the device.
+    ctx.follow_torch_stream(device)
+    comm = bd.Comm(device=torch.device("cpu") if rehearse else device) if distributed else None
 
     def step():
         return ctx.render_device(image.data_ptr(), n_rays, pixel_map=pixels,
                                  sample_num_ptr=sample_num.data_ptr(), sample_flags_ptr=flags.data_ptr())
 
     def gather_image():
-        """Final image(s) to rank 0 over RCCL (part of the job, inside the timed region)."""
+        """Final image(s) to rank 0 over RCCL (part of the job, inside the timed region): one gather into a buffer rank 0 keeps,
+        one index_select through the layout's cached permutation on rank 0's GPU. No numpy, no upload, no loop over ranks."""
         if not distributed:
             return None
-        parts = bd.gather_rows(image.cpu() if rehearse else image, dst=0)
-        if parts is not None and tiled:
-            return bd.assemble(parts, res, TILE)      # rank 0 de-tiles into (n_q, res*res)
-        return parts
+        gathered = comm.gather_flat(image.cpu().reshape(-1) if rehearse else image.reshape(-1), dst=0)
+        if gathered is not None and tiled:
+            return layout.detile(gathered, 1)         # rank 0 de-tiles into (n_q, res*res)
+        return gathered
 
     def fence():
         if distributed:
@@ -393,7 +403,7 @@ def main():
             torch.cuda.synchronize()
             ctx.render_device(alone.data_ptr(), res * res, sample_num_ptr=num_alone.data_ptr())
             torch.cuda.synchronize()
-            nums = bd.assemble([part.reshape(1, -1) for part in gathered_nums], res, TILE).reshape(-1)
+            nums = layout.detile(torch.stack([part.reshape(-1) for part in gathered_nums]), 1).reshape(-1)
             x, y = assembled.cpu().numpy(), alone.cpu().numpy()
             a, b = x.view(np.uint64), y.view(np.uint64)
             with np.errstate(invalid="ignore"):
@@ -439,6 +449,9 @@ def main():
                                  if tiled else
                                  f"{world} GPUs, one {res}^2 frame per GPU (views at 360/N deg), grid replicated, frames gathered over RCCL")),
                 "chunks_per_step": stats.n_chunks,
+                # bit-identical images from run to run and however the frame is cut? (exact tier: always; tolerant tier: with
+                # --reproducible; otherwise equal to rounding, ~1e-15 of the maximum - bl_stats.composed_maps)
+                "bit_reproducible": not bool(stats.composed_maps),
             },
             "ranks_seen_by_rccl": world,
             "ms_per_step_per_rank": {"min": 1000.0 * min(main_run["per_rank"]) / args.steps, "max": 1000.0 * max(main_run["per_rank"]) / args.steps},

@@ -105,6 +105,25 @@ class Context:
         """"exact" (default) or "tolerant": arithmetic tier of the coefficient kernel (bl_set_arithmetic)."""
         self._check(self._lib.bl_set_arithmetic(self._ctx, {"exact": 0, "tolerant": 1}[mode]))
 
+    def set_reproducible(self, on=True):
+        """Tolerant tier: bit-reproducible images (one transfer record per sample instead of composed maps; bl_set_reproducible)."""
+        self._check(self._lib.bl_set_reproducible(self._ctx, 1 if on else 0))
+
+    def set_tail_policy(self, policy):
+        """"auto" (default: quad in formula mode), "wide" or "quad": who finishes the last rays of a chunk (bl_set_tail_policy)."""
+        self._check(self._lib.bl_set_tail_policy(self._ctx, {"auto": 0, "wide": 1, "quad": 2}[policy]))
+
+    def set_caller_stream(self, stream=None, enabled=True):
+        """Every later render starts behind the work queued so far on `stream` (a raw hipStream_t handle, e.g.
+        torch.cuda.current_stream().cuda_stream; None / 0: the NULL stream) - bl_set_caller_stream."""
+        self._check(self._lib.bl_set_caller_stream(self._ctx, C.c_void_p(int(stream or 0)), 1 if enabled else 0))
+
+    def follow_torch_stream(self, device=None):
+        """set_caller_stream(torch's current stream on `device`): tensors torch filled, and collectives torch has waited for on
+        that stream, are complete before a render touches the buffers."""
+        import torch
+        self.set_caller_stream(torch.cuda.current_stream(device).cuda_stream)
+
     def debug_set_switches(self, *names):
         """Measurement switches of this context by name (_capi.SWITCHES: "RECORD_EVERY_STEP", "GENERAL_FUSED", ...); none: all off.
         They select another kernel or layout with the same results (bl_stats.switches echoes them)."""

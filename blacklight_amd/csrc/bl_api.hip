@@ -865,6 +865,25 @@ int bl_set_arithmetic(bl_ctx *ctx, int mode) {
   return BL_OK;
 }
 
+int bl_set_reproducible(bl_ctx *ctx, int on) {
+  if (ctx == nullptr) return BL_E_ARG;
+  ctx->reproducible = on ? 1 : 0;
+  return BL_OK;
+}
+
+int bl_set_tail_policy(bl_ctx *ctx, int policy) {
+  if (ctx == nullptr || (policy != BL_TAIL_AUTO && policy != BL_TAIL_WIDE && policy != BL_TAIL_QUAD)) return BL_E_ARG;
+  ctx->tail_policy = policy;
+  return BL_OK;
+}
+
+int bl_set_caller_stream(bl_ctx *ctx, void *stream, int enabled) {
+  if (ctx == nullptr) return BL_E_ARG;
+  ctx->caller_stream = static_cast<hipStream_t>(stream);
+  ctx->caller_stream_set = enabled != 0;
+  return BL_OK;
+}
+
 int bl_debug_set_switches(bl_ctx *ctx, uint32_t switches) {
   if (ctx == nullptr) return BL_E_ARG;
   ctx->switches = switches;
@@ -930,6 +949,7 @@ void bl_free(bl_ctx *ctx) {
   for (auto &e : ctx->events)
     if (e != nullptr) (void)hipEventDestroy(e);
   if (ctx->host_counters != nullptr) (void)hipHostFree(ctx->host_counters);
+  if (ctx->caller_event != nullptr) (void)hipEventDestroy(ctx->caller_event);
   if (ctx->stream != nullptr) (void)hipStreamDestroy(ctx->stream);
   if (ctx->stream_geo != nullptr) (void)hipStreamDestroy(ctx->stream_geo);
   delete ctx;

@@ -125,6 +125,11 @@ struct bl_ctx {
   uint64_t scratch_limit = 144ull << 30;
   int overlap_chunks = 0;             // bl_set_overlap(): geodesic kernel of chunk c + 1 beside the shading of chunk c
   int arithmetic = BL_ARITH_EXACT;    // bl_set_arithmetic()
+  int reproducible = 0;               // bl_set_reproducible(): tolerant tier without composed transfer maps
+  int tail_policy = BL_TAIL_AUTO;     // bl_set_tail_policy()
+  hipStream_t caller_stream = nullptr;   // bl_set_caller_stream(): work queued there before a bl_render call precedes its kernels
+  bool caller_stream_set = false;
+  hipEvent_t caller_event = nullptr;
   int undefined_policy = BL_UNDEFINED_REFUSE;   // bl_set_undefined_policy(): BL_UNDEFINED_EDGE | BL_UNDEFINED_KAPPA
   bool kappa_warned = false;
   bool debug_counters = false;        // BLACKLIGHT_AMD_DEBUG_COUNTERS (bl_init): print the -DBL_GEO_STATS counters after a render
@@ -229,6 +234,7 @@ struct bl_ctx {
   DeviceBuffer<int> d_pixel_map, d_block_locs, d_tile_order;
   int tile_order_res = 0;
   DeviceBuffer<BlShadeCold> d_shade_cold;
+  std::vector<unsigned char> shade_cold_host;   // the bytes d_shade_cold holds (BuildShadeArgs uploads on change only)
   // host-output staging
   DeviceBuffer<double> d_image, d_camera_pos, d_camera_dir;
   DeviceBuffer<int> d_out_sample_num;

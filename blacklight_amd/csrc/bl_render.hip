@@ -306,7 +306,7 @@ void PlanJob(RenderJob &job) {
   // ray's neighbouring samples before they leave it (the geodesic kernel numbers the segments: BlTraceArgs::segment_rows)
   job.fused2 = job.fused && job.interleaved && !job.freq_split && !(ctx->switches & BL_SWITCH_GENERAL_FUSED)
       && bl_fused2_applicable(&ctx->grid_dev, job.n_nu, job.n_rays) != 0;
-  job.composed = job.fused2 && !(ctx->switches & BL_SWITCH_SAMPLE_RECORDS);
+  job.composed = job.fused2 && !ctx->reproducible && !(ctx->switches & BL_SWITCH_SAMPLE_RECORDS);
   // Plain images of a spherical Kerr-Schild simulation with fallback values beyond the grid: nothing is recorded of the steps that
   // lie in the empty shell between the grid's outer edge and the camera's sphere (both tiers; the samples count as ever)
   job.skip_shell = job.simulation && !job.aux && !ctx->polarized && !job.slow && !job.geo_load && !job.geo_save && !job.sample_save
@@ -317,7 +317,11 @@ void PlanJob(RenderJob &job) {
   // On request (a measurement switch: it pays on frames whose last rays run for thousands of steps and costs the others, DESIGN.md
   // section 5j) the last rays of a chunk are finished with a ray per quad of lanes (Dormand-Prince stepper without sample times; the instantiation that skips the shell has no register for it)
   const bool parkable = p.ray_integrator == BL_INTEGRATOR_DP && !job.need_time && !job.skip_shell && !job.geo_load;
-  job.park = parkable && (ctx->switches & (BL_SWITCH_QUAD_TAIL | BL_SWITCH_QUAD_EVERY_RAY)) != 0;
+  // (bl_set_tail_policy; BL_TAIL_AUTO: formula-mode frames - rays that circle for thousands of steps while the SIMDs around them idle,
+  // configuration 2: 77 -> 67 ms - and not over a simulation grid, where the benchmark frame loses 6 ms to it. Bit-identical either way.)
+  const bool quad_wanted = ctx->tail_policy == BL_TAIL_QUAD || (ctx->tail_policy == BL_TAIL_AUTO && !job.simulation && job.n_rays >= 64 * 64);
+  job.park = parkable && (quad_wanted || (ctx->switches & (BL_SWITCH_QUAD_TAIL | BL_SWITCH_QUAD_EVERY_RAY)) != 0)
+      && !(ctx->switches & (BL_SWITCH_TAIL_OVERLAP | BL_SWITCH_TAIL_REPACKED));
   // On request (a measurement switch: it does not pay) the coefficient kernel runs beside the last rays
   // of a chunk: plain images whose coefficient kernel takes a range of records
   job.tail_overlap = parkable && !job.park && (ctx->switches & (BL_SWITCH_TAIL_OVERLAP | BL_SWITCH_TAIL_REPACKED)) != 0 && !job.aux && !ctx->polarized && !job.slow
@@ -471,6 +475,13 @@ void StageInputsAndOutputs(RenderJob &job) {
   const bl_params &p = ctx->params;
   hipStream_t stream = ctx->stream;
   const long long n_rays = job.n_rays;
+  if (ctx->caller_stream_set) {
+    // bl_set_caller_stream: whatever the caller queued on its stream up to now (fills of the output buffers, a collective still
+    // reading the previous frame out of them) is ahead of everything this call queues (both of its streams start behind `stream`) - a wait on the device, none on the host
+    if (ctx->caller_event == nullptr) Check(hipEventCreateWithFlags(&ctx->caller_event, hipEventDisableTiming), "hipEventCreate");
+    Check(hipEventRecord(ctx->caller_event, ctx->caller_stream), "event on the caller's stream");
+    Check(hipStreamWaitEvent(stream, ctx->caller_event, 0), "stream wait");
+  }
   ctx->d_freq.Ensure(job.n_nu);
   Check(hipMemcpyAsync(ctx->d_freq.ptr, ctx->frequencies.data(), job.n_nu * sizeof(double), hipMemcpyHostToDevice, stream), "freq upload");
   if (d->pixel_map != nullptr) {
@@ -501,6 +512,7 @@ void StageInputsAndOutputs(RenderJob &job) {
     if (job.cam_dir == nullptr) { ctx->d_camera_dir.Ensure(static_cast<size_t>(n_rays) * 4); job.cam_dir = ctx->d_camera_dir.ptr; }
   }
   if (job.geo_load && (job.cam_pos != nullptr || job.cam_dir != nullptr)) {   // camera_pos / camera_dir come from the file as well
+    if (ctx->caller_stream_set) Check(hipStreamSynchronize(ctx->caller_stream), "caller's stream");   // (blocking copies below: no stream orders them)
     std::vector<double> rows(static_cast<size_t>(n_rays) * 4);
     for (int which = 0; which < 2; which++) {
       double *target = which == 0 ? job.cam_pos : job.cam_dir;
@@ -733,7 +745,8 @@ void BuildShadeArgs(RenderJob &job) {
   hipStream_t stream = ctx->stream;
   BlShadeArgs &sa = job.sa;
   sa.st = ctx->st;
-  BlShadeCold cold{};
+  BlShadeCold cold;
+  std::memset(static_cast<void *>(&cold), 0, sizeof cold);   // (padding too: the block is compared byte for byte below)
   cold.omit_near = p.cut_omit_near;
   cold.omit_far = p.cut_omit_far;
   cold.plane = p.cut_plane;
@@ -843,9 +856,13 @@ void BuildShadeArgs(RenderJob &job) {
   sa.samples_renormalised = job.geo_load ? 1 : 0;
   sa.general_locate = (ctx->switches & BL_SWITCH_GENERAL_LOCATE) ? 1 : 0;
   sa.unpipelined_shade = (ctx->switches & BL_SWITCH_UNPIPELINED_SHADE) ? 1 : 0;
-  ctx->d_shade_cold.Ensure(1);
-  Check(hipMemcpyAsync(ctx->d_shade_cold.ptr, &cold, sizeof(BlShadeCold), hipMemcpyHostToDevice, stream), "shade parameter upload");
-  Check(hipStreamSynchronize(stream), "shade parameter upload");   // cold is a local
+  // (uploaded when it differs from what the device holds: a frame loop uploads it once and waits for nothing here)
+  if (ctx->shade_cold_host.size() != sizeof(BlShadeCold) || std::memcmp(ctx->shade_cold_host.data(), &cold, sizeof(BlShadeCold)) != 0) {
+    ctx->d_shade_cold.Ensure(1);
+    ctx->shade_cold_host.assign(reinterpret_cast<const unsigned char *>(&cold), reinterpret_cast<const unsigned char *>(&cold) + sizeof(BlShadeCold));
+    Check(hipMemcpyAsync(ctx->d_shade_cold.ptr, ctx->shade_cold_host.data(), sizeof(BlShadeCold), hipMemcpyHostToDevice, stream), "shade parameter upload");
+    Check(hipStreamSynchronize(stream), "shade parameter upload");
+  }
   sa.cold = ctx->d_shade_cold.ptr;
   sa.frequencies = ctx->d_freq.ptr;
   sa.n_nu = job.n_nu;
@@ -1581,6 +1598,8 @@ void FinishStats(RenderJob &job) {
   st.switches = ctx->switches;
   st.fused_variant = job.fused ? (job.fused2 ? 2 : 1) : (job.exact_fused ? 3 : 0);
   st.n_parked = static_cast<int64_t>(job.total_parked);
+  st.composed_maps = job.composed ? 1 : 0;
+  st.tail_policy = job.park ? BL_TAIL_QUAD : BL_TAIL_WIDE;
   ctx->stats = st;
   if (ctx->debug_counters) {   // kernels built with -DBL_GEO_STATS fill these
     std::fprintf(stderr, "debug counters:");

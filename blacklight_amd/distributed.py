@@ -17,15 +17,82 @@ level:
 do { Integrate; AddGeodesics } while (!done) loop (blacklight.cpp:196-233) over all ranks, returning on rank 0 exactly
 what `Context.render_adaptive` returns on one GPU, so `Context.write_output` writes the same file.
 """
+import functools
+
 import numpy as np
 
 TILE = 32
 
 
-def tile_pixels(resolution, rank, world, tile=TILE):
-    """Pixel indices (m = m2 * resolution + m1, as the reference's camera, camera.cpp:393-396) of the
-    tiles owned by `rank`. Tile-major, row-major inside a tile, which is also the order the geodesic
-    kernel wants (each wave starts as a compact 2-D patch)."""
+class ShareLayout:
+    """How the rays of one level are dealt to the ranks, and the way back: `where[r]` = destination pixel of every ray of
+    rank r, in the order the rank traces them. Built once (level 0: cached per (resolution, world, tile) by `frame_layout`;
+    a refined level: once per level from its block list), vectorised over all ranks; nothing here is recomputed per
+    frame, per output or per rank. The inverse - for every pixel of the level, where its value sits in the gathered buffer -
+    lives on the device the gathered buffers live on (`_index`), so that de-tiling is index_select on that device:
+    no numpy, no upload, no loop over ranks in the frame loop."""
+    builds = 0   # how many layouts were ever built (tests: a second frame builds none)
+
+    def __init__(self, where, n_total, n_padded):
+        ShareLayout.builds += 1
+        self.world = len(where)
+        self.n_total, self.n_padded = int(n_total), int(n_padded)
+        self.pixels = where
+        self.counts = [int(w.size) for w in where]
+        self.even = all(c == self.n_padded for c in self.counts)   # every share fills its padded buffer: rows keep one stride
+        n_rays = sum(self.counts)
+        if n_rays != self.n_total:
+            raise ValueError("the shares do not cover the level")
+        dest = np.concatenate(where).astype(np.int64) if self.world > 1 else np.asarray(where[0], dtype=np.int64)
+        rank_of_ray = np.repeat(np.arange(self.world, dtype=np.int64), self.counts)
+        slot_of_ray = np.arange(n_rays, dtype=np.int64) - np.repeat(np.cumsum([0] + self.counts[:-1]), self.counts)
+        # for pixel m of the level: the rank that traced it, its position in that rank's share, the length of that share
+        self._rank = np.empty(self.n_total, dtype=np.int64)
+        self._slot = np.empty(self.n_total, dtype=np.int64)
+        self._rank[dest] = rank_of_ray
+        self._slot[dest] = slot_of_ray
+        self._cache = {}
+
+    def _index(self, device):
+        """Per pixel of the level, as int64 tensors on `device` (uploaded once): its place rank * n_padded + slot in buffers whose
+        rows are n_padded apart and, where the shares differ in length, (rank * n_padded, slot, length of the rank's share)."""
+        import torch
+        key = str(device)
+        if key not in self._cache:
+            padded = torch.from_numpy(self._rank * self.n_padded + self._slot).to(device)
+            packed = None
+            if not self.even:
+                count_of = np.asarray(self.counts, dtype=np.int64)[self._rank]
+                packed = tuple(torch.from_numpy(v).to(device) for v in (self._rank * self.n_padded, self._slot, count_of))
+            self._cache[key] = (padded, packed)
+        return self._cache[key]
+
+    def detile(self, gathered, rows, ray_major=False, packed=True):
+        """gathered: (world, rows * n_padded), rank r's flat buffer in row r. packed (what bl_render leaves when it is given
+        counts[r] rays): `rows` rows of counts[r] values back to back in front of the buffer; not packed: rows n_padded apart;
+        ray_major: counts[r] rays of `rows` values each. Returns (rows, n_total) - or (n_total, rows) - on the same device."""
+        import torch
+        padded, uneven = self._index(gathered.device)
+        if ray_major:
+            return gathered.reshape(self.world * self.n_padded, rows).index_select(0, padded)
+        if uneven is None or not packed or rows == 1:
+            by_row = gathered.reshape(self.world, rows, self.n_padded)
+            by_row = by_row[0] if self.world == 1 else by_row.permute(1, 0, 2).reshape(rows, self.world * self.n_padded)
+            return by_row.index_select(1, padded)
+        # shares of different lengths: row q of rank r starts at q * counts[r] of its buffer
+        rank_base, slot, count_of = uneven
+        flat = gathered.reshape(-1)
+        out = torch.empty((rows, self.n_total), dtype=gathered.dtype, device=gathered.device)
+        first = rank_base * rows + slot
+        for q in range(rows):
+            torch.index_select(flat, 0, first + q * count_of, out=out[q])
+        return out
+
+
+def _tile_shares(resolution, world, tile):
+    """Pixel indices (m = m2 * resolution + m1, as the reference's camera, camera.cpp:393-396) of every rank's tiles:
+    tile-major, row-major inside a tile, which is also the order the geodesic kernel wants (each wave starts as a compact
+    2-D patch)."""
     if resolution % tile != 0:
         raise ValueError("camera_resolution must be a multiple of the tile size")
     tiles_per_side = resolution // tile
@@ -35,12 +102,37 @@ def tile_pixels(resolution, rank, world, tile=TILE):
     all_ids = np.arange(tiles_per_side * tiles_per_side)
     centre = 0.5 * (tiles_per_side - 1)
     dist2 = (all_ids // tiles_per_side - centre) ** 2 + (all_ids % tiles_per_side - centre) ** 2
-    ids = all_ids[np.argsort(dist2, kind="stable")][rank::world]
-    ty, tx = ids // tiles_per_side, ids % tiles_per_side
+    order = all_ids[np.argsort(dist2, kind="stable")]
     yy, xx = np.meshgrid(np.arange(tile), np.arange(tile), indexing="ij")
-    m2 = (ty[:, None, None] * tile + yy[None]).reshape(-1)
-    m1 = (tx[:, None, None] * tile + xx[None]).reshape(-1)
-    return (m2 * resolution + m1).astype(np.int32)
+    shares = []
+    for rank in range(world):
+        ids = order[rank::world]
+        ty, tx = ids // tiles_per_side, ids % tiles_per_side
+        m2 = (ty[:, None, None] * tile + yy[None]).reshape(-1)
+        m1 = (tx[:, None, None] * tile + xx[None]).reshape(-1)
+        pixels = (m2 * resolution + m1).astype(np.int32)
+        pixels.flags.writeable = False
+        shares.append(pixels)
+    return shares
+
+
+@functools.lru_cache(maxsize=16)
+def frame_layout(resolution, world, tile=TILE):
+    """The level-0 layout of a camera (cached: a frame loop asks for it every frame and gets the same object)."""
+    return ShareLayout(_tile_shares(resolution, world, tile), resolution * resolution, padded_count(resolution, world, tile))
+
+
+def block_layout(n_blocks, block_size, world):
+    """A refined level: blocks rank, rank + world, ... of the level's block list, block_size^2 pixels each."""
+    per_block = block_size * block_size
+    within = np.arange(per_block, dtype=np.int64)[None, :]
+    where = [(np.arange(r, n_blocks, world, dtype=np.int64)[:, None] * per_block + within).reshape(-1) for r in range(world)]
+    return ShareLayout(where, n_blocks * per_block, ((n_blocks + world - 1) // world) * per_block)
+
+
+def tile_pixels(resolution, rank, world, tile=TILE):
+    """Pixel indices of the tiles owned by `rank` (read-only view of the cached layout's array)."""
+    return frame_layout(resolution, world, tile).pixels[rank]
 
 
 def padded_count(resolution, world, tile=TILE):
@@ -57,29 +149,40 @@ def default_tile(resolution, block_size=1):
     return tile if resolution % tile == 0 and tile % max(block_size, 1) == 0 else resolution
 
 
-def gather_rows(local, dst=0):
-    """Gather a (n_q, n_local) tensor from every rank on `dst` (RCCL gather over xGMI on GPUs)."""
+def gather_shares(local, dst=0, buffer=None):
+    """Gather one flat tensor of the same length from every rank into ONE (world, n) tensor on `dst` (RCCL gather over xGMI
+    on GPUs; the receive buffers are the rows of that tensor, nothing is copied afterwards). `buffer`: a (world, n) tensor
+    to receive into (a frame loop keeps one). Returns it on `dst`, None elsewhere."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size()
+    flat = local.reshape(-1)
     if dist.get_rank() == dst:
-        parts = [torch.empty_like(local) for _ in range(world)]
-        dist.gather(local, parts, dst=dst)
-        return parts
-    dist.gather(local, None, dst=dst)
+        if buffer is None or buffer.shape != (world, flat.numel()) or buffer.dtype != flat.dtype or buffer.device != flat.device:
+            buffer = torch.empty((world, flat.numel()), dtype=flat.dtype, device=flat.device)
+        dist.gather(flat, list(buffer.unbind(0)), dst=dst)
+        return buffer
+    dist.gather(flat, None, dst=dst)
     return None
 
 
+def gather_rows(local, dst=0):
+    """Gather a (n_q, n_local) tensor from every rank on `dst`: the list of the ranks' tensors (views of one buffer)."""
+    gathered = gather_shares(local, dst)
+    return None if gathered is None else [part.view(local.shape) for part in gathered.unbind(0)]
+
+
 def assemble(parts, resolution, tile=TILE):
-    """Rank 0: scatter the gathered (n_q, n_padded) blocks back into (n_q, resolution**2)."""
+    """Rank 0: the gathered (n_q, n_padded) shares of a frame - a list of them, or one (world, n_q * n_padded) tensor as
+    gather_shares returns it - back into (n_q, resolution**2), on the device they are on, through the cached layout."""
     import torch
-    world = len(parts)
-    n_q = parts[0].shape[0]
-    image = torch.empty((n_q, resolution * resolution), dtype=parts[0].dtype, device=parts[0].device)
-    for rank, part in enumerate(parts):
-        pixels = torch.from_numpy(tile_pixels(resolution, rank, world, tile).astype(np.int64)).to(part.device)
-        image[:, pixels] = part[:, : pixels.numel()]
-    return image
+    if isinstance(parts, (list, tuple)):
+        world, n_q = len(parts), parts[0].shape[0]
+        gathered = torch.stack([part.reshape(-1) for part in parts])
+    else:
+        world, gathered = parts.shape[0], parts
+        n_q = gathered.shape[1] // padded_count(resolution, world, tile)
+    return frame_layout(resolution, world, tile).detile(gathered, n_q, packed=False)
 
 
 class RankError(RuntimeError):
@@ -117,8 +220,14 @@ class Comm:
         raise RankError("; ".join(f"rank {r}: {t.strip()}" for r, t in enumerate(texts) if t is not None))
 
     def gather_flat(self, local, dst=0):
-        """local: a tensor on self.device, the same shape on every rank. Rank dst gets the list of all of them."""
-        return gather_rows(local, dst=dst)
+        """local: a flat tensor on self.device, the same length on every rank. Rank dst gets them as ONE (world, n) tensor,
+        received into a buffer this object keeps per length and type (a frame loop allocates nothing after its first frame)."""
+        key = (local.numel(), local.dtype)
+        buffers = self.__dict__.setdefault("_gather_buffers", {})
+        gathered = gather_shares(local, dst=dst, buffer=buffers.get(key))
+        if gathered is not None:
+            buffers[key] = gathered
+        return gathered
 
     def reduce_counts(self, max_value, sum_value):
         """(max over ranks of max_value, sum over ranks of sum_value), on every rank."""
@@ -183,10 +292,9 @@ def _render_into_buffers(ctx, comm, specs, n_local, n_padded, level, pixels, blo
     if n_local == 0:
         return buffers, None
     if comm.on_gpu and hasattr(ctx, "render_device"):
-        # torch.zeros queued its fill kernels on torch's current stream; the library renders on non-blocking streams of its own,
-        # which nothing orders behind that one - a fill still pending could wipe what bl_ray_init_kernel writes at the very start
-        # of the render. Wait for the fills before handing the pointers over.
-        torch.cuda.current_stream(comm.device).synchronize()
+        # torch.zeros queued its fill kernels on torch's current stream; the library renders on non-blocking streams of its own:
+        # bl_set_caller_stream puts the render behind those fills (and behind the previous level's gathers) on the device
+        ctx.follow_torch_stream(comm.device)
         ptr = {name: buffers[name].data_ptr() for name in buffers}
         stats = ctx.render_device(ptr["image"], n_local, level=level, pixel_map=pixels, block_locs=blocks,
                                   sample_num_ptr=ptr["sample_num"], sample_flags_ptr=ptr["sample_flags"],
@@ -202,14 +310,6 @@ def _render_into_buffers(ctx, comm, specs, n_local, n_padded, level, pixels, blo
     return buffers, out["stats"]
 
 
-def _level_layout(key, flat, n_local):
-    """A share's flat values as (rows, n_local) with rays along the columns."""
-    if key in ("camera_pos", "camera_dir"):
-        return flat[: 4 * n_local].reshape(n_local, 4).T          # the library writes rays x 4
-    rows = flat.size // max(n_local, 1) if n_local else 0
-    return flat.reshape(rows, n_local) if n_local else flat.reshape(0, 0)
-
-
 def render_level(ctx, comm, level=0, block_locs=None, want_camera=False, tile=None):
     """One adaptive level over all ranks. Level 0: the camera in tiles (tile_pixels); refined levels: blocks
     rank, rank + world, ... of `block_locs`. Returns on rank 0 the dict Context.render returns for the whole level
@@ -220,28 +320,23 @@ def render_level(ctx, comm, level=0, block_locs=None, want_camera=False, tile=No
     rank, world = comm.rank, comm.world
     bs = int(ctx.params.get("adaptive_block_size") or 1) if int(ctx.params.get("adaptive_max_level") or 0) > 0 else 1
     if level == 0:
-        res = ctx.resolution
-        tile = tile or default_tile(res, bs)
-        counts = [int(tile_pixels(res, r, world, tile).size) for r in range(world)]
-        pixels, blocks = tile_pixels(res, rank, world, tile), None
-        n_total = res * res
-        n_padded = padded_count(res, world, tile)
+        layout = frame_layout(ctx.resolution, world, tile or default_tile(ctx.resolution, bs))   # cached: built once per camera
     else:
-        n_blocks = int(block_locs.shape[0])
-        counts = [len(range(r, n_blocks, world)) * bs * bs for r in range(world)]
-        pixels, blocks = None, np.ascontiguousarray(block_locs[rank::world], dtype=np.int32)
-        n_total = n_blocks * bs * bs
-        n_padded = ((n_blocks + world - 1) // world) * bs * bs
+        layout = block_layout(int(block_locs.shape[0]), bs, world)                                # once per level
+    counts, n_total, n_padded = layout.counts, layout.n_total, layout.n_padded
+
+    def share_of(r):
+        if level == 0:
+            return layout.pixels[r], None
+        return None, np.ascontiguousarray(block_locs[r::world], dtype=np.int32)
+
     specs = _row_specs(ctx, want_camera)
     emulated = getattr(comm, "emulated", False)
     if emulated:
         # every rank's share in turn, into buffers of its own: what the gathers below would deliver
         shares, max_num, n_flagged = [], 0, 0
         for r in range(world):
-            if level == 0:
-                pixels_r, blocks_r = tile_pixels(ctx.resolution, r, world, tile), None
-            else:
-                pixels_r, blocks_r = None, np.ascontiguousarray(block_locs[r::world], dtype=np.int32)
+            pixels_r, blocks_r = share_of(r)
             buffers_r, stats_r = _render_into_buffers(ctx, comm, specs, counts[r], n_padded, level, pixels_r, blocks_r, want_camera)
             shares.append(buffers_r)
             if stats_r is not None:
@@ -250,6 +345,7 @@ def render_level(ctx, comm, level=0, block_locs=None, want_camera=False, tile=No
             ctx.clear_warnings()
     else:
         n_local = counts[rank]
+        pixels, blocks = share_of(rank)
         buffers, stats, error = None, None, None
         try:
             buffers, stats = _render_into_buffers(ctx, comm, specs, n_local, n_padded, level, pixels, blocks, want_camera)
@@ -262,27 +358,16 @@ def render_level(ctx, comm, level=0, block_locs=None, want_camera=False, tile=No
         n_flagged = stats.n_flagged if stats is not None else 0
         max_num, n_flagged = comm.reduce_counts(max_num, n_flagged)
     result = dict(max_sample_num=max_num, n_flagged=n_flagged, n_rays=n_total) if rank == 0 else None
+    import torch
     for name, rows, dtype in specs:
-        parts = [share[name] for share in shares] if emulated else comm.gather_flat(buffers[name])
+        gathered = torch.stack([share[name] for share in shares]) if emulated else comm.gather_flat(buffers[name])
         if rank != 0:
             continue
-        full = None
-        for r, part in enumerate(parts):
-            host = part.cpu().numpy()          # one download per rank's share, on rank 0 only
-            share = _level_layout(name, host[: rows * counts[r]], counts[r])
-            if full is None:
-                full = np.empty((rows, n_total), dtype=host.dtype)
-            if level == 0:
-                where = tile_pixels(ctx.resolution, r, world, tile).astype(np.int64)
-            else:
-                ids = np.arange(r, n_total // (bs * bs), world, dtype=np.int64)
-                where = (ids[:, None] * (bs * bs) + np.arange(bs * bs)[None, :]).reshape(-1)
-            if where.size:
-                full[:, where] = share
+        # de-tiled where the gather left it (the GPU for RCCL), then ONE download per output of the level
+        ray_major = name in ("camera_pos", "camera_dir")          # the library writes rays x 4 there, rows x rays elsewhere
+        full = layout.detile(gathered, rows, ray_major=ray_major).cpu().numpy()
         if name in ("sample_num", "sample_flags"):
             result[name] = full[0]
-        elif name in ("camera_pos", "camera_dir"):
-            result[name] = np.ascontiguousarray(full.T)
         elif name == "rendering":
             result[name] = full.reshape(ctx.num_render_images, 3, -1)
         else:

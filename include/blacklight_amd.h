@@ -289,6 +289,10 @@ typedef struct bl_stats {
   int32_t fused_variant;      /* the locate step inside the coefficient kernel: 2 = bl_shade_fused2_kernel, 1 = bl_shade_fused_kernel
                                  (tolerant tier), 3 = bl_shade_exact2_kernel (exact tier), 0 = a locate kernel of its own ran  */
   int64_t n_parked;           /* rays whose last steps ran with a ray per quad of lanes (bl_geodesic_quad_kernel)                 */
+  int32_t composed_maps;      /* 1: the tolerant tier composed the affine transfer maps of neighbouring samples (intensities equal from
+                                 run to run to rounding, ~1e-15, not bit for bit); 0: every image row of this render is bit-reproducible
+                                 (always so in the exact tier and under bl_set_reproducible)                                         */
+  int32_t tail_policy;        /* BL_TAIL_* the render ran with (after BL_TAIL_AUTO was resolved)                                     */
 } bl_stats;
 
 /* Measurement switches: environment variables BLACKLIGHT_AMD_<NAME>, read ONCE by bl_init (never during a render) and echoed in
@@ -373,6 +377,29 @@ BL_API int bl_set_undefined_policy(bl_ctx *ctx, int policy);
 #define BL_ARITH_EXACT 0
 #define BL_ARITH_TOLERANT 1
 BL_API int bl_set_arithmetic(bl_ctx *ctx, int mode);
+/* Tolerant tier only (the exact tier is always bit-reproducible). on = 0 (default): the coefficient kernel composes the affine
+ * transfer maps of a ray's neighbouring samples before they leave it (a quarter of the transfer records); which samples are
+ * composed together follows the order in which the persistent geodesic waves emitted them, so two renders of one frame - or a
+ * frame and its tiles - agree to rounding (~1e-15 of the image maximum), not bit for bit. on = 1: one transfer record per
+ * sample, applied in ray order: tolerant images are then bit-identical from run to run and however a frame is cut into
+ * bl_render calls, ranks or chunks, like the reference's are across thread counts (blacklight.cpp:196-233 is one deterministic
+ * loop). Costs ~1.5 % of the benchmark frame. bl_stats.composed_maps says which way the last render went. */
+BL_API int bl_set_reproducible(bl_ctx *ctx, int on);
+/* Who finishes the last rays of a chunk of geodesics (per-ray independence, geodesics.cpp:109-324; the results are bit-identical
+ * either way, only the time differs). BL_TAIL_WIDE: the persistent one-ray-per-lane stepper alone. BL_TAIL_QUAD: it parks rays
+ * that outlive their neighbours and bl_geodesic_quad_kernel finishes them with a ray per quad of lanes (1.5 - 1.65 x faster per
+ * ray; pays where a few rays run for thousands of steps - formula-mode frames - and costs where they do not). BL_TAIL_AUTO
+ * (default): QUAD in formula mode, WIDE over a simulation grid. */
+#define BL_TAIL_AUTO 0
+#define BL_TAIL_WIDE 1
+#define BL_TAIL_QUAD 2
+BL_API int bl_set_tail_policy(bl_ctx *ctx, int policy);
+/* Ordering against the caller's own GPU work. bl_render runs on streams of its own (non-blocking: the NULL stream does not order
+ * them) and returns when its outputs are complete, so nothing the caller does AFTER the call needs ordering. What the caller
+ * queued BEFORE it - a fill of the output buffers, an RCCL gather still reading the previous frame out of them - does:
+ * with enabled != 0, every later bl_render first makes its streams wait (on the device, hipStreamWaitEvent: no host wait) for
+ * all work queued on `stream` (a hipStream_t; NULL is the NULL stream) up to the moment of the call. */
+BL_API int bl_set_caller_stream(bl_ctx *ctx, void *stream, int enabled);
 /* Cap on scratch HBM (bytes) used for per-sample records; default 144 GiB (half of the MI355X HBM). */
 BL_API int bl_set_scratch_limit(bl_ctx *ctx, uint64_t bytes);
 /* on != 0: when a render needs several chunks, run the geodesic kernel of chunk c + 1 on a second stream

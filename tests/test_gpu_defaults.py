@@ -1,0 +1,107 @@
+"""What the library does when nobody sets a switch: the fast bit-identical choices the host can make are the
+defaults, the choices that trade a property away are API calls whose effect bl_stats reports.
+
+  * bl_set_reproducible: the tolerant tier without composed transfer maps - two renders of a frame, and a frame and its tiles, are the
+    same bits (the reference is one deterministic loop, blacklight.cpp:196-233, and bit-deterministic across thread counts);
+  * bl_set_tail_policy / BL_TAIL_AUTO: formula-mode frames finish their last rays in bl_geodesic_quad_kernel without any switch
+    (bl_stats.switches == 0), bit-identical to the wide stepper alone;
+  * bl_set_caller_stream: a render ordered behind work on the caller's stream.
+"""
+import numpy as np
+import pytest
+
+import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+
+def _benchmark_like(res=128, grid_n=64):
+    import bench
+    import blacklight_amd as bl
+    from blacklight_amd import mock
+    params = dict(bench.WORKLOAD, camera_resolution=res)
+    return bl.Params.from_dict(params), mock.generate(n_r=grid_n, n_th=grid_n, n_ph=grid_n)
+
+
+def test_tolerant_renders_are_bit_equal_under_set_reproducible():
+    import blacklight_amd as bl
+    from blacklight_amd import distributed as bd
+    p, grid = _benchmark_like()
+    with bl.Context(p) as ctx:
+        ctx.set_grid(grid)
+        ctx.set_arithmetic("tolerant")
+        composed = ctx.render()
+        assert composed["stats"].fused_variant == 2 and composed["stats"].composed_maps == 1 and composed["stats"].switches == 0
+        ctx.set_reproducible(True)
+        first = ctx.render()
+        assert first["stats"].fused_variant == 2 and first["stats"].composed_maps == 0 and first["stats"].switches == 0
+        for _ in range(3):
+            again = ctx.render()
+            assert gu.same_bits(again["image"], first["image"]).all()
+            assert np.array_equal(again["sample_num"], first["sample_num"])
+        # a frame and its tiles (three ranks' shares, shares of different lengths)
+        res = 128
+        tiled = np.empty_like(first["image"])
+        for rank in range(3):
+            pixels = bd.tile_pixels(res, rank, 3, 32)
+            share = ctx.render(pixel_map=pixels)
+            tiled[:, pixels] = share["image"]
+        assert gu.same_bits(tiled, first["image"]).all()
+        # ... and the composed maps differ from it by rounding only
+        with np.errstate(invalid="ignore"):
+            assert np.nanmax(np.abs(composed["image"] - first["image"])) <= 1.0e-13 * np.nanmax(np.abs(first["image"]))
+        ctx.set_reproducible(False)
+        assert ctx.render()["stats"].composed_maps == 1
+
+
+def test_formula_frames_take_the_quad_tail_by_default():
+    import blacklight_amd as bl
+    fx, params, _ = gu.load_case("formula_dp")
+    p = bl.Params.from_dict(dict(params, camera_resolution=96))
+    with bl.Context(p) as ctx:
+        for tier in ("exact", "tolerant"):
+            ctx.set_arithmetic(tier)
+            auto = ctx.render()
+            assert auto["stats"].switches == 0 and auto["stats"].tail_policy == 2 and auto["stats"].n_parked > 0, tier
+            ctx.set_tail_policy("wide")
+            wide = ctx.render()
+            assert wide["stats"].tail_policy == 1 and wide["stats"].n_parked == 0
+            ctx.set_tail_policy("auto")
+            assert np.array_equal(auto["sample_num"], wide["sample_num"]) and np.array_equal(auto["sample_flags"], wide["sample_flags"])
+            assert gu.same_bits(auto["image"], wide["image"]).all(), tier
+    # small frames and simulation frames stay with the wide stepper
+    with bl.Context(bl.Params.from_dict(dict(params, camera_resolution=32))) as ctx:
+        assert ctx.render()["stats"].tail_policy == 1
+    p, grid = _benchmark_like(96, 32)
+    with bl.Context(p) as ctx:
+        ctx.set_grid(grid)
+        assert ctx.render()["stats"].tail_policy == 1
+        ctx.set_tail_policy("quad")
+        quad = ctx.render()
+        ctx.set_tail_policy("wide")
+        assert gu.same_bits(quad["image"], ctx.render()["image"]).all()
+
+
+def test_render_waits_for_the_callers_stream():
+    """A fill queued on a torch stream just before the render must not land after the render's own writes."""
+    import torch
+    import blacklight_amd as bl
+    p, grid = _benchmark_like(64, 32)
+    with bl.Context(p) as ctx:
+        ctx.set_grid(grid)
+        want = ctx.render()
+        n = want["sample_num"].size
+        side = torch.cuda.Stream()
+        image = torch.empty((1, n), dtype=torch.float64, device="cuda")
+        sample_num = torch.empty(n, dtype=torch.int32, device="cuda")
+        ballast = torch.empty(1 << 28, dtype=torch.float64, device="cuda")   # 2 GiB of fills ahead of the small ones
+        with torch.cuda.stream(side):
+            for _ in range(4):
+                ballast.fill_(1.0)
+            image.fill_(-7.0)
+            sample_num.fill_(-7)
+            ctx.follow_torch_stream()
+        ctx.render_device(image.data_ptr(), n, sample_num_ptr=sample_num.data_ptr())
+        torch.cuda.synchronize()
+        assert np.array_equal(sample_num.cpu().numpy(), want["sample_num"])
+        assert gu.same_bits(image.cpu().numpy(), want["image"]).all()

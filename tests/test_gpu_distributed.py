@@ -106,29 +106,33 @@ def test_device_resident_gather_over_rccl(case, built_library, tmp_path):
     _assert_npz_equals_golden(np.load(out_path), fx)
 
 
-@pytest.mark.parametrize("tier", ["exact", "tolerant"])
+@pytest.mark.parametrize("tier", ["exact", "tolerant", "tolerant-reproducible"])
 def test_bench_tiled_frame_rehearsal(tier, built_library):
     """bench.py's own multi-GPU code path - tile dealing, padded shares, gather, de-tiling - with four ranks that share the one
     GPU and gather over gloo (`--rehearse`; a box allows six processes on its card, hence four ranks and not eight): the frame
     the ranks assemble equals the frame rank 0 renders alone - bit for bit in the exact tier; in the tolerant tier to rounding
     level (which of a ray's affine maps are composed with which follows the order in which the persistent geodesic kernel emitted
-    the records, and that differs between a share and the whole frame), NaN masks and counts equal. No 8-GPU node was available
+    the records, and that differs between a share and the whole frame), NaN masks and counts equal; and bit for bit again in the
+    tolerant tier under bl_set_reproducible (`--reproducible`: one transfer record per sample). No 8-GPU node was available
     to this builder: the RCCL path itself runs with one rank (above) and in the driver's scaling run."""
     import json
     import subprocess
     import sys
     world = 4
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    reproducible = tier.endswith("-reproducible")
+    tier = tier.split("-")[0]
     run = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
                           "--master-port", str(_free_port()), os.path.join(repo, "bench.py"), "--gpus", str(world), "--rehearse", "--steps", "1",
-                          "--warmup", "0", "--no-cpu-baseline", "--resolution", "256", "--grid", "64", "--arithmetic", tier],
+                          "--warmup", "0", "--no-cpu-baseline", "--resolution", "256", "--grid", "64", "--arithmetic", tier] + (["--reproducible"] if reproducible else []),
                          capture_output=True, text=True, timeout=900, cwd=repo)
     assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-4000:]
     line = json.loads([text for text in run.stdout.splitlines() if text.startswith("{")][-1])
     assert line["n_gpus"] == world and line["scaling"] == "strong" and line["config"]["arithmetic"] == tier
     rehearsal = line["rehearsal"]
     assert rehearsal["nan_mask_equal"] and rehearsal["sample_num_equal"], rehearsal
-    if tier == "exact":
+    assert line["config"]["bit_reproducible"] == (tier == "exact" or reproducible), line["config"]
+    if tier == "exact" or reproducible:
         assert rehearsal["assembled_frame_equals_single_rank_frame_bit_for_bit"], rehearsal
     else:
         assert rehearsal["image_linf_over_max"] < 1.0e-13, rehearsal
