@@ -49,7 +49,7 @@ class RenderDesc(C.Structure):
 # BL_SWITCH_* of include/blacklight_amd.h: measurement switches (bl_stats.switches, bl_debug_set_switches)
 SWITCHES = {name: 1 << bit for bit, name in enumerate(
     ["TENSOR_TRANSPORT", "SPLIT_RECORDS", "RECORD_EVERY_STEP", "TOLERANT_POLARIZED_COEFFICIENTS", "GENERAL_LOCATE", "LANE_TRANSFER",
-     "NO_FUSED_LOCATE", "GENERAL_FUSED", "SAMPLE_RECORDS", "UNPIPELINED_SHADE", "QUAD_TAIL", "QUAD_EVERY_RAY", "TAIL_OVERLAP", "TAIL_REPACKED"])}
+     "NO_FUSED_LOCATE", "GENERAL_FUSED", "SAMPLE_RECORDS", "UNPIPELINED_SHADE", "QUAD_TAIL", "QUAD_EVERY_RAY", "TAIL_OVERLAP", "TAIL_REPACKED", "BRICK_CELLS", "SPLIT_LONG"])}
 
 BL_MAX_LEVELS = 16
 

@@ -110,8 +110,8 @@ class Context:
         self._check(self._lib.bl_set_reproducible(self._ctx, 1 if on else 0))
 
     def set_tail_policy(self, policy):
-        """"auto" (default: quad in formula mode), "wide" or "quad": who finishes the last rays of a chunk (bl_set_tail_policy)."""
-        self._check(self._lib.bl_set_tail_policy(self._ctx, {"auto": 0, "wide": 1, "quad": 2}[policy]))
+        """"auto" (default), "wide", "quad" or "split": who steps the rays a chunk waits for longest (bl_set_tail_policy)."""
+        self._check(self._lib.bl_set_tail_policy(self._ctx, {"auto": 0, "wide": 1, "quad": 2, "split": 3}[policy]))
 
     def set_caller_stream(self, stream=None, enabled=True):
         """Every later render starts behind the work queued so far on `stream` (a raw hipStream_t handle, e.g.

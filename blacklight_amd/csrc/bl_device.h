@@ -89,6 +89,7 @@ enum BlCounter {
 
 struct BlGridDevice {
   const float *cells;        // [n_k][n_j][n_i][8]
+  const float *bricks;       // BL_SWITCH_BRICK_CELLS: [n_k][n_j][n_i][8 corners][8] - every anchor cell's stencil pre-gathered - else null
   const float *kappa;        // [n_k][n_j][n_i] electron entropy (plasma_model = code_kappa), else null
   const double *xf[3];       // faces  (r, theta, phi)
   const double *xv[3];       // centres
@@ -300,6 +301,12 @@ struct BlTraceArgs {
   int park_age;
   int quad_first_round;   // bl_geodesic_quad_kernel: its first this many waves (one per SIMD) run at raised priority
   int park_always;
+  // Rays predicted long, on compute units of their own from the first moment (BL_SWITCH_SPLIT_LONG, a measurement: DESIGN.md section
+  // 5k). bl_split_long_kernel parks - before either stepper starts - the rays of a plane camera whose impact parameter lies in
+  // [split_b_lo, split_b_hi] (in units of M: the band around the photon ring's critical curve) and marks their start state (r < 0);
+  // bl_geodesic_kernel passes a marked ray over, bl_geodesic_quad_kernel steps the parked ones on a stream whose CU mask the
+  // other stream's excludes. split_b_hi = 0: no split.
+  double split_b_lo, split_b_hi;
 };
 #define BL_RAY_START_FIELDS 17
 // A parked ray (BlTraceArgs::parked): everything bl_geodesic_kernel holds of a ray between two steps, BL_PARK_DOUBLES doubles

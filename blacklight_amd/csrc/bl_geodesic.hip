@@ -181,7 +181,9 @@ __global__ void __launch_bounds__(64, BL_GEO_ONE_WAVE(kIntegrator, kTime, kSpinZ
   if (kPark && lane_here() == 0) {
     park_lds[0] = reinterpret_cast<long long>(P.parked);
     park_lds[1] = (long long)P.park_capacity;
-    const int below = P.parked == nullptr ? -1 : (P.park_always != 0 ? 64 : (P.park_below < 63 ? P.park_below : 63));
+    // (with the rays predicted long parked beforehand - BlTraceArgs::split_b_hi - this kernel parks nothing: the other stepper has
+    // read the list by now)
+    const int below = (P.parked == nullptr || P.split_b_hi > 0.0) ? -1 : (P.park_always != 0 ? 64 : (P.park_below < 63 ? P.park_below : 63));
     park_lds[2] = (long long)(((unsigned long long)(unsigned int)P.park_after << 32) | (unsigned long long)(unsigned int)below);
     park_lds[3] = 0;
     park_lds[4] = 0;
@@ -285,6 +287,12 @@ __global__ void __launch_bounds__(64, BL_GEO_ONE_WAVE(kIntegrator, kTime, kSpinZ
           s.y[7] = 0.0;
           s.kt = start[7 * stride];
           r_cur = start[8 * stride];
+          if (kPark && r_cur < 0.0) {
+            // a ray bl_split_long_kernel parked before the first step (BlTraceArgs::split_b_hi): bl_geodesic_quad_kernel's; the
+            // reservation the leader made for it above goes back (the parked ray holds one of its own)
+            have_ray = false;
+            atomicAdd(&P.counters[BL_CNT_COMMITTED], (unsigned long long)(-(long long)P.ray_max_steps));
+          }
           if (kIntegrator == BL_INTEGRATOR_DP) {
 #pragma unroll
             for (int p = 0; p < 8; p++) k0[p] = start[(9 + p) * stride];
@@ -758,9 +766,50 @@ __global__ void __launch_bounds__(64, BL_GEO_ONE_WAVE(kIntegrator, kTime, kSpinZ
 }
 
 
+// Rays predicted long (BlTraceArgs::split_b_lo): one ray of the chunk per lane, after bl_ray_init_kernel and the chunk's counter
+// reset, before either stepper. A ray in the band is written to parked[] as it stands before its first step - what
+// bl_geodesic_kernel would write with park_always - with its rows and its reservation, and its start state is marked.
+__global__ void __launch_bounds__(256) bl_split_long_kernel(BlTraceArgs P) {
+  const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= (long long)P.chunk_rays) return;
+  const long long ray = P.ray_out_index[q];
+  const long long pixel = P.pixel_map != nullptr ? (long long)P.pixel_map[ray] : ray;
+  double u_ind, v_ind;
+  bl_pixel_indices(P.cam, pixel, P.block_locs, &u_ind, &v_ind);
+  const double scale = P.st.bh_m * P.cam.camera_width;
+  const double b = blm_sqrt(u_ind * u_ind + v_ind * v_ind) * scale;
+  if (!(b >= P.split_b_lo && b <= P.split_b_hi)) return;
+  const long long at = (long long)atomicAdd(&P.counters[BL_CNT_PARKED], 1ull);
+  if (at >= (long long)P.park_capacity) return;   // (the buffer holds every ray of the chunk: bl_render.hip)
+  double *start = P.ray_start + q;
+  const long long stride = P.ray_start_stride;
+  double *pk = P.parked + at * BL_PARK_DOUBLES;
+  for (int p = 0; p < 7; p++) pk[p] = start[p * stride];
+  pk[7] = 0.0;
+  for (int p = 0; p < 8; p++) pk[8 + p] = start[(9 + p) * stride];
+  const double r = start[8 * stride];
+  pk[16] = start[7 * stride];
+  pk[17] = -P.ray_step * r;
+  pk[18] = r;
+  pk[19] = 0.0;
+  pk[20] = __longlong_as_double((long long)(unsigned long long)(unsigned int)q);                      // slot, no samples so far
+  pk[21] = __longlong_as_double((long long)(((unsigned long long)(unsigned int)-1) << 32));          // truncating sample -1, no retries
+  pk[22] = __longlong_as_double(0ll);
+  pk[23] = 0.0;
+  P.ray_offset[q] = (long long)atomicAdd(&P.counters[BL_CNT_SAMPLES], (unsigned long long)P.ray_max_steps);
+  atomicAdd(&P.counters[BL_CNT_COMMITTED], (unsigned long long)P.ray_max_steps);
+  start[8 * stride] = -r;
+}
+
 // =================================================================================================
 // Launch wrappers (called from bl_api.hip)
 // =================================================================================================
+extern "C" hipError_t bl_launch_split_long(const BlTraceArgs *args, hipStream_t stream) {
+  if (args->parked == nullptr || args->ray_start == nullptr) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(bl_split_long_kernel, dim3((args->chunk_rays + 255) / 256), dim3(256), 0, stream, *args);
+  return hipGetLastError();
+}
+
 // Start states of the rays [chunk_begin, chunk_begin + chunk_rays) (bl_ray_init_kernel)
 extern "C" hipError_t bl_launch_ray_init(const BlTraceArgs *args, int integrator, hipStream_t stream) {
   const bool spin_zero = args->st.bh_a == 0.0;
@@ -785,12 +834,15 @@ extern "C" hipError_t bl_launch_ray_init(const BlTraceArgs *args, int integrator
     else DO((bl_geodesic_kernel<I, false, false, false>));                            \
   } while (0)
 
-extern "C" hipError_t bl_launch_geodesic(const BlTraceArgs *args, int integrator, int grid, hipStream_t stream) {
+// lds_pad: bytes of LDS a workgroup (= a wave) reserves without using them - 39 KiB keeps a CU to four waves, one per SIMD, where the
+// dispatcher would otherwise fill a CU's eight slots before the next CU's first (BL_TAIL_SPLIT: a CU mask that leaves a shader engine
+// one CU and another two makes it do that, and a wave that shares its SIMD steps its rays at half the speed)
+extern "C" hipError_t bl_launch_geodesic(const BlTraceArgs *args, int integrator, int grid, hipStream_t stream, int lds_pad) {
   const bool with_time = args->sample_t != nullptr;
   const bool spin_zero = args->st.bh_a == 0.0;   // also true for -0.0: the instantiation never reads bh_a
   const bool shell = args->ray_skipped != nullptr;
   if (shell && with_time) return hipErrorInvalidValue;
-#define BL_LAUNCH_G(K) hipLaunchKernelGGL(K, dim3(grid), dim3(64), 0, stream, *args)
+#define BL_LAUNCH_G(K) hipLaunchKernelGGL(K, dim3(grid), dim3(64), lds_pad, stream, *args)
   switch (integrator) {
     case BL_INTEGRATOR_DP: BL_GEODESIC_CASES(BL_INTEGRATOR_DP, BL_LAUNCH_G); break;
     case BL_INTEGRATOR_RK4: BL_GEODESIC_CASES(BL_INTEGRATOR_RK4, BL_LAUNCH_G); break;

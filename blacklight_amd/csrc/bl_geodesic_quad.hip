@@ -465,9 +465,10 @@ __global__ void __launch_bounds__(64, 2) bl_geodesic_quad_kernel(BlTraceArgs P) 
 }
 
 // The parked rays of a chunk (BL_CNT_PARKED of them, known on the device only): a grid of waves that take them sixteen at a time
-extern "C" hipError_t bl_launch_geodesic_quad(const BlTraceArgs *args, int grid, hipStream_t stream) {
+// (lds_pad: as for bl_launch_geodesic)
+extern "C" hipError_t bl_launch_geodesic_quad(const BlTraceArgs *args, int grid, hipStream_t stream, int lds_pad) {
   if (args->parked == nullptr || args->sample_t != nullptr || args->ray_skipped != nullptr) return hipErrorInvalidValue;
-  if (args->st.bh_a == 0.0) hipLaunchKernelGGL((bl_geodesic_quad_kernel<true>), dim3(grid), dim3(64), 0, stream, *args);
-  else hipLaunchKernelGGL((bl_geodesic_quad_kernel<false>), dim3(grid), dim3(64), 0, stream, *args);
+  if (args->st.bh_a == 0.0) hipLaunchKernelGGL((bl_geodesic_quad_kernel<true>), dim3(grid), dim3(64), lds_pad, stream, *args);
+  else hipLaunchKernelGGL((bl_geodesic_quad_kernel<false>), dim3(grid), dim3(64), lds_pad, stream, *args);
   return hipGetLastError();
 }

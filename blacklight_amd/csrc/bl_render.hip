@@ -154,6 +154,9 @@ struct RenderJob {
   bool tail_beside = false;   // tail_overlap, and the coefficient kernel's first pass runs beside the second launch (else after it)
   bool tail_overlap = false;  // the last rays of a chunk are parked and finished by a second launch of the geodesic kernel, beside
                               // which the coefficient kernel covers the records of the first (BlShadeArgs::record_range)
+  bool split_long = false;    // BL_TAIL_SPLIT: rays predicted long on compute units of their own (bl_split_long_kernel)
+  int split_cus = 0;          // ... how many compute units
+  double split_b_lo = 0.0, split_b_hi = 0.0;   // ... and which impact parameters
   size_t park_capacity = 0;
   int quad_grid = 0;          // waves of bl_geodesic_quad_kernel
   int n_nu = 0, n_q = 0, max_steps = 0;
@@ -163,7 +166,7 @@ struct RenderJob {
   uint64_t bytes_per_record = 0;
   size_t record_capacity = 0;
   long long record_gate = 0;
-  int n_slots = 1, geo_grid = 1;
+  int n_slots = 1, geo_grid = 1, geo_waves_per_cu = 1;
   // outputs (device pointers: the caller's, or staging)
   double *image = nullptr, *cam_pos = nullptr, *cam_dir = nullptr, *render_out = nullptr;
   int *out_num = nullptr;
@@ -322,9 +325,18 @@ void PlanJob(RenderJob &job) {
   const bool quad_wanted = ctx->tail_policy == BL_TAIL_QUAD || (ctx->tail_policy == BL_TAIL_AUTO && !job.simulation && job.n_rays >= 64 * 64);
   job.park = parkable && (quad_wanted || (ctx->switches & (BL_SWITCH_QUAD_TAIL | BL_SWITCH_QUAD_EVERY_RAY)) != 0)
       && !(ctx->switches & (BL_SWITCH_TAIL_OVERLAP | BL_SWITCH_TAIL_REPACKED));
+  // On request (a measurement switch): the rays of a plane camera's root level whose impact parameter lies in a
+  // band around the photon ring's, stepped by bl_geodesic_quad_kernel on compute units the other stepper is kept off
+  const bool split_forced = ctx->tail_policy == BL_TAIL_SPLIT || (ctx->switches & BL_SWITCH_SPLIT_LONG) != 0;
+  // (BL_TAIL_AUTO: where the geodesic stage waits for single rays - at most two rays per lane of a grid of one wave per SIMD - and the
+  // critical curve is the circle b = 3 sqrt(3) M: no spin)
+  const bool split_auto = ctx->tail_policy == BL_TAIL_AUTO && !ctx->split_unavailable && ctx->st.bh_a == 0.0 && !p.ray_flat
+      && job.n_rays >= 32768 && job.n_rays <= 2ll * 256 * ctx->num_cus;
+  job.split_long = parkable && !job.park && (split_forced || split_auto) && p.camera_type == BL_CAMERA_PLANE && d->level == 0
+      && !(ctx->switches & (BL_SWITCH_TAIL_OVERLAP | BL_SWITCH_TAIL_REPACKED));
   // On request (a measurement switch: it does not pay) the coefficient kernel runs beside the last rays
   // of a chunk: plain images whose coefficient kernel takes a range of records
-  job.tail_overlap = parkable && !job.park && (ctx->switches & (BL_SWITCH_TAIL_OVERLAP | BL_SWITCH_TAIL_REPACKED)) != 0 && !job.aux && !ctx->polarized && !job.slow
+  job.tail_overlap = parkable && !job.park && !job.split_long && (ctx->switches & (BL_SWITCH_TAIL_OVERLAP | BL_SWITCH_TAIL_REPACKED)) != 0 && !job.aux && !ctx->polarized && !job.slow
       && !job.block_interp && !job.tau_row && !job.freq_split && !job.geo_save && !job.sample_save && job.n_nu < 4
       && (job.fused2 || job.exact_fused || !job.simulation);
   // ... and in the exact coefficient kernel (plain images): the frequency loop as lanes of bl_coefficients_freq_kernel
@@ -380,7 +392,8 @@ void PlanScratch(RenderJob &job) {
   // (the waves of bl_geodesic_quad_kernel take blocks of record slots as well: a wave per SIMD)
   // (one to a SIMD: with three - as many as fit its registers - every ray runs at a third of the speed, the longest ones too, and
   // configuration 2 takes 94 ms instead of 67)
-  const long long quad_waves = job.park ? static_cast<long long>(ctx->num_cus) * 4 * ctx->quad_waves_per_simd : (job.tail_overlap ? max_grid : 0);
+  const long long quad_waves = job.park ? static_cast<long long>(ctx->num_cus) * 4 * ctx->quad_waves_per_simd
+      : (job.split_long ? 64ll * 4 : (job.tail_overlap ? max_grid : 0));   // (split: at most 64 compute units, sized below)
   const uint64_t worst_case = static_cast<uint64_t>(job.n_rays) * job.max_steps + static_cast<uint64_t>(max_grid + quad_waves) * BL_RECORD_BLOCK;
   const uint64_t fixed = per_ray * static_cast<uint64_t>(job.n_rays);
   auto capacity_for = [&](int n_slots) -> uint64_t {
@@ -412,12 +425,53 @@ void PlanScratch(RenderJob &job) {
   job.record_capacity = static_cast<size_t>(capacity);
   job.record_gate = gate;
   job.geo_grid = static_cast<int>(grid);
+  job.geo_waves_per_cu = waves_per_cu;
   job.quad_grid = static_cast<int>(quad_waves);
   // (the last rays beside the coefficient kernel: one scratch set - with two, the next chunk's rays run there already)
   if (job.n_slots != 1) job.tail_overlap = false;
   job.tail_beside = job.tail_overlap && (ctx->switches & BL_SWITCH_TAIL_OVERLAP) != 0;
   // a lane parks at most one ray (its wave ends), unless every ray is parked
   job.park_capacity = (job.park || job.tail_overlap) ? (park_every_ray ? static_cast<size_t>(job.n_rays) : static_cast<size_t>(grid) * 64) : 0;
+  // (the split is decided once for all rays of the call: only where one chunk is sure to take them all)
+  if (job.split_long && (job.n_slots != 1 || capacity < worst_case)) job.split_long = false;
+  if (job.split_long) {
+    // Which rays. Alone in a wave a ray of the benchmark camera takes 3.2 ms at b = 5.20 M, 2.3 ... 2.9 ms between 4.9 and 5.18, 2.3 ms
+    // at 5.23 and 1.8 ms at 5.3 (tools/gpu_ray_length_by_radius.py): the band reaches 0.03 M beyond the critical curve and inwards
+    // as far as the quad stepper's compute units hold it in ONE round of quads (a second round doubles its time) - a quad per ray,
+    // 16 per wave, a wave per SIMD. The compute units: an eighth of the device, bits 0 ... num_cus / 8 - 1 of the mask - on MI355X
+    // one CU of every shader engine of every XCD (tools/ubench/cu_mask_probe.hip), which leaves the other stepper's share of every
+    // shader engine equal; other counts were measured and lose (uneven shader engines fill unevenly: DESIGN.md section 5k).
+    // How densely the call's rays cover the ring is counted on the host from every 1 / stride-th of them.
+    const double centre = ctx->split_centre > 0.0 ? ctx->split_centre : 5.196152422706632 * ctx->st.bh_m;
+    const double scale = ctx->st.bh_m * p.camera_width / p.camera_resolution, half = 0.5 * p.camera_resolution - 0.5;
+    const double ref_lo = centre - 0.3 * ctx->st.bh_m, ref_hi = centre + 0.1 * ctx->st.bh_m;
+    const long long stride = std::max<long long>(1, job.n_rays / 32768);
+    long long seen = 0, inside = 0;
+    for (long long ray = 0; ray < job.n_rays; ray += stride, seen++) {
+      const long long pixel = job.d->pixel_map != nullptr ? job.d->pixel_map[ray] : ray;
+      const double u = (static_cast<double>(pixel % p.camera_resolution) - half) * scale, v = (static_cast<double>(pixel / p.camera_resolution) - half) * scale;
+      const double b = std::sqrt(u * u + v * v);
+      inside += (b >= ref_lo && b <= ref_hi) ? 1 : 0;
+    }
+    const double per_width = static_cast<double>(inside) * static_cast<double>(job.n_rays) / static_cast<double>(std::max<long long>(seen, 1)) / (ref_hi - ref_lo);
+    job.split_cus = ctx->split_cus > 0 ? std::min(ctx->split_cus, ctx->num_cus / 2) : std::max(1, ctx->num_cus / 8);
+    const double outer = 0.03 * ctx->st.bh_m;
+    double width = per_width > 0.0 ? 0.9 * 64.0 * job.split_cus / per_width : 0.0;   // of the band, for one round of quads
+    width = std::min(width, 0.45 * ctx->st.bh_m);
+    if (ctx->split_band > 0.0) {   // (BLACKLIGHT_AMD_SPLIT_BAND: a symmetric band of that half-width, for measurements)
+      job.split_b_lo = centre - ctx->split_band;
+      job.split_b_hi = centre + ctx->split_band;
+    } else if (width >= 0.08 * ctx->st.bh_m) {
+      job.split_b_lo = centre - (width - outer);
+      job.split_b_hi = centre + outer;
+    } else {
+      job.split_long = false;   // no ring in these rays, or too many rays on it for an eighth of the device
+    }
+  }
+  if (job.split_long) {
+    job.park_capacity = static_cast<size_t>(job.n_rays);
+    job.quad_grid = job.split_cus * 4;
+  }
 }
 
 void EnsureScratch(RenderJob &job) {
@@ -439,7 +493,7 @@ void EnsureScratch(RenderJob &job) {
     if (job.freq_split) sl.d_freq_inputs.Ensure(cap);   // instead of the transfer records
     else sl.d_transfer.Ensure(cap * n_nu);
     if (job.composed) sl.d_composed.Ensure(cap);
-    if (job.park || job.tail_overlap) sl.d_parked.Ensure(job.park_capacity * BL_PARK_DOUBLES);
+    if (job.park || job.tail_overlap || job.split_long) sl.d_parked.Ensure(job.park_capacity * BL_PARK_DOUBLES);
     if (job.tau_row) sl.d_tau_inc.Ensure(cap * n_nu);
     sl.d_counters.Ensure(BL_CNT_TOTAL);
     if (job.aux) sl.d_aux.Ensure(cap);
@@ -841,6 +895,7 @@ void BuildShadeArgs(RenderJob &job) {
       sa.fast_angle_band = std::max(1.0e-12, ctx->guard_band > 1.0e-8 ? ctx->guard_band : 0.0);   // (the debug switch widens both kinds of band)
     }
     sa.grid = ctx->grid_dev;
+    if (!(ctx->switches & BL_SWITCH_BRICK_CELLS)) sa.grid.bricks = nullptr;
     sa.lds_table_bytes = ctx->lds_table_bytes;
     sa.undefined_edge = (ctx->undefined_policy & BL_UNDEFINED_EDGE) ? 1 : 0;
     // Polarized runs in the tolerant tier keep the exact tier's per-frequency coefficient kernel: the reference's polarized step
@@ -971,7 +1026,12 @@ void BindChunk(RenderJob &job, int k, long long begin, int rays) {
   ta.ray_skipped = job.skip_shell ? ctx->d_ray_skipped.ptr + begin : nullptr;
   ta.segment_rows = job.composed ? 1 : 0;
   ta.ray_rows = job.composed ? ctx->d_ray_rows.ptr + begin : nullptr;
-  ta.parked = (job.park || job.tail_overlap) ? sl.d_parked.ptr : nullptr;
+  ta.parked = (job.park || job.tail_overlap || job.split_long) ? sl.d_parked.ptr : nullptr;
+  ta.split_b_lo = ta.split_b_hi = 0.0;
+  if (job.split_long) {
+    ta.split_b_lo = job.split_b_lo;
+    ta.split_b_hi = job.split_b_hi;
+  }
   ta.park_capacity = static_cast<int>(std::min<size_t>(job.park_capacity, 0x7fffffff));
   ta.park_below = ctx->park_below;
   ta.park_after = ctx->park_after;
@@ -1363,9 +1423,27 @@ void LaunchGeodesicStage(RenderJob &job, int k, long long begin, int rays, hipSt
     Check(hipStreamSynchronize(stream_geo), "kernel execution");   // the counters are reset before the host writes two of them
     job.in_flight[k].done = LoadChunkFromCheckpoint(job, k, begin, rays);
   } else {
-    Check(bl_launch_geodesic(&job.ta, ctx->params.ray_integrator, std::min(job.geo_grid, (rays + 63) / 64), stream_geo), "geodesic kernel launch");
+    if (job.split_long) {
+      // the band's rays parked; then the two steppers side by side on disjoint compute units, and the stage ends with both
+      hipEvent_t *ev = SlotEvents(job, k);
+      Check(bl_launch_split_long(&job.ta, stream_geo), "split kernel launch");
+      Check(hipEventRecord(ev[7], stream_geo), "event");
+      Check(hipStreamWaitEvent(ctx->stream_most, ev[7], 0), "stream wait");
+      Check(hipStreamWaitEvent(ctx->stream_few, ev[7], 0), "stream wait");
+      // (as many waves per SIMD as the unsplit launch would have had: a wave that shares its SIMD steps its rays more slowly)
+      const int per_simd = std::max(1, (std::min(job.geo_grid, (rays + 63) / 64) + ctx->num_cus * 4 - 1) / (ctx->num_cus * 4));
+      const int wide_grid = std::min(std::min(job.geo_grid, (rays + 63) / 64), (ctx->num_cus - job.split_cus) * 4 * per_simd);
+      const int pad = per_simd == 1 ? ctx->split_lds_pad : 0;
+      Check(bl_launch_geodesic(&job.ta, ctx->params.ray_integrator, std::max(wide_grid, 1), ctx->stream_most, pad), "geodesic kernel launch");
+      Check(bl_launch_geodesic_quad(&job.ta, job.quad_grid, ctx->stream_few, ctx->split_lds_pad), "geodesic quad kernel launch");
+      Check(hipEventRecord(ev[8], ctx->stream_most), "event");
+      Check(hipEventRecord(ev[9], ctx->stream_few), "event");
+      Check(hipStreamWaitEvent(stream_geo, ev[8], 0), "stream wait");
+      Check(hipStreamWaitEvent(stream_geo, ev[9], 0), "stream wait");
+    } else
+    Check(bl_launch_geodesic(&job.ta, ctx->params.ray_integrator, std::min(job.geo_grid, (rays + 63) / 64), stream_geo, 0), "geodesic kernel launch");
     // the rays it parked, sixteen to a wave, a wave per SIMD (waves that find none end at once)
-    if (job.park) Check(bl_launch_geodesic_quad(&job.ta, job.quad_grid, stream_geo), "geodesic quad kernel launch");
+    if (job.park) Check(bl_launch_geodesic_quad(&job.ta, job.quad_grid, stream_geo, 0), "geodesic quad kernel launch");
     if (job.tail_overlap) {
       // what the first launch left: the number of its records, for the coefficient kernel that starts now on the other stream;
       // then the parked rays, by the same stepper
@@ -1456,6 +1534,14 @@ void CollectChunk(RenderJob &job, int k) {
   float ms = 0.0f;
   Check(hipEventElapsedTime(&ms, e[0], e[1]), "event time"); job.ms_geo += ms;
   Check(hipEventElapsedTime(&ms, e[2], e[3]), "event time"); job.ms_locate += ms;
+  if (job.split_long && ctx->debug_counters) {
+    float a = 0, b = 0, c = 0;
+    (void)hipEventElapsedTime(&a, e[0], e[7]);
+    (void)hipEventElapsedTime(&b, e[0], e[8]);
+    (void)hipEventElapsedTime(&c, e[0], e[9]);
+    std::fprintf(stderr, "split long: rays parked by %.3f ms, wide stepper done at %.3f ms, quad stepper at %.3f ms; %llu rays with b in [%.3f, %.3f] M on %d CUs\n", a, b, c, hc[BL_CNT_PARKED],
+                 job.split_b_lo, job.split_b_hi, job.split_cus);
+  }
   if (job.tail_beside && ctx->debug_counters) {
     float a = 0, b = 0, c = 0, d = 0, f = 0;
     (void)hipEventElapsedTime(&a, e[0], e[7]);
@@ -1599,7 +1685,7 @@ void FinishStats(RenderJob &job) {
   st.fused_variant = job.fused ? (job.fused2 ? 2 : 1) : (job.exact_fused ? 3 : 0);
   st.n_parked = static_cast<int64_t>(job.total_parked);
   st.composed_maps = job.composed ? 1 : 0;
-  st.tail_policy = job.park ? BL_TAIL_QUAD : BL_TAIL_WIDE;
+  st.tail_policy = job.park ? BL_TAIL_QUAD : (job.split_long ? BL_TAIL_SPLIT : BL_TAIL_WIDE);
   ctx->stats = st;
   if (ctx->debug_counters) {   // kernels built with -DBL_GEO_STATS fill these
     std::fprintf(stderr, "debug counters:");
@@ -1644,6 +1730,29 @@ void SlowLightMessages(RenderJob &job) {
 
 }  // namespace
 
+namespace {
+// BL_TAIL_SPLIT: two streams whose CU masks partition the device - bit c of a mask = compute unit c may run the stream's kernels -
+// `cus` compute units for bl_geodesic_quad_kernel, the rest for bl_geodesic_kernel. False when the runtime refuses.
+bool EnsureSplitStreams(bl_ctx *ctx, int cus) {
+  if (ctx->stream_few != nullptr && ctx->split_cus_made == cus) return true;
+  if (ctx->stream_few != nullptr) (void)hipStreamDestroy(ctx->stream_few);
+  if (ctx->stream_most != nullptr) (void)hipStreamDestroy(ctx->stream_most);
+  ctx->stream_few = ctx->stream_most = nullptr;
+  const int words = (ctx->num_cus + 31) / 32;
+  std::vector<uint32_t> few(words, 0u), most(words, 0u);
+  for (int c = 0; c < ctx->num_cus; c++) (c < cus ? few : most)[c / 32] |= 1u << (c % 32);
+  if (hipExtStreamCreateWithCUMask(&ctx->stream_few, static_cast<uint32_t>(words), few.data()) != hipSuccess
+      || hipExtStreamCreateWithCUMask(&ctx->stream_most, static_cast<uint32_t>(words), most.data()) != hipSuccess) {
+    (void)hipGetLastError();
+    if (ctx->stream_few != nullptr) (void)hipStreamDestroy(ctx->stream_few);
+    ctx->stream_few = ctx->stream_most = nullptr;
+    return false;
+  }
+  ctx->split_cus_made = cus;
+  return true;
+}
+}  // namespace
+
 namespace blhost {
 void EnsureStreams(bl_ctx *ctx) {
   if (ctx->stream == nullptr) Check(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking), "hipStreamCreate");
@@ -1661,6 +1770,13 @@ extern "C" int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
     Check(hipSetDevice(ctx->device), "hipSetDevice");
     EnsureStreams(ctx);
     PlanScratch(job);
+    if (job.split_long && !EnsureSplitStreams(ctx, job.split_cus)) {
+      if (ctx->tail_policy == BL_TAIL_SPLIT) throw Failure{BL_E_DEVICE, "BL_TAIL_SPLIT: the runtime gave no stream with a CU mask (hipExtStreamCreateWithCUMask)."};
+      ctx->split_unavailable = true;   // BL_TAIL_AUTO: the one-stepper path, from now on
+      job.split_long = false;
+      job.park_capacity = 0;
+      job.quad_grid = 0;
+    }
     EnsureScratch(job);
     StageInputsAndOutputs(job);
     BuildTraceArgs(job);
@@ -1674,6 +1790,8 @@ extern "C" int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
     if (job.slow) SlowLightMessages(job);
   } catch (const Failure &failure) {
     // leave no chunk half collected behind: a later call starts from idle streams
+    if (ctx->stream_few != nullptr) (void)hipStreamSynchronize(ctx->stream_few);
+    if (ctx->stream_most != nullptr) (void)hipStreamSynchronize(ctx->stream_most);
     (void)hipStreamSynchronize(ctx->stream_geo);
     (void)hipStreamSynchronize(ctx->stream);
     return Fail(ctx, failure);

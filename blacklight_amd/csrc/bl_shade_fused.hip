@@ -364,6 +364,19 @@ __device__ __forceinline__ void gather_issue(const char *cells, uint32_t cell_by
   }
 }
 
+// The same sixteen loads from a BRICK (BlGridDevice::bricks): the eight corner cells of anchor cell c pre-gathered into 256 contiguous,
+// 256-byte-aligned bytes at c x 256 (corner = 4 dk + 2 dj + di, as above) - two whole 128-byte lines per sample instead of four
+// 64-byte segments in four rows, one address per sample, sixteen immediate offsets. A measurement (BL_SWITCH_BRICK_CELLS; DESIGN.md
+// section 6): eight times the cell array, and neighbouring anchors no longer share lines.
+__device__ __forceinline__ void gather_issue_bricks(const char *bricks, uint32_t cell_bytes, float4 (&lo)[8], float4 (&hi)[8]) {
+  const float4 *p = reinterpret_cast<const float4 *>(bricks + (size_t)(cell_bytes << 3));   // (cell x 256 < 2^32: bl_set_grid)
+#pragma unroll
+  for (int corner = 0; corner < 8; corner++) {
+    lo[corner] = p[2 * corner];
+    hi[corner] = p[2 * corner + 1];
+  }
+}
+
 // gather_finish_tolerant() for an interpolated sample (bl_shade_fast.hip): the trilinear read with fused multiply-adds, the <= 0
 // rule, the rounding to float; true when a sum lies too close to the midpoint of two floats for the tier to decide the rounding
 __device__ __forceinline__ bool trilinear(const float4 (&lo)[8], const float4 (&hi)[8], double f_i, double f_j, double f_k, float pr[8]) {
@@ -567,7 +580,7 @@ __device__ __forceinline__ double2 shade(const BlSpacetime &st, const double (&K
 // read. A wave that holds a sample left to the exact kernel, or an optically thick step (whose map replaces what lies behind it,
 // a NaN included: not a product of numbers), writes its samples' own records instead, by record index, and marks its segments'
 // rows as standing for those (BL_COMPOSED_EXPANDED).
-template <bool kSpinZero, bool kComposed>
+template <bool kSpinZero, bool kComposed, bool kBricks = false>
 __global__ void __launch_bounds__(256, BL_FAST_WAVES) bl_shade_fused2_kernel(const BlShadeArgs P) {
   using namespace fused2;
   extern __shared__ double lds[];
@@ -607,7 +620,7 @@ __global__ void __launch_bounds__(256, BL_FAST_WAVES) bl_shade_fused2_kernel(con
   const double freq_inv = uniform_value(fastmath::rcp(freq));
   const double x_unit = P.x_unit;
   const bool fallback_nan = P.plasma.fallback_nan != 0;
-  const char *cells = reinterpret_cast<const char *>(P.grid.cells);
+  const char *cells = reinterpret_cast<const char *>(kBricks ? P.grid.bricks : P.grid.cells);
   const uint32_t row_bytes = (uint32_t)P.grid.stride_row * 32u, plane_bytes = (uint32_t)P.grid.stride_plane * 32u;
   const char *ray_kt = reinterpret_cast<const char *>(P.ray_kt), *ray_factor = reinterpret_cast<const char *>(P.ray_factor);
   const char *ray_offset = reinterpret_cast<const char *>(P.ray_offset);
@@ -663,7 +676,8 @@ __global__ void __launch_bounds__(256, BL_FAST_WAVES) bl_shade_fused2_kernel(con
     float pr[8];
     const bool near_midpoint = trilinear(lo, hi, loc_prev.f_i, loc_prev.f_j, loc_prev.f_k, pr);
     gathers_wave += (unsigned long long)__popcll(__ballot(interp));
-    fused2::gather_issue(cells, loc_cur.cell_bytes, (loc_cur.status & 0xffu) == (uint32_t)kSampleInterp, row_bytes, plane_bytes, lo, hi);
+    if (kBricks) fused2::gather_issue_bricks(cells, loc_cur.cell_bytes, lo, hi);
+    else fused2::gather_issue(cells, loc_cur.cell_bytes, (loc_cur.status & 0xffu) == (uint32_t)kSampleInterp, row_bytes, plane_bytes, lo, hi);
     double2 cold0, cold1;
     {
       const double2 *rec = reinterpret_cast<const double2 *>(record_base(base_index) + (size_t)(cur_in ? lane_bytes : 0u));
@@ -1021,10 +1035,32 @@ extern "C" hipError_t bl_launch_shade_fused2(const BlShadeArgs *args, int grid, 
   const size_t lds = 48 * sizeof(double) + 64 * (size_t)(g.n[0] + g.n[1] + g.n[2]);
   const bool spin_zero = args->st.bh_a == 0.0, composed = args->composed != nullptr;
 #define BL_LAUNCH_F2(S, C) hipLaunchKernelGGL((bl_shade_fused2_kernel<S, C>), dim3(grid), dim3(256), lds, stream, *args)
-  if (spin_zero && composed) BL_LAUNCH_F2(true, true);
+  if (spin_zero && composed && g.bricks != nullptr) hipLaunchKernelGGL((bl_shade_fused2_kernel<true, true, true>), dim3(grid), dim3(256), lds, stream, *args);
+  else if (spin_zero && composed) BL_LAUNCH_F2(true, true);
   else if (spin_zero) BL_LAUNCH_F2(true, false);
   else if (composed) BL_LAUNCH_F2(false, true);
   else BL_LAUNCH_F2(false, false);
 #undef BL_LAUNCH_F2
+  return hipGetLastError();
+}
+
+// BlGridDevice::bricks from BlGridDevice::cells (one block, [k][j][i][8 floats]): the eight corner cells of every anchor cell side by
+// side, corner = 4 dk + 2 dj + di; neighbours beyond the last cell of an axis are that cell (no anchor of an interpolated sample
+// lies there). One thread per (anchor cell, corner, half cell).
+__global__ void __launch_bounds__(256) bl_build_bricks_kernel(const float4 *cells, float4 *bricks, int n_i, int n_j, int n_k) {
+  const unsigned long long total = (unsigned long long)n_i * n_j * n_k * 16ull;
+  const unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const unsigned long long cell = t >> 4;
+  const int part = (int)(t & 15), corner = part >> 1, half = part & 1;
+  const int i = (int)(cell % n_i), j = (int)(cell / n_i % n_j), k = (int)(cell / ((unsigned long long)n_i * n_j));
+  const int ii = i + (corner & 1) < n_i ? i + (corner & 1) : n_i - 1, jj = j + ((corner >> 1) & 1) < n_j ? j + ((corner >> 1) & 1) : n_j - 1;
+  const int kk = k + (corner >> 2) < n_k ? k + (corner >> 2) : n_k - 1;
+  bricks[t] = cells[(((unsigned long long)kk * n_j + jj) * n_i + ii) * 2ull + half];
+}
+extern "C" hipError_t bl_launch_build_bricks(const float *cells, float *bricks, int n_i, int n_j, int n_k, hipStream_t stream) {
+  const unsigned long long total = (unsigned long long)n_i * n_j * n_k * 16ull;
+  hipLaunchKernelGGL(bl_build_bricks_kernel, dim3((unsigned int)((total + 255ull) / 256ull)), dim3(256), 0, stream, reinterpret_cast<const float4 *>(cells),
+                     reinterpret_cast<float4 *>(bricks), n_i, n_j, n_k);
   return hipGetLastError();
 }

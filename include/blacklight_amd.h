@@ -311,6 +311,8 @@ typedef struct bl_stats {
 #define BL_SWITCH_QUAD_TAIL (1u << 10)                      /* the last rays of a chunk finished by bl_geodesic_quad_kernel (a ray per quad of lanes) */
 #define BL_SWITCH_QUAD_EVERY_RAY (1u << 11)                 /* every ray parked before its first step: all stepping in bl_geodesic_quad_kernel */
 #define BL_SWITCH_TAIL_OVERLAP (1u << 12)                   /* the coefficient kernel beside the last rays of a chunk (a second geodesic launch)  */
+#define BL_SWITCH_BRICK_CELLS (1u << 14)                    /* bl_set_grid also stores every anchor cell's 2 x 2 x 2 stencil contiguously (8 x the cells), bl_shade_fused2_kernel gathers from it */
+#define BL_SWITCH_SPLIT_LONG (1u << 15)                     /* rays predicted long (a band of impact parameters around the photon ring) stepped by bl_geodesic_quad_kernel on compute units of their own from the first moment */
 #define BL_SWITCH_TAIL_REPACKED (1u << 13)                  /* the last rays of a chunk repacked into full waves by a second geodesic launch, nothing beside it */
 
 typedef struct bl_ctx bl_ctx;
@@ -385,14 +387,21 @@ BL_API int bl_set_arithmetic(bl_ctx *ctx, int mode);
  * bl_render calls, ranks or chunks, like the reference's are across thread counts (blacklight.cpp:196-233 is one deterministic
  * loop). Costs ~1.5 % of the benchmark frame. bl_stats.composed_maps says which way the last render went. */
 BL_API int bl_set_reproducible(bl_ctx *ctx, int on);
-/* Who finishes the last rays of a chunk of geodesics (per-ray independence, geodesics.cpp:109-324; the results are bit-identical
- * either way, only the time differs). BL_TAIL_WIDE: the persistent one-ray-per-lane stepper alone. BL_TAIL_QUAD: it parks rays
- * that outlive their neighbours and bl_geodesic_quad_kernel finishes them with a ray per quad of lanes (1.5 - 1.65 x faster per
- * ray; pays where a few rays run for thousands of steps - formula-mode frames - and costs where they do not). BL_TAIL_AUTO
- * (default): QUAD in formula mode, WIDE over a simulation grid. */
+/* Who steps the rays a chunk of geodesics waits for longest (per-ray independence, geodesics.cpp:109-324; the results are
+ * bit-identical whichever way, only the time differs). BL_TAIL_WIDE: the persistent one-ray-per-lane stepper alone.
+ * BL_TAIL_QUAD: it parks rays that outlive their neighbours and bl_geodesic_quad_kernel finishes them with a ray per quad of
+ * lanes (1.5 - 1.65 x faster per ray; pays where a few rays run for thousands of steps - formula-mode frames - and costs where
+ * they do not). BL_TAIL_SPLIT: the rays of a plane camera whose impact parameter lies within 0.12 M of the photon ring's
+ * 3 sqrt(3) M - the longest of a frame by a factor of two - are given to bl_geodesic_quad_kernel before their first step, on a
+ * stream whose CU mask keeps the other stepper off its compute units (hipExtStreamCreateWithCUMask); pays where the geodesic
+ * stage waits for single rays - a rank's share of a tiled frame: an eighth of the benchmark frame 8.0 -> 7.2 ms - and needs a
+ * non-rotating hole (the critical curve is a circle), the Dormand-Prince stepper and a call whose rays fit one chunk.
+ * BL_TAIL_AUTO (default): QUAD in formula mode; SPLIT where it applies and the call has at most two rays per lane of the
+ * device; else WIDE. bl_stats.tail_policy says what the last render did. */
 #define BL_TAIL_AUTO 0
 #define BL_TAIL_WIDE 1
 #define BL_TAIL_QUAD 2
+#define BL_TAIL_SPLIT 3
 BL_API int bl_set_tail_policy(bl_ctx *ctx, int policy);
 /* Ordering against the caller's own GPU work. bl_render runs on streams of its own (non-blocking: the NULL stream does not order
  * them) and returns when its outputs are complete, so nothing the caller does AFTER the call needs ordering. What the caller

@@ -9,6 +9,7 @@ defaults, the choices that trade a property away are API calls whose effect bl_s
 """
 import numpy as np
 import pytest
+import torch   # (before the library: torch brings a HIP runtime of its own, which has to be the one the process loads first)
 
 import golden_util as gu
 
@@ -84,8 +85,8 @@ def test_formula_frames_take_the_quad_tail_by_default():
 
 def test_render_waits_for_the_callers_stream():
     """A fill queued on a torch stream just before the render must not land after the render's own writes."""
-    import torch
     import blacklight_amd as bl
+    torch.cuda.init()
     p, grid = _benchmark_like(64, 32)
     with bl.Context(p) as ctx:
         ctx.set_grid(grid)
@@ -105,3 +106,29 @@ def test_render_waits_for_the_callers_stream():
         torch.cuda.synchronize()
         assert np.array_equal(sample_num.cpu().numpy(), want["sample_num"])
         assert gu.same_bits(image.cpu().numpy(), want["image"]).all()
+
+
+def test_a_share_of_a_frame_takes_the_split_steppers_by_default():
+    """BL_TAIL_AUTO over a simulation grid: a call with at most two rays per lane of the device, a plane camera and no spin gives the
+    photon ring's rays to the quad stepper on compute units of its own (BL_TAIL_SPLIT) - same bits; with spin, or more rays, it does not."""
+    import blacklight_amd as bl
+    p, grid = _benchmark_like(256, 32)
+    with bl.Context(p) as ctx:
+        ctx.set_grid(grid)
+        auto = ctx.render()
+        assert auto["stats"].tail_policy == 3 and auto["stats"].switches == 0 and 0 < auto["stats"].n_parked < 4096
+        ctx.set_tail_policy("wide")
+        wide = ctx.render()
+        assert wide["stats"].tail_policy == 1 and wide["stats"].n_parked == 0
+        assert np.array_equal(auto["sample_num"], wide["sample_num"]) and np.array_equal(auto["sample_flags"], wide["sample_flags"])
+        assert gu.same_bits(auto["image"], wide["image"]).all()
+        ctx.set_tail_policy("auto")
+        # a window of the frame that the ring does not cross: nothing to split
+        corner = (np.arange(64)[:, None] * 256 + np.arange(64)[None, :]).reshape(-1).astype(np.int32)
+        corner = np.tile(corner, 8)   # (32 768 rays, so that the size alone would qualify)
+        assert ctx.render(pixel_map=corner)["stats"].tail_policy == 1
+    import bench
+    from blacklight_amd import mock
+    with bl.Context(bl.Params.from_dict(dict(bench.WORKLOAD, camera_resolution=256, simulation_a=0.5))) as ctx:
+        ctx.set_grid(mock.generate(n_r=32, n_th=32, n_ph=32))
+        assert ctx.render()["stats"].tail_policy == 1

@@ -14,6 +14,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _three_ways(ctx, extra=()):
+    ctx.set_tail_policy("wide")   # the baseline is the ray-per-lane stepper alone (BL_TAIL_AUTO would park rays of formula frames itself)
     out = {}
     for name, switches in (("lane", ()), ("tail", ("QUAD_TAIL",)), ("quad", ("QUAD_EVERY_RAY",))):
         ctx.debug_set_switches(*switches, *extra)
@@ -101,6 +102,7 @@ def test_the_last_rays_of_a_frame_are_parked():
 # ---- the coefficient kernel beside the last rays of a chunk (BL_SWITCH_TAIL_OVERLAP; bl_render.hip: tail_overlap)
 
 def _overlap_on_off(ctx, extra=()):
+    ctx.set_tail_policy("wide")
     out = {}
     for name, switches in (("off", ()), ("on", ("TAIL_OVERLAP",))):
         ctx.debug_set_switches(*switches, *extra)
@@ -162,3 +164,33 @@ def test_simulation_frames_with_the_coefficient_kernel_beside_the_last_rays(seed
             _assert_overlap_equal(out, tier, over)
             if seed < 2:
                 assert out["on"]["stats"].fused_variant == (3 if tier == "exact" else 2), out["on"]["stats"].fused_variant
+
+
+@pytest.mark.parametrize("spin", [0.0, 0.7])
+def test_rays_predicted_long_on_their_own_compute_units(spin):
+    """BL_TAIL_SPLIT: the rays whose impact parameter lies in the band around the photon ring's are parked before their first
+    step and stepped by bl_geodesic_quad_kernel on a CU-masked stream beside the other stepper (hipExtStreamCreateWithCUMask): the
+    same frame, bit for bit in the exact tier, to rounding in the tolerant one."""
+    import bench
+    import blacklight_amd as bl
+    from blacklight_amd import mock
+    params = dict(bench.WORKLOAD, camera_resolution=128, simulation_a=spin)
+    grid = mock.generate(n_r=32, n_th=32, n_ph=32)
+    with bl.Context(bl.Params.from_dict(params)) as ctx:
+        ctx.set_grid(grid)
+        for tier in ("exact", "tolerant"):
+            ctx.set_arithmetic(tier)
+            ctx.set_tail_policy("wide")
+            plain = ctx.render()
+            ctx.set_tail_policy("split")
+            split = ctx.render()
+            assert plain["stats"].tail_policy == 1 and split["stats"].tail_policy == 3
+            assert plain["stats"].n_parked == 0 and 100 < split["stats"].n_parked < 128 * 128 // 4, split["stats"].n_parked
+            assert np.array_equal(split["sample_num"], plain["sample_num"]) and np.array_equal(split["sample_flags"], plain["sample_flags"])
+            assert split["stats"].n_samples == plain["stats"].n_samples and split["stats"].n_gathers == plain["stats"].n_gathers
+            if tier == "exact":
+                assert gu.same_bits(split["image"], plain["image"]).all()
+            else:
+                assert np.array_equal(np.isnan(split["image"]), np.isnan(plain["image"]))
+                with np.errstate(invalid="ignore"):
+                    assert np.nanmax(np.abs(split["image"] - plain["image"])) <= 1.0e-13 * np.nanmax(np.abs(plain["image"]))

@@ -17,7 +17,7 @@ grid = mock.generate(n_r=64, n_th=64, n_ph=64)
 with bl.Context(bl.Params.from_dict(dict(bench.WORKLOAD))) as ctx:
     ctx.set_grid(grid)
     ctx.set_arithmetic("exact")
-    for b in list(np.arange(0.5, 4.0, 0.5)) + list(np.arange(4.0, 7.01, 0.2)) + list(np.arange(7.5, 12.1, 0.5)):
+    for b in (list(np.arange(0.5, 4.0, 0.5)) + list(np.arange(4.0, 7.01, 0.2)) + list(np.arange(7.5, 12.1, 0.5)) if not os.environ.get("FINE") else list(np.arange(4.9, 5.7, 0.025))):
         ang = np.linspace(0.0, 2.0 * np.pi, 64, endpoint=False)
         r_px = b / width * res
         m1 = np.clip(np.round(res / 2 - 0.5 + r_px * np.cos(ang)).astype(np.int64), 0, res - 1)
