@@ -971,8 +971,7 @@ void bl_free(bl_ctx *ctx) {
   if (ctx->caller_event != nullptr) (void)hipEventDestroy(ctx->caller_event);
   if (ctx->stream != nullptr) (void)hipStreamDestroy(ctx->stream);
   if (ctx->stream_geo != nullptr) (void)hipStreamDestroy(ctx->stream_geo);
-  if (ctx->stream_few != nullptr) (void)hipStreamDestroy(ctx->stream_few);
-  if (ctx->stream_most != nullptr) (void)hipStreamDestroy(ctx->stream_most);
+  // (stream_few / stream_most are the process's, borrowed: EnsureSplitStreams)
   delete ctx;
 }
 

@@ -124,7 +124,7 @@ struct bl_ctx {
   hipStream_t stream_geo = nullptr;   // geodesic kernel of the next chunk, concurrent with the above
   // BL_SWITCH_SPLIT_LONG: two streams whose CU masks partition the device - split_cus compute units for bl_geodesic_quad_kernel
   // and the rays predicted long, the rest for bl_geodesic_kernel (hipExtStreamCreateWithCUMask)
-  hipStream_t stream_few = nullptr, stream_most = nullptr;
+  hipStream_t stream_few = nullptr, stream_most = nullptr;   // (borrowed from a process-wide table, never destroyed: bl_render.hip)
   int split_cus = 0;                  // BLACKLIGHT_AMD_SPLIT_CUS: compute units of the quad stepper; 0 = an eighth of the device
   int split_cus_made = 0;             // ... of the streams that exist
   int split_lds_pad = 39 * 1024;      // BLACKLIGHT_AMD_SPLIT_LDS_PAD: LDS a wave of either stepper reserves so that a CU takes four of them, one per SIMD

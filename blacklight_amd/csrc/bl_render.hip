@@ -474,7 +474,22 @@ void PlanScratch(RenderJob &job) {
   }
 }
 
+void EnsureScratchOnce(RenderJob &job);
+// The budget counts what the context already holds as available (PlanScratch); arrays of an earlier render in another mode - per-
+// frequency transfer records where this one wants per-sample factors - are not among those this render grows. When an allocation
+// fails, everything the scratch sets hold goes back to the device and the render's own arrays are allocated afresh.
 void EnsureScratch(RenderJob &job) {
+  try {
+    EnsureScratchOnce(job);
+  } catch (const Failure &) {
+    (void)hipGetLastError();
+    job.ctx->slot[0].Free();
+    job.ctx->slot[1].Free();
+    EnsureScratchOnce(job);
+  }
+}
+
+void EnsureScratchOnce(RenderJob &job) {
   bl_ctx *ctx = job.ctx;
   const size_t cap = job.record_capacity;
   const size_t n_nu = static_cast<size_t>(job.n_nu);
@@ -1733,21 +1748,31 @@ void SlowLightMessages(RenderJob &job) {
 namespace {
 // BL_TAIL_SPLIT: two streams whose CU masks partition the device - bit c of a mask = compute unit c may run the stream's kernels -
 // `cus` compute units for bl_geodesic_quad_kernel, the rest for bl_geodesic_kernel. False when the runtime refuses.
+// The pair belongs to the PROCESS, one per (device, cus), and is never destroyed: contexts borrow it. (Destroying a CU-masked
+// stream leaves its queue in the runtime's list - ROCr 7.0 as torch ships it: the next device allocation that has to trim scratch,
+// GpuAgent::Trim -> AqlQueue::AsyncReclaimMainScratch, walks into it. Found by the -m gpu suite, 300 contexts into the run. Two
+// contexts of one device that render at once share the pair; their kernels queue behind each other there, which orders nothing
+// that the events of each call do not order already.)
 bool EnsureSplitStreams(bl_ctx *ctx, int cus) {
   if (ctx->stream_few != nullptr && ctx->split_cus_made == cus) return true;
-  if (ctx->stream_few != nullptr) (void)hipStreamDestroy(ctx->stream_few);
-  if (ctx->stream_most != nullptr) (void)hipStreamDestroy(ctx->stream_most);
-  ctx->stream_few = ctx->stream_most = nullptr;
-  const int words = (ctx->num_cus + 31) / 32;
-  std::vector<uint32_t> few(words, 0u), most(words, 0u);
-  for (int c = 0; c < ctx->num_cus; c++) (c < cus ? few : most)[c / 32] |= 1u << (c % 32);
-  if (hipExtStreamCreateWithCUMask(&ctx->stream_few, static_cast<uint32_t>(words), few.data()) != hipSuccess
-      || hipExtStreamCreateWithCUMask(&ctx->stream_most, static_cast<uint32_t>(words), most.data()) != hipSuccess) {
-    (void)hipGetLastError();
-    if (ctx->stream_few != nullptr) (void)hipStreamDestroy(ctx->stream_few);
-    ctx->stream_few = ctx->stream_most = nullptr;
-    return false;
+  static std::mutex table_lock;
+  static std::map<std::pair<int, int>, std::pair<hipStream_t, hipStream_t>> table;
+  std::lock_guard<std::mutex> guard(table_lock);
+  auto found = table.find({ctx->device, cus});
+  if (found == table.end()) {
+    const int words = (ctx->num_cus + 31) / 32;
+    std::vector<uint32_t> few(words, 0u), most(words, 0u);
+    for (int c = 0; c < ctx->num_cus; c++) (c < cus ? few : most)[c / 32] |= 1u << (c % 32);
+    hipStream_t stream_few = nullptr, stream_most = nullptr;
+    if (hipExtStreamCreateWithCUMask(&stream_few, static_cast<uint32_t>(words), few.data()) != hipSuccess
+        || hipExtStreamCreateWithCUMask(&stream_most, static_cast<uint32_t>(words), most.data()) != hipSuccess) {
+      (void)hipGetLastError();
+      return false;   // (a first stream that was made stays: see above)
+    }
+    found = table.emplace(std::make_pair(ctx->device, cus), std::make_pair(stream_few, stream_most)).first;
   }
+  ctx->stream_few = found->second.first;
+  ctx->stream_most = found->second.second;
   ctx->split_cus_made = cus;
   return true;
 }

@@ -106,6 +106,8 @@ def test_render_waits_for_the_callers_stream():
         torch.cuda.synchronize()
         assert np.array_equal(sample_num.cpu().numpy(), want["sample_num"])
         assert gu.same_bits(image.cpu().numpy(), want["image"]).all()
+        del ballast, image, sample_num
+        torch.cuda.empty_cache()   # (the suite's large-frame tests size their scratch by what is free)
 
 
 def test_a_share_of_a_frame_takes_the_split_steppers_by_default():
