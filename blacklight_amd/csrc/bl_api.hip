@@ -367,6 +367,7 @@ int bl_init(const bl_params *p, int device, bl_ctx **out) {
       ctx->tail_policy = name == "wide" ? BL_TAIL_WIDE : (name == "quad" ? BL_TAIL_QUAD : (name == "split" ? BL_TAIL_SPLIT : BL_TAIL_AUTO));
     }
     if (const char *cus = std::getenv("BLACKLIGHT_AMD_SPLIT_CUS")) ctx->split_cus = std::max(0, std::min(128, std::atoi(cus)));
+    if (const char *blocks = std::getenv("BLACKLIGHT_AMD_POLCOEF_BLOCKS")) ctx->polcoef_blocks_per_cu = std::max(1, std::min(64, std::atoi(blocks)));
     if (const char *pad = std::getenv("BLACKLIGHT_AMD_SPLIT_LDS_PAD")) ctx->split_lds_pad = std::max(0, std::min(64 * 1024, std::atoi(pad)));
     if (const char *band = std::getenv("BLACKLIGHT_AMD_SPLIT_BAND")) ctx->split_band = std::max(0.0, std::atof(band));
     if (const char *centre = std::getenv("BLACKLIGHT_AMD_SPLIT_CENTRE")) ctx->split_centre = std::max(0.0, std::atof(centre));
@@ -393,6 +394,9 @@ int bl_init(const bl_params *p, int device, bl_ctx **out) {
     hipDeviceProp_t prop;
     Check(hipGetDeviceProperties(&prop, device), "hipGetDeviceProperties");
     ctx->num_cus = prop.multiProcessorCount;
+    // scratch for sample records: four fifths of the device's memory unless bl_set_scratch_limit says otherwise (MI355X: 230 of
+    // 288 GB - a 1024^2 full-Stokes frame in two chunks; whatever a render plans is capped by what is actually free)
+    ctx->scratch_limit = static_cast<uint64_t>(0.8 * static_cast<double>(prop.totalGlobalMem));
     EnsureStreams(ctx);
   } catch (const Failure &failure) {
     int code = Fail(nullptr, failure);

@@ -54,6 +54,29 @@ __global__ void __launch_bounds__(256, 2) bl_polarized_coefficients_kernel(const
         if (sh.have_coefficients) simulation_coefficients<true>(P, sh, freq, momentum_factor, &j_val, &alpha_val);
         polarized_coefficients(P, sh, freq, momentum_factor, j_val, alpha_val, pc);
       }
+#ifdef BL_POL_CONDITION_STATS
+      // (a measurement build, tools/build_variant.sh -DBL_POL_CONDITION_STATS: how many samples' joint coupling step - polarized.cpp:
+      // 657-778 - loses more than 2, 3, 4, 6 digits to the cancellations in lambda_1, lambda_2 = sqrt(lambda_a +- lambda_b) and in
+      // 1 / (alpha_I^2 - lambda_1^2); BL_CNT_DEBUG + 0 ... 3, samples with coefficients in + 4, with rho and alpha_P both non-zero in + 5)
+      if (sh.have_coefficients) {
+        const double a_sq = pc[1].x * pc[1].x + pc[1].y * pc[1].y, r_sq = pc[2].x * pc[2].x + pc[2].y * pc[2].y;
+        const double a_r = pc[1].x * pc[2].x + pc[1].y * pc[2].y;
+        const double lb = 0.5 * (a_sq - r_sq), la = sqrt(lb * lb + a_r * a_r);
+        const double l1_sq = la + lb, l2_sq = la - lb;
+        double kappa = 1.0;
+        if (a_sq > 0.0 && r_sq > 0.0) {
+          kappa = fmax(kappa, la / fabs(l1_sq));
+          kappa = fmax(kappa, la / fabs(l2_sq));
+          kappa = fmax(kappa, alpha_val * alpha_val / fabs(alpha_val * alpha_val - l1_sq));
+        }
+        atomicAdd(&P.counters[BL_CNT_DEBUG + 4], 1ull);
+        if (a_sq > 0.0 && r_sq > 0.0) atomicAdd(&P.counters[BL_CNT_DEBUG + 5], 1ull);
+        if (!(kappa < 1e2)) atomicAdd(&P.counters[BL_CNT_DEBUG + 0], 1ull);
+        if (!(kappa < 1e3)) atomicAdd(&P.counters[BL_CNT_DEBUG + 1], 1ull);
+        if (!(kappa < 1e4)) atomicAdd(&P.counters[BL_CNT_DEBUG + 2], 1ull);
+        if (!(kappa < 1e6)) atomicAdd(&P.counters[BL_CNT_DEBUG + 3], 1ull);
+      }
+#endif
       P.transfer[at + l] = make_double2(j_val, alpha_val);
       double2 *out = P.pol_coeffs + (at + l) * 3;
       out[0] = pc[0];

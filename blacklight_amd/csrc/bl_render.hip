@@ -149,6 +149,7 @@ struct RenderJob {
   bool fused2 = false;  // ... the benchmark's case of it: bl_shade_fused2_kernel (bl_shade_fused.hip)
   bool composed = false;   // ... writing one affine transfer map per ray segment instead of one per sample (BlShadeArgs::composed)
   bool exact_fused = false;   // exact tier, the same grids, plain image at one frequency: bl_shade_exact2_kernel locates its samples itself
+  bool pol_fused = false;     // polarized runs over the same grids (either tier): bl_shade_polarized2_kernel locates its samples itself
   bool locate_inside = false; // fused || exact_fused: no locate kernel, no located samples in HBM
   bool park = false;          // the last rays of a chunk go to bl_geodesic_quad_kernel (BlTraceArgs::parked): a measurement switch
   bool tail_beside = false;   // tail_overlap, and the coefficient kernel's first pass runs beside the second launch (else after it)
@@ -303,8 +304,15 @@ void PlanJob(RenderJob &job) {
       && !(p.cut_omit_near || p.cut_omit_far || p.cut_omit_in >= 0.0 || p.cut_omit_out >= 0.0 || p.cut_midplane_theta != 0.0 || p.cut_midplane_z != 0.0 || p.cut_plane)
       && !job.geo_load && !job.geo_save && !job.sample_save && !(ctx->switches & (BL_SWITCH_NO_FUSED_LOCATE | BL_SWITCH_SPLIT_RECORDS))
       && bl_fused2_applicable(&ctx->grid_dev, job.n_nu, job.n_rays) != 0;
-  job.interleaved = (job.fused || job.exact_fused || !job.simulation) && !job.geo_load && !job.geo_save && !job.sample_save && !(ctx->switches & BL_SWITCH_SPLIT_RECORDS);
-  job.locate_inside = job.fused || job.exact_fused;
+  // Polarized runs over such a grid: the frame-and-inputs kernel with the locate step inside (bit-identical to bl_locate_plain_kernel +
+  // bl_shade_kernel<polarized>, whose conditions these are; electron entropy from the grid is a ninth value it does not gather)
+  job.pol_fused = ctx->polarized && job.simulation && !job.slow && !job.block_interp && p.plasma_model != BL_PLASMA_CODE_KAPPA && !p.ray_flat
+      && ctx->grid_dev.n_blocks == 0 && !ctx->grid_dev.fmks && p.simulation_interp && p.simulation_coord == BL_COORD_SKS
+      && !(p.cut_omit_near || p.cut_omit_far || p.cut_omit_in >= 0.0 || p.cut_omit_out >= 0.0 || p.cut_midplane_theta != 0.0 || p.cut_midplane_z != 0.0 || p.cut_plane)
+      && !job.geo_load && !job.geo_save && !job.sample_save && !job.need_time && !(ctx->switches & (BL_SWITCH_NO_FUSED_LOCATE | BL_SWITCH_SPLIT_RECORDS))
+      && bl_fused2_applicable(&ctx->grid_dev, 1, job.n_rays) != 0;
+  job.interleaved = (job.fused || job.exact_fused || job.pol_fused || !job.simulation) && !job.geo_load && !job.geo_save && !job.sample_save && !(ctx->switches & BL_SWITCH_SPLIT_RECORDS);
+  job.locate_inside = job.fused || job.exact_fused || job.pol_fused;
   // One frequency over a single block with evenly spaced faces: the benchmark's kernel, which also composes the affine maps of a
   // ray's neighbouring samples before they leave it (the geodesic kernel numbers the segments: BlTraceArgs::segment_rows)
   job.fused2 = job.fused && job.interleaved && !job.freq_split && !(ctx->switches & BL_SWITCH_GENERAL_FUSED)
@@ -365,7 +373,7 @@ void PlanScratch(RenderJob &job) {
       + ((job.simulation && !job.locate_inside) ? sizeof(BlLocated) + sizeof(unsigned long long) : 0)
       + (job.freq_split ? sizeof(BlFreqInputs) : sizeof(double2) * n_nu) + (job.tau_row ? sizeof(double) * n_nu : 0)
       + (job.composed ? sizeof(double2) : 0)
-      + (job.aux ? sizeof(BlAuxSample) : 0) + (job.need_time ? sizeof(double) : 0) + (job.slow ? sizeof(double) : 0)
+      + ((job.aux && !job.rows_only) ? sizeof(BlAuxSample) : 0) + (job.need_time ? sizeof(double) : 0) + (job.slow ? sizeof(double) : 0)
       + (ctx->polarized ? sizeof(BlPolSample) + sizeof(BlCoefInputs) + 3 * sizeof(double2) * n_nu : 0)
       + (job.coef_split ? sizeof(BlCoefInputs) : 0)
       + (job.matrix_transport ? BL_POL_MATRIX_DOUBLES * sizeof(double) : 0)
@@ -511,7 +519,7 @@ void EnsureScratchOnce(RenderJob &job) {
     if (job.park || job.tail_overlap || job.split_long) sl.d_parked.Ensure(job.park_capacity * BL_PARK_DOUBLES);
     if (job.tau_row) sl.d_tau_inc.Ensure(cap * n_nu);
     sl.d_counters.Ensure(BL_CNT_TOTAL);
-    if (job.aux) sl.d_aux.Ensure(cap);
+    if (job.aux && !job.rows_only) sl.d_aux.Ensure(cap);   // (rows_only: nobody writes or reads the 96-byte records)
     if (job.need_time) sl.d_sample_t.Ensure(cap);
     if (job.slow) sl.d_slow_frac.Ensure(cap);
     if (ctx->polarized) {
@@ -1076,7 +1084,7 @@ void BindChunk(RenderJob &job, int k, long long begin, int rays) {
   sa.record_range = 0;
   sa.skip_redo = 0;
   sa.tau_inc = job.tau_row ? sl.d_tau_inc.ptr : nullptr;
-  sa.aux = job.aux ? sl.d_aux.ptr : nullptr;
+  sa.aux = (job.aux && !job.rows_only) ? sl.d_aux.ptr : nullptr;
   sa.sample_t = ta.sample_t;
   sa.coef_inputs = (job.coef_split || ctx->polarized) ? sl.d_coef_inputs.ptr : nullptr;
   sa.anchors = job.block_interp ? sl.d_anchors.ptr : nullptr;
@@ -1484,6 +1492,7 @@ void LaunchShadingStage(RenderJob &job, int k, bool geodesic_beside, hipStream_t
     if (job.fast) Check(bl_launch_shade_fast(&sa, job.shade_grid, stream), "coefficient kernel launch");
     else if (job.fast_formula) Check(bl_launch_shade_formula_fast(&sa, ctx->num_cus * 4 * 4, stream), "coefficient kernel launch");
     else if (job.exact_fused) Check(bl_launch_shade_exact2(&sa, job.shade_grid, stream), "coefficient kernel launch");
+    else if (job.pol_fused) Check(bl_launch_shade_polarized2(&sa, job.shade_grid, stream), "coefficient kernel launch");
     else Check(bl_launch_shade(&sa, p.model_type, job.shade_grid, stream), "coefficient kernel launch");
   };
   if (job.tail_beside) {
@@ -1510,7 +1519,7 @@ void LaunchShadingStage(RenderJob &job, int k, bool geodesic_beside, hipStream_t
   Check(hipEventRecord(e[3], stream), "event");
   coefficient_kernel();
   }
-  if (ctx->polarized) Check(bl_launch_polarized_coefficients(&sa, ctx->num_cus * 8, stream), "polarized coefficient kernel launch");
+  if (ctx->polarized) Check(bl_launch_polarized_coefficients(&sa, ctx->num_cus * ctx->polcoef_blocks_per_cu, stream), "polarized coefficient kernel launch");
   if (job.coef_split) Check(bl_launch_coefficients_freq(&sa, ctx->num_cus * 16, stream), "per-frequency coefficient kernel launch");
   Check(hipEventRecord(e[4], stream), "event");
   Check(job.aux ? bl_launch_transfer_aux(&xa, stream)
@@ -1697,7 +1706,7 @@ void FinishStats(RenderJob &job) {
   st.n_deferred = static_cast<int64_t>(job.total_redo);
   st.n_undefined = static_cast<int64_t>(job.total_undefined);
   st.switches = ctx->switches;
-  st.fused_variant = job.fused ? (job.fused2 ? 2 : 1) : (job.exact_fused ? 3 : 0);
+  st.fused_variant = job.fused ? (job.fused2 ? 2 : 1) : (job.exact_fused ? 3 : (job.pol_fused ? 4 : 0));
   st.n_parked = static_cast<int64_t>(job.total_parked);
   st.composed_maps = job.composed ? 1 : 0;
   st.tail_policy = job.park ? BL_TAIL_QUAD : (job.split_long ? BL_TAIL_SPLIT : BL_TAIL_WIDE);

@@ -332,79 +332,9 @@ __global__ void __launch_bounds__(256, 2) bl_shade_kernel(const BlShadeArgs P) {
         shade_formula(P, st, ks.r, x1, x2, x3, &sh);
     }
     double2 *out = P.transfer + row * P.n_nu;
-    if (kAux && !(kPolarized && P.aux_record_unused)) {
-      BlAuxSample aux;
-      aux.delta_lambda = delta_lambda;
-      aux.t = P.sample_t != nullptr ? P.sample_t[idx_cur] : 0.0;
-      aux.plane = P.cam_x[1] * x1 + P.cam_x[2] * x2 + P.cam_x[3] * x3;
-      aux.length_term = 0.0;
-      aux.pad = 0.0;
-      if (P.aux_need_length) {
-        // unpolarized.cpp:115-129 with the renormalised sample momentum
-        double gcov[4][4], gcon[4][4];
-        if (st.ray_flat) {
-          bl_minkowski(gcov);
-          bl_minkowski(gcon);
-        } else {
-          bl_gcov_ks(ks, gcov);
-          bl_gcon_ks(ks, gcon);
-        }
-        double temp_a[4] = {0.0, 0.0, 0.0, 0.0};
-        for (int a = 1; a < 4; a++)
-          for (int mu = 0; mu < 4; mu++) temp_a[a] += (gcon[a][mu] - gcon[0][a] * gcon[0][mu] / gcon[0][0]) * kcov[mu];
-        double dl_dlambda_sq = 0.0;
-        for (int a = 1; a < 4; a++)
-          for (int b = 1; b < 4; b++) dl_dlambda_sq += gcov[a][b] * temp_a[a] * temp_a[b];
-        aux.length_term = blm_sqrt(dl_dlambda_sq) * delta_lambda * P.x_unit;
-      }
-      const double nan = __longlong_as_double(0x7ff8000000000000ll);
-      for (int a = 0; a < BL_NUM_CELL_VALUES; a++) aux.cell[a] = sh.have_cell ? sh.cell[a] : nan;
-      P.aux[row] = aux;
-    }
+    if (kAux && !(kPolarized && P.aux_record_unused)) write_aux_record(P, st, ks, idx_cur, row, sh, kcov, x1, x2, x3, delta_lambda);
     if (kPolarized) {
-      BlPolSample *ps = P.pol_samples + row;
-      ps->x[0] = x1; ps->x[1] = x2; ps->x[2] = x3;
-      ps->delta_lambda = delta_lambda;
-    }
-    if (kPolarized) {
-      // polarized run (an auxiliary-image, extended, simulation-mode instantiation): the per-frequency formulas (Bessel functions, a dozen powers and exponentials) need few
-      // registers and many waves - bl_polarized_coefficients_kernel evaluates them from these scalars
-      BlCoefInputs ci;
-      if (sh.have_coefficients) {
-        ci.nu_fluid_over_nu = sh.nu_fluid_over_nu;
-        ci.n_e_cgs = sh.n_e_cgs;
-        ci.nu_c_cgs = sh.nu_c_cgs;
-        ci.theta_e = sh.theta_e;
-        ci.kb_tt_e_cgs = sh.kb_tt_e_cgs;
-        ci.cos2_theta_b = sh.cos2_theta_b;
-        ci.cos_sign = sh.cos_sign;
-        ci.have_coefficients = 1.0;
-      } else {
-        // cut samples, cells cut or without field: the coefficient code never reached its tetrad, but the polarized transfer
-        // needs the frame (with zero velocity / field where the sample was cut). Rare, and a frame's worth of registers:
-        // bl_polarized_frame_kernel builds it from what is parked here in the fields nobody reads for such a sample -
-        // the renormalised k_mu and the sampled velocity and field.
-        ci.nu_fluid_over_nu = kcov[0];
-        ci.n_e_cgs = kcov[1];
-        ci.nu_c_cgs = kcov[2];
-        ci.theta_e = kcov[3];
-        ci.kb_tt_e_cgs = __hiloint2double(__float_as_int(pr[3]), __float_as_int(pr[2]));
-        ci.cos2_theta_b = __hiloint2double(__float_as_int(pr[5]), __float_as_int(pr[4]));
-        ci.cos_sign = __hiloint2double(__float_as_int(pr[7]), __float_as_int(pr[6]));
-        ci.have_coefficients = 0.0;
-        // ... and listed for that kernel (the list of the tolerant tier's deferred records, unused in polarized runs): one
-        // atomic per wave for the lanes that are here; a full list makes the frame kernel scan every record instead
-        if (P.redo_list != nullptr) {
-          const unsigned long long here = __ballot(1);
-          const unsigned int rank = __builtin_amdgcn_mbcnt_hi((unsigned int)(here >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)here, 0u));
-          unsigned long long first = 0ull;
-          if (rank == 0u) first = atomicAdd(&P.counters[BL_CNT_REDO], (unsigned long long)__popcll(here));
-          const unsigned long long at = (((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(first >> 32)) << 32)
-                                         | (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)first)) + rank;
-          if (at < P.redo_capacity) P.redo_list[at] = idx_cur;
-        }
-      }
-      P.coef_inputs[idx_cur] = ci;
+      write_polarized_inputs(P, idx_cur, row, sh, kcov, pr, x1, x2, x3, delta_lambda);
       continue;
     }
     if (!kAux && !kPolarized && !kRedo && kModel == BL_MODEL_SIMULATION && P.coef_split) {
@@ -632,11 +562,12 @@ extern "C" hipError_t bl_launch_shade(const BlShadeArgs *args, int model, int gr
   const bool spin_zero = args->st.bh_a == 0.0;
 #define BL_LAUNCH_S(M, A, W) hipLaunchKernelGGL((bl_shade_kernel<M, A, W, false, false, false>), dim3(grid), dim3(256), 0, stream, *args)
   if (model == BL_MODEL_SIMULATION) {
-    if (aux && args->pol_samples != nullptr && sks_curved && spin_zero)   // polarized run: frame and coefficient inputs per sample, no frequency loop
+    // (a polarized run is an auxiliary-image run whether or not it keeps BlAuxSample records: BlShadeArgs::aux_record_unused)
+    if (args->pol_samples != nullptr && sks_curved && spin_zero)   // polarized run: frame and coefficient inputs per sample, no frequency loop
       hipLaunchKernelGGL((bl_shade_kernel<BL_MODEL_SIMULATION, true, true, true, true, true>), dim3(grid), dim3(256), 0, stream, *args);
-    else if (aux && args->pol_samples != nullptr && sks_curved)
+    else if (args->pol_samples != nullptr && sks_curved)
       hipLaunchKernelGGL((bl_shade_kernel<BL_MODEL_SIMULATION, true, true, true, true, false>), dim3(grid), dim3(256), 0, stream, *args);
-    else if (aux && args->pol_samples != nullptr)
+    else if (args->pol_samples != nullptr)
       hipLaunchKernelGGL((bl_shade_kernel<BL_MODEL_SIMULATION, true, true, false, true, false>), dim3(grid), dim3(256), 0, stream, *args);
     else if (aux && power) BL_LAUNCH_S(BL_MODEL_SIMULATION, true, true);
     else if (aux) BL_LAUNCH_S(BL_MODEL_SIMULATION, true, false);

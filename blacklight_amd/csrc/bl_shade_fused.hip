@@ -1004,6 +1004,171 @@ __global__ void __launch_bounds__(256, 2) bl_shade_exact2_kernel(const BlShadeAr
   if ((threadIdx.x & 63) == 0 && gathers_wave != 0ull) atomicAdd(&P.counters[BL_CNT_GATHERS], gathers_wave);
 }
 
+// =================================================================================================
+// Polarized runs, locate step inside (bl_shade_polarized2_kernel): bl_locate_plain_kernel + bl_shade_kernel<simulation, aux, extended,
+// curved SKS, polarized> behind bl_shade_exact2_kernel's pipeline - the same calls on the same operands, so the same BlPolSample frames,
+// BlCoefInputs and auxiliary records, bit for bit (both tiers: the frame of a polarized sample is exact arithmetic in either) -
+// without the locate kernel's launch and the 40 bytes of located sample per record it writes and this kernel would read back.
+// Reference: simulation_sampling.cpp:201-575, :806-839; simulation_coefficients.cpp:253-455; polarized.cpp:163-265.
+// =================================================================================================
+// kAuxRecords: the run keeps BlAuxSample records (an auxiliary row besides tau, or a rendering); without them the kernel is 40
+// registers lighter.
+template <bool kSpinZero, bool kAuxRecords>
+__global__ void __launch_bounds__(256, 2) bl_shade_polarized2_kernel(const BlShadeArgs P) {
+  using namespace fused2;
+  extern __shared__ double lds[];
+  const uint32_t lds_base = lds_address(lds);
+  stage_axis_rows<false>(P.grid, reinterpret_cast<AxisRow *>(lds));
+  __syncthreads();
+  const uint32_t n_records = (uint32_t)record_range_end(P);
+  const uint32_t first_record = (uint32_t)record_range_first(P);
+  if (n_records <= first_record) return;
+  const uint32_t stride = gridDim.x * blockDim.x;
+  const uint32_t last = n_records - 1u;
+  const BlSpacetime st = P.st;
+  const GridScalars G = grid_scalars(P.grid, lds_base);
+  const double camera_r = P.cuts.camera_r;
+  const float fallback_rho = P.cold->fallback_rho, fallback_pgas = P.cold->fallback_pgas;
+  const bool nan_rays = P.plasma.fallback_nan != 0;
+  const char *cells = reinterpret_cast<const char *>(P.grid.cells);
+  const uint32_t row_bytes = (uint32_t)P.grid.stride_row * 32u, plane_bytes = (uint32_t)P.grid.stride_plane * 32u;
+  const char *ray_kt = reinterpret_cast<const char *>(P.ray_kt), *ray_offset = reinterpret_cast<const char *>(P.ray_offset);
+  unsigned long long gathers_wave = 0ull;
+  const char *records = reinterpret_cast<const char *>(P.records_hot);
+  const uint32_t lane_index = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t lane_bytes = lane_index << 6;
+  uint32_t base_index = first_record;
+  auto record_base = [&](uint32_t first) { return records + ((size_t)(first < last ? first : last) << 6); };
+  double2 prev0 = make_double2(0.0, 0.0), prev1 = make_double2(0.0, __longlong_as_double((long long)BL_DEAD_RAY)), prev2 = prev0, prev3 = prev0;
+  double2 cur0, cur1;
+  double kt_prev = 0.0;
+  long long row_prev = 0;
+  unsigned char flag_prev = 0;
+  LocatedExact loc_prev, loc_cur;
+  loc_prev.f_i = loc_prev.f_j = loc_prev.f_k = loc_prev.ph_unwrapped = 0.0;
+  loc_prev.status = kSampleNone;
+  loc_prev.cell_bytes = 0u;
+  float4 lo[8], hi[8];
+#pragma unroll
+  for (int c = 0; c < 8; c++) lo[c] = hi[c] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  bool cur_in = first_record + lane_index < n_records;
+  {
+    const double2 *rec = reinterpret_cast<const double2 *>(record_base(first_record) + (size_t)(cur_in ? lane_bytes : 0u));
+    cur0 = rec[0];
+    cur1 = rec[1];
+    cur1.y = cur_in ? cur1.y : __longlong_as_double((long long)BL_DEAD_RAY);
+  }
+  loc_cur = locate_exact<kSpinZero>(st, P.grid, G, camera_r, (uint32_t)__double_as_longlong(cur1.y) != BL_DEAD_RAY, cur0.x, cur0.y, cur1.x);
+  bool prev_in = false;
+  while (__any(prev_in || cur_in)) {
+    const uint32_t ray = (uint32_t)__double_as_longlong(prev1.y);
+    const bool live = ray != BL_DEAD_RAY;
+    const uint32_t n = (uint32_t)(((unsigned long long)__double_as_longlong(prev1.y)) >> 32);
+    int status = (int)loc_prev.status;
+    const uint32_t next_first = base_index + stride;
+    const bool next_in = next_first + lane_index < n_records;
+    double2 next0, next1;
+    {
+      const double2 *rec = reinterpret_cast<const double2 *>(record_base(next_first) + (size_t)(next_in ? lane_bytes : 0u));
+      next0 = rec[0];
+      next1 = rec[1];
+    }
+    const double kt = kt_prev;
+    const long long row_first = row_prev;
+    const unsigned char ray_flag = flag_prev;
+    float pr[8];
+    gather_finish(P, fallback_rho, fallback_pgas, status, lo, hi, loc_prev.f_i, loc_prev.f_j, loc_prev.f_k, pr);
+    gathers_wave += (unsigned long long)__popcll(__ballot(status == (int)kSampleInterp));
+    double2 cold0, cold1;
+    {
+      const double2 *rec = reinterpret_cast<const double2 *>(record_base(base_index) + (size_t)(cur_in ? lane_bytes : 0u));
+      cold0 = rec[2];
+      cold1 = rec[3];
+    }
+    {
+      const uint32_t ray_cur = (uint32_t)__double_as_longlong(cur1.y);
+      const uint32_t ray_slot = ray_cur != BL_DEAD_RAY ? ray_cur : 0u;
+      kt_prev = *reinterpret_cast<const double *>(ray_kt + (size_t)(ray_slot << 3));
+      row_prev = *reinterpret_cast<const long long *>(ray_offset + (size_t)(ray_slot << 3));
+      flag_prev = P.ray_flags[ray_slot];
+    }
+    if (live) {
+      // ---- bl_shade_kernel's body for a polarized run (bl_shade.hip), call for call
+      const unsigned long long idx_cur = (unsigned long long)(base_index - stride + lane_index);
+      const size_t row = (size_t)(row_first + (long long)n);
+      const double x1 = prev0.x, x2 = prev0.y, x3 = prev1.x;
+      const double delta_lambda = -prev3.y;   // ReverseGeodesics: sample_len = -geodesic_len (geodesics.cpp:840)
+      double kcov[4] = {kt, prev2.x, prev2.y, prev3.x};
+      BlKerrSchild ks;
+      bl_kerr_schild<kSpinZero>(st, x1, x2, x3, &ks);
+      {   // per-sample renormalisation of the stored momentum (geodesics.cpp:352-371)
+        double gcon[4][4];
+        bl_gcon_ks(ks, gcon);
+        const double factor = bl_renormalization_factor_g(gcon, kcov[0], kcov[1], kcov[2], kcov[3]);
+        kcov[1] *= factor;
+        kcov[2] *= factor;
+        kcov[3] *= factor;
+      }
+      SampleShade sh;
+      sh.have_coefficients = false;
+      sh.nu_fluid_over_nu = 0.0;
+      sh.n_e_cgs = sh.nu_c_cgs = sh.theta_e = sh.sin_theta_b = sh.kb_tt_e_cgs = 0.0;
+      sh.cos_theta_b = sh.sin2_theta_b = sh.cos2_theta_b = 0.0;
+      sh.cos_sign = 1.0;
+      sh.n_n0_fluid = 0.0;
+      sh.fu[0] = sh.fu[1] = sh.fu[2] = sh.fu[3] = 0.0;
+      sh.have_cell = false;
+      // rays that ended on ray_max_steps / retries with fallback_nan sample NaN primitives at every sample, cuts not applied
+      // (simulation_sampling.cpp:211-216)
+      if (nan_rays && ray_flag != 0) {
+        const float fnan = __int_as_float(0x7fc00000);
+        for (int v = 0; v < 8; v++) pr[v] = fnan;
+        status = kSampleOffGrid;
+      }
+      if (status != kSampleCut)
+        sample_finish_simulation<true, true>(P, st, ks, x3 / ks.r, loc_prev.ph_unwrapped, pr, 0.0f, kcov, P.aux_need_coefficients, &sh, P.pol_samples + row);
+      if (kAuxRecords) write_aux_record(P, st, ks, idx_cur, row, sh, kcov, x1, x2, x3, delta_lambda);
+      write_polarized_inputs(P, idx_cur, row, sh, kcov, pr, x1, x2, x3, delta_lambda);
+    }
+    // the corner cells of `cur`: requested behind the frame's arithmetic, whose tetrad needs the sixty-four registers they land in
+    // (with the requests in front of it the kernel keeps 3 ... 24 registers in scratch memory); the search for `next` and the
+    // other wave of the SIMD cover their way
+    fused2::gather_issue(cells, loc_cur.cell_bytes, loc_cur.status == (uint32_t)kSampleInterp, row_bytes, plane_bytes, lo, hi);
+    const bool live_next = next_in && (uint32_t)__double_as_longlong(next1.y) != BL_DEAD_RAY;
+    LocatedExact loc_next = loc_cur;
+    if (__any(live_next)) loc_next = locate_exact<kSpinZero>(st, P.grid, G, camera_r, live_next, next0.x, next0.y, next1.x);
+    else loc_next.status = kSampleNone, loc_next.cell_bytes = 0u;
+    prev0 = cur0;
+    prev1 = cur1;
+    prev2 = cold0;
+    prev3 = cold1;
+    loc_prev = loc_cur;
+    prev_in = cur_in;
+    cur0 = next0;
+    cur1 = next1;
+    cur1.y = next_in ? next1.y : __longlong_as_double((long long)BL_DEAD_RAY);
+    loc_cur = loc_next;
+    cur_in = next_in;
+    base_index = next_first;
+  }
+  if ((threadIdx.x & 63) == 0 && gathers_wave != 0ull) atomicAdd(&P.counters[BL_CNT_GATHERS], gathers_wave);
+}
+
+extern "C" hipError_t bl_launch_shade_polarized2(const BlShadeArgs *args, int grid, hipStream_t stream) {
+  const BlGridDevice &g = args->grid;
+  const size_t lds = 64 * (size_t)(g.n[0] + g.n[1] + g.n[2]);
+  if (args->pol_samples == nullptr || args->coef_inputs == nullptr) return hipErrorInvalidValue;
+  const bool spin_zero = args->st.bh_a == 0.0, records = args->aux_record_unused == 0;
+  if (records && args->aux == nullptr) return hipErrorInvalidValue;
+#define BL_LAUNCH_P2(S, A) hipLaunchKernelGGL((bl_shade_polarized2_kernel<S, A>), dim3(grid), dim3(256), lds, stream, *args)
+  if (spin_zero && records) BL_LAUNCH_P2(true, true);
+  else if (spin_zero) BL_LAUNCH_P2(true, false);
+  else if (records) BL_LAUNCH_P2(false, true);
+  else BL_LAUNCH_P2(false, false);
+#undef BL_LAUNCH_P2
+  return hipGetLastError();
+}
+
 // (the exact tier's use of the fused kernel: one frequency, plain image; bl_render.hip checks the rest with bl_fused2_applicable)
 extern "C" hipError_t bl_launch_shade_exact2(const BlShadeArgs *args, int grid, hipStream_t stream) {
   const BlGridDevice &g = args->grid;

@@ -287,7 +287,8 @@ typedef struct bl_stats {
   int64_t n_undefined;        /* BL_UNDEFINED_EDGE: samples where the reference reads past its arrays (edge cell used)     */
   uint32_t switches;          /* BL_SWITCH_* bits active in this context (measurement switches, below); 0 in production  */
   int32_t fused_variant;      /* the locate step inside the coefficient kernel: 2 = bl_shade_fused2_kernel, 1 = bl_shade_fused_kernel
-                                 (tolerant tier), 3 = bl_shade_exact2_kernel (exact tier), 0 = a locate kernel of its own ran  */
+                                 (tolerant tier), 3 = bl_shade_exact2_kernel (exact tier), 4 = bl_shade_polarized2_kernel (polarized runs),
+                                 0 = a locate kernel of its own ran  */
   int64_t n_parked;           /* rays whose last steps ran with a ray per quad of lanes (bl_geodesic_quad_kernel)                 */
   int32_t composed_maps;      /* 1: the tolerant tier composed the affine transfer maps of neighbouring samples (intensities equal from
                                  run to run to rounding, ~1e-15, not bit for bit); 0: every image row of this render is bit-reproducible
@@ -409,7 +410,7 @@ BL_API int bl_set_tail_policy(bl_ctx *ctx, int policy);
  * with enabled != 0, every later bl_render first makes its streams wait (on the device, hipStreamWaitEvent: no host wait) for
  * all work queued on `stream` (a hipStream_t; NULL is the NULL stream) up to the moment of the call. */
 BL_API int bl_set_caller_stream(bl_ctx *ctx, void *stream, int enabled);
-/* Cap on scratch HBM (bytes) used for per-sample records; default 144 GiB (half of the MI355X HBM). */
+/* Cap on scratch HBM (bytes) used for per-sample records; default four fifths of the device's memory (MI355X: 230 GB of 288). */
 BL_API int bl_set_scratch_limit(bl_ctx *ctx, uint64_t bytes);
 /* on != 0: when a render needs several chunks, run the geodesic kernel of chunk c + 1 on a second stream
  * beside the shading kernels of chunk c (two scratch sets of half the budget). Off by default: measured

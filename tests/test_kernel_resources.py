@@ -30,14 +30,19 @@ BENCHMARK_KERNELS = {
     "_Z20bl_shade_fast_kernelILb0ELb0EEv11BlShadeArgs": (2, 0),
     "_Z20bl_shade_fast_kernelILb1ELb1EEv11BlShadeArgs": (2, 0),              # ... power laws / Cartesian grids
     "_Z20bl_shade_fast_kernelILb0ELb1EEv11BlShadeArgs": (2, 0),
-    "_Z22bl_shade_fused2_kernelILb1ELb1EEv11BlShadeArgs": (2, 0),            # ... the benchmark's kernel: locate step inside, composed maps
-    "_Z22bl_shade_fused2_kernelILb1ELb0EEv11BlShadeArgs": (2, 0),            # ... one record per sample
-    "_Z22bl_shade_fused2_kernelILb0ELb1EEv11BlShadeArgs": (2, 0),            # ... any spin
-    "_Z22bl_shade_fused2_kernelILb0ELb0EEv11BlShadeArgs": (2, 0),
+    "_Z22bl_shade_fused2_kernelILb1ELb1ELb0EEv11BlShadeArgs": (2, 0),            # ... the benchmark's kernel: locate step inside, composed maps
+    "_Z22bl_shade_fused2_kernelILb1ELb0ELb0EEv11BlShadeArgs": (2, 0),            # ... one record per sample
+    "_Z22bl_shade_fused2_kernelILb0ELb1ELb0EEv11BlShadeArgs": (2, 0),            # ... any spin
+    "_Z22bl_shade_fused2_kernelILb0ELb0ELb0EEv11BlShadeArgs": (2, 0),
+    "_Z22bl_shade_fused2_kernelILb1ELb1ELb1EEv11BlShadeArgs": (2, 0),        # ... gathering from pre-gathered bricks (BL_SWITCH_BRICK_CELLS: a measured experiment)
     "_Z21bl_shade_fused_kernelILb1EEv11BlShadeArgs": (2, 0),                 # ... locate step inside, general grids / up to three frequencies
     "_Z21bl_shade_fused_kernelILb0EEv11BlShadeArgs": (2, 0),
     "_Z22bl_shade_exact2_kernelILb1EEv11BlShadeArgs": (2, 0),                # exact tier, locate step inside (the benchmark's exact kernel)
     "_Z22bl_shade_exact2_kernelILb0EEv11BlShadeArgs": (2, 0),
+    "_Z26bl_shade_polarized2_kernelILb1ELb0EEv11BlShadeArgs": (2, 0),        # polarized runs, locate step inside, no auxiliary records
+    "_Z26bl_shade_polarized2_kernelILb0ELb0EEv11BlShadeArgs": (2, 0),
+    "_Z26bl_shade_polarized2_kernelILb1ELb1EEv11BlShadeArgs": (2, 0),        # ... with auxiliary records
+    "_Z26bl_shade_polarized2_kernelILb0ELb1EEv11BlShadeArgs": (2, 0),
     "_Z21bl_shade_exact_kernelILb1EEv11BlShadeArgs": (2, 0),                 # exact tier behind a locate kernel, software-pipelined
     "_Z21bl_shade_exact_kernelILb0EEv11BlShadeArgs": (2, 0),
     "_Z22bl_locate_plain_kernelILb1EEv11BlShadeArgs": (4, 0),                # exact tier's locate step, common grid case
