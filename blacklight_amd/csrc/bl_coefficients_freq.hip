@@ -10,8 +10,13 @@
 // =================================================================================================
 // kTolerant: the tolerant arithmetic tier's functions and fused multiply-adds in the formulas (bl_coefficients.inc,
 // second inclusion) - the kernel is almost entirely the double-double pow / log of the pinned library otherwise.
-template <bool kTolerant>
-__global__ void __launch_bounds__(256, 2) bl_polarized_coefficients_kernel(const BlShadeArgs P) {
+#ifndef BL_POLCOEF_WAVES
+#define BL_POLCOEF_WAVES 2
+#endif
+// kThermalOnly: no power-law and no kappa-distribution electrons (the host knows): without their formulas the exact kernel fits three
+// waves per SIMD instead of two (168 registers), which is worth 8 ms of a 1024^2 frame's 106.
+template <bool kTolerant, bool kThermalOnly>
+__global__ void __launch_bounds__(256, (kThermalOnly && !kTolerant) ? 3 : BL_POLCOEF_WAVES) bl_polarized_coefficients_kernel(const BlShadeArgs P) {
   const unsigned long long n_records = P.counters_in[BL_CNT_RECORDS];
   const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
   for (unsigned long long idx = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; idx < n_records; idx += stride) {
@@ -48,11 +53,11 @@ __global__ void __launch_bounds__(256, 2) bl_polarized_coefficients_kernel(const
       double j_val = 0.0, alpha_val = 0.0;
       double2 pc[3] = {make_double2(0.0, 0.0), make_double2(0.0, 0.0), make_double2(0.0, 0.0)};
       if (kTolerant) {
-        if (sh.have_coefficients) simulation_coefficients_fast<true>(P, sh, freq, momentum_factor, &j_val, &alpha_val);
-        polarized_coefficients_fast(P, sh, freq, momentum_factor, j_val, alpha_val, pc);
+        if (sh.have_coefficients) simulation_coefficients_fast<!kThermalOnly>(P, sh, freq, momentum_factor, &j_val, &alpha_val);
+        polarized_coefficients_fast<!kThermalOnly>(P, sh, freq, momentum_factor, j_val, alpha_val, pc);
       } else {
-        if (sh.have_coefficients) simulation_coefficients<true>(P, sh, freq, momentum_factor, &j_val, &alpha_val);
-        polarized_coefficients(P, sh, freq, momentum_factor, j_val, alpha_val, pc);
+        if (sh.have_coefficients) simulation_coefficients<!kThermalOnly>(P, sh, freq, momentum_factor, &j_val, &alpha_val);
+        polarized_coefficients<!kThermalOnly>(P, sh, freq, momentum_factor, j_val, alpha_val, pc);
       }
 #ifdef BL_POL_CONDITION_STATS
       // (a measurement build, tools/build_variant.sh -DBL_POL_CONDITION_STATS: how many samples' joint coupling step - polarized.cpp:
@@ -213,8 +218,14 @@ __global__ void bl_debug_math_kernel(int op, long long n, const double *x, const
 
 
 extern "C" hipError_t bl_launch_polarized_coefficients(const BlShadeArgs *args, int grid, hipStream_t stream) {
-  if (args->tolerant) hipLaunchKernelGGL(bl_polarized_coefficients_kernel<true>, dim3(grid), dim3(256), 0, stream, *args);
-  else hipLaunchKernelGGL(bl_polarized_coefficients_kernel<false>, dim3(grid), dim3(256), 0, stream, *args);
+  // (simulation_coefficients<kExtended> also holds the unpolarized kappa terms: never in a polarized run)
+  const bool thermal_only = args->plasma.power_frac == 0.0 && args->plasma.kappa_unpolarized == 0 && args->plasma.kappa_frac_zero != 0;
+#define BL_LAUNCH_PC(T, O) hipLaunchKernelGGL((bl_polarized_coefficients_kernel<T, O>), dim3(grid), dim3(256), 0, stream, *args)
+  if (args->tolerant && thermal_only) BL_LAUNCH_PC(true, true);
+  else if (args->tolerant) BL_LAUNCH_PC(true, false);
+  else if (thermal_only) BL_LAUNCH_PC(false, true);
+  else BL_LAUNCH_PC(false, false);
+#undef BL_LAUNCH_PC
   hipLaunchKernelGGL(bl_polarized_frame_kernel, dim3(grid), dim3(256), 0, stream, *args);
   return hipGetLastError();
 }

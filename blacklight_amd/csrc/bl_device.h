@@ -147,6 +147,7 @@ struct BlPlasmaDevice {
   int any_cell_cut;          // some cell cut threshold (simulation_coefficients.cpp:361-375) is >= 0
   // power-law electrons (simulation_coefficients.cpp:54-66, :556-584); power_frac = 0: none
   double power_frac, plasma_p, power_jj, power_aa;
+  int kappa_frac_zero;       // plasma_kappa_frac == 0 (BlShadeCold::kappa.frac lives in HBM; the launchers choose instantiations by this)
   int code_kappa;            // plasma_model = code_kappa: theta_e from the simulation's electron entropy (:351-358)
   int cut_mask;              // bit c set: cell cut threshold c (BlShadeCold::fast_cut order) is active
   int kappa_unpolarized;     // kappa-distribution electrons in an unpolarized run (BL_UNDEFINED_KAPPA): BlShadeCold::kappa's intensity terms

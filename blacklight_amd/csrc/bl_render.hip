@@ -866,6 +866,7 @@ void BuildShadeArgs(RenderJob &job) {
     cold.fallback_pgas = p.fallback_nan ? 0.0f : p.fallback_pgas;
     cold.fallback_kappa = p.fallback_nan ? 0.0f : p.fallback_kappa;
     pl.code_kappa = p.plasma_model == BL_PLASMA_CODE_KAPPA ? 1 : 0;
+    pl.kappa_frac_zero = p.plasma_kappa_frac == 0.0 ? 1 : 0;
     pl.kappa_unpolarized = (p.plasma_kappa_frac != 0.0 && !ctx->polarized) ? 1 : 0;
     // cell cuts (simulation_coefficients.cpp:361-375): "cut >= 0 and value < cut". A disabled threshold goes to the
     // device as -inf (lower) / +inf (upper), against which no value - NaN included - compares true: same
@@ -1519,7 +1520,7 @@ void LaunchShadingStage(RenderJob &job, int k, bool geodesic_beside, hipStream_t
   Check(hipEventRecord(e[3], stream), "event");
   coefficient_kernel();
   }
-  if (ctx->polarized) Check(bl_launch_polarized_coefficients(&sa, ctx->num_cus * ctx->polcoef_blocks_per_cu, stream), "polarized coefficient kernel launch");
+  if (ctx->polarized) Check(bl_launch_polarized_coefficients(&sa, ctx->num_cus * (ctx->polcoef_blocks_per_cu > 0 ? ctx->polcoef_blocks_per_cu : 20), stream), "polarized coefficient kernel launch");
   if (job.coef_split) Check(bl_launch_coefficients_freq(&sa, ctx->num_cus * 16, stream), "per-frequency coefficient kernel launch");
   Check(hipEventRecord(e[4], stream), "event");
   Check(job.aux ? bl_launch_transfer_aux(&xa, stream)
