@@ -105,12 +105,22 @@ def test_save_matches_the_reference_file(built_library, expected, case, tmp_path
             assert not got[name][m, num:].any()
     # sample_len is zero-initialised by the reference, so it compares whole (above)
 
-    # ... and what was saved loads back to the same image, here and - where the reference travelled - there
+    # ... and what was saved loads back to the same image
     with _context(expected, case, checkpoint_geodesic_load="true", checkpoint_geodesic_file=mine) as ctx:
         again = ctx.render()
         assert gu.same_bits(again["image"], _want(expected, case)).all()
-    if case == "sim" or not (os.path.exists(REFERENCE) and os.path.exists(PRELOAD)):
-        return            # (the simulation case would need its athdf file, which is not a fixture)
+
+
+def test_the_reference_loads_our_checkpoint(built_library, expected, tmp_path):
+    """The compiled reference (oracle/_ref/blacklight with the pinned math library preloaded), where it travelled with the tree, loads a
+    geodesic checkpoint this library saved and renders the reference's own image from it. Skipped - visibly - where the binary is not
+    there. (Formula case: the simulation case would need its athdf file, which is not a fixture.)"""
+    case = "formula"
+    if not (os.path.exists(REFERENCE) and os.path.exists(PRELOAD)):
+        pytest.skip("oracle/_ref/blacklight and libblmath_preload.so did not travel with this tree")
+    mine = str(tmp_path / "mine.ckpt")
+    with _context(expected, case, checkpoint_geodesic_save="true", checkpoint_geodesic_file=mine) as ctx:
+        ctx.render()
     work = tmp_path / "reference"
     (work / "data").mkdir(parents=True)
     (work / "output").mkdir()

@@ -217,6 +217,8 @@ CASES = {
                                     adaptive_rel_lapl_frac=-1.0, adaptive_num_regions=0, camera_type="pinhole",
                                     camera_r=100.0, output_camera="true"), None, [136]),
     "formula_dp": (FORMULA_BASE, dict(camera_resolution=32), None, [0, 528, 1023]),
+    # BASELINE.json's configuration 1 at the size it names: input/example_formula.input with a 64 x 64 camera
+    "formula_64": (FORMULA_BASE, dict(camera_resolution=64), None, [0, 2080, 4095]),
     "formula_absorb": (FORMULA_BASE, dict(camera_resolution=16, formula_a=1.0e6, formula_l0=1.0, formula_h=3.33,
                                           formula_alpha=0.0, camera_type="pinhole", camera_r=100.0), None, [136]),
     "formula_flat": (FORMULA_BASE, dict(camera_resolution=16, ray_flat="true", camera_r=100.0, formula_spin=0.0), None, [136]),
