@@ -98,6 +98,13 @@ OTHER_WORKLOADS = {
     "adaptive2048": "configuration 4: example_adaptive.input's refinement (8 x 8 blocks, one level, relative Laplacian) over a 2048^2 root camera, "
                     "full-Stokes polarized transfer + image_tau, 256^3 mock, whole adaptive loop",
     "truecolor1024x64": "configuration 5's physics: example_true_color.input's 64 frequencies (lin_wave, 1.5e11 ... 3.3e11 Hz), 1024^2 camera, 256^3 mock",
+    # SURVEY.md 8(f) rows at the benchmark's size (parity for them: tests/; these lines say how fast they run)
+    "refined256": "8(f)1 mesh refinement: the 256^3 mock as a two-level mesh (4 coarse + 32 fine MeshBlocks of 64^3 cells, scrambled), 1024^2 camera, "
+                  "benchmark physics (simulation_sampling.cpp:352-394: block search per sample)",
+    "blockinterp256": "8(f)1 inter-block interpolation: the 256^3 mock as 4 x 4 x 4 MeshBlocks of 64^3 cells with simulation_block_interp = true "
+                      "(simulation_sampling.cpp:1068-1321; samples at the upper edge of the file's last block use the edge cell, BL_UNDEFINED_EDGE), 1024^2 camera",
+    "slowlight10": "8(f)3 slow light: a window of 10 time slices of the 256^3 mock (5.4 GB of cells resident), interpolation in time, 1024^2 camera "
+                   "(simulation_sampling.cpp:296-349, :736-912)",
 }
 
 
@@ -123,8 +130,26 @@ def other_workload(args):
                           adaptive_rel_lapl_frac=0.25, adaptive_num_regions=0)
         if name == "truecolor1024x64":
             params.update(image_num_frequencies=64, image_frequency_start=1.5e11, image_frequency_end=3.3e11, image_frequency_spacing="lin_wave")
+        if name == "refined256":
+            import golden_util as gu
+            grid = gu.refined_grid(grid, block=(args.grid // 4,) * 3)
+        if name == "blockinterp256":
+            import golden_util as gu
+            grid = gu.split_grid(grid, 4, 4, 4)
+            params.update(simulation_block_interp=True)
+        if name == "slowlight10":
+            # the window's slices 20 M apart, the latest at the camera's time: the rays' samples (coordinate times 0 ... -110 M from the
+            # camera at r = 50) spread over the first six slices
+            params.update(slow_light_on=True, slow_interp=True, slow_chunk_size=10, slow_t_start=180.0, slow_dt=20.0, slow_num_images=1, slow_offset=0,
+                          simulation_multiple=True, simulation_start=0, simulation_end=9)
     with bl.Context(bl.Params.from_dict(params)) as ctx:
-        if grid is not None:
+        if name == "slowlight10":
+            for n in range(10):   # slice n: n = 0 the latest file (simulation_reader.cpp:211-303)
+                ctx.set_grid_slice(n, grid, 180.0 - 20.0 * n)
+            ctx.set_snapshot(0)
+        elif grid is not None:
+            if name == "blockinterp256":
+                ctx.set_undefined_policy("edge")
             ctx.set_grid(grid)
         ctx.set_arithmetic(args.arithmetic)
         render = ctx.render_adaptive if name == "adaptive2048" else ctx.render

@@ -82,4 +82,21 @@ __device__ __forceinline__ int wave_max_nonneg(int v) {
 
 __device__ __forceinline__ long long std_max_ll(long long a, long long b) { return a > b ? a : b; }
 
+// A kernel's argument block where it lies in the kernel-argument segment, behind a pointer the optimiser cannot trace back to the
+// kernel's entry. A by-value struct argument is copied into registers in the entry block - every field any path of the kernel reads,
+// live from the first instruction on: the general locate and coefficient kernels spilled 116 ... 249 scalar registers to vector lanes
+// that way. Fields read through this reference are loaded (s_load: the address space is still known, the loads are scalar) where
+// they are used. For kernels whose only parameter is the struct (it starts at offset 0 of the segment).
+template <typename Args>
+__device__ __forceinline__ const Args &kernel_arguments_in_place() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef const __attribute__((address_space(4))) Args *InSegment;
+  InSegment p = (InSegment)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+  return *(const Args *)p;
+#else
+  return *static_cast<const Args *>(nullptr);
+#endif
+}
+
 }  // namespace

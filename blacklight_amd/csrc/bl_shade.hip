@@ -19,7 +19,9 @@
 // compile-time choice: table pointers that may be either LDS or global become flat loads, each of which waits on both
 // memory counters).
 template <bool kRefined, bool kSlow, bool kSpinZero, bool kTablesInHbm = false>
-__global__ void __launch_bounds__(256, 4) bl_locate_kernel(const BlShadeArgs P) {
+__global__ void __launch_bounds__(256, 4) bl_locate_kernel(const BlShadeArgs P_at_entry) {
+  const BlShadeArgs &P = kernel_arguments_in_place<BlShadeArgs>();   // (bl_kernel_util.h; P_at_entry is never read)
+  (void)P_at_entry;
   const BlSpacetime st = P.st;
   extern __shared__ double lds_tables[];
   GridTables tab;
@@ -179,7 +181,12 @@ __global__ void __launch_bounds__(256, 4) bl_locate_plain_kernel(const BlShadeAr
 // kRedo: second pass of the tolerant tier - shades only the records the tolerant kernel listed (cut decisions
 // inside its guard band), or every record when the list overflowed, and writes (a, c) records like that kernel.
 template <int kModel, bool kAux, bool kExtended, bool kSksCurved, bool kPolarized, bool kSpinZero, bool kRedo = false>
-__global__ void __launch_bounds__(256, 2) bl_shade_kernel(const BlShadeArgs P) {
+__global__ void __launch_bounds__(256, 2) bl_shade_kernel(const BlShadeArgs P_at_entry) {
+  // (The second pass of the tolerant tier - a few listed records, 170 ... 241 scalar registers spilled with its arguments held from
+  // the entry on - reads its arguments where it uses them: bl_kernel_util.h. The first-pass instantiations keep theirs in registers:
+  // the extended one spills ~100 of them to vector lanes and is still 8 - 10 % faster that way than with a scalar load per use,
+  // measured on the refined-mesh, block-interpolation and slow-light frames of bench.py --workload, profiles/r05_f_rows.txt.)
+  const BlShadeArgs &P = kRedo ? kernel_arguments_in_place<BlShadeArgs>() : P_at_entry;
   const BlSpacetime st = P.st;
   // (the second pass covers the whole list, or every record, whatever range the pass before it covered: BlShadeArgs::record_range)
   const unsigned long long first_record = kRedo ? 0ull : record_range_first(P);

@@ -92,14 +92,14 @@ def split_grid(grid, nbi, nbj, nbk, last=None):
 REFINED_BLOCK = (8, 6, 8)   # cells per block (i, j, k) of the refined version of the 32 x 24 x 32 mock
 
 
-def refined_blocks(prim, xf, xv, last=None):
+def refined_blocks(prim, xf, xv, last=None, block=None):
     """A two-level mesh from one block of data: prim [n_var][n_k][n_j][n_i] float32, xf / xv = three float32
     face / centre rows. The domain is cut into 2 x 2 x 2 octants; octants with an odd index sum become one
     coarse block each (level 0: pairwise averages of the fine cells in single precision, every second face),
     the others eight fine blocks each (level 1), all of REFINED_BLOCK cells, in a scrambled order. Only
     correctly rounded single-precision operations, so that tools/make_goldens.py (which writes the result as
     an .athdf for the reference) and the tests build the same bits. Returns a dict of arrays."""
-    bi, bj, bk = REFINED_BLOCK
+    bi, bj, bk = block or REFINED_BLOCK   # (block: a quarter of another grid's cells per axis, bench.py --workload refined256)
     n_var, n_k, n_j, n_i = prim.shape
     assert (n_i, n_j, n_k) == (4 * bi, 4 * bj, 4 * bk)
     f32 = np.float32
@@ -141,10 +141,10 @@ def refined_blocks(prim, xf, xv, last=None):
     return out
 
 
-def refined_grid(grid, last=None):
+def refined_grid(grid, last=None, block=None):
     """The single-block Grid as the two-level mesh of refined_blocks()."""
     from blacklight_amd.mock import Grid
-    blocks = refined_blocks(grid.prim[:, 0], [grid.x1f[0], grid.x2f[0], grid.x3f[0]], [grid.x1v[0], grid.x2v[0], grid.x3v[0]], last)
+    blocks = refined_blocks(grid.prim[:, 0], [grid.x1f[0], grid.x2f[0], grid.x3f[0]], [grid.x1v[0], grid.x2v[0], grid.x3v[0]], last, block)
 
     def row(name):
         return np.ascontiguousarray(blocks[name].astype(np.float64))
@@ -152,7 +152,7 @@ def refined_grid(grid, last=None):
     return Grid(prim=np.ascontiguousarray(blocks["prim"]), x1f=row("x1f"), x2f=row("x2f"), x3f=row("x3f"),
                 x1v=row("x1v"), x2v=row("x2v"), x3v=row("x3v"), ind_kappa=grid.ind_kappa,
                 levels=np.ascontiguousarray(blocks["levels"], dtype=np.int32),
-                locations=np.ascontiguousarray(blocks["locations"], dtype=np.int32), n_3_root=2 * REFINED_BLOCK[2])
+                locations=np.ascontiguousarray(blocks["locations"], dtype=np.int32), n_3_root=2 * (block or REFINED_BLOCK)[2])
 
 
 SLOW_CASES = ["slow_interp", "slow_nearest"]
