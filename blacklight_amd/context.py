@@ -102,7 +102,8 @@ class Context:
         self._check(self._lib.bl_set_undefined_policy(self._ctx, flags))
 
     def set_arithmetic(self, mode):
-        """"exact" (default) or "tolerant": arithmetic tier of the coefficient kernel (bl_set_arithmetic)."""
+        """"tolerant" (what a context starts in unless BLACKLIGHT_AMD_ARITHMETIC=exact) or "exact" (bit-identical to the reference):
+        the arithmetic tier (bl_set_arithmetic)."""
         self._check(self._lib.bl_set_arithmetic(self._ctx, {"exact": 0, "tolerant": 1}[mode]))
 
     def set_reproducible(self, on=True):

@@ -362,6 +362,8 @@ int bl_init(const bl_params *p, int device, bl_ctx **out) {
     if (const char *after = std::getenv("BLACKLIGHT_AMD_PARK_AFTER")) ctx->park_after = std::max(0, std::atoi(after));
     if (const char *quiet = std::getenv("BLACKLIGHT_AMD_PARK_QUIET")) ctx->park_quiet = std::max(1, std::atoi(quiet));
     if (const char *age = std::getenv("BLACKLIGHT_AMD_PARK_AGE")) ctx->park_age = std::max(0, std::atoi(age));
+    // the arithmetic tier a context starts in: tolerant (north_star's tolerance), or what the deployment says
+    if (const char *tier = std::getenv("BLACKLIGHT_AMD_ARITHMETIC")) ctx->arithmetic = std::string(tier) == "exact" ? BL_ARITH_EXACT : BL_ARITH_TOLERANT;
     if (const char *policy = std::getenv("BLACKLIGHT_AMD_TAIL_POLICY")) {   // (A/B runs: bl_set_tail_policy from the environment)
       const std::string name = policy;
       ctx->tail_policy = name == "wide" ? BL_TAIL_WIDE : (name == "quad" ? BL_TAIL_QUAD : (name == "split" ? BL_TAIL_SPLIT : BL_TAIL_AUTO));

@@ -137,7 +137,7 @@ struct bl_ctx {
   unsigned long long *host_counters = nullptr;   // pinned, BL_CNT_TOTAL per scratch set
   uint64_t scratch_limit = 144ull << 30;
   int overlap_chunks = 0;             // bl_set_overlap(): geodesic kernel of chunk c + 1 beside the shading of chunk c
-  int arithmetic = BL_ARITH_EXACT;    // bl_set_arithmetic()
+  int arithmetic = BL_ARITH_TOLERANT; // bl_set_arithmetic(); BLACKLIGHT_AMD_ARITHMETIC = exact | tolerant sets what a new context starts with
   int reproducible = 0;               // bl_set_reproducible(): tolerant tier without composed transfer maps
   int tail_policy = BL_TAIL_AUTO;     // bl_set_tail_policy()
   hipStream_t caller_stream = nullptr;   // bl_set_caller_stream(): work queued there before a bl_render call precedes its kernels

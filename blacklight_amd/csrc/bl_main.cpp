@@ -150,7 +150,7 @@ int main(int argc, char *argv[]) {
   // Options that the reference's command line has no place for come from the environment:
   //   BLACKLIGHT_AMD_DEVICES    = N | all   GPUs to spread every image over (default 1; N may exceed the GPUs present:
   //                                         device d % present, which is how one GPU rehearses several)
-  //   BLACKLIGHT_AMD_ARITHMETIC = tolerant  bl_set_arithmetic(BL_ARITH_TOLERANT)
+  //   BLACKLIGHT_AMD_ARITHMETIC = exact | tolerant   the arithmetic tier (read by bl_init itself: tolerant unless it says exact)
   //   BLACKLIGHT_AMD_UNDEFINED  = edge | kappa | edge,kappa   bl_set_undefined_policy(BL_UNDEFINED_EDGE / BL_UNDEFINED_KAPPA)
   int n_devices = 1;
   if (const char *text = std::getenv("BLACKLIGHT_AMD_DEVICES")) {
@@ -169,8 +169,6 @@ int main(int argc, char *argv[]) {
       std::cout << bl_last_global_error();
       return 1;
     }
-    if (const char *text = std::getenv("BLACKLIGHT_AMD_ARITHMETIC"))
-      if (std::string(text) == "tolerant") bl_set_arithmetic(contexts[dev], BL_ARITH_TOLERANT);
     if (const char *text = std::getenv("BLACKLIGHT_AMD_UNDEFINED")) {
       const std::string chosen(text);
       const int policy = (chosen.find("edge") != std::string::npos ? BL_UNDEFINED_EDGE : 0) | (chosen.find("kappa") != std::string::npos ? BL_UNDEFINED_KAPPA : 0);

@@ -353,15 +353,15 @@ BL_API int bl_image_num_quantities(const bl_ctx *ctx);
 BL_API int bl_render_num_images(const bl_ctx *ctx);
 BL_API int bl_camera_frame_get(const bl_ctx *ctx, bl_camera_frame *out);
 BL_API int bl_frequencies(const bl_ctx *ctx, double *out, int n);
-/* Arithmetic tier of the coefficient kernel. BL_ARITH_EXACT (default): every operation in the reference's order with
- * the pinned math library - images equal the reference's bit for bit (tier-B goldens). BL_ARITH_TOLERANT: the tolerance
- * north_star grants for intensities ("within a stated fp64 tolerance", per-pixel L-infinity < 1e-6 of the image
- * maximum; measured ~1e-13) is used between the sampled primitives and the transfer record of a sample - fused
- * multiply-adds, faster exp / expm1 / cbrt, the fluid-frame angle and frequency as invariants instead of through
- * the tetrad of simulation_coefficients.cpp:398-455. Ray-step counts, flags, cell indices, NaN masks and every cut
- * decision stay those of the exact tier. Built for plain unpolarized images of spherical Kerr-Schild simulations
- * with thermal electrons (the benchmark and the many-frequency renders); other configurations run in exact
- * arithmetic regardless - bl_stats.arithmetic reports the tier that ran. */
+/* Arithmetic tier. BL_ARITH_TOLERANT (what a new context starts in, unless the environment says BLACKLIGHT_AMD_ARITHMETIC=exact): the
+ * tolerance north_star grants for intensities ("within a stated fp64 tolerance", per-pixel L-infinity < 1e-6 of the image maximum;
+ * measured 6e-15 on the benchmark frame, asserted at 1e-11) is used between the sampled primitives and the transfer record of a sample -
+ * fused multiply-adds, lighter exp / expm1 / cbrt, the fluid-frame angle and frequency as invariants instead of through the tetrad
+ * of simulation_coefficients.cpp:398-455, transport matrices in polarized runs. Ray-step counts, flags, cell indices, NaN masks and
+ * every cut decision are those of the exact tier. Configurations the tier has no kernel for run in exact arithmetic regardless -
+ * bl_stats.arithmetic reports the tier that ran. BL_ARITH_EXACT: every operation in the reference's order with the pinned math
+ * library - images equal the reference's bit for bit (tier-B goldens), at 0.57 of the tolerant tier's speed on the benchmark frame.
+ * (Rounds 1 - 4 started contexts in the exact tier; the parity suite pins it through the environment variable, tests/conftest.py.) */
 /* What to do with a sample for which the reference reads past the end of one of its arrays (no bounds checks in its Array):
  * inter-block interpolation at an upper edge of the file's last MeshBlock (simulation_sampling.cpp:520-522), FMKS sampling in
  * the last polar zone of the last azimuthal plane (:412-415 with :809-819). BL_UNDEFINED_REFUSE (default): bl_render fails with

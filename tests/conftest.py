@@ -7,6 +7,10 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 sys.path.insert(0, os.path.join(REPO, "tests"))
+# The parity suite compares with the reference bit for bit: every context of the test session - and of the programs it starts -
+# begins in the exact arithmetic tier (a new context otherwise starts in the tolerant one, include/blacklight_amd.h). Tests of the
+# tolerant tier ask for it by name.
+os.environ.setdefault("BLACKLIGHT_AMD_ARITHMETIC", "exact")
 
 
 def pytest_configure(config):

@@ -134,3 +134,26 @@ def test_a_share_of_a_frame_takes_the_split_steppers_by_default():
     with bl.Context(bl.Params.from_dict(dict(bench.WORKLOAD, camera_resolution=256, simulation_a=0.5))) as ctx:
         ctx.set_grid(mock.generate(n_r=32, n_th=32, n_ph=32))
         assert ctx.render()["stats"].tail_policy == 1
+
+
+def test_a_context_starts_in_the_tolerant_tier(monkeypatch):
+    """north_star's tolerance is what a caller gets who sets nothing (the default was the slow tier); the exact tier is
+    bl_set_arithmetic(BL_ARITH_EXACT) or BLACKLIGHT_AMD_ARITHMETIC=exact, which is how this test session pins it (conftest.py)."""
+    import blacklight_amd as bl
+    p, grid = _benchmark_like()
+    monkeypatch.delenv("BLACKLIGHT_AMD_ARITHMETIC", raising=False)
+    with bl.Context(p) as ctx:
+        ctx.set_grid(grid)
+        fast = ctx.render()
+        assert fast["stats"].arithmetic == 1 and fast["stats"].fused_variant == 2
+        ctx.set_arithmetic("exact")
+        exact = ctx.render()
+        assert exact["stats"].arithmetic == 0 and exact["stats"].fused_variant == 3
+    assert np.array_equal(fast["sample_num"], exact["sample_num"]) and np.array_equal(np.isnan(fast["image"]), np.isnan(exact["image"]))
+    with np.errstate(invalid="ignore"):
+        assert np.nanmax(np.abs(fast["image"] - exact["image"])) <= 1.0e-11 * np.nanmax(np.abs(exact["image"]))
+    monkeypatch.setenv("BLACKLIGHT_AMD_ARITHMETIC", "exact")
+    with bl.Context(p) as ctx:
+        ctx.set_grid(grid)
+        again = ctx.render()
+        assert again["stats"].arithmetic == 0 and gu.same_bits(again["image"], exact["image"]).all()

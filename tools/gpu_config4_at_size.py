@@ -3,6 +3,7 @@ adaptive refinement with 8x8 blocks, one level, relative-Laplacian criterion) wi
 mock. Prints the time of the whole adaptive loop and the number of refined blocks."""
 import json
 import os
+os.environ.setdefault("BLACKLIGHT_AMD_ARITHMETIC", "exact")   # (a context starts in this tier; the tool names the tolerant one where it wants it)
 import sys
 import time
 

@@ -8,6 +8,7 @@ against the windows tests/test_gpu_configs_at_size.py::test_config_5_windows_of_
 """
 import json
 import os
+os.environ.setdefault("BLACKLIGHT_AMD_ARITHMETIC", "exact")   # (a context starts in this tier; the tool names the tolerant one where it wants it)
 import sys
 import time
 import zipfile

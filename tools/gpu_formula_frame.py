@@ -2,6 +2,7 @@
 ray_max_steps = 7000) with a 512^2 camera, one MI355X. Prints per-kernel times; `python tools/gpu_formula_frame.py [exact|tolerant] [reps]`."""
 import json
 import os
+os.environ.setdefault("BLACKLIGHT_AMD_ARITHMETIC", "exact")   # (a context starts in this tier; the tool names the tolerant one where it wants it)
 import sys
 import time
 

@@ -5,6 +5,7 @@ bit for bit in the exact tier, and the loaded frame in the tolerant tier equal t
 saved and loaded under a scratch limit of several chunks.    python3 tools/gpu_fuzz_checkpoint.py [n_seeds] [first_seed]"""
 import json
 import os
+os.environ.setdefault("BLACKLIGHT_AMD_ARITHMETIC", "exact")   # (a context starts in this tier; the tool names the tolerant one where it wants it)
 import sys
 import tempfile
 import time

@@ -5,6 +5,7 @@ The fixture's polar cut stays on - without it the reference reads past its array
 with its angle drawn.     python3 tools/gpu_fuzz_fmks.py [n_seeds] [first_seed]"""
 import json
 import os
+os.environ.setdefault("BLACKLIGHT_AMD_ARITHMETIC", "exact")   # (a context starts in this tier; the tool names the tolerant one where it wants it)
 import sys
 import time
 

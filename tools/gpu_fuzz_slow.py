@@ -4,6 +4,7 @@ times, window handling, time interpolation on and off, trilinear / nearest sampl
 the CPU oracle bit for bit, warnings and refusals included (a tool, not a test).   python3 tools/gpu_fuzz_slow.py [n_seeds] [first]"""
 import json
 import os
+os.environ.setdefault("BLACKLIGHT_AMD_ARITHMETIC", "exact")   # (a context starts in this tier; the tool names the tolerant one where it wants it)
 import sys
 import time
 

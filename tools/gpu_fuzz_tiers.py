@@ -12,6 +12,7 @@ for every `oracle_every`-th seed the exact tier bit for bit against the CPU orac
 import dataclasses
 import json
 import os
+os.environ.setdefault("BLACKLIGHT_AMD_ARITHMETIC", "exact")   # (a context starts in this tier; the tool names the tolerant one where it wants it)
 import sys
 import time
 

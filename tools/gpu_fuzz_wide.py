@@ -11,6 +11,7 @@ electron entropy, Cartesian grids - run for many more seeds than the test keeps,
     python3 tools/gpu_fuzz_wide.py [n_seeds] [first_seed]"""
 import json
 import os
+os.environ.setdefault("BLACKLIGHT_AMD_ARITHMETIC", "exact")   # (a context starts in this tier; the tool names the tolerant one where it wants it)
 import sys
 import time
 

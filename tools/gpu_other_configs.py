@@ -3,6 +3,7 @@ checks that they run at size and reports their speed): config 1 = example_formul
 physics = example_true_color (10 frequencies, lin_wave) at 1024^2 over the 256^3 mock."""
 import json
 import os
+os.environ.setdefault("BLACKLIGHT_AMD_ARITHMETIC", "exact")   # (a context starts in this tier; the tool names the tolerant one where it wants it)
 import sys
 import time
 

@@ -2,6 +2,7 @@
 over the 256^3 mock, plain camera of the given resolution (default 1024). Prints per-kernel times."""
 import json
 import os
+os.environ.setdefault("BLACKLIGHT_AMD_ARITHMETIC", "exact")   # (a context starts in this tier; the tool names the tolerant one where it wants it)
 import sys
 import time
 

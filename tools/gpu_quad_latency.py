@@ -1,6 +1,7 @@
 """The time of a ray alone: frames of 64 rays around the photon ring (one wave of bl_geodesic_kernel, four of bl_geodesic_quad_kernel with
 BL_SWITCH_QUAD_EVERY_RAY) - the geodesic stage's time is its longest ray's.   python3 tools/gpu_quad_latency.py"""
 import os
+os.environ.setdefault("BLACKLIGHT_AMD_ARITHMETIC", "exact")   # (a context starts in this tier; the tool names the tolerant one where it wants it)
 import sys
 
 import numpy as np

@@ -1,6 +1,7 @@
 """How long the benchmark frame's rays take by impact parameter: 64 pixels of the 1024^2 plane camera on a ring of radius b (one wave of
 bl_geodesic_kernel; its time is its longest ray's), b in steps.   python3 tools/gpu_ray_length_by_radius.py"""
 import os
+os.environ.setdefault("BLACKLIGHT_AMD_ARITHMETIC", "exact")   # (a context starts in this tier; the tool names the tolerant one where it wants it)
 import sys
 
 import numpy as np

@@ -2,6 +2,7 @@
 general-spin instantiations. python tools/gpu_spin_frame.py [exact|tolerant]"""
 import json
 import os
+os.environ.setdefault("BLACKLIGHT_AMD_ARITHMETIC", "exact")   # (a context starts in this tier; the tool names the tolerant one where it wants it)
 import sys
 import time
 

@@ -3,6 +3,7 @@
 distances, how many samples went to the exact second pass.  python3 tools/gpu_tier_distance.py [resolution] [grid]
 BLACKLIGHT_AMD_GENERAL_FUSED=1 in the environment selects the general fused kernel (A/B of the two)."""
 import os
+os.environ.setdefault("BLACKLIGHT_AMD_ARITHMETIC", "exact")   # (a context starts in this tier; the tool names the tolerant one where it wants it)
 import sys
 
 import numpy as np
