@@ -188,6 +188,7 @@ __global__ void __launch_bounds__(64, BL_GEO_ONE_WAVE(kIntegrator, kTime, kSpinZ
     park_lds[3] = 0;
     park_lds[4] = 0;
   }
+  if (kPark) __syncthreads();   // (lane 0's words before any lane reads them; one s_barrier on a one-wave workgroup, executed once)
 #ifdef BL_GEO_STATS
   // per lane: step attempts, accepted steps, samples emitted; per wave (lane 0): loop iterations, emission iterations, refills,
   // lane-iterations with a ray

@@ -100,15 +100,23 @@ void LoadGeodesicCheckpoint(bl_ctx *ctx) {
   struct stat info {};
   std::string key = p.checkpoint_geodesic_file.s;
   if (stat(p.checkpoint_geodesic_file.s, &info) == 0)
-    key += "|" + std::to_string(static_cast<long long>(info.st_size)) + "|" + std::to_string(static_cast<long long>(info.st_mtime)) + "|"
-        + std::to_string(static_cast<long long>(info.st_ino));
+    key += "|" + std::to_string(static_cast<long long>(info.st_size)) + "|" + std::to_string(static_cast<long long>(info.st_mtim.tv_sec)) + "."
+        + std::to_string(static_cast<long long>(info.st_mtim.tv_nsec)) + "|" + std::to_string(static_cast<long long>(info.st_ctim.tv_sec)) + "."
+        + std::to_string(static_cast<long long>(info.st_ctim.tv_nsec)) + "|" + std::to_string(static_cast<long long>(info.st_ino));   // (a file rewritten in place within a second is another file)
   key += "|" + std::to_string(p.camera_resolution) + "|" + std::to_string(p.image_num_frequencies) + "|" + std::to_string(p.ray_max_steps);
+  // (The table's lock covers the look-up only. Two contexts that ask for the same file for the first time at the same moment both read
+  // it - tens of GB at 1024^2 - and the second keeps the first one's copy; a context that loads another file never waits behind them.)
   std::shared_ptr<const bl_ctx::Checkpoint> loaded;
   {
     std::lock_guard<std::mutex> guard(table_lock);
     loaded = table[key].lock();
-    if (!loaded) {   // (read under the lock: a second context asking for the same file waits for the first one's read instead of repeating it)
-      loaded = ReadGeodesicCheckpoint(p);
+  }
+  if (!loaded) {
+    std::shared_ptr<const bl_ctx::Checkpoint> mine = ReadGeodesicCheckpoint(p);
+    std::lock_guard<std::mutex> guard(table_lock);
+    loaded = table[key].lock();
+    if (!loaded) {
+      loaded = mine;
       table[key] = loaded;
     }
   }

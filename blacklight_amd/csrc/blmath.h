@@ -406,8 +406,11 @@ static inline __device__ double bl_pow_neg_fifth(double x) {
     const double delta = __builtin_fma(y * 0x1p-54, ln_y, (y * 0.2) * rho);
     const double s = y + delta;
     const double t = (y - s) + delta;                        /* y + delta = s + t exactly (|delta| << |y|) */
-    /* s lies in [1/2, 1]: half a unit in its last place is 2^-54 (2^-53 above 1, which m >= 1 never reaches) */
-    fast = !(blm_abs(t) >= 0x1p-54 * (1.0 - 0x1p-12));
+    /* Half a unit in the last place of s: 2^-54 for s in [1/2, 1] (m >= 1 keeps s <= 1) - and 2^-55 below 1/2, where the factor
+       Y^(2^-54) can push s for x just under a power of 32, and for s = 1/2 itself when the remainder points downwards (the
+       neighbour below is half as far away). Without the case the guard never fired in that binade (|t| <= 2^-55 there). */
+    const double half_ulp = (s < 0.5 || (s == 0.5 && t < 0.0)) ? 0x1p-55 : 0x1p-54;
+    fast = !(blm_abs(t) >= half_ulp * (1.0 - 0x1p-12));
     result = s * blm_pow2i(-q);                              /* exact: |q| <= 180 */
   }
   return fast ? result : bl_pow(x, -0.2);

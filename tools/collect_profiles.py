@@ -24,7 +24,7 @@ source = (f"profiles/{tag}_hbm_traffic_raw.json: rocprofv3 --pmc FETCH_SIZE and 
 record = {"csrc_sha256_16": bench.kernel_source_hash(),
           "launch": f"one launch per frame of the 1024^2 / 256^3 benchmark; {line['roofline']['algorithmic_bytes_per_launch'] / 1e9:.2f} GB algorithmic "
                     "per launch (256 B x gathered samples + 13 B x rays)"}
-for tier, prefix in (("tolerant", "void " + line["roofline"]["kernel"]), ("exact", "void bl_shade_exact_kernel")):
+for tier, prefix in (("tolerant", "void " + line["roofline"]["kernel"]), ("exact", "void bl_shade_exact")):
     for k, v in raw.items():
         if k.startswith(prefix):
             record[tier] = {"kernel": k, "coefficient_kernel_bytes_per_launch": v["fetch_bytes_per_launch_x2_corrected"] + v["write_bytes_per_launch"],
