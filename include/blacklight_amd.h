@@ -309,12 +309,12 @@ typedef struct bl_stats {
 #define BL_SWITCH_GENERAL_FUSED (1u << 7)                   /* bl_shade_fused_kernel where bl_shade_fused2_kernel applies       */
 #define BL_SWITCH_SAMPLE_RECORDS (1u << 8)                  /* tolerant tier: one transfer record per sample where composed maps apply */
 #define BL_SWITCH_UNPIPELINED_SHADE (1u << 9)               /* bl_shade_kernel where bl_shade_exact_kernel applies              */
-#define BL_SWITCH_QUAD_TAIL (1u << 10)                      /* the last rays of a chunk finished by bl_geodesic_quad_kernel (a ray per quad of lanes) */
+#define BL_SWITCH_QUAD_TAIL (1u << 10)                      /* = bl_set_tail_policy(BL_TAIL_QUAD): the last rays of a chunk finished by bl_geodesic_quad_kernel */
 #define BL_SWITCH_QUAD_EVERY_RAY (1u << 11)                 /* every ray parked before its first step: all stepping in bl_geodesic_quad_kernel */
-#define BL_SWITCH_TAIL_OVERLAP (1u << 12)                   /* the coefficient kernel beside the last rays of a chunk (a second geodesic launch)  */
-#define BL_SWITCH_BRICK_CELLS (1u << 14)                    /* bl_set_grid also stores every anchor cell's 2 x 2 x 2 stencil contiguously (8 x the cells), bl_shade_fused2_kernel gathers from it */
-#define BL_SWITCH_SPLIT_LONG (1u << 15)                     /* rays predicted long (a band of impact parameters around the photon ring) stepped by bl_geodesic_quad_kernel on compute units of their own from the first moment */
-#define BL_SWITCH_TAIL_REPACKED (1u << 13)                  /* the last rays of a chunk repacked into full waves by a second geodesic launch, nothing beside it */
+#define BL_SWITCH_TAIL_OVERLAP (1u << 12)                   /* (measured: loses) the coefficient kernel beside the last rays of a chunk (a second geodesic launch)  */
+#define BL_SWITCH_BRICK_CELLS (1u << 14)                    /* (measured: loses) bl_set_grid also stores every anchor cell's 2 x 2 x 2 stencil contiguously (8 x the cells), bl_shade_fused2_kernel gathers from it */
+#define BL_SWITCH_SPLIT_LONG (1u << 15)                     /* = bl_set_tail_policy(BL_TAIL_SPLIT), with the BLACKLIGHT_AMD_SPLIT_* knobs of the sweeps: rays predicted long (a band of impact parameters around the photon ring) stepped by bl_geodesic_quad_kernel on compute units of their own from the first moment */
+#define BL_SWITCH_TAIL_REPACKED (1u << 13)                  /* (measured: loses) the last rays of a chunk repacked into full waves by a second geodesic launch, nothing beside it */
 
 typedef struct bl_ctx bl_ctx;
 
