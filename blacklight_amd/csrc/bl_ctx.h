@@ -127,6 +127,7 @@ struct bl_ctx {
   // and the rays predicted long, the rest for bl_geodesic_kernel (hipExtStreamCreateWithCUMask)
   hipStream_t stream_few = nullptr, stream_most = nullptr;   // (borrowed from a process-wide table, never destroyed: bl_render.hip)
   int split_cus = 0;                  // BLACKLIGHT_AMD_SPLIT_CUS: compute units of the quad stepper; 0 = an eighth of the device
+  int split_rounds = 0;               // BLACKLIGHT_AMD_SPLIT_ROUNDS: rounds of quads the band is sized for; 0 = chosen by bl_render
   int split_cus_made = 0;             // ... of the streams that exist
   int polcoef_blocks_per_cu = 0;      // BLACKLIGHT_AMD_POLCOEF_BLOCKS: 256-thread workgroups of bl_polarized_coefficients_kernel per compute unit (0: twenty)
   int split_lds_pad = 39 * 1024;      // BLACKLIGHT_AMD_SPLIT_LDS_PAD: LDS a wave of either stepper reserves so that a CU takes four of them, one per SIMD

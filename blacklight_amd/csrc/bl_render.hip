@@ -344,10 +344,11 @@ void PlanJob(RenderJob &job) {
   // On request (a measurement switch): the rays of a plane camera's root level whose impact parameter lies in a
   // band around the photon ring's, stepped by bl_geodesic_quad_kernel on compute units the other stepper is kept off
   const bool split_forced = ctx->tail_policy == BL_TAIL_SPLIT || (ctx->switches & BL_SWITCH_SPLIT_LONG) != 0;
-  // (BL_TAIL_AUTO: where the geodesic stage waits for single rays - at most two rays per lane of a grid of one wave per SIMD - and the
-  // critical curve is the circle b = 3 sqrt(3) M: no spin)
+  // (BL_TAIL_AUTO: where the geodesic stage waits for single rays - up to eight rays per lane of a grid of one wave per SIMD: a share
+  // of a frame tiled over two or more GPUs, measured 1.13 / 1.09 / 1.02 x at an eighth / a quarter / a half of the benchmark frame, 1.00 for
+  // the whole - and the critical curve is the circle b = 3 sqrt(3) M: no spin)
   const bool split_auto = ctx->tail_policy == BL_TAIL_AUTO && !ctx->split_unavailable && ctx->st.bh_a == 0.0 && !p.ray_flat
-      && job.n_rays >= 32768 && job.n_rays <= 2ll * 256 * ctx->num_cus;
+      && job.n_rays >= 32768 && job.n_rays <= 8ll * 256 * ctx->num_cus;
   job.split_long = parkable && !job.park && (split_forced || split_auto) && p.camera_type == BL_CAMERA_PLANE && d->level == 0
       && !(ctx->switches & (BL_SWITCH_TAIL_OVERLAP | BL_SWITCH_TAIL_REPACKED));
   // On request (a measurement switch: it does not pay) the coefficient kernel runs beside the last rays
@@ -472,7 +473,10 @@ void PlanScratch(RenderJob &job) {
     const double per_width = static_cast<double>(inside) * static_cast<double>(job.n_rays) / static_cast<double>(std::max<long long>(seen, 1)) / (ref_hi - ref_lo);
     job.split_cus = ctx->split_cus > 0 ? std::min(ctx->split_cus, ctx->num_cus / 2) : std::max(1, ctx->num_cus / 8);
     const double outer = 0.03 * ctx->st.bh_m;
-    double width = per_width > 0.0 ? 0.9 * 64.0 * job.split_cus / per_width : 0.0;   // of the band, for one round of quads
+    // (rounds of quads: one where the stage is a few rays per lane long - a second round would end after the other stepper -, more
+    // where the other stepper has many rays per lane to get through and the quad stepper's compute units would stand idle meanwhile)
+    const int rounds = ctx->split_rounds > 0 ? ctx->split_rounds : (job.n_rays > 2ll * 256 * ctx->num_cus ? 2 : 1);   // (a quarter of the frame: 14.0 ms with two, 14.6 with one, 14.5 with three)
+    double width = per_width > 0.0 ? 0.9 * 64.0 * job.split_cus * rounds / per_width : 0.0;   // of the band
     width = std::min(width, 0.45 * ctx->st.bh_m);
     if (ctx->split_band > 0.0) {   // (BLACKLIGHT_AMD_SPLIT_BAND: a symmetric band of that half-width, for measurements)
       job.split_b_lo = centre - ctx->split_band;

@@ -397,8 +397,8 @@ BL_API int bl_set_reproducible(bl_ctx *ctx, int on);
  * stream whose CU mask keeps the other stepper off its compute units (hipExtStreamCreateWithCUMask); pays where the geodesic
  * stage waits for single rays - a rank's share of a tiled frame: an eighth of the benchmark frame 8.0 -> 7.2 ms - and needs a
  * non-rotating hole (the critical curve is a circle), the Dormand-Prince stepper and a call whose rays fit one chunk.
- * BL_TAIL_AUTO (default): QUAD in formula mode; SPLIT where it applies and the call has at most two rays per lane of the
- * device; else WIDE. bl_stats.tail_policy says what the last render did. */
+ * BL_TAIL_AUTO (default): QUAD in formula mode; SPLIT where it applies and the call has at most eight rays per lane of the
+ * device (a share of a frame tiled over two or more GPUs); else WIDE. bl_stats.tail_policy says what the last render did. */
 #define BL_TAIL_AUTO 0
 #define BL_TAIL_WIDE 1
 #define BL_TAIL_QUAD 2

@@ -111,7 +111,7 @@ def test_render_waits_for_the_callers_stream():
 
 
 def test_a_share_of_a_frame_takes_the_split_steppers_by_default():
-    """BL_TAIL_AUTO over a simulation grid: a call with at most two rays per lane of the device, a plane camera and no spin gives the
+    """BL_TAIL_AUTO over a simulation grid: a call with at most eight rays per lane of the device (a share of a tiled frame), a plane camera and no spin gives the
     photon ring's rays to the quad stepper on compute units of its own (BL_TAIL_SPLIT) - same bits; with spin, or more rays, it does not."""
     import blacklight_amd as bl
     p, grid = _benchmark_like(256, 32)
