@@ -218,3 +218,40 @@ def test_block_layout_matches_the_round_robin_deal():
     full = layout.detile(gathered, 2)
     m = torch.arange(n_blocks * 16, dtype=torch.float64)
     assert torch.equal(full[0], m) and torch.equal(full[1], -m)
+
+
+def _frame_loop_worker(rank, world, port, resolution, tile, result_path):
+    """bench.py's N > 1 frame loop on CPU tensors over gloo: Comm.gather_flat into the buffer rank 0 keeps, ShareLayout.detile, twice -
+    the second frame must reuse buffer, layout and index."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from blacklight_amd import distributed as bd
+    comm = bd.Comm(device=torch.device("cpu"))
+    layout = bd.frame_layout(resolution, world, tile)
+    pixels = layout.pixels[rank]
+    image = torch.zeros((1, layout.n_padded), dtype=torch.float64)
+    frames, buffers = [], []
+    for frame in range(2):
+        image[0, : pixels.size] = torch.from_numpy(pixels.astype(np.float64)) + 1000.0 * frame
+        builds = bd.ShareLayout.builds
+        gathered = comm.gather_flat(image.reshape(-1), dst=0)
+        if rank == 0:
+            frames.append(layout.detile(gathered, 1).clone())
+            buffers.append(gathered.data_ptr())
+        assert bd.ShareLayout.builds == builds and bd.frame_layout(resolution, world, tile) is layout
+    if rank == 0:
+        torch.save({"frames": frames, "same_buffer": buffers[0] == buffers[1]}, result_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_frame_loop_of_the_benchmark_over_gloo(tmp_path, world):
+    resolution, tile = 96, 32   # nine tiles: shares of 5 + 4 (world 2) or 3 + 3 + 3 tiles
+    result_path = str(tmp_path / "frames.pt")
+    mp.spawn(_frame_loop_worker, args=(world, _free_port(), resolution, tile, result_path), nprocs=world, join=True)
+    out = torch.load(result_path)
+    want = torch.arange(resolution * resolution, dtype=torch.float64)
+    assert torch.equal(out["frames"][0][0], want) and torch.equal(out["frames"][1][0], want + 1000.0)
+    assert out["same_buffer"]
