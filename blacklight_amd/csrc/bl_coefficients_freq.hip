@@ -16,7 +16,9 @@
 // kThermalOnly: no power-law and no kappa-distribution electrons (the host knows): without their formulas the exact kernel fits three
 // waves per SIMD instead of two (168 registers), which is worth 8 ms of a 1024^2 frame's 106.
 template <bool kTolerant, bool kThermalOnly>
-__global__ void __launch_bounds__(256, (kThermalOnly && !kTolerant) ? 3 : BL_POLCOEF_WAVES) bl_polarized_coefficients_kernel(const BlShadeArgs P) {
+__global__ void __launch_bounds__(256, (kThermalOnly && !kTolerant) ? 3 : BL_POLCOEF_WAVES) bl_polarized_coefficients_kernel(const BlShadeArgs P_at_entry) {
+  // (with power-law or kappa electrons the kernel holds ~45 more scalars than there are registers for: it reads its arguments where it uses them)
+  const BlShadeArgs &P = kThermalOnly ? P_at_entry : kernel_arguments_in_place<BlShadeArgs>();
   const unsigned long long n_records = P.counters_in[BL_CNT_RECORDS];
   const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
   for (unsigned long long idx = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; idx < n_records; idx += stride) {

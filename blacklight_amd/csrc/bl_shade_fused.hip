@@ -1127,8 +1127,10 @@ __global__ void __launch_bounds__(256, 2) bl_shade_polarized2_kernel(const BlSha
       }
       if (status != kSampleCut)
         sample_finish_simulation<true, true>(P, st, ks, x3 / ks.r, loc_prev.ph_unwrapped, pr, 0.0f, kcov, P.aux_need_coefficients, &sh, P.pol_samples + row);
-      if (kAuxRecords) write_aux_record(P, st, ks, idx_cur, row, sh, kcov, x1, x2, x3, delta_lambda);
-      write_polarized_inputs(P, idx_cur, row, sh, kcov, pr, x1, x2, x3, delta_lambda);
+      // (what these two read of the arguments - output arrays, the list of samples without coefficients - they read where they use it)
+      const BlShadeArgs &A = kernel_arguments_in_place<BlShadeArgs>();
+      if (kAuxRecords) write_aux_record(A, st, ks, idx_cur, row, sh, kcov, x1, x2, x3, delta_lambda);
+      write_polarized_inputs(A, idx_cur, row, sh, kcov, pr, x1, x2, x3, delta_lambda);
     }
     // the corner cells of `cur`: requested behind the frame's arithmetic, whose tetrad needs the sixty-four registers they land in
     // (with the requests in front of it the kernel keeps 3 ... 24 registers in scratch memory); the search for `next` and the
