@@ -84,11 +84,11 @@ __global__ void __launch_bounds__(256, (kThermalOnly && !kTolerant) ? 3 : BL_POL
         if (!(kappa < 1e6)) atomicAdd(&P.counters[BL_CNT_DEBUG + 3], 1ull);
       }
 #endif
-      P.transfer[at + l] = make_double2(j_val, alpha_val);
-      double2 *out = P.pol_coeffs + (at + l) * 3;
-      out[0] = pc[0];
-      out[1] = pc[1];
-      out[2] = pc[2];
+      double2 *out = P.pol_coeffs + (at + l) * 4;
+      out[0] = make_double2(j_val, alpha_val);
+      out[1] = pc[0];
+      out[2] = pc[1];
+      out[3] = pc[2];
     }
   }
 }

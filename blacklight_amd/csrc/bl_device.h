@@ -419,7 +419,8 @@ struct BlShadeArgs {
   const unsigned char *ray_flags;
   // polarized transfer only (runs in auxiliary-image mode): null otherwise
   BlPolSample *pol_samples;   // [sample row]
-  double2 *pol_coeffs;        // [sample row][n_nu][3]: (j_Q, j_V), (alpha_Q, alpha_V), (rho_Q, rho_V)
+  double2 *pol_coeffs;        // [sample row][n_nu][4]: (j_I, alpha_I), (j_Q, j_V), (alpha_Q, alpha_V), (rho_Q, rho_V) - one 64-byte record, half a
+                              // cache line, for the lane of the sequential kernels that walks the ray (polarized runs have no `transfer` array)
   BlCoefInputs *coef_inputs;  // [record capacity]: coefficient kernel -> polarized coefficient kernel
   unsigned int *anchors;      // inter-block interpolation: [record capacity][8] cells of the eight anchors, else null
   double power_pol[7];        // simulation_coefficients.cpp:67-80: jj_q, jj_v, aa_q, aa_v, rho, rho_q, rho_v
@@ -449,6 +450,8 @@ struct BlTransferArgs {
   int simulation_coord, rotation_split;
   double cam_u_con[4], cam_u_cov[4], cam_vert_con_c[4];
   const double2 *transfer;
+  int ja_stride;                           // records between the (j, alpha) of consecutive (sample, frequency) pairs as bl_transfer_aux_kernel reads them:
+                                           // 1, or 4 in polarized runs, where `transfer` is pol_coeffs
   const double *tau_inc;                   // bl_tau_kernel: [sample row][n_nu], rows summed into image row tau_row + l
   int tau_row;
   const unsigned long long *counters;      // BL_CNT_NEXT_RAY: rays of the chunk the geodesic kernel traced (bl_rays_done)

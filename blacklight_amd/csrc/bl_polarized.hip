@@ -462,8 +462,7 @@ __global__ void __launch_bounds__(64) bl_transfer_polarized_kernel(BlTransferArg
   const size_t row = (size_t)P.n_rays_total;
   double *img = P.image + out_index;
   const BlPolSample *samples = P.pol_samples + (size_t)P.ray_offset[slot];
-  const double2 *ja = P.transfer + (size_t)P.ray_offset[slot] * P.n_nu;
-  const double2 *pc = P.pol_coeffs + (size_t)P.ray_offset[slot] * P.n_nu * 3;
+  const double2 *pc = P.pol_coeffs + (size_t)P.ray_offset[slot] * P.n_nu * 4;
   for (int l = 0; l < P.n_nu; l++) {
     const double freq = P.frequencies[l];
     if (num <= 0) {   // :94-96: nothing integrated; rows stay as the auxiliary kernel zeroed them
@@ -499,7 +498,7 @@ __global__ void __launch_bounds__(64) bl_transfer_polarized_kernel(BlTransferArg
       Coupling c;
       {
         const size_t at = (size_t)rec * P.n_nu + l;
-        const double2 c0 = ja[at], c1 = pc[at * 3 + 0], c2 = pc[at * 3 + 1], c3 = pc[at * 3 + 2];
+        const double2 c0 = pc[at * 4 + 0], c1 = pc[at * 4 + 1], c2 = pc[at * 4 + 2], c3 = pc[at * 4 + 3];
         c.j_s[0] = c0.x; c.j_s[1] = c1.x; c.j_s[2] = 0.0; c.j_s[3] = c1.y;
         c.alpha_s[0] = c0.y; c.alpha_s[1] = c2.x; c.alpha_s[2] = 0.0; c.alpha_s[3] = c2.y;
         c.rho_s[0] = 0.0; c.rho_s[1] = c3.x; c.rho_s[2] = 0.0; c.rho_s[3] = c3.y;
@@ -918,7 +917,7 @@ __global__ void __launch_bounds__(256, 2) bl_transport_matrix_kernel(BlTransferA
         const int unit = lane + 64 * j;
         const int sample = unit / 6;
         if (base_cur + sample < num_cur)
-          matrices[(size_t)base_cur * 6 + unit] = *reinterpret_cast<const double2 *>(tile + sample * kMkOutStride + (unit - sample * 6) * 16);
+          matrices[(size_t)(base_cur + sample) * (BL_POL_MATRIX_DOUBLES / 2) + (unit - sample * 6)] = *reinterpret_cast<const double2 *>(tile + sample * kMkOutStride + (unit - sample * 6) * 16);
       }
     }
     return live;
@@ -943,8 +942,7 @@ __global__ void __launch_bounds__(64, 2) bl_transfer_polarized_matrix_kernel(BlT
   double *img = P.image + out_index;
   const BlPolSample *samples = P.pol_samples + (size_t)P.ray_offset[slot];
   const double *matrices = P.pol_matrix + (size_t)P.ray_offset[slot] * BL_POL_MATRIX_DOUBLES;
-  const double2 *ja = P.transfer + (size_t)P.ray_offset[slot] * P.n_nu;
-  const double2 *pc = P.pol_coeffs + (size_t)P.ray_offset[slot] * P.n_nu * 3;
+  const double2 *pc = P.pol_coeffs + (size_t)P.ray_offset[slot] * P.n_nu * 4;
   // the last sample's second half step and the camera projection do not depend on the frequency
   double m_cam[10];
   if (num > 0) {
@@ -996,7 +994,7 @@ __global__ void __launch_bounds__(64, 2) bl_transfer_polarized_matrix_kernel(BlT
       const double2 *mq = reinterpret_cast<const double2 *>(matrices + (size_t)(num - 1) * BL_POL_MATRIX_DOUBLES);
       n0 = mq[0]; n1 = mq[1]; n2 = mq[2]; n3 = mq[3]; n4 = mq[4]; n5 = mq[5];
       const size_t at = (size_t)(num - 1) * P.n_nu + l;
-      nc0 = ja[at]; nc1 = pc[at * 3 + 0]; nc2 = pc[at * 3 + 1]; nc3 = pc[at * 3 + 2];
+      nc0 = pc[at * 4 + 0]; nc1 = pc[at * 4 + 1]; nc2 = pc[at * 4 + 2]; nc3 = pc[at * 4 + 3];
     }
     for (int rec = num - 1; rec >= 0; rec--) {
       const double2 m0 = n0, m1 = n1, m2 = n2, m3 = n3, m4 = n4;
@@ -1010,7 +1008,7 @@ __global__ void __launch_bounds__(64, 2) bl_transfer_polarized_matrix_kernel(BlT
         const double2 *mq = reinterpret_cast<const double2 *>(matrices + (size_t)next * BL_POL_MATRIX_DOUBLES);
         n0 = mq[0]; n1 = mq[1]; n2 = mq[2]; n3 = mq[3]; n4 = mq[4]; n5 = mq[5];
         const size_t at = (size_t)next * P.n_nu + l;
-        nc0 = ja[at]; nc1 = pc[at * 3 + 0]; nc2 = pc[at * 3 + 1]; nc3 = pc[at * 3 + 2];
+        nc0 = pc[at * 4 + 0]; nc1 = pc[at * 4 + 1]; nc2 = pc[at * 4 + 2]; nc3 = pc[at * 4 + 3];
       }
       double ss_start[4];
       ss_start[0] = m0.x * ss_end[0] + m0.y * ss_end[1] + m1.x * ss_end[2];
@@ -1023,9 +1021,9 @@ __global__ void __launch_bounds__(64, 2) bl_transfer_polarized_matrix_kernel(BlT
       for (int a = 0; a < 4; a++) ss_end[a] = ss_start[a] + c.j_s[a] * delta_lambda_cgs + c.alpha_s[a] + c.rho_s[a];
 #else
       couple_sample<CouplingMathTolerant>(&c, P.rotation_split != 0, delta_lambda_cgs, ss_start, ss_end);
-#endif
       tau += c.delta_tau;   // unpolarized.cpp:139-140 (BlAuxImages::polarized_rows_only: written below)
     }
+#endif
     const double nu_cu = freq * freq * freq;
     img[(size_t)(4 * l + 0) * row] = (m_cam[0] * ss_end[0] + m_cam[1] * ss_end[1] + m_cam[2] * ss_end[2]) * nu_cu;
     img[(size_t)(4 * l + 1) * row] = (m_cam[3] * ss_end[0] + m_cam[4] * ss_end[1] + m_cam[5] * ss_end[2]) * nu_cu;

@@ -380,10 +380,10 @@ void PlanScratch(RenderJob &job) {
   // more than records)
   job.bytes_per_record = sizeof(BlSampleHot) + sizeof(BlSampleCold)
       + ((job.simulation && !job.locate_inside) ? sizeof(BlLocated) + sizeof(unsigned long long) : 0)
-      + (job.freq_split ? sizeof(BlFreqInputs) : sizeof(double2) * n_nu) + (job.tau_row ? sizeof(double) * n_nu : 0)
+      + (job.freq_split ? sizeof(BlFreqInputs) : (ctx->polarized ? 0 : sizeof(double2) * n_nu)) + (job.tau_row ? sizeof(double) * n_nu : 0)
       + (job.composed ? sizeof(double2) : 0)
       + ((job.aux && !job.rows_only) ? sizeof(BlAuxSample) : 0) + (job.need_time ? sizeof(double) : 0) + (job.slow ? sizeof(double) : 0)
-      + (ctx->polarized ? sizeof(BlPolSample) + sizeof(BlCoefInputs) + 3 * sizeof(double2) * n_nu : 0)
+      + (ctx->polarized ? sizeof(BlPolSample) + sizeof(BlCoefInputs) + 4 * sizeof(double2) * n_nu : 0)
       + (job.coef_split ? sizeof(BlCoefInputs) : 0)
       + (job.matrix_transport ? BL_POL_MATRIX_DOUBLES * sizeof(double) : 0)
       + (job.block_interp ? 8 * sizeof(unsigned int) : 0);
@@ -526,7 +526,7 @@ void EnsureScratchOnce(RenderJob &job) {
       sl.d_located_tag.Ensure(cap);
     }
     if (job.freq_split) sl.d_freq_inputs.Ensure(cap);   // instead of the transfer records
-    else sl.d_transfer.Ensure(cap * n_nu);
+    else if (!ctx->polarized) sl.d_transfer.Ensure(cap * n_nu);   // (polarized runs: the eight coefficients of a sample side by side, d_pol_coeffs)
     if (job.composed) sl.d_composed.Ensure(cap);
     if (job.park || job.tail_overlap || job.split_long) sl.d_parked.Ensure(job.park_capacity * BL_PARK_DOUBLES);
     if (job.tau_row) sl.d_tau_inc.Ensure(cap * n_nu);
@@ -537,7 +537,7 @@ void EnsureScratchOnce(RenderJob &job) {
     if (ctx->polarized) {
       sl.d_pol_samples.Ensure(cap);
       if (job.matrix_transport) sl.d_pol_matrix.Ensure(cap * BL_POL_MATRIX_DOUBLES);
-      sl.d_pol_coeffs.Ensure(cap * n_nu * 3);
+      sl.d_pol_coeffs.Ensure(cap * n_nu * 4);
       sl.d_coef_inputs.Ensure(cap);
     }
     if (job.coef_split) sl.d_coef_inputs.Ensure(cap);
@@ -1091,7 +1091,7 @@ void BindChunk(RenderJob &job, int k, long long begin, int rays) {
   sa.ray_factor = ta.ray_factor;
   sa.ray_offset = ta.ray_offset;
   sa.ray_flags = ta.ray_flags;
-  sa.transfer = sl.d_transfer.ptr;
+  sa.transfer = ctx->polarized ? nullptr : sl.d_transfer.ptr;
   sa.composed = job.composed ? sl.d_composed.ptr : nullptr;
   sa.fused_variant = job.fused2 ? 1 : 0;
   sa.record_range = 0;
@@ -1108,7 +1108,8 @@ void BindChunk(RenderJob &job, int k, long long begin, int rays) {
   }
   xa.chunk_rays = rays;
   xa.counters = sl.d_counters.ptr;
-  xa.transfer = sl.d_transfer.ptr;
+  xa.transfer = ctx->polarized ? sl.d_pol_coeffs.ptr : sl.d_transfer.ptr;
+  xa.ja_stride = ctx->polarized ? 4 : 1;
   xa.composed = sa.composed;
   xa.ray_rows = ta.ray_rows;
   xa.tau_inc = sa.tau_inc;

@@ -634,63 +634,73 @@ __global__ void __launch_bounds__(256, BL_FAST_WAVES) bl_shade_fused2_kernel(con
   const uint32_t lane_bytes = lane_index << 6;
   uint32_t base_index = first_record;   // record index of lane 0 of block 0 for the sample `prev` ... (wave-uniform)
   auto record_base = [&](uint32_t first) { return records + ((size_t)(first < last ? first : last) << 6); };
-  double2 prev0 = make_double2(0.0, 0.0), prev1 = make_double2(0.0, __longlong_as_double((long long)BL_DEAD_RAY)), prev2 = prev0, prev3 = prev0;
-  double2 cur0, cur1;
-  double kt_prev = 0.0, factor_prev = 1.0;   // per-ray constants of `prev`, requested an iteration ago with its cells
-  long long row_prev = 0;
-  Located loc_prev, loc_cur;
-  loc_prev.f_i = loc_prev.f_j = loc_prev.f_k = 0.0;
-  loc_prev.status = kSampleNone;
-  loc_prev.cell_bytes = 0u;
+  // Three slots take the roles prev -> next -> cur -> prev in turn, and the loop body is written out once per assignment of roles:
+  // a sample's registers stay where its requests landed from its first iteration to its last, instead of moving down the pipeline
+  // with 46 copies an iteration (the compiler does not unroll a loop whose exit is a wave vote by itself).
+  struct Slot {
+    double2 h0, h1, c0, c1;   // the sample's record: x y | z (ray, row) | k_x k_y | k_z length
+    Located loc;
+    double kt, factor;        // per-ray constants, requested with the cells
+    long long row;
+    bool in;
+  };
+  Slot s0, s1, s2;
+  s0.h0 = s0.c0 = s0.c1 = make_double2(0.0, 0.0);
+  s0.h1 = make_double2(0.0, __longlong_as_double((long long)BL_DEAD_RAY));
+  s0.kt = 0.0;
+  s0.factor = 1.0;
+  s0.row = 0;
+  s0.loc.f_i = s0.loc.f_j = s0.loc.f_k = 0.0;
+  s0.loc.status = kSampleNone;
+  s0.loc.cell_bytes = 0u;
+  s0.in = false;
   float4 lo[8], hi[8];
 #pragma unroll
   for (int c = 0; c < 8; c++) lo[c] = hi[c] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   // (32-bit record indices: the launcher keeps n_records + 3 strides below 2^32)
-  bool cur_in = first_record + lane_index < n_records;
+  s1.in = first_record + lane_index < n_records;
   {
-    const double2 *rec = reinterpret_cast<const double2 *>(record_base(first_record) + (size_t)(cur_in ? lane_bytes : 0u));
-    cur0 = rec[0];
-    cur1 = rec[1];
-    cur1.y = cur_in ? cur1.y : __longlong_as_double((long long)BL_DEAD_RAY);
+    const double2 *rec = reinterpret_cast<const double2 *>(record_base(first_record) + (size_t)(s1.in ? lane_bytes : 0u));
+    s1.h0 = rec[0];
+    s1.h1 = rec[1];
+    s1.h1.y = s1.in ? s1.h1.y : __longlong_as_double((long long)BL_DEAD_RAY);
   }
-  loc_cur = locate<kSpinZero>(st, G, camera_r, band, (uint32_t)__double_as_longlong(cur1.y) != BL_DEAD_RAY, cur0.x, cur0.y, cur1.x);
-  // `prev` is sample base_index - stride + lane_index (none in the first iteration), `cur` base_index + lane_index, `next` one stride on
-  bool prev_in = false;
-  while (__any(prev_in || cur_in)) {
-    const uint32_t ray = (uint32_t)__double_as_longlong(prev1.y);
+  s1.loc = locate<kSpinZero>(st, G, camera_r, band, (uint32_t)__double_as_longlong(s1.h1.y) != BL_DEAD_RAY, s1.h0.x, s1.h0.y, s1.h1.x);
+  // p (`prev`) is sample base_index - stride + lane_index (none in the first iteration), c (`cur`) base_index + lane_index, x (`next`)
+  // one stride on
+  auto iteration = [&](Slot &p, Slot &c, Slot &x) __attribute__((always_inline)) {
+    const uint32_t ray = (uint32_t)__double_as_longlong(p.h1.y);
     const bool live = ray != BL_DEAD_RAY;
-    const uint32_t n = (uint32_t)(((unsigned long long)__double_as_longlong(prev1.y)) >> 32);
-    const uint32_t status = loc_prev.status & 0xffu;
+    const uint32_t n = (uint32_t)(((unsigned long long)__double_as_longlong(p.h1.y)) >> 32);
+    const uint32_t status = p.loc.status & 0xffu;
     const bool interp = status == (uint32_t)kSampleInterp;
     // the position record of `next`: the oldest request of the iteration, used at its end
     const uint32_t next_first = base_index + stride;
-    const bool next_in = next_first + lane_index < n_records;
-    double2 next0, next1;
+    x.in = next_first + lane_index < n_records;
     {
-      const double2 *rec = reinterpret_cast<const double2 *>(record_base(next_first) + (size_t)(next_in ? lane_bytes : 0u));
-      next0 = rec[0];
-      next1 = rec[1];
+      const double2 *rec = reinterpret_cast<const double2 *>(record_base(next_first) + (size_t)(x.in ? lane_bytes : 0u));
+      x.h0 = rec[0];
+      x.h1 = rec[1];
     }
-    const double kt = kt_prev, momentum_factor = factor_prev;
-    const long long row_first = row_prev;
+    const double kt = p.kt, momentum_factor = p.factor;
+    const long long row_first = p.row;
     float pr[8];
-    const bool near_midpoint = trilinear(lo, hi, loc_prev.f_i, loc_prev.f_j, loc_prev.f_k, pr);
+    const bool near_midpoint = trilinear(lo, hi, p.loc.f_i, p.loc.f_j, p.loc.f_k, pr);
     gathers_wave += (unsigned long long)__popcll(__ballot(interp));
-    if (kBricks) fused2::gather_issue_bricks(cells, loc_cur.cell_bytes, lo, hi);
-    else fused2::gather_issue(cells, loc_cur.cell_bytes, (loc_cur.status & 0xffu) == (uint32_t)kSampleInterp, row_bytes, plane_bytes, lo, hi);
-    double2 cold0, cold1;
+    if (kBricks) fused2::gather_issue_bricks(cells, c.loc.cell_bytes, lo, hi);
+    else fused2::gather_issue(cells, c.loc.cell_bytes, (c.loc.status & 0xffu) == (uint32_t)kSampleInterp, row_bytes, plane_bytes, lo, hi);
     {
-      const double2 *rec = reinterpret_cast<const double2 *>(record_base(base_index) + (size_t)(cur_in ? lane_bytes : 0u));
-      cold0 = rec[2];
-      cold1 = rec[3];
+      const double2 *rec = reinterpret_cast<const double2 *>(record_base(base_index) + (size_t)(c.in ? lane_bytes : 0u));
+      c.c0 = rec[2];
+      c.c1 = rec[3];
     }
     // ... and its per-ray constants (random 8-byte reads: a whole iteration ahead of their use, like the cells)
     {
-      const uint32_t ray_cur = (uint32_t)__double_as_longlong(cur1.y);
+      const uint32_t ray_cur = (uint32_t)__double_as_longlong(c.h1.y);
       const uint32_t ray_bytes = (ray_cur != BL_DEAD_RAY ? ray_cur : 0u) << 3;
-      kt_prev = *reinterpret_cast<const double *>(ray_kt + (size_t)ray_bytes);
-      factor_prev = *reinterpret_cast<const double *>(ray_factor + (size_t)ray_bytes);
-      row_prev = *reinterpret_cast<const long long *>(ray_offset + (size_t)ray_bytes);
+      c.kt = *reinterpret_cast<const double *>(ray_kt + (size_t)ray_bytes);
+      c.factor = *reinterpret_cast<const double *>(ray_factor + (size_t)ray_bytes);
+      c.row = *reinterpret_cast<const long long *>(ray_offset + (size_t)ray_bytes);
     }
     // ---- arithmetic of `prev` (ReverseGeodesics: sample_len = -geodesic_len, geodesics.cpp:840)
     // (Inside a branch - taken by every wave that holds a sample on the grid - not for the lanes it skips: a basic block is the
@@ -699,11 +709,11 @@ __global__ void __launch_bounds__(256, BL_FAST_WAVES) bl_shade_fused2_kernel(con
     bool have = false, undecided_cut = false;
     double2 rec = make_double2(1.0, 0.0);
     if (interp)
-      rec = shade<kSpinZero>(st, K, freq, freq_inv, x_unit, cut_mask, cut_table, pr, prev0.x, prev0.y, prev1.x, prev2.x, prev2.y, prev3.x, kt, momentum_factor,
-                             -prev3.y, &have, &undecided_cut);
+      rec = shade<kSpinZero>(st, K, freq, freq_inv, x_unit, cut_mask, cut_table, pr, p.h0.x, p.h0.y, p.h1.x, p.c0.x, p.c0.y, p.c1.x, kt, momentum_factor,
+                             -p.c1.y, &have, &undecided_cut);
     // a sample off the grid has fallback primitives without a field (no coefficients: I <- I) or NaN ones (I <- I + NaN,
     // simulation_sampling.cpp:377-384); a cut sample has none either
-    const bool defer = interp && (undecided_cut || near_midpoint || (loc_prev.status & kPlainUndecided) != 0u);
+    const bool defer = interp && (undecided_cut || near_midpoint || (p.loc.status & kPlainUndecided) != 0u);
     if (!(interp && have)) rec = make_double2(1.0, (status == (uint32_t)kSampleOffGrid && fallback_nan) ? nan : 0.0);
     if (!kComposed) {
       if (live && !defer) {
@@ -763,25 +773,23 @@ __global__ void __launch_bounds__(256, BL_FAST_WAVES) bl_shade_fused2_kernel(con
       }
     }
     if (__builtin_expect(live && defer, 0)) {
-      KernArgs A = kernargs();
-      unsigned long long *counters = A->counters;
+      KernArgs args = kernargs();
+      unsigned long long *counters = args->counters;
       const unsigned long long at = atomicAdd(&counters[BL_CNT_REDO], 1ull);
-      if (at < A->redo_capacity) A->redo_list[at] = (unsigned long long)(base_index - stride + lane_index);
+      if (at < args->redo_capacity) args->redo_list[at] = (unsigned long long)(base_index - stride + lane_index);
     }
     // ---- the search for `next`
-    const Located loc_next = locate<kSpinZero>(st, G, camera_r, band, next_in && (uint32_t)__double_as_longlong(next1.y) != BL_DEAD_RAY, next0.x, next0.y, next1.x);
-    prev0 = cur0;
-    prev1 = cur1;
-    prev2 = cold0;
-    prev3 = cold1;
-    loc_prev = loc_cur;
-    prev_in = cur_in;
-    cur0 = next0;
-    cur1 = next1;
-    cur1.y = next_in ? next1.y : __longlong_as_double((long long)BL_DEAD_RAY);
-    loc_cur = loc_next;
-    cur_in = next_in;
+    x.loc = locate<kSpinZero>(st, G, camera_r, band, x.in && (uint32_t)__double_as_longlong(x.h1.y) != BL_DEAD_RAY, x.h0.x, x.h0.y, x.h1.x);
+    x.h1.y = x.in ? x.h1.y : __longlong_as_double((long long)BL_DEAD_RAY);
     base_index = next_first;
+  };
+  for (;;) {
+    if (!__any(s0.in || s1.in)) break;
+    iteration(s0, s1, s2);
+    if (!__any(s1.in || s2.in)) break;
+    iteration(s1, s2, s0);
+    if (!__any(s2.in || s0.in)) break;
+    iteration(s2, s0, s1);
   }
   if ((threadIdx.x & 63) == 0 && gathers_wave != 0ull) atomicAdd(&P.counters[BL_CNT_GATHERS], gathers_wave);
 }

@@ -203,7 +203,7 @@ __global__ void __launch_bounds__(64) bl_transfer_aux_kernel(BlTransferArgs P) {
     double *img = P.image + out_index;   // img[q * row] = image(q, pixel)
     for (int q = 0; q < A.n_q; q++) img[(size_t)q * row] = 0.0;
     const BlAuxSample *aux = P.aux + (size_t)P.ray_offset[slot];
-    const double2 *ja = P.transfer + (size_t)P.ray_offset[slot] * P.n_nu;
+    const double2 *ja = P.transfer + (size_t)P.ray_offset[slot] * P.n_nu * P.ja_stride;
     const bool use_j = A.image_light || A.image_emission || A.image_emission_ave;
     const bool use_alpha = A.image_light || A.image_tau || A.image_tau_int;
     if (P.render_params != nullptr) {
@@ -271,7 +271,7 @@ __global__ void __launch_bounds__(64) bl_transfer_aux_kernel(BlTransferArgs P) {
       // reference sample order is reversed integration order (geodesics.cpp:832-840)
       for (int n = num - 1; n >= 0; n--) {
         const BlAuxSample s = aux[n];
-        const double2 c = ja[(size_t)n * P.n_nu + l];
+        const double2 c = ja[((size_t)n * P.n_nu + l) * P.ja_stride];
         const double delta_lambda = s.delta_lambda;
         const double delta_lambda_cgs = delta_lambda * P.x_unit / (freq * momentum_factor);
         const double t_cgs = s.t * P.t_unit;
