@@ -323,9 +323,10 @@ void PlanJob(RenderJob &job) {
   job.locate_inside = job.fused || job.exact_fused || job.pol_fused;
   // One frequency over a single block with evenly spaced faces: the benchmark's kernel, which also composes the affine maps of a
   // ray's neighbouring samples before they leave it (the geodesic kernel numbers the segments: BlTraceArgs::segment_rows)
-  job.fused2 = job.fused && job.interleaved && !job.freq_split && !(ctx->switches & BL_SWITCH_GENERAL_FUSED)
-      && bl_fused2_applicable(&ctx->grid_dev, job.n_nu, job.n_rays) != 0;
-  job.composed = job.fused2 && !ctx->reproducible && !(ctx->switches & BL_SWITCH_SAMPLE_RECORDS);
+  // (with four or more frequencies it ends at the sample's factors, which no frequency enters: BlFreqInputs)
+  job.fused2 = job.fused && job.interleaved && !(ctx->switches & BL_SWITCH_GENERAL_FUSED)
+      && bl_fused2_applicable(&ctx->grid_dev, job.freq_split ? 1 : job.n_nu, job.n_rays) != 0;
+  job.composed = job.fused2 && !job.freq_split && !ctx->reproducible && !(ctx->switches & BL_SWITCH_SAMPLE_RECORDS);
   // Plain images of a spherical Kerr-Schild simulation with fallback values beyond the grid: nothing is recorded of the steps that
   // lie in the empty shell between the grid's outer edge and the camera's sphere (both tiers; the samples count as ever)
   job.skip_shell = job.simulation && !job.aux && !ctx->polarized && !job.slow && !job.geo_load && !job.geo_save && !job.sample_save

@@ -418,10 +418,14 @@ __device__ __forceinline__ bool trilinear(const float4 (&lo)[8], const float4 (&
 // cut_table (LDS): per cut quantity (rho, n_e, p_gas, Theta_e, B, sigma, 1 / beta) six numbers: lower and upper threshold, the
 // guard band around the lower one (lo, hi), the guard band around the upper one (lo, hi); a switched-off threshold is -inf / +inf
 // with an empty band.
-template <bool kSpinZero>
+// kFactors (several frequencies, BlShadeArgs::freq_split): the function ends at the sample's factors - fast_shade_sample()'s, what
+// is left once everything that does not depend on the frequency has been evaluated (BlFreqInputs) - for bl_transfer_freq_kernel,
+// and stores them itself (in row factors_row of `factors`; -1 for a sample the caller has already left to the exact kernel: eight
+// more live doubles across the caller's loop are eight too many).
+template <bool kSpinZero, bool kFactors = false>
 __device__ __forceinline__ double2 shade(const BlSpacetime &st, const double (&K)[6], double freq, double freq_inv, double x_unit, int cut_mask,
                                          uint32_t cut_table, const float pr[8], double x, double y, double z, double kx, double ky, double kz, double kt,
-                                         double momentum_factor, double delta_lambda, bool *have_out, bool *undecided_out) {
+                                         double momentum_factor, double delta_lambda, bool *have_out, bool *undecided_out, double2 (*factors)[4] = nullptr) {
   const double bh_m = st.bh_m;
   const double bh_a = kSpinZero ? 0.0 : st.bh_a;
   const double a2 = bh_a * bh_a;
@@ -534,8 +538,21 @@ __device__ __forceinline__ double2 shade(const BlSpacetime &st, const double (&K
   const double bs2 = b_sq * (1.0 - cos2);
   const double b_sin_inv = rsqrt_k(bs2);                   // (inf along the field: nu / nu_s = inf there, as from 1 / 0)
   const double b_sin = bs2 > 0.0 ? bs2 * b_sin_inv : 0.0;
-  // ---- coefficients at the one frequency (simulation_coefficients.cpp:464-523) and the transfer record (unpolarized.cpp:74-110)
   const double mf_inv = fastmath::rcp(momentum_factor);
+  if (kFactors) {
+    // nu = s_nu f_l, x = nu / nu_s = s_x f_l: the roots of s_x, h nu / (k T_e), j_nu nu^2 e^(x^(1/3)) / var_c^2 and the length at unit frequency
+    const double s_nu = -k_u * momentum_factor;
+    const double s_x = s_nu * b_sin_inv * (kte_inv * kte_inv) * K[4];
+    const double s_1_3 = cbrt_k(s_x);
+    const double s_1_6 = sqrt_k(s_1_3);
+    const double s_nu_inv = -k_u_inv * mf_inv;
+    (*factors)[0] = make_double2(have ? 1.0 : 0.0, s_1_6 * s_1_3);   // flag 1: factors follow; 0: nothing to add (cut cell, no field)
+    (*factors)[1] = make_double2(s_1_3, s_1_6);
+    (*factors)[2] = make_double2(KS(kH) * s_nu * kte_inv, K[5] * (rho * b_sin) * (s_nu_inv * s_nu_inv));
+    (*factors)[3] = make_double2(delta_lambda * x_unit * mf_inv, 0.0);
+    return make_double2(1.0, 0.0);
+  }
+  // ---- coefficients at the one frequency (simulation_coefficients.cpp:464-523) and the transfer record (unpolarized.cpp:74-110)
   const double nu = -k_u * momentum_factor * freq;                 // :461-463 times the camera frequency
   const double nu_inv = -k_u_inv * mf_inv * freq_inv;
   const double xx = nu * b_sin_inv * (kte_inv * kte_inv) * K[4];   // nu / nu_s
@@ -580,7 +597,8 @@ __device__ __forceinline__ double2 shade(const BlSpacetime &st, const double (&K
 // read. A wave that holds a sample left to the exact kernel, or an optically thick step (whose map replaces what lies behind it,
 // a NaN included: not a product of numbers), writes its samples' own records instead, by record index, and marks its segments'
 // rows as standing for those (BL_COMPOSED_EXPANDED).
-template <bool kSpinZero, bool kComposed, bool kBricks = false>
+// kFactors: several frequencies - a sample leaves as its factors (BlFreqInputs, row ray_offset + n) instead of a transfer record.
+template <bool kSpinZero, bool kComposed, bool kBricks = false, bool kFactors = false>
 __global__ void __launch_bounds__(256, BL_FAST_WAVES) bl_shade_fused2_kernel(const BlShadeArgs P) {
   using namespace fused2;
   extern __shared__ double lds[];
@@ -686,6 +704,12 @@ __global__ void __launch_bounds__(256, BL_FAST_WAVES) bl_shade_fused2_kernel(con
     const long long row_first = p.row;
     float pr[8];
     const bool near_midpoint = trilinear(lo, hi, p.loc.f_i, p.loc.f_j, p.loc.f_k, pr);
+    if (kFactors) {
+      // (the eight values are only read inside the branch below, and the optimiser would move the trilinear sums there - behind
+      // the requests that reuse the landing registers they read, which then have to be copied first: 50 registers, 8 of them spilled)
+#pragma unroll
+      for (int q = 0; q < 8; q++) asm volatile("" : "+v"(pr[q]));
+    }
     gathers_wave += (unsigned long long)__popcll(__ballot(interp));
     if (kBricks) fused2::gather_issue_bricks(cells, c.loc.cell_bytes, lo, hi);
     else fused2::gather_issue(cells, c.loc.cell_bytes, (c.loc.status & 0xffu) == (uint32_t)kSampleInterp, row_bytes, plane_bytes, lo, hi);
@@ -708,14 +732,26 @@ __global__ void __launch_bounds__(256, BL_FAST_WAVES) bl_shade_fused2_kernel(con
     // search it interleaves all of them and needs 277 vector registers; as a block of its own the kernel fits 220.)
     bool have = false, undecided_cut = false;
     double2 rec = make_double2(1.0, 0.0);
+    double2 factors[4];
+    if (kFactors) factors[0] = factors[1] = factors[2] = factors[3] = make_double2(0.0, 0.0);
     if (interp)
-      rec = shade<kSpinZero>(st, K, freq, freq_inv, x_unit, cut_mask, cut_table, pr, p.h0.x, p.h0.y, p.h1.x, p.c0.x, p.c0.y, p.c1.x, kt, momentum_factor,
-                             -p.c1.y, &have, &undecided_cut);
+      rec = shade<kSpinZero, kFactors>(st, K, freq, freq_inv, x_unit, cut_mask, cut_table, pr, p.h0.x, p.h0.y, p.h1.x, p.c0.x, p.c0.y, p.c1.x, kt, momentum_factor,
+                                       -p.c1.y, &have, &undecided_cut, kFactors ? &factors : nullptr);
     // a sample off the grid has fallback primitives without a field (no coefficients: I <- I) or NaN ones (I <- I + NaN,
     // simulation_sampling.cpp:377-384); a cut sample has none either
     const bool defer = interp && (undecided_cut || near_midpoint || (p.loc.status & kPlainUndecided) != 0u);
     if (!(interp && have)) rec = make_double2(1.0, (status == (uint32_t)kSampleOffGrid && fallback_nan) ? nan : 0.0);
-    if (!kComposed) {
+    if (kFactors) {
+      // flag 0: nothing to add (cut sample); 2: NaN primitives off the grid
+      if (live && !defer) {
+        if (!interp) factors[0].x = (status == (uint32_t)kSampleOffGrid && fallback_nan) ? 2.0 : 0.0;
+        double2 *out = reinterpret_cast<double2 *>(P.freq_inputs + (size_t)(row_first + (long long)n));
+        out[0] = factors[0];
+        out[1] = factors[1];
+        out[2] = factors[2];
+        out[3] = factors[3];
+      }
+    } else if (!kComposed) {
       if (live && !defer) {
         double2 *out = P.transfer + (size_t)(row_first + (long long)n);
         *out = rec;
@@ -1210,7 +1246,10 @@ extern "C" hipError_t bl_launch_shade_fused2(const BlShadeArgs *args, int grid, 
   const size_t lds = 48 * sizeof(double) + 64 * (size_t)(g.n[0] + g.n[1] + g.n[2]);
   const bool spin_zero = args->st.bh_a == 0.0, composed = args->composed != nullptr;
 #define BL_LAUNCH_F2(S, C) hipLaunchKernelGGL((bl_shade_fused2_kernel<S, C>), dim3(grid), dim3(256), lds, stream, *args)
-  if (spin_zero && composed && g.bricks != nullptr) hipLaunchKernelGGL((bl_shade_fused2_kernel<true, true, true>), dim3(grid), dim3(256), lds, stream, *args);
+  if (args->freq_split) {
+    if (spin_zero) hipLaunchKernelGGL((bl_shade_fused2_kernel<true, false, false, true>), dim3(grid), dim3(256), lds, stream, *args);
+    else hipLaunchKernelGGL((bl_shade_fused2_kernel<false, false, false, true>), dim3(grid), dim3(256), lds, stream, *args);
+  } else if (spin_zero && composed && g.bricks != nullptr) hipLaunchKernelGGL((bl_shade_fused2_kernel<true, true, true>), dim3(grid), dim3(256), lds, stream, *args);
   else if (spin_zero && composed) BL_LAUNCH_F2(true, true);
   else if (spin_zero) BL_LAUNCH_F2(true, false);
   else if (composed) BL_LAUNCH_F2(false, true);

@@ -30,11 +30,13 @@ BENCHMARK_KERNELS = {
     "_Z20bl_shade_fast_kernelILb0ELb0EEv11BlShadeArgs": (2, 0),
     "_Z20bl_shade_fast_kernelILb1ELb1EEv11BlShadeArgs": (2, 0),              # ... power laws / Cartesian grids
     "_Z20bl_shade_fast_kernelILb0ELb1EEv11BlShadeArgs": (2, 0),
-    "_Z22bl_shade_fused2_kernelILb1ELb1ELb0EEv11BlShadeArgs": (2, 0),            # ... the benchmark's kernel: locate step inside, composed maps
-    "_Z22bl_shade_fused2_kernelILb1ELb0ELb0EEv11BlShadeArgs": (2, 0),            # ... one record per sample
-    "_Z22bl_shade_fused2_kernelILb0ELb1ELb0EEv11BlShadeArgs": (2, 0),            # ... any spin
-    "_Z22bl_shade_fused2_kernelILb0ELb0ELb0EEv11BlShadeArgs": (2, 0),
-    "_Z22bl_shade_fused2_kernelILb1ELb1ELb1EEv11BlShadeArgs": (2, 0),        # ... gathering from pre-gathered bricks (BL_SWITCH_BRICK_CELLS: a measured experiment)
+    "_Z22bl_shade_fused2_kernelILb1ELb1ELb0ELb0EEv11BlShadeArgs": (2, 0),        # ... the benchmark's kernel: locate step inside, composed maps
+    "_Z22bl_shade_fused2_kernelILb1ELb0ELb0ELb0EEv11BlShadeArgs": (2, 0),        # ... one record per sample
+    "_Z22bl_shade_fused2_kernelILb0ELb1ELb0ELb0EEv11BlShadeArgs": (2, 0),        # ... any spin
+    "_Z22bl_shade_fused2_kernelILb0ELb0ELb0ELb0EEv11BlShadeArgs": (2, 0),
+    "_Z22bl_shade_fused2_kernelILb1ELb0ELb0ELb1EEv11BlShadeArgs": (2, 0),        # ... several frequencies: a sample leaves as its factors
+    "_Z22bl_shade_fused2_kernelILb0ELb0ELb0ELb1EEv11BlShadeArgs": (2, 0),
+    "_Z22bl_shade_fused2_kernelILb1ELb1ELb1ELb0EEv11BlShadeArgs": (2, 0),    # ... gathering from pre-gathered bricks (BL_SWITCH_BRICK_CELLS: a measured experiment)
     "_Z21bl_shade_fused_kernelILb1EEv11BlShadeArgs": (2, 0),                 # ... locate step inside, general grids / up to three frequencies
     "_Z21bl_shade_fused_kernelILb0EEv11BlShadeArgs": (2, 0),
     "_Z22bl_shade_exact2_kernelILb1EEv11BlShadeArgs": (2, 0),                # exact tier, locate step inside (the benchmark's exact kernel)
