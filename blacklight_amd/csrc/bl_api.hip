@@ -369,6 +369,7 @@ int bl_init(const bl_params *p, int device, bl_ctx **out) {
       ctx->tail_policy = name == "wide" ? BL_TAIL_WIDE : (name == "quad" ? BL_TAIL_QUAD : (name == "split" ? BL_TAIL_SPLIT : BL_TAIL_AUTO));
     }
     if (const char *cus = std::getenv("BLACKLIGHT_AMD_SPLIT_CUS")) ctx->split_cus = std::max(0, std::min(128, std::atoi(cus)));
+    if (const char *overlap = std::getenv("BLACKLIGHT_AMD_POLARIZED_OVERLAP")) ctx->pol_overlap = std::atoi(overlap);
     if (const char *blocks = std::getenv("BLACKLIGHT_AMD_POLCOEF_BLOCKS")) ctx->polcoef_blocks_per_cu = std::max(0, std::min(64, std::atoi(blocks)));
     if (const char *rounds = std::getenv("BLACKLIGHT_AMD_SPLIT_ROUNDS")) ctx->split_rounds = std::max(0, std::min(8, std::atoi(rounds)));
     if (const char *pad = std::getenv("BLACKLIGHT_AMD_SPLIT_LDS_PAD")) ctx->split_lds_pad = std::max(0, std::min(64 * 1024, std::atoi(pad)));

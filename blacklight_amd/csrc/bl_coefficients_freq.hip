@@ -219,7 +219,12 @@ __global__ void bl_debug_math_kernel(int op, long long n, const double *x, const
 }
 
 
-extern "C" hipError_t bl_launch_polarized_coefficients(const BlShadeArgs *args, int grid, hipStream_t stream) {
+// frames: 1 the per-frequency coefficients, then the frames of the samples without coefficients; 0 the coefficients only; 2 the frames only
+extern "C" hipError_t bl_launch_polarized_coefficients_parts(const BlShadeArgs *args, int grid, int frames, hipStream_t stream) {
+  if (frames == 2) {
+    hipLaunchKernelGGL(bl_polarized_frame_kernel, dim3(grid), dim3(256), 0, stream, *args);
+    return hipGetLastError();
+  }
   // (simulation_coefficients<kExtended> also holds the unpolarized kappa terms: never in a polarized run)
   const bool thermal_only = args->plasma.power_frac == 0.0 && args->plasma.kappa_unpolarized == 0 && args->plasma.kappa_frac_zero != 0;
 #define BL_LAUNCH_PC(T, O) hipLaunchKernelGGL((bl_polarized_coefficients_kernel<T, O>), dim3(grid), dim3(256), 0, stream, *args)
@@ -228,8 +233,11 @@ extern "C" hipError_t bl_launch_polarized_coefficients(const BlShadeArgs *args, 
   else if (thermal_only) BL_LAUNCH_PC(false, true);
   else BL_LAUNCH_PC(false, false);
 #undef BL_LAUNCH_PC
-  hipLaunchKernelGGL(bl_polarized_frame_kernel, dim3(grid), dim3(256), 0, stream, *args);
+  if (frames == 1) hipLaunchKernelGGL(bl_polarized_frame_kernel, dim3(grid), dim3(256), 0, stream, *args);
   return hipGetLastError();
+}
+extern "C" hipError_t bl_launch_polarized_coefficients(const BlShadeArgs *args, int grid, hipStream_t stream) {
+  return bl_launch_polarized_coefficients_parts(args, grid, 1, stream);
 }
 
 extern "C" hipError_t bl_launch_debug_math(int op, long long n, const double *x, const double *y, double *out, hipStream_t stream) {

@@ -41,6 +41,7 @@ extern "C" hipError_t bl_launch_shade_exact2(const BlShadeArgs *args, int grid, 
 extern "C" hipError_t bl_launch_shade_polarized2(const BlShadeArgs *args, int grid, hipStream_t stream);
 extern "C" hipError_t bl_launch_shade_formula_fast(const BlShadeArgs *args, int grid, hipStream_t stream);
 extern "C" hipError_t bl_launch_polarized_coefficients(const BlShadeArgs *args, int grid, hipStream_t stream);
+extern "C" hipError_t bl_launch_polarized_coefficients_parts(const BlShadeArgs *args, int grid, int frames, hipStream_t stream);
 extern "C" hipError_t bl_launch_transfer(const BlTransferArgs *args, hipStream_t stream);
 extern "C" hipError_t bl_launch_tau(const BlTransferArgs *args, hipStream_t stream);
 extern "C" hipError_t bl_launch_transfer_freq(const BlTransferArgs *args, hipStream_t stream);
@@ -48,6 +49,8 @@ extern "C" hipError_t bl_launch_coefficients_freq(const BlShadeArgs *args, int g
 extern "C" hipError_t bl_launch_transfer_aux(const BlTransferArgs *args, hipStream_t stream);
 extern "C" hipError_t bl_launch_transfer_polarized(const BlTransferArgs *args, hipStream_t stream);
 extern "C" hipError_t bl_launch_transfer_polarized_matrix(const BlTransferArgs *args, int num_cus, hipStream_t stream);
+extern "C" hipError_t bl_launch_transport_matrices(const BlTransferArgs *args, int num_cus, hipStream_t stream);
+extern "C" hipError_t bl_launch_transfer_polarized_rays(const BlTransferArgs *args, hipStream_t stream);
 extern "C" hipError_t bl_launch_debug_math(int op, long long n, const double *x, const double *y, double *out, hipStream_t stream);
 
 namespace blhost {
@@ -129,6 +132,7 @@ struct bl_ctx {
   int split_cus = 0;                  // BLACKLIGHT_AMD_SPLIT_CUS: compute units of the quad stepper; 0 = an eighth of the device
   int split_rounds = 0;               // BLACKLIGHT_AMD_SPLIT_ROUNDS: rounds of quads the band is sized for; 0 = chosen by bl_render
   int split_cus_made = 0;             // ... of the streams that exist
+  int pol_overlap = 1;                // the transport matrices on a second stream beside the per-frequency coefficient kernel (BLACKLIGHT_AMD_POLARIZED_OVERLAP=0: in sequence)
   int polcoef_blocks_per_cu = 0;      // BLACKLIGHT_AMD_POLCOEF_BLOCKS: 256-thread workgroups of bl_polarized_coefficients_kernel per compute unit (0: twenty)
   int split_lds_pad = 39 * 1024;      // BLACKLIGHT_AMD_SPLIT_LDS_PAD: LDS a wave of either stepper reserves so that a CU takes four of them, one per SIMD
   bool split_unavailable = false;     // the runtime refused a CU-masked stream: BL_TAIL_AUTO stops asking

@@ -1033,11 +1033,18 @@ __global__ void __launch_bounds__(64, 2) bl_transfer_polarized_matrix_kernel(BlT
   }
 }
 
-extern "C" hipError_t bl_launch_transfer_polarized_matrix(const BlTransferArgs *args, int num_cus, hipStream_t stream) {
+// (the two halves apart: the matrices need the samples' geometry only and may be built beside the per-frequency coefficient kernel)
+extern "C" hipError_t bl_launch_transport_matrices(const BlTransferArgs *args, int num_cus, hipStream_t stream) {
   hipLaunchKernelGGL(bl_transport_matrix_kernel, dim3(num_cus * 2 * 4), dim3(256), 0, stream, *args);
-  hipError_t err = hipGetLastError();
-  if (err != hipSuccess) return err;
+  return hipGetLastError();
+}
+extern "C" hipError_t bl_launch_transfer_polarized_rays(const BlTransferArgs *args, hipStream_t stream) {
   const int grid = (args->chunk_rays + 63) / 64;
   hipLaunchKernelGGL(bl_transfer_polarized_matrix_kernel, dim3(grid), dim3(64), 0, stream, *args);
   return hipGetLastError();
+}
+extern "C" hipError_t bl_launch_transfer_polarized_matrix(const BlTransferArgs *args, int num_cus, hipStream_t stream) {
+  const hipError_t err = bl_launch_transport_matrices(args, num_cus, stream);
+  if (err != hipSuccess) return err;
+  return bl_launch_transfer_polarized_rays(args, stream);
 }

@@ -14,7 +14,7 @@
 namespace {
 
 // geodesic start / end, locate start, coefficient start, transfer start, end, counters copied to the host
-constexpr int kEventsPerChunk = 10;
+constexpr int kEventsPerChunk = 12;
 
 // RadiationIntegrator::Hypergeometric (simulation_coefficients.cpp:740-773): 2F1 for z < 0 through its Pfaff
 // transformation, ten terms of the series
@@ -1534,16 +1534,34 @@ void LaunchShadingStage(RenderJob &job, int k, bool geodesic_beside, hipStream_t
   Check(hipEventRecord(e[3], stream), "event");
   coefficient_kernel();
   }
-  if (ctx->polarized) Check(bl_launch_polarized_coefficients(&sa, ctx->num_cus * (ctx->polcoef_blocks_per_cu > 0 ? ctx->polcoef_blocks_per_cu : 20), stream), "polarized coefficient kernel launch");
+  // The transport matrices - memory - on the second stream beside the per-frequency coefficient kernel - arithmetic: both read what
+  // bl_shade_polarized2_kernel left, neither reads the other. (The coefficient kernel's workgroups fill the device first, so the
+  // matrices overlap its last quarter only: 276 -> 270 ms per 1024^2 frame, 1.10 -> 1.08 s at 2048^2 adaptive; a smaller grid for the
+  // coefficient kernel or a priority stream for the matrices move the split, not the sum. BLACKLIGHT_AMD_POLARIZED_OVERLAP=0: in sequence.)
+  const bool matrices_beside = ctx->polarized && job.matrix_transport && ctx->pol_overlap != 0 && ctx->stream_geo != stream;
+  const int polcoef_grid = ctx->num_cus * (ctx->polcoef_blocks_per_cu > 0 ? ctx->polcoef_blocks_per_cu : 20);
+  if (matrices_beside) {
+    // (the frames of the samples without coefficients first: the matrices read them)
+    Check(bl_launch_polarized_coefficients_parts(&sa, polcoef_grid, 2, stream), "polarized frame kernel launch");
+    Check(hipEventRecord(e[10], stream), "event");
+    Check(hipStreamWaitEvent(ctx->stream_geo, e[10], 0), "stream wait");
+    Check(bl_launch_transport_matrices(&xa, ctx->num_cus, ctx->stream_geo), "transport matrix kernel launch");
+    Check(hipEventRecord(e[11], ctx->stream_geo), "event");
+  }
+  if (ctx->polarized) Check(bl_launch_polarized_coefficients_parts(&sa, polcoef_grid, matrices_beside ? 0 : 1, stream), "polarized coefficient kernel launch");
   if (job.coef_split) Check(bl_launch_coefficients_freq(&sa, ctx->num_cus * 16, stream), "per-frequency coefficient kernel launch");
   Check(hipEventRecord(e[4], stream), "event");
   Check(job.aux ? bl_launch_transfer_aux(&xa, stream)
                 : (job.freq_split ? bl_launch_transfer_freq(&xa, stream) : (job.composed ? bl_launch_transfer_composed(&xa, stream) : bl_launch_transfer(&xa, stream))),
         "transfer kernel launch");
   if (job.tau_row) Check(bl_launch_tau(&xa, stream), "optical-depth kernel launch");
-  if (ctx->polarized)
+  if (ctx->polarized && matrices_beside) {
+    Check(hipStreamWaitEvent(stream, e[11], 0), "stream wait");
+    Check(bl_launch_transfer_polarized_rays(&xa, stream), "polarized transfer kernel launch");
+  } else if (ctx->polarized) {
     Check(job.matrix_transport ? bl_launch_transfer_polarized_matrix(&xa, ctx->num_cus, stream) : bl_launch_transfer_polarized(&xa, stream),
           "polarized transfer kernel launch");
+  }
   Check(hipEventRecord(e[5], stream), "event");
   Check(hipMemcpyAsync(ctx->host_counters + static_cast<size_t>(k) * BL_CNT_TOTAL, sl.d_counters.ptr, BL_CNT_TOTAL * sizeof(unsigned long long),
                        hipMemcpyDeviceToHost, stream), "counter download");
