@@ -157,3 +157,29 @@ def test_a_context_starts_in_the_tolerant_tier(monkeypatch):
         ctx.set_grid(grid)
         again = ctx.render()
         assert again["stats"].arithmetic == 0 and gu.same_bits(again["image"], exact["image"]).all()
+
+
+def test_polarized_frames_build_their_matrices_beside_the_coefficients_and_get_the_same_bits(monkeypatch):
+    """Polarized runs in the tolerant tier build the transport matrices on a second stream beside the per-frequency coefficient kernel
+    (both read bl_shade_polarized2_kernel's output only; polarized.cpp:150-198 needs the geometry, :387-779 the coefficients): the same
+    kernels on the same data as one after the other - BLACKLIGHT_AMD_POLARIZED_OVERLAP=0, read when a context is made -, so the same bits;
+    several chunks as well."""
+    import blacklight_amd as bl
+    import bench
+    _, grid = _benchmark_like(res=96)
+    params = dict(bench.WORKLOAD, camera_resolution=96, image_polarization=True, image_tau=True)
+    images = {}
+    for overlap in ("1", "0"):
+        monkeypatch.setenv("BLACKLIGHT_AMD_POLARIZED_OVERLAP", overlap)
+        with bl.Context(bl.Params.from_dict(params)) as ctx:
+            ctx.set_grid(grid)
+            ctx.set_arithmetic("tolerant")
+            whole = ctx.render()
+            assert whole["stats"].arithmetic == 1 and whole["stats"].n_chunks == 1
+            ctx.set_scratch_limit(1 << 30)
+            chunked = ctx.render()
+            assert chunked["stats"].n_chunks > 1
+            assert gu.same_bits(chunked["image"], whole["image"]).all()
+            images[overlap] = whole["image"]
+    assert images["1"].shape[0] >= 5 and np.isfinite(images["1"]).any()
+    assert gu.same_bits(images["1"], images["0"]).all()
