@@ -13,7 +13,8 @@
 
 namespace {
 
-// geodesic start / end, locate start, coefficient start, transfer start, end, counters copied to the host
+// geodesic start / end, locate start, coefficient start, transfer start, end, counters copied to the host; [7 ... 9] the split or
+// overlapped geodesic stage; [10, 11] polarized runs: frames built / transport matrices built (on the second stream)
 constexpr int kEventsPerChunk = 12;
 
 // RadiationIntegrator::Hypergeometric (simulation_coefficients.cpp:740-773): 2F1 for z < 0 through its Pfaff
@@ -1538,7 +1539,8 @@ void LaunchShadingStage(RenderJob &job, int k, bool geodesic_beside, hipStream_t
   // bl_shade_polarized2_kernel left, neither reads the other. (The coefficient kernel's workgroups fill the device first, so the
   // matrices overlap its last quarter only: 276 -> 270 ms per 1024^2 frame, 1.10 -> 1.08 s at 2048^2 adaptive; a smaller grid for the
   // coefficient kernel or a priority stream for the matrices move the split, not the sum. BLACKLIGHT_AMD_POLARIZED_OVERLAP=0: in sequence.)
-  const bool matrices_beside = ctx->polarized && job.matrix_transport && ctx->pol_overlap != 0 && ctx->stream_geo != stream;
+  // (one scratch set: with two, the second stream carries the next chunk's geodesic stage, and the matrices would queue behind it)
+  const bool matrices_beside = ctx->polarized && job.matrix_transport && ctx->pol_overlap != 0 && job.n_slots == 1 && ctx->stream_geo != stream;
   const int polcoef_grid = ctx->num_cus * (ctx->polcoef_blocks_per_cu > 0 ? ctx->polcoef_blocks_per_cu : 20);
   if (matrices_beside) {
     // (the frames of the samples without coefficients first: the matrices read them)
