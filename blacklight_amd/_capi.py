@@ -47,9 +47,8 @@ class RenderDesc(C.Structure):
 
 
 # BL_SWITCH_* of include/blacklight_amd.h: measurement switches (bl_stats.switches, bl_debug_set_switches)
-SWITCHES = {name: 1 << bit for bit, name in enumerate(
-    ["TENSOR_TRANSPORT", "SPLIT_RECORDS", "RECORD_EVERY_STEP", "TOLERANT_POLARIZED_COEFFICIENTS", "GENERAL_LOCATE", "LANE_TRANSFER",
-     "NO_FUSED_LOCATE", "GENERAL_FUSED", "SAMPLE_RECORDS", "UNPIPELINED_SHADE", "QUAD_TAIL", "QUAD_EVERY_RAY", "TAIL_OVERLAP", "TAIL_REPACKED", "BRICK_CELLS", "SPLIT_LONG"])}
+SWITCHES = {"TENSOR_TRANSPORT": 1 << 0, "SPLIT_RECORDS": 1 << 1, "RECORD_EVERY_STEP": 1 << 2, "TOLERANT_POLARIZED_COEFFICIENTS": 1 << 3,
+            "GENERAL_LOCATE": 1 << 4, "LANE_TRANSFER": 1 << 5, "NO_FUSED_LOCATE": 1 << 6, "SAMPLE_RECORDS": 1 << 8, "QUAD_EVERY_RAY": 1 << 11}
 
 BL_MAX_LEVELS = 16
 

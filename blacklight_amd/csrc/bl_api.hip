@@ -350,32 +350,17 @@ int bl_init(const bl_params *p, int device, bl_ctx **out) {
         {"BLACKLIGHT_AMD_RECORD_EVERY_STEP", BL_SWITCH_RECORD_EVERY_STEP},
         {"BLACKLIGHT_AMD_TOLERANT_POLARIZED_COEFFICIENTS", BL_SWITCH_TOLERANT_POLARIZED_COEFFICIENTS},
         {"BLACKLIGHT_AMD_GENERAL_LOCATE", BL_SWITCH_GENERAL_LOCATE}, {"BLACKLIGHT_AMD_LANE_TRANSFER", BL_SWITCH_LANE_TRANSFER},
-        {"BLACKLIGHT_AMD_NO_FUSED_LOCATE", BL_SWITCH_NO_FUSED_LOCATE}, {"BLACKLIGHT_AMD_GENERAL_FUSED", BL_SWITCH_GENERAL_FUSED},
-        {"BLACKLIGHT_AMD_SAMPLE_RECORDS", BL_SWITCH_SAMPLE_RECORDS}, {"BLACKLIGHT_AMD_UNPIPELINED_SHADE", BL_SWITCH_UNPIPELINED_SHADE},
-        {"BLACKLIGHT_AMD_QUAD_TAIL", BL_SWITCH_QUAD_TAIL}, {"BLACKLIGHT_AMD_QUAD_EVERY_RAY", BL_SWITCH_QUAD_EVERY_RAY},
-        {"BLACKLIGHT_AMD_TAIL_OVERLAP", BL_SWITCH_TAIL_OVERLAP}, {"BLACKLIGHT_AMD_TAIL_REPACKED", BL_SWITCH_TAIL_REPACKED},
-        {"BLACKLIGHT_AMD_BRICK_CELLS", BL_SWITCH_BRICK_CELLS}, {"BLACKLIGHT_AMD_SPLIT_LONG", BL_SWITCH_SPLIT_LONG}};
+        {"BLACKLIGHT_AMD_NO_FUSED_LOCATE", BL_SWITCH_NO_FUSED_LOCATE}, {"BLACKLIGHT_AMD_SAMPLE_RECORDS", BL_SWITCH_SAMPLE_RECORDS},
+        {"BLACKLIGHT_AMD_QUAD_EVERY_RAY", BL_SWITCH_QUAD_EVERY_RAY}};
     for (const auto &sw : kSwitches)
       if (std::getenv(sw.name) != nullptr) ctx->switches |= sw.bit;
     ctx->debug_counters = std::getenv("BLACKLIGHT_AMD_DEBUG_COUNTERS") != nullptr;
-    if (const char *below = std::getenv("BLACKLIGHT_AMD_PARK_BELOW")) ctx->park_below = std::max(0, std::min(64, std::atoi(below)));
-    if (const char *after = std::getenv("BLACKLIGHT_AMD_PARK_AFTER")) ctx->park_after = std::max(0, std::atoi(after));
-    if (const char *quiet = std::getenv("BLACKLIGHT_AMD_PARK_QUIET")) ctx->park_quiet = std::max(1, std::atoi(quiet));
-    if (const char *age = std::getenv("BLACKLIGHT_AMD_PARK_AGE")) ctx->park_age = std::max(0, std::atoi(age));
     // the arithmetic tier a context starts in: tolerant (north_star's tolerance), or what the deployment says
     if (const char *tier = std::getenv("BLACKLIGHT_AMD_ARITHMETIC")) ctx->arithmetic = std::string(tier) == "exact" ? BL_ARITH_EXACT : BL_ARITH_TOLERANT;
     if (const char *policy = std::getenv("BLACKLIGHT_AMD_TAIL_POLICY")) {   // (A/B runs: bl_set_tail_policy from the environment)
       const std::string name = policy;
       ctx->tail_policy = name == "wide" ? BL_TAIL_WIDE : (name == "quad" ? BL_TAIL_QUAD : (name == "split" ? BL_TAIL_SPLIT : BL_TAIL_AUTO));
     }
-    if (const char *cus = std::getenv("BLACKLIGHT_AMD_SPLIT_CUS")) ctx->split_cus = std::max(0, std::min(128, std::atoi(cus)));
-    if (const char *overlap = std::getenv("BLACKLIGHT_AMD_POLARIZED_OVERLAP")) ctx->pol_overlap = std::atoi(overlap);
-    if (const char *blocks = std::getenv("BLACKLIGHT_AMD_POLCOEF_BLOCKS")) ctx->polcoef_blocks_per_cu = std::max(0, std::min(64, std::atoi(blocks)));
-    if (const char *rounds = std::getenv("BLACKLIGHT_AMD_SPLIT_ROUNDS")) ctx->split_rounds = std::max(0, std::min(8, std::atoi(rounds)));
-    if (const char *pad = std::getenv("BLACKLIGHT_AMD_SPLIT_LDS_PAD")) ctx->split_lds_pad = std::max(0, std::min(64 * 1024, std::atoi(pad)));
-    if (const char *band = std::getenv("BLACKLIGHT_AMD_SPLIT_BAND")) ctx->split_band = std::max(0.0, std::atof(band));
-    if (const char *centre = std::getenv("BLACKLIGHT_AMD_SPLIT_CENTRE")) ctx->split_centre = std::max(0.0, std::atof(centre));
-    if (const char *waves = std::getenv("BLACKLIGHT_AMD_QUAD_WAVES")) ctx->quad_waves_per_simd = std::max(1, std::min(3, std::atoi(waves)));
   }
   try {
     ValidateGeodesic(ctx);
@@ -786,16 +771,6 @@ int bl_set_grid(bl_ctx *ctx, const bl_grid_desc *g) {
         if (failure.message != kIrregular) throw;
         UploadRefinedGrid(ctx, g);   // blocks of several levels, or a tiling with holes
       }
-    }
-    // measurement switch: the cells once more as pre-gathered stencils (one block whose bricks 32-bit byte offsets cover)
-    ctx->grid_dev.bricks = nullptr;
-    if ((ctx->switches & BL_SWITCH_BRICK_CELLS) && ctx->cells_target == nullptr && ctx->grid_dev.n_blocks == 0
-        && static_cast<unsigned long long>(ctx->n_i) * ctx->n_j * ctx->n_k <= (1ull << 24)) {
-      EnsureStreams(ctx);
-      ctx->d_bricks.Ensure(static_cast<size_t>(ctx->n_i) * ctx->n_j * ctx->n_k * 64);
-      Check(bl_launch_build_bricks(ctx->d_cells.ptr, ctx->d_bricks.ptr, ctx->n_i, ctx->n_j, ctx->n_k, ctx->stream), "brick kernel launch");
-      Check(hipStreamSynchronize(ctx->stream), "brick kernel");
-      ctx->grid_dev.bricks = ctx->d_bricks.ptr;
     }
     ctx->grid_meta = *g;
     ctx->grid_outer_x1 = g->x1f[g->n_i];

@@ -29,13 +29,11 @@ extern "C" hipError_t bl_launch_ray_init(const BlTraceArgs *args, int integrator
 extern "C" hipError_t bl_launch_geodesic(const BlTraceArgs *args, int integrator, int grid, hipStream_t stream, int lds_pad);
 extern "C" hipError_t bl_launch_geodesic_quad(const BlTraceArgs *args, int grid, hipStream_t stream, int lds_pad);
 extern "C" hipError_t bl_launch_split_long(const BlTraceArgs *args, hipStream_t stream);
-extern "C" hipError_t bl_launch_geodesic_resume(const BlTraceArgs *args, int grid, hipStream_t stream);
 extern "C" int bl_geodesic_occupancy(int integrator, int with_time, int spin_zero, int shell);
 extern "C" hipError_t bl_launch_locate(const BlShadeArgs *args, int grid, int lds_bytes, hipStream_t stream);
 extern "C" hipError_t bl_launch_shade(const BlShadeArgs *args, int model, int grid, hipStream_t stream);
 extern "C" hipError_t bl_launch_shade_fast(const BlShadeArgs *args, int grid, hipStream_t stream);
 extern "C" int bl_fused2_applicable(const BlGridDevice *grid, int n_nu, long long n_rays);
-extern "C" hipError_t bl_launch_build_bricks(const float *cells, float *bricks, int n_i, int n_j, int n_k, hipStream_t stream);
 extern "C" hipError_t bl_launch_transfer_composed(const BlTransferArgs *args, hipStream_t stream);
 extern "C" hipError_t bl_launch_shade_exact2(const BlShadeArgs *args, int grid, hipStream_t stream);
 extern "C" hipError_t bl_launch_shade_polarized2(const BlShadeArgs *args, int grid, hipStream_t stream);
@@ -129,15 +127,9 @@ struct bl_ctx {
   // BL_SWITCH_SPLIT_LONG: two streams whose CU masks partition the device - split_cus compute units for bl_geodesic_quad_kernel
   // and the rays predicted long, the rest for bl_geodesic_kernel (hipExtStreamCreateWithCUMask)
   hipStream_t stream_few = nullptr, stream_most = nullptr;   // (borrowed from a process-wide table, never destroyed: bl_render.hip)
-  int split_cus = 0;                  // BLACKLIGHT_AMD_SPLIT_CUS: compute units of the quad stepper; 0 = an eighth of the device
-  int split_rounds = 0;               // BLACKLIGHT_AMD_SPLIT_ROUNDS: rounds of quads the band is sized for; 0 = chosen by bl_render
-  int split_cus_made = 0;             // ... of the streams that exist
-  int pol_overlap = 1;                // the transport matrices on a second stream beside the per-frequency coefficient kernel (BLACKLIGHT_AMD_POLARIZED_OVERLAP=0: in sequence)
-  int polcoef_blocks_per_cu = 0;      // BLACKLIGHT_AMD_POLCOEF_BLOCKS: 256-thread workgroups of bl_polarized_coefficients_kernel per compute unit (0: twenty)
-  int split_lds_pad = 39 * 1024;      // BLACKLIGHT_AMD_SPLIT_LDS_PAD: LDS a wave of either stepper reserves so that a CU takes four of them, one per SIMD
+  int split_cus_made = 0;             // compute units of the quad stepper's stream as it exists (an eighth of the device)
+  int split_lds_pad = 39 * 1024;      // LDS a wave of either stepper reserves so that a CU takes four of them, one per SIMD
   bool split_unavailable = false;     // the runtime refused a CU-masked stream: BL_TAIL_AUTO stops asking
-  double split_band = 0.0;            // BLACKLIGHT_AMD_SPLIT_BAND: a symmetric band of this half-width in M (measurements); 0 = sized by bl_render
-  double split_centre = 0.0;          // BLACKLIGHT_AMD_SPLIT_CENTRE: 0 = 3 sqrt(3) M
   std::vector<hipEvent_t> events;     // kEventsPerChunk per scratch set + begin / end of the render
   unsigned long long *host_counters = nullptr;   // pinned, BL_CNT_TOTAL per scratch set
   uint64_t scratch_limit = 144ull << 30;
@@ -152,10 +144,6 @@ struct bl_ctx {
   bool kappa_warned = false;
   bool debug_counters = false;        // BLACKLIGHT_AMD_DEBUG_COUNTERS (bl_init): print the -DBL_GEO_STATS counters after a render
   unsigned int switches = 0;          // BL_SWITCH_* (include/blacklight_amd.h): the environment as bl_init found it, never read again
-  int quad_waves_per_simd = 1;        // waves of bl_geodesic_quad_kernel per SIMD (BLACKLIGHT_AMD_QUAD_WAVES: a measurement knob)
-  int park_age = -1;                  // BlTraceArgs::park_age; -1: an eighth of ray_max_steps (BLACKLIGHT_AMD_PARK_AGE)
-  int park_quiet = 1 << 30;           // BlTraceArgs::park_quiet (BLACKLIGHT_AMD_PARK_QUIET)
-  int park_below = 0, park_after = 0; // BlTraceArgs::park_below, ::park_after (BLACKLIGHT_AMD_PARK_BELOW, _PARK_AFTER): every wave parks its rays once the queue is dry   // BlTraceArgs::park_below, ::park_after (BLACKLIGHT_AMD_PARK_BELOW, _PARK_AFTER in bl_init's environment: measurement knobs)
   double guard_band = 1.0e-9;         // tolerant tier: relative half-width around a cut threshold left to the exact kernel
 
   // image rows (radiation_integrator.cpp:436-520)
@@ -171,7 +159,6 @@ struct bl_ctx {
   int n_i = 0, n_j = 0, n_k = 0;
   bl_grid_desc grid_meta{};
   DeviceBuffer<float> d_cells;
-  DeviceBuffer<float> d_bricks;  // BL_SWITCH_BRICK_CELLS: the cells as pre-gathered 2 x 2 x 2 stencils (BlGridDevice::bricks)
   DeviceBuffer<float> d_kappa;   // electron entropy per cell (plasma_model = code_kappa)
   DeviceBuffer<double> d_coords;   // x1f x1v x2f x2v x3f x3v packed
   DeviceBuffer<unsigned short> d_buckets;

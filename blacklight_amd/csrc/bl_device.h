@@ -83,13 +83,11 @@ enum BlCounter {
 // per scratch set: the counters above, four transfer statistics, eight debug counters (kernels built with -DBL_GEO_STATS)
 #define BL_CNT_DEBUG (BL_CNT_COUNT + 4)
 #define BL_CNT_QUAD_NEXT (BL_CNT_COUNT + 12)   // work queue head of the launch that finishes the parked rays: parked rays handed out
-#define BL_CNT_RECORDS_FIRST (BL_CNT_COUNT + 13)   // BL_CNT_RECORDS as the first geodesic launch of a chunk left it (BlShadeArgs::record_range)
 #define BL_CNT_PARKED_YOUNG (BL_CNT_COUNT + 14)   // parked rays with fewer than BlTraceArgs::park_age samples so far (BL_CNT_PARKED: the others)
 #define BL_CNT_TOTAL (BL_CNT_COUNT + 15)
 
 struct BlGridDevice {
   const float *cells;        // [n_k][n_j][n_i][8]
-  const float *bricks;       // BL_SWITCH_BRICK_CELLS: [n_k][n_j][n_i][8 corners][8] - every anchor cell's stencil pre-gathered - else null
   const float *kappa;        // [n_k][n_j][n_i] electron entropy (plasma_model = code_kappa), else null
   const double *xf[3];       // faces  (r, theta, phi)
   const double *xv[3];       // centres
@@ -389,21 +387,13 @@ struct BlShadeArgs {
   int lds_table_bytes;        // size of the coordinate tables the locate kernel stages in LDS; 0: searched in HBM
   int samples_renormalised;   // records come from a geodesic checkpoint: momenta as stored, no renormalisation per sample
   int tolerant;               // bl_set_arithmetic(BL_ARITH_TOLERANT): kernels that have a tolerant instantiation use it
-  int fused_variant;          // tolerant tier, locate step inside: 1 = bl_shade_fused2_kernel (bl_fused2_applicable), 0 = bl_shade_fused_kernel
   // Composed transfer maps (bl_shade_fused2_kernel): one (a, c) per SEGMENT of a ray (BlTraceArgs::segment_rows) in row
   // ray_offset[ray] + segment of `composed`; `transfer` is then indexed by RECORD and written only for the samples of a wave that
   // holds a deferred sample or an optically thick step (the segment's row then says where they are: BL_COMPOSED_EXPANDED)
   double2 *composed;          // [segment row], or null: one transfer record per sample
   int general_locate;         // measurement switch (bl_stats.switches): the general locate kernel where the plain one applies
-  int unpipelined_shade;      // ... the general exact coefficient kernel where the software-pipelined one applies
   int undefined_edge;         // bl_set_undefined_policy(BL_UNDEFINED_EDGE): samples where the reference reads past its arrays use the edge
   const unsigned long long *counters_in;
-  // Which records a coefficient kernel covers: 0 all of the chunk's, [0, BL_CNT_RECORDS); 1 those of the chunk's first geodesic
-  // launch, [0, BL_CNT_RECORDS_FIRST) - shaded while the launch that finishes the parked rays still runs; 2 the rest,
-  // [BL_CNT_RECORDS_FIRST, BL_CNT_RECORDS). (bl_shade_fused2_kernel, bl_shade_exact2_kernel, bl_shade_formula_fast_kernel,
-  // bl_shade_kernel; the boundary is a multiple of 64.) skip_redo: the launcher leaves the exact second pass to a later call.
-  int record_range;
-  int skip_redo;
   unsigned long long *counters;
   const double *ray_kt, *ray_factor;
   const long long *ray_offset;   // [chunk_rays]: sample n of ray q has row ray_offset[q] + n in transfer, aux, pol_samples, freq_inputs, ...

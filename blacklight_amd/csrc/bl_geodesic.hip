@@ -135,17 +135,11 @@ __device__ __forceinline__ double opaque_uniform(double v) {
   asm volatile("" : "+s"(v));
   return v;
 }
-template <int kIntegrator, bool kTime, bool kSpinZero, bool kShell = false, bool kResume = false>
-// kResume: the launch that finishes the rays an earlier launch parked (BlTraceArgs::parked) - its lanes are refilled from the
-// parked rays, as they stood between two steps, instead of the chunk's queue; it parks nothing itself.
+template <int kIntegrator, bool kTime, bool kSpinZero, bool kShell = false>
 // kShell: the instantiation that leaves no records of steps in the empty shell around the grid (BlTraceArgs::skip_low).
 // Two waves per SIMD: the benchmark's instantiation (Dormand-Prince, no sample times, zero spin) and the Runge-Kutta steppers
 // fit 256 registers; see BL_GEO_ONE_WAVE for the others.
 __global__ void __launch_bounds__(64, BL_GEO_ONE_WAVE(kIntegrator, kTime, kSpinZero) ? 1 : BL_GEO_WAVES) bl_geodesic_kernel(BlTraceArgs P) {
-  // The launch that finishes the parked rays runs beside the coefficient kernel (bl_render.hip: tail_overlap), and the frame waits
-  // for its longest ray: its waves go first when a SIMD's vector unit is asked for by two (an eighth of the benchmark frame: the
-  // geodesic stage took 5.7 ms beside the coefficient kernel at equal priority, 4.1 alone)
-  if (kResume) __builtin_amdgcn_s_setprio(3);
   const BlSpacetime st = P.st;
 
   bool have_ray = false;
@@ -172,9 +166,7 @@ __global__ void __launch_bounds__(64, BL_GEO_ONE_WAVE(kIntegrator, kTime, kSpinZ
   // first found the queue dry (low half) and before (high half). Read through the LDS address space, volatile: a flat load would wait for the
   // sample stores in flight (s_waitcnt vmcnt(0)) in every pass, which a wave alone on its SIMD cannot afford (an eighth of the
   // benchmark frame: 4.1 -> 5.6 ms); a plain load would be hoisted into a register.
-  constexpr bool kPark = kIntegrator == BL_INTEGRATOR_DP && !kTime && !kShell && !kResume;
-  const long long n_parked_old = kResume ? (long long)(P.counters[BL_CNT_PARKED] < (unsigned long long)P.park_capacity ? P.counters[BL_CNT_PARKED] : (unsigned long long)P.park_capacity) : 0;
-  const long long n_parked = kResume ? n_parked_old + (long long)P.counters[BL_CNT_PARKED_YOUNG] : 0;   // (together no more than park_capacity)
+  constexpr bool kPark = kIntegrator == BL_INTEGRATOR_DP && !kTime && !kShell;
   __shared__ long long park_lds[5];
   typedef volatile __attribute__((address_space(3))) long long *ParkWord;
   const ParkWord park_word = (ParkWord)park_lds;
@@ -207,43 +199,7 @@ __global__ void __launch_bounds__(64, BL_GEO_ONE_WAVE(kIntegrator, kTime, kSpinZ
     // took (BL_CNT_NEXT_RAY < chunk_rays) are the next chunk's.
     bool need = !have_ray && !exhausted;
     unsigned long long need_mask = __ballot(need);
-    if (kResume && need_mask != 0ull) {
-      // the parked rays, in the order in which they were parked (bl_device.h: BL_PARK_DOUBLES)
-      const int leader = __ffsll((long long)need_mask) - 1;
-      const int lane = lane_here();
-      unsigned long long base = 0ull;
-      if (lane == leader) base = atomicAdd(&P.counters[BL_CNT_QUAD_NEXT], (unsigned long long)__popcll(need_mask));
-      base = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(base >> 32), leader) << 32)
-          | (unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)base, leader);
-      if (need) {
-        const long long at = (long long)base + __popcll(need_mask & ((1ull << lane) - 1ull));
-        if (at >= n_parked) {
-          exhausted = true;
-        } else {
-          have_ray = true;
-          const double *pk = P.parked + (at < n_parked_old ? at : (long long)P.park_capacity - 1 - (at - n_parked_old)) * BL_PARK_DOUBLES;
-#pragma unroll
-          for (int p = 0; p < 8; p++) {
-            s.y[p] = pk[p];
-            k0[p] = pk[8 + p];
-          }
-          s.kt = pk[16];
-          h_new = pk[17];
-          r_cur = pk[18];
-          r_prev_sample = pk[19];
-          const long long w0 = __double_as_longlong(pk[20]), w1 = __double_as_longlong(pk[21]), w2 = __double_as_longlong(pk[22]);
-          slot = (unsigned int)w0;
-          sample_num = (int)(w0 >> 32);
-          num_retry = (int)(unsigned int)w1;
-          trunc_at = (int)(w1 >> 32);
-          seg = (int)(unsigned int)w2;
-          previous_fail = ((w2 >> 32) & 1) != 0;
-          flag = ((w2 >> 32) & 2) != 0;
-          skipped = 0;
-        }
-      }
-    }
-    if (!kResume && need_mask != 0ull) {
+    if (need_mask != 0ull) {
 #ifdef BL_GEO_STATS
       st_refill += 1;
 #endif
@@ -748,7 +704,7 @@ __global__ void __launch_bounds__(64, BL_GEO_ONE_WAVE(kIntegrator, kTime, kSpinZ
       // rows of the kept samples in the per-sample arrays, in the order in which rays finish; slots not emitted go back
       const int rows = (!kShell && P.segment_rows) ? seg : final_num;
       if (!kShell && P.segment_rows) P.ray_rows[slot] = rows;
-      if (!kResume) P.ray_offset[slot] = (long long)atomicAdd(&P.counters[BL_CNT_SAMPLES], (unsigned long long)rows);   // (a parked ray has its rows)
+      P.ray_offset[slot] = (long long)atomicAdd(&P.counters[BL_CNT_SAMPLES], (unsigned long long)rows);
       atomicAdd(&P.counters[BL_CNT_COMMITTED], (unsigned long long)(-(long long)(P.ray_max_steps - (sample_num - (kShell ? skipped : 0)))));
       have_ray = false;
     }
@@ -818,13 +774,14 @@ extern "C" hipError_t bl_launch_ray_init(const BlTraceArgs *args, int integrator
   const bool dp = integrator == BL_INTEGRATOR_DP;
   if (dp && spin_zero) hipLaunchKernelGGL((bl_ray_init_kernel<true, true>), dim3(grid), dim3(256), 0, stream, *args);
   else if (dp) hipLaunchKernelGGL((bl_ray_init_kernel<true, false>), dim3(grid), dim3(256), 0, stream, *args);
-  else if (spin_zero) hipLaunchKernelGGL((bl_ray_init_kernel<false, true>), dim3(grid), dim3(256), 0, stream, *args);
   else hipLaunchKernelGGL((bl_ray_init_kernel<false, false>), dim3(grid), dim3(256), 0, stream, *args);
   return hipGetLastError();
 }
 
-// One expression per instantiation of the geodesic kernel (integrator x sample times x zero spin x empty shell; the last two
-// only without sample times)
+// One expression per instantiation of the geodesic kernel. Dormand-Prince (the default, and what every BASELINE configuration uses):
+// sample times x zero spin x empty shell, the last two only without sample times. The fixed-step steppers have the general
+// instantiation with and without sample times only (zero spin runs through the general formulas, bit for bit the same; bl_render.hip
+// leaves the shell's steps recorded for them).
 #define BL_GEODESIC_CASES(I, DO)                                                      \
   do {                                                                                \
     if (with_time && spin_zero) DO((bl_geodesic_kernel<I, true, true, false>));       \
@@ -832,6 +789,11 @@ extern "C" hipError_t bl_launch_ray_init(const BlTraceArgs *args, int integrator
     else if (spin_zero && shell) DO((bl_geodesic_kernel<I, false, true, true>));      \
     else if (spin_zero) DO((bl_geodesic_kernel<I, false, true, false>));              \
     else if (shell) DO((bl_geodesic_kernel<I, false, false, true>));                  \
+    else DO((bl_geodesic_kernel<I, false, false, false>));                            \
+  } while (0)
+#define BL_GEODESIC_CASES_FIXED_STEP(I, DO)                                           \
+  do {                                                                                \
+    if (with_time) DO((bl_geodesic_kernel<I, true, false, false>));                   \
     else DO((bl_geodesic_kernel<I, false, false, false>));                            \
   } while (0)
 
@@ -842,23 +804,14 @@ extern "C" hipError_t bl_launch_geodesic(const BlTraceArgs *args, int integrator
   const bool with_time = args->sample_t != nullptr;
   const bool spin_zero = args->st.bh_a == 0.0;   // also true for -0.0: the instantiation never reads bh_a
   const bool shell = args->ray_skipped != nullptr;
-  if (shell && with_time) return hipErrorInvalidValue;
+  if (shell && (with_time || integrator != BL_INTEGRATOR_DP)) return hipErrorInvalidValue;
 #define BL_LAUNCH_G(K) hipLaunchKernelGGL(K, dim3(grid), dim3(64), lds_pad, stream, *args)
   switch (integrator) {
     case BL_INTEGRATOR_DP: BL_GEODESIC_CASES(BL_INTEGRATOR_DP, BL_LAUNCH_G); break;
-    case BL_INTEGRATOR_RK4: BL_GEODESIC_CASES(BL_INTEGRATOR_RK4, BL_LAUNCH_G); break;
-    default: BL_GEODESIC_CASES(BL_INTEGRATOR_RK2, BL_LAUNCH_G); break;
+    case BL_INTEGRATOR_RK4: BL_GEODESIC_CASES_FIXED_STEP(BL_INTEGRATOR_RK4, BL_LAUNCH_G); break;
+    default: BL_GEODESIC_CASES_FIXED_STEP(BL_INTEGRATOR_RK2, BL_LAUNCH_G); break;
   }
 #undef BL_LAUNCH_G
-  return hipGetLastError();
-}
-
-// The rays the launch above parked (BlTraceArgs::parked; Dormand-Prince, no sample times, every step recorded), finished by
-// the same stepper: what bl_render.hip launches behind it when the coefficient kernel is to run beside the last rays of a chunk
-extern "C" hipError_t bl_launch_geodesic_resume(const BlTraceArgs *args, int grid, hipStream_t stream) {
-  if (args->parked == nullptr || args->sample_t != nullptr || args->ray_skipped != nullptr) return hipErrorInvalidValue;
-  if (args->st.bh_a == 0.0) hipLaunchKernelGGL((bl_geodesic_kernel<BL_INTEGRATOR_DP, false, true, false, true>), dim3(grid), dim3(64), 0, stream, *args);
-  else hipLaunchKernelGGL((bl_geodesic_kernel<BL_INTEGRATOR_DP, false, false, false, true>), dim3(grid), dim3(64), 0, stream, *args);
   return hipGetLastError();
 }
 
@@ -870,11 +823,12 @@ extern "C" int bl_geodesic_occupancy(int integrator, int with_time_flag, int spi
 #define BL_OCCUPANCY_G(K) err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, K, 64, 0)
   switch (integrator) {
     case BL_INTEGRATOR_DP: BL_GEODESIC_CASES(BL_INTEGRATOR_DP, BL_OCCUPANCY_G); break;
-    case BL_INTEGRATOR_RK4: BL_GEODESIC_CASES(BL_INTEGRATOR_RK4, BL_OCCUPANCY_G); break;
-    default: BL_GEODESIC_CASES(BL_INTEGRATOR_RK2, BL_OCCUPANCY_G); break;
+    case BL_INTEGRATOR_RK4: BL_GEODESIC_CASES_FIXED_STEP(BL_INTEGRATOR_RK4, BL_OCCUPANCY_G); break;
+    default: BL_GEODESIC_CASES_FIXED_STEP(BL_INTEGRATOR_RK2, BL_OCCUPANCY_G); break;
   }
 #undef BL_OCCUPANCY_G
 #undef BL_GEODESIC_CASES
+#undef BL_GEODESIC_CASES_FIXED_STEP
   if (err != hipSuccess || blocks < 1) blocks = 4;
   return blocks;
 }

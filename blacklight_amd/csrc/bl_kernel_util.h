@@ -43,13 +43,6 @@ __device__ __forceinline__ double std_min(double a, double b) { return (b < a) ?
 
 __device__ __forceinline__ int wave_lane() { return threadIdx.x & 63; }
 
-// The records a coefficient kernel covers (BlShadeArgs::record_range): [record_range_first, record_range_end)
-__device__ __forceinline__ unsigned long long record_range_first(const BlShadeArgs &P) {
-  return P.record_range == 2 ? P.counters_in[BL_CNT_RECORDS_FIRST] : 0ull;
-}
-__device__ __forceinline__ unsigned long long record_range_end(const BlShadeArgs &P) {
-  return P.record_range == 1 ? P.counters_in[BL_CNT_RECORDS_FIRST] : P.counters_in[BL_CNT_RECORDS];
-}
 
 // Wave-level scan / reduction with DPP row shifts and row broadcasts (VALU only: a ds_bpermute
 // shuffle costs an LDS round trip that nothing hides at one wave per SIMD).

@@ -14,7 +14,7 @@
 namespace {
 
 // geodesic start / end, locate start, coefficient start, transfer start, end, counters copied to the host; [7 ... 9] the split or
-// overlapped geodesic stage; [10, 11] polarized runs: frames built / transport matrices built (on the second stream)
+// geodesic stage; [10, 11] polarized runs: frames built / transport matrices built (on the second stream)
 constexpr int kEventsPerChunk = 12;
 
 // RadiationIntegrator::Hypergeometric (simulation_coefficients.cpp:740-773): 2F1 for z < 0 through its Pfaff
@@ -154,16 +154,12 @@ struct RenderJob {
   bool fast_formula = false;   // tolerant tier in formula mode: bl_shade_formula_fast_kernel
   bool tau_row = false;   // tolerant tier: an optical-depth image beside the intensities on the plain path (bl_tau_kernel)
   bool skip_shell = false;   // steps between the grid's outer edge and the camera's sphere leave no records (BlTraceArgs::skip_low)
-  bool fused = false;   // tolerant tier, common grid case: the locate step runs inside the coefficient kernel (bl_shade_fused_kernel)
-  bool fused2 = false;  // ... the benchmark's case of it: bl_shade_fused2_kernel (bl_shade_fused.hip)
+  bool fused2 = false;  // tolerant tier, the benchmark's grids: the locate step runs inside the coefficient kernel (bl_shade_fused2_kernel, bl_shade_fused.hip)
   bool composed = false;   // ... writing one affine transfer map per ray segment instead of one per sample (BlShadeArgs::composed)
   bool exact_fused = false;   // exact tier, the same grids, plain image at one frequency: bl_shade_exact2_kernel locates its samples itself
   bool pol_fused = false;     // polarized runs over the same grids (either tier): bl_shade_polarized2_kernel locates its samples itself
-  bool locate_inside = false; // fused || exact_fused: no locate kernel, no located samples in HBM
-  bool park = false;          // the last rays of a chunk go to bl_geodesic_quad_kernel (BlTraceArgs::parked): a measurement switch
-  bool tail_beside = false;   // tail_overlap, and the coefficient kernel's first pass runs beside the second launch (else after it)
-  bool tail_overlap = false;  // the last rays of a chunk are parked and finished by a second launch of the geodesic kernel, beside
-                              // which the coefficient kernel covers the records of the first (BlShadeArgs::record_range)
+  bool locate_inside = false; // fused2 || exact_fused || pol_fused: no locate kernel, no located samples in HBM
+  bool park = false;          // BL_TAIL_QUAD: the last rays of a chunk go to bl_geodesic_quad_kernel (BlTraceArgs::parked)
   bool split_long = false;    // BL_TAIL_SPLIT: rays predicted long on compute units of their own (bl_split_long_kernel)
   int split_cus = 0;          // ... how many compute units
   double split_b_lo = 0.0, split_b_hi = 0.0;   // ... and which impact parameters
@@ -300,11 +296,14 @@ void PlanJob(RenderJob &job) {
   job.freq_split = job.fast && job.n_nu >= 4 && p.plasma_power_frac == 0.0 && !job.tau_row;   // (the factors are the thermal formulas')
   // The fast path over one grid (or equal blocks merged into one) with its coordinate tables in LDS, trilinear sampling and no
   // optional geometric cut locates its samples inside the coefficient kernel: no located samples in HBM at all
-  job.fused = job.fast && !job.tau_row && ctx->grid_dev.n_blocks == 0 && ctx->lds_table_bytes > 0 && !ctx->grid_dev.fmks && p.simulation_interp && p.plasma_power_frac == 0.0
+  // (one frequency - with four or more it ends at the sample's factors, which no frequency enters: BlFreqInputs - over a single block
+  // with evenly spaced faces, bl_fused2_applicable; everything else goes through a locate kernel and bl_shade_fast_kernel)
+  job.fused2 = job.fast && !job.tau_row && ctx->grid_dev.n_blocks == 0 && ctx->lds_table_bytes > 0 && !ctx->grid_dev.fmks && p.simulation_interp && p.plasma_power_frac == 0.0
       && p.simulation_coord == BL_COORD_SKS   // (its locate step is the spherical one: Cartesian grids go through the locate kernel)
       && !(p.cut_omit_near || p.cut_omit_far || p.cut_omit_in >= 0.0 || p.cut_omit_out >= 0.0 || p.cut_midplane_theta != 0.0 || p.cut_midplane_z != 0.0 || p.cut_plane)
-      && static_cast<size_t>(ctx->lds_table_bytes) + (44 + 5 * static_cast<size_t>(job.n_nu) + ctx->n_i + ctx->n_j + ctx->n_k) * sizeof(double) <= 60u * 1024u
-      && !job.sample_save && !(ctx->switches & BL_SWITCH_NO_FUSED_LOCATE);   // (a sample checkpoint is made of the located samples)
+      && !job.sample_save && !(ctx->switches & (BL_SWITCH_NO_FUSED_LOCATE | BL_SWITCH_SPLIT_RECORDS))   // (a sample checkpoint is made of the located samples)
+      && !job.geo_load && !job.geo_save   // (interleaved records whose momenta are not renormalised yet)
+      && bl_fused2_applicable(&ctx->grid_dev, job.freq_split ? 1 : job.n_nu, job.n_rays) != 0;
   // The exact tier's plain image at one frequency over such a grid: the locate step inside bl_shade_exact2_kernel (bit-identical
   // to bl_locate_plain_kernel + bl_shade_exact_kernel, whose conditions these are)
   job.exact_fused = !job.fast && job.simulation && !job.aux && !ctx->polarized && !job.slow && !job.block_interp && job.n_nu == 1
@@ -320,44 +319,35 @@ void PlanJob(RenderJob &job) {
       && !(p.cut_omit_near || p.cut_omit_far || p.cut_omit_in >= 0.0 || p.cut_omit_out >= 0.0 || p.cut_midplane_theta != 0.0 || p.cut_midplane_z != 0.0 || p.cut_plane)
       && !job.geo_load && !job.geo_save && !job.sample_save && !job.need_time && !(ctx->switches & (BL_SWITCH_NO_FUSED_LOCATE | BL_SWITCH_SPLIT_RECORDS))
       && bl_fused2_applicable(&ctx->grid_dev, 1, job.n_rays) != 0;
-  job.interleaved = (job.fused || job.exact_fused || job.pol_fused || !job.simulation) && !job.geo_load && !job.geo_save && !job.sample_save && !(ctx->switches & BL_SWITCH_SPLIT_RECORDS);
-  job.locate_inside = job.fused || job.exact_fused || job.pol_fused;
-  // One frequency over a single block with evenly spaced faces: the benchmark's kernel, which also composes the affine maps of a
-  // ray's neighbouring samples before they leave it (the geodesic kernel numbers the segments: BlTraceArgs::segment_rows)
-  // (with four or more frequencies it ends at the sample's factors, which no frequency enters: BlFreqInputs)
-  job.fused2 = job.fused && job.interleaved && !(ctx->switches & BL_SWITCH_GENERAL_FUSED)
-      && bl_fused2_applicable(&ctx->grid_dev, job.freq_split ? 1 : job.n_nu, job.n_rays) != 0;
+  job.interleaved = (job.fused2 || job.exact_fused || job.pol_fused || !job.simulation) && !job.geo_load && !job.geo_save && !job.sample_save && !(ctx->switches & BL_SWITCH_SPLIT_RECORDS);
+  job.locate_inside = job.fused2 || job.exact_fused || job.pol_fused;
+  // The benchmark's kernel also composes the affine maps of a ray's neighbouring samples before they leave it (the geodesic kernel
+  // numbers the segments: BlTraceArgs::segment_rows)
   job.composed = job.fused2 && !job.freq_split && !ctx->reproducible && !(ctx->switches & BL_SWITCH_SAMPLE_RECORDS);
   // Plain images of a spherical Kerr-Schild simulation with fallback values beyond the grid: nothing is recorded of the steps that
   // lie in the empty shell between the grid's outer edge and the camera's sphere (both tiers; the samples count as ever)
   job.skip_shell = job.simulation && !job.aux && !ctx->polarized && !job.slow && !job.geo_load && !job.geo_save && !job.sample_save
       && !job.need_time && p.simulation_coord == BL_COORD_SKS && !ctx->grid_dev.fmks && !p.fallback_nan && ctx->grid_outer_x1 > 0.0
+      && p.ray_integrator == BL_INTEGRATOR_DP   // (the fixed-step steppers have no instantiation for it: bl_launch_geodesic)
       && ctx->grid_outer_x1 < p.camera_r && !(ctx->switches & BL_SWITCH_RECORD_EVERY_STEP);
   // (the geodesic kernel's instantiation that skips the shell has no register to number segments with: per-sample records there)
   if (job.skip_shell) job.composed = false;
-  // On request (a measurement switch: it pays on frames whose last rays run for thousands of steps and costs the others, DESIGN.md
-  // section 5j) the last rays of a chunk are finished with a ray per quad of lanes (Dormand-Prince stepper without sample times; the instantiation that skips the shell has no register for it)
+  // The last rays of a chunk finished with a ray per quad of lanes (Dormand-Prince stepper without sample times; the instantiation
+  // that skips the shell has no register for it): pays on frames whose last rays run for thousands of steps, costs the others
   const bool parkable = p.ray_integrator == BL_INTEGRATOR_DP && !job.need_time && !job.skip_shell && !job.geo_load;
   // (bl_set_tail_policy; BL_TAIL_AUTO: formula-mode frames - rays that circle for thousands of steps while the SIMDs around them idle,
   // configuration 2: 77 -> 67 ms - and not over a simulation grid, where the benchmark frame loses 6 ms to it. Bit-identical either way.)
   const bool quad_wanted = ctx->tail_policy == BL_TAIL_QUAD || (ctx->tail_policy == BL_TAIL_AUTO && !job.simulation && job.n_rays >= 64 * 64);
-  job.park = parkable && (quad_wanted || (ctx->switches & (BL_SWITCH_QUAD_TAIL | BL_SWITCH_QUAD_EVERY_RAY)) != 0)
-      && !(ctx->switches & (BL_SWITCH_TAIL_OVERLAP | BL_SWITCH_TAIL_REPACKED));
-  // On request (a measurement switch): the rays of a plane camera's root level whose impact parameter lies in a
-  // band around the photon ring's, stepped by bl_geodesic_quad_kernel on compute units the other stepper is kept off
-  const bool split_forced = ctx->tail_policy == BL_TAIL_SPLIT || (ctx->switches & BL_SWITCH_SPLIT_LONG) != 0;
+  job.park = parkable && (quad_wanted || (ctx->switches & BL_SWITCH_QUAD_EVERY_RAY) != 0);
+  // BL_TAIL_SPLIT: the rays of a plane camera's root level whose impact parameter lies in a band around the photon ring's, stepped by
+  // bl_geodesic_quad_kernel on compute units the other stepper is kept off
+  const bool split_forced = ctx->tail_policy == BL_TAIL_SPLIT;
   // (BL_TAIL_AUTO: where the geodesic stage waits for single rays - up to eight rays per lane of a grid of one wave per SIMD: a share
   // of a frame tiled over two or more GPUs, measured 1.13 / 1.09 / 1.02 x at an eighth / a quarter / a half of the benchmark frame, 1.00 for
   // the whole - and the critical curve is the circle b = 3 sqrt(3) M: no spin)
   const bool split_auto = ctx->tail_policy == BL_TAIL_AUTO && !ctx->split_unavailable && ctx->st.bh_a == 0.0 && !p.ray_flat
       && job.n_rays >= 32768 && job.n_rays <= 8ll * 256 * ctx->num_cus;
-  job.split_long = parkable && !job.park && (split_forced || split_auto) && p.camera_type == BL_CAMERA_PLANE && d->level == 0
-      && !(ctx->switches & (BL_SWITCH_TAIL_OVERLAP | BL_SWITCH_TAIL_REPACKED));
-  // On request (a measurement switch: it does not pay) the coefficient kernel runs beside the last rays
-  // of a chunk: plain images whose coefficient kernel takes a range of records
-  job.tail_overlap = parkable && !job.park && !job.split_long && (ctx->switches & (BL_SWITCH_TAIL_OVERLAP | BL_SWITCH_TAIL_REPACKED)) != 0 && !job.aux && !ctx->polarized && !job.slow
-      && !job.block_interp && !job.tau_row && !job.freq_split && !job.geo_save && !job.sample_save && job.n_nu < 4
-      && (job.fused2 || job.exact_fused || !job.simulation);
+  job.split_long = parkable && !job.park && (split_forced || split_auto) && p.camera_type == BL_CAMERA_PLANE && d->level == 0;
   // ... and in the exact coefficient kernel (plain images): the frequency loop as lanes of bl_coefficients_freq_kernel
   job.coef_split = !job.fast && job.simulation && !job.aux && !ctx->polarized && job.n_nu >= 4;
   // (polarized runs list the samples without coefficients there - cut samples, cut cells - which are many more)
@@ -411,8 +401,8 @@ void PlanScratch(RenderJob &job) {
   // (the waves of bl_geodesic_quad_kernel take blocks of record slots as well: a wave per SIMD)
   // (one to a SIMD: with three - as many as fit its registers - every ray runs at a third of the speed, the longest ones too, and
   // configuration 2 takes 94 ms instead of 67)
-  const long long quad_waves = job.park ? static_cast<long long>(ctx->num_cus) * 4 * ctx->quad_waves_per_simd
-      : (job.split_long ? 64ll * 4 : (job.tail_overlap ? max_grid : 0));   // (split: at most 64 compute units, sized below)
+  const long long quad_waves = job.park ? static_cast<long long>(ctx->num_cus) * 4
+      : (job.split_long ? 64ll * 4 : 0);   // (split: at most 64 compute units, sized below)
   const uint64_t worst_case = static_cast<uint64_t>(job.n_rays) * job.max_steps + static_cast<uint64_t>(max_grid + quad_waves) * BL_RECORD_BLOCK;
   const uint64_t fixed = per_ray * static_cast<uint64_t>(job.n_rays);
   auto capacity_for = [&](int n_slots) -> uint64_t {
@@ -446,11 +436,8 @@ void PlanScratch(RenderJob &job) {
   job.geo_grid = static_cast<int>(grid);
   job.geo_waves_per_cu = waves_per_cu;
   job.quad_grid = static_cast<int>(quad_waves);
-  // (the last rays beside the coefficient kernel: one scratch set - with two, the next chunk's rays run there already)
-  if (job.n_slots != 1) job.tail_overlap = false;
-  job.tail_beside = job.tail_overlap && (ctx->switches & BL_SWITCH_TAIL_OVERLAP) != 0;
   // a lane parks at most one ray (its wave ends), unless every ray is parked
-  job.park_capacity = (job.park || job.tail_overlap) ? (park_every_ray ? static_cast<size_t>(job.n_rays) : static_cast<size_t>(grid) * 64) : 0;
+  job.park_capacity = job.park ? (park_every_ray ? static_cast<size_t>(job.n_rays) : static_cast<size_t>(grid) * 64) : 0;
   // (the split is decided once for all rays of the call: only where one chunk is sure to take them all)
   if (job.split_long && (job.n_slots != 1 || capacity < worst_case)) job.split_long = false;
   if (job.split_long) {
@@ -461,7 +448,7 @@ void PlanScratch(RenderJob &job) {
     // one CU of every shader engine of every XCD (tools/ubench/cu_mask_probe.hip), which leaves the other stepper's share of every
     // shader engine equal; other counts were measured and lose (uneven shader engines fill unevenly: DESIGN.md section 5k).
     // How densely the call's rays cover the ring is counted on the host from every 1 / stride-th of them.
-    const double centre = ctx->split_centre > 0.0 ? ctx->split_centre : 5.196152422706632 * ctx->st.bh_m;
+    const double centre = 5.196152422706632 * ctx->st.bh_m;
     const double scale = ctx->st.bh_m * p.camera_width / p.camera_resolution, half = 0.5 * p.camera_resolution - 0.5;
     const double ref_lo = centre - 0.3 * ctx->st.bh_m, ref_hi = centre + 0.1 * ctx->st.bh_m;
     const long long stride = std::max<long long>(1, job.n_rays / 32768);
@@ -473,17 +460,14 @@ void PlanScratch(RenderJob &job) {
       inside += (b >= ref_lo && b <= ref_hi) ? 1 : 0;
     }
     const double per_width = static_cast<double>(inside) * static_cast<double>(job.n_rays) / static_cast<double>(std::max<long long>(seen, 1)) / (ref_hi - ref_lo);
-    job.split_cus = ctx->split_cus > 0 ? std::min(ctx->split_cus, ctx->num_cus / 2) : std::max(1, ctx->num_cus / 8);
+    job.split_cus = std::max(1, ctx->num_cus / 8);
     const double outer = 0.03 * ctx->st.bh_m;
     // (rounds of quads: one where the stage is a few rays per lane long - a second round would end after the other stepper -, more
     // where the other stepper has many rays per lane to get through and the quad stepper's compute units would stand idle meanwhile)
-    const int rounds = ctx->split_rounds > 0 ? ctx->split_rounds : (job.n_rays > 2ll * 256 * ctx->num_cus ? 2 : 1);   // (a quarter of the frame: 14.0 ms with two, 14.6 with one, 14.5 with three)
+    const int rounds = job.n_rays > 2ll * 256 * ctx->num_cus ? 2 : 1;   // (a quarter of the frame: 14.0 ms with two, 14.6 with one, 14.5 with three)
     double width = per_width > 0.0 ? 0.9 * 64.0 * job.split_cus * rounds / per_width : 0.0;   // of the band
     width = std::min(width, 0.45 * ctx->st.bh_m);
-    if (ctx->split_band > 0.0) {   // (BLACKLIGHT_AMD_SPLIT_BAND: a symmetric band of that half-width, for measurements)
-      job.split_b_lo = centre - ctx->split_band;
-      job.split_b_hi = centre + ctx->split_band;
-    } else if (width >= 0.08 * ctx->st.bh_m) {
+    if (width >= 0.08 * ctx->st.bh_m) {
       job.split_b_lo = centre - (width - outer);
       job.split_b_hi = centre + outer;
     } else {
@@ -530,7 +514,7 @@ void EnsureScratchOnce(RenderJob &job) {
     if (job.freq_split) sl.d_freq_inputs.Ensure(cap);   // instead of the transfer records
     else if (!ctx->polarized) sl.d_transfer.Ensure(cap * n_nu);   // (polarized runs: the eight coefficients of a sample side by side, d_pol_coeffs)
     if (job.composed) sl.d_composed.Ensure(cap);
-    if (job.park || job.tail_overlap || job.split_long) sl.d_parked.Ensure(job.park_capacity * BL_PARK_DOUBLES);
+    if (job.park || job.split_long) sl.d_parked.Ensure(job.park_capacity * BL_PARK_DOUBLES);
     if (job.tau_row) sl.d_tau_inc.Ensure(cap * n_nu);
     sl.d_counters.Ensure(BL_CNT_TOTAL);
     if (job.aux && !job.rows_only) sl.d_aux.Ensure(cap);   // (rows_only: nobody writes or reads the 96-byte records)
@@ -933,7 +917,6 @@ void BuildShadeArgs(RenderJob &job) {
       sa.fast_angle_band = std::max(1.0e-12, ctx->guard_band > 1.0e-8 ? ctx->guard_band : 0.0);   // (the debug switch widens both kinds of band)
     }
     sa.grid = ctx->grid_dev;
-    if (!(ctx->switches & BL_SWITCH_BRICK_CELLS)) sa.grid.bricks = nullptr;
     sa.lds_table_bytes = ctx->lds_table_bytes;
     sa.undefined_edge = (ctx->undefined_policy & BL_UNDEFINED_EDGE) ? 1 : 0;
     // Polarized runs in the tolerant tier keep the exact tier's per-frequency coefficient kernel: the reference's polarized step
@@ -948,7 +931,6 @@ void BuildShadeArgs(RenderJob &job) {
   }
   sa.samples_renormalised = job.geo_load ? 1 : 0;
   sa.general_locate = (ctx->switches & BL_SWITCH_GENERAL_LOCATE) ? 1 : 0;
-  sa.unpipelined_shade = (ctx->switches & BL_SWITCH_UNPIPELINED_SHADE) ? 1 : 0;
   // (uploaded when it differs from what the device holds: a frame loop uploads it once and waits for nothing here)
   if (ctx->shade_cold_host.size() != sizeof(BlShadeCold) || std::memcmp(ctx->shade_cold_host.data(), &cold, sizeof(BlShadeCold)) != 0) {
     ctx->d_shade_cold.Ensure(1);
@@ -1064,17 +1046,17 @@ void BindChunk(RenderJob &job, int k, long long begin, int rays) {
   ta.ray_skipped = job.skip_shell ? ctx->d_ray_skipped.ptr + begin : nullptr;
   ta.segment_rows = job.composed ? 1 : 0;
   ta.ray_rows = job.composed ? ctx->d_ray_rows.ptr + begin : nullptr;
-  ta.parked = (job.park || job.tail_overlap || job.split_long) ? sl.d_parked.ptr : nullptr;
+  ta.parked = (job.park || job.split_long) ? sl.d_parked.ptr : nullptr;
   ta.split_b_lo = ta.split_b_hi = 0.0;
   if (job.split_long) {
     ta.split_b_lo = job.split_b_lo;
     ta.split_b_hi = job.split_b_hi;
   }
   ta.park_capacity = static_cast<int>(std::min<size_t>(job.park_capacity, 0x7fffffff));
-  ta.park_below = ctx->park_below;
-  ta.park_after = ctx->park_after;
-  ta.park_quiet = ctx->park_quiet;
-  ta.park_age = ctx->park_age >= 0 ? ctx->park_age : job.max_steps / 8;
+  ta.park_below = 0;           // (a wave parks its rays once the queue is dry and none of its lanes holds ... see bl_geodesic.hip; the
+  ta.park_after = 0;           //  other thresholds were measurement knobs of rounds 4 and 5, left at the values that won)
+  ta.park_quiet = 1 << 30;
+  ta.park_age = job.max_steps / 8;
   ta.quad_first_round = ctx->num_cus * 4;
   ta.park_always = (job.park && (ctx->switches & BL_SWITCH_QUAD_EVERY_RAY)) ? 1 : 0;
   ta.ray_flags = ctx->d_ray_flags.ptr + begin;
@@ -1095,9 +1077,6 @@ void BindChunk(RenderJob &job, int k, long long begin, int rays) {
   sa.ray_flags = ta.ray_flags;
   sa.transfer = ctx->polarized ? nullptr : sl.d_transfer.ptr;
   sa.composed = job.composed ? sl.d_composed.ptr : nullptr;
-  sa.fused_variant = job.fused2 ? 1 : 0;
-  sa.record_range = 0;
-  sa.skip_redo = 0;
   sa.tau_inc = job.tau_row ? sl.d_tau_inc.ptr : nullptr;
   sa.aux = (job.aux && !job.rows_only) ? sl.d_aux.ptr : nullptr;
   sa.sample_t = ta.sample_t;
@@ -1483,14 +1462,6 @@ void LaunchGeodesicStage(RenderJob &job, int k, long long begin, int rays, hipSt
     Check(bl_launch_geodesic(&job.ta, ctx->params.ray_integrator, std::min(job.geo_grid, (rays + 63) / 64), stream_geo, 0), "geodesic kernel launch");
     // the rays it parked, sixteen to a wave, a wave per SIMD (waves that find none end at once)
     if (job.park) Check(bl_launch_geodesic_quad(&job.ta, job.quad_grid, stream_geo, 0), "geodesic quad kernel launch");
-    if (job.tail_overlap) {
-      // what the first launch left: the number of its records, for the coefficient kernel that starts now on the other stream;
-      // then the parked rays, by the same stepper
-      Check(hipMemcpyAsync(sl.d_counters.ptr + BL_CNT_RECORDS_FIRST, sl.d_counters.ptr + BL_CNT_RECORDS, sizeof(unsigned long long), hipMemcpyDeviceToDevice,
-                           stream_geo), "counter copy");
-      Check(hipEventRecord(e[7], stream_geo), "event");
-      Check(bl_launch_geodesic_resume(&job.ta, std::min(job.geo_grid, (rays + 63) / 64), stream_geo), "geodesic kernel launch");
-    }
   }
   Check(hipEventRecord(e[1], stream_geo), "event");
 }
@@ -1511,37 +1482,19 @@ void LaunchShadingStage(RenderJob &job, int k, bool geodesic_beside, hipStream_t
     else if (job.pol_fused) Check(bl_launch_shade_polarized2(&sa, job.shade_grid, stream), "coefficient kernel launch");
     else Check(bl_launch_shade(&sa, p.model_type, job.shade_grid, stream), "coefficient kernel launch");
   };
-  if (job.tail_beside) {
-    // The records of the chunk's first geodesic launch while the second, which finishes the parked rays, runs on the other
-    // stream; then the records of the second and whatever the tolerant kernel left to the exact one in either pass.
-    Check(hipStreamWaitEvent(stream, e[7], 0), "stream wait");
-    Check(hipEventRecord(e[2], stream), "event");
-    Check(hipEventRecord(e[3], stream), "event");
-    sa.record_range = 1;
-    sa.skip_redo = 1;
-    coefficient_kernel();
-    Check(hipEventRecord(e[8], stream), "event");
-    Check(hipStreamWaitEvent(stream, e[1], 0), "stream wait");
-    Check(hipEventRecord(e[9], stream), "event");
-    sa.record_range = 2;
-    sa.skip_redo = 0;
-    coefficient_kernel();
-    sa.record_range = 0;
-  } else {
   Check(hipStreamWaitEvent(stream, e[1], 0), "stream wait");
   Check(hipEventRecord(e[2], stream), "event");
   if (job.simulation && !job.locate_inside)
     Check(bl_launch_locate(&sa, geodesic_beside ? job.locate_grid_shared : job.locate_grid_alone, ctx->lds_table_bytes, stream), "locate kernel launch");
   Check(hipEventRecord(e[3], stream), "event");
   coefficient_kernel();
-  }
   // The transport matrices - memory - on the second stream beside the per-frequency coefficient kernel - arithmetic: both read what
   // bl_shade_polarized2_kernel left, neither reads the other. (The coefficient kernel's workgroups fill the device first, so the
   // matrices overlap its last quarter only: 276 -> 270 ms per 1024^2 frame, 1.10 -> 1.08 s at 2048^2 adaptive; a smaller grid for the
   // coefficient kernel or a priority stream for the matrices move the split, not the sum. BLACKLIGHT_AMD_POLARIZED_OVERLAP=0: in sequence.)
   // (one scratch set: with two, the second stream carries the next chunk's geodesic stage, and the matrices would queue behind it)
-  const bool matrices_beside = ctx->polarized && job.matrix_transport && ctx->pol_overlap != 0 && job.n_slots == 1 && ctx->stream_geo != stream;
-  const int polcoef_grid = ctx->num_cus * (ctx->polcoef_blocks_per_cu > 0 ? ctx->polcoef_blocks_per_cu : 20);
+  const bool matrices_beside = ctx->polarized && job.matrix_transport && job.n_slots == 1 && ctx->stream_geo != stream;
+  const int polcoef_grid = ctx->num_cus * 20;
   if (matrices_beside) {
     // (the frames of the samples without coefficients first: the matrices read them)
     Check(bl_launch_polarized_coefficients_parts(&sa, polcoef_grid, 2, stream), "polarized frame kernel launch");
@@ -1601,25 +1554,7 @@ void CollectChunk(RenderJob &job, int k) {
     std::fprintf(stderr, "split long: rays parked by %.3f ms, wide stepper done at %.3f ms, quad stepper at %.3f ms; %llu rays with b in [%.3f, %.3f] M on %d CUs\n", a, b, c, hc[BL_CNT_PARKED],
                  job.split_b_lo, job.split_b_hi, job.split_cus);
   }
-  if (job.tail_beside && ctx->debug_counters) {
-    float a = 0, b = 0, c = 0, d = 0, f = 0;
-    (void)hipEventElapsedTime(&a, e[0], e[7]);
-    (void)hipEventElapsedTime(&b, e[7], e[1]);
-    (void)hipEventElapsedTime(&c, e[0], e[3]);
-    (void)hipEventElapsedTime(&d, e[0], e[8]);
-    (void)hipEventElapsedTime(&f, e[0], e[9]);
-    float g = 0, h = 0;
-    (void)hipEventElapsedTime(&g, e[0], e[4]);
-    (void)hipEventElapsedTime(&h, e[0], e[5]);
-    std::fprintf(stderr, "tail overlap: first launch %.2f ms, second +%.2f; pass A %.2f ... %.2f, pass B %.2f ... %.2f, transfer ... %.2f; parked %llu, records %llu of %llu\n", a, b, c, d, f, g, h,
-                 hc[BL_CNT_PARKED], hc[BL_CNT_RECORDS_FIRST], hc[BL_CNT_RECORDS]);
-  }
-  if (job.tail_beside) {   // the two passes of the coefficient kernel, not the wait for the last rays between them
-    Check(hipEventElapsedTime(&ms, e[3], e[8]), "event time"); job.ms_shade += ms;
-    Check(hipEventElapsedTime(&ms, e[9], e[4]), "event time"); job.ms_shade += ms;
-  } else {
-    Check(hipEventElapsedTime(&ms, e[3], e[4]), "event time"); job.ms_shade += ms;
-  }
+  Check(hipEventElapsedTime(&ms, e[3], e[4]), "event time"); job.ms_shade += ms;
   Check(hipEventElapsedTime(&ms, e[4], e[5]), "event time"); job.ms_transfer += ms;
   fl.busy = false;
   if (fl.done < 0) fl.done = static_cast<long long>(std::min<unsigned long long>(hc[BL_CNT_NEXT_RAY], static_cast<unsigned long long>(fl.rays)));
@@ -1650,8 +1585,8 @@ void CollectChunk(RenderJob &job, int k) {
 void RunChunks(RenderJob &job) {
   bl_ctx *ctx = job.ctx;
   hipStream_t stream = ctx->stream;
-  // one scratch set: one stream, chunks back to back - unless the coefficient kernel is to run beside the last rays of a chunk
-  hipStream_t stream_geo = (job.n_slots == 2 || job.tail_overlap) ? ctx->stream_geo : stream;
+  // one scratch set: one stream, chunks back to back
+  hipStream_t stream_geo = job.n_slots == 2 ? ctx->stream_geo : stream;
   hipEvent_t ev_begin = ctx->events[2 * kEventsPerChunk], ev_end = ctx->events[2 * kEventsPerChunk + 1];
   Check(hipEventRecord(ev_begin, stream), "event");                // the uploads above were queued on `stream`
   if (stream_geo != stream) Check(hipStreamWaitEvent(stream_geo, ev_begin, 0), "stream wait");
@@ -1741,7 +1676,7 @@ void FinishStats(RenderJob &job) {
   st.n_deferred = static_cast<int64_t>(job.total_redo);
   st.n_undefined = static_cast<int64_t>(job.total_undefined);
   st.switches = ctx->switches;
-  st.fused_variant = job.fused ? (job.fused2 ? 2 : 1) : (job.exact_fused ? 3 : (job.pol_fused ? 4 : 0));
+  st.fused_variant = job.fused2 ? 2 : (job.exact_fused ? 3 : (job.pol_fused ? 4 : 0));
   st.n_parked = static_cast<int64_t>(job.total_parked);
   st.composed_maps = job.composed ? 1 : 0;
   st.tail_policy = job.park ? BL_TAIL_QUAD : (job.split_long ? BL_TAIL_SPLIT : BL_TAIL_WIDE);

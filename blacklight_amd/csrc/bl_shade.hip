@@ -188,9 +188,8 @@ __global__ void __launch_bounds__(256, 2) bl_shade_kernel(const BlShadeArgs P_at
   // measured on the refined-mesh, block-interpolation and slow-light frames of bench.py --workload, profiles/r05_f_rows.txt.)
   const BlShadeArgs &P = kRedo ? kernel_arguments_in_place<BlShadeArgs>() : P_at_entry;
   const BlSpacetime st = P.st;
-  // (the second pass covers the whole list, or every record, whatever range the pass before it covered: BlShadeArgs::record_range)
-  const unsigned long long first_record = kRedo ? 0ull : record_range_first(P);
-  const unsigned long long n_all = (kRedo ? P.counters_in[BL_CNT_RECORDS] : record_range_end(P)) - first_record;
+  const unsigned long long first_record = 0ull;
+  const unsigned long long n_all = P.counters_in[BL_CNT_RECORDS];
   const unsigned long long n_listed = kRedo ? P.counters_in[BL_CNT_REDO] : 0ull;
   const bool listed = kRedo && n_listed <= P.redo_capacity;
   const unsigned long long n_records = listed ? n_listed : n_all;   // work items: list entries or records
@@ -222,7 +221,7 @@ __global__ void __launch_bounds__(256, 2) bl_shade_kernel(const BlShadeArgs P_at
     const uint32_t n = (uint32_t)(((unsigned long long)__double_as_longlong(q1.y)) >> 32);
     const double x1 = q0.x, x2 = q0.y, x3 = q1.x;
     if (kRedo && kModel == BL_MODEL_SIMULATION && P.located == nullptr && live) {
-      // second pass behind bl_shade_fused_kernel, which leaves no located samples: the few samples it deferred are located
+      // second pass behind bl_shade_fused2_kernel, which leaves no located samples: the few samples it deferred are located
       // here, by the locate kernel's own code on the coordinate tables where they lie in HBM (the grid read was counted there)
       GridTables tab;
       for (int a = 0; a < 3; a++) {
@@ -541,19 +540,19 @@ extern "C" hipError_t bl_launch_locate(const BlShadeArgs *args, int grid, int ld
     else hipLaunchKernelGGL((bl_locate_plain_kernel<false>), dim3(grid), dim3(256), lds_bytes, stream, *args);
     return hipGetLastError();
   }
-#define BL_LAUNCH_L(R, S, LDS)                                                                                        \
+  // (zero spin known at compile time where the path is a common one: single-block and refined grids; slow light and tables beyond
+  // the LDS budget run the general instantiation, bit for bit the same at a = 0 - bl_geometry.h, "zero spin")
+#define BL_LAUNCH_L(R, LDS)                                                                                           \
   do {                                                                                                                \
-    if (spin_zero) hipLaunchKernelGGL((bl_locate_kernel<R, S, true>), dim3(grid), dim3(256), LDS, stream, *args);     \
-    else hipLaunchKernelGGL((bl_locate_kernel<R, S, false>), dim3(grid), dim3(256), LDS, stream, *args);              \
+    if (spin_zero) hipLaunchKernelGGL((bl_locate_kernel<R, false, true>), dim3(grid), dim3(256), LDS, stream, *args);  \
+    else hipLaunchKernelGGL((bl_locate_kernel<R, false, false>), dim3(grid), dim3(256), LDS, stream, *args);           \
   } while (0)
-  if (refined && slow) BL_LAUNCH_L(true, true, 0);
-  else if (refined) BL_LAUNCH_L(true, false, 0);
-  else if (lds_bytes == 0) {   // merged grid with tables beyond the LDS budget (not with slow light: its instantiation needs them in LDS)
-    if (spin_zero) hipLaunchKernelGGL((bl_locate_kernel<false, false, true, true>), dim3(grid), dim3(256), 0, stream, *args);
-    else hipLaunchKernelGGL((bl_locate_kernel<false, false, false, true>), dim3(grid), dim3(256), 0, stream, *args);
-  }
-  else if (slow) BL_LAUNCH_L(false, true, lds_bytes);
-  else BL_LAUNCH_L(false, false, lds_bytes);
+  if (refined && slow) hipLaunchKernelGGL((bl_locate_kernel<true, true, false>), dim3(grid), dim3(256), 0, stream, *args);
+  else if (refined) BL_LAUNCH_L(true, 0);
+  else if (lds_bytes == 0)   // merged grid with tables beyond the LDS budget (not with slow light: its instantiation needs them in LDS)
+    hipLaunchKernelGGL((bl_locate_kernel<false, false, false, true>), dim3(grid), dim3(256), 0, stream, *args);
+  else if (slow) hipLaunchKernelGGL((bl_locate_kernel<false, true, false>), dim3(grid), dim3(256), lds_bytes, stream, *args);
+  else BL_LAUNCH_L(false, lds_bytes);
 #undef BL_LAUNCH_L
   return hipGetLastError();
 }
@@ -570,21 +569,18 @@ extern "C" hipError_t bl_launch_shade(const BlShadeArgs *args, int model, int gr
 #define BL_LAUNCH_S(M, A, W) hipLaunchKernelGGL((bl_shade_kernel<M, A, W, false, false, false>), dim3(grid), dim3(256), 0, stream, *args)
   if (model == BL_MODEL_SIMULATION) {
     // (a polarized run is an auxiliary-image run whether or not it keeps BlAuxSample records: BlShadeArgs::aux_record_unused)
-    if (args->pol_samples != nullptr && sks_curved && spin_zero)   // polarized run: frame and coefficient inputs per sample, no frequency loop
-      hipLaunchKernelGGL((bl_shade_kernel<BL_MODEL_SIMULATION, true, true, true, true, true>), dim3(grid), dim3(256), 0, stream, *args);
-    else if (args->pol_samples != nullptr && sks_curved)
+    // polarized run: frame and coefficient inputs per sample, no frequency loop (the grids bl_shade_polarized2_kernel does not take)
+    if (args->pol_samples != nullptr && sks_curved)
       hipLaunchKernelGGL((bl_shade_kernel<BL_MODEL_SIMULATION, true, true, true, true, false>), dim3(grid), dim3(256), 0, stream, *args);
     else if (args->pol_samples != nullptr)
       hipLaunchKernelGGL((bl_shade_kernel<BL_MODEL_SIMULATION, true, true, false, true, false>), dim3(grid), dim3(256), 0, stream, *args);
     else if (aux && power) BL_LAUNCH_S(BL_MODEL_SIMULATION, true, true);
     else if (aux) BL_LAUNCH_S(BL_MODEL_SIMULATION, true, false);
     else if (power) BL_LAUNCH_S(BL_MODEL_SIMULATION, false, true);
-    else if (sks_curved && !args->unpipelined_shade) {   // the benchmark's case: the software-pipelined kernel
+    else if (sks_curved) {   // plain image of a spherical Kerr-Schild simulation in a curved spacetime: the software-pipelined kernel
       if (spin_zero) hipLaunchKernelGGL((bl_shade_exact_kernel<true>), dim3(grid), dim3(256), 0, stream, *args);
       else hipLaunchKernelGGL((bl_shade_exact_kernel<false>), dim3(grid), dim3(256), 0, stream, *args);
     }
-    else if (sks_curved && spin_zero) hipLaunchKernelGGL((bl_shade_kernel<BL_MODEL_SIMULATION, false, false, true, false, true>), dim3(grid), dim3(256), 0, stream, *args);
-    else if (sks_curved) hipLaunchKernelGGL((bl_shade_kernel<BL_MODEL_SIMULATION, false, false, true, false, false>), dim3(grid), dim3(256), 0, stream, *args);
     else BL_LAUNCH_S(BL_MODEL_SIMULATION, false, false);
   } else {
     if (aux) BL_LAUNCH_S(BL_MODEL_FORMULA, true, false);
@@ -605,15 +601,11 @@ extern "C" hipError_t bl_launch_shade_redo(const BlShadeArgs *args, int model, i
   const bool fused = args->located == nullptr;
   const bool cartesian = !fused && args->plasma.simulation_coord == BL_COORD_CKS;
   const bool power_law = !fused && (args->plasma.power_frac != 0.0 || args->tau_inc != nullptr);
-#define BL_LAUNCH_R(EXTENDED, SKS)                                                                                                        \
-  do {                                                                                                                                    \
-    if (spin_zero)                                                                                                                        \
-      hipLaunchKernelGGL((bl_shade_kernel<BL_MODEL_SIMULATION, false, EXTENDED, SKS, false, true, true>), dim3(grid), dim3(256), 0, stream, *args);  \
-    else                                                                                                                                  \
-      hipLaunchKernelGGL((bl_shade_kernel<BL_MODEL_SIMULATION, false, EXTENDED, SKS, false, false, true>), dim3(grid), dim3(256), 0, stream, *args); \
-  } while (0)
+  // (the common case - behind a kernel with the locate step inside - knows zero spin at compile time)
+#define BL_LAUNCH_R(EXTENDED, SKS) hipLaunchKernelGGL((bl_shade_kernel<BL_MODEL_SIMULATION, false, EXTENDED, SKS, false, false, true>), dim3(grid), dim3(256), 0, stream, *args)
   if (cartesian) BL_LAUNCH_R(true, false);
   else if (power_law) BL_LAUNCH_R(true, true);
+  else if (spin_zero) hipLaunchKernelGGL((bl_shade_kernel<BL_MODEL_SIMULATION, false, false, true, false, true, true>), dim3(grid), dim3(256), 0, stream, *args);
   else BL_LAUNCH_R(false, true);
 #undef BL_LAUNCH_R
   return hipGetLastError();

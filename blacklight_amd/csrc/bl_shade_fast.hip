@@ -1,5 +1,5 @@
-// bl_shade_fast.hip - the tolerant arithmetic tier's coefficient kernels (gfx950): bl_shade_fused_kernel (locate step inside:
-// the benchmark's kernel), bl_shade_fast_kernel (behind a locate kernel), bl_shade_formula_fast_kernel. See bl_sampling_fast.h
+// bl_shade_fast.hip - the tolerant arithmetic tier's coefficient kernels (gfx950) other than the benchmark's (bl_shade_fused.hip):
+// bl_shade_fast_kernel (behind a locate kernel), bl_shade_formula_fast_kernel. See bl_sampling_fast.h
 // for what the tier is and what it keeps of the exact tier.
 #include "bl_sampling_fast.h"
 
@@ -410,133 +410,6 @@ __global__ void __launch_bounds__(256, BL_FAST_WAVES) bl_shade_fast_kernel(const
   }
 }
 
-// Tolerant tier, common case of the grid (locate_plain_sample): the locate step inside the coefficient kernel. The located
-// samples - 32 bytes written and 32 read per sample, and the 32 bytes of record the locate kernel reads - never exist: the
-// locate kernel alone, at 371 vector instructions per sample, was bound by those 64 bytes per sample (10.9 ms per frame at
-// 4.4 TB/s). Three samples in flight per lane:
-//   next: its position record is requested before the arithmetic of `prev` and located after it (coordinate tables in LDS);
-//   cur:  located -> corner cells and momentum record requested at the top of the iteration;
-//   prev: cells and records arrived -> trilinear read, arithmetic.
-// One wait per iteration (before the search, on loads a whole sample's arithmetic old). Deferred cut decisions go to the
-// exact kernel's second pass, which locates those samples itself (BlShadeArgs::located == nullptr).
-template <bool kSpinZero>
-__global__ void __launch_bounds__(256, BL_FAST_WAVES) bl_shade_fused_kernel(const BlShadeArgs P) {
-  const BlSpacetime st = P.st;
-  const unsigned long long n_records = P.counters_in[BL_CNT_RECORDS];
-  const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
-  unsigned long long idx = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-  extern __shared__ double fast_table[];   // bl_shade_fast_kernel's table, then the grid's coordinate tables
-  const int table_doubles = 44 + 5 * P.n_nu;
-  for (int i = threadIdx.x; i < table_doubles; i += blockDim.x) {
-    const BlShadeCold &cc = *P.cold;
-    double value;
-    if (i < 44) {
-      value = i < 14 ? cc.fast_cut[i] : (i < 28 ? cc.fast_cut_lo[i - 14] : (i < 42 ? cc.fast_cut_hi[i - 28]
-          : (i == 42 ? (double)cc.fallback_rho : (double)cc.fallback_pgas)));
-    } else {
-      const int which = (i - 44) / P.n_nu;
-      const double f = P.frequencies[(i - 44) - which * P.n_nu];
-      const double f_1_3 = fastmath::cbrt(f);
-      value = which == 0 ? f : (which == 1 ? bl_sqrt_g(f) : (which == 2 ? f_1_3 : (which == 3 ? bl_sqrt_g(f_1_3) : fastmath::rcp(f))));
-    }
-    fast_table[i] = value;
-  }
-  PlainGrid pg;
-  stage_grid_tables(P.grid, fast_table + table_doubles, &pg);
-  __syncthreads();
-  stage_reciprocal_widths(P.grid, fast_table + table_doubles + P.lds_table_bytes / sizeof(double), &pg);
-  __syncthreads();
-  if (n_records == 0ull) return;
-  const unsigned long long last = n_records - 1ull;
-  const double camera_r = P.cuts.camera_r;
-  const double angle_band = P.fast_angle_band;
-  double acos_c[14];   // in registers for the whole loop (bl_fastmath.h) where there is room: the spinning instantiation keeps literals
-#pragma unroll
-  for (int t = 0; t < 14; t++) acos_c[t] = kSpinZero ? fastmath::opaque_register(fastmath::kAcosCoefficients[t]) : fastmath::kAcosCoefficients[t];
-  unsigned long long gathers_local = 0ull;
-  // (a position beyond the last record reads the last record and comes back marked dead: whether a slot of the pipeline holds a
-  // sample is then a property of its record, not a flag carried beside it - four lane masks fewer across the loop)
-  auto load_position = [&](unsigned long long at, double2 &q0, double2 &q1) {
-    const bool have = at < n_records;
-    const double2 *hot = reinterpret_cast<const double2 *>(P.records_hot + (have ? at : last) * P.record_stride);
-    q0 = hot[0];
-    q1 = hot[1];
-    q1.y = have ? q1.y : __longlong_as_double((long long)BL_DEAD_RAY);
-  };
-  FastRay rec_prev;                        // q0, q1: position record; q2, q3: momentum record
-  double2 hot_cur0, hot_cur1, hot_next0, hot_next1;
-  PlainLocated loc_prev, loc_cur;
-  float4 lo[8], hi[8];
-  unsigned long long idx_prev = ~0ull, idx_cur = idx;
-  rec_prev.q0 = rec_prev.q1 = rec_prev.q2 = rec_prev.q3 = make_double2(0.0, 0.0);
-  rec_prev.q1.y = __longlong_as_double((long long)BL_DEAD_RAY);
-  loc_prev.f_i = loc_prev.f_j = loc_prev.f_k = loc_prev.ph_unwrapped = 0.0;
-  loc_prev.status = kSampleNone;
-  loc_prev.cell = 0u;
-#pragma unroll
-  for (int c = 0; c < 8; c++) lo[c] = hi[c] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-  load_position(idx_cur, hot_cur0, hot_cur1);
-  idx += stride;
-  unsigned long long idx_next = idx;
-  // (the position record of `next` is requested a whole iteration before its search, so that the wait in front of the search
-  // is for loads of the previous iteration, not for the cells and records requested in this one)
-  load_position(idx_next, hot_next0, hot_next1);
-  idx += stride;
-  {
-    const bool live = (uint32_t)__double_as_longlong(hot_cur1.y) != BL_DEAD_RAY;
-    loc_cur = locate_plain_sample_tolerant<kSpinZero>(st, P.grid, pg, camera_r, angle_band, acos_c, live, hot_cur0.x, hot_cur0.y, hot_cur1.x);
-  }
-  while (idx_prev < n_records || idx_cur < n_records) {   // (idx_prev starts beyond every record)
-    const uint32_t ray = (uint32_t)__double_as_longlong(rec_prev.q1.y);
-    const bool live = ray != BL_DEAD_RAY;
-    const uint32_t n = (uint32_t)(((unsigned long long)__double_as_longlong(rec_prev.q1.y)) >> 32);
-    const int status = (int)(loc_prev.status & 0xffu);
-    const bool undecided = (loc_prev.status & kPlainUndecided) != 0u;   // theta or phi too close to a decision: the exact kernel's sample
-    // per-ray constants of `prev`: requested before the next sample's cells
-    const double kt = P.ray_kt[live ? ray : 0u], momentum_factor = P.ray_factor[live ? ray : 0u];
-    const size_t row = (size_t)P.ray_offset[live ? ray : 0u] + n;
-    float pr[8];
-    const bool near_midpoint = gather_finish_tolerant(P, (float)fast_table[42], (float)fast_table[43], status, lo, hi, loc_prev.f_i, loc_prev.f_j,
-                                                      loc_prev.f_k, pr);
-    gathers_local += (live && status == kSampleInterp) ? 1ull : 0ull;
-    gather_issue(P, (int)(loc_cur.status & 0xffu), loc_cur.cell, lo, hi);
-    double2 cold_cur0, cold_cur1;
-    {
-      const double2 *cold = reinterpret_cast<const double2 *>(P.records_cold + (idx_cur < n_records ? idx_cur : last) * P.record_stride);
-      cold_cur0 = cold[0];
-      cold_cur1 = cold[1];
-    }
-    double2 hot_after0, hot_after1;
-    load_position(idx, hot_after0, hot_after1);
-    if (live) {
-      // ReverseGeodesics: sample_len = -geodesic_len (geodesics.cpp:840)
-      if (undecided || near_midpoint || !fast_shade_sample<kSpinZero>(P, fast_table, pr, status, row, rec_prev.q0.x, rec_prev.q0.y, rec_prev.q1.x, rec_prev.q2.x,
-                                                     rec_prev.q2.y, rec_prev.q3.x, kt, momentum_factor, -rec_prev.q3.y)) {
-        fast_defer(P, idx_prev);
-      }
-    }
-    // the search for `next`
-    const bool live_next = (uint32_t)__double_as_longlong(hot_next1.y) != BL_DEAD_RAY;
-    const PlainLocated loc_next = locate_plain_sample_tolerant<kSpinZero>(st, P.grid, pg, camera_r, angle_band, acos_c, live_next, hot_next0.x, hot_next0.y, hot_next1.x);
-    rec_prev.q0 = hot_cur0;
-    rec_prev.q1 = hot_cur1;
-    rec_prev.q2 = cold_cur0;
-    rec_prev.q3 = cold_cur1;
-    loc_prev = loc_cur;
-    idx_prev = idx_cur;
-    hot_cur0 = hot_next0;
-    hot_cur1 = hot_next1;
-    loc_cur = loc_next;
-    idx_cur = idx_next;
-    hot_next0 = hot_after0;
-    hot_next1 = hot_after1;
-    idx_next = idx;
-    idx += stride;
-  }
-  for (int offset = 32; offset > 0; offset >>= 1) gathers_local += __shfl_xor(gathers_local, offset, 64);
-  if ((threadIdx.x & 63) == 0 && gathers_local != 0ull) atomicAdd(&P.counters[BL_CNT_GATHERS], gathers_local);
-}
-
 // Tolerant tier, formula mode (formula_coefficients.cpp:62-180; BASELINE configuration 2): one sample per lane, no grid. The
 // reference finds the azimuth with atan2 and atan, takes its sine and cosine, and builds u^mu through the Boyer-Lindquist
 // metric and the Jacobian to Cartesian Kerr-Schild coordinates; with u_r = u_theta = 0 that Jacobian collapses - r (sin
@@ -547,11 +420,11 @@ __global__ void __launch_bounds__(256, 4) bl_shade_formula_fast_kernel(const BlS
   const BlFormulaDevice fm = P.formula;
   const double bh_m = P.st.bh_m, bh_a = P.st.bh_a, a2 = bh_a * bh_a;
   const bool flat = P.st.ray_flat != 0;
-  const unsigned long long n_records = record_range_end(P);
+  const unsigned long long n_records = P.counters_in[BL_CNT_RECORDS];
   const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
   const double r0_inv2 = 1.0 / (fm.r0 * fm.r0), h2 = fm.h * fm.h, nup_inv = 1.0 / fm.nup;
   const double band_lo = P.cuts.camera_r * (1.0 - 1.0e-9), band_hi = P.cuts.camera_r * (1.0 + 1.0e-9);
-  unsigned long long idx = record_range_first(P) + (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long idx = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
   bool more = idx < n_records;
   FastRay next;
   next.q0 = next.q1 = next.q2 = next.q3 = make_double2(0.0, 0.0);
@@ -654,23 +527,15 @@ extern "C" hipError_t bl_launch_shade_fused2(const BlShadeArgs *args, int grid, 
 // Tolerant tier in formula mode: the fast kernel, then the exact kernel over the records it deferred
 extern "C" hipError_t bl_launch_shade_formula_fast(const BlShadeArgs *args, int grid, hipStream_t stream) {
   hipLaunchKernelGGL(bl_shade_formula_fast_kernel, dim3(grid), dim3(256), 0, stream, *args);
-  if (args->skip_redo) return hipGetLastError();
   return bl_launch_shade_redo(args, BL_MODEL_FORMULA, grid, stream);
 }
 
 // Tolerant tier, simulations: the fast coefficient kernel, then the exact kernel over the records it deferred
 extern "C" hipError_t bl_launch_shade_fast(const BlShadeArgs *args, int grid, hipStream_t stream) {
   const bool spin_zero = args->st.bh_a == 0.0;
-  if (args->located == nullptr && args->fused_variant == 1) {   // the benchmark's case has a kernel of its own (bl_shade_fused.hip)
+  if (args->located == nullptr) {   // no locate kernel ran: the kernel with the locate step inside (bl_shade_fused.hip)
     const hipError_t err = bl_launch_shade_fused2(args, grid, stream);
-    if (err != hipSuccess || args->skip_redo) return err;
-    return bl_launch_shade_redo(args, BL_MODEL_SIMULATION, grid, stream);
-  }
-  if (args->located == nullptr) {   // no locate kernel ran: the fused kernel (coordinate tables in LDS behind its own table)
-    const size_t lds = (44 + 5 * args->n_nu) * sizeof(double) + args->lds_table_bytes
-        + (size_t)(args->grid.n[0] + args->grid.n[1] + args->grid.n[2]) * sizeof(double);   // (+ the reciprocal widths)
-    if (spin_zero) hipLaunchKernelGGL((bl_shade_fused_kernel<true>), dim3(grid), dim3(256), lds, stream, *args);
-    else hipLaunchKernelGGL((bl_shade_fused_kernel<false>), dim3(grid), dim3(256), lds, stream, *args);
+    if (err != hipSuccess) return err;
     return bl_launch_shade_redo(args, BL_MODEL_SIMULATION, grid, stream);
   }
   const size_t lds = (44 + 5 * args->n_nu) * sizeof(double);
@@ -678,7 +543,7 @@ extern "C" hipError_t bl_launch_shade_fast(const BlShadeArgs *args, int grid, hi
   const bool general = args->plasma.power_frac != 0.0 || args->tau_inc != nullptr || args->plasma.simulation_coord == BL_COORD_CKS;
 #define BL_LAUNCH_F(SPIN, GENERAL) hipLaunchKernelGGL((bl_shade_fast_kernel<SPIN, GENERAL>), dim3(grid), dim3(256), lds, stream, *args)
   if (general) {
-    if (spin_zero) BL_LAUNCH_F(true, true); else BL_LAUNCH_F(false, true);
+    BL_LAUNCH_F(false, true);
   } else {
     if (spin_zero) BL_LAUNCH_F(true, false); else BL_LAUNCH_F(false, false);
   }

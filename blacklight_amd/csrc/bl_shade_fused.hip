@@ -1,6 +1,6 @@
 // bl_shade_fused.hip - the benchmark's coefficient kernel (gfx950): tolerant arithmetic tier, locate step inside, ONE frequency,
 // one grid block whose faces are evenly spaced in log r, theta and phi and cover the whole sphere (what Athena++ / the mock write
-// for a spherical Kerr-Schild run). Everything else the tier covers stays on bl_shade_fused_kernel / bl_shade_fast_kernel
+// for a spherical Kerr-Schild run). Everything else the tier covers stays on a locate kernel + bl_shade_fast_kernel
 // (bl_shade_fast.hip), whose arithmetic this kernel restates; what is different here is everything around the arithmetic:
 //
 //   * the loop body is one straight line. Every lane runs the whole sample - a dead slot, a cut or an off-grid sample on harmless
@@ -364,19 +364,6 @@ __device__ __forceinline__ void gather_issue(const char *cells, uint32_t cell_by
   }
 }
 
-// The same sixteen loads from a BRICK (BlGridDevice::bricks): the eight corner cells of anchor cell c pre-gathered into 256 contiguous,
-// 256-byte-aligned bytes at c x 256 (corner = 4 dk + 2 dj + di, as above) - two whole 128-byte lines per sample instead of four
-// 64-byte segments in four rows, one address per sample, sixteen immediate offsets. A measurement (BL_SWITCH_BRICK_CELLS; DESIGN.md
-// section 6): eight times the cell array, and neighbouring anchors no longer share lines.
-__device__ __forceinline__ void gather_issue_bricks(const char *bricks, uint32_t cell_bytes, float4 (&lo)[8], float4 (&hi)[8]) {
-  const float4 *p = reinterpret_cast<const float4 *>(bricks + (size_t)(cell_bytes << 3));   // (cell x 256 < 2^32: bl_set_grid)
-#pragma unroll
-  for (int corner = 0; corner < 8; corner++) {
-    lo[corner] = p[2 * corner];
-    hi[corner] = p[2 * corner + 1];
-  }
-}
-
 // gather_finish_tolerant() for an interpolated sample (bl_shade_fast.hip): the trilinear read with fused multiply-adds, the <= 0
 // rule, the rounding to float; true when a sum lies too close to the midpoint of two floats for the tier to decide the rounding
 __device__ __forceinline__ bool trilinear(const float4 (&lo)[8], const float4 (&hi)[8], double f_i, double f_j, double f_k, float pr[8]) {
@@ -586,7 +573,7 @@ __device__ __forceinline__ double2 shade(const BlSpacetime &st, const double (&K
 
 }  // namespace fused2
 
-// Three samples in flight per lane, as in bl_shade_fused_kernel:
+// Three samples in flight per lane:
 //   next: its position record was requested an iteration ago and is located at the end of this one (row tables in LDS);
 //   cur:  located -> corner cells and momentum record requested after the trilinear read has freed the landing registers;
 //   prev: cells and records arrived -> trilinear read, arithmetic, record.
@@ -598,7 +585,7 @@ __device__ __forceinline__ double2 shade(const BlSpacetime &st, const double (&K
 // a NaN included: not a product of numbers), writes its samples' own records instead, by record index, and marks its segments'
 // rows as standing for those (BL_COMPOSED_EXPANDED).
 // kFactors: several frequencies - a sample leaves as its factors (BlFreqInputs, row ray_offset + n) instead of a transfer record.
-template <bool kSpinZero, bool kComposed, bool kBricks = false, bool kFactors = false>
+template <bool kSpinZero, bool kComposed, bool kFactors = false>
 __global__ void __launch_bounds__(256, BL_FAST_WAVES) bl_shade_fused2_kernel(const BlShadeArgs P) {
   using namespace fused2;
   extern __shared__ double lds[];
@@ -622,8 +609,8 @@ __global__ void __launch_bounds__(256, BL_FAST_WAVES) bl_shade_fused2_kernel(con
     stage_axis_rows<true>(P.grid, reinterpret_cast<AxisRow *>(lds + 48));
   }
   __syncthreads();
-  const uint32_t n_records = (uint32_t)record_range_end(P);   // (a scratch set holds fewer than 2^32 records)
-  const uint32_t first_record = (uint32_t)record_range_first(P);   // (a multiple of 64: BlShadeArgs::record_range)
+  const uint32_t n_records = (uint32_t)P.counters_in[BL_CNT_RECORDS];   // (a scratch set holds fewer than 2^32 records)
+  const uint32_t first_record = 0u;
   if (n_records <= first_record) return;
   const uint32_t stride = gridDim.x * blockDim.x;
   const uint32_t last = n_records - 1u;
@@ -638,7 +625,7 @@ __global__ void __launch_bounds__(256, BL_FAST_WAVES) bl_shade_fused2_kernel(con
   const double freq_inv = uniform_value(fastmath::rcp(freq));
   const double x_unit = P.x_unit;
   const bool fallback_nan = P.plasma.fallback_nan != 0;
-  const char *cells = reinterpret_cast<const char *>(kBricks ? P.grid.bricks : P.grid.cells);
+  const char *cells = reinterpret_cast<const char *>(P.grid.cells);
   const uint32_t row_bytes = (uint32_t)P.grid.stride_row * 32u, plane_bytes = (uint32_t)P.grid.stride_plane * 32u;
   const char *ray_kt = reinterpret_cast<const char *>(P.ray_kt), *ray_factor = reinterpret_cast<const char *>(P.ray_factor);
   const char *ray_offset = reinterpret_cast<const char *>(P.ray_offset);
@@ -711,8 +698,7 @@ __global__ void __launch_bounds__(256, BL_FAST_WAVES) bl_shade_fused2_kernel(con
       for (int q = 0; q < 8; q++) asm volatile("" : "+v"(pr[q]));
     }
     gathers_wave += (unsigned long long)__popcll(__ballot(interp));
-    if (kBricks) fused2::gather_issue_bricks(cells, c.loc.cell_bytes, lo, hi);
-    else fused2::gather_issue(cells, c.loc.cell_bytes, (c.loc.status & 0xffu) == (uint32_t)kSampleInterp, row_bytes, plane_bytes, lo, hi);
+    fused2::gather_issue(cells, c.loc.cell_bytes, (c.loc.status & 0xffu) == (uint32_t)kSampleInterp, row_bytes, plane_bytes, lo, hi);
     {
       const double2 *rec = reinterpret_cast<const double2 *>(record_base(base_index) + (size_t)(c.in ? lane_bytes : 0u));
       c.c0 = rec[2];
@@ -926,8 +912,8 @@ __global__ void __launch_bounds__(256, 2) bl_shade_exact2_kernel(const BlShadeAr
   const uint32_t lds_base = lds_address(lds);
   stage_axis_rows<false>(P.grid, reinterpret_cast<AxisRow *>(lds));
   __syncthreads();
-  const uint32_t n_records = (uint32_t)record_range_end(P);
-  const uint32_t first_record = (uint32_t)record_range_first(P);
+  const uint32_t n_records = (uint32_t)P.counters_in[BL_CNT_RECORDS];
+  const uint32_t first_record = 0u;
   if (n_records <= first_record) return;
   const uint32_t stride = gridDim.x * blockDim.x;
   const uint32_t last = n_records - 1u;
@@ -1064,8 +1050,8 @@ __global__ void __launch_bounds__(256, 2) bl_shade_polarized2_kernel(const BlSha
   const uint32_t lds_base = lds_address(lds);
   stage_axis_rows<false>(P.grid, reinterpret_cast<AxisRow *>(lds));
   __syncthreads();
-  const uint32_t n_records = (uint32_t)record_range_end(P);
-  const uint32_t first_record = (uint32_t)record_range_first(P);
+  const uint32_t n_records = (uint32_t)P.counters_in[BL_CNT_RECORDS];
+  const uint32_t first_record = 0u;
   if (n_records <= first_record) return;
   const uint32_t stride = gridDim.x * blockDim.x;
   const uint32_t last = n_records - 1u;
@@ -1224,7 +1210,7 @@ extern "C" hipError_t bl_launch_shade_exact2(const BlShadeArgs *args, int grid, 
   return hipGetLastError();
 }
 
-// Whether a render can take this kernel (the caller has checked what bl_shade_fused_kernel needs, one frequency without the
+// Whether a render can take this kernel (the caller has checked what the locate step inside needs, one frequency without the
 // per-frequency split, interleaved records whose momenta are not renormalised yet): one block, faces evenly spaced in log r / theta
 // / phi with the angles covering the sphere, at least two cells per axis, a cell array and ray slots that 32-bit byte offsets cover
 // (record indices always do: PlanScratch), room in LDS for the row tables.
@@ -1247,34 +1233,12 @@ extern "C" hipError_t bl_launch_shade_fused2(const BlShadeArgs *args, int grid, 
   const bool spin_zero = args->st.bh_a == 0.0, composed = args->composed != nullptr;
 #define BL_LAUNCH_F2(S, C) hipLaunchKernelGGL((bl_shade_fused2_kernel<S, C>), dim3(grid), dim3(256), lds, stream, *args)
   if (args->freq_split) {
-    if (spin_zero) hipLaunchKernelGGL((bl_shade_fused2_kernel<true, false, false, true>), dim3(grid), dim3(256), lds, stream, *args);
-    else hipLaunchKernelGGL((bl_shade_fused2_kernel<false, false, false, true>), dim3(grid), dim3(256), lds, stream, *args);
-  } else if (spin_zero && composed && g.bricks != nullptr) hipLaunchKernelGGL((bl_shade_fused2_kernel<true, true, true>), dim3(grid), dim3(256), lds, stream, *args);
-  else if (spin_zero && composed) BL_LAUNCH_F2(true, true);
+    if (spin_zero) hipLaunchKernelGGL((bl_shade_fused2_kernel<true, false, true>), dim3(grid), dim3(256), lds, stream, *args);
+    else hipLaunchKernelGGL((bl_shade_fused2_kernel<false, false, true>), dim3(grid), dim3(256), lds, stream, *args);
+  } else if (spin_zero && composed) BL_LAUNCH_F2(true, true);
   else if (spin_zero) BL_LAUNCH_F2(true, false);
   else if (composed) BL_LAUNCH_F2(false, true);
   else BL_LAUNCH_F2(false, false);
 #undef BL_LAUNCH_F2
-  return hipGetLastError();
-}
-
-// BlGridDevice::bricks from BlGridDevice::cells (one block, [k][j][i][8 floats]): the eight corner cells of every anchor cell side by
-// side, corner = 4 dk + 2 dj + di; neighbours beyond the last cell of an axis are that cell (no anchor of an interpolated sample
-// lies there). One thread per (anchor cell, corner, half cell).
-__global__ void __launch_bounds__(256) bl_build_bricks_kernel(const float4 *cells, float4 *bricks, int n_i, int n_j, int n_k) {
-  const unsigned long long total = (unsigned long long)n_i * n_j * n_k * 16ull;
-  const unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= total) return;
-  const unsigned long long cell = t >> 4;
-  const int part = (int)(t & 15), corner = part >> 1, half = part & 1;
-  const int i = (int)(cell % n_i), j = (int)(cell / n_i % n_j), k = (int)(cell / ((unsigned long long)n_i * n_j));
-  const int ii = i + (corner & 1) < n_i ? i + (corner & 1) : n_i - 1, jj = j + ((corner >> 1) & 1) < n_j ? j + ((corner >> 1) & 1) : n_j - 1;
-  const int kk = k + (corner >> 2) < n_k ? k + (corner >> 2) : n_k - 1;
-  bricks[t] = cells[(((unsigned long long)kk * n_j + jj) * n_i + ii) * 2ull + half];
-}
-extern "C" hipError_t bl_launch_build_bricks(const float *cells, float *bricks, int n_i, int n_j, int n_k, hipStream_t stream) {
-  const unsigned long long total = (unsigned long long)n_i * n_j * n_k * 16ull;
-  hipLaunchKernelGGL(bl_build_bricks_kernel, dim3((unsigned int)((total + 255ull) / 256ull)), dim3(256), 0, stream, reinterpret_cast<const float4 *>(cells),
-                     reinterpret_cast<float4 *>(bricks), n_i, n_j, n_k);
   return hipGetLastError();
 }

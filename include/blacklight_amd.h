@@ -286,8 +286,8 @@ typedef struct bl_stats {
   int64_t n_deferred;         /* tolerant tier: samples whose cut decision was left to the exact kernel           */
   int64_t n_undefined;        /* BL_UNDEFINED_EDGE: samples where the reference reads past its arrays (edge cell used)     */
   uint32_t switches;          /* BL_SWITCH_* bits active in this context (measurement switches, below); 0 in production  */
-  int32_t fused_variant;      /* the locate step inside the coefficient kernel: 2 = bl_shade_fused2_kernel, 1 = bl_shade_fused_kernel
-                                 (tolerant tier), 3 = bl_shade_exact2_kernel (exact tier), 4 = bl_shade_polarized2_kernel (polarized runs),
+  int32_t fused_variant;      /* the locate step inside the coefficient kernel: 2 = bl_shade_fused2_kernel (tolerant tier),
+                                 3 = bl_shade_exact2_kernel (exact tier), 4 = bl_shade_polarized2_kernel (polarized runs),
                                  0 = a locate kernel of its own ran  */
   int64_t n_parked;           /* rays whose last steps ran with a ray per quad of lanes (bl_geodesic_quad_kernel)                 */
   int32_t composed_maps;      /* 1: the tolerant tier composed the affine transfer maps of neighbouring samples (intensities equal from
@@ -306,15 +306,11 @@ typedef struct bl_stats {
 #define BL_SWITCH_GENERAL_LOCATE (1u << 4)                  /* bl_locate_kernel where bl_locate_plain_kernel applies            */
 #define BL_SWITCH_LANE_TRANSFER (1u << 5)                   /* one lane per ray where bl_transfer_quad_kernel applies           */
 #define BL_SWITCH_NO_FUSED_LOCATE (1u << 6)                 /* a locate kernel + bl_shade_fast_kernel / bl_shade_exact_kernel   */
-#define BL_SWITCH_GENERAL_FUSED (1u << 7)                   /* bl_shade_fused_kernel where bl_shade_fused2_kernel applies       */
 #define BL_SWITCH_SAMPLE_RECORDS (1u << 8)                  /* tolerant tier: one transfer record per sample where composed maps apply */
-#define BL_SWITCH_UNPIPELINED_SHADE (1u << 9)               /* bl_shade_kernel where bl_shade_exact_kernel applies              */
-#define BL_SWITCH_QUAD_TAIL (1u << 10)                      /* = bl_set_tail_policy(BL_TAIL_QUAD): the last rays of a chunk finished by bl_geodesic_quad_kernel */
 #define BL_SWITCH_QUAD_EVERY_RAY (1u << 11)                 /* every ray parked before its first step: all stepping in bl_geodesic_quad_kernel */
-#define BL_SWITCH_TAIL_OVERLAP (1u << 12)                   /* (measured: loses) the coefficient kernel beside the last rays of a chunk (a second geodesic launch)  */
-#define BL_SWITCH_BRICK_CELLS (1u << 14)                    /* (measured: loses) bl_set_grid also stores every anchor cell's 2 x 2 x 2 stencil contiguously (8 x the cells), bl_shade_fused2_kernel gathers from it */
-#define BL_SWITCH_SPLIT_LONG (1u << 15)                     /* = bl_set_tail_policy(BL_TAIL_SPLIT), with the BLACKLIGHT_AMD_SPLIT_* knobs of the sweeps: rays predicted long (a band of impact parameters around the photon ring) stepped by bl_geodesic_quad_kernel on compute units of their own from the first moment */
-#define BL_SWITCH_TAIL_REPACKED (1u << 13)                  /* (measured: loses) the last rays of a chunk repacked into full waves by a second geodesic launch, nothing beside it */
+/* (Nine switches. Rounds 3 - 5 had eight more for experiments the measurements buried - a second pre-fused2 kernel, pre-gathered
+ * cell bricks, the coefficient kernel beside a chunk's last rays, repacked tails - and for what bl_set_tail_policy now says; their
+ * numbers are in docs/notebook.md, their code in the history.) */
 
 typedef struct bl_ctx bl_ctx;
 

@@ -2,8 +2,8 @@
 
 The quad kernel performs the operations of the ray-per-lane kernel on the same operands, spread over four lanes: positions, step
 lengths, sample counts and flags must be the same bits. BL_SWITCH_QUAD_EVERY_RAY parks every ray before its first step - the
-whole frame is stepped by the quad kernel -, BL_SWITCH_QUAD_TAIL parks the last rays of a chunk, each somewhere along its way;
-the default parks none (what the quad kernel gains and where it costs). All three must give the same frame, and the oracle's (geodesics.cpp:39-396).
+whole frame is stepped by the quad kernel -, bl_set_tail_policy(BL_TAIL_QUAD) parks the last rays of a chunk, each somewhere along
+its way; BL_TAIL_WIDE parks none (docs/notebook.md: what the quad kernel gains and where it costs). All three must give the same frame, and the oracle's (geodesics.cpp:39-396).
 """
 import numpy as np
 import pytest
@@ -14,12 +14,14 @@ pytestmark = pytest.mark.gpu
 
 
 def _three_ways(ctx, extra=()):
-    ctx.set_tail_policy("wide")   # the baseline is the ray-per-lane stepper alone (BL_TAIL_AUTO would park rays of formula frames itself)
+    # the baseline is the ray-per-lane stepper alone (BL_TAIL_AUTO would park rays of formula frames itself)
     out = {}
-    for name, switches in (("lane", ()), ("tail", ("QUAD_TAIL",)), ("quad", ("QUAD_EVERY_RAY",))):
+    for name, policy, switches in (("lane", "wide", ()), ("tail", "quad", ()), ("quad", "wide", ("QUAD_EVERY_RAY",))):
+        ctx.set_tail_policy(policy)
         ctx.debug_set_switches(*switches, *extra)
         out[name] = ctx.render()
     ctx.debug_set_switches()
+    ctx.set_tail_policy("auto")
     return out
 
 
@@ -89,7 +91,7 @@ def test_simulation_frames_through_the_quad_kernel(seed):
 
 
 def test_the_last_rays_of_a_frame_are_parked():
-    """BL_SWITCH_QUAD_TAIL: the waves of a frame that has run out of rays hand their last ones to the quad kernel"""
+    """BL_TAIL_QUAD: the waves of a frame that has run out of rays hand their last ones to the quad kernel"""
     import blacklight_amd as bl
     fx, params, _ = gu.load_case("formula_dp")
     p = bl.Params.from_dict(dict(params, camera_resolution=96))
@@ -97,73 +99,6 @@ def test_the_last_rays_of_a_frame_are_parked():
         out = _three_ways(ctx)
     _assert_same_frames(out, "exact", "formula_dp at 96^2")
     assert 0 < out["tail"]["stats"].n_parked < out["tail"]["stats"].n_rays
-
-
-# ---- the coefficient kernel beside the last rays of a chunk (BL_SWITCH_TAIL_OVERLAP; bl_render.hip: tail_overlap)
-
-def _overlap_on_off(ctx, extra=()):
-    ctx.set_tail_policy("wide")
-    out = {}
-    for name, switches in (("off", ()), ("on", ("TAIL_OVERLAP",))):
-        ctx.debug_set_switches(*switches, *extra)
-        out[name] = ctx.render()
-    ctx.debug_set_switches()
-    return out
-
-
-def _assert_overlap_equal(out, tier, what, expect_parked=True):
-    off, on = out["off"], out["on"]
-    assert off["stats"].n_parked == 0
-    if expect_parked:
-        assert 0 < on["stats"].n_parked <= on["stats"].n_rays, what
-    assert np.array_equal(on["sample_num"], off["sample_num"]) and np.array_equal(on["sample_flags"], off["sample_flags"]), what
-    assert on["stats"].n_samples == off["stats"].n_samples and on["stats"].n_gathers == off["stats"].n_gathers, what
-    assert on["stats"].n_deferred == off["stats"].n_deferred, what
-    if tier == "exact":
-        assert gu.same_bits(on["image"], off["image"]).all(), what
-    else:
-        assert np.array_equal(np.isnan(on["image"]), np.isnan(off["image"])), what
-        with np.errstate(invalid="ignore"):
-            assert np.nanmax(np.abs(on["image"] - off["image"])) <= 1.0e-13 * np.nanmax(np.abs(off["image"])), what
-
-
-@pytest.mark.parametrize("seed", range(4))
-def test_formula_frames_with_the_coefficient_kernel_beside_the_last_rays(seed):
-    import blacklight_amd as bl
-    rng = np.random.default_rng(7300 + seed)
-    fx, params, _ = gu.load_case("formula_dp")
-    over = dict(camera_resolution=int(rng.choice([48, 96])), camera_r=float(rng.uniform(60.0, 1000.0)), camera_th=float(rng.uniform(5.0, 175.0)),
-                camera_width=float(rng.uniform(12.0, 40.0)), formula_spin=float([0.0, 0.9, 0.5, 0.99][seed]),
-                ray_max_steps=int(rng.choice([2500, 7000])))
-    p = bl.Params.from_dict(dict(params, **over))
-    with bl.Context(p) as ctx:
-        for tier in ("exact", "tolerant"):
-            ctx.set_arithmetic(tier)
-            out = _overlap_on_off(ctx)
-            _assert_overlap_equal(out, tier, over)
-            assert np.isfinite(out["off"]["image"]).any(), over
-
-
-@pytest.mark.parametrize("seed", range(4))
-def test_simulation_frames_with_the_coefficient_kernel_beside_the_last_rays(seed):
-    """The benchmark's kernels (bl_shade_fused2_kernel with composed maps, bl_shade_exact2_kernel) over a range of records"""
-    import blacklight_amd as bl
-    from blacklight_amd import mock
-    rng = np.random.default_rng(7400 + seed)
-    fx, params, mock_args = gu.load_case("sim_dp_interp")
-    over = dict(camera_resolution=int(rng.choice([64, 128])), camera_r=float(rng.uniform(60.0, 300.0)), camera_th=float(rng.uniform(10.0, 170.0)),
-                camera_ph=float(rng.uniform(0.0, 360.0)), camera_width=float(rng.uniform(20.0, 60.0)), simulation_a=0.0 if seed % 2 == 0 else 0.9,
-                ray_integrator="dp", fallback_nan="false", fallback_rho=1.0e-6, fallback_pgas=1.0e-8)
-    p = bl.Params.from_dict(dict(params, **over))
-    grid = mock.generate(n_r=32, n_th=32, n_ph=32) if seed < 2 else gu.golden_grid(mock_args)
-    with bl.Context(p) as ctx:
-        ctx.set_grid(grid)
-        for tier in ("exact", "tolerant"):
-            ctx.set_arithmetic(tier)
-            out = _overlap_on_off(ctx, extra=("RECORD_EVERY_STEP",))
-            _assert_overlap_equal(out, tier, over)
-            if seed < 2:
-                assert out["on"]["stats"].fused_variant == (3 if tier == "exact" else 2), out["on"]["stats"].fused_variant
 
 
 @pytest.mark.parametrize("spin", [0.0, 0.7])

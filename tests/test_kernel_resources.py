@@ -13,32 +13,24 @@ RESOURCES = [os.path.join(bl_build.OBJ, name + ".resources.txt")
 
 # mangled name -> (waves per SIMD, largest scratch in bytes per lane)
 BENCHMARK_KERNELS = {
-    "_Z18bl_geodesic_kernelILi0ELb0ELb1ELb0ELb0EEv11BlTraceArgs": (2, 0),      # Dormand-Prince, no sample times, zero spin
-    "_Z18bl_geodesic_kernelILi0ELb0ELb0ELb0ELb0EEv11BlTraceArgs": (1, 0),      # ... any spin: one wave, accumulation registers behind it
-    "_Z18bl_geodesic_kernelILi0ELb0ELb1ELb1ELb0EEv11BlTraceArgs": (2, 0),    # ... leaving no records of the empty shell around the grid
-    "_Z18bl_geodesic_kernelILi0ELb0ELb0ELb1ELb0EEv11BlTraceArgs": (1, 0),
-    "_Z18bl_geodesic_kernelILi0ELb0ELb1ELb0ELb1EEv11BlTraceArgs": (2, 0),    # ... finishing parked rays (BL_SWITCH_TAIL_OVERLAP: a measured experiment)
-    "_Z18bl_geodesic_kernelILi0ELb0ELb0ELb0ELb1EEv11BlTraceArgs": (1, 0),
-    "_Z23bl_geodesic_quad_kernelILb1EEv11BlTraceArgs": (2, 0),             # a ray per quad of lanes (BL_SWITCH_QUAD_TAIL: a measured experiment)
+    "_Z18bl_geodesic_kernelILi0ELb0ELb1ELb0EEv11BlTraceArgs": (2, 0),      # Dormand-Prince, no sample times, zero spin
+    "_Z18bl_geodesic_kernelILi0ELb0ELb0ELb0EEv11BlTraceArgs": (1, 0),      # ... any spin: one wave, accumulation registers behind it
+    "_Z18bl_geodesic_kernelILi0ELb0ELb1ELb1EEv11BlTraceArgs": (2, 0),      # ... leaving no records of the empty shell around the grid
+    "_Z18bl_geodesic_kernelILi0ELb0ELb0ELb1EEv11BlTraceArgs": (1, 0),
+    "_Z23bl_geodesic_quad_kernelILb1EEv11BlTraceArgs": (2, 0),             # a ray per quad of lanes (BL_TAIL_QUAD, BL_TAIL_SPLIT)
     "_Z23bl_geodesic_quad_kernelILb0EEv11BlTraceArgs": (2, 0),
     "_Z16bl_locate_kernelILb0ELb0ELb1ELb0EEv11BlShadeArgs": (4, 0),          # merged grid, no slow light, zero spin (at least 4)
     "_Z16bl_locate_kernelILb0ELb0ELb0ELb0EEv11BlShadeArgs": (4, 0),
-    "_Z15bl_shade_kernelILi0ELb0ELb0ELb1ELb0ELb1ELb0EEv11BlShadeArgs": (2, 0),   # simulation, thermal electrons, SKS + curved, zero spin
-    "_Z15bl_shade_kernelILi0ELb0ELb0ELb1ELb0ELb0ELb0EEv11BlShadeArgs": (2, 0),   # ... any spin
-    "_Z15bl_shade_kernelILi0ELb0ELb0ELb0ELb0ELb0ELb0EEv11BlShadeArgs": (2, 0),   # the same for any coordinates
+    "_Z15bl_shade_kernelILi0ELb0ELb0ELb0ELb0ELb0ELb0EEv11BlShadeArgs": (2, 0),   # simulation, thermal electrons, any coordinates
     "_Z20bl_shade_fast_kernelILb1ELb0EEv11BlShadeArgs": (2, 0),              # tolerant tier, zero spin
     "_Z20bl_shade_fast_kernelILb0ELb0EEv11BlShadeArgs": (2, 0),
-    "_Z20bl_shade_fast_kernelILb1ELb1EEv11BlShadeArgs": (2, 0),              # ... power laws / Cartesian grids
-    "_Z20bl_shade_fast_kernelILb0ELb1EEv11BlShadeArgs": (2, 0),
-    "_Z22bl_shade_fused2_kernelILb1ELb1ELb0ELb0EEv11BlShadeArgs": (2, 0),        # ... the benchmark's kernel: locate step inside, composed maps
-    "_Z22bl_shade_fused2_kernelILb1ELb0ELb0ELb0EEv11BlShadeArgs": (2, 0),        # ... one record per sample
-    "_Z22bl_shade_fused2_kernelILb0ELb1ELb0ELb0EEv11BlShadeArgs": (2, 0),        # ... any spin
-    "_Z22bl_shade_fused2_kernelILb0ELb0ELb0ELb0EEv11BlShadeArgs": (2, 0),
-    "_Z22bl_shade_fused2_kernelILb1ELb0ELb0ELb1EEv11BlShadeArgs": (2, 0),        # ... several frequencies: a sample leaves as its factors
-    "_Z22bl_shade_fused2_kernelILb0ELb0ELb0ELb1EEv11BlShadeArgs": (2, 0),
-    "_Z22bl_shade_fused2_kernelILb1ELb1ELb1ELb0EEv11BlShadeArgs": (2, 0),    # ... gathering from pre-gathered bricks (BL_SWITCH_BRICK_CELLS: a measured experiment)
-    "_Z21bl_shade_fused_kernelILb1EEv11BlShadeArgs": (2, 0),                 # ... locate step inside, general grids / up to three frequencies
-    "_Z21bl_shade_fused_kernelILb0EEv11BlShadeArgs": (2, 0),
+    "_Z20bl_shade_fast_kernelILb0ELb1EEv11BlShadeArgs": (2, 0),              # ... power laws / Cartesian grids
+    "_Z22bl_shade_fused2_kernelILb1ELb1ELb0EEv11BlShadeArgs": (2, 0),        # ... the benchmark's kernel: locate step inside, composed maps
+    "_Z22bl_shade_fused2_kernelILb1ELb0ELb0EEv11BlShadeArgs": (2, 0),        # ... one record per sample
+    "_Z22bl_shade_fused2_kernelILb0ELb1ELb0EEv11BlShadeArgs": (2, 0),        # ... any spin
+    "_Z22bl_shade_fused2_kernelILb0ELb0ELb0EEv11BlShadeArgs": (2, 0),
+    "_Z22bl_shade_fused2_kernelILb1ELb0ELb1EEv11BlShadeArgs": (2, 0),        # ... several frequencies: a sample leaves as its factors
+    "_Z22bl_shade_fused2_kernelILb0ELb0ELb1EEv11BlShadeArgs": (2, 0),
     "_Z22bl_shade_exact2_kernelILb1EEv11BlShadeArgs": (2, 0),                # exact tier, locate step inside (the benchmark's exact kernel)
     "_Z22bl_shade_exact2_kernelILb0EEv11BlShadeArgs": (2, 0),
     "_Z26bl_shade_polarized2_kernelILb1ELb0EEv11BlShadeArgs": (2, 0),        # polarized runs, locate step inside, no auxiliary records

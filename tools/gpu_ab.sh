@@ -2,7 +2,7 @@
 # A/B on one GPU box, so that clock differences between boxes do not enter the comparison: bench.py once per measurement
 # switch (BLACKLIGHT_AMD_<NAME>, include/blacklight_amd.h; "-" = none) and once per library build under variants/*.so
 # (tools/build_variant.sh: the current library with one source rebuilt under extra flags).
-#   gpurun -- 'bash tools/gpu_ab.sh [steps] [switches ...]'     e.g.  bash tools/gpu_ab.sh 10 - GENERAL_FUSED SAMPLE_RECORDS
+#   gpurun -- 'bash tools/gpu_ab.sh [steps] [switches ...]'     e.g.  bash tools/gpu_ab.sh 10 - NO_FUSED_LOCATE SAMPLE_RECORDS
 #   ARITH=exact for the exact tier, ROUNDS=2 for two passes
 set -eu
 : "${GRAFT_REPO_ROOT:?run through gpurun}"

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Hardware counters of one tolerant-tier benchmark frame per kernel, once per measurement switch ("-" = none), each counter in a
 # pass of its own (rocprofv3 --pmc alone: no trace domains beside it):
-#   gpurun -- 'COUNTERS="FETCH_SIZE WRITE_SIZE TCC_HIT_sum TCC_REQ_sum" bash tools/gpu_counters_ab.sh name - BRICK_CELLS'
+#   gpurun -- 'COUNTERS="FETCH_SIZE WRITE_SIZE TCC_HIT_sum TCC_REQ_sum" bash tools/gpu_counters_ab.sh name - NO_FUSED_LOCATE'
 #   -> gpurun_out/counters_<name>.txt     (FETCH_SIZE is printed x 2-corrected as MI355X_MICROARCH.md prescribes for gfx950)
 set -eu
 : "${GRAFT_REPO_ROOT:?run through gpurun}"

@@ -52,6 +52,5 @@ PY
 }
 probe "benchmark frame" benchmark
 probe "polarized, matrices beside coefficients" polarized
-BLACKLIGHT_AMD_POLARIZED_OVERLAP=0 probe "polarized, one after the other" polarized
 cat "$OUT"
 rocm-smi --showpower --showclocks 2>/dev/null | grep -E "Power|sclk" | head -4
