@@ -7,7 +7,9 @@ Mrays/s (+ achieved HBM GB/s) for a 1024^2 camera over a 256^3 mock GRMHD snapsh
 A "step" is one complete render (camera -> geodesics -> sampling -> coefficients -> transfer ->
 image in HBM) of the 1024^2 example_simulation camera over the 256^3 mock snapshot, both synthetic
 and generated natively (blacklight_amd.mock restates the reference's generator). The grid is staged
-into HBM once, before the timed region.
+into HBM once, before the timed region. Every step integrates its geodesics (bl_set_geodesic_reuse is
+switched off here): what a series of snapshots gains from integrating them once, as the reference
+does, is `--workload series8`, a line of its own.
 
 Multi-GPU: one process per GPU over torch.distributed (nccl = RCCL). Started as the driver does
 (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`) the ranks come from the environment;
@@ -105,7 +107,117 @@ OTHER_WORKLOADS = {
                       "(simulation_sampling.cpp:1068-1321; samples at the upper edge of the file's last block use the edge cell, BL_UNDEFINED_EDGE), 1024^2 camera",
     "slowlight10": "8(f)3 slow light: a window of 10 time slices of the 256^3 mock (5.4 GB of cells resident), interpolation in time, 1024^2 camera "
                    "(simulation_sampling.cpp:296-349, :736-912)",
+    # the reference's production mode (simulation_multiple): geodesics once per series (blacklight.cpp:93-94 against the run loop :178-250)
+    "series8": "a series of 8 snapshots of the 256^3 mock (cells differ from snapshot to snapshot, geometry the same), 1024^2 benchmark camera: "
+               "frame 1 integrates the geodesics and leaves their sample records in HBM, frames 2 ... 8 shade them again (bl_set_geodesic_reuse)",
+    "series8_refined": "the same series over the two-level refined mesh of refined256: frames 2 ... 8 also keep the located samples "
+                       "(the reference's first_time sampling, radiation_integrator.cpp:693-704)",
 }
+
+
+def relative_distance(got, want):
+    """north_star's bar, per pixel: max_m |got_m - want_m| / |want_m| over finite pixels with want_m > 0, the number of pixels above
+    1e-6, and whether both frames are non-finite in the same places. Arrays of one shape (numpy)."""
+    got = np.asarray(got, dtype=np.float64).reshape(-1)
+    want = np.asarray(want, dtype=np.float64).reshape(-1)
+    use = np.isfinite(want) & np.isfinite(got) & (want > 0.0)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        rel = np.abs(got[use] - want[use]) / want[use]
+    return {"per_pixel_rel_linf": float(rel.max()) if rel.size else 0.0, "pixels_above_1e-6": int((rel > 1.0e-6).sum()),
+            "pixels_compared": int(use.sum()),
+            "same_nonfinite_and_nonpositive_pixels": bool(np.array_equal(np.isfinite(got) & (got > 0.0), np.isfinite(want) & (want > 0.0)))}
+
+
+def series_workload(args):
+    """--workload series8[_refined]: the reference's loop over snapshots (blacklight.cpp:178-250) on one GPU. Per frame: bl_set_grid of
+    the snapshot's cells (timed apart: it is the reader's side of the boundary), then bl_render into HBM (timed). One JSON line:
+    value = rays / s over frames 2 ... 8; frame 1 and the whole series beside it."""
+    import dataclasses
+    import torch
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import blacklight_amd as bl
+    from blacklight_amd import mock
+    name = args.workload
+    n_frames = 8
+    res = args.resolution
+    params = dict(WORKLOAD, camera_resolution=res, simulation_multiple=True, simulation_start=0, simulation_end=n_frames - 1)
+    base = mock.generate(n_r=args.grid, n_th=args.grid, n_ph=args.grid)
+    if name == "series8_refined":
+        import golden_util as gu
+        base = gu.refined_grid(base, block=(args.grid // 4,) * 3)
+
+    def snapshot(n):
+        # density and pressure of snapshot n (the fields a movie changes most); geometry, velocities and field lines as in snapshot 0
+        prim = base.prim.copy()
+        prim[0:2] *= np.float32(1.0 + 0.07 * n)
+        return dataclasses.replace(base, prim=prim)
+
+    device = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    n_rays = res * res
+    image = torch.zeros((1, n_rays), dtype=torch.float64, device=device)
+    sample_num = torch.zeros(n_rays, dtype=torch.int32, device=device)
+    flags = torch.zeros(n_rays, dtype=torch.uint8, device=device)
+    frames = []
+    with bl.Context(bl.Params.from_dict(params), device=0) as ctx:
+        ctx.set_arithmetic(args.arithmetic)
+        ctx.set_reproducible(args.reproducible)
+        ctx.follow_torch_stream(device)
+        for rep in range(args.warmup + 1):   # (warm-up series first: allocations, first use of the kernels; the last series is the one reported)
+            frames = []
+            ctx.set_geodesic_reuse(False)    # forget what an earlier series left
+            ctx.set_geodesic_reuse(True)
+            for n in range(n_frames):
+                grid = snapshot(n)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                ctx.set_grid(grid)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                st = ctx.render_device(image.data_ptr(), n_rays, sample_num_ptr=sample_num.data_ptr(), sample_flags_ptr=flags.data_ptr())
+                torch.cuda.synchronize()
+                t2 = time.perf_counter()
+                frames.append(dict(ms_set_grid=1000.0 * (t1 - t0), ms_render=1000.0 * (t2 - t1), geodesics_reused=int(st.geodesics_reused),
+                                   sampling_reused=int(st.sampling_reused), launches_geodesic=int(st.launches_geodesic), launches_locate=int(st.launches_locate),
+                                   kernel_ms={"geodesic": st.ms_geodesic, "locate": st.ms_locate, "shade": st.ms_shade, "transfer": st.ms_transfer},
+                                   n_gathers=int(st.n_gathers), n_samples=int(st.n_samples)))
+        last_stats = st
+        # the last frame again with its geodesics integrated afresh: the same frame?
+        reused_image, reused_num = image.clone(), sample_num.clone()
+        ctx.set_geodesic_reuse(False)
+        fresh = ctx.render_device(image.data_ptr(), n_rays, sample_num_ptr=sample_num.data_ptr(), sample_flags_ptr=flags.data_ptr())
+        torch.cuda.synchronize()
+        check = relative_distance(reused_image.cpu().numpy(), image.cpu().numpy())
+        check.update(sample_num_equal=bool((reused_num == sample_num).all().item()), bit_identical=bool(torch.equal(reused_image.view(torch.int64), image.view(torch.int64))),
+                     fresh_render_launches_geodesic=int(fresh.launches_geodesic), composed_maps=int(fresh.composed_maps))
+    later = frames[1:]
+    ms_later = sum(f["ms_render"] for f in later) / len(later)
+    ms_all = sum(f["ms_render"] for f in frames)
+    gathers = later[-1]["n_gathers"]
+    line = {
+        "metric": "Mrays/sec, frames 2 ... 8 of a series of snapshots (geodesics once per series), 1024^2 camera over 256^3 GRMHD grid",
+        "value": n_rays / (ms_later * 1.0e-3) / 1.0e6, "unit": "Mrays/s", "n_gpus": 1, "steps": len(later), "warmup": args.warmup,
+        "ms_per_step": ms_later, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": OTHER_WORKLOADS[name] + "; image rows stay in HBM; bl_set_grid of each snapshot timed apart",
+                   "arithmetic": "tolerant" if last_stats.arithmetic == 1 else "exact", "rays_per_step": n_rays,
+                   "samples_per_ray": later[-1]["n_samples"] / n_rays, "parallelism": "1 GPU", "fused_variant": int(last_stats.fused_variant)},
+        "frame_1": {"ms_render": frames[0]["ms_render"], "mrays_per_s": n_rays / (frames[0]["ms_render"] * 1.0e-3) / 1.0e6, "launches_geodesic": frames[0]["launches_geodesic"],
+                    "kernel_ms": frames[0]["kernel_ms"]},
+        "frames_2_to_8": {"ms_render_mean": ms_later, "ms_render_min": min(f["ms_render"] for f in later), "ms_render_max": max(f["ms_render"] for f in later),
+                          "all_reused_geodesics": all(f["geodesics_reused"] == 1 and f["launches_geodesic"] == 0 for f in later),
+                          "all_reused_located_samples": all(f["sampling_reused"] == 1 for f in later),
+                          "launches_locate": [f["launches_locate"] for f in later], "kernel_ms_mean": {k: sum(f["kernel_ms"][k] for f in later) / len(later) for k in later[0]["kernel_ms"]}},
+        "whole_series": {"frames": n_frames, "ms_render_total": ms_all, "mrays_per_s": n_frames * n_rays / (ms_all * 1.0e-3) / 1.0e6,
+                         "ms_set_grid_mean": sum(f["ms_set_grid"] for f in frames) / n_frames},
+        "reused_vs_fresh_last_frame": check,
+        "hbm_gbs_algorithmic_whole_pipeline": (256.0 * gathers + 13.0 * n_rays) / (ms_later * 1.0e-3) / 1.0e9,
+        "hbm_frac_algorithmic_whole_pipeline": (256.0 * gathers + 13.0 * n_rays) / (ms_later * 1.0e-3) / 1.0e9 / HBM_PEAK_GBS,
+        "switches": int(last_stats.switches),
+    }
+    shade_ms = line["frames_2_to_8"]["kernel_ms_mean"]["shade"]
+    line["roofline"] = {"bound": "hbm", "kernel": "coefficient kernel of frames 2 ... 8", "achieved": (256.0 * gathers + 13.0 * n_rays) / (shade_ms * 1.0e-3) / 1.0e9,
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (256.0 * gathers + 13.0 * n_rays) / (shade_ms * 1.0e-3) / 1.0e9 / HBM_PEAK_GBS, "traffic": None}
+    print(json.dumps(line), flush=True)
 
 
 def other_workload(args):
@@ -143,6 +255,7 @@ def other_workload(args):
             params.update(slow_light_on=True, slow_interp=True, slow_chunk_size=10, slow_t_start=180.0, slow_dt=20.0, slow_num_images=1, slow_offset=0,
                           simulation_multiple=True, simulation_start=0, simulation_end=9)
     with bl.Context(bl.Params.from_dict(params)) as ctx:
+        ctx.set_geodesic_reuse(False)   # every step a complete render: geodesics included
         if name == "slowlight10":
             for n in range(10):   # slice n: n = 0 the latest file (simulation_reader.cpp:211-303)
                 ctx.set_grid_slice(n, grid, 180.0 - 20.0 * n)
@@ -269,7 +382,7 @@ def main():
     if args.workload != "benchmark":
         if args.gpus != 1:
             raise SystemExit("bench.py --workload: the other configurations are timed on one GPU")
-        return other_workload(args)
+        return series_workload(args) if args.workload.startswith("series8") else other_workload(args)
     if args.gpus < 1:
         raise SystemExit("--gpus must be positive")
 
@@ -316,6 +429,7 @@ def main():
 
     ctx = bl.Context(params, device=local_rank)
     ctx.set_grid(grid)          # staged into HBM once, outside the timed region
+    ctx.set_geodesic_reuse(False)   # every step is a complete render: its geodesics are integrated, not taken from the step before
     ctx.set_reproducible(args.reproducible)
     if args.scratch_gib > 0.0:
         ctx.set_scratch_limit(int(args.scratch_gib * (1 << 30)))
@@ -412,6 +526,8 @@ def main():
         tier_distance = {"image_linf_over_max": float((torch.nan_to_num(diff, nan=float("inf")).max() / peak).item()),
                          "nan_mask_equal": bool((torch.isnan(image) == torch.isnan(exact_image)).all().item()),
                          "sample_num_equal": bool((sample_num == exact_num).all().item()), "pixels": int(n_rays)}
+        # ... and the way north_star words the bar: per pixel, relative to that pixel's own intensity
+        tier_distance.update(relative_distance(image[0, :n_rays].cpu().numpy(), exact_image[0, :n_rays].cpu().numpy()))
 
     rehearsal = None
     if rehearse and tiled:
@@ -446,13 +562,14 @@ def main():
         ms_per_step = 1000.0 * elapsed / args.steps
         value = total_rays / (elapsed / args.steps) / 1.0e6
         achieved = main_run["bytes_per_launch"] / (main_run["shade_ms_per_launch"] * 1.0e-3) / 1.0e9
-        traffic, traffic_source, traffic_stale = None, None, None
+        traffic, traffic_source, traffic_stale, traffic_whole = None, None, None, None
         traffic_file = os.path.join(REPO, "profiles", "hbm_traffic.json")
         if os.path.exists(traffic_file) and not distributed:
             with open(traffic_file) as f:
                 recorded = json.load(f)
             entry = recorded.get(main_run["tier_ran"], {})
             traffic = entry.get("coefficient_kernel_bytes_per_launch")
+            traffic_whole = entry.get("whole_pipeline_bytes_per_frame")
             traffic_source = entry.get("source")
             traffic_stale = recorded.get("csrc_sha256_16") != kernel_source_hash()
         tier_text = {"tolerant": "tolerant arithmetic tier (intensities within north_star's fp64 tolerance, counts / flags / cuts bit-exact)",
@@ -474,6 +591,7 @@ def main():
                                  if tiled else
                                  f"{world} GPUs, one {res}^2 frame per GPU (views at 360/N deg), grid replicated, frames gathered over RCCL")),
                 "chunks_per_step": stats.n_chunks,
+                "geodesics_integrated_per_step": int(stats.launches_geodesic),   # 1: every step integrates its rays (no reuse of an earlier step's)
                 # bit-identical images from run to run and however the frame is cut? (exact tier: always; tolerant tier: with
                 # --reproducible; otherwise equal to rounding, ~1e-15 of the maximum - bl_stats.composed_maps)
                 "bit_reproducible": not bool(stats.composed_maps),
@@ -484,10 +602,10 @@ def main():
             "hbm_gbs_algorithmic_whole_pipeline": (256.0 * total_gathers + 13.0 * total_rays) / (elapsed / args.steps) / 1.0e9,
             "hbm_frac_algorithmic_whole_pipeline": (256.0 * total_gathers + 13.0 * total_rays) / (elapsed / args.steps) / 1.0e9 / HBM_PEAK_GBS,
             # the coefficient kernel of the tier that ran: with no launch of a locate kernel it is the one that locates as well
-            "roofline": {"bound": "hbm", "kernel": (({2: "bl_shade_fused2_kernel", 1: "bl_shade_fused_kernel"}.get(stats.fused_variant, "bl_shade_fast_kernel"))
+            "roofline": {"bound": "hbm", "kernel": (("bl_shade_fused2_kernel" if stats.fused_variant == 2 else "bl_shade_fast_kernel")
                                                     if main_run["tier_ran"] == "tolerant" else ("bl_shade_exact2_kernel" if stats.fused_variant == 3 else "bl_shade_exact_kernel")),
                          "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source, "traffic_stale": traffic_stale,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_whole_pipeline": traffic_whole, "traffic_source": traffic_source, "traffic_stale": traffic_stale,
                          "algorithmic_bytes_per_launch": main_run["bytes_per_launch"], "ms_per_launch": main_run["shade_ms_per_launch"]},
         }
         if rehearsal is not None:
@@ -523,6 +641,7 @@ def main():
                 "nan_mask_equal": bool(np.array_equal(np.isnan(gpu_img), np.isnan(cpu["image"][0]))),
                 "sample_num_bit_exact": bool(np.array_equal(gpu_num, cpu["sample_num"])),
             }
+            line["parity_vs_oracle_on_sample"].update(relative_distance(gpu_img, cpu["image"][0]))
         print(json.dumps(line), flush=True)
 
     ctx.close()

@@ -75,7 +75,7 @@ class Stats(C.Structure):
         ("ms_locate", C.c_float), ("ms_wall", C.c_float), ("launches_locate", C.c_int32),
         ("arithmetic", C.c_int32), ("n_deferred", C.c_int64), ("n_undefined", C.c_int64),
         ("switches", C.c_uint32), ("fused_variant", C.c_int32), ("n_parked", C.c_int64),
-        ("composed_maps", C.c_int32), ("tail_policy", C.c_int32),
+        ("composed_maps", C.c_int32), ("tail_policy", C.c_int32), ("geodesics_reused", C.c_int32), ("sampling_reused", C.c_int32),
     ]
 
 
@@ -108,6 +108,7 @@ def lib():
     L.bl_set_arithmetic.argtypes = [C.c_void_p, C.c_int]
     L.bl_set_reproducible.argtypes = [C.c_void_p, C.c_int]
     L.bl_set_tail_policy.argtypes = [C.c_void_p, C.c_int]
+    L.bl_set_geodesic_reuse.argtypes = [C.c_void_p, C.c_int]
     L.bl_set_caller_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     L.bl_device_count.restype = C.c_int
     L.bl_set_undefined_policy.argtypes = [C.c_void_p, C.c_int]

@@ -114,6 +114,11 @@ class Context:
         """"auto" (default), "wide", "quad" or "split": who steps the rays a chunk waits for longest (bl_set_tail_policy)."""
         self._check(self._lib.bl_set_tail_policy(self._ctx, {"auto": 0, "wide": 1, "quad": 2, "split": 3}[policy]))
 
+    def set_geodesic_reuse(self, on=True):
+        """Geodesics once per series (default on): a root-level render of an unchanged camera shades the sample records the last one
+        left in HBM instead of integrating its rays again (bl_set_geodesic_reuse; stats.geodesics_reused says which way it went)."""
+        self._check(self._lib.bl_set_geodesic_reuse(self._ctx, 1 if on else 0))
+
     def set_caller_stream(self, stream=None, enabled=True):
         """Every later render starts behind the work queued so far on `stream` (a raw hipStream_t handle, e.g.
         torch.cuda.current_stream().cuda_stream; None / 0: the NULL stream) - bl_set_caller_stream."""

@@ -356,9 +356,25 @@ int bl_init(const bl_params *p, int device, bl_ctx **out) {
       if (std::getenv(sw.name) != nullptr) ctx->switches |= sw.bit;
     ctx->debug_counters = std::getenv("BLACKLIGHT_AMD_DEBUG_COUNTERS") != nullptr;
     // the arithmetic tier a context starts in: tolerant (north_star's tolerance), or what the deployment says
-    if (const char *tier = std::getenv("BLACKLIGHT_AMD_ARITHMETIC")) ctx->arithmetic = std::string(tier) == "exact" ? BL_ARITH_EXACT : BL_ARITH_TOLERANT;
+    // (exact | tolerant, in any case; anything else is an error of bl_init - a typo must not silently select a tier)
+    if (const char *tier = std::getenv("BLACKLIGHT_AMD_ARITHMETIC")) {
+      std::string name = tier;
+      for (char &c : name) c = static_cast<char>(std::tolower(static_cast<unsigned char>(c)));
+      if (name == "exact") ctx->arithmetic = BL_ARITH_EXACT;
+      else if (name == "tolerant") ctx->arithmetic = BL_ARITH_TOLERANT;
+      else {
+        g_global_error = "Error: BLACKLIGHT_AMD_ARITHMETIC must be exact or tolerant, not \"" + std::string(tier) + "\".\n";
+        delete ctx;
+        return BL_E_INPUT;
+      }
+    }
     if (const char *policy = std::getenv("BLACKLIGHT_AMD_TAIL_POLICY")) {   // (A/B runs: bl_set_tail_policy from the environment)
       const std::string name = policy;
+      if (name != "auto" && name != "wide" && name != "quad" && name != "split") {
+        g_global_error = "Error: BLACKLIGHT_AMD_TAIL_POLICY must be auto, wide, quad or split, not \"" + name + "\".\n";
+        delete ctx;
+        return BL_E_INPUT;
+      }
       ctx->tail_policy = name == "wide" ? BL_TAIL_WIDE : (name == "quad" ? BL_TAIL_QUAD : (name == "split" ? BL_TAIL_SPLIT : BL_TAIL_AUTO));
     }
   }
@@ -751,6 +767,44 @@ void UploadRefinedGrid(bl_ctx *ctx, const bl_grid_desc *g) {
 }
 }  // namespace
 
+namespace {
+// Hash (FNV-1a, 64 bits) of everything about a grid that decides WHERE a sample lies on it: the block table, the coordinate arrays,
+// the FMKS look-up table. Two bl_set_grid calls with the same hash hand over the same geometry (the cells may differ): located
+// samples of the first stay valid for the second (the reference's `first_time`, radiation_integrator.cpp:693-704).
+unsigned long long GridGeometryHash(const bl_grid_desc *g) {
+  unsigned long long h = 1469598103934665603ull;
+  auto mix = [&h](const void *data, size_t bytes) {
+    const unsigned char *p = static_cast<const unsigned char *>(data);
+    // (eight bytes a step where they are there: coordinate arrays are doubles)
+    size_t at = 0;
+    for (; at + 8 <= bytes; at += 8) {
+      unsigned long long word;
+      std::memcpy(&word, p + at, 8);
+      h = (h ^ word) * 1099511628211ull;
+      h ^= h >> 29;
+    }
+    for (; at < bytes; at++) h = (h ^ p[at]) * 1099511628211ull;
+  };
+  const int32_t dims[5] = {g->n_blocks, g->n_i, g->n_j, g->n_k, g->n_3_root};
+  mix(dims, sizeof dims);
+  const size_t n_b = static_cast<size_t>(g->n_blocks);
+  mix(g->x1f, n_b * (g->n_i + 1) * sizeof(double)); mix(g->x1v, n_b * g->n_i * sizeof(double));
+  mix(g->x2f, n_b * (g->n_j + 1) * sizeof(double)); mix(g->x2v, n_b * g->n_j * sizeof(double));
+  mix(g->x3f, n_b * (g->n_k + 1) * sizeof(double)); mix(g->x3v, n_b * g->n_k * sizeof(double));
+  if (g->levels != nullptr) mix(g->levels, n_b * sizeof(int32_t));
+  if (g->locations != nullptr) mix(g->locations, n_b * 3 * sizeof(int32_t));
+  if (g->sks_map != nullptr) {
+    const int32_t map_dims[2] = {g->sks_map_n1, g->sks_map_n2};
+    mix(map_dims, sizeof map_dims);
+    mix(g->sks_map, 2 * static_cast<size_t>(g->sks_map_n1) * g->sks_map_n2 * sizeof(double));
+    const double scalars[3] = {g->sks_map_r_in, g->sks_map_dr, g->sks_map_dtheta};
+    mix(scalars, sizeof scalars);
+    mix(g->simulation_bounds, sizeof g->simulation_bounds);
+  }
+  return h != 0 ? h : 1;
+}
+}  // namespace
+
 int bl_set_grid(bl_ctx *ctx, const bl_grid_desc *g) {
   if (ctx == nullptr || g == nullptr) return BL_E_ARG;
   try {
@@ -762,6 +816,7 @@ int bl_set_grid(bl_ctx *ctx, const bl_grid_desc *g) {
     if (g->n_i < 2 || g->n_j < 2 || g->n_k < 2 || g->prim == nullptr) throw Failure{BL_E_ARG, "Bad grid description."};
     Check(hipSetDevice(ctx->device), "hipSetDevice");
     ctx->have_grid = false;   // a failed upload leaves no grid behind (the previous one may be half overwritten)
+    ctx->grid_geometry = 0;
     if (ctx->params.simulation_interp && ctx->params.simulation_block_interp) {
       UploadRefinedGrid(ctx, g);   // inter-block interpolation works on the MeshBlocks as they are
     } else {
@@ -773,6 +828,7 @@ int bl_set_grid(bl_ctx *ctx, const bl_grid_desc *g) {
       }
     }
     ctx->grid_meta = *g;
+    if (ctx->cells_target == nullptr) ctx->grid_geometry = GridGeometryHash(g);   // (slow light locates per snapshot: no located samples are kept)
     ctx->grid_outer_x1 = g->x1f[g->n_i];
     for (int blk = 1; blk < g->n_blocks; blk++)
       ctx->grid_outer_x1 = std::max(ctx->grid_outer_x1, g->x1f[static_cast<size_t>(blk) * (g->n_i + 1) + g->n_i]);
@@ -835,6 +891,17 @@ int bl_camera_frame_get(const bl_ctx *ctx, bl_camera_frame *out) {
 int bl_frequencies(const bl_ctx *ctx, double *out, int n) {
   if (ctx == nullptr || out == nullptr) return BL_E_ARG;
   for (int l = 0; l < n && l < static_cast<int>(ctx->frequencies.size()); l++) out[l] = ctx->frequencies[l];
+  return BL_OK;
+}
+
+int bl_set_geodesic_reuse(bl_ctx *ctx, int on) {
+  if (ctx == nullptr) return BL_E_ARG;
+  ctx->geodesic_reuse = on ? 1 : 0;
+  if (!on && ctx->device != BL_DEVICE_NONE) {   // what was kept goes back to the device
+    (void)hipSetDevice(ctx->device);
+    ctx->resident.valid = ctx->resident.located_valid = false;
+    ctx->resident.store.Free();
+  }
   return BL_OK;
 }
 

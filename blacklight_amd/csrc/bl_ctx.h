@@ -226,6 +226,43 @@ struct bl_ctx {
     }
   };
   ChunkSlot slot[2];
+  // bl_set_geodesic_reuse: the root level's geodesics as its last render left them. The buffers are the ones scratch set 0 and the
+  // per-ray arrays below point at (`parked` false) or, while a render of another level works there, set aside in `store`
+  // (`parked` true: that render allocates its own, which are set aside in turn when the root level comes back - two sets of
+  // buffers that change places, no copy).
+  struct ResidentGeodesics {
+    bool valid = false, parked = false;
+    bool located_valid = false;               // ... and d_located / d_located_tag / d_anchors hold the samples as located on `geometry`
+    std::vector<unsigned char> key;           // everything the records depend on (bl_render.hip: GeodesicKey)
+    std::vector<unsigned char> located_key;   // ... and the located samples besides (LocatedKey)
+    size_t record_capacity = 0;
+    int tail_policy = BL_TAIL_WIDE;
+    unsigned long long n_parked = 0, n_flagged = 0;
+    unsigned long long counters[BL_CNT_TOTAL] = {};   // scratch set 0's counters as the geodesic (and locate) stage left them
+    struct Buffers {
+      DeviceBuffer<BlSampleHot> records_hot;
+      DeviceBuffer<BlSampleCold> records_cold;
+      DeviceBuffer<double> sample_t;
+      DeviceBuffer<BlLocated> located;
+      DeviceBuffer<unsigned long long> located_tag;
+      DeviceBuffer<unsigned int> anchors;
+      DeviceBuffer<double> ray_kt, ray_factor;
+      DeviceBuffer<int> ray_sample_num, ray_skipped, ray_rows;
+      DeviceBuffer<unsigned char> ray_flags;
+      DeviceBuffer<long long> ray_out_index, ray_offset;
+      uint64_t Bytes() const {
+        return records_hot.count * sizeof(BlSampleHot) + records_cold.count * sizeof(BlSampleCold) + sample_t.count * sizeof(double) + located.count * sizeof(BlLocated)
+            + located_tag.count * sizeof(unsigned long long) + anchors.count * sizeof(unsigned int) + (ray_kt.count + ray_factor.count) * sizeof(double)
+            + (ray_sample_num.count + ray_skipped.count + ray_rows.count) * sizeof(int) + ray_flags.count + (ray_out_index.count + ray_offset.count) * sizeof(long long);
+      }
+      void Free() {
+        records_hot.Free(); records_cold.Free(); sample_t.Free(); located.Free(); located_tag.Free(); anchors.Free(); ray_kt.Free(); ray_factor.Free();
+        ray_sample_num.Free(); ray_skipped.Free(); ray_rows.Free(); ray_flags.Free(); ray_out_index.Free(); ray_offset.Free();
+      }
+    } store;
+  } resident;
+  int geodesic_reuse = 1;             // bl_set_geodesic_reuse()
+  unsigned long long grid_geometry = 0;   // hash of the grid's geometry as bl_set_grid last saw it (block table, coordinates, look-up tables)
   // per ray of a bl_render call (indexed by traversal position; a chunk's kernels get pointers to its first ray)
   DeviceBuffer<double> d_ray_kt, d_ray_factor;
   DeviceBuffer<double> d_ray_start;              // BL_RAY_START_FIELDS rows: start state of every ray (bl_ray_init_kernel -> geodesic kernel)

@@ -736,6 +736,7 @@ __global__ void __launch_bounds__(256) bl_split_long_kernel(BlTraceArgs P) {
   const double scale = P.st.bh_m * P.cam.camera_width;
   const double b = blm_sqrt(u_ind * u_ind + v_ind * v_ind) * scale;
   if (!(b >= P.split_b_lo && b <= P.split_b_hi)) return;
+  if (P.ray_start[q + 8 * P.ray_start_stride] < 0.0) return;   // (marked already: a ray is parked once)
   const long long at = (long long)atomicAdd(&P.counters[BL_CNT_PARKED], 1ull);
   if (at >= (long long)P.park_capacity) return;   // (the buffer holds every ray of the chunk: bl_render.hip)
   double *start = P.ray_start + q;

@@ -174,6 +174,10 @@ int main(int argc, char *argv[]) {
       const int policy = (chosen.find("edge") != std::string::npos ? BL_UNDEFINED_EDGE : 0) | (chosen.find("kappa") != std::string::npos ? BL_UNDEFINED_KAPPA : 0);
       bl_set_undefined_policy(contexts[dev], policy);
     }
+    // Adaptive runs decide where to refine from the intensities (radiation_adaptive.cpp:19-312): they are rendered bit-reproducibly
+    // in either tier (one transfer record per sample, 1.5 % of a frame), so that two runs of one input take the same decisions -
+    // as the reference's do across thread counts. And so are runs over several devices: a frame and its tiles are then the same bits.
+    if (params.adaptive_max_level > 0 || n_devices > 1) bl_set_reproducible(contexts[dev], 1);
   }
   bl_ctx *ctx = contexts[0];
   const bool simulation = params.model_type == BL_MODEL_SIMULATION;
@@ -425,6 +429,8 @@ int main(int argc, char *argv[]) {
       return 1;
     }
   }
+  bl_stats last_stats{};
+  bl_get_stats(contexts[0], &last_stats);   // (of the last root-level... of the last render of the first device: the tier is the context's)
   for (bl_ctx *c : contexts) bl_free(c);
 
   double time_full = Now() - time_start;   // blacklight.cpp:259-269
@@ -437,5 +443,10 @@ int main(int argc, char *argv[]) {
   std::cout << "\n  Integrating image:     " << time_image << " s";
   std::cout << "\n  Rendering:             " << time_render << " s";
   std::cout << "\n\n";
+  // (one line more than the reference prints: which arithmetic produced the file. The exact tier's images are the reference's bits -
+  // with the pinned math library -, the tolerant tier's lie within north_star's fp64 tolerance of them.)
+  std::cout << "blacklight_amd: " << (last_stats.arithmetic == BL_ARITH_TOLERANT ? "tolerant" : "exact") << " arithmetic tier"
+            << (last_stats.arithmetic == BL_ARITH_TOLERANT ? (last_stats.composed_maps ? ", composed transfer maps (equal from run to run to rounding)" : ", bit-reproducible") : "")
+            << (last_stats.geodesics_reused ? "; geodesics integrated once for the series" : "") << " (BLACKLIGHT_AMD_ARITHMETIC=exact|tolerant)\n";
   return 0;
 }

@@ -1017,13 +1017,9 @@ __global__ void __launch_bounds__(64, 2) bl_transfer_polarized_matrix_kernel(BlT
       ss_start[3] = m4.y * ss_end[3];
       const double delta_lambda_cgs = delta_lambda * P.x_unit / (freq * momentum_factor);
       ss_end[0] = ss_end[1] = ss_end[2] = ss_end[3] = 0.0;
-#ifdef BL_TPS_NOCOUPLE
-      for (int a = 0; a < 4; a++) ss_end[a] = ss_start[a] + c.j_s[a] * delta_lambda_cgs + c.alpha_s[a] + c.rho_s[a];
-#else
       couple_sample<CouplingMathTolerant>(&c, P.rotation_split != 0, delta_lambda_cgs, ss_start, ss_end);
       tau += c.delta_tau;   // unpolarized.cpp:139-140 (BlAuxImages::polarized_rows_only: written below)
     }
-#endif
     const double nu_cu = freq * freq * freq;
     img[(size_t)(4 * l + 0) * row] = (m_cam[0] * ss_end[0] + m_cam[1] * ss_end[1] + m_cam[2] * ss_end[2]) * nu_cu;
     img[(size_t)(4 * l + 1) * row] = (m_cam[3] * ss_end[0] + m_cam[4] * ss_end[1] + m_cam[5] * ss_end[2]) * nu_cu;

@@ -142,6 +142,9 @@ struct CheckpointSave {
   std::vector<size_t> offset;
 };
 
+struct SplitIncomplete {};   // BL_TAIL_SPLIT: the chunk ended before its last ray (RunChunks)
+struct ReuseImpossible {};   // scratch for a render over the resident records could not be allocated beside them (EnsureScratch)
+
 // Everything one bl_render call decides before its first kernel, and what its chunks add up to
 struct RenderJob {
   bl_ctx *ctx = nullptr;
@@ -161,6 +164,12 @@ struct RenderJob {
   bool locate_inside = false; // fused2 || exact_fused || pol_fused: no locate kernel, no located samples in HBM
   bool park = false;          // BL_TAIL_QUAD: the last rays of a chunk go to bl_geodesic_quad_kernel (BlTraceArgs::parked)
   bool split_long = false;    // BL_TAIL_SPLIT: rays predicted long on compute units of their own (bl_split_long_kernel)
+  bool allow_split = true;    // false: the call is being rendered again after its split chunk closed the reservation gate early
+  bool allow_reuse = true;    // false: ... after memory for a render over the resident records could not be had
+  bool keepable = false;      // root level, geodesics integrated here: what this render leaves may serve the next (bl_set_geodesic_reuse)
+  bool reuse = false;         // the resident records of an earlier render of this camera are shaded again: no geodesic stage
+  bool reuse_located = false; // ... and its located samples: no locate kernel
+  std::vector<unsigned char> geo_key, located_key;
   int split_cus = 0;          // ... how many compute units
   double split_b_lo = 0.0, split_b_hi = 0.0;   // ... and which impact parameters
   size_t park_capacity = 0;
@@ -347,7 +356,7 @@ void PlanJob(RenderJob &job) {
   // the whole - and the critical curve is the circle b = 3 sqrt(3) M: no spin)
   const bool split_auto = ctx->tail_policy == BL_TAIL_AUTO && !ctx->split_unavailable && ctx->st.bh_a == 0.0 && !p.ray_flat
       && job.n_rays >= 32768 && job.n_rays <= 8ll * 256 * ctx->num_cus;
-  job.split_long = parkable && !job.park && (split_forced || split_auto) && p.camera_type == BL_CAMERA_PLANE && d->level == 0;
+  job.split_long = job.allow_split && parkable && !job.park && (split_forced || split_auto) && p.camera_type == BL_CAMERA_PLANE && d->level == 0;
   // ... and in the exact coefficient kernel (plain images): the frequency loop as lanes of bl_coefficients_freq_kernel
   job.coef_split = !job.fast && job.simulation && !job.aux && !ctx->polarized && job.n_nu >= 4;
   // (polarized runs list the samples without coefficients there - cut samples, cut cells - which are many more)
@@ -361,6 +370,136 @@ void PlanJob(RenderJob &job) {
   const BlAuxImages &AI = ctx->aux_images;
   job.rows_only = ctx->polarized && ctx->render_num_images == 0 && !fill_present && !(AI.image_time || AI.image_length || AI.image_lambda
       || AI.image_emission || AI.image_lambda_ave || AI.image_emission_ave || AI.image_tau_int || AI.image_crossings);
+}
+
+// ---- geodesics once per series (bl_set_geodesic_reuse; reference: blacklight.cpp:93-94 against its run loop :178-250, and the
+// `first_time` sampling of radiation_integrator.cpp:693-704)
+struct KeyWriter {
+  std::vector<unsigned char> *out;
+  template <typename T>
+  void Put(const T &value) {
+    const unsigned char *p = reinterpret_cast<const unsigned char *>(&value);
+    out->insert(out->end(), p, p + sizeof(T));
+  }
+};
+
+unsigned long long HashWords(const int32_t *data, size_t count) {
+  unsigned long long h = 1469598103934665603ull;
+  size_t at = 0;
+  for (; at + 2 <= count; at += 2) {
+    unsigned long long word;
+    std::memcpy(&word, data + at, 8);
+    h = (h ^ word) * 1099511628211ull;
+    h ^= h >> 29;
+  }
+  if (at < count) h = (h ^ static_cast<unsigned int>(data[at])) * 1099511628211ull;
+  return h;
+}
+
+// Everything the sample records of a root-level render and their layout depend on, value by value (no struct padding): two
+// renders with equal keys would write the same records. The located samples depend on the grid's geometry and the locate
+// step's settings besides.
+void BuildReuseKeys(RenderJob &job) {
+  bl_ctx *ctx = job.ctx;
+  const bl_render_desc *d = job.d;
+  const bl_params &p = ctx->params;
+  job.geo_key.clear();
+  KeyWriter key{&job.geo_key};
+  key.Put(ctx->st.bh_m); key.Put(ctx->st.bh_a); key.Put(ctx->st.ray_flat);
+  const bl_camera_frame &f = ctx->frame;
+  for (const double (*v)[4] : {&f.cam_x, &f.u_con, &f.u_cov, &f.norm_con, &f.norm_con_c, &f.hor_con_c, &f.vert_con_c})
+    for (int mu = 0; mu < 4; mu++) key.Put((*v)[mu]);
+  key.Put(f.r_horizon); key.Put(f.r_terminate);
+  key.Put(p.camera_type); key.Put(p.camera_width); key.Put(p.camera_r); key.Put(p.camera_resolution); key.Put(p.image_normalization);
+  key.Put(p.ray_integrator); key.Put(p.ray_step); key.Put(p.ray_tol_abs); key.Put(p.ray_tol_rel); key.Put(p.ray_max_steps); key.Put(p.ray_max_retries);
+  key.Put(d->level); key.Put(d->n_rays);
+  const unsigned long long map_hash = d->pixel_map != nullptr ? HashWords(d->pixel_map, static_cast<size_t>(d->n_rays)) : 0ull;
+  key.Put(d->pixel_map != nullptr ? 1 : 0); key.Put(map_hash);
+  // the layout of the records and what the stepper leaves out of them
+  key.Put(job.need_time ? 1 : 0); key.Put(job.interleaved ? 1 : 0); key.Put(job.composed ? 1 : 0); key.Put(job.skip_shell ? 1 : 0);
+  key.Put(job.skip_shell ? ctx->grid_outer_x1 : 0.0);
+  // who steps which rays (the records' order; bl_stats says it)
+  key.Put(ctx->tail_policy); key.Put(ctx->switches); key.Put(ctx->overlap_chunks); key.Put(ctx->num_cus);
+  job.located_key = job.geo_key;
+  KeyWriter located{&job.located_key};
+  located.Put(ctx->grid_geometry); located.Put(ctx->undefined_policy); located.Put(job.fast ? 1 : 0); located.Put(job.block_interp ? 1 : 0);
+  located.Put(ctx->guard_band); located.Put(p.simulation_interp); located.Put(p.simulation_coord);
+}
+
+// The root level's buffers and the other levels' change places (bl_ctx::ResidentGeodesics)
+void SwapResidentBuffers(bl_ctx *ctx) {
+  bl_ctx::ResidentGeodesics::Buffers &st = ctx->resident.store;
+  bl_ctx::ChunkSlot &sl = ctx->slot[0];
+  std::swap(st.records_hot, sl.d_records_hot);
+  std::swap(st.records_cold, sl.d_records_cold);
+  std::swap(st.sample_t, sl.d_sample_t);
+  std::swap(st.located, sl.d_located);
+  std::swap(st.located_tag, sl.d_located_tag);
+  std::swap(st.anchors, sl.d_anchors);
+  std::swap(st.ray_kt, ctx->d_ray_kt);
+  std::swap(st.ray_factor, ctx->d_ray_factor);
+  std::swap(st.ray_sample_num, ctx->d_ray_sample_num);
+  std::swap(st.ray_skipped, ctx->d_ray_skipped);
+  std::swap(st.ray_rows, ctx->d_ray_rows);
+  std::swap(st.ray_flags, ctx->d_ray_flags);
+  std::swap(st.ray_out_index, ctx->d_ray_out_index);
+  std::swap(st.ray_offset, ctx->d_ray_offset);
+  ctx->resident.parked = !ctx->resident.parked;
+}
+
+void DropResident(bl_ctx *ctx) {
+  bl_ctx::ResidentGeodesics &res = ctx->resident;
+  if (res.valid && res.parked) {   // the buffers set aside are the root level's: back to the device
+    res.store.Free();
+    res.parked = false;
+  }
+  res.valid = res.located_valid = false;
+}
+
+// Which way this render goes: over the resident records (a root-level render of the same camera left them), or integrating its
+// own - in scratch set 0 as ever, with the resident records of the root level, if any, set aside first
+void DecideReuse(RenderJob &job) {
+  bl_ctx *ctx = job.ctx;
+  bl_ctx::ResidentGeodesics &res = ctx->resident;
+  job.keepable = ctx->geodesic_reuse != 0 && job.d->level == 0 && !job.geo_load;
+  if (job.keepable) BuildReuseKeys(job);
+  job.reuse = job.keepable && job.allow_reuse && res.valid && res.key == job.geo_key;
+  if (job.reuse) {
+    if (res.parked) SwapResidentBuffers(ctx);
+    job.reuse_located = job.simulation && !job.locate_inside && !job.slow && res.located_valid && res.located_key == job.located_key;
+    job.geo_save = false;   // (the render that integrated them wrote the file: geodesic_checkpoint.cpp is called once per run of the program)
+  } else if (res.valid) {
+    if (job.keepable) DropResident(ctx);            // another camera: this render's records take their place
+    else if (!res.parked) SwapResidentBuffers(ctx);   // another level: it works in buffers of its own
+  }
+}
+
+// After a render that integrated the root level's geodesics in one chunk: what it left is the resident set
+void KeepResident(RenderJob &job) {
+  bl_ctx *ctx = job.ctx;
+  bl_ctx::ResidentGeodesics &res = ctx->resident;
+  const bool located_here = job.simulation && !job.locate_inside && !job.slow;
+  const unsigned long long *hc = ctx->host_counters;   // scratch set 0's, as CollectChunk read them
+  if (job.keepable && !job.reuse) {
+    res.valid = false;
+    if (job.n_chunks != 1 || job.n_slots != 1) return;   // (the chunks overwrote one another's records: recomputed next time)
+    res.valid = true;
+    res.parked = false;
+    res.key = job.geo_key;
+    res.record_capacity = job.record_capacity;
+    res.tail_policy = job.park ? BL_TAIL_QUAD : (job.split_long ? BL_TAIL_SPLIT : BL_TAIL_WIDE);
+    res.n_parked = job.total_parked;
+    res.n_flagged = job.total_flagged;
+    std::memcpy(res.counters, hc, sizeof res.counters);
+  } else if (!(job.reuse && located_here && !job.reuse_located)) {
+    return;
+  }
+  // (here: a render that integrated the geodesics, or one that located the resident samples on a new geometry)
+  res.located_valid = located_here;
+  res.located_key = job.located_key;
+  for (int c : {BL_CNT_GATHERS, BL_CNT_UNDEFINED, BL_CNT_INTERP_FAILED}) res.counters[c] = located_here ? hc[c] : 0ull;
+  res.counters[BL_CNT_REDO] = 0ull;
+  for (int c = BL_CNT_COUNT; c < BL_CNT_COUNT + 12; c++) res.counters[c] = 0ull;   // the transfer kernel's statistics, debug counters
 }
 
 // ---- scratch: what a sample record costs, how many fit, how many persistent waves trace rays into them
@@ -379,6 +518,17 @@ void PlanScratch(RenderJob &job) {
       + (job.coef_split ? sizeof(BlCoefInputs) : 0)
       + (job.matrix_transport ? BL_POL_MATRIX_DOUBLES * sizeof(double) : 0)
       + (job.block_interp ? 8 * sizeof(unsigned int) : 0);
+  if (job.reuse) {
+    // over the resident records: the scratch set as the render that integrated them sized it, no stepper, nothing parked
+    job.n_slots = 1;
+    job.record_capacity = ctx->resident.record_capacity;
+    job.record_gate = static_cast<long long>(job.record_capacity);
+    job.geo_grid = 1;
+    job.park = job.split_long = false;
+    job.park_capacity = 0;
+    job.quad_grid = 0;
+    return;
+  }
   const uint64_t per_slot_fixed = ((job.fast || job.fast_formula || ctx->polarized) ? job.redo_capacity * sizeof(unsigned long long) : 0) + BL_CNT_TOTAL * sizeof(unsigned long long);
   const bool park_every_ray = job.park && (ctx->switches & BL_SWITCH_QUAD_EVERY_RAY) != 0;
   const uint64_t per_ray = (2 + (job.geo_load ? 0 : BL_RAY_START_FIELDS) + (park_every_ray ? BL_PARK_DOUBLES : 0)) * sizeof(double) + (job.skip_shell ? 2 : 1) * sizeof(int) + 1 + 2 * sizeof(long long);
@@ -388,6 +538,7 @@ void PlanScratch(RenderJob &job) {
   {
     size_t free_bytes = 0, total_bytes = 0;
     if (hipMemGetInfo(&free_bytes, &total_bytes) == hipSuccess) {
+      // (the root level's resident records, set aside, are not this render's to use: they stay out of the budget)
       const uint64_t held = ctx->slot[0].Bytes() + ctx->slot[1].Bytes() + ctx->RayBytes();
       const uint64_t available = static_cast<uint64_t>(0.9 * static_cast<double>(free_bytes + held));
       if (available < budget) budget = available;
@@ -489,6 +640,8 @@ void EnsureScratch(RenderJob &job) {
     EnsureScratchOnce(job);
   } catch (const Failure &) {
     (void)hipGetLastError();
+    if (job.reuse) throw ReuseImpossible{};   // (scratch set 0 holds the resident records: the call is planned again without them)
+    DropResident(job.ctx);                    // (... set aside: they make room)
     job.ctx->slot[0].Free();
     job.ctx->slot[1].Free();
     EnsureScratchOnce(job);
@@ -934,9 +1087,10 @@ void BuildShadeArgs(RenderJob &job) {
   // (uploaded when it differs from what the device holds: a frame loop uploads it once and waits for nothing here)
   if (ctx->shade_cold_host.size() != sizeof(BlShadeCold) || std::memcmp(ctx->shade_cold_host.data(), &cold, sizeof(BlShadeCold)) != 0) {
     ctx->d_shade_cold.Ensure(1);
-    ctx->shade_cold_host.assign(reinterpret_cast<const unsigned char *>(&cold), reinterpret_cast<const unsigned char *>(&cold) + sizeof(BlShadeCold));
-    Check(hipMemcpyAsync(ctx->d_shade_cold.ptr, ctx->shade_cold_host.data(), sizeof(BlShadeCold), hipMemcpyHostToDevice, stream), "shade parameter upload");
+    ctx->shade_cold_host.clear();   // (what the device holds is unknown until the copy has completed)
+    Check(hipMemcpyAsync(ctx->d_shade_cold.ptr, &cold, sizeof(BlShadeCold), hipMemcpyHostToDevice, stream), "shade parameter upload");
     Check(hipStreamSynchronize(stream), "shade parameter upload");
+    ctx->shade_cold_host.assign(reinterpret_cast<const unsigned char *>(&cold), reinterpret_cast<const unsigned char *>(&cold) + sizeof(BlShadeCold));
   }
   sa.cold = ctx->d_shade_cold.ptr;
   sa.frequencies = ctx->d_freq.ptr;
@@ -1484,7 +1638,7 @@ void LaunchShadingStage(RenderJob &job, int k, bool geodesic_beside, hipStream_t
   };
   Check(hipStreamWaitEvent(stream, e[1], 0), "stream wait");
   Check(hipEventRecord(e[2], stream), "event");
-  if (job.simulation && !job.locate_inside)
+  if (job.simulation && !job.locate_inside && !job.reuse_located)
     Check(bl_launch_locate(&sa, geodesic_beside ? job.locate_grid_shared : job.locate_grid_alone, ctx->lds_table_bytes, stream), "locate kernel launch");
   Check(hipEventRecord(e[3], stream), "event");
   coefficient_kernel();
@@ -1590,6 +1744,35 @@ void RunChunks(RenderJob &job) {
   hipEvent_t ev_begin = ctx->events[2 * kEventsPerChunk], ev_end = ctx->events[2 * kEventsPerChunk + 1];
   Check(hipEventRecord(ev_begin, stream), "event");                // the uploads above were queued on `stream`
   if (stream_geo != stream) Check(hipStreamWaitEvent(stream_geo, ev_begin, 0), "stream wait");
+  if (job.reuse) {
+    // Shade the resident records again: the per-ray rows and the records are where the stepper left them; the counters go back to
+    // what they were when it ended (and when the locate kernel ended, if its samples are kept too). The caller's camera_pos /
+    // camera_dir - a pure function of the pixel - are written again by the kernel that wrote them then.
+    bl_ctx::ChunkSlot &sl = ctx->slot[0];
+    hipEvent_t *e = SlotEvents(job, 0);
+    BindChunk(job, 0, 0, static_cast<int>(job.n_rays));
+    if (job.cam_pos != nullptr || job.cam_dir != nullptr) Check(bl_launch_ray_init(&job.ta, ctx->params.ray_integrator, stream), "ray start kernel launch");
+    unsigned long long *staged = ctx->host_counters + BL_CNT_TOTAL;   // (pinned; the second set's half: a reuse render has one set)
+    std::memcpy(staged, ctx->resident.counters, BL_CNT_TOTAL * sizeof(unsigned long long));
+    if (!job.reuse_located)
+      for (int c : {BL_CNT_GATHERS, BL_CNT_UNDEFINED, BL_CNT_INTERP_FAILED}) staged[c] = 0ull;
+    Check(hipMemcpyAsync(sl.d_counters.ptr, staged, BL_CNT_TOTAL * sizeof(unsigned long long), hipMemcpyHostToDevice, stream), "counter upload");
+    Check(hipEventRecord(e[0], stream), "event");
+    Check(hipEventRecord(e[1], stream), "event");
+    job.in_flight[0].busy = true;
+    job.in_flight[0].begin = 0;
+    job.in_flight[0].rays = static_cast<int>(job.n_rays);
+    job.in_flight[0].done = job.n_rays;
+    LaunchShadingStage(job, 0, false, stream);
+    if (job.sample_save) {
+      Check(hipStreamSynchronize(stream), "kernel execution");
+      SaveChunkSampling(job, 0, 0, static_cast<int>(job.n_rays));
+    }
+    CollectChunk(job, 0);
+    Check(hipEventRecord(ev_end, stream), "event");
+    Check(hipStreamSynchronize(stream), "kernel execution");
+    return;
+  }
   if (!job.geo_load) {
     // start states of every ray of the call, once (bl_ray_init_kernel; the geodesic kernel of each chunk reads its share)
     BindChunk(job, 0, 0, static_cast<int>(job.n_rays));
@@ -1623,6 +1806,10 @@ void RunChunks(RenderJob &job) {
       done = job.in_flight[k].done;
     }
     if (done <= 0) throw no_progress();
+    // (the split is planned for calls one chunk is sure to take - PlanScratch - but the band's reservations are counted twice for a
+    // moment, and a frame whose rays all use every step they may can see the gate close on that: the marked rays of a second chunk
+    // would be lost. Rendered again with one stepper instead.)
+    if (job.split_long && done < rays) throw SplitIncomplete{};
     begin += done;
   }
   const int oldest = job.n_chunks % job.n_slots;   // chunks are collected in order: the next one to collect sits on this set
@@ -1653,8 +1840,10 @@ void FinishStats(RenderJob &job) {
   bl_stats st{};
   st.n_rays = job.n_rays;
   st.n_chunks = job.n_chunks;
-  st.launches_geodesic = job.n_chunks;
-  st.launches_locate = (job.simulation && !job.locate_inside) ? job.n_chunks : 0;
+  st.launches_geodesic = job.reuse ? 0 : job.n_chunks;
+  st.launches_locate = (job.simulation && !job.locate_inside && !job.reuse_located) ? job.n_chunks : 0;
+  st.geodesics_reused = job.reuse ? 1 : 0;
+  st.sampling_reused = job.reuse_located ? 1 : 0;
   st.launches_shade = job.n_chunks;
   st.launches_transfer = job.n_chunks;
   st.n_samples = static_cast<int64_t>(job.total_samples);
@@ -1664,7 +1853,7 @@ void FinishStats(RenderJob &job) {
   st.max_sample_num = static_cast<int32_t>(job.max_num);
   const double bytes_per_gather = (job.simulation && !p.simulation_interp) ? 32.0 : 256.0;
   st.algorithmic_bytes = bytes_per_gather * static_cast<double>(job.total_gathers) + 13.0 * static_cast<double>(job.n_rays);
-  st.ms_geodesic = job.geo_load ? 0.0f : job.ms_geo;   // nothing was integrated
+  st.ms_geodesic = (job.geo_load || job.reuse) ? 0.0f : job.ms_geo;   // nothing was integrated
   st.ms_locate = job.ms_locate;
   st.ms_shade = job.ms_shade;
   st.ms_transfer = job.ms_transfer;
@@ -1677,16 +1866,16 @@ void FinishStats(RenderJob &job) {
   st.n_undefined = static_cast<int64_t>(job.total_undefined);
   st.switches = ctx->switches;
   st.fused_variant = job.fused2 ? 2 : (job.exact_fused ? 3 : (job.pol_fused ? 4 : 0));
-  st.n_parked = static_cast<int64_t>(job.total_parked);
+  st.n_parked = static_cast<int64_t>(job.reuse ? ctx->resident.n_parked : job.total_parked);
   st.composed_maps = job.composed ? 1 : 0;
-  st.tail_policy = job.park ? BL_TAIL_QUAD : (job.split_long ? BL_TAIL_SPLIT : BL_TAIL_WIDE);
+  st.tail_policy = job.reuse ? ctx->resident.tail_policy : (job.park ? BL_TAIL_QUAD : (job.split_long ? BL_TAIL_SPLIT : BL_TAIL_WIDE));
   ctx->stats = st;
   if (ctx->debug_counters) {   // kernels built with -DBL_GEO_STATS fill these
     std::fprintf(stderr, "debug counters:");
     for (int k = 0; k < 8; k++) std::fprintf(stderr, " %llu", job.debug_counters[k]);
     std::fprintf(stderr, "\n");
   }
-  if (job.total_flagged > 0)
+  if (job.total_flagged > 0 && !job.reuse)   // (geodesics.cpp:389-394: raised where the geodesics are integrated - once per series)
     Warn(ctx, std::to_string(job.total_flagged) + " out of " + std::to_string(job.n_rays) + " geodesics terminate unexpectedly.");
   if (job.total_undefined > 0)   // BL_UNDEFINED_EDGE (this text has no counterpart in the reference)
     Warn(ctx, std::to_string(job.total_undefined) + " samples lie where the reference reads past its arrays; the edge cell was used for them.");
@@ -1766,38 +1955,67 @@ void EnsureStreams(bl_ctx *ctx) {
 
 extern "C" int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
   if (ctx == nullptr || d == nullptr) return BL_E_ARG;
-  try {
-    RenderJob job;
-    job.ctx = ctx;
-    job.d = d;
-    PlanJob(job);
-    Check(hipSetDevice(ctx->device), "hipSetDevice");
-    EnsureStreams(ctx);
-    PlanScratch(job);
-    if (job.split_long && !EnsureSplitStreams(ctx, job.split_cus)) {
-      if (ctx->tail_policy == BL_TAIL_SPLIT) throw Failure{BL_E_DEVICE, "BL_TAIL_SPLIT: the runtime gave no stream with a CU mask (hipExtStreamCreateWithCUMask)."};
-      ctx->split_unavailable = true;   // BL_TAIL_AUTO: the one-stepper path, from now on
-      job.split_long = false;
-      job.park_capacity = 0;
-      job.quad_grid = 0;
-    }
-    EnsureScratch(job);
-    StageInputsAndOutputs(job);
-    BuildTraceArgs(job);
-    BuildShadeArgs(job);
-    BuildTransferArgs(job);
-    RunChunks(job);
-    if (job.geo_save) WriteGeodesicCheckpoint(job);
-    if (job.sample_save) WriteSampleCheckpoint(job);
-    DownloadOutputs(job);
-    FinishStats(job);
-    if (job.slow) SlowLightMessages(job);
-  } catch (const Failure &failure) {
-    // leave no chunk half collected behind: a later call starts from idle streams
+  auto drain = [ctx]() {   // leave no chunk half collected behind: a later call starts from idle streams
     if (ctx->stream_few != nullptr) (void)hipStreamSynchronize(ctx->stream_few);
     if (ctx->stream_most != nullptr) (void)hipStreamSynchronize(ctx->stream_most);
-    (void)hipStreamSynchronize(ctx->stream_geo);
-    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->stream_geo != nullptr) (void)hipStreamSynchronize(ctx->stream_geo);
+    if (ctx->stream != nullptr) (void)hipStreamSynchronize(ctx->stream);
+  };
+  try {
+    // (planned again at most twice: without the split stepper after a chunk that closed its gate early, without the resident
+    // records after scratch beside them could not be had)
+    bool allow_split = true, allow_reuse = true;
+    for (int attempt = 0;; attempt++) {
+      RenderJob job;
+      job.ctx = ctx;
+      job.d = d;
+      job.allow_split = allow_split;
+      job.allow_reuse = allow_reuse;
+      try {
+        PlanJob(job);
+        Check(hipSetDevice(ctx->device), "hipSetDevice");
+        EnsureStreams(ctx);
+        DecideReuse(job);
+        PlanScratch(job);
+        if (job.split_long && !EnsureSplitStreams(ctx, job.split_cus)) {
+          if (ctx->tail_policy == BL_TAIL_SPLIT) throw Failure{BL_E_DEVICE, "BL_TAIL_SPLIT: the runtime gave no stream with a CU mask (hipExtStreamCreateWithCUMask)."};
+          ctx->split_unavailable = true;   // BL_TAIL_AUTO: the one-stepper path, from now on
+          job.split_long = false;
+          job.park_capacity = 0;
+          job.quad_grid = 0;
+        }
+        EnsureScratch(job);
+        StageInputsAndOutputs(job);
+        BuildTraceArgs(job);
+        BuildShadeArgs(job);
+        BuildTransferArgs(job);
+        RunChunks(job);
+        if (job.geo_save) WriteGeodesicCheckpoint(job);
+        if (job.sample_save) WriteSampleCheckpoint(job);
+        DownloadOutputs(job);
+        FinishStats(job);
+        KeepResident(job);
+        if (job.slow) SlowLightMessages(job);
+        break;
+      } catch (const SplitIncomplete &) {
+        drain();
+        if (job.keepable) DropResident(ctx);
+        if (!allow_split || attempt >= 2) throw Failure{BL_E_DEVICE, "A chunk of rays ended early twice."};
+        allow_split = false;
+      } catch (const ReuseImpossible &) {
+        drain();
+        (void)hipGetLastError();
+        DropResident(ctx);
+        if (!allow_reuse || attempt >= 2) throw Failure{BL_E_DEVICE, "Scratch memory for the render could not be allocated."};
+        allow_reuse = false;
+      } catch (const Failure &) {
+        // (what scratch set 0 holds is no longer known to be a whole set of records)
+        if (job.keepable) DropResident(ctx);
+        throw;
+      }
+    }
+  } catch (const Failure &failure) {
+    drain();
     return Fail(ctx, failure);
   }
   return BL_OK;

@@ -220,14 +220,20 @@ class Comm:
         raise RankError("; ".join(f"rank {r}: {t.strip()}" for r, t in enumerate(texts) if t is not None))
 
     def gather_flat(self, local, dst=0):
-        """local: a flat tensor on self.device, the same length on every rank. Rank dst gets them as ONE (world, n) tensor,
-        received into a buffer this object keeps per length and type (a frame loop allocates nothing after its first frame)."""
-        key = (local.numel(), local.dtype)
-        buffers = self.__dict__.setdefault("_gather_buffers", {})
-        gathered = gather_shares(local, dst=dst, buffer=buffers.get(key))
-        if gathered is not None:
-            buffers[key] = gathered
-        return gathered
+        """local: a flat tensor on self.device, the same length on every rank. Rank dst gets them as ONE (world, n) tensor - a view
+        of the one receive buffer this object keeps per element type, grown to the largest gather seen (a frame loop allocates
+        nothing after its first frame; refined levels, whose length differs from level to level and frame to frame, share it
+        instead of leaving a buffer each behind). The view is valid until the next gather of that type."""
+        torch = self.torch
+        pools = self.__dict__.setdefault("_gather_pools", {})
+        view = None
+        if self.dist.get_rank() == dst:
+            need = self.world * local.numel()
+            pool = pools.get(local.dtype)
+            if pool is None or pool.numel() < need or pool.device != local.device:
+                pool = pools[local.dtype] = torch.empty(need, dtype=local.dtype, device=local.device)
+            view = pool[:need].view(self.world, local.numel())
+        return gather_shares(local, dst=dst, buffer=view)
 
     def reduce_counts(self, max_value, sum_value):
         """(max over ranks of max_value, sum over ranks of sum_value), on every rank."""

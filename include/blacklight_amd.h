@@ -294,6 +294,9 @@ typedef struct bl_stats {
                                  run to run to rounding, ~1e-15, not bit for bit); 0: every image row of this render is bit-reproducible
                                  (always so in the exact tier and under bl_set_reproducible)                                         */
   int32_t tail_policy;        /* BL_TAIL_* the render ran with (after BL_TAIL_AUTO was resolved)                                     */
+  int32_t geodesics_reused;   /* 1: the sample records of an earlier render of the same camera were shaded again - no ray was
+                                 integrated (launches_geodesic = 0, ms_geodesic = 0); bl_set_geodesic_reuse                              */
+  int32_t sampling_reused;    /* 1: ... and the located samples too (same grid geometry: no locate kernel ran, launches_locate = 0)     */
 } bl_stats;
 
 /* Measurement switches: environment variables BLACKLIGHT_AMD_<NAME>, read ONCE by bl_init (never during a render) and echoed in
@@ -406,6 +409,21 @@ BL_API int bl_set_tail_policy(bl_ctx *ctx, int policy);
  * with enabled != 0, every later bl_render first makes its streams wait (on the device, hipStreamWaitEvent: no host wait) for
  * all work queued on `stream` (a hipStream_t; NULL is the NULL stream) up to the moment of the call. */
 BL_API int bl_set_caller_stream(bl_ctx *ctx, void *stream, int enabled);
+/* Geodesics once per series. The reference integrates the root camera's geodesics ONCE, before its loop over snapshots
+ * (blacklight.cpp:93-94 against :178-250), and - while the mesh does not change and slow light is off - locates the samples on the
+ * grid once (`first_time`, radiation_integrator.cpp:693-704); per snapshot it only reads the cells, evaluates the coefficients and
+ * integrates. on != 0 (default): a root-level bl_render whose rays fit one chunk leaves its sample records (64 B per sample: 48 GB
+ * for the 1024^2 benchmark camera) and per-ray rows in HBM; the next root-level bl_render of this context with the SAME camera -
+ * same parameters, pixel map, record layout, tail policy - after a new bl_set_grid / bl_slow_light_read shades those records again
+ * instead of launching the stepper (bl_stats.geodesics_reused = 1, launches_geodesic = 0), and where a locate kernel of its own
+ * ran, skips that too when the grid's geometry is bit for bit the one it located the samples on (bl_stats.sampling_reused).
+ * Renders of refined levels in between (the adaptive loop of every snapshot) leave the root level's records alone: they work in
+ * buffers of their own. The records go when the camera changes, when a render fails, when memory for another render cannot be
+ * had otherwise, and with bl_free. Images are the same bits either way in the exact tier and under bl_set_reproducible (the records
+ * ARE what the stepper would write again); with composed maps, equal to rounding like any two renders. The reference's warning
+ * about geodesics that end unexpectedly is raised by the render that integrated them, once. on = 0: every render integrates its
+ * rays (what a benchmark of the whole pipeline wants: bench.py's headline). */
+BL_API int bl_set_geodesic_reuse(bl_ctx *ctx, int on);
 /* Cap on scratch HBM (bytes) used for per-sample records; default four fifths of the device's memory (MI355X: 230 GB of 288). */
 BL_API int bl_set_scratch_limit(bl_ctx *ctx, uint64_t bytes);
 /* on != 0: when a render needs several chunks, run the geodesic kernel of chunk c + 1 on a second stream

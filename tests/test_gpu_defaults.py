@@ -183,3 +183,27 @@ def test_polarized_frames_build_their_matrices_beside_the_coefficients_and_get_t
             images[overlap] = whole["image"]
     assert images["1"].shape[0] >= 5 and np.isfinite(images["1"]).any()
     assert gu.same_bits(images["1"], images["0"]).all()
+
+
+def test_a_context_made_with_no_environment_starts_in_the_tolerant_tier():
+    """the parity suite pins the exact tier through BLACKLIGHT_AMD_ARITHMETIC (tests/conftest.py), so the path a caller gets
+    with nothing set is tested here, in a process without the variable: tolerant tier, composed maps, the benchmark's kernel, and the
+    stats say so."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import torch, bench, blacklight_amd as bl\n"
+        "from blacklight_amd import mock\n"
+        "ctx = bl.Context(bl.Params.from_dict(dict(bench.WORKLOAD, camera_resolution=64)))\n"
+        "ctx.set_grid(mock.generate(n_r=32, n_th=32, n_ph=32))\n"
+        "st = ctx.render()['stats']\n"
+        "print('TIER', st.arithmetic, st.composed_maps, st.fused_variant, st.switches, st.geodesics_reused)\n"
+        "st = ctx.render()['stats']\n"
+        "print('AGAIN', st.arithmetic, st.composed_maps, st.fused_variant, st.switches, st.geodesics_reused)\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if not k.startswith("BLACKLIGHT_AMD_")}
+    run = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert "TIER 1 1 2 0 0" in run.stdout and "AGAIN 1 1 2 0 1" in run.stdout, run.stdout

@@ -190,3 +190,22 @@ def test_npz_record_beyond_4_gib(built_library, tmp_path, monkeypatch):
     with zipfile.ZipFile(path) as z, z.open("I_nu.npy") as member:
         while member.read(1 << 26):     # read to the end: zipfile compares the CRC-32 of 4.4 GB with the header's
             pass
+
+
+def test_the_arithmetic_tier_from_the_environment_is_parsed_strictly(built_library, monkeypatch):
+    """BLACKLIGHT_AMD_ARITHMETIC = exact | tolerant in any case; anything else fails bl_init with the reason (a typo used to
+    select the tolerant tier silently). Same for BLACKLIGHT_AMD_TAIL_POLICY."""
+    import blacklight_amd as bl
+    fx, p, ctx = _host_context("formula_dp")
+    ctx.close()
+    for good in ("exact", "EXACT", "Tolerant"):
+        monkeypatch.setenv("BLACKLIGHT_AMD_ARITHMETIC", good)
+        bl.Context(p, device=BL_DEVICE_NONE).close()
+    for bad in ("exakt", "exact ", "1", ""):
+        monkeypatch.setenv("BLACKLIGHT_AMD_ARITHMETIC", bad)
+        with pytest.raises(bl.BlacklightError, match="BLACKLIGHT_AMD_ARITHMETIC must be exact or tolerant"):
+            bl.Context(p, device=BL_DEVICE_NONE)
+    monkeypatch.setenv("BLACKLIGHT_AMD_ARITHMETIC", "exact")
+    monkeypatch.setenv("BLACKLIGHT_AMD_TAIL_POLICY", "quadd")
+    with pytest.raises(bl.BlacklightError, match="BLACKLIGHT_AMD_TAIL_POLICY"):
+        bl.Context(p, device=BL_DEVICE_NONE)

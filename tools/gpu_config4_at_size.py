@@ -23,6 +23,7 @@ p.update(camera_resolution=res, image_polarization=True, image_tau=True, adaptiv
          adaptive_abs_grad_frac=-1.0, adaptive_rel_grad_cut=0.0, adaptive_rel_grad_frac=-1.0, adaptive_abs_lapl_cut=0.0,
          adaptive_abs_lapl_frac=-1.0, adaptive_rel_lapl_cut=1.0, adaptive_rel_lapl_frac=0.25, adaptive_num_regions=0)
 with bl.Context(bl.Params.from_dict(p)) as ctx:
+    ctx.set_geodesic_reuse(False)   # a measurement of whole renders: every one integrates its geodesics
     ctx.set_grid(grid)
     ctx.set_arithmetic(os.environ.get("ARITH", "exact"))
     ctx.render_adaptive()                      # first run: allocations

@@ -30,6 +30,7 @@ params.pop("image_frequency", None)
 grid = mock.generate(n_r=256, n_th=256, n_ph=256)
 report = {"workload": f"{res}^2 x {n_freq} frequencies over the 256^3 mock, one MI355X", "arithmetic": tier}
 with bl.Context(bl.Params.from_dict(params)) as ctx:
+    ctx.set_geodesic_reuse(False)   # a measurement of whole renders: every one integrates its geodesics
     ctx.set_grid(grid)
     ctx.set_arithmetic(tier)
     t0 = time.perf_counter()

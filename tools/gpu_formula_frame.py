@@ -17,6 +17,7 @@ reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 fx, params, _ = gu.load_case("formula_dp")
 params = dict(params, camera_resolution=512)
 with bl.Context(bl.Params.from_dict(params)) as ctx:
+    ctx.set_geodesic_reuse(False)   # a measurement of whole renders: every one integrates its geodesics
     ctx.set_arithmetic(tier)
     ctx.render()
     best, st = 1e30, None

@@ -33,6 +33,7 @@ fx, params, _ = gu.load_case("formula_dp")
 params = dict(params)
 params.update(camera_resolution=512)
 with bl.Context(bl.Params.from_dict(params)) as ctx:
+    ctx.set_geodesic_reuse(False)   # a measurement of whole renders: every one integrates its geodesics
     res, sec = timed(ctx)
     st = res["stats"]
     out["formula_512"] = dict(seconds=sec, mrays_per_s=512 * 512 / sec / 1e6, samples_per_ray=st.n_samples / (512 * 512),
@@ -42,6 +43,7 @@ for nf, tier in ((10, "exact"), (10, "tolerant"), (64, "exact"), (64, "tolerant"
     p = dict(bench.WORKLOAD)
     p.update(image_num_frequencies=nf, image_frequency_start=1.5e11, image_frequency_end=3.3e11, image_frequency_spacing="lin_wave")
     with bl.Context(bl.Params.from_dict(p)) as ctx:
+        ctx.set_geodesic_reuse(False)   # a measurement of whole renders: every one integrates its geodesics
         ctx.set_grid(grid)
         ctx.set_arithmetic(tier)
         res, sec = timed(ctx, n=2)
@@ -55,6 +57,7 @@ for tier in ("exact", "tolerant"):
     p = dict(bench.WORKLOAD)
     p.update(camera_r=100.0, fallback_nan=False, fallback_rho=1.0e-6, fallback_pgas=1.0e-8)
     with bl.Context(bl.Params.from_dict(p)) as ctx:
+        ctx.set_geodesic_reuse(False)   # a measurement of whole renders: every one integrates its geodesics
         ctx.set_grid(grid)
         ctx.set_arithmetic(tier)
         for every in (False, True):

@@ -19,6 +19,7 @@ grid = mock.generate(n_r=256, n_th=256, n_ph=256)
 p = dict(bench.WORKLOAD)
 p.update(camera_resolution=res, image_polarization=True, image_tau=True)
 with bl.Context(bl.Params.from_dict(p)) as ctx:
+    ctx.set_geodesic_reuse(False)   # a measurement of whole renders: every one integrates its geodesics
     ctx.set_grid(grid)
     ctx.set_arithmetic(os.environ.get("ARITH", "exact"))
     if "SCRATCH_GB" in os.environ:

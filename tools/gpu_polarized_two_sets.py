@@ -16,6 +16,7 @@ res = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 params = dict(bench.WORKLOAD, camera_resolution=res, image_polarization=True, image_tau=True)
 grid = mock.generate(n_r=256, n_th=256, n_ph=256)
 with bl.Context(bl.Params.from_dict(params)) as ctx:
+    ctx.set_geodesic_reuse(False)   # a measurement of whole renders: every one integrates its geodesics
     ctx.set_grid(grid)
     ctx.set_arithmetic("tolerant")
     reference = None

@@ -17,6 +17,7 @@ for spin in (0.9, 0.0):
     for width, res in ((12.0, 8), (12.0, 16), (30.0, 64)):
         p = bl.Params.from_dict(dict(params, camera_resolution=res, camera_width=width, formula_spin=spin))
         with bl.Context(p) as ctx:
+            ctx.set_geodesic_reuse(False)   # a measurement of whole renders: every one integrates its geodesics
             row = []
             for name, switches in (("ray per lane", ()), ("ray per quad", ("QUAD_EVERY_RAY",))):
                 ctx.debug_set_switches(*switches)

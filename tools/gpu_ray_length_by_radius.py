@@ -16,6 +16,7 @@ res = 1024
 width = bench.WORKLOAD["camera_width"]
 grid = mock.generate(n_r=64, n_th=64, n_ph=64)
 with bl.Context(bl.Params.from_dict(dict(bench.WORKLOAD))) as ctx:
+    ctx.set_geodesic_reuse(False)   # a measurement of whole renders: every one integrates its geodesics
     ctx.set_grid(grid)
     ctx.set_arithmetic("exact")
     for b in (list(np.arange(0.5, 4.0, 0.5)) + list(np.arange(4.0, 7.01, 0.2)) + list(np.arange(7.5, 12.1, 0.5)) if not os.environ.get("FINE") else list(np.arange(4.9, 5.7, 0.025))):

@@ -18,6 +18,7 @@ from blacklight_amd import mock                # noqa: E402
 params = dict(bench.WORKLOAD)
 grid = mock.generate(n_r=256, n_th=256, n_ph=256)
 with bl.Context(bl.Params.from_dict(params)) as ctx:
+    ctx.set_geodesic_reuse(False)   # a measurement of whole renders: every one integrates its geodesics
     ctx.set_grid(grid)
     ctx.set_arithmetic("tolerant")
     for world in (8, 1):

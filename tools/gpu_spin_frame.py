@@ -16,6 +16,7 @@ grid = mock.generate(n_r=256, n_th=256, n_ph=256)
 p = dict(bench.WORKLOAD)
 p.update(simulation_a=0.9375)
 with bl.Context(bl.Params.from_dict(p)) as ctx:
+    ctx.set_geodesic_reuse(False)   # a measurement of whole renders: every one integrates its geodesics
     ctx.set_grid(grid)
     ctx.set_arithmetic(sys.argv[1] if len(sys.argv) > 1 else "tolerant")
     ctx.render()

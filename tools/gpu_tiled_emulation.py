@@ -36,6 +36,7 @@ p = dict(bench.WORKLOAD)
 out = {"note": "emulated on one GPU, rank by rank (see the docstring of tools/gpu_tiled_emulation.py); median of %d renders per rank, gather of the share through "
                "a world-size-1 RCCL group included" % reps}
 with bl.Context(bl.Params.from_dict(p)) as ctx:
+    ctx.set_geodesic_reuse(False)   # a measurement of whole renders: every one integrates its geodesics
     ctx.set_grid(grid)
     ctx.set_arithmetic(os.environ.get("ARITH", "tolerant"))
     for world in [int(w) for w in os.environ.get("WORLDS", "1,2,4,8").split(",")]:
