@@ -420,6 +420,7 @@ void BuildReuseKeys(RenderJob &job) {
   key.Put(job.skip_shell ? ctx->grid_outer_x1 : 0.0);
   // who steps which rays (the records' order; bl_stats says it)
   key.Put(ctx->tail_policy); key.Put(ctx->switches); key.Put(ctx->overlap_chunks); key.Put(ctx->num_cus);
+  key.Put(ctx->scratch_limit);   // (a caller that lowers the cap wants the memory back: the records are integrated again, in as many chunks as it takes)
   job.located_key = job.geo_key;
   KeyWriter located{&job.located_key};
   located.Put(ctx->grid_geometry); located.Put(ctx->undefined_policy); located.Put(job.fast ? 1 : 0); located.Put(job.block_interp ? 1 : 0);
