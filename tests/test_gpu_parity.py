@@ -395,7 +395,10 @@ def test_empty_shell_steps_leave_no_records(seed, built_library, monkeypatch):
                 assert np.nanmax(np.abs(got["image"] - every["image"])) <= 1.0e-13 * np.nanmax(np.abs(every["image"])), over
             assert np.array_equal(np.isnan(got["image"]), np.isnan(every["image"]))
         assert every["stats"].n_samples_emitted >= every["stats"].n_samples
-        assert got["stats"].n_samples_emitted < 0.9 * every["stats"].n_samples_emitted, over
+        if over["ray_integrator"] == "dp":
+            assert got["stats"].n_samples_emitted < 0.9 * every["stats"].n_samples_emitted, over
+        else:   # (the fixed-step steppers have no instantiation that skips the shell since round 6: every step is recorded)
+            assert got["stats"].n_samples_emitted == every["stats"].n_samples_emitted, over
     assert gu.same_bits(out["exact"]["image"], want["image"]).all(), over
     assert np.nanmax(want["image"]) > 0.0
 
