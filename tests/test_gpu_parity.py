@@ -398,7 +398,8 @@ def test_empty_shell_steps_leave_no_records(seed, built_library, monkeypatch):
         if over["ray_integrator"] == "dp":
             assert got["stats"].n_samples_emitted < 0.9 * every["stats"].n_samples_emitted, over
         else:   # (the fixed-step steppers have no instantiation that skips the shell since round 6: every step is recorded)
-            assert got["stats"].n_samples_emitted == every["stats"].n_samples_emitted, over
+            # (record slots are handed out in blocks of 1 024 per wave: equal up to the blocks' slack)
+            assert abs(got["stats"].n_samples_emitted - every["stats"].n_samples_emitted) <= 8 * 1024, over
     assert gu.same_bits(out["exact"]["image"], want["image"]).all(), over
     assert np.nanmax(want["image"]) > 0.0
 
