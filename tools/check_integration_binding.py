@@ -1,14 +1,15 @@
 #!/usr/bin/env python3
-"""Compile proof of INTEGRATION.md section 2: the four fenced blocks marked `<!-- binding:NAME -->` there are spliced into a copy
-of the reference's main() (/root/reference/src/blacklight.cpp, read where it lies; the patched copy lives under /tmp and is never
-committed), compiled with the reference's other translation units (the objects oracle/Makefile builds into oracle/_ref/obj) and
+"""Compile proof of INTEGRATION.md section 2: the five fenced blocks marked `<!-- binding:NAME -->` there are spliced into a copy
+of the reference's main() (/root/reference/src/blacklight.cpp, read where it lies; the patched copy lives in a temporary directory
+and is never committed), compiled with the reference's other translation units (the objects oracle/Makefile builds into oracle/_ref/obj) and
 linked against blacklight_amd/libblacklight_amd.so -> oracle/_ref/blacklight_bound (git-ignored, travels to the GPU box like the
 other binaries there). Then the program is run:
 
   * here (no GPU): BLACKLIGHT_AMD_BINDING_DEVICE=-2 - a host-only context: the reference's InputReader, constructors and the
     library's parameter validation / camera frame / frequency list run, bl_render refuses with its BL_E_DEVICE text;
-  * on a GPU box (tests/test_gpu_binding.py): input/example_formula.input at 64 x 64 end to end - reference InputReader and
-    OutputWriter around bl_init / bl_render - and the .npz against the reference's own (tests/golden/formula_64.npz).
+  * on a GPU box (tests/test_gpu_binding.py): input/example_formula.input at 64 x 64, a two-file .athdf series through the reference's
+    SimulationReader, and that series with adaptive refinement, end to end - reference InputReader, SimulationReader and OutputWriter
+    around bl_init / bl_set_grid / bl_render / bl_adaptive_refine - every .npz against the reference's own.
 
     python tools/check_integration_binding.py [--no-run] [--no-build]
 """
@@ -16,10 +17,10 @@ import os
 import re
 import subprocess
 import sys
+import tempfile
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = "/root/reference"
-WORK = "/tmp/bl_binding"
 OUT = os.path.join(REPO, "oracle", "_ref", "blacklight_bound")
 REFFLAGS = ["-std=c++17", "-fopenmp", "-O3", "-flto", "-fno-math-errno", "-fno-signed-zeros", "-fno-trapping-math"]   # oracle/Makefile
 
@@ -27,7 +28,7 @@ REFFLAGS = ["-std=c++17", "-fopenmp", "-O3", "-flto", "-fno-math-errno", "-fno-s
 def snippets():
     text = open(os.path.join(REPO, "INTEGRATION.md")).read()
     found = dict(re.findall(r"<!-- binding:(\w+) -->\n```cpp\n(.*?)```", text, flags=re.S))
-    missing = {"includes", "init", "grid", "render"} - set(found)
+    missing = {"includes", "init", "grid", "render", "adaptive"} - set(found)
     if missing:
         raise SystemExit(f"INTEGRATION.md: binding blocks missing: {sorted(missing)}")
     return found
@@ -46,6 +47,7 @@ def splice(source, blocks):
                           blocks["init"])
     source = replace_once(source, "      time_read += p_simulation_reader->Read(n);\n", "      time_read += p_simulation_reader->Read(n);\n" + blocks["grid"])
     source = replace_once(source, "        adaptive_complete =\n            p_radiation_integrator->Integrate(n, &time_sample, &time_image, &time_render);\n", blocks["render"])
+    source = replace_once(source, "          time_geodesic += p_geodesic_integrator->AddGeodesics(p_radiation_integrator);\n", blocks["adaptive"])
     source = replace_once(source, "  delete p_input_reader;\n", "  delete p_input_reader;\n  bl_free(bl_context);\n")
     return source
 
@@ -57,7 +59,7 @@ def main():
         sys.path.insert(0, REPO)
         import __graft_entry__
         __graft_entry__.build()   # the library, and oracle/_ref/obj with the reference's objects
-    os.makedirs(WORK, exist_ok=True)
+    WORK = tempfile.mkdtemp(prefix="bl_binding_")   # (a directory of this run's own: builds side by side do not meet)
     main_cpp = open(os.path.join(REF, "src", "blacklight.cpp")).read()
     main_cpp = main_cpp.replace('#include "utils/exceptions.hpp"                           // BlacklightException', '#include "utils/exceptions.hpp"')
     patched = os.path.join(WORK, "blacklight_bound.cpp")

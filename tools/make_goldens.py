@@ -1259,6 +1259,41 @@ def make_fmks_slow_fixture():
     np.savez_compressed(os.path.join(out_dir, "expected_fmks_slow.npz"), **expected)
 
 
+# ------------------------------------------------------------------------------------------------
+# The INTEGRATION.md binding on an adaptive series (tests/golden/reader/expected_binding_adaptive.npz): the reference itself on the
+# first committed .athdf file of the reader fixtures (it decodes HDF5 by hand: no h5py needed here) with sim_adaptive's refinement
+# criteria, two levels, output_camera - what oracle/_ref/blacklight_bound must reproduce record for record (tests/test_gpu_binding.py).
+def make_binding_adaptive_fixture():
+    out_dir = os.path.join(OUT, "reader")
+    workdir = os.path.join(WORK, "binding_adaptive")
+    for sub in (os.path.join(workdir, "data"), os.path.join(workdir, "output")):
+        os.makedirs(sub, exist_ok=True)
+    for name in ("series_0003.athdf", "series_0004.athdf"):
+        with open(os.path.join(out_dir, name), "rb") as src, open(os.path.join(workdir, "data", name), "wb") as dst:
+            dst.write(src.read())
+    params = dict(SIM_BASE)
+    # (one file: with simulation_multiple the reference stops at its second snapshot with "Attempting to reallocate array." - its
+    # AugmentCamera allocates camera_loc[level] again, camera.cpp:445-458 - so an adaptive series has no reference output to compare with)
+    params.update(camera_resolution=32, checkpoint_geodesic_save="false", simulation_multiple="false",
+                  simulation_file="data/series_0003.athdf", output_file="output/out_03.npz", output_camera="true",
+                  adaptive_max_level=2, adaptive_block_size=8, adaptive_frequency_num=1, adaptive_val_cut=0.0, adaptive_val_frac=-1.0,
+                  adaptive_abs_grad_cut=0.0, adaptive_abs_grad_frac=-1.0, adaptive_rel_grad_cut=0.5, adaptive_rel_grad_frac=0.25,
+                  adaptive_abs_lapl_cut=0.0, adaptive_abs_lapl_frac=-1.0, adaptive_rel_lapl_cut=1.0, adaptive_rel_lapl_frac=0.25,
+                  adaptive_num_regions=1, adaptive_region_1_level=1, adaptive_region_1_x_min=-11.0, adaptive_region_1_x_max=-5.0,
+                  adaptive_region_1_y_min=2.0, adaptive_region_1_y_max=9.0)
+    write_input(os.path.join(workdir, "case.input"), params)
+    expected = {"params": json.dumps(params)}
+    for tier, preload in (("A", False), ("B", True)):
+        expected[f"{tier}_warnings"] = run_reference(workdir, "case.input", preload)
+        for number in (3,):
+            npz = np.load(os.path.join(workdir, "output", f"out_{number:02d}.npz"))
+            for key in npz.files:
+                expected[f"{tier}_{number}_{key}"] = npz[key]
+    np.savez_compressed(os.path.join(out_dir, "expected_binding_adaptive.npz"), **expected)
+    print("binding adaptive fixture:", {n: (int(expected[f"B_{n}_adaptive_num_levels"][0]), expected[f"B_{n}_adaptive_num_blocks"].tolist()) for n in (3,)},
+          "warnings:", repr(expected["B_warnings"]))
+
+
 if __name__ == "__main__":
     names = sys.argv[1:] or (["mock"] + list(CASES))
     for case_name in names:
@@ -1288,6 +1323,8 @@ if __name__ == "__main__":
             make_harm3d_fixtures()
         elif case_name == "slowcli":
             make_slow_cli_fixture()
+        elif case_name == "binding_adaptive":
+            make_binding_adaptive_fixture()
         elif case_name in SLOW_CASES:
             make_slow_fixture(case_name)
         else:
