@@ -98,3 +98,19 @@ def test_reference_main_with_the_binding_runs_the_adaptive_loop(tmp_path):
     got = np.load(tmp_path / "bound_adaptive.npz")
     assert int(got["adaptive_num_levels"][0]) == 2 and got["adaptive_num_blocks"].tolist() == [16, 64, 56]
     _assert_records_equal(got, expected, "B_3_")
+
+
+def test_command_line_driver_on_the_same_adaptive_file(tmp_path):
+    """... and the library's own command-line driver (bl_main.cpp: its reader, its loop, its writer) on that input: the same file."""
+    import json
+    exe = os.path.join(REPO, "blacklight_amd", "bin", "blacklight_amd")
+    reader_dir = os.path.join(gu.GOLDEN_DIR, "reader")
+    expected = np.load(os.path.join(reader_dir, "expected_binding_adaptive.npz"), allow_pickle=False)
+    params = json.loads(str(expected["params"]))
+    params.update(simulation_file=os.path.join(reader_dir, "series_0003.athdf"), output_file=str(tmp_path / "cli_adaptive.npz"), num_threads=1)
+    _write_input(tmp_path / "adaptive.input", params)
+    run = subprocess.run([exe, str(tmp_path / "adaptive.input")], capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert run.stderr == str(expected["B_warnings"])
+    assert "exact arithmetic tier" in run.stdout   # (tests/conftest.py pins the tier; the driver says which one wrote the file)
+    _assert_records_equal(np.load(tmp_path / "cli_adaptive.npz"), expected, "B_3_")
