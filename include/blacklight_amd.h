@@ -353,8 +353,9 @@ BL_API int bl_render_num_images(const bl_ctx *ctx);
 BL_API int bl_camera_frame_get(const bl_ctx *ctx, bl_camera_frame *out);
 BL_API int bl_frequencies(const bl_ctx *ctx, double *out, int n);
 /* Arithmetic tier. BL_ARITH_TOLERANT (what a new context starts in, unless the environment says BLACKLIGHT_AMD_ARITHMETIC=exact): the
- * tolerance north_star grants for intensities ("within a stated fp64 tolerance", per-pixel L-infinity < 1e-6 of the image maximum;
- * measured 6e-15 on the benchmark frame, asserted at 1e-11) is used between the sampled primitives and the transfer record of a sample -
+ * tolerance north_star grants for intensities ("within a stated fp64 tolerance", per-pixel L-infinity < 1e-6: every pixel relative to
+ * its own intensity; measured 2e-14 per pixel - 6e-15 of the image maximum - on the benchmark frame's 1 048 576 pixels and against the
+ * reference's own windows of it, asserted at 1e-10 per pixel: tests/test_gpu_window_1024.py, test_gpu_configs_at_size.py) is used between the sampled primitives and the transfer record of a sample -
  * fused multiply-adds, lighter exp / expm1 / cbrt, the fluid-frame angle and frequency as invariants instead of through the tetrad
  * of simulation_coefficients.cpp:398-455, transport matrices in polarized runs. Ray-step counts, flags, cell indices, NaN masks and
  * every cut decision are those of the exact tier. Configurations the tier has no kernel for run in exact arithmetic regardless -

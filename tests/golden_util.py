@@ -227,3 +227,16 @@ def same_bits(a, b):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     return (a.view(np.uint64) == b.view(np.uint64)) | (np.isnan(a) & np.isnan(b)) | ((a == 0) & (b == 0))
+
+
+def per_pixel_relative(got, want):
+    """north_star's parity bar as it words it - "per-pixel L-infinity < 1e-6 vs reference": max_m |got_m - want_m| / |want_m| over the
+    finite pixels with want_m > 0, the number of pixels above 1e-6, and whether the two frames are finite and positive in the same
+    pixels (bench.py's relative_distance is the same function)."""
+    got = np.asarray(got, dtype=np.float64).reshape(-1)
+    want = np.asarray(want, dtype=np.float64).reshape(-1)
+    use = np.isfinite(want) & np.isfinite(got) & (want > 0.0)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        rel = np.abs(got[use] - want[use]) / want[use]
+    same_support = bool(np.array_equal(np.isfinite(got) & (got > 0.0), np.isfinite(want) & (want > 0.0)))
+    return (float(rel.max()) if rel.size else 0.0), int((rel > 1.0e-6).sum()), int(use.sum()), same_support

@@ -153,3 +153,22 @@ def test_reference_window_of_the_polarized_2048_frame(built_library, big_grid):
         same = gu.same_bits(exact["image"][row], want)
         assert same.all(), f"{key}: {(~same).sum()} of {same.size} window pixels differ from the reference"
         assert float(np.nanmax(np.abs(tolerant["image"][row] - want)) / np.nanmax(np.abs(want))) < 1.0e-9, key
+
+
+def test_tolerant_tier_per_pixel_at_the_benchmark_size(built_library, big_grid):
+    """north_star: "per-pixel L-infinity < 1e-6 vs reference". The tier bench.py quotes against the exact tier - the reference's bits,
+    tests/test_gpu_window_1024.py - on all 1 048 576 pixels of the benchmark frame, each relative to its own intensity."""
+    import bench
+    import blacklight_amd as bl
+    with bl.Context(bl.Params.from_dict(dict(bench.WORKLOAD))) as ctx:
+        ctx.set_grid(big_grid)
+        ctx.set_arithmetic("exact")
+        exact = ctx.render()
+        ctx.set_arithmetic("tolerant")
+        tolerant = ctx.render()
+        assert exact["stats"].arithmetic == 0 and tolerant["stats"].arithmetic == 1 and tolerant["stats"].composed_maps == 1
+    assert np.array_equal(exact["sample_num"], tolerant["sample_num"]) and np.array_equal(exact["sample_flags"], tolerant["sample_flags"])
+    worst, above, compared, same_support = gu.per_pixel_relative(tolerant["image"][0], exact["image"][0])
+    assert same_support and compared > 1_000_000
+    assert above == 0 and worst < 1.0e-6, (worst, above)
+    assert worst < 1.0e-10, worst
