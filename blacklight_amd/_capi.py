@@ -109,6 +109,9 @@ def lib():
     L.bl_set_reproducible.argtypes = [C.c_void_p, C.c_int]
     L.bl_set_tail_policy.argtypes = [C.c_void_p, C.c_int]
     L.bl_set_geodesic_reuse.argtypes = [C.c_void_p, C.c_int]
+    L.bl_host_alloc.argtypes = [C.c_void_p, C.c_size_t]
+    L.bl_host_alloc.restype = C.c_void_p
+    L.bl_host_free.argtypes = [C.c_void_p, C.c_void_p]
     L.bl_set_caller_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     L.bl_device_count.restype = C.c_int
     L.bl_set_undefined_policy.argtypes = [C.c_void_p, C.c_int]

@@ -894,6 +894,22 @@ int bl_frequencies(const bl_ctx *ctx, double *out, int n) {
   return BL_OK;
 }
 
+void *bl_host_alloc(bl_ctx *ctx, size_t bytes) {
+  if (ctx == nullptr || ctx->device == BL_DEVICE_NONE || bytes == 0) return nullptr;
+  void *p = nullptr;
+  if (hipSetDevice(ctx->device) != hipSuccess || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  return p;
+}
+
+void bl_host_free(bl_ctx *ctx, void *p) {
+  if (ctx == nullptr || p == nullptr || ctx->device == BL_DEVICE_NONE) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipHostFree(p);
+}
+
 int bl_set_geodesic_reuse(bl_ctx *ctx, int on) {
   if (ctx == nullptr) return BL_E_ARG;
   ctx->geodesic_reuse = on ? 1 : 0;

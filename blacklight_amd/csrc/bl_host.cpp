@@ -11,7 +11,11 @@
 #include <cstdio>
 #include <cstring>
 #include <ctime>
+#include <fcntl.h>
+#include <unistd.h>
+
 #include <fstream>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -174,7 +178,66 @@ uint32_t Crc32Update(uint32_t crc, const uint8_t *data, size_t n) {
   return crc ^ 0xFFFFFFFFu;
 }
 
-uint32_t Crc32(const NpyRecord &r) { return Crc32Update(Crc32Update(0, r.head.data(), r.head.size()), r.data, r.data_bytes); }
+// CRC-32 of the concatenation A | B from crc(A), crc(B) and the length of B: the CRC register is linear over GF(2), so appending
+// len_b zero bytes to A is a 32 x 32 bit matrix applied to crc(A) - the matrix for one zero byte squared up along the bits of len_b -
+// and crc(A | B) = that ^ crc(B). (The construction zlib's crc32_combine uses; written out here from the algebra.)
+uint32_t Gf2Times(const uint32_t *matrix, uint32_t vec) {
+  uint32_t sum = 0;
+  for (int bit = 0; vec != 0; vec >>= 1, bit++)
+    if (vec & 1u) sum ^= matrix[bit];
+  return sum;
+}
+void Gf2Square(uint32_t *square, const uint32_t *matrix) {
+  for (int n = 0; n < 32; n++) square[n] = Gf2Times(matrix, matrix[n]);
+}
+uint32_t Crc32Combine(uint32_t crc_a, uint32_t crc_b, uint64_t len_b) {
+  if (len_b == 0) return crc_a;
+  uint32_t even[32], odd[32];
+  odd[0] = 0xEDB88320u;   // the register's shift by one zero BIT: the polynomial, then the identity shifted
+  for (int n = 1; n < 32; n++) odd[n] = 1u << (n - 1);
+  Gf2Square(even, odd);   // two bits
+  Gf2Square(odd, even);   // four bits
+  do {                     // eight bits = one byte on the first pass, then squared per bit of len_b
+    Gf2Square(even, odd);
+    if (len_b & 1u) crc_a = Gf2Times(even, crc_a);
+    len_b >>= 1;
+    if (len_b == 0) break;
+    Gf2Square(odd, even);
+    if (len_b & 1u) crc_a = Gf2Times(odd, crc_a);
+    len_b >>= 1;
+  } while (len_b != 0);
+  return crc_a ^ crc_b;
+}
+
+// Host threads for the byte work on large records (a 4096^2 x 64 image is 8.6 GB: one thread took 3.9 s for its CRC, round 5)
+int ByteWorkers(size_t bytes) {
+  if (bytes < (32u << 20)) return 1;
+  const unsigned int cores = std::thread::hardware_concurrency();
+  return static_cast<int>(std::min<size_t>(std::min<unsigned int>(cores == 0 ? 4 : cores, 16), bytes >> 24));
+}
+
+// ... of a large array: slices in parallel, combined in order
+uint32_t Crc32Large(uint32_t crc, const uint8_t *data, size_t n) {
+  const int workers = ByteWorkers(n);
+  if (workers <= 1) return Crc32Update(crc, data, n);
+  (void)Crc32Update(0, data, 0);   // (the tables, before the threads race to build them)
+  const size_t share = (n + workers - 1) / workers;
+  std::vector<uint32_t> part(workers, 0);
+  std::vector<std::thread> pool;
+  for (int t = 0; t < workers; t++)
+    pool.emplace_back([&, t]() {
+      const size_t first = std::min(n, share * t), last = std::min(n, share * (t + 1));
+      part[t] = Crc32Update(0, data + first, last - first);
+    });
+  for (std::thread &t : pool) t.join();
+  for (int t = 0; t < workers; t++) {
+    const size_t first = std::min(n, share * t), last = std::min(n, share * (t + 1));
+    crc = Crc32Combine(crc, part[t], last - first);
+  }
+  return crc;
+}
+
+uint32_t Crc32(const NpyRecord &r) { return Crc32Large(Crc32Update(0, r.head.data(), r.head.size()), r.data, r.data_bytes); }
 
 template <typename T>
 void Put(Bytes *b, T v) {
@@ -552,14 +615,56 @@ int bl_write_output(bl_ctx *ctx, const char *path_override, const bl_output_desc
   Put<uint32_t>(&end, static_cast<uint32_t>(std::min<size_t>(central_length, UINT32_MAX)));
   Put<uint32_t>(&end, static_cast<uint32_t>(std::min<size_t>(offset, UINT32_MAX)));
   Put<uint16_t>(&end, 0);
-  for (size_t n = 0; n < records.size(); n++) {
-    stream.write(reinterpret_cast<const char *>(local_headers[n].data()), static_cast<std::streamsize>(local_headers[n].size()));
-    stream.write(reinterpret_cast<const char *>(records[n].head.data()), static_cast<std::streamsize>(records[n].head.size()));
-    stream.write(reinterpret_cast<const char *>(records[n].data), static_cast<std::streamsize>(records[n].data_bytes));
+  // Small pieces through the stream; the data of a large record straight to its place in the file from several host threads (pwrite:
+  // the copy into the page cache is what a write costs, and it parallelises) - the same bytes at the same offsets.
+  bool written = true;
+  size_t position = 0;
+  auto put = [&](const uint8_t *bytes, size_t count) {
+    stream.write(reinterpret_cast<const char *>(bytes), static_cast<std::streamsize>(count));
+    position += count;
+  };
+  for (size_t n = 0; n < records.size() && written; n++) {
+    put(local_headers[n].data(), local_headers[n].size());
+    put(records[n].head.data(), records[n].head.size());
+    const size_t bytes = records[n].data_bytes;
+    const int workers = ByteWorkers(bytes);
+    if (workers <= 1) {
+      put(records[n].data, bytes);
+      continue;
+    }
+    stream.flush();
+    const int fd = ::open(path.c_str(), O_WRONLY);
+    if (fd < 0 || !stream.good()) {
+      if (fd >= 0) ::close(fd);
+      put(records[n].data, bytes);   // (no second descriptor: the plain way)
+      continue;
+    }
+    const size_t share = ((bytes + workers - 1) / workers + 4095) / 4096 * 4096;
+    std::vector<char> ok(workers, 1);
+    std::vector<std::thread> pool;
+    const uint8_t *data = records[n].data;
+    for (int t = 0; t < workers; t++)
+      pool.emplace_back([&, t]() {
+        size_t first = std::min(bytes, share * t);
+        const size_t last = std::min(bytes, share * (t + 1));
+        while (first < last) {
+          const ssize_t did = ::pwrite(fd, data + first, std::min<size_t>(last - first, 256u << 20), static_cast<off_t>(position + first));
+          if (did <= 0) {
+            ok[t] = 0;
+            return;
+          }
+          first += static_cast<size_t>(did);
+        }
+      });
+    for (std::thread &t : pool) t.join();
+    ::close(fd);
+    for (char good : ok) written = written && good != 0;
+    position += bytes;
+    stream.seekp(static_cast<std::streamoff>(position));
   }
-  for (const Bytes &h : central_headers) stream.write(reinterpret_cast<const char *>(h.data()), static_cast<std::streamsize>(h.size()));
-  stream.write(reinterpret_cast<const char *>(end.data()), static_cast<std::streamsize>(end.size()));
-  return stream.good() ? BL_OK : bl_internal_fail(ctx, BL_E_INPUT, "Could not write output file.");
+  for (const Bytes &h : central_headers) put(h.data(), h.size());
+  put(end.data(), end.size());
+  return (written && stream.good()) ? BL_OK : bl_internal_fail(ctx, BL_E_INPUT, "Could not write output file.");
 }
 
 }  // extern "C"

@@ -118,11 +118,60 @@ int DefaultTile(int res, int block) {
   return (res % tile == 0 && tile % block == 0) ? tile : res;
 }
 
+// An array of doubles the GPU downloads into at the link's rate: pinned through the library (bl_host_alloc) where that works,
+// plain memory otherwise (a host-only context, an allocation the runtime refuses)
+struct HostArray {
+  bl_ctx *owner = nullptr;
+  double *ptr = nullptr;
+  size_t count = 0;
+  bool pinned = false;
+  HostArray() = default;
+  HostArray(bl_ctx *ctx, size_t n, bool pin) { Allocate(ctx, n, pin); }
+  HostArray(const HostArray &) = delete;
+  HostArray &operator=(const HostArray &) = delete;
+  HostArray(HostArray &&other) noexcept : owner(other.owner), ptr(other.ptr), count(other.count), pinned(other.pinned) { other.ptr = nullptr; other.count = 0; }
+  HostArray &operator=(HostArray &&other) noexcept {
+    if (this != &other) {
+      Free();
+      owner = other.owner; ptr = other.ptr; count = other.count; pinned = other.pinned;
+      other.ptr = nullptr;
+      other.count = 0;
+    }
+    return *this;
+  }
+  ~HostArray() { Free(); }
+  void Allocate(bl_ctx *ctx, size_t n, bool pin) {
+    Free();
+    owner = ctx;
+    count = n;
+    if (n == 0) return;
+    // (pinning costs the runtime a pass over the pages: worth it for buffers that receive several images - the root level's, over a
+    // series - not for one download, which four host threads bring in at about the same rate; small arrays never)
+    ptr = (pin && n * sizeof(double) >= (8u << 20)) ? static_cast<double *>(bl_host_alloc(ctx, n * sizeof(double))) : nullptr;
+    pinned = ptr != nullptr;
+    if (!pinned) ptr = static_cast<double *>(std::malloc(n * sizeof(double)));
+    if (ptr == nullptr) {
+      std::cout << "Error: Could not allocate " << n * sizeof(double) << " bytes for the image.\n";
+      std::exit(1);
+    }
+  }
+  void Free() {
+    if (ptr != nullptr) {
+      if (pinned) bl_host_free(owner, ptr);
+      else std::free(ptr);
+    }
+    ptr = nullptr;
+    count = 0;
+  }
+  double *data() { return ptr; }
+  const double *data() const { return ptr; }
+};
+
 struct LevelShare {
   std::vector<int32_t> pixels;       // level 0: this device's pixels
   std::vector<int32_t> block_locs;   // refined levels: this device's blocks (v, u)
   std::vector<int64_t> where;        // position of each of its rays in the level's arrays
-  std::vector<double> image, camera, render;
+  HostArray image, camera, render;
   bl_stats stats{};
   int rc = BL_OK;
 };
@@ -186,6 +235,7 @@ int main(int argc, char *argv[]) {
   const int bs = params.adaptive_max_level > 0 ? params.adaptive_block_size : 1;
   const bool want_camera = params.has[BL_P_output_camera] && params.output_camera && params.output_format == BL_OUTPUT_NPZ;
 
+  HostArray root_image, root_camera, root_render;
   for (int run = 0; run < num_runs; run++) {
     if (simulation) {
       double t0 = Now();
@@ -255,7 +305,7 @@ int main(int argc, char *argv[]) {
     }
 
     // do { Integrate; if (!done) AddGeodesics } while (!done)   (blacklight.cpp:196-233)
-    std::vector<std::vector<double>> images, cameras, renders;
+    std::vector<HostArray> images, cameras, renders;   // refined levels; the root level's arrays outlive the run (root_image ...)
     const int n_render = bl_render_num_images(ctx);
     std::vector<std::vector<int32_t>> locs(1);
     std::vector<int32_t> counts = {bs > 0 && params.adaptive_max_level > 0 ? (res / bs) * (res / bs) : 0};
@@ -264,9 +314,16 @@ int main(int argc, char *argv[]) {
     while (true) {
       const long long n_rays = level == 0 ? static_cast<long long>(res) * res
                                           : static_cast<long long>(counts[level]) * bs * bs;
-      images.emplace_back(static_cast<size_t>(n_q) * n_rays);
-      cameras.emplace_back(want_camera ? static_cast<size_t>(n_rays) * 4 : 0);
-      renders.emplace_back(static_cast<size_t>(n_render) * 3 * n_rays);
+      if (level == 0 && root_image.count == static_cast<size_t>(n_q) * n_rays) {   // the root level's buffers: allocated once, pinned when a series fills them again and again
+        images.push_back(std::move(root_image));
+        cameras.push_back(std::move(root_camera));
+        renders.push_back(std::move(root_render));
+      } else {
+        const bool pin = level == 0 && num_runs > 1;
+        images.emplace_back(ctx, static_cast<size_t>(n_q) * n_rays, pin);
+        cameras.emplace_back(ctx, want_camera ? static_cast<size_t>(n_rays) * 4 : 0, pin);
+        renders.emplace_back(ctx, static_cast<size_t>(n_render) * 3 * n_rays, pin);
+      }
       bl_render_desc d = {};
       d.level = level;
       d.n_blocks = level == 0 ? 0 : counts[level];
@@ -303,9 +360,9 @@ int main(int argc, char *argv[]) {
             }
           }
           const size_t n_local = sh.where.size();
-          sh.image.resize(static_cast<size_t>(n_q) * n_local);
-          sh.camera.resize(want_camera ? n_local * 4 : 0);
-          sh.render.resize(static_cast<size_t>(n_render) * 3 * n_local);
+          sh.image.Allocate(contexts[dev], static_cast<size_t>(n_q) * n_local, false);
+          sh.camera.Allocate(contexts[dev], want_camera ? n_local * 4 : 0, false);
+          sh.render.Allocate(contexts[dev], static_cast<size_t>(n_render) * 3 * n_local, false);
         }
         std::vector<std::thread> workers;
         for (int dev = 0; dev < n_devices; dev++)
@@ -339,12 +396,17 @@ int main(int argc, char *argv[]) {
             return 1;
           }
           const size_t n_local = sh.where.size();
-          for (size_t i = 0; i < n_local; i++) {
+          // the share's rays back into the level's order, run by run: a tile's row (or a refined block) is consecutive on both sides
+          for (size_t i = 0; i < n_local;) {
             const size_t at = static_cast<size_t>(sh.where[i]);
-            for (int q = 0; q < n_q; q++) images.back()[static_cast<size_t>(q) * n_rays + at] = sh.image[static_cast<size_t>(q) * n_local + i];
-            for (int q = 0; q < 3 * n_render; q++) renders.back()[static_cast<size_t>(q) * n_rays + at] = sh.render[static_cast<size_t>(q) * n_local + i];
-            if (want_camera)
-              for (int c = 0; c < 4; c++) cameras.back()[4 * at + c] = sh.camera[4 * i + c];
+            size_t run = 1;
+            while (i + run < n_local && sh.where[i + run] == sh.where[i] + static_cast<int64_t>(run)) run++;
+            for (int q = 0; q < n_q; q++)
+              std::memcpy(images.back().data() + static_cast<size_t>(q) * n_rays + at, sh.image.data() + static_cast<size_t>(q) * n_local + i, run * sizeof(double));
+            for (int q = 0; q < 3 * n_render; q++)
+              std::memcpy(renders.back().data() + static_cast<size_t>(q) * n_rays + at, sh.render.data() + static_cast<size_t>(q) * n_local + i, run * sizeof(double));
+            if (want_camera) std::memcpy(cameras.back().data() + 4 * at, sh.camera.data() + 4 * i, run * 4 * sizeof(double));
+            i += run;
           }
           if (n_local == 0) continue;
           // kernel times add up over devices that worked side by side: keep the slowest device's, sum the counts
@@ -428,7 +490,13 @@ int main(int argc, char *argv[]) {
       std::cout << bl_last_error(ctx);
       return 1;
     }
+    root_image = std::move(images[0]);   // (kept for the next run)
+    root_camera = std::move(cameras[0]);
+    root_render = std::move(renders[0]);
   }
+  root_image.Free();
+  root_camera.Free();
+  root_render.Free();
   bl_stats last_stats{};
   bl_get_stats(contexts[0], &last_stats);   // (of the last root-level... of the last render of the first device: the tier is the context's)
   for (bl_ctx *c : contexts) bl_free(c);

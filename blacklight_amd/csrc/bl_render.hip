@@ -9,6 +9,8 @@
 // per ray where ray_max_steps allows 2 000 - is one chunk this way; sized for the worst case it was two.
 #include <sys/stat.h>
 
+#include <thread>
+
 #include "bl_ctx.h"
 
 namespace {
@@ -169,6 +171,16 @@ struct RenderJob {
   bool keepable = false;      // root level, geodesics integrated here: what this render leaves may serve the next (bl_set_geodesic_reuse)
   bool reuse = false;         // the resident records of an earlier render of this camera are shaded again: no geodesic stage
   bool reuse_located = false; // ... and its located samples: no locate kernel
+  bool raster = false;        // large host outputs (many image rows): rays in pixel order, so that a chunk is a range of columns of
+                              // every row and goes to the caller's buffer while the next chunk renders (DownloadChunk)
+  bool chunk_downloads = false;   // ... and this call does download chunk by chunk (more than one chunk, or a first chunk that left rays)
+  std::vector<std::thread> downloads;   // blocking copies into pageable memory, one host thread per chunk in flight
+  std::vector<hipError_t> download_status;
+  RenderJob() { download_status.reserve(4096); }
+  ~RenderJob() {
+    for (std::thread &t : downloads)
+      if (t.joinable()) t.join();
+  }
   std::vector<unsigned char> geo_key, located_key;
   int split_cus = 0;          // ... how many compute units
   double split_b_lo = 0.0, split_b_hi = 0.0;   // ... and which impact parameters
@@ -370,6 +382,12 @@ void PlanJob(RenderJob &job) {
   const BlAuxImages &AI = ctx->aux_images;
   job.rows_only = ctx->polarized && ctx->render_num_images == 0 && !fill_present && !(AI.image_time || AI.image_length || AI.image_lambda
       || AI.image_emission || AI.image_lambda_ave || AI.image_emission_ave || AI.image_tau_int || AI.image_crossings);
+  // Host outputs of a quarter of a GiB and more in eight rows or more (configuration 5: 64 frequencies): the rays are traced in pixel
+  // order - not the 8 x 8 tiles, centre first, that make chunks drain faster - so that what a chunk finishes is a range of columns,
+  // downloaded while the next chunk renders (the image rows of a 4096^2 x 64 frame are 8.6 GB: 0.7 s of PCIe that used to follow the
+  // last kernel)
+  job.raster = !d->outputs_on_device && d->level == 0 && d->pixel_map == nullptr && job.n_q >= 8
+      && static_cast<uint64_t>(job.n_q) * static_cast<uint64_t>(job.n_rays) * sizeof(double) >= (256ull << 20) && !job.geo_load && !job.geo_save && !job.sample_save;
 }
 
 // ---- geodesics once per series (bl_set_geodesic_reuse; reference: blacklight.cpp:93-94 against its run loop :178-250, and the
@@ -416,7 +434,7 @@ void BuildReuseKeys(RenderJob &job) {
   const unsigned long long map_hash = d->pixel_map != nullptr ? HashWords(d->pixel_map, static_cast<size_t>(d->n_rays)) : 0ull;
   key.Put(d->pixel_map != nullptr ? 1 : 0); key.Put(map_hash);
   // the layout of the records and what the stepper leaves out of them
-  key.Put(job.need_time ? 1 : 0); key.Put(job.interleaved ? 1 : 0); key.Put(job.composed ? 1 : 0); key.Put(job.skip_shell ? 1 : 0);
+  key.Put(job.need_time ? 1 : 0); key.Put(job.interleaved ? 1 : 0); key.Put(job.composed ? 1 : 0); key.Put(job.skip_shell ? 1 : 0); key.Put(job.raster ? 1 : 0);
   key.Put(job.skip_shell ? ctx->grid_outer_x1 : 0.0);
   // who steps which rays (the records' order; bl_stats says it)
   key.Put(ctx->tail_policy); key.Put(ctx->switches); key.Put(ctx->overlap_chunks); key.Put(ctx->num_cus);
@@ -826,7 +844,7 @@ void BuildTraceArgs(RenderJob &job) {
   ta.ray_max_steps = job.max_steps;
   ta.ray_max_retries = p.ray_integrator == BL_INTEGRATOR_DP ? p.ray_max_retries : 0;
   ta.n_rays_total = job.n_rays;
-  ta.swizzle_tiles = (d->level == 0 && d->pixel_map == nullptr && p.camera_resolution % 8 == 0 && job.n_rays == job.level_pixels)
+  ta.swizzle_tiles = (d->level == 0 && d->pixel_map == nullptr && p.camera_resolution % 8 == 0 && job.n_rays == job.level_pixels && !job.raster)
       ? p.camera_resolution : 0;
   // Order in which the 8x8 pixel tiles of a full frame are traced: centre of the image first. Rays near
   // the centre (photon ring, disc) are the long ones, the periphery is short; a chunk that ends on short
@@ -1736,6 +1754,9 @@ void CollectChunk(RenderJob &job, int k) {
   job.n_chunks++;
 }
 
+void DownloadChunk(RenderJob &job, long long begin, long long count);
+hipError_t DownloadColumns(const RenderJob &job, long long begin, long long count, int threads);
+
 // ---- all chunks of the call
 void RunChunks(RenderJob &job) {
   bl_ctx *ctx = job.ctx;
@@ -1811,6 +1832,12 @@ void RunChunks(RenderJob &job) {
     // moment, and a frame whose rays all use every step they may can see the gate close on that: the marked rays of a second chunk
     // would be lost. Rendered again with one stepper instead.)
     if (job.split_long && done < rays) throw SplitIncomplete{};
+    if (job.raster && job.n_slots == 1 && (job.chunk_downloads || begin + done < n_rays) && job.download_status.size() < 4000) {
+      job.chunk_downloads = true;
+      DownloadChunk(job, begin, done);   // (the chunk is complete: CollectChunk has waited for its kernels)
+    } else if (job.chunk_downloads) {
+      Check(DownloadColumns(job, begin, done, 1), "download of a chunk's outputs");
+    }
     begin += done;
   }
   const int oldest = job.n_chunks % job.n_slots;   // chunks are collected in order: the next one to collect sits on this set
@@ -1820,18 +1847,96 @@ void RunChunks(RenderJob &job) {
   Check(hipStreamSynchronize(stream), "kernel execution");
 }
 
-void DownloadOutputs(RenderJob &job) {
+// ---- results to the caller's host memory
+// Memory the runtime can copy into without staging (hipHostMalloc - bl_host_alloc - or hipHostRegister)
+bool IsPinnedHost(const void *p) {
+  hipPointerAttribute_t attr{};
+  if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+    (void)hipGetLastError();   // (plain malloc memory is "invalid value" to the runtime)
+    return false;
+  }
+  return attr.type == hipMemoryTypeHost;
+}
+
+// `rows` rows of `width` bytes each, device -> host, both sides with a pitch. Pinned destination: one copy at the link's rate. Pageable:
+// the runtime stages such a copy through a buffer of its own at ~16 GB/s per calling thread (measured: 537 MB of image rows in
+// 33.7 ms, round 5); `threads` host threads, each with a share of the rows (or of the bytes of a single row), overlap their stagings.
+hipError_t CopyToHost(int device, void *dst, size_t dst_pitch, const void *src, size_t src_pitch, size_t width, size_t rows, int threads) {
+  if (width == 0 || rows == 0) return hipSuccess;
+  if (dst_pitch == width && src_pitch == width) {   // contiguous: one long row, cut anywhere
+    width *= rows;
+    rows = 1;
+    dst_pitch = src_pitch = width;
+  }
+  const size_t total = width * rows;
+  if (IsPinnedHost(dst) || threads <= 1 || total < (32ull << 20)) return hipMemcpy2D(dst, dst_pitch, src, src_pitch, width, rows, hipMemcpyDeviceToHost);
+  std::vector<hipError_t> status(threads, hipSuccess);
+  std::vector<std::thread> workers;
+  for (int t = 0; t < threads; t++) {
+    workers.emplace_back([=, &status]() {
+      status[t] = hipSetDevice(device);
+      if (status[t] != hipSuccess) return;
+      if (rows == 1) {   // shares of the bytes, on 4 KiB boundaries
+        const size_t share = ((width + threads - 1) / threads + 4095) / 4096 * 4096;
+        const size_t first = std::min(width, share * t), last = std::min(width, share * (t + 1));
+        if (last > first) status[t] = hipMemcpy(static_cast<char *>(dst) + first, static_cast<const char *>(src) + first, last - first, hipMemcpyDeviceToHost);
+      } else {
+        const size_t first = rows * t / threads, last = rows * (t + 1) / threads;
+        if (last > first)
+          status[t] = hipMemcpy2D(static_cast<char *>(dst) + first * dst_pitch, dst_pitch, static_cast<const char *>(src) + first * src_pitch, src_pitch, width, last - first,
+                                  hipMemcpyDeviceToHost);
+      }
+    });
+  }
+  for (std::thread &w : workers) w.join();
+  for (hipError_t e : status)
+    if (e != hipSuccess) return e;
+  return hipSuccess;
+}
+
+// The outputs of the rays [begin, begin + count) of the call - columns of every row - with `threads` host threads
+hipError_t DownloadColumns(const RenderJob &job, long long begin, long long count, int threads) {
   bl_ctx *ctx = job.ctx;
   const bl_render_desc *d = job.d;
-  const long long n_rays = job.n_rays;
+  const size_t n_rays = static_cast<size_t>(job.n_rays), first = static_cast<size_t>(begin), n = static_cast<size_t>(count);
+  hipError_t err = hipSuccess;
+  auto rows = [&](void *dst, const void *src, size_t element, size_t n_rows) {   // [n_rows][n_rays] arrays of `element` bytes
+    if (dst == nullptr || err != hipSuccess) return;
+    err = CopyToHost(ctx->device, static_cast<char *>(dst) + first * element, n_rays * element, static_cast<const char *>(src) + first * element, n_rays * element, n * element, n_rows,
+                     threads);
+  };
+  if (job.n_q > 0) rows(d->image, job.image, sizeof(double), static_cast<size_t>(job.n_q));
+  rows(d->sample_num, job.out_num, sizeof(int), 1);
+  rows(d->sample_flags, job.out_flags, 1, 1);
+  rows(d->camera_pos, job.cam_pos, 32, 1);   // [n_rays][4]
+  rows(d->camera_dir, job.cam_dir, 32, 1);
+  if (ctx->render_num_images > 0) rows(d->render, job.render_out, sizeof(double), static_cast<size_t>(ctx->render_num_images) * 3);
+  return err;
+}
+
+// A finished chunk's columns on their way while the next chunk renders (RenderJob::raster): a host thread of its own, since a copy into
+// pageable memory blocks the thread that asks for it
+void DownloadChunk(RenderJob &job, long long begin, long long count) {
+  job.download_status.push_back(hipSuccess);
+  hipError_t *status = &job.download_status.back();
+  const RenderJob *const_job = &job;
+  const int device = job.ctx->device;
+  job.downloads.emplace_back([=]() {
+    *status = hipSetDevice(device);
+    if (*status == hipSuccess) *status = DownloadColumns(*const_job, begin, count, 1);
+  });
+}
+
+void DownloadOutputs(RenderJob &job) {
+  const bl_render_desc *d = job.d;
   if (d->outputs_on_device) return;
-  if (job.n_q > 0) Check(hipMemcpy(d->image, job.image, static_cast<size_t>(job.n_q) * n_rays * sizeof(double), hipMemcpyDeviceToHost), "image download");
-  if (d->sample_num != nullptr) Check(hipMemcpy(d->sample_num, job.out_num, n_rays * sizeof(int), hipMemcpyDeviceToHost), "sample_num download");
-  if (d->sample_flags != nullptr) Check(hipMemcpy(d->sample_flags, job.out_flags, n_rays, hipMemcpyDeviceToHost), "flags download");
-  if (d->camera_pos != nullptr) Check(hipMemcpy(d->camera_pos, job.cam_pos, static_cast<size_t>(n_rays) * 32, hipMemcpyDeviceToHost), "camera_pos download");
-  if (d->camera_dir != nullptr) Check(hipMemcpy(d->camera_dir, job.cam_dir, static_cast<size_t>(n_rays) * 32, hipMemcpyDeviceToHost), "camera_dir download");
-  if (ctx->render_num_images > 0)
-    Check(hipMemcpy(d->render, job.render_out, static_cast<size_t>(ctx->render_num_images) * 3 * n_rays * sizeof(double), hipMemcpyDeviceToHost), "render download");
+  if (job.chunk_downloads) {   // every chunk went as it finished
+    for (std::thread &t : job.downloads)
+      if (t.joinable()) t.join();
+    for (hipError_t e : job.download_status) Check(e, "download of a chunk's outputs");
+    return;
+  }
+  Check(DownloadColumns(job, 0, job.n_rays, 4), "download of the outputs");
 }
 
 // bl_stats of the call, and the reference's warning about rays that ended unexpectedly (geodesics.cpp:389-394)

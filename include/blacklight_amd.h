@@ -425,6 +425,14 @@ BL_API int bl_set_caller_stream(bl_ctx *ctx, void *stream, int enabled);
  * about geodesics that end unexpectedly is raised by the render that integrated them, once. on = 0: every render integrates its
  * rays (what a benchmark of the whole pipeline wants: bench.py's headline). */
 BL_API int bl_set_geodesic_reuse(bl_ctx *ctx, int on);
+/* Host memory the device copies into at the link's rate (pinned: hipHostMalloc). bl_render recognises such buffers among the pointers
+ * of bl_render_desc - and any the caller pinned itself (hipHostRegister) - and downloads into them with one asynchronous-engine copy
+ * (537 MB of image rows: ~10 ms) where pageable memory goes through the runtime's staging buffer (~16 GB/s per thread; bl_render
+ * then splits the copy over four host threads). Large results in many rows (eight image rows or more, a quarter of a GiB or more)
+ * leave chunk by chunk while the next chunk renders, whichever kind of memory receives them. NULL when the allocation fails or
+ * the context is host-only: fall back to malloc. Free with bl_host_free (NULL is fine). */
+BL_API void *bl_host_alloc(bl_ctx *ctx, size_t bytes);
+BL_API void bl_host_free(bl_ctx *ctx, void *p);
 /* Cap on scratch HBM (bytes) used for per-sample records; default four fifths of the device's memory (MI355X: 230 GB of 288). */
 BL_API int bl_set_scratch_limit(bl_ctx *ctx, uint64_t bytes);
 /* on != 0: when a render needs several chunks, run the geodesic kernel of chunk c + 1 on a second stream

@@ -209,3 +209,34 @@ def test_the_arithmetic_tier_from_the_environment_is_parsed_strictly(built_libra
     monkeypatch.setenv("BLACKLIGHT_AMD_TAIL_POLICY", "quadd")
     with pytest.raises(bl.BlacklightError, match="BLACKLIGHT_AMD_TAIL_POLICY"):
         bl.Context(p, device=BL_DEVICE_NONE)
+
+
+def test_large_records_are_written_by_several_threads_with_the_same_bytes(built_library, tmp_path):
+    """Records of 32 MiB and more get their CRC-32 from slices computed side by side and combined (GF(2) algebra of the CRC register),
+    and their bytes from several pwrite calls (bl_host.cpp): the file must be the ZIP the single-threaded writer produces - every
+    member's stored CRC equal to zlib's over its bytes, the array equal to what went in, stored entries at the offsets the headers name."""
+    import zlib
+    import blacklight_amd as bl
+    fx, params, _ = gu.load_case("formula_64")
+    res = 512
+    q = dict(params, camera_resolution=res, image_num_frequencies=20, image_frequency_start=1.0e11, image_frequency_end=3.0e11,
+             image_frequency_spacing="log")
+    ctx = bl.Context(bl.Params.from_dict(q), device=BL_DEVICE_NONE)
+    image = np.random.default_rng(5).standard_normal((ctx.num_quantities, res * res))
+    assert image.nbytes > (32 << 20)
+    path = tmp_path / "large.npz"
+    ctx.write_output([dict(image=image, block_locs=None)], path=path)
+    ctx.close()
+    with zipfile.ZipFile(path) as z:
+        assert z.testzip() is None
+        info = z.getinfo("I_nu.npy")
+        assert info.compress_type == zipfile.ZIP_STORED and info.file_size == image.nbytes + 128
+        with open(path, "rb") as f:   # the member's bytes where the local header says they are
+            f.seek(info.header_offset)
+            local = f.read(30)
+            name_len, extra_len = struct.unpack("<HH", local[26:30])
+            f.seek(info.header_offset + 30 + name_len + extra_len)
+            member = f.read(info.file_size)
+        assert zlib.crc32(member) == info.CRC
+        assert member[128:] == image.tobytes()
+    assert np.array_equal(np.load(path)["I_nu"].reshape(image.shape), image)
