@@ -236,6 +236,7 @@ int main(int argc, char *argv[]) {
   const bool want_camera = params.has[BL_P_output_camera] && params.output_camera && params.output_format == BL_OUTPUT_NPZ;
 
   HostArray root_image, root_camera, root_render;
+  bool have_root = false;
   for (int run = 0; run < num_runs; run++) {
     if (simulation) {
       double t0 = Now();
@@ -314,7 +315,7 @@ int main(int argc, char *argv[]) {
     while (true) {
       const long long n_rays = level == 0 ? static_cast<long long>(res) * res
                                           : static_cast<long long>(counts[level]) * bs * bs;
-      if (level == 0 && root_image.count == static_cast<size_t>(n_q) * n_rays) {   // the root level's buffers: allocated once, pinned when a series fills them again and again
+      if (level == 0 && have_root) {   // the root level's buffers: allocated once, pinned when a series fills them again and again
         images.push_back(std::move(root_image));
         cameras.push_back(std::move(root_camera));
         renders.push_back(std::move(root_render));
@@ -490,6 +491,7 @@ int main(int argc, char *argv[]) {
       std::cout << bl_last_error(ctx);
       return 1;
     }
+    have_root = true;
     root_image = std::move(images[0]);   // (kept for the next run)
     root_camera = std::move(cameras[0]);
     root_render = std::move(renders[0]);

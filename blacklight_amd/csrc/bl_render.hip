@@ -1936,7 +1936,7 @@ void DownloadOutputs(RenderJob &job) {
     for (hipError_t e : job.download_status) Check(e, "download of a chunk's outputs");
     return;
   }
-  Check(DownloadColumns(job, 0, job.n_rays, 4), "download of the outputs");
+  Check(DownloadColumns(job, 0, job.n_rays, 1), "download of the outputs");   // (pageable memory: several threads bring nothing - measured, 4 threads 41.6 ms against 33.7 for 537 MB: the pages' first touch is what it waits for)
 }
 
 // bl_stats of the call, and the reference's warning about rays that ended unexpectedly (geodesics.cpp:389-394)
