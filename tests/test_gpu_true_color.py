@@ -116,7 +116,9 @@ def test_true_color_at_size_is_independent_of_how_it_is_split(built_library):
 def test_many_frequency_frames_download_chunk_by_chunk_with_the_same_bits():
     """Large host outputs in many rows (>= 8 image rows, >= 256 MiB: configuration 5's kind) are traced in pixel order and leave chunk by
     chunk while the next chunk renders (bl_render.hip: RenderJob::raster, DownloadChunk), into pageable or pinned memory
-    (Context.pinned_array / bl_host_alloc). The frame must be the one a render into device memory gives - tile order, one download."""
+    (Context.pinned_array / bl_host_alloc). The frame must be the one a render into device memory gives - tile order, one download:
+    bit for bit in the exact tier; in the tolerant tier to rounding (its many-frequency kernel is reproducible from run to run to the
+    last bit but one or two pixels in a million, whichever way the frame is produced: DESIGN.md, open points)."""
     import torch
     import bench
     import blacklight_amd as bl
@@ -130,22 +132,27 @@ def test_many_frequency_frames_download_chunk_by_chunk_with_the_same_bits():
     with bl.Context(bl.Params.from_dict(params)) as ctx:
         ctx.set_geodesic_reuse(False)
         ctx.set_grid(grid)
-        ctx.set_arithmetic("tolerant")
-        on_device = torch.zeros((n_freq, n), dtype=torch.float64, device="cuda")
-        num_device = torch.zeros(n, dtype=torch.int32, device="cuda")
-        st = ctx.render_device(on_device.data_ptr(), n, sample_num_ptr=num_device.data_ptr())
-        torch.cuda.synchronize()
-        assert st.n_chunks == 1
-        want, want_num = on_device.cpu().numpy(), num_device.cpu().numpy()
-        whole = ctx.render()                      # one chunk, pageable memory
-        assert whole["stats"].n_chunks == 1
-        ctx.set_scratch_limit(24 << 30)
-        chunked = ctx.render()                    # several chunks, each downloaded as it finishes, pageable memory
-        assert chunked["stats"].n_chunks >= 3, chunked["stats"].n_chunks
         pinned = dict(image=ctx.pinned_array((n_freq, n)), sample_num=ctx.pinned_array(n, np.int32), sample_flags=ctx.pinned_array(n, np.uint8))
-        pinned["image"][:] = -1.0
-        into_pinned = ctx.render(out=pinned)      # ... into pinned memory
-        assert into_pinned["stats"].n_chunks >= 3 and into_pinned["image"] is pinned["image"]
-        for got in (whole, chunked, into_pinned):
-            assert np.array_equal(got["sample_num"], want_num)
-            assert gu.same_bits(got["image"], want).all()
+        for tier, limit in (("exact", 48 << 30), ("tolerant", 24 << 30)):
+            ctx.set_arithmetic(tier)
+            ctx.set_scratch_limit(200 << 30)
+            on_device = torch.zeros((n_freq, n), dtype=torch.float64, device="cuda")
+            num_device = torch.zeros(n, dtype=torch.int32, device="cuda")
+            st = ctx.render_device(on_device.data_ptr(), n, sample_num_ptr=num_device.data_ptr())
+            torch.cuda.synchronize()
+            want, want_num = on_device.cpu().numpy(), num_device.cpu().numpy()
+            whole = ctx.render()                      # pageable memory, the download after the last chunk
+            ctx.set_scratch_limit(limit)
+            chunked = ctx.render()                    # several chunks, each downloaded as it finishes, pageable memory
+            assert chunked["stats"].n_chunks >= 3 > whole["stats"].n_chunks, (chunked["stats"].n_chunks, whole["stats"].n_chunks)
+            pinned["image"][:] = -1.0
+            into_pinned = ctx.render(out=pinned)      # ... into pinned memory
+            assert into_pinned["stats"].n_chunks >= 3 and into_pinned["image"] is pinned["image"]
+            for got in (whole, chunked, into_pinned):
+                assert np.array_equal(got["sample_num"], want_num)
+                if tier == "exact":
+                    assert gu.same_bits(got["image"], want).all()
+                else:
+                    assert np.array_equal(np.isnan(got["image"]), np.isnan(want))
+                    with np.errstate(invalid="ignore"):
+                        assert np.nanmax(np.abs(got["image"] - want) / np.abs(want)) < 1.0e-14
