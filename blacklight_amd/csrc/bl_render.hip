@@ -297,7 +297,8 @@ void PlanJob(RenderJob &job) {
   const bool tau_only = job.aux && !ctx->polarized && p.image_light && rows.image_tau && ctx->render_num_images == 0 && !job.geo_load && !job.geo_save
       && !(rows.image_time || rows.image_length || rows.image_lambda || rows.image_emission || rows.image_lambda_ave || rows.image_emission_ave
            || rows.image_tau_int || rows.image_crossings);
-  job.fast = ctx->arithmetic == BL_ARITH_TOLERANT && job.simulation && (!job.aux || tau_only) && !ctx->polarized && !job.slow && !job.block_interp
+  // (inter-block interpolation and slow light: bl_shade_fast_kernel behind their locate kernels, primitives by the exact tier's sampling)
+  job.fast = ctx->arithmetic == BL_ARITH_TOLERANT && job.simulation && (!job.aux || tau_only) && !ctx->polarized
       && p.plasma_kappa_frac == 0.0 && p.plasma_model != BL_PLASMA_CODE_KAPPA
       && !p.ray_flat && ctx->plasma_thermal_frac != 0.0
       && job.n_nu <= 1024;   // (its LDS table holds five numbers per frequency)
@@ -319,7 +320,7 @@ void PlanJob(RenderJob &job) {
   // optional geometric cut locates its samples inside the coefficient kernel: no located samples in HBM at all
   // (one frequency - with four or more it ends at the sample's factors, which no frequency enters: BlFreqInputs - over a single block
   // with evenly spaced faces, bl_fused2_applicable; everything else goes through a locate kernel and bl_shade_fast_kernel)
-  job.fused2 = job.fast && !job.tau_row && ctx->grid_dev.n_blocks == 0 && ctx->lds_table_bytes > 0 && !ctx->grid_dev.fmks && p.simulation_interp && p.plasma_power_frac == 0.0
+  job.fused2 = job.fast && !job.tau_row && !job.slow && ctx->grid_dev.n_blocks == 0 && ctx->lds_table_bytes > 0 && !ctx->grid_dev.fmks && p.simulation_interp && p.plasma_power_frac == 0.0
       && p.simulation_coord == BL_COORD_SKS   // (its locate step is the spherical one: Cartesian grids go through the locate kernel)
       && !(p.cut_omit_near || p.cut_omit_far || p.cut_omit_in >= 0.0 || p.cut_omit_out >= 0.0 || p.cut_midplane_theta != 0.0 || p.cut_midplane_z != 0.0 || p.cut_plane)
       && !job.sample_save && !(ctx->switches & (BL_SWITCH_NO_FUSED_LOCATE | BL_SWITCH_SPLIT_RECORDS))   // (a sample checkpoint is made of the located samples)

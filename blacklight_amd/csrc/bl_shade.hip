@@ -600,7 +600,7 @@ extern "C" hipError_t bl_launch_shade_redo(const BlShadeArgs *args, int model, i
   const bool spin_zero = args->st.bh_a == 0.0;
   const bool fused = args->located == nullptr;
   const bool cartesian = !fused && args->plasma.simulation_coord == BL_COORD_CKS;
-  const bool power_law = !fused && (args->plasma.power_frac != 0.0 || args->tau_inc != nullptr);
+  const bool power_law = !fused && (args->plasma.power_frac != 0.0 || args->tau_inc != nullptr || args->anchors != nullptr || args->slow.n > 0);   // (the extended instantiation)
   // (the common case - behind a kernel with the locate step inside - knows zero spin at compile time)
 #define BL_LAUNCH_R(EXTENDED, SKS) hipLaunchKernelGGL((bl_shade_kernel<BL_MODEL_SIMULATION, false, EXTENDED, SKS, false, false, true>), dim3(grid), dim3(256), 0, stream, *args)
   if (cartesian) BL_LAUNCH_R(true, false);

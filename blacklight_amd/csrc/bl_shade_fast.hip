@@ -374,6 +374,10 @@ __global__ void __launch_bounds__(256, BL_FAST_WAVES) bl_shade_fast_kernel(const
 #pragma unroll
   for (int c = 0; c < 8; c++) lo[c] = hi[c] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   fast_load_located(P, have_next ? idx : last, loc_next);
+  // Inter-block interpolation and slow light (the general instantiation; wave-uniform): the primitives come from the exact tier's own
+  // sampling functions - eight anchor cells named by the locate kernel, one or two time slices - read where they lie, not through
+  // the pipelined corner reads; what the tier saves there is the arithmetic behind them (simulation_sampling.cpp:505-546, :736-912)
+  const bool sampled_elsewhere = kGeneral && (P.anchors != nullptr || P.slow.n > 0);
   while (have_prev || have_cur || have_next) {
     // (a dead record slot carries tag 0 = kSampleNone from the locate kernel: cell 0 was requested for it)
     const uint32_t ray = have_prev ? (uint32_t)__double_as_longlong(ray_prev.q1.y) : BL_DEAD_RAY;
@@ -384,9 +388,21 @@ __global__ void __launch_bounds__(256, BL_FAST_WAVES) bl_shade_fast_kernel(const
     const double kt = P.ray_kt[live ? ray : 0u], momentum_factor = P.ray_factor[live ? ray : 0u];
     const size_t row = (size_t)P.ray_offset[live ? ray : 0u] + n;
     float pr[8];
-    const bool near_midpoint = gather_finish_tolerant(P, (float)fast_table[42], (float)fast_table[43], live ? status : (int)kSampleNone, lo, hi,
-                                                      loc_prev.l0.x, loc_prev.l0.y, loc_prev.l1.x, pr);
-    gather_issue(P, have_cur ? (int)(loc_cur.tag >> 32) & 0xff : (int)kSampleNone, (uint32_t)loc_cur.tag, lo, hi);
+    bool near_midpoint = gather_finish_tolerant(P, (float)fast_table[42], (float)fast_table[43], (live && !sampled_elsewhere) ? status : (int)kSampleNone, lo, hi,
+                                                loc_prev.l0.x, loc_prev.l0.y, loc_prev.l1.x, pr);
+    if (kGeneral && sampled_elsewhere && live) {
+      float kappa_unused;
+      const unsigned int *anchors = P.anchors != nullptr ? P.anchors + idx_prev * 8 : nullptr;
+      if (P.slow.n > 0)
+        sample_primitives_slow(P, status, (uint32_t)loc_prev.tag, anchors, (int)(loc_prev.tag >> 40), P.slow.frac[idx_prev], loc_prev.l0.x, loc_prev.l0.y, loc_prev.l1.x,
+                               pr, &kappa_unused);
+      else if (status == kSampleAdvanced)
+        sample_primitives_advanced(P, anchors, loc_prev.l0.x, loc_prev.l0.y, loc_prev.l1.x, pr, &kappa_unused);
+      else
+        sample_primitives(P, status, (uint32_t)loc_prev.tag, loc_prev.l0.x, loc_prev.l0.y, loc_prev.l1.x, pr);
+      near_midpoint = false;   // (the exact tier's values: nothing to guard)
+    }
+    gather_issue(P, (have_cur && !sampled_elsewhere) ? (int)(loc_cur.tag >> 32) & 0xff : (int)kSampleNone, (uint32_t)loc_cur.tag, lo, hi);
     fast_load_ray(P, have_cur ? idx_cur : last, ray_cur);
     const FastRay rec = ray_prev;
     const unsigned long long idx_rec = idx_prev;
@@ -539,8 +555,9 @@ extern "C" hipError_t bl_launch_shade_fast(const BlShadeArgs *args, int grid, hi
     return bl_launch_shade_redo(args, BL_MODEL_SIMULATION, grid, stream);
   }
   const size_t lds = (44 + 5 * args->n_nu) * sizeof(double);
-  // power laws, Cartesian grids and an optical-depth image go through the general instantiation
-  const bool general = args->plasma.power_frac != 0.0 || args->tau_inc != nullptr || args->plasma.simulation_coord == BL_COORD_CKS;
+  // power laws, Cartesian grids, an optical-depth image, inter-block interpolation and slow light go through the general instantiation
+  const bool general = args->plasma.power_frac != 0.0 || args->tau_inc != nullptr || args->plasma.simulation_coord == BL_COORD_CKS || args->anchors != nullptr
+      || args->slow.n > 0;
 #define BL_LAUNCH_F(SPIN, GENERAL) hipLaunchKernelGGL((bl_shade_fast_kernel<SPIN, GENERAL>), dim3(grid), dim3(256), lds, stream, *args)
   if (general) {
     BL_LAUNCH_F(false, true);

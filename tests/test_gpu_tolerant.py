@@ -34,8 +34,8 @@ def _applies(params):
         cuts = (on("cut_omit_near") or on("cut_omit_far") or float(params.get("cut_omit_in", -1.0)) >= 0.0 or float(params.get("cut_omit_out", -1.0)) >= 0.0
                 or float(params.get("cut_midplane_theta", 0.0)) != 0.0 or float(params.get("cut_midplane_z", 0.0)) != 0.0 or on("cut_plane"))
         return not aux and not cuts
-    return (params["model_type"] == "simulation" and not aux and not on("image_polarization") and not on("slow_light_on")
-            and not on("simulation_block_interp")
+    # (inter-block interpolation and slow light since round 6: bl_shade_fast_kernel behind their locate kernels)
+    return (params["model_type"] == "simulation" and not aux and not on("image_polarization")
             and float(params.get("plasma_kappa_frac", 0.0)) == 0.0 and params.get("plasma_model", "ti_te_beta") == "ti_te_beta"
             and not on("ray_flat") and on("image_light"))
 
@@ -435,3 +435,77 @@ def test_tolerant_tier_at_the_benchmark_size(built_library):
                 dist = np.nanmax(np.abs(got - want)) / np.nanmax(np.abs(want))
                 print(f"windows vs reference tier {tier}: {dist:.2e}")
                 assert dist < (EXPECTED if tier == "B" else TOLERANCE)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_tolerant_tier_with_inter_block_interpolation(seed, built_library):
+    """simulation_block_interp (simulation_sampling.cpp:505-546, :1068-1321) in the tolerant tier (round 6): the primitives are the exact
+    tier's - eight anchor cells named by the locate kernel, InterpolateAdvanced's weights - the arithmetic behind them the tier's.
+    Meshes: equal blocks, and the two-level refined mesh; cameras, spins, cuts and frequency lists drawn."""
+    rng = np.random.default_rng(9300 + seed)
+    fx, params, mock_args = gu.load_case("sim_blockinterp" if seed % 2 == 0 else "sim_blockinterp_refined")
+    over = dict(camera_resolution=20, camera_th=float(rng.uniform(10.0, 170.0)), camera_ph=float(rng.uniform(0.0, 360.0)),
+                camera_width=float(rng.uniform(10.0, 30.0)), simulation_a=float(rng.choice([0.0, 0.5, 0.9])),
+                plasma_rat_high=float(rng.uniform(3.0, 40.0)), cut_sigma_max=float(rng.choice([-1.0, 1.0, 10.0])),
+                cut_theta_e_max=float(rng.choice([-1.0, 50.0])), image_num_frequencies=int(rng.choice([1, 1, 5])))
+    if over["image_num_frequencies"] > 1:
+        over.update(image_frequency_start=1.0e11, image_frequency_end=float(10.0 ** rng.uniform(11.3, 12.0)), image_frequency_spacing="log")
+    params = dict(params, **over)
+    assert _applies(params) and str(params["simulation_block_interp"]) == "true"
+    import blacklight_amd as bl
+    grid = gu.golden_grid(mock_args)
+    out = {}
+    with bl.Context(bl.Params.from_dict(params)) as ctx:
+        ctx.set_undefined_policy("edge")   # (the drawn cameras may reach the upper edges of the file's last block)
+        ctx.set_grid(grid)
+        for tier in ("exact", "tolerant"):
+            ctx.set_arithmetic(tier)
+            ctx.clear_warnings()
+            out[tier] = ctx.render()
+    exact, tol = out["exact"], out["tolerant"]
+    assert tol["stats"].arithmetic == 1 and exact["stats"].arithmetic == 0 and tol["stats"].launches_locate == 1
+    assert np.array_equal(tol["sample_num"], exact["sample_num"]) and np.array_equal(tol["sample_flags"], exact["sample_flags"])
+    assert tol["stats"].n_gathers == exact["stats"].n_gathers and tol["stats"].n_undefined == exact["stats"].n_undefined
+    assert np.array_equal(np.isnan(tol["image"]), np.isnan(exact["image"])), over
+    d = _distance(tol["image"], exact["image"])
+    print(f"seed {seed}: {d:.2e}, deferred {tol['stats'].n_deferred}")
+    assert d < EXPECTED, over
+    assert np.isfinite(exact["image"]).mean() > 0.5 and np.nanmax(exact["image"]) > 0.0
+
+
+@pytest.mark.parametrize("case", ["slow_interp", "slow_nearest"])
+def test_tolerant_tier_with_slow_light(case, built_library):
+    """slow_light_on (simulation_sampling.cpp:296-349, :736-912) in the tolerant tier (round 6): every image of the fixtures' series,
+    one frequency and four, against the exact tier - whose images are the reference's (tests/test_gpu_slow_light.py)."""
+    import blacklight_amd as bl
+    fx = np.load(os.path.join(gu.GOLDEN_DIR, f"{case}.npz"), allow_pickle=False)
+    base = json.loads(str(fx["params"]))
+    grids = gu.slow_light_grids(fx)
+    file_times = [float(t) for t in fx["file_times"]]
+    for n_freq in (1, 4):
+        params = dict(base, image_num_frequencies=n_freq)
+        if n_freq > 1:
+            params.update(image_frequency_start=1.0e11, image_frequency_end=6.0e11, image_frequency_spacing="log")
+        assert _applies(params)
+        images = {}
+        for tier in ("exact", "tolerant"):
+            with bl.Context(bl.Params.from_dict(params)) as ctx:
+                ctx.set_arithmetic(tier)
+                held, got = None, []
+                for image, (t_cam, files) in enumerate(gu.slow_light_windows(params, file_times)):
+                    new = len(files) if held is None or files[0] - held[0] >= len(files) else files[0] - held[0]
+                    if 0 < new < len(files):
+                        ctx.shift_grid_slices(new)
+                    for n in range(new):
+                        ctx.set_grid_slice(n, grids[files[n]], file_times[files[n]])
+                    held = files
+                    ctx.set_snapshot(image)
+                    out = ctx.render()
+                    assert out["stats"].arithmetic == (1 if tier == "tolerant" else 0)
+                    got.append(out)
+                images[tier] = got
+        for image, (e, t) in enumerate(zip(images["exact"], images["tolerant"])):
+            assert np.array_equal(t["sample_num"], e["sample_num"]) and np.array_equal(t["sample_flags"], e["sample_flags"])
+            assert np.array_equal(np.isnan(t["image"]), np.isnan(e["image"])), (case, n_freq, image)
+            assert _distance(t["image"], e["image"]) < EXPECTED, (case, n_freq, image)
+        assert np.nanmax(images["exact"][0]["image"]) > 0.0
