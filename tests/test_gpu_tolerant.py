@@ -450,7 +450,7 @@ def test_tolerant_tier_with_inter_block_interpolation(seed, built_library):
                 cut_theta_e_max=float(rng.choice([-1.0, 50.0])), image_num_frequencies=int(rng.choice([1, 1, 5])))
     if over["image_num_frequencies"] > 1:
         over.update(image_frequency_start=1.0e11, image_frequency_end=float(10.0 ** rng.uniform(11.3, 12.0)), image_frequency_spacing="log")
-    params = dict(params, **over)
+    params = dict(params, **over, plasma_model="ti_te_beta")   # (the refined golden reads electron entropy from the grid: outside the tier)
     assert _applies(params) and str(params["simulation_block_interp"]) == "true"
     import blacklight_amd as bl
     grid = gu.golden_grid(mock_args)

@@ -54,7 +54,7 @@ def test_reference_windows_of_the_benchmark_frame(built_library):
     assert above == 0 and worst < 1.0e-6, (worst, above, compared)
     assert worst < 1.0e-10, worst   # (measured 2e-14: what the tier actually delivers here)
     dim = want_b[np.isfinite(want_b) & (want_b > 0.0)]
-    assert dim.max() / dim.min() > 1.0e3   # (the window does hold dim pixels: an L-infinity over the image maximum would not see them)
+    assert dim.max() / dim.min() > 3.0e2   # (the windows do hold dim pixels - 1 / 600 of the brightest: an L-infinity over the image maximum would not see them)
 
 
 FORMULA_FIXTURE = os.path.join(gu.GOLDEN_DIR, "window_512_formula.npz")
