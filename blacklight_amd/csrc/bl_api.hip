@@ -686,19 +686,46 @@ void UploadRefinedGrid(bl_ctx *ctx, const bl_grid_desc *g) {
     Check(hipMemcpy(d_kappa.ptr, g->prim + static_cast<size_t>(g->ind_kappa) * n_cells, n_cells * sizeof(float),
                     hipMemcpyHostToDevice), "grid upload");
   }
-  // coordinate rows of every block, then the block boundaries
+  // Coordinate rows, each distinct one once (faces and centres of a block along an axis, compared bit for bit: blocks of one level at
+  // one position share them), which row every block uses, the first centre of the next block of the file (what the reference reads one
+  // past a block's last centre), then the block boundaries
   std::vector<double> coords;
-  size_t off_f[3], off_v[3], off_e[3];
+  std::vector<int> block_row(static_cast<size_t>(n_b) * 3);
+  size_t off_f[3], off_v[3], off_e[3], off_n[3];
+  int n_rows[3];
   for (int a = 0; a < 3; a++) {
+    const size_t row_len = static_cast<size_t>(nb[a]) * 2 + 1;
+    std::map<std::vector<unsigned long long>, int> seen;   // (rows compared word for word: the same bits, not merely equal values)
+    std::vector<const double *> row_f, row_v;
+    for (int blk = 0; blk < n_b; blk++) {
+      const double *f = block_xf[a] + static_cast<size_t>(blk) * (nb[a] + 1), *v = block_xv[a] + static_cast<size_t>(blk) * nb[a];
+      std::vector<unsigned long long> key(row_len);
+      std::memcpy(key.data(), f, (static_cast<size_t>(nb[a]) + 1) * sizeof(double));
+      std::memcpy(key.data() + nb[a] + 1, v, static_cast<size_t>(nb[a]) * sizeof(double));
+      auto found = seen.find(key);
+      if (found == seen.end()) {
+        found = seen.emplace(std::move(key), static_cast<int>(row_f.size())).first;
+        row_f.push_back(f);
+        row_v.push_back(v);
+      }
+      block_row[static_cast<size_t>(a) * n_b + blk] = found->second;
+    }
+    n_rows[a] = static_cast<int>(row_f.size());
     off_f[a] = coords.size();
-    coords.insert(coords.end(), block_xf[a], block_xf[a] + static_cast<size_t>(n_b) * (nb[a] + 1));
+    for (const double *f : row_f) coords.insert(coords.end(), f, f + nb[a] + 1);
     off_v[a] = coords.size();
-    coords.insert(coords.end(), block_xv[a], block_xv[a] + static_cast<size_t>(n_b) * nb[a]);
+    for (const double *v : row_v) coords.insert(coords.end(), v, v + nb[a]);
+    off_n[a] = coords.size();
+    for (int blk = 0; blk < n_b; blk++)
+      coords.push_back(blk + 1 < n_b ? block_xv[a][static_cast<size_t>(blk + 1) * nb[a]] : std::numeric_limits<double>::quiet_NaN());
     off_e[a] = coords.size();
     coords.insert(coords.end(), edge[a].begin(), edge[a].end());
   }
   ctx->d_coords.Ensure(coords.size());
   Check(hipMemcpy(ctx->d_coords.ptr, coords.data(), coords.size() * sizeof(double), hipMemcpyHostToDevice), "coordinate upload");
+  // (the lattice, then the blocks' rows)
+  const size_t lattice_ints = lattice.size();
+  lattice.insert(lattice.end(), block_row.begin(), block_row.end());
   ctx->d_lattice.Ensure(lattice.size());
   Check(hipMemcpy(ctx->d_lattice.ptr, lattice.data(), lattice.size() * sizeof(int), hipMemcpyHostToDevice), "lattice upload");
   BlGridDevice dev{};
@@ -711,6 +738,9 @@ void UploadRefinedGrid(bl_ctx *ctx, const bl_grid_desc *g) {
   for (int a = 0; a < 3; a++) {
     dev.bxf[a] = ctx->d_coords.ptr + off_f[a];
     dev.bxv[a] = ctx->d_coords.ptr + off_v[a];
+    dev.xv_next[a] = ctx->d_coords.ptr + off_n[a];
+    dev.block_row[a] = ctx->d_lattice.ptr + lattice_ints + static_cast<size_t>(a) * n_b;
+    dev.n_rows[a] = n_rows[a];
     dev.edge[a] = ctx->d_coords.ptr + off_e[a];
     dev.n_edge[a] = n_edge[a];
     dev.n[a] = nb[a];
@@ -758,6 +788,18 @@ void UploadRefinedGrid(bl_ctx *ctx, const bl_grid_desc *g) {
     dev.hash_mask = slots - 1;
     dev.max_level = max_level;
     dev.n_3_level0 = g->n_3_root / nb[2];
+  }
+  {
+    // what bl_locate_kernel<kRefined> stages in LDS when it fits (four workgroups to a compute unit: 36 KiB each): block boundaries,
+    // lattice, rows, the blocks' rows and next centres, and with inter-block interpolation the MeshBlock table and its hash
+    size_t doubles = 0, ints = lattice_ints + static_cast<size_t>(n_b) * 3;
+    for (int a = 0; a < 3; a++) doubles += static_cast<size_t>(n_edge[a]) + 1 + static_cast<size_t>(n_rows[a]) * (2 * nb[a] + 1) + n_b;
+    if (dev.block_interp) {
+      doubles += dev.hash_mask + 1;                                        // (the keys: 8 bytes each)
+      ints += static_cast<size_t>(n_b) * 4 + dev.hash_mask + 1;
+    }
+    const size_t bytes = doubles * sizeof(double) + (ints + 3) / 4 * 4 * sizeof(int);
+    dev.refined_lds_bytes = bytes <= 36u * 1024u ? static_cast<int>(bytes) : 0;
   }
   ctx->grid_dev = dev;
   ctx->lds_table_bytes = 0;

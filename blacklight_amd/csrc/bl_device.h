@@ -113,8 +113,15 @@ struct BlGridDevice {
   const double *edge[3];     // ascending distinct block boundaries per axis, n_edge[a] + 1 values
   int n_edge[3];
   const int *lattice;        // [n_edge[2]][n_edge[1]][n_edge[0]] -> block covering that box, -1: none
-  const double *bxf[3];      // [n_blocks][nb[a] + 1] faces of every block
-  const double *bxv[3];      // [n_blocks][nb[a]] centres
+  // Coordinate rows of the blocks, each distinct row once (blocks at one level and position along an axis share theirs: a 256^3 mesh in
+  // 64^3 blocks has 4 - 6 rows per axis, 36 - 64 blocks): small enough for the locate kernel to stage in LDS (refined_lds_bytes)
+  const double *bxf[3];      // [n_rows[a]][nb[a] + 1] faces
+  const double *bxv[3];      // [n_rows[a]][nb[a]] centres
+  const int *block_row[3];   // [n_blocks]: a block's row along each axis
+  const double *xv_next[3];  // [n_blocks]: first centre of the NEXT block of the file along the axis (what the reference's Array holds behind a
+                             // block's last centre, simulation_sampling.cpp:520-522); unused for the last block
+  int n_rows[3];
+  int refined_lds_bytes;     // > 0: edges, lattice, rows, block table and hash fit the locate kernel's LDS budget (bl_locate_kernel<kRefined>)
   // Inter-block interpolation (simulation_block_interp; simulation_sampling.cpp:505-546, :1068-1321): the MeshBlock
   // table and a hash from (level, location) to block - the reference scans all blocks for every such lookup
   int block_interp;

@@ -276,7 +276,7 @@ __device__ long long find_nearby(const BlGridDevice &g, bool sks, int b, int k, 
       int is = i == i_safe ? (upper_i ? (i - n_i / 2) * 2 : i * 2) : i == -1 ? n_i - 2 : 0;
       int js = j == j_safe ? (upper_j ? (j - n_j / 2) * 2 : j * 2) : j == -1 ? n_j - 2 : 0;
       int ks = k == k_safe ? (upper_k ? (k - n_k / 2) * 2 : k * 2) : k == -1 ? n_k - 2 : 0;
-      const double *x1v = g.bxv[0] + (size_t)b * n_i, *x2v = g.bxv[1] + (size_t)b * n_j, *x3v = g.bxv[2] + (size_t)b * n_k;
+      const double *x1v = g.bxv[0] + (size_t)g.block_row[0][b] * n_i, *x2v = g.bxv[1] + (size_t)g.block_row[1][b] * n_j, *x3v = g.bxv[2] + (size_t)g.block_row[2][b] * n_k;
       ks += (k < c[2] || (k == c[2] && s[2] > x3v[c[2]])) ? 1 : 0;
       js += (j < c[1] || (j == c[1] && s[1] > x2v[c[1]])) ? 1 : 0;
       is += (i < c[0] || (i == c[0] && s[0] > x1v[c[0]])) ? 1 : 0;
@@ -294,10 +294,10 @@ struct LocatedSample {
   uint32_t cell, status;
 };
 
-__device__ __forceinline__ void locate_sample_refined(const BlShadeArgs &P, unsigned int *anchors, double s1, double s2, double s3,
+// g: P.grid, or the kernel's copy of it whose tables point into LDS (bl_locate_kernel)
+__device__ __forceinline__ void locate_sample_refined(const BlShadeArgs &P, const BlGridDevice &g, unsigned int *anchors, double s1, double s2, double s3,
                                                       LocatedSample *out, unsigned long long *gathers) {
   const BlPlasmaDevice &pl = P.plasma;
-  const BlGridDevice &g = P.grid;
   const double s[3] = {s1, s2, s3};
   int box[3];
   for (int a = 0; a < 3; a++) {
@@ -316,8 +316,9 @@ __device__ __forceinline__ void locate_sample_refined(const BlShadeArgs &P, unsi
   const double *xv[3];
   for (int a = 0; a < 3; a++) {
     const int n = g.nb[a];
-    const double *xf = g.bxf[a] + (size_t)b * (n + 1);
-    xv[a] = g.bxv[a] + (size_t)b * n;
+    const int row = g.block_row[a][b];
+    const double *xf = g.bxf[a] + (size_t)row * (n + 1);
+    xv[a] = g.bxv[a] + (size_t)row * n;
     // start from the position in a uniform block, then walk to the first cell whose upper face is >= s
     int i = (int)((s[a] - xf[0]) / (xf[n] - xf[0]) * (double)n);
     i = i < 0 ? 0 : (i > n - 1 ? n - 1 : i);
@@ -338,7 +339,7 @@ __device__ __forceinline__ void locate_sample_refined(const BlShadeArgs &P, unsi
     bool undefined = false;
     for (int a = 0; a < 3; a++) {
       const int n = g.nb[a], i = c[a];
-      const double *xf = g.bxf[a] + (size_t)b * (n + 1);
+      const double *xf = g.bxf[a] + (size_t)g.block_row[a][b] * (n + 1);
       m[a] = s[a] >= xv[a][i] ? i : i - 1;
       pp[a] = m[a] + 1;
       // :520-522 read x1v(b, i + 1) at a block's upper edge: the next block's first centre in the reference's
@@ -347,7 +348,7 @@ __device__ __forceinline__ void locate_sample_refined(const BlShadeArgs &P, unsi
       if (past_the_array) undefined = true;
       const double x_m = m[a] == -1 ? 2.0 * xf[i] - xv[a][i] : xv[a][m[a]];
       // BL_UNDEFINED_EDGE: the centre mirrored about the block's upper face, the rule the lower edge has (x_m above)
-      const double x_p = (pp[a] == n) ? (past_the_array ? 2.0 * xf[i + 1] - xv[a][i] : 2.0 * xv[a][i + 1] - xv[a][i]) : xv[a][pp[a]];
+      const double x_p = (pp[a] == n) ? (past_the_array ? 2.0 * xf[i + 1] - xv[a][i] : 2.0 * g.xv_next[a][b] - xv[a][i]) : xv[a][pp[a]];
       f[a] = (s[a] - x_m) / (x_p - x_m);
     }
     if (undefined) {
@@ -435,9 +436,9 @@ __device__ __forceinline__ int locate_time(const BlSlowDevice &sl, double x0, ui
 template <bool kRefined, bool kSpinZero>
 __device__ __forceinline__ void locate_sample(const BlShadeArgs &P, const GridTables &tab, const BlSpacetime &st,
                                               double x1, double x2, double x3, double r, LocatedSample *out,
-                                              unsigned long long *gathers, unsigned int *anchors) {
+                                              unsigned long long *gathers, unsigned int *anchors, const BlGridDevice *grid_in_lds = nullptr) {
   const BlPlasmaDevice &pl = P.plasma;
-  const BlGridDevice &g = P.grid;
+  const BlGridDevice &g = (kRefined && grid_in_lds != nullptr) ? *grid_in_lds : P.grid;
   const bool sks = pl.simulation_coord == BL_COORD_SKS;
   double s1 = x1, s2 = x2, s3 = x3;
   out->ph = 0.0;
@@ -456,7 +457,7 @@ __device__ __forceinline__ void locate_sample(const BlShadeArgs &P, const GridTa
     s3 = ph;
   }
   if (kRefined) {
-    locate_sample_refined(P, anchors, s1, s2, s3, out, gathers);
+    locate_sample_refined(P, g, anchors, s1, s2, s3, out, gathers);
     return;
   }
   const int n_i = g.n[0], n_j = g.n[1], n_k = g.n[2];

@@ -25,10 +25,73 @@ __global__ void __launch_bounds__(256, 4) bl_locate_kernel(const BlShadeArgs P_a
   const BlSpacetime st = P.st;
   extern __shared__ double lds_tables[];
   GridTables tab;
+  // Refined meshes: the grid description as the search functions read it - with its tables in LDS where they fit (refined_lds_bytes:
+  // block boundaries, lattice, the distinct coordinate rows, every block's rows and next centre, the MeshBlock table and hash of
+  // inter-block interpolation). The search is a chain of dependent reads - boundary, lattice, row, faces, centres, and for a sample
+  // near a block's edge a dozen hash probes - that took 33 ms (65 with inter-block interpolation) per 1024^2 frame from HBM.
+  __shared__ BlGridDevice grid_lds;   // (the copy itself in LDS too: read by every lane, written once)
+  const BlGridDevice *grid_for_search = nullptr;
   if (kRefined) {
     for (int a = 0; a < 3; a++) {
       tab.xf[a] = tab.xv[a] = nullptr;
       tab.bucket[a] = nullptr;
+    }
+    const BlGridDevice &g = P.grid;
+    if (g.refined_lds_bytes > 0) {
+      const bool writer = threadIdx.x == 0;
+      if (writer) grid_lds = g;
+      __syncthreads();
+      double *dd = lds_tables;
+      auto stage_doubles = [&](const double *src, int count) {
+        double *at = dd;
+        for (int i = threadIdx.x; i < count; i += blockDim.x) at[i] = src[i];
+        dd += count;
+        return at;
+      };
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        const double *edge = stage_doubles(g.edge[a], g.n_edge[a] + 1);
+        const double *bxf = stage_doubles(g.bxf[a], g.n_rows[a] * (g.nb[a] + 1));
+        const double *bxv = stage_doubles(g.bxv[a], g.n_rows[a] * g.nb[a]);
+        const double *xv_next = stage_doubles(g.xv_next[a], g.n_blocks);
+        if (writer) {
+          grid_lds.edge[a] = edge;
+          grid_lds.bxf[a] = bxf;
+          grid_lds.bxv[a] = bxv;
+          grid_lds.xv_next[a] = xv_next;
+        }
+      }
+      if (g.block_interp) {
+        unsigned long long *keys = reinterpret_cast<unsigned long long *>(dd);
+        for (int i = threadIdx.x; i <= (int)g.hash_mask; i += blockDim.x) keys[i] = g.hash_keys[i];
+        if (writer) grid_lds.hash_keys = keys;
+        dd += g.hash_mask + 1;
+      }
+      int *ii = reinterpret_cast<int *>(dd);
+      auto stage_ints = [&](const int *src, int count) {
+        int *at = ii;
+        for (int i = threadIdx.x; i < count; i += blockDim.x) at[i] = src[i];
+        ii += count;
+        return at;
+      };
+      const int *lattice = stage_ints(g.lattice, g.n_edge[0] * g.n_edge[1] * g.n_edge[2]);
+      if (writer) grid_lds.lattice = lattice;
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        const int *rows = stage_ints(g.block_row[a], g.n_blocks);
+        if (writer) grid_lds.block_row[a] = rows;
+      }
+      if (g.block_interp) {
+        const int *levels = stage_ints(g.levels, g.n_blocks), *locations = stage_ints(g.locations, 3 * g.n_blocks);
+        const int *hash_blocks = stage_ints(g.hash_blocks, (int)g.hash_mask + 1);
+        if (writer) {
+          grid_lds.levels = levels;
+          grid_lds.locations = locations;
+          grid_lds.hash_blocks = hash_blocks;
+        }
+      }
+      __syncthreads();
+      grid_for_search = &grid_lds;
     }
   } else if (kTablesInHbm) {
     const BlGridDevice &g = P.grid;
@@ -99,7 +162,7 @@ __global__ void __launch_bounds__(256, 4) bl_locate_kernel(const BlShadeArgs P_a
       t_ind = (unsigned long long)locate_time(P.slow, P.sample_t[at] + P.slow.snapshot_time, ray, &t_frac);
       P.slow.frac[at] = t_frac;
     }
-    if (!skip) locate_sample<kRefined, kSpinZero>(P, tab, st, x1, x2, x3, r, &loc, &gathers_local, P.anchors != nullptr ? P.anchors + at * 8 : nullptr);
+    if (!skip) locate_sample<kRefined, kSpinZero>(P, tab, st, x1, x2, x3, r, &loc, &gathers_local, P.anchors != nullptr ? P.anchors + at * 8 : nullptr, grid_for_search);
     double2 *dst = reinterpret_cast<double2 *>(P.located + at);
     const unsigned long long tag = (t_ind << 40) | ((unsigned long long)loc.status << 32) | loc.cell;
     dst[0] = make_double2(loc.f_i, loc.f_j);
@@ -547,8 +610,8 @@ extern "C" hipError_t bl_launch_locate(const BlShadeArgs *args, int grid, int ld
     if (spin_zero) hipLaunchKernelGGL((bl_locate_kernel<R, false, true>), dim3(grid), dim3(256), LDS, stream, *args);  \
     else hipLaunchKernelGGL((bl_locate_kernel<R, false, false>), dim3(grid), dim3(256), LDS, stream, *args);           \
   } while (0)
-  if (refined && slow) hipLaunchKernelGGL((bl_locate_kernel<true, true, false>), dim3(grid), dim3(256), 0, stream, *args);
-  else if (refined) BL_LAUNCH_L(true, 0);
+  if (refined && slow) hipLaunchKernelGGL((bl_locate_kernel<true, true, false>), dim3(grid), dim3(256), args->grid.refined_lds_bytes, stream, *args);
+  else if (refined) BL_LAUNCH_L(true, args->grid.refined_lds_bytes);
   else if (lds_bytes == 0)   // merged grid with tables beyond the LDS budget (not with slow light: its instantiation needs them in LDS)
     hipLaunchKernelGGL((bl_locate_kernel<false, false, false, true>), dim3(grid), dim3(256), 0, stream, *args);
   else if (slow) hipLaunchKernelGGL((bl_locate_kernel<false, true, false>), dim3(grid), dim3(256), lds_bytes, stream, *args);

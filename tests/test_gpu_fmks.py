@@ -124,9 +124,12 @@ def test_fmks_slow_light_against_the_reference(built_library, fmks_slow, case, t
             assert gu.same_bits(out["image"], want).all(), image
             want_a = np.stack([fx[f"{case}_A_{image}_{name}"].reshape(-1) for name in rows])
             assert np.max(np.abs(out["image"] - want_a) / np.max(np.abs(want_a), axis=1, keepdims=True)) < 1.0e-6
-            ctx.set_arithmetic("tolerant")   # (slow light is rendered in exact arithmetic whatever was asked for)
+            ctx.set_arithmetic("tolerant")   # (slow light has the tolerant tier's coefficient kernel since round 6: within its tolerance)
             again = ctx.render()
-            assert again["stats"].arithmetic == 0 and gu.same_bits(again["image"], want).all()
+            assert again["stats"].arithmetic == 1 and np.array_equal(again["sample_num"], out["sample_num"])
+            assert np.array_equal(np.isnan(again["image"]), np.isnan(want))
+            with np.errstate(invalid="ignore"):
+                assert np.nanmax(np.abs(again["image"] - want) / np.nanmax(np.abs(want), axis=1, keepdims=True)) < 1.0e-10
             ctx.set_arithmetic("exact")
     params["output_file"] = str(tmp_path / "image_{02d}.npz")
     input_path = tmp_path / "fmks_slow.input"
