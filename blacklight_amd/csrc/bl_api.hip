@@ -691,7 +691,7 @@ void UploadRefinedGrid(bl_ctx *ctx, const bl_grid_desc *g) {
   // past a block's last centre), then the block boundaries
   std::vector<double> coords;
   std::vector<int> block_row(static_cast<size_t>(n_b) * 3);
-  size_t off_f[3], off_v[3], off_e[3], off_n[3];
+  size_t off_f[3], off_v[3], off_e[3], off_n[3], off_g[3];
   int n_rows[3];
   for (int a = 0; a < 3; a++) {
     const size_t row_len = static_cast<size_t>(nb[a]) * 2 + 1;
@@ -718,6 +718,26 @@ void UploadRefinedGrid(bl_ctx *ctx, const bl_grid_desc *g) {
     off_n[a] = coords.size();
     for (int blk = 0; blk < n_b; blk++)
       coords.push_back(blk + 1 < n_b ? block_xv[a][static_cast<size_t>(blk + 1) * nb[a]] : std::numeric_limits<double>::quiet_NaN());
+    off_g[a] = coords.size();
+    for (const double *f : row_f) {
+      // logarithmic where every face is positive and the ratios of neighbouring faces agree better than their differences do
+      bool positive = f[0] > 0.0;
+      double ratio_lo = 1.0e300, ratio_hi = 0.0, step_lo = 1.0e300, step_hi = 0.0;
+      for (int i = 0; i < nb[a] && positive; i++) {
+        ratio_lo = std::min(ratio_lo, f[i + 1] / f[i]); ratio_hi = std::max(ratio_hi, f[i + 1] / f[i]);
+        step_lo = std::min(step_lo, f[i + 1] - f[i]); step_hi = std::max(step_hi, f[i + 1] - f[i]);
+      }
+      const bool logarithmic = positive && nb[a] > 1 && (ratio_hi / ratio_lo - 1.0) < 0.5 * (step_hi / step_lo - 1.0);
+      if (logarithmic) {
+        coords.push_back(1.0);
+        coords.push_back(std::log2(f[0]));
+        coords.push_back(nb[a] / (std::log2(f[nb[a]]) - std::log2(f[0])));
+      } else {
+        coords.push_back(0.0);
+        coords.push_back(f[0]);
+        coords.push_back(nb[a] / (f[nb[a]] - f[0]));
+      }
+    }
     off_e[a] = coords.size();
     coords.insert(coords.end(), edge[a].begin(), edge[a].end());
   }
@@ -739,6 +759,7 @@ void UploadRefinedGrid(bl_ctx *ctx, const bl_grid_desc *g) {
     dev.bxf[a] = ctx->d_coords.ptr + off_f[a];
     dev.bxv[a] = ctx->d_coords.ptr + off_v[a];
     dev.xv_next[a] = ctx->d_coords.ptr + off_n[a];
+    dev.row_guess[a] = ctx->d_coords.ptr + off_g[a];
     dev.block_row[a] = ctx->d_lattice.ptr + lattice_ints + static_cast<size_t>(a) * n_b;
     dev.n_rows[a] = n_rows[a];
     dev.edge[a] = ctx->d_coords.ptr + off_e[a];
@@ -793,7 +814,7 @@ void UploadRefinedGrid(bl_ctx *ctx, const bl_grid_desc *g) {
     // what bl_locate_kernel<kRefined> stages in LDS when it fits (four workgroups to a compute unit: 36 KiB each): block boundaries,
     // lattice, rows, the blocks' rows and next centres, and with inter-block interpolation the MeshBlock table and its hash
     size_t doubles = 0, ints = lattice_ints + static_cast<size_t>(n_b) * 3;
-    for (int a = 0; a < 3; a++) doubles += static_cast<size_t>(n_edge[a]) + 1 + static_cast<size_t>(n_rows[a]) * (2 * nb[a] + 1) + n_b;
+    for (int a = 0; a < 3; a++) doubles += static_cast<size_t>(n_edge[a]) + 1 + static_cast<size_t>(n_rows[a]) * (2 * nb[a] + 1 + 3) + n_b;
     if (dev.block_interp) {
       doubles += dev.hash_mask + 1;                                        // (the keys: 8 bytes each)
       ints += static_cast<size_t>(n_b) * 4 + dev.hash_mask + 1;

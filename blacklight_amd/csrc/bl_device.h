@@ -120,6 +120,9 @@ struct BlGridDevice {
   const int *block_row[3];   // [n_blocks]: a block's row along each axis
   const double *xv_next[3];  // [n_blocks]: first centre of the NEXT block of the file along the axis (what the reference's Array holds behind a
                              // block's last centre, simulation_sampling.cpp:520-522); unused for the last block
+  const double *row_guess[3];   // [n_rows[a]][3]: where in a row to start the search for a coordinate s - kind (0: faces evenly spaced, 1: evenly
+                                // spaced in log s), origin (the first face, or its log2), cells per unit (of s, or of log2 s); any start gives
+                                // the same cell, a good one saves the walk
   int n_rows[3];
   int refined_lds_bytes;     // > 0: edges, lattice, rows, block table and hash fit the locate kernel's LDS budget (bl_locate_kernel<kRefined>)
   // Inter-block interpolation (simulation_block_interp; simulation_sampling.cpp:505-546, :1068-1321): the MeshBlock

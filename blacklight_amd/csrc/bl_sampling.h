@@ -319,8 +319,11 @@ __device__ __forceinline__ void locate_sample_refined(const BlShadeArgs &P, cons
     const int row = g.block_row[a][b];
     const double *xf = g.bxf[a] + (size_t)row * (n + 1);
     xv[a] = g.bxv[a] + (size_t)row * n;
-    // start from the position in a uniform block, then walk to the first cell whose upper face is >= s
-    int i = (int)((s[a] - xf[0]) / (xf[n] - xf[0]) * (double)n);
+    // start from the position the row's spacing predicts (linear, or logarithmic: the radial rows of a spherical mesh), then walk to
+    // the first cell whose upper face is >= s: the cell does not depend on where the walk starts
+    const double *guess = g.row_guess[a] + 3 * (size_t)row;
+    const double from_origin = (guess[0] != 0.0 ? (double)__log2f((float)s[a]) : s[a]) - guess[1];
+    int i = (int)(from_origin * guess[2]);
     i = i < 0 ? 0 : (i > n - 1 ? n - 1 : i);
     while (i < n - 1 && xf[i + 1] < s[a]) i++;
     while (i > 0 && xf[i] >= s[a]) i--;
@@ -349,7 +352,7 @@ __device__ __forceinline__ void locate_sample_refined(const BlShadeArgs &P, cons
       const double x_m = m[a] == -1 ? 2.0 * xf[i] - xv[a][i] : xv[a][m[a]];
       // BL_UNDEFINED_EDGE: the centre mirrored about the block's upper face, the rule the lower edge has (x_m above)
       const double x_p = (pp[a] == n) ? (past_the_array ? 2.0 * xf[i + 1] - xv[a][i] : 2.0 * g.xv_next[a][b] - xv[a][i]) : xv[a][pp[a]];
-      f[a] = (s[a] - x_m) / (x_p - x_m);
+      f[a] = blm_div(s[a] - x_m, x_p - x_m);   // (ordinary operands: the IEEE quotient, blmath.h)
     }
     if (undefined) {
       atomicAdd(&P.counters[BL_CNT_UNDEFINED], 1ull);
@@ -382,7 +385,7 @@ __device__ __forceinline__ void locate_sample_refined(const BlShadeArgs &P, cons
   for (int a = 0; a < 3; a++) {   // :485-490 with the block's own centres
     const int i = c[a];
     m[a] = (i == 0 || (i != g.nb[a] - 1 && s[a] >= xv[a][i])) ? i : i - 1;
-    f[a] = (s[a] - xv[a][m[a]]) / (xv[a][m[a] + 1] - xv[a][m[a]]);
+    f[a] = blm_div(s[a] - xv[a][m[a]], xv[a][m[a] + 1] - xv[a][m[a]]);   // (ordinary operands: the IEEE quotient, blmath.h)
   }
   out->f_i = f[0];
   out->f_j = f[1];
@@ -1357,6 +1360,25 @@ __device__ __forceinline__ void gather_issue(const BlShadeArgs &P, int status, u
 #pragma unroll
   for (int corner = 0; corner < 8; corner++) {
     const float4 *p = base + (corner >> 2) * plane + ((corner >> 1) & 1) * row + (corner & 1) * next;
+    lo[corner] = p[0];
+    hi[corner] = p[1];
+  }
+}
+// Inter-block interpolation: the eight anchor cells the locate kernel named (BlShadeArgs::anchors), requested the same way
+struct FastAnchors {
+  uint4 lo, hi;
+};
+__device__ __forceinline__ void fast_load_anchors(const BlShadeArgs &P, unsigned long long idx, FastAnchors &r) {
+  const uint4 *p = reinterpret_cast<const uint4 *>(P.anchors + idx * 8);
+  r.lo = p[0];
+  r.hi = p[1];
+}
+__device__ __forceinline__ void gather_issue_anchors(const BlShadeArgs &P, bool advanced, const FastAnchors &anchors, float4 (&lo)[8], float4 (&hi)[8]) {
+  const float4 *cells = reinterpret_cast<const float4 *>(P.grid.cells);
+  const unsigned int cell[8] = {anchors.lo.x, anchors.lo.y, anchors.lo.z, anchors.lo.w, anchors.hi.x, anchors.hi.y, anchors.hi.z, anchors.hi.w};
+#pragma unroll
+  for (int corner = 0; corner < 8; corner++) {
+    const float4 *p = cells + (advanced ? (size_t)cell[corner] * 2 : 0);
     lo[corner] = p[0];
     hi[corner] = p[1];
   }

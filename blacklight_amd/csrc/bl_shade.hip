@@ -54,7 +54,9 @@ __global__ void __launch_bounds__(256, 4) bl_locate_kernel(const BlShadeArgs P_a
         const double *bxf = stage_doubles(g.bxf[a], g.n_rows[a] * (g.nb[a] + 1));
         const double *bxv = stage_doubles(g.bxv[a], g.n_rows[a] * g.nb[a]);
         const double *xv_next = stage_doubles(g.xv_next[a], g.n_blocks);
+        const double *row_guess = stage_doubles(g.row_guess[a], 3 * g.n_rows[a]);
         if (writer) {
+          grid_lds.row_guess[a] = row_guess;
           grid_lds.edge[a] = edge;
           grid_lds.bxf[a] = bxf;
           grid_lds.bxv[a] = bxv;

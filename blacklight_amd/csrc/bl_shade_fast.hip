@@ -284,7 +284,7 @@ __device__ __forceinline__ bool gather_finish_tolerant(const BlShadeArgs &P, flo
                                                        const float4 (&hi)[8], double f_i, double f_j, double f_k, float pr[8]) {
   const BlPlasmaDevice &pl = P.plasma;
   bool near_midpoint = false;
-  if (status == kSampleInterp) {
+  if (status == kSampleInterp || status == kSampleAdvanced) {   // (advanced: InterpolateAdvanced's weights are these, its cells the eight anchors)
     const double w_k[2] = {1.0 - f_k, f_k}, w_j[2] = {1.0 - f_j, f_j}, w_i[2] = {1.0 - f_i, f_i};
     double val[8];
     float first[8];
@@ -374,10 +374,15 @@ __global__ void __launch_bounds__(256, BL_FAST_WAVES) bl_shade_fast_kernel(const
 #pragma unroll
   for (int c = 0; c < 8; c++) lo[c] = hi[c] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   fast_load_located(P, have_next ? idx : last, loc_next);
-  // Inter-block interpolation and slow light (the general instantiation; wave-uniform): the primitives come from the exact tier's own
-  // sampling functions - eight anchor cells named by the locate kernel, one or two time slices - read where they lie, not through
-  // the pipelined corner reads; what the tier saves there is the arithmetic behind them (simulation_sampling.cpp:505-546, :736-912)
-  const bool sampled_elsewhere = kGeneral && (P.anchors != nullptr || P.slow.n > 0);
+  // Inter-block interpolation (the general instantiation; wave-uniform): the eight cells are the anchors the locate kernel named, loaded
+  // with the located sample and requested like corner cells one stage later. Slow light: the primitives come from the exact tier's own
+  // sampling function - one or two time slices - read where they lie, not through the pipelined reads; what the tier saves there
+  // is the arithmetic behind them (simulation_sampling.cpp:505-546, :736-912)
+  const bool sampled_elsewhere = kGeneral && P.slow.n > 0;
+  const bool by_anchors = kGeneral && P.anchors != nullptr && !sampled_elsewhere;
+  FastAnchors anchors_cur, anchors_next;
+  anchors_cur.lo = anchors_cur.hi = anchors_next.lo = anchors_next.hi = make_uint4(0u, 0u, 0u, 0u);
+  if (kGeneral && by_anchors) fast_load_anchors(P, have_next ? idx : last, anchors_next);
   while (have_prev || have_cur || have_next) {
     // (a dead record slot carries tag 0 = kSampleNone from the locate kernel: cell 0 was requested for it)
     const uint32_t ray = have_prev ? (uint32_t)__double_as_longlong(ray_prev.q1.y) : BL_DEAD_RAY;
@@ -402,7 +407,8 @@ __global__ void __launch_bounds__(256, BL_FAST_WAVES) bl_shade_fast_kernel(const
         sample_primitives(P, status, (uint32_t)loc_prev.tag, loc_prev.l0.x, loc_prev.l0.y, loc_prev.l1.x, pr);
       near_midpoint = false;   // (the exact tier's values: nothing to guard)
     }
-    gather_issue(P, (have_cur && !sampled_elsewhere) ? (int)(loc_cur.tag >> 32) & 0xff : (int)kSampleNone, (uint32_t)loc_cur.tag, lo, hi);
+    if (kGeneral && by_anchors) gather_issue_anchors(P, have_cur && ((int)(loc_cur.tag >> 32) & 0xff) == (int)kSampleAdvanced, anchors_cur, lo, hi);
+    else gather_issue(P, (have_cur && !sampled_elsewhere) ? (int)(loc_cur.tag >> 32) & 0xff : (int)kSampleNone, (uint32_t)loc_cur.tag, lo, hi);
     fast_load_ray(P, have_cur ? idx_cur : last, ray_cur);
     const FastRay rec = ray_prev;
     const unsigned long long idx_rec = idx_prev;
@@ -416,6 +422,10 @@ __global__ void __launch_bounds__(256, BL_FAST_WAVES) bl_shade_fast_kernel(const
     idx += stride;
     have_next = have_next && idx < n_records;
     fast_load_located(P, have_next ? idx : last, loc_next);
+    if (kGeneral && by_anchors) {
+      anchors_cur = anchors_next;
+      fast_load_anchors(P, have_next ? idx : last, anchors_next);
+    }
     if (live) {
       // ReverseGeodesics: sample_len = -geodesic_len (geodesics.cpp:840)
       if (near_midpoint || !fast_shade_sample<kSpinZero, kGeneral>(P, fast_table, pr, status, row, rec.q0.x, rec.q0.y, rec.q1.x, rec.q2.x, rec.q2.y,
