@@ -47,7 +47,7 @@ class RenderDesc(C.Structure):
 
 
 # BL_SWITCH_* of include/blacklight_amd.h: measurement switches (bl_stats.switches, bl_debug_set_switches)
-SWITCHES = {"TENSOR_TRANSPORT": 1 << 0, "SPLIT_RECORDS": 1 << 1, "RECORD_EVERY_STEP": 1 << 2, "TOLERANT_POLARIZED_COEFFICIENTS": 1 << 3,
+SWITCHES = {"TENSOR_TRANSPORT": 1 << 0, "SPLIT_RECORDS": 1 << 1, "RECORD_EVERY_STEP": 1 << 2,
             "GENERAL_LOCATE": 1 << 4, "LANE_TRANSFER": 1 << 5, "NO_FUSED_LOCATE": 1 << 6, "SAMPLE_RECORDS": 1 << 8, "QUAD_EVERY_RAY": 1 << 11}
 
 BL_MAX_LEVELS = 16

@@ -348,7 +348,6 @@ int bl_init(const bl_params *p, int device, bl_ctx **out) {
     const struct { const char *name; unsigned int bit; } kSwitches[] = {
         {"BLACKLIGHT_AMD_TENSOR_TRANSPORT", BL_SWITCH_TENSOR_TRANSPORT}, {"BLACKLIGHT_AMD_SPLIT_RECORDS", BL_SWITCH_SPLIT_RECORDS},
         {"BLACKLIGHT_AMD_RECORD_EVERY_STEP", BL_SWITCH_RECORD_EVERY_STEP},
-        {"BLACKLIGHT_AMD_TOLERANT_POLARIZED_COEFFICIENTS", BL_SWITCH_TOLERANT_POLARIZED_COEFFICIENTS},
         {"BLACKLIGHT_AMD_GENERAL_LOCATE", BL_SWITCH_GENERAL_LOCATE}, {"BLACKLIGHT_AMD_LANE_TRANSFER", BL_SWITCH_LANE_TRANSFER},
         {"BLACKLIGHT_AMD_NO_FUSED_LOCATE", BL_SWITCH_NO_FUSED_LOCATE}, {"BLACKLIGHT_AMD_SAMPLE_RECORDS", BL_SWITCH_SAMPLE_RECORDS},
         {"BLACKLIGHT_AMD_QUAD_EVERY_RAY", BL_SWITCH_QUAD_EVERY_RAY}};

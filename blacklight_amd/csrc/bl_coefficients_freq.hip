@@ -228,9 +228,10 @@ extern "C" hipError_t bl_launch_polarized_coefficients_parts(const BlShadeArgs *
   // (simulation_coefficients<kExtended> also holds the unpolarized kappa terms: never in a polarized run)
   const bool thermal_only = args->plasma.power_frac == 0.0 && args->plasma.kappa_unpolarized == 0 && args->plasma.kappa_frac_zero != 0;
 #define BL_LAUNCH_PC(T, O) hipLaunchKernelGGL((bl_polarized_coefficients_kernel<T, O>), dim3(grid), dim3(256), 0, stream, *args)
-  if (args->tolerant && thermal_only) BL_LAUNCH_PC(true, true);
-  else if (args->tolerant) BL_LAUNCH_PC(true, false);
-  else if (thermal_only) BL_LAUNCH_PC(false, true);
+  // (the exact tier's formulas in either tier: the polarized step amplifies last-place differences of the coefficients by orders of
+  // magnitude in optically and Faraday thick cells - docs/notebook.md - so a tolerant kernel here moved rows with the reference's own
+  // conditioning; it was a measurement switch until round 6)
+  if (thermal_only) BL_LAUNCH_PC(false, true);
   else BL_LAUNCH_PC(false, false);
 #undef BL_LAUNCH_PC
   if (frames == 1) hipLaunchKernelGGL(bl_polarized_frame_kernel, dim3(grid), dim3(256), 0, stream, *args);

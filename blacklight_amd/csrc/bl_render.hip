@@ -298,7 +298,7 @@ void PlanJob(RenderJob &job) {
       && !(rows.image_time || rows.image_length || rows.image_lambda || rows.image_emission || rows.image_lambda_ave || rows.image_emission_ave
            || rows.image_tau_int || rows.image_crossings);
   // (inter-block interpolation and slow light: bl_shade_fast_kernel behind their locate kernels, primitives by the exact tier's sampling)
-  job.fast = ctx->arithmetic == BL_ARITH_TOLERANT && job.simulation && (!job.aux || tau_only) && !ctx->polarized
+  job.fast = ctx->arithmetic == BL_ARITH_TOLERANT && job.simulation && (!job.aux || tau_only) && !ctx->polarized && !(job.slow && job.block_interp)
       && p.plasma_kappa_frac == 0.0 && p.plasma_model != BL_PLASMA_CODE_KAPPA
       && !p.ray_flat && ctx->plasma_thermal_frac != 0.0
       && job.n_nu <= 1024;   // (its LDS table holds five numbers per frequency)
@@ -1096,7 +1096,7 @@ void BuildShadeArgs(RenderJob &job) {
     // amplifies last-place differences of the coefficients by up to ten orders of magnitude in optically and Faraday thick
     // configurations, so only bit-identical coefficients keep Stokes V within the tier's tolerance
     // everywhere. The tolerant coefficient kernel (106 -> 59 ms per 1024^2 frame) is there for the asking.
-    sa.tolerant = (job.fast || (job.tolerant_polarized && (ctx->switches & BL_SWITCH_TOLERANT_POLARIZED_COEFFICIENTS) != 0)) ? 1 : 0;
+    sa.tolerant = job.fast ? 1 : 0;
   } else {
     BlFormulaDevice &fm = sa.formula;
     fm.r0 = p.formula_r0; fm.h = p.formula_h; fm.l0 = p.formula_l0; fm.q = p.formula_q; fm.nup = p.formula_nup;

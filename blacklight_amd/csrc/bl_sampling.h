@@ -1364,6 +1364,54 @@ __device__ __forceinline__ void gather_issue(const BlShadeArgs &P, int status, u
     hi[corner] = p[1];
   }
 }
+// Slow light through the pipelined corner reads (bl_shade_fast_kernel): gather_issue() from the cell array of one time slice, and the
+// eight values of that slice from the cells as they arrived - sample_slice_values()'s sums in its order, without fused
+// multiply-adds: the exact tier's bits - then the blend in time of sample_primitives_slow()
+__device__ __forceinline__ void gather_issue_slice(const float *slice_cells, const BlGridDevice &g, int status, uint32_t cell, float4 (&lo)[8], float4 (&hi)[8]) {
+  const bool interp = status == kSampleInterp;
+  const size_t first = (interp || status == kSampleNearest) ? (size_t)cell : 0;
+  const float4 *base = reinterpret_cast<const float4 *>(slice_cells) + first * 2;
+  const size_t row = interp ? (size_t)g.stride_row * 2 : 0, plane = interp ? (size_t)g.stride_plane * 2 : 0, next = interp ? 2 : 0;
+#pragma unroll
+  for (int corner = 0; corner < 8; corner++) {
+    const float4 *p = base + (corner >> 2) * plane + ((corner >> 1) & 1) * row + (corner & 1) * next;
+    lo[corner] = p[0];
+    hi[corner] = p[1];
+  }
+}
+// (straight-line: both kinds of sample take the sums, the nearest-cell sample then takes its cell - a branch around them puts the array
+// in memory)
+__device__ __forceinline__ void slice_values_from_cells(int status, const float4 (&lo)[8], const float4 (&hi)[8], double f_i, double f_j, double f_k, double val[8]) {
+#pragma clang fp contract(off)
+  const bool nearest = status == kSampleNearest;
+  const double w_k[2] = {1.0 - f_k, f_k}, w_j[2] = {1.0 - f_j, f_j}, w_i[2] = {1.0 - f_i, f_i};
+  double w[8];
+  float c[8][8];
+#pragma unroll
+  for (int corner = 0; corner < 8; corner++) {
+    w[corner] = w_k[corner >> 2] * w_j[(corner >> 1) & 1] * w_i[corner & 1];
+    unpack_cell(lo[corner], hi[corner], c[corner]);
+  }
+#pragma unroll
+  for (int q = 0; q < 8; q++) {
+    double sum = w[0] * (double)c[0][q];
+#pragma unroll
+    for (int corner = 1; corner < 8; corner++) sum += w[corner] * (double)c[corner][q];
+    if (q < 2) sum = sum <= 0.0 ? (double)c[0][q] : sum;
+    val[q] = nearest ? (double)c[0][q] : sum;
+  }
+}
+// ... the later slice's values from its cells, blended into the earlier slice's one quantity at a time (every sum in
+// sample_slice_values()'s order)
+__device__ __forceinline__ void slice_blend_from_cells(int status, const float4 (&lo)[8], const float4 (&hi)[8], double f_i, double f_j, double f_k, double t_frac,
+                                                       double val[8]) {
+#pragma clang fp contract(off)
+  double next[8];
+  slice_values_from_cells(status, lo, hi, f_i, f_j, f_k, next);
+#pragma unroll
+  for (int q = 0; q < 8; q++) val[q] = (1.0 - t_frac) * val[q] + t_frac * next[q];
+}
+
 // Inter-block interpolation: the eight anchor cells the locate kernel named (BlShadeArgs::anchors), requested the same way
 struct FastAnchors {
   uint4 lo, hi;

@@ -332,13 +332,24 @@ __device__ __forceinline__ bool gather_finish_tolerant(const BlShadeArgs &P, flo
 // ~1 700 instructions of arithmetic instead of in front of them (the unpipelined version waited for memory in 54 % of its
 // wave cycles). Nothing between the requests and the end of the arithmetic reads global memory: thresholds, fallback
 // values and frequencies sit in LDS, the per-ray constants are requested before the cells.
-template <bool kSpinZero, bool kGeneral>
-__global__ void __launch_bounds__(256, BL_FAST_WAVES) bl_shade_fast_kernel(const BlShadeArgs P) {
+// kMode: 0 thermal electrons on a spherical Kerr-Schild grid; 1 the general arithmetic (power laws, Cartesian grids, an optical-depth
+// image); 2 the general arithmetic behind inter-block interpolation (anchor cells); 3 behind slow light (time slices)
+template <bool kSpinZero, int kMode>
+__global__ void __launch_bounds__(256, BL_FAST_WAVES) bl_shade_fast_kernel(const BlShadeArgs P_at_entry) {
+  constexpr bool kGeneral = kMode != 0, kAnchors = kMode == 2, kSlices = kMode == 3;
+  // (the instantiation for anchor cells and time slices reads its arguments where it uses them - bl_kernel_util.h: held in scalar
+  // registers from the entry on, a hundred of them spill into vector lanes it has no room for)
+  const BlShadeArgs &P = (kSlices || kAnchors) ? kernel_arguments_in_place<BlShadeArgs>() : P_at_entry;
   const unsigned long long n_records = P.counters_in[BL_CNT_RECORDS];
   const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
   unsigned long long idx = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;   // record of `next`
   // LDS: 3 x 14 cut thresholds / guard bands, the two fallback primitives, the frequencies and their roots / reciprocals
   extern __shared__ double fast_table[];
+  // (slow light: behind the table, the cell array of every time slice of the window)
+  const unsigned long long *slice_cells = reinterpret_cast<const unsigned long long *>(fast_table + 44 + 5 * P.n_nu);
+  if (kSlices && P.slow.n > 0)
+    for (int i = threadIdx.x; i < P.slow.n; i += blockDim.x)
+      reinterpret_cast<unsigned long long *>(fast_table + 44 + 5 * P.n_nu)[i] = reinterpret_cast<unsigned long long>(P.slow.cells[i]);
   for (int i = threadIdx.x; i < 44 + 5 * P.n_nu; i += blockDim.x) {
     const BlShadeCold &cc = *P.cold;
     double value;
@@ -378,11 +389,15 @@ __global__ void __launch_bounds__(256, BL_FAST_WAVES) bl_shade_fast_kernel(const
   // with the located sample and requested like corner cells one stage later. Slow light: the primitives come from the exact tier's own
   // sampling function - one or two time slices - read where they lie, not through the pipelined reads; what the tier saves there
   // is the arithmetic behind them (simulation_sampling.cpp:505-546, :736-912)
-  const bool sampled_elsewhere = kGeneral && P.slow.n > 0;
-  const bool by_anchors = kGeneral && P.anchors != nullptr && !sampled_elsewhere;
+  // Slow light without it: the first slice's cells come through the pipelined reads (from that slice's array), the second slice's are
+  // requested into the same registers once the first slice's eight values are formed - one exposed round trip per sample where the
+  // plain loop of the exact kernel has sixteen - and both are summed in the exact tier's order: its bits, nothing to guard.
+  const bool slow_pipelined = kSlices && P.slow.n > 0 && P.anchors == nullptr;
+  constexpr bool sampled_elsewhere = false;   // (slow light WITH inter-block interpolation stays in the exact tier: bl_render.hip)
+  const bool by_anchors = kAnchors && P.anchors != nullptr && P.slow.n == 0;
   FastAnchors anchors_cur, anchors_next;
   anchors_cur.lo = anchors_cur.hi = anchors_next.lo = anchors_next.hi = make_uint4(0u, 0u, 0u, 0u);
-  if (kGeneral && by_anchors) fast_load_anchors(P, have_next ? idx : last, anchors_next);
+  if (kAnchors && by_anchors) fast_load_anchors(P, have_next ? idx : last, anchors_next);
   while (have_prev || have_cur || have_next) {
     // (a dead record slot carries tag 0 = kSampleNone from the locate kernel: cell 0 was requested for it)
     const uint32_t ray = have_prev ? (uint32_t)__double_as_longlong(ray_prev.q1.y) : BL_DEAD_RAY;
@@ -393,21 +408,27 @@ __global__ void __launch_bounds__(256, BL_FAST_WAVES) bl_shade_fast_kernel(const
     const double kt = P.ray_kt[live ? ray : 0u], momentum_factor = P.ray_factor[live ? ray : 0u];
     const size_t row = (size_t)P.ray_offset[live ? ray : 0u] + n;
     float pr[8];
-    bool near_midpoint = gather_finish_tolerant(P, (float)fast_table[42], (float)fast_table[43], (live && !sampled_elsewhere) ? status : (int)kSampleNone, lo, hi,
+    const bool on_slices = kSlices && slow_pipelined && live && (status == kSampleInterp || status == kSampleNearest);
+    bool near_midpoint = gather_finish_tolerant(P, (float)fast_table[42], (float)fast_table[43], (live && !sampled_elsewhere && !on_slices) ? status : (int)kSampleNone, lo, hi,
                                                 loc_prev.l0.x, loc_prev.l0.y, loc_prev.l1.x, pr);
-    if (kGeneral && sampled_elsewhere && live) {
-      float kappa_unused;
-      const unsigned int *anchors = P.anchors != nullptr ? P.anchors + idx_prev * 8 : nullptr;
-      if (P.slow.n > 0)
-        sample_primitives_slow(P, status, (uint32_t)loc_prev.tag, anchors, (int)(loc_prev.tag >> 40), P.slow.frac[idx_prev], loc_prev.l0.x, loc_prev.l0.y, loc_prev.l1.x,
-                               pr, &kappa_unused);
-      else if (status == kSampleAdvanced)
-        sample_primitives_advanced(P, anchors, loc_prev.l0.x, loc_prev.l0.y, loc_prev.l1.x, pr, &kappa_unused);
-      else
-        sample_primitives(P, status, (uint32_t)loc_prev.tag, loc_prev.l0.x, loc_prev.l0.y, loc_prev.l1.x, pr);
-      near_midpoint = false;   // (the exact tier's values: nothing to guard)
+    if (kSlices && slow_pipelined) {
+      double val[8];
+      slice_values_from_cells(on_slices ? status : (int)kSampleNearest, lo, hi, loc_prev.l0.x, loc_prev.l0.y, loc_prev.l1.x, val);
+      if (P.slow.interp) {   // (wave-uniform) the later slice, into the registers the earlier one has left
+        const int t_ind = (int)(loc_prev.tag >> 40);
+        gather_issue_slice(reinterpret_cast<const float *>(slice_cells[on_slices ? t_ind + 1 : 0]), P.grid, on_slices ? status : (int)kSampleNone, (uint32_t)loc_prev.tag, lo, hi);
+        slice_blend_from_cells(on_slices ? status : (int)kSampleNearest, lo, hi, loc_prev.l0.x, loc_prev.l0.y, loc_prev.l1.x, P.slow.frac[idx_prev], val);
+      }
+      if (on_slices) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) pr[q] = (float)val[q];
+        near_midpoint = false;
+      }
     }
-    if (kGeneral && by_anchors) gather_issue_anchors(P, have_cur && ((int)(loc_cur.tag >> 32) & 0xff) == (int)kSampleAdvanced, anchors_cur, lo, hi);
+    if (kAnchors && by_anchors) gather_issue_anchors(P, have_cur && ((int)(loc_cur.tag >> 32) & 0xff) == (int)kSampleAdvanced, anchors_cur, lo, hi);
+    else if (kSlices && slow_pipelined)
+      gather_issue_slice(reinterpret_cast<const float *>(slice_cells[have_cur ? (int)(loc_cur.tag >> 40) : 0]), P.grid, have_cur ? (int)(loc_cur.tag >> 32) & 0xff : (int)kSampleNone,
+                         (uint32_t)loc_cur.tag, lo, hi);
     else gather_issue(P, (have_cur && !sampled_elsewhere) ? (int)(loc_cur.tag >> 32) & 0xff : (int)kSampleNone, (uint32_t)loc_cur.tag, lo, hi);
     fast_load_ray(P, have_cur ? idx_cur : last, ray_cur);
     const FastRay rec = ray_prev;
@@ -422,7 +443,7 @@ __global__ void __launch_bounds__(256, BL_FAST_WAVES) bl_shade_fast_kernel(const
     idx += stride;
     have_next = have_next && idx < n_records;
     fast_load_located(P, have_next ? idx : last, loc_next);
-    if (kGeneral && by_anchors) {
+    if (kAnchors && by_anchors) {
       anchors_cur = anchors_next;
       fast_load_anchors(P, have_next ? idx : last, anchors_next);
     }
@@ -564,15 +585,18 @@ extern "C" hipError_t bl_launch_shade_fast(const BlShadeArgs *args, int grid, hi
     if (err != hipSuccess) return err;
     return bl_launch_shade_redo(args, BL_MODEL_SIMULATION, grid, stream);
   }
-  const size_t lds = (44 + 5 * args->n_nu) * sizeof(double);
-  // power laws, Cartesian grids, an optical-depth image, inter-block interpolation and slow light go through the general instantiation
-  const bool general = args->plasma.power_frac != 0.0 || args->tau_inc != nullptr || args->plasma.simulation_coord == BL_COORD_CKS || args->anchors != nullptr
-      || args->slow.n > 0;
-#define BL_LAUNCH_F(SPIN, GENERAL) hipLaunchKernelGGL((bl_shade_fast_kernel<SPIN, GENERAL>), dim3(grid), dim3(256), lds, stream, *args)
-  if (general) {
-    BL_LAUNCH_F(false, true);
+  const size_t lds = (44 + 5 * args->n_nu + (args->slow.n > 0 ? args->slow.n : 0)) * sizeof(double);
+  // power laws, Cartesian grids and an optical-depth image go through the general instantiation; inter-block interpolation and slow light
+  // through the one that also knows anchor cells and time slices
+  const bool slices = args->anchors != nullptr || args->slow.n > 0;
+  const bool general = args->plasma.power_frac != 0.0 || args->tau_inc != nullptr || args->plasma.simulation_coord == BL_COORD_CKS;
+#define BL_LAUNCH_F(SPIN, MODE) hipLaunchKernelGGL((bl_shade_fast_kernel<SPIN, MODE>), dim3(grid), dim3(256), lds, stream, *args)
+  if (slices) {
+    if (args->slow.n > 0) BL_LAUNCH_F(false, 3); else BL_LAUNCH_F(false, 2);
+  } else if (general) {
+    BL_LAUNCH_F(false, 1);
   } else {
-    if (spin_zero) BL_LAUNCH_F(true, false); else BL_LAUNCH_F(false, false);
+    if (spin_zero) BL_LAUNCH_F(true, 0); else BL_LAUNCH_F(false, 0);
   }
 #undef BL_LAUNCH_F
   return bl_launch_shade_redo(args, BL_MODEL_SIMULATION, grid, stream);

@@ -305,13 +305,12 @@ typedef struct bl_stats {
 #define BL_SWITCH_TENSOR_TRANSPORT (1u << 0)                /* polarized, tolerant tier: the exact tier's tensor transport      */
 #define BL_SWITCH_SPLIT_RECORDS (1u << 1)                   /* sample records as two arrays of 32-byte halves                   */
 #define BL_SWITCH_RECORD_EVERY_STEP (1u << 2)               /* steps in the empty shell around the grid leave records too       */
-#define BL_SWITCH_TOLERANT_POLARIZED_COEFFICIENTS (1u << 3) /* polarized, tolerant tier: the tolerant per-frequency kernel      */
 #define BL_SWITCH_GENERAL_LOCATE (1u << 4)                  /* bl_locate_kernel where bl_locate_plain_kernel applies            */
 #define BL_SWITCH_LANE_TRANSFER (1u << 5)                   /* one lane per ray where bl_transfer_quad_kernel applies           */
 #define BL_SWITCH_NO_FUSED_LOCATE (1u << 6)                 /* a locate kernel + bl_shade_fast_kernel / bl_shade_exact_kernel   */
 #define BL_SWITCH_SAMPLE_RECORDS (1u << 8)                  /* tolerant tier: one transfer record per sample where composed maps apply */
 #define BL_SWITCH_QUAD_EVERY_RAY (1u << 11)                 /* every ray parked before its first step: all stepping in bl_geodesic_quad_kernel */
-/* (Nine switches. Rounds 3 - 5 had eight more for experiments the measurements buried - a second pre-fused2 kernel, pre-gathered
+/* (Eight switches. Rounds 3 - 5 had eight more for experiments the measurements buried - a second pre-fused2 kernel, pre-gathered
  * cell bricks, the coefficient kernel beside a chunk's last rays, repacked tails - and for what bl_set_tail_policy now says; their
  * numbers are in docs/notebook.md, their code in the history.) */
 

@@ -82,10 +82,9 @@ def test_tolerant_tier_on_the_goldens(case, built_library):
             assert gu.same_bits(tol["image"], exact["image"]).all()
             return
         # polarized runs: the transport between two couplings is one 4 x 4 matrix per sample, built sample-parallel in closed
-        # form (bl_transport_matrix_kernel), instead of the tensor walked along the ray; frame, coupling and - by
-        # default since DESIGN.md 5h - the per-frequency coefficient formulas stay exact (their tolerant instantiation, fused
-        # multiply-adds and the tier's exp / log / pow / cbrt, is BLACKLIGHT_AMD_TOLERANT_POLARIZED_COEFFICIENTS: the reference's
-        # polarized step can amplify its last-place differences far beyond this bound away from the goldens).
+        # form (bl_transport_matrix_kernel), instead of the tensor walked along the ray; frame, coupling and the per-frequency
+        # coefficient formulas stay exact (the reference's polarized step can amplify last-place differences of the coefficients far
+        # beyond this bound away from the goldens: docs/notebook.md).
         assert tol["stats"].arithmetic == 1
         d_exact = _distance(tol["image"], exact["image"])
         d_b = _distance(tol["image"], gu.expected_image(fx, "B", n_pix))

@@ -22,9 +22,11 @@ BENCHMARK_KERNELS = {
     "_Z16bl_locate_kernelILb0ELb0ELb1ELb0EEv11BlShadeArgs": (4, 0),          # merged grid, no slow light, zero spin (at least 4)
     "_Z16bl_locate_kernelILb0ELb0ELb0ELb0EEv11BlShadeArgs": (4, 0),
     "_Z15bl_shade_kernelILi0ELb0ELb0ELb0ELb0ELb0ELb0EEv11BlShadeArgs": (2, 0),   # simulation, thermal electrons, any coordinates
-    "_Z20bl_shade_fast_kernelILb1ELb0EEv11BlShadeArgs": (2, 0),              # tolerant tier, zero spin
-    "_Z20bl_shade_fast_kernelILb0ELb0EEv11BlShadeArgs": (2, 0),
-    "_Z20bl_shade_fast_kernelILb0ELb1EEv11BlShadeArgs": (2, 0),              # ... power laws / Cartesian grids
+    "_Z20bl_shade_fast_kernelILb1ELi0EEv11BlShadeArgs": (2, 0),              # tolerant tier, zero spin
+    "_Z20bl_shade_fast_kernelILb0ELi0EEv11BlShadeArgs": (2, 0),
+    "_Z20bl_shade_fast_kernelILb0ELi1EEv11BlShadeArgs": (2, 0),              # ... power laws / Cartesian grids
+    "_Z20bl_shade_fast_kernelILb0ELi2EEv11BlShadeArgs": (2, 0),              # ... behind inter-block interpolation (anchor cells)
+    "_Z20bl_shade_fast_kernelILb0ELi3EEv11BlShadeArgs": (2, 0),              # ... behind slow light (time slices)
     "_Z22bl_shade_fused2_kernelILb1ELb1ELb0EEv11BlShadeArgs": (2, 0),        # ... the benchmark's kernel: locate step inside, composed maps
     "_Z22bl_shade_fused2_kernelILb1ELb0ELb0EEv11BlShadeArgs": (2, 0),        # ... one record per sample
     "_Z22bl_shade_fused2_kernelILb0ELb1ELb0EEv11BlShadeArgs": (2, 0),        # ... any spin
