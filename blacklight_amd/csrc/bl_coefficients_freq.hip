@@ -146,7 +146,8 @@ __global__ void __launch_bounds__(256) bl_polarized_frame_kernel(const BlShadeAr
     if (ray == BL_DEAD_RAY) continue;
     const double2 *in = reinterpret_cast<const double2 *>(P.coef_inputs + idx);
     const double2 c3 = in[3];
-    if (c3.y != 0.0) continue;   // have_coefficients: the coefficient kernel wrote the frame
+    // have_coefficients: the coefficient kernel wrote the frame (where it evaluated the coefficients itself it left no inputs: a flag)
+    if (P.have_flags != nullptr ? P.have_flags[idx] != 0 : c3.y != 0.0) continue;
     const uint32_t n = (uint32_t)(tag >> 32);
     const double2 q0 = hot[0], c0 = in[0], c1 = in[1], c2 = in[2];
     const double kcov[4] = {c0.x, c0.y, c1.x, c1.y};

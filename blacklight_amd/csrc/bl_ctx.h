@@ -211,6 +211,7 @@ struct bl_ctx {
     DeviceBuffer<double2> d_pol_coeffs;
     DeviceBuffer<unsigned int> d_anchors;          // inter-block interpolation: eight anchor cells per record
     DeviceBuffer<BlCoefInputs> d_coef_inputs;      // polarized runs: coefficient kernel -> polarized coefficient kernel
+    DeviceBuffer<unsigned char> d_have_flags;      // ... where bl_shade_polarized2_kernel evaluates the coefficients itself: which records have them
     DeviceBuffer<unsigned long long> d_redo;       // tolerant tier: records left to the exact coefficient kernel
     DeviceBuffer<double> d_tau_inc;                // tolerant tier with an optical-depth image: alpha x length per sample and frequency
     uint64_t Bytes() const {
@@ -218,10 +219,10 @@ struct bl_ctx {
           + d_located_tag.count * sizeof(unsigned long long) + (d_transfer.count + d_composed.count) * sizeof(double2) + d_parked.count * sizeof(double) + d_aux.count * sizeof(BlAuxSample)
           + (d_sample_t.count + d_slow_frac.count + d_pol_matrix.count + d_tau_inc.count) * sizeof(double) + d_pol_samples.count * sizeof(BlPolSample)
           + d_freq_inputs.count * sizeof(BlFreqInputs) + d_pol_coeffs.count * sizeof(double2) + d_anchors.count * sizeof(unsigned int)
-          + d_coef_inputs.count * sizeof(BlCoefInputs) + d_redo.count * sizeof(unsigned long long);
+          + d_coef_inputs.count * sizeof(BlCoefInputs) + d_redo.count * sizeof(unsigned long long) + d_have_flags.count;
     }
     void Free() {
-      d_redo.Free(); d_tau_inc.Free(); d_aux.Free(); d_sample_t.Free(); d_slow_frac.Free(); d_pol_samples.Free(); d_pol_matrix.Free(); d_freq_inputs.Free(); d_pol_coeffs.Free(); d_coef_inputs.Free(); d_anchors.Free();
+      d_have_flags.Free(); d_redo.Free(); d_tau_inc.Free(); d_aux.Free(); d_sample_t.Free(); d_slow_frac.Free(); d_pol_samples.Free(); d_pol_matrix.Free(); d_freq_inputs.Free(); d_pol_coeffs.Free(); d_coef_inputs.Free(); d_anchors.Free();
       d_records_hot.Free(); d_records_cold.Free(); d_located.Free(); d_located_tag.Free(); d_transfer.Free(); d_composed.Free(); d_parked.Free(); d_counters.Free();
     }
   };

@@ -422,6 +422,8 @@ struct BlShadeArgs {
   double2 *pol_coeffs;        // [sample row][n_nu][4]: (j_I, alpha_I), (j_Q, j_V), (alpha_Q, alpha_V), (rho_Q, rho_V) - one 64-byte record, half a
                               // cache line, for the lane of the sequential kernels that walks the ray (polarized runs have no `transfer` array)
   BlCoefInputs *coef_inputs;  // [record capacity]: coefficient kernel -> polarized coefficient kernel
+  unsigned char *have_flags;  // [record capacity] or null: bl_shade_polarized2_kernel<..., kCoefficients> evaluates the coefficients itself and
+                              // says here which records have them (bl_polarized_frame_kernel: the others' frames)
   unsigned int *anchors;      // inter-block interpolation: [record capacity][8] cells of the eight anchors, else null
   double power_pol[7];        // simulation_coefficients.cpp:67-80: jj_q, jj_v, aa_q, aa_v, rho, rho_q, rho_v
   double plasma_gamma_min;

@@ -163,6 +163,7 @@ struct RenderJob {
   bool composed = false;   // ... writing one affine transfer map per ray segment instead of one per sample (BlShadeArgs::composed)
   bool exact_fused = false;   // exact tier, the same grids, plain image at one frequency: bl_shade_exact2_kernel locates its samples itself
   bool pol_fused = false;     // polarized runs over the same grids (either tier): bl_shade_polarized2_kernel locates its samples itself
+  bool pol_coefficients_inside = false;   // ... and, at one frequency with thermal electrons only, evaluates their polarized coefficients itself
   bool locate_inside = false; // fused2 || exact_fused || pol_fused: no locate kernel, no located samples in HBM
   bool park = false;          // BL_TAIL_QUAD: the last rays of a chunk go to bl_geodesic_quad_kernel (BlTraceArgs::parked)
   bool split_long = false;    // BL_TAIL_SPLIT: rays predicted long on compute units of their own (bl_split_long_kernel)
@@ -383,6 +384,8 @@ void PlanJob(RenderJob &job) {
   const BlAuxImages &AI = ctx->aux_images;
   job.rows_only = ctx->polarized && ctx->render_num_images == 0 && !fill_present && !(AI.image_time || AI.image_length || AI.image_lambda
       || AI.image_emission || AI.image_lambda_ave || AI.image_emission_ave || AI.image_tau_int || AI.image_crossings);
+  // configuration 4's case: no BlCoefInputs through HBM, no bl_polarized_coefficients_kernel launch (bl_shade_fused.hip: kCoefficients)
+  job.pol_coefficients_inside = job.pol_fused && job.n_nu == 1 && job.rows_only && p.plasma_power_frac == 0.0 && p.plasma_kappa_frac == 0.0;
   // Host outputs of a quarter of a GiB and more in eight rows or more (configuration 5: 64 frequencies): the rays are traced in pixel
   // order - not the 8 x 8 tiles, centre first, that make chunks drain faster - so that what a chunk finishes is a range of columns,
   // downloaded while the next chunk renders (the image rows of a 4096^2 x 64 frame are 8.6 GB: 0.7 s of PCIe that used to follow the
@@ -534,7 +537,7 @@ void PlanScratch(RenderJob &job) {
       + (job.freq_split ? sizeof(BlFreqInputs) : (ctx->polarized ? 0 : sizeof(double2) * n_nu)) + (job.tau_row ? sizeof(double) * n_nu : 0)
       + (job.composed ? sizeof(double2) : 0)
       + ((job.aux && !job.rows_only) ? sizeof(BlAuxSample) : 0) + (job.need_time ? sizeof(double) : 0) + (job.slow ? sizeof(double) : 0)
-      + (ctx->polarized ? sizeof(BlPolSample) + sizeof(BlCoefInputs) + 4 * sizeof(double2) * n_nu : 0)
+      + (ctx->polarized ? sizeof(BlPolSample) + sizeof(BlCoefInputs) + 4 * sizeof(double2) * n_nu + (job.pol_coefficients_inside ? 1 : 0) : 0)
       + (job.coef_split ? sizeof(BlCoefInputs) : 0)
       + (job.matrix_transport ? BL_POL_MATRIX_DOUBLES * sizeof(double) : 0)
       + (job.block_interp ? 8 * sizeof(unsigned int) : 0);
@@ -698,6 +701,7 @@ void EnsureScratchOnce(RenderJob &job) {
       if (job.matrix_transport) sl.d_pol_matrix.Ensure(cap * BL_POL_MATRIX_DOUBLES);
       sl.d_pol_coeffs.Ensure(cap * n_nu * 4);
       sl.d_coef_inputs.Ensure(cap);
+      if (job.pol_coefficients_inside) sl.d_have_flags.Ensure(cap);
     }
     if (job.coef_split) sl.d_coef_inputs.Ensure(cap);
     if (job.block_interp) sl.d_anchors.Ensure(cap * 8);
@@ -1255,6 +1259,7 @@ void BindChunk(RenderJob &job, int k, long long begin, int rays) {
   sa.aux = (job.aux && !job.rows_only) ? sl.d_aux.ptr : nullptr;
   sa.sample_t = ta.sample_t;
   sa.coef_inputs = (job.coef_split || ctx->polarized) ? sl.d_coef_inputs.ptr : nullptr;
+  sa.have_flags = job.pol_coefficients_inside ? sl.d_have_flags.ptr : nullptr;
   sa.anchors = job.block_interp ? sl.d_anchors.ptr : nullptr;
   sa.redo_list = (job.fast || job.fast_formula || ctx->polarized) ? sl.d_redo.ptr : nullptr;
   if (job.slow) {
@@ -1667,7 +1672,8 @@ void LaunchShadingStage(RenderJob &job, int k, bool geodesic_beside, hipStream_t
   // matrices overlap its last quarter only: 276 -> 270 ms per 1024^2 frame, 1.10 -> 1.08 s at 2048^2 adaptive; a smaller grid for the
   // coefficient kernel or a priority stream for the matrices move the split, not the sum. BLACKLIGHT_AMD_POLARIZED_OVERLAP=0: in sequence.)
   // (one scratch set: with two, the second stream carries the next chunk's geodesic stage, and the matrices would queue behind it)
-  const bool matrices_beside = ctx->polarized && job.matrix_transport && job.n_slots == 1 && ctx->stream_geo != stream;
+  // (with the coefficients evaluated inside the coefficient kernel there is nothing left beside which to build them: in sequence)
+  const bool matrices_beside = ctx->polarized && job.matrix_transport && job.n_slots == 1 && ctx->stream_geo != stream && !job.pol_coefficients_inside;
   const int polcoef_grid = ctx->num_cus * 20;
   if (matrices_beside) {
     // (the frames of the samples without coefficients first: the matrices read them)
@@ -1677,7 +1683,7 @@ void LaunchShadingStage(RenderJob &job, int k, bool geodesic_beside, hipStream_t
     Check(bl_launch_transport_matrices(&xa, ctx->num_cus, ctx->stream_geo), "transport matrix kernel launch");
     Check(hipEventRecord(e[11], ctx->stream_geo), "event");
   }
-  if (ctx->polarized) Check(bl_launch_polarized_coefficients_parts(&sa, polcoef_grid, matrices_beside ? 0 : 1, stream), "polarized coefficient kernel launch");
+  if (ctx->polarized) Check(bl_launch_polarized_coefficients_parts(&sa, polcoef_grid, job.pol_coefficients_inside ? 2 : (matrices_beside ? 0 : 1), stream), "polarized coefficient kernel launch");
   if (job.coef_split) Check(bl_launch_coefficients_freq(&sa, ctx->num_cus * 16, stream), "per-frequency coefficient kernel launch");
   Check(hipEventRecord(e[4], stream), "event");
   Check(job.aux ? bl_launch_transfer_aux(&xa, stream)

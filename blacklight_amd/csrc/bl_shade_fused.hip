@@ -1043,7 +1043,11 @@ __global__ void __launch_bounds__(256, 2) bl_shade_exact2_kernel(const BlShadeAr
 // =================================================================================================
 // kAuxRecords: the run keeps BlAuxSample records (an auxiliary row besides tau, or a rendering); without them the kernel is 40
 // registers lighter.
-template <bool kSpinZero, bool kAuxRecords>
+// kCoefficients: one frequency, thermal electrons only (configuration 4): the sample's eight polarized coefficients are evaluated here,
+// from the scalars the frame's arithmetic has just left in registers, instead of by bl_polarized_coefficients_kernel from a 64-byte
+// BlCoefInputs written and read back through HBM (per 1024^2 frame: 48 GB written, 100 GB fetched - with the record's tag - and a
+// kernel's worth of launch and tail). The same functions on the same operands: the same bits.
+template <bool kSpinZero, bool kAuxRecords, bool kCoefficients = false>
 __global__ void __launch_bounds__(256, 2) bl_shade_polarized2_kernel(const BlShadeArgs P) {
   using namespace fused2;
   extern __shared__ double lds[];
@@ -1071,7 +1075,7 @@ __global__ void __launch_bounds__(256, 2) bl_shade_polarized2_kernel(const BlSha
   auto record_base = [&](uint32_t first) { return records + ((size_t)(first < last ? first : last) << 6); };
   double2 prev0 = make_double2(0.0, 0.0), prev1 = make_double2(0.0, __longlong_as_double((long long)BL_DEAD_RAY)), prev2 = prev0, prev3 = prev0;
   double2 cur0, cur1;
-  double kt_prev = 0.0;
+  double kt_prev = 0.0, factor_prev = 1.0;
   long long row_prev = 0;
   unsigned char flag_prev = 0;
   LocatedExact loc_prev, loc_cur;
@@ -1103,7 +1107,7 @@ __global__ void __launch_bounds__(256, 2) bl_shade_polarized2_kernel(const BlSha
       next0 = rec[0];
       next1 = rec[1];
     }
-    const double kt = kt_prev;
+    const double kt = kt_prev, momentum_factor = factor_prev;
     const long long row_first = row_prev;
     const unsigned char ray_flag = flag_prev;
     float pr[8];
@@ -1119,6 +1123,7 @@ __global__ void __launch_bounds__(256, 2) bl_shade_polarized2_kernel(const BlSha
       const uint32_t ray_cur = (uint32_t)__double_as_longlong(cur1.y);
       const uint32_t ray_slot = ray_cur != BL_DEAD_RAY ? ray_cur : 0u;
       kt_prev = *reinterpret_cast<const double *>(ray_kt + (size_t)(ray_slot << 3));
+      if (kCoefficients) factor_prev = P.ray_factor[ray_slot];
       row_prev = *reinterpret_cast<const long long *>(ray_offset + (size_t)(ray_slot << 3));
       flag_prev = P.ray_flags[ray_slot];
     }
@@ -1160,7 +1165,37 @@ __global__ void __launch_bounds__(256, 2) bl_shade_polarized2_kernel(const BlSha
       // (what these two read of the arguments - output arrays, the list of samples without coefficients - they read where they use it)
       const BlShadeArgs &A = kernel_arguments_in_place<BlShadeArgs>();
       if (kAuxRecords) write_aux_record(A, st, ks, idx_cur, row, sh, kcov, x1, x2, x3, delta_lambda);
-      write_polarized_inputs(A, idx_cur, row, sh, kcov, pr, x1, x2, x3, delta_lambda);
+      if (!kCoefficients) {
+        write_polarized_inputs(A, idx_cur, row, sh, kcov, pr, x1, x2, x3, delta_lambda);
+      } else {
+        // a sample with coefficients leaves them; one without leaves what bl_polarized_frame_kernel builds its frame from, as ever
+        if (!sh.have_coefficients) write_polarized_inputs(A, idx_cur, row, sh, kcov, pr, x1, x2, x3, delta_lambda);
+        else {
+          BlPolSample *ps = A.pol_samples + row;
+          ps->x[0] = x1; ps->x[1] = x2; ps->x[2] = x3;
+          ps->delta_lambda = delta_lambda;
+        }
+        A.have_flags[idx_cur] = sh.have_coefficients ? 1 : 0;
+        // bl_polarized_coefficients_kernel<false, true>'s body (bl_coefficients_freq.hip), call for call
+        sh.sin2_theta_b = 1.0 - sh.cos2_theta_b;
+        sh.sin_theta_b = bl_sqrt_g(sh.sin2_theta_b);
+        sh.cos_theta_b = bl_sqrt_g(sh.cos2_theta_b) * sh.cos_sign;
+        sh.theta_e_096 = sh.kk_0 = sh.kk_1 = sh.kk_2 = 0.0;
+        if (sh.have_coefficients && A.plasma.plasma_thermal_frac != 0.0) {
+          sh.theta_e_096 = bl_pow(sh.theta_e, 0.96);
+          if (sh.theta_e >= 0.01) bl_cyl_bessel_k012(1.0 / sh.theta_e, &sh.kk_0, &sh.kk_1, &sh.kk_2);
+        }
+        const double freq = A.frequencies[0];
+        double j_val = 0.0, alpha_val = 0.0;
+        double2 pc[3] = {make_double2(0.0, 0.0), make_double2(0.0, 0.0), make_double2(0.0, 0.0)};
+        if (sh.have_coefficients) simulation_coefficients<false>(A, sh, freq, momentum_factor, &j_val, &alpha_val);
+        polarized_coefficients<false>(A, sh, freq, momentum_factor, j_val, alpha_val, pc);
+        double2 *out = A.pol_coeffs + row * 4;
+        out[0] = make_double2(j_val, alpha_val);
+        out[1] = pc[0];
+        out[2] = pc[1];
+        out[3] = pc[2];
+      }
     }
     // the corner cells of `cur`: requested behind the frame's arithmetic, whose tetrad needs the sixty-four registers they land in
     // (with the requests in front of it the kernel keeps 3 ... 24 registers in scratch memory); the search for `next` and the
@@ -1193,7 +1228,10 @@ extern "C" hipError_t bl_launch_shade_polarized2(const BlShadeArgs *args, int gr
   const bool spin_zero = args->st.bh_a == 0.0, records = args->aux_record_unused == 0;
   if (records && args->aux == nullptr) return hipErrorInvalidValue;
 #define BL_LAUNCH_P2(S, A) hipLaunchKernelGGL((bl_shade_polarized2_kernel<S, A>), dim3(grid), dim3(256), lds, stream, *args)
-  if (spin_zero && records) BL_LAUNCH_P2(true, true);
+  if (args->have_flags != nullptr && !records) {   // (bl_render.hip: one frequency, thermal electrons only)
+    if (spin_zero) hipLaunchKernelGGL((bl_shade_polarized2_kernel<true, false, true>), dim3(grid), dim3(256), lds, stream, *args);
+    else hipLaunchKernelGGL((bl_shade_polarized2_kernel<false, false, true>), dim3(grid), dim3(256), lds, stream, *args);
+  } else if (spin_zero && records) BL_LAUNCH_P2(true, true);
   else if (spin_zero) BL_LAUNCH_P2(true, false);
   else if (records) BL_LAUNCH_P2(false, true);
   else BL_LAUNCH_P2(false, false);
