@@ -419,6 +419,53 @@ namespace {
 // a tiling (bl_set_grid then takes the refined-mesh path).
 const char *const kIrregular = "Multi-block grid is not a regular tiling by equal blocks of one level.";
 
+// The cells into their HBM layout on the device. The caller's arrays are [variable][block][k][j][i] (simulation_reader.cpp:767-780);
+// the kernels read [cell][8 variables]. Eight planes are uploaded as they lie (a copy each, no pass over them on the host) and
+// one kernel interleaves them - a lane per cell: eight coalesced reads, 32 contiguous bytes written - placing a block's cells at the
+// block's position in the merged array where there is one (block_origin: first target cell of every block, and the target's row
+// and plane strides; null: the blocks stay one behind the other). On the host this repack was 0.3 s per 256^3 snapshot, ten times
+// the render of a series' frame over resident geodesics.
+__global__ void __launch_bounds__(256) bl_interleave_cells_kernel(const float *planes, float *cells, unsigned long long n_cells, int nb_i, int nb_j, int nb_k,
+                                                                  const unsigned long long *block_origin, unsigned long long row_stride,
+                                                                  unsigned long long plane_stride) {
+  const unsigned long long c = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n_cells) return;
+  unsigned long long target = c;
+  if (block_origin != nullptr) {
+    const unsigned long long block_cells = (unsigned long long)nb_i * nb_j * nb_k;
+    const unsigned long long blk = c / block_cells, rest = c - blk * block_cells;
+    const unsigned long long k = rest / ((unsigned long long)nb_i * nb_j), j = (rest / nb_i) % nb_j, i = rest % nb_i;
+    target = block_origin[blk] + k * plane_stride + j * row_stride + i;
+  }
+  float v[8];
+#pragma unroll
+  for (int q = 0; q < 8; q++) v[q] = planes[(unsigned long long)q * n_cells + c];
+  float4 *out = reinterpret_cast<float4 *>(cells + target * 8);
+  out[0] = make_float4(v[0], v[1], v[2], v[3]);
+  out[1] = make_float4(v[4], v[5], v[6], v[7]);
+}
+
+// planes[v] = the caller's variable order[v]; block_origin (host, n_blocks entries) or null
+void UploadCells(bl_ctx *ctx, const bl_grid_desc *g, const int order[8], size_t n_cells, DeviceBuffer<float> &d_cells, const int nb[3],
+                 const std::vector<unsigned long long> *block_origin, unsigned long long row_stride, unsigned long long plane_stride) {
+  EnsureStreams(ctx);
+  d_cells.Ensure(n_cells * 8);
+  ctx->d_cell_planes.Ensure(n_cells * 8);
+  for (int v = 0; v < 8; v++)
+    Check(hipMemcpyAsync(ctx->d_cell_planes.ptr + static_cast<size_t>(v) * n_cells, g->prim + static_cast<size_t>(order[v]) * n_cells, n_cells * sizeof(float),
+                         hipMemcpyHostToDevice, ctx->stream), "grid upload");
+  const unsigned long long *origin = nullptr;
+  if (block_origin != nullptr) {
+    ctx->d_block_origin.Ensure(block_origin->size());
+    Check(hipMemcpyAsync(ctx->d_block_origin.ptr, block_origin->data(), block_origin->size() * sizeof(unsigned long long), hipMemcpyHostToDevice, ctx->stream), "grid upload");
+    origin = ctx->d_block_origin.ptr;
+  }
+  hipLaunchKernelGGL(bl_interleave_cells_kernel, dim3(static_cast<unsigned int>((n_cells + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_cell_planes.ptr, d_cells.ptr,
+                     static_cast<unsigned long long>(n_cells), nb[0], nb[1], nb[2], origin, row_stride, plane_stride);
+  Check(hipGetLastError(), "cell interleave kernel launch");
+  Check(hipStreamSynchronize(ctx->stream), "grid upload");   // (the caller's arrays are borrowed for the duration of bl_set_grid)
+}
+
 void UploadMergedGrid(bl_ctx *ctx, const bl_grid_desc *g) {
     // Several blocks (simulation_sampling.cpp:352-394 searches them per sample): supported when they are
     // equal blocks at one refinement level tiling a box, in any order. They are merged into one global
@@ -489,23 +536,15 @@ void UploadMergedGrid(bl_ctx *ctx, const bl_grid_desc *g) {
     const int order[8] = {g->ind_rho, g->ind_pgas, g->ind_uu1, g->ind_uu2, g->ind_uu3, g->ind_bb1, g->ind_bb2, g->ind_bb3};
     for (int v : order)
       if (v < 0 || v >= g->n_var) throw Failure{BL_E_ARG, "Grid variable index out of range."};
-    std::vector<float> cells(n_cells * 8);
-    for (int blk = 0; blk < n_b; blk++) {
-      const int pi = block_pos[0][blk], pj = block_pos[1][blk], pk = block_pos[2][blk];
-      for (int v = 0; v < 8; v++) {
-        const float *src = g->prim + (static_cast<size_t>(order[v]) * n_b + blk) * block_cells;
-        for (int k = 0; k < nb_cells[2]; k++)
-          for (int j = 0; j < nb_cells[1]; j++) {
-            const size_t row = (static_cast<size_t>(pk * nb_cells[2] + k) * n_j + (pj * nb_cells[1] + j)) * n_i + static_cast<size_t>(pi) * nb_cells[0];
-            const float *line = src + (static_cast<size_t>(k) * nb_cells[1] + j) * nb_cells[0];
-            for (int i = 0; i < nb_cells[0]; i++) cells[(row + i) * 8 + v] = line[i];
-          }
-      }
-    }
     DeviceBuffer<float> &d_cells = ctx->cells_target != nullptr ? *ctx->cells_target : ctx->d_cells;
     DeviceBuffer<float> &d_kappa = ctx->kappa_target != nullptr ? *ctx->kappa_target : ctx->d_kappa;
-    d_cells.Ensure(cells.size());
-    Check(hipMemcpy(d_cells.ptr, cells.data(), cells.size() * sizeof(float), hipMemcpyHostToDevice), "grid upload");
+    {
+      std::vector<unsigned long long> origin(n_b);   // first cell of every block in the merged array
+      for (int blk = 0; blk < n_b; blk++)
+        origin[blk] = (static_cast<unsigned long long>(block_pos[2][blk]) * nb_cells[2] * n_j + static_cast<unsigned long long>(block_pos[1][blk]) * nb_cells[1]) * n_i
+            + static_cast<unsigned long long>(block_pos[0][blk]) * nb_cells[0];
+      UploadCells(ctx, g, order, n_cells, d_cells, nb_cells, n_b > 1 ? &origin : nullptr, static_cast<unsigned long long>(n_i), static_cast<unsigned long long>(n_i) * n_j);
+    }
     const bool code_kappa = ctx->params.plasma_model == BL_PLASMA_CODE_KAPPA;
     if (code_kappa) {
       // the ninth value of a cell (simulation_reader.cpp:1164-1172) in its own [k][j][i] array: only the
@@ -669,15 +708,9 @@ void UploadRefinedGrid(bl_ctx *ctx, const bl_grid_desc *g) {
   const int order[8] = {g->ind_rho, g->ind_pgas, g->ind_uu1, g->ind_uu2, g->ind_uu3, g->ind_bb1, g->ind_bb2, g->ind_bb3};
   for (int v : order)
     if (v < 0 || v >= g->n_var) throw Failure{BL_E_ARG, "Grid variable index out of range."};
-  std::vector<float> cells(n_cells * 8);
-  for (int v = 0; v < 8; v++) {
-    const float *src = g->prim + static_cast<size_t>(order[v]) * n_cells;
-    for (size_t c = 0; c < n_cells; c++) cells[c * 8 + v] = src[c];
-  }
   DeviceBuffer<float> &d_cells = ctx->cells_target != nullptr ? *ctx->cells_target : ctx->d_cells;
   DeviceBuffer<float> &d_kappa = ctx->kappa_target != nullptr ? *ctx->kappa_target : ctx->d_kappa;
-  d_cells.Ensure(cells.size());
-  Check(hipMemcpy(d_cells.ptr, cells.data(), cells.size() * sizeof(float), hipMemcpyHostToDevice), "grid upload");
+  UploadCells(ctx, g, order, n_cells, d_cells, nb, nullptr, 0, 0);   // (the blocks stay one behind the other: the caller's order)
   const bool code_kappa = ctx->params.plasma_model == BL_PLASMA_CODE_KAPPA;
   if (code_kappa) {
     if (g->ind_kappa < 0 || g->ind_kappa >= g->n_var) throw Failure{BL_E_ARG, "Grid variable index out of range."};

@@ -159,6 +159,8 @@ struct bl_ctx {
   int n_i = 0, n_j = 0, n_k = 0;
   bl_grid_desc grid_meta{};
   DeviceBuffer<float> d_cells;
+  DeviceBuffer<float> d_cell_planes;                 // bl_set_grid: the caller's eight variable planes as uploaded, before bl_interleave_cells_kernel
+  DeviceBuffer<unsigned long long> d_block_origin;   // ... and where every block's cells go in a merged array
   DeviceBuffer<float> d_kappa;   // electron entropy per cell (plasma_model = code_kappa)
   DeviceBuffer<double> d_coords;   // x1f x1v x2f x2v x3f x3v packed
   DeviceBuffer<unsigned short> d_buckets;
