@@ -35,10 +35,12 @@ BENCHMARK_KERNELS = {
     "_Z22bl_shade_fused2_kernelILb0ELb0ELb1EEv11BlShadeArgs": (2, 0),
     "_Z22bl_shade_exact2_kernelILb1EEv11BlShadeArgs": (2, 0),                # exact tier, locate step inside (the benchmark's exact kernel)
     "_Z22bl_shade_exact2_kernelILb0EEv11BlShadeArgs": (2, 0),
-    "_Z26bl_shade_polarized2_kernelILb1ELb0EEv11BlShadeArgs": (2, 0),        # polarized runs, locate step inside, no auxiliary records
-    "_Z26bl_shade_polarized2_kernelILb0ELb0EEv11BlShadeArgs": (2, 0),
-    "_Z26bl_shade_polarized2_kernelILb1ELb1EEv11BlShadeArgs": (2, 0),        # ... with auxiliary records
-    "_Z26bl_shade_polarized2_kernelILb0ELb1EEv11BlShadeArgs": (2, 0),
+    "_Z26bl_shade_polarized2_kernelILb1ELb0ELb0EEv11BlShadeArgs": (2, 0),    # polarized runs, locate step inside, no auxiliary records
+    "_Z26bl_shade_polarized2_kernelILb0ELb0ELb0EEv11BlShadeArgs": (2, 0),
+    "_Z26bl_shade_polarized2_kernelILb1ELb1ELb0EEv11BlShadeArgs": (2, 0),    # ... with auxiliary records
+    "_Z26bl_shade_polarized2_kernelILb0ELb1ELb0EEv11BlShadeArgs": (2, 0),
+    "_Z26bl_shade_polarized2_kernelILb1ELb0ELb1EEv11BlShadeArgs": (2, 0),    # ... one frequency, thermal electrons: the polarized coefficients evaluated inside
+    "_Z26bl_shade_polarized2_kernelILb0ELb0ELb1EEv11BlShadeArgs": (2, 0),
     "_Z21bl_shade_exact_kernelILb1EEv11BlShadeArgs": (2, 0),                 # exact tier behind a locate kernel, software-pipelined
     "_Z21bl_shade_exact_kernelILb0EEv11BlShadeArgs": (2, 0),
     "_Z22bl_locate_plain_kernelILb1EEv11BlShadeArgs": (4, 0),                # exact tier's locate step, common grid case
