@@ -385,7 +385,7 @@ void PlanJob(RenderJob &job) {
   job.rows_only = ctx->polarized && ctx->render_num_images == 0 && !fill_present && !(AI.image_time || AI.image_length || AI.image_lambda
       || AI.image_emission || AI.image_lambda_ave || AI.image_emission_ave || AI.image_tau_int || AI.image_crossings);
   // configuration 4's case: no BlCoefInputs through HBM, no bl_polarized_coefficients_kernel launch (bl_shade_fused.hip: kCoefficients)
-  job.pol_coefficients_inside = job.pol_fused && job.n_nu == 1 && job.rows_only && p.plasma_power_frac == 0.0 && p.plasma_kappa_frac == 0.0;
+  job.pol_coefficients_inside = job.pol_fused && job.n_nu == 1 && job.rows_only && p.plasma_power_frac == 0.0 && p.plasma_kappa_frac == 0.0 && ctx->st.bh_a == 0.0;
   // Host outputs of a quarter of a GiB and more in eight rows or more (configuration 5: 64 frequencies): the rays are traced in pixel
   // order - not the 8 x 8 tiles, centre first, that make chunks drain faster - so that what a chunk finishes is a range of columns,
   // downloaded while the next chunk renders (the image rows of a 4096^2 x 64 frame are 8.6 GB: 0.7 s of PCIe that used to follow the

@@ -1228,9 +1228,8 @@ extern "C" hipError_t bl_launch_shade_polarized2(const BlShadeArgs *args, int gr
   const bool spin_zero = args->st.bh_a == 0.0, records = args->aux_record_unused == 0;
   if (records && args->aux == nullptr) return hipErrorInvalidValue;
 #define BL_LAUNCH_P2(S, A) hipLaunchKernelGGL((bl_shade_polarized2_kernel<S, A>), dim3(grid), dim3(256), lds, stream, *args)
-  if (args->have_flags != nullptr && !records) {   // (bl_render.hip: one frequency, thermal electrons only)
-    if (spin_zero) hipLaunchKernelGGL((bl_shade_polarized2_kernel<true, false, true>), dim3(grid), dim3(256), lds, stream, *args);
-    else hipLaunchKernelGGL((bl_shade_polarized2_kernel<false, false, true>), dim3(grid), dim3(256), lds, stream, *args);
+  if (args->have_flags != nullptr && !records && spin_zero) {   // (bl_render.hip: one frequency, thermal electrons only, no spin)
+    hipLaunchKernelGGL((bl_shade_polarized2_kernel<true, false, true>), dim3(grid), dim3(256), lds, stream, *args);
   } else if (spin_zero && records) BL_LAUNCH_P2(true, true);
   else if (spin_zero) BL_LAUNCH_P2(true, false);
   else if (records) BL_LAUNCH_P2(false, true);

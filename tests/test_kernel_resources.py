@@ -40,7 +40,6 @@ BENCHMARK_KERNELS = {
     "_Z26bl_shade_polarized2_kernelILb1ELb1ELb0EEv11BlShadeArgs": (2, 0),    # ... with auxiliary records
     "_Z26bl_shade_polarized2_kernelILb0ELb1ELb0EEv11BlShadeArgs": (2, 0),
     "_Z26bl_shade_polarized2_kernelILb1ELb0ELb1EEv11BlShadeArgs": (2, 0),    # ... one frequency, thermal electrons: the polarized coefficients evaluated inside
-    "_Z26bl_shade_polarized2_kernelILb0ELb0ELb1EEv11BlShadeArgs": (2, 0),
     "_Z21bl_shade_exact_kernelILb1EEv11BlShadeArgs": (2, 0),                 # exact tier behind a locate kernel, software-pipelined
     "_Z21bl_shade_exact_kernelILb0EEv11BlShadeArgs": (2, 0),
     "_Z22bl_locate_plain_kernelILb1EEv11BlShadeArgs": (4, 0),                # exact tier's locate step, common grid case
