@@ -310,7 +310,7 @@ struct BlTraceArgs {
   int park_age;
   int quad_first_round;   // bl_geodesic_quad_kernel: its first this many waves (one per SIMD) run at raised priority
   int park_always;
-  // Rays predicted long, on compute units of their own from the first moment (BL_SWITCH_SPLIT_LONG, a measurement: DESIGN.md section
+  // Rays predicted long, on compute units of their own from the first moment (BL_TAIL_SPLIT: docs/notebook.md section
   // 5k). bl_split_long_kernel parks - before either stepper starts - the rays of a plane camera whose impact parameter lies in
   // [split_b_lo, split_b_hi] (in units of M: the band around the photon ring's critical curve) and marks their start state (r < 0);
   // bl_geodesic_kernel passes a marked ray over, bl_geodesic_quad_kernel steps the parked ones on a stream whose CU mask the

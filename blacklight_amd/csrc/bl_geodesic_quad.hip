@@ -3,7 +3,7 @@
 //   bl_geodesic_quad_kernel   finishes the rays bl_geodesic_kernel parked (BlTraceArgs::parked, bl_device.h).
 //
 // Behind a measurement switch (BL_SWITCH_QUAD_TAIL / BL_SWITCH_QUAD_EVERY_RAY): bit-identical to the ray-per-lane kernel, 1.5 - 1.65
-// times faster for a ray alone, 2.6 times dearer per ray-step in issue slots - see the end of this comment and DESIGN.md section 5j.
+// times faster for a ray alone, 2.6 times dearer per ray-step in issue slots - see the end of this comment and docs/notebook.md section 5j.
 //
 // A ray is a chain of steps, a step a chain of six right-hand sides, and a wave issues its instructions one after the other
 // however few of its lanes hold a ray: with a ray per lane the last rays of a chunk - the long rays of the 512^2 formula frame,
@@ -26,7 +26,7 @@
 // cycles whatever it holds, so a lone ray is stepped 1.5 - 1.65 times faster (tools/gpu_quad_latency.py: 49.8 -> 33.3 ms for 64
 // rays around the photon ring at a = 0.9); but a wave holds 16 rays instead of 64, so where SIMDs are not idle it is 2.6 times
 // dearer per ray-step. With every wave parking its rays once the queue is dry, configuration 2 takes 67 ms instead of 77 and the
-// benchmark frame 55.6 instead of 49.2; an eighth of the benchmark frame is unchanged (DESIGN.md section 5j has the table).
+// benchmark frame 55.6 instead of 49.2; an eighth of the benchmark frame is unchanged (docs/notebook.md section 5j has the table).
 #include "bl_geodesic_common.h"
 
 namespace {

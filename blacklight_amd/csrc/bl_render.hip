@@ -620,7 +620,7 @@ void PlanScratch(RenderJob &job) {
     // as far as the quad stepper's compute units hold it in ONE round of quads (a second round doubles its time) - a quad per ray,
     // 16 per wave, a wave per SIMD. The compute units: an eighth of the device, bits 0 ... num_cus / 8 - 1 of the mask - on MI355X
     // one CU of every shader engine of every XCD (tools/ubench/cu_mask_probe.hip), which leaves the other stepper's share of every
-    // shader engine equal; other counts were measured and lose (uneven shader engines fill unevenly: DESIGN.md section 5k).
+    // shader engine equal; other counts were measured and lose (uneven shader engines fill unevenly: docs/notebook.md section 5k).
     // How densely the call's rays cover the ring is counted on the host from every 1 / stride-th of them.
     const double centre = 5.196152422706632 * ctx->st.bh_m;
     const double scale = ctx->st.bh_m * p.camera_width / p.camera_resolution, half = 0.5 * p.camera_resolution - 0.5;
@@ -1098,7 +1098,7 @@ void BuildShadeArgs(RenderJob &job) {
     sa.undefined_edge = (ctx->undefined_policy & BL_UNDEFINED_EDGE) ? 1 : 0;
     // Polarized runs in the tolerant tier keep the exact tier's per-frequency coefficient kernel: the reference's polarized step
     // amplifies last-place differences of the coefficients by up to ten orders of magnitude in optically and Faraday thick
-    // configurations, so only bit-identical coefficients keep Stokes V within the tier's tolerance
+    // configurations (docs/notebook.md section 5h), so only bit-identical coefficients keep Stokes V within the tier's tolerance
     // everywhere. The tolerant coefficient kernel (106 -> 59 ms per 1024^2 frame) is there for the asking.
     sa.tolerant = job.fast ? 1 : 0;
   } else {

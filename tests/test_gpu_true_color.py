@@ -71,7 +71,7 @@ def test_true_color_at_size_is_independent_of_how_it_is_split(built_library):
         assert full["image"].shape == (n_freq, res * res)
         assert full["stats"].n_chunks > 1           # 1 KiB of transfer records per sample
         # the tolerant tier on the same frame: per-sample factors and one lane per (ray, frequency), no transfer records
-        #  - every row within north_star's tolerance of the exact tier's, integer results identical
+        # (docs/notebook.md section 5f) - every row within north_star's tolerance of the exact tier's, integer results identical
         ctx.set_arithmetic("tolerant")
         tolerant = ctx.render()
         ctx.set_arithmetic("exact")

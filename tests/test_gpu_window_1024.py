@@ -202,7 +202,7 @@ def test_polarized_frame_at_size_is_independent_of_how_it_is_split(built_library
     with bl.Context(p) as ctx:
         ctx.set_grid(grid)
         full = _split_property(ctx, 1024, 3, 32)
-        # the tolerant tier on the same frame - transport matrices instead of the tensor transport, rays of
+        # the tolerant tier on the same frame - transport matrices instead of the tensor transport (docs/notebook.md section 5d), rays of
         # every length across the 64-sample segments of bl_transport_matrix_kernel: north_star's tolerance row by row
         ctx.set_arithmetic("tolerant")
         tolerant = ctx.render()

@@ -1,4 +1,4 @@
-# Every sweep tool once, seeds from $1 (default 100000): a final check of a library before a release.
+# Every sweep tool once (docs/notebook.md section 5h), seeds from $1 (default 100000): a final check of a library before a release.
 # $2 = 1 or 2 runs one half (a gpurun call is at most 20 minutes: the two halves take ~5 and ~10).
 set -u
 : "${GRAFT_REPO_ROOT:?run through gpurun}"
