@@ -112,6 +112,8 @@ OTHER_WORKLOADS = {
                "frame 1 integrates the geodesics and leaves their sample records in HBM, frames 2 ... 8 shade them again (bl_set_geodesic_reuse)",
     "series8_refined": "the same series over the two-level refined mesh of refined256: frames 2 ... 8 also keep the located samples "
                        "(the reference's first_time sampling, radiation_integrator.cpp:693-704)",
+    "series8_pipelined": "series8 with the next snapshot staged (bl_set_grid on a second host thread, into the second cell array) while the current one "
+                         "renders: value = rays per second of the whole series' wall time, staging included",
 }
 
 
@@ -126,6 +128,62 @@ def relative_distance(got, want):
     return {"per_pixel_rel_linf": float(rel.max()) if rel.size else 0.0, "pixels_above_1e-6": int((rel > 1.0e-6).sum()),
             "pixels_compared": int(use.sum()),
             "same_nonfinite_and_nonpositive_pixels": bool(np.array_equal(np.isfinite(got) & (got > 0.0), np.isfinite(want) & (want > 0.0)))}
+
+
+def pipelined_series(args, params, grids, image, sample_num, flags, device):
+    """--workload series8_pipelined: frame n renders on this thread while a second host thread hands snapshot n + 1 to bl_set_grid (same
+    geometry: its cells go up beside the render and take effect with the next one). The clock runs from the first bl_set_grid to the
+    last image; frames are checked against the unpipelined series."""
+    import threading
+    import torch
+    import blacklight_amd as bl
+    n_frames, n_rays = len(grids), image.shape[1]
+    line = None
+    with bl.Context(bl.Params.from_dict(params), device=0) as ctx:
+        ctx.set_arithmetic(args.arithmetic)
+        ctx.set_reproducible(True)   # (so that the check below can ask for the same bits)
+        ctx.follow_torch_stream(device)
+        reference = []
+        for rep in range(args.warmup + 1):
+            ctx.set_geodesic_reuse(False)
+            ctx.set_geodesic_reuse(True)
+            images, stats = [], []
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ctx.set_grid(grids[0])
+            staged = None
+            for n in range(n_frames):
+                if staged is not None:
+                    staged.join()          # snapshot n is in place
+                if n + 1 < n_frames:
+                    staged = threading.Thread(target=ctx.set_grid, args=(grids[n + 1],))
+                    staged.start()         # ... and n + 1 goes up while n renders
+                else:
+                    staged = None
+                st = ctx.render_device(image.data_ptr(), n_rays, sample_num_ptr=sample_num.data_ptr(), sample_flags_ptr=flags.data_ptr())
+                stats.append((int(st.geodesics_reused), st.ms_shade, st.ms_geodesic))
+                if rep == args.warmup:
+                    images.append(image.clone())
+            torch.cuda.synchronize()
+            elapsed = time.perf_counter() - t0
+        # the same series one step after the other: the same frames?
+        ctx.set_geodesic_reuse(False)
+        ctx.set_geodesic_reuse(True)
+        same = True
+        for n in range(n_frames):
+            ctx.set_grid(grids[n])
+            ctx.render_device(image.data_ptr(), n_rays, sample_num_ptr=sample_num.data_ptr(), sample_flags_ptr=flags.data_ptr())
+            torch.cuda.synchronize()
+            same = same and bool(torch.equal(image.view(torch.int64), images[n].view(torch.int64)))
+        line = {
+            "metric": "Mrays/sec of a whole series of 8 snapshots, grid staging included, next snapshot staged beside the render",
+            "value": n_frames * n_rays / elapsed / 1.0e6, "unit": "Mrays/s", "n_gpus": 1, "steps": n_frames, "warmup": args.warmup,
+            "ms_per_step": 1000.0 * elapsed / n_frames, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": OTHER_WORKLOADS["series8_pipelined"], "arithmetic": args.arithmetic, "rays_per_step": n_rays, "parallelism": "1 GPU, 2 host threads"},
+            "frames_reused_geodesics": [s[0] for s in stats], "shade_ms": [round(s[1], 2) for s in stats], "geodesic_ms": [round(s[2], 2) for s in stats],
+            "frames_equal_the_unpipelined_series_bit_for_bit": same,
+        }
+    print(json.dumps(line), flush=True)
 
 
 def series_workload(args):
@@ -158,6 +216,8 @@ def series_workload(args):
     image = torch.zeros((1, n_rays), dtype=torch.float64, device=device)
     sample_num = torch.zeros(n_rays, dtype=torch.int32, device=device)
     flags = torch.zeros(n_rays, dtype=torch.uint8, device=device)
+    if name == "series8_pipelined":
+        return pipelined_series(args, params, [snapshot(n) for n in range(n_frames)], image, sample_num, flags, device)
     frames = []
     with bl.Context(bl.Params.from_dict(params), device=0) as ctx:
         ctx.set_arithmetic(args.arithmetic)

@@ -446,24 +446,45 @@ __global__ void __launch_bounds__(256) bl_interleave_cells_kernel(const float *p
 }
 
 // planes[v] = the caller's variable order[v]; block_origin (host, n_blocks entries) or null
-void UploadCells(bl_ctx *ctx, const bl_grid_desc *g, const int order[8], size_t n_cells, DeviceBuffer<float> &d_cells, const int nb[3],
-                 const std::vector<unsigned long long> *block_origin, unsigned long long row_stride, unsigned long long plane_stride) {
-  EnsureStreams(ctx);
+// The planes of `g` into `d_cells` as ctx->placement says, on `stream`; returns when the cells are in place (the caller's arrays are
+// borrowed for the duration of bl_set_grid)
+void UploadCellsAs(bl_ctx *ctx, const bl_grid_desc *g, DeviceBuffer<float> &d_cells, hipStream_t stream, bool upload_origin) {
+  const bl_ctx::CellPlacement &pl = ctx->placement;
+  const size_t n_cells = pl.n_cells;
   d_cells.Ensure(n_cells * 8);
   ctx->d_cell_planes.Ensure(n_cells * 8);
   for (int v = 0; v < 8; v++)
-    Check(hipMemcpyAsync(ctx->d_cell_planes.ptr + static_cast<size_t>(v) * n_cells, g->prim + static_cast<size_t>(order[v]) * n_cells, n_cells * sizeof(float),
-                         hipMemcpyHostToDevice, ctx->stream), "grid upload");
+    Check(hipMemcpyAsync(ctx->d_cell_planes.ptr + static_cast<size_t>(v) * n_cells, g->prim + static_cast<size_t>(pl.order[v]) * n_cells, n_cells * sizeof(float),
+                         hipMemcpyHostToDevice, stream), "grid upload");
   const unsigned long long *origin = nullptr;
-  if (block_origin != nullptr) {
-    ctx->d_block_origin.Ensure(block_origin->size());
-    Check(hipMemcpyAsync(ctx->d_block_origin.ptr, block_origin->data(), block_origin->size() * sizeof(unsigned long long), hipMemcpyHostToDevice, ctx->stream), "grid upload");
+  if (pl.has_origin) {
+    if (upload_origin) {
+      ctx->d_block_origin.Ensure(pl.origin.size());
+      Check(hipMemcpyAsync(ctx->d_block_origin.ptr, pl.origin.data(), pl.origin.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, stream), "grid upload");
+    }
     origin = ctx->d_block_origin.ptr;
   }
-  hipLaunchKernelGGL(bl_interleave_cells_kernel, dim3(static_cast<unsigned int>((n_cells + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_cell_planes.ptr, d_cells.ptr,
-                     static_cast<unsigned long long>(n_cells), nb[0], nb[1], nb[2], origin, row_stride, plane_stride);
+  hipLaunchKernelGGL(bl_interleave_cells_kernel, dim3(static_cast<unsigned int>((n_cells + 255) / 256)), dim3(256), 0, stream, ctx->d_cell_planes.ptr, d_cells.ptr,
+                     static_cast<unsigned long long>(n_cells), pl.nb[0], pl.nb[1], pl.nb[2], origin, pl.row_stride, pl.plane_stride);
   Check(hipGetLastError(), "cell interleave kernel launch");
-  Check(hipStreamSynchronize(ctx->stream), "grid upload");   // (the caller's arrays are borrowed for the duration of bl_set_grid)
+  Check(hipStreamSynchronize(stream), "grid upload");
+}
+
+// planes[v] = the caller's variable order[v]; block_origin (host, n_blocks entries) or null
+void UploadCells(bl_ctx *ctx, const bl_grid_desc *g, const int order[8], size_t n_cells, DeviceBuffer<float> &d_cells, const int nb[3],
+                 const std::vector<unsigned long long> *block_origin, unsigned long long row_stride, unsigned long long plane_stride) {
+  EnsureStreams(ctx);
+  bl_ctx::CellPlacement &pl = ctx->placement;
+  pl.valid = false;
+  pl.n_cells = n_cells;
+  for (int a = 0; a < 3; a++) pl.nb[a] = nb[a];
+  for (int v = 0; v < 8; v++) pl.order[v] = order[v];
+  pl.has_origin = block_origin != nullptr;
+  pl.origin = block_origin != nullptr ? *block_origin : std::vector<unsigned long long>();
+  pl.row_stride = row_stride;
+  pl.plane_stride = plane_stride;
+  UploadCellsAs(ctx, g, d_cells, ctx->stream, true);
+  pl.valid = ctx->cells_target == nullptr;   // (the time slices of slow light have no second array to change places with)
 }
 
 void UploadMergedGrid(bl_ctx *ctx, const bl_grid_desc *g) {
@@ -910,8 +931,27 @@ int bl_set_grid(bl_ctx *ctx, const bl_grid_desc *g) {
     if (g->n_blocks < 1) throw Failure{BL_E_ARG, "Bad grid description."};
     if (g->n_i < 2 || g->n_j < 2 || g->n_k < 2 || g->prim == nullptr) throw Failure{BL_E_ARG, "Bad grid description."};
     Check(hipSetDevice(ctx->device), "hipSetDevice");
+    // The next snapshot of a series - the geometry in place, to the bit, and the same variables: only the cells are new. They go up on
+    // a stream of their own into the second cell array while a render of this context may be running on another host thread, and the
+    // arrays change places once that render has ended. (With electron entropy from the grid there is a second array to double: the
+    // long way.)
+    const bool code_kappa = ctx->params.plasma_model == BL_PLASMA_CODE_KAPPA;
+    const int order_now[8] = {g->ind_rho, g->ind_pgas, g->ind_uu1, g->ind_uu2, g->ind_uu3, g->ind_bb1, g->ind_bb2, g->ind_bb3};
+    if (ctx->have_grid && ctx->cells_target == nullptr && ctx->placement.valid && !code_kappa && ctx->grid_geometry != 0 && GridGeometryHash(g) == ctx->grid_geometry
+        && std::equal(order_now, order_now + 8, ctx->placement.order) && g->n_var == ctx->grid_meta.n_var
+        && g->plasma_gamma == ctx->grid_meta.plasma_gamma && g->plasma_gamma_i == ctx->grid_meta.plasma_gamma_i && g->plasma_gamma_e == ctx->grid_meta.plasma_gamma_e) {
+      if (ctx->stream_upload == nullptr) Check(hipStreamCreateWithFlags(&ctx->stream_upload, hipStreamNonBlocking), "hipStreamCreate");
+      UploadCellsAs(ctx, g, ctx->d_cells_back, ctx->stream_upload, false);
+      std::lock_guard<std::mutex> guard(ctx->render_lock);
+      std::swap(ctx->d_cells, ctx->d_cells_back);
+      ctx->grid_dev.cells = ctx->d_cells.ptr;
+      ctx->grid_meta = *g;
+      return BL_OK;
+    }
+    std::lock_guard<std::mutex> guard(ctx->render_lock);   // (everything about the grid changes: not beside a render)
     ctx->have_grid = false;   // a failed upload leaves no grid behind (the previous one may be half overwritten)
     ctx->grid_geometry = 0;
+    ctx->placement.valid = false;
     if (ctx->params.simulation_interp && ctx->params.simulation_block_interp) {
       UploadRefinedGrid(ctx, g);   // inter-block interpolation works on the MeshBlocks as they are
     } else {
@@ -1132,6 +1172,7 @@ void bl_free(bl_ctx *ctx) {
   if (ctx->caller_event != nullptr) (void)hipEventDestroy(ctx->caller_event);
   if (ctx->stream != nullptr) (void)hipStreamDestroy(ctx->stream);
   if (ctx->stream_geo != nullptr) (void)hipStreamDestroy(ctx->stream_geo);
+  if (ctx->stream_upload != nullptr) (void)hipStreamDestroy(ctx->stream_upload);
   // (stream_few / stream_most are the process's, borrowed: EnsureSplitStreams)
   delete ctx;
 }

@@ -159,6 +159,21 @@ struct bl_ctx {
   int n_i = 0, n_j = 0, n_k = 0;
   bl_grid_desc grid_meta{};
   DeviceBuffer<float> d_cells;
+  // bl_set_grid beside bl_render (another host thread: the next snapshot of a series staged while this one renders). The render holds
+  // render_lock from start to end; a bl_set_grid whose geometry is the one in place uploads its cells into d_cells_back on a stream of
+  // its own without the lock, then takes it - waiting for the render to end - to let the two cell arrays change places.
+  std::mutex render_lock;
+  DeviceBuffer<float> d_cells_back;
+  hipStream_t stream_upload = nullptr;
+  struct CellPlacement {   // how the caller's planes become d_cells, as the full upload decided (UploadCells)
+    bool valid = false, code_kappa = false;
+    size_t n_cells = 0;
+    int nb[3] = {0, 0, 0};
+    int order[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool has_origin = false;
+    std::vector<unsigned long long> origin;
+    unsigned long long row_stride = 0, plane_stride = 0;
+  } placement;
   DeviceBuffer<float> d_cell_planes;                 // bl_set_grid: the caller's eight variable planes as uploaded, before bl_interleave_cells_kernel
   DeviceBuffer<unsigned long long> d_block_origin;   // ... and where every block's cells go in a merged array
   DeviceBuffer<float> d_kappa;   // electron entropy per cell (plasma_model = code_kappa)

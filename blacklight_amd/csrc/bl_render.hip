@@ -2068,6 +2068,7 @@ void EnsureStreams(bl_ctx *ctx) {
 
 extern "C" int bl_render(bl_ctx *ctx, const bl_render_desc *d) {
   if (ctx == nullptr || d == nullptr) return BL_E_ARG;
+  std::lock_guard<std::mutex> render_guard(ctx->render_lock);   // (bl_set_grid on another host thread stages the next snapshot meanwhile: bl_api.hip)
   auto drain = [ctx]() {   // leave no chunk half collected behind: a later call starts from idle streams
     if (ctx->stream_few != nullptr) (void)hipStreamSynchronize(ctx->stream_few);
     if (ctx->stream_most != nullptr) (void)hipStreamSynchronize(ctx->stream_most);

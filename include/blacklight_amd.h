@@ -325,9 +325,14 @@ BL_API int bl_init(const bl_params *p, int device, bl_ctx **out);
 /* HIP devices visible to this process (0: none). One context per device and one host thread per context is how one process
  * drives several GPUs: bl_render is thread-safe across contexts (bin/blacklight_amd with BLACKLIGHT_AMD_DEVICES does that). */
 BL_API int bl_device_count(void);
-/* Repack the grid into the HBM layout and upload it; once per snapshot. Equal blocks of one level tiling a
- * box are merged into one [k][j][i][8 floats] array; other sets of non-overlapping equal-sized blocks (mesh
- * refinement) stay [block][k][j][i][8] behind a lattice of block boundaries. Overlapping blocks are refused. */
+/* The grid into its HBM layout; once per snapshot. Equal blocks of one level tiling a box are merged into one [k][j][i][8 floats]
+ * array; other sets of non-overlapping equal-sized blocks (mesh refinement) stay [block][k][j][i][8] behind a lattice of block
+ * boundaries. Overlapping blocks are refused. The variable planes are uploaded as they lie and interleaved on the device (a 256^3
+ * snapshot: 33 ms, the PCIe copy of its 537 MB).
+ * Beside a render: when the geometry handed over is, to the bit, the one in place (the next snapshot of a series) bl_set_grid may be
+ * called on another host thread while bl_render of the same context runs: the cells go up on a stream of their own into a second
+ * cell array, and the call returns once that render has ended and the arrays have changed places - the new cells are what the NEXT
+ * bl_render reads. One bl_set_grid at a time per context; any other change of the grid waits for the render and excludes it. */
 BL_API int bl_set_grid(bl_ctx *ctx, const bl_grid_desc *g);
 /* ---- slow light (slow_light_on = true): the reader keeps a window of slow_chunk_size files, latest first
  * (simulation_reader.cpp:211-303), all on the geometry of the first; every sample reads the slice(s) around

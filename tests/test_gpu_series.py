@@ -240,3 +240,47 @@ def test_formula_frames_reuse_too():
         assert first["stats"].geodesics_reused == 0 and second["stats"].geodesics_reused == 1
         assert second["stats"].tail_policy == first["stats"].tail_policy and second["stats"].n_parked == first["stats"].n_parked
         _same_frame(second, first)
+
+
+def test_next_snapshot_staged_beside_the_render():
+    """bl_set_grid on a second host thread while bl_render runs (same geometry: the cells go up into the second cell array and take
+    effect with the next render): the frames of a series staged that way are the frames of the series rendered step by step, and a
+    change of geometry in between still waits its turn."""
+    import threading
+    import bench
+    import blacklight_amd as bl
+    from blacklight_amd import mock
+    params = dict(bench.WORKLOAD, camera_resolution=192)
+    base = mock.generate(n_r=64, n_th=64, n_ph=64)
+    snaps = _snapshots(base, 6)
+    want = []
+    with bl.Context(bl.Params.from_dict(params)) as ctx:
+        ctx.set_arithmetic("exact")
+        for grid in snaps:
+            ctx.set_grid(grid)
+            want.append(ctx.render())
+    with bl.Context(bl.Params.from_dict(params)) as ctx:
+        ctx.set_arithmetic("exact")
+        ctx.set_grid(snaps[0])
+        got, staged = [], None
+        for n in range(len(snaps)):
+            if staged is not None:
+                staged.join()
+            staged = None
+            if n + 1 < len(snaps):
+                staged = threading.Thread(target=ctx.set_grid, args=(snaps[n + 1],))
+                staged.start()
+            got.append(ctx.render())
+        assert [g["stats"].geodesics_reused for g in got] == [0, 1, 1, 1, 1, 1]
+        for a, b in zip(got, want):
+            _same_frame(a, b)
+        # another geometry from the second thread: excluded by the render, complete before the next one
+        other = mock.generate(n_r=48, n_th=48, n_ph=48)
+        worker = threading.Thread(target=ctx.set_grid, args=(other,))
+        worker.start()
+        during = ctx.render()          # (either grid, whole: the two calls exclude each other)
+        worker.join()
+        after = ctx.render()
+    alone = _fresh(params, other, "exact")
+    _same_frame(after, alone)
+    assert gu.same_bits(during["image"], want[-1]["image"]).all() or gu.same_bits(during["image"], alone["image"]).all()
