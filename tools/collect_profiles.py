@@ -1,5 +1,6 @@
-"""Copy the summaries of tools/gpu_profile_r4.sh (gpurun_out/prof_r4) to profiles/r04_* and write profiles/hbm_traffic.json (what
-bench.py's roofline.traffic reads) with the hash of the kernel sources the numbers were measured on.   python3 tools/collect_profiles.py [r04]"""
+"""Copy the summaries of tools/gpu_profile_rN.sh (gpurun_out/prof_rN) to profiles/r0N_* and write profiles/hbm_traffic.json (what
+bench.py's roofline.traffic and .traffic_whole_pipeline read) with the hash of the kernel sources the numbers were measured on.
+    python3 tools/collect_profiles.py r06"""
 import json
 import os
 import shutil
@@ -30,6 +31,15 @@ for tier, prefix in (("tolerant", "void " + line["roofline"]["kernel"]), ("exact
             record[tier] = {"kernel": k, "coefficient_kernel_bytes_per_launch": v["fetch_bytes_per_launch_x2_corrected"] + v["write_bytes_per_launch"],
                             "fetch_bytes_per_launch": v["fetch_bytes_per_launch_x2_corrected"], "write_bytes_per_launch": v["write_bytes_per_launch"],
                             "source": source}
+# the whole pipeline of a frame, fabric bytes: ray start + stepper + coefficient kernel (+ the tolerant tier's exact second pass) + transfer
+def per_launch(prefix):
+    return sum(v["fetch_bytes_per_launch_x2_corrected"] + v["write_bytes_per_launch"] for k, v in raw.items() if k.startswith(prefix))
+common = per_launch("void bl_ray_init_kernel") + per_launch("void bl_geodesic_kernel")
+if "tolerant" in record:
+    record["tolerant"]["whole_pipeline_bytes_per_frame"] = (common + record["tolerant"]["coefficient_kernel_bytes_per_launch"]
+                                                            + per_launch("void bl_shade_kernel<0, false, false, true, false, true, true>") + per_launch("bl_transfer_composed_kernel"))
+if "exact" in record:
+    record["exact"]["whole_pipeline_bytes_per_frame"] = common + record["exact"]["coefficient_kernel_bytes_per_launch"] + per_launch("void bl_transfer_kernel<false>")
 record["all_kernels"] = raw
 json.dump(record, open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
 print(json.dumps({k: v for k, v in record.items() if k != "all_kernels"}, indent=1))
