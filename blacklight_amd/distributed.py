@@ -365,13 +365,26 @@ def render_level(ctx, comm, level=0, block_locs=None, want_camera=False, tile=No
         max_num, n_flagged = comm.reduce_counts(max_num, n_flagged)
     result = dict(max_sample_num=max_num, n_flagged=n_flagged, n_rays=n_total) if rank == 0 else None
     import torch
+    landed = {}
     for name, rows, dtype in specs:
         gathered = torch.stack([share[name] for share in shares]) if emulated else comm.gather_flat(buffers[name])
         if rank != 0:
             continue
-        # de-tiled where the gather left it (the GPU for RCCL), then ONE download per output of the level
+        # de-tiled where the gather left it (the GPU for RCCL); the downloads of all outputs of the level are queued - into pinned
+        # memory from torch's caching host allocator, without waiting - and waited for once, below
         ray_major = name in ("camera_pos", "camera_dir")          # the library writes rays x 4 there, rows x rays elsewhere
-        full = layout.detile(gathered, rows, ray_major=ray_major).cpu().numpy()
+        whole = layout.detile(gathered, rows, ray_major=ray_major)
+        if whole.is_cuda:
+            host = torch.empty(whole.shape, dtype=whole.dtype, pin_memory=True)
+            host.copy_(whole, non_blocking=True)
+            whole = host
+        landed[name] = whole
+    if any(t.is_pinned() for t in landed.values()):
+        torch.cuda.current_stream().synchronize()
+    for name, rows, dtype in specs:
+        if rank != 0:
+            continue
+        full = landed[name].numpy()
         if name in ("sample_num", "sample_flags"):
             result[name] = full[0]
         elif name == "rendering":
