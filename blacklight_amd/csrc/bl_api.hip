@@ -1047,6 +1047,7 @@ void bl_host_free(bl_ctx *ctx, void *p) {
 
 int bl_set_geodesic_reuse(bl_ctx *ctx, int on) {
   if (ctx == nullptr) return BL_E_ARG;
+  std::lock_guard<std::mutex> guard(ctx->render_lock);   // (not beside a render of this context)
   ctx->geodesic_reuse = on ? 1 : 0;
   if (!on && ctx->device != BL_DEVICE_NONE) {   // what was kept goes back to the device
     (void)hipSetDevice(ctx->device);
