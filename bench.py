@@ -599,6 +599,35 @@ def main():
         # ... and the way north_star words the bar: per pixel, relative to that pixel's own intensity
         tier_distance.update(relative_distance(image[0, :n_rays].cpu().numpy(), exact_image[0, :n_rays].cpu().numpy()))
 
+    # A short series on the side (N = 1): the reference's production mode integrates the geodesics once per series - frames 2 ... 4 of
+    # four snapshots shade the records frame 1 left (`--workload series8` is the full measurement; `value` above is a complete render)
+    series = None
+    if not distributed:
+        import dataclasses
+        ctx.set_arithmetic(args.arithmetic)
+        ctx.set_geodesic_reuse(True)
+        frame_ms, staged_ms, reused = [], [], []
+        for n in range(4):
+            prim = grid.prim.copy()
+            prim[0:2] *= np.float32(1.0 + 0.07 * n)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ctx.set_grid(dataclasses.replace(grid, prim=prim))
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            st = step()
+            torch.cuda.synchronize()
+            frame_ms.append(1000.0 * (time.perf_counter() - t1))
+            staged_ms.append(1000.0 * (t1 - t0))
+            reused.append(int(st.geodesics_reused))
+        ctx.set_geodesic_reuse(False)
+        ctx.set_grid(grid)
+        step()   # (the benchmark's own frame back in `image` for the cross-check against the oracle below)
+        torch.cuda.synchronize()
+        later = frame_ms[1:]
+        series = {"frames": 4, "frame_1_ms": frame_ms[0], "frames_2_to_4_ms": sum(later) / len(later), "geodesics_reused": reused,
+                  "mrays_per_s_frames_2_to_4": n_rays / (sum(later) / len(later) * 1.0e-3) / 1.0e6, "ms_set_grid": sum(staged_ms) / len(staged_ms)}
+
     rehearsal = None
     if rehearse and tiled:
         # the frame the ranks put together against the frame one rank renders alone: same bits, or the tiling / padding /
@@ -678,6 +707,8 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_whole_pipeline": traffic_whole, "traffic_source": traffic_source, "traffic_stale": traffic_stale,
                          "algorithmic_bytes_per_launch": main_run["bytes_per_launch"], "ms_per_launch": main_run["shade_ms_per_launch"]},
         }
+        if series is not None:
+            line["series"] = series
         if rehearsal is not None:
             line["rehearsal"] = rehearsal
             line["data"] = "synthetic; REHEARSAL: the ranks shared one GPU and gathered over gloo - times mean nothing"
