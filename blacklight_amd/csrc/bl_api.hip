@@ -1052,6 +1052,7 @@ int bl_set_geodesic_reuse(bl_ctx *ctx, int on) {
   if (!on && ctx->device != BL_DEVICE_NONE) {   // what was kept goes back to the device
     (void)hipSetDevice(ctx->device);
     ctx->resident.valid = ctx->resident.located_valid = false;
+    ctx->resident.parked = false;
     ctx->resident.store.Free();
   }
   return BL_OK;
