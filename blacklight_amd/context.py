@@ -133,7 +133,7 @@ class Context:
         self.set_caller_stream(torch.cuda.current_stream(device).cuda_stream)
 
     def debug_set_switches(self, *names):
-        """Measurement switches of this context by name (_capi.SWITCHES: "RECORD_EVERY_STEP", "GENERAL_FUSED", ...); none: all off.
+        """Measurement switches of this context by name (_capi.SWITCHES: "RECORD_EVERY_STEP", "NO_FUSED_LOCATE", ...); none: all off.
         They select another kernel or layout with the same results (bl_stats.switches echoes them)."""
         mask = 0
         for name in names:
