@@ -875,6 +875,60 @@ void UploadRefinedGrid(bl_ctx *ctx, const bl_grid_desc *g) {
     const size_t bytes = doubles * sizeof(double) + (ints + 3) / 4 * 4 * sizeof(int);
     dev.refined_lds_bytes = bytes <= 36u * 1024u ? static_cast<int>(bytes) : 0;
   }
+  {
+    // what bl_shade_fused2_kernel<..., kRefined> asks of a mesh (bl_shade_fused.hip): boxes and rows evenly spaced in log r / theta / phi to
+    // 1e-4 of a cell (its guesses are then right wherever its margins let it decide), the sphere covered without a hole, 32-bit byte
+    // offsets into the cell array, room in LDS for the row chunks and one descriptor per box at two workgroups to a compute unit
+    auto evenly = [](const double *f, int n, bool logarithmic, double *origin, double *inv_w) {
+      if (n < 1 || (logarithmic && !(f[0] > 0.0))) return false;
+      const double first = logarithmic ? std::log2(f[0]) : f[0], last = logarithmic ? std::log2(f[n]) : f[n];
+      const double width = (last - first) / n;
+      if (!(width > 0.0)) return false;
+      for (int c = 0; c <= n; c++)
+        if (!(std::abs((logarithmic ? std::log2(f[c]) : f[c]) - (first + c * width)) <= 1.0e-4 * width)) return false;
+      *origin = first;
+      *inv_w = 1.0 / width;
+      return true;
+    };
+    bool ok = nb[0] >= 2 && nb[1] >= 2 && nb[2] >= 2 && n_cells * 32ull < (1ull << 32) && static_cast<unsigned long long>(nb[1]) * nb[2] < (1ull << 24);
+    for (size_t box = 0; box < n_boxes && ok; box++) ok = lattice[box] >= 0;
+    ok = ok && edge[1].front() <= 0.0 && edge[1].back() >= kPi && edge[2].front() <= 0.0 && edge[2].back() >= 2.0 * kPi;
+    double origin[3] = {0.0, 0.0, 0.0}, inv_w[3] = {0.0, 0.0, 0.0};
+    for (int a = 0; a < 3 && ok; a++) ok = evenly(edge[a].data(), n_edge[a], a == 0, &origin[a], &inv_w[a]);
+    size_t chunk_at[3] = {0, 0, 0}, bytes = 48 * sizeof(double);
+    for (int a = 0; a < 3 && ok; a++) {
+      chunk_at[a] = bytes - 48 * sizeof(double);   // (relative to the first chunk: the kernel adds where that lies)
+      for (int q = 0; q < n_rows[a] && ok; q++) {
+        const double *guess = coords.data() + off_g[a] + 3 * static_cast<size_t>(q);
+        double row_origin, row_inv_w;
+        ok = (guess[0] != 0.0) == (a == 0) && evenly(coords.data() + off_f[a] + static_cast<size_t>(q) * (nb[a] + 1), nb[a], a == 0, &row_origin, &row_inv_w);
+      }
+      bytes += static_cast<size_t>(n_rows[a]) * (16 + 64 * static_cast<size_t>(nb[a]));
+    }
+    bytes += 16 * n_boxes;
+    ok = ok && bytes <= 76u * 1024u;
+    if (ok) {
+      std::vector<unsigned int> desc(4 * n_boxes);
+      for (size_t box = 0; box < n_boxes; box++) {
+        const int blk = lattice[box];
+        desc[4 * box] = static_cast<unsigned int>(static_cast<size_t>(blk) * block_cells * 32);
+        for (int a = 0; a < 3; a++)
+          desc[4 * box + 1 + a] = static_cast<unsigned int>(chunk_at[a] + static_cast<size_t>(block_row[static_cast<size_t>(a) * n_b + blk]) * (16 + 64 * static_cast<size_t>(nb[a])));
+      }
+      ctx->d_fused_desc.Ensure(desc.size());
+      Check(hipMemcpy(ctx->d_fused_desc.ptr, desc.data(), desc.size() * sizeof(unsigned int), hipMemcpyHostToDevice), "lattice upload");
+      dev.fused_desc = ctx->d_fused_desc.ptr;
+      dev.fused_lds_bytes = static_cast<int>(bytes);
+      dev.box_l0 = static_cast<float>(origin[0]);
+      dev.box_linv = static_cast<float>(inv_w[0]);
+      for (int a = 1; a < 3; a++) {
+        dev.box_x0[a - 1] = origin[a];
+        dev.box_inv_w[a - 1] = inv_w[a];
+      }
+      dev.r_face_in = edge[0].front();
+      dev.r_face_out = edge[0].back();
+    }
+  }
   ctx->grid_dev = dev;
   ctx->lds_table_bytes = 0;
   ctx->n_i = nb[0];

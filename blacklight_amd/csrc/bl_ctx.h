@@ -34,6 +34,7 @@ extern "C" hipError_t bl_launch_locate(const BlShadeArgs *args, int grid, int ld
 extern "C" hipError_t bl_launch_shade(const BlShadeArgs *args, int model, int grid, hipStream_t stream);
 extern "C" hipError_t bl_launch_shade_fast(const BlShadeArgs *args, int grid, hipStream_t stream);
 extern "C" int bl_fused2_applicable(const BlGridDevice *grid, int n_nu, long long n_rays);
+extern "C" int bl_fused2_refined_applicable(const BlGridDevice *grid, int n_nu, long long n_rays);
 extern "C" hipError_t bl_launch_transfer_composed(const BlTransferArgs *args, hipStream_t stream);
 extern "C" hipError_t bl_launch_shade_exact2(const BlShadeArgs *args, int grid, hipStream_t stream);
 extern "C" hipError_t bl_launch_shade_polarized2(const BlShadeArgs *args, int grid, hipStream_t stream);
@@ -180,6 +181,7 @@ struct bl_ctx {
   DeviceBuffer<double> d_coords;   // x1f x1v x2f x2v x3f x3v packed
   DeviceBuffer<unsigned short> d_buckets;
   DeviceBuffer<int> d_lattice;   // refined mesh: box of the block-boundary lattice -> block
+  DeviceBuffer<unsigned int> d_fused_desc;   // ... -> what bl_shade_fused2_kernel<..., kRefined> needs of the block (BlGridDevice::fused_desc)
   DeviceBuffer<double> d_sks_map;   // simulation_coord = fmks: the reader's SKS -> FMKS look-up table
   DeviceBuffer<int> d_block_table;                  // inter-block interpolation: levels, locations, hash blocks
   DeviceBuffer<unsigned long long> d_block_keys;    // ... and hash keys

@@ -125,6 +125,13 @@ struct BlGridDevice {
                                 // the same cell, a good one saves the walk
   int n_rows[3];
   int refined_lds_bytes;     // > 0: edges, lattice, rows, block table and hash fit the locate kernel's LDS budget (bl_locate_kernel<kRefined>)
+  // The locate step inside bl_shade_fused2_kernel<..., kRefined> (bl_shade_fused.hip): a mesh whose boxes are evenly spaced in log r, theta
+  // and phi, cover the sphere, and whose rows are evenly spaced likewise. Per box one descriptor: byte offset of the block's cells, LDS
+  // offsets of the block's three row chunks (16-byte header with the row's cell guess, then 64 bytes per cell).
+  const unsigned int *fused_desc;   // [n_edge[2]][n_edge[1]][n_edge[0]][4]
+  int fused_lds_bytes;              // > 0: the kernel takes this mesh (cut table + row chunks + descriptors)
+  float box_l0, box_linv;           // box along r = floor((log2 r - box_l0) * box_linv)
+  double box_x0[2], box_inv_w[2];   // along theta and phi = floor((x - box_x0) * box_inv_w)
   // Inter-block interpolation (simulation_block_interp; simulation_sampling.cpp:505-546, :1068-1321): the MeshBlock
   // table and a hash from (level, location) to block - the reference scans all blocks for every such lookup
   int block_interp;

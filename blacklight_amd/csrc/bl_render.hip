@@ -317,16 +317,27 @@ void PlanJob(RenderJob &job) {
   // Several frequencies in the fast path: per-sample factors (BlFreqInputs) instead of per-frequency transfer records,
   // evaluated by bl_transfer_freq_kernel with one lane per ray and frequency
   job.freq_split = job.fast && job.n_nu >= 4 && p.plasma_power_frac == 0.0 && !job.tau_row;   // (the factors are the thermal formulas')
+  // Plain images of a spherical Kerr-Schild simulation with fallback values beyond the grid: nothing is recorded of the steps that
+  // lie in the empty shell between the grid's outer edge and the camera's sphere (both tiers; the samples count as ever)
+  job.skip_shell = job.simulation && !job.aux && !ctx->polarized && !job.slow && !job.geo_load && !job.geo_save && !job.sample_save
+      && !job.need_time && p.simulation_coord == BL_COORD_SKS && !ctx->grid_dev.fmks && !p.fallback_nan && ctx->grid_outer_x1 > 0.0
+      && p.ray_integrator == BL_INTEGRATOR_DP   // (the fixed-step steppers have no instantiation for it: bl_launch_geodesic)
+      && ctx->grid_outer_x1 < p.camera_r && !(ctx->switches & BL_SWITCH_RECORD_EVERY_STEP);
   // The fast path over one grid (or equal blocks merged into one) with its coordinate tables in LDS, trilinear sampling and no
   // optional geometric cut locates its samples inside the coefficient kernel: no located samples in HBM at all
   // (one frequency - with four or more it ends at the sample's factors, which no frequency enters: BlFreqInputs - over a single block
   // with evenly spaced faces, bl_fused2_applicable; everything else goes through a locate kernel and bl_shade_fast_kernel)
-  job.fused2 = job.fast && !job.tau_row && !job.slow && ctx->grid_dev.n_blocks == 0 && ctx->lds_table_bytes > 0 && !ctx->grid_dev.fmks && p.simulation_interp && p.plasma_power_frac == 0.0
+  // (a mesh with refinement whose blocks and rows are evenly spaced has an instantiation of that kernel too - one frequency, composed
+  // maps: bl_fused2_refined_applicable and the conditions of job.composed below)
+  const bool records_every_sample = ctx->reproducible || (ctx->switches & BL_SWITCH_SAMPLE_RECORDS) != 0;
+  const bool fused2_grid = ctx->grid_dev.n_blocks == 0
+      ? ctx->lds_table_bytes > 0 && bl_fused2_applicable(&ctx->grid_dev, job.freq_split ? 1 : job.n_nu, job.n_rays) != 0
+      : !job.freq_split && !records_every_sample && !job.skip_shell && bl_fused2_refined_applicable(&ctx->grid_dev, job.n_nu, job.n_rays) != 0;
+  job.fused2 = job.fast && !job.tau_row && !job.slow && !job.block_interp && fused2_grid && !ctx->grid_dev.fmks && p.simulation_interp && p.plasma_power_frac == 0.0
       && p.simulation_coord == BL_COORD_SKS   // (its locate step is the spherical one: Cartesian grids go through the locate kernel)
       && !(p.cut_omit_near || p.cut_omit_far || p.cut_omit_in >= 0.0 || p.cut_omit_out >= 0.0 || p.cut_midplane_theta != 0.0 || p.cut_midplane_z != 0.0 || p.cut_plane)
       && !job.sample_save && !(ctx->switches & (BL_SWITCH_NO_FUSED_LOCATE | BL_SWITCH_SPLIT_RECORDS))   // (a sample checkpoint is made of the located samples)
-      && !job.geo_load && !job.geo_save   // (interleaved records whose momenta are not renormalised yet)
-      && bl_fused2_applicable(&ctx->grid_dev, job.freq_split ? 1 : job.n_nu, job.n_rays) != 0;
+      && !job.geo_load && !job.geo_save;  // (interleaved records whose momenta are not renormalised yet)
   // The exact tier's plain image at one frequency over such a grid: the locate step inside bl_shade_exact2_kernel (bit-identical
   // to bl_locate_plain_kernel + bl_shade_exact_kernel, whose conditions these are)
   job.exact_fused = !job.fast && job.simulation && !job.aux && !ctx->polarized && !job.slow && !job.block_interp && job.n_nu == 1
@@ -346,13 +357,7 @@ void PlanJob(RenderJob &job) {
   job.locate_inside = job.fused2 || job.exact_fused || job.pol_fused;
   // The benchmark's kernel also composes the affine maps of a ray's neighbouring samples before they leave it (the geodesic kernel
   // numbers the segments: BlTraceArgs::segment_rows)
-  job.composed = job.fused2 && !job.freq_split && !ctx->reproducible && !(ctx->switches & BL_SWITCH_SAMPLE_RECORDS);
-  // Plain images of a spherical Kerr-Schild simulation with fallback values beyond the grid: nothing is recorded of the steps that
-  // lie in the empty shell between the grid's outer edge and the camera's sphere (both tiers; the samples count as ever)
-  job.skip_shell = job.simulation && !job.aux && !ctx->polarized && !job.slow && !job.geo_load && !job.geo_save && !job.sample_save
-      && !job.need_time && p.simulation_coord == BL_COORD_SKS && !ctx->grid_dev.fmks && !p.fallback_nan && ctx->grid_outer_x1 > 0.0
-      && p.ray_integrator == BL_INTEGRATOR_DP   // (the fixed-step steppers have no instantiation for it: bl_launch_geodesic)
-      && ctx->grid_outer_x1 < p.camera_r && !(ctx->switches & BL_SWITCH_RECORD_EVERY_STEP);
+  job.composed = job.fused2 && !job.freq_split && !records_every_sample;
   // (the geodesic kernel's instantiation that skips the shell has no register to number segments with: per-sample records there)
   if (job.skip_shell) job.composed = false;
   // The last rays of a chunk finished with a ray per quad of lanes (Dormand-Prince stepper without sample times; the instantiation

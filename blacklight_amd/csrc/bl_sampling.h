@@ -361,6 +361,18 @@ __device__ __forceinline__ void locate_sample_refined(const BlShadeArgs &P, cons
         return;
       }
     }
+    // All eight anchors inside the sample's own block (all but the outermost half cell of a block: 95 % of the samples with 64^3
+    // blocks): FindNearbyInds returns each index as it is (:1075-1079) and InterpolateAdvanced has InterpolateSimple's weights and
+    // order (:1365-1386 / :1334-1351), so the sample is an ordinary trilinear one anchored at cell (m_k, m_j, m_i) - no anchor list
+    // written here or read by the coefficient kernel.
+    if (m[0] >= 0 && m[1] >= 0 && m[2] >= 0 && pp[0] < g.nb[0] && pp[1] < g.nb[1] && pp[2] < g.nb[2]) {
+      out->f_i = f[0];
+      out->f_j = f[1];
+      out->f_k = f[2];
+      out->status = kSampleInterp;
+      out->cell = (uint32_t)(block_base + (size_t)m[2] * g.stride_plane + (size_t)m[1] * g.stride_row + m[0]);
+      return;
+    }
     const bool sks = pl.simulation_coord == BL_COORD_SKS;
     bool failed = false;
     for (int corner = 0; corner < 8; corner++) {
@@ -1421,12 +1433,17 @@ __device__ __forceinline__ void fast_load_anchors(const BlShadeArgs &P, unsigned
   r.lo = p[0];
   r.hi = p[1];
 }
-__device__ __forceinline__ void gather_issue_anchors(const BlShadeArgs &P, bool advanced, const FastAnchors &anchors, float4 (&lo)[8], float4 (&hi)[8]) {
+__device__ __forceinline__ void gather_issue_anchors(const BlShadeArgs &P, int status, uint32_t cell_of_tag, const FastAnchors &anchors, float4 (&lo)[8],
+                                                     float4 (&hi)[8]) {
+  // a sample whose anchors all lie in its own block comes as an ordinary trilinear one (locate_sample_refined): corners from its cell
   const float4 *cells = reinterpret_cast<const float4 *>(P.grid.cells);
-  const unsigned int cell[8] = {anchors.lo.x, anchors.lo.y, anchors.lo.z, anchors.lo.w, anchors.hi.x, anchors.hi.y, anchors.hi.z, anchors.hi.w};
+  const bool advanced = status == (int)kSampleAdvanced, interp = status == (int)kSampleInterp;
+  const unsigned int listed[8] = {anchors.lo.x, anchors.lo.y, anchors.lo.z, anchors.lo.w, anchors.hi.x, anchors.hi.y, anchors.hi.z, anchors.hi.w};
+  const unsigned int row = (unsigned int)P.grid.stride_row, plane = (unsigned int)P.grid.stride_plane;
 #pragma unroll
   for (int corner = 0; corner < 8; corner++) {
-    const float4 *p = cells + (advanced ? (size_t)cell[corner] * 2 : 0);
+    const unsigned int own = cell_of_tag + ((corner >> 2) ? plane : 0u) + (((corner >> 1) & 1) ? row : 0u) + (unsigned int)(corner & 1);
+    const float4 *p = cells + (advanced ? (size_t)listed[corner] * 2 : (interp ? (size_t)own * 2 : 0));
     lo[corner] = p[0];
     hi[corner] = p[1];
   }

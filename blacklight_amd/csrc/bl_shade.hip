@@ -301,7 +301,11 @@ __global__ void __launch_bounds__(256, 2) bl_shade_kernel(const BlShadeArgs P_at
       loc.cell = 0u;
       loc.status = kSampleCut;
       unsigned long long counted_already = 0ull;
-      if (!(r_here > P.cuts.camera_r)) locate_sample<false, kSpinZero>(P, tab, st, x1, x2, x3, r_here, &loc, &counted_already, nullptr);
+      // (a mesh with refinement behind bl_shade_fused2_kernel<..., kRefined>: the refined search on its tables in HBM)
+      if (!(r_here > P.cuts.camera_r)) {
+        if (P.grid.n_blocks > 0) locate_sample<true, kSpinZero>(P, tab, st, x1, x2, x3, r_here, &loc, &counted_already, nullptr);
+        else locate_sample<false, kSpinZero>(P, tab, st, x1, x2, x3, r_here, &loc, &counted_already, nullptr);
+      }
       l0 = make_double2(loc.f_i, loc.f_j);
       l1 = make_double2(loc.f_k, 0.0);
       tag = ((unsigned long long)loc.status << 32) | loc.cell;

@@ -425,7 +425,7 @@ __global__ void __launch_bounds__(256, BL_FAST_WAVES) bl_shade_fast_kernel(const
         near_midpoint = false;
       }
     }
-    if (kAnchors && by_anchors) gather_issue_anchors(P, have_cur && ((int)(loc_cur.tag >> 32) & 0xff) == (int)kSampleAdvanced, anchors_cur, lo, hi);
+    if (kAnchors && by_anchors) gather_issue_anchors(P, have_cur ? (int)(loc_cur.tag >> 32) & 0xff : (int)kSampleNone, (uint32_t)loc_cur.tag, anchors_cur, lo, hi);
     else if (kSlices && slow_pipelined)
       gather_issue_slice(reinterpret_cast<const float *>(slice_cells[have_cur ? (int)(loc_cur.tag >> 40) : 0]), P.grid, have_cur ? (int)(loc_cur.tag >> 32) & 0xff : (int)kSampleNone,
                          (uint32_t)loc_cur.tag, lo, hi);

@@ -207,6 +207,12 @@ struct GridScalars {
   int n_i1, n_j1, n_k1;                      // n - 1 per axis
   uint32_t n_i, n_j;                         // cell index = (k n_j + j) n_i + i
   uint32_t lds_r, lds_th, lds_ph;            // LDS byte addresses of the three row tables
+  // mesh with refinement (kRefined): the box of the block lattice is guessed like a cell, its descriptor names the block's cells and rows
+  float box_l0, box_linv;
+  double box_th_x0, box_th_inv_w, box_ph_x0, box_ph_inv_w;
+  int n_box_i1, n_box_j1, n_box_k1;          // boxes per axis - 1
+  uint32_t n_box_i, n_box_j;
+  uint32_t lds_desc;                         // LDS byte address of the descriptors
 };
 
 // LDS reads by byte address (the row tables live behind the kernel's extern array; LDS addresses are 32-bit numbers, which is
@@ -270,6 +276,77 @@ __device__ __forceinline__ GridScalars grid_scalars(const BlGridDevice &g, uint3
   return G;
 }
 
+// Mesh with refinement: per distinct coordinate row of the blocks a chunk - 16 bytes of header (where the row's cell guess starts and
+// how many cells a unit of the coordinate holds: two floats for log2 r, two doubles for theta and phi), then the row's cells as above,
+// the anchor rule of a block's ends at every row's ends - and behind the chunks one descriptor per box of the block lattice
+// (BlGridDevice::fused_desc, its chunk offsets made LDS addresses here).
+__device__ __forceinline__ void stage_refined_rows(const BlGridDevice &g, char *chunks, uint32_t chunks_address) {
+  char *at = chunks;
+  for (int a = 0; a < 3; a++) {
+    const int n = g.nb[a], n_rows = g.n_rows[a];
+    const size_t chunk = 16 + 64 * (size_t)n;
+    for (int t = threadIdx.x; t < n_rows * n; t += blockDim.x) {
+      const int q = t / n, c = t - q * n;
+      const double *xf = g.bxf[a] + (size_t)q * (n + 1), *xv = g.bxv[a] + (size_t)q * n;
+      const int c_ge = c == n - 1 ? c - 1 : c, c_lt = c == 0 ? 0 : c - 1;
+      AxisRow row;
+      row.xf_lo = xf[c];
+      row.xf_hi = xf[c + 1];
+      row.xv = xv[c];
+      row.dj_ge = (uint32_t)(c - c_ge);
+      row.dj_lt = (uint32_t)(c - c_lt);
+      row.xv_ge = xv[c_ge];
+      row.xv_lt = xv[c_lt];
+      row.w_ge = 1.0 / (xv[c_ge + 1] - xv[c_ge]);
+      row.w_lt = 1.0 / (xv[c_lt + 1] - xv[c_lt]);
+      *reinterpret_cast<AxisRow *>(at + (size_t)q * chunk + 16 + 64 * (size_t)c) = row;
+    }
+    for (int q = threadIdx.x; q < n_rows; q += blockDim.x) {
+      const double *guess = g.row_guess[a] + 3 * (size_t)q;
+      if (a == 0) *reinterpret_cast<float4 *>(at + (size_t)q * chunk) = make_float4((float)guess[1], (float)guess[2], 0.0f, 0.0f);
+      else *reinterpret_cast<double2 *>(at + (size_t)q * chunk) = make_double2(guess[1], guess[2]);
+    }
+    at += (size_t)n_rows * chunk;
+  }
+  uint4 *desc = reinterpret_cast<uint4 *>(at);
+  const int n_boxes = g.n_edge[0] * g.n_edge[1] * g.n_edge[2];
+  for (int t = threadIdx.x; t < n_boxes; t += blockDim.x) {
+    uint4 d = reinterpret_cast<const uint4 *>(g.fused_desc)[t];
+    d.y += chunks_address;
+    d.z += chunks_address;
+    d.w += chunks_address;
+    desc[t] = d;
+  }
+}
+__device__ __forceinline__ GridScalars grid_scalars_refined(const BlGridDevice &g, uint32_t chunks_address) {
+  GridScalars G;
+  G.th_x0 = G.th_inv_w = G.ph_x0 = G.ph_inv_w = 0.0;
+  G.r_l0 = G.r_linv = 0.0f;
+  G.r_in = g.r_face_in;
+  G.r_out = g.r_face_out;
+  G.n_i1 = g.nb[0] - 1;
+  G.n_j1 = g.nb[1] - 1;
+  G.n_k1 = g.nb[2] - 1;
+  G.n_i = (uint32_t)g.nb[0];
+  G.n_j = (uint32_t)g.nb[1];
+  G.lds_r = G.lds_th = G.lds_ph = 0u;
+  G.box_l0 = g.box_l0;
+  G.box_linv = g.box_linv;
+  G.box_th_x0 = g.box_x0[0];
+  G.box_th_inv_w = g.box_inv_w[0];
+  G.box_ph_x0 = g.box_x0[1];
+  G.box_ph_inv_w = g.box_inv_w[1];
+  G.n_box_i1 = g.n_edge[0] - 1;
+  G.n_box_j1 = g.n_edge[1] - 1;
+  G.n_box_k1 = g.n_edge[2] - 1;
+  G.n_box_i = (uint32_t)g.n_edge[0];
+  G.n_box_j = (uint32_t)g.n_edge[1];
+  uint32_t bytes = 0u;
+  for (int a = 0; a < 3; a++) bytes += (uint32_t)g.n_rows[a] * (16u + 64u * (uint32_t)g.nb[a]);
+  G.lds_desc = chunks_address + bytes;
+  return G;
+}
+
 // One axis: row of the guessed cell -> anchor shift, fraction, signed distance to the nearest face (negative: the guess is wrong
 // or the coordinate lies beyond the grid) and distance to the centre
 __device__ __forceinline__ void axis_lookup(uint32_t row_addr, double s, double *frac, uint32_t *dj, double *face_margin, double *centre_margin) {
@@ -286,7 +363,11 @@ __device__ __forceinline__ void axis_lookup(uint32_t row_addr, double s, double 
 }
 
 // The locate step (locate_plain_sample_tolerant's results; bl_sampling_fast.h) for the grids this kernel takes
-template <bool kSpinZero>
+// kRefined: mesh with refinement - the sample's box of the block lattice is guessed like a cell, the box's descriptor names the block's
+// three rows, and the cell is guessed and confirmed in those. A wrong box names a block whose rows do not hold the coordinate: the
+// row's faces fail to confirm it (blocks do not overlap, so rows that do confirm all three coordinates are the sample's block's),
+// and the sample is left to the exact kernel like any other the margins do not decide.
+template <bool kSpinZero, bool kRefined = false>
 __device__ __forceinline__ Located locate(const BlSpacetime &st, const GridScalars &G, double camera_r, double band, bool live, double x, double y, double z) {
   x = live ? x : 1.0;
   y = live ? y : 1.0;
@@ -318,17 +399,39 @@ __device__ __forceinline__ Located locate(const BlSpacetime &st, const GridScala
   const double ph_once = ph;
   ph -= ph >= two_pi ? two_pi : 0.0;
   // guessed cells
-  int gi = (int)((__builtin_amdgcn_logf((float)r) - G.r_l0) * G.r_linv);
-  int gj = (int)((th - G.th_x0) * G.th_inv_w);
-  int gk = (int)((ph - G.ph_x0) * G.ph_inv_w);
+  const float log2_r = __builtin_amdgcn_logf((float)r);
+  int gi, gj, gk;
+  uint32_t rows_r = G.lds_r, rows_th = G.lds_th, rows_ph = G.lds_ph, block_bytes = 0u;
+  if (kRefined) {
+    int bi = (int)((log2_r - G.box_l0) * G.box_linv);
+    int bj = (int)((th - G.box_th_x0) * G.box_th_inv_w);
+    int bk = (int)((ph - G.box_ph_x0) * G.box_ph_inv_w);
+    bi = bi < 0 ? 0 : (bi > G.n_box_i1 ? G.n_box_i1 : bi);
+    bj = bj < 0 ? 0 : (bj > G.n_box_j1 ? G.n_box_j1 : bj);
+    bk = bk < 0 ? 0 : (bk > G.n_box_k1 ? G.n_box_k1 : bk);
+    const v4u desc = lds_read_bits(G.lds_desc + ((__umul24(__umul24((uint32_t)bk, G.n_box_j) + (uint32_t)bj, G.n_box_i) + (uint32_t)bi) << 4));
+    block_bytes = desc.x;
+    const v4u head_r = lds_read_bits(desc.y);
+    const v2d head_th = lds_read2(desc.z), head_ph = lds_read2(desc.w);
+    rows_r = desc.y + 16u;
+    rows_th = desc.z + 16u;
+    rows_ph = desc.w + 16u;
+    gi = (int)((log2_r - __uint_as_float(head_r.x)) * __uint_as_float(head_r.y));
+    gj = (int)((th - head_th.x) * head_th.y);
+    gk = (int)((ph - head_ph.x) * head_ph.y);
+  } else {
+    gi = (int)((log2_r - G.r_l0) * G.r_linv);
+    gj = (int)((th - G.th_x0) * G.th_inv_w);
+    gk = (int)((ph - G.ph_x0) * G.ph_inv_w);
+  }
   gi = gi < 0 ? 0 : (gi > G.n_i1 ? G.n_i1 : gi);
   gj = gj < 0 ? 0 : (gj > G.n_j1 ? G.n_j1 : gj);
   gk = gk < 0 ? 0 : (gk > G.n_k1 ? G.n_k1 : gk);
   double f_i, f_j, f_k, m_i, m_j, m_k, c_i, c_j, c_k;
   uint32_t di, dj, dk;
-  axis_lookup(G.lds_r + ((uint32_t)gi << 6), r, &f_i, &di, &m_i, &c_i);
-  axis_lookup(G.lds_th + ((uint32_t)gj << 6), th, &f_j, &dj, &m_j, &c_j);
-  axis_lookup(G.lds_ph + ((uint32_t)gk << 6), ph, &f_k, &dk, &m_k, &c_k);
+  axis_lookup(rows_r + ((uint32_t)gi << 6), r, &f_i, &di, &m_i, &c_i);
+  axis_lookup(rows_th + ((uint32_t)gj << 6), th, &f_j, &dj, &m_j, &c_j);
+  axis_lookup(rows_ph + ((uint32_t)gk << 6), ph, &f_k, &dk, &m_k, &c_k);
   // r is the exact tier's r: its cell is confirmed exactly (first c with xf[c + 1] >= r: xf[c] < r <= xf[c + 1]; m_i is
   // min(r - xf[c], xf[c + 1] - r)) - except on a face itself, where the signed minimum is zero either way: left to the exact pass
   // theta, phi: the tier's own angles, so every value they are compared with must be further away than the band
@@ -345,7 +448,7 @@ __device__ __forceinline__ Located locate(const BlSpacetime &st, const GridScala
   out.f_j = f_j;
   out.f_k = f_k;
   const uint32_t cell = __umul24(__umul24((uint32_t)gk - dk, G.n_j) + ((uint32_t)gj - dj), G.n_i) + ((uint32_t)gi - di);
-  out.cell_bytes = sampled ? cell << 5 : 0u;
+  out.cell_bytes = sampled ? (cell << 5) + block_bytes : 0u;
   out.status = (!live ? (uint32_t)kSampleNone : (cut ? (uint32_t)kSampleCut : (off_grid ? (uint32_t)kSampleOffGrid : (uint32_t)kSampleInterp)))
       | (undecided ? kPlainUndecided : 0u);
   return out;
@@ -585,7 +688,8 @@ __device__ __forceinline__ double2 shade(const BlSpacetime &st, const double (&K
 // a NaN included: not a product of numbers), writes its samples' own records instead, by record index, and marks its segments'
 // rows as standing for those (BL_COMPOSED_EXPANDED).
 // kFactors: several frequencies - a sample leaves as its factors (BlFreqInputs, row ray_offset + n) instead of a transfer record.
-template <bool kSpinZero, bool kComposed, bool kFactors = false>
+// kRefined: a mesh with refinement whose lattice of blocks and whose rows are evenly spaced (BlGridDevice::fused_lds_bytes > 0).
+template <bool kSpinZero, bool kComposed, bool kFactors = false, bool kRefined = false>
 __global__ void __launch_bounds__(256, BL_FAST_WAVES) bl_shade_fused2_kernel(const BlShadeArgs P) {
   using namespace fused2;
   extern __shared__ double lds[];
@@ -606,7 +710,8 @@ __global__ void __launch_bounds__(256, BL_FAST_WAVES) bl_shade_fused2_kernel(con
       else value = upper_on ? cc.fast_cut_hi[2 * v + 1] : -inf;
       lds[i] = value;
     }
-    stage_axis_rows<true>(P.grid, reinterpret_cast<AxisRow *>(lds + 48));
+    if (kRefined) stage_refined_rows(P.grid, reinterpret_cast<char *>(lds + 48), lds_base + 48u * 8u);
+    else stage_axis_rows<true>(P.grid, reinterpret_cast<AxisRow *>(lds + 48));
   }
   __syncthreads();
   const uint32_t n_records = (uint32_t)P.counters_in[BL_CNT_RECORDS];   // (a scratch set holds fewer than 2^32 records)
@@ -615,7 +720,7 @@ __global__ void __launch_bounds__(256, BL_FAST_WAVES) bl_shade_fused2_kernel(con
   const uint32_t stride = gridDim.x * blockDim.x;
   const uint32_t last = n_records - 1u;
   const BlSpacetime st = P.st;
-  const GridScalars G = grid_scalars(P.grid, lds_base + 48u * 8u);
+  const GridScalars G = kRefined ? grid_scalars_refined(P.grid, lds_base + 48u * 8u) : grid_scalars(P.grid, lds_base + 48u * 8u);
   const uint32_t cut_table = lds_base;
   const int cut_mask = P.plasma.cut_mask;
   const double camera_r = P.cuts.camera_r;
@@ -670,7 +775,7 @@ __global__ void __launch_bounds__(256, BL_FAST_WAVES) bl_shade_fused2_kernel(con
     s1.h1 = rec[1];
     s1.h1.y = s1.in ? s1.h1.y : __longlong_as_double((long long)BL_DEAD_RAY);
   }
-  s1.loc = locate<kSpinZero>(st, G, camera_r, band, (uint32_t)__double_as_longlong(s1.h1.y) != BL_DEAD_RAY, s1.h0.x, s1.h0.y, s1.h1.x);
+  s1.loc = locate<kSpinZero, kRefined>(st, G, camera_r, band, (uint32_t)__double_as_longlong(s1.h1.y) != BL_DEAD_RAY, s1.h0.x, s1.h0.y, s1.h1.x);
   // p (`prev`) is sample base_index - stride + lane_index (none in the first iteration), c (`cur`) base_index + lane_index, x (`next`)
   // one stride on
   auto iteration = [&](Slot &p, Slot &c, Slot &x) __attribute__((always_inline)) {
@@ -801,7 +906,7 @@ __global__ void __launch_bounds__(256, BL_FAST_WAVES) bl_shade_fused2_kernel(con
       if (at < args->redo_capacity) args->redo_list[at] = (unsigned long long)(base_index - stride + lane_index);
     }
     // ---- the search for `next`
-    x.loc = locate<kSpinZero>(st, G, camera_r, band, x.in && (uint32_t)__double_as_longlong(x.h1.y) != BL_DEAD_RAY, x.h0.x, x.h0.y, x.h1.x);
+    x.loc = locate<kSpinZero, kRefined>(st, G, camera_r, band, x.in && (uint32_t)__double_as_longlong(x.h1.y) != BL_DEAD_RAY, x.h0.x, x.h0.y, x.h1.x);
     x.h1.y = x.in ? x.h1.y : __longlong_as_double((long long)BL_DEAD_RAY);
     base_index = next_first;
   };
@@ -1264,8 +1369,26 @@ extern "C" int bl_fused2_applicable(const BlGridDevice *grid, int n_nu, long lon
   return lds <= 64u * 1024u ? 1 : 0;
 }
 
+// ... or its instantiation for a mesh with refinement (one frequency, composed maps: what bl_render.hip asks for beside this; the
+// geometry was checked when the mesh was staged, UploadRefinedGrid)
+extern "C" int bl_fused2_refined_applicable(const BlGridDevice *grid, int n_nu, long long n_rays) {
+  return (grid->n_blocks > 0 && grid->fused_lds_bytes > 0 && !grid->block_interp && n_nu == 1 && n_rays < (1ll << 29)) ? 1 : 0;
+}
+
 extern "C" hipError_t bl_launch_shade_fused2(const BlShadeArgs *args, int grid, hipStream_t stream) {
   const BlGridDevice &g = args->grid;
+  if (g.n_blocks > 0) {
+    if (args->composed == nullptr || args->freq_split || g.fused_lds_bytes <= 0) return hipErrorInvalidValue;
+    if (g.fused_lds_bytes > 64 * 1024) {   // (more dynamic LDS than a launch gets unasked: up to 76 KiB, two workgroups to a compute unit's 160)
+      const void *kernel = args->st.bh_a == 0.0 ? reinterpret_cast<const void *>(&bl_shade_fused2_kernel<true, true, false, true>)
+                                                : reinterpret_cast<const void *>(&bl_shade_fused2_kernel<false, true, false, true>);
+      const hipError_t err = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 76 * 1024);
+      if (err != hipSuccess) return err;
+    }
+    if (args->st.bh_a == 0.0) hipLaunchKernelGGL((bl_shade_fused2_kernel<true, true, false, true>), dim3(grid), dim3(256), (size_t)g.fused_lds_bytes, stream, *args);
+    else hipLaunchKernelGGL((bl_shade_fused2_kernel<false, true, false, true>), dim3(grid), dim3(256), (size_t)g.fused_lds_bytes, stream, *args);
+    return hipGetLastError();
+  }
   const size_t lds = 48 * sizeof(double) + 64 * (size_t)(g.n[0] + g.n[1] + g.n[2]);
   const bool spin_zero = args->st.bh_a == 0.0, composed = args->composed != nullptr;
 #define BL_LAUNCH_F2(S, C) hipLaunchKernelGGL((bl_shade_fused2_kernel<S, C>), dim3(grid), dim3(256), lds, stream, *args)

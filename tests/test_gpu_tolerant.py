@@ -309,6 +309,43 @@ def test_tolerant_locate_on_unevenly_spaced_axes(warp, built_library):
     assert d < EXPECTED
 
 
+@pytest.mark.parametrize("spin,camera_th", [(0.0, 75.0), (0.9, 20.0), (0.0, 179.0)])
+def test_tolerant_tier_over_a_refined_mesh_locates_inside_the_coefficient_kernel(spin, camera_th, built_library):
+    """A two-level mesh whose boxes and rows are evenly spaced in log r, theta and phi: bl_shade_fused2_kernel<..., kRefined> guesses
+    the box of the block lattice, then the cell in the block's rows, and confirms both by the rows' faces (no locate kernel, no
+    located samples). Counts, flags, S_in and NaN mask are the exact tier's (whose locate kernel does the reference's search,
+    simulation_sampling.cpp:352-394, :458-490); the image at rounding level; the same with every sample left to the exact kernel's
+    second pass (which then locates them itself on the tables in HBM), and through the locate kernel + bl_shade_fast_kernel."""
+    import blacklight_amd as bl
+    fx, params, mock_args = gu.load_case("sim_dp_interp")
+    params = dict(params, camera_resolution=40, camera_th=camera_th, camera_ph=130.0, simulation_a=spin, simulation_interp="true",
+                  fallback_nan="false", fallback_rho=1.0e-6, fallback_pgas=1.0e-8)
+    grid = gu.golden_grid(dict(mock_args, _refined=1))
+    with bl.Context(bl.Params.from_dict(params)) as ctx:
+        ctx.set_grid(grid)
+        ctx.set_arithmetic("exact")
+        exact = ctx.render()
+        ctx.set_arithmetic("tolerant")
+        inside = ctx.render()
+        ctx.debug_set_switches("NO_FUSED_LOCATE")
+        outside = ctx.render()
+        ctx.debug_set_switches()
+        ctx.debug_set_guard_band(1.0e30)
+        deferred = ctx.render()
+    assert exact["stats"].launches_locate == 1 and exact["stats"].fused_variant == 0
+    assert inside["stats"].arithmetic == 1 and inside["stats"].fused_variant == 2 and inside["stats"].launches_locate == 0 and inside["stats"].composed_maps == 1
+    assert outside["stats"].arithmetic == 1 and outside["stats"].fused_variant == 0 and outside["stats"].launches_locate == 1
+    assert deferred["stats"].fused_variant == 2 and deferred["stats"].n_deferred > 100 * max(inside["stats"].n_deferred, 1)
+    for got in (inside, outside, deferred):
+        assert got["stats"].n_gathers == exact["stats"].n_gathers
+        assert np.array_equal(got["sample_num"], exact["sample_num"]) and np.array_equal(got["sample_flags"], exact["sample_flags"])
+        assert np.array_equal(np.isnan(got["image"]), np.isnan(exact["image"]))
+        assert _distance(got["image"], exact["image"]) < EXPECTED
+    # few samples are left undecided by the guesses (a float log2 r, boxes and cells evenly spaced to 1e-4)
+    assert inside["stats"].n_deferred < 2.0e-3 * inside["stats"].n_gathers, (inside["stats"].n_deferred, inside["stats"].n_gathers)
+    print(f"a = {spin}: inside {_distance(inside['image'], exact['image']):.2e}, deferred {inside['stats'].n_deferred} of {inside['stats'].n_gathers}")
+
+
 @pytest.mark.parametrize("band,resolution,frequencies,variant", [(1.0e30, 24, 1, ""), (1.0e30, 56, 1, ""), (1.0e30, 24, 5, ""), (1.0e30, 56, 5, ""),
                                                                  (1.0e30, 24, 1, "power"), (1.0e30, 24, 3, "cks"), (1.0e30, 24, 3, "cks power")])
 def test_deferred_cut_decisions(band, resolution, frequencies, variant, built_library):

@@ -27,12 +27,14 @@ BENCHMARK_KERNELS = {
     "_Z20bl_shade_fast_kernelILb0ELi1EEv11BlShadeArgs": (2, 0),              # ... power laws / Cartesian grids
     "_Z20bl_shade_fast_kernelILb0ELi2EEv11BlShadeArgs": (2, 0),              # ... behind inter-block interpolation (anchor cells)
     "_Z20bl_shade_fast_kernelILb0ELi3EEv11BlShadeArgs": (2, 0),              # ... behind slow light (time slices)
-    "_Z22bl_shade_fused2_kernelILb1ELb1ELb0EEv11BlShadeArgs": (2, 0),        # ... the benchmark's kernel: locate step inside, composed maps
-    "_Z22bl_shade_fused2_kernelILb1ELb0ELb0EEv11BlShadeArgs": (2, 0),        # ... one record per sample
-    "_Z22bl_shade_fused2_kernelILb0ELb1ELb0EEv11BlShadeArgs": (2, 0),        # ... any spin
-    "_Z22bl_shade_fused2_kernelILb0ELb0ELb0EEv11BlShadeArgs": (2, 0),
-    "_Z22bl_shade_fused2_kernelILb1ELb0ELb1EEv11BlShadeArgs": (2, 0),        # ... several frequencies: a sample leaves as its factors
-    "_Z22bl_shade_fused2_kernelILb0ELb0ELb1EEv11BlShadeArgs": (2, 0),
+    "_Z22bl_shade_fused2_kernelILb1ELb1ELb0ELb0EEv11BlShadeArgs": (2, 0),     # ... the benchmark's kernel: locate step inside, composed maps
+    "_Z22bl_shade_fused2_kernelILb1ELb0ELb0ELb0EEv11BlShadeArgs": (2, 0),        # ... one record per sample
+    "_Z22bl_shade_fused2_kernelILb0ELb1ELb0ELb0EEv11BlShadeArgs": (2, 0),        # ... any spin
+    "_Z22bl_shade_fused2_kernelILb0ELb0ELb0ELb0EEv11BlShadeArgs": (2, 0),
+    "_Z22bl_shade_fused2_kernelILb1ELb0ELb1ELb0EEv11BlShadeArgs": (2, 0),        # ... several frequencies: a sample leaves as its factors
+    "_Z22bl_shade_fused2_kernelILb0ELb0ELb1ELb0EEv11BlShadeArgs": (2, 0),
+    "_Z22bl_shade_fused2_kernelILb1ELb1ELb0ELb1EEv11BlShadeArgs": (2, 0),     # ... over a mesh with refinement (box descriptors and row chunks in LDS)
+    "_Z22bl_shade_fused2_kernelILb0ELb1ELb0ELb1EEv11BlShadeArgs": (2, 0),
     "_Z22bl_shade_exact2_kernelILb1EEv11BlShadeArgs": (2, 0),                # exact tier, locate step inside (the benchmark's exact kernel)
     "_Z22bl_shade_exact2_kernelILb0EEv11BlShadeArgs": (2, 0),
     "_Z26bl_shade_polarized2_kernelILb1ELb0ELb0EEv11BlShadeArgs": (2, 0),    # polarized runs, locate step inside, no auxiliary records
