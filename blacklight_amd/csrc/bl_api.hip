@@ -679,6 +679,27 @@ void UploadMergedGrid(bl_ctx *ctx, const bl_grid_desc *g) {
     ctx->n_k = n_k;
 }
 
+// Where the search along n ascending faces starts (BlGridDevice::row_guess, box_guess): kind (1: logarithmic), origin, cells per unit.
+// Logarithmic where every face is positive and the ratios of neighbouring faces agree better than their differences do.
+void SearchGuess(const double *f, int n, double guess[3]) {
+  bool positive = f[0] > 0.0;
+  double ratio_lo = 1.0e300, ratio_hi = 0.0, step_lo = 1.0e300, step_hi = 0.0;
+  for (int i = 0; i < n && positive; i++) {
+    ratio_lo = std::min(ratio_lo, f[i + 1] / f[i]); ratio_hi = std::max(ratio_hi, f[i + 1] / f[i]);
+    step_lo = std::min(step_lo, f[i + 1] - f[i]); step_hi = std::max(step_hi, f[i + 1] - f[i]);
+  }
+  const bool logarithmic = positive && n > 1 && (ratio_hi / ratio_lo - 1.0) < 0.5 * (step_hi / step_lo - 1.0);
+  if (logarithmic) {
+    guess[0] = 1.0;
+    guess[1] = std::log2(f[0]);
+    guess[2] = n / (std::log2(f[n]) - std::log2(f[0]));
+  } else {
+    guess[0] = 0.0;
+    guess[1] = f[0];
+    guess[2] = n / (f[n] - f[0]);
+  }
+}
+
 // Mesh with refinement (blocks of several levels), or any other set of non-overlapping equal-sized blocks:
 // cells stay block by block; the distinct block boundaries along each axis span a lattice of boxes, each
 // covered by at most one block, from which the locate kernel finds the block of a sample (the reference
@@ -773,23 +794,9 @@ void UploadRefinedGrid(bl_ctx *ctx, const bl_grid_desc *g) {
       coords.push_back(blk + 1 < n_b ? block_xv[a][static_cast<size_t>(blk + 1) * nb[a]] : std::numeric_limits<double>::quiet_NaN());
     off_g[a] = coords.size();
     for (const double *f : row_f) {
-      // logarithmic where every face is positive and the ratios of neighbouring faces agree better than their differences do
-      bool positive = f[0] > 0.0;
-      double ratio_lo = 1.0e300, ratio_hi = 0.0, step_lo = 1.0e300, step_hi = 0.0;
-      for (int i = 0; i < nb[a] && positive; i++) {
-        ratio_lo = std::min(ratio_lo, f[i + 1] / f[i]); ratio_hi = std::max(ratio_hi, f[i + 1] / f[i]);
-        step_lo = std::min(step_lo, f[i + 1] - f[i]); step_hi = std::max(step_hi, f[i + 1] - f[i]);
-      }
-      const bool logarithmic = positive && nb[a] > 1 && (ratio_hi / ratio_lo - 1.0) < 0.5 * (step_hi / step_lo - 1.0);
-      if (logarithmic) {
-        coords.push_back(1.0);
-        coords.push_back(std::log2(f[0]));
-        coords.push_back(nb[a] / (std::log2(f[nb[a]]) - std::log2(f[0])));
-      } else {
-        coords.push_back(0.0);
-        coords.push_back(f[0]);
-        coords.push_back(nb[a] / (f[nb[a]] - f[0]));
-      }
+      double guess[3];
+      SearchGuess(f, nb[a], guess);
+      coords.insert(coords.end(), guess, guess + 3);
     }
     off_e[a] = coords.size();
     coords.insert(coords.end(), edge[a].begin(), edge[a].end());
@@ -817,6 +824,9 @@ void UploadRefinedGrid(bl_ctx *ctx, const bl_grid_desc *g) {
     dev.n_rows[a] = n_rows[a];
     dev.edge[a] = ctx->d_coords.ptr + off_e[a];
     dev.n_edge[a] = n_edge[a];
+    dev.edge_first[a] = edge[a].front();
+    dev.edge_last[a] = edge[a].back();
+    SearchGuess(edge[a].data(), n_edge[a], dev.box_guess[a]);
     dev.n[a] = nb[a];
     dev.nb[a] = nb[a];
   }

@@ -124,6 +124,8 @@ struct BlGridDevice {
                                 // spaced in log s), origin (the first face, or its log2), cells per unit (of s, or of log2 s); any start gives
                                 // the same cell, a good one saves the walk
   int n_rows[3];
+  double edge_first[3], edge_last[3];   // edge[a][0], edge[a][n_edge[a]]
+  double box_guess[3][3];    // the same three numbers for the block boundaries along each axis
   int refined_lds_bytes;     // > 0: edges, lattice, rows, block table and hash fit the locate kernel's LDS budget (bl_locate_kernel<kRefined>)
   // The locate step inside bl_shade_fused2_kernel<..., kRefined> (bl_shade_fused.hip): a mesh whose boxes are evenly spaced in log r, theta
   // and phi, cover the sphere, and whose rows are evenly spaced likewise. Per box one descriptor: byte offset of the block's cells, LDS

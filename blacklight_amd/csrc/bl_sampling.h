@@ -148,7 +148,8 @@ struct SampleShade {
 
 // Status of a located sample (BlLocated::status)
 enum SampleStatus { kSampleNone = 0, kSampleCut = 1, kSampleOffGrid = 2, kSampleNearest = 3, kSampleInterp = 4,
-                    kSampleFormula = 5, kSampleAdvanced = 6 };
+                    kSampleFormula = 5, kSampleAdvanced = 6,
+                    kSamplePending = 7 };   // (never stored: locate_sample_refined's answer to defer_nearby, bl_locate_kernel's note to itself)
 
 __device__ __forceinline__ void unpack_cell(const float4 &lo, const float4 &hi, float v[8]) {
   v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w;
@@ -173,19 +174,60 @@ __device__ __forceinline__ int first_upper_face(const double *table, int n, doub
 
 // ---- inter-block interpolation (simulation_block_interp = true)
 
+// The tables of a mesh with refinement as the search reads them: where they lie in HBM (BlGridDevice's pointers), or the locate
+// kernel's copies of them in LDS (read by ds_read through LDS-typed pointers - a pointer that may be either becomes a flat load,
+// which waits on both memory counters and goes through the texture addresser). The mesh's scalars come from BlShadeArgs::grid itself.
+struct RefinedTables {
+  const double *edge[3], *bxf[3], *bxv[3], *xv_next[3], *row_guess[3];
+  const int *lattice, *block_row[3];
+  // inter-block interpolation: the MeshBlock table and the hash from (level, location) to block
+  const int *levels, *locations, *hash_blocks;
+  const unsigned long long *hash_keys;
+  bool in_lds;   // (wave-uniform) what kTableAnywhere reads go by
+};
+// where a search function's tables lie: known when it is compiled, or a wave-uniform branch per read (one copy of FindNearbyInds for both)
+enum { kTableHbm = 0, kTableLds = 1, kTableAnywhere = 2 };
+__device__ __forceinline__ RefinedTables refined_tables_in_hbm(const BlGridDevice &g) {
+  RefinedTables t;
+  for (int a = 0; a < 3; a++) {
+    t.edge[a] = g.edge[a];
+    t.bxf[a] = g.bxf[a];
+    t.bxv[a] = g.bxv[a];
+    t.xv_next[a] = g.xv_next[a];
+    t.row_guess[a] = g.row_guess[a];
+    t.block_row[a] = g.block_row[a];
+  }
+  t.lattice = g.lattice;
+  t.levels = g.levels;
+  t.locations = g.locations;
+  t.hash_blocks = g.hash_blocks;
+  t.hash_keys = g.hash_keys;
+  t.in_lds = false;
+  return t;
+}
+template <int kWhere, typename T>
+__device__ __forceinline__ T table_read(const RefinedTables &t, const T *table, size_t i) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (kWhere == kTableLds || (kWhere == kTableAnywhere && t.in_lds))
+    return (reinterpret_cast<const __attribute__((address_space(3))) T *>((uint32_t)(size_t)table))[i];
+#endif
+  return table[i];
+}
+
 // Block of a refinement level at a logical location, -1: none. The reference finds it by scanning all blocks
 // (simulation_sampling.cpp:1246-1256 and alike); blocks do not overlap, so the key is unique.
 __device__ __forceinline__ unsigned long long block_key(int level, int li, int lj, int lk) {
   return ((unsigned long long)(unsigned)level << 57) | ((unsigned long long)(unsigned)li << 38) | ((unsigned long long)(unsigned)lj << 19)
       | (unsigned long long)(unsigned)lk;
 }
-__device__ __forceinline__ int find_block(const BlGridDevice &g, int level, int li, int lj, int lk) {
+template <int kWhere>
+__device__ __forceinline__ int find_block(const BlGridDevice &g, const RefinedTables &t, int level, int li, int lj, int lk) {
   if (level < 0 || level > g.max_level || li < 0 || lj < 0 || lk < 0 || li >= (1 << 19) || lj >= (1 << 19) || lk >= (1 << 19)) return -1;
   const unsigned long long key = block_key(level, li, lj, lk);
   unsigned int slot = (unsigned int)((key * 0x9e3779b97f4a7c15ull) >> 32) & g.hash_mask;
   while (true) {
-    const unsigned long long found = g.hash_keys[slot];
-    if (found == key) return g.hash_blocks[slot];
+    const unsigned long long found = table_read<kWhere>(t, t.hash_keys, slot);
+    if (found == key) return table_read<kWhere>(t, t.hash_blocks, slot);
     if (found == ~0ull) return -1;
     slot = (slot + 1) & g.hash_mask;
   }
@@ -194,14 +236,15 @@ __device__ __forceinline__ int find_block(const BlGridDevice &g, int level, int 
 // FindNearbyInds (simulation_sampling.cpp:1068-1321): the cell that stands for cell (k, j, i) of block b when an
 // index is one beyond the block. c[] = cell closest to the sample, s[] = the sample. Returns the cell's position
 // in the [block][k][j][i] array, or -1 where the reference throws "Grid interpolation failed."
-__device__ long long find_nearby(const BlGridDevice &g, bool sks, int b, int k, int j, int i, const int c[3], const double s[3]) {
+template <int kWhere>
+__device__ long long find_nearby(const BlGridDevice &g, const RefinedTables &t, bool sks, int b, int k, int j, int i, const int c[3], const double s[3]) {
   const int n_i = g.nb[0], n_j = g.nb[1], n_k = g.nb[2];
   const size_t block_cells = (size_t)g.nb[2] * g.stride_plane;
   const int i_safe = max(min(i, n_i - 1), 0), j_safe = max(min(j, n_j - 1), 0), k_safe = max(min(k, n_k - 1), 0);
   if (i == i_safe && j == j_safe && k == k_safe)
     return (long long)(b * block_cells + (size_t)k * g.stride_plane + (size_t)j * g.stride_row + i);
-  const int level = g.levels[b];
-  const int li = g.locations[3 * b], lj = g.locations[3 * b + 1], lk = g.locations[3 * b + 2];
+  const int level = table_read<kWhere>(t, t.levels, b);
+  const int li = table_read<kWhere>(t, t.locations, 3 * b), lj = table_read<kWhere>(t, t.locations, 3 * b + 1), lk = table_read<kWhere>(t, t.locations, 3 * b + 2);
   const bool upper_i = i > n_i / 2, upper_j = j > n_j / 2, upper_k = k > n_k / 2;
   const int n3 = g.n_3_level0 << level;
   const int fi = upper_i ? li * 2 + 1 : li * 2, fj = upper_j ? lj * 2 + 1 : lj * 2, fk = upper_k ? lk * 2 + 1 : lk * 2;
@@ -209,31 +252,31 @@ __device__ long long find_nearby(const BlGridDevice &g, bool sks, int b, int k, 
   bool x1_off_grid = i != i_safe, x2_off_grid = j != j_safe, x3_off_grid = k != k_safe;
   if (x1_off_grid) {
     const int d = i == -1 ? -1 : 1;
-    if (find_block(g, level, li + d, lj, lk) >= 0
-        || find_block(g, level - 1, i == -1 ? (li - 1) / 2 : (li + 1) / 2, lj / 2, lk / 2) >= 0
-        || find_block(g, level + 1, i == -1 ? li * 2 - 1 : li * 2 + 2, fj, fk) >= 0)
+    if (find_block<kWhere>(g, t, level, li + d, lj, lk) >= 0
+        || find_block<kWhere>(g, t, level - 1, i == -1 ? (li - 1) / 2 : (li + 1) / 2, lj / 2, lk / 2) >= 0
+        || find_block<kWhere>(g, t, level + 1, i == -1 ? li * 2 - 1 : li * 2 + 2, fj, fk) >= 0)
       x1_off_grid = false;
   }
   if (x2_off_grid) {
     const int d = j == -1 ? -1 : 1;
-    if (find_block(g, level, li, lj + d, lk) >= 0
-        || find_block(g, level - 1, li / 2, j == -1 ? (lj - 1) / 2 : (lj + 1) / 2, lk / 2) >= 0
-        || find_block(g, level + 1, fi, j == -1 ? lj * 2 - 1 : lj * 2 + 2, fk) >= 0)
+    if (find_block<kWhere>(g, t, level, li, lj + d, lk) >= 0
+        || find_block<kWhere>(g, t, level - 1, li / 2, j == -1 ? (lj - 1) / 2 : (lj + 1) / 2, lk / 2) >= 0
+        || find_block<kWhere>(g, t, level + 1, fi, j == -1 ? lj * 2 - 1 : lj * 2 + 2, fk) >= 0)
       x2_off_grid = false;
   }
   if (x3_off_grid) {
     const int d = k == -1 ? -1 : 1;
-    if (find_block(g, level, li, lj, lk + d) >= 0
-        || find_block(g, level - 1, li / 2, lj / 2, k == -1 ? (lk - 1) / 2 : (lk + 1) / 2) >= 0
-        || find_block(g, level + 1, fi, fj, k == -1 ? lk * 2 - 1 : lk * 2 + 2) >= 0)
+    if (find_block<kWhere>(g, t, level, li, lj, lk + d) >= 0
+        || find_block<kWhere>(g, t, level - 1, li / 2, lj / 2, k == -1 ? (lk - 1) / 2 : (lk + 1) / 2) >= 0
+        || find_block<kWhere>(g, t, level + 1, fi, fj, k == -1 ? lk * 2 - 1 : lk * 2 + 2) >= 0)
       x3_off_grid = false;
     // across the periodic boundary in x^3 (:1181-1219)
     if (x3_off_grid && sks && k == -1 && lk == 0
-        && (find_block(g, level, li, lj, n3 - 1) >= 0 || find_block(g, level - 1, li / 2, lj / 2, (g.n_3_level0 << (level - 1)) - 1) >= 0
-            || find_block(g, level + 1, fi, fj, (g.n_3_level0 << (level + 1)) - 1) >= 0))
+        && (find_block<kWhere>(g, t, level, li, lj, n3 - 1) >= 0 || find_block<kWhere>(g, t, level - 1, li / 2, lj / 2, (g.n_3_level0 << (level - 1)) - 1) >= 0
+            || find_block<kWhere>(g, t, level + 1, fi, fj, (g.n_3_level0 << (level + 1)) - 1) >= 0))
       x3_off_grid = false;
     if (x3_off_grid && sks && k == n_k && lk == n3 - 1
-        && (find_block(g, level, li, lj, 0) >= 0 || find_block(g, level - 1, li / 2, lj / 2, 0) >= 0 || find_block(g, level + 1, fi, fj, 0) >= 0))
+        && (find_block<kWhere>(g, t, level, li, lj, 0) >= 0 || find_block<kWhere>(g, t, level - 1, li / 2, lj / 2, 0) >= 0 || find_block<kWhere>(g, t, level + 1, fi, fj, 0) >= 0))
       x3_off_grid = false;
   }
   if (x1_off_grid) i = i_safe;
@@ -245,7 +288,7 @@ __device__ long long find_nearby(const BlGridDevice &g, bool sks, int b, int k, 
     int lks = k == k_safe ? lk : k == -1 ? lk - 1 : lk + 1;
     if (wrap_low) lks = n3 - 1;
     if (wrap_high) lks = 0;
-    const int b_alt = find_block(g, level, i == i_safe ? li : i == -1 ? li - 1 : li + 1, j == j_safe ? lj : j == -1 ? lj - 1 : lj + 1, lks);
+    const int b_alt = find_block<kWhere>(g, t, level, i == i_safe ? li : i == -1 ? li - 1 : li + 1, j == j_safe ? lj : j == -1 ? lj - 1 : lj + 1, lks);
     if (b_alt >= 0) {
       const int is = i == i_safe ? i : i == -1 ? n_i - 1 : 0, js = j == j_safe ? j : j == -1 ? n_j - 1 : 0, ks = k == k_safe ? k : k == -1 ? n_k - 1 : 0;
       return (long long)(b_alt * block_cells + (size_t)ks * g.stride_plane + (size_t)js * g.stride_row + is);
@@ -256,7 +299,7 @@ __device__ long long find_nearby(const BlGridDevice &g, bool sks, int b, int k, 
     int lks = k == k_safe ? lk / 2 : k == -1 ? (lk - 1) / 2 : (lk + 1) / 2;
     if (wrap_low) lks = (g.n_3_level0 << (level - 1)) - 1;
     if (wrap_high) lks = 0;
-    const int b_alt = find_block(g, level - 1, i == i_safe ? li / 2 : i == -1 ? (li - 1) / 2 : (li + 1) / 2,
+    const int b_alt = find_block<kWhere>(g, t, level - 1, i == i_safe ? li / 2 : i == -1 ? (li - 1) / 2 : (li + 1) / 2,
                                  j == j_safe ? lj / 2 : j == -1 ? (lj - 1) / 2 : (lj + 1) / 2, lks);
     if (b_alt >= 0) {
       const int is = i == i_safe ? (li % 2 * n_i + i) / 2 : i == -1 ? n_i - 1 : 0;
@@ -270,16 +313,17 @@ __device__ long long find_nearby(const BlGridDevice &g, bool sks, int b, int k, 
     int lks = lk * 2 + (k == k_safe ? 0 : k == -1 ? -1 : 1) + (upper_k ? 1 : 0);
     if (wrap_low && level + 1 <= g.max_level) lks = (g.n_3_level0 << (level + 1)) - 1;
     if (wrap_high) lks = 0;
-    const int b_alt = find_block(g, level + 1, li * 2 + (i == i_safe ? 0 : i == -1 ? -1 : 1) + (upper_i ? 1 : 0),
+    const int b_alt = find_block<kWhere>(g, t, level + 1, li * 2 + (i == i_safe ? 0 : i == -1 ? -1 : 1) + (upper_i ? 1 : 0),
                                  lj * 2 + (j == j_safe ? 0 : j == -1 ? -1 : 1) + (upper_j ? 1 : 0), lks);
     if (b_alt >= 0) {
       int is = i == i_safe ? (upper_i ? (i - n_i / 2) * 2 : i * 2) : i == -1 ? n_i - 2 : 0;
       int js = j == j_safe ? (upper_j ? (j - n_j / 2) * 2 : j * 2) : j == -1 ? n_j - 2 : 0;
       int ks = k == k_safe ? (upper_k ? (k - n_k / 2) * 2 : k * 2) : k == -1 ? n_k - 2 : 0;
-      const double *x1v = g.bxv[0] + (size_t)g.block_row[0][b] * n_i, *x2v = g.bxv[1] + (size_t)g.block_row[1][b] * n_j, *x3v = g.bxv[2] + (size_t)g.block_row[2][b] * n_k;
-      ks += (k < c[2] || (k == c[2] && s[2] > x3v[c[2]])) ? 1 : 0;
-      js += (j < c[1] || (j == c[1] && s[1] > x2v[c[1]])) ? 1 : 0;
-      is += (i < c[0] || (i == c[0] && s[0] > x1v[c[0]])) ? 1 : 0;
+      const double *x1v = t.bxv[0] + (size_t)table_read<kWhere>(t, t.block_row[0], b) * n_i, *x2v = t.bxv[1] + (size_t)table_read<kWhere>(t, t.block_row[1], b) * n_j,
+                   *x3v = t.bxv[2] + (size_t)table_read<kWhere>(t, t.block_row[2], b) * n_k;
+      ks += (k < c[2] || (k == c[2] && s[2] > table_read<kWhere>(t, x3v, c[2]))) ? 1 : 0;
+      js += (j < c[1] || (j == c[1] && s[1] > table_read<kWhere>(t, x2v, c[1]))) ? 1 : 0;
+      is += (i < c[0] || (i == c[0] && s[0] > table_read<kWhere>(t, x1v, c[0]))) ? 1 : 0;
       return (long long)(b_alt * block_cells + (size_t)ks * g.stride_plane + (size_t)js * g.stride_row + is);
     }
   }
@@ -294,71 +338,169 @@ struct LocatedSample {
   uint32_t cell, status;
 };
 
+// Where along a table of ascending faces the search for s starts: the position the table's spacing predicts (BlGridDevice::row_guess,
+// box_guess: kind, origin, cells per unit)
+__device__ __forceinline__ int guessed_index(double kind, double origin, double per_unit, double s, int n) {
+  const double from_origin = (kind != 0.0 ? (double)__log2f((float)s) : s) - origin;
+  const int i = (int)(from_origin * per_unit);
+  return i < 0 ? 0 : (i > n - 1 ? n - 1 : i);
+}
+// The first of n cells whose upper face is >= s (the rule of the reference's linear scans, simulation_sampling.cpp:458-466;
+// faces[0] <= s <= faces[n]), walked to from i: the cell does not depend on where the walk starts
+template <int kWhere>
+__device__ __forceinline__ int walk_to_cell(const RefinedTables &t, const double *faces, int n, double s, int i) {
+  while (i < n - 1 && table_read<kWhere>(t, faces, i + 1) < s) i++;
+  while (i > 0 && table_read<kWhere>(t, faces, i) >= s) i--;
+  return i;
+}
+// ... and whether i is that cell already, from its two faces
+__device__ __forceinline__ bool is_the_cell(int i, int n, double s, double face_lo, double face_hi) {
+  return (i == n - 1 || face_hi >= s) && (i == 0 || face_lo < s);
+}
+
 // g: P.grid, or the kernel's copy of it whose tables point into LDS (bl_locate_kernel)
-__device__ __forceinline__ void locate_sample_refined(const BlShadeArgs &P, const BlGridDevice &g, unsigned int *anchors, double s1, double s2, double s3,
-                                                      LocatedSample *out, unsigned long long *gathers) {
+// The search is a straight line of five rounds of table reads - the edges around the guessed box of the block lattice, the box's
+// block, the block's rows, the rows' spacing, faces and centres around the guessed cell - with the reads of a round independent
+// of one another; a guess its faces do not confirm (a table that is not evenly spaced, the last place of a float log2) walks.
+// angle_band > 0: s2 and s3 are the tolerant tier's angles (bl_fastmath.h: below 1e-15 of the exact tier's). The search then says
+// whether they decide it - every value they were compared with further away than the band: the faces and the centre of the cell
+// found, the ends of the mesh - and returns false BEFORE anything is counted or written where they do not: the caller searches
+// again with the exact tier's angles. (The radius is the exact tier's in both tiers.)
+// defer_nearby: a sample of inter-block interpolation with an anchor beyond its own block (one in twenty with 64^3 blocks) is not
+// finished here - FindNearbyInds for eight corners, a dozen hash probes each, which a wave would run for its one or two such lanes
+// with the others idle - but comes back as kSamplePending, nothing counted or written: the locate kernel collects those and runs
+// them through this function again 64 to a wave.
+// kWhere: kTableHbm, kTableLds, kTableAnywhere. kNearby false: the instantiation of the locate kernel's main loop, which defers those samples always and has no FindNearbyInds in it.
+template <int kWhere, bool kNearby>
+__device__ __forceinline__ bool locate_sample_refined(const BlShadeArgs &P, const RefinedTables &t, unsigned int *anchors, double s1, double s2, double s3,
+                                                      LocatedSample *out, unsigned long long *gathers, double angle_band = 0.0, bool defer_nearby = false) {
   const BlPlasmaDevice &pl = P.plasma;
+  const BlGridDevice &g = P.grid;   // (scalars only below: the tables are t's)
   const double s[3] = {s1, s2, s3};
   int box[3];
-  for (int a = 0; a < 3; a++) {
-    if (s[a] < g.edge[a][0] || s[a] > g.edge[a][g.n_edge[a]]) {
-      out->status = kSampleOffGrid;
-      return;
+  {
+    bool off_grid = false, confirmed = true;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      off_grid = off_grid || s[a] < g.edge_first[a] || s[a] > g.edge_last[a];
+      box[a] = guessed_index(g.box_guess[a][0], g.box_guess[a][1], g.box_guess[a][2], s[a], g.n_edge[a]);
     }
-    box[a] = first_upper_face(g.edge[a], g.n_edge[a], s[a]);
+    if (off_grid) {
+      if (angle_band > 0.0 && !(s[0] < g.edge_first[0] || s[0] > g.edge_last[0])) return false;   // (off the mesh by an angle)
+      out->status = kSampleOffGrid;
+      return true;
+    }
+    double lo[3], hi[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      lo[a] = table_read<kWhere>(t, t.edge[a], box[a]);
+      hi[a] = table_read<kWhere>(t, t.edge[a], box[a] + 1);
+    }
+#pragma unroll
+    for (int a = 0; a < 3; a++) confirmed = confirmed && is_the_cell(box[a], g.n_edge[a], s[a], lo[a], hi[a]);
+    if (!confirmed) {
+#pragma unroll
+      for (int a = 0; a < 3; a++) box[a] = walk_to_cell<kWhere>(t, t.edge[a], g.n_edge[a], s[a], box[a]);
+    }
   }
-  const int b = g.lattice[((size_t)box[2] * g.n_edge[1] + box[1]) * g.n_edge[0] + box[0]];
+  const int b = table_read<kWhere>(t, t.lattice, ((size_t)box[2] * g.n_edge[1] + box[1]) * g.n_edge[0] + box[0]);
   if (b < 0) {
+    if (angle_band > 0.0) return false;   // (a hole in the mesh: which box it is hangs on the angles)
     out->status = kSampleOffGrid;
-    return;
+    return true;
   }
   int c[3];
-  const double *xv[3];
-  for (int a = 0; a < 3; a++) {
-    const int n = g.nb[a];
-    const int row = g.block_row[a][b];
-    const double *xf = g.bxf[a] + (size_t)row * (n + 1);
-    xv[a] = g.bxv[a] + (size_t)row * n;
-    // start from the position the row's spacing predicts (linear, or logarithmic: the radial rows of a spherical mesh), then walk to
-    // the first cell whose upper face is >= s: the cell does not depend on where the walk starts
-    const double *guess = g.row_guess[a] + 3 * (size_t)row;
-    const double from_origin = (guess[0] != 0.0 ? (double)__log2f((float)s[a]) : s[a]) - guess[1];
-    int i = (int)(from_origin * guess[2]);
-    i = i < 0 ? 0 : (i > n - 1 ? n - 1 : i);
-    while (i < n - 1 && xf[i + 1] < s[a]) i++;
-    while (i > 0 && xf[i] >= s[a]) i--;
-    c[a] = i;
+  double face_lo[3], face_hi[3];        // faces of cell c
+  double centre[3][3];                  // centres of cells c - 1, c, c + 1 (the row's first / last once more at its ends)
+  {
+    int row[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) row[a] = table_read<kWhere>(t, t.block_row[a], b);
+    const double *xf[3], *xv[3];
+    double guess[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      const int n = g.nb[a];
+      xf[a] = t.bxf[a] + (size_t)row[a] * (n + 1);
+      xv[a] = t.bxv[a] + (size_t)row[a] * n;
+#pragma unroll
+      for (int q = 0; q < 3; q++) guess[a][q] = table_read<kWhere>(t, t.row_guess[a], 3 * (size_t)row[a] + q);
+    }
+#pragma unroll
+    for (int a = 0; a < 3; a++) c[a] = guessed_index(guess[a][0], guess[a][1], guess[a][2], s[a], g.nb[a]);
+    auto read_around = [&](int a) {
+      const int n = g.nb[a], i = c[a];
+      face_lo[a] = table_read<kWhere>(t, xf[a], i);
+      face_hi[a] = table_read<kWhere>(t, xf[a], i + 1);
+      centre[a][0] = table_read<kWhere>(t, xv[a], i > 0 ? i - 1 : 0);
+      centre[a][1] = table_read<kWhere>(t, xv[a], i);
+      centre[a][2] = table_read<kWhere>(t, xv[a], i < n - 1 ? i + 1 : n - 1);
+    };
+#pragma unroll
+    for (int a = 0; a < 3; a++) read_around(a);
+    bool confirmed = true;
+#pragma unroll
+    for (int a = 0; a < 3; a++) confirmed = confirmed && is_the_cell(c[a], g.nb[a], s[a], face_lo[a], face_hi[a]);
+    if (!confirmed) {
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        c[a] = walk_to_cell<kWhere>(t, xf[a], g.nb[a], s[a], c[a]);
+        read_around(a);
+      }
+    }
+  }
+  if (angle_band > 0.0) {
+    double margin = __builtin_inf();
+#pragma unroll
+    for (int a = 1; a < 3; a++) {
+      const double d_lo = s[a] - face_lo[a], d_hi = face_hi[a] - s[a], d_c = __builtin_fabs(s[a] - centre[a][1]);
+      margin = margin < d_lo ? margin : d_lo;
+      margin = margin < d_hi ? margin : d_hi;
+      margin = margin < d_c ? margin : d_c;
+    }
+    if (!(margin > angle_band)) return false;
+  }
+  if ((defer_nearby || !kNearby) && pl.simulation_interp && g.block_interp) {
+    bool inside = true;
+#pragma unroll
+    for (int a = 0; a < 3; a++) inside = inside && (s[a] >= centre[a][1] ? c[a] + 1 < g.nb[a] : c[a] >= 1);
+    if (!inside) {
+      out->status = kSamplePending;
+      return true;
+    }
   }
   *gathers += 1ull;
   const size_t block_base = (size_t)b * g.nb[2] * g.stride_plane;
   if (!pl.simulation_interp) {
     out->status = kSampleNearest;
     out->cell = (uint32_t)(block_base + (size_t)c[2] * g.stride_plane + (size_t)c[1] * g.stride_row + c[0]);
-    return;
+    return true;
   }
   if (g.block_interp) {   // inter-block interpolation (:505-546)
     int m[3], pp[3];
     double f[3];
     bool undefined = false;
+#pragma unroll
     for (int a = 0; a < 3; a++) {
       const int n = g.nb[a], i = c[a];
-      const double *xf = g.bxf[a] + (size_t)g.block_row[a][b] * (n + 1);
-      m[a] = s[a] >= xv[a][i] ? i : i - 1;
+      const double xv_i = centre[a][1];
+      const bool upper = s[a] >= xv_i;
+      m[a] = upper ? i : i - 1;
       pp[a] = m[a] + 1;
       // :520-522 read x1v(b, i + 1) at a block's upper edge: the next block's first centre in the reference's
       // Array (xv[a][i + 1] here as well: rows are contiguous); past the array for the last block - undefined
       const bool past_the_array = pp[a] == n && b == g.n_blocks - 1;
       if (past_the_array) undefined = true;
-      const double x_m = m[a] == -1 ? 2.0 * xf[i] - xv[a][i] : xv[a][m[a]];
+      const double x_m = m[a] == -1 ? 2.0 * face_lo[a] - xv_i : (upper ? xv_i : centre[a][0]);
       // BL_UNDEFINED_EDGE: the centre mirrored about the block's upper face, the rule the lower edge has (x_m above)
-      const double x_p = (pp[a] == n) ? (past_the_array ? 2.0 * xf[i + 1] - xv[a][i] : 2.0 * g.xv_next[a][b] - xv[a][i]) : xv[a][pp[a]];
+      const double x_p = (pp[a] == n) ? (past_the_array ? 2.0 * face_hi[a] - xv_i : 2.0 * table_read<kWhere>(t, t.xv_next[a], b) - xv_i) : (upper ? centre[a][2] : xv_i);
       f[a] = blm_div(s[a] - x_m, x_p - x_m);   // (ordinary operands: the IEEE quotient, blmath.h)
     }
     if (undefined) {
       atomicAdd(&P.counters[BL_CNT_UNDEFINED], 1ull);
       if (!P.undefined_edge) {
         out->status = kSampleCut;
-        return;
+        return true;
       }
     }
     // All eight anchors inside the sample's own block (all but the outermost half cell of a block: 95 % of the samples with 64^3
@@ -371,39 +513,45 @@ __device__ __forceinline__ void locate_sample_refined(const BlShadeArgs &P, cons
       out->f_k = f[2];
       out->status = kSampleInterp;
       out->cell = (uint32_t)(block_base + (size_t)m[2] * g.stride_plane + (size_t)m[1] * g.stride_row + m[0]);
-      return;
+      return true;
     }
     const bool sks = pl.simulation_coord == BL_COORD_SKS;
     bool failed = false;
-    for (int corner = 0; corner < 8; corner++) {
-      const long long cell = find_nearby(g, sks, b, (corner & 4) ? pp[2] : m[2], (corner & 2) ? pp[1] : m[1], (corner & 1) ? pp[0] : m[0], c, s);
-      failed = failed || cell < 0;
-      anchors[corner] = (unsigned int)cell;
+    if (kNearby) {   // (the other instantiation has left above)
+      for (int corner = 0; corner < 8; corner++) {
+        const long long cell = find_nearby<kWhere>(g, t, sks, b, (corner & 4) ? pp[2] : m[2], (corner & 2) ? pp[1] : m[1], (corner & 1) ? pp[0] : m[0], c, s);
+        failed = failed || cell < 0;
+        anchors[corner] = (unsigned int)cell;
+      }
     }
     if (failed) {
       atomicAdd(&P.counters[BL_CNT_INTERP_FAILED], 1ull);
       out->status = kSampleCut;
-      return;
+      return true;
     }
     out->f_i = f[0];
     out->f_j = f[1];
     out->f_k = f[2];
     out->status = kSampleAdvanced;
     out->cell = anchors[0];
-    return;
+    return true;
   }
   int m[3];
   double f[3];
+#pragma unroll
   for (int a = 0; a < 3; a++) {   // :485-490 with the block's own centres
     const int i = c[a];
-    m[a] = (i == 0 || (i != g.nb[a] - 1 && s[a] >= xv[a][i])) ? i : i - 1;
-    f[a] = blm_div(s[a] - xv[a][m[a]], xv[a][m[a] + 1] - xv[a][m[a]]);   // (ordinary operands: the IEEE quotient, blmath.h)
+    const bool upper = i == 0 || (i != g.nb[a] - 1 && s[a] >= centre[a][1]);
+    m[a] = upper ? i : i - 1;
+    const double x_m = upper ? centre[a][1] : centre[a][0], x_p = upper ? centre[a][2] : centre[a][1];
+    f[a] = blm_div(s[a] - x_m, x_p - x_m);   // (ordinary operands: the IEEE quotient, blmath.h)
   }
   out->f_i = f[0];
   out->f_j = f[1];
   out->f_k = f[2];
   out->status = kSampleInterp;
   out->cell = (uint32_t)(block_base + (size_t)m[2] * g.stride_plane + (size_t)m[1] * g.stride_row + m[0]);
+  return true;
 }
 
 // Locate one sample on the simulation grid: ConvertFromCKS (radiation_geometry.cpp:37-57), block test
@@ -448,32 +596,20 @@ __device__ __forceinline__ int locate_time(const BlSlowDevice &sl, double x0, ui
   return t_ind;
 }
 
-template <bool kRefined, bool kSpinZero>
-__device__ __forceinline__ void locate_sample(const BlShadeArgs &P, const GridTables &tab, const BlSpacetime &st,
-                                              double x1, double x2, double x3, double r, LocatedSample *out,
-                                              unsigned long long *gathers, unsigned int *anchors, const BlGridDevice *grid_in_lds = nullptr) {
+// Block test, cell search and fractions for a sample at (s1, s2, s3) in the simulation's coordinates. angle_band > 0 (spherical
+// grids, not FMKS): s2 and s3 are the tolerant tier's angles, and the function returns false, before anything is counted or written,
+// where they do not decide the search (locate_sample_refined; locate_sample_tolerant in bl_sampling_fast.h is the caller).
+// kRefined: refined (a mesh with refinement: its tables, where they lie in HBM when null; kWhere: where else they may be) instead of tab.
+template <bool kRefined, int kWhere = kTableHbm, bool kNearby = true>
+__device__ __forceinline__ bool locate_from_coordinates(const BlShadeArgs &P, const GridTables &tab, const RefinedTables *refined, double s1, double s2, double s3,
+                                                        LocatedSample *out, unsigned long long *gathers, unsigned int *anchors, double angle_band = 0.0,
+                                                        bool defer_nearby = false) {
   const BlPlasmaDevice &pl = P.plasma;
-  const BlGridDevice &g = (kRefined && grid_in_lds != nullptr) ? *grid_in_lds : P.grid;
-  const bool sks = pl.simulation_coord == BL_COORD_SKS;
-  double s1 = x1, s2 = x2, s3 = x3;
-  out->ph = 0.0;
-  out->f_i = out->f_j = out->f_k = 0.0;
-  out->cell = 0u;
-  if (sks) {
-    // z / r is cos(theta) in ConvertFromCKS, in the SKS metric and in the Jacobian (same expression)
-    double th = bl_acos(blm_div(x3, r));   // (|z| <= r, both of the order of the coordinates: ordinary operands)
-    // zero spin: atan(0 / r) = +0 and atan2(y, x) - 0 = atan2(y, x)
-    double ph = kSpinZero ? bl_atan2(x2, x1) : bl_atan2(x2, x1) - bl_atan(blm_div(st.bh_a, r));
-    out->ph = ph;
-    ph += ph < 0.0 ? 2.0 * kPi : 0.0;
-    ph -= ph >= 2.0 * kPi ? 2.0 * kPi : 0.0;
-    s1 = r;
-    s2 = th;
-    s3 = ph;
-  }
+  const BlGridDevice &g = P.grid;
   if (kRefined) {
-    locate_sample_refined(P, g, anchors, s1, s2, s3, out, gathers);
-    return;
+    if (refined != nullptr) return locate_sample_refined<kWhere, kNearby>(P, *refined, anchors, s1, s2, s3, out, gathers, angle_band, defer_nearby);
+    const RefinedTables in_hbm = refined_tables_in_hbm(g);
+    return locate_sample_refined<kTableHbm, kNearby>(P, in_hbm, anchors, s1, s2, s3, out, gathers, angle_band, defer_nearby);
   }
   const int n_i = g.n[0], n_j = g.n[1], n_k = g.n[2];
   if (g.fmks) {
@@ -486,7 +622,7 @@ __device__ __forceinline__ void locate_sample(const BlShadeArgs &P, const GridTa
     if (!(s1 >= g.fmks_bounds[0] && s1 <= g.fmks_bounds[1] && s2 >= g.fmks_bounds[2] && s2 <= g.fmks_bounds[3]
           && s3 >= g.fmks_bounds[4] && s3 <= g.fmks_bounds[5])) {
       out->status = kSampleOffGrid;
-      return;
+      return true;
     }
     const size_t m1 = (size_t)g.sks_map_n1, m2 = (size_t)g.sks_map_n2;
     double i_ind, j_ind;
@@ -497,7 +633,7 @@ __device__ __forceinline__ void locate_sample(const BlShadeArgs &P, const GridTa
       atomicAdd(&P.counters[BL_CNT_UNDEFINED], 1ull);
       if (!P.undefined_edge) {
         out->status = kSampleCut;
-        return;
+        return true;
       }
       if (mi + 1 >= m1) { mi = m1 - 2; f_i = 1.0; }   // BL_UNDEFINED_EDGE: the table's last entry
       if (mj + 1 >= m2) { mj = m2 - 2; f_j = 1.0; }
@@ -523,7 +659,7 @@ __device__ __forceinline__ void locate_sample(const BlShadeArgs &P, const GridTa
       atomicAdd(&P.counters[BL_CNT_UNDEFINED], 1ull);
       if (!P.undefined_edge) {
         out->status = kSampleCut;
-        return;
+        return true;
       }
       // BL_UNDEFINED_EDGE: the zone's own row / column stands for the missing one
       if (pl.simulation_interp) {
@@ -545,21 +681,27 @@ __device__ __forceinline__ void locate_sample(const BlShadeArgs &P, const GridTa
       out->f_k = f_k;
       out->status = kSampleInterp;
     }
-    return;
+    return true;
   }
   if (s1 < tab.xf[0][0] || s1 > tab.xf[0][n_i] || s2 < tab.xf[1][0] || s2 > tab.xf[1][n_j]
       || s3 < tab.xf[2][0] || s3 > tab.xf[2][n_k]) {
+    if (angle_band > 0.0 && !(s1 < tab.xf[0][0] || s1 > tab.xf[0][n_i])) return false;   // (off the grid by an angle)
     out->status = kSampleOffGrid;
-    return;
+    return true;
   }
   int i = find_cell(g, tab, 0, s1);
   int j = find_cell(g, tab, 1, s2);
   int k = find_cell(g, tab, 2, s3);
+  if (angle_band > 0.0) {   // the angles against the faces and the centre of the cell they found
+    const double d_j = fmin(fmin(s2 - tab.xf[1][j], tab.xf[1][j + 1] - s2), __builtin_fabs(s2 - tab.xv[1][j]));
+    const double d_k = fmin(fmin(s3 - tab.xf[2][k], tab.xf[2][k + 1] - s3), __builtin_fabs(s3 - tab.xv[2][k]));
+    if (!(fmin(d_j, d_k) > angle_band)) return false;
+  }
   *gathers += 1ull;
   if (!pl.simulation_interp) {   // :710-734
     out->status = kSampleNearest;
     out->cell = (uint32_t)((k * n_j + j) * n_i + i);
-    return;
+    return true;
   }
   // :485-490
   // the anchor rule is per block (the indices of :485-487 are block-local): several equal blocks live in one
@@ -576,6 +718,33 @@ __device__ __forceinline__ void locate_sample(const BlShadeArgs &P, const GridTa
   out->f_k = blm_div(s3 - tab.xv[2][k_m], tab.xv[2][k_m + 1] - tab.xv[2][k_m]);
   out->status = kSampleInterp;
   out->cell = (uint32_t)((k_m * n_j + j_m) * n_i + i_m);
+  return true;
+}
+
+// Locate one sample: ConvertFromCKS (radiation_geometry.cpp:37-57) with the pinned inverse trigonometric functions, then the search
+template <bool kRefined, bool kSpinZero, int kWhere = kTableHbm, bool kNearby = true>
+__device__ __forceinline__ void locate_sample(const BlShadeArgs &P, const GridTables &tab, const BlSpacetime &st,
+                                              double x1, double x2, double x3, double r, LocatedSample *out,
+                                              unsigned long long *gathers, unsigned int *anchors, const RefinedTables *refined = nullptr,
+                                              bool defer_nearby = false) {
+  const bool sks = P.plasma.simulation_coord == BL_COORD_SKS;
+  double s1 = x1, s2 = x2, s3 = x3;
+  out->ph = 0.0;
+  out->f_i = out->f_j = out->f_k = 0.0;
+  out->cell = 0u;
+  if (sks) {
+    // z / r is cos(theta) in ConvertFromCKS, in the SKS metric and in the Jacobian (same expression)
+    double th = bl_acos(blm_div(x3, r));   // (|z| <= r, both of the order of the coordinates: ordinary operands)
+    // zero spin: atan(0 / r) = +0 and atan2(y, x) - 0 = atan2(y, x)
+    double ph = kSpinZero ? bl_atan2(x2, x1) : bl_atan2(x2, x1) - bl_atan(blm_div(st.bh_a, r));
+    out->ph = ph;
+    ph += ph < 0.0 ? 2.0 * kPi : 0.0;
+    ph -= ph >= 2.0 * kPi ? 2.0 * kPi : 0.0;
+    s1 = r;
+    s2 = th;
+    s3 = ph;
+  }
+  locate_from_coordinates<kRefined, kWhere, kNearby>(P, tab, refined, s1, s2, s3, out, gathers, anchors, 0.0, defer_nearby);
 }
 
 // SampleSimulation's nearest / trilinear read (simulation_sampling.cpp:666-1033, InterpolateSimple

@@ -59,6 +59,31 @@ __device__ __forceinline__ PlainLocated locate_plain_sample_tolerant(const BlSpa
   return out;
 }
 
+// locate_sample() (bl_sampling.h) for the locate kernels of the tolerant tier - meshes with refinement, inter-block interpolation,
+// slow light, grids in blocks with holes: the angles by the tier's functions (a third of the pinned ones' instructions; the exact
+// tier's locate kernel spends two thirds of its 1 000 vector instructions per sample on them), the search on them, and where they do
+// not decide it - a face, a centre or an end of the azimuth's range within `band` - the exact tier's angles and the search again.
+// Status, cell, anchors and every count are the exact tier's; the fractions differ from its by the angles' 1e-15.
+template <bool kRefined, bool kSpinZero, int kWhere = kTableHbm, bool kNearby = true>
+__device__ __forceinline__ void locate_sample_tolerant(const BlShadeArgs &P, const GridTables &tab, const BlSpacetime &st, double x1, double x2, double x3,
+                                                       double r, LocatedSample *out, unsigned long long *gathers, unsigned int *anchors,
+                                                       const RefinedTables *refined, double band, bool defer_nearby = false) {
+  if (band > 0.0 && P.plasma.simulation_coord == BL_COORD_SKS && !P.grid.fmks) {
+    const double th = fastmath::acos(blm_div(x3, r));
+    const double ph_unwrapped = kSpinZero ? fastmath::atan2(x2, x1) : fastmath::atan2(x2, x1) - fastmath::atan2(st.bh_a, r);
+    double ph = ph_unwrapped;
+    ph += ph < 0.0 ? 2.0 * kPi : 0.0;
+    const double ph_once = ph;
+    ph -= ph >= 2.0 * kPi ? 2.0 * kPi : 0.0;
+    const double e0 = __builtin_fabs(ph_unwrapped), e1 = __builtin_fabs(ph_once - 2.0 * kPi);
+    out->ph = ph_unwrapped;
+    out->f_i = out->f_j = out->f_k = 0.0;
+    out->cell = 0u;
+    if (e0 > band && e1 > band && locate_from_coordinates<kRefined, kWhere, kNearby>(P, tab, refined, r, th, ph, out, gathers, anchors, band, defer_nearby)) return;
+  }
+  locate_sample<kRefined, kSpinZero, kWhere, kNearby>(P, tab, st, x1, x2, x3, r, out, gathers, anchors, refined, defer_nearby);
+}
+
 // tolerant arithmetic tier of the coefficient formulas (sin, cos, tanh keep the pinned versions: few calls, and their
 // arguments need a real range reduction)
 #define BLC_NAME(f) f##_fast

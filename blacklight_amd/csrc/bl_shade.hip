@@ -8,7 +8,9 @@
 //                        (simulation_sampling.cpp:666-1033, simulation_coefficients.cpp:253-524,
 //                        formula_coefficients.cpp:62-180, unpolarized.cpp:74-110)
 //   auxiliary images     bl_shade_kernel<., true> writes (j, alpha) and a BlAuxSample per sample.   (unpolarized.cpp:113-196)
-#include "bl_sampling.h"
+#include <type_traits>
+
+#include "bl_sampling_fast.h"
 
 // ---- locate kernel (simulation mode): one sample record per lane. Coordinate conversion and the
 // LDS table walks of the cell search; no grid reads (the coefficient kernel issues those, where they
@@ -25,12 +27,11 @@ __global__ void __launch_bounds__(256, 4) bl_locate_kernel(const BlShadeArgs P_a
   const BlSpacetime st = P.st;
   extern __shared__ double lds_tables[];
   GridTables tab;
-  // Refined meshes: the grid description as the search functions read it - with its tables in LDS where they fit (refined_lds_bytes:
-  // block boundaries, lattice, the distinct coordinate rows, every block's rows and next centre, the MeshBlock table and hash of
-  // inter-block interpolation). The search is a chain of dependent reads - boundary, lattice, row, faces, centres, and for a sample
-  // near a block's edge a dozen hash probes - that took 33 ms (65 with inter-block interpolation) per 1024^2 frame from HBM.
-  __shared__ BlGridDevice grid_lds;   // (the copy itself in LDS too: read by every lane, written once)
-  const BlGridDevice *grid_for_search = nullptr;
+  // Refined meshes: the tables of the search - block boundaries, lattice, the distinct coordinate rows with their spacing, every
+  // block's rows and next centre - in LDS where they fit (refined_lds_bytes), read through LDS-typed pointers; the mesh's scalars come
+  // from the kernel arguments. (The search is five rounds of dependent reads; from HBM it took 33 ms per 1024^2 frame.)
+  RefinedTables refined = refined_tables_in_hbm(P.grid);
+  bool tables_in_lds = false;
   if (kRefined) {
     for (int a = 0; a < 3; a++) {
       tab.xf[a] = tab.xv[a] = nullptr;
@@ -38,9 +39,7 @@ __global__ void __launch_bounds__(256, 4) bl_locate_kernel(const BlShadeArgs P_a
     }
     const BlGridDevice &g = P.grid;
     if (g.refined_lds_bytes > 0) {
-      const bool writer = threadIdx.x == 0;
-      if (writer) grid_lds = g;
-      __syncthreads();
+      tables_in_lds = true;
       double *dd = lds_tables;
       auto stage_doubles = [&](const double *src, int count) {
         double *at = dd;
@@ -50,23 +49,16 @@ __global__ void __launch_bounds__(256, 4) bl_locate_kernel(const BlShadeArgs P_a
       };
 #pragma unroll
       for (int a = 0; a < 3; a++) {
-        const double *edge = stage_doubles(g.edge[a], g.n_edge[a] + 1);
-        const double *bxf = stage_doubles(g.bxf[a], g.n_rows[a] * (g.nb[a] + 1));
-        const double *bxv = stage_doubles(g.bxv[a], g.n_rows[a] * g.nb[a]);
-        const double *xv_next = stage_doubles(g.xv_next[a], g.n_blocks);
-        const double *row_guess = stage_doubles(g.row_guess[a], 3 * g.n_rows[a]);
-        if (writer) {
-          grid_lds.row_guess[a] = row_guess;
-          grid_lds.edge[a] = edge;
-          grid_lds.bxf[a] = bxf;
-          grid_lds.bxv[a] = bxv;
-          grid_lds.xv_next[a] = xv_next;
-        }
+        refined.edge[a] = stage_doubles(g.edge[a], g.n_edge[a] + 1);
+        refined.bxf[a] = stage_doubles(g.bxf[a], g.n_rows[a] * (g.nb[a] + 1));
+        refined.bxv[a] = stage_doubles(g.bxv[a], g.n_rows[a] * g.nb[a]);
+        refined.xv_next[a] = stage_doubles(g.xv_next[a], g.n_blocks);
+        refined.row_guess[a] = stage_doubles(g.row_guess[a], 3 * g.n_rows[a]);
       }
-      if (g.block_interp) {
+      if (g.block_interp) {   // (the hash's keys: eight bytes each, with the doubles)
         unsigned long long *keys = reinterpret_cast<unsigned long long *>(dd);
         for (int i = threadIdx.x; i <= (int)g.hash_mask; i += blockDim.x) keys[i] = g.hash_keys[i];
-        if (writer) grid_lds.hash_keys = keys;
+        refined.hash_keys = keys;
         dd += g.hash_mask + 1;
       }
       int *ii = reinterpret_cast<int *>(dd);
@@ -76,24 +68,16 @@ __global__ void __launch_bounds__(256, 4) bl_locate_kernel(const BlShadeArgs P_a
         ii += count;
         return at;
       };
-      const int *lattice = stage_ints(g.lattice, g.n_edge[0] * g.n_edge[1] * g.n_edge[2]);
-      if (writer) grid_lds.lattice = lattice;
+      refined.lattice = stage_ints(g.lattice, g.n_edge[0] * g.n_edge[1] * g.n_edge[2]);
 #pragma unroll
-      for (int a = 0; a < 3; a++) {
-        const int *rows = stage_ints(g.block_row[a], g.n_blocks);
-        if (writer) grid_lds.block_row[a] = rows;
-      }
+      for (int a = 0; a < 3; a++) refined.block_row[a] = stage_ints(g.block_row[a], g.n_blocks);
       if (g.block_interp) {
-        const int *levels = stage_ints(g.levels, g.n_blocks), *locations = stage_ints(g.locations, 3 * g.n_blocks);
-        const int *hash_blocks = stage_ints(g.hash_blocks, (int)g.hash_mask + 1);
-        if (writer) {
-          grid_lds.levels = levels;
-          grid_lds.locations = locations;
-          grid_lds.hash_blocks = hash_blocks;
-        }
+        refined.levels = stage_ints(g.levels, g.n_blocks);
+        refined.locations = stage_ints(g.locations, 3 * g.n_blocks);
+        refined.hash_blocks = stage_ints(g.hash_blocks, (int)g.hash_mask + 1);
       }
+      refined.in_lds = true;
       __syncthreads();
-      grid_for_search = &grid_lds;
     }
   } else if (kTablesInHbm) {
     const BlGridDevice &g = P.grid;
@@ -124,31 +108,19 @@ __global__ void __launch_bounds__(256, 4) bl_locate_kernel(const BlShadeArgs P_a
   const unsigned long long n_records = P.counters_in[BL_CNT_RECORDS];
   const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
   unsigned long long gathers_local = 0ull;
-  // Position and id of the next record are requested one iteration ahead
-  unsigned long long idx = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-  bool more = idx < n_records;
-  double2 nq0 = make_double2(0.0, 0.0), nq1 = nq0;
-  if (more) {
-    const double2 *src = reinterpret_cast<const double2 *>(P.records_hot + (idx) * P.record_stride);
-    nq0 = src[0];
-    nq1 = src[1];
-  }
-  while (more) {
-    const unsigned long long at = idx;
-    const double x1 = nq0.x, x2 = nq0.y, x3 = nq1.x;
-    const uint32_t ray = (uint32_t)__double_as_longlong(nq1.y);
-    idx += stride;
-    more = idx < n_records;
-    if (more) {
-      const double2 *src = reinterpret_cast<const double2 *>(P.records_hot + (idx) * P.record_stride);
-      nq0 = src[0];
-      nq1 = src[1];
-    }
+  // tolerant tier (its located samples carry the tag where the exact tier's carry the azimuth): the angles by the tier's functions
+  const double angle_band = P.tag_in_record ? P.fast_angle_band : 0.0;
+  // One record: radius and cuts, the time slice, the search; true: left for later (may_defer, locate_sample_refined's defer_nearby)
+  // (where: the main loop's instantiations know where the tables lie - kTableLds, kTableHbm - and have no FindNearbyInds in them: its
+  // samples wait for the pass over the lists, kTableAnywhere, which has the one copy)
+  auto locate_record = [&](auto where, unsigned long long at, double x1, double x2, double x3, uint32_t ray, bool may_defer) __attribute__((always_inline)) -> bool {
+    constexpr int kWhere = decltype(where)::value;
+    constexpr bool kNearby = !kRefined || kWhere == kTableAnywhere;
     if (ray == BL_DEAD_RAY) {
       // kSampleNone: the tolerant coefficient kernel requests corner cells from the tag alone
       if (P.tag_in_record) reinterpret_cast<double2 *>(P.located + at)[1] = make_double2(0.0, 0.0);
       else P.located_tag[at] = 0ull;
-      continue;
+      return false;
     }
     double r2;
     const double r = bl_radial_coordinate2<kSpinZero>(st, x1, x2, x3, &r2);
@@ -164,7 +136,10 @@ __global__ void __launch_bounds__(256, 4) bl_locate_kernel(const BlShadeArgs P_a
       t_ind = (unsigned long long)locate_time(P.slow, P.sample_t[at] + P.slow.snapshot_time, ray, &t_frac);
       P.slow.frac[at] = t_frac;
     }
-    if (!skip) locate_sample<kRefined, kSpinZero>(P, tab, st, x1, x2, x3, r, &loc, &gathers_local, P.anchors != nullptr ? P.anchors + at * 8 : nullptr, grid_for_search);
+    if (!skip)
+      locate_sample_tolerant<kRefined, kSpinZero, kWhere, kNearby>(P, tab, st, x1, x2, x3, r, &loc, &gathers_local, P.anchors != nullptr ? P.anchors + at * 8 : nullptr,
+                                                                   &refined, angle_band, may_defer);
+    if (kRefined && loc.status == kSamplePending) return true;
     double2 *dst = reinterpret_cast<double2 *>(P.located + at);
     const unsigned long long tag = (t_ind << 40) | ((unsigned long long)loc.status << 32) | loc.cell;
     dst[0] = make_double2(loc.f_i, loc.f_j);
@@ -174,7 +149,64 @@ __global__ void __launch_bounds__(256, 4) bl_locate_kernel(const BlShadeArgs P_a
       dst[1] = make_double2(loc.f_k, loc.ph);
       P.located_tag[at] = tag;
     }
+    return false;
+  };
+  // Inter-block interpolation: samples with an anchor beyond their own block wait in a list per wave (LDS) until there are 64 of them
+  // (a wave's instructions reach LDS in order: what one lane has written the next instruction's lanes read)
+  __shared__ unsigned long long pending_lists[kRefined ? 4 * 128 : 1];
+  const bool collect = kRefined && P.grid.block_interp != 0 && P.plasma.simulation_interp != 0;
+  unsigned long long *pending = pending_lists + (kRefined ? (threadIdx.x >> 6) * 128 : 0);
+  const uint32_t lane = threadIdx.x & 63u;
+  uint32_t n_pending = 0u;   // (wave-uniform: the loop below is left by the whole wave at once)
+  auto locate_pending = [&](uint32_t first, uint32_t count) __attribute__((always_inline)) {
+    __builtin_amdgcn_wave_barrier();
+    if (lane < count) {
+      const unsigned long long at = pending[first + lane];
+      const double2 *src = reinterpret_cast<const double2 *>(P.records_hot + at * P.record_stride);
+      const double2 q0 = src[0], q1 = src[1];
+      locate_record(std::integral_constant<int, kTableAnywhere>{}, at, q0.x, q0.y, q1.x, (uint32_t)__double_as_longlong(q1.y), false);
+    }
+    __builtin_amdgcn_wave_barrier();
+  };
+  // Position and id of the next record are requested one iteration ahead
+  unsigned long long idx = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  bool more = idx < n_records;
+  double2 nq0 = make_double2(0.0, 0.0), nq1 = nq0;
+  if (more) {
+    const double2 *src = reinterpret_cast<const double2 *>(P.records_hot + (idx) * P.record_stride);
+    nq0 = src[0];
+    nq1 = src[1];
   }
+  while (__any(more)) {
+    const bool have = more;
+    const unsigned long long at = idx;
+    const double x1 = nq0.x, x2 = nq0.y, x3 = nq1.x;
+    const uint32_t ray = (uint32_t)__double_as_longlong(nq1.y);
+    idx += stride;
+    more = more && idx < n_records;
+    if (more) {
+      const double2 *src = reinterpret_cast<const double2 *>(P.records_hot + (idx) * P.record_stride);
+      nq0 = src[0];
+      nq1 = src[1];
+    }
+    bool waits = false;
+    if (have) {
+      if (kRefined && tables_in_lds) waits = locate_record(std::integral_constant<int, kTableLds>{}, at, x1, x2, x3, ray, collect);
+      else waits = locate_record(std::integral_constant<int, kTableHbm>{}, at, x1, x2, x3, ray, collect);
+    }
+    if (kRefined && collect) {
+      const unsigned long long mask = __ballot(waits);
+      if (mask != 0ull) {
+        if (waits) pending[n_pending + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = at;
+        n_pending += (uint32_t)__popcll(mask);
+        if (n_pending >= 64u) {
+          n_pending -= 64u;
+          locate_pending(n_pending, 64u);
+        }
+      }
+    }
+  }
+  if (kRefined && collect && n_pending > 0u) locate_pending(0u, n_pending);
   // S_in accounting: one atomic per wave
   for (int offset = 32; offset > 0; offset >>= 1) gathers_local += __shfl_xor(gathers_local, offset, 64);
   if ((threadIdx.x & 63) == 0 && gathers_local != 0ull) atomicAdd(&P.counters[BL_CNT_GATHERS], gathers_local);

@@ -2,6 +2,7 @@
 # Hardware counters of one tolerant-tier benchmark frame per kernel, once per measurement switch ("-" = none), each counter in a
 # pass of its own (rocprofv3 --pmc alone: no trace domains beside it):
 #   gpurun -- 'COUNTERS="FETCH_SIZE WRITE_SIZE TCC_HIT_sum TCC_REQ_sum" bash tools/gpu_counters_ab.sh name - NO_FUSED_LOCATE'
+#   (BENCH_ARGS="--workload blockinterp256 --steps 1 --warmup 0": another workload's frame)
 #   -> gpurun_out/counters_<name>.txt     (FETCH_SIZE is printed x 2-corrected as MI355X_MICROARCH.md prescribes for gfx950)
 set -eu
 : "${GRAFT_REPO_ROOT:?run through gpurun}"
@@ -17,10 +18,10 @@ for sw in "${SWITCHES[@]}"; do
   rm -rf gpurun_out/cab; mkdir -p gpurun_out/cab
   for c in ${COUNTERS:-FETCH_SIZE WRITE_SIZE}; do
     if [ "$sw" = "-" ]; then
-      timeout -k 10 300 rocprofv3 --pmc "$c" --output-format csv -d "gpurun_out/cab/$c" -o t -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --arithmetic "${ARITH:-tolerant}" > /dev/null 2> "gpurun_out/cab/$c.err" || tail -3 "gpurun_out/cab/$c.err"
+      timeout -k 10 300 rocprofv3 --pmc "$c" --output-format csv -d "gpurun_out/cab/$c" -o t -- python3 bench.py ${BENCH_ARGS:---steps 1 --warmup 0 --no-cpu-baseline} --arithmetic "${ARITH:-tolerant}" > /dev/null 2> "gpurun_out/cab/$c.err" || tail -3 "gpurun_out/cab/$c.err"
     else
       export "BLACKLIGHT_AMD_$sw=1"
-      timeout -k 10 300 rocprofv3 --pmc "$c" --output-format csv -d "gpurun_out/cab/$c" -o t -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --arithmetic "${ARITH:-tolerant}" > /dev/null 2> "gpurun_out/cab/$c.err" || tail -3 "gpurun_out/cab/$c.err"
+      timeout -k 10 300 rocprofv3 --pmc "$c" --output-format csv -d "gpurun_out/cab/$c" -o t -- python3 bench.py ${BENCH_ARGS:---steps 1 --warmup 0 --no-cpu-baseline} --arithmetic "${ARITH:-tolerant}" > /dev/null 2> "gpurun_out/cab/$c.err" || tail -3 "gpurun_out/cab/$c.err"
       unset "BLACKLIGHT_AMD_$sw"
     fi
   done
