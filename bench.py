@@ -110,8 +110,9 @@ OTHER_WORKLOADS = {
     # the reference's production mode (simulation_multiple): geodesics once per series (blacklight.cpp:93-94 against the run loop :178-250)
     "series8": "a series of 8 snapshots of the 256^3 mock (cells differ from snapshot to snapshot, geometry the same), 1024^2 benchmark camera: "
                "frame 1 integrates the geodesics and leaves their sample records in HBM, frames 2 ... 8 shade them again (bl_set_geodesic_reuse)",
-    "series8_refined": "the same series over the two-level refined mesh of refined256: frames 2 ... 8 also keep the located samples "
-                       "(the reference's first_time sampling, radiation_integrator.cpp:693-704)",
+    "series8_refined": "the same series over the two-level refined mesh of refined256 (locate step inside the coefficient kernel, as on the "
+                       "benchmark's grid; --arithmetic exact: frames 2 ... 8 also keep the located samples - the reference's first_time "
+                       "sampling, radiation_integrator.cpp:693-704)",
     "series8_pipelined": "series8 with the next snapshot staged (bl_set_grid on a second host thread, into the second cell array) while the current one "
                          "renders: value = rays per second of the whole series' wall time, staging included",
 }

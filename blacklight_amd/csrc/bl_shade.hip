@@ -641,20 +641,14 @@ extern "C" hipError_t bl_launch_locate(const BlShadeArgs *args, int grid, int ld
     else hipLaunchKernelGGL((bl_locate_plain_kernel<false>), dim3(grid), dim3(256), lds_bytes, stream, *args);
     return hipGetLastError();
   }
-  // (zero spin known at compile time where the path is a common one: single-block and refined grids; slow light and tables beyond
-  // the LDS budget run the general instantiation, bit for bit the same at a = 0 - bl_geometry.h, "zero spin")
-#define BL_LAUNCH_L(R, LDS)                                                                                           \
-  do {                                                                                                                \
-    if (spin_zero) hipLaunchKernelGGL((bl_locate_kernel<R, false, true>), dim3(grid), dim3(256), LDS, stream, *args);  \
-    else hipLaunchKernelGGL((bl_locate_kernel<R, false, false>), dim3(grid), dim3(256), LDS, stream, *args);           \
-  } while (0)
+  // (one instantiation for any spin - bit for bit the same at a = 0, bl_geometry.h "zero spin": the paths with zero spin known at
+  // compile time are the common ones, bl_locate_plain_kernel above and the coefficient kernels with the locate step inside)
   if (refined && slow) hipLaunchKernelGGL((bl_locate_kernel<true, true, false>), dim3(grid), dim3(256), args->grid.refined_lds_bytes, stream, *args);
-  else if (refined) BL_LAUNCH_L(true, args->grid.refined_lds_bytes);
+  else if (refined) hipLaunchKernelGGL((bl_locate_kernel<true, false, false>), dim3(grid), dim3(256), args->grid.refined_lds_bytes, stream, *args);
   else if (lds_bytes == 0)   // merged grid with tables beyond the LDS budget (not with slow light: its instantiation needs them in LDS)
     hipLaunchKernelGGL((bl_locate_kernel<false, false, false, true>), dim3(grid), dim3(256), 0, stream, *args);
   else if (slow) hipLaunchKernelGGL((bl_locate_kernel<false, true, false>), dim3(grid), dim3(256), lds_bytes, stream, *args);
-  else BL_LAUNCH_L(false, lds_bytes);
-#undef BL_LAUNCH_L
+  else hipLaunchKernelGGL((bl_locate_kernel<false, false, false>), dim3(grid), dim3(256), lds_bytes, stream, *args);
   return hipGetLastError();
 }
 

@@ -41,14 +41,14 @@ def _fresh(params, grid, tier, reproducible=False, undefined=None, **render_args
         return out
 
 
-def _same_frame(got, want, bitwise=True):
+def _same_frame(got, want, bitwise=True, tolerance=1.0e-13):
     assert np.array_equal(got["sample_num"], want["sample_num"]) and np.array_equal(got["sample_flags"], want["sample_flags"])
     if bitwise:
         assert gu.same_bits(got["image"], want["image"]).all()
     else:
         assert np.array_equal(np.isnan(got["image"]), np.isnan(want["image"]))
         with np.errstate(invalid="ignore"):
-            assert np.nanmax(np.abs(got["image"] - want["image"])) <= 1.0e-13 * np.nanmax(np.abs(want["image"]))
+            assert np.nanmax(np.abs(got["image"] - want["image"])) <= tolerance * np.nanmax(np.abs(want["image"]))
     assert got["stats"].n_samples == want["stats"].n_samples and got["stats"].n_gathers == want["stats"].n_gathers
 
 
@@ -178,6 +178,26 @@ def test_located_samples_are_kept_while_the_geometry_is(layout):
                 assert flags == [(0, 0, 1), (1, 1, 0), (1, 0, 1), (1, 1, 0)], flags
             for g, grid_n in zip(got, (snaps[0], snaps[1], moved, moved)):
                 _same_frame(g, _fresh(params, grid_n, tier, reproducible=True, undefined=undefined))
+
+
+def test_refined_mesh_series_with_the_locate_step_inside():
+    """The tolerant tier's default over a mesh with refinement (bl_shade_fused2_kernel<..., kRefined>: nothing located outside the
+    coefficient kernel, composed maps): frames 2 and 3 of a series run that kernel over the resident records"""
+    import blacklight_amd as bl
+    fx, params, mock_args = gu.load_case("sim_dp_interp")
+    params = dict(params, camera_resolution=48)
+    snaps = _snapshots(gu.refined_grid(gu.golden_grid(mock_args)), 3)
+    with bl.Context(bl.Params.from_dict(params)) as ctx:
+        ctx.set_arithmetic("tolerant")
+        frames = []
+        for grid in snaps:
+            ctx.set_grid(grid)
+            frames.append(ctx.render())
+    flags = [(f["stats"].geodesics_reused, f["stats"].sampling_reused, f["stats"].launches_locate, f["stats"].fused_variant, f["stats"].composed_maps) for f in frames]
+    assert flags == [(0, 0, 0, 2, 1), (1, 0, 0, 2, 1), (1, 0, 0, 2, 1)], flags
+    for frame, grid in zip(frames, snaps):
+        _same_frame(frame, _fresh(params, grid, "tolerant", reproducible=True), bitwise=False)   # (through the locate kernel, a record per sample)
+        _same_frame(frame, _fresh(params, grid, "exact"), bitwise=False, tolerance=1.0e-11)
 
 
 def test_adaptive_levels_leave_the_root_records_alone():

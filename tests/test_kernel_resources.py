@@ -19,8 +19,8 @@ BENCHMARK_KERNELS = {
     "_Z18bl_geodesic_kernelILi0ELb0ELb0ELb1EEv11BlTraceArgs": (1, 0),
     "_Z23bl_geodesic_quad_kernelILb1EEv11BlTraceArgs": (2, 0),             # a ray per quad of lanes (BL_TAIL_QUAD, BL_TAIL_SPLIT)
     "_Z23bl_geodesic_quad_kernelILb0EEv11BlTraceArgs": (2, 0),
-    "_Z16bl_locate_kernelILb0ELb0ELb1ELb0EEv11BlShadeArgs": (4, 0),          # merged grid, no slow light, zero spin (at least 4)
-    "_Z16bl_locate_kernelILb0ELb0ELb0ELb0EEv11BlShadeArgs": (4, 0),
+    "_Z16bl_locate_kernelILb0ELb0ELb0ELb0EEv11BlShadeArgs": (4, 0),          # merged grid, no slow light (at least 4)
+    "_Z16bl_locate_kernelILb1ELb0ELb0ELb0EEv11BlShadeArgs": (4, 0),          # mesh with refinement
     "_Z15bl_shade_kernelILi0ELb0ELb0ELb0ELb0ELb0ELb0EEv11BlShadeArgs": (2, 0),   # simulation, thermal electrons, any coordinates
     "_Z20bl_shade_fast_kernelILb1ELi0EEv11BlShadeArgs": (2, 0),              # tolerant tier, zero spin
     "_Z20bl_shade_fast_kernelILb0ELi0EEv11BlShadeArgs": (2, 0),
