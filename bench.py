@@ -97,6 +97,7 @@ def cpu_baseline(params_dict, grid, resolution, stride):
 OTHER_WORKLOADS = {
     "formula512": "configuration 2: example_formula.input (formula mode, a = 0.9, camera at r = 1000, ray_max_steps = 7000), 512^2 camera",
     "polarized1024": "configuration 4's physics: full-Stokes polarized transfer + image_tau, 1024^2 plane camera over the 256^3 mock",
+    "polarized_refined1024": "configuration 4's physics over the two-level refined mesh of refined256 (what real Athena++ / AthenaK dumps are)",
     "adaptive2048": "configuration 4: example_adaptive.input's refinement (8 x 8 blocks, one level, relative Laplacian) over a 2048^2 root camera, "
                     "full-Stokes polarized transfer + image_tau, 256^3 mock, whole adaptive loop",
     "truecolor1024x64": "configuration 5's physics: example_true_color.input's 64 frequencies (lin_wave, 1.5e11 ... 3.3e11 Hz), 1024^2 camera, 256^3 mock",
@@ -295,8 +296,11 @@ def other_workload(args):
     else:
         params = dict(WORKLOAD)
         grid = mock.generate(n_r=args.grid, n_th=args.grid, n_ph=args.grid)
-        if name in ("polarized1024", "adaptive2048"):
+        if name in ("polarized1024", "adaptive2048", "polarized_refined1024"):
             params.update(image_polarization=True, image_tau=True)
+        if name == "polarized_refined1024":
+            import golden_util as gu
+            grid = gu.refined_grid(grid, block=(args.grid // 4,) * 3)
         if name == "adaptive2048":
             params.update(camera_resolution=2048, adaptive_max_level=1, adaptive_block_size=8, adaptive_frequency_num=1, adaptive_val_cut=0.0,
                           adaptive_val_frac=-1.0, adaptive_abs_grad_cut=0.0, adaptive_abs_grad_frac=-1.0, adaptive_rel_grad_cut=0.0,

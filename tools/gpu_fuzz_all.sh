@@ -10,6 +10,8 @@ if [ "$PART" != 2 ]; then
   run tiers timeout -k 10 300 python3 tools/gpu_fuzz_tiers.py 1500 $S 10
   FUZZ_RES=128,256 FUZZ_CHUNKS=1 run tiers_large timeout -k 10 400 python3 tools/gpu_fuzz_tiers.py 60 $S 20
   run wide timeout -k 10 500 python3 tools/gpu_fuzz_wide.py 700 $S
+  FUZZ_LAYOUT=5 FUZZ_RES=48,64 FUZZ_CHUNKS=1 run refined timeout -k 10 300 python3 tools/gpu_fuzz_tiers.py 1500 $S 50   # (two-level meshes: the locate step inside)
+  FUZZ_LAYOUT=6 run refined_warped timeout -k 10 300 python3 tools/gpu_fuzz_tiers.py 1500 $S 50   # (... over unevenly spaced angles: the locate kernel)
 fi
 if [ "$PART" != 1 ]; then
   FUZZ_POLARIZED=1 run polarized timeout -k 10 300 python3 tools/gpu_fuzz_wide.py 300 $S

@@ -5,7 +5,7 @@ of tests/test_gpu_tolerant.py are the part of this that runs every time).
     python3 tools/gpu_fuzz_tiers.py [n_seeds] [first_seed] [oracle_every]
 
 Every seed draws a camera (plane / pinhole, anywhere around the hole, inside or outside the grid), a spin, a mock grid of its own
-size (evenly spaced or warped polar / azimuthal faces, one block or split into blocks), sampling mode, temperature model, cuts,
+size (evenly spaced or warped polar / azimuthal faces, one block, split into blocks, or a two-level mesh), sampling mode, temperature model, cuts,
 fallback values, frequencies, optionally power-law electrons, a Cartesian reading of the grid, an optical-depth image. It then
 checks what the tiers promise: sample counts, flags, NaN masks and S_in identical, intensities within 1e-11 of a row's maximum; and
 for every `oracle_every`-th seed the exact tier bit for bit against the CPU oracle. Prints one line per violation and a summary."""
@@ -88,18 +88,20 @@ def draw(seed):
         over.update(cut_omit_near="true" if rng.random() < 0.5 else "false", cut_midplane_theta=float(rng.choice([0.0, 20.0])))
     n_r, n_th, n_ph = int(rng.choice([12, 20, 32, 48])), int(rng.choice([8, 16, 24, 40])), int(rng.choice([8, 16, 32]))
     grid = mock.generate(n_r=n_r, n_th=n_th, n_ph=n_ph)
-    layout = int(rng.integers(0, 5))
+    layout = int(rng.integers(0, 7))   # (5, 6: the two-level mesh of golden_util.refined_blocks, evenly spaced / over warped angles)
     changes = {}
-    if layout in (1, 3) and not cks:
+    if layout in (1, 3, 6) and not cks:
         x2f = warped(grid.x2f, float(rng.uniform(-0.6, 0.6)))
         changes.update(x2f=x2f, x2v=centres(x2f))
-    if layout in (2, 3) and not cks:
+    if layout in (2, 3, 6) and not cks:
         x3f = warped(grid.x3f, float(rng.uniform(-0.6, 0.6)))
         changes.update(x3f=x3f, x3v=centres(x3f))
     if changes:
         grid = dataclasses.replace(grid, **changes)
     if layout == 4:
         grid = gu.split_grid(grid, 2, 2, 2)
+    elif layout in (5, 6):
+        grid = gu.refined_grid(grid, block=(n_r // 4, n_th // 4, n_ph // 4))
     else:
         grid = gu.single_block_table(grid)
     return dict(params, **over), grid, dict(kind=kind, layout=layout, grid=[n_r, n_th, n_ph])
