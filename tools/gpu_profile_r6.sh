@@ -62,6 +62,11 @@ if [ "$PART" = 2 ]; then
     trace $w "rocprofv3 --kernel-trace --stats -- python3 bench.py --workload $w --steps 2 --warmup 1  (3 renders)" python3 bench.py --workload "$w" --steps 2 --warmup 1
   done
   python3 bench.py --workload formula512 --arithmetic exact --steps 2 --warmup 1 > "$OUT/config_formula512_exact.json" 2> /dev/null
+  # (the mesh rows in the exact tier, and configuration 4's physics over the refined mesh: lines only)
+  for w in refined256 blockinterp256 slowlight10; do
+    python3 bench.py --workload $w --arithmetic exact --steps 2 --warmup 1 > "$OUT/config_${w}_exact.json" 2> /dev/null
+  done
+  python3 bench.py --workload polarized_refined1024 --steps 2 --warmup 1 > "$OUT/config_polarized_refined1024.json" 2> /dev/null
   for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES"; do
     name=$(echo "$set" | tr ' ' '_' | cut -c1-40)
     rocprofv3 --pmc $set --output-format csv -d "$OUT/ppmc_$name" -- python3 bench.py --workload polarized1024 --steps 1 --warmup 0 > /dev/null 2> "$OUT/ppmc_$name.err"
