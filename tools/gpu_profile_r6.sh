@@ -33,7 +33,7 @@ if [ "$PART" = 1 ]; then
   echo "bench done"; tail -c 300 "$OUT/bench_default.json"; echo
   rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/bench_under_rocprof.json" 2> "$OUT/trace.err"
   cp "$(find "$OUT/trace" -name "*kernel_stats.csv" | head -1)" "$OUT/kernel_stats.csv"
-  python3 tools/summarise_trace.py "$OUT/trace" "$OUT/kernel_trace_summary.txt" "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline  (4 tolerant-tier frames, 4 exact-tier frames, 1 more tolerant; one launch of each kernel per frame)" > /dev/null
+  python3 tools/summarise_trace.py "$OUT/trace" "$OUT/kernel_trace_summary.txt" "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline  (4 tolerant-tier frames, 4 exact-tier frames, 1 more tolerant for the per-pixel comparison, then the line's series leg: 1 fresh frame and a series of 4, frames 2 - 4 of it over resident records - the coefficient kernel's 30.4 ... 30.9 ms launches; one launch of each kernel per frame)" > /dev/null
   rm -rf "$OUT/trace"
   for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum" "TCC_REQ_sum" \
              "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_BUSY_CYCLES" \
