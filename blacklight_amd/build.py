@@ -19,7 +19,7 @@ LIB = os.path.join(HERE, "libblacklight_amd.so")
 EXE = os.path.join(HERE, "bin", "blacklight_amd")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 
-SOURCES = ["bl_shade.hip", "bl_shade_fast.hip", "bl_shade_fused.hip", "bl_geodesic.hip", "bl_geodesic_quad.hip", "bl_coefficients_freq.hip", "bl_transfer.hip", "bl_polarized.hip", "bl_api.hip",
+SOURCES = ["bl_locate.hip", "bl_shade.hip", "bl_shade_fast.hip", "bl_shade_fused.hip", "bl_geodesic.hip", "bl_geodesic_quad.hip", "bl_coefficients_freq.hip", "bl_transfer.hip", "bl_polarized.hip", "bl_api.hip",
            "bl_render.hip", "bl_params.cpp", "bl_host.cpp", "bl_snapshot.cpp"]   # (slowest first: they are compiled side by side)
 ARCH = "gfx950"
 DEVICE_FLAGS = ["-mllvm", "-disable-machine-licm"]

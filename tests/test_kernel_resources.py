@@ -9,7 +9,7 @@ import pytest
 from blacklight_amd import build as bl_build
 
 RESOURCES = [os.path.join(bl_build.OBJ, name + ".resources.txt")
-             for name in ("bl_geodesic", "bl_geodesic_quad", "bl_shade", "bl_shade_fast", "bl_shade_fused", "bl_transfer")]   # one translation unit per stage of the pipeline
+             for name in ("bl_geodesic", "bl_geodesic_quad", "bl_locate", "bl_shade", "bl_shade_fast", "bl_shade_fused", "bl_transfer")]   # one translation unit per stage of the pipeline
 
 # mangled name -> (waves per SIMD, largest scratch in bytes per lane)
 BENCHMARK_KERNELS = {
