@@ -104,6 +104,8 @@ OTHER_WORKLOADS = {
     # SURVEY.md 8(f) rows at the benchmark's size (parity for them: tests/; these lines say how fast they run)
     "refined256": "8(f)1 mesh refinement: the 256^3 mock as a two-level mesh (4 coarse + 32 fine MeshBlocks of 64^3 cells, scrambled), 1024^2 camera, "
                   "benchmark physics (simulation_sampling.cpp:352-394: block search per sample)",
+    "refined256_deep": "the mesh of refined256 cut into 16^3-cell MeshBlocks (2 304 blocks, 24 distinct coordinate rows per axis, 16^3 boxes: the "
+                       "table sizes of a deep hierarchy - beyond the LDS budgets of the kernels that search from LDS)",
     "blockinterp256": "8(f)1 inter-block interpolation: the 256^3 mock as 4 x 4 x 4 MeshBlocks of 64^3 cells with simulation_block_interp = true "
                       "(simulation_sampling.cpp:1068-1321; samples at the upper edge of the file's last block use the edge cell, BL_UNDEFINED_EDGE), 1024^2 camera",
     "slowlight10": "8(f)3 slow light: a window of 10 time slices of the 256^3 mock (5.4 GB of cells resident), interpolation in time, 1024^2 camera "
@@ -308,9 +310,11 @@ def other_workload(args):
                           adaptive_rel_lapl_frac=0.25, adaptive_num_regions=0)
         if name == "truecolor1024x64":
             params.update(image_num_frequencies=64, image_frequency_start=1.5e11, image_frequency_end=3.3e11, image_frequency_spacing="lin_wave")
-        if name == "refined256":
+        if name in ("refined256", "refined256_deep"):
             import golden_util as gu
             grid = gu.refined_grid(grid, block=(args.grid // 4,) * 3)
+            if name == "refined256_deep":
+                grid = gu.subdivide_blocks(grid, 4)
         if name == "blockinterp256":
             import golden_util as gu
             grid = gu.split_grid(grid, 4, 4, 4)

@@ -888,7 +888,7 @@ void UploadRefinedGrid(bl_ctx *ctx, const bl_grid_desc *g) {
   {
     // what bl_shade_fused2_kernel<..., kRefined> asks of a mesh (bl_shade_fused.hip): boxes and rows evenly spaced in log r / theta / phi to
     // 1e-4 of a cell (its guesses are then right wherever its margins let it decide), the sphere covered without a hole, 32-bit byte
-    // offsets into the cell array, room in LDS for the row chunks and one descriptor per box at two workgroups to a compute unit
+    // offsets into the cell array, room in LDS for the row chunks and one descriptor per box (one 512-lane workgroup to a compute unit)
     auto evenly = [](const double *f, int n, bool logarithmic, double *origin, double *inv_w) {
       if (n < 1 || (logarithmic && !(f[0] > 0.0))) return false;
       const double first = logarithmic ? std::log2(f[0]) : f[0], last = logarithmic ? std::log2(f[n]) : f[n];
@@ -916,7 +916,7 @@ void UploadRefinedGrid(bl_ctx *ctx, const bl_grid_desc *g) {
       bytes += static_cast<size_t>(n_rows[a]) * (16 + 64 * static_cast<size_t>(nb[a]));
     }
     bytes += 16 * n_boxes;
-    ok = ok && bytes <= 76u * 1024u;
+    ok = ok && bytes <= static_cast<size_t>(BL_FUSED_REFINED_LDS);
     if (ok) {
       std::vector<unsigned int> desc(4 * n_boxes);
       for (size_t box = 0; box < n_boxes; box++) {

@@ -86,6 +86,9 @@ enum BlCounter {
 #define BL_CNT_PARKED_YOUNG (BL_CNT_COUNT + 14)   // parked rays with fewer than BlTraceArgs::park_age samples so far (BL_CNT_PARKED: the others)
 #define BL_CNT_TOTAL (BL_CNT_COUNT + 15)
 
+// dynamic LDS the refined instantiation of bl_shade_fused2_kernel may take (one 512-lane workgroup to a compute unit of 160 KiB)
+#define BL_FUSED_REFINED_LDS (150 * 1024)
+
 struct BlGridDevice {
   const float *cells;        // [n_k][n_j][n_i][8]
   const float *kappa;        // [n_k][n_j][n_i] electron entropy (plasma_model = code_kappa), else null

@@ -689,8 +689,10 @@ __device__ __forceinline__ double2 shade(const BlSpacetime &st, const double (&K
 // rows as standing for those (BL_COMPOSED_EXPANDED).
 // kFactors: several frequencies - a sample leaves as its factors (BlFreqInputs, row ray_offset + n) instead of a transfer record.
 // kRefined: a mesh with refinement whose lattice of blocks and whose rows are evenly spaced (BlGridDevice::fused_lds_bytes > 0).
+// (Its workgroups may be 512 lanes, one to a compute unit - the same two waves per SIMD - so that one copy of the tables serves eight waves
+// and may take most of the compute unit's 160 KiB: a mesh of thousands of small blocks fits. bl_launch_shade_fused2 chooses.)
 template <bool kSpinZero, bool kComposed, bool kFactors = false, bool kRefined = false>
-__global__ void __launch_bounds__(256, BL_FAST_WAVES) bl_shade_fused2_kernel(const BlShadeArgs P) {
+__global__ void __launch_bounds__(kRefined ? 512 : 256, kRefined ? 1 : BL_FAST_WAVES) bl_shade_fused2_kernel(const BlShadeArgs P) {
   using namespace fused2;
   extern __shared__ double lds[];
   // ---- LDS: the cut table (7 x 6 doubles), then one row per cell for r, theta, phi
@@ -1379,14 +1381,19 @@ extern "C" hipError_t bl_launch_shade_fused2(const BlShadeArgs *args, int grid, 
   const BlGridDevice &g = args->grid;
   if (g.n_blocks > 0) {
     if (args->composed == nullptr || args->freq_split || g.fused_lds_bytes <= 0) return hipErrorInvalidValue;
-    if (g.fused_lds_bytes > 64 * 1024) {   // (more dynamic LDS than a launch gets unasked: up to 76 KiB, two workgroups to a compute unit's 160)
-      const void *kernel = args->st.bh_a == 0.0 ? reinterpret_cast<const void *>(&bl_shade_fused2_kernel<true, true, false, true>)
-                                                : reinterpret_cast<const void *>(&bl_shade_fused2_kernel<false, true, false, true>);
-      const hipError_t err = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 76 * 1024);
+    const void *kernel = args->st.bh_a == 0.0 ? reinterpret_cast<const void *>(&bl_shade_fused2_kernel<true, true, false, true>)
+                                              : reinterpret_cast<const void *>(&bl_shade_fused2_kernel<false, true, false, true>);
+    if (g.fused_lds_bytes > 64 * 1024) {   // (more dynamic LDS than a launch gets unasked: up to BL_FUSED_REFINED_LDS of the compute unit's 160 KiB)
+      const hipError_t err = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BL_FUSED_REFINED_LDS);
       if (err != hipSuccess) return err;
     }
-    if (args->st.bh_a == 0.0) hipLaunchKernelGGL((bl_shade_fused2_kernel<true, true, false, true>), dim3(grid), dim3(256), (size_t)g.fused_lds_bytes, stream, *args);
-    else hipLaunchKernelGGL((bl_shade_fused2_kernel<false, true, false, true>), dim3(grid), dim3(256), (size_t)g.fused_lds_bytes, stream, *args);
+    // Tables that fit twice into a compute unit's LDS: 256-lane workgroups as for one block (`grid` of them). Larger ones: one 512-lane
+    // workgroup to a compute unit, and one round of them (a workgroup's LDS is free for the next only when its last wave has ended:
+    // with several rounds every round's tail idles seven waves; measured 29.6 against 27.5 ms on the mesh that fits either way)
+    const bool two_to_a_unit = g.fused_lds_bytes <= 76 * 1024;
+    const dim3 blocks(two_to_a_unit ? grid : (grid >= 8 ? grid / 8 : 1)), lanes(two_to_a_unit ? 256 : 512);
+    if (args->st.bh_a == 0.0) hipLaunchKernelGGL((bl_shade_fused2_kernel<true, true, false, true>), blocks, lanes, (size_t)g.fused_lds_bytes, stream, *args);
+    else hipLaunchKernelGGL((bl_shade_fused2_kernel<false, true, false, true>), blocks, lanes, (size_t)g.fused_lds_bytes, stream, *args);
     return hipGetLastError();
   }
   const size_t lds = 48 * sizeof(double) + 64 * (size_t)(g.n[0] + g.n[1] + g.n[2]);

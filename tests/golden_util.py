@@ -155,6 +155,40 @@ def refined_grid(grid, last=None, block=None):
                 locations=np.ascontiguousarray(blocks["locations"], dtype=np.int32), n_3_root=2 * (block or REFINED_BLOCK)[2])
 
 
+def subdivide_blocks(grid, split):
+    """Every MeshBlock of a Grid cut into split^3 (or split_i x split_j x split_k) smaller ones of the same level (what a run with smaller MeshBlocks of the same mesh
+    writes): cells and coordinates are the blocks' own values, locations multiply by split. A deep hierarchy's table sizes - thousands
+    of blocks, dozens of distinct coordinate rows - from the two-level mesh of refined_blocks()."""
+    import dataclasses
+    n_var, n_b, n_k, n_j, n_i = grid.prim.shape
+    split_i, split_j, split_k = (split, split, split) if np.isscalar(split) else split
+    assert n_i % split_i == 0 and n_j % split_j == 0 and n_k % split_k == 0
+    si, sj, sk = n_i // split_i, n_j // split_j, n_k // split_k
+    n_new = n_b * split_i * split_j * split_k
+    prim = np.empty((n_var, n_new, sk, sj, si), dtype=np.float32)
+    rows = {name: np.empty((n_new, n), dtype=np.float64) for name, n in
+            (("x1f", si + 1), ("x2f", sj + 1), ("x3f", sk + 1), ("x1v", si), ("x2v", sj), ("x3v", sk))}
+    levels = np.empty(n_new, dtype=np.int32) if grid.levels is not None else None
+    locations = np.empty((n_new, 3), dtype=np.int32) if grid.locations is not None else None
+    n = 0
+    for b in range(n_b):
+        for c in range(split_k):
+            for bb in range(split_j):
+                for a in range(split_i):
+                    prim[:, n] = grid.prim[:, b, c * sk:(c + 1) * sk, bb * sj:(bb + 1) * sj, a * si:(a + 1) * si]
+                    rows["x1f"][n] = grid.x1f[b, a * si:(a + 1) * si + 1]
+                    rows["x2f"][n] = grid.x2f[b, bb * sj:(bb + 1) * sj + 1]
+                    rows["x3f"][n] = grid.x3f[b, c * sk:(c + 1) * sk + 1]
+                    rows["x1v"][n] = grid.x1v[b, a * si:(a + 1) * si]
+                    rows["x2v"][n] = grid.x2v[b, bb * sj:(bb + 1) * sj]
+                    rows["x3v"][n] = grid.x3v[b, c * sk:(c + 1) * sk]
+                    if levels is not None:
+                        levels[n] = grid.levels[b]
+                        locations[n] = grid.locations[b] * np.array([split_i, split_j, split_k]) + np.array([a, bb, c])
+                    n += 1
+    return dataclasses.replace(grid, prim=np.ascontiguousarray(prim), levels=levels, locations=locations, **rows)
+
+
 SLOW_CASES = ["slow_interp", "slow_nearest"]
 
 

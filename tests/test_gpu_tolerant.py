@@ -346,6 +346,38 @@ def test_tolerant_tier_over_a_refined_mesh_locates_inside_the_coefficient_kernel
     print(f"a = {spin}: inside {_distance(inside['image'], exact['image']):.2e}, deferred {inside['stats'].n_deferred} of {inside['stats'].n_gathers}")
 
 
+@pytest.mark.parametrize("split,block_interp", [(2, False), ((4, 3, 4), False), (2, True)])
+def test_meshes_of_many_small_blocks(split, block_interp, built_library):
+    """The two-level mesh cut into smaller MeshBlocks (288 / 2 304 blocks): more distinct coordinate rows, a finer block lattice - at
+    split 4 beyond what the locate kernel stages in LDS, so that it searches the tables where they lie in HBM. Exact tier against the
+    CPU oracle bit for bit (whose search is the reference's scan over all blocks), tolerant tier against the exact one."""
+    import blacklight_amd as bl
+    from blacklight_amd import _capi
+    import oracle_api
+    fx, params, mock_args = gu.load_case("sim_dp_interp")
+    params = dict(params, camera_resolution=24, camera_th=70.0, camera_ph=200.0, simulation_interp="true", fallback_nan="false",
+                  fallback_rho=1.0e-6, fallback_pgas=1.0e-8, simulation_block_interp="true" if block_interp else "false")
+    grid = gu.subdivide_blocks(gu.golden_grid(dict(mock_args, _refined=1)), split)
+    p = bl.Params.from_dict(params)
+    with bl.Context(p) as ctx:
+        if block_interp:
+            ctx.set_undefined_policy("edge")
+        ctx.set_grid(grid)
+        ctx.set_arithmetic("exact")
+        exact = ctx.render()
+        ctx.set_arithmetic("tolerant")
+        tol = ctx.render()
+    if not block_interp:   # (the oracle refuses the undefined reads that BL_UNDEFINED_EDGE defines)
+        want = oracle_api.render(p.ptr, grid.desc(), _capi.RenderDesc, _capi.CameraFrame, n_rays=24 * 24, max_steps=int(p.get("ray_max_steps")))
+        assert gu.same_bits(exact["image"], want["image"]).all() and exact["stats"].n_gathers == want["n_gathers"]
+        assert np.array_equal(exact["sample_num"], want["sample_num"])
+    assert tol["stats"].arithmetic == 1 and tol["stats"].n_gathers == exact["stats"].n_gathers
+    assert np.array_equal(tol["sample_num"], exact["sample_num"]) and np.array_equal(np.isnan(tol["image"]), np.isnan(exact["image"]))
+    d = _distance(tol["image"], exact["image"])
+    print(f"split {split}: {grid.prim.shape[1]} blocks, fused_variant {tol['stats'].fused_variant}, {d:.2e}, deferred {tol['stats'].n_deferred}")
+    assert d < EXPECTED and np.nanmax(exact["image"]) > 0.0
+
+
 @pytest.mark.parametrize("band,resolution,frequencies,variant", [(1.0e30, 24, 1, ""), (1.0e30, 56, 1, ""), (1.0e30, 24, 5, ""), (1.0e30, 56, 5, ""),
                                                                  (1.0e30, 24, 1, "power"), (1.0e30, 24, 3, "cks"), (1.0e30, 24, 3, "cks power")])
 def test_deferred_cut_decisions(band, resolution, frequencies, variant, built_library):

@@ -67,6 +67,9 @@ if [ "$PART" = 2 ]; then
     python3 bench.py --workload $w --arithmetic exact --steps 2 --warmup 1 > "$OUT/config_${w}_exact.json" 2> /dev/null
   done
   python3 bench.py --workload polarized_refined1024 --steps 2 --warmup 1 > "$OUT/config_polarized_refined1024.json" 2> /dev/null
+  for tier in tolerant exact; do   # (the mesh of refined256 in 16^3-cell blocks: the table sizes of a deep hierarchy)
+    python3 bench.py --workload refined256_deep --arithmetic $tier --steps 2 --warmup 1 > "$OUT/config_refined256_deep_$tier.json" 2> /dev/null
+  done
   for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES"; do
     name=$(echo "$set" | tr ' ' '_' | cut -c1-40)
     rocprofv3 --pmc $set --output-format csv -d "$OUT/ppmc_$name" -- python3 bench.py --workload polarized1024 --steps 1 --warmup 0 > /dev/null 2> "$OUT/ppmc_$name.err"
