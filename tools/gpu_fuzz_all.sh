@@ -11,6 +11,7 @@ if [ "$PART" != 2 ]; then
   FUZZ_RES=128,256 FUZZ_CHUNKS=1 run tiers_large timeout -k 10 400 python3 tools/gpu_fuzz_tiers.py 60 $S 20
   run wide timeout -k 10 500 python3 tools/gpu_fuzz_wide.py 700 $S
   FUZZ_LAYOUT=5 FUZZ_RES=48,64 FUZZ_CHUNKS=1 run refined timeout -k 10 300 python3 tools/gpu_fuzz_tiers.py 1500 $S 50   # (two-level meshes: the locate step inside)
+  FUZZ_LAYOUT=7 FUZZ_RES=48,64 run refined_small_blocks timeout -k 10 300 python3 tools/gpu_fuzz_tiers.py 1600 $S 50   # (... in up to 64 times as many blocks)
   FUZZ_LAYOUT=6 run refined_warped timeout -k 10 300 python3 tools/gpu_fuzz_tiers.py 1500 $S 50   # (... over unevenly spaced angles: the locate kernel)
 fi
 if [ "$PART" != 1 ]; then

@@ -88,7 +88,7 @@ def draw(seed):
         over.update(cut_omit_near="true" if rng.random() < 0.5 else "false", cut_midplane_theta=float(rng.choice([0.0, 20.0])))
     n_r, n_th, n_ph = int(rng.choice([12, 20, 32, 48])), int(rng.choice([8, 16, 24, 40])), int(rng.choice([8, 16, 32]))
     grid = mock.generate(n_r=n_r, n_th=n_th, n_ph=n_ph)
-    layout = int(rng.integers(0, 7))   # (5, 6: the two-level mesh of golden_util.refined_blocks, evenly spaced / over warped angles)
+    layout = int(rng.integers(0, 8))   # (5, 6: the two-level mesh of golden_util.refined_blocks, evenly spaced / over warped angles; 7: in smaller blocks)
     changes = {}
     if layout in (1, 3, 6) and not cks:
         x2f = warped(grid.x2f, float(rng.uniform(-0.6, 0.6)))
@@ -100,8 +100,12 @@ def draw(seed):
         grid = dataclasses.replace(grid, **changes)
     if layout == 4:
         grid = gu.split_grid(grid, 2, 2, 2)
-    elif layout in (5, 6):
+    elif layout in (5, 6, 7):
         grid = gu.refined_grid(grid, block=(n_r // 4, n_th // 4, n_ph // 4))
+        if layout == 7:   # every block cut in two or four along the axes that allow it (blocks of at least two cells)
+            def cut(n):
+                return int(rng.choice([c for c in (1, 2, 4) if (n // 4) % c == 0 and (n // 4) // c >= 2]))
+            grid = gu.subdivide_blocks(grid, (cut(n_r), cut(n_th), cut(n_ph)))
     else:
         grid = gu.single_block_table(grid)
     return dict(params, **over), grid, dict(kind=kind, layout=layout, grid=[n_r, n_th, n_ph])
