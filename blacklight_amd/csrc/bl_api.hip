@@ -874,7 +874,7 @@ void UploadRefinedGrid(bl_ctx *ctx, const bl_grid_desc *g) {
     dev.n_3_level0 = g->n_3_root / nb[2];
   }
   {
-    // what bl_locate_kernel<kRefined> stages in LDS when it fits (four workgroups to a compute unit: 36 KiB each): block boundaries,
+    // what bl_locate_kernel<kRefined> stages in LDS when it fits (four workgroups to a compute unit up to 36 KiB, one of 1 024 lanes beyond): block boundaries,
     // lattice, rows, the blocks' rows and next centres, and with inter-block interpolation the MeshBlock table and its hash
     size_t doubles = 0, ints = lattice_ints + static_cast<size_t>(n_b) * 3;
     for (int a = 0; a < 3; a++) doubles += static_cast<size_t>(n_edge[a]) + 1 + static_cast<size_t>(n_rows[a]) * (2 * nb[a] + 1 + 3) + n_b;
@@ -883,7 +883,7 @@ void UploadRefinedGrid(bl_ctx *ctx, const bl_grid_desc *g) {
       ints += static_cast<size_t>(n_b) * 4 + dev.hash_mask + 1;
     }
     const size_t bytes = doubles * sizeof(double) + (ints + 3) / 4 * 4 * sizeof(int);
-    dev.refined_lds_bytes = bytes <= 36u * 1024u ? static_cast<int>(bytes) : 0;
+    dev.refined_lds_bytes = bytes <= static_cast<size_t>(BL_LOCATE_REFINED_LDS) ? static_cast<int>(bytes) : 0;
   }
   {
     // what bl_shade_fused2_kernel<..., kRefined> asks of a mesh (bl_shade_fused.hip): boxes and rows evenly spaced in log r / theta / phi to

@@ -88,6 +88,8 @@ enum BlCounter {
 
 // dynamic LDS the refined instantiation of bl_shade_fused2_kernel may take (one 512-lane workgroup to a compute unit of 160 KiB)
 #define BL_FUSED_REFINED_LDS (150 * 1024)
+// ... and the tables of bl_locate_kernel<kRefined> (one 1 024-lane workgroup to a compute unit; 16 KiB more for its waves' lists)
+#define BL_LOCATE_REFINED_LDS (136 * 1024)
 
 struct BlGridDevice {
   const float *cells;        // [n_k][n_j][n_i][8]

@@ -20,8 +20,10 @@
 // kTablesInHbm: the coordinate tables of a merged grid are too large for LDS and are searched where they lie (a
 // compile-time choice: table pointers that may be either LDS or global become flat loads, each of which waits on both
 // memory counters).
+// (The instantiations for meshes with refinement may be launched with 1 024 lanes, one workgroup to a compute unit - the same four
+// waves per SIMD - so that one copy of the tables serves sixteen waves and may take most of the unit's 160 KiB: bl_launch_locate.)
 template <bool kRefined, bool kSlow, bool kSpinZero, bool kTablesInHbm = false>
-__global__ void __launch_bounds__(256, 4) bl_locate_kernel(const BlShadeArgs P_at_entry) {
+__global__ void __launch_bounds__(kRefined ? 1024 : 256, kRefined ? 1 : 4) bl_locate_kernel(const BlShadeArgs P_at_entry) {
   const BlShadeArgs &P = kernel_arguments_in_place<BlShadeArgs>();   // (bl_kernel_util.h; P_at_entry is never read)
   (void)P_at_entry;
   const BlSpacetime st = P.st;
@@ -153,9 +155,9 @@ __global__ void __launch_bounds__(256, 4) bl_locate_kernel(const BlShadeArgs P_a
   };
   // Inter-block interpolation: samples with an anchor beyond their own block wait in a list per wave (LDS) until there are 64 of them
   // (a wave's instructions reach LDS in order: what one lane has written the next instruction's lanes read)
-  __shared__ unsigned long long pending_lists[kRefined ? 4 * 128 : 1];
+  // (the lists lie behind the tables in the dynamic LDS: 1 KiB per wave, bl_launch_locate adds them to the launch's bytes)
   const bool collect = kRefined && P.grid.block_interp != 0 && P.plasma.simulation_interp != 0;
-  unsigned long long *pending = pending_lists + (kRefined ? (threadIdx.x >> 6) * 128 : 0);
+  unsigned long long *pending = reinterpret_cast<unsigned long long *>(lds_tables) + (kRefined ? (size_t)(P.grid.refined_lds_bytes + 7) / 8 + (threadIdx.x >> 6) * 128 : 0);
   const uint32_t lane = threadIdx.x & 63u;
   uint32_t n_pending = 0u;   // (wave-uniform: the loop below is left by the whole wave at once)
   auto locate_pending = [&](uint32_t first, uint32_t count) __attribute__((always_inline)) {
@@ -283,8 +285,25 @@ extern "C" hipError_t bl_launch_locate(const BlShadeArgs *args, int grid, int ld
   }
   // (one instantiation for any spin - bit for bit the same at a = 0, bl_geometry.h "zero spin": the paths with zero spin known at
   // compile time are the common ones, bl_locate_plain_kernel above and the coefficient kernels with the locate step inside)
-  if (refined && slow) hipLaunchKernelGGL((bl_locate_kernel<true, true, false>), dim3(grid), dim3(256), args->grid.refined_lds_bytes, stream, *args);
-  else if (refined) hipLaunchKernelGGL((bl_locate_kernel<true, false, false>), dim3(grid), dim3(256), args->grid.refined_lds_bytes, stream, *args);
+  if (refined) {
+    // Tables that fit four times into a compute unit's LDS (36 KiB): 256-lane workgroups. Larger ones (up to BL_LOCATE_REFINED_LDS): one
+    // 1 024-lane workgroup to a compute unit, one round of them. Beyond that the tables are searched where they lie in HBM
+    // (refined_lds_bytes = 0). Behind the tables: the waves' lists of samples that wait for FindNearbyInds, 1 KiB each.
+    const int table_bytes = args->grid.refined_lds_bytes;
+    const bool four_to_a_unit = table_bytes <= 36 * 1024;
+    const int lanes = four_to_a_unit ? 256 : 1024;
+    const size_t bytes = (size_t)(table_bytes + 7) / 8 * 8 + (size_t)(lanes / 64) * 1024;
+    // (`grid` counts 256-lane workgroups: sixteen to a compute unit when the kernel runs alone - then one large workgroup per unit - or one
+    // to a unit beside the next chunk's stepper - then as many lanes as that)
+    const dim3 blocks(four_to_a_unit ? grid : (grid >= 1024 ? grid / 16 : (grid >= 4 ? grid / 4 : 1)));
+    const void *kernel = slow ? reinterpret_cast<const void *>(&bl_locate_kernel<true, true, false>) : reinterpret_cast<const void *>(&bl_locate_kernel<true, false, false>);
+    if (bytes > 64 * 1024) {
+      const hipError_t err = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BL_LOCATE_REFINED_LDS + 16 * 1024);
+      if (err != hipSuccess) return err;
+    }
+    if (slow) hipLaunchKernelGGL((bl_locate_kernel<true, true, false>), blocks, dim3(lanes), bytes, stream, *args);
+    else hipLaunchKernelGGL((bl_locate_kernel<true, false, false>), blocks, dim3(lanes), bytes, stream, *args);
+  }
   else if (lds_bytes == 0)   // merged grid with tables beyond the LDS budget (not with slow light: its instantiation needs them in LDS)
     hipLaunchKernelGGL((bl_locate_kernel<false, false, false, true>), dim3(grid), dim3(256), 0, stream, *args);
   else if (slow) hipLaunchKernelGGL((bl_locate_kernel<false, true, false>), dim3(grid), dim3(256), lds_bytes, stream, *args);
