@@ -415,7 +415,7 @@ struct BlShadeArgs {
   // ray_offset[ray] + segment of `composed`; `transfer` is then indexed by RECORD and written only for the samples of a wave that
   // holds a deferred sample or an optically thick step (the segment's row then says where they are: BL_COMPOSED_EXPANDED)
   double2 *composed;          // [segment row], or null: one transfer record per sample
-  int general_locate;         // measurement switch (bl_stats.switches): the general locate kernel where the plain one applies
+  int general_locate;         // measurement switch (bl_stats.switches): the general locate kernel where the plain one applies; refined tables in HBM
   int undefined_edge;         // bl_set_undefined_policy(BL_UNDEFINED_EDGE): samples where the reference reads past its arrays use the edge
   const unsigned long long *counters_in;
   unsigned long long *counters;

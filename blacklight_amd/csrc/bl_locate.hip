@@ -15,7 +15,9 @@
 // ---- locate kernel (simulation mode): one sample record per lane. Coordinate conversion and the
 // LDS table walks of the cell search; no grid reads (the coefficient kernel issues those, where they
 // overlap its arithmetic instead of saturating the texture addresser here).
-// kRefined: mesh with refinement; block and cell come from tables in global memory, no LDS staging.
+// kRefined: mesh with refinement; block and cell from the mesh's tables (RefinedTables, bl_sampling.h) - staged in LDS where they fit
+// (up to BL_LOCATE_REFINED_LDS), searched in HBM otherwise; the record loop is compiled once for either and once more for the samples that
+// wait for FindNearbyInds.
 // kSlow: slow light; the time slice of every sample that passed the cuts is found first (:296-349).
 // kTablesInHbm: the coordinate tables of a merged grid are too large for LDS and are searched where they lie (a
 // compile-time choice: table pointers that may be either LDS or global become flat loads, each of which waits on both
@@ -31,7 +33,7 @@ __global__ void __launch_bounds__(kRefined ? 1024 : 256, kRefined ? 1 : 4) bl_lo
   GridTables tab;
   // Refined meshes: the tables of the search - block boundaries, lattice, the distinct coordinate rows with their spacing, every
   // block's rows and next centre - in LDS where they fit (refined_lds_bytes), read through LDS-typed pointers; the mesh's scalars come
-  // from the kernel arguments. (The search is five rounds of dependent reads; from HBM it took 33 ms per 1024^2 frame.)
+  // from the kernel arguments. (The search is five rounds of dependent reads: 15 - 18 ms per 1024^2 frame from LDS, 21 - 23 from HBM.)
   RefinedTables refined = refined_tables_in_hbm(P.grid);
   bool tables_in_lds = false;
   if (kRefined) {
@@ -40,7 +42,7 @@ __global__ void __launch_bounds__(kRefined ? 1024 : 256, kRefined ? 1 : 4) bl_lo
       tab.bucket[a] = nullptr;
     }
     const BlGridDevice &g = P.grid;
-    if (g.refined_lds_bytes > 0) {
+    if (g.refined_lds_bytes > 0 && !P.general_locate) {   // (the measurement switch: the tables searched where they lie in HBM)
       tables_in_lds = true;
       double *dd = lds_tables;
       auto stage_doubles = [&](const double *src, int count) {
@@ -157,7 +159,7 @@ __global__ void __launch_bounds__(kRefined ? 1024 : 256, kRefined ? 1 : 4) bl_lo
   // (a wave's instructions reach LDS in order: what one lane has written the next instruction's lanes read)
   // (the lists lie behind the tables in the dynamic LDS: 1 KiB per wave, bl_launch_locate adds them to the launch's bytes)
   const bool collect = kRefined && P.grid.block_interp != 0 && P.plasma.simulation_interp != 0;
-  unsigned long long *pending = reinterpret_cast<unsigned long long *>(lds_tables) + (kRefined ? (size_t)(P.grid.refined_lds_bytes + 7) / 8 + (threadIdx.x >> 6) * 128 : 0);
+  unsigned long long *pending = reinterpret_cast<unsigned long long *>(lds_tables) + (kRefined ? (size_t)((P.general_locate ? 0 : P.grid.refined_lds_bytes) + 7) / 8 + (threadIdx.x >> 6) * 128 : 0);
   const uint32_t lane = threadIdx.x & 63u;
   uint32_t n_pending = 0u;   // (wave-uniform: the loop below is left by the whole wave at once)
   auto locate_pending = [&](uint32_t first, uint32_t count) __attribute__((always_inline)) {
@@ -289,7 +291,7 @@ extern "C" hipError_t bl_launch_locate(const BlShadeArgs *args, int grid, int ld
     // Tables that fit four times into a compute unit's LDS (36 KiB): 256-lane workgroups. Larger ones (up to BL_LOCATE_REFINED_LDS): one
     // 1 024-lane workgroup to a compute unit, one round of them. Beyond that the tables are searched where they lie in HBM
     // (refined_lds_bytes = 0). Behind the tables: the waves' lists of samples that wait for FindNearbyInds, 1 KiB each.
-    const int table_bytes = args->grid.refined_lds_bytes;
+    const int table_bytes = args->general_locate ? 0 : args->grid.refined_lds_bytes;
     const bool four_to_a_unit = table_bytes <= 36 * 1024;
     const int lanes = four_to_a_unit ? 256 : 1024;
     const size_t bytes = (size_t)(table_bytes + 7) / 8 * 8 + (size_t)(lanes / 64) * 1024;

@@ -305,7 +305,8 @@ typedef struct bl_stats {
 #define BL_SWITCH_TENSOR_TRANSPORT (1u << 0)                /* polarized, tolerant tier: the exact tier's tensor transport      */
 #define BL_SWITCH_SPLIT_RECORDS (1u << 1)                   /* sample records as two arrays of 32-byte halves                   */
 #define BL_SWITCH_RECORD_EVERY_STEP (1u << 2)               /* steps in the empty shell around the grid leave records too       */
-#define BL_SWITCH_GENERAL_LOCATE (1u << 4)                  /* bl_locate_kernel where bl_locate_plain_kernel applies            */
+#define BL_SWITCH_GENERAL_LOCATE (1u << 4)                  /* bl_locate_kernel where bl_locate_plain_kernel applies; a refined
+                                                               mesh's tables searched in HBM where they would be staged in LDS */
 #define BL_SWITCH_LANE_TRANSFER (1u << 5)                   /* one lane per ray where bl_transfer_quad_kernel applies           */
 #define BL_SWITCH_NO_FUSED_LOCATE (1u << 6)                 /* a locate kernel + bl_shade_fast_kernel / bl_shade_exact_kernel   */
 #define BL_SWITCH_SAMPLE_RECORDS (1u << 8)                  /* tolerant tier: one transfer record per sample where composed maps apply */

@@ -367,6 +367,15 @@ def test_meshes_of_many_small_blocks(split, block_interp, built_library):
         exact = ctx.render()
         ctx.set_arithmetic("tolerant")
         tol = ctx.render()
+        # ... and with the mesh's tables searched where they lie in HBM (what a mesh beyond the LDS budgets gets), both tiers
+        ctx.debug_set_switches("GENERAL_LOCATE", "NO_FUSED_LOCATE")
+        tol_hbm = ctx.render()
+        ctx.set_arithmetic("exact")
+        exact_hbm = ctx.render()
+    assert exact_hbm["stats"].launches_locate == 1 and gu.same_bits(exact_hbm["image"], exact["image"]).all()
+    assert np.array_equal(exact_hbm["sample_num"], exact["sample_num"]) and exact_hbm["stats"].n_gathers == exact["stats"].n_gathers
+    assert tol_hbm["stats"].launches_locate == 1 and tol_hbm["stats"].arithmetic == 1 and tol_hbm["stats"].n_gathers == exact["stats"].n_gathers
+    assert np.array_equal(tol_hbm["sample_num"], exact["sample_num"]) and _distance(tol_hbm["image"], exact["image"]) < EXPECTED
     if not block_interp:   # (the oracle refuses the undefined reads that BL_UNDEFINED_EDGE defines)
         want = oracle_api.render(p.ptr, grid.desc(), _capi.RenderDesc, _capi.CameraFrame, n_rays=24 * 24, max_steps=int(p.get("ray_max_steps")))
         assert gu.same_bits(exact["image"], want["image"]).all() and exact["stats"].n_gathers == want["n_gathers"]
