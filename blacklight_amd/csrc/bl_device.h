@@ -90,6 +90,8 @@ enum BlCounter {
 #define BL_FUSED_REFINED_LDS (150 * 1024)
 // ... and the tables of bl_locate_kernel<kRefined> (one 1 024-lane workgroup to a compute unit; 16 KiB more for its waves' lists)
 #define BL_LOCATE_REFINED_LDS (136 * 1024)
+// ... and of the exact second pass behind the fused kernel (256-lane workgroups, two to a compute unit, 8 KiB of anchor rows beside)
+#define BL_REDO_TABLES_LDS (48 * 1024)
 
 struct BlGridDevice {
   const float *cells;        // [n_k][n_j][n_i][8]

@@ -44,43 +44,7 @@ __global__ void __launch_bounds__(kRefined ? 1024 : 256, kRefined ? 1 : 4) bl_lo
     const BlGridDevice &g = P.grid;
     if (g.refined_lds_bytes > 0 && !P.general_locate) {   // (the measurement switch: the tables searched where they lie in HBM)
       tables_in_lds = true;
-      double *dd = lds_tables;
-      auto stage_doubles = [&](const double *src, int count) {
-        double *at = dd;
-        for (int i = threadIdx.x; i < count; i += blockDim.x) at[i] = src[i];
-        dd += count;
-        return at;
-      };
-#pragma unroll
-      for (int a = 0; a < 3; a++) {
-        refined.edge[a] = stage_doubles(g.edge[a], g.n_edge[a] + 1);
-        refined.bxf[a] = stage_doubles(g.bxf[a], g.n_rows[a] * (g.nb[a] + 1));
-        refined.bxv[a] = stage_doubles(g.bxv[a], g.n_rows[a] * g.nb[a]);
-        refined.xv_next[a] = stage_doubles(g.xv_next[a], g.n_blocks);
-        refined.row_guess[a] = stage_doubles(g.row_guess[a], 3 * g.n_rows[a]);
-      }
-      if (g.block_interp) {   // (the hash's keys: eight bytes each, with the doubles)
-        unsigned long long *keys = reinterpret_cast<unsigned long long *>(dd);
-        for (int i = threadIdx.x; i <= (int)g.hash_mask; i += blockDim.x) keys[i] = g.hash_keys[i];
-        refined.hash_keys = keys;
-        dd += g.hash_mask + 1;
-      }
-      int *ii = reinterpret_cast<int *>(dd);
-      auto stage_ints = [&](const int *src, int count) {
-        int *at = ii;
-        for (int i = threadIdx.x; i < count; i += blockDim.x) at[i] = src[i];
-        ii += count;
-        return at;
-      };
-      refined.lattice = stage_ints(g.lattice, g.n_edge[0] * g.n_edge[1] * g.n_edge[2]);
-#pragma unroll
-      for (int a = 0; a < 3; a++) refined.block_row[a] = stage_ints(g.block_row[a], g.n_blocks);
-      if (g.block_interp) {
-        refined.levels = stage_ints(g.levels, g.n_blocks);
-        refined.locations = stage_ints(g.locations, 3 * g.n_blocks);
-        refined.hash_blocks = stage_ints(g.hash_blocks, (int)g.hash_mask + 1);
-      }
-      refined.in_lds = true;
+      stage_refined_tables(g, lds_tables, &refined);
       __syncthreads();
     }
   } else if (kTablesInHbm) {

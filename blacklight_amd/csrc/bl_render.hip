@@ -333,7 +333,7 @@ void PlanJob(RenderJob &job) {
   const bool fused2_grid = ctx->grid_dev.n_blocks == 0
       ? ctx->lds_table_bytes > 0 && bl_fused2_applicable(&ctx->grid_dev, job.freq_split ? 1 : job.n_nu, job.n_rays) != 0
       : !job.freq_split && !records_every_sample && !job.skip_shell && bl_fused2_refined_applicable(&ctx->grid_dev, job.n_nu, job.n_rays) != 0;
-  job.fused2 = job.fast && !job.tau_row && !job.slow && !job.block_interp && fused2_grid && !ctx->grid_dev.fmks && p.simulation_interp && p.plasma_power_frac == 0.0
+  job.fused2 = job.fast && !job.tau_row && !job.slow && fused2_grid && !ctx->grid_dev.fmks && p.simulation_interp && p.plasma_power_frac == 0.0
       && p.simulation_coord == BL_COORD_SKS   // (its locate step is the spherical one: Cartesian grids go through the locate kernel)
       && !(p.cut_omit_near || p.cut_omit_far || p.cut_omit_in >= 0.0 || p.cut_omit_out >= 0.0 || p.cut_midplane_theta != 0.0 || p.cut_midplane_z != 0.0 || p.cut_plane)
       && !job.sample_save && !(ctx->switches & (BL_SWITCH_NO_FUSED_LOCATE | BL_SWITCH_SPLIT_RECORDS))   // (a sample checkpoint is made of the located samples)
@@ -380,6 +380,10 @@ void PlanJob(RenderJob &job) {
   job.coef_split = !job.fast && job.simulation && !job.aux && !ctx->polarized && job.n_nu >= 4;
   // (polarized runs list the samples without coefficients there - cut samples, cut cells - which are many more)
   job.redo_capacity = ctx->polarized ? (1u << 24) : (1u << 20);
+  // (inter-block interpolation with the locate step inside the coefficient kernel: the samples with an anchor beyond their own block -
+  // up to a quarter of them, bl_fused2_refined_applicable - are the exact pass's; room for an eighth of the samples the rays may have)
+  if (job.fused2 && job.block_interp)
+    job.redo_capacity = static_cast<size_t>(std::min<long long>(1ll << 29, std::max<long long>(1ll << 20, job.n_rays * static_cast<long long>(p.ray_max_steps) / 8)));
   // polarized run with no per-sample row but tau and no rendering: tau is integrated by the polarized transfer kernel
   bool fill_present = false;
   for (int n_i = 0; n_i < ctx->render_num_images; n_i++)
@@ -545,7 +549,7 @@ void PlanScratch(RenderJob &job) {
       + (ctx->polarized ? sizeof(BlPolSample) + sizeof(BlCoefInputs) + 4 * sizeof(double2) * n_nu + (job.pol_coefficients_inside ? 1 : 0) : 0)
       + (job.coef_split ? sizeof(BlCoefInputs) : 0)
       + (job.matrix_transport ? BL_POL_MATRIX_DOUBLES * sizeof(double) : 0)
-      + (job.block_interp ? 8 * sizeof(unsigned int) : 0);
+      + ((job.block_interp && !job.locate_inside) ? 8 * sizeof(unsigned int) : 0);
   if (job.reuse) {
     // over the resident records: the scratch set as the render that integrated them sized it, no stepper, nothing parked
     job.n_slots = 1;
@@ -709,7 +713,7 @@ void EnsureScratchOnce(RenderJob &job) {
       if (job.pol_coefficients_inside) sl.d_have_flags.Ensure(cap);
     }
     if (job.coef_split) sl.d_coef_inputs.Ensure(cap);
-    if (job.block_interp) sl.d_anchors.Ensure(cap * 8);
+    if (job.block_interp && !job.locate_inside) sl.d_anchors.Ensure(cap * 8);   // (locate step inside: the exact pass keeps a sample's anchors in registers)
     if (job.fast || job.fast_formula || ctx->polarized) sl.d_redo.Ensure(job.redo_capacity);   // polarized runs: the samples whose frame bl_polarized_frame_kernel builds
   }
   const size_t n_rays = static_cast<size_t>(job.n_rays);
@@ -1265,7 +1269,7 @@ void BindChunk(RenderJob &job, int k, long long begin, int rays) {
   sa.sample_t = ta.sample_t;
   sa.coef_inputs = (job.coef_split || ctx->polarized) ? sl.d_coef_inputs.ptr : nullptr;
   sa.have_flags = job.pol_coefficients_inside ? sl.d_have_flags.ptr : nullptr;
-  sa.anchors = job.block_interp ? sl.d_anchors.ptr : nullptr;
+  sa.anchors = (job.block_interp && !job.locate_inside) ? sl.d_anchors.ptr : nullptr;
   sa.redo_list = (job.fast || job.fast_formula || ctx->polarized) ? sl.d_redo.ptr : nullptr;
   if (job.slow) {
     sa.slow.frac = sl.d_slow_frac.ptr;

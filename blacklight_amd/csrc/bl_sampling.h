@@ -205,6 +205,48 @@ __device__ __forceinline__ RefinedTables refined_tables_in_hbm(const BlGridDevic
   t.in_lds = false;
   return t;
 }
+// A workgroup's copy of the mesh's tables in LDS (`lds`: BlGridDevice::refined_lds_bytes of them), and *t pointing at it: every lane of
+// the workgroup calls this and passes a barrier before the first search (bl_locate_kernel; the exact second pass behind the fused kernel)
+__device__ __forceinline__ void stage_refined_tables(const BlGridDevice &g, double *lds, RefinedTables *t) {
+  double *dd = lds;
+  auto stage_doubles = [&](const double *src, int count) {
+    double *at = dd;
+    for (int i = threadIdx.x; i < count; i += blockDim.x) at[i] = src[i];
+    dd += count;
+    return at;
+  };
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    t->edge[a] = stage_doubles(g.edge[a], g.n_edge[a] + 1);
+    t->bxf[a] = stage_doubles(g.bxf[a], g.n_rows[a] * (g.nb[a] + 1));
+    t->bxv[a] = stage_doubles(g.bxv[a], g.n_rows[a] * g.nb[a]);
+    t->xv_next[a] = stage_doubles(g.xv_next[a], g.n_blocks);
+    t->row_guess[a] = stage_doubles(g.row_guess[a], 3 * g.n_rows[a]);
+  }
+  if (g.block_interp) {   // (the hash's keys: eight bytes each, with the doubles)
+    unsigned long long *keys = reinterpret_cast<unsigned long long *>(dd);
+    for (int i = threadIdx.x; i <= (int)g.hash_mask; i += blockDim.x) keys[i] = g.hash_keys[i];
+    t->hash_keys = keys;
+    dd += g.hash_mask + 1;
+  }
+  int *ii = reinterpret_cast<int *>(dd);
+  auto stage_ints = [&](const int *src, int count) {
+    int *at = ii;
+    for (int i = threadIdx.x; i < count; i += blockDim.x) at[i] = src[i];
+    ii += count;
+    return at;
+  };
+  t->lattice = stage_ints(g.lattice, g.n_edge[0] * g.n_edge[1] * g.n_edge[2]);
+#pragma unroll
+  for (int a = 0; a < 3; a++) t->block_row[a] = stage_ints(g.block_row[a], g.n_blocks);
+  if (g.block_interp) {
+    t->levels = stage_ints(g.levels, g.n_blocks);
+    t->locations = stage_ints(g.locations, 3 * g.n_blocks);
+    t->hash_blocks = stage_ints(g.hash_blocks, (int)g.hash_mask + 1);
+  }
+  t->in_lds = true;
+}
+
 template <int kWhere, typename T>
 __device__ __forceinline__ T table_read(const RefinedTables &t, const T *table, size_t i) {
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -28,6 +28,18 @@ __global__ void __launch_bounds__(256, 2) bl_shade_kernel(const BlShadeArgs P_at
   // measured on the refined-mesh, block-interpolation and slow-light frames of bench.py --workload, profiles/r05_f_rows.txt.)
   const BlShadeArgs &P = kRedo ? kernel_arguments_in_place<BlShadeArgs>() : P_at_entry;
   const BlSpacetime st = P.st;
+  // (inter-block interpolation behind bl_shade_fused2_kernel<..., kRefined>: the eight anchor cells of a sample located here - in LDS, a
+  // row per lane: FindNearbyInds' loop over the corners indexes them, which registers cannot take without scratch memory)
+  __shared__ unsigned int anchor_rows[(kRedo && kExtended) ? 256 * 8 : 1];
+  unsigned int *anchors_here = (kRedo && kExtended) ? anchor_rows + threadIdx.x * 8 : nullptr;
+  // ... and the mesh's tables for locating those samples, in LDS where bl_launch_shade_redo gave the room (BL_REDO_TABLES_LDS; else in HBM)
+  extern __shared__ double redo_tables[];
+  RefinedTables refined = refined_tables_in_hbm(P.grid);
+  if (kRedo && kExtended && kModel == BL_MODEL_SIMULATION && P.located == nullptr && P.grid.n_blocks > 0 && P.grid.refined_lds_bytes > 0
+      && P.grid.refined_lds_bytes <= BL_REDO_TABLES_LDS) {
+    stage_refined_tables(P.grid, redo_tables, &refined);
+    __syncthreads();
+  }
   const unsigned long long first_record = 0ull;
   const unsigned long long n_all = P.counters_in[BL_CNT_RECORDS];
   const unsigned long long n_listed = kRedo ? P.counters_in[BL_CNT_REDO] : 0ull;
@@ -78,7 +90,7 @@ __global__ void __launch_bounds__(256, 2) bl_shade_kernel(const BlShadeArgs P_at
       unsigned long long counted_already = 0ull;
       // (a mesh with refinement behind bl_shade_fused2_kernel<..., kRefined>: the refined search on its tables in HBM)
       if (!(r_here > P.cuts.camera_r)) {
-        if (P.grid.n_blocks > 0) locate_sample<true, kSpinZero>(P, tab, st, x1, x2, x3, r_here, &loc, &counted_already, nullptr);
+        if (P.grid.n_blocks > 0) locate_sample<true, kSpinZero, kTableAnywhere>(P, tab, st, x1, x2, x3, r_here, &loc, &counted_already, kExtended ? anchors_here : nullptr, &refined);
         else locate_sample<false, kSpinZero>(P, tab, st, x1, x2, x3, r_here, &loc, &counted_already, nullptr);
       }
       l0 = make_double2(loc.f_i, loc.f_j);
@@ -106,7 +118,7 @@ __global__ void __launch_bounds__(256, 2) bl_shade_kernel(const BlShadeArgs P_at
         sample_primitives_slow(P, status, (uint32_t)tag, P.anchors != nullptr ? P.anchors + idx_cur * 8 : nullptr, (int)(tag >> 40),
                                P.slow.frac[idx_cur], l0.x, l0.y, l1.x, pr, &kappa_f);
       } else if (kExtended && status == kSampleAdvanced) {
-        sample_primitives_advanced(P, P.anchors + idx_cur * 8, l0.x, l0.y, l1.x, pr, &kappa_f);
+        sample_primitives_advanced(P, (kRedo && P.located == nullptr) ? anchors_here : P.anchors + idx_cur * 8, l0.x, l0.y, l1.x, pr, &kappa_f);
       } else {
         sample_primitives(P, status, (uint32_t)tag, l0.x, l0.y, l1.x, pr);
         if (kExtended && P.plasma.code_kappa) kappa_f = sample_kappa(P, status, (uint32_t)tag, l0.x, l0.y, l1.x);
@@ -415,9 +427,14 @@ extern "C" hipError_t bl_launch_shade_redo(const BlShadeArgs *args, int model, i
   const bool spin_zero = args->st.bh_a == 0.0;
   const bool fused = args->located == nullptr;
   const bool cartesian = !fused && args->plasma.simulation_coord == BL_COORD_CKS;
-  const bool power_law = !fused && (args->plasma.power_frac != 0.0 || args->tau_inc != nullptr || args->anchors != nullptr || args->slow.n > 0);   // (the extended instantiation)
+  // (the extended instantiation; behind the fused kernel it is the one that knows the anchor cells of inter-block interpolation)
+  const bool power_law = fused ? args->grid.block_interp != 0
+                               : (args->plasma.power_frac != 0.0 || args->tau_inc != nullptr || args->anchors != nullptr || args->slow.n > 0);
   // (the common case - behind a kernel with the locate step inside - knows zero spin at compile time)
-#define BL_LAUNCH_R(EXTENDED, SKS) hipLaunchKernelGGL((bl_shade_kernel<BL_MODEL_SIMULATION, false, EXTENDED, SKS, false, false, true>), dim3(grid), dim3(256), 0, stream, *args)
+  // (behind the fused kernel over a mesh with inter-block interpolation: room for the mesh's tables in LDS, if they are small enough)
+  const size_t tables = (fused && args->grid.n_blocks > 0 && args->grid.refined_lds_bytes > 0 && args->grid.refined_lds_bytes <= BL_REDO_TABLES_LDS)
+      ? (size_t)args->grid.refined_lds_bytes : 0;
+#define BL_LAUNCH_R(EXTENDED, SKS) hipLaunchKernelGGL((bl_shade_kernel<BL_MODEL_SIMULATION, false, EXTENDED, SKS, false, false, true>), dim3(grid), dim3(256), (EXTENDED) ? tables : 0, stream, *args)
   if (cartesian) BL_LAUNCH_R(true, false);
   else if (power_law) BL_LAUNCH_R(true, true);
   else if (spin_zero) hipLaunchKernelGGL((bl_shade_kernel<BL_MODEL_SIMULATION, false, false, true, false, true, true>), dim3(grid), dim3(256), 0, stream, *args);

@@ -213,6 +213,7 @@ struct GridScalars {
   int n_box_i1, n_box_j1, n_box_k1;          // boxes per axis - 1
   uint32_t n_box_i, n_box_j;
   uint32_t lds_desc;                         // LDS byte address of the descriptors
+  int block_interp;                          // inter-block interpolation: a sample with an anchor beyond its own block is the exact pass's
 };
 
 // LDS reads by byte address (the row tables live behind the kernel's extern array; LDS addresses are 32-bit numbers, which is
@@ -270,6 +271,7 @@ __device__ __forceinline__ GridScalars grid_scalars(const BlGridDevice &g, uint3
   G.n_k1 = g.n[2] - 1;
   G.n_i = (uint32_t)g.n[0];
   G.n_j = (uint32_t)g.n[1];
+  G.block_interp = 0;
   G.lds_r = lds_rows;
   G.lds_th = G.lds_r + 64u * (uint32_t)g.n[0];
   G.lds_ph = G.lds_th + 64u * (uint32_t)g.n[1];
@@ -339,6 +341,7 @@ __device__ __forceinline__ GridScalars grid_scalars_refined(const BlGridDevice &
   G.n_box_i1 = g.n_edge[0] - 1;
   G.n_box_j1 = g.n_edge[1] - 1;
   G.n_box_k1 = g.n_edge[2] - 1;
+  G.block_interp = g.block_interp;
   G.n_box_i = (uint32_t)g.n_edge[0];
   G.n_box_j = (uint32_t)g.n_edge[1];
   uint32_t bytes = 0u;
@@ -349,11 +352,13 @@ __device__ __forceinline__ GridScalars grid_scalars_refined(const BlGridDevice &
 
 // One axis: row of the guessed cell -> anchor shift, fraction, signed distance to the nearest face (negative: the guess is wrong
 // or the coordinate lies beyond the grid) and distance to the centre
-__device__ __forceinline__ void axis_lookup(uint32_t row_addr, double s, double *frac, uint32_t *dj, double *face_margin, double *centre_margin) {
+__device__ __forceinline__ void axis_lookup(uint32_t row_addr, double s, double *frac, uint32_t *dj, double *face_margin, double *centre_margin,
+                                            bool *upper = nullptr) {
   const v2d faces = lds_read2(row_addr);
   const v4u mid = lds_read_bits(row_addr + 16u);
   const double xv = __hiloint2double((int)mid.y, (int)mid.x);
   const bool ge = s >= xv;
+  if (upper != nullptr) *upper = ge;
   const v2d anchor = lds_read2(row_addr + (ge ? 32u : 48u));
   *dj = ge ? mid.z : mid.w;
   *frac = (s - anchor.x) * anchor.y;
@@ -429,9 +434,15 @@ __device__ __forceinline__ Located locate(const BlSpacetime &st, const GridScala
   gk = gk < 0 ? 0 : (gk > G.n_k1 ? G.n_k1 : gk);
   double f_i, f_j, f_k, m_i, m_j, m_k, c_i, c_j, c_k;
   uint32_t di, dj, dk;
-  axis_lookup(rows_r + ((uint32_t)gi << 6), r, &f_i, &di, &m_i, &c_i);
-  axis_lookup(rows_th + ((uint32_t)gj << 6), th, &f_j, &dj, &m_j, &c_j);
-  axis_lookup(rows_ph + ((uint32_t)gk << 6), ph, &f_k, &dk, &m_k, &c_k);
+  bool up_i = false, up_j = false, up_k = false;
+  axis_lookup(rows_r + ((uint32_t)gi << 6), r, &f_i, &di, &m_i, &c_i, kRefined ? &up_i : nullptr);
+  axis_lookup(rows_th + ((uint32_t)gj << 6), th, &f_j, &dj, &m_j, &c_j, kRefined ? &up_j : nullptr);
+  axis_lookup(rows_ph + ((uint32_t)gk << 6), ph, &f_k, &dk, &m_k, &c_k, kRefined ? &up_k : nullptr);
+  // Inter-block interpolation (simulation_sampling.cpp:505-546): the anchor is c or c - 1 by the centre alone, also at a block's ends, and
+  // the cell beyond the block is another block's (FindNearbyInds). The row's anchor shift says where that happens - above the last
+  // cell's centre it is 1 (the plain rule steps back), below the first cell's it is 0 (it stays): such a sample is the exact pass's.
+  // Every other sample has all eight anchors in its own block and the plain rule's anchor and fraction (locate_sample_refined).
+  const bool beyond_the_block = kRefined && G.block_interp != 0 && ((up_i ? di == 1u : di == 0u) || (up_j ? dj == 1u : dj == 0u) || (up_k ? dk == 1u : dk == 0u));
   // r is the exact tier's r: its cell is confirmed exactly (first c with xf[c + 1] >= r: xf[c] < r <= xf[c + 1]; m_i is
   // min(r - xf[c], xf[c + 1] - r)) - except on a face itself, where the signed minimum is zero either way: left to the exact pass
   // theta, phi: the tier's own angles, so every value they are compared with must be further away than the band
@@ -442,7 +453,7 @@ __device__ __forceinline__ Located locate(const BlSpacetime &st, const GridScala
   m = m < e0 ? m : e0;
   m = m < e1 ? m : e1;
   const bool sampled = live && !cut && !off_grid;
-  const bool undecided = sampled && (!(m > band) || !(m_i > 0.0));
+  const bool undecided = sampled && (!(m > band) || !(m_i > 0.0) || beyond_the_block);
   Located out;
   out.f_i = f_i;
   out.f_j = f_j;
@@ -780,6 +791,17 @@ __global__ void __launch_bounds__(kRefined ? 512 : 256, kRefined ? 1 : BL_FAST_W
   s1.loc = locate<kSpinZero, kRefined>(st, G, camera_r, band, (uint32_t)__double_as_longlong(s1.h1.y) != BL_DEAD_RAY, s1.h0.x, s1.h0.y, s1.h1.x);
   // p (`prev`) is sample base_index - stride + lane_index (none in the first iteration), c (`cur`) base_index + lane_index, x (`next`)
   // one stride on
+  // (kRefined) the wave's samples for the exact pass, collected in LDS behind the tables and handed to the list 64 at a time
+  uint32_t *deferred_here = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(lds) + (kRefined ? P.grid.fused_lds_bytes : 0)) + (kRefined ? (threadIdx.x >> 6) * 128u : 0u);
+  uint32_t n_deferred_here = 0u;   // (wave-uniform)
+  auto hand_over_deferred = [&](uint32_t first, uint32_t count) __attribute__((always_inline)) {
+    KernArgs args = kernargs();
+    const uint32_t lane = threadIdx.x & 63u;
+    unsigned long long at = 0ull;
+    if (lane == 0u) at = atomicAdd(&args->counters[BL_CNT_REDO], (unsigned long long)count);
+    at = (unsigned long long)__builtin_amdgcn_readfirstlane((int)(at >> 32)) << 32 | (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)at);
+    if (lane < count && at + lane < args->redo_capacity) args->redo_list[at + lane] = (unsigned long long)deferred_here[first + lane];
+  };
   auto iteration = [&](Slot &p, Slot &c, Slot &x) __attribute__((always_inline)) {
     const uint32_t ray = (uint32_t)__double_as_longlong(p.h1.y);
     const bool live = ray != BL_DEAD_RAY;
@@ -901,7 +923,21 @@ __global__ void __launch_bounds__(kRefined ? 512 : 256, kRefined ? 1 : BL_FAST_W
         }
       }
     }
-    if (__builtin_expect(live && defer, 0)) {
+    if (kRefined) {
+      // Over a mesh with inter-block interpolation one sample in twenty is the exact pass's: one atomic per sample on the list's one
+      // counter would serialise the launch. The wave collects its samples' record indices in LDS (128 entries behind the tables) and
+      // hands them over 64 at a time: one atomic and one coalesced store per 64 entries.
+      const unsigned long long waiting = __ballot(live && defer);
+      if (__builtin_expect(waiting != 0ull, 0)) {
+        const uint32_t lane = threadIdx.x & 63u;
+        if (live && defer) deferred_here[n_deferred_here + (uint32_t)__popcll(waiting & ((1ull << lane) - 1ull))] = base_index - stride + lane_index;
+        n_deferred_here += (uint32_t)__popcll(waiting);
+        if (n_deferred_here >= 64u) {
+          n_deferred_here -= 64u;
+          hand_over_deferred(n_deferred_here, 64u);
+        }
+      }
+    } else if (__builtin_expect(live && defer, 0)) {
       KernArgs args = kernargs();
       unsigned long long *counters = args->counters;
       const unsigned long long at = atomicAdd(&counters[BL_CNT_REDO], 1ull);
@@ -920,6 +956,7 @@ __global__ void __launch_bounds__(kRefined ? 512 : 256, kRefined ? 1 : BL_FAST_W
     if (!__any(s2.in || s0.in)) break;
     iteration(s2, s0, s1);
   }
+  if (kRefined && n_deferred_here != 0u) hand_over_deferred(0u, n_deferred_here);
   if ((threadIdx.x & 63) == 0 && gathers_wave != 0ull) atomicAdd(&P.counters[BL_CNT_GATHERS], gathers_wave);
 }
 #pragma clang fp contract(off)
@@ -1373,8 +1410,12 @@ extern "C" int bl_fused2_applicable(const BlGridDevice *grid, int n_nu, long lon
 
 // ... or its instantiation for a mesh with refinement (one frequency, composed maps: what bl_render.hip asks for beside this; the
 // geometry was checked when the mesh was staged, UploadRefinedGrid)
+// With inter-block interpolation the samples with an anchor beyond their own block - the outer half cell of every block - go to the exact
+// pass (bl_shade_kernel<..., kRedo>, which finds their anchor cells): 5 % of the samples with 64^3 blocks, 18 % with 16^3; blocks of
+// fewer than twelve cells along an axis (a quarter of the samples and more) stay on the locate kernel + bl_shade_fast_kernel.
 extern "C" int bl_fused2_refined_applicable(const BlGridDevice *grid, int n_nu, long long n_rays) {
-  return (grid->n_blocks > 0 && grid->fused_lds_bytes > 0 && !grid->block_interp && n_nu == 1 && n_rays < (1ll << 29)) ? 1 : 0;
+  if (grid->block_interp && (grid->nb[0] < 12 || grid->nb[1] < 12 || grid->nb[2] < 12)) return 0;
+  return (grid->n_blocks > 0 && grid->fused_lds_bytes > 0 && n_nu == 1 && n_rays < (1ll << 29)) ? 1 : 0;
 }
 
 extern "C" hipError_t bl_launch_shade_fused2(const BlShadeArgs *args, int grid, hipStream_t stream) {
@@ -1383,8 +1424,8 @@ extern "C" hipError_t bl_launch_shade_fused2(const BlShadeArgs *args, int grid, 
     if (args->composed == nullptr || args->freq_split || g.fused_lds_bytes <= 0) return hipErrorInvalidValue;
     const void *kernel = args->st.bh_a == 0.0 ? reinterpret_cast<const void *>(&bl_shade_fused2_kernel<true, true, false, true>)
                                               : reinterpret_cast<const void *>(&bl_shade_fused2_kernel<false, true, false, true>);
-    if (g.fused_lds_bytes > 64 * 1024) {   // (more dynamic LDS than a launch gets unasked: up to BL_FUSED_REFINED_LDS of the compute unit's 160 KiB)
-      const hipError_t err = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BL_FUSED_REFINED_LDS);
+    if (g.fused_lds_bytes + 4096 > 64 * 1024) {   // (more dynamic LDS than a launch gets unasked: up to BL_FUSED_REFINED_LDS of the compute unit's 160 KiB)
+      const hipError_t err = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BL_FUSED_REFINED_LDS + 4096);
       if (err != hipSuccess) return err;
     }
     // Tables that fit twice into a compute unit's LDS: 256-lane workgroups as for one block (`grid` of them). Larger ones: one 512-lane
@@ -1392,8 +1433,9 @@ extern "C" hipError_t bl_launch_shade_fused2(const BlShadeArgs *args, int grid, 
     // with several rounds every round's tail idles seven waves; measured 29.6 against 27.5 ms on the mesh that fits either way)
     const bool two_to_a_unit = g.fused_lds_bytes <= 76 * 1024;
     const dim3 blocks(two_to_a_unit ? grid : (grid >= 8 ? grid / 8 : 1)), lanes(two_to_a_unit ? 256 : 512);
-    if (args->st.bh_a == 0.0) hipLaunchKernelGGL((bl_shade_fused2_kernel<true, true, false, true>), blocks, lanes, (size_t)g.fused_lds_bytes, stream, *args);
-    else hipLaunchKernelGGL((bl_shade_fused2_kernel<false, true, false, true>), blocks, lanes, (size_t)g.fused_lds_bytes, stream, *args);
+    const size_t lds_bytes = (size_t)g.fused_lds_bytes + (size_t)(lanes.x / 64) * 512;   // (+ the waves' lists of samples for the exact pass)
+    if (args->st.bh_a == 0.0) hipLaunchKernelGGL((bl_shade_fused2_kernel<true, true, false, true>), blocks, lanes, lds_bytes, stream, *args);
+    else hipLaunchKernelGGL((bl_shade_fused2_kernel<false, true, false, true>), blocks, lanes, lds_bytes, stream, *args);
     return hipGetLastError();
   }
   const size_t lds = 48 * sizeof(double) + 64 * (size_t)(g.n[0] + g.n[1] + g.n[2]);

@@ -550,6 +550,37 @@ def test_tolerant_tier_with_inter_block_interpolation(seed, built_library):
     assert np.isfinite(exact["image"]).mean() > 0.5 and np.nanmax(exact["image"]) > 0.0
 
 
+@pytest.mark.parametrize("spin,camera_th", [(0.0, 60.0), (0.9, 100.0)])
+def test_inter_block_interpolation_with_the_locate_step_inside(spin, camera_th, built_library):
+    """MeshBlocks of twelve cells and more per axis, evenly spaced: bl_shade_fused2_kernel<..., kRefined> shades the samples whose eight
+    anchors lie in their own block (ordinary trilinear samples: InterpolateAdvanced = InterpolateSimple there) and hands the others - the
+    outer half cell of every block, a sixth of the samples here - to the exact pass through the waves' lists; that pass finds their
+    anchor cells (FindNearbyInds) and shades them. Counts, S_in, undefined-read counts and NaN mask are the exact tier's, the image at
+    rounding level, and the same through the locate kernel + bl_shade_fast_kernel."""
+    import blacklight_amd as bl
+    fx, params, mock_args = gu.load_case("sim_blockinterp")
+    params = dict(params, camera_resolution=40, camera_th=camera_th, camera_ph=250.0, simulation_a=spin, plasma_model="ti_te_beta",
+                  fallback_nan="false", fallback_rho=1.0e-6, fallback_pgas=1.0e-8, image_tau="false")
+    grid = gu.golden_grid(dict({k: v for k, v in mock_args.items() if not k.startswith("_")}, _blocks=[2, 2, 2]))   # blocks of 16 x 12 x 16 cells
+    with bl.Context(bl.Params.from_dict(params)) as ctx:
+        ctx.set_undefined_policy("edge")
+        ctx.set_grid(grid)
+        ctx.set_arithmetic("exact")
+        exact = ctx.render()
+        ctx.set_arithmetic("tolerant")
+        inside = ctx.render()
+        ctx.debug_set_switches("NO_FUSED_LOCATE")
+        outside = ctx.render()
+    assert inside["stats"].fused_variant == 2 and inside["stats"].launches_locate == 0 and inside["stats"].composed_maps == 1
+    assert outside["stats"].fused_variant == 0 and outside["stats"].launches_locate == 1
+    assert 0.02 * inside["stats"].n_gathers < inside["stats"].n_deferred < 0.4 * inside["stats"].n_gathers   # (the outer half cells)
+    for got in (inside, outside):
+        assert got["stats"].arithmetic == 1 and got["stats"].n_gathers == exact["stats"].n_gathers and got["stats"].n_undefined == exact["stats"].n_undefined
+        assert np.array_equal(got["sample_num"], exact["sample_num"]) and np.array_equal(np.isnan(got["image"]), np.isnan(exact["image"]))
+        assert _distance(got["image"], exact["image"]) < EXPECTED
+    print(f"a = {spin}: {_distance(inside['image'], exact['image']):.2e}, to the exact pass {inside['stats'].n_deferred} of {inside['stats'].n_gathers}")
+
+
 @pytest.mark.parametrize("case", ["slow_interp", "slow_nearest"])
 def test_tolerant_tier_with_slow_light(case, built_library):
     """slow_light_on (simulation_sampling.cpp:296-349, :736-912) in the tolerant tier (round 6): every image of the fixtures' series,
