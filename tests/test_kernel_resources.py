@@ -100,3 +100,14 @@ def test_no_kernel_needs_scratch_memory(built_library):
         assert len(names) == len(scratch) and len(names) >= 2
         over = {n: s for n, s in zip(names, scratch) if s > SCRATCH_ALLOWED.get(n, 0)}
         assert not over, over
+
+
+def test_the_surface_stays_what_the_design_says(built_library):
+    """DESIGN.md section 0 counts 75 kernel instantiations (98 at the end of round 5): a new one is a decision, not an accident."""
+    import glob
+    reports = sorted(glob.glob(os.path.join(bl_build.OBJ, "*.resources.txt")))
+    if not reports:
+        bl_build.build(force=True)
+        reports = sorted(glob.glob(os.path.join(bl_build.OBJ, "*.resources.txt")))
+    names = [n for path in reports for n in re.findall(r"remark: Function Name: (\S+)", open(path).read())]
+    assert len(names) == len(set(names)) and len(names) <= 75, len(names)
