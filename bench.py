@@ -156,14 +156,21 @@ def pipelined_series(args, params, grids, image, sample_num, flags, device):
             t0 = time.perf_counter()
             ctx.set_grid(grids[0])
             staged = None
+
+            def stage(grid, go):
+                go.wait()           # (set on the way into bl_render, which takes the context's render lock first thing; this thread gets the
+                ctx.set_grid(grid)  # interpreter when that call releases it: frame n is rendered from snapshot n, n + 1 goes up beside it)
+
             for n in range(n_frames):
                 if staged is not None:
                     staged.join()          # snapshot n is in place
+                go = threading.Event()
                 if n + 1 < n_frames:
-                    staged = threading.Thread(target=ctx.set_grid, args=(grids[n + 1],))
+                    staged = threading.Thread(target=stage, args=(grids[n + 1], go))
                     staged.start()         # ... and n + 1 goes up while n renders
                 else:
                     staged = None
+                go.set()
                 st = ctx.render_device(image.data_ptr(), n_rays, sample_num_ptr=sample_num.data_ptr(), sample_flags_ptr=flags.data_ptr())
                 stats.append((int(st.geodesics_reused), st.ms_shade, st.ms_geodesic))
                 if rep == args.warmup:

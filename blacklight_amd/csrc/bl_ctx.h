@@ -35,6 +35,7 @@ extern "C" hipError_t bl_launch_shade(const BlShadeArgs *args, int model, int gr
 extern "C" hipError_t bl_launch_shade_fast(const BlShadeArgs *args, int grid, hipStream_t stream);
 extern "C" int bl_fused2_applicable(const BlGridDevice *grid, int n_nu, long long n_rays);
 extern "C" int bl_fused2_refined_applicable(const BlGridDevice *grid, int n_nu, long long n_rays);
+extern "C" int bl_polarized2_refined_applicable(const BlGridDevice *grid, long long n_rays);
 extern "C" hipError_t bl_launch_transfer_composed(const BlTransferArgs *args, hipStream_t stream);
 extern "C" hipError_t bl_launch_shade_exact2(const BlShadeArgs *args, int grid, hipStream_t stream);
 extern "C" hipError_t bl_launch_shade_polarized2(const BlShadeArgs *args, int grid, hipStream_t stream);

@@ -348,11 +348,12 @@ void PlanJob(RenderJob &job) {
       && bl_fused2_applicable(&ctx->grid_dev, job.n_nu, job.n_rays) != 0;
   // Polarized runs over such a grid: the frame-and-inputs kernel with the locate step inside (bit-identical to bl_locate_plain_kernel +
   // bl_shade_kernel<polarized>, whose conditions these are; electron entropy from the grid is a ninth value it does not gather)
+  // (... or a mesh with refinement whose tables the tolerant tier's fused kernel takes: the polarized kernel's locate step knows them too)
   job.pol_fused = ctx->polarized && job.simulation && !job.slow && !job.block_interp && p.plasma_model != BL_PLASMA_CODE_KAPPA && !p.ray_flat
-      && ctx->grid_dev.n_blocks == 0 && !ctx->grid_dev.fmks && p.simulation_interp && p.simulation_coord == BL_COORD_SKS
+      && !ctx->grid_dev.fmks && p.simulation_interp && p.simulation_coord == BL_COORD_SKS
       && !(p.cut_omit_near || p.cut_omit_far || p.cut_omit_in >= 0.0 || p.cut_omit_out >= 0.0 || p.cut_midplane_theta != 0.0 || p.cut_midplane_z != 0.0 || p.cut_plane)
       && !job.geo_load && !job.geo_save && !job.sample_save && !job.need_time && !(ctx->switches & (BL_SWITCH_NO_FUSED_LOCATE | BL_SWITCH_SPLIT_RECORDS))
-      && bl_fused2_applicable(&ctx->grid_dev, 1, job.n_rays) != 0;
+      && (ctx->grid_dev.n_blocks == 0 ? bl_fused2_applicable(&ctx->grid_dev, 1, job.n_rays) != 0 : bl_polarized2_refined_applicable(&ctx->grid_dev, job.n_rays) != 0);
   job.interleaved = (job.fused2 || job.exact_fused || job.pol_fused || !job.simulation) && !job.geo_load && !job.geo_save && !job.sample_save && !(ctx->switches & BL_SWITCH_SPLIT_RECORDS);
   job.locate_inside = job.fused2 || job.exact_fused || job.pol_fused;
   // The benchmark's kernel also composes the affine maps of a ray's neighbouring samples before they leave it (the geodesic kernel

@@ -272,6 +272,11 @@ __device__ __forceinline__ GridScalars grid_scalars(const BlGridDevice &g, uint3
   G.n_i = (uint32_t)g.n[0];
   G.n_j = (uint32_t)g.n[1];
   G.block_interp = 0;
+  G.lds_desc = 0u;   // (one block: no descriptors)
+  G.box_l0 = G.box_linv = 0.0f;
+  G.box_th_x0 = G.box_th_inv_w = G.box_ph_x0 = G.box_ph_inv_w = 0.0;
+  G.n_box_i1 = G.n_box_j1 = G.n_box_k1 = 0;
+  G.n_box_i = G.n_box_j = 1u;
   G.lds_r = lds_rows;
   G.lds_th = G.lds_r + 64u * (uint32_t)g.n[0];
   G.lds_ph = G.lds_th + 64u * (uint32_t)g.n[1];
@@ -282,6 +287,7 @@ __device__ __forceinline__ GridScalars grid_scalars(const BlGridDevice &g, uint3
 // how many cells a unit of the coordinate holds: two floats for log2 r, two doubles for theta and phi), then the row's cells as above,
 // the anchor rule of a block's ends at every row's ends - and behind the chunks one descriptor per box of the block lattice
 // (BlGridDevice::fused_desc, its chunk offsets made LDS addresses here).
+template <bool kReciprocal>
 __device__ __forceinline__ void stage_refined_rows(const BlGridDevice &g, char *chunks, uint32_t chunks_address) {
   char *at = chunks;
   for (int a = 0; a < 3; a++) {
@@ -299,8 +305,9 @@ __device__ __forceinline__ void stage_refined_rows(const BlGridDevice &g, char *
       row.dj_lt = (uint32_t)(c - c_lt);
       row.xv_ge = xv[c_ge];
       row.xv_lt = xv[c_lt];
-      row.w_ge = 1.0 / (xv[c_ge + 1] - xv[c_ge]);
-      row.w_lt = 1.0 / (xv[c_lt + 1] - xv[c_lt]);
+      const double width_ge = xv[c_ge + 1] - xv[c_ge], width_lt = xv[c_lt + 1] - xv[c_lt];
+      row.w_ge = kReciprocal ? 1.0 / width_ge : width_ge;
+      row.w_lt = kReciprocal ? 1.0 / width_lt : width_lt;
       *reinterpret_cast<AxisRow *>(at + (size_t)q * chunk + 16 + 64 * (size_t)c) = row;
     }
     for (int q = threadIdx.x; q < n_rows; q += blockDim.x) {
@@ -723,7 +730,7 @@ __global__ void __launch_bounds__(kRefined ? 512 : 256, kRefined ? 1 : BL_FAST_W
       else value = upper_on ? cc.fast_cut_hi[2 * v + 1] : -inf;
       lds[i] = value;
     }
-    if (kRefined) stage_refined_rows(P.grid, reinterpret_cast<char *>(lds + 48), lds_base + 48u * 8u);
+    if (kRefined) stage_refined_rows<true>(P.grid, reinterpret_cast<char *>(lds + 48), lds_base + 48u * 8u);
     else stage_axis_rows<true>(P.grid, reinterpret_cast<AxisRow *>(lds + 48));
   }
   __syncthreads();
@@ -992,7 +999,11 @@ __device__ __forceinline__ void axis_lookup_exact(uint32_t table, int cell, doub
 }
 
 // locate_plain_sample() (bl_sampling.h) on the row tables
-template <bool kSpinZero>
+// kMeshes (the polarized kernel): G may describe a mesh with refinement (G.lds_desc != 0: stage_refined_rows<false>, a wave-uniform
+// branch) - the box of the block lattice is guessed like a cell, its descriptor names the block's rows, and the guessed cell is confirmed
+// exactly by the row's faces (both of them: a wrong box names a block whose rows do not hold the coordinate); anything else walks from
+// there, box by box and cell by cell, to what locate_sample_refined() - the locate kernel's function - finds: its results bit for bit.
+template <bool kSpinZero, bool kMeshes = false>
 __device__ __forceinline__ LocatedExact locate_exact(const BlSpacetime &st, const BlGridDevice &g, const GridScalars &G, double camera_r, bool live, double x1, double x2,
                                                      double x3) {
   x1 = live ? x1 : 1.0;
@@ -1007,6 +1018,70 @@ __device__ __forceinline__ LocatedExact locate_exact(const BlSpacetime &st, cons
   ph += ph < 0.0 ? 2.0 * kPi : 0.0;
   ph -= ph >= 2.0 * kPi ? 2.0 * kPi : 0.0;
   const bool off_grid = r < G.r_in || r > G.r_out;                 // :352-394 (theta and phi cover the sphere: bl_fused2_applicable)
+  const bool sampled = live && !cut && !off_grid;
+  if (kMeshes && G.lds_desc != 0u) {
+    const float log2_r = __builtin_amdgcn_logf((float)r);
+    int bi = (int)((log2_r - G.box_l0) * G.box_linv);
+    int bj = (int)((th - G.box_th_x0) * G.box_th_inv_w);
+    int bk = (int)((ph - G.box_ph_x0) * G.box_ph_inv_w);
+    bi = bi < 0 ? 0 : (bi > G.n_box_i1 ? G.n_box_i1 : bi);
+    bj = bj < 0 ? 0 : (bj > G.n_box_j1 ? G.n_box_j1 : bj);
+    bk = bk < 0 ? 0 : (bk > G.n_box_k1 ? G.n_box_k1 : bk);
+    v4u desc = lds_read_bits(G.lds_desc + ((__umul24(__umul24((uint32_t)bk, G.n_box_j) + (uint32_t)bj, G.n_box_i) + (uint32_t)bi) << 4));
+    const v4u head_r = lds_read_bits(desc.y);
+    const v2d head_th = lds_read2(desc.z), head_ph = lds_read2(desc.w);
+    int ci = (int)((log2_r - __uint_as_float(head_r.x)) * __uint_as_float(head_r.y));
+    int cj = (int)((th - head_th.x) * head_th.y);
+    int ck = (int)((ph - head_ph.x) * head_ph.y);
+    ci = ci < 0 ? 0 : (ci > G.n_i1 ? G.n_i1 : ci);
+    cj = cj < 0 ? 0 : (cj > G.n_j1 ? G.n_j1 : cj);
+    ck = ck < 0 ? 0 : (ck > G.n_k1 ? G.n_k1 : ck);
+    auto faces_of = [&](uint32_t rows, int c) { return lds_read2(rows + 16u + ((uint32_t)c << 6)); };
+    auto inside = [&](uint32_t rows, int c, double x) {   // (strictly above the lower face: on it the sample is the block's below)
+      const v2d faces = faces_of(rows, c);
+      return x > faces.x && x <= faces.y;
+    };
+    if (__builtin_expect(sampled && !(inside(desc.y, ci, r) && inside(desc.z, cj, th) && inside(desc.w, ck, ph)), 0)) {
+      // The guesses do not hold (the last place of a float log2, a coordinate on a face): walk. First to the box - the block of the
+      // box at hand spans [first face of its row, last face]: a coordinate at or below the first belongs to a box further down, one
+      // above the last to a box further up (the rule of locate_sample_refined: the first box whose upper edge is >= the coordinate) -
+      // then along the block's rows to the first cell whose upper face is >= the coordinate. All from the rows in LDS.
+      for (int step = 0; step < 3 * 4096; step++) {
+        const double first_r = faces_of(desc.y, 0).x, last_r = faces_of(desc.y, G.n_i1).y;
+        const double first_th = faces_of(desc.z, 0).x, last_th = faces_of(desc.z, G.n_j1).y;
+        const double first_ph = faces_of(desc.w, 0).x, last_ph = faces_of(desc.w, G.n_k1).y;
+        const int move_i = (r <= first_r && bi > 0) ? -1 : ((r > last_r && bi < G.n_box_i1) ? 1 : 0);
+        const int move_j = (th <= first_th && bj > 0) ? -1 : ((th > last_th && bj < G.n_box_j1) ? 1 : 0);
+        const int move_k = (ph <= first_ph && bk > 0) ? -1 : ((ph > last_ph && bk < G.n_box_k1) ? 1 : 0);
+        if (move_i == 0 && move_j == 0 && move_k == 0) break;
+        bi += move_i;
+        bj += move_j;
+        bk += move_k;
+        desc = lds_read_bits(G.lds_desc + ((__umul24(__umul24((uint32_t)bk, G.n_box_j) + (uint32_t)bj, G.n_box_i) + (uint32_t)bi) << 4));
+      }
+      while (ci < G.n_i1 && r > faces_of(desc.y, ci).y) ci++;
+      while (ci > 0 && r <= faces_of(desc.y, ci).x) ci--;
+      while (cj < G.n_j1 && th > faces_of(desc.z, cj).y) cj++;
+      while (cj > 0 && th <= faces_of(desc.z, cj).x) cj--;
+      while (ck < G.n_k1 && ph > faces_of(desc.w, ck).y) ck++;
+      while (ck > 0 && ph <= faces_of(desc.w, ck).x) ck--;
+    }
+    LocatedExact out;
+    uint32_t i_m, j_m, k_m;
+    axis_lookup_exact(desc.y + 16u, ci, r, &out.f_i, &i_m);
+    axis_lookup_exact(desc.z + 16u, cj, th, &out.f_j, &j_m);
+    axis_lookup_exact(desc.w + 16u, ck, ph, &out.f_k, &k_m);
+    out.cell_bytes = desc.x + ((__umul24(__umul24(k_m, G.n_j) + j_m, G.n_i) + i_m) << 5);
+    const uint32_t status = (uint32_t)kSampleInterp;
+    const bool read = sampled && status == (uint32_t)kSampleInterp;
+    out.f_i = read ? out.f_i : 0.0;
+    out.f_j = read ? out.f_j : 0.0;
+    out.f_k = read ? out.f_k : 0.0;
+    out.ph_unwrapped = (!live || cut) ? 0.0 : ph_unwrapped;
+    out.status = !live ? (uint32_t)kSampleNone : (cut ? (uint32_t)kSampleCut : (off_grid ? (uint32_t)kSampleOffGrid : status));
+    out.cell_bytes = read ? out.cell_bytes : 0u;
+    return out;
+  }
   int gi = (int)((__builtin_amdgcn_logf((float)r) - G.r_l0) * G.r_linv);
   int gj = (int)((th - G.th_x0) * G.th_inv_w);
   int gk = (int)((ph - G.ph_x0) * G.ph_inv_w);
@@ -1037,7 +1112,6 @@ __device__ __forceinline__ LocatedExact locate_exact(const BlSpacetime &st, cons
   axis_lookup_exact(G.lds_r, gi, r, &out.f_i, &i_m);
   axis_lookup_exact(G.lds_th, gj, th, &out.f_j, &j_m);
   axis_lookup_exact(G.lds_ph, gk, ph, &out.f_k, &k_m);
-  const bool sampled = live && !cut && !off_grid;
   out.f_i = sampled ? out.f_i : 0.0;
   out.f_j = sampled ? out.f_j : 0.0;
   out.f_k = sampled ? out.f_k : 0.0;
@@ -1196,7 +1270,11 @@ __global__ void __launch_bounds__(256, 2) bl_shade_polarized2_kernel(const BlSha
   using namespace fused2;
   extern __shared__ double lds[];
   const uint32_t lds_base = lds_address(lds);
-  stage_axis_rows<false>(P.grid, reinterpret_cast<AxisRow *>(lds));
+  // (a mesh with refinement that the tolerant tier's fused kernel would take - BlGridDevice::fused_lds_bytes - has its row chunks and box
+  // descriptors here too, with widths where that kernel keeps reciprocals: locate_exact<., true>)
+  const bool mesh = P.grid.n_blocks > 0;
+  if (mesh) stage_refined_rows<false>(P.grid, reinterpret_cast<char *>(lds), lds_base);
+  else stage_axis_rows<false>(P.grid, reinterpret_cast<AxisRow *>(lds));
   __syncthreads();
   const uint32_t n_records = (uint32_t)P.counters_in[BL_CNT_RECORDS];
   const uint32_t first_record = 0u;
@@ -1204,7 +1282,7 @@ __global__ void __launch_bounds__(256, 2) bl_shade_polarized2_kernel(const BlSha
   const uint32_t stride = gridDim.x * blockDim.x;
   const uint32_t last = n_records - 1u;
   const BlSpacetime st = P.st;
-  const GridScalars G = grid_scalars(P.grid, lds_base);
+  const GridScalars G = mesh ? grid_scalars_refined(P.grid, lds_base) : grid_scalars(P.grid, lds_base);
   const double camera_r = P.cuts.camera_r;
   const float fallback_rho = P.cold->fallback_rho, fallback_pgas = P.cold->fallback_pgas;
   const bool nan_rays = P.plasma.fallback_nan != 0;
@@ -1236,7 +1314,7 @@ __global__ void __launch_bounds__(256, 2) bl_shade_polarized2_kernel(const BlSha
     cur1 = rec[1];
     cur1.y = cur_in ? cur1.y : __longlong_as_double((long long)BL_DEAD_RAY);
   }
-  loc_cur = locate_exact<kSpinZero>(st, P.grid, G, camera_r, (uint32_t)__double_as_longlong(cur1.y) != BL_DEAD_RAY, cur0.x, cur0.y, cur1.x);
+  loc_cur = locate_exact<kSpinZero, true>(st, P.grid, G, camera_r, (uint32_t)__double_as_longlong(cur1.y) != BL_DEAD_RAY, cur0.x, cur0.y, cur1.x);
   bool prev_in = false;
   while (__any(prev_in || cur_in)) {
     const uint32_t ray = (uint32_t)__double_as_longlong(prev1.y);
@@ -1347,7 +1425,7 @@ __global__ void __launch_bounds__(256, 2) bl_shade_polarized2_kernel(const BlSha
     fused2::gather_issue(cells, loc_cur.cell_bytes, loc_cur.status == (uint32_t)kSampleInterp, row_bytes, plane_bytes, lo, hi);
     const bool live_next = next_in && (uint32_t)__double_as_longlong(next1.y) != BL_DEAD_RAY;
     LocatedExact loc_next = loc_cur;
-    if (__any(live_next)) loc_next = locate_exact<kSpinZero>(st, P.grid, G, camera_r, live_next, next0.x, next0.y, next1.x);
+    if (__any(live_next)) loc_next = locate_exact<kSpinZero, true>(st, P.grid, G, camera_r, live_next, next0.x, next0.y, next1.x);
     else loc_next.status = kSampleNone, loc_next.cell_bytes = 0u;
     prev0 = cur0;
     prev1 = cur1;
@@ -1367,12 +1445,21 @@ __global__ void __launch_bounds__(256, 2) bl_shade_polarized2_kernel(const BlSha
 
 extern "C" hipError_t bl_launch_shade_polarized2(const BlShadeArgs *args, int grid, hipStream_t stream) {
   const BlGridDevice &g = args->grid;
-  const size_t lds = 64 * (size_t)(g.n[0] + g.n[1] + g.n[2]);
+  // (a mesh with refinement: the fused kernel's tables without its 48 doubles of cut thresholds - bl_polarized2_refined_applicable)
+  const size_t lds = g.n_blocks > 0 ? (size_t)g.fused_lds_bytes - 48 * sizeof(double) : 64 * (size_t)(g.n[0] + g.n[1] + g.n[2]);
   if (args->pol_samples == nullptr || args->coef_inputs == nullptr) return hipErrorInvalidValue;
   const bool spin_zero = args->st.bh_a == 0.0, records = args->aux_record_unused == 0;
   if (records && args->aux == nullptr) return hipErrorInvalidValue;
+  const bool inside = args->have_flags != nullptr && !records && spin_zero;   // (bl_render.hip: one frequency, thermal electrons only, no spin)
+  if (lds > 64 * 1024) {   // (two 256-lane workgroups to a compute unit: up to 76 KiB each)
+    const void *kernel = inside ? reinterpret_cast<const void *>(&bl_shade_polarized2_kernel<true, false, true>)
+        : (spin_zero ? (records ? reinterpret_cast<const void *>(&bl_shade_polarized2_kernel<true, true>) : reinterpret_cast<const void *>(&bl_shade_polarized2_kernel<true, false>))
+                     : (records ? reinterpret_cast<const void *>(&bl_shade_polarized2_kernel<false, true>) : reinterpret_cast<const void *>(&bl_shade_polarized2_kernel<false, false>)));
+    const hipError_t err = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 76 * 1024);
+    if (err != hipSuccess) return err;
+  }
 #define BL_LAUNCH_P2(S, A) hipLaunchKernelGGL((bl_shade_polarized2_kernel<S, A>), dim3(grid), dim3(256), lds, stream, *args)
-  if (args->have_flags != nullptr && !records && spin_zero) {   // (bl_render.hip: one frequency, thermal electrons only, no spin)
+  if (inside) {
     hipLaunchKernelGGL((bl_shade_polarized2_kernel<true, false, true>), dim3(grid), dim3(256), lds, stream, *args);
   } else if (spin_zero && records) BL_LAUNCH_P2(true, true);
   else if (spin_zero) BL_LAUNCH_P2(true, false);
@@ -1406,6 +1493,11 @@ extern "C" int bl_fused2_applicable(const BlGridDevice *grid, int n_nu, long lon
   if (g.stride_row != g.n[0] || g.stride_plane != g.n[0] * g.n[1]) return 0;
   const size_t lds = 48 * sizeof(double) + 64 * (size_t)(g.n[0] + g.n[1] + g.n[2]);
   return lds <= 64u * 1024u ? 1 : 0;
+}
+
+// The polarized kernel over a mesh with refinement: the same tables (widths for reciprocals), 256-lane workgroups two to a compute unit
+extern "C" int bl_polarized2_refined_applicable(const BlGridDevice *grid, long long n_rays) {
+  return (grid->n_blocks > 0 && grid->fused_lds_bytes > 0 && grid->fused_lds_bytes <= 76 * 1024 && !grid->block_interp && n_rays < (1ll << 29)) ? 1 : 0;
 }
 
 // ... or its instantiation for a mesh with refinement (one frequency, composed maps: what bl_render.hip asks for beside this; the

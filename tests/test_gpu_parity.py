@@ -495,6 +495,46 @@ def test_randomised_polarized_configurations_against_oracle(seed, built_library)
     assert same.all(), f"{(~same).sum()} of {same.size} values differ for {over}"
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_polarized_runs_over_a_refined_mesh(seed, built_library):
+    """The polarized coefficient kernel's locate step over the two-level mesh (and the same mesh in smaller blocks): box descriptors and
+    row chunks in LDS, cells confirmed exactly, a walk where the guesses do not hold. Exact tier: every Stokes row equal to the CPU
+    oracle's and to the path through the locate kernel, bit for bit; the tolerant tier (transport matrices) within its tolerance."""
+    import blacklight_amd as bl
+    from blacklight_amd import _capi
+    import oracle_api
+    rng = np.random.default_rng(8800 + seed)
+    fx, params, mock_args = gu.load_case("sim_polarized")
+    over = dict(camera_resolution=14, simulation_a=float(rng.choice([0.0, 0.0, 0.6])), simulation_interp="true", image_tau=str(rng.choice(["true", "false"])),
+                camera_th=float(rng.uniform(15.0, 165.0)), camera_ph=float(rng.uniform(0.0, 360.0)), image_rotation_split=str(rng.choice(["true", "false"])))
+    if seed % 3 == 2:
+        over.update(plasma_power_frac=float(rng.uniform(0.05, 0.4)), plasma_p=2.8, plasma_gamma_min=2.0, plasma_gamma_max=1.0e4)
+    params = dict(params, **over)
+    p = bl.Params.from_dict(params)
+    grid = gu.golden_grid(dict(mock_args, _refined=1))
+    if seed % 2 == 1:
+        grid = gu.subdivide_blocks(grid, (2, 3, 2))
+    with bl.Context(p) as ctx:
+        ctx.set_grid(grid)
+        ctx.set_arithmetic("exact")
+        inside = ctx.render()
+        ctx.debug_set_switches("NO_FUSED_LOCATE")
+        outside = ctx.render()
+        ctx.debug_set_switches()
+        ctx.set_arithmetic("tolerant")
+        tolerant = ctx.render()
+    assert inside["stats"].fused_variant == 4 and inside["stats"].launches_locate == 0
+    assert outside["stats"].fused_variant == 0 and outside["stats"].launches_locate == 1
+    want = oracle_api.render(p.ptr, grid.desc(), _capi.RenderDesc, _capi.CameraFrame, n_rays=14 * 14, max_steps=int(p.get("ray_max_steps")))
+    assert np.array_equal(inside["sample_num"], want["sample_num"]) and inside["stats"].n_gathers == want["n_gathers"] == outside["stats"].n_gathers, over
+    assert gu.same_bits(inside["image"], outside["image"]).all(), over
+    assert gu.same_bits(inside["image"], want["image"]).all(), over
+    assert tolerant["stats"].fused_variant == 4 and np.array_equal(tolerant["sample_num"], want["sample_num"])
+    scale = np.nanmax(np.abs(inside["image"]), axis=-1, keepdims=True)
+    with np.errstate(invalid="ignore"):
+        assert np.nanmax(np.abs(tolerant["image"] - inside["image"]) / np.where(scale > 0, scale, 1.0)) < 1.0e-9, over
+
+
 @pytest.mark.parametrize("seed", range(8))
 def test_block_interpolation_against_oracle(seed, built_library):
     """simulation_block_interp = true (FindNearbyInds / InterpolateAdvanced) on equal blocks and on the two-level mesh,

@@ -283,13 +283,20 @@ def test_next_snapshot_staged_beside_the_render():
         ctx.set_arithmetic("exact")
         ctx.set_grid(snaps[0])
         got, staged = [], None
+
+        def stage(grid, go):
+            go.wait()          # (set by the rendering thread on its way into bl_render, which takes the context's render lock first thing:
+            ctx.set_grid(grid)  # this thread gets the interpreter when that call releases it - the cells go up beside the render)
+
         for n in range(len(snaps)):
             if staged is not None:
                 staged.join()
             staged = None
+            go = threading.Event()
             if n + 1 < len(snaps):
-                staged = threading.Thread(target=ctx.set_grid, args=(snaps[n + 1],))
+                staged = threading.Thread(target=stage, args=(snaps[n + 1], go))
                 staged.start()
+            go.set()
             got.append(ctx.render())
         assert [g["stats"].geodesics_reused for g in got] == [0, 1, 1, 1, 1, 1]
         for a, b in zip(got, want):
