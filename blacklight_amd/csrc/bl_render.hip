@@ -342,10 +342,10 @@ void PlanJob(RenderJob &job) {
   // to bl_locate_plain_kernel + bl_shade_exact_kernel, whose conditions these are)
   job.exact_fused = !job.fast && job.simulation && !job.aux && !ctx->polarized && !job.slow && !job.block_interp && job.n_nu == 1
       && p.plasma_kappa_frac == 0.0 && p.plasma_power_frac == 0.0 && p.plasma_model != BL_PLASMA_CODE_KAPPA && !p.ray_flat
-      && ctx->plasma_thermal_frac != 0.0 && ctx->grid_dev.n_blocks == 0 && !ctx->grid_dev.fmks && p.simulation_interp && p.simulation_coord == BL_COORD_SKS
+      && ctx->plasma_thermal_frac != 0.0 && !ctx->grid_dev.fmks && p.simulation_interp && p.simulation_coord == BL_COORD_SKS
       && !(p.cut_omit_near || p.cut_omit_far || p.cut_omit_in >= 0.0 || p.cut_omit_out >= 0.0 || p.cut_midplane_theta != 0.0 || p.cut_midplane_z != 0.0 || p.cut_plane)
       && !job.geo_load && !job.geo_save && !job.sample_save && !(ctx->switches & (BL_SWITCH_NO_FUSED_LOCATE | BL_SWITCH_SPLIT_RECORDS))
-      && bl_fused2_applicable(&ctx->grid_dev, job.n_nu, job.n_rays) != 0;
+      && (ctx->grid_dev.n_blocks == 0 ? bl_fused2_applicable(&ctx->grid_dev, job.n_nu, job.n_rays) != 0 : bl_polarized2_refined_applicable(&ctx->grid_dev, job.n_rays) != 0);
   // Polarized runs over such a grid: the frame-and-inputs kernel with the locate step inside (bit-identical to bl_locate_plain_kernel +
   // bl_shade_kernel<polarized>, whose conditions these are; electron entropy from the grid is a ninth value it does not gather)
   // (... or a mesh with refinement whose tables the tolerant tier's fused kernel takes: the polarized kernel's locate step knows them too)

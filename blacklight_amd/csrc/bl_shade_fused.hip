@@ -1020,14 +1020,19 @@ __device__ __forceinline__ LocatedExact locate_exact(const BlSpacetime &st, cons
   const bool off_grid = r < G.r_in || r > G.r_out;                 // :352-394 (theta and phi cover the sphere: bl_fused2_applicable)
   const bool sampled = live && !cut && !off_grid;
   if (kMeshes && G.lds_desc != 0u) {
+    // (the lattice's scalars from the kernel arguments where they are needed: held in scalar registers across the sample loop they cost
+    // the one-block case - the benchmark's exact kernel - eighty spilled scalars and 1.5 ms of its 63.5)
+    KernArgs A = kernargs();
+    const int n_box_i1 = A->grid.n_edge[0] - 1, n_box_j1 = A->grid.n_edge[1] - 1, n_box_k1 = A->grid.n_edge[2] - 1;
+    const uint32_t n_box_i = (uint32_t)A->grid.n_edge[0], n_box_j = (uint32_t)A->grid.n_edge[1];
     const float log2_r = __builtin_amdgcn_logf((float)r);
-    int bi = (int)((log2_r - G.box_l0) * G.box_linv);
-    int bj = (int)((th - G.box_th_x0) * G.box_th_inv_w);
-    int bk = (int)((ph - G.box_ph_x0) * G.box_ph_inv_w);
-    bi = bi < 0 ? 0 : (bi > G.n_box_i1 ? G.n_box_i1 : bi);
-    bj = bj < 0 ? 0 : (bj > G.n_box_j1 ? G.n_box_j1 : bj);
-    bk = bk < 0 ? 0 : (bk > G.n_box_k1 ? G.n_box_k1 : bk);
-    v4u desc = lds_read_bits(G.lds_desc + ((__umul24(__umul24((uint32_t)bk, G.n_box_j) + (uint32_t)bj, G.n_box_i) + (uint32_t)bi) << 4));
+    int bi = (int)((log2_r - A->grid.box_l0) * A->grid.box_linv);
+    int bj = (int)((th - A->grid.box_x0[0]) * A->grid.box_inv_w[0]);
+    int bk = (int)((ph - A->grid.box_x0[1]) * A->grid.box_inv_w[1]);
+    bi = bi < 0 ? 0 : (bi > n_box_i1 ? n_box_i1 : bi);
+    bj = bj < 0 ? 0 : (bj > n_box_j1 ? n_box_j1 : bj);
+    bk = bk < 0 ? 0 : (bk > n_box_k1 ? n_box_k1 : bk);
+    v4u desc = lds_read_bits(G.lds_desc + ((__umul24(__umul24((uint32_t)bk, n_box_j) + (uint32_t)bj, n_box_i) + (uint32_t)bi) << 4));
     const v4u head_r = lds_read_bits(desc.y);
     const v2d head_th = lds_read2(desc.z), head_ph = lds_read2(desc.w);
     int ci = (int)((log2_r - __uint_as_float(head_r.x)) * __uint_as_float(head_r.y));
@@ -1050,14 +1055,14 @@ __device__ __forceinline__ LocatedExact locate_exact(const BlSpacetime &st, cons
         const double first_r = faces_of(desc.y, 0).x, last_r = faces_of(desc.y, G.n_i1).y;
         const double first_th = faces_of(desc.z, 0).x, last_th = faces_of(desc.z, G.n_j1).y;
         const double first_ph = faces_of(desc.w, 0).x, last_ph = faces_of(desc.w, G.n_k1).y;
-        const int move_i = (r <= first_r && bi > 0) ? -1 : ((r > last_r && bi < G.n_box_i1) ? 1 : 0);
-        const int move_j = (th <= first_th && bj > 0) ? -1 : ((th > last_th && bj < G.n_box_j1) ? 1 : 0);
-        const int move_k = (ph <= first_ph && bk > 0) ? -1 : ((ph > last_ph && bk < G.n_box_k1) ? 1 : 0);
+        const int move_i = (r <= first_r && bi > 0) ? -1 : ((r > last_r && bi < n_box_i1) ? 1 : 0);
+        const int move_j = (th <= first_th && bj > 0) ? -1 : ((th > last_th && bj < n_box_j1) ? 1 : 0);
+        const int move_k = (ph <= first_ph && bk > 0) ? -1 : ((ph > last_ph && bk < n_box_k1) ? 1 : 0);
         if (move_i == 0 && move_j == 0 && move_k == 0) break;
         bi += move_i;
         bj += move_j;
         bk += move_k;
-        desc = lds_read_bits(G.lds_desc + ((__umul24(__umul24((uint32_t)bk, G.n_box_j) + (uint32_t)bj, G.n_box_i) + (uint32_t)bi) << 4));
+        desc = lds_read_bits(G.lds_desc + ((__umul24(__umul24((uint32_t)bk, n_box_j) + (uint32_t)bj, n_box_i) + (uint32_t)bi) << 4));
       }
       while (ci < G.n_i1 && r > faces_of(desc.y, ci).y) ci++;
       while (ci > 0 && r <= faces_of(desc.y, ci).x) ci--;
@@ -1128,7 +1133,9 @@ __global__ void __launch_bounds__(256, 2) bl_shade_exact2_kernel(const BlShadeAr
   using namespace fused2;
   extern __shared__ double lds[];
   const uint32_t lds_base = lds_address(lds);
-  stage_axis_rows<false>(P.grid, reinterpret_cast<AxisRow *>(lds));
+  const bool mesh = P.grid.n_blocks > 0;   // (a mesh with refinement: as in the polarized kernel below)
+  if (mesh) stage_refined_rows<false>(P.grid, reinterpret_cast<char *>(lds), lds_base);
+  else stage_axis_rows<false>(P.grid, reinterpret_cast<AxisRow *>(lds));
   __syncthreads();
   const uint32_t n_records = (uint32_t)P.counters_in[BL_CNT_RECORDS];
   const uint32_t first_record = 0u;
@@ -1136,7 +1143,7 @@ __global__ void __launch_bounds__(256, 2) bl_shade_exact2_kernel(const BlShadeAr
   const uint32_t stride = gridDim.x * blockDim.x;
   const uint32_t last = n_records - 1u;
   const BlSpacetime st = P.st;
-  const GridScalars G = grid_scalars(P.grid, lds_base);
+  const GridScalars G = mesh ? grid_scalars_refined(P.grid, lds_base) : grid_scalars(P.grid, lds_base);
   const double camera_r = P.cuts.camera_r;
   const float fallback_rho = P.cold->fallback_rho, fallback_pgas = P.cold->fallback_pgas;
   const char *cells = reinterpret_cast<const char *>(P.grid.cells);
@@ -1168,7 +1175,7 @@ __global__ void __launch_bounds__(256, 2) bl_shade_exact2_kernel(const BlShadeAr
     cur1 = rec[1];
     cur1.y = cur_in ? cur1.y : __longlong_as_double((long long)BL_DEAD_RAY);
   }
-  loc_cur = locate_exact<kSpinZero>(st, P.grid, G, camera_r, (uint32_t)__double_as_longlong(cur1.y) != BL_DEAD_RAY, cur0.x, cur0.y, cur1.x);
+  loc_cur = locate_exact<kSpinZero, true>(st, P.grid, G, camera_r, (uint32_t)__double_as_longlong(cur1.y) != BL_DEAD_RAY, cur0.x, cur0.y, cur1.x);
   bool prev_in = false;
   while (__any(prev_in || cur_in)) {
     const uint32_t ray = (uint32_t)__double_as_longlong(prev1.y);
@@ -1234,7 +1241,7 @@ __global__ void __launch_bounds__(256, 2) bl_shade_exact2_kernel(const BlShadeAr
     }
     const bool live_next = next_in && (uint32_t)__double_as_longlong(next1.y) != BL_DEAD_RAY;
     LocatedExact loc_next = loc_cur;
-    if (__any(live_next)) loc_next = locate_exact<kSpinZero>(st, P.grid, G, camera_r, live_next, next0.x, next0.y, next1.x);
+    if (__any(live_next)) loc_next = locate_exact<kSpinZero, true>(st, P.grid, G, camera_r, live_next, next0.x, next0.y, next1.x);
     else loc_next.status = kSampleNone, loc_next.cell_bytes = 0u;
     prev0 = cur0;
     prev1 = cur1;
@@ -1472,7 +1479,12 @@ extern "C" hipError_t bl_launch_shade_polarized2(const BlShadeArgs *args, int gr
 // (the exact tier's use of the fused kernel: one frequency, plain image; bl_render.hip checks the rest with bl_fused2_applicable)
 extern "C" hipError_t bl_launch_shade_exact2(const BlShadeArgs *args, int grid, hipStream_t stream) {
   const BlGridDevice &g = args->grid;
-  const size_t lds = 64 * (size_t)(g.n[0] + g.n[1] + g.n[2]);
+  const size_t lds = g.n_blocks > 0 ? (size_t)g.fused_lds_bytes - 48 * sizeof(double) : 64 * (size_t)(g.n[0] + g.n[1] + g.n[2]);
+  if (lds > 64 * 1024) {   // (a mesh's tables, two workgroups to a compute unit: bl_polarized2_refined_applicable)
+    const void *kernel = args->st.bh_a == 0.0 ? reinterpret_cast<const void *>(&bl_shade_exact2_kernel<true>) : reinterpret_cast<const void *>(&bl_shade_exact2_kernel<false>);
+    const hipError_t err = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 76 * 1024);
+    if (err != hipSuccess) return err;
+  }
   if (args->st.bh_a == 0.0) hipLaunchKernelGGL((bl_shade_exact2_kernel<true>), dim3(grid), dim3(256), lds, stream, *args);
   else hipLaunchKernelGGL((bl_shade_exact2_kernel<false>), dim3(grid), dim3(256), lds, stream, *args);
   return hipGetLastError();

@@ -325,14 +325,20 @@ def test_tolerant_tier_over_a_refined_mesh_locates_inside_the_coefficient_kernel
         ctx.set_grid(grid)
         ctx.set_arithmetic("exact")
         exact = ctx.render()
-        ctx.set_arithmetic("tolerant")
-        inside = ctx.render()
         ctx.debug_set_switches("NO_FUSED_LOCATE")
+        exact_outside = ctx.render()
+        ctx.set_arithmetic("tolerant")
         outside = ctx.render()
         ctx.debug_set_switches()
+        inside = ctx.render()
         ctx.debug_set_guard_band(1.0e30)
         deferred = ctx.render()
-    assert exact["stats"].launches_locate == 1 and exact["stats"].fused_variant == 0
+    # (the exact tier's kernel with the locate step inside takes the mesh too - bl_shade_exact2_kernel, locate_exact<., kMeshes> - and gives
+    # the bits of the path through the locate kernel)
+    assert exact["stats"].launches_locate == 0 and exact["stats"].fused_variant == 3
+    assert exact_outside["stats"].launches_locate == 1 and exact_outside["stats"].fused_variant == 0
+    assert gu.same_bits(exact["image"], exact_outside["image"]).all() and np.array_equal(exact["sample_num"], exact_outside["sample_num"])
+    assert exact["stats"].n_gathers == exact_outside["stats"].n_gathers
     assert inside["stats"].arithmetic == 1 and inside["stats"].fused_variant == 2 and inside["stats"].launches_locate == 0 and inside["stats"].composed_maps == 1
     assert outside["stats"].arithmetic == 1 and outside["stats"].fused_variant == 0 and outside["stats"].launches_locate == 1
     assert deferred["stats"].fused_variant == 2 and deferred["stats"].n_deferred > 100 * max(inside["stats"].n_deferred, 1)
